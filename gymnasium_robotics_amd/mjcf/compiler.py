@@ -1,0 +1,1228 @@
+"""MJCF -> flat model tables (host, cold path).
+
+This is the replacement for ``mujoco.MjModel.from_xml_path`` at
+/root/reference/gymnasium_robotics/envs/robot_env.py:293 for the MJCF subset
+the five env families use.  It produces the tables
+listed in ``include/grx_model_fields.def``:
+
+* ``<include>``, nested ``<default class>`` / ``childclass``, ``<compiler>``
+  angle / eulerseq / meshdir, ``<option>``;
+* bodies (static bodies are fused into their moving ancestor -- dynamically
+  equivalent because a joint-less body is welded to its parent), joints
+  (free / slide / hinge), explicit ``<inertial>`` or geom-derived inertia;
+* collidable geoms, sites, mocap bodies, weld equalities, contact excludes,
+  joint-transmission actuators;
+* compile-time constants the soft-constraint model needs: ``dof_invweight0``
+  and per-body ``invweight0`` (inverse inertia seen at the body COM at
+  ``qpos0``), ``meaninertia``;
+* the statically filtered collision candidate list with mixed contact
+  parameters.
+
+Everything here is fp64 numpy; nothing on the per-step path calls it.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import mathutil as mu
+
+# MuJoCo enums (public API values)
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = range(8)
+GEOM_TYPES = {
+    "plane": GEOM_PLANE,
+    "hfield": GEOM_HFIELD,
+    "sphere": GEOM_SPHERE,
+    "capsule": GEOM_CAPSULE,
+    "ellipsoid": GEOM_ELLIPSOID,
+    "cylinder": GEOM_CYLINDER,
+    "box": GEOM_BOX,
+    "mesh": GEOM_MESH,
+}
+JNT_TYPES = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}
+EQ_CONNECT, EQ_WELD, EQ_JOINT = 0, 1, 2
+MJ_MINVAL = 1e-15
+
+# dims / opt slot indices: keep in sync with include/grx_model.h
+DIMS = [
+    "nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "nmocap", "neq", "npair",
+    "nmeshvert", "nmeshadj", "integrator", "iterations", "cone", "noslip_iterations",
+    "eulerdamp", "ntree", "maxdepth",
+]
+NDIMS = 32
+OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia"]
+NOPTS = 16
+
+
+def _floats(s, n=None, default=None):
+    if s is None:
+        return None if default is None else np.array(default, dtype=np.float64)
+    v = np.array([float(x) for x in s.split()], dtype=np.float64)
+    if n is not None and len(v) < n and default is not None:
+        d = np.array(default, dtype=np.float64)
+        d[: len(v)] = v
+        v = d
+    return v
+
+
+def _bool(s, default=None):
+    if s is None:
+        return default
+    return s.strip().lower() == "true"
+
+
+# ----------------------------------------------------------------------------
+# XML loading with <include> expansion
+# ----------------------------------------------------------------------------
+def _load_xml(path: str, base_dir: Optional[str] = None) -> ET.Element:
+    root = ET.parse(path).getroot()
+    base_dir = base_dir or os.path.dirname(os.path.abspath(path))
+    _expand_includes(root, base_dir)
+    return root
+
+
+def _expand_includes(elem: ET.Element, base_dir: str) -> None:
+    i = 0
+    while i < len(elem):
+        child = elem[i]
+        if child.tag == "include":
+            inc_path = os.path.join(base_dir, child.attrib["file"])
+            inc_root = ET.parse(inc_path).getroot()
+            # MuJoCo resolves nested includes relative to the top-level model dir
+            _expand_includes(inc_root, base_dir)
+            elem.remove(child)
+            for k, sub in enumerate(list(inc_root)):
+                elem.insert(i + k, sub)
+            # do not advance: re-scan inserted nodes (already expanded)
+            i += len(list(inc_root))
+        else:
+            _expand_includes(child, base_dir)
+            i += 1
+
+
+# ----------------------------------------------------------------------------
+# defaults
+# ----------------------------------------------------------------------------
+class _Defaults:
+    """Resolved attribute defaults per class name and element tag."""
+
+    ACT_TAGS = ("general", "motor", "position", "velocity")
+
+    def __init__(self):
+        self.classes: Dict[str, Dict[str, Dict[str, str]]] = {"main": {}}
+
+    def add_tree(self, elem: ET.Element, parent: str = None):
+        if parent is None:
+            name = elem.attrib.get("class", "main")
+            cur = self.classes.setdefault(name, {})
+        else:
+            name = elem.attrib["class"]
+            cur = {t: dict(a) for t, a in self.classes[parent].items()}
+            self.classes[name] = cur
+        for ch in elem:
+            if ch.tag == "default":
+                continue
+            if ch.tag in self.ACT_TAGS:
+                tag = "general"
+                attrs = _actuator_shortcut(ch.tag, dict(ch.attrib)) if ch.tag != "general" else dict(ch.attrib)
+            else:
+                tag, attrs = ch.tag, dict(ch.attrib)
+            cur.setdefault(tag, {}).update(attrs)
+        for ch in elem:
+            if ch.tag == "default":
+                self.add_tree(ch, name)
+
+    def get(self, cls: Optional[str], tag: str) -> Dict[str, str]:
+        c = self.classes.get(cls or "main")
+        if c is None:
+            raise ValueError(f"unknown default class {cls}")
+        return c.get(tag, {})
+
+
+def _actuator_shortcut(tag: str, a: Dict[str, str]) -> Dict[str, str]:
+    """Rewrite <position>/<motor>/<velocity> as <general> attributes."""
+    a = dict(a)
+    if tag == "motor":
+        a.setdefault("gaintype", "fixed")
+        a.setdefault("biastype", "none")
+        a.setdefault("gainprm", "1 0 0")
+    elif tag == "position":
+        kp = float(a.pop("kp", "1")) if "kp" in a else None
+        kv = float(a.pop("kv", "0")) if "kv" in a else None
+        if kp is not None:
+            a["gainprm"] = f"{kp} 0 0"
+            a["_kp"] = str(kp)
+        if kv is not None:
+            a["_kv"] = str(kv)
+        a["_position"] = "1"
+    elif tag == "velocity":
+        kv = float(a.pop("kv", "1"))
+        a["gainprm"] = f"{kv} 0 0"
+        a["biasprm"] = f"0 0 {-kv}"
+        a["biastype"] = "affine"
+    return a
+
+
+# ----------------------------------------------------------------------------
+# intermediate representation
+# ----------------------------------------------------------------------------
+@dataclass
+class _Joint:
+    name: str
+    type: int
+    pos: np.ndarray
+    axis: np.ndarray
+    ref: float
+    springref: float
+    range: np.ndarray
+    limited: bool
+    margin: float
+    solref: np.ndarray
+    solimp: np.ndarray
+    stiffness: float
+    damping: float
+    armature: float
+    frictionloss: float
+    solreffriction: np.ndarray
+    solimpfriction: np.ndarray
+    body: int = -1
+    qposadr: int = -1
+    dofadr: int = -1
+
+
+@dataclass
+class _Geom:
+    name: str
+    type: int
+    pos: np.ndarray
+    quat: np.ndarray
+    size: np.ndarray
+    contype: int
+    conaffinity: int
+    condim: int
+    priority: int
+    friction: np.ndarray
+    solmix: float
+    solref: np.ndarray
+    solimp: np.ndarray
+    margin: float
+    gap: float
+    mass: Optional[float]
+    density: float
+    group: int
+    mesh: Optional[str]
+    body: int = -1
+
+
+@dataclass
+class _Site:
+    name: str
+    type: int
+    pos: np.ndarray
+    quat: np.ndarray
+    size: np.ndarray
+    body: int = -1
+
+
+@dataclass
+class _Body:
+    name: str
+    parent: int
+    pos: np.ndarray
+    quat: np.ndarray
+    mocap: bool
+    joints: List[_Joint] = field(default_factory=list)
+    geoms: List[_Geom] = field(default_factory=list)
+    sites: List[_Site] = field(default_factory=list)
+    # inertial (explicit or derived)
+    mass: float = 0.0
+    ipos: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    inertia: np.ndarray = field(default_factory=lambda: np.zeros((3, 3)))  # about COM, body frame
+    explicit_inertial: bool = False
+
+
+@dataclass
+class CompiledModel:
+    """Flat tables (dict of numpy arrays) + name maps + blob packing."""
+
+    tables: Dict[str, np.ndarray]
+    names: Dict[str, Dict[str, int]]
+    info: Dict[str, object]
+
+    def dim(self, key: str) -> int:
+        return int(self.tables["dims"][DIMS.index(key)])
+
+    def opt(self, key: str) -> float:
+        return float(self.tables["opt"][OPTS.index(key)])
+
+    def pack(self):
+        return pack_blob(self.tables)
+
+    def copy(self) -> "CompiledModel":
+        return CompiledModel({k: v.copy() for k, v in self.tables.items()},
+                             {k: dict(v) for k, v in self.names.items()}, dict(self.info))
+
+
+# ----------------------------------------------------------------------------
+# field list (parsed from the shared .def so Python and C cannot drift)
+# ----------------------------------------------------------------------------
+_DEF_PATH = os.path.join(os.path.dirname(__file__), "..", "..", "include", "grx_model_fields.def")
+_PKG_DEF_PATH = os.path.join(os.path.dirname(__file__), "grx_model_fields.def")
+
+
+def field_list():
+    path = _DEF_PATH if os.path.exists(_DEF_PATH) else _PKG_DEF_PATH
+    out = []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith("GRX_FI(") or line.startswith("GRX_FF("):
+                kind = "i" if line.startswith("GRX_FI(") else "f"
+                name = line[line.index("(") + 1: line.index(")")].strip()
+                out.append((name, kind))
+    return out
+
+
+def pack_blob(tables: Dict[str, np.ndarray]):
+    """-> (H int32[2*nfields], I int32[], F float64[]) as documented in the .def"""
+    fl = field_list()
+    H = np.zeros(2 * len(fl), dtype=np.int32)
+    ints, flts = [], []
+    io = fo = 0
+    for k, (name, kind) in enumerate(fl):
+        a = np.ascontiguousarray(tables[name]).ravel()
+        if kind == "i":
+            a = a.astype(np.int32)
+            H[2 * k], H[2 * k + 1] = io, a.size
+            ints.append(a)
+            io += a.size
+        else:
+            a = a.astype(np.float64)
+            H[2 * k], H[2 * k + 1] = fo, a.size
+            flts.append(a)
+            fo += a.size
+    I = np.concatenate(ints) if ints else np.zeros(0, np.int32)
+    F = np.concatenate(flts) if flts else np.zeros(0, np.float64)
+    return H, np.ascontiguousarray(I, dtype=np.int32), np.ascontiguousarray(F, dtype=np.float64)
+
+
+def save_model(model: CompiledModel, path: str) -> None:
+    import json
+
+    np.savez_compressed(
+        path,
+        __names__=np.frombuffer(json.dumps(model.names).encode(), dtype=np.uint8),
+        __info__=np.frombuffer(json.dumps(model.info, default=str).encode(), dtype=np.uint8),
+        **model.tables,
+    )
+
+
+def load_model(path: str) -> CompiledModel:
+    import json
+
+    z = np.load(path)
+    names = json.loads(bytes(z["__names__"]).decode())
+    info = json.loads(bytes(z["__info__"]).decode())
+    tables = {k: z[k] for k in z.files if not k.startswith("__")}
+    return CompiledModel(tables, names, info)
+
+
+# ----------------------------------------------------------------------------
+# the compiler
+# ----------------------------------------------------------------------------
+class MjcfCompiler:
+    def __init__(self, xml_path: str):
+        self.xml_path = os.path.abspath(xml_path)
+        self.dir = os.path.dirname(self.xml_path)
+        self.root = _load_xml(self.xml_path)
+        self.defaults = _Defaults()
+        self.angle_scale = np.pi / 180.0  # MJCF default angle unit is degree
+        self.eulerseq = "xyz"
+        self.meshdir = ""
+        self.autolimits = True
+        self.inertiafromgeom = "auto"
+        self.inertiagrouprange = (0, 5)
+        self.bodies: List[_Body] = []
+        self.meshes: Dict[str, Dict[str, object]] = {}
+        self.opt = dict(timestep=0.002, gravity=np.array([0, 0, -9.81]), tolerance=1e-8, impratio=1.0,
+                        integrator=0, iterations=100, cone=0, noslip_iterations=0, eulerdamp=1)
+
+    # -- attribute helpers -------------------------------------------------
+    def _attrs(self, elem: ET.Element, tag: str, childclass: Optional[str]) -> Dict[str, str]:
+        cls = elem.attrib.get("class", childclass)
+        a = dict(self.defaults.get(cls, tag))
+        a.update(elem.attrib)
+        return a
+
+    def _orientation(self, a: Dict[str, str]) -> np.ndarray:
+        if "quat" in a:
+            return mu.quat_normalize(_floats(a["quat"]))
+        if "euler" in a:
+            return mu.euler2quat(_floats(a["euler"]) * self.angle_scale, self.eulerseq)
+        if "axisangle" in a:
+            v = _floats(a["axisangle"])
+            return mu.axisangle2quat(v[:3], v[3] * self.angle_scale)
+        if "xyaxes" in a:
+            return mu.xyaxes2quat(_floats(a["xyaxes"]))
+        if "zaxis" in a:
+            return mu.zaxis2quat(_floats(a["zaxis"]))
+        return np.array([1.0, 0.0, 0.0, 0.0])
+
+    # -- sections ------------------------------------------------------------
+    def _parse_globals(self):
+        for c in self.root.findall("compiler"):
+            a = c.attrib
+            if "angle" in a:
+                self.angle_scale = 1.0 if a["angle"] == "radian" else np.pi / 180.0
+            self.eulerseq = a.get("eulerseq", self.eulerseq)
+            self.meshdir = a.get("meshdir", self.meshdir)
+            if "autolimits" in a:
+                self.autolimits = _bool(a["autolimits"])
+            self.inertiafromgeom = a.get("inertiafromgeom", self.inertiafromgeom).lower()
+            if "inertiagrouprange" in a:
+                g = a["inertiagrouprange"].split()
+                self.inertiagrouprange = (int(g[0]), int(g[1]))
+            if a.get("coordinate", "local") != "local":
+                raise NotImplementedError("coordinate=global")
+        for o in self.root.findall("option"):
+            a = o.attrib
+            if "timestep" in a:
+                self.opt["timestep"] = float(a["timestep"])
+            if "gravity" in a:
+                self.opt["gravity"] = _floats(a["gravity"])
+            if "tolerance" in a:
+                self.opt["tolerance"] = float(a["tolerance"])
+            if "impratio" in a:
+                self.opt["impratio"] = float(a["impratio"])
+            if "iterations" in a:
+                self.opt["iterations"] = int(a["iterations"])
+            if "noslip_iterations" in a:
+                self.opt["noslip_iterations"] = int(a["noslip_iterations"])
+            if "integrator" in a:
+                self.opt["integrator"] = {"euler": 0, "rk4": 1, "implicit": 2, "implicitfast": 3}[a["integrator"].lower()]
+            if "cone" in a:
+                self.opt["cone"] = {"pyramidal": 0, "elliptic": 1}[a["cone"].lower()]
+            for fl in o.findall("flag"):
+                if fl.attrib.get("eulerdamp", "enable") == "disable":
+                    self.opt["eulerdamp"] = 0
+        for d in self.root.findall("default"):
+            self.defaults.add_tree(d)
+        for asset in self.root.findall("asset"):
+            for m in asset.findall("mesh"):
+                a = dict(self.defaults.get(m.attrib.get("class"), "mesh"))
+                a.update(m.attrib)
+                name = a.get("name") or os.path.splitext(os.path.basename(a["file"]))[0]
+                self.meshes[name] = dict(file=a["file"], scale=_floats(a.get("scale"), 3, [1, 1, 1]))
+
+    # -- bodies ------------------------------------------------------------------
+    def _parse_body(self, elem: ET.Element, parent: int, childclass: Optional[str]):
+        a = elem.attrib
+        childclass = a.get("childclass", childclass)
+        body = _Body(
+            name=a.get("name", f"_body{len(self.bodies)}"),
+            parent=parent,
+            pos=_floats(a.get("pos"), 3, [0, 0, 0]),
+            quat=self._orientation(a),
+            mocap=_bool(a.get("mocap"), False),
+        )
+        bid = len(self.bodies)
+        self.bodies.append(body)
+        for ch in elem:
+            if ch.tag == "inertial":
+                ia = ch.attrib
+                body.explicit_inertial = True
+                body.mass = float(ia["mass"])
+                body.ipos = _floats(ia.get("pos"), 3, [0, 0, 0])
+                iq = self._orientation(ia)
+                if "fullinertia" in ia:
+                    f = _floats(ia["fullinertia"])
+                    I = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]])
+                else:
+                    I = np.diag(_floats(ia.get("diaginertia"), 3, [0, 0, 0]))
+                R = mu.quat2mat(iq)
+                body.inertia = R @ I @ R.T
+            elif ch.tag in ("joint", "freejoint"):
+                body.joints.append(self._parse_joint(ch, childclass, bid))
+            elif ch.tag == "geom":
+                body.geoms.append(self._parse_geom(ch, childclass, bid))
+            elif ch.tag == "site":
+                body.sites.append(self._parse_site(ch, childclass, bid))
+        for ch in elem:
+            if ch.tag == "body":
+                self._parse_body(ch, bid, childclass)
+        return bid
+
+    def _parse_joint(self, elem, childclass, bid) -> _Joint:
+        if elem.tag == "freejoint":
+            a = dict(elem.attrib)
+            a["type"] = "free"
+        else:
+            a = self._attrs(elem, "joint", childclass)
+        jt = JNT_TYPES[a.get("type", "hinge")]
+        ang = self.angle_scale if jt in (JNT_HINGE, JNT_BALL) else 1.0
+        rng = _floats(a.get("range"), 2, [0, 0])
+        if "limited" in a and a["limited"] != "auto":
+            limited = _bool(a["limited"])
+        else:
+            limited = bool(self.autolimits and "range" in a)
+        axis = _floats(a.get("axis"), 3, [0, 0, 1])
+        n = np.linalg.norm(axis)
+        axis = axis / n if n > 0 else axis
+        ref = float(a.get("ref", 0.0)) * ang
+        return _Joint(
+            name=a.get("name", f"_jnt_{bid}_{id(elem)}"),
+            type=jt,
+            pos=_floats(a.get("pos"), 3, [0, 0, 0]),
+            axis=axis,
+            ref=ref,
+            springref=float(a.get("springref", 0.0)) * ang,
+            range=rng * ang,
+            limited=limited and jt in (JNT_SLIDE, JNT_HINGE, JNT_BALL),
+            margin=float(a.get("margin", 0.0)),
+            solref=_floats(a.get("solreflimit"), 2, [0.02, 1.0]),
+            solimp=_floats(a.get("solimplimit"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]),
+            stiffness=float(a.get("stiffness", 0.0)),
+            damping=float(a.get("damping", 0.0)),
+            armature=float(a.get("armature", 0.0)),
+            frictionloss=float(a.get("frictionloss", 0.0)),
+            solreffriction=_floats(a.get("solreffriction"), 2, [0.02, 1.0]),
+            solimpfriction=_floats(a.get("solimpfriction"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]),
+            body=bid,
+        )
+
+    def _parse_geom(self, elem, childclass, bid) -> _Geom:
+        a = self._attrs(elem, "geom", childclass)
+        gt = GEOM_TYPES[a.get("type", "sphere")]
+        size = _floats(a.get("size"), 3, [0, 0, 0])
+        pos = _floats(a.get("pos"), 3, [0, 0, 0])
+        quat = self._orientation(a)
+        if "fromto" in a:
+            ft = _floats(a["fromto"])
+            p0, p1 = ft[:3], ft[3:]
+            pos = 0.5 * (p0 + p1)
+            quat = mu.zaxis2quat(p1 - p0)
+            half = 0.5 * np.linalg.norm(p1 - p0)
+            if gt in (GEOM_CAPSULE, GEOM_CYLINDER):
+                size = np.array([size[0], half, 0.0])
+            elif gt in (GEOM_BOX, GEOM_ELLIPSOID):
+                size = np.array([size[0], size[0], half])
+        mass = float(a["mass"]) if "mass" in a else None
+        return _Geom(
+            name=a.get("name", ""),
+            type=gt,
+            pos=pos,
+            quat=quat,
+            size=size,
+            contype=int(a.get("contype", 1)),
+            conaffinity=int(a.get("conaffinity", 1)),
+            condim=int(a.get("condim", 3)),
+            priority=int(a.get("priority", 0)),
+            friction=_floats(a.get("friction"), 3, [1.0, 0.005, 0.0001]),
+            solmix=float(a.get("solmix", 1.0)),
+            solref=_floats(a.get("solref"), 2, [0.02, 1.0]),
+            solimp=_floats(a.get("solimp"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]),
+            margin=float(a.get("margin", 0.0)),
+            gap=float(a.get("gap", 0.0)),
+            mass=mass,
+            density=float(a.get("density", 1000.0)),
+            group=int(a.get("group", 0)),
+            mesh=a.get("mesh"),
+            body=bid,
+        )
+
+    def _parse_site(self, elem, childclass, bid) -> _Site:
+        a = self._attrs(elem, "site", childclass)
+        st = GEOM_TYPES[a.get("type", "sphere")]
+        size = _floats(a.get("size"), 3, [0.005, 0.005, 0.005])
+        pos = _floats(a.get("pos"), 3, [0, 0, 0])
+        quat = self._orientation(a)
+        if "fromto" in a:
+            ft = _floats(a["fromto"])
+            pos = 0.5 * (ft[:3] + ft[3:])
+            quat = mu.zaxis2quat(ft[3:] - ft[:3])
+            size = np.array([size[0], 0.5 * np.linalg.norm(ft[3:] - ft[:3]), 0.0])
+        return _Site(name=a.get("name", ""), type=st, pos=pos, quat=quat, size=size, body=bid)
+
+    # -- mesh hulls -----------------------------------------------------------------
+    def _load_mesh_hull(self, name: str):
+        """Returns (hull vertices (n,3), adjacency list) of the mesh's convex hull."""
+        m = self.meshes[name]
+        if "hull" in m:
+            return m["hull"]
+        path = os.path.join(self.dir, self.meshdir, m["file"])
+        with open(path, "rb") as f:
+            b = f.read()
+        ntri = struct.unpack("<I", b[80:84])[0]
+        if 84 + 50 * ntri != len(b):
+            raise NotImplementedError(f"only binary STL supported: {path}")
+        rec = np.frombuffer(b[84: 84 + 50 * ntri], dtype=np.uint8).reshape(ntri, 50)
+        v = rec[:, 12:48].copy().view("<f4").reshape(-1, 3).astype(np.float64) * m["scale"]
+        v = np.unique(v, axis=0)
+        from scipy.spatial import ConvexHull
+
+        hull = ConvexHull(v)
+        idx = np.unique(hull.simplices.ravel())
+        remap = -np.ones(len(v), dtype=np.int64)
+        remap[idx] = np.arange(len(idx))
+        hv = v[idx]
+        adj = [set() for _ in range(len(idx))]
+        for s in hull.simplices:
+            for i in range(3):
+                p, q = remap[s[i]], remap[s[(i + 1) % 3]]
+                adj[p].add(int(q))
+                adj[q].add(int(p))
+        m["hull"] = (hv, [sorted(s) for s in adj])
+        return m["hull"]
+
+    # -- inertia from geoms -----------------------------------------------------------
+    @staticmethod
+    def _geom_volume_inertia(g: _Geom):
+        """(volume, unit-density inertia about geom centre in geom frame) for primitives."""
+        s = g.size
+        if g.type == GEOM_SPHERE:
+            vol = 4.0 / 3.0 * np.pi * s[0] ** 3
+            I = np.eye(3) * (0.4 * vol * s[0] ** 2)
+        elif g.type == GEOM_BOX:
+            vol = 8 * s[0] * s[1] * s[2]
+            I = np.diag([vol / 3 * (s[1] ** 2 + s[2] ** 2), vol / 3 * (s[0] ** 2 + s[2] ** 2), vol / 3 * (s[0] ** 2 + s[1] ** 2)])
+        elif g.type == GEOM_CYLINDER:
+            r, h = s[0], s[1]
+            vol = np.pi * r * r * 2 * h
+            ix = vol * (3 * r * r + (2 * h) ** 2) / 12.0
+            I = np.diag([ix, ix, vol * r * r / 2])
+        elif g.type == GEOM_CAPSULE:
+            r, h = s[0], s[1]
+            vc = np.pi * r * r * 2 * h
+            vs = 4.0 / 3.0 * np.pi * r ** 3
+            vol = vc + vs
+            ixc = vc * (3 * r * r + (2 * h) ** 2) / 12.0
+            izc = vc * r * r / 2
+            # two hemispheres: sphere inertia + parallel axis for hemisphere offsets
+            izs = 0.4 * vs * r * r
+            ixs = 0.4 * vs * r * r + vs * h * h + 0.75 * vs * r * h
+            I = np.diag([ixc + ixs, ixc + ixs, izc + izs])
+        elif g.type == GEOM_ELLIPSOID:
+            vol = 4.0 / 3.0 * np.pi * s[0] * s[1] * s[2]
+            I = np.diag([vol / 5 * (s[1] ** 2 + s[2] ** 2), vol / 5 * (s[0] ** 2 + s[2] ** 2), vol / 5 * (s[0] ** 2 + s[1] ** 2)])
+        else:
+            return 0.0, np.zeros((3, 3))
+        return vol, I
+
+    def _derive_inertia(self, body: _Body):
+        if self.inertiafromgeom == "false" or (self.inertiafromgeom == "auto" and body.explicit_inertial):
+            return
+        tot_m = 0.0
+        com = np.zeros(3)
+        parts = []
+        for g in body.geoms:
+            if not (self.inertiagrouprange[0] <= g.group <= self.inertiagrouprange[1]):
+                continue
+            if g.type == GEOM_MESH:
+                hv, _ = self._load_mesh_hull(g.mesh)
+                vol, c, I = _polyhedron_mass_props(hv)
+                gm = g.mass if g.mass is not None else g.density * vol
+                scale = gm / vol if vol > 0 else 0.0
+                R = mu.quat2mat(g.quat)
+                parts.append((gm, g.pos + R @ c, R @ (I * scale) @ R.T))
+            else:
+                vol, I = self._geom_volume_inertia(g)
+                if vol <= 0:
+                    continue
+                gm = g.mass if g.mass is not None else g.density * vol
+                R = mu.quat2mat(g.quat)
+                parts.append((gm, g.pos.copy(), R @ (I * gm / vol) @ R.T))
+        for gm, c, _ in parts:
+            tot_m += gm
+            com += gm * c
+        if tot_m <= 0:
+            return
+        com /= tot_m
+        I = np.zeros((3, 3))
+        for gm, c, Ig in parts:
+            d = c - com
+            I += Ig + gm * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+        body.mass, body.ipos, body.inertia = tot_m, com, I
+
+    # -- main ------------------------------------------------------------------------
+    def compile(self) -> CompiledModel:
+        self._parse_globals()
+        world = _Body(name="world", parent=-1, pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]), mocap=False)
+        self.bodies.append(world)
+        for wb in self.root.findall("worldbody"):
+            for ch in wb:
+                if ch.tag == "geom":
+                    world.geoms.append(self._parse_geom(ch, None, 0))
+                elif ch.tag == "site":
+                    world.sites.append(self._parse_site(ch, None, 0))
+            for ch in wb:
+                if ch.tag == "body":
+                    self._parse_body(ch, 0, None)
+        for b in self.bodies[1:]:
+            self._derive_inertia(b)
+        return _Lowering(self).run()
+
+
+def _polyhedron_mass_props(hv: np.ndarray):
+    """Volume, COM and unit-density inertia (about COM) of the convex hull of hv."""
+    from scipy.spatial import ConvexHull
+
+    hull = ConvexHull(hv)
+    c0 = hv.mean(axis=0)
+    vol = 0.0
+    com = np.zeros(3)
+    C = np.zeros((3, 3))  # integral of x x^T about c0
+    for s in hull.simplices:
+        a, b, c = hv[s[0]] - c0, hv[s[1]] - c0, hv[s[2]] - c0
+        v = abs(np.dot(a, np.cross(b, c))) / 6.0
+        vol += v
+        com += v * (a + b + c) / 4.0
+        sm = a + b + c
+        C += v / 20.0 * (np.outer(a, a) + np.outer(b, b) + np.outer(c, c) + np.outer(sm, sm))
+    com /= vol
+    C = C - vol * np.outer(com, com)
+    I = np.trace(C) * np.eye(3) - C
+    return vol, c0 + com, I
+
+
+# ----------------------------------------------------------------------------
+# lowering: full tree -> invweights -> fused tree -> tables
+# ----------------------------------------------------------------------------
+class _Lowering:
+    def __init__(self, c: MjcfCompiler):
+        self.c = c
+        self.bodies = c.bodies
+
+    # full-tree forward kinematics at qpos0 (all joints at their reference)
+    def _kin0(self):
+        nb = len(self.bodies)
+        xpos = np.zeros((nb, 3))
+        xquat = np.zeros((nb, 4))
+        xquat[0] = [1, 0, 0, 0]
+        for i in range(1, nb):
+            b = self.bodies[i]
+            p = b.parent
+            xpos[i] = xpos[p] + mu.rot_vec(xquat[p], b.pos)
+            xquat[i] = mu.quat_normalize(mu.quat_mul(xquat[p], b.quat))
+        return xpos, xquat
+
+    def run(self) -> CompiledModel:
+        c = self.c
+        B = self.bodies
+        nb = len(B)
+        xpos, xquat = self._kin0()
+        xmat = np.array([mu.quat2mat(q) for q in xquat])
+
+        # ---- dof enumeration on the full tree
+        jnts: List[_Joint] = []
+        nq = nv = 0
+        for bi, b in enumerate(B):
+            for j in b.joints:
+                j.body = bi
+                j.qposadr, j.dofadr = nq, nv
+                nq += {JNT_FREE: 7, JNT_BALL: 4}.get(j.type, 1)
+                nv += {JNT_FREE: 6, JNT_BALL: 3}.get(j.type, 1)
+                jnts.append(j)
+        weld = list(range(nb))  # weld id: nearest ancestor-or-self with joints (0 = static)
+        for i in range(1, nb):
+            if not B[i].joints:
+                weld[i] = weld[B[i].parent] if not B[i].mocap else 0
+        # dof -> (joint, local index)
+        dof_jnt = []
+        for j in jnts:
+            dof_jnt += [(j, k) for k in range({JNT_FREE: 6, JNT_BALL: 3}.get(j.type, 1))]
+
+        def chain_dofs(bi):
+            """dofs affecting body bi, root first"""
+            out = []
+            while bi > 0:
+                for j in reversed(B[bi].joints):
+                    n = {JNT_FREE: 6, JNT_BALL: 3}.get(j.type, 1)
+                    out = list(range(j.dofadr, j.dofadr + n)) + out
+                bi = B[bi].parent
+            return out
+
+        def jac(bi, point):
+            """6 x nv (translation rows first) Jacobian of a world point fixed to body bi at qpos0"""
+            J = np.zeros((6, nv))
+            for d in chain_dofs(bi):
+                j, k = dof_jnt[d]
+                jb = j.body
+                R = xmat[jb]
+                if j.type == JNT_SLIDE:
+                    J[:3, d] = R @ j.axis
+                elif j.type == JNT_HINGE:
+                    ax = R @ j.axis
+                    anchor = xpos[jb] + R @ j.pos
+                    J[:3, d] = np.cross(ax, point - anchor)
+                    J[3:, d] = ax
+                elif j.type == JNT_FREE:
+                    if k < 3:
+                        J[k, d] = 1.0
+                    else:
+                        ax = R[:, k - 3]
+                        J[:3, d] = np.cross(ax, point - xpos[jb])
+                        J[3:, d] = ax
+                else:
+                    ax = R[:, k]
+                    anchor = xpos[jb] + R @ j.pos
+                    J[:3, d] = np.cross(ax, point - anchor)
+                    J[3:, d] = ax
+            return J
+
+        # ---- mass matrix at qpos0 (sum_b J^T I J + armature)
+        M = np.zeros((nv, nv))
+        for bi in range(1, nb):
+            b = B[bi]
+            if b.mass <= 0 and not np.any(b.inertia):
+                continue
+            xi = xpos[bi] + xmat[bi] @ b.ipos
+            J = jac(bi, xi)
+            Iw = xmat[bi] @ b.inertia @ xmat[bi].T
+            M += b.mass * J[:3].T @ J[:3] + J[3:].T @ Iw @ J[3:]
+        for d, (j, k) in enumerate(dof_jnt):
+            M[d, d] += j.armature
+        Minv = np.linalg.inv(M) if nv else np.zeros((0, 0))
+        dof_invweight0 = np.diag(Minv).copy() if nv else np.zeros(0)
+        for j in jnts:
+            if j.type == JNT_FREE:
+                a = j.dofadr
+                dof_invweight0[a: a + 3] = dof_invweight0[a: a + 3].mean()
+                dof_invweight0[a + 3: a + 6] = dof_invweight0[a + 3: a + 6].mean()
+            elif j.type == JNT_BALL:
+                a = j.dofadr
+                dof_invweight0[a: a + 3] = dof_invweight0[a: a + 3].mean()
+        body_invweight0 = np.zeros((nb, 2))
+        for bi in range(1, nb):
+            if weld[bi] == 0:
+                continue
+            xi = xpos[bi] + xmat[bi] @ B[bi].ipos
+            J = jac(bi, xi)
+            A = J @ Minv @ J.T
+            body_invweight0[bi, 0] = max(MJ_MINVAL, np.trace(A[:3, :3]) / 3)
+            body_invweight0[bi, 1] = max(MJ_MINVAL, np.trace(A[3:, 3:]) / 3)
+        meaninertia = float(np.mean(np.diag(M))) if nv else 1.0
+
+        # ---- fuse static bodies
+        keep = [i for i in range(nb) if i == 0 or B[i].joints or B[i].mocap]
+        new_id = {old: k for k, old in enumerate(keep)}
+
+        def anchor_of(i):
+            """(kept ancestor-or-self, relative pos, relative quat) of body i"""
+            p = np.zeros(3)
+            q = np.array([1.0, 0, 0, 0])
+            while i not in new_id:
+                b = B[i]
+                p = b.pos + mu.rot_vec(b.quat, p)
+                q = mu.quat_mul(b.quat, q)
+                i = b.parent
+            return i, p, mu.quat_normalize(q)
+
+        fb_mass = {k: 0.0 for k in keep}
+        fb_com = {k: np.zeros(3) for k in keep}
+        parts = {k: [] for k in keep}
+        for i in range(1, nb):
+            b = B[i]
+            if b.mass <= 0 and not np.any(b.inertia):
+                continue
+            k, p, q = anchor_of(i)
+            if k == 0:
+                continue
+            R = mu.quat2mat(q)
+            parts[k].append((b.mass, p + R @ b.ipos, R @ b.inertia @ R.T))
+        fb_inertia = {k: np.zeros((3, 3)) for k in keep}
+        for k in keep:
+            m = sum(x[0] for x in parts[k])
+            if m > 0:
+                com = sum(x[0] * x[1] for x in parts[k]) / m
+            else:
+                com = np.zeros(3)
+            I = np.zeros((3, 3))
+            for pm, pc, pI in parts[k]:
+                d = pc - com
+                I += pI + pm * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+            fb_mass[k], fb_com[k], fb_inertia[k] = m, com, I
+
+        T: Dict[str, np.ndarray] = {}
+        names: Dict[str, Dict[str, int]] = {k: {} for k in ("body", "joint", "geom", "site", "actuator", "mocap", "body_orig")}
+        info: Dict[str, object] = {"xml": os.path.basename(c.xml_path)}
+        nbk = len(keep)
+        body_parent = np.zeros(nbk, np.int32)
+        body_depth = np.zeros(nbk, np.int32)
+        body_rootid = np.zeros(nbk, np.int32)
+        for k, old in enumerate(keep):
+            names["body"][B[old].name] = k
+            if k == 0:
+                continue
+            par, _, _ = anchor_of(B[old].parent)
+            body_parent[k] = new_id[par]
+            body_depth[k] = body_depth[body_parent[k]] + 1
+            body_rootid[k] = k if body_parent[k] == 0 else body_rootid[body_parent[k]]
+        # original body name -> (fused id, rel pos, rel quat)
+        body_orig = {}
+        for i in range(nb):
+            k, p, q = anchor_of(i)
+            body_orig[B[i].name] = (new_id[k], p.tolist(), q.tolist())
+        info["body_orig"] = body_orig
+
+        body_pos = np.zeros((nbk, 3))
+        body_quat = np.tile(np.array([1.0, 0, 0, 0]), (nbk, 1))
+        body_ipos = np.zeros((nbk, 3))
+        body_inertia = np.zeros((nbk, 6))
+        body_mass = np.zeros(nbk)
+        body_jntadr = -np.ones(nbk, np.int32)
+        body_jntnum = np.zeros(nbk, np.int32)
+        body_dofadr = -np.ones(nbk, np.int32)
+        body_dofnum = np.zeros(nbk, np.int32)
+        body_mocapid = -np.ones(nbk, np.int32)
+        nmocap = 0
+        mocap_pos0, mocap_quat0 = [], []
+        jcount = 0
+        for k, old in enumerate(keep):
+            if k == 0:
+                continue
+            b = B[old]
+            # pose relative to the kept parent: compose through fused static ancestors
+            par_old = b.parent
+            pk, pp, pq = anchor_of(par_old)
+            body_pos[k] = pp + mu.rot_vec(pq, b.pos)
+            body_quat[k] = mu.quat_normalize(mu.quat_mul(pq, b.quat))
+            body_ipos[k] = fb_com[old]
+            I = fb_inertia[old]
+            body_inertia[k] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+            body_mass[k] = fb_mass[old]
+            if b.joints:
+                body_jntadr[k] = jcount
+                body_jntnum[k] = len(b.joints)
+                body_dofadr[k] = b.joints[0].dofadr
+                body_dofnum[k] = sum({JNT_FREE: 6, JNT_BALL: 3}.get(j.type, 1) for j in b.joints)
+                jcount += len(b.joints)
+            if b.mocap:
+                body_mocapid[k] = nmocap
+                names["mocap"][b.name] = nmocap
+                nmocap += 1
+                mocap_pos0.append(body_pos[k].copy())
+                mocap_quat0.append(body_quat[k].copy())
+
+        njnt = len(jnts)
+        qpos0 = np.zeros(nq)
+        for j in jnts:
+            names["joint"][j.name] = jnts.index(j)
+            if j.type == JNT_FREE:
+                bi = j.body
+                qpos0[j.qposadr: j.qposadr + 3] = xpos[bi]
+                qpos0[j.qposadr + 3: j.qposadr + 7] = xquat[bi]
+            elif j.type == JNT_BALL:
+                qpos0[j.qposadr: j.qposadr + 4] = [1, 0, 0, 0]
+            else:
+                qpos0[j.qposadr] = j.ref
+
+        def arr(fn, dtype=np.float64):
+            return np.array([fn(j) for j in jnts], dtype=dtype).reshape(njnt, -1) if njnt else np.zeros((0, 1), dtype)
+
+        T["jnt_type"] = arr(lambda j: j.type, np.int32)
+        T["jnt_qposadr"] = arr(lambda j: j.qposadr, np.int32)
+        T["jnt_dofadr"] = arr(lambda j: j.dofadr, np.int32)
+        T["jnt_bodyid"] = arr(lambda j: new_id[j.body], np.int32)
+        T["jnt_limited"] = arr(lambda j: int(j.limited), np.int32)
+        T["jnt_pos"] = arr(lambda j: j.pos)
+        T["jnt_axis"] = arr(lambda j: j.axis)
+        T["jnt_range"] = arr(lambda j: j.range)
+        T["jnt_margin"] = arr(lambda j: j.margin)
+        T["jnt_solref"] = arr(lambda j: j.solref)
+        T["jnt_solimp"] = arr(lambda j: j.solimp)
+        T["jnt_stiffness"] = arr(lambda j: j.stiffness)
+        # spring rest value: for slide/hinge q_spring = springref (MJCF), offset handled by engine as q - springref
+        T["jnt_springref"] = arr(lambda j: j.springref)
+
+        dof_bodyid = np.zeros(nv, np.int32)
+        dof_jntid = np.zeros(nv, np.int32)
+        dof_parentid = -np.ones(nv, np.int32)
+        dof_arm = np.zeros(nv)
+        dof_damp = np.zeros(nv)
+        dof_fl = np.zeros(nv)
+        dof_solref = np.zeros((nv, 2))
+        dof_solimp = np.zeros((nv, 5))
+        last_dof_of_body = {0: -1}
+        for k, old in enumerate(keep):
+            if k == 0:
+                continue
+            prev = last_dof_of_body[int(body_parent[k])]
+            for j in B[old].joints:
+                n = {JNT_FREE: 6, JNT_BALL: 3}.get(j.type, 1)
+                for t in range(n):
+                    d = j.dofadr + t
+                    dof_bodyid[d] = k
+                    dof_jntid[d] = jnts.index(j)
+                    dof_parentid[d] = prev
+                    dof_arm[d] = j.armature
+                    dof_damp[d] = j.damping
+                    dof_fl[d] = j.frictionloss
+                    dof_solref[d] = j.solreffriction
+                    dof_solimp[d] = j.solimpfriction
+                    prev = d
+            last_dof_of_body[k] = prev
+
+        # ---- geoms (collidable only) and sites, re-expressed in fused frames
+        geoms = []
+        for i in range(nb):
+            for g in B[i].geoms:
+                if g.contype == 0 and g.conaffinity == 0:
+                    continue
+                geoms.append((i, g))
+        ng = len(geoms)
+        geom_type = np.zeros(ng, np.int32)
+        geom_bodyid = np.zeros(ng, np.int32)
+        geom_meshadr = -np.ones(ng, np.int32)
+        geom_meshnum = np.zeros(ng, np.int32)
+        geom_pos = np.zeros((ng, 3))
+        geom_quat = np.zeros((ng, 4))
+        geom_size = np.zeros((ng, 3))
+        geom_invw = np.zeros((ng, 2))
+        geom_rbound = np.zeros(ng)
+        mesh_vert, mesh_adjadr, mesh_adjnum, mesh_adj = [], [], [], []
+        mesh_cache = {}
+        for gi, (i, g) in enumerate(geoms):
+            k, p, q = anchor_of(i)
+            names["geom"][g.name or f"_geom{gi}"] = gi
+            geom_type[gi] = g.type
+            geom_bodyid[gi] = new_id[k]
+            geom_pos[gi] = p + mu.rot_vec(q, g.pos)
+            geom_quat[gi] = mu.quat_normalize(mu.quat_mul(q, g.quat))
+            geom_size[gi] = g.size
+            geom_invw[gi] = body_invweight0[i]
+            s = g.size
+            if g.type == GEOM_MESH:
+                if g.mesh not in mesh_cache:
+                    hv, adj = c._load_mesh_hull(g.mesh)
+                    adr = len(mesh_vert)
+                    for v, a in zip(hv, adj):
+                        mesh_vert.append(v)
+                        mesh_adjadr.append(len(mesh_adj))
+                        mesh_adjnum.append(len(a))
+                        mesh_adj.extend(a)
+                    mesh_cache[g.mesh] = (adr, len(hv))
+                geom_meshadr[gi], geom_meshnum[gi] = mesh_cache[g.mesh]
+                hv = np.array(mesh_vert[geom_meshadr[gi]: geom_meshadr[gi] + geom_meshnum[gi]])
+                geom_rbound[gi] = np.linalg.norm(hv, axis=1).max()
+            elif g.type == GEOM_SPHERE:
+                geom_rbound[gi] = s[0]
+            elif g.type == GEOM_CAPSULE:
+                geom_rbound[gi] = s[0] + s[1]
+            elif g.type == GEOM_CYLINDER:
+                geom_rbound[gi] = np.hypot(s[0], s[1])
+            elif g.type in (GEOM_BOX, GEOM_ELLIPSOID):
+                geom_rbound[gi] = np.linalg.norm(s) if g.type == GEOM_BOX else s.max()
+        sites = [(i, s) for i in range(nb) for s in B[i].sites]
+        ns = len(sites)
+        site_bodyid = np.zeros(ns, np.int32)
+        site_type = np.zeros(ns, np.int32)
+        site_pos = np.zeros((ns, 3))
+        site_quat = np.zeros((ns, 4))
+        site_size = np.zeros((ns, 3))
+        for si, (i, s) in enumerate(sites):
+            k, p, q = anchor_of(i)
+            names["site"][s.name or f"_site{si}"] = si
+            site_bodyid[si] = new_id[k]
+            site_type[si] = s.type
+            site_pos[si] = p + mu.rot_vec(q, s.pos)
+            site_quat[si] = mu.quat_normalize(mu.quat_mul(q, s.quat))
+            site_size[si] = s.size
+
+        # ---- collision candidate pairs
+        excludes = set()
+        for ct in c.root.findall("contact"):
+            for ex in ct.findall("exclude"):
+                b1 = next(i for i, b in enumerate(B) if b.name == ex.attrib["body1"])
+                b2 = next(i for i, b in enumerate(B) if b.name == ex.attrib["body2"])
+                excludes.add((min(b1, b2), max(b1, b2)))
+        weldparent = [weld[B[weld[i]].parent] if weld[i] > 0 else 0 for i in range(nb)]
+        supported = {
+            (GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_CYLINDER),
+            (GEOM_PLANE, GEOM_BOX), (GEOM_PLANE, GEOM_MESH), (GEOM_SPHERE, GEOM_SPHERE),
+            (GEOM_SPHERE, GEOM_CAPSULE), (GEOM_SPHERE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CAPSULE),
+            (GEOM_CAPSULE, GEOM_BOX), (GEOM_BOX, GEOM_BOX),
+        }
+        pairs = []
+        for a in range(ng):
+            for b_ in range(a + 1, ng):
+                (i1, g1), (i2, g2) = geoms[a], geoms[b_]
+                w1, w2 = weld[i1], weld[i2]
+                if w1 == w2:
+                    continue
+                if w1 != 0 and w2 != 0 and (w1 == weldparent[i2] or w2 == weldparent[i1]):
+                    continue
+                if not ((g1.contype & g2.conaffinity) or (g2.contype & g1.conaffinity)):
+                    continue
+                if (min(i1, i2), max(i1, i2)) in excludes:
+                    continue
+                ga, gb, A_, B_ = (g1, g2, a, b_) if g1.type <= g2.type else (g2, g1, b_, a)
+                if ga.type == GEOM_PLANE and gb.type == GEOM_PLANE:
+                    continue
+                pairs.append((A_, B_, ga, gb))
+        npair = len(pairs)
+        pair_geom1 = np.zeros(npair, np.int32)
+        pair_geom2 = np.zeros(npair, np.int32)
+        pair_condim = np.zeros(npair, np.int32)
+        pair_supported = np.zeros(npair, np.int32)
+        pair_friction = np.zeros((npair, 5))
+        pair_solref = np.zeros((npair, 2))
+        pair_solimp = np.zeros((npair, 5))
+        pair_margin = np.zeros(npair)
+        pair_gap = np.zeros(npair)
+        for pi, (A_, B_, ga, gb) in enumerate(pairs):
+            pair_geom1[pi], pair_geom2[pi] = A_, B_
+            pair_supported[pi] = int((ga.type, gb.type) in supported)
+            if ga.priority != gb.priority:
+                gp = ga if ga.priority > gb.priority else gb
+                pair_condim[pi] = gp.condim
+                fr = gp.friction
+                pair_solref[pi], pair_solimp[pi] = gp.solref, gp.solimp
+            else:
+                pair_condim[pi] = max(ga.condim, gb.condim)
+                fr = np.maximum(ga.friction, gb.friction)
+                if ga.solmix >= MJ_MINVAL and gb.solmix >= MJ_MINVAL:
+                    mix = ga.solmix / (ga.solmix + gb.solmix)
+                elif ga.solmix < MJ_MINVAL and gb.solmix < MJ_MINVAL:
+                    mix = 0.5
+                elif ga.solmix < MJ_MINVAL:
+                    mix = 0.0
+                else:
+                    mix = 1.0
+                if ga.solref[0] > 0 and gb.solref[0] > 0:
+                    pair_solref[pi] = mix * ga.solref + (1 - mix) * gb.solref
+                else:
+                    pair_solref[pi] = np.minimum(ga.solref, gb.solref)
+                pair_solimp[pi] = mix * ga.solimp + (1 - mix) * gb.solimp
+            pair_friction[pi] = [fr[0], fr[0], fr[1], fr[2], fr[2]]
+            pair_margin[pi] = max(ga.margin, gb.margin)
+            pair_gap[pi] = max(ga.gap, gb.gap)
+
+        # ---- equality constraints
+        eqs = []
+        for eqsec in c.root.findall("equality"):
+            for e in eqsec:
+                a = dict(c.defaults.get(e.attrib.get("class"), "equality"))
+                a.update(e.attrib)
+                if e.tag != "weld":
+                    raise NotImplementedError(f"equality type {e.tag}")
+                i1 = next(i for i, b in enumerate(B) if b.name == a["body1"])
+                i2 = next(i for i, b in enumerate(B) if b.name == a.get("body2", "world"))
+                k1, p1, q1 = anchor_of(i1)
+                k2, p2, q2 = anchor_of(i2)
+                anchor = _floats(a.get("anchor"), 3, [0, 0, 0])
+                R1 = xmat[i1]
+                relpos = R1.T @ (xpos[i2] + xmat[i2] @ anchor - xpos[i1])
+                relquat = mu.quat_mul(mu.quat_conj(xquat[i1]), xquat[i2])
+                if "relpose" in a:
+                    rp = _floats(a["relpose"])
+                    if np.any(rp[3:] != 0) and not np.allclose(rp, [0, 1, 0, 0, 0, 0, 0]):
+                        relpos, relquat = rp[:3], mu.quat_normalize(rp[3:])
+                data = np.zeros(11)
+                data[0:3] = anchor
+                data[3:6] = relpos
+                data[6:10] = relquat
+                data[10] = float(a.get("torquescale", 1.0))
+                eqs.append(dict(
+                    type=EQ_WELD, obj1=new_id[k1], obj2=new_id[k2], active=int(_bool(a.get("active"), True)),
+                    data=data, solref=_floats(a.get("solref"), 2, [0.02, 1.0]),
+                    solimp=_floats(a.get("solimp"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]),
+                    invw=body_invweight0[i1] + body_invweight0[i2],
+                        relpose=np.concatenate([p1, q1, p2, q2]),
+                ))
+        neq = len(eqs)
+
+        # ---- actuators
+        acts = []
+        for asec in c.root.findall("actuator"):
+            for e in asec:
+                cls = e.attrib.get("class")
+                a = dict(c.defaults.get(cls, "general"))
+                own = _actuator_shortcut(e.tag, dict(e.attrib)) if e.tag != "general" else dict(e.attrib)
+                a.update(own)
+                if a.get("_position") or e.tag == "position":
+                    kp = float(a.get("_kp", _floats(a.get("gainprm"), 3, [1, 0, 0])[0]))
+                    kv = float(a.get("_kv", 0.0))
+                    a["gainprm"] = f"{kp} 0 0"
+                    a["biasprm"] = f"0 {-kp} {-kv}"
+                    a["biastype"] = "affine"
+                    a["gaintype"] = "fixed"
+                if "joint" not in a:
+                    raise NotImplementedError("only joint transmissions are supported")
+                jid = names["joint"][a["joint"]]
+                ctrlrange = _floats(a.get("ctrlrange"), 2, [0, 0])
+                forcerange = _floats(a.get("forcerange"), 2, [0, 0])
+                cl = a.get("ctrllimited", "auto")
+                fl = a.get("forcelimited", "auto")
+                acts.append(dict(
+                    name=a.get("name", f"_act{len(acts)}"), trnid=jid,
+                    gaintype={"fixed": 0, "affine": 1}[a.get("gaintype", "fixed")],
+                    biastype={"none": 0, "affine": 1}[a.get("biastype", "none")],
+                    ctrllimited=int(_bool(cl) if cl != "auto" else (c.autolimits and "ctrlrange" in a)),
+                    forcelimited=int(_bool(fl) if fl != "auto" else (c.autolimits and "forcerange" in a)),
+                    gear=_floats(a.get("gear"), 6, [1, 0, 0, 0, 0, 0])[0],
+                    gainprm=_floats(a.get("gainprm"), 3, [1, 0, 0])[:3],
+                    biasprm=_floats(a.get("biasprm"), 3, [0, 0, 0])[:3],
+                    ctrlrange=ctrlrange, forcerange=forcerange,
+                ))
+        nu = len(acts)
+        for i, a in enumerate(acts):
+            names["actuator"][a["name"]] = i
+
+        # ---- assemble tables
+        dims = np.zeros(NDIMS, np.int32)
+        vals = dict(nq=nq, nv=nv, nu=nu, nbody=nbk, njnt=njnt, ngeom=ng, nsite=ns, nmocap=nmocap, neq=neq,
+                    npair=npair, nmeshvert=len(mesh_vert), nmeshadj=len(mesh_adj),
+                    integrator=c.opt["integrator"], iterations=c.opt["iterations"], cone=c.opt["cone"],
+                    noslip_iterations=c.opt["noslip_iterations"], eulerdamp=c.opt["eulerdamp"],
+                    ntree=int(np.sum(body_parent[1:] == 0)), maxdepth=int(body_depth.max()))
+        for k, v in vals.items():
+            dims[DIMS.index(k)] = v
+        optv = np.zeros(NOPTS)
+        g = c.opt["gravity"]
+        for k, v in dict(timestep=c.opt["timestep"], gravity_x=g[0], gravity_y=g[1], gravity_z=g[2],
+                         tolerance=c.opt["tolerance"], impratio=c.opt["impratio"], meaninertia=meaninertia).items():
+            optv[OPTS.index(k)] = v
+        T.update(
+            dims=dims, opt=optv, qpos0=qpos0,
+            body_parent=body_parent, body_jntadr=body_jntadr, body_jntnum=body_jntnum, body_dofadr=body_dofadr,
+            body_dofnum=body_dofnum, body_mocapid=body_mocapid, body_rootid=body_rootid, body_depth=body_depth,
+            body_pos=body_pos, body_quat=body_quat, body_ipos=body_ipos, body_inertia=body_inertia, body_mass=body_mass,
+            dof_bodyid=dof_bodyid, dof_jntid=dof_jntid, dof_parentid=dof_parentid, dof_armature=dof_arm,
+            dof_damping=dof_damp, dof_frictionloss=dof_fl, dof_invweight0=dof_invweight0,
+            dof_solref=dof_solref, dof_solimp=dof_solimp,
+            geom_type=geom_type, geom_bodyid=geom_bodyid, geom_meshadr=geom_meshadr, geom_meshnum=geom_meshnum,
+            geom_pos=geom_pos, geom_quat=geom_quat, geom_size=geom_size, geom_invweight0=geom_invw, geom_rbound=geom_rbound,
+            site_bodyid=site_bodyid, site_type=site_type, site_pos=site_pos, site_quat=site_quat, site_size=site_size,
+            pair_geom1=pair_geom1, pair_geom2=pair_geom2, pair_condim=pair_condim, pair_supported=pair_supported,
+            pair_friction=pair_friction, pair_solref=pair_solref, pair_solimp=pair_solimp, pair_margin=pair_margin,
+            pair_gap=pair_gap,
+            eq_type=np.array([e["type"] for e in eqs], np.int32), eq_obj1=np.array([e["obj1"] for e in eqs], np.int32),
+            eq_obj2=np.array([e["obj2"] for e in eqs], np.int32), eq_active=np.array([e["active"] for e in eqs], np.int32),
+            eq_data=np.array([e["data"] for e in eqs]).reshape(neq, 11), eq_solref=np.array([e["solref"] for e in eqs]).reshape(neq, 2),
+            eq_solimp=np.array([e["solimp"] for e in eqs]).reshape(neq, 5), eq_invweight=np.array([e["invw"] for e in eqs]).reshape(neq, 2),
+            eq_relpose=np.array([e["relpose"] for e in eqs]).reshape(neq, 14),
+            act_trntype=np.zeros(nu, np.int32), act_trnid=np.array([a["trnid"] for a in acts], np.int32),
+            act_gaintype=np.array([a["gaintype"] for a in acts], np.int32), act_biastype=np.array([a["biastype"] for a in acts], np.int32),
+            act_ctrllimited=np.array([a["ctrllimited"] for a in acts], np.int32),
+            act_forcelimited=np.array([a["forcelimited"] for a in acts], np.int32),
+            act_gear=np.array([a["gear"] for a in acts], np.float64),
+            act_gainprm=np.array([a["gainprm"] for a in acts]).reshape(nu, 3), act_biasprm=np.array([a["biasprm"] for a in acts]).reshape(nu, 3),
+            act_ctrlrange=np.array([a["ctrlrange"] for a in acts]).reshape(nu, 2),
+            act_forcerange=np.array([a["forcerange"] for a in acts]).reshape(nu, 2),
+            mocap_pos0=np.array(mocap_pos0).reshape(nmocap, 3), mocap_quat0=np.array(mocap_quat0).reshape(nmocap, 4),
+            mesh_vert=np.array(mesh_vert).reshape(len(mesh_vert), 3), mesh_adjadr=np.array(mesh_adjadr, np.int32),
+            mesh_adjnum=np.array(mesh_adjnum, np.int32), mesh_adj=np.array(mesh_adj, np.int32),
+        )
+        info["nbody_full"] = nb
+        info["unsupported_pairs"] = int(np.sum(pair_supported == 0))
+        return CompiledModel(T, names, info)
+
+
+def compile_mjcf(xml_path: str) -> CompiledModel:
+    return MjcfCompiler(xml_path).compile()
