@@ -1,0 +1,1183 @@
+// grx_engine.h -- wave-per-world batched rigid-body engine for gfx950 (CDNA4).
+//
+// One 64-lane wavefront owns ONE world.  All per-world working state lives in LDS
+// for the whole fused env-step (n_substeps physics steps + task code), so HBM is
+// touched once per env-step.  Lanes are mapped to bodies / dofs / constraint rows /
+// matrix entries stage by stage; stages are separated by wave barriers.
+//
+// This is the replacement for the third-party call
+//   mujoco.mj_step(model, data, nstep)   /root/reference/gymnasium_robotics/envs/robot_env.py:341
+//   mujoco.mj_forward(model, data)       /root/reference/gymnasium_robotics/envs/fetch/fetch_env.py:303,401
+// (stage inventory K1-K14 in SURVEY.md §8(a)); arithmetic is fp32.
+//
+// Programming model used below (so that tests can run the SAME source through a
+// sequential lane emulator on a machine without a GPU, see tests/emu/):
+//   * code outside FOR_LANES is wave-uniform (every lane computes the same thing),
+//   * code inside FOR_LANES{...} is per lane; it may only read LDS data written
+//     before the previous WAVE_SYNC(), and lane-private values never outlive the block,
+//   * LANE0{...} marks single-writer uniform stores.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(GRX_EMU)
+#define GRX_DEV static inline
+#define FOR_LANES for (int lane = 0; lane < 64; ++lane)
+#define LANE0 if (1)
+#define WAVE_SYNC() ((void)0)
+#define GRX_ATOMIC_ADD(p, v) grx_emu_fetch_add((p), (v))
+static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; return o; }
+#else
+#define GRX_DEV __device__ __forceinline__
+#define FOR_LANES for (int lane = lane_, once_ = 1; once_; once_ = 0)
+#define LANE0 if (lane_ == 0)
+#define WAVE_SYNC() __syncthreads()
+#define GRX_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#endif
+
+#define GRX_MINVAL 1e-15f
+#define GRX_MINIMP 0.0001f
+#define GRX_MAXIMP 0.9999f
+#define GRX_MAXCON 40
+#define GRX_MAXEFC 160
+#define GRX_NEWTON_MAXIT 8
+#define GRX_LS_MAXIT 12
+
+// status bits reported per world
+#define GRX_ST_BADNUM 1
+#define GRX_ST_CON_OVERFLOW 2
+#define GRX_ST_EFC_OVERFLOW 4
+#define GRX_ST_FACTOR 8
+
+enum { GRX_ROW_EQ = 0, GRX_ROW_FRICTION = 1, GRX_ROW_LIMIT = 2, GRX_ROW_CONTACT = 3 };
+
+// ------------------------------------------------------------------------------------------
+// model: device-resident fp32 / int32 copies of the tables in include/grx_model_fields.def
+// ------------------------------------------------------------------------------------------
+struct GrxModel {
+#define GRX_FI(name) const int* name;
+#define GRX_FF(name) const float* name;
+#include "../../include/grx_model_fields.def"
+#undef GRX_FI
+#undef GRX_FF
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp;
+  float timestep, gravity[3], meaninertia, impratio;
+};
+
+// per-world LDS working set; every pointer addresses LDS (or host memory in the emulator)
+struct GrxCtx {
+  // state
+  float *qpos, *qvel, *qacc_ws, *mocap_pos, *mocap_quat, *ctrl;
+  // position stage
+  float *ploc, *qloc, *janchor, *jaxis;  // local poses (3,4 per body), joint anchor/axis (3,3 per joint) in parent frame -> world
+  float *xpos, *xquat, *xmat, *cinert, *crb, *cvel, *cacc, *cfrc;
+  float *gxpos, *gxmat, *sxpos, *sxmat;
+  float *cdof, *cdof_dot;
+  float *M, *A;
+  float *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc, *Ma, *grad, *search,
+      *Mv, *tmpv;
+  // contacts
+  float *con_dist, *con_pos, *con_frame;
+  int *con_pair, *con_efc;
+  // constraint rows
+  float *J, *efc_pos, *efc_D, *efc_aref, *efc_jar, *efc_jv, *efc_force, *efc_floss;
+  int *efc_kind, *efc_id, *efc_sub, *efc_quad;
+  // scratch
+  float* red;  // 128 floats
+  int* ired;   // 64 ints
+  int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
+};
+
+// LDS footprint in 4-byte words for a model with the given dims
+GRX_DEV int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap) {
+  int w = 0;
+  w += nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;
+  w += 3 * nbody + 4 * nbody + 3 * njnt + 3 * njnt;
+  w += (3 + 4 + 9 + 10 + 10 + 6 + 6 + 6) * nbody;
+  w += 12 * ngeom + 12 * nsite;
+  w += 12 * nv;
+  w += 2 * nv * nv;
+  w += 12 * nv;
+  w += GRX_MAXCON * (1 + 3 + 9 + 2);
+  w += GRX_MAXEFC * nv + GRX_MAXEFC * (7 + 4);
+  w += 128 + 64 + 16;
+  return w;
+}
+
+GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
+  float* p = base;
+#define CARVE(field, n) c->field = p; p += (n);
+  CARVE(qpos, m->nq) CARVE(qvel, m->nv) CARVE(qacc_ws, m->nv) CARVE(mocap_pos, 3 * m->nmocap) CARVE(mocap_quat, 4 * m->nmocap)
+  CARVE(ctrl, m->nu)
+  CARVE(ploc, 3 * m->nbody) CARVE(qloc, 4 * m->nbody) CARVE(janchor, 3 * m->njnt) CARVE(jaxis, 3 * m->njnt)
+  CARVE(xpos, 3 * m->nbody) CARVE(xquat, 4 * m->nbody) CARVE(xmat, 9 * m->nbody) CARVE(cinert, 10 * m->nbody)
+  CARVE(crb, 10 * m->nbody) CARVE(cvel, 6 * m->nbody) CARVE(cacc, 6 * m->nbody) CARVE(cfrc, 6 * m->nbody)
+  CARVE(gxpos, 3 * m->ngeom) CARVE(gxmat, 9 * m->ngeom) CARVE(sxpos, 3 * m->nsite) CARVE(sxmat, 9 * m->nsite)
+  CARVE(cdof, 6 * m->nv) CARVE(cdof_dot, 6 * m->nv)
+  CARVE(M, m->nv * m->nv) CARVE(A, m->nv * m->nv)
+  CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv) CARVE(qfrc_smooth, m->nv)
+  CARVE(qacc_smooth, m->nv) CARVE(qfrc_constraint, m->nv) CARVE(qacc, m->nv) CARVE(Ma, m->nv) CARVE(grad, m->nv)
+  CARVE(search, m->nv) CARVE(Mv, m->nv) CARVE(tmpv, m->nv)
+  CARVE(con_dist, GRX_MAXCON) CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 9 * GRX_MAXCON)
+  c->con_pair = (int*)p; p += GRX_MAXCON;
+  c->con_efc = (int*)p; p += GRX_MAXCON;
+  CARVE(J, GRX_MAXEFC * m->nv) CARVE(efc_pos, GRX_MAXEFC) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC)
+  CARVE(efc_jar, GRX_MAXEFC) CARVE(efc_jv, GRX_MAXEFC) CARVE(efc_force, GRX_MAXEFC) CARVE(efc_floss, GRX_MAXEFC)
+  c->efc_kind = (int*)p; p += GRX_MAXEFC;
+  c->efc_id = (int*)p; p += GRX_MAXEFC;
+  c->efc_sub = (int*)p; p += GRX_MAXEFC;
+  c->efc_quad = (int*)p; p += GRX_MAXEFC;
+  CARVE(red, 128)
+  c->ired = (int*)p; p += 64;
+  c->cnt = (int*)p; p += 16;
+#undef CARVE
+}
+
+// ------------------------------------------------------------------------------------------
+// small math (all per-lane, registers)
+// ------------------------------------------------------------------------------------------
+GRX_DEV float dot3f(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+GRX_DEV void cross3f(float* r, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+GRX_DEV void mulQuatf(float* r, const float* a, const float* b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+GRX_DEV void normalize4f(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < 1e-12f) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  float r = 1.0f / n;
+  q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
+}
+GRX_DEV void quat2matf(float* m, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+GRX_DEV void rotVecQuatf(float* r, const float* v, const float* q) {
+  float m[9]; quat2matf(m, q);
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+GRX_DEV void mulMatVec3f(float* r, const float* m, const float* v) {
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+GRX_DEV void mulMatTVec3f(float* r, const float* m, const float* v) {
+  float x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+GRX_DEV void mulMat3f(float* r, const float* a, const float* b) {
+  float t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  for (int i = 0; i < 9; i++) r[i] = t[i];
+}
+// spatial inertia (10: Ixx Iyy Izz Ixy Ixz Iyz hx hy hz m, about the tree reference point) times motion vector [w; v]
+GRX_DEV void inertMulf(float* f, const float* I, const float* v) {
+  f[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2] + (I[7] * v[5] - I[8] * v[4]);
+  f[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2] + (I[8] * v[3] - I[6] * v[5]);
+  f[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2] + (I[6] * v[4] - I[7] * v[3]);
+  f[3] = I[9] * v[3] + (v[1] * I[8] - v[2] * I[7]);
+  f[4] = I[9] * v[4] + (v[2] * I[6] - v[0] * I[8]);
+  f[5] = I[9] * v[5] + (v[0] * I[7] - v[1] * I[6]);
+}
+GRX_DEV void crossMotionf(float* r, const float* v, const float* m) {
+  float a[3], b[3], c[3];
+  cross3f(a, v, m); cross3f(b, v, m + 3); cross3f(c, v + 3, m);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+GRX_DEV void crossForcef(float* r, const float* v, const float* f) {
+  float a[3], b[3], c[3];
+  cross3f(a, v, f); cross3f(b, v + 3, f + 3); cross3f(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+
+// wave-wide sums of per-lane partials staged in red[0..63] (and red[64..127] for the second value).
+// Uniform context.
+#if defined(GRX_EMU)
+GRX_DEV float grx_wave_sum(const float* red, int lane_) { (void)lane_; float s = 0; for (int i = 0; i < 64; i++) s += red[i]; return s; }
+#else
+GRX_DEV float grx_wave_sum(const float* red, int lane_) {
+  float v = red[lane_];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
+// K1 forward kinematics
+// ------------------------------------------------------------------------------------------
+GRX_DEV void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
+  FOR_LANES {
+    for (int b = lane; b < m->nbody; b += 64) {
+      float* pl = c->ploc + 3 * b; float* ql = c->qloc + 4 * b;
+      if (b == 0) {
+        c->xpos[0] = c->xpos[1] = c->xpos[2] = 0; c->xquat[0] = 1; c->xquat[1] = c->xquat[2] = c->xquat[3] = 0;
+        for (int k = 0; k < 9; k++) c->xmat[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+        continue;
+      }
+      int mid = m->body_mocapid[b];
+      if (mid >= 0) {
+        float q[4] = {c->mocap_quat[4 * mid], c->mocap_quat[4 * mid + 1], c->mocap_quat[4 * mid + 2], c->mocap_quat[4 * mid + 3]};
+        normalize4f(q);
+        pl[0] = c->mocap_pos[3 * mid]; pl[1] = c->mocap_pos[3 * mid + 1]; pl[2] = c->mocap_pos[3 * mid + 2];
+        ql[0] = q[0]; ql[1] = q[1]; ql[2] = q[2]; ql[3] = q[3];
+        continue;
+      }
+      int ja = m->body_jntadr[b], jn = m->body_jntnum[b];
+      if (jn == 1 && m->jnt_type[ja] == 0) {  // free joint: qpos is the world pose
+        int qa = m->jnt_qposadr[ja];
+        float q[4] = {c->qpos[qa + 3], c->qpos[qa + 4], c->qpos[qa + 5], c->qpos[qa + 6]};
+        normalize4f(q);
+        pl[0] = c->qpos[qa]; pl[1] = c->qpos[qa + 1]; pl[2] = c->qpos[qa + 2];
+        for (int k = 0; k < 4; k++) { ql[k] = q[k]; c->qpos[qa + 3 + k] = q[k]; }
+        for (int k = 0; k < 3; k++) { c->janchor[3 * ja + k] = pl[k]; c->jaxis[3 * ja + k] = (k == 2) ? 1.0f : 0.0f; }
+        continue;
+      }
+      float p[3] = {m->body_pos[3 * b], m->body_pos[3 * b + 1], m->body_pos[3 * b + 2]};
+      float q[4] = {m->body_quat[4 * b], m->body_quat[4 * b + 1], m->body_quat[4 * b + 2], m->body_quat[4 * b + 3]};
+      for (int k = 0; k < jn; k++) {
+        int j = ja + k, qa = m->jnt_qposadr[j];
+        float jp[3] = {m->jnt_pos[3 * j], m->jnt_pos[3 * j + 1], m->jnt_pos[3 * j + 2]};
+        float jx[3] = {m->jnt_axis[3 * j], m->jnt_axis[3 * j + 1], m->jnt_axis[3 * j + 2]};
+        float anchor[3], axis[3];
+        rotVecQuatf(anchor, jp, q); anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
+        rotVecQuatf(axis, jx, q);
+        for (int t = 0; t < 3; t++) { c->janchor[3 * j + t] = anchor[t]; c->jaxis[3 * j + t] = axis[t]; }
+        float dq = c->qpos[qa] - m->qpos0[qa];
+        if (m->jnt_type[j] == 2) {
+          p[0] += axis[0] * dq; p[1] += axis[1] * dq; p[2] += axis[2] * dq;
+        } else if (m->jnt_type[j] == 3) {
+          float sn, cs; sincosf(0.5f * dq, &sn, &cs);
+          float qr[4] = {cs, jx[0] * sn, jx[1] * sn, jx[2] * sn}, qn[4], off[3];
+          mulQuatf(qn, q, qr); normalize4f(qn);
+          q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; q[3] = qn[3];
+          rotVecQuatf(off, jp, q);
+          p[0] = anchor[0] - off[0]; p[1] = anchor[1] - off[1]; p[2] = anchor[2] - off[2];
+        }
+      }
+      pl[0] = p[0]; pl[1] = p[1]; pl[2] = p[2]; ql[0] = q[0]; ql[1] = q[1]; ql[2] = q[2]; ql[3] = q[3];
+    }
+  }
+  WAVE_SYNC();
+  for (int lev = 1; lev <= m->maxdepth; lev++) {
+    int a0 = m->level_adr[lev], a1 = m->level_adr[lev + 1];
+    FOR_LANES {
+      for (int k = a0 + lane; k < a1; k += 64) {
+        int b = m->body_order[k], par = m->body_parent[b];
+        float* xp = c->xpos + 3 * b; float* xq = c->xquat + 4 * b;
+        const float* pl = c->ploc + 3 * b; const float* ql = c->qloc + 4 * b;
+        int isfree = (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == 0);
+        if (m->body_mocapid[b] >= 0 || isfree) {
+          xp[0] = pl[0]; xp[1] = pl[1]; xp[2] = pl[2]; xq[0] = ql[0]; xq[1] = ql[1]; xq[2] = ql[2]; xq[3] = ql[3];
+        } else {
+          float v[3], q[4];
+          mulMatVec3f(v, c->xmat + 9 * par, pl);
+          xp[0] = c->xpos[3 * par] + v[0]; xp[1] = c->xpos[3 * par + 1] + v[1]; xp[2] = c->xpos[3 * par + 2] + v[2];
+          mulQuatf(q, c->xquat + 4 * par, ql); normalize4f(q);
+          xq[0] = q[0]; xq[1] = q[1]; xq[2] = q[2]; xq[3] = q[3];
+          // joint anchors / axes to world frame (they were expressed in the parent frame)
+          int ja = m->body_jntadr[b], jn = m->body_jntnum[b];
+          for (int t = 0; t < jn; t++) {
+            float a[3], x[3];
+            mulMatVec3f(a, c->xmat + 9 * par, c->janchor + 3 * (ja + t));
+            mulMatVec3f(x, c->xmat + 9 * par, c->jaxis + 3 * (ja + t));
+            for (int e = 0; e < 3; e++) { c->janchor[3 * (ja + t) + e] = a[e] + c->xpos[3 * par + e]; c->jaxis[3 * (ja + t) + e] = x[e]; }
+          }
+        }
+        float R[9]; quat2matf(R, xq);
+        for (int e = 0; e < 9; e++) c->xmat[9 * b + e] = R[e];
+      }
+    }
+    WAVE_SYNC();
+  }
+  FOR_LANES {
+    for (int g = lane; g < m->ngeom + m->nsite; g += 64) {
+      int isg = g < m->ngeom; int i = isg ? g : g - m->ngeom;
+      int b = isg ? m->geom_bodyid[i] : m->site_bodyid[i];
+      const float* lp = isg ? m->geom_pos + 3 * i : m->site_pos + 3 * i;
+      const float* lq = isg ? m->geom_quat + 4 * i : m->site_quat + 4 * i;
+      float* op = isg ? c->gxpos + 3 * i : c->sxpos + 3 * i; float* om = isg ? c->gxmat + 9 * i : c->sxmat + 9 * i;
+      float lpv[3] = {lp[0], lp[1], lp[2]}, lqv[4] = {lq[0], lq[1], lq[2], lq[3]}, v[3], R[9], Rw[9];
+      mulMatVec3f(v, c->xmat + 9 * b, lpv);
+      op[0] = c->xpos[3 * b] + v[0]; op[1] = c->xpos[3 * b + 1] + v[1]; op[2] = c->xpos[3 * b + 2] + v[2];
+      quat2matf(R, lqv); mulMat3f(Rw, c->xmat + 9 * b, R);
+      for (int e = 0; e < 9; e++) om[e] = Rw[e];
+    }
+  }
+  WAVE_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// K2/K3 spatial inertias, motion axes, composite inertias, mass matrix
+// reference point of each kinematic tree = xpos of its root body (any point is valid)
+// ------------------------------------------------------------------------------------------
+GRX_DEV void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
+  FOR_LANES {
+    for (int b = 1 + lane; b < m->nbody; b += 64) {
+      const float* R = c->xmat + 9 * b; const float* in = m->body_inertia + 6 * b;
+      const float* cref = c->xpos + 3 * m->body_rootid[b];
+      float ip[3] = {m->body_ipos[3 * b], m->body_ipos[3 * b + 1], m->body_ipos[3 * b + 2]}, r[3];
+      mulMatVec3f(r, R, ip);
+      r[0] += c->xpos[3 * b] - cref[0]; r[1] += c->xpos[3 * b + 1] - cref[1]; r[2] += c->xpos[3 * b + 2] - cref[2];
+      float Ib[9] = {in[0], in[3], in[4], in[3], in[1], in[5], in[4], in[5], in[2]}, t[9], Rt[9], Iw[9];
+      for (int a = 0; a < 3; a++) for (int e = 0; e < 3; e++) Rt[3 * a + e] = R[3 * e + a];
+      mulMat3f(t, R, Ib); mulMat3f(Iw, t, Rt);
+      float mass = m->body_mass[b], rr = dot3f(r, r);
+      float* I = c->cinert + 10 * b;
+      I[0] = Iw[0] + mass * (rr - r[0] * r[0]); I[1] = Iw[4] + mass * (rr - r[1] * r[1]); I[2] = Iw[8] + mass * (rr - r[2] * r[2]);
+      I[3] = Iw[1] - mass * r[0] * r[1]; I[4] = Iw[2] - mass * r[0] * r[2]; I[5] = Iw[5] - mass * r[1] * r[2];
+      I[6] = mass * r[0]; I[7] = mass * r[1]; I[8] = mass * r[2]; I[9] = mass;
+    }
+    for (int j = lane; j < m->njnt; j += 64) {
+      int b = m->jnt_bodyid[j], da = m->jnt_dofadr[j], jt = m->jnt_type[j];
+      const float* cref = c->xpos + 3 * m->body_rootid[b];
+      float off[3] = {cref[0] - c->janchor[3 * j], cref[1] - c->janchor[3 * j + 1], cref[2] - c->janchor[3 * j + 2]};
+      const float* ax = c->jaxis + 3 * j;
+      if (jt == 2) {
+        float* cd = c->cdof + 6 * da; cd[0] = cd[1] = cd[2] = 0; cd[3] = ax[0]; cd[4] = ax[1]; cd[5] = ax[2];
+      } else if (jt == 3) {
+        float* cd = c->cdof + 6 * da; float axv[3] = {ax[0], ax[1], ax[2]}, t[3];
+        cross3f(t, axv, off);
+        cd[0] = axv[0]; cd[1] = axv[1]; cd[2] = axv[2]; cd[3] = t[0]; cd[4] = t[1]; cd[5] = t[2];
+      } else if (jt == 0) {
+        for (int k = 0; k < 3; k++) { float* cd = c->cdof + 6 * (da + k); for (int e = 0; e < 6; e++) cd[e] = (e == 3 + k) ? 1.0f : 0.0f; }
+        for (int k = 0; k < 3; k++) {
+          float* cd = c->cdof + 6 * (da + 3 + k);
+          float axv[3] = {c->xmat[9 * b + k], c->xmat[9 * b + 3 + k], c->xmat[9 * b + 6 + k]}, t[3];
+          cross3f(t, axv, off);  // off = cref - xpos(body) = 0 for a root free body
+          cd[0] = axv[0]; cd[1] = axv[1]; cd[2] = axv[2]; cd[3] = t[0]; cd[4] = t[1]; cd[5] = t[2];
+        }
+      }
+    }
+  }
+  WAVE_SYNC();
+  // composite inertia = sum over the subtree (no serial tree walk)
+  FOR_LANES {
+    for (int it = lane; it < 10 * m->nbody; it += 64) {
+      int b = it / 10, k = it - 10 * b;
+      if (b == 0) { c->crb[it] = 0; continue; }
+      int a = m->body_subadr[b], n = m->body_subnum[b];
+      float s = 0;
+      for (int e = 0; e < n; e++) s += c->cinert[10 * m->body_sub[a + e] + k];
+      c->crb[it] = s;
+    }
+  }
+  WAVE_SYNC();
+  FOR_LANES {
+    for (int e = lane; e < m->nmpair; e += 64) {
+      int i = m->mpair_i[e], j = m->mpair_j[e];
+      float buf[6], cd[6];
+      for (int t = 0; t < 6; t++) cd[t] = c->cdof[6 * i + t];
+      inertMulf(buf, c->crb + 10 * m->dof_bodyid[i], cd);
+      float v = 0;
+      for (int t = 0; t < 6; t++) v += c->cdof[6 * j + t] * buf[t];
+      if (i == j) v += m->dof_armature[i];
+      c->M[i * m->nv + j] = v; c->M[j * m->nv + i] = v;
+    }
+  }
+  WAVE_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 dense symmetric solve in LDS:  A x = b, A overwritten.  Elimination runs from the last
+// dof to the first (A = L' D L), i.e. leaves of the kinematic tree before the root -- the same
+// order MuJoCo's sparse L'DL uses, which keeps the 1e11-damped base dofs out of the pivots of
+// everything else.  x is returned in b.
+// ------------------------------------------------------------------------------------------
+GRX_DEV int grx_sym_factor(float* A, int n, int lane_) {
+  int bad = 0;
+  for (int k = n - 1; k >= 0; k--) {
+    float d = A[k * n + k];
+    if (!(d > 1e-30f)) { bad = 1; d = 1e-30f; }
+    float rinv = 1.0f / d;
+    FOR_LANES {
+      int li = lane >> 3, lj = lane & 7;
+      for (int i = li; i < k; i += 8) {
+        float ti = A[k * n + i] * rinv;
+        for (int j = lj; j < k; j += 8) A[i * n + j] -= ti * A[k * n + j];
+      }
+    }
+    WAVE_SYNC();
+    LANE0 { A[k * n + k] = rinv; }
+  }
+  WAVE_SYNC();
+  return bad;
+}
+// A holds the factor from grx_sym_factor: row k = [t_k0 .. t_k,k-1, 1/d_k]
+GRX_DEV void grx_sym_solve(const float* A, int n, float* x, int lane_) {
+  // L' y = b  (y_i = b_i - sum_{k>i} (t_ki/d_k) y_k)
+  for (int k = n - 1; k > 0; k--) {
+    float yk = x[k] * A[k * n + k];
+    FOR_LANES { for (int i = lane; i < k; i += 64) x[i] -= A[k * n + i] * yk; }
+    WAVE_SYNC();
+  }
+  FOR_LANES { for (int i = lane; i < n; i += 64) x[i] *= A[i * n + i]; }
+  WAVE_SYNC();
+  // L x = z  (x_k = z_k - sum_{i<k} (t_ki/d_k) x_i)
+  for (int i = 0; i < n - 1; i++) {
+    float xi = x[i];
+    FOR_LANES { for (int k = i + 1 + lane; k < n; k += 64) x[k] -= A[k * n + i] * A[k * n + k] * xi; }
+    WAVE_SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// velocity stage: cvel, cdof_dot, RNE bias (K2/K5), passive (K6), actuation (K7)
+// ------------------------------------------------------------------------------------------
+GRX_DEV void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
+  const int nv = m->nv;
+  // body spatial velocities = sum over the dof chain (parallel, no tree walk)
+  FOR_LANES {
+    for (int it = lane; it < 6 * m->nbody; it += 64) {
+      int b = it / 6, k = it - 6 * b;
+      float s = 0;
+      for (int d = m->body_lastdof[b]; d >= 0; d = m->dof_parentid[d]) s += c->cdof[6 * d + k] * c->qvel[d];
+      c->cvel[it] = s;
+    }
+    // cdof_dot = crossMotion(velocity just before this dof, cdof)
+    for (int d = lane; d < nv; d += 64) {
+      float v[6] = {0, 0, 0, 0, 0, 0}, cd[6], r[6];
+      for (int e = m->dof_cvelstart[d]; e >= 0; e = m->dof_parentid[e])
+        for (int k = 0; k < 6; k++) v[k] += c->cdof[6 * e + k] * c->qvel[e];
+      for (int k = 0; k < 6; k++) cd[k] = c->cdof[6 * d + k];
+      int jt = m->jnt_type[m->dof_jntid[d]];
+      if (jt == 0 && d - m->jnt_dofadr[m->dof_jntid[d]] < 3) { for (int k = 0; k < 6; k++) r[k] = 0; }
+      else crossMotionf(r, v, cd);
+      for (int k = 0; k < 6; k++) c->cdof_dot[6 * d + k] = r[k];
+    }
+    // passive forces
+    for (int d = lane; d < nv; d += 64) {
+      float f = -m->dof_damping[d] * c->qvel[d];
+      int j = m->dof_jntid[d];
+      if (m->jnt_stiffness[j] != 0.0f && m->jnt_type[j] >= 2) f -= m->jnt_stiffness[j] * (c->qpos[m->jnt_qposadr[j]] - m->jnt_springref[j]);
+      c->qfrc_passive[d] = f;
+      c->qfrc_actuator[d] = 0;
+    }
+  }
+  WAVE_SYNC();
+  FOR_LANES {
+    // accelerations with qacc = 0 and per-body inertial forces
+    for (int b = 1 + lane; b < m->nbody; b += 64) {
+      float a[6] = {0, 0, 0, -m->gravity[0], -m->gravity[1], -m->gravity[2]}, v[6], Ia[6], Iv[6], t[6];
+      for (int d = m->body_lastdof[b]; d >= 0; d = m->dof_parentid[d])
+        for (int k = 0; k < 6; k++) a[k] += c->cdof_dot[6 * d + k] * c->qvel[d];
+      for (int k = 0; k < 6; k++) v[k] = c->cvel[6 * b + k];
+      inertMulf(Ia, c->cinert + 10 * b, a); inertMulf(Iv, c->cinert + 10 * b, v);
+      crossForcef(t, v, Iv);
+      for (int k = 0; k < 6; k++) c->cacc[6 * b + k] = Ia[k] + t[k];
+    }
+    // actuators (one lane each; joint transmission)
+    for (int i = lane; i < m->nu; i += 64) {
+      int j = m->act_trnid[i]; float gear = m->act_gear[i];
+      float len = gear * c->qpos[m->jnt_qposadr[j]], vel = gear * c->qvel[m->jnt_dofadr[j]];
+      float u = c->ctrl[i];
+      if (m->act_ctrllimited[i]) u = fminf(m->act_ctrlrange[2 * i + 1], fmaxf(m->act_ctrlrange[2 * i], u));
+      float gain = m->act_gainprm[3 * i];
+      if (m->act_gaintype[i] == 1) gain += m->act_gainprm[3 * i + 1] * len + m->act_gainprm[3 * i + 2] * vel;
+      float bias = 0;
+      if (m->act_biastype[i] == 1) bias = m->act_biasprm[3 * i] + m->act_biasprm[3 * i + 1] * len + m->act_biasprm[3 * i + 2] * vel;
+      float f = gain * u + bias;
+      if (m->act_forcelimited[i]) f = fminf(m->act_forcerange[2 * i + 1], fmaxf(m->act_forcerange[2 * i], f));
+      c->qfrc_actuator[m->jnt_dofadr[j]] = gear * f;  // models in scope have at most one actuator per dof
+    }
+  }
+  WAVE_SYNC();
+  FOR_LANES {
+    // subtree force sums
+    for (int it = lane; it < 6 * m->nbody; it += 64) {
+      int b = it / 6, k = it - 6 * b;
+      if (b == 0) { c->cfrc[it] = 0; continue; }
+      int a = m->body_subadr[b], n = m->body_subnum[b];
+      float s = 0;
+      for (int e = 0; e < n; e++) s += c->cacc[6 * m->body_sub[a + e] + k];
+      c->cfrc[it] = s;
+    }
+  }
+  WAVE_SYNC();
+  FOR_LANES {
+    for (int d = lane; d < nv; d += 64) {
+      float s = 0; int b = m->dof_bodyid[d];
+      for (int k = 0; k < 6; k++) s += c->cdof[6 * d + k] * c->cfrc[6 * b + k];
+      c->qfrc_bias[d] = s;
+      float f = c->qfrc_passive[d] - s + c->qfrc_actuator[d];
+      c->qfrc_smooth[d] = f; c->qacc_smooth[d] = f;
+    }
+  }
+  WAVE_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// K8 collision: static candidate list -> narrow phase
+// ------------------------------------------------------------------------------------------
+GRX_DEV void grx_make_frame(float* f) {
+  float* x = f; float* y = f + 3; float* z = f + 6;
+  if (x[1] < 0.5f && x[1] > -0.5f) { y[0] = 0; y[1] = 1; y[2] = 0; } else { y[0] = 0; y[1] = 0; y[2] = 1; }
+  float d = dot3f(x, y); y[0] -= d * x[0]; y[1] -= d * x[1]; y[2] -= d * x[2];
+  float n = 1.0f / sqrtf(dot3f(y, y)); y[0] *= n; y[1] *= n; y[2] *= n;
+  cross3f(z, x, y);
+}
+
+GRX_DEV void grx_add_contact(GrxCtx* c, int pair, const float* pos, const float* normal, float dist) {
+  int slot = GRX_ATOMIC_ADD(&c->cnt[0], 1);
+  if (slot >= GRX_MAXCON) { c->cnt[2] |= GRX_ST_CON_OVERFLOW; return; }
+  float f[9] = {normal[0], normal[1], normal[2], 0, 0, 0, 0, 0, 0};
+  grx_make_frame(f);
+  c->con_dist[slot] = dist; c->con_pair[slot] = pair;
+  for (int k = 0; k < 3; k++) c->con_pos[3 * slot + k] = pos[k];
+  for (int k = 0; k < 9; k++) c->con_frame[9 * slot + k] = f[k];
+}
+
+GRX_DEV void grx_plane_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  const float* pp = c->gxpos + 3 * g1; const float* pm = c->gxmat + 9 * g1;
+  const float* bp = c->gxpos + 3 * g2; const float* bm = c->gxmat + 9 * g2; const float* sz = m->geom_size + 3 * g2;
+  float n[3] = {pm[2], pm[5], pm[8]};
+  int cnt = 0;
+  for (int k = 0; k < 8 && cnt < 4; k++) {
+    float loc[3] = {(k & 1) ? sz[0] : -sz[0], (k & 2) ? sz[1] : -sz[1], (k & 4) ? sz[2] : -sz[2]}, w[3];
+    mulMatVec3f(w, bm, loc); w[0] += bp[0]; w[1] += bp[1]; w[2] += bp[2];
+    float d[3] = {w[0] - pp[0], w[1] - pp[1], w[2] - pp[2]};
+    float dist = dot3f(d, n);
+    if (dist > margin) continue;
+    float pos[3] = {w[0] - 0.5f * dist * n[0], w[1] - 0.5f * dist * n[1], w[2] - 0.5f * dist * n[2]};
+    grx_add_contact(c, pair, pos, n, dist); cnt++;
+  }
+}
+
+// Sutherland-Hodgman clip of a convex polygon against sign*p[axis] <= lim
+GRX_DEV int grx_clip_poly(float* px, float* py, int n, int axis, float lim, float sign) {
+  float ox[16], oy[16]; int no = 0;
+  for (int i = 0; i < n && no < 15; i++) {
+    int i2 = (i + 1 == n) ? 0 : i + 1;
+    float ax = px[i], ay = py[i], bx = px[i2], by = py[i2];
+    float da = sign * (axis ? ay : ax) - lim, db = sign * (axis ? by : bx) - lim;
+    if (da <= 0) { ox[no] = ax; oy[no] = ay; no++; }
+    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+      float t = da / (da - db);
+      ox[no] = ax + t * (bx - ax); oy[no] = ay + t * (by - ay); no++;
+    }
+  }
+  for (int i = 0; i < no; i++) { px[i] = ox[i]; py[i] = oy[i]; }
+  return no;
+}
+
+GRX_DEV void grx_box_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  const float* p1 = c->gxpos + 3 * g1; const float* R1 = c->gxmat + 9 * g1; const float* a = m->geom_size + 3 * g1;
+  const float* p2 = c->gxpos + 3 * g2; const float* R2 = c->gxmat + 9 * g2; const float* b = m->geom_size + 3 * g2;
+  float A[3][3], B[3][3];
+  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = R1[3 * k + i]; B[i][k] = R2[3 * k + i]; }
+  float d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  float Q[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Q[i][j] = fabsf(dot3f(A[i], B[j]));
+  float best = -1e30f; int code = -1; float bn[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++) {
+    float t = dot3f(d, A[i]);
+    float sep = fabsf(t) - (a[i] + b[0] * Q[i][0] + b[1] * Q[i][1] + b[2] * Q[i][2]);
+    if (sep > margin) return;
+    if (sep > best) { best = sep; code = i; float sg = t < 0 ? -1.0f : 1.0f; for (int k = 0; k < 3; k++) bn[k] = sg * A[i][k]; }
+  }
+  for (int j = 0; j < 3; j++) {
+    float t = dot3f(d, B[j]);
+    float sep = fabsf(t) - (b[j] + a[0] * Q[0][j] + a[1] * Q[1][j] + a[2] * Q[2][j]);
+    if (sep > margin) return;
+    if (sep > best) { best = sep; code = 3 + j; float sg = t < 0 ? -1.0f : 1.0f; for (int k = 0; k < 3; k++) bn[k] = sg * B[j][k]; }
+  }
+  float ebest = -1e30f; int ei = -1, ej = -1; float en[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float ax[3]; cross3f(ax, A[i], B[j]);
+      float l = sqrtf(dot3f(ax, ax));
+      if (l < 1e-6f) continue;
+      float li = 1.0f / l; ax[0] *= li; ax[1] *= li; ax[2] *= li;
+      float t = dot3f(d, ax), ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += a[k] * fabsf(dot3f(A[k], ax)); rb += b[k] * fabsf(dot3f(B[k], ax)); }
+      float sep = fabsf(t) - (ra + rb);
+      if (sep > margin) return;
+      if (sep > ebest) { ebest = sep; ei = i; ej = j; float sg = t < 0 ? -1.0f : 1.0f; for (int k = 0; k < 3; k++) en[k] = sg * ax[k]; }
+    }
+  if (ei >= 0 && ebest > best + 1e-7f + 0.02f * fabsf(best)) {
+    float pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+    for (int k = 0; k < 3; k++) {
+      if (k != ei) { float sg = dot3f(en, A[k]) > 0 ? 1.0f : -1.0f; for (int e = 0; e < 3; e++) pa[e] += sg * a[k] * A[k][e]; }
+      if (k != ej) { float sg = dot3f(en, B[k]) > 0 ? -1.0f : 1.0f; for (int e = 0; e < 3; e++) pb[e] += sg * b[k] * B[k][e]; }
+    }
+    float w[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    float uv = dot3f(A[ei], B[ej]), uw = dot3f(A[ei], w), vw = dot3f(B[ej], w);
+    float den = 1.0f - uv * uv;
+    float sc = den > 1e-12f ? (uv * vw - uw) / den : 0.0f, tc = den > 1e-12f ? (vw - uv * uw) / den : 0.0f;
+    float pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = 0.5f * ((pa[k] + sc * A[ei][k]) + (pb[k] + tc * B[ej][k]));
+    grx_add_contact(c, pair, pos, en, ebest);
+    return;
+  }
+  int ref1 = code < 3;
+  const float* pr = ref1 ? p1 : p2; const float* pi = ref1 ? p2 : p1;
+  float (*Ar)[3] = ref1 ? A : B; float (*Ai)[3] = ref1 ? B : A;
+  const float* sr = ref1 ? a : b; const float* si = ref1 ? b : a;
+  int ax = ref1 ? code : code - 3;
+  float nr[3]; for (int k = 0; k < 3; k++) nr[k] = ref1 ? bn[k] : -bn[k];
+  int iax = 0; float mind = 1e30f, isg = 1;
+  for (int k = 0; k < 3; k++) {
+    float dd = dot3f(Ai[k], nr);
+    if (dd < mind) { mind = dd; iax = k; isg = 1; }
+    if (-dd < mind) { mind = -dd; iax = k; isg = -1; }
+  }
+  int u = (iax + 1) % 3, v = (iax + 2) % 3;
+  float fc[3]; for (int k = 0; k < 3; k++) fc[k] = pi[k] + isg * si[iax] * Ai[iax][k];
+  int ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+  float rc[3]; for (int k = 0; k < 3; k++) rc[k] = pr[k] + sr[ax] * nr[k];
+  float px[16], py[16], hq[4];
+  for (int q = 0; q < 4; q++) {
+    float su = (q == 0 || q == 3) ? 1.0f : -1.0f, sv = (q < 2) ? 1.0f : -1.0f, w[3];
+    for (int k = 0; k < 3; k++) w[k] = fc[k] + su * si[u] * Ai[u][k] + sv * si[v] * Ai[v][k] - rc[k];
+    px[q] = dot3f(w, Ar[ru]); py[q] = dot3f(w, Ar[rv]); hq[q] = dot3f(w, nr);
+  }
+  float x0 = px[0], y0 = py[0], x1 = px[1] - x0, y1 = py[1] - y0, x2 = px[3] - x0, y2 = py[3] - y0;
+  float h1 = hq[1] - hq[0], h2 = hq[3] - hq[0];
+  float det = x1 * y2 - x2 * y1, gu = 0, gv = 0;
+  int flat = !(fabsf(det) > 1e-14f);
+  if (!flat) { gu = (h1 * y2 - h2 * y1) / det; gv = (x1 * h2 - x2 * h1) / det; }
+  int n = 4;
+  n = grx_clip_poly(px, py, n, 0, sr[ru], 1.0f); if (n) n = grx_clip_poly(px, py, n, 0, sr[ru], -1.0f);
+  if (n) n = grx_clip_poly(px, py, n, 1, sr[rv], 1.0f);
+  if (n) n = grx_clip_poly(px, py, n, 1, sr[rv], -1.0f);
+  int cnt = 0;
+  for (int q = 0; q < n && cnt < 8; q++) {
+    float h = flat ? hq[0] : hq[0] + gu * (px[q] - x0) + gv * (py[q] - y0);
+    if (h > margin) continue;
+    int dup = 0;
+    for (int e = 0; e < q; e++) if (fabsf(px[e] - px[q]) + fabsf(py[e] - py[q]) < 1e-7f) dup = 1;
+    if (dup) continue;
+    float pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = rc[k] + px[q] * Ar[ru][k] + py[q] * Ar[rv][k] + 0.5f * h * nr[k];
+    grx_add_contact(c, pair, pos, bn, h); cnt++;
+  }
+}
+
+GRX_DEV void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
+  LANE0 { c->cnt[0] = 0; }
+  WAVE_SYNC();
+  // primitive pairs: one lane per candidate pair; mesh pairs are flagged for the cooperative pass
+  for (int base = 0; base < m->ndevpair; base += 64) {
+    FOR_LANES {
+      int k = base + lane;
+      c->ired[lane] = -1;
+      if (k < m->ndevpair) {
+        int p = m->devpair[k], g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+        int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+        float margin = m->pair_margin[p];
+        float dx[3] = {c->gxpos[3 * g2] - c->gxpos[3 * g1], c->gxpos[3 * g2 + 1] - c->gxpos[3 * g1 + 1], c->gxpos[3 * g2 + 2] - c->gxpos[3 * g1 + 2]};
+        int pass;
+        if (t1 == 0) {
+          float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]};
+          pass = dot3f(dx, n) <= m->geom_rbound[g2] + margin;
+        } else {
+          float r = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+          pass = dot3f(dx, dx) <= r * r;
+        }
+        if (pass) {
+          if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
+          else if (t1 == 6 && t2 == 6) grx_box_box(m, c, p, g1, g2, margin);
+          else if (t1 == 0 && t2 == 7) c->ired[lane] = p;
+        }
+      }
+    }
+    WAVE_SYNC();
+    // plane vs convex mesh hull: all lanes scan the hull vertices of one pair at a time
+    for (int l = 0; l < 64; l++) {
+      int p = c->ired[l];
+      if (p < 0) continue;
+      int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+      int adr = m->geom_meshadr[g2], num = m->geom_meshnum[g2];
+      float margin = m->pair_margin[p];
+      const float* gm = c->gxmat + 9 * g2;
+      float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}, nl[3];
+      mulMatTVec3f(nl, gm, n);
+      float off = dot3f(c->gxpos + 3 * g2, n) - dot3f(c->gxpos + 3 * g1, n);
+      FOR_LANES {
+        float bd = 1e30f; int bi = -1;
+        for (int v = lane; v < num; v += 64) {
+          float dd = m->mesh_vert[3 * (adr + v)] * nl[0] + m->mesh_vert[3 * (adr + v) + 1] * nl[1] + m->mesh_vert[3 * (adr + v) + 2] * nl[2] + off;
+          if (dd < bd) { bd = dd; bi = v; }
+        }
+        c->red[lane] = bd; c->red[64 + lane] = (float)bi;
+      }
+      WAVE_SYNC();
+      LANE0 {
+        float bd = 1e30f; int best = -1;
+        for (int e = 0; e < 64; e++) {
+          float dd = c->red[e]; int vi = (int)c->red[64 + e];
+          if (vi >= 0 && (dd < bd || (dd == bd && vi < best))) { bd = dd; best = vi; }
+        }
+        if (best >= 0 && bd <= margin) {
+          int verts[4] = {best, -1, -1, -1}; float dists[4] = {bd, 0, 0, 0}; int cn = 1;
+          int aa = m->mesh_adjadr[adr + best], an = m->mesh_adjnum[adr + best];
+          for (int e = 0; e < an && cn < 4; e++) {
+            int v = m->mesh_adj[aa + e];
+            float dd = m->mesh_vert[3 * (adr + v)] * nl[0] + m->mesh_vert[3 * (adr + v) + 1] * nl[1] + m->mesh_vert[3 * (adr + v) + 2] * nl[2] + off;
+            if (dd <= margin) { verts[cn] = v; dists[cn] = dd; cn++; }
+          }
+          for (int e = 0; e < cn; e++) {
+            float lv[3] = {m->mesh_vert[3 * (adr + verts[e])], m->mesh_vert[3 * (adr + verts[e]) + 1], m->mesh_vert[3 * (adr + verts[e]) + 2]}, w[3], pos[3];
+            mulMatVec3f(w, gm, lv);
+            for (int t = 0; t < 3; t++) pos[t] = w[t] + c->gxpos[3 * g2 + t] - 0.5f * dists[e] * n[t];
+            grx_add_contact(c, p, pos, n, dists[e]);
+          }
+        }
+      }
+      WAVE_SYNC();
+    }
+  }
+  LANE0 { if (c->cnt[0] > GRX_MAXCON) c->cnt[0] = GRX_MAXCON; }
+  WAVE_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// K9 constraint rows (equality weld, dof frictionloss, joint limits, pyramidal contacts)
+// ------------------------------------------------------------------------------------------
+GRX_DEV float grx_impedance(const float* solimp, float pos) {
+  float dmin = fminf(GRX_MAXIMP, fmaxf(GRX_MINIMP, solimp[0])), dmax = fminf(GRX_MAXIMP, fmaxf(GRX_MINIMP, solimp[1]));
+  float width = fmaxf(0.0f, solimp[2]), mid = fminf(GRX_MAXIMP, fmaxf(GRX_MINIMP, solimp[3])), power = fmaxf(1.0f, solimp[4]);
+  if (dmin == dmax || width <= GRX_MINVAL) return 0.5f * (dmin + dmax);
+  float x = fabsf(pos) / width;
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  float y;
+  if (power == 1.0f) y = x;
+  else if (power == 2.0f) y = (x <= mid) ? x * x / mid : 1.0f - (1.0f - x) * (1.0f - x) / (1.0f - mid);
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.0f);
+  else y = 1.0f - powf(1.0f - x, power) / powf(1.0f - mid, power - 1.0f);
+  return dmin + y * (dmax - dmin);
+}
+
+// column d of the translational / rotational Jacobian of a world point on body b (zero if d not in chain)
+GRX_DEV void grx_jac_col(const GrxModel* m, const GrxCtx* c, int b, const float* point, int d, float* jp, float* jr) {
+  unsigned lo = (unsigned)m->dof_chainmask[2 * b], hi = (unsigned)m->dof_chainmask[2 * b + 1];
+  int in = d < 32 ? (lo >> d) & 1u : (hi >> (d - 32)) & 1u;
+  if (!in) { jp[0] = jp[1] = jp[2] = 0; jr[0] = jr[1] = jr[2] = 0; return; }
+  const float* cref = c->xpos + 3 * m->body_rootid[b];
+  float off[3] = {point[0] - cref[0], point[1] - cref[1], point[2] - cref[2]}, t[3];
+  const float* cd = c->cdof + 6 * d;
+  float w[3] = {cd[0], cd[1], cd[2]};
+  cross3f(t, w, off);
+  jr[0] = w[0]; jr[1] = w[1]; jr[2] = w[2]; jp[0] = cd[3] + t[0]; jp[1] = cd[4] + t[1]; jp[2] = cd[5] + t[2];
+}
+
+GRX_DEV void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
+  const int nv = m->nv;
+  int ncon = c->cnt[0];
+  // ---- row bookkeeping (counts are tiny: serial prefix by every lane over LDS tables)
+  int ne = 0;
+  for (int e = 0; e < m->neq; e++) if (m->eq_active[e] && m->eq_type[e] == 1) ne += 6;
+  int nf = 0;
+  for (int d = 0; d < nv; d++) if (m->dof_frictionloss[d] > 0) nf++;
+  // limits: ired[j] = bit0 lower active, bit1 upper active
+  FOR_LANES {
+    for (int j = lane; j < m->njnt; j += 64) {
+      int f = 0;
+      if (m->jnt_limited[j] && m->jnt_type[j] >= 2) {
+        float q = c->qpos[m->jnt_qposadr[j]], mg = m->jnt_margin[j];
+        if (q - m->jnt_range[2 * j] < mg) f |= 1;
+        if (m->jnt_range[2 * j + 1] - q < mg) f |= 2;
+      }
+      c->ired[j] = f;
+    }
+  }
+  WAVE_SYNC();
+  int nl = 0;
+  for (int j = 0; j < m->njnt; j++) { int f = c->ired[j]; nl += (f & 1) + ((f >> 1) & 1); }
+  int nc = 0;
+  for (int k = 0; k < ncon; k++) {
+    int p = c->con_pair[k];
+    if (c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p]) { int dim = m->pair_condim[p]; nc += (dim == 1) ? 1 : 2 * (dim - 1); }
+  }
+  int nefc = ne + nf + nl + nc;
+  int overflow = nefc > GRX_MAXEFC;
+  // ---- descriptors
+  FOR_LANES {
+    for (int r = lane; r < ne; r += 64) {  // welds are the only equality type in scope
+      int e = 0, acc = 0;
+      for (int q = 0; q < m->neq; q++) if (m->eq_active[q] && m->eq_type[q] == 1) { if (r < acc + 6) { e = q; break; } acc += 6; }
+      c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = e; c->efc_sub[r] = r - acc;
+    }
+    for (int d = lane; d < nv; d += 64) {
+      if (m->dof_frictionloss[d] > 0) {
+        int r = ne; for (int q = 0; q < d; q++) if (m->dof_frictionloss[q] > 0) r++;
+        c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d; c->efc_sub[r] = 0;
+      }
+    }
+    for (int j = lane; j < m->njnt; j += 64) {
+      int f = c->ired[j];
+      if (f) {
+        int r = ne + nf;
+        for (int q = 0; q < j; q++) { int g = c->ired[q]; r += (g & 1) + ((g >> 1) & 1); }
+        if (f & 1) { if (r < GRX_MAXEFC) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j; c->efc_sub[r] = 0; } r++; }
+        if (f & 2) { if (r < GRX_MAXEFC) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j; c->efc_sub[r] = 1; } }
+      }
+    }
+    for (int k = lane; k < ncon; k += 64) {
+      int p = c->con_pair[k];
+      int active = c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p];
+      int r = ne + nf + nl;
+      for (int q = 0; q < k; q++) {
+        int pq = c->con_pair[q];
+        if (c->con_dist[q] < m->pair_margin[pq] - m->pair_gap[pq]) { int dq = m->pair_condim[pq]; r += (dq == 1) ? 1 : 2 * (dq - 1); }
+      }
+      c->con_efc[k] = active ? r : -1;
+      if (active) {
+        int dim = m->pair_condim[p], nr = (dim == 1) ? 1 : 2 * (dim - 1);
+        for (int q = 0; q < nr; q++) if (r + q < GRX_MAXEFC) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = k; c->efc_sub[r + q] = q; }
+      }
+    }
+  }
+  if (overflow) nefc = GRX_MAXEFC;
+  LANE0 { c->cnt[1] = nefc; c->cnt[3] = ne; c->cnt[4] = nf; c->cnt[5] = nl; if (overflow) c->cnt[2] |= GRX_ST_EFC_OVERFLOW; }
+  WAVE_SYNC();
+  // ---- Jacobian rows.  zero fill, then per (row-group, dof) items
+  FOR_LANES { for (int i = lane; i < nefc * nv; i += 64) c->J[i] = 0; }
+  WAVE_SYNC();
+  FOR_LANES {
+    // welds: one lane per (weld, dof)
+    for (int it = lane; it < (ne / 6) * nv; it += 64) {
+      int w = it / nv, d = it - w * nv;
+      int e = c->efc_id[6 * w];
+      int b0 = m->eq_obj1[e], b1 = m->eq_obj2[e];
+      const float* data = m->eq_data + 11 * e; const float* rel = m->eq_relpose + 14 * e;
+      float bx[2][3], bq[2][4], pos[2][3];
+      for (int s = 0; s < 2; s++) {
+        int bb = s ? b1 : b0; float v[3], rp[3] = {rel[7 * s], rel[7 * s + 1], rel[7 * s + 2]}, rq[4] = {rel[7 * s + 3], rel[7 * s + 4], rel[7 * s + 5], rel[7 * s + 6]};
+        mulMatVec3f(v, c->xmat + 9 * bb, rp);
+        for (int k = 0; k < 3; k++) bx[s][k] = c->xpos[3 * bb + k] + v[k];
+        mulQuatf(bq[s], c->xquat + 4 * bb, rq); normalize4f(bq[s]);
+        float an[3] = {data[3 * (1 - s)], data[3 * (1 - s) + 1], data[3 * (1 - s) + 2]};
+        rotVecQuatf(v, an, bq[s]);
+        for (int k = 0; k < 3; k++) pos[s][k] = bx[s][k] + v[k];
+      }
+      float jp0[3], jr0[3], jp1[3], jr1[3];
+      grx_jac_col(m, c, b0, pos[0], d, jp0, jr0); grx_jac_col(m, c, b1, pos[1], d, jp1, jr1);
+      float ts = data[10];
+      float relq[4] = {data[6], data[7], data[8], data[9]}, quat[4], quat1[4] = {bq[1][0], -bq[1][1], -bq[1][2], -bq[1][3]};
+      mulQuatf(quat, bq[0], relq);
+      float axis[4] = {0, jr0[0] - jr1[0], jr0[1] - jr1[1], jr0[2] - jr1[2]}, t1[4], t2[4];
+      mulQuatf(t1, quat1, axis); mulQuatf(t2, t1, quat);
+      for (int r = 0; r < 3; r++) { c->J[(6 * w + r) * nv + d] = jp0[r] - jp1[r]; c->J[(6 * w + 3 + r) * nv + d] = 0.5f * ts * t2[1 + r]; }
+      if (d == 0) {  // residuals (one lane per weld)
+        float quat2[4]; mulQuatf(quat2, quat1, quat);
+        for (int r = 0; r < 3; r++) { c->efc_pos[6 * w + r] = pos[0][r] - pos[1][r]; c->efc_pos[6 * w + 3 + r] = ts * quat2[1 + r]; }
+      }
+    }
+    // frictionloss + limits: one lane per row
+    for (int r = ne + lane; r < ne + nf + nl && r < nefc; r += 64) {
+      if (c->efc_kind[r] == GRX_ROW_FRICTION) { c->J[r * nv + c->efc_id[r]] = 1.0f; c->efc_pos[r] = 0; }
+      else {
+        int j = c->efc_id[r], side = c->efc_sub[r]; float q = c->qpos[m->jnt_qposadr[j]];
+        c->J[r * nv + m->jnt_dofadr[j]] = side ? -1.0f : 1.0f;
+        c->efc_pos[r] = side ? m->jnt_range[2 * j + 1] - q : q - m->jnt_range[2 * j];
+      }
+    }
+    // contacts: one lane per (contact, dof)
+    for (int it = lane; it < ncon * nv; it += 64) {
+      int k = it / nv, d = it - k * nv;
+      int r0 = c->con_efc[k];
+      if (r0 < 0) continue;
+      int p = c->con_pair[k], dim = m->pair_condim[p];
+      int b1 = m->geom_bodyid[m->pair_geom1[p]], b2 = m->geom_bodyid[m->pair_geom2[p]];
+      float pos[3] = {c->con_pos[3 * k], c->con_pos[3 * k + 1], c->con_pos[3 * k + 2]};
+      float jp1[3], jr1[3], jp2[3], jr2[3];
+      grx_jac_col(m, c, b1, pos, d, jp1, jr1); grx_jac_col(m, c, b2, pos, d, jp2, jr2);
+      float dp[3] = {jp2[0] - jp1[0], jp2[1] - jp1[1], jp2[2] - jp1[2]}, dr[3] = {jr2[0] - jr1[0], jr2[1] - jr1[1], jr2[2] - jr1[2]};
+      const float* fr = c->con_frame + 9 * k;
+      float jc[6];
+      for (int r = 0; r < 3; r++) { jc[r] = fr[3 * r] * dp[0] + fr[3 * r + 1] * dp[1] + fr[3 * r + 2] * dp[2]; jc[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2]; }
+      if (dim == 1) { if (r0 < nefc) c->J[r0 * nv + d] = jc[0]; }
+      else
+        for (int q = 1; q < dim; q++) {
+          float mu = m->pair_friction[5 * p + q - 1];
+          int ra = r0 + 2 * (q - 1);
+          if (ra < nefc) c->J[ra * nv + d] = jc[0] + mu * jc[q];
+          if (ra + 1 < nefc) c->J[(ra + 1) * nv + d] = jc[0] - mu * jc[q];
+        }
+    }
+  }
+  WAVE_SYNC();
+  // ---- per-row impedance, regulariser, reference acceleration
+  FOR_LANES {
+    for (int r = lane; r < nefc; r += 64) {
+      int kind = c->efc_kind[r], id = c->efc_id[r];
+      float solref[2], solimp[5], pos, margin = 0, dA, floss = 0, rscale = 1.0f;
+      if (kind == GRX_ROW_EQ) {
+        for (int k = 0; k < 2; k++) solref[k] = m->eq_solref[2 * id + k];
+        for (int k = 0; k < 5; k++) solimp[k] = m->eq_solimp[5 * id + k];
+        pos = c->efc_pos[r]; dA = m->eq_invweight[2 * id + (c->efc_sub[r] >= 3)];
+      } else if (kind == GRX_ROW_FRICTION) {
+        for (int k = 0; k < 2; k++) solref[k] = m->dof_solref[2 * id + k];
+        for (int k = 0; k < 5; k++) solimp[k] = m->dof_solimp[5 * id + k];
+        pos = 0; dA = m->dof_invweight0[id]; floss = m->dof_frictionloss[id];
+      } else if (kind == GRX_ROW_LIMIT) {
+        for (int k = 0; k < 2; k++) solref[k] = m->jnt_solref[2 * id + k];
+        for (int k = 0; k < 5; k++) solimp[k] = m->jnt_solimp[5 * id + k];
+        pos = c->efc_pos[r]; margin = m->jnt_margin[id]; dA = m->dof_invweight0[m->jnt_dofadr[id]];
+      } else {
+        int p = c->con_pair[id], dim = m->pair_condim[p];
+        for (int k = 0; k < 2; k++) solref[k] = m->pair_solref[2 * p + k];
+        for (int k = 0; k < 5; k++) solimp[k] = m->pair_solimp[5 * p + k];
+        pos = c->con_dist[id]; margin = m->pair_margin[p] - m->pair_gap[p];
+        int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+        float tran = m->geom_invweight0[2 * g1] + m->geom_invweight0[2 * g2];
+        if (dim == 1) dA = tran;
+        else {  // every pyramid row of a contact shares R = 2 mu^2 R(first row)
+          float f0 = m->pair_friction[5 * p];
+          dA = tran + f0 * f0 * tran;
+          float mu = f0 / sqrtf(m->impratio);
+          rscale = 2.0f * mu * mu;
+        }
+        c->efc_pos[r] = pos;
+      }
+      float imp = grx_impedance(solimp, pos - margin);
+      float dmax = fminf(GRX_MAXIMP, fmaxf(GRX_MINIMP, solimp[1]));
+      float kk, bb;
+      if (solref[0] > 0) { float tc = fmaxf(solref[0], 2.0f * m->timestep), dr = solref[1]; kk = 1.0f / (dmax * dmax * tc * tc * dr * dr); bb = 2.0f / (dmax * tc); }
+      else { kk = -solref[0] / (dmax * dmax); bb = -solref[1] / dmax; }
+      if (kind == GRX_ROW_FRICTION) kk = 0;
+      float R = fmaxf(GRX_MINVAL, (1.0f - imp) * dA / imp) * rscale;
+      float vel = 0;
+      for (int d = 0; d < nv; d++) vel += c->J[r * nv + d] * c->qvel[d];
+      c->efc_D[r] = 1.0f / R;
+      c->efc_aref[r] = -bb * vel - kk * imp * (pos - margin);
+      c->efc_floss[r] = floss;
+    }
+  }
+  WAVE_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// K10 constraint solve: Newton on the primal problem (MuJoCo's default solver [3P]) with an
+// exact line search; wave-parallel over dofs / rows / Hessian entries.
+// ------------------------------------------------------------------------------------------
+// Ma = M a ; jar = J a - aref ; force / active flags ; returns total cost if want_cost
+GRX_DEV float grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int nefc, int want_cost, int lane_) {
+  const int nv = m->nv;
+  FOR_LANES {
+    float part = 0;
+    for (int i = lane; i < nv; i += 64) {
+      float s = 0;
+      for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * a[j];
+      c->Ma[i] = s;
+      part += 0.5f * (s - c->qfrc_smooth[i]) * (a[i] - c->qacc_smooth[i]);
+    }
+    for (int r = lane; r < nefc; r += 64) {
+      float s = 0;
+      for (int j = 0; j < nv; j++) s += c->J[r * nv + j] * a[j];
+      float x = s - c->efc_aref[r], D = c->efc_D[r], f; int quad;
+      int kind = c->efc_kind[r];
+      if (kind == GRX_ROW_EQ) { f = -D * x; part += 0.5f * D * x * x; quad = 1; }
+      else if (kind == GRX_ROW_FRICTION) {
+        float fl = c->efc_floss[r], Rf = fl / D;
+        if (x <= -Rf) { f = fl; part += -0.5f * Rf * fl - fl * x; quad = 0; }
+        else if (x >= Rf) { f = -fl; part += -0.5f * Rf * fl + fl * x; quad = 0; }
+        else { f = -D * x; part += 0.5f * D * x * x; quad = 1; }
+      } else {
+        if (x < 0) { f = -D * x; part += 0.5f * D * x * x; quad = 1; } else { f = 0; quad = 0; }
+      }
+      c->efc_jar[r] = x; c->efc_force[r] = f; c->efc_quad[r] = quad;
+    }
+    c->red[lane] = part;
+  }
+  WAVE_SYNC();
+  float cost = 0;
+  if (want_cost) { cost = grx_wave_sum(c->red, lane_); WAVE_SYNC(); }
+  return cost;
+}
+
+// derivative (d1) and curvature (d2) of the cost along the search direction at step alpha
+GRX_DEV void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, float* d1, float* d2, int lane_) {
+  FOR_LANES {
+    float g = 0, h = 0;
+    for (int r = lane; r < nefc; r += 64) {
+      float jv = c->efc_jv[r], D = c->efc_D[r], x = c->efc_jar[r] + alpha * jv;
+      int kind = c->efc_kind[r];
+      if (kind == GRX_ROW_EQ) { g += D * x * jv; h += D * jv * jv; }
+      else if (kind == GRX_ROW_FRICTION) {
+        float fl = c->efc_floss[r], Rf = fl / D;
+        if (x <= -Rf) g -= fl * jv; else if (x >= Rf) g += fl * jv; else { g += D * x * jv; h += D * jv * jv; }
+      } else if (x < 0) { g += D * x * jv; h += D * jv * jv; }
+    }
+    c->red[lane] = g; c->red[64 + lane] = h;
+  }
+  WAVE_SYNC();
+  float g = grx_wave_sum(c->red, lane_), h = grx_wave_sum(c->red + 64, lane_);
+  WAVE_SYNC();
+  *d1 = q1 + alpha * q2 + g; *d2 = q2 + h;
+}
+
+GRX_DEV void grx_solve(const GrxModel* m, GrxCtx* c, int lane_) {
+  const int nv = m->nv;
+  int nefc = c->cnt[1];
+  if (nefc == 0) {
+    FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qacc[i] = c->qacc_smooth[i]; c->qfrc_constraint[i] = 0; } }
+    WAVE_SYNC();
+    return;
+  }
+  // warm start: keep whichever of (previous qacc, unconstrained qacc) has the lower cost
+  float cw = grx_newton_eval(m, c, c->qacc_ws, nefc, 1, lane_);
+  float cs = grx_newton_eval(m, c, c->qacc_smooth, nefc, 1, lane_);
+  FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc[i] = (cw < cs) ? c->qacc_ws[i] : c->qacc_smooth[i]; }
+  WAVE_SYNC();
+  float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+  for (int it = 0; it < GRX_NEWTON_MAXIT; it++) {
+    grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
+    // gradient = M a - qfrc_smooth - J' f
+    FOR_LANES {
+      float part = 0;
+      for (int i = lane; i < nv; i += 64) {
+        float s = c->Ma[i] - c->qfrc_smooth[i];
+        for (int r = 0; r < nefc; r++) s -= c->J[r * nv + i] * c->efc_force[r];
+        c->grad[i] = s; c->search[i] = -s; part += s * s;
+      }
+      c->red[lane] = part;
+    }
+    WAVE_SYNC();
+    float gn = sqrtf(grx_wave_sum(c->red, lane_));
+    WAVE_SYNC();
+    if (scale * gn < 1e-7f) break;
+    // Hessian H = M + J' diag(D_active) J
+    FOR_LANES {
+      int li = lane >> 3, lj = lane & 7;
+      for (int i = li; i < nv; i += 8)
+        for (int j = lj; j <= i; j += 8) {
+          float s = c->M[i * nv + j];
+          for (int r = 0; r < nefc; r++)
+            if (c->efc_quad[r]) s += c->efc_D[r] * c->J[r * nv + i] * c->J[r * nv + j];
+          c->A[i * nv + j] = s; c->A[j * nv + i] = s;
+        }
+    }
+    WAVE_SYNC();
+    if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+    grx_sym_solve(c->A, nv, c->search, lane_);
+    // Mv, Jv, quadratic coefficients of the Gauss term along the direction
+    FOR_LANES {
+      float p1 = 0, p2 = 0;
+      for (int i = lane; i < nv; i += 64) {
+        float s = 0;
+        for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * c->search[j];
+        c->Mv[i] = s;
+        p1 += c->search[i] * (c->Ma[i] - c->qfrc_smooth[i]); p2 += c->search[i] * s;
+      }
+      for (int r = lane; r < nefc; r += 64) {
+        float s = 0;
+        for (int j = 0; j < nv; j++) s += c->J[r * nv + j] * c->search[j];
+        c->efc_jv[r] = s;
+      }
+      c->red[lane] = p1; c->red[64 + lane] = p2;
+    }
+    WAVE_SYNC();
+    float q1 = grx_wave_sum(c->red, lane_), q2 = grx_wave_sum(c->red + 64, lane_);
+    WAVE_SYNC();
+    // exact line search: root of the monotone piecewise-linear derivative, starting from the Newton step
+    float d1, d2, alpha = 1.0f, lo = 0.0f, hi = 0.0f, dlo, dhi = 0.0f;
+    grx_ls_eval(c, nefc, 0.0f, q1, q2, &dlo, &d2, lane_);
+    if (!(dlo < 0)) break;
+    int have_hi = 0;
+    float gtol = 1e-6f * fabsf(dlo);
+    grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
+    for (int k = 0; k < GRX_LS_MAXIT; k++) {
+      if (fabsf(d1) <= gtol) break;
+      if (d1 < 0) { lo = alpha; dlo = d1; } else { hi = alpha; dhi = d1; have_hi = 1; }
+      float na = alpha - d1 / d2;
+      if (have_hi) { if (!(na > lo && na < hi)) na = lo + (hi - lo) * (dlo / (dlo - dhi)); if (!(na > lo && na < hi)) na = 0.5f * (lo + hi); }
+      else if (!(na > lo)) na = 2.0f * alpha;
+      alpha = na;
+      grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
+    }
+    FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc[i] += alpha * c->search[i]; }
+    WAVE_SYNC();
+  }
+  grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
+  FOR_LANES {
+    for (int i = lane; i < nv; i += 64) {
+      float s = 0;
+      for (int r = 0; r < nefc; r++) s += c->J[r * nv + i] * c->efc_force[r];
+      c->qfrc_constraint[i] = s;
+    }
+  }
+  WAVE_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// mj_forward / mj_Euler equivalents
+// ------------------------------------------------------------------------------------------
+GRX_DEV void grx_forward(const GrxModel* m, GrxCtx* c, int lane_) {
+  const int nv = m->nv;
+  grx_kinematics(m, c, lane_);
+  grx_inertia_cdof(m, c, lane_);
+  grx_collision(m, c, lane_);
+  grx_make_constraint(m, c, lane_);
+  grx_velocity(m, c, lane_);
+  // qacc_smooth = M^-1 qfrc_smooth
+  FOR_LANES { for (int i = lane; i < nv * nv; i += 64) c->A[i] = c->M[i]; }
+  WAVE_SYNC();
+  if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+  grx_sym_solve(c->A, nv, c->qacc_smooth, lane_);
+  grx_solve(m, c, lane_);
+  FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc_ws[i] = c->qacc[i]; }
+  WAVE_SYNC();
+}
+
+// semi-implicit Euler with implicit joint damping
+GRX_DEV void grx_euler(const GrxModel* m, GrxCtx* c, int lane_) {
+  const int nv = m->nv; const float h = m->timestep;
+  if (m->anydamp && m->eulerdamp) {
+    FOR_LANES {
+      for (int i = lane; i < nv * nv; i += 64) { int r = i / nv, q = i - r * nv; c->A[i] = c->M[i] + ((r == q) ? h * m->dof_damping[r] : 0.0f); }
+      for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qfrc_smooth[i] + c->qfrc_constraint[i];
+    }
+    WAVE_SYNC();
+    if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+    grx_sym_solve(c->A, nv, c->tmpv, lane_);
+  } else {
+    FOR_LANES { for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qacc[i]; }
+    WAVE_SYNC();
+  }
+  FOR_LANES { for (int i = lane; i < nv; i += 64) c->qvel[i] += h * c->tmpv[i]; }
+  WAVE_SYNC();
+  FOR_LANES {
+    for (int j = lane; j < m->njnt; j += 64) {
+      int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == 0) {
+        for (int k = 0; k < 3; k++) c->qpos[qa + k] += h * c->qvel[da + k];
+        float w[3] = {c->qvel[da + 3], c->qvel[da + 4], c->qvel[da + 5]};
+        float n = sqrtf(dot3f(w, w));
+        if (n > 1e-12f) {
+          float sn, cs; sincosf(0.5f * h * n, &sn, &cs);
+          float ri = sn / n, qr[4] = {cs, w[0] * ri, w[1] * ri, w[2] * ri}, q[4] = {c->qpos[qa + 3], c->qpos[qa + 4], c->qpos[qa + 5], c->qpos[qa + 6]}, qn[4];
+          mulQuatf(qn, q, qr); normalize4f(qn);
+          for (int k = 0; k < 4; k++) c->qpos[qa + 3 + k] = qn[k];
+        }
+      } else c->qpos[qa] += h * c->qvel[da];
+    }
+  }
+  WAVE_SYNC();
+}
+
+GRX_DEV void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {
+  FOR_LANES {
+    int bad = 0;
+    for (int i = lane; i < m->nq; i += 64) { float v = c->qpos[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
+    for (int i = lane; i < m->nv; i += 64) { float v = c->qvel[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
+    if (bad) c->cnt[2] |= GRX_ST_BADNUM;
+  }
+  WAVE_SYNC();
+}
+
+// one mj_step
+GRX_DEV void grx_step1(const GrxModel* m, GrxCtx* c, int lane_) {
+  grx_forward(m, c, lane_);
+  grx_euler(m, c, lane_);
+}

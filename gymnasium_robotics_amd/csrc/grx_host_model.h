@@ -1,0 +1,60 @@
+// grx_host_model.h -- host-side packing of the compiled-model blob (include/grx_model_fields.def)
+// into one fp32 and one int32 array, and a GrxModel whose table pointers address those arrays
+// relative to arbitrary base pointers (host memory for the lane emulator, HBM for the GPU).
+#pragma once
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/grx_model.h"
+#include "grx_engine.h"
+
+struct GrxPackedModel {
+  std::vector<float> f;       // all GRX_FF tables, converted to fp32
+  std::vector<int32_t> i;     // all GRX_FI tables
+  std::vector<int> off, cnt;  // per table (in .def order): offset inside f or i, element count
+  std::vector<char> kind;     // 'f' or 'i'
+  std::vector<std::string> name;
+  GrxModel proto;             // scalar members filled; pointers unset
+};
+
+inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, GrxPackedModel* out) {
+  grx_model_view v;
+  grx_model_view_init(&v, H, I, F);
+  out->f.clear(); out->i.clear(); out->off.clear(); out->cnt.clear(); out->kind.clear(); out->name.clear();
+#define GRX_FI(n) out->name.push_back(#n); out->kind.push_back('i'); out->off.push_back((int)out->i.size()); out->cnt.push_back(v.n_##n); \
+  out->i.insert(out->i.end(), v.n, v.n + v.n_##n); while (out->i.size() % 4) out->i.push_back(0);
+#define GRX_FF(n) out->name.push_back(#n); out->kind.push_back('f'); out->off.push_back((int)out->f.size()); out->cnt.push_back(v.n_##n); \
+  for (int k_ = 0; k_ < v.n_##n; k_++) out->f.push_back((float)v.n[k_]); while (out->f.size() % 4) out->f.push_back(0.0f);
+#include "../../include/grx_model_fields.def"
+#undef GRX_FI
+#undef GRX_FF
+  GrxModel& m = out->proto;
+  std::memset(&m, 0, sizeof(m));
+  const int32_t* d = v.dims;
+  m.nq = d[GRX_NQ]; m.nv = d[GRX_NV]; m.nu = d[GRX_NU]; m.nbody = d[GRX_NBODY]; m.njnt = d[GRX_NJNT]; m.ngeom = d[GRX_NGEOM];
+  m.nsite = d[GRX_NSITE]; m.nmocap = d[GRX_NMOCAP]; m.neq = d[GRX_NEQ]; m.npair = d[GRX_NPAIR]; m.maxdepth = d[GRX_MAXDEPTH];
+  m.eulerdamp = d[GRX_EULERDAMP]; m.ndevpair = v.n_devpair; m.nmpair = v.n_mpair_i;
+  m.anydamp = 0;
+  for (int k = 0; k < v.n_dof_damping; k++) if (v.dof_damping[k] > 0) m.anydamp = 1;
+  m.timestep = (float)v.opt[GRX_TIMESTEP];
+  m.gravity[0] = (float)v.opt[GRX_GRAVITY_X]; m.gravity[1] = (float)v.opt[GRX_GRAVITY_Y]; m.gravity[2] = (float)v.opt[GRX_GRAVITY_Z];
+  m.meaninertia = (float)v.opt[GRX_MEANINERTIA]; m.impratio = (float)v.opt[GRX_IMPRATIO];
+}
+
+// model view whose tables live at (fbase, ibase)
+inline GrxModel grx_bind_model(const GrxPackedModel& p, const float* fbase, const int32_t* ibase) {
+  GrxModel m = p.proto;
+  int k = 0;
+#define GRX_FI(n) m.n = ibase + p.off[k]; ++k;
+#define GRX_FF(n) m.n = fbase + p.off[k]; ++k;
+#include "../../include/grx_model_fields.def"
+#undef GRX_FI
+#undef GRX_FF
+  return m;
+}
+
+inline int grx_find_table(const GrxPackedModel& p, const char* name) {
+  for (size_t k = 0; k < p.name.size(); k++) if (p.name[k] == name) return (int)k;
+  return -1;
+}

@@ -1219,6 +1219,64 @@ class _Lowering:
             mesh_vert=np.array(mesh_vert).reshape(len(mesh_vert), 3), mesh_adjadr=np.array(mesh_adjadr, np.int32),
             mesh_adjnum=np.array(mesh_adjnum, np.int32), mesh_adj=np.array(mesh_adj, np.int32),
         )
+        # ---- derived tree tables (static structure used by the wave-per-world engine)
+        order = sorted(range(1, nbk), key=lambda k: (body_depth[k], k))
+        maxdepth = int(body_depth.max()) if nbk > 1 else 0
+        level_adr = np.zeros(maxdepth + 2, np.int32)
+        for k in order:
+            level_adr[body_depth[k] + 1] += 1
+        level_adr = np.cumsum(level_adr).astype(np.int32)
+        subs = [[k] for k in range(nbk)]
+        for k in range(nbk - 1, 0, -1):
+            if body_parent[k] > 0:
+                subs[body_parent[k]] = subs[body_parent[k]] + subs[k]
+        subs[0] = [0]
+        body_subadr = np.zeros(nbk, np.int32)
+        body_subnum = np.zeros(nbk, np.int32)
+        body_sub = []
+        for k in range(nbk):
+            body_subadr[k], body_subnum[k] = len(body_sub), len(subs[k])
+            body_sub += sorted(subs[k])
+        body_lastdof = -np.ones(nbk, np.int32)
+        for k in range(1, nbk):
+            if body_dofnum[k] > 0:
+                body_lastdof[k] = body_dofadr[k] + body_dofnum[k] - 1
+            else:
+                body_lastdof[k] = body_lastdof[body_parent[k]]
+        mpi, mpj = [], []
+        for i in range(nv):
+            j = i
+            while j >= 0:
+                mpi.append(i)
+                mpj.append(j)
+                j = int(dof_parentid[j])
+        dof_cvelstart = np.zeros(nv, np.int32)
+        for d in range(nv):
+            j = jnts[dof_jntid[d]]
+            if j.type == JNT_FREE:
+                t = d - j.dofadr
+                dof_cvelstart[d] = dof_parentid[j.dofadr] if t < 3 else j.dofadr + 2
+            elif j.type == JNT_BALL:
+                dof_cvelstart[d] = dof_parentid[j.dofadr]
+            else:
+                dof_cvelstart[d] = dof_parentid[d]
+        chainmask = np.zeros((nbk, 2), np.int64)
+        for k in range(1, nbk):
+            d = int(body_lastdof[k])
+            msk = 0
+            while d >= 0:
+                msk |= 1 << d
+                d = int(dof_parentid[d])
+            chainmask[k] = [msk & 0xFFFFFFFF, (msk >> 32) & 0xFFFFFFFF]
+        chainmask = chainmask.astype(np.uint32).view(np.int32) if False else np.array(
+            [[(v if v < 2 ** 31 else v - 2 ** 32) for v in row] for row in chainmask], np.int32)
+        T.update(
+            body_order=np.array(order, np.int32), level_adr=level_adr, body_subadr=body_subadr, body_subnum=body_subnum,
+            body_sub=np.array(body_sub, np.int32), body_lastdof=body_lastdof, mpair_i=np.array(mpi, np.int32),
+            mpair_j=np.array(mpj, np.int32), dof_cvelstart=dof_cvelstart, dof_chainmask=chainmask,
+            devpair=np.nonzero(pair_supported)[0].astype(np.int32),
+        )
+        info["nmpair"] = len(mpi)
         info["nbody_full"] = nb
         info["unsupported_pairs"] = int(np.sum(pair_supported == 0))
         return CompiledModel(T, names, info)

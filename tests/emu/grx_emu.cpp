@@ -1,0 +1,91 @@
+// grx_emu.cpp -- TEST INFRASTRUCTURE: sequential 64-lane emulator build of the device engine.
+//
+// Compiles gymnasium_robotics_amd/csrc/grx_engine.h + grx_fetch_task.h with GRX_EMU so the
+// exact kernel source can be checked against the fp64 oracle on a machine without a GPU
+// (lanes are executed one after another inside each FOR_LANES block).  Never loaded by the
+// product; the product path is the HIP build of the same headers (csrc/grx_kernels.hip).
+#define GRX_EMU 1
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../gymnasium_robotics_amd/csrc/grx_fetch_task.h"
+#include "../../gymnasium_robotics_amd/csrc/grx_host_model.h"
+
+struct Emu {
+  GrxPackedModel pm;
+  GrxModel m;
+  std::vector<float> lds;
+  GrxCtx c;
+};
+
+extern "C" {
+
+void* emu_create(const int32_t* H, const int32_t* I, const double* F) {
+  Emu* e = new Emu();
+  grx_pack_model(H, I, F, &e->pm);
+  e->m = grx_bind_model(e->pm, e->pm.f.data(), e->pm.i.data());
+  int words = grx_ctx_words(e->m.nq, e->m.nv, e->m.nu, e->m.nbody, e->m.njnt, e->m.ngeom, e->m.nsite, e->m.nmocap);
+  e->lds.assign((size_t)words + 64, 0.0f);
+  grx_ctx_carve(&e->c, e->lds.data(), &e->m);
+  return e;
+}
+void emu_destroy(void* h) { delete (Emu*)h; }
+int emu_ctx_words(void* h) { return (int)((Emu*)h)->lds.size(); }
+
+int emu_set_table(void* h, const char* name, const double* data, int n) {
+  Emu* e = (Emu*)h;
+  int k = grx_find_table(e->pm, name);
+  if (k < 0 || e->pm.kind[k] != 'f' || n > e->pm.cnt[k]) return -1;
+  for (int i = 0; i < n; i++) e->pm.f[e->pm.off[k] + i] = (float)data[i];
+  return 0;
+}
+
+static void load_state(Emu* e, const float* qpos, const float* qvel, const float* qacc_ws, const float* mocap) {
+  GrxCtx* c = &e->c; const GrxModel* m = &e->m;
+  std::fill(e->lds.begin(), e->lds.end(), 0.0f);
+  memcpy(c->qpos, qpos, sizeof(float) * m->nq); memcpy(c->qvel, qvel, sizeof(float) * m->nv);
+  memcpy(c->qacc_ws, qacc_ws, sizeof(float) * m->nv);
+  for (int k = 0; k < m->nmocap; k++) { memcpy(c->mocap_pos + 3 * k, mocap + 7 * k, 12); memcpy(c->mocap_quat + 4 * k, mocap + 7 * k + 3, 16); }
+}
+static void store_state(Emu* e, float* qpos, float* qvel, float* qacc_ws, float* mocap, int* status) {
+  GrxCtx* c = &e->c; const GrxModel* m = &e->m;
+  memcpy(qpos, c->qpos, sizeof(float) * m->nq); memcpy(qvel, c->qvel, sizeof(float) * m->nv);
+  memcpy(qacc_ws, c->qacc_ws, sizeof(float) * m->nv);
+  for (int k = 0; k < m->nmocap; k++) { memcpy(mocap + 7 * k, c->mocap_pos + 3 * k, 12); memcpy(mocap + 7 * k + 3, c->mocap_quat + 4 * k, 16); }
+  *status = c->cnt[2];
+}
+
+// env.step() of one world (state in/out by pointer)
+void emu_fetch_step(void* h, const GrxFetchTask* t, float* qpos, float* qvel, float* qacc_ws, float* mocap, float* aux,
+                    const float* action, float* obs, float* achieved, int* status) {
+  Emu* e = (Emu*)h;
+  load_state(e, qpos, qvel, qacc_ws, mocap);
+  float aux_in[8]; memcpy(aux_in, aux, sizeof(aux_in));
+  grx_fetch_step_world(&e->m, t, &e->c, aux_in, action, aux, obs, achieved, 0);
+  store_state(e, qpos, qvel, qacc_ws, mocap, status);
+}
+
+// mj_forward + outputs (reset path) ; nstep > 0 additionally integrates nstep raw physics steps first (env setup)
+void emu_forward(void* h, const GrxFetchTask* t, float* qpos, float* qvel, float* qacc_ws, float* mocap, float* aux, float* obs,
+                 float* achieved, int* status, int nstep) {
+  Emu* e = (Emu*)h;
+  load_state(e, qpos, qvel, qacc_ws, mocap);
+  for (int s = 0; s < nstep; s++) grx_step1(&e->m, &e->c, 0);
+  if (nstep == 0) grx_forward(&e->m, &e->c, 0);
+  grx_fetch_outputs(&e->m, t, &e->c, aux, obs, achieved, 0);
+  store_state(e, qpos, qvel, qacc_ws, mocap, status);
+}
+
+// debug access to the working set of the last call
+float* emu_ctx_ptr(void* h, const char* name) {
+  Emu* e = (Emu*)h; GrxCtx* c = &e->c;
+#define P(n) if (!strcmp(name, #n)) return (float*)c->n;
+  P(qpos) P(qvel) P(xpos) P(xquat) P(xmat) P(cinert) P(crb) P(cvel) P(cdof) P(cdof_dot) P(M) P(A) P(qfrc_bias) P(qfrc_passive)
+  P(qfrc_actuator) P(qfrc_smooth) P(qacc_smooth) P(qfrc_constraint) P(qacc) P(J) P(efc_pos) P(efc_D) P(efc_aref) P(efc_force)
+  P(con_dist) P(con_pos) P(con_frame) P(gxpos) P(gxmat) P(sxpos) P(sxmat) P(cnt) P(efc_kind) P(efc_id) P(con_pair) P(janchor) P(jaxis)
+#undef P
+  return nullptr;
+}
+}
