@@ -1,0 +1,50 @@
+"""Loader for the HIP extension (libgrx_hip.so, C ABI in include/grx_capi.h).
+
+There is deliberately NO fallback: if the extension is missing or no MI355X is visible the
+product path raises.  (The fp64 oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libgrx_hip.so")
+_lib = None
+
+
+class FetchBuffersStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask")]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.grx_last_error.restype = ctypes.c_char_p
+        L.grx_model_create.argtypes = [vp, ci, vp, ci, vp, ci, ci, ctypes.POINTER(vp)]
+        L.grx_model_destroy.argtypes = [vp]
+        L.grx_model_set_table.argtypes = [vp, ctypes.c_char_p, vp, ci]
+        L.grx_model_lds_bytes.argtypes = [vp]
+        L.grx_model_dim.argtypes = [vp, ctypes.c_char_p]
+        L.grx_fetch_step.argtypes = [vp, vp, vp, ci, vp]
+        L.grx_fetch_forward.argtypes = [vp, vp, vp, ci, ci, vp]
+        L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError("libgrx_hip: " + lib().grx_last_error().decode())
+
+
+EXPORTED_SYMBOLS = [
+    "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_compute_reward", "grx_last_error",
+]

@@ -1,0 +1,45 @@
+"""Vectorised restatement of the multi-goal API (/root/reference/gymnasium_robotics/core.py:8-114).
+
+``GoalVecEnv`` keeps the GoalEnv contract -- dict observations with the keys ``observation`` /
+``achieved_goal`` / ``desired_goal`` (core.py:31-43) and the three ``compute_*`` methods that accept
+arbitrary leading batch dimensions (core.py:45-114) -- with a leading ``num_envs`` axis on everything,
+following the gymnasium.vector.VectorEnv conventions [3P].
+"""
+import numpy as np
+
+from .spaces import Dict
+
+
+class GoalVecEnv:
+    metadata = {"render_modes": []}
+    num_envs: int
+    single_observation_space: Dict
+    observation_space: Dict
+    REQUIRED_KEYS = ("observation", "achieved_goal", "desired_goal")
+
+    def _check_goal_space(self):
+        if not isinstance(self.single_observation_space, Dict):
+            raise TypeError("GoalEnv requires an observation space of type Dict")
+        for key in self.REQUIRED_KEYS:
+            if key not in self.single_observation_space:
+                raise KeyError(f'GoalEnv requires the "{key}" key to be part of the observation dictionary.')
+
+    def compute_reward(self, achieved_goal, desired_goal, info):
+        raise NotImplementedError
+
+    def compute_terminated(self, achieved_goal, desired_goal, info):
+        raise NotImplementedError
+
+    def compute_truncated(self, achieved_goal, desired_goal, info):
+        raise NotImplementedError
+
+    def close(self):
+        pass
+
+
+def np_random(seed=None):
+    """gymnasium.utils.seeding.np_random [3P]: PCG64 seeded through a SeedSequence."""
+    if seed is not None and not (isinstance(seed, (int, np.integer)) and seed >= 0):
+        raise ValueError(f"Seed must be a non-negative integer or None, got {seed!r}")
+    ss = np.random.SeedSequence(seed)
+    return np.random.Generator(np.random.PCG64(ss)), ss.entropy

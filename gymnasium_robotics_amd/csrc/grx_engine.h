@@ -22,6 +22,7 @@
 
 #if defined(GRX_EMU)
 #define GRX_DEV static inline
+#define GRX_HD static inline
 #define FOR_LANES for (int lane = 0; lane < 64; ++lane)
 #define LANE0 if (1)
 #define WAVE_SYNC() ((void)0)
@@ -29,6 +30,7 @@
 static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 #else
 #define GRX_DEV __device__ __forceinline__
+#define GRX_HD __host__ __device__ inline
 #define FOR_LANES for (int lane = lane_, once_ = 1; once_; once_ = 0)
 #define LANE0 if (lane_ == 0)
 #define WAVE_SYNC() __syncthreads()
@@ -89,7 +91,7 @@ struct GrxCtx {
 };
 
 // LDS footprint in 4-byte words for a model with the given dims
-GRX_DEV int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap) {
+GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap) {
   int w = 0;
   w += nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;
   w += 3 * nbody + 4 * nbody + 3 * njnt + 3 * njnt;

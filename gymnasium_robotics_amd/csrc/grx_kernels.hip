@@ -1,0 +1,209 @@
+// grx_kernels.hip -- gfx950 kernels + the C ABI declared in include/grx_capi.h.
+//
+// Launch geometry: one 64-lane wavefront (= one workgroup) per world, dynamic LDS holds the
+// world's whole working set (grx_ctx_words), so the 20 fused substeps of an env.step() read
+// and write HBM exactly once.  Worlds are independent: no inter-workgroup communication.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/grx_capi.h"
+#include "grx_fetch_task.h"
+#include "grx_host_model.h"
+
+static_assert(sizeof(grx_fetch_task) == sizeof(GrxFetchTask), "grx_fetch_task must mirror GrxFetchTask");
+static_assert(sizeof(grx_fetch_buffers) == sizeof(GrxFetchBuffers), "grx_fetch_buffers must mirror GrxFetchBuffers");
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void grx_load_world(const GrxModel& m, const GrxFetchBuffers& b, GrxCtx& c, int w, float* lds, int words, int lane_) {
+  for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;  // also zeroes the structurally-zero part of M
+  __syncthreads();
+  for (int i = lane_; i < m.nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * m.nq + i];
+  for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
+  for (int i = lane_; i < 7 * m.nmocap; i += 64) {
+    int k = i / 7, e = i - 7 * k; float v = b.mocap[(size_t)w * 7 * m.nmocap + i];
+    if (e < 3) c.mocap_pos[3 * k + e] = v; else c.mocap_quat[4 * k + e - 3] = v;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetchTask& t, const GrxFetchBuffers& b, GrxCtx& c, int w, int lane_) {
+  for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
+  for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)w * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * m.nv + i] = c.qacc_ws[i]; }
+  for (int i = lane_; i < 7 * m.nmocap; i += 64) {
+    int k = i / 7, e = i - 7 * k;
+    b.mocap[(size_t)w * 7 * m.nmocap + i] = (e < 3) ? c.mocap_pos[3 * k + e] : c.mocap_quat[4 * k + e - 3];
+  }
+  if (lane_ == 0) {
+    const float* ag = b.achieved + (size_t)w * 3;
+    float d = grx_goal_distance3(ag, b.goal + (size_t)w * 3);
+    b.reward[w] = grx_fetch_reward(d, t.distance_threshold, t.sparse_reward);
+    b.success[w] = (d < t.distance_threshold) ? 1 : 0;
+    b.status[w] = c.cnt[2];
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
+  extern __shared__ float lds[];
+  const int w = blockIdx.x, lane_ = threadIdx.x;
+  if (w >= n_worlds) return;
+  if (b.mask && !b.mask[w]) return;
+  GrxCtx c;
+  grx_ctx_carve(&c, lds, &m);
+  grx_load_world(m, b, c, w, lds, words, lane_);
+  float* aux = b.aux + (size_t)w * 8;
+  float aux_in[8];
+  for (int k = 0; k < 8; k++) aux_in[k] = aux[k];
+  grx_fetch_step_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, aux, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
+  __syncthreads();
+  grx_store_world(m, t, b, c, w, lane_);
+}
+
+// reset path: (optional raw settle steps) + mj_forward + outputs
+extern "C" __global__ void __launch_bounds__(64)
+grx_fetch_forward_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words, int nstep) {
+  extern __shared__ float lds[];
+  const int w = blockIdx.x, lane_ = threadIdx.x;
+  if (w >= n_worlds) return;
+  if (b.mask && !b.mask[w]) return;
+  GrxCtx c;
+  grx_ctx_carve(&c, lds, &m);
+  grx_load_world(m, b, c, w, lds, words, lane_);
+  for (int s = 0; s < nstep; s++) grx_step1(&m, &c, lane_);
+  if (nstep == 0) grx_forward(&m, &c, lane_);
+  grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)w * 8, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
+  __syncthreads();
+  grx_store_world(m, t, b, c, w, lane_);
+}
+
+// HER relabel: reward for B (achieved, desired) pairs; 16 B/lane loads where the layout allows
+extern "C" __global__ void __launch_bounds__(256)
+grx_fetch_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, float thresh, int sparse, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
+    float a[3] = {ag[3 * i], ag[3 * i + 1], ag[3 * i + 2]}, g[3] = {dg[3 * i], dg[3 * i + 1], dg[3 * i + 2]};
+    out[i] = grx_fetch_reward(grx_goal_distance3(a, g), thresh, sparse);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+struct grx_model {
+  GrxPackedModel pm;
+  float* d_f = nullptr;
+  int32_t* d_i = nullptr;
+  GrxModel dev;  // table pointers address d_f / d_i
+  int device = 0;
+  int words = 0;
+};
+
+static thread_local std::string g_err;
+static int fail(const std::string& msg) { g_err = msg; return -1; }
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* grx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out) {
+  (void)nH; (void)nI; (void)nF;
+  if (!H || !I || !F || !out) return fail("grx_model_create: null argument");
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("grx_model_create: no such HIP device");
+  HIP_OK(hipSetDevice(device));
+  grx_model* m = new grx_model();
+  m->device = device;
+  grx_pack_model(H, I, F, &m->pm);
+  HIP_OK(hipMalloc(&m->d_f, sizeof(float) * (m->pm.f.size() + 4)));
+  HIP_OK(hipMalloc(&m->d_i, sizeof(int32_t) * (m->pm.i.size() + 4)));
+  HIP_OK(hipMemcpy(m->d_f, m->pm.f.data(), sizeof(float) * m->pm.f.size(), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(m->d_i, m->pm.i.data(), sizeof(int32_t) * m->pm.i.size(), hipMemcpyHostToDevice));
+  m->dev = grx_bind_model(m->pm, m->d_f, m->d_i);
+  const GrxModel& g = m->dev;
+  m->words = grx_ctx_words(g.nq, g.nv, g.nu, g.nbody, g.njnt, g.ngeom, g.nsite, g.nmocap);
+  int bytes = m->words * 4;
+  if (bytes > 160 * 1024) return fail("model working set exceeds the 160 KiB LDS of a CU");
+  HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  *out = m;
+  return 0;
+}
+
+extern "C" int grx_model_destroy(grx_model* m) {
+  if (!m) return 0;
+  (void)hipSetDevice(m->device);
+  (void)hipFree(m->d_f); (void)hipFree(m->d_i);
+  delete m;
+  return 0;
+}
+
+extern "C" int grx_model_set_table(grx_model* m, const char* name, const double* data, int n) {
+  if (!m || !name || !data) return fail("grx_model_set_table: null argument");
+  int k = grx_find_table(m->pm, name);
+  if (k < 0 || m->pm.kind[k] != 'f') return fail(std::string("grx_model_set_table: no fp table named ") + name);
+  if (n > m->pm.cnt[k]) return fail("grx_model_set_table: too many elements");
+  for (int i = 0; i < n; i++) m->pm.f[m->pm.off[k] + i] = (float)data[i];
+  HIP_OK(hipSetDevice(m->device));
+  HIP_OK(hipMemcpy(m->d_f + m->pm.off[k], m->pm.f.data() + m->pm.off[k], sizeof(float) * n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int grx_model_lds_bytes(const grx_model* m) { return m ? m->words * 4 : -1; }
+
+extern "C" int grx_model_dim(const grx_model* m, const char* name) {
+  if (!m) return -1;
+  const GrxModel& g = m->dev;
+  if (!strcmp(name, "nq")) return g.nq;
+  if (!strcmp(name, "nv")) return g.nv;
+  if (!strcmp(name, "nu")) return g.nu;
+  if (!strcmp(name, "nbody")) return g.nbody;
+  if (!strcmp(name, "nmocap")) return g.nmocap;
+  if (!strcmp(name, "ndevpair")) return g.ndevpair;
+  return -1;
+}
+
+static int check_buffers(const grx_fetch_buffers* b) {
+  if (!b || !b->qpos || !b->qvel || !b->qacc_ws || !b->mocap || !b->aux || !b->goal || !b->obs || !b->achieved || !b->reward ||
+      !b->success || !b->status)
+    return fail("grx_fetch_*: null buffer");
+  return 0;
+}
+
+extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, void* stream) {
+  if (!m || !task) return fail("grx_fetch_step: null argument");
+  if (check_buffers(buf)) return -1;
+  if (!buf->action) return fail("grx_fetch_step: null action buffer");
+  if (n_worlds <= 0) return 0;
+  GrxFetchTask t; memcpy(&t, task, sizeof(t));
+  GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
+  hipLaunchKernelGGL(grx_fetch_step_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->dev, t, b, n_worlds, m->words);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream) {
+  if (!m || !task) return fail("grx_fetch_forward: null argument");
+  if (check_buffers(buf)) return -1;
+  if (n_worlds <= 0) return 0;
+  GrxFetchTask t; memcpy(&t, task, sizeof(t));
+  GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
+  hipLaunchKernelGGL(grx_fetch_forward_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->dev, t, b, n_worlds, m->words, nstep);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
+                                        float* reward_out, void* stream) {
+  if (!achieved || !desired || !reward_out) return fail("grx_fetch_compute_reward: null argument");
+  if (batch <= 0) return 0;
+  long long blocks = (batch + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(grx_fetch_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, achieved, desired, (long long)batch,
+                     distance_threshold, sparse, reward_out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

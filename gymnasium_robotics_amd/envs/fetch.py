@@ -1,0 +1,306 @@
+"""Batched Fetch environments on the MI355X engine (host side, Python).
+
+Vectorised drop-in for the reference classes
+    MujocoFetchReachEnv / MujocoFetchPushEnv / MujocoFetchPickAndPlaceEnv
+(/root/reference/gymnasium_robotics/envs/fetch/*.py) behind the unchanged Gymnasium GoalEnv contract:
+
+    reset(seed=, options=) -> (obs_dict, info)            envs/robot_env.py:154-186
+    step(actions)          -> (obs_dict, reward, terminated, truncated, info)   envs/robot_env.py:114-152
+    compute_reward(achieved_goal, desired_goal, info)      envs/fetch/fetch_env.py:74-80 (batched, HER)
+
+Everything per-step runs in ONE HIP kernel launch (csrc/grx_kernels.hip) over all ``num_envs`` worlds.
+The host keeps what the reference keeps on the host at episode boundaries: the PCG64 draws of
+``_reset_sim`` / ``_sample_goal`` (fetch_env.py:153-166,375-402) so that ``reset(seed=s)`` gives world
+``i`` exactly the start state and goal the reference produces for ``seed = s + i``.
+"""
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..core import GoalVecEnv, np_random
+from ..mjcf import CompiledModel, compile_mjcf, load_model
+from ..spaces import Box, Dict, batch_space
+from .fetch_spec import DISTANCE_THRESHOLD, FETCH_TASKS, MAX_EPISODE_STEPS, N_SUBSTEPS, make_fetch_task, parse_env_id
+
+_MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
+
+
+def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledModel:
+    """Compiled model tables for a Fetch task: compiled from MJCF when an asset tree is given
+    (``assets_root`` or $GRX_ASSETS_ROOT = .../gymnasium_robotics/envs/assets), else the packaged blob."""
+    xml = FETCH_TASKS[task]["xml"]
+    assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
+    if assets_root:
+        return compile_mjcf(os.path.join(assets_root, xml))
+    path = os.path.join(_MODELS_DIR, os.path.splitext(os.path.basename(xml))[0] + ".npz")
+    if not os.path.exists(path):
+        raise OSError(f"File {path} does not exist (no packaged model and no assets_root given)")
+    return load_model(path)
+
+
+class FetchVecEnv(GoalVecEnv):
+    """``num_envs`` Fetch worlds stepping in lock-step on one GPU.
+
+    autoreset_mode: "next_step" (Gymnasium >= 1.0 default), "same_step" or "disabled".
+    output: "numpy" returns float64 numpy arrays like the reference; "torch" returns the fp32
+            device tensors the kernel wrote (valid until the next step) -- no PCIe traffic.
+    """
+
+    def __init__(self, env_id: str = "FetchPickAndPlace-v4", num_envs: int = 1, device: Optional[str] = None,
+                 max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step",
+                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None,
+                 reward_type: Optional[str] = None, seed_offset: int = 0):
+        task, rt = parse_env_id(env_id)
+        self.env_id, self.task_name, self.reward_type = env_id, task, reward_type or rt
+        self.cfg = FETCH_TASKS[task]
+        self.num_envs = int(num_envs)
+        self.max_episode_steps = max_episode_steps
+        if autoreset_mode not in ("next_step", "same_step", "disabled"):
+            raise ValueError(f"unknown autoreset_mode {autoreset_mode}")
+        self.autoreset_mode, self.output = autoreset_mode, output
+        self.seed_offset = int(seed_offset)
+        if not torch.cuda.is_available():
+            raise RuntimeError("FetchVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
+        self.device = torch.device(device or "cuda:0")
+        self.model = (model or load_fetch_model(task, assets_root)).copy()
+        # reset_mocap_welds (utils/mujoco_utils.py:74-80): eq_data[:7] = [0,0,0,0,0,0,1]
+        eq = self.model.tables["eq_data"]
+        eq[self.model.tables["eq_type"] == 1, :7] = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+        self.task = make_fetch_task(self.model, task, self.reward_type)
+        self.nq, self.nv, self.nmocap = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nmocap")
+        self.obs_dim = int(self.task.obs_dim)
+        self.dt = N_SUBSTEPS * self.model.opt("timestep")
+        self._L = _native.lib()
+        H, I, F = self.model.pack()
+        self._h = ctypes.c_void_p()
+        dev_index = self.device.index or 0
+        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, dev_index,
+                                               ctypes.byref(self._h)))
+        self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
+        self._alloc(self.num_envs)
+        self._env_setup()
+        # spaces (envs/robot_env.py:87-100)
+        self.single_action_space = Box(-1.0, 1.0, (4,), np.float32)
+        self.single_observation_space = Dict(dict(
+            desired_goal=Box(-np.inf, np.inf, (3,), np.float64), achieved_goal=Box(-np.inf, np.inf, (3,), np.float64),
+            observation=Box(-np.inf, np.inf, (self.obs_dim,), np.float64)))
+        self.action_space = batch_space(self.single_action_space, self.num_envs)
+        self.observation_space = batch_space(self.single_observation_space, self.num_envs)
+        self._check_goal_space()
+        self.np_randoms = [np_random(None)[0] for _ in range(self.num_envs)]
+        self._elapsed = np.zeros(self.num_envs, np.int64)
+        self._needs_reset = np.zeros(self.num_envs, bool)
+        self._has_reset = False
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, n):
+        d, f32 = self.device, torch.float32
+        z = lambda *s, dtype=f32: torch.zeros(*s, dtype=dtype, device=d)
+        self.qpos, self.qvel, self.qacc_ws = z(n, self.nq), z(n, self.nv), z(n, self.nv)
+        self.mocap, self.aux, self.goal, self.action = z(n, 7 * self.nmocap), z(n, 8), z(n, 3), z(n, 4)
+        self.obs, self.achieved, self.reward = z(n, self.obs_dim), z(n, 3), z(n)
+        self.success, self.status = z(n, dtype=torch.uint8), z(n, dtype=torch.int32)
+        self.mask = torch.ones(n, dtype=torch.uint8, device=d)
+        self._bufs = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action, self.obs,
+                                     self.achieved, self.reward, self.success, self.status, None)
+        self._bufs_masked = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action,
+                                            self.obs, self.achieved, self.reward, self.success, self.status, self.mask)
+
+    @staticmethod
+    def _make_bufs(*tensors):
+        b = _native.FetchBuffersStruct()
+        for (name, _), t in zip(_native.FetchBuffersStruct._fields_, tensors):
+            setattr(b, name, None if t is None else t.data_ptr())
+        return b
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ construction (fetch_env.py:404-428)
+    def _env_setup(self):
+        T, n, cfg = self.model.tables, self.model.names, self.cfg
+        jq = T["jnt_qposadr"].ravel()
+        q0 = T["qpos0"].astype(np.float64).copy()
+        for name, v in cfg["initial_qpos"].items():
+            v = np.atleast_1d(np.asarray(v, dtype=np.float64))
+            a = int(jq[n["joint"][name]])
+            q0[a: a + len(v)] = v
+        one = FetchVecEnv.__new__(FetchVecEnv)  # 1-world scratch buffers sharing the model
+        one.__dict__.update(device=self.device, nq=self.nq, nv=self.nv, nmocap=self.nmocap, obs_dim=self.obs_dim)
+        one._alloc(1)
+        one.qpos[0] = torch.from_numpy(q0).float()
+        one.mocap[0] = torch.from_numpy(np.concatenate([T["mocap_pos0"].ravel(), T["mocap_quat0"].ravel()])).float()
+        with torch.cuda.device(self.device):
+            _native.check(self._L.grx_fetch_forward(self._h, ctypes.byref(self.task), ctypes.byref(one._bufs), 1, 0, self._stream()))
+            grip0 = one.obs[0, :3].double().cpu().numpy()
+            target = np.array([-0.498, 0.005, -0.431 + cfg["gripper_extra_height"]]) + grip0
+            one.mocap[0] = torch.tensor(list(target) + [1.0, 0.0, 1.0, 0.0])
+            _native.check(self._L.grx_fetch_forward(self._h, ctypes.byref(self.task), ctypes.byref(one._bufs), 1, 10 * N_SUBSTEPS,
+                                                    self._stream()))
+            torch.cuda.synchronize(self.device)
+        if int(one.status[0]) != 0:
+            raise RuntimeError(f"engine reported status {int(one.status[0])} during env setup")
+        self.initial_gripper_xpos = one.obs[0, :3].double().cpu().numpy()
+        self.height_offset = float(one.achieved[0, 2]) if cfg["has_object"] else 0.0
+        self.initial_qpos = one.qpos[0].clone()
+        self.initial_qvel = one.qvel[0].clone()
+        self._mocap0 = torch.from_numpy(np.concatenate([T["mocap_pos0"].ravel(), T["mocap_quat0"].ravel()])).float().to(self.device)
+        self._obj_qadr = int(jq[n["joint"]["object0:joint"]]) if cfg["has_object"] else -1
+
+    # ------------------------------------------------------------------ reset (robot_env.py:154-186)
+    def _sample_reset(self, rng):
+        """PCG64 draw order of _reset_sim + _sample_goal for one world (fetch_env.py:153-166,388-391)."""
+        cfg, g0 = self.cfg, self.initial_gripper_xpos
+        oxy = None
+        if cfg["has_object"]:
+            oxy = g0[:2]
+            while np.linalg.norm(oxy - g0[:2]) < 0.1:
+                oxy = g0[:2] + rng.uniform(-cfg["obj_range"], cfg["obj_range"], size=2)
+        goal = g0[:3] + rng.uniform(-cfg["target_range"], cfg["target_range"], size=3)
+        if cfg["has_object"]:
+            goal = goal + cfg["target_offset"]
+            goal[2] = self.height_offset
+            if cfg["target_in_the_air"] and rng.uniform() < 0.5:
+                goal[2] += rng.uniform(0, 0.45)
+        return oxy, goal
+
+    def _reset_worlds(self, idx: np.ndarray):
+        n = len(idx)
+        if n == 0:
+            return
+        goals = np.zeros((n, 3), np.float32)
+        oxy = np.zeros((n, 2), np.float32)
+        for k, w in enumerate(idx):
+            o, g = self._sample_reset(self.np_randoms[w])
+            goals[k] = g
+            if o is not None:
+                oxy[k] = o
+        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        rows = self.initial_qpos.unsqueeze(0).repeat(n, 1)
+        if self._obj_qadr >= 0:
+            rows[:, self._obj_qadr: self._obj_qadr + 2] = torch.from_numpy(oxy).to(self.device)
+        self.qpos[ti] = rows
+        self.qvel[ti] = self.initial_qvel
+        self.qacc_ws[ti] = 0.0
+        self.mocap[ti] = self._mocap0
+        self.goal[ti] = torch.from_numpy(goals).to(self.device)
+        self.mask.zero_()
+        self.mask[ti] = 1
+        _native.check(self._L.grx_fetch_forward(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs_masked), self.num_envs, 0,
+                                                self._stream()))
+        self._elapsed[idx] = 0
+        self._needs_reset[idx] = False
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
+            self.np_randoms = [np_random(s)[0] for s in seeds]
+        with torch.cuda.device(self.device):
+            self._reset_worlds(np.arange(self.num_envs))
+        self._has_reset = True
+        return self._obs_dict(), {}
+
+    # ------------------------------------------------------------------ step (robot_env.py:114-152)
+    def step(self, actions):
+        if not self._has_reset:
+            raise RuntimeError("Cannot call env.step() before calling env.reset()")
+        if isinstance(actions, torch.Tensor):
+            if tuple(actions.shape) != (self.num_envs, 4):
+                raise ValueError("Action dimension mismatch")
+            self.action.copy_(actions.to(torch.float32), non_blocking=True)
+        else:
+            a = np.asarray(actions, dtype=np.float32)
+            if a.shape != (self.num_envs, 4):
+                raise ValueError("Action dimension mismatch")
+            self.action.copy_(torch.from_numpy(a), non_blocking=True)
+        with torch.cuda.device(self.device):
+            pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
+            if len(pending):
+                self.mask.fill_(1)
+                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs_masked), self.num_envs,
+                                                     self._stream()))
+            else:
+                _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs), self.num_envs,
+                                                     self._stream()))
+            stepped = ~self._needs_reset if len(pending) else np.ones(self.num_envs, bool)
+            self._elapsed[stepped] += 1
+            truncated = np.zeros(self.num_envs, bool)
+            if self.max_episode_steps is not None:
+                truncated = stepped & (self._elapsed >= self.max_episode_steps)
+            terminated = np.zeros(self.num_envs, bool)
+            info = {}
+            if len(pending):  # Gymnasium NEXT_STEP: the reset replaces the step; reward 0, flags False
+                self._reset_worlds(pending)
+                self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
+            if self.autoreset_mode == "same_step" and truncated.any():
+                done = np.nonzero(truncated)[0]
+                info["final_obs"] = self._obs_dict(rows=done)
+                keep_r, keep_s = self.reward.clone(), self.success.clone()
+                self._reset_worlds(done)
+                self.reward.copy_(keep_r)
+                self.success.copy_(keep_s)
+            elif self.autoreset_mode == "next_step":
+                self._needs_reset |= truncated
+        obs = self._obs_dict()
+        if self.output == "torch":
+            info["is_success"] = self.success
+            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), info
+        info["is_success"] = self.success.cpu().numpy().astype(np.float32)
+        info["status"] = self.status.cpu().numpy()
+        r = self.reward.cpu().numpy()
+        return obs, (r if self.reward_type == "sparse" else r.astype(np.float64)), terminated, truncated, info
+
+    def _obs_dict(self, rows=None):
+        if self.output == "torch":
+            sel = (lambda t: t) if rows is None else (lambda t: t[torch.from_numpy(rows).to(self.device)])
+            return {"observation": sel(self.obs), "achieved_goal": sel(self.achieved), "desired_goal": sel(self.goal)}
+        sel = (lambda a: a) if rows is None else (lambda a: a[rows])
+        return {"observation": sel(self.obs.double().cpu().numpy()), "achieved_goal": sel(self.achieved.double().cpu().numpy()),
+                "desired_goal": sel(self.goal.double().cpu().numpy())}
+
+    # ------------------------------------------------------------------ GoalEnv API (fetch_env.py:74-80; core.py:45-114)
+    def compute_reward(self, achieved_goal, desired_goal, info=None):
+        """Batched reward recompute (HER relabelling): any leading batch shape, last dim 3."""
+        as_numpy = not isinstance(achieved_goal, torch.Tensor)
+        ag = torch.as_tensor(np.asarray(achieved_goal, dtype=np.float32) if as_numpy else achieved_goal, dtype=torch.float32, device=self.device).contiguous()
+        dg = torch.as_tensor(np.asarray(desired_goal, dtype=np.float32) if as_numpy else desired_goal, dtype=torch.float32, device=self.device).contiguous()
+        if ag.shape != dg.shape or ag.shape[-1] != 3:
+            raise ValueError("achieved_goal and desired_goal must have the same (..., 3) shape")
+        out = torch.empty(ag.shape[:-1], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._L.grx_fetch_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), DISTANCE_THRESHOLD,
+                                                           int(self.reward_type == "sparse"), out.data_ptr(), self._stream()))
+        if not as_numpy:
+            return out
+        r = out.cpu().numpy()
+        return r if self.reward_type == "sparse" else r.astype(np.float64)
+
+    def compute_terminated(self, achieved_goal, desired_goal, info=None):
+        return np.zeros(np.asarray(achieved_goal).shape[:-1], bool)  # robot_env.py:106-108
+
+    def compute_truncated(self, achieved_goal, desired_goal, info=None):
+        return np.zeros(np.asarray(achieved_goal).shape[:-1], bool)  # robot_env.py:110-112
+
+    # ------------------------------------------------------------------ state access (checkpoint / tests)
+    def get_state(self):
+        return {k: getattr(self, k).clone() for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal")}
+
+    def set_state(self, state):
+        for k, v in state.items():
+            getattr(self, k).copy_(v)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.grx_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,74 @@
+/* grx_capi.h -- C ABI of the MI355X batched-physics library (libgrx_hip.so).
+ *
+ * The reference has no native FFI: its hot path crosses Python -> C only at the
+ * third-party MuJoCo bindings.  Each entry point below names the reference call
+ * site(s) it replaces (paths relative to /root/reference/gymnasium_robotics):
+ *
+ *   grx_model_create ........ mujoco.MjModel.from_xml_path + MjData      envs/robot_env.py:293-294
+ *                              (the MJCF itself is compiled on the host by
+ *                              gymnasium_robotics_amd/mjcf/compiler.py; this uploads the tables)
+ *   grx_model_set_table ..... in-place MjModel edits, e.g. eq_data      utils/mujoco_utils.py:74-80
+ *   grx_fetch_step .......... BaseRobotEnv.step for N worlds            envs/robot_env.py:114-152
+ *                              = _set_action (fetch/fetch_env.py:85-105,305-310)
+ *                              + mujoco.mj_step(nstep=20)                (envs/robot_env.py:341)
+ *                              + _step_callback (fetch/fetch_env.py:295-303)
+ *                              + _get_obs / _is_success / compute_reward (fetch/fetch_env.py:74-80,107-170,312-360)
+ *   grx_fetch_forward ....... mujoco.mj_forward after a reset + _get_obs fetch/fetch_env.py:401, envs/robot_env.py:183
+ *                              (nstep > 0: the raw mj_step settle loop of _env_setup, fetch/fetch_env.py:419-420)
+ *   grx_fetch_compute_reward  GoalEnv.compute_reward on a batch (HER)   fetch/fetch_env.py:74-80, core.py:45-67
+ *
+ * All array arguments are plain device (HBM) pointers; rows are world-major.  `stream` is a
+ * hipStream_t passed as void*.  Every function returns 0 on success, a negative value on error
+ * (message via grx_last_error()).
+ */
+#ifndef GRX_CAPI_H
+#define GRX_CAPI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct grx_model grx_model;
+
+/* mirrors struct GrxFetchTask (csrc/grx_fetch_task.h) */
+typedef struct grx_fetch_task {
+  int has_object, block_gripper, n_substeps, sparse_reward;
+  int grip_body;
+  float grip_relpos[3], grip_relquat[4];
+  int site_grip, site_obj;
+  int jq_rf, jq_lf, jd_rf, jd_lf;
+  int obs_dim, goal_dim;
+  float distance_threshold, dt;
+} grx_fetch_task;
+
+/* mirrors struct GrxFetchBuffers: device pointers, world-major rows */
+typedef struct grx_fetch_buffers {
+  float *qpos, *qvel, *qacc_ws, *mocap; /* [N,nq] [N,nv] [N,nv] [N,7*nmocap] */
+  float* aux;                           /* [N,8]  */
+  const float* goal;                    /* [N,3]  */
+  const float* action;                  /* [N,4]  */
+  float *obs, *achieved;                /* [N,obs_dim] [N,3] */
+  float* reward;                        /* [N]    */
+  unsigned char* success;               /* [N]    */
+  int* status;                          /* [N]  GRX_ST_* bits, 0 = healthy */
+  const unsigned char* mask;            /* [N] or NULL */
+} grx_fetch_buffers;
+
+int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);
+int grx_model_destroy(grx_model* m);
+int grx_model_set_table(grx_model* m, const char* name, const double* data, int n);
+int grx_model_lds_bytes(const grx_model* m);
+int grx_model_dim(const grx_model* m, const char* name);
+
+int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, void* stream);
+int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream);
+int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
+                             float* reward_out, void* stream);
+const char* grx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,169 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through the C ABI of
+libgrx_hip.so via FetchVecEnv; the oracle / golden fixtures are only the checker.
+
+Tolerances (stated by BASELINE.json north_star): obs/reward within 1e-4 of the reference path,
+done/success flags bit-exact.  "Teacher-forced" = every compared step starts from the oracle's
+pre-step state, which is how per-step parity is defined for chaotic contact dynamics (SURVEY.md §7 hard part 2).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+IDS = {"FetchReach": "FetchReach-v4", "FetchPush": "FetchPush-v4", "FetchPickAndPlace": "FetchPickAndPlace-v4"}
+
+
+def _env(task, n, **kw):
+    import torch
+
+    from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
+
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return FetchVecEnv(IDS[task], num_envs=n, device="cuda:0", **kw)
+
+
+def _load_state(env, g, sel):
+    import torch
+
+    dev = env.device
+    for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"):
+        getattr(env, k).copy_(torch.from_numpy(g[k][sel].astype(np.float32)).to(dev))
+
+
+@pytest.mark.parametrize("task", ["FetchReach", "FetchPush", "FetchPickAndPlace"])
+def test_teacher_forced_step_matches_golden(task):
+    g = np.load(os.path.join(GOLDEN, f"fetch_{task}_teacher.npz"))
+    n = g["obs"].shape[0]
+    env = _env(task, n, autoreset_mode="disabled", max_episode_steps=None)
+    env.reset(seed=0)
+    _load_state(env, g, slice(None))
+    obs, r, term, trunc, info = env.step(g["action"])
+    assert int(np.abs(info["status"]).max()) == 0
+    err = np.abs(obs["observation"] - g["obs"]).max(axis=1)
+    assert err.max() < TOL, f"worst snapshot {err.argmax()} err {err.max():.3e} (nefc {g['nefc'][err.argmax()]})"
+    assert np.abs(obs["achieved_goal"] - g["achieved"]).max() < TOL
+    # flags / sparse reward: bit-exact except where the fp64 distance sits within 1e-6 of the threshold
+    d = np.linalg.norm(g["achieved"] - g["goal"], axis=-1)
+    safe = np.abs(d - 0.05) > 1e-6
+    assert np.array_equal(r[safe], g["reward"][safe].astype(np.float32))
+    assert np.array_equal(info["is_success"][safe], g["success"][safe].astype(np.float32))
+    assert not term.any() and not trunc.any()
+    # post-step state
+    assert np.abs(env.qpos.cpu().numpy() - g["qpos_next"]).max() < TOL
+
+
+@pytest.mark.parametrize("task", ["FetchReach", "FetchPush", "FetchPickAndPlace"])
+def test_reset_matches_golden(task):
+    """reset(seed=s) gives world i the start state + goal of the reference's reset(seed=s+i) (PCG64 draw order)."""
+    g = np.load(os.path.join(GOLDEN, f"fetch_{task}_teacher.npz"))
+    n = len(g["reset_seed"])
+    env = _env(task, n)
+    obs, info = env.reset(seed=int(g["reset_seed"][0]))
+    assert np.abs(env.initial_gripper_xpos - g["initial_gripper_xpos"]).max() < 2e-5
+    assert np.abs(obs["desired_goal"] - g["reset_goal"]).max() < 2e-5
+    assert np.abs(obs["observation"] - g["reset_obs"]).max() < TOL
+    assert np.abs(env.qpos.cpu().numpy() - g["reset_qpos"]).max() < TOL
+
+
+def test_live_oracle_free_running_reach():
+    """Contact-free task: a whole free-running episode stays within tolerance of the fp64 oracle."""
+    from oracle.fetch_oracle import OracleFetchEnv
+
+    env = _env("FetchReach", 2)
+    obs, _ = env.reset(seed=3)
+    orc = OracleFetchEnv(env.model, "FetchReach")
+    o, _ = orc.reset(seed=3)
+    rng = np.random.default_rng(5)
+    worst = np.abs(obs["observation"][0] - o["observation"]).max()
+    for _ in range(50):
+        a = rng.uniform(-1, 1, (2, 4)).astype(np.float32)
+        obs, r, _, _, info = env.step(a)
+        o, ro, _, _, io = orc.step(a[0].astype(np.float64))
+        worst = max(worst, np.abs(obs["observation"][0] - o["observation"]).max())
+    assert worst < TOL, worst
+
+
+def test_determinism_rollout_bit_identical():
+    """tests/test_envs.py:62-117 of the reference: same seed + same actions => identical outputs."""
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (20, 64, 4)).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        env = _env("FetchPickAndPlace", 64)
+        obs, _ = env.reset(seed=0)
+        traj = [obs["observation"].copy()]
+        for a in acts:
+            obs, r, te, tr, info = env.step(a)
+            traj += [obs["observation"].copy(), r.copy(), info["is_success"].copy()]
+        outs.append(traj)
+        env.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+
+
+def test_reward_invariant_and_her_recompute():
+    """core.py:59-62: reward == compute_reward(achieved_goal, desired_goal, info), bit-exactly, and
+    compute_reward accepts arbitrary leading batch dims (HER relabelling)."""
+    for env_id in ("FetchPickAndPlace-v4", "FetchPickAndPlaceDense-v4"):
+        from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
+
+        env = FetchVecEnv(env_id, num_envs=128, device="cuda:0")
+        obs, _ = env.reset(seed=1)
+        rng = np.random.default_rng(2)
+        ags, dgs, rs = [], [], []
+        for _ in range(5):
+            obs, r, _, _, info = env.step(rng.uniform(-1, 1, (128, 4)).astype(np.float32))
+            ags.append(obs["achieved_goal"]); dgs.append(obs["desired_goal"]); rs.append(r)
+        ag, dg, rr = np.stack(ags), np.stack(dgs), np.stack(rs)
+        rc = env.compute_reward(ag, dg, {})
+        assert rc.shape == (5, 128) and rc.dtype == rr.dtype
+        assert np.array_equal(rc, rr)
+        # relabel with shuffled goals against a numpy restatement of fetch_env.py:74-80
+        perm = rng.permutation(128)
+        rl = env.compute_reward(ag, dg[:, perm], {})
+        d = np.linalg.norm(ag.astype(np.float32) - dg[:, perm].astype(np.float32), axis=-1)
+        ref = -(d > 0.05).astype(np.float32) if env.reward_type == "sparse" else -d
+        safe = np.abs(d - 0.05) > 1e-6
+        assert np.allclose(rl[safe], ref[safe], atol=1e-6)
+
+
+def test_time_limit_and_autoreset_next_step():
+    env = _env("FetchReach", 4, max_episode_steps=5)
+    env.reset(seed=0)
+    a = np.zeros((4, 4), np.float32)
+    for t in range(5):
+        obs, r, term, trunc, info = env.step(a)
+        assert not term.any()
+        assert trunc.all() == (t == 4)
+    goal_before = obs["desired_goal"].copy()
+    obs, r, term, trunc, info = env.step(a)  # this call resets instead of stepping
+    assert not trunc.any() and (r == 0).all()
+    assert not np.allclose(obs["desired_goal"], goal_before)
+    assert (env._elapsed == 0).all()
+
+
+def test_action_shape_error_and_step_before_reset():
+    env = _env("FetchReach", 2)
+    with pytest.raises(RuntimeError):
+        env.step(np.zeros((2, 4), np.float32))
+    env.reset(seed=0)
+    with pytest.raises(ValueError, match="Action dimension mismatch"):
+        env.step(np.zeros((2, 3), np.float32))
+
+
+def test_large_batch_worlds_independent():
+    """4096 worlds: world i of the big batch == the same world stepped in a batch of 8 (tile-sharding invariant)."""
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (3, 4096, 4)).astype(np.float32)
+    big = _env("FetchPickAndPlace", 4096)
+    big.reset(seed=100)
+    small = _env("FetchPickAndPlace", 8, seed_offset=1000)
+    small.reset(seed=100)
+    for a in acts:
+        ob, rb, _, _, ib = big.step(a)
+        os_, rs, _, _, is_ = small.step(a[1000:1008])
+    assert np.array_equal(ob["observation"][1000:1008], os_["observation"])
+    assert int(np.abs(ib["status"]).max()) == 0

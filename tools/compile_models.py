@@ -1,0 +1,23 @@
+"""Compile the reference's MJCF assets into packaged model blobs (gymnasium_robotics_amd/models/*.npz).
+
+Run in a container where the reference tree is mounted (it is not present on the GPU box):
+    python tools/compile_models.py [/root/reference/gymnasium_robotics/envs/assets]
+The blobs contain only numeric tables derived from the MJCF/STL inputs (SURVEY.md §2 row 10:
+"read-only input -- the new framework must parse these (or a pre-compiled blob derived from them)").
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from gymnasium_robotics_amd.mjcf import compile_mjcf, save_model  # noqa: E402
+
+ASSETS = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/gymnasium_robotics/envs/assets"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gymnasium_robotics_amd", "models")
+os.makedirs(OUT, exist_ok=True)
+for xml in ("fetch/reach.xml", "fetch/push.xml", "fetch/pick_and_place.xml"):
+    m = compile_mjcf(os.path.join(ASSETS, xml))
+    # keep hull vertices only for meshes that take part in a supported pair
+    out = os.path.join(OUT, os.path.splitext(os.path.basename(xml))[0] + ".npz")
+    save_model(m, out)
+    print(xml, "->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "unsupported pairs:", m.info["unsupported_pairs"],
+          f"{os.path.getsize(out) / 1024:.0f} KiB")
