@@ -65,6 +65,7 @@ typedef struct orc_sim {
   /* diagnostics */
   int solver_iter, bad_state, unsupported_hits;
   double solver_gradnorm;
+  double min_activation_gap; /* min over steps/rows of |dist - margin|: how close any unilateral row came to (de)activating */
   int opt_disable_mesh_plane; /* test knob */
 } orc_sim;
 
@@ -164,6 +165,7 @@ void orc_reset_data(orc_sim* s) {
   memcpy(s->mocap_quat, s->m.mocap_quat0, sizeof(double) * 4 * (size_t)s->nmocap);
   s->time = 0;
   s->bad_state = 0;
+  s->min_activation_gap = 1e30;
 }
 
 /* ------------------------------------------------------------------ K1 kinematics */
@@ -688,6 +690,7 @@ static void make_constraint(orc_sim* s) {
   /* contacts (pyramidal cone) */
   for (int c = 0; c < s->ncon; c++) {
     orc_contact* con = &s->con[c];
+    if (fabs(con->dist - con->includemargin) < s->min_activation_gap) s->min_activation_gap = fabs(con->dist - con->includemargin);
     if (con->dist >= con->includemargin) continue;
     int b1 = m->geom_bodyid[con->geom1], b2 = m->geom_bodyid[con->geom2];
     jac_point(s, b1, con->pos, jp1, jr1); jac_point(s, b2, con->pos, jp2, jr2);
@@ -1091,6 +1094,7 @@ double* orc_ptr(orc_sim* s, const char* name) {
   P(efc_R) P(efc_aref) P(efc_force) P(efc_vel) P(efc_diagApprox)
 #undef P
   if (!strcmp(name, "time")) return &s->time;
+  if (!strcmp(name, "min_activation_gap")) return &s->min_activation_gap;
   return NULL;
 }
 /* mutable model table (e.g. eq_data for reset_mocap_welds, mujoco_utils.py:74-80) */

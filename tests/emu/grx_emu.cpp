@@ -8,7 +8,22 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
+#include <math.h>
+#include <stdint.h>
+
+#ifdef GRX_EMU_FP64  // diagnostic build: the same kernel source in double precision (isolates fp32 rounding from logic)
+#define float double
+#define sqrtf sqrt
+#define fabsf fabs
+#define fminf fmin
+#define fmaxf fmax
+#define sincosf sincos
+#define atan2f atan2
+#define powf pow
+#define fmaf fma
+#endif
 
 #include "../../gymnasium_robotics_amd/csrc/grx_fetch_task.h"
 #include "../../gymnasium_robotics_amd/csrc/grx_host_model.h"

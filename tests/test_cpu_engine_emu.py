@@ -1,0 +1,57 @@
+"""CPU tests of the DEVICE ENGINE SOURCE through the sequential lane emulator (tests/emu), checked against
+the fp64 oracle's golden fixtures.  These validate the kernel logic (not the HIP build) without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def emu_factory(fetch_models):
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd.envs.fetch_spec import make_fetch_task
+
+    def make(task):
+        m = fetch_models[task].copy()
+        m.tables["eq_data"][:, :7] = [0, 0, 0, 0, 0, 0, 1]  # reset_mocap_welds
+        return EmuSim(m, make_fetch_task(m, task))
+
+    return make
+
+
+@pytest.mark.parametrize("task,stride", [("FetchReach", 4), ("FetchPush", 3), ("FetchPickAndPlace", 3)])
+def test_emulated_kernel_step_matches_golden(emu_factory, task, stride):
+    g = np.load(os.path.join(GOLDEN, f"fetch_{task}_teacher.npz"))
+    emu = emu_factory(task)
+    worst = 0.0
+    for i in range(0, g["obs"].shape[0], stride):
+        for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux"):
+            getattr(emu, k)[:] = g[k][i]
+        emu.step(g["action"][i])
+        assert emu.status.value == 0
+        err = np.abs(emu.obs - g["obs"][i]).max()
+        if g["activation_gap"][i] >= 1e-6:
+            worst = max(worst, err)
+            assert err < 1e-4, (i, err)
+        else:
+            assert err < 5e-3, (i, err)
+    assert worst > 0
+
+
+def test_emulated_reset_forward_matches_golden(emu_factory):
+    g = np.load(os.path.join(GOLDEN, "fetch_FetchPickAndPlace_teacher.npz"))
+    emu = emu_factory("FetchPickAndPlace")
+    for i in range(len(g["reset_seed"])):
+        emu.qpos[:] = g["reset_qpos"][i]
+        emu.qvel[:] = 0  # overwritten below with the settle velocities
+        # the golden reset obs were produced with qvel = initial_qvel; recover it from a step fixture of the same episode
+        first = np.nonzero((g["seed"] == g["reset_seed"][i]) & (g["t"] == 0))[0][0]
+        emu.qvel[:] = g["qvel"][first]
+        emu.qacc_ws[:] = 0
+        emu.mocap[:] = [0, 0, 0, 1, 0, 0, 0]
+        emu.forward(0)
+        assert np.abs(emu.obs - g["reset_obs"][i]).max() < 1e-5
+        assert np.abs(emu.aux[:7] - g["aux"][first][:7]).max() < 1e-5

@@ -24,7 +24,7 @@ def snapshots(task, episodes, bias_down):
     env = OracleFetchEnv(model, task)
     rng = np.random.default_rng(1234)
     rec = {k: [] for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success",
-                           "qpos_next", "qvel_next", "ncon", "nefc", "seed", "t")}
+                           "qpos_next", "qvel_next", "ncon", "nefc", "seed", "t", "activation_gap")}
     resets = {k: [] for k in ("seed", "obs", "achieved", "goal", "qpos")}
     for ep in range(episodes):
         obs, _ = env.reset(seed=ep)
@@ -39,7 +39,9 @@ def snapshots(task, episodes, bias_down):
             rec["qpos"].append(s.qpos.copy()); rec["qvel"].append(s.qvel.copy()); rec["qacc_ws"].append(s.qacc_warmstart.copy())
             rec["mocap"].append(np.concatenate([s.mocap_pos, s.mocap_quat])); rec["aux"].append(np.concatenate([p, q, [0.0]]))
             rec["goal"].append(env.goal.copy()); rec["action"].append(a)
+            s.min_activation_gap[0] = 1e30
             obs, r, _, _, info = env.step(a.astype(np.float64))
+            rec["activation_gap"].append(float(s.min_activation_gap[0]))
             rec["obs"].append(obs["observation"]); rec["achieved"].append(obs["achieved_goal"]); rec["reward"].append(r)
             rec["success"].append(info["is_success"]); rec["qpos_next"].append(s.qpos.copy()); rec["qvel_next"].append(s.qvel.copy())
             rec["ncon"].append(s.ncon); rec["nefc"].append(s.nefc); rec["seed"].append(ep); rec["t"].append(t)
