@@ -37,12 +37,24 @@ static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; ret
 #define GRX_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #endif
 
+// optional per-stage cycle accounting (tools/profile_stages.py builds a -DGRX_PROFILE variant; empty otherwise)
+#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+#define GRX_NPROF 16
+#define GRX_TICK(c, id) do { if (lane_ == 0) { long long t_ = clock64(); (c)->prof[id] += t_ - (c)->prof_last[0]; (c)->prof_last[0] = t_; } } while (0)
+#else
+#define GRX_TICK(c, id) ((void)0)
+#endif
+enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX_P_MSOLVE, GRX_P_NEVAL, GRX_P_NGRAD, GRX_P_NHESS, GRX_P_NFACTOR,
+       GRX_P_NLS, GRX_P_NFINAL, GRX_P_EULER, GRX_P_OTHER };
+
 #define GRX_MINVAL 1e-15f
 #define GRX_MINIMP 0.0001f
 #define GRX_MAXIMP 0.9999f
 #define GRX_MAXCON 40
 #define GRX_MAXEFC 160
 #define GRX_NEWTON_MAXIT 8
+#define GRX_NEWTON_RTOL 1e-5f
+#define GRX_NEWTON_ATOL 1e-5f
 #define GRX_LS_MAXIT 12
 
 // status bits reported per world
@@ -88,6 +100,9 @@ struct GrxCtx {
   float* red;  // 128 floats
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
+#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+  long long* prof; long long* prof_last;
+#endif
 };
 
 // LDS footprint in 4-byte words for a model with the given dims
@@ -209,6 +224,16 @@ GRX_DEV float grx_wave_sum(const float* red, int lane_) { (void)lane_; float s =
 GRX_DEV float grx_wave_sum(const float* red, int lane_) {
   float v = red[lane_];
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#endif
+
+#if defined(GRX_EMU)
+GRX_DEV float grx_wave_max(const float* red, int lane_) { (void)lane_; float s = red[0]; for (int i = 1; i < 64; i++) s = fmaxf(s, red[i]); return s; }
+#else
+GRX_DEV float grx_wave_max(const float* red, int lane_) {
+  float v = red[lane_];
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
 #endif
@@ -972,7 +997,7 @@ GRX_DEV float grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int 
       float s = 0;
       for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * a[j];
       c->Ma[i] = s;
-      part += 0.5f * (s - c->qfrc_smooth[i]) * (a[i] - c->qacc_smooth[i]);
+      part += 0.5f * s * a[i] - c->qfrc_smooth[i] * a[i];
     }
     for (int r = lane; r < nefc; r += 64) {
       float s = 0;
@@ -1023,18 +1048,24 @@ GRX_DEV void grx_solve(const GrxModel* m, GrxCtx* c, int lane_) {
   const int nv = m->nv;
   int nefc = c->cnt[1];
   if (nefc == 0) {
+    FOR_LANES { for (int i = lane; i < nv * nv; i += 64) c->A[i] = c->M[i]; }
+    WAVE_SYNC();
+    if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+    grx_sym_solve(c->A, nv, c->qacc_smooth, lane_);
     FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qacc[i] = c->qacc_smooth[i]; c->qfrc_constraint[i] = 0; } }
     WAVE_SYNC();
     return;
   }
-  // warm start: keep whichever of (previous qacc, unconstrained qacc) has the lower cost
-  float cw = grx_newton_eval(m, c, c->qacc_ws, nefc, 1, lane_);
-  float cs = grx_newton_eval(m, c, c->qacc_smooth, nefc, 1, lane_);
-  FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc[i] = (cw < cs) ? c->qacc_ws[i] : c->qacc_smooth[i]; }
+  // Start from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart, M^-1 qfrc_smooth);
+  // the minimiser of the strictly convex problem does not depend on the start, and skipping the comparison saves one
+  // factorisation of M per substep (qacc_smooth is only formed when there are no constraint rows at all).
+  FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc[i] = c->qacc_ws[i]; }
   WAVE_SYNC();
   float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+  GRX_TICK(c, GRX_P_NEVAL);
   for (int it = 0; it < GRX_NEWTON_MAXIT; it++) {
     grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
+    GRX_TICK(c, GRX_P_NEVAL);
     // gradient = M a - qfrc_smooth - J' f
     FOR_LANES {
       float part = 0;
@@ -1048,21 +1079,43 @@ GRX_DEV void grx_solve(const GrxModel* m, GrxCtx* c, int lane_) {
     WAVE_SYNC();
     float gn = sqrtf(grx_wave_sum(c->red, lane_));
     WAVE_SYNC();
-    if (scale * gn < 1e-7f) break;
-    // Hessian H = M + J' diag(D_active) J
+    GRX_TICK(c, GRX_P_NGRAD);
+    if (scale * gn < 1e-8f) break;
+    // Hessian H = M + J' diag(D_active) J.  Lanes form an 8x8 grid; lane (li,lj) owns the entries
+    // {li, li+8, li+16, ..} x {lj, lj+8, ..} of the lower triangle, so each row costs 2*ceil(nv/8) LDS reads
+    // per lane and the loop over rows has no branches (inactive rows carry D = 0 in efc_jv, reused as scratch).
+    FOR_LANES { for (int r = lane; r < nefc; r += 64) c->efc_jv[r] = c->efc_quad[r] ? c->efc_D[r] : 0.0f; }
+    WAVE_SYNC();
     FOR_LANES {
-      int li = lane >> 3, lj = lane & 7;
-      for (int i = li; i < nv; i += 8)
-        for (int j = lj; j <= i; j += 8) {
-          float s = c->M[i * nv + j];
-          for (int r = 0; r < nefc; r++)
-            if (c->efc_quad[r]) s += c->efc_D[r] * c->J[r * nv + i] * c->J[r * nv + j];
-          c->A[i * nv + j] = s; c->A[j * nv + i] = s;
+      const int li = lane >> 3, lj = lane & 7;
+      for (int i0 = li; i0 < nv; i0 += 24)
+        for (int j0 = lj; j0 < nv && j0 <= i0 + 16; j0 += 24) {
+          // 3x3 register tile: rows i0, i0+8, i0+16 ; cols j0, j0+8, j0+16
+          float acc[3][3];
+          for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) acc[a][b] = 0.0f;
+          const int i1 = i0 + 8, i2 = i0 + 16, j1 = j0 + 8, j2 = j0 + 16;
+          const int vi1 = i1 < nv, vi2 = i2 < nv, vj1 = j1 < nv, vj2 = j2 < nv;
+          for (int r = 0; r < nefc; r++) {
+            const float* Jr = c->J + r * nv;
+            float d = c->efc_jv[r];
+            float a0 = Jr[i0] * d, a1 = vi1 ? Jr[i1] * d : 0.0f, a2 = vi2 ? Jr[i2] * d : 0.0f;
+            float b0 = Jr[j0], b1 = vj1 ? Jr[j1] : 0.0f, b2 = vj2 ? Jr[j2] : 0.0f;
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2;
+            acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2;
+            acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2;
+          }
+          for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+              int i = i0 + 8 * a, j = j0 + 8 * b;
+              if (i < nv && j < nv && j <= i) { float v = c->M[i * nv + j] + acc[a][b]; c->A[i * nv + j] = v; c->A[j * nv + i] = v; }
+            }
         }
     }
     WAVE_SYNC();
+    GRX_TICK(c, GRX_P_NHESS);
     if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
     grx_sym_solve(c->A, nv, c->search, lane_);
+    GRX_TICK(c, GRX_P_NFACTOR);
     // Mv, Jv, quadratic coefficients of the Gauss term along the direction
     FOR_LANES {
       float p1 = 0, p2 = 0;
@@ -1098,8 +1151,19 @@ GRX_DEV void grx_solve(const GrxModel* m, GrxCtx* c, int lane_) {
       alpha = na;
       grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
     }
-    FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc[i] += alpha * c->search[i]; }
+    FOR_LANES {
+      float ms = 0, ma = 0;
+      for (int i = lane; i < nv; i += 64) { float d = alpha * c->search[i]; float q = c->qacc[i] + d; c->qacc[i] = q; ms = fmaxf(ms, fabsf(d)); ma = fmaxf(ma, fabsf(q)); }
+      c->red[lane] = ms; c->red[64 + lane] = ma;
+    }
     WAVE_SYNC();
+    float stepmax = grx_wave_max(c->red, lane_), qmax = grx_wave_max(c->red + 64, lane_);
+    WAVE_SYNC();
+    LANE0 { c->cnt[6] += 1; }
+    GRX_TICK(c, GRX_P_NLS);
+    // converged when the accepted step is below the resolution we can hold in fp32 (quadratic convergence: the
+    // step just applied is ~ the error BEFORE it, the error after it is far smaller)
+    if (stepmax <= GRX_NEWTON_RTOL * qmax + GRX_NEWTON_ATOL) break;
   }
   grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
   FOR_LANES {
@@ -1117,16 +1181,18 @@ GRX_DEV void grx_solve(const GrxModel* m, GrxCtx* c, int lane_) {
 // ------------------------------------------------------------------------------------------
 GRX_DEV void grx_forward(const GrxModel* m, GrxCtx* c, int lane_) {
   const int nv = m->nv;
+  GRX_TICK(c, GRX_P_OTHER);
   grx_kinematics(m, c, lane_);
+  GRX_TICK(c, GRX_P_KIN);
   grx_inertia_cdof(m, c, lane_);
+  GRX_TICK(c, GRX_P_INERTIA);
   grx_collision(m, c, lane_);
+  GRX_TICK(c, GRX_P_COLLIDE);
   grx_make_constraint(m, c, lane_);
+  GRX_TICK(c, GRX_P_CONSTR);
   grx_velocity(m, c, lane_);
-  // qacc_smooth = M^-1 qfrc_smooth
-  FOR_LANES { for (int i = lane; i < nv * nv; i += 64) c->A[i] = c->M[i]; }
-  WAVE_SYNC();
-  if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
-  grx_sym_solve(c->A, nv, c->qacc_smooth, lane_);
+  GRX_TICK(c, GRX_P_VEL);
+  GRX_TICK(c, GRX_P_MSOLVE);
   grx_solve(m, c, lane_);
   FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc_ws[i] = c->qacc[i]; }
   WAVE_SYNC();
@@ -1181,5 +1247,7 @@ GRX_DEV void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {
 // one mj_step
 GRX_DEV void grx_step1(const GrxModel* m, GrxCtx* c, int lane_) {
   grx_forward(m, c, lane_);
+  GRX_TICK(c, GRX_P_NFINAL);
   grx_euler(m, c, lane_);
+  GRX_TICK(c, GRX_P_EULER);
 }

@@ -47,6 +47,12 @@ __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetc
   }
 }
 
+#ifdef GRX_PROFILE
+__device__ long long g_grx_prof[GRX_NPROF];
+extern "C" int grx_profile_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grx_prof), sizeof(long long) * GRX_NPROF); }
+extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grx_prof), z, sizeof(z)); }
+#endif
+
 extern "C" __global__ void __launch_bounds__(64)
 grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
@@ -55,6 +61,11 @@ grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_world
   if (b.mask && !b.mask[w]) return;
   GrxCtx c;
   grx_ctx_carve(&c, lds, &m);
+#ifdef GRX_PROFILE
+  __shared__ long long prof_s[GRX_NPROF + 1];
+  c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
+  if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
+#endif
   grx_load_world(m, b, c, w, lds, words, lane_);
   float* aux = b.aux + (size_t)w * 8;
   float aux_in[8];
@@ -62,6 +73,10 @@ grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_world
   grx_fetch_step_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, aux, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, w, lane_);
+#ifdef GRX_PROFILE
+  GRX_TICK(&c, GRX_P_OTHER);
+  if (lane_ == 0 && w == n_worlds / 2) for (int k = 0; k < GRX_NPROF; k++) g_grx_prof[k] = c.prof[k];
+#endif
 }
 
 // reset path: (optional raw settle steps) + mj_forward + outputs
@@ -73,6 +88,10 @@ grx_fetch_forward_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_wo
   if (b.mask && !b.mask[w]) return;
   GrxCtx c;
   grx_ctx_carve(&c, lds, &m);
+#ifdef GRX_PROFILE
+  __shared__ long long prof_s[GRX_NPROF + 1];
+  c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
+#endif
   grx_load_world(m, b, c, w, lds, words, lane_);
   for (int s = 0; s < nstep; s++) grx_step1(&m, &c, lane_);
   if (nstep == 0) grx_forward(&m, &c, lane_);

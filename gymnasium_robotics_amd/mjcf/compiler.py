@@ -998,17 +998,7 @@ class _Lowering:
             geom_invw[gi] = body_invweight0[i]
             s = g.size
             if g.type == GEOM_MESH:
-                if g.mesh not in mesh_cache:
-                    hv, adj = c._load_mesh_hull(g.mesh)
-                    adr = len(mesh_vert)
-                    for v, a in zip(hv, adj):
-                        mesh_vert.append(v)
-                        mesh_adjadr.append(len(mesh_adj))
-                        mesh_adjnum.append(len(a))
-                        mesh_adj.extend(a)
-                    mesh_cache[g.mesh] = (adr, len(hv))
-                geom_meshadr[gi], geom_meshnum[gi] = mesh_cache[g.mesh]
-                hv = np.array(mesh_vert[geom_meshadr[gi]: geom_meshadr[gi] + geom_meshnum[gi]])
+                hv, _ = c._load_mesh_hull(g.mesh)
                 geom_rbound[gi] = np.linalg.norm(hv, axis=1).max()
             elif g.type == GEOM_SPHERE:
                 geom_rbound[gi] = s[0]
@@ -1098,6 +1088,49 @@ class _Lowering:
             pair_friction[pi] = [fr[0], fr[0], fr[1], fr[2], fr[2]]
             pair_margin[pi] = max(ga.margin, gb.margin)
             pair_gap[pi] = max(ga.gap, gb.gap)
+
+        # ---- hull vertex tables.  A mesh whose body can only translate (slide joints all the way up) keeps a constant
+        # orientation, so against a static plane the deepest hull vertex and its hull neighbours are known at compile
+        # time: keep only those (the plane-mesh routine uses exactly "deepest vertex + its hull neighbours within margin").
+        def only_slides(i):
+            while i > 0:
+                if any(j.type != JNT_SLIDE for j in B[i].joints):
+                    return False
+                i = B[i].parent
+            return True
+
+        for gi, (i, g) in enumerate(geoms):
+            if g.type != GEOM_MESH:
+                continue
+            my_pairs = [(A_, B_, ga, gb) for (A_, B_, ga, gb) in pairs if gi in (A_, B_)]
+            sup = [pr for pr in my_pairs if (pr[2].type, pr[3].type) in supported]
+            if not sup:
+                continue  # no implemented narrow phase touches this mesh: no vertices needed on the device
+            hv, adj = c._load_mesh_hull(g.mesh)
+            keep_v = None
+            planes_static = all(pr[2].type == GEOM_PLANE and weld[geoms[pr[0]][0]] == 0 for pr in sup)
+            if planes_static and only_slides(i):
+                Rg = xmat[i] @ mu.quat2mat(g.quat)
+                keep_set = set()
+                for pr in sup:
+                    pi_, pg = geoms[pr[0]]
+                    n_w = (xmat[pi_] @ mu.quat2mat(pg.quat))[:, 2]
+                    h = (hv @ Rg.T) @ n_w
+                    vstar = int(np.argmin(h))
+                    keep_set |= {vstar} | set(adj[vstar])
+                keep_v = sorted(keep_set)
+            if keep_v is not None:
+                remap = {v: k for k, v in enumerate(keep_v)}
+                hv2 = hv[keep_v]
+                adj2 = [[remap[w] for w in adj[v] if w in remap] for v in keep_v]
+            else:
+                hv2, adj2 = hv, adj
+            geom_meshadr[gi], geom_meshnum[gi] = len(mesh_vert), len(hv2)
+            for v, a_ in zip(hv2, adj2):
+                mesh_vert.append(v)
+                mesh_adjadr.append(len(mesh_adj))
+                mesh_adjnum.append(len(a_))
+                mesh_adj.extend(a_)
 
         # ---- equality constraints
         eqs = []

@@ -1,0 +1,38 @@
+"""Per-stage cycle breakdown of grx_fetch_step_kernel (needs a GPU).  Builds/loads the -DGRX_PROFILE variant of the
+HIP library, runs a few steps and prints shader-clock cycles per stage for one representative world.
+    python tools/profile_stages.py [n_worlds]
+"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from gymnasium_robotics_amd import _native
+prof_so = os.path.join(ROOT, "gymnasium_robotics_amd", "_lib", "libgrx_hip_prof.so")
+if not os.path.exists(prof_so):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DGRX_PROFILE", "-o", prof_so,
+                           os.path.join(ROOT, "gymnasium_robotics_amd", "csrc", "grx_kernels.hip")])
+_native.LIB_PATH = prof_so
+from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+env = FetchVecEnv("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
+env.reset(seed=0)
+L = _native.lib()
+names = ["kinematics", "inertia_cdof_crb_M", "collision", "make_constraint", "velocity_rne", "M_factor_solve", "newton_eval", "newton_grad",
+         "newton_hessian", "newton_factor_solve", "newton_linesearch", "newton_final", "euler", "other"]
+g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+tot = np.zeros(16)
+K = 10
+for k in range(K):
+    a = torch.rand(n, 4, device="cuda:0", generator=g) * 2 - 1
+    a[:, 2] = -a[:, 2].abs()  # push towards the table so that contacts are active
+    env.step(a)
+    torch.cuda.synchronize()
+    out = (ctypes.c_longlong * 16)()
+    L.grx_profile_read(out)
+    if k >= 2:
+        tot += np.array(list(out), dtype=np.float64)
+tot /= (K - 2)
+s = tot.sum()
+print(f"cycles per env.step (20 substeps) of world {n//2}: {s:.0f}  (= {s/20:.0f} per substep)")
+for nm, v in zip(names, tot):
+    print(f"  {nm:22s} {v:12.0f}  {100*v/s:5.1f}%")
