@@ -456,6 +456,57 @@ GRX_DEV void grx_sym_solve(const float* A, int n, float* x, int lane_) {
   }
 }
 
+// A x = b in one call.  On the GPU, for the dof counts of the models in scope, the whole system is held in
+// registers: lane j owns column j of A (lane nv owns b), the pivot column is broadcast with v_readlane and the
+// elimination runs from the last dof to the first exactly like grx_sym_factor -- no LDS round trips, no barriers.
+#if !defined(GRX_EMU)
+// v_readlane_b32 moves raw bits: the builtin is typed (int,int), so floats go through a bit cast
+__device__ __forceinline__ float grx_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+template <int NV>
+__device__ __forceinline__ void grx_sym_solve_reg(const float* A, float* x, int lane_) {
+  float a[NV];
+  const int col = lane_ < NV ? lane_ : NV;
+#pragma unroll
+  for (int i = 0; i < NV; i++) a[i] = (lane_ < NV) ? A[col * NV + i] : ((lane_ == NV) ? x[i] : 0.0f);  // A symmetric: column = row
+#pragma unroll
+  for (int k = NV - 1; k > 0; k--) {
+    const float pinv = 1.0f / grx_readlane_f(a[k], k);
+#pragma unroll
+    for (int i = 0; i < k; i++) {
+      const float mi = grx_readlane_f(a[i], k) * pinv;
+      a[i] = fmaf(-mi, a[k], a[i]);
+    }
+  }
+  // now A is lower triangular (entries above the diagonal eliminated); forward substitution on uniform values
+  float b[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) b[i] = grx_readlane_f(a[i], NV);
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const float xk = b[k] / grx_readlane_f(a[k], k);
+    b[k] = xk;
+#pragma unroll
+    for (int i = k + 1; i < NV; i++) b[i] = fmaf(-grx_readlane_f(a[i], k), xk, b[i]);
+  }
+  __syncthreads();
+  if (lane_ == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) x[i] = b[i];
+  }
+  __syncthreads();
+}
+#endif
+
+GRX_DEV int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
+#if !defined(GRX_EMU)
+  if (n == 21) { grx_sym_solve_reg<21>(A, x, lane_); return 0; }
+  if (n == 15) { grx_sym_solve_reg<15>(A, x, lane_); return 0; }
+#endif
+  int bad = grx_sym_factor(A, n, lane_);
+  grx_sym_solve(A, n, x, lane_);
+  return bad;
+}
+
 // ------------------------------------------------------------------------------------------
 // velocity stage: cvel, cdof_dot, RNE bias (K2/K5), passive (K6), actuation (K7)
 // ------------------------------------------------------------------------------------------
@@ -1044,14 +1095,73 @@ GRX_DEV void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, f
   *d1 = q1 + alpha * q2 + g; *d2 = q2 + h;
 }
 
+// H = M + J' diag(D_active) J  ->  c->A   (efc_jv is used as scratch for the masked D)
+GRX_DEV void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
+  const int nv = m->nv;
+    // Hessian H = M + J' diag(D_active) J
+  FOR_LANES { for (int r = lane; r < nefc; r += 64) c->efc_jv[r] = c->efc_quad[r] ? c->efc_D[r] : 0.0f; }  // efc_jv reused as scratch
+  WAVE_SYNC();
+#if !defined(GRX_EMU)
+  if (nv <= 32) {
+    // matrix cores: H = (D J)' J as a chain of v_mfma_f32_32x32x2_f32 (exact f32, two constraint rows per instruction).
+    // operand maps: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; C: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+    const int idx = lane_ & 31, half = lane_ >> 5;
+    const bool incol = idx < nv;
+    for (int r0 = 0; r0 < nefc; r0 += 2) {
+      const int row = r0 + half;
+      float v = 0.0f, d = 0.0f;
+      if (incol && row < nefc) { v = c->J[row * nv + idx]; d = c->efc_jv[row]; }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v * d, v, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+      if (i < nv && incol) c->A[i * nv + idx] = c->M[i * nv + idx] + acc[e];
+    }
+    __syncthreads();
+  } else
+#endif
+  {
+  FOR_LANES {
+    const int li = lane >> 3, lj = lane & 7;
+    for (int i0 = li; i0 < nv; i0 += 24)
+      for (int j0 = lj; j0 < nv && j0 <= i0 + 16; j0 += 24) {
+        // 3x3 register tile: rows i0, i0+8, i0+16 ; cols j0, j0+8, j0+16
+        float acc[3][3];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) acc[a][b] = 0.0f;
+        const int i1 = i0 + 8, i2 = i0 + 16, j1 = j0 + 8, j2 = j0 + 16;
+        const int vi1 = i1 < nv, vi2 = i2 < nv, vj1 = j1 < nv, vj2 = j2 < nv;
+        for (int r = 0; r < nefc; r++) {
+          const float* Jr = c->J + r * nv;
+          float d = c->efc_jv[r];
+          float a0 = Jr[i0] * d, a1 = vi1 ? Jr[i1] * d : 0.0f, a2 = vi2 ? Jr[i2] * d : 0.0f;
+          float b0 = Jr[j0], b1 = vj1 ? Jr[j1] : 0.0f, b2 = vj2 ? Jr[j2] : 0.0f;
+          acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2;
+          acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2;
+          acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2;
+        }
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) {
+            int i = i0 + 8 * a, j = j0 + 8 * b;
+            if (i < nv && j < nv && j <= i) { float v = c->M[i * nv + j] + acc[a][b]; c->A[i * nv + j] = v; c->A[j * nv + i] = v; }
+          }
+      }
+  }
+  WAVE_SYNC();
+  }
+}
+
 GRX_DEV void grx_solve(const GrxModel* m, GrxCtx* c, int lane_) {
   const int nv = m->nv;
   int nefc = c->cnt[1];
   if (nefc == 0) {
     FOR_LANES { for (int i = lane; i < nv * nv; i += 64) c->A[i] = c->M[i]; }
     WAVE_SYNC();
-    if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
-    grx_sym_solve(c->A, nv, c->qacc_smooth, lane_);
+    if (grx_sym_solve_full(c->A, nv, c->qacc_smooth, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
     FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qacc[i] = c->qacc_smooth[i]; c->qfrc_constraint[i] = 0; } }
     WAVE_SYNC();
     return;
@@ -1081,40 +1191,9 @@ GRX_DEV void grx_solve(const GrxModel* m, GrxCtx* c, int lane_) {
     WAVE_SYNC();
     GRX_TICK(c, GRX_P_NGRAD);
     if (scale * gn < 1e-8f) break;
-    // Hessian H = M + J' diag(D_active) J.  Lanes form an 8x8 grid; lane (li,lj) owns the entries
-    // {li, li+8, li+16, ..} x {lj, lj+8, ..} of the lower triangle, so each row costs 2*ceil(nv/8) LDS reads
-    // per lane and the loop over rows has no branches (inactive rows carry D = 0 in efc_jv, reused as scratch).
-    FOR_LANES { for (int r = lane; r < nefc; r += 64) c->efc_jv[r] = c->efc_quad[r] ? c->efc_D[r] : 0.0f; }
-    WAVE_SYNC();
-    FOR_LANES {
-      const int li = lane >> 3, lj = lane & 7;
-      for (int i0 = li; i0 < nv; i0 += 24)
-        for (int j0 = lj; j0 < nv && j0 <= i0 + 16; j0 += 24) {
-          // 3x3 register tile: rows i0, i0+8, i0+16 ; cols j0, j0+8, j0+16
-          float acc[3][3];
-          for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) acc[a][b] = 0.0f;
-          const int i1 = i0 + 8, i2 = i0 + 16, j1 = j0 + 8, j2 = j0 + 16;
-          const int vi1 = i1 < nv, vi2 = i2 < nv, vj1 = j1 < nv, vj2 = j2 < nv;
-          for (int r = 0; r < nefc; r++) {
-            const float* Jr = c->J + r * nv;
-            float d = c->efc_jv[r];
-            float a0 = Jr[i0] * d, a1 = vi1 ? Jr[i1] * d : 0.0f, a2 = vi2 ? Jr[i2] * d : 0.0f;
-            float b0 = Jr[j0], b1 = vj1 ? Jr[j1] : 0.0f, b2 = vj2 ? Jr[j2] : 0.0f;
-            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2;
-            acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2;
-            acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2;
-          }
-          for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) {
-              int i = i0 + 8 * a, j = j0 + 8 * b;
-              if (i < nv && j < nv && j <= i) { float v = c->M[i * nv + j] + acc[a][b]; c->A[i * nv + j] = v; c->A[j * nv + i] = v; }
-            }
-        }
-    }
-    WAVE_SYNC();
+    grx_hessian(m, c, nefc, lane_);
     GRX_TICK(c, GRX_P_NHESS);
-    if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
-    grx_sym_solve(c->A, nv, c->search, lane_);
+    if (grx_sym_solve_full(c->A, nv, c->search, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
     GRX_TICK(c, GRX_P_NFACTOR);
     // Mv, Jv, quadratic coefficients of the Gauss term along the direction
     FOR_LANES {
@@ -1207,8 +1286,7 @@ GRX_DEV void grx_euler(const GrxModel* m, GrxCtx* c, int lane_) {
       for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qfrc_smooth[i] + c->qfrc_constraint[i];
     }
     WAVE_SYNC();
-    if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
-    grx_sym_solve(c->A, nv, c->tmpv, lane_);
+    if (grx_sym_solve_full(c->A, nv, c->tmpv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
   } else {
     FOR_LANES { for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qacc[i]; }
     WAVE_SYNC();

@@ -109,6 +109,29 @@ grx_fetch_reward_kernel(const float* __restrict__ ag, const float* __restrict__ 
   }
 }
 
+// unit-test hook for the two GPU-specific numerical primitives (register-resident solve, MFMA Hessian)
+extern "C" __global__ void __launch_bounds__(64)
+grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_in, const float* J_in, const float* D_in, float* out) {
+  extern __shared__ float lds[];
+  const int lane_ = threadIdx.x;
+  GrxModel m; m.nv = nv;
+  GrxCtx c;
+  c.A = lds; c.M = c.A + nv * nv; c.J = c.M + nv * nv; c.efc_D = c.J + GRX_MAXEFC * nv; c.efc_jv = c.efc_D + GRX_MAXEFC;
+  c.efc_quad = (int*)(c.efc_jv + GRX_MAXEFC); c.tmpv = (float*)(c.efc_quad + GRX_MAXEFC);
+  for (int i = lane_; i < nv * nv; i += 64) { c.A[i] = A_in[i]; c.M[i] = A_in[i]; }
+  for (int i = lane_; i < nv; i += 64) c.tmpv[i] = b_in[i];
+  for (int i = lane_; i < nefc * nv; i += 64) c.J[i] = J_in[i];
+  for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0; }
+  __syncthreads();
+  if (mode == 0) {
+    grx_sym_solve_full(c.A, nv, c.tmpv, lane_);
+    for (int i = lane_; i < nv; i += 64) out[i] = c.tmpv[i];
+  } else {
+    grx_hessian(&m, &c, nefc, lane_);
+    for (int i = lane_; i < nv * nv; i += 64) out[i] = c.A[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -211,6 +234,14 @@ extern "C" int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task,
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
   hipLaunchKernelGGL(grx_fetch_forward_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->dev, t, b, n_worlds, m->words, nstep);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// test-only entry point (tests/test_gpu_primitives.py); all pointers are device pointers
+extern "C" int grx_debug_primitive(int mode, int nv, int nefc, const float* A, const float* b, const float* J, const float* D, float* out, void* stream) {
+  int bytes = (2 * nv * nv + GRX_MAXEFC * nv + 3 * GRX_MAXEFC + nv + 64) * 4;
+  hipLaunchKernelGGL(grx_debug_kernel, dim3(1), dim3(64), bytes, (hipStream_t)stream, mode, nv, nefc, A, b, J, D, out);
   HIP_OK(hipGetLastError());
   return 0;
 }
