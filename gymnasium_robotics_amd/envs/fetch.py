@@ -42,6 +42,24 @@ def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledMo
     return load_model(path)
 
 
+def sample_fetch_reset(cfg, rng, initial_gripper_xpos, height_offset):
+    """PCG64 draw order of _reset_sim + _sample_goal for one world (fetch_env.py:153-166,388-391).
+    Returns (object_xy or None, goal)."""
+    g0 = np.asarray(initial_gripper_xpos, dtype=np.float64)
+    oxy = None
+    if cfg["has_object"]:
+        oxy = g0[:2]
+        while np.linalg.norm(oxy - g0[:2]) < 0.1:
+            oxy = g0[:2] + rng.uniform(-cfg["obj_range"], cfg["obj_range"], size=2)
+    goal = g0[:3] + rng.uniform(-cfg["target_range"], cfg["target_range"], size=3)
+    if cfg["has_object"]:
+        goal = goal + cfg["target_offset"]
+        goal[2] = height_offset
+        if cfg["target_in_the_air"] and rng.uniform() < 0.5:
+            goal[2] += rng.uniform(0, 0.45)
+    return oxy, goal
+
+
 class FetchVecEnv(GoalVecEnv):
     """``num_envs`` Fetch worlds stepping in lock-step on one GPU.
 
@@ -153,20 +171,7 @@ class FetchVecEnv(GoalVecEnv):
 
     # ------------------------------------------------------------------ reset (robot_env.py:154-186)
     def _sample_reset(self, rng):
-        """PCG64 draw order of _reset_sim + _sample_goal for one world (fetch_env.py:153-166,388-391)."""
-        cfg, g0 = self.cfg, self.initial_gripper_xpos
-        oxy = None
-        if cfg["has_object"]:
-            oxy = g0[:2]
-            while np.linalg.norm(oxy - g0[:2]) < 0.1:
-                oxy = g0[:2] + rng.uniform(-cfg["obj_range"], cfg["obj_range"], size=2)
-        goal = g0[:3] + rng.uniform(-cfg["target_range"], cfg["target_range"], size=3)
-        if cfg["has_object"]:
-            goal = goal + cfg["target_offset"]
-            goal[2] = self.height_offset
-            if cfg["target_in_the_air"] and rng.uniform() < 0.5:
-                goal[2] += rng.uniform(0, 0.45)
-        return oxy, goal
+        return sample_fetch_reset(self.cfg, rng, self.initial_gripper_xpos, self.height_offset)
 
     def _reset_worlds(self, idx: np.ndarray):
         n = len(idx)
