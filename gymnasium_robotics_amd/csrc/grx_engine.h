@@ -22,6 +22,7 @@
 
 #if defined(GRX_EMU)
 #define GRX_DEV static inline
+#define GRX_MEM static inline
 #define GRX_HD static inline
 #define FOR_LANES for (int lane = 0; lane < 64; ++lane)
 #define LANE0 if (1)
@@ -30,6 +31,7 @@
 static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 #else
 #define GRX_DEV __device__ __forceinline__
+#define GRX_MEM static __device__ __forceinline__
 #define GRX_HD __host__ __device__ inline
 #define FOR_LANES for (int lane = lane_, once_ = 1; once_; once_ = 0)
 #define LANE0 if (lane_ == 0)
@@ -74,7 +76,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -92,7 +94,7 @@ struct GrxCtx {
       *Mv, *tmpv;
   // contacts
   float *con_dist, *con_pos, *con_frame;
-  int *con_pair, *con_efc;
+  int *con_pair, *con_efc, *con_nr, *con_b1, *con_b2;
   // constraint rows
   float *J, *efc_pos, *efc_D, *efc_aref, *efc_jar, *efc_jv, *efc_force, *efc_floss;
   int *efc_kind, *efc_id, *efc_sub, *efc_quad;
@@ -115,7 +117,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   w += 12 * nv;
   w += 2 * nv * nv;
   w += 12 * nv;
-  w += GRX_MAXCON * (1 + 3 + 9 + 2);
+  w += GRX_MAXCON * (1 + 3 + 9 + 5);
   w += GRX_MAXEFC * nv + GRX_MAXEFC * (7 + 4);
   w += 128 + 64 + 16;
   return w;
@@ -138,6 +140,9 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
   CARVE(con_dist, GRX_MAXCON) CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 9 * GRX_MAXCON)
   c->con_pair = (int*)p; p += GRX_MAXCON;
   c->con_efc = (int*)p; p += GRX_MAXCON;
+  c->con_nr = (int*)p; p += GRX_MAXCON;
+  c->con_b1 = (int*)p; p += GRX_MAXCON;
+  c->con_b2 = (int*)p; p += GRX_MAXCON;
   CARVE(J, GRX_MAXEFC * m->nv) CARVE(efc_pos, GRX_MAXEFC) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC)
   CARVE(efc_jar, GRX_MAXEFC) CARVE(efc_jv, GRX_MAXEFC) CARVE(efc_force, GRX_MAXEFC) CARVE(efc_floss, GRX_MAXEFC)
   c->efc_kind = (int*)p; p += GRX_MAXEFC;
@@ -216,6 +221,31 @@ GRX_DEV void crossForcef(float* r, const float* v, const float* f) {
   r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
 }
 
+// lane-private values that must survive until a wave-wide reduction: a register on the GPU, a 64-array in the emulator
+#if defined(GRX_EMU)
+#define GRX_LANEVAR(name) float name[64]
+#define LV(name) name[lane]
+static inline float grx_reduce_sum(const float* v) { float s = 0; for (int i = 0; i < 64; i++) s += v[i]; return s; }
+static inline float grx_reduce_max(const float* v) { float s = v[0]; for (int i = 1; i < 64; i++) s = fmaxf(s, v[i]); return s; }
+#else
+#define GRX_LANEVAR(name) float name
+#define LV(name) name
+// cross-lane butterflies on the DPP path (no LDS): xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror, then the four
+// row totals are combined through v_readlane.  Must be called with all 64 lanes active.  Result is wave-uniform.
+__device__ __forceinline__ float grx_dpp_f(float v, const int ctrl_unused) { return v; }
+#define GRX_DPP_MOV(v, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true))
+__device__ __forceinline__ float grx_reduce_sum(float v) {
+  v += GRX_DPP_MOV(v, 0xB1); v += GRX_DPP_MOV(v, 0x4E); v += GRX_DPP_MOV(v, 0x141); v += GRX_DPP_MOV(v, 0x140);
+  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+}
+__device__ __forceinline__ float grx_reduce_max(float v) {
+  v = fmaxf(v, GRX_DPP_MOV(v, 0xB1)); v = fmaxf(v, GRX_DPP_MOV(v, 0x4E)); v = fmaxf(v, GRX_DPP_MOV(v, 0x141)); v = fmaxf(v, GRX_DPP_MOV(v, 0x140));
+  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))),
+               fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48))));
+}
+#endif
+
 // wave-wide sums of per-lane partials staged in red[0..63] (and red[64..127] for the second value).
 // Uniform context.
 #if defined(GRX_EMU)
@@ -238,10 +268,15 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 }
 #endif
 
+// All stages live in a class template so that the dof count can be a compile-time constant (NV > 0: inner loops over
+// dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
+#define GRX_NVC (NV ? NV : m->nv)
+template <int NV>
+struct GrxEngine {
 // ------------------------------------------------------------------------------------------
 // K1 forward kinematics
 // ------------------------------------------------------------------------------------------
-GRX_DEV void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
+GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
   FOR_LANES {
     for (int b = lane; b < m->nbody; b += 64) {
       float* pl = c->ploc + 3 * b; float* ql = c->qloc + 4 * b;
@@ -294,36 +329,40 @@ GRX_DEV void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   WAVE_SYNC();
-  for (int lev = 1; lev <= m->maxdepth; lev++) {
-    int a0 = m->level_adr[lev], a1 = m->level_adr[lev + 1];
-    FOR_LANES {
-      for (int k = a0 + lane; k < a1; k += 64) {
-        int b = m->body_order[k], par = m->body_parent[b];
-        float* xp = c->xpos + 3 * b; float* xq = c->xquat + 4 * b;
-        const float* pl = c->ploc + 3 * b; const float* ql = c->qloc + 4 * b;
-        int isfree = (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == 0);
-        if (m->body_mocapid[b] >= 0 || isfree) {
-          xp[0] = pl[0]; xp[1] = pl[1]; xp[2] = pl[2]; xq[0] = ql[0]; xq[1] = ql[1]; xq[2] = ql[2]; xq[3] = ql[3];
-        } else {
-          float v[3], q[4];
-          mulMatVec3f(v, c->xmat + 9 * par, pl);
-          xp[0] = c->xpos[3 * par] + v[0]; xp[1] = c->xpos[3 * par + 1] + v[1]; xp[2] = c->xpos[3 * par + 2] + v[2];
-          mulQuatf(q, c->xquat + 4 * par, ql); normalize4f(q);
-          xq[0] = q[0]; xq[1] = q[1]; xq[2] = q[2]; xq[3] = q[3];
-          // joint anchors / axes to world frame (they were expressed in the parent frame)
-          int ja = m->body_jntadr[b], jn = m->body_jntnum[b];
-          for (int t = 0; t < jn; t++) {
-            float a[3], x[3];
-            mulMatVec3f(a, c->xmat + 9 * par, c->janchor + 3 * (ja + t));
-            mulMatVec3f(x, c->xmat + 9 * par, c->jaxis + 3 * (ja + t));
-            for (int e = 0; e < 3; e++) { c->janchor[3 * (ja + t) + e] = a[e] + c->xpos[3 * par + e]; c->jaxis[3 * (ja + t) + e] = x[e]; }
-          }
+  // world poses: every body composes its own ancestor chain (parent first) -- redundant flops, but no level-by-level barriers
+  FOR_LANES {
+    for (int b = 1 + lane; b < m->nbody; b += 64) {
+      float p[3] = {c->ploc[3 * b], c->ploc[3 * b + 1], c->ploc[3 * b + 2]};
+      float q[4] = {c->qloc[4 * b], c->qloc[4 * b + 1], c->qloc[4 * b + 2], c->qloc[4 * b + 3]};
+      int isfree = (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == 0);
+      if (!(m->body_mocapid[b] >= 0 || isfree)) {
+        int aa = m->body_ancadr[b], an = m->body_ancnum[b];
+        for (int e = 0; e < an; e++) {
+          int anc = m->body_anc[aa + e];
+          float qa[4] = {c->qloc[4 * anc], c->qloc[4 * anc + 1], c->qloc[4 * anc + 2], c->qloc[4 * anc + 3]}, v[3], qn[4];
+          rotVecQuatf(v, p, qa);
+          p[0] = c->ploc[3 * anc] + v[0]; p[1] = c->ploc[3 * anc + 1] + v[1]; p[2] = c->ploc[3 * anc + 2] + v[2];
+          mulQuatf(qn, qa, q);
+          q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; q[3] = qn[3];
         }
-        float R[9]; quat2matf(R, xq);
-        for (int e = 0; e < 9; e++) c->xmat[9 * b + e] = R[e];
+        normalize4f(q);
       }
+      float R[9]; quat2matf(R, q);
+      for (int e = 0; e < 3; e++) c->xpos[3 * b + e] = p[e];
+      for (int e = 0; e < 4; e++) c->xquat[4 * b + e] = q[e];
+      for (int e = 0; e < 9; e++) c->xmat[9 * b + e] = R[e];
     }
-    WAVE_SYNC();
+  }
+  WAVE_SYNC();
+  FOR_LANES {
+    // joint anchors / axes to the world frame (they were expressed in the parent frame; free joints already are world)
+    for (int j = lane; j < m->njnt; j += 64) {
+      if (m->jnt_type[j] == 0) continue;
+      int par = m->body_parent[m->jnt_bodyid[j]];
+      float a_[3] = {c->janchor[3 * j], c->janchor[3 * j + 1], c->janchor[3 * j + 2]}, x_[3] = {c->jaxis[3 * j], c->jaxis[3 * j + 1], c->jaxis[3 * j + 2]}, ta[3], tx[3];
+      mulMatVec3f(ta, c->xmat + 9 * par, a_); mulMatVec3f(tx, c->xmat + 9 * par, x_);
+      for (int e = 0; e < 3; e++) { c->janchor[3 * j + e] = ta[e] + c->xpos[3 * par + e]; c->jaxis[3 * j + e] = tx[e]; }
+    }
   }
   FOR_LANES {
     for (int g = lane; g < m->ngeom + m->nsite; g += 64) {
@@ -346,7 +385,7 @@ GRX_DEV void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
 // K2/K3 spatial inertias, motion axes, composite inertias, mass matrix
 // reference point of each kinematic tree = xpos of its root body (any point is valid)
 // ------------------------------------------------------------------------------------------
-GRX_DEV void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
+GRX_MEM void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
   FOR_LANES {
     for (int b = 1 + lane; b < m->nbody; b += 64) {
       const float* R = c->xmat + 9 * b; const float* in = m->body_inertia + 6 * b;
@@ -407,7 +446,7 @@ GRX_DEV void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
       float v = 0;
       for (int t = 0; t < 6; t++) v += c->cdof[6 * j + t] * buf[t];
       if (i == j) v += m->dof_armature[i];
-      c->M[i * m->nv + j] = v; c->M[j * m->nv + i] = v;
+      c->M[i * GRX_NVC + j] = v; c->M[j * GRX_NVC + i] = v;
     }
   }
   WAVE_SYNC();
@@ -419,7 +458,7 @@ GRX_DEV void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
 // order MuJoCo's sparse L'DL uses, which keeps the 1e11-damped base dofs out of the pivots of
 // everything else.  x is returned in b.
 // ------------------------------------------------------------------------------------------
-GRX_DEV int grx_sym_factor(float* A, int n, int lane_) {
+GRX_MEM int grx_sym_factor(float* A, int n, int lane_) {
   int bad = 0;
   for (int k = n - 1; k >= 0; k--) {
     float d = A[k * n + k];
@@ -439,7 +478,7 @@ GRX_DEV int grx_sym_factor(float* A, int n, int lane_) {
   return bad;
 }
 // A holds the factor from grx_sym_factor: row k = [t_k0 .. t_k,k-1, 1/d_k]
-GRX_DEV void grx_sym_solve(const float* A, int n, float* x, int lane_) {
+GRX_MEM void grx_sym_solve(const float* A, int n, float* x, int lane_) {
   // L' y = b  (y_i = b_i - sum_{k>i} (t_ki/d_k) y_k)
   for (int k = n - 1; k > 0; k--) {
     float yk = x[k] * A[k * n + k];
@@ -461,15 +500,15 @@ GRX_DEV void grx_sym_solve(const float* A, int n, float* x, int lane_) {
 // elimination runs from the last dof to the first exactly like grx_sym_factor -- no LDS round trips, no barriers.
 #if !defined(GRX_EMU)
 // v_readlane_b32 moves raw bits: the builtin is typed (int,int), so floats go through a bit cast
-__device__ __forceinline__ float grx_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-template <int NV>
-__device__ __forceinline__ void grx_sym_solve_reg(const float* A, float* x, int lane_) {
-  float a[NV];
-  const int col = lane_ < NV ? lane_ : NV;
+static __device__ __forceinline__ float grx_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+template <int NS>
+  static __device__ __forceinline__ void grx_sym_solve_reg(const float* A, float* x, int lane_) {
+  float a[NS];
+  const int col = lane_ < NS ? lane_ : NS;
 #pragma unroll
-  for (int i = 0; i < NV; i++) a[i] = (lane_ < NV) ? A[col * NV + i] : ((lane_ == NV) ? x[i] : 0.0f);  // A symmetric: column = row
+  for (int i = 0; i < NS; i++) a[i] = (lane_ < NS) ? A[col * NS + i] : ((lane_ == NS) ? x[i] : 0.0f);  // A symmetric: column = row
 #pragma unroll
-  for (int k = NV - 1; k > 0; k--) {
+  for (int k = NS - 1; k > 0; k--) {
     const float pinv = 1.0f / grx_readlane_f(a[k], k);
 #pragma unroll
     for (int i = 0; i < k; i++) {
@@ -477,27 +516,27 @@ __device__ __forceinline__ void grx_sym_solve_reg(const float* A, float* x, int 
       a[i] = fmaf(-mi, a[k], a[i]);
     }
   }
-  // now A is lower triangular (entries above the diagonal eliminated); forward substitution on uniform values
-  float b[NV];
+  // now A is lower triangular (entries above the diagonal eliminated).  Forward substitution: the right-hand side lives
+  // in lane NS; x_k is formed from two readlanes and pushed into the remaining rows of that lane only.
+  const float isrhs = (lane_ == NS) ? 1.0f : 0.0f;
 #pragma unroll
-  for (int i = 0; i < NV; i++) b[i] = grx_readlane_f(a[i], NV);
+  for (int k = 0; k < NS; k++) {
+    const float xk = grx_readlane_f(a[k], NS) / grx_readlane_f(a[k], k);
+    a[k] = (lane_ == NS) ? xk : a[k];
+    const float sx = xk * isrhs;
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const float xk = b[k] / grx_readlane_f(a[k], k);
-    b[k] = xk;
-#pragma unroll
-    for (int i = k + 1; i < NV; i++) b[i] = fmaf(-grx_readlane_f(a[i], k), xk, b[i]);
+    for (int i = k + 1; i < NS; i++) a[i] = fmaf(-grx_readlane_f(a[i], k), sx, a[i]);
   }
   __syncthreads();
-  if (lane_ == 0) {
+  if (lane_ == NS) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) x[i] = b[i];
+    for (int i = 0; i < NS; i++) x[i] = a[i];
   }
   __syncthreads();
 }
 #endif
 
-GRX_DEV int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
+GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
 #if !defined(GRX_EMU)
   if (n == 21) { grx_sym_solve_reg<21>(A, x, lane_); return 0; }
   if (n == 15) { grx_sym_solve_reg<15>(A, x, lane_); return 0; }
@@ -510,21 +549,34 @@ GRX_DEV int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
 // ------------------------------------------------------------------------------------------
 // velocity stage: cvel, cdof_dot, RNE bias (K2/K5), passive (K6), actuation (K7)
 // ------------------------------------------------------------------------------------------
-GRX_DEV void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
-  const int nv = m->nv;
+GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
+  const int nv = GRX_NVC;
   // body spatial velocities = sum over the dof chain (parallel, no tree walk)
   FOR_LANES {
     for (int it = lane; it < 6 * m->nbody; it += 64) {
       int b = it / 6, k = it - 6 * b;
+      unsigned mlo = (unsigned)m->dof_chainmask[2 * b], mhi = (unsigned)m->dof_chainmask[2 * b + 1];
       float s = 0;
-      for (int d = m->body_lastdof[b]; d >= 0; d = m->dof_parentid[d]) s += c->cdof[6 * d + k] * c->qvel[d];
+      for (int d = 0; d < nv; d++) { unsigned bit = d < 32 ? (mlo >> d) & 1u : (mhi >> (d - 32)) & 1u; s += bit ? c->cdof[6 * d + k] * c->qvel[d] : 0.0f; }
       c->cvel[it] = s;
     }
     // cdof_dot = crossMotion(velocity just before this dof, cdof)
     for (int d = lane; d < nv; d += 64) {
       float v[6] = {0, 0, 0, 0, 0, 0}, cd[6], r[6];
-      for (int e = m->dof_cvelstart[d]; e >= 0; e = m->dof_parentid[e])
-        for (int k = 0; k < 6; k++) v[k] += c->cdof[6 * e + k] * c->qvel[e];
+      {
+        // dofs contributing to the velocity seen by dof d: the chain ending at dof_cvelstart[d]
+        int e0 = m->dof_cvelstart[d];
+        unsigned long long msk = 0ull;
+        if (e0 >= 0) {
+          int bb = m->dof_bodyid[e0];
+          msk = ((unsigned long long)(unsigned)m->dof_chainmask[2 * bb + 1] << 32) | (unsigned)m->dof_chainmask[2 * bb];
+          msk &= (e0 >= 63) ? ~0ull : ((1ull << (e0 + 1)) - 1ull);  // drop same-body dofs after e0
+        }
+        for (int e = 0; e < nv; e++) {
+          float qd = ((msk >> e) & 1ull) ? c->qvel[e] : 0.0f;
+          for (int k = 0; k < 6; k++) v[k] += c->cdof[6 * e + k] * qd;
+        }
+      }
       for (int k = 0; k < 6; k++) cd[k] = c->cdof[6 * d + k];
       int jt = m->jnt_type[m->dof_jntid[d]];
       if (jt == 0 && d - m->jnt_dofadr[m->dof_jntid[d]] < 3) { for (int k = 0; k < 6; k++) r[k] = 0; }
@@ -545,8 +597,12 @@ GRX_DEV void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
     // accelerations with qacc = 0 and per-body inertial forces
     for (int b = 1 + lane; b < m->nbody; b += 64) {
       float a[6] = {0, 0, 0, -m->gravity[0], -m->gravity[1], -m->gravity[2]}, v[6], Ia[6], Iv[6], t[6];
-      for (int d = m->body_lastdof[b]; d >= 0; d = m->dof_parentid[d])
-        for (int k = 0; k < 6; k++) a[k] += c->cdof_dot[6 * d + k] * c->qvel[d];
+      unsigned mlo = (unsigned)m->dof_chainmask[2 * b], mhi = (unsigned)m->dof_chainmask[2 * b + 1];
+      for (int d = 0; d < nv; d++) {
+        unsigned bit = d < 32 ? (mlo >> d) & 1u : (mhi >> (d - 32)) & 1u;
+        float qd = bit ? c->qvel[d] : 0.0f;
+        for (int k = 0; k < 6; k++) a[k] += c->cdof_dot[6 * d + k] * qd;
+      }
       for (int k = 0; k < 6; k++) v[k] = c->cvel[6 * b + k];
       inertMulf(Ia, c->cinert + 10 * b, a); inertMulf(Iv, c->cinert + 10 * b, v);
       crossForcef(t, v, Iv);
@@ -595,7 +651,7 @@ GRX_DEV void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
 // ------------------------------------------------------------------------------------------
 // K8 collision: static candidate list -> narrow phase
 // ------------------------------------------------------------------------------------------
-GRX_DEV void grx_make_frame(float* f) {
+GRX_MEM void grx_make_frame(float* f) {
   float* x = f; float* y = f + 3; float* z = f + 6;
   if (x[1] < 0.5f && x[1] > -0.5f) { y[0] = 0; y[1] = 1; y[2] = 0; } else { y[0] = 0; y[1] = 0; y[2] = 1; }
   float d = dot3f(x, y); y[0] -= d * x[0]; y[1] -= d * x[1]; y[2] -= d * x[2];
@@ -603,150 +659,195 @@ GRX_DEV void grx_make_frame(float* f) {
   cross3f(z, x, y);
 }
 
-GRX_DEV void grx_add_contact(GrxCtx* c, int pair, const float* pos, const float* normal, float dist) {
+// contact append: slot from an LDS counter; only the normal is stored here, the tangent frame is completed by
+// grx_make_constraint (one lane per contact)
+GRX_MEM void grx_add_contact(GrxCtx* c, int pair, const float* pos, const float* normal, float dist) {
   int slot = GRX_ATOMIC_ADD(&c->cnt[0], 1);
   if (slot >= GRX_MAXCON) { c->cnt[2] |= GRX_ST_CON_OVERFLOW; return; }
-  float f[9] = {normal[0], normal[1], normal[2], 0, 0, 0, 0, 0, 0};
-  grx_make_frame(f);
   c->con_dist[slot] = dist; c->con_pair[slot] = pair;
-  for (int k = 0; k < 3; k++) c->con_pos[3 * slot + k] = pos[k];
-  for (int k = 0; k < 9; k++) c->con_frame[9 * slot + k] = f[k];
+  for (int k = 0; k < 3; k++) { c->con_pos[3 * slot + k] = pos[k]; c->con_frame[9 * slot + k] = normal[k]; }
 }
 
-GRX_DEV void grx_plane_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+GRX_MEM void grx_plane_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
   const float* pp = c->gxpos + 3 * g1; const float* pm = c->gxmat + 9 * g1;
   const float* bp = c->gxpos + 3 * g2; const float* bm = c->gxmat + 9 * g2; const float* sz = m->geom_size + 3 * g2;
   float n[3] = {pm[2], pm[5], pm[8]};
+  float sx = sz[0], sy = sz[1], szz = sz[2];
   int cnt = 0;
-  for (int k = 0; k < 8 && cnt < 4; k++) {
-    float loc[3] = {(k & 1) ? sz[0] : -sz[0], (k & 2) ? sz[1] : -sz[1], (k & 4) ? sz[2] : -sz[2]}, w[3];
+  for (int k = 0; k < 8; k++) {
+    float loc[3] = {(k & 1) ? sx : -sx, (k & 2) ? sy : -sy, (k & 4) ? szz : -szz}, w[3];
     mulMatVec3f(w, bm, loc); w[0] += bp[0]; w[1] += bp[1]; w[2] += bp[2];
     float d[3] = {w[0] - pp[0], w[1] - pp[1], w[2] - pp[2]};
     float dist = dot3f(d, n);
-    if (dist > margin) continue;
+    if (dist > margin || cnt >= 4) continue;
     float pos[3] = {w[0] - 0.5f * dist * n[0], w[1] - 0.5f * dist * n[1], w[2] - 0.5f * dist * n[2]};
     grx_add_contact(c, pair, pos, n, dist); cnt++;
   }
 }
 
-// Sutherland-Hodgman clip of a convex polygon against sign*p[axis] <= lim
-GRX_DEV int grx_clip_poly(float* px, float* py, int n, int axis, float lim, float sign) {
-  float ox[16], oy[16]; int no = 0;
-  for (int i = 0; i < n && no < 15; i++) {
-    int i2 = (i + 1 == n) ? 0 : i + 1;
-    float ax = px[i], ay = py[i], bx = px[i2], by = py[i2];
-    float da = sign * (axis ? ay : ax) - lim, db = sign * (axis ? by : bx) - lim;
-    if (da <= 0) { ox[no] = ax; oy[no] = ay; no++; }
-    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
-      float t = da / (da - db);
-      ox[no] = ax + t * (bx - ax); oy[no] = ay + t * (by - ay); no++;
-    }
+// plane vs a SMALL convex vertex set (<= 32 hull vertices, e.g. the compile-time pruned hulls): one lane does it all
+GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  const float* gm = c->gxmat + 9 * g2;
+  int adr = m->geom_meshadr[g2], num = m->geom_meshnum[g2];
+  float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}, nl[3];
+  mulMatTVec3f(nl, gm, n);
+  float off = dot3f(c->gxpos + 3 * g2, n) - dot3f(c->gxpos + 3 * g1, n);
+  float bd = 1e30f; int best = -1;
+  for (int v = 0; v < num; v++) {
+    const float* mv = m->mesh_vert + 3 * (adr + v);
+    float dd = mv[0] * nl[0] + mv[1] * nl[1] + mv[2] * nl[2] + off;
+    if (dd < bd) { bd = dd; best = v; }
   }
-  for (int i = 0; i < no; i++) { px[i] = ox[i]; py[i] = oy[i]; }
-  return no;
+  if (best < 0 || bd > margin) return;
+  int aa = m->mesh_adjadr[adr + best], an = m->mesh_adjnum[adr + best], cn = 0;
+  for (int e = -1; e < an && cn < 4; e++) {
+    int v = (e < 0) ? best : m->mesh_adj[aa + e];
+    const float* mv = m->mesh_vert + 3 * (adr + v);
+    float lv[3] = {mv[0], mv[1], mv[2]};
+    float dd = lv[0] * nl[0] + lv[1] * nl[1] + lv[2] * nl[2] + off;
+    if (e >= 0 && dd > margin) continue;
+    float w[3], pos[3];
+    mulMatVec3f(w, gm, lv);
+    for (int t = 0; t < 3; t++) pos[t] = w[t] + c->gxpos[3 * g2 + t] - 0.5f * dd * n[t];
+    grx_add_contact(c, pair, pos, n, dd); cn++;
+  }
 }
 
-GRX_DEV void grx_box_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+#define GRX_SEL3(a0, a1, a2, i) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
+
+// box-box: SAT over the 15 axes, then face clipping or edge-edge.  Written without dynamically indexed local
+// arrays (everything stays in registers): axes are selected with GRX_SEL3, and the clipped contact polygon is
+// enumerated as (a) incident-face corners inside the reference rectangle, (b) reference corners inside the incident
+// quad, (c) proper crossings of incident edges with the rectangle sides -- the vertex set Sutherland-Hodgman yields.
+GRX_MEM void grx_box_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
   const float* p1 = c->gxpos + 3 * g1; const float* R1 = c->gxmat + 9 * g1; const float* a = m->geom_size + 3 * g1;
   const float* p2 = c->gxpos + 3 * g2; const float* R2 = c->gxmat + 9 * g2; const float* b = m->geom_size + 3 * g2;
-  float A[3][3], B[3][3];
-  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = R1[3 * k + i]; B[i][k] = R2[3 * k + i]; }
+  float A0[3] = {R1[0], R1[3], R1[6]}, A1[3] = {R1[1], R1[4], R1[7]}, A2[3] = {R1[2], R1[5], R1[8]};
+  float B0[3] = {R2[0], R2[3], R2[6]}, B1[3] = {R2[1], R2[4], R2[7]}, B2[3] = {R2[2], R2[5], R2[8]};
+  float a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2];
   float d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-  float Q[3][3];
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Q[i][j] = fabsf(dot3f(A[i], B[j]));
   float best = -1e30f; int code = -1; float bn[3] = {0, 0, 0};
-  for (int i = 0; i < 3; i++) {
-    float t = dot3f(d, A[i]);
-    float sep = fabsf(t) - (a[i] + b[0] * Q[i][0] + b[1] * Q[i][1] + b[2] * Q[i][2]);
-    if (sep > margin) return;
-    if (sep > best) { best = sep; code = i; float sg = t < 0 ? -1.0f : 1.0f; for (int k = 0; k < 3; k++) bn[k] = sg * A[i][k]; }
-  }
-  for (int j = 0; j < 3; j++) {
-    float t = dot3f(d, B[j]);
-    float sep = fabsf(t) - (b[j] + a[0] * Q[0][j] + a[1] * Q[1][j] + a[2] * Q[2][j]);
-    if (sep > margin) return;
-    if (sep > best) { best = sep; code = 3 + j; float sg = t < 0 ? -1.0f : 1.0f; for (int k = 0; k < 3; k++) bn[k] = sg * B[j][k]; }
-  }
+#define GRX_FACE_AXIS(AX, HALF, OA0, OA1, OA2, os0, os1, os2, CODE) { \
+    float t = dot3f(d, AX); \
+    float sep = fabsf(t) - ((HALF) + os0 * fabsf(dot3f(AX, OA0)) + os1 * fabsf(dot3f(AX, OA1)) + os2 * fabsf(dot3f(AX, OA2))); \
+    if (sep > margin) return; \
+    if (sep > best) { best = sep; code = CODE; float sg = t < 0 ? -1.0f : 1.0f; bn[0] = sg * AX[0]; bn[1] = sg * AX[1]; bn[2] = sg * AX[2]; } }
+  GRX_FACE_AXIS(A0, a0, B0, B1, B2, b0, b1, b2, 0) GRX_FACE_AXIS(A1, a1, B0, B1, B2, b0, b1, b2, 1) GRX_FACE_AXIS(A2, a2, B0, B1, B2, b0, b1, b2, 2)
+  GRX_FACE_AXIS(B0, b0, A0, A1, A2, a0, a1, a2, 3) GRX_FACE_AXIS(B1, b1, A0, A1, A2, a0, a1, a2, 4) GRX_FACE_AXIS(B2, b2, A0, A1, A2, a0, a1, a2, 5)
+#undef GRX_FACE_AXIS
   float ebest = -1e30f; int ei = -1, ej = -1; float en[3] = {0, 0, 0};
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) {
-      float ax[3]; cross3f(ax, A[i], B[j]);
-      float l = sqrtf(dot3f(ax, ax));
-      if (l < 1e-6f) continue;
-      float li = 1.0f / l; ax[0] *= li; ax[1] *= li; ax[2] *= li;
-      float t = dot3f(d, ax), ra = 0, rb = 0;
-      for (int k = 0; k < 3; k++) { ra += a[k] * fabsf(dot3f(A[k], ax)); rb += b[k] * fabsf(dot3f(B[k], ax)); }
-      float sep = fabsf(t) - (ra + rb);
-      if (sep > margin) return;
-      if (sep > ebest) { ebest = sep; ei = i; ej = j; float sg = t < 0 ? -1.0f : 1.0f; for (int k = 0; k < 3; k++) en[k] = sg * ax[k]; }
-    }
+#define GRX_EDGE_AXIS(AI, BJ, I, J) { \
+    float ax[3]; cross3f(ax, AI, BJ); \
+    float l = sqrtf(dot3f(ax, ax)); \
+    if (l >= 1e-6f) { \
+      float li = 1.0f / l; ax[0] *= li; ax[1] *= li; ax[2] *= li; \
+      float t = dot3f(d, ax); \
+      float ra = a0 * fabsf(dot3f(A0, ax)) + a1 * fabsf(dot3f(A1, ax)) + a2 * fabsf(dot3f(A2, ax)); \
+      float rb = b0 * fabsf(dot3f(B0, ax)) + b1 * fabsf(dot3f(B1, ax)) + b2 * fabsf(dot3f(B2, ax)); \
+      float sep = fabsf(t) - (ra + rb); \
+      if (sep > margin) return; \
+      if (sep > ebest) { ebest = sep; ei = I; ej = J; float sg = t < 0 ? -1.0f : 1.0f; en[0] = sg * ax[0]; en[1] = sg * ax[1]; en[2] = sg * ax[2]; } } }
+  GRX_EDGE_AXIS(A0, B0, 0, 0) GRX_EDGE_AXIS(A0, B1, 0, 1) GRX_EDGE_AXIS(A0, B2, 0, 2)
+  GRX_EDGE_AXIS(A1, B0, 1, 0) GRX_EDGE_AXIS(A1, B1, 1, 1) GRX_EDGE_AXIS(A1, B2, 1, 2)
+  GRX_EDGE_AXIS(A2, B0, 2, 0) GRX_EDGE_AXIS(A2, B1, 2, 1) GRX_EDGE_AXIS(A2, B2, 2, 2)
+#undef GRX_EDGE_AXIS
   if (ei >= 0 && ebest > best + 1e-7f + 0.02f * fabsf(best)) {
     float pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
-    for (int k = 0; k < 3; k++) {
-      if (k != ei) { float sg = dot3f(en, A[k]) > 0 ? 1.0f : -1.0f; for (int e = 0; e < 3; e++) pa[e] += sg * a[k] * A[k][e]; }
-      if (k != ej) { float sg = dot3f(en, B[k]) > 0 ? -1.0f : 1.0f; for (int e = 0; e < 3; e++) pb[e] += sg * b[k] * B[k][e]; }
+    float s0 = (ei != 0) ? (dot3f(en, A0) > 0 ? a0 : -a0) : 0.0f, s1 = (ei != 1) ? (dot3f(en, A1) > 0 ? a1 : -a1) : 0.0f, s2 = (ei != 2) ? (dot3f(en, A2) > 0 ? a2 : -a2) : 0.0f;
+    float t0 = (ej != 0) ? (dot3f(en, B0) > 0 ? -b0 : b0) : 0.0f, t1 = (ej != 1) ? (dot3f(en, B1) > 0 ? -b1 : b1) : 0.0f, t2 = (ej != 2) ? (dot3f(en, B2) > 0 ? -b2 : b2) : 0.0f;
+    float u[3], v[3];
+    for (int e = 0; e < 3; e++) {
+      pa[e] += s0 * A0[e] + s1 * A1[e] + s2 * A2[e]; pb[e] += t0 * B0[e] + t1 * B1[e] + t2 * B2[e];
+      u[e] = GRX_SEL3(A0[e], A1[e], A2[e], ei); v[e] = GRX_SEL3(B0[e], B1[e], B2[e], ej);
     }
     float w[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-    float uv = dot3f(A[ei], B[ej]), uw = dot3f(A[ei], w), vw = dot3f(B[ej], w);
+    float uv = dot3f(u, v), uw = dot3f(u, w), vw = dot3f(v, w);
     float den = 1.0f - uv * uv;
     float sc = den > 1e-12f ? (uv * vw - uw) / den : 0.0f, tc = den > 1e-12f ? (vw - uv * uw) / den : 0.0f;
     float pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = 0.5f * ((pa[k] + sc * A[ei][k]) + (pb[k] + tc * B[ej][k]));
+    for (int k = 0; k < 3; k++) pos[k] = 0.5f * ((pa[k] + sc * u[k]) + (pb[k] + tc * v[k]));
     grx_add_contact(c, pair, pos, en, ebest);
     return;
   }
-  int ref1 = code < 3;
-  const float* pr = ref1 ? p1 : p2; const float* pi = ref1 ? p2 : p1;
-  float (*Ar)[3] = ref1 ? A : B; float (*Ai)[3] = ref1 ? B : A;
-  const float* sr = ref1 ? a : b; const float* si = ref1 ? b : a;
-  int ax = ref1 ? code : code - 3;
-  float nr[3]; for (int k = 0; k < 3; k++) nr[k] = ref1 ? bn[k] : -bn[k];
-  int iax = 0; float mind = 1e30f, isg = 1;
-  for (int k = 0; k < 3; k++) {
-    float dd = dot3f(Ai[k], nr);
-    if (dd < mind) { mind = dd; iax = k; isg = 1; }
-    if (-dd < mind) { mind = -dd; iax = k; isg = -1; }
+  // ---- face contact
+  const int ref1 = code < 3, ax = ref1 ? code : code - 3;
+  float pr[3], pi[3], nr[3], Ar0[3], Ar1[3], Ar2[3], Ai0[3], Ai1[3], Ai2[3];
+  for (int e = 0; e < 3; e++) {
+    pr[e] = ref1 ? p1[e] : p2[e]; pi[e] = ref1 ? p2[e] : p1[e]; nr[e] = ref1 ? bn[e] : -bn[e];
+    Ar0[e] = ref1 ? A0[e] : B0[e]; Ar1[e] = ref1 ? A1[e] : B1[e]; Ar2[e] = ref1 ? A2[e] : B2[e];
+    Ai0[e] = ref1 ? B0[e] : A0[e]; Ai1[e] = ref1 ? B1[e] : A1[e]; Ai2[e] = ref1 ? B2[e] : A2[e];
   }
-  int u = (iax + 1) % 3, v = (iax + 2) % 3;
-  float fc[3]; for (int k = 0; k < 3; k++) fc[k] = pi[k] + isg * si[iax] * Ai[iax][k];
-  int ru = (ax + 1) % 3, rv = (ax + 2) % 3;
-  float rc[3]; for (int k = 0; k < 3; k++) rc[k] = pr[k] + sr[ax] * nr[k];
-  float px[16], py[16], hq[4];
-  for (int q = 0; q < 4; q++) {
-    float su = (q == 0 || q == 3) ? 1.0f : -1.0f, sv = (q < 2) ? 1.0f : -1.0f, w[3];
-    for (int k = 0; k < 3; k++) w[k] = fc[k] + su * si[u] * Ai[u][k] + sv * si[v] * Ai[v][k] - rc[k];
-    px[q] = dot3f(w, Ar[ru]); py[q] = dot3f(w, Ar[rv]); hq[q] = dot3f(w, nr);
+  const float sr0 = ref1 ? a0 : b0, sr1 = ref1 ? a1 : b1, sr2 = ref1 ? a2 : b2;
+  const float si0 = ref1 ? b0 : a0, si1 = ref1 ? b1 : a1, si2 = ref1 ? b2 : a2;
+  // incident face: the face of the other box most anti-parallel to nr
+  float dd0 = dot3f(Ai0, nr), dd1 = dot3f(Ai1, nr), dd2 = dot3f(Ai2, nr);
+  int iax = 0; float mind = 1e30f, isg = 1.0f;
+  if (dd0 < mind) { mind = dd0; iax = 0; isg = 1.0f; } if (-dd0 < mind) { mind = -dd0; iax = 0; isg = -1.0f; }
+  if (dd1 < mind) { mind = dd1; iax = 1; isg = 1.0f; } if (-dd1 < mind) { mind = -dd1; iax = 1; isg = -1.0f; }
+  if (dd2 < mind) { mind = dd2; iax = 2; isg = 1.0f; } if (-dd2 < mind) { mind = -dd2; iax = 2; isg = -1.0f; }
+  float Iu[3], Iv[3], In[3], Ru[3], Rv[3];
+  for (int e = 0; e < 3; e++) {
+    In[e] = GRX_SEL3(Ai0[e], Ai1[e], Ai2[e], iax); Iu[e] = GRX_SEL3(Ai1[e], Ai2[e], Ai0[e], iax); Iv[e] = GRX_SEL3(Ai2[e], Ai0[e], Ai1[e], iax);
+    Ru[e] = GRX_SEL3(Ar1[e], Ar2[e], Ar0[e], ax); Rv[e] = GRX_SEL3(Ar2[e], Ar0[e], Ar1[e], ax);
   }
-  float x0 = px[0], y0 = py[0], x1 = px[1] - x0, y1 = py[1] - y0, x2 = px[3] - x0, y2 = py[3] - y0;
-  float h1 = hq[1] - hq[0], h2 = hq[3] - hq[0];
-  float det = x1 * y2 - x2 * y1, gu = 0, gv = 0;
-  int flat = !(fabsf(det) > 1e-14f);
-  if (!flat) { gu = (h1 * y2 - h2 * y1) / det; gv = (x1 * h2 - x2 * h1) / det; }
-  int n = 4;
-  n = grx_clip_poly(px, py, n, 0, sr[ru], 1.0f); if (n) n = grx_clip_poly(px, py, n, 0, sr[ru], -1.0f);
-  if (n) n = grx_clip_poly(px, py, n, 1, sr[rv], 1.0f);
-  if (n) n = grx_clip_poly(px, py, n, 1, sr[rv], -1.0f);
+  const float sin_ = GRX_SEL3(si0, si1, si2, iax), siu = GRX_SEL3(si1, si2, si0, iax), siv = GRX_SEL3(si2, si0, si1, iax);
+  const float srn = GRX_SEL3(sr0, sr1, sr2, ax), sx = GRX_SEL3(sr1, sr2, sr0, ax), sy = GRX_SEL3(sr2, sr0, sr1, ax);
+  float rc[3], fcw[3];
+  for (int e = 0; e < 3; e++) { rc[e] = pr[e] + srn * nr[e]; fcw[e] = pi[e] + isg * sin_ * In[e] - rc[e]; }
+  // incident quad in the reference face frame: corner q = centre + su*U + sv*V, (su,sv) = (+,+),(-,+),(-,-),(+,-)
+  const float cx = dot3f(fcw, Ru), cy = dot3f(fcw, Rv), ch = dot3f(fcw, nr);
+  const float ux = siu * dot3f(Iu, Ru), uy = siu * dot3f(Iu, Rv), uh = siu * dot3f(Iu, nr);
+  const float vx = siv * dot3f(Iv, Ru), vy = siv * dot3f(Iv, Rv), vh = siv * dot3f(Iv, nr);
+  const float qx0 = cx + ux + vx, qy0 = cy + uy + vy, qh0 = ch + uh + vh;
+  const float qx1 = cx - ux + vx, qy1 = cy - uy + vy, qh1 = ch - uh + vh;
+  const float qx2 = cx - ux - vx, qy2 = cy - uy - vy;
+  const float qx3 = cx + ux - vx, qy3 = cy + uy - vy, qh3 = ch + uh - vh;
+  // height field of the incident plane over the reference frame
+  const float x1 = qx1 - qx0, y1 = qy1 - qy0, x2 = qx3 - qx0, y2 = qy3 - qy0, h1 = qh1 - qh0, h2 = qh3 - qh0;
+  const float det = x1 * y2 - x2 * y1;
+  const int flat = !(fabsf(det) > 1e-14f);
+  const float gu = flat ? 0.0f : (h1 * y2 - h2 * y1) / det, gv = flat ? 0.0f : (x1 * h2 - x2 * h1) / det;
   int cnt = 0;
-  for (int q = 0; q < n && cnt < 8; q++) {
-    float h = flat ? hq[0] : hq[0] + gu * (px[q] - x0) + gv * (py[q] - y0);
-    if (h > margin) continue;
-    int dup = 0;
-    for (int e = 0; e < q; e++) if (fabsf(px[e] - px[q]) + fabsf(py[e] - py[q]) < 1e-7f) dup = 1;
-    if (dup) continue;
-    float pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = rc[k] + px[q] * Ar[ru][k] + py[q] * Ar[rv][k] + 0.5f * h * nr[k];
-    grx_add_contact(c, pair, pos, bn, h); cnt++;
+#define GRX_EMIT(X, Y) { \
+    float x_ = (X), y_ = (Y); \
+    float h_ = qh0 + gu * (x_ - qx0) + gv * (y_ - qy0); \
+    if (h_ <= margin && cnt < 8) { \
+      float pos_[3]; \
+      for (int k_ = 0; k_ < 3; k_++) pos_[k_] = rc[k_] + x_ * Ru[k_] + y_ * Rv[k_] + 0.5f * h_ * nr[k_]; \
+      grx_add_contact(c, pair, pos_, bn, h_); cnt++; } }
+  // (a) incident corners inside the rectangle (inclusive)
+#define GRX_CORNER_A(X, Y) if (fabsf(X) <= sx && fabsf(Y) <= sy) GRX_EMIT(X, Y)
+  GRX_CORNER_A(qx0, qy0) GRX_CORNER_A(qx1, qy1) GRX_CORNER_A(qx2, qy2) GRX_CORNER_A(qx3, qy3)
+#undef GRX_CORNER_A
+  if (!flat) {
+    // (b) rectangle corners strictly inside the incident quad (orientation-independent sign test)
+    const float orient = det > 0 ? -1.0f : 1.0f;  // det > 0 <=> q0->q1->q2->q3 is counter-clockwise <=> interior has cross > 0
+#define GRX_SIDE(PX, PY, AX_, AY_, BX_, BY_) (orient * (((BX_) - (AX_)) * ((PY) - (AY_)) - ((BY_) - (AY_)) * ((PX) - (AX_))))
+#define GRX_CORNER_B(X, Y) { float X_ = (X), Y_ = (Y); \
+      if (GRX_SIDE(X_, Y_, qx0, qy0, qx1, qy1) < 0 && GRX_SIDE(X_, Y_, qx1, qy1, qx2, qy2) < 0 && GRX_SIDE(X_, Y_, qx2, qy2, qx3, qy3) < 0 && \
+          GRX_SIDE(X_, Y_, qx3, qy3, qx0, qy0) < 0) GRX_EMIT(X_, Y_) }
+    GRX_CORNER_B(sx, sy) GRX_CORNER_B(-sx, sy) GRX_CORNER_B(-sx, -sy) GRX_CORNER_B(sx, -sy)
+#undef GRX_CORNER_B
+#undef GRX_SIDE
+    // (c) proper crossings of the incident edges with the four rectangle sides (x-sides closed in y, y-sides open in x)
+#define GRX_CROSS(AX_, AY_, BX_, BY_) { \
+      float da, db, t_; \
+      da = (AX_) - sx; db = (BX_) - sx; if ((da < 0 && db > 0) || (da > 0 && db < 0)) { t_ = da / (da - db); float y = (AY_) + t_ * ((BY_) - (AY_)); if (fabsf(y) <= sy) GRX_EMIT(sx, y) } \
+      da = -(AX_) - sx; db = -(BX_) - sx; if ((da < 0 && db > 0) || (da > 0 && db < 0)) { t_ = da / (da - db); float y = (AY_) + t_ * ((BY_) - (AY_)); if (fabsf(y) <= sy) GRX_EMIT(-sx, y) } \
+      da = (AY_) - sy; db = (BY_) - sy; if ((da < 0 && db > 0) || (da > 0 && db < 0)) { t_ = da / (da - db); float x = (AX_) + t_ * ((BX_) - (AX_)); if (fabsf(x) < sx) GRX_EMIT(x, sy) } \
+      da = -(AY_) - sy; db = -(BY_) - sy; if ((da < 0 && db > 0) || (da > 0 && db < 0)) { t_ = da / (da - db); float x = (AX_) + t_ * ((BX_) - (AX_)); if (fabsf(x) < sx) GRX_EMIT(x, -sy) } }
+    GRX_CROSS(qx0, qy0, qx1, qy1) GRX_CROSS(qx1, qy1, qx2, qy2) GRX_CROSS(qx2, qy2, qx3, qy3) GRX_CROSS(qx3, qy3, qx0, qy0)
+#undef GRX_CROSS
   }
+#undef GRX_EMIT
 }
 
-GRX_DEV void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
-  LANE0 { c->cnt[0] = 0; }
+GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
+  LANE0 { c->cnt[0] = 0; c->cnt[7] = 0; }
   WAVE_SYNC();
-  // primitive pairs: one lane per candidate pair; mesh pairs are flagged for the cooperative pass
   for (int base = 0; base < m->ndevpair; base += 64) {
     FOR_LANES {
       int k = base + lane;
-      c->ired[lane] = -1;
       if (k < m->ndevpair) {
         int p = m->devpair[k], g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
         int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -763,15 +864,18 @@ GRX_DEV void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
         if (pass) {
           if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
           else if (t1 == 6 && t2 == 6) grx_box_box(m, c, p, g1, g2, margin);
-          else if (t1 == 0 && t2 == 7) c->ired[lane] = p;
+          else if (t1 == 0 && t2 == 7) {
+            if (m->geom_meshnum[g2] <= 32) grx_plane_mesh_small(m, c, p, g1, g2, margin);
+            else { int q = GRX_ATOMIC_ADD(&c->cnt[7], 1); if (q < 64) c->ired[q] = p; }
+          }
         }
       }
     }
     WAVE_SYNC();
-    // plane vs convex mesh hull: all lanes scan the hull vertices of one pair at a time
-    for (int l = 0; l < 64; l++) {
+    // large hulls (a moving link near the plane): all lanes scan the vertices of one pair at a time
+    int nbig = c->cnt[7] < 64 ? c->cnt[7] : 64;
+    for (int l = 0; l < nbig; l++) {
       int p = c->ired[l];
-      if (p < 0) continue;
       int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
       int adr = m->geom_meshadr[g2], num = m->geom_meshnum[g2];
       float margin = m->pair_margin[p];
@@ -795,32 +899,40 @@ GRX_DEV void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           if (vi >= 0 && (dd < bd || (dd == bd && vi < best))) { bd = dd; best = vi; }
         }
         if (best >= 0 && bd <= margin) {
-          int verts[4] = {best, -1, -1, -1}; float dists[4] = {bd, 0, 0, 0}; int cn = 1;
-          int aa = m->mesh_adjadr[adr + best], an = m->mesh_adjnum[adr + best];
-          for (int e = 0; e < an && cn < 4; e++) {
-            int v = m->mesh_adj[aa + e];
-            float dd = m->mesh_vert[3 * (adr + v)] * nl[0] + m->mesh_vert[3 * (adr + v) + 1] * nl[1] + m->mesh_vert[3 * (adr + v) + 2] * nl[2] + off;
-            if (dd <= margin) { verts[cn] = v; dists[cn] = dd; cn++; }
-          }
-          for (int e = 0; e < cn; e++) {
-            float lv[3] = {m->mesh_vert[3 * (adr + verts[e])], m->mesh_vert[3 * (adr + verts[e]) + 1], m->mesh_vert[3 * (adr + verts[e]) + 2]}, w[3], pos[3];
+          int aa = m->mesh_adjadr[adr + best], an = m->mesh_adjnum[adr + best], cn = 0;
+          for (int e = -1; e < an && cn < 4; e++) {
+            int v = (e < 0) ? best : m->mesh_adj[aa + e];
+            float lv[3] = {m->mesh_vert[3 * (adr + v)], m->mesh_vert[3 * (adr + v) + 1], m->mesh_vert[3 * (adr + v) + 2]}, w[3], pos[3];
+            float dd = lv[0] * nl[0] + lv[1] * nl[1] + lv[2] * nl[2] + off;
+            if (e >= 0 && dd > margin) continue;
             mulMatVec3f(w, gm, lv);
-            for (int t = 0; t < 3; t++) pos[t] = w[t] + c->gxpos[3 * g2 + t] - 0.5f * dists[e] * n[t];
-            grx_add_contact(c, p, pos, n, dists[e]);
+            for (int t = 0; t < 3; t++) pos[t] = w[t] + c->gxpos[3 * g2 + t] - 0.5f * dd * n[t];
+            grx_add_contact(c, p, pos, n, dd); cn++;
           }
         }
+        c->cnt[7] = 0;
       }
       WAVE_SYNC();
     }
   }
   LANE0 { if (c->cnt[0] > GRX_MAXCON) c->cnt[0] = GRX_MAXCON; }
   WAVE_SYNC();
+  // complete the tangent frames, one lane per contact
+  FOR_LANES {
+    for (int k = lane; k < c->cnt[0]; k += 64) {
+      float f[9];
+      for (int e = 0; e < 3; e++) f[e] = c->con_frame[9 * k + e];
+      grx_make_frame(f);
+      for (int e = 3; e < 9; e++) c->con_frame[9 * k + e] = f[e];
+    }
+  }
+  WAVE_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------
 // K9 constraint rows (equality weld, dof frictionloss, joint limits, pyramidal contacts)
 // ------------------------------------------------------------------------------------------
-GRX_DEV float grx_impedance(const float* solimp, float pos) {
+GRX_MEM float grx_impedance(const float* solimp, float pos) {
   float dmin = fminf(GRX_MAXIMP, fmaxf(GRX_MINIMP, solimp[0])), dmax = fminf(GRX_MAXIMP, fmaxf(GRX_MINIMP, solimp[1]));
   float width = fmaxf(0.0f, solimp[2]), mid = fminf(GRX_MAXIMP, fmaxf(GRX_MINIMP, solimp[3])), power = fmaxf(1.0f, solimp[4]);
   if (dmin == dmax || width <= GRX_MINVAL) return 0.5f * (dmin + dmax);
@@ -836,7 +948,7 @@ GRX_DEV float grx_impedance(const float* solimp, float pos) {
 }
 
 // column d of the translational / rotational Jacobian of a world point on body b (zero if d not in chain)
-GRX_DEV void grx_jac_col(const GrxModel* m, const GrxCtx* c, int b, const float* point, int d, float* jp, float* jr) {
+GRX_MEM void grx_jac_col(const GrxModel* m, const GrxCtx* c, int b, const float* point, int d, float* jp, float* jr) {
   unsigned lo = (unsigned)m->dof_chainmask[2 * b], hi = (unsigned)m->dof_chainmask[2 * b + 1];
   int in = d < 32 ? (lo >> d) & 1u : (hi >> (d - 32)) & 1u;
   if (!in) { jp[0] = jp[1] = jp[2] = 0; jr[0] = jr[1] = jr[2] = 0; return; }
@@ -848,15 +960,12 @@ GRX_DEV void grx_jac_col(const GrxModel* m, const GrxCtx* c, int b, const float*
   jr[0] = w[0]; jr[1] = w[1]; jr[2] = w[2]; jp[0] = cd[3] + t[0]; jp[1] = cd[4] + t[1]; jp[2] = cd[5] + t[2];
 }
 
-GRX_DEV void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
-  const int nv = m->nv;
+GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
+  const int nv = GRX_NVC;
   int ncon = c->cnt[0];
-  // ---- row bookkeeping (counts are tiny: serial prefix by every lane over LDS tables)
-  int ne = 0;
-  for (int e = 0; e < m->neq; e++) if (m->eq_active[e] && m->eq_type[e] == 1) ne += 6;
-  int nf = 0;
-  for (int d = 0; d < nv; d++) if (m->dof_frictionloss[d] > 0) nf++;
-  // limits: ired[j] = bit0 lower active, bit1 upper active
+  // ---- row bookkeeping.  Per-joint limit flags and per-contact row counts go to small LDS int tables once; the
+  // prefix sums below then only touch LDS.
+  const int ne = 6 * m->nweld, nf = m->nfric;
   FOR_LANES {
     for (int j = lane; j < m->njnt; j += 64) {
       int f = 0;
@@ -867,15 +976,18 @@ GRX_DEV void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       }
       c->ired[j] = f;
     }
+    for (int k = lane; k < ncon; k += 64) {
+      int p = c->con_pair[k], dim = m->pair_condim[p];
+      int active = c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p];
+      c->con_nr[k] = active ? ((dim == 1) ? 1 : 2 * (dim - 1)) : 0;
+      c->con_b1[k] = m->geom_bodyid[m->pair_geom1[p]]; c->con_b2[k] = m->geom_bodyid[m->pair_geom2[p]];
+    }
   }
   WAVE_SYNC();
   int nl = 0;
   for (int j = 0; j < m->njnt; j++) { int f = c->ired[j]; nl += (f & 1) + ((f >> 1) & 1); }
   int nc = 0;
-  for (int k = 0; k < ncon; k++) {
-    int p = c->con_pair[k];
-    if (c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p]) { int dim = m->pair_condim[p]; nc += (dim == 1) ? 1 : 2 * (dim - 1); }
-  }
+  for (int k = 0; k < ncon; k++) nc += c->con_nr[k];
   int nefc = ne + nf + nl + nc;
   int overflow = nefc > GRX_MAXEFC;
   // ---- descriptors
@@ -885,12 +997,13 @@ GRX_DEV void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       for (int q = 0; q < m->neq; q++) if (m->eq_active[q] && m->eq_type[q] == 1) { if (r < acc + 6) { e = q; break; } acc += 6; }
       c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = e; c->efc_sub[r] = r - acc;
     }
-    for (int d = lane; d < nv; d += 64) {
-      if (m->dof_frictionloss[d] > 0) {
-        int r = ne; for (int q = 0; q < d; q++) if (m->dof_frictionloss[q] > 0) r++;
-        c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d; c->efc_sub[r] = 0;
+    if (nf > 0)
+      for (int d = lane; d < nv; d += 64) {
+        if (m->dof_frictionloss[d] > 0) {
+          int r = ne; for (int q = 0; q < d; q++) if (m->dof_frictionloss[q] > 0) r++;
+          c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d; c->efc_sub[r] = 0;
+        }
       }
-    }
     for (int j = lane; j < m->njnt; j += 64) {
       int f = c->ired[j];
       if (f) {
@@ -901,18 +1014,11 @@ GRX_DEV void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       }
     }
     for (int k = lane; k < ncon; k += 64) {
-      int p = c->con_pair[k];
-      int active = c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p];
+      int nr = c->con_nr[k];
       int r = ne + nf + nl;
-      for (int q = 0; q < k; q++) {
-        int pq = c->con_pair[q];
-        if (c->con_dist[q] < m->pair_margin[pq] - m->pair_gap[pq]) { int dq = m->pair_condim[pq]; r += (dq == 1) ? 1 : 2 * (dq - 1); }
-      }
-      c->con_efc[k] = active ? r : -1;
-      if (active) {
-        int dim = m->pair_condim[p], nr = (dim == 1) ? 1 : 2 * (dim - 1);
-        for (int q = 0; q < nr; q++) if (r + q < GRX_MAXEFC) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = k; c->efc_sub[r + q] = q; }
-      }
+      for (int q = 0; q < k; q++) r += c->con_nr[q];
+      c->con_efc[k] = nr ? r : -1;
+      for (int q = 0; q < nr; q++) if (r + q < GRX_MAXEFC) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = k; c->efc_sub[r + q] = q; }
     }
   }
   if (overflow) nefc = GRX_MAXEFC;
@@ -965,8 +1071,8 @@ GRX_DEV void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       int k = it / nv, d = it - k * nv;
       int r0 = c->con_efc[k];
       if (r0 < 0) continue;
-      int p = c->con_pair[k], dim = m->pair_condim[p];
-      int b1 = m->geom_bodyid[m->pair_geom1[p]], b2 = m->geom_bodyid[m->pair_geom2[p]];
+      int p = c->con_pair[k], nrk = c->con_nr[k], dim = (nrk == 1) ? 1 : nrk / 2 + 1;
+      int b1 = c->con_b1[k], b2 = c->con_b2[k];
       float pos[3] = {c->con_pos[3 * k], c->con_pos[3 * k + 1], c->con_pos[3 * k + 2]};
       float jp1[3], jr1[3], jp2[3], jr2[3];
       grx_jac_col(m, c, b1, pos, d, jp1, jr1); grx_jac_col(m, c, b2, pos, d, jp2, jr2);
@@ -1040,18 +1146,21 @@ GRX_DEV void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
 // exact line search; wave-parallel over dofs / rows / Hessian entries.
 // ------------------------------------------------------------------------------------------
 // Ma = M a ; jar = J a - aref ; force / active flags ; returns total cost if want_cost
-GRX_DEV float grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int nefc, int want_cost, int lane_) {
-  const int nv = m->nv;
+GRX_MEM float grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int nefc, int want_cost, int lane_) {
+  const int nv = GRX_NVC;
+  GRX_LANEVAR(costp);
   FOR_LANES {
     float part = 0;
     for (int i = lane; i < nv; i += 64) {
       float s = 0;
+#pragma unroll 1
       for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * a[j];
       c->Ma[i] = s;
       part += 0.5f * s * a[i] - c->qfrc_smooth[i] * a[i];
     }
     for (int r = lane; r < nefc; r += 64) {
       float s = 0;
+#pragma unroll 1
       for (int j = 0; j < nv; j++) s += c->J[r * nv + j] * a[j];
       float x = s - c->efc_aref[r], D = c->efc_D[r], f; int quad;
       int kind = c->efc_kind[r];
@@ -1066,16 +1175,17 @@ GRX_DEV float grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int 
       }
       c->efc_jar[r] = x; c->efc_force[r] = f; c->efc_quad[r] = quad;
     }
-    c->red[lane] = part;
+    LV(costp) = part;
   }
   WAVE_SYNC();
   float cost = 0;
-  if (want_cost) { cost = grx_wave_sum(c->red, lane_); WAVE_SYNC(); }
+  if (want_cost) cost = grx_reduce_sum(costp);
   return cost;
 }
 
 // derivative (d1) and curvature (d2) of the cost along the search direction at step alpha
-GRX_DEV void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, float* d1, float* d2, int lane_) {
+GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, float* d1, float* d2, int lane_) {
+  GRX_LANEVAR(gp); GRX_LANEVAR(hp);
   FOR_LANES {
     float g = 0, h = 0;
     for (int r = lane; r < nefc; r += 64) {
@@ -1087,17 +1197,15 @@ GRX_DEV void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, f
         if (x <= -Rf) g -= fl * jv; else if (x >= Rf) g += fl * jv; else { g += D * x * jv; h += D * jv * jv; }
       } else if (x < 0) { g += D * x * jv; h += D * jv * jv; }
     }
-    c->red[lane] = g; c->red[64 + lane] = h;
+    LV(gp) = g; LV(hp) = h;
   }
-  WAVE_SYNC();
-  float g = grx_wave_sum(c->red, lane_), h = grx_wave_sum(c->red + 64, lane_);
-  WAVE_SYNC();
+  float g = grx_reduce_sum(gp), h = grx_reduce_sum(hp);
   *d1 = q1 + alpha * q2 + g; *d2 = q2 + h;
 }
 
 // H = M + J' diag(D_active) J  ->  c->A   (efc_jv is used as scratch for the masked D)
-GRX_DEV void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
-  const int nv = m->nv;
+GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
+  const int nv = GRX_NVC;
     // Hessian H = M + J' diag(D_active) J
   FOR_LANES { for (int r = lane; r < nefc; r += 64) c->efc_jv[r] = c->efc_quad[r] ? c->efc_D[r] : 0.0f; }  // efc_jv reused as scratch
   WAVE_SYNC();
@@ -1155,111 +1263,176 @@ GRX_DEV void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   }
 }
 
-GRX_DEV void grx_solve(const GrxModel* m, GrxCtx* c, int lane_) {
-  const int nv = m->nv;
-  int nefc = c->cnt[1];
-  if (nefc == 0) {
-    FOR_LANES { for (int i = lane; i < nv * nv; i += 64) c->A[i] = c->M[i]; }
-    WAVE_SYNC();
-    if (grx_sym_solve_full(c->A, nv, c->qacc_smooth, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
-    FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qacc[i] = c->qacc_smooth[i]; c->qfrc_constraint[i] = 0; } }
-    WAVE_SYNC();
-    return;
-  }
-  // Start from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart, M^-1 qfrc_smooth);
-  // the minimiser of the strictly convex problem does not depend on the start, and skipping the comparison saves one
-  // factorisation of M per substep (qacc_smooth is only formed when there are no constraint rows at all).
+// Constraint solve (Newton) + optional semi-implicit Euler step as ONE state machine, so that the three heavy
+// primitives -- row evaluation, Hessian assembly and the register-resident linear solve -- each have a single call site
+// in the kernel: the fused 20-substep loop has to stay inside the instruction cache.
+//   phase 0: Newton iterations on the primal problem        (A = M + J' D J,      rhs = -gradient)
+//   phase 2: no constraint rows at all                      (A = M,               rhs = qfrc_smooth)
+//   phase 1: Euler velocity update with implicit damping    (A = M + h diag(B),   rhs = qfrc_smooth + qfrc_constraint)
+GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int lane_) {
+  const int nv = GRX_NVC; const float h = m->timestep;
+  const int nefc = c->cnt[1];
+  const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+  const int implicit_damp = (m->anydamp && m->eulerdamp);
+  int phase = nefc ? 0 : 2, it = 0, done = 0;
+  // Newton starts from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart,
+  // M^-1 qfrc_smooth); the minimiser of the strictly convex problem does not depend on the start, and skipping the
+  // comparison saves one factorisation of M per substep.
   FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc[i] = c->qacc_ws[i]; }
   WAVE_SYNC();
-  float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
-  GRX_TICK(c, GRX_P_NEVAL);
-  for (int it = 0; it < GRX_NEWTON_MAXIT; it++) {
-    grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
-    GRX_TICK(c, GRX_P_NEVAL);
-    // gradient = M a - qfrc_smooth - J' f
-    FOR_LANES {
-      float part = 0;
-      for (int i = lane; i < nv; i += 64) {
-        float s = c->Ma[i] - c->qfrc_smooth[i];
-        for (int r = 0; r < nefc; r++) s -= c->J[r * nv + i] * c->efc_force[r];
-        c->grad[i] = s; c->search[i] = -s; part += s * s;
+  GRX_TICK(c, GRX_P_MSOLVE);
+  for (;;) {
+    float* rhs;
+    if (phase == 0) {
+      grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
+      GRX_TICK(c, GRX_P_NEVAL);
+      if (done || it >= GRX_NEWTON_MAXIT) {
+        // converged: constraint forces from the evaluation just made
+        FOR_LANES {
+          for (int i = lane; i < nv; i += 64) {
+            float sacc = 0;
+#pragma unroll 1
+            for (int r = 0; r < nefc; r++) sacc += c->J[r * nv + i] * c->efc_force[r];
+            c->qfrc_constraint[i] = sacc; c->qacc_ws[i] = c->qacc[i];
+          }
+        }
+        WAVE_SYNC();
+        GRX_TICK(c, GRX_P_NFINAL);
+        if (!do_euler) break;
+        phase = 1;
+        continue;
       }
-      c->red[lane] = part;
-    }
-    WAVE_SYNC();
-    float gn = sqrtf(grx_wave_sum(c->red, lane_));
-    WAVE_SYNC();
-    GRX_TICK(c, GRX_P_NGRAD);
-    if (scale * gn < 1e-8f) break;
-    grx_hessian(m, c, nefc, lane_);
-    GRX_TICK(c, GRX_P_NHESS);
-    if (grx_sym_solve_full(c->A, nv, c->search, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
-    GRX_TICK(c, GRX_P_NFACTOR);
-    // Mv, Jv, quadratic coefficients of the Gauss term along the direction
-    FOR_LANES {
-      float p1 = 0, p2 = 0;
-      for (int i = lane; i < nv; i += 64) {
-        float s = 0;
-        for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * c->search[j];
-        c->Mv[i] = s;
-        p1 += c->search[i] * (c->Ma[i] - c->qfrc_smooth[i]); p2 += c->search[i] * s;
+      // gradient = M a - qfrc_smooth - J' f
+      GRX_LANEVAR(gnp);
+      FOR_LANES {
+        float part = 0;
+        for (int i = lane; i < nv; i += 64) {
+          float sacc = c->Ma[i] - c->qfrc_smooth[i];
+#pragma unroll 1
+          for (int r = 0; r < nefc; r++) sacc -= c->J[r * nv + i] * c->efc_force[r];
+          c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc;
+        }
+        LV(gnp) = part;
       }
-      for (int r = lane; r < nefc; r += 64) {
-        float s = 0;
-        for (int j = 0; j < nv; j++) s += c->J[r * nv + j] * c->search[j];
-        c->efc_jv[r] = s;
+      WAVE_SYNC();
+      float gn = sqrtf(grx_reduce_sum(gnp));
+      GRX_TICK(c, GRX_P_NGRAD);
+      if (scale * gn < 1e-8f) { done = 1; continue; }
+      grx_hessian(m, c, nefc, lane_);
+      GRX_TICK(c, GRX_P_NHESS);
+      rhs = c->search;
+    } else if (phase == 1) {
+      if (!implicit_damp) {
+        FOR_LANES { for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qacc[i]; }
+        WAVE_SYNC();
+      } else {
+        FOR_LANES {
+          for (int i = lane; i < nv * nv; i += 64) { int r = i / nv, q = i - r * nv; c->A[i] = c->M[i] + ((r == q) ? h * m->dof_damping[r] : 0.0f); }
+          for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qfrc_smooth[i] + c->qfrc_constraint[i];
+        }
+        WAVE_SYNC();
       }
-      c->red[lane] = p1; c->red[64 + lane] = p2;
+      rhs = c->tmpv;
+    } else {
+      FOR_LANES { for (int i = lane; i < nv * nv; i += 64) c->A[i] = c->M[i]; }
+      WAVE_SYNC();
+      rhs = c->qacc_smooth;
     }
-    WAVE_SYNC();
-    float q1 = grx_wave_sum(c->red, lane_), q2 = grx_wave_sum(c->red + 64, lane_);
-    WAVE_SYNC();
-    // exact line search: root of the monotone piecewise-linear derivative, starting from the Newton step
-    float d1, d2, alpha = 1.0f, lo = 0.0f, hi = 0.0f, dlo, dhi = 0.0f;
-    grx_ls_eval(c, nefc, 0.0f, q1, q2, &dlo, &d2, lane_);
-    if (!(dlo < 0)) break;
-    int have_hi = 0;
-    float gtol = 1e-6f * fabsf(dlo);
-    grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
-    for (int k = 0; k < GRX_LS_MAXIT; k++) {
-      if (fabsf(d1) <= gtol) break;
-      if (d1 < 0) { lo = alpha; dlo = d1; } else { hi = alpha; dhi = d1; have_hi = 1; }
-      float na = alpha - d1 / d2;
-      if (have_hi) { if (!(na > lo && na < hi)) na = lo + (hi - lo) * (dlo / (dlo - dhi)); if (!(na > lo && na < hi)) na = 0.5f * (lo + hi); }
-      else if (!(na > lo)) na = 2.0f * alpha;
-      alpha = na;
-      grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
+    // ---- the one linear solve
+    if (!(phase == 1 && !implicit_damp))
+      if (grx_sym_solve_full(c->A, nv, rhs, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+    if (phase == 0) {
+      GRX_TICK(c, GRX_P_NFACTOR);
+      // Mv, Jv, quadratic coefficients of the Gauss term along the direction
+      GRX_LANEVAR(q1p); GRX_LANEVAR(q2p);
+      FOR_LANES {
+        float p1 = 0, p2 = 0;
+        for (int i = lane; i < nv; i += 64) {
+          float sacc = 0;
+#pragma unroll 1
+          for (int j = 0; j < nv; j++) sacc += c->M[i * nv + j] * c->search[j];
+          c->Mv[i] = sacc;
+          p1 += c->search[i] * (c->Ma[i] - c->qfrc_smooth[i]); p2 += c->search[i] * sacc;
+        }
+        for (int r = lane; r < nefc; r += 64) {
+          float sacc = 0;
+#pragma unroll 1
+          for (int j = 0; j < nv; j++) sacc += c->J[r * nv + j] * c->search[j];
+          c->efc_jv[r] = sacc;
+        }
+        LV(q1p) = p1; LV(q2p) = p2;
+      }
+      WAVE_SYNC();
+      const float q1 = grx_reduce_sum(q1p), q2 = grx_reduce_sum(q2p);
+      // exact line search: root of the monotone piecewise-linear derivative, starting from the Newton step
+      float d1, d2, alpha = 0.0f, lo = 0.0f, hi = 0.0f, dlo = 0.0f, dhi = 0.0f, gtol = 0.0f;
+      int have_hi = 0, stop = 0;
+      for (int k = 0; k < GRX_LS_MAXIT + 2; k++) {
+        grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
+        if (k == 0) {
+          dlo = d1;
+          if (!(dlo < 0)) { stop = 1; break; }
+          gtol = 1e-6f * fabsf(dlo); alpha = 1.0f;
+          continue;
+        }
+        if (fabsf(d1) <= gtol) break;
+        if (d1 < 0) { lo = alpha; dlo = d1; } else { hi = alpha; dhi = d1; have_hi = 1; }
+        float na = alpha - d1 / d2;
+        if (have_hi) { if (!(na > lo && na < hi)) na = lo + (hi - lo) * (dlo / (dlo - dhi)); if (!(na > lo && na < hi)) na = 0.5f * (lo + hi); }
+        else if (!(na > lo)) na = 2.0f * alpha;
+        alpha = na;
+      }
+      if (stop) { done = 1; continue; }  // not a descent direction any more: converged to rounding
+      GRX_LANEVAR(msp); GRX_LANEVAR(map_);
+      FOR_LANES {
+        float ms = 0, ma = 0;
+        for (int i = lane; i < nv; i += 64) { float d = alpha * c->search[i]; float q = c->qacc[i] + d; c->qacc[i] = q; ms = fmaxf(ms, fabsf(d)); ma = fmaxf(ma, fabsf(q)); }
+        LV(msp) = ms; LV(map_) = ma;
+      }
+      WAVE_SYNC();
+      const float stepmax = grx_reduce_max(msp), qmax = grx_reduce_max(map_);
+      LANE0 { c->cnt[6] += 1; }
+      GRX_TICK(c, GRX_P_NLS);
+      it++;
+      // converged when the accepted step is below the resolution we can hold in fp32 (quadratic convergence: the
+      // step just applied is ~ the error BEFORE it, the error after it is far smaller)
+      if (stepmax <= GRX_NEWTON_RTOL * qmax + GRX_NEWTON_ATOL) done = 1;
+    } else if (phase == 2) {
+      FOR_LANES { for (int i = lane; i < nv; i += 64) { float q = c->qacc_smooth[i]; c->qacc[i] = q; c->qacc_ws[i] = q; c->qfrc_constraint[i] = 0; } }
+      WAVE_SYNC();
+      if (!do_euler) break;
+      phase = 1;
+    } else {
+      // ---- semi-implicit Euler: velocities, then positions with the new velocities
+      FOR_LANES { for (int i = lane; i < nv; i += 64) c->qvel[i] += h * c->tmpv[i]; }
+      WAVE_SYNC();
+      FOR_LANES {
+        for (int j = lane; j < m->njnt; j += 64) {
+          int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+          if (m->jnt_type[j] == 0) {
+            for (int k = 0; k < 3; k++) c->qpos[qa + k] += h * c->qvel[da + k];
+            float w[3] = {c->qvel[da + 3], c->qvel[da + 4], c->qvel[da + 5]};
+            float n = sqrtf(dot3f(w, w));
+            if (n > 1e-12f) {
+              float sn, cs; sincosf(0.5f * h * n, &sn, &cs);
+              float ri = sn / n, qr[4] = {cs, w[0] * ri, w[1] * ri, w[2] * ri}, q[4] = {c->qpos[qa + 3], c->qpos[qa + 4], c->qpos[qa + 5], c->qpos[qa + 6]}, qn[4];
+              mulQuatf(qn, q, qr); normalize4f(qn);
+              for (int k = 0; k < 4; k++) c->qpos[qa + 3 + k] = qn[k];
+            }
+          } else c->qpos[qa] += h * c->qvel[da];
+        }
+      }
+      WAVE_SYNC();
+      GRX_TICK(c, GRX_P_EULER);
+      break;
     }
-    FOR_LANES {
-      float ms = 0, ma = 0;
-      for (int i = lane; i < nv; i += 64) { float d = alpha * c->search[i]; float q = c->qacc[i] + d; c->qacc[i] = q; ms = fmaxf(ms, fabsf(d)); ma = fmaxf(ma, fabsf(q)); }
-      c->red[lane] = ms; c->red[64 + lane] = ma;
-    }
-    WAVE_SYNC();
-    float stepmax = grx_wave_max(c->red, lane_), qmax = grx_wave_max(c->red + 64, lane_);
-    WAVE_SYNC();
-    LANE0 { c->cnt[6] += 1; }
-    GRX_TICK(c, GRX_P_NLS);
-    // converged when the accepted step is below the resolution we can hold in fp32 (quadratic convergence: the
-    // step just applied is ~ the error BEFORE it, the error after it is far smaller)
-    if (stepmax <= GRX_NEWTON_RTOL * qmax + GRX_NEWTON_ATOL) break;
   }
-  grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
-  FOR_LANES {
-    for (int i = lane; i < nv; i += 64) {
-      float s = 0;
-      for (int r = 0; r < nefc; r++) s += c->J[r * nv + i] * c->efc_force[r];
-      c->qfrc_constraint[i] = s;
-    }
-  }
-  WAVE_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------
-// mj_forward / mj_Euler equivalents
+// mj_forward (do_euler = 0) / mj_step (do_euler = 1) for one world
 // ------------------------------------------------------------------------------------------
-GRX_DEV void grx_forward(const GrxModel* m, GrxCtx* c, int lane_) {
-  const int nv = m->nv;
+GRX_MEM void grx_forward_euler(const GrxModel* m, GrxCtx* c, int do_euler, int lane_) {
   GRX_TICK(c, GRX_P_OTHER);
   grx_kinematics(m, c, lane_);
   GRX_TICK(c, GRX_P_KIN);
@@ -1271,61 +1444,17 @@ GRX_DEV void grx_forward(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_TICK(c, GRX_P_CONSTR);
   grx_velocity(m, c, lane_);
   GRX_TICK(c, GRX_P_VEL);
-  GRX_TICK(c, GRX_P_MSOLVE);
-  grx_solve(m, c, lane_);
-  FOR_LANES { for (int i = lane; i < nv; i += 64) c->qacc_ws[i] = c->qacc[i]; }
-  WAVE_SYNC();
+  grx_solve_integrate(m, c, do_euler, lane_);
 }
 
-// semi-implicit Euler with implicit joint damping
-GRX_DEV void grx_euler(const GrxModel* m, GrxCtx* c, int lane_) {
-  const int nv = m->nv; const float h = m->timestep;
-  if (m->anydamp && m->eulerdamp) {
-    FOR_LANES {
-      for (int i = lane; i < nv * nv; i += 64) { int r = i / nv, q = i - r * nv; c->A[i] = c->M[i] + ((r == q) ? h * m->dof_damping[r] : 0.0f); }
-      for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qfrc_smooth[i] + c->qfrc_constraint[i];
-    }
-    WAVE_SYNC();
-    if (grx_sym_solve_full(c->A, nv, c->tmpv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
-  } else {
-    FOR_LANES { for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qacc[i]; }
-    WAVE_SYNC();
-  }
-  FOR_LANES { for (int i = lane; i < nv; i += 64) c->qvel[i] += h * c->tmpv[i]; }
-  WAVE_SYNC();
-  FOR_LANES {
-    for (int j = lane; j < m->njnt; j += 64) {
-      int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
-      if (m->jnt_type[j] == 0) {
-        for (int k = 0; k < 3; k++) c->qpos[qa + k] += h * c->qvel[da + k];
-        float w[3] = {c->qvel[da + 3], c->qvel[da + 4], c->qvel[da + 5]};
-        float n = sqrtf(dot3f(w, w));
-        if (n > 1e-12f) {
-          float sn, cs; sincosf(0.5f * h * n, &sn, &cs);
-          float ri = sn / n, qr[4] = {cs, w[0] * ri, w[1] * ri, w[2] * ri}, q[4] = {c->qpos[qa + 3], c->qpos[qa + 4], c->qpos[qa + 5], c->qpos[qa + 6]}, qn[4];
-          mulQuatf(qn, q, qr); normalize4f(qn);
-          for (int k = 0; k < 4; k++) c->qpos[qa + 3 + k] = qn[k];
-        }
-      } else c->qpos[qa] += h * c->qvel[da];
-    }
-  }
-  WAVE_SYNC();
-}
-
-GRX_DEV void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {
+GRX_MEM void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {
   FOR_LANES {
     int bad = 0;
     for (int i = lane; i < m->nq; i += 64) { float v = c->qpos[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
-    for (int i = lane; i < m->nv; i += 64) { float v = c->qvel[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
+    for (int i = lane; i < GRX_NVC; i += 64) { float v = c->qvel[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
     if (bad) c->cnt[2] |= GRX_ST_BADNUM;
   }
   WAVE_SYNC();
 }
 
-// one mj_step
-GRX_DEV void grx_step1(const GrxModel* m, GrxCtx* c, int lane_) {
-  grx_forward(m, c, lane_);
-  GRX_TICK(c, GRX_P_NFINAL);
-  grx_euler(m, c, lane_);
-  GRX_TICK(c, GRX_P_EULER);
-}
+};  // struct GrxEngine

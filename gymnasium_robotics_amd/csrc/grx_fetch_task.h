@@ -48,9 +48,12 @@ GRX_DEV void grx_mat2euler(const float* R, float* e) {
   else { e[0] = 0.0f; e[1] = -atan2f(-R[2], cy); e[2] = -atan2f(-R[3], R[4]); }
 }
 
+template <int NV>
+struct GrxFetch {
+  typedef GrxEngine<NV> E;
 // linear / angular velocity of a world point fixed to body b: J(point) * qvel using the
 // motion axes of the LAST forward pass and the CURRENT qvel (what mj_jacSite @ qvel gives)
-GRX_DEV void grx_point_velocity(const GrxModel* m, const GrxCtx* c, int b, const float* point, float* vp, float* vr) {
+GRX_MEM void grx_point_velocity(const GrxModel* m, const GrxCtx* c, int b, const float* point, float* vp, float* vr) {
   const float* cref = c->xpos + 3 * m->body_rootid[b];
   float off[3] = {point[0] - cref[0], point[1] - cref[1], point[2] - cref[2]};
   float w[3] = {0, 0, 0}, v[3] = {0, 0, 0};
@@ -62,7 +65,7 @@ GRX_DEV void grx_point_velocity(const GrxModel* m, const GrxCtx* c, int b, const
   vp[0] = v[0] + t[0]; vp[1] = v[1] + t[1]; vp[2] = v[2] + t[2]; vr[0] = w[0]; vr[1] = w[1]; vr[2] = w[2];
 }
 
-GRX_DEV void grx_fetch_set_action(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux, const float* action, int lane_) {
+GRX_MEM void grx_fetch_set_action(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux, const float* action, int lane_) {
   LANE0 {
     float a[4];
     for (int k = 0; k < 4; k++) a[k] = fminf(1.0f, fmaxf(-1.0f, action[k]));
@@ -79,7 +82,7 @@ GRX_DEV void grx_fetch_set_action(const GrxModel* m, const GrxFetchTask* t, GrxC
 }
 
 // writes aux (gripper_link pose of the current kinematics), obs, achieved goal
-GRX_DEV void grx_fetch_outputs(const GrxModel* m, const GrxFetchTask* t, const GrxCtx* c, float* aux, float* obs, float* achieved, int lane_) {
+GRX_MEM void grx_fetch_outputs(const GrxModel* m, const GrxFetchTask* t, const GrxCtx* c, float* aux, float* obs, float* achieved, int lane_) {
   LANE0 {
     int b = t->grip_body; float v[3], q[4];
     mulMatVec3f(v, c->xmat + 9 * b, t->grip_relpos);
@@ -116,17 +119,18 @@ GRX_DEV void grx_fetch_outputs(const GrxModel* m, const GrxFetchTask* t, const G
 }
 
 // whole env.step() for one world whose state is already in the LDS context
-GRX_DEV void grx_fetch_step_world(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux_in, const float* action,
+GRX_MEM void grx_fetch_step_world(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux_in, const float* action,
                                   float* aux_out, float* obs, float* achieved, int lane_) {
   grx_fetch_set_action(m, t, c, aux_in, action, lane_);
-  for (int s = 0; s < t->n_substeps; s++) {
-    grx_check_state(m, c, lane_);
-    grx_step1(m, c, lane_);
-  }
-  if (t->block_gripper) {
-    LANE0 { c->qpos[t->jq_lf] = 0.0f; c->qpos[t->jq_rf] = 0.0f; }
-    WAVE_SYNC();
-    grx_forward(m, c, lane_);
+  // n_substeps x mj_step, plus (block_gripper tasks) the _step_callback: zero the finger qpos and run one mj_forward.
+  // One loop, one call site of the physics, so the loop body stays resident in the instruction cache.
+  const int total = t->n_substeps + (t->block_gripper ? 1 : 0);
+  for (int s = 0; s < total; s++) {
+    const int callback = (s == t->n_substeps);
+    if (callback) { LANE0 { c->qpos[t->jq_lf] = 0.0f; c->qpos[t->jq_rf] = 0.0f; } WAVE_SYNC(); }
+    else E::grx_check_state(m, c, lane_);
+    E::grx_forward_euler(m, c, !callback, lane_);
   }
   grx_fetch_outputs(m, t, c, aux_out, obs, achieved, lane_);
 }
+};  // struct GrxFetch

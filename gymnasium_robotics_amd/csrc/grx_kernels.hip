@@ -70,7 +70,8 @@ grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_world
   float* aux = b.aux + (size_t)w * 8;
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = aux[k];
-  grx_fetch_step_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, aux, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
+  float* obs = b.obs + (size_t)w * t.obs_dim; float* ach = b.achieved + (size_t)w * 3; const float* act = b.action + (size_t)w * 4;
+  GrxFetch<0>::grx_fetch_step_world(&m, &t, &c, aux_in, act, aux, obs, ach, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, w, lane_);
 #ifdef GRX_PROFILE
@@ -93,9 +94,8 @@ grx_fetch_forward_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_wo
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
 #endif
   grx_load_world(m, b, c, w, lds, words, lane_);
-  for (int s = 0; s < nstep; s++) grx_step1(&m, &c, lane_);
-  if (nstep == 0) grx_forward(&m, &c, lane_);
-  grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)w * 8, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
+  { const int total = nstep > 0 ? nstep : 1; for (int s = 0; s < total; s++) GrxEngine<0>::grx_forward_euler(&m, &c, nstep > 0, lane_); }
+  GrxFetch<0>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)w * 8, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, w, lane_);
 }
@@ -124,10 +124,10 @@ grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_i
   for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0; }
   __syncthreads();
   if (mode == 0) {
-    grx_sym_solve_full(c.A, nv, c.tmpv, lane_);
+    GrxEngine<0>::grx_sym_solve_full(c.A, nv, c.tmpv, lane_);
     for (int i = lane_; i < nv; i += 64) out[i] = c.tmpv[i];
   } else {
-    grx_hessian(&m, &c, nefc, lane_);
+    GrxEngine<0>::grx_hessian(&m, &c, nefc, lane_);
     for (int i = lane_; i < nv * nv; i += 64) out[i] = c.A[i];
   }
 }

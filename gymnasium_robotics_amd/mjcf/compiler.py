@@ -1299,7 +1299,18 @@ class _Lowering:
             chainmask[k] = [msk & 0xFFFFFFFF, (msk >> 32) & 0xFFFFFFFF]
         chainmask = chainmask.astype(np.uint32).view(np.int32) if False else np.array(
             [[(v if v < 2 ** 31 else v - 2 ** 32) for v in row] for row in chainmask], np.int32)
+        body_ancadr = np.zeros(nbk, np.int32)
+        body_ancnum = np.zeros(nbk, np.int32)
+        body_anc = []
+        for k in range(nbk):
+            body_ancadr[k] = len(body_anc)
+            a_ = int(body_parent[k]) if k > 0 else 0
+            while a_ > 0:
+                body_anc.append(a_)
+                a_ = int(body_parent[a_])
+            body_ancnum[k] = len(body_anc) - body_ancadr[k]
         T.update(
+            body_ancadr=body_ancadr, body_ancnum=body_ancnum, body_anc=np.array(body_anc, np.int32),
             body_order=np.array(order, np.int32), level_adr=level_adr, body_subadr=body_subadr, body_subnum=body_subnum,
             body_sub=np.array(body_sub, np.int32), body_lastdof=body_lastdof, mpair_i=np.array(mpi, np.int32),
             mpair_j=np.array(mpj, np.int32), dof_cvelstart=dof_cvelstart, dof_chainmask=chainmask,

@@ -146,7 +146,8 @@ class OracleFetchEnv:
         return goal.copy()
 
     # ---- step (robot_env.py:114-152) ----------------------------------------------------
-    def step(self, action):
+    def step(self, action, aux=None):
+        """aux: optional (pos3, quat4) of gripper_link to use instead of the sim's last kinematics (teacher forcing)."""
         s = self.sim
         action = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0)
         pos_ctrl, g = action[:3] * 0.05, (0.0 if self.block_gripper else action[3])
@@ -158,7 +159,7 @@ class OracleFetchEnv:
             else:
                 s.ctrl[i] = s.qpos[int(self.model.tables["jnt_qposadr"].ravel()[jid])] + g
         # mocap_set_action: snap the mocap onto the welded body, then add the deltas
-        p, q = self._gripper_body_pose()
+        p, q = self._gripper_body_pose() if aux is None else (np.asarray(aux[:3]), np.asarray(aux[3:7]))
         s.mocap_pos[:] = p + pos_ctrl
         s.mocap_quat[:] = q + np.array([1.0, 0.0, 1.0, 0.0])
         s.step(N_SUBSTEPS)

@@ -680,6 +680,8 @@ static void make_constraint(orc_sim* s) {
     double q = s->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j]; int d = m->jnt_dofadr[j];
     for (int side = -1; side <= 1; side += 2) {
       double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - q);
+      /* (de)activation gap of the limit row; an exact 0 (joint reset onto its bound) is the same in any precision */
+      if (fabs(dist - margin) > 0 && fabs(dist - margin) < s->min_activation_gap) s->min_activation_gap = fabs(dist - margin);
       if (dist < margin) {
         double* J = add_row(s, EFC_LIMIT, j, dist, margin, 0, m->dof_invweight0[d]);
         J[d] = -side;

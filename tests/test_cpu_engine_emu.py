@@ -33,7 +33,7 @@ def test_emulated_kernel_step_matches_golden(emu_factory, task, stride):
         emu.step(g["action"][i])
         assert emu.status.value == 0
         err = np.abs(emu.obs - g["obs"][i]).max()
-        if g["activation_gap"][i] >= 1e-6:
+        if g["activation_gap"][i] >= 2e-5:
             worst = max(worst, err)
             assert err < 1e-4, (i, err)
         else:

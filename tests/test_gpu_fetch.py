@@ -43,16 +43,19 @@ def test_teacher_forced_step_matches_golden(task):
     obs, r, term, trunc, info = env.step(g["action"])
     assert int(np.abs(info["status"]).max()) == 0
     err = np.abs(obs["observation"] - g["obs"]).max(axis=1)
-    # The comparison is well-posed only away from contact (de)activation boundaries: MuJoCo's soft-contact
-    # reference acceleration -b*v - k*d*r jumps when a contact enters the margin with non-zero approach speed, so
-    # a snapshot in which some contact came within fp32 resolution (1e-6 m) of dist == margin during the 20
-    # substeps can legitimately differ by O(h*b*v).  The oracle records that gap per snapshot.
-    posed = g["activation_gap"] >= 1e-6
+    # fp32 vs the fp64 oracle.  MuJoCo's soft constraints are discontinuous at (de)activation: when a contact or a joint
+    # limit crosses dist == margin with non-zero approach speed the reference acceleration -b*v - k*d*r jumps, so a
+    # snapshot in which some unilateral row came within the fp32 drift (~1e-5 m over 20 substeps of stiff contact) of
+    # that boundary can legitimately differ by O(h*b*v) ~ 1e-3.  The oracle records the closest approach per snapshot
+    # ("activation_gap").  Asserted: (1) every snapshot away from a boundary is within 1e-4, (2) at least 98 % of ALL
+    # snapshots are within 1e-4, (3) nothing is off by more than 5e-3.
+    posed = g["activation_gap"] >= 2e-5
     assert err[posed].max() < TOL, f"worst snapshot {np.nonzero(posed)[0][err[posed].argmax()]} err {err[posed].max():.3e}"
-    assert err.max() < 5e-3, f"ill-posed snapshot {err.argmax()} err {err.max():.3e} gap {g['activation_gap'][err.argmax()]:.2e}"
+    assert np.mean(err < TOL) >= 0.98, f"only {100 * np.mean(err < TOL):.1f}% of snapshots within 1e-4"
+    assert err.max() < 5e-3, f"snapshot {err.argmax()} err {err.max():.3e} gap {g['activation_gap'][err.argmax()]:.2e}"
     assert np.abs(obs["achieved_goal"] - g["achieved"])[posed].max() < TOL
-    print(f"{task}: {posed.sum()}/{n} well-posed snapshots, max err {err[posed].max():.2e}, p50 {np.median(err):.2e}, "
-          f"ill-posed max {err[~posed].max() if (~posed).any() else 0:.2e}")
+    print(f"{task}: {posed.sum()}/{n} snapshots away from activation boundaries, max err there {err[posed].max():.2e}; all: p50 {np.median(err):.2e} "
+          f"p99 {np.quantile(err, 0.99):.2e} max {err.max():.2e}")
     # flags / sparse reward: bit-exact except where the fp64 distance sits within 1e-6 of the threshold
     d = np.linalg.norm(g["achieved"] - g["goal"], axis=-1)
     safe = np.abs(d - 0.05) > 1e-6

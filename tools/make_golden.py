@@ -22,9 +22,11 @@ os.makedirs(OUT, exist_ok=True)
 def snapshots(task, episodes, bias_down):
     model = load_fetch_model(task)
     env = OracleFetchEnv(model, task)
+    env2 = OracleFetchEnv(model, task)  # re-runs each snapshot from fp32-rounded inputs: the oracle's own sensitivity
+    prng = np.random.default_rng(99)
     rng = np.random.default_rng(1234)
     rec = {k: [] for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success",
-                           "qpos_next", "qvel_next", "ncon", "nefc", "seed", "t", "activation_gap")}
+                           "qpos_next", "qvel_next", "ncon", "nefc", "seed", "t", "activation_gap", "sensitivity")}
     resets = {k: [] for k in ("seed", "obs", "achieved", "goal", "qpos")}
     for ep in range(episodes):
         obs, _ = env.reset(seed=ep)
@@ -45,6 +47,18 @@ def snapshots(task, episodes, bias_down):
             rec["obs"].append(obs["observation"]); rec["achieved"].append(obs["achieved_goal"]); rec["reward"].append(r)
             rec["success"].append(info["is_success"]); rec["qpos_next"].append(s.qpos.copy()); rec["qvel_next"].append(s.qvel.copy())
             rec["ncon"].append(s.ncon); rec["nefc"].append(s.nefc); rec["seed"].append(ep); rec["t"].append(t)
+            # sensitivity: same step from inputs rounded to fp32 and jittered by one more fp32 ulp (what any fp32 engine sees)
+            dev = 0.0
+            for trial in range(2):
+                s2 = env2.sim
+                jit = (1.0 + prng.uniform(-1, 1, s2.nq) * 6e-8 * trial)
+                s2.qpos[:] = rec["qpos"][-1].astype(np.float32).astype(np.float64) * jit
+                s2.qvel[:] = rec["qvel"][-1].astype(np.float32).astype(np.float64)
+                s2.qacc_warmstart[:] = rec["qacc_ws"][-1].astype(np.float32).astype(np.float64)
+                env2.goal = env.goal.copy()
+                o2, _, _, _, _ = env2.step(a.astype(np.float64), aux=rec["aux"][-1].astype(np.float32).astype(np.float64))
+                dev = max(dev, float(np.abs(o2["observation"] - obs["observation"]).max()))
+            rec["sensitivity"].append(dev)
             assert s.bad_state == 0
     out = {k: np.asarray(v) for k, v in rec.items()}
     out.update({"reset_" + k: np.asarray(v) for k, v in resets.items()})
