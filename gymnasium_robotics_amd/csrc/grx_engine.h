@@ -52,8 +52,8 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_MINVAL 1e-15f
 #define GRX_MINIMP 0.0001f
 #define GRX_MAXIMP 0.9999f
-#define GRX_MAXCON 40
-#define GRX_MAXEFC 160
+#define GRX_MAXCON 32
+#define GRX_MAXEFC 128
 #define GRX_NEWTON_MAXIT 8
 #define GRX_NEWTON_RTOL 1e-5f
 #define GRX_NEWTON_ATOL 1e-5f
@@ -107,52 +107,48 @@ struct GrxCtx {
 #endif
 };
 
-// LDS footprint in 4-byte words for a model with the given dims
+// LDS layout.  Arrays that only live in the position/velocity stages of a substep (P1: local poses, spatial inertias,
+// body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
+// Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
+// body frames, motion axes, M, J, row parameters) is persistent.
 GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap) {
-  int w = 0;
-  w += nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;
-  w += 3 * nbody + 4 * nbody + 3 * njnt + 3 * njnt;
-  w += (3 + 4 + 9 + 10 + 10 + 6 + 6 + 6) * nbody;
-  w += 12 * ngeom + 12 * nsite;
-  w += 12 * nv;
-  w += 2 * nv * nv;
-  w += 12 * nv;
-  w += GRX_MAXCON * (1 + 3 + 9 + 5);
-  w += GRX_MAXEFC * nv + GRX_MAXEFC * (7 + 4);
-  w += 128 + 64 + 16;
-  return w;
+  int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
+  pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
+  pers += nv * nv + 7 * nv;                                          // M, qfrc_* / qacc vectors
+  pers += GRX_MAXEFC * nv + GRX_MAXEFC * 7;                          // J, efc_pos D aref floss kind id sub
+  pers += 128 + 64 + 16;                                             // red, ired, cnt
+  int p1 = 3 * nbody + 4 * nbody + 6 * njnt + (10 + 10 + 6 + 6 + 6) * nbody + 12 * ngeom + 6 * nv + GRX_MAXCON * (1 + 3 + 9 + 5);
+  int p2 = nv * nv + 5 * nv + 4 * GRX_MAXEFC;
+  return pers + (p1 > p2 ? p1 : p2) + 8;
 }
 
 GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
   float* p = base;
 #define CARVE(field, n) c->field = p; p += (n);
+#define CARVEI(field, n) c->field = (int*)p; p += (n);
+  // ---- persistent
   CARVE(qpos, m->nq) CARVE(qvel, m->nv) CARVE(qacc_ws, m->nv) CARVE(mocap_pos, 3 * m->nmocap) CARVE(mocap_quat, 4 * m->nmocap)
   CARVE(ctrl, m->nu)
-  CARVE(ploc, 3 * m->nbody) CARVE(qloc, 4 * m->nbody) CARVE(janchor, 3 * m->njnt) CARVE(jaxis, 3 * m->njnt)
-  CARVE(xpos, 3 * m->nbody) CARVE(xquat, 4 * m->nbody) CARVE(xmat, 9 * m->nbody) CARVE(cinert, 10 * m->nbody)
-  CARVE(crb, 10 * m->nbody) CARVE(cvel, 6 * m->nbody) CARVE(cacc, 6 * m->nbody) CARVE(cfrc, 6 * m->nbody)
-  CARVE(gxpos, 3 * m->ngeom) CARVE(gxmat, 9 * m->ngeom) CARVE(sxpos, 3 * m->nsite) CARVE(sxmat, 9 * m->nsite)
-  CARVE(cdof, 6 * m->nv) CARVE(cdof_dot, 6 * m->nv)
-  CARVE(M, m->nv * m->nv) CARVE(A, m->nv * m->nv)
+  CARVE(xpos, 3 * m->nbody) CARVE(xquat, 4 * m->nbody) CARVE(xmat, 9 * m->nbody) CARVE(sxpos, 3 * m->nsite) CARVE(sxmat, 9 * m->nsite)
+  CARVE(cdof, 6 * m->nv) CARVE(M, m->nv * m->nv)
   CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv) CARVE(qfrc_smooth, m->nv)
-  CARVE(qacc_smooth, m->nv) CARVE(qfrc_constraint, m->nv) CARVE(qacc, m->nv) CARVE(Ma, m->nv) CARVE(grad, m->nv)
-  CARVE(search, m->nv) CARVE(Mv, m->nv) CARVE(tmpv, m->nv)
+  CARVE(qacc_smooth, m->nv) CARVE(qfrc_constraint, m->nv) CARVE(qacc, m->nv)
+  CARVE(J, GRX_MAXEFC * m->nv) CARVE(efc_pos, GRX_MAXEFC) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC) CARVE(efc_floss, GRX_MAXEFC)
+  CARVEI(efc_kind, GRX_MAXEFC) CARVEI(efc_id, GRX_MAXEFC) CARVEI(efc_sub, GRX_MAXEFC)
+  CARVE(red, 128) CARVEI(ired, 64) CARVEI(cnt, 16)
+  float* overlay = p;
+  // ---- P1 (kinematics .. velocity stage)
+  CARVE(ploc, 3 * m->nbody) CARVE(qloc, 4 * m->nbody) CARVE(janchor, 3 * m->njnt) CARVE(jaxis, 3 * m->njnt)
+  CARVE(cinert, 10 * m->nbody) CARVE(crb, 10 * m->nbody) CARVE(cvel, 6 * m->nbody) CARVE(cacc, 6 * m->nbody) CARVE(cfrc, 6 * m->nbody)
+  CARVE(gxpos, 3 * m->ngeom) CARVE(gxmat, 9 * m->ngeom) CARVE(cdof_dot, 6 * m->nv)
   CARVE(con_dist, GRX_MAXCON) CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 9 * GRX_MAXCON)
-  c->con_pair = (int*)p; p += GRX_MAXCON;
-  c->con_efc = (int*)p; p += GRX_MAXCON;
-  c->con_nr = (int*)p; p += GRX_MAXCON;
-  c->con_b1 = (int*)p; p += GRX_MAXCON;
-  c->con_b2 = (int*)p; p += GRX_MAXCON;
-  CARVE(J, GRX_MAXEFC * m->nv) CARVE(efc_pos, GRX_MAXEFC) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC)
-  CARVE(efc_jar, GRX_MAXEFC) CARVE(efc_jv, GRX_MAXEFC) CARVE(efc_force, GRX_MAXEFC) CARVE(efc_floss, GRX_MAXEFC)
-  c->efc_kind = (int*)p; p += GRX_MAXEFC;
-  c->efc_id = (int*)p; p += GRX_MAXEFC;
-  c->efc_sub = (int*)p; p += GRX_MAXEFC;
-  c->efc_quad = (int*)p; p += GRX_MAXEFC;
-  CARVE(red, 128)
-  c->ired = (int*)p; p += 64;
-  c->cnt = (int*)p; p += 16;
+  CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
+  // ---- P2 (solve / integrate) on top of P1
+  p = overlay;
+  CARVE(A, m->nv * m->nv) CARVE(Ma, m->nv) CARVE(grad, m->nv) CARVE(search, m->nv) CARVE(Mv, m->nv) CARVE(tmpv, m->nv)
+  CARVE(efc_jar, GRX_MAXEFC) CARVE(efc_jv, GRX_MAXEFC) CARVE(efc_force, GRX_MAXEFC) CARVEI(efc_quad, GRX_MAXEFC)
 #undef CARVE
+#undef CARVEI
 }
 
 // ------------------------------------------------------------------------------------------
@@ -432,6 +428,7 @@ GRX_MEM void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
       if (b == 0) { c->crb[it] = 0; continue; }
       int a = m->body_subadr[b], n = m->body_subnum[b];
       float s = 0;
+#pragma unroll 8
       for (int e = 0; e < n; e++) s += c->cinert[10 * m->body_sub[a + e] + k];
       c->crb[it] = s;
     }
@@ -557,6 +554,7 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
       int b = it / 6, k = it - 6 * b;
       unsigned mlo = (unsigned)m->dof_chainmask[2 * b], mhi = (unsigned)m->dof_chainmask[2 * b + 1];
       float s = 0;
+#pragma unroll 8
       for (int d = 0; d < nv; d++) { unsigned bit = d < 32 ? (mlo >> d) & 1u : (mhi >> (d - 32)) & 1u; s += bit ? c->cdof[6 * d + k] * c->qvel[d] : 0.0f; }
       c->cvel[it] = s;
     }
@@ -572,6 +570,7 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
           msk = ((unsigned long long)(unsigned)m->dof_chainmask[2 * bb + 1] << 32) | (unsigned)m->dof_chainmask[2 * bb];
           msk &= (e0 >= 63) ? ~0ull : ((1ull << (e0 + 1)) - 1ull);  // drop same-body dofs after e0
         }
+#pragma unroll 4
         for (int e = 0; e < nv; e++) {
           float qd = ((msk >> e) & 1ull) ? c->qvel[e] : 0.0f;
           for (int k = 0; k < 6; k++) v[k] += c->cdof[6 * e + k] * qd;
@@ -598,6 +597,7 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
     for (int b = 1 + lane; b < m->nbody; b += 64) {
       float a[6] = {0, 0, 0, -m->gravity[0], -m->gravity[1], -m->gravity[2]}, v[6], Ia[6], Iv[6], t[6];
       unsigned mlo = (unsigned)m->dof_chainmask[2 * b], mhi = (unsigned)m->dof_chainmask[2 * b + 1];
+#pragma unroll 4
       for (int d = 0; d < nv; d++) {
         unsigned bit = d < 32 ? (mlo >> d) & 1u : (mhi >> (d - 32)) & 1u;
         float qd = bit ? c->qvel[d] : 0.0f;
@@ -631,6 +631,7 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
       if (b == 0) { c->cfrc[it] = 0; continue; }
       int a = m->body_subadr[b], n = m->body_subnum[b];
       float s = 0;
+#pragma unroll 8
       for (int e = 0; e < n; e++) s += c->cacc[6 * m->body_sub[a + e] + k];
       c->cfrc[it] = s;
     }
@@ -1025,8 +1026,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   LANE0 { c->cnt[1] = nefc; c->cnt[3] = ne; c->cnt[4] = nf; c->cnt[5] = nl; if (overflow) c->cnt[2] |= GRX_ST_EFC_OVERFLOW; }
   WAVE_SYNC();
   // ---- Jacobian rows.  zero fill, then per (row-group, dof) items
-  FOR_LANES { for (int i = lane; i < nefc * nv; i += 64) c->J[i] = 0; }
-  WAVE_SYNC();
+  // (every (row group, dof) item below writes all of its entries, zeros included: no separate clear of J)
   FOR_LANES {
     // welds: one lane per (weld, dof)
     for (int it = lane; it < (ne / 6) * nv; it += 64) {
@@ -1059,10 +1059,14 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     }
     // frictionloss + limits: one lane per row
     for (int r = ne + lane; r < ne + nf + nl && r < nefc; r += 64) {
-      if (c->efc_kind[r] == GRX_ROW_FRICTION) { c->J[r * nv + c->efc_id[r]] = 1.0f; c->efc_pos[r] = 0; }
-      else {
-        int j = c->efc_id[r], side = c->efc_sub[r]; float q = c->qpos[m->jnt_qposadr[j]];
-        c->J[r * nv + m->jnt_dofadr[j]] = side ? -1.0f : 1.0f;
+      if (c->efc_kind[r] == GRX_ROW_FRICTION) {
+        int dd = c->efc_id[r];
+        for (int d = 0; d < nv; d++) c->J[r * nv + d] = (d == dd) ? 1.0f : 0.0f;
+        c->efc_pos[r] = 0;
+      } else {
+        int j = c->efc_id[r], side = c->efc_sub[r], dd = m->jnt_dofadr[j]; float q = c->qpos[m->jnt_qposadr[j]];
+        float v = side ? -1.0f : 1.0f;
+        for (int d = 0; d < nv; d++) c->J[r * nv + d] = (d == dd) ? v : 0.0f;
         c->efc_pos[r] = side ? m->jnt_range[2 * j + 1] - q : q - m->jnt_range[2 * j];
       }
     }
@@ -1132,6 +1136,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       if (kind == GRX_ROW_FRICTION) kk = 0;
       float R = fmaxf(GRX_MINVAL, (1.0f - imp) * dA / imp) * rscale;
       float vel = 0;
+#pragma unroll 8
       for (int d = 0; d < nv; d++) vel += c->J[r * nv + d] * c->qvel[d];
       c->efc_D[r] = 1.0f / R;
       c->efc_aref[r] = -bb * vel - kk * imp * (pos - margin);
@@ -1153,14 +1158,14 @@ GRX_MEM float grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int 
     float part = 0;
     for (int i = lane; i < nv; i += 64) {
       float s = 0;
-#pragma unroll 1
+#pragma unroll 8
       for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * a[j];
       c->Ma[i] = s;
       part += 0.5f * s * a[i] - c->qfrc_smooth[i] * a[i];
     }
     for (int r = lane; r < nefc; r += 64) {
       float s = 0;
-#pragma unroll 1
+#pragma unroll 8
       for (int j = 0; j < nv; j++) s += c->J[r * nv + j] * a[j];
       float x = s - c->efc_aref[r], D = c->efc_D[r], f; int quad;
       int kind = c->efc_kind[r];
@@ -1291,7 +1296,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         FOR_LANES {
           for (int i = lane; i < nv; i += 64) {
             float sacc = 0;
-#pragma unroll 1
+#pragma unroll 8
             for (int r = 0; r < nefc; r++) sacc += c->J[r * nv + i] * c->efc_force[r];
             c->qfrc_constraint[i] = sacc; c->qacc_ws[i] = c->qacc[i];
           }
@@ -1308,7 +1313,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         float part = 0;
         for (int i = lane; i < nv; i += 64) {
           float sacc = c->Ma[i] - c->qfrc_smooth[i];
-#pragma unroll 1
+#pragma unroll 8
           for (int r = 0; r < nefc; r++) sacc -= c->J[r * nv + i] * c->efc_force[r];
           c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc;
         }
@@ -1327,9 +1332,11 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         WAVE_SYNC();
       } else {
         FOR_LANES {
-          for (int i = lane; i < nv * nv; i += 64) { int r = i / nv, q = i - r * nv; c->A[i] = c->M[i] + ((r == q) ? h * m->dof_damping[r] : 0.0f); }
+          for (int i = lane; i < nv * nv; i += 64) c->A[i] = c->M[i];
           for (int i = lane; i < nv; i += 64) c->tmpv[i] = c->qfrc_smooth[i] + c->qfrc_constraint[i];
         }
+        WAVE_SYNC();
+        FOR_LANES { for (int i = lane; i < nv; i += 64) c->A[i * nv + i] += h * m->dof_damping[i]; }
         WAVE_SYNC();
       }
       rhs = c->tmpv;
@@ -1344,37 +1351,35 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
     if (phase == 0) {
       GRX_TICK(c, GRX_P_NFACTOR);
       // Mv, Jv, quadratic coefficients of the Gauss term along the direction
-      GRX_LANEVAR(q1p); GRX_LANEVAR(q2p);
+      GRX_LANEVAR(q1p); GRX_LANEVAR(q2p); GRX_LANEVAR(g0p);
       FOR_LANES {
-        float p1 = 0, p2 = 0;
+        float p1 = 0, p2 = 0, p0 = 0;
         for (int i = lane; i < nv; i += 64) {
+          p0 += c->grad[i] * c->search[i];
           float sacc = 0;
-#pragma unroll 1
+#pragma unroll 8
           for (int j = 0; j < nv; j++) sacc += c->M[i * nv + j] * c->search[j];
           c->Mv[i] = sacc;
           p1 += c->search[i] * (c->Ma[i] - c->qfrc_smooth[i]); p2 += c->search[i] * sacc;
         }
         for (int r = lane; r < nefc; r += 64) {
           float sacc = 0;
-#pragma unroll 1
+#pragma unroll 8
           for (int j = 0; j < nv; j++) sacc += c->J[r * nv + j] * c->search[j];
           c->efc_jv[r] = sacc;
         }
-        LV(q1p) = p1; LV(q2p) = p2;
+        LV(q1p) = p1; LV(q2p) = p2; LV(g0p) = p0;
       }
       WAVE_SYNC();
-      const float q1 = grx_reduce_sum(q1p), q2 = grx_reduce_sum(q2p);
+      const float q1 = grx_reduce_sum(q1p), q2 = grx_reduce_sum(q2p), dphi0 = grx_reduce_sum(g0p);
       // exact line search: root of the monotone piecewise-linear derivative, starting from the Newton step
-      float d1, d2, alpha = 0.0f, lo = 0.0f, hi = 0.0f, dlo = 0.0f, dhi = 0.0f, gtol = 0.0f;
-      int have_hi = 0, stop = 0;
-      for (int k = 0; k < GRX_LS_MAXIT + 2; k++) {
+      // phi'(0) = gradient . search (exact, from the pass above); the first row pass is at the full Newton step
+      float d1, d2, alpha = 1.0f, lo = 0.0f, hi = 0.0f, dlo = dphi0, dhi = 0.0f;
+      const float gtol = 1e-6f * fabsf(dphi0);
+      int have_hi = 0;
+      const int stop = !(dphi0 < 0);
+      for (int k = 0; k < GRX_LS_MAXIT + 1 && !stop; k++) {
         grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
-        if (k == 0) {
-          dlo = d1;
-          if (!(dlo < 0)) { stop = 1; break; }
-          gtol = 1e-6f * fabsf(dlo); alpha = 1.0f;
-          continue;
-        }
         if (fabsf(d1) <= gtol) break;
         if (d1 < 0) { lo = alpha; dlo = d1; } else { hi = alpha; dhi = d1; have_hi = 1; }
         float na = alpha - d1 / d2;

@@ -53,7 +53,7 @@ extern "C" int grx_profile_read(long long* out) { return (int)hipMemcpyFromSymbo
 extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grx_prof), z, sizeof(z)); }
 #endif
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 2)
 grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int w = blockIdx.x, lane_ = threadIdx.x;

@@ -113,6 +113,17 @@ class FetchVecEnv(GoalVecEnv):
         self._elapsed = np.zeros(self.num_envs, np.int64)
         self._needs_reset = np.zeros(self.num_envs, bool)
         self._has_reset = False
+        self.kernel_events = None  # set to [] to collect (start, end) torch.cuda.Event pairs around every step-kernel launch
+
+    def _launch_step(self, bufs):
+        ev = self.kernel_events
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, self._stream()))
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, n):
@@ -227,11 +238,9 @@ class FetchVecEnv(GoalVecEnv):
             if len(pending):
                 self.mask.fill_(1)
                 self.mask[torch.from_numpy(pending).to(self.device)] = 0
-                _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs_masked), self.num_envs,
-                                                     self._stream()))
+                self._launch_step(self._bufs_masked)
             else:
-                _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs), self.num_envs,
-                                                     self._stream()))
+                self._launch_step(self._bufs)
             stepped = ~self._needs_reset if len(pending) else np.ones(self.num_envs, bool)
             self._elapsed[stepped] += 1
             truncated = np.zeros(self.num_envs, bool)
