@@ -55,8 +55,10 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_MAXCON 32
 #define GRX_MAXEFC 128
 #define GRX_NEWTON_MAXIT 8
+#ifndef GRX_NEWTON_RTOL
 #define GRX_NEWTON_RTOL 1e-5f
 #define GRX_NEWTON_ATOL 1e-5f
+#endif
 #define GRX_LS_MAXIT 12
 
 // status bits reported per world
@@ -97,7 +99,7 @@ struct GrxCtx {
   int *con_pair, *con_efc, *con_nr, *con_b1, *con_b2;
   // constraint rows
   float *J, *efc_pos, *efc_D, *efc_aref, *efc_jar, *efc_jv, *efc_force, *efc_floss;
-  int *efc_kind, *efc_id, *efc_sub, *efc_quad;
+  int *efc_kind, *efc_id, *efc_quad;  // efc_id packs (id << 4) | sub
   // scratch
   float* red;  // 128 floats
   int* ired;   // 64 ints
@@ -111,13 +113,15 @@ struct GrxCtx {
 // body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
 // Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
 // body frames, motion axes, M, J, row parameters) is persistent.
-GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap) {
+GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
-  pers += nv * nv + 7 * nv;                                          // M, qfrc_* / qacc vectors
-  pers += GRX_MAXEFC * nv + GRX_MAXEFC * 7;                          // J, efc_pos D aref floss kind id sub
-  pers += 128 + 64 + 16;                                             // red, ired, cnt
-  int p1 = 3 * nbody + 4 * nbody + 6 * njnt + (10 + 10 + 6 + 6 + 6) * nbody + 12 * ngeom + 6 * nv + GRX_MAXCON * (1 + 3 + 9 + 5);
+  pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
+  pers += GRX_MAXEFC * nv + GRX_MAXEFC * (4 + (nfric ? 1 : 0));      // J, efc D aref kind id|sub (+ floss)
+  pers += 32 + 8;                                                   // ired, cnt
+  int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
+  int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
+  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 9 + 5);
   int p2 = nv * nv + 5 * nv + 4 * GRX_MAXEFC;
   return pers + (p1 > p2 ? p1 : p2) + 8;
 }
@@ -131,16 +135,29 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
   CARVE(ctrl, m->nu)
   CARVE(xpos, 3 * m->nbody) CARVE(xquat, 4 * m->nbody) CARVE(xmat, 9 * m->nbody) CARVE(sxpos, 3 * m->nsite) CARVE(sxmat, 9 * m->nsite)
   CARVE(cdof, 6 * m->nv) CARVE(M, m->nv * m->nv)
-  CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv) CARVE(qfrc_smooth, m->nv)
-  CARVE(qacc_smooth, m->nv) CARVE(qfrc_constraint, m->nv) CARVE(qacc, m->nv)
-  CARVE(J, GRX_MAXEFC * m->nv) CARVE(efc_pos, GRX_MAXEFC) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC) CARVE(efc_floss, GRX_MAXEFC)
-  CARVEI(efc_kind, GRX_MAXEFC) CARVEI(efc_id, GRX_MAXEFC) CARVEI(efc_sub, GRX_MAXEFC)
-  CARVE(red, 128) CARVEI(ired, 64) CARVEI(cnt, 16)
+  CARVE(qfrc_smooth, m->nv) CARVE(qacc_smooth, m->nv) CARVE(qfrc_constraint, m->nv) CARVE(qacc, m->nv)
+  c->red = p;  // 128-float scratch of the big-mesh collision path; J is not written before the constraint stage
+  CARVE(J, GRX_MAXEFC * m->nv) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC)
+  c->efc_pos = c->efc_aref;  // residuals live in the aref slot until the per-row pass turns them into aref
+  c->efc_floss = p; if (m->nfric) p += GRX_MAXEFC;
+  CARVEI(efc_kind, GRX_MAXEFC) CARVEI(efc_id, GRX_MAXEFC)
+  CARVEI(ired, 32) CARVEI(cnt, 8)
   float* overlay = p;
   // ---- P1 (kinematics .. velocity stage)
-  CARVE(ploc, 3 * m->nbody) CARVE(qloc, 4 * m->nbody) CARVE(janchor, 3 * m->njnt) CARVE(jaxis, 3 * m->njnt)
-  CARVE(cinert, 10 * m->nbody) CARVE(crb, 10 * m->nbody) CARVE(cvel, 6 * m->nbody) CARVE(cacc, 6 * m->nbody) CARVE(cfrc, 6 * m->nbody)
-  CARVE(gxpos, 3 * m->ngeom) CARVE(gxmat, 9 * m->ngeom) CARVE(cdof_dot, 6 * m->nv)
+  {
+    float* u = p;  // union 1: local poses + joint frames (kinematics, inertia stage) | body velocity/force vectors (velocity stage)
+    CARVE(ploc, 3 * m->nbody) CARVE(qloc, 4 * m->nbody) CARVE(janchor, 3 * m->njnt) CARVE(jaxis, 3 * m->njnt)
+    float* e1 = p; p = u;
+    CARVE(cvel, 6 * m->nbody) CARVE(cacc, 6 * m->nbody) CARVE(cfrc, 6 * m->nbody)
+    if (e1 > p) p = e1;
+    u = p;         // union 2: composite inertias (inertia stage) | geom frames (collision stage)
+    CARVE(crb, 10 * m->nbody)
+    e1 = p; p = u;
+    CARVE(gxpos, 3 * m->ngeom) CARVE(gxmat, 9 * m->ngeom)
+    if (e1 > p) p = e1;
+  }
+  CARVE(cinert, 10 * m->nbody) CARVE(cdof_dot, 6 * m->nv)
+  CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv)
   CARVE(con_dist, GRX_MAXCON) CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 9 * GRX_MAXCON)
   CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
   // ---- P2 (solve / integrate) on top of P1
@@ -361,17 +378,13 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   FOR_LANES {
-    for (int g = lane; g < m->ngeom + m->nsite; g += 64) {
-      int isg = g < m->ngeom; int i = isg ? g : g - m->ngeom;
-      int b = isg ? m->geom_bodyid[i] : m->site_bodyid[i];
-      const float* lp = isg ? m->geom_pos + 3 * i : m->site_pos + 3 * i;
-      const float* lq = isg ? m->geom_quat + 4 * i : m->site_quat + 4 * i;
-      float* op = isg ? c->gxpos + 3 * i : c->sxpos + 3 * i; float* om = isg ? c->gxmat + 9 * i : c->sxmat + 9 * i;
-      float lpv[3] = {lp[0], lp[1], lp[2]}, lqv[4] = {lq[0], lq[1], lq[2], lq[3]}, v[3], R[9], Rw[9];
+    for (int i = lane; i < m->nsite; i += 64) {
+      int b = m->site_bodyid[i];
+      float lpv[3] = {m->site_pos[3 * i], m->site_pos[3 * i + 1], m->site_pos[3 * i + 2]}, lqv[4] = {m->site_quat[4 * i], m->site_quat[4 * i + 1], m->site_quat[4 * i + 2], m->site_quat[4 * i + 3]}, v[3], R[9], Rw[9];
       mulMatVec3f(v, c->xmat + 9 * b, lpv);
-      op[0] = c->xpos[3 * b] + v[0]; op[1] = c->xpos[3 * b + 1] + v[1]; op[2] = c->xpos[3 * b + 2] + v[2];
+      for (int e = 0; e < 3; e++) c->sxpos[3 * i + e] = c->xpos[3 * b + e] + v[e];
       quat2matf(R, lqv); mulMat3f(Rw, c->xmat + 9 * b, R);
-      for (int e = 0; e < 9; e++) om[e] = Rw[e];
+      for (int e = 0; e < 9; e++) c->sxmat[9 * i + e] = Rw[e];
     }
   }
   WAVE_SYNC();
@@ -844,6 +857,17 @@ GRX_MEM void grx_box_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2,
 }
 
 GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
+  // geom frames (they share LDS with the composite inertias of the previous stage)
+  FOR_LANES {
+    for (int i = lane; i < m->ngeom; i += 64) {
+      int b = m->geom_bodyid[i];
+      float lpv[3] = {m->geom_pos[3 * i], m->geom_pos[3 * i + 1], m->geom_pos[3 * i + 2]}, lqv[4] = {m->geom_quat[4 * i], m->geom_quat[4 * i + 1], m->geom_quat[4 * i + 2], m->geom_quat[4 * i + 3]}, v[3], R[9], Rw[9];
+      mulMatVec3f(v, c->xmat + 9 * b, lpv);
+      for (int e = 0; e < 3; e++) c->gxpos[3 * i + e] = c->xpos[3 * b + e] + v[e];
+      quat2matf(R, lqv); mulMat3f(Rw, c->xmat + 9 * b, R);
+      for (int e = 0; e < 9; e++) c->gxmat[9 * i + e] = Rw[e];
+    }
+  }
   LANE0 { c->cnt[0] = 0; c->cnt[7] = 0; }
   WAVE_SYNC();
   for (int base = 0; base < m->ndevpair; base += 64) {
@@ -867,14 +891,14 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           else if (t1 == 6 && t2 == 6) grx_box_box(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 7) {
             if (m->geom_meshnum[g2] <= 32) grx_plane_mesh_small(m, c, p, g1, g2, margin);
-            else { int q = GRX_ATOMIC_ADD(&c->cnt[7], 1); if (q < 64) c->ired[q] = p; }
+            else { int q = GRX_ATOMIC_ADD(&c->cnt[7], 1); if (q < 32) c->ired[q] = p; }
           }
         }
       }
     }
     WAVE_SYNC();
     // large hulls (a moving link near the plane): all lanes scan the vertices of one pair at a time
-    int nbig = c->cnt[7] < 64 ? c->cnt[7] : 64;
+    int nbig = c->cnt[7] < 32 ? c->cnt[7] : 32;
     for (int l = 0; l < nbig; l++) {
       int p = c->ired[l];
       int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
@@ -996,13 +1020,13 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     for (int r = lane; r < ne; r += 64) {  // welds are the only equality type in scope
       int e = 0, acc = 0;
       for (int q = 0; q < m->neq; q++) if (m->eq_active[q] && m->eq_type[q] == 1) { if (r < acc + 6) { e = q; break; } acc += 6; }
-      c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = e; c->efc_sub[r] = r - acc;
+      c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (e << 4) | (r - acc);
     }
     if (nf > 0)
       for (int d = lane; d < nv; d += 64) {
         if (m->dof_frictionloss[d] > 0) {
           int r = ne; for (int q = 0; q < d; q++) if (m->dof_frictionloss[q] > 0) r++;
-          c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d; c->efc_sub[r] = 0;
+          c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d << 4;
         }
       }
     for (int j = lane; j < m->njnt; j += 64) {
@@ -1010,8 +1034,8 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       if (f) {
         int r = ne + nf;
         for (int q = 0; q < j; q++) { int g = c->ired[q]; r += (g & 1) + ((g >> 1) & 1); }
-        if (f & 1) { if (r < GRX_MAXEFC) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j; c->efc_sub[r] = 0; } r++; }
-        if (f & 2) { if (r < GRX_MAXEFC) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j; c->efc_sub[r] = 1; } }
+        if (f & 1) { if (r < GRX_MAXEFC) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j << 4; } r++; }
+        if (f & 2) { if (r < GRX_MAXEFC) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = (j << 4) | 1; } }
       }
     }
     for (int k = lane; k < ncon; k += 64) {
@@ -1019,7 +1043,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       int r = ne + nf + nl;
       for (int q = 0; q < k; q++) r += c->con_nr[q];
       c->con_efc[k] = nr ? r : -1;
-      for (int q = 0; q < nr; q++) if (r + q < GRX_MAXEFC) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = k; c->efc_sub[r + q] = q; }
+      for (int q = 0; q < nr; q++) if (r + q < GRX_MAXEFC) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = (k << 4) | q; }
     }
   }
   if (overflow) nefc = GRX_MAXEFC;
@@ -1031,7 +1055,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     // welds: one lane per (weld, dof)
     for (int it = lane; it < (ne / 6) * nv; it += 64) {
       int w = it / nv, d = it - w * nv;
-      int e = c->efc_id[6 * w];
+      int e = c->efc_id[6 * w] >> 4;
       int b0 = m->eq_obj1[e], b1 = m->eq_obj2[e];
       const float* data = m->eq_data + 11 * e; const float* rel = m->eq_relpose + 14 * e;
       float bx[2][3], bq[2][4], pos[2][3];
@@ -1060,11 +1084,11 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     // frictionloss + limits: one lane per row
     for (int r = ne + lane; r < ne + nf + nl && r < nefc; r += 64) {
       if (c->efc_kind[r] == GRX_ROW_FRICTION) {
-        int dd = c->efc_id[r];
+        int dd = c->efc_id[r] >> 4;
         for (int d = 0; d < nv; d++) c->J[r * nv + d] = (d == dd) ? 1.0f : 0.0f;
         c->efc_pos[r] = 0;
       } else {
-        int j = c->efc_id[r], side = c->efc_sub[r], dd = m->jnt_dofadr[j]; float q = c->qpos[m->jnt_qposadr[j]];
+        int j = c->efc_id[r] >> 4, side = c->efc_id[r] & 15, dd = m->jnt_dofadr[j]; float q = c->qpos[m->jnt_qposadr[j]];
         float v = side ? -1.0f : 1.0f;
         for (int d = 0; d < nv; d++) c->J[r * nv + d] = (d == dd) ? v : 0.0f;
         c->efc_pos[r] = side ? m->jnt_range[2 * j + 1] - q : q - m->jnt_range[2 * j];
@@ -1098,12 +1122,12 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   // ---- per-row impedance, regulariser, reference acceleration
   FOR_LANES {
     for (int r = lane; r < nefc; r += 64) {
-      int kind = c->efc_kind[r], id = c->efc_id[r];
+      int kind = c->efc_kind[r], id = c->efc_id[r] >> 4, sub = c->efc_id[r] & 15;
       float solref[2], solimp[5], pos, margin = 0, dA, floss = 0, rscale = 1.0f;
       if (kind == GRX_ROW_EQ) {
         for (int k = 0; k < 2; k++) solref[k] = m->eq_solref[2 * id + k];
         for (int k = 0; k < 5; k++) solimp[k] = m->eq_solimp[5 * id + k];
-        pos = c->efc_pos[r]; dA = m->eq_invweight[2 * id + (c->efc_sub[r] >= 3)];
+        pos = c->efc_pos[r]; dA = m->eq_invweight[2 * id + (sub >= 3)];
       } else if (kind == GRX_ROW_FRICTION) {
         for (int k = 0; k < 2; k++) solref[k] = m->dof_solref[2 * id + k];
         for (int k = 0; k < 5; k++) solimp[k] = m->dof_solimp[5 * id + k];
@@ -1140,7 +1164,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       for (int d = 0; d < nv; d++) vel += c->J[r * nv + d] * c->qvel[d];
       c->efc_D[r] = 1.0f / R;
       c->efc_aref[r] = -bb * vel - kk * imp * (pos - margin);
-      c->efc_floss[r] = floss;
+      if (m->nfric) c->efc_floss[r] = floss;
     }
   }
   WAVE_SYNC();
@@ -1151,41 +1175,39 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
 // exact line search; wave-parallel over dofs / rows / Hessian entries.
 // ------------------------------------------------------------------------------------------
 // Ma = M a ; jar = J a - aref ; force / active flags ; returns total cost if want_cost
-GRX_MEM float grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int nefc, int want_cost, int lane_) {
+// Row states: 0 = inactive (satisfied inequality), 1 = quadratic, 2 / 3 = friction-loss row saturated at -f / +f.
+// Returns 1 if any row changed state with respect to the previous evaluation (stored in efc_quad), else 0.
+GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int nefc, int lane_) {
   const int nv = GRX_NVC;
-  GRX_LANEVAR(costp);
+  GRX_LANEVAR(chgp);
   FOR_LANES {
-    float part = 0;
+    float chg = 0;
     for (int i = lane; i < nv; i += 64) {
       float s = 0;
 #pragma unroll 8
       for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * a[j];
       c->Ma[i] = s;
-      part += 0.5f * s * a[i] - c->qfrc_smooth[i] * a[i];
     }
     for (int r = lane; r < nefc; r += 64) {
       float s = 0;
 #pragma unroll 8
       for (int j = 0; j < nv; j++) s += c->J[r * nv + j] * a[j];
-      float x = s - c->efc_aref[r], D = c->efc_D[r], f; int quad;
+      float x = s - c->efc_aref[r], D = c->efc_D[r], f; int st;
       int kind = c->efc_kind[r];
-      if (kind == GRX_ROW_EQ) { f = -D * x; part += 0.5f * D * x * x; quad = 1; }
+      if (kind == GRX_ROW_EQ) { f = -D * x; st = 1; }
       else if (kind == GRX_ROW_FRICTION) {
         float fl = c->efc_floss[r], Rf = fl / D;
-        if (x <= -Rf) { f = fl; part += -0.5f * Rf * fl - fl * x; quad = 0; }
-        else if (x >= Rf) { f = -fl; part += -0.5f * Rf * fl + fl * x; quad = 0; }
-        else { f = -D * x; part += 0.5f * D * x * x; quad = 1; }
+        if (x <= -Rf) { f = fl; st = 3; } else if (x >= Rf) { f = -fl; st = 2; } else { f = -D * x; st = 1; }
       } else {
-        if (x < 0) { f = -D * x; part += 0.5f * D * x * x; quad = 1; } else { f = 0; quad = 0; }
+        if (x < 0) { f = -D * x; st = 1; } else { f = 0; st = 0; }
       }
-      c->efc_jar[r] = x; c->efc_force[r] = f; c->efc_quad[r] = quad;
+      if (st != c->efc_quad[r]) chg = 1.0f;
+      c->efc_jar[r] = x; c->efc_force[r] = f; c->efc_quad[r] = st;
     }
-    LV(costp) = part;
+    LV(chgp) = chg;
   }
   WAVE_SYNC();
-  float cost = 0;
-  if (want_cost) cost = grx_reduce_sum(costp);
-  return cost;
+  return grx_reduce_max(chgp) > 0.5f;
 }
 
 // derivative (d1) and curvature (d2) of the cost along the search direction at step alpha
@@ -1212,7 +1234,7 @@ GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, f
 GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   const int nv = GRX_NVC;
     // Hessian H = M + J' diag(D_active) J
-  FOR_LANES { for (int r = lane; r < nefc; r += 64) c->efc_jv[r] = c->efc_quad[r] ? c->efc_D[r] : 0.0f; }  // efc_jv reused as scratch
+  FOR_LANES { for (int r = lane; r < nefc; r += 64) c->efc_jv[r] = (c->efc_quad[r] == 1) ? c->efc_D[r] : 0.0f; }  // efc_jv reused as scratch
   WAVE_SYNC();
 #if !defined(GRX_EMU)
   if (nv <= 32) {
@@ -1279,7 +1301,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const int nefc = c->cnt[1];
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   const int implicit_damp = (m->anydamp && m->eulerdamp);
-  int phase = nefc ? 0 : 2, it = 0, done = 0;
+  int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0;
   // Newton starts from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart,
   // M^-1 qfrc_smooth); the minimiser of the strictly convex problem does not depend on the start, and skipping the
   // comparison saves one factorisation of M per substep.
@@ -1289,8 +1311,11 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   for (;;) {
     float* rhs;
     if (phase == 0) {
-      grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
+      const int changed = grx_newton_eval(m, c, c->qacc, nefc, lane_);
       GRX_TICK(c, GRX_P_NEVAL);
+      // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
+      // piecewise-quadratic cost: no further iteration can move it beyond rounding
+      if (it > 0 && full_step && !changed) done = 1;
       if (done || it >= GRX_NEWTON_MAXIT) {
         // converged: constraint forces from the evaluation just made
         FOR_LANES {
@@ -1378,9 +1403,10 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       const float gtol = 1e-6f * fabsf(dphi0);
       int have_hi = 0;
       const int stop = !(dphi0 < 0);
+      full_step = 0;
       for (int k = 0; k < GRX_LS_MAXIT + 1 && !stop; k++) {
         grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
-        if (fabsf(d1) <= gtol) break;
+        if (fabsf(d1) <= gtol) { full_step = (k == 0); break; }
         if (d1 < 0) { lo = alpha; dlo = d1; } else { hi = alpha; dhi = d1; have_hi = 1; }
         float na = alpha - d1 / d2;
         if (have_hi) { if (!(na > lo && na < hi)) na = lo + (hi - lo) * (dlo / (dlo - dhi)); if (!(na > lo && na < hi)) na = 0.5f * (lo + hi); }

@@ -121,7 +121,7 @@ grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_i
   for (int i = lane_; i < nv * nv; i += 64) { c.A[i] = A_in[i]; c.M[i] = A_in[i]; }
   for (int i = lane_; i < nv; i += 64) c.tmpv[i] = b_in[i];
   for (int i = lane_; i < nefc * nv; i += 64) c.J[i] = J_in[i];
-  for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0; }
+  for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0 ? 1 : 0; }
   __syncthreads();
   if (mode == 0) {
     GrxEngine<0>::grx_sym_solve_full(c.A, nv, c.tmpv, lane_);
@@ -166,9 +166,11 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   HIP_OK(hipMemcpy(m->d_i, m->pm.i.data(), sizeof(int32_t) * m->pm.i.size(), hipMemcpyHostToDevice));
   m->dev = grx_bind_model(m->pm, m->d_f, m->d_i);
   const GrxModel& g = m->dev;
-  m->words = grx_ctx_words(g.nq, g.nv, g.nu, g.nbody, g.njnt, g.ngeom, g.nsite, g.nmocap);
+  m->words = grx_ctx_words(g.nq, g.nv, g.nu, g.nbody, g.njnt, g.ngeom, g.nsite, g.nmocap, g.nfric);
   int bytes = m->words * 4;
   if (bytes > 160 * 1024) return fail("model working set exceeds the 160 KiB LDS of a CU");
+  if (g.njnt > 32) return fail("engine limit: at most 32 joints per world (limit-flag table in LDS)");
+  if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   *out = m;
