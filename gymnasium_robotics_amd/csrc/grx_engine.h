@@ -53,7 +53,8 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_MINIMP 0.0001f
 #define GRX_MAXIMP 0.9999f
 #define GRX_MAXCON 32
-#define GRX_MAXEFC 128
+#define GRX_MAXEFC 144   // constraint rows per world
+#define GRX_JPOOL 2032    // words of packed Jacobian storage per world (rows are stored over their dof span only)
 #define GRX_NEWTON_MAXIT 8
 #ifndef GRX_NEWTON_RTOL
 #define GRX_NEWTON_RTOL 1e-5f
@@ -96,10 +97,11 @@ struct GrxCtx {
       *Mv, *tmpv;
   // contacts
   float *con_dist, *con_pos, *con_frame;
-  int *con_pair, *con_efc, *con_nr, *con_b1, *con_b2;
+  int *con_pair, *con_efc, *con_nr, *con_b1, *con_b2, *con_span;  // con_span = lo | len << 8 of the union dof chain
   // constraint rows
-  float *J, *efc_pos, *efc_D, *efc_aref, *efc_jar, *efc_jv, *efc_force, *efc_floss;
-  int *efc_kind, *efc_id, *efc_quad;  // efc_id packs (id << 4) | sub
+  // Jacobian rows are stored packed: row r covers dofs [lo, lo+len) at Jp[off .. off+len); efc_row[r] = off | lo << 12 | len << 20
+  float *Jp, *efc_pos, *efc_D, *efc_aref, *efc_jar, *efc_jv, *efc_force, *efc_floss;
+  int *efc_kind, *efc_id, *efc_quad, *efc_row;  // efc_id packs (id << 4) | sub
   // scratch
   float* red;  // 128 floats
   int* ired;   // 64 ints
@@ -117,11 +119,11 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
-  pers += GRX_MAXEFC * nv + GRX_MAXEFC * (4 + (nfric ? 1 : 0));      // J, efc D aref kind id|sub (+ floss)
+  pers += GRX_JPOOL + GRX_MAXEFC * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
   pers += 32 + 8;                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
-  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 9 + 5);
+  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 3 + 6);
   int p2 = nv * nv + 5 * nv + 4 * GRX_MAXEFC;
   return pers + (p1 > p2 ? p1 : p2) + 8;
 }
@@ -136,11 +138,11 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
   CARVE(xpos, 3 * m->nbody) CARVE(xquat, 4 * m->nbody) CARVE(xmat, 9 * m->nbody) CARVE(sxpos, 3 * m->nsite) CARVE(sxmat, 9 * m->nsite)
   CARVE(cdof, 6 * m->nv) CARVE(M, m->nv * m->nv)
   CARVE(qfrc_smooth, m->nv) CARVE(qacc_smooth, m->nv) CARVE(qfrc_constraint, m->nv) CARVE(qacc, m->nv)
-  c->red = p;  // 128-float scratch of the big-mesh collision path; J is not written before the constraint stage
-  CARVE(J, GRX_MAXEFC * m->nv) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC)
+  c->red = p;  // 128-float scratch of the big-mesh collision path; the Jacobian pool is not written before the constraint stage
+  CARVE(Jp, GRX_JPOOL) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC)
   c->efc_pos = c->efc_aref;  // residuals live in the aref slot until the per-row pass turns them into aref
   c->efc_floss = p; if (m->nfric) p += GRX_MAXEFC;
-  CARVEI(efc_kind, GRX_MAXEFC) CARVEI(efc_id, GRX_MAXEFC)
+  CARVEI(efc_kind, GRX_MAXEFC) CARVEI(efc_id, GRX_MAXEFC) CARVEI(efc_row, GRX_MAXEFC)
   CARVEI(ired, 32) CARVEI(cnt, 8)
   float* overlay = p;
   // ---- P1 (kinematics .. velocity stage)
@@ -158,8 +160,9 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
   }
   CARVE(cinert, 10 * m->nbody) CARVE(cdof_dot, 6 * m->nv)
   CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv)
-  CARVE(con_dist, GRX_MAXCON) CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 9 * GRX_MAXCON)
+  CARVE(con_dist, GRX_MAXCON) CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 3 * GRX_MAXCON)  // con_frame: contact normal only
   CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
+  CARVEI(con_span, GRX_MAXCON)
   // ---- P2 (solve / integrate) on top of P1
   p = overlay;
   CARVE(A, m->nv * m->nv) CARVE(Ma, m->nv) CARVE(grad, m->nv) CARVE(search, m->nv) CARVE(Mv, m->nv) CARVE(tmpv, m->nv)
@@ -679,7 +682,7 @@ GRX_MEM void grx_add_contact(GrxCtx* c, int pair, const float* pos, const float*
   int slot = GRX_ATOMIC_ADD(&c->cnt[0], 1);
   if (slot >= GRX_MAXCON) { c->cnt[2] |= GRX_ST_CON_OVERFLOW; return; }
   c->con_dist[slot] = dist; c->con_pair[slot] = pair;
-  for (int k = 0; k < 3; k++) { c->con_pos[3 * slot + k] = pos[k]; c->con_frame[9 * slot + k] = normal[k]; }
+  for (int k = 0; k < 3; k++) { c->con_pos[3 * slot + k] = pos[k]; c->con_frame[3 * slot + k] = normal[k]; }
 }
 
 GRX_MEM void grx_plane_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
@@ -942,16 +945,6 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   }
   LANE0 { if (c->cnt[0] > GRX_MAXCON) c->cnt[0] = GRX_MAXCON; }
   WAVE_SYNC();
-  // complete the tangent frames, one lane per contact
-  FOR_LANES {
-    for (int k = lane; k < c->cnt[0]; k += 64) {
-      float f[9];
-      for (int e = 0; e < 3; e++) f[e] = c->con_frame[9 * k + e];
-      grx_make_frame(f);
-      for (int e = 3; e < 9; e++) c->con_frame[9 * k + e] = f[e];
-    }
-  }
-  WAVE_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -985,6 +978,20 @@ GRX_MEM void grx_jac_col(const GrxModel* m, const GrxCtx* c, int b, const float*
   jr[0] = w[0]; jr[1] = w[1]; jr[2] = w[2]; jp[0] = cd[3] + t[0]; jp[1] = cd[4] + t[1]; jp[2] = cd[5] + t[2];
 }
 
+// dof span [lo, lo+len) of a 64-bit dof mask
+GRX_MEM void grx_mask_span(unsigned long long msk, int* lo, int* len) {
+  if (!msk) { *lo = 0; *len = 0; return; }
+  int l = __builtin_ctzll(msk), h = 63 - __builtin_clzll(msk);
+  *lo = l; *len = h - l + 1;
+}
+GRX_MEM unsigned long long grx_chainmask(const GrxModel* m, int b) {
+  return ((unsigned long long)(unsigned)m->dof_chainmask[2 * b + 1] << 32) | (unsigned)m->dof_chainmask[2 * b];
+}
+#define GRX_ROW_OFF(info) ((info) & 0xFFF)
+#define GRX_ROW_LO(info) (((info) >> 12) & 0xFF)
+#define GRX_ROW_LEN(info) (((info) >> 20) & 0xFF)
+#define GRX_ROW_PACK(off, lo, len) ((off) | ((lo) << 12) | ((len) << 20))
+
 GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   const int nv = GRX_NVC;
   int ncon = c->cnt[0];
@@ -1005,28 +1012,45 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       int p = c->con_pair[k], dim = m->pair_condim[p];
       int active = c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p];
       c->con_nr[k] = active ? ((dim == 1) ? 1 : 2 * (dim - 1)) : 0;
-      c->con_b1[k] = m->geom_bodyid[m->pair_geom1[p]]; c->con_b2[k] = m->geom_bodyid[m->pair_geom2[p]];
+      int cb1 = m->geom_bodyid[m->pair_geom1[p]], cb2 = m->geom_bodyid[m->pair_geom2[p]], slo, slen;
+      c->con_b1[k] = cb1; c->con_b2[k] = cb2;
+      grx_mask_span(grx_chainmask(m, cb1) | grx_chainmask(m, cb2), &slo, &slen);
+      c->con_span[k] = slo | (slen << 8);
     }
   }
   WAVE_SYNC();
   int nl = 0;
   for (int j = 0; j < m->njnt; j++) { int f = c->ired[j]; nl += (f & 1) + ((f >> 1) & 1); }
-  int nc = 0;
-  for (int k = 0; k < ncon; k++) nc += c->con_nr[k];
+  // pool words used by the welds (all six rows of a weld share the span of the two body chains)
+  int wpool = 0;
+  for (int q = 0; q < m->neq; q++)
+    if (m->eq_active[q] && m->eq_type[q] == 1) { int slo, slen; grx_mask_span(grx_chainmask(m, m->eq_obj1[q]) | grx_chainmask(m, m->eq_obj2[q]), &slo, &slen); wpool += 6 * slen; }
+  // contacts come last: keep as many whole contacts as fit into the row table and the Jacobian pool
+  int nc = 0, pool = wpool + nf + nl, overflow = (ne + nf + nl > GRX_MAXEFC) || (pool > GRX_JPOOL), ncon_fit = ncon;
+  for (int k = 0; k < ncon; k++) {
+    int nr = c->con_nr[k], need = nr * (c->con_span[k] >> 8);
+    if (k < ncon_fit && (ne + nf + nl + nc + nr > GRX_MAXEFC || pool + need > GRX_JPOOL)) { ncon_fit = k; overflow = 1; }
+    if (k < ncon_fit) { nc += nr; pool += need; }
+  }
   int nefc = ne + nf + nl + nc;
-  int overflow = nefc > GRX_MAXEFC;
+  if (nefc > GRX_MAXEFC) nefc = GRX_MAXEFC;
   // ---- descriptors
   FOR_LANES {
     for (int r = lane; r < ne; r += 64) {  // welds are the only equality type in scope
       int e = 0, acc = 0;
       for (int q = 0; q < m->neq; q++) if (m->eq_active[q] && m->eq_type[q] == 1) { if (r < acc + 6) { e = q; break; } acc += 6; }
       c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (e << 4) | (r - acc);
+      int slo, slen, woff = 0;
+      for (int q = 0; q < e; q++)
+        if (m->eq_active[q] && m->eq_type[q] == 1) { grx_mask_span(grx_chainmask(m, m->eq_obj1[q]) | grx_chainmask(m, m->eq_obj2[q]), &slo, &slen); woff += 6 * slen; }
+      grx_mask_span(grx_chainmask(m, m->eq_obj1[e]) | grx_chainmask(m, m->eq_obj2[e]), &slo, &slen);
+      c->efc_row[r] = GRX_ROW_PACK(woff + (r - acc) * slen, slo, slen);
     }
     if (nf > 0)
       for (int d = lane; d < nv; d += 64) {
         if (m->dof_frictionloss[d] > 0) {
           int r = ne; for (int q = 0; q < d; q++) if (m->dof_frictionloss[q] > 0) r++;
-          c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d << 4;
+          c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), d, 1);
         }
       }
     for (int j = lane; j < m->njnt; j += 64) {
@@ -1034,19 +1058,20 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       if (f) {
         int r = ne + nf;
         for (int q = 0; q < j; q++) { int g = c->ired[q]; r += (g & 1) + ((g >> 1) & 1); }
-        if (f & 1) { if (r < GRX_MAXEFC) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j << 4; } r++; }
-        if (f & 2) { if (r < GRX_MAXEFC) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = (j << 4) | 1; } }
+        int dd = m->jnt_dofadr[j];
+        if (f & 1) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); } r++; }
+        if (f & 2) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = (j << 4) | 1; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); } }
       }
     }
     for (int k = lane; k < ncon; k += 64) {
-      int nr = c->con_nr[k];
-      int r = ne + nf + nl;
-      for (int q = 0; q < k; q++) r += c->con_nr[q];
+      int nr = (k < ncon_fit) ? c->con_nr[k] : 0;
+      int r = ne + nf + nl, off = wpool + nf + nl;
+      for (int q = 0; q < k; q++) { r += c->con_nr[q]; off += c->con_nr[q] * (c->con_span[q] >> 8); }
       c->con_efc[k] = nr ? r : -1;
-      for (int q = 0; q < nr; q++) if (r + q < GRX_MAXEFC) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = (k << 4) | q; }
+      int slo = c->con_span[k] & 0xFF, slen = c->con_span[k] >> 8;
+      for (int q = 0; q < nr; q++) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = (k << 4) | q; c->efc_row[r + q] = GRX_ROW_PACK(off + q * slen, slo, slen); }
     }
   }
-  if (overflow) nefc = GRX_MAXEFC;
   LANE0 { c->cnt[1] = nefc; c->cnt[3] = ne; c->cnt[4] = nf; c->cnt[5] = nl; if (overflow) c->cnt[2] |= GRX_ST_EFC_OVERFLOW; }
   WAVE_SYNC();
   // ---- Jacobian rows.  zero fill, then per (row-group, dof) items
@@ -1075,7 +1100,9 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       mulQuatf(quat, bq[0], relq);
       float axis[4] = {0, jr0[0] - jr1[0], jr0[1] - jr1[1], jr0[2] - jr1[2]}, t1[4], t2[4];
       mulQuatf(t1, quat1, axis); mulQuatf(t2, t1, quat);
-      for (int r = 0; r < 3; r++) { c->J[(6 * w + r) * nv + d] = jp0[r] - jp1[r]; c->J[(6 * w + 3 + r) * nv + d] = 0.5f * ts * t2[1 + r]; }
+      { int info = c->efc_row[6 * w], jd = d - GRX_ROW_LO(info), len = GRX_ROW_LEN(info), off = GRX_ROW_OFF(info);
+        if ((unsigned)jd < (unsigned)len)
+          for (int r = 0; r < 3; r++) { c->Jp[off + r * len + jd] = jp0[r] - jp1[r]; c->Jp[off + (3 + r) * len + jd] = 0.5f * ts * t2[1 + r]; } }
       if (d == 0) {  // residuals (one lane per weld)
         float quat2[4]; mulQuatf(quat2, quat1, quat);
         for (int r = 0; r < 3; r++) { c->efc_pos[6 * w + r] = pos[0][r] - pos[1][r]; c->efc_pos[6 * w + 3 + r] = ts * quat2[1 + r]; }
@@ -1084,37 +1111,40 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     // frictionloss + limits: one lane per row
     for (int r = ne + lane; r < ne + nf + nl && r < nefc; r += 64) {
       if (c->efc_kind[r] == GRX_ROW_FRICTION) {
-        int dd = c->efc_id[r] >> 4;
-        for (int d = 0; d < nv; d++) c->J[r * nv + d] = (d == dd) ? 1.0f : 0.0f;
+        c->Jp[GRX_ROW_OFF(c->efc_row[r])] = 1.0f;
         c->efc_pos[r] = 0;
       } else {
-        int j = c->efc_id[r] >> 4, side = c->efc_id[r] & 15, dd = m->jnt_dofadr[j]; float q = c->qpos[m->jnt_qposadr[j]];
-        float v = side ? -1.0f : 1.0f;
-        for (int d = 0; d < nv; d++) c->J[r * nv + d] = (d == dd) ? v : 0.0f;
+        int j = c->efc_id[r] >> 4, side = c->efc_id[r] & 15; float q = c->qpos[m->jnt_qposadr[j]];
+        c->Jp[GRX_ROW_OFF(c->efc_row[r])] = side ? -1.0f : 1.0f;
         c->efc_pos[r] = side ? m->jnt_range[2 * j + 1] - q : q - m->jnt_range[2 * j];
       }
     }
-    // contacts: one lane per (contact, dof)
+    // contacts: one lane per (contact, dof of its span)
     for (int it = lane; it < ncon * nv; it += 64) {
-      int k = it / nv, d = it - k * nv;
+      int k = it / nv, jd = it - k * nv;
       int r0 = c->con_efc[k];
       if (r0 < 0) continue;
+      int slo = c->con_span[k] & 0xFF, slen = c->con_span[k] >> 8;
+      if (jd >= slen) continue;
+      int d = slo + jd;
       int p = c->con_pair[k], nrk = c->con_nr[k], dim = (nrk == 1) ? 1 : nrk / 2 + 1;
       int b1 = c->con_b1[k], b2 = c->con_b2[k];
       float pos[3] = {c->con_pos[3 * k], c->con_pos[3 * k + 1], c->con_pos[3 * k + 2]};
       float jp1[3], jr1[3], jp2[3], jr2[3];
       grx_jac_col(m, c, b1, pos, d, jp1, jr1); grx_jac_col(m, c, b2, pos, d, jp2, jr2);
       float dp[3] = {jp2[0] - jp1[0], jp2[1] - jp1[1], jp2[2] - jp1[2]}, dr[3] = {jr2[0] - jr1[0], jr2[1] - jr1[1], jr2[2] - jr1[2]};
-      const float* fr = c->con_frame + 9 * k;
+      float fr[9] = {c->con_frame[3 * k], c->con_frame[3 * k + 1], c->con_frame[3 * k + 2], 0, 0, 0, 0, 0, 0};
+      grx_make_frame(fr);
       float jc[6];
       for (int r = 0; r < 3; r++) { jc[r] = fr[3 * r] * dp[0] + fr[3 * r + 1] * dp[1] + fr[3 * r + 2] * dp[2]; jc[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2]; }
-      if (dim == 1) { if (r0 < nefc) c->J[r0 * nv + d] = jc[0]; }
+      const int off0 = GRX_ROW_OFF(c->efc_row[r0]);
+      if (dim == 1) c->Jp[off0 + jd] = jc[0];
       else
         for (int q = 1; q < dim; q++) {
           float mu = m->pair_friction[5 * p + q - 1];
-          int ra = r0 + 2 * (q - 1);
-          if (ra < nefc) c->J[ra * nv + d] = jc[0] + mu * jc[q];
-          if (ra + 1 < nefc) c->J[(ra + 1) * nv + d] = jc[0] - mu * jc[q];
+          int ro = off0 + 2 * (q - 1) * slen + jd;
+          c->Jp[ro] = jc[0] + mu * jc[q];
+          c->Jp[ro + slen] = jc[0] - mu * jc[q];
         }
     }
   }
@@ -1160,8 +1190,9 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       if (kind == GRX_ROW_FRICTION) kk = 0;
       float R = fmaxf(GRX_MINVAL, (1.0f - imp) * dA / imp) * rscale;
       float vel = 0;
+      { const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
 #pragma unroll 8
-      for (int d = 0; d < nv; d++) vel += c->J[r * nv + d] * c->qvel[d];
+        for (int j = 0; j < len; j++) vel += c->Jp[off + j] * c->qvel[lo + j]; }
       c->efc_D[r] = 1.0f / R;
       c->efc_aref[r] = -bb * vel - kk * imp * (pos - margin);
       if (m->nfric) c->efc_floss[r] = floss;
@@ -1190,8 +1221,9 @@ GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int ne
     }
     for (int r = lane; r < nefc; r += 64) {
       float s = 0;
+      { const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
 #pragma unroll 8
-      for (int j = 0; j < nv; j++) s += c->J[r * nv + j] * a[j];
+        for (int j = 0; j < len; j++) s += c->Jp[off + j] * a[lo + j]; }
       float x = s - c->efc_aref[r], D = c->efc_D[r], f; int st;
       int kind = c->efc_kind[r];
       if (kind == GRX_ROW_EQ) { f = -D * x; st = 1; }
@@ -1231,14 +1263,16 @@ GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, f
 }
 
 // H = M + J' diag(D_active) J  ->  c->A   (efc_jv is used as scratch for the masked D)
+// Also returns J' f (the constraint force in joint space for the row forces of the last evaluation) in c->grad: on the
+// matrix-core path it rides along as one extra output column of the same MFMA chain.
 GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   const int nv = GRX_NVC;
     // Hessian H = M + J' diag(D_active) J
   FOR_LANES { for (int r = lane; r < nefc; r += 64) c->efc_jv[r] = (c->efc_quad[r] == 1) ? c->efc_D[r] : 0.0f; }  // efc_jv reused as scratch
   WAVE_SYNC();
 #if !defined(GRX_EMU)
-  if (nv <= 32) {
-    // matrix cores: H = (D J)' J as a chain of v_mfma_f32_32x32x2_f32 (exact f32, two constraint rows per instruction).
+  if (nv < 32) {
+    // matrix cores: [H | J'f] = J' [D J | f] as a chain of v_mfma_f32_32x32x2_f32 (exact f32, two constraint rows per instruction).
     // operand maps: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; C: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     f32x16 acc;
@@ -1246,16 +1280,30 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     for (int e = 0; e < 16; e++) acc[e] = 0.0f;
     const int idx = lane_ & 31, half = lane_ >> 5;
     const bool incol = idx < nv;
+    // branch-free operand fetch (clamped addresses, selects instead of divergent paths) so that the LDS reads of
+    // several row pairs are in flight together
+    const bool isf = (idx == nv);
+#pragma unroll 4
     for (int r0 = 0; r0 < nefc; r0 += 2) {
       const int row = r0 + half;
-      float v = 0.0f, d = 0.0f;
-      if (incol && row < nefc) { v = c->J[row * nv + idx]; d = c->efc_jv[row]; }
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v * d, v, acc, 0, 0, 0);
+      const bool rowok = row < nefc;
+      const int rr = rowok ? row : 0;
+      const int info = c->efc_row[rr];
+      const float dq = c->efc_jv[rr], fr = c->efc_force[rr];
+      const int jd = idx - GRX_ROW_LO(info);
+      const bool in = rowok && incol && ((unsigned)jd < (unsigned)GRX_ROW_LEN(info));
+      const float v = c->Jp[GRX_ROW_OFF(info) + (in ? jd : 0)];
+      const float a = in ? v : 0.0f;                                   // A[i = idx][k = row] = J[row][idx]
+      const float b = in ? v * dq : ((isf && rowok) ? fr : 0.0f);     // B[k = row][j = idx] = D J[row][idx]; column nv: f[row]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-      if (i < nv && incol) c->A[i * nv + idx] = c->M[i * nv + idx] + acc[e];
+      if (i < nv) {
+        if (incol) c->A[i * nv + idx] = c->M[i * nv + idx] + acc[e];
+        else if (idx == nv) c->grad[i] = acc[e];
+      }
     }
     __syncthreads();
   } else
@@ -1271,10 +1319,12 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
         const int i1 = i0 + 8, i2 = i0 + 16, j1 = j0 + 8, j2 = j0 + 16;
         const int vi1 = i1 < nv, vi2 = i2 < nv, vj1 = j1 < nv, vj2 = j2 < nv;
         for (int r = 0; r < nefc; r++) {
-          const float* Jr = c->J + r * nv;
+          const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
+#define GRX_JAT(dof) (((unsigned)((dof) - lo) < (unsigned)len) ? c->Jp[off + (dof) - lo] : 0.0f)
           float d = c->efc_jv[r];
-          float a0 = Jr[i0] * d, a1 = vi1 ? Jr[i1] * d : 0.0f, a2 = vi2 ? Jr[i2] * d : 0.0f;
-          float b0 = Jr[j0], b1 = vj1 ? Jr[j1] : 0.0f, b2 = vj2 ? Jr[j2] : 0.0f;
+          float a0 = GRX_JAT(i0) * d, a1 = vi1 ? GRX_JAT(i1) * d : 0.0f, a2 = vi2 ? GRX_JAT(i2) * d : 0.0f;
+          float b0 = GRX_JAT(j0), b1 = vj1 ? GRX_JAT(j1) : 0.0f, b2 = vj2 ? GRX_JAT(j2) : 0.0f;
+#undef GRX_JAT
           acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2;
           acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2;
           acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2;
@@ -1285,6 +1335,11 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
             if (i < nv && j < nv && j <= i) { float v = c->M[i * nv + j] + acc[a][b]; c->A[i * nv + j] = v; c->A[j * nv + i] = v; }
           }
       }
+    for (int i = lane; i < nv; i += 64) {
+      float sacc = 0;
+      for (int r = 0; r < nefc; r++) { const int info = c->efc_row[r], jd = i - GRX_ROW_LO(info); if ((unsigned)jd < (unsigned)GRX_ROW_LEN(info)) sacc += c->Jp[GRX_ROW_OFF(info) + jd] * c->efc_force[r]; }
+      c->grad[i] = sacc;
+    }
   }
   WAVE_SYNC();
   }
@@ -1316,16 +1371,12 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
       if (it > 0 && full_step && !changed) done = 1;
+      // Hessian of the current active set and J'f of the current row forces, in one pass over the rows
+      grx_hessian(m, c, nefc, lane_);
+      GRX_TICK(c, GRX_P_NHESS);
       if (done || it >= GRX_NEWTON_MAXIT) {
         // converged: constraint forces from the evaluation just made
-        FOR_LANES {
-          for (int i = lane; i < nv; i += 64) {
-            float sacc = 0;
-#pragma unroll 8
-            for (int r = 0; r < nefc; r++) sacc += c->J[r * nv + i] * c->efc_force[r];
-            c->qfrc_constraint[i] = sacc; c->qacc_ws[i] = c->qacc[i];
-          }
-        }
+        FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qfrc_constraint[i] = c->grad[i]; c->qacc_ws[i] = c->qacc[i]; } }
         WAVE_SYNC();
         GRX_TICK(c, GRX_P_NFINAL);
         if (!do_euler) break;
@@ -1337,9 +1388,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       FOR_LANES {
         float part = 0;
         for (int i = lane; i < nv; i += 64) {
-          float sacc = c->Ma[i] - c->qfrc_smooth[i];
-#pragma unroll 8
-          for (int r = 0; r < nefc; r++) sacc -= c->J[r * nv + i] * c->efc_force[r];
+          float sacc = c->Ma[i] - c->qfrc_smooth[i] - c->grad[i];
           c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc;
         }
         LV(gnp) = part;
@@ -1348,8 +1397,6 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       float gn = sqrtf(grx_reduce_sum(gnp));
       GRX_TICK(c, GRX_P_NGRAD);
       if (scale * gn < 1e-8f) { done = 1; continue; }
-      grx_hessian(m, c, nefc, lane_);
-      GRX_TICK(c, GRX_P_NHESS);
       rhs = c->search;
     } else if (phase == 1) {
       if (!implicit_damp) {
@@ -1389,8 +1436,9 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         }
         for (int r = lane; r < nefc; r += 64) {
           float sacc = 0;
+          { const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
 #pragma unroll 8
-          for (int j = 0; j < nv; j++) sacc += c->J[r * nv + j] * c->search[j];
+            for (int j = 0; j < len; j++) sacc += c->Jp[off + j] * c->search[lo + j]; }
           c->efc_jv[r] = sacc;
         }
         LV(q1p) = p1; LV(q2p) = p2; LV(g0p) = p0;

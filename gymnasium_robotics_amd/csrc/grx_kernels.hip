@@ -116,12 +116,13 @@ grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_i
   const int lane_ = threadIdx.x;
   GrxModel m; m.nv = nv;
   GrxCtx c;
-  c.A = lds; c.M = c.A + nv * nv; c.J = c.M + nv * nv; c.efc_D = c.J + GRX_MAXEFC * nv; c.efc_jv = c.efc_D + GRX_MAXEFC;
-  c.efc_quad = (int*)(c.efc_jv + GRX_MAXEFC); c.tmpv = (float*)(c.efc_quad + GRX_MAXEFC);
+  c.A = lds; c.M = c.A + nv * nv; c.Jp = c.M + nv * nv; c.efc_D = c.Jp + GRX_MAXEFC * nv; c.efc_jv = c.efc_D + GRX_MAXEFC;
+  c.efc_quad = (int*)(c.efc_jv + GRX_MAXEFC); c.efc_row = c.efc_quad + GRX_MAXEFC; c.tmpv = (float*)(c.efc_row + GRX_MAXEFC);
+  c.grad = c.tmpv + nv; c.efc_force = c.grad + nv;
   for (int i = lane_; i < nv * nv; i += 64) { c.A[i] = A_in[i]; c.M[i] = A_in[i]; }
   for (int i = lane_; i < nv; i += 64) c.tmpv[i] = b_in[i];
-  for (int i = lane_; i < nefc * nv; i += 64) c.J[i] = J_in[i];
-  for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0 ? 1 : 0; }
+  for (int i = lane_; i < nefc * nv; i += 64) c.Jp[i] = J_in[i];
+  for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0 ? 1 : 0; c.efc_row[i] = GRX_ROW_PACK(i * nv, 0, nv); c.efc_force[i] = 0.5f + 0.01f * (float)i; }
   __syncthreads();
   if (mode == 0) {
     GrxEngine<0>::grx_sym_solve_full(c.A, nv, c.tmpv, lane_);
@@ -129,6 +130,7 @@ grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_i
   } else {
     GrxEngine<0>::grx_hessian(&m, &c, nefc, lane_);
     for (int i = lane_; i < nv * nv; i += 64) out[i] = c.A[i];
+    for (int i = lane_; i < nv; i += 64) out[nv * nv + i] = c.grad[i];  // J' f
   }
 }
 
@@ -242,7 +244,7 @@ extern "C" int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task,
 
 // test-only entry point (tests/test_gpu_primitives.py); all pointers are device pointers
 extern "C" int grx_debug_primitive(int mode, int nv, int nefc, const float* A, const float* b, const float* J, const float* D, float* out, void* stream) {
-  int bytes = (2 * nv * nv + GRX_MAXEFC * nv + 3 * GRX_MAXEFC + nv + 64) * 4;
+  int bytes = (2 * nv * nv + GRX_MAXEFC * nv + 5 * GRX_MAXEFC + 2 * nv + 64) * 4;
   hipLaunchKernelGGL(grx_debug_kernel, dim3(1), dim3(64), bytes, (hipStream_t)stream, mode, nv, nefc, A, b, J, D, out);
   HIP_OK(hipGetLastError());
   return 0;

@@ -97,7 +97,7 @@ float* emu_ctx_ptr(void* h, const char* name) {
   Emu* e = (Emu*)h; GrxCtx* c = &e->c;
 #define P(n) if (!strcmp(name, #n)) return (float*)c->n;
   P(qpos) P(qvel) P(xpos) P(xquat) P(xmat) P(cinert) P(crb) P(cvel) P(cdof) P(cdof_dot) P(M) P(A) P(qfrc_bias) P(qfrc_passive)
-  P(qfrc_actuator) P(qfrc_smooth) P(qacc_smooth) P(qfrc_constraint) P(qacc) P(J) P(efc_pos) P(efc_D) P(efc_aref) P(efc_force)
+  P(qfrc_actuator) P(qfrc_smooth) P(qacc_smooth) P(qfrc_constraint) P(qacc) P(Jp) P(efc_pos) P(efc_D) P(efc_aref) P(efc_force)
   P(con_dist) P(con_pos) P(con_frame) P(gxpos) P(gxmat) P(sxpos) P(sxmat) P(cnt) P(efc_kind) P(efc_id) P(con_pair) P(janchor) P(jaxis)
 #undef P
   return nullptr;

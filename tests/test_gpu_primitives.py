@@ -17,7 +17,7 @@ def _run(mode, nv, nefc, A, b, J, D):
     L.grx_debug_primitive.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
     tA, tb, tJ, tD = t(A), t(b), t(J), t(D)
-    out = torch.zeros(nv * nv if mode else nv, device="cuda")
+    out = torch.zeros(nv * nv + nv if mode else nv, device="cuda")
     _native.check(L.grx_debug_primitive(mode, nv, nefc, tA.data_ptr(), tb.data_ptr(), tJ.data_ptr(), tD.data_ptr(), out.data_ptr(),
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
@@ -36,7 +36,7 @@ def test_spd_solve(nv):
     assert np.abs(x - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("nv,nefc", [(21, 47), (15, 7), (21, 128)])
+@pytest.mark.parametrize("nv,nefc", [(21, 47), (15, 7), (21, 144)])
 def test_mfma_hessian(nv, nefc):
     rng = np.random.default_rng(nefc)
     Q = rng.standard_normal((nv, nv))
@@ -44,6 +44,10 @@ def test_mfma_hessian(nv, nefc):
     J = rng.standard_normal((nefc, nv)) * (rng.random((nefc, nv)) < 0.6)
     D = rng.random(nefc) * 100 + 1
     D[rng.random(nefc) < 0.3] *= -1  # negative = inactive row
-    H = _run(1, nv, nefc, M, np.zeros(nv), J, D).reshape(nv, nv)
+    out = _run(1, nv, nefc, M, np.zeros(nv), J, D)
+    H, jtf = out[: nv * nv].reshape(nv, nv), out[nv * nv:]
     ref = M + J.T @ (np.where(D > 0, D, 0)[:, None] * J)
     assert np.abs(H - ref).max() < 1e-5 * np.abs(ref).max()
+    # the same MFMA chain also delivers J' f for the row forces of the last evaluation (here f_r = 0.5 + 0.01 r)
+    f = 0.5 + 0.01 * np.arange(nefc)
+    assert np.abs(jtf - J.T @ f).max() < 1e-5 * max(1.0, np.abs(J.T @ f).max())
