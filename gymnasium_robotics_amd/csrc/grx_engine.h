@@ -1280,22 +1280,30 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     for (int e = 0; e < 16; e++) acc[e] = 0.0f;
     const int idx = lane_ & 31, half = lane_ >> 5;
     const bool incol = idx < nv;
-    // branch-free operand fetch (clamped addresses, selects instead of divergent paths) so that the LDS reads of
-    // several row pairs are in flight together
+    // Branch-free operand fetch (clamped addresses, selects instead of divergent paths), software-pipelined by hand over
+    // four row pairs: 12 independent LDS reads (row info, masked D, force), then 4 reads of the packed Jacobian, then 4 MFMAs.
     const bool isf = (idx == nv);
-#pragma unroll 4
-    for (int r0 = 0; r0 < nefc; r0 += 2) {
-      const int row = r0 + half;
-      const bool rowok = row < nefc;
-      const int rr = rowok ? row : 0;
-      const int info = c->efc_row[rr];
-      const float dq = c->efc_jv[rr], fr = c->efc_force[rr];
-      const int jd = idx - GRX_ROW_LO(info);
-      const bool in = rowok && incol && ((unsigned)jd < (unsigned)GRX_ROW_LEN(info));
-      const float v = c->Jp[GRX_ROW_OFF(info) + (in ? jd : 0)];
-      const float a = in ? v : 0.0f;                                   // A[i = idx][k = row] = J[row][idx]
-      const float b = in ? v * dq : ((isf && rowok) ? fr : 0.0f);     // B[k = row][j = idx] = D J[row][idx]; column nv: f[row]
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int r0 = 0; r0 < nefc; r0 += 8) {
+      int info[4]; float dq[4], fr[4], v[4]; bool rowok[4], in[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int row = r0 + 2 * u + half;
+        rowok[u] = row < nefc;
+        const int rr = rowok[u] ? row : 0;
+        info[u] = c->efc_row[rr]; dq[u] = c->efc_jv[rr]; fr[u] = c->efc_force[rr];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int jd = idx - GRX_ROW_LO(info[u]);
+        in[u] = rowok[u] && incol && ((unsigned)jd < (unsigned)GRX_ROW_LEN(info[u]));
+        v[u] = c->Jp[GRX_ROW_OFF(info[u]) + (in[u] ? jd : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float a = in[u] ? v[u] : 0.0f;                                        // A[i = idx][k = row] = J[row][idx]
+        const float b = in[u] ? v[u] * dq[u] : ((isf && rowok[u]) ? fr[u] : 0.0f);  // B[k = row][j = idx] = D J[row][idx]; column nv: f[row]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int e = 0; e < 16; e++) {
