@@ -35,6 +35,8 @@ def lib():
         L.grx_fetch_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_fetch_forward.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
+        cd = ctypes.c_double
+        L.grx_fetch_sample_resets.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         _lib = L
     return _lib
 
@@ -46,5 +48,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_compute_reward", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_last_error",
 ]

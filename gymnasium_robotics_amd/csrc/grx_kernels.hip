@@ -5,6 +5,7 @@
 // and write HBM exactly once.  Worlds are independent: no inter-workgroup communication.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -247,6 +248,56 @@ extern "C" int grx_debug_primitive(int mode, int nv, int nefc, const float* A, c
   int bytes = (2 * nv * nv + GRX_MAXEFC * nv + 5 * GRX_MAXEFC + 2 * nv + 64) * 4;
   hipLaunchKernelGGL(grx_debug_kernel, dim3(1), dim3(64), bytes, (hipStream_t)stream, mode, nv, nefc, A, b, J, D, out);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side episode-boundary sampling.  The reference draws object/goal positions from numpy's PCG64
+// (Generator.uniform) in a data-dependent rejection loop (envs/fetch/fetch_env.py:153-166,388-391).  The per-world
+// generator states are created by numpy (SeedSequence seeding stays in Python) and advanced here, bit-exactly:
+//   PCG64 = 128-bit LCG (multiplier 0x2360ED051FC65DA44385DF649FCCF645) with XSL-RR output,
+//   uniform(lo, hi) = lo + (hi - lo) * ((next64 >> 11) * 2^-53).
+// ------------------------------------------------------------------------------------------
+typedef unsigned __int128 grx_u128;
+static inline uint64_t grx_pcg64_next(uint64_t* st /* state_hi, state_lo, inc_hi, inc_lo */) {
+  const grx_u128 mult = ((grx_u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+  grx_u128 state = ((grx_u128)st[0] << 64) | st[1], inc = ((grx_u128)st[2] << 64) | st[3];
+  state = state * mult + inc;
+  st[0] = (uint64_t)(state >> 64); st[1] = (uint64_t)state;
+  uint64_t hi = st[0], lo = st[1], x = hi ^ lo; unsigned rot = (unsigned)(hi >> 58);
+  return (x >> rot) | (x << ((64 - rot) & 63));
+}
+static inline double grx_pcg64_uniform(uint64_t* st, double lo, double hi) {
+  return lo + (hi - lo) * ((double)(grx_pcg64_next(st) >> 11) * (1.0 / 9007199254740992.0));
+}
+
+// states: [n_total, 4] uint64 (state_hi, state_lo, inc_hi, inc_lo); idx: worlds to sample (n of them)
+// out_oxy [n,2] (only if has_object), out_goal [n,3]; target_offset[3]
+extern "C" int grx_fetch_sample_resets(uint64_t* states, const int64_t* idx, int n, int has_object, int target_in_the_air, double obj_range,
+                                       double target_range, const double* target_offset, const double* gripper_xpos, double height_offset,
+                                       double* out_oxy, double* out_goal) {
+  if (!states || !idx || !out_goal || !gripper_xpos || !target_offset) return fail("grx_fetch_sample_resets: null argument");
+  for (int k = 0; k < n; k++) {
+    uint64_t* st = states + 4 * idx[k];
+    if (has_object) {
+      double ox = gripper_xpos[0], oy = gripper_xpos[1];
+      for (;;) {
+        double dx = ox - gripper_xpos[0], dy = oy - gripper_xpos[1];
+        if (!(sqrt(dx * dx + dy * dy) < 0.1)) break;
+        ox = gripper_xpos[0] + grx_pcg64_uniform(st, -obj_range, obj_range);
+        oy = gripper_xpos[1] + grx_pcg64_uniform(st, -obj_range, obj_range);
+      }
+      out_oxy[2 * k] = ox; out_oxy[2 * k + 1] = oy;
+    }
+    double g[3];
+    for (int e = 0; e < 3; e++) g[e] = gripper_xpos[e] + grx_pcg64_uniform(st, -target_range, target_range);
+    if (has_object) {
+      for (int e = 0; e < 3; e++) g[e] += target_offset[e];
+      g[2] = height_offset;
+      if (target_in_the_air && grx_pcg64_uniform(st, 0.0, 1.0) < 0.5) g[2] += grx_pcg64_uniform(st, 0.0, 0.45);
+    }
+    for (int e = 0; e < 3; e++) out_goal[3 * k + e] = g[e];
+  }
   return 0;
 }
 

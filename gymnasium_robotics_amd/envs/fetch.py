@@ -109,7 +109,7 @@ class FetchVecEnv(GoalVecEnv):
         self.action_space = batch_space(self.single_action_space, self.num_envs)
         self.observation_space = batch_space(self.single_observation_space, self.num_envs)
         self._check_goal_space()
-        self.np_randoms = [np_random(None)[0] for _ in range(self.num_envs)]
+        self._seed_worlds([None] * self.num_envs)
         self._elapsed = np.zeros(self.num_envs, np.int64)
         self._needs_reset = np.zeros(self.num_envs, bool)
         self._has_reset = False
@@ -181,21 +181,41 @@ class FetchVecEnv(GoalVecEnv):
         self._obj_qadr = int(jq[n["joint"]["object0:joint"]]) if cfg["has_object"] else -1
 
     # ------------------------------------------------------------------ reset (robot_env.py:154-186)
-    def _sample_reset(self, rng):
-        return sample_fetch_reset(self.cfg, rng, self.initial_gripper_xpos, self.height_offset)
+    def _seed_worlds(self, seeds):
+        """One numpy PCG64 per world, seeded like gymnasium.utils.seeding.np_random [3P]; only the raw 128-bit
+        (state, inc) pairs are kept -- the stream is advanced by grx_fetch_sample_resets (bit-exact with numpy)."""
+        st = np.zeros((self.num_envs, 4), np.uint64)
+        mask = (1 << 64) - 1
+        for i, sd in enumerate(seeds):
+            s = np_random(sd)[0].bit_generator.state["state"]
+            st[i] = [s["state"] >> 64, s["state"] & mask, s["inc"] >> 64, s["inc"] & mask]
+        self._rng_state = st
+
+    def world_rng(self, i):
+        """numpy Generator positioned at world i's current stream position (for inspection / tests)."""
+        bg = np.random.PCG64()
+        st = bg.state
+        a = [int(x) for x in self._rng_state[i]]
+        st["state"] = {"state": (a[0] << 64) | a[1], "inc": (a[2] << 64) | a[3]}
+        bg.state = st
+        return np.random.Generator(bg)
 
     def _reset_worlds(self, idx: np.ndarray):
         n = len(idx)
         if n == 0:
             return
-        goals = np.zeros((n, 3), np.float32)
-        oxy = np.zeros((n, 2), np.float32)
-        for k, w in enumerate(idx):
-            o, g = self._sample_reset(self.np_randoms[w])
-            goals[k] = g
-            if o is not None:
-                oxy[k] = o
-        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        goals64 = np.zeros((n, 3), np.float64)
+        oxy64 = np.zeros((n, 2), np.float64)
+        idx64 = np.ascontiguousarray(idx, dtype=np.int64)
+        cfg = self.cfg
+        toff = np.ascontiguousarray(np.broadcast_to(np.asarray(cfg["target_offset"], dtype=np.float64), (3,)))
+        g0 = np.ascontiguousarray(self.initial_gripper_xpos, dtype=np.float64)
+        _native.check(self._L.grx_fetch_sample_resets(
+            self._rng_state.ctypes.data, idx64.ctypes.data, n, int(cfg["has_object"]), int(cfg["target_in_the_air"]),
+            float(cfg["obj_range"]), float(cfg["target_range"]), toff.ctypes.data, g0.ctypes.data, float(self.height_offset),
+            oxy64.ctypes.data, goals64.ctypes.data))
+        goals, oxy = goals64.astype(np.float32), oxy64.astype(np.float32)
+        ti = torch.from_numpy(idx64).to(self.device)
         rows = self.initial_qpos.unsqueeze(0).repeat(n, 1)
         if self._obj_qadr >= 0:
             rows[:, self._obj_qadr: self._obj_qadr + 2] = torch.from_numpy(oxy).to(self.device)
@@ -214,7 +234,7 @@ class FetchVecEnv(GoalVecEnv):
     def reset(self, *, seed=None, options=None):
         if seed is not None:
             seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
-            self.np_randoms = [np_random(s)[0] for s in seeds]
+            self._seed_worlds(seeds)
         with torch.cuda.device(self.device):
             self._reset_worlds(np.arange(self.num_envs))
         self._has_reset = True

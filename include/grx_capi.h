@@ -16,6 +16,7 @@
  *   grx_fetch_forward ....... mujoco.mj_forward after a reset + _get_obs fetch/fetch_env.py:401, envs/robot_env.py:183
  *                              (nstep > 0: the raw mj_step settle loop of _env_setup, fetch/fetch_env.py:419-420)
  *   grx_fetch_compute_reward  GoalEnv.compute_reward on a batch (HER)   fetch/fetch_env.py:74-80, core.py:45-67
+ *   grx_fetch_sample_resets . np_random.uniform draws of _reset_sim/_sample_goal  fetch/fetch_env.py:153-166,388-391
  *
  * All array arguments are plain device (HBM) pointers; rows are world-major.  `stream` is a
  * hipStream_t passed as void*.  Every function returns 0 on success, a negative value on error
@@ -66,6 +67,12 @@ int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fet
 int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream);
 int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
                              float* reward_out, void* stream);
+/* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
+ * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's
+ * numpy PCG64 (created and seeded by numpy on the Python side), advanced in place.  All pointers are HOST pointers. */
+int grx_fetch_sample_resets(uint64_t* states, const int64_t* idx, int n, int has_object, int target_in_the_air, double obj_range,
+                            double target_range, const double* target_offset, const double* gripper_xpos, double height_offset,
+                            double* out_oxy, double* out_goal);
 const char* grx_last_error(void);
 
 #ifdef __cplusplus
