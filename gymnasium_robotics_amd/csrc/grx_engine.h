@@ -702,6 +702,47 @@ GRX_MEM void grx_plane_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g
   }
 }
 
+#define GRX_SEL3(a0, a1, a2, i) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
+
+GRX_MEM void grx_plane_sphere(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]};
+  const float* ce = c->gxpos + 3 * g2; float r = m->geom_size[3 * g2];
+  float d[3] = {ce[0] - c->gxpos[3 * g1], ce[1] - c->gxpos[3 * g1 + 1], ce[2] - c->gxpos[3 * g1 + 2]};
+  float dist = dot3f(d, n) - r;
+  if (dist > margin) return;
+  float pos[3] = {ce[0] - n[0] * (r + 0.5f * dist), ce[1] - n[1] * (r + 0.5f * dist), ce[2] - n[2] * (r + 0.5f * dist)};
+  grx_add_contact(c, pair, pos, n, dist);
+}
+
+// sphere (geom1) vs box (geom2): closest point of the box to the sphere centre; normal from the sphere to the box
+GRX_MEM void grx_sphere_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  const float* ce = c->gxpos + 3 * g1; float r = m->geom_size[3 * g1];
+  const float* bp = c->gxpos + 3 * g2; const float* bm = c->gxmat + 9 * g2; const float* sz = m->geom_size + 3 * g2;
+  float dw[3] = {ce[0] - bp[0], ce[1] - bp[1], ce[2] - bp[2]}, loc[3];
+  mulMatTVec3f(loc, bm, dw);
+  float s0 = sz[0], s1 = sz[1], s2 = sz[2];
+  float c0 = fminf(s0, fmaxf(-s0, loc[0])), c1 = fminf(s1, fmaxf(-s1, loc[1])), c2 = fminf(s2, fmaxf(-s2, loc[2]));
+  float nl[3], dist;
+  if (c0 != loc[0] || c1 != loc[1] || c2 != loc[2]) {
+    float dv[3] = {c0 - loc[0], c1 - loc[1], c2 - loc[2]};
+    float len = sqrtf(dot3f(dv, dv));
+    dist = len - r;
+    if (dist > margin) return;
+    float li = 1.0f / len; nl[0] = dv[0] * li; nl[1] = dv[1] * li; nl[2] = dv[2] * li;
+  } else {
+    float d0 = s0 - fabsf(loc[0]), d1 = s1 - fabsf(loc[1]), d2 = s2 - fabsf(loc[2]);
+    int ax = 0; float best = d0;
+    if (d1 < best) { best = d1; ax = 1; }
+    if (d2 < best) { best = d2; ax = 2; }
+    float sg = (GRX_SEL3(loc[0], loc[1], loc[2], ax) >= 0) ? -1.0f : 1.0f;
+    nl[0] = (ax == 0) ? sg : 0.0f; nl[1] = (ax == 1) ? sg : 0.0f; nl[2] = (ax == 2) ? sg : 0.0f;
+    dist = -best - r;
+  }
+  float n[3]; mulMatVec3f(n, bm, nl);
+  float pos[3] = {ce[0] + n[0] * (r + 0.5f * dist), ce[1] + n[1] * (r + 0.5f * dist), ce[2] + n[2] * (r + 0.5f * dist)};
+  grx_add_contact(c, pair, pos, n, dist);
+}
+
 // plane vs a SMALL convex vertex set (<= 32 hull vertices, e.g. the compile-time pruned hulls): one lane does it all
 GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
   const float* gm = c->gxmat + 9 * g2;
@@ -730,7 +771,6 @@ GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1
   }
 }
 
-#define GRX_SEL3(a0, a1, a2, i) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
 
 // box-box: SAT over the 15 axes, then face clipping or edge-edge.  Written without dynamically indexed local
 // arrays (everything stays in registers): axes are selected with GRX_SEL3, and the clipped contact polygon is
@@ -890,7 +930,9 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           pass = dot3f(dx, dx) <= r * r;
         }
         if (pass) {
-          if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
+          if (t1 == 0 && t2 == 2) grx_plane_sphere(m, c, p, g1, g2, margin);
+          else if (t1 == 2 && t2 == 6) grx_sphere_box(m, c, p, g1, g2, margin);
+          else if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
           else if (t1 == 6 && t2 == 6) grx_box_box(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 7) {
             if (m->geom_meshnum[g2] <= 32) grx_plane_mesh_small(m, c, p, g1, g2, margin);

@@ -12,10 +12,13 @@
 
 #include "../../include/grx_capi.h"
 #include "grx_fetch_task.h"
+#include "grx_point_task.h"
 #include "grx_host_model.h"
 
 static_assert(sizeof(grx_fetch_task) == sizeof(GrxFetchTask), "grx_fetch_task must mirror GrxFetchTask");
 static_assert(sizeof(grx_fetch_buffers) == sizeof(GrxFetchBuffers), "grx_fetch_buffers must mirror GrxFetchBuffers");
+static_assert(sizeof(grx_point_task) == sizeof(GrxPointTask), "grx_point_task must mirror GrxPointTask");
+static_assert(sizeof(grx_point_buffers) == sizeof(GrxPointBuffers), "grx_point_buffers must mirror GrxPointBuffers");
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -101,6 +104,46 @@ grx_fetch_forward_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_wo
   grx_store_world(m, t, b, c, w, lane_);
 }
 
+// PointMaze env.step(): one wavefront per world, same engine
+extern "C" __global__ void __launch_bounds__(64, 2)
+grx_point_step_kernel(GrxModel m, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
+  extern __shared__ float lds[];
+  const int w = blockIdx.x, lane_ = threadIdx.x;
+  if (w >= n_worlds) return;
+  if (b.mask && !b.mask[w]) return;
+  GrxCtx c;
+  grx_ctx_carve(&c, lds, &m);
+#ifdef GRX_PROFILE
+  __shared__ long long prof_s[GRX_NPROF + 1];
+  c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
+#endif
+  for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
+  __syncthreads();
+  for (int i = lane_; i < m.nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * m.nq + i];
+  for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
+  __syncthreads();
+  float* obs = b.obs + (size_t)w * (m.nq + m.nv); float* ach = b.achieved + (size_t)w * 2;
+  GrxPoint<0>::grx_point_step_world(&m, &t, &c, b.action + (size_t)w * m.nu, obs, ach, lane_);
+  __syncthreads();
+  for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
+  for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)w * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * m.nv + i] = c.qacc_ws[i]; }
+  if (lane_ == 0) {
+    float d = grx_goal_distance2(ach, b.goal + (size_t)w * 2);
+    int succ = d <= t.goal_radius;
+    b.reward[w] = grx_maze_reward(d, t.goal_radius, t.sparse_reward);
+    b.success[w] = succ; b.terminated[w] = (!t.continuing_task && succ) ? 1 : 0;
+    b.status[w] = c.cnt[2];
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+grx_maze_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, float radius, int sparse, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
+    float a[2] = {ag[2 * i], ag[2 * i + 1]}, g[2] = {dg[2 * i], dg[2 * i + 1]};
+    out[i] = grx_maze_reward(grx_goal_distance2(a, g), radius, sparse);
+  }
+}
+
 // HER relabel: reward for B (achieved, desired) pairs; 16 B/lane loads where the layout allows
 extern "C" __global__ void __launch_bounds__(256)
 grx_fetch_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, float thresh, int sparse, float* __restrict__ out) {
@@ -176,6 +219,7 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   *out = m;
   return 0;
 }
@@ -239,6 +283,31 @@ extern "C" int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task,
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
   hipLaunchKernelGGL(grx_fetch_forward_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->dev, t, b, n_worlds, m->words, nstep);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int grx_point_step(const grx_model* m, const grx_point_task* task, const grx_point_buffers* buf, int n_worlds, void* stream) {
+  if (!m || !task || !buf) return fail("grx_point_step: null argument");
+  if (!buf->qpos || !buf->qvel || !buf->qacc_ws || !buf->goal || !buf->action || !buf->obs || !buf->achieved || !buf->reward || !buf->success ||
+      !buf->terminated || !buf->status)
+    return fail("grx_point_step: null buffer");
+  if (n_worlds <= 0) return 0;
+  GrxPointTask t; memcpy(&t, task, sizeof(t));
+  GrxPointBuffers b; memcpy(&b, buf, sizeof(b));
+  hipLaunchKernelGGL(grx_point_step_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->dev, t, b, n_worlds, m->words);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t batch, float goal_radius, int sparse, float* reward_out,
+                                       void* stream) {
+  if (!achieved || !desired || !reward_out) return fail("grx_maze_compute_reward: null argument");
+  if (batch <= 0) return 0;
+  long long blocks = (batch + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(grx_maze_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, achieved, desired, (long long)batch, goal_radius,
+                     sparse, reward_out);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,54 @@
+// grx_point_task.h -- PointMaze task code fused around the physics substep.
+//
+// Device restatement of
+//   PointEnv.step ............ /root/reference/gymnasium_robotics/envs/maze/point.py:55-77  (clip action, clip qvel to +-5,
+//                              do_simulation(a, frame_skip = 1), obs = qpos | qvel)
+//   PointMazeEnv.step ........ envs/maze/point_maze.py:392-406 (achieved goal = xy, reward, terminated, success)
+//   MazeEnv.compute_reward ... envs/maze/maze_v4.py:381-388   (dense exp(-d), sparse d <= 0.45)
+//   MazeEnv.compute_terminated envs/maze/maze_v4.py:390-398
+#pragma once
+#include "grx_engine.h"
+
+struct GrxPointTask {
+  int n_substeps, sparse_reward, continuing_task, pad_;
+  float goal_radius, vel_clip;
+};
+
+struct GrxPointBuffers {
+  float *qpos, *qvel, *qacc_ws;  // [N,nq] [N,nv] [N,nv]
+  const float* goal;             // [N,2]
+  const float* action;           // [N,nu]
+  float *obs, *achieved;         // [N,nq+nv] [N,2]
+  float* reward;                 // [N]
+  unsigned char *success, *terminated;  // [N]
+  int* status;                   // [N]
+  const unsigned char* mask;     // [N] or null
+};
+
+GRX_DEV float grx_goal_distance2(const float* a, const float* b) {
+  float dx = a[0] - b[0], dy = a[1] - b[1];
+  return sqrtf(fmaf(dy, dy, dx * dx));
+}
+GRX_DEV float grx_maze_reward(float d, float radius, int sparse) { return sparse ? ((d <= radius) ? 1.0f : 0.0f) : expf(-d); }
+
+template <int NV>
+struct GrxPoint {
+  typedef GrxEngine<NV> E;
+  GRX_MEM void grx_point_step_world(const GrxModel* m, const GrxPointTask* t, GrxCtx* c, const float* action, float* obs, float* achieved,
+                                    int lane_) {
+    FOR_LANES {
+      for (int i = lane; i < m->nu; i += 64) c->ctrl[i] = fminf(1.0f, fmaxf(-1.0f, action[i]));
+      for (int i = lane; i < GRX_NVC; i += 64) c->qvel[i] = fminf(t->vel_clip, fmaxf(-t->vel_clip, c->qvel[i]));
+    }
+    WAVE_SYNC();
+    for (int s = 0; s < t->n_substeps; s++) {
+      E::grx_check_state(m, c, lane_);
+      E::grx_forward_euler(m, c, 1, lane_);
+    }
+    FOR_LANES {
+      for (int i = lane; i < m->nq; i += 64) { float q = c->qpos[i]; obs[i] = q; if (i < 2) achieved[i] = q; }
+      for (int i = lane; i < GRX_NVC; i += 64) obs[m->nq + i] = c->qvel[i];
+    }
+    WAVE_SYNC();
+  }
+};

@@ -1,0 +1,139 @@
+"""Maze family specifications (host side): map tables, cell <-> xy mapping, wall injection, reset sampling.
+
+Restates, in vectorisable form, the host logic of
+  /root/reference/gymnasium_robotics/envs/maze/maps.py            (map tables, registry ids __init__.py:960-1078)
+  /root/reference/gymnasium_robotics/envs/maze/maze_v4.py:148-242 (Maze.make_maze: walls + goal/reset cell lists)
+  /root/reference/gymnasium_robotics/envs/maze/maze_v4.py:278-379 (generate_target_goal / generate_reset_pos / reset / add_xy_position_noise)
+"""
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+R, G, C = "r", "g", "c"
+
+
+def _parse(rows):
+    """'1 0 r ...' strings -> list of lists with ints for 0/1 and 'r'/'g'/'c' markers"""
+    return [[int(t) if t in "01" else t for t in row.split()] for row in rows]
+
+
+MAPS = {
+    "UMaze": _parse(["1 1 1 1 1", "1 0 0 0 1", "1 1 1 0 1", "1 0 0 0 1", "1 1 1 1 1"]),
+    "Open": _parse(["1 1 1 1 1 1 1", "1 0 0 0 0 0 1", "1 0 0 0 0 0 1", "1 0 0 0 0 0 1", "1 1 1 1 1 1 1"]),
+    "Open_Diverse_G": _parse(["1 1 1 1 1 1 1", "1 r g g g g 1", "1 g g g g g 1", "1 g g g g g 1", "1 1 1 1 1 1 1"]),
+    "Open_Diverse_GR": _parse(["1 1 1 1 1 1 1", "1 c c c c c 1", "1 c c c c c 1", "1 c c c c c 1", "1 1 1 1 1 1 1"]),
+    "Medium": _parse(["1 1 1 1 1 1 1 1", "1 0 0 1 1 0 0 1", "1 0 0 1 0 0 0 1", "1 1 0 0 0 1 1 1", "1 0 0 1 0 0 0 1", "1 0 1 0 0 1 0 1",
+                      "1 0 0 0 1 0 0 1", "1 1 1 1 1 1 1 1"]),
+    "Medium_Diverse_G": _parse(["1 1 1 1 1 1 1 1", "1 r 0 1 1 0 0 1", "1 0 0 1 0 0 g 1", "1 1 0 0 0 1 1 1", "1 0 0 1 0 0 0 1",
+                                "1 g 1 0 0 1 0 1", "1 0 0 0 1 g 0 1", "1 1 1 1 1 1 1 1"]),
+    "Medium_Diverse_GR": _parse(["1 1 1 1 1 1 1 1", "1 c 0 1 1 0 0 1", "1 0 0 1 0 0 c 1", "1 1 0 0 0 1 1 1", "1 0 0 1 0 0 0 1",
+                                 "1 c 1 0 0 1 0 1", "1 0 0 0 1 c 0 1", "1 1 1 1 1 1 1 1"]),
+    "Large": _parse(["1 1 1 1 1 1 1 1 1 1 1 1", "1 0 0 0 0 1 0 0 0 0 0 1", "1 0 1 1 0 1 0 1 0 1 0 1", "1 0 0 0 0 0 0 1 0 0 0 1",
+                     "1 0 1 1 1 1 0 1 1 1 0 1", "1 0 0 1 0 1 0 0 0 0 0 1", "1 1 0 1 0 1 0 1 0 1 1 1", "1 0 0 1 0 0 0 1 0 0 0 1",
+                     "1 1 1 1 1 1 1 1 1 1 1 1"]),
+    "Large_Diverse_G": _parse(["1 1 1 1 1 1 1 1 1 1 1 1", "1 r 0 0 0 1 g 0 0 0 0 1", "1 0 1 1 0 1 0 1 0 1 0 1", "1 0 0 0 0 g 0 1 0 0 g 1",
+                               "1 0 1 1 1 1 0 1 1 1 0 1", "1 0 g 1 0 1 0 0 0 0 0 1", "1 1 0 1 0 1 0 1 0 1 1 1", "1 0 0 1 g 0 g 1 0 g 0 1",
+                               "1 1 1 1 1 1 1 1 1 1 1 1"]),
+    "Large_Diverse_GR": _parse(["1 1 1 1 1 1 1 1 1 1 1 1", "1 c 0 0 0 1 c 0 0 0 0 1", "1 0 1 1 0 1 0 1 0 1 0 1", "1 0 0 0 0 c 0 1 0 0 c 1",
+                                "1 0 1 1 1 1 0 1 1 1 0 1", "1 0 c 1 0 1 0 0 0 0 0 1", "1 1 0 1 0 1 0 1 0 1 1 1", "1 0 0 1 c 0 c 1 0 c 0 1",
+                                "1 1 1 1 1 1 1 1 1 1 1 1"]),
+}
+POINT_MAX_EPISODE_STEPS = {"UMaze": 300, "Open": 300, "Medium": 600, "Large": 800}  # __init__.py:962-1078
+POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT = 1.0, 0.4                                   # point_maze.py:331-332
+GOAL_RADIUS = 0.45
+
+
+def parse_point_maze_id(env_id: str):
+    """'PointMaze_Medium_Diverse_GRDense-v3' -> ('Medium_Diverse_GR', 'dense', max_episode_steps)"""
+    base = env_id.split("-v")[0]
+    if not base.startswith("PointMaze_"):
+        raise KeyError(f"unknown PointMaze env id {env_id}")
+    name = base[len("PointMaze_"):]
+    reward_type = "sparse"
+    if name.endswith("Dense"):
+        name, reward_type = name[: -len("Dense")], "dense"
+    if name not in MAPS:
+        raise KeyError(f"unknown PointMaze env id {env_id}")
+    return name, reward_type, POINT_MAX_EPISODE_STEPS[name.split("_")[0]]
+
+
+class Maze:
+    """Cell grid <-> simulation coordinates and the goal / reset cell lists (maze_v4.py:62-146,199-242)."""
+
+    def __init__(self, maze_map, maze_size_scaling: float, maze_height: float):
+        self.maze_map, self.maze_size_scaling, self.maze_height = maze_map, float(maze_size_scaling), float(maze_height)
+        self.map_length, self.map_width = len(maze_map), len(maze_map[0])
+        self.x_map_center = self.map_width / 2 * self.maze_size_scaling
+        self.y_map_center = self.map_length / 2 * self.maze_size_scaling
+        goals, resets, combined, empty, walls = [], [], [], [], []
+        for i in range(self.map_length):
+            for j in range(self.map_width):
+                xy = self.cell_rowcol_to_xy((i, j))
+                cell = maze_map[i][j]
+                if cell == 1:
+                    walls.append((i, j, xy))
+                elif cell == R:
+                    resets.append(xy)
+                elif cell == G:
+                    goals.append(xy)
+                elif cell == C:
+                    combined.append(xy)
+                elif cell == 0:
+                    empty.append(xy)
+        if not goals and not resets and not combined:
+            combined = empty
+        elif not resets and not combined:
+            resets = empty
+        elif not goals and not combined:
+            goals = empty
+        self.unique_goal_locations = goals + combined
+        self.unique_reset_locations = resets + combined
+        self.walls = walls
+
+    def cell_rowcol_to_xy(self, rowcol):
+        x = (rowcol[1] + 0.5) * self.maze_size_scaling - self.x_map_center
+        y = self.y_map_center - (rowcol[0] + 0.5) * self.maze_size_scaling
+        return np.array([x, y])
+
+    def add_walls(self, root: ET.Element) -> None:
+        """MJCF rewrite of Maze.make_maze (maze_v4.py:168-212): one world-fixed box per wall cell + the target site."""
+        wb = root.find("worldbody")
+        s, h = self.maze_size_scaling, self.maze_height
+        for i, j, xy in self.walls:
+            ET.SubElement(wb, "geom", name=f"block_{i}_{j}", pos=f"{xy[0]} {xy[1]} {h / 2 * s}", size=f"{0.5 * s} {0.5 * s} {h / 2 * s}",
+                          type="box", contype="1", conaffinity="1")
+        ET.SubElement(wb, "site", name="target", pos=f"0 0 {h / 2 * s}", size=f"{0.2 * s}", type="sphere")
+
+
+def sample_maze_reset(maze: Maze, rng, position_noise_range: float = 0.25, options=None):
+    """PCG64 draw order of MazeEnv.reset (maze_v4.py:299-358).  Returns (goal_xy, reset_xy)."""
+
+    def noise(xy):
+        xy = xy.copy()
+        xy[0] += rng.uniform(low=-position_noise_range, high=position_noise_range) * maze.maze_size_scaling
+        xy[1] += rng.uniform(low=-position_noise_range, high=position_noise_range) * maze.maze_size_scaling
+        return xy
+
+    def gen_goal():
+        return maze.unique_goal_locations[rng.integers(low=0, high=len(maze.unique_goal_locations))].copy()
+
+    def check_cell(cell, what):
+        assert maze.map_length > cell[0] and maze.map_width > cell[1]
+        assert maze.maze_map[cell[0]][cell[1]] != 1, f"{what} can't be placed in a wall cell, {cell}"
+
+    options = options or {}
+    if options.get("goal_cell") is not None:
+        check_cell(options["goal_cell"], "Goal")
+        goal = maze.cell_rowcol_to_xy(options["goal_cell"])
+    else:
+        goal = gen_goal()
+    goal = noise(goal)
+    if options.get("reset_cell") is not None:
+        check_cell(options["reset_cell"], "Reset")
+        reset_pos = maze.cell_rowcol_to_xy(options["reset_cell"])
+    else:
+        reset_pos = goal.copy()
+        while np.linalg.norm(reset_pos - goal) <= 0.5 * maze.maze_size_scaling:
+            reset_pos = maze.unique_reset_locations[rng.integers(low=0, high=len(maze.unique_reset_locations))].copy()
+    reset_pos = noise(reset_pos)
+    return goal, reset_pos

@@ -1,0 +1,204 @@
+"""Batched PointMaze environments on the MI355X engine (host side, Python).
+
+Vectorised drop-in for PointMazeEnv (/root/reference/gymnasium_robotics/envs/maze/point_maze.py:316-419, ids
+PointMaze_{UMaze,Open,Medium,Large}[_Diverse_G|_Diverse_GR][Dense]-v3, __init__.py:960-1078) with the GoalEnv contract.
+Per-step work = ONE launch of grx_point_step_kernel; episode-boundary sampling (goal cell, reset cell, xy noise:
+maze_v4.py:278-379) stays on the host with one numpy PCG64 per world, so ``reset(seed=s, options=...)`` reproduces the
+reference's draws for seed ``s + i`` (pinned by the reference's own golden vectors, tests/test_cpu_maze.py).
+"""
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..core import GoalVecEnv, np_random
+from ..mjcf import CompiledModel, compile_mjcf, load_model
+from ..spaces import Box, Dict, batch_space
+from .maze_spec import GOAL_RADIUS, MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze, parse_point_maze_id, sample_maze_reset
+
+_MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
+
+
+def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: Optional[str] = None) -> CompiledModel:
+    """Model tables of point.xml + one wall box per wall cell.  Compiled from MJCF when an asset tree is available
+    (needed for custom maze maps), else the packaged blob of the registered wall layout."""
+    assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
+    if assets_root:
+        return compile_mjcf(os.path.join(assets_root, "point", "point.xml"), mutate=maze.add_walls)
+    if layout_name is None:
+        raise OSError("custom maze maps need the MJCF assets (assets_root / $GRX_ASSETS_ROOT)")
+    path = os.path.join(_MODELS_DIR, f"point_{layout_name.split('_')[0]}.npz")
+    if not os.path.exists(path):
+        raise OSError(f"File {path} does not exist")
+    return load_model(path)
+
+
+class PointMazeVecEnv(GoalVecEnv):
+    def __init__(self, env_id: Optional[str] = "PointMaze_UMaze-v3", num_envs: int = 1, device: Optional[str] = None, maze_map=None,
+                 reward_type: Optional[str] = None, continuing_task: bool = True, reset_target: bool = False,
+                 position_noise_range: float = 0.25, max_episode_steps: Optional[int] = -1, autoreset_mode: str = "next_step",
+                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
+        layout, rt, mes = (None, "sparse", 300)
+        if maze_map is None:
+            layout, rt, mes = parse_point_maze_id(env_id)
+            maze_map = MAPS[layout]
+        if reset_target:
+            raise NotImplementedError("reset_target=True (goal redraw inside step, maze_v4.py:400-418) is not implemented yet")
+        self.env_id, self.reward_type = env_id, reward_type or rt
+        self.continuing_task, self.position_noise_range = continuing_task, position_noise_range
+        self.max_episode_steps = mes if max_episode_steps == -1 else max_episode_steps
+        self.autoreset_mode, self.output, self.num_envs, self.seed_offset = autoreset_mode, output, int(num_envs), int(seed_offset)
+        if not torch.cuda.is_available():
+            raise RuntimeError("PointMazeVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
+        self.device = torch.device(device or "cuda:0")
+        self.maze = Maze(maze_map, POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT)
+        self.model = model or load_point_maze_model(self.maze, layout, assets_root)
+        self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
+        self._L = _native.lib()
+        H, I, F = self.model.pack()
+        self._h = ctypes.c_void_p()
+        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0,
+                                               ctypes.byref(self._h)))
+        self.task = _native.PointTaskStruct(1, int(self.reward_type == "sparse"), int(continuing_task), 0, GOAL_RADIUS, 5.0)
+        n, d = self.num_envs, self.device
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
+        self.qpos, self.qvel, self.qacc_ws = z(n, self.nq), z(n, self.nv), z(n, self.nv)
+        self.goal, self.action, self.obs, self.achieved, self.reward = z(n, 2), z(n, self.nu), z(n, self.nq + self.nv), z(n, 2), z(n)
+        self.success, self.terminated = z(n, dtype=torch.uint8), z(n, dtype=torch.uint8)
+        self.status, self.mask = z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
+        self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)
+        self.single_observation_space = Dict(dict(
+            observation=Box(-np.inf, np.inf, (self.nq + self.nv,), np.float64), achieved_goal=Box(-np.inf, np.inf, (2,), np.float64),
+            desired_goal=Box(-np.inf, np.inf, (2,), np.float64)))
+        self.action_space = batch_space(self.single_action_space, n)
+        self.observation_space = batch_space(self.single_observation_space, n)
+        self._check_goal_space()
+        self.np_randoms = [np_random(None)[0] for _ in range(n)]
+        self._elapsed = np.zeros(n, np.int64)
+        self._needs_reset = np.zeros(n, bool)
+        self._has_reset = False
+
+    def _make_bufs(self, mask):
+        b = _native.PointBuffersStruct()
+        for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status"):
+            setattr(b, name, getattr(self, name).data_ptr())
+        b.mask = None if mask is None else mask.data_ptr()
+        return b
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ reset (point_maze.py:377-390, maze_v4.py:299-358)
+    def _reset_worlds(self, idx, options=None):
+        if len(idx) == 0:
+            return
+        goals, starts = np.zeros((len(idx), 2)), np.zeros((len(idx), 2))
+        for k, w in enumerate(idx):
+            goals[k], starts[k] = sample_maze_reset(self.maze, self.np_randoms[w], self.position_noise_range, options)
+        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        q = torch.zeros(len(idx), self.nq, device=self.device)
+        q[:, :2] = torch.from_numpy(starts.astype(np.float32)).to(self.device)
+        self.qpos[ti] = q
+        self.qvel[ti] = 0.0
+        self.qacc_ws[ti] = 0.0
+        self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
+        o = torch.zeros(len(idx), self.nq + self.nv, device=self.device)
+        o[:, : self.nq] = q
+        self.obs[ti] = o
+        self.achieved[ti] = q[:, :2]
+        d = torch.linalg.norm(self.achieved[ti] - self.goal[ti], dim=-1)
+        self.success[ti] = (d <= GOAL_RADIUS).to(torch.uint8)
+        self._elapsed[idx] = 0
+        self._needs_reset[idx] = False
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
+            self.np_randoms = [np_random(s)[0] for s in seeds]
+        with torch.cuda.device(self.device):
+            self._reset_worlds(np.arange(self.num_envs), options)
+        self._has_reset = True
+        return self._obs_dict(), self._info()
+
+    def _info(self):
+        if self.output == "torch":
+            return {"success": self.success.bool()}
+        return {"success": self.success.cpu().numpy().astype(bool), "status": self.status.cpu().numpy()}
+
+    # ------------------------------------------------------------------ step (point_maze.py:392-406)
+    def step(self, actions):
+        if not self._has_reset:
+            raise RuntimeError("Cannot call env.step() before calling env.reset()")
+        a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions, dtype=np.float32))
+        if tuple(a.shape) != (self.num_envs, self.nu):
+            raise ValueError("Action dimension mismatch")
+        self.action.copy_(a.to(torch.float32), non_blocking=True)
+        with torch.cuda.device(self.device):
+            pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
+            bufs = self._bufs
+            if len(pending):
+                self.mask.fill_(1)
+                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                bufs = self._bufs_masked
+            _native.check(self._L.grx_point_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, self._stream()))
+            stepped = ~self._needs_reset
+            self._elapsed[stepped] += 1
+            terminated = self.terminated.cpu().numpy().astype(bool) & stepped if not self.continuing_task else np.zeros(self.num_envs, bool)
+            truncated = np.zeros(self.num_envs, bool)
+            if self.max_episode_steps is not None:
+                truncated = stepped & (self._elapsed >= self.max_episode_steps)
+            if len(pending):
+                self._reset_worlds(pending)
+                self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
+            done = terminated | truncated
+            if self.autoreset_mode == "next_step":
+                self._needs_reset |= done
+            elif self.autoreset_mode == "same_step" and done.any():
+                keep = self.reward.clone()
+                self._reset_worlds(np.nonzero(done)[0])
+                self.reward.copy_(keep)
+        obs = self._obs_dict()
+        if self.output == "torch":
+            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), self._info()
+        return obs, self.reward.double().cpu().numpy(), terminated, truncated, self._info()
+
+    def _obs_dict(self):
+        if self.output == "torch":
+            return {"observation": self.obs, "achieved_goal": self.achieved, "desired_goal": self.goal}
+        return {"observation": self.obs.double().cpu().numpy(), "achieved_goal": self.achieved.double().cpu().numpy(),
+                "desired_goal": self.goal.double().cpu().numpy()}
+
+    # ------------------------------------------------------------------ GoalEnv API (maze_v4.py:381-398)
+    def compute_reward(self, achieved_goal, desired_goal, info=None):
+        as_numpy = not isinstance(achieved_goal, torch.Tensor)
+        ag = torch.as_tensor(np.asarray(achieved_goal, dtype=np.float32) if as_numpy else achieved_goal, dtype=torch.float32, device=self.device).contiguous()
+        dg = torch.as_tensor(np.asarray(desired_goal, dtype=np.float32) if as_numpy else desired_goal, dtype=torch.float32, device=self.device).contiguous()
+        if ag.shape != dg.shape or ag.shape[-1] != 2:
+            raise ValueError("achieved_goal and desired_goal must have the same (..., 2) shape")
+        out = torch.empty(ag.shape[:-1], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._L.grx_maze_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), GOAL_RADIUS,
+                                                          int(self.reward_type == "sparse"), out.data_ptr(), self._stream()))
+        return out.double().cpu().numpy() if as_numpy else out
+
+    def compute_terminated(self, achieved_goal, desired_goal, info=None):
+        d = np.linalg.norm(np.asarray(achieved_goal) - np.asarray(desired_goal), axis=-1)
+        return (d <= GOAL_RADIUS) if not self.continuing_task else np.zeros(d.shape, bool)
+
+    def compute_truncated(self, achieved_goal, desired_goal, info=None):
+        return np.zeros(np.asarray(achieved_goal).shape[:-1], bool)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.grx_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -337,10 +337,14 @@ def load_model(path: str) -> CompiledModel:
 # the compiler
 # ----------------------------------------------------------------------------
 class MjcfCompiler:
-    def __init__(self, xml_path: str):
+    def __init__(self, xml_path: str, mutate=None):
+        """mutate: optional callable(root_element) applied after <include> expansion, before compilation -- the
+        in-memory equivalent of the reference's Maze.make_maze XML rewrite (envs/maze/maze_v4.py:168-242)."""
         self.xml_path = os.path.abspath(xml_path)
         self.dir = os.path.dirname(self.xml_path)
         self.root = _load_xml(self.xml_path)
+        if mutate is not None:
+            mutate(self.root)
         self.defaults = _Defaults()
         self.angle_scale = np.pi / 180.0  # MJCF default angle unit is degree
         self.eulerseq = "xyz"
@@ -1033,7 +1037,7 @@ class _Lowering:
                 excludes.add((min(b1, b2), max(b1, b2)))
         weldparent = [weld[B[weld[i]].parent] if weld[i] > 0 else 0 for i in range(nb)]
         # narrow-phase routines implemented by BOTH the device engine and the oracle
-        supported = {(GEOM_PLANE, GEOM_BOX), (GEOM_PLANE, GEOM_MESH), (GEOM_BOX, GEOM_BOX)}
+        supported = {(GEOM_PLANE, GEOM_BOX), (GEOM_PLANE, GEOM_MESH), (GEOM_BOX, GEOM_BOX), (GEOM_PLANE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_BOX)}
         pairs = []
         for a in range(ng):
             for b_ in range(a + 1, ng):
@@ -1322,5 +1326,5 @@ class _Lowering:
         return CompiledModel(T, names, info)
 
 
-def compile_mjcf(xml_path: str) -> CompiledModel:
-    return MjcfCompiler(xml_path).compile()
+def compile_mjcf(xml_path: str, mutate=None) -> CompiledModel:
+    return MjcfCompiler(xml_path, mutate=mutate).compile()

@@ -57,6 +57,22 @@ typedef struct grx_fetch_buffers {
   const unsigned char* mask;            /* [N] or NULL */
 } grx_fetch_buffers;
 
+/* mirrors struct GrxPointTask / GrxPointBuffers (csrc/grx_point_task.h) */
+typedef struct grx_point_task {
+  int n_substeps, sparse_reward, continuing_task, pad_;
+  float goal_radius, vel_clip;
+} grx_point_task;
+typedef struct grx_point_buffers {
+  float *qpos, *qvel, *qacc_ws; /* [N,nq] [N,nv] [N,nv] */
+  const float* goal;            /* [N,2] */
+  const float* action;          /* [N,nu] */
+  float *obs, *achieved;        /* [N,nq+nv] [N,2] */
+  float* reward;                /* [N] */
+  unsigned char *success, *terminated; /* [N] */
+  int* status;                  /* [N] */
+  const unsigned char* mask;    /* [N] or NULL */
+} grx_point_buffers;
+
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);
 int grx_model_destroy(grx_model* m);
 int grx_model_set_table(grx_model* m, const char* name, const double* data, int n);
@@ -67,6 +83,12 @@ int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fet
 int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream);
 int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
                              float* reward_out, void* stream);
+/* PointMaze: PointMazeEnv.step for N worlds = clip + velocity clip + mj_step(1) + obs/reward/terminated/success
+ * (envs/maze/point.py:55-77, envs/maze/point_maze.py:392-406); batched MazeEnv.compute_reward (envs/maze/maze_v4.py:381-388). */
+int grx_point_step(const grx_model* m, const grx_point_task* task, const grx_point_buffers* buf, int n_worlds, void* stream);
+int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t batch, float goal_radius, int sparse, float* reward_out,
+                            void* stream);
+
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's
  * numpy PCG64 (created and seeded by numpy on the Python side), advanced in place.  All pointers are HOST pointers. */

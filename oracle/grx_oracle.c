@@ -425,6 +425,45 @@ static void collide_plane_box(orc_sim* s, int pair, int g1, int g2, double margi
   }
 }
 
+static void collide_plane_sphere(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* pm = s->geom_xmat + 9 * g1; double n[3] = {pm[2], pm[5], pm[8]};
+  const double* c = s->geom_xpos + 3 * g2; double r = m->geom_size[3 * g2];
+  double d[3] = {c[0] - s->geom_xpos[3 * g1], c[1] - s->geom_xpos[3 * g1 + 1], c[2] - s->geom_xpos[3 * g1 + 2]};
+  double dist = dot3(d, n) - r;
+  if (dist > margin) return;
+  double pos[3] = {c[0] - n[0] * (r + 0.5 * dist), c[1] - n[1] * (r + 0.5 * dist), c[2] - n[2] * (r + 0.5 * dist)};
+  add_contact(s, pair, pos, n, dist);
+}
+
+/* sphere (geom1) vs box (geom2): closest point of the box to the sphere centre; normal from the sphere to the box */
+static void collide_sphere_box(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* c = s->geom_xpos + 3 * g1; double r = m->geom_size[3 * g1];
+  const double* bp = s->geom_xpos + 3 * g2; const double* bm = s->geom_xmat + 9 * g2; const double* sz = m->geom_size + 3 * g2;
+  double dw[3] = {c[0] - bp[0], c[1] - bp[1], c[2] - bp[2]}, loc[3], cl[3];
+  mulMatTVec3(loc, bm, dw);
+  int inside = 1;
+  for (int k = 0; k < 3; k++) { cl[k] = fmin(sz[k], fmax(-sz[k], loc[k])); if (cl[k] != loc[k]) inside = 0; }
+  double nl[3], dist;
+  if (!inside) {
+    double dv[3] = {cl[0] - loc[0], cl[1] - loc[1], cl[2] - loc[2]};
+    double len = norm3(dv);
+    dist = len - r;
+    if (dist > margin) return;
+    for (int k = 0; k < 3; k++) nl[k] = dv[k] / len;
+  } else {
+    /* centre inside the box: push out through the nearest face */
+    int ax = 0; double best = 1e30;
+    for (int k = 0; k < 3; k++) { double dd = sz[k] - fabs(loc[k]); if (dd < best) { best = dd; ax = k; } }
+    nl[0] = nl[1] = nl[2] = 0; nl[ax] = loc[ax] >= 0 ? -1 : 1;
+    dist = -best - r;
+  }
+  double n[3]; mulMatVec3(n, bm, nl);
+  double pos[3] = {c[0] + n[0] * (r + 0.5 * dist), c[1] + n[1] * (r + 0.5 * dist), c[2] + n[2] * (r + 0.5 * dist)};
+  add_contact(s, pair, pos, n, dist);
+}
+
 /* plane vs convex hull of a mesh: deepest hull vertex + up to 3 of its hull neighbours
  * that are also within the margin (restated from memory of MuJoCo's plane-convex routine;
  * unverifiable here -- see DESIGN.md "mesh policy") */
@@ -614,7 +653,9 @@ static void collision(orc_sim* s) {
       if (norm3(d) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue;
     }
     if (!m->pair_supported[p]) { s->unsupported_hits++; continue; }
-    if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_BOX) collide_plane_box(s, p, g1, g2, margin);
+    if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_SPHERE) collide_plane_sphere(s, p, g1, g2, margin);
+    else if (t1 == GRX_GEOM_SPHERE && t2 == GRX_GEOM_BOX) collide_sphere_box(s, p, g1, g2, margin);
+    else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_BOX) collide_plane_box(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_MESH) collide_plane_mesh(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_BOX && t2 == GRX_GEOM_BOX) collide_box_box(s, p, g1, g2, margin);
     else s->unsupported_hits++;

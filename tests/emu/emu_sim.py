@@ -13,7 +13,7 @@ _ROOT = os.path.abspath(os.path.join(_HERE, "..", ".."))
 def build(force=False):
     so = os.path.join(_HERE, "libgrx_emu.so")
     srcs = [os.path.join(_HERE, "grx_emu.cpp")] + [
-        os.path.join(_ROOT, "gymnasium_robotics_amd", "csrc", f) for f in ("grx_engine.h", "grx_fetch_task.h", "grx_host_model.h")
+        os.path.join(_ROOT, "gymnasium_robotics_amd", "csrc", f) for f in ("grx_engine.h", "grx_fetch_task.h", "grx_point_task.h", "grx_host_model.h")
     ] + [os.path.join(_ROOT, "include", "grx_model_fields.def")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(
@@ -40,7 +40,7 @@ class EmuSim:
         self.qacc_ws = np.zeros(self.nv, np.float32)
         self.mocap = np.zeros(7 * self.nmocap, np.float32)
         self.aux = np.zeros(8, np.float32)
-        self.obs = np.zeros(task_struct.obs_dim, np.float32)
+        self.obs = np.zeros(getattr(task_struct, "obs_dim", self.nq + self.nv), np.float32)
         self.achieved = np.zeros(3, np.float32)
         self.status = ctypes.c_int(0)
 
@@ -65,3 +65,10 @@ class EmuSim:
         ptr = self.L.emu_ctx_ptr(ctypes.c_void_p(self.h), name.encode())
         a = np.ctypeslib.as_array(ptr, shape=(n,)).copy()
         return a.view(np.int32) if dtype == np.int32 else a
+
+
+    def point_step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        self.L.emu_point_step(ctypes.c_void_p(self.h), ctypes.byref(self.task), p(self.qpos), p(self.qvel), p(self.qacc_ws), p(a), p(self.obs),
+                              p(self.achieved), ctypes.byref(self.status))

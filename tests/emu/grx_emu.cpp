@@ -26,6 +26,7 @@
 #endif
 
 #include "../../gymnasium_robotics_amd/csrc/grx_fetch_task.h"
+#include "../../gymnasium_robotics_amd/csrc/grx_point_task.h"
 #include "../../gymnasium_robotics_amd/csrc/grx_host_model.h"
 
 struct Emu {
@@ -89,6 +90,16 @@ void emu_forward(void* h, const GrxFetchTask* t, float* qpos, float* qvel, float
   load_state(e, qpos, qvel, qacc_ws, mocap);
   { const int total = nstep > 0 ? nstep : 1; for (int s = 0; s < total; s++) GrxEngine<0>::grx_forward_euler(&e->m, &e->c, nstep > 0, 0); }
   GrxFetch<0>::grx_fetch_outputs(&e->m, t, &e->c, aux, obs, achieved, 0);
+  store_state(e, qpos, qvel, qacc_ws, mocap, status);
+}
+
+// PointMaze env.step() of one world
+void emu_point_step(void* h, const GrxPointTask* t, float* qpos, float* qvel, float* qacc_ws, const float* action, float* obs, float* achieved,
+                    int* status) {
+  Emu* e = (Emu*)h;
+  float mocap[8] = {0};
+  load_state(e, qpos, qvel, qacc_ws, mocap);
+  GrxPoint<0>::grx_point_step_world(&e->m, t, &e->c, action, obs, achieved, 0);
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 

@@ -1,0 +1,82 @@
+"""CPU tests of the Maze family: the reference's own golden vectors for reset (RNG draw order + cell -> xy mapping),
+reset properties, registry, and the PointMaze kernel source (lane emulator) against the fp64 oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from gymnasium_robotics_amd.core import np_random
+from gymnasium_robotics_amd.envs.maze_spec import MAPS, Maze, parse_point_maze_id, sample_maze_reset
+from gymnasium_robotics_amd.mjcf import load_model
+
+MODELS = os.path.join(os.path.dirname(__file__), "..", "gymnasium_robotics_amd", "models")
+
+
+def test_reference_golden_reset_cell():
+    """/root/reference/tests/envs/maze/test_point_maze.py:20-31: reset(seed=42, options={"reset_cell": [1, 2]}) -> obs [0.67929896, 0.59868401, 0, 0]"""
+    maze = Maze([[1, 1, 1, 1], [1, "r", "r", 1], [1, "r", "g", 1], [1, 1, 1, 1]], 1.0, 0.4)
+    goal, reset_pos = sample_maze_reset(maze, np_random(42)[0], 0.25, {"reset_cell": [1, 2]})
+    np.testing.assert_almost_equal(np.array([0.67929896, 0.59868401]), reset_pos, decimal=7)
+
+
+def test_reference_golden_goal_cell():
+    """test_point_maze.py:34-45: reset(seed=42, options={"goal_cell": [2, 1]}) -> desired_goal [-0.36302198, -0.53056078]"""
+    maze = Maze([[1, 1, 1, 1], [1, "r", "g", 1], [1, "g", "g", 1], [1, 1, 1, 1]], 1.0, 0.4)
+    goal, reset_pos = sample_maze_reset(maze, np_random(42)[0], 0.25, {"goal_cell": [2, 1]})
+    np.testing.assert_almost_equal(np.array([-0.36302198, -0.53056078]), goal, decimal=7)
+
+
+def test_reset_never_starts_inside_goal_radius():
+    """test_point_maze.py:9-17 / test_ant_maze.py:12-21: 1000 resets, distance to the goal always > 0.45"""
+    maze = Maze(MAPS["UMaze"], 1.0, 0.4)
+    rng = np_random(0)[0]
+    for _ in range(1000):
+        goal, pos = sample_maze_reset(maze, rng, 0.25)
+        assert np.linalg.norm(pos - goal) > 0.45
+    with pytest.raises(AssertionError):
+        sample_maze_reset(maze, rng, 0.25, {"goal_cell": [0, 0]})
+
+
+def test_registry_and_wall_layouts():
+    assert parse_point_maze_id("PointMaze_UMaze-v3") == ("UMaze", "sparse", 300)
+    assert parse_point_maze_id("PointMaze_Medium_Diverse_GRDense-v3") == ("Medium_Diverse_GR", "dense", 600)
+    assert parse_point_maze_id("PointMaze_Large_Diverse_G-v3")[2] == 800
+    with pytest.raises(KeyError):
+        parse_point_maze_id("PointMaze_Huge-v3")
+    for base in ("UMaze", "Open", "Medium", "Large"):
+        m = load_model(os.path.join(MODELS, f"point_{base}.npz"))
+        maze = Maze(MAPS[base], 1.0, 0.4)
+        assert m.dim("ngeom") == len(maze.walls) + 2 and m.dim("npair") == len(maze.walls) + 1  # + ground plane, particle
+        assert (m.dim("nq"), m.dim("nv"), m.dim("nu")) == (2, 2, 2) and m.info["unsupported_pairs"] == 0
+        for v in ("_Diverse_G", "_Diverse_GR"):  # same walls, different goal/reset cells
+            if base + v in MAPS:
+                assert [(i, j) for i, j, _ in Maze(MAPS[base + v], 1.0, 0.4).walls] == [(i, j) for i, j, _ in maze.walls]
+    d = Maze(MAPS["Large_Diverse_GR"], 1.0, 0.4)
+    assert len(d.unique_goal_locations) == 8 and len(d.unique_reset_locations) == 8  # 8 combined cells
+
+
+def test_emulated_point_kernel_matches_oracle():
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd import _native
+    from oracle.maze_oracle import OraclePointMazeEnv
+
+    model = load_model(os.path.join(MODELS, "point_UMaze.npz"))
+    maze = Maze(MAPS["UMaze"], 1.0, 0.4)
+    env = OraclePointMazeEnv(model, maze)
+    emu = EmuSim(model, _native.PointTaskStruct(1, 1, 1, 0, 0.45, 5.0))
+    rng = np.random.default_rng(3)
+    worst, hits = 0.0, 0
+    for ep in range(3):
+        obs, _ = env.reset(seed=ep)
+        emu.qpos[:], emu.qvel[:], emu.qacc_ws[:] = obs["observation"][:2], 0, 0
+        drive = rng.uniform(-1, 1, 2)
+        for t in range(150):
+            a = np.clip(drive + 0.3 * rng.uniform(-1, 1, 2), -1, 1).astype(np.float32)  # persistent push: runs into walls
+            obs, r, te, tr, info = env.step(a.astype(np.float64))
+            emu.point_step(a)
+            assert emu.status.value == 0
+            worst = max(worst, np.abs(emu.obs - obs["observation"]).max())
+            hits += env.sim.nefc > 1
+    assert hits > 20, "the rollout never touched a wall"
+    assert worst < 1e-4, worst

@@ -21,3 +21,12 @@ for xml in ("fetch/reach.xml", "fetch/push.xml", "fetch/pick_and_place.xml"):
     save_model(m, out)
     print(xml, "->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "unsupported pairs:", m.info["unsupported_pairs"],
           f"{os.path.getsize(out) / 1024:.0f} KiB")
+
+from gymnasium_robotics_amd.envs.maze_spec import MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze  # noqa: E402
+
+for layout in ("UMaze", "Open", "Medium", "Large"):
+    maze = Maze(MAPS[layout], POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT)
+    m = compile_mjcf(os.path.join(ASSETS, "point", "point.xml"), mutate=maze.add_walls)
+    out = os.path.join(OUT, f"point_{layout}.npz")
+    save_model(m, out)
+    print("point.xml +", layout, "walls ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "ngeom", "npair")}, f"{os.path.getsize(out) / 1024:.0f} KiB")
