@@ -124,6 +124,14 @@ def main():
     # dominant kernel: average duration of the grx_fetch_step_kernel launches of the timed region
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in env.kernel_events]))
 
+    # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
+    # (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); the committed summary is profiles/pmc_r01_hbm_traffic.*
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_r01_hbm_traffic.json")) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"] if n == WORLDS_PER_GPU else None
+    except OSError:
+        pass
     if rank == 0:
         total_steps = n * n_gpus * args.steps
         value = total_steps / elapsed
@@ -137,7 +145,8 @@ def main():
                        "parallelism": f"world-shard x{n_gpus}" + (", RCCL all_gather of outputs" if n_gpus > 1 else ""),
                        "status_max": status_max},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "grx_fetch_step_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": "profiles/pmc_r01_hbm_traffic.txt (rocprofv3 PMC, bytes per launch)",
+                         "kernel": "grx_fetch_step_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "note": "fused path is VALU/LDS/latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md"},
         }
