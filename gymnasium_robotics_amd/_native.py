@@ -18,7 +18,7 @@ class FetchBuffersStruct(ctypes.Structure):
 
 
 class PointTaskStruct(ctypes.Structure):
-    _fields_ = [("n_substeps", ctypes.c_int), ("sparse_reward", ctypes.c_int), ("continuing_task", ctypes.c_int), ("pad_", ctypes.c_int),
+    _fields_ = [("n_substeps", ctypes.c_int), ("sparse_reward", ctypes.c_int), ("continuing_task", ctypes.c_int), ("agent", ctypes.c_int),
                 ("goal_radius", ctypes.c_float), ("vel_clip", ctypes.c_float)]
 
 

@@ -79,7 +79,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -103,6 +103,7 @@ struct GrxCtx {
   float *Jp, *efc_pos, *efc_D, *efc_aref, *efc_jar, *efc_jv, *efc_force, *efc_floss;
   int *efc_kind, *efc_id, *efc_quad, *efc_row;  // efc_id packs (id << 4) | sub
   // scratch
+  float *rk_q0, *rk_v0, *rk_Fv, *rk_Fa;  // RK4: state at the start of the step, per-stage velocities / accelerations
   float* red;  // 128 floats
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
@@ -115,12 +116,13 @@ struct GrxCtx {
 // body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
 // Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
 // body frames, motion axes, M, J, row parameters) is persistent.
-GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric) {
+GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
   pers += GRX_JPOOL + GRX_MAXEFC * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
-  pers += 32 + 8;                                                   // ired, cnt
+  pers += 32 + 8;
+  if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
   int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 3 + 6);
@@ -144,6 +146,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
   c->efc_floss = p; if (m->nfric) p += GRX_MAXEFC;
   CARVEI(efc_kind, GRX_MAXEFC) CARVEI(efc_id, GRX_MAXEFC) CARVEI(efc_row, GRX_MAXEFC)
   CARVEI(ired, 32) CARVEI(cnt, 8)
+  if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
   float* overlay = p;
   // ---- P1 (kinematics .. velocity stage)
   {
@@ -743,6 +746,80 @@ GRX_MEM void grx_sphere_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int 
   grx_add_contact(c, pair, pos, n, dist);
 }
 
+// plane vs capsule: the two end spheres
+GRX_MEM void grx_plane_capsule(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]};
+  const float* ce = c->gxpos + 3 * g2; const float* R = c->gxmat + 9 * g2;
+  float r = m->geom_size[3 * g2], hl = m->geom_size[3 * g2 + 1], ax[3] = {R[2], R[5], R[8]};
+  for (int e = -1; e <= 1; e += 2) {
+    float p[3] = {ce[0] + e * hl * ax[0], ce[1] + e * hl * ax[1], ce[2] + e * hl * ax[2]};
+    float d[3] = {p[0] - c->gxpos[3 * g1], p[1] - c->gxpos[3 * g1 + 1], p[2] - c->gxpos[3 * g1 + 2]};
+    float dist = dot3f(d, n) - r;
+    if (dist > margin) continue;
+    float pos[3] = {p[0] - n[0] * (r + 0.5f * dist), p[1] - n[1] * (r + 0.5f * dist), p[2] - n[2] * (r + 0.5f * dist)};
+    grx_add_contact(c, pair, pos, n, dist);
+  }
+}
+
+GRX_MEM float grx_box_point_dist2(float s0, float s1, float s2, float p0, float p1, float p2) {
+  float d0 = p0 - fminf(s0, fmaxf(-s0, p0)), d1 = p1 - fminf(s1, fmaxf(-s1, p1)), d2 = p2 - fminf(s2, fmaxf(-s2, p2));
+  return d0 * d0 + d1 * d1 + d2 * d2;
+}
+// sphere of radius r at box-frame point p against the box (normal from the sphere to the box); returns 1 if a contact was made
+GRX_MEM int grx_sphere_box_local(GrxCtx* c, int pair, const float* bp, const float* bm, float s0, float s1, float s2, const float* p, float r, float margin) {
+  float c0 = fminf(s0, fmaxf(-s0, p[0])), c1 = fminf(s1, fmaxf(-s1, p[1])), c2 = fminf(s2, fmaxf(-s2, p[2]));
+  float nl[3], dist;
+  if (c0 != p[0] || c1 != p[1] || c2 != p[2]) {
+    float dv[3] = {c0 - p[0], c1 - p[1], c2 - p[2]};
+    float len = sqrtf(dot3f(dv, dv));
+    dist = len - r;
+    if (dist > margin) return 0;
+    float li = 1.0f / len; nl[0] = dv[0] * li; nl[1] = dv[1] * li; nl[2] = dv[2] * li;
+  } else {
+    float d0 = s0 - fabsf(p[0]), d1 = s1 - fabsf(p[1]), d2 = s2 - fabsf(p[2]);
+    int ax = 0; float best = d0;
+    if (d1 < best) { best = d1; ax = 1; }
+    if (d2 < best) { best = d2; ax = 2; }
+    float sg = (GRX_SEL3(p[0], p[1], p[2], ax) >= 0) ? -1.0f : 1.0f;
+    nl[0] = (ax == 0) ? sg : 0.0f; nl[1] = (ax == 1) ? sg : 0.0f; nl[2] = (ax == 2) ? sg : 0.0f;
+    dist = -best - r;
+  }
+  float n[3], pw[3]; mulMatVec3f(n, bm, nl); mulMatVec3f(pw, bm, p);
+  float pos[3] = {pw[0] + bp[0] + n[0] * (r + 0.5f * dist), pw[1] + bp[1] + n[1] * (r + 0.5f * dist), pw[2] + bp[2] + n[2] * (r + 0.5f * dist)};
+  grx_add_contact(c, pair, pos, n, dist);
+  return 1;
+}
+// capsule (geom1) vs box (geom2): axis point closest to the box (golden-section search, the distance is convex along the
+// axis) as a sphere contact, plus the farther end sphere when it is inside the margin as well (see oracle/grx_oracle.c)
+GRX_MEM void grx_capsule_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  const float* ce = c->gxpos + 3 * g1; const float* R = c->gxmat + 9 * g1;
+  const float* bp = c->gxpos + 3 * g2; const float* bm = c->gxmat + 9 * g2; const float* sz = m->geom_size + 3 * g2;
+  const float r = m->geom_size[3 * g1], hl = m->geom_size[3 * g1 + 1], s0 = sz[0], s1 = sz[1], s2 = sz[2];
+  float axw[3] = {R[2], R[5], R[8]}, dw[3] = {ce[0] - bp[0], ce[1] - bp[1], ce[2] - bp[2]}, cen[3], ax[3];
+  mulMatTVec3f(cen, bm, dw); mulMatTVec3f(ax, bm, axw);
+  float lo = -hl, hi = hl;
+  const float gr = 0.6180339887f;
+  float t1 = hi - gr * (hi - lo), t2 = lo + gr * (hi - lo);
+  float f1 = grx_box_point_dist2(s0, s1, s2, cen[0] + t1 * ax[0], cen[1] + t1 * ax[1], cen[2] + t1 * ax[2]);
+  float f2 = grx_box_point_dist2(s0, s1, s2, cen[0] + t2 * ax[0], cen[1] + t2 * ax[1], cen[2] + t2 * ax[2]);
+  for (int it = 0; it < 30; it++) {
+    if (f1 <= f2) { hi = t2; t2 = t1; f2 = f1; t1 = hi - gr * (hi - lo); f1 = grx_box_point_dist2(s0, s1, s2, cen[0] + t1 * ax[0], cen[1] + t1 * ax[1], cen[2] + t1 * ax[2]); }
+    else { lo = t1; t1 = t2; f1 = f2; t2 = lo + gr * (hi - lo); f2 = grx_box_point_dist2(s0, s1, s2, cen[0] + t2 * ax[0], cen[1] + t2 * ax[1], cen[2] + t2 * ax[2]); }
+  }
+  float ts = 0.5f * (lo + hi);
+  for (int e = -1; e <= 1; e += 2) {
+    float fe = grx_box_point_dist2(s0, s1, s2, cen[0] + e * hl * ax[0], cen[1] + e * hl * ax[1], cen[2] + e * hl * ax[2]);
+    if (fe <= fminf(f1, f2)) ts = e * hl;
+  }
+  float ps[3] = {cen[0] + ts * ax[0], cen[1] + ts * ax[1], cen[2] + ts * ax[2]};
+  if (!grx_sphere_box_local(c, pair, bp, bm, s0, s1, s2, ps, r, margin)) return;
+  float te = (ts >= 0) ? -hl : hl;
+  if (fabsf(te - ts) > 0.2f * hl) {
+    float pf[3] = {cen[0] + te * ax[0], cen[1] + te * ax[1], cen[2] + te * ax[2]};
+    grx_sphere_box_local(c, pair, bp, bm, s0, s1, s2, pf, r, margin);
+  }
+}
+
 // plane vs a SMALL convex vertex set (<= 32 hull vertices, e.g. the compile-time pruned hulls): one lane does it all
 GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
   const float* gm = c->gxmat + 9 * g2;
@@ -931,6 +1008,8 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
         }
         if (pass) {
           if (t1 == 0 && t2 == 2) grx_plane_sphere(m, c, p, g1, g2, margin);
+          else if (t1 == 0 && t2 == 3) grx_plane_capsule(m, c, p, g1, g2, margin);
+          else if (t1 == 3 && t2 == 6) grx_capsule_box(m, c, p, g1, g2, margin);
           else if (t1 == 2 && t2 == 6) grx_sphere_box(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
           else if (t1 == 6 && t2 == 6) grx_box_box(m, c, p, g1, g2, margin);
@@ -1574,6 +1653,58 @@ GRX_MEM void grx_forward_euler(const GrxModel* m, GrxCtx* c, int do_euler, int l
   grx_velocity(m, c, lane_);
   GRX_TICK(c, GRX_P_VEL);
   grx_solve_integrate(m, c, do_euler, lane_);
+}
+
+// qpos <- q0 (+) hh * v  (mj_integratePos semantics: quaternion exponential for free joints), one lane per joint
+GRX_MEM void grx_integrate_pos(const GrxModel* m, GrxCtx* c, const float* q0, const float* v, float hh, int lane_) {
+  FOR_LANES {
+    for (int j = lane; j < m->njnt; j += 64) {
+      int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == 0) {
+        for (int k = 0; k < 3; k++) c->qpos[qa + k] = q0[qa + k] + hh * v[da + k];
+        float w[3] = {v[da + 3], v[da + 4], v[da + 5]};
+        float n = sqrtf(dot3f(w, w));
+        float q[4] = {q0[qa + 3], q0[qa + 4], q0[qa + 5], q0[qa + 6]};
+        if (n > 1e-12f) {
+          float sn, cs; sincosf(0.5f * hh * n, &sn, &cs);
+          float ri = sn / n, qr[4] = {cs, w[0] * ri, w[1] * ri, w[2] * ri}, qn[4];
+          mulQuatf(qn, q, qr); normalize4f(qn);
+          for (int k = 0; k < 4; k++) q[k] = qn[k];
+        }
+        for (int k = 0; k < 4; k++) c->qpos[qa + 3 + k] = q[k];
+      } else c->qpos[qa] = q0[qa] + hh * v[da];
+    }
+  }
+  WAVE_SYNC();
+}
+
+// Runge-Kutta 4 (mj_RungeKutta [3P]).  Call after the forward pass of stage `stage` (0..3): records the
+// stage derivative and moves the state to the next stage point (stages 0..2) or to the end of the step (stage 3).
+GRX_MEM void grx_rk4_after_forward(const GrxModel* m, GrxCtx* c, int stage, int lane_) {
+  const int nv = GRX_NVC; const float h = m->timestep;
+  FOR_LANES {
+    if (stage == 0) {
+      for (int i = lane; i < m->nq; i += 64) c->rk_q0[i] = c->qpos[i];
+      for (int i = lane; i < nv; i += 64) c->rk_v0[i] = c->qvel[i];
+    }
+    for (int i = lane; i < nv; i += 64) { c->rk_Fv[stage * nv + i] = c->qvel[i]; c->rk_Fa[stage * nv + i] = c->qacc[i]; }
+  }
+  WAVE_SYNC();
+  const float hh = (stage < 2) ? 0.5f * h : h;
+  FOR_LANES {
+    for (int i = lane; i < nv; i += 64) {
+      float dv, da;
+      if (stage < 3) { dv = c->rk_Fv[stage * nv + i]; da = c->rk_Fa[stage * nv + i]; }
+      else {
+        dv = (c->rk_Fv[i] + 2.0f * c->rk_Fv[nv + i] + 2.0f * c->rk_Fv[2 * nv + i] + c->rk_Fv[3 * nv + i]) * (1.0f / 6.0f);
+        da = (c->rk_Fa[i] + 2.0f * c->rk_Fa[nv + i] + 2.0f * c->rk_Fa[2 * nv + i] + c->rk_Fa[3 * nv + i]) * (1.0f / 6.0f);
+      }
+      c->tmpv[i] = dv;
+      c->qvel[i] = c->rk_v0[i] + hh * da;
+    }
+  }
+  WAVE_SYNC();
+  grx_integrate_pos(m, c, c->rk_q0, c->tmpv, hh, lane_);
 }
 
 GRX_MEM void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {

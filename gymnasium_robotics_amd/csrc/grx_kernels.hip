@@ -122,7 +122,7 @@ grx_point_step_kernel(GrxModel m, GrxPointTask t, GrxPointBuffers b, int n_world
   for (int i = lane_; i < m.nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * m.nq + i];
   for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
   __syncthreads();
-  float* obs = b.obs + (size_t)w * (m.nq + m.nv); float* ach = b.achieved + (size_t)w * 2;
+  float* obs = b.obs + (size_t)w * (m.nq + m.nv - (t.agent ? 2 : 0)); float* ach = b.achieved + (size_t)w * 2;
   GrxPoint<0>::grx_point_step_world(&m, &t, &c, b.action + (size_t)w * m.nu, obs, ach, lane_);
   __syncthreads();
   for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
@@ -212,7 +212,7 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   HIP_OK(hipMemcpy(m->d_i, m->pm.i.data(), sizeof(int32_t) * m->pm.i.size(), hipMemcpyHostToDevice));
   m->dev = grx_bind_model(m->pm, m->d_f, m->d_i);
   const GrxModel& g = m->dev;
-  m->words = grx_ctx_words(g.nq, g.nv, g.nu, g.nbody, g.njnt, g.ngeom, g.nsite, g.nmocap, g.nfric);
+  m->words = grx_ctx_words(g.nq, g.nv, g.nu, g.nbody, g.njnt, g.ngeom, g.nsite, g.nmocap, g.nfric, g.integrator);
   int bytes = m->words * 4;
   if (bytes > 160 * 1024) return fail("model working set exceeds the 160 KiB LDS of a CU");
   if (g.njnt > 32) return fail("engine limit: at most 32 joints per world (limit-flag table in LDS)");

@@ -6,11 +6,14 @@
 //   PointMazeEnv.step ........ envs/maze/point_maze.py:392-406 (achieved goal = xy, reward, terminated, success)
 //   MazeEnv.compute_reward ... envs/maze/maze_v4.py:381-388   (dense exp(-d), sparse d <= 0.45)
 //   MazeEnv.compute_terminated envs/maze/maze_v4.py:390-398
+//   AntMazeEnv.step / _get_obs envs/maze/ant_maze_v5.py:295-320 (AntEnv.step [3P]: ctrl = action, do_simulation(a, 5) with the
+//                              RK4 integrator of ant.xml; obs = qpos | qvel; achieved goal = xy, observation = the rest)
 #pragma once
 #include "grx_engine.h"
 
 struct GrxPointTask {
-  int n_substeps, sparse_reward, continuing_task, pad_;
+  int n_substeps, sparse_reward, continuing_task;
+  int agent;  // 0 = point mass (point.py), 1 = ant (gymnasium AntEnv-v5 [3P] wrapped by ant_maze_v5.py:295-320)
   float goal_radius, vel_clip;
 };
 
@@ -36,18 +39,26 @@ struct GrxPoint {
   typedef GrxEngine<NV> E;
   GRX_MEM void grx_point_step_world(const GrxModel* m, const GrxPointTask* t, GrxCtx* c, const float* action, float* obs, float* achieved,
                                     int lane_) {
+    const int ant = t->agent;
     FOR_LANES {
-      for (int i = lane; i < m->nu; i += 64) c->ctrl[i] = fminf(1.0f, fmaxf(-1.0f, action[i]));
-      for (int i = lane; i < GRX_NVC; i += 64) c->qvel[i] = fminf(t->vel_clip, fmaxf(-t->vel_clip, c->qvel[i]));
+      // point: np.clip(action, -1, 1) and the velocity clip of point.py:57,73-77; ant: ctrl = action (ctrlrange is applied by the actuator model)
+      for (int i = lane; i < m->nu; i += 64) c->ctrl[i] = ant ? action[i] : fminf(1.0f, fmaxf(-1.0f, action[i]));
+      if (!ant) for (int i = lane; i < GRX_NVC; i += 64) c->qvel[i] = fminf(t->vel_clip, fmaxf(-t->vel_clip, c->qvel[i]));
     }
     WAVE_SYNC();
-    for (int s = 0; s < t->n_substeps; s++) {
-      E::grx_check_state(m, c, lane_);
-      E::grx_forward_euler(m, c, 1, lane_);
+    // Euler models: one forward+integrate per substep.  RK4 models: four forward passes per substep.  One loop, one call site.
+    const int rk4 = (m->integrator == 1);
+    const int total = rk4 ? 4 * t->n_substeps : t->n_substeps;
+    for (int it = 0; it < total; it++) {
+      const int stage = it & 3;
+      if (!rk4 || stage == 0) E::grx_check_state(m, c, lane_);
+      E::grx_forward_euler(m, c, !rk4, lane_);
+      if (rk4) E::grx_rk4_after_forward(m, c, stage, lane_);
     }
+    const int skip = ant ? 2 : 0;  // AntMaze strips the xy position from the observation (it is the achieved goal)
     FOR_LANES {
-      for (int i = lane; i < m->nq; i += 64) { float q = c->qpos[i]; obs[i] = q; if (i < 2) achieved[i] = q; }
-      for (int i = lane; i < GRX_NVC; i += 64) obs[m->nq + i] = c->qvel[i];
+      for (int i = lane; i < m->nq; i += 64) { float q = c->qpos[i]; if (i >= skip) obs[i - skip] = q; if (i < 2) achieved[i] = q; }
+      for (int i = lane; i < GRX_NVC; i += 64) obs[m->nq - skip + i] = c->qvel[i];
     }
     WAVE_SYNC();
   }

@@ -40,6 +40,8 @@ MAPS = {
 }
 POINT_MAX_EPISODE_STEPS = {"UMaze": 300, "Open": 300, "Medium": 600, "Large": 800}  # __init__.py:962-1078
 POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT = 1.0, 0.4                                   # point_maze.py:331-332
+ANT_MAX_EPISODE_STEPS = {"UMaze": 700, "Open": 700, "Medium": 1000, "Large": 1000}    # __init__.py:839-958
+ANT_MAZE_SIZE_SCALING, ANT_MAZE_HEIGHT, ANT_FRAME_SKIP = 4.0, 0.5, 5                    # ant_maze_v5.py:241-242; AntEnv frame_skip [3P]
 GOAL_RADIUS = 0.45
 
 
@@ -55,6 +57,20 @@ def parse_point_maze_id(env_id: str):
     if name not in MAPS:
         raise KeyError(f"unknown PointMaze env id {env_id}")
     return name, reward_type, POINT_MAX_EPISODE_STEPS[name.split("_")[0]]
+
+
+def parse_ant_maze_id(env_id: str):
+    """'AntMaze_Large_Diverse_GR-v5' -> ('Large_Diverse_GR', 'sparse', 1000)"""
+    base, _, ver = env_id.partition("-v")
+    if not base.startswith("AntMaze_") or ver not in ("5",):
+        raise KeyError(f"unknown / unsupported AntMaze env id {env_id} (only the v5 ids are in scope)")
+    name = base[len("AntMaze_"):]
+    reward_type = "sparse"
+    if name.endswith("Dense"):
+        name, reward_type = name[: -len("Dense")], "dense"
+    if name not in MAPS:
+        raise KeyError(f"unknown AntMaze env id {env_id}")
+    return name, reward_type, ANT_MAX_EPISODE_STEPS[name.split("_")[0]]
 
 
 class Maze:

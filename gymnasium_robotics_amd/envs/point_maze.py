@@ -17,33 +17,40 @@ from .. import _native
 from ..core import GoalVecEnv, np_random
 from ..mjcf import CompiledModel, compile_mjcf, load_model
 from ..spaces import Box, Dict, batch_space
-from .maze_spec import GOAL_RADIUS, MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze, parse_point_maze_id, sample_maze_reset
+from .maze_spec import (ANT_FRAME_SKIP, ANT_MAZE_HEIGHT, ANT_MAZE_SIZE_SCALING, GOAL_RADIUS, MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze,
+                        parse_ant_maze_id, parse_point_maze_id, sample_maze_reset)
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
 
 
-def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: Optional[str] = None) -> CompiledModel:
-    """Model tables of point.xml + one wall box per wall cell.  Compiled from MJCF when an asset tree is available
-    (needed for custom maze maps), else the packaged blob of the registered wall layout."""
+def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: Optional[str] = None, agent: str = "point") -> CompiledModel:
+    """Model tables of the agent MJCF (point.xml / ant.xml) + one wall box per wall cell.  Compiled from MJCF when an asset
+    tree is available (needed for custom maze maps), else the packaged blob of the registered wall layout.
+    ant.xml: the reference takes it from the gymnasium package [3P]; the tree's envs/mujoco/assets/ant.xml is the same model."""
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
-        return compile_mjcf(os.path.join(assets_root, "point", "point.xml"), mutate=maze.add_walls)
+        xml = os.path.join(assets_root, "point", "point.xml") if agent == "point" else os.path.join(assets_root, "..", "mujoco", "assets", "ant.xml")
+        return compile_mjcf(xml, mutate=maze.add_walls)
     if layout_name is None:
         raise OSError("custom maze maps need the MJCF assets (assets_root / $GRX_ASSETS_ROOT)")
-    path = os.path.join(_MODELS_DIR, f"point_{layout_name.split('_')[0]}.npz")
+    path = os.path.join(_MODELS_DIR, f"{agent}_{layout_name.split('_')[0]}.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")
     return load_model(path)
 
 
 class PointMazeVecEnv(GoalVecEnv):
+    AGENT, N_SUBSTEPS, OBS_SKIP, DEFAULT_MAX_EPISODE_STEPS = "point", 1, 0, 300
+    MAZE_GEOMETRY = (POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT)
+    _parse_id = staticmethod(parse_point_maze_id)
+
     def __init__(self, env_id: Optional[str] = "PointMaze_UMaze-v3", num_envs: int = 1, device: Optional[str] = None, maze_map=None,
                  reward_type: Optional[str] = None, continuing_task: bool = True, reset_target: bool = False,
                  position_noise_range: float = 0.25, max_episode_steps: Optional[int] = -1, autoreset_mode: str = "next_step",
                  output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
-        layout, rt, mes = (None, "sparse", 300)
+        layout, rt, mes = (None, "sparse", self.DEFAULT_MAX_EPISODE_STEPS)
         if maze_map is None:
-            layout, rt, mes = parse_point_maze_id(env_id)
+            layout, rt, mes = self._parse_id(env_id)
             maze_map = MAPS[layout]
         if reset_target:
             raise NotImplementedError("reset_target=True (goal redraw inside step, maze_v4.py:400-418) is not implemented yet")
@@ -54,29 +61,32 @@ class PointMazeVecEnv(GoalVecEnv):
         if not torch.cuda.is_available():
             raise RuntimeError("PointMazeVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
         self.device = torch.device(device or "cuda:0")
-        self.maze = Maze(maze_map, POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT)
-        self.model = model or load_point_maze_model(self.maze, layout, assets_root)
+        self.maze = Maze(maze_map, *self.MAZE_GEOMETRY)
+        self.model = model or load_point_maze_model(self.maze, layout, assets_root, self.AGENT)
         self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
         self._L = _native.lib()
         H, I, F = self.model.pack()
         self._h = ctypes.c_void_p()
         _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0,
                                                ctypes.byref(self._h)))
-        self.task = _native.PointTaskStruct(1, int(self.reward_type == "sparse"), int(continuing_task), 0, GOAL_RADIUS, 5.0)
+        self.task = _native.PointTaskStruct(self.N_SUBSTEPS, int(self.reward_type == "sparse"), int(continuing_task), int(self.AGENT == "ant"),
+                                            GOAL_RADIUS, 5.0)
+        self.obs_dim = self.nq + self.nv - self.OBS_SKIP
         n, d = self.num_envs, self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
         self.qpos, self.qvel, self.qacc_ws = z(n, self.nq), z(n, self.nv), z(n, self.nv)
-        self.goal, self.action, self.obs, self.achieved, self.reward = z(n, 2), z(n, self.nu), z(n, self.nq + self.nv), z(n, 2), z(n)
+        self.goal, self.action, self.obs, self.achieved, self.reward = z(n, 2), z(n, self.nu), z(n, self.obs_dim), z(n, 2), z(n)
         self.success, self.terminated = z(n, dtype=torch.uint8), z(n, dtype=torch.uint8)
         self.status, self.mask = z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)
         self.single_observation_space = Dict(dict(
-            observation=Box(-np.inf, np.inf, (self.nq + self.nv,), np.float64), achieved_goal=Box(-np.inf, np.inf, (2,), np.float64),
+            observation=Box(-np.inf, np.inf, (self.obs_dim,), np.float64), achieved_goal=Box(-np.inf, np.inf, (2,), np.float64),
             desired_goal=Box(-np.inf, np.inf, (2,), np.float64)))
         self.action_space = batch_space(self.single_action_space, n)
         self.observation_space = batch_space(self.single_observation_space, n)
         self._check_goal_space()
+        self._qpos0 = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32)).to(d)
         self.np_randoms = [np_random(None)[0] for _ in range(n)]
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
@@ -100,14 +110,14 @@ class PointMazeVecEnv(GoalVecEnv):
         for k, w in enumerate(idx):
             goals[k], starts[k] = sample_maze_reset(self.maze, self.np_randoms[w], self.position_noise_range, options)
         ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
-        q = torch.zeros(len(idx), self.nq, device=self.device)
+        q = self._qpos0.unsqueeze(0).repeat(len(idx), 1)  # init_qpos = the model's qpos0 with xy <- reset position
         q[:, :2] = torch.from_numpy(starts.astype(np.float32)).to(self.device)
         self.qpos[ti] = q
         self.qvel[ti] = 0.0
         self.qacc_ws[ti] = 0.0
         self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
-        o = torch.zeros(len(idx), self.nq + self.nv, device=self.device)
-        o[:, : self.nq] = q
+        o = torch.zeros(len(idx), self.obs_dim, device=self.device)
+        o[:, : self.nq - self.OBS_SKIP] = q[:, self.OBS_SKIP:]
         self.obs[ti] = o
         self.achieved[ti] = q[:, :2]
         d = torch.linalg.norm(self.achieved[ti] - self.goal[ti], dim=-1)
@@ -202,3 +212,15 @@ class PointMazeVecEnv(GoalVecEnv):
             self.close()
         except Exception:
             pass
+
+
+class AntMazeVecEnv(PointMazeVecEnv):
+    """Batched AntMaze (ids AntMaze_*-v5, /root/reference/gymnasium_robotics/envs/maze/ant_maze_v5.py:221-320): the same maze logic
+    around gymnasium's Ant [3P] -- free-floating torso + 8 hinges, RK4, 5 substeps of 0.01 s, observation = qpos[2:] | qvel (27)."""
+
+    AGENT, N_SUBSTEPS, OBS_SKIP, DEFAULT_MAX_EPISODE_STEPS = "ant", ANT_FRAME_SKIP, 2, 700
+    MAZE_GEOMETRY = (ANT_MAZE_SIZE_SCALING, ANT_MAZE_HEIGHT)
+    _parse_id = staticmethod(parse_ant_maze_id)
+
+    def __init__(self, env_id: Optional[str] = "AntMaze_UMaze-v5", num_envs: int = 1, **kw):
+        super().__init__(env_id, num_envs, **kw)

@@ -1037,7 +1037,8 @@ class _Lowering:
                 excludes.add((min(b1, b2), max(b1, b2)))
         weldparent = [weld[B[weld[i]].parent] if weld[i] > 0 else 0 for i in range(nb)]
         # narrow-phase routines implemented by BOTH the device engine and the oracle
-        supported = {(GEOM_PLANE, GEOM_BOX), (GEOM_PLANE, GEOM_MESH), (GEOM_BOX, GEOM_BOX), (GEOM_PLANE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_BOX)}
+        supported = {(GEOM_PLANE, GEOM_BOX), (GEOM_PLANE, GEOM_MESH), (GEOM_BOX, GEOM_BOX), (GEOM_PLANE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_BOX),
+                     (GEOM_PLANE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX)}
         pairs = []
         for a in range(ng):
             for b_ in range(a + 1, ng):

@@ -59,14 +59,15 @@ typedef struct grx_fetch_buffers {
 
 /* mirrors struct GrxPointTask / GrxPointBuffers (csrc/grx_point_task.h) */
 typedef struct grx_point_task {
-  int n_substeps, sparse_reward, continuing_task, pad_;
+  int n_substeps, sparse_reward, continuing_task;
+  int agent; /* 0 = PointMaze particle, 1 = AntMaze ant (RK4, obs without xy) */
   float goal_radius, vel_clip;
 } grx_point_task;
 typedef struct grx_point_buffers {
   float *qpos, *qvel, *qacc_ws; /* [N,nq] [N,nv] [N,nv] */
   const float* goal;            /* [N,2] */
   const float* action;          /* [N,nu] */
-  float *obs, *achieved;        /* [N,nq+nv] [N,2] */
+  float *obs, *achieved;        /* [N,nq+nv] (ant: [N,nq+nv-2]) [N,2] */
   float* reward;                /* [N] */
   unsigned char *success, *terminated; /* [N] */
   int* status;                  /* [N] */
@@ -83,7 +84,8 @@ int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fet
 int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream);
 int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
                              float* reward_out, void* stream);
-/* PointMaze: PointMazeEnv.step for N worlds = clip + velocity clip + mj_step(1) + obs/reward/terminated/success
+/* Maze family (PointMaze and AntMaze, selected by task->agent; AntMazeEnv.step: envs/maze/ant_maze_v5.py:295-310).
+ * PointMaze: PointMazeEnv.step for N worlds = clip + velocity clip + mj_step(1) + obs/reward/terminated/success
  * (envs/maze/point.py:55-77, envs/maze/point_maze.py:392-406); batched MazeEnv.compute_reward (envs/maze/maze_v4.py:381-388). */
 int grx_point_step(const grx_model* m, const grx_point_task* task, const grx_point_buffers* buf, int n_worlds, void* stream);
 int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t batch, float goal_radius, int sparse, float* reward_out,

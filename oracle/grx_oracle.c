@@ -464,6 +464,79 @@ static void collide_sphere_box(orc_sim* s, int pair, int g1, int g2, double marg
   add_contact(s, pair, pos, n, dist);
 }
 
+/* plane vs capsule: the two end spheres (MuJoCo's plane-capsule routine) */
+static void collide_plane_capsule(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* pm = s->geom_xmat + 9 * g1; double n[3] = {pm[2], pm[5], pm[8]};
+  const double* c = s->geom_xpos + 3 * g2; const double* R = s->geom_xmat + 9 * g2;
+  double r = m->geom_size[3 * g2], hl = m->geom_size[3 * g2 + 1], ax[3] = {R[2], R[5], R[8]};
+  for (int e = -1; e <= 1; e += 2) {
+    double p[3] = {c[0] + e * hl * ax[0], c[1] + e * hl * ax[1], c[2] + e * hl * ax[2]};
+    double d[3] = {p[0] - s->geom_xpos[3 * g1], p[1] - s->geom_xpos[3 * g1 + 1], p[2] - s->geom_xpos[3 * g1 + 2]};
+    double dist = dot3(d, n) - r;
+    if (dist > margin) continue;
+    double pos[3] = {p[0] - n[0] * (r + 0.5 * dist), p[1] - n[1] * (r + 0.5 * dist), p[2] - n[2] * (r + 0.5 * dist)};
+    add_contact(s, pair, pos, n, dist);
+  }
+}
+
+/* squared distance from a point (box frame) to the box, and the clamped point */
+static double box_point_dist2(const double* sz, const double* p, double* cl) {
+  double d2 = 0;
+  for (int k = 0; k < 3; k++) { cl[k] = fmin(sz[k], fmax(-sz[k], p[k])); d2 += (p[k] - cl[k]) * (p[k] - cl[k]); }
+  return d2;
+}
+/* sphere of radius r at box-frame point p against the box: contact (normal from the sphere to the box) */
+static int sphere_box_local(orc_sim* s, int pair, const double* bp, const double* bm, const double* sz, const double* p, double r, double margin) {
+  double cl[3], nl[3], dist;
+  double d2 = box_point_dist2(sz, p, cl);
+  if (d2 > 0) {
+    double len = sqrt(d2); dist = len - r;
+    if (dist > margin) return 0;
+    for (int k = 0; k < 3; k++) nl[k] = (cl[k] - p[k]) / len;
+  } else {
+    int ax = 0; double best = 1e30;
+    for (int k = 0; k < 3; k++) { double dd = sz[k] - fabs(p[k]); if (dd < best) { best = dd; ax = k; } }
+    nl[0] = nl[1] = nl[2] = 0; nl[ax] = p[ax] >= 0 ? -1 : 1; dist = -best - r;
+  }
+  double n[3], pw[3]; mulMatVec3(n, bm, nl); mulMatVec3(pw, bm, p);
+  double pos[3] = {pw[0] + bp[0] + n[0] * (r + 0.5 * dist), pw[1] + bp[1] + n[1] * (r + 0.5 * dist), pw[2] + bp[2] + n[2] * (r + 0.5 * dist)};
+  add_contact(s, pair, pos, n, dist);
+  return 1;
+}
+/* capsule (geom1) vs box (geom2).  MuJoCo has a dedicated routine whose exact contact placement cannot be checked here;
+ * this restatement takes the point of the capsule axis closest to the box (convex 1-D minimisation) as a sphere contact,
+ * plus the farther end sphere when it is inside the margin too (capsule lying along a face): at most 2 contacts. */
+static void collide_capsule_box(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* c = s->geom_xpos + 3 * g1; const double* R = s->geom_xmat + 9 * g1;
+  const double* bp = s->geom_xpos + 3 * g2; const double* bm = s->geom_xmat + 9 * g2; const double* sz = m->geom_size + 3 * g2;
+  double r = m->geom_size[3 * g1], hl = m->geom_size[3 * g1 + 1];
+  double axw[3] = {R[2], R[5], R[8]}, dw[3] = {c[0] - bp[0], c[1] - bp[1], c[2] - bp[2]}, cen[3], ax[3];
+  mulMatTVec3(cen, bm, dw); mulMatTVec3(ax, bm, axw);
+  /* golden-section search of t in [-hl, hl] for the axis point closest to the box (distance is convex in t) */
+  double lo = -hl, hi = hl, cl[3];
+  const double gr = 0.6180339887498949;
+  double t1 = hi - gr * (hi - lo), t2 = lo + gr * (hi - lo);
+  double p1[3] = {cen[0] + t1 * ax[0], cen[1] + t1 * ax[1], cen[2] + t1 * ax[2]}, p2[3] = {cen[0] + t2 * ax[0], cen[1] + t2 * ax[1], cen[2] + t2 * ax[2]};
+  double f1 = box_point_dist2(sz, p1, cl), f2 = box_point_dist2(sz, p2, cl);
+  for (int it = 0; it < 48; it++) {
+    if (f1 <= f2) { hi = t2; t2 = t1; f2 = f1; t1 = hi - gr * (hi - lo); for (int k = 0; k < 3; k++) p1[k] = cen[k] + t1 * ax[k]; f1 = box_point_dist2(sz, p1, cl); }
+    else { lo = t1; t1 = t2; f1 = f2; t2 = lo + gr * (hi - lo); for (int k = 0; k < 3; k++) p2[k] = cen[k] + t2 * ax[k]; f2 = box_point_dist2(sz, p2, cl); }
+  }
+  double ts = 0.5 * (lo + hi);
+  /* snap to an end point when the minimum sits there */
+  double pe[3], fe;
+  for (int e = -1; e <= 1; e += 2) { for (int k = 0; k < 3; k++) pe[k] = cen[k] + e * hl * ax[k]; fe = box_point_dist2(sz, pe, cl); if (fe <= fmin(f1, f2)) ts = e * hl; }
+  double ps[3] = {cen[0] + ts * ax[0], cen[1] + ts * ax[1], cen[2] + ts * ax[2]};
+  if (!sphere_box_local(s, pair, bp, bm, sz, ps, r, margin)) return;
+  double te = (ts >= 0) ? -hl : hl;
+  if (fabs(te - ts) > 0.2 * hl) {
+    double pf[3] = {cen[0] + te * ax[0], cen[1] + te * ax[1], cen[2] + te * ax[2]};
+    sphere_box_local(s, pair, bp, bm, sz, pf, r, margin);
+  }
+}
+
 /* plane vs convex hull of a mesh: deepest hull vertex + up to 3 of its hull neighbours
  * that are also within the margin (restated from memory of MuJoCo's plane-convex routine;
  * unverifiable here -- see DESIGN.md "mesh policy") */
@@ -654,6 +727,8 @@ static void collision(orc_sim* s) {
     }
     if (!m->pair_supported[p]) { s->unsupported_hits++; continue; }
     if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_SPHERE) collide_plane_sphere(s, p, g1, g2, margin);
+    else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_CAPSULE) collide_plane_capsule(s, p, g1, g2, margin);
+    else if (t1 == GRX_GEOM_CAPSULE && t2 == GRX_GEOM_BOX) collide_capsule_box(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_SPHERE && t2 == GRX_GEOM_BOX) collide_sphere_box(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_BOX) collide_plane_box(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_MESH) collide_plane_mesh(s, p, g1, g2, margin);
@@ -1118,13 +1193,50 @@ static void euler(orc_sim* s) {
   free(qacc);
 }
 
+/* advance (qpos0, qvel0) by velocity v and acceleration a over step hh into the live state (mj_integratePos semantics) */
+static void rk_advance(orc_sim* s, const double* qpos0, const double* qvel0, const double* v, const double* a, double hh) {
+  const grx_model_view* m = &s->m;
+  for (int d = 0; d < s->nv; d++) s->qvel[d] = qvel0[d] + hh * a[d];
+  memcpy(s->qpos, qpos0, sizeof(double) * (size_t)s->nq);
+  for (int j = 0; j < s->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == GRX_JNT_FREE) {
+      for (int k = 0; k < 3; k++) s->qpos[qa + k] += hh * v[da + k];
+      double w[3] = {v[da + 3], v[da + 4], v[da + 5]}, n = norm3(w);
+      if (n > MINVAL) {
+        double ax[3] = {w[0] / n, w[1] / n, w[2] / n}, qr[4], qn[4];
+        axisAngle2Quat(qr, ax, hh * n); mulQuat(qn, s->qpos + qa + 3, qr); normalize4(qn); memcpy(s->qpos + qa + 3, qn, sizeof(qn));
+      }
+    } else s->qpos[qa] += hh * v[da];
+  }
+}
+
+/* restates mj_RungeKutta(m, d, 4) [3P]: classical tableau, a full forward pass per stage */
+static void rk4(orc_sim* s) {
+  int nq = s->nq, nv = s->nv; double h = s->m.opt[GRX_TIMESTEP];
+  static const double A[3] = {0.5, 0.5, 1.0}, B[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+  double* q0 = ALLOC(nq); double* v0 = ALLOC(nv); double* Fv = ALLOC(4 * nv); double* Fa = ALLOC(4 * nv);
+  memcpy(q0, s->qpos, sizeof(double) * (size_t)nq); memcpy(v0, s->qvel, sizeof(double) * (size_t)nv);
+  memcpy(Fv, s->qvel, sizeof(double) * (size_t)nv); memcpy(Fa, s->qacc, sizeof(double) * (size_t)nv);  /* stage 0 = the forward pass already done */
+  for (int i = 1; i < 4; i++) {
+    rk_advance(s, q0, v0, Fv + (i - 1) * nv, Fa + (i - 1) * nv, A[i - 1] * h);
+    orc_forward(s);
+    memcpy(Fv + i * nv, s->qvel, sizeof(double) * (size_t)nv); memcpy(Fa + i * nv, s->qacc, sizeof(double) * (size_t)nv);
+  }
+  double* dv = ALLOC(nv); double* da = ALLOC(nv);
+  for (int d = 0; d < nv; d++) for (int j = 0; j < 4; j++) { dv[d] += B[j] * Fv[j * nv + d]; da[d] += B[j] * Fa[j * nv + d]; }
+  rk_advance(s, q0, v0, dv, da, h);
+  s->time += h;
+  free(q0); free(v0); free(Fv); free(Fa); free(dv); free(da);
+}
+
 /* restates mj_step(model, data, nstep) [3P] */
 void orc_step(orc_sim* s, int nstep) {
   for (int k = 0; k < nstep; k++) {
     if (bad_number(s->qpos, s->nq, 1e10) || bad_number(s->qvel, s->nv, 1e10)) { s->bad_state |= 1; orc_reset_data(s); s->bad_state |= 1; }
     orc_forward(s);
     if (bad_number(s->qacc, s->nv, 1e10)) { s->bad_state |= 1; orc_reset_data(s); s->bad_state |= 1; orc_forward(s); }
-    euler(s);
+    if (s->m.dims[GRX_INTEGRATOR] == 1) rk4(s); else euler(s);
   }
 }
 

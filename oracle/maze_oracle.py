@@ -47,3 +47,36 @@ class OraclePointMazeEnv:
         reward = float(np.exp(-d)) if self.reward_type == "dense" else float(d <= GOAL_RADIUS)
         terminated = (not self.continuing_task) and bool(d <= GOAL_RADIUS)
         return obs, reward, terminated, False, {"success": bool(d <= GOAL_RADIUS)}
+
+
+class OracleAntMazeEnv(OraclePointMazeEnv):
+    """ant_maze_v5.py:221-320 on top of gymnasium's AntEnv-v5 [3P] (frame_skip 5, obs = qpos | qvel with positions kept,
+    reset_noise_scale = 0, init_qpos = the model's qpos0)."""
+
+    FRAME_SKIP = 5
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        self.goal, reset_pos = sample_maze_reset(self.maze, self.np_random, self.position_noise_range, options)
+        s = self.sim
+        s.reset_data()
+        s.qpos[:2] = reset_pos
+        s.qvel[:] = 0
+        s.forward()
+        obs = self._obs()
+        return obs, {"success": bool(np.linalg.norm(obs["achieved_goal"] - self.goal) <= GOAL_RADIUS)}
+
+    def _obs(self):
+        o = np.concatenate([self.sim.qpos, self.sim.qvel])
+        return {"observation": o[2:].copy(), "achieved_goal": o[:2].copy(), "desired_goal": self.goal.copy()}
+
+    def step(self, action):
+        s = self.sim
+        s.ctrl[:] = np.asarray(action, dtype=np.float64)
+        s.step(self.FRAME_SKIP)
+        obs = self._obs()
+        d = np.linalg.norm(obs["achieved_goal"] - self.goal)
+        reward = float(np.exp(-d)) if self.reward_type == "dense" else float(d <= GOAL_RADIUS)
+        terminated = (not self.continuing_task) and bool(d <= GOAL_RADIUS)
+        return obs, reward, terminated, False, {"success": bool(d <= GOAL_RADIUS)}

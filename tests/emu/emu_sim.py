@@ -40,7 +40,7 @@ class EmuSim:
         self.qacc_ws = np.zeros(self.nv, np.float32)
         self.mocap = np.zeros(7 * self.nmocap, np.float32)
         self.aux = np.zeros(8, np.float32)
-        self.obs = np.zeros(getattr(task_struct, "obs_dim", self.nq + self.nv), np.float32)
+        self.obs = np.zeros(getattr(task_struct, "obs_dim", self.nq + self.nv - (2 if getattr(task_struct, "agent", 0) else 0)), np.float32)
         self.achieved = np.zeros(3, np.float32)
         self.status = ctypes.c_int(0)
 

@@ -80,3 +80,30 @@ def test_emulated_point_kernel_matches_oracle():
             hits += env.sim.nefc > 1
     assert hits > 20, "the rollout never touched a wall"
     assert worst < 1e-4, worst
+
+
+def test_emulated_ant_kernel_matches_oracle_teacher_forced():
+    """AntMaze step (RK4, capsule/sphere contacts, joint limits) through the lane emulator vs the oracle, every step
+    restarted from the oracle's state (legged contact dynamics are chaotic)."""
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd import _native
+    from oracle.maze_oracle import OracleAntMazeEnv
+
+    model = load_model(os.path.join(MODELS, "ant_UMaze.npz"))
+    maze = Maze(MAPS["UMaze"], 4.0, 0.5)
+    env = OracleAntMazeEnv(model, maze)
+    emu = EmuSim(model, _native.PointTaskStruct(5, 1, 1, 1, 0.45, 5.0))
+    rng = np.random.default_rng(0)
+    errs = []
+    obs, _ = env.reset(seed=1)
+    for t in range(60):
+        a = rng.uniform(-1, 1, 8).astype(np.float32)
+        s = env.sim
+        emu.qpos[:], emu.qvel[:], emu.qacc_ws[:] = s.qpos, s.qvel, s.qacc_warmstart
+        obs, r, te, tr, info = env.step(a.astype(np.float64))
+        emu.point_step(a)
+        assert emu.status.value == 0 and s.bad_state == 0
+        errs.append(max(np.abs(emu.obs - obs["observation"]).max(), np.abs(emu.achieved[:2] - obs["achieved_goal"]).max()))
+    errs = np.array(errs)
+    assert np.mean(errs < 1e-4) >= 0.9 and errs.max() < 5e-3, (np.quantile(errs, [0.5, 0.9, 1.0]))
