@@ -107,15 +107,29 @@ struct GrxCtx {
   float* red;  // 128 floats
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
+  int mslot;   // slot of this world's model in g_grx_models (GPU build)
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   long long* prof; long long* prof_last;
 #endif
 };
 
+// The GPU build keeps the model descriptors (table pointers + scalars) in constant memory.  Every stage re-derives its
+// model pointer from the slot index through an opaque scalar: the table pointers a stage needs are then fetched with
+// s_load at the top of that stage and die at its end, instead of ~100 pointers staying live (and spilled) across the
+// whole substep loop.
+#if defined(GRX_EMU)
+#define GRX_FRESH_MODEL(m, c) ((void)0)
+#else
+#define GRX_MAX_MODELS 32
+__constant__ GrxModel g_grx_models[GRX_MAX_MODELS];
+#define GRX_FRESH_MODEL(m, c) do { int s_ = (c)->mslot; asm volatile("" : "+s"(s_)); (m) = g_grx_models + s_; } while (0)
+#endif
+
 // LDS layout.  Arrays that only live in the position/velocity stages of a substep (P1: local poses, spatial inertias,
 // body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
 // Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
 // body frames, motion axes, M, J, row parameters) is persistent.
+struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator; };
 GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
@@ -130,7 +144,10 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   return pers + (p1 > p2 ? p1 : p2) + 8;
 }
 
-GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
+// dims by value: when they are compile-time constants (a specialised kernel) every LDS address below folds to an
+// immediate offset of the ds_read/ds_write instructions
+GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
+  const GrxDims* m = &d;
   float* p = base;
 #define CARVE(field, n) c->field = p; p += (n);
 #define CARVEI(field, n) c->field = (int*)p; p += (n);
@@ -173,6 +190,12 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxModel* m) {
 #undef CARVE
 #undef CARVEI
 }
+
+GRX_HD GrxDims grx_dims_of(const GrxModel* m) {
+  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator};
+  return d;
+}
+GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator); }
 
 // ------------------------------------------------------------------------------------------
 // small math (all per-lane, registers)
@@ -296,6 +319,7 @@ struct GrxEngine {
 // K1 forward kinematics
 // ------------------------------------------------------------------------------------------
 GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_FRESH_MODEL(m, c);
   FOR_LANES {
     for (int b = lane; b < m->nbody; b += 64) {
       float* pl = c->ploc + 3 * b; float* ql = c->qloc + 4 * b;
@@ -401,6 +425,7 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
 // reference point of each kinematic tree = xpos of its root body (any point is valid)
 // ------------------------------------------------------------------------------------------
 GRX_MEM void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_FRESH_MODEL(m, c);
   FOR_LANES {
     for (int b = 1 + lane; b < m->nbody; b += 64) {
       const float* R = c->xmat + 9 * b; const float* in = m->body_inertia + 6 * b;
@@ -566,6 +591,7 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
 // velocity stage: cvel, cdof_dot, RNE bias (K2/K5), passive (K6), actuation (K7)
 // ------------------------------------------------------------------------------------------
 GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC;
   // body spatial velocities = sum over the dof chain (parallel, no tree walk)
   FOR_LANES {
@@ -977,6 +1003,7 @@ GRX_MEM void grx_box_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2,
 }
 
 GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_FRESH_MODEL(m, c);
   // geom frames (they share LDS with the composite inertias of the previous stage)
   FOR_LANES {
     for (int i = lane; i < m->ngeom; i += 64) {
@@ -1114,6 +1141,7 @@ GRX_MEM unsigned long long grx_chainmask(const GrxModel* m, int b) {
 #define GRX_ROW_PACK(off, lo, len) ((off) | ((lo) << 12) | ((len) << 20))
 
 GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC;
   int ncon = c->cnt[0];
   // ---- row bookkeeping.  Per-joint limit flags and per-contact row counts go to small LDS int tables once; the
@@ -1481,6 +1509,7 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
 //   phase 2: no constraint rows at all                      (A = M,               rhs = qfrc_smooth)
 //   phase 1: Euler velocity update with implicit damping    (A = M + h diag(B),   rhs = qfrc_smooth + qfrc_constraint)
 GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int lane_) {
+  GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC; const float h = m->timestep;
   const int nefc = c->cnt[1];
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
@@ -1500,18 +1529,19 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
       if (it > 0 && full_step && !changed) done = 1;
-      // Hessian of the current active set and J'f of the current row forces, in one pass over the rows
-      grx_hessian(m, c, nefc, lane_);
-      GRX_TICK(c, GRX_P_NHESS);
       if (done || it >= GRX_NEWTON_MAXIT) {
-        // converged: constraint forces from the evaluation just made
-        FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qfrc_constraint[i] = c->grad[i]; c->qacc_ws[i] = c->qacc[i]; } }
+        // converged: at the minimiser the gradient M a - qfrc_smooth - J'f vanishes, so the joint-space constraint force
+        // J'f of the final evaluation is M a - qfrc_smooth (to the solver's residual) -- no further pass over the rows
+        FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qfrc_constraint[i] = c->Ma[i] - c->qfrc_smooth[i]; c->qacc_ws[i] = c->qacc[i]; } }
         WAVE_SYNC();
         GRX_TICK(c, GRX_P_NFINAL);
         if (!do_euler) break;
         phase = 1;
         continue;
       }
+      // Hessian of the current active set and J'f of the current row forces, in one pass over the rows
+      grx_hessian(m, c, nefc, lane_);
+      GRX_TICK(c, GRX_P_NHESS);
       // gradient = M a - qfrc_smooth - J' f
       GRX_LANEVAR(gnp);
       FOR_LANES {
@@ -1708,13 +1738,27 @@ GRX_MEM void grx_rk4_after_forward(const GrxModel* m, GrxCtx* c, int stage, int 
 }
 
 GRX_MEM void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_FRESH_MODEL(m, c);
+  // mj_checkPos / mj_checkVel (engine_forward.c): a non-finite or huge coordinate resets the world to the model's
+  // initial state (mj_resetData) and raises the warning; the status word plays the role of the warning counter.
+  GRX_LANEVAR(badp);
   FOR_LANES {
     int bad = 0;
     for (int i = lane; i < m->nq; i += 64) { float v = c->qpos[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
     for (int i = lane; i < GRX_NVC; i += 64) { float v = c->qvel[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
-    if (bad) c->cnt[2] |= GRX_ST_BADNUM;
+    LV(badp) = bad ? 1.0f : 0.0f;
   }
   WAVE_SYNC();
+  if (grx_reduce_max(badp) > 0.5f) {
+    FOR_LANES {
+      for (int i = lane; i < m->nq; i += 64) c->qpos[i] = m->qpos0[i];
+      for (int i = lane; i < GRX_NVC; i += 64) { c->qvel[i] = 0.0f; c->qacc_ws[i] = 0.0f; }
+      for (int i = lane; i < 3 * m->nmocap; i += 64) c->mocap_pos[i] = m->mocap_pos0[i];
+      for (int i = lane; i < 4 * m->nmocap; i += 64) c->mocap_quat[i] = m->mocap_quat0[i];
+    }
+    LANE0 { c->cnt[2] |= GRX_ST_BADNUM; }
+    WAVE_SYNC();
+  }
 }
 
 };  // struct GrxEngine

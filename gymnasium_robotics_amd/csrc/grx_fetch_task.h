@@ -66,6 +66,7 @@ GRX_MEM void grx_point_velocity(const GrxModel* m, const GrxCtx* c, int b, const
 }
 
 GRX_MEM void grx_fetch_set_action(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux, const float* action, int lane_) {
+  GRX_FRESH_MODEL(m, c);
   LANE0 {
     float a[4];
     for (int k = 0; k < 4; k++) a[k] = fminf(1.0f, fmaxf(-1.0f, action[k]));
@@ -83,6 +84,7 @@ GRX_MEM void grx_fetch_set_action(const GrxModel* m, const GrxFetchTask* t, GrxC
 
 // writes aux (gripper_link pose of the current kinematics), obs, achieved goal
 GRX_MEM void grx_fetch_outputs(const GrxModel* m, const GrxFetchTask* t, const GrxCtx* c, float* aux, float* obs, float* achieved, int lane_) {
+  GRX_FRESH_MODEL(m, c);
   LANE0 {
     int b = t->grip_body; float v[3], q[4];
     mulMatVec3f(v, c->xmat + 9 * b, t->grip_relpos);

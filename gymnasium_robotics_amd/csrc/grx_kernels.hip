@@ -57,14 +57,38 @@ extern "C" int grx_profile_read(long long* out) { return (int)hipMemcpyFromSymbo
 extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grx_prof), z, sizeof(z)); }
 #endif
 
-extern "C" __global__ void __launch_bounds__(64, 2)
-grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
+// Model shapes.  A step kernel specialised for a shape has all ten layout dims as compile-time constants: the LDS
+// carve folds into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs)
+// and the loops over dofs unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
+template <int NQ, int NV, int NU, int NBODY, int NJNT, int NGEOM, int NSITE, int NMOCAP>
+struct GrxShape {
+  static constexpr int kNV = NV;
+  static __device__ __forceinline__ GrxDims dims(const GrxModel&) { return GrxDims{NQ, NV, NU, NBODY, NJNT, NGEOM, NSITE, NMOCAP, 0, 0}; }
+  static bool matches(const GrxModel& g) {
+    return g.nq == NQ && g.nv == NV && g.nu == NU && g.nbody == NBODY && g.njnt == NJNT && g.ngeom == NGEOM && g.nsite == NSITE &&
+           g.nmocap == NMOCAP && g.nfric == 0 && g.integrator == 0;
+  }
+};
+struct GrxShapeAny {
+  static constexpr int kNV = 0;
+  static __device__ __forceinline__ GrxDims dims(const GrxModel& m) { return grx_dims_of(&m); }
+  static bool matches(const GrxModel&) { return true; }
+};
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
+typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1> GrxShapeFetchArm;    // FetchReach (arm only)
+
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int w = blockIdx.x, lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
+  const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
-  grx_ctx_carve(&c, lds, &m);
+  c.mslot = mslot;
+  grx_ctx_carve(&c, lds, S::dims(m));
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
@@ -75,7 +99,7 @@ grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_world
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = aux[k];
   float* obs = b.obs + (size_t)w * t.obs_dim; float* ach = b.achieved + (size_t)w * 3; const float* act = b.action + (size_t)w * 4;
-  GrxFetch<0>::grx_fetch_step_world(&m, &t, &c, aux_in, act, aux, obs, ach, lane_);
+  GrxFetch<S::kNV>::grx_fetch_step_world(&m, &t, &c, aux_in, act, aux, obs, ach, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, w, lane_);
 #ifdef GRX_PROFILE
@@ -86,13 +110,15 @@ grx_fetch_step_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_world
 
 // reset path: (optional raw settle steps) + mj_forward + outputs
 extern "C" __global__ void __launch_bounds__(64)
-grx_fetch_forward_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words, int nstep) {
+grx_fetch_forward_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words, int nstep) {
   extern __shared__ float lds[];
   const int w = blockIdx.x, lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
+  const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
-  grx_ctx_carve(&c, lds, &m);
+  c.mslot = mslot;
+  grx_ctx_carve(&c, lds, grx_dims_of(&m));
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
@@ -106,13 +132,15 @@ grx_fetch_forward_kernel(GrxModel m, GrxFetchTask t, GrxFetchBuffers b, int n_wo
 
 // PointMaze env.step(): one wavefront per world, same engine
 extern "C" __global__ void __launch_bounds__(64, 2)
-grx_point_step_kernel(GrxModel m, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
+grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int w = blockIdx.x, lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
+  const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
-  grx_ctx_carve(&c, lds, &m);
+  c.mslot = mslot;
+  grx_ctx_carve(&c, lds, grx_dims_of(&m));
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
@@ -181,6 +209,8 @@ grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_i
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+static int g_slot_used[GRX_MAX_MODELS];
+
 struct grx_model {
   GrxPackedModel pm;
   float* d_f = nullptr;
@@ -188,6 +218,8 @@ struct grx_model {
   GrxModel dev;  // table pointers address d_f / d_i
   int device = 0;
   int words = 0;
+  int slot = -1;  // index of the device-side descriptor in g_grx_models (constant memory)
+  int shape = 0;  // 0 = generic step kernel, else index of the specialised GrxShape
 };
 
 static thread_local std::string g_err;
@@ -217,15 +249,23 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   if (bytes > 160 * 1024) return fail("model working set exceeds the 160 KiB LDS of a CU");
   if (g.njnt > 32) return fail("engine limit: at most 32 joints per world (limit-flag table in LDS)");
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
-  HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  m->shape = 0;
+  if (GrxShapeFetchPick::matches(g)) { m->shape = 1; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPick>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  else if (GrxShapeFetchObject::matches(g)) { m->shape = 2; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchObject>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  else if (GrxShapeFetchArm::matches(g)) { m->shape = 3; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchArm>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  for (int k = 0; k < GRX_MAX_MODELS && m->slot < 0; k++) if (!g_slot_used[k]) { g_slot_used[k] = 1; m->slot = k; }
+  if (m->slot < 0) return fail("grx_model_create: all model descriptor slots are in use (destroy a model first)");
+  HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_grx_models), &m->dev, sizeof(GrxModel), sizeof(GrxModel) * (size_t)m->slot, hipMemcpyHostToDevice));
   *out = m;
   return 0;
 }
 
 extern "C" int grx_model_destroy(grx_model* m) {
   if (!m) return 0;
+  if (m->slot >= 0) g_slot_used[m->slot] = 0;
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_f); (void)hipFree(m->d_i);
   delete m;
@@ -271,7 +311,14 @@ extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, co
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  hipLaunchKernelGGL(grx_fetch_step_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->dev, t, b, n_worlds, m->words);
+  const dim3 grid(n_worlds), block(64);
+  const size_t lds_bytes = (size_t)m->words * 4;
+  switch (m->shape) {  // the specialised kernels are bit-identical to the generic one (same source, dims folded)
+    case 1: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchPick>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
+    case 2: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchObject>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
+    case 3: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchArm>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
+    default: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -282,7 +329,7 @@ extern "C" int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task,
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  hipLaunchKernelGGL(grx_fetch_forward_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->dev, t, b, n_worlds, m->words, nstep);
+  hipLaunchKernelGGL(grx_fetch_forward_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, nstep);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -295,7 +342,7 @@ extern "C" int grx_point_step(const grx_model* m, const grx_point_task* task, co
   if (n_worlds <= 0) return 0;
   GrxPointTask t; memcpy(&t, task, sizeof(t));
   GrxPointBuffers b; memcpy(&b, buf, sizeof(b));
-  hipLaunchKernelGGL(grx_point_step_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->dev, t, b, n_worlds, m->words);
+  hipLaunchKernelGGL(grx_point_step_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words);
   HIP_OK(hipGetLastError());
   return 0;
 }

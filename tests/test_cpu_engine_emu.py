@@ -55,3 +55,16 @@ def test_emulated_reset_forward_matches_golden(emu_factory):
         emu.forward(0)
         assert np.abs(emu.obs - g["reset_obs"][i]).max() < 1e-5
         assert np.abs(emu.aux[:7] - g["aux"][first][:7]).max() < 1e-5
+
+
+def test_emulated_bad_state_resets_world(emu_factory, fetch_models):
+    """mj_checkPos/mj_checkVel behaviour: a NaN coordinate resets the world to qpos0 and flags the status word."""
+    g = np.load(os.path.join(GOLDEN, "fetch_FetchReach_teacher.npz"))
+    emu = emu_factory("FetchReach")
+    for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux"):
+        getattr(emu, k)[:] = g[k][0]
+    emu.qvel[3] = np.nan
+    emu.step(np.zeros(4, np.float32))
+    assert emu.status.value & 1  # GRX_ST_BADNUM
+    assert np.isfinite(emu.obs).all() and np.isfinite(emu.qpos).all() and np.isfinite(emu.qvel).all()
+    assert np.abs(emu.qpos).max() < 10 and np.abs(emu.qvel).max() < 1e3
