@@ -542,37 +542,38 @@ GRX_MEM void grx_sym_solve(const float* A, int n, float* x, int lane_) {
 #if !defined(GRX_EMU)
 // v_readlane_b32 moves raw bits: the builtin is typed (int,int), so floats go through a bit cast
 static __device__ __forceinline__ float grx_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// reciprocal of a strictly positive pivot: v_rcp_f32 (1 ulp) + one Newton step
+static __device__ __forceinline__ float grx_rcp_refined(float d) { float r = __builtin_amdgcn_rcpf(d); return fmaf(fmaf(-d, r, 1.0f), r, r); }
+// Lane i (< NS) owns ROW i of the symmetric matrix and b_i.  Step k of the elimination broadcasts row k with v_readlane
+// (one readlane + one fma per remaining column) and every lane i < k subtracts its multiple of it; rows end up lower
+// triangular, pivots final when they are used.  The forward substitution then needs one broadcast per unknown.
 template <int NS>
   static __device__ __forceinline__ void grx_sym_solve_reg(const float* A, float* x, int lane_) {
   float a[NS];
-  const int col = lane_ < NS ? lane_ : NS;
+  const int row = lane_ < NS ? lane_ : 0;
 #pragma unroll
-  for (int i = 0; i < NS; i++) a[i] = (lane_ < NS) ? A[col * NS + i] : ((lane_ == NS) ? x[i] : 0.0f);  // A symmetric: column = row
+  for (int i = 0; i < NS; i++) a[i] = A[row * NS + i];
+  float b = x[row], rd = 0.0f;
 #pragma unroll
   for (int k = NS - 1; k > 0; k--) {
-    const float pinv = 1.0f / grx_readlane_f(a[k], k);
+    const float pinv = grx_rcp_refined(grx_readlane_f(a[k], k));
+    rd = (lane_ == k) ? pinv : rd;
+    const float mi = (lane_ < k) ? -a[k] * pinv : 0.0f;
 #pragma unroll
-    for (int i = 0; i < k; i++) {
-      const float mi = grx_readlane_f(a[i], k) * pinv;
-      a[i] = fmaf(-mi, a[k], a[i]);
-    }
+    for (int j = 0; j < k; j++) a[j] = fmaf(mi, grx_readlane_f(a[j], k), a[j]);
+    b = fmaf(mi, grx_readlane_f(b, k), b);
   }
-  // now A is lower triangular (entries above the diagonal eliminated).  Forward substitution: the right-hand side lives
-  // in lane NS; x_k is formed from two readlanes and pushed into the remaining rows of that lane only.
-  const float isrhs = (lane_ == NS) ? 1.0f : 0.0f;
+  { const float pinv = grx_rcp_refined(grx_readlane_f(a[0], 0)); rd = (lane_ == 0) ? pinv : rd; }
+  float xo = 0.0f;
 #pragma unroll
   for (int k = 0; k < NS; k++) {
-    const float xk = grx_readlane_f(a[k], NS) / grx_readlane_f(a[k], k);
-    a[k] = (lane_ == NS) ? xk : a[k];
-    const float sx = xk * isrhs;
-#pragma unroll
-    for (int i = k + 1; i < NS; i++) a[i] = fmaf(-grx_readlane_f(a[i], k), sx, a[i]);
+    const float t = b * rd;                 // lane k: b_k / L_kk = x_k (b_k is final once x_0 .. x_k-1 have been applied)
+    const float xk = grx_readlane_f(t, k);
+    xo = (lane_ == k) ? t : xo;
+    b = fmaf(-a[k], xk, b);                 // lanes i > k: b_i -= L_ik x_k ; lanes <= k are finished, their b is dead
   }
   __syncthreads();
-  if (lane_ == NS) {
-#pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = a[i];
-  }
+  if (lane_ < NS) x[lane_] = xo;
   __syncthreads();
 }
 #endif

@@ -9,7 +9,8 @@ import numpy as np, torch
 from gymnasium_robotics_amd import _native
 prof_so = os.path.join(ROOT, "gymnasium_robotics_amd", "_lib", "libgrx_hip_prof.so")
 if not os.path.exists(prof_so):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DGRX_PROFILE", "-o", prof_so,
+    from __graft_entry__ import HIPCC_FLAGS
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-DGRX_PROFILE", "-o", prof_so,
                            os.path.join(ROOT, "gymnasium_robotics_amd", "csrc", "grx_kernels.hip")])
 _native.LIB_PATH = prof_so
 from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
