@@ -41,10 +41,13 @@ static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; ret
 
 // optional per-stage cycle accounting (tools/profile_stages.py builds a -DGRX_PROFILE variant; empty otherwise)
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
-#define GRX_NPROF 16
+#define GRX_NPROF 48
+// sub-stage buckets 16.. (finer breakdown inside a stage; what remains goes to the stage's own bucket)
+#define GRX_SUBTICK(c, k) GRX_TICK(c, 16 + (k))
 #define GRX_TICK(c, id) do { if (lane_ == 0) { long long t_ = clock64(); (c)->prof[id] += t_ - (c)->prof_last[0]; (c)->prof_last[0] = t_; } } while (0)
 #else
 #define GRX_TICK(c, id) ((void)0)
+#define GRX_SUBTICK(c, k) ((void)0)
 #endif
 enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX_P_MSOLVE, GRX_P_NEVAL, GRX_P_NGRAD, GRX_P_NHESS, GRX_P_NFACTOR,
        GRX_P_NLS, GRX_P_NFINAL, GRX_P_EULER, GRX_P_OTHER };
@@ -79,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -312,8 +315,22 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 
 // All stages live in a class template so that the dof count can be a compile-time constant (NV > 0: inner loops over
 // dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
-#define GRX_NVC (NV ? NV : m->nv)
-template <int NV>
+// Model shape: the ten layout dims as compile-time constants (0 = read from the model at run time).
+template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_>
+struct GrxShape {
+  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_;
+  static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
+};
+typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
+#define GRX_NVC (S::kFixed ? S::NV : m->nv)
+#define GRX_NQC (S::kFixed ? S::NQ : m->nq)
+#define GRX_NUC (S::kFixed ? S::NU : m->nu)
+#define GRX_NBC (S::kFixed ? S::NB : m->nbody)
+#define GRX_NJC (S::kFixed ? S::NJ : m->njnt)
+#define GRX_NGC (S::kFixed ? S::NG : m->ngeom)
+#define GRX_NSC (S::kFixed ? S::NS : m->nsite)
+#define GRX_NMC (S::kFixed ? S::NM : m->nmocap)
+template <class S>
 struct GrxEngine {
 // ------------------------------------------------------------------------------------------
 // K1 forward kinematics
@@ -321,7 +338,7 @@ struct GrxEngine {
 GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_FRESH_MODEL(m, c);
   FOR_LANES {
-    for (int b = lane; b < m->nbody; b += 64) {
+    for (int b = lane; b < GRX_NBC; b += 64) {
       float* pl = c->ploc + 3 * b; float* ql = c->qloc + 4 * b;
       if (b == 0) {
         c->xpos[0] = c->xpos[1] = c->xpos[2] = 0; c->xquat[0] = 1; c->xquat[1] = c->xquat[2] = c->xquat[3] = 0;
@@ -372,34 +389,50 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   WAVE_SYNC();
-  // world poses: every body composes its own ancestor chain (parent first) -- redundant flops, but no level-by-level barriers
-  FOR_LANES {
-    for (int b = 1 + lane; b < m->nbody; b += 64) {
-      float p[3] = {c->ploc[3 * b], c->ploc[3 * b + 1], c->ploc[3 * b + 2]};
-      float q[4] = {c->qloc[4 * b], c->qloc[4 * b + 1], c->qloc[4 * b + 2], c->qloc[4 * b + 3]};
-      int isfree = (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == 0);
-      if (!(m->body_mocapid[b] >= 0 || isfree)) {
-        int aa = m->body_ancadr[b], an = m->body_ancnum[b];
-        for (int e = 0; e < an; e++) {
-          int anc = m->body_anc[aa + e];
-          float qa[4] = {c->qloc[4 * anc], c->qloc[4 * anc + 1], c->qloc[4 * anc + 2], c->qloc[4 * anc + 3]}, v[3], qn[4];
+  GRX_SUBTICK(c, 9);
+  // world poses by pointer jumping: in round s every body composes its pose (relative to the ancestor 2^s levels up) with
+  // that ancestor's pose (relative to ITS ancestor 2^s levels up): ceil(log2(depth)) rounds instead of one composition per
+  // ancestor.  Rounds ping-pong between {ploc,qloc} and {xpos,xquat}; body_jump is the static schedule.
+  const int nbk = GRX_NBC, nj = m->njump;
+  for (int s = 0; s < nj; s++) {
+    const float* sp = (s & 1) ? c->xpos : c->ploc; const float* sq = (s & 1) ? c->xquat : c->qloc;
+    float* dp = (s & 1) ? c->ploc : c->xpos; float* dq = (s & 1) ? c->qloc : c->xquat;
+    FOR_LANES {
+      for (int b = 1 + lane; b < nbk; b += 64) {
+        float p[3] = {sp[3 * b], sp[3 * b + 1], sp[3 * b + 2]}, q[4] = {sq[4 * b], sq[4 * b + 1], sq[4 * b + 2], sq[4 * b + 3]};
+        const int anc = m->body_jump[s * nbk + b];
+        if (anc > 0) {
+          float qa[4] = {sq[4 * anc], sq[4 * anc + 1], sq[4 * anc + 2], sq[4 * anc + 3]}, v[3], qn[4];
           rotVecQuatf(v, p, qa);
-          p[0] = c->ploc[3 * anc] + v[0]; p[1] = c->ploc[3 * anc + 1] + v[1]; p[2] = c->ploc[3 * anc + 2] + v[2];
+          p[0] = sp[3 * anc] + v[0]; p[1] = sp[3 * anc + 1] + v[1]; p[2] = sp[3 * anc + 2] + v[2];
           mulQuatf(qn, qa, q);
           q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; q[3] = qn[3];
         }
-        normalize4f(q);
+        for (int e = 0; e < 3; e++) dp[3 * b + e] = p[e];
+        for (int e = 0; e < 4; e++) dq[4 * b + e] = q[e];
       }
-      float R[9]; quat2matf(R, q);
-      for (int e = 0; e < 3; e++) c->xpos[3 * b + e] = p[e];
-      for (int e = 0; e < 4; e++) c->xquat[4 * b + e] = q[e];
-      for (int e = 0; e < 9; e++) c->xmat[9 * b + e] = R[e];
+    }
+    WAVE_SYNC();
+  }
+  {
+    const float* sp = (nj & 1) ? c->xpos : c->ploc; const float* sq = (nj & 1) ? c->xquat : c->qloc;
+    FOR_LANES {
+      for (int b = 1 + lane; b < nbk; b += 64) {
+        float p[3] = {sp[3 * b], sp[3 * b + 1], sp[3 * b + 2]}, q[4] = {sq[4 * b], sq[4 * b + 1], sq[4 * b + 2], sq[4 * b + 3]};
+        int isfree = (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == 0);
+        if (!(m->body_mocapid[b] >= 0 || isfree)) normalize4f(q);
+        float R[9]; quat2matf(R, q);
+        for (int e = 0; e < 3; e++) c->xpos[3 * b + e] = p[e];
+        for (int e = 0; e < 4; e++) c->xquat[4 * b + e] = q[e];
+        for (int e = 0; e < 9; e++) c->xmat[9 * b + e] = R[e];
+      }
     }
   }
   WAVE_SYNC();
+  GRX_SUBTICK(c, 10);
   FOR_LANES {
     // joint anchors / axes to the world frame (they were expressed in the parent frame; free joints already are world)
-    for (int j = lane; j < m->njnt; j += 64) {
+    for (int j = lane; j < GRX_NJC; j += 64) {
       if (m->jnt_type[j] == 0) continue;
       int par = m->body_parent[m->jnt_bodyid[j]];
       float a_[3] = {c->janchor[3 * j], c->janchor[3 * j + 1], c->janchor[3 * j + 2]}, x_[3] = {c->jaxis[3 * j], c->jaxis[3 * j + 1], c->jaxis[3 * j + 2]}, ta[3], tx[3];
@@ -408,7 +441,7 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   FOR_LANES {
-    for (int i = lane; i < m->nsite; i += 64) {
+    for (int i = lane; i < GRX_NSC; i += 64) {
       int b = m->site_bodyid[i];
       float lpv[3] = {m->site_pos[3 * i], m->site_pos[3 * i + 1], m->site_pos[3 * i + 2]}, lqv[4] = {m->site_quat[4 * i], m->site_quat[4 * i + 1], m->site_quat[4 * i + 2], m->site_quat[4 * i + 3]}, v[3], R[9], Rw[9];
       mulMatVec3f(v, c->xmat + 9 * b, lpv);
@@ -427,7 +460,7 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
 GRX_MEM void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_FRESH_MODEL(m, c);
   FOR_LANES {
-    for (int b = 1 + lane; b < m->nbody; b += 64) {
+    for (int b = 1 + lane; b < GRX_NBC; b += 64) {
       const float* R = c->xmat + 9 * b; const float* in = m->body_inertia + 6 * b;
       const float* cref = c->xpos + 3 * m->body_rootid[b];
       float ip[3] = {m->body_ipos[3 * b], m->body_ipos[3 * b + 1], m->body_ipos[3 * b + 2]}, r[3];
@@ -442,7 +475,7 @@ GRX_MEM void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
       I[3] = Iw[1] - mass * r[0] * r[1]; I[4] = Iw[2] - mass * r[0] * r[2]; I[5] = Iw[5] - mass * r[1] * r[2];
       I[6] = mass * r[0]; I[7] = mass * r[1]; I[8] = mass * r[2]; I[9] = mass;
     }
-    for (int j = lane; j < m->njnt; j += 64) {
+    for (int j = lane; j < GRX_NJC; j += 64) {
       int b = m->jnt_bodyid[j], da = m->jnt_dofadr[j], jt = m->jnt_type[j];
       const float* cref = c->xpos + 3 * m->body_rootid[b];
       float off[3] = {cref[0] - c->janchor[3 * j], cref[1] - c->janchor[3 * j + 1], cref[2] - c->janchor[3 * j + 2]};
@@ -465,19 +498,20 @@ GRX_MEM void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   WAVE_SYNC();
-  // composite inertia = sum over the subtree (no serial tree walk)
+  GRX_SUBTICK(c, 14);
+  // composite inertia = sum over the subtree (no serial tree walk; membership from the static 64-bit subtree masks)
   FOR_LANES {
-    for (int it = lane; it < 10 * m->nbody; it += 64) {
+    for (int it = lane; it < 10 * GRX_NBC; it += 64) {
       int b = it / 10, k = it - 10 * b;
-      if (b == 0) { c->crb[it] = 0; continue; }
-      int a = m->body_subadr[b], n = m->body_subnum[b];
+      unsigned mlo = (unsigned)m->body_submask[2 * b], mhi = (S::kFixed && S::NB <= 32) ? 0u : (unsigned)m->body_submask[2 * b + 1];
       float s = 0;
-#pragma unroll 8
-      for (int e = 0; e < n; e++) s += c->cinert[10 * m->body_sub[a + e] + k];
+#pragma unroll 16
+      for (int e = 1; e < GRX_NBC; e++) { unsigned bit = e < 32 ? (mlo >> e) & 1u : (mhi >> (e - 32)) & 1u; s += bit ? c->cinert[10 * e + k] : 0.0f; }
       c->crb[it] = s;
     }
   }
   WAVE_SYNC();
+  GRX_SUBTICK(c, 15);
   FOR_LANES {
     for (int e = lane; e < m->nmpair; e += 64) {
       int i = m->mpair_i[e], j = m->mpair_j[e];
@@ -596,37 +630,13 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
   const int nv = GRX_NVC;
   // body spatial velocities = sum over the dof chain (parallel, no tree walk)
   FOR_LANES {
-    for (int it = lane; it < 6 * m->nbody; it += 64) {
+    for (int it = lane; it < 6 * GRX_NBC; it += 64) {
       int b = it / 6, k = it - 6 * b;
       unsigned mlo = (unsigned)m->dof_chainmask[2 * b], mhi = (unsigned)m->dof_chainmask[2 * b + 1];
       float s = 0;
 #pragma unroll 8
       for (int d = 0; d < nv; d++) { unsigned bit = d < 32 ? (mlo >> d) & 1u : (mhi >> (d - 32)) & 1u; s += bit ? c->cdof[6 * d + k] * c->qvel[d] : 0.0f; }
       c->cvel[it] = s;
-    }
-    // cdof_dot = crossMotion(velocity just before this dof, cdof)
-    for (int d = lane; d < nv; d += 64) {
-      float v[6] = {0, 0, 0, 0, 0, 0}, cd[6], r[6];
-      {
-        // dofs contributing to the velocity seen by dof d: the chain ending at dof_cvelstart[d]
-        int e0 = m->dof_cvelstart[d];
-        unsigned long long msk = 0ull;
-        if (e0 >= 0) {
-          int bb = m->dof_bodyid[e0];
-          msk = ((unsigned long long)(unsigned)m->dof_chainmask[2 * bb + 1] << 32) | (unsigned)m->dof_chainmask[2 * bb];
-          msk &= (e0 >= 63) ? ~0ull : ((1ull << (e0 + 1)) - 1ull);  // drop same-body dofs after e0
-        }
-#pragma unroll 4
-        for (int e = 0; e < nv; e++) {
-          float qd = ((msk >> e) & 1ull) ? c->qvel[e] : 0.0f;
-          for (int k = 0; k < 6; k++) v[k] += c->cdof[6 * e + k] * qd;
-        }
-      }
-      for (int k = 0; k < 6; k++) cd[k] = c->cdof[6 * d + k];
-      int jt = m->jnt_type[m->dof_jntid[d]];
-      if (jt == 0 && d - m->jnt_dofadr[m->dof_jntid[d]] < 3) { for (int k = 0; k < 6; k++) r[k] = 0; }
-      else crossMotionf(r, v, cd);
-      for (int k = 0; k < 6; k++) c->cdof_dot[6 * d + k] = r[k];
     }
     // passive forces
     for (int d = lane; d < nv; d += 64) {
@@ -639,8 +649,28 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
   }
   WAVE_SYNC();
   FOR_LANES {
+    // cdof_dot = crossMotion(velocity just before this dof, cdof).  That velocity is the spatial velocity of the body
+    // owning dof_cvelstart[d], minus the dofs of that body that come after it (only multi-dof joints have any).
+    for (int d = lane; d < nv; d += 64) {
+      float v[6] = {0, 0, 0, 0, 0, 0}, cd[6], r[6];
+      const int e0 = m->dof_cvelstart[d];
+      if (e0 >= 0) {
+        const int bb = m->dof_bodyid[e0], last = m->body_dofadr[bb] + m->body_dofnum[bb] - 1;
+        for (int k = 0; k < 6; k++) v[k] = c->cvel[6 * bb + k];
+        for (int e = e0 + 1; e <= last; e++) { float qd = c->qvel[e]; for (int k = 0; k < 6; k++) v[k] -= c->cdof[6 * e + k] * qd; }
+      }
+      for (int k = 0; k < 6; k++) cd[k] = c->cdof[6 * d + k];
+      int jt = m->jnt_type[m->dof_jntid[d]];
+      if (jt == 0 && d - m->jnt_dofadr[m->dof_jntid[d]] < 3) { for (int k = 0; k < 6; k++) r[k] = 0; }
+      else crossMotionf(r, v, cd);
+      for (int k = 0; k < 6; k++) c->cdof_dot[6 * d + k] = r[k];
+    }
+  }
+  WAVE_SYNC();
+  GRX_SUBTICK(c, 6);
+  FOR_LANES {
     // accelerations with qacc = 0 and per-body inertial forces
-    for (int b = 1 + lane; b < m->nbody; b += 64) {
+    for (int b = 1 + lane; b < GRX_NBC; b += 64) {
       float a[6] = {0, 0, 0, -m->gravity[0], -m->gravity[1], -m->gravity[2]}, v[6], Ia[6], Iv[6], t[6];
       unsigned mlo = (unsigned)m->dof_chainmask[2 * b], mhi = (unsigned)m->dof_chainmask[2 * b + 1];
 #pragma unroll 4
@@ -655,7 +685,7 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
       for (int k = 0; k < 6; k++) c->cacc[6 * b + k] = Ia[k] + t[k];
     }
     // actuators (one lane each; joint transmission)
-    for (int i = lane; i < m->nu; i += 64) {
+    for (int i = lane; i < GRX_NUC; i += 64) {
       int j = m->act_trnid[i]; float gear = m->act_gear[i];
       float len = gear * c->qpos[m->jnt_qposadr[j]], vel = gear * c->qvel[m->jnt_dofadr[j]];
       float u = c->ctrl[i];
@@ -670,19 +700,20 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   WAVE_SYNC();
+  GRX_SUBTICK(c, 7);
   FOR_LANES {
     // subtree force sums
-    for (int it = lane; it < 6 * m->nbody; it += 64) {
+    for (int it = lane; it < 6 * GRX_NBC; it += 64) {
       int b = it / 6, k = it - 6 * b;
-      if (b == 0) { c->cfrc[it] = 0; continue; }
-      int a = m->body_subadr[b], n = m->body_subnum[b];
+      unsigned mlo = (unsigned)m->body_submask[2 * b], mhi = (S::kFixed && S::NB <= 32) ? 0u : (unsigned)m->body_submask[2 * b + 1];
       float s = 0;
-#pragma unroll 8
-      for (int e = 0; e < n; e++) s += c->cacc[6 * m->body_sub[a + e] + k];
+#pragma unroll 16
+      for (int e = 1; e < GRX_NBC; e++) { unsigned bit = e < 32 ? (mlo >> e) & 1u : (mhi >> (e - 32)) & 1u; s += bit ? c->cacc[6 * e + k] : 0.0f; }
       c->cfrc[it] = s;
     }
   }
   WAVE_SYNC();
+  GRX_SUBTICK(c, 8);
   FOR_LANES {
     for (int d = lane; d < nv; d += 64) {
       float s = 0; int b = m->dof_bodyid[d];
@@ -1007,7 +1038,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_FRESH_MODEL(m, c);
   // geom frames (they share LDS with the composite inertias of the previous stage)
   FOR_LANES {
-    for (int i = lane; i < m->ngeom; i += 64) {
+    for (int i = lane; i < GRX_NGC; i += 64) {
       int b = m->geom_bodyid[i];
       float lpv[3] = {m->geom_pos[3 * i], m->geom_pos[3 * i + 1], m->geom_pos[3 * i + 2]}, lqv[4] = {m->geom_quat[4 * i], m->geom_quat[4 * i + 1], m->geom_quat[4 * i + 2], m->geom_quat[4 * i + 3]}, v[3], R[9], Rw[9];
       mulMatVec3f(v, c->xmat + 9 * b, lpv);
@@ -1018,6 +1049,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   }
   LANE0 { c->cnt[0] = 0; c->cnt[7] = 0; }
   WAVE_SYNC();
+  GRX_SUBTICK(c, 12);
   for (int base = 0; base < m->ndevpair; base += 64) {
     FOR_LANES {
       int k = base + lane;
@@ -1049,6 +1081,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
       }
     }
     WAVE_SYNC();
+    GRX_SUBTICK(c, 13);
     // large hulls (a moving link near the plane): all lanes scan the vertices of one pair at a time
     int nbig = c->cnt[7] < 32 ? c->cnt[7] : 32;
     for (int l = 0; l < nbig; l++) {
@@ -1149,7 +1182,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   // prefix sums below then only touch LDS.
   const int ne = 6 * m->nweld, nf = m->nfric;
   FOR_LANES {
-    for (int j = lane; j < m->njnt; j += 64) {
+    for (int j = lane; j < GRX_NJC; j += 64) {
       int f = 0;
       if (m->jnt_limited[j] && m->jnt_type[j] >= 2) {
         float q = c->qpos[m->jnt_qposadr[j]], mg = m->jnt_margin[j];
@@ -1169,8 +1202,9 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   WAVE_SYNC();
+  GRX_SUBTICK(c, 0);
   int nl = 0;
-  for (int j = 0; j < m->njnt; j++) { int f = c->ired[j]; nl += (f & 1) + ((f >> 1) & 1); }
+  for (int j = 0; j < GRX_NJC; j++) { int f = c->ired[j]; nl += (f & 1) + ((f >> 1) & 1); }
   // pool words used by the welds (all six rows of a weld share the span of the two body chains)
   int wpool = 0;
   for (int q = 0; q < m->neq; q++)
@@ -1184,6 +1218,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   }
   int nefc = ne + nf + nl + nc;
   if (nefc > GRX_MAXEFC) nefc = GRX_MAXEFC;
+  GRX_SUBTICK(c, 1);
   // ---- descriptors
   FOR_LANES {
     for (int r = lane; r < ne; r += 64) {  // welds are the only equality type in scope
@@ -1203,7 +1238,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
           c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), d, 1);
         }
       }
-    for (int j = lane; j < m->njnt; j += 64) {
+    for (int j = lane; j < GRX_NJC; j += 64) {
       int f = c->ired[j];
       if (f) {
         int r = ne + nf;
@@ -1224,6 +1259,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   }
   LANE0 { c->cnt[1] = nefc; c->cnt[3] = ne; c->cnt[4] = nf; c->cnt[5] = nl; if (overflow) c->cnt[2] |= GRX_ST_EFC_OVERFLOW; }
   WAVE_SYNC();
+  GRX_SUBTICK(c, 2);
   // ---- Jacobian rows.  zero fill, then per (row-group, dof) items
   // (every (row group, dof) item below writes all of its entries, zeros included: no separate clear of J)
   FOR_LANES {
@@ -1259,6 +1295,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       }
     }
     // frictionloss + limits: one lane per row
+    GRX_SUBTICK(c, 3);
     for (int r = ne + lane; r < ne + nf + nl && r < nefc; r += 64) {
       if (c->efc_kind[r] == GRX_ROW_FRICTION) {
         c->Jp[GRX_ROW_OFF(c->efc_row[r])] = 1.0f;
@@ -1270,6 +1307,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       }
     }
     // contacts: one lane per (contact, dof of its span)
+    GRX_SUBTICK(c, 4);
     for (int it = lane; it < ncon * nv; it += 64) {
       int k = it / nv, jd = it - k * nv;
       int r0 = c->con_efc[k];
@@ -1299,6 +1337,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   WAVE_SYNC();
+  GRX_SUBTICK(c, 5);
   // ---- per-row impedance, regulariser, reference acceleration
   FOR_LANES {
     for (int r = lane; r < nefc; r += 64) {
@@ -1646,7 +1685,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       FOR_LANES { for (int i = lane; i < nv; i += 64) c->qvel[i] += h * c->tmpv[i]; }
       WAVE_SYNC();
       FOR_LANES {
-        for (int j = lane; j < m->njnt; j += 64) {
+        for (int j = lane; j < GRX_NJC; j += 64) {
           int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
           if (m->jnt_type[j] == 0) {
             for (int k = 0; k < 3; k++) c->qpos[qa + k] += h * c->qvel[da + k];
@@ -1689,7 +1728,7 @@ GRX_MEM void grx_forward_euler(const GrxModel* m, GrxCtx* c, int do_euler, int l
 // qpos <- q0 (+) hh * v  (mj_integratePos semantics: quaternion exponential for free joints), one lane per joint
 GRX_MEM void grx_integrate_pos(const GrxModel* m, GrxCtx* c, const float* q0, const float* v, float hh, int lane_) {
   FOR_LANES {
-    for (int j = lane; j < m->njnt; j += 64) {
+    for (int j = lane; j < GRX_NJC; j += 64) {
       int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
       if (m->jnt_type[j] == 0) {
         for (int k = 0; k < 3; k++) c->qpos[qa + k] = q0[qa + k] + hh * v[da + k];
@@ -1715,7 +1754,7 @@ GRX_MEM void grx_rk4_after_forward(const GrxModel* m, GrxCtx* c, int stage, int 
   const int nv = GRX_NVC; const float h = m->timestep;
   FOR_LANES {
     if (stage == 0) {
-      for (int i = lane; i < m->nq; i += 64) c->rk_q0[i] = c->qpos[i];
+      for (int i = lane; i < GRX_NQC; i += 64) c->rk_q0[i] = c->qpos[i];
       for (int i = lane; i < nv; i += 64) c->rk_v0[i] = c->qvel[i];
     }
     for (int i = lane; i < nv; i += 64) { c->rk_Fv[stage * nv + i] = c->qvel[i]; c->rk_Fa[stage * nv + i] = c->qacc[i]; }
@@ -1745,17 +1784,17 @@ GRX_MEM void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_LANEVAR(badp);
   FOR_LANES {
     int bad = 0;
-    for (int i = lane; i < m->nq; i += 64) { float v = c->qpos[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
+    for (int i = lane; i < GRX_NQC; i += 64) { float v = c->qpos[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
     for (int i = lane; i < GRX_NVC; i += 64) { float v = c->qvel[i]; if (!(v == v) || fabsf(v) > 1e10f) bad = 1; }
     LV(badp) = bad ? 1.0f : 0.0f;
   }
   WAVE_SYNC();
   if (grx_reduce_max(badp) > 0.5f) {
     FOR_LANES {
-      for (int i = lane; i < m->nq; i += 64) c->qpos[i] = m->qpos0[i];
+      for (int i = lane; i < GRX_NQC; i += 64) c->qpos[i] = m->qpos0[i];
       for (int i = lane; i < GRX_NVC; i += 64) { c->qvel[i] = 0.0f; c->qacc_ws[i] = 0.0f; }
-      for (int i = lane; i < 3 * m->nmocap; i += 64) c->mocap_pos[i] = m->mocap_pos0[i];
-      for (int i = lane; i < 4 * m->nmocap; i += 64) c->mocap_quat[i] = m->mocap_quat0[i];
+      for (int i = lane; i < 3 * GRX_NMC; i += 64) c->mocap_pos[i] = m->mocap_pos0[i];
+      for (int i = lane; i < 4 * GRX_NMC; i += 64) c->mocap_quat[i] = m->mocap_quat0[i];
     }
     LANE0 { c->cnt[2] |= GRX_ST_BADNUM; }
     WAVE_SYNC();

@@ -48,9 +48,9 @@ GRX_DEV void grx_mat2euler(const float* R, float* e) {
   else { e[0] = 0.0f; e[1] = -atan2f(-R[2], cy); e[2] = -atan2f(-R[3], R[4]); }
 }
 
-template <int NV>
+template <class S>
 struct GrxFetch {
-  typedef GrxEngine<NV> E;
+  typedef GrxEngine<S> E;
 // linear / angular velocity of a world point fixed to body b: J(point) * qvel using the
 // motion axes of the LAST forward pass and the CURRENT qvel (what mj_jacSite @ qvel gives)
 GRX_MEM void grx_point_velocity(const GrxModel* m, const GrxCtx* c, int b, const float* point, float* vp, float* vr) {
@@ -71,7 +71,7 @@ GRX_MEM void grx_fetch_set_action(const GrxModel* m, const GrxFetchTask* t, GrxC
     float a[4];
     for (int k = 0; k < 4; k++) a[k] = fminf(1.0f, fmaxf(-1.0f, action[k]));
     float g = t->block_gripper ? 0.0f : a[3];
-    for (int i = 0; i < m->nu; i++) {
+    for (int i = 0; i < GRX_NUC; i++) {
       int j = m->act_trnid[i];
       c->ctrl[i] = (m->act_biastype[i] == 0) ? g : c->qpos[m->jnt_qposadr[j]] + g;
     }

@@ -36,6 +36,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.nsite = d[GRX_NSITE]; m.nmocap = d[GRX_NMOCAP]; m.neq = d[GRX_NEQ]; m.npair = d[GRX_NPAIR]; m.maxdepth = d[GRX_MAXDEPTH];
   m.eulerdamp = d[GRX_EULERDAMP]; m.ndevpair = v.n_devpair; m.nmpair = v.n_mpair_i;
   m.integrator = d[GRX_INTEGRATOR];
+  m.njump = m.nbody > 0 ? v.n_body_jump / m.nbody : 0;
   m.nfric = 0; m.nweld = 0;
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;
   for (int k = 0; k < v.n_eq_type; k++) if (v.eq_active[k] && v.eq_type[k] == GRX_EQ_WELD) m.nweld++;

@@ -57,23 +57,17 @@ extern "C" int grx_profile_read(long long* out) { return (int)hipMemcpyFromSymbo
 extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grx_prof), z, sizeof(z)); }
 #endif
 
-// Model shapes.  A step kernel specialised for a shape has all ten layout dims as compile-time constants: the LDS
-// carve folds into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs)
-// and the loops over dofs unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
-template <int NQ, int NV, int NU, int NBODY, int NJNT, int NGEOM, int NSITE, int NMOCAP>
-struct GrxShape {
-  static constexpr int kNV = NV;
-  static __device__ __forceinline__ GrxDims dims(const GrxModel&) { return GrxDims{NQ, NV, NU, NBODY, NJNT, NGEOM, NSITE, NMOCAP, 0, 0}; }
-  static bool matches(const GrxModel& g) {
-    return g.nq == NQ && g.nv == NV && g.nu == NU && g.nbody == NBODY && g.njnt == NJNT && g.ngeom == NGEOM && g.nsite == NSITE &&
-           g.nmocap == NMOCAP && g.nfric == 0 && g.integrator == 0;
-  }
-};
-struct GrxShapeAny {
-  static constexpr int kNV = 0;
-  static __device__ __forceinline__ GrxDims dims(const GrxModel& m) { return grx_dims_of(&m); }
-  static bool matches(const GrxModel&) { return true; }
-};
+// Model shapes.  A step kernel specialised for a shape has all layout dims as compile-time constants: the LDS carve folds
+// into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs) and the loops over
+// dofs / bodies / joints unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
+template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(const GrxModel& m) {
+  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, 0, 0};
+  return grx_dims_of(&m);
+}
+template <class S> static bool grx_shape_matches(const GrxModel& g) {
+  return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
+         g.nmocap == S::NM && g.nfric == 0 && g.integrator == 0;
+}
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1> GrxShapeFetchArm;    // FetchReach (arm only)
@@ -88,7 +82,7 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
-  grx_ctx_carve(&c, lds, S::dims(m));
+  grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
@@ -99,12 +93,12 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = aux[k];
   float* obs = b.obs + (size_t)w * t.obs_dim; float* ach = b.achieved + (size_t)w * 3; const float* act = b.action + (size_t)w * 4;
-  GrxFetch<S::kNV>::grx_fetch_step_world(&m, &t, &c, aux_in, act, aux, obs, ach, lane_);
+  GrxFetch<S>::grx_fetch_step_world(&m, &t, &c, aux_in, act, aux, obs, ach, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, w, lane_);
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
-  if (lane_ == 0 && w == n_worlds / 2) for (int k = 0; k < GRX_NPROF; k++) g_grx_prof[k] = c.prof[k];
+  if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);  // summed over worlds
 #endif
 }
 
@@ -124,8 +118,8 @@ grx_fetch_forward_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_wor
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
 #endif
   grx_load_world(m, b, c, w, lds, words, lane_);
-  { const int total = nstep > 0 ? nstep : 1; for (int s = 0; s < total; s++) GrxEngine<0>::grx_forward_euler(&m, &c, nstep > 0, lane_); }
-  GrxFetch<0>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)w * 8, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
+  { const int total = nstep > 0 ? nstep : 1; for (int s = 0; s < total; s++) GrxEngine<GrxShapeAny>::grx_forward_euler(&m, &c, nstep > 0, lane_); }
+  GrxFetch<GrxShapeAny>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)w * 8, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, w, lane_);
 }
@@ -151,7 +145,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
   for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
   __syncthreads();
   float* obs = b.obs + (size_t)w * (m.nq + m.nv - (t.agent ? 2 : 0)); float* ach = b.achieved + (size_t)w * 2;
-  GrxPoint<0>::grx_point_step_world(&m, &t, &c, b.action + (size_t)w * m.nu, obs, ach, lane_);
+  GrxPoint<GrxShapeAny>::grx_point_step_world(&m, &t, &c, b.action + (size_t)w * m.nu, obs, ach, lane_);
   __syncthreads();
   for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
   for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)w * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * m.nv + i] = c.qacc_ws[i]; }
@@ -197,10 +191,10 @@ grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_i
   for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0 ? 1 : 0; c.efc_row[i] = GRX_ROW_PACK(i * nv, 0, nv); c.efc_force[i] = 0.5f + 0.01f * (float)i; }
   __syncthreads();
   if (mode == 0) {
-    GrxEngine<0>::grx_sym_solve_full(c.A, nv, c.tmpv, lane_);
+    GrxEngine<GrxShapeAny>::grx_sym_solve_full(c.A, nv, c.tmpv, lane_);
     for (int i = lane_; i < nv; i += 64) out[i] = c.tmpv[i];
   } else {
-    GrxEngine<0>::grx_hessian(&m, &c, nefc, lane_);
+    GrxEngine<GrxShapeAny>::grx_hessian(&m, &c, nefc, lane_);
     for (int i = lane_; i < nv * nv; i += 64) out[i] = c.A[i];
     for (int i = lane_; i < nv; i += 64) out[nv * nv + i] = c.grad[i];  // J' f
   }
@@ -251,9 +245,9 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   m->shape = 0;
-  if (GrxShapeFetchPick::matches(g)) { m->shape = 1; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPick>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  else if (GrxShapeFetchObject::matches(g)) { m->shape = 2; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchObject>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  else if (GrxShapeFetchArm::matches(g)) { m->shape = 3; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchArm>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  if (grx_shape_matches<GrxShapeFetchPick>(g)) { m->shape = 1; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPick>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  else if (grx_shape_matches<GrxShapeFetchObject>(g)) { m->shape = 2; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchObject>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  else if (grx_shape_matches<GrxShapeFetchArm>(g)) { m->shape = 3; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchArm>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   for (int k = 0; k < GRX_MAX_MODELS && m->slot < 0; k++) if (!g_slot_used[k]) { g_slot_used[k] = 1; m->slot = k; }

@@ -34,15 +34,15 @@ GRX_DEV float grx_goal_distance2(const float* a, const float* b) {
 }
 GRX_DEV float grx_maze_reward(float d, float radius, int sparse) { return sparse ? ((d <= radius) ? 1.0f : 0.0f) : expf(-d); }
 
-template <int NV>
+template <class S>
 struct GrxPoint {
-  typedef GrxEngine<NV> E;
+  typedef GrxEngine<S> E;
   GRX_MEM void grx_point_step_world(const GrxModel* m, const GrxPointTask* t, GrxCtx* c, const float* action, float* obs, float* achieved,
                                     int lane_) {
     const int ant = t->agent;
     FOR_LANES {
       // point: np.clip(action, -1, 1) and the velocity clip of point.py:57,73-77; ant: ctrl = action (ctrlrange is applied by the actuator model)
-      for (int i = lane; i < m->nu; i += 64) c->ctrl[i] = ant ? action[i] : fminf(1.0f, fmaxf(-1.0f, action[i]));
+      for (int i = lane; i < GRX_NUC; i += 64) c->ctrl[i] = ant ? action[i] : fminf(1.0f, fmaxf(-1.0f, action[i]));
       if (!ant) for (int i = lane; i < GRX_NVC; i += 64) c->qvel[i] = fminf(t->vel_clip, fmaxf(-t->vel_clip, c->qvel[i]));
     }
     WAVE_SYNC();
@@ -57,8 +57,8 @@ struct GrxPoint {
     }
     const int skip = ant ? 2 : 0;  // AntMaze strips the xy position from the observation (it is the achieved goal)
     FOR_LANES {
-      for (int i = lane; i < m->nq; i += 64) { float q = c->qpos[i]; if (i >= skip) obs[i - skip] = q; if (i < 2) achieved[i] = q; }
-      for (int i = lane; i < GRX_NVC; i += 64) obs[m->nq - skip + i] = c->qvel[i];
+      for (int i = lane; i < GRX_NQC; i += 64) { float q = c->qpos[i]; if (i >= skip) obs[i - skip] = q; if (i < 2) achieved[i] = q; }
+      for (int i = lane; i < GRX_NVC; i += 64) obs[GRX_NQC - skip + i] = c->qvel[i];
     }
     WAVE_SYNC();
   }

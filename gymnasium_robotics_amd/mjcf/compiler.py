@@ -1314,7 +1314,32 @@ class _Lowering:
                 body_anc.append(a_)
                 a_ = int(body_parent[a_])
             body_ancnum[k] = len(body_anc) - body_ancadr[k]
+        if nbk > 64:
+            raise ValueError("engine limit: at most 64 bodies after static-body fusing (subtree masks are 64-bit)")
+        submask = np.zeros((nbk, 2), np.int64)
+        for k in range(1, nbk):
+            msk = 0
+            for e in subs[k]:
+                msk |= 1 << e
+            submask[k] = [msk & 0xFFFFFFFF, (msk >> 32) & 0xFFFFFFFF]
+        submask = np.array([[(v if v < 2 ** 31 else v - 2 ** 32) for v in row] for row in submask], np.int32)
+        # pointer jumping: a body whose pose needs its own ancestors (not mocap, not a free-joint root) reaches the ancestor
+        # 2^s levels up in round s; bodies with world poses already known (mocap / free) never jump
+        def _needs_chain(k):
+            if k == 0 or body_mocapid[k] >= 0:
+                return False
+            return not (body_jntnum[k] == 1 and jnts[body_jntadr[k]].type == JNT_FREE)
+        njump = max(1, int(np.ceil(np.log2(max(maxdepth, 1) + 1))))
+        jump = np.zeros((njump, nbk), np.int32)
+        for k in range(1, nbk):
+            if _needs_chain(k):
+                jump[0, k] = body_parent[k]
+        for s_ in range(1, njump):
+            for k in range(1, nbk):
+                a_ = jump[s_ - 1, k]
+                jump[s_, k] = jump[s_ - 1, a_] if a_ > 0 else 0
         T.update(
+            body_submask=submask, body_jump=jump.reshape(-1),
             body_ancadr=body_ancadr, body_ancnum=body_ancnum, body_anc=np.array(body_anc, np.int32),
             body_order=np.array(order, np.int32), level_adr=level_adr, body_subadr=body_subadr, body_subnum=body_subnum,
             body_sub=np.array(body_sub, np.int32), body_lastdof=body_lastdof, mpair_i=np.array(mpi, np.int32),

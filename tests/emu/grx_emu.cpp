@@ -79,7 +79,7 @@ void emu_fetch_step(void* h, const GrxFetchTask* t, float* qpos, float* qvel, fl
   Emu* e = (Emu*)h;
   load_state(e, qpos, qvel, qacc_ws, mocap);
   float aux_in[8]; memcpy(aux_in, aux, sizeof(aux_in));
-  GrxFetch<0>::grx_fetch_step_world(&e->m, t, &e->c, aux_in, action, aux, obs, achieved, 0);
+  GrxFetch<GrxShapeAny>::grx_fetch_step_world(&e->m, t, &e->c, aux_in, action, aux, obs, achieved, 0);
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 
@@ -88,8 +88,8 @@ void emu_forward(void* h, const GrxFetchTask* t, float* qpos, float* qvel, float
                  float* achieved, int* status, int nstep) {
   Emu* e = (Emu*)h;
   load_state(e, qpos, qvel, qacc_ws, mocap);
-  { const int total = nstep > 0 ? nstep : 1; for (int s = 0; s < total; s++) GrxEngine<0>::grx_forward_euler(&e->m, &e->c, nstep > 0, 0); }
-  GrxFetch<0>::grx_fetch_outputs(&e->m, t, &e->c, aux, obs, achieved, 0);
+  { const int total = nstep > 0 ? nstep : 1; for (int s = 0; s < total; s++) GrxEngine<GrxShapeAny>::grx_forward_euler(&e->m, &e->c, nstep > 0, 0); }
+  GrxFetch<GrxShapeAny>::grx_fetch_outputs(&e->m, t, &e->c, aux, obs, achieved, 0);
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 
@@ -99,7 +99,7 @@ void emu_point_step(void* h, const GrxPointTask* t, float* qpos, float* qvel, fl
   Emu* e = (Emu*)h;
   float mocap[8] = {0};
   load_state(e, qpos, qvel, qacc_ws, mocap);
-  GrxPoint<0>::grx_point_step_world(&e->m, t, &e->c, action, obs, achieved, 0);
+  GrxPoint<GrxShapeAny>::grx_point_step_world(&e->m, t, &e->c, action, obs, achieved, 0);
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 

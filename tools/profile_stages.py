@@ -21,19 +21,24 @@ L = _native.lib()
 names = ["kinematics", "inertia_cdof_crb_M", "collision", "make_constraint", "velocity_rne", "M_factor_solve", "newton_eval", "newton_grad",
          "newton_hessian", "newton_factor_solve", "newton_linesearch", "newton_final", "euler", "other"]
 g = torch.Generator(device="cuda:0"); g.manual_seed(0)
-tot = np.zeros(16)
+NP = 48
+tot = np.zeros(NP)
 K = 10
 for k in range(K):
     a = torch.rand(n, 4, device="cuda:0", generator=g) * 2 - 1
     a[:, 2] = -a[:, 2].abs()  # push towards the table so that contacts are active
+    L.grx_profile_reset()
     env.step(a)
     torch.cuda.synchronize()
-    out = (ctypes.c_longlong * 16)()
+    out = (ctypes.c_longlong * NP)()
     L.grx_profile_read(out)
     if k >= 2:
-        tot += np.array(list(out), dtype=np.float64)
+        tot += np.array(list(out), dtype=np.float64) / n  # kernel sums over worlds
 tot /= (K - 2)
 s = tot.sum()
-print(f"cycles per env.step (20 substeps) of world {n//2}: {s:.0f}  (= {s/20:.0f} per substep)")
+print(f"cycles per env.step (20 substeps), mean over {n} worlds: {s:.0f}  (= {s/20:.0f} per substep)")
 for nm, v in zip(names, tot):
     print(f"  {nm:22s} {v:12.0f}  {100*v/s:5.1f}%")
+for k in range(16, NP):
+    if tot[k] > 0:
+        print(f"  sub[{k-16:2d}]                {tot[k]:12.0f}  {100*tot[k]/s:5.1f}%")
