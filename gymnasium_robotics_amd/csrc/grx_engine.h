@@ -82,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -289,6 +289,52 @@ __device__ __forceinline__ float grx_reduce_max(float v) {
   return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))),
                fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48))));
 }
+#endif
+
+// integer lane variables, exclusive prefix sums over the 64 lanes and reads of one lane's value (uniform index)
+#if defined(GRX_EMU)
+#define GRX_LANEVAR_I(name) int name[64]
+#define GRX_SCAN_EXCL(in, out, total) do { int s_ = 0; for (int i_ = 0; i_ < 64; i_++) { int t_ = (in)[i_]; (out)[i_] = s_; s_ += t_; } (total) = s_; } while (0)
+#define GRX_LANE_READ_I(var, idx) ((var)[idx])
+#else
+#define GRX_LANEVAR_I(name) int name
+// Hillis-Steele inside each row of 16 lanes (row_shr 1,2,4,8, zero fill), then row_bcast15 into rows 1,3 and row_bcast31 into rows 2,3
+__device__ __forceinline__ int grx_scan_incl_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+#define GRX_SCAN_EXCL(in, out, total) do { const int inc_ = grx_scan_incl_i(in); (out) = inc_ - (in); (total) = __builtin_amdgcn_readlane(inc_, 63); } while (0)
+#define GRX_LANE_READ_I(var, idx) __builtin_amdgcn_readlane(var, idx)
+#endif
+
+// reductions inside groups of 8 consecutive lanes (all 8 lanes receive the result) and wave ballots
+#if defined(GRX_EMU)
+#define GRX_OCT_MAX(in, out) do { for (int g_ = 0; g_ < 8; g_++) { float m_ = (in)[8 * g_]; for (int i_ = 1; i_ < 8; i_++) m_ = fmaxf(m_, (in)[8 * g_ + i_]); \
+    for (int i_ = 0; i_ < 8; i_++) (out)[8 * g_ + i_] = m_; } } while (0)
+#define GRX_OCT_MIN_I(in, out) do { for (int g_ = 0; g_ < 8; g_++) { int m_ = (in)[8 * g_]; for (int i_ = 1; i_ < 8; i_++) m_ = (in)[8 * g_ + i_] < m_ ? (in)[8 * g_ + i_] : m_; \
+    for (int i_ = 0; i_ < 8; i_++) (out)[8 * g_ + i_] = m_; } } while (0)
+static inline unsigned long long grx_emu_ballot(const int* v) { unsigned long long b = 0; for (int i = 0; i < 64; i++) if (v[i]) b |= 1ull << i; return b; }
+#define GRX_BALLOT(var) grx_emu_ballot(var)
+#else
+__device__ __forceinline__ float grx_oct_max_f(float v) {  // xor 1, xor 2 (quad_perm), row_half_mirror
+  v = fmaxf(v, GRX_DPP_MOV(v, 0xB1)); v = fmaxf(v, GRX_DPP_MOV(v, 0x4E)); v = fmaxf(v, GRX_DPP_MOV(v, 0x141));
+  return v;
+}
+__device__ __forceinline__ int grx_oct_min_i(int v) {
+  int t;
+  t = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); v = t < v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); v = t < v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true); v = t < v ? t : v;
+  return v;
+}
+#define GRX_OCT_MAX(in, out) do { (out) = grx_oct_max_f(in); } while (0)
+#define GRX_OCT_MIN_I(in, out) do { (out) = grx_oct_min_i(in); } while (0)
+#define GRX_BALLOT(var) ((unsigned long long)__ballot((var) != 0))
 #endif
 
 // wave-wide sums of per-lane partials staged in red[0..63] (and red[64..127] for the second value).
@@ -907,132 +953,211 @@ GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1
 }
 
 
-// box-box: SAT over the 15 axes, then face clipping or edge-edge.  Written without dynamically indexed local
-// arrays (everything stays in registers): axes are selected with GRX_SEL3, and the clipped contact polygon is
-// enumerated as (a) incident-face corners inside the reference rectangle, (b) reference corners inside the incident
-// quad, (c) proper crossings of incident edges with the rectangle sides -- the vertex set Sutherland-Hodgman yields.
-GRX_MEM void grx_box_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
-  const float* p1 = c->gxpos + 3 * g1; const float* R1 = c->gxmat + 9 * g1; const float* a = m->geom_size + 3 * g1;
-  const float* p2 = c->gxpos + 3 * g2; const float* R2 = c->gxmat + 9 * g2; const float* b = m->geom_size + 3 * g2;
-  float A0[3] = {R1[0], R1[3], R1[6]}, A1[3] = {R1[1], R1[4], R1[7]}, A2[3] = {R1[2], R1[5], R1[8]};
-  float B0[3] = {R2[0], R2[3], R2[6]}, B1[3] = {R2[1], R2[4], R2[7]}, B2[3] = {R2[2], R2[5], R2[8]};
-  float a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2];
-  float d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-  float best = -1e30f; int code = -1; float bn[3] = {0, 0, 0};
-#define GRX_FACE_AXIS(AX, HALF, OA0, OA1, OA2, os0, os1, os2, CODE) { \
-    float t = dot3f(d, AX); \
-    float sep = fabsf(t) - ((HALF) + os0 * fabsf(dot3f(AX, OA0)) + os1 * fabsf(dot3f(AX, OA1)) + os2 * fabsf(dot3f(AX, OA2))); \
-    if (sep > margin) return; \
-    if (sep > best) { best = sep; code = CODE; float sg = t < 0 ? -1.0f : 1.0f; bn[0] = sg * AX[0]; bn[1] = sg * AX[1]; bn[2] = sg * AX[2]; } }
-  GRX_FACE_AXIS(A0, a0, B0, B1, B2, b0, b1, b2, 0) GRX_FACE_AXIS(A1, a1, B0, B1, B2, b0, b1, b2, 1) GRX_FACE_AXIS(A2, a2, B0, B1, B2, b0, b1, b2, 2)
-  GRX_FACE_AXIS(B0, b0, A0, A1, A2, a0, a1, a2, 3) GRX_FACE_AXIS(B1, b1, A0, A1, A2, a0, a1, a2, 4) GRX_FACE_AXIS(B2, b2, A0, A1, A2, a0, a1, a2, 5)
-#undef GRX_FACE_AXIS
-  float ebest = -1e30f; int ei = -1, ej = -1; float en[3] = {0, 0, 0};
-#define GRX_EDGE_AXIS(AI, BJ, I, J) { \
-    float ax[3]; cross3f(ax, AI, BJ); \
-    float l = sqrtf(dot3f(ax, ax)); \
-    if (l >= 1e-6f) { \
-      float li = 1.0f / l; ax[0] *= li; ax[1] *= li; ax[2] *= li; \
-      float t = dot3f(d, ax); \
-      float ra = a0 * fabsf(dot3f(A0, ax)) + a1 * fabsf(dot3f(A1, ax)) + a2 * fabsf(dot3f(A2, ax)); \
-      float rb = b0 * fabsf(dot3f(B0, ax)) + b1 * fabsf(dot3f(B1, ax)) + b2 * fabsf(dot3f(B2, ax)); \
-      float sep = fabsf(t) - (ra + rb); \
-      if (sep > margin) return; \
-      if (sep > ebest) { ebest = sep; ei = I; ej = J; float sg = t < 0 ? -1.0f : 1.0f; en[0] = sg * ax[0]; en[1] = sg * ax[1]; en[2] = sg * ax[2]; } } }
-  GRX_EDGE_AXIS(A0, B0, 0, 0) GRX_EDGE_AXIS(A0, B1, 0, 1) GRX_EDGE_AXIS(A0, B2, 0, 2)
-  GRX_EDGE_AXIS(A1, B0, 1, 0) GRX_EDGE_AXIS(A1, B1, 1, 1) GRX_EDGE_AXIS(A1, B2, 1, 2)
-  GRX_EDGE_AXIS(A2, B0, 2, 0) GRX_EDGE_AXIS(A2, B1, 2, 1) GRX_EDGE_AXIS(A2, B2, 2, 2)
-#undef GRX_EDGE_AXIS
-  if (ei >= 0 && ebest > best + 1e-7f + 0.02f * fabsf(best)) {
-    float pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
-    float s0 = (ei != 0) ? (dot3f(en, A0) > 0 ? a0 : -a0) : 0.0f, s1 = (ei != 1) ? (dot3f(en, A1) > 0 ? a1 : -a1) : 0.0f, s2 = (ei != 2) ? (dot3f(en, A2) > 0 ? a2 : -a2) : 0.0f;
-    float t0 = (ej != 0) ? (dot3f(en, B0) > 0 ? -b0 : b0) : 0.0f, t1 = (ej != 1) ? (dot3f(en, B1) > 0 ? -b1 : b1) : 0.0f, t2 = (ej != 2) ? (dot3f(en, B2) > 0 ? -b2 : b2) : 0.0f;
-    float u[3], v[3];
-    for (int e = 0; e < 3; e++) {
-      pa[e] += s0 * A0[e] + s1 * A1[e] + s2 * A2[e]; pb[e] += t0 * B0[e] + t1 * B1[e] + t2 * B2[e];
-      u[e] = GRX_SEL3(A0[e], A1[e], A2[e], ei); v[e] = GRX_SEL3(B0[e], B1[e], B2[e], ej);
+// box-box: SAT over the 15 axes, then face clipping or edge-edge (the contact set Sutherland-Hodgman clipping yields:
+// (a) incident-face corners inside the reference rectangle, (b) reference corners inside the incident quad, (c) proper
+// crossings of incident edges with the rectangle sides; at most 8, in that order).
+// Eight lanes work on one pair: lane t evaluates the axes t and t+8, then the contact candidates t, t+8 and t+16; the
+// winners are found with DPP reductions inside the octet and the surviving candidates are compacted, in candidate
+// order, with wave ballots.  Up to eight pairs per pass; the pair queue is filled by grx_collision.
+// Everything stays in registers (no dynamically indexed local arrays): axes are selected with GRX_SEL3.
+#define GRX_BB_LOAD(PAIR) \
+  const int g1 = m->pair_geom1[PAIR], g2 = m->pair_geom2[PAIR]; const float margin = m->pair_margin[PAIR]; \
+  const float* p1 = c->gxpos + 3 * g1; const float* R1 = c->gxmat + 9 * g1; const float* p2 = c->gxpos + 3 * g2; const float* R2 = c->gxmat + 9 * g2; \
+  const float A0[3] = {R1[0], R1[3], R1[6]}, A1[3] = {R1[1], R1[4], R1[7]}, A2[3] = {R1[2], R1[5], R1[8]}; \
+  const float B0[3] = {R2[0], R2[3], R2[6]}, B1[3] = {R2[1], R2[4], R2[7]}, B2[3] = {R2[2], R2[5], R2[8]}; \
+  const float a0 = m->geom_size[3 * g1], a1 = m->geom_size[3 * g1 + 1], a2 = m->geom_size[3 * g1 + 2]; \
+  const float b0 = m->geom_size[3 * g2], b1 = m->geom_size[3 * g2 + 1], b2 = m->geom_size[3 * g2 + 2]; \
+  const float d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+// axis T (0-2: faces of box 1, 3-5: faces of box 2, 6-14: edge i of box 1 x edge j of box 2): unit axis, projection of d, separation
+#define GRX_BB_AXIS(T, AXV, TP, SEP, OK) { \
+  const int T_ = (T), iu_ = T_ < 3 ? T_ : (T_ < 6 ? 0 : (T_ - 6) / 3), jv_ = T_ < 3 ? 0 : (T_ < 6 ? T_ - 3 : (T_ - 6) % 3); \
+  float u_[3], v_[3], x_[3]; \
+  for (int e_ = 0; e_ < 3; e_++) { u_[e_] = GRX_SEL3(A0[e_], A1[e_], A2[e_], iu_); v_[e_] = GRX_SEL3(B0[e_], B1[e_], B2[e_], jv_); } \
+  cross3f(x_, u_, v_); \
+  const float l_ = sqrtf(dot3f(x_, x_)), li_ = 1.0f / fmaxf(l_, 1e-12f); \
+  OK = (T_ < 15) && ((T_ < 6) || (l_ >= 1e-6f)); \
+  for (int e_ = 0; e_ < 3; e_++) AXV[e_] = T_ < 3 ? u_[e_] : (T_ < 6 ? v_[e_] : x_[e_] * li_); \
+  TP = dot3f(d, AXV); \
+  float ra_ = a0 * fabsf(dot3f(A0, AXV)) + a1 * fabsf(dot3f(A1, AXV)) + a2 * fabsf(dot3f(A2, AXV)); \
+  float rb_ = b0 * fabsf(dot3f(B0, AXV)) + b1 * fabsf(dot3f(B1, AXV)) + b2 * fabsf(dot3f(B2, AXV)); \
+  if (T_ < 3) ra_ = GRX_SEL3(a0, a1, a2, T_); else if (T_ < 6) rb_ = GRX_SEL3(b0, b1, b2, T_ - 3); \
+  SEP = fabsf(TP) - (ra_ + rb_); }
+
+GRX_MEM void grx_box_box_queue(const GrxModel* m, GrxCtx* c, const int* queue, int nq, int lane_) {
+  for (int pb = 0; pb < nq; pb += 8) {
+    // ---- separating axes
+    GRX_LANEVAR(sf); GRX_LANEVAR(se); GRX_LANEVAR(sall); GRX_LANEVAR_I(cf); GRX_LANEVAR_I(ce);
+    FOR_LANES {
+      const int g = lane >> 3, t = lane & 7;
+      float f = -1e30f, e = -1e30f; int fi = 99, ei = 99;
+      if (pb + g < nq) {
+        const int pair = queue[pb + g];
+        GRX_BB_LOAD(pair)
+        float ax[3], tp, sep; int ok;
+        GRX_BB_AXIS(t, ax, tp, sep, ok)
+        if (ok) { if (t < 6) { f = sep; fi = t; } else { e = sep; ei = t; } }
+        GRX_BB_AXIS(t + 8, ax, tp, sep, ok)
+        if (ok && sep > e) { e = sep; ei = t + 8; }
+        (void)tp; (void)margin;
+      }
+      LV(sf) = f; LV(se) = e; LV(cf) = fi; LV(ce) = ei; LV(sall) = fmaxf(f, e);
     }
-    float w[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-    float uv = dot3f(u, v), uw = dot3f(u, w), vw = dot3f(v, w);
-    float den = 1.0f - uv * uv;
-    float sc = den > 1e-12f ? (uv * vw - uw) / den : 0.0f, tc = den > 1e-12f ? (vw - uv * uw) / den : 0.0f;
-    float pos[3];
-    for (int k = 0; k < 3; k++) pos[k] = 0.5f * ((pa[k] + sc * u[k]) + (pb[k] + tc * v[k]));
-    grx_add_contact(c, pair, pos, en, ebest);
-    return;
-  }
-  // ---- face contact
-  const int ref1 = code < 3, ax = ref1 ? code : code - 3;
-  float pr[3], pi[3], nr[3], Ar0[3], Ar1[3], Ar2[3], Ai0[3], Ai1[3], Ai2[3];
-  for (int e = 0; e < 3; e++) {
-    pr[e] = ref1 ? p1[e] : p2[e]; pi[e] = ref1 ? p2[e] : p1[e]; nr[e] = ref1 ? bn[e] : -bn[e];
-    Ar0[e] = ref1 ? A0[e] : B0[e]; Ar1[e] = ref1 ? A1[e] : B1[e]; Ar2[e] = ref1 ? A2[e] : B2[e];
-    Ai0[e] = ref1 ? B0[e] : A0[e]; Ai1[e] = ref1 ? B1[e] : A1[e]; Ai2[e] = ref1 ? B2[e] : A2[e];
-  }
-  const float sr0 = ref1 ? a0 : b0, sr1 = ref1 ? a1 : b1, sr2 = ref1 ? a2 : b2;
-  const float si0 = ref1 ? b0 : a0, si1 = ref1 ? b1 : a1, si2 = ref1 ? b2 : a2;
-  // incident face: the face of the other box most anti-parallel to nr
-  float dd0 = dot3f(Ai0, nr), dd1 = dot3f(Ai1, nr), dd2 = dot3f(Ai2, nr);
-  int iax = 0; float mind = 1e30f, isg = 1.0f;
-  if (dd0 < mind) { mind = dd0; iax = 0; isg = 1.0f; } if (-dd0 < mind) { mind = -dd0; iax = 0; isg = -1.0f; }
-  if (dd1 < mind) { mind = dd1; iax = 1; isg = 1.0f; } if (-dd1 < mind) { mind = -dd1; iax = 1; isg = -1.0f; }
-  if (dd2 < mind) { mind = dd2; iax = 2; isg = 1.0f; } if (-dd2 < mind) { mind = -dd2; iax = 2; isg = -1.0f; }
-  float Iu[3], Iv[3], In[3], Ru[3], Rv[3];
-  for (int e = 0; e < 3; e++) {
-    In[e] = GRX_SEL3(Ai0[e], Ai1[e], Ai2[e], iax); Iu[e] = GRX_SEL3(Ai1[e], Ai2[e], Ai0[e], iax); Iv[e] = GRX_SEL3(Ai2[e], Ai0[e], Ai1[e], iax);
-    Ru[e] = GRX_SEL3(Ar1[e], Ar2[e], Ar0[e], ax); Rv[e] = GRX_SEL3(Ar2[e], Ar0[e], Ar1[e], ax);
-  }
-  const float sin_ = GRX_SEL3(si0, si1, si2, iax), siu = GRX_SEL3(si1, si2, si0, iax), siv = GRX_SEL3(si2, si0, si1, iax);
-  const float srn = GRX_SEL3(sr0, sr1, sr2, ax), sx = GRX_SEL3(sr1, sr2, sr0, ax), sy = GRX_SEL3(sr2, sr0, sr1, ax);
-  float rc[3], fcw[3];
-  for (int e = 0; e < 3; e++) { rc[e] = pr[e] + srn * nr[e]; fcw[e] = pi[e] + isg * sin_ * In[e] - rc[e]; }
-  // incident quad in the reference face frame: corner q = centre + su*U + sv*V, (su,sv) = (+,+),(-,+),(-,-),(+,-)
-  const float cx = dot3f(fcw, Ru), cy = dot3f(fcw, Rv), ch = dot3f(fcw, nr);
-  const float ux = siu * dot3f(Iu, Ru), uy = siu * dot3f(Iu, Rv), uh = siu * dot3f(Iu, nr);
-  const float vx = siv * dot3f(Iv, Ru), vy = siv * dot3f(Iv, Rv), vh = siv * dot3f(Iv, nr);
-  const float qx0 = cx + ux + vx, qy0 = cy + uy + vy, qh0 = ch + uh + vh;
-  const float qx1 = cx - ux + vx, qy1 = cy - uy + vy, qh1 = ch - uh + vh;
-  const float qx2 = cx - ux - vx, qy2 = cy - uy - vy;
-  const float qx3 = cx + ux - vx, qy3 = cy + uy - vy, qh3 = ch + uh - vh;
-  // height field of the incident plane over the reference frame
-  const float x1 = qx1 - qx0, y1 = qy1 - qy0, x2 = qx3 - qx0, y2 = qy3 - qy0, h1 = qh1 - qh0, h2 = qh3 - qh0;
-  const float det = x1 * y2 - x2 * y1;
-  const int flat = !(fabsf(det) > 1e-14f);
-  const float gu = flat ? 0.0f : (h1 * y2 - h2 * y1) / det, gv = flat ? 0.0f : (x1 * h2 - x2 * h1) / det;
-  int cnt = 0;
-#define GRX_EMIT(X, Y) { \
-    float x_ = (X), y_ = (Y); \
-    float h_ = qh0 + gu * (x_ - qx0) + gv * (y_ - qy0); \
-    if (h_ <= margin && cnt < 8) { \
-      float pos_[3]; \
-      for (int k_ = 0; k_ < 3; k_++) pos_[k_] = rc[k_] + x_ * Ru[k_] + y_ * Rv[k_] + 0.5f * h_ * nr[k_]; \
-      grx_add_contact(c, pair, pos_, bn, h_); cnt++; } }
-  // (a) incident corners inside the rectangle (inclusive)
-#define GRX_CORNER_A(X, Y) if (fabsf(X) <= sx && fabsf(Y) <= sy) GRX_EMIT(X, Y)
-  GRX_CORNER_A(qx0, qy0) GRX_CORNER_A(qx1, qy1) GRX_CORNER_A(qx2, qy2) GRX_CORNER_A(qx3, qy3)
-#undef GRX_CORNER_A
-  if (!flat) {
-    // (b) rectangle corners strictly inside the incident quad (orientation-independent sign test)
-    const float orient = det > 0 ? -1.0f : 1.0f;  // det > 0 <=> q0->q1->q2->q3 is counter-clockwise <=> interior has cross > 0
+    GRX_LANEVAR(bestf); GRX_LANEVAR(beste); GRX_LANEVAR(maxall); GRX_LANEVAR_I(codef); GRX_LANEVAR_I(codee);
+    GRX_OCT_MAX(sf, bestf); GRX_OCT_MAX(se, beste); GRX_OCT_MAX(sall, maxall);
+    FOR_LANES { if (!(LV(sf) == LV(bestf))) LV(cf) = 99; if (!(LV(se) == LV(beste))) LV(ce) = 99; }
+    GRX_OCT_MIN_I(cf, codef); GRX_OCT_MIN_I(ce, codee);
+    // ---- contact candidates
+    GRX_LANEVAR(nx); GRX_LANEVAR(ny); GRX_LANEVAR(nz);
+    GRX_LANEVAR(cpx0); GRX_LANEVAR(cpy0); GRX_LANEVAR(cpz0); GRX_LANEVAR(ch0); GRX_LANEVAR_I(cv0);
+    GRX_LANEVAR(cpx1); GRX_LANEVAR(cpy1); GRX_LANEVAR(cpz1); GRX_LANEVAR(ch1); GRX_LANEVAR_I(cv1);
+    GRX_LANEVAR(cpx2); GRX_LANEVAR(cpy2); GRX_LANEVAR(cpz2); GRX_LANEVAR(ch2); GRX_LANEVAR_I(cv2);
+    FOR_LANES {
+      const int g = lane >> 3, t = lane & 7;
+      int v0 = 0, v1 = 0, v2 = 0; float P0[3] = {0, 0, 0}, P1[3] = {0, 0, 0}, P2[3] = {0, 0, 0}, h0 = 0, h1 = 0, h2 = 0, nrm[3] = {0, 0, 0};
+      if (pb + g < nq) {
+        const int pair = queue[pb + g];
+        GRX_BB_LOAD(pair)
+        const float best = LV(bestf), ebest = LV(beste); const int code = LV(codef), ecode = LV(codee);
+        if (LV(maxall) <= margin && code < 6) {
+          if (ecode < 15 && ebest > best + 1e-7f + 0.02f * fabsf(best)) {
+            // edge-edge: a single contact, lane 0 of the octet
+            const int ei = (ecode - 6) / 3, ej = (ecode - 6) % 3;
+            float en[3], tp, sep; int ok;
+            GRX_BB_AXIS(ecode, en, tp, sep, ok)
+            (void)sep; (void)ok;
+            const float sg = tp < 0 ? -1.0f : 1.0f;
+            en[0] *= sg; en[1] *= sg; en[2] *= sg;
+            float pa[3] = {p1[0], p1[1], p1[2]}, pb_[3] = {p2[0], p2[1], p2[2]};
+            float s0 = (ei != 0) ? (dot3f(en, A0) > 0 ? a0 : -a0) : 0.0f, s1 = (ei != 1) ? (dot3f(en, A1) > 0 ? a1 : -a1) : 0.0f, s2 = (ei != 2) ? (dot3f(en, A2) > 0 ? a2 : -a2) : 0.0f;
+            float t0 = (ej != 0) ? (dot3f(en, B0) > 0 ? -b0 : b0) : 0.0f, t1 = (ej != 1) ? (dot3f(en, B1) > 0 ? -b1 : b1) : 0.0f, t2 = (ej != 2) ? (dot3f(en, B2) > 0 ? -b2 : b2) : 0.0f;
+            float u[3], v[3];
+            for (int e = 0; e < 3; e++) {
+              pa[e] += s0 * A0[e] + s1 * A1[e] + s2 * A2[e]; pb_[e] += t0 * B0[e] + t1 * B1[e] + t2 * B2[e];
+              u[e] = GRX_SEL3(A0[e], A1[e], A2[e], ei); v[e] = GRX_SEL3(B0[e], B1[e], B2[e], ej);
+            }
+            float w[3] = {pa[0] - pb_[0], pa[1] - pb_[1], pa[2] - pb_[2]};
+            float uv = dot3f(u, v), uw = dot3f(u, w), vw = dot3f(v, w);
+            float den = 1.0f - uv * uv;
+            float sc = den > 1e-12f ? (uv * vw - uw) / den : 0.0f, tc = den > 1e-12f ? (vw - uv * uw) / den : 0.0f;
+            for (int k = 0; k < 3; k++) { P0[k] = 0.5f * ((pa[k] + sc * u[k]) + (pb_[k] + tc * v[k])); nrm[k] = en[k]; }
+            h0 = ebest; v0 = (t == 0);
+          } else {
+            // ---- face contact
+            float bn[3], tp, sep; int ok;
+            GRX_BB_AXIS(code, bn, tp, sep, ok)
+            (void)sep; (void)ok;
+            { const float sg = tp < 0 ? -1.0f : 1.0f; bn[0] *= sg; bn[1] *= sg; bn[2] *= sg; }
+            const int ref1 = code < 3, ax = ref1 ? code : code - 3;
+            float pr[3], pi[3], nr[3], Ar0[3], Ar1[3], Ar2[3], Ai0[3], Ai1[3], Ai2[3];
+            for (int e = 0; e < 3; e++) {
+              pr[e] = ref1 ? p1[e] : p2[e]; pi[e] = ref1 ? p2[e] : p1[e]; nr[e] = ref1 ? bn[e] : -bn[e];
+              Ar0[e] = ref1 ? A0[e] : B0[e]; Ar1[e] = ref1 ? A1[e] : B1[e]; Ar2[e] = ref1 ? A2[e] : B2[e];
+              Ai0[e] = ref1 ? B0[e] : A0[e]; Ai1[e] = ref1 ? B1[e] : A1[e]; Ai2[e] = ref1 ? B2[e] : A2[e];
+            }
+            const float sr0 = ref1 ? a0 : b0, sr1 = ref1 ? a1 : b1, sr2 = ref1 ? a2 : b2;
+            const float si0 = ref1 ? b0 : a0, si1 = ref1 ? b1 : a1, si2 = ref1 ? b2 : a2;
+            // incident face: the face of the other box most anti-parallel to nr
+            float dd0 = dot3f(Ai0, nr), dd1 = dot3f(Ai1, nr), dd2 = dot3f(Ai2, nr);
+            int iax = 0; float mind = 1e30f, isg = 1.0f;
+            if (dd0 < mind) { mind = dd0; iax = 0; isg = 1.0f; } if (-dd0 < mind) { mind = -dd0; iax = 0; isg = -1.0f; }
+            if (dd1 < mind) { mind = dd1; iax = 1; isg = 1.0f; } if (-dd1 < mind) { mind = -dd1; iax = 1; isg = -1.0f; }
+            if (dd2 < mind) { mind = dd2; iax = 2; isg = 1.0f; } if (-dd2 < mind) { mind = -dd2; iax = 2; isg = -1.0f; }
+            float Iu[3], Iv[3], In[3], Ru[3], Rv[3];
+            for (int e = 0; e < 3; e++) {
+              In[e] = GRX_SEL3(Ai0[e], Ai1[e], Ai2[e], iax); Iu[e] = GRX_SEL3(Ai1[e], Ai2[e], Ai0[e], iax); Iv[e] = GRX_SEL3(Ai2[e], Ai0[e], Ai1[e], iax);
+              Ru[e] = GRX_SEL3(Ar1[e], Ar2[e], Ar0[e], ax); Rv[e] = GRX_SEL3(Ar2[e], Ar0[e], Ar1[e], ax);
+            }
+            const float sin_ = GRX_SEL3(si0, si1, si2, iax), siu = GRX_SEL3(si1, si2, si0, iax), siv = GRX_SEL3(si2, si0, si1, iax);
+            const float srn = GRX_SEL3(sr0, sr1, sr2, ax), sx = GRX_SEL3(sr1, sr2, sr0, ax), sy = GRX_SEL3(sr2, sr0, sr1, ax);
+            float rc[3], fcw[3];
+            for (int e = 0; e < 3; e++) { rc[e] = pr[e] + srn * nr[e]; fcw[e] = pi[e] + isg * sin_ * In[e] - rc[e]; }
+            // incident quad in the reference face frame: corner q = centre + su*U + sv*V, (su,sv) = (+,+),(-,+),(-,-),(+,-)
+            const float cx = dot3f(fcw, Ru), cy = dot3f(fcw, Rv), chh = dot3f(fcw, nr);
+            const float ux = siu * dot3f(Iu, Ru), uy = siu * dot3f(Iu, Rv), uh = siu * dot3f(Iu, nr);
+            const float vx = siv * dot3f(Iv, Ru), vy = siv * dot3f(Iv, Rv), vh = siv * dot3f(Iv, nr);
+            const float qx0 = cx + ux + vx, qy0 = cy + uy + vy, qh0 = chh + uh + vh;
+            const float qx1 = cx - ux + vx, qy1 = cy - uy + vy, qh1 = chh - uh + vh;
+            const float qx2 = cx - ux - vx, qy2 = cy - uy - vy;
+            const float qx3 = cx + ux - vx, qy3 = cy + uy - vy, qh3 = chh + uh - vh;
+            // height field of the incident plane over the reference frame
+            const float x1 = qx1 - qx0, y1 = qy1 - qy0, x2 = qx3 - qx0, y2 = qy3 - qy0, hh1 = qh1 - qh0, hh2 = qh3 - qh0;
+            const float det = x1 * y2 - x2 * y1;
+            const int flat = !(fabsf(det) > 1e-14f);
+            const float gu = flat ? 0.0f : (hh1 * y2 - hh2 * y1) / det, gv = flat ? 0.0f : (x1 * hh2 - x2 * hh1) / det;
+            const float orient = det > 0 ? -1.0f : 1.0f;  // det > 0 <=> q0->q1->q2->q3 is counter-clockwise <=> interior has cross > 0
+#define GRX_SEL4(v0_, v1_, v2_, v3_, i_) ((i_) == 0 ? (v0_) : ((i_) == 1 ? (v1_) : ((i_) == 2 ? (v2_) : (v3_))))
 #define GRX_SIDE(PX, PY, AX_, AY_, BX_, BY_) (orient * (((BX_) - (AX_)) * ((PY) - (AY_)) - ((BY_) - (AY_)) * ((PX) - (AX_))))
-#define GRX_CORNER_B(X, Y) { float X_ = (X), Y_ = (Y); \
-      if (GRX_SIDE(X_, Y_, qx0, qy0, qx1, qy1) < 0 && GRX_SIDE(X_, Y_, qx1, qy1, qx2, qy2) < 0 && GRX_SIDE(X_, Y_, qx2, qy2, qx3, qy3) < 0 && \
-          GRX_SIDE(X_, Y_, qx3, qy3, qx0, qy0) < 0) GRX_EMIT(X_, Y_) }
-    GRX_CORNER_B(sx, sy) GRX_CORNER_B(-sx, sy) GRX_CORNER_B(-sx, -sy) GRX_CORNER_B(sx, -sy)
-#undef GRX_CORNER_B
+            // candidate I: 0-3 incident corners inside the rectangle (inclusive); 4-7 rectangle corners strictly inside the
+            // incident quad; 8-23 proper crossings of incident edge e = (I-8)/4 with rectangle side (I-8)%4 = +x, -x, +y, -y
+            // (x-sides closed in y, y-sides open in x)
+#define GRX_BB_CAND(I, VALID, POS, H) { \
+              const int i_ = (I); int ok_ = 0; float X_ = 0, Y_ = 0; \
+              if (i_ < 4) { X_ = GRX_SEL4(qx0, qx1, qx2, qx3, i_); Y_ = GRX_SEL4(qy0, qy1, qy2, qy3, i_); ok_ = fabsf(X_) <= sx && fabsf(Y_) <= sy; } \
+              else if (!flat && i_ < 8) { \
+                const int k_ = i_ - 4; X_ = (k_ == 0 || k_ == 3) ? sx : -sx; Y_ = (k_ < 2) ? sy : -sy; \
+                ok_ = GRX_SIDE(X_, Y_, qx0, qy0, qx1, qy1) < 0 && GRX_SIDE(X_, Y_, qx1, qy1, qx2, qy2) < 0 && GRX_SIDE(X_, Y_, qx2, qy2, qx3, qy3) < 0 && \
+                      GRX_SIDE(X_, Y_, qx3, qy3, qx0, qy0) < 0; \
+              } else if (!flat && i_ < 24) { \
+                const int e_ = (i_ - 8) >> 2, s_ = (i_ - 8) & 3, e1_ = (e_ + 1) & 3; \
+                const float ax_ = GRX_SEL4(qx0, qx1, qx2, qx3, e_), ay_ = GRX_SEL4(qy0, qy1, qy2, qy3, e_); \
+                const float bx_ = GRX_SEL4(qx0, qx1, qx2, qx3, e1_), by_ = GRX_SEL4(qy0, qy1, qy2, qy3, e1_); \
+                const int hz_ = s_ < 2; const float sg_ = (s_ & 1) ? -1.0f : 1.0f; \
+                const float pa_ = hz_ ? ax_ : ay_, pb2_ = hz_ ? bx_ : by_, lim_ = hz_ ? sx : sy; \
+                const float da_ = sg_ * pa_ - lim_, db_ = sg_ * pb2_ - lim_; \
+                const int cr_ = (da_ < 0 && db_ > 0) || (da_ > 0 && db_ < 0); \
+                const float t_ = da_ / (da_ - db_), oa_ = hz_ ? ay_ : ax_, ob_ = hz_ ? by_ : bx_, o_ = oa_ + t_ * (ob_ - oa_); \
+                if (hz_) { ok_ = cr_ && fabsf(o_) <= sy; X_ = sg_ * sx; Y_ = o_; } else { ok_ = cr_ && fabsf(o_) < sx; X_ = o_; Y_ = sg_ * sy; } \
+              } \
+              const float h_ = qh0 + gu * (X_ - qx0) + gv * (Y_ - qy0); \
+              VALID = ok_ && h_ <= margin; H = h_; \
+              for (int k_ = 0; k_ < 3; k_++) POS[k_] = rc[k_] + X_ * Ru[k_] + Y_ * Rv[k_] + 0.5f * h_ * nr[k_]; }
+            GRX_BB_CAND(t, v0, P0, h0)
+            GRX_BB_CAND(t + 8, v1, P1, h1)
+            GRX_BB_CAND(t + 16, v2, P2, h2)
+#undef GRX_BB_CAND
 #undef GRX_SIDE
-    // (c) proper crossings of the incident edges with the four rectangle sides (x-sides closed in y, y-sides open in x)
-#define GRX_CROSS(AX_, AY_, BX_, BY_) { \
-      float da, db, t_; \
-      da = (AX_) - sx; db = (BX_) - sx; if ((da < 0 && db > 0) || (da > 0 && db < 0)) { t_ = da / (da - db); float y = (AY_) + t_ * ((BY_) - (AY_)); if (fabsf(y) <= sy) GRX_EMIT(sx, y) } \
-      da = -(AX_) - sx; db = -(BX_) - sx; if ((da < 0 && db > 0) || (da > 0 && db < 0)) { t_ = da / (da - db); float y = (AY_) + t_ * ((BY_) - (AY_)); if (fabsf(y) <= sy) GRX_EMIT(-sx, y) } \
-      da = (AY_) - sy; db = (BY_) - sy; if ((da < 0 && db > 0) || (da > 0 && db < 0)) { t_ = da / (da - db); float x = (AX_) + t_ * ((BX_) - (AX_)); if (fabsf(x) < sx) GRX_EMIT(x, sy) } \
-      da = -(AY_) - sy; db = -(BY_) - sy; if ((da < 0 && db > 0) || (da > 0 && db < 0)) { t_ = da / (da - db); float x = (AX_) + t_ * ((BX_) - (AX_)); if (fabsf(x) < sx) GRX_EMIT(x, -sy) } }
-    GRX_CROSS(qx0, qy0, qx1, qy1) GRX_CROSS(qx1, qy1, qx2, qy2) GRX_CROSS(qx2, qy2, qx3, qy3) GRX_CROSS(qx3, qy3, qx0, qy0)
-#undef GRX_CROSS
+#undef GRX_SEL4
+            for (int k = 0; k < 3; k++) nrm[k] = bn[k];
+          }
+        }
+      }
+      LV(nx) = nrm[0]; LV(ny) = nrm[1]; LV(nz) = nrm[2];
+      LV(cpx0) = P0[0]; LV(cpy0) = P0[1]; LV(cpz0) = P0[2]; LV(ch0) = h0; LV(cv0) = v0;
+      LV(cpx1) = P1[0]; LV(cpy1) = P1[1]; LV(cpz1) = P1[2]; LV(ch1) = h1; LV(cv1) = v1;
+      LV(cpx2) = P2[0]; LV(cpy2) = P2[1]; LV(cpz2) = P2[2]; LV(ch2) = h2; LV(cv2) = v2;
+    }
+    // ---- ordered compaction: candidate order inside a pair, pair order across the octets, at most 8 contacts per pair
+    const unsigned long long m0 = GRX_BALLOT(cv0), m1 = GRX_BALLOT(cv1), m2 = GRX_BALLOT(cv2);
+    WAVE_SYNC();
+    const int base = c->cnt[0];
+    int total = 0;
+    for (int g = 0; g < 8; g++) { int n = __builtin_popcountll((m0 >> (8 * g)) & 0xFFull) + __builtin_popcountll((m1 >> (8 * g)) & 0xFFull) + __builtin_popcountll((m2 >> (8 * g)) & 0xFFull); total += n < 8 ? n : 8; }
+    FOR_LANES {
+      const int g = lane >> 3, t = lane & 7;
+      if (pb + g < nq) {
+        const int pair = queue[pb + g];
+        int gbase = base;
+        for (int q = 0; q < g; q++) { int n = __builtin_popcountll((m0 >> (8 * q)) & 0xFFull) + __builtin_popcountll((m1 >> (8 * q)) & 0xFFull) + __builtin_popcountll((m2 >> (8 * q)) & 0xFFull); gbase += n < 8 ? n : 8; }
+        const unsigned b0_ = (unsigned)((m0 >> (8 * g)) & 0xFFull), b1_ = (unsigned)((m1 >> (8 * g)) & 0xFFull), b2_ = (unsigned)((m2 >> (8 * g)) & 0xFFull), low = (1u << t) - 1u;
+        const int r0 = __builtin_popcount(b0_ & low), r1 = __builtin_popcount(b0_) + __builtin_popcount(b1_ & low), r2 = __builtin_popcount(b0_) + __builtin_popcount(b1_) + __builtin_popcount(b2_ & low);
+        const float nrm[3] = {LV(nx), LV(ny), LV(nz)};
+#define GRX_BB_WRITE(V, R, PX, PY, PZ, H) if ((V) && (R) < 8) { const int slot = gbase + (R); \
+          if (slot >= GRX_MAXCON) c->cnt[2] |= GRX_ST_CON_OVERFLOW; \
+          else { c->con_dist[slot] = (H); c->con_pair[slot] = pair; c->con_pos[3 * slot] = (PX); c->con_pos[3 * slot + 1] = (PY); c->con_pos[3 * slot + 2] = (PZ); \
+                 for (int k_ = 0; k_ < 3; k_++) c->con_frame[3 * slot + k_] = nrm[k_]; } }
+        GRX_BB_WRITE(LV(cv0), r0, LV(cpx0), LV(cpy0), LV(cpz0), LV(ch0))
+        GRX_BB_WRITE(LV(cv1), r1, LV(cpx1), LV(cpy1), LV(cpz1), LV(ch1))
+        GRX_BB_WRITE(LV(cv2), r2, LV(cpx2), LV(cpy2), LV(cpz2), LV(ch2))
+#undef GRX_BB_WRITE
+      }
+    }
+    WAVE_SYNC();
+    LANE0 { c->cnt[0] = base + total; }
+    WAVE_SYNC();
   }
-#undef GRX_EMIT
 }
+#undef GRX_BB_AXIS
+#undef GRX_BB_LOAD
 
 GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_FRESH_MODEL(m, c);
@@ -1051,8 +1176,9 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   WAVE_SYNC();
   GRX_SUBTICK(c, 12);
   for (int base = 0; base < m->ndevpair; base += 64) {
+    GRX_LANEVAR_I(boxq);
     FOR_LANES {
-      int k = base + lane;
+      int k = base + lane, isbox = 0;
       if (k < m->ndevpair) {
         int p = m->devpair[k], g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
         int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -1072,16 +1198,28 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           else if (t1 == 3 && t2 == 6) grx_capsule_box(m, c, p, g1, g2, margin);
           else if (t1 == 2 && t2 == 6) grx_sphere_box(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
-          else if (t1 == 6 && t2 == 6) grx_box_box(m, c, p, g1, g2, margin);
+          else if (t1 == 6 && t2 == 6) isbox = 1;
           else if (t1 == 0 && t2 == 7) {
             if (m->geom_meshnum[g2] <= 32) grx_plane_mesh_small(m, c, p, g1, g2, margin);
             else { int q = GRX_ATOMIC_ADD(&c->cnt[7], 1); if (q < 32) c->ired[q] = p; }
           }
         }
       }
+      LV(boxq) = isbox;
     }
     WAVE_SYNC();
     GRX_SUBTICK(c, 13);
+    // box-box pairs that passed the broad phase: queue them (pair order) and let eight lanes work on each
+    {
+      const unsigned long long bm = GRX_BALLOT(boxq);
+      if (bm) {
+        int* queue = (int*)c->red;
+        FOR_LANES { if (LV(boxq)) queue[__builtin_popcountll(bm & ((1ull << lane) - 1ull))] = m->devpair[base + lane]; }
+        WAVE_SYNC();
+        grx_box_box_queue(m, c, queue, __builtin_popcountll(bm), lane_);
+      }
+    }
+    GRX_SUBTICK(c, 11);
     // large hulls (a moving link near the plane): all lanes scan the vertices of one pair at a time
     int nbig = c->cnt[7] < 32 ? c->cnt[7] : 32;
     for (int l = 0; l < nbig; l++) {
@@ -1177,13 +1315,15 @@ GRX_MEM unsigned long long grx_chainmask(const GrxModel* m, int b) {
 GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC;
-  int ncon = c->cnt[0];
-  // ---- row bookkeeping.  Per-joint limit flags and per-contact row counts go to small LDS int tables once; the
-  // prefix sums below then only touch LDS.
-  const int ne = 6 * m->nweld, nf = m->nfric;
+  const int ncon = c->cnt[0];
+  // ---- row bookkeeping: one lane per joint (limit flags) and one lane per contact (row count, dof span), then
+  // exclusive prefix sums across the wave give every limit / contact its first row and its Jacobian-pool offset.
+  const int ne = 6 * m->nweld, nf = m->nfric, wpool = m->wpool;
+  GRX_LANEVAR_I(limc); GRX_LANEVAR_I(conr); GRX_LANEVAR_I(conw); GRX_LANEVAR_I(coni);
   FOR_LANES {
-    for (int j = lane; j < GRX_NJC; j += 64) {
-      int f = 0;
+    int f = 0;
+    if (lane < GRX_NJC) {
+      const int j = lane;
       if (m->jnt_limited[j] && m->jnt_type[j] >= 2) {
         float q = c->qpos[m->jnt_qposadr[j]], mg = m->jnt_margin[j];
         if (q - m->jnt_range[2 * j] < mg) f |= 1;
@@ -1191,45 +1331,53 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       }
       c->ired[j] = f;
     }
-    for (int k = lane; k < ncon; k += 64) {
+    LV(limc) = (f & 1) + ((f >> 1) & 1);
+    int nr = 0, slen = 0;
+    if (lane < ncon) {
+      const int k = lane;
       int p = c->con_pair[k], dim = m->pair_condim[p];
       int active = c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p];
-      c->con_nr[k] = active ? ((dim == 1) ? 1 : 2 * (dim - 1)) : 0;
-      int cb1 = m->geom_bodyid[m->pair_geom1[p]], cb2 = m->geom_bodyid[m->pair_geom2[p]], slo, slen;
+      nr = active ? ((dim == 1) ? 1 : 2 * (dim - 1)) : 0;
+      int cb1 = m->geom_bodyid[m->pair_geom1[p]], cb2 = m->geom_bodyid[m->pair_geom2[p]], slo;
       c->con_b1[k] = cb1; c->con_b2[k] = cb2;
       grx_mask_span(grx_chainmask(m, cb1) | grx_chainmask(m, cb2), &slo, &slen);
       c->con_span[k] = slo | (slen << 8);
     }
+    LV(conr) = nr; LV(conw) = nr * slen; LV(coni) = nr ? slen : 0;
   }
   WAVE_SYNC();
   GRX_SUBTICK(c, 0);
-  int nl = 0;
-  for (int j = 0; j < GRX_NJC; j++) { int f = c->ired[j]; nl += (f & 1) + ((f >> 1) & 1); }
-  // pool words used by the welds (all six rows of a weld share the span of the two body chains)
-  int wpool = 0;
-  for (int q = 0; q < m->neq; q++)
-    if (m->eq_active[q] && m->eq_type[q] == 1) { int slo, slen; grx_mask_span(grx_chainmask(m, m->eq_obj1[q]) | grx_chainmask(m, m->eq_obj2[q]), &slo, &slen); wpool += 6 * slen; }
+  GRX_LANEVAR_I(limx); GRX_LANEVAR_I(conrx); GRX_LANEVAR_I(conwx);
+  int nl, nc_all, pool_all;
+  GRX_SCAN_EXCL(limc, limx, nl);
+  GRX_SCAN_EXCL(conr, conrx, nc_all);
+  GRX_SCAN_EXCL(conw, conwx, pool_all);
   // contacts come last: keep as many whole contacts as fit into the row table and the Jacobian pool
-  int nc = 0, pool = wpool + nf + nl, overflow = (ne + nf + nl > GRX_MAXEFC) || (pool > GRX_JPOOL), ncon_fit = ncon;
-  for (int k = 0; k < ncon; k++) {
-    int nr = c->con_nr[k], need = nr * (c->con_span[k] >> 8);
-    if (k < ncon_fit && (ne + nf + nl + nc + nr > GRX_MAXEFC || pool + need > GRX_JPOOL)) { ncon_fit = k; overflow = 1; }
-    if (k < ncon_fit) { nc += nr; pool += need; }
+  const int rows0 = ne + nf + nl, pool0 = wpool + nf + nl;
+  int overflow = (rows0 > GRX_MAXEFC) || (pool0 > GRX_JPOOL), ncon_fit = ncon, nc = nc_all;
+  if (rows0 + nc_all > GRX_MAXEFC || pool0 + pool_all > GRX_JPOOL) {  // rare: find the first contact that does not fit
+    GRX_LANEVAR(failp);
+    FOR_LANES {
+      int fits = (lane >= ncon) || (rows0 + LV(conrx) + LV(conr) <= GRX_MAXEFC && pool0 + LV(conwx) + LV(conw) <= GRX_JPOOL);
+      LV(failp) = fits ? -1000.0f : -(float)lane;
+    }
+    const float mx = grx_reduce_max(failp);
+    if (mx > -999.0f) { ncon_fit = (int)(-mx); overflow = 1; nc = GRX_LANE_READ_I(conrx, ncon_fit); }
   }
-  int nefc = ne + nf + nl + nc;
+  int nefc = rows0 + nc;
   if (nefc > GRX_MAXEFC) nefc = GRX_MAXEFC;
+  // items of the contact-Jacobian pass: one per (kept contact, dof of its span); the running item offset rides in the
+  // upper half of con_span so that an item can find its contact with a binary search
+  GRX_LANEVAR_I(conix); int nitem;
+  FOR_LANES { if (lane >= ncon_fit) LV(coni) = 0; }
+  GRX_SCAN_EXCL(coni, conix, nitem);
   GRX_SUBTICK(c, 1);
   // ---- descriptors
   FOR_LANES {
-    for (int r = lane; r < ne; r += 64) {  // welds are the only equality type in scope
-      int e = 0, acc = 0;
-      for (int q = 0; q < m->neq; q++) if (m->eq_active[q] && m->eq_type[q] == 1) { if (r < acc + 6) { e = q; break; } acc += 6; }
-      c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (e << 4) | (r - acc);
-      int slo, slen, woff = 0;
-      for (int q = 0; q < e; q++)
-        if (m->eq_active[q] && m->eq_type[q] == 1) { grx_mask_span(grx_chainmask(m, m->eq_obj1[q]) | grx_chainmask(m, m->eq_obj2[q]), &slo, &slen); woff += 6 * slen; }
-      grx_mask_span(grx_chainmask(m, m->eq_obj1[e]) | grx_chainmask(m, m->eq_obj2[e]), &slo, &slen);
-      c->efc_row[r] = GRX_ROW_PACK(woff + (r - acc) * slen, slo, slen);
+    if (lane < ne) {  // welds are the only equality type in scope; spans and pool offsets are static (weld_row)
+      const int r = lane, w = r / 6, sub = r - 6 * w, info0 = m->weld_row[w];
+      c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (m->weld_eq[w] << 4) | sub;
+      c->efc_row[r] = info0 + sub * GRX_ROW_LEN(info0);  // the offset field is the low one: adding sub*len moves to row sub
     }
     if (nf > 0)
       for (int d = lane; d < nv; d += 64) {
@@ -1238,22 +1386,23 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
           c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), d, 1);
         }
       }
-    for (int j = lane; j < GRX_NJC; j += 64) {
-      int f = c->ired[j];
+    if (lane < GRX_NJC) {
+      const int j = lane, f = c->ired[j];
       if (f) {
-        int r = ne + nf;
-        for (int q = 0; q < j; q++) { int g = c->ired[q]; r += (g & 1) + ((g >> 1) & 1); }
+        int r = ne + nf + LV(limx);
         int dd = m->jnt_dofadr[j];
         if (f & 1) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); } r++; }
         if (f & 2) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = (j << 4) | 1; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); } }
       }
     }
-    for (int k = lane; k < ncon; k += 64) {
-      int nr = (k < ncon_fit) ? c->con_nr[k] : 0;
-      int r = ne + nf + nl, off = wpool + nf + nl;
-      for (int q = 0; q < k; q++) { r += c->con_nr[q]; off += c->con_nr[q] * (c->con_span[q] >> 8); }
+    if (lane < ncon) {
+      const int k = lane;
+      int nr = (k < ncon_fit) ? LV(conr) : 0;
+      int r = rows0 + LV(conrx), off = pool0 + LV(conwx);
       c->con_efc[k] = nr ? r : -1;
-      int slo = c->con_span[k] & 0xFF, slen = c->con_span[k] >> 8;
+      c->con_nr[k] = nr;
+      int slo = c->con_span[k] & 0xFF, slen = (c->con_span[k] >> 8) & 0xFF;
+      c->con_span[k] = slo | (slen << 8) | (LV(conix) << 16);
       for (int q = 0; q < nr; q++) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = (k << 4) | q; c->efc_row[r + q] = GRX_ROW_PACK(off + q * slen, slo, slen); }
     }
   }
@@ -1266,7 +1415,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     // welds: one lane per (weld, dof)
     for (int it = lane; it < (ne / 6) * nv; it += 64) {
       int w = it / nv, d = it - w * nv;
-      int e = c->efc_id[6 * w] >> 4;
+      int e = m->weld_eq[w];
       int b0 = m->eq_obj1[e], b1 = m->eq_obj2[e];
       const float* data = m->eq_data + 11 * e; const float* rel = m->eq_relpose + 14 * e;
       float bx[2][3], bq[2][4], pos[2][3];
@@ -1308,12 +1457,12 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     }
     // contacts: one lane per (contact, dof of its span)
     GRX_SUBTICK(c, 4);
-    for (int it = lane; it < ncon * nv; it += 64) {
-      int k = it / nv, jd = it - k * nv;
+    for (int it = lane; it < nitem; it += 64) {
+      int k = 0;  // largest k with item offset <= it (contacts without items share the offset of the next one)
+      for (int step = GRX_MAXCON / 2; step > 0; step >>= 1) { int kk = k + step; if (kk < ncon_fit && (c->con_span[kk] >> 16) <= it) k = kk; }
+      const int jd = it - (c->con_span[k] >> 16);
       int r0 = c->con_efc[k];
-      if (r0 < 0) continue;
-      int slo = c->con_span[k] & 0xFF, slen = c->con_span[k] >> 8;
-      if (jd >= slen) continue;
+      int slo = c->con_span[k] & 0xFF, slen = (c->con_span[k] >> 8) & 0xFF;
       int d = slo + jd;
       int p = c->con_pair[k], nrk = c->con_nr[k], dim = (nrk == 1) ? 1 : nrk / 2 + 1;
       int b1 = c->con_b1[k], b2 = c->con_b2[k];

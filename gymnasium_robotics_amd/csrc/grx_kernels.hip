@@ -243,6 +243,8 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   if (bytes > 160 * 1024) return fail("model working set exceeds the 160 KiB LDS of a CU");
   if (g.njnt > 32) return fail("engine limit: at most 32 joints per world (limit-flag table in LDS)");
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
+  if (g.nbody > 64) return fail("engine limit: at most 64 bodies per world (one lane per body, 64-bit subtree masks)");
+  if (g.nweld > GRX_MAXEFC / 16) return fail("engine limit: too many weld constraints (weld frames are staged in the row-parameter slot)");
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   m->shape = 0;
   if (grx_shape_matches<GrxShapeFetchPick>(g)) { m->shape = 1; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPick>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }

@@ -1338,7 +1338,20 @@ class _Lowering:
             for k in range(1, nbk):
                 a_ = jump[s_ - 1, k]
                 jump[s_, k] = jump[s_ - 1, a_] if a_ > 0 else 0
+        # welds: static dof span (union of the two body chains) and Jacobian-pool offset of every active weld
+        weld_eq, weld_row, woff = [], [], 0
+        for q, e in enumerate(eqs):
+            if e["active"] and e["type"] == 1:
+                msk = 0
+                for bb in (e["obj1"], e["obj2"]):
+                    msk |= (int(chainmask[bb][0]) & 0xFFFFFFFF) | ((int(chainmask[bb][1]) & 0xFFFFFFFF) << 32)
+                lo = (msk & -msk).bit_length() - 1 if msk else 0
+                ln = msk.bit_length() - lo if msk else 0
+                weld_eq.append(q)
+                weld_row.append(woff | (lo << 12) | (ln << 20))
+                woff += 6 * ln
         T.update(
+            weld_eq=np.array(weld_eq, np.int32), weld_row=np.array(weld_row, np.int32),
             body_submask=submask, body_jump=jump.reshape(-1),
             body_ancadr=body_ancadr, body_ancnum=body_ancnum, body_anc=np.array(body_anc, np.int32),
             body_order=np.array(order, np.int32), level_adr=level_adr, body_subadr=body_subadr, body_subnum=body_subnum,
