@@ -1,0 +1,99 @@
+"""Collect the rocprofv3 evidence bench.py's roofline object refers to (run ON the GPU box, from the repo root):
+
+    python tools/collect_profiles.py <tag>
+
+1. `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 30 --warmup 5 --no-cpu-baseline`
+   -> gpurun_out/rocprof_<tag>_kernel_stats.txt (per-kernel totals / averages from the top_kernels view)
+2. two separate `rocprofv3 --pmc <C> --kernel-trace --output-format csv` passes (C = FETCH_SIZE, WRITE_SIZE; counters are
+   collected in their own runs, without any other trace domain) of the same command with fewer steps
+   -> gpurun_out/pmc_<tag>_hbm_traffic.{txt,json}: HBM bytes per launch of the step kernel.  FETCH_SIZE / WRITE_SIZE are
+   in KiB; on gfx950 FETCH_SIZE counts 64 B per wide (128 B) read request, so reads are doubled (MI355X_MICROARCH.md,
+   HBM / rocprofv3 section); both the corrected and the raw figure are reported.
+Copy the summaries you want judged into profiles/.
+"""
+import csv
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+OUT = os.path.join(ROOT, "gpurun_out")
+KERNEL = "grx_fetch_step_kernel"
+ALGO_BYTES = 715 * 4096
+
+
+def run(cmd, log):
+    env = dict(os.environ, TMPDIR="/tmp")
+    with open(log, "w") as f:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=f, stderr=subprocess.STDOUT, check=False)
+
+
+def kernel_stats(tag):
+    d = os.path.join(OUT, f"rocprof_{tag}")
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+           "--steps", "30", "--warmup", "5", "--no-cpu-baseline"]
+    run(cmd, os.path.join(OUT, f"rocprof_{tag}.log"))
+    dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline   (MI355X, build '{tag}')",
+             "source: top_kernels view of the rocprofv3 results database; durations in us",
+             "name | total_calls | total_duration_us | average_us | percentage"]
+    if dbs:
+        con = sqlite3.connect(dbs[0])
+        for name, calls, total, avg, pct in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+            short = name if len(name) < 160 else name[:157] + "..."
+            lines.append(f"{short} | {calls} | {total:.0f} | {avg:.1f} | {pct:.3f}")
+    else:
+        lines.append("(no results database produced -- see the log)")
+    with open(os.path.join(OUT, f"rocprof_{tag}_kernel_stats.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines[:6]))
+
+
+def pmc(tag):
+    res, meta = {}, {}
+    for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(OUT, f"pmc_{tag}_{cnt}")
+        cmd = ["rocprofv3", "--pmc", cnt, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
+        run(cmd, os.path.join(OUT, f"pmc_{tag}_{cnt}.log"))
+        vals = []
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == cnt:
+                        vals.append(float(row["Counter_Value"]))
+                        meta = {k: row.get(k) for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
+        res[cnt] = vals
+    lines = [f"rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline   (separate passes, MI355X, build '{tag}')",
+             f"kernel dispatch info: {meta}"]
+    summary = {}
+    for cnt, vals in res.items():
+        if vals:
+            mean = sum(vals) / len(vals)
+            summary[cnt] = mean
+            lines.append(f"{cnt}: {len(vals)} launches of {KERNEL}: mean {mean:.1f} KiB  min {min(vals):.1f}  max {max(vals):.1f}")
+        else:
+            lines.append(f"{cnt}: no samples (see the log)")
+    out = {"kernel": KERNEL, "build": tag, "algorithmic_bytes_per_launch": ALGO_BYTES}
+    if len(summary) == 2:
+        fetch, write = summary["FETCH_SIZE"] * 1024, summary["WRITE_SIZE"] * 1024
+        traffic, raw = 2 * fetch + write, fetch + write
+        lines.append(f"per launch: FETCH_SIZE {fetch/1e3:.0f} kB (x2 gfx950 wide-read correction: {2*fetch/1e3:.0f} kB), WRITE_SIZE {write/1e3:.0f} kB; "
+                     f"algorithmic bytes 715 B x 4096 worlds = {ALGO_BYTES/1e3:.0f} kB")
+        lines.append(f"traffic (FETCH*2 + WRITE) = {traffic:.0f} B per launch = {traffic/ALGO_BYTES:.2f} x algorithmic; raw (FETCH + WRITE) = {raw/ALGO_BYTES:.2f} x")
+        out.update(traffic_bytes_per_launch=int(traffic), raw_bytes_per_launch=int(raw), fetch_kib=summary["FETCH_SIZE"], write_kib=summary["WRITE_SIZE"])
+    with open(os.path.join(OUT, f"pmc_{tag}_hbm_traffic.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    with open(os.path.join(OUT, f"pmc_{tag}_hbm_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    os.makedirs(OUT, exist_ok=True)
+    kernel_stats(tag)
+    pmc(tag)
