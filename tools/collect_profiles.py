@@ -92,8 +92,44 @@ def pmc(tag):
     print("\n".join(lines))
 
 
+SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_ANY",
+               "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU"]
+
+
+def sq_mix(tag):
+    """Where the waves of the step kernel spend their cycles (the kernel is issue-bound, not HBM-bound): one SQ pass, 8 counters.
+    WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (MI355X_MICROARCH.md, PMC slot table)."""
+    d = os.path.join(OUT, f"pmc_{tag}_SQ")
+    cmd = ["rocprofv3", "--pmc"] + SQ_COUNTERS + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
+    run(cmd, os.path.join(OUT, f"pmc_{tag}_SQ.log"))
+    acc = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if KERNEL in row.get("Kernel_Name", ""):
+                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    lines = [f"rocprofv3 --pmc {' '.join(SQ_COUNTERS)} --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline   (MI355X, build '{tag}')",
+             f"means over the launches of {KERNEL}:"]
+    mean = {k: sum(v) / len(v) for k, v in acc.items() if v}
+    for k in SQ_COUNTERS:
+        lines.append(f"  {k:22s} {mean[k]:16.0f}" if k in mean else f"  {k:22s} (not collected)")
+    wc = mean.get("SQ_WAVE_CYCLES")
+    if wc:
+        for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+            if k in mean:
+                lines.append(f"  {k} / SQ_WAVE_CYCLES = {mean[k] / wc:.3f}")
+    with open(os.path.join(OUT, f"pmc_{tag}_sq_mix.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
 if __name__ == "__main__":
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "sq":
+        sq_mix(tag)
+        sys.exit(0)
     kernel_stats(tag)
     pmc(tag)
+    sq_mix(tag)
