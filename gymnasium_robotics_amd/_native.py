@@ -27,6 +27,11 @@ class PointBuffersStruct(ctypes.Structure):
         "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask")]
 
 
+class HandBuffersStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask")]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -47,6 +52,8 @@ def lib():
         L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
+        L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
+        L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_float, ci, vp, vp]
         cd = ctypes.c_double
         L.grx_fetch_sample_resets.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         _lib = L
@@ -60,5 +67,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_goal_compute_reward", "grx_last_error",
 ]

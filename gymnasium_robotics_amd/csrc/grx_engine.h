@@ -71,7 +71,7 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_ST_EFC_OVERFLOW 4
 #define GRX_ST_FACTOR 8
 
-enum { GRX_ROW_EQ = 0, GRX_ROW_FRICTION = 1, GRX_ROW_LIMIT = 2, GRX_ROW_CONTACT = 3 };
+enum { GRX_ROW_EQ = 0, GRX_ROW_FRICTION = 1, GRX_ROW_LIMIT = 2, GRX_ROW_CONTACT = 3, GRX_ROW_TENDON = 4 };
 
 // ------------------------------------------------------------------------------------------
 // model: device-resident fp32 / int32 copies of the tables in include/grx_model_fields.def
@@ -82,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -362,9 +362,9 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 // All stages live in a class template so that the dof count can be a compile-time constant (NV > 0: inner loops over
 // dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
 // Model shape: the ten layout dims as compile-time constants (0 = read from the model at run time).
-template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_>
+template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0>
 struct GrxShape {
-  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_;
+  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_;
   static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
@@ -662,6 +662,7 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
 #if !defined(GRX_EMU)
   if (n == 21) { grx_sym_solve_reg<21>(A, x, lane_); return 0; }
   if (n == 15) { grx_sym_solve_reg<15>(A, x, lane_); return 0; }
+  if (n == 24) { grx_sym_solve_reg<24>(A, x, lane_); return 0; }
 #endif
   int bad = grx_sym_factor(A, n, lane_);
   grx_sym_solve(A, n, x, lane_);
@@ -892,6 +893,26 @@ GRX_MEM int grx_sphere_box_local(GrxCtx* c, int pair, const float* bp, const flo
   float pos[3] = {pw[0] + bp[0] + n[0] * (r + 0.5f * dist), pw[1] + bp[1] + n[1] * (r + 0.5f * dist), pw[2] + bp[2] + n[2] * (r + 0.5f * dist)};
   grx_add_contact(c, pair, pos, n, dist);
   return 1;
+}
+// capsule vs capsule: closest points of the two axis segments (clamped), then a sphere-sphere contact (see oracle/grx_oracle.c)
+GRX_MEM void grx_capsule_capsule(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  const float* c1 = c->gxpos + 3 * g1; const float* R1 = c->gxmat + 9 * g1; const float* c2 = c->gxpos + 3 * g2; const float* R2 = c->gxmat + 9 * g2;
+  const float r1 = m->geom_size[3 * g1], h1 = m->geom_size[3 * g1 + 1], r2 = m->geom_size[3 * g2], h2 = m->geom_size[3 * g2 + 1];
+  const float a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]}, w[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+  const float b = dot3f(a1, a2), d = dot3f(a1, w), e = dot3f(a2, w), den = 1.0f - b * b;
+  float x1 = den > GRX_MINVAL ? (b * e - d) / den : 0.0f;
+  x1 = fminf(h1, fmaxf(-h1, x1));
+  float x2 = b * x1 + e;
+  if (x2 > h2) { x2 = h2; x1 = fminf(h1, fmaxf(-h1, b * x2 - d)); }
+  else if (x2 < -h2) { x2 = -h2; x1 = fminf(h1, fmaxf(-h1, b * x2 - d)); }
+  float p1[3], n[3];
+  for (int k = 0; k < 3; k++) { p1[k] = c1[k] + x1 * a1[k]; n[k] = c2[k] + x2 * a2[k] - p1[k]; }
+  const float len = sqrtf(dot3f(n, n));
+  if (len < GRX_MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else { const float li = 1.0f / len; n[0] *= li; n[1] *= li; n[2] *= li; }
+  const float dist = len - r1 - r2;
+  if (dist > margin) return;
+  float pos[3] = {p1[0] + n[0] * (r1 + 0.5f * dist), p1[1] + n[1] * (r1 + 0.5f * dist), p1[2] + n[2] * (r1 + 0.5f * dist)};
+  grx_add_contact(c, pair, pos, n, dist);
 }
 // capsule (geom1) vs box (geom2): axis point closest to the box (golden-section search, the distance is convex along the
 // axis) as a sphere contact, plus the farther end sphere when it is inside the margin as well (see oracle/grx_oracle.c)
@@ -1196,6 +1217,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           if (t1 == 0 && t2 == 2) grx_plane_sphere(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 3) grx_plane_capsule(m, c, p, g1, g2, margin);
           else if (t1 == 3 && t2 == 6) grx_capsule_box(m, c, p, g1, g2, margin);
+          else if (t1 == 3 && t2 == 3) grx_capsule_capsule(m, c, p, g1, g2, margin);
           else if (t1 == 2 && t2 == 6) grx_sphere_box(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
           else if (t1 == 6 && t2 == 6) isbox = 1;
@@ -1320,6 +1342,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   // exclusive prefix sums across the wave give every limit / contact its first row and its Jacobian-pool offset.
   const int ne = 6 * m->nweld, nf = m->nfric, wpool = m->wpool;
   GRX_LANEVAR_I(limc); GRX_LANEVAR_I(conr); GRX_LANEVAR_I(conw); GRX_LANEVAR_I(coni);
+  GRX_LANEVAR_I(tenf); GRX_LANEVAR_I(tenc); GRX_LANEVAR_I(tenw); GRX_LANEVAR(tenl);
   FOR_LANES {
     int f = 0;
     if (lane < GRX_NJC) {
@@ -1344,16 +1367,31 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       c->con_span[k] = slo | (slen << 8);
     }
     LV(conr) = nr; LV(conw) = nr * slen; LV(coni) = nr ? slen : 0;
+    // fixed-tendon limits: one lane per tendon (length = sum coef * qpos)
+    int tf = 0; float tl = 0.0f;
+    if (lane < m->ntendon && m->tendon_limited[lane]) {
+      const int t = lane;
+      for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) tl += m->wrap_coef[w] * c->qpos[m->wrap_qadr[w]];
+      const float mg = m->tendon_margin[t];
+      if (tl - m->tendon_range[2 * t] < mg) tf |= 1;
+      if (m->tendon_range[2 * t + 1] - tl < mg) tf |= 2;
+    }
+    LV(tenf) = tf; LV(tenl) = tl;
+    LV(tenc) = (tf & 1) + ((tf >> 1) & 1);
+    LV(tenw) = LV(tenc) * (lane < m->ntendon ? (m->tendon_span[lane] >> 8) : 0);
   }
   WAVE_SYNC();
   GRX_SUBTICK(c, 0);
-  GRX_LANEVAR_I(limx); GRX_LANEVAR_I(conrx); GRX_LANEVAR_I(conwx);
-  int nl, nc_all, pool_all;
+  GRX_LANEVAR_I(limx); GRX_LANEVAR_I(conrx); GRX_LANEVAR_I(conwx); GRX_LANEVAR_I(tenx); GRX_LANEVAR_I(tenwx);
+  int nl, nc_all, pool_all, nlt = 0, tpool = 0;
   GRX_SCAN_EXCL(limc, limx, nl);
+  if (m->ntendon) { GRX_SCAN_EXCL(tenc, tenx, nlt); GRX_SCAN_EXCL(tenw, tenwx, tpool); }
+  const int nlj = nl;   // joint-limit rows; tendon-limit rows follow them (MuJoCo's row order)
+  nl += nlt;
   GRX_SCAN_EXCL(conr, conrx, nc_all);
   GRX_SCAN_EXCL(conw, conwx, pool_all);
   // contacts come last: keep as many whole contacts as fit into the row table and the Jacobian pool
-  const int rows0 = ne + nf + nl, pool0 = wpool + nf + nl;
+  const int rows0 = ne + nf + nl, pool0 = wpool + nf + nlj + tpool;
   int overflow = (rows0 > GRX_MAXEFC) || (pool0 > GRX_JPOOL), ncon_fit = ncon, nc = nc_all;
   if (rows0 + nc_all > GRX_MAXEFC || pool0 + pool_all > GRX_JPOOL) {  // rare: find the first contact that does not fit
     GRX_LANEVAR(failp);
@@ -1394,6 +1432,12 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
         if (f & 1) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); } r++; }
         if (f & 2) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = (j << 4) | 1; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); } }
       }
+    }
+    if (LV(tenf)) {
+      const int t = lane, f = LV(tenf), sp = m->tendon_span[t], slo = sp & 0xFF, slen = sp >> 8;
+      int r = ne + nf + nlj + LV(tenx), off = wpool + nf + nlj + LV(tenwx);
+      if (f & 1) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_TENDON; c->efc_id[r] = t << 4; c->efc_row[r] = GRX_ROW_PACK(off, slo, slen); } r++; off += slen; }
+      if (f & 2) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_TENDON; c->efc_id[r] = (t << 4) | 1; c->efc_row[r] = GRX_ROW_PACK(off, slo, slen); } }
     }
     if (lane < ncon) {
       const int k = lane;
@@ -1445,7 +1489,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     }
     // frictionloss + limits: one lane per row
     GRX_SUBTICK(c, 3);
-    for (int r = ne + lane; r < ne + nf + nl && r < nefc; r += 64) {
+    for (int r = ne + lane; r < ne + nf + nlj && r < nefc; r += 64) {
       if (c->efc_kind[r] == GRX_ROW_FRICTION) {
         c->Jp[GRX_ROW_OFF(c->efc_row[r])] = 1.0f;
         c->efc_pos[r] = 0;
@@ -1453,6 +1497,21 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
         int j = c->efc_id[r] >> 4, side = c->efc_id[r] & 15; float q = c->qpos[m->jnt_qposadr[j]];
         c->Jp[GRX_ROW_OFF(c->efc_row[r])] = side ? -1.0f : 1.0f;
         c->efc_pos[r] = side ? m->jnt_range[2 * j + 1] - q : q - m->jnt_range[2 * j];
+      }
+    }
+    // tendon limits: one lane per tendon writes its (up to two) rows over the tendon's dof span
+    if (LV(tenf)) {
+      const int t = lane, f = LV(tenf);
+      int r = ne + nf + nlj + LV(tenx);
+      for (int side = 0; side < 2; side++) {
+        if (!((f >> side) & 1)) continue;
+        if (r < nefc) {
+          const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
+          for (int j = 0; j < len; j++) c->Jp[off + j] = 0.0f;
+          for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) c->Jp[off + m->wrap_dof[w] - lo] += side ? -m->wrap_coef[w] : m->wrap_coef[w];
+          c->efc_pos[r] = side ? m->tendon_range[2 * t + 1] - LV(tenl) : LV(tenl) - m->tendon_range[2 * t];
+        }
+        r++;
       }
     }
     // contacts: one lane per (contact, dof of its span)
@@ -1504,6 +1563,10 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
         for (int k = 0; k < 2; k++) solref[k] = m->jnt_solref[2 * id + k];
         for (int k = 0; k < 5; k++) solimp[k] = m->jnt_solimp[5 * id + k];
         pos = c->efc_pos[r]; margin = m->jnt_margin[id]; dA = m->dof_invweight0[m->jnt_dofadr[id]];
+      } else if (kind == GRX_ROW_TENDON) {
+        for (int k = 0; k < 2; k++) solref[k] = m->tendon_solref[2 * id + k];
+        for (int k = 0; k < 5; k++) solimp[k] = m->tendon_solimp[5 * id + k];
+        pos = c->efc_pos[r]; margin = m->tendon_margin[id]; dA = m->tendon_invweight0[id];
       } else {
         int p = c->con_pair[id], dim = m->pair_condim[p];
         for (int k = 0; k < 2; k++) solref[k] = m->pair_solref[2 * p + k];

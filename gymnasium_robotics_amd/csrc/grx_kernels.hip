@@ -13,12 +13,15 @@
 #include "../../include/grx_capi.h"
 #include "grx_fetch_task.h"
 #include "grx_point_task.h"
+#include "grx_hand_task.h"
 #include "grx_host_model.h"
 
 static_assert(sizeof(grx_fetch_task) == sizeof(GrxFetchTask), "grx_fetch_task must mirror GrxFetchTask");
 static_assert(sizeof(grx_fetch_buffers) == sizeof(GrxFetchBuffers), "grx_fetch_buffers must mirror GrxFetchBuffers");
 static_assert(sizeof(grx_point_task) == sizeof(GrxPointTask), "grx_point_task must mirror GrxPointTask");
 static_assert(sizeof(grx_point_buffers) == sizeof(GrxPointBuffers), "grx_point_buffers must mirror GrxPointBuffers");
+static_assert(sizeof(grx_hand_task) == sizeof(GrxHandTask), "grx_hand_task must mirror GrxHandTask");
+static_assert(sizeof(grx_hand_buffers) == sizeof(GrxHandBuffers), "grx_hand_buffers must mirror GrxHandBuffers");
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -61,16 +64,17 @@ extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)h
 // into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs) and the loops over
 // dofs / bodies / joints unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
 template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(const GrxModel& m) {
-  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, 0, 0};
+  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG};
   return grx_dims_of(&m);
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == 0 && g.integrator == 0;
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG;
 }
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1> GrxShapeFetchArm;    // FetchReach (arm only)
+typedef GrxShape<24, 24, 20, 25, 24, 23, 20, 0, 24> GrxShapeHandReach;  // Shadow hand, reach.xml (24 hinges, 24 friction-loss dofs)
 
 template <class S>
 __global__ void __launch_bounds__(64, 2)
@@ -156,6 +160,53 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
     b.success[w] = succ; b.terminated[w] = (!t.continuing_task && succ) ? 1 : 0;
     b.status[w] = c.cnt[2];
   }
+}
+
+// Shadow hand reach env.step() (or mj_forward + outputs when forward_only): one wavefront per world, same engine
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
+  extern __shared__ float lds[];
+  const int w = blockIdx.x, lane_ = threadIdx.x;
+  if (w >= n_worlds) return;
+  if (b.mask && !b.mask[w]) return;
+  const GrxModel& m = g_grx_models[mslot];
+  GrxCtx c;
+  c.mslot = mslot;
+  grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
+#ifdef GRX_PROFILE
+  __shared__ long long prof_s[GRX_NPROF + 1];
+  c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
+#endif
+  const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv, nu = S::kFixed ? S::NU : m.nu;
+  for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
+  __syncthreads();
+  for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
+  for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
+  __syncthreads();
+  const int od = nq + nv + 3 * GRX_HAND_NTIPS;
+  float* obs = b.obs + (size_t)w * od; float* ach = b.achieved + (size_t)w * 3 * GRX_HAND_NTIPS; float* palm = b.palm + (size_t)w * 3;
+  if (forward_only) {
+    GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
+    GrxHand<S>::grx_hand_outputs(&m, &t, &c, obs, ach, palm, lane_);
+  } else {
+    GrxHand<S>::grx_hand_step_world(&m, &t, &c, b.action + (size_t)w * nu, obs, ach, palm, lane_);
+  }
+  __syncthreads();
+  for (int i = lane_; i < nq; i += 64) b.qpos[(size_t)w * nq + i] = c.qpos[i];
+  for (int i = lane_; i < nv; i += 64) { b.qvel[(size_t)w * nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * nv + i] = c.qacc_ws[i]; }
+  if (lane_ == 0) {
+    const float d = grx_goal_distance_n(ach, b.goal + (size_t)w * 3 * GRX_HAND_NTIPS, 3 * GRX_HAND_NTIPS);
+    b.reward[w] = grx_hand_reward(d, t.distance_threshold, t.sparse_reward);
+    b.success[w] = (d < t.distance_threshold) ? 1 : 0;
+    b.status[w] = c.cnt[2];
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+grx_goal_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int dim, float thr, int sparse, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x)
+    out[i] = grx_hand_reward(grx_goal_distance_n(ag + i * dim, dg + i * dim, dim), thr, sparse);
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -252,6 +303,8 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   else if (grx_shape_matches<GrxShapeFetchArm>(g)) { m->shape = 3; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchArm>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (grx_shape_matches<GrxShapeHandReach>(g)) { m->shape = 4; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandReach>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   for (int k = 0; k < GRX_MAX_MODELS && m->slot < 0; k++) if (!g_slot_used[k]) { g_slot_used[k] = 1; m->slot = k; }
   if (m->slot < 0) return fail("grx_model_create: all model descriptor slots are in use (destroy a model first)");
   HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_grx_models), &m->dev, sizeof(GrxModel), sizeof(GrxModel) * (size_t)m->slot, hipMemcpyHostToDevice));
@@ -339,6 +392,36 @@ extern "C" int grx_point_step(const grx_model* m, const grx_point_task* task, co
   GrxPointTask t; memcpy(&t, task, sizeof(t));
   GrxPointBuffers b; memcpy(&b, buf, sizeof(b));
   hipLaunchKernelGGL(grx_point_step_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int forward_only, void* stream) {
+  if (!m || !task || !buf) return fail("grx_hand_step: null argument");
+  if (!buf->qpos || !buf->qvel || !buf->qacc_ws || !buf->goal || !buf->obs || !buf->achieved || !buf->palm || !buf->reward || !buf->success || !buf->status)
+    return fail("grx_hand_step: null buffer");
+  if (!forward_only && !buf->action) return fail("grx_hand_step: null action buffer");
+  if (n_worlds <= 0) return 0;
+  GrxHandTask t; memcpy(&t, task, sizeof(t));
+  GrxHandBuffers b; memcpy(&b, buf, sizeof(b));
+  for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
+  if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
+  const dim3 grid(n_worlds), block(64);
+  const size_t lds_bytes = (size_t)m->words * 4;
+  if (m->shape == 4) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandReach>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  else hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
+                                       float* reward_out, void* stream) {
+  if (!achieved || !desired || !reward_out || dim <= 0) return fail("grx_goal_compute_reward: bad argument");
+  if (batch <= 0) return 0;
+  long long blocks = (batch + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(grx_goal_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, achieved, desired, (long long)batch, dim,
+                     distance_threshold, sparse, reward_out);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,228 @@
+"""Batched Shadow Dexterous Hand reach environment on the MI355X engine (ids HandReach-v3 / HandReachDense-v3).
+
+Host-side mirror of /root/reference/gymnasium_robotics/envs/shadow_dexterous_hand/reach.py (MujocoHandReachEnv) and
+hand_env.py (MujocoHandEnv) on top of robot_env.py (BaseRobotEnv / MujocoRobotEnv): same constructor meaning, dict
+observations (observation 63 = 24 joint positions | 24 joint velocities | 5 fingertip positions, goals 15), action 20
+(absolute joint targets scaled to the actuator ranges), `compute_reward` on arbitrary leading batch dims, truncation at 50
+steps, never terminated.  One call of `step` = one launch of `grx_hand_step_kernel` (set_action + 20 substeps + obs + reward).
+"""
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..core import GoalVecEnv, np_random
+from ..mjcf import CompiledModel, compile_mjcf, load_model
+from ..spaces import Box, Dict, batch_space
+from .hand_spec import (DISTANCE_THRESHOLD, MAX_EPISODE_STEPS, N_ACTIONS, initial_qpos_vector, make_hand_task, parse_hand_reach_id,
+                        sample_hand_reach_goal)
+
+_MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
+GOAL_DIM = 15
+
+
+def load_hand_reach_model(assets_root: Optional[str] = None) -> CompiledModel:
+    """hand/reach.xml compiled from MJCF when an asset tree is given (assets_root / $GRX_ASSETS_ROOT), else the packaged blob."""
+    assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
+    if assets_root:
+        return compile_mjcf(os.path.join(assets_root, "hand", "reach.xml"))
+    path = os.path.join(_MODELS_DIR, "hand_reach.npz")
+    if not os.path.exists(path):
+        raise OSError(f"File {path} does not exist")
+    return load_model(path)
+
+
+class HandReachVecEnv(GoalVecEnv):
+    def __init__(self, env_id: str = "HandReach-v3", num_envs: int = 1, device: Optional[str] = None, reward_type: Optional[str] = None,
+                 relative_control: bool = False, max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step",
+                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
+        if relative_control:
+            # hand_env.py:43-52 reads data.get_joint_qpos / model.actuator_names, which the mujoco bindings do not have: the
+            # reference itself cannot run this branch on the mujoco (non mujoco_py) backend
+            raise NotImplementedError("relative_control=True is not available on the mujoco backend of the reference either")
+        self.env_id, self.reward_type = env_id, reward_type or parse_hand_reach_id(env_id)
+        self.max_episode_steps, self.autoreset_mode, self.output = max_episode_steps, autoreset_mode, output
+        self.num_envs, self.seed_offset = int(num_envs), int(seed_offset)
+        if not torch.cuda.is_available():
+            raise RuntimeError("HandReachVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
+        self.device = torch.device(device or "cuda:0")
+        self.model = model or load_hand_reach_model(assets_root)
+        self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
+        if self.nu != N_ACTIONS:
+            raise ValueError("Action dimension mismatch")
+        self._L = _native.lib()
+        H, I, F = self.model.pack()
+        self._h = ctypes.c_void_p()
+        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0,
+                                               ctypes.byref(self._h)))
+        self.task = make_hand_task(self.model, self.reward_type)
+        self.obs_dim = self.nq + self.nv + GOAL_DIM
+        n, d = self.num_envs, self.device
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
+        self.qpos, self.qvel, self.qacc_ws = z(n, self.nq), z(n, self.nv), z(n, self.nv)
+        self.goal, self.action, self.obs, self.achieved = z(n, GOAL_DIM), z(n, self.nu), z(n, self.obs_dim), z(n, GOAL_DIM)
+        self.palm, self.reward = z(n, 3), z(n)
+        self.success, self.status, self.mask = z(n, dtype=torch.uint8), z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
+        self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)
+        self.single_observation_space = Dict(dict(
+            observation=Box(-np.inf, np.inf, (self.obs_dim,), np.float64), achieved_goal=Box(-np.inf, np.inf, (GOAL_DIM,), np.float64),
+            desired_goal=Box(-np.inf, np.inf, (GOAL_DIM,), np.float64)))
+        self.action_space = batch_space(self.single_action_space, n)
+        self.observation_space = batch_space(self.single_observation_space, n)
+        self._check_goal_space()
+        self.np_randoms = [np_random(None)[0] for _ in range(n)]
+        self._elapsed = np.zeros(n, np.int64)
+        self._needs_reset = np.zeros(n, bool)
+        self._has_reset = False
+        self.kernel_events = None  # when a list: (start, end) HIP events around every step-kernel launch (benchmarks)
+        self._env_setup()
+
+    def _make_bufs(self, mask):
+        b = _native.HandBuffersStruct()
+        for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status"):
+            setattr(b, name, getattr(self, name).data_ptr())
+        b.mask = None if mask is None else mask.data_ptr()
+        return b
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _launch(self, bufs, forward_only):
+        if self.kernel_events is not None and not forward_only:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, int(forward_only), self._stream()))
+        if self.kernel_events is not None and not forward_only:
+            b.record()
+            self.kernel_events.append((a, b))
+
+    # ------------------------------------------------------------------ _env_setup (reach.py:408-416) on the device
+    def _env_setup(self):
+        self._initial_qpos = torch.from_numpy(initial_qpos_vector(self.model).astype(np.float32)).to(self.device)
+        with torch.cuda.device(self.device):
+            self.qpos[:] = self._initial_qpos
+            self.qvel.zero_()
+            self.qacc_ws.zero_()
+            self._launch(self._bufs, True)
+            torch.cuda.synchronize(self.device)
+        if int(self.status[0]) != 0:
+            raise RuntimeError(f"engine reported status {int(self.status[0])} during env setup")
+        self.initial_goal = self.achieved[0].double().cpu().numpy().copy()
+        self.palm_xpos = self.palm[0].double().cpu().numpy().copy()
+
+    # ------------------------------------------------------------------ reset (robot_env.py:154-182, 300-313; reach.py:99-126)
+    def _reset_worlds(self, idx):
+        if len(idx) == 0:
+            return
+        goals = np.stack([sample_hand_reach_goal(self.np_randoms[w], self.initial_goal, self.palm_xpos) for w in idx])
+        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        self.qpos[ti] = self._initial_qpos
+        self.qvel[ti] = 0.0
+        self.qacc_ws[ti] = 0.0
+        self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
+        self.mask.zero_()
+        self.mask[ti] = 1
+        self._launch(self._bufs_masked, True)
+        self._elapsed[idx] = 0
+        self._needs_reset[idx] = False
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
+            self.np_randoms = [np_random(s)[0] for s in seeds]
+        with torch.cuda.device(self.device):
+            self._reset_worlds(np.arange(self.num_envs))
+        self._has_reset = True
+        return self._obs_dict(), {}
+
+    # ------------------------------------------------------------------ step (robot_env.py:114-152)
+    def step(self, actions):
+        if not self._has_reset:
+            raise RuntimeError("Cannot call env.step() before calling env.reset()")
+        a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions, dtype=np.float32))
+        if tuple(a.shape) != (self.num_envs, self.nu):
+            raise ValueError("Action dimension mismatch")
+        self.action.copy_(a.to(torch.float32), non_blocking=True)
+        with torch.cuda.device(self.device):
+            pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
+            if len(pending):
+                self.mask.fill_(1)
+                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                self._launch(self._bufs_masked, False)
+            else:
+                self._launch(self._bufs, False)
+            stepped = ~self._needs_reset
+            self._elapsed[stepped] += 1
+            truncated = np.zeros(self.num_envs, bool)
+            if self.max_episode_steps is not None:
+                truncated = stepped & (self._elapsed >= self.max_episode_steps)
+            terminated = np.zeros(self.num_envs, bool)
+            info = {}
+            if len(pending):
+                self._reset_worlds(pending)
+                self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
+            if self.autoreset_mode == "same_step" and truncated.any():
+                keep_r, keep_s = self.reward.clone(), self.success.clone()
+                self._reset_worlds(np.nonzero(truncated)[0])
+                self.reward.copy_(keep_r)
+                self.success.copy_(keep_s)
+            elif self.autoreset_mode == "next_step":
+                self._needs_reset |= truncated
+        obs = self._obs_dict()
+        if self.output == "torch":
+            info["is_success"] = self.success
+            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), info
+        info["is_success"] = self.success.cpu().numpy().astype(np.float32)
+        info["status"] = self.status.cpu().numpy()
+        r = self.reward.cpu().numpy()
+        return obs, (r if self.reward_type == "sparse" else r.astype(np.float64)), terminated, truncated, info
+
+    def _obs_dict(self):
+        if self.output == "torch":
+            return {"observation": self.obs, "achieved_goal": self.achieved, "desired_goal": self.goal}
+        return {"observation": self.obs.double().cpu().numpy(), "achieved_goal": self.achieved.double().cpu().numpy(),
+                "desired_goal": self.goal.double().cpu().numpy()}
+
+    # ------------------------------------------------------------------ GoalEnv API (reach.py:92-97; core.py:45-114)
+    def compute_reward(self, achieved_goal, desired_goal, info=None):
+        as_numpy = not isinstance(achieved_goal, torch.Tensor)
+        ag = torch.as_tensor(np.asarray(achieved_goal, dtype=np.float32) if as_numpy else achieved_goal, dtype=torch.float32, device=self.device).contiguous()
+        dg = torch.as_tensor(np.asarray(desired_goal, dtype=np.float32) if as_numpy else desired_goal, dtype=torch.float32, device=self.device).contiguous()
+        if ag.shape != dg.shape or ag.shape[-1] != GOAL_DIM:
+            raise ValueError(f"achieved_goal and desired_goal must have the same (..., {GOAL_DIM}) shape")
+        out = torch.empty(ag.shape[:-1], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._L.grx_goal_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), GOAL_DIM, DISTANCE_THRESHOLD,
+                                                          int(self.reward_type == "sparse"), out.data_ptr(), self._stream()))
+        if not as_numpy:
+            return out
+        r = out.cpu().numpy()
+        return r if self.reward_type == "sparse" else r.astype(np.float64)
+
+    def compute_terminated(self, achieved_goal, desired_goal, info=None):
+        return np.zeros(np.asarray(achieved_goal).shape[:-1], bool)  # robot_env.py:106-108
+
+    def compute_truncated(self, achieved_goal, desired_goal, info=None):
+        return np.zeros(np.asarray(achieved_goal).shape[:-1], bool)  # robot_env.py:110-112
+
+    def get_state(self):
+        return {k: getattr(self, k).clone() for k in ("qpos", "qvel", "qacc_ws", "goal")}
+
+    def set_state(self, state):
+        for k, v in state.items():
+            getattr(self, k).copy_(v)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.grx_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1038,7 +1038,7 @@ class _Lowering:
         weldparent = [weld[B[weld[i]].parent] if weld[i] > 0 else 0 for i in range(nb)]
         # narrow-phase routines implemented by BOTH the device engine and the oracle
         supported = {(GEOM_PLANE, GEOM_BOX), (GEOM_PLANE, GEOM_MESH), (GEOM_BOX, GEOM_BOX), (GEOM_PLANE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_BOX),
-                     (GEOM_PLANE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX)}
+                     (GEOM_PLANE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CAPSULE)}
         pairs = []
         for a in range(ng):
             for b_ in range(a + 1, ng):
@@ -1056,6 +1056,34 @@ class _Lowering:
                 if ga.type == GEOM_PLANE and gb.type == GEOM_PLANE:
                     continue
                 pairs.append((A_, B_, ga, gb))
+        # explicit <contact><pair> elements (MuJoCo XML reference, contact/pair): they bypass the contype/conaffinity and
+        # parent-child filters, take their parameters from the pair defaults (condim 3, friction 1 1 0.005 0.0001 0.0001,
+        # solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2, margin 0, gap 0) unless given, and replace a dynamically generated pair
+        # of the same two geoms.  A pair listed twice is kept once.
+        gindex = {g.name: gi for gi, (i, g) in enumerate(geoms) if g.name}
+        explicit = {}
+        for ct in c.root.findall("contact"):
+            for pe in ct.findall("pair"):
+                a = dict(c.defaults.get(pe.attrib.get("class"), "pair"))
+                a.update(pe.attrib)
+                if a["geom1"] not in gindex or a["geom2"] not in gindex:
+                    raise ValueError(f"contact pair refers to unknown geom {a['geom1']} / {a['geom2']}")
+                ia, ib = gindex[a["geom1"]], gindex[a["geom2"]]
+                ga, gb = geoms[ia][1], geoms[ib][1]
+                if ga.type > gb.type:
+                    ia, ib, ga, gb = ib, ia, gb, ga
+                key = (min(ia, ib), max(ia, ib))
+                if key in explicit:
+                    continue
+                fr = _floats(a.get("friction"), 5, [1, 1, 0.005, 0.0001, 0.0001])
+                explicit[key] = dict(A=ia, B=ib, ga=ga, gb=gb, condim=int(a.get("condim", 3)), friction=fr,
+                                     solref=_floats(a.get("solref"), 2, [0.02, 1.0]), solimp=_floats(a.get("solimp"), 5, [0.9, 0.95, 0.001, 0.5, 2]),
+                                     margin=float(a.get("margin", 0.0)), gap=float(a.get("gap", 0.0)))
+        pairs = [pr for pr in pairs if (min(pr[0], pr[1]), max(pr[0], pr[1])) not in explicit]
+        ndyn = len(pairs)
+        for key in sorted(explicit):
+            e = explicit[key]
+            pairs.append((e["A"], e["B"], e["ga"], e["gb"]))
         npair = len(pairs)
         pair_geom1 = np.zeros(npair, np.int32)
         pair_geom2 = np.zeros(npair, np.int32)
@@ -1069,6 +1097,13 @@ class _Lowering:
         for pi, (A_, B_, ga, gb) in enumerate(pairs):
             pair_geom1[pi], pair_geom2[pi] = A_, B_
             pair_supported[pi] = int((ga.type, gb.type) in supported)
+            if pi >= ndyn:
+                e = explicit[(min(A_, B_), max(A_, B_))]
+                pair_condim[pi] = e["condim"]
+                pair_friction[pi] = e["friction"]
+                pair_solref[pi], pair_solimp[pi] = e["solref"], e["solimp"]
+                pair_margin[pi], pair_gap[pi] = e["margin"], e["gap"]
+                continue
             if ga.priority != gb.priority:
                 gp = ga if ga.priority > gb.priority else gb
                 pair_condim[pi] = gp.condim
@@ -1207,6 +1242,49 @@ class _Lowering:
         nu = len(acts)
         for i, a in enumerate(acts):
             names["actuator"][a["name"]] = i
+
+        # ---- fixed tendons.  Only their limit rows are on the path (the models in scope attach no actuator, spring, damper
+        # or friction loss to a tendon): length = sum coef * qpos, Jacobian = the coefficients, invweight0 = J M^-1 J' at qpos0.
+        tendons, wrap_dof, wrap_qadr, wrap_coef = [], [], [], []
+        for tsec in c.root.findall("tendon"):
+            for e in tsec:
+                if e.tag != "fixed":
+                    raise NotImplementedError("only fixed tendons are supported")
+                a = dict(c.defaults.get(e.attrib.get("class"), "tendon"))
+                a.update(e.attrib)
+                if any(float(a.get(k, 0.0)) != 0.0 for k in ("stiffness", "damping", "frictionloss")):
+                    raise NotImplementedError("tendon stiffness / damping / frictionloss")
+                Jt = np.zeros(nv)
+                adr = len(wrap_dof)
+                for w in e.findall("joint"):
+                    j = jnts[names["joint"][w.attrib["joint"]]]
+                    if j.type not in (JNT_HINGE, JNT_SLIDE):
+                        raise ValueError("fixed tendons couple hinge / slide joints only")
+                    wrap_dof.append(j.dofadr); wrap_qadr.append(j.qposadr); wrap_coef.append(float(w.attrib["coef"]))
+                    Jt[j.dofadr] += float(w.attrib["coef"])
+                nz = np.nonzero(Jt)[0]
+                lo = int(nz.min()) if len(nz) else 0
+                ln = int(nz.max()) - lo + 1 if len(nz) else 0
+                lim = a.get("limited", "auto")
+                tendons.append(dict(
+                    adr=adr, num=len(wrap_dof) - adr, span=lo | (ln << 8),
+                    limited=int(_bool(lim) if lim != "auto" else (c.autolimits and "range" in a)),
+                    range=_floats(a.get("range"), 2, [0, 0]), margin=float(a.get("margin", 0.0)),
+                    solref=_floats(a.get("solreflimit"), 2, [0.02, 1.0]), solimp=_floats(a.get("solimplimit"), 5, [0.9, 0.95, 0.001, 0.5, 2]),
+                    invweight0=float(Jt @ Minv @ Jt) if nv else 0.0,
+                ))
+        ntendon = len(tendons)
+        if ntendon > 64:
+            raise ValueError("engine limit: at most 64 tendons (one lane per tendon)")
+        T.update(
+            tendon_adr=np.array([t["adr"] for t in tendons], np.int32), tendon_num=np.array([t["num"] for t in tendons], np.int32),
+            tendon_limited=np.array([t["limited"] for t in tendons], np.int32), tendon_span=np.array([t["span"] for t in tendons], np.int32),
+            tendon_range=np.array([t["range"] for t in tendons]).reshape(ntendon, 2), tendon_margin=np.array([t["margin"] for t in tendons], np.float64),
+            tendon_solref=np.array([t["solref"] for t in tendons]).reshape(ntendon, 2),
+            tendon_solimp=np.array([t["solimp"] for t in tendons]).reshape(ntendon, 5),
+            tendon_invweight0=np.array([t["invweight0"] for t in tendons], np.float64),
+            wrap_dof=np.array(wrap_dof, np.int32), wrap_qadr=np.array(wrap_qadr, np.int32), wrap_coef=np.array(wrap_coef, np.float64),
+        )
 
         # ---- assemble tables
         dims = np.zeros(NDIMS, np.int32)

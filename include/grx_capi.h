@@ -74,6 +74,25 @@ typedef struct grx_point_buffers {
   const unsigned char* mask;    /* [N] or NULL */
 } grx_point_buffers;
 
+/* mirrors struct GrxHandTask / GrxHandBuffers (csrc/grx_hand_task.h): Shadow Dexterous Hand reach task */
+typedef struct grx_hand_task {
+  int n_substeps, sparse_reward;
+  int site[5];   /* fingertip sites, envs/shadow_dexterous_hand/reach.py:8-14 order */
+  int palm_body; /* body used by _sample_goal (reach.py:413-416) */
+  float distance_threshold;
+} grx_hand_task;
+typedef struct grx_hand_buffers {
+  float *qpos, *qvel, *qacc_ws; /* [N,nq] [N,nv] [N,nv] */
+  const float* goal;            /* [N,15] */
+  const float* action;          /* [N,nu] (may be NULL when forward_only) */
+  float *obs, *achieved;        /* [N,nq+nv+15] [N,15] */
+  float* palm;                  /* [N,3] */
+  float* reward;                /* [N] */
+  unsigned char* success;       /* [N] */
+  int* status;                  /* [N] */
+  const unsigned char* mask;    /* [N] or NULL */
+} grx_hand_buffers;
+
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);
 int grx_model_destroy(grx_model* m);
 int grx_model_set_table(grx_model* m, const char* name, const double* data, int n);
@@ -90,6 +109,14 @@ int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_
 int grx_point_step(const grx_model* m, const grx_point_task* task, const grx_point_buffers* buf, int n_worlds, void* stream);
 int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t batch, float goal_radius, int sparse, float* reward_out,
                             void* stream);
+
+/* Shadow hand reach: BaseRobotEnv.step with MujocoHandEnv._set_action (absolute position control) + mj_step(n_substeps) +
+ * MujocoHandReachEnv._get_obs / compute_reward / _is_success for N worlds (envs/robot_env.py:114-152,
+ * envs/shadow_dexterous_hand/hand_env.py:36-58, reach.py:92-134,398-428).  forward_only != 0: mj_forward + outputs (reset path,
+ * robot_env.py:300-313, and _env_setup, reach.py:408-416).  grx_goal_compute_reward: batched compute_reward for dim-vector goals. */
+int grx_hand_step(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int forward_only, void* stream);
+int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
+                            float* reward_out, void* stream);
 
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's

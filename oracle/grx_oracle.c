@@ -35,7 +35,7 @@
 #define MINIMP 0.0001
 #define MAXIMP 0.9999
 
-enum { EFC_EQUALITY = 0, EFC_FRICTION = 1, EFC_LIMIT = 2, EFC_CONTACT = 3 };
+enum { EFC_EQUALITY = 0, EFC_FRICTION = 1, EFC_LIMIT = 2, EFC_CONTACT = 3, EFC_TLIMIT = 4 };
 
 typedef struct {
   double dist, pos[3], frame[9];
@@ -57,7 +57,7 @@ typedef struct orc_sim {
   double *M, *L /*dense chol of M (reverse order)*/, *cvel, *cacc, *cfrc;
   double *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc, *act_force;
   /* constraints */
-  int ncon, nefc, ne, nf, nl;
+  int ncon, nefc, ne, nf, nl, ntl /* tendon-limit rows among the nl limit rows */;
   orc_contact con[MAXCON];
   double *efc_J /*MAXEFC*nv*/, efc_pos[MAXEFC], efc_margin[MAXEFC], efc_D[MAXEFC], efc_R[MAXEFC], efc_aref[MAXEFC],
       efc_vel[MAXEFC], efc_force[MAXEFC], efc_frictionloss[MAXEFC], efc_diagApprox[MAXEFC], efc_KBIP[4 * MAXEFC];
@@ -537,6 +537,32 @@ static void collide_capsule_box(orc_sim* s, int pair, int g1, int g2, double mar
   }
 }
 
+/* capsule vs capsule: closest points of the two axis segments (clamped), then a sphere-sphere contact between them
+ * (normal from geom1 to geom2, position halfway through the overlap).  MuJoCo's routine additionally emits a second
+ * contact for exactly parallel axes (|det| < mjMINVAL), a measure-zero configuration that is not restated. */
+static void collide_capsule_capsule(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* c1 = s->geom_xpos + 3 * g1; const double* R1 = s->geom_xmat + 9 * g1;
+  const double* c2 = s->geom_xpos + 3 * g2; const double* R2 = s->geom_xmat + 9 * g2;
+  double r1 = m->geom_size[3 * g1], h1 = m->geom_size[3 * g1 + 1], r2 = m->geom_size[3 * g2], h2 = m->geom_size[3 * g2 + 1];
+  double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]}, w[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+  /* minimise |c1 + x1 a1 - c2 - x2 a2|^2 over x1 in [-h1, h1], x2 in [-h2, h2] */
+  double b = dot3(a1, a2), d = dot3(a1, w), e = dot3(a2, w), den = 1 - b * b, x1, x2;
+  x1 = den > MINVAL ? (b * e - d) / den : 0;
+  x1 = fmin(h1, fmax(-h1, x1));
+  x2 = b * x1 + e;
+  if (x2 > h2) { x2 = h2; x1 = fmin(h1, fmax(-h1, b * x2 - d)); }
+  else if (x2 < -h2) { x2 = -h2; x1 = fmin(h1, fmax(-h1, b * x2 - d)); }
+  double p1[3], p2[3], n[3];
+  for (int k = 0; k < 3; k++) { p1[k] = c1[k] + x1 * a1[k]; p2[k] = c2[k] + x2 * a2[k]; n[k] = p2[k] - p1[k]; }
+  double len = norm3(n);
+  if (len < MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else { n[0] /= len; n[1] /= len; n[2] /= len; }
+  double dist = len - r1 - r2;
+  if (dist > margin) return;
+  double pos[3] = {p1[0] + n[0] * (r1 + 0.5 * dist), p1[1] + n[1] * (r1 + 0.5 * dist), p1[2] + n[2] * (r1 + 0.5 * dist)};
+  add_contact(s, pair, pos, n, dist);
+}
+
 /* plane vs convex hull of a mesh: deepest hull vertex + up to 3 of its hull neighbours
  * that are also within the margin (restated from memory of MuJoCo's plane-convex routine;
  * unverifiable here -- see DESIGN.md "mesh policy") */
@@ -729,6 +755,7 @@ static void collision(orc_sim* s) {
     if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_SPHERE) collide_plane_sphere(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_CAPSULE) collide_plane_capsule(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_CAPSULE && t2 == GRX_GEOM_BOX) collide_capsule_box(s, p, g1, g2, margin);
+    else if (t1 == GRX_GEOM_CAPSULE && t2 == GRX_GEOM_CAPSULE) collide_capsule_capsule(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_SPHERE && t2 == GRX_GEOM_BOX) collide_sphere_box(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_BOX) collide_plane_box(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_MESH) collide_plane_mesh(s, p, g1, g2, margin);
@@ -804,6 +831,21 @@ static void make_constraint(orc_sim* s) {
       }
     }
   }
+  /* tendon limits (fixed tendons: length = sum coef * qpos, J = coefficients) */
+  s->ntl = 0;
+  for (int t = 0; t < m->n_tendon_adr; t++) {
+    if (!m->tendon_limited[t]) continue;
+    double len = 0, margin = m->tendon_margin[t];
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) len += m->wrap_coef[w] * s->qpos[m->wrap_qadr[w]];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->tendon_range[2 * t + (side + 1) / 2] - len);
+      if (fabs(dist - margin) > 0 && fabs(dist - margin) < s->min_activation_gap) s->min_activation_gap = fabs(dist - margin);
+      if (dist < margin) {
+        double* J = add_row(s, EFC_TLIMIT, t, dist, margin, 0, m->tendon_invweight0[t]);
+        if (J) { s->ntl++; for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) J[m->wrap_dof[w]] += -side * m->wrap_coef[w]; }
+      }
+    }
+  }
   s->nl = s->nefc - s->ne - s->nf;
   /* contacts (pyramidal cone) */
   for (int c = 0; c < s->ncon; c++) {
@@ -870,6 +912,7 @@ static void make_impedance(orc_sim* s) {
       case EFC_EQUALITY: solref = m->eq_solref + 2 * id; solimp = m->eq_solimp + 5 * id; break;
       case EFC_FRICTION: solref = m->dof_solref + 2 * id; solimp = m->dof_solimp + 5 * id; break;
       case EFC_LIMIT: solref = m->jnt_solref + 2 * id; solimp = m->jnt_solimp + 5 * id; break;
+      case EFC_TLIMIT: solref = m->tendon_solref + 2 * id; solimp = m->tendon_solimp + 5 * id; break;
       default: solref = s->con[id].solref; solimp = s->con[id].solimp; break;
     }
     double pos = s->efc_pos[i] - s->efc_margin[i];
@@ -1267,6 +1310,7 @@ int orc_int(orc_sim* s, const char* name) {
   if (!strcmp(name, "ne")) return s->ne;
   if (!strcmp(name, "nf")) return s->nf;
   if (!strcmp(name, "nl")) return s->nl;
+  if (!strcmp(name, "ntl")) return s->ntl;
   if (!strcmp(name, "solver_iter")) return s->solver_iter;
   if (!strcmp(name, "bad_state")) return s->bad_state;
   if (!strcmp(name, "unsupported_hits")) return s->unsupported_hits;

@@ -72,3 +72,13 @@ class EmuSim:
         p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
         self.L.emu_point_step(ctypes.c_void_p(self.h), ctypes.byref(self.task), p(self.qpos), p(self.qvel), p(self.qacc_ws), p(a), p(self.obs),
                               p(self.achieved), ctypes.byref(self.status))
+
+    def hand_step(self, action, forward_only=False):
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        if not hasattr(self, "hand_obs"):
+            self.hand_obs = np.zeros(self.nq + self.nv + 15, np.float32)
+            self.hand_achieved = np.zeros(15, np.float32)
+            self.palm = np.zeros(3, np.float32)
+        self.L.emu_hand_step(ctypes.c_void_p(self.h), ctypes.byref(self.task), p(self.qpos), p(self.qvel), p(self.qacc_ws), p(a), p(self.hand_obs),
+                             p(self.hand_achieved), p(self.palm), ctypes.byref(self.status), ctypes.c_int(int(forward_only)))

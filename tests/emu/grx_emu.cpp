@@ -27,6 +27,7 @@
 
 #include "../../gymnasium_robotics_amd/csrc/grx_fetch_task.h"
 #include "../../gymnasium_robotics_amd/csrc/grx_point_task.h"
+#include "../../gymnasium_robotics_amd/csrc/grx_hand_task.h"
 #include "../../gymnasium_robotics_amd/csrc/grx_host_model.h"
 
 struct Emu {
@@ -100,6 +101,21 @@ void emu_point_step(void* h, const GrxPointTask* t, float* qpos, float* qvel, fl
   float mocap[8] = {0};
   load_state(e, qpos, qvel, qacc_ws, mocap);
   GrxPoint<GrxShapeAny>::grx_point_step_world(&e->m, t, &e->c, action, obs, achieved, 0);
+  store_state(e, qpos, qvel, qacc_ws, mocap, status);
+}
+
+// HandReach env.step() of one world (nstep < 0: mj_forward + outputs only)
+void emu_hand_step(void* h, const GrxHandTask* t, float* qpos, float* qvel, float* qacc_ws, const float* action, float* obs, float* achieved,
+                   float* palm, int* status, int forward_only) {
+  Emu* e = (Emu*)h;
+  float mocap[8] = {0};
+  load_state(e, qpos, qvel, qacc_ws, mocap);
+  if (forward_only) {
+    GrxEngine<GrxShapeAny>::grx_forward_euler(&e->m, &e->c, 0, 0);
+    GrxHand<GrxShapeAny>::grx_hand_outputs(&e->m, t, &e->c, obs, achieved, palm, 0);
+  } else {
+    GrxHand<GrxShapeAny>::grx_hand_step_world(&e->m, t, &e->c, action, obs, achieved, palm, 0);
+  }
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 

@@ -1,0 +1,99 @@
+"""GPU parity tests of the HandReach family: grx_hand_step_kernel through the C ABI against the oracle's golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "hand_HandReach_teacher.npz")
+
+
+@pytest.fixture(scope="module")
+def env_and_golden():
+    import torch
+
+    from gymnasium_robotics_amd.envs.hand import HandReachVecEnv
+
+    g = np.load(GOLDEN)
+    n = g["obs"].shape[0]
+    env = HandReachVecEnv("HandReach-v3", num_envs=n, device="cuda:0", output="numpy", autoreset_mode="disabled", max_episode_steps=None)
+    env.reset(seed=0)
+    return env, g, torch
+
+
+def test_env_setup_matches_oracle(env_and_golden):
+    env, g, _ = env_and_golden
+    assert np.abs(env.initial_goal - g["initial_goal"]).max() < 2e-6
+    assert np.abs(env.palm_xpos - g["palm_xpos"]).max() < 1e-6
+    doc = np.array([[0.99, 0.8, 0.15], [1.02, 0.8, 0.15], [1.04, 0.81, 0.155], [1.07, 0.82, 0.16], [0.95, 0.84, 0.16]])  # reach.py:352-370
+    assert np.abs(env.initial_goal.reshape(5, 3) - doc).max() < 6e-3
+
+
+def test_reset_observation_and_goals_match_oracle(env_and_golden):
+    env, g, _ = env_and_golden
+    obs, _ = env.reset(seed=0)
+    k = len(g["reset_seed"])
+    assert np.abs(obs["observation"][:k] - g["reset_obs"]).max() < 2e-6      # world i is seeded with seed + i
+    assert np.abs(obs["desired_goal"][:k] - g["reset_goal"]).max() < 5e-7     # goals are built from the device (fp32) initial fingertip positions
+
+
+def test_teacher_forced_step_matches_golden(env_and_golden):
+    env, g, torch = env_and_golden
+    env.reset(seed=0)
+    dev = env.device
+    for k in ("qpos", "qvel", "qacc_ws", "goal"):
+        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(dev))
+    obs, r, term, trunc, info = env.step(g["action"])
+    assert int(info["status"].max()) == 0
+    err = np.abs(obs["observation"] - g["obs"]).max(axis=1)
+    far = g["activation_gap"] >= 2e-5
+    assert err[far].max() < 2e-4, (int(np.argmax(err * far)), float(err[far].max()))
+    assert err.max() < 5e-3
+    assert np.median(err) < 2e-5
+    assert (g["ntendon_rows"] > 0).sum() > 100 and (g["ncon"] > 0).sum() > 60
+    # reward / success: identical wherever the distance is not within fp32 noise of the threshold
+    d = np.linalg.norm(g["achieved"] - g["goal"], axis=1)
+    clear = np.abs(d - 0.01) > 1e-5
+    assert np.array_equal(r[clear], g["reward"][clear].astype(np.float32))
+    assert np.array_equal(info["is_success"][clear], g["success"][clear].astype(np.float32))
+    assert not term.any() and not trunc.any()
+
+
+def test_step_reward_equals_compute_reward_bitwise(env_and_golden):
+    env, g, torch = env_and_golden
+    env.reset(seed=3)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        obs, r, _, _, info = env.step(rng.uniform(-1, 1, (env.num_envs, 20)).astype(np.float32))
+    r2 = env.compute_reward(obs["achieved_goal"].astype(np.float32), obs["desired_goal"].astype(np.float32), info)
+    assert np.array_equal(r, r2) and r.dtype == np.float32
+    ag = torch.rand(7, 11, 15, device=env.device)
+    assert tuple(env.compute_reward(ag, ag + 0.001, None).shape) == (7, 11)
+    assert float(env.compute_reward(ag, ag, None).abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        env.compute_reward(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32), None)
+
+
+def test_determinism_truncation_and_errors(env_and_golden):
+    _, _, torch = env_and_golden
+    from gymnasium_robotics_amd.envs.hand import HandReachVecEnv
+
+    outs = []
+    for _ in range(2):
+        env = HandReachVecEnv("HandReachDense-v3", num_envs=8, device="cuda:0", output="numpy", max_episode_steps=5)
+        env.reset(seed=11)
+        rng = np.random.default_rng(5)
+        for t in range(6):
+            obs, r, term, trunc, info = env.step(rng.uniform(-1, 1, (8, 20)).astype(np.float32))
+            if t == 4:
+                assert trunc.all() and not term.any()
+            if t == 5:   # next_step autoreset: the reset replaces the step
+                assert (r == 0).all() and not trunc.any()
+        outs.append(obs["observation"].copy())
+        assert r.dtype == np.float64
+        with pytest.raises(ValueError):
+            env.step(np.zeros((8, 19), np.float32))
+        env.close()
+    assert np.array_equal(outs[0], outs[1])
+    with pytest.raises(NotImplementedError):
+        HandReachVecEnv("HandReach-v3", num_envs=1, relative_control=True)

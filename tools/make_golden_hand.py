@@ -1,0 +1,57 @@
+"""Golden fixtures of the HandReach family from the fp64 oracle (oracle/hand_oracle.py): teacher-forcing snapshots
+(pre-step state, action, oracle post-step outputs) + reset observations.  See tools/make_golden.py for the Fetch ones.
+
+    python tools/make_golden_hand.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from gymnasium_robotics_amd.envs.hand import load_hand_reach_model  # noqa: E402
+from oracle.hand_oracle import OracleHandReachEnv  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def snapshots(episodes=6):
+    model = load_hand_reach_model()
+    env = OracleHandReachEnv(model)
+    rng = np.random.default_rng(4321)
+    rec = {k: [] for k in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "ncon", "nefc", "ntendon_rows",
+                           "nlimit_rows", "seed", "t", "activation_gap")}
+    resets = {k: [] for k in ("seed", "obs", "achieved", "goal")}
+    for ep in range(episodes):
+        obs, _ = env.reset(seed=ep)
+        resets["seed"].append(ep); resets["obs"].append(obs["observation"]); resets["achieved"].append(obs["achieved_goal"]); resets["goal"].append(obs["desired_goal"])
+        for t in range(50):
+            a = rng.uniform(-1, 1, 20).astype(np.float32)
+            if ep % 3 == 1:   # make a fist: finger-thumb / finger-finger contact pairs and the coupling tendons at their limits
+                a = np.clip(a * 0.3 + 0.8, -1, 1).astype(np.float32)
+            if ep % 3 == 2:   # spread and stretch: joint limits on the other side
+                a = np.clip(a * 0.3 - 0.8, -1, 1).astype(np.float32)
+            s = env.sim
+            rec["qpos"].append(s.qpos.copy()); rec["qvel"].append(s.qvel.copy()); rec["qacc_ws"].append(s.qacc_warmstart.copy())
+            rec["goal"].append(env.goal.copy()); rec["action"].append(a)
+            s.min_activation_gap[0] = 1e30
+            obs, r, _, _, info = env.step(a.astype(np.float64))
+            rec["activation_gap"].append(float(s.min_activation_gap[0]))
+            rec["obs"].append(obs["observation"]); rec["achieved"].append(obs["achieved_goal"]); rec["reward"].append(r); rec["success"].append(info["is_success"])
+            ntl = int(s._L.orc_int(s._h, b"ntl"))
+            rec["ncon"].append(s.ncon); rec["nefc"].append(s.nefc); rec["ntendon_rows"].append(ntl); rec["nlimit_rows"].append(int(s._L.orc_int(s._h, b"nl")) - ntl)
+            rec["seed"].append(ep); rec["t"].append(t)
+            assert s.bad_state == 0
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out.update({"reset_" + k: np.asarray(v) for k, v in resets.items()})
+    out["initial_goal"], out["palm_xpos"] = env.initial_goal, env.palm_xpos
+    return out
+
+
+if __name__ == "__main__":
+    d = snapshots()
+    path = os.path.join(OUT, "hand_HandReach_teacher.npz")
+    np.savez_compressed(path, **d)
+    print("HandReach", d["obs"].shape, "max nefc", d["nefc"].max(), "max ncon", d["ncon"].max(), "steps with tendon rows", int((d["ntendon_rows"] > 0).sum()),
+          "steps with contacts", int((d["ncon"] > 0).sum()), f"{os.path.getsize(path)/1024:.0f} KiB")
