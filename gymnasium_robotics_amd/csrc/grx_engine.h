@@ -56,8 +56,8 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_MINIMP 0.0001f
 #define GRX_MAXIMP 0.9999f
 #define GRX_MAXCON 32
-#define GRX_MAXEFC 144   // constraint rows per world
-#define GRX_JPOOL 2032    // words of packed Jacobian storage per world (rows are stored over their dof span only)
+#define GRX_MAXEFC 144   // default constraint rows per world (models with wide contact rows get more: grx_pack_model)
+#define GRX_JPOOL 2032    // default words of packed Jacobian storage per world (rows are stored over their dof span only); < 4096 (12-bit row offsets)
 #define GRX_NEWTON_MAXIT 8
 #ifndef GRX_NEWTON_RTOL
 #define GRX_NEWTON_RTOL 1e-5f
@@ -82,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -111,6 +111,7 @@ struct GrxCtx {
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
+  int maxefc, jpool;  // capacities of the row tables / the packed Jacobian pool of this model
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   long long* prof; long long* prof_last;
 #endif
@@ -132,18 +133,19 @@ __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];
 // body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
 // Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
 // body frames, motion axes, M, J, row parameters) is persistent.
-struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator; };
-GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator) {
+struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool; };
+GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator, int maxefc = GRX_MAXEFC,
+                          int jpool = GRX_JPOOL) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
-  pers += GRX_JPOOL + GRX_MAXEFC * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
+  pers += jpool + maxefc * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
   pers += 32 + 8;
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
   int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 3 + 6);
-  int p2 = nv * nv + 5 * nv + 4 * GRX_MAXEFC;
+  int p2 = nv * nv + 5 * nv + 4 * maxefc;
   return pers + (p1 > p2 ? p1 : p2) + 8;
 }
 
@@ -161,10 +163,11 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   CARVE(cdof, 6 * m->nv) CARVE(M, m->nv * m->nv)
   CARVE(qfrc_smooth, m->nv) CARVE(qacc_smooth, m->nv) CARVE(qfrc_constraint, m->nv) CARVE(qacc, m->nv)
   c->red = p;  // 128-float scratch of the big-mesh collision path; the Jacobian pool is not written before the constraint stage
-  CARVE(Jp, GRX_JPOOL) CARVE(efc_D, GRX_MAXEFC) CARVE(efc_aref, GRX_MAXEFC)
+  c->maxefc = m->maxefc; c->jpool = m->jpool;
+  CARVE(Jp, m->jpool) CARVE(efc_D, m->maxefc) CARVE(efc_aref, m->maxefc)
   c->efc_pos = c->efc_aref;  // residuals live in the aref slot until the per-row pass turns them into aref
-  c->efc_floss = p; if (m->nfric) p += GRX_MAXEFC;
-  CARVEI(efc_kind, GRX_MAXEFC) CARVEI(efc_id, GRX_MAXEFC) CARVEI(efc_row, GRX_MAXEFC)
+  c->efc_floss = p; if (m->nfric) p += m->maxefc;
+  CARVEI(efc_kind, m->maxefc) CARVEI(efc_id, m->maxefc) CARVEI(efc_row, m->maxefc)
   CARVEI(ired, 32) CARVEI(cnt, 8)
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
   float* overlay = p;
@@ -189,16 +192,16 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   // ---- P2 (solve / integrate) on top of P1
   p = overlay;
   CARVE(A, m->nv * m->nv) CARVE(Ma, m->nv) CARVE(grad, m->nv) CARVE(search, m->nv) CARVE(Mv, m->nv) CARVE(tmpv, m->nv)
-  CARVE(efc_jar, GRX_MAXEFC) CARVE(efc_jv, GRX_MAXEFC) CARVE(efc_force, GRX_MAXEFC) CARVEI(efc_quad, GRX_MAXEFC)
+  CARVE(efc_jar, m->maxefc) CARVE(efc_jv, m->maxefc) CARVE(efc_force, m->maxefc) CARVEI(efc_quad, m->maxefc)
 #undef CARVE
 #undef CARVEI
 }
 
 GRX_HD GrxDims grx_dims_of(const GrxModel* m) {
-  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator};
+  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool};
   return d;
 }
-GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator); }
+GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool); }
 
 // ------------------------------------------------------------------------------------------
 // small math (all per-lane, registers)
@@ -362,9 +365,9 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 // All stages live in a class template so that the dof count can be a compile-time constant (NV > 0: inner loops over
 // dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
 // Model shape: the ten layout dims as compile-time constants (0 = read from the model at run time).
-template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0>
+template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0, int MAXEFC_ = GRX_MAXEFC, int JPOOL_ = GRX_JPOOL>
 struct GrxShape {
-  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_;
+  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_, ME = MAXEFC_, JP = JPOOL_;
   static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
@@ -663,6 +666,7 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
   if (n == 21) { grx_sym_solve_reg<21>(A, x, lane_); return 0; }
   if (n == 15) { grx_sym_solve_reg<15>(A, x, lane_); return 0; }
   if (n == 24) { grx_sym_solve_reg<24>(A, x, lane_); return 0; }
+  if (n == 30) { grx_sym_solve_reg<30>(A, x, lane_); return 0; }
 #endif
   int bad = grx_sym_factor(A, n, lane_);
   grx_sym_solve(A, n, x, lane_);
@@ -1392,18 +1396,19 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_SCAN_EXCL(conw, conwx, pool_all);
   // contacts come last: keep as many whole contacts as fit into the row table and the Jacobian pool
   const int rows0 = ne + nf + nl, pool0 = wpool + nf + nlj + tpool;
-  int overflow = (rows0 > GRX_MAXEFC) || (pool0 > GRX_JPOOL), ncon_fit = ncon, nc = nc_all;
-  if (rows0 + nc_all > GRX_MAXEFC || pool0 + pool_all > GRX_JPOOL) {  // rare: find the first contact that does not fit
+  const int maxefc = c->maxefc, jpool = c->jpool;
+  int overflow = (rows0 > maxefc) || (pool0 > jpool), ncon_fit = ncon, nc = nc_all;
+  if (rows0 + nc_all > maxefc || pool0 + pool_all > jpool) {  // rare: find the first contact that does not fit
     GRX_LANEVAR(failp);
     FOR_LANES {
-      int fits = (lane >= ncon) || (rows0 + LV(conrx) + LV(conr) <= GRX_MAXEFC && pool0 + LV(conwx) + LV(conw) <= GRX_JPOOL);
+      int fits = (lane >= ncon) || (rows0 + LV(conrx) + LV(conr) <= maxefc && pool0 + LV(conwx) + LV(conw) <= jpool);
       LV(failp) = fits ? -1000.0f : -(float)lane;
     }
     const float mx = grx_reduce_max(failp);
     if (mx > -999.0f) { ncon_fit = (int)(-mx); overflow = 1; nc = GRX_LANE_READ_I(conrx, ncon_fit); }
   }
   int nefc = rows0 + nc;
-  if (nefc > GRX_MAXEFC) nefc = GRX_MAXEFC;
+  if (nefc > maxefc) nefc = maxefc;
   // items of the contact-Jacobian pass: one per (kept contact, dof of its span); the running item offset rides in the
   // upper half of con_span so that an item can find its contact with a binary search
   GRX_LANEVAR_I(conix); int nitem;

@@ -12,12 +12,20 @@
 
 #define GRX_HAND_NTIPS 5
 
+// kind 0: HandReach (goal = 5 fingertip positions, 15 numbers).
+// kind 1: HandManipulate* (goal = object pose, 7 numbers: manipulate.py:87-142, 298-316):
+//   obs = robot qpos[nq_robot] | robot qvel[nq_robot] | object qvel[6] | object qpos[7];  achieved = object qpos[7]
 struct GrxHandTask {
   int n_substeps, sparse_reward;
   int site[GRX_HAND_NTIPS];  // fingertip sites, reach.py:8-14 order
   int palm_body;             // body whose position _sample_goal offsets from (reach.py:413-416)
   float distance_threshold;
+  int kind, nq_robot, obj_qadr, obj_dadr;
+  int ignore_position, ignore_rotation;   // target_position == "ignore" / target_rotation == "ignore" (manipulate.py:92-97)
+  float rotation_threshold;
 };
+GRX_DEV int grx_hand_goal_dim(const GrxHandTask* t) { return t->kind ? 7 : 3 * GRX_HAND_NTIPS; }
+GRX_DEV int grx_hand_obs_dim(const GrxHandTask* t, int nq, int nv) { return t->kind ? 2 * t->nq_robot + 6 + 7 : nq + nv + 3 * GRX_HAND_NTIPS; }
 
 struct GrxHandBuffers {
   float *qpos, *qvel, *qacc_ws;  // [N,nq] [N,nv] [N,nv]
@@ -40,12 +48,41 @@ GRX_DEV float grx_goal_distance_n(const float* a, const float* b, int n) {
 }
 GRX_DEV float grx_hand_reward(float d, float thr, int sparse) { return sparse ? ((d > thr) ? -1.0f : -0.0f) : -d; }
 
+// manipulate.py:87-142.  The reference takes the angle as 2 acos(clip(w)) of quat_a * conj(quat_b), whose scalar part is the
+// 4-vector dot product; 2 atan2(|vector part|, w) is the same angle for unit quaternions and keeps fp32 accuracy near 0.
+GRX_DEV void grx_manip_distance(const float* a, const float* b, int ignore_pos, int ignore_rot, float* d_pos, float* d_rot) {
+  *d_pos = ignore_pos ? 0.0f : grx_goal_distance_n(a, b, 3);
+  float dr = 0.0f;
+  if (!ignore_rot) {
+    const float w0 = a[3], x0 = a[4], y0 = a[5], z0 = a[6], w1 = b[3], x1 = -b[4], y1 = -b[5], z1 = -b[6];
+    const float w = w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1;
+    const float x = w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1, y = w0 * y1 + y0 * w1 + z0 * x1 - x0 * z1, z = w0 * z1 + z0 * w1 + x0 * y1 - y0 * x1;
+    dr = 2.0f * atan2f(sqrtf(x * x + y * y + z * z), w);
+  }
+  *d_rot = dr;
+}
+GRX_DEV int grx_manip_success(float d_pos, float d_rot, float thr_pos, float thr_rot) { return (d_pos < thr_pos) && (d_rot < thr_rot); }
+GRX_DEV float grx_manip_reward(float d_pos, float d_rot, float thr_pos, float thr_rot, int sparse) {
+  return sparse ? (grx_manip_success(d_pos, d_rot, thr_pos, thr_rot) ? 0.0f : -1.0f) : -(10.0f * d_pos + d_rot);
+}
+
 template <class S>
 struct GrxHand {
   typedef GrxEngine<S> E;
   GRX_MEM void grx_hand_outputs(const GrxModel* m, const GrxHandTask* t, const GrxCtx* c, float* obs, float* achieved, float* palm, int lane_) {
     GRX_FRESH_MODEL(m, c);
     const int nq = GRX_NQC, nv = GRX_NVC;
+    if (t->kind) {
+      const int nr = t->nq_robot;
+      FOR_LANES {
+        for (int i = lane; i < nr; i += 64) { obs[i] = c->qpos[i]; obs[nr + i] = c->qvel[i]; }
+        for (int i = lane; i < 6; i += 64) obs[2 * nr + i] = c->qvel[t->obj_dadr + i];
+        for (int i = lane; i < 7; i += 64) { const float v = c->qpos[t->obj_qadr + i]; obs[2 * nr + 6 + i] = v; achieved[i] = v; }
+        for (int i = lane; i < 3; i += 64) palm[i] = c->xpos[3 * t->palm_body + i];
+      }
+      WAVE_SYNC();
+      return;
+    }
     FOR_LANES {
       for (int i = lane; i < nq; i += 64) obs[i] = c->qpos[i];
       for (int i = lane; i < nv; i += 64) obs[nq + i] = c->qvel[i];

@@ -42,6 +42,11 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   for (int k = 0; k < v.n_weld_row; k++) m.wpool += 6 * ((v.weld_row[k] >> 20) & 0xFF);
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;
   for (int k = 0; k < v.n_eq_type; k++) if (v.eq_active[k] && v.eq_type[k] == GRX_EQ_WELD) m.nweld++;
+  // Capacities of the row tables and of the packed-Jacobian pool: the compiler may request more than the defaults for models
+  // with wide / tall contact rows (dims slots GRX_MAXEFC_REQ / GRX_JPOOL_REQ, 0 = default); row offsets are 12-bit.
+  m.maxefc = d[GRX_MAXEFC_REQ] > 0 ? ((d[GRX_MAXEFC_REQ] + 15) / 16) * 16 : GRX_MAXEFC;
+  m.jpool = d[GRX_JPOOL_REQ] > 0 ? ((d[GRX_JPOOL_REQ] + 15) / 16) * 16 : GRX_JPOOL;
+  if (m.jpool > 4080) m.jpool = 4080;
   m.anydamp = 0;
   for (int k = 0; k < v.n_dof_damping; k++) if (v.dof_damping[k] > 0) m.anydamp = 1;
   m.timestep = (float)v.opt[GRX_TIMESTEP];

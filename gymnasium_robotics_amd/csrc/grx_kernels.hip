@@ -64,17 +64,18 @@ extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)h
 // into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs) and the loops over
 // dofs / bodies / joints unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
 template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(const GrxModel& m) {
-  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG};
+  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP};
   return grx_dims_of(&m);
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG;
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP;
 }
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1> GrxShapeFetchArm;    // FetchReach (arm only)
 typedef GrxShape<24, 24, 20, 25, 24, 23, 20, 0, 24> GrxShapeHandReach;  // Shadow hand, reach.xml (24 hinges, 24 friction-loss dofs)
+typedef GrxShape<31, 30, 20, 26, 25, 24, 11, 0, 24> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
 
 template <class S>
 __global__ void __launch_bounds__(64, 2)
@@ -184,8 +185,8 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
   for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
   __syncthreads();
-  const int od = nq + nv + 3 * GRX_HAND_NTIPS;
-  float* obs = b.obs + (size_t)w * od; float* ach = b.achieved + (size_t)w * 3 * GRX_HAND_NTIPS; float* palm = b.palm + (size_t)w * 3;
+  const int od = grx_hand_obs_dim(&t, nq, nv), gd = grx_hand_goal_dim(&t);
+  float* obs = b.obs + (size_t)w * od; float* ach = b.achieved + (size_t)w * gd; float* palm = b.palm + (size_t)w * 3;
   if (forward_only) {
     GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
     GrxHand<S>::grx_hand_outputs(&m, &t, &c, obs, ach, palm, lane_);
@@ -196,9 +197,16 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   for (int i = lane_; i < nq; i += 64) b.qpos[(size_t)w * nq + i] = c.qpos[i];
   for (int i = lane_; i < nv; i += 64) { b.qvel[(size_t)w * nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * nv + i] = c.qacc_ws[i]; }
   if (lane_ == 0) {
-    const float d = grx_goal_distance_n(ach, b.goal + (size_t)w * 3 * GRX_HAND_NTIPS, 3 * GRX_HAND_NTIPS);
-    b.reward[w] = grx_hand_reward(d, t.distance_threshold, t.sparse_reward);
-    b.success[w] = (d < t.distance_threshold) ? 1 : 0;
+    if (t.kind) {
+      float dp, dr;
+      grx_manip_distance(ach, b.goal + (size_t)w * gd, t.ignore_position, t.ignore_rotation, &dp, &dr);
+      b.reward[w] = grx_manip_reward(dp, dr, t.distance_threshold, t.rotation_threshold, t.sparse_reward);
+      b.success[w] = grx_manip_success(dp, dr, t.distance_threshold, t.rotation_threshold);
+    } else {
+      const float d = grx_goal_distance_n(ach, b.goal + (size_t)w * gd, gd);
+      b.reward[w] = grx_hand_reward(d, t.distance_threshold, t.sparse_reward);
+      b.success[w] = (d < t.distance_threshold) ? 1 : 0;
+    }
     b.status[w] = c.cnt[2];
   }
 }
@@ -207,6 +215,16 @@ extern "C" __global__ void __launch_bounds__(256)
 grx_goal_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int dim, float thr, int sparse, float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x)
     out[i] = grx_hand_reward(grx_goal_distance_n(ag + i * dim, dg + i * dim, dim), thr, sparse);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+grx_manip_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int ignore_pos, int ignore_rot, float thr_pos, float thr_rot,
+                        int sparse, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
+    float dp, dr;
+    grx_manip_distance(ag + i * 7, dg + i * 7, ignore_pos, ignore_rot, &dp, &dr);
+    out[i] = grx_manip_reward(dp, dr, thr_pos, thr_rot, sparse);
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -289,13 +307,13 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   HIP_OK(hipMemcpy(m->d_i, m->pm.i.data(), sizeof(int32_t) * m->pm.i.size(), hipMemcpyHostToDevice));
   m->dev = grx_bind_model(m->pm, m->d_f, m->d_i);
   const GrxModel& g = m->dev;
-  m->words = grx_ctx_words(g.nq, g.nv, g.nu, g.nbody, g.njnt, g.ngeom, g.nsite, g.nmocap, g.nfric, g.integrator);
+  m->words = grx_ctx_words(grx_dims_of(&g));
   int bytes = m->words * 4;
   if (bytes > 160 * 1024) return fail("model working set exceeds the 160 KiB LDS of a CU");
   if (g.njnt > 32) return fail("engine limit: at most 32 joints per world (limit-flag table in LDS)");
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
   if (g.nbody > 64) return fail("engine limit: at most 64 bodies per world (one lane per body, 64-bit subtree masks)");
-  if (g.nweld > GRX_MAXEFC / 16) return fail("engine limit: too many weld constraints (weld frames are staged in the row-parameter slot)");
+  if (g.nweld > g.maxefc / 16) return fail("engine limit: too many weld constraints (weld frames are staged in the row-parameter slot)");
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   m->shape = 0;
   if (grx_shape_matches<GrxShapeFetchPick>(g)) { m->shape = 1; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPick>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
@@ -305,6 +323,7 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   if (grx_shape_matches<GrxShapeHandReach>(g)) { m->shape = 4; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandReach>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  if (grx_shape_matches<GrxShapeHandBlock>(g)) { m->shape = 5; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   for (int k = 0; k < GRX_MAX_MODELS && m->slot < 0; k++) if (!g_slot_used[k]) { g_slot_used[k] = 1; m->slot = k; }
   if (m->slot < 0) return fail("grx_model_create: all model descriptor slots are in use (destroy a model first)");
   HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_grx_models), &m->dev, sizeof(GrxModel), sizeof(GrxModel) * (size_t)m->slot, hipMemcpyHostToDevice));
@@ -404,11 +423,16 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   if (n_worlds <= 0) return 0;
   GrxHandTask t; memcpy(&t, task, sizeof(t));
   GrxHandBuffers b; memcpy(&b, buf, sizeof(b));
-  for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
+  if (t.kind) {
+    if (t.nq_robot <= 0 || t.nq_robot > m->dev.nv || t.obj_qadr < 0 || t.obj_qadr + 7 > m->dev.nq || t.obj_dadr < 0 || t.obj_dadr + 6 > m->dev.nv)
+      return fail("grx_hand_step: object joint addresses out of range");
+  } else
+    for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
   const dim3 grid(n_worlds), block(64);
   const size_t lds_bytes = (size_t)m->words * 4;
-  if (m->shape == 4) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandReach>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  if (m->shape == 5) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlock>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  else if (m->shape == 4) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandReach>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   else hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   HIP_OK(hipGetLastError());
   return 0;
@@ -422,6 +446,18 @@ extern "C" int grx_goal_compute_reward(const float* achieved, const float* desir
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(grx_goal_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, achieved, desired, (long long)batch, dim,
                      distance_threshold, sparse, reward_out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int grx_manip_compute_reward(const float* achieved, const float* desired, int64_t batch, int ignore_position, int ignore_rotation,
+                                        float distance_threshold, float rotation_threshold, int sparse, float* reward_out, void* stream) {
+  if (!achieved || !desired || !reward_out) return fail("grx_manip_compute_reward: null argument");
+  if (batch <= 0) return 0;
+  long long blocks = (batch + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(grx_manip_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, achieved, desired, (long long)batch, ignore_position,
+                     ignore_rotation, distance_threshold, rotation_threshold, sparse, reward_out);
   HIP_OK(hipGetLastError());
   return 0;
 }

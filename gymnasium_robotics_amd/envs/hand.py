@@ -43,13 +43,14 @@ class HandReachVecEnv(GoalVecEnv):
             # hand_env.py:43-52 reads data.get_joint_qpos / model.actuator_names, which the mujoco bindings do not have: the
             # reference itself cannot run this branch on the mujoco (non mujoco_py) backend
             raise NotImplementedError("relative_control=True is not available on the mujoco backend of the reference either")
-        self.env_id, self.reward_type = env_id, reward_type or parse_hand_reach_id(env_id)
+        self.env_id = env_id
+        self._parse_id(env_id, reward_type)
         self.max_episode_steps, self.autoreset_mode, self.output = max_episode_steps, autoreset_mode, output
         self.num_envs, self.seed_offset = int(num_envs), int(seed_offset)
         if not torch.cuda.is_available():
             raise RuntimeError("HandReachVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
         self.device = torch.device(device or "cuda:0")
-        self.model = model or load_hand_reach_model(assets_root)
+        self.model = model or self._load_model(assets_root)
         self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
         if self.nu != N_ACTIONS:
             raise ValueError("Action dimension mismatch")
@@ -58,8 +59,9 @@ class HandReachVecEnv(GoalVecEnv):
         self._h = ctypes.c_void_p()
         _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0,
                                                ctypes.byref(self._h)))
-        self.task = make_hand_task(self.model, self.reward_type)
-        self.obs_dim = self.nq + self.nv + GOAL_DIM
+        self.task = self._make_task()
+        GOAL_DIM = self.GOAL_DIM
+        self.obs_dim = self._obs_dim()
         n, d = self.num_envs, self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
         self.qpos, self.qvel, self.qacc_ws = z(n, self.nq), z(n, self.nv), z(n, self.nv)
@@ -80,6 +82,21 @@ class HandReachVecEnv(GoalVecEnv):
         self._has_reset = False
         self.kernel_events = None  # when a list: (start, end) HIP events around every step-kernel launch (benchmarks)
         self._env_setup()
+
+    # ---- hooks specialised by the manipulation envs
+    GOAL_DIM = GOAL_DIM
+
+    def _parse_id(self, env_id, reward_type):
+        self.reward_type = reward_type or parse_hand_reach_id(env_id)
+
+    def _load_model(self, assets_root):
+        return load_hand_reach_model(assets_root)
+
+    def _make_task(self):
+        return make_hand_task(self.model, self.reward_type)
+
+    def _obs_dim(self):
+        return self.nq + self.nv + self.GOAL_DIM
 
     def _make_bufs(self, mask):
         b = _native.HandBuffersStruct()
@@ -192,16 +209,19 @@ class HandReachVecEnv(GoalVecEnv):
         as_numpy = not isinstance(achieved_goal, torch.Tensor)
         ag = torch.as_tensor(np.asarray(achieved_goal, dtype=np.float32) if as_numpy else achieved_goal, dtype=torch.float32, device=self.device).contiguous()
         dg = torch.as_tensor(np.asarray(desired_goal, dtype=np.float32) if as_numpy else desired_goal, dtype=torch.float32, device=self.device).contiguous()
-        if ag.shape != dg.shape or ag.shape[-1] != GOAL_DIM:
-            raise ValueError(f"achieved_goal and desired_goal must have the same (..., {GOAL_DIM}) shape")
+        if ag.shape != dg.shape or ag.shape[-1] != self.GOAL_DIM:
+            raise ValueError(f"achieved_goal and desired_goal must have the same (..., {self.GOAL_DIM}) shape")
         out = torch.empty(ag.shape[:-1], dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _native.check(self._L.grx_goal_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), GOAL_DIM, DISTANCE_THRESHOLD,
-                                                          int(self.reward_type == "sparse"), out.data_ptr(), self._stream()))
+            self._launch_reward(ag, dg, out)
         if not as_numpy:
             return out
         r = out.cpu().numpy()
         return r if self.reward_type == "sparse" else r.astype(np.float64)
+
+    def _launch_reward(self, ag, dg, out):
+        _native.check(self._L.grx_goal_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), self.GOAL_DIM, DISTANCE_THRESHOLD,
+                                                      int(self.reward_type == "sparse"), out.data_ptr(), self._stream()))
 
     def compute_terminated(self, achieved_goal, desired_goal, info=None):
         return np.zeros(np.asarray(achieved_goal).shape[:-1], bool)  # robot_env.py:106-108
@@ -226,3 +246,95 @@ class HandReachVecEnv(GoalVecEnv):
             self.close()
         except Exception:
             pass
+
+
+def load_hand_block_model(assets_root: Optional[str] = None) -> CompiledModel:
+    """hand/manipulate_block.xml without its visual-only target body (manipulate_spec.drop_target_body)."""
+    from .manipulate_spec import drop_target_body
+
+    assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
+    if assets_root:
+        return compile_mjcf(os.path.join(assets_root, "hand", "manipulate_block.xml"), mutate=drop_target_body)
+    path = os.path.join(_MODELS_DIR, "hand_block.npz")
+    if not os.path.exists(path):
+        raise OSError(f"File {path} does not exist")
+    return load_model(path)
+
+
+class HandBlockVecEnv(HandReachVecEnv):
+    """Batched HandManipulateBlock{RotateZ, RotateParallel, RotateXYZ, Full}[Dense]-v1
+    (/root/reference/gymnasium_robotics/envs/shadow_dexterous_hand/manipulate.py: MujocoManipulateEnv; manipulate_block.py:214-230).
+    Observation 61 = 24 robot joint positions | 24 velocities | object velocity 6 | object pose 7; goals are 7-vector poses.
+    The visual-only, non-colliding `target` body of the MJCF is not simulated (its state is not observable through the env API)."""
+
+    GOAL_DIM = 7
+
+    def __init__(self, env_id: str = "HandManipulateBlockRotateXYZ-v1", num_envs: int = 1, max_episode_steps: Optional[int] = 100, **kw):
+        super().__init__(env_id, num_envs, max_episode_steps=max_episode_steps, **kw)
+
+    def _parse_id(self, env_id, reward_type):
+        from .manipulate_spec import canonical_parallel_quats, parse_block_id
+
+        self.target_position, self.target_rotation, rt = parse_block_id(env_id)
+        self.reward_type = reward_type or rt
+        self._pquats = canonical_parallel_quats()
+
+    def _load_model(self, assets_root):
+        return load_hand_block_model(assets_root)
+
+    def _make_task(self):
+        from .manipulate_spec import make_block_task
+
+        return make_block_task(self.model, self.target_position, self.target_rotation, self.reward_type)
+
+    def _obs_dim(self):
+        return 2 * 24 + 6 + 7
+
+    def _env_setup(self):
+        # manipulate.py:149-152 with initial_qpos = {}: the model's qpos0
+        self._initial_qpos = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32)).to(self.device)
+        self._qa = int(self.task.obj_qadr)
+        self._obj0 = self.model.tables["qpos0"][self._qa: self._qa + 7].astype(np.float64)
+        self.reset_attempts = np.zeros(self.num_envs, np.int64)
+
+    # manipulate.py:154-224 (_reset_sim: pose randomisation, ten settle steps with a zero action, on-palm test, retried until it
+    # holds -- robot_env.py:163-171) and :226-279 (_sample_goal from the settled pose).  The reference does not call mj_resetData
+    # here, so the warm start of the previous episode survives the reset.
+    def _reset_worlds(self, idx):
+        from .manipulate_spec import PALM_HEIGHT, SETTLE_STEPS, sample_block_goal, sample_reset_object_pose
+
+        if len(idx) == 0:
+            return
+        pending = np.asarray(idx, dtype=np.int64)
+        self.reset_attempts[pending] = 0
+        saved_action = self.action.clone()
+        while len(pending):
+            self.reset_attempts[pending] += 1
+            poses = np.stack([sample_reset_object_pose(self.np_randoms[w], self._obj0[:3], self._obj0[3:], self.target_position, self.target_rotation,
+                                                       self._pquats) for w in pending])
+            ti = torch.from_numpy(pending).to(self.device)
+            q = self._initial_qpos.unsqueeze(0).repeat(len(pending), 1)
+            q[:, self._qa: self._qa + 7] = torch.from_numpy(poses.astype(np.float32)).to(self.device)
+            self.qpos[ti] = q
+            self.qvel[ti] = 0.0
+            self.action.zero_()
+            self.mask.zero_()
+            self.mask[ti] = 1
+            for _ in range(SETTLE_STEPS):
+                self._launch(self._bufs_masked, False)
+            z = self.qpos[ti, self._qa + 2].cpu().numpy()
+            pending = pending[~(z > PALM_HEIGHT)]
+        self.action.copy_(saved_action)
+        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        obj = self.qpos[ti, self._qa: self._qa + 7].double().cpu().numpy()
+        goals = np.stack([sample_block_goal(self.np_randoms[w], obj[k], self.target_position, self.target_rotation, self._pquats) for k, w in enumerate(idx)])
+        self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
+        self._elapsed[idx] = 0
+        self._needs_reset[idx] = False
+
+    def _launch_reward(self, ag, dg, out):
+        from .manipulate_spec import DISTANCE_THRESHOLD as DT, ROTATION_THRESHOLD as RT
+
+        _native.check(self._L.grx_manip_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), int(self.target_position == "ignore"),
+                                                       int(self.target_rotation == "ignore"), DT, RT, int(self.reward_type == "sparse"),
+                                                       out.data_ptr(), self._stream()))

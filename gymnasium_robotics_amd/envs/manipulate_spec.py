@@ -1,0 +1,198 @@
+"""HandManipulateBlock* task description shared by the device env and the test oracle (host logic only).
+
+Mirrors /root/reference/gymnasium_robotics/envs/shadow_dexterous_hand/manipulate.py (reset pose randomisation, goal sampling,
+goal distance / reward / success) and manipulate_block.py:214-230 (target position range), plus the quaternion helpers of
+gymnasium_robotics/utils/rotations.py that those use.  The helpers are pinned against the reference's own code through
+tests/golden/ref_rotations.npz (tools/make_reference_vectors.py).
+"""
+import itertools
+
+import numpy as np
+
+TARGET_POSITION_RANGE = np.array([(-0.04, 0.04), (-0.06, 0.02), (0.0, 0.06)])   # manipulate_block.py:226
+DISTANCE_THRESHOLD, ROTATION_THRESHOLD = 0.01, 0.1                               # manipulate.py:32-33
+N_SUBSTEPS, MAX_EPISODE_STEPS, SETTLE_STEPS, PALM_HEIGHT = 20, 100, 10, 0.04     # manipulate.py:34,205-216; __init__.py:284
+# registered ids (gymnasium_robotics/__init__.py:222-300): name -> (target_position, target_rotation)
+BLOCK_VARIANTS = {
+    "HandManipulateBlockRotateZ": ("ignore", "z"), "HandManipulateBlockRotateParallel": ("ignore", "parallel"),
+    "HandManipulateBlockRotateXYZ": ("ignore", "xyz"), "HandManipulateBlockFull": ("random", "xyz"),
+}
+
+
+def parse_block_id(env_id: str):
+    """'HandManipulateBlockRotateXYZ-v1', '...Dense-v1' -> (target_position, target_rotation, reward_type)."""
+    name, _, version = env_id.rpartition("-")
+    dense = name.endswith("Dense")
+    base = name[:-5] if dense else name
+    if version != "v1" or base not in BLOCK_VARIANTS:
+        raise ValueError(f"unknown HandManipulateBlock id {env_id!r}")
+    return (*BLOCK_VARIANTS[base], "dense" if dense else "sparse")
+
+
+def drop_target_body(root):
+    """MJCF mutation: remove the 'target' body.  It is a free, non-colliding (contype = conaffinity = 0) visual marker whose state
+    never enters observation, reward or goal (manipulate.py:298-316); without it the device model has nv = 30 instead of 36."""
+    for wb in root.iter("worldbody"):
+        for b in list(wb):
+            if b.tag == "body" and b.attrib.get("name") == "target":
+                wb.remove(b)
+
+
+# ---- quaternion helpers (w, x, y, z), restating utils/rotations.py
+def quat_conj(q):
+    q = np.asarray(q, dtype=np.float64)
+    return q * np.array([1.0, -1.0, -1.0, -1.0])
+
+
+def quat_mul(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    aw, av, bw, bv = a[..., :1], a[..., 1:], b[..., :1], b[..., 1:]
+    return np.concatenate([aw * bw - np.sum(av * bv, axis=-1, keepdims=True), aw * bv + bw * av + np.cross(av, bv)], axis=-1)
+
+
+def quat_from_angle_and_axis(angle, axis):
+    """manipulate.py:10-15."""
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    q = np.concatenate([[np.cos(angle / 2.0)], np.sin(angle / 2.0) * axis])
+    return q / np.linalg.norm(q)
+
+
+def euler2quat(euler):
+    """rotations.py:140-159: intrinsic x-y-z Euler angles, i.e. the quaternion product qx(e0) qy(e1) qz(e2)."""
+    e = np.asarray(euler, dtype=np.float64)
+    half = e / 2.0
+    zeros = np.zeros_like(half[..., 0])
+    qx = np.stack([np.cos(half[..., 0]), np.sin(half[..., 0]), zeros, zeros], axis=-1)
+    qy = np.stack([np.cos(half[..., 1]), zeros, np.sin(half[..., 1]), zeros], axis=-1)
+    qz = np.stack([np.cos(half[..., 2]), zeros, zeros, np.sin(half[..., 2])], axis=-1)
+    return quat_mul(qx, quat_mul(qy, qz))
+
+
+def _quat2mat(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _mat2euler(R):
+    """rotations.py:162-184 for one matrix (fixed-axis x-y-z)."""
+    cy = np.sqrt(R[2, 2] * R[2, 2] + R[1, 2] * R[1, 2])
+    if cy > np.finfo(np.float64).eps * 4.0:
+        return np.array([-np.arctan2(R[1, 2], R[2, 2]), -np.arctan2(-R[0, 2], cy), -np.arctan2(R[0, 1], R[0, 0])])
+    return np.array([0.0, -np.arctan2(-R[0, 2], cy), -np.arctan2(-R[1, 0], R[1, 1])])
+
+
+def canonical_parallel_quats():
+    """manipulate.py:66-68: euler2quat of the canonical Euler triples rotations.get_parallel_rotations() (rotations.py:394-408)
+    returns -- first occurrence, over itertools.product of (0, 90, -90, 180) degrees per axis, of each distinct triple."""
+    mult90 = [0, np.pi / 2, -np.pi / 2, np.pi]
+    rots = []
+    for e in itertools.product(mult90, repeat=3):
+        canonical = np.round(_mat2euler(_quat2mat(euler2quat(np.array(e)))) / (np.pi / 2))
+        if canonical[0] == -2:
+            canonical[0] = 2
+        if canonical[2] == -2:
+            canonical[2] = 2
+        canonical = canonical * (np.pi / 2)
+        if all((canonical != r).any() for r in rots):
+            rots.append(canonical)
+    assert len(rots) == 24
+    return [euler2quat(r) for r in rots]
+
+
+# ---- reset / goal sampling (draw-for-draw) ------------------------------------------------------------------------------
+def sample_reset_object_pose(np_random, initial_pos, initial_quat, target_position, target_rotation, pquats=None,
+                             randomize_initial_rotation=True, randomize_initial_position=True):
+    """manipulate.py:170-203 (MujocoManipulateEnv._reset_sim): object pose before the settle steps."""
+    pos, quat = np.array(initial_pos, dtype=np.float64), np.array(initial_quat, dtype=np.float64)
+    if randomize_initial_rotation:
+        if target_rotation == "z":
+            angle = np_random.uniform(-np.pi, np.pi)
+            quat = quat_mul(quat, quat_from_angle_and_axis(angle, np.array([0.0, 0.0, 1.0])))
+        elif target_rotation == "parallel":
+            angle = np_random.uniform(-np.pi, np.pi)
+            z_quat = quat_from_angle_and_axis(angle, np.array([0.0, 0.0, 1.0]))
+            parallel_quat = pquats[np_random.integers(len(pquats))]
+            quat = quat_mul(quat, quat_mul(z_quat, parallel_quat))
+        elif target_rotation in ("xyz", "ignore"):
+            angle = np_random.uniform(-np.pi, np.pi)
+            axis = np_random.uniform(-1.0, 1.0, size=3)
+            quat = quat_mul(quat, quat_from_angle_and_axis(angle, axis))
+        elif target_rotation != "fixed":
+            raise ValueError(f'Unknown target_rotation option "{target_rotation}".')
+    if randomize_initial_position and target_position != "fixed":
+        pos = pos + np_random.normal(size=3, scale=0.005)
+    quat = quat / np.linalg.norm(quat)
+    return np.concatenate([pos, quat])
+
+
+def sample_block_goal(np_random, object_qpos, target_position, target_rotation, pquats=None):
+    """manipulate.py:226-279 (_sample_goal) from the object's CURRENT pose (after the settle steps)."""
+    object_qpos = np.asarray(object_qpos, dtype=np.float64)
+    if target_position == "random":
+        offset = np_random.uniform(TARGET_POSITION_RANGE[:, 0], TARGET_POSITION_RANGE[:, 1])
+        target_pos = object_qpos[:3] + offset
+    elif target_position in ("ignore", "fixed"):
+        target_pos = object_qpos[:3].copy()
+    else:
+        raise ValueError(f'Unknown target_position option "{target_position}".')
+    if target_rotation == "z":
+        target_quat = quat_from_angle_and_axis(np_random.uniform(-np.pi, np.pi), np.array([0.0, 0.0, 1.0]))
+    elif target_rotation == "parallel":
+        target_quat = quat_from_angle_and_axis(np_random.uniform(-np.pi, np.pi), np.array([0.0, 0.0, 1.0]))
+        target_quat = quat_mul(target_quat, pquats[np_random.integers(len(pquats))])
+    elif target_rotation == "xyz":
+        angle = np_random.uniform(-np.pi, np.pi)
+        axis = np_random.uniform(-1.0, 1.0, size=3)
+        target_quat = quat_from_angle_and_axis(angle, axis)
+    else:
+        # 'ignore' / 'fixed' call data.get_joint_qpos, which the mujoco bindings do not have (manipulate.py:270): no registered id
+        raise ValueError(f'Unknown target_rotation option "{target_rotation}".')
+    target_quat = target_quat / np.linalg.norm(target_quat)
+    return np.concatenate([target_pos, target_quat])
+
+
+def block_goal_distance(goal_a, goal_b, target_position, target_rotation):
+    """manipulate.py:87-118 (without the ignore_z special case, which only the pen variants use)."""
+    goal_a, goal_b = np.asarray(goal_a, dtype=np.float64), np.asarray(goal_b, dtype=np.float64)
+    d_pos = np.zeros_like(goal_a[..., 0])
+    d_rot = np.zeros_like(goal_b[..., 0])
+    if target_position != "ignore":
+        d_pos = np.linalg.norm(goal_a[..., :3] - goal_b[..., :3], axis=-1)
+    if target_rotation != "ignore":
+        w = quat_mul(goal_a[..., 3:], quat_conj(goal_b[..., 3:]))[..., 0]
+        d_rot = 2 * np.arccos(np.clip(w, -1.0, 1.0))
+    return d_pos, d_rot
+
+
+def block_is_success(achieved, desired, target_position, target_rotation):
+    d_pos, d_rot = block_goal_distance(achieved, desired, target_position, target_rotation)
+    return ((d_pos < DISTANCE_THRESHOLD) & (d_rot < ROTATION_THRESHOLD)).astype(np.float32)
+
+
+def block_reward(achieved, desired, target_position, target_rotation, reward_type):
+    """manipulate.py:120-128."""
+    if reward_type == "sparse":
+        return block_is_success(achieved, desired, target_position, target_rotation) - 1.0
+    d_pos, d_rot = block_goal_distance(achieved, desired, target_position, target_rotation)
+    return -(10.0 * d_pos + d_rot)
+
+
+# ---- C struct (GrxHandTask with kind = 1, csrc/grx_hand_task.h) ------------------------------------------------------------
+def make_block_task(model, target_position, target_rotation, reward_type):
+    from .hand_spec import HandTaskStruct
+
+    t = HandTaskStruct()
+    t.n_substeps, t.sparse_reward = N_SUBSTEPS, int(reward_type == "sparse")
+    t.palm_body = int(model.names["body"]["robot0:palm"])
+    t.distance_threshold, t.rotation_threshold = DISTANCE_THRESHOLD, ROTATION_THRESHOLD
+    j = int(model.names["joint"]["object:joint"])
+    t.kind, t.nq_robot = 1, 24
+    t.obj_qadr = int(np.asarray(model.tables["jnt_qposadr"]).reshape(-1)[j])
+    t.obj_dadr = int(np.asarray(model.tables["jnt_dofadr"]).reshape(-1)[j])
+    t.ignore_position, t.ignore_rotation = int(target_position == "ignore"), int(target_rotation == "ignore")
+    robot = [n for n in model.names["joint"] if n.startswith("robot")]
+    assert len(robot) == t.nq_robot and max(model.names["joint"][n] for n in robot) == t.nq_robot - 1  # robot joints come first
+    return t

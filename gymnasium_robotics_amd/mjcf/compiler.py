@@ -53,7 +53,7 @@ MJ_MINVAL = 1e-15
 DIMS = [
     "nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "nmocap", "neq", "npair",
     "nmeshvert", "nmeshadj", "integrator", "iterations", "cone", "noslip_iterations",
-    "eulerdamp", "ntree", "maxdepth",
+    "eulerdamp", "ntree", "maxdepth", "maxefc_req", "jpool_req",
 ]
 NDIMS = 32
 OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia"]
@@ -337,7 +337,7 @@ def load_model(path: str) -> CompiledModel:
 # the compiler
 # ----------------------------------------------------------------------------
 class MjcfCompiler:
-    def __init__(self, xml_path: str, mutate=None):
+    def __init__(self, xml_path: str, mutate=None, capacity=None):
         """mutate: optional callable(root_element) applied after <include> expansion, before compilation -- the
         in-memory equivalent of the reference's Maze.make_maze XML rewrite (envs/maze/maze_v4.py:168-242)."""
         self.xml_path = os.path.abspath(xml_path)
@@ -345,6 +345,7 @@ class MjcfCompiler:
         self.root = _load_xml(self.xml_path)
         if mutate is not None:
             mutate(self.root)
+        self.capacity = dict(capacity or {})   # engine row-table / Jacobian-pool capacities requested for this model (0 = default)
         self.defaults = _Defaults()
         self.angle_scale = np.pi / 180.0  # MJCF default angle unit is degree
         self.eulerseq = "xyz"
@@ -1292,7 +1293,8 @@ class _Lowering:
                     npair=npair, nmeshvert=len(mesh_vert), nmeshadj=len(mesh_adj),
                     integrator=c.opt["integrator"], iterations=c.opt["iterations"], cone=c.opt["cone"],
                     noslip_iterations=c.opt["noslip_iterations"], eulerdamp=c.opt["eulerdamp"],
-                    ntree=int(np.sum(body_parent[1:] == 0)), maxdepth=int(body_depth.max()))
+                    ntree=int(np.sum(body_parent[1:] == 0)), maxdepth=int(body_depth.max()),
+                    maxefc_req=int(c.capacity.get("maxefc", 0)), jpool_req=int(c.capacity.get("jpool", 0)))
         for k, v in vals.items():
             dims[DIMS.index(k)] = v
         optv = np.zeros(NOPTS)
@@ -1443,5 +1445,6 @@ class _Lowering:
         return CompiledModel(T, names, info)
 
 
-def compile_mjcf(xml_path: str, mutate=None) -> CompiledModel:
-    return MjcfCompiler(xml_path, mutate=mutate).compile()
+def compile_mjcf(xml_path: str, mutate=None, capacity=None) -> CompiledModel:
+    """capacity: optional {"maxefc": rows, "jpool": words} request for the engine's per-world constraint tables."""
+    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity).compile()

@@ -80,12 +80,16 @@ typedef struct grx_hand_task {
   int site[5];   /* fingertip sites, envs/shadow_dexterous_hand/reach.py:8-14 order */
   int palm_body; /* body used by _sample_goal (reach.py:413-416) */
   float distance_threshold;
+  int kind;      /* 0 = HandReach (goal dim 15, obs nq+nv+15); 1 = HandManipulate* (goal dim 7, obs 2 nq_robot + 6 + 7) */
+  int nq_robot, obj_qadr, obj_dadr;      /* kind 1: robot joints come first; qpos / dof address of object:joint */
+  int ignore_position, ignore_rotation;  /* kind 1: target_position / target_rotation == "ignore" (manipulate.py:92-97) */
+  float rotation_threshold;              /* kind 1: manipulate.py:33 */
 } grx_hand_task;
 typedef struct grx_hand_buffers {
   float *qpos, *qvel, *qacc_ws; /* [N,nq] [N,nv] [N,nv] */
-  const float* goal;            /* [N,15] */
+  const float* goal;            /* [N,goal_dim] */
   const float* action;          /* [N,nu] (may be NULL when forward_only) */
-  float *obs, *achieved;        /* [N,nq+nv+15] [N,15] */
+  float *obs, *achieved;        /* [N,obs_dim] [N,goal_dim] */
   float* palm;                  /* [N,3] */
   float* reward;                /* [N] */
   unsigned char* success;       /* [N] */
@@ -117,6 +121,9 @@ int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t
 int grx_hand_step(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int forward_only, void* stream);
 int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
                             float* reward_out, void* stream);
+/* batched MujocoManipulateEnv.compute_reward on 7-vector pose goals (shadow_dexterous_hand/manipulate.py:87-142) */
+int grx_manip_compute_reward(const float* achieved, const float* desired, int64_t batch, int ignore_position, int ignore_rotation,
+                             float distance_threshold, float rotation_threshold, int sparse, float* reward_out, void* stream);
 
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's

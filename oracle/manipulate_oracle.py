@@ -1,0 +1,73 @@
+"""Single-world fp64 HandManipulateBlock environment on the C oracle -- TEST INFRASTRUCTURE ONLY.
+
+Restates /root/reference/gymnasium_robotics/envs/robot_env.py:114-182 (step / reset loop), shadow_dexterous_hand/hand_env.py:36-58
+(_set_action) and manipulate.py:144-316 (MujocoManipulateEnv: _reset_sim with the pose randomisation, ten settle steps and the
+on-palm test; _sample_goal; _get_obs; reward).  The model is compiled WITHOUT the visual-only target body (manipulate_spec.drop_target_body).
+Note the reference's _reset_sim does not call mj_resetData (manipulate.py:154-161): warm start and ctrl survive a reset.
+"""
+import numpy as np
+
+from gymnasium_robotics_amd.envs.manipulate_spec import (N_SUBSTEPS, PALM_HEIGHT, SETTLE_STEPS, block_is_success, block_reward, canonical_parallel_quats,
+                                                         sample_block_goal, sample_reset_object_pose)
+
+from .oracle_sim import OracleSim
+
+
+class OracleHandBlockEnv:
+    def __init__(self, model, target_position="ignore", target_rotation="xyz", reward_type="sparse"):
+        self.sim, self.model = OracleSim(model), model
+        self.target_position, self.target_rotation, self.reward_type = target_position, target_rotation, reward_type
+        self.pquats = canonical_parallel_quats()
+        self.ctrlrange = np.array(model.tables["act_ctrlrange"], dtype=np.float64).reshape(-1, 2)
+        j = int(model.names["joint"]["object:joint"])
+        self.qa = int(np.asarray(model.tables["jnt_qposadr"]).reshape(-1)[j])
+        self.da = int(np.asarray(model.tables["jnt_dofadr"]).reshape(-1)[j])
+        self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(None)))
+        s = self.sim
+        s.reset_data()
+        s.forward()                                      # _env_setup with initial_qpos = {} (manipulate.py:149-152)
+        self.initial_qpos, self.initial_qvel = s.qpos.copy(), s.qvel.copy()
+        self.goal = np.concatenate([s.qpos[self.qa: self.qa + 3], [1.0, 0.0, 0.0, 0.0]])
+
+    def _set_action(self, action):
+        a = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0)
+        half, centre = (self.ctrlrange[:, 1] - self.ctrlrange[:, 0]) / 2.0, (self.ctrlrange[:, 1] + self.ctrlrange[:, 0]) / 2.0
+        self.sim.ctrl[:] = np.clip(centre + a * half, self.ctrlrange[:, 0], self.ctrlrange[:, 1])
+
+    def _obs(self):
+        s = self.sim
+        ag = s.qpos[self.qa: self.qa + 7].copy()
+        return {"observation": np.concatenate([s.qpos[:24], s.qvel[:24], s.qvel[self.da: self.da + 6], ag]), "achieved_goal": ag,
+                "desired_goal": self.goal.copy()}
+
+    def _reset_sim(self):
+        s = self.sim
+        s.qpos[:] = self.initial_qpos
+        s.qvel[:] = self.initial_qvel
+        s.forward()
+        pose = sample_reset_object_pose(self.np_random, s.qpos[self.qa: self.qa + 3], s.qpos[self.qa + 3: self.qa + 7], self.target_position,
+                                        self.target_rotation, self.pquats)
+        s.qpos[self.qa: self.qa + 7] = pose
+        for _ in range(SETTLE_STEPS):
+            self._set_action(np.zeros(20))
+            s.step(N_SUBSTEPS)
+        s.forward()
+        return bool(s.qpos[self.qa + 2] > PALM_HEIGHT)   # site object:center sits at the body origin (manipulate_block.xml:28)
+
+    def reset(self, seed=None):
+        if seed is not None:
+            self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        self.reset_attempts = 0
+        while True:
+            self.reset_attempts += 1
+            if self._reset_sim():
+                break
+        self.goal = sample_block_goal(self.np_random, self.sim.qpos[self.qa: self.qa + 7], self.target_position, self.target_rotation, self.pquats)
+        return self._obs(), {}
+
+    def step(self, action):
+        self._set_action(action)
+        self.sim.step(N_SUBSTEPS)
+        obs = self._obs()
+        info = {"is_success": float(block_is_success(obs["achieved_goal"], self.goal, self.target_position, self.target_rotation))}
+        return obs, block_reward(obs["achieved_goal"], self.goal, self.target_position, self.target_rotation, self.reward_type), False, False, info

@@ -43,7 +43,7 @@ void* emu_create(const int32_t* H, const int32_t* I, const double* F) {
   Emu* e = new Emu();
   grx_pack_model(H, I, F, &e->pm);
   e->m = grx_bind_model(e->pm, e->pm.f.data(), e->pm.i.data());
-  int words = grx_ctx_words(e->m.nq, e->m.nv, e->m.nu, e->m.nbody, e->m.njnt, e->m.ngeom, e->m.nsite, e->m.nmocap, e->m.nfric, e->m.integrator);
+  int words = grx_ctx_words(grx_dims_of(&e->m));
   e->lds.assign((size_t)words + 64, 0.0f);
   grx_ctx_carve(&e->c, e->lds.data(), grx_dims_of(&e->m));
   return e;

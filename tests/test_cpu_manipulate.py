@@ -1,0 +1,85 @@
+"""CPU tests of the HandManipulateBlock family: the restated quaternion / goal-distance helpers against vectors produced by the
+REFERENCE's own utils/rotations.py (tests/golden/ref_rotations.npz, tools/make_reference_vectors.py), the host samplers, and the
+device engine source (lane emulator) against the oracle's teacher-forced fixture."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(__file__)
+REF = os.path.join(HERE, "golden", "ref_rotations.npz")
+GOLDEN = os.path.join(HERE, "golden", "hand_BlockRotateXYZ_teacher.npz")
+
+
+def test_quaternion_helpers_match_reference_vectors():
+    from gymnasium_robotics_amd.envs import manipulate_spec as ms
+
+    g = np.load(REF)
+    assert np.abs(ms.quat_mul(g["qa"], g["qb"]) - g["quat_mul"]).max() < 1e-15
+    assert np.array_equal(ms.quat_conj(g["qa"]), g["quat_conjugate"])
+    assert np.abs(ms.euler2quat(g["euler"]) - g["euler2quat"]).max() < 1e-15
+    assert np.array_equal(np.array(ms.canonical_parallel_quats()), g["parallel_quats"])   # same 24 orientations, same order
+    pose = lambda q: np.concatenate([np.zeros((len(q), 3)), q], axis=1)
+    d_pos, d_rot = ms.block_goal_distance(pose(g["qa"]), pose(g["qb"]), "ignore", "xyz")
+    assert np.abs(d_rot - g["angle_diff"]).max() < 1e-7 and not d_pos.any()
+    assert np.abs(d_rot[8:16] - 2 * np.pi).max() < 1e-6      # antipodal quaternions: the reference reports 2 pi (manipulate.py:113-115)
+    assert ms.block_is_success(pose(g["qa"][:8]), pose(g["qb"][:8]), "ignore", "xyz").all()
+    assert (ms.block_reward(pose(g["qa"]), pose(g["qb"]), "ignore", "xyz", "sparse")[16:] == -1.0).all()
+
+
+def test_ids_and_samplers():
+    from gymnasium_robotics_amd.core import np_random
+    from gymnasium_robotics_amd.envs import manipulate_spec as ms
+
+    assert ms.parse_block_id("HandManipulateBlockRotateXYZ-v1") == ("ignore", "xyz", "sparse")
+    assert ms.parse_block_id("HandManipulateBlockFullDense-v1") == ("random", "xyz", "dense")
+    assert ms.parse_block_id("HandManipulateBlockRotateParallel-v1")[1] == "parallel"
+    with pytest.raises(ValueError):
+        ms.parse_block_id("HandManipulateBlock-v1")
+    pq = ms.canonical_parallel_quats()
+    p0, q0 = np.array([1.0, 0.87, 0.2]), np.array([1.0, 0.0, 0.0, 0.0])
+    for tp, tr in ms.BLOCK_VARIANTS.values():
+        rng = np_random(3)[0]
+        pose = ms.sample_reset_object_pose(rng, p0, q0, tp, tr, pq)
+        assert pose.shape == (7,) and abs(np.linalg.norm(pose[3:]) - 1) < 1e-12 and np.abs(pose[:3] - p0).max() < 0.03
+        if tr == "z":
+            assert abs(pose[4]) < 1e-12 and abs(pose[5]) < 1e-12      # rotation about z only
+        goal = ms.sample_block_goal(rng, pose, tp, tr, pq)
+        assert abs(np.linalg.norm(goal[3:]) - 1) < 1e-12
+        off = goal[:3] - pose[:3]
+        if tp == "random":
+            assert (off >= ms.TARGET_POSITION_RANGE[:, 0]).all() and (off <= ms.TARGET_POSITION_RANGE[:, 1]).all() and off.any()
+        else:
+            assert not off.any()
+    # draw-for-draw: uniform angle, 3 uniform axis components, 3 normals (manipulate.py:187-197)
+    a, b = np_random(5)[0], np_random(5)[0]
+    pose = ms.sample_reset_object_pose(a, p0, q0, "ignore", "xyz", pq)
+    ang, axis, noise = b.uniform(-np.pi, np.pi), b.uniform(-1.0, 1.0, size=3), b.normal(size=3, scale=0.005)
+    assert np.allclose(pose[:3], p0 + noise, atol=0) and np.allclose(pose[3:], ms.quat_from_angle_and_axis(ang, axis), atol=1e-15)
+    assert a.uniform() == b.uniform()
+
+
+def test_emulated_block_step_matches_golden():
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd.envs.hand import load_hand_block_model
+    from gymnasium_robotics_amd.envs.manipulate_spec import make_block_task
+
+    model = load_hand_block_model()
+    assert (model.dim("nq"), model.dim("nv")) == (31, 30)     # hand 24 + free block; the visual target body is not simulated
+    g = np.load(GOLDEN)
+    emu = EmuSim(model, make_block_task(model, "ignore", "xyz", "sparse"))
+    pos_err, vel_err = [], []
+    for i in range(0, g["obs"].shape[0], 3):
+        for k in ("qpos", "qvel", "qacc_ws"):
+            getattr(emu, k)[:] = g[k][i]
+        emu.hand_step(g["action"][i])
+        assert emu.status.value == 0
+        e = np.abs(emu.hand_obs[:61] - g["obs"][i])
+        pe, ve = max(e[:24].max(), e[54:].max()), e[24:54].max()      # positions / pose vs velocities (rad/s, m/s)
+        pos_err.append(pe); vel_err.append(ve)
+        lim = (2e-4, 5e-3) if g["activation_gap"][i] >= 2e-5 else (5e-3, 0.2)
+        assert pe < lim[0] and ve < lim[1], (i, pe, ve, g["activation_gap"][i])
+        assert np.array_equal(emu.hand_achieved[:7], emu.hand_obs[54:61])
+    assert np.median(pos_err) < 1e-5 and np.median(vel_err) < 3e-4
+    assert g["ncon"].max() >= 8 and g["nefc"].max() >= 60      # contact-rich fixture (block held by palm and fingers)

@@ -28,6 +28,14 @@ save_model(m, out)
 print("hand/reach.xml ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "tendons:", len(m.tables["tendon_adr"]),
       "unsupported pairs:", m.info["unsupported_pairs"], f"{os.path.getsize(out) / 1024:.0f} KiB")
 
+from gymnasium_robotics_amd.envs.manipulate_spec import drop_target_body  # noqa: E402
+
+m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block.xml"), mutate=drop_target_body)
+out = os.path.join(OUT, "hand_block.npz")
+save_model(m, out)
+print("hand/manipulate_block.xml (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")},
+      "unsupported pairs:", m.info["unsupported_pairs"], f"{os.path.getsize(out) / 1024:.0f} KiB")
+
 from gymnasium_robotics_amd.envs.maze_spec import MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze  # noqa: E402
 
 for layout in ("UMaze", "Open", "Medium", "Large"):

@@ -49,7 +49,43 @@ def snapshots(episodes=6):
     return out
 
 
+def block_snapshots(variant="HandManipulateBlockRotateXYZ-v1", episodes=6, steps=40):
+    from gymnasium_robotics_amd.envs.hand import load_hand_block_model
+    from gymnasium_robotics_amd.envs.manipulate_spec import parse_block_id
+    from oracle.manipulate_oracle import OracleHandBlockEnv
+
+    tp, tr, rt = parse_block_id(variant)
+    env = OracleHandBlockEnv(load_hand_block_model(), tp, tr, rt)
+    rng = np.random.default_rng(777)
+    rec = {k: [] for k in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "ncon", "nefc", "seed", "t", "activation_gap")}
+    resets = {k: [] for k in ("seed", "obs", "goal", "attempts")}
+    for ep in range(episodes):
+        obs, _ = env.reset(seed=ep)
+        resets["seed"].append(ep); resets["obs"].append(obs["observation"]); resets["goal"].append(obs["desired_goal"]); resets["attempts"].append(env.reset_attempts)
+        for t in range(steps):
+            a = rng.uniform(-1, 1, 20).astype(np.float32)
+            if ep % 2:   # gentle actions keep the block in the hand (more contact-rich snapshots)
+                a = (0.25 * a).astype(np.float32)
+            s = env.sim
+            rec["qpos"].append(s.qpos.copy()); rec["qvel"].append(s.qvel.copy()); rec["qacc_ws"].append(s.qacc_warmstart.copy())
+            rec["goal"].append(env.goal.copy()); rec["action"].append(a)
+            s.min_activation_gap[0] = 1e30
+            obs, r, _, _, info = env.step(a.astype(np.float64))
+            rec["activation_gap"].append(float(s.min_activation_gap[0]))
+            rec["obs"].append(obs["observation"]); rec["achieved"].append(obs["achieved_goal"]); rec["reward"].append(r); rec["success"].append(info["is_success"])
+            rec["ncon"].append(s.ncon); rec["nefc"].append(s.nefc); rec["seed"].append(ep); rec["t"].append(t)
+            assert s.bad_state == 0
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out.update({"reset_" + k: np.asarray(v) for k, v in resets.items()})
+    return out
+
+
 if __name__ == "__main__":
+    d = block_snapshots()
+    path = os.path.join(OUT, "hand_BlockRotateXYZ_teacher.npz")
+    np.savez_compressed(path, **d)
+    print("HandManipulateBlockRotateXYZ", d["obs"].shape, "max nefc", d["nefc"].max(), "max ncon", d["ncon"].max(), "reset attempts", d["reset_attempts"],
+          f"{os.path.getsize(path)/1024:.0f} KiB")
     d = snapshots()
     path = os.path.join(OUT, "hand_HandReach_teacher.npz")
     np.savez_compressed(path, **d)
