@@ -82,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -133,9 +133,9 @@ __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];
 // body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
 // Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
 // body frames, motion axes, M, J, row parameters) is persistent.
-struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool; };
+struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool, ntouch; };
 GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator, int maxefc = GRX_MAXEFC,
-                          int jpool = GRX_JPOOL) {
+                          int jpool = GRX_JPOOL, int ntouch = 0) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
@@ -144,7 +144,9 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
-  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 3 + 6);
+  const int ckeep = ntouch ? GRX_MAXCON * (3 + 3 + 5) : 0;   // touch sensors read the contacts after the solve: keep pos / normal / pair / rows / bodies out of the overlay
+  pers += ckeep;
+  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 3 + 6) - ckeep;
   int p2 = nv * nv + 5 * nv + 4 * maxefc;
   return pers + (p1 > p2 ? p1 : p2) + 8;
 }
@@ -170,6 +172,10 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   CARVEI(efc_kind, m->maxefc) CARVEI(efc_id, m->maxefc) CARVEI(efc_row, m->maxefc)
   CARVEI(ired, 32) CARVEI(cnt, 8)
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
+  if (m->ntouch) {
+    CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 3 * GRX_MAXCON)
+    CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
+  }
   float* overlay = p;
   // ---- P1 (kinematics .. velocity stage)
   {
@@ -186,9 +192,11 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   }
   CARVE(cinert, 10 * m->nbody) CARVE(cdof_dot, 6 * m->nv)
   CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv)
-  CARVE(con_dist, GRX_MAXCON) CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 3 * GRX_MAXCON)  // con_frame: contact normal only
-  CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
-  CARVEI(con_span, GRX_MAXCON)
+  CARVE(con_dist, GRX_MAXCON) CARVEI(con_span, GRX_MAXCON)
+  if (!m->ntouch) {
+    CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 3 * GRX_MAXCON)  // con_frame: contact normal only
+    CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
+  }
   // ---- P2 (solve / integrate) on top of P1
   p = overlay;
   CARVE(A, m->nv * m->nv) CARVE(Ma, m->nv) CARVE(grad, m->nv) CARVE(search, m->nv) CARVE(Mv, m->nv) CARVE(tmpv, m->nv)
@@ -198,10 +206,10 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
 }
 
 GRX_HD GrxDims grx_dims_of(const GrxModel* m) {
-  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool};
+  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool, m->ntouch};
   return d;
 }
-GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool); }
+GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool, d.ntouch); }
 
 // ------------------------------------------------------------------------------------------
 // small math (all per-lane, registers)
@@ -365,9 +373,10 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 // All stages live in a class template so that the dof count can be a compile-time constant (NV > 0: inner loops over
 // dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
 // Model shape: the ten layout dims as compile-time constants (0 = read from the model at run time).
-template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0, int MAXEFC_ = GRX_MAXEFC, int JPOOL_ = GRX_JPOOL>
+template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0, int MAXEFC_ = GRX_MAXEFC, int JPOOL_ = GRX_JPOOL,
+          int NTOUCH_ = 0>
 struct GrxShape {
-  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_, ME = MAXEFC_, JP = JPOOL_;
+  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_, ME = MAXEFC_, JP = JPOOL_, NT = NTOUCH_;
   static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
@@ -1992,6 +2001,67 @@ GRX_MEM void grx_rk4_after_forward(const GrxModel* m, GrxCtx* c, int stage, int 
   }
   WAVE_SYNC();
   grx_integrate_pos(m, c, c->rk_q0, c->tmpv, hh, lane_);
+}
+
+// ------------------------------------------------------------------------------------------
+// K12 touch sensors (MuJoCo mjSENS_TOUCH): out[t] = sum of the normal forces of the active contacts that involve the zone's body
+// and whose ray (from the contact point along the contact normal, flipped when the zone's body is the contact's second body)
+// meets the zone (sphere or box site).  Runs after the constraint solve of the same forward pass (row forces in efc_force).
+// mode 1: raw value, 2: value > 0, 3: log(value + 1)  (manipulate_touch_sensors.py:124-131)
+// ------------------------------------------------------------------------------------------
+GRX_MEM float grx_ray_sphere(const float* p, const float* d, float r) {
+  const float a = dot3f(d, d), b = dot3f(d, p), cc = dot3f(p, p) - r * r, det = b * b - a * cc;
+  if (det < GRX_MINVAL || a < GRX_MINVAL) return -1.0f;
+  const float sq = sqrtf(det), x0 = (-b - sq) / a, x1 = (-b + sq) / a;
+  return x0 >= 0 ? x0 : (x1 >= 0 ? x1 : -1.0f);
+}
+GRX_MEM float grx_ray_box(const float* p, const float* d, const float* sz) {
+  float best = -1.0f;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    if (fabsf(d[i]) < GRX_MINVAL) continue;
+#pragma unroll
+    for (int side = -1; side <= 1; side += 2) {
+      const float t = ((float)side * sz[i] - p[i]) / d[i];
+      if (t >= 0 && fabsf(p[j] + t * d[j]) <= sz[j] && fabsf(p[k] + t * d[k]) <= sz[k] && (best < 0 || t < best)) best = t;
+    }
+  }
+  return best;
+}
+GRX_MEM void grx_touch_sensors(const GrxModel* m, const GrxCtx* c, float* out, int mode, int lane_) {
+  GRX_FRESH_MODEL(m, c);
+  const int ncon = c->cnt[0] < GRX_MAXCON ? c->cnt[0] : GRX_MAXCON, nefc = c->cnt[1];
+  FOR_LANES {
+    for (int t = lane; t < m->ntouch; t += 64) {
+      const int b = m->touch_body[t], type = m->touch_type[t];
+      const float lp[3] = {m->touch_pos[3 * t], m->touch_pos[3 * t + 1], m->touch_pos[3 * t + 2]};
+      const float lq[4] = {m->touch_quat[4 * t], m->touch_quat[4 * t + 1], m->touch_quat[4 * t + 2], m->touch_quat[4 * t + 3]};
+      const float sz[3] = {m->touch_size[3 * t], m->touch_size[3 * t + 1], m->touch_size[3 * t + 2]};
+      float zp[3], zl[9], zR[9], v[3], val = 0.0f;
+      mulMatVec3f(v, c->xmat + 9 * b, lp);
+      for (int k = 0; k < 3; k++) zp[k] = c->xpos[3 * b + k] + v[k];
+      quat2matf(zl, lq); mulMat3f(zR, c->xmat + 9 * b, zl);
+      for (int k = 0; k < ncon; k++) {
+        const int r0 = c->con_efc[k];
+        if (r0 < 0) continue;
+        const int b1 = c->con_b1[k], b2 = c->con_b2[k];
+        if (b != b1 && b != b2) continue;
+        float fn = 0.0f;
+        for (int q = 0; q < c->con_nr[k] && r0 + q < nefc; q++) fn += c->efc_force[r0 + q];
+        if (!(fn > 0.0f)) continue;
+        const float sg = (b == b2) ? -1.0f : 1.0f;
+        const float dw[3] = {sg * c->con_frame[3 * k], sg * c->con_frame[3 * k + 1], sg * c->con_frame[3 * k + 2]};
+        const float pw[3] = {c->con_pos[3 * k] - zp[0], c->con_pos[3 * k + 1] - zp[1], c->con_pos[3 * k + 2] - zp[2]};
+        float pl[3], dl[3];
+        mulMatTVec3f(pl, zR, pw); mulMatTVec3f(dl, zR, dw);
+        const float hit = (type == 2) ? grx_ray_sphere(pl, dl, sz[0]) : grx_ray_box(pl, dl, sz);
+        if (hit >= 0.0f) val += fn;
+      }
+      out[t] = (mode == 2) ? (val > 0.0f ? 1.0f : 0.0f) : (mode == 3 ? logf(val + 1.0f) : val);
+    }
+  }
+  WAVE_SYNC();
 }
 
 GRX_MEM void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {

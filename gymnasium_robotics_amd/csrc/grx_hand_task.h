@@ -23,9 +23,12 @@ struct GrxHandTask {
   int kind, nq_robot, obj_qadr, obj_dadr;
   int ignore_position, ignore_rotation;   // target_position == "ignore" / target_rotation == "ignore" (manipulate.py:92-97)
   float rotation_threshold;
+  int touch_mode;   // 0: no touch values in the observation; 1 sensordata, 2 boolean, 3 log(x+1) (manipulate_touch_sensors.py:124-131)
 };
 GRX_DEV int grx_hand_goal_dim(const GrxHandTask* t) { return t->kind ? 7 : 3 * GRX_HAND_NTIPS; }
-GRX_DEV int grx_hand_obs_dim(const GrxHandTask* t, int nq, int nv) { return t->kind ? 2 * t->nq_robot + 6 + 7 : nq + nv + 3 * GRX_HAND_NTIPS; }
+GRX_DEV int grx_hand_obs_dim(const GrxHandTask* t, int nq, int nv, int ntouch) {
+  return t->kind ? 2 * t->nq_robot + 6 + 7 + (t->touch_mode ? ntouch : 0) : nq + nv + 3 * GRX_HAND_NTIPS;
+}
 
 struct GrxHandBuffers {
   float *qpos, *qvel, *qacc_ws;  // [N,nq] [N,nv] [N,nv]
@@ -81,6 +84,7 @@ struct GrxHand {
         for (int i = lane; i < 3; i += 64) palm[i] = c->xpos[3 * t->palm_body + i];
       }
       WAVE_SYNC();
+      if (t->touch_mode) E::grx_touch_sensors(m, c, obs + 2 * nr + 13, t->touch_mode, lane_);   // same forward pass as the contacts
       return;
     }
     FOR_LANES {

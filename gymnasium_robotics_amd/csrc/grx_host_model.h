@@ -37,7 +37,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.eulerdamp = d[GRX_EULERDAMP]; m.ndevpair = v.n_devpair; m.nmpair = v.n_mpair_i;
   m.integrator = d[GRX_INTEGRATOR];
   m.njump = m.nbody > 0 ? v.n_body_jump / m.nbody : 0;
-  m.ntendon = v.n_tendon_adr;
+  m.ntendon = v.n_tendon_adr; m.ntouch = v.n_touch_body;
   m.nfric = 0; m.nweld = 0; m.wpool = 0;
   for (int k = 0; k < v.n_weld_row; k++) m.wpool += 6 * ((v.weld_row[k] >> 20) & 0xFF);
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;

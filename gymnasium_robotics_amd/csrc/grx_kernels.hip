@@ -64,18 +64,19 @@ extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)h
 // into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs) and the loops over
 // dofs / bodies / joints unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
 template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(const GrxModel& m) {
-  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP};
+  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP, S::NT};
   return grx_dims_of(&m);
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP;
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT;
 }
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1> GrxShapeFetchArm;    // FetchReach (arm only)
 typedef GrxShape<24, 24, 20, 25, 24, 23, 20, 0, 24> GrxShapeHandReach;  // Shadow hand, reach.xml (24 hinges, 24 friction-loss dofs)
 typedef GrxShape<31, 30, 20, 26, 25, 24, 11, 0, 24> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
+typedef GrxShape<31, 30, 20, 26, 25, 24, 11, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
 template <class S>
 __global__ void __launch_bounds__(64, 2)
@@ -185,7 +186,7 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
   for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
   __syncthreads();
-  const int od = grx_hand_obs_dim(&t, nq, nv), gd = grx_hand_goal_dim(&t);
+  const int od = grx_hand_obs_dim(&t, nq, nv, m.ntouch), gd = grx_hand_goal_dim(&t);
   float* obs = b.obs + (size_t)w * od; float* ach = b.achieved + (size_t)w * gd; float* palm = b.palm + (size_t)w * 3;
   if (forward_only) {
     GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
@@ -323,6 +324,7 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   if (grx_shape_matches<GrxShapeHandReach>(g)) { m->shape = 4; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandReach>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  if (grx_shape_matches<GrxShapeHandBlockTouch>(g)) { m->shape = 6; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandBlockTouch>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   if (grx_shape_matches<GrxShapeHandBlock>(g)) { m->shape = 5; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   for (int k = 0; k < GRX_MAX_MODELS && m->slot < 0; k++) if (!g_slot_used[k]) { g_slot_used[k] = 1; m->slot = k; }
   if (m->slot < 0) return fail("grx_model_create: all model descriptor slots are in use (destroy a model first)");
@@ -426,12 +428,14 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   if (t.kind) {
     if (t.nq_robot <= 0 || t.nq_robot > m->dev.nv || t.obj_qadr < 0 || t.obj_qadr + 7 > m->dev.nq || t.obj_dadr < 0 || t.obj_dadr + 6 > m->dev.nv)
       return fail("grx_hand_step: object joint addresses out of range");
+    if (t.touch_mode && m->dev.ntouch == 0) return fail("grx_hand_step: touch_mode set but the model has no touch sensors");
   } else
     for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
   const dim3 grid(n_worlds), block(64);
   const size_t lds_bytes = (size_t)m->words * 4;
-  if (m->shape == 5) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlock>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  if (m->shape == 6) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlockTouch>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  else if (m->shape == 5) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlock>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   else if (m->shape == 4) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandReach>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   else hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   HIP_OK(hipGetLastError());

@@ -248,21 +248,23 @@ class HandReachVecEnv(GoalVecEnv):
             pass
 
 
-def load_hand_block_model(assets_root: Optional[str] = None) -> CompiledModel:
-    """hand/manipulate_block.xml without its visual-only target body (manipulate_spec.drop_target_body)."""
-    from .manipulate_spec import drop_target_body
+def load_hand_block_model(assets_root: Optional[str] = None, touch: bool = False) -> CompiledModel:
+    """hand/manipulate_block[_touch_sensors].xml without its visual-only target body (manipulate_spec.drop_target_body); with
+    touch=True the 92 'robot0:TS_*' touch zones are compiled into the touch_* tables."""
+    from .manipulate_spec import drop_target_body, touch_filter
 
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
-        return compile_mjcf(os.path.join(assets_root, "hand", "manipulate_block.xml"), mutate=drop_target_body)
-    path = os.path.join(_MODELS_DIR, "hand_block.npz")
+        xml = "manipulate_block_touch_sensors.xml" if touch else "manipulate_block.xml"
+        return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None)
+    path = os.path.join(_MODELS_DIR, "hand_block_touch.npz" if touch else "hand_block.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")
     return load_model(path)
 
 
 class HandBlockVecEnv(HandReachVecEnv):
-    """Batched HandManipulateBlock{RotateZ, RotateParallel, RotateXYZ, Full}[Dense]-v1
+    """Batched HandManipulateBlock{RotateZ, RotateParallel, RotateXYZ, Full}[_ContinuousTouchSensors | _BooleanTouchSensors][Dense]-v1
     (/root/reference/gymnasium_robotics/envs/shadow_dexterous_hand/manipulate.py: MujocoManipulateEnv; manipulate_block.py:214-230).
     Observation 61 = 24 robot joint positions | 24 velocities | object velocity 6 | object pose 7; goals are 7-vector poses.
     The visual-only, non-colliding `target` body of the MJCF is not simulated (its state is not observable through the env API)."""
@@ -275,20 +277,22 @@ class HandBlockVecEnv(HandReachVecEnv):
     def _parse_id(self, env_id, reward_type):
         from .manipulate_spec import canonical_parallel_quats, parse_block_id
 
-        self.target_position, self.target_rotation, rt = parse_block_id(env_id)
+        self.target_position, self.target_rotation, rt, self.touch_get_obs = parse_block_id(env_id)
         self.reward_type = reward_type or rt
         self._pquats = canonical_parallel_quats()
 
     def _load_model(self, assets_root):
-        return load_hand_block_model(assets_root)
+        return load_hand_block_model(assets_root, touch=self.touch_get_obs != "off")
 
     def _make_task(self):
         from .manipulate_spec import make_block_task
 
-        return make_block_task(self.model, self.target_position, self.target_rotation, self.reward_type)
+        return make_block_task(self.model, self.target_position, self.target_rotation, self.reward_type, self.touch_get_obs)
 
     def _obs_dim(self):
-        return 2 * 24 + 6 + 7
+        from .manipulate_spec import N_TOUCH
+
+        return 2 * 24 + 6 + 7 + (N_TOUCH if self.touch_get_obs != "off" else 0)   # 61, or 153 with touch (manipulate_touch_sensors.py:113-137)
 
     def _env_setup(self):
         # manipulate.py:149-152 with initial_qpos = {}: the model's qpos0

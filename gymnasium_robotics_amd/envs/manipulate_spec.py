@@ -19,14 +19,28 @@ BLOCK_VARIANTS = {
 }
 
 
+TOUCH_MODES = {"off": 0, "sensordata": 1, "boolean": 2, "log": 3}   # manipulate_touch_sensors.py:36-41, 124-131
+N_TOUCH = 92
+
+
+def touch_filter(sensor_name: str) -> bool:
+    """The sensors the touch envs read: names containing 'robot0:TS_' (manipulate_touch_sensors.py:66-81)."""
+    return "robot0:TS_" in sensor_name
+
+
 def parse_block_id(env_id: str):
-    """'HandManipulateBlockRotateXYZ-v1', '...Dense-v1' -> (target_position, target_rotation, reward_type)."""
+    """'HandManipulateBlockRotateXYZ-v1', '..._ContinuousTouchSensors-v1', '..._BooleanTouchSensorsDense-v1', ... ->
+    (target_position, target_rotation, reward_type, touch_get_obs)   (gymnasium_robotics/__init__.py:124-341)."""
     name, _, version = env_id.rpartition("-")
     dense = name.endswith("Dense")
     base = name[:-5] if dense else name
+    touch = "off"
+    for suffix, mode in (("_ContinuousTouchSensors", "sensordata"), ("_BooleanTouchSensors", "boolean")):
+        if base.endswith(suffix):
+            base, touch = base[: -len(suffix)], mode
     if version != "v1" or base not in BLOCK_VARIANTS:
         raise ValueError(f"unknown HandManipulateBlock id {env_id!r}")
-    return (*BLOCK_VARIANTS[base], "dense" if dense else "sparse")
+    return (*BLOCK_VARIANTS[base], "dense" if dense else "sparse", touch)
 
 
 def drop_target_body(root):
@@ -181,7 +195,7 @@ def block_reward(achieved, desired, target_position, target_rotation, reward_typ
 
 
 # ---- C struct (GrxHandTask with kind = 1, csrc/grx_hand_task.h) ------------------------------------------------------------
-def make_block_task(model, target_position, target_rotation, reward_type):
+def make_block_task(model, target_position, target_rotation, reward_type, touch_get_obs="off"):
     from .hand_spec import HandTaskStruct
 
     t = HandTaskStruct()
@@ -193,6 +207,9 @@ def make_block_task(model, target_position, target_rotation, reward_type):
     t.obj_qadr = int(np.asarray(model.tables["jnt_qposadr"]).reshape(-1)[j])
     t.obj_dadr = int(np.asarray(model.tables["jnt_dofadr"]).reshape(-1)[j])
     t.ignore_position, t.ignore_rotation = int(target_position == "ignore"), int(target_rotation == "ignore")
+    t.touch_mode = TOUCH_MODES[touch_get_obs]
+    if t.touch_mode and len(model.tables["touch_body"]) != N_TOUCH:
+        raise ValueError("touch observations need the model compiled with its 92 touch zones")
     robot = [n for n in model.names["joint"] if n.startswith("robot")]
     assert len(robot) == t.nq_robot and max(model.names["joint"][n] for n in robot) == t.nq_robot - 1  # robot joints come first
     return t

@@ -337,7 +337,7 @@ def load_model(path: str) -> CompiledModel:
 # the compiler
 # ----------------------------------------------------------------------------
 class MjcfCompiler:
-    def __init__(self, xml_path: str, mutate=None, capacity=None):
+    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None):
         """mutate: optional callable(root_element) applied after <include> expansion, before compilation -- the
         in-memory equivalent of the reference's Maze.make_maze XML rewrite (envs/maze/maze_v4.py:168-242)."""
         self.xml_path = os.path.abspath(xml_path)
@@ -345,6 +345,7 @@ class MjcfCompiler:
         self.root = _load_xml(self.xml_path)
         if mutate is not None:
             mutate(self.root)
+        self.touch_filter = touch_filter      # callable(sensor name) -> bool: which <touch> sensors the engine evaluates
         self.capacity = dict(capacity or {})   # engine row-table / Jacobian-pool capacities requested for this model (0 = default)
         self.defaults = _Defaults()
         self.angle_scale = np.pi / 180.0  # MJCF default angle unit is degree
@@ -1013,7 +1014,31 @@ class _Lowering:
                 geom_rbound[gi] = np.hypot(s[0], s[1])
             elif g.type in (GEOM_BOX, GEOM_ELLIPSOID):
                 geom_rbound[gi] = np.linalg.norm(s) if g.type == GEOM_BOX else s.max()
-        sites = [(i, s) for i in range(nb) for s in B[i].sites]
+        # touch sensors selected by touch_filter: their zones (sites) go to the touch_* tables, in sensor order, and are left out of
+        # the engine's site tables (92 zones x 12 words of world frames per world would not pay for themselves in LDS)
+        touch_sel = []
+        if c.touch_filter is not None:
+            for sec in c.root.findall("sensor"):
+                for e in sec.findall("touch"):
+                    if c.touch_filter(e.attrib.get("name", "")):
+                        touch_sel.append((e.attrib.get("name", ""), e.attrib["site"]))
+        touch_sites = {sn for _, sn in touch_sel}
+        all_sites = {s.name: (i, s) for i in range(nb) for s in B[i].sites if s.name}
+        nt = len(touch_sel)
+        touch_body, touch_type = np.zeros(nt, np.int32), np.zeros(nt, np.int32)
+        touch_pos, touch_quat, touch_size = np.zeros((nt, 3)), np.zeros((nt, 4)), np.zeros((nt, 3))
+        for ti, (sname, site_name) in enumerate(touch_sel):
+            i, sdef = all_sites[site_name]
+            if sdef.type not in (GEOM_SPHERE, GEOM_BOX):
+                raise NotImplementedError("touch zones: sphere and box sites only")
+            k, p, q = anchor_of(i)
+            touch_body[ti], touch_type[ti] = new_id[k], sdef.type
+            touch_pos[ti] = p + mu.rot_vec(q, sdef.pos)
+            touch_quat[ti] = mu.quat_normalize(mu.quat_mul(q, sdef.quat))
+            touch_size[ti] = sdef.size
+        T.update(touch_body=touch_body, touch_type=touch_type, touch_pos=touch_pos, touch_quat=touch_quat, touch_size=touch_size)
+        names["touch"] = {sname: ti for ti, (sname, _) in enumerate(touch_sel)}
+        sites = [(i, s) for i in range(nb) for s in B[i].sites if s.name not in touch_sites]
         ns = len(sites)
         site_bodyid = np.zeros(ns, np.int32)
         site_type = np.zeros(ns, np.int32)
@@ -1445,6 +1470,7 @@ class _Lowering:
         return CompiledModel(T, names, info)
 
 
-def compile_mjcf(xml_path: str, mutate=None, capacity=None) -> CompiledModel:
-    """capacity: optional {"maxefc": rows, "jpool": words} request for the engine's per-world constraint tables."""
-    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity).compile()
+def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None) -> CompiledModel:
+    """capacity: optional {"maxefc": rows, "jpool": words} request for the engine's per-world constraint tables.
+    touch_filter: optional callable(sensor name) selecting the <touch> sensors the engine evaluates."""
+    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter).compile()

@@ -84,6 +84,7 @@ typedef struct grx_hand_task {
   int nq_robot, obj_qadr, obj_dadr;      /* kind 1: robot joints come first; qpos / dof address of object:joint */
   int ignore_position, ignore_rotation;  /* kind 1: target_position / target_rotation == "ignore" (manipulate.py:92-97) */
   float rotation_threshold;              /* kind 1: manipulate.py:33 */
+  int touch_mode; /* kind 1: 0 none, 1 sensordata, 2 boolean, 3 log(x+1): touch values appended to the observation (manipulate_touch_sensors.py:113-137) */
 } grx_hand_task;
 typedef struct grx_hand_buffers {
   float *qpos, *qvel, *qacc_ws; /* [N,nq] [N,nv] [N,nv] */

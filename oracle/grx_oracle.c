@@ -56,6 +56,7 @@ typedef struct orc_sim {
   double *subtree_com, *subtree_mass, *cinert /*36/body*/, *crb /*36/body*/, *cdof /*6/dof*/, *cdof_dot;
   double *M, *L /*dense chol of M (reverse order)*/, *cvel, *cacc, *cfrc;
   double *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc, *act_force;
+  double* touch; /* one value per touch sensor of the touch_* tables */
   /* constraints */
   int ncon, nefc, ne, nf, nl, ntl /* tendon-limit rows among the nl limit rows */;
   orc_contact con[MAXCON];
@@ -133,7 +134,7 @@ orc_sim* orc_create(const int32_t* H, int nH, const int32_t* I, int nI, const do
   s->xpos = ALLOC(3 * nb); s->xquat = ALLOC(4 * nb); s->xmat = ALLOC(9 * nb); s->xipos = ALLOC(3 * nb);
   s->xanchor = ALLOC(3 * s->njnt); s->xaxis = ALLOC(3 * s->njnt);
   s->geom_xpos = ALLOC(3 * s->ngeom); s->geom_xmat = ALLOC(9 * s->ngeom);
-  s->site_xpos = ALLOC(3 * s->nsite); s->site_xmat = ALLOC(9 * s->nsite);
+  s->site_xpos = ALLOC(3 * s->nsite); s->site_xmat = ALLOC(9 * s->nsite); s->touch = ALLOC(s->m.n_touch_body);
   s->subtree_com = ALLOC(3 * nb); s->subtree_mass = ALLOC(nb); s->cinert = ALLOC(36 * nb); s->crb = ALLOC(36 * nb);
   s->cdof = ALLOC(6 * nv); s->cdof_dot = ALLOC(6 * nv); s->M = ALLOC(nv * nv); s->L = ALLOC(nv * nv);
   s->cvel = ALLOC(6 * nb); s->cacc = ALLOC(6 * nb); s->cfrc = ALLOC(6 * nb);
@@ -1167,6 +1168,56 @@ static int bad_number(const double* x, int n, double maxval) {
   return 0;
 }
 
+/* distance along the ray (origin p, direction d, both in the zone frame) to a sphere of radius r / a box of half sizes sz, or -1
+ * (restating MuJoCo's mju_rayGeom for the two zone types in scope: nearest non-negative root; an origin inside the zone hits) */
+static double ray_sphere(const double* p, const double* d, double r) {
+  double a = dot3(d, d), b = dot3(d, p), c = dot3(p, p) - r * r, det = b * b - a * c;
+  if (det < MINVAL || a < MINVAL) return -1;
+  double sq = sqrt(det), x0 = (-b - sq) / a, x1 = (-b + sq) / a;
+  return x0 >= 0 ? x0 : (x1 >= 0 ? x1 : -1);
+}
+static double ray_box(const double* p, const double* d, const double* sz) {
+  double best = -1;
+  for (int i = 0; i < 3; i++) {
+    if (fabs(d[i]) < MINVAL) continue;
+    for (int side = -1; side <= 1; side += 2) {
+      double t = (side * sz[i] - p[i]) / d[i];
+      if (t < 0) continue;
+      int j = (i + 1) % 3, k = (i + 2) % 3;
+      if (fabs(p[j] + t * d[j]) <= sz[j] && fabs(p[k] + t * d[k]) <= sz[k] && (best < 0 || t < best)) best = t;
+    }
+  }
+  return best;
+}
+
+/* touch sensors (MuJoCo mjSENS_TOUCH [3P]): sum of the normal forces of the active contacts that involve the zone's body and
+ * whose ray (from the contact point along the contact normal, flipped when the zone's body is the second one) meets the zone */
+static void touch_sensors(orc_sim* s) {
+  const grx_model_view* m = &s->m;
+  for (int t = 0; t < m->n_touch_body; t++) {
+    int b = m->touch_body[t];
+    double zp[3], zq[4], zR[9], v[3], val = 0;
+    mulMatVec3(v, s->xmat + 9 * b, m->touch_pos + 3 * t);
+    for (int k = 0; k < 3; k++) zp[k] = s->xpos[3 * b + k] + v[k];
+    mulQuat(zq, s->xquat + 4 * b, m->touch_quat + 4 * t); normalize4(zq); quat2mat(zR, zq);
+    for (int c = 0; c < s->ncon; c++) {
+      const orc_contact* con = &s->con[c];
+      int b1 = m->geom_bodyid[con->geom1], b2 = m->geom_bodyid[con->geom2];
+      if (con->efc_address < 0 || (b != b1 && b != b2)) continue;
+      int nr = con->dim == 1 ? 1 : 2 * (con->dim - 1);
+      double fn = 0;
+      for (int k = 0; k < nr && con->efc_address + k < s->nefc; k++) fn += s->efc_force[con->efc_address + k];
+      if (fn <= 0) continue;
+      double sg = (b == b2) ? -1.0 : 1.0, dw[3] = {sg * con->frame[0], sg * con->frame[1], sg * con->frame[2]};
+      double pw[3] = {con->pos[0] - zp[0], con->pos[1] - zp[1], con->pos[2] - zp[2]}, pl[3], dl[3];
+      mulMatTVec3(pl, zR, pw); mulMatTVec3(dl, zR, dw);
+      double hit = m->touch_type[t] == GRX_GEOM_SPHERE ? ray_sphere(pl, dl, m->touch_size[3 * t]) : ray_box(pl, dl, m->touch_size + 3 * t);
+      if (hit >= 0) val += fn;
+    }
+    s->touch[t] = val;
+  }
+}
+
 /* restates mj_forward [3P] */
 void orc_forward(orc_sim* s) {
   int nv = s->nv;
@@ -1200,6 +1251,8 @@ void orc_forward(orc_sim* s) {
     solve_newton(s);
   }
   memcpy(s->qacc_warmstart, s->qacc, sizeof(double) * (size_t)nv);
+  if (s->nefc == 0) memset(s->efc_force, 0, sizeof(s->efc_force));
+  touch_sensors(s);
 }
 
 /* restates mj_Euler [3P]: implicit joint damping */
@@ -1289,7 +1342,7 @@ double* orc_ptr(orc_sim* s, const char* name) {
   P(qpos) P(qvel) P(ctrl) P(mocap_pos) P(mocap_quat) P(qacc_warmstart) P(xpos) P(xquat) P(xmat) P(xipos) P(geom_xpos)
   P(geom_xmat) P(site_xpos) P(site_xmat) P(subtree_com) P(cdof) P(cdof_dot) P(M) P(cvel) P(qfrc_bias) P(qfrc_passive)
   P(qfrc_actuator) P(qfrc_smooth) P(qacc_smooth) P(qfrc_constraint) P(qacc) P(efc_J) P(efc_pos) P(efc_margin) P(efc_D)
-  P(efc_R) P(efc_aref) P(efc_force) P(efc_vel) P(efc_diagApprox)
+  P(efc_R) P(efc_aref) P(efc_force) P(efc_vel) P(efc_diagApprox) P(touch)
 #undef P
   if (!strcmp(name, "time")) return &s->time;
   if (!strcmp(name, "min_activation_gap")) return &s->min_activation_gap;

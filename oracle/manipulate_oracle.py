@@ -14,8 +14,8 @@ from .oracle_sim import OracleSim
 
 
 class OracleHandBlockEnv:
-    def __init__(self, model, target_position="ignore", target_rotation="xyz", reward_type="sparse"):
-        self.sim, self.model = OracleSim(model), model
+    def __init__(self, model, target_position="ignore", target_rotation="xyz", reward_type="sparse", touch_get_obs="off"):
+        self.sim, self.model, self.touch_get_obs = OracleSim(model), model, touch_get_obs
         self.target_position, self.target_rotation, self.reward_type = target_position, target_rotation, reward_type
         self.pquats = canonical_parallel_quats()
         self.ctrlrange = np.array(model.tables["act_ctrlrange"], dtype=np.float64).reshape(-1, 2)
@@ -37,7 +37,14 @@ class OracleHandBlockEnv:
     def _obs(self):
         s = self.sim
         ag = s.qpos[self.qa: self.qa + 7].copy()
-        return {"observation": np.concatenate([s.qpos[:24], s.qvel[:24], s.qvel[self.da: self.da + 6], ag]), "achieved_goal": ag,
+        touch = []   # manipulate_touch_sensors.py:113-137 (sensordata of the last forward pass)
+        if self.touch_get_obs == "sensordata":
+            touch = s.touch.copy()
+        elif self.touch_get_obs == "boolean":
+            touch = (s.touch > 0.0).astype(np.float64)
+        elif self.touch_get_obs == "log":
+            touch = np.log(s.touch + 1.0)
+        return {"observation": np.concatenate([s.qpos[:24], s.qvel[:24], s.qvel[self.da: self.da + 6], ag, touch]), "achieved_goal": ag,
                 "desired_goal": self.goal.copy()}
 
     def _reset_sim(self):

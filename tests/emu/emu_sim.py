@@ -77,7 +77,7 @@ class EmuSim:
         a = np.ascontiguousarray(action, dtype=np.float32)
         p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
         if not hasattr(self, "hand_obs"):
-            self.hand_obs = np.zeros(self.nq + self.nv + 15, np.float32)
+            self.hand_obs = np.zeros(256, np.float32)
             self.hand_achieved = np.zeros(15, np.float32)
             self.palm = np.zeros(3, np.float32)
         self.L.emu_hand_step(ctypes.c_void_p(self.h), ctypes.byref(self.task), p(self.qpos), p(self.qvel), p(self.qacc_ws), p(a), p(self.hand_obs),

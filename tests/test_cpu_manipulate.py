@@ -31,8 +31,10 @@ def test_ids_and_samplers():
     from gymnasium_robotics_amd.core import np_random
     from gymnasium_robotics_amd.envs import manipulate_spec as ms
 
-    assert ms.parse_block_id("HandManipulateBlockRotateXYZ-v1") == ("ignore", "xyz", "sparse")
-    assert ms.parse_block_id("HandManipulateBlockFullDense-v1") == ("random", "xyz", "dense")
+    assert ms.parse_block_id("HandManipulateBlockRotateXYZ-v1") == ("ignore", "xyz", "sparse", "off")
+    assert ms.parse_block_id("HandManipulateBlockFullDense-v1") == ("random", "xyz", "dense", "off")
+    assert ms.parse_block_id("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1") == ("ignore", "xyz", "sparse", "sensordata")
+    assert ms.parse_block_id("HandManipulateBlockRotateZ_BooleanTouchSensorsDense-v1") == ("ignore", "z", "dense", "boolean")
     assert ms.parse_block_id("HandManipulateBlockRotateParallel-v1")[1] == "parallel"
     with pytest.raises(ValueError):
         ms.parse_block_id("HandManipulateBlock-v1")
@@ -83,3 +85,31 @@ def test_emulated_block_step_matches_golden():
         assert np.array_equal(emu.hand_achieved[:7], emu.hand_obs[54:61])
     assert np.median(pos_err) < 1e-5 and np.median(vel_err) < 3e-4
     assert g["ncon"].max() >= 8 and g["nefc"].max() >= 60      # contact-rich fixture (block held by palm and fingers)
+
+
+def test_emulated_touch_sensors_match_golden():
+    """K12: 92 touch zones (77 boxes, 15 spheres) evaluated from the contacts of the last forward pass."""
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd.envs.hand import load_hand_block_model
+    from gymnasium_robotics_amd.envs.manipulate_spec import make_block_task
+
+    model = load_hand_block_model(touch=True)
+    T = model.tables
+    assert len(T["touch_body"]) == 92 and sorted(set(T["touch_type"].tolist())) == [2, 6] and model.dim("nsite") == 11
+    g = np.load(os.path.join(HERE, "golden", "hand_BlockRotateXYZ_touch_teacher.npz"))
+    emu = EmuSim(model, make_block_task(model, "ignore", "xyz", "sparse", "sensordata"))
+    hits, rel = 0, []
+    for i in range(g["obs"].shape[0]):
+        for k in ("qpos", "qvel", "qacc_ws"):
+            getattr(emu, k)[:] = g[k][i]
+        emu.hand_step(g["action"][i])
+        assert emu.status.value == 0
+        touch, ref = emu.hand_obs[61:153], g["obs"][i][61:]
+        rel.append(np.abs(touch - ref).max() / max(1.0, ref.max()))
+        if g["activation_gap"][i] >= 2e-5:
+            assert np.array_equal(touch > 0, ref > 0), i                 # the same zones fire
+            assert np.abs(touch - ref).max() < 2e-3 * max(1.0, ref.max()), (i, np.abs(touch - ref).max())
+            hits += int((ref > 0).sum())
+        assert np.abs(emu.hand_obs[:61] - g["obs"][i][:61])[[*range(24), *range(54, 61)]].max() < 5e-3
+    assert hits > 30 and np.median(rel) < 1e-4

@@ -54,8 +54,8 @@ def block_snapshots(variant="HandManipulateBlockRotateXYZ-v1", episodes=6, steps
     from gymnasium_robotics_amd.envs.manipulate_spec import parse_block_id
     from oracle.manipulate_oracle import OracleHandBlockEnv
 
-    tp, tr, rt = parse_block_id(variant)
-    env = OracleHandBlockEnv(load_hand_block_model(), tp, tr, rt)
+    tp, tr, rt, touch = parse_block_id(variant)
+    env = OracleHandBlockEnv(load_hand_block_model(touch=touch != "off"), tp, tr, rt, touch)
     rng = np.random.default_rng(777)
     rec = {k: [] for k in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "ncon", "nefc", "seed", "t", "activation_gap")}
     resets = {k: [] for k in ("seed", "obs", "goal", "attempts")}
@@ -86,6 +86,11 @@ if __name__ == "__main__":
     np.savez_compressed(path, **d)
     print("HandManipulateBlockRotateXYZ", d["obs"].shape, "max nefc", d["nefc"].max(), "max ncon", d["ncon"].max(), "reset attempts", d["reset_attempts"],
           f"{os.path.getsize(path)/1024:.0f} KiB")
+    d = block_snapshots("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", episodes=4, steps=30)
+    path = os.path.join(OUT, "hand_BlockRotateXYZ_touch_teacher.npz")
+    np.savez_compressed(path, **d)
+    print("HandManipulateBlockRotateXYZ_ContinuousTouchSensors", d["obs"].shape, "steps with active zones", int((d["obs"][:, 61:] > 0).any(axis=1).sum()),
+          "max zones", int((d["obs"][:, 61:] > 0).sum(axis=1).max()), f"{os.path.getsize(path)/1024:.0f} KiB")
     d = snapshots()
     path = os.path.join(OUT, "hand_HandReach_teacher.npz")
     np.savez_compressed(path, **d)
