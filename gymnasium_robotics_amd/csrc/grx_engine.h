@@ -144,7 +144,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
-  const int ckeep = ntouch ? GRX_MAXCON * (3 + 3 + 5) : 0;   // touch sensors read the contacts after the solve: keep pos / normal / pair / rows / bodies out of the overlay
+  const int ckeep = ntouch ? GRX_MAXCON * (3 + 3 + 3) : 0;   // touch sensors read the contacts after the solve: keep pos / normal / pair / rows out of the overlay
   pers += ckeep;
   int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 3 + 6) - ckeep;
   int p2 = nv * nv + 5 * nv + 4 * maxefc;
@@ -174,7 +174,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
   if (m->ntouch) {
     CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 3 * GRX_MAXCON)
-    CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
+    CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON)
   }
   float* overlay = p;
   // ---- P1 (kinematics .. velocity stage)
@@ -192,10 +192,10 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   }
   CARVE(cinert, 10 * m->nbody) CARVE(cdof_dot, 6 * m->nv)
   CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv)
-  CARVE(con_dist, GRX_MAXCON) CARVEI(con_span, GRX_MAXCON)
+  CARVE(con_dist, GRX_MAXCON) CARVEI(con_span, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
   if (!m->ntouch) {
     CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 3 * GRX_MAXCON)  // con_frame: contact normal only
-    CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
+    CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON)
   }
   // ---- P2 (solve / integrate) on top of P1
   p = overlay;
@@ -673,6 +673,7 @@ template <int NS>
 GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
 #if !defined(GRX_EMU)
   if (n == 21) { grx_sym_solve_reg<21>(A, x, lane_); return 0; }
+  if (n == 14) { grx_sym_solve_reg<14>(A, x, lane_); return 0; }
   if (n == 15) { grx_sym_solve_reg<15>(A, x, lane_); return 0; }
   if (n == 24) { grx_sym_solve_reg<24>(A, x, lane_); return 0; }
   if (n == 30) { grx_sym_solve_reg<30>(A, x, lane_); return 0; }
@@ -2045,7 +2046,7 @@ GRX_MEM void grx_touch_sensors(const GrxModel* m, const GrxCtx* c, float* out, i
       for (int k = 0; k < ncon; k++) {
         const int r0 = c->con_efc[k];
         if (r0 < 0) continue;
-        const int b1 = c->con_b1[k], b2 = c->con_b2[k];
+        const int pr = c->con_pair[k], b1 = m->geom_bodyid[m->pair_geom1[pr]], b2 = m->geom_bodyid[m->pair_geom2[pr]];
         if (b != b1 && b != b2) continue;
         float fn = 0.0f;
         for (int q = 0; q < c->con_nr[k] && r0 + q < nefc; q++) fn += c->efc_force[r0 + q];

@@ -74,9 +74,14 @@ template <class S> static bool grx_shape_matches(const GrxModel& g) {
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1> GrxShapeFetchArm;    // FetchReach (arm only)
+// ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
+typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1> GrxShapeAntLarge;
+typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1> GrxShapeAntMedium;
+typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1> GrxShapeAntOpen;
+typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1> GrxShapeAntUMaze;
 typedef GrxShape<24, 24, 20, 25, 24, 23, 20, 0, 24> GrxShapeHandReach;  // Shadow hand, reach.xml (24 hinges, 24 friction-loss dofs)
-typedef GrxShape<31, 30, 20, 26, 25, 24, 11, 0, 24> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
-typedef GrxShape<31, 30, 20, 26, 25, 24, 11, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
 template <class S>
 __global__ void __launch_bounds__(64, 2)
@@ -131,7 +136,8 @@ grx_fetch_forward_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_wor
 }
 
 // PointMaze env.step(): one wavefront per world, same engine
-extern "C" __global__ void __launch_bounds__(64, 2)
+template <class S>
+__global__ void __launch_bounds__(64, 2)
 grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int w = blockIdx.x, lane_ = threadIdx.x;
@@ -140,7 +146,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
-  grx_ctx_carve(&c, lds, grx_dims_of(&m));
+  grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
@@ -151,7 +157,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
   for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
   __syncthreads();
   float* obs = b.obs + (size_t)w * (m.nq + m.nv - (t.agent ? 2 : 0)); float* ach = b.achieved + (size_t)w * 2;
-  GrxPoint<GrxShapeAny>::grx_point_step_world(&m, &t, &c, b.action + (size_t)w * m.nu, obs, ach, lane_);
+  GrxPoint<S>::grx_point_step_world(&m, &t, &c, b.action + (size_t)w * m.nu, obs, ach, lane_);
   __syncthreads();
   for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
   for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)w * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * m.nv + i] = c.qacc_ws[i]; }
@@ -321,7 +327,10 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   else if (grx_shape_matches<GrxShapeFetchObject>(g)) { m->shape = 2; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchObject>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   else if (grx_shape_matches<GrxShapeFetchArm>(g)) { m->shape = 3; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchArm>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+#define GRX_TRY_POINT_SHAPE(SHAPE, ID) if (grx_shape_matches<SHAPE>(g)) { m->shape = ID; HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel<SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  GRX_TRY_POINT_SHAPE(GrxShapeAntLarge, 10) GRX_TRY_POINT_SHAPE(GrxShapeAntMedium, 11) GRX_TRY_POINT_SHAPE(GrxShapeAntOpen, 12) GRX_TRY_POINT_SHAPE(GrxShapeAntUMaze, 13)
+#undef GRX_TRY_POINT_SHAPE
   HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   if (grx_shape_matches<GrxShapeHandReach>(g)) { m->shape = 4; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandReach>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   if (grx_shape_matches<GrxShapeHandBlockTouch>(g)) { m->shape = 6; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandBlockTouch>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
@@ -412,7 +421,15 @@ extern "C" int grx_point_step(const grx_model* m, const grx_point_task* task, co
   if (n_worlds <= 0) return 0;
   GrxPointTask t; memcpy(&t, task, sizeof(t));
   GrxPointBuffers b; memcpy(&b, buf, sizeof(b));
-  hipLaunchKernelGGL(grx_point_step_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words);
+  const dim3 grid(n_worlds), block(64);
+  const size_t lds_bytes = (size_t)m->words * 4;
+  switch (m->shape) {
+    case 10: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntLarge>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
+    case 11: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntMedium>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
+    case 12: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntOpen>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
+    case 13: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntUMaze>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
+    default: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }

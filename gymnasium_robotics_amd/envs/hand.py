@@ -256,7 +256,8 @@ def load_hand_block_model(assets_root: Optional[str] = None, touch: bool = False
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
         xml = "manipulate_block_touch_sensors.xml" if touch else "manipulate_block.xml"
-        return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None)
+        # the task reads no site (manipulate.py:298-316 use qpos / qvel only): none is tracked by the engine
+        return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None, keep_sites=[])
     path = os.path.join(_MODELS_DIR, "hand_block_touch.npz" if touch else "hand_block.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")

@@ -337,7 +337,7 @@ def load_model(path: str) -> CompiledModel:
 # the compiler
 # ----------------------------------------------------------------------------
 class MjcfCompiler:
-    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None):
+    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None):
         """mutate: optional callable(root_element) applied after <include> expansion, before compilation -- the
         in-memory equivalent of the reference's Maze.make_maze XML rewrite (envs/maze/maze_v4.py:168-242)."""
         self.xml_path = os.path.abspath(xml_path)
@@ -345,6 +345,7 @@ class MjcfCompiler:
         self.root = _load_xml(self.xml_path)
         if mutate is not None:
             mutate(self.root)
+        self.keep_sites = None if keep_sites is None else set(keep_sites)   # names of the sites the engine tracks (None = all)
         self.touch_filter = touch_filter      # callable(sensor name) -> bool: which <touch> sensors the engine evaluates
         self.capacity = dict(capacity or {})   # engine row-table / Jacobian-pool capacities requested for this model (0 = default)
         self.defaults = _Defaults()
@@ -1038,7 +1039,7 @@ class _Lowering:
             touch_size[ti] = sdef.size
         T.update(touch_body=touch_body, touch_type=touch_type, touch_pos=touch_pos, touch_quat=touch_quat, touch_size=touch_size)
         names["touch"] = {sname: ti for ti, (sname, _) in enumerate(touch_sel)}
-        sites = [(i, s) for i in range(nb) for s in B[i].sites if s.name not in touch_sites]
+        sites = [(i, s) for i in range(nb) for s in B[i].sites if s.name not in touch_sites and (c.keep_sites is None or s.name in c.keep_sites)]
         ns = len(sites)
         site_bodyid = np.zeros(ns, np.int32)
         site_type = np.zeros(ns, np.int32)
@@ -1470,7 +1471,8 @@ class _Lowering:
         return CompiledModel(T, names, info)
 
 
-def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None) -> CompiledModel:
+def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None) -> CompiledModel:
     """capacity: optional {"maxefc": rows, "jpool": words} request for the engine's per-world constraint tables.
-    touch_filter: optional callable(sensor name) selecting the <touch> sensors the engine evaluates."""
-    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter).compile()
+    touch_filter: optional callable(sensor name) selecting the <touch> sensors the engine evaluates.
+    keep_sites: optional list of site names whose world frames the engine tracks (default: every site of the model)."""
+    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites).compile()

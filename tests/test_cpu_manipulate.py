@@ -96,7 +96,7 @@ def test_emulated_touch_sensors_match_golden():
 
     model = load_hand_block_model(touch=True)
     T = model.tables
-    assert len(T["touch_body"]) == 92 and sorted(set(T["touch_type"].tolist())) == [2, 6] and model.dim("nsite") == 11
+    assert len(T["touch_body"]) == 92 and sorted(set(T["touch_type"].tolist())) == [2, 6] and model.dim("nsite") == 0
     g = np.load(os.path.join(HERE, "golden", "hand_BlockRotateXYZ_touch_teacher.npz"))
     emu = EmuSim(model, make_block_task(model, "ignore", "xyz", "sparse", "sensordata"))
     hits, rel = 0, []

@@ -30,13 +30,13 @@ print("hand/reach.xml ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody"
 
 from gymnasium_robotics_amd.envs.manipulate_spec import drop_target_body, touch_filter  # noqa: E402
 
-m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block_touch_sensors.xml"), mutate=drop_target_body, touch_filter=touch_filter)
+m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block_touch_sensors.xml"), mutate=drop_target_body, touch_filter=touch_filter, keep_sites=[])
 out = os.path.join(OUT, "hand_block_touch.npz")
 save_model(m, out)
 print("hand/manipulate_block_touch_sensors.xml (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")},
       "touch zones:", len(m.tables["touch_body"]), f"{os.path.getsize(out) / 1024:.0f} KiB")
 
-m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block.xml"), mutate=drop_target_body)
+m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block.xml"), mutate=drop_target_body, keep_sites=[])
 out = os.path.join(OUT, "hand_block.npz")
 save_model(m, out)
 print("hand/manipulate_block.xml (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")},
