@@ -11,7 +11,25 @@ from .spaces import Dict
 
 
 class GoalVecEnv:
+    """Constructor arguments are recorded so that the env pickles the way gymnasium's EzPickle [3P] envs do: by value of its
+    constructor call (the reference's envs derive from EzPickle, e.g. shadow_dexterous_hand/reach.py:56,78-87; its tests
+    tests/test_envs.py:164-178 and tests/envs/hand/test_reach.py pickle every env).  Device state is not serialised."""
+
     metadata = {"render_modes": []}
+
+    def __new__(cls, *args, **kwargs):
+        obj = super().__new__(cls)
+        obj._ezpickle_args, obj._ezpickle_kwargs = args, kwargs
+        return obj
+
+    def __getstate__(self):
+        return {"_ezpickle_args": self._ezpickle_args, "_ezpickle_kwargs": self._ezpickle_kwargs}
+
+    def __setstate__(self, d):
+        out = type(self)(*d["_ezpickle_args"], **d["_ezpickle_kwargs"])
+        self.__dict__.update(out.__dict__)
+        out.__dict__.pop("_h", None)   # the native handle now belongs to self: do not let the temporary destroy it
+
     num_envs: int
     single_observation_space: Dict
     observation_space: Dict

@@ -38,7 +38,9 @@ def load_hand_reach_model(assets_root: Optional[str] = None) -> CompiledModel:
 class HandReachVecEnv(GoalVecEnv):
     def __init__(self, env_id: str = "HandReach-v3", num_envs: int = 1, device: Optional[str] = None, reward_type: Optional[str] = None,
                  relative_control: bool = False, max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step",
-                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
+                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0,
+                 distance_threshold: Optional[float] = None):
+        self.distance_threshold = DISTANCE_THRESHOLD if distance_threshold is None else float(distance_threshold)   # reach.py:60
         if relative_control:
             # hand_env.py:43-52 reads data.get_joint_qpos / model.actuator_names, which the mujoco bindings do not have: the
             # reference itself cannot run this branch on the mujoco (non mujoco_py) backend
@@ -93,7 +95,9 @@ class HandReachVecEnv(GoalVecEnv):
         return load_hand_reach_model(assets_root)
 
     def _make_task(self):
-        return make_hand_task(self.model, self.reward_type)
+        t = make_hand_task(self.model, self.reward_type)
+        t.distance_threshold = self.distance_threshold
+        return t
 
     def _obs_dim(self):
         return self.nq + self.nv + self.GOAL_DIM
@@ -220,7 +224,7 @@ class HandReachVecEnv(GoalVecEnv):
         return r if self.reward_type == "sparse" else r.astype(np.float64)
 
     def _launch_reward(self, ag, dg, out):
-        _native.check(self._L.grx_goal_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), self.GOAL_DIM, DISTANCE_THRESHOLD,
+        _native.check(self._L.grx_goal_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), self.GOAL_DIM, self.distance_threshold,
                                                       int(self.reward_type == "sparse"), out.data_ptr(), self._stream()))
 
     def compute_terminated(self, achieved_goal, desired_goal, info=None):

@@ -34,6 +34,13 @@ class Dict(dict):
     def sample(self):
         return {k: s.sample() for k, s in self.items()}
 
+    def seed(self, seed=None):
+        for i, s in enumerate(self.values()):
+            s.seed(None if seed is None else seed + i)
+
+    def contains(self, x):
+        return isinstance(x, dict) and x.keys() == self.keys() and all(s.contains(x[k]) for k, s in self.items())
+
 
 def batch_space(space, n):
     if isinstance(space, Dict):
