@@ -55,7 +55,7 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_MINVAL 1e-15f
 #define GRX_MINIMP 0.0001f
 #define GRX_MAXIMP 0.9999f
-#define GRX_MAXCON 32
+#define GRX_MAXCON 32    // default (and largest) contact-list capacity per world; a model may request fewer (<= 32: one lane per contact)
 #define GRX_MAXEFC 144   // default constraint rows per world (models with wide contact rows get more: grx_pack_model)
 #define GRX_JPOOL 2032    // default words of packed Jacobian storage per world (rows are stored over their dof span only); < 4096 (12-bit row offsets)
 #define GRX_NEWTON_MAXIT 8
@@ -82,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -111,7 +111,7 @@ struct GrxCtx {
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
-  int maxefc, jpool;  // capacities of the row tables / the packed Jacobian pool of this model
+  int maxefc, jpool, maxcon;  // capacities of the row tables / the packed Jacobian pool / the contact list of this model
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   long long* prof; long long* prof_last;
 #endif
@@ -133,9 +133,9 @@ __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];
 // body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
 // Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
 // body frames, motion axes, M, J, row parameters) is persistent.
-struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool, ntouch; };
+struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool, ntouch, maxcon; };
 GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator, int maxefc = GRX_MAXEFC,
-                          int jpool = GRX_JPOOL, int ntouch = 0) {
+                          int jpool = GRX_JPOOL, int ntouch = 0, int maxcon = GRX_MAXCON) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
@@ -144,9 +144,9 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
-  const int ckeep = ntouch ? GRX_MAXCON * (3 + 3 + 3) : 0;   // touch sensors read the contacts after the solve: keep pos / normal / pair / rows out of the overlay
+  const int ckeep = ntouch ? maxcon * (3 + 3 + 3) : 0;   // touch sensors read the contacts after the solve: keep pos / normal / pair / rows out of the overlay
   pers += ckeep;
-  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + GRX_MAXCON * (1 + 3 + 3 + 6) - ckeep;
+  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + maxcon * (1 + 3 + 3 + 6) - ckeep;
   int p2 = nv * nv + 5 * nv + 4 * maxefc;
   return pers + (p1 > p2 ? p1 : p2) + 8;
 }
@@ -165,7 +165,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   CARVE(cdof, 6 * m->nv) CARVE(M, m->nv * m->nv)
   CARVE(qfrc_smooth, m->nv) CARVE(qacc_smooth, m->nv) CARVE(qfrc_constraint, m->nv) CARVE(qacc, m->nv)
   c->red = p;  // 128-float scratch of the big-mesh collision path; the Jacobian pool is not written before the constraint stage
-  c->maxefc = m->maxefc; c->jpool = m->jpool;
+  c->maxefc = m->maxefc; c->jpool = m->jpool; c->maxcon = m->maxcon;
   CARVE(Jp, m->jpool) CARVE(efc_D, m->maxefc) CARVE(efc_aref, m->maxefc)
   c->efc_pos = c->efc_aref;  // residuals live in the aref slot until the per-row pass turns them into aref
   c->efc_floss = p; if (m->nfric) p += m->maxefc;
@@ -173,8 +173,8 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   CARVEI(ired, 32) CARVEI(cnt, 8)
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
   if (m->ntouch) {
-    CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 3 * GRX_MAXCON)
-    CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON)
+    CARVE(con_pos, 3 * m->maxcon) CARVE(con_frame, 3 * m->maxcon)
+    CARVEI(con_pair, m->maxcon) CARVEI(con_efc, m->maxcon) CARVEI(con_nr, m->maxcon)
   }
   float* overlay = p;
   // ---- P1 (kinematics .. velocity stage)
@@ -192,10 +192,10 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   }
   CARVE(cinert, 10 * m->nbody) CARVE(cdof_dot, 6 * m->nv)
   CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv)
-  CARVE(con_dist, GRX_MAXCON) CARVEI(con_span, GRX_MAXCON) CARVEI(con_b1, GRX_MAXCON) CARVEI(con_b2, GRX_MAXCON)
+  CARVE(con_dist, m->maxcon) CARVEI(con_span, m->maxcon) CARVEI(con_b1, m->maxcon) CARVEI(con_b2, m->maxcon)
   if (!m->ntouch) {
-    CARVE(con_pos, 3 * GRX_MAXCON) CARVE(con_frame, 3 * GRX_MAXCON)  // con_frame: contact normal only
-    CARVEI(con_pair, GRX_MAXCON) CARVEI(con_efc, GRX_MAXCON) CARVEI(con_nr, GRX_MAXCON)
+    CARVE(con_pos, 3 * m->maxcon) CARVE(con_frame, 3 * m->maxcon)  // con_frame: contact normal only
+    CARVEI(con_pair, m->maxcon) CARVEI(con_efc, m->maxcon) CARVEI(con_nr, m->maxcon)
   }
   // ---- P2 (solve / integrate) on top of P1
   p = overlay;
@@ -206,10 +206,10 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
 }
 
 GRX_HD GrxDims grx_dims_of(const GrxModel* m) {
-  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool, m->ntouch};
+  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool, m->ntouch, m->maxcon};
   return d;
 }
-GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool, d.ntouch); }
+GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool, d.ntouch, d.maxcon); }
 
 // ------------------------------------------------------------------------------------------
 // small math (all per-lane, registers)
@@ -374,9 +374,9 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 // dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
 // Model shape: the ten layout dims as compile-time constants (0 = read from the model at run time).
 template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0, int MAXEFC_ = GRX_MAXEFC, int JPOOL_ = GRX_JPOOL,
-          int NTOUCH_ = 0>
+          int NTOUCH_ = 0, int MAXCON_ = GRX_MAXCON>
 struct GrxShape {
-  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_, ME = MAXEFC_, JP = JPOOL_, NT = NTOUCH_;
+  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_, ME = MAXEFC_, JP = JPOOL_, NT = NTOUCH_, MC = MAXCON_;
   static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
@@ -802,7 +802,7 @@ GRX_MEM void grx_make_frame(float* f) {
 // grx_make_constraint (one lane per contact)
 GRX_MEM void grx_add_contact(GrxCtx* c, int pair, const float* pos, const float* normal, float dist) {
   int slot = GRX_ATOMIC_ADD(&c->cnt[0], 1);
-  if (slot >= GRX_MAXCON) { c->cnt[2] |= GRX_ST_CON_OVERFLOW; return; }
+  if (slot >= c->maxcon) { c->cnt[2] |= GRX_ST_CON_OVERFLOW; return; }
   c->con_dist[slot] = dist; c->con_pair[slot] = pair;
   for (int k = 0; k < 3; k++) { c->con_pos[3 * slot + k] = pos[k]; c->con_frame[3 * slot + k] = normal[k]; }
 }
@@ -1177,7 +1177,7 @@ GRX_MEM void grx_box_box_queue(const GrxModel* m, GrxCtx* c, const int* queue, i
         const int r0 = __builtin_popcount(b0_ & low), r1 = __builtin_popcount(b0_) + __builtin_popcount(b1_ & low), r2 = __builtin_popcount(b0_) + __builtin_popcount(b1_) + __builtin_popcount(b2_ & low);
         const float nrm[3] = {LV(nx), LV(ny), LV(nz)};
 #define GRX_BB_WRITE(V, R, PX, PY, PZ, H) if ((V) && (R) < 8) { const int slot = gbase + (R); \
-          if (slot >= GRX_MAXCON) c->cnt[2] |= GRX_ST_CON_OVERFLOW; \
+          if (slot >= c->maxcon) c->cnt[2] |= GRX_ST_CON_OVERFLOW; \
           else { c->con_dist[slot] = (H); c->con_pair[slot] = pair; c->con_pos[3 * slot] = (PX); c->con_pos[3 * slot + 1] = (PY); c->con_pos[3 * slot + 2] = (PZ); \
                  for (int k_ = 0; k_ < 3; k_++) c->con_frame[3 * slot + k_] = nrm[k_]; } }
         GRX_BB_WRITE(LV(cv0), r0, LV(cpx0), LV(cpy0), LV(cpz0), LV(ch0))
@@ -1299,7 +1299,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
       WAVE_SYNC();
     }
   }
-  LANE0 { if (c->cnt[0] > GRX_MAXCON) c->cnt[0] = GRX_MAXCON; }
+  LANE0 { if (c->cnt[0] > c->maxcon) c->cnt[0] = c->maxcon; }
   WAVE_SYNC();
 }
 
@@ -2032,7 +2032,7 @@ GRX_MEM float grx_ray_box(const float* p, const float* d, const float* sz) {
 }
 GRX_MEM void grx_touch_sensors(const GrxModel* m, const GrxCtx* c, float* out, int mode, int lane_) {
   GRX_FRESH_MODEL(m, c);
-  const int ncon = c->cnt[0] < GRX_MAXCON ? c->cnt[0] : GRX_MAXCON, nefc = c->cnt[1];
+  const int ncon = c->cnt[0] < c->maxcon ? c->cnt[0] : c->maxcon, nefc = c->cnt[1];
   FOR_LANES {
     for (int t = lane; t < m->ntouch; t += 64) {
       const int b = m->touch_body[t], type = m->touch_type[t];

@@ -47,6 +47,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.maxefc = d[GRX_MAXEFC_REQ] > 0 ? ((d[GRX_MAXEFC_REQ] + 15) / 16) * 16 : GRX_MAXEFC;
   m.jpool = d[GRX_JPOOL_REQ] > 0 ? ((d[GRX_JPOOL_REQ] + 15) / 16) * 16 : GRX_JPOOL;
   if (m.jpool > 4080) m.jpool = 4080;
+  m.maxcon = (d[GRX_MAXCON_REQ] > 0 && d[GRX_MAXCON_REQ] < GRX_MAXCON) ? d[GRX_MAXCON_REQ] : GRX_MAXCON;
   m.anydamp = 0;
   for (int k = 0; k < v.n_dof_damping; k++) if (v.dof_damping[k] > 0) m.anydamp = 1;
   m.timestep = (float)v.opt[GRX_TIMESTEP];

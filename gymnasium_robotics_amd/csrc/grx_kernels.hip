@@ -64,12 +64,12 @@ extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)h
 // into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs) and the loops over
 // dofs / bodies / joints unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
 template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(const GrxModel& m) {
-  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP, S::NT};
+  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP, S::NT, S::MC};
   return grx_dims_of(&m);
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT;
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC;
 }
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
@@ -79,7 +79,7 @@ typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1> GrxShapeAntMedium;
 typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1> GrxShapeAntOpen;
 typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1> GrxShapeAntUMaze;
-typedef GrxShape<24, 24, 20, 25, 24, 23, 20, 0, 24> GrxShapeHandReach;  // Shadow hand, reach.xml (24 hinges, 24 friction-loss dofs)
+typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 0, 16> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 

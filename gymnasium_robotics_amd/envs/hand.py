@@ -24,11 +24,16 @@ _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mo
 GOAL_DIM = 15
 
 
+# the task reads the five fingertip sites only (reach.py:398-405); without an object the hand produces a handful of contacts
+# (explicit finger pairs): 16 contact slots.  Both trim the per-world LDS footprint to 7 worlds per CU.
+HAND_REACH_COMPILE = dict(keep_sites=["robot0:S_fftip", "robot0:S_mftip", "robot0:S_rftip", "robot0:S_lftip", "robot0:S_thtip"], capacity={"maxcon": 16})
+
+
 def load_hand_reach_model(assets_root: Optional[str] = None) -> CompiledModel:
     """hand/reach.xml compiled from MJCF when an asset tree is given (assets_root / $GRX_ASSETS_ROOT), else the packaged blob."""
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
-        return compile_mjcf(os.path.join(assets_root, "hand", "reach.xml"))
+        return compile_mjcf(os.path.join(assets_root, "hand", "reach.xml"), **HAND_REACH_COMPILE)
     path = os.path.join(_MODELS_DIR, "hand_reach.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")

@@ -53,7 +53,7 @@ MJ_MINVAL = 1e-15
 DIMS = [
     "nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "nmocap", "neq", "npair",
     "nmeshvert", "nmeshadj", "integrator", "iterations", "cone", "noslip_iterations",
-    "eulerdamp", "ntree", "maxdepth", "maxefc_req", "jpool_req",
+    "eulerdamp", "ntree", "maxdepth", "maxefc_req", "jpool_req", "maxcon_req",
 ]
 NDIMS = 32
 OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia"]
@@ -1320,7 +1320,8 @@ class _Lowering:
                     integrator=c.opt["integrator"], iterations=c.opt["iterations"], cone=c.opt["cone"],
                     noslip_iterations=c.opt["noslip_iterations"], eulerdamp=c.opt["eulerdamp"],
                     ntree=int(np.sum(body_parent[1:] == 0)), maxdepth=int(body_depth.max()),
-                    maxefc_req=int(c.capacity.get("maxefc", 0)), jpool_req=int(c.capacity.get("jpool", 0)))
+                    maxefc_req=int(c.capacity.get("maxefc", 0)), jpool_req=int(c.capacity.get("jpool", 0)),
+                    maxcon_req=int(c.capacity.get("maxcon", 0)))
         for k, v in vals.items():
             dims[DIMS.index(k)] = v
         optv = np.zeros(NOPTS)
@@ -1472,7 +1473,7 @@ class _Lowering:
 
 
 def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None) -> CompiledModel:
-    """capacity: optional {"maxefc": rows, "jpool": words} request for the engine's per-world constraint tables.
+    """capacity: optional {"maxefc": rows, "jpool": words, "maxcon": contacts} request for the engine's per-world constraint tables.
     touch_filter: optional callable(sensor name) selecting the <touch> sensors the engine evaluates.
     keep_sites: optional list of site names whose world frames the engine tracks (default: every site of the model)."""
     return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites).compile()

@@ -11,7 +11,7 @@
 enum grx_dim {
   GRX_NQ = 0, GRX_NV, GRX_NU, GRX_NBODY, GRX_NJNT, GRX_NGEOM, GRX_NSITE, GRX_NMOCAP, GRX_NEQ, GRX_NPAIR,
   GRX_NMESHVERT, GRX_NMESHADJ, GRX_INTEGRATOR, GRX_ITERATIONS, GRX_CONE, GRX_NOSLIP_ITERATIONS,
-  GRX_EULERDAMP, GRX_NTREE, GRX_MAXDEPTH, GRX_MAXEFC_REQ, GRX_JPOOL_REQ,
+  GRX_EULERDAMP, GRX_NTREE, GRX_MAXDEPTH, GRX_MAXEFC_REQ, GRX_JPOOL_REQ, GRX_MAXCON_REQ,
   GRX_NDIMS = 32
 };
 enum grx_opt {

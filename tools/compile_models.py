@@ -22,7 +22,9 @@ for xml in ("fetch/reach.xml", "fetch/push.xml", "fetch/pick_and_place.xml"):
     print(xml, "->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "unsupported pairs:", m.info["unsupported_pairs"],
           f"{os.path.getsize(out) / 1024:.0f} KiB")
 
-m = compile_mjcf(os.path.join(ASSETS, "hand", "reach.xml"))
+from gymnasium_robotics_amd.envs.hand import HAND_REACH_COMPILE  # noqa: E402
+
+m = compile_mjcf(os.path.join(ASSETS, "hand", "reach.xml"), **HAND_REACH_COMPILE)
 out = os.path.join(OUT, "hand_reach.npz")
 save_model(m, out)
 print("hand/reach.xml ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "tendons:", len(m.tables["tendon_adr"]),
