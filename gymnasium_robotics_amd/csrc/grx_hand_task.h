@@ -23,6 +23,7 @@ struct GrxHandTask {
   int kind, nq_robot, obj_qadr, obj_dadr;
   int ignore_position, ignore_rotation;   // target_position == "ignore" / target_rotation == "ignore" (manipulate.py:92-97)
   float rotation_threshold;
+  int ignore_z;     // ignore_z_target_rotation (pen variants, manipulate.py:100-108)
   int touch_mode;   // 0: no touch values in the observation; 1 sensordata, 2 boolean, 3 log(x+1) (manipulate_touch_sensors.py:124-131)
 };
 GRX_DEV int grx_hand_goal_dim(const GrxHandTask* t) { return t->kind ? 7 : 3 * GRX_HAND_NTIPS; }
@@ -53,10 +54,34 @@ GRX_DEV float grx_hand_reward(float d, float thr, int sparse) { return sparse ? 
 
 // manipulate.py:87-142.  The reference takes the angle as 2 acos(clip(w)) of quat_a * conj(quat_b), whose scalar part is the
 // 4-vector dot product; 2 atan2(|vector part|, w) is the same angle for unit quaternions and keeps fp32 accuracy near 0.
-GRX_DEV void grx_manip_distance(const float* a, const float* b, int ignore_pos, int ignore_rot, float* d_pos, float* d_rot) {
-  *d_pos = ignore_pos ? 0.0f : grx_goal_distance_n(a, b, 3);
+// Euler angles of utils/rotations.py (quat2euler = mat2euler(quat2mat), rotations.py:162-184,227-272) and back (euler2quat,
+// rotations.py:140-159 = qx(e0) qy(e1) qz(e2)); used only by the ignore-z special case
+GRX_DEV void grx_quat2euler(const float* q, float* e) {
+  const float w = q[0], x = q[1], y = q[2], z = q[3], n = w * w + x * x + y * y + z * z, s = n > 1.1920929e-07f * 4.0f ? 2.0f / n : 0.0f;
+  const float m00 = 1.0f - s * (y * y + z * z), m01 = s * (x * y - w * z), m02 = s * (x * z + w * y);
+  const float m10 = s * (x * y + w * z), m11 = 1.0f - s * (x * x + z * z), m12 = s * (y * z - w * x), m22 = 1.0f - s * (x * x + y * y);
+  const float cy = sqrtf(m22 * m22 + m12 * m12);
+  if (cy > 8.8817842e-16f) { e[2] = -atan2f(m01, m00); e[1] = -atan2f(-m02, cy); e[0] = -atan2f(m12, m22); }
+  else { e[2] = -atan2f(-m10, m11); e[1] = -atan2f(-m02, cy); e[0] = 0.0f; }
+}
+GRX_DEV void grx_euler2quat(const float* e, float* q) {
+  const float cx = cosf(0.5f * e[0]), sx = sinf(0.5f * e[0]), cy = cosf(0.5f * e[1]), sy = sinf(0.5f * e[1]), cz = cosf(0.5f * e[2]), sz = sinf(0.5f * e[2]);
+  // qy qz
+  const float aw = cy * cz, ax = sy * sz, ay = sy * cz, az = cy * sz;
+  q[0] = cx * aw - sx * ax; q[1] = cx * ax + sx * aw; q[2] = cx * ay - sx * az; q[3] = cx * az + sx * ay;
+}
+
+GRX_DEV void grx_manip_distance(const float* a_in, const float* b, int ignore_pos, int ignore_rot, int ignore_z, float* d_pos, float* d_rot) {
+  *d_pos = ignore_pos ? 0.0f : grx_goal_distance_n(a_in, b, 3);
   float dr = 0.0f;
   if (!ignore_rot) {
+    float a[7] = {a_in[0], a_in[1], a_in[2], a_in[3], a_in[4], a_in[5], a_in[6]};
+    if (ignore_z) {   // give quat_a the z Euler angle of quat_b, then compare (manipulate.py:100-108)
+      float ea[3], eb[3];
+      grx_quat2euler(a + 3, ea); grx_quat2euler(b + 3, eb);
+      ea[2] = eb[2];
+      grx_euler2quat(ea, a + 3);
+    }
     const float w0 = a[3], x0 = a[4], y0 = a[5], z0 = a[6], w1 = b[3], x1 = -b[4], y1 = -b[5], z1 = -b[6];
     const float w = w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1;
     const float x = w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1, y = w0 * y1 + y0 * w1 + z0 * x1 - x0 * z1, z = w0 * z1 + z0 * w1 + x0 * y1 - y0 * x1;

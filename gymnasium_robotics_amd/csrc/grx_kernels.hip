@@ -206,7 +206,7 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   if (lane_ == 0) {
     if (t.kind) {
       float dp, dr;
-      grx_manip_distance(ach, b.goal + (size_t)w * gd, t.ignore_position, t.ignore_rotation, &dp, &dr);
+      grx_manip_distance(ach, b.goal + (size_t)w * gd, t.ignore_position, t.ignore_rotation, t.ignore_z, &dp, &dr);
       b.reward[w] = grx_manip_reward(dp, dr, t.distance_threshold, t.rotation_threshold, t.sparse_reward);
       b.success[w] = grx_manip_success(dp, dr, t.distance_threshold, t.rotation_threshold);
     } else {
@@ -225,11 +225,11 @@ grx_goal_reward_kernel(const float* __restrict__ ag, const float* __restrict__ d
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-grx_manip_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int ignore_pos, int ignore_rot, float thr_pos, float thr_rot,
+grx_manip_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int ignore_pos, int ignore_rot, int ignore_z, float thr_pos, float thr_rot,
                         int sparse, float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
     float dp, dr;
-    grx_manip_distance(ag + i * 7, dg + i * 7, ignore_pos, ignore_rot, &dp, &dr);
+    grx_manip_distance(ag + i * 7, dg + i * 7, ignore_pos, ignore_rot, ignore_z, &dp, &dr);
     out[i] = grx_manip_reward(dp, dr, thr_pos, thr_rot, sparse);
   }
 }
@@ -472,13 +472,13 @@ extern "C" int grx_goal_compute_reward(const float* achieved, const float* desir
 }
 
 extern "C" int grx_manip_compute_reward(const float* achieved, const float* desired, int64_t batch, int ignore_position, int ignore_rotation,
-                                        float distance_threshold, float rotation_threshold, int sparse, float* reward_out, void* stream) {
+                                        int ignore_z, float distance_threshold, float rotation_threshold, int sparse, float* reward_out, void* stream) {
   if (!achieved || !desired || !reward_out) return fail("grx_manip_compute_reward: null argument");
   if (batch <= 0) return 0;
   long long blocks = (batch + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(grx_manip_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, achieved, desired, (long long)batch, ignore_position,
-                     ignore_rotation, distance_threshold, rotation_threshold, sparse, reward_out);
+                     ignore_rotation, ignore_z, distance_threshold, rotation_threshold, sparse, reward_out);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -45,13 +45,15 @@ class HandReachVecEnv(GoalVecEnv):
                  relative_control: bool = False, max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step",
                  output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0,
                  distance_threshold: Optional[float] = None):
-        self.distance_threshold = DISTANCE_THRESHOLD if distance_threshold is None else float(distance_threshold)   # reach.py:60
         if relative_control:
             # hand_env.py:43-52 reads data.get_joint_qpos / model.actuator_names, which the mujoco bindings do not have: the
             # reference itself cannot run this branch on the mujoco (non mujoco_py) backend
             raise NotImplementedError("relative_control=True is not available on the mujoco backend of the reference either")
         self.env_id = env_id
+        self.distance_threshold = DISTANCE_THRESHOLD   # reach.py:60; the manipulate envs set their own in _parse_id
         self._parse_id(env_id, reward_type)
+        if distance_threshold is not None:
+            self.distance_threshold = float(distance_threshold)
         self.max_episode_steps, self.autoreset_mode, self.output = max_episode_steps, autoreset_mode, output
         self.num_envs, self.seed_offset = int(num_envs), int(seed_offset)
         if not torch.cuda.is_available():
@@ -257,24 +259,26 @@ class HandReachVecEnv(GoalVecEnv):
             pass
 
 
-def load_hand_block_model(assets_root: Optional[str] = None, touch: bool = False) -> CompiledModel:
-    """hand/manipulate_block[_touch_sensors].xml without its visual-only target body (manipulate_spec.drop_target_body); with
+def load_hand_block_model(assets_root: Optional[str] = None, touch: bool = False, obj: str = "block") -> CompiledModel:
+    """hand/manipulate_{block,pen}[_touch_sensors].xml without its visual-only target body (manipulate_spec.drop_target_body); with
     touch=True the 92 'robot0:TS_*' touch zones are compiled into the touch_* tables."""
-    from .manipulate_spec import drop_target_body, touch_filter
+    from .manipulate_spec import OBJECTS, drop_target_body, touch_filter
 
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
-        xml = "manipulate_block_touch_sensors.xml" if touch else "manipulate_block.xml"
+        xml = OBJECTS[obj]["xml"] + ("_touch_sensors.xml" if touch else ".xml")
         # the task reads no site (manipulate.py:298-316 use qpos / qvel only): none is tracked by the engine
         return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None, keep_sites=[])
-    path = os.path.join(_MODELS_DIR, "hand_block_touch.npz" if touch else "hand_block.npz")
+    path = os.path.join(_MODELS_DIR, f"hand_{obj}_touch.npz" if touch else f"hand_{obj}.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")
     return load_model(path)
 
 
 class HandBlockVecEnv(HandReachVecEnv):
-    """Batched HandManipulateBlock{RotateZ, RotateParallel, RotateXYZ, Full}[_ContinuousTouchSensors | _BooleanTouchSensors][Dense]-v1
+    """Batched HandManipulateBlock{, RotateZ, RotateParallel, RotateXYZ, Full} and HandManipulatePen{, Rotate, Full}
+    [_ContinuousTouchSensors | _BooleanTouchSensors][Dense]-v1 (pen: manipulate_pen.py:216-235 -- no initial rotation noise, z rotation
+    ignored in the goal distance, position threshold 0.05)
     (/root/reference/gymnasium_robotics/envs/shadow_dexterous_hand/manipulate.py: MujocoManipulateEnv; manipulate_block.py:214-230).
     Observation 61 = 24 robot joint positions | 24 velocities | object velocity 6 | object pose 7; goals are 7-vector poses.
     The visual-only, non-colliding `target` body of the MJCF is not simulated (its state is not observable through the env API)."""
@@ -287,17 +291,22 @@ class HandBlockVecEnv(HandReachVecEnv):
     def _parse_id(self, env_id, reward_type):
         from .manipulate_spec import canonical_parallel_quats, parse_block_id
 
+        from .manipulate_spec import OBJECTS, object_of
+
         self.target_position, self.target_rotation, rt, self.touch_get_obs = parse_block_id(env_id)
+        self.object = object_of(env_id)
+        self._objcfg = OBJECTS[self.object]
+        self.distance_threshold = self._objcfg["distance_threshold"]
         self.reward_type = reward_type or rt
         self._pquats = canonical_parallel_quats()
 
     def _load_model(self, assets_root):
-        return load_hand_block_model(assets_root, touch=self.touch_get_obs != "off")
+        return load_hand_block_model(assets_root, touch=self.touch_get_obs != "off", obj=self.object)
 
     def _make_task(self):
         from .manipulate_spec import make_block_task
 
-        return make_block_task(self.model, self.target_position, self.target_rotation, self.reward_type, self.touch_get_obs)
+        return make_block_task(self.model, self.target_position, self.target_rotation, self.reward_type, self.touch_get_obs, self.object)
 
     def _obs_dim(self):
         from .manipulate_spec import N_TOUCH
@@ -325,7 +334,7 @@ class HandBlockVecEnv(HandReachVecEnv):
         while len(pending):
             self.reset_attempts[pending] += 1
             poses = np.stack([sample_reset_object_pose(self.np_randoms[w], self._obj0[:3], self._obj0[3:], self.target_position, self.target_rotation,
-                                                       self._pquats) for w in pending])
+                                                       self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"]) for w in pending])
             ti = torch.from_numpy(pending).to(self.device)
             q = self._initial_qpos.unsqueeze(0).repeat(len(pending), 1)
             q[:, self._qa: self._qa + 7] = torch.from_numpy(poses.astype(np.float32)).to(self.device)
@@ -347,8 +356,12 @@ class HandBlockVecEnv(HandReachVecEnv):
         self._needs_reset[idx] = False
 
     def _launch_reward(self, ag, dg, out):
-        from .manipulate_spec import DISTANCE_THRESHOLD as DT, ROTATION_THRESHOLD as RT
+        from .manipulate_spec import ROTATION_THRESHOLD as RT
 
         _native.check(self._L.grx_manip_compute_reward(ag.data_ptr(), dg.data_ptr(), out.numel(), int(self.target_position == "ignore"),
-                                                       int(self.target_rotation == "ignore"), DT, RT, int(self.reward_type == "sparse"),
+                                                       int(self.target_rotation == "ignore"), int(self._objcfg["ignore_z_target_rotation"]),
+                                                       self.distance_threshold, RT, int(self.reward_type == "sparse"),
                                                        out.data_ptr(), self._stream()))
+
+
+HandManipulateVecEnv = HandBlockVecEnv   # the class covers the block and the pen objects

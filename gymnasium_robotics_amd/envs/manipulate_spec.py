@@ -12,10 +12,18 @@ import numpy as np
 TARGET_POSITION_RANGE = np.array([(-0.04, 0.04), (-0.06, 0.02), (0.0, 0.06)])   # manipulate_block.py:226
 DISTANCE_THRESHOLD, ROTATION_THRESHOLD = 0.01, 0.1                               # manipulate.py:32-33
 N_SUBSTEPS, MAX_EPISODE_STEPS, SETTLE_STEPS, PALM_HEIGHT = 20, 100, 10, 0.04     # manipulate.py:34,205-216; __init__.py:284
-# registered ids (gymnasium_robotics/__init__.py:222-300): name -> (target_position, target_rotation)
+# registered ids (gymnasium_robotics/__init__.py:124-341, 644-800): name -> (object, target_position, target_rotation)
 BLOCK_VARIANTS = {
-    "HandManipulateBlockRotateZ": ("ignore", "z"), "HandManipulateBlockRotateParallel": ("ignore", "parallel"),
-    "HandManipulateBlockRotateXYZ": ("ignore", "xyz"), "HandManipulateBlockFull": ("random", "xyz"),
+    "HandManipulateBlockRotateZ": ("block", "ignore", "z"), "HandManipulateBlockRotateParallel": ("block", "ignore", "parallel"),
+    "HandManipulateBlockRotateXYZ": ("block", "ignore", "xyz"), "HandManipulateBlockFull": ("block", "random", "xyz"),
+    "HandManipulateBlock": ("block", "random", "xyz"),
+    "HandManipulatePenRotate": ("pen", "ignore", "xyz"), "HandManipulatePenFull": ("pen", "random", "xyz"), "HandManipulatePen": ("pen", "random", "xyz"),
+}
+NO_TOUCH_IDS = ("HandManipulateBlockFull", "HandManipulatePenFull")   # the *Full ids have no touch-sensor twins
+# per-object constructor constants: manipulate_block.py:214-230, manipulate_pen.py:216-235
+OBJECTS = {
+    "block": dict(xml="manipulate_block", randomize_initial_rotation=True, ignore_z_target_rotation=False, distance_threshold=0.01),
+    "pen": dict(xml="manipulate_pen", randomize_initial_rotation=False, ignore_z_target_rotation=True, distance_threshold=0.05),
 }
 
 
@@ -38,9 +46,21 @@ def parse_block_id(env_id: str):
     for suffix, mode in (("_ContinuousTouchSensors", "sensordata"), ("_BooleanTouchSensors", "boolean")):
         if base.endswith(suffix):
             base, touch = base[: -len(suffix)], mode
-    if version != "v1" or base not in BLOCK_VARIANTS:
-        raise ValueError(f"unknown HandManipulateBlock id {env_id!r}")
-    return (*BLOCK_VARIANTS[base], "dense" if dense else "sparse", touch)
+    if version != "v1" or base not in BLOCK_VARIANTS or (touch != "off" and base in NO_TOUCH_IDS):
+        raise ValueError(f"unknown HandManipulate id {env_id!r}")
+    _obj, tp, tr = BLOCK_VARIANTS[base]
+    return (tp, tr, "dense" if dense else "sparse", touch)
+
+
+def object_of(env_id: str) -> str:
+    """'block' or 'pen' (the egg's ellipsoid needs a general convex narrow phase: not supported)."""
+    name = env_id.rpartition("-")[0]
+    name = name[:-5] if name.endswith("Dense") else name
+    for suffix in ("_ContinuousTouchSensors", "_BooleanTouchSensors"):
+        name = name[: -len(suffix)] if name.endswith(suffix) else name
+    if name not in BLOCK_VARIANTS:
+        raise ValueError(f"unknown HandManipulate id {env_id!r}")
+    return BLOCK_VARIANTS[name][0]
 
 
 def drop_target_body(root):
@@ -88,6 +108,12 @@ def _quat2mat(q):
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def quat2euler(q):
+    """rotations.py:227-232 for one quaternion."""
+    q = np.asarray(q, dtype=np.float64)
+    return _mat2euler(_quat2mat(q / np.sqrt(np.sum(q * q)))) if np.sum(q * q) > np.finfo(np.float64).eps else np.zeros(3)
 
 
 def _mat2euler(R):
@@ -168,40 +194,50 @@ def sample_block_goal(np_random, object_qpos, target_position, target_rotation, 
     return np.concatenate([target_pos, target_quat])
 
 
-def block_goal_distance(goal_a, goal_b, target_position, target_rotation):
-    """manipulate.py:87-118 (without the ignore_z special case, which only the pen variants use)."""
+def block_goal_distance(goal_a, goal_b, target_position, target_rotation, ignore_z=False):
+    """manipulate.py:87-118; ignore_z (pen variants): quat_a takes the z Euler angle of quat_b before the comparison."""
     goal_a, goal_b = np.asarray(goal_a, dtype=np.float64), np.asarray(goal_b, dtype=np.float64)
     d_pos = np.zeros_like(goal_a[..., 0])
     d_rot = np.zeros_like(goal_b[..., 0])
     if target_position != "ignore":
         d_pos = np.linalg.norm(goal_a[..., :3] - goal_b[..., :3], axis=-1)
     if target_rotation != "ignore":
-        w = quat_mul(goal_a[..., 3:], quat_conj(goal_b[..., 3:]))[..., 0]
+        quat_a = goal_a[..., 3:]
+        if ignore_z:
+            flat_a, flat_b = quat_a.reshape(-1, 4), goal_b[..., 3:].reshape(-1, 4)
+            fixed = np.empty_like(flat_a)
+            for k in range(len(flat_a)):
+                ea, eb = quat2euler(flat_a[k]), quat2euler(flat_b[k])
+                ea[2] = eb[2]
+                fixed[k] = euler2quat(ea)
+            quat_a = fixed.reshape(quat_a.shape)
+        w = quat_mul(quat_a, quat_conj(goal_b[..., 3:]))[..., 0]
         d_rot = 2 * np.arccos(np.clip(w, -1.0, 1.0))
     return d_pos, d_rot
 
 
-def block_is_success(achieved, desired, target_position, target_rotation):
-    d_pos, d_rot = block_goal_distance(achieved, desired, target_position, target_rotation)
-    return ((d_pos < DISTANCE_THRESHOLD) & (d_rot < ROTATION_THRESHOLD)).astype(np.float32)
+def block_is_success(achieved, desired, target_position, target_rotation, ignore_z=False, distance_threshold=DISTANCE_THRESHOLD):
+    d_pos, d_rot = block_goal_distance(achieved, desired, target_position, target_rotation, ignore_z)
+    return ((d_pos < distance_threshold) & (d_rot < ROTATION_THRESHOLD)).astype(np.float32)
 
 
-def block_reward(achieved, desired, target_position, target_rotation, reward_type):
+def block_reward(achieved, desired, target_position, target_rotation, reward_type, ignore_z=False, distance_threshold=DISTANCE_THRESHOLD):
     """manipulate.py:120-128."""
     if reward_type == "sparse":
-        return block_is_success(achieved, desired, target_position, target_rotation) - 1.0
-    d_pos, d_rot = block_goal_distance(achieved, desired, target_position, target_rotation)
+        return block_is_success(achieved, desired, target_position, target_rotation, ignore_z, distance_threshold) - 1.0
+    d_pos, d_rot = block_goal_distance(achieved, desired, target_position, target_rotation, ignore_z)
     return -(10.0 * d_pos + d_rot)
 
 
 # ---- C struct (GrxHandTask with kind = 1, csrc/grx_hand_task.h) ------------------------------------------------------------
-def make_block_task(model, target_position, target_rotation, reward_type, touch_get_obs="off"):
+def make_block_task(model, target_position, target_rotation, reward_type, touch_get_obs="off", obj="block"):
     from .hand_spec import HandTaskStruct
 
     t = HandTaskStruct()
     t.n_substeps, t.sparse_reward = N_SUBSTEPS, int(reward_type == "sparse")
     t.palm_body = int(model.names["body"]["robot0:palm"])
-    t.distance_threshold, t.rotation_threshold = DISTANCE_THRESHOLD, ROTATION_THRESHOLD
+    t.distance_threshold, t.rotation_threshold = OBJECTS[obj]["distance_threshold"], ROTATION_THRESHOLD   # the env may override the former
+    t.ignore_z = int(OBJECTS[obj]["ignore_z_target_rotation"])
     j = int(model.names["joint"]["object:joint"])
     t.kind, t.nq_robot = 1, 24
     t.obj_qadr = int(np.asarray(model.tables["jnt_qposadr"]).reshape(-1)[j])

@@ -84,6 +84,7 @@ typedef struct grx_hand_task {
   int nq_robot, obj_qadr, obj_dadr;      /* kind 1: robot joints come first; qpos / dof address of object:joint */
   int ignore_position, ignore_rotation;  /* kind 1: target_position / target_rotation == "ignore" (manipulate.py:92-97) */
   float rotation_threshold;              /* kind 1: manipulate.py:33 */
+  int ignore_z;   /* kind 1: ignore_z_target_rotation (pen variants, manipulate.py:100-108) */
   int touch_mode; /* kind 1: 0 none, 1 sensordata, 2 boolean, 3 log(x+1): touch values appended to the observation (manipulate_touch_sensors.py:113-137) */
 } grx_hand_task;
 typedef struct grx_hand_buffers {
@@ -124,7 +125,7 @@ int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t
                             float* reward_out, void* stream);
 /* batched MujocoManipulateEnv.compute_reward on 7-vector pose goals (shadow_dexterous_hand/manipulate.py:87-142) */
 int grx_manip_compute_reward(const float* achieved, const float* desired, int64_t batch, int ignore_position, int ignore_rotation,
-                             float distance_threshold, float rotation_threshold, int sparse, float* reward_out, void* stream);
+                             int ignore_z, float distance_threshold, float rotation_threshold, int sparse, float* reward_out, void* stream);
 
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's

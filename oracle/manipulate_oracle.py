@@ -14,8 +14,10 @@ from .oracle_sim import OracleSim
 
 
 class OracleHandBlockEnv:
-    def __init__(self, model, target_position="ignore", target_rotation="xyz", reward_type="sparse", touch_get_obs="off"):
-        self.sim, self.model, self.touch_get_obs = OracleSim(model), model, touch_get_obs
+    def __init__(self, model, target_position="ignore", target_rotation="xyz", reward_type="sparse", touch_get_obs="off", obj="block"):
+        from gymnasium_robotics_amd.envs.manipulate_spec import OBJECTS
+
+        self.sim, self.model, self.touch_get_obs, self.objcfg = OracleSim(model), model, touch_get_obs, OBJECTS[obj]
         self.target_position, self.target_rotation, self.reward_type = target_position, target_rotation, reward_type
         self.pquats = canonical_parallel_quats()
         self.ctrlrange = np.array(model.tables["act_ctrlrange"], dtype=np.float64).reshape(-1, 2)
@@ -53,7 +55,7 @@ class OracleHandBlockEnv:
         s.qvel[:] = self.initial_qvel
         s.forward()
         pose = sample_reset_object_pose(self.np_random, s.qpos[self.qa: self.qa + 3], s.qpos[self.qa + 3: self.qa + 7], self.target_position,
-                                        self.target_rotation, self.pquats)
+                                        self.target_rotation, self.pquats, randomize_initial_rotation=self.objcfg["randomize_initial_rotation"])
         s.qpos[self.qa: self.qa + 7] = pose
         for _ in range(SETTLE_STEPS):
             self._set_action(np.zeros(20))
@@ -76,5 +78,6 @@ class OracleHandBlockEnv:
         self._set_action(action)
         self.sim.step(N_SUBSTEPS)
         obs = self._obs()
-        info = {"is_success": float(block_is_success(obs["achieved_goal"], self.goal, self.target_position, self.target_rotation))}
-        return obs, block_reward(obs["achieved_goal"], self.goal, self.target_position, self.target_rotation, self.reward_type), False, False, info
+        iz, dt = self.objcfg["ignore_z_target_rotation"], self.objcfg["distance_threshold"]
+        info = {"is_success": float(block_is_success(obs["achieved_goal"], self.goal, self.target_position, self.target_rotation, iz, dt))}
+        return obs, block_reward(obs["achieved_goal"], self.goal, self.target_position, self.target_rotation, self.reward_type, iz, dt), False, False, info

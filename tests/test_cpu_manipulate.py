@@ -25,6 +25,10 @@ def test_quaternion_helpers_match_reference_vectors():
     assert np.abs(d_rot[8:16] - 2 * np.pi).max() < 1e-6      # antipodal quaternions: the reference reports 2 pi (manipulate.py:113-115)
     assert ms.block_is_success(pose(g["qa"][:8]), pose(g["qb"][:8]), "ignore", "xyz").all()
     assert (ms.block_reward(pose(g["qa"]), pose(g["qb"]), "ignore", "xyz", "sparse")[16:] == -1.0).all()
+    # ignore_z_target_rotation (pen variants): quat2euler and the z-substituted distance, goal by goal as env.step() calls it
+    assert np.abs(np.array([ms.quat2euler(q) for q in g["qa"]]) - g["quat2euler"]).max() < 1e-14
+    _, d_iz = ms.block_goal_distance(pose(g["qa"]), pose(g["qb"]), "ignore", "xyz", ignore_z=True)
+    assert np.abs(d_iz - g["angle_diff_ignore_z"]).max() < 1e-7
 
 
 def test_ids_and_samplers():
@@ -36,11 +40,16 @@ def test_ids_and_samplers():
     assert ms.parse_block_id("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1") == ("ignore", "xyz", "sparse", "sensordata")
     assert ms.parse_block_id("HandManipulateBlockRotateZ_BooleanTouchSensorsDense-v1") == ("ignore", "z", "dense", "boolean")
     assert ms.parse_block_id("HandManipulateBlockRotateParallel-v1")[1] == "parallel"
-    with pytest.raises(ValueError):
-        ms.parse_block_id("HandManipulateBlock-v1")
+    assert ms.parse_block_id("HandManipulateBlock-v1") == ("random", "xyz", "sparse", "off")
+    assert ms.parse_block_id("HandManipulatePenRotate_BooleanTouchSensors-v1") == ("ignore", "xyz", "sparse", "boolean") and ms.object_of("HandManipulatePen-v1") == "pen"
+    for bad in ("HandManipulateBlockFull_BooleanTouchSensors-v1", "HandManipulateEgg-v1", "HandManipulateBlock-v0"):
+        with pytest.raises(ValueError):
+            ms.parse_block_id(bad)
     pq = ms.canonical_parallel_quats()
     p0, q0 = np.array([1.0, 0.87, 0.2]), np.array([1.0, 0.0, 0.0, 0.0])
-    for tp, tr in ms.BLOCK_VARIANTS.values():
+    keep = ms.sample_reset_object_pose(np_random(1)[0], p0, q0, "ignore", "xyz", pq, randomize_initial_rotation=False)   # pen: position noise only
+    assert np.array_equal(keep[3:], q0) and np.abs(keep[:3] - p0).max() > 0
+    for _obj, tp, tr in ms.BLOCK_VARIANTS.values():
         rng = np_random(3)[0]
         pose = ms.sample_reset_object_pose(rng, p0, q0, tp, tr, pq)
         assert pose.shape == (7,) and abs(np.linalg.norm(pose[3:]) - 1) < 1e-12 and np.abs(pose[:3] - p0).max() < 0.03
@@ -113,3 +122,28 @@ def test_emulated_touch_sensors_match_golden():
             hits += int((ref > 0).sum())
         assert np.abs(emu.hand_obs[:61] - g["obs"][i][:61])[[*range(24), *range(54, 61)]].max() < 5e-3
     assert hits > 30 and np.median(rel) < 1e-4
+
+
+def test_emulated_pen_step_matches_golden():
+    """HandManipulatePen*: capsule object against the hand's capsules / boxes, ignore-z goal distance, 0.05 m position threshold."""
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd.envs.hand import load_hand_block_model
+    from gymnasium_robotics_amd.envs.manipulate_spec import make_block_task
+
+    model = load_hand_block_model(obj="pen")
+    g = np.load(os.path.join(HERE, "golden", "hand_PenRotate_teacher.npz"))
+    task = make_block_task(model, "ignore", "xyz", "sparse", obj="pen")
+    assert task.ignore_z == 1 and abs(task.distance_threshold - 0.05) < 1e-7
+    emu = EmuSim(model, task)
+    pe_all = []
+    for i in range(0, g["obs"].shape[0], 2):
+        for k in ("qpos", "qvel", "qacc_ws"):
+            getattr(emu, k)[:] = g[k][i]
+        emu.hand_step(g["action"][i])
+        assert emu.status.value == 0
+        e = np.abs(emu.hand_obs[:61] - g["obs"][i])
+        pe = max(e[:24].max(), e[54:].max())
+        pe_all.append(pe)
+        assert pe < (2e-4 if g["activation_gap"][i] >= 2e-5 else 5e-3), (i, pe)
+    assert np.median(pe_all) < 1e-5

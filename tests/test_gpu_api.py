@@ -19,7 +19,7 @@ def _make(env_id, **kw):
 
 
 ALL_IDS = ["FetchReach-v4", "FetchPush-v4", "FetchPickAndPlaceDense-v4", "HandReach-v3", "HandManipulateBlockRotateXYZ-v1",
-           "HandManipulateBlockFull_BooleanTouchSensors-v1", "PointMaze_UMaze-v3", "AntMaze_UMaze-v5"]
+           "HandManipulateBlock_BooleanTouchSensors-v1", "HandManipulatePen_ContinuousTouchSensors-v1", "PointMaze_UMaze-v3", "AntMaze_UMaze-v5"]
 
 
 def _assert_equal(a, b):

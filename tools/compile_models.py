@@ -44,6 +44,13 @@ save_model(m, out)
 print("hand/manipulate_block.xml (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")},
       "unsupported pairs:", m.info["unsupported_pairs"], f"{os.path.getsize(out) / 1024:.0f} KiB")
 
+for xml, name, tf in (("manipulate_pen.xml", "hand_pen.npz", None), ("manipulate_pen_touch_sensors.xml", "hand_pen_touch.npz", touch_filter)):
+    m = compile_mjcf(os.path.join(ASSETS, "hand", xml), mutate=drop_target_body, touch_filter=tf, keep_sites=[])
+    out = os.path.join(OUT, name)
+    save_model(m, out)
+    print(f"hand/{xml} (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "touch zones:", len(m.tables["touch_body"]),
+          f"{os.path.getsize(out) / 1024:.0f} KiB")
+
 from gymnasium_robotics_amd.envs.maze_spec import MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze  # noqa: E402
 
 for layout in ("UMaze", "Open", "Medium", "Large"):

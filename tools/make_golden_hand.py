@@ -51,11 +51,12 @@ def snapshots(episodes=6):
 
 def block_snapshots(variant="HandManipulateBlockRotateXYZ-v1", episodes=6, steps=40):
     from gymnasium_robotics_amd.envs.hand import load_hand_block_model
-    from gymnasium_robotics_amd.envs.manipulate_spec import parse_block_id
+    from gymnasium_robotics_amd.envs.manipulate_spec import object_of, parse_block_id
     from oracle.manipulate_oracle import OracleHandBlockEnv
 
     tp, tr, rt, touch = parse_block_id(variant)
-    env = OracleHandBlockEnv(load_hand_block_model(touch=touch != "off"), tp, tr, rt, touch)
+    obj = object_of(variant)
+    env = OracleHandBlockEnv(load_hand_block_model(touch=touch != "off", obj=obj), tp, tr, rt, touch, obj)
     rng = np.random.default_rng(777)
     rec = {k: [] for k in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "ncon", "nefc", "seed", "t", "activation_gap")}
     resets = {k: [] for k in ("seed", "obs", "goal", "attempts")}
@@ -91,6 +92,11 @@ if __name__ == "__main__":
     np.savez_compressed(path, **d)
     print("HandManipulateBlockRotateXYZ_ContinuousTouchSensors", d["obs"].shape, "steps with active zones", int((d["obs"][:, 61:] > 0).any(axis=1).sum()),
           "max zones", int((d["obs"][:, 61:] > 0).sum(axis=1).max()), f"{os.path.getsize(path)/1024:.0f} KiB")
+    d = block_snapshots("HandManipulatePenRotate-v1", episodes=4, steps=30)
+    path = os.path.join(OUT, "hand_PenRotate_teacher.npz")
+    np.savez_compressed(path, **d)
+    print("HandManipulatePenRotate", d["obs"].shape, "max nefc", d["nefc"].max(), "max ncon", d["ncon"].max(), "reset attempts", d["reset_attempts"],
+          f"{os.path.getsize(path)/1024:.0f} KiB")
     d = snapshots()
     path = os.path.join(OUT, "hand_HandReach_teacher.npz")
     np.savez_compressed(path, **d)
