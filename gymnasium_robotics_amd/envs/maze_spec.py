@@ -153,3 +153,17 @@ def sample_maze_reset(maze: Maze, rng, position_noise_range: float = 0.25, optio
             reset_pos = maze.unique_reset_locations[rng.integers(low=0, high=len(maze.unique_reset_locations))].copy()
     reset_pos = noise(reset_pos)
     return goal, reset_pos
+
+
+def redraw_goal(maze: Maze, rng, achieved_xy, goal_xy, position_noise_range: float = 0.25):
+    """MazeEnv.update_goal (maze_v4.py:400-418) for one world whose agent is within GOAL_RADIUS of its goal: draw goal cell +
+    xy noise until the new goal is farther than the radius (same PCG64 draw order as the reference loop)."""
+    goal = np.asarray(goal_xy, dtype=np.float64).copy()
+    if len(maze.unique_goal_locations) <= 1:
+        return goal
+    achieved_xy = np.asarray(achieved_xy, dtype=np.float64)
+    while np.linalg.norm(achieved_xy - goal) <= GOAL_RADIUS:
+        goal = maze.unique_goal_locations[rng.integers(low=0, high=len(maze.unique_goal_locations))].copy()
+        goal[0] += rng.uniform(low=-position_noise_range, high=position_noise_range) * maze.maze_size_scaling
+        goal[1] += rng.uniform(low=-position_noise_range, high=position_noise_range) * maze.maze_size_scaling
+    return goal

@@ -17,7 +17,7 @@ from .. import _native
 from ..core import GoalVecEnv, np_random
 from ..mjcf import CompiledModel, compile_mjcf, load_model
 from ..spaces import Box, Dict, batch_space
-from .maze_spec import (ANT_FRAME_SKIP, ANT_MAZE_HEIGHT, ANT_MAZE_SIZE_SCALING, GOAL_RADIUS, MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze,
+from .maze_spec import (redraw_goal, ANT_FRAME_SKIP, ANT_MAZE_HEIGHT, ANT_MAZE_SIZE_SCALING, GOAL_RADIUS, MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze,
                         parse_ant_maze_id, parse_point_maze_id, sample_maze_reset)
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
@@ -52,8 +52,7 @@ class PointMazeVecEnv(GoalVecEnv):
         if maze_map is None:
             layout, rt, mes = self._parse_id(env_id)
             maze_map = MAPS[layout]
-        if reset_target:
-            raise NotImplementedError("reset_target=True (goal redraw inside step, maze_v4.py:400-418) is not implemented yet")
+        self.reset_target = bool(reset_target)
         self.env_id, self.reward_type = env_id, reward_type or rt
         self.continuing_task, self.position_noise_range = continuing_task, position_noise_range
         self.max_episode_steps = mes if max_episode_steps == -1 else max_episode_steps
@@ -164,6 +163,13 @@ class PointMazeVecEnv(GoalVecEnv):
             if len(pending):
                 self._reset_worlds(pending)
                 self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
+            new_goals = None
+            if self.reset_target and self.continuing_task and len(self.maze.unique_goal_locations) > 1:
+                # MazeEnv.update_goal (maze_v4.py:400-418): the returned observation still carries the goal that was just reached
+                hit = np.nonzero(self.success.cpu().numpy().astype(bool) & stepped)[0]
+                if len(hit):
+                    ag, dg = self.achieved[hit].double().cpu().numpy(), self.goal[hit].double().cpu().numpy()
+                    new_goals = (hit, np.stack([redraw_goal(self.maze, self.np_randoms[w], ag[k], dg[k], self.position_noise_range) for k, w in enumerate(hit)]))
             done = terminated | truncated
             if self.autoreset_mode == "next_step":
                 self._needs_reset |= done
@@ -172,6 +178,13 @@ class PointMazeVecEnv(GoalVecEnv):
                 self._reset_worlds(np.nonzero(done)[0])
                 self.reward.copy_(keep)
         obs = self._obs_dict()
+        if new_goals is not None:
+            if self.output == "torch":
+                obs = dict(obs, desired_goal=self.goal.clone())
+            hit, goals = new_goals
+            still = ~done[hit] if self.autoreset_mode == "same_step" else np.ones(len(hit), bool)   # worlds reset in this call keep their reset goal
+            if still.any():
+                self.goal[torch.from_numpy(hit[still]).to(self.device)] = torch.from_numpy(goals[still].astype(np.float32)).to(self.device)
         if self.output == "torch":
             return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), self._info()
         return obs, self.reward.double().cpu().numpy(), terminated, truncated, self._info()

@@ -107,3 +107,25 @@ def test_emulated_ant_kernel_matches_oracle_teacher_forced():
         errs.append(max(np.abs(emu.obs - obs["observation"]).max(), np.abs(emu.achieved[:2] - obs["achieved_goal"]).max()))
     errs = np.array(errs)
     assert np.mean(errs < 1e-4) >= 0.9 and errs.max() < 5e-3, (np.quantile(errs, [0.5, 0.9, 1.0]))
+
+
+def test_redraw_goal_draw_order_and_contract():
+    """MazeEnv.update_goal (maze_v4.py:400-418): goal cell index, x noise, y noise per attempt, until farther than 0.45."""
+    from gymnasium_robotics_amd.core import np_random
+    from gymnasium_robotics_amd.envs.maze_spec import GOAL_RADIUS, MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze, redraw_goal
+
+    maze = Maze(MAPS["Large_Diverse_GR"], POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT)
+    assert len(maze.unique_goal_locations) > 1
+    a, b = np_random(9)[0], np_random(9)[0]
+    at = maze.unique_goal_locations[0].copy()
+    new = redraw_goal(maze, a, at, at, 0.25)
+    assert np.linalg.norm(new - at) > GOAL_RADIUS
+    g = at.copy()
+    while np.linalg.norm(at - g) <= GOAL_RADIUS:
+        g = maze.unique_goal_locations[b.integers(low=0, high=len(maze.unique_goal_locations))].copy()
+        g[0] += b.uniform(low=-0.25, high=0.25) * maze.maze_size_scaling
+        g[1] += b.uniform(low=-0.25, high=0.25) * maze.maze_size_scaling
+    assert np.array_equal(new, g) and a.uniform() == b.uniform()
+    single = Maze(MAPS["UMaze"], POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT)   # one goal cell only: nothing to redraw
+    if len(single.unique_goal_locations) <= 1:
+        assert np.array_equal(redraw_goal(single, a, at, at, 0.25), at)

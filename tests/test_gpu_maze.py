@@ -138,3 +138,38 @@ def test_ant_maze_large_runs_and_flags():
     d = np.linalg.norm(obs["achieved_goal"] - obs["desired_goal"], axis=1)
     assert np.array_equal(info["success"], d <= 0.45)
     assert 0.2 < obs["observation"][:, 0].mean() < 0.9  # torso height stays physical
+
+
+def test_reset_target_redraws_goal_like_the_oracle():
+    """reset_target=True (maze_v4.py:400-418): the step that reaches the goal still reports the old goal, the next one a new goal;
+    world-by-world identical to the oracle env driven with the same seed and actions."""
+    from oracle.maze_oracle import OraclePointMazeEnv
+
+    n = 4
+    env = _mk("PointMaze_Large_Diverse_GR-v3", n, reset_target=True, max_episode_steps=None)
+    obs, _ = env.reset(seed=3)
+    orcs = [OraclePointMazeEnv(env.model, env.maze, reward_type=env.reward_type, reset_target=True) for _ in range(n)]
+    for i, o in enumerate(orcs):
+        o.reset(seed=3 + i)
+    changed = 0
+    for t in range(400):
+        d = obs["desired_goal"] - np.stack([o.sim.qpos[:2] for o in orcs])
+        act = np.clip(d * 3.0, -1, 1).astype(np.float32)            # drive straight at the goal (walls permitting)
+        prev_goal = obs["desired_goal"].copy()
+        import torch
+        for name in ("qpos", "qvel", "qacc_ws"):   # teacher forcing: every step starts from the oracle's state
+            src = np.stack([getattr(o.sim, "qacc_warmstart" if name == "qacc_ws" else name) for o in orcs]).astype(np.float32)
+            getattr(env, name).copy_(torch.from_numpy(src).to(env.device))
+        obs, r, term, trunc, info = env.step(act)
+        assert np.array_equal(obs["desired_goal"], prev_goal) or t > 0   # the reaching step reports the goal it reached
+        for i, o in enumerate(orcs):
+            oo, orr, _, _, oi = o.step(act[i])
+            assert np.abs(obs["observation"][i] - oo["observation"]).max() < 2e-3
+            assert np.abs(obs["desired_goal"][i] - oo["desired_goal"]).max() < 1e-6
+            assert bool(info["success"][i]) == oi["success"] or abs(np.linalg.norm(oo["achieved_goal"] - oo["desired_goal"]) - 0.45) < 1e-4
+            if oi["success"]:
+                changed += 1
+                assert np.abs(env.goal[i].double().cpu().numpy() - o.goal).max() < 1e-6 and np.linalg.norm(o.goal - oo["achieved_goal"]) > 0.45
+        assert not term.any()
+    assert changed >= 2
+    env.close()
