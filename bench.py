@@ -25,6 +25,14 @@ sys.path.insert(0, ROOT)
 
 ENV_ID = "FetchPickAndPlace-v4"
 WORLDS_PER_GPU = 4096
+# Other BASELINE.json configs can be timed with --workload (the driver's default run is cfg 2 = "fetch").  Per config: env id, worlds
+# per GPU, action dim, step-kernel name, algorithmic HBM bytes per env-step
+WORKLOADS = {
+    "fetch": ("FetchPickAndPlace-v4", 4096, 4, "grx_fetch_step_kernel", 715),
+    "hand_touch": ("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", 16384, 20, "grx_hand_step_kernel", 1635),   # cfg 3
+    "hand_reach": ("HandReach-v3", 16384, 20, "grx_hand_step_kernel", 1035),   # r 24+24+24+20, w 72, out 63+15+15+1
+    "antmaze": ("AntMaze_Large_Diverse_GR-v5", 8192, 8, "grx_point_step_kernel", 507),                                      # cfg 4 (8192 per GPU x 8)
+}
 HER_K = 4  # relabelled goals per transition ("future" strategy with k=4)
 # algorithmic HBM bytes per env-step of the fused kernel (SURVEY.md §8(d) cfg 2):
 # read qpos22+qvel21+warm21+mocap7+act4 = 75 words, write 22+21+21+7 = 71, outputs obs25+ag3+dg3+r1 = 32 -> 178*4 + 3 flag bytes
@@ -53,6 +61,86 @@ def cpu_baseline(seconds: float = 12.0):
                       "oracle = fp64 restatement (MuJoCo is not installable here), Python task layer + C physics"}
 
 
+def other_workload(args):
+    """Same contract as the default run for the other single-kernel families: random actions, same-step autoreset at the family's
+    time limit, one RCCL all-gather of the per-step outputs when N > 1.  No HER leg, no CPU baseline."""
+    env_id, n_default, act_dim, kernel, algo = WORKLOADS[args.workload]
+    world_size, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(f"cuda:{local_rank}"))
+    device = f"cuda:{local_rank}"
+    n = args.worlds_per_gpu if args.worlds_per_gpu != WORLDS_PER_GPU else n_default
+    if args.workload == "antmaze":
+        from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv as Env
+    else:
+        from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv, HandReachVecEnv
+        Env = HandReachVecEnv if args.workload == "hand_reach" else HandBlockVecEnv
+    env = Env(env_id, num_envs=n, device=device, output="torch", autoreset_mode="same_step", seed_offset=rank * n)
+    env.reset(seed=0)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    gdim = env.goal.shape[1]
+    out_dim = env.obs_dim + 2 * gdim + 2
+    packed = torch.empty(n, out_dim, device=device)
+    gathered = torch.empty(n * world_size, out_dim, device=device) if dist else None
+    events = []
+
+    def one_step(timed):
+        a = torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        obs, r, term, trunc, info = env.step(a)
+        e1.record()
+        if timed:
+            events.append((e0, e1))
+        if dist:
+            packed[:, : env.obs_dim] = obs["observation"]
+            packed[:, env.obs_dim: env.obs_dim + gdim] = obs["achieved_goal"]
+            packed[:, env.obs_dim + gdim: env.obs_dim + 2 * gdim] = obs["desired_goal"]
+            packed[:, -2] = r
+            packed[:, -1] = (info["is_success"] if "is_success" in info else info["success"]).float()
+            dist.all_gather_into_tensor(gathered, packed)
+
+    for _ in range(args.warmup):
+        one_step(False)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # env.step() here = the step kernel (+ masked reset launches at episode ends): events bracket the whole call
+    step_ms = float(np.median([a.elapsed_time(b) for a, b in events]))
+    if rank == 0:
+        value = n * world_size * args.steps / elapsed
+        achieved = algo * n / (step_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "env-steps/s (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{env_id}, {n} worlds/GPU x {world_size} GPU, uniform random actions, same-step autoreset at the time limit",
+                       "worlds_per_gpu": n, "parallelism": f"world-shard x{world_size}" + (", RCCL all_gather of outputs" if world_size > 1 else ""),
+                       "status_flagged_worlds": int((env.status != 0).sum().item())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": kernel, "kernel_ms": step_ms, "algorithmic_bytes_per_launch": algo * n,
+                         "note": "median env.step() device time (step kernel; episode-end steps add masked reset launches); issue-bound, see DESIGN.md"},
+        }))
+    if dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,7 +148,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--worlds-per-gpu", type=int, default=WORLDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="fetch")
     args = ap.parse_args()
+    if args.workload != "fetch":
+        return other_workload(args)
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
