@@ -71,9 +71,9 @@ template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
          g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC;
 }
-typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
-typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1> GrxShapeFetchArm;    // FetchReach (arm only)
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
+typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchArm;    // FetchReach (arm only)
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1> GrxShapeAntMedium;
@@ -84,7 +84,7 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24> GrxShapeHandBlock;  // Shadow
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
 template <class S>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
 grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int w = blockIdx.x, lane_ = threadIdx.x;

@@ -29,13 +29,18 @@ from .fetch_spec import DISTANCE_THRESHOLD, FETCH_TASKS, MAX_EPISODE_STEPS, N_SU
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
 
 
+# Engine capacities of the Fetch models: random rollouts peak at 16 contacts / 89 rows / ~1 000 Jacobian-pool words (the defaults are
+# 32 / 144 / 2 032); the trimmed tables bring the per-world LDS footprint to 14 granules = 9 worlds per CU.
+FETCH_CAPACITY = {"maxcon": 24, "maxefc": 112, "jpool": 1536}
+
+
 def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledModel:
     """Compiled model tables for a Fetch task: compiled from MJCF when an asset tree is given
     (``assets_root`` or $GRX_ASSETS_ROOT = .../gymnasium_robotics/envs/assets), else the packaged blob."""
     xml = FETCH_TASKS[task]["xml"]
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
-        return compile_mjcf(os.path.join(assets_root, xml))
+        return compile_mjcf(os.path.join(assets_root, xml), capacity=FETCH_CAPACITY)
     path = os.path.join(_MODELS_DIR, os.path.splitext(os.path.basename(xml))[0] + ".npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist (no packaged model and no assets_root given)")

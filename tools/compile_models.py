@@ -14,8 +14,10 @@ from gymnasium_robotics_amd.mjcf import compile_mjcf, save_model  # noqa: E402
 ASSETS = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/gymnasium_robotics/envs/assets"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gymnasium_robotics_amd", "models")
 os.makedirs(OUT, exist_ok=True)
+from gymnasium_robotics_amd.envs.fetch import FETCH_CAPACITY  # noqa: E402
+
 for xml in ("fetch/reach.xml", "fetch/push.xml", "fetch/pick_and_place.xml"):
-    m = compile_mjcf(os.path.join(ASSETS, xml))
+    m = compile_mjcf(os.path.join(ASSETS, xml), capacity=FETCH_CAPACITY)
     # keep hull vertices only for meshes that take part in a supported pair
     out = os.path.join(OUT, os.path.splitext(os.path.basename(xml))[0] + ".npz")
     save_model(m, out)
