@@ -14,9 +14,13 @@ if not os.path.exists(prof_so):
                            os.path.join(ROOT, "gymnasium_robotics_amd", "csrc", "grx_kernels.hip")])
 _native.LIB_PATH = prof_so
 from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
+from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv, HandReachVecEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-env = FetchVecEnv("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
+env_id = sys.argv[2] if len(sys.argv) > 2 else "FetchPickAndPlace-v4"
+Env = FetchVecEnv if env_id.startswith("Fetch") else (HandReachVecEnv if env_id.startswith("HandReach") else HandBlockVecEnv)
+env = Env(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
 env.reset(seed=0)
+NA = env.single_action_space.shape[0]
 L = _native.lib()
 names = ["kinematics", "inertia_cdof_crb_M", "collision", "make_constraint", "velocity_rne", "M_factor_solve", "newton_eval", "newton_grad",
          "newton_hessian", "newton_factor_solve", "newton_linesearch", "newton_final", "euler", "other"]
@@ -25,8 +29,11 @@ NP = 48
 tot = np.zeros(NP)
 K = 10
 for k in range(K):
-    a = torch.rand(n, 4, device="cuda:0", generator=g) * 2 - 1
-    a[:, 2] = -a[:, 2].abs()  # push towards the table so that contacts are active
+    a = torch.rand(n, NA, device="cuda:0", generator=g) * 2 - 1
+    if NA == 4:
+        a[:, 2] = -a[:, 2].abs()  # push towards the table so that contacts are active
+    else:
+        a *= 0.3                   # gentle hand motion keeps the object in the hand
     L.grx_profile_reset()
     env.step(a)
     torch.cuda.synchronize()
@@ -36,7 +43,7 @@ for k in range(K):
         tot += np.array(list(out), dtype=np.float64) / n  # kernel sums over worlds
 tot /= (K - 2)
 s = tot.sum()
-print(f"cycles per env.step (20 substeps), mean over {n} worlds: {s:.0f}  (= {s/20:.0f} per substep)")
+print(f"{env_id}: cycles per env.step (20 substeps), mean over {n} worlds: {s:.0f}  (= {s/20:.0f} per substep)")
 for nm, v in zip(names, tot):
     print(f"  {nm:22s} {v:12.0f}  {100*v/s:5.1f}%")
 for k in range(16, NP):
