@@ -1222,19 +1222,21 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     FOR_LANES {
       int k = base + lane, isbox = 0;
       if (k < m->ndevpair) {
-        int p = m->devpair[k], g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
-        int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-        float margin = m->pair_margin[p];
+        // one packed record per candidate (geoms, types, margin, broad-phase radius): a single level of model-table loads
+        const unsigned rec = (unsigned)m->devpair_geoms[k];
+        const int g1 = rec & 0xFFF, g2 = (rec >> 12) & 0xFFF, t1 = (rec >> 24) & 0xF, t2 = rec >> 28;
+        const float margin = m->devpair_bound[2 * k], rb = m->devpair_bound[2 * k + 1];
         float dx[3] = {c->gxpos[3 * g2] - c->gxpos[3 * g1], c->gxpos[3 * g2 + 1] - c->gxpos[3 * g1 + 1], c->gxpos[3 * g2 + 2] - c->gxpos[3 * g1 + 2]};
         int pass;
         if (t1 == 0) {
           float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]};
-          pass = dot3f(dx, n) <= m->geom_rbound[g2] + margin;
+          pass = dot3f(dx, n) <= rb + margin;
         } else {
-          float r = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+          float r = rb + margin;
           pass = dot3f(dx, dx) <= r * r;
         }
         if (pass) {
+          const int p = m->devpair[k];
           if (t1 == 0 && t2 == 2) grx_plane_sphere(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 3) grx_plane_capsule(m, c, p, g1, g2, margin);
           else if (t1 == 3 && t2 == 6) grx_capsule_box(m, c, p, g1, g2, margin);

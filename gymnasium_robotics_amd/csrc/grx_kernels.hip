@@ -150,6 +150,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
+  if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
 #endif
   for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
   __syncthreads();
@@ -168,6 +169,10 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
     b.success[w] = succ; b.terminated[w] = (!t.continuing_task && succ) ? 1 : 0;
     b.status[w] = c.cnt[2];
   }
+#ifdef GRX_PROFILE
+  GRX_TICK(&c, GRX_P_OTHER);
+  if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);
+#endif
 }
 
 // Shadow hand reach env.step() (or mj_forward + outputs when forward_only): one wavefront per world, same engine

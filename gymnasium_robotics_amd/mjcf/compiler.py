@@ -1466,6 +1466,12 @@ class _Lowering:
             mpair_j=np.array(mpj, np.int32), dof_cvelstart=dof_cvelstart, dof_chainmask=chainmask,
             devpair=np.nonzero(pair_supported)[0].astype(np.int32),
         )
+        if ng >= 4096:
+            raise ValueError("engine limit: at most 4095 geoms (packed candidate records)")
+        dp = T["devpair"]
+        g1s, g2s = pair_geom1[dp], pair_geom2[dp]
+        T["devpair_geoms"] = (g1s | (g2s << 12) | (geom_type[g1s] << 24) | (geom_type[g2s] << 28)).astype(np.int64).astype(np.uint32).view(np.int32) if len(dp) else np.zeros(0, np.int32)
+        T["devpair_bound"] = np.stack([pair_margin[dp], np.where(geom_type[g1s] == GEOM_PLANE, geom_rbound[g2s], geom_rbound[g1s] + geom_rbound[g2s])], axis=1) if len(dp) else np.zeros((0, 2))
         info["nmpair"] = len(mpi)
         info["nbody_full"] = nb
         info["unsupported_pairs"] = int(np.sum(pair_supported == 0))
