@@ -75,10 +75,10 @@ typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFe
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchArm;    // FetchReach (arm only)
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
-typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1> GrxShapeAntLarge;
-typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1> GrxShapeAntMedium;
-typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1> GrxShapeAntOpen;
-typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1> GrxShapeAntUMaze;
+typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
+typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
+typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntOpen;
+typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntUMaze;
 typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 0, 16> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
@@ -137,7 +137,7 @@ grx_fetch_forward_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_wor
 
 // PointMaze env.step(): one wavefront per world, same engine
 template <class S>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
 grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int w = blockIdx.x, lane_ = threadIdx.x;

@@ -23,6 +23,11 @@ from .maze_spec import (redraw_goal, ANT_FRAME_SKIP, ANT_MAZE_HEIGHT, ANT_MAZE_S
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
 
 
+# Engine capacities of the ant models: random rollouts peak at 4 contacts / 18 rows / ~200 Jacobian-pool words; 16 / 96 / 1 024 leave a
+# wide margin (the legs can touch at most a few walls and the floor at once) and cut the per-world LDS footprint to 10 worlds per CU.
+ANT_CAPACITY = {"maxcon": 16, "maxefc": 96, "jpool": 1024}
+
+
 def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: Optional[str] = None, agent: str = "point") -> CompiledModel:
     """Model tables of the agent MJCF (point.xml / ant.xml) + one wall box per wall cell.  Compiled from MJCF when an asset
     tree is available (needed for custom maze maps), else the packaged blob of the registered wall layout.
@@ -30,7 +35,7 @@ def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: O
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
         xml = os.path.join(assets_root, "point", "point.xml") if agent == "point" else os.path.join(assets_root, "..", "mujoco", "assets", "ant.xml")
-        return compile_mjcf(xml, mutate=maze.add_walls)
+        return compile_mjcf(xml, mutate=maze.add_walls, capacity=ANT_CAPACITY if agent == "ant" else None)
     if layout_name is None:
         raise OSError("custom maze maps need the MJCF assets (assets_root / $GRX_ASSETS_ROOT)")
     path = os.path.join(_MODELS_DIR, f"{agent}_{layout_name.split('_')[0]}.npz")

@@ -63,10 +63,11 @@ for layout in ("UMaze", "Open", "Medium", "Large"):
     print("point.xml +", layout, "walls ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "ngeom", "npair")}, f"{os.path.getsize(out) / 1024:.0f} KiB")
 
 from gymnasium_robotics_amd.envs.maze_spec import ANT_MAZE_HEIGHT, ANT_MAZE_SIZE_SCALING  # noqa: E402
+from gymnasium_robotics_amd.envs.point_maze import ANT_CAPACITY  # noqa: E402
 
 for layout in ("UMaze", "Open", "Medium", "Large"):
     maze = Maze(MAPS[layout], ANT_MAZE_SIZE_SCALING, ANT_MAZE_HEIGHT)
-    m = compile_mjcf(os.path.join(ASSETS, "..", "mujoco", "assets", "ant.xml"), mutate=maze.add_walls)
+    m = compile_mjcf(os.path.join(ASSETS, "..", "mujoco", "assets", "ant.xml"), mutate=maze.add_walls, capacity=ANT_CAPACITY)
     out = os.path.join(OUT, f"ant_{layout}.npz")
     save_model(m, out)
     print("ant.xml +", layout, "walls ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "ngeom", "npair")}, f"{os.path.getsize(out) / 1024:.0f} KiB")
