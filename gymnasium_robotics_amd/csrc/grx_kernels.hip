@@ -79,7 +79,7 @@ typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntL
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
 typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntOpen;
 typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntUMaze;
-typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 0, 16> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
+typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, 96, 512, 0, 16> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
@@ -177,7 +177,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
 
 // Shadow hand reach env.step() (or mj_forward + outputs when forward_only): one wavefront per world, same engine
 template <class S>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, (S::kFixed && S::JP < GRX_JPOOL) ? 3 : 2)
 grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int w = blockIdx.x, lane_ = threadIdx.x;

@@ -25,8 +25,9 @@ GOAL_DIM = 15
 
 
 # the task reads the five fingertip sites only (reach.py:398-405); without an object the hand produces a handful of contacts
-# (explicit finger pairs): 16 contact slots.  Both trim the per-world LDS footprint to 7 worlds per CU.
-HAND_REACH_COMPILE = dict(keep_sites=["robot0:S_fftip", "robot0:S_mftip", "robot0:S_rftip", "robot0:S_lftip", "robot0:S_thtip"], capacity={"maxcon": 16})
+# (explicit finger pairs), 24 friction-loss rows and a few limit / tendon rows (peaks in random rollouts: 4 contacts, 33 rows, < 100 pool
+# words): 16 contact slots, 96 rows, 512 pool words.  Together they trim the per-world LDS footprint to 9 worlds per CU.
+HAND_REACH_COMPILE = dict(keep_sites=["robot0:S_fftip", "robot0:S_mftip", "robot0:S_rftip", "robot0:S_lftip", "robot0:S_thtip"], capacity={"maxcon": 16, "maxefc": 96, "jpool": 512})
 
 
 def load_hand_reach_model(assets_root: Optional[str] = None) -> CompiledModel:
