@@ -82,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan;
   float timestep, gravity[3], meaninertia, impratio;
 };
 
@@ -100,7 +100,7 @@ struct GrxCtx {
       *Mv, *tmpv;
   // contacts
   float *con_dist, *con_pos, *con_frame;
-  int *con_pair, *con_efc, *con_nr, *con_b1, *con_b2, *con_span;  // con_span = lo | len << 8 of the union dof chain
+  int *con_pair, *con_efc, *con_nr, *con_b1, *con_b2, *con_span, *con_ioff;  // con_span = loA | lenA << 8 | loB << 16 | lenB << 24 (pair_span); con_ioff = first item of the contact-Jacobian pass
   // constraint rows
   // Jacobian rows are stored packed: row r covers dofs [lo, lo+len) at Jp[off .. off+len); efc_row[r] = off | lo << 12 | len << 20
   float *Jp, *efc_pos, *efc_D, *efc_aref, *efc_jar, *efc_jv, *efc_force, *efc_floss;
@@ -146,7 +146,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
   const int ckeep = ntouch ? maxcon * (3 + 3 + 3) : 0;   // touch sensors read the contacts after the solve: keep pos / normal / pair / rows out of the overlay
   pers += ckeep;
-  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + maxcon * (1 + 3 + 3 + 6) - ckeep;
+  int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + maxcon * (1 + 3 + 3 + 7) - ckeep;
   int p2 = nv * nv + 5 * nv + 4 * maxefc;
   return pers + (p1 > p2 ? p1 : p2) + 8;
 }
@@ -192,7 +192,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   }
   CARVE(cinert, 10 * m->nbody) CARVE(cdof_dot, 6 * m->nv)
   CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv)
-  CARVE(con_dist, m->maxcon) CARVEI(con_span, m->maxcon) CARVEI(con_b1, m->maxcon) CARVEI(con_b2, m->maxcon)
+  CARVE(con_dist, m->maxcon) CARVEI(con_span, m->maxcon) CARVEI(con_ioff, m->maxcon) CARVEI(con_b1, m->maxcon) CARVEI(con_b2, m->maxcon)
   if (!m->ntouch) {
     CARVE(con_pos, 3 * m->maxcon) CARVE(con_frame, 3 * m->maxcon)  // con_frame: contact normal only
     CARVEI(con_pair, m->maxcon) CARVEI(con_efc, m->maxcon) CARVEI(con_nr, m->maxcon)
@@ -374,9 +374,11 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 // dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
 // Model shape: the ten layout dims as compile-time constants (0 = read from the model at run time).
 template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0, int MAXEFC_ = GRX_MAXEFC, int JPOOL_ = GRX_JPOOL,
-          int NTOUCH_ = 0, int MAXCON_ = GRX_MAXCON>
+          int NTOUCH_ = 0, int MAXCON_ = GRX_MAXCON, int TWOSPAN_ = 0>
 struct GrxShape {
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_, ME = MAXEFC_, JP = JPOOL_, NT = NTOUCH_, MC = MAXCON_;
+  // rows may carry a second dof span (models compiled with split pair spans); fixed shapes without it skip that bookkeeping
+  static constexpr bool kTwoSpan = (NV_ == 0) || (TWOSPAN_ != 0);
   static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
@@ -1356,6 +1358,32 @@ GRX_MEM unsigned long long grx_chainmask(const GrxModel* m, int b) {
 #define GRX_ROW_LO(info) (((info) >> 12) & 0xFF)
 #define GRX_ROW_LEN(info) (((info) >> 20) & 0xFF)
 #define GRX_ROW_PACK(off, lo, len) ((off) | ((lo) << 12) | ((len) << 20))
+// Second dof span of a row (contacts whose two body chains leave a gap of unused dofs between them): it rides in the upper bits of
+// efc_id = sub | id << 4 | loB << 12 | lenB << 20, and its entries follow the first span's entries in the pool.
+#define GRX_ROW_IDOF(id) (((id) >> 4) & 0xFF)
+#define GRX_ROWB_LO(id) (((id) >> 12) & 0xFF)
+#define GRX_ROWB_LEN(id) (((id) >> 20) & 0xFF)
+// index of dof d inside the row's storage, or -1 when the row has no entry for it
+GRX_MEM int grx_row_pos(int info, int id, int d) {
+  const int ja = d - GRX_ROW_LO(info);
+  if ((unsigned)ja < (unsigned)GRX_ROW_LEN(info)) return ja;
+  if (!S::kTwoSpan) return -1;
+  const int jb = d - GRX_ROWB_LO(id);
+  return ((unsigned)jb < (unsigned)GRX_ROWB_LEN(id)) ? GRX_ROW_LEN(info) + jb : -1;
+}
+// row r of J times a dof vector
+GRX_MEM float grx_row_dot(const GrxCtx* c, int r, const float* v) {
+  const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
+  float s = 0;
+#pragma unroll 8
+  for (int j = 0; j < len; j++) s += c->Jp[off + j] * v[lo + j];
+  if (S::kTwoSpan) {
+    const int id = c->efc_id[r], lob = GRX_ROWB_LO(id), lenb = GRX_ROWB_LEN(id);
+#pragma unroll 2
+    for (int j = 0; j < lenb; j++) s += c->Jp[off + len + j] * v[lob + j];
+  }
+  return s;
+}
 
 GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_FRESH_MODEL(m, c);
@@ -1384,10 +1412,11 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       int p = c->con_pair[k], dim = m->pair_condim[p];
       int active = c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p];
       nr = active ? ((dim == 1) ? 1 : 2 * (dim - 1)) : 0;
-      int cb1 = m->geom_bodyid[m->pair_geom1[p]], cb2 = m->geom_bodyid[m->pair_geom2[p]], slo;
+      int cb1 = m->geom_bodyid[m->pair_geom1[p]], cb2 = m->geom_bodyid[m->pair_geom2[p]];
       c->con_b1[k] = cb1; c->con_b2[k] = cb2;
-      grx_mask_span(grx_chainmask(m, cb1) | grx_chainmask(m, cb2), &slo, &slen);
-      c->con_span[k] = slo | (slen << 8);
+      const int sp = m->pair_span[p];   // static: the two dof spans of the pair's body chains
+      slen = ((sp >> 8) & 0xFF) + ((sp >> 24) & 0xFF);
+      c->con_span[k] = sp;
     }
     LV(conr) = nr; LV(conw) = nr * slen; LV(coni) = nr ? slen : 0;
     // fixed-tendon limits: one lane per tendon (length = sum coef * qpos)
@@ -1428,8 +1457,8 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   }
   int nefc = rows0 + nc;
   if (nefc > maxefc) nefc = maxefc;
-  // items of the contact-Jacobian pass: one per (kept contact, dof of its span); the running item offset rides in the
-  // upper half of con_span so that an item can find its contact with a binary search
+  // items of the contact-Jacobian pass: one per (kept contact, dof of its spans); the running item offset (con_ioff) lets an
+  // item find its contact with a binary search
   GRX_LANEVAR_I(conix); int nitem;
   FOR_LANES { if (lane >= ncon_fit) LV(coni) = 0; }
   GRX_SCAN_EXCL(coni, conix, nitem);
@@ -1469,9 +1498,12 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       int r = rows0 + LV(conrx), off = pool0 + LV(conwx);
       c->con_efc[k] = nr ? r : -1;
       c->con_nr[k] = nr;
-      int slo = c->con_span[k] & 0xFF, slen = (c->con_span[k] >> 8) & 0xFF;
-      c->con_span[k] = slo | (slen << 8) | (LV(conix) << 16);
-      for (int q = 0; q < nr; q++) { c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = (k << 4) | q; c->efc_row[r + q] = GRX_ROW_PACK(off + q * slen, slo, slen); }
+      const int sp = c->con_span[k], slo = sp & 0xFF, slena = (sp >> 8) & 0xFF, slob = (sp >> 16) & 0xFF, slenb = (sp >> 24) & 0xFF, slen = slena + slenb;
+      c->con_ioff[k] = LV(conix);
+      for (int q = 0; q < nr; q++) {
+        c->efc_kind[r + q] = GRX_ROW_CONTACT; c->efc_id[r + q] = (k << 4) | q | (slob << 12) | (slenb << 20);
+        c->efc_row[r + q] = GRX_ROW_PACK(off + q * slen, slo, slena);
+      }
     }
   }
   LANE0 { c->cnt[1] = nefc; c->cnt[3] = ne; c->cnt[4] = nf; c->cnt[5] = nl; if (overflow) c->cnt[2] |= GRX_ST_EFC_OVERFLOW; }
@@ -1518,7 +1550,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
         c->Jp[GRX_ROW_OFF(c->efc_row[r])] = 1.0f;
         c->efc_pos[r] = 0;
       } else {
-        int j = c->efc_id[r] >> 4, side = c->efc_id[r] & 15; float q = c->qpos[m->jnt_qposadr[j]];
+        int j = GRX_ROW_IDOF(c->efc_id[r]), side = c->efc_id[r] & 15; float q = c->qpos[m->jnt_qposadr[j]];
         c->Jp[GRX_ROW_OFF(c->efc_row[r])] = side ? -1.0f : 1.0f;
         c->efc_pos[r] = side ? m->jnt_range[2 * j + 1] - q : q - m->jnt_range[2 * j];
       }
@@ -1542,11 +1574,11 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     GRX_SUBTICK(c, 4);
     for (int it = lane; it < nitem; it += 64) {
       int k = 0;  // largest k with item offset <= it (contacts without items share the offset of the next one)
-      for (int step = GRX_MAXCON / 2; step > 0; step >>= 1) { int kk = k + step; if (kk < ncon_fit && (c->con_span[kk] >> 16) <= it) k = kk; }
-      const int jd = it - (c->con_span[k] >> 16);
+      for (int step = GRX_MAXCON / 2; step > 0; step >>= 1) { int kk = k + step; if (kk < ncon_fit && c->con_ioff[kk] <= it) k = kk; }
+      const int jd = it - c->con_ioff[k];
       int r0 = c->con_efc[k];
-      int slo = c->con_span[k] & 0xFF, slen = (c->con_span[k] >> 8) & 0xFF;
-      int d = slo + jd;
+      const int sp = c->con_span[k], slena = (sp >> 8) & 0xFF, slen = slena + ((sp >> 24) & 0xFF);
+      int d = jd < slena ? (sp & 0xFF) + jd : ((sp >> 16) & 0xFF) + jd - slena;
       int p = c->con_pair[k], nrk = c->con_nr[k], dim = (nrk == 1) ? 1 : nrk / 2 + 1;
       int b1 = c->con_b1[k], b2 = c->con_b2[k];
       float pos[3] = {c->con_pos[3 * k], c->con_pos[3 * k + 1], c->con_pos[3 * k + 2]};
@@ -1573,7 +1605,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   // ---- per-row impedance, regulariser, reference acceleration
   FOR_LANES {
     for (int r = lane; r < nefc; r += 64) {
-      int kind = c->efc_kind[r], id = c->efc_id[r] >> 4, sub = c->efc_id[r] & 15;
+      int kind = c->efc_kind[r], id = GRX_ROW_IDOF(c->efc_id[r]), sub = c->efc_id[r] & 15;
       float solref[2], solimp[5], pos, margin = 0, dA, floss = 0, rscale = 1.0f;
       if (kind == GRX_ROW_EQ) {
         for (int k = 0; k < 2; k++) solref[k] = m->eq_solref[2 * id + k];
@@ -1614,10 +1646,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       else { kk = -solref[0] / (dmax * dmax); bb = -solref[1] / dmax; }
       if (kind == GRX_ROW_FRICTION) kk = 0;
       float R = fmaxf(GRX_MINVAL, (1.0f - imp) * dA / imp) * rscale;
-      float vel = 0;
-      { const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
-#pragma unroll 8
-        for (int j = 0; j < len; j++) vel += c->Jp[off + j] * c->qvel[lo + j]; }
+      const float vel = grx_row_dot(c, r, c->qvel);
       c->efc_D[r] = 1.0f / R;
       c->efc_aref[r] = -bb * vel - kk * imp * (pos - margin);
       if (m->nfric) c->efc_floss[r] = floss;
@@ -1645,10 +1674,7 @@ GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int ne
       c->Ma[i] = s;
     }
     for (int r = lane; r < nefc; r += 64) {
-      float s = 0;
-      { const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
-#pragma unroll 8
-        for (int j = 0; j < len; j++) s += c->Jp[off + j] * a[lo + j]; }
+      const float s = grx_row_dot(c, r, a);
       float x = s - c->efc_aref[r], D = c->efc_D[r], f; int st;
       int kind = c->efc_kind[r];
       if (kind == GRX_ROW_EQ) { f = -D * x; st = 1; }
@@ -1706,22 +1732,22 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     const int idx = lane_ & 31, half = lane_ >> 5;
     const bool incol = idx < nv;
     // Branch-free operand fetch (clamped addresses, selects instead of divergent paths), software-pipelined by hand over
-    // four row pairs: 12 independent LDS reads (row info, masked D, force), then 4 reads of the packed Jacobian, then 4 MFMAs.
+    // four row pairs: 16 independent LDS reads (row info, second span, masked D, force), then 4 reads of the packed Jacobian, then 4 MFMAs.
     const bool isf = (idx == nv);
     for (int r0 = 0; r0 < nefc; r0 += 8) {
-      int info[4]; float dq[4], fr[4], v[4]; bool rowok[4], in[4];
+      int info[4], idb[4]; float dq[4], fr[4], v[4]; bool rowok[4], in[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int row = r0 + 2 * u + half;
         rowok[u] = row < nefc;
         const int rr = rowok[u] ? row : 0;
-        info[u] = c->efc_row[rr]; dq[u] = c->efc_jv[rr]; fr[u] = c->efc_force[rr];
+        info[u] = c->efc_row[rr]; idb[u] = S::kTwoSpan ? c->efc_id[rr] : 0; dq[u] = c->efc_jv[rr]; fr[u] = c->efc_force[rr];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int jd = idx - GRX_ROW_LO(info[u]);
-        in[u] = rowok[u] && incol && ((unsigned)jd < (unsigned)GRX_ROW_LEN(info[u]));
-        v[u] = c->Jp[GRX_ROW_OFF(info[u]) + (in[u] ? jd : 0)];
+        const int pos = grx_row_pos(info[u], idb[u], idx);
+        in[u] = rowok[u] && incol && pos >= 0;
+        v[u] = c->Jp[GRX_ROW_OFF(info[u]) + (in[u] ? pos : 0)];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -1752,8 +1778,8 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
         const int i1 = i0 + 8, i2 = i0 + 16, j1 = j0 + 8, j2 = j0 + 16;
         const int vi1 = i1 < nv, vi2 = i2 < nv, vj1 = j1 < nv, vj2 = j2 < nv;
         for (int r = 0; r < nefc; r++) {
-          const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
-#define GRX_JAT(dof) (((unsigned)((dof) - lo) < (unsigned)len) ? c->Jp[off + (dof) - lo] : 0.0f)
+          const int info = c->efc_row[r], idb = c->efc_id[r], off = GRX_ROW_OFF(info);
+#define GRX_JAT(dof) (grx_row_pos(info, idb, (dof)) >= 0 ? c->Jp[off + grx_row_pos(info, idb, (dof))] : 0.0f)
           float d = c->efc_jv[r];
           float a0 = GRX_JAT(i0) * d, a1 = vi1 ? GRX_JAT(i1) * d : 0.0f, a2 = vi2 ? GRX_JAT(i2) * d : 0.0f;
           float b0 = GRX_JAT(j0), b1 = vj1 ? GRX_JAT(j1) : 0.0f, b2 = vj2 ? GRX_JAT(j2) : 0.0f;
@@ -1770,7 +1796,7 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
       }
     for (int i = lane; i < nv; i += 64) {
       float sacc = 0;
-      for (int r = 0; r < nefc; r++) { const int info = c->efc_row[r], jd = i - GRX_ROW_LO(info); if ((unsigned)jd < (unsigned)GRX_ROW_LEN(info)) sacc += c->Jp[GRX_ROW_OFF(info) + jd] * c->efc_force[r]; }
+      for (int r = 0; r < nefc; r++) { const int info = c->efc_row[r], pos = grx_row_pos(info, c->efc_id[r], i); if (pos >= 0) sacc += c->Jp[GRX_ROW_OFF(info) + pos] * c->efc_force[r]; }
       c->grad[i] = sacc;
     }
   }
@@ -1870,11 +1896,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
           p1 += c->search[i] * (c->Ma[i] - c->qfrc_smooth[i]); p2 += c->search[i] * sacc;
         }
         for (int r = lane; r < nefc; r += 64) {
-          float sacc = 0;
-          { const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
-#pragma unroll 8
-            for (int j = 0; j < len; j++) sacc += c->Jp[off + j] * c->search[lo + j]; }
-          c->efc_jv[r] = sacc;
+          c->efc_jv[r] = grx_row_dot(c, r, c->search);
         }
         LV(q1p) = p1; LV(q2p) = p2; LV(g0p) = p0;
       }

@@ -38,6 +38,8 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.integrator = d[GRX_INTEGRATOR];
   m.njump = m.nbody > 0 ? v.n_body_jump / m.nbody : 0;
   m.ntendon = v.n_tendon_adr; m.ntouch = v.n_touch_body;
+  m.twospan = 0;
+  for (int k = 0; k < v.n_pair_span; k++) if (((unsigned)v.pair_span[k] >> 24) != 0) m.twospan = 1;
   m.nfric = 0; m.nweld = 0; m.wpool = 0;
   for (int k = 0; k < v.n_weld_row; k++) m.wpool += 6 * ((v.weld_row[k] >> 20) & 0xFF);
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;

@@ -69,7 +69,7 @@ template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(cons
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC;
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan);
 }
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
@@ -79,9 +79,9 @@ typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntL
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
 typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntOpen;
 typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntUMaze;
-typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, 96, 512, 0, 16> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
+typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, 96, 512, 0, 16, 1> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 0, GRX_MAXCON, 1> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92, GRX_MAXCON, 1> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
 template <class S>
 __global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
@@ -270,11 +270,11 @@ grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_i
   GrxCtx c;
   c.A = lds; c.M = c.A + nv * nv; c.Jp = c.M + nv * nv; c.efc_D = c.Jp + GRX_MAXEFC * nv; c.efc_jv = c.efc_D + GRX_MAXEFC;
   c.efc_quad = (int*)(c.efc_jv + GRX_MAXEFC); c.efc_row = c.efc_quad + GRX_MAXEFC; c.tmpv = (float*)(c.efc_row + GRX_MAXEFC);
-  c.grad = c.tmpv + nv; c.efc_force = c.grad + nv;
+  c.grad = c.tmpv + nv; c.efc_force = c.grad + nv; c.efc_id = (int*)(c.efc_force + GRX_MAXEFC);
   for (int i = lane_; i < nv * nv; i += 64) { c.A[i] = A_in[i]; c.M[i] = A_in[i]; }
   for (int i = lane_; i < nv; i += 64) c.tmpv[i] = b_in[i];
   for (int i = lane_; i < nefc * nv; i += 64) c.Jp[i] = J_in[i];
-  for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0 ? 1 : 0; c.efc_row[i] = GRX_ROW_PACK(i * nv, 0, nv); c.efc_force[i] = 0.5f + 0.01f * (float)i; }
+  for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0 ? 1 : 0; c.efc_row[i] = GRX_ROW_PACK(i * nv, 0, nv); c.efc_id[i] = 0; c.efc_force[i] = 0.5f + 0.01f * (float)i; }
   __syncthreads();
   if (mode == 0) {
     GrxEngine<GrxShapeAny>::grx_sym_solve_full(c.A, nv, c.tmpv, lane_);
@@ -507,7 +507,7 @@ extern "C" int grx_maze_compute_reward(const float* achieved, const float* desir
 
 // test-only entry point (tests/test_gpu_primitives.py); all pointers are device pointers
 extern "C" int grx_debug_primitive(int mode, int nv, int nefc, const float* A, const float* b, const float* J, const float* D, float* out, void* stream) {
-  int bytes = (2 * nv * nv + GRX_MAXEFC * nv + 5 * GRX_MAXEFC + 2 * nv + 64) * 4;
+  int bytes = (2 * nv * nv + GRX_MAXEFC * nv + 6 * GRX_MAXEFC + 2 * nv + 64) * 4;
   hipLaunchKernelGGL(grx_debug_kernel, dim3(1), dim3(64), bytes, (hipStream_t)stream, mode, nv, nefc, A, b, J, D, out);
   HIP_OK(hipGetLastError());
   return 0;

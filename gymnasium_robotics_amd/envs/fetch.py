@@ -31,7 +31,7 @@ _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mo
 
 # Engine capacities of the Fetch models: random rollouts peak at 16 contacts / 89 rows / ~1 000 Jacobian-pool words (the defaults are
 # 32 / 144 / 2 032); the trimmed tables bring the per-world LDS footprint to 14 granules = 9 worlds per CU.
-FETCH_CAPACITY = {"maxcon": 24, "maxefc": 112, "jpool": 1536}
+FETCH_CAPACITY = {"maxcon": 24, "maxefc": 112, "jpool": 1536, "split_spans": False}   # the arm chain is (nearly) contiguous: single-span rows
 
 
 def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledModel:

@@ -25,7 +25,7 @@ _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mo
 
 # Engine capacities of the ant models: random rollouts peak at 4 contacts / 18 rows / ~200 Jacobian-pool words; 16 / 96 / 1 024 leave a
 # wide margin (the legs can touch at most a few walls and the floor at once) and cut the per-world LDS footprint to 10 worlds per CU.
-ANT_CAPACITY = {"maxcon": 16, "maxefc": 96, "jpool": 1024}
+ANT_CAPACITY = {"maxcon": 16, "maxefc": 96, "jpool": 1024, "split_spans": False}
 
 
 def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: Optional[str] = None, agent: str = "point") -> CompiledModel:

@@ -1466,6 +1466,33 @@ class _Lowering:
             mpair_j=np.array(mpj, np.int32), dof_cvelstart=dof_cvelstart, dof_chainmask=chainmask,
             devpair=np.nonzero(pair_supported)[0].astype(np.int32),
         )
+        # dof spans of every pair's Jacobian rows: the union of the two body chains, split at its widest run of unused dofs when
+        # that run is at least two dofs wide (finger + free object of the hand: wrist..finger | object instead of all 30 dofs)
+        def _spans(msk):
+            if not msk:
+                return 0
+            lo, hi = (msk & -msk).bit_length() - 1, msk.bit_length() - 1
+            best, run0, d = (0, 0), None, lo
+            while d <= hi:
+                if not (msk >> d) & 1:
+                    run0 = d if run0 is None else run0
+                else:
+                    if run0 is not None and d - run0 > best[0]:
+                        best = (d - run0, run0)
+                    run0 = None
+                d += 1
+            if best[0] >= 2 and c.capacity.get("split_spans", True):
+                a_hi, b_lo = best[1] - 1, best[1] + best[0]
+                return lo | ((a_hi - lo + 1) << 8) | (b_lo << 16) | ((hi - b_lo + 1) << 24)
+            return lo | ((hi - lo + 1) << 8)
+
+        def _mask_of(bid):
+            return (int(chainmask[bid][0]) & 0xFFFFFFFF) | ((int(chainmask[bid][1]) & 0xFFFFFFFF) << 32)
+
+        pair_span = np.zeros(npair, np.int64)
+        for pi_ in range(npair):
+            pair_span[pi_] = _spans(_mask_of(int(geom_bodyid[pair_geom1[pi_]])) | _mask_of(int(geom_bodyid[pair_geom2[pi_]])))
+        T["pair_span"] = pair_span.astype(np.uint32).view(np.int32) if npair else np.zeros(0, np.int32)
         if ng >= 4096:
             raise ValueError("engine limit: at most 4095 geoms (packed candidate records)")
         dp = T["devpair"]
@@ -1479,7 +1506,7 @@ class _Lowering:
 
 
 def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None) -> CompiledModel:
-    """capacity: optional {"maxefc": rows, "jpool": words, "maxcon": contacts} request for the engine's per-world constraint tables.
+    """capacity: optional {"maxefc": rows, "jpool": words, "maxcon": contacts, "split_spans": bool} request for the engine's per-world constraint tables.
     touch_filter: optional callable(sensor name) selecting the <touch> sensors the engine evaluates.
     keep_sites: optional list of site names whose world frames the engine tracks (default: every site of the model)."""
     return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites).compile()
