@@ -80,8 +80,8 @@ typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntM
 typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntOpen;
 typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntUMaze;
 typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, 96, 512, 0, 16, 1> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 0, GRX_MAXCON, 1> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, GRX_MAXEFC, GRX_JPOOL, 92, GRX_MAXCON, 1> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 944, 92, 24, 1> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
 template <class S>
 __global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)

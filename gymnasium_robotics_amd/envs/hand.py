@@ -260,6 +260,12 @@ class HandReachVecEnv(GoalVecEnv):
             pass
 
 
+# Engine capacities of the hand + object models.  With split dof spans a finger-object row takes 12-20 pool words (6 rows per condim-4
+# contact); random rollouts peak at 10 contacts / 69 rows.  24 contacts / 112 rows / 1 024 pool words give 8 worlds per CU; worlds that
+# exceed them in a substep drop the excess contacts for that substep and raise GRX_ST_EFC_OVERFLOW in `status`.
+HAND_MANIP_CAPACITY = {"maxcon": 24, "maxefc": 112, "jpool": 1024}
+
+
 def load_hand_block_model(assets_root: Optional[str] = None, touch: bool = False, obj: str = "block") -> CompiledModel:
     """hand/manipulate_{block,pen}[_touch_sensors].xml without its visual-only target body (manipulate_spec.drop_target_body); with
     touch=True the 92 'robot0:TS_*' touch zones are compiled into the touch_* tables."""
@@ -269,7 +275,8 @@ def load_hand_block_model(assets_root: Optional[str] = None, touch: bool = False
     if assets_root:
         xml = OBJECTS[obj]["xml"] + ("_touch_sensors.xml" if touch else ".xml")
         # the task reads no site (manipulate.py:298-316 use qpos / qvel only): none is tracked by the engine
-        return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None, keep_sites=[])
+        return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None, keep_sites=[],
+                            capacity=dict(HAND_MANIP_CAPACITY, jpool=944) if touch else HAND_MANIP_CAPACITY)   # touch keeps contact data out of the overlay: same 16 LDS granules with a slightly smaller pool
     path = os.path.join(_MODELS_DIR, f"hand_{obj}_touch.npz" if touch else f"hand_{obj}.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")

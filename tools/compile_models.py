@@ -32,22 +32,25 @@ save_model(m, out)
 print("hand/reach.xml ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "tendons:", len(m.tables["tendon_adr"]),
       "unsupported pairs:", m.info["unsupported_pairs"], f"{os.path.getsize(out) / 1024:.0f} KiB")
 
+from gymnasium_robotics_amd.envs.hand import HAND_MANIP_CAPACITY  # noqa: E402
 from gymnasium_robotics_amd.envs.manipulate_spec import drop_target_body, touch_filter  # noqa: E402
 
-m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block_touch_sensors.xml"), mutate=drop_target_body, touch_filter=touch_filter, keep_sites=[])
+m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block_touch_sensors.xml"), mutate=drop_target_body, touch_filter=touch_filter, keep_sites=[],
+                 capacity=dict(HAND_MANIP_CAPACITY, jpool=944))
 out = os.path.join(OUT, "hand_block_touch.npz")
 save_model(m, out)
 print("hand/manipulate_block_touch_sensors.xml (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")},
       "touch zones:", len(m.tables["touch_body"]), f"{os.path.getsize(out) / 1024:.0f} KiB")
 
-m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block.xml"), mutate=drop_target_body, keep_sites=[])
+m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block.xml"), mutate=drop_target_body, keep_sites=[], capacity=HAND_MANIP_CAPACITY)
 out = os.path.join(OUT, "hand_block.npz")
 save_model(m, out)
 print("hand/manipulate_block.xml (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")},
       "unsupported pairs:", m.info["unsupported_pairs"], f"{os.path.getsize(out) / 1024:.0f} KiB")
 
 for xml, name, tf in (("manipulate_pen.xml", "hand_pen.npz", None), ("manipulate_pen_touch_sensors.xml", "hand_pen_touch.npz", touch_filter)):
-    m = compile_mjcf(os.path.join(ASSETS, "hand", xml), mutate=drop_target_body, touch_filter=tf, keep_sites=[])
+    m = compile_mjcf(os.path.join(ASSETS, "hand", xml), mutate=drop_target_body, touch_filter=tf, keep_sites=[],
+                     capacity=dict(HAND_MANIP_CAPACITY, jpool=944) if tf else HAND_MANIP_CAPACITY)
     out = os.path.join(OUT, name)
     save_model(m, out)
     print(f"hand/{xml} (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "touch zones:", len(m.tables["touch_body"]),
