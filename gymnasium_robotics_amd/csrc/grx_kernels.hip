@@ -71,9 +71,9 @@ template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
          g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan);
 }
-typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
-typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 112, 1536, 0, 24> GrxShapeFetchArm;    // FetchReach (arm only)
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
+typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchArm;    // FetchReach (arm only)
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;

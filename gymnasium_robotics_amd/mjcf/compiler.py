@@ -264,6 +264,15 @@ class CompiledModel:
     def pack(self):
         return pack_blob(self.tables)
 
+    def with_capacity(self, **capacity) -> "CompiledModel":
+        """Copy of the model with other engine table capacities (maxcon / maxefc / jpool; 0 = engine default).  The capacities are
+        requests stored in the dims block, so no recompilation is needed; a model whose capacities match no specialised kernel runs on
+        the generic one."""
+        m = self.copy()
+        for key, val in capacity.items():
+            m.tables["dims"][DIMS.index(key + "_req")] = int(val)
+        return m
+
     def copy(self) -> "CompiledModel":
         return CompiledModel({k: v.copy() for k, v in self.tables.items()},
                              {k: dict(v) for k, v in self.names.items()}, dict(self.info))
