@@ -273,8 +273,18 @@ grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_i
   c.grad = c.tmpv + nv; c.efc_force = c.grad + nv; c.efc_id = (int*)(c.efc_force + GRX_MAXEFC);
   for (int i = lane_; i < nv * nv; i += 64) { c.A[i] = A_in[i]; c.M[i] = A_in[i]; }
   for (int i = lane_; i < nv; i += 64) c.tmpv[i] = b_in[i];
-  for (int i = lane_; i < nefc * nv; i += 64) c.Jp[i] = J_in[i];
-  for (int i = lane_; i < nefc; i += 64) { c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0 ? 1 : 0; c.efc_row[i] = GRX_ROW_PACK(i * nv, 0, nv); c.efc_id[i] = 0; c.efc_force[i] = 0.5f + 0.01f * (float)i; }
+  // mode 1: every row stored over all dofs; mode 2: every row stored as two spans [0, na) and [nb, nv) (the dofs in between must be zero)
+  const int na = nv / 3, nb = nv - nv / 3, two = (mode == 2), rl = two ? na + (nv - nb) : nv;
+  for (int i = lane_; i < nefc * nv; i += 64) {
+    const int r = i / nv, d = i - r * nv;
+    if (!two) c.Jp[i] = J_in[i];
+    else if (d < na) c.Jp[r * rl + d] = J_in[i];
+    else if (d >= nb) c.Jp[r * rl + na + d - nb] = J_in[i];
+  }
+  for (int i = lane_; i < nefc; i += 64) {
+    c.efc_D[i] = fabsf(D_in[i]); c.efc_quad[i] = D_in[i] > 0 ? 1 : 0; c.efc_force[i] = 0.5f + 0.01f * (float)i;
+    c.efc_row[i] = GRX_ROW_PACK(i * rl, 0, two ? na : nv); c.efc_id[i] = two ? ((nb << 12) | ((nv - nb) << 20)) : 0;
+  }
   __syncthreads();
   if (mode == 0) {
     GrxEngine<GrxShapeAny>::grx_sym_solve_full(c.A, nv, c.tmpv, lane_);

@@ -24,7 +24,7 @@ def _run(mode, nv, nefc, A, b, J, D):
     return out.cpu().numpy().astype(np.float64)
 
 
-@pytest.mark.parametrize("nv", [15, 21, 9])
+@pytest.mark.parametrize("nv", [14, 15, 21, 24, 30, 9])   # 14..30: register-resident instantiations; 9: LDS fallback
 def test_spd_solve(nv):
     rng = np.random.default_rng(nv)
     Q = rng.standard_normal((nv, nv))
@@ -49,5 +49,23 @@ def test_mfma_hessian(nv, nefc):
     ref = M + J.T @ (np.where(D > 0, D, 0)[:, None] * J)
     assert np.abs(H - ref).max() < 1e-5 * np.abs(ref).max()
     # the same MFMA chain also delivers J' f for the row forces of the last evaluation (here f_r = 0.5 + 0.01 r)
+    f = 0.5 + 0.01 * np.arange(nefc)
+    assert np.abs(jtf - J.T @ f).max() < 1e-5 * max(1.0, np.abs(J.T @ f).max())
+
+
+@pytest.mark.parametrize("nv,nefc", [(30, 70), (24, 33)])
+def test_mfma_hessian_two_span_rows(nv, nefc):
+    """Rows stored as two dof spans (hand models: wrist..finger | object), read back through grx_row_pos in the MFMA operand fetch."""
+    rng = np.random.default_rng(nv + nefc)
+    Q = rng.standard_normal((nv, nv))
+    M = Q @ Q.T + nv * np.eye(nv)
+    J = rng.standard_normal((nefc, nv))
+    J[:, nv // 3: nv - nv // 3] = 0.0          # the gap between the two spans carries no entries
+    D = rng.random(nefc) * 100 + 1
+    D[rng.random(nefc) < 0.3] *= -1
+    out = _run(2, nv, nefc, M, np.zeros(nv), J, D)
+    H, jtf = out[: nv * nv].reshape(nv, nv), out[nv * nv:]
+    ref = M + J.T @ (np.where(D > 0, D, 0)[:, None] * J)
+    assert np.abs(H - ref).max() < 1e-5 * np.abs(ref).max()
     f = 0.5 + 0.01 * np.arange(nefc)
     assert np.abs(jtf - J.T @ f).max() < 1e-5 * max(1.0, np.abs(J.T @ f).max())
