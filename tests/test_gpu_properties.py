@@ -1,0 +1,93 @@
+"""Size-independent physical properties at the BASELINE.json batch sizes (no per-world oracle at these sizes): unit quaternions,
+no tunnelling through the support surface, soft joint limits respected, finite and bounded outputs, reward == compute_reward,
+rare capacity flags.  Random actions, free running."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rollout(env, steps, act_dim, seed=0):
+    import torch
+
+    env.reset(seed=seed)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(seed)
+    flagged = 0
+    for _ in range(steps):
+        obs, r, term, trunc, info = env.step(torch.rand(env.num_envs, act_dim, device="cuda:0", generator=g) * 2 - 1)
+        flagged += int((env.status != 0).sum())
+    return obs, r, info, flagged
+
+
+def _limit_violation(env, qpos):
+    T = env.model.tables
+    lim = np.asarray(T["jnt_limited"]).reshape(-1).astype(bool) & (np.asarray(T["jnt_type"]).reshape(-1) >= 2)
+    adr, rng = np.asarray(T["jnt_qposadr"]).reshape(-1)[lim], np.asarray(T["jnt_range"]).reshape(-1, 2)[lim]
+    q = qpos[:, adr]
+    return float(np.maximum(rng[:, 0] - q, q - rng[:, 1]).max())
+
+
+def _soft_limits_ok(env, qpos, slack):
+    """Joint limits are soft constraints (solref 0.02 s): motors at full effort push a little past them -- measured maxima in these
+    rollouts: Fetch 0.055 (finger slides under kp = 30000), hand 0.0013 rad, ant 0.15 rad (gear-150 motors)."""
+    T = env.model.tables
+    lim = np.asarray(T["jnt_limited"]).reshape(-1).astype(bool) & (np.asarray(T["jnt_type"]).reshape(-1) >= 2)
+    adr, rng = np.asarray(T["jnt_qposadr"]).reshape(-1)[lim], np.asarray(T["jnt_range"]).reshape(-1, 2)[lim]
+    q = qpos[:, adr]
+    return bool((q >= rng[:, 0] - slack).all() and (q <= rng[:, 1] + slack).all())
+
+
+def test_fetch_pick_and_place_4096_worlds():
+    from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
+
+    env = FetchVecEnv("FetchPickAndPlace-v4", num_envs=4096, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
+    obs, r, info, flagged = _rollout(env, 50, 4)
+    q, v = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+    assert np.isfinite(q).all() and np.isfinite(v).all() and np.isfinite(obs["observation"].cpu().numpy()).all()
+    assert np.abs(np.linalg.norm(q[:, -4:], axis=1) - 1).max() < 1e-5           # object orientation stays a unit quaternion
+    z = q[:, -5]                                                                 # block height: on the table (top at z ~ 0.4), in the gripper, or pushed off onto the floor
+    assert z.min() > 0.01 and z.max() < 1.2 and (z > 0.40).mean() > 0.9 and not ((z > 0.06) & (z < 0.395) & (np.abs(v[:, -4]) < 1e-3)).any()   # nothing rests inside the table or the floor
+    assert np.abs(v).max() < 100
+    assert _soft_limits_ok(env, q, 0.08)
+    assert flagged <= 0.002 * 4096 * 50                                          # capacity flags are rare (measured ~0.035 %)
+    r2 = env.compute_reward(obs["achieved_goal"], obs["desired_goal"], None)
+    assert bool((r2 == r).all())
+    d = (obs["achieved_goal"] - obs["desired_goal"]).norm(dim=1)
+    assert bool(((d < 0.05 - 1e-6) <= info["is_success"].bool()).all()) and bool((info["is_success"].bool() <= (d < 0.05 + 1e-6)).all())
+    env.close()
+
+
+def test_hand_block_touch_16384_worlds():
+    from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv
+
+    env = HandBlockVecEnv("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", num_envs=16384, device="cuda:0", output="torch",
+                          autoreset_mode="disabled", max_episode_steps=None)
+    obs, r, info, flagged = _rollout(env, 12, 20)
+    o = obs["observation"].cpu().numpy()
+    q = env.qpos.cpu().numpy()
+    assert o.shape == (16384, 153) and np.isfinite(o).all()
+    assert np.abs(np.linalg.norm(q[:, 27:31], axis=1) - 1).max() < 1e-5          # block orientation
+    touch = o[:, 61:]
+    assert touch.min() >= 0 and touch.max() < 200 and (touch > 0).any(axis=1).mean() > 0.5   # newtons; most blocks are still being held
+    assert _soft_limits_ok(env, q, 0.01)                                         # 24 hinge limits (margin 0.01, soft)
+    assert (q[:, 26] > -0.05).all()                                              # nothing falls through the floor
+    assert flagged <= 0.001 * 16384 * 12
+    assert bool((env.compute_reward(obs["achieved_goal"], obs["desired_goal"], None) == r).all())
+    env.close()
+
+
+def test_ant_maze_8192_worlds():
+    from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv
+
+    env = AntMazeVecEnv("AntMaze_Large_Diverse_GR-v5", num_envs=8192, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
+    obs, r, info, flagged = _rollout(env, 40, 8)
+    q, v = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() < 1e-5            # torso orientation
+    assert q[:, 2].min() > 0.15 and q[:, 2].max() < 6.0                           # the torso stays above the floor; random full-torque actions make it hop, not explode
+    assert _soft_limits_ok(env, q, 0.25)
+    assert flagged == 0
+    half = 0.5 * 4.0 * np.array([env.maze.map_width, env.maze.map_length])       # the ant stays inside the walled maze
+    assert (np.abs(q[:, :2]) < half[None, :] + 1.0).all()
+    env.close()
