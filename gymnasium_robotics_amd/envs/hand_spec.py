@@ -45,23 +45,27 @@ def fingertip_site_ids(model):
     return [int(model.names["site"][n]) for n in FINGERTIP_SITE_NAMES]
 
 
+_FINGERS = [name for name in FINGERTIP_SITE_NAMES if name != "robot0:S_thtip"]
+_THUMB_IDX = FINGERTIP_SITE_NAMES.index("robot0:S_thtip")
+_MEET_OFFSET = np.array([0.0, -0.09, 0.05])
+
+
 def sample_hand_reach_goal(np_random: np.random.Generator, initial_goal: np.ndarray, palm_xpos: np.ndarray) -> np.ndarray:
-    """reach.py:99-126, draw for draw: choice of the finger, normal meeting-point noise, the 10 % 'stay' branch."""
-    thumb_name = "robot0:S_thtip"
-    finger_names = [name for name in FINGERTIP_SITE_NAMES if name != thumb_name]
-    finger_name = np_random.choice(finger_names)
-    thumb_idx = FINGERTIP_SITE_NAMES.index(thumb_name)
-    finger_idx = FINGERTIP_SITE_NAMES.index(finger_name)
-    meeting_pos = np.asarray(palm_xpos, dtype=np.float64) + np.array([0.0, -0.09, 0.05])
-    meeting_pos = meeting_pos + np_random.normal(scale=0.005, size=meeting_pos.shape)
-    goal = np.asarray(initial_goal, dtype=np.float64).copy().reshape(-1, 3)
-    for idx in [thumb_idx, finger_idx]:
+    """reach.py:99-126, draw for draw: choice of the finger, normal meeting-point noise, the 10 % 'stay' branch.
+    `Generator.choice(list)` without p draws `integers(0, len)` (checked stream-for-stream in tests/test_cpu_hand.py); using the
+    latter skips the list -> array conversion, which dominated the host cost of resetting thousands of worlds."""
+    finger_idx = FINGERTIP_SITE_NAMES.index(_FINGERS[np_random.integers(0, len(_FINGERS))])
+    meeting_pos = np.asarray(palm_xpos, dtype=np.float64) + _MEET_OFFSET
+    meeting_pos = meeting_pos + np_random.normal(scale=0.005, size=3)
+    goal = np.array(initial_goal, dtype=np.float64).reshape(-1, 3)
+    for idx in (_THUMB_IDX, finger_idx):
         offset_direction = meeting_pos - goal[idx]
-        offset_direction /= np.linalg.norm(offset_direction)
+        offset_direction /= np.sqrt(offset_direction @ offset_direction)
         goal[idx] = meeting_pos - 0.005 * offset_direction
     if np_random.uniform() < 0.1:
-        goal = np.asarray(initial_goal, dtype=np.float64).copy()
-    return goal.flatten()
+        # With some probability all fingers are asked to move back to the origin (reach.py:122-125)
+        goal = np.array(initial_goal, dtype=np.float64)
+    return goal.reshape(-1)
 
 
 def hand_reach_reward(achieved, desired, reward_type="sparse"):

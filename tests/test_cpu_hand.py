@@ -64,6 +64,17 @@ def test_goal_sampler_contract():
     assert np.isclose(hand_reach_reward(a, b, "dense"), -np.linalg.norm(b))
 
 
+def test_choice_equals_integers_stream():
+    """The sampler replaces np_random.choice(finger_names) (reach.py:103) by an index draw: same value, same generator state after."""
+    from gymnasium_robotics_amd.core import np_random
+
+    names = ["robot0:S_fftip", "robot0:S_mftip", "robot0:S_rftip", "robot0:S_lftip"]
+    for seed in range(300):
+        a, b = np_random(seed)[0], np_random(seed)[0]
+        assert a.choice(names) == names[b.integers(0, len(names))]
+        assert a.normal(scale=0.005, size=3).tolist() == b.normal(scale=0.005, size=3).tolist() and a.uniform() == b.uniform()
+
+
 def test_reset_goals_match_golden():
     """Seeded goal sampling reproduces the goals the oracle env drew (same host sampler, same numpy bit stream)."""
     from gymnasium_robotics_amd.core import np_random
