@@ -9,13 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _make(env_id, **kw):
-    from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
-    from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv, HandReachVecEnv
-    from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv, PointMazeVecEnv
+    import gymnasium_robotics_amd as grx
 
-    cls = (FetchVecEnv if env_id.startswith("Fetch") else HandReachVecEnv if env_id.startswith("HandReach") else HandBlockVecEnv
-           if env_id.startswith("HandManipulate") else AntMazeVecEnv if env_id.startswith("AntMaze") else PointMazeVecEnv)
-    return cls(env_id, num_envs=3, device="cuda:0", output="numpy", **kw)
+    return grx.make_vec(env_id, num_envs=3, device="cuda:0", output="numpy", **kw)
 
 
 ALL_IDS = ["FetchReach-v4", "FetchPush-v4", "FetchPickAndPlaceDense-v4", "HandReach-v3", "HandManipulateBlockRotateXYZ-v1",
