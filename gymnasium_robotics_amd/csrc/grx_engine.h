@@ -413,9 +413,13 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
         ql[0] = q[0]; ql[1] = q[1]; ql[2] = q[2]; ql[3] = q[3];
         continue;
       }
-      int ja = m->body_jntadr[b], jn = m->body_jntnum[b];
-      if (jn == 1 && m->jnt_type[ja] == 0) {  // free joint: qpos is the world pose
-        int qa = m->jnt_qposadr[ja];
+      const unsigned ja = (unsigned)m->body_jntadr[b]; const int jn = m->body_jntnum[b];   // unsigned: no sign-extended 64-bit index pair kept live
+      int jt0 = -1, qa = 0;
+      if (jn == 1) { jt0 = m->jnt_type[ja]; qa = m->jnt_qposadr[ja]; }   // both table reads before the divergent branches
+#ifndef GRX_EMU
+      asm volatile("" : "+v"(qa));   // keep the read here (sunk to its use, the 64-bit index pair is spilled to scratch across the branches)
+#endif
+      if (jt0 == 0) {  // free joint: qpos is the world pose
         float q[4] = {c->qpos[qa + 3], c->qpos[qa + 4], c->qpos[qa + 5], c->qpos[qa + 6]};
         normalize4f(q);
         pl[0] = c->qpos[qa]; pl[1] = c->qpos[qa + 1]; pl[2] = c->qpos[qa + 2];
@@ -426,7 +430,7 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
       float p[3] = {m->body_pos[3 * b], m->body_pos[3 * b + 1], m->body_pos[3 * b + 2]};
       float q[4] = {m->body_quat[4 * b], m->body_quat[4 * b + 1], m->body_quat[4 * b + 2], m->body_quat[4 * b + 3]};
       for (int k = 0; k < jn; k++) {
-        int j = ja + k, qa = m->jnt_qposadr[j];
+        const unsigned j = ja + (unsigned)k; const int qa = m->jnt_qposadr[j];
         float jp[3] = {m->jnt_pos[3 * j], m->jnt_pos[3 * j + 1], m->jnt_pos[3 * j + 2]};
         float jx[3] = {m->jnt_axis[3 * j], m->jnt_axis[3 * j + 1], m->jnt_axis[3 * j + 2]};
         float anchor[3], axis[3];

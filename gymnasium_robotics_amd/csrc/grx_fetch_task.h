@@ -123,6 +123,11 @@ GRX_MEM void grx_fetch_outputs(const GrxModel* m, const GrxFetchTask* t, const G
 // whole env.step() for one world whose state is already in the LDS context
 GRX_MEM void grx_fetch_step_world(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux_in, const float* action,
                                   float* aux_out, float* obs, float* achieved, int lane_) {
+  grx_fetch_sim_world(m, t, c, aux_in, action, lane_);
+  grx_fetch_outputs(m, t, c, aux_out, obs, achieved, lane_);
+}
+// the simulation part alone: the step kernel derives the output pointers after it, so no global address stays live across the substeps
+GRX_MEM void grx_fetch_sim_world(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux_in, const float* action, int lane_) {
   grx_fetch_set_action(m, t, c, aux_in, action, lane_);
   // n_substeps x mj_step, plus (block_gripper tasks) the _step_callback: zero the finger qpos and run one mj_forward.
   // One loop, one call site of the physics, so the loop body stays resident in the instruction cache.
@@ -133,6 +138,5 @@ GRX_MEM void grx_fetch_step_world(const GrxModel* m, const GrxFetchTask* t, GrxC
     else E::grx_check_state(m, c, lane_);
     E::grx_forward_euler(m, c, !callback, lane_);
   }
-  grx_fetch_outputs(m, t, c, aux_out, obs, achieved, lane_);
 }
 };  // struct GrxFetch

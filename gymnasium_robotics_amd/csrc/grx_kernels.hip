@@ -60,6 +60,19 @@ extern "C" int grx_profile_read(long long* out) { return (int)hipMemcpyFromSymbo
 extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grx_prof), z, sizeof(z)); }
 #endif
 
+// World <-> workgroup mapping.  The dispatcher deals workgroups round-robin to the 8 XCDs, each with its own L2, so with w = blockIdx.x
+// the rows of neighbouring worlds (88-B qpos rows, 100-B obs rows, 4-B reward / flag entries: several worlds per 128-B line) are
+// fetched by up to 8 L2s and written back as 8 partial lines.  The grid is rounded up to a multiple of 8 and XCD k takes the
+// k-th contiguous slice of the worlds, so a line is read and merged in one L2 (rocprofv3 FETCH_SIZE / WRITE_SIZE: profiles/).
+static inline unsigned grx_grid_for(int n_worlds) { return (unsigned)((n_worlds + 7) & ~7); }
+static __device__ __forceinline__ int grx_world_of_block() { return (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); }
+// the same index re-derived after the substep loop from the (architected) workgroup id: the epilogue's addresses are then computed
+// there instead of being kept -- as 64-bit VGPR pairs spilled to scratch -- across the whole simulation
+static __device__ __forceinline__ int grx_world_of_block_late() {
+  unsigned bx = blockIdx.x; asm volatile("" : "+s"(bx));
+  return (int)((bx & 7u) * (gridDim.x >> 3) + (bx >> 3));
+}
+
 // Model shapes.  A step kernel specialised for a shape has all layout dims as compile-time constants: the LDS carve folds
 // into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs) and the loops over
 // dofs / bodies / joints unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
@@ -87,7 +100,7 @@ template <class S>
 __global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
 grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
-  const int w = blockIdx.x, lane_ = threadIdx.x;
+  const int w = grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
   const GrxModel& m = g_grx_models[mslot];
@@ -100,13 +113,13 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
 #endif
   grx_load_world(m, b, c, w, lds, words, lane_);
-  float* aux = b.aux + (size_t)w * 8;
   float aux_in[8];
-  for (int k = 0; k < 8; k++) aux_in[k] = aux[k];
-  float* obs = b.obs + (size_t)w * t.obs_dim; float* ach = b.achieved + (size_t)w * 3; const float* act = b.action + (size_t)w * 4;
-  GrxFetch<S>::grx_fetch_step_world(&m, &t, &c, aux_in, act, aux, obs, ach, lane_);
+  for (int k = 0; k < 8; k++) aux_in[k] = b.aux[(size_t)w * 8 + k];
+  GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_);
+  const int wl = grx_world_of_block_late();
+  GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)wl * 8, b.obs + (size_t)wl * t.obs_dim, b.achieved + (size_t)wl * 3, lane_);
   __syncthreads();
-  grx_store_world(m, t, b, c, w, lane_);
+  grx_store_world(m, t, b, c, wl, lane_);
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
   if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);  // summed over worlds
@@ -117,7 +130,7 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
 extern "C" __global__ void __launch_bounds__(64)
 grx_fetch_forward_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words, int nstep) {
   extern __shared__ float lds[];
-  const int w = blockIdx.x, lane_ = threadIdx.x;
+  const int w = grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
   const GrxModel& m = g_grx_models[mslot];
@@ -140,7 +153,7 @@ template <class S>
 __global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
 grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
-  const int w = blockIdx.x, lane_ = threadIdx.x;
+  const int w = grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
   const GrxModel& m = g_grx_models[mslot];
@@ -157,17 +170,19 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
   for (int i = lane_; i < m.nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * m.nq + i];
   for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
   __syncthreads();
-  float* obs = b.obs + (size_t)w * (m.nq + m.nv - (t.agent ? 2 : 0)); float* ach = b.achieved + (size_t)w * 2;
-  GrxPoint<S>::grx_point_step_world(&m, &t, &c, b.action + (size_t)w * m.nu, obs, ach, lane_);
+  GrxPoint<S>::grx_point_sim_world(&m, &t, &c, b.action + (size_t)w * m.nu, lane_);
+  const int wl = grx_world_of_block_late();
+  float* obs = b.obs + (size_t)wl * (m.nq + m.nv - (t.agent ? 2 : 0)); float* ach = b.achieved + (size_t)wl * 2;
+  GrxPoint<S>::grx_point_outputs(&m, &t, &c, obs, ach, lane_);
   __syncthreads();
-  for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
-  for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)w * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * m.nv + i] = c.qacc_ws[i]; }
+  for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)wl * m.nq + i] = c.qpos[i];
+  for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)wl * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)wl * m.nv + i] = c.qacc_ws[i]; }
   if (lane_ == 0) {
-    float d = grx_goal_distance2(ach, b.goal + (size_t)w * 2);
+    float d = grx_goal_distance2(ach, b.goal + (size_t)wl * 2);
     int succ = d <= t.goal_radius;
-    b.reward[w] = grx_maze_reward(d, t.goal_radius, t.sparse_reward);
-    b.success[w] = succ; b.terminated[w] = (!t.continuing_task && succ) ? 1 : 0;
-    b.status[w] = c.cnt[2];
+    b.reward[wl] = grx_maze_reward(d, t.goal_radius, t.sparse_reward);
+    b.success[wl] = succ; b.terminated[wl] = (!t.continuing_task && succ) ? 1 : 0;
+    b.status[wl] = c.cnt[2];
   }
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
@@ -180,7 +195,7 @@ template <class S>
 __global__ void __launch_bounds__(64, (S::kFixed && S::JP < GRX_JPOOL) ? 3 : 2)
 grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
-  const int w = blockIdx.x, lane_ = threadIdx.x;
+  const int w = grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
   const GrxModel& m = g_grx_models[mslot];
@@ -410,7 +425,7 @@ extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, co
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  const dim3 grid(n_worlds), block(64);
+  const dim3 grid(grx_grid_for(n_worlds)), block(64);
   const size_t lds_bytes = (size_t)m->words * 4;
   switch (m->shape) {  // the specialised kernels are bit-identical to the generic one (same source, dims folded)
     case 1: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchPick>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
@@ -428,7 +443,7 @@ extern "C" int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task,
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  hipLaunchKernelGGL(grx_fetch_forward_kernel, dim3(n_worlds), dim3(64), m->words * 4, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, nstep);
+  hipLaunchKernelGGL(grx_fetch_forward_kernel, dim3(grx_grid_for(n_worlds)), dim3(64), m->words * 4, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, nstep);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -441,7 +456,7 @@ extern "C" int grx_point_step(const grx_model* m, const grx_point_task* task, co
   if (n_worlds <= 0) return 0;
   GrxPointTask t; memcpy(&t, task, sizeof(t));
   GrxPointBuffers b; memcpy(&b, buf, sizeof(b));
-  const dim3 grid(n_worlds), block(64);
+  const dim3 grid(grx_grid_for(n_worlds)), block(64);
   const size_t lds_bytes = (size_t)m->words * 4;
   switch (m->shape) {
     case 10: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntLarge>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
@@ -469,7 +484,7 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   } else
     for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
-  const dim3 grid(n_worlds), block(64);
+  const dim3 grid(grx_grid_for(n_worlds)), block(64);
   const size_t lds_bytes = (size_t)m->words * 4;
   if (m->shape == 6) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlockTouch>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   else if (m->shape == 5) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlock>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);

@@ -39,6 +39,11 @@ struct GrxPoint {
   typedef GrxEngine<S> E;
   GRX_MEM void grx_point_step_world(const GrxModel* m, const GrxPointTask* t, GrxCtx* c, const float* action, float* obs, float* achieved,
                                     int lane_) {
+    grx_point_sim_world(m, t, c, action, lane_);
+    grx_point_outputs(m, t, c, obs, achieved, lane_);
+  }
+  // simulation and observation parts: the step kernel derives the output addresses between the two (nothing global live across the substeps)
+  GRX_MEM void grx_point_sim_world(const GrxModel* m, const GrxPointTask* t, GrxCtx* c, const float* action, int lane_) {
     const int ant = t->agent;
     FOR_LANES {
       // point: np.clip(action, -1, 1) and the velocity clip of point.py:57,73-77; ant: ctrl = action (ctrlrange is applied by the actuator model)
@@ -55,7 +60,9 @@ struct GrxPoint {
       E::grx_forward_euler(m, c, !rk4, lane_);
       if (rk4) E::grx_rk4_after_forward(m, c, stage, lane_);
     }
-    const int skip = ant ? 2 : 0;  // AntMaze strips the xy position from the observation (it is the achieved goal)
+  }
+  GRX_MEM void grx_point_outputs(const GrxModel* m, const GrxPointTask* t, GrxCtx* c, float* obs, float* achieved, int lane_) {
+    const int skip = t->agent ? 2 : 0;  // AntMaze strips the xy position from the observation (it is the achieved goal)
     FOR_LANES {
       for (int i = lane; i < GRX_NQC; i += 64) { float q = c->qpos[i]; if (i >= skip) obs[i - skip] = q; if (i < 2) achieved[i] = q; }
       for (int i = lane; i < GRX_NVC; i += 64) obs[GRX_NQC - skip + i] = c->qvel[i];
