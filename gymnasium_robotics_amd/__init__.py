@@ -10,7 +10,7 @@ the batched device environments here:
     obs, reward, terminated, truncated, info = envs.step(actions)        # VectorEnv contract
 
 ``registered_env_ids()`` lists every id this build serves; an id the reference registers but the engine does not cover
-(FetchSlide, HandManipulateEgg*, Adroit*, FrankaKitchen, the multi-goal mazes) raises ``UnsupportedEnvError`` with the reason.
+(Adroit*, FrankaKitchen) raises ``UnsupportedEnvError`` with the reason.
 Nothing here imports torch or loads the HIP library until an environment is constructed.
 """
 from typing import List
@@ -23,10 +23,8 @@ class UnsupportedEnvError(KeyError):
 
 
 _NOT_SERVED = {
-    "FetchSlide": "the puck is a cylinder: cylinder-box contact needs the general convex narrow phase (libccd MPR)",
-    "HandManipulateEgg": "the egg is an ellipsoid: needs the general convex narrow phase (libccd MPR)",
     "AdroitHand": "the Adroit models enable MuJoCo's noslip post-solver, which the engine does not restate",
-    "FrankaKitchen": "mesh-mesh contacts (kettle, cabinets) need the general convex narrow phase",
+    "FrankaKitchen": "mesh-mesh contacts (kettle, cabinets): the convex narrow phase has no mesh support function yet",
 }
 
 
@@ -34,8 +32,7 @@ def _fetch_ids() -> List[str]:
     # gymnasium_robotics/__init__.py:26-80: sparse + Dense twins, versions v1..v4 share the constructor arguments; v4 = mujoco bindings
     from .envs.fetch_spec import FETCH_TASKS
 
-    served = [t for t in FETCH_TASKS if t != "FetchSlide"]
-    return [f"{t}{sfx}-v4" for t in served for sfx in ("", "Dense")]
+    return [f"{t}{sfx}-v4" for t in FETCH_TASKS for sfx in ("", "Dense")]
 
 
 def _hand_reach_ids() -> List[str]:

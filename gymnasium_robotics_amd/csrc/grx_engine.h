@@ -82,8 +82,9 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan;
-  float timestep, gravity[3], meaninertia, impratio;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex;
+  float timestep, gravity[3], meaninertia, impratio, mpr_tolerance;
+  int mpr_iterations;
 };
 
 // per-world LDS working set; every pointer addresses LDS (or host memory in the emulator)
@@ -934,6 +935,232 @@ GRX_MEM void grx_capsule_capsule(const GrxModel* m, GrxCtx* c, int pair, int g1,
   float pos[3] = {p1[0] + n[0] * (r1 + 0.5f * dist), p1[1] + n[1] * (r1 + 0.5f * dist), p1[2] + n[2] * (r1 + 0.5f * dist)};
   grx_add_contact(c, pair, pos, n, dist);
 }
+// ------------------------------------------------------------------------------------------
+// General convex pairs (ellipsoid / cylinder against sphere, capsule, ellipsoid, cylinder, box): Minkowski Portal Refinement, one
+// lane per pair, one contact per pair (what MuJoCo's libccd route produces; see the oracle's header comment on the algorithm and on
+// what is not restated).  Everything is computed relative to the centre of geom 1, so the fp32 support points are O(geom size)
+// instead of O(world coordinates); a Minkowski point is kept with its witness on geom 1 (the witness on geom 2 is w - v).
+// ------------------------------------------------------------------------------------------
+#define GRX_MPR_EPS 1.1920929e-7f
+struct GrxMprPt { float v[3], w[3]; };
+GRX_MEM int grx_mpr_zero(float x) { return fabsf(x) < GRX_MPR_EPS; }
+GRX_MEM int grx_mpr_eq(float a, float b) {
+  float ab = fabsf(a - b);
+  if (ab < GRX_MPR_EPS) return 1;
+  a = fabsf(a); b = fabsf(b);
+  return ab < GRX_MPR_EPS * (b > a ? b : a);
+}
+GRX_MEM float grx_sgn1f(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+GRX_MEM void grx_normalize3f(float* v) { float n2 = dot3f(v, v); if (n2 > 0.0f) { float s = 1.0f / sqrtf(n2); v[0] *= s; v[1] *= s; v[2] *= s; } }
+// farthest point of the geom along the world direction d, relative to the geom centre
+GRX_MEM void grx_geom_support(const float* R, const float* sz, int type, const float* d, float* out) {
+  float dl[3], r[3] = {0.0f, 0.0f, 0.0f};
+  mulMatTVec3f(dl, R, d);
+  if (type == 2) { r[0] = dl[0] * sz[0]; r[1] = dl[1] * sz[0]; r[2] = dl[2] * sz[0]; }
+  else if (type == 3) { r[0] = dl[0] * sz[0]; r[1] = dl[1] * sz[0]; r[2] = dl[2] * sz[0] + grx_sgn1f(dl[2]) * sz[1]; }
+  else if (type == 4) {
+    float t[3] = {dl[0] * sz[0], dl[1] * sz[1], dl[2] * sz[2]};
+    grx_normalize3f(t);
+    r[0] = t[0] * sz[0]; r[1] = t[1] * sz[1]; r[2] = t[2] * sz[2];
+  } else if (type == 5) {
+    float h = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
+    if (h > GRX_MINVAL) { float ih = sz[0] / h; r[0] = dl[0] * ih; r[1] = dl[1] * ih; }
+    r[2] = grx_sgn1f(dl[2]) * sz[1];
+  } else if (type == 6) { r[0] = grx_sgn1f(dl[0]) * sz[0]; r[1] = grx_sgn1f(dl[1]) * sz[1]; r[2] = grx_sgn1f(dl[2]) * sz[2]; }
+  mulMatVec3f(out, R, r);
+}
+struct GrxMprPair { const float *R1, *R2; float s1[3], s2[3], c21[3], hm; int t1, t2; };
+GRX_MEM void grx_mpr_support(const GrxMprPair* q, const float* d, GrxMprPt* o) {
+  float nd[3] = {-d[0], -d[1], -d[2]}, b[3];
+  grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
+  grx_geom_support(q->R2, q->s2, q->t2, nd, b);
+  for (int k = 0; k < 3; k++) { o->w[k] += d[k] * q->hm; o->v[k] = o->w[k] - (b[k] + q->c21[k] - d[k] * q->hm); }
+}
+GRX_MEM void grx_mpr_portal_dir(const GrxMprPt* P, float* dir) {
+  float a[3], b[3];
+  for (int k = 0; k < 3; k++) { a[k] = P[2].v[k] - P[1].v[k]; b[k] = P[3].v[k] - P[1].v[k]; }
+  cross3f(dir, a, b); grx_normalize3f(dir);
+}
+GRX_MEM int grx_mpr_reach_tolerance(const GrxMprPt* P, const GrxMprPt* v4, const float* dir, float tol) {
+  float d4 = dot3f(v4->v, dir), mn = fminf(d4 - dot3f(P[1].v, dir), fminf(d4 - dot3f(P[2].v, dir), d4 - dot3f(P[3].v, dir)));
+  return grx_mpr_eq(mn, tol) || mn < tol;
+}
+GRX_MEM void grx_mpr_expand(GrxMprPt* P, const GrxMprPt* v4) {
+  float cr[3];
+  cross3f(cr, v4->v, P[0].v);
+  if (dot3f(P[1].v, cr) > 0.0f) { if (dot3f(P[2].v, cr) > 0.0f) P[1] = *v4; else P[3] = *v4; }
+  else { if (dot3f(P[3].v, cr) > 0.0f) P[2] = *v4; else P[1] = *v4; }
+}
+GRX_MEM float grx_mpr_seg_dist2(const float* a, const float* b, float* w) {
+  float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, t = -dot3f(a, d), dd = dot3f(d, d);
+  t = dd > 0.0f ? fminf(1.0f, fmaxf(0.0f, t / dd)) : 0.0f;
+  for (int k = 0; k < 3; k++) w[k] = a[k] + t * d[k];
+  return dot3f(w, w);
+}
+GRX_MEM float grx_mpr_tri_dist2(const float* x0, const float* b, const float* cc, float* w) {
+  float d1[3], d2[3];
+  for (int k = 0; k < 3; k++) { d1[k] = b[k] - x0[k]; d2[k] = cc[k] - x0[k]; }
+  float u = dot3f(x0, x0), v = dot3f(d1, d1), ww = dot3f(d2, d2), p = dot3f(x0, d1), q = dot3f(x0, d2), r = dot3f(d1, d2);
+  float den = ww * v - r * r, best;
+  if (!grx_mpr_zero(den)) {
+    float sp = (q * r - ww * p) / den, tp = (-sp * r - q) / ww;
+    if ((grx_mpr_zero(sp) || sp > 0.0f) && (grx_mpr_eq(sp, 1.0f) || sp < 1.0f) && (grx_mpr_zero(tp) || tp > 0.0f) && (grx_mpr_eq(tp, 1.0f) || tp < 1.0f) &&
+        (grx_mpr_eq(tp + sp, 1.0f) || tp + sp < 1.0f)) {
+      for (int k = 0; k < 3; k++) w[k] = x0[k] + sp * d1[k] + tp * d2[k];
+      best = sp * sp * v + tp * tp * ww + 2.0f * sp * tp * r + 2.0f * sp * p + 2.0f * tp * q + u;
+      return best > 0.0f ? best : 0.0f;
+    }
+  }
+  float w2[3], dist;
+  best = grx_mpr_seg_dist2(x0, b, w);
+  dist = grx_mpr_seg_dist2(x0, cc, w2); if (dist < best) { best = dist; w[0] = w2[0]; w[1] = w2[1]; w[2] = w2[2]; }
+  dist = grx_mpr_seg_dist2(b, cc, w2); if (dist < best) { best = dist; w[0] = w2[0]; w[1] = w2[1]; w[2] = w2[2]; }
+  return best;
+}
+// 0 = penetration (depth, dir, pos, surface witnesses w1 on geom 1 / w2 on geom 2 -- all relative to the centre of geom 1), -1 = separated
+GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float* depth, float* dir, float* pos, float* w1, float* w2) {
+  GrxMprPt P[4], v4;
+  float d[3], a[3], b[3], dotv;
+  for (int k = 0; k < 3; k++) { P[0].w[k] = 0.0f; P[0].v[k] = -q->c21[k]; }
+  if (grx_mpr_eq(P[0].v[0], 0.0f) && grx_mpr_eq(P[0].v[1], 0.0f) && grx_mpr_eq(P[0].v[2], 0.0f)) P[0].v[0] += GRX_MPR_EPS * 10.0f;
+  for (int k = 0; k < 3; k++) d[k] = -P[0].v[k];
+  grx_normalize3f(d);
+  grx_mpr_support(q, d, &P[1]);
+  dotv = dot3f(P[1].v, d);
+  if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
+  cross3f(d, P[0].v, P[1].v);
+  if (grx_mpr_zero(dot3f(d, d))) {
+    for (int k = 0; k < 3; k++) { w1[k] = P[1].w[k]; w2[k] = P[1].w[k] - P[1].v[k]; pos[k] = 0.5f * (w1[k] + w2[k]); }
+    if (grx_mpr_eq(P[1].v[0], 0.0f) && grx_mpr_eq(P[1].v[1], 0.0f) && grx_mpr_eq(P[1].v[2], 0.0f)) { *depth = 0.0f; dir[0] = dir[1] = dir[2] = 0.0f; return 0; }
+    dir[0] = P[1].v[0]; dir[1] = P[1].v[1]; dir[2] = P[1].v[2]; *depth = sqrtf(dot3f(dir, dir)); grx_normalize3f(dir);
+    return 0;
+  }
+  grx_normalize3f(d);
+  grx_mpr_support(q, d, &P[2]);
+  dotv = dot3f(P[2].v, d);
+  if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
+  for (int k = 0; k < 3; k++) { a[k] = P[1].v[k] - P[0].v[k]; b[k] = P[2].v[k] - P[0].v[k]; }
+  cross3f(d, a, b); grx_normalize3f(d);
+  if (dot3f(d, P[0].v) > 0.0f) { GrxMprPt t = P[1]; P[1] = P[2]; P[2] = t; d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+  for (int guard = 0;; guard++) {
+    if (guard > 200) return -1;
+    grx_mpr_support(q, d, &P[3]);
+    dotv = dot3f(P[3].v, d);
+    if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
+    int cont = 0;
+    cross3f(a, P[1].v, P[3].v); dotv = dot3f(a, P[0].v);
+    if (dotv < 0.0f && !grx_mpr_zero(dotv)) { P[2] = P[3]; cont = 1; }
+    if (!cont) {
+      cross3f(a, P[3].v, P[2].v); dotv = dot3f(a, P[0].v);
+      if (dotv < 0.0f && !grx_mpr_zero(dotv)) { P[1] = P[3]; cont = 1; }
+    }
+    if (!cont) break;
+    for (int k = 0; k < 3; k++) { a[k] = P[1].v[k] - P[0].v[k]; b[k] = P[2].v[k] - P[0].v[k]; }
+    cross3f(d, a, b); grx_normalize3f(d);
+  }
+  for (int guard = 0;; guard++) {
+    if (guard > 200) return -1;
+    grx_mpr_portal_dir(P, d);
+    dotv = dot3f(d, P[1].v);
+    if (grx_mpr_zero(dotv) || dotv > 0.0f) break;
+    grx_mpr_support(q, d, &v4);
+    dotv = dot3f(v4.v, d);
+    if (!(grx_mpr_zero(dotv) || dotv > 0.0f) || grx_mpr_reach_tolerance(P, &v4, d, tol)) return -1;
+    grx_mpr_expand(P, &v4);
+  }
+  for (int it = 0;; it++) {
+    grx_mpr_portal_dir(P, d);
+    grx_mpr_support(q, d, &v4);
+    if (grx_mpr_reach_tolerance(P, &v4, d, tol) || it > maxit) {
+      float w[3];
+      *depth = sqrtf(grx_mpr_tri_dist2(P[1].v, P[2].v, P[3].v, w));
+      if (grx_mpr_zero(w[0]) && grx_mpr_zero(w[1]) && grx_mpr_zero(w[2])) { w[0] = d[0]; w[1] = d[1]; w[2] = d[2]; }
+      grx_normalize3f(w); dir[0] = w[0]; dir[1] = w[1]; dir[2] = w[2];
+      float bc[4], cr[3], sum;
+      cross3f(cr, P[1].v, P[2].v); bc[0] = dot3f(cr, P[3].v);
+      cross3f(cr, P[3].v, P[2].v); bc[1] = dot3f(cr, P[0].v);
+      cross3f(cr, P[0].v, P[1].v); bc[2] = dot3f(cr, P[3].v);
+      cross3f(cr, P[2].v, P[1].v); bc[3] = dot3f(cr, P[0].v);
+      sum = bc[0] + bc[1] + bc[2] + bc[3];
+      if (grx_mpr_zero(sum) || sum < 0.0f) {
+        bc[0] = 0.0f;
+        cross3f(cr, P[2].v, P[3].v); bc[1] = dot3f(cr, d);
+        cross3f(cr, P[3].v, P[1].v); bc[2] = dot3f(cr, d);
+        cross3f(cr, P[1].v, P[2].v); bc[3] = dot3f(cr, d);
+        sum = bc[1] + bc[2] + bc[3];
+      }
+      // witness on geom 2 = w - v (+ the centre offset, which cancels in the relative frame except for P0: its witnesses are the two centres)
+      const float is = 1.0f / sum;
+      for (int k = 0; k < 3; k++) {
+        float p1 = 0.0f, p2 = bc[0] * q->c21[k];
+        for (int i = 1; i < 4; i++) { p1 += bc[i] * P[i].w[k]; p2 += bc[i] * (P[i].w[k] - P[i].v[k]); }
+        pos[k] = 0.5f * (p1 + p2) * is;
+      }
+      // surface witnesses: the foot of the origin on the portal plane in barycentric coordinates of the triangle alone
+      cross3f(cr, P[2].v, P[3].v); bc[1] = dot3f(cr, d);
+      cross3f(cr, P[3].v, P[1].v); bc[2] = dot3f(cr, d);
+      cross3f(cr, P[1].v, P[2].v); bc[3] = dot3f(cr, d);
+      const float it3 = 1.0f / (bc[1] + bc[2] + bc[3]);
+      for (int k = 0; k < 3; k++) {
+        w1[k] = (bc[1] * P[1].w[k] + bc[2] * P[2].w[k] + bc[3] * P[3].w[k]) * it3;
+        w2[k] = (bc[1] * (P[1].w[k] - P[1].v[k]) + bc[2] * (P[2].w[k] - P[2].v[k]) + bc[3] * (P[3].w[k] - P[3].v[k])) * it3;
+      }
+      return 0;
+    }
+    grx_mpr_expand(P, &v4);
+  }
+}
+// analytic outward normal of a smooth geom (sphere, capsule, ellipsoid) at the world point p (see the oracle: the portal direction of a
+// shallow contact is ill-conditioned, MuJoCo replaces it for smooth geoms); returns 0 for the other types
+GRX_MEM int grx_smooth_normal(const float* R, const float* ce, const float* sz, int type, const float* p, float* n) {
+  float d[3] = {p[0] - ce[0], p[1] - ce[1], p[2] - ce[2]}, loc[3], nl[3];
+  mulMatTVec3f(loc, R, d);
+  if (type == 2) { nl[0] = loc[0]; nl[1] = loc[1]; nl[2] = loc[2]; }
+  else if (type == 3) { nl[0] = loc[0]; nl[1] = loc[1]; nl[2] = loc[2] > sz[1] ? loc[2] - sz[1] : (loc[2] < -sz[1] ? loc[2] + sz[1] : 0.0f); }
+  else if (type == 4) { nl[0] = loc[0] / (sz[0] * sz[0]); nl[1] = loc[1] / (sz[1] * sz[1]); nl[2] = loc[2] / (sz[2] * sz[2]); }
+  else return 0;
+  const float l2 = dot3f(nl, nl);
+  if (l2 < 1e-30f) return 0;
+  const float il = 1.0f / sqrtf(l2);
+  nl[0] *= il; nl[1] *= il; nl[2] *= il;
+  mulMatVec3f(n, R, nl);
+  return 1;
+}
+GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, int t1, int t2, float margin) {
+  GrxMprPair q;
+  q.R1 = c->gxmat + 9 * g1; q.R2 = c->gxmat + 9 * g2; q.t1 = t1; q.t2 = t2; q.hm = 0.5f * margin;
+  for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = c->gxpos[3 * g2 + k] - c->gxpos[3 * g1 + k]; }
+  float depth, dir[3], pos[3], w1[3], w2[3];
+  if (grx_mpr_penetration(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;
+  if (dir[0] == 0.0f && dir[1] == 0.0f && dir[2] == 0.0f) return;
+  for (int k = 0; k < 3; k++) pos[k] += c->gxpos[3 * g1 + k];
+  float n1[3] = {0.0f, 0.0f, 0.0f}, n2[3] = {0.0f, 0.0f, 0.0f};
+  const int h1 = grx_smooth_normal(q.R1, c->gxpos + 3 * g1, q.s1, t1, pos, n1), h2 = grx_smooth_normal(q.R2, c->gxpos + 3 * g2, q.s2, t2, pos, n2);
+  if (h1 || h2) {
+    float n[3] = {n1[0] - n2[0], n1[1] - n2[1], n1[2] - n2[2]};
+    const float l2 = dot3f(n, n);
+    if (l2 > 1e-30f) {
+      const float il = 1.0f / sqrtf(l2); dir[0] = n[0] * il; dir[1] = n[1] * il; dir[2] = n[2] * il;
+      // penetration along the corrected normal: extreme point of a smooth geom, portal witness of a box / cylinder (see the oracle)
+      float nd[3] = {-dir[0], -dir[1], -dir[2]};
+      if (h1) { grx_geom_support(q.R1, q.s1, t1, dir, w1); for (int k = 0; k < 3; k++) w1[k] += dir[k] * q.hm; }
+      if (h2) { grx_geom_support(q.R2, q.s2, t2, nd, w2); for (int k = 0; k < 3; k++) w2[k] += q.c21[k] - dir[k] * q.hm; }
+      depth = (w1[0] - w2[0]) * dir[0] + (w1[1] - w2[1]) * dir[1] + (w1[2] - w2[2]) * dir[2];
+    }
+  }
+  grx_add_contact(c, pair, pos, dir, margin - depth);
+}
+GRX_MEM void grx_plane_ellipsoid(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}, nd[3] = {-n[0], -n[1], -n[2]}, p[3];
+  const float sz[3] = {m->geom_size[3 * g2], m->geom_size[3 * g2 + 1], m->geom_size[3 * g2 + 2]};
+  grx_geom_support(c->gxmat + 9 * g2, sz, 4, nd, p);
+  float dd[3];
+  for (int k = 0; k < 3; k++) { p[k] += c->gxpos[3 * g2 + k]; dd[k] = p[k] - c->gxpos[3 * g1 + k]; }
+  const float dist = dot3f(dd, n);
+  if (dist > margin) return;
+  float pos[3] = {p[0] - 0.5f * dist * n[0], p[1] - 0.5f * dist * n[1], p[2] - 0.5f * dist * n[2]};
+  grx_add_contact(c, pair, pos, n, dist);
+}
 // capsule (geom1) vs box (geom2): axis point closest to the box (golden-section search, the distance is convex along the
 // axis) as a sphere contact, plus the farther end sphere when it is inside the margin as well (see oracle/grx_oracle.c)
 GRX_MEM void grx_capsule_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
@@ -1250,6 +1477,8 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           else if (t1 == 2 && t2 == 6) grx_sphere_box(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
           else if (t1 == 6 && t2 == 6) isbox = 1;
+          else if (!S::kFixed && t1 == 0 && t2 == 4) grx_plane_ellipsoid(m, c, p, g1, g2, margin);
+          else if (!S::kFixed && t1 >= 2 && t2 <= 6 && (t1 == 4 || t1 == 5 || t2 == 4 || t2 == 5)) grx_convex_pair(m, c, p, g1, g2, t1, t2, margin);   // generic kernels only
           else if (t1 == 0 && t2 == 7) {
             if (m->geom_meshnum[g2] <= 32) grx_plane_mesh_small(m, c, p, g1, g2, margin);
             else { int q = GRX_ATOMIC_ADD(&c->cnt[7], 1); if (q < 32) c->ired[q] = p; }

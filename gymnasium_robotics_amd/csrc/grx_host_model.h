@@ -40,6 +40,12 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.ntendon = v.n_tendon_adr; m.ntouch = v.n_touch_body;
   m.twospan = 0;
   for (int k = 0; k < v.n_pair_span; k++) if (((unsigned)v.pair_span[k] >> 24) != 0) m.twospan = 1;
+  // candidate pairs that go to the general convex (MPR) narrow phase: only the generic kernels carry that code
+  m.nconvex = 0;
+  for (int k = 0; k < v.n_devpair_geoms; k++) {
+    const unsigned rec = (unsigned)v.devpair_geoms[k]; const int t1 = (rec >> 24) & 0xF, t2 = rec >> 28;
+    if ((t1 == 0 && t2 == 4) || (t1 >= 2 && t2 <= 6 && (t1 == 4 || t1 == 5 || t2 == 4 || t2 == 5))) m.nconvex++;
+  }
   m.nfric = 0; m.nweld = 0; m.wpool = 0;
   for (int k = 0; k < v.n_weld_row; k++) m.wpool += 6 * ((v.weld_row[k] >> 20) & 0xFF);
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;
@@ -55,6 +61,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.timestep = (float)v.opt[GRX_TIMESTEP];
   m.gravity[0] = (float)v.opt[GRX_GRAVITY_X]; m.gravity[1] = (float)v.opt[GRX_GRAVITY_Y]; m.gravity[2] = (float)v.opt[GRX_GRAVITY_Z];
   m.meaninertia = (float)v.opt[GRX_MEANINERTIA]; m.impratio = (float)v.opt[GRX_IMPRATIO];
+  m.mpr_tolerance = (float)v.opt[GRX_MPR_TOLERANCE]; m.mpr_iterations = (int)v.opt[GRX_MPR_ITERATIONS];
 }
 
 // model view whose tables live at (fbase, ibase)

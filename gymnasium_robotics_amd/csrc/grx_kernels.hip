@@ -82,7 +82,7 @@ template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(cons
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan);
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && g.nconvex == 0;
 }
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)

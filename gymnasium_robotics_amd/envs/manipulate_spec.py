@@ -17,12 +17,15 @@ BLOCK_VARIANTS = {
     "HandManipulateBlockRotateZ": ("block", "ignore", "z"), "HandManipulateBlockRotateParallel": ("block", "ignore", "parallel"),
     "HandManipulateBlockRotateXYZ": ("block", "ignore", "xyz"), "HandManipulateBlockFull": ("block", "random", "xyz"),
     "HandManipulateBlock": ("block", "random", "xyz"),
+    "HandManipulateEggRotate": ("egg", "ignore", "xyz"), "HandManipulateEggFull": ("egg", "random", "xyz"), "HandManipulateEgg": ("egg", "random", "xyz"),
     "HandManipulatePenRotate": ("pen", "ignore", "xyz"), "HandManipulatePenFull": ("pen", "random", "xyz"), "HandManipulatePen": ("pen", "random", "xyz"),
 }
-NO_TOUCH_IDS = ("HandManipulateBlockFull", "HandManipulatePenFull")   # the *Full ids have no touch-sensor twins
+NO_TOUCH_IDS = ("HandManipulateBlockFull", "HandManipulateEggFull", "HandManipulatePenFull")   # the *Full ids have no touch-sensor twins
 # per-object constructor constants: manipulate_block.py:214-230, manipulate_pen.py:216-235
 OBJECTS = {
     "block": dict(xml="manipulate_block", randomize_initial_rotation=True, ignore_z_target_rotation=False, distance_threshold=0.01),
+    # manipulate_egg.py:216-230: the Manipulate defaults; the ellipsoid goes through the general convex (MPR) narrow phase
+    "egg": dict(xml="manipulate_egg", randomize_initial_rotation=True, ignore_z_target_rotation=False, distance_threshold=0.01),
     "pen": dict(xml="manipulate_pen", randomize_initial_rotation=False, ignore_z_target_rotation=True, distance_threshold=0.05),
 }
 
@@ -53,7 +56,7 @@ def parse_block_id(env_id: str):
 
 
 def object_of(env_id: str) -> str:
-    """'block' or 'pen' (the egg's ellipsoid needs a general convex narrow phase: not supported)."""
+    """'block', 'egg' or 'pen'."""
     name = env_id.rpartition("-")[0]
     name = name[:-5] if name.endswith("Dense") else name
     for suffix in ("_ContinuousTouchSensors", "_BooleanTouchSensors"):

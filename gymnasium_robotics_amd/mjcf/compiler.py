@@ -56,7 +56,7 @@ DIMS = [
     "eulerdamp", "ntree", "maxdepth", "maxefc_req", "jpool_req", "maxcon_req",
 ]
 NDIMS = 32
-OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia"]
+OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia", "mpr_tolerance", "mpr_iterations"]
 NOPTS = 16
 
 
@@ -367,7 +367,7 @@ class MjcfCompiler:
         self.bodies: List[_Body] = []
         self.meshes: Dict[str, Dict[str, object]] = {}
         self.opt = dict(timestep=0.002, gravity=np.array([0, 0, -9.81]), tolerance=1e-8, impratio=1.0,
-                        integrator=0, iterations=100, cone=0, noslip_iterations=0, eulerdamp=1)
+                        integrator=0, iterations=100, cone=0, noslip_iterations=0, eulerdamp=1, mpr_tolerance=1e-6, mpr_iterations=50)
 
     # -- attribute helpers -------------------------------------------------
     def _attrs(self, elem: ET.Element, tag: str, childclass: Optional[str]) -> Dict[str, str]:
@@ -420,6 +420,10 @@ class MjcfCompiler:
                 self.opt["iterations"] = int(a["iterations"])
             if "noslip_iterations" in a:
                 self.opt["noslip_iterations"] = int(a["noslip_iterations"])
+            if "mpr_tolerance" in a:
+                self.opt["mpr_tolerance"] = float(a["mpr_tolerance"])
+            if "mpr_iterations" in a:
+                self.opt["mpr_iterations"] = int(a["mpr_iterations"])
             if "integrator" in a:
                 self.opt["integrator"] = {"euler": 0, "rk4": 1, "implicit": 2, "implicitfast": 3}[a["integrator"].lower()]
             if "cone" in a:
@@ -1074,7 +1078,10 @@ class _Lowering:
         weldparent = [weld[B[weld[i]].parent] if weld[i] > 0 else 0 for i in range(nb)]
         # narrow-phase routines implemented by BOTH the device engine and the oracle
         supported = {(GEOM_PLANE, GEOM_BOX), (GEOM_PLANE, GEOM_MESH), (GEOM_BOX, GEOM_BOX), (GEOM_PLANE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_BOX),
-                     (GEOM_PLANE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CAPSULE)}
+                     (GEOM_PLANE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_ELLIPSOID)}
+        # general convex narrow phase (MPR, one contact): every pair of primitives that involves an ellipsoid or a cylinder
+        prim = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX)
+        supported |= {(ta, tb) for ta in prim for tb in prim if ta <= tb and (GEOM_ELLIPSOID in (ta, tb) or GEOM_CYLINDER in (ta, tb))}
         pairs = []
         for a in range(ng):
             for b_ in range(a + 1, ng):
@@ -1336,7 +1343,8 @@ class _Lowering:
         optv = np.zeros(NOPTS)
         g = c.opt["gravity"]
         for k, v in dict(timestep=c.opt["timestep"], gravity_x=g[0], gravity_y=g[1], gravity_z=g[2],
-                         tolerance=c.opt["tolerance"], impratio=c.opt["impratio"], meaninertia=meaninertia).items():
+                         tolerance=c.opt["tolerance"], impratio=c.opt["impratio"], meaninertia=meaninertia,
+                         mpr_tolerance=c.opt["mpr_tolerance"], mpr_iterations=c.opt["mpr_iterations"]).items():
             optv[OPTS.index(k)] = v
         T.update(
             dims=dims, opt=optv, qpos0=qpos0,

@@ -736,6 +736,261 @@ static void collide_box_box(orc_sim* s, int pair, int g1, int g2, double margin)
   }
 }
 
+
+/* ------------------------------------------------------------------ general convex pairs: Minkowski Portal Refinement
+ * MuJoCo (up to 3.1; later versions keep it behind the "nativeccd" disable flag) sends every pair that involves an ellipsoid, a
+ * cylinder or a mesh -- other than against a plane -- to libccd's ccdMPRPenetration [3P, not in /root/reference], with
+ *   centre(geom)      = geom_xpos,
+ *   support(geom, d)  = the geom's farthest point along d, plus d * margin/2 (each geom inflated by half the pair margin),
+ *   tolerance         = opt.mpr_tolerance (1e-6),  iteration cap = opt.mpr_iterations (50),
+ * and turns the result into ONE contact: dist = margin - depth, normal = the returned direction (geom1 -> geom2), pos = the
+ * returned position.  This is a restatement of the published algorithm (G. Snethen, "XenoCollide: Complex Collision Made Simple",
+ * Game Programming Gems 7; the structure of libccd's mpr.c: discover portal -> refine portal -> find penetration), written from
+ * its description; the normal of contacts with smooth geoms is then replaced by the analytic one (smooth_normal below).
+ * PARITY UNPINNED like the rest of this file. */
+#define MPR_EPS 2.220446049250313e-16
+typedef struct { double v[3], v1[3], v2[3]; } mpr_pt;
+static int mpr_zero(double x) { return fabs(x) < MPR_EPS; }
+static int mpr_eq(double a, double b) {
+  double ab = fabs(a - b);
+  if (ab < MPR_EPS) return 1;
+  a = fabs(a); b = fabs(b);
+  return ab < MPR_EPS * (b > a ? b : a);
+}
+static double sgn1(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); }
+static void normalize3(double* v) { double n = norm3(v); if (n > 0) { v[0] /= n; v[1] /= n; v[2] /= n; } }
+
+/* farthest point of geom g along the world direction d (unit), inflated by hm along d */
+static void geom_support(const orc_sim* s, int g, const double* d, double hm, double* out) {
+  const grx_model_view* m = &s->m;
+  const double* R = s->geom_xmat + 9 * g; const double* pos = s->geom_xpos + 3 * g; const double* sz = m->geom_size + 3 * g;
+  double dl[3], r[3] = {0, 0, 0};
+  mulMatTVec3(dl, R, d);
+  switch (m->geom_type[g]) {
+    case GRX_GEOM_SPHERE: for (int k = 0; k < 3; k++) r[k] = dl[k] * sz[0]; break;
+    case GRX_GEOM_CAPSULE: for (int k = 0; k < 3; k++) r[k] = dl[k] * sz[0]; r[2] += sgn1(dl[2]) * sz[1]; break;
+    case GRX_GEOM_ELLIPSOID: {
+      double t[3] = {dl[0] * sz[0], dl[1] * sz[1], dl[2] * sz[2]};
+      normalize3(t);
+      for (int k = 0; k < 3; k++) r[k] = t[k] * sz[k];
+      break;
+    }
+    case GRX_GEOM_CYLINDER: {
+      double h = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      if (h > MINVAL) { r[0] = dl[0] / h * sz[0]; r[1] = dl[1] / h * sz[0]; }
+      r[2] = sgn1(dl[2]) * sz[1];
+      break;
+    }
+    case GRX_GEOM_BOX: for (int k = 0; k < 3; k++) r[k] = sgn1(dl[k]) * sz[k]; break;
+    default: break;
+  }
+  mulMatVec3(out, R, r);
+  for (int k = 0; k < 3; k++) out[k] += pos[k] + d[k] * hm;
+}
+static void mpr_support(const orc_sim* s, int g1, int g2, const double* d, double hm, mpr_pt* o) {
+  double nd[3] = {-d[0], -d[1], -d[2]};
+  geom_support(s, g1, d, hm, o->v1); geom_support(s, g2, nd, hm, o->v2);
+  for (int k = 0; k < 3; k++) o->v[k] = o->v1[k] - o->v2[k];
+}
+static void mpr_portal_dir(const mpr_pt* P, double* dir) {
+  double a[3], b[3];
+  for (int k = 0; k < 3; k++) { a[k] = P[2].v[k] - P[1].v[k]; b[k] = P[3].v[k] - P[1].v[k]; }
+  cross3(dir, a, b); normalize3(dir);
+}
+static int mpr_reach_tolerance(const mpr_pt* P, const mpr_pt* v4, const double* dir, double tol) {
+  double d4 = dot3(v4->v, dir), m1 = d4 - dot3(P[1].v, dir), m2 = d4 - dot3(P[2].v, dir), m3 = d4 - dot3(P[3].v, dir);
+  double mn = fmin(m1, fmin(m2, m3));
+  return mpr_eq(mn, tol) || mn < tol;
+}
+static void mpr_expand(mpr_pt* P, const mpr_pt* v4) {
+  double c[3];
+  cross3(c, v4->v, P[0].v);
+  if (dot3(P[1].v, c) > 0) { if (dot3(P[2].v, c) > 0) P[1] = *v4; else P[3] = *v4; }
+  else { if (dot3(P[3].v, c) > 0) P[2] = *v4; else P[1] = *v4; }
+}
+/* squared distance origin -> segment [a,b], witness w */
+static double mpr_seg_dist2(const double* a, const double* b, double* w) {
+  double d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, t = -dot3(a, d), dd = dot3(d, d);
+  t = dd > 0 ? fmin(1.0, fmax(0.0, t / dd)) : 0.0;
+  for (int k = 0; k < 3; k++) w[k] = a[k] + t * d[k];
+  return dot3(w, w);
+}
+/* squared distance origin -> triangle (x0,b,c), witness w (closest point) */
+static double mpr_tri_dist2(const double* x0, const double* b, const double* c, double* w) {
+  double d1[3], d2[3];
+  for (int k = 0; k < 3; k++) { d1[k] = b[k] - x0[k]; d2[k] = c[k] - x0[k]; }
+  double u = dot3(x0, x0), v = dot3(d1, d1), ww = dot3(d2, d2), p = dot3(x0, d1), q = dot3(x0, d2), r = dot3(d1, d2);
+  double den = ww * v - r * r, best;
+  if (!mpr_zero(den)) {
+    double sp = (q * r - ww * p) / den, tp = (-sp * r - q) / ww;
+    if ((mpr_zero(sp) || sp > 0) && (mpr_eq(sp, 1) || sp < 1) && (mpr_zero(tp) || tp > 0) && (mpr_eq(tp, 1) || tp < 1) && (mpr_eq(tp + sp, 1) || tp + sp < 1)) {
+      for (int k = 0; k < 3; k++) w[k] = x0[k] + sp * d1[k] + tp * d2[k];
+      best = sp * sp * v + tp * tp * ww + 2 * sp * tp * r + 2 * sp * p + 2 * tp * q + u;
+      return best > 0 ? best : 0;
+    }
+  }
+  double w2[3], dist;
+  best = mpr_seg_dist2(x0, b, w);
+  dist = mpr_seg_dist2(x0, c, w2); if (dist < best) { best = dist; memcpy(w, w2, sizeof(w2)); }
+  dist = mpr_seg_dist2(b, c, w2); if (dist < best) { best = dist; memcpy(w, w2, sizeof(w2)); }
+  return best;
+}
+/* 0 = penetration found: depth, dir, pos as libccd defines them, plus the points w1 / w2 of the two geoms' surfaces that the final
+ * portal triangle is made of, taken at the foot of the origin on the portal plane;  -1 = separated */
+static int mpr_penetration(const orc_sim* s, int g1, int g2, double hm, double tol, int maxit, double* depth, double* dir, double* pos, double* w1, double* w2) {
+  mpr_pt P[4], v4;
+  double d[3], a[3], b[3], dotv;
+  /* portal discovery: P0 = interior point (difference of the centres) */
+  for (int k = 0; k < 3; k++) { P[0].v1[k] = s->geom_xpos[3 * g1 + k]; P[0].v2[k] = s->geom_xpos[3 * g2 + k]; P[0].v[k] = P[0].v1[k] - P[0].v2[k]; }
+  if (mpr_eq(P[0].v[0], 0) && mpr_eq(P[0].v[1], 0) && mpr_eq(P[0].v[2], 0)) P[0].v[0] += MPR_EPS * 10;
+  for (int k = 0; k < 3; k++) d[k] = -P[0].v[k];
+  normalize3(d);
+  mpr_support(s, g1, g2, d, hm, &P[1]);
+  dotv = dot3(P[1].v, d);
+  if (mpr_zero(dotv) || dotv < 0) return -1;
+  cross3(d, P[0].v, P[1].v);
+  if (mpr_zero(dot3(d, d))) {
+    /* the origin lies on the ray P0 -> P1 */
+    for (int k = 0; k < 3; k++) { w1[k] = P[1].v1[k]; w2[k] = P[1].v2[k]; pos[k] = 0.5 * (w1[k] + w2[k]); }
+    if (mpr_eq(P[1].v[0], 0) && mpr_eq(P[1].v[1], 0) && mpr_eq(P[1].v[2], 0)) { *depth = 0; dir[0] = dir[1] = dir[2] = 0; return 0; }   /* touching */
+    memcpy(dir, P[1].v, 3 * sizeof(double)); *depth = norm3(dir); normalize3(dir);
+    return 0;
+  }
+  normalize3(d);
+  mpr_support(s, g1, g2, d, hm, &P[2]);
+  dotv = dot3(P[2].v, d);
+  if (mpr_zero(dotv) || dotv < 0) return -1;
+  for (int k = 0; k < 3; k++) { a[k] = P[1].v[k] - P[0].v[k]; b[k] = P[2].v[k] - P[0].v[k]; }
+  cross3(d, a, b); normalize3(d);
+  if (dot3(d, P[0].v) > 0) { mpr_pt t = P[1]; P[1] = P[2]; P[2] = t; d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+  for (int guard = 0;; guard++) {
+    if (guard > 200) return -1;
+    mpr_support(s, g1, g2, d, hm, &P[3]);
+    dotv = dot3(P[3].v, d);
+    if (mpr_zero(dotv) || dotv < 0) return -1;
+    int cont = 0;
+    cross3(a, P[1].v, P[3].v); dotv = dot3(a, P[0].v);
+    if (dotv < 0 && !mpr_zero(dotv)) { P[2] = P[3]; cont = 1; }
+    if (!cont) {
+      cross3(a, P[3].v, P[2].v); dotv = dot3(a, P[0].v);
+      if (dotv < 0 && !mpr_zero(dotv)) { P[1] = P[3]; cont = 1; }
+    }
+    if (!cont) break;
+    for (int k = 0; k < 3; k++) { a[k] = P[1].v[k] - P[0].v[k]; b[k] = P[2].v[k] - P[0].v[k]; }
+    cross3(d, a, b); normalize3(d);
+  }
+  /* portal refinement: move the portal outwards until the origin is inside the tetrahedron P0..P3 */
+  for (int guard = 0;; guard++) {
+    if (guard > 200) return -1;
+    mpr_portal_dir(P, d);
+    dotv = dot3(d, P[1].v);
+    if (mpr_zero(dotv) || dotv > 0) break;
+    mpr_support(s, g1, g2, d, hm, &v4);
+    dotv = dot3(v4.v, d);
+    if (!(mpr_zero(dotv) || dotv > 0) || mpr_reach_tolerance(P, &v4, d, tol)) return -1;
+    mpr_expand(P, &v4);
+  }
+  /* penetration: push the portal to the surface of the Minkowski difference */
+  for (int it = 0;; it++) {
+    mpr_portal_dir(P, d);
+    mpr_support(s, g1, g2, d, hm, &v4);
+    if (mpr_reach_tolerance(P, &v4, d, tol) || it > maxit) {
+      double w[3];
+      *depth = sqrt(mpr_tri_dist2(P[1].v, P[2].v, P[3].v, w));
+      if (mpr_zero(w[0]) && mpr_zero(w[1]) && mpr_zero(w[2])) memcpy(w, d, sizeof(w));
+      normalize3(w); memcpy(dir, w, sizeof(w));
+      /* position: barycentric coordinates of the origin in the portal tetrahedron, applied to the two witness sets */
+      double bc[4], c[3], sum;
+      cross3(c, P[1].v, P[2].v); bc[0] = dot3(c, P[3].v);
+      cross3(c, P[3].v, P[2].v); bc[1] = dot3(c, P[0].v);
+      cross3(c, P[0].v, P[1].v); bc[2] = dot3(c, P[3].v);
+      cross3(c, P[2].v, P[1].v); bc[3] = dot3(c, P[0].v);
+      sum = bc[0] + bc[1] + bc[2] + bc[3];
+      if (mpr_zero(sum) || sum < 0) {
+        bc[0] = 0;
+        cross3(c, P[2].v, P[3].v); bc[1] = dot3(c, d);
+        cross3(c, P[3].v, P[1].v); bc[2] = dot3(c, d);
+        cross3(c, P[1].v, P[2].v); bc[3] = dot3(c, d);
+        sum = bc[1] + bc[2] + bc[3];
+      }
+      for (int k = 0; k < 3; k++) {
+        double p1 = 0, p2 = 0;
+        for (int i = 0; i < 4; i++) { p1 += bc[i] * P[i].v1[k]; p2 += bc[i] * P[i].v2[k]; }
+        pos[k] = 0.5 * (p1 + p2) / sum;
+      }
+      /* surface witnesses: barycentric weights of the foot of the origin in the portal triangle alone (no interior point) */
+      cross3(c, P[2].v, P[3].v); bc[1] = dot3(c, d);
+      cross3(c, P[3].v, P[1].v); bc[2] = dot3(c, d);
+      cross3(c, P[1].v, P[2].v); bc[3] = dot3(c, d);
+      sum = bc[1] + bc[2] + bc[3];
+      for (int k = 0; k < 3; k++) {
+        w1[k] = (bc[1] * P[1].v1[k] + bc[2] * P[2].v1[k] + bc[3] * P[3].v1[k]) / sum;
+        w2[k] = (bc[1] * P[1].v2[k] + bc[2] * P[2].v2[k] + bc[3] * P[3].v2[k]) / sum;
+      }
+      return 0;
+    }
+    mpr_expand(P, &v4);
+  }
+}
+/* Analytic outward normal of a smooth geom (sphere, capsule, ellipsoid) at the world point p; 0 if the geom type has none.
+ * For shallow penetrations the portal direction is the normal of a triangle whose size (~sqrt(tolerance * curvature radius)) is
+ * comparable to the depth, i.e. ill-conditioned; MuJoCo therefore replaces the normal of contacts that involve smooth geoms by
+ * the analytic one evaluated at the contact position (mjc_fixNormal [3P]).  Restated from its description: one smooth geom ->
+ * its normal; two -> the normalised sum of geom 1's outward normal and geom 2's inward normal; none -> the portal direction. */
+static int smooth_normal(const orc_sim* s, int g, const double* p, double* n) {
+  const grx_model_view* m = &s->m;
+  const double* R = s->geom_xmat + 9 * g; const double* c = s->geom_xpos + 3 * g; const double* sz = m->geom_size + 3 * g;
+  double d[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]}, loc[3], nl[3];
+  mulMatTVec3(loc, R, d);
+  switch (m->geom_type[g]) {
+    case GRX_GEOM_SPHERE: memcpy(nl, loc, sizeof(nl)); break;
+    case GRX_GEOM_CAPSULE: nl[0] = loc[0]; nl[1] = loc[1]; nl[2] = loc[2] > sz[1] ? loc[2] - sz[1] : (loc[2] < -sz[1] ? loc[2] + sz[1] : 0.0); break;
+    case GRX_GEOM_ELLIPSOID: for (int k = 0; k < 3; k++) nl[k] = loc[k] / (sz[k] * sz[k]); break;
+    default: return 0;
+  }
+  double len = norm3(nl);
+  if (len < MINVAL) return 0;
+  for (int k = 0; k < 3; k++) nl[k] /= len;
+  mulMatVec3(n, R, nl);
+  return 1;
+}
+static void collide_convex(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  double depth, dir[3], pos[3], w1[3], w2[3], n1[3], n2[3];
+  if (mpr_penetration(s, g1, g2, 0.5 * margin, m->opt[GRX_MPR_TOLERANCE], (int)m->opt[GRX_MPR_ITERATIONS], &depth, dir, pos, w1, w2) != 0) return;
+  if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return;   /* touching, normal undefined: no contact */
+  const int h1 = smooth_normal(s, g1, pos, n1), h2 = smooth_normal(s, g2, pos, n2);
+  if (h1 || h2) {
+    double n[3] = {(h1 ? n1[0] : 0) - (h2 ? n2[0] : 0), (h1 ? n1[1] : 0) - (h2 ? n2[1] : 0), (h1 ? n1[2] : 0) - (h2 ? n2[2] : 0)};
+    double len = norm3(n);
+    if (len > MINVAL) {
+      for (int k = 0; k < 3; k++) dir[k] = n[k] / len;
+      /* Penetration measured along the corrected normal: (point of geom 1 - point of geom 2) . n, where the point of a smooth geom
+       * is its extreme point along n and the point of a box / cylinder is the portal witness (it lies on the touching face near the
+       * contact; the extreme point of a box would be a far corner, with a lever arm of the box size on any error of n).
+       * (The distance to the final portal triangle, which libccd reports, depends on the size of that triangle -- rounding-level
+       * decisions of the refinement -- when depth ~ sqrt(tolerance * radius): the regime of every resting hand contact.) */
+      double nd[3] = {-dir[0], -dir[1], -dir[2]};
+      if (h1) geom_support(s, g1, dir, 0.5 * margin, w1);
+      if (h2) geom_support(s, g2, nd, 0.5 * margin, w2);
+      depth = (w1[0] - w2[0]) * dir[0] + (w1[1] - w2[1]) * dir[1] + (w1[2] - w2[2]) * dir[2];
+    }
+  }
+  add_contact(s, pair, pos, dir, margin - depth);
+}
+/* plane vs ellipsoid: the deepest point of the ellipsoid (MuJoCo's analytic plane routine: one contact) */
+static void collide_plane_ellipsoid(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* pm = s->geom_xmat + 9 * g1; double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-n[0], -n[1], -n[2]}, p[3];
+  (void)m;
+  geom_support(s, g2, nd, 0.0, p);
+  double dd[3] = {p[0] - s->geom_xpos[3 * g1], p[1] - s->geom_xpos[3 * g1 + 1], p[2] - s->geom_xpos[3 * g1 + 2]};
+  double dist = dot3(dd, n);
+  if (dist > margin) return;
+  double pos[3] = {p[0] - 0.5 * dist * n[0], p[1] - 0.5 * dist * n[1], p[2] - 0.5 * dist * n[2]};
+  add_contact(s, pair, pos, n, dist);
+}
+
 static void collision(orc_sim* s) {
   const grx_model_view* m = &s->m;
   s->ncon = 0;
@@ -761,6 +1016,9 @@ static void collision(orc_sim* s) {
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_BOX) collide_plane_box(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_MESH) collide_plane_mesh(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_BOX && t2 == GRX_GEOM_BOX) collide_box_box(s, p, g1, g2, margin);
+    else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_ELLIPSOID) collide_plane_ellipsoid(s, p, g1, g2, margin);
+    else if (t1 >= GRX_GEOM_SPHERE && t2 <= GRX_GEOM_BOX && (t1 == GRX_GEOM_ELLIPSOID || t1 == GRX_GEOM_CYLINDER || t2 == GRX_GEOM_ELLIPSOID || t2 == GRX_GEOM_CYLINDER))
+      collide_convex(s, p, g1, g2, margin);
     else s->unsupported_hits++;
   }
 }

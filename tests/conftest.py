@@ -16,4 +16,4 @@ def pytest_configure(config):
 def fetch_models():
     from gymnasium_robotics_amd.envs.fetch import load_fetch_model
 
-    return {t: load_fetch_model(t) for t in ("FetchReach", "FetchPush", "FetchPickAndPlace")}
+    return {t: load_fetch_model(t) for t in ("FetchReach", "FetchPush", "FetchSlide", "FetchPickAndPlace")}

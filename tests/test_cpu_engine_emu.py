@@ -22,7 +22,7 @@ def emu_factory(fetch_models):
     return make
 
 
-@pytest.mark.parametrize("task,stride", [("FetchReach", 4), ("FetchPush", 3), ("FetchPickAndPlace", 3)])
+@pytest.mark.parametrize("task,stride", [("FetchReach", 4), ("FetchPush", 3), ("FetchSlide", 3), ("FetchPickAndPlace", 3)])
 def test_emulated_kernel_step_matches_golden(emu_factory, task, stride):
     g = np.load(os.path.join(GOLDEN, f"fetch_{task}_teacher.npz"))
     emu = emu_factory(task)
@@ -32,7 +32,14 @@ def test_emulated_kernel_step_matches_golden(emu_factory, task, stride):
             getattr(emu, k)[:] = g[k][i]
         emu.step(g["action"][i])
         assert emu.status.value == 0
-        err = np.abs(emu.obs - g["obs"][i]).max()
+        e = np.abs(emu.obs - g["obs"][i])
+        if task == "FetchSlide":
+            # The puck rests on ONE contact whose position inside the flat cap is not unique (the convex narrow phase reports some
+            # point of the portal): fp32 and fp64 legitimately pick different points, the torque differs and so do the puck's rotation
+            # (obs 11:14) and rotational velocity (17:20).  Everything translational is held to the usual bounds.
+            assert e[11:14].max() < 5e-3 and e[17:20].max() < 2e-2, (i, e[11:14].max(), e[17:20].max())
+            e = np.delete(e, np.r_[11:14, 17:20])
+        err = e.max()
         if g["activation_gap"][i] >= 2e-5:
             worst = max(worst, err)
             assert err < 1e-4, (i, err)

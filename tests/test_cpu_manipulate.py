@@ -42,7 +42,7 @@ def test_ids_and_samplers():
     assert ms.parse_block_id("HandManipulateBlockRotateParallel-v1")[1] == "parallel"
     assert ms.parse_block_id("HandManipulateBlock-v1") == ("random", "xyz", "sparse", "off")
     assert ms.parse_block_id("HandManipulatePenRotate_BooleanTouchSensors-v1") == ("ignore", "xyz", "sparse", "boolean") and ms.object_of("HandManipulatePen-v1") == "pen"
-    for bad in ("HandManipulateBlockFull_BooleanTouchSensors-v1", "HandManipulateEgg-v1", "HandManipulateBlock-v0"):
+    for bad in ("HandManipulateBlockFull_BooleanTouchSensors-v1", "HandManipulateEggFull_ContinuousTouchSensors-v1", "HandManipulateBlock-v0"):
         with pytest.raises(ValueError):
             ms.parse_block_id(bad)
     pq = ms.canonical_parallel_quats()

@@ -14,7 +14,7 @@ def _make(env_id, **kw):
     return grx.make_vec(env_id, num_envs=3, device="cuda:0", output="numpy", **kw)
 
 
-ALL_IDS = ["FetchReach-v4", "FetchPush-v4", "FetchPickAndPlaceDense-v4", "HandReach-v3", "HandManipulateBlockRotateXYZ-v1",
+ALL_IDS = ["FetchReach-v4", "FetchPush-v4", "FetchSlide-v4", "FetchPickAndPlaceDense-v4", "HandManipulateEggFull-v1", "HandReach-v3", "HandManipulateBlockRotateXYZ-v1",
            "HandManipulateBlock_BooleanTouchSensors-v1", "HandManipulatePen_ContinuousTouchSensors-v1", "PointMaze_UMaze-v3", "AntMaze_UMaze-v5"]
 
 

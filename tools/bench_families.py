@@ -6,10 +6,11 @@ from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
 from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv, HandReachVecEnv
 from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv, PointMazeVecEnv
 
-CASES = ((FetchVecEnv, "FetchReach-v4", 4096, 4), (FetchVecEnv, "FetchPush-v4", 4096, 4), (FetchVecEnv, "FetchPickAndPlace-v4", 4096, 4),
+CASES = ((FetchVecEnv, "FetchReach-v4", 4096, 4), (FetchVecEnv, "FetchPush-v4", 4096, 4), (FetchVecEnv, "FetchSlide-v4", 4096, 4), (FetchVecEnv, "FetchPickAndPlace-v4", 4096, 4),
          (HandReachVecEnv, "HandReach-v3", 4096, 20), (HandReachVecEnv, "HandReach-v3", 16384, 20),
          (HandBlockVecEnv, "HandManipulateBlockRotateXYZ-v1", 4096, 20), (HandBlockVecEnv, "HandManipulateBlockRotateXYZ-v1", 16384, 20),
          (HandBlockVecEnv, "HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", 16384, 20),
+         (HandBlockVecEnv, "HandManipulateEggRotate-v1", 16384, 20), (HandBlockVecEnv, "HandManipulatePenRotate-v1", 16384, 20),
          (AntMazeVecEnv, "AntMaze_Large_Diverse_GR-v5", 8192, 8), (PointMazeVecEnv, "PointMaze_Large_Diverse_GR-v3", 65536, 2))
 for cls, env_id, n, na in CASES:
     env = cls(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)

@@ -16,7 +16,7 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gymnasium_
 os.makedirs(OUT, exist_ok=True)
 from gymnasium_robotics_amd.envs.fetch import FETCH_CAPACITY  # noqa: E402
 
-for xml in ("fetch/reach.xml", "fetch/push.xml", "fetch/pick_and_place.xml"):
+for xml in ("fetch/reach.xml", "fetch/push.xml", "fetch/slide.xml", "fetch/pick_and_place.xml"):
     m = compile_mjcf(os.path.join(ASSETS, xml), capacity=FETCH_CAPACITY)
     # keep hull vertices only for meshes that take part in a supported pair
     out = os.path.join(OUT, os.path.splitext(os.path.basename(xml))[0] + ".npz")
@@ -48,7 +48,8 @@ save_model(m, out)
 print("hand/manipulate_block.xml (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")},
       "unsupported pairs:", m.info["unsupported_pairs"], f"{os.path.getsize(out) / 1024:.0f} KiB")
 
-for xml, name, tf in (("manipulate_pen.xml", "hand_pen.npz", None), ("manipulate_pen_touch_sensors.xml", "hand_pen_touch.npz", touch_filter)):
+for xml, name, tf in (("manipulate_pen.xml", "hand_pen.npz", None), ("manipulate_pen_touch_sensors.xml", "hand_pen_touch.npz", touch_filter),
+                      ("manipulate_egg.xml", "hand_egg.npz", None), ("manipulate_egg_touch_sensors.xml", "hand_egg_touch.npz", touch_filter)):
     m = compile_mjcf(os.path.join(ASSETS, "hand", xml), mutate=drop_target_body, touch_filter=tf, keep_sites=[],
                      capacity=dict(HAND_MANIP_CAPACITY, jpool=944) if tf else HAND_MANIP_CAPACITY)
     out = os.path.join(OUT, name)
