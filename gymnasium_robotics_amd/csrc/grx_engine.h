@@ -375,12 +375,13 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 // dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
 // Model shape: the ten layout dims as compile-time constants (0 = read from the model at run time).
 template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0, int MAXEFC_ = GRX_MAXEFC, int JPOOL_ = GRX_JPOOL,
-          int NTOUCH_ = 0, int MAXCON_ = GRX_MAXCON, int TWOSPAN_ = 0>
+          int NTOUCH_ = 0, int MAXCON_ = GRX_MAXCON, int TWOSPAN_ = 0, int CONVEX_ = 0>
 struct GrxShape {
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_, ME = MAXEFC_, JP = JPOOL_, NT = NTOUCH_, MC = MAXCON_;
   // rows may carry a second dof span (models compiled with split pair spans); fixed shapes without it skip that bookkeeping
   static constexpr bool kTwoSpan = (NV_ == 0) || (TWOSPAN_ != 0);
   static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
+  static constexpr bool kConvex = (NV_ == 0) || (CONVEX_ != 0);   // carries the general convex (MPR) narrow phase: the generic kernels and the shapes of models that need it
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NVC (S::kFixed ? S::NV : m->nv)
@@ -1477,8 +1478,8 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           else if (t1 == 2 && t2 == 6) grx_sphere_box(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
           else if (t1 == 6 && t2 == 6) isbox = 1;
-          else if (!S::kFixed && t1 == 0 && t2 == 4) grx_plane_ellipsoid(m, c, p, g1, g2, margin);
-          else if (!S::kFixed && t1 >= 2 && t2 <= 6 && (t1 == 4 || t1 == 5 || t2 == 4 || t2 == 5)) grx_convex_pair(m, c, p, g1, g2, t1, t2, margin);   // generic kernels only
+          else if (S::kConvex && t1 == 0 && t2 == 4) grx_plane_ellipsoid(m, c, p, g1, g2, margin);
+          else if (S::kConvex && t1 >= 2 && t2 <= 6 && (t1 == 4 || t1 == 5 || t2 == 4 || t2 == 5)) grx_convex_pair(m, c, p, g1, g2, t1, t2, margin);
           else if (t1 == 0 && t2 == 7) {
             if (m->geom_meshnum[g2] <= 32) grx_plane_mesh_small(m, c, p, g1, g2, margin);
             else { int q = GRX_ATOMIC_ADD(&c->cnt[7], 1); if (q < 32) c->ired[q] = p; }

@@ -82,11 +82,12 @@ template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(cons
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && g.nconvex == 0;
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0));
 }
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchArm;    // FetchReach (arm only)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32, 0, 1> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
@@ -94,6 +95,8 @@ typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntO
 typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntUMaze;
 typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, 96, 512, 0, 16, 1> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 1> GrxShapeHandEgg;     // manipulate_egg.xml: the ellipsoid goes through the convex narrow phase
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 944, 92, 24, 1, 1> GrxShapeHandEggTouch;
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 944, 92, 24, 1> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
 template <class S>
@@ -192,7 +195,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
 
 // Shadow hand reach env.step() (or mj_forward + outputs when forward_only): one wavefront per world, same engine
 template <class S>
-__global__ void __launch_bounds__(64, (S::kFixed && S::JP < GRX_JPOOL) ? 3 : 2)
+__global__ void __launch_bounds__(64, (S::kFixed && S::JP <= 512) ? 3 : 2)   // third wave per SIMD only where the LDS footprint lets more than 8 worlds share a CU (HandReach); the object models sit at 8
 grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int w = grx_world_of_block(), lane_ = threadIdx.x;
@@ -360,6 +363,7 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   m->shape = 0;
   if (grx_shape_matches<GrxShapeFetchPick>(g)) { m->shape = 1; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPick>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   else if (grx_shape_matches<GrxShapeFetchObject>(g)) { m->shape = 2; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchObject>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  else if (grx_shape_matches<GrxShapeFetchPuck>(g)) { m->shape = 7; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPuck>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   else if (grx_shape_matches<GrxShapeFetchArm>(g)) { m->shape = 3; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchArm>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -369,6 +373,8 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   if (grx_shape_matches<GrxShapeHandReach>(g)) { m->shape = 4; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandReach>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   if (grx_shape_matches<GrxShapeHandBlockTouch>(g)) { m->shape = 6; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandBlockTouch>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  if (grx_shape_matches<GrxShapeHandEgg>(g)) { m->shape = 8; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandEgg>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  if (grx_shape_matches<GrxShapeHandEggTouch>(g)) { m->shape = 9; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandEggTouch>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   if (grx_shape_matches<GrxShapeHandBlock>(g)) { m->shape = 5; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
   for (int k = 0; k < GRX_MAX_MODELS && m->slot < 0; k++) if (!g_slot_used[k]) { g_slot_used[k] = 1; m->slot = k; }
   if (m->slot < 0) return fail("grx_model_create: all model descriptor slots are in use (destroy a model first)");
@@ -431,6 +437,7 @@ extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, co
     case 1: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchPick>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
     case 2: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchObject>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
     case 3: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchArm>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
+    case 7: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchPuck>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
     default: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words);
   }
   HIP_OK(hipGetLastError());
@@ -486,7 +493,9 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
   const dim3 grid(grx_grid_for(n_worlds)), block(64);
   const size_t lds_bytes = (size_t)m->words * 4;
-  if (m->shape == 6) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlockTouch>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  if (m->shape == 9) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandEggTouch>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  else if (m->shape == 8) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandEgg>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
+  else if (m->shape == 6) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlockTouch>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   else if (m->shape == 5) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlock>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   else if (m->shape == 4) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandReach>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
   else hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
