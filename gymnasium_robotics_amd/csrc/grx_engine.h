@@ -970,27 +970,33 @@ GRX_MEM void grx_geom_support(const float* R, const float* sz, int type, const f
   } else if (type == 6) { r[0] = grx_sgn1f(dl[0]) * sz[0]; r[1] = grx_sgn1f(dl[1]) * sz[1]; r[2] = grx_sgn1f(dl[2]) * sz[2]; }
   mulMatVec3f(out, R, r);
 }
-struct GrxMprPair { const float *R1, *R2; float s1[3], s2[3], c21[3], hm; int t1, t2; };
+struct GrxMprPair { float R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2; };   // the two frames are copied into registers: ~20 support evaluations each read them twice
 GRX_MEM void grx_mpr_support(const GrxMprPair* q, const float* d, GrxMprPt* o) {
   float nd[3] = {-d[0], -d[1], -d[2]}, b[3];
   grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
   grx_geom_support(q->R2, q->s2, q->t2, nd, b);
   for (int k = 0; k < 3; k++) { o->w[k] += d[k] * q->hm; o->v[k] = o->w[k] - (b[k] + q->c21[k] - d[k] * q->hm); }
 }
-GRX_MEM void grx_mpr_portal_dir(const GrxMprPt* P, float* dir) {
+// the portal is kept as four separate points (not an array): every access is to a named variable, so the 30 floats stay in registers
+GRX_MEM void grx_mpr_portal_dir(const GrxMprPt& P1, const GrxMprPt& P2, const GrxMprPt& P3, float* dir) {
   float a[3], b[3];
-  for (int k = 0; k < 3; k++) { a[k] = P[2].v[k] - P[1].v[k]; b[k] = P[3].v[k] - P[1].v[k]; }
+  for (int k = 0; k < 3; k++) { a[k] = P2.v[k] - P1.v[k]; b[k] = P3.v[k] - P1.v[k]; }
   cross3f(dir, a, b); grx_normalize3f(dir);
 }
-GRX_MEM int grx_mpr_reach_tolerance(const GrxMprPt* P, const GrxMprPt* v4, const float* dir, float tol) {
-  float d4 = dot3f(v4->v, dir), mn = fminf(d4 - dot3f(P[1].v, dir), fminf(d4 - dot3f(P[2].v, dir), d4 - dot3f(P[3].v, dir)));
+GRX_MEM int grx_mpr_reach_tolerance(const GrxMprPt& P1, const GrxMprPt& P2, const GrxMprPt& P3, const GrxMprPt& v4, const float* dir, float tol) {
+  float d4 = dot3f(v4.v, dir), mn = fminf(d4 - dot3f(P1.v, dir), fminf(d4 - dot3f(P2.v, dir), d4 - dot3f(P3.v, dir)));
   return grx_mpr_eq(mn, tol) || mn < tol;
 }
-GRX_MEM void grx_mpr_expand(GrxMprPt* P, const GrxMprPt* v4) {
+GRX_MEM void grx_mpr_set(GrxMprPt& dst, const GrxMprPt& src, int take) {
+  for (int k = 0; k < 3; k++) { dst.v[k] = take ? src.v[k] : dst.v[k]; dst.w[k] = take ? src.w[k] : dst.w[k]; }
+}
+GRX_MEM void grx_mpr_expand(const GrxMprPt& P0, GrxMprPt& P1, GrxMprPt& P2, GrxMprPt& P3, const GrxMprPt& v4) {
   float cr[3];
-  cross3f(cr, v4->v, P[0].v);
-  if (dot3f(P[1].v, cr) > 0.0f) { if (dot3f(P[2].v, cr) > 0.0f) P[1] = *v4; else P[3] = *v4; }
-  else { if (dot3f(P[3].v, cr) > 0.0f) P[2] = *v4; else P[1] = *v4; }
+  cross3f(cr, v4.v, P0.v);
+  const int s1 = dot3f(P1.v, cr) > 0.0f, s2 = dot3f(P2.v, cr) > 0.0f, s3 = dot3f(P3.v, cr) > 0.0f;
+  // s1: (s2 ? P1 : P3) <- v4;   !s1: (s3 ? P2 : P1) <- v4
+  const int to1 = (s1 && s2) || (!s1 && !s3), to2 = !s1 && s3, to3 = s1 && !s2;
+  grx_mpr_set(P1, v4, to1); grx_mpr_set(P2, v4, to2); grx_mpr_set(P3, v4, to3);
 }
 GRX_MEM float grx_mpr_seg_dist2(const float* a, const float* b, float* w) {
   float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, t = -dot3f(a, d), dd = dot3f(d, d);
@@ -1020,95 +1026,96 @@ GRX_MEM float grx_mpr_tri_dist2(const float* x0, const float* b, const float* cc
 }
 // 0 = penetration (depth, dir, pos, surface witnesses w1 on geom 1 / w2 on geom 2 -- all relative to the centre of geom 1), -1 = separated
 GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float* depth, float* dir, float* pos, float* w1, float* w2) {
-  GrxMprPt P[4], v4;
+  GrxMprPt P0, P1, P2, P3, v4;
   float d[3], a[3], b[3], dotv;
-  for (int k = 0; k < 3; k++) { P[0].w[k] = 0.0f; P[0].v[k] = -q->c21[k]; }
-  if (grx_mpr_eq(P[0].v[0], 0.0f) && grx_mpr_eq(P[0].v[1], 0.0f) && grx_mpr_eq(P[0].v[2], 0.0f)) P[0].v[0] += GRX_MPR_EPS * 10.0f;
-  for (int k = 0; k < 3; k++) d[k] = -P[0].v[k];
+  for (int k = 0; k < 3; k++) { P0.w[k] = 0.0f; P0.v[k] = -q->c21[k]; }
+  if (grx_mpr_eq(P0.v[0], 0.0f) && grx_mpr_eq(P0.v[1], 0.0f) && grx_mpr_eq(P0.v[2], 0.0f)) P0.v[0] += GRX_MPR_EPS * 10.0f;
+  for (int k = 0; k < 3; k++) d[k] = -P0.v[k];
   grx_normalize3f(d);
-  grx_mpr_support(q, d, &P[1]);
-  dotv = dot3f(P[1].v, d);
+  grx_mpr_support(q, d, &P1);
+  dotv = dot3f(P1.v, d);
   if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
-  cross3f(d, P[0].v, P[1].v);
+  cross3f(d, P0.v, P1.v);
   if (grx_mpr_zero(dot3f(d, d))) {
-    for (int k = 0; k < 3; k++) { w1[k] = P[1].w[k]; w2[k] = P[1].w[k] - P[1].v[k]; pos[k] = 0.5f * (w1[k] + w2[k]); }
-    if (grx_mpr_eq(P[1].v[0], 0.0f) && grx_mpr_eq(P[1].v[1], 0.0f) && grx_mpr_eq(P[1].v[2], 0.0f)) { *depth = 0.0f; dir[0] = dir[1] = dir[2] = 0.0f; return 0; }
-    dir[0] = P[1].v[0]; dir[1] = P[1].v[1]; dir[2] = P[1].v[2]; *depth = sqrtf(dot3f(dir, dir)); grx_normalize3f(dir);
+    for (int k = 0; k < 3; k++) { w1[k] = P1.w[k]; w2[k] = P1.w[k] - P1.v[k]; pos[k] = 0.5f * (w1[k] + w2[k]); }
+    if (grx_mpr_eq(P1.v[0], 0.0f) && grx_mpr_eq(P1.v[1], 0.0f) && grx_mpr_eq(P1.v[2], 0.0f)) { *depth = 0.0f; dir[0] = dir[1] = dir[2] = 0.0f; return 0; }
+    dir[0] = P1.v[0]; dir[1] = P1.v[1]; dir[2] = P1.v[2]; *depth = sqrtf(dot3f(dir, dir)); grx_normalize3f(dir);
     return 0;
   }
   grx_normalize3f(d);
-  grx_mpr_support(q, d, &P[2]);
-  dotv = dot3f(P[2].v, d);
+  grx_mpr_support(q, d, &P2);
+  dotv = dot3f(P2.v, d);
   if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
-  for (int k = 0; k < 3; k++) { a[k] = P[1].v[k] - P[0].v[k]; b[k] = P[2].v[k] - P[0].v[k]; }
+  for (int k = 0; k < 3; k++) { a[k] = P1.v[k] - P0.v[k]; b[k] = P2.v[k] - P0.v[k]; }
   cross3f(d, a, b); grx_normalize3f(d);
-  if (dot3f(d, P[0].v) > 0.0f) { GrxMprPt t = P[1]; P[1] = P[2]; P[2] = t; d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+  if (dot3f(d, P0.v) > 0.0f) { GrxMprPt t = P1; P1 = P2; P2 = t; d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
   for (int guard = 0;; guard++) {
     if (guard > 200) return -1;
-    grx_mpr_support(q, d, &P[3]);
-    dotv = dot3f(P[3].v, d);
+    grx_mpr_support(q, d, &P3);
+    dotv = dot3f(P3.v, d);
     if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
     int cont = 0;
-    cross3f(a, P[1].v, P[3].v); dotv = dot3f(a, P[0].v);
-    if (dotv < 0.0f && !grx_mpr_zero(dotv)) { P[2] = P[3]; cont = 1; }
+    cross3f(a, P1.v, P3.v); dotv = dot3f(a, P0.v);
+    if (dotv < 0.0f && !grx_mpr_zero(dotv)) { P2 = P3; cont = 1; }
     if (!cont) {
-      cross3f(a, P[3].v, P[2].v); dotv = dot3f(a, P[0].v);
-      if (dotv < 0.0f && !grx_mpr_zero(dotv)) { P[1] = P[3]; cont = 1; }
+      cross3f(a, P3.v, P2.v); dotv = dot3f(a, P0.v);
+      if (dotv < 0.0f && !grx_mpr_zero(dotv)) { P1 = P3; cont = 1; }
     }
     if (!cont) break;
-    for (int k = 0; k < 3; k++) { a[k] = P[1].v[k] - P[0].v[k]; b[k] = P[2].v[k] - P[0].v[k]; }
+    for (int k = 0; k < 3; k++) { a[k] = P1.v[k] - P0.v[k]; b[k] = P2.v[k] - P0.v[k]; }
     cross3f(d, a, b); grx_normalize3f(d);
   }
   for (int guard = 0;; guard++) {
     if (guard > 200) return -1;
-    grx_mpr_portal_dir(P, d);
-    dotv = dot3f(d, P[1].v);
+    grx_mpr_portal_dir(P1, P2, P3, d);
+    dotv = dot3f(d, P1.v);
     if (grx_mpr_zero(dotv) || dotv > 0.0f) break;
     grx_mpr_support(q, d, &v4);
     dotv = dot3f(v4.v, d);
-    if (!(grx_mpr_zero(dotv) || dotv > 0.0f) || grx_mpr_reach_tolerance(P, &v4, d, tol)) return -1;
-    grx_mpr_expand(P, &v4);
+    if (!(grx_mpr_zero(dotv) || dotv > 0.0f) || grx_mpr_reach_tolerance(P1, P2, P3, v4, d, tol)) return -1;
+    grx_mpr_expand(P0, P1, P2, P3, v4);
   }
   for (int it = 0;; it++) {
-    grx_mpr_portal_dir(P, d);
+    grx_mpr_portal_dir(P1, P2, P3, d);
     grx_mpr_support(q, d, &v4);
-    if (grx_mpr_reach_tolerance(P, &v4, d, tol) || it > maxit) {
+    if (grx_mpr_reach_tolerance(P1, P2, P3, v4, d, tol) || it > maxit) {
       float w[3];
-      *depth = sqrtf(grx_mpr_tri_dist2(P[1].v, P[2].v, P[3].v, w));
+      *depth = sqrtf(grx_mpr_tri_dist2(P1.v, P2.v, P3.v, w));
       if (grx_mpr_zero(w[0]) && grx_mpr_zero(w[1]) && grx_mpr_zero(w[2])) { w[0] = d[0]; w[1] = d[1]; w[2] = d[2]; }
       grx_normalize3f(w); dir[0] = w[0]; dir[1] = w[1]; dir[2] = w[2];
       float bc[4], cr[3], sum;
-      cross3f(cr, P[1].v, P[2].v); bc[0] = dot3f(cr, P[3].v);
-      cross3f(cr, P[3].v, P[2].v); bc[1] = dot3f(cr, P[0].v);
-      cross3f(cr, P[0].v, P[1].v); bc[2] = dot3f(cr, P[3].v);
-      cross3f(cr, P[2].v, P[1].v); bc[3] = dot3f(cr, P[0].v);
+      cross3f(cr, P1.v, P2.v); bc[0] = dot3f(cr, P3.v);
+      cross3f(cr, P3.v, P2.v); bc[1] = dot3f(cr, P0.v);
+      cross3f(cr, P0.v, P1.v); bc[2] = dot3f(cr, P3.v);
+      cross3f(cr, P2.v, P1.v); bc[3] = dot3f(cr, P0.v);
       sum = bc[0] + bc[1] + bc[2] + bc[3];
       if (grx_mpr_zero(sum) || sum < 0.0f) {
         bc[0] = 0.0f;
-        cross3f(cr, P[2].v, P[3].v); bc[1] = dot3f(cr, d);
-        cross3f(cr, P[3].v, P[1].v); bc[2] = dot3f(cr, d);
-        cross3f(cr, P[1].v, P[2].v); bc[3] = dot3f(cr, d);
+        cross3f(cr, P2.v, P3.v); bc[1] = dot3f(cr, d);
+        cross3f(cr, P3.v, P1.v); bc[2] = dot3f(cr, d);
+        cross3f(cr, P1.v, P2.v); bc[3] = dot3f(cr, d);
         sum = bc[1] + bc[2] + bc[3];
       }
       // witness on geom 2 = w - v (+ the centre offset, which cancels in the relative frame except for P0: its witnesses are the two centres)
       const float is = 1.0f / sum;
       for (int k = 0; k < 3; k++) {
         float p1 = 0.0f, p2 = bc[0] * q->c21[k];
-        for (int i = 1; i < 4; i++) { p1 += bc[i] * P[i].w[k]; p2 += bc[i] * (P[i].w[k] - P[i].v[k]); }
+        p1 += bc[1] * P1.w[k] + bc[2] * P2.w[k] + bc[3] * P3.w[k];
+        p2 += bc[1] * (P1.w[k] - P1.v[k]) + bc[2] * (P2.w[k] - P2.v[k]) + bc[3] * (P3.w[k] - P3.v[k]);
         pos[k] = 0.5f * (p1 + p2) * is;
       }
       // surface witnesses: the foot of the origin on the portal plane in barycentric coordinates of the triangle alone
-      cross3f(cr, P[2].v, P[3].v); bc[1] = dot3f(cr, d);
-      cross3f(cr, P[3].v, P[1].v); bc[2] = dot3f(cr, d);
-      cross3f(cr, P[1].v, P[2].v); bc[3] = dot3f(cr, d);
+      cross3f(cr, P2.v, P3.v); bc[1] = dot3f(cr, d);
+      cross3f(cr, P3.v, P1.v); bc[2] = dot3f(cr, d);
+      cross3f(cr, P1.v, P2.v); bc[3] = dot3f(cr, d);
       const float it3 = 1.0f / (bc[1] + bc[2] + bc[3]);
       for (int k = 0; k < 3; k++) {
-        w1[k] = (bc[1] * P[1].w[k] + bc[2] * P[2].w[k] + bc[3] * P[3].w[k]) * it3;
-        w2[k] = (bc[1] * (P[1].w[k] - P[1].v[k]) + bc[2] * (P[2].w[k] - P[2].v[k]) + bc[3] * (P[3].w[k] - P[3].v[k])) * it3;
+        w1[k] = (bc[1] * P1.w[k] + bc[2] * P2.w[k] + bc[3] * P3.w[k]) * it3;
+        w2[k] = (bc[1] * (P1.w[k] - P1.v[k]) + bc[2] * (P2.w[k] - P2.v[k]) + bc[3] * (P3.w[k] - P3.v[k])) * it3;
       }
       return 0;
     }
-    grx_mpr_expand(P, &v4);
+    grx_mpr_expand(P0, P1, P2, P3, v4);
   }
 }
 // analytic outward normal of a smooth geom (sphere, capsule, ellipsoid) at the world point p (see the oracle: the portal direction of a
@@ -1129,7 +1136,8 @@ GRX_MEM int grx_smooth_normal(const float* R, const float* ce, const float* sz, 
 }
 GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, int t1, int t2, float margin) {
   GrxMprPair q;
-  q.R1 = c->gxmat + 9 * g1; q.R2 = c->gxmat + 9 * g2; q.t1 = t1; q.t2 = t2; q.hm = 0.5f * margin;
+  for (int k = 0; k < 9; k++) { q.R1[k] = c->gxmat[9 * g1 + k]; q.R2[k] = c->gxmat[9 * g2 + k]; }
+  q.t1 = t1; q.t2 = t2; q.hm = 0.5f * margin;
   for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = c->gxpos[3 * g2 + k] - c->gxpos[3 * g1 + k]; }
   float depth, dir[3], pos[3], w1[3], w2[3];
   if (grx_mpr_penetration(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;

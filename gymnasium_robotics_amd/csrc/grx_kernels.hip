@@ -100,7 +100,7 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 944, 92, 24, 1, 1> Gr
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 944, 92, 24, 1> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
 template <class S>
-__global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
+__global__ void __launch_bounds__(64, (S::kFixed && !S::kConvex) ? 3 : 2)   // the convex narrow phase needs the full VGPR budget (41 spills at 168)
 grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int w = grx_world_of_block(), lane_ = threadIdx.x;
