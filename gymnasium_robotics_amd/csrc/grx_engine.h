@@ -1159,6 +1159,43 @@ GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int
   }
   grx_add_contact(c, pair, pos, dir, margin - depth);
 }
+// plane vs cylinder: near-cap rim point, far-cap rim point, two more corners of a triangle inscribed in the near rim (see the oracle)
+GRX_MEM void grx_plane_cylinder(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  const float* pm = c->gxmat + 9 * g1; const float* cm = c->gxmat + 9 * g2; const float* cp = c->gxpos + 3 * g2;
+  const float r = m->geom_size[3 * g2], hl = m->geom_size[3 * g2 + 1];
+  float n[3] = {pm[2], pm[5], pm[8]}, ax[3] = {cm[2], cm[5], cm[8]};
+  float prjaxis = dot3f(n, ax);
+  if (prjaxis > 0.0f) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; prjaxis = -prjaxis; }
+  float dd[3] = {cp[0] - c->gxpos[3 * g1], cp[1] - c->gxpos[3 * g1 + 1], cp[2] - c->gxpos[3 * g1 + 2]};
+  const float dist0 = dot3f(dd, n);
+  float vec[3] = {ax[0] * prjaxis - n[0], ax[1] * prjaxis - n[1], ax[2] * prjaxis - n[2]};
+  const float len2 = dot3f(vec, vec);
+  if (len2 >= 1e-30f) { const float sc = r / sqrtf(len2); vec[0] *= sc; vec[1] *= sc; vec[2] *= sc; }
+  else { vec[0] = cm[0] * r; vec[1] = cm[3] * r; vec[2] = cm[6] * r; }
+  const float prjvec = dot3f(vec, n);
+  ax[0] *= hl; ax[1] *= hl; ax[2] *= hl; prjaxis *= hl;
+  float dist = dist0 + prjaxis + prjvec, pos[3];
+  if (dist > margin) return;
+  for (int k = 0; k < 3; k++) pos[k] = cp[k] + vec[k] + ax[k] - n[k] * dist * 0.5f;
+  grx_add_contact(c, pair, pos, n, dist);
+  dist = dist0 - prjaxis + prjvec;
+  if (dist <= margin) {
+    for (int k = 0; k < 3; k++) pos[k] = cp[k] + vec[k] - ax[k] - n[k] * dist * 0.5f;
+    grx_add_contact(c, pair, pos, n, dist);
+  }
+  dist = dist0 + prjaxis - 0.5f * prjvec;
+  if (dist <= margin) {
+    float v1[3];
+    cross3f(v1, vec, ax);
+    const float l2 = dot3f(v1, v1);
+    if (l2 > 0.0f) { const float sc = r * 0.8660254f / sqrtf(l2); v1[0] *= sc; v1[1] *= sc; v1[2] *= sc; }
+    for (int sg = 0; sg < 2; sg++) {
+      const float sgn = sg ? -1.0f : 1.0f;
+      for (int k = 0; k < 3; k++) pos[k] = cp[k] + sgn * v1[k] + ax[k] - 0.5f * vec[k] - n[k] * dist * 0.5f;
+      grx_add_contact(c, pair, pos, n, dist);
+    }
+  }
+}
 GRX_MEM void grx_plane_ellipsoid(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
   float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}, nd[3] = {-n[0], -n[1], -n[2]}, p[3];
   const float sz[3] = {m->geom_size[3 * g2], m->geom_size[3 * g2 + 1], m->geom_size[3 * g2 + 2]};
@@ -1487,6 +1524,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           else if (t1 == 0 && t2 == 6) grx_plane_box(m, c, p, g1, g2, margin);
           else if (t1 == 6 && t2 == 6) isbox = 1;
           else if (S::kConvex && t1 == 0 && t2 == 4) grx_plane_ellipsoid(m, c, p, g1, g2, margin);
+          else if (S::kConvex && t1 == 0 && t2 == 5) grx_plane_cylinder(m, c, p, g1, g2, margin);
           else if (S::kConvex && t1 >= 2 && t2 <= 6 && (t1 == 4 || t1 == 5 || t2 == 4 || t2 == 5)) grx_convex_pair(m, c, p, g1, g2, t1, t2, margin);
           else if (t1 == 0 && t2 == 7) {
             if (m->geom_meshnum[g2] <= 32) grx_plane_mesh_small(m, c, p, g1, g2, margin);

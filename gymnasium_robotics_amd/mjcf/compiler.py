@@ -1078,7 +1078,7 @@ class _Lowering:
         weldparent = [weld[B[weld[i]].parent] if weld[i] > 0 else 0 for i in range(nb)]
         # narrow-phase routines implemented by BOTH the device engine and the oracle
         supported = {(GEOM_PLANE, GEOM_BOX), (GEOM_PLANE, GEOM_MESH), (GEOM_BOX, GEOM_BOX), (GEOM_PLANE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_BOX),
-                     (GEOM_PLANE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_ELLIPSOID)}
+                     (GEOM_PLANE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_ELLIPSOID), (GEOM_PLANE, GEOM_CYLINDER)}
         # general convex narrow phase (MPR, one contact): every pair of primitives that involves an ellipsoid or a cylinder
         prim = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX)
         supported |= {(ta, tb) for ta in prim for tb in prim if ta <= tb and (GEOM_ELLIPSOID in (ta, tb) or GEOM_CYLINDER in (ta, tb))}

@@ -978,6 +978,46 @@ static void collide_convex(orc_sim* s, int pair, int g1, int g2, double margin) 
   }
   add_contact(s, pair, pos, dir, margin - depth);
 }
+/* plane vs cylinder (MuJoCo's analytic routine [3P], restated from its description): the rim point of the near cap closest to
+ * the plane; the corresponding rim point of the far cap; and, when the near cap is close to parallel, the two other corners of an
+ * equilateral triangle inscribed in its rim -- up to four contacts, all with the plane normal. */
+static void collide_plane_cylinder(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* pm = s->geom_xmat + 9 * g1; const double* cm = s->geom_xmat + 9 * g2; const double* cp = s->geom_xpos + 3 * g2;
+  const double r = m->geom_size[3 * g2], hl = m->geom_size[3 * g2 + 1];
+  double n[3] = {pm[2], pm[5], pm[8]}, ax[3] = {cm[2], cm[5], cm[8]};
+  double prjaxis = dot3(n, ax);
+  if (prjaxis > 0) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; prjaxis = -prjaxis; }
+  double dd[3] = {cp[0] - s->geom_xpos[3 * g1], cp[1] - s->geom_xpos[3 * g1 + 1], cp[2] - s->geom_xpos[3 * g1 + 2]};
+  const double dist0 = dot3(dd, n);
+  double vec[3] = {ax[0] * prjaxis - n[0], ax[1] * prjaxis - n[1], ax[2] * prjaxis - n[2]};
+  double len2 = dot3(vec, vec);
+  if (len2 >= MINVAL * MINVAL) { double sc = r / sqrt(len2); vec[0] *= sc; vec[1] *= sc; vec[2] *= sc; }
+  else { vec[0] = cm[0] * r; vec[1] = cm[3] * r; vec[2] = cm[6] * r; }          /* cap parallel to the plane: the cylinder's x axis */
+  const double prjvec = dot3(vec, n);
+  ax[0] *= hl; ax[1] *= hl; ax[2] *= hl; prjaxis *= hl;
+  double dist = dist0 + prjaxis + prjvec, pos[3];
+  if (dist > margin) return;
+  for (int k = 0; k < 3; k++) pos[k] = cp[k] + vec[k] + ax[k] - n[k] * dist * 0.5;
+  add_contact(s, pair, pos, n, dist);
+  dist = dist0 - prjaxis + prjvec;
+  if (dist <= margin) {
+    for (int k = 0; k < 3; k++) pos[k] = cp[k] + vec[k] - ax[k] - n[k] * dist * 0.5;
+    add_contact(s, pair, pos, n, dist);
+  }
+  const double prjvec1 = -0.5 * prjvec;
+  dist = dist0 + prjaxis + prjvec1;
+  if (dist <= margin) {
+    double v1[3];
+    cross3(v1, vec, ax);
+    double l = norm3(v1);
+    if (l > 0) { double sc = r * sqrt(3.0) * 0.5 / l; v1[0] *= sc; v1[1] *= sc; v1[2] *= sc; }
+    for (int sgn = 1; sgn >= -1; sgn -= 2) {
+      for (int k = 0; k < 3; k++) pos[k] = cp[k] + sgn * v1[k] + ax[k] - 0.5 * vec[k] - n[k] * dist * 0.5;
+      add_contact(s, pair, pos, n, dist);
+    }
+  }
+}
 /* plane vs ellipsoid: the deepest point of the ellipsoid (MuJoCo's analytic plane routine: one contact) */
 static void collide_plane_ellipsoid(orc_sim* s, int pair, int g1, int g2, double margin) {
   const grx_model_view* m = &s->m;
@@ -1017,6 +1057,7 @@ static void collision(orc_sim* s) {
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_MESH) collide_plane_mesh(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_BOX && t2 == GRX_GEOM_BOX) collide_box_box(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_ELLIPSOID) collide_plane_ellipsoid(s, p, g1, g2, margin);
+    else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_CYLINDER) collide_plane_cylinder(s, p, g1, g2, margin);
     else if (t1 >= GRX_GEOM_SPHERE && t2 <= GRX_GEOM_BOX && (t1 == GRX_GEOM_ELLIPSOID || t1 == GRX_GEOM_CYLINDER || t2 == GRX_GEOM_ELLIPSOID || t2 == GRX_GEOM_CYLINDER))
       collide_convex(s, p, g1, g2, margin);
     else s->unsupported_hits++;

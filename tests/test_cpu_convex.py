@@ -50,6 +50,25 @@ def test_oracle_convex_known_answers(tmp_path):
     assert r.shape[0] == 1 and abs(r[0, 0] - (0.03 - hz)) < 1e-9 and np.abs(r[0, 4:7] - [0, 0, 1]).max() < 1e-12
 
 
+def test_oracle_plane_cylinder(tmp_path):
+    # upright cylinder 2 mm into the plane: the near rim point + two more corners of the inscribed triangle, all at the cap's depth
+    r = _contacts(tmp_path, 'type="plane" size="1 1 1"', 'type="cylinder" size="0.025 0.02"', "0.3 0.1 0.018")
+    assert r.shape[0] == 3 and np.abs(r[:, 0] + 0.002).max() < 1e-12 and np.abs(r[:, 4:7] - [0, 0, 1]).max() < 1e-12
+    rim = np.hypot(r[:, 1] - 0.3, r[:, 2] - 0.1)
+    assert np.abs(rim - 0.025).max() < 1e-9 and np.abs(r[:, 3] - (-0.001)).max() < 1e-12
+    cen = r[:, 1:3].mean(axis=0)
+    assert np.abs(cen - [0.3, 0.1]).max() < 1e-9                                   # equilateral: the three points balance the cap
+    # lying on its side (axis along y), 1 mm deep: the two end points of the lowest generator
+    r = _contacts(tmp_path, 'type="plane" size="1 1 1"', 'type="cylinder" size="0.025 0.02"', "0 0 0.024", "0.7071068 0.7071068 0 0")
+    assert r.shape[0] == 2 and np.abs(r[:, 0] + 0.001).max() < 1e-6 and np.abs(np.sort(r[:, 2]) - [-0.02, 0.02]).max() < 1e-6
+    # tilted 30 degrees: one rim point, the deepest one
+    r = _contacts(tmp_path, 'type="plane" size="1 1 1"', 'type="cylinder" size="0.025 0.02"', "0 0 0.029", "0.9659258 0.258819 0 0")
+    lowest = 0.029 - (0.025 * np.sin(np.pi / 6) + 0.02 * np.cos(np.pi / 6))
+    assert r.shape[0] == 1 and abs(r[0, 0] - lowest) < 1e-6
+    # above the margin: nothing
+    assert _contacts(tmp_path, 'type="plane" size="1 1 1"', 'type="cylinder" size="0.025 0.02"', "0 0 0.03").shape[0] == 0
+
+
 def test_oracle_smooth_pair_depth_is_the_extent_along_the_normal(tmp_path):
     """Random egg-capsule poses: dist == centre distance along n - extents along n, and n is the average analytic normal at pos."""
     rng = np.random.default_rng(0)

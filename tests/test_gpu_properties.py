@@ -91,3 +91,49 @@ def test_ant_maze_8192_worlds():
     half = 0.5 * 4.0 * np.array([env.maze.map_width, env.maze.map_length])       # the ant stays inside the walled maze
     assert (np.abs(q[:, :2]) < half[None, :] + 1.0).all()
     env.close()
+
+
+def test_fetch_slide_4096_worlds_puck_slides_and_stays_on_the_table():
+    """Free-running FetchSlide: the cylinder puck (convex narrow phase, one contact) neither sinks nor pops, keeps a unit quaternion, and
+    moves when the gripper sweeps through it."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    env = grx.make_vec("FetchSlide-v4", num_envs=4096, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
+    obs, _ = env.reset(seed=0)
+    p0 = env.qpos[:, -7:-4].clone()
+    g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+    flagged = 0
+    for t in range(40):
+        a = torch.rand(4096, 4, device="cuda:0", generator=g) * 2 - 1
+        a[:, 2] = -1.0 if t < 6 else 0.0                      # lower the gripper to puck height, then sweep randomly in the plane
+        obs, r, _, _, info = env.step(a)
+        flagged += int((env.status != 0).sum())
+    q, v = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert np.abs(np.linalg.norm(q[:, -4:], axis=1) - 1).max() < 1e-5
+    z = q[:, -5]
+    on_table = z > 0.405                                      # friction 0.1: pucks that were hit hard slide off the 1.25 m x 0.9 m table
+    assert on_table.mean() > 0.85 and z[on_table].max() < 0.4225 and z.min() > 0.0, (float(on_table.mean()), float(z.max()), float(z.min()))   # resting height 0.42 minus the soft single-contact penetration; nothing pops up or tunnels
+    moved = np.linalg.norm(q[:, -7:-5] - p0[:, :2].cpu().numpy(), axis=1)
+    assert (moved > 0.02).mean() > 0.05 and (moved < 5e-3).mean() > 0.2          # some pucks were hit and slid; untouched ones stay put up to the ~2 mm creep of the rocking single-contact support (DESIGN.md section 7)
+    assert flagged <= 0.002 * 4096 * 40
+    assert bool((env.compute_reward(obs["achieved_goal"], obs["desired_goal"], None) == r).all())
+    env.close()
+
+
+def test_hand_egg_16384_worlds():
+    import gymnasium_robotics_amd as grx
+
+    env = grx.make_vec("HandManipulateEgg_ContinuousTouchSensors-v1", num_envs=16384, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
+    obs, r, info, flagged = _rollout(env, 12, 20)
+    o, q = obs["observation"].cpu().numpy(), env.qpos.cpu().numpy()
+    assert o.shape == (16384, 153) and np.isfinite(o).all()
+    assert np.abs(np.linalg.norm(q[:, 27:31], axis=1) - 1).max() < 1e-5
+    touch = o[:, 61:]
+    assert touch.min() >= 0 and touch.max() < 200 and (touch > 0).any(axis=1).mean() > 0.5
+    assert _soft_limits_ok(env, q, 0.01)
+    assert flagged <= 0.001 * 16384 * 12
+    assert bool((env.compute_reward(obs["achieved_goal"], obs["desired_goal"], None) == r).all())
+    env.close()
