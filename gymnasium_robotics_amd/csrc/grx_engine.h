@@ -381,6 +381,9 @@ struct GrxShape {
   // rows may carry a second dof span (models compiled with split pair spans); fixed shapes without it skip that bookkeeping
   static constexpr bool kTwoSpan = (NV_ == 0) || (TWOSPAN_ != 0);
   static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
+  // incremental Hessian corrections between Newton iterations (grx_hessian_update): compiled into the kernels of models with a free
+  // object in contact (several iterations per substep are common there); articulated-only models and the RK4 ant converge in one
+  static constexpr bool kIncrHess = (NV_ == 0) || (NQ_ != NV_ && INTEG_ == 0);
   static constexpr bool kConvex = (NV_ == 0) || (CONVEX_ != 0);   // carries the general convex (MPR) narrow phase: the generic kernels and the shapes of models that need it
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
@@ -685,6 +688,15 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
   if (n == 15) { grx_sym_solve_reg<15>(A, x, lane_); return 0; }
   if (n == 24) { grx_sym_solve_reg<24>(A, x, lane_); return 0; }
   if (n == 30) { grx_sym_solve_reg<30>(A, x, lane_); return 0; }
+#endif
+#if defined(GRX_EMU)
+  if (n == 21 || n == 14 || n == 15 || n == 24 || n == 30) {   // mirror the device: these sizes are solved without touching A
+    static float copy[30 * 30];
+    for (int i = 0; i < n * n; i++) copy[i] = A[i];
+    int bad_ = grx_sym_factor(copy, n, lane_);
+    grx_sym_solve(copy, n, x, lane_);
+    return bad_;
+  }
 #endif
   int bad = grx_sym_factor(A, n, lane_);
   grx_sym_solve(A, n, x, lane_);
@@ -1941,7 +1953,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
 // ------------------------------------------------------------------------------------------
 // Ma = M a ; jar = J a - aref ; force / active flags ; returns total cost if want_cost
 // Row states: 0 = inactive (satisfied inequality), 1 = quadratic, 2 / 3 = friction-loss row saturated at -f / +f.
-// Returns 1 if any row changed state with respect to the previous evaluation (stored in efc_quad), else 0.
+// Returns 1 if any row changed state with respect to the previous evaluation (bits 0-1 of efc_quad), else 0.
 GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int nefc, int lane_) {
   const int nv = GRX_NVC;
   GRX_LANEVAR(chgp);
@@ -1964,8 +1976,9 @@ GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int ne
       } else {
         if (x < 0) { f = -D * x; st = 1; } else { f = 0; st = 0; }
       }
-      if (st != c->efc_quad[r]) chg = 1.0f;
-      c->efc_jar[r] = x; c->efc_force[r] = f; c->efc_quad[r] = st;
+      const int old = c->efc_quad[r];
+      if (st != (old & 3)) chg = 1.0f;
+      c->efc_jar[r] = x; c->efc_force[r] = f; c->efc_quad[r] = (old & 0x30) | st;   // bits 4-5: the state this row has in the assembled Hessian
     }
     LV(chgp) = chg;
   }
@@ -1999,7 +2012,13 @@ GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, f
 GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   const int nv = GRX_NVC;
     // Hessian H = M + J' diag(D_active) J
-  FOR_LANES { for (int r = lane; r < nefc; r += 64) c->efc_jv[r] = (c->efc_quad[r] == 1) ? c->efc_D[r] : 0.0f; }  // efc_jv reused as scratch
+  FOR_LANES {
+    for (int r = lane; r < nefc; r += 64) {
+      const int st = c->efc_quad[r] & 3;
+      c->efc_jv[r] = (st == 1) ? c->efc_D[r] : 0.0f;   // efc_jv reused as scratch
+      c->efc_quad[r] = st | (st << 4);                  // the Hessian now represents this row in state st (grx_hessian_update)
+    }
+  }
   WAVE_SYNC();
 #if !defined(GRX_EMU)
   if (nv < 32) {
@@ -2084,6 +2103,52 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   }
 }
 
+// Incremental Hessian.  A row contributes to the problem through (d, k): force = -d (J a) + k, with (D, D aref) in the quadratic
+// state, (0, -+floss) for a saturated friction-loss row and (0, 0) when inactive; H = M + sum d J'J and g0 = sum k J, so that
+// J'f = -(H - M) a + g0 and the gradient is H a - qfrc_smooth - g0.  Between two Newton iterations of one substep only the rows whose
+// state flipped change (d, k): apply their rank-1 corrections to A and g0 instead of re-assembling H over all rows (one flip is the
+// common case; the iterations after the first are what separates an expensive world from a cheap one).  Returns 0 when more than
+// GRX_HUPD_MAX rows flipped (the caller re-assembles).  Uses c->ired (row list) and c->Mv (the row, expanded) as scratch.
+#define GRX_HUPD_MAX 8
+GRX_MEM int grx_hessian_update(const GrxModel* m, GrxCtx* c, int nefc, float* g0, int lane_) {
+  const int nv = GRX_NVC;
+  int* list = c->ired;
+  int nd = 0;
+  for (int base = 0; base < nefc; base += 64) {
+    GRX_LANEVAR_I(dirty);
+    FOR_LANES { const int r = base + lane; const int q = r < nefc ? c->efc_quad[r] : 0; LV(dirty) = (r < nefc) && ((q & 3) != ((q >> 4) & 3)); }
+    const unsigned long long bm = GRX_BALLOT(dirty);
+    FOR_LANES { if (LV(dirty)) { const int k = nd + __builtin_popcountll(bm & ((1ull << lane) - 1ull)); if (k < GRX_HUPD_MAX) list[k] = base + lane; } }
+    nd += __builtin_popcountll(bm);
+  }
+  WAVE_SYNC();
+  if (nd > GRX_HUPD_MAX) return 0;
+  for (int e = 0; e < nd; e++) {
+    const int r = list[e];
+    const int q = c->efc_quad[r], st = q & 3, hs = (q >> 4) & 3, info = c->efc_row[r], idb = S::kTwoSpan ? c->efc_id[r] : 0;
+    const float D = c->efc_D[r], kq = D * c->efc_aref[r];
+    const float fl = (st >= 2 || hs >= 2) ? c->efc_floss[r] : 0.0f;
+    const float dd = (st == 1 ? D : 0.0f) - (hs == 1 ? D : 0.0f);
+    const float dk = (st == 1 ? kq : (st == 2 ? -fl : (st == 3 ? fl : 0.0f))) - (hs == 1 ? kq : (hs == 2 ? -fl : (hs == 3 ? fl : 0.0f)));
+    FOR_LANES { for (int i = lane; i < nv; i += 64) { const int pos = grx_row_pos(info, idb, i); c->Mv[i] = pos >= 0 ? c->Jp[GRX_ROW_OFF(info) + pos] : 0.0f; } }
+    WAVE_SYNC();
+    FOR_LANES {
+      for (int i = lane; i < nv; i += 64) {
+        const float vi = c->Mv[i];
+        if (vi != 0.0f) {
+          const float s_ = dd * vi;
+          for (int j = 0; j < nv; j++) c->A[i * nv + j] += s_ * c->Mv[j];
+          g0[i] += dk * vi;
+        }
+      }
+    }
+    WAVE_SYNC();
+    LANE0 { c->efc_quad[r] = st | (st << 4); }
+  }
+  WAVE_SYNC();
+  return 1;
+}
+
 // Constraint solve (Newton) + optional semi-implicit Euler step as ONE state machine, so that the three heavy
 // primitives -- row evaluation, Hessian assembly and the register-resident linear solve -- each have a single call site
 // in the kernel: the fused 20-substep loop has to stay inside the instruction cache.
@@ -2096,7 +2161,9 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const int nefc = c->cnt[1];
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   const int implicit_damp = (m->anydamp && m->eulerdamp);
-  int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0;
+  int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0, g0_ready = 0;
+  // the linear solve leaves c->A intact where it runs from registers (grx_sym_solve_full): the Hessian can then be corrected in place
+  const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 30);
   // Newton starts from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart,
   // M^-1 qfrc_smooth); the minimiser of the strictly convex problem does not depend on the start, and skipping the
   // comparison saves one factorisation of M per substep.
@@ -2121,18 +2188,59 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         phase = 1;
         continue;
       }
-      // Hessian of the current active set and J'f of the current row forces, in one pass over the rows
-      grx_hessian(m, c, nefc, lane_);
-      GRX_TICK(c, GRX_P_NHESS);
-      // gradient = M a - qfrc_smooth - J' f
-      GRX_LANEVAR(gnp);
-      FOR_LANES {
-        float part = 0;
-        for (int i = lane; i < nv; i += 64) {
-          float sacc = c->Ma[i] - c->qfrc_smooth[i] - c->grad[i];
-          c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc;
+      // Hessian of the current active set.  First iteration of a substep: assembled over all rows together with J'f of the current
+      // row forces (one pass).  Later iterations: rank-1 corrections for the rows that flipped (grx_hessian_update); g0 = sum k J
+      // is formed on first use from the J'f of the assembly, which was taken at the acceleration a_h: g0 = J'f + (H - M) a_h.
+      int incremental = 0;
+      if (it > 0 && keepA) {
+        if (!g0_ready) {
+          const float* ah = c->qacc_ws;   // the last assembly was the one of iteration 0, at the warm start (qacc_ws is not written before convergence)
+          FOR_LANES {
+            for (int i = lane; i < nv; i += 64) {
+              float sacc = c->tmpv[i];
+#pragma unroll 8
+              for (int j = 0; j < nv; j++) sacc += (c->A[i * nv + j] - c->M[i * nv + j]) * ah[j];
+              c->tmpv[i] = sacc;
+            }
+          }
+          WAVE_SYNC();
+          g0_ready = 1;
         }
-        LV(gnp) = part;
+        incremental = grx_hessian_update(m, c, nefc, c->tmpv, lane_);
+      }
+      if (!incremental) grx_hessian(m, c, nefc, lane_);
+      GRX_TICK(c, GRX_P_NHESS);
+      GRX_LANEVAR(gnp);
+      if (incremental) {
+        // gradient = H a - qfrc_smooth - g0
+        FOR_LANES {
+          float part = 0;
+          for (int i = lane; i < nv; i += 64) {
+            float sacc = -c->qfrc_smooth[i] - c->tmpv[i];
+#pragma unroll 8
+            for (int j = 0; j < nv; j++) sacc += c->A[i * nv + j] * c->qacc[j];
+            c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc;
+          }
+          LV(gnp) = part;
+        }
+      } else {
+        // gradient = M a - qfrc_smooth - J' f ; keep J'f (and, after a re-assembly at a later iterate, turn it into g0 right away)
+        FOR_LANES {
+          float part = 0;
+          for (int i = lane; i < nv; i += 64) {
+            const float jf = c->grad[i];
+            float sacc = c->Ma[i] - c->qfrc_smooth[i] - jf;
+            float g0i = jf;
+            if (it > 0 && keepA) {
+#pragma unroll 8
+              for (int j = 0; j < nv; j++) g0i += (c->A[i * nv + j] - c->M[i * nv + j]) * c->qacc[j];
+            }
+            c->tmpv[i] = g0i;
+            c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc;
+          }
+          LV(gnp) = part;
+        }
+        g0_ready = (it > 0);
       }
       WAVE_SYNC();
       float gn = sqrtf(grx_reduce_sum(gnp));

@@ -58,6 +58,9 @@ __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetc
 __device__ long long g_grx_prof[GRX_NPROF];
 extern "C" int grx_profile_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grx_prof), sizeof(long long) * GRX_NPROF); }
 extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grx_prof), z, sizeof(z)); }
+// per-world start / end timestamps of the last Fetch step launch (wall_clock64: one clock for the whole device): load balance across worlds
+__device__ long long g_grx_world_span[2 * 16384];
+extern "C" int grx_profile_world_spans(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grx_world_span), sizeof(long long) * 2 * n); }
 #endif
 
 // World <-> workgroup mapping.  The dispatcher deals workgroups round-robin to the 8 XCDs, each with its own L2, so with w = blockIdx.x
@@ -68,6 +71,7 @@ static inline unsigned grx_grid_for(int n_worlds) { return (unsigned)((n_worlds 
 static __device__ __forceinline__ int grx_world_of_block() { return (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); }
 // the same index re-derived after the substep loop from the (architected) workgroup id: the epilogue's addresses are then computed
 // there instead of being kept -- as 64-bit VGPR pairs spilled to scratch -- across the whole simulation
+static __device__ __forceinline__ unsigned grx_block_late() { unsigned bx = blockIdx.x; asm volatile("" : "+s"(bx)); return bx; }
 static __device__ __forceinline__ int grx_world_of_block_late() {
   unsigned bx = blockIdx.x; asm volatile("" : "+s"(bx));
   return (int)((bx & 7u) * (gridDim.x >> 3) + (bx >> 3));
@@ -103,9 +107,10 @@ template <class S>
 __global__ void __launch_bounds__(64, (S::kFixed && !S::kConvex) ? 3 : 2)   // the convex narrow phase needs the full VGPR budget (41 spills at 168)
 grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
-  const int w = grx_world_of_block(), lane_ = threadIdx.x;
+  const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
+  const long long t_start = b.cost ? (long long)clock64() : 0ll;
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -113,19 +118,25 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
-  if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
+  if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); if (w < 16384) g_grx_world_span[2 * w] = wall_clock64(); }
 #endif
   grx_load_world(m, b, c, w, lds, words, lane_);
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = b.aux[(size_t)w * 8 + k];
   GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_);
-  const int wl = grx_world_of_block_late();
+  const int wl = b.order ? b.order[grx_block_late()] : grx_world_of_block_late();
   GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)wl * 8, b.obs + (size_t)wl * t.obs_dim, b.achieved + (size_t)wl * 3, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, wl, lane_);
+#ifdef GRX_PROFILE_ITER
+  if (b.cost && lane_ == 0) b.cost[wl] = c.cnt[6] | (c.cnt[0] << 16);   // diagnostic build: Newton iterations of the step, contacts of the last substep
+#else
+  if (b.cost && lane_ == 0) b.cost[wl] = (int)(((long long)clock64() - t_start) >> 4);
+#endif
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
   if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);  // summed over worlds
+  if (lane_ == 0 && w < 16384) g_grx_world_span[2 * w + 1] = wall_clock64();
 #endif
 }
 

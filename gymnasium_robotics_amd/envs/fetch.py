@@ -78,8 +78,9 @@ class FetchVecEnv(GoalVecEnv):
     def __init__(self, env_id: str = "FetchPickAndPlace-v4", num_envs: int = 1, device: Optional[str] = None,
                  max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step",
                  output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None,
-                 reward_type: Optional[str] = None, seed_offset: int = 0):
+                 reward_type: Optional[str] = None, seed_offset: int = 0, balance: bool = True):
         task, rt = parse_env_id(env_id)
+        self.balance = balance   # cost-ordered dispatch of the step kernel (see _alloc); results do not depend on it
         self.env_id, self.task_name, self.reward_type = env_id, task, reward_type or rt
         self.cfg = FETCH_TASKS[task]
         self.num_envs = int(num_envs)
@@ -131,6 +132,8 @@ class FetchVecEnv(GoalVecEnv):
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
+        if self.balance:
+            self._rebalance()
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, n):
@@ -141,10 +144,27 @@ class FetchVecEnv(GoalVecEnv):
         self.obs, self.achieved, self.reward = z(n, self.obs_dim), z(n, 3), z(n)
         self.success, self.status = z(n, dtype=torch.uint8), z(n, dtype=torch.int32)
         self.mask = torch.ones(n, dtype=torch.uint8, device=d)
+        # Cost-ordered dispatch (include/grx_capi.h, grx_fetch_buffers.order / .cost): every step launch records how long each world took
+        # and the next launch starts the expensive worlds first.  A world's cost is strongly correlated from one step to the next (it is
+        # in contact or it is not), and with ~2 worlds per resident wave slot the launch otherwise ends with a few slots finishing two
+        # expensive worlds while the rest of the chip idles.  Worlds stay inside their XCD's slice (L2 locality of neighbouring rows).
+        self.balance = bool(self.balance) and n % 8 == 0 and n >= 1024
+        self.cost = torch.zeros(n, dtype=torch.int32, device=d) if self.balance else None
+        self.order = None
+        if self.balance:
+            per = n // 8
+            self._slice_base = (torch.arange(8, device=d, dtype=torch.int32) * per).unsqueeze(1)          # [8,1]
+            self.order = (self._slice_base + torch.arange(per, device=d, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)   # workgroup b -> slice b & 7, position b >> 3
         self._bufs = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action, self.obs,
-                                     self.achieved, self.reward, self.success, self.status, None)
+                                     self.achieved, self.reward, self.success, self.status, None, self.order, self.cost)
         self._bufs_masked = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action,
-                                            self.obs, self.achieved, self.reward, self.success, self.status, self.mask)
+                                            self.obs, self.achieved, self.reward, self.success, self.status, self.mask, self.order, self.cost)
+
+    def _rebalance(self):
+        """order <- per XCD slice, worlds by decreasing cost of the launch that just ran (in place: the buffer struct keeps its pointer)."""
+        per = self.num_envs // 8
+        rank = torch.argsort(self.cost.view(8, per), dim=1, descending=True).to(torch.int32)
+        self.order.copy_((self._slice_base + rank).t().reshape(-1))
 
     @staticmethod
     def _make_bufs(*tensors):
@@ -166,7 +186,7 @@ class FetchVecEnv(GoalVecEnv):
             a = int(jq[n["joint"][name]])
             q0[a: a + len(v)] = v
         one = FetchVecEnv.__new__(FetchVecEnv)  # 1-world scratch buffers sharing the model
-        one.__dict__.update(device=self.device, nq=self.nq, nv=self.nv, nmocap=self.nmocap, obs_dim=self.obs_dim)
+        one.__dict__.update(device=self.device, nq=self.nq, nv=self.nv, nmocap=self.nmocap, obs_dim=self.obs_dim, balance=False)
         one._alloc(1)
         one.qpos[0] = torch.from_numpy(q0).float()
         one.mocap[0] = torch.from_numpy(np.concatenate([T["mocap_pos0"].ravel(), T["mocap_quat0"].ravel()])).float()
