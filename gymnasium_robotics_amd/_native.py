@@ -29,7 +29,7 @@ class PointBuffersStruct(ctypes.Structure):
 
 class HandBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask")]
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost")]
 
 
 def lib():

@@ -209,9 +209,10 @@ template <class S>
 __global__ void __launch_bounds__(64, (S::kFixed && S::JP <= 512) ? 3 : 2)   // third wave per SIMD only where the LDS footprint lets more than 8 worlds share a CU (HandReach); the object models sit at 8
 grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
-  const int w = grx_world_of_block(), lane_ = threadIdx.x;
+  const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
+  const long long t_start = b.cost ? (long long)clock64() : 0ll;
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -250,6 +251,7 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
       b.success[w] = (d < t.distance_threshold) ? 1 : 0;
     }
     b.status[w] = c.cnt[2];
+    if (b.cost) b.cost[w] = (int)(((long long)clock64() - t_start) >> 4);
   }
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);

@@ -103,6 +103,8 @@ typedef struct grx_hand_buffers {
   unsigned char* success;       /* [N] */
   int* status;                  /* [N] */
   const unsigned char* mask;    /* [N] or NULL */
+  const int* order;             /* [8 * ceil(N / 8)] or NULL: cost-ordered dispatch, as in grx_fetch_buffers */
+  int* cost;                    /* [N] or NULL */
 } grx_hand_buffers;
 
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);
