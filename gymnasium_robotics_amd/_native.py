@@ -55,6 +55,7 @@ def lib():
         L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_float, ci, vp, vp]
         L.grx_manip_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]
+        L.grx_order_by_cost.argtypes = [vp, ci, vp, vp]
         cd = ctypes.c_double
         L.grx_fetch_sample_resets.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         _lib = L
@@ -68,5 +69,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
 ]

@@ -516,6 +516,43 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   return 0;
 }
 
+// Cost-ordered dispatch, device side: one workgroup per XCD slice sorts (cost, world) keys of its contiguous `per` worlds in LDS
+// (bitonic, descending cost, ties by world index) and writes order[i * 8 + slice] = the i-th most expensive world of the slice --
+// workgroup b of the next step launch runs on XCD b & 7 and starts in index order.
+extern "C" __global__ void __launch_bounds__(256)
+grx_order_kernel(const int* __restrict__ cost, int per, int npow2, int* __restrict__ order) {
+  extern __shared__ unsigned long long keys[];
+  const int s = blockIdx.x, base = s * per;
+  for (int i = threadIdx.x; i < npow2; i += 256)
+    keys[i] = i < per ? (((unsigned long long)(unsigned)cost[base + i] << 32) | (unsigned)(0x7FFFFFFF - i)) : 0ull;   // padding sorts last
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = keys[i], b = keys[l];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < per; i += 256) order[i * 8 + s] = base + (0x7FFFFFFF - (int)(unsigned)(keys[i] & 0xFFFFFFFFull));
+}
+
+extern "C" int grx_order_by_cost(const int* cost, int n_worlds, int* order, void* stream) {
+  if (!cost || !order) return fail("grx_order_by_cost: null argument");
+  if (n_worlds <= 0 || (n_worlds & 7)) return fail("grx_order_by_cost: the number of worlds must be a positive multiple of 8 (one contiguous slice per XCD)");
+  const int per = n_worlds >> 3;
+  int npow2 = 1;
+  while (npow2 < per) npow2 <<= 1;
+  if ((size_t)npow2 * 8 > 64 * 1024) return fail("grx_order_by_cost: more than 65536 worlds per launch are not supported");
+  hipLaunchKernelGGL(grx_order_kernel, dim3(8), dim3(256), (size_t)npow2 * 8, (hipStream_t)stream, cost, per, npow2, order);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
                                        float* reward_out, void* stream) {
   if (!achieved || !desired || !reward_out || dim <= 0) return fail("grx_goal_compute_reward: bad argument");

@@ -162,9 +162,7 @@ class FetchVecEnv(GoalVecEnv):
 
     def _rebalance(self):
         """order <- per XCD slice, worlds by decreasing cost of the launch that just ran (in place: the buffer struct keeps its pointer)."""
-        per = self.num_envs // 8
-        rank = torch.argsort(self.cost.view(8, per), dim=1, descending=True).to(torch.int32)
-        self.order.copy_((self._slice_base + rank).t().reshape(-1))
+        _native.check(self._L.grx_order_by_cost(self.cost.data_ptr(), self.num_envs, self.order.data_ptr(), self._stream()))
 
     @staticmethod
     def _make_bufs(*tensors):

@@ -141,9 +141,7 @@ class HandReachVecEnv(GoalVecEnv):
             b.record()
             self.kernel_events.append((a, b))
         if self.balance and not forward_only:
-            per = self.num_envs // 8
-            rank = torch.argsort(self.cost.view(8, per), dim=1, descending=True).to(torch.int32)
-            self.order.copy_((self._slice_base + rank).t().reshape(-1))
+            _native.check(self._L.grx_order_by_cost(self.cost.data_ptr(), self.num_envs, self.order.data_ptr(), self._stream()))
 
     # ------------------------------------------------------------------ _env_setup (reach.py:408-416) on the device
     def _env_setup(self):

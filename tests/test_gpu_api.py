@@ -79,3 +79,42 @@ def test_serialize_deserialize_keeps_constructor_arguments():
     assert env1.distance_threshold == env2.distance_threshold == 1e-6
     assert env2.task.distance_threshold == np.float32(1e-6)
     env1.close(); env2.close()
+
+
+def test_order_by_cost_and_balance_invariance():
+    """grx_order_by_cost: per XCD slice (n / 8 contiguous worlds) decreasing cost, ties by world index, workgroup b -> slice b & 7.
+    The dispatch order is a scheduling choice only: a balanced and an unbalanced env produce bit-identical outputs."""
+    import ctypes
+
+    import torch
+
+    import gymnasium_robotics_amd as grx
+    from gymnasium_robotics_amd import _native
+
+    L = _native.lib()
+    n = 2048
+    g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+    cost = torch.randint(0, 5000, (n,), device="cuda:0", generator=g, dtype=torch.int32)
+    order = torch.full((n,), -1, device="cuda:0", dtype=torch.int32)
+    _native.check(L.grx_order_by_cost(cost.data_ptr(), n, order.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    o, c = order.cpu().numpy().reshape(n // 8, 8), cost.cpu().numpy()
+    assert sorted(o.ravel().tolist()) == list(range(n))                       # a permutation
+    per = n // 8
+    for s in range(8):
+        w = o[:, s]
+        assert (w // per == s).all()                                          # slice s stays on XCD s
+        key = np.stack([-c[w].astype(np.int64), w.astype(np.int64)], axis=1)
+        assert (np.lexsort((key[:, 1], key[:, 0])) == np.arange(per)).all()   # decreasing cost, ties by index
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        _native.check(L.grx_order_by_cost(cost.data_ptr(), 1001, order.data_ptr(), None))
+    a = grx.make_vec("FetchPickAndPlace-v4", num_envs=1024, device="cuda:0", balance=True)
+    b = grx.make_vec("FetchPickAndPlace-v4", num_envs=1024, device="cuda:0", balance=False)
+    assert a.balance and not b.balance
+    a.reset(seed=5); b.reset(seed=5)
+    rng = np.random.default_rng(0)
+    for _ in range(6):
+        act = rng.uniform(-1, 1, (1024, 4)).astype(np.float32)
+        sa, sb = a.step(act), b.step(act)
+        assert np.array_equal(sa[0]["observation"], sb[0]["observation"]) and np.array_equal(sa[1], sb[1])
+    assert int(a.cost.min()) > 0 and not np.array_equal(a.order.cpu().numpy(), np.arange(1024).reshape(8, 128).T.ravel())

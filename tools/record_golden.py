@@ -15,8 +15,8 @@ import sys
 
 import numpy as np
 
-DEFAULT_IDS = ["FetchReach-v4", "FetchPush-v4", "FetchPickAndPlace-v4", "HandReach-v3", "HandManipulateBlockRotateXYZ-v1",
-               "HandManipulatePenRotate-v1"]
+DEFAULT_IDS = ["FetchReach-v4", "FetchPush-v4", "FetchSlide-v4", "FetchPickAndPlace-v4", "HandReach-v3", "HandManipulateBlockRotateXYZ-v1",
+               "HandManipulateEggRotate-v1", "HandManipulatePenRotate-v1"]   # Slide / Egg exercise MuJoCo's convex collider: record mujoco.__version__ (libccd MPR <= 3.1, native GJK/EPA later)
 
 
 def record(env_id, episodes=6, steps=50, seed0=0):
