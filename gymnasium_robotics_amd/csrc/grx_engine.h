@@ -1954,20 +1954,23 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
 // Ma = M a ; jar = J a - aref ; force / active flags ; returns total cost if want_cost
 // Row states: 0 = inactive (satisfied inequality), 1 = quadratic, 2 / 3 = friction-loss row saturated at -f / +f.
 // Returns 1 if any row changed state with respect to the previous evaluation (bits 0-1 of efc_quad), else 0.
-GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int nefc, int lane_) {
+// carried != 0: Ma and jar were advanced along the accepted step (Ma += alpha Mv, jar += alpha Jv) by the caller, only the row states
+// and forces are re-derived (no mat-vec, no row dot products).
+GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int nefc, int carried, int lane_) {
   const int nv = GRX_NVC;
   GRX_LANEVAR(chgp);
   FOR_LANES {
     float chg = 0;
-    for (int i = lane; i < nv; i += 64) {
-      float s = 0;
+    if (!carried) {
+      for (int i = lane; i < nv; i += 64) {
+        float s = 0;
 #pragma unroll 8
-      for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * a[j];
-      c->Ma[i] = s;
+        for (int j = 0; j < nv; j++) s += c->M[i * nv + j] * a[j];
+        c->Ma[i] = s;
+      }
     }
     for (int r = lane; r < nefc; r += 64) {
-      const float s = grx_row_dot(c, r, a);
-      float x = s - c->efc_aref[r], D = c->efc_D[r], f; int st;
+      float x = carried ? c->efc_jar[r] : grx_row_dot(c, r, a) - c->efc_aref[r], D = c->efc_D[r], f; int st;
       int kind = c->efc_kind[r];
       if (kind == GRX_ROW_EQ) { f = -D * x; st = 1; }
       else if (kind == GRX_ROW_FRICTION) {
@@ -2173,7 +2176,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   for (;;) {
     float* rhs;
     if (phase == 0) {
-      const int changed = grx_newton_eval(m, c, c->qacc, nefc, lane_);
+      const int changed = grx_newton_eval(m, c, c->qacc, nefc, it > 0 && S::kIncrHess, lane_);
       GRX_TICK(c, GRX_P_NEVAL);
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
@@ -2311,6 +2314,10 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       FOR_LANES {
         float ms = 0, ma = 0;
         for (int i = lane; i < nv; i += 64) { float d = alpha * c->search[i]; float q = c->qacc[i] + d; c->qacc[i] = q; ms = fmaxf(ms, fabsf(d)); ma = fmaxf(ma, fabsf(q)); }
+        if (S::kIncrHess) {   // carry M a and J a - aref along the step: the next evaluation only re-derives row states and forces
+          for (int i = lane; i < nv; i += 64) c->Ma[i] += alpha * c->Mv[i];
+          for (int r = lane; r < nefc; r += 64) c->efc_jar[r] += alpha * c->efc_jv[r];
+        }
         LV(msp) = ms; LV(map_) = ma;
       }
       WAVE_SYNC();
