@@ -32,7 +32,7 @@ struct GrxFetchBuffers {
   int* status;                           // [N]
   const unsigned char* mask;             // [N] or null: worlds to process
   const int* order;                      // [grid] or null: world handled by workgroup b (dispatch order = cost order, see grx_fetch_step_kernel)
-  int* cost;                             // [N] or null: out, shader cycles / 16 this world took (the next launch's ordering key)
+  int* cost;                             // [N] or null: out, cost estimate of this world (the next launch's ordering key)
 };
 
 // distance with a fixed operation order so that the fused step kernel and the standalone

@@ -42,7 +42,7 @@ struct GrxHandBuffers {
   int* status;                   // [N]
   const unsigned char* mask;     // [N] or null
   const int* order;              // [grid] or null: world handled by workgroup b (cost-ordered dispatch, see grx_fetch_buffers)
-  int* cost;                     // [N] or null: out, shader cycles / 16 of this world
+  int* cost;                     // [N] or null: out, cost estimate of this world
 };
 
 // Euclidean distance with a fixed accumulation order, shared by the step kernel and the recompute kernel so that

@@ -110,7 +110,6 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
-  const long long t_start = b.cost ? (long long)clock64() : 0ll;
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -131,7 +130,10 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
 #ifdef GRX_PROFILE_ITER
   if (b.cost && lane_ == 0) b.cost[wl] = c.cnt[6] | (c.cnt[0] << 16);   // diagnostic build: Newton iterations of the step, contacts of the last substep
 #else
-  if (b.cost && lane_ == 0) b.cost[wl] = (int)(((long long)clock64() - t_start) >> 4);
+  // cost model fitted to measured world durations (tools/profile_balance.py): ~12 us per Newton iteration of the step + ~24 us per contact of
+  // the last substep, on top of a constant.  Counting instead of timing keeps the dispatch order reproducible from run to run and keeps a
+  // 64-bit timestamp from living (spilled) across the substep loop.
+  if (b.cost && lane_ == 0) b.cost[wl] = 12 * c.cnt[6] + 24 * c.cnt[0];
 #endif
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
@@ -212,7 +214,6 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
-  const long long t_start = b.cost ? (long long)clock64() : 0ll;
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -251,7 +252,7 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
       b.success[w] = (d < t.distance_threshold) ? 1 : 0;
     }
     b.status[w] = c.cnt[2];
-    if (b.cost) b.cost[w] = (int)(((long long)clock64() - t_start) >> 4);
+    if (b.cost) b.cost[w] = 12 * c.cnt[6] + 24 * c.cnt[0];   // iterations of the step + contacts of the last substep (see grx_fetch_step_kernel)
   }
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);

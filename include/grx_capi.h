@@ -57,7 +57,7 @@ typedef struct grx_fetch_buffers {
   const unsigned char* mask;            /* [N] or NULL */
   /* Optional load balancing (both NULL = off).  A world costs between 0.9x and 2.2x the median (contacts, Newton iterations) and a
    * launch of 4096 worlds is only ~2 worlds per resident wave slot, so the launch ends when the unluckiest slot does.  `cost` receives
-   * every world's duration (shader cycles / 16); `order[b]` names the world workgroup b handles, so the caller can start the expensive
+   * every world's cost estimate (12 x Newton iterations of the step + 24 x contacts of its last substep ~ microseconds above the base); `order[b]` names the world workgroup b handles, so the caller can start the expensive
    * worlds first (workgroups start in index order; b & 7 is the XCD: keep a world in the XCD slice that owns its neighbours). */
   const int* order;                     /* [8 * ceil(N / 8)] or NULL; entries >= N are idle workgroups */
   int* cost;                            /* [N] or NULL */

@@ -117,4 +117,4 @@ def test_order_by_cost_and_balance_invariance():
         act = rng.uniform(-1, 1, (1024, 4)).astype(np.float32)
         sa, sb = a.step(act), b.step(act)
         assert np.array_equal(sa[0]["observation"], sb[0]["observation"]) and np.array_equal(sa[1], sb[1])
-    assert int(a.cost.min()) > 0 and not np.array_equal(a.order.cpu().numpy(), np.arange(1024).reshape(8, 128).T.ravel())
+    assert int(a.cost.min()) >= 12 * 20 and not np.array_equal(a.order.cpu().numpy(), np.arange(1024).reshape(8, 128).T.ravel())
