@@ -1990,23 +1990,30 @@ GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int ne
 }
 
 // derivative (d1) and curvature (d2) of the cost along the search direction at step alpha
-GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, float* d1, float* d2, int lane_) {
-  GRX_LANEVAR(gp); GRX_LANEVAR(hp);
+// *same (optional) <- 1 when every row is, at step alpha, in the state it has at alpha = 0 (efc_quad): the cost is then exactly
+// quadratic on [0, alpha]
+GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, float* d1, float* d2, int* same, int lane_) {
+#ifdef GRX_LS_STATS
+  { extern int g_ls_calls; g_ls_calls++; }
+#endif
+  GRX_LANEVAR(gp); GRX_LANEVAR(hp); GRX_LANEVAR_I(difp);
   FOR_LANES {
-    float g = 0, h = 0;
+    float g = 0, h = 0; int dif = 0;
     for (int r = lane; r < nefc; r += 64) {
       float jv = c->efc_jv[r], D = c->efc_D[r], x = c->efc_jar[r] + alpha * jv;
-      int kind = c->efc_kind[r];
-      if (kind == GRX_ROW_EQ) { g += D * x * jv; h += D * jv * jv; }
+      int kind = c->efc_kind[r], st;
+      if (kind == GRX_ROW_EQ) { g += D * x * jv; h += D * jv * jv; st = 1; }
       else if (kind == GRX_ROW_FRICTION) {
         float fl = c->efc_floss[r], Rf = fl / D;
-        if (x <= -Rf) g -= fl * jv; else if (x >= Rf) g += fl * jv; else { g += D * x * jv; h += D * jv * jv; }
-      } else if (x < 0) { g += D * x * jv; h += D * jv * jv; }
+        if (x <= -Rf) { g -= fl * jv; st = 3; } else if (x >= Rf) { g += fl * jv; st = 2; } else { g += D * x * jv; h += D * jv * jv; st = 1; }
+      } else if (x < 0) { g += D * x * jv; h += D * jv * jv; st = 1; } else st = 0;
+      if (same) dif |= (st != (c->efc_quad[r] & 3));
     }
-    LV(gp) = g; LV(hp) = h;
+    LV(gp) = g; LV(hp) = h; LV(difp) = dif;
   }
   float g = grx_reduce_sum(gp), h = grx_reduce_sum(hp);
   *d1 = q1 + alpha * q2 + g; *d2 = q2 + h;
+  if (same) *same = (GRX_BALLOT(difp) == 0ull);
 }
 
 // H = M + J' diag(D_active) J  ->  c->A   (efc_jv is used as scratch for the masked D)
@@ -2301,7 +2308,11 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       const int stop = !(dphi0 < 0);
       full_step = 0;
       for (int k = 0; k < GRX_LS_MAXIT + 1 && !stop; k++) {
-        grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, lane_);
+        int same = 0;
+        grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, k == 0 ? &same : (int*)0, lane_);
+        // The search direction is the exact Newton step of the current active set: when no row changes state on [0, 1] the cost is
+        // quadratic there and alpha = 1 is its minimiser, whatever rounding left in d1 (a difference of two numbers of size |phi'(0)|).
+        if (k == 0 && same) { full_step = 1; break; }
         if (fabsf(d1) <= gtol) { full_step = (k == 0); break; }
         if (d1 < 0) { lo = alpha; dlo = d1; } else { hi = alpha; dhi = d1; have_hi = 1; }
         float na = alpha - d1 / d2;
@@ -2323,6 +2334,9 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       WAVE_SYNC();
       const float stepmax = grx_reduce_max(msp), qmax = grx_reduce_max(map_);
       LANE0 { c->cnt[6] += 1; }
+#ifdef GRX_LS_STATS
+      { extern int g_ls_iters, g_ls_full; g_ls_iters++; g_ls_full += full_step; }
+#endif
       GRX_TICK(c, GRX_P_NLS);
       it++;
       // converged when the accepted step is below the resolution we can hold in fp32 (quadratic convergence: the
