@@ -1265,17 +1265,38 @@ GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1
   mulMatTVec3f(nl, gm, n);
   float off = dot3f(c->gxpos + 3 * g2, n) - dot3f(c->gxpos + 3 * g1, n);
   float bd = 1e30f; int best = -1;
-  for (int v = 0; v < num; v++) {
-    const float* mv = m->mesh_vert + 3 * (adr + v);
-    float dd = mv[0] * nl[0] + mv[1] * nl[1] + mv[2] * nl[2] + off;
-    if (dd < bd) { bd = dd; best = v; }
+  // the vertex tables live in global memory: fetch eight vertices per round with independent loads (one latency per round, not per vertex)
+  for (int v0 = 0; v0 < num; v0 += 8) {
+    float vx[8], vy[8], vz[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int v = (v0 + u < num) ? v0 + u : num - 1;
+      const float* mv = m->mesh_vert + 3 * (adr + v);
+      vx[u] = mv[0]; vy[u] = mv[1]; vz[u] = mv[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const float dd = vx[u] * nl[0] + vy[u] * nl[1] + vz[u] * nl[2] + off;
+      if (v0 + u < num && dd < bd) { bd = dd; best = v0 + u; }
+    }
   }
   if (best < 0 || bd > margin) return;
-  int aa = m->mesh_adjadr[adr + best], an = m->mesh_adjnum[adr + best], cn = 0;
+  // the deepest vertex, then its hull neighbours inside the margin (at most 4 contacts): neighbour indices and their vertices in two rounds
+  const int aa = m->mesh_adjadr[adr + best], an = m->mesh_adjnum[adr + best];
+  int nb[8]; float wx[8], wy[8], wz[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) nb[u] = (u < an) ? m->mesh_adj[aa + u] : best;
+#pragma unroll
+  for (int u = 0; u < 8; u++) { const float* mv = m->mesh_vert + 3 * (adr + nb[u]); wx[u] = mv[0]; wy[u] = mv[1]; wz[u] = mv[2]; }
+  int cn = 0;
   for (int e = -1; e < an && cn < 4; e++) {
-    int v = (e < 0) ? best : m->mesh_adj[aa + e];
-    const float* mv = m->mesh_vert + 3 * (adr + v);
-    float lv[3] = {mv[0], mv[1], mv[2]};
+    float lv[3];
+    if (e < 0) { const float* mv = m->mesh_vert + 3 * (adr + best); lv[0] = mv[0]; lv[1] = mv[1]; lv[2] = mv[2]; }
+    else if (e < 8) {
+      lv[0] = lv[1] = lv[2] = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (u == e) { lv[0] = wx[u]; lv[1] = wy[u]; lv[2] = wz[u]; }
+    } else { const float* mv = m->mesh_vert + 3 * (adr + m->mesh_adj[aa + e]); lv[0] = mv[0]; lv[1] = mv[1]; lv[2] = mv[2]; }
     float dd = lv[0] * nl[0] + lv[1] * nl[1] + lv[2] * nl[2] + off;
     if (e >= 0 && dd > margin) continue;
     float w[3], pos[3];
