@@ -1265,17 +1265,17 @@ GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1
   mulMatTVec3f(nl, gm, n);
   float off = dot3f(c->gxpos + 3 * g2, n) - dot3f(c->gxpos + 3 * g1, n);
   float bd = 1e30f; int best = -1;
-  // the vertex tables live in global memory: fetch eight vertices per round with independent loads (one latency per round, not per vertex)
-  for (int v0 = 0; v0 < num; v0 += 8) {
-    float vx[8], vy[8], vz[8];
+  // the vertex tables live in global memory: fetch four vertices per round with independent loads (one latency per round, not per vertex)
+  for (int v0 = 0; v0 < num; v0 += 4) {
+    float vx[4], vy[4], vz[4];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 4; u++) {
       const int v = (v0 + u < num) ? v0 + u : num - 1;
       const float* mv = m->mesh_vert + 3 * (adr + v);
       vx[u] = mv[0]; vy[u] = mv[1]; vz[u] = mv[2];
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 4; u++) {
       const float dd = vx[u] * nl[0] + vy[u] * nl[1] + vz[u] * nl[2] + off;
       if (v0 + u < num && dd < bd) { bd = dd; best = v0 + u; }
     }
@@ -1289,21 +1289,22 @@ GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1
 #pragma unroll
   for (int u = 0; u < 8; u++) { const float* mv = m->mesh_vert + 3 * (adr + nb[u]); wx[u] = mv[0]; wy[u] = mv[1]; wz[u] = mv[2]; }
   int cn = 0;
-  for (int e = -1; e < an && cn < 4; e++) {
-    float lv[3];
-    if (e < 0) { const float* mv = m->mesh_vert + 3 * (adr + best); lv[0] = mv[0]; lv[1] = mv[1]; lv[2] = mv[2]; }
-    else if (e < 8) {
-      lv[0] = lv[1] = lv[2] = 0.0f;
-#pragma unroll
-      for (int u = 0; u < 8; u++) if (u == e) { lv[0] = wx[u]; lv[1] = wy[u]; lv[2] = wz[u]; }
-    } else { const float* mv = m->mesh_vert + 3 * (adr + m->mesh_adj[aa + e]); lv[0] = mv[0]; lv[1] = mv[1]; lv[2] = mv[2]; }
-    float dd = lv[0] * nl[0] + lv[1] * nl[1] + lv[2] * nl[2] + off;
-    if (e >= 0 && dd > margin) continue;
-    float w[3], pos[3];
-    mulMatVec3f(w, gm, lv);
-    for (int t = 0; t < 3; t++) pos[t] = w[t] + c->gxpos[3 * g2 + t] - 0.5f * dd * n[t];
-    grx_add_contact(c, pair, pos, n, dd); cn++;
-  }
+  // fully unrolled over the fetched neighbours (static register indices); hull vertices of higher degree take the tail loop
+#define GRX_PM_EMIT(LX, LY, LZ, IS_BEST) { \
+    const float lx_ = (LX), ly_ = (LY), lz_ = (LZ); \
+    const float dd = lx_ * nl[0] + ly_ * nl[1] + lz_ * nl[2] + off; \
+    if ((IS_BEST) || dd <= margin) { \
+      const float lv[3] = {lx_, ly_, lz_}; float w[3], pos[3]; \
+      mulMatVec3f(w, gm, lv); \
+      for (int t = 0; t < 3; t++) pos[t] = w[t] + c->gxpos[3 * g2 + t] - 0.5f * dd * n[t]; \
+      grx_add_contact(c, pair, pos, n, dd); cn++; \
+    } }
+  { const float* mv = m->mesh_vert + 3 * (adr + best); GRX_PM_EMIT(mv[0], mv[1], mv[2], 1) }
+#define GRX_PM_NB(U) if ((U) < an && cn < 4) GRX_PM_EMIT(wx[U], wy[U], wz[U], 0)
+  GRX_PM_NB(0) GRX_PM_NB(1) GRX_PM_NB(2) GRX_PM_NB(3) GRX_PM_NB(4) GRX_PM_NB(5) GRX_PM_NB(6) GRX_PM_NB(7)
+#undef GRX_PM_NB
+  for (int e = 8; e < an && cn < 4; e++) { const float* mv = m->mesh_vert + 3 * (adr + m->mesh_adj[aa + e]); GRX_PM_EMIT(mv[0], mv[1], mv[2], 0) }
+#undef GRX_PM_EMIT
 }
 
 
@@ -2011,9 +2012,9 @@ GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int ne
 }
 
 // derivative (d1) and curvature (d2) of the cost along the search direction at step alpha
-// *same (optional) <- 1 when every row is, at step alpha, in the state it has at alpha = 0 (efc_quad): the cost is then exactly
+// *same <- (want_same and) every row is, at step alpha, in the state it has at alpha = 0 (efc_quad): the cost is then exactly
 // quadratic on [0, alpha]
-GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, float* d1, float* d2, int* same, int lane_) {
+GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, float* d1, float* d2, int want_same, int* same, int lane_) {
 #ifdef GRX_LS_STATS
   { extern int g_ls_calls; g_ls_calls++; }
 #endif
@@ -2028,13 +2029,13 @@ GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, f
         float fl = c->efc_floss[r], Rf = fl / D;
         if (x <= -Rf) { g -= fl * jv; st = 3; } else if (x >= Rf) { g += fl * jv; st = 2; } else { g += D * x * jv; h += D * jv * jv; st = 1; }
       } else if (x < 0) { g += D * x * jv; h += D * jv * jv; st = 1; } else st = 0;
-      if (same) dif |= (st != (c->efc_quad[r] & 3));
+      if (want_same) dif |= (st != (c->efc_quad[r] & 3));
     }
     LV(gp) = g; LV(hp) = h; LV(difp) = dif;
   }
   float g = grx_reduce_sum(gp), h = grx_reduce_sum(hp);
   *d1 = q1 + alpha * q2 + g; *d2 = q2 + h;
-  if (same) *same = (GRX_BALLOT(difp) == 0ull);
+  *same = want_same && (GRX_BALLOT(difp) == 0ull);
 }
 
 // H = M + J' diag(D_active) J  ->  c->A   (efc_jv is used as scratch for the masked D)
@@ -2330,7 +2331,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       full_step = 0;
       for (int k = 0; k < GRX_LS_MAXIT + 1 && !stop; k++) {
         int same = 0;
-        grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, k == 0 ? &same : (int*)0, lane_);
+        grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, k == 0, &same, lane_);
         // The search direction is the exact Newton step of the current active set: when no row changes state on [0, 1] the cost is
         // quadratic there and alpha = 1 is its minimiser, whatever rounding left in d1 (a difference of two numbers of size |phi'(0)|).
         if (k == 0 && same) { full_step = 1; break; }
