@@ -2205,7 +2205,10 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   for (;;) {
     float* rhs;
     if (phase == 0) {
-      const int changed = grx_newton_eval(m, c, c->qacc, nefc, it > 0 && S::kIncrHess, lane_);
+      // After a step, M a and J a - aref are current (carried) and convergence has already been decided: the only thing the evaluation would
+      // still produce are the row forces, which nothing reads after the solve unless the model has touch sensors.
+      const int skip_eval = done && it > 0 && S::kIncrHess && (S::kFixed ? S::NT : m->ntouch) == 0;
+      const int changed = skip_eval ? 0 : grx_newton_eval(m, c, c->qacc, nefc, it > 0 && S::kIncrHess, lane_);
       GRX_TICK(c, GRX_P_NEVAL);
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
@@ -2334,7 +2337,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         grx_ls_eval(c, nefc, alpha, q1, q2, &d1, &d2, k == 0, &same, lane_);
         // The search direction is the exact Newton step of the current active set: when no row changes state on [0, 1] the cost is
         // quadratic there and alpha = 1 is its minimiser, whatever rounding left in d1 (a difference of two numbers of size |phi'(0)|).
-        if (k == 0 && same) { full_step = 1; break; }
+        if (k == 0 && same) { full_step = 2; break; }
         if (fabsf(d1) <= gtol) { full_step = (k == 0); break; }
         if (d1 < 0) { lo = alpha; dlo = d1; } else { hi = alpha; dhi = d1; have_hi = 1; }
         float na = alpha - d1 / d2;
@@ -2364,6 +2367,9 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       // converged when the accepted step is below the resolution we can hold in fp32 (quadratic convergence: the
       // step just applied is ~ the error BEFORE it, the error after it is far smaller)
       if (stepmax <= GRX_NEWTON_RTOL * qmax + GRX_NEWTON_ATOL) done = 1;
+      // an exact full step (no row changes state on [0,1], decided with the very arithmetic the carried evaluation would repeat) lands on
+      // the minimiser of the current piece and leaves every row in its state: converged
+      if (S::kIncrHess && full_step == 2) done = 1;
     } else if (phase == 2) {
       FOR_LANES { for (int i = lane; i < nv; i += 64) { float q = c->qacc_smooth[i]; c->qacc[i] = q; c->qacc_ws[i] = q; c->qfrc_constraint[i] = 0; } }
       WAVE_SYNC();
