@@ -129,3 +129,18 @@ def test_redraw_goal_draw_order_and_contract():
     single = Maze(MAPS["UMaze"], POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT)   # one goal cell only: nothing to redraw
     if len(single.unique_goal_locations) <= 1:
         assert np.array_equal(redraw_goal(single, a, at, at, 0.25), at)
+
+
+def test_map_tables_equal_the_reference_module():
+    """tests/golden/ref_maze_maps.json was written by importing the reference's own maps.py (tools/make_reference_vectors.py):
+    every registered layout of this package is the same table, marker for marker."""
+    import json
+
+    from gymnasium_robotics_amd.envs import maze_spec
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_maze_maps.json")) as f:
+        ref = json.load(f)
+    assert (maze_spec.R, maze_spec.G, maze_spec.C) == (ref["markers"]["R"], ref["markers"]["G"], ref["markers"]["C"])
+    assert set(ref["maps"]) == set(maze_spec.MAPS)
+    for name, table in ref["maps"].items():
+        assert maze_spec.MAPS[name] == table, name
