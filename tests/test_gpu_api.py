@@ -118,3 +118,34 @@ def test_order_by_cost_and_balance_invariance():
         sa, sb = a.step(act), b.step(act)
         assert np.array_equal(sa[0]["observation"], sb[0]["observation"]) and np.array_equal(sa[1], sb[1])
     assert int(a.cost.min()) >= 12 * 20 and not np.array_equal(a.order.cpu().numpy(), np.arange(1024).reshape(8, 128).T.ravel())
+
+
+def test_device_rewards_equal_the_reference_run_vectors():
+    """The batched reward kernels (the HER relabelling entry points) against rewards computed by the reference's own methods
+    (tests/golden/ref_host_logic.npz, tools/make_reference_host_vectors.py); fp32 device arithmetic: pairs whose distance sits on a
+    threshold are excluded from the exact comparison."""
+    import os
+
+    import gymnasium_robotics_amd as grx
+
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_host_logic.npz"))
+    for env_id, key in (("FetchPush-v4", "sparse"), ("FetchPushDense-v4", "dense")):
+        env = grx.make_vec(env_id, num_envs=2, device="cuda:0")
+        r = env.compute_reward(ref["fetch_ag"], ref["fetch_dg"], {})
+        d = np.linalg.norm(ref["fetch_ag"] - ref["fetch_dg"], axis=-1)
+        clear = np.abs(d - 0.05) > 1e-6
+        assert r.shape == ref[f"fetch_reward_{key}"].shape
+        assert np.allclose(r[clear], ref[f"fetch_reward_{key}"][clear], rtol=0, atol=1e-6)
+    for env_id, key in (("HandReach-v3", "sparse"), ("HandReachDense-v3", "dense")):
+        env = grx.make_vec(env_id, num_envs=2, device="cuda:0")
+        r = env.compute_reward(ref["hand_reach_ag"], ref["hand_reach_dg"], {})
+        d = np.linalg.norm(ref["hand_reach_ag"] - ref["hand_reach_dg"], axis=-1)
+        clear = np.abs(d - 0.01) > 1e-6
+        assert np.allclose(r[clear], ref[f"hand_reach_reward_{key}"][clear], rtol=0, atol=1e-6)
+    for env_id, tag, key in (("HandManipulateBlockRotateXYZ-v1", "ignore_xyz", "sparse"), ("HandManipulateBlockRotateXYZDense-v1", "ignore_xyz", "dense"),
+                             ("HandManipulateBlockFull-v1", "random_xyz", "sparse"), ("HandManipulateBlockFullDense-v1", "random_xyz", "dense")):
+        env = grx.make_vec(env_id, num_envs=2, device="cuda:0")
+        r = env.compute_reward(ref["manip_ga"], ref["manip_gb"], {})
+        clear = (np.abs(ref[f"manip_{tag}_dpos"] - 0.01) > 1e-5) & (np.abs(ref[f"manip_{tag}_drot"] - 0.1) > 1e-4)
+        # dense: -(10 d_pos + d_rot); the fp32 angle of two nearly identical orientations carries ~3e-4 rad of rounding (2 atan2 of a 1e-4 sine)
+        assert np.allclose(r[clear], ref[f"manip_{tag}_reward_{key}"][clear], rtol=0, atol=1e-3 if key == "dense" else 0), (env_id, np.abs(r - ref[f"manip_{tag}_reward_{key}"])[clear].max())
