@@ -149,8 +149,12 @@ class OracleFetchEnv:
     def step(self, action, aux=None):
         """aux: optional (pos3, quat4) of gripper_link to use instead of the sim's last kinematics (teacher forcing)."""
         s = self.sim
-        action = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0)
-        pos_ctrl, g = action[:3] * 0.05, (0.0 if self.block_gripper else action[3])
+        # robot_env.py:132 clips with the float32 bounds of the action space and fetch_env.py:85-93 scales in place: the arithmetic runs in
+        # the dtype of the action that was passed in (float32 actions -> float32 product), as in the reference
+        action = np.clip(np.asarray(action), np.float32(-1.0), np.float32(1.0))
+        pos_ctrl = np.array(action[:3], copy=True)
+        pos_ctrl *= 0.05
+        pos_ctrl, g = pos_ctrl.astype(np.float64), (0.0 if self.block_gripper else float(action[3]))
         # ctrl_set_action: position servos take targets relative to the current qpos
         for i in range(s.nu):
             jid = int(self.model.tables["act_trnid"][i])

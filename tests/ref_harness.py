@@ -1,0 +1,130 @@
+"""Run the REFERENCE's own environment code (BaseRobotEnv.step, MujocoFetchEnv._set_action / _step_callback / _get_obs, the
+mujoco_utils helpers, ...) on top of the oracle's physics, in the build container where neither gymnasium nor mujoco exists.
+
+Stand-ins: a minimal `gymnasium`, a `gymnasium_robotics` package object whose __path__ is the reference tree (its __init__ is not
+executed), and a `mujoco` module whose enums carry MuJoCo's public values and whose mj_step / mj_forward / mj_jacSite / mj_name2id
+delegate to the oracle simulation (oracle/grx_oracle.c) through the MjModel / MjData proxies below.  What runs is the reference's
+task layer, line for line; what it runs on is the checker's restatement of the physics.  Used only by CPU tests that skip when
+/root/reference is not mounted (the GPU box)."""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF_ROOT = "/root/reference"
+
+
+def available():
+    return os.path.isdir(os.path.join(REF_ROOT, "gymnasium_robotics"))
+
+
+class _Enum:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def install():
+    """Idempotent.  Returns the stand-in mujoco module (its `bind(sim_proxy)` is set per environment by FetchOnOracle)."""
+    if "mujoco" in sys.modules and getattr(sys.modules["mujoco"], "_grx_stand_in", False):
+        return sys.modules["mujoco"]
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import make_reference_host_vectors as mk
+
+    mk.install_stand_ins()
+    mj = types.ModuleType("mujoco")
+    mj._grx_stand_in = True
+    mj.mjtEq = _Enum(mjEQ_CONNECT=0, mjEQ_WELD=1)
+    mj.mjtObj = _Enum(mjOBJ_BODY=1, mjOBJ_JOINT=3, mjOBJ_SITE=6)
+    mj.mjtJoint = _Enum(mjJNT_FREE=0, mjJNT_BALL=1, mjJNT_SLIDE=2, mjJNT_HINGE=3)
+    mj.MjModel = type("MjModel", (), {})
+    mj.MjData = type("MjData", (), {})
+    mj.mj_name2id = lambda model, typ, name: model._name2id(typ, name)
+    mj.mj_step = lambda model, data, nstep=1: data._step(nstep)
+    mj.mj_forward = lambda model, data: data._forward()
+
+    def mj_jacSite(model, data, jacp, jacr, site_id):
+        p, r = data._env.sim.jac_site(site_id)
+        if jacp is not None:
+            jacp[:] = p
+        if jacr is not None:
+            jacr[:] = r
+    mj.mj_jacSite = mj_jacSite
+    sys.modules["mujoco"] = mj
+    return mj
+
+
+class ModelProxy:
+    """The MjModel attributes the Fetch task code reads, from the compiled model tables.  Bodies: 0 = the mocap body, 1 =
+    robot0:gripper_link (the weld's second body; the engine fuses it into its parent, its pose comes from the oracle env)."""
+
+    def __init__(self, env):
+        T, n = env.model.tables, env.model.names
+        self.nmocap, self.nv, self.na = 1, env.model.dim("nv"), 0
+        self.actuator_biastype = np.asarray(T["act_biastype"]).ravel()
+        self.actuator_trnid = np.stack([np.asarray(T["act_trnid"]).ravel(), -np.ones_like(np.asarray(T["act_trnid"]).ravel())], axis=1)
+        self.jnt_qposadr, self.jnt_dofadr, self.jnt_type = (np.asarray(T[k]).ravel() for k in ("jnt_qposadr", "jnt_dofadr", "jnt_type"))
+        self.eq_type, self.eq_obj1id, self.eq_obj2id = np.array([1]), np.array([0]), np.array([1])
+        self.body_mocapid = np.array([0, -1])
+        self.opt = types.SimpleNamespace(timestep=env.model.opt("timestep"))
+        self._names = {1: {"robot0:mocap": 0, "robot0:gripper_link": 1}, 3: dict(n["joint"]), 6: dict(n["site"])}
+
+    def _name2id(self, typ, name):
+        return self._names[typ].get(name, -1)
+
+
+class DataProxy:
+    """The MjData attributes the Fetch task code reads / writes, as live views of the oracle simulation."""
+
+    def __init__(self, env):
+        self._env, s = env, env.sim
+        self.qpos, self.qvel, self.ctrl = s.qpos, s.qvel, s.ctrl
+        self.mocap_pos, self.mocap_quat = s.mocap_pos.reshape(1, 3), s.mocap_quat.reshape(1, 4)
+        self.act = np.zeros(0)
+        self.time = 0.0
+
+    @property
+    def site_xpos(self):
+        return self._env.sim.site_xpos.reshape(-1, 3)
+
+    @property
+    def site_xmat(self):
+        return self._env.sim.site_xmat.reshape(-1, 9)
+
+    @property
+    def xpos(self):
+        return np.stack([self._env.sim.mocap_pos, self._env._gripper_body_pose()[0]])
+
+    @property
+    def xquat(self):
+        return np.stack([self._env.sim.mocap_quat, self._env._gripper_body_pose()[1]])
+
+    def _step(self, nstep):
+        self._env.sim.step(nstep)
+
+    def _forward(self):
+        self._env.sim.forward()
+
+
+def fetch_on_oracle(oracle_env, reward_type="sparse"):
+    """An instance of the reference's MujocoFetchEnv class (created without running its constructor: that needs MuJoCo) whose model /
+    data are proxies onto `oracle_env`'s simulation.  Its step() is the reference's BaseRobotEnv.step."""
+    mj = install()
+    from gymnasium_robotics.envs.fetch import fetch_env
+    from gymnasium_robotics.utils import mujoco_utils
+
+    cfg = oracle_env.cfg
+    env = object.__new__(fetch_env.MujocoFetchEnv)
+    env.model, env.data = ModelProxy(oracle_env), DataProxy(oracle_env)
+    env._mujoco, env._utils = mj, mujoco_utils
+    env._model_names = types.SimpleNamespace(joint_names=[k for k in sorted(oracle_env.model.names["joint"], key=lambda k: oracle_env.model.names["joint"][k])])
+    env.n_substeps, env.render_mode = 20, None
+    env.action_space = types.SimpleNamespace(shape=(4,), low=-np.ones(4, np.float32), high=np.ones(4, np.float32))
+    for k in ("has_object", "block_gripper", "target_in_the_air", "target_offset", "obj_range", "target_range", "gripper_extra_height"):
+        setattr(env, k, cfg[k])
+    env.distance_threshold, env.reward_type = 0.05, reward_type
+    env.initial_gripper_xpos = oracle_env.initial_gripper_xpos.copy()
+    if cfg["has_object"]:
+        env.height_offset = oracle_env.height_offset
+    env.goal = oracle_env.goal.copy()
+    return env
