@@ -128,3 +128,53 @@ def fetch_on_oracle(oracle_env, reward_type="sparse"):
         env.height_offset = oracle_env.height_offset
     env.goal = oracle_env.goal.copy()
     return env
+
+
+class HandModelProxy:
+    def __init__(self, env):
+        T, n = env.model.tables, env.model.names
+        self.nmocap, self.nv, self.na = 0, env.model.dim("nv"), 0
+        self.actuator_ctrlrange = np.array(T["act_ctrlrange"], dtype=np.float64).reshape(-1, 2)
+        self.jnt_qposadr, self.jnt_dofadr, self.jnt_type = (np.asarray(T[k]).ravel() for k in ("jnt_qposadr", "jnt_dofadr", "jnt_type"))
+        self.opt = types.SimpleNamespace(timestep=env.model.opt("timestep"))
+        self._names = {1: dict(n["body"]), 3: dict(n["joint"]), 6: dict(n["site"])}
+
+    def _name2id(self, typ, name):
+        return self._names[typ].get(name, -1)
+
+
+class HandDataProxy:
+    def __init__(self, env):
+        self._env, s = env, env.sim
+        self.qpos, self.qvel, self.ctrl, self.act, self.time = s.qpos, s.qvel, s.ctrl, np.zeros(0), 0.0
+
+    @property
+    def site_xpos(self):
+        return self._env.sim.site_xpos.reshape(-1, 3)
+
+    def _step(self, nstep):
+        self._env.sim.step(nstep)
+
+    def _forward(self):
+        self._env.sim.forward()
+
+
+def hand_on_oracle(oracle_env, kind, **attrs):
+    """kind 'reach': the reference's MujocoHandReachEnv; 'manipulate': its MujocoManipulateEnv (block / egg / pen share the class) --
+    created without running the constructor, model / data proxied onto the oracle simulation; step() is BaseRobotEnv.step."""
+    mj = install()
+    from gymnasium_robotics.envs.shadow_dexterous_hand import manipulate, reach
+    from gymnasium_robotics.utils import mujoco_utils
+
+    cls = reach.MujocoHandReachEnv if kind == "reach" else manipulate.MujocoManipulateEnv
+    env = object.__new__(cls)
+    env.model, env.data = HandModelProxy(oracle_env), HandDataProxy(oracle_env)
+    env._mujoco, env._utils = mj, mujoco_utils
+    names = oracle_env.model.names["joint"]
+    env._model_names = types.SimpleNamespace(joint_names=[k for k in sorted(names, key=lambda k: names[k])])
+    env.n_substeps, env.render_mode, env.relative_control = 20, None, False
+    env.action_space = types.SimpleNamespace(shape=(20,), low=-np.ones(20, np.float32), high=np.ones(20, np.float32))
+    env.goal = oracle_env.goal.copy()
+    for k, v in attrs.items():
+        setattr(env, k, v)
+    return env
