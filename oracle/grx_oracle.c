@@ -14,9 +14,13 @@
  *   -> qacc_smooth -> constraint solve (exact Newton on the primal problem)
  *   -> semi-implicit Euler with implicit joint damping.
  *
- * PARITY UNPINNED: the reference's tests hold no post-mj_step golden vectors
- * (SURVEY.md §8(c)); this oracle is pinned only by the known-answer anchors in
- * tests/ (documented Fetch start pose, rest heights, conservation laws).
+ * PARITY UNPINNED for this file (the physics): the reference's tests hold no
+ * post-mj_step golden vectors; it is checked only by the
+ * known-answer anchors in tests/ (documented Fetch start pose, rest heights,
+ * conservation laws, analytic contact cases).  The Python task layers on top of
+ * it (oracle/*_oracle.py) ARE pinned: the reference's own step() / reset() code,
+ * executed on this physics through tests/ref_harness.py, reproduces them bit
+ * for bit (tests/test_cpu_reference_task_layer.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The model tables come from include/grx_model_fields.def.

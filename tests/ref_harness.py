@@ -32,6 +32,14 @@ def install():
     import make_reference_host_vectors as mk
 
     mk.install_stand_ins()
+    gym = sys.modules["gymnasium"]
+
+    # gymnasium.Env.reset seeds self.np_random with seeding.np_random(seed) = Generator(PCG64(SeedSequence(seed)))
+    def _env_reset(self, *, seed=None, options=None):
+        if seed is not None:
+            self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+    gym.Env.reset = _env_reset
+    gym.spaces.Dict = type("Dict", (), {"__init__": lambda self, spaces=None, **kw: setattr(self, "spaces", dict(spaces or {}))})
     mj = types.ModuleType("mujoco")
     mj._grx_stand_in = True
     mj.mjtEq = _Enum(mjEQ_CONNECT=0, mjEQ_WELD=1)
@@ -42,6 +50,7 @@ def install():
     mj.mj_name2id = lambda model, typ, name: model._name2id(typ, name)
     mj.mj_step = lambda model, data, nstep=1: data._step(nstep)
     mj.mj_forward = lambda model, data: data._forward()
+    mj.mj_resetData = lambda model, data: data._reset()
 
     def mj_jacSite(model, data, jacp, jacr, site_id):
         p, r = data._env.sim.jac_site(site_id)
@@ -105,6 +114,18 @@ class DataProxy:
     def _forward(self):
         self._env.sim.forward()
 
+    def _reset(self):
+        self._env.sim.reset_data()
+
+
+def _reset_attrs(env, oracle_env):
+    """what MujocoRobotEnv.__init__ stores for reset (robot_env.py:277-298)"""
+    import gymnasium
+
+    env.initial_time = 0.0
+    env.initial_qpos, env.initial_qvel = np.array(oracle_env.initial_qpos, dtype=np.float64).copy(), np.zeros(oracle_env.model.dim("nv"))
+    env.observation_space = gymnasium.spaces.Dict({"observation": None, "achieved_goal": None, "desired_goal": None})
+
 
 def fetch_on_oracle(oracle_env, reward_type="sparse"):
     """An instance of the reference's MujocoFetchEnv class (created without running its constructor: that needs MuJoCo) whose model /
@@ -127,6 +148,8 @@ def fetch_on_oracle(oracle_env, reward_type="sparse"):
     if cfg["has_object"]:
         env.height_offset = oracle_env.height_offset
     env.goal = oracle_env.goal.copy()
+    _reset_attrs(env, oracle_env)
+    env.initial_qvel = np.array(oracle_env.initial_qvel, dtype=np.float64).copy()
     return env
 
 
@@ -158,6 +181,9 @@ class HandDataProxy:
     def _forward(self):
         self._env.sim.forward()
 
+    def _reset(self):
+        self._env.sim.reset_data()
+
 
 def hand_on_oracle(oracle_env, kind, **attrs):
     """kind 'reach': the reference's MujocoHandReachEnv; 'manipulate': its MujocoManipulateEnv (block / egg / pen share the class) --
@@ -175,6 +201,7 @@ def hand_on_oracle(oracle_env, kind, **attrs):
     env.n_substeps, env.render_mode, env.relative_control = 20, None, False
     env.action_space = types.SimpleNamespace(shape=(20,), low=-np.ones(20, np.float32), high=np.ones(20, np.float32))
     env.goal = oracle_env.goal.copy()
+    _reset_attrs(env, oracle_env)
     for k, v in attrs.items():
         setattr(env, k, v)
     return env
