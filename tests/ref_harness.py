@@ -205,3 +205,66 @@ def hand_on_oracle(oracle_env, kind, **attrs):
     for k, v in attrs.items():
         setattr(env, k, v)
     return env
+
+
+def _install_mujoco_env_stand_in():
+    """gymnasium.envs.mujoco.mujoco_env.MujocoEnv [3P, absent]: only the three methods PointEnv relies on, restated from their
+    documented behaviour -- do_simulation (ctrl <- action, mj_step(n_frames)), set_state (qpos / qvel <- copies, mj_forward) and reset
+    (seed, mj_resetData, reset_model).  Everything else in the call chain (PointEnv, PointMazeEnv, MazeEnv, Maze) is the reference's."""
+    import gymnasium
+
+    if "gymnasium.envs.mujoco.mujoco_env" in sys.modules:
+        return
+    mj = sys.modules["mujoco"]
+
+    class MujocoEnv(gymnasium.Env):
+        def do_simulation(self, ctrl, n_frames):
+            if np.array(ctrl).shape != (self.model.nu,):
+                raise ValueError(f"Action dimension mismatch. Expected {(self.model.nu,)}, found {np.array(ctrl).shape}")
+            self.data.ctrl[:] = ctrl
+            mj.mj_step(self.model, self.data, nstep=n_frames)
+
+        def set_state(self, qpos, qvel):
+            self.data.qpos[:] = np.copy(qpos)
+            self.data.qvel[:] = np.copy(qvel)
+            mj.mj_forward(self.model, self.data)
+
+        def reset(self, *, seed=None, options=None):
+            super().reset(seed=seed)
+            mj.mj_resetData(self.model, self.data)
+            return self.reset_model(), {}
+
+    envs, mjmod, mjenv = types.ModuleType("gymnasium.envs"), types.ModuleType("gymnasium.envs.mujoco"), types.ModuleType("gymnasium.envs.mujoco.mujoco_env")
+    envs.__path__, mjmod.__path__ = [], []
+    mjenv.MujocoEnv = MujocoEnv
+    mjmod.mujoco_env, envs.mujoco, gymnasium.envs = mjenv, mjmod, envs
+    sys.modules.update({"gymnasium.envs": envs, "gymnasium.envs.mujoco": mjmod, "gymnasium.envs.mujoco.mujoco_env": mjenv})
+    # the maze package __init__ also imports the AntMaze classes, which subclass gymnasium's AntEnv [3P, absent]: placeholders so that
+    # the import succeeds (nothing of them is used)
+    for ver in ("ant_v4", "ant_v5"):
+        mod = types.ModuleType(f"gymnasium.envs.mujoco.{ver}")
+        mod.AntEnv = type("AntEnv", (MujocoEnv,), {})
+        setattr(mjmod, ver, mod)
+        sys.modules[f"gymnasium.envs.mujoco.{ver}"] = mod
+
+
+def point_maze_on_oracle(oracle_env, maze_map, reward_type, continuing_task, reset_target, xml_path):
+    """The reference's PointMazeEnv (constructor bypassed) with its own Maze built by the reference's Maze.make_maze from `maze_map`,
+    a reference PointEnv whose model / data are proxies onto the oracle simulation, and the reference's step() / reset()."""
+    install()
+    _install_mujoco_env_stand_in()
+    from gymnasium_robotics.envs.maze import maze_v4, point, point_maze
+
+    maze, _tmp = maze_v4.Maze.make_maze(xml_path, maze_map, 1, 0.4)
+    pe = object.__new__(point.PointEnv)
+    s = oracle_env.sim
+    pe.model = types.SimpleNamespace(nu=2, na=0, site_pos=np.zeros((4, 3)))
+    pe.data = types.SimpleNamespace(qpos=s.qpos, qvel=s.qvel, ctrl=s.ctrl, _step=lambda n: s.step(n), _forward=lambda: s.forward(), _reset=lambda: s.reset_data())
+    pe.frame_skip, pe.render_mode = 1, None
+    pe.init_qpos, pe.init_qvel = np.zeros(2), np.zeros(2)
+    env = object.__new__(point_maze.PointMazeEnv)
+    env.maze, env.point_env = maze, pe
+    env.reward_type, env.continuing_task, env.reset_target = reward_type, continuing_task, reset_target
+    env.position_noise_range, env.target_site_id, env.render_mode = 0.25, 0, None
+    env.observation_space = sys.modules["gymnasium"].spaces.Dict({"observation": None, "achieved_goal": None, "desired_goal": None})
+    return env

@@ -154,3 +154,49 @@ def test_reference_manipulate_reset_on_oracle_physics(env_id):
             assert np.array_equal(a_env.sim.qpos, b_env.sim.qpos)
     finally:
         type(ref.data).site_xpos = property(lambda self: self._env.sim.site_xpos.reshape(-1, 3))
+
+
+@pytest.mark.parametrize("layout,reward_type,continuing,reset_target", [("UMaze", "sparse", True, False), ("Medium_Diverse_GR", "dense", False, False),
+                                                                        ("Large_Diverse_G", "sparse", True, True)])
+def test_reference_point_maze_on_oracle_physics(layout, reward_type, continuing, reset_target):
+    """point_maze.py:375-406 (reset / step), point.py:55-77 (PointEnv.step: action clip, velocity clip, do_simulation), maze_v4.py:148-242
+    (Maze.make_maze), :278-418 (goal / reset sampling, noise, reward, termination, update_goal) executed as is; only gymnasium's MujocoEnv
+    base class is a stand-in (see ref_harness)."""
+    import os
+
+    from gymnasium_robotics_amd.envs import maze_spec
+    from gymnasium_robotics_amd.envs.point_maze import load_point_maze_model
+    from oracle.maze_oracle import OraclePointMazeEnv
+
+    base = layout.split("_")[0]
+    maze = maze_spec.Maze(maze_spec.MAPS[layout], maze_spec.POINT_MAZE_SIZE_SCALING, maze_spec.POINT_MAZE_HEIGHT)
+    model = load_point_maze_model(maze, base)
+    a_env = OraclePointMazeEnv(model, maze, reward_type, continuing, reset_target=reset_target)
+    b_env = OraclePointMazeEnv(model, maze, reward_type, continuing, reset_target=reset_target)
+    xml = os.path.join(ref_harness.REF_ROOT, "gymnasium_robotics", "envs", "assets", "point", "point.xml")
+    ref = ref_harness.point_maze_on_oracle(b_env, maze_spec.MAPS[layout], reward_type, continuing, reset_target, xml)
+    # the reference's own Maze against this package's
+    assert np.allclose(np.array(ref.maze.unique_goal_locations), np.array(maze.unique_goal_locations)) and np.allclose(np.array(ref.maze.unique_reset_locations), np.array(maze.unique_reset_locations))
+    rng = np.random.default_rng(0)
+    events = {"success": 0, "terminated": 0, "goal_redrawn": 0}
+    for seed in (0, 9):
+        oa, ia = a_env.reset(seed=seed, options={"goal_cell": np.array([1, 1]), "reset_cell": np.array([1, 2])} if seed == 9 and layout == "UMaze" else None)
+        ob, ib = ref.reset(seed=seed, options={"goal_cell": np.array([1, 1]), "reset_cell": np.array([1, 2])} if seed == 9 and layout == "UMaze" else None)
+        for k in ("observation", "achieved_goal", "desired_goal"):
+            assert np.array_equal(ob[k], oa[k]), (seed, k)
+        assert ib["success"] == ia["success"]
+        for t in range(150):
+            act = rng.uniform(-1.5, 1.5, 2).astype(np.float32)
+            if t >= 10:                           # then steer at the goal (straight-line: works where no wall is in between) so that success / termination / goal redraw happen
+                act = np.clip(6 * (a_env.goal - a_env.sim.qpos[:2]) - 1.5 * a_env.sim.qvel[:2], -1, 1).astype(np.float32)
+            g_before = a_env.goal.copy()
+            sa, sb = a_env.step(act), ref.step(act)
+            for k in ("observation", "achieved_goal", "desired_goal"):
+                assert np.array_equal(sb[0][k], sa[0][k]), (seed, t, k)
+            assert abs(float(sb[1]) - float(sa[1])) <= 1e-15 and bool(sb[2]) == bool(sa[2]) and bool(sb[3]) == bool(sa[3]) and sb[4]["success"] == sa[4]["success"]   # dense: exp(-d), last bit of libm vs numpy
+            assert np.array_equal(ref.goal, a_env.goal)
+            events["success"] += bool(sa[4]["success"]); events["terminated"] += bool(sa[2]); events["goal_redrawn"] += not np.array_equal(g_before, a_env.goal)
+            if sa[2]:
+                break
+    if layout == "UMaze":
+        assert events["success"] > 0, events                # neighbouring cells: the goal is reached
