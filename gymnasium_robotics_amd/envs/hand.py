@@ -307,7 +307,10 @@ class HandBlockVecEnv(HandReachVecEnv):
 
     GOAL_DIM = 7
 
-    def __init__(self, env_id: str = "HandManipulateBlockRotateXYZ-v1", num_envs: int = 1, max_episode_steps: Optional[int] = 100, **kw):
+    def __init__(self, env_id: str = "HandManipulateBlockRotateXYZ-v1", num_envs: int = 1, max_episode_steps: Optional[int] = 100,
+                 target_position: Optional[str] = None, target_rotation: Optional[str] = None, **kw):
+        # constructor overrides of the registered values, as gym.make(id, target_position="fixed") allows (tests/envs/hand/test_manipulate.py:21)
+        self._tp_override, self._tr_override = target_position, target_rotation
         super().__init__(env_id, num_envs, max_episode_steps=max_episode_steps, **kw)
 
     def _parse_id(self, env_id, reward_type):
@@ -316,6 +319,14 @@ class HandBlockVecEnv(HandReachVecEnv):
         from .manipulate_spec import OBJECTS, object_of
 
         self.target_position, self.target_rotation, rt, self.touch_get_obs = parse_block_id(env_id)
+        if self._tp_override is not None:
+            if self._tp_override not in ("ignore", "random", "fixed"):
+                raise ValueError(f'Unknown target_position option "{self._tp_override}".')
+            self.target_position = self._tp_override
+        if self._tr_override is not None:
+            if self._tr_override not in ("z", "parallel", "xyz"):      # "ignore" / "fixed" call a mujoco_py-only API in the reference (manipulate.py:270)
+                raise ValueError(f'Unknown target_rotation option "{self._tr_override}".')
+            self.target_rotation = self._tr_override
         self.object = object_of(env_id)
         self._objcfg = OBJECTS[self.object]
         self.distance_threshold = self._objcfg["distance_threshold"]

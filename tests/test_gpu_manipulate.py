@@ -151,3 +151,21 @@ def test_pen_variant_matches_golden_and_reference_distance():
     _, d_host = block_goal_distance(pose64(ref["qa"]), pose64(ref["qb"]), "ignore", "xyz", ignore_z=True)
     assert np.abs(d_host - d_ref).max() < 1e-6
     env.close(); dense.close()
+
+
+@pytest.mark.parametrize("env_id", ["HandManipulateEgg-v1", "HandManipulatePen-v1", "HandManipulateBlock-v1"])
+def test_serialize_deserialize_with_constructor_override(env_id):
+    """/root/reference/tests/envs/hand/test_manipulate.py:19-28: gym.make(id, target_position="fixed"), reset, pickle round trip."""
+    import pickle
+
+    import gymnasium_robotics_amd as grx
+
+    env1 = grx.make_vec(env_id, num_envs=2, device="cuda:0", target_position="fixed")
+    obs, _ = env1.reset(seed=0)
+    env2 = pickle.loads(pickle.dumps(env1))
+    assert env1.target_position == env2.target_position == "fixed"
+    # 'fixed': the goal position is the object's settled position (manipulate.py:239-242); positions count in the distance (not 'ignore')
+    assert np.array_equal(obs["desired_goal"][:, :3].astype(np.float32), obs["achieved_goal"][:, :3].astype(np.float32))
+    assert env1.task.ignore_position == 0
+    with pytest.raises(ValueError, match="Unknown target_rotation"):
+        grx.make_vec(env_id, num_envs=2, device="cuda:0", target_rotation="fixed")
