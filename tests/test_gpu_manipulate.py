@@ -153,9 +153,11 @@ def test_pen_variant_matches_golden_and_reference_distance():
     env.close(); dense.close()
 
 
-@pytest.mark.parametrize("env_id", ["HandManipulateEgg-v1", "HandManipulatePen-v1", "HandManipulateBlock-v1"])
+@pytest.mark.parametrize("env_id", ["HandManipulateEgg-v1", "HandManipulatePen-v1", "HandManipulateBlock-v1", "HandManipulateEgg_ContinuousTouchSensors-v1",
+                                    "HandManipulatePen_BooleanTouchSensors-v1", "HandManipulateBlock_BooleanTouchSensors-v1"])
 def test_serialize_deserialize_with_constructor_override(env_id):
-    """/root/reference/tests/envs/hand/test_manipulate.py:19-28: gym.make(id, target_position="fixed"), reset, pickle round trip."""
+    """/root/reference/tests/envs/hand/test_manipulate.py:19-28 and test_manipulate_touch_sensors.py:17-26: gym.make(id, target_position="fixed"),
+    reset, pickle round trip."""
     import pickle
 
     import gymnasium_robotics_amd as grx
