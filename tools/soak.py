@@ -1,0 +1,37 @@
+"""Long free-running rollouts with autoreset on one MI355X: finite outputs, capacity / bad-state flag rates, success rates.
+    python tools/soak.py [steps]   (run on the GPU box; summary to stdout)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch  # noqa: E402
+
+import gymnasium_robotics_amd as grx  # noqa: E402
+
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+CASES = [("FetchPickAndPlace-v4", 4096), ("FetchSlide-v4", 4096), ("HandReach-v3", 4096), ("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", 4096),
+         ("HandManipulateEggRotate-v1", 4096), ("AntMaze_Large_Diverse_GR-v5", 4096), ("PointMaze_Medium-v3", 4096)]
+for env_id, n in CASES:
+    env = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step")
+    obs, _ = env.reset(seed=0)
+    na = env.single_action_space.shape[0]
+    g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+    flags = {1: 0, 2: 0, 4: 0, 8: 0}
+    finite, succ, t0 = True, 0.0, time.time()
+    for t in range(STEPS):
+        obs, r, term, trunc, info = env.step(torch.rand(n, na, device="cuda:0", generator=g) * 2 - 1)
+        st = env.status
+        for b in flags:
+            flags[b] += int(((st & b) != 0).sum())
+        if t % 50 == 49:
+            finite = finite and bool(torch.isfinite(obs["observation"]).all()) and bool(torch.isfinite(r).all())
+            key = "is_success" if "is_success" in info else "success"
+            succ += float(torch.as_tensor(info[key]).float().mean())
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    tot = n * STEPS
+    print(f"{env_id}: {n} worlds x {STEPS} steps in {dt:.1f} s ({tot / dt:,.0f} env-steps/s incl. resets); finite {finite}; world-steps flagged: "
+          f"bad-number {flags[1]} ({100 * flags[1] / tot:.4f} %), contact-capacity {flags[2]} ({100 * flags[2] / tot:.4f} %), row/pool-capacity {flags[4]} "
+          f"({100 * flags[4] / tot:.4f} %), factorisation {flags[8]}; mean success rate at sampled steps {succ / max(1, STEPS // 50):.4f}")
+    env.close()
