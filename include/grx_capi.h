@@ -44,6 +44,14 @@ typedef struct grx_fetch_task {
   float distance_threshold, dt;
 } grx_fetch_task;
 
+/* bits of the per-world `status` words the step kernels write (0 = healthy; csrc/grx_engine.h GRX_ST_*) */
+enum grx_status_bits {
+  GRX_STATUS_BADNUM = 1,        /* a NaN / overflowing coordinate was found: the world was reset to qpos0 (MuJoCo's mj_checkPos / mj_checkVel behaviour) */
+  GRX_STATUS_CON_OVERFLOW = 2,  /* more contacts than the model's contact capacity in some substep: the excess was dropped for that substep */
+  GRX_STATUS_EFC_OVERFLOW = 4,  /* more constraint rows / Jacobian-pool words than the capacity: the excess contacts were dropped for that substep */
+  GRX_STATUS_FACTOR = 8         /* a non-positive pivot in a Cholesky factorisation (fallback solver path) */
+};
+
 /* mirrors struct GrxFetchBuffers: device pointers, world-major rows */
 typedef struct grx_fetch_buffers {
   float *qpos, *qvel, *qacc_ws, *mocap; /* [N,nq] [N,nv] [N,nv] [N,7*nmocap] */
