@@ -55,7 +55,7 @@ def lib():
         L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_float, ci, vp, vp]
         L.grx_manip_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]
-        L.grx_order_by_cost.argtypes = [vp, ci, vp, vp]
+        L.grx_order_by_cost.argtypes = [vp, vp, ctypes.c_float, ci, vp, vp]
         cd = ctypes.c_double
         L.grx_fetch_sample_resets.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         _lib = L

@@ -521,11 +521,20 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
 // (bitonic, descending cost, ties by world index) and writes order[i * 8 + slice] = the i-th most expensive world of the slice --
 // workgroup b of the next step launch runs on XCD b & 7 and starts in index order.
 extern "C" __global__ void __launch_bounds__(256)
-grx_order_kernel(const int* __restrict__ cost, int per, int npow2, int* __restrict__ order) {
+grx_order_kernel(const int* __restrict__ cost, float* __restrict__ ema, float alpha, int per, int npow2, int* __restrict__ order) {
   extern __shared__ unsigned long long keys[];
   const int s = blockIdx.x, base = s * per;
-  for (int i = threadIdx.x; i < npow2; i += 256)
-    keys[i] = i < per ? (((unsigned long long)(unsigned)cost[base + i] << 32) | (unsigned)(0x7FFFFFFF - i)) : 0ull;   // padding sorts last
+  for (int i = threadIdx.x; i < npow2; i += 256) {
+    unsigned k = 0;
+    if (i < per) {
+      // the sort key: the last cost, or its exponential moving average (a world's cost has a persistent part -- is the object in contact -- and
+      // a per-step part; averaging predicts the next step better than the last sample alone)
+      float c = (float)cost[base + i];
+      if (ema) { c = (1.0f - alpha) * ema[base + i] + alpha * c; ema[base + i] = c; }
+      k = (unsigned)fminf(fmaxf(c * 16.0f, 0.0f), 4.0e9f);
+    }
+    keys[i] = i < per ? (((unsigned long long)k << 32) | (unsigned)(0x7FFFFFFF - i)) : 0ull;   // padding sorts last
+  }
   __syncthreads();
   for (int k = 2; k <= npow2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -542,14 +551,15 @@ grx_order_kernel(const int* __restrict__ cost, int per, int npow2, int* __restri
   for (int i = threadIdx.x; i < per; i += 256) order[i * 8 + s] = base + (0x7FFFFFFF - (int)(unsigned)(keys[i] & 0xFFFFFFFFull));
 }
 
-extern "C" int grx_order_by_cost(const int* cost, int n_worlds, int* order, void* stream) {
+extern "C" int grx_order_by_cost(const int* cost, float* ema, float alpha, int n_worlds, int* order, void* stream) {
   if (!cost || !order) return fail("grx_order_by_cost: null argument");
+  if (ema && !(alpha > 0.0f && alpha <= 1.0f)) return fail("grx_order_by_cost: alpha must be in (0, 1]");
   if (n_worlds <= 0 || (n_worlds & 7)) return fail("grx_order_by_cost: the number of worlds must be a positive multiple of 8 (one contiguous slice per XCD)");
   const int per = n_worlds >> 3;
   int npow2 = 1;
   while (npow2 < per) npow2 <<= 1;
   if ((size_t)npow2 * 8 > 64 * 1024) return fail("grx_order_by_cost: more than 65536 worlds per launch are not supported");
-  hipLaunchKernelGGL(grx_order_kernel, dim3(8), dim3(256), (size_t)npow2 * 8, (hipStream_t)stream, cost, per, npow2, order);
+  hipLaunchKernelGGL(grx_order_kernel, dim3(8), dim3(256), (size_t)npow2 * 8, (hipStream_t)stream, cost, ema, alpha, per, npow2, order);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -124,8 +124,9 @@ int grx_model_dim(const grx_model* m, const char* name);
 int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, void* stream);
 int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream);
 /* order <- the dispatch order for the next step launch from the per-world costs the last one wrote (grx_fetch_buffers.cost /
- * grx_hand_buffers.cost): per XCD slice of n_worlds / 8 contiguous worlds, decreasing cost.  n_worlds must be a multiple of 8. */
-int grx_order_by_cost(const int* cost, int n_worlds, int* order, void* stream);
+ * grx_hand_buffers.cost): per XCD slice of n_worlds / 8 contiguous worlds, decreasing cost.  With `ema` the key is the exponential moving
+ * average ema <- (1 - alpha) ema + alpha cost, kept in the caller's buffer (measured best around alpha = 0.15).  n_worlds must be a multiple of 8. */
+int grx_order_by_cost(const int* cost, float* ema /* [N] in/out or NULL */, float alpha, int n_worlds, int* order, void* stream);
 int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
                              float* reward_out, void* stream);
 /* Maze family (PointMaze and AntMaze, selected by task->agent; AntMazeEnv.step: envs/maze/ant_maze_v5.py:295-310).

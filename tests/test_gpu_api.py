@@ -96,7 +96,7 @@ def test_order_by_cost_and_balance_invariance():
     g = torch.Generator(device="cuda:0"); g.manual_seed(0)
     cost = torch.randint(0, 5000, (n,), device="cuda:0", generator=g, dtype=torch.int32)
     order = torch.full((n,), -1, device="cuda:0", dtype=torch.int32)
-    _native.check(L.grx_order_by_cost(cost.data_ptr(), n, order.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    _native.check(L.grx_order_by_cost(cost.data_ptr(), None, 0.0, n, order.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     o, c = order.cpu().numpy().reshape(n // 8, 8), cost.cpu().numpy()
     assert sorted(o.ravel().tolist()) == list(range(n))                       # a permutation
@@ -107,7 +107,11 @@ def test_order_by_cost_and_balance_invariance():
         key = np.stack([-c[w].astype(np.int64), w.astype(np.int64)], axis=1)
         assert (np.lexsort((key[:, 1], key[:, 0])) == np.arange(per)).all()   # decreasing cost, ties by index
     with pytest.raises(RuntimeError, match="multiple of 8"):
-        _native.check(L.grx_order_by_cost(cost.data_ptr(), 1001, order.data_ptr(), None))
+        _native.check(L.grx_order_by_cost(cost.data_ptr(), None, 0.0, 1001, order.data_ptr(), None))
+    ema = torch.full((n,), 100.0, device="cuda:0")
+    _native.check(L.grx_order_by_cost(cost.data_ptr(), ema.data_ptr(), 0.25, n, order.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.allclose(ema.cpu().numpy(), 75.0 + 0.25 * c, rtol=1e-6)
     a = grx.make_vec("FetchPickAndPlace-v4", num_envs=1024, device="cuda:0", balance=True)
     b = grx.make_vec("FetchPickAndPlace-v4", num_envs=1024, device="cuda:0", balance=False)
     assert a.balance and not b.balance
