@@ -31,13 +31,16 @@ def run(cmd, log):
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=f, stderr=subprocess.STDOUT, check=False)
 
 
-def kernel_stats(tag):
-    d = os.path.join(OUT, f"rocprof_{tag}")
+def kernel_stats(tag, workload=None):
+    """workload: one of bench.py's --workload names (antmaze, hand_touch, hand_reach): kernel stats of that BASELINE config instead of cfg 2"""
+    suffix = f"_{workload}" if workload else ""
+    d = os.path.join(OUT, f"rocprof_{tag}{suffix}")
+    extra = ["--workload", workload] if workload else []
     cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-           "--steps", "30", "--warmup", "5", "--no-cpu-baseline"]
-    run(cmd, os.path.join(OUT, f"rocprof_{tag}.log"))
+           "--steps", "30", "--warmup", "5", "--no-cpu-baseline"] + extra
+    run(cmd, os.path.join(OUT, f"rocprof_{tag}{suffix}.log"))
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
-    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline   (MI355X, build '{tag}')",
+    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline {' '.join(extra)}  (MI355X, build '{tag}')",
              "source: top_kernels view of the rocprofv3 results database; durations in us",
              "name | total_calls | total_duration_us | average_us | percentage"]
     if dbs:
@@ -47,7 +50,7 @@ def kernel_stats(tag):
             lines.append(f"{short} | {calls} | {total:.0f} | {avg:.1f} | {pct:.3f}")
     else:
         lines.append("(no results database produced -- see the log)")
-    with open(os.path.join(OUT, f"rocprof_{tag}_kernel_stats.txt"), "w") as f:
+    with open(os.path.join(OUT, f"rocprof_{tag}_kernel_stats{suffix}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines[:6]))
 
@@ -129,6 +132,10 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[2] == "sq":
         sq_mix(tag)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "workloads":      # kernel stats of the other BASELINE configs
+        for w in ("antmaze", "hand_touch", "hand_reach"):
+            kernel_stats(tag, w)
         sys.exit(0)
     kernel_stats(tag)
     pmc(tag)
