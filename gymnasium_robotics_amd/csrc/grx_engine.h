@@ -82,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj;
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance;
   int mpr_iterations;
 };
@@ -651,11 +651,11 @@ static __device__ __forceinline__ float grx_rcp_refined(float d) { float r = __b
 // (one readlane + one fma per remaining column) and every lane i < k subtracts its multiple of it; rows end up lower
 // triangular, pivots final when they are used.  The forward substitution then needs one broadcast per unknown.
 template <int NS>
-  static __device__ __forceinline__ void grx_sym_solve_reg(const float* A, float* x, int lane_) {
+  static __device__ __forceinline__ void grx_sym_solve_reg(const float* A, int ld, float* x, int lane_) {
   float a[NS];
   const int row = lane_ < NS ? lane_ : 0;
 #pragma unroll
-  for (int i = 0; i < NS; i++) a[i] = A[row * NS + i];
+  for (int i = 0; i < NS; i++) a[i] = A[row * ld + i];     // ld: row stride (a diagonal block of a larger matrix can be solved in place)
   float b = x[row], rd = 0.0f;
 #pragma unroll
   for (int k = NS - 1; k > 0; k--) {
@@ -681,13 +681,19 @@ template <int NS>
 }
 #endif
 
-GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_) {
+// nsplit: the last nsplit (= 6) dofs are a free object whose block of A is decoupled from the rest (all entries between the two
+// blocks are exactly zero: always true for M + h B, true for the Hessian while no contact links object and robot).  The two diagonal
+// blocks are then solved one after the other -- the same arithmetic as the full elimination, in which every multiplier between the
+// blocks is an exact zero, at (nr^2 + 36) / n^2 of its broadcasts (15 + 6 instead of 21: 43 % fewer).
+GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit = 0) {
 #if !defined(GRX_EMU)
-  if (n == 21) { grx_sym_solve_reg<21>(A, x, lane_); return 0; }
-  if (n == 14) { grx_sym_solve_reg<14>(A, x, lane_); return 0; }
-  if (n == 15) { grx_sym_solve_reg<15>(A, x, lane_); return 0; }
-  if (n == 24) { grx_sym_solve_reg<24>(A, x, lane_); return 0; }
-  if (n == 30) { grx_sym_solve_reg<30>(A, x, lane_); return 0; }
+  if (nsplit == 6 && n == 21) { grx_sym_solve_reg<15>(A, n, x, lane_); grx_sym_solve_reg<6>(A + 15 * n + 15, n, x + 15, lane_); return 0; }
+  if (nsplit == 6 && n == 30) { grx_sym_solve_reg<24>(A, n, x, lane_); grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_); return 0; }
+  if (n == 21) { grx_sym_solve_reg<21>(A, n, x, lane_); return 0; }
+  if (n == 14) { grx_sym_solve_reg<14>(A, n, x, lane_); return 0; }
+  if (n == 15) { grx_sym_solve_reg<15>(A, n, x, lane_); return 0; }
+  if (n == 24) { grx_sym_solve_reg<24>(A, n, x, lane_); return 0; }
+  if (n == 30) { grx_sym_solve_reg<30>(A, n, x, lane_); return 0; }
 #endif
 #if defined(GRX_EMU)
   if (n == 21 || n == 14 || n == 15 || n == 24 || n == 30) {   // mirror the device: these sizes are solved without touching A
@@ -2302,8 +2308,22 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       rhs = c->qacc_smooth;
     }
     // ---- the one linear solve
-    if (!(phase == 1 && !implicit_damp))
-      if (grx_sym_solve_full(c->A, nv, rhs, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+    if (!(phase == 1 && !implicit_damp)) {
+      // a trailing free object (m->nfreeobj = 6): M + h B is always block diagonal; the Hessian is while no active row links object and robot
+      int nsplit = 0;
+      if (m->nfreeobj == 6 && (nv == 21 || nv == 30)) {
+        if (phase == 0) {
+          GRX_LANEVAR_I(nzp);
+          FOR_LANES {
+            int nz = 0;
+            for (int e = lane; e < (nv - 6) * 6; e += 64) { const int i = e / 6, j = nv - 6 + (e - 6 * i); nz |= (c->A[i * nv + j] != 0.0f) | (c->A[j * nv + i] != 0.0f); }
+            LV(nzp) = nz;
+          }
+          nsplit = (GRX_BALLOT(nzp) == 0ull) ? 6 : 0;
+        } else nsplit = 6;
+      }
+      if (grx_sym_solve_full(c->A, nv, rhs, lane_, nsplit)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+    }
     if (phase == 0) {
       GRX_TICK(c, GRX_P_NFACTOR);
       // Mv, Jv, quadratic coefficients of the Gauss term along the direction

@@ -38,6 +38,12 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.integrator = d[GRX_INTEGRATOR];
   m.njump = m.nbody > 0 ? v.n_body_jump / m.nbody : 0;
   m.ntendon = v.n_tendon_adr; m.ntouch = v.n_touch_body;
+  // trailing free object: the last joint is a free joint of a body hanging off the world (its 6 dofs are the last ones and M has no entries
+  // between them and the other dofs)
+  m.nfreeobj = 0;
+  if (m.njnt > 1 && m.nv > 6 && v.jnt_type[m.njnt - 1] == GRX_JNT_FREE && v.jnt_dofadr[m.njnt - 1] == m.nv - 6 &&
+      v.body_parent[v.jnt_bodyid[m.njnt - 1]] == 0)
+    m.nfreeobj = 6;
   m.twospan = 0;
   for (int k = 0; k < v.n_pair_span; k++) if (((unsigned)v.pair_span[k] >> 24) != 0) m.twospan = 1;
   // candidate pairs that go to the general convex (MPR) narrow phase: only the generic kernels carry that code
