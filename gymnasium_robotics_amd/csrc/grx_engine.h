@@ -1706,6 +1706,12 @@ GRX_MEM float grx_row_dot(const GrxCtx* c, int r, const float* v) {
 }
 
 GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
+#if !defined(GRX_EMU)
+  // The lane index is made opaque for this stage: its cheap lane-derived values (packed row descriptors) are then recomputed here
+  // instead of being hoisted out of the 20-substep loop, kept live across it and spilled to scratch (one dword per lane, but written
+  // back to HBM by every wave).  Doing this for the whole pass costs more recomputation than it saves (measured -3 % on the hand models).
+  asm volatile("" : "+v"(lane_));
+#endif
   GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC;
   const int ncon = c->cnt[0];
@@ -1790,7 +1796,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (m->weld_eq[w] << 4) | sub;
       c->efc_row[r] = info0 + sub * GRX_ROW_LEN(info0);  // the offset field is the low one: adding sub*len moves to row sub
     }
-    if (nf > 0)
+    if ((S::kFixed ? S::NF > 0 : true) && nf > 0)   // compile-time dead for the shapes without friction-loss dofs
       for (int d = lane; d < nv; d += 64) {
         if (m->dof_frictionloss[d] > 0) {
           int r = ne; for (int q = 0; q < d; q++) if (m->dof_frictionloss[q] > 0) r++;
