@@ -44,6 +44,8 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   if (m.njnt > 1 && m.nv > 6 && v.jnt_type[m.njnt - 1] == GRX_JNT_FREE && v.jnt_dofadr[m.njnt - 1] == m.nv - 6 &&
       v.body_parent[v.jnt_bodyid[m.njnt - 1]] == 0)
     m.nfreeobj = 6;
+  m.ngridgeom = v.n_grid_geom; m.ngridwall = v.n_grid_wall_geom; m.gridnx = m.gridny = 0; m.gridx0 = m.gridy0 = m.gridinv = 0.0f;
+  if (v.n_grid_param >= 5) { m.gridx0 = (float)v.grid_param[0]; m.gridy0 = (float)v.grid_param[1]; m.gridinv = (float)v.grid_param[2]; m.gridnx = (int)v.grid_param[3]; m.gridny = (int)v.grid_param[4]; }
   m.twospan = 0;
   for (int k = 0; k < v.n_pair_span; k++) if (((unsigned)v.pair_span[k] >> 24) != 0) m.twospan = 1;
   // candidate pairs that go to the general convex (MPR) narrow phase: only the generic kernels carry that code

@@ -1512,7 +1512,51 @@ class _Lowering:
         T["pair_span"] = pair_span.astype(np.uint32).view(np.int32) if npair else np.zeros(0, np.int32)
         if ng >= 4096:
             raise ValueError("engine limit: at most 4095 geoms (packed candidate records)")
-        dp = T["devpair"]
+        # Wall lattice (maze layouts): world-fixed, axis-aligned boxes of one size on a regular xy grid.  A moving sphere / capsule can only
+        # touch the walls of the 3 x 3 cells around it, so its wall pairs leave the flat candidate list (819 sphere tests per pass for
+        # AntMaze_Large) and are looked up through the cell table instead: grid_param = (x0, y0, 1 / cell, nx, ny), grid_cell[iy * nx + ix] =
+        # wall number or -1, grid_wall_geom[wall] = geom id, grid_geom[k] = the k-th moving geom (| type << 12), grid_geom_bound[k] = (broad-phase radius incl. margin, margin), grid_pair[k * nwall + wall] = pair index.
+        dp = np.asarray(T["devpair"]).astype(np.int64)
+        T["grid_param"], T["grid_cell"], T["grid_wall_geom"], T["grid_geom"], T["grid_pair"] = np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
+        T["grid_geom_bound"] = np.zeros(0)
+        ident = np.array([1.0, 0.0, 0.0, 0.0])
+        walls = [gi for gi in range(ng) if geom_type[gi] == GEOM_BOX and geom_bodyid[gi] == 0 and np.abs(np.abs(geom_quat[gi]) - ident).max() < 1e-12]
+        if len(walls) >= 8:
+            sz = geom_size[walls]
+            cell = 2.0 * sz[0, 0]
+            same = np.abs(sz - sz[0]).max() < 1e-12 and abs(sz[0, 0] - sz[0, 1]) < 1e-12 and np.abs(geom_pos[walls][:, 2] - geom_pos[walls[0]][2]).max() < 1e-12
+            xy = geom_pos[walls][:, :2]
+            ij = (xy - xy.min(axis=0)) / cell
+            if same and np.abs(ij - np.round(ij)).max() < 1e-9:
+                ij = np.round(ij).astype(int)
+                nx_, ny_ = int(ij[:, 0].max()) + 1, int(ij[:, 1].max()) + 1
+                cellmap = -np.ones((ny_, nx_), np.int32)
+                for w_, (ix_, iy_) in enumerate(ij):
+                    cellmap[iy_, ix_] = w_
+                wall_no = {gi: w_ for w_, gi in enumerate(walls)}
+                pair_of = {}
+                for pi_ in dp:
+                    a_, b_ = int(pair_geom1[pi_]), int(pair_geom2[pi_])
+                    if b_ in wall_no and geom_type[a_] in (GEOM_SPHERE, GEOM_CAPSULE) and geom_bodyid[a_] != 0:
+                        pair_of[(a_, wall_no[b_])] = int(pi_)
+                movers = sorted({a_ for a_, _ in pair_of})
+                movers = [a_ for a_ in movers if all((a_, w_) in pair_of for w_ in range(len(walls)))]
+                # a mover must fit into the 3 x 3 neighbourhood: bounding radius + margin below half a cell
+                movers = [a_ for a_ in movers if geom_rbound[a_] + max(pair_margin[pair_of[(a_, w_)]] for w_ in range(len(walls))) < 0.5 * cell]
+                if movers:
+                    x0_, y0_ = xy.min(axis=0) - 0.5 * cell
+                    T["grid_param"] = np.array([x0_, y0_, 1.0 / cell, nx_, ny_], dtype=np.float64)
+                    T["grid_cell"], T["grid_wall_geom"] = cellmap.reshape(-1), np.array(walls, np.int32)
+                    T["grid_geom"] = np.array([a_ | (int(geom_type[a_]) << 12) for a_ in movers], np.int32)      # geom id | type << 12
+                    # per mover: broad-phase radius (its own + the walls' + margin) and the pair margin (one value per mover: checked)
+                    mg = [sorted({float(pair_margin[pair_of[(a_, w_)]]) for w_ in range(len(walls))}) for a_ in movers]
+                    assert all(len(x_) == 1 for x_ in mg)
+                    T["grid_geom_bound"] = np.array([[geom_rbound[a_] + geom_rbound[walls[0]] + mg[k_][0], mg[k_][0]] for k_, a_ in enumerate(movers)], dtype=np.float64).reshape(-1)
+                    T["grid_pair"] = np.array([[pair_of[(a_, w_)] for w_ in range(len(walls))] for a_ in movers], np.int32).reshape(-1)
+                    gridded = set(T["grid_pair"].tolist())
+                    dp = np.array([pi_ for pi_ in dp if int(pi_) not in gridded], dtype=np.int64)
+                    T["devpair"] = dp.astype(np.int32)
+                    info["grid"] = dict(nx=nx_, ny=ny_, walls=len(walls), movers=len(movers), pairs_left=len(dp))
         g1s, g2s = pair_geom1[dp], pair_geom2[dp]
         T["devpair_geoms"] = (g1s | (g2s << 12) | (geom_type[g1s] << 24) | (geom_type[g2s] << 28)).astype(np.int64).astype(np.uint32).view(np.int32) if len(dp) else np.zeros(0, np.int32)
         T["devpair_bound"] = np.stack([pair_margin[dp], np.where(geom_type[g1s] == GEOM_PLANE, geom_rbound[g2s], geom_rbound[g1s] + geom_rbound[g2s])], axis=1) if len(dp) else np.zeros((0, 2))
