@@ -2242,8 +2242,8 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
     if (phase == 0) {
       // After a step, M a and J a - aref are current (carried) and convergence has already been decided: the only thing the evaluation would
       // still produce are the row forces, which nothing reads after the solve unless the model has touch sensors.
-      const int skip_eval = done && it > 0 && S::kIncrHess && (S::kFixed ? S::NT : m->ntouch) == 0;
-      const int changed = skip_eval ? 0 : grx_newton_eval(m, c, c->qacc, nefc, it > 0 && S::kIncrHess, lane_);
+      const int skip_eval = done && it > 0 && (S::kFixed ? S::NT : m->ntouch) == 0;
+      const int changed = skip_eval ? 0 : grx_newton_eval(m, c, c->qacc, nefc, it > 0, lane_);
       GRX_TICK(c, GRX_P_NEVAL);
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
@@ -2399,7 +2399,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       FOR_LANES {
         float ms = 0, ma = 0;
         for (int i = lane; i < nv; i += 64) { float d = alpha * c->search[i]; float q = c->qacc[i] + d; c->qacc[i] = q; ms = fmaxf(ms, fabsf(d)); ma = fmaxf(ma, fabsf(q)); }
-        if (S::kIncrHess) {   // carry M a and J a - aref along the step: the next evaluation only re-derives row states and forces
+        {   // carry M a and J a - aref along the step: the next evaluation only re-derives row states and forces
           for (int i = lane; i < nv; i += 64) c->Ma[i] += alpha * c->Mv[i];
           for (int r = lane; r < nefc; r += 64) c->efc_jar[r] += alpha * c->efc_jv[r];
         }
@@ -2418,7 +2418,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       if (stepmax <= GRX_NEWTON_RTOL * qmax + GRX_NEWTON_ATOL) done = 1;
       // an exact full step (no row changes state on [0,1], decided with the very arithmetic the carried evaluation would repeat) lands on
       // the minimiser of the current piece and leaves every row in its state: converged
-      if (S::kIncrHess && full_step == 2) done = 1;
+      if (full_step == 2) done = 1;
     } else if (phase == 2) {
       FOR_LANES { for (int i = lane; i < nv; i += 64) { float q = c->qacc_smooth[i]; c->qacc[i] = q; c->qacc_ws[i] = q; c->qfrc_constraint[i] = 0; } }
       WAVE_SYNC();
