@@ -51,6 +51,20 @@ class GoalVecEnv:
     def compute_truncated(self, achieved_goal, desired_goal, info):
         raise NotImplementedError
 
+    # The step kernel is launched on the caller's stream and `step` returns without waiting for it when output="torch"; the split below is the
+    # AsyncVectorEnv-style [3P] spelling of that: launch, do something else on the host (policy inference of the previous batch), collect.
+    def step_async(self, actions):
+        self._pending_step = self.step(actions)
+
+    def step_wait(self):
+        import torch
+
+        if getattr(self, "_pending_step", None) is None:
+            raise RuntimeError("step_wait() called without a pending step_async()")
+        out, self._pending_step = self._pending_step, None
+        torch.cuda.current_stream(self.device).synchronize()
+        return out
+
     def close(self):
         pass
 

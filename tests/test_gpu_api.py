@@ -153,3 +153,18 @@ def test_device_rewards_equal_the_reference_run_vectors():
         clear = (np.abs(ref[f"manip_{tag}_dpos"] - 0.01) > 1e-5) & (np.abs(ref[f"manip_{tag}_drot"] - 0.1) > 1e-4)
         # dense: -(10 d_pos + d_rot); the fp32 angle of two nearly identical orientations carries ~3e-4 rad of rounding (2 atan2 of a 1e-4 sine)
         assert np.allclose(r[clear], ref[f"manip_{tag}_reward_{key}"][clear], rtol=0, atol=1e-3 if key == "dense" else 0), (env_id, np.abs(r - ref[f"manip_{tag}_reward_{key}"])[clear].max())
+
+
+def test_step_async_wait_equals_step():
+    import gymnasium_robotics_amd as grx
+
+    a = grx.make_vec("FetchPush-v4", num_envs=64, device="cuda:0", output="torch")
+    b = grx.make_vec("FetchPush-v4", num_envs=64, device="cuda:0", output="torch")
+    a.reset(seed=1); b.reset(seed=1)
+    act = np.random.default_rng(0).uniform(-1, 1, (64, 4)).astype(np.float32)
+    with pytest.raises(RuntimeError, match="without a pending"):
+        a.step_wait()
+    a.step_async(act)
+    oa = a.step_wait()
+    ob = b.step(act)
+    assert bool((oa[0]["observation"] == ob[0]["observation"]).all()) and bool((oa[1] == ob[1]).all())
