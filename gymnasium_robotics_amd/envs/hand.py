@@ -18,7 +18,7 @@ from ..core import GoalVecEnv, np_random
 from ..mjcf import CompiledModel, compile_mjcf, load_model
 from ..spaces import Box, Dict, batch_space
 from .hand_spec import (DISTANCE_THRESHOLD, MAX_EPISODE_STEPS, N_ACTIONS, initial_qpos_vector, make_hand_task, parse_hand_reach_id,
-                        sample_hand_reach_goal)
+                        sample_hand_reach_goal, sample_hand_reach_goal_batch)
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
 GOAL_DIM = 15
@@ -163,7 +163,7 @@ class HandReachVecEnv(GoalVecEnv):
     def _reset_worlds(self, idx):
         if len(idx) == 0:
             return
-        goals = np.stack([sample_hand_reach_goal(self.np_randoms[w], self.initial_goal, self.palm_xpos) for w in idx])
+        goals = sample_hand_reach_goal_batch([self.np_randoms[w] for w in idx], self.initial_goal, self.palm_xpos)
         ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
         self.qpos[ti] = self._initial_qpos
         self.qvel[ti] = 0.0
@@ -359,7 +359,7 @@ class HandBlockVecEnv(HandReachVecEnv):
     # holds -- robot_env.py:163-171) and :226-279 (_sample_goal from the settled pose).  The reference does not call mj_resetData
     # here, so the warm start of the previous episode survives the reset.
     def _reset_worlds(self, idx):
-        from .manipulate_spec import PALM_HEIGHT, SETTLE_STEPS, sample_block_goal, sample_reset_object_pose
+        from .manipulate_spec import PALM_HEIGHT, SETTLE_STEPS, sample_block_goal_batch, sample_reset_object_pose_batch
 
         if len(idx) == 0:
             return
@@ -368,8 +368,8 @@ class HandBlockVecEnv(HandReachVecEnv):
         saved_action = self.action.clone()
         while len(pending):
             self.reset_attempts[pending] += 1
-            poses = np.stack([sample_reset_object_pose(self.np_randoms[w], self._obj0[:3], self._obj0[3:], self.target_position, self.target_rotation,
-                                                       self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"]) for w in pending])
+            poses = sample_reset_object_pose_batch([self.np_randoms[w] for w in pending], self._obj0[:3], self._obj0[3:], self.target_position, self.target_rotation,
+                                                   self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"])
             ti = torch.from_numpy(pending).to(self.device)
             q = self._initial_qpos.unsqueeze(0).repeat(len(pending), 1)
             q[:, self._qa: self._qa + 7] = torch.from_numpy(poses.astype(np.float32)).to(self.device)
@@ -385,7 +385,7 @@ class HandBlockVecEnv(HandReachVecEnv):
         self.action.copy_(saved_action)
         ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
         obj = self.qpos[ti, self._qa: self._qa + 7].double().cpu().numpy()
-        goals = np.stack([sample_block_goal(self.np_randoms[w], obj[k], self.target_position, self.target_rotation, self._pquats) for k, w in enumerate(idx)])
+        goals = sample_block_goal_batch([self.np_randoms[w] for w in idx], obj, self.target_position, self.target_rotation, self._pquats)
         self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False

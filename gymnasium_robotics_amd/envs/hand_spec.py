@@ -68,6 +68,29 @@ def sample_hand_reach_goal(np_random: np.random.Generator, initial_goal: np.ndar
     return goal.reshape(-1)
 
 
+def sample_hand_reach_goal_batch(np_randoms, initial_goal: np.ndarray, palm_xpos: np.ndarray) -> np.ndarray:
+    """sample_hand_reach_goal for many worlds: three draws per world from its own generator (finger index, 3 normals, 1 uniform -- the
+    reference's order), the geometry once on arrays."""
+    n = len(np_randoms)
+    fi, noise, stay = np.zeros(n, np.int64), np.zeros((n, 3)), np.zeros(n)
+    finger_of = np.array([FINGERTIP_SITE_NAMES.index(f) for f in _FINGERS])
+    for k, r in enumerate(np_randoms):
+        fi[k] = r.integers(0, len(_FINGERS))
+        noise[k] = r.normal(scale=0.005, size=3)
+        stay[k] = r.uniform()
+    meeting = np.asarray(palm_xpos, dtype=np.float64) + _MEET_OFFSET
+    meeting = meeting + noise                                            # [n, 3]
+    goal = np.tile(np.array(initial_goal, dtype=np.float64).reshape(1, -1, 3), (n, 1, 1))
+    rows = np.arange(n)
+    for idx in (np.full(n, _THUMB_IDX), finger_of[fi]):
+        d = meeting - goal[rows, idx]
+        d = d / np.sqrt(d[:, 0:1] * d[:, 0:1] + d[:, 1:2] * d[:, 1:2] + d[:, 2:3] * d[:, 2:3])
+        goal[rows, idx] = meeting - 0.005 * d
+    goal = goal.reshape(n, -1)
+    goal[stay < 0.1] = np.array(initial_goal, dtype=np.float64).reshape(-1)
+    return goal
+
+
 def hand_reach_reward(achieved, desired, reward_type="sparse"):
     """reach.py:92-97."""
     d = np.linalg.norm(np.asarray(achieved) - np.asarray(desired), axis=-1)

@@ -197,6 +197,81 @@ def sample_block_goal(np_random, object_qpos, target_position, target_rotation, 
     return np.concatenate([target_pos, target_quat])
 
 
+def _quat_from_angle_and_axis_batch(angle, axis):
+    axis = axis / np.linalg.norm(axis, axis=-1, keepdims=True)
+    q = np.concatenate([np.cos(angle / 2.0)[:, None], np.sin(angle / 2.0)[:, None] * axis], axis=-1)
+    return q / np.linalg.norm(q, axis=-1, keepdims=True)
+
+
+def _draw_rotation(np_randoms, target_rotation, npar):
+    """per-world draws of one random rotation, in the reference's order: angle [, parallel index | axis]"""
+    n = len(np_randoms)
+    ang, axis, pidx = np.zeros(n), np.tile(np.array([0.0, 0.0, 1.0]), (n, 1)), np.zeros(n, np.int64)
+    for k, r in enumerate(np_randoms):
+        ang[k] = r.uniform(-np.pi, np.pi)
+        if target_rotation == "parallel":
+            pidx[k] = r.integers(npar)
+        elif target_rotation != "z":
+            axis[k] = r.uniform(-1.0, 1.0, size=3)
+    return ang, axis, pidx
+
+
+def sample_reset_object_pose_batch(np_randoms, initial_pos, initial_quat, target_position, target_rotation, pquats=None,
+                                   randomize_initial_rotation=True, randomize_initial_position=True):
+    """sample_reset_object_pose for many worlds: the draws come from each world's own generator in the reference's order, the quaternion
+    algebra runs once on arrays (a reset of 4 096 worlds spent 170 ms in per-world numpy calls)."""
+    n = len(np_randoms)
+    pos, quat = np.tile(np.asarray(initial_pos, dtype=np.float64), (n, 1)), np.tile(np.asarray(initial_quat, dtype=np.float64), (n, 1))
+    if target_rotation not in ("z", "parallel", "xyz", "ignore", "fixed"):
+        raise ValueError(f'Unknown target_rotation option "{target_rotation}".')
+    rotate = randomize_initial_rotation and target_rotation != "fixed"
+    move = randomize_initial_position and target_position != "fixed"
+    ang = axis = pidx = None
+    noise = np.zeros((n, 3))
+    if rotate and move:          # both kinds of draws interleave per world: angle [..], then the position noise
+        ang, axis, pidx = np.zeros(n), np.tile(np.array([0.0, 0.0, 1.0]), (n, 1)), np.zeros(n, np.int64)
+        for k, r in enumerate(np_randoms):
+            a_, x_, p_ = _draw_rotation([r], target_rotation, len(pquats) if pquats is not None else 0)
+            ang[k], axis[k], pidx[k] = a_[0], x_[0], p_[0]
+            noise[k] = r.normal(size=3, scale=0.005)
+    elif rotate:
+        ang, axis, pidx = _draw_rotation(np_randoms, target_rotation, len(pquats) if pquats is not None else 0)
+    elif move:
+        for k, r in enumerate(np_randoms):
+            noise[k] = r.normal(size=3, scale=0.005)
+    if rotate:
+        off = _quat_from_angle_and_axis_batch(ang, axis)
+        if target_rotation == "parallel":
+            off = quat_mul(off, np.asarray(pquats)[pidx])
+        quat = quat_mul(quat, off)
+    pos = pos + noise
+    quat = quat / np.linalg.norm(quat, axis=-1, keepdims=True)
+    return np.concatenate([pos, quat], axis=-1)
+
+
+def sample_block_goal_batch(np_randoms, object_qpos, target_position, target_rotation, pquats=None):
+    """sample_block_goal for many worlds (object_qpos [n, 7]): per-world draws, array algebra."""
+    object_qpos = np.asarray(object_qpos, dtype=np.float64)
+    n = len(np_randoms)
+    if target_position not in ("random", "ignore", "fixed"):
+        raise ValueError(f'Unknown target_position option "{target_position}".')
+    if target_rotation not in ("z", "parallel", "xyz"):
+        raise ValueError(f'Unknown target_rotation option "{target_rotation}".')
+    offset = np.zeros((n, 3))
+    ang, axis, pidx = np.zeros(n), np.tile(np.array([0.0, 0.0, 1.0]), (n, 1)), np.zeros(n, np.int64)
+    for k, r in enumerate(np_randoms):
+        if target_position == "random":
+            offset[k] = r.uniform(TARGET_POSITION_RANGE[:, 0], TARGET_POSITION_RANGE[:, 1])
+        a_, x_, p_ = _draw_rotation([r], target_rotation, len(pquats) if pquats is not None else 0)
+        ang[k], axis[k], pidx[k] = a_[0], x_[0], p_[0]
+    target_pos = object_qpos[:, :3] + offset
+    target_quat = _quat_from_angle_and_axis_batch(ang, axis)
+    if target_rotation == "parallel":
+        target_quat = quat_mul(target_quat, np.asarray(pquats)[pidx])
+    target_quat = target_quat / np.linalg.norm(target_quat, axis=-1, keepdims=True)
+    return np.concatenate([target_pos, target_quat], axis=-1)
+
+
 def block_goal_distance(goal_a, goal_b, target_position, target_rotation, ignore_z=False):
     """manipulate.py:87-118; ignore_z (pen variants): quat_a takes the z Euler angle of quat_b before the comparison."""
     goal_a, goal_b = np.asarray(goal_a, dtype=np.float64), np.asarray(goal_b, dtype=np.float64)

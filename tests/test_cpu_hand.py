@@ -120,3 +120,18 @@ def test_emulated_hand_reset_forward_matches_golden(hand_model):
     emu.hand_step(np.zeros(20, np.float32), forward_only=True)
     assert np.abs(emu.hand_obs[:63] - g["reset_obs"][0]).max() < 2e-6
     assert np.abs(emu.palm - g["palm_xpos"]).max() < 1e-6
+
+
+def test_batched_goal_sampler_equals_the_per_world_one():
+    from gymnasium_robotics_amd.core import np_random
+    from gymnasium_robotics_amd.envs.hand_spec import sample_hand_reach_goal, sample_hand_reach_goal_batch
+
+    rng = np.random.default_rng(0)
+    init, palm = rng.uniform(-0.05, 0.05, 15) + 1.0, np.array([1.0, 0.9, 0.15])
+    a = [np_random(k)[0] for k in range(200)]
+    b = [np_random(k)[0] for k in range(200)]
+    one = np.stack([sample_hand_reach_goal(r, init, palm) for r in a])
+    many = sample_hand_reach_goal_batch(b, init, palm)
+    assert np.allclose(one, many, rtol=0, atol=1e-15)      # the squared norm is summed in a different order (dot vs explicit): last bit
+    assert (np.abs(one - init).max(axis=1) == 0).sum() > 5            # the 10 % stay branch occurred
+    assert all(x.uniform() == y.uniform() for x, y in zip(a, b))
