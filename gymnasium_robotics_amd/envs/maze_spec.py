@@ -5,6 +5,7 @@ Restates, in vectorisable form, the host logic of
   /root/reference/gymnasium_robotics/envs/maze/maze_v4.py:148-242 (Maze.make_maze: walls + goal/reset cell lists)
   /root/reference/gymnasium_robotics/envs/maze/maze_v4.py:278-379 (generate_target_goal / generate_reset_pos / reset / add_xy_position_noise)
 """
+import math
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -122,16 +123,14 @@ class Maze:
 
 
 def sample_maze_reset(maze: Maze, rng, position_noise_range: float = 0.25, options=None):
-    """PCG64 draw order of MazeEnv.reset (maze_v4.py:299-358).  Returns (goal_xy, reset_xy)."""
+    """PCG64 draw order of MazeEnv.reset (maze_v4.py:299-358).  Returns (goal_xy, reset_xy).
+    Written on Python floats (the same float64 arithmetic as the reference's two-element arrays, without their per-call numpy
+    overhead: this runs once per world and reset, thousands of times per vector reset)."""
+    pr, sc = position_noise_range, maze.maze_size_scaling
+    lo, span = -pr, pr - (-pr)
 
-    def noise(xy):
-        xy = xy.copy()
-        xy[0] += rng.uniform(low=-position_noise_range, high=position_noise_range) * maze.maze_size_scaling
-        xy[1] += rng.uniform(low=-position_noise_range, high=position_noise_range) * maze.maze_size_scaling
-        return xy
-
-    def gen_goal():
-        return maze.unique_goal_locations[rng.integers(low=0, high=len(maze.unique_goal_locations))].copy()
+    def unif():      # Generator.uniform(low, high) is low + (high - low) * next_double: the same draw through the cheaper call
+        return lo + span * rng.random()
 
     def check_cell(cell, what):
         assert maze.map_length > cell[0] and maze.map_width > cell[1]
@@ -140,19 +139,23 @@ def sample_maze_reset(maze: Maze, rng, position_noise_range: float = 0.25, optio
     options = options or {}
     if options.get("goal_cell") is not None:
         check_cell(options["goal_cell"], "Goal")
-        goal = maze.cell_rowcol_to_xy(options["goal_cell"])
+        g = maze.cell_rowcol_to_xy(options["goal_cell"])
     else:
-        goal = gen_goal()
-    goal = noise(goal)
+        g = maze.unique_goal_locations[rng.integers(0, len(maze.unique_goal_locations))]
+    gx = float(g[0]) + unif() * sc
+    gy = float(g[1]) + unif() * sc
     if options.get("reset_cell") is not None:
         check_cell(options["reset_cell"], "Reset")
-        reset_pos = maze.cell_rowcol_to_xy(options["reset_cell"])
+        r = maze.cell_rowcol_to_xy(options["reset_cell"])
+        rx, ry = float(r[0]), float(r[1])
     else:
-        reset_pos = goal.copy()
-        while np.linalg.norm(reset_pos - goal) <= 0.5 * maze.maze_size_scaling:
-            reset_pos = maze.unique_reset_locations[rng.integers(low=0, high=len(maze.unique_reset_locations))].copy()
-    reset_pos = noise(reset_pos)
-    return goal, reset_pos
+        rx, ry, far, locs = gx, gy, 0.5 * sc, maze.unique_reset_locations
+        while math.sqrt((rx - gx) * (rx - gx) + (ry - gy) * (ry - gy)) <= far:
+            r = locs[rng.integers(0, len(locs))]
+            rx, ry = float(r[0]), float(r[1])
+    rx += unif() * sc
+    ry += unif() * sc
+    return np.array([gx, gy]), np.array([rx, ry])
 
 
 def redraw_goal(maze: Maze, rng, achieved_xy, goal_xy, position_noise_range: float = 0.25):
