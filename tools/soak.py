@@ -17,19 +17,19 @@ for env_id, n in CASES:
     obs, _ = env.reset(seed=0)
     na = env.single_action_space.shape[0]
     g = torch.Generator(device="cuda:0"); g.manual_seed(0)
-    flags = {1: 0, 2: 0, 4: 0, 8: 0}
+    bits = torch.tensor([1, 2, 4, 8], device="cuda:0", dtype=torch.int32)
+    counts = torch.zeros(4, device="cuda:0", dtype=torch.int64)      # accumulated on the device: no per-step synchronisation
     finite, succ, t0 = True, 0.0, time.time()
     for t in range(STEPS):
         obs, r, term, trunc, info = env.step(torch.rand(n, na, device="cuda:0", generator=g) * 2 - 1)
-        st = env.status
-        for b in flags:
-            flags[b] += int(((st & b) != 0).sum())
+        counts += ((env.status.unsqueeze(1) & bits) != 0).sum(dim=0)
         if t % 50 == 49:
             finite = finite and bool(torch.isfinite(obs["observation"]).all()) and bool(torch.isfinite(r).all())
             key = "is_success" if "is_success" in info else "success"
             succ += float(torch.as_tensor(info[key]).float().mean())
     torch.cuda.synchronize()
     dt = time.time() - t0
+    flags = {int(b): int(c) for b, c in zip(bits.tolist(), counts.tolist())}
     tot = n * STEPS
     print(f"{env_id}: {n} worlds x {STEPS} steps in {dt:.1f} s ({tot / dt:,.0f} env-steps/s incl. resets); finite {finite}; world-steps flagged: "
           f"bad-number {flags[1]} ({100 * flags[1] / tot:.4f} %), contact-capacity {flags[2]} ({100 * flags[2] / tot:.4f} %), row/pool-capacity {flags[4]} "
