@@ -82,7 +82,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree;
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv;
   int mpr_iterations;
 };
@@ -639,6 +639,8 @@ GRX_MEM void grx_sym_solve(const float* A, int n, float* x, int lane_) {
   }
 }
 
+// dof_parentid of the Shadow hand's 24 dofs (see kGrxHandAnc below; checked by the host before a hand shape is selected)
+#define GRX_HAND_DOF_PARENTS {-1, 0, 1, 2, 3, 4, 1, 6, 7, 8, 1, 10, 11, 12, 1, 14, 15, 16, 17, 1, 19, 20, 21, 22}
 // A x = b in one call.  On the GPU, for the dof counts of the models in scope, the whole system is held in
 // registers: lane j owns column j of A (lane nv owns b), the pivot column is broadcast with v_readlane and the
 // elimination runs from the last dof to the first exactly like grx_sym_factor -- no LDS round trips, no barriers.
@@ -650,7 +652,14 @@ static __device__ __forceinline__ float grx_rcp_refined(float d) { float r = __b
 // Lane i (< NS) owns ROW i of the symmetric matrix and b_i.  Step k of the elimination broadcasts row k with v_readlane
 // (one readlane + one fma per remaining column) and every lane i < k subtracts its multiple of it; rows end up lower
 // triangular, pivots final when they are used.  The forward substitution then needs one broadcast per unknown.
-template <int NS>
+// Dof tree of the Shadow hand (shared_asset / robot.xml of the hand models): wrist 0-1, then five chains hanging off dof 1
+// (FF 2-5, MF 6-9, RF 10-13, LF 14-18, TH 19-23).  kGrxHandAnc[k] = the ancestor dofs of dof k as a bit mask.  M and M + h B have
+// exactly this pattern below the diagonal, and the last-to-first elimination creates no fill-in (the LTDL argument mj_factorM relies
+// on), so the HAND variant of the register solve broadcasts only those columns: 83 instead of 276, decided at compile time, the
+// skipped updates being exact zeros of the dense elimination.  grx_fill_model_scalars sets m->handtree only if dof_parentid matches.
+static constexpr unsigned kGrxHandAnc[24] = {0x0, 0x1, 0x3, 0x7, 0xF, 0x1F, 0x3, 0x43, 0xC3, 0x1C3, 0x3, 0x403, 0xC03, 0x1C03,
+                                             0x3, 0x4003, 0xC003, 0x1C003, 0x3C003, 0x3, 0x80003, 0x180003, 0x380003, 0x780003};
+template <int NS, bool HAND = false>
   static __device__ __forceinline__ void grx_sym_solve_reg(const float* A, int ld, float* x, int lane_) {
   float a[NS];
   const int row = lane_ < NS ? lane_ : 0;
@@ -663,7 +672,7 @@ template <int NS>
     rd = (lane_ == k) ? pinv : rd;
     const float mi = (lane_ < k) ? -a[k] * pinv : 0.0f;
 #pragma unroll
-    for (int j = 0; j < k; j++) a[j] = fmaf(mi, grx_readlane_f(a[j], k), a[j]);
+    for (int j = 0; j < k; j++) { if (!HAND || ((kGrxHandAnc[k % 24] >> j) & 1u)) a[j] = fmaf(mi, grx_readlane_f(a[j], k), a[j]); }
     b = fmaf(mi, grx_readlane_f(b, k), b);
   }
   { const float pinv = grx_rcp_refined(grx_readlane_f(a[0], 0)); rd = (lane_ == 0) ? pinv : rd; }
@@ -685,8 +694,13 @@ template <int NS>
 // blocks are exactly zero: always true for M + h B, true for the Hessian while no contact links object and robot).  The two diagonal
 // blocks are then solved one after the other -- the same arithmetic as the full elimination, in which every multiplier between the
 // blocks is an exact zero, at (nr^2 + 36) / n^2 of its broadcasts (15 + 6 instead of 21: 43 % fewer).
-GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit = 0) {
+GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit = 0, int tree = 0) {
 #if !defined(GRX_EMU)
+  if (S::kFixed && S::NF == 24 && tree) {      // hand shapes (the host matched m->handtree): M / M + h B solves
+    grx_sym_solve_reg<24, true>(A, n, x, lane_);
+    if (S::NV == 30) grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_);
+    return 0;
+  }
   if (nsplit == 6 && n == 21) { grx_sym_solve_reg<15>(A, n, x, lane_); grx_sym_solve_reg<6>(A + 15 * n + 15, n, x + 15, lane_); return 0; }
   if (nsplit == 6 && n == 30) { grx_sym_solve_reg<24>(A, n, x, lane_); grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_); return 0; }
   if (n == 21) { grx_sym_solve_reg<21>(A, n, x, lane_); return 0; }
@@ -2351,7 +2365,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
           nsplit = (GRX_BALLOT(nzp) == 0ull) ? 6 : 0;
         } else nsplit = 6;
       }
-      if (grx_sym_solve_full(c->A, nv, rhs, lane_, nsplit)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+      if (grx_sym_solve_full(c->A, nv, rhs, lane_, nsplit, phase != 0)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
     }
     if (phase == 0) {
       GRX_TICK(c, GRX_P_NFACTOR);

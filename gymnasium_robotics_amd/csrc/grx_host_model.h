@@ -64,6 +64,12 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.jpool = d[GRX_JPOOL_REQ] > 0 ? ((d[GRX_JPOOL_REQ] + 15) / 16) * 16 : GRX_JPOOL;
   if (m.jpool > 4080) m.jpool = 4080;
   m.maxcon = (d[GRX_MAXCON_REQ] > 0 && d[GRX_MAXCON_REQ] < GRX_MAXCON) ? d[GRX_MAXCON_REQ] : GRX_MAXCON;
+  {
+    static const int hand_parent[24] = GRX_HAND_DOF_PARENTS;
+    m.handtree = (v.n_dof_parentid >= 24) ? 1 : 0;
+    for (int k = 0; k < 24 && m.handtree; k++) if (v.dof_parentid[k] != hand_parent[k]) m.handtree = 0;
+    for (int k = 24; k < v.n_dof_parentid && m.handtree; k++) if (v.dof_parentid[k] >= 0 && v.dof_parentid[k] < 24) m.handtree = 0;   // nothing else hangs off the hand
+  }
   m.anydamp = 0;
   for (int k = 0; k < v.n_dof_damping; k++) if (v.dof_damping[k] > 0) m.anydamp = 1;
   m.timestep = (float)v.opt[GRX_TIMESTEP];

@@ -86,7 +86,7 @@ template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(cons
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0));
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (S::NF != 24 || g.handtree);
 }
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
@@ -428,6 +428,8 @@ extern "C" int grx_model_dim(const grx_model* m, const char* name) {
   if (!strcmp(name, "nbody")) return g.nbody;
   if (!strcmp(name, "nmocap")) return g.nmocap;
   if (!strcmp(name, "ndevpair")) return g.ndevpair;
+  if (!strcmp(name, "shape")) return m->shape;          // id of the shape-specialised kernel the launches use, 0 = the generic one
+  if (!strcmp(name, "handtree")) return g.handtree;
   return -1;
 }
 

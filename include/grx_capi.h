@@ -119,7 +119,7 @@ int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const d
 int grx_model_destroy(grx_model* m);
 int grx_model_set_table(grx_model* m, const char* name, const double* data, int n);
 int grx_model_lds_bytes(const grx_model* m);
-int grx_model_dim(const grx_model* m, const char* name);
+int grx_model_dim(const grx_model* m, const char* name);   /* "nq" "nv" "nu" "nbody" "nmocap" "ndevpair"; "shape" = id of the shape-specialised kernel (0 generic); "handtree"; -1 unknown */
 
 int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, void* stream);
 int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream);
