@@ -1,19 +1,27 @@
-"""bench.py -- env-steps/s of the batched Fetch hot path on N MI355X GPUs of one node.
+"""bench.py -- env-steps/s of the batched env.step() hot path on N MI355X GPUs of one node.
 
-Metric (BASELINE.json): "env-steps/s (whole node) at N parallel envs".  Workload at N=1 = BASELINE.json
-configs[1]: FetchPickAndPlace-v4, 4096 envs on one MI355X, sparse reward + HER reward recompute,
-random actions, episodes auto-reset at 50 steps (SAME_STEP, so every timed vector step runs the full
-20-substep physics for every world).  Weak scaling: 4096 worlds per GPU; worlds are tile-sharded over the
-ranks and the only collective is the RCCL all-gather of the per-step outputs.
+Metric (BASELINE.json): "env-steps/s (whole node) at N parallel envs".  Default workload = BASELINE.json configs[1]:
+FetchPickAndPlace-v4, 4096 envs per MI355X, sparse reward + HER reward recompute, uniform random actions.  Episodes are
+staggered (world i starts at elapsed step i mod 50), so EVERY timed vector step contains its steady-state share of
+autoresets (4096 / 50 = 82 worlds per step: host draws + the reset kernel), not only the 20-substep physics.
+Weak scaling: the same number of worlds on every GPU; worlds are tile-sharded over the ranks and the only collective is
+ONE RCCL all-gather per step of the packed output rows the step kernel itself wrote.
 
-One "step" = one env.step() of all worlds = ONE launch of grx_fetch_step_kernel (+ the HER reward kernel).
+One "step" = one env.step() of all worlds = ONE launch of the family's step kernel (+ the HER reward kernel for cfg 2).
+--workload selects the other BASELINE configs under the same contract and the same JSON schema:
+    fetch       cfg 2  FetchPickAndPlace-v4, 4096 worlds / GPU
+    hand_touch  cfg 3  HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1, 16384 worlds / GPU
+    antmaze     cfg 4  AntMaze_Large_Diverse_GR-v5, 8192 worlds / GPU (65536 over 8)
+    hand_reach         HandReach-v3, 16384 worlds / GPU
 
     python bench.py --gpus 1 --steps 100 --warmup 10
+    python bench.py --gpus 8            (spawns 8 ranks itself when not started by torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -23,97 +31,132 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ENV_ID = "FetchPickAndPlace-v4"
-WORLDS_PER_GPU = 4096
-# Other BASELINE.json configs can be timed with --workload (the driver's default run is cfg 2 = "fetch").  Per config: env id, worlds
-# per GPU, action dim, step-kernel name, algorithmic HBM bytes per env-step
+# per workload: env id, worlds per GPU, step-kernel name, algorithmic HBM bytes per env-step,
+# time limit of the registered id
 WORKLOADS = {
-    "fetch": ("FetchPickAndPlace-v4", 4096, 4, "grx_fetch_step_kernel", 715),
-    "hand_touch": ("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", 16384, 20, "grx_hand_step_kernel", 1635),   # cfg 3
-    "hand_reach": ("HandReach-v3", 16384, 20, "grx_hand_step_kernel", 1035),   # r 24+24+24+20, w 72, out 63+15+15+1
-    "antmaze": ("AntMaze_Large_Diverse_GR-v5", 8192, 8, "grx_point_step_kernel", 507),                                      # cfg 4 (8192 per GPU x 8)
+    "fetch": dict(env_id="FetchPickAndPlace-v4", worlds=4096, kernel="grx_fetch_step_kernel", algo=715, horizon=50),
+    "hand_touch": dict(env_id="HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", worlds=16384, kernel="grx_hand_step_kernel", algo=1635, horizon=100),
+    "hand_reach": dict(env_id="HandReach-v3", worlds=16384, kernel="grx_hand_step_kernel", algo=1035, horizon=50),   # r 24+24+24+20, w 72, out 63+15+15+1
+    "antmaze": dict(env_id="AntMaze_Large_Diverse_GR-v5", worlds=8192, kernel="grx_point_step_kernel", algo=507, horizon=1000),
 }
-HER_K = 4  # relabelled goals per transition ("future" strategy with k=4)
-# algorithmic HBM bytes per env-step of the fused kernel (SURVEY.md §8(d) cfg 2):
-# read qpos22+qvel21+warm21+mocap7+act4 = 75 words, write 22+21+21+7 = 71, outputs obs25+ag3+dg3+r1 = 32 -> 178*4 + 3 flag bytes
-ALGO_BYTES_PER_ENV_STEP = 715
-HER_BYTES_PER_TRANSITION = 28
+HER_K = 4  # relabelled goals per transition ("future" strategy with k=4); 28 B per relabelled transition
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(seconds: float = 12.0):
-    """Oracle (fp64 restatement, oracle/) timed on one host core on the same workload, single world."""
-    from gymnasium_robotics_amd.envs.fetch import load_fetch_model
-    from oracle.fetch_oracle import OracleFetchEnv
+def make_env(workload, n, device, rank):
+    w = WORKLOADS[workload]
+    kw = dict(num_envs=n, device=device, output="torch", autoreset_mode="same_step", seed_offset=rank * n)
+    if workload == "fetch":
+        from gymnasium_robotics_amd.envs.fetch import FetchVecEnv as Env
+    elif workload == "antmaze":
+        from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv as Env
+    elif workload == "hand_reach":
+        from gymnasium_robotics_amd.envs.hand import HandReachVecEnv as Env
+    else:
+        from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv as Env
+    return Env(w["env_id"], **kw)
 
-    env = OracleFetchEnv(load_fetch_model("FetchPickAndPlace"), "FetchPickAndPlace")
-    rng = np.random.default_rng(0)
-    env.reset(seed=0)
+
+# ---------------------------------------------------------------------------------------------- CPU baseline (oracle, test infrastructure)
+def _oracle_env(workload):
+    if workload == "fetch":
+        from gymnasium_robotics_amd.envs.fetch import load_fetch_model
+        from oracle.fetch_oracle import OracleFetchEnv
+        return OracleFetchEnv(load_fetch_model("FetchPickAndPlace"), "FetchPickAndPlace"), 4
+    if workload == "antmaze":
+        from gymnasium_robotics_amd.envs.maze_spec import ANT_MAZE_HEIGHT, ANT_MAZE_SIZE_SCALING, MAPS, Maze, parse_ant_maze_id
+        from gymnasium_robotics_amd.envs.point_maze import load_point_maze_model
+        from oracle.maze_oracle import OracleAntMazeEnv
+        layout = parse_ant_maze_id(WORKLOADS[workload]["env_id"])[0]
+        maze = Maze(MAPS[layout], ANT_MAZE_SIZE_SCALING, ANT_MAZE_HEIGHT)
+        return OracleAntMazeEnv(load_point_maze_model(maze, layout, None, "ant"), maze), 8
+    if workload == "hand_reach":
+        from gymnasium_robotics_amd.envs.hand import load_hand_reach_model
+        from oracle.hand_oracle import OracleHandReachEnv
+        return OracleHandReachEnv(load_hand_reach_model(None)), 20
+    from gymnasium_robotics_amd.envs.hand import load_hand_block_model
+    from oracle.manipulate_oracle import OracleHandBlockEnv
+    return OracleHandBlockEnv(load_hand_block_model(None, touch=True), "ignore", "xyz", "sparse", "sensordata"), 20
+
+
+def _cpu_worker(args):
+    workload, seconds, seed = args
+    sys.path.insert(0, ROOT)
+    env, act = _oracle_env(workload)
+    rng = np.random.default_rng(seed)
+    env.reset(seed=seed)
+    horizon = WORKLOADS[workload]["horizon"]
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        for t in range(50):
-            env.step(rng.uniform(-1, 1, 4))
+        for _ in range(min(horizon, 25)):
+            env.step(rng.uniform(-1, 1, act))
             n += 1
-        env.reset()
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} env.step() calls of 1 world, {ENV_ID}, random actions, 50-step episodes ({dt:.1f} s of CPU work); "
-                      "oracle = fp64 restatement (MuJoCo is not installable here), Python task layer + C physics"}
+        if n % horizon < 25:
+            env.reset()
+    return n, time.perf_counter() - t0
 
 
-def other_workload(args):
-    """Same contract as the default run for the other single-kernel families: random actions, same-step autoreset at the family's
-    time limit, one RCCL all-gather of the per-step outputs when N > 1.  No HER leg, no CPU baseline."""
-    env_id, n_default, act_dim, kernel, algo = WORKLOADS[args.workload]
-    world_size, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+def cpu_baseline(workload, seconds=8.0):
+    """The oracle (fp64 restatement under oracle/: C physics + Python task layer; MuJoCo cannot be installed here) timed on the host
+    cores: one process = one world on one core, then min(8, cores) processes side by side."""
+    import multiprocessing as mp
+
+    n1, t1 = _cpu_worker((workload, seconds, 0))
+    cores = max(1, min(8, os.cpu_count() or 1))
+    multi = None
+    if cores > 1:
+        with mp.get_context("spawn").Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(workload, seconds, k) for k in range(cores)])
+        multi = sum(n / t for n, t in res)
+    return {"value": n1 / t1, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "value_all_cores": multi, "cores_all": cores,
+            "sample": f"{n1} env.step() calls of 1 world on 1 core ({t1:.1f} s), then {cores} independent worlds on {cores} cores for {seconds:.0f} s each; "
+                      f"{WORKLOADS[workload]['env_id']}, random actions; oracle = fp64 restatement (not MuJoCo), Python task layer + C physics"}
+
+
+# ---------------------------------------------------------------------------------------------- one rank
+def run_rank(args, rank, world_size, local_rank):
+    w = WORKLOADS[args.workload]
     torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    dist = None
     if world_size > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(f"cuda:{local_rank}"))
-    device = f"cuda:{local_rank}"
-    n = args.worlds_per_gpu if args.worlds_per_gpu != WORLDS_PER_GPU else n_default
-    if args.workload == "antmaze":
-        from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv as Env
-    else:
-        from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv, HandReachVecEnv
-        Env = HandReachVecEnv if args.workload == "hand_reach" else HandBlockVecEnv
-    env = Env(env_id, num_envs=n, device=device, output="torch", autoreset_mode="same_step", seed_offset=rank * n)
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+    n = args.worlds_per_gpu or w["worlds"]
+    env = make_env(args.workload, n, device, rank)
     env.reset(seed=0)
+    if args.stagger:   # steady state: every step resets its share of the worlds (world i is i mod horizon steps into its episode)
+        env._elapsed[:] = np.arange(n) % (env.max_episode_steps or w["horizon"])
+    act_dim = env.single_action_space.shape[0]
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
-    gdim = env.goal.shape[1]
-    out_dim = env.obs_dim + 2 * gdim + 2
-    packed = torch.empty(n, out_dim, device=device)
-    gathered = torch.empty(n * world_size, out_dim, device=device) if dist else None
-    events = []
+    gathered = torch.empty(n * world_size, env.packed.shape[1], device=device) if dist else None
+    her = args.workload == "fetch"
+    perm = torch.randperm(n, device=device, generator=gen) if her else None
 
-    def one_step(timed):
+    def one_step():
         a = torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
         obs, r, term, trunc, info = env.step(a)
-        e1.record()
-        if timed:
-            events.append((e0, e1))
-        if dist:
-            packed[:, : env.obs_dim] = obs["observation"]
-            packed[:, env.obs_dim: env.obs_dim + gdim] = obs["achieved_goal"]
-            packed[:, env.obs_dim + gdim: env.obs_dim + 2 * gdim] = obs["desired_goal"]
-            packed[:, -2] = r
-            packed[:, -1] = (info["is_success"] if "is_success" in info else info["success"]).float()
-            dist.all_gather_into_tensor(gathered, packed)
+        if her:   # HER relabel: reward recompute for HER_K substituted goals per transition
+            ag = obs["achieved_goal"].unsqueeze(0).expand(HER_K, n, 3).contiguous()
+            dg = torch.stack([obs["desired_goal"][torch.roll(perm, k)] for k in range(HER_K)])
+            env.compute_reward(ag, dg, None)
+        if dist:   # the step kernel wrote the packed [obs | achieved | desired | reward | success] rows: one collective, no pack kernels
+            dist.all_gather_into_tensor(gathered, env.packed)
 
     for _ in range(args.warmup):
-        one_step(False)
+        one_step()
+    env.clear_status()
+    env.kernel_events = []   # HIP events (torch's current stream = the launch stream) around every step-kernel launch of the timed region
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step(True)
+        one_step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -122,23 +165,50 @@ def other_workload(args):
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # env.step() here = the step kernel (+ masked reset launches at episode ends): events bracket the whole call
-    step_ms = float(np.median([a.elapsed_time(b) for a, b in events]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in env.kernel_events]))
+    counts = env.status_counts()
+
+    # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE
+    # cannot be read from inside the process); tools/collect_profiles.py writes the summary bench.py quotes
+    traffic, traffic_src = None, None
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"pmc_{tag}_hbm_traffic{'' if args.workload == 'fetch' else '_' + args.workload}.json")
+        if os.path.exists(path) and n == w["worlds"]:
+            with open(path) as f:
+                traffic, traffic_src = json.load(f)["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+            break
+    line = None
     if rank == 0:
         value = n * world_size * args.steps / elapsed
-        achieved = algo * n / (step_ms * 1e-3) / 1e9
-        print(json.dumps({
-            "metric": "env-steps/s (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{env_id}, {n} worlds/GPU x {world_size} GPU, uniform random actions, same-step autoreset at the time limit",
-                       "worlds_per_gpu": n, "parallelism": f"world-shard x{world_size}" + (", RCCL all_gather of outputs" if world_size > 1 else ""),
-                       "status_flagged_worlds": int((env.status != 0).sum().item())},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": kernel, "kernel_ms": step_ms, "algorithmic_bytes_per_launch": algo * n,
-                         "note": "median env.step() device time (step kernel; episode-end steps add masked reset launches); issue-bound, see DESIGN.md"},
-        }))
+        achieved = w["algo"] * n / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/s (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w['env_id']}, {n} worlds/GPU x {world_size} GPU, uniform random actions, same-step autoreset at the time limit "
+                                   f"({'episodes staggered: every step resets its share of the worlds' if args.stagger else 'episodes in lock-step'})"
+                                   + (f", sparse reward + HER recompute (k={HER_K})" if her else ""),
+                       "worlds_per_gpu": n, "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather of kernel-packed output rows per step" if world_size > 1 else ""),
+                       "capacity_overflow_worlds": counts["con_overflow"] + counts["efc_overflow"], "badnum_worlds": counts["badnum"],
+                       "status_note": "worlds (of rank 0) whose sticky status flagged a dropped contact / bad number at least once in the timed region"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": w["kernel"], "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": w["algo"] * n,
+                         "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 5"},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
     if dist:
         dist.destroy_process_group()
+    return line
+
+
+def _spawned(local_rank, args, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus), RANK=str(local_rank), LOCAL_RANK=str(local_rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    line = run_rank(args, local_rank, args.gpus, local_rank)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -146,106 +216,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--worlds-per-gpu", type=int, default=WORLDS_PER_GPU)
+    ap.add_argument("--worlds-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stagger", dest="stagger", action="store_false")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="fetch")
     args = ap.parse_args()
-    if args.workload != "fetch":
-        return other_workload(args)
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world_size > 1:
-        import torch.distributed as dist
+    if "WORLD_SIZE" in os.environ:   # started by torchrun: one rank per process already
+        ws = int(os.environ["WORLD_SIZE"])
+        if ws != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but torchrun started {ws} ranks")
+        line = run_rank(args, int(os.environ.get("RANK", "0")), ws, int(os.environ.get("LOCAL_RANK", "0")))
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        return
+    if args.gpus > 1:   # plain `python bench.py --gpus N`: become the launcher (one process per GPU, RCCL over xGMI)
+        avail = torch.cuda.device_count()
+        if avail < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} requested but only {avail} HIP device(s) are visible")
+        import torch.multiprocessing as mp
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(f"cuda:{local_rank}"))
-    n_gpus = world_size
-    device = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
-
-    from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
-
-    n = args.worlds_per_gpu
-    env = FetchVecEnv(ENV_ID, num_envs=n, device=device, output="torch", autoreset_mode="same_step", seed_offset=rank * n)
-    env.reset(seed=0)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + rank)
-    out_dim = env.obs_dim + 3 + 3 + 1 + 1  # obs, achieved, desired, reward, success
-    packed = torch.empty(n, out_dim, device=device)
-    gathered = torch.empty(n * n_gpus, out_dim, device=device) if dist else None
-    perm = torch.randperm(n, device=device, generator=gen)
-
-    def one_step():
-        a = torch.rand(n, 4, device=device, generator=gen) * 2 - 1
-        obs, r, term, trunc, info = env.step(a)
-        # HER relabel: reward recompute for HER_K substituted goals per transition
-        ag = obs["achieved_goal"].unsqueeze(0).expand(HER_K, n, 3).contiguous()
-        dg = torch.stack([obs["desired_goal"][torch.roll(perm, k)] for k in range(HER_K)])
-        env.compute_reward(ag, dg, None)
-        if dist:
-            packed[:, : env.obs_dim] = obs["observation"]
-            packed[:, env.obs_dim: env.obs_dim + 3] = obs["achieved_goal"]
-            packed[:, env.obs_dim + 3: env.obs_dim + 6] = obs["desired_goal"]
-            packed[:, -2] = r
-            packed[:, -1] = info["is_success"].float()
-            dist.all_gather_into_tensor(gathered, packed)
-
-    for _ in range(args.warmup):
-        one_step()
-    env.kernel_events = []  # HIP events (torch's current stream = the launch stream) around every grx_fetch_step_kernel launch
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    status_max = int(env.status.max().item())
-    # dominant kernel: average duration of the grx_fetch_step_kernel launches of the timed region
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in env.kernel_events]))
-
-    # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
-    # (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); the committed summary is profiles/pmc_r01_hbm_traffic.*
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_r01_hbm_traffic.json")) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"] if n == WORLDS_PER_GPU else None
-    except OSError:
-        pass
-    if rank == 0:
-        total_steps = n * n_gpus * args.steps
-        value = total_steps / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
-        line = {
-            "metric": "env-steps/s (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{ENV_ID}, {n} worlds/GPU x {n_gpus} GPU, 20 fused substeps, sparse reward + HER recompute (k={HER_K}), "
-                                   "uniform random actions, same-step autoreset at 50 steps", "worlds_per_gpu": n,
-                       "parallelism": f"world-shard x{n_gpus}" + (", RCCL all_gather of outputs" if n_gpus > 1 else ""),
-                       "status_max": status_max},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/pmc_r01_hbm_traffic.txt (rocprofv3 PMC, bytes per launch)",
-                         "kernel": "grx_fetch_step_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
-                         "note": "fused path is VALU/LDS/latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md"},
-        }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line))
-    if dist:
-        dist.destroy_process_group()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_spawned, args=(args, port), nprocs=args.gpus, join=True)
+        return
+    line = run_rank(args, 0, 1, 0)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ _lib = None
 
 class FetchBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost")]
+        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed")]
 
 
 class PointTaskStruct(ctypes.Structure):
@@ -24,12 +24,12 @@ class PointTaskStruct(ctypes.Structure):
 
 class PointBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask")]
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask", "packed")]
 
 
 class HandBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost")]
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost", "packed")]
 
 
 def lib():

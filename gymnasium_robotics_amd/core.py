@@ -65,6 +65,25 @@ class GoalVecEnv:
         torch.cuda.current_stream(self.device).synchronize()
         return out
 
+    # `status` (int32 per world): low half = GRX_STATUS_* flags of the last launch, high half = the same flags OR-accumulated by the kernels
+    # since clear_status() (include/grx_capi.h).  A capacity overflow drops contacts for one substep: training code should poll this.
+    def status_counts(self):
+        st = (self.status >> 16).cpu().numpy()
+        return {"badnum": int((st & 1 != 0).sum()), "con_overflow": int((st & 2 != 0).sum()), "efc_overflow": int((st & 4 != 0).sum()),
+                "factor": int((st & 8 != 0).sum()), "worlds": int(self.num_envs)}
+
+    def clear_status(self):
+        self.status.zero_()
+
+    def _status_info(self, info):
+        """info["status"] (this step's flags) and info["status_sticky"] for both output modes."""
+        if self.output == "torch":
+            info["status"] = self.status
+        else:
+            st = self.status.cpu().numpy()
+            info["status"], info["status_sticky"] = st & 0xFFFF, st >> 16
+        return info
+
     def close(self):
         pass
 

@@ -660,7 +660,7 @@ static __device__ __forceinline__ float grx_rcp_refined(float d) { float r = __b
 static constexpr unsigned kGrxHandAnc[24] = {0x0, 0x1, 0x3, 0x7, 0xF, 0x1F, 0x3, 0x43, 0xC3, 0x1C3, 0x3, 0x403, 0xC03, 0x1C03,
                                              0x3, 0x4003, 0xC003, 0x1C003, 0x3C003, 0x3, 0x80003, 0x180003, 0x380003, 0x780003};
 template <int NS, bool HAND = false>
-  static __device__ __forceinline__ void grx_sym_solve_reg(const float* A, int ld, float* x, int lane_) {
+  static __device__ __forceinline__ int grx_sym_solve_reg(const float* A, int ld, float* x, int lane_) {
   float a[NS];
   const int row = lane_ < NS ? lane_ : 0;
 #pragma unroll
@@ -687,6 +687,7 @@ template <int NS, bool HAND = false>
   __syncthreads();
   if (lane_ < NS) x[lane_] = xo;
   __syncthreads();
+  return __ballot((lane_ < NS) && !(rd > 0.0f)) != 0ull;   // a non-positive (or NaN) pivot: the matrix was not positive definite (GRX_ST_FACTOR)
 }
 #endif
 
@@ -697,17 +698,17 @@ template <int NS, bool HAND = false>
 GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit = 0, int tree = 0) {
 #if !defined(GRX_EMU)
   if (S::kFixed && S::NF == 24 && tree) {      // hand shapes (the host matched m->handtree): M / M + h B solves
-    grx_sym_solve_reg<24, true>(A, n, x, lane_);
-    if (S::NV == 30) grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_);
-    return 0;
+    int bad_ = grx_sym_solve_reg<24, true>(A, n, x, lane_);
+    if (S::NV == 30) bad_ |= grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_);
+    return bad_;
   }
-  if (nsplit == 6 && n == 21) { grx_sym_solve_reg<15>(A, n, x, lane_); grx_sym_solve_reg<6>(A + 15 * n + 15, n, x + 15, lane_); return 0; }
-  if (nsplit == 6 && n == 30) { grx_sym_solve_reg<24>(A, n, x, lane_); grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_); return 0; }
-  if (n == 21) { grx_sym_solve_reg<21>(A, n, x, lane_); return 0; }
-  if (n == 14) { grx_sym_solve_reg<14>(A, n, x, lane_); return 0; }
-  if (n == 15) { grx_sym_solve_reg<15>(A, n, x, lane_); return 0; }
-  if (n == 24) { grx_sym_solve_reg<24>(A, n, x, lane_); return 0; }
-  if (n == 30) { grx_sym_solve_reg<30>(A, n, x, lane_); return 0; }
+  if (nsplit == 6 && n == 21) { int bad_ = grx_sym_solve_reg<15>(A, n, x, lane_); return bad_ | grx_sym_solve_reg<6>(A + 15 * n + 15, n, x + 15, lane_); }
+  if (nsplit == 6 && n == 30) { int bad_ = grx_sym_solve_reg<24>(A, n, x, lane_); return bad_ | grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_); }
+  if (n == 21) return grx_sym_solve_reg<21>(A, n, x, lane_);
+  if (n == 14) return grx_sym_solve_reg<14>(A, n, x, lane_);
+  if (n == 15) return grx_sym_solve_reg<15>(A, n, x, lane_);
+  if (n == 24) return grx_sym_solve_reg<24>(A, n, x, lane_);
+  if (n == 30) return grx_sym_solve_reg<30>(A, n, x, lane_);
 #endif
 #if defined(GRX_EMU)
   if (n == 21 || n == 14 || n == 15 || n == 24 || n == 30) {   // mirror the device: these sizes are solved without touching A

@@ -43,6 +43,7 @@ struct GrxHandBuffers {
   const unsigned char* mask;     // [N] or null
   const int* order;              // [grid] or null: world handled by workgroup b (cost-ordered dispatch, see grx_fetch_buffers)
   int* cost;                     // [N] or null: out, cost estimate of this world
+  float* packed;                 // [N, obs_dim + 2 goal_dim + 2] or null: out, the row [obs | achieved | desired | reward | success]
 };
 
 // Euclidean distance with a fixed accumulation order, shared by the step kernel and the recompute kernel so that

@@ -38,6 +38,10 @@ __device__ __forceinline__ void grx_load_world(const GrxModel& m, const GrxFetch
   __syncthreads();
 }
 
+// status word: bits 0-15 = GRX_ST_* flags of this launch, bits 16-31 = the same flags OR-accumulated over every launch since the host
+// last cleared the buffer (sticky: a capacity overflow in step 17 is still visible after step 50)
+__device__ __forceinline__ int grx_status_word(int old, int now) { return (now & 0xFFFF) | ((((old >> 16) | now) & 0xFFFF) << 16); }
+
 __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetchTask& t, const GrxFetchBuffers& b, GrxCtx& c, int w, int lane_) {
   for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
   for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)w * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * m.nv + i] = c.qacc_ws[i]; }
@@ -50,7 +54,14 @@ __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetc
     float d = grx_goal_distance3(ag, b.goal + (size_t)w * 3);
     b.reward[w] = grx_fetch_reward(d, t.distance_threshold, t.sparse_reward);
     b.success[w] = (d < t.distance_threshold) ? 1 : 0;
-    b.status[w] = c.cnt[2];
+    b.status[w] = grx_status_word(b.status[w], c.cnt[2]);
+    if (b.packed) {   // [obs | achieved | desired | reward | success] row for the cross-rank gather: no pack kernels on the host side
+      float* row = b.packed + (size_t)w * (t.obs_dim + 8);
+      const float* ob = b.obs + (size_t)w * t.obs_dim;
+      for (int k = 0; k < t.obs_dim; k++) row[k] = ob[k];
+      for (int k = 0; k < 3; k++) { row[t.obs_dim + k] = ag[k]; row[t.obs_dim + 3 + k] = b.goal[(size_t)w * 3 + k]; }
+      row[t.obs_dim + 6] = b.reward[w]; row[t.obs_dim + 7] = (d < t.distance_threshold) ? 1.0f : 0.0f;
+    }
   }
 }
 
@@ -198,7 +209,17 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
     int succ = d <= t.goal_radius;
     b.reward[wl] = grx_maze_reward(d, t.goal_radius, t.sparse_reward);
     b.success[wl] = succ; b.terminated[wl] = (!t.continuing_task && succ) ? 1 : 0;
-    b.status[wl] = c.cnt[2];
+    b.status[wl] = grx_status_word(b.status[wl], c.cnt[2]);
+  }
+  if (b.packed) {   // [obs | achieved | desired | reward | success] row for the cross-rank gather
+    const int od = m.nq + m.nv - (t.agent ? 2 : 0);
+    float* row = b.packed + (size_t)wl * (od + 6);
+    for (int i = lane_; i < od; i += 64) row[i] = obs[i];
+    if (lane_ == 0) {
+      const float d = grx_goal_distance2(ach, b.goal + (size_t)wl * 2);
+      row[od] = ach[0]; row[od + 1] = ach[1]; row[od + 2] = b.goal[(size_t)wl * 2]; row[od + 3] = b.goal[(size_t)wl * 2 + 1];
+      row[od + 4] = grx_maze_reward(d, t.goal_radius, t.sparse_reward); row[od + 5] = (d <= t.goal_radius) ? 1.0f : 0.0f;
+    }
   }
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
@@ -251,8 +272,15 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
       b.reward[w] = grx_hand_reward(d, t.distance_threshold, t.sparse_reward);
       b.success[w] = (d < t.distance_threshold) ? 1 : 0;
     }
-    b.status[w] = c.cnt[2];
+    b.status[w] = grx_status_word(b.status[w], c.cnt[2]);
     if (b.cost) b.cost[w] = 12 * c.cnt[6] + 24 * c.cnt[0];   // iterations of the step + contacts of the last substep (see grx_fetch_step_kernel)
+  }
+  if (b.packed) {   // [obs | achieved | desired | reward | success] row for the cross-rank gather
+    float* row = b.packed + (size_t)w * (od + 2 * gd + 2);
+    __syncthreads();   // reward / success of lane 0 above
+    for (int i = lane_; i < od; i += 64) row[i] = obs[i];
+    for (int i = lane_; i < gd; i += 64) { row[od + i] = ach[i]; row[od + gd + i] = b.goal[(size_t)w * gd + i]; }
+    if (lane_ == 0) { row[od + 2 * gd] = b.reward[w]; row[od + 2 * gd + 1] = b.success[w] ? 1.0f : 0.0f; }
   }
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
@@ -350,15 +378,29 @@ static int fail(const std::string& msg) { g_err = msg; return -1; }
 
 extern "C" const char* grx_last_error(void) { return g_err.c_str(); }
 
-extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out) {
-  (void)nH; (void)nI; (void)nF;
-  if (!H || !I || !F || !out) return fail("grx_model_create: null argument");
-  int ndev = 0;
-  HIP_OK(hipGetDeviceCount(&ndev));
-  if (device < 0 || device >= ndev) return fail("grx_model_create: no such HIP device");
-  HIP_OK(hipSetDevice(device));
-  grx_model* m = new grx_model();
-  m->device = device;
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a model: several live models share the generic
+// kernels, so the attribute is only ever raised (a later, smaller model must not lower the limit of an earlier, larger one).
+#include <map>
+static int grx_raise_lds_limit(const void* fn, int bytes) {
+  static std::map<const void*, int> limit;
+  int& cur = limit[fn];
+  if (bytes <= cur) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+  cur = bytes;
+  return 0;
+}
+
+static void grx_model_free(grx_model* m) {
+  if (!m) return;
+  if (m->slot >= 0) g_slot_used[m->slot] = 0;
+  (void)hipSetDevice(m->device);
+  if (m->d_f) (void)hipFree(m->d_f);
+  if (m->d_i) (void)hipFree(m->d_i);
+  delete m;
+}
+
+static int grx_model_create_impl(const int32_t* H, const int32_t* I, const double* F, grx_model* m) {
   grx_pack_model(H, I, F, &m->pm);
   HIP_OK(hipMalloc(&m->d_f, sizeof(float) * (m->pm.f.size() + 4)));
   HIP_OK(hipMalloc(&m->d_i, sizeof(int32_t) * (m->pm.i.size() + 4)));
@@ -373,36 +415,47 @@ extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int 
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
   if (g.nbody > 64) return fail("engine limit: at most 64 bodies per world (one lane per body, 64-bit subtree masks)");
   if (g.nweld > g.maxefc / 16) return fail("engine limit: too many weld constraints (weld frames are staged in the row-parameter slot)");
-  HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+#define GRX_LDS(KERNEL) do { if (grx_raise_lds_limit((const void*)(KERNEL), bytes)) return -1; } while (0)
+  GRX_LDS(grx_fetch_step_kernel<GrxShapeAny>);
   m->shape = 0;
-  if (grx_shape_matches<GrxShapeFetchPick>(g)) { m->shape = 1; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPick>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  else if (grx_shape_matches<GrxShapeFetchObject>(g)) { m->shape = 2; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchObject>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  else if (grx_shape_matches<GrxShapeFetchPuck>(g)) { m->shape = 7; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchPuck>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  else if (grx_shape_matches<GrxShapeFetchArm>(g)) { m->shape = 3; HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_step_kernel<GrxShapeFetchArm>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  HIP_OK(hipFuncSetAttribute((const void*)grx_fetch_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-#define GRX_TRY_POINT_SHAPE(SHAPE, ID) if (grx_shape_matches<SHAPE>(g)) { m->shape = ID; HIP_OK(hipFuncSetAttribute((const void*)grx_point_step_kernel<SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  if (grx_shape_matches<GrxShapeFetchPick>(g)) { m->shape = 1; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchPick>); }
+  else if (grx_shape_matches<GrxShapeFetchObject>(g)) { m->shape = 2; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchObject>); }
+  else if (grx_shape_matches<GrxShapeFetchPuck>(g)) { m->shape = 7; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchPuck>); }
+  else if (grx_shape_matches<GrxShapeFetchArm>(g)) { m->shape = 3; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchArm>); }
+  GRX_LDS(grx_fetch_forward_kernel);
+  GRX_LDS(grx_point_step_kernel<GrxShapeAny>);
+#define GRX_TRY_POINT_SHAPE(SHAPE, ID) if (grx_shape_matches<SHAPE>(g)) { m->shape = ID; GRX_LDS(grx_point_step_kernel<SHAPE>); }
   GRX_TRY_POINT_SHAPE(GrxShapeAntLarge, 10) GRX_TRY_POINT_SHAPE(GrxShapeAntMedium, 11) GRX_TRY_POINT_SHAPE(GrxShapeAntOpen, 12) GRX_TRY_POINT_SHAPE(GrxShapeAntUMaze, 13)
 #undef GRX_TRY_POINT_SHAPE
-  HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  if (grx_shape_matches<GrxShapeHandReach>(g)) { m->shape = 4; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandReach>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  if (grx_shape_matches<GrxShapeHandBlockTouch>(g)) { m->shape = 6; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandBlockTouch>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  if (grx_shape_matches<GrxShapeHandEgg>(g)) { m->shape = 8; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandEgg>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  if (grx_shape_matches<GrxShapeHandEggTouch>(g)) { m->shape = 9; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandEggTouch>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
-  if (grx_shape_matches<GrxShapeHandBlock>(g)) { m->shape = 5; HIP_OK(hipFuncSetAttribute((const void*)grx_hand_step_kernel<GrxShapeHandBlock>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+  GRX_LDS(grx_hand_step_kernel<GrxShapeAny>);
+  if (grx_shape_matches<GrxShapeHandReach>(g)) { m->shape = 4; GRX_LDS(grx_hand_step_kernel<GrxShapeHandReach>); }
+  if (grx_shape_matches<GrxShapeHandBlockTouch>(g)) { m->shape = 6; GRX_LDS(grx_hand_step_kernel<GrxShapeHandBlockTouch>); }
+  if (grx_shape_matches<GrxShapeHandEgg>(g)) { m->shape = 8; GRX_LDS(grx_hand_step_kernel<GrxShapeHandEgg>); }
+  if (grx_shape_matches<GrxShapeHandEggTouch>(g)) { m->shape = 9; GRX_LDS(grx_hand_step_kernel<GrxShapeHandEggTouch>); }
+  if (grx_shape_matches<GrxShapeHandBlock>(g)) { m->shape = 5; GRX_LDS(grx_hand_step_kernel<GrxShapeHandBlock>); }
+#undef GRX_LDS
   for (int k = 0; k < GRX_MAX_MODELS && m->slot < 0; k++) if (!g_slot_used[k]) { g_slot_used[k] = 1; m->slot = k; }
   if (m->slot < 0) return fail("grx_model_create: all model descriptor slots are in use (destroy a model first)");
   HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_grx_models), &m->dev, sizeof(GrxModel), sizeof(GrxModel) * (size_t)m->slot, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out) {
+  (void)nH; (void)nI; (void)nF;
+  if (!H || !I || !F || !out) return fail("grx_model_create: null argument");
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("grx_model_create: no such HIP device");
+  HIP_OK(hipSetDevice(device));
+  grx_model* m = new grx_model();
+  m->device = device;
+  if (grx_model_create_impl(H, I, F, m)) { grx_model_free(m); return -1; }   // every failure path releases the host object, the device tables and the descriptor slot
   *out = m;
   return 0;
 }
 
 extern "C" int grx_model_destroy(grx_model* m) {
-  if (!m) return 0;
-  if (m->slot >= 0) g_slot_used[m->slot] = 0;
-  (void)hipSetDevice(m->device);
-  (void)hipFree(m->d_f); (void)hipFree(m->d_i);
-  delete m;
+  grx_model_free(m);
   return 0;
 }
 

@@ -26,6 +26,7 @@ struct GrxPointBuffers {
   unsigned char *success, *terminated;  // [N]
   int* status;                   // [N]
   const unsigned char* mask;     // [N] or null
+  float* packed;                 // [N, obs_dim + 2 + 2 + 2] or null: out, the row [obs | achieved | desired | reward | success]
 };
 
 GRX_DEV float grx_goal_distance2(const float* a, const float* b) {

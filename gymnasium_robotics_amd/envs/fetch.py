@@ -148,7 +148,8 @@ class FetchVecEnv(GoalVecEnv):
         # and the next launch starts the expensive worlds first.  A world's cost is strongly correlated from one step to the next (it is
         # in contact or it is not), and with ~2 worlds per resident wave slot the launch otherwise ends with a few slots finishing two
         # expensive worlds while the rest of the chip idles.  Worlds stay inside their XCD's slice (L2 locality of neighbouring rows).
-        self.balance = bool(self.balance) and n % 8 == 0 and n >= 1024
+        self.balance = bool(self.balance) and n % 8 == 0 and 1024 <= n <= 65536 * 8   # grx_order_by_cost sorts one XCD slice (n / 8 worlds, <= 65536) per workgroup in LDS
+        self.packed = z(n, self.obs_dim + 8)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather, parallel.py)
         self.cost = torch.zeros(n, dtype=torch.int32, device=d) if self.balance else None
         self.cost_ema = torch.zeros(n, dtype=torch.float32, device=d) if self.balance else None
         self.balance_alpha = 0.1   # weight of the newest sample in the moving average the order is sorted by (A/B on FetchPickAndPlace: 1.0 -> 2.69 ms, 0.15 -> 2.64 ms per step)
@@ -158,9 +159,9 @@ class FetchVecEnv(GoalVecEnv):
             self._slice_base = (torch.arange(8, device=d, dtype=torch.int32) * per).unsqueeze(1)          # [8,1]
             self.order = (self._slice_base + torch.arange(per, device=d, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)   # workgroup b -> slice b & 7, position b >> 3
         self._bufs = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action, self.obs,
-                                     self.achieved, self.reward, self.success, self.status, None, self.order, self.cost)
+                                     self.achieved, self.reward, self.success, self.status, None, self.order, self.cost, self.packed)
         self._bufs_masked = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action,
-                                            self.obs, self.achieved, self.reward, self.success, self.status, self.mask, self.order, self.cost)
+                                            self.obs, self.achieved, self.reward, self.success, self.status, self.mask, self.order, self.cost, self.packed)
 
     def _rebalance(self):
         """order <- per XCD slice, worlds by decreasing cost of the launch that just ran (in place: the buffer struct keeps its pointer)."""
@@ -305,14 +306,17 @@ class FetchVecEnv(GoalVecEnv):
                 self._reset_worlds(done)
                 self.reward.copy_(keep_r)
                 self.success.copy_(keep_s)
+                td = torch.from_numpy(done).to(self.device)   # the packed rows of the reset worlds: reset observation, terminal reward / success
+                self.packed[td, -2] = keep_r[td]
+                self.packed[td, -1] = keep_s[td].float()
             elif self.autoreset_mode == "next_step":
                 self._needs_reset |= truncated
         obs = self._obs_dict()
         if self.output == "torch":
             info["is_success"] = self.success
-            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), info
+            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), self._status_info(info)
         info["is_success"] = self.success.cpu().numpy().astype(np.float32)
-        info["status"] = self.status.cpu().numpy()
+        self._status_info(info)
         r = self.reward.cpu().numpy()
         return obs, (r if self.reward_type == "sparse" else r.astype(np.float64)), terminated, truncated, info
 

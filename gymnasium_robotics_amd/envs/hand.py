@@ -77,11 +77,12 @@ class HandReachVecEnv(GoalVecEnv):
         self.qpos, self.qvel, self.qacc_ws = z(n, self.nq), z(n, self.nv), z(n, self.nv)
         self.goal, self.action, self.obs, self.achieved = z(n, GOAL_DIM), z(n, self.nu), z(n, self.obs_dim), z(n, GOAL_DIM)
         self.palm, self.reward = z(n, 3), z(n)
+        self.packed = z(n, self.obs_dim + 2 * GOAL_DIM + 2)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather)
         self.success, self.status, self.mask = z(n, dtype=torch.uint8), z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
         # cost-ordered dispatch (see FetchVecEnv._alloc / include/grx_capi.h): the worlds that took longest in the last launch start first.
         # Off by default for the hand: measured neutral to -1.5 % (16 384 worlds are 8 per wave slot, the tail is short; at 4 096 the cost of a
         # world under random finger motion is not persistent enough to pay for the argsort)
-        self.balance = bool(balance) and n % 8 == 0 and n >= 1024
+        self.balance = bool(balance) and n % 8 == 0 and 1024 <= n <= 65536 * 8
         self.cost = torch.zeros(n, dtype=torch.int32, device=d) if self.balance else None
         self.cost_ema = torch.zeros(n, dtype=torch.float32, device=d) if self.balance else None
         self.balance_alpha = 0.1   # weight of the newest sample in the moving average the order is sorted by (A/B on FetchPickAndPlace: 1.0 -> 2.69 ms, 0.15 -> 2.64 ms per step)
@@ -124,7 +125,7 @@ class HandReachVecEnv(GoalVecEnv):
 
     def _make_bufs(self, mask):
         b = _native.HandBuffersStruct()
-        for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status"):
+        for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "packed"):
             setattr(b, name, getattr(self, name).data_ptr())
         b.mask = None if mask is None else mask.data_ptr()
         b.order = None if self.order is None else self.order.data_ptr()
@@ -134,7 +135,11 @@ class HandReachVecEnv(GoalVecEnv):
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _launch(self, bufs, forward_only):
+    def _launch(self, bufs, forward_only, settle=False):
+        """settle: a reset-time settle launch of the step kernel (manipulate.py:205-224) -- not a timed env.step(), no cost re-ordering."""
+        if settle:
+            _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, 0, self._stream()))
+            return
         if self.kernel_events is not None and not forward_only:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -211,26 +216,34 @@ class HandReachVecEnv(GoalVecEnv):
                 self._reset_worlds(pending)
                 self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
             if self.autoreset_mode == "same_step" and truncated.any():
-                keep_r, keep_s = self.reward.clone(), self.success.clone()
-                self._reset_worlds(np.nonzero(truncated)[0])
+                done = np.nonzero(truncated)[0]
+                td = torch.from_numpy(done).to(self.device)
+                info["final_obs"] = self._obs_dict(rows=done)   # the terminal observation (bootstrapping), as FetchVecEnv reports it
+                keep_r, keep_s, keep_st = self.reward.clone(), self.success.clone(), self.status.clone()
+                self._reset_worlds(done)
                 self.reward.copy_(keep_r)
                 self.success.copy_(keep_s)
+                self.status.copy_((keep_st & 0xFFFF) | (self.status & -65536))   # this step's flags are the step launch's, not the reset launches'; sticky bits keep accumulating
+                self.packed[td, -2] = keep_r[td]
+                self.packed[td, -1] = keep_s[td].float()
             elif self.autoreset_mode == "next_step":
                 self._needs_reset |= truncated
         obs = self._obs_dict()
         if self.output == "torch":
             info["is_success"] = self.success
-            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), info
+            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), self._status_info(info)
         info["is_success"] = self.success.cpu().numpy().astype(np.float32)
-        info["status"] = self.status.cpu().numpy()
+        self._status_info(info)
         r = self.reward.cpu().numpy()
         return obs, (r if self.reward_type == "sparse" else r.astype(np.float64)), terminated, truncated, info
 
-    def _obs_dict(self):
+    def _obs_dict(self, rows=None):
         if self.output == "torch":
-            return {"observation": self.obs, "achieved_goal": self.achieved, "desired_goal": self.goal}
-        return {"observation": self.obs.double().cpu().numpy(), "achieved_goal": self.achieved.double().cpu().numpy(),
-                "desired_goal": self.goal.double().cpu().numpy()}
+            sel = (lambda t: t) if rows is None else (lambda t: t[torch.from_numpy(rows).to(self.device)])
+            return {"observation": sel(self.obs), "achieved_goal": sel(self.achieved), "desired_goal": sel(self.goal)}
+        sel = (lambda a: a) if rows is None else (lambda a: a[rows])
+        return {"observation": sel(self.obs.double().cpu().numpy()), "achieved_goal": sel(self.achieved.double().cpu().numpy()),
+                "desired_goal": sel(self.goal.double().cpu().numpy())}
 
     # ------------------------------------------------------------------ GoalEnv API (reach.py:92-97; core.py:45-114)
     def compute_reward(self, achieved_goal, desired_goal, info=None):
@@ -379,7 +392,7 @@ class HandBlockVecEnv(HandReachVecEnv):
             self.mask.zero_()
             self.mask[ti] = 1
             for _ in range(SETTLE_STEPS):
-                self._launch(self._bufs_masked, False)
+                self._launch(self._bufs_masked, False, settle=True)
             z = self.qpos[ti, self._qa + 2].cpu().numpy()
             pending = pending[~(z > PALM_HEIGHT)]
         self.action.copy_(saved_action)

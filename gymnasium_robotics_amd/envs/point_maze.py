@@ -82,6 +82,7 @@ class PointMazeVecEnv(GoalVecEnv):
         self.goal, self.action, self.obs, self.achieved, self.reward = z(n, 2), z(n, self.nu), z(n, self.obs_dim), z(n, 2), z(n)
         self.success, self.terminated = z(n, dtype=torch.uint8), z(n, dtype=torch.uint8)
         self.status, self.mask = z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
+        self.packed = z(n, self.obs_dim + 6)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)
         self.single_observation_space = Dict(dict(
@@ -95,10 +96,11 @@ class PointMazeVecEnv(GoalVecEnv):
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
+        self.kernel_events = None  # when a list: (start, end) HIP events around every step-kernel launch (benchmarks)
 
     def _make_bufs(self, mask):
         b = _native.PointBuffersStruct()
-        for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status"):
+        for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "packed"):
             setattr(b, name, getattr(self, name).data_ptr())
         b.mask = None if mask is None else mask.data_ptr()
         return b
@@ -126,6 +128,7 @@ class PointMazeVecEnv(GoalVecEnv):
         self.achieved[ti] = q[:, :2]
         d = torch.linalg.norm(self.achieved[ti] - self.goal[ti], dim=-1)
         self.success[ti] = (d <= GOAL_RADIUS).to(torch.uint8)
+        self.packed[ti] = torch.cat([o, self.achieved[ti], self.goal[ti], self.reward[ti].unsqueeze(1), self.success[ti].float().unsqueeze(1)], dim=1)
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
 
@@ -138,10 +141,11 @@ class PointMazeVecEnv(GoalVecEnv):
         self._has_reset = True
         return self._obs_dict(), self._info()
 
-    def _info(self):
+    def _info(self, success=None):
+        s = self.success if success is None else success
         if self.output == "torch":
-            return {"success": self.success.bool()}
-        return {"success": self.success.cpu().numpy().astype(bool), "status": self.status.cpu().numpy()}
+            return self._status_info({"success": s.bool()})
+        return self._status_info({"success": s.cpu().numpy().astype(bool)})
 
     # ------------------------------------------------------------------ step (point_maze.py:392-406)
     def step(self, actions):
@@ -158,7 +162,14 @@ class PointMazeVecEnv(GoalVecEnv):
                 self.mask.fill_(1)
                 self.mask[torch.from_numpy(pending).to(self.device)] = 0
                 bufs = self._bufs_masked
+            ev = self.kernel_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             _native.check(self._L.grx_point_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, self._stream()))
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
             stepped = ~self._needs_reset
             self._elapsed[stepped] += 1
             terminated = self.terminated.cpu().numpy().astype(bool) & stepped if not self.continuing_task else np.zeros(self.num_envs, bool)
@@ -168,7 +179,7 @@ class PointMazeVecEnv(GoalVecEnv):
             if len(pending):
                 self._reset_worlds(pending)
                 self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
-            new_goals = None
+            new_goals, final_obs, step_success = None, None, None
             if self.reset_target and self.continuing_task and len(self.maze.unique_goal_locations) > 1:
                 # MazeEnv.update_goal (maze_v4.py:400-418): the returned observation still carries the goal that was just reached
                 hit = np.nonzero(self.success.cpu().numpy().astype(bool) & stepped)[0]
@@ -179,9 +190,15 @@ class PointMazeVecEnv(GoalVecEnv):
             if self.autoreset_mode == "next_step":
                 self._needs_reset |= done
             elif self.autoreset_mode == "same_step" and done.any():
-                keep = self.reward.clone()
-                self._reset_worlds(np.nonzero(done)[0])
+                # the step's reward / success / terminal observation belong to the finished episode; the returned observation is the reset one
+                rows = np.nonzero(done)[0]
+                final_obs = self._obs_dict(rows=rows)
+                keep, step_success = self.reward.clone(), self.success.clone()
+                self._reset_worlds(rows)
                 self.reward.copy_(keep)
+                td = torch.from_numpy(rows).to(self.device)
+                self.packed[td, -2] = keep[td]
+                self.packed[td, -1] = step_success[td].float()
         obs = self._obs_dict()
         if new_goals is not None:
             if self.output == "torch":
@@ -190,15 +207,20 @@ class PointMazeVecEnv(GoalVecEnv):
             still = ~done[hit] if self.autoreset_mode == "same_step" else np.ones(len(hit), bool)   # worlds reset in this call keep their reset goal
             if still.any():
                 self.goal[torch.from_numpy(hit[still]).to(self.device)] = torch.from_numpy(goals[still].astype(np.float32)).to(self.device)
+        info = self._info(step_success)
+        if final_obs is not None:
+            info["final_obs"] = final_obs
         if self.output == "torch":
-            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), self._info()
-        return obs, self.reward.double().cpu().numpy(), terminated, truncated, self._info()
+            return obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), info
+        return obs, self.reward.double().cpu().numpy(), terminated, truncated, info
 
-    def _obs_dict(self):
+    def _obs_dict(self, rows=None):
         if self.output == "torch":
-            return {"observation": self.obs, "achieved_goal": self.achieved, "desired_goal": self.goal}
-        return {"observation": self.obs.double().cpu().numpy(), "achieved_goal": self.achieved.double().cpu().numpy(),
-                "desired_goal": self.goal.double().cpu().numpy()}
+            sel = (lambda t: t) if rows is None else (lambda t: t[torch.from_numpy(rows).to(self.device)])
+            return {"observation": sel(self.obs), "achieved_goal": sel(self.achieved), "desired_goal": sel(self.goal)}
+        sel = (lambda a: a) if rows is None else (lambda a: a[rows])
+        return {"observation": sel(self.obs.double().cpu().numpy()), "achieved_goal": sel(self.achieved.double().cpu().numpy()),
+                "desired_goal": sel(self.goal.double().cpu().numpy())}
 
     # ------------------------------------------------------------------ GoalEnv API (maze_v4.py:381-398)
     def compute_reward(self, achieved_goal, desired_goal, info=None):

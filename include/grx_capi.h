@@ -44,7 +44,9 @@ typedef struct grx_fetch_task {
   float distance_threshold, dt;
 } grx_fetch_task;
 
-/* bits of the per-world `status` words the step kernels write (0 = healthy; csrc/grx_engine.h GRX_ST_*) */
+/* bits of the per-world `status` words the step kernels write (0 = healthy; csrc/grx_engine.h GRX_ST_*).
+ * Bits 0-15 hold the flags of the LAST launch; bits 16-31 hold the same flags OR-accumulated over every launch since the caller last
+ * zeroed the buffer (sticky: `status >> 16` answers "did this world ever drop a contact / hit a bad number since I last looked"). */
 enum grx_status_bits {
   GRX_STATUS_BADNUM = 1,        /* a NaN / overflowing coordinate was found: the world was reset to qpos0 (MuJoCo's mj_checkPos / mj_checkVel behaviour) */
   GRX_STATUS_CON_OVERFLOW = 2,  /* more contacts than the model's contact capacity in some substep: the excess was dropped for that substep */
@@ -69,6 +71,8 @@ typedef struct grx_fetch_buffers {
    * worlds first (workgroups start in index order; b & 7 is the XCD: keep a world in the XCD slice that owns its neighbours). */
   const int* order;                     /* [8 * ceil(N / 8)] or NULL; entries >= N are idle workgroups */
   int* cost;                            /* [N] or NULL */
+  float* packed;                        /* [N, obs_dim+3+3+2] or NULL: the row [obs | achieved | desired | reward | success], written by the step kernel itself so
+                                         * that the cross-rank exchange (RCCL all-gather) ships one buffer and needs no pack kernels */
 } grx_fetch_buffers;
 
 /* mirrors struct GrxPointTask / GrxPointBuffers (csrc/grx_point_task.h) */
@@ -86,6 +90,7 @@ typedef struct grx_point_buffers {
   unsigned char *success, *terminated; /* [N] */
   int* status;                  /* [N] */
   const unsigned char* mask;    /* [N] or NULL */
+  float* packed;                /* [N, obs_dim+2+2+2] or NULL: [obs | achieved | desired | reward | success] (see grx_fetch_buffers.packed) */
 } grx_point_buffers;
 
 /* mirrors struct GrxHandTask / GrxHandBuffers (csrc/grx_hand_task.h): Shadow Dexterous Hand reach task */
@@ -113,6 +118,7 @@ typedef struct grx_hand_buffers {
   const unsigned char* mask;    /* [N] or NULL */
   const int* order;             /* [8 * ceil(N / 8)] or NULL: cost-ordered dispatch, as in grx_fetch_buffers */
   int* cost;                    /* [N] or NULL */
+  float* packed;                /* [N, obs_dim+2*goal_dim+2] or NULL: [obs | achieved | desired | reward | success] */
 } grx_hand_buffers;
 
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);
