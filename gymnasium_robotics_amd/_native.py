@@ -17,6 +17,10 @@ class FetchBuffersStruct(ctypes.Structure):
         "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed")]
 
 
+class FetchResetArgsStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("idx", "samples", "init_qpos", "init_qvel", "init_mocap")] + [("obj_qadr", ctypes.c_int)]
+
+
 class PointTaskStruct(ctypes.Structure):
     _fields_ = [("n_substeps", ctypes.c_int), ("sparse_reward", ctypes.c_int), ("continuing_task", ctypes.c_int), ("agent", ctypes.c_int),
                 ("goal_radius", ctypes.c_float), ("vel_clip", ctypes.c_float)]
@@ -49,6 +53,7 @@ def lib():
         L.grx_model_dim.argtypes = [vp, ctypes.c_char_p]
         L.grx_fetch_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_fetch_forward.argtypes = [vp, vp, vp, ci, ci, vp]
+        L.grx_fetch_reset.argtypes = [vp, vp, vp, vp, ci, vp]
         L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
@@ -69,5 +74,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
 ]

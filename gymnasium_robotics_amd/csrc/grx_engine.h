@@ -23,6 +23,7 @@
 #if defined(GRX_EMU)
 #define GRX_DEV static inline
 #define GRX_MEM static inline
+#define GRX_MEM_CALL static inline
 #define GRX_HD static inline
 #define FOR_LANES for (int lane = 0; lane < 64; ++lane)
 #define LANE0 if (1)
@@ -32,6 +33,7 @@ static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; ret
 #else
 #define GRX_DEV __device__ __forceinline__
 #define GRX_MEM static __device__ __forceinline__
+#define GRX_MEM_CALL static __device__ __attribute__((noinline))   // a real call: the routine gets its own register budget (rare, register-hungry paths)
 #define GRX_HD __host__ __device__ inline
 #define FOR_LANES for (int lane = lane_, once_ = 1; once_; once_ = 0)
 #define LANE0 if (lane_ == 0)
@@ -82,7 +84,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair;
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv;
   int mpr_iterations;
 };
@@ -111,6 +113,7 @@ struct GrxCtx {
   float* red;  // 128 floats
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
+  float* meshcache;  // models with hull-vs-convex pairs: 4 x (pair + 1, separating direction) + the slot to evict next, kept across the substeps of a step (grx_mesh_pairs)
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
   int maxefc, jpool, maxcon;  // capacities of the row tables / the packed Jacobian pool / the contact list of this model
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
@@ -126,7 +129,7 @@ struct GrxCtx {
 #define GRX_FRESH_MODEL(m, c) ((void)0)
 #else
 #define GRX_MAX_MODELS 32
-__constant__ GrxModel g_grx_models[GRX_MAX_MODELS];
+static __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];   // one copy per translation unit (see csrc/grx_kernels.hip on the build)
 #define GRX_FRESH_MODEL(m, c) do { int s_ = (c)->mslot; asm volatile("" : "+s"(s_)); (m) = g_grx_models + s_; } while (0)
 #endif
 
@@ -134,14 +137,14 @@ __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];
 // body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
 // Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
 // body frames, motion axes, M, J, row parameters) is persistent.
-struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool, ntouch, maxcon; };
+struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool, ntouch, maxcon, nmesh; };
 GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator, int maxefc = GRX_MAXEFC,
-                          int jpool = GRX_JPOOL, int ntouch = 0, int maxcon = GRX_MAXCON) {
+                          int jpool = GRX_JPOOL, int ntouch = 0, int maxcon = GRX_MAXCON, int nmesh = 0) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
   pers += jpool + maxefc * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
-  pers += 32 + 8;
+  pers += 32 + 8 + (nmesh ? 17 : 0);
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
@@ -172,6 +175,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   c->efc_floss = p; if (m->nfric) p += m->maxefc;
   CARVEI(efc_kind, m->maxefc) CARVEI(efc_id, m->maxefc) CARVEI(efc_row, m->maxefc)
   CARVEI(ired, 32) CARVEI(cnt, 8)
+  CARVE(meshcache, m->nmesh ? 17 : 0)
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
   if (m->ntouch) {
     CARVE(con_pos, 3 * m->maxcon) CARVE(con_frame, 3 * m->maxcon)
@@ -207,10 +211,10 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
 }
 
 GRX_HD GrxDims grx_dims_of(const GrxModel* m) {
-  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool, m->ntouch, m->maxcon};
+  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool, m->ntouch, m->maxcon, m->nmeshpair > 0};
   return d;
 }
-GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool, d.ntouch, d.maxcon); }
+GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool, d.ntouch, d.maxcon, d.nmesh); }
 
 // ------------------------------------------------------------------------------------------
 // small math (all per-lane, registers)
@@ -384,7 +388,9 @@ struct GrxShape {
   // incremental Hessian corrections between Newton iterations (grx_hessian_update): compiled into the kernels of models with a free
   // object in contact (several iterations per substep are common there); articulated-only models and the RK4 ant converge in one
   static constexpr bool kIncrHess = (NV_ == 0) || (NQ_ != NV_ && INTEG_ == 0);
-  static constexpr bool kConvex = (NV_ == 0) || (CONVEX_ != 0);   // carries the general convex (MPR) narrow phase: the generic kernels and the shapes of models that need it
+  static constexpr bool kConvex = (NV_ == 0) || ((CONVEX_ & 1) != 0);   // carries the general convex (MPR) narrow phase for primitive pairs: the generic kernels and the shapes of models that need it
+  static constexpr bool kMesh = (NV_ == 0) || ((CONVEX_ & 2) != 0);     // carries the wave-cooperative hull-vs-convex routine (models with mesh-mesh / mesh-primitive pairs)
+  static constexpr int NMESH = (CONVEX_ & 2) ? 1 : 0;
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NVC (S::kFixed ? S::NV : m->nv)
@@ -395,6 +401,9 @@ typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NGC (S::kFixed ? S::NG : m->ngeom)
 #define GRX_NSC (S::kFixed ? S::NS : m->nsite)
 #define GRX_NMC (S::kFixed ? S::NM : m->nmocap)
+#if defined(GRX_EMU)
+static long g_grx_mesh_stats[4];   // emulator diagnostics: hull pairs skipped by a cached separating direction / sent through the portal search
+#endif
 template <class S>
 struct GrxEngine {
 // ------------------------------------------------------------------------------------------
@@ -969,6 +978,22 @@ GRX_MEM void grx_capsule_capsule(const GrxModel* m, GrxCtx* c, int pair, int g1,
   float pos[3] = {p1[0] + n[0] * (r1 + 0.5f * dist), p1[1] + n[1] * (r1 + 0.5f * dist), p1[2] + n[2] * (r1 + 0.5f * dist)};
   grx_add_contact(c, pair, pos, n, dist);
 }
+// sphere vs sphere and sphere (geom1) vs capsule (geom2): the capsule contributes the point of its axis segment closest to the sphere centre
+GRX_MEM void grx_sphere_sphere_raw(GrxCtx* c, int pair, const float* c1, float r1, const float* c2, float r2, float margin) {
+  float n[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+  const float len = sqrtf(dot3f(n, n)), dist = len - r1 - r2;
+  if (dist > margin) return;
+  if (len < GRX_MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else { const float li = 1.0f / len; n[0] *= li; n[1] *= li; n[2] *= li; }
+  float pos[3] = {c1[0] + n[0] * (r1 + 0.5f * dist), c1[1] + n[1] * (r1 + 0.5f * dist), c1[2] + n[2] * (r1 + 0.5f * dist)};
+  grx_add_contact(c, pair, pos, n, dist);
+}
+GRX_MEM void grx_sphere_capsule(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
+  const float* c1 = c->gxpos + 3 * g1; const float* c2 = c->gxpos + 3 * g2; const float* R2 = c->gxmat + 9 * g2;
+  const float ax[3] = {R2[2], R2[5], R2[8]}, d[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+  const float h = m->geom_size[3 * g2 + 1], x = fminf(h, fmaxf(-h, dot3f(ax, d)));
+  const float p2[3] = {c2[0] + x * ax[0], c2[1] + x * ax[1], c2[2] + x * ax[2]};
+  grx_sphere_sphere_raw(c, pair, c1, m->geom_size[3 * g1], p2, m->geom_size[3 * g2], margin);
+}
 // ------------------------------------------------------------------------------------------
 // General convex pairs (ellipsoid / cylinder against sphere, capsule, ellipsoid, cylinder, box): Minkowski Portal Refinement, one
 // lane per pair, one contact per pair (what MuJoCo's libccd route produces; see the oracle's header comment on the algorithm and on
@@ -1003,11 +1028,41 @@ GRX_MEM void grx_geom_support(const float* R, const float* sz, int type, const f
   } else if (type == 6) { r[0] = grx_sgn1f(dl[0]) * sz[0]; r[1] = grx_sgn1f(dl[1]) * sz[1]; r[2] = grx_sgn1f(dl[2]) * sz[2]; }
   mulMatVec3f(out, R, r);
 }
-struct GrxMprPair { float R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2; };   // the two frames are copied into registers: ~20 support evaluations each read them twice
+struct GrxMprPair { float R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // the two frames are copied into registers: ~20 support evaluations each read them twice
+                    const float *v1, *v2; int n1, n2, lane;                      // hull vertices (geom frame) of mesh geoms: only read by the wave-cooperative variant
+                    GrxMprPt* pts; };                                            // wave-cooperative variant: LDS storage of the five portal points (keeps them out of the VGPR budget)
+// Convex hull of a mesh: the hull vertex farthest along the (geom-frame) direction dl; the lowest vertex index wins ties, like the oracle's
+// exhaustive scan.  Called from wave-uniform code: on the GPU the 64 lanes share the scan (lane l takes the vertices l, l + 64, ...; the
+// loads are coalesced) and agree on the winner through two DPP reductions -- a hull of 500 vertices costs 8 loads per lane.
+GRX_MEM void grx_mesh_support(const float* verts, int n, const float* dl, float* r, int lane_) {
+  r[0] = r[1] = r[2] = 0.0f;
+  if (n <= 0) return;
+#if defined(GRX_EMU)
+  (void)lane_;
+  float best = -3.0e38f; int bi = 0;
+  for (int v = 0; v < n; v++) { const float t = verts[3 * v] * dl[0] + verts[3 * v + 1] * dl[1] + verts[3 * v + 2] * dl[2]; if (t > best) { best = t; bi = v; } }
+#else
+  float best = -3.0e38f; int mine = 0;
+  for (int v0 = lane_; v0 < n; v0 += 256) {   // four independent vertex fetches in flight per lane: one memory latency per 256 vertices
+    float x[4], y[4], z[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int v = v0 + 64 * u < n ? v0 + 64 * u : n - 1; x[u] = verts[3 * v]; y[u] = verts[3 * v + 1]; z[u] = verts[3 * v + 2]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const float t = x[u] * dl[0] + y[u] * dl[1] + z[u] * dl[2]; if (v0 + 64 * u < n && t > best) { best = t; mine = v0 + 64 * u; } }
+  }
+  const float mx = grx_reduce_max(best);
+  const int bi = (int)(-grx_reduce_max((best == mx) ? -(float)mine : -3.0e38f));   // vertex indices are far below 2^24: exact in fp32
+#endif
+  r[0] = verts[3 * bi]; r[1] = verts[3 * bi + 1]; r[2] = verts[3 * bi + 2];
+}
+// W: wave-cooperative variant (uniform control flow, every lane holds the same values; mesh geoms allowed)
+template <bool W>
 GRX_MEM void grx_mpr_support(const GrxMprPair* q, const float* d, GrxMprPt* o) {
   float nd[3] = {-d[0], -d[1], -d[2]}, b[3];
-  grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
-  grx_geom_support(q->R2, q->s2, q->t2, nd, b);
+  if (W && q->t1 == 7) { float dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); grx_mesh_support(q->v1, q->n1, dl, r, q->lane); mulMatVec3f(o->w, q->R1, r); }
+  else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
+  if (W && q->t2 == 7) { float dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); grx_mesh_support(q->v2, q->n2, dl, r, q->lane); mulMatVec3f(b, q->R2, r); }
+  else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
   for (int k = 0; k < 3; k++) { o->w[k] += d[k] * q->hm; o->v[k] = o->w[k] - (b[k] + q->c21[k] - d[k] * q->hm); }
 }
 // the portal is kept as four separate points (not an array): every access is to a named variable, so the 30 floats stay in registers
@@ -1058,16 +1113,23 @@ GRX_MEM float grx_mpr_tri_dist2(const float* x0, const float* b, const float* cc
   return best;
 }
 // 0 = penetration (depth, dir, pos, surface witnesses w1 on geom 1 / w2 on geom 2 -- all relative to the centre of geom 1), -1 = separated
-GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float* depth, float* dir, float* pos, float* w1, float* w2) {
-  GrxMprPt P0, P1, P2, P3, v4;
+// sep (may be null): on a -1 return caused by a support point on the far side of the origin (v . d <= 0), sep[0..2] <- that direction d
+// and sep[3] <- 1: d separates the two (inflated) geoms, which any later call can re-check with ONE support evaluation (grx_mesh_pairs)
+template <bool W>
+GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float* depth, float* dir, float* pos, float* w1, float* w2, float* sep = nullptr) {
+#define GRX_MPR_SEP(D) do { if (W && sep) { sep[0] = (D)[0]; sep[1] = (D)[1]; sep[2] = (D)[2]; sep[3] = 1.0f; } } while (0)
+  // lane-per-pair variant: the portal lives in registers; wave-cooperative variant: in LDS (every lane writes the same values)
+  GrxMprPt r0_, r1_, r2_, r3_, r4_;
+  GrxMprPt& P0 = W ? q->pts[0] : r0_; GrxMprPt& P1 = W ? q->pts[1] : r1_; GrxMprPt& P2 = W ? q->pts[2] : r2_; GrxMprPt& P3 = W ? q->pts[3] : r3_;
+  GrxMprPt& v4 = W ? q->pts[4] : r4_;
   float d[3], a[3], b[3], dotv;
   for (int k = 0; k < 3; k++) { P0.w[k] = 0.0f; P0.v[k] = -q->c21[k]; }
   if (grx_mpr_eq(P0.v[0], 0.0f) && grx_mpr_eq(P0.v[1], 0.0f) && grx_mpr_eq(P0.v[2], 0.0f)) P0.v[0] += GRX_MPR_EPS * 10.0f;
   for (int k = 0; k < 3; k++) d[k] = -P0.v[k];
   grx_normalize3f(d);
-  grx_mpr_support(q, d, &P1);
+  grx_mpr_support<W>(q, d, &P1);
   dotv = dot3f(P1.v, d);
-  if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
+  if (grx_mpr_zero(dotv) || dotv < 0.0f) { GRX_MPR_SEP(d); return -1; }
   cross3f(d, P0.v, P1.v);
   if (grx_mpr_zero(dot3f(d, d))) {
     for (int k = 0; k < 3; k++) { w1[k] = P1.w[k]; w2[k] = P1.w[k] - P1.v[k]; pos[k] = 0.5f * (w1[k] + w2[k]); }
@@ -1076,17 +1138,17 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
     return 0;
   }
   grx_normalize3f(d);
-  grx_mpr_support(q, d, &P2);
+  grx_mpr_support<W>(q, d, &P2);
   dotv = dot3f(P2.v, d);
-  if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
+  if (grx_mpr_zero(dotv) || dotv < 0.0f) { GRX_MPR_SEP(d); return -1; }
   for (int k = 0; k < 3; k++) { a[k] = P1.v[k] - P0.v[k]; b[k] = P2.v[k] - P0.v[k]; }
   cross3f(d, a, b); grx_normalize3f(d);
   if (dot3f(d, P0.v) > 0.0f) { GrxMprPt t = P1; P1 = P2; P2 = t; d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
   for (int guard = 0;; guard++) {
     if (guard > 200) return -1;
-    grx_mpr_support(q, d, &P3);
+    grx_mpr_support<W>(q, d, &P3);
     dotv = dot3f(P3.v, d);
-    if (grx_mpr_zero(dotv) || dotv < 0.0f) return -1;
+    if (grx_mpr_zero(dotv) || dotv < 0.0f) { GRX_MPR_SEP(d); return -1; }
     int cont = 0;
     cross3f(a, P1.v, P3.v); dotv = dot3f(a, P0.v);
     if (dotv < 0.0f && !grx_mpr_zero(dotv)) { P2 = P3; cont = 1; }
@@ -1103,14 +1165,15 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
     grx_mpr_portal_dir(P1, P2, P3, d);
     dotv = dot3f(d, P1.v);
     if (grx_mpr_zero(dotv) || dotv > 0.0f) break;
-    grx_mpr_support(q, d, &v4);
+    grx_mpr_support<W>(q, d, &v4);
     dotv = dot3f(v4.v, d);
-    if (!(grx_mpr_zero(dotv) || dotv > 0.0f) || grx_mpr_reach_tolerance(P1, P2, P3, v4, d, tol)) return -1;
+    if (!(grx_mpr_zero(dotv) || dotv > 0.0f)) { GRX_MPR_SEP(d); return -1; }
+    if (grx_mpr_reach_tolerance(P1, P2, P3, v4, d, tol)) return -1;
     grx_mpr_expand(P0, P1, P2, P3, v4);
   }
   for (int it = 0;; it++) {
     grx_mpr_portal_dir(P1, P2, P3, d);
-    grx_mpr_support(q, d, &v4);
+    grx_mpr_support<W>(q, d, &v4);
     if (grx_mpr_reach_tolerance(P1, P2, P3, v4, d, tol) || it > maxit) {
       float w[3];
       *depth = sqrtf(grx_mpr_tri_dist2(P1.v, P2.v, P3.v, w));
@@ -1151,6 +1214,7 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
     grx_mpr_expand(P0, P1, P2, P3, v4);
   }
 }
+#undef GRX_MPR_SEP
 // analytic outward normal of a smooth geom (sphere, capsule, ellipsoid) at the world point p (see the oracle: the portal direction of a
 // shallow contact is ill-conditioned, MuJoCo replaces it for smooth geoms); returns 0 for the other types
 GRX_MEM int grx_smooth_normal(const float* R, const float* ce, const float* sz, int type, const float* p, float* n) {
@@ -1173,7 +1237,8 @@ GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int
   q.t1 = t1; q.t2 = t2; q.hm = 0.5f * margin;
   for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = c->gxpos[3 * g2 + k] - c->gxpos[3 * g1 + k]; }
   float depth, dir[3], pos[3], w1[3], w2[3];
-  if (grx_mpr_penetration(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;
+  q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr;
+  if (grx_mpr_penetration<false>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;
   if (dir[0] == 0.0f && dir[1] == 0.0f && dir[2] == 0.0f) return;
   for (int k = 0; k < 3; k++) pos[k] += c->gxpos[3 * g1 + k];
   float n1[3] = {0.0f, 0.0f, 0.0f}, n2[3] = {0.0f, 0.0f, 0.0f};
@@ -1191,6 +1256,106 @@ GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int
     }
   }
   grx_add_contact(c, pair, pos, dir, margin - depth);
+}
+// ------------------------------------------------------------------------------------------
+// Hull-vs-convex pairs (the convex hull of a mesh against a primitive or another hull: the Fetch arm / gripper / base links, assets/fetch/
+// robot.xml:16-93).  MuJoCo sends them through the same general convex routine as the ellipsoid / cylinder pairs; here the pair is
+// handled by the WHOLE wavefront: the portal refinement runs in wave-uniform control flow (every lane holds the same values) and the hull
+// support function is a cooperative scan over the vertices (grx_mesh_support), because a lane-private walk over a hull in global memory
+// is a chain of dependent loads (~25 us per support point).  Candidates are rare -- one persistent pair per Fetch world passes the
+// bounding-box filter, a contact exists in 0.04 % of the substeps -- and a separating direction found by one substep is kept for the next
+// ones (c->meshcache): re-checking it costs ONE support evaluation instead of the six or seven of a fresh portal search, and a direction
+// that still separates the two inflated geoms proves that the routine would report "no contact".
+// ------------------------------------------------------------------------------------------
+// separating-axis test of the two geoms' oriented bounding boxes (geom_aabb), each grown by margin / 2 (the oracle's obb_overlap)
+GRX_MEM int grx_obb_overlap(const GrxModel* m, const GrxCtx* c, int g1, int g2, float margin) {
+  const float* R1 = c->gxmat + 9 * g1; const float* R2 = c->gxmat + 9 * g2; const float* a1 = m->geom_aabb + 6 * g1; const float* a2 = m->geom_aabb + 6 * g2;
+  float c1[3], c2[3], t[3];
+  { const float l1[3] = {a1[0], a1[1], a1[2]}, l2[3] = {a2[0], a2[1], a2[2]}; mulMatVec3f(c1, R1, l1); mulMatVec3f(c2, R2, l2); }
+  for (int k = 0; k < 3; k++) t[k] = (c2[k] + c->gxpos[3 * g2 + k]) - (c1[k] + c->gxpos[3 * g1 + k]);
+  const float e1[3] = {a1[3] + 0.5f * margin, a1[4] + 0.5f * margin, a1[5] + 0.5f * margin}, e2[3] = {a2[3] + 0.5f * margin, a2[4] + 0.5f * margin, a2[5] + 0.5f * margin};
+  float C[3][3], AC[3][3];   // C[i][j] = A_i . B_j
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { C[i][j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j]; AC[i][j] = fabsf(C[i][j]); }
+  float ta[3], tb[3];
+  for (int i = 0; i < 3; i++) { ta[i] = t[0] * R1[i] + t[1] * R1[3 + i] + t[2] * R1[6 + i]; tb[i] = t[0] * R2[i] + t[1] * R2[3 + i] + t[2] * R2[6 + i]; }
+  for (int i = 0; i < 3; i++) {
+    if (fabsf(ta[i]) > e1[i] + e2[0] * AC[i][0] + e2[1] * AC[i][1] + e2[2] * AC[i][2]) return 0;
+    if (fabsf(tb[i]) > e2[i] + e1[0] * AC[0][i] + e1[1] * AC[1][i] + e1[2] * AC[2][i]) return 0;
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {   // axis A_i x B_j, in the frame of box 1: components are +-C[k][j]; unnormalised on both sides of the test
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const float l2 = 1.0f - C[i][j] * C[i][j];
+      if (l2 < 1e-6f) continue;   // nearly parallel edges: the face axes decide
+      const float tp = fabsf(ta[i2] * C[i1][j] - ta[i1] * C[i2][j]);
+      const float ra = e1[i1] * AC[i2][j] + e1[i2] * AC[i1][j], rb = e2[j1] * AC[i][j2] + e2[j2] * AC[i][j1];
+      if (tp > (ra + rb) * 1.0001f + 1e-7f) return 0;
+    }
+  return 1;
+}
+
+// the queued hull-vs-convex pairs of this pass, one after the other, all lanes on each (wave-uniform code)
+GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int nq, int lane_) {
+  for (int e = 0; e < nq; e++) {
+    const int pair = queue[e], g1 = m->pair_geom1[pair], g2 = m->pair_geom2[pair];
+    const float margin = m->pair_margin[pair];
+    GrxMprPair q;
+    for (int k = 0; k < 9; k++) { q.R1[k] = c->gxmat[9 * g1 + k]; q.R2[k] = c->gxmat[9 * g2 + k]; }
+    q.t1 = m->geom_type[g1]; q.t2 = m->geom_type[g2]; q.hm = 0.5f * margin; q.lane = lane_;
+    for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = c->gxpos[3 * g2 + k] - c->gxpos[3 * g1 + k]; }
+    q.v1 = q.t1 == 7 ? m->mesh_vert + 3 * m->geom_meshadr[g1] : m->mesh_vert; q.n1 = q.t1 == 7 ? m->geom_meshnum[g1] : 0;
+    q.v2 = q.t2 == 7 ? m->mesh_vert + 3 * m->geom_meshadr[g2] : m->mesh_vert; q.n2 = q.t2 == 7 ? m->geom_meshnum[g2] : 0;
+    q.pts = (GrxMprPt*)(c->Jp + 192);   // 30 words behind the pair queue: the Jacobian pool is free until the constraint stage
+    // a direction kept from an earlier substep: still separating?
+    float* mc = c->meshcache;
+    const float key = (float)(pair + 1);
+    const int slot = mc[0] == key ? 0 : (mc[4] == key ? 1 : (mc[8] == key ? 2 : (mc[12] == key ? 3 : -1)));
+    if (slot >= 0) {
+      const float d[3] = {mc[4 * slot + 1], mc[4 * slot + 2], mc[4 * slot + 3]};
+      GrxMprPt sp;
+      grx_mpr_support<true>(&q, d, &sp);
+      if (dot3f(sp.v, d) < -1e-6f) {   // strictly on the far side: the (inflated) geoms are disjoint
+#if defined(GRX_EMU)
+        g_grx_mesh_stats[0]++;
+#endif
+        continue;
+      }
+    }
+#if defined(GRX_EMU)
+    g_grx_mesh_stats[1]++;
+#endif
+    float depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
+#if defined(GRX_EMU) && defined(GRX_MESH_DEBUG)
+    fprintf(stderr, "meshpair %d (g %d %d) slot %d rc %d sep %g\n", pair, g1, g2, slot, rc, (double)sep[3]);
+#endif
+    WAVE_SYNC();
+    if (rc != 0) {
+      if (sep[3] != 0.0f) {   // keep the direction for the next substeps
+        const int w = slot >= 0 ? slot : ((int)mc[16] & 3);   // the pair's own slot, else round robin over the four
+        LANE0 { mc[4 * w] = key; mc[4 * w + 1] = sep[0]; mc[4 * w + 2] = sep[1]; mc[4 * w + 3] = sep[2]; if (slot < 0) mc[16] = (float)((w + 1) & 3); }
+      }
+      WAVE_SYNC();
+      continue;
+    }
+    if (dir[0] == 0.0f && dir[1] == 0.0f && dir[2] == 0.0f) continue;
+    for (int k = 0; k < 3; k++) pos[k] += c->gxpos[3 * g1 + k];
+    float n1[3] = {0.0f, 0.0f, 0.0f}, n2[3] = {0.0f, 0.0f, 0.0f};
+    const int h1 = grx_smooth_normal(q.R1, c->gxpos + 3 * g1, q.s1, q.t1, pos, n1), h2 = grx_smooth_normal(q.R2, c->gxpos + 3 * g2, q.s2, q.t2, pos, n2);
+    if (h1 || h2) {   // a smooth primitive against the hull: analytic normal, depth along it (see grx_convex_pair)
+      float n[3] = {n1[0] - n2[0], n1[1] - n2[1], n1[2] - n2[2]};
+      const float l2 = dot3f(n, n);
+      if (l2 > 1e-30f) {
+        const float il = 1.0f / sqrtf(l2); dir[0] = n[0] * il; dir[1] = n[1] * il; dir[2] = n[2] * il;
+        float nd[3] = {-dir[0], -dir[1], -dir[2]};
+        if (h1) { grx_geom_support(q.R1, q.s1, q.t1, dir, w1); for (int k = 0; k < 3; k++) w1[k] += dir[k] * q.hm; }
+        if (h2) { grx_geom_support(q.R2, q.s2, q.t2, nd, w2); for (int k = 0; k < 3; k++) w2[k] += q.c21[k] - dir[k] * q.hm; }
+        depth = (w1[0] - w2[0]) * dir[0] + (w1[1] - w2[1]) * dir[1] + (w1[2] - w2[2]) * dir[2];
+      }
+    }
+    LANE0 { grx_add_contact(c, pair, pos, dir, margin - depth); }
+    WAVE_SYNC();
+  }
 }
 // plane vs cylinder: near-cap rim point, far-cap rim point, two more corners of a triangle inscribed in the near rim (see the oracle)
 GRX_MEM void grx_plane_cylinder(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
@@ -1575,9 +1740,9 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     WAVE_SYNC();
   }
   for (int base = 0; base < m->ndevpair; base += 64) {
-    GRX_LANEVAR_I(boxq);
+    GRX_LANEVAR_I(boxq); GRX_LANEVAR_I(meshq);
     FOR_LANES {
-      int k = base + lane, isbox = 0;
+      int k = base + lane, isbox = 0, ismesh = 0;
       if (k < m->ndevpair) {
         // one packed record per candidate (geoms, types, margin, broad-phase radius): a single level of model-table loads
         const unsigned rec = (unsigned)m->devpair_geoms[k];
@@ -1594,7 +1759,10 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
         }
         if (pass) {
           const int p = m->devpair[k];
-          if (t1 == 0 && t2 == 2) grx_plane_sphere(m, c, p, g1, g2, margin);
+          if (t2 == 7 && t1 != 0) { if (S::kMesh) ismesh = grx_obb_overlap(m, c, g1, g2, margin); }
+          else if (t1 == 2 && t2 == 2) grx_sphere_sphere_raw(c, p, c->gxpos + 3 * g1, m->geom_size[3 * g1], c->gxpos + 3 * g2, m->geom_size[3 * g2], margin);
+          else if (t1 == 2 && t2 == 3) grx_sphere_capsule(m, c, p, g1, g2, margin);
+          else if (t1 == 0 && t2 == 2) grx_plane_sphere(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 3) grx_plane_capsule(m, c, p, g1, g2, margin);
           else if (t1 == 3 && t2 == 6) grx_capsule_box(m, c, p, g1, g2, margin);
           else if (t1 == 3 && t2 == 3) grx_capsule_capsule(m, c, p, g1, g2, margin);
@@ -1610,10 +1778,19 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           }
         }
       }
-      LV(boxq) = isbox;
+      LV(boxq) = isbox; LV(meshq) = ismesh;
     }
     WAVE_SYNC();
     GRX_SUBTICK(c, 13);
+    if (S::kMesh) {   // hull-vs-convex pairs that passed the bounding-box filter: pair order, the whole wave on each
+      const unsigned long long mm = GRX_BALLOT(meshq);
+      if (mm) {
+        int* queue = (int*)(c->Jp + 128);   // the Jacobian pool is free until the constraint stage; [0, 128) is c->red
+        FOR_LANES { if (LV(meshq)) queue[__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = m->devpair[base + lane]; }
+        WAVE_SYNC();
+        grx_mesh_pairs(m, c, queue, __builtin_popcountll(mm), lane_);
+      }
+    }
     // box-box pairs that passed the broad phase: queue them (pair order) and let eight lanes work on each
     {
       const unsigned long long bm = GRX_BALLOT(boxq);

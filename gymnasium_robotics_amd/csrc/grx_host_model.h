@@ -54,6 +54,8 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
     const unsigned rec = (unsigned)v.devpair_geoms[k]; const int t1 = (rec >> 24) & 0xF, t2 = rec >> 28;
     if ((t1 == 0 && (t2 == 4 || t2 == 5)) || (t1 >= 2 && t2 <= 6 && (t1 == 4 || t1 == 5 || t2 == 4 || t2 == 5))) m.nconvex++;
   }
+  m.nmeshpair = 0;   // hull against a primitive or another hull: the wave-cooperative routine (grx_mesh_pairs) and its 8-word direction cache
+  for (int k = 0; k < v.n_devpair_geoms; k++) { const unsigned rec = (unsigned)v.devpair_geoms[k]; if ((rec >> 28) == 7 && ((rec >> 24) & 0xF) != 0) m.nmeshpair++; }
   m.nfric = 0; m.nweld = 0; m.wpool = 0;
   for (int k = 0; k < v.n_weld_row; k++) m.wpool += 6 * ((v.weld_row[k] >> 20) & 0xFF);
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;

@@ -3,6 +3,17 @@
 // Launch geometry: one 64-lane wavefront (= one workgroup) per world, dynamic LDS holds the
 // world's whole working set (grx_ctx_words), so the 20 fused substeps of an env.step() read
 // and write HBM exactly once.  Worlds are independent: no inter-workgroup communication.
+//
+// Build: this ONE source is compiled either as a single translation unit (no GRX_TU_* macro: the profiling variant) or, for the product
+// library, four times in parallel with -DGRX_TU_FETCH / -DGRX_TU_HAND / -DGRX_TU_POINT / -DGRX_TU_API (one family of kernel
+// instantiations each; __graft_entry__.build links the objects).  Every unit has its own copy of the constant-memory model descriptors
+// (g_grx_models is static): grx_model_create uploads a descriptor to each of them through grx_tu_*_prepare.
+#if !defined(GRX_TU_FETCH) && !defined(GRX_TU_HAND) && !defined(GRX_TU_POINT) && !defined(GRX_TU_API)
+#define GRX_TU_FETCH 1
+#define GRX_TU_HAND 1
+#define GRX_TU_POINT 1
+#define GRX_TU_API 1
+#endif
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -92,27 +103,29 @@ static __device__ __forceinline__ int grx_world_of_block_late() {
 // into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs) and the loops over
 // dofs / bodies / joints unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
 template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(const GrxModel& m) {
-  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP, S::NT, S::MC};
+  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP, S::NT, S::MC, S::NMESH};
   return grx_dims_of(&m);
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (S::NF != 24 || g.handtree);
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (S::kMesh == (g.nmeshpair != 0)) && (S::NF != 24 || g.handtree);
 }
-typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchObject; // FetchPush / FetchSlide-like (arm + object)
-typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 112, 1520, 0, 32> GrxShapeFetchArm;    // FetchReach (arm only)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1520, 0, 32, 0, 1> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
+// last template argument: bit 0 = general convex routine for primitive pairs (ellipsoid / cylinder), bit 1 = hull-vs-convex pairs (every model with
+// collidable mesh geoms next to boxes / other meshes: all Fetch and Shadow-hand models)
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1504, 0, 32, 0, 2> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1504, 0, 32, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
+typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 112, 1504, 0, 32, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1504, 0, 32, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
 typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntOpen;
 typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntUMaze;
-typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, 96, 512, 0, 16, 1> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 1> GrxShapeHandEgg;     // manipulate_egg.xml: the ellipsoid goes through the convex narrow phase
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 944, 92, 24, 1, 1> GrxShapeHandEggTouch;
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 944, 92, 24, 1> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
+typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, 96, 512, 0, 16, 1, 2> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 2> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 3> GrxShapeHandEgg;     // manipulate_egg.xml: the ellipsoid goes through the convex narrow phase
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 3> GrxShapeHandEggTouch;
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 2> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
 template <class S>
 __global__ void __launch_bounds__(64, (S::kFixed && !S::kConvex) ? 3 : 2)   // the convex narrow phase needs the full VGPR budget (41 spills at 168)
@@ -153,8 +166,10 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
 #endif
 }
 
-// reset path: (optional raw settle steps) + mj_forward + outputs
-extern "C" __global__ void __launch_bounds__(64)
+// reset-time mj_forward + outputs (nstep > 0: raw settle steps first, _env_setup).  Shape-specialised like the step kernel: the generic
+// instantiation needs 275 VGPRs (one wave per SIMD) and took 1.6 x a whole env.step().
+template <class S>
+__global__ void __launch_bounds__(64, (S::kFixed && !S::kConvex) ? 3 : 2)
 grx_fetch_forward_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words, int nstep) {
   extern __shared__ float lds[];
   const int w = grx_world_of_block(), lane_ = threadIdx.x;
@@ -163,14 +178,60 @@ grx_fetch_forward_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_wor
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
-  grx_ctx_carve(&c, lds, grx_dims_of(&m));
+  grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
 #endif
   grx_load_world(m, b, c, w, lds, words, lane_);
-  { const int total = nstep > 0 ? nstep : 1; for (int s = 0; s < total; s++) GrxEngine<GrxShapeAny>::grx_forward_euler(&m, &c, nstep > 0, lane_); }
-  GrxFetch<GrxShapeAny>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)w * 8, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
+  { const int total = nstep > 0 ? nstep : 1; for (int s = 0; s < total; s++) GrxEngine<S>::grx_forward_euler(&m, &c, nstep > 0, lane_); }
+  const int wl = grx_world_of_block_late();
+  GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)wl * 8, b.obs + (size_t)wl * t.obs_dim, b.achieved + (size_t)wl * 3, lane_);
+  __syncthreads();
+  grx_store_world(m, t, b, c, wl, lane_);
+}
+
+// Episode reset of a COMPACTED list of worlds (fetch_env.py:375-402 _reset_sim + :153-166 _sample_goal + mj_forward + _get_obs): workgroup k
+// resets world idx[k] -- initial state rows, the object position and the goal the host drew for it -- so an autoreset of 82 of 4096 worlds is
+// an 82-workgroup launch instead of a masked launch over the whole grid, and nothing on the host waits for the device.
+struct GrxFetchResetArgs {
+  const int* idx;          // [n] worlds to reset
+  const float* samples;    // [n,5] object xy, goal xyz (host PCG64 draws, grx_fetch_sample_resets)
+  const float *init_qpos, *init_qvel, *init_mocap;   // [nq] [nv] [7*nmocap]: the state _env_setup left (fetch_env.py:404-428)
+  int obj_qadr;            // qpos address of object0:joint, -1 without object
+};
+template <class S>
+__global__ void __launch_bounds__(64, (S::kFixed && !S::kConvex) ? 3 : 2)
+grx_fetch_reset_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, GrxFetchResetArgs r, int n_reset, int words) {
+  extern __shared__ float lds[];
+  const int k = blockIdx.x, lane_ = threadIdx.x;
+  if (k >= n_reset) return;
+  const int w = r.idx[k];
+  const GrxModel& m = g_grx_models[mslot];
+  GrxCtx c;
+  c.mslot = mslot;
+  grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
+#ifdef GRX_PROFILE
+  __shared__ long long prof_s[GRX_NPROF + 1];
+  c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
+#endif
+  for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
+  __syncthreads();
+  for (int i = lane_; i < m.nq; i += 64) c.qpos[i] = r.init_qpos[i];
+  for (int i = lane_; i < m.nv; i += 64) c.qvel[i] = r.init_qvel[i];   // qacc_warmstart stays 0 (mj_resetData)
+  for (int i = lane_; i < 7 * m.nmocap; i += 64) {
+    const int q = i / 7, e = i - 7 * q; const float v = r.init_mocap[i];
+    if (e < 3) c.mocap_pos[3 * q + e] = v; else c.mocap_quat[4 * q + e - 3] = v;
+  }
+  __syncthreads();
+  if (lane_ == 0) {
+    if (r.obj_qadr >= 0) { c.qpos[r.obj_qadr] = r.samples[5 * k]; c.qpos[r.obj_qadr + 1] = r.samples[5 * k + 1]; }
+    float* goal = const_cast<float*>(b.goal) + (size_t)w * 3;
+    goal[0] = r.samples[5 * k + 2]; goal[1] = r.samples[5 * k + 3]; goal[2] = r.samples[5 * k + 4];
+  }
+  __syncthreads();
+  GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
+  GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)w * 8, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, w, lane_);
 }
@@ -288,6 +349,110 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// per-family translation units: shape selection, LDS limits, descriptor upload, launches
+// ------------------------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a model: several live models share the generic
+// kernels, so the attribute is only ever raised (a later, smaller model must not lower the limit of an earlier, larger one).
+#include <map>
+static hipError_t grx_raise_lds_limit(const void* fn, int bytes) {
+  static std::map<const void*, int> limit;
+  int& cur = limit[fn];
+  if (bytes <= cur) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) cur = bytes;
+  return e;
+}
+static hipError_t grx_upload_descriptor(const GrxModel* g, int slot) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_grx_models), g, sizeof(GrxModel), sizeof(GrxModel) * (size_t)slot, hipMemcpyHostToDevice);
+}
+#define GRX_LDS(KERNEL) do { hipError_t e_ = grx_raise_lds_limit((const void*)(KERNEL), bytes); if (e_ != hipSuccess) return (int)e_; } while (0)
+// grx_tu_*_prepare: returns a hipError_t (0 = ok); *shape <- id of the shape-specialised kernels that serve the model (unchanged if none)
+
+#if GRX_TU_FETCH
+#define GRX_FETCH_SHAPES(X) X(1, GrxShapeFetchPick) X(2, GrxShapeFetchObject) X(7, GrxShapeFetchPuck) X(3, GrxShapeFetchArm)
+extern "C" int grx_tu_fetch_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
+  GRX_LDS(grx_fetch_step_kernel<GrxShapeAny>); GRX_LDS(grx_fetch_forward_kernel<GrxShapeAny>); GRX_LDS(grx_fetch_reset_kernel<GrxShapeAny>);
+  int found = 0;
+#define X(ID, SHAPE) if (!found && grx_shape_matches<SHAPE>(*g)) { found = ID; GRX_LDS(grx_fetch_step_kernel<SHAPE>); GRX_LDS(grx_fetch_forward_kernel<SHAPE>); GRX_LDS(grx_fetch_reset_kernel<SHAPE>); }
+  GRX_FETCH_SHAPES(X)
+#undef X
+  if (found) *shape = found;
+  return (int)grx_upload_descriptor(g, slot);
+}
+// kind 0: env.step, 1: forward (nstep), 2: compacted reset
+extern "C" int grx_tu_fetch_launch(int kind, int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxFetchTask* t, const GrxFetchBuffers* b,
+                                   const GrxFetchResetArgs* r, int n, int words, int nstep) {
+  const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+#define GRX_FETCH_GO(SHAPE) do { \
+    if (kind == 0) hipLaunchKernelGGL(grx_fetch_step_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words); \
+    else if (kind == 1) hipLaunchKernelGGL(grx_fetch_forward_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words, nstep); \
+    else hipLaunchKernelGGL(grx_fetch_reset_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, *r, n, words); } while (0)
+  switch (shape) {   // the specialised kernels are bit-identical to the generic one (same source, dims folded)
+#define X(ID, SHAPE) case ID: GRX_FETCH_GO(SHAPE); break;
+    GRX_FETCH_SHAPES(X)
+#undef X
+    default: GRX_FETCH_GO(GrxShapeAny);
+  }
+#undef GRX_FETCH_GO
+  return (int)hipGetLastError();
+}
+#endif
+
+#if GRX_TU_POINT
+#define GRX_POINT_SHAPES(X) X(10, GrxShapeAntLarge) X(11, GrxShapeAntMedium) X(12, GrxShapeAntOpen) X(13, GrxShapeAntUMaze)
+extern "C" int grx_tu_point_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
+  GRX_LDS(grx_point_step_kernel<GrxShapeAny>);
+#define X(ID, SHAPE) if (grx_shape_matches<SHAPE>(*g)) { *shape = ID; GRX_LDS(grx_point_step_kernel<SHAPE>); }
+  GRX_POINT_SHAPES(X)
+#undef X
+  return (int)grx_upload_descriptor(g, slot);
+}
+extern "C" int grx_tu_point_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxPointTask* t, const GrxPointBuffers* b, int n, int words) {
+  const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+  switch (shape) {
+#define X(ID, SHAPE) case ID: hipLaunchKernelGGL(grx_point_step_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words); break;
+    GRX_POINT_SHAPES(X)
+#undef X
+    default: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+  }
+  return (int)hipGetLastError();
+}
+#endif
+
+#if GRX_TU_HAND
+#define GRX_HAND_SHAPES(X) X(4, GrxShapeHandReach) X(6, GrxShapeHandBlockTouch) X(8, GrxShapeHandEgg) X(9, GrxShapeHandEggTouch) X(5, GrxShapeHandBlock)
+extern "C" int grx_tu_hand_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
+  GRX_LDS(grx_hand_step_kernel<GrxShapeAny>);
+#define X(ID, SHAPE) if (grx_shape_matches<SHAPE>(*g)) { *shape = ID; GRX_LDS(grx_hand_step_kernel<SHAPE>); }
+  GRX_HAND_SHAPES(X)
+#undef X
+  return (int)grx_upload_descriptor(g, slot);
+}
+extern "C" int grx_tu_hand_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxHandTask* t, const GrxHandBuffers* b, int n, int words,
+                                  int forward_only) {
+  const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+  switch (shape) {
+#define X(ID, SHAPE) case ID: hipLaunchKernelGGL(grx_hand_step_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only); break;
+    GRX_HAND_SHAPES(X)
+#undef X
+    default: hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
+  }
+  return (int)hipGetLastError();
+}
+#endif
+#undef GRX_LDS
+
+#if GRX_TU_API
+extern "C" int grx_tu_fetch_prepare(const GrxModel* g, int bytes, int slot, int* shape);
+extern "C" int grx_tu_point_prepare(const GrxModel* g, int bytes, int slot, int* shape);
+extern "C" int grx_tu_hand_prepare(const GrxModel* g, int bytes, int slot, int* shape);
+extern "C" int grx_tu_fetch_launch(int kind, int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxFetchTask* t, const GrxFetchBuffers* b,
+                                   const GrxFetchResetArgs* r, int n, int words, int nstep);
+extern "C" int grx_tu_point_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxPointTask* t, const GrxPointBuffers* b, int n, int words);
+extern "C" int grx_tu_hand_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxHandTask* t, const GrxHandBuffers* b, int n, int words,
+                                  int forward_only);
+
 extern "C" __global__ void __launch_bounds__(256)
 grx_goal_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int dim, float thr, int sparse, float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x)
@@ -378,19 +543,6 @@ static int fail(const std::string& msg) { g_err = msg; return -1; }
 
 extern "C" const char* grx_last_error(void) { return g_err.c_str(); }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a model: several live models share the generic
-// kernels, so the attribute is only ever raised (a later, smaller model must not lower the limit of an earlier, larger one).
-#include <map>
-static int grx_raise_lds_limit(const void* fn, int bytes) {
-  static std::map<const void*, int> limit;
-  int& cur = limit[fn];
-  if (bytes <= cur) return 0;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
-  cur = bytes;
-  return 0;
-}
-
 static void grx_model_free(grx_model* m) {
   if (!m) return;
   if (m->slot >= 0) g_slot_used[m->slot] = 0;
@@ -415,27 +567,14 @@ static int grx_model_create_impl(const int32_t* H, const int32_t* I, const doubl
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
   if (g.nbody > 64) return fail("engine limit: at most 64 bodies per world (one lane per body, 64-bit subtree masks)");
   if (g.nweld > g.maxefc / 16) return fail("engine limit: too many weld constraints (weld frames are staged in the row-parameter slot)");
-#define GRX_LDS(KERNEL) do { if (grx_raise_lds_limit((const void*)(KERNEL), bytes)) return -1; } while (0)
-  GRX_LDS(grx_fetch_step_kernel<GrxShapeAny>);
-  m->shape = 0;
-  if (grx_shape_matches<GrxShapeFetchPick>(g)) { m->shape = 1; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchPick>); }
-  else if (grx_shape_matches<GrxShapeFetchObject>(g)) { m->shape = 2; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchObject>); }
-  else if (grx_shape_matches<GrxShapeFetchPuck>(g)) { m->shape = 7; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchPuck>); }
-  else if (grx_shape_matches<GrxShapeFetchArm>(g)) { m->shape = 3; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchArm>); }
-  GRX_LDS(grx_fetch_forward_kernel);
-  GRX_LDS(grx_point_step_kernel<GrxShapeAny>);
-#define GRX_TRY_POINT_SHAPE(SHAPE, ID) if (grx_shape_matches<SHAPE>(g)) { m->shape = ID; GRX_LDS(grx_point_step_kernel<SHAPE>); }
-  GRX_TRY_POINT_SHAPE(GrxShapeAntLarge, 10) GRX_TRY_POINT_SHAPE(GrxShapeAntMedium, 11) GRX_TRY_POINT_SHAPE(GrxShapeAntOpen, 12) GRX_TRY_POINT_SHAPE(GrxShapeAntUMaze, 13)
-#undef GRX_TRY_POINT_SHAPE
-  GRX_LDS(grx_hand_step_kernel<GrxShapeAny>);
-  if (grx_shape_matches<GrxShapeHandReach>(g)) { m->shape = 4; GRX_LDS(grx_hand_step_kernel<GrxShapeHandReach>); }
-  if (grx_shape_matches<GrxShapeHandBlockTouch>(g)) { m->shape = 6; GRX_LDS(grx_hand_step_kernel<GrxShapeHandBlockTouch>); }
-  if (grx_shape_matches<GrxShapeHandEgg>(g)) { m->shape = 8; GRX_LDS(grx_hand_step_kernel<GrxShapeHandEgg>); }
-  if (grx_shape_matches<GrxShapeHandEggTouch>(g)) { m->shape = 9; GRX_LDS(grx_hand_step_kernel<GrxShapeHandEggTouch>); }
-  if (grx_shape_matches<GrxShapeHandBlock>(g)) { m->shape = 5; GRX_LDS(grx_hand_step_kernel<GrxShapeHandBlock>); }
-#undef GRX_LDS
   for (int k = 0; k < GRX_MAX_MODELS && m->slot < 0; k++) if (!g_slot_used[k]) { g_slot_used[k] = 1; m->slot = k; }
   if (m->slot < 0) return fail("grx_model_create: all model descriptor slots are in use (destroy a model first)");
+  m->shape = 0;
+  // every family unit gets the descriptor (its own constant-memory copy) and raises the LDS limit of the kernels that can serve the model
+  int e;
+  if ((e = grx_tu_fetch_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (fetch kernels): ") + hipGetErrorString((hipError_t)e));
+  if ((e = grx_tu_point_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (point kernels): ") + hipGetErrorString((hipError_t)e));
+  if ((e = grx_tu_hand_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (hand kernels): ") + hipGetErrorString((hipError_t)e));
   HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_grx_models), &m->dev, sizeof(GrxModel), sizeof(GrxModel) * (size_t)m->slot, hipMemcpyHostToDevice));
   return 0;
 }
@@ -500,16 +639,8 @@ extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, co
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  const dim3 grid(grx_grid_for(n_worlds)), block(64);
-  const size_t lds_bytes = (size_t)m->words * 4;
-  switch (m->shape) {  // the specialised kernels are bit-identical to the generic one (same source, dims folded)
-    case 1: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchPick>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
-    case 2: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchObject>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
-    case 3: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchArm>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
-    case 7: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchPuck>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
-    default: hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words);
-  }
-  HIP_OK(hipGetLastError());
+  const int e = grx_tu_fetch_launch(0, m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, 0);
+  if (e) return fail(std::string("grx_fetch_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
 
@@ -519,8 +650,23 @@ extern "C" int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task,
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  hipLaunchKernelGGL(grx_fetch_forward_kernel, dim3(grx_grid_for(n_worlds)), dim3(64), m->words * 4, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, nstep);
-  HIP_OK(hipGetLastError());
+  const int e = grx_tu_fetch_launch(1, m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, nstep);
+  if (e) return fail(std::string("grx_fetch_forward launch: ") + hipGetErrorString((hipError_t)e));
+  return 0;
+}
+
+static_assert(sizeof(grx_fetch_reset_args) == sizeof(GrxFetchResetArgs), "grx_fetch_reset_args must mirror GrxFetchResetArgs");
+extern "C" int grx_fetch_reset(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, const grx_fetch_reset_args* args, int n_reset, void* stream) {
+  if (!m || !task || !args) return fail("grx_fetch_reset: null argument");
+  if (check_buffers(buf)) return -1;
+  if (n_reset <= 0) return 0;
+  if (!args->idx || !args->samples || !args->init_qpos || !args->init_qvel || (m->dev.nmocap && !args->init_mocap)) return fail("grx_fetch_reset: null reset array");
+  if (args->obj_qadr >= 0 && args->obj_qadr + 7 > m->dev.nq) return fail("grx_fetch_reset: object joint address out of range");
+  GrxFetchTask t; memcpy(&t, task, sizeof(t));
+  GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
+  GrxFetchResetArgs r; memcpy(&r, args, sizeof(r));
+  const int e = grx_tu_fetch_launch(2, m->shape, (unsigned)n_reset, (size_t)m->words * 4, stream, m->slot, &t, &b, &r, n_reset, m->words, 0);
+  if (e) return fail(std::string("grx_fetch_reset launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
 
@@ -532,16 +678,8 @@ extern "C" int grx_point_step(const grx_model* m, const grx_point_task* task, co
   if (n_worlds <= 0) return 0;
   GrxPointTask t; memcpy(&t, task, sizeof(t));
   GrxPointBuffers b; memcpy(&b, buf, sizeof(b));
-  const dim3 grid(grx_grid_for(n_worlds)), block(64);
-  const size_t lds_bytes = (size_t)m->words * 4;
-  switch (m->shape) {
-    case 10: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntLarge>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
-    case 11: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntMedium>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
-    case 12: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntOpen>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
-    case 13: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAntUMaze>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words); break;
-    default: hipLaunchKernelGGL(grx_point_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words);
-  }
-  HIP_OK(hipGetLastError());
+  const int e = grx_tu_point_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words);
+  if (e) return fail(std::string("grx_point_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
 
@@ -560,15 +698,8 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   } else
     for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
-  const dim3 grid(grx_grid_for(n_worlds)), block(64);
-  const size_t lds_bytes = (size_t)m->words * 4;
-  if (m->shape == 9) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandEggTouch>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
-  else if (m->shape == 8) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandEgg>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
-  else if (m->shape == 6) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlockTouch>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
-  else if (m->shape == 5) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandBlock>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
-  else if (m->shape == 4) hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeHandReach>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
-  else hipLaunchKernelGGL(grx_hand_step_kernel<GrxShapeAny>, grid, block, lds_bytes, (hipStream_t)stream, m->slot, t, b, n_worlds, m->words, forward_only);
-  HIP_OK(hipGetLastError());
+  const int e = grx_tu_hand_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  if (e) return fail(std::string("grx_hand_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
 
@@ -724,3 +855,5 @@ extern "C" int grx_fetch_compute_reward(const float* achieved, const float* desi
   HIP_OK(hipGetLastError());
   return 0;
 }
+
+#endif  // GRX_TU_API

@@ -29,11 +29,11 @@ from .fetch_spec import DISTANCE_THRESHOLD, FETCH_TASKS, MAX_EPISODE_STEPS, N_SU
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
 
 
-# Engine capacities of the Fetch models (defaults: 32 contacts / 144 rows / 2 032 Jacobian-pool words).  112 rows / 1 520 pool words bring
+# Engine capacities of the Fetch models (defaults: 32 contacts / 144 rows / 2 032 Jacobian-pool words).  112 rows / 1 504 pool words bring
 # the per-world LDS footprint to 14 granules = 9 worlds per CU.  Measured on 2.46 M random-action world-steps of FetchPickAndPlace: 0.035 %
 # of them hit a capacity in some substep (excess contacts dropped for that substep, GRX_ST_EFC_OVERFLOW raised in `status`), against
 # 0.004 % with the defaults; `model.with_capacity(maxefc=0, jpool=0)` restores the defaults (generic kernel).
-FETCH_CAPACITY = {"maxcon": 32, "maxefc": 112, "jpool": 1520, "split_spans": False}   # the arm chain is (nearly) contiguous: single-span rows
+FETCH_CAPACITY = {"maxcon": 32, "maxefc": 112, "jpool": 1504, "split_spans": False}   # the arm chain is (nearly) contiguous: single-span rows
 
 
 def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledModel:
@@ -149,6 +149,7 @@ class FetchVecEnv(GoalVecEnv):
         # in contact or it is not), and with ~2 worlds per resident wave slot the launch otherwise ends with a few slots finishing two
         # expensive worlds while the rest of the chip idles.  Worlds stay inside their XCD's slice (L2 locality of neighbouring rows).
         self.balance = bool(self.balance) and n % 8 == 0 and 1024 <= n <= 65536 * 8   # grx_order_by_cost sorts one XCD slice (n / 8 worlds, <= 65536) per workgroup in LDS
+        self._reset_stage = z(n, 6)   # device side of the reset staging buffer (see _reset_worlds)
         self.packed = z(n, self.obs_dim + 8)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather, parallel.py)
         self.cost = torch.zeros(n, dtype=torch.int32, device=d) if self.balance else None
         self.cost_ema = torch.zeros(n, dtype=torch.float32, device=d) if self.balance else None
@@ -228,10 +229,10 @@ class FetchVecEnv(GoalVecEnv):
         bg.state = st
         return np.random.Generator(bg)
 
-    def _reset_worlds(self, idx: np.ndarray):
+    def _stage_reset(self, idx: np.ndarray):
+        """Host: the PCG64 draws of the listed worlds (bit-exact C sampler) into a pinned staging buffer; device: ONE asynchronous copy.
+        _launch_reset then runs the compacted, shape-specialised reset kernel (grx_fetch_reset).  Nothing here waits for the device."""
         n = len(idx)
-        if n == 0:
-            return
         goals64 = np.zeros((n, 3), np.float64)
         oxy64 = np.zeros((n, 2), np.float64)
         idx64 = np.ascontiguousarray(idx, dtype=np.int64)
@@ -242,22 +243,31 @@ class FetchVecEnv(GoalVecEnv):
             self._rng_state.ctypes.data, idx64.ctypes.data, n, int(cfg["has_object"]), int(cfg["target_in_the_air"]),
             float(cfg["obj_range"]), float(cfg["target_range"]), toff.ctypes.data, g0.ctypes.data, float(self.height_offset),
             oxy64.ctypes.data, goals64.ctypes.data))
-        goals, oxy = goals64.astype(np.float32), oxy64.astype(np.float32)
-        ti = torch.from_numpy(idx64).to(self.device)
-        rows = self.initial_qpos.unsqueeze(0).repeat(n, 1)
-        if self._obj_qadr >= 0:
-            rows[:, self._obj_qadr: self._obj_qadr + 2] = torch.from_numpy(oxy).to(self.device)
-        self.qpos[ti] = rows
-        self.qvel[ti] = self.initial_qvel
-        self.qacc_ws[ti] = 0.0
-        self.mocap[ti] = self._mocap0
-        self.goal[ti] = torch.from_numpy(goals).to(self.device)
-        self.mask.zero_()
-        self.mask[ti] = 1
-        _native.check(self._L.grx_fetch_forward(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs_masked), self.num_envs, 0,
-                                                self._stream()))
+        # staging: n world indices (int32 bits) followed by n x (object x, y, goal x, y, z), in pinned memory -> device, asynchronously
+        stage = torch.empty(6 * n, dtype=torch.float32, pin_memory=True)
+        sv = stage.numpy()
+        sv[:n] = idx64.astype(np.int32).view(np.float32)
+        sm = sv[n:].reshape(n, 5)
+        sm[:, 0:2] = oxy64
+        sm[:, 2:5] = goals64
+        dev = self._reset_stage.view(-1)[: 6 * n]
+        dev.copy_(stage, non_blocking=True)
+        return n, dev[:n].view(torch.int32), dev[n:]
+
+    def _launch_reset(self, staged, idx):
+        n, idx_dev, samples = staged
+        args = _native.FetchResetArgsStruct(idx_dev.data_ptr(), samples.data_ptr(), self.initial_qpos.data_ptr(), self.initial_qvel.data_ptr(),
+                                            self._mocap0.data_ptr(), int(self._obj_qadr))
+        _native.check(self._L.grx_fetch_reset(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs), ctypes.byref(args), n, self._stream()))
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
+
+    def _reset_worlds(self, idx: np.ndarray):
+        if len(idx) == 0:
+            return None
+        staged = self._stage_reset(idx)
+        self._launch_reset(staged, idx)
+        return staged[1].long()
 
     def reset(self, *, seed=None, options=None):
         if seed is not None:
@@ -297,17 +307,19 @@ class FetchVecEnv(GoalVecEnv):
             terminated = np.zeros(self.num_envs, bool)
             info = {}
             if len(pending):  # Gymnasium NEXT_STEP: the reset replaces the step; reward 0, flags False
-                self._reset_worlds(pending)
-                self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
+                tp = self._reset_worlds(pending)
+                self.reward[tp] = 0.0
+                self.packed[tp, -2] = 0.0
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
-                info["final_obs"] = self._obs_dict(rows=done)
+                staged = self._stage_reset(done)
+                td = staged[1].long()
+                info["final_obs"] = self._obs_dict(rows=done, rows_dev=td)   # the terminal observation, gathered before the reset overwrites the rows
                 keep_r, keep_s = self.reward.clone(), self.success.clone()
-                self._reset_worlds(done)
+                self._launch_reset(staged, done)
                 self.reward.copy_(keep_r)
                 self.success.copy_(keep_s)
-                td = torch.from_numpy(done).to(self.device)   # the packed rows of the reset worlds: reset observation, terminal reward / success
-                self.packed[td, -2] = keep_r[td]
+                self.packed[td, -2] = keep_r[td]   # the packed rows of the reset worlds: reset observation, terminal reward / success
                 self.packed[td, -1] = keep_s[td].float()
             elif self.autoreset_mode == "next_step":
                 self._needs_reset |= truncated
@@ -320,9 +332,11 @@ class FetchVecEnv(GoalVecEnv):
         r = self.reward.cpu().numpy()
         return obs, (r if self.reward_type == "sparse" else r.astype(np.float64)), terminated, truncated, info
 
-    def _obs_dict(self, rows=None):
+    def _obs_dict(self, rows=None, rows_dev=None):
         if self.output == "torch":
-            sel = (lambda t: t) if rows is None else (lambda t: t[torch.from_numpy(rows).to(self.device)])
+            if rows is not None and rows_dev is None:
+                rows_dev = torch.from_numpy(rows).to(self.device)
+            sel = (lambda t: t) if rows is None else (lambda t: t[rows_dev])
             return {"observation": sel(self.obs), "achieved_goal": sel(self.achieved), "desired_goal": sel(self.goal)}
         sel = (lambda a: a) if rows is None else (lambda a: a[rows])
         return {"observation": sel(self.obs.double().cpu().numpy()), "achieved_goal": sel(self.achieved.double().cpu().numpy()),

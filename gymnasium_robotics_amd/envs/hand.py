@@ -305,7 +305,7 @@ def load_hand_block_model(assets_root: Optional[str] = None, touch: bool = False
         xml = OBJECTS[obj]["xml"] + ("_touch_sensors.xml" if touch else ".xml")
         # the task reads no site (manipulate.py:298-316 use qpos / qvel only): none is tracked by the engine
         return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None, keep_sites=[],
-                            capacity=dict(HAND_MANIP_CAPACITY, jpool=944) if touch else HAND_MANIP_CAPACITY)   # touch keeps contact data out of the overlay: same 16 LDS granules with a slightly smaller pool
+                            capacity=dict(HAND_MANIP_CAPACITY, jpool=928) if touch else HAND_MANIP_CAPACITY)   # touch keeps contact data out of the overlay: same 16 LDS granules with a slightly smaller pool
     path = os.path.join(_MODELS_DIR, f"hand_{obj}_touch.npz" if touch else f"hand_{obj}.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")

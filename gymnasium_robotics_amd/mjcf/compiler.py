@@ -600,6 +600,13 @@ class MjcfCompiler:
         m["hull"] = (hv, [sorted(s) for s in adj])
         return m["hull"]
 
+    def _mesh_center(self, name: str):
+        """Centre of mass of the mesh's convex hull (mesh frame): the origin of the compiled geom frame."""
+        m = self.meshes[name]
+        if "ctr" not in m:
+            m["ctr"] = _polyhedron_mass_props(self._load_mesh_hull(name)[0])[1]
+        return m["ctr"]
+
     # -- inertia from geoms -----------------------------------------------------------
     @staticmethod
     def _geom_volume_inertia(g: _Geom):
@@ -1005,6 +1012,7 @@ class _Lowering:
         geom_size = np.zeros((ng, 3))
         geom_invw = np.zeros((ng, 2))
         geom_rbound = np.zeros(ng)
+        geom_aabb = np.zeros((ng, 6))   # centre, half extents in the geom frame
         mesh_vert, mesh_adjadr, mesh_adjnum, mesh_adj = [], [], [], []
         mesh_cache = {}
         for gi, (i, g) in enumerate(geoms):
@@ -1018,8 +1026,16 @@ class _Lowering:
             geom_invw[gi] = body_invweight0[i]
             s = g.size
             if g.type == GEOM_MESH:
+                # The geom frame of a mesh is moved to the centre of mass of its hull (MuJoCo re-centres a mesh at its centre of mass as
+                # well; it also rotates the frame to the principal axes, which no routine here depends on): the convex routine casts its
+                # first ray from the geom centre, which has to be an interior point.  World geometry is unchanged.
                 hv, _ = c._load_mesh_hull(g.mesh)
-                geom_rbound[gi] = np.linalg.norm(hv, axis=1).max()
+                ctr = c._mesh_center(g.mesh)
+                geom_pos[gi] = geom_pos[gi] + mu.rot_vec(geom_quat[gi], ctr)
+                hvc = hv - ctr
+                geom_rbound[gi] = np.linalg.norm(hvc, axis=1).max()
+                lo, hi = hvc.min(axis=0), hvc.max(axis=0)
+                geom_aabb[gi] = np.concatenate([0.5 * (lo + hi), 0.5 * (hi - lo)])
             elif g.type == GEOM_SPHERE:
                 geom_rbound[gi] = s[0]
             elif g.type == GEOM_CAPSULE:
@@ -1028,6 +1044,14 @@ class _Lowering:
                 geom_rbound[gi] = np.hypot(s[0], s[1])
             elif g.type in (GEOM_BOX, GEOM_ELLIPSOID):
                 geom_rbound[gi] = np.linalg.norm(s) if g.type == GEOM_BOX else s.max()
+            if g.type == GEOM_SPHERE:
+                geom_aabb[gi, 3:] = s[0]
+            elif g.type == GEOM_CAPSULE:
+                geom_aabb[gi, 3:] = [s[0], s[0], s[0] + s[1]]
+            elif g.type == GEOM_CYLINDER:
+                geom_aabb[gi, 3:] = [s[0], s[0], s[1]]
+            elif g.type in (GEOM_BOX, GEOM_ELLIPSOID):
+                geom_aabb[gi, 3:] = s
         # touch sensors selected by touch_filter: their zones (sites) go to the touch_* tables, in sensor order, and are left out of
         # the engine's site tables (92 zones x 12 words of world frames per world would not pay for themselves in LDS)
         touch_sel = []
@@ -1082,6 +1106,9 @@ class _Lowering:
         # general convex narrow phase (MPR, one contact): every pair of primitives that involves an ellipsoid or a cylinder
         prim = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX)
         supported |= {(ta, tb) for ta in prim for tb in prim if ta <= tb and (GEOM_ELLIPSOID in (ta, tb) or GEOM_CYLINDER in (ta, tb))}
+        supported |= {(GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE)}
+        # convex hull of a mesh against any primitive or another hull: the same routine with a hull-vertex support function
+        supported |= {(ta, GEOM_MESH) for ta in prim + (GEOM_MESH,)}
         pairs = []
         for a in range(ng):
             for b_ in range(a + 1, ng):
@@ -1190,6 +1217,7 @@ class _Lowering:
             if not sup:
                 continue  # no implemented narrow phase touches this mesh: no vertices needed on the device
             hv, adj = c._load_mesh_hull(g.mesh)
+            hv = hv - c._mesh_center(g.mesh)   # geom frame = hull centre of mass (see geom_pos above)
             keep_v = None
             planes_static = all(pr[2].type == GEOM_PLANE and weld[geoms[pr[0]][0]] == 0 for pr in sup)
             if planes_static and only_slides(i):
@@ -1355,7 +1383,7 @@ class _Lowering:
             dof_damping=dof_damp, dof_frictionloss=dof_fl, dof_invweight0=dof_invweight0,
             dof_solref=dof_solref, dof_solimp=dof_solimp,
             geom_type=geom_type, geom_bodyid=geom_bodyid, geom_meshadr=geom_meshadr, geom_meshnum=geom_meshnum,
-            geom_pos=geom_pos, geom_quat=geom_quat, geom_size=geom_size, geom_invweight0=geom_invw, geom_rbound=geom_rbound,
+            geom_pos=geom_pos, geom_quat=geom_quat, geom_size=geom_size, geom_invweight0=geom_invw, geom_rbound=geom_rbound, geom_aabb=geom_aabb,
             site_bodyid=site_bodyid, site_type=site_type, site_pos=site_pos, site_quat=site_quat, site_size=site_size,
             pair_geom1=pair_geom1, pair_geom2=pair_geom2, pair_condim=pair_condim, pair_supported=pair_supported,
             pair_friction=pair_friction, pair_solref=pair_solref, pair_solimp=pair_solimp, pair_margin=pair_margin,

@@ -129,6 +129,17 @@ int grx_model_dim(const grx_model* m, const char* name);   /* "nq" "nv" "nu" "nb
 
 int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, void* stream);
 int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream);
+/* Episode reset of a COMPACTED list of worlds: _reset_sim (fetch/fetch_env.py:375-402: initial state, object xy) + _sample_goal (:153-166)
+ * + mj_forward + _get_obs (envs/robot_env.py:154-186) for the n_reset worlds idx[0..n_reset): one workgroup per listed world, shape-specialised
+ * like the step kernel.  The draws come from grx_fetch_sample_resets (host); all arrays here are DEVICE pointers (stage them with one
+ * asynchronous copy from pinned memory: nothing on the host has to wait for the device). */
+typedef struct grx_fetch_reset_args {
+  const int* idx;        /* [n_reset] world indices */
+  const float* samples;  /* [n_reset,5] object x, y, goal x, y, z */
+  const float *init_qpos, *init_qvel, *init_mocap; /* [nq] [nv] [7*nmocap]: the state _env_setup left (fetch_env.py:404-428) */
+  int obj_qadr;          /* qpos address of object0:joint, -1 for the tasks without object */
+} grx_fetch_reset_args;
+int grx_fetch_reset(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, const grx_fetch_reset_args* args, int n_reset, void* stream);
 /* order <- the dispatch order for the next step launch from the per-world costs the last one wrote (grx_fetch_buffers.cost /
  * grx_hand_buffers.cost): per XCD slice of n_worlds / 8 contiguous worlds, decreasing cost.  With `ema` the key is the exponential moving
  * average ema <- (1 - alpha) ema + alpha cost, kept in the caller's buffer (measured best around alpha = 0.15).  n_worlds must be a multiple of 8. */

@@ -69,6 +69,7 @@ typedef struct orc_sim {
   int efc_type[MAXEFC], efc_id[MAXEFC];
   /* diagnostics */
   int solver_iter, bad_state, unsupported_hits;
+  long mesh_candidates, mesh_contacts; /* hull pairs that reached the convex routine / contacts it produced (cumulative) */
   double solver_gradnorm;
   double min_activation_gap; /* min over steps/rows of |dist - margin|: how close any unilateral row came to (de)activating */
   int opt_disable_mesh_plane; /* test knob */
@@ -568,6 +569,29 @@ static void collide_capsule_capsule(orc_sim* s, int pair, int g1, int g2, double
   add_contact(s, pair, pos, n, dist);
 }
 
+/* sphere vs sphere, sphere vs capsule (sphere against the closest point of the capsule's axis segment): MuJoCo's analytic routines
+ * mjc_SphereSphere / mjc_SphereCapsule [3P] -- normal from geom1 to geom2, position halfway through the overlap */
+static void sphere_sphere_raw(orc_sim* s, int pair, const double* c1, double r1, const double* c2, double r2, double margin) {
+  double n[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+  double len = norm3(n);
+  double dist = len - r1 - r2;
+  if (dist > margin) return;
+  if (len < MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else { n[0] /= len; n[1] /= len; n[2] /= len; }
+  double pos[3] = {c1[0] + n[0] * (r1 + 0.5 * dist), c1[1] + n[1] * (r1 + 0.5 * dist), c1[2] + n[2] * (r1 + 0.5 * dist)};
+  add_contact(s, pair, pos, n, dist);
+}
+static void collide_sphere_sphere(orc_sim* s, int pair, int g1, int g2, double margin) {
+  sphere_sphere_raw(s, pair, s->geom_xpos + 3 * g1, s->m.geom_size[3 * g1], s->geom_xpos + 3 * g2, s->m.geom_size[3 * g2], margin);
+}
+static void collide_sphere_capsule(orc_sim* s, int pair, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* c1 = s->geom_xpos + 3 * g1; const double* c2 = s->geom_xpos + 3 * g2; const double* R2 = s->geom_xmat + 9 * g2;
+  double ax[3] = {R2[2], R2[5], R2[8]}, d[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+  double h = m->geom_size[3 * g2 + 1], x = fmin(h, fmax(-h, dot3(ax, d)));
+  double p2[3] = {c2[0] + x * ax[0], c2[1] + x * ax[1], c2[2] + x * ax[2]};
+  sphere_sphere_raw(s, pair, c1, m->geom_size[3 * g1], p2, m->geom_size[3 * g2], margin);
+}
+
 /* plane vs convex hull of a mesh: deepest hull vertex + up to 3 of its hull neighbours
  * that are also within the margin (restated from memory of MuJoCo's plane-convex routine;
  * unverifiable here -- see DESIGN.md "mesh policy") */
@@ -786,12 +810,22 @@ static void geom_support(const orc_sim* s, int g, const double* d, double hm, do
       break;
     }
     case GRX_GEOM_BOX: for (int k = 0; k < 3; k++) r[k] = sgn1(dl[k]) * sz[k]; break;
+    case GRX_GEOM_MESH: {   /* convex hull of the mesh: the hull vertex farthest along d (exhaustive; first maximum wins ties) */
+      const int adr = m->geom_meshadr[g], num = m->geom_meshnum[g];
+      double best = -1e300; int bi = 0;
+      for (int v = 0; v < num; v++) { double t = dot3(m->mesh_vert + 3 * (adr + v), dl); if (t > best) { best = t; bi = v; } }
+      if (num > 0) for (int k = 0; k < 3; k++) r[k] = m->mesh_vert[3 * (adr + bi) + k];
+      break;
+    }
     default: break;
   }
   mulMatVec3(out, R, r);
   for (int k = 0; k < 3; k++) out[k] += pos[k] + d[k] * hm;
 }
+static long g_mpr_support_calls = 0;
+long orc_mpr_support_calls(void) { return g_mpr_support_calls; }
 static void mpr_support(const orc_sim* s, int g1, int g2, const double* d, double hm, mpr_pt* o) {
+  g_mpr_support_calls++;
   double nd[3] = {-d[0], -d[1], -d[2]};
   geom_support(s, g1, d, hm, o->v1); geom_support(s, g2, nd, hm, o->v2);
   for (int k = 0; k < 3; k++) o->v[k] = o->v1[k] - o->v2[k];
@@ -1035,6 +1069,39 @@ static void collide_plane_ellipsoid(orc_sim* s, int pair, int g1, int g2, double
   add_contact(s, pair, pos, n, dist);
 }
 
+/* Separating-axis test of the two geoms' oriented bounding boxes (geom_aabb: centre and half extents in the geom frame), each
+ * grown by margin / 2: 1 if they may be closer than `margin` (the 6 face axes and the 9 edge-edge axes; a conservative filter in front of
+ * the convex routine, it never changes a result) */
+static int obb_overlap(const orc_sim* s, int g1, int g2, double margin) {
+  const grx_model_view* m = &s->m;
+  const double* R1 = s->geom_xmat + 9 * g1; const double* R2 = s->geom_xmat + 9 * g2;
+  double c1[3], c2[3], e1[3], e2[3], t[3], A[3][3], B[3][3];
+  mulMatVec3(c1, R1, m->geom_aabb + 6 * g1); mulMatVec3(c2, R2, m->geom_aabb + 6 * g2);
+  for (int k = 0; k < 3; k++) {
+    c1[k] += s->geom_xpos[3 * g1 + k]; c2[k] += s->geom_xpos[3 * g2 + k]; t[k] = c2[k] - c1[k];
+    e1[k] = m->geom_aabb[6 * g1 + 3 + k] + 0.5 * margin; e2[k] = m->geom_aabb[6 * g2 + 3 + k] + 0.5 * margin;
+    for (int j = 0; j < 3; j++) { A[k][j] = R1[3 * j + k]; B[k][j] = R2[3 * j + k]; }   /* A[k] = k-th axis of box 1 (column k of R1) */
+  }
+  for (int i = 0; i < 3; i++) {   /* face axes of box 1 and of box 2 */
+    double ra = e1[i], rb = 0, tp = fabs(dot3(t, A[i]));
+    for (int j = 0; j < 3; j++) rb += e2[j] * fabs(dot3(A[i], B[j]));
+    if (tp > ra + rb) return 0;
+    ra = 0; rb = e2[i]; tp = fabs(dot3(t, B[i]));
+    for (int j = 0; j < 3; j++) ra += e1[j] * fabs(dot3(B[i], A[j]));
+    if (tp > ra + rb) return 0;
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double ax[3]; cross3(ax, A[i], B[j]);
+      double l = norm3(ax);
+      if (l < 1e-9) continue;
+      double ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += e1[k] * fabs(dot3(ax, A[k])); rb += e2[k] * fabs(dot3(ax, B[k])); }
+      if (fabs(dot3(t, ax)) > ra + rb + 1e-12 * l) return 0;
+    }
+  return 1;
+}
+
 static void collision(orc_sim* s) {
   const grx_model_view* m = &s->m;
   s->ncon = 0;
@@ -1052,6 +1119,16 @@ static void collision(orc_sim* s) {
       if (norm3(d) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue;
     }
     if (!m->pair_supported[p]) { s->unsupported_hits++; continue; }
+    if (t2 == GRX_GEOM_MESH && t1 != GRX_GEOM_PLANE) {   /* hull against a primitive or another hull: the general convex routine (libccd in MuJoCo [3P]) */
+      if (!obb_overlap(s, g1, g2, margin)) continue;       /* conservative filter on the geoms' oriented bounding boxes */
+      s->mesh_candidates++;
+      int before = s->ncon;
+      collide_convex(s, p, g1, g2, margin);
+      s->mesh_contacts += s->ncon - before;
+      continue;
+    }
+    if (t1 == GRX_GEOM_SPHERE && t2 == GRX_GEOM_SPHERE) { collide_sphere_sphere(s, p, g1, g2, margin); continue; }
+    if (t1 == GRX_GEOM_SPHERE && t2 == GRX_GEOM_CAPSULE) { collide_sphere_capsule(s, p, g1, g2, margin); continue; }
     if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_SPHERE) collide_plane_sphere(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_PLANE && t2 == GRX_GEOM_CAPSULE) collide_plane_capsule(s, p, g1, g2, margin);
     else if (t1 == GRX_GEOM_CAPSULE && t2 == GRX_GEOM_BOX) collide_capsule_box(s, p, g1, g2, margin);
@@ -1670,6 +1747,8 @@ int orc_int(orc_sim* s, const char* name) {
   if (!strcmp(name, "solver_iter")) return s->solver_iter;
   if (!strcmp(name, "bad_state")) return s->bad_state;
   if (!strcmp(name, "unsupported_hits")) return s->unsupported_hits;
+  if (!strcmp(name, "mesh_candidates")) return (int)s->mesh_candidates;
+  if (!strcmp(name, "mesh_contacts")) return (int)s->mesh_contacts;
   if (!strcmp(name, "nv")) return s->nv;
   if (!strcmp(name, "nq")) return s->nq;
   return -1;

@@ -99,6 +99,8 @@ class OracleSim:
     solver_iter = property(lambda self: self._L.orc_int(self._h, b"solver_iter"))
     bad_state = property(lambda self: self._L.orc_int(self._h, b"bad_state"))
     unsupported_hits = property(lambda self: self._L.orc_int(self._h, b"unsupported_hits"))
+    mesh_candidates = property(lambda self: self._L.orc_int(self._h, b"mesh_candidates"))
+    mesh_contacts = property(lambda self: self._L.orc_int(self._h, b"mesh_contacts"))
 
     def set_option(self, name, v):
         self._L.orc_set_int(self._h, name.encode(), int(v))

@@ -12,9 +12,10 @@ _ROOT = os.path.abspath(os.path.join(_HERE, "..", ".."))
 
 def build(force=False):
     so = os.path.join(_HERE, "libgrx_emu.so")
-    srcs = [os.path.join(_HERE, "grx_emu.cpp")] + [
-        os.path.join(_ROOT, "gymnasium_robotics_amd", "csrc", f) for f in ("grx_engine.h", "grx_fetch_task.h", "grx_point_task.h", "grx_host_model.h")
-    ] + [os.path.join(_ROOT, "include", "grx_model_fields.def")]
+    import glob
+
+    srcs = [os.path.join(_HERE, "grx_emu.cpp")] + sorted(glob.glob(os.path.join(_ROOT, "gymnasium_robotics_amd", "csrc", "*.h"))) + sorted(
+        glob.glob(os.path.join(_ROOT, "include", "*")))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(
             ["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-misleading-indentation", "-o", so, srcs[0]], cwd=_HERE)

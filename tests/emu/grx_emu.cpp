@@ -119,6 +119,8 @@ void emu_hand_step(void* h, const GrxHandTask* t, float* qpos, float* qvel, floa
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 
+long emu_mesh_stat(int k) { return g_grx_mesh_stats[k]; }
+
 // debug access to the working set of the last call
 float* emu_ctx_ptr(void* h, const char* name) {
   Emu* e = (Emu*)h; GrxCtx* c = &e->c;

@@ -66,6 +66,50 @@ def test_teacher_forced_step_matches_golden(task):
     assert np.abs(env.qpos.cpu().numpy() - g["qpos_next"])[posed].max() < TOL
 
 
+def test_teacher_forced_hull_contacts_match_golden():
+    """Hull-vs-convex narrow phase (mesh-mesh / mesh-box pairs of the Fetch links, assets/fetch/robot.xml:16-93): 168 snapshots of scripted
+    rollouts that fold the arm into the head / torso and press the wrist / gripper housing onto the table (tools/make_golden_hull.py), 147 of
+    them with hull contacts.  A face-face hull contact has no unique contact point (any point of the overlap polygon), so fp32 and fp64 portal
+    refinements legitimately differ there: the median is held at rounding level, the tail is bounded."""
+    g = np.load(os.path.join(GOLDEN, "fetch_hull_teacher.npz"))
+    n = g["obs"].shape[0]
+    env = _env("FetchPickAndPlace", n, autoreset_mode="disabled", max_episode_steps=None)
+    env.reset(seed=0)
+    _load_state(env, g, slice(None))
+    obs, r, term, trunc, info = env.step(g["action"])
+    assert int((info["status"] & ~6).max()) == 0   # no bad number / solver failure (capacity flags may fire in the folded poses)
+    err = np.abs(obs["observation"] - g["obs"]).max(axis=1)
+    hull = g["hull_contacts"] > 0
+    print(f"hull snapshots: p50 {np.median(err[hull]):.2e} p90 {np.quantile(err[hull], 0.9):.2e} max {err[hull].max():.2e}; others max {err[~hull].max():.2e}")
+    assert hull.sum() > 120
+    assert np.median(err[hull]) < 2e-5 and np.quantile(err[hull], 0.9) < 1e-3 and err.max() < 2e-2
+    assert err[~hull].max() < TOL
+
+
+def test_compacted_reset_kernel_matches_masked_forward():
+    """grx_fetch_reset (compacted list, initial rows + host draws applied on the device) gives the rows the old path produced:
+    initial state written by the host + masked grx_fetch_forward."""
+    import ctypes
+
+    import torch
+
+    from gymnasium_robotics_amd import _native
+
+    env = _env("FetchPickAndPlace", 64)
+    env.reset(seed=11)
+    ref = {k: getattr(env, k).clone() for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "obs", "achieved", "reward", "success")}
+    # same worlds through the masked forward path, from the rows the reset kernel was told to write
+    env.qacc_ws.fill_(7.0)   # must be zeroed by both paths
+    q = env.initial_qpos.unsqueeze(0).repeat(64, 1)
+    q[:, env._obj_qadr: env._obj_qadr + 2] = ref["qpos"][:, env._obj_qadr: env._obj_qadr + 2]
+    env.qpos.copy_(q); env.qvel.copy_(env.initial_qvel.unsqueeze(0).repeat(64, 1)); env.qacc_ws.zero_(); env.mocap.copy_(env._mocap0.unsqueeze(0).repeat(64, 1))
+    env.mask.fill_(1)
+    _native.check(env._L.grx_fetch_forward(env._h, ctypes.byref(env.task), ctypes.byref(env._bufs_masked), 64, 0, env._stream()))
+    torch.cuda.synchronize()
+    for k, v in ref.items():
+        assert torch.equal(getattr(env, k), v), k
+
+
 @pytest.mark.parametrize("task", ["FetchReach", "FetchPush", "FetchPickAndPlace"])
 def test_reset_matches_golden(task):
     """reset(seed=s) gives world i the start state + goal of the reference's reset(seed=s+i) (PCG64 draw order)."""

@@ -36,7 +36,7 @@ from gymnasium_robotics_amd.envs.hand import HAND_MANIP_CAPACITY  # noqa: E402
 from gymnasium_robotics_amd.envs.manipulate_spec import drop_target_body, touch_filter  # noqa: E402
 
 m = compile_mjcf(os.path.join(ASSETS, "hand", "manipulate_block_touch_sensors.xml"), mutate=drop_target_body, touch_filter=touch_filter, keep_sites=[],
-                 capacity=dict(HAND_MANIP_CAPACITY, jpool=944))
+                 capacity=dict(HAND_MANIP_CAPACITY, jpool=928))
 out = os.path.join(OUT, "hand_block_touch.npz")
 save_model(m, out)
 print("hand/manipulate_block_touch_sensors.xml (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")},
@@ -51,7 +51,7 @@ print("hand/manipulate_block.xml (no target body) ->", out, {k: m.dim(k) for k i
 for xml, name, tf in (("manipulate_pen.xml", "hand_pen.npz", None), ("manipulate_pen_touch_sensors.xml", "hand_pen_touch.npz", touch_filter),
                       ("manipulate_egg.xml", "hand_egg.npz", None), ("manipulate_egg_touch_sensors.xml", "hand_egg_touch.npz", touch_filter)):
     m = compile_mjcf(os.path.join(ASSETS, "hand", xml), mutate=drop_target_body, touch_filter=tf, keep_sites=[],
-                     capacity=dict(HAND_MANIP_CAPACITY, jpool=944) if tf else HAND_MANIP_CAPACITY)
+                     capacity=dict(HAND_MANIP_CAPACITY, jpool=928) if tf else HAND_MANIP_CAPACITY)
     out = os.path.join(OUT, name)
     save_model(m, out)
     print(f"hand/{xml} (no target body) ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "touch zones:", len(m.tables["touch_body"]),
