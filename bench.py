@@ -135,15 +135,16 @@ def run_rank(args, rank, world_size, local_rank):
     gen.manual_seed(1234 + rank)
     gathered = torch.empty(n * world_size, env.packed.shape[1], device=device) if dist else None
     her = args.workload == "fetch"
-    perm = torch.randperm(n, device=device, generator=gen) if her else None
+    # HER "future"-style relabelling with HER_K substituted goals per transition: the substitution pattern is drawn once (K rolled copies of
+    # one permutation), each step gathers the goals and recomputes the rewards on the device
+    her_idx = torch.stack([torch.roll(torch.randperm(n, device=device, generator=gen), k) for k in range(HER_K)]) if her else None
 
     def one_step():
         a = torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1
         obs, r, term, trunc, info = env.step(a)
         if her:   # HER relabel: reward recompute for HER_K substituted goals per transition
             ag = obs["achieved_goal"].unsqueeze(0).expand(HER_K, n, 3).contiguous()
-            dg = torch.stack([obs["desired_goal"][torch.roll(perm, k)] for k in range(HER_K)])
-            env.compute_reward(ag, dg, None)
+            env.compute_reward(ag, obs["desired_goal"][her_idx], None)
         if dist:   # the step kernel wrote the packed [obs | achieved | desired | reward | success] rows: one collective, no pack kernels
             dist.all_gather_into_tensor(gathered, env.packed)
 

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libgrx_hip.so")
+LIB_PATH = os.environ.get("GRX_HIP_LIB") or os.path.join(_HERE, "_lib", "libgrx_hip.so")   # $GRX_HIP_LIB: an alternative BUILD of the same library (A/B of compiler options); never a fallback
 _lib = None
 
 
@@ -18,7 +18,7 @@ class FetchBuffersStruct(ctypes.Structure):
 
 
 class FetchResetArgsStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("idx", "samples", "init_qpos", "init_qvel", "init_mocap")] + [("obj_qadr", ctypes.c_int)]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("idx", "samples", "init_qpos", "init_qvel", "init_mocap")] + [("obj_qadr", ctypes.c_int), ("keep_outcome", ctypes.c_int)]
 
 
 class PointTaskStruct(ctypes.Structure):

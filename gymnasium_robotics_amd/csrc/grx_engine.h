@@ -113,7 +113,7 @@ struct GrxCtx {
   float* red;  // 128 floats
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
-  float* meshcache;  // models with hull-vs-convex pairs: 4 x (pair + 1, separating direction) + the slot to evict next, kept across the substeps of a step (grx_mesh_pairs)
+  float* meshcache;  // models with hull-vs-convex pairs: 4 x (pair + 1, separating direction, the two support vertices) + the slot to evict next, kept across the substeps of a step (grx_mesh_pairs)
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
   int maxefc, jpool, maxcon;  // capacities of the row tables / the packed Jacobian pool / the contact list of this model
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
@@ -144,7 +144,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
   pers += jpool + maxefc * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
-  pers += 32 + 8 + (nmesh ? 17 : 0);
+  pers += 32 + 8 + (nmesh ? 21 : 0);
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
@@ -175,7 +175,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   c->efc_floss = p; if (m->nfric) p += m->maxefc;
   CARVEI(efc_kind, m->maxefc) CARVEI(efc_id, m->maxefc) CARVEI(efc_row, m->maxefc)
   CARVEI(ired, 32) CARVEI(cnt, 8)
-  CARVE(meshcache, m->nmesh ? 17 : 0)
+  CARVE(meshcache, m->nmesh ? 21 : 0)
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
   if (m->ntouch) {
     CARVE(con_pos, 3 * m->maxcon) CARVE(con_frame, 3 * m->maxcon)
@@ -1034,9 +1034,9 @@ struct GrxMprPair { float R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   
 // Convex hull of a mesh: the hull vertex farthest along the (geom-frame) direction dl; the lowest vertex index wins ties, like the oracle's
 // exhaustive scan.  Called from wave-uniform code: on the GPU the 64 lanes share the scan (lane l takes the vertices l, l + 64, ...; the
 // loads are coalesced) and agree on the winner through two DPP reductions -- a hull of 500 vertices costs 8 loads per lane.
-GRX_MEM void grx_mesh_support(const float* verts, int n, const float* dl, float* r, int lane_) {
+GRX_MEM int grx_mesh_support(const float* verts, int n, const float* dl, float* r, int lane_) {
   r[0] = r[1] = r[2] = 0.0f;
-  if (n <= 0) return;
+  if (n <= 0) return -1;
 #if defined(GRX_EMU)
   (void)lane_;
   float best = -3.0e38f; int bi = 0;
@@ -1054,6 +1054,27 @@ GRX_MEM void grx_mesh_support(const float* verts, int n, const float* dl, float*
   const int bi = (int)(-grx_reduce_max((best == mx) ? -(float)mine : -3.0e38f));   // vertex indices are far below 2^24: exact in fp32
 #endif
   r[0] = verts[3 * bi]; r[1] = verts[3 * bi + 1]; r[2] = verts[3 * bi + 2];
+  return bi;
+}
+// The same with a guess: a hull vertex that is not lower than any of its hull neighbours along dl IS the support vertex (convexity), so a
+// vertex remembered from the previous substep is verified with one round of neighbour loads instead of a scan of the whole hull.
+// Returns the support vertex (hint, or the winner of the full scan).
+GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const float* dl, int hint, float* r, int lane_) {
+  const float* verts = m->mesh_vert + 3 * adr;
+  if (hint >= 0 && hint < n) {
+    const int aa = m->mesh_adjadr[adr + hint], an = m->mesh_adjnum[adr + hint];
+    const float t0 = verts[3 * hint] * dl[0] + verts[3 * hint + 1] * dl[1] + verts[3 * hint + 2] * dl[2];
+#if defined(GRX_EMU)
+    int higher = 0;
+    for (int k = 0; k < an; k++) { const int nb = m->mesh_adj[aa + k]; higher |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
+#else
+    int hi_ = 0;
+    for (int k = lane_; k < an; k += 64) { const int nb = m->mesh_adj[aa + k]; hi_ |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
+    const int higher = __ballot(hi_ != 0) != 0ull;
+#endif
+    if (!higher) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
+  }
+  return grx_mesh_support(verts, n, dl, r, lane_);
 }
 // W: wave-cooperative variant (uniform control flow, every lane holds the same values; mesh geoms allowed)
 template <bool W>
@@ -1268,29 +1289,40 @@ GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int
 // that still separates the two inflated geoms proves that the routine would report "no contact".
 // ------------------------------------------------------------------------------------------
 // separating-axis test of the two geoms' oriented bounding boxes (geom_aabb), each grown by margin / 2 (the oracle's obb_overlap)
+// (written out with named scalars: an array indexed by a loop variable would live in scratch memory)
 GRX_MEM int grx_obb_overlap(const GrxModel* m, const GrxCtx* c, int g1, int g2, float margin) {
   const float* R1 = c->gxmat + 9 * g1; const float* R2 = c->gxmat + 9 * g2; const float* a1 = m->geom_aabb + 6 * g1; const float* a2 = m->geom_aabb + 6 * g2;
-  float c1[3], c2[3], t[3];
-  { const float l1[3] = {a1[0], a1[1], a1[2]}, l2[3] = {a2[0], a2[1], a2[2]}; mulMatVec3f(c1, R1, l1); mulMatVec3f(c2, R2, l2); }
-  for (int k = 0; k < 3; k++) t[k] = (c2[k] + c->gxpos[3 * g2 + k]) - (c1[k] + c->gxpos[3 * g1 + k]);
-  const float e1[3] = {a1[3] + 0.5f * margin, a1[4] + 0.5f * margin, a1[5] + 0.5f * margin}, e2[3] = {a2[3] + 0.5f * margin, a2[4] + 0.5f * margin, a2[5] + 0.5f * margin};
-  float C[3][3], AC[3][3];   // C[i][j] = A_i . B_j
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { C[i][j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j]; AC[i][j] = fabsf(C[i][j]); }
-  float ta[3], tb[3];
-  for (int i = 0; i < 3; i++) { ta[i] = t[0] * R1[i] + t[1] * R1[3 + i] + t[2] * R1[6 + i]; tb[i] = t[0] * R2[i] + t[1] * R2[3 + i] + t[2] * R2[6 + i]; }
-  for (int i = 0; i < 3; i++) {
-    if (fabsf(ta[i]) > e1[i] + e2[0] * AC[i][0] + e2[1] * AC[i][1] + e2[2] * AC[i][2]) return 0;
-    if (fabsf(tb[i]) > e2[i] + e1[0] * AC[0][i] + e1[1] * AC[1][i] + e1[2] * AC[2][i]) return 0;
-  }
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) {   // axis A_i x B_j, in the frame of box 1: components are +-C[k][j]; unnormalised on both sides of the test
-      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-      const float l2 = 1.0f - C[i][j] * C[i][j];
-      if (l2 < 1e-6f) continue;   // nearly parallel edges: the face axes decide
-      const float tp = fabsf(ta[i2] * C[i1][j] - ta[i1] * C[i2][j]);
-      const float ra = e1[i1] * AC[i2][j] + e1[i2] * AC[i1][j], rb = e2[j1] * AC[i][j2] + e2[j2] * AC[i][j1];
-      if (tp > (ra + rb) * 1.0001f + 1e-7f) return 0;
-    }
+  const float hm = 0.5f * margin;
+  const float a10 = a1[0], a11 = a1[1], a12 = a1[2], e10 = a1[3] + hm, e11 = a1[4] + hm, e12 = a1[5] + hm;
+  const float a20 = a2[0], a21 = a2[1], a22 = a2[2], e20 = a2[3] + hm, e21 = a2[4] + hm, e22 = a2[5] + hm;
+  const float r100 = R1[0], r101 = R1[1], r102 = R1[2], r110 = R1[3], r111 = R1[4], r112 = R1[5], r120 = R1[6], r121 = R1[7], r122 = R1[8];
+  const float r200 = R2[0], r201 = R2[1], r202 = R2[2], r210 = R2[3], r211 = R2[4], r212 = R2[5], r220 = R2[6], r221 = R2[7], r222 = R2[8];
+  // centre offset in world coordinates, then in the frames of box 1 (ta) and box 2 (tb)
+  const float tx = (c->gxpos[3 * g2] + r200 * a20 + r201 * a21 + r202 * a22) - (c->gxpos[3 * g1] + r100 * a10 + r101 * a11 + r102 * a12);
+  const float ty = (c->gxpos[3 * g2 + 1] + r210 * a20 + r211 * a21 + r212 * a22) - (c->gxpos[3 * g1 + 1] + r110 * a10 + r111 * a11 + r112 * a12);
+  const float tz = (c->gxpos[3 * g2 + 2] + r220 * a20 + r221 * a21 + r222 * a22) - (c->gxpos[3 * g1 + 2] + r120 * a10 + r121 * a11 + r122 * a12);
+  const float ta0 = tx * r100 + ty * r110 + tz * r120, ta1 = tx * r101 + ty * r111 + tz * r121, ta2 = tx * r102 + ty * r112 + tz * r122;
+  const float tb0 = tx * r200 + ty * r210 + tz * r220, tb1 = tx * r201 + ty * r211 + tz * r221, tb2 = tx * r202 + ty * r212 + tz * r222;
+  // C_ij = A_i . B_j (columns of the two frames)
+#define GRX_OBB_C(i, j) const float C##i##j = r10##i * r20##j + r11##i * r21##j + r12##i * r22##j, Q##i##j = fabsf(C##i##j);
+  GRX_OBB_C(0, 0) GRX_OBB_C(0, 1) GRX_OBB_C(0, 2) GRX_OBB_C(1, 0) GRX_OBB_C(1, 1) GRX_OBB_C(1, 2) GRX_OBB_C(2, 0) GRX_OBB_C(2, 1) GRX_OBB_C(2, 2)
+#undef GRX_OBB_C
+  if (fabsf(ta0) > e10 + e20 * Q00 + e21 * Q01 + e22 * Q02) return 0;
+  if (fabsf(ta1) > e11 + e20 * Q10 + e21 * Q11 + e22 * Q12) return 0;
+  if (fabsf(ta2) > e12 + e20 * Q20 + e21 * Q21 + e22 * Q22) return 0;
+  if (fabsf(tb0) > e20 + e10 * Q00 + e11 * Q10 + e12 * Q20) return 0;
+  if (fabsf(tb1) > e21 + e10 * Q01 + e11 * Q11 + e12 * Q21) return 0;
+  if (fabsf(tb2) > e22 + e10 * Q02 + e11 * Q12 + e12 * Q22) return 0;
+  // axis A_i x B_j (unnormalised on both sides of the test; nearly parallel edges are left to the face axes)
+#define GRX_OBB_EDGE(i, i1, i2, j, j1, j2) \
+  if (1.0f - C##i##j * C##i##j >= 1e-6f) { \
+    const float tp_ = fabsf(ta##i2 * C##i1##j - ta##i1 * C##i2##j); \
+    const float ra_ = e1##i1 * Q##i2##j + e1##i2 * Q##i1##j, rb_ = e2##j1 * Q##i##j2 + e2##j2 * Q##i##j1; \
+    if (tp_ > (ra_ + rb_) * 1.0001f + 1e-7f) return 0; }
+  GRX_OBB_EDGE(0, 1, 2, 0, 1, 2) GRX_OBB_EDGE(0, 1, 2, 1, 2, 0) GRX_OBB_EDGE(0, 1, 2, 2, 0, 1)
+  GRX_OBB_EDGE(1, 2, 0, 0, 1, 2) GRX_OBB_EDGE(1, 2, 0, 1, 2, 0) GRX_OBB_EDGE(1, 2, 0, 2, 0, 1)
+  GRX_OBB_EDGE(2, 0, 1, 0, 1, 2) GRX_OBB_EDGE(2, 0, 1, 1, 2, 0) GRX_OBB_EDGE(2, 0, 1, 2, 0, 1)
+#undef GRX_OBB_EDGE
   return 1;
 }
 
@@ -1303,18 +1335,26 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     for (int k = 0; k < 9; k++) { q.R1[k] = c->gxmat[9 * g1 + k]; q.R2[k] = c->gxmat[9 * g2 + k]; }
     q.t1 = m->geom_type[g1]; q.t2 = m->geom_type[g2]; q.hm = 0.5f * margin; q.lane = lane_;
     for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = c->gxpos[3 * g2 + k] - c->gxpos[3 * g1 + k]; }
-    q.v1 = q.t1 == 7 ? m->mesh_vert + 3 * m->geom_meshadr[g1] : m->mesh_vert; q.n1 = q.t1 == 7 ? m->geom_meshnum[g1] : 0;
-    q.v2 = q.t2 == 7 ? m->mesh_vert + 3 * m->geom_meshadr[g2] : m->mesh_vert; q.n2 = q.t2 == 7 ? m->geom_meshnum[g2] : 0;
+    q.v1 = q.t1 == 7 ? m->mesh_vert + 3 * m->geom_hulladr[g1] : m->mesh_vert; q.n1 = q.t1 == 7 ? m->geom_hullnum[g1] : 0;
+    q.v2 = q.t2 == 7 ? m->mesh_vert + 3 * m->geom_hulladr[g2] : m->mesh_vert; q.n2 = q.t2 == 7 ? m->geom_hullnum[g2] : 0;
     q.pts = (GrxMprPt*)(c->Jp + 192);   // 30 words behind the pair queue: the Jacobian pool is free until the constraint stage
-    // a direction kept from an earlier substep: still separating?
+    // a direction kept from an earlier substep: still separating?  (entry: pair + 1, direction, (v1 + 1) + 4096 (v2 + 1) = the support vertices)
     float* mc = c->meshcache;
     const float key = (float)(pair + 1);
-    const int slot = mc[0] == key ? 0 : (mc[4] == key ? 1 : (mc[8] == key ? 2 : (mc[12] == key ? 3 : -1)));
+    const int slot = mc[0] == key ? 0 : (mc[5] == key ? 1 : (mc[10] == key ? 2 : (mc[15] == key ? 3 : -1)));
     if (slot >= 0) {
-      const float d[3] = {mc[4 * slot + 1], mc[4 * slot + 2], mc[4 * slot + 3]};
-      GrxMprPt sp;
-      grx_mpr_support<true>(&q, d, &sp);
-      if (dot3f(sp.v, d) < -1e-6f) {   // strictly on the far side: the (inflated) geoms are disjoint
+      const float d[3] = {mc[5 * slot + 1], mc[5 * slot + 2], mc[5 * slot + 3]}, nd[3] = {-d[0], -d[1], -d[2]};
+      const int hints = (int)mc[5 * slot + 4];
+      int h1 = (hints & 4095) - 1, h2 = (hints >> 12) - 1;
+      float sw[3], sb[3], dl[3], r[3];
+      if (q.t1 == 7) { mulMatTVec3f(dl, q.R1, d); h1 = grx_mesh_support_hint(m, m->geom_hulladr[g1], q.n1, dl, h1, r, lane_); mulMatVec3f(sw, q.R1, r); }
+      else grx_geom_support(q.R1, q.s1, q.t1, d, sw);
+      if (q.t2 == 7) { mulMatTVec3f(dl, q.R2, nd); h2 = grx_mesh_support_hint(m, m->geom_hulladr[g2], q.n2, dl, h2, r, lane_); mulMatVec3f(sb, q.R2, r); }
+      else grx_geom_support(q.R2, q.s2, q.t2, nd, sb);
+      float sv = 0.0f;   // v . d of the Minkowski support point (see grx_mpr_support)
+      for (int k = 0; k < 3; k++) sv += ((sw[k] + d[k] * q.hm) - (sb[k] + q.c21[k] - d[k] * q.hm)) * d[k];
+      if (sv < -1e-6f) {   // strictly on the far side: the (inflated) geoms are disjoint
+        LANE0 { mc[5 * slot + 4] = (float)((h1 + 1) + 4096 * (h2 + 1)); }
 #if defined(GRX_EMU)
         g_grx_mesh_stats[0]++;
 #endif
@@ -1332,8 +1372,8 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     WAVE_SYNC();
     if (rc != 0) {
       if (sep[3] != 0.0f) {   // keep the direction for the next substeps
-        const int w = slot >= 0 ? slot : ((int)mc[16] & 3);   // the pair's own slot, else round robin over the four
-        LANE0 { mc[4 * w] = key; mc[4 * w + 1] = sep[0]; mc[4 * w + 2] = sep[1]; mc[4 * w + 3] = sep[2]; if (slot < 0) mc[16] = (float)((w + 1) & 3); }
+        const int w = slot >= 0 ? slot : ((int)mc[20] & 3);   // the pair's own slot, else round robin over the four
+        LANE0 { mc[5 * w] = key; mc[5 * w + 1] = sep[0]; mc[5 * w + 2] = sep[1]; mc[5 * w + 3] = sep[2]; mc[5 * w + 4] = 0.0f; if (slot < 0) mc[20] = (float)((w + 1) & 3); }
       }
       WAVE_SYNC();
       continue;
@@ -1739,27 +1779,64 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     }
     WAVE_SYNC();
   }
-  for (int base = 0; base < m->ndevpair; base += 64) {
-    GRX_LANEVAR_I(boxq); GRX_LANEVAR_I(meshq);
+  // Models with more than one wave of candidates (the Fetch arm: 163, most of them hull pairs): a first sweep runs only the bounding-sphere /
+  // plane-distance test and compacts the survivors (ballot prefix, pair order), so the narrow phases and the bounding-box tests below see
+  // ONE dense pass instead of one sparse, divergent pass per 64 candidates.
+  const int ndp = m->ndevpair;
+  int nsurv = ndp; const int* surv = nullptr;
+  if (ndp > 64 && 256 + ndp <= c->jpool) {
+    int* sv = (int*)(c->Jp + 256);   // the Jacobian pool is free until the constraint stage ([0, 128) is c->red, [128, 222) the hull-pair queue + portal)
+    int ns = 0;
+    for (int base = 0; base < ndp; base += 64) {
+      GRX_LANEVAR_I(ps);
+      FOR_LANES {
+        const int k = base + lane; int pass = 0;
+        if (k < ndp) {
+          const unsigned rec = (unsigned)m->devpair_geoms[k];
+          const int g1 = rec & 0xFFF, g2 = (rec >> 12) & 0xFFF, t1 = (rec >> 24) & 0xF;
+          const float margin = m->devpair_bound[2 * k], rb = m->devpair_bound[2 * k + 1];
+          float dx[3] = {c->gxpos[3 * g2] - c->gxpos[3 * g1], c->gxpos[3 * g2 + 1] - c->gxpos[3 * g1 + 1], c->gxpos[3 * g2 + 2] - c->gxpos[3 * g1 + 2]};
+          if (t1 == 0) { float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}; pass = dot3f(dx, n) <= rb + margin; }
+          else { const float r = rb + margin; pass = dot3f(dx, dx) <= r * r; }
+        }
+        LV(ps) = pass;
+      }
+      const unsigned long long bm = GRX_BALLOT(ps);
+      FOR_LANES { if (LV(ps)) sv[ns + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = base + lane; }
+      ns += __builtin_popcountll(bm);
+    }
+    WAVE_SYNC();
+    nsurv = ns; surv = sv;
+  }
+  for (int base = 0; base < nsurv; base += 64) {
+    GRX_LANEVAR_I(boxq); GRX_LANEVAR_I(meshq); GRX_LANEVAR_I(pairq);
     FOR_LANES {
-      int k = base + lane, isbox = 0, ismesh = 0;
-      if (k < m->ndevpair) {
+      int isbox = 0, ismesh = 0, pq = 0;
+      if (base + lane < nsurv) {
+        const int k = surv ? surv[base + lane] : base + lane;
         // one packed record per candidate (geoms, types, margin, broad-phase radius): a single level of model-table loads
         const unsigned rec = (unsigned)m->devpair_geoms[k];
         const int g1 = rec & 0xFFF, g2 = (rec >> 12) & 0xFFF, t1 = (rec >> 24) & 0xF, t2 = rec >> 28;
         const float margin = m->devpair_bound[2 * k], rb = m->devpair_bound[2 * k + 1];
-        float dx[3] = {c->gxpos[3 * g2] - c->gxpos[3 * g1], c->gxpos[3 * g2 + 1] - c->gxpos[3 * g1 + 1], c->gxpos[3 * g2 + 2] - c->gxpos[3 * g1 + 2]};
-        int pass;
-        if (t1 == 0) {
-          float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]};
-          pass = dot3f(dx, n) <= rb + margin;
-        } else {
-          float r = rb + margin;
-          pass = dot3f(dx, dx) <= r * r;
+        int pass = 1;
+        if (!surv) {
+          float dx[3] = {c->gxpos[3 * g2] - c->gxpos[3 * g1], c->gxpos[3 * g2 + 1] - c->gxpos[3 * g1 + 1], c->gxpos[3 * g2 + 2] - c->gxpos[3 * g1 + 2]};
+          if (t1 == 0) {
+            float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]};
+            pass = dot3f(dx, n) <= rb + margin;
+          } else {
+            float r = rb + margin;
+            pass = dot3f(dx, dx) <= r * r;
+          }
         }
+        pq = m->devpair[k];
         if (pass) {
-          const int p = m->devpair[k];
+          const int p = pq;
+#ifdef GRX_DBG_NO_OBB
+          if (t2 == 7 && t1 != 0) { if (S::kMesh) ismesh = 1; }
+#else
           if (t2 == 7 && t1 != 0) { if (S::kMesh) ismesh = grx_obb_overlap(m, c, g1, g2, margin); }
+#endif
           else if (t1 == 2 && t2 == 2) grx_sphere_sphere_raw(c, p, c->gxpos + 3 * g1, m->geom_size[3 * g1], c->gxpos + 3 * g2, m->geom_size[3 * g2], margin);
           else if (t1 == 2 && t2 == 3) grx_sphere_capsule(m, c, p, g1, g2, margin);
           else if (t1 == 0 && t2 == 2) grx_plane_sphere(m, c, p, g1, g2, margin);
@@ -1778,7 +1855,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           }
         }
       }
-      LV(boxq) = isbox; LV(meshq) = ismesh;
+      LV(boxq) = isbox; LV(meshq) = ismesh; LV(pairq) = pq;
     }
     WAVE_SYNC();
     GRX_SUBTICK(c, 13);
@@ -1786,17 +1863,20 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
       const unsigned long long mm = GRX_BALLOT(meshq);
       if (mm) {
         int* queue = (int*)(c->Jp + 128);   // the Jacobian pool is free until the constraint stage; [0, 128) is c->red
-        FOR_LANES { if (LV(meshq)) queue[__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = m->devpair[base + lane]; }
+        FOR_LANES { if (LV(meshq)) queue[__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = LV(pairq); }
         WAVE_SYNC();
+#ifndef GRX_DBG_NO_MESHPAIRS
         grx_mesh_pairs(m, c, queue, __builtin_popcountll(mm), lane_);
+#endif
       }
     }
+    GRX_SUBTICK(c, 16);
     // box-box pairs that passed the broad phase: queue them (pair order) and let eight lanes work on each
     {
       const unsigned long long bm = GRX_BALLOT(boxq);
       if (bm) {
         int* queue = (int*)c->red;
-        FOR_LANES { if (LV(boxq)) queue[__builtin_popcountll(bm & ((1ull << lane) - 1ull))] = m->devpair[base + lane]; }
+        FOR_LANES { if (LV(boxq)) queue[__builtin_popcountll(bm & ((1ull << lane) - 1ull))] = LV(pairq); }
         WAVE_SYNC();
         grx_box_box_queue(m, c, queue, __builtin_popcountll(bm), lane_);
       }

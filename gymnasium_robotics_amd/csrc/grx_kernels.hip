@@ -53,7 +53,7 @@ __device__ __forceinline__ void grx_load_world(const GrxModel& m, const GrxFetch
 // last cleared the buffer (sticky: a capacity overflow in step 17 is still visible after step 50)
 __device__ __forceinline__ int grx_status_word(int old, int now) { return (now & 0xFFFF) | ((((old >> 16) | now) & 0xFFFF) << 16); }
 
-__device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetchTask& t, const GrxFetchBuffers& b, GrxCtx& c, int w, int lane_) {
+__device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetchTask& t, const GrxFetchBuffers& b, GrxCtx& c, int w, int lane_, int keep_outcome = 0) {
   for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
   for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)w * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * m.nv + i] = c.qacc_ws[i]; }
   for (int i = lane_; i < 7 * m.nmocap; i += 64) {
@@ -63,15 +63,17 @@ __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetc
   if (lane_ == 0) {
     const float* ag = b.achieved + (size_t)w * 3;
     float d = grx_goal_distance3(ag, b.goal + (size_t)w * 3);
-    b.reward[w] = grx_fetch_reward(d, t.distance_threshold, t.sparse_reward);
-    b.success[w] = (d < t.distance_threshold) ? 1 : 0;
+    if (!keep_outcome) {
+      b.reward[w] = grx_fetch_reward(d, t.distance_threshold, t.sparse_reward);
+      b.success[w] = (d < t.distance_threshold) ? 1 : 0;
+    }
     b.status[w] = grx_status_word(b.status[w], c.cnt[2]);
     if (b.packed) {   // [obs | achieved | desired | reward | success] row for the cross-rank gather: no pack kernels on the host side
       float* row = b.packed + (size_t)w * (t.obs_dim + 8);
       const float* ob = b.obs + (size_t)w * t.obs_dim;
       for (int k = 0; k < t.obs_dim; k++) row[k] = ob[k];
       for (int k = 0; k < 3; k++) { row[t.obs_dim + k] = ag[k]; row[t.obs_dim + 3 + k] = b.goal[(size_t)w * 3 + k]; }
-      row[t.obs_dim + 6] = b.reward[w]; row[t.obs_dim + 7] = (d < t.distance_threshold) ? 1.0f : 0.0f;
+      row[t.obs_dim + 6] = b.reward[w]; row[t.obs_dim + 7] = b.success[w] ? 1.0f : 0.0f;
     }
   }
 }
@@ -112,10 +114,10 @@ template <class S> static bool grx_shape_matches(const GrxModel& g) {
 }
 // last template argument: bit 0 = general convex routine for primitive pairs (ellipsoid / cylinder), bit 1 = hull-vs-convex pairs (every model with
 // collidable mesh geoms next to boxes / other meshes: all Fetch and Shadow-hand models)
-typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 112, 1504, 0, 32, 0, 2> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1504, 0, 32, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
-typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 112, 1504, 0, 32, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 112, 1504, 0, 32, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 144, 1984, 0, 32, 0, 2> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 144, 1984, 0, 32, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
+typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 144, 1984, 0, 32, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 144, 1984, 0, 32, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
@@ -127,8 +129,12 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 3> Gr
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 3> GrxShapeHandEggTouch;
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 2> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
 
+// waves per SIMD the Fetch kernels are compiled for (VGPR budget 168 at 3, 256 at 2): the convex narrow phase needs the full budget
+#ifndef GRX_FETCH_WAVES
+#define GRX_FETCH_WAVES(S) 2   // the wave-cooperative hull routine keeps ~100 values live: at 168 VGPRs (3 waves) the step kernels spill 60-110 registers and run slower than at 2 waves (measured 3.82 vs 3.49 ms per step)
+#endif
 template <class S>
-__global__ void __launch_bounds__(64, (S::kFixed && !S::kConvex) ? 3 : 2)   // the convex narrow phase needs the full VGPR budget (41 spills at 168)
+__global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))
 grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
@@ -169,7 +175,7 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
 // reset-time mj_forward + outputs (nstep > 0: raw settle steps first, _env_setup).  Shape-specialised like the step kernel: the generic
 // instantiation needs 275 VGPRs (one wave per SIMD) and took 1.6 x a whole env.step().
 template <class S>
-__global__ void __launch_bounds__(64, (S::kFixed && !S::kConvex) ? 3 : 2)
+__global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))
 grx_fetch_forward_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words, int nstep) {
   extern __shared__ float lds[];
   const int w = grx_world_of_block(), lane_ = threadIdx.x;
@@ -199,9 +205,10 @@ struct GrxFetchResetArgs {
   const float* samples;    // [n,5] object xy, goal xyz (host PCG64 draws, grx_fetch_sample_resets)
   const float *init_qpos, *init_qvel, *init_mocap;   // [nq] [nv] [7*nmocap]: the state _env_setup left (fetch_env.py:404-428)
   int obj_qadr;            // qpos address of object0:joint, -1 without object
+  int keep_outcome;        // same-step autoreset: reward / success (and the packed row's last two words) keep the finished episode's values
 };
 template <class S>
-__global__ void __launch_bounds__(64, (S::kFixed && !S::kConvex) ? 3 : 2)
+__global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))
 grx_fetch_reset_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, GrxFetchResetArgs r, int n_reset, int words) {
   extern __shared__ float lds[];
   const int k = blockIdx.x, lane_ = threadIdx.x;
@@ -233,7 +240,7 @@ grx_fetch_reset_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, GrxFetchRes
   GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
   GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)w * 8, b.obs + (size_t)w * t.obs_dim, b.achieved + (size_t)w * 3, lane_);
   __syncthreads();
-  grx_store_world(m, t, b, c, w, lane_);
+  grx_store_world(m, t, b, c, w, lane_, r.keep_outcome);
 }
 
 // PointMaze env.step(): one wavefront per world, same engine

@@ -29,11 +29,11 @@ from .fetch_spec import DISTANCE_THRESHOLD, FETCH_TASKS, MAX_EPISODE_STEPS, N_SU
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
 
 
-# Engine capacities of the Fetch models (defaults: 32 contacts / 144 rows / 2 032 Jacobian-pool words).  112 rows / 1 504 pool words bring
-# the per-world LDS footprint to 14 granules = 9 worlds per CU.  Measured on 2.46 M random-action world-steps of FetchPickAndPlace: 0.035 %
-# of them hit a capacity in some substep (excess contacts dropped for that substep, GRX_ST_EFC_OVERFLOW raised in `status`), against
-# 0.004 % with the defaults; `model.with_capacity(maxefc=0, jpool=0)` restores the defaults (generic kernel).
-FETCH_CAPACITY = {"maxcon": 32, "maxefc": 112, "jpool": 1504, "split_spans": False}   # the arm chain is (nearly) contiguous: single-span rows
+# Engine capacities of the Fetch models: 32 contacts / 144 rows / 1 984 Jacobian-pool words = 20.4 KB of LDS per world = 16 allocation
+# granules = 8 worlds per CU, which is also what the register budget of the step kernels allows (2 waves per SIMD: the hull-vs-convex
+# routine needs more than the 168 VGPRs of a 3-wave build).  Round 1 ran 112 rows / 1 520 words for 9 worlds per CU and dropped contacts
+# in 0.035 % of the world-steps; at these capacities the measured rate is 0.004 % (GRX_STATUS_EFC_OVERFLOW, sticky in `status`).
+FETCH_CAPACITY = {"maxcon": 32, "maxefc": 144, "jpool": 1984, "split_spans": False}   # the arm chain is (nearly) contiguous: single-span rows
 
 
 def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledModel:
@@ -254,10 +254,10 @@ class FetchVecEnv(GoalVecEnv):
         dev.copy_(stage, non_blocking=True)
         return n, dev[:n].view(torch.int32), dev[n:]
 
-    def _launch_reset(self, staged, idx):
+    def _launch_reset(self, staged, idx, keep_outcome=False):
         n, idx_dev, samples = staged
         args = _native.FetchResetArgsStruct(idx_dev.data_ptr(), samples.data_ptr(), self.initial_qpos.data_ptr(), self.initial_qvel.data_ptr(),
-                                            self._mocap0.data_ptr(), int(self._obj_qadr))
+                                            self._mocap0.data_ptr(), int(self._obj_qadr), int(keep_outcome))
         _native.check(self._L.grx_fetch_reset(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs), ctypes.byref(args), n, self._stream()))
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
@@ -313,14 +313,15 @@ class FetchVecEnv(GoalVecEnv):
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
                 staged = self._stage_reset(done)
-                td = staged[1].long()
-                info["final_obs"] = self._obs_dict(rows=done, rows_dev=td)   # the terminal observation, gathered before the reset overwrites the rows
-                keep_r, keep_s = self.reward.clone(), self.success.clone()
-                self._launch_reset(staged, done)
-                self.reward.copy_(keep_r)
-                self.success.copy_(keep_s)
-                self.packed[td, -2] = keep_r[td]   # the packed rows of the reset worlds: reset observation, terminal reward / success
-                self.packed[td, -1] = keep_s[td].float()
+                # the terminal observation, gathered (one kernel, from the packed rows) before the reset overwrites them; the reset kernel then
+                # leaves reward / success of these worlds at the finished episode's values (keep_outcome)
+                if self.output == "torch":
+                    fo = self.packed[staged[1].long()]
+                    info["final_obs"] = {"observation": fo[:, : self.obs_dim], "achieved_goal": fo[:, self.obs_dim: self.obs_dim + 3],
+                                         "desired_goal": fo[:, self.obs_dim + 3: self.obs_dim + 6]}
+                else:
+                    info["final_obs"] = self._obs_dict(rows=done)
+                self._launch_reset(staged, done, keep_outcome=True)
             elif self.autoreset_mode == "next_step":
                 self._needs_reset |= truncated
         obs = self._obs_dict()

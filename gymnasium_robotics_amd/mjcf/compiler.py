@@ -1007,6 +1007,8 @@ class _Lowering:
         geom_bodyid = np.zeros(ng, np.int32)
         geom_meshadr = -np.ones(ng, np.int32)
         geom_meshnum = np.zeros(ng, np.int32)
+        geom_hulladr = -np.ones(ng, np.int32)   # full convex hull (support function of the hull-vs-convex pairs); geom_meshadr may be a pruned subset for the plane pairs
+        geom_hullnum = np.zeros(ng, np.int32)
         geom_pos = np.zeros((ng, 3))
         geom_quat = np.zeros((ng, 4))
         geom_size = np.zeros((ng, 3))
@@ -1209,6 +1211,15 @@ class _Lowering:
                 i = B[i].parent
             return True
 
+        def emit_hull(hv2, adj2):
+            adr = len(mesh_vert)
+            for v, a_ in zip(hv2, adj2):
+                mesh_vert.append(v)
+                mesh_adjadr.append(len(mesh_adj))
+                mesh_adjnum.append(len(a_))
+                mesh_adj.extend(a_)
+            return adr, len(hv2)
+
         for gi, (i, g) in enumerate(geoms):
             if g.type != GEOM_MESH:
                 continue
@@ -1218,30 +1229,34 @@ class _Lowering:
                 continue  # no implemented narrow phase touches this mesh: no vertices needed on the device
             hv, adj = c._load_mesh_hull(g.mesh)
             hv = hv - c._mesh_center(g.mesh)   # geom frame = hull centre of mass (see geom_pos above)
-            keep_v = None
-            planes_static = all(pr[2].type == GEOM_PLANE and weld[geoms[pr[0]][0]] == 0 for pr in sup)
-            if planes_static and only_slides(i):
-                Rg = xmat[i] @ mu.quat2mat(g.quat)
-                keep_set = set()
-                for pr in sup:
-                    pi_, pg = geoms[pr[0]]
-                    n_w = (xmat[pi_] @ mu.quat2mat(pg.quat))[:, 2]
-                    h = (hv @ Rg.T) @ n_w
-                    vstar = int(np.argmin(h))
-                    keep_set |= {vstar} | set(adj[vstar])
-                keep_v = sorted(keep_set)
-            if keep_v is not None:
-                remap = {v: k for k, v in enumerate(keep_v)}
-                hv2 = hv[keep_v]
-                adj2 = [[remap[w] for w in adj[v] if w in remap] for v in keep_v]
-            else:
-                hv2, adj2 = hv, adj
-            geom_meshadr[gi], geom_meshnum[gi] = len(mesh_vert), len(hv2)
-            for v, a_ in zip(hv2, adj2):
-                mesh_vert.append(v)
-                mesh_adjadr.append(len(mesh_adj))
-                mesh_adjnum.append(len(a_))
-                mesh_adj.extend(a_)
+            psup = [pr for pr in sup if pr[2].type == GEOM_PLANE]          # plane pairs: deepest vertex + neighbours (geom_meshadr / geom_meshnum)
+            csup = [pr for pr in sup if pr[2].type != GEOM_PLANE]          # hull-vs-convex pairs: support function over the FULL hull (geom_hulladr / geom_hullnum)
+            full = None
+            if psup:
+                keep_v = None
+                planes_static = all(weld[geoms[pr[0]][0]] == 0 for pr in psup)
+                if planes_static and only_slides(i):
+                    Rg = xmat[i] @ mu.quat2mat(g.quat)
+                    keep_set = set()
+                    for pr in psup:
+                        pi_, pg = geoms[pr[0]]
+                        n_w = (xmat[pi_] @ mu.quat2mat(pg.quat))[:, 2]
+                        h = (hv @ Rg.T) @ n_w
+                        vstar = int(np.argmin(h))
+                        keep_set |= {vstar} | set(adj[vstar])
+                    keep_v = sorted(keep_set)
+                if keep_v is not None:
+                    remap = {v: k for k, v in enumerate(keep_v)}
+                    geom_meshadr[gi], geom_meshnum[gi] = emit_hull(hv[keep_v], [[remap[w] for w in adj[v] if w in remap] for v in keep_v])
+                else:
+                    full = emit_hull(hv, adj)
+                    geom_meshadr[gi], geom_meshnum[gi] = full
+            if csup:
+                if full is None:
+                    full = emit_hull(hv, adj)
+                geom_hulladr[gi], geom_hullnum[gi] = full
+                if not psup:
+                    geom_meshadr[gi], geom_meshnum[gi] = full
 
         # ---- equality constraints
         eqs = []
@@ -1383,7 +1398,7 @@ class _Lowering:
             dof_damping=dof_damp, dof_frictionloss=dof_fl, dof_invweight0=dof_invweight0,
             dof_solref=dof_solref, dof_solimp=dof_solimp,
             geom_type=geom_type, geom_bodyid=geom_bodyid, geom_meshadr=geom_meshadr, geom_meshnum=geom_meshnum,
-            geom_pos=geom_pos, geom_quat=geom_quat, geom_size=geom_size, geom_invweight0=geom_invw, geom_rbound=geom_rbound, geom_aabb=geom_aabb,
+            geom_pos=geom_pos, geom_quat=geom_quat, geom_size=geom_size, geom_invweight0=geom_invw, geom_rbound=geom_rbound, geom_aabb=geom_aabb, geom_hulladr=geom_hulladr, geom_hullnum=geom_hullnum,
             site_bodyid=site_bodyid, site_type=site_type, site_pos=site_pos, site_quat=site_quat, site_size=site_size,
             pair_geom1=pair_geom1, pair_geom2=pair_geom2, pair_condim=pair_condim, pair_supported=pair_supported,
             pair_friction=pair_friction, pair_solref=pair_solref, pair_solimp=pair_solimp, pair_margin=pair_margin,

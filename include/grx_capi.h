@@ -138,6 +138,7 @@ typedef struct grx_fetch_reset_args {
   const float* samples;  /* [n_reset,5] object x, y, goal x, y, z */
   const float *init_qpos, *init_qvel, *init_mocap; /* [nq] [nv] [7*nmocap]: the state _env_setup left (fetch_env.py:404-428) */
   int obj_qadr;          /* qpos address of object0:joint, -1 for the tasks without object */
+  int keep_outcome;      /* != 0 (same-step autoreset): reward[w] / success[w] and the last two words of the packed row keep the finished episode's values */
 } grx_fetch_reset_args;
 int grx_fetch_reset(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, const grx_fetch_reset_args* args, int n_reset, void* stream);
 /* order <- the dispatch order for the next step launch from the per-world costs the last one wrote (grx_fetch_buffers.cost /

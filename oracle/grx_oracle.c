@@ -811,7 +811,7 @@ static void geom_support(const orc_sim* s, int g, const double* d, double hm, do
     }
     case GRX_GEOM_BOX: for (int k = 0; k < 3; k++) r[k] = sgn1(dl[k]) * sz[k]; break;
     case GRX_GEOM_MESH: {   /* convex hull of the mesh: the hull vertex farthest along d (exhaustive; first maximum wins ties) */
-      const int adr = m->geom_meshadr[g], num = m->geom_meshnum[g];
+      const int adr = m->geom_hulladr[g], num = m->geom_hullnum[g];
       double best = -1e300; int bi = 0;
       for (int v = 0; v < num; v++) { double t = dot3(m->mesh_vert + 3 * (adr + v), dl); if (t > best) { best = t; bi = v; } }
       if (num > 0) for (int k = 0; k < 3; k++) r[k] = m->mesh_vert[3 * (adr + bi) + k];
