@@ -297,7 +297,10 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
 
 // Shadow hand reach env.step() (or mj_forward + outputs when forward_only): one wavefront per world, same engine
 template <class S>
-__global__ void __launch_bounds__(64, (S::kFixed && S::JP <= 512) ? 3 : 2)   // third wave per SIMD only where the LDS footprint lets more than 8 worlds share a CU (HandReach); the object models sit at 8
+#ifndef GRX_HANDREACH_WAVES
+#define GRX_HANDREACH_WAVES 2   // with the hull-pair routine the 168-VGPR build spills 73 registers: 11.9 ms per step at 16 384 worlds against 10.95 ms at 2 waves
+#endif
+__global__ void __launch_bounds__(64, (S::kFixed && S::JP <= 512) ? GRX_HANDREACH_WAVES : 2)   // third wave per SIMD only where the LDS footprint lets more than 8 worlds share a CU (HandReach); the object models sit at 8
 grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;

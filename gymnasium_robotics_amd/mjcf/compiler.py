@@ -56,7 +56,7 @@ DIMS = [
     "eulerdamp", "ntree", "maxdepth", "maxefc_req", "jpool_req", "maxcon_req",
 ]
 NDIMS = 32
-OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia", "mpr_tolerance", "mpr_iterations"]
+OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia", "mpr_tolerance", "mpr_iterations", "noslip_tolerance"]
 NOPTS = 16
 
 
@@ -346,7 +346,7 @@ def load_model(path: str) -> CompiledModel:
 # the compiler
 # ----------------------------------------------------------------------------
 class MjcfCompiler:
-    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None):
+    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None):
         """mutate: optional callable(root_element) applied after <include> expansion, before compilation -- the
         in-memory equivalent of the reference's Maze.make_maze XML rewrite (envs/maze/maze_v4.py:168-242)."""
         self.xml_path = os.path.abspath(xml_path)
@@ -356,6 +356,9 @@ class MjcfCompiler:
             mutate(self.root)
         self.keep_sites = None if keep_sites is None else set(keep_sites)   # names of the sites the engine tracks (None = all)
         self.touch_filter = touch_filter      # callable(sensor name) -> bool: which <touch> sensors the engine evaluates
+        # name of a static child of the world whose position is per-world STATE (the reference rewrites model.body_pos at reset:
+        # adroit_hammer.py:374-376): everything welded to it gets a shift flag, the engine adds the world's shift vector to it
+        self.shift_body = shift_body
         self.capacity = dict(capacity or {})   # engine row-table / Jacobian-pool capacities requested for this model (0 = default)
         self.defaults = _Defaults()
         self.angle_scale = np.pi / 180.0  # MJCF default angle unit is degree
@@ -367,7 +370,8 @@ class MjcfCompiler:
         self.bodies: List[_Body] = []
         self.meshes: Dict[str, Dict[str, object]] = {}
         self.opt = dict(timestep=0.002, gravity=np.array([0, 0, -9.81]), tolerance=1e-8, impratio=1.0,
-                        integrator=0, iterations=100, cone=0, noslip_iterations=0, eulerdamp=1, mpr_tolerance=1e-6, mpr_iterations=50)
+                        integrator=0, iterations=100, cone=0, noslip_iterations=0, eulerdamp=1, mpr_tolerance=1e-6, mpr_iterations=50,
+                        noslip_tolerance=1e-6)
 
     # -- attribute helpers -------------------------------------------------
     def _attrs(self, elem: ET.Element, tag: str, childclass: Optional[str]) -> Dict[str, str]:
@@ -420,6 +424,8 @@ class MjcfCompiler:
                 self.opt["iterations"] = int(a["iterations"])
             if "noslip_iterations" in a:
                 self.opt["noslip_iterations"] = int(a["noslip_iterations"])
+            if "noslip_tolerance" in a:
+                self.opt["noslip_tolerance"] = float(a["noslip_tolerance"])
             if "mpr_tolerance" in a:
                 self.opt["mpr_tolerance"] = float(a["mpr_tolerance"])
             if "mpr_iterations" in a:
@@ -896,7 +902,22 @@ class _Lowering:
             k, p, q = anchor_of(i)
             body_orig[B[i].name] = (new_id[k], p.tolist(), q.tolist())
         info["body_orig"] = body_orig
+        # per-world shift group (c.shift_body): the named static child of the world and every body welded to it
+        shift_set = set()
+        if c.shift_body is not None:
+            root_i = next(i for i, b in enumerate(B) if b.name == c.shift_body)
+            if B[root_i].parent != 0 or B[root_i].joints:
+                raise NotImplementedError("shift_body must be a joint-less child of the world")
+            shift_set = {root_i}
+            grew = True
+            while grew:
+                grew = False
+                for i in range(1, nb):
+                    if i not in shift_set and B[i].parent in shift_set and not B[i].joints and not B[i].mocap:
+                        shift_set.add(i); grew = True
+            info["shift_pos0"] = B[root_i].pos.tolist()
 
+        body_shift = np.zeros(nbk, np.int32)
         body_pos = np.zeros((nbk, 3))
         body_quat = np.tile(np.array([1.0, 0, 0, 0]), (nbk, 1))
         body_ipos = np.zeros((nbk, 3))
@@ -918,6 +939,7 @@ class _Lowering:
             par_old = b.parent
             pk, pp, pq = anchor_of(par_old)
             body_pos[k] = pp + mu.rot_vec(pq, b.pos)
+            body_shift[k] = int(par_old in shift_set)   # a moving child of the shift group: its world-frame origin moves with the group
             body_quat[k] = mu.quat_normalize(mu.quat_mul(pq, b.quat))
             body_ipos[k] = fb_com[old]
             I = fb_inertia[old]
@@ -1013,6 +1035,7 @@ class _Lowering:
         geom_quat = np.zeros((ng, 4))
         geom_size = np.zeros((ng, 3))
         geom_invw = np.zeros((ng, 2))
+        geom_shift = np.zeros(ng, np.int32)
         geom_rbound = np.zeros(ng)
         geom_aabb = np.zeros((ng, 6))   # centre, half extents in the geom frame
         mesh_vert, mesh_adjadr, mesh_adjnum, mesh_adj = [], [], [], []
@@ -1022,6 +1045,7 @@ class _Lowering:
             names["geom"][g.name or f"_geom{gi}"] = gi
             geom_type[gi] = g.type
             geom_bodyid[gi] = new_id[k]
+            geom_shift[gi] = int(i in shift_set)
             geom_pos[gi] = p + mu.rot_vec(q, g.pos)
             geom_quat[gi] = mu.quat_normalize(mu.quat_mul(q, g.quat))
             geom_size[gi] = g.size
@@ -1069,8 +1093,8 @@ class _Lowering:
         touch_pos, touch_quat, touch_size = np.zeros((nt, 3)), np.zeros((nt, 4)), np.zeros((nt, 3))
         for ti, (sname, site_name) in enumerate(touch_sel):
             i, sdef = all_sites[site_name]
-            if sdef.type not in (GEOM_SPHERE, GEOM_BOX):
-                raise NotImplementedError("touch zones: sphere and box sites only")
+            if sdef.type not in (GEOM_SPHERE, GEOM_BOX, GEOM_CYLINDER):
+                raise NotImplementedError("touch zones: sphere, box and cylinder sites only")
             k, p, q = anchor_of(i)
             touch_body[ti], touch_type[ti] = new_id[k], sdef.type
             touch_pos[ti] = p + mu.rot_vec(q, sdef.pos)
@@ -1078,9 +1102,11 @@ class _Lowering:
             touch_size[ti] = sdef.size
         T.update(touch_body=touch_body, touch_type=touch_type, touch_pos=touch_pos, touch_quat=touch_quat, touch_size=touch_size)
         names["touch"] = {sname: ti for ti, (sname, _) in enumerate(touch_sel)}
-        sites = [(i, s) for i in range(nb) for s in B[i].sites if s.name not in touch_sites and (c.keep_sites is None or s.name in c.keep_sites)]
+        sites = [(i, s) for i in range(nb) for s in B[i].sites
+                 if (s.name not in touch_sites and c.keep_sites is None) or (c.keep_sites is not None and s.name in c.keep_sites)]   # a touch zone stays an engine site only when asked for by name
         ns = len(sites)
         site_bodyid = np.zeros(ns, np.int32)
+        site_shift = np.zeros(ns, np.int32)
         site_type = np.zeros(ns, np.int32)
         site_pos = np.zeros((ns, 3))
         site_quat = np.zeros((ns, 4))
@@ -1089,6 +1115,7 @@ class _Lowering:
             k, p, q = anchor_of(i)
             names["site"][s.name or f"_site{si}"] = si
             site_bodyid[si] = new_id[k]
+            site_shift[si] = int(i in shift_set)
             site_type[si] = s.type
             site_pos[si] = p + mu.rot_vec(q, s.pos)
             site_quat[si] = mu.quat_normalize(mu.quat_mul(q, s.quat))
@@ -1387,10 +1414,12 @@ class _Lowering:
         g = c.opt["gravity"]
         for k, v in dict(timestep=c.opt["timestep"], gravity_x=g[0], gravity_y=g[1], gravity_z=g[2],
                          tolerance=c.opt["tolerance"], impratio=c.opt["impratio"], meaninertia=meaninertia,
-                         mpr_tolerance=c.opt["mpr_tolerance"], mpr_iterations=c.opt["mpr_iterations"]).items():
+                         mpr_tolerance=c.opt["mpr_tolerance"], mpr_iterations=c.opt["mpr_iterations"],
+                         noslip_tolerance=c.opt["noslip_tolerance"]).items():
             optv[OPTS.index(k)] = v
         T.update(
             dims=dims, opt=optv, qpos0=qpos0,
+            body_shift=body_shift, geom_shift=geom_shift, site_shift=site_shift,
             body_parent=body_parent, body_jntadr=body_jntadr, body_jntnum=body_jntnum, body_dofadr=body_dofadr,
             body_dofnum=body_dofnum, body_mocapid=body_mocapid, body_rootid=body_rootid, body_depth=body_depth,
             body_pos=body_pos, body_quat=body_quat, body_ipos=body_ipos, body_inertia=body_inertia, body_mass=body_mass,
@@ -1609,8 +1638,8 @@ class _Lowering:
         return CompiledModel(T, names, info)
 
 
-def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None) -> CompiledModel:
+def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None) -> CompiledModel:
     """capacity: optional {"maxefc": rows, "jpool": words, "maxcon": contacts, "split_spans": bool} request for the engine's per-world constraint tables.
     touch_filter: optional callable(sensor name) selecting the <touch> sensors the engine evaluates.
     keep_sites: optional list of site names whose world frames the engine tracks (default: every site of the model)."""
-    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites).compile()
+    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites, shift_body=shift_body).compile()

@@ -17,6 +17,7 @@ enum grx_dim {
 enum grx_opt {
   GRX_TIMESTEP = 0, GRX_GRAVITY_X, GRX_GRAVITY_Y, GRX_GRAVITY_Z, GRX_TOLERANCE, GRX_IMPRATIO, GRX_MEANINERTIA,
   GRX_MPR_TOLERANCE, GRX_MPR_ITERATIONS,   /* convex (MPR) narrow phase: MuJoCo option mpr_tolerance (1e-6) / mpr_iterations (50) */
+  GRX_NOSLIP_TOLERANCE,                    /* MuJoCo option noslip_tolerance (1e-6) */
   GRX_NOPTS = 16
 };
 

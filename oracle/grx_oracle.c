@@ -55,6 +55,8 @@ typedef struct orc_sim {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair;
   /* state */
   double time, *qpos, *qvel, *ctrl, *mocap_pos, *mocap_quat, *qacc_warmstart;
+  double shift[3]; /* per-world position offset of the model's shift group (body_shift / geom_shift / site_shift): model.body_pos edits of the reference (adroit_hammer.py:374-376) */
+  int noslip_iter_done;
   /* position stage */
   double *xpos, *xquat, *xmat, *xipos, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
   double *subtree_com, *subtree_mass, *cinert /*36/body*/, *crb /*36/body*/, *cdof /*6/dof*/, *cdof_dot;
@@ -201,6 +203,7 @@ static void kinematics(orc_sim* s) {
         double v[3];
         mulMatVec3(v, xmat + 9 * par, m->body_pos + 3 * i);
         p[0] = xpos[3 * par] + v[0]; p[1] = xpos[3 * par + 1] + v[1]; p[2] = xpos[3 * par + 2] + v[2];
+        if (m->body_shift[i]) { p[0] += s->shift[0]; p[1] += s->shift[1]; p[2] += s->shift[2]; }   /* child of the (world-fixed) shift group */
         mulQuat(q, xquat + 4 * par, m->body_quat + 4 * i);
         for (int k = 0; k < jn; k++) {
           int j = ja + k;
@@ -231,13 +234,13 @@ static void kinematics(orc_sim* s) {
   for (int g = 0; g < s->ngeom; g++) {
     int b = m->geom_bodyid[g]; double v[3], R[9];
     mulMatVec3(v, xmat + 9 * b, m->geom_pos + 3 * g);
-    for (int k = 0; k < 3; k++) s->geom_xpos[3 * g + k] = xpos[3 * b + k] + v[k];
+    for (int k = 0; k < 3; k++) s->geom_xpos[3 * g + k] = xpos[3 * b + k] + v[k] + (m->geom_shift[g] ? s->shift[k] : 0.0);
     quat2mat(R, m->geom_quat + 4 * g); mulMat3(s->geom_xmat + 9 * g, xmat + 9 * b, R);
   }
   for (int g = 0; g < s->nsite; g++) {
     int b = m->site_bodyid[g]; double v[3], R[9];
     mulMatVec3(v, xmat + 9 * b, m->site_pos + 3 * g);
-    for (int k = 0; k < 3; k++) s->site_xpos[3 * g + k] = xpos[3 * b + k] + v[k];
+    for (int k = 0; k < 3; k++) s->site_xpos[3 * g + k] = xpos[3 * b + k] + v[k] + (m->site_shift[g] ? s->shift[k] : 0.0);
     quat2mat(R, m->site_quat + 4 * g); mulMat3(s->site_xmat + 9 * g, xmat + 9 * b, R);
   }
 }
@@ -1542,6 +1545,79 @@ static void solve_newton(orc_sim* s) {
   free(Ma); free(jar); free(force); free(grad); free(search); free(Mv); free(jv); free(Hm); free(Lh); free(tmp); free(quad);
 }
 
+/* Noslip post-solver (MuJoCo option noslip_iterations; Adroit: adroit_assets.xml:3 -- restated from the structure of mj_solNoSlip [3P]):
+ * projected Gauss-Seidel on the DUAL problem with the regulariser R removed, over the friction-loss rows (box [-floss, floss]) and the pairs
+ * of opposing pyramid edges of every frictional contact (their sum -- the normal force -- is kept, the difference is re-solved); equality,
+ * limit and frictionless rows keep the forces of the main solver.  A = J M^-1 J' is formed explicitly here (fp64, plain); the device uses the
+ * same updates matrix-free.  Ends with qfrc_constraint = J'f and qacc = qacc_smooth + M^-1 qfrc_constraint. */
+static void solve_noslip(orc_sim* s, int maxiter) {
+  const grx_model_view* m = &s->m; const int nv = s->nv, nefc = s->nefc;
+  if (nefc == 0 || maxiter <= 0) return;
+  double* B = ALLOC(nefc * nv);   /* M^-1 J' (one column per row, stored as rows) */
+  double* A = ALLOC(nefc * nefc);
+  double* b = ALLOC(nefc);
+  double* f = s->efc_force;
+  for (int r = 0; r < nefc; r++) {
+    memcpy(B + (size_t)r * nv, s->efc_J + (size_t)r * nv, sizeof(double) * (size_t)nv);
+    chol_reverse_solve(s->L, nv, B + (size_t)r * nv);
+  }
+  for (int r = 0; r < nefc; r++) {
+    double v = 0; for (int j = 0; j < nv; j++) v += s->efc_J[(size_t)r * nv + j] * s->qacc_smooth[j];
+    b[r] = v - s->efc_aref[r];
+    for (int c = 0; c < nefc; c++) { double a = 0; for (int j = 0; j < nv; j++) a += s->efc_J[(size_t)r * nv + j] * B[(size_t)c * nv + j]; A[(size_t)r * nefc + c] = a; }
+  }
+  const double scale = 1.0 / (m->opt[GRX_MEANINERTIA] * (nv > 1 ? nv : 1)), tol = m->opt[GRX_NOSLIP_TOLERANCE];
+  int iter = 0;
+  while (iter < maxiter) {
+    double improvement = 0;
+    if (iter == 0) for (int i = 0; i < nefc; i++) improvement += 0.5 * f[i] * f[i] * s->efc_R[i];   /* cost change of dropping the regulariser */
+    /* dry friction */
+    for (int i = s->ne; i < s->ne + s->nf; i++) {
+      double res = b[i]; for (int c = 0; c < nefc; c++) res += A[(size_t)i * nefc + c] * f[c];
+      const double Aii = A[(size_t)i * nefc + i], old = f[i], fl = s->efc_frictionloss[i];
+      double fn = old - res / fmax(MINVAL, Aii);
+      fn = fn < -fl ? -fl : (fn > fl ? fl : fn);
+      f[i] = fn;
+      const double d = fn - old;
+      improvement -= 0.5 * d * d * Aii + d * res;
+    }
+    /* contact friction: pairs of opposing pyramid edges */
+    for (int c = 0; c < s->ncon; c++) {
+      const orc_contact* con = &s->con[c];
+      if (con->efc_address < 0 || con->dim == 1) continue;
+      for (int j = con->efc_address; j < con->efc_address + 2 * (con->dim - 1) && j + 1 < nefc; j += 2) {
+        double res[2];
+        for (int k = 0; k < 2; k++) { res[k] = b[j + k]; for (int q = 0; q < nefc; q++) res[k] += A[(size_t)(j + k) * nefc + q] * f[q]; }
+        const double A00 = A[(size_t)j * nefc + j], A01 = A[(size_t)j * nefc + j + 1], A10 = A[(size_t)(j + 1) * nefc + j], A11 = A[(size_t)(j + 1) * nefc + j + 1];
+        const double o0 = f[j], o1 = f[j + 1];
+        const double bc0 = res[0] - (A00 * o0 + A01 * o1), bc1 = res[1] - (A10 * o0 + A11 * o1);
+        const double mid = 0.5 * (o0 + o1);
+        const double K1 = A00 + A11 - A01 - A10, K0 = mid * (A00 - A11) + bc0 - bc1;
+        if (K1 < MINVAL) { f[j] = f[j + 1] = mid; }
+        else {
+          const double y = -K0 / K1;
+          if (y < -mid) { f[j] = 0; f[j + 1] = 2 * mid; }
+          else if (y > mid) { f[j] = 2 * mid; f[j + 1] = 0; }
+          else { f[j] = mid + y; f[j + 1] = mid - y; }
+        }
+        const double d0 = f[j] - o0, d1 = f[j + 1] - o1;
+        improvement -= 0.5 * (d0 * (A00 * d0 + A01 * d1) + d1 * (A10 * d0 + A11 * d1)) + d0 * res[0] + d1 * res[1];
+      }
+    }
+    iter++;
+    if (improvement * scale < tol) break;
+  }
+  s->noslip_iter_done = iter;
+  for (int i = 0; i < nv; i++) {
+    double v = 0; for (int r = 0; r < nefc; r++) v += s->efc_J[(size_t)r * nv + i] * f[r];
+    s->qfrc_constraint[i] = v;
+  }
+  memcpy(s->qacc, s->qfrc_constraint, sizeof(double) * (size_t)nv);
+  chol_reverse_solve(s->L, nv, s->qacc);
+  for (int i = 0; i < nv; i++) s->qacc[i] += s->qacc_smooth[i];
+  free(B); free(A); free(b);
+}
+
 /* ------------------------------------------------------------------ forward / step */
 static int bad_number(const double* x, int n, double maxval) {
   for (int i = 0; i < n; i++) if (!(x[i] == x[i]) || x[i] > maxval || x[i] < -maxval) return 1;
@@ -1572,6 +1648,25 @@ static double ray_box(const double* p, const double* d, const double* sz) {
 
 /* touch sensors (MuJoCo mjSENS_TOUCH [3P]): sum of the normal forces of the active contacts that involve the zone's body and
  * whose ray (from the contact point along the contact normal, flipped when the zone's body is the second one) meets the zone */
+/* ray against a cylinder zone (radius r, half height h along z; mju_rayGeom semantics [3P]): nearest non-negative hit of the side or a cap, -1 if none */
+static double ray_cylinder(const double* p, const double* d, double r, double h) {
+  double best = -1;
+  double a = d[0] * d[0] + d[1] * d[1], b = d[0] * p[0] + d[1] * p[1], c = p[0] * p[0] + p[1] * p[1] - r * r;
+  if (a > MINVAL) {
+    double det = b * b - a * c;
+    if (det >= 0) {
+      double sq = sqrt(det);
+      for (int k = 0; k < 2; k++) { double t = (-b + (k ? sq : -sq)) / a; if (t >= 0 && fabs(p[2] + t * d[2]) <= h && (best < 0 || t < best)) best = t; }
+    }
+  }
+  if (fabs(d[2]) > MINVAL)
+    for (int side = -1; side <= 1; side += 2) {
+      double t = (side * h - p[2]) / d[2], x = p[0] + t * d[0], y = p[1] + t * d[1];
+      if (t >= 0 && x * x + y * y <= r * r && (best < 0 || t < best)) best = t;
+    }
+  return best;
+}
+
 static void touch_sensors(orc_sim* s) {
   const grx_model_view* m = &s->m;
   for (int t = 0; t < m->n_touch_body; t++) {
@@ -1591,7 +1686,8 @@ static void touch_sensors(orc_sim* s) {
       double sg = (b == b2) ? -1.0 : 1.0, dw[3] = {sg * con->frame[0], sg * con->frame[1], sg * con->frame[2]};
       double pw[3] = {con->pos[0] - zp[0], con->pos[1] - zp[1], con->pos[2] - zp[2]}, pl[3], dl[3];
       mulMatTVec3(pl, zR, pw); mulMatTVec3(dl, zR, dw);
-      double hit = m->touch_type[t] == GRX_GEOM_SPHERE ? ray_sphere(pl, dl, m->touch_size[3 * t]) : ray_box(pl, dl, m->touch_size + 3 * t);
+      double hit = m->touch_type[t] == GRX_GEOM_SPHERE ? ray_sphere(pl, dl, m->touch_size[3 * t])
+                 : (m->touch_type[t] == GRX_GEOM_CYLINDER ? ray_cylinder(pl, dl, m->touch_size[3 * t], m->touch_size[3 * t + 1]) : ray_box(pl, dl, m->touch_size + 3 * t));
       if (hit >= 0) val += fn;
     }
     s->touch[t] = val;
@@ -1629,6 +1725,7 @@ void orc_forward(orc_sim* s) {
     s->solver_iter = 0;
   } else {
     solve_newton(s);
+    if (s->m.dims[GRX_NOSLIP_ITERATIONS] > 0) solve_noslip(s, s->m.dims[GRX_NOSLIP_ITERATIONS]);
   }
   memcpy(s->qacc_warmstart, s->qacc, sizeof(double) * (size_t)nv);
   if (s->nefc == 0) memset(s->efc_force, 0, sizeof(s->efc_force));
@@ -1725,6 +1822,7 @@ double* orc_ptr(orc_sim* s, const char* name) {
   P(efc_R) P(efc_aref) P(efc_force) P(efc_vel) P(efc_diagApprox) P(touch)
 #undef P
   if (!strcmp(name, "time")) return &s->time;
+  if (!strcmp(name, "shift")) return s->shift;
   if (!strcmp(name, "min_activation_gap")) return &s->min_activation_gap;
   return NULL;
 }
@@ -1745,6 +1843,7 @@ int orc_int(orc_sim* s, const char* name) {
   if (!strcmp(name, "nl")) return s->nl;
   if (!strcmp(name, "ntl")) return s->ntl;
   if (!strcmp(name, "solver_iter")) return s->solver_iter;
+  if (!strcmp(name, "noslip_iter")) return s->noslip_iter_done;
   if (!strcmp(name, "bad_state")) return s->bad_state;
   if (!strcmp(name, "unsupported_hits")) return s->unsupported_hits;
   if (!strcmp(name, "mesh_candidates")) return (int)s->mesh_candidates;

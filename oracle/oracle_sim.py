@@ -63,7 +63,7 @@ class OracleSim:
             xipos=3 * self.nbody, geom_xpos=3 * self.ngeom, geom_xmat=9 * self.ngeom, site_xpos=3 * self.nsite,
             site_xmat=9 * self.nsite, subtree_com=3 * self.nbody, cdof=6 * self.nv, M=self.nv * self.nv,
             cvel=6 * self.nbody, qfrc_bias=self.nv, qfrc_passive=self.nv, qfrc_actuator=self.nv, qfrc_smooth=self.nv,
-            qacc_smooth=self.nv, qfrc_constraint=self.nv, qacc=self.nv, time=1, min_activation_gap=1,
+            qacc_smooth=self.nv, qfrc_constraint=self.nv, qacc=self.nv, time=1, min_activation_gap=1, shift=3,
             touch=len(model.tables.get("touch_body", [])),
         )
         for name, n in sizes.items():
@@ -97,6 +97,7 @@ class OracleSim:
     nefc = property(lambda self: self._L.orc_int(self._h, b"nefc"))
     ncon = property(lambda self: self._L.orc_int(self._h, b"ncon"))
     solver_iter = property(lambda self: self._L.orc_int(self._h, b"solver_iter"))
+    noslip_iter = property(lambda self: self._L.orc_int(self._h, b"noslip_iter"))
     bad_state = property(lambda self: self._L.orc_int(self._h, b"bad_state"))
     unsupported_hits = property(lambda self: self._L.orc_int(self._h, b"unsupported_hits"))
     mesh_candidates = property(lambda self: self._L.orc_int(self._h, b"mesh_candidates"))

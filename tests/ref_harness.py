@@ -268,3 +268,61 @@ def point_maze_on_oracle(oracle_env, maze_map, reward_type, continuing_task, res
     env.position_noise_range, env.target_site_id, env.render_mode = 0.25, 0, None
     env.observation_space = sys.modules["gymnasium"].spaces.Dict({"observation": None, "achieved_goal": None, "desired_goal": None})
     return env
+
+
+class _BodyPosProxy:
+    """model.body_pos of the Adroit hammer env: the only write the reference makes is body_pos[nail_board, 2] = z (adroit_hammer.py:374-376),
+    which the oracle holds as the per-world shift of the board group; reads return the stored row."""
+
+    def __init__(self, oracle_env, board_id, pos0):
+        self._env, self._id, self._row = oracle_env, board_id, np.array(pos0, dtype=np.float64)
+
+    def __setitem__(self, key, value):
+        if key == (self._id, 2):
+            self._row[2] = float(value)
+            self._env.set_board_z(float(value))
+        elif key == self._id:
+            self._row[:] = value
+            self._env.set_board_z(float(self._row[2]))
+        else:
+            raise KeyError(f"unexpected model.body_pos write {key}")
+
+    def __getitem__(self, key):
+        assert key == self._id
+        return self._row
+
+
+def adroit_hammer_on_oracle(oracle_env, reward_type="dense"):
+    """The reference's AdroitHandHammerEnv (constructor bypassed: it needs MuJoCo) with model / data proxies onto the oracle simulation;
+    step / _get_obs / reset / reset_model are the reference's code, MujocoEnv's do_simulation / set_state / reset the stand-in above."""
+    install()
+    _install_mujoco_env_stand_in()
+    from gymnasium_robotics.envs.adroit_hand import adroit_hammer
+
+    s, m = oracle_env.sim, oracle_env.model
+    env = object.__new__(adroit_hammer.AdroitHandHammerEnv)
+    board_id = 10 ** 6   # the board is fused into the world body by the compiler: any id the proxy recognises will do
+    env.model = types.SimpleNamespace(nu=m.dim("nu"), na=0, body_pos=_BodyPosProxy(oracle_env, board_id, m.info["shift_pos0"]),
+                                      actuator_ctrlrange=np.array(m.tables["act_ctrlrange"], dtype=np.float64).reshape(-1, 2))
+
+    class Data:
+        qpos, qvel, ctrl = s.qpos, s.qvel, s.ctrl
+        xpos = property(lambda self: s.xpos.reshape(-1, 3))
+        xquat = property(lambda self: s.xquat.reshape(-1, 4))
+        site_xpos = property(lambda self: s.site_xpos.reshape(-1, 3))
+        sensordata = property(lambda self: s.touch)
+        _step = staticmethod(lambda n: s.step(n))
+        _forward = staticmethod(lambda: s.forward())
+        _reset = staticmethod(lambda: s.reset_data())
+    env.data = Data()
+    env._model_names = types.SimpleNamespace(sensor_name2id={"S_nail": 0})
+    env.frame_skip, env.render_mode = 5, None
+    env.sparse_reward = reward_type == "sparse"
+    env.init_qpos, env.init_qvel = oracle_env.init_qpos.copy(), oracle_env.init_qvel.copy()
+    env.act_mean = np.mean(env.model.actuator_ctrlrange, axis=1)
+    env.act_rng = 0.5 * (env.model.actuator_ctrlrange[:, 1] - env.model.actuator_ctrlrange[:, 0])
+    n = m.names
+    env.target_obj_site_id, env.S_grasp_site_id = n["site"]["S_target"], n["site"]["S_grasp"]
+    env.tool_site_id, env.goal_site_id = n["site"]["tool"], n["site"]["nail_goal"]
+    env.obj_body_id, env.target_body_id = n["body"]["Object"], board_id
+    return env

@@ -233,3 +233,28 @@ def test_reference_touch_observation(mode):
         assert np.array_equal(sb[0]["achieved_goal"], sa[0]["achieved_goal"]) and float(sb[1]) == float(sa[1])
         fired += int((sa[0]["observation"][61:] > 0).sum())
     assert fired > 0
+
+
+@pytest.mark.parametrize("reward_type", ["dense", "sparse"])
+def test_reference_adroit_hammer_on_oracle_physics(reward_type):
+    """adroit_hammer.py:291-378 executed as is (action scaling, do_simulation(a, 5), the 46-vector observation with quat2euler and the clipped
+    velocities / touch reading, dense and sparse reward, success flag, reset_model's board-height draw written to model.body_pos) on the oracle
+    physics: identical to the restated task layer (oracle/adroit_oracle.py) step for step."""
+    from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_hammer_model
+    from oracle.adroit_oracle import OracleAdroitHammerEnv
+
+    ref_harness.install()
+    model = load_adroit_hammer_model()
+    a_env, b_env = OracleAdroitHammerEnv(model, reward_type), OracleAdroitHammerEnv(model, reward_type)
+    ref = ref_harness.adroit_hammer_on_oracle(b_env, reward_type)
+    rng = np.random.default_rng(4)
+    for seed in (0, 5):
+        oa, _ = a_env.reset(seed=seed)
+        ob, _ = ref.reset(seed=seed)
+        assert ob.shape == (46,) and np.array_equal(ob, oa)
+        assert a_env.board_z == b_env.board_z and 0.1 <= a_env.board_z <= 0.25
+        for t in range(40):
+            act = rng.uniform(-1.2, 1.2, 26).astype(np.float32)
+            sa, sb = a_env.step(act), ref.step(act)
+            assert np.array_equal(sb[0], sa[0]), (seed, t, np.abs(sb[0] - sa[0]).max())
+            assert float(sb[1]) == float(sa[1]) and bool(sb[4]["success"]) == bool(sa[4]["success"]) and sb[2] is False and sb[3] is False
