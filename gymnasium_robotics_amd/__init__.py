@@ -10,7 +10,7 @@ the batched device environments here:
     obs, reward, terminated, truncated, info = envs.step(actions)        # VectorEnv contract
 
 ``registered_env_ids()`` lists every id this build serves; an id the reference registers but the engine does not cover
-(Adroit*, FrankaKitchen) raises ``UnsupportedEnvError`` with the reason.
+(AdroitHandDoor / Pen / Relocate, FrankaKitchen) raises ``UnsupportedEnvError`` with the reason.
 Nothing here imports torch or loads the HIP library until an environment is constructed.
 """
 from typing import List
@@ -23,8 +23,10 @@ class UnsupportedEnvError(KeyError):
 
 
 _NOT_SERVED = {
-    "AdroitHand": "the Adroit models enable MuJoCo's noslip post-solver, which the engine does not restate",
-    "FrankaKitchen": "mesh-mesh contacts (kettle, cabinets): the convex narrow phase has no mesh support function yet",
+    "AdroitHandDoor": "only the hammer task of the Adroit family is served so far (door: per-world body_pos of the door frame + latch hinge, adroit_door.py:360-368)",
+    "AdroitHandPen": "only the hammer task of the Adroit family is served so far (pen: per-world target body_quat, adroit_pen.py:383)",
+    "AdroitHandRelocate": "only the hammer task of the Adroit family is served so far (relocate: per-world body_pos + site_pos, adroit_relocate.py:355-369)",
+    "FrankaKitchen": "condim-6 finger pads (10 pyramid rows per contact) and a 258-geom scene that needs a spatial broad phase: not built yet",
 }
 
 
@@ -57,13 +59,17 @@ def _maze_ids() -> List[str]:
     return [f"{agent}_{m}{sfx}-{ver}" for agent, ver in (("PointMaze", "v3"), ("AntMaze", "v5")) for m in MAPS for sfx in ("", "Dense")]
 
 
+def _adroit_ids() -> List[str]:
+    return [f"AdroitHandHammer{sfx}-{ver}" for sfx in ("", "Sparse") for ver in ("v1", "v2")]   # __init__.py:1082-1101 (v1: same class, deprecated alias)
+
+
 def registered_env_ids() -> List[str]:
     """Every id ``make_vec`` serves, in the reference's registration order of families."""
-    return _fetch_ids() + _hand_reach_ids() + _hand_manipulate_ids() + _maze_ids()
+    return _fetch_ids() + _hand_reach_ids() + _hand_manipulate_ids() + _maze_ids() + _adroit_ids()
 
 
 def env_family(env_id: str) -> str:
-    """'fetch' | 'hand_reach' | 'hand_manipulate' | 'point_maze' | 'ant_maze' for a served id; raises for the rest."""
+    """'fetch' | 'hand_reach' | 'hand_manipulate' | 'adroit_hammer' | 'point_maze' | 'ant_maze' for a served id; raises for the rest."""
     for prefix, why in _NOT_SERVED.items():
         if env_id.startswith(prefix):
             raise UnsupportedEnvError(f"{env_id}: not served by this build -- {why}")
@@ -75,6 +81,8 @@ def env_family(env_id: str) -> str:
         return "hand_reach"
     if env_id.startswith("HandManipulate"):
         return "hand_manipulate"
+    if env_id.startswith("AdroitHandHammer"):
+        return "adroit_hammer"
     return "point_maze" if env_id.startswith("PointMaze") else "ant_maze"
 
 
@@ -90,6 +98,8 @@ def make_vec(env_id: str, num_envs: int = 1, **kwargs):
         from .envs.hand import HandReachVecEnv as cls
     elif family == "hand_manipulate":
         from .envs.hand import HandBlockVecEnv as cls
+    elif family == "adroit_hammer":
+        from .envs.adroit import AdroitHammerVecEnv as cls
     elif family == "point_maze":
         from .envs.point_maze import PointMazeVecEnv as cls
     else:

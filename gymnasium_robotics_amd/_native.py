@@ -31,6 +31,14 @@ class PointBuffersStruct(ctypes.Structure):
         "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask", "packed")]
 
 
+class AdroitTaskStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("n_substeps", "sparse_reward", "site_grasp", "site_target", "site_goal", "site_tool", "obj_body", "nq_obs", "obs_dim")]
+
+
+class AdroitBuffersStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")]
+
+
 class HandBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost", "packed")]
@@ -58,6 +66,7 @@ def lib():
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
+        L.grx_adroit_step.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_float, ci, vp, vp]
         L.grx_manip_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]
         L.grx_order_by_cost.argtypes = [vp, vp, ctypes.c_float, ci, vp, vp]
@@ -74,5 +83,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
 ]

@@ -84,8 +84,8 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair;
-  float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations;
+  float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv, noslip_tolerance;
   int mpr_iterations;
 };
 
@@ -113,6 +113,8 @@ struct GrxCtx {
   float* red;  // 128 floats
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
+  float* shift;      // models with a shift group: the world's 3-vector (state, loaded with qpos)
+  float* minv;       // models with the noslip post-solver: M^-1 (nv x nv), formed once per substep
   float* meshcache;  // models with hull-vs-convex pairs: 4 x (pair + 1, separating direction, the two support vertices) + the slot to evict next, kept across the substeps of a step (grx_mesh_pairs)
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
   int maxefc, jpool, maxcon;  // capacities of the row tables / the packed Jacobian pool / the contact list of this model
@@ -137,18 +139,18 @@ static __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];   // one copy per tra
 // body velocities/forces, geom frames, contacts) and arrays that only live in the solve/integrate stage (P2: Hessian,
 // Newton vectors, per-row solver scratch) share one overlay region; everything that must survive a whole substep (state,
 // body frames, motion axes, M, J, row parameters) is persistent.
-struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool, ntouch, maxcon, nmesh; };
+struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool, ntouch, maxcon, nmesh, nshift, noslip; };
 GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator, int maxefc = GRX_MAXEFC,
-                          int jpool = GRX_JPOOL, int ntouch = 0, int maxcon = GRX_MAXCON, int nmesh = 0) {
+                          int jpool = GRX_JPOOL, int ntouch = 0, int maxcon = GRX_MAXCON, int nmesh = 0, int nshift = 0, int noslip = 0) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
   pers += jpool + maxefc * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
-  pers += 32 + 8 + (nmesh ? 21 : 0);
+  pers += (njnt > 32 ? 64 : 32) + 8 + (nmesh ? 21 : 0) + (nshift ? 4 : 0) + (noslip ? nv * nv : 0);
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
-  const int ckeep = ntouch ? maxcon * (3 + 3 + 3) : 0;   // touch sensors read the contacts after the solve: keep pos / normal / pair / rows out of the overlay
+  const int ckeep = (ntouch || noslip) ? maxcon * (3 + 3 + 3) : 0;   // touch sensors and the noslip pass read the contacts after the solve: keep pos / normal / pair / rows out of the overlay
   pers += ckeep;
   int p1 = (u1a > u1b ? u1a : u1b) + (u2a > u2b ? u2a : u2b) + 10 * nbody + 6 * nv + 3 * nv + maxcon * (1 + 3 + 3 + 7) - ckeep;
   int p2 = nv * nv + 5 * nv + 4 * maxefc;
@@ -174,10 +176,11 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   c->efc_pos = c->efc_aref;  // residuals live in the aref slot until the per-row pass turns them into aref
   c->efc_floss = p; if (m->nfric) p += m->maxefc;
   CARVEI(efc_kind, m->maxefc) CARVEI(efc_id, m->maxefc) CARVEI(efc_row, m->maxefc)
-  CARVEI(ired, 32) CARVEI(cnt, 8)
+  CARVEI(ired, m->njnt > 32 ? 64 : 32) CARVEI(cnt, 8)
+  CARVE(shift, m->nshift ? 4 : 0) CARVE(minv, m->noslip ? m->nv * m->nv : 0)
   CARVE(meshcache, m->nmesh ? 21 : 0)
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
-  if (m->ntouch) {
+  if (m->ntouch || m->noslip) {
     CARVE(con_pos, 3 * m->maxcon) CARVE(con_frame, 3 * m->maxcon)
     CARVEI(con_pair, m->maxcon) CARVEI(con_efc, m->maxcon) CARVEI(con_nr, m->maxcon)
   }
@@ -198,7 +201,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   CARVE(cinert, 10 * m->nbody) CARVE(cdof_dot, 6 * m->nv)
   CARVE(qfrc_bias, m->nv) CARVE(qfrc_passive, m->nv) CARVE(qfrc_actuator, m->nv)
   CARVE(con_dist, m->maxcon) CARVEI(con_span, m->maxcon) CARVEI(con_ioff, m->maxcon) CARVEI(con_b1, m->maxcon) CARVEI(con_b2, m->maxcon)
-  if (!m->ntouch) {
+  if (!(m->ntouch || m->noslip)) {
     CARVE(con_pos, 3 * m->maxcon) CARVE(con_frame, 3 * m->maxcon)  // con_frame: contact normal only
     CARVEI(con_pair, m->maxcon) CARVEI(con_efc, m->maxcon) CARVEI(con_nr, m->maxcon)
   }
@@ -211,10 +214,10 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
 }
 
 GRX_HD GrxDims grx_dims_of(const GrxModel* m) {
-  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool, m->ntouch, m->maxcon, m->nmeshpair > 0};
+  GrxDims d = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nfric, m->integrator, m->maxefc, m->jpool, m->ntouch, m->maxcon, m->nmeshpair > 0, m->nshift > 0, m->noslip_iterations > 0};
   return d;
 }
-GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool, d.ntouch, d.maxcon, d.nmesh); }
+GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.nmocap, d.nfric, d.integrator, d.maxefc, d.jpool, d.ntouch, d.maxcon, d.nmesh, d.nshift, d.noslip); }
 
 // ------------------------------------------------------------------------------------------
 // small math (all per-lane, registers)
@@ -391,6 +394,9 @@ struct GrxShape {
   static constexpr bool kConvex = (NV_ == 0) || ((CONVEX_ & 1) != 0);   // carries the general convex (MPR) narrow phase for primitive pairs: the generic kernels and the shapes of models that need it
   static constexpr bool kMesh = (NV_ == 0) || ((CONVEX_ & 2) != 0);     // carries the wave-cooperative hull-vs-convex routine (models with mesh-mesh / mesh-primitive pairs)
   static constexpr int NMESH = (CONVEX_ & 2) ? 1 : 0;
+  static constexpr int NSHIFT = (CONVEX_ & 4) ? 1 : 0;   // the model has a per-world shift group (Adroit's nail board)
+  static constexpr int NOSLIP = (CONVEX_ & 8) ? 1 : 0;   // the model runs the noslip post-solver
+  static constexpr bool kShift = (NV_ == 0) || NSHIFT, kNoslip = (NV_ == 0) || NOSLIP;
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NVC (S::kFixed ? S::NV : m->nv)
@@ -442,6 +448,7 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
         continue;
       }
       float p[3] = {m->body_pos[3 * b], m->body_pos[3 * b + 1], m->body_pos[3 * b + 2]};
+      if (S::kShift && m->nshift && m->body_shift[b]) { p[0] += c->shift[0]; p[1] += c->shift[1]; p[2] += c->shift[2]; }   // child of the (world-fixed) shift group
       float q[4] = {m->body_quat[4 * b], m->body_quat[4 * b + 1], m->body_quat[4 * b + 2], m->body_quat[4 * b + 3]};
       for (int k = 0; k < jn; k++) {
         const unsigned j = ja + (unsigned)k; const int qa = m->jnt_qposadr[j];
@@ -523,7 +530,8 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
       int b = m->site_bodyid[i];
       float lpv[3] = {m->site_pos[3 * i], m->site_pos[3 * i + 1], m->site_pos[3 * i + 2]}, lqv[4] = {m->site_quat[4 * i], m->site_quat[4 * i + 1], m->site_quat[4 * i + 2], m->site_quat[4 * i + 3]}, v[3], R[9], Rw[9];
       mulMatVec3f(v, c->xmat + 9 * b, lpv);
-      for (int e = 0; e < 3; e++) c->sxpos[3 * i + e] = c->xpos[3 * b + e] + v[e];
+      const int sh = S::kShift && m->nshift && m->site_shift[i];
+      for (int e = 0; e < 3; e++) c->sxpos[3 * i + e] = c->xpos[3 * b + e] + v[e] + (sh ? c->shift[e] : 0.0f);
       quat2matf(R, lqv); mulMat3f(Rw, c->xmat + 9 * b, R);
       for (int e = 0; e < 9; e++) c->sxmat[9 * i + e] = Rw[e];
     }
@@ -718,10 +726,11 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit 
   if (n == 15) return grx_sym_solve_reg<15>(A, n, x, lane_);
   if (n == 24) return grx_sym_solve_reg<24>(A, n, x, lane_);
   if (n == 30) return grx_sym_solve_reg<30>(A, n, x, lane_);
+  if (n == 33) return grx_sym_solve_reg<33>(A, n, x, lane_);
 #endif
 #if defined(GRX_EMU)
-  if (n == 21 || n == 14 || n == 15 || n == 24 || n == 30) {   // mirror the device: these sizes are solved without touching A
-    static float copy[30 * 30];
+  if (n == 21 || n == 14 || n == 15 || n == 24 || n == 30 || n == 33) {   // mirror the device: these sizes are solved without touching A
+    static float copy[33 * 33];
     for (int i = 0; i < n * n; i++) copy[i] = A[i];
     int bad_ = grx_sym_factor(copy, n, lane_);
     grx_sym_solve(copy, n, x, lane_);
@@ -1748,7 +1757,8 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
       int b = m->geom_bodyid[i];
       float lpv[3] = {m->geom_pos[3 * i], m->geom_pos[3 * i + 1], m->geom_pos[3 * i + 2]}, lqv[4] = {m->geom_quat[4 * i], m->geom_quat[4 * i + 1], m->geom_quat[4 * i + 2], m->geom_quat[4 * i + 3]}, v[3], R[9], Rw[9];
       mulMatVec3f(v, c->xmat + 9 * b, lpv);
-      for (int e = 0; e < 3; e++) c->gxpos[3 * i + e] = c->xpos[3 * b + e] + v[e];
+      const int sh = S::kShift && m->nshift && m->geom_shift[i];
+      for (int e = 0; e < 3; e++) c->gxpos[3 * i + e] = c->xpos[3 * b + e] + v[e] + (sh ? c->shift[e] : 0.0f);
       quat2matf(R, lqv); mulMat3f(Rw, c->xmat + 9 * b, R);
       for (int e = 0; e < 9; e++) c->gxmat[9 * i + e] = Rw[e];
     }
@@ -2488,6 +2498,112 @@ GRX_MEM int grx_hessian_update(const GrxModel* m, GrxCtx* c, int nefc, float* g0
   return 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// K10b noslip post-solver (MuJoCo option noslip_iterations; Adroit: assets/adroit_hand/adroit_assets.xml:3): projected Gauss-Seidel on the
+// dual with the regulariser removed, over the friction-loss rows and the pairs of opposing pyramid edges of the frictional contacts (the
+// oracle's solve_noslip restates the reference algorithm with an explicit A = J M^-1 J').  Here it is matrix-free, at wavefront level: the
+// rows are visited one after the other, every dot product runs across the lanes (lane i = dof i):
+//     t = M^-1 J_r'            (lane i: sum over the row's span of Minv[i][d] J_r[d])
+//     A_rr = J_r . t ,  res_r = J_r . a - aref_r          (a = the acceleration implied by the current forces, kept in c->qacc)
+//     f_r <- projected update ,  a += t * delta
+// M^-1 is formed once per substep (LDL' of M, one right-hand side per lane).  Ends with M a in c->Ma (so that the caller's
+// qfrc_constraint = M a - qfrc_smooth holds for the new forces).
+// ------------------------------------------------------------------------------------------
+GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
+  const int nv = GRX_NVC, maxiter = m->noslip_iterations;
+  const int ne = c->cnt[3], nf = c->cnt[4], ncon = c->cnt[0] < c->maxcon ? c->cnt[0] : c->maxcon;
+  // ---- M^-1: factor a copy of M in the (dead) Hessian buffer, then lane i solves for the i-th unit vector in its own row of c->minv
+  FOR_LANES { for (int i = lane; i < nv * nv; i += 64) { c->A[i] = c->M[i]; c->minv[i] = ((i / nv) == (i % nv)) ? 1.0f : 0.0f; } }
+  WAVE_SYNC();
+  if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+  FOR_LANES {
+    if (lane < nv) {
+      float* x = c->minv + lane * nv; const float* A = c->A;
+      for (int k = nv - 1; k > 0; k--) { const float yk = x[k] * A[k * nv + k]; for (int i = 0; i < k; i++) x[i] -= A[k * nv + i] * yk; }
+      for (int i = 0; i < nv; i++) x[i] *= A[i * nv + i];
+      for (int i = 0; i < nv - 1; i++) { const float xi = x[i]; for (int k = i + 1; k < nv; k++) x[k] -= A[k * nv + i] * A[k * nv + k] * xi; }
+    }
+  }
+  WAVE_SYNC();
+  const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
+  float improvement0 = 0.0f;   // cost change of dropping the regulariser: 0.5 sum f^2 R (enters the first sweep's improvement)
+  {
+    GRX_LANEVAR(ip);
+    FOR_LANES { float sacc = 0.0f; for (int r = lane; r < nefc; r += 64) { const float f = c->efc_force[r]; sacc += 0.5f * f * f / c->efc_D[r]; } LV(ip) = sacc; }
+    improvement0 = grx_reduce_sum(ip);
+  }
+  for (int iter = 0; iter < maxiter; iter++) {
+    float improvement = iter == 0 ? improvement0 : 0.0f;
+    // ---- dry friction: J = e_d, so t is a column of M^-1 and no reduction is needed
+    for (int r = ne; r < ne + nf; r++) {
+      const int d = GRX_ROW_IDOF(c->efc_id[r]);
+      const float Arr = c->minv[d * nv + d], res = c->qacc[d] - c->efc_aref[r], old = c->efc_force[r], fl = c->efc_floss[r];
+      float fn = old - res / fmaxf(GRX_MINVAL, Arr);
+      fn = fn < -fl ? -fl : (fn > fl ? fl : fn);
+      const float dl = fn - old;
+      improvement -= 0.5f * dl * dl * Arr + dl * res;
+      WAVE_SYNC();
+      c->efc_force[r] = fn;
+      FOR_LANES { if (lane < nv) c->qacc[lane] += c->minv[lane * nv + d] * dl; }
+      WAVE_SYNC();
+    }
+    // ---- contact friction: pairs of opposing pyramid edges (their sum, the normal force, is kept)
+    for (int k = 0; k < ncon; k++) {
+      const int r0 = c->con_efc[k], nr = c->con_nr[k];
+      if (r0 < 0 || nr < 2) continue;
+      for (int j = r0; j + 1 < r0 + nr && j + 1 < nefc; j += 2) {
+        GRX_LANEVAR(tA); GRX_LANEVAR(tB); GRX_LANEVAR(p00); GRX_LANEVAR(p01); GRX_LANEVAR(p11); GRX_LANEVAR(pr0); GRX_LANEVAR(pr1);
+        const int infoA = c->efc_row[j], idA = c->efc_id[j], infoB = c->efc_row[j + 1], idB = c->efc_id[j + 1];
+        FOR_LANES {
+          float ta = 0.0f, tb = 0.0f, ja = 0.0f, jb = 0.0f, al = 0.0f;
+          if (lane < nv) {
+            const float* mi = c->minv + lane * nv;
+            const int offA = GRX_ROW_OFF(infoA), loA = GRX_ROW_LO(infoA), lenA = GRX_ROW_LEN(infoA), offB = GRX_ROW_OFF(infoB), loB = GRX_ROW_LO(infoB), lenB = GRX_ROW_LEN(infoB);
+            for (int e = 0; e < lenA; e++) ta += c->Jp[offA + e] * mi[loA + e];
+            for (int e = 0; e < lenB; e++) tb += c->Jp[offB + e] * mi[loB + e];
+            if (S::kTwoSpan) {
+              const int lo2A = GRX_ROWB_LO(idA), len2A = GRX_ROWB_LEN(idA), lo2B = GRX_ROWB_LO(idB), len2B = GRX_ROWB_LEN(idB);
+              for (int e = 0; e < len2A; e++) ta += c->Jp[offA + lenA + e] * mi[lo2A + e];
+              for (int e = 0; e < len2B; e++) tb += c->Jp[offB + lenB + e] * mi[lo2B + e];
+            }
+            const int pa = grx_row_pos(infoA, idA, lane), pb = grx_row_pos(infoB, idB, lane);
+            ja = pa >= 0 ? c->Jp[offA + pa] : 0.0f; jb = pb >= 0 ? c->Jp[offB + pb] : 0.0f;
+            al = c->qacc[lane];
+          }
+          LV(tA) = ta; LV(tB) = tb; LV(p00) = ja * ta; LV(p01) = ja * tb; LV(p11) = jb * tb; LV(pr0) = ja * al; LV(pr1) = jb * al;
+        }
+        const float A00 = grx_reduce_sum(p00), A01 = grx_reduce_sum(p01), A11 = grx_reduce_sum(p11);
+        const float res0 = grx_reduce_sum(pr0) - c->efc_aref[j], res1 = grx_reduce_sum(pr1) - c->efc_aref[j + 1];
+        const float o0 = c->efc_force[j], o1 = c->efc_force[j + 1];
+        const float bc0 = res0 - (A00 * o0 + A01 * o1), bc1 = res1 - (A01 * o0 + A11 * o1);
+        const float mid = 0.5f * (o0 + o1), K1 = A00 + A11 - 2.0f * A01, K0 = mid * (A00 - A11) + bc0 - bc1;
+        float f0, f1;
+        if (K1 < GRX_MINVAL) { f0 = f1 = mid; }
+        else {
+          const float y = -K0 / K1;
+          if (y < -mid) { f0 = 0.0f; f1 = 2.0f * mid; } else if (y > mid) { f0 = 2.0f * mid; f1 = 0.0f; } else { f0 = mid + y; f1 = mid - y; }
+        }
+        const float d0 = f0 - o0, d1 = f1 - o1;
+        improvement -= 0.5f * (d0 * (A00 * d0 + A01 * d1) + d1 * (A01 * d0 + A11 * d1)) + d0 * res0 + d1 * res1;
+        WAVE_SYNC();
+        c->efc_force[j] = f0; c->efc_force[j + 1] = f1;
+        FOR_LANES { if (lane < nv) c->qacc[lane] += LV(tA) * d0 + LV(tB) * d1; }
+        WAVE_SYNC();
+      }
+    }
+    if (improvement * scale < m->noslip_tolerance) break;
+  }
+  // M a for the caller (qfrc_constraint = M a - qfrc_smooth)
+  FOR_LANES {
+    for (int i = lane; i < nv; i += 64) {
+      float sacc = 0.0f;
+      for (int j = 0; j < nv; j++) sacc += c->M[i * nv + j] * c->qacc[j];
+      c->Ma[i] = sacc;
+    }
+  }
+  WAVE_SYNC();
+}
+
 // Constraint solve (Newton) + optional semi-implicit Euler step as ONE state machine, so that the three heavy
 // primitives -- row evaluation, Hessian assembly and the register-resident linear solve -- each have a single call site
 // in the kernel: the fused 20-substep loop has to stay inside the instruction cache.
@@ -2502,7 +2618,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const int implicit_damp = (m->anydamp && m->eulerdamp);
   int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0, g0_ready = 0;
   // the linear solve leaves c->A intact where it runs from registers (grx_sym_solve_full): the Hessian can then be corrected in place
-  const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 30);
+  const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 30 || nv == 33);
   // Newton starts from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart,
   // M^-1 qfrc_smooth); the minimiser of the strictly convex problem does not depend on the start, and skipping the
   // comparison saves one factorisation of M per substep.
@@ -2514,13 +2630,15 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
     if (phase == 0) {
       // After a step, M a and J a - aref are current (carried) and convergence has already been decided: the only thing the evaluation would
       // still produce are the row forces, which nothing reads after the solve unless the model has touch sensors.
-      const int skip_eval = done && it > 0 && (S::kFixed ? S::NT : m->ntouch) == 0;
+      const int noslip = S::kNoslip && m->noslip_iterations > 0;
+      const int skip_eval = done && it > 0 && (S::kFixed ? S::NT : m->ntouch) == 0 && !noslip;
       const int changed = skip_eval ? 0 : grx_newton_eval(m, c, c->qacc, nefc, it > 0, lane_);
       GRX_TICK(c, GRX_P_NEVAL);
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
       if (it > 0 && full_step && !changed) done = 1;
       if (done || it >= GRX_NEWTON_MAXIT) {
+        if (noslip) grx_noslip(m, c, nefc, lane_);   // re-solves the friction forces without regularisation: new qacc, new M a
         // converged: at the minimiser the gradient M a - qfrc_smooth - J'f vanishes, so the joint-space constraint force
         // J'f of the final evaluation is M a - qfrc_smooth (to the solver's residual) -- no further pass over the rows
         FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qfrc_constraint[i] = c->Ma[i] - c->qfrc_smooth[i]; c->qacc_ws[i] = c->qacc[i]; } }
@@ -2797,7 +2915,7 @@ GRX_MEM void grx_rk4_after_forward(const GrxModel* m, GrxCtx* c, int stage, int 
 // K12 touch sensors (MuJoCo mjSENS_TOUCH): out[t] = sum of the normal forces of the active contacts that involve the zone's body
 // and whose ray (from the contact point along the contact normal, flipped when the zone's body is the contact's second body)
 // meets the zone (sphere or box site).  Runs after the constraint solve of the same forward pass (row forces in efc_force).
-// mode 1: raw value, 2: value > 0, 3: log(value + 1)  (manipulate_touch_sensors.py:124-131)
+// mode 1: raw value, 2: value > 0, 3: log(value + 1)  (manipulate_touch_sensors.py:124-131), 4: clip(value, -1, 1) (adroit_hammer.py:344-346)
 // ------------------------------------------------------------------------------------------
 GRX_MEM float grx_ray_sphere(const float* p, const float* d, float r) {
   const float a = dot3f(d, d), b = dot3f(d, p), cc = dot3f(p, p) - r * r, det = b * b - a * cc;
@@ -2815,6 +2933,27 @@ GRX_MEM float grx_ray_box(const float* p, const float* d, const float* sz) {
     for (int side = -1; side <= 1; side += 2) {
       const float t = ((float)side * sz[i] - p[i]) / d[i];
       if (t >= 0 && fabsf(p[j] + t * d[j]) <= sz[j] && fabsf(p[k] + t * d[k]) <= sz[k] && (best < 0 || t < best)) best = t;
+    }
+  }
+  return best;
+}
+// cylinder zone (radius r, half height h along z): nearest non-negative hit of the side or a cap (the oracle's ray_cylinder)
+GRX_MEM float grx_ray_cylinder(const float* p, const float* d, float r, float h) {
+  float best = -1.0f;
+  const float a = d[0] * d[0] + d[1] * d[1], b = d[0] * p[0] + d[1] * p[1], cc = p[0] * p[0] + p[1] * p[1] - r * r;
+  if (a > GRX_MINVAL) {
+    const float det = b * b - a * cc;
+    if (det >= 0.0f) {
+      const float sq = sqrtf(det), t0 = (-b - sq) / a, t1 = (-b + sq) / a;
+      if (t0 >= 0.0f && fabsf(p[2] + t0 * d[2]) <= h) best = t0;
+      if (t1 >= 0.0f && fabsf(p[2] + t1 * d[2]) <= h && (best < 0.0f || t1 < best)) best = t1;
+    }
+  }
+  if (fabsf(d[2]) > GRX_MINVAL) {
+#pragma unroll
+    for (int side = -1; side <= 1; side += 2) {
+      const float t = ((float)side * h - p[2]) / d[2], x = p[0] + t * d[0], y = p[1] + t * d[1];
+      if (t >= 0.0f && x * x + y * y <= r * r && (best < 0.0f || t < best)) best = t;
     }
   }
   return best;
@@ -2845,10 +2984,10 @@ GRX_MEM void grx_touch_sensors(const GrxModel* m, const GrxCtx* c, float* out, i
         const float pw[3] = {c->con_pos[3 * k] - zp[0], c->con_pos[3 * k + 1] - zp[1], c->con_pos[3 * k + 2] - zp[2]};
         float pl[3], dl[3];
         mulMatTVec3f(pl, zR, pw); mulMatTVec3f(dl, zR, dw);
-        const float hit = (type == 2) ? grx_ray_sphere(pl, dl, sz[0]) : grx_ray_box(pl, dl, sz);
+        const float hit = (type == 2) ? grx_ray_sphere(pl, dl, sz[0]) : (type == 5 ? grx_ray_cylinder(pl, dl, sz[0], sz[1]) : grx_ray_box(pl, dl, sz));
         if (hit >= 0.0f) val += fn;
       }
-      out[t] = (mode == 2) ? (val > 0.0f ? 1.0f : 0.0f) : (mode == 3 ? logf(val + 1.0f) : val);
+      out[t] = (mode == 2) ? (val > 0.0f ? 1.0f : 0.0f) : (mode == 3 ? logf(val + 1.0f) : (mode == 4 ? fminf(1.0f, fmaxf(-1.0f, val)) : val));
     }
   }
   WAVE_SYNC();

@@ -56,6 +56,11 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   }
   m.nmeshpair = 0;   // hull against a primitive or another hull: the wave-cooperative routine (grx_mesh_pairs) and its 8-word direction cache
   for (int k = 0; k < v.n_devpair_geoms; k++) { const unsigned rec = (unsigned)v.devpair_geoms[k]; if ((rec >> 28) == 7 && ((rec >> 24) & 0xF) != 0) m.nmeshpair++; }
+  m.nshift = 0;
+  for (int k = 0; k < v.n_body_shift; k++) m.nshift += v.body_shift[k] != 0;
+  for (int k = 0; k < v.n_geom_shift; k++) m.nshift += v.geom_shift[k] != 0;
+  for (int k = 0; k < v.n_site_shift; k++) m.nshift += v.site_shift[k] != 0;
+  m.noslip_iterations = d[GRX_NOSLIP_ITERATIONS]; m.noslip_tolerance = (float)v.opt[GRX_NOSLIP_TOLERANCE];
   m.nfric = 0; m.nweld = 0; m.wpool = 0;
   for (int k = 0; k < v.n_weld_row; k++) m.wpool += 6 * ((v.weld_row[k] >> 20) & 0xFF);
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;

@@ -5,13 +5,14 @@
 // and write HBM exactly once.  Worlds are independent: no inter-workgroup communication.
 //
 // Build: this ONE source is compiled either as a single translation unit (no GRX_TU_* macro: the profiling variant) or, for the product
-// library, four times in parallel with -DGRX_TU_FETCH / -DGRX_TU_HAND / -DGRX_TU_POINT / -DGRX_TU_API (one family of kernel
+// library, four times in parallel with -DGRX_TU_FETCH / -DGRX_TU_HAND / -DGRX_TU_POINT / -DGRX_TU_ADROIT / -DGRX_TU_API (one family of kernel
 // instantiations each; __graft_entry__.build links the objects).  Every unit has its own copy of the constant-memory model descriptors
 // (g_grx_models is static): grx_model_create uploads a descriptor to each of them through grx_tu_*_prepare.
-#if !defined(GRX_TU_FETCH) && !defined(GRX_TU_HAND) && !defined(GRX_TU_POINT) && !defined(GRX_TU_API)
+#if !defined(GRX_TU_FETCH) && !defined(GRX_TU_HAND) && !defined(GRX_TU_POINT) && !defined(GRX_TU_ADROIT) && !defined(GRX_TU_API)
 #define GRX_TU_FETCH 1
 #define GRX_TU_HAND 1
 #define GRX_TU_POINT 1
+#define GRX_TU_ADROIT 1
 #define GRX_TU_API 1
 #endif
 #include <hip/hip_runtime.h>
@@ -25,6 +26,7 @@
 #include "grx_fetch_task.h"
 #include "grx_point_task.h"
 #include "grx_hand_task.h"
+#include "grx_adroit_task.h"
 #include "grx_host_model.h"
 
 static_assert(sizeof(grx_fetch_task) == sizeof(GrxFetchTask), "grx_fetch_task must mirror GrxFetchTask");
@@ -33,6 +35,8 @@ static_assert(sizeof(grx_point_task) == sizeof(GrxPointTask), "grx_point_task mu
 static_assert(sizeof(grx_point_buffers) == sizeof(GrxPointBuffers), "grx_point_buffers must mirror GrxPointBuffers");
 static_assert(sizeof(grx_hand_task) == sizeof(GrxHandTask), "grx_hand_task must mirror GrxHandTask");
 static_assert(sizeof(grx_hand_buffers) == sizeof(GrxHandBuffers), "grx_hand_buffers must mirror GrxHandBuffers");
+static_assert(sizeof(grx_adroit_task) == sizeof(GrxAdroitTask), "grx_adroit_task must mirror GrxAdroitTask");
+static_assert(sizeof(grx_adroit_buffers) == sizeof(GrxAdroitBuffers), "grx_adroit_buffers must mirror GrxAdroitBuffers");
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -105,12 +109,12 @@ static __device__ __forceinline__ int grx_world_of_block_late() {
 // into immediate offsets of the ds_read/ds_write instructions (no address arithmetic, no pointer SGPRs) and the loops over
 // dofs / bodies / joints unroll.  GrxShapeAny is the generic kernel (dims read from the model at run time).
 template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(const GrxModel& m) {
-  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP, S::NT, S::MC, S::NMESH};
+  if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP, S::NT, S::MC, S::NMESH, S::NSHIFT, S::NOSLIP};
   return grx_dims_of(&m);
 }
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (S::kMesh == (g.nmeshpair != 0)) && (S::NF != 24 || g.handtree);
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (S::kMesh == (g.nmeshpair != 0)) && (S::kShift == (g.nshift != 0)) && (S::kNoslip == (g.noslip_iterations > 0)) && (S::NF != 24 || g.handtree);
 }
 // last template argument: bit 0 = general convex routine for primitive pairs (ellipsoid / cylinder), bit 1 = hull-vs-convex pairs (every model with
 // collidable mesh geoms next to boxes / other meshes: all Fetch and Shadow-hand models)
@@ -359,6 +363,47 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
 #endif
 }
 
+// AdroitHandHammer env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world, same engine + the noslip pass
+// nv = 33, every dof carries a friction-loss row (class main: 0.001; the nail: 2.5), general-affine actuators, cylinder / capsule pairs through the convex routine
+typedef GrxShape<33, 33, 26, 29, 33, 30, 4, 1, 33, 0, 144, 2032, 1, 32, 1, 13> GrxShapeAdroitHammer;   // CONVEX bits: 1 (cylinders) | 4 (board shift group) | 8 (noslip)
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words, int forward_only) {
+  extern __shared__ float lds[];
+  const int w = grx_world_of_block(), lane_ = threadIdx.x;
+  if (w >= n_worlds) return;
+  if (b.mask && !b.mask[w]) return;
+  const GrxModel& m = g_grx_models[mslot];
+  GrxCtx c;
+  c.mslot = mslot;
+  grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
+#ifdef GRX_PROFILE
+  __shared__ long long prof_s[GRX_NPROF + 1];
+  c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
+  if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
+#endif
+  const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv, nu = S::kFixed ? S::NU : m.nu;
+  for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
+  __syncthreads();
+  for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
+  for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
+  for (int i = lane_; i < 7 * m.nmocap; i += 64) { const int q = i / 7, e = i - 7 * q; if (e < 3) c.mocap_pos[3 * q + e] = m.mocap_pos0[3 * q + e]; else c.mocap_quat[4 * q + e - 3] = m.mocap_quat0[4 * q + e - 3]; }
+  if (m.nshift && lane_ < 3) c.shift[lane_] = b.shift[(size_t)w * 3 + lane_];
+  __syncthreads();
+  if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
+  else GrxAdroit<S>::grx_adroit_sim_world(&m, &t, &c, b.action + (size_t)w * nu, b.act_mean, b.act_rng, lane_);
+  const int wl = grx_world_of_block_late();
+  GrxAdroit<S>::grx_adroit_outputs(&m, &t, &c, b.obs + (size_t)wl * t.obs_dim, b.reward + wl, b.success + wl, lane_);
+  __syncthreads();
+  for (int i = lane_; i < nq; i += 64) b.qpos[(size_t)wl * nq + i] = c.qpos[i];
+  for (int i = lane_; i < nv; i += 64) { b.qvel[(size_t)wl * nv + i] = c.qvel[i]; b.qacc_ws[(size_t)wl * nv + i] = c.qacc_ws[i]; }
+  if (lane_ == 0) b.status[wl] = grx_status_word(b.status[wl], c.cnt[2]);
+#ifdef GRX_PROFILE
+  GRX_TICK(&c, GRX_P_OTHER);
+  if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // per-family translation units: shape selection, LDS limits, descriptor upload, launches
 // ------------------------------------------------------------------------------------------
@@ -451,9 +496,26 @@ extern "C" int grx_tu_hand_launch(int shape, unsigned grid, size_t lds_bytes, vo
   return (int)hipGetLastError();
 }
 #endif
+#if GRX_TU_ADROIT
+extern "C" int grx_tu_adroit_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
+  GRX_LDS(grx_adroit_step_kernel<GrxShapeAny>);
+  if (grx_shape_matches<GrxShapeAdroitHammer>(*g)) { *shape = 20; GRX_LDS(grx_adroit_step_kernel<GrxShapeAdroitHammer>); }
+  return (int)grx_upload_descriptor(g, slot);
+}
+extern "C" int grx_tu_adroit_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxAdroitTask* t, const GrxAdroitBuffers* b, int n, int words,
+                                    int forward_only) {
+  const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+  if (shape == 20) hipLaunchKernelGGL(grx_adroit_step_kernel<GrxShapeAdroitHammer>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
+  else hipLaunchKernelGGL(grx_adroit_step_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
+  return (int)hipGetLastError();
+}
+#endif
 #undef GRX_LDS
 
 #if GRX_TU_API
+extern "C" int grx_tu_adroit_prepare(const GrxModel* g, int bytes, int slot, int* shape);
+extern "C" int grx_tu_adroit_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxAdroitTask* t, const GrxAdroitBuffers* b, int n, int words,
+                                    int forward_only);
 extern "C" int grx_tu_fetch_prepare(const GrxModel* g, int bytes, int slot, int* shape);
 extern "C" int grx_tu_point_prepare(const GrxModel* g, int bytes, int slot, int* shape);
 extern "C" int grx_tu_hand_prepare(const GrxModel* g, int bytes, int slot, int* shape);
@@ -573,7 +635,7 @@ static int grx_model_create_impl(const int32_t* H, const int32_t* I, const doubl
   m->words = grx_ctx_words(grx_dims_of(&g));
   int bytes = m->words * 4;
   if (bytes > 160 * 1024) return fail("model working set exceeds the 160 KiB LDS of a CU");
-  if (g.njnt > 32) return fail("engine limit: at most 32 joints per world (limit-flag table in LDS)");
+  if (g.njnt > 64) return fail("engine limit: at most 64 joints per world (one lane per joint)");
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
   if (g.nbody > 64) return fail("engine limit: at most 64 bodies per world (one lane per body, 64-bit subtree masks)");
   if (g.nweld > g.maxefc / 16) return fail("engine limit: too many weld constraints (weld frames are staged in the row-parameter slot)");
@@ -585,6 +647,7 @@ static int grx_model_create_impl(const int32_t* H, const int32_t* I, const doubl
   if ((e = grx_tu_fetch_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (fetch kernels): ") + hipGetErrorString((hipError_t)e));
   if ((e = grx_tu_point_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (point kernels): ") + hipGetErrorString((hipError_t)e));
   if ((e = grx_tu_hand_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (hand kernels): ") + hipGetErrorString((hipError_t)e));
+  if ((e = grx_tu_adroit_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (adroit kernels): ") + hipGetErrorString((hipError_t)e));
   HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_grx_models), &m->dev, sizeof(GrxModel), sizeof(GrxModel) * (size_t)m->slot, hipMemcpyHostToDevice));
   return 0;
 }
@@ -710,6 +773,23 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
   const int e = grx_tu_hand_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_hand_step launch: ") + hipGetErrorString((hipError_t)e));
+  return 0;
+}
+
+extern "C" int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, const grx_adroit_buffers* buf, int n_worlds, int forward_only, void* stream) {
+  if (!m || !task || !buf) return fail("grx_adroit_step: null argument");
+  if (!buf->qpos || !buf->qvel || !buf->qacc_ws || !buf->obs || !buf->reward || !buf->success || !buf->status) return fail("grx_adroit_step: null buffer");
+  if (!forward_only && (!buf->action || !buf->act_mean || !buf->act_rng)) return fail("grx_adroit_step: null action buffers");
+  if (m->dev.nshift && !buf->shift) return fail("grx_adroit_step: the model has a shift group but no shift buffer was given");
+  if (n_worlds <= 0) return 0;
+  GrxAdroitTask t; memcpy(&t, task, sizeof(t));
+  GrxAdroitBuffers b; memcpy(&b, buf, sizeof(b));
+  const GrxModel& g = m->dev;
+  if (t.site_grasp < 0 || t.site_grasp >= g.nsite || t.site_target < 0 || t.site_target >= g.nsite || t.site_goal < 0 || t.site_goal >= g.nsite || t.site_tool < 0 ||
+      t.site_tool >= g.nsite || t.obj_body <= 0 || t.obj_body >= g.nbody || t.nq_obs != g.nq - 6 || g.nv < 6 || g.ntouch != 1 || t.obs_dim != t.nq_obs + 19)
+    return fail("grx_adroit_step: task ids / dimensions do not fit the model");
+  const int e = grx_tu_adroit_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  if (e) return fail(std::string("grx_adroit_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
 

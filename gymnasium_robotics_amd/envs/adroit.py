@@ -1,0 +1,198 @@
+"""Batched AdroitHandHammer environments on the MI355X engine (host side, Python).
+
+Vectorised drop-in for AdroitHandHammerEnv (/root/reference/gymnasium_robotics/envs/adroit_hand/adroit_hammer.py, ids AdroitHandHammer-v2 /
+AdroitHandHammerSparse-v2 and their -v1 aliases, gymnasium_robotics/__init__.py:1082-1101).  Unlike the goal-conditioned families this is a
+plain Env: observation = a 46-vector per world (not a dict), reward float, terminated always False, info["success"].
+Per-step work = ONE launch of grx_adroit_step_kernel (action scaling, 5 physics substeps incl. the noslip post-solver, observation, reward,
+success).  Host side of a reset: one PCG64 draw per world for the board height (reset_model, :372-378), written to the per-world `shift` state.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..core import GoalVecEnv, np_random
+from ..mjcf import CompiledModel
+from ..spaces import Box, batch_space
+from .adroit_spec import MAX_EPISODE_STEPS, OBS_DIM, action_scaling, load_adroit_hammer_model, make_adroit_task, parse_adroit_id
+
+
+class AdroitHammerVecEnv(GoalVecEnv):
+    """autoreset_mode: "next_step" (Gymnasium >= 1.0 default), "same_step" or "disabled"; output: "numpy" (float64 arrays like the reference)
+    or "torch" (the fp32 device tensors the kernel wrote)."""
+
+    def __init__(self, env_id: str = "AdroitHandHammer-v2", num_envs: int = 1, device: Optional[str] = None, reward_type: Optional[str] = None,
+                 max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step", output: str = "numpy",
+                 assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
+        _, rt = parse_adroit_id(env_id)
+        self.env_id, self.reward_type = env_id, reward_type or rt
+        if self.reward_type not in ("dense", "sparse"):
+            raise ValueError(f"Unknown reward type, expected `dense` or `sparse` but got {self.reward_type}")   # adroit_hammer.py:226-229
+        if autoreset_mode not in ("next_step", "same_step", "disabled"):
+            raise ValueError(f"unknown autoreset_mode {autoreset_mode}")
+        self.num_envs, self.max_episode_steps, self.autoreset_mode, self.output, self.seed_offset = int(num_envs), max_episode_steps, autoreset_mode, output, int(seed_offset)
+        if not torch.cuda.is_available():
+            raise RuntimeError("AdroitHammerVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
+        self.device = torch.device(device or "cuda:0")
+        self.model = model or load_adroit_hammer_model(assets_root)
+        self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
+        self.obs_dim = OBS_DIM
+        self._L = _native.lib()
+        H, I, F = self.model.pack()
+        self._h = ctypes.c_void_p()
+        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0, ctypes.byref(self._h)))
+        self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
+        self.task = make_adroit_task(self.model, self.reward_type)
+        n, d = self.num_envs, self.device
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
+        self.qpos, self.qvel, self.qacc_ws, self.shift = z(n, self.nq), z(n, self.nv), z(n, self.nv), z(n, 3)
+        self.action, self.obs, self.reward = z(n, self.nu), z(n, self.obs_dim), z(n)
+        self.success, self.status, self.mask = z(n, dtype=torch.uint8), z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
+        am, ar = action_scaling(self.model)
+        self._act_mean, self._act_rng = torch.from_numpy(am.astype(np.float32)).to(d), torch.from_numpy(ar.astype(np.float32)).to(d)
+        self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)                      # adroit_hammer.py:231-233
+        self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float64)      # :205-207
+        self.action_space = batch_space(self.single_action_space, n)
+        self.observation_space = batch_space(self.single_observation_space, n)
+        self._init_qpos = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32)).to(d)   # MujocoEnv.init_qpos [3P]: data.qpos after mj_resetData
+        self._board_z0 = float(self.model.info["shift_pos0"][2])
+        self.board_z = np.full(n, self._board_z0)
+        self.np_randoms = [np_random(None)[0] for _ in range(n)]
+        self._elapsed = np.zeros(n, np.int64)
+        self._needs_reset = np.zeros(n, bool)
+        self._has_reset = False
+        self.kernel_events = None
+
+    def _make_bufs(self, mask):
+        b = _native.AdroitBuffersStruct()
+        for name in ("qpos", "qvel", "qacc_ws", "shift", "action", "obs", "reward", "success", "status"):
+            setattr(b, name, getattr(self, name).data_ptr())
+        b.act_mean, b.act_rng = self._act_mean.data_ptr(), self._act_rng.data_ptr()
+        b.mask = None if mask is None else mask.data_ptr()
+        return b
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _launch(self, bufs, forward_only):
+        timed = self.kernel_events is not None and not forward_only
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _native.check(self._L.grx_adroit_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, int(forward_only), self._stream()))
+        if timed:
+            e1.record()
+            self.kernel_events.append((e0, e1))
+
+    # ------------------------------------------------------------------ reset (MujocoEnv.reset [3P] -> reset_model, adroit_hammer.py:372-378)
+    def _reset_worlds(self, idx):
+        if len(idx) == 0:
+            return None
+        z = np.array([self.np_randoms[w].uniform(low=0.1, high=0.25) for w in idx])
+        self.board_z[idx] = z
+        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        sh = torch.zeros(len(idx), 3, device=self.device)
+        sh[:, 2] = torch.from_numpy((z - self._board_z0).astype(np.float32)).to(self.device)
+        self.shift[ti] = sh
+        self.qpos[ti] = self._init_qpos
+        self.qvel[ti] = 0.0
+        self.qacc_ws[ti] = 0.0
+        self.mask.zero_()
+        self.mask[ti] = 1
+        self._launch(self._bufs_masked, True)
+        self._elapsed[idx] = 0
+        self._needs_reset[idx] = False
+        return ti
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
+            self.np_randoms = [np_random(s)[0] for s in seeds]
+        with torch.cuda.device(self.device):
+            self._reset_worlds(np.arange(self.num_envs))
+            if options is not None and "initial_state_dict" in options:
+                self.set_env_state(options["initial_state_dict"])
+        self._has_reset = True
+        return self._obs(), {}
+
+    # ------------------------------------------------------------------ step (adroit_hammer.py:291-329)
+    def step(self, actions):
+        if not self._has_reset:
+            raise RuntimeError("Cannot call env.step() before calling env.reset()")
+        a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions, dtype=np.float32))
+        if tuple(a.shape) != (self.num_envs, self.nu):
+            raise ValueError(f"Action dimension mismatch. Expected {(self.num_envs, self.nu)}, found {tuple(a.shape)}")
+        self.action.copy_(a.to(torch.float32), non_blocking=True)
+        info = {}
+        with torch.cuda.device(self.device):
+            pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
+            if len(pending):
+                self.mask.fill_(1)
+                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                self._launch(self._bufs_masked, False)
+            else:
+                self._launch(self._bufs, False)
+            stepped = ~self._needs_reset
+            self._elapsed[stepped] += 1
+            truncated = np.zeros(self.num_envs, bool)
+            if self.max_episode_steps is not None:
+                truncated = stepped & (self._elapsed >= self.max_episode_steps)
+            terminated = np.zeros(self.num_envs, bool)
+            if len(pending):
+                tp = self._reset_worlds(pending)
+                self.reward[tp] = 0.0
+            if self.autoreset_mode == "same_step" and truncated.any():
+                done = np.nonzero(truncated)[0]
+                td = torch.from_numpy(done).to(self.device)
+                info["final_obs"] = self.obs[td].clone() if self.output == "torch" else self.obs[td].double().cpu().numpy()
+                keep_r, keep_s, keep_st = self.reward.clone(), self.success.clone(), self.status.clone()
+                self._reset_worlds(done)
+                self.reward.copy_(keep_r)
+                self.success.copy_(keep_s)
+                self.status.copy_((keep_st & 0xFFFF) | (self.status & -65536))
+            elif self.autoreset_mode == "next_step":
+                self._needs_reset |= truncated
+        if self.output == "torch":
+            info["success"] = self.success.bool()
+            return self.obs, self.reward, torch.from_numpy(terminated), torch.from_numpy(truncated), self._status_info(info)
+        info["success"] = self.success.cpu().numpy().astype(bool)
+        return self._obs(), self.reward.double().cpu().numpy(), terminated, truncated, self._status_info(info)
+
+    def _obs(self):
+        return self.obs if self.output == "torch" else self.obs.double().cpu().numpy()
+
+    # ------------------------------------------------------------------ get_env_state / set_env_state (adroit_hammer.py:380-402), batched
+    def get_env_state(self):
+        target = self.obs[:, 42:45].double().cpu().numpy()
+        board = np.tile(np.asarray(self.model.info["shift_pos0"], dtype=np.float64), (self.num_envs, 1))
+        board[:, 2] = self.board_z
+        return dict(qpos=self.qpos.double().cpu().numpy(), qvel=self.qvel.double().cpu().numpy(), board_pos=board, target_pos=target)
+
+    def set_env_state(self, state_dict):
+        for key, width in (("qpos", self.nq), ("qvel", self.nv), ("board_pos", 3)):
+            if key not in state_dict or np.asarray(state_dict[key]).shape != (self.num_envs, width):
+                raise AssertionError(f"The state dictionary must hold `{key}` of shape {(self.num_envs, width)}")
+        board = np.asarray(state_dict["board_pos"], dtype=np.float64)
+        if not np.allclose(board[:, :2], np.asarray(self.model.info["shift_pos0"])[:2]):
+            raise NotImplementedError("only the height of the nail board is per-world state (the reference's reset_model never moves it sideways)")
+        self.board_z[:] = board[:, 2]
+        with torch.cuda.device(self.device):
+            self.shift[:, 2] = torch.from_numpy((board[:, 2] - self._board_z0).astype(np.float32)).to(self.device)
+            self.qpos.copy_(torch.from_numpy(np.asarray(state_dict["qpos"], dtype=np.float32)).to(self.device))
+            self.qvel.copy_(torch.from_numpy(np.asarray(state_dict["qvel"], dtype=np.float32)).to(self.device))
+            self.qacc_ws.zero_()
+            self._launch(self._bufs, True)   # set_state -> mj_forward
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.grx_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -100,3 +100,11 @@ def quat2euler(quat):
     if cy > np.finfo(np.float64).eps * 4.0:
         return np.array([-np.arctan2(R[1, 2], R[2, 2]), -np.arctan2(-R[0, 2], cy), -np.arctan2(R[0, 1], R[0, 0])])
     return np.array([0.0, -np.arctan2(-R[0, 2], cy), -np.arctan2(-R[1, 0], R[1, 1])])
+
+
+def make_adroit_task(model, reward_type: str):
+    from .. import _native
+
+    n = model.names
+    return _native.AdroitTaskStruct(FRAME_SKIP, int(reward_type == "sparse"), int(n["site"]["S_grasp"]), int(n["site"]["S_target"]), int(n["site"]["nail_goal"]),
+                                    int(n["site"]["tool"]), int(n["body"]["Object"]), int(model.dim("nq")) - 6, OBS_DIM)

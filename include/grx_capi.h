@@ -121,6 +121,26 @@ typedef struct grx_hand_buffers {
   float* packed;                /* [N, obs_dim+2*goal_dim+2] or NULL: [obs | achieved | desired | reward | success] */
 } grx_hand_buffers;
 
+/* mirrors struct GrxAdroitTask / GrxAdroitBuffers (csrc/grx_adroit_task.h): AdroitHandHammer */
+typedef struct grx_adroit_task {
+  int n_substeps, sparse_reward;
+  int site_grasp, site_target, site_goal, site_tool; /* S_grasp, S_target, nail_goal, tool (adroit_hammer.py:264-268) */
+  int obj_body;                                      /* "Object" */
+  int nq_obs;                                        /* nq - 6 leading qpos entries in the observation */
+  int obs_dim;                                       /* 46 */
+} grx_adroit_task;
+typedef struct grx_adroit_buffers {
+  float *qpos, *qvel, *qacc_ws;    /* [N,nq] [N,nv] [N,nv] */
+  const float* shift;              /* [N,3] per-world offset of the board group = model.body_pos[nail_board] - XML value (adroit_hammer.py:374-376) */
+  const float* action;             /* [N,nu] (may be NULL when forward_only) */
+  const float *act_mean, *act_rng; /* [nu] (adroit_hammer.py:269-272) */
+  float* obs;                      /* [N,obs_dim] */
+  float* reward;                   /* [N] */
+  unsigned char* success;          /* [N] */
+  int* status;                     /* [N] */
+  const unsigned char* mask;       /* [N] or NULL */
+} grx_adroit_buffers;
+
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);
 int grx_model_destroy(grx_model* m);
 int grx_model_set_table(grx_model* m, const char* name, const double* data, int n);
@@ -159,6 +179,10 @@ int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t
  * envs/shadow_dexterous_hand/hand_env.py:36-58, reach.py:92-134,398-428).  forward_only != 0: mj_forward + outputs (reset path,
  * robot_env.py:300-313, and _env_setup, reach.py:408-416).  grx_goal_compute_reward: batched compute_reward for dim-vector goals. */
 int grx_hand_step(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int forward_only, void* stream);
+/* AdroitHandHammerEnv.step for N worlds: clip + a = act_mean + a * act_rng + do_simulation(a, 5) (= mj_step x 5 with the noslip post-solver,
+ * adroit_assets.xml:3) + _get_obs + reward + success (envs/adroit_hand/adroit_hammer.py:291-357); forward_only != 0: the reset path
+ * (set_state -> mj_forward, _get_obs: :372-378) */
+int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, const grx_adroit_buffers* buf, int n_worlds, int forward_only, void* stream);
 int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
                             float* reward_out, void* stream);
 /* batched MujocoManipulateEnv.compute_reward on 7-vector pose goals (shadow_dexterous_hand/manipulate.py:87-142) */
