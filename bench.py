@@ -12,6 +12,7 @@ One "step" = one env.step() of all worlds = ONE launch of the family's step kern
     fetch       cfg 2  FetchPickAndPlace-v4, 4096 worlds / GPU
     hand_touch  cfg 3  HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1, 16384 worlds / GPU
     antmaze     cfg 4  AntMaze_Large_Diverse_GR-v5, 8192 worlds / GPU (65536 over 8)
+    adroit      cfg 5b AdroitHandHammer-v2, 16384 worlds / GPU
     hand_reach         HandReach-v3, 16384 worlds / GPU
 
     python bench.py --gpus 1 --steps 100 --warmup 10
@@ -38,6 +39,7 @@ WORKLOADS = {
     "hand_touch": dict(env_id="HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", worlds=16384, kernel="grx_hand_step_kernel", algo=1635, horizon=100),
     "hand_reach": dict(env_id="HandReach-v3", worlds=16384, kernel="grx_hand_step_kernel", algo=1035, horizon=50),   # r 24+24+24+20, w 72, out 63+15+15+1
     "antmaze": dict(env_id="AntMaze_Large_Diverse_GR-v5", worlds=8192, kernel="grx_point_step_kernel", algo=507, horizon=1000),
+    "adroit": dict(env_id="AdroitHandHammer-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=1098, horizon=200),   # cfg 5b (5 substeps + noslip)
 }
 HER_K = 4  # relabelled goals per transition ("future" strategy with k=4); 28 B per relabelled transition
 HBM_PEAK_GBS = 8000.0
@@ -52,6 +54,8 @@ def make_env(workload, n, device, rank):
         from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv as Env
     elif workload == "hand_reach":
         from gymnasium_robotics_amd.envs.hand import HandReachVecEnv as Env
+    elif workload == "adroit":
+        from gymnasium_robotics_amd.envs.adroit import AdroitHammerVecEnv as Env
     else:
         from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv as Env
     return Env(w["env_id"], **kw)
@@ -70,6 +74,10 @@ def _oracle_env(workload):
         layout = parse_ant_maze_id(WORKLOADS[workload]["env_id"])[0]
         maze = Maze(MAPS[layout], ANT_MAZE_SIZE_SCALING, ANT_MAZE_HEIGHT)
         return OracleAntMazeEnv(load_point_maze_model(maze, layout, None, "ant"), maze), 8
+    if workload == "adroit":
+        from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_hammer_model
+        from oracle.adroit_oracle import OracleAdroitHammerEnv
+        return OracleAdroitHammerEnv(load_adroit_hammer_model()), 26
     if workload == "hand_reach":
         from gymnasium_robotics_amd.envs.hand import load_hand_reach_model
         from oracle.hand_oracle import OracleHandReachEnv
@@ -133,7 +141,10 @@ def run_rank(args, rank, world_size, local_rank):
     act_dim = env.single_action_space.shape[0]
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
-    gathered = torch.empty(n * world_size, env.packed.shape[1], device=device) if dist else None
+    out_rows = getattr(env, "packed", None)
+    if out_rows is None:
+        out_rows = env.obs   # plain (non-goal) environments: the observation rows are the per-step output
+    gathered = torch.empty(n * world_size, out_rows.shape[1], device=device) if dist else None
     her = args.workload == "fetch"
     # HER "future"-style relabelling with HER_K substituted goals per transition: the substitution pattern is drawn once (K rolled copies of
     # one permutation), each step gathers the goals and recomputes the rewards on the device
@@ -146,7 +157,7 @@ def run_rank(args, rank, world_size, local_rank):
             ag = obs["achieved_goal"].unsqueeze(0).expand(HER_K, n, 3).contiguous()
             env.compute_reward(ag, obs["desired_goal"][her_idx], None)
         if dist:   # the step kernel wrote the packed [obs | achieved | desired | reward | success] rows: one collective, no pack kernels
-            dist.all_gather_into_tensor(gathered, env.packed)
+            dist.all_gather_into_tensor(gathered, out_rows)
 
     for _ in range(args.warmup):
         one_step()

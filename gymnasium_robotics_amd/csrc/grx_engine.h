@@ -706,6 +706,35 @@ template <int NS, bool HAND = false>
   __syncthreads();
   return __ballot((lane_ < NS) && !(rd > 0.0f)) != 0ull;   // a non-positive (or NaN) pivot: the matrix was not positive definite (GRX_ST_FACTOR)
 }
+// In-place Gauss-Jordan inverse of a symmetric positive definite matrix, same register layout (lane i = row i, NS registers): step k broadcasts
+// row k with v_readlane, every other row subtracts its multiple of it, the pivot column becomes the k-th column of the inverse.  No LDS traffic,
+// no barrier: ~2 NS^2 instructions against ~NS^3 / 8 dependent LDS round trips of the factor-and-substitute route (noslip needs all of M^-1).
+template <int NS>
+  static __device__ __forceinline__ void grx_sym_inverse_reg(const float* A, int ld, float* out, int lane_) {
+  float a[NS];
+  const int row = lane_ < NS ? lane_ : 0;
+#pragma unroll
+  for (int i = 0; i < NS; i++) a[i] = A[row * ld + i];
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const float p = grx_rcp_refined(grx_readlane_f(a[k], k));
+    const bool own = (lane_ == k);
+    const float f = own ? 0.0f : a[k] * p;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      if (j == k) continue;
+      const float akj = grx_readlane_f(a[j], k);
+      a[j] = own ? akj * p : fmaf(-f, akj, a[j]);
+    }
+    a[k] = own ? p : -f;
+  }
+  __syncthreads();
+  if (lane_ < NS) {
+#pragma unroll
+    for (int i = 0; i < NS; i++) out[lane_ * ld + i] = a[i];
+  }
+  __syncthreads();
+}
 #endif
 
 // nsplit: the last nsplit (= 6) dofs are a free object whose block of A is decoupled from the rest (all entries between the two
@@ -2370,18 +2399,20 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   }
   WAVE_SYNC();
 #if !defined(GRX_EMU)
-  if (nv < 32) {
+  if (nv < 32 || (S::kFixed && S::NV <= 40)) {
     // matrix cores: [H | J'f] = J' [D J | f] as a chain of v_mfma_f32_32x32x2_f32 (exact f32, two constraint rows per instruction).
+    // nv >= 32 (Adroit: 33): the chain forms the leading 32 x 32 block; the remaining rows / columns and J'f follow in a lane-per-dof pass.
+    const int nvm = nv < 32 ? nv : 32;
     // operand maps: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; C: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = 0.0f;
     const int idx = lane_ & 31, half = lane_ >> 5;
-    const bool incol = idx < nv;
+    const bool incol = idx < nvm;
     // Branch-free operand fetch (clamped addresses, selects instead of divergent paths), software-pipelined by hand over
     // four row pairs: 16 independent LDS reads (row info, second span, masked D, force), then 4 reads of the packed Jacobian, then 4 MFMAs.
-    const bool isf = (idx == nv);
+    const bool isf = (idx == nv);   // the spare column carries J'f (only when nv < 32)
     for (int r0 = 0; r0 < nefc; r0 += 8) {
       int info[4], idb[4]; float dq[4], fr[4], v[4]; bool rowok[4], in[4];
 #pragma unroll
@@ -2407,9 +2438,31 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-      if (i < nv) {
+      if (i < nvm) {
         if (incol) c->A[i * nv + idx] = c->M[i * nv + idx] + acc[e];
         else if (idx == nv) c->grad[i] = acc[e];
+      }
+    }
+    if (nv >= 32) {   // rows / columns 32 .. nv-1 of H and the whole of J'f: lane j = dof j, one pass over the rows per extra dof
+      if (lane_ < nv) {
+        const int j = lane_;
+        float gj = 0.0f;
+        for (int r = 0; r < nefc; r++) {
+          const int info = c->efc_row[r], idb = S::kTwoSpan ? c->efc_id[r] : 0, pj = grx_row_pos(info, idb, j);
+          if (pj >= 0) gj += c->Jp[GRX_ROW_OFF(info) + pj] * c->efc_force[r];
+        }
+        c->grad[j] = gj;
+        for (int i = 32; i < nv; i++) {
+          float hij = 0.0f;
+          for (int r = 0; r < nefc; r++) {
+            const float dq = c->efc_jv[r];
+            if (dq == 0.0f) continue;
+            const int info = c->efc_row[r], idb = S::kTwoSpan ? c->efc_id[r] : 0, pi = grx_row_pos(info, idb, i), pj = grx_row_pos(info, idb, j);
+            if (pi >= 0 && pj >= 0) hij += dq * c->Jp[GRX_ROW_OFF(info) + pi] * c->Jp[GRX_ROW_OFF(info) + pj];
+          }
+          const float v = c->M[i * nv + j] + hij;
+          c->A[i * nv + j] = v; c->A[j * nv + i] = v;
+        }
       }
     }
     __syncthreads();
@@ -2512,19 +2565,52 @@ GRX_MEM int grx_hessian_update(const GrxModel* m, GrxCtx* c, int nefc, float* g0
 GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   const int nv = GRX_NVC, maxiter = m->noslip_iterations;
   const int ne = c->cnt[3], nf = c->cnt[4], ncon = c->cnt[0] < c->maxcon ? c->cnt[0] : c->maxcon;
-  // ---- M^-1: factor a copy of M in the (dead) Hessian buffer, then lane i solves for the i-th unit vector in its own row of c->minv
+  GRX_TICK(c, GRX_P_NEVAL);
+  // ---- M^-1.  Specialised shapes on the GPU: Gauss-Jordan in registers.  Otherwise: factor a copy of M in the (dead) Hessian buffer, then
+  // lane i solves for the i-th unit vector in its own row of c->minv.
+#if !defined(GRX_EMU)
+  if (S::kFixed && S::NV > 0 && S::NV <= 40) grx_sym_inverse_reg<(S::NV > 0 && S::NV <= 40) ? S::NV : 1>(c->M, nv, c->minv, lane_);
+  else
+#endif
+  {
   FOR_LANES { for (int i = lane; i < nv * nv; i += 64) { c->A[i] = c->M[i]; c->minv[i] = ((i / nv) == (i % nv)) ? 1.0f : 0.0f; } }
   WAVE_SYNC();
   if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
+  // lane i: forward / backward substitution of the i-th unit vector in its own row of c->minv.  The inner loops are blocked by eight
+  // independent read-modify-writes (loads first, then the updates): unblocked, every update waits a full LDS round trip for the previous one.
   FOR_LANES {
     if (lane < nv) {
       float* x = c->minv + lane * nv; const float* A = c->A;
-      for (int k = nv - 1; k > 0; k--) { const float yk = x[k] * A[k * nv + k]; for (int i = 0; i < k; i++) x[i] -= A[k * nv + i] * yk; }
+      for (int k = nv - 1; k > 0; k--) {
+        const float yk = x[k] * A[k * nv + k];
+        int i = 0;
+        for (; i + 8 <= k; i += 8) {
+          float av[8], xv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { av[u] = A[k * nv + i + u]; xv[u] = x[i + u]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) x[i + u] = fmaf(-av[u], yk, xv[u]);
+        }
+        for (; i < k; i++) x[i] -= A[k * nv + i] * yk;
+      }
       for (int i = 0; i < nv; i++) x[i] *= A[i * nv + i];
-      for (int i = 0; i < nv - 1; i++) { const float xi = x[i]; for (int k = i + 1; k < nv; k++) x[k] -= A[k * nv + i] * A[k * nv + k] * xi; }
+      for (int i = 0; i < nv - 1; i++) {
+        const float xi = x[i];
+        int k = i + 1;
+        for (; k + 8 <= nv; k += 8) {
+          float av[8], dv[8], xv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { av[u] = A[(k + u) * nv + i]; dv[u] = A[(k + u) * nv + k + u]; xv[u] = x[k + u]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) x[k + u] = fmaf(-av[u] * dv[u], xi, xv[u]);
+        }
+        for (; k < nv; k++) x[k] -= A[k * nv + i] * A[k * nv + k] * xi;
+      }
     }
   }
   WAVE_SYNC();
+  }
+  GRX_SUBTICK(c, 17);
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   float improvement0 = 0.0f;   // cost change of dropping the regulariser: 0.5 sum f^2 R (enters the first sweep's improvement)
   {
@@ -2532,6 +2618,75 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     FOR_LANES { float sacc = 0.0f; for (int r = lane; r < nefc; r += 64) { const float f = c->efc_force[r]; sacc += 0.5f * f * f / c->efc_D[r]; } LV(ip) = sacc; }
     improvement0 = grx_reduce_sum(ip);
   }
+#if !defined(GRX_EMU)
+  {
+    // GPU: the sweep state lives in registers -- lane i holds a_i, lane r holds the r-th friction-loss row (dof, aref, bound, force, A_rr);
+    // a row update is a handful of v_readlane broadcasts plus one LDS read of the M^-1 column, no barrier.  Same arithmetic, same order
+    // as the plain version below (which the lane emulator runs).
+    float a_l = lane_ < nv ? c->qacc[lane_] : 0.0f;
+    int fr_d = 0; float fr_aref = 0.0f, fr_fl = 0.0f, fr_f = 0.0f, fr_arr = 1.0f;
+    if (lane_ < nf) {
+      const int r = ne + lane_;
+      fr_d = GRX_ROW_IDOF(c->efc_id[r]); fr_aref = c->efc_aref[r]; fr_fl = c->efc_floss[r]; fr_f = c->efc_force[r]; fr_arr = c->minv[fr_d * nv + fr_d];
+    }
+    for (int iter = 0; iter < maxiter; iter++) {
+      float improvement = iter == 0 ? improvement0 : 0.0f;
+      for (int r = 0; r < nf; r++) {
+        const int d = __builtin_amdgcn_readlane(fr_d, r);
+        const float Arr = grx_readlane_f(fr_arr, r), res = grx_readlane_f(a_l, d) - grx_readlane_f(fr_aref, r), old = grx_readlane_f(fr_f, r), fl = grx_readlane_f(fr_fl, r);
+        float fn = old - res / fmaxf(GRX_MINVAL, Arr);
+        fn = fn < -fl ? -fl : (fn > fl ? fl : fn);
+        const float dl = fn - old;
+        improvement -= 0.5f * dl * dl * Arr + dl * res;
+        fr_f = (lane_ == r) ? fn : fr_f;
+        if (dl != 0.0f) { const float col = lane_ < nv ? c->minv[lane_ * nv + d] : 0.0f; a_l = fmaf(col, dl, a_l); }
+      }
+      for (int k = 0; k < ncon; k++) {
+        const int r0 = c->con_efc[k], nr = c->con_nr[k];
+        if (r0 < 0 || nr < 2) continue;
+        for (int j = r0; j + 1 < r0 + nr && j + 1 < nefc; j += 2) {
+          const int infoA = c->efc_row[j], idA = c->efc_id[j], infoB = c->efc_row[j + 1], idB = c->efc_id[j + 1];
+          float ta = 0.0f, tb = 0.0f, ja = 0.0f, jb = 0.0f;
+          if (lane_ < nv) {
+            const float* mi = c->minv + lane_ * nv;
+            const int offA = GRX_ROW_OFF(infoA), loA = GRX_ROW_LO(infoA), lenA = GRX_ROW_LEN(infoA), offB = GRX_ROW_OFF(infoB), loB = GRX_ROW_LO(infoB), lenB = GRX_ROW_LEN(infoB);
+            for (int e = 0; e < lenA; e++) ta += c->Jp[offA + e] * mi[loA + e];
+            for (int e = 0; e < lenB; e++) tb += c->Jp[offB + e] * mi[loB + e];
+            if (S::kTwoSpan) {
+              const int lo2A = GRX_ROWB_LO(idA), len2A = GRX_ROWB_LEN(idA), lo2B = GRX_ROWB_LO(idB), len2B = GRX_ROWB_LEN(idB);
+              for (int e = 0; e < len2A; e++) ta += c->Jp[offA + lenA + e] * mi[lo2A + e];
+              for (int e = 0; e < len2B; e++) tb += c->Jp[offB + lenB + e] * mi[lo2B + e];
+            }
+            const int pa = grx_row_pos(infoA, idA, lane_), pb = grx_row_pos(infoB, idB, lane_);
+            ja = pa >= 0 ? c->Jp[offA + pa] : 0.0f; jb = pb >= 0 ? c->Jp[offB + pb] : 0.0f;
+          }
+          const float A00 = grx_reduce_sum(ja * ta), A01 = grx_reduce_sum(ja * tb), A11 = grx_reduce_sum(jb * tb);
+          const float res0 = grx_reduce_sum(ja * a_l) - c->efc_aref[j], res1 = grx_reduce_sum(jb * a_l) - c->efc_aref[j + 1];
+          const float o0 = c->efc_force[j], o1 = c->efc_force[j + 1];
+          const float bc0 = res0 - (A00 * o0 + A01 * o1), bc1 = res1 - (A01 * o0 + A11 * o1);
+          const float mid = 0.5f * (o0 + o1), K1 = A00 + A11 - 2.0f * A01, K0 = mid * (A00 - A11) + bc0 - bc1;
+          float f0, f1;
+          if (K1 < GRX_MINVAL) { f0 = f1 = mid; }
+          else {
+            const float y = -K0 / K1;
+            if (y < -mid) { f0 = 0.0f; f1 = 2.0f * mid; } else if (y > mid) { f0 = 2.0f * mid; f1 = 0.0f; } else { f0 = mid + y; f1 = mid - y; }
+          }
+          const float d0 = f0 - o0, d1 = f1 - o1;
+          improvement -= 0.5f * (d0 * (A00 * d0 + A01 * d1) + d1 * (A01 * d0 + A11 * d1)) + d0 * res0 + d1 * res1;
+          __syncthreads();
+          if (lane_ == 0) { c->efc_force[j] = f0; c->efc_force[j + 1] = f1; }
+          __syncthreads();
+          a_l += ta * d0 + tb * d1;
+        }
+      }
+      if (improvement * scale < m->noslip_tolerance) break;
+    }
+    __syncthreads();
+    if (lane_ < nv) c->qacc[lane_] = a_l;
+    if (lane_ < nf) c->efc_force[ne + lane_] = fr_f;
+    __syncthreads();
+  }
+#else
   for (int iter = 0; iter < maxiter; iter++) {
     float improvement = iter == 0 ? improvement0 : 0.0f;
     // ---- dry friction: J = e_d, so t is a column of M^-1 and no reduction is needed
@@ -2593,6 +2748,8 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     }
     if (improvement * scale < m->noslip_tolerance) break;
   }
+#endif
+  GRX_SUBTICK(c, 18);
   // M a for the caller (qfrc_constraint = M a - qfrc_smooth)
   FOR_LANES {
     for (int i = lane; i < nv; i += 64) {
