@@ -1900,7 +1900,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     GRX_SUBTICK(c, 13);
     if (S::kMesh) {   // hull-vs-convex pairs that passed the bounding-box filter: pair order, the whole wave on each
       const unsigned long long mm = GRX_BALLOT(meshq);
-      if (mm) {
+      if (__builtin_expect(mm != 0ull, 0)) {   // marked cold: the register allocator then places the spill code this region needs around IT instead of inside the hot stages
         int* queue = (int*)(c->Jp + 128);   // the Jacobian pool is free until the constraint stage; [0, 128) is c->red
         FOR_LANES { if (LV(meshq)) queue[__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = LV(pairq); }
         WAVE_SYNC();

@@ -135,7 +135,7 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 2> Gr
 
 // waves per SIMD the Fetch kernels are compiled for (VGPR budget 168 at 3, 256 at 2): the convex narrow phase needs the full budget
 #ifndef GRX_FETCH_WAVES
-#define GRX_FETCH_WAVES(S) 2   // the wave-cooperative hull routine keeps ~100 values live: at 168 VGPRs (3 waves) the step kernels spill 60-110 registers and run slower than at 2 waves (measured 3.82 vs 3.49 ms per step)
+#define GRX_FETCH_WAVES(S) 2   // the wave-cooperative hull routine keeps ~100 values live: at 168 VGPRs (3 waves) the step kernels spill 60-130 registers and run slower than at 2 waves even with 9 instead of 8 worlds per CU and the hull branch marked cold (measured 3.75 vs 3.44 ms per step)
 #endif
 template <class S>
 __global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))

@@ -21,6 +21,9 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 OUT = os.path.join(ROOT, "gpurun_out")
+sys.path.insert(0, ROOT)
+from bench import WORKLOADS  # noqa: E402  (kernel names, worlds per GPU and algorithmic bytes per env-step of every bench workload)
+
 KERNEL = "grx_fetch_step_kernel"
 ALGO_BYTES = 715 * 4096
 
@@ -55,42 +58,47 @@ def kernel_stats(tag, workload=None):
     print("\n".join(lines[:6]))
 
 
-def pmc(tag):
+def pmc(tag, workload=None):
+    """HBM traffic per launch of the workload's step kernel: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), nothing else traced"""
+    w = WORKLOADS[workload or "fetch"]
+    kernel, algo_bytes = w["kernel"], w["algo"] * w["worlds"]
+    suffix = f"_{workload}" if workload else ""
+    extra = ["--workload", workload] if workload else []
     res, meta = {}, {}
     for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = os.path.join(OUT, f"pmc_{tag}_{cnt}")
+        d = os.path.join(OUT, f"pmc_{tag}_{cnt}{suffix}")
         cmd = ["rocprofv3", "--pmc", cnt, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
-        run(cmd, os.path.join(OUT, f"pmc_{tag}_{cnt}.log"))
+               os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"] + extra
+        run(cmd, os.path.join(OUT, f"pmc_{tag}_{cnt}{suffix}.log"))
         vals = []
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    if KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == cnt:
+                    if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == cnt:
                         vals.append(float(row["Counter_Value"]))
                         meta = {k: row.get(k) for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
         res[cnt] = vals
-    lines = [f"rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline   (separate passes, MI355X, build '{tag}')",
+    lines = [f"rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline {' '.join(extra)}  (separate passes, MI355X, build '{tag}')",
              f"kernel dispatch info: {meta}"]
     summary = {}
     for cnt, vals in res.items():
         if vals:
             mean = sum(vals) / len(vals)
             summary[cnt] = mean
-            lines.append(f"{cnt}: {len(vals)} launches of {KERNEL}: mean {mean:.1f} KiB  min {min(vals):.1f}  max {max(vals):.1f}")
+            lines.append(f"{cnt}: {len(vals)} launches of {kernel}: mean {mean:.1f} KiB  min {min(vals):.1f}  max {max(vals):.1f}")
         else:
             lines.append(f"{cnt}: no samples (see the log)")
-    out = {"kernel": KERNEL, "build": tag, "algorithmic_bytes_per_launch": ALGO_BYTES}
+    out = {"kernel": kernel, "build": tag, "algorithmic_bytes_per_launch": algo_bytes}
     if len(summary) == 2:
         fetch, write = summary["FETCH_SIZE"] * 1024, summary["WRITE_SIZE"] * 1024
         traffic, raw = 2 * fetch + write, fetch + write
         lines.append(f"per launch: FETCH_SIZE {fetch/1e3:.0f} kB (x2 gfx950 wide-read correction: {2*fetch/1e3:.0f} kB), WRITE_SIZE {write/1e3:.0f} kB; "
-                     f"algorithmic bytes 715 B x 4096 worlds = {ALGO_BYTES/1e3:.0f} kB")
-        lines.append(f"traffic (FETCH*2 + WRITE) = {traffic:.0f} B per launch = {traffic/ALGO_BYTES:.2f} x algorithmic; raw (FETCH + WRITE) = {raw/ALGO_BYTES:.2f} x")
+                     f"algorithmic bytes {w['algo']} B x {w['worlds']} worlds = {algo_bytes/1e3:.0f} kB")
+        lines.append(f"traffic (FETCH*2 + WRITE) = {traffic:.0f} B per launch = {traffic/algo_bytes:.2f} x algorithmic; raw (FETCH + WRITE) = {raw/algo_bytes:.2f} x")
         out.update(traffic_bytes_per_launch=int(traffic), raw_bytes_per_launch=int(raw), fetch_kib=summary["FETCH_SIZE"], write_kib=summary["WRITE_SIZE"])
-    with open(os.path.join(OUT, f"pmc_{tag}_hbm_traffic.txt"), "w") as f:
+    with open(os.path.join(OUT, f"pmc_{tag}_hbm_traffic{suffix}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
-    with open(os.path.join(OUT, f"pmc_{tag}_hbm_traffic.json"), "w") as f:
+    with open(os.path.join(OUT, f"pmc_{tag}_hbm_traffic{suffix}.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("\n".join(lines))
 
@@ -133,9 +141,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "sq":
         sq_mix(tag)
         sys.exit(0)
-    if len(sys.argv) > 2 and sys.argv[2] == "workloads":      # kernel stats of the other BASELINE configs
-        for w in ("antmaze", "hand_touch", "hand_reach"):
+    if len(sys.argv) > 2 and sys.argv[2] == "workloads":      # kernel stats + HBM traffic of the other BASELINE configs
+        for w in (sys.argv[3:] or ["antmaze", "hand_touch", "adroit", "hand_reach"]):
             kernel_stats(tag, w)
+            pmc(tag, w)
         sys.exit(0)
     kernel_stats(tag)
     pmc(tag)
