@@ -44,3 +44,50 @@ def test_shard_range_errors():
         assert False
     except ValueError:
         pass
+
+
+def _env_worker(rank, world, port, n_total, steps, ret):
+    """each rank owns a tile of the worlds of ONE logical vector env (seed_offset = first world of the tile) and contributes its packed rows"""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emu_vec_env import EmuFetchVecEnv
+
+    from gymnasium_robotics_amd.parallel import all_gather_outputs, shard_range
+
+    lo, hi = shard_range(n_total, rank, world)
+    env = EmuFetchVecEnv("FetchPickAndPlace-v4", num_envs=hi - lo, seed_offset=lo)
+    rng = np.random.default_rng(7)
+    acts = rng.uniform(-1, 1, (steps, n_total, 4)).astype(np.float32)   # the same global action stream on every rank
+    out = [all_gather_outputs(env.reset(seed=11))]
+    for t in range(steps):
+        out.append(all_gather_outputs(env.step(acts[t, lo:hi])))
+    ret[rank] = torch.stack(out).numpy()
+    dist.destroy_process_group()
+
+
+def test_sharded_env_equals_the_unsharded_one():
+    """SURVEY.md 8(e) with a real env API object (worlds stepped by the lane emulator): 2 ranks x 2 worlds, every step one all-gather of the
+    packed [obs | achieved | desired | reward | success] rows.  Every rank must see, in world order, exactly the rows a single 4-world env
+    produces for the same seed and actions (world i is seeded seed + i wherever it lives)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from emu_vec_env import EmuFetchVecEnv
+
+    n_total, steps = 4, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_env_worker, args=(2, 29531, n_total, steps, ret), nprocs=2, join=True)
+    env = EmuFetchVecEnv("FetchPickAndPlace-v4", num_envs=n_total)
+    rng = np.random.default_rng(7)
+    acts = rng.uniform(-1, 1, (steps, n_total, 4)).astype(np.float32)
+    ref = [env.reset(seed=11)] + [env.step(acts[t]) for t in range(steps)]
+    ref = torch.stack(ref).numpy()
+    assert ret[0].shape == ref.shape == (steps + 1, n_total, 33)
+    assert np.array_equal(ret[0], ref) and np.array_equal(ret[1], ref)
+    assert len({tuple(row[25:28]) for row in ref[0]}) == n_total      # four different worlds (different object positions), in seed order
