@@ -119,7 +119,7 @@ def test_ant_maze_teacher_forced_matches_oracle():
     assert int(np.abs(info["status"]).max()) == 0
     err = np.maximum(np.abs(obs["observation"] - np.asarray(exp_obs)).max(axis=1), np.abs(obs["achieved_goal"] - np.asarray(exp_ag)).max(axis=1))
     print("ant teacher-forced err p50 %.2e p90 %.2e max %.2e" % tuple(np.quantile(err, [0.5, 0.9, 1.0])))
-    assert np.mean(err < 1e-4) >= 0.9 and err.max() < 5e-3
+    assert err.max() < 1e-4   # every snapshot (measured max 1.2e-5, tests/golden/tolerance_table.json)
 
 
 def test_ant_maze_large_runs_and_flags():

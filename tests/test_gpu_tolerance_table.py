@@ -1,0 +1,29 @@
+"""The committed per-family tolerance table (tests/golden/tolerance_table.json, measured on an MI355X by tools/measure_tolerances.py) is the
+regression bar for the fp32-vs-fp64 parity of every served family: each error quantile of a new build must stay within 2x of the recorded one
+(plus 1e-6 of slack for the entries that sit at rounding level), and the families whose contacts are all analytic must meet the north-star bound
+(1e-4) on EVERY snapshot.  What remains above 1e-4 is confined to contacts that go through the general convex routine (one contact point on a line /
+face contact is not unique: FetchSlide's puck, the egg, hull-hull contacts, the Adroit hammer's cylinder head) -- see DESIGN.md section 7."""
+import json
+
+import numpy as np
+import pytest
+
+from tolerance_cases import CASES, TABLE, ant_errors, family_errors
+
+pytestmark = pytest.mark.gpu
+ANALYTIC = {"FetchReach": ["obs"], "FetchPush": ["obs"], "FetchPickAndPlace": ["obs"], "HandReach": ["positions", "velocities"], "HandPen": ["positions", "velocities"],
+            "HandBlock": ["positions"], "AdroitHammer": ["qpos", "positions"], "AntMaze": ["positions", "velocities"]}
+
+
+@pytest.mark.parametrize("family", list(CASES) + ["AntMaze"])
+def test_family_stays_within_the_recorded_quantiles(family):
+    with open(TABLE) as f:
+        table = json.load(f)[family]
+    res = ant_errors() if family == "AntMaze" else family_errors(family)
+    res.pop("_far")
+    for comp, err in res.items():
+        rec = table[comp]
+        for q, val in (("p50", np.median(err)), ("p90", np.quantile(err, 0.9)), ("p99", np.quantile(err, 0.99)), ("max", err.max())):
+            assert val <= 2.0 * rec[q] + 1e-6, (family, comp, q, float(val), rec[q])
+        if comp in ANALYTIC.get(family, []):
+            assert err.max() < 1e-4, (family, comp, float(err.max()))

@@ -1,0 +1,98 @@
+"""Per-family teacher-forced error of the HIP path against the oracle's golden fixtures, split into the observation components that have different
+conditioning (positions / angles vs velocities).  Used by tools/measure_tolerances.py (writes tests/golden/tolerance_table.json from a GPU run)
+and by tests/test_gpu_tolerance_table.py (asserts that a later build does not regress against that table).  GPU only."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TABLE = os.path.join(GOLDEN, "tolerance_table.json")
+
+# family -> (env id, fixture, state keys to load, {component: observation columns})
+HAND_POS = np.r_[0:24, 54:61]     # 24 joint angles + object pose
+HAND_VEL = np.r_[24:54]           # 24 joint velocities + 6 object velocities
+CASES = {
+    "FetchReach": ("FetchReach-v4", "fetch_FetchReach_teacher.npz", ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"), {"obs": np.r_[0:10]}),
+    "FetchPush": ("FetchPush-v4", "fetch_FetchPush_teacher.npz", ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"), {"obs": np.r_[0:25]}),
+    "FetchPickAndPlace": ("FetchPickAndPlace-v4", "fetch_FetchPickAndPlace_teacher.npz", ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"), {"obs": np.r_[0:25]}),
+    "FetchSlide": ("FetchSlide-v4", "fetch_FetchSlide_teacher.npz", ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"),
+                   {"translational": np.r_[0:11, 14:17, 20:25], "puck_rotation": np.r_[11:14], "puck_rot_velocity": np.r_[17:20]}),
+    "FetchHullContacts": ("FetchPickAndPlace-v4", "fetch_hull_teacher.npz", ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"), {"obs": np.r_[0:25]}),
+    "HandReach": ("HandReach-v3", "hand_HandReach_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": np.r_[0:24, 48:63], "velocities": np.r_[24:48]}),
+    "HandBlock": ("HandManipulateBlockRotateXYZ-v1", "hand_BlockRotateXYZ_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": HAND_POS, "velocities": HAND_VEL}),
+    "HandEgg": ("HandManipulateEggRotate-v1", "hand_EggRotate_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": HAND_POS, "velocities": HAND_VEL}),
+    "HandPen": ("HandManipulatePenRotate-v1", "hand_PenRotate_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": HAND_POS, "velocities": HAND_VEL}),
+    "AdroitHammer": ("AdroitHandHammer-v2", "adroit_hammer_teacher.npz", ("qpos", "qvel", "qacc_ws"),
+                     {"qpos": np.r_[0:27], "positions": np.r_[33:39, 42:45], "hammer_euler": np.r_[39:42], "hammer_velocity": np.r_[27:33]}),
+}
+
+
+def family_errors(name):
+    """{component: per-snapshot max abs error}, plus "_far" = mask of the snapshots away from an activation boundary (if the fixture records it)"""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    env_id, fixture, keys, comps = CASES[name]
+    g = np.load(os.path.join(GOLDEN, fixture))
+    n = g["obs"].shape[0]
+    env = grx.make_vec(env_id, num_envs=n, device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
+    env.reset(seed=0)
+    for k in keys:
+        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    if name == "AdroitHammer":
+        env.shift[:, 2] = torch.from_numpy((g["board_z"] - env._board_z0).astype(np.float32)).to(env.device)
+    out = env.step(g["action"])
+    obs = out[0]["observation"] if isinstance(out[0], dict) else out[0]
+    e = np.abs(obs - g["obs"])
+    res = {c: e[:, cols].max(axis=1) for c, cols in comps.items()}
+    res["_far"] = (g["activation_gap"] >= 2e-5) if "activation_gap" in g.files else np.ones(n, bool)
+    env.close()
+    return res
+
+
+def ant_errors(n=96):
+    """AntMaze (RK4): teacher-forced against the live oracle (no fixture: the rollout is generated here, seeded)"""
+    import torch
+
+    from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv
+    from oracle.maze_oracle import OracleAntMazeEnv
+
+    env = AntMazeVecEnv("AntMaze_UMaze-v5", num_envs=n, device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
+    env.reset(seed=3)
+    orc = OracleAntMazeEnv(env.model, env.maze)
+    orc.reset(seed=3)
+    rng = np.random.default_rng(0)
+    pre_q, pre_v, pre_w, acts, exp_obs = [], [], [], [], []
+    drive = rng.uniform(-1, 1, 8)
+    for t in range(n):
+        if t % 24 == 0:
+            drive = rng.uniform(-1, 1, 8)
+        a = np.clip(drive + 0.5 * rng.uniform(-1, 1, 8), -1, 1).astype(np.float32)
+        s = orc.sim
+        pre_q.append(s.qpos.copy()); pre_v.append(s.qvel.copy()); pre_w.append(s.qacc_warmstart.copy()); acts.append(a)
+        o, *_ = orc.step(a.astype(np.float64))
+        exp_obs.append(o["observation"])
+    f = lambda x: torch.from_numpy(np.asarray(x, dtype=np.float32)).cuda()
+    env.qpos.copy_(f(pre_q)); env.qvel.copy_(f(pre_v)); env.qacc_ws.copy_(f(pre_w))
+    obs, *_ = env.step(np.asarray(acts))
+    e = np.abs(obs["observation"] - np.asarray(exp_obs))
+    env.close()
+    return {"positions": e[:, :13].max(axis=1), "velocities": e[:, 13:].max(axis=1), "_far": np.ones(n, bool)}
+
+
+def quantiles(err):
+    return {"p50": float(np.median(err)), "p90": float(np.quantile(err, 0.9)), "p99": float(np.quantile(err, 0.99)), "max": float(err.max()),
+            "frac_within_1e-4": float(np.mean(err < 1e-4))}
+
+
+def measure_all():
+    table = {}
+    for name in list(CASES) + ["AntMaze"]:
+        res = ant_errors() if name == "AntMaze" else family_errors(name)
+        far = res.pop("_far")
+        table[name] = {"n": int(len(far)), "n_away_from_activation_boundary": int(far.sum())}
+        for comp, err in res.items():
+            table[name][comp] = quantiles(err)
+            table[name][comp]["max_away_from_boundary"] = float(err[far].max()) if far.any() else None
+    return table
