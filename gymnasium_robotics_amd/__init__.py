@@ -23,9 +23,6 @@ class UnsupportedEnvError(KeyError):
 
 
 _NOT_SERVED = {
-    "AdroitHandDoor": "only the hammer task of the Adroit family is served so far (door: per-world body_pos of the door frame + latch hinge, adroit_door.py:360-368)",
-    "AdroitHandPen": "only the hammer task of the Adroit family is served so far (pen: per-world target body_quat, adroit_pen.py:383)",
-    "AdroitHandRelocate": "only the hammer task of the Adroit family is served so far (relocate: per-world body_pos + site_pos, adroit_relocate.py:355-369)",
     "FrankaKitchen": "condim-6 finger pads (10 pyramid rows per contact) and a 258-geom scene that needs a spatial broad phase: not built yet",
 }
 
@@ -60,7 +57,7 @@ def _maze_ids() -> List[str]:
 
 
 def _adroit_ids() -> List[str]:
-    return [f"AdroitHandHammer{sfx}-{ver}" for sfx in ("", "Sparse") for ver in ("v1", "v2")]   # __init__.py:1082-1101 (v1: same class, deprecated alias)
+    return [f"AdroitHand{task}{sfx}-{ver}" for task in ("Door", "Hammer", "Pen", "Relocate") for sfx in ("", "Sparse") for ver in ("v1", "v2")]   # __init__.py:1078-1115 (v1: same class, deprecated alias)
 
 
 def registered_env_ids() -> List[str]:
@@ -69,7 +66,7 @@ def registered_env_ids() -> List[str]:
 
 
 def env_family(env_id: str) -> str:
-    """'fetch' | 'hand_reach' | 'hand_manipulate' | 'adroit_hammer' | 'point_maze' | 'ant_maze' for a served id; raises for the rest."""
+    """'fetch' | 'hand_reach' | 'hand_manipulate' | 'adroit' | 'point_maze' | 'ant_maze' for a served id; raises for the rest."""
     for prefix, why in _NOT_SERVED.items():
         if env_id.startswith(prefix):
             raise UnsupportedEnvError(f"{env_id}: not served by this build -- {why}")
@@ -81,8 +78,8 @@ def env_family(env_id: str) -> str:
         return "hand_reach"
     if env_id.startswith("HandManipulate"):
         return "hand_manipulate"
-    if env_id.startswith("AdroitHandHammer"):
-        return "adroit_hammer"
+    if env_id.startswith("AdroitHand"):
+        return "adroit"
     return "point_maze" if env_id.startswith("PointMaze") else "ant_maze"
 
 
@@ -98,8 +95,8 @@ def make_vec(env_id: str, num_envs: int = 1, **kwargs):
         from .envs.hand import HandReachVecEnv as cls
     elif family == "hand_manipulate":
         from .envs.hand import HandBlockVecEnv as cls
-    elif family == "adroit_hammer":
-        from .envs.adroit import AdroitHammerVecEnv as cls
+    elif family == "adroit":
+        from .envs.adroit import AdroitVecEnv as cls
     elif family == "point_maze":
         from .envs.point_maze import PointMazeVecEnv as cls
     else:

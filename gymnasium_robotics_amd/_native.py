@@ -32,11 +32,12 @@ class PointBuffersStruct(ctypes.Structure):
 
 
 class AdroitTaskStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int) for n in ("n_substeps", "sparse_reward", "site_grasp", "site_target", "site_goal", "site_tool", "obj_body", "nq_obs", "obs_dim")]
+    _fields_ = [("n_substeps", ctypes.c_int), ("sparse_reward", ctypes.c_int), ("kind", ctypes.c_int), ("site", ctypes.c_int * 5), ("obj_body", ctypes.c_int),
+                ("nq_obs", ctypes.c_int), ("obs_dim", ctypes.c_int), ("qadr", ctypes.c_int * 2), ("len", ctypes.c_float * 2)]
 
 
 class AdroitBuffersStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")]
 
 
 class HandBuffersStruct(ctypes.Structure):

@@ -60,7 +60,6 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_MAXCON 32    // default (and largest) contact-list capacity per world; a model may request fewer (<= 32: one lane per contact)
 #define GRX_MAXEFC 144   // default constraint rows per world (models with wide contact rows get more: grx_pack_model)
 #define GRX_JPOOL 2032    // default words of packed Jacobian storage per world (rows are stored over their dof span only); < 4096 (12-bit row offsets)
-#define GRX_NEWTON_MAXIT 8
 #ifndef GRX_NEWTON_RTOL
 #define GRX_NEWTON_RTOL 1e-5f
 #define GRX_NEWTON_ATOL 1e-5f
@@ -84,7 +83,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations, iterations;
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv, noslip_tolerance;
   int mpr_iterations;
 };
@@ -113,7 +112,7 @@ struct GrxCtx {
   float* red;  // 128 floats
   int* ired;   // 64 ints
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
-  float* shift;      // models with a shift group: the world's 3-vector (state, loaded with qpos)
+  float* shift;      // models with a shift group: the world's offset t[3] and rotation q[4] (state, loaded with qpos); flag 1 = x + t, flag 2 = R(q) x + t
   float* minv;       // models with the noslip post-solver: M^-1 (nv x nv), formed once per substep
   float* meshcache;  // models with hull-vs-convex pairs: 4 x (pair + 1, separating direction, the two support vertices) + the slot to evict next, kept across the substeps of a step (grx_mesh_pairs)
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
@@ -146,7 +145,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
   pers += jpool + maxefc * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
-  pers += (njnt > 32 ? 64 : 32) + 8 + (nmesh ? 21 : 0) + (nshift ? 4 : 0) + (noslip ? nv * nv : 0);
+  pers += (njnt > 32 ? 64 : 32) + 8 + (nmesh ? 21 : 0) + (nshift ? 8 : 0) + (noslip ? nv * nv : 0);
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
@@ -177,7 +176,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   c->efc_floss = p; if (m->nfric) p += m->maxefc;
   CARVEI(efc_kind, m->maxefc) CARVEI(efc_id, m->maxefc) CARVEI(efc_row, m->maxefc)
   CARVEI(ired, m->njnt > 32 ? 64 : 32) CARVEI(cnt, 8)
-  CARVE(shift, m->nshift ? 4 : 0) CARVE(minv, m->noslip ? m->nv * m->nv : 0)
+  CARVE(shift, m->nshift ? 8 : 0) CARVE(minv, m->noslip ? m->nv * m->nv : 0)
   CARVE(meshcache, m->nmesh ? 21 : 0)
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
   if (m->ntouch || m->noslip) {
@@ -264,6 +263,14 @@ GRX_DEV void mulMat3f(float* r, const float* a, const float* b) {
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
   for (int i = 0; i < 9; i++) r[i] = t[i];
+}
+// pose (flag 2) members of the per-world shift group: x <- R(q) x, frame <- R(q) frame (the offset t is added by the caller)
+GRX_DEV void grx_apply_group_rotation(const float* q, float* x, float* frame) {
+  float Rg[9], t[9];
+  quat2matf(Rg, q);
+  mulMatVec3f(x, Rg, x);
+  mulMat3f(t, Rg, frame);
+  for (int e = 0; e < 9; e++) frame[e] = t[e];
 }
 // spatial inertia (10: Ixx Iyy Izz Ixy Ixz Iyz hx hy hz m, about the tree reference point) times motion vector [w; v]
 GRX_DEV void inertMulf(float* f, const float* I, const float* v) {
@@ -397,6 +404,7 @@ struct GrxShape {
   static constexpr int NSHIFT = (CONVEX_ & 4) ? 1 : 0;   // the model has a per-world shift group (Adroit's nail board)
   static constexpr int NOSLIP = (CONVEX_ & 8) ? 1 : 0;   // the model runs the noslip post-solver
   static constexpr bool kShift = (NV_ == 0) || NSHIFT, kNoslip = (NV_ == 0) || NOSLIP;
+  static constexpr bool kShiftRot = (NV_ == 0) || ((CONVEX_ & 16) != 0);   // the shift group also rotates (flag 2: Adroit pen's target body, model.body_quat edits)
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NVC (S::kFixed ? S::NV : m->nv)
@@ -530,9 +538,11 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
       int b = m->site_bodyid[i];
       float lpv[3] = {m->site_pos[3 * i], m->site_pos[3 * i + 1], m->site_pos[3 * i + 2]}, lqv[4] = {m->site_quat[4 * i], m->site_quat[4 * i + 1], m->site_quat[4 * i + 2], m->site_quat[4 * i + 3]}, v[3], R[9], Rw[9];
       mulMatVec3f(v, c->xmat + 9 * b, lpv);
-      const int sh = S::kShift && m->nshift && m->site_shift[i];
-      for (int e = 0; e < 3; e++) c->sxpos[3 * i + e] = c->xpos[3 * b + e] + v[e] + (sh ? c->shift[e] : 0.0f);
+      const int sh = (S::kShift && m->nshift) ? m->site_shift[i] : 0;
+      for (int e = 0; e < 3; e++) v[e] += c->xpos[3 * b + e];
       quat2matf(R, lqv); mulMat3f(Rw, c->xmat + 9 * b, R);
+      if (S::kShiftRot && sh == 2) grx_apply_group_rotation(c->shift + 3, v, Rw);
+      for (int e = 0; e < 3; e++) c->sxpos[3 * i + e] = v[e] + (sh ? c->shift[e] : 0.0f);
       for (int e = 0; e < 9; e++) c->sxmat[9 * i + e] = Rw[e];
     }
   }
@@ -756,10 +766,11 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit 
   if (n == 24) return grx_sym_solve_reg<24>(A, n, x, lane_);
   if (n == 30) return grx_sym_solve_reg<30>(A, n, x, lane_);
   if (n == 33) return grx_sym_solve_reg<33>(A, n, x, lane_);
+  if (n == 36) return grx_sym_solve_reg<36>(A, n, x, lane_);
 #endif
 #if defined(GRX_EMU)
-  if (n == 21 || n == 14 || n == 15 || n == 24 || n == 30 || n == 33) {   // mirror the device: these sizes are solved without touching A
-    static float copy[33 * 33];
+  if (n == 21 || n == 14 || n == 15 || n == 24 || n == 30 || n == 33 || n == 36) {   // mirror the device: these sizes are solved without touching A
+    static float copy[36 * 36];
     for (int i = 0; i < n * n; i++) copy[i] = A[i];
     int bad_ = grx_sym_factor(copy, n, lane_);
     grx_sym_solve(copy, n, x, lane_);
@@ -1038,7 +1049,9 @@ GRX_MEM void grx_sphere_capsule(const GrxModel* m, GrxCtx* c, int pair, int g1, 
 // what is not restated).  Everything is computed relative to the centre of geom 1, so the fp32 support points are O(geom size)
 // instead of O(world coordinates); a Minkowski point is kept with its witness on geom 1 (the witness on geom 2 is w - v).
 // ------------------------------------------------------------------------------------------
+#ifndef GRX_MPR_EPS   // fp32 machine epsilon (the oracle's restatement uses the fp64 one; the diagnostic fp64 build of the emulator overrides it)
 #define GRX_MPR_EPS 1.1920929e-7f
+#endif
 struct GrxMprPt { float v[3], w[3]; };
 GRX_MEM int grx_mpr_zero(float x) { return fabsf(x) < GRX_MPR_EPS; }
 GRX_MEM int grx_mpr_eq(float a, float b) {
@@ -1512,6 +1525,14 @@ GRX_MEM void grx_capsule_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int
     ts = den > 0.0f ? tlo - dlo * (thi - tlo) / den : 0.5f * (tlo + thi);
   }
 #undef GRX_CB_DG
+  {   // the axis segment passes through the box (penetration deeper than the radius): g vanishes on the whole inside stretch; take its middle
+    float ta = -hl, tb = hl; int hit = 1;
+#define GRX_CB_SLAB(K, SK) if (fabsf(ax[K]) < GRX_MINVAL) { if (fabsf(cen[K]) > SK) hit = 0; } else { float u_ = (-SK - cen[K]) / ax[K], v_ = (SK - cen[K]) / ax[K]; \
+      if (u_ > v_) { const float w_ = u_; u_ = v_; v_ = w_; } ta = fmaxf(ta, u_); tb = fminf(tb, v_); }
+    GRX_CB_SLAB(0, s0) GRX_CB_SLAB(1, s1) GRX_CB_SLAB(2, s2)
+#undef GRX_CB_SLAB
+    if (hit && ta < tb) ts = 0.5f * (ta + tb);
+  }
   float ps[3] = {cen[0] + ts * ax[0], cen[1] + ts * ax[1], cen[2] + ts * ax[2]};
   if (!grx_sphere_box_local(c, pair, bp, bm, s0, s1, s2, ps, r, margin)) return;
   float te = (ts >= 0) ? -hl : hl;
@@ -1786,9 +1807,11 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
       int b = m->geom_bodyid[i];
       float lpv[3] = {m->geom_pos[3 * i], m->geom_pos[3 * i + 1], m->geom_pos[3 * i + 2]}, lqv[4] = {m->geom_quat[4 * i], m->geom_quat[4 * i + 1], m->geom_quat[4 * i + 2], m->geom_quat[4 * i + 3]}, v[3], R[9], Rw[9];
       mulMatVec3f(v, c->xmat + 9 * b, lpv);
-      const int sh = S::kShift && m->nshift && m->geom_shift[i];
-      for (int e = 0; e < 3; e++) c->gxpos[3 * i + e] = c->xpos[3 * b + e] + v[e] + (sh ? c->shift[e] : 0.0f);
+      const int sh = (S::kShift && m->nshift) ? m->geom_shift[i] : 0;
+      for (int e = 0; e < 3; e++) v[e] += c->xpos[3 * b + e];
       quat2matf(R, lqv); mulMat3f(Rw, c->xmat + 9 * b, R);
+      if (S::kShiftRot && sh == 2) grx_apply_group_rotation(c->shift + 3, v, Rw);
+      for (int e = 0; e < 3; e++) c->gxpos[3 * i + e] = v[e] + (sh ? c->shift[e] : 0.0f);
       for (int e = 0; e < 9; e++) c->gxmat[9 * i + e] = Rw[e];
     }
   }
@@ -1966,6 +1989,34 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   }
   LANE0 { if (c->cnt[0] > c->maxcon) c->cnt[0] = c->maxcon; }
   WAVE_SYNC();
+  // The noslip sweeps are Gauss-Seidel over the contact list: while they have not converged their iterates depend on the ORDER of the list.
+  // The late queues above (box-box, hull pairs, large plane-mesh pairs) append their contacts after everything else; put the list back into
+  // pair order (stable: a pair's contacts keep their order), the order of the reference's list.  One lane per contact, rank by counting.
+  if (S::kNoslip && m->noslip_iterations > 0) {
+    const int nc = c->cnt[0];
+    GRX_LANEVAR_I(rk); GRX_LANEVAR_I(pk); GRX_LANEVAR(dk); GRX_LANEVAR(x0); GRX_LANEVAR(x1); GRX_LANEVAR(x2); GRX_LANEVAR(f0); GRX_LANEVAR(f1); GRX_LANEVAR(f2);
+    FOR_LANES {
+      int r = 0, key = 0;
+      if (lane < nc) {
+        key = c->con_pair[lane];
+        for (int j = 0; j < nc; j++) { const int kj = c->con_pair[j]; r += (kj < key) || (kj == key && j < lane); }
+        LV(dk) = c->con_dist[lane];
+        LV(x0) = c->con_pos[3 * lane]; LV(x1) = c->con_pos[3 * lane + 1]; LV(x2) = c->con_pos[3 * lane + 2];
+        LV(f0) = c->con_frame[3 * lane]; LV(f1) = c->con_frame[3 * lane + 1]; LV(f2) = c->con_frame[3 * lane + 2];
+      }
+      LV(rk) = r; LV(pk) = key;
+    }
+    WAVE_SYNC();
+    FOR_LANES {
+      if (lane < nc) {
+        const int r = LV(rk);
+        c->con_pair[r] = LV(pk); c->con_dist[r] = LV(dk);
+        c->con_pos[3 * r] = LV(x0); c->con_pos[3 * r + 1] = LV(x1); c->con_pos[3 * r + 2] = LV(x2);
+        c->con_frame[3 * r] = LV(f0); c->con_frame[3 * r + 1] = LV(f1); c->con_frame[3 * r + 2] = LV(f2);
+      }
+    }
+    WAVE_SYNC();
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2775,7 +2826,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const int implicit_damp = (m->anydamp && m->eulerdamp);
   int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0, g0_ready = 0;
   // the linear solve leaves c->A intact where it runs from registers (grx_sym_solve_full): the Hessian can then be corrected in place
-  const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 30 || nv == 33);
+  const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 30 || nv == 33 || nv == 36);
   // Newton starts from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart,
   // M^-1 qfrc_smooth); the minimiser of the strictly convex problem does not depend on the start, and skipping the
   // comparison saves one factorisation of M per substep.
@@ -2794,7 +2845,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
       if (it > 0 && full_step && !changed) done = 1;
-      if (done || it >= GRX_NEWTON_MAXIT) {
+      if (done || it >= m->iterations) {   // MuJoCo's option iterations (default 100; the hand models: 20)
         if (noslip) grx_noslip(m, c, nefc, lane_);   // re-solves the friction forces without regularisation: new qacc, new M a
         // converged: at the minimiser the gradient M a - qfrc_smooth - J'f vanishes, so the joint-space constraint force
         // J'f of the final evaluation is M a - qfrc_smooth (to the solver's residual) -- no further pass over the rows

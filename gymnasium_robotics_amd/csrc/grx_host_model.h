@@ -60,6 +60,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   for (int k = 0; k < v.n_body_shift; k++) m.nshift += v.body_shift[k] != 0;
   for (int k = 0; k < v.n_geom_shift; k++) m.nshift += v.geom_shift[k] != 0;
   for (int k = 0; k < v.n_site_shift; k++) m.nshift += v.site_shift[k] != 0;
+  m.iterations = d[GRX_ITERATIONS] > 0 ? d[GRX_ITERATIONS] : 100;
   m.noslip_iterations = d[GRX_NOSLIP_ITERATIONS]; m.noslip_tolerance = (float)v.opt[GRX_NOSLIP_TOLERANCE];
   m.nfric = 0; m.nweld = 0; m.wpool = 0;
   for (int k = 0; k < v.n_weld_row; k++) m.wpool += 6 * ((v.weld_row[k] >> 20) & 0xFF);

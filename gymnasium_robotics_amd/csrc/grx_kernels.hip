@@ -366,6 +366,11 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
 // AdroitHandHammer env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world, same engine + the noslip pass
 // nv = 33, every dof carries a friction-loss row (class main: 0.001; the nail: 2.5), general-affine actuators, cylinder / capsule pairs through the convex routine
 typedef GrxShape<33, 33, 26, 29, 33, 30, 4, 1, 33, 0, 144, 2032, 1, 32, 1, 13> GrxShapeAdroitHammer;   // CONVEX bits: 1 (cylinders) | 4 (board shift group) | 8 (noslip)
+// AdroitHandDoor (nv 30: 4 arm + 24 hand + hinge + latch; the door frame is the shift group), AdroitHandPen (nv 30: 24 hand + 6 pen joints; the target
+// cylinder is a ROTATING shift group: bit 16), AdroitHandRelocate (nv 36: 6 arm + 24 hand + 6 ball joints; the ball's body is the shift group, no cylinders)
+typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, 144, 2032, 0, 32, 1, 13> GrxShapeAdroitDoor;
+typedef GrxShape<30, 30, 24, 27, 30, 26, 5, 1, 30, 0, 144, 2032, 0, 32, 1, 29> GrxShapeAdroitPen;
+typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, 144, 2032, 0, 32, 1, 12> GrxShapeAdroitRelocate;
 template <class S>
 __global__ void __launch_bounds__(64, 2)
 grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words, int forward_only) {
@@ -388,12 +393,12 @@ grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
   for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
   for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
   for (int i = lane_; i < 7 * m.nmocap; i += 64) { const int q = i / 7, e = i - 7 * q; if (e < 3) c.mocap_pos[3 * q + e] = m.mocap_pos0[3 * q + e]; else c.mocap_quat[4 * q + e - 3] = m.mocap_quat0[4 * q + e - 3]; }
-  if (m.nshift && lane_ < 3) c.shift[lane_] = b.shift[(size_t)w * 3 + lane_];
+  if (m.nshift && lane_ < 7) c.shift[lane_] = b.shift[(size_t)w * 7 + lane_];
   __syncthreads();
   if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
   else GrxAdroit<S>::grx_adroit_sim_world(&m, &t, &c, b.action + (size_t)w * nu, b.act_mean, b.act_rng, lane_);
   const int wl = grx_world_of_block_late();
-  GrxAdroit<S>::grx_adroit_outputs(&m, &t, &c, b.obs + (size_t)wl * t.obs_dim, b.reward + wl, b.success + wl, lane_);
+  GrxAdroit<S>::grx_adroit_outputs(&m, &t, &c, b.target ? b.target + (size_t)wl * 3 : nullptr, b.obs + (size_t)wl * t.obs_dim, b.reward + wl, b.success + wl, lane_);
   __syncthreads();
   for (int i = lane_; i < nq; i += 64) b.qpos[(size_t)wl * nq + i] = c.qpos[i];
   for (int i = lane_; i < nv; i += 64) { b.qvel[(size_t)wl * nv + i] = c.qvel[i]; b.qacc_ws[(size_t)wl * nv + i] = c.qacc_ws[i]; }
@@ -499,14 +504,23 @@ extern "C" int grx_tu_hand_launch(int shape, unsigned grid, size_t lds_bytes, vo
 #if GRX_TU_ADROIT
 extern "C" int grx_tu_adroit_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
   GRX_LDS(grx_adroit_step_kernel<GrxShapeAny>);
-  if (grx_shape_matches<GrxShapeAdroitHammer>(*g)) { *shape = 20; GRX_LDS(grx_adroit_step_kernel<GrxShapeAdroitHammer>); }
+#define GRX_ADROIT_SHAPES(X) X(20, GrxShapeAdroitHammer) X(21, GrxShapeAdroitDoor) X(22, GrxShapeAdroitPen) X(23, GrxShapeAdroitRelocate)
+  int found = 0;
+#define X(ID, SHAPE) if (!found && grx_shape_matches<SHAPE>(*g)) { found = ID; GRX_LDS(grx_adroit_step_kernel<SHAPE>); }
+  GRX_ADROIT_SHAPES(X)
+#undef X
+  if (found) *shape = found;
   return (int)grx_upload_descriptor(g, slot);
 }
 extern "C" int grx_tu_adroit_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxAdroitTask* t, const GrxAdroitBuffers* b, int n, int words,
                                     int forward_only) {
   const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
-  if (shape == 20) hipLaunchKernelGGL(grx_adroit_step_kernel<GrxShapeAdroitHammer>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
-  else hipLaunchKernelGGL(grx_adroit_step_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
+  switch (shape) {
+#define X(ID, SHAPE) case ID: hipLaunchKernelGGL(grx_adroit_step_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only); break;
+    GRX_ADROIT_SHAPES(X)
+#undef X
+    default: hipLaunchKernelGGL(grx_adroit_step_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
+  }
   return (int)hipGetLastError();
 }
 #endif
@@ -785,9 +799,15 @@ extern "C" int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, 
   GrxAdroitTask t; memcpy(&t, task, sizeof(t));
   GrxAdroitBuffers b; memcpy(&b, buf, sizeof(b));
   const GrxModel& g = m->dev;
-  if (t.site_grasp < 0 || t.site_grasp >= g.nsite || t.site_target < 0 || t.site_target >= g.nsite || t.site_goal < 0 || t.site_goal >= g.nsite || t.site_tool < 0 ||
-      t.site_tool >= g.nsite || t.obj_body <= 0 || t.obj_body >= g.nbody || t.nq_obs != g.nq - 6 || g.nv < 6 || g.ntouch != 1 || t.obs_dim != t.nq_obs + 19)
-    return fail("grx_adroit_step: task ids / dimensions do not fit the model");
+  static const int nsites[4] = {4, 2, 5, 1}, tail[4] = {19, 12, 21, 9};
+  if (t.kind < 0 || t.kind > 3) return fail("grx_adroit_step: unknown task kind");
+  for (int k = 0; k < nsites[t.kind]; k++) if (t.site[k] < 0 || t.site[k] >= g.nsite) return fail("grx_adroit_step: site id out of range");
+  if (t.kind != GRX_ADROIT_DOOR && (t.obj_body <= 0 || t.obj_body >= g.nbody || t.nq_obs != g.nq - 6 || g.nv < 6)) return fail("grx_adroit_step: object body / nq_obs do not fit the model");
+  if (t.kind == GRX_ADROIT_DOOR && (t.nq_obs != g.nq - 3 || t.qadr[0] < 0 || t.qadr[0] >= g.nq || t.qadr[1] < 0 || t.qadr[1] >= g.nq)) return fail("grx_adroit_step: door qpos indices do not fit the model");
+  if (t.obs_dim != t.nq_obs + tail[t.kind]) return fail("grx_adroit_step: obs_dim does not fit the task kind");
+  if (t.kind == GRX_ADROIT_HAMMER && g.ntouch != 1) return fail("grx_adroit_step: the hammer task reads one touch sensor");
+  if (t.kind == GRX_ADROIT_PEN && !(t.len[0] > 0.0f && t.len[1] > 0.0f)) return fail("grx_adroit_step: pen / target lengths must be positive");
+  if (t.kind == GRX_ADROIT_RELOCATE && !buf->target) return fail("grx_adroit_step: the relocate task needs the target buffer");
   const int e = grx_tu_adroit_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_adroit_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;

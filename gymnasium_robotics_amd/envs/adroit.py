@@ -1,10 +1,12 @@
-"""Batched AdroitHandHammer environments on the MI355X engine (host side, Python).
+"""Batched Adroit hand environments on the MI355X engine (host side, Python).
 
-Vectorised drop-in for AdroitHandHammerEnv (/root/reference/gymnasium_robotics/envs/adroit_hand/adroit_hammer.py, ids AdroitHandHammer-v2 /
-AdroitHandHammerSparse-v2 and their -v1 aliases, gymnasium_robotics/__init__.py:1082-1101).  Unlike the goal-conditioned families this is a
-plain Env: observation = a 46-vector per world (not a dict), reward float, terminated always False, info["success"].
+Vectorised drop-in for AdroitHandHammerEnv / AdroitHandDoorEnv / AdroitHandPenEnv / AdroitHandRelocateEnv
+(/root/reference/gymnasium_robotics/envs/adroit_hand/adroit_{hammer,door,pen,relocate}.py, ids AdroitHand<Task>[Sparse]-v2 and their -v1 aliases,
+gymnasium_robotics/__init__.py:1078-1115).  Unlike the goal-conditioned families these are plain Envs: observation = one vector per world (46 / 39 /
+45 / 39, not a dict), reward float, terminated always False, info["success"].
 Per-step work = ONE launch of grx_adroit_step_kernel (action scaling, 5 physics substeps incl. the noslip post-solver, observation, reward,
-success).  Host side of a reset: one PCG64 draw per world for the board height (reset_model, :372-378), written to the per-world `shift` state.
+success).  Host side of a reset: the PCG64 draws of reset_model per world; the model edits the reference makes there (model.body_pos /
+body_quat / site_pos) are per-world state here (`shift`, `target`: adroit_spec.sample_reset).
 """
 import ctypes
 from typing import Optional
@@ -16,17 +18,18 @@ from .. import _native
 from ..core import GoalVecEnv, np_random
 from ..mjcf import CompiledModel
 from ..spaces import Box, batch_space
-from .adroit_spec import MAX_EPISODE_STEPS, OBS_DIM, action_scaling, load_adroit_hammer_model, make_adroit_task, parse_adroit_id
+from .adroit_spec import IDENTITY_SHIFT, MAX_EPISODE_STEPS, SPECS, action_scaling, group_shift, load_adroit_model, make_adroit_task, parse_adroit_id, sample_reset
 
 
-class AdroitHammerVecEnv(GoalVecEnv):
+class AdroitVecEnv(GoalVecEnv):
     """autoreset_mode: "next_step" (Gymnasium >= 1.0 default), "same_step" or "disabled"; output: "numpy" (float64 arrays like the reference)
     or "torch" (the fp32 device tensors the kernel wrote)."""
 
     def __init__(self, env_id: str = "AdroitHandHammer-v2", num_envs: int = 1, device: Optional[str] = None, reward_type: Optional[str] = None,
                  max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step", output: str = "numpy",
                  assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
-        _, rt = parse_adroit_id(env_id)
+        self.task_name, rt = parse_adroit_id(env_id)
+        self.spec = SPECS[self.task_name]
         self.env_id, self.reward_type = env_id, reward_type or rt
         if self.reward_type not in ("dense", "sparse"):
             raise ValueError(f"Unknown reward type, expected `dense` or `sparse` but got {self.reward_type}")   # adroit_hammer.py:226-229
@@ -34,20 +37,22 @@ class AdroitHammerVecEnv(GoalVecEnv):
             raise ValueError(f"unknown autoreset_mode {autoreset_mode}")
         self.num_envs, self.max_episode_steps, self.autoreset_mode, self.output, self.seed_offset = int(num_envs), max_episode_steps, autoreset_mode, output, int(seed_offset)
         if not torch.cuda.is_available():
-            raise RuntimeError("AdroitHammerVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
+            raise RuntimeError("AdroitVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
         self.device = torch.device(device or "cuda:0")
-        self.model = model or load_adroit_hammer_model(assets_root)
+        self.model = model or load_adroit_model(self.task_name, assets_root)
         self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
-        self.obs_dim = OBS_DIM
+        self.obs_dim = self.spec["obs_dim"]
         self._L = _native.lib()
         H, I, F = self.model.pack()
         self._h = ctypes.c_void_p()
         _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0, ctypes.byref(self._h)))
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
-        self.task = make_adroit_task(self.model, self.reward_type)
+        self.task = make_adroit_task(self.model, self.reward_type, self.task_name)
         n, d = self.num_envs, self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
-        self.qpos, self.qvel, self.qacc_ws, self.shift = z(n, self.nq), z(n, self.nv), z(n, self.nv), z(n, 3)
+        self.qpos, self.qvel, self.qacc_ws = z(n, self.nq), z(n, self.nv), z(n, self.nv)
+        self.shift = torch.from_numpy(np.tile(IDENTITY_SHIFT.astype(np.float32), (n, 1))).to(d)
+        self.target = z(n, 3) if self.task_name == "relocate" else None
         self.action, self.obs, self.reward = z(n, self.nu), z(n, self.obs_dim), z(n)
         self.success, self.status, self.mask = z(n, dtype=torch.uint8), z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
         am, ar = action_scaling(self.model)
@@ -58,18 +63,26 @@ class AdroitHammerVecEnv(GoalVecEnv):
         self.action_space = batch_space(self.single_action_space, n)
         self.observation_space = batch_space(self.single_observation_space, n)
         self._init_qpos = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32)).to(d)   # MujocoEnv.init_qpos [3P]: data.qpos after mj_resetData
-        self._board_z0 = float(self.model.info["shift_pos0"][2])
-        self.board_z = np.full(n, self._board_z0)
+        # the model edit of each world as the reference's get_env_state reports it: body_pos (hammer board, door frame, relocate ball) or body_quat (pen target)
+        edit0 = self.model.info["shift_quat0"] if self.task_name == "pen" else self.model.info["shift_pos0"]
+        self.model_edit = np.tile(np.asarray(edit0, dtype=np.float64), (n, 1))
+        self.target_pos = np.zeros((n, 3)) if self.task_name == "relocate" else None
         self.np_randoms = [np_random(None)[0] for _ in range(n)]
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
         self.kernel_events = None
 
+    @property
+    def board_z(self):
+        """hammer: model.body_pos[nail_board, 2] of every world"""
+        return self.model_edit[:, 2]
+
     def _make_bufs(self, mask):
         b = _native.AdroitBuffersStruct()
         for name in ("qpos", "qvel", "qacc_ws", "shift", "action", "obs", "reward", "success", "status"):
             setattr(b, name, getattr(self, name).data_ptr())
+        b.target = None if self.target is None else self.target.data_ptr()
         b.act_mean, b.act_rng = self._act_mean.data_ptr(), self._act_rng.data_ptr()
         b.mask = None if mask is None else mask.data_ptr()
         return b
@@ -87,16 +100,22 @@ class AdroitHammerVecEnv(GoalVecEnv):
             e1.record()
             self.kernel_events.append((e0, e1))
 
-    # ------------------------------------------------------------------ reset (MujocoEnv.reset [3P] -> reset_model, adroit_hammer.py:372-378)
+    # ------------------------------------------------------------------ reset (MujocoEnv.reset [3P] -> reset_model of the task)
+    def _write_edits(self, idx, shifts, targets=None):
+        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        self.shift[ti] = torch.from_numpy(np.asarray(shifts, dtype=np.float32).reshape(len(idx), 7)).to(self.device)
+        if targets is not None:
+            self.target[ti] = torch.from_numpy(np.asarray(targets, dtype=np.float32).reshape(len(idx), 3)).to(self.device)
+        return ti
+
     def _reset_worlds(self, idx):
         if len(idx) == 0:
             return None
-        z = np.array([self.np_randoms[w].uniform(low=0.1, high=0.25) for w in idx])
-        self.board_z[idx] = z
-        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
-        sh = torch.zeros(len(idx), 3, device=self.device)
-        sh[:, 2] = torch.from_numpy((z - self._board_z0).astype(np.float32)).to(self.device)
-        self.shift[ti] = sh
+        draws = [sample_reset(self.task_name, self.np_randoms[w], self.model) for w in idx]
+        self.model_edit[idx] = np.stack([d["edit"] for d in draws])
+        if self.target_pos is not None:
+            self.target_pos[idx] = np.stack([d["target"] for d in draws])
+        ti = self._write_edits(idx, np.stack([d["shift"] for d in draws]), None if self.target is None else np.stack([d["target"] for d in draws]))
         self.qpos[ti] = self._init_qpos
         self.qvel[ti] = 0.0
         self.qacc_ws[ti] = 0.0
@@ -164,24 +183,43 @@ class AdroitHammerVecEnv(GoalVecEnv):
     def _obs(self):
         return self.obs if self.output == "torch" else self.obs.double().cpu().numpy()
 
-    # ------------------------------------------------------------------ get_env_state / set_env_state (adroit_hammer.py:380-402), batched
+    # ------------------------------------------------------------------ get_env_state / set_env_state, batched
+    # (adroit_hammer.py:380-402, adroit_door.py:375-392, adroit_pen.py:399-419, adroit_relocate.py:375-410)
     def get_env_state(self):
-        target = self.obs[:, 42:45].double().cpu().numpy()
-        board = np.tile(np.asarray(self.model.info["shift_pos0"], dtype=np.float64), (self.num_envs, 1))
-        board[:, 2] = self.board_z
-        return dict(qpos=self.qpos.double().cpu().numpy(), qvel=self.qvel.double().cpu().numpy(), board_pos=board, target_pos=target)
+        st = dict(qpos=self.qpos.double().cpu().numpy(), qvel=self.qvel.double().cpu().numpy())
+        obs = self.obs.double().cpu().numpy()
+        if self.task_name == "hammer":
+            st.update(board_pos=self.model_edit.copy(), target_pos=obs[:, 42:45])
+        elif self.task_name == "door":
+            st.update(door_body_pos=self.model_edit.copy())
+        elif self.task_name == "pen":
+            st.update(desired_orien=self.model_edit.copy())
+        else:   # data.xpos[Object], site S_grasp and the target site as of the last forward pass: recovered from the observation's differences
+            tgt = self.target_pos.copy()
+            st.update(hand_qpos=st["qpos"][:, :30].copy(), obj_pos=tgt + obs[:, 36:39], target_pos=tgt, palm_pos=tgt + obs[:, 33:36])
+        return st
 
     def set_env_state(self, state_dict):
-        for key, width in (("qpos", self.nq), ("qvel", self.nv), ("board_pos", 3)):
-            if key not in state_dict or np.asarray(state_dict[key]).shape != (self.num_envs, width):
-                raise AssertionError(f"The state dictionary must hold `{key}` of shape {(self.num_envs, width)}")
-        board = np.asarray(state_dict["board_pos"], dtype=np.float64)
-        if not np.allclose(board[:, :2], np.asarray(self.model.info["shift_pos0"])[:2]):
-            raise NotImplementedError("only the height of the nail board is per-world state (the reference's reset_model never moves it sideways)")
-        self.board_z[:] = board[:, 2]
+        n = self.num_envs
+        need = dict(hammer=(("board_pos", 3),), door=(("door_body_pos", 3),), pen=(("desired_orien", 4),), relocate=(("obj_pos", 3), ("target_pos", 3)))[self.task_name]
+        for key, width in (("qpos", self.nq), ("qvel", self.nv)) + need:
+            if key not in state_dict or np.asarray(state_dict[key]).shape != (n, width):
+                raise AssertionError(f"The state dictionary must hold `{key}` of shape {(n, width)}")
+        qp = np.asarray(state_dict["qpos"], dtype=np.float64)
+        if self.task_name == "pen":
+            edit = np.asarray(state_dict["desired_orien"], dtype=np.float64)
+            shifts = np.stack([group_shift(self.model, quat=q) for q in edit])
+        else:
+            if self.task_name == "relocate":   # model.body_pos[Object] = obj_pos - qpos[OBJTx..OBJTz] (adroit_relocate.py:405-407)
+                edit = np.asarray(state_dict["obj_pos"], dtype=np.float64) - qp[:, 30:33]
+                self.target_pos[:] = np.asarray(state_dict["target_pos"], dtype=np.float64)
+            else:
+                edit = np.asarray(state_dict[need[0][0]], dtype=np.float64)
+            shifts = np.stack([group_shift(self.model, pos=p) for p in edit])
+        self.model_edit[:] = edit
         with torch.cuda.device(self.device):
-            self.shift[:, 2] = torch.from_numpy((board[:, 2] - self._board_z0).astype(np.float32)).to(self.device)
-            self.qpos.copy_(torch.from_numpy(np.asarray(state_dict["qpos"], dtype=np.float32)).to(self.device))
+            self._write_edits(np.arange(n), shifts, self.target_pos)
+            self.qpos.copy_(torch.from_numpy(qp.astype(np.float32)).to(self.device))
             self.qvel.copy_(torch.from_numpy(np.asarray(state_dict["qvel"], dtype=np.float32)).to(self.device))
             self.qacc_ws.zero_()
             self._launch(self._bufs, True)   # set_state -> mj_forward
@@ -196,3 +234,6 @@ class AdroitHammerVecEnv(GoalVecEnv):
             self.close()
         except Exception:
             pass
+
+
+AdroitHammerVecEnv = AdroitVecEnv   # round-1/2 name of the class

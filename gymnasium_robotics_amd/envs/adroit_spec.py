@@ -1,35 +1,61 @@
-"""Adroit hand task description shared by the device env and the test oracle (host logic only).
+"""Adroit hand task descriptions shared by the device env and the test oracle (host logic only).
 
-Mirrors /root/reference/gymnasium_robotics/envs/adroit_hand/adroit_hammer.py: the actuator gain / bias rewrite of the constructor
-(:234-262), the action scaling (:291-293), frame_skip = 5 (:211), the 46-vector observation (:331-357), the dense / sparse reward and the
-success flag (:296-324), reset_model's board-height draw (:372-378) and the registered ids (gymnasium_robotics/__init__.py:1082-1101).
+Mirrors /root/reference/gymnasium_robotics/envs/adroit_hand/{adroit_hammer,adroit_door,adroit_pen,adroit_relocate}.py: the actuator gain / bias
+rewrite of the constructors (adroit_hammer.py:234-262, identical in the other three), the action scaling (:291-293), frame_skip = 5 (:211), the
+observations, the dense / sparse rewards and success flags, each reset_model's draws, and the registered ids (gymnasium_robotics/__init__.py:990-1101).
+
+Per-world MODEL edits of the reference (reset_model writes model.body_pos / body_quat / site_pos) are per-world STATE here:
+  hammer    body_pos[nail_board, 2] = U(0.1, 0.25)                                  -> shift offset (0, 0, z - z0)
+  door      body_pos[frame] = (U(-0.3,-0.2), U(0.25,0.35), U(0.252,0.35))           -> shift offset pos - pos0
+  pen       body_quat[target] = euler2quat((U(-1,1), U(-1,1), 0))                    -> shift rotation about the target body's origin
+  relocate  body_pos[Object, :2] = (U(-0.15,0.15), U(-0.15,0.3)); site_pos[target] = (U(-0.2,0.2), U(-0.2,0.2), U(0.15,0.35))
+                                                                                     -> shift offset of the ball's body + the world's target vector
 """
 import os
 from typing import Optional
 
 import numpy as np
 
-FRAME_SKIP = 5                 # adroit_hammer.py:211
-MAX_EPISODE_STEPS = 200        # __init__.py:1099
-OBS_DIM = 46                   # adroit_hammer.py:205-207
-HAMMER_XML = os.path.join("adroit_hand", "adroit_hammer.xml")
-# engine compile options: the board is the per-world shift group (model.body_pos[nail_board] is redrawn at every reset, :374-376), the nail's
-# touch sensor feeds the observation (:344-346), and only the four sites the task reads are tracked
-HAMMER_COMPILE = dict(shift_body="nail_board", touch_filter=lambda name: name == "S_nail", keep_sites=["S_grasp", "S_target", "nail_goal", "tool"])
+from .manipulate_spec import euler2quat, quat_conj, quat_mul
+
+FRAME_SKIP = 5                 # adroit_hammer.py:211 (all four)
+MAX_EPISODE_STEPS = 200        # __init__.py:1092,1099,1106,1113 (all four tasks)
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
+_no_touch = lambda name: False
+
+# engine compile options per task: the shift group, the touch sensors the observation reads, the sites the task reads
+SPECS = {
+    "hammer": dict(kind=0, xml="adroit_hammer.xml", npz="adroit_hammer.npz", obs_dim=46, max_episode_steps=200, state_keys=("board_pos", "target_pos"),
+                   compile=dict(shift_body="nail_board", touch_filter=lambda name: name == "S_nail", keep_sites=["S_grasp", "S_target", "nail_goal", "tool"]),
+                   sites=("S_grasp", "S_target", "nail_goal", "tool")),
+    "door": dict(kind=1, xml="adroit_door.xml", npz="adroit_door.npz", obs_dim=39, max_episode_steps=200, state_keys=("door_body_pos",),
+                 compile=dict(shift_body="frame", touch_filter=_no_touch, keep_sites=["S_grasp", "S_handle"]), sites=("S_grasp", "S_handle")),
+    "pen": dict(kind=2, xml="adroit_pen.xml", npz="adroit_pen.npz", obs_dim=45, max_episode_steps=200, state_keys=("desired_orien",),
+                compile=dict(shift_body="target", shift_rotates=True, touch_filter=_no_touch,
+                             keep_sites=["eps_ball", "object_top", "object_bottom", "target_top", "target_bottom"]),
+                sites=("eps_ball", "object_top", "object_bottom", "target_top", "target_bottom")),
+    "relocate": dict(kind=3, xml="adroit_relocate.xml", npz="adroit_relocate.npz", obs_dim=39, max_episode_steps=200, state_keys=("obj_pos", "target_pos"),
+                     compile=dict(shift_body="Object", touch_filter=_no_touch, keep_sites=["S_grasp"]), sites=("S_grasp",)),
+}
+_ID_TASK = {"AdroitHandHammer": "hammer", "AdroitHandDoor": "door", "AdroitHandPen": "pen", "AdroitHandRelocate": "relocate"}
+OBS_DIM = SPECS["hammer"]["obs_dim"]
+HAMMER_XML = os.path.join("adroit_hand", "adroit_hammer.xml")
+HAMMER_COMPILE = SPECS["hammer"]["compile"]
 
 
 def parse_adroit_id(env_id: str):
-    """'AdroitHandHammer-v2' / 'AdroitHandHammerSparse-v2' (also -v1: same environment class) -> ('hammer', reward_type)"""
+    """'AdroitHandDoor-v1' / 'AdroitHandPenSparse-v1' / ... (also -v2: hammer, -v1 everywhere else is the registered one; both accepted) -> (task, reward_type)"""
     name, _, version = env_id.rpartition("-")
-    if version not in ("v1", "v2") or name not in ("AdroitHandHammer", "AdroitHandHammerSparse"):
+    sparse = name.endswith("Sparse")
+    base = name[:-6] if sparse else name
+    if version not in ("v1", "v2") or base not in _ID_TASK:
         raise KeyError(f"unknown / unsupported Adroit env id {env_id}")
-    return "hammer", ("sparse" if name.endswith("Sparse") else "dense")
+    return _ID_TASK[base], ("sparse" if sparse else "dense")
 
 
 def apply_actuator_overrides(model):
-    """adroit_hammer.py:234-262: the wrist actuators A_WRJ1..A_WRJ0 get gain 10 / bias (0, -10, 0), the finger actuators A_FFJ3..A_THJ0 gain 1 /
-    bias (0, -1, 0); the two arm actuators keep the values of the XML.  Edits the compiled tables in place (MjModel is edited in place there)."""
+    """adroit_hammer.py:234-262 (door :222-250, pen :232-260, relocate :225-253): the wrist actuators A_WRJ1..A_WRJ0 get gain 10 / bias (0, -10, 0), the finger
+    actuators A_FFJ3..A_THJ0 gain 1 / bias (0, -1, 0); the arm actuators keep the values of the XML.  Edits the compiled tables in place."""
     T, A = model.tables, model.names["actuator"]
     gain, bias = T["act_gainprm"].reshape(-1, 3), T["act_biasprm"].reshape(-1, 3)
     gain[A["A_WRJ1"]: A["A_WRJ0"] + 1] = [10.0, 0.0, 0.0]
@@ -39,16 +65,21 @@ def apply_actuator_overrides(model):
     return model
 
 
-def load_adroit_hammer_model(assets_root: Optional[str] = None, capacity=None):
+def load_adroit_model(task: str, assets_root: Optional[str] = None, capacity=None):
     from ..mjcf import compile_mjcf, load_model
 
+    spec = SPECS[task]
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
-        return apply_actuator_overrides(compile_mjcf(os.path.join(assets_root, HAMMER_XML), capacity=capacity, **HAMMER_COMPILE))
-    path = os.path.join(_MODELS_DIR, "adroit_hammer.npz")
+        return apply_actuator_overrides(compile_mjcf(os.path.join(assets_root, "adroit_hand", spec["xml"]), capacity=capacity, **spec["compile"]))
+    path = os.path.join(_MODELS_DIR, spec["npz"])
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist (no packaged model and no assets_root given)")
     return load_model(path)   # the packaged blob already carries the constructor's actuator rewrite
+
+
+def load_adroit_hammer_model(assets_root: Optional[str] = None, capacity=None):
+    return load_adroit_model("hammer", assets_root, capacity)
 
 
 def action_scaling(model):
@@ -57,13 +88,63 @@ def action_scaling(model):
     return cr.mean(axis=1), 0.5 * (cr[:, 1] - cr[:, 0])
 
 
+# ---------------------------------------------------------------------------------------------------- per-world model edits -> engine state
+IDENTITY_SHIFT = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+
+
+def _quat2mat(q):
+    w, x, y, z = q
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+
+
+def group_shift(model, pos=None, quat=None) -> np.ndarray:
+    """7-vector (t, q) the engine applies to the model's shift group for model.body_pos[body] = pos and / or model.body_quat[body] = quat:
+    members move as x -> R (x - p0) + pos with R = R(quat) R(quat0)^T, i.e. x -> R x + t with t = pos - R p0 (translation-only groups: R = 1, t = pos - p0)."""
+    p0, q0 = np.asarray(model.info["shift_pos0"], dtype=np.float64), np.asarray(model.info.get("shift_quat0", [1.0, 0, 0, 0]), dtype=np.float64)
+    pos = p0 if pos is None else np.asarray(pos, dtype=np.float64)
+    if quat is None:
+        return np.concatenate([pos - p0, [1.0, 0.0, 0.0, 0.0]])
+    q = np.asarray(quat, dtype=np.float64)
+    q = q / np.linalg.norm(q)                 # mj_kinematics normalises body_quat before use [3P]
+    rel = quat_mul(q, quat_conj(q0))
+    return np.concatenate([pos - _quat2mat(rel) @ p0, rel])
+
+
 def board_shift(model, z: float) -> np.ndarray:
-    """shift vector of the board group for model.body_pos[nail_board, 2] = z (the XML value is the zero of the shift)"""
-    return np.array([0.0, 0.0, z - model.info["shift_pos0"][2]])
+    """hammer: model.body_pos[nail_board, 2] = z"""
+    p = np.array(model.info["shift_pos0"], dtype=np.float64)
+    p[2] = z
+    return group_shift(model, pos=p)
 
 
+def sample_reset(task: str, rng, model):
+    """reset_model's draws, in the reference's order -> dict(edit=<what get_env_state reports>, shift=7-vector, target=3-vector or None)"""
+    p0 = np.array(model.info["shift_pos0"], dtype=np.float64)
+    if task == "hammer":       # adroit_hammer.py:374-376
+        p0[2] = rng.uniform(low=0.1, high=0.25)
+        return dict(edit=p0, shift=group_shift(model, pos=p0), target=None)
+    if task == "door":         # adroit_door.py:362-370
+        pos = np.array([rng.uniform(low=-0.3, high=-0.2), rng.uniform(low=0.25, high=0.35), rng.uniform(low=0.252, high=0.35)])
+        return dict(edit=pos, shift=group_shift(model, pos=pos), target=None)
+    if task == "pen":          # adroit_pen.py:380-383
+        e = np.zeros(3)
+        e[0] = rng.uniform(low=-1, high=1)
+        e[1] = rng.uniform(low=-1, high=1)
+        quat = euler2quat(e)
+        return dict(edit=quat, shift=group_shift(model, quat=quat), target=None)
+    if task == "relocate":     # adroit_relocate.py:353-372
+        p0[0] = rng.uniform(low=-0.15, high=0.15)
+        p0[1] = rng.uniform(low=-0.15, high=0.3)
+        target = np.array([rng.uniform(low=-0.2, high=0.2), rng.uniform(low=-0.2, high=0.2), rng.uniform(low=0.15, high=0.35)])
+        return dict(edit=p0, shift=group_shift(model, pos=p0), target=target)
+    raise KeyError(task)
+
+
+# ---------------------------------------------------------------------------------------------------- rewards (float64, the reference's order of operations)
 def hammer_reward(palm, hamm, head, nail, goal, qvel, sparse: bool):
-    """adroit_hammer.py:303-324 (float64 arithmetic, the reference's order of operations) -> (reward, goal_achieved)"""
+    """adroit_hammer.py:303-324 -> (reward, goal_achieved)"""
     goal_distance = np.linalg.norm(nail - goal)
     goal_achieved = bool(goal_distance < 0.01)
     reward = 10.0 if goal_achieved else -0.1
@@ -78,6 +159,58 @@ def hammer_reward(palm, hamm, head, nail, goal, qvel, sparse: bool):
             reward += 25
         if goal_distance < 0.010:
             reward += 75
+    return reward, goal_achieved
+
+
+def door_reward(goal_distance, palm, handle, qvel, sparse: bool):
+    """adroit_door.py:287-316 (goal_distance = the door hinge angle)"""
+    goal_achieved = bool(goal_distance >= 1.35)
+    reward = 10.0 if goal_achieved else -0.1
+    if not sparse:
+        reward = -0.1 * np.linalg.norm(palm - handle)
+        reward += -0.1 * (goal_distance - 1.57) * (goal_distance - 1.57)
+        reward += -1e-5 * np.sum(qvel ** 2)
+        if goal_distance > 0.2:
+            reward += 2
+        if goal_distance > 1.0:
+            reward += 8
+        if goal_distance > 1.35:
+            reward += 10
+    return reward, goal_achieved
+
+
+def pen_reward(obj_pos, desired_loc, obj_orien, desired_orien, sparse: bool):
+    """adroit_pen.py:306-327"""
+    goal_distance = np.linalg.norm(obj_pos - desired_loc)
+    orien_similarity = np.dot(obj_orien, desired_orien)
+    goal_achieved = bool(goal_distance < 0.075 and orien_similarity > 0.95)
+    reward = 10.0 if goal_achieved else -0.1
+    if not sparse:
+        reward = -goal_distance + orien_similarity
+        if goal_distance < 0.075 and orien_similarity > 0.9:
+            reward += 10
+        if goal_distance < 0.075 and orien_similarity > 0.95:
+            reward += 50
+        if obj_pos[2] < 0.075:
+            reward -= 5
+    return reward, goal_achieved
+
+
+def relocate_reward(obj_pos, palm_pos, target_pos, sparse: bool):
+    """adroit_relocate.py:298-321"""
+    goal_distance = float(np.linalg.norm(obj_pos - target_pos))
+    goal_achieved = goal_distance < 0.1
+    reward = 10.0 if goal_achieved else -0.1
+    if not sparse:
+        reward = -0.1 * np.linalg.norm(palm_pos - obj_pos)
+        if obj_pos[2] > 0.04:
+            reward += 1.0
+            reward += -0.5 * np.linalg.norm(palm_pos - target_pos)
+            reward += -0.5 * np.linalg.norm(obj_pos - target_pos)
+        if goal_distance < 0.1:
+            reward += 10.0
+        if goal_distance < 0.05:
+            reward += 20.0
     return reward, goal_achieved
 
 
@@ -102,9 +235,32 @@ def quat2euler(quat):
     return np.array([0.0, -np.arctan2(-R[0, 2], cy), -np.arctan2(-R[1, 0], R[1, 1])])
 
 
-def make_adroit_task(model, reward_type: str):
+def pen_lengths(model):
+    """pen_length, tar_length (adroit_pen.py:385-392): |top - bottom| of the two site pairs (rigid: the local distance)"""
+    S, P = model.names["site"], np.asarray(model.tables["site_pos"], dtype=np.float64).reshape(-1, 3)
+    return float(np.linalg.norm(P[S["object_top"]] - P[S["object_bottom"]])), float(np.linalg.norm(P[S["target_top"]] - P[S["target_bottom"]]))
+
+
+def door_qpos_indices(model):
+    """(hinge, latch): the reference reads qpos[jnt_dofadr[door_hinge]] (adroit_door.py:264-266,287) -- equal to the qpos address in this all-1-dof model -- and qpos[-1]"""
+    j = model.names["joint"]["door_hinge"]
+    return int(np.asarray(model.tables["jnt_dofadr"]).ravel()[j]), int(model.dim("nq")) - 1
+
+
+def make_adroit_task(model, reward_type: str, task: str = "hammer"):
     from .. import _native
 
-    n = model.names
-    return _native.AdroitTaskStruct(FRAME_SKIP, int(reward_type == "sparse"), int(n["site"]["S_grasp"]), int(n["site"]["S_target"]), int(n["site"]["nail_goal"]),
-                                    int(n["site"]["tool"]), int(n["body"]["Object"]), int(model.dim("nq")) - 6, OBS_DIM)
+    spec, n = SPECS[task], model.names
+    t = _native.AdroitTaskStruct()
+    t.n_substeps, t.sparse_reward, t.kind = FRAME_SKIP, int(reward_type == "sparse"), spec["kind"]
+    for k, name in enumerate(spec["sites"]):
+        t.site[k] = int(n["site"][name])
+    t.obj_body = int(n["body"]["Object"]) if task != "door" else 0
+    nq = int(model.dim("nq"))
+    t.nq_obs = nq - 3 if task == "door" else nq - 6
+    t.obs_dim = spec["obs_dim"]
+    if task == "door":
+        t.qadr[0], t.qadr[1] = door_qpos_indices(model)
+    if task == "pen":
+        t.len[0], t.len[1] = pen_lengths(model)
+    return t

@@ -346,7 +346,7 @@ def load_model(path: str) -> CompiledModel:
 # the compiler
 # ----------------------------------------------------------------------------
 class MjcfCompiler:
-    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None):
+    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None, shift_rotates=False):
         """mutate: optional callable(root_element) applied after <include> expansion, before compilation -- the
         in-memory equivalent of the reference's Maze.make_maze XML rewrite (envs/maze/maze_v4.py:168-242)."""
         self.xml_path = os.path.abspath(xml_path)
@@ -358,7 +358,10 @@ class MjcfCompiler:
         self.touch_filter = touch_filter      # callable(sensor name) -> bool: which <touch> sensors the engine evaluates
         # name of a static child of the world whose position is per-world STATE (the reference rewrites model.body_pos at reset:
         # adroit_hammer.py:374-376): everything welded to it gets a shift flag, the engine adds the world's shift vector to it
+        # A shift body WITH joints (adroit_relocate.py:358-363 moves the ball's body) only offsets its own origin.  shift_rotates: the group's
+        # members are also rotated about the world origin by the world's quaternion (adroit_pen.py:381 rewrites model.body_quat of the target).
         self.shift_body = shift_body
+        self.shift_rotates = bool(shift_rotates)
         self.capacity = dict(capacity or {})   # engine row-table / Jacobian-pool capacities requested for this model (0 = default)
         self.defaults = _Defaults()
         self.angle_scale = np.pi / 180.0  # MJCF default angle unit is degree
@@ -903,19 +906,28 @@ class _Lowering:
             body_orig[B[i].name] = (new_id[k], p.tolist(), q.tolist())
         info["body_orig"] = body_orig
         # per-world shift group (c.shift_body): the named static child of the world and every body welded to it
-        shift_set = set()
+        shift_set, shift_jointed = set(), -1
         if c.shift_body is not None:
             root_i = next(i for i, b in enumerate(B) if b.name == c.shift_body)
-            if B[root_i].parent != 0 or B[root_i].joints:
-                raise NotImplementedError("shift_body must be a joint-less child of the world")
-            shift_set = {root_i}
-            grew = True
-            while grew:
-                grew = False
-                for i in range(1, nb):
-                    if i not in shift_set and B[i].parent in shift_set and not B[i].joints and not B[i].mocap:
-                        shift_set.add(i); grew = True
+            if B[root_i].parent != 0:
+                raise NotImplementedError("shift_body must be a child of the world")
+            if B[root_i].joints:
+                if c.shift_rotates:
+                    raise NotImplementedError("a rotating shift group must be static")
+                shift_jointed = root_i
+            else:
+                shift_set = {root_i}
+                grew = True
+                while grew:
+                    grew = False
+                    for i in range(1, nb):
+                        if i not in shift_set and B[i].parent in shift_set and not B[i].joints and not B[i].mocap:
+                            shift_set.add(i); grew = True
+                if c.shift_rotates and any(B[i].parent in shift_set and i not in shift_set for i in range(1, nb)):
+                    raise NotImplementedError("a rotating shift group must not carry moving children")
             info["shift_pos0"] = B[root_i].pos.tolist()
+            info["shift_quat0"] = B[root_i].quat.tolist()
+        shift_flag = 2 if c.shift_rotates else 1
 
         body_shift = np.zeros(nbk, np.int32)
         body_pos = np.zeros((nbk, 3))
@@ -939,7 +951,7 @@ class _Lowering:
             par_old = b.parent
             pk, pp, pq = anchor_of(par_old)
             body_pos[k] = pp + mu.rot_vec(pq, b.pos)
-            body_shift[k] = int(par_old in shift_set)   # a moving child of the shift group: its world-frame origin moves with the group
+            body_shift[k] = int(par_old in shift_set or old == shift_jointed)   # a moving child of the shift group: its world-frame origin moves with the group
             body_quat[k] = mu.quat_normalize(mu.quat_mul(pq, b.quat))
             body_ipos[k] = fb_com[old]
             I = fb_inertia[old]
@@ -1045,7 +1057,7 @@ class _Lowering:
             names["geom"][g.name or f"_geom{gi}"] = gi
             geom_type[gi] = g.type
             geom_bodyid[gi] = new_id[k]
-            geom_shift[gi] = int(i in shift_set)
+            geom_shift[gi] = shift_flag * int(i in shift_set)
             geom_pos[gi] = p + mu.rot_vec(q, g.pos)
             geom_quat[gi] = mu.quat_normalize(mu.quat_mul(q, g.quat))
             geom_size[gi] = g.size
@@ -1115,7 +1127,7 @@ class _Lowering:
             k, p, q = anchor_of(i)
             names["site"][s.name or f"_site{si}"] = si
             site_bodyid[si] = new_id[k]
-            site_shift[si] = int(i in shift_set)
+            site_shift[si] = shift_flag * int(i in shift_set)
             site_type[si] = s.type
             site_pos[si] = p + mu.rot_vec(q, s.pos)
             site_quat[si] = mu.quat_normalize(mu.quat_mul(q, s.quat))
@@ -1638,8 +1650,8 @@ class _Lowering:
         return CompiledModel(T, names, info)
 
 
-def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None) -> CompiledModel:
+def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None, shift_rotates=False) -> CompiledModel:
     """capacity: optional {"maxefc": rows, "jpool": words, "maxcon": contacts, "split_spans": bool} request for the engine's per-world constraint tables.
     touch_filter: optional callable(sensor name) selecting the <touch> sensors the engine evaluates.
     keep_sites: optional list of site names whose world frames the engine tracks (default: every site of the model)."""
-    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites, shift_body=shift_body).compile()
+    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites, shift_body=shift_body, shift_rotates=shift_rotates).compile()

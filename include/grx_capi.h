@@ -121,17 +121,27 @@ typedef struct grx_hand_buffers {
   float* packed;                /* [N, obs_dim+2*goal_dim+2] or NULL: [obs | achieved | desired | reward | success] */
 } grx_hand_buffers;
 
-/* mirrors struct GrxAdroitTask / GrxAdroitBuffers (csrc/grx_adroit_task.h): AdroitHandHammer */
+/* mirrors struct GrxAdroitTask / GrxAdroitBuffers (csrc/grx_adroit_task.h): AdroitHandHammer / Door / Pen / Relocate */
+#define GRX_ADROIT_HAMMER 0
+#define GRX_ADROIT_DOOR 1
+#define GRX_ADROIT_PEN 2
+#define GRX_ADROIT_RELOCATE 3
 typedef struct grx_adroit_task {
   int n_substeps, sparse_reward;
-  int site_grasp, site_target, site_goal, site_tool; /* S_grasp, S_target, nail_goal, tool (adroit_hammer.py:264-268) */
-  int obj_body;                                      /* "Object" */
-  int nq_obs;                                        /* nq - 6 leading qpos entries in the observation */
-  int obs_dim;                                       /* 46 */
+  int kind;     /* GRX_ADROIT_* */
+  int site[5];  /* hammer: S_grasp, S_target, nail_goal, tool (adroit_hammer.py:264-268) | door: S_grasp, S_handle (adroit_door.py:267-268) |
+                   pen: eps_ball, object_top, object_bottom, target_top, target_bottom (adroit_pen.py:259-263) | relocate: S_grasp (adroit_relocate.py:259) */
+  int obj_body; /* "Object" (hammer / pen / ball); unused by the door */
+  int nq_obs;   /* leading qpos entries in the observation: nq - 6 (door: nq - 3 = qpos[1:-2]) */
+  int obs_dim;  /* 46 / 39 / 45 / 39 */
+  int qadr[2];  /* door: the qpos index read as the hinge angle (the reference indexes qpos with jnt_dofadr, adroit_door.py:264-266) and the latch (nq - 1) */
+  float len[2]; /* pen: pen_length, tar_length (adroit_pen.py:385-392) */
 } grx_adroit_task;
 typedef struct grx_adroit_buffers {
   float *qpos, *qvel, *qacc_ws;    /* [N,nq] [N,nv] [N,nv] */
-  const float* shift;              /* [N,3] per-world offset of the board group = model.body_pos[nail_board] - XML value (adroit_hammer.py:374-376) */
+  const float* shift;              /* [N,7] per-world pose of the model's shift group: offset t[3] (= model.body_pos[body] - XML value: adroit_hammer.py:374-376,
+                                      adroit_door.py:362-370, adroit_relocate.py:358-363) and rotation q[4] (model.body_quat[target], adroit_pen.py:381; identity otherwise) */
+  const float* target;             /* [N,3] relocate: model.site_pos[target] (adroit_relocate.py:364-372); NULL for the other tasks */
   const float* action;             /* [N,nu] (may be NULL when forward_only) */
   const float *act_mean, *act_rng; /* [nu] (adroit_hammer.py:269-272) */
   float* obs;                      /* [N,obs_dim] */
@@ -179,9 +189,9 @@ int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t
  * envs/shadow_dexterous_hand/hand_env.py:36-58, reach.py:92-134,398-428).  forward_only != 0: mj_forward + outputs (reset path,
  * robot_env.py:300-313, and _env_setup, reach.py:408-416).  grx_goal_compute_reward: batched compute_reward for dim-vector goals. */
 int grx_hand_step(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int forward_only, void* stream);
-/* AdroitHandHammerEnv.step for N worlds: clip + a = act_mean + a * act_rng + do_simulation(a, 5) (= mj_step x 5 with the noslip post-solver,
- * adroit_assets.xml:3) + _get_obs + reward + success (envs/adroit_hand/adroit_hammer.py:291-357); forward_only != 0: the reset path
- * (set_state -> mj_forward, _get_obs: :372-378) */
+/* AdroitHand{Hammer,Door,Pen,Relocate}Env.step for N worlds: clip + a = act_mean + a * act_rng + do_simulation(a, 5) (= mj_step x 5 with the
+ * noslip post-solver, adroit_assets.xml:3) + _get_obs + reward + success (envs/adroit_hand/adroit_hammer.py:291-357, adroit_door.py:281-347,
+ * adroit_pen.py:288-365, adroit_relocate.py:290-338); forward_only != 0: the reset path (set_state -> mj_forward, _get_obs) */
 int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, const grx_adroit_buffers* buf, int n_worlds, int forward_only, void* stream);
 int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
                             float* reward_out, void* stream);

@@ -1,53 +1,93 @@
-"""Single-world fp64 AdroitHandHammer environment on the C oracle -- TEST INFRASTRUCTURE ONLY.
+"""Single-world fp64 Adroit hand environments on the C oracle -- TEST INFRASTRUCTURE ONLY.
 
-Restates /root/reference/gymnasium_robotics/envs/adroit_hand/adroit_hammer.py:291-378 (step / _get_obs / reset_model) and the gymnasium
-MujocoEnv methods it relies on [3P]: do_simulation (ctrl <- a, mj_step(frame_skip)), set_state (qpos / qvel <- copies, mj_forward), reset
-(seed, mj_resetData, reset_model).  The reference's own class runs on the same physics in tests/test_cpu_reference_task_layer.py.
+Restates step / _get_obs / reset_model of /root/reference/gymnasium_robotics/envs/adroit_hand/adroit_hammer.py:291-378, adroit_door.py:281-373,
+adroit_pen.py:288-397, adroit_relocate.py:290-373 and the gymnasium MujocoEnv methods they rely on [3P]: do_simulation (ctrl <- a,
+mj_step(frame_skip)), set_state (qpos / qvel <- copies, mj_forward), reset (seed, mj_resetData, reset_model).  The reference's own classes run on
+the same physics in tests/test_cpu_reference_task_layer.py.
 """
 import numpy as np
 
-from gymnasium_robotics_amd.envs.adroit_spec import FRAME_SKIP, action_scaling, board_shift, hammer_reward, quat2euler
+from gymnasium_robotics_amd.envs.adroit_spec import (FRAME_SKIP, SPECS, action_scaling, door_qpos_indices, door_reward, group_shift, hammer_reward,
+                                                     pen_reward, quat2euler, relocate_reward, sample_reset)
 
 from .oracle_sim import OracleSim
 
 
-class OracleAdroitHammerEnv:
-    def __init__(self, model, reward_type="dense"):
-        self.sim, self.model, self.sparse = OracleSim(model), model, reward_type == "sparse"
+class OracleAdroitEnv:
+    def __init__(self, model, reward_type="dense", task="hammer"):
+        self.sim, self.model, self.sparse, self.task = OracleSim(model), model, reward_type == "sparse", task
         n = model.names
-        self.site = {k: int(n["site"][k]) for k in ("S_grasp", "S_target", "nail_goal", "tool")}
-        self.obj_body = int(n["body"]["Object"])
+        self.site = {k: int(n["site"][k]) for k in SPECS[task]["sites"]}
+        self.obj_body = int(n["body"]["Object"]) if task != "door" else 0
         self.act_mean, self.act_rng = action_scaling(model)
         self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(None)))
         self.sim.reset_data()
         self.init_qpos, self.init_qvel = self.sim.qpos.copy(), self.sim.qvel.copy()   # MujocoEnv.__init__ [3P]: copies of data.qpos / qvel
-        self.board_z = float(model.info["shift_pos0"][2])
+        self.model_edit = np.array(model.info["shift_quat0"] if task == "pen" else model.info["shift_pos0"], dtype=np.float64)
+        self.target_pos = np.zeros(3)
+        if task == "relocate":     # XML value of the target site (the compiled model does not track it: it has no physical role)
+            self.target_pos = np.array([-0.007, 0.0, 0.2])
+        if task == "door":
+            self.hinge, self.latch = door_qpos_indices(model)
+        self.pen_length = self.tar_length = None
         self.sim.forward()
+
+    board_z = property(lambda self: float(self.model_edit[2]))
 
     def _site(self, name):
         return self.sim.site_xpos.reshape(-1, 3)[self.site[name]].copy()
 
+    def _obj_pos(self):
+        return self.sim.xpos.reshape(-1, 3)[self.obj_body].copy()
+
+    def _pen_orien(self):
+        return (self._site("object_top") - self._site("object_bottom")) / self.pen_length, (self._site("target_top") - self._site("target_bottom")) / self.tar_length
+
     def _get_obs(self):
         s = self.sim
-        qp, qv = s.qpos.copy(), np.clip(s.qvel, -1.0, 1.0)
-        obj_pos = s.xpos.reshape(-1, 3)[self.obj_body].copy()
-        obj_rot = quat2euler(s.xquat.reshape(-1, 4)[self.obj_body])
-        nail_impact = np.clip(s.touch[0], -1.0, 1.0)
-        return np.concatenate([qp[:-6], qv[-6:], self._site("S_grasp"), obj_pos, obj_rot, self._site("S_target"), [nail_impact]])
+        qp = s.qpos.copy()
+        if self.task == "hammer":
+            qv = np.clip(s.qvel, -1.0, 1.0)
+            obj_rot = quat2euler(s.xquat.reshape(-1, 4)[self.obj_body])
+            nail_impact = np.clip(s.touch[0], -1.0, 1.0)
+            return np.concatenate([qp[:-6], qv[-6:], self._site("S_grasp"), self._obj_pos(), obj_rot, self._site("S_target"), [nail_impact]])
+        if self.task == "door":
+            handle, palm = self._site("S_handle"), self._site("S_grasp")
+            door_pos = np.array([s.qpos[self.hinge]])
+            door_open = 1.0 if door_pos > 1.0 else -1.0
+            return np.concatenate([qp[1:-2], [qp[-1]], door_pos, palm, handle, palm - handle, [door_open]])
+        if self.task == "pen":
+            obj_pos, desired_pos = self._obj_pos(), self._site("eps_ball")
+            oo, do = self._pen_orien()
+            return np.concatenate([qp[:-6], obj_pos, s.qvel[-6:].copy(), oo, do, obj_pos - desired_pos, oo - do])
+        obj_pos, palm, target = self._obj_pos(), self._site("S_grasp"), self.target_pos
+        return np.concatenate([qp[:-6], palm - obj_pos, palm - target, obj_pos - target])
+
+    # ---- the model edits of reset_model / set_env_state
+    def set_model_edit(self, edit, target=None):
+        self.model_edit = np.array(edit, dtype=np.float64)
+        self.sim.shift[:] = group_shift(self.model, quat=self.model_edit) if self.task == "pen" else group_shift(self.model, pos=self.model_edit)
+        if target is not None:
+            self.target_pos = np.array(target, dtype=np.float64)
 
     def set_board_z(self, z):
-        self.board_z = float(z)
-        self.sim.shift[:] = board_shift(self.model, self.board_z)
+        p = self.model_edit.copy()
+        p[2] = float(z)
+        self.set_model_edit(p)
 
     def reset(self, seed=None):
         if seed is not None:
             self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
         s = self.sim
         s.reset_data()
-        self.set_board_z(self.np_random.uniform(low=0.1, high=0.25))
+        d = sample_reset(self.task, self.np_random, self.model)
+        self.set_model_edit(d["edit"], d["target"])
         s.qpos[:] = self.init_qpos
         s.qvel[:] = self.init_qvel
         s.forward()
+        if self.task == "pen":   # adroit_pen.py:385-392
+            self.pen_length = np.linalg.norm(self._site("object_top") - self._site("object_bottom"))
+            self.tar_length = np.linalg.norm(self._site("target_top") - self._site("target_bottom"))
         return self._get_obs(), {}
 
     def step(self, a):
@@ -56,6 +96,18 @@ class OracleAdroitHammerEnv:
         s.ctrl[:] = self.act_mean + a * self.act_rng
         s.step(FRAME_SKIP)
         obs = self._get_obs()
-        hamm = s.xpos.reshape(-1, 3)[self.obj_body].copy()
-        reward, success = hammer_reward(self._site("S_grasp"), hamm, self._site("tool"), self._site("S_target"), self._site("nail_goal"), s.qvel, self.sparse)
+        if self.task == "hammer":
+            reward, success = hammer_reward(self._site("S_grasp"), self._obj_pos(), self._site("tool"), self._site("S_target"), self._site("nail_goal"), s.qvel, self.sparse)
+        elif self.task == "door":
+            reward, success = door_reward(s.qpos[self.hinge], self._site("S_grasp"), self._site("S_handle"), s.qvel, self.sparse)
+        elif self.task == "pen":
+            oo, do = self._pen_orien()
+            reward, success = pen_reward(self._obj_pos(), self._site("eps_ball"), oo, do, self.sparse)
+        else:
+            reward, success = relocate_reward(self._obj_pos(), self._site("S_grasp"), self.target_pos, self.sparse)
         return obs, reward, False, False, dict(success=success)
+
+
+class OracleAdroitHammerEnv(OracleAdroitEnv):
+    def __init__(self, model, reward_type="dense"):
+        super().__init__(model, reward_type, "hammer")

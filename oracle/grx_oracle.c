@@ -55,7 +55,7 @@ typedef struct orc_sim {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair;
   /* state */
   double time, *qpos, *qvel, *ctrl, *mocap_pos, *mocap_quat, *qacc_warmstart;
-  double shift[3]; /* per-world position offset of the model's shift group (body_shift / geom_shift / site_shift): model.body_pos edits of the reference (adroit_hammer.py:374-376) */
+  double shift[7]; /* per-world offset t[3] and rotation q[4] (flag 2 members: x <- R(q) x + t; adroit_pen.py:381 model.body_quat edit) of the model's shift group (body_shift / geom_shift / site_shift): model.body_pos edits of the reference (adroit_hammer.py:374-376) */
   int noslip_iter_done;
   /* position stage */
   double *xpos, *xquat, *xmat, *xipos, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
@@ -128,6 +128,7 @@ static void mulMat3(double* r, const double* a, const double* b) {
 
 orc_sim* orc_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF) {
   orc_sim* s = (orc_sim*)calloc(1, sizeof(orc_sim));
+  s->shift[3] = 1.0;   /* identity rotation of the shift group */
   s->H = (int32_t*)malloc(sizeof(int32_t) * (size_t)nH); memcpy(s->H, H, sizeof(int32_t) * (size_t)nH);
   s->I = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nI + 1)); memcpy(s->I, I, sizeof(int32_t) * (size_t)nI);
   s->F = (double*)malloc(sizeof(double) * (size_t)(nF + 1)); memcpy(s->F, F, sizeof(double) * (size_t)nF);
@@ -234,14 +235,18 @@ static void kinematics(orc_sim* s) {
   for (int g = 0; g < s->ngeom; g++) {
     int b = m->geom_bodyid[g]; double v[3], R[9];
     mulMatVec3(v, xmat + 9 * b, m->geom_pos + 3 * g);
-    for (int k = 0; k < 3; k++) s->geom_xpos[3 * g + k] = xpos[3 * b + k] + v[k] + (m->geom_shift[g] ? s->shift[k] : 0.0);
+    for (int k = 0; k < 3; k++) v[k] += xpos[3 * b + k];
     quat2mat(R, m->geom_quat + 4 * g); mulMat3(s->geom_xmat + 9 * g, xmat + 9 * b, R);
+    if (m->geom_shift[g] == 2) { double Rg[9], t[9], w[3]; quat2mat(Rg, s->shift + 3); mulMatVec3(w, Rg, v); mulMat3(t, Rg, s->geom_xmat + 9 * g); memcpy(v, w, sizeof w); memcpy(s->geom_xmat + 9 * g, t, sizeof t); }
+    for (int k = 0; k < 3; k++) s->geom_xpos[3 * g + k] = v[k] + (m->geom_shift[g] ? s->shift[k] : 0.0);
   }
   for (int g = 0; g < s->nsite; g++) {
     int b = m->site_bodyid[g]; double v[3], R[9];
     mulMatVec3(v, xmat + 9 * b, m->site_pos + 3 * g);
-    for (int k = 0; k < 3; k++) s->site_xpos[3 * g + k] = xpos[3 * b + k] + v[k] + (m->site_shift[g] ? s->shift[k] : 0.0);
+    for (int k = 0; k < 3; k++) v[k] += xpos[3 * b + k];
     quat2mat(R, m->site_quat + 4 * g); mulMat3(s->site_xmat + 9 * g, xmat + 9 * b, R);
+    if (m->site_shift[g] == 2) { double Rg[9], t[9], w[3]; quat2mat(Rg, s->shift + 3); mulMatVec3(w, Rg, v); mulMat3(t, Rg, s->site_xmat + 9 * g); memcpy(v, w, sizeof w); memcpy(s->site_xmat + 9 * g, t, sizeof t); }
+    for (int k = 0; k < 3; k++) s->site_xpos[3 * g + k] = v[k] + (m->site_shift[g] ? s->shift[k] : 0.0);
   }
 }
 
@@ -537,6 +542,16 @@ static void collide_capsule_box(orc_sim* s, int pair, int g1, int g2, double mar
   /* snap to an end point when the minimum sits there */
   double pe[3], fe;
   for (int e = -1; e <= 1; e += 2) { for (int k = 0; k < 3; k++) pe[k] = cen[k] + e * hl * ax[k]; fe = box_point_dist2(sz, pe, cl); if (fe <= fmin(f1, f2)) ts = e * hl; }
+  /* the axis segment passes through the box (penetration deeper than the radius): every point of the inside stretch has distance 0 and the
+   * minimiser above is not unique; take the middle of the stretch (slab clipping of the segment against the three pairs of faces) */
+  {
+    double ta = -hl, tb = hl; int hit = 1;
+    for (int k = 0; k < 3 && hit; k++) {
+      if (fabs(ax[k]) < MINVAL) { if (fabs(cen[k]) > sz[k]) hit = 0; }
+      else { double u = (-sz[k] - cen[k]) / ax[k], v = (sz[k] - cen[k]) / ax[k]; if (u > v) { double w = u; u = v; v = w; } if (u > ta) ta = u; if (v < tb) tb = v; }
+    }
+    if (hit && ta < tb) ts = 0.5 * (ta + tb);
+  }
   double ps[3] = {cen[0] + ts * ax[0], cen[1] + ts * ax[1], cen[2] + ts * ax[2]};
   if (!sphere_box_local(s, pair, bp, bm, sz, ps, r, margin)) return;
   double te = (ts >= 0) ? -hl : hl;

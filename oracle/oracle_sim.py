@@ -63,7 +63,7 @@ class OracleSim:
             xipos=3 * self.nbody, geom_xpos=3 * self.ngeom, geom_xmat=9 * self.ngeom, site_xpos=3 * self.nsite,
             site_xmat=9 * self.nsite, subtree_com=3 * self.nbody, cdof=6 * self.nv, M=self.nv * self.nv,
             cvel=6 * self.nbody, qfrc_bias=self.nv, qfrc_passive=self.nv, qfrc_actuator=self.nv, qfrc_smooth=self.nv,
-            qacc_smooth=self.nv, qfrc_constraint=self.nv, qacc=self.nv, time=1, min_activation_gap=1, shift=3,
+            qacc_smooth=self.nv, qfrc_constraint=self.nv, qacc=self.nv, time=1, min_activation_gap=1, shift=7,
             touch=len(model.tables.get("touch_body", [])),
         )
         for name, n in sizes.items():

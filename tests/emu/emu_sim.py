@@ -84,12 +84,14 @@ class EmuSim:
         self.L.emu_hand_step(ctypes.c_void_p(self.h), ctypes.byref(self.task), p(self.qpos), p(self.qvel), p(self.qacc_ws), p(a), p(self.hand_obs),
                              p(self.hand_achieved), p(self.palm), ctypes.byref(self.status), ctypes.c_int(int(forward_only)))
 
-    def adroit_step(self, action, shift, act_mean, act_rng, forward_only=False):
-        """AdroitHandHammer env.step() (or the reset-time forward pass) of one world; returns (obs[46], reward, success)"""
+    def adroit_step(self, action, shift, act_mean, act_rng, forward_only=False, target=None):
+        """Adroit env.step() (or the reset-time forward pass) of one world; shift = the world's 7-vector group pose; returns (obs, reward, success)"""
         p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
         a, sh = np.ascontiguousarray(action, dtype=np.float32), np.ascontiguousarray(shift, dtype=np.float32)
+        assert sh.shape == (7,)
+        tg = np.ascontiguousarray(np.zeros(3) if target is None else target, dtype=np.float32)
         am, ar = np.ascontiguousarray(act_mean, dtype=np.float32), np.ascontiguousarray(act_rng, dtype=np.float32)
         obs, rew, suc = np.zeros(int(self.task.obs_dim), np.float32), ctypes.c_float(0), ctypes.c_ubyte(0)
-        self.L.emu_adroit_step(ctypes.c_void_p(self.h), ctypes.byref(self.task), p(self.qpos), p(self.qvel), p(self.qacc_ws), p(sh), p(a), p(am), p(ar), p(obs),
+        self.L.emu_adroit_step(ctypes.c_void_p(self.h), ctypes.byref(self.task), p(self.qpos), p(self.qvel), p(self.qacc_ws), p(sh), p(tg), p(a), p(am), p(ar), p(obs),
                                ctypes.byref(rew), ctypes.byref(suc), ctypes.byref(self.status), ctypes.c_int(int(forward_only)))
         return obs, float(rew.value), int(suc.value)

@@ -120,17 +120,17 @@ void emu_hand_step(void* h, const GrxHandTask* t, float* qpos, float* qvel, floa
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 
-// AdroitHandHammer env.step() of one world (forward_only: mj_forward + outputs, the reset path)
-void emu_adroit_step(void* h, const GrxAdroitTask* t, float* qpos, float* qvel, float* qacc_ws, const float* shift, const float* action, const float* act_mean,
-                     const float* act_rng, float* obs, float* reward, unsigned char* success, int* status, int forward_only) {
+// AdroitHand{Hammer,Door,Pen,Relocate} env.step() of one world (forward_only: mj_forward + outputs, the reset path)
+void emu_adroit_step(void* h, const GrxAdroitTask* t, float* qpos, float* qvel, float* qacc_ws, const float* shift, const float* target, const float* action,
+                     const float* act_mean, const float* act_rng, float* obs, float* reward, unsigned char* success, int* status, int forward_only) {
   Emu* e = (Emu*)h;
   float mocap[8] = {0};
   for (int k = 0; k < e->m.nmocap && k < 1; k++) { memcpy(mocap, e->m.mocap_pos0, 12); memcpy(mocap + 3, e->m.mocap_quat0, 16); }
   load_state(e, qpos, qvel, qacc_ws, mocap);
-  if (e->m.nshift) for (int k = 0; k < 3; k++) e->c.shift[k] = shift[k];
+  if (e->m.nshift) for (int k = 0; k < 7; k++) e->c.shift[k] = shift[k];
   if (forward_only) GrxEngine<GrxShapeAny>::grx_forward_euler(&e->m, &e->c, 0, 0);
   else GrxAdroit<GrxShapeAny>::grx_adroit_sim_world(&e->m, t, &e->c, action, act_mean, act_rng, 0);
-  GrxAdroit<GrxShapeAny>::grx_adroit_outputs(&e->m, t, &e->c, obs, reward, success, 0);
+  GrxAdroit<GrxShapeAny>::grx_adroit_outputs(&e->m, t, &e->c, target, obs, reward, success, 0);
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 

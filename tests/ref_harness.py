@@ -326,3 +326,104 @@ def adroit_hammer_on_oracle(oracle_env, reward_type="dense"):
     env.tool_site_id, env.goal_site_id = n["site"]["tool"], n["site"]["nail_goal"]
     env.obj_body_id, env.target_body_id = n["body"]["Object"], board_id
     return env
+
+
+class _RowEditProxy:
+    """model.body_pos / body_quat / site_pos of the Adroit envs: the reference only ever writes the rows of ONE body or site (reset_model /
+    set_env_state); the write is forwarded to `on_change(row)`, reads return the stored row."""
+
+    def __init__(self, row_id, row0, on_change):
+        self._id, self._row, self._cb = row_id, np.array(row0, dtype=np.float64), on_change
+
+    def __setitem__(self, key, value):
+        if isinstance(key, tuple):
+            assert key[0] == self._id, f"unexpected model write {key}"
+            self._row[key[1]] = float(value)
+        else:
+            assert key == self._id, f"unexpected model write {key}"
+            self._row[:] = value
+        self._cb(self._row.copy())
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            assert key[0] == self._id
+            return self._row[key[1]]
+        assert key == self._id
+        return self._row
+
+
+def adroit_on_oracle(oracle_env, task, reward_type="dense"):
+    """The reference's AdroitHand{Door,Pen,Relocate,Hammer}Env (constructor bypassed: it needs MuJoCo) with model / data proxies onto the oracle
+    simulation; step / _get_obs / reset / reset_model / get_env_state / set_env_state are the reference's code, MujocoEnv's do_simulation /
+    set_state / reset the stand-in above."""
+    if task == "hammer":
+        return adroit_hammer_on_oracle(oracle_env, reward_type)
+    install()
+    _install_mujoco_env_stand_in()
+    import importlib
+
+    mod = importlib.import_module(f"gymnasium_robotics.envs.adroit_hand.adroit_{task}")
+    cls = {"door": "AdroitHandDoorEnv", "pen": "AdroitHandPenEnv", "relocate": "AdroitHandRelocateEnv"}[task]
+    s, m, n = oracle_env.sim, oracle_env.model, oracle_env.model.names
+    env = object.__new__(getattr(mod, cls))
+    edit_id = 10 ** 6        # the edited body is fused into the world (door frame, pen target) or addressed by name only: any id the proxy recognises
+    target_site = 10 ** 6 + 1
+    env.model = types.SimpleNamespace(nu=m.dim("nu"), na=0, actuator_ctrlrange=np.array(m.tables["act_ctrlrange"], dtype=np.float64).reshape(-1, 2))
+    nsite = m.dim("nsite")
+
+    class SiteXpos:   # data.site_xpos: the engine's sites + (relocate) the world-fixed target site whose model.site_pos is per-world state
+        def __getitem__(self, key):
+            if key == target_site:
+                return oracle_env.target_pos
+            return s.site_xpos.reshape(-1, 3)[key]
+
+    class Data:
+        qpos, qvel, ctrl = s.qpos, s.qvel, s.ctrl
+        xpos = property(lambda self: s.xpos.reshape(-1, 3))
+        xquat = property(lambda self: s.xquat.reshape(-1, 4))
+        site_xpos = SiteXpos()
+        _step = staticmethod(lambda k: s.step(k))
+        _forward = staticmethod(lambda: s.forward())
+        _reset = staticmethod(lambda: s.reset_data())
+    env.data = Data()
+    env.frame_skip, env.render_mode = 5, None
+    env.sparse_reward = reward_type == "sparse"
+    env.init_qpos, env.init_qvel = oracle_env.init_qpos.copy(), oracle_env.init_qvel.copy()
+    env.act_mean = np.mean(env.model.actuator_ctrlrange, axis=1)
+    env.act_rng = 0.5 * (env.model.actuator_ctrlrange[:, 1] - env.model.actuator_ctrlrange[:, 0])
+    # gymnasium.spaces.Box / Dict [3P, absent]: only `contains` (documented behaviour: shape + bounds; same keys, every member contained) and `.spaces`
+    class _Box:
+        def __init__(self, k):
+            self.shape = (k,)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and np.issubdtype(x.dtype, np.floating) and not np.isnan(x).any()
+
+    class _Dict:
+        def __init__(self, spaces):
+            self.spaces = dict(spaces)
+
+        def contains(self, d):
+            return isinstance(d, dict) and set(d) == set(self.spaces) and all(sp.contains(d[k]) for k, sp in self.spaces.items())
+
+    gym = types.SimpleNamespace(spaces=types.SimpleNamespace(Dict=_Dict))
+    box = _Box
+    if task == "door":
+        env.model.body_pos = _RowEditProxy(edit_id, m.info["shift_pos0"], lambda row: oracle_env.set_model_edit(row))
+        env.door_hinge_addrs = int(np.asarray(m.tables["jnt_dofadr"]).ravel()[n["joint"]["door_hinge"]])
+        env.grasp_site_id, env.handle_site_id, env.door_body_id = n["site"]["S_grasp"], n["site"]["S_handle"], edit_id
+        env._state_space = gym.spaces.Dict({"qpos": box(30), "qvel": box(30), "door_body_pos": box(3)})
+    elif task == "pen":
+        env.model.body_quat = _RowEditProxy(edit_id, m.info["shift_quat0"], lambda row: oracle_env.set_model_edit(row))
+        env.target_obj_body_id, env.obj_body_id = edit_id, n["body"]["Object"]
+        env.eps_ball_site_id, env.obj_t_site_id, env.obj_b_site_id = n["site"]["eps_ball"], n["site"]["object_top"], n["site"]["object_bottom"]
+        env.tar_t_site_id, env.tar_b_site_id = n["site"]["target_top"], n["site"]["target_bottom"]
+        env._state_space = gym.spaces.Dict({"qpos": box(30), "qvel": box(30), "desired_orien": box(4)})
+    else:
+        env.model.body_pos = _RowEditProxy(n["body"]["Object"], m.info["shift_pos0"], lambda row: oracle_env.set_model_edit(row))
+        env.model.site_pos = _RowEditProxy(target_site, oracle_env.target_pos, lambda row: oracle_env.set_model_edit(oracle_env.model_edit, row))
+        env.target_obj_site_id, env.S_grasp_site_id, env.obj_body_id = target_site, n["site"]["S_grasp"], n["body"]["Object"]
+        env.obj_translation_qpos_indices = np.array([int(m.tables["jnt_qposadr"][n["joint"][j]]) for j in ("OBJTx", "OBJTy", "OBJTz")])
+        env._state_space = gym.spaces.Dict({"qpos": box(36), "qvel": box(36), "obj_pos": box(3), "target_pos": box(3)})
+    return env

@@ -1,4 +1,4 @@
-"""AdroitHandHammer on the CPU side: registry / spec logic, the oracle's noslip pass against its own definition, and the DEVICE ENGINE SOURCE
+"""The Adroit hand tasks on the CPU side: registry / spec logic, the oracle's noslip pass against its own definition, and the DEVICE ENGINE SOURCE
 (lane emulator, tests/emu) against the fp64 oracle's golden fixtures (tools/make_golden_adroit.py)."""
 import os
 
@@ -18,9 +18,16 @@ def model():
 def test_registry_and_model_dimensions(model):
     import gymnasium_robotics_amd as grx
 
-    assert grx.env_family("AdroitHandHammer-v2") == "adroit_hammer" and grx.env_family("AdroitHandHammerSparse-v2") == "adroit_hammer"
+    assert grx.env_family("AdroitHandHammer-v2") == "adroit" and grx.env_family("AdroitHandPenSparse-v2") == "adroit"
     with pytest.raises(grx.UnsupportedEnvError):
-        grx.env_family("AdroitHandDoor-v2")
+        grx.env_family("FrankaKitchen-v1")
+    # door 30 / 30 / 28, pen 30 / 30 / 24, relocate 36 / 36 / 30; every dof carries a friction-loss row (adroit_assets.xml:12)
+    from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_model
+    for task, dims in (("door", (30, 30, 28)), ("pen", (30, 30, 24)), ("relocate", (36, 36, 30))):
+        mm = load_adroit_model(task)
+        assert (mm.dim("nq"), mm.dim("nv"), mm.dim("nu")) == dims and int(mm.tables["dims"][15]) == 20 and mm.info["unsupported_pairs"] == 0
+        assert (np.asarray(mm.tables["dof_frictionloss"]) > 0).all()
+    assert abs(float(load_adroit_model("door").tables["dof_frictionloss"][28]) - 2.0) < 1e-12     # door_hinge (adroit_door.xml:62)
     # 33 / 33 / 26, hammer = 3 slides + 3 hinges (no free joint), 44 limited tendons, noslip_iterations 20, iterations 20
     assert (model.dim("nq"), model.dim("nv"), model.dim("nu")) == (33, 33, 26)
     assert len(model.tables["tendon_adr"]) == 44 and int(model.tables["dims"][15]) == 20 and int(model.tables["dims"][13]) == 20
@@ -55,44 +62,69 @@ def test_oracle_noslip_removes_friction_creep(model):
     assert 1 <= it < 20
 
 
-def test_emulated_kernel_matches_golden(model):
-    """Teacher-forced env.step() of the engine source (fp32, emulated lanes) against 420 oracle snapshots.  qpos and the site / body positions hold
-    1e-4 throughout.  The hammer's velocities and Euler angles are ill-conditioned whenever its cylinder head or capsule handle rests on the
-    table: the general convex routine returns ONE point of a line / face contact (as MuJoCo's does), fp32 and fp64 pick different ones and the
-    8.9e-5 kg m^2 hammer turns the difference into angular velocity.  The same source compiled in fp64 agrees with the oracle to 1e-6 (median 1e-11),
-    so the quantiles asserted below measure rounding sensitivity, not logic."""
+@pytest.mark.parametrize("task", ["hammer", "door", "pen", "relocate"])
+def test_emulated_kernel_matches_golden(task):
+    """Teacher-forced env.step() of the engine source (fp32, emulated lanes) against every third of the 420 oracle snapshots of each task.  Joint
+    angles and site / body positions hold 1e-4 (tests/adroit_cases.py names the exceptions).  The objects' velocities and Euler angles are
+    ill-conditioned whenever a cylinder or capsule rests on another convex geom: the general convex routine returns ONE point of a line / face
+    contact (as MuJoCo's does), fp32 and fp64 pick different ones and a light object (hammer: 8.9e-5 kg m^2) turns the difference into angular
+    velocity.  The same source compiled in fp64 (tools/emu_fp64_check.py) agrees with the oracle to 5e-6 on every snapshot, so the quantiles
+    asserted here measure rounding sensitivity, not logic."""
+    from adroit_cases import check
     from emu_sim import EmuSim
 
-    from gymnasium_robotics_amd.envs.adroit_spec import action_scaling, board_shift, make_adroit_task
+    from gymnasium_robotics_amd.envs.adroit_spec import action_scaling, load_adroit_model, make_adroit_task
 
-    g = np.load(os.path.join(GOLDEN, "adroit_hammer_teacher.npz"))
-    emu = EmuSim(model, make_adroit_task(model, "dense"))
+    model = load_adroit_model(task)
+    g = np.load(os.path.join(GOLDEN, f"adroit_{task}_teacher.npz"))
+    emu = EmuSim(model, make_adroit_task(model, "dense", task))
     am, ar = action_scaling(model)
-    e_q, e_pos, e_vel, e_rot, e_rew = [], [], [], [], []
-    for i in range(0, g["obs"].shape[0], 3):
+    idx = list(range(0, g["obs"].shape[0], 3))
+    obs, rew = [], []
+    for i in idx:
         emu.qpos[:], emu.qvel[:], emu.qacc_ws[:] = g["qpos"][i], g["qvel"][i], g["qacc_ws"][i]
-        obs, rew, suc = emu.adroit_step(g["action"][i], board_shift(model, float(g["board_z"][i])), am, ar)
-        assert emu.status.value == 0
-        e = np.abs(obs - g["obs"][i])
-        e_q.append(e[:27].max()); e_vel.append(e[27:33].max()); e_pos.append(max(e[33:39].max(), e[42:45].max())); e_rot.append(e[39:42].max())
-        e_rew.append(abs(rew - g["reward"][i])); assert suc == int(g["success"][i])
-        assert e[45] < 1e-3
-    e_q, e_pos, e_vel, e_rot = map(np.array, (e_q, e_pos, e_vel, e_rot))
-    assert e_q.max() < 1e-4 and e_pos.max() < 2e-4, (e_q.max(), e_pos.max())
-    assert np.median(e_vel) < 5e-3 and np.quantile(e_vel, 0.9) < 6e-2 and e_vel.max() < 0.5, (np.median(e_vel), np.quantile(e_vel, 0.9), e_vel.max())
-    assert np.median(e_rot) < 1e-4 and e_rot.max() < 5e-3, (np.median(e_rot), e_rot.max())
-    assert np.median(e_rew) < 1e-4 and max(e_rew) < 5e-3
+        o, r, suc = emu.adroit_step(g["action"][i], g["shift"][i], am, ar, target=g["target"][i])
+        assert emu.status.value == 0 and suc == int(g["success"][i])
+        obs.append(o); rew.append(r)
+    print(check(task, np.array(obs), g["obs"][idx], np.array(rew), g["reward"][idx]))
 
 
-def test_emulated_reset_forward_matches_golden(model):
+@pytest.mark.parametrize("task", ["hammer", "door", "pen", "relocate"])
+def test_emulated_reset_forward_matches_golden(task):
     from emu_sim import EmuSim
 
-    from gymnasium_robotics_amd.envs.adroit_spec import action_scaling, board_shift, make_adroit_task
+    from gymnasium_robotics_amd.envs.adroit_spec import action_scaling, load_adroit_model, make_adroit_task
 
-    g = np.load(os.path.join(GOLDEN, "adroit_hammer_teacher.npz"))
-    emu = EmuSim(model, make_adroit_task(model, "dense"))
+    model = load_adroit_model(task)
+    g = np.load(os.path.join(GOLDEN, f"adroit_{task}_teacher.npz"))
+    emu = EmuSim(model, make_adroit_task(model, "dense", task))
     am, ar = action_scaling(model)
     for k in range(len(g["reset_seed"])):
         emu.qpos[:], emu.qvel[:], emu.qacc_ws[:] = model.tables["qpos0"], 0, 0
-        obs, _, _ = emu.adroit_step(np.zeros(26, np.float32), board_shift(model, float(g["reset_board_z"][k])), am, ar, forward_only=True)
+        obs, _, _ = emu.adroit_step(np.zeros(model.dim("nu"), np.float32), g["reset_shift"][k], am, ar, forward_only=True, target=g["reset_target"][k])
         assert np.abs(obs - g["reset_obs"][k]).max() < 1e-6
+
+
+def test_reset_draws_follow_the_reference_order():
+    """sample_reset: the draws of each reset_model in the reference's order, and the engine state they turn into (shift offset / rotation, target)."""
+    from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_model, sample_reset
+    from gymnasium_robotics_amd.envs.manipulate_spec import euler2quat
+
+    mk = lambda: np.random.Generator(np.random.PCG64(np.random.SeedSequence(7)))
+    m = load_adroit_model("door")
+    d, r = sample_reset("door", mk(), m), mk()
+    want = np.array([r.uniform(low=-0.3, high=-0.2), r.uniform(low=0.25, high=0.35), r.uniform(low=0.252, high=0.35)])     # adroit_door.py:362-370
+    assert np.array_equal(d["edit"], want) and np.allclose(d["shift"][:3], want - np.array(m.info["shift_pos0"])) and np.array_equal(d["shift"][3:], [1, 0, 0, 0])
+    m = load_adroit_model("pen")
+    d, r = sample_reset("pen", mk(), m), mk()
+    q = euler2quat(np.array([r.uniform(low=-1, high=1), r.uniform(low=-1, high=1), 0.0]))                                    # adroit_pen.py:380-383
+    assert np.array_equal(d["edit"], q) and np.allclose(d["shift"][3:], q)
+    # the rotation is about the target body's origin: the origin itself stays where it is
+    from gymnasium_robotics_amd.envs.adroit_spec import _quat2mat
+    p0 = np.array(m.info["shift_pos0"])
+    assert np.allclose(_quat2mat(d["shift"][3:]) @ p0 + d["shift"][:3], p0)
+    m = load_adroit_model("relocate")
+    d, r = sample_reset("relocate", mk(), m), mk()
+    ox, oy = r.uniform(low=-0.15, high=0.15), r.uniform(low=-0.15, high=0.3)                                                 # adroit_relocate.py:353-372
+    tg = np.array([r.uniform(low=-0.2, high=0.2), r.uniform(low=-0.2, high=0.2), r.uniform(low=0.15, high=0.35)])
+    assert np.array_equal(d["target"], tg) and np.allclose(d["shift"][:3], [ox - m.info["shift_pos0"][0], oy - m.info["shift_pos0"][1], 0.0])

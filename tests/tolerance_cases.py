@@ -22,8 +22,12 @@ CASES = {
     "HandBlock": ("HandManipulateBlockRotateXYZ-v1", "hand_BlockRotateXYZ_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": HAND_POS, "velocities": HAND_VEL}),
     "HandEgg": ("HandManipulateEggRotate-v1", "hand_EggRotate_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": HAND_POS, "velocities": HAND_VEL}),
     "HandPen": ("HandManipulatePenRotate-v1", "hand_PenRotate_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": HAND_POS, "velocities": HAND_VEL}),
-    "AdroitHammer": ("AdroitHandHammer-v2", "adroit_hammer_teacher.npz", ("qpos", "qvel", "qacc_ws"),
+    "AdroitHammer": ("AdroitHandHammer-v2", "adroit_hammer_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift"),
                      {"qpos": np.r_[0:27], "positions": np.r_[33:39, 42:45], "hammer_euler": np.r_[39:42], "hammer_velocity": np.r_[27:33]}),
+    "AdroitDoor": ("AdroitHandDoor-v2", "adroit_door_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift"), {"qpos": np.r_[0:29], "positions": np.r_[29:38]}),
+    "AdroitPen": ("AdroitHandPen-v2", "adroit_pen_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift"),
+                  {"qpos": np.r_[0:24], "pen_position_orientation": np.r_[24:27, 33:36, 39:45], "pen_velocity": np.r_[27:33]}),
+    "AdroitRelocate": ("AdroitHandRelocate-v2", "adroit_relocate_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift", "target"), {"qpos": np.r_[0:30], "positions": np.r_[30:39]}),
 }
 
 
@@ -40,8 +44,6 @@ def family_errors(name):
     env.reset(seed=0)
     for k in keys:
         getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
-    if name == "AdroitHammer":
-        env.shift[:, 2] = torch.from_numpy((g["board_z"] - env._board_z0).astype(np.float32)).to(env.device)
     out = env.step(g["action"])
     obs = out[0]["observation"] if isinstance(out[0], dict) else out[0]
     e = np.abs(obs - g["obs"])

@@ -75,3 +75,12 @@ for layout in ("UMaze", "Open", "Medium", "Large"):
     out = os.path.join(OUT, f"ant_{layout}.npz")
     save_model(m, out)
     print("ant.xml +", layout, "walls ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "ngeom", "npair")}, f"{os.path.getsize(out) / 1024:.0f} KiB")
+
+from gymnasium_robotics_amd.envs.adroit_spec import SPECS as ADROIT_SPECS, apply_actuator_overrides  # noqa: E402
+
+for task, spec in ADROIT_SPECS.items():
+    m = apply_actuator_overrides(compile_mjcf(os.path.join(ASSETS, "adroit_hand", spec["xml"]), **spec["compile"]))   # the constructors' gain / bias rewrite is baked in
+    out = os.path.join(OUT, spec["npz"])
+    save_model(m, out)
+    print(f"adroit_hand/{spec['xml']} ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "nsite", "npair")}, "unsupported pairs:", m.info["unsupported_pairs"],
+          f"{os.path.getsize(out) / 1024:.0f} KiB")
