@@ -40,6 +40,10 @@ WORKLOADS = {
     "hand_reach": dict(env_id="HandReach-v3", worlds=16384, kernel="grx_hand_step_kernel", algo=1035, horizon=50),   # r 24+24+24+20, w 72, out 63+15+15+1
     "antmaze": dict(env_id="AntMaze_Large_Diverse_GR-v5", worlds=8192, kernel="grx_point_step_kernel", algo=507, horizon=1000),
     "adroit": dict(env_id="AdroitHandHammer-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=1098, horizon=200),   # cfg 5b (5 substeps + noslip)
+    # the other Adroit tasks; algorithmic bytes = 4 * (r: nq + 2 nv + nu + 7 (+3) | w: nq + 2 nv | out: obs + 1) + 2
+    "adroit_door": dict(env_id="AdroitHandDoor-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=4 * (30 + 60 + 28 + 7 + 90 + 40) + 2, horizon=200),
+    "adroit_pen": dict(env_id="AdroitHandPen-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=4 * (30 + 60 + 24 + 7 + 90 + 46) + 2, horizon=200),
+    "adroit_relocate": dict(env_id="AdroitHandRelocate-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=4 * (36 + 72 + 30 + 10 + 108 + 40) + 2, horizon=200),
 }
 HER_K = 4  # relabelled goals per transition ("future" strategy with k=4); 28 B per relabelled transition
 HBM_PEAK_GBS = 8000.0
@@ -54,8 +58,8 @@ def make_env(workload, n, device, rank):
         from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv as Env
     elif workload == "hand_reach":
         from gymnasium_robotics_amd.envs.hand import HandReachVecEnv as Env
-    elif workload == "adroit":
-        from gymnasium_robotics_amd.envs.adroit import AdroitHammerVecEnv as Env
+    elif workload.startswith("adroit"):
+        from gymnasium_robotics_amd.envs.adroit import AdroitVecEnv as Env
     else:
         from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv as Env
     return Env(w["env_id"], **kw)
@@ -74,10 +78,12 @@ def _oracle_env(workload):
         layout = parse_ant_maze_id(WORKLOADS[workload]["env_id"])[0]
         maze = Maze(MAPS[layout], ANT_MAZE_SIZE_SCALING, ANT_MAZE_HEIGHT)
         return OracleAntMazeEnv(load_point_maze_model(maze, layout, None, "ant"), maze), 8
-    if workload == "adroit":
-        from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_hammer_model
-        from oracle.adroit_oracle import OracleAdroitHammerEnv
-        return OracleAdroitHammerEnv(load_adroit_hammer_model()), 26
+    if workload.startswith("adroit"):
+        from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_model, parse_adroit_id
+        from oracle.adroit_oracle import OracleAdroitEnv
+        task = parse_adroit_id(WORKLOADS[workload]["env_id"])[0]
+        model = load_adroit_model(task)
+        return OracleAdroitEnv(model, "dense", task), model.dim("nu")
     if workload == "hand_reach":
         from gymnasium_robotics_amd.envs.hand import load_hand_reach_model
         from oracle.hand_oracle import OracleHandReachEnv
@@ -146,16 +152,22 @@ def run_rank(args, rank, world_size, local_rank):
         out_rows = env.obs   # plain (non-goal) environments: the observation rows are the per-step output
     gathered = torch.empty(n * world_size, out_rows.shape[1], device=device) if dist else None
     her = args.workload == "fetch"
-    # HER "future"-style relabelling with HER_K substituted goals per transition: the substitution pattern is drawn once (K rolled copies of
-    # one permutation), each step gathers the goals and recomputes the rewards on the device
-    her_idx = torch.stack([torch.roll(torch.randperm(n, device=device, generator=gen), k) for k in range(HER_K)]) if her else None
+    # HER "future" relabelling on the device (gymnasium_robotics_amd/her.py): the packed rows of the last `horizon` steps stay in an HBM ring; every
+    # step ONE kernel gathers HER_K relabelled transitions per world (goal substitution + reward recompute + replay write)
+    replay = None
+    if her:
+        from gymnasium_robotics_amd.her import HerReplay
+
+        replay = HerReplay(env, horizon=w["horizon"], capacity=HER_K * n * 8, seed=rank, continuous=True)
+        replay.begin_episode(env.packed)
+        replay.episode_start.copy_(torch.from_numpy(-env._elapsed.astype(np.int32)).to(device))   # staggered: world i is elapsed[i] steps into its episode
 
     def one_step():
         a = torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1
         obs, r, term, trunc, info = env.step(a)
-        if her:   # HER relabel: reward recompute for HER_K substituted goals per transition
-            ag = obs["achieved_goal"].unsqueeze(0).expand(HER_K, n, 3).contiguous()
-            env.compute_reward(ag, obs["desired_goal"][her_idx], None)
+        if her:
+            replay.append(a, env.packed, (term | trunc).to(device, non_blocking=True))
+            replay.relabel(HER_K * n, k_future=HER_K)
         if dist:   # the step kernel wrote the packed [obs | achieved | desired | reward | success] rows: one collective, no pack kernels
             dist.all_gather_into_tensor(gathered, out_rows)
 
@@ -199,7 +211,7 @@ def run_rank(args, rank, world_size, local_rank):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{w['env_id']}, {n} worlds/GPU x {world_size} GPU, uniform random actions, same-step autoreset at the time limit "
                                    f"({'episodes staggered: every step resets its share of the worlds' if args.stagger else 'episodes in lock-step'})"
-                                   + (f", sparse reward + HER recompute (k={HER_K})" if her else ""),
+                                   + (f", sparse reward + on-device HER relabel + replay write ({HER_K} transitions per world and step, future k={HER_K})" if her else ""),
                        "worlds_per_gpu": n, "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather of kernel-packed output rows per step" if world_size > 1 else ""),
                        "capacity_overflow_worlds": counts["con_overflow"] + counts["efc_overflow"], "badnum_worlds": counts["badnum"],
                        "status_note": "worlds (of rank 0) whose sticky status flagged a dropped contact / bad number at least once in the timed region"},

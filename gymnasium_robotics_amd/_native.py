@@ -40,6 +40,12 @@ class AdroitBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")]
 
 
+class HerArgsStruct(ctypes.Structure):
+    _fields_ = [("rows", ctypes.c_void_p), ("acts", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in ("T", "N", "W", "obs_dim", "goal_dim", "act_dim")] + [
+        (n, ctypes.c_void_p) for n in ("t_idx", "w_idx", "t_goal")] + [("kind", ctypes.c_int), ("p0", ctypes.c_float), ("p1", ctypes.c_float)] + [
+        (n, ctypes.c_int) for n in ("sparse", "ignore_pos", "ignore_rot", "ignore_z")] + [("out", ctypes.c_void_p)]
+
+
 class HandBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost", "packed")]
@@ -64,6 +70,7 @@ def lib():
         L.grx_fetch_forward.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_fetch_reset.argtypes = [vp, vp, vp, vp, ci, vp]
         L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
+        L.grx_her_relabel.argtypes = [vp, ctypes.c_int64, vp]
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
@@ -84,5 +91,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
 ]

@@ -572,6 +572,62 @@ grx_fetch_reward_kernel(const float* __restrict__ ag, const float* __restrict__ 
   }
 }
 
+// HER relabel + replay write (the caller of compute_reward: /root/reference/README.md:72-76, core.py:45-67).  Episode storage on the device: a ring of
+// R = T + 1 rows per world, rows[r] = the packed output row [obs | achieved | desired | reward | success] the step kernels write (a reset row or the
+// row after a step), acts[r] = the action that LED to row r.  Row indices are absolute step counts, taken modulo R here (an episode buffer of T steps is
+// the special case that never wraps).  Sample b = (row t_idx[b], world w_idx[b], goal row t_goal[b]): the transition (row t -> action -> row t + 1)
+// with the desired goal replaced by the goal ACHIEVED at row t_goal (t_goal < 0: the episode's own goal), its reward recomputed with the very
+// device functions compute_reward uses, written as one packed replay row
+//     [obs_t | achieved_t | goal | action_t | reward | obs_t+1 | achieved_t+1 | success]          (OW = 2 obs_dim + 3 goal_dim + act_dim + 2)
+// One thread per output word (coalesced stores, gathers of whole rows): the trajectories never leave HBM.
+struct GrxHerArgs {
+  const float* rows; const float* acts;
+  int T, N, W, obs_dim, goal_dim, act_dim;
+  const int *t_idx, *w_idx, *t_goal;
+  int kind;            // 0: Euclidean goals with a distance threshold (Fetch: -(d > thr) / -d), 1: same with the hand's -0.0 convention (HandReach), 2: maze, 3: manipulate pose goals
+  float p0, p1;        // kind 0 / 1: threshold; 2: goal radius; 3: position threshold, rotation threshold
+  int sparse, ignore_pos, ignore_rot, ignore_z;
+  float* out;
+};
+GRX_DEV void grx_her_outcome(const GrxHerArgs& a, const float* ag, const float* g, float* reward, float* success) {
+  if (a.kind == 3) {
+    float dp, dr;
+    grx_manip_distance(ag, g, a.ignore_pos, a.ignore_rot, a.ignore_z, &dp, &dr);
+    *reward = grx_manip_reward(dp, dr, a.p0, a.p1, a.sparse); *success = grx_manip_success(dp, dr, a.p0, a.p1) ? 1.0f : 0.0f;
+  } else if (a.kind == 2) {
+    const float d = grx_goal_distance2(ag, g);
+    *reward = grx_maze_reward(d, a.p0, a.sparse); *success = (d <= a.p0) ? 1.0f : 0.0f;
+  } else if (a.kind == 1) {
+    const float d = grx_goal_distance_n(ag, g, a.goal_dim);
+    *reward = grx_hand_reward(d, a.p0, a.sparse); *success = (d < a.p0) ? 1.0f : 0.0f;
+  } else {
+    const float d = grx_goal_distance3(ag, g);
+    *reward = grx_fetch_reward(d, a.p0, a.sparse); *success = (d < a.p0) ? 1.0f : 0.0f;
+  }
+}
+extern "C" __global__ void __launch_bounds__(256)
+grx_her_relabel_kernel(GrxHerArgs a, long long B) {
+  const int od = a.obs_dim, gd = a.goal_dim, ad = a.act_dim, OW = 2 * od + 3 * gd + ad + 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B * OW; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / OW; const int e = (int)(i - b * OW);
+    const int R = a.T + 1, t = a.t_idx[b] % R, t1 = (a.t_idx[b] + 1) % R, w = a.w_idx[b], tg = a.t_goal[b];
+    const float* r0 = a.rows + ((size_t)t * a.N + w) * a.W;
+    const float* r1 = a.rows + ((size_t)t1 * a.N + w) * a.W;
+    const float* g = tg < 0 ? r0 + od + gd : a.rows + ((size_t)(tg % R) * a.N + w) * a.W + od;   // the substituted goal: achieved at row tg
+    float v;
+    if (e < od + gd) v = r0[e];
+    else if (e < od + 2 * gd) v = g[e - od - gd];
+    else if (e < od + 2 * gd + ad) v = a.acts[((size_t)t1 * a.N + w) * ad + (e - od - 2 * gd)];
+    else if (e == od + 2 * gd + ad || e == OW - 1) {
+      float ag[16], gg[16], rw, sc;
+      for (int k = 0; k < gd; k++) { ag[k] = r1[od + k]; gg[k] = g[k]; }
+      grx_her_outcome(a, ag, gg, &rw, &sc);
+      v = (e == OW - 1) ? sc : rw;
+    } else v = r1[e - (od + 2 * gd + ad + 1)];
+    a.out[i] = v;
+  }
+}
+
 // unit-test hook for the two GPU-specific numerical primitives (register-resident solve, MFMA Hessian)
 extern "C" __global__ void __launch_bounds__(64)
 grx_debug_kernel(int mode, int nv, int nefc, const float* A_in, const float* b_in, const float* J_in, const float* D_in, float* out) {
@@ -892,6 +948,23 @@ extern "C" int grx_maze_compute_reward(const float* achieved, const float* desir
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(grx_maze_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, achieved, desired, (long long)batch, goal_radius,
                      sparse, reward_out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int grx_her_relabel(const grx_her_args* args, int64_t batch, void* stream) {
+  if (!args) return fail("grx_her_relabel: null argument");
+  GrxHerArgs a; memcpy(&a, args, sizeof(a));
+  if (!a.rows || !a.acts || !a.t_idx || !a.w_idx || !a.t_goal || !a.out) return fail("grx_her_relabel: null buffer");
+  if (a.T <= 0 || a.N <= 0 || a.obs_dim <= 0 || a.goal_dim <= 0 || a.goal_dim > 16 || a.act_dim <= 0 || a.W < a.obs_dim + 2 * a.goal_dim)
+    return fail("grx_her_relabel: dimensions out of range (goal_dim <= 16, W >= obs_dim + 2 goal_dim)");
+  if (a.kind < 0 || a.kind > 3 || (a.kind == 0 && a.goal_dim != 3) || (a.kind == 2 && a.goal_dim != 2) || (a.kind == 3 && a.goal_dim != 7))
+    return fail("grx_her_relabel: reward kind does not fit goal_dim");
+  if (batch <= 0) return 0;
+  const long long words = (long long)batch * (2 * a.obs_dim + 3 * a.goal_dim + a.act_dim + 2);
+  long long blocks = (words + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(grx_her_relabel_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (long long)batch);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -400,6 +400,8 @@ class HandBlockVecEnv(HandReachVecEnv):
         obj = self.qpos[ti, self._qa: self._qa + 7].double().cpu().numpy()
         goals = sample_block_goal_batch([self.np_randoms[w] for w in idx], obj, self.target_position, self.target_rotation, self._pquats)
         self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
+        gd = self.goal.shape[1]   # the settle launches wrote the packed rows against the PREVIOUS goal: the reset row carries the new one
+        self.packed[ti, self.obs_dim + gd: self.obs_dim + 2 * gd] = self.goal[ti]
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
 

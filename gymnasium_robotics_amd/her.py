@@ -1,0 +1,143 @@
+"""Hindsight-experience-replay storage and relabelling on the device -- the caller of ``GoalEnv.compute_reward``.
+
+The reference documents the use (README.md:72-76, gymnasium_robotics/core.py:45-67): "substitute a goal and recompute the reward":
+
+    env.unwrapped.compute_reward(obs["achieved_goal"], substituted_goal, info)
+
+With thousands of worlds stepped per launch, doing that through the host would move every trajectory over PCIe.  Here the episode rows the step
+kernels already write (``env.packed`` = ``[obs | achieved | desired | reward | success]`` per world) are appended to a device buffer, and ONE kernel
+(``grx_her_relabel``) gathers a batch of transitions, substitutes the goals ("future" strategy: a goal achieved later in the same episode, with
+probability k / (k + 1)), recomputes reward and success with the device functions behind ``compute_reward`` and writes packed replay rows
+
+    [obs_t | achieved_t | goal | action_t | reward | obs_t+1 | achieved_t+1 | success]
+
+into a device ring buffer.  Nothing leaves HBM; the learner reads ``replay.rows``.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native
+
+FETCH, HAND_REACH, MAZE, MANIPULATE = 0, 1, 2, 3
+
+
+def reward_spec(env) -> dict:
+    """kind / thresholds / flags of grx_her_relabel for a goal-conditioned device environment (the same parameters its compute_reward uses)"""
+    name = type(env).__name__
+    sparse = int(getattr(env, "reward_type", "sparse") == "sparse")
+    if name == "FetchVecEnv":
+        return dict(kind=FETCH, p0=float(env.task.distance_threshold), p1=0.0, sparse=sparse)
+    if name == "HandReachVecEnv":
+        return dict(kind=HAND_REACH, p0=float(env.distance_threshold), p1=0.0, sparse=sparse)
+    if name in ("PointMazeVecEnv", "AntMazeVecEnv"):
+        return dict(kind=MAZE, p0=0.45, p1=0.0, sparse=sparse)
+    if name == "HandBlockVecEnv":   # the arguments of its grx_manip_compute_reward call (envs/hand.py:_launch_reward)
+        from .envs.manipulate_spec import ROTATION_THRESHOLD
+
+        return dict(kind=MANIPULATE, p0=float(env.distance_threshold), p1=float(ROTATION_THRESHOLD), sparse=sparse, ignore_pos=int(env.target_position == "ignore"),
+                    ignore_rot=int(env.target_rotation == "ignore"), ignore_z=int(env._objcfg["ignore_z_target_rotation"]))
+    raise TypeError(f"{name} is not a goal-conditioned environment")
+
+
+class HerReplay:
+    """A ring of the last `horizon` + 1 output rows of every world + the actions that led to them + a replay ring [capacity, OW], all on the
+    environment's device.  Episodes may start at different steps in different worlds (same-step autoreset): `episode_start[w]` is the row at which
+    world w's current episode began, and only rows of the current episode that are still in the ring are sampled.
+
+        buf = HerReplay(env, horizon=50, capacity=1 << 20)
+        obs, _ = env.reset(seed=0); buf.begin_episode(env.packed)
+        for t in range(50):
+            obs, r, term, trunc, info = env.step(a); buf.append(a, env.packed)        # append(..., reset_mask) when worlds were autoreset in this step
+        buf.relabel(batch=4 * env.num_envs, k_future=4)        # one kernel: gather + goal substitution + reward recompute + replay write
+    """
+
+    def __init__(self, env, horizon: int, capacity: int, obs_dim: Optional[int] = None, goal_dim: Optional[int] = None, seed: int = 0, continuous: bool = False):
+        self.env, self.T, self.N = env, int(horizon), int(env.num_envs)
+        self.device = env.device
+        self.W = int(env.packed.shape[1])
+        self.goal_dim = int(goal_dim if goal_dim is not None else env.single_observation_space["desired_goal"].shape[0])
+        self.obs_dim = int(obs_dim if obs_dim is not None else self.W - 2 * self.goal_dim - 2)
+        self.act_dim = int(env.single_action_space.shape[0])
+        self.OW = 2 * self.obs_dim + 3 * self.goal_dim + self.act_dim + 2
+        self.spec = reward_spec(env)
+        self.continuous = bool(continuous)        # False: append() past `horizon` steps is an error (one episode per buffer); True: the ring wraps
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=self.device)
+        self.R = self.T + 1
+        self.episode, self.actions = z(self.R, self.N, self.W), z(self.R, self.N, self.act_dim)   # actions[r] = the action that led to row r
+        self.episode_start = z(self.N, dtype=torch.int32)
+        self.rows, self.capacity, self.head, self.size = z(int(capacity), self.OW), int(capacity), 0, 0
+        self.t = 0                                 # absolute index of the newest row
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+        self._L = _native.lib()
+
+    # ---------------------------------------------------------------- episode storage (device copies of what the step kernel wrote)
+    def begin_episode(self, packed_rows: torch.Tensor):
+        self.episode[0].copy_(packed_rows)
+        self.episode_start.zero_()
+        self.t = 0
+
+    def append(self, actions: torch.Tensor, packed_rows: torch.Tensor, reset_mask: Optional[torch.Tensor] = None):
+        """row t + 1 <- the rows of this step.  reset_mask (bool [N], device): worlds that were autoreset inside this step -- their row is the first one
+        of a new episode (the finished episode's last next-observation went to info["final_obs"], that transition is not stored)."""
+        if self.t >= self.T and not self.continuous:
+            raise RuntimeError("episode buffer is full: call begin_episode()")
+        self.t += 1
+        r = self.t % self.R
+        self.actions[r].copy_(actions)
+        self.episode[r].copy_(packed_rows)
+        if reset_mask is not None:
+            self.episode_start.masked_fill_(reset_mask, self.t)
+
+    # ---------------------------------------------------------------- sampling + the fused relabel kernel
+    def sample_indices(self, batch: int, k_future: int = 4):
+        """(t, world, t_goal): a uniform world, a uniform transition of that world's current episode among the rows still in the ring; with
+        probability k / (k + 1) the goal achieved at a uniformly drawn LATER row of the same episode (the "future" strategy of Andrychowicz et al.
+        2017), else -1 = keep the episode's goal.  Worlds whose episode has no transition yet (just reset) are not drawn."""
+        g, d = self._gen, self.device
+        lo_all = torch.clamp(self.episode_start, min=max(self.t - self.T, 0))             # first row of the episode that is still stored (rows start at 0)
+        has = (lo_all < self.t).to(torch.float32)                                         # worlds whose current episode has a transition already
+        w = torch.multinomial(has, batch, replacement=True, generator=g).to(torch.int32)  # uniform over those worlds (no host sync)
+        lo = lo_all[w.long()]
+        u = torch.rand(2, batch, device=d, generator=g)
+        t = lo + torch.clamp((u[0] * (self.t - lo).to(torch.float32)).to(torch.int32), max=self.t)       # floor(U * span) in [0, span)
+        t = torch.minimum(t, torch.full_like(t, self.t - 1))
+        fut = t + 1 + (u[1] * (self.t - t).to(torch.float32)).to(torch.int32)
+        fut = torch.minimum(fut, torch.full_like(fut, self.t))
+        keep = torch.rand(batch, device=d, generator=g) >= k_future / (k_future + 1.0)
+        return t, w, torch.where(keep, torch.full_like(fut, -1), fut)
+
+    def relabel_into(self, out: torch.Tensor, t: torch.Tensor, w: torch.Tensor, t_goal: torch.Tensor):
+        """the kernel alone: out[b] <- relabelled transition (t[b], w[b], t_goal[b]); int32 index tensors on the device"""
+        a = _native.HerArgsStruct()
+        a.rows, a.acts = self.episode.data_ptr(), self.actions.data_ptr()
+        a.T, a.N, a.W, a.obs_dim, a.goal_dim, a.act_dim = self.T, self.N, self.W, self.obs_dim, self.goal_dim, self.act_dim   # ring of T + 1 rows
+        a.t_idx, a.w_idx, a.t_goal, a.out = t.data_ptr(), w.data_ptr(), t_goal.data_ptr(), out.data_ptr()
+        for k, v in self.spec.items():
+            setattr(a, k, v)
+        assert out.is_contiguous() and tuple(out.shape) == (len(t), self.OW) and t.dtype == w.dtype == t_goal.dtype == torch.int32
+        _native.check(self._L.grx_her_relabel(ctypes.byref(a), len(t), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
+
+    def relabel(self, batch: int, k_future: int = 4):
+        """sample + relabel + write `batch` rows at the head of the replay ring; returns the view of the rows just written"""
+        if batch > self.capacity:
+            raise ValueError("batch larger than the replay capacity")
+        if self.head + batch > self.capacity:
+            self.head = 0                                    # keep every batch contiguous (a ring of whole batches)
+        t, w, tg = self.sample_indices(batch, k_future)
+        view = self.rows[self.head: self.head + batch]
+        self.relabel_into(view, t, w, tg)
+        self.head += batch
+        self.size = min(self.capacity, max(self.size, self.head))
+        return view
+
+    # ---------------------------------------------------------------- views of a replay row
+    def split(self, rows: torch.Tensor) -> dict:
+        o, g, a = self.obs_dim, self.goal_dim, self.act_dim
+        c = np.cumsum([0, o, g, g, a, 1, o, g, 1])
+        names = ("observation", "achieved_goal", "desired_goal", "action", "reward", "next_observation", "next_achieved_goal", "success")
+        return {n: rows[:, c[i]: c[i + 1]] for i, n in enumerate(names)}

@@ -199,6 +199,24 @@ int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t
 int grx_manip_compute_reward(const float* achieved, const float* desired, int64_t batch, int ignore_position, int ignore_rotation,
                              int ignore_z, float distance_threshold, float rotation_threshold, int sparse, float* reward_out, void* stream);
 
+/* On-device HER relabel + replay write -- the caller of GoalEnv.compute_reward (/root/reference/README.md:72-76, gymnasium_robotics/core.py:45-67:
+ * "substitute the goal, recompute the reward").  rows: [T+1, N, W] a ring of the packed output rows the step kernels write ([obs | achieved |
+ * desired | reward | success]; a reset row or the row after a step), acts: [T+1, N, act_dim], acts[r] = the action that led to row r.  Row indices are
+ * absolute step counts, used modulo T+1 (an episode buffer of T steps never wraps: row 0 = the reset, acts[0] unused).  For sample b the transition
+ * from row t_idx[b] of world w_idx[b] is written to out[b] = [obs_t | achieved_t | goal | action_t | reward | obs_t+1 | achieved_t+1 | success] with
+ * goal = the goal achieved at row t_goal[b] (t_goal[b] < 0: the episode's own goal) and reward / success recomputed from (achieved_t+1, goal) by the
+ * device functions behind grx_*_compute_reward.  All pointers are device pointers. */
+typedef struct grx_her_args {
+  const float* rows; const float* acts;
+  int T, N, W, obs_dim, goal_dim, act_dim;
+  const int *t_idx, *w_idx, *t_goal;   /* [batch] */
+  int kind;                            /* 0 Fetch (fetch_env.py:74-80), 1 HandReach (reach.py:92-100: -0.0 for success), 2 maze (maze_v4.py:381-388), 3 manipulate poses (manipulate.py:87-142) */
+  float p0, p1;                        /* 0 / 1: distance_threshold; 2: goal radius 0.45; 3: distance_threshold, rotation_threshold */
+  int sparse, ignore_pos, ignore_rot, ignore_z;
+  float* out;                          /* [batch, 2 obs_dim + 3 goal_dim + act_dim + 2] */
+} grx_her_args;
+int grx_her_relabel(const grx_her_args* args, int64_t batch, void* stream);
+
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's
  * numpy PCG64 (created and seeded by numpy on the Python side), advanced in place.  All pointers are HOST pointers. */
