@@ -164,6 +164,12 @@ class HandReachVecEnv(GoalVecEnv):
         self.initial_goal = self.achieved[0].double().cpu().numpy().copy()
         self.palm_xpos = self.palm[0].double().cpu().numpy().copy()
 
+    def _begin_overlapped_reset(self):
+        return None
+
+    def _cancel_chains(self):
+        pass
+
     # ------------------------------------------------------------------ reset (robot_env.py:154-182, 300-313; reach.py:99-126)
     def _reset_worlds(self, idx):
         if len(idx) == 0:
@@ -185,6 +191,7 @@ class HandReachVecEnv(GoalVecEnv):
             seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
             self.np_randoms = [np_random(s)[0] for s in seeds]
         with torch.cuda.device(self.device):
+            self._cancel_chains()
             self._reset_worlds(np.arange(self.num_envs))
         self._has_reset = True
         return self._obs_dict(), {}
@@ -199,6 +206,7 @@ class HandReachVecEnv(GoalVecEnv):
         self.action.copy_(a.to(torch.float32), non_blocking=True)
         with torch.cuda.device(self.device):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
+            spec = self._begin_overlapped_reset() if self.autoreset_mode == "same_step" else None
             if len(pending):
                 self.mask.fill_(1)
                 self.mask[torch.from_numpy(pending).to(self.device)] = 0
@@ -220,7 +228,10 @@ class HandReachVecEnv(GoalVecEnv):
                 td = torch.from_numpy(done).to(self.device)
                 info["final_obs"] = self._obs_dict(rows=done)   # the terminal observation (bootstrapping), as FetchVecEnv reports it
                 keep_r, keep_s, keep_st = self.reward.clone(), self.success.clone(), self.status.clone()
-                self._reset_worlds(done)
+                if spec is not None:
+                    self._finish_overlapped_reset(spec, done)
+                else:
+                    self._reset_worlds(done)
                 self.reward.copy_(keep_r)
                 self.success.copy_(keep_s)
                 self.status.copy_((keep_st & 0xFFFF) | (self.status & -65536))   # this step's flags are the step launch's, not the reset launches'; sticky bits keep accumulating
@@ -372,12 +383,17 @@ class HandBlockVecEnv(HandReachVecEnv):
     # holds -- robot_env.py:163-171) and :226-279 (_sample_goal from the settled pose).  The reference does not call mj_resetData
     # here, so the warm start of the previous episode survives the reset.
     def _reset_worlds(self, idx):
-        from .manipulate_spec import PALM_HEIGHT, SETTLE_STEPS, sample_block_goal_batch, sample_reset_object_pose_batch
-
         if len(idx) == 0:
             return
         pending = np.asarray(idx, dtype=np.int64)
         self.reset_attempts[pending] = 0
+        self._settle_until_on_palm(pending)
+        self._sample_goals(idx)
+
+    def _settle_until_on_palm(self, pending):
+        """the retry loop of robot_env.py:163-171 around _reset_sim (manipulate.py:154-224) for the listed worlds, in the main buffers"""
+        from .manipulate_spec import PALM_HEIGHT, SETTLE_STEPS, sample_reset_object_pose_batch
+
         saved_action = self.action.clone()
         while len(pending):
             self.reset_attempts[pending] += 1
@@ -396,6 +412,10 @@ class HandBlockVecEnv(HandReachVecEnv):
             z = self.qpos[ti, self._qa + 2].cpu().numpy()
             pending = pending[~(z > PALM_HEIGHT)]
         self.action.copy_(saved_action)
+
+    def _sample_goals(self, idx):
+        from .manipulate_spec import sample_block_goal_batch
+
         ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
         obj = self.qpos[ti, self._qa: self._qa + 7].double().cpu().numpy()
         goals = sample_block_goal_batch([self.np_randoms[w] for w in idx], obj, self.target_position, self.target_rotation, self._pquats)
@@ -404,6 +424,110 @@ class HandBlockVecEnv(HandReachVecEnv):
         self.packed[ti, self.obs_dim + gd: self.obs_dim + 2 * gd] = self.goal[ti]
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
+
+    # ---- same-step autoreset at the time limit, overlapped with the step launches.  Which worlds hit the limit in a step() is known in advance
+    # (manipulate envs never terminate early: compute_terminated is always False, core.py:100-101), and their reset needs nothing from the last
+    # steps of the old episode except the solver's warm start.  The ten settle steps are ten DEPENDENT launches of ~1.8 ms each however few worlds they
+    # carry (one wavefront's latency through 20 substeps) -- 18 ms against the 12 ms step of 16 384 worlds.  So the settle chain of the worlds that
+    # will hit the limit at the NEXT step is started now, on a high-priority side stream over a compacted side arena, and runs underneath two step
+    # launches; when its worlds are done the settled state is scattered into the main buffers.  Same draws, same kernels, same number of settle steps
+    # as the sequential path; the one difference: the settle's first solve starts from the warm start the world had when the chain was started (one or
+    # two steps before the end of the episode) instead of the one left by the final step.
+    def _arena(self):
+        if getattr(self, "_ar", None) is None:
+            n, d = 2 * self.num_envs, self.device
+            z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
+            ar = {k: z(n, getattr(self, k).shape[1]) for k in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "packed")}
+            ar.update(reward=z(n), success=z(n, dtype=torch.uint8), status=z(n, dtype=torch.int32))
+            self._ar, self._ar_head, self._chains, self._step_no = ar, 0, [], 0
+            self._chain_started = np.zeros(self.num_envs, bool)
+            self._side = [torch.cuda.Stream(device=d, priority=-1) for _ in range(2)]
+        return self._ar
+
+    def _arena_bufs(self, lo):
+        b = _native.HandBuffersStruct()
+        for name, t in self._ar.items():
+            setattr(b, name, t[lo:].data_ptr())
+        b.mask = b.order = b.cost = None
+        return b
+
+    def _start_chain(self, worlds, due_at):
+        from .manipulate_spec import SETTLE_STEPS, sample_reset_object_pose_batch
+
+        ar, k, cap = self._arena(), len(worlds), 2 * self.num_envs
+        lo = self._ar_head if self._ar_head + k <= cap else 0
+        if any(lo < c["lo"] + c["k"] and c["lo"] < lo + k for c in self._chains):
+            return False                                        # no room next to the chains in flight: these worlds take the sequential path
+        self._ar_head = lo + k
+        self.reset_attempts[worlds] = 1
+        poses = sample_reset_object_pose_batch([self.np_randoms[w] for w in worlds], self._obj0[:3], self._obj0[3:], self.target_position, self.target_rotation,
+                                               self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"])
+        ti = torch.from_numpy(worlds).to(self.device)
+        q = self._initial_qpos.unsqueeze(0).repeat(k, 1)
+        q[:, self._qa: self._qa + 7] = torch.from_numpy(poses.astype(np.float32)).to(self.device)
+        ar["qpos"][lo: lo + k] = q
+        ar["qvel"][lo: lo + k] = 0.0
+        ar["qacc_ws"][lo: lo + k] = self.qacc_ws[ti]
+        ar["goal"][lo: lo + k] = self.goal[ti]
+        ar["status"][lo: lo + k] = 0
+        side = self._side[due_at & 1]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        side.wait_event(ready)
+        bufs, sp = self._arena_bufs(lo), ctypes.c_void_p(side.cuda_stream)
+        for _ in range(SETTLE_STEPS):   # the arena's action rows stay zero: _set_action(np.zeros(20)) (manipulate.py:206-216)
+            _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), k, 0, sp))
+        done = torch.cuda.Event()
+        done.record(side)
+        self._chains.append(dict(worlds=worlds, ti=ti, lo=lo, k=k, due_at=due_at, event=done))
+        self._chain_started[worlds] = True
+        return True
+
+    def _begin_overlapped_reset(self):
+        if self.max_episode_steps is None:
+            return None
+        self._arena()
+        self._step_no += 1
+        rem = self.max_episode_steps - self._elapsed            # steps left before this one
+        fresh = ~self._needs_reset & ~self._chain_started
+        for worlds, due_at in ((np.nonzero(fresh & (rem <= 1))[0], self._step_no), (np.nonzero(fresh & (rem == 2))[0], self._step_no + 1)):
+            if len(worlds):
+                self._start_chain(worlds, due_at)
+        return self._step_no
+
+    def _finish_overlapped_reset(self, step_no, done_idx):
+        from .manipulate_spec import PALM_HEIGHT
+
+        mine = [c for c in self._chains if c["due_at"] <= step_no]
+        self._chains = [c for c in self._chains if c["due_at"] > step_no]
+        covered = np.zeros(self.num_envs, bool)
+        ar, failed = self._ar, []
+        for c in mine:
+            torch.cuda.current_stream(self.device).wait_event(c["event"])
+            lo, k, ti = c["lo"], c["k"], c["ti"]
+            for name in ("qpos", "qvel", "qacc_ws", "obs", "achieved", "palm", "packed"):
+                getattr(self, name)[ti] = ar[name][lo: lo + k]
+            self.status[ti] |= ar["status"][lo: lo + k] & -65536     # sticky flags of the settle steps
+            z = ar["qpos"][lo: lo + k, self._qa + 2].cpu().numpy()
+            failed.append(c["worlds"][~(z > PALM_HEIGHT)])
+            covered[c["worlds"]] = True
+            self._chain_started[c["worlds"]] = False
+        assert not (covered & ~np.isin(np.arange(self.num_envs), done_idx)).any(), "a settle chain finished for a world that is not at its time limit"
+        failed = np.concatenate(failed) if failed else np.zeros(0, np.int64)
+        if len(failed):                                   # object fell off the palm: the sequential retry loop takes over from the state just copied
+            self._settle_until_on_palm(failed)
+        rest = np.asarray(done_idx)[~covered[done_idx]]   # worlds without a chain (no room in the arena): the sequential path
+        if len(rest):
+            self.reset_attempts[rest] = 0
+            self._settle_until_on_palm(rest)
+        self._sample_goals(done_idx)
+
+    def _cancel_chains(self):
+        """reset() / set-state calls: settle chains in flight belong to episodes that no longer exist"""
+        if getattr(self, "_ar", None) is not None:
+            for c in self._chains:
+                c["event"].synchronize()
+            self._chains, self._chain_started[:] = [], False
 
     def _launch_reward(self, ag, dg, out):
         from .manipulate_spec import ROTATION_THRESHOLD as RT
