@@ -68,6 +68,15 @@ class EmuSim:
         return a.view(np.int32) if dtype == np.int32 else a
 
 
+    def physics_steps(self, nstep=1, ctrl=None):
+        """nstep raw physics steps of the loaded state (self.qpos / qvel / qacc_ws); returns (ncon, nefc) of the last one"""
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        c = None if ctrl is None else p(np.ascontiguousarray(ctrl, dtype=np.float32))
+        ncon, nefc = ctypes.c_int(0), ctypes.c_int(0)
+        self.L.emu_physics_steps(ctypes.c_void_p(self.h), p(self.qpos), p(self.qvel), p(self.qacc_ws), c, ctypes.byref(self.status), ctypes.byref(ncon), ctypes.byref(nefc),
+                                 ctypes.c_int(nstep))
+        return ncon.value, nefc.value
+
     def point_step(self, action):
         a = np.ascontiguousarray(action, dtype=np.float32)
         p = lambda x: x.ctypes.data_as(ctypes.c_void_p)

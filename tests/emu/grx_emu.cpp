@@ -95,6 +95,19 @@ void emu_forward(void* h, const GrxFetchTask* t, float* qpos, float* qvel, float
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 
+// nstep raw physics steps of any compiled model (no task code): the engine's mj_step for small hand-written models (condim 6, shift groups ...)
+void emu_physics_steps(void* h, float* qpos, float* qvel, float* qacc_ws, const float* ctrl, int* status, int* ncon, int* nefc, int nstep) {
+  Emu* e = (Emu*)h;
+  float mocap[8] = {0};
+  for (int k = 0; k < e->m.nmocap && k < 1; k++) { memcpy(mocap, e->m.mocap_pos0, 12); memcpy(mocap + 3, e->m.mocap_quat0, 16); }
+  load_state(e, qpos, qvel, qacc_ws, mocap);
+  if (e->m.nshift) { for (int k = 0; k < 7; k++) e->c.shift[k] = (k == 3) ? 1.0f : 0.0f; }
+  for (int k = 0; k < e->m.nu; k++) e->c.ctrl[k] = ctrl ? ctrl[k] : 0.0f;
+  for (int s = 0; s < nstep; s++) GrxEngine<GrxShapeAny>::grx_forward_euler(&e->m, &e->c, 1, 0);
+  *ncon = e->c.cnt[0]; *nefc = e->c.cnt[1];
+  store_state(e, qpos, qvel, qacc_ws, mocap, status);
+}
+
 // PointMaze env.step() of one world
 void emu_point_step(void* h, const GrxPointTask* t, float* qpos, float* qvel, float* qacc_ws, const float* action, float* obs, float* achieved,
                     int* status) {

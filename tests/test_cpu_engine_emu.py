@@ -1,6 +1,7 @@
 """CPU tests of the DEVICE ENGINE SOURCE through the sequential lane emulator (tests/emu), checked against
 the fp64 oracle's golden fixtures.  These validate the kernel logic (not the HIP build) without a GPU."""
 import os
+import types
 
 import numpy as np
 import pytest
@@ -95,3 +96,34 @@ def test_emulated_bad_state_resets_world(emu_factory, fetch_models):
     assert emu.status.value & 1  # GRX_ST_BADNUM
     assert np.isfinite(emu.obs).all() and np.isfinite(emu.qpos).all() and np.isfinite(emu.qvel).all()
     assert np.abs(emu.qpos).max() < 10 and np.abs(emu.qvel).max() < 1e3
+
+
+def test_emulated_condim6_contact_matches_oracle(tmp_path):
+    """K9 with condim 6 (ten pyramid rows per contact: two tangents, torsion, two rolling axes -- FrankaKitchen's finger pads, franka_assets/assets.xml:51-55):
+    the engine source assembles the same rows as the oracle and a ball thrown onto the floor with spin and roll follows the oracle's trajectory."""
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd.mjcf import compile_mjcf
+    from oracle.oracle_sim import OracleSim
+
+    xml = """<mujoco><option timestep="0.002"/><worldbody>
+    <geom name="floor" type="plane" size="2 2 0.1" condim="6" friction="0.8 0.03 0.002"/>
+    <body pos="0 0 0.12"><freejoint/><geom type="sphere" size="0.1" mass="0.7" condim="6" friction="0.8 0.03 0.002"/></body>
+    <body pos="0.5 0 0.06"><freejoint/><geom type="box" size="0.05 0.04 0.06" mass="0.4" condim="6" friction="0.6 0.02 0.001"/></body>
+    </worldbody></mujoco>"""
+    path = os.path.join(tmp_path, "c6.xml")
+    with open(path, "w") as f:
+        f.write(xml)
+    m = compile_mjcf(path)
+    s, emu = OracleSim(m), EmuSim(m, types.SimpleNamespace(obs_dim=1))
+    s.qvel[:6] = [0.4, -0.2, -0.5, 1.0, 3.0, 6.0]     # the ball: sliding, falling, rolling and spinning
+    s.qvel[6:] = [-0.3, 0.1, 0.0, 0.0, 0.0, 2.0]      # the box: sliding and spinning on its face
+    worst, saw10 = 0.0, False
+    for t in range(150):
+        emu.qpos[:], emu.qvel[:], emu.qacc_ws[:] = s.qpos, s.qvel, s.qacc_warmstart
+        ncon, nefc = emu.physics_steps(1)
+        s.step(1)
+        assert emu.status.value == 0 and (ncon, nefc) == (s.ncon, s.nefc), (t, ncon, nefc, s.ncon, s.nefc)
+        saw10 |= nefc >= 10 and nefc % 10 == 0
+        worst = max(worst, np.abs(emu.qpos - s.qpos).max(), np.abs(emu.qvel - s.qvel).max())
+    assert saw10 and worst < 1e-4, worst

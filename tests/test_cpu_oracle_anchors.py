@@ -97,6 +97,31 @@ def test_anchor_03_pyramid_condim4_has_six_rows_sharing_R():
     assert abs((0.1 - s.qpos[2]) / rest_depth(3.0 / (mu * mu * (1 + mu * mu))) - 1) < 1e-7
 
 
+def test_anchor_03b_pyramid_condim6_has_ten_rows_sharing_R():
+    """condim 6 (FrankaKitchen's finger pads, franka_assets/assets.xml:51-55): 2 (6 - 1) = 10 rows -- two tangents, torsion, two rolling axes -- all with
+    the R of the first pair: 10 D k d r = m g, i.e. the rest depth of the condim-3 formula with the factor 2 replaced by 5.  The MJCF friction
+    attribute only carries (slide, spin, roll); the compiler must spread them to the five pyramid coefficients (slide, slide, spin, roll, roll)."""
+    mu = 0.7
+    xml = SPHERE.format(cd=6, mu=mu, spin=0.03, mass=0.9).replace("0.0001", "0.002")
+    m = _compile(xml)
+    s = OracleSim(m)
+    _settle(s)
+    assert s.nefc == 10
+    R = s.efc("R")
+    assert np.allclose(R, R[0], rtol=0, atol=0)
+    assert abs((0.1 - s.qpos[2]) / rest_depth(5.0 / (mu * mu * (1 + mu * mu))) - 1) < 1e-7
+    fr = np.asarray(m.tables["pair_friction"]).reshape(-1, 5)[0]
+    assert np.allclose(fr, [mu, mu, 0.03, 0.002, 0.002])
+    # rolling resistance is real: the same ball given a roll about y decelerates with the roll rows in place and keeps rolling without them (condim 3)
+    def roll_speed_after(cd):
+        b = OracleSim(_compile(SPHERE.format(cd=cd, mu=mu, spin=0.03, mass=0.9).replace("0.0001", "0.002")))
+        b.step(500)
+        b.qvel[:] = [0.1, 0, 0, 0, 1.0, 0]          # v = w x r: pure rolling along x
+        b.step(400)
+        return abs(b.qvel[4])
+    assert roll_speed_after(6) < 0.9 * roll_speed_after(3)
+
+
 def test_anchor_04_impedance_sigmoid_spot_values():
     """R / diagApprox = (1 - d)/d read back at prescribed penetrations of a frictionless sphere: d(0) = dmin, d(width) = dmax,
     d(mid * width) = dmin + mid (dmax - dmin) for any power, and the power-law value below the midpoint."""
