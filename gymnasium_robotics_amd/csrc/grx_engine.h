@@ -145,7 +145,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
   pers += jpool + maxefc * (5 + (nfric ? 1 : 0));            // packed J, efc D aref kind id|sub row (+ floss)
-  pers += (njnt > 32 ? 64 : 32) + 8 + (nmesh ? 21 : 0) + (nshift ? 8 : 0) + (noslip ? nv * nv : 0);
+  pers += (njnt > 32 ? 64 : 32) + 8 + (nmesh ? 21 : 0) + (nshift ? 8 : 0);   // noslip: M^-1 lives in the Hessian buffer (dead once Newton has finished)
   if (integrator == 1) pers += nq + nv + 8 * nv;                    // RK4 stage storage                                                   // ired, cnt
   int u1a = 7 * nbody + 6 * njnt, u1b = 18 * nbody;                  // {ploc qloc janchor jaxis} | {cvel cacc cfrc}
   int u2a = 10 * nbody, u2b = 12 * ngeom;                            // {crb} | {gxpos gxmat}
@@ -176,7 +176,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   c->efc_floss = p; if (m->nfric) p += m->maxefc;
   CARVEI(efc_kind, m->maxefc) CARVEI(efc_id, m->maxefc) CARVEI(efc_row, m->maxefc)
   CARVEI(ired, m->njnt > 32 ? 64 : 32) CARVEI(cnt, 8)
-  CARVE(shift, m->nshift ? 8 : 0) CARVE(minv, m->noslip ? m->nv * m->nv : 0)
+  CARVE(shift, m->nshift ? 8 : 0)
   CARVE(meshcache, m->nmesh ? 21 : 0)
   if (m->integrator == 1) { CARVE(rk_q0, m->nq) CARVE(rk_v0, m->nv) CARVE(rk_Fv, 4 * m->nv) CARVE(rk_Fa, 4 * m->nv) }
   if (m->ntouch || m->noslip) {
@@ -206,6 +206,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   }
   // ---- P2 (solve / integrate) on top of P1
   p = overlay;
+  c->minv = p;   // noslip's M^-1 takes the Hessian's place: the pass runs after the last Newton iteration, the Euler stage rebuilds A afterwards
   CARVE(A, m->nv * m->nv) CARVE(Ma, m->nv) CARVE(grad, m->nv) CARVE(search, m->nv) CARVE(Mv, m->nv) CARVE(tmpv, m->nv)
   CARVE(efc_jar, m->maxefc) CARVE(efc_jv, m->maxefc) CARVE(efc_force, m->maxefc) CARVEI(efc_quad, m->maxefc)
 #undef CARVE
@@ -2617,49 +2618,35 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   const int nv = GRX_NVC, maxiter = m->noslip_iterations;
   const int ne = c->cnt[3], nf = c->cnt[4], ncon = c->cnt[0] < c->maxcon ? c->cnt[0] : c->maxcon;
   GRX_TICK(c, GRX_P_NEVAL);
-  // ---- M^-1.  Specialised shapes on the GPU: Gauss-Jordan in registers.  Otherwise: factor a copy of M in the (dead) Hessian buffer, then
-  // lane i solves for the i-th unit vector in its own row of c->minv.
+  // ---- M^-1 into c->minv (= the Hessian's buffer: Newton is done with it).  Specialised shapes on the GPU: Gauss-Jordan in registers.
 #if !defined(GRX_EMU)
   if (S::kFixed && S::NV > 0 && S::NV <= 40) grx_sym_inverse_reg<(S::NV > 0 && S::NV <= 40) ? S::NV : 1>(c->M, nv, c->minv, lane_);
   else
 #endif
   {
-  FOR_LANES { for (int i = lane; i < nv * nv; i += 64) { c->A[i] = c->M[i]; c->minv[i] = ((i / nv) == (i % nv)) ? 1.0f : 0.0f; } }
-  WAVE_SYNC();
-  if (grx_sym_factor(c->A, nv, lane_)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
-  // lane i: forward / backward substitution of the i-th unit vector in its own row of c->minv.  The inner loops are blocked by eight
-  // independent read-modify-writes (loads first, then the updates): unblocked, every update waits a full LDS round trip for the previous one.
-  FOR_LANES {
-    if (lane < nv) {
-      float* x = c->minv + lane * nv; const float* A = c->A;
-      for (int k = nv - 1; k > 0; k--) {
-        const float yk = x[k] * A[k * nv + k];
-        int i = 0;
-        for (; i + 8 <= k; i += 8) {
-          float av[8], xv[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) { av[u] = A[k * nv + i + u]; xv[u] = x[i + u]; }
-#pragma unroll
-          for (int u = 0; u < 8; u++) x[i + u] = fmaf(-av[u], yk, xv[u]);
+    // in-place Gauss-Jordan in LDS (lane i = row i; the matrix is positive definite: no pivoting): step k eliminates column k from every other
+    // row and turns it into the k-th column of the inverse, then row k is scaled -- the arithmetic of grx_sym_inverse_reg, through LDS
+    FOR_LANES { for (int i = lane; i < nv * nv; i += 64) c->minv[i] = c->M[i]; }
+    WAVE_SYNC();
+    int bad = 0;
+    for (int k = 0; k < nv; k++) {
+      const float d = c->minv[k * nv + k];
+      bad |= !(d > 0.0f);
+      const float pinv = 1.0f / d;
+      FOR_LANES {
+        for (int i = lane; i < nv; i += 64) {
+          if (i == k) continue;
+          float* row = c->minv + i * nv; const float* piv = c->minv + k * nv;
+          const float f = row[k] * pinv;
+          for (int j = 0; j < nv; j++) if (j != k) row[j] = fmaf(-f, piv[j], row[j]);
+          row[k] = -f;
         }
-        for (; i < k; i++) x[i] -= A[k * nv + i] * yk;
       }
-      for (int i = 0; i < nv; i++) x[i] *= A[i * nv + i];
-      for (int i = 0; i < nv - 1; i++) {
-        const float xi = x[i];
-        int k = i + 1;
-        for (; k + 8 <= nv; k += 8) {
-          float av[8], dv[8], xv[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) { av[u] = A[(k + u) * nv + i]; dv[u] = A[(k + u) * nv + k + u]; xv[u] = x[k + u]; }
-#pragma unroll
-          for (int u = 0; u < 8; u++) x[k + u] = fmaf(-av[u] * dv[u], xi, xv[u]);
-        }
-        for (; k < nv; k++) x[k] -= A[k * nv + i] * A[k * nv + k] * xi;
-      }
+      WAVE_SYNC();
+      FOR_LANES { for (int j = lane; j < nv; j += 64) c->minv[k * nv + j] = (j == k) ? pinv : c->minv[k * nv + j] * pinv; }
+      WAVE_SYNC();
     }
-  }
-  WAVE_SYNC();
+    if (bad) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
   }
   GRX_SUBTICK(c, 17);
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
