@@ -18,7 +18,7 @@ from .. import _native
 from ..core import GoalVecEnv, np_random
 from ..mjcf import CompiledModel
 from ..spaces import Box, batch_space
-from .adroit_spec import IDENTITY_SHIFT, MAX_EPISODE_STEPS, SPECS, action_scaling, group_shift, load_adroit_model, make_adroit_task, parse_adroit_id, sample_reset
+from .adroit_spec import IDENTITY_SHIFT, MAX_EPISODE_STEPS, SPECS, action_scaling, group_shift, load_adroit_model, make_adroit_task, parse_adroit_id, sample_reset_batch
 
 
 class AdroitVecEnv(GoalVecEnv):
@@ -111,11 +111,11 @@ class AdroitVecEnv(GoalVecEnv):
     def _reset_worlds(self, idx):
         if len(idx) == 0:
             return None
-        draws = [sample_reset(self.task_name, self.np_randoms[w], self.model) for w in idx]
-        self.model_edit[idx] = np.stack([d["edit"] for d in draws])
+        d = sample_reset_batch(self.task_name, [self.np_randoms[w] for w in idx], self.model)
+        self.model_edit[idx] = d["edit"]
         if self.target_pos is not None:
-            self.target_pos[idx] = np.stack([d["target"] for d in draws])
-        ti = self._write_edits(idx, np.stack([d["shift"] for d in draws]), None if self.target is None else np.stack([d["target"] for d in draws]))
+            self.target_pos[idx] = d["target"]
+        ti = self._write_edits(idx, d["shift"], d["target"] if self.target is not None else None)
         self.qpos[ti] = self._init_qpos
         self.qvel[ti] = 0.0
         self.qacc_ws[ti] = 0.0
@@ -208,14 +208,14 @@ class AdroitVecEnv(GoalVecEnv):
         qp = np.asarray(state_dict["qpos"], dtype=np.float64)
         if self.task_name == "pen":
             edit = np.asarray(state_dict["desired_orien"], dtype=np.float64)
-            shifts = np.stack([group_shift(self.model, quat=q) for q in edit])
+            shifts = group_shift(self.model, quat=edit)
         else:
             if self.task_name == "relocate":   # model.body_pos[Object] = obj_pos - qpos[OBJTx..OBJTz] (adroit_relocate.py:405-407)
                 edit = np.asarray(state_dict["obj_pos"], dtype=np.float64) - qp[:, 30:33]
                 self.target_pos[:] = np.asarray(state_dict["target_pos"], dtype=np.float64)
             else:
                 edit = np.asarray(state_dict[need[0][0]], dtype=np.float64)
-            shifts = np.stack([group_shift(self.model, pos=p) for p in edit])
+            shifts = group_shift(self.model, pos=edit)
         self.model_edit[:] = edit
         with torch.cuda.device(self.device):
             self._write_edits(np.arange(n), shifts, self.target_pos)

@@ -16,7 +16,7 @@ from typing import Optional
 
 import numpy as np
 
-from .manipulate_spec import euler2quat, quat_conj, quat_mul
+from .manipulate_spec import quat_conj, quat_mul
 
 FRAME_SKIP = 5                 # adroit_hammer.py:211 (all four)
 MAX_EPISODE_STEPS = 200        # __init__.py:1092,1099,1106,1113 (all four tasks)
@@ -92,24 +92,46 @@ def action_scaling(model):
 IDENTITY_SHIFT = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
 
 
+def euler2quat(euler):
+    """utils/rotations.py:140-159, operation for operation (batched over leading axes)"""
+    euler = np.asarray(euler, dtype=np.float64)
+    ai, aj, ak = euler[..., 2] / 2, -euler[..., 1] / 2, euler[..., 0] / 2
+    si, sj, sk = np.sin(ai), np.sin(aj), np.sin(ak)
+    ci, cj, ck = np.cos(ai), np.cos(aj), np.cos(ak)
+    cc, cs = ci * ck, ci * sk
+    sc, ss = si * ck, si * sk
+    quat = np.empty(euler.shape[:-1] + (4,), dtype=np.float64)
+    quat[..., 0] = cj * cc + sj * ss
+    quat[..., 3] = cj * sc - sj * cs
+    quat[..., 2] = -(cj * ss + sj * cc)
+    quat[..., 1] = cj * cs - sj * sc
+    return quat
+
+
 def _quat2mat(q):
-    w, x, y, z = q
-    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
-                     [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
-                     [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+    """rotation matrix of unit quaternion(s) (..., 4) -> (..., 3, 3)"""
+    q = np.asarray(q, dtype=np.float64)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0] = w * w + x * x - y * y - z * z; R[..., 0, 1] = 2 * (x * y - w * z); R[..., 0, 2] = 2 * (x * z + w * y)
+    R[..., 1, 0] = 2 * (x * y + w * z); R[..., 1, 1] = w * w - x * x + y * y - z * z; R[..., 1, 2] = 2 * (y * z - w * x)
+    R[..., 2, 0] = 2 * (x * z - w * y); R[..., 2, 1] = 2 * (y * z + w * x); R[..., 2, 2] = w * w - x * x - y * y + z * z
+    return R
 
 
 def group_shift(model, pos=None, quat=None) -> np.ndarray:
-    """7-vector (t, q) the engine applies to the model's shift group for model.body_pos[body] = pos and / or model.body_quat[body] = quat:
-    members move as x -> R (x - p0) + pos with R = R(quat) R(quat0)^T, i.e. x -> R x + t with t = pos - R p0 (translation-only groups: R = 1, t = pos - p0)."""
+    """7-vector(s) (t, q) the engine applies to the model's shift group for model.body_pos[body] = pos and / or model.body_quat[body] = quat (one
+    world, or a batch along the leading axis): members move as x -> R (x - p0) + pos with R = R(quat) R(quat0)^T, i.e. x -> R x + t with
+    t = pos - R p0 (translation-only groups: R = 1, t = pos - p0)."""
     p0, q0 = np.asarray(model.info["shift_pos0"], dtype=np.float64), np.asarray(model.info.get("shift_quat0", [1.0, 0, 0, 0]), dtype=np.float64)
-    pos = p0 if pos is None else np.asarray(pos, dtype=np.float64)
+    lead = np.shape(pos)[:-1] if pos is not None else np.shape(quat)[:-1]
+    pos = np.broadcast_to(p0, lead + (3,)) if pos is None else np.asarray(pos, dtype=np.float64)
     if quat is None:
-        return np.concatenate([pos - p0, [1.0, 0.0, 0.0, 0.0]])
+        return np.concatenate([pos - p0, np.broadcast_to(IDENTITY_SHIFT[3:], lead + (4,))], axis=-1)
     q = np.asarray(quat, dtype=np.float64)
-    q = q / np.linalg.norm(q)                 # mj_kinematics normalises body_quat before use [3P]
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)                 # mj_kinematics normalises body_quat before use [3P]
     rel = quat_mul(q, quat_conj(q0))
-    return np.concatenate([pos - _quat2mat(rel) @ p0, rel])
+    return np.concatenate([pos - _quat2mat(rel) @ p0, rel], axis=-1)
 
 
 def board_shift(model, z: float) -> np.ndarray:
@@ -119,27 +141,34 @@ def board_shift(model, z: float) -> np.ndarray:
     return group_shift(model, pos=p)
 
 
-def sample_reset(task: str, rng, model):
-    """reset_model's draws, in the reference's order -> dict(edit=<what get_env_state reports>, shift=7-vector, target=3-vector or None)"""
-    p0 = np.array(model.info["shift_pos0"], dtype=np.float64)
+def sample_reset_batch(task: str, rngs, model):
+    """reset_model's draws for a list of per-world generators, in the reference's order -> dict(edit [k, 3 or 4] = what get_env_state reports,
+    shift [k, 7], target [k, 3] or None).  Only the draws run per world; the arithmetic on them is batched."""
+    k = len(rngs)
+    p0 = np.tile(np.asarray(model.info["shift_pos0"], dtype=np.float64), (k, 1))
     if task == "hammer":       # adroit_hammer.py:374-376
-        p0[2] = rng.uniform(low=0.1, high=0.25)
+        p0[:, 2] = [r.uniform(low=0.1, high=0.25) for r in rngs]
         return dict(edit=p0, shift=group_shift(model, pos=p0), target=None)
     if task == "door":         # adroit_door.py:362-370
-        pos = np.array([rng.uniform(low=-0.3, high=-0.2), rng.uniform(low=0.25, high=0.35), rng.uniform(low=0.252, high=0.35)])
+        pos = np.array([[r.uniform(low=-0.3, high=-0.2), r.uniform(low=0.25, high=0.35), r.uniform(low=0.252, high=0.35)] for r in rngs]).reshape(k, 3)
         return dict(edit=pos, shift=group_shift(model, pos=pos), target=None)
     if task == "pen":          # adroit_pen.py:380-383
-        e = np.zeros(3)
-        e[0] = rng.uniform(low=-1, high=1)
-        e[1] = rng.uniform(low=-1, high=1)
+        e = np.zeros((k, 3))
+        e[:, :2] = np.array([[r.uniform(low=-1, high=1), r.uniform(low=-1, high=1)] for r in rngs]).reshape(k, 2)
         quat = euler2quat(e)
         return dict(edit=quat, shift=group_shift(model, quat=quat), target=None)
     if task == "relocate":     # adroit_relocate.py:353-372
-        p0[0] = rng.uniform(low=-0.15, high=0.15)
-        p0[1] = rng.uniform(low=-0.15, high=0.3)
-        target = np.array([rng.uniform(low=-0.2, high=0.2), rng.uniform(low=-0.2, high=0.2), rng.uniform(low=0.15, high=0.35)])
-        return dict(edit=p0, shift=group_shift(model, pos=p0), target=target)
+        d = np.array([[r.uniform(low=-0.15, high=0.15), r.uniform(low=-0.15, high=0.3), r.uniform(low=-0.2, high=0.2), r.uniform(low=-0.2, high=0.2),
+                       r.uniform(low=0.15, high=0.35)] for r in rngs]).reshape(k, 5)
+        p0[:, :2] = d[:, :2]
+        return dict(edit=p0, shift=group_shift(model, pos=p0), target=d[:, 2:].copy())
     raise KeyError(task)
+
+
+def sample_reset(task: str, rng, model):
+    """one world: dict(edit, shift, target)"""
+    d = sample_reset_batch(task, [rng], model)
+    return {k: (None if v is None else v[0]) for k, v in d.items()}
 
 
 # ---------------------------------------------------------------------------------------------------- rewards (float64, the reference's order of operations)
