@@ -83,7 +83,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations, iterations;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations, iterations, njeq;
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv, noslip_tolerance;
   int mpr_iterations;
 };
@@ -2103,7 +2103,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   const int ncon = c->cnt[0];
   // ---- row bookkeeping: one lane per joint (limit flags) and one lane per contact (row count, dof span), then
   // exclusive prefix sums across the wave give every limit / contact its first row and its Jacobian-pool offset.
-  const int ne = 6 * m->nweld, nf = m->nfric, wpool = m->wpool;
+  const int nwr = 6 * m->nweld, ne = nwr + m->njeq, nf = m->nfric, wpool = m->wpool;   // equality rows: the welds' six each, then one per joint equality
   GRX_LANEVAR_I(limc); GRX_LANEVAR_I(conr); GRX_LANEVAR_I(conw); GRX_LANEVAR_I(coni);
   GRX_LANEVAR_I(tenf); GRX_LANEVAR_I(tenc); GRX_LANEVAR_I(tenw); GRX_LANEVAR(tenl);
   FOR_LANES {
@@ -2177,10 +2177,13 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_SUBTICK(c, 1);
   // ---- descriptors
   FOR_LANES {
-    if (lane < ne) {  // welds are the only equality type in scope; spans and pool offsets are static (weld_row)
+    if (lane < nwr) {  // welds: spans and pool offsets are static (weld_row)
       const int r = lane, w = r / 6, sub = r - 6 * w, info0 = m->weld_row[w];
       c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (m->weld_eq[w] << 4) | sub;
       c->efc_row[r] = info0 + sub * GRX_ROW_LEN(info0);  // the offset field is the low one: adding sub*len moves to row sub
+    } else if (lane < ne) {  // joint equalities (sub 8: their invweight sits in the second eq_invweight slot too)
+      const int r = lane, j = r - nwr;
+      c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (m->jeq_eq[j] << 4) | 8; c->efc_row[r] = m->jeq_row[j];
     }
     if ((S::kFixed ? S::NF > 0 : true) && nf > 0)   // compile-time dead for the shapes without friction-loss dofs
       for (int d = lane; d < nv; d += 64) {
@@ -2225,7 +2228,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   // (every (row group, dof) item below writes all of its entries, zeros included: no separate clear of J)
   FOR_LANES {
     // welds: one lane per (weld, dof)
-    for (int it = lane; it < (ne / 6) * nv; it += 64) {
+    for (int it = lane; it < (nwr / 6) * nv; it += 64) {
       int w = it / nv, d = it - w * nv;
       int e = m->weld_eq[w];
       int b0 = m->eq_obj1[e], b1 = m->eq_obj2[e];
@@ -2254,6 +2257,18 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
         float quat2[4]; mulQuatf(quat2, quat1, quat);
         for (int r = 0; r < 3; r++) { c->efc_pos[6 * w + r] = pos[0][r] - pos[1][r]; c->efc_pos[6 * w + 3 + r] = ts * quat2[1 + r]; }
       }
+    }
+    // joint equalities: one lane per constraint.  r = (q1 - q1_0) - poly(q2 - q2_0), J = e_dof1 - poly'(q2 - q2_0) e_dof2 (MuJoCo mjEQ_JOINT [3P])
+    for (int j = lane; j < m->njeq; j += 64) {
+      const int r = nwr + j, e = m->jeq_eq[j], info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
+      const float* data = m->eq_data + 11 * e;
+      const float x = c->qpos[m->jeq_qadr[2 * j + 1]] - data[6];
+      const float poly = data[0] + x * (data[1] + x * (data[2] + x * (data[3] + x * data[4])));
+      const float deriv = data[1] + x * (2.0f * data[2] + x * (3.0f * data[3] + x * 4.0f * data[4]));
+      for (int k = 0; k < len; k++) c->Jp[off + k] = 0.0f;
+      c->Jp[off + m->jeq_dof[2 * j] - lo] = 1.0f;
+      c->Jp[off + m->jeq_dof[2 * j + 1] - lo] += -deriv;
+      c->efc_pos[r] = (c->qpos[m->jeq_qadr[2 * j]] - data[5]) - poly;
     }
     // frictionloss + limits: one lane per row
     GRX_SUBTICK(c, 3);

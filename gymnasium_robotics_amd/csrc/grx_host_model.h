@@ -64,6 +64,8 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.noslip_iterations = d[GRX_NOSLIP_ITERATIONS]; m.noslip_tolerance = (float)v.opt[GRX_NOSLIP_TOLERANCE];
   m.nfric = 0; m.nweld = 0; m.wpool = 0;
   for (int k = 0; k < v.n_weld_row; k++) m.wpool += 6 * ((v.weld_row[k] >> 20) & 0xFF);
+  m.njeq = v.n_jeq_eq;
+  for (int k = 0; k < v.n_jeq_row; k++) m.wpool += (v.jeq_row[k] >> 20) & 0xFF;
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;
   for (int k = 0; k < v.n_eq_type; k++) if (v.eq_active[k] && v.eq_type[k] == GRX_EQ_WELD) m.nweld++;
   // Capacities of the row tables and of the packed-Jacobian pool: the compiler may request more than the defaults for models

@@ -1303,6 +1303,25 @@ class _Lowering:
             for e in eqsec:
                 a = dict(c.defaults.get(e.attrib.get("class"), "equality"))
                 a.update(e.attrib)
+                if e.tag == "joint":
+                    # q1 - q1_0 = poly(q2 - q2_0) (MuJoCo XML reference, equality/joint; kitchen_franka/.../oven_asset.xml:40-46: knob <-> burner).
+                    # One row, J = e_dof1 - poly'(.) e_dof2; diagApprox = dof_invweight0[dof1] + dof_invweight0[dof2] (mj_setConst [3P]).
+                    j1 = jnts[names["joint"][a["joint1"]]]
+                    if "joint2" not in a:
+                        raise NotImplementedError("joint equality without joint2")
+                    j2 = jnts[names["joint"][a["joint2"]]]
+                    if j1.type not in (JNT_HINGE, JNT_SLIDE) or j2.type not in (JNT_HINGE, JNT_SLIDE):
+                        raise ValueError("joint equalities couple hinge / slide joints only")
+                    data = np.zeros(11)
+                    data[0:5] = _floats(a.get("polycoef"), 5, [0, 1, 0, 0, 0])
+                    data[5], data[6] = qpos0[j1.qposadr], qpos0[j2.qposadr]
+                    iw = float(dof_invweight0[j1.dofadr] + dof_invweight0[j2.dofadr])
+                    eqs.append(dict(
+                        type=EQ_JOINT, obj1=int(names["joint"][a["joint1"]]), obj2=int(names["joint"][a["joint2"]]), active=int(_bool(a.get("active"), True)),
+                        data=data, solref=_floats(a.get("solref"), 2, [0.02, 1.0]), solimp=_floats(a.get("solimp"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]),
+                        invw=np.array([iw, iw]), relpose=np.zeros(14), dofs=(int(j1.dofadr), int(j2.dofadr)), qadrs=(int(j1.qposadr), int(j2.qposadr)),
+                    ))
+                    continue
                 if e.tag != "weld":
                     raise NotImplementedError(f"equality type {e.tag}")
                 i1 = next(i for i, b in enumerate(B) if b.name == a["body1"])
@@ -1558,7 +1577,18 @@ class _Lowering:
                 weld_eq.append(q)
                 weld_row.append(woff | (lo << 12) | (ln << 20))
                 woff += 6 * ln
+        # joint equalities: one row each over the dof span [min(dof1, dof2), max]; their rows follow the welds' in the row table and in the pool
+        jeq_eq, jeq_row, jeq_dof, jeq_qadr = [], [], [], []
+        for q, e in enumerate(eqs):
+            if e["active"] and e["type"] == EQ_JOINT:
+                d1, d2 = e["dofs"]
+                lo, ln = min(d1, d2), abs(d1 - d2) + 1
+                jeq_eq.append(q); jeq_row.append(woff | (lo << 12) | (ln << 20)); jeq_dof += [d1, d2]; jeq_qadr += list(e["qadrs"])
+                woff += ln
+        if jeq_eq and any(e["active"] and e["type"] == EQ_WELD and q > jeq_eq[0] for q, e in enumerate(eqs)):
+            raise NotImplementedError("welds listed after joint equalities (the row table keeps welds first)")
         T.update(
+            jeq_eq=np.array(jeq_eq, np.int32), jeq_row=np.array(jeq_row, np.int32), jeq_dof=np.array(jeq_dof, np.int32), jeq_qadr=np.array(jeq_qadr, np.int32),
             weld_eq=np.array(weld_eq, np.int32), weld_row=np.array(weld_row, np.int32),
             body_submask=submask, body_jump=jump.reshape(-1),
             body_ancadr=body_ancadr, body_ancnum=body_ancnum, body_anc=np.array(body_anc, np.int32),

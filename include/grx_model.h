@@ -25,7 +25,7 @@ enum grx_opt {
 enum { GRX_JNT_FREE = 0, GRX_JNT_BALL = 1, GRX_JNT_SLIDE = 2, GRX_JNT_HINGE = 3 };
 enum { GRX_GEOM_PLANE = 0, GRX_GEOM_SPHERE = 2, GRX_GEOM_CAPSULE = 3, GRX_GEOM_ELLIPSOID = 4,
        GRX_GEOM_CYLINDER = 5, GRX_GEOM_BOX = 6, GRX_GEOM_MESH = 7 };
-enum { GRX_EQ_CONNECT = 0, GRX_EQ_WELD = 1 };
+enum { GRX_EQ_CONNECT = 0, GRX_EQ_WELD = 1, GRX_EQ_JOINT = 2 };
 
 /* host-side (fp64) view of the blob: one pointer per table of grx_model_fields.def */
 typedef struct grx_model_view {

@@ -1208,6 +1208,18 @@ static void make_constraint(orc_sim* s) {
       for (int r = 0; r < 3; r++) rows[3 + r][d] = 0.5 * torquescale * t2[1 + r];
     }
   }
+  /* equality: joint (MuJoCo mjEQ_JOINT [3P]: q1 - q1_0 = poly(q2 - q2_0), eq_data = polycoef[5], q1_0, q2_0; obj1 / obj2 = the joints).  One row:
+   * residual (q1 - q1_0) - poly(x), J = e_dof1 - poly'(x) e_dof2, diagApprox = the two dofs' invweight0 (eq_invweight).  Rows follow the welds'. */
+  for (int e = 0; e < s->neq; e++) {
+    if (!m->eq_active[e] || m->eq_type[e] != GRX_EQ_JOINT) continue;
+    const double* data = m->eq_data + 11 * e;
+    const int j1 = m->eq_obj1[e], j2 = m->eq_obj2[e];
+    const double x = s->qpos[m->jnt_qposadr[j2]] - data[6];
+    const double poly = data[0] + x * (data[1] + x * (data[2] + x * (data[3] + x * data[4])));
+    const double deriv = data[1] + x * (2 * data[2] + x * (3 * data[3] + x * 4 * data[4]));
+    double* row = add_row(s, EFC_EQUALITY, e, (s->qpos[m->jnt_qposadr[j1]] - data[5]) - poly, 0, 0, m->eq_invweight[2 * e]);
+    if (row) { row[m->jnt_dofadr[j1]] = 1.0; row[m->jnt_dofadr[j2]] += -deriv; }
+  }
   s->ne = s->nefc;
   /* dof friction loss */
   for (int d = 0; d < nv; d++)

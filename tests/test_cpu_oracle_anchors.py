@@ -362,3 +362,29 @@ def test_anchor_18_invweight0_of_free_and_hinged_bodies():
     assert np.allclose(T["dof_invweight0"][:6].ravel(), [1 / 3.0] * 3 + [np.mean(1 / I)] * 3, rtol=1e-12)
     Ih = 0.4 * 2 * 0.05 ** 2 + 2 * 0.25
     assert abs(T["dof_invweight0"].ravel()[6] * Ih - 1) < 1e-12
+
+
+def test_anchor_21_joint_equality_couples_two_hinges():
+    """<equality><joint polycoef="0 a 0 0 0"> (FrankaKitchen's knob <-> burner couplings, kitchen_franka/.../oven_asset.xml:40-46): a soft row with residual
+    q1 - a q2, J = (1, -a), diagApprox = invweight0(dof1) + invweight0(dof2).  Two hinges about the gravity axis (no load), the first one driven to a
+    fixed angle by a stiff position actuator: the coupled joint settles at q1 = a q2 exactly (no force left in the row), and the row's regulariser is
+    (1 - d)/d (1/I1 + 1/I2)."""
+    a = 3.0
+    xml = f"""<mujoco><option timestep="0.002"/><worldbody>
+    <body pos="0 0 0.2"><joint name="j1" type="hinge" axis="0 0 1" damping="0.05"/><geom type="box" size="0.1 0.02 0.02" pos="0.1 0 0" mass="0.5" contype="0" conaffinity="0"/></body>
+    <body pos="0.5 0 0.2"><joint name="j2" type="hinge" axis="0 0 1" damping="0.05"/><geom type="box" size="0.05 0.02 0.02" pos="0.05 0 0" mass="0.2" contype="0" conaffinity="0"/></body>
+    </worldbody>
+    <equality><joint joint1="j1" joint2="j2" polycoef="0 {a} 0 0 0"/></equality>
+    <actuator><position joint="j1" kp="50"/></actuator></mujoco>"""
+    m = _compile(xml)
+    s = OracleSim(m)
+    s.ctrl[0] = 0.6
+    s.forward()
+    assert s.nefc == 1
+    iw = np.asarray(m.tables["dof_invweight0"]).ravel()
+    d0 = impedance(0.0)
+    assert abs(s.efc("R")[0] / ((1 - d0) / d0 * (iw[0] + iw[1])) - 1) < 1e-12
+    assert np.allclose(s.efc("J")[0], [1.0, -a])
+    s.step(6000)
+    assert np.abs(s.qvel).max() < 1e-7
+    assert abs(s.qpos[0] - 0.6) < 1e-6 and abs(s.qpos[0] - a * s.qpos[1]) < 1e-7
