@@ -12,7 +12,8 @@ One "step" = one env.step() of all worlds = ONE launch of the family's step kern
     fetch       cfg 2  FetchPickAndPlace-v4, 4096 worlds / GPU
     hand_touch  cfg 3  HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1, 16384 worlds / GPU
     antmaze     cfg 4  AntMaze_Large_Diverse_GR-v5, 8192 worlds / GPU (65536 over 8)
-    adroit      cfg 5b AdroitHandHammer-v2, 16384 worlds / GPU
+    adroit      cfg 5b AdroitHandHammer-v2, 16384 worlds / GPU (adroit_door | adroit_pen | adroit_relocate: the other Adroit tasks)
+    kitchen     cfg 5a FrankaKitchen-v1, 16384 worlds / GPU, default observation noise
     hand_reach         HandReach-v3, 16384 worlds / GPU
 
     python bench.py --gpus 1 --steps 100 --warmup 10
@@ -43,6 +44,8 @@ WORKLOADS = {
     # the other Adroit tasks; algorithmic bytes = 4 * (r: nq + 2 nv + nu + 7 (+3) | w: nq + 2 nv | out: obs + 1) + 2
     "adroit_door": dict(env_id="AdroitHandDoor-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=4 * (30 + 60 + 28 + 7 + 90 + 40) + 2, horizon=200),
     "adroit_pen": dict(env_id="AdroitHandPen-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=4 * (30 + 60 + 24 + 7 + 90 + 46) + 2, horizon=200),
+    # cfg 5a: r qpos30 qvel29 warm29 act9 last9 noise59 = 165, w 30 + 29 + 29 + 9 = 97, out obs59 + completed1 = 60 words
+    "kitchen": dict(env_id="FrankaKitchen-v1", worlds=16384, kernel="grx_kitchen_step_kernel", algo=4 * (165 + 97 + 60), horizon=280),
     "adroit_relocate": dict(env_id="AdroitHandRelocate-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=4 * (36 + 72 + 30 + 10 + 108 + 40) + 2, horizon=200),
 }
 HER_K = 4  # relabelled goals per transition ("future" strategy with k=4); 28 B per relabelled transition
@@ -58,6 +61,8 @@ def make_env(workload, n, device, rank):
         from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv as Env
     elif workload == "hand_reach":
         from gymnasium_robotics_amd.envs.hand import HandReachVecEnv as Env
+    elif workload == "kitchen":
+        from gymnasium_robotics_amd.envs.kitchen import KitchenVecEnv as Env
     elif workload.startswith("adroit"):
         from gymnasium_robotics_amd.envs.adroit import AdroitVecEnv as Env
     else:
@@ -78,6 +83,10 @@ def _oracle_env(workload):
         layout = parse_ant_maze_id(WORKLOADS[workload]["env_id"])[0]
         maze = Maze(MAPS[layout], ANT_MAZE_SIZE_SCALING, ANT_MAZE_HEIGHT)
         return OracleAntMazeEnv(load_point_maze_model(maze, layout, None, "ant"), maze), 8
+    if workload == "kitchen":
+        from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model
+        from oracle.kitchen_oracle import OracleKitchenEnv
+        return OracleKitchenEnv(load_kitchen_model()), 9
     if workload.startswith("adroit"):
         from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_model, parse_adroit_id
         from oracle.adroit_oracle import OracleAdroitEnv

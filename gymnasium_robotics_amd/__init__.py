@@ -22,9 +22,7 @@ class UnsupportedEnvError(KeyError):
     """The reference registers this id, the device engine does not serve it (DESIGN.md section 6 says why)."""
 
 
-_NOT_SERVED = {
-    "FrankaKitchen": "condim-6 finger pads (10 pyramid rows per contact) and a 258-geom scene that needs a spatial broad phase: not built yet",
-}
+_NOT_SERVED = {}   # reference id prefix -> why the engine does not serve it (empty since round 2: FrankaKitchen was the last one)
 
 
 def _fetch_ids() -> List[str]:
@@ -62,11 +60,11 @@ def _adroit_ids() -> List[str]:
 
 def registered_env_ids() -> List[str]:
     """Every id ``make_vec`` serves, in the reference's registration order of families."""
-    return _fetch_ids() + _hand_reach_ids() + _hand_manipulate_ids() + _maze_ids() + _adroit_ids()
+    return _fetch_ids() + _hand_reach_ids() + _hand_manipulate_ids() + _maze_ids() + _adroit_ids() + ["FrankaKitchen-v1"]   # __init__.py:1117-1122
 
 
 def env_family(env_id: str) -> str:
-    """'fetch' | 'hand_reach' | 'hand_manipulate' | 'adroit' | 'point_maze' | 'ant_maze' for a served id; raises for the rest."""
+    """'fetch' | 'hand_reach' | 'hand_manipulate' | 'adroit' | 'kitchen' | 'point_maze' | 'ant_maze' for a served id; raises for the rest."""
     for prefix, why in _NOT_SERVED.items():
         if env_id.startswith(prefix):
             raise UnsupportedEnvError(f"{env_id}: not served by this build -- {why}")
@@ -80,6 +78,8 @@ def env_family(env_id: str) -> str:
         return "hand_manipulate"
     if env_id.startswith("AdroitHand"):
         return "adroit"
+    if env_id.startswith("FrankaKitchen"):
+        return "kitchen"
     return "point_maze" if env_id.startswith("PointMaze") else "ant_maze"
 
 
@@ -97,6 +97,8 @@ def make_vec(env_id: str, num_envs: int = 1, **kwargs):
         from .envs.hand import HandBlockVecEnv as cls
     elif family == "adroit":
         from .envs.adroit import AdroitVecEnv as cls
+    elif family == "kitchen":
+        from .envs.kitchen import KitchenVecEnv as cls
     elif family == "point_maze":
         from .envs.point_maze import PointMazeVecEnv as cls
     else:

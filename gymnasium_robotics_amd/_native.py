@@ -40,6 +40,16 @@ class AdroitBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")]
 
 
+class KitchenTaskStruct(ctypes.Structure):
+    _fields_ = [("n_substeps", ctypes.c_int), ("obs_dim", ctypes.c_int), ("dt", ctypes.c_float), ("vel_lo", ctypes.c_float * 9), ("vel_hi", ctypes.c_float * 9),
+                ("pos_lo", ctypes.c_float * 9), ("pos_hi", ctypes.c_float * 9), ("noise_scale", ctypes.c_float * 59), ("task_adr", ctypes.c_int * 7),
+                ("task_num", ctypes.c_int * 7), ("task_goal", ctypes.c_float * 17), ("bonus_thresh", ctypes.c_float)]
+
+
+class KitchenBuffersStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "last_qpos", "action", "noise", "obs", "completed", "status", "mask")]
+
+
 class HerArgsStruct(ctypes.Structure):
     _fields_ = [("rows", ctypes.c_void_p), ("acts", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in ("T", "N", "W", "obs_dim", "goal_dim", "act_dim")] + [
         (n, ctypes.c_void_p) for n in ("t_idx", "w_idx", "t_goal")] + [("kind", ctypes.c_int), ("p0", ctypes.c_float), ("p1", ctypes.c_float)] + [
@@ -58,6 +68,8 @@ def lib():
             raise RuntimeError(
                 f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        import torch  # noqa: F401  -- first: the library must bind to the HIP runtime torch has already loaded (loaded the other way round, a second runtime instance sees no device)
+
         L = ctypes.CDLL(LIB_PATH)
         vp, ci = ctypes.c_void_p, ctypes.c_int
         L.grx_last_error.restype = ctypes.c_char_p
@@ -71,6 +83,8 @@ def lib():
         L.grx_fetch_reset.argtypes = [vp, vp, vp, vp, ci, vp]
         L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_her_relabel.argtypes = [vp, ctypes.c_int64, vp]
+        L.grx_kitchen_step.argtypes = [vp, vp, vp, ci, ci, vp]
+        L.grx_sample_uniform_rows.argtypes = [vp, vp, ci, ci, vp]
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
@@ -91,5 +105,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
 ]

@@ -5,14 +5,15 @@
 // and write HBM exactly once.  Worlds are independent: no inter-workgroup communication.
 //
 // Build: this ONE source is compiled either as a single translation unit (no GRX_TU_* macro: the profiling variant) or, for the product
-// library, four times in parallel with -DGRX_TU_FETCH / -DGRX_TU_HAND / -DGRX_TU_POINT / -DGRX_TU_ADROIT / -DGRX_TU_API (one family of kernel
+// library, four times in parallel with -DGRX_TU_FETCH / -DGRX_TU_HAND / -DGRX_TU_POINT / -DGRX_TU_ADROIT / -DGRX_TU_KITCHEN / -DGRX_TU_API (one family of kernel
 // instantiations each; __graft_entry__.build links the objects).  Every unit has its own copy of the constant-memory model descriptors
 // (g_grx_models is static): grx_model_create uploads a descriptor to each of them through grx_tu_*_prepare.
-#if !defined(GRX_TU_FETCH) && !defined(GRX_TU_HAND) && !defined(GRX_TU_POINT) && !defined(GRX_TU_ADROIT) && !defined(GRX_TU_API)
+#if !defined(GRX_TU_FETCH) && !defined(GRX_TU_HAND) && !defined(GRX_TU_POINT) && !defined(GRX_TU_ADROIT) && !defined(GRX_TU_KITCHEN) && !defined(GRX_TU_API)
 #define GRX_TU_FETCH 1
 #define GRX_TU_HAND 1
 #define GRX_TU_POINT 1
 #define GRX_TU_ADROIT 1
+#define GRX_TU_KITCHEN 1
 #define GRX_TU_API 1
 #endif
 #include <hip/hip_runtime.h>
@@ -27,6 +28,7 @@
 #include "grx_point_task.h"
 #include "grx_hand_task.h"
 #include "grx_adroit_task.h"
+#include "grx_kitchen_task.h"
 #include "grx_host_model.h"
 
 static_assert(sizeof(grx_fetch_task) == sizeof(GrxFetchTask), "grx_fetch_task must mirror GrxFetchTask");
@@ -37,6 +39,8 @@ static_assert(sizeof(grx_hand_task) == sizeof(GrxHandTask), "grx_hand_task must 
 static_assert(sizeof(grx_hand_buffers) == sizeof(GrxHandBuffers), "grx_hand_buffers must mirror GrxHandBuffers");
 static_assert(sizeof(grx_adroit_task) == sizeof(GrxAdroitTask), "grx_adroit_task must mirror GrxAdroitTask");
 static_assert(sizeof(grx_adroit_buffers) == sizeof(GrxAdroitBuffers), "grx_adroit_buffers must mirror GrxAdroitBuffers");
+static_assert(sizeof(grx_kitchen_task) == sizeof(GrxKitchenTask), "grx_kitchen_task must mirror GrxKitchenTask");
+static_assert(sizeof(grx_kitchen_buffers) == sizeof(GrxKitchenBuffers), "grx_kitchen_buffers must mirror GrxKitchenBuffers");
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -409,6 +413,45 @@ grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
 #endif
 }
 
+// FrankaKitchen-v1 env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world; 40 substeps; nv = 29 (9 robot dofs, 5 joint
+// equalities knob <-> burner / switch <-> light, the free kettle), 124 colliding geoms / 3 736 candidate pairs, condim-6 finger pads, hull pairs
+typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 192, 2240, 0, 32, 1, 3> GrxShapeKitchen;
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_worlds, int words, int forward_only) {
+  extern __shared__ float lds[];
+  const int w = grx_world_of_block(), lane_ = threadIdx.x;
+  if (w >= n_worlds) return;
+  if (b.mask && !b.mask[w]) return;
+  const GrxModel& m = g_grx_models[mslot];
+  GrxCtx c;
+  c.mslot = mslot;
+  grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
+#ifdef GRX_PROFILE
+  __shared__ long long prof_s[GRX_NPROF + 1];
+  c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
+  if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
+#endif
+  const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv;
+  for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
+  __syncthreads();
+  for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
+  for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
+  __syncthreads();
+  float* last = b.last_qpos + (size_t)w * GRX_KITCHEN_NROBOT;
+  if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
+  else GrxKitchen<S>::grx_kitchen_sim_world(&m, &t, &c, b.action + (size_t)w * GRX_KITCHEN_NROBOT, last, lane_);
+  GrxKitchen<S>::grx_kitchen_outputs(&m, &t, &c, b.noise ? b.noise + (size_t)w * t.obs_dim : nullptr, b.obs + (size_t)w * t.obs_dim, last, b.completed + w, lane_);
+  __syncthreads();
+  for (int i = lane_; i < nq; i += 64) b.qpos[(size_t)w * nq + i] = c.qpos[i];
+  for (int i = lane_; i < nv; i += 64) { b.qvel[(size_t)w * nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * nv + i] = c.qacc_ws[i]; }
+  if (lane_ == 0) b.status[w] = grx_status_word(b.status[w], c.cnt[2]);
+#ifdef GRX_PROFILE
+  GRX_TICK(&c, GRX_P_OTHER);
+  if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // per-family translation units: shape selection, LDS limits, descriptor upload, launches
 // ------------------------------------------------------------------------------------------
@@ -524,12 +567,29 @@ extern "C" int grx_tu_adroit_launch(int shape, unsigned grid, size_t lds_bytes, 
   return (int)hipGetLastError();
 }
 #endif
+#if GRX_TU_KITCHEN
+extern "C" int grx_tu_kitchen_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
+  GRX_LDS(grx_kitchen_step_kernel<GrxShapeAny>);
+  if (grx_shape_matches<GrxShapeKitchen>(*g)) { *shape = 30; GRX_LDS(grx_kitchen_step_kernel<GrxShapeKitchen>); }
+  return (int)grx_upload_descriptor(g, slot);
+}
+extern "C" int grx_tu_kitchen_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxKitchenTask* t, const GrxKitchenBuffers* b, int n, int words,
+                                     int forward_only) {
+  const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+  if (shape == 30) hipLaunchKernelGGL(grx_kitchen_step_kernel<GrxShapeKitchen>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
+  else hipLaunchKernelGGL(grx_kitchen_step_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
+  return (int)hipGetLastError();
+}
+#endif
 #undef GRX_LDS
 
 #if GRX_TU_API
 extern "C" int grx_tu_adroit_prepare(const GrxModel* g, int bytes, int slot, int* shape);
 extern "C" int grx_tu_adroit_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxAdroitTask* t, const GrxAdroitBuffers* b, int n, int words,
                                     int forward_only);
+extern "C" int grx_tu_kitchen_prepare(const GrxModel* g, int bytes, int slot, int* shape);
+extern "C" int grx_tu_kitchen_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxKitchenTask* t, const GrxKitchenBuffers* b, int n, int words,
+                                     int forward_only);
 extern "C" int grx_tu_fetch_prepare(const GrxModel* g, int bytes, int slot, int* shape);
 extern "C" int grx_tu_point_prepare(const GrxModel* g, int bytes, int slot, int* shape);
 extern "C" int grx_tu_hand_prepare(const GrxModel* g, int bytes, int slot, int* shape);
@@ -718,6 +778,7 @@ static int grx_model_create_impl(const int32_t* H, const int32_t* I, const doubl
   if ((e = grx_tu_point_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (point kernels): ") + hipGetErrorString((hipError_t)e));
   if ((e = grx_tu_hand_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (hand kernels): ") + hipGetErrorString((hipError_t)e));
   if ((e = grx_tu_adroit_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (adroit kernels): ") + hipGetErrorString((hipError_t)e));
+  if ((e = grx_tu_kitchen_prepare(&g, bytes, m->slot, &m->shape)) != 0) return fail(std::string("grx_model_create (kitchen kernels): ") + hipGetErrorString((hipError_t)e));
   HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_grx_models), &m->dev, sizeof(GrxModel), sizeof(GrxModel) * (size_t)m->slot, hipMemcpyHostToDevice));
   return 0;
 }
@@ -866,6 +927,22 @@ extern "C" int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, 
   if (t.kind == GRX_ADROIT_RELOCATE && !buf->target) return fail("grx_adroit_step: the relocate task needs the target buffer");
   const int e = grx_tu_adroit_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_adroit_step launch: ") + hipGetErrorString((hipError_t)e));
+  return 0;
+}
+
+extern "C" int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task, const grx_kitchen_buffers* buf, int n_worlds, int forward_only, void* stream) {
+  if (!m || !task || !buf) return fail("grx_kitchen_step: null argument");
+  if (!buf->qpos || !buf->qvel || !buf->qacc_ws || !buf->last_qpos || !buf->obs || !buf->completed || !buf->status) return fail("grx_kitchen_step: null buffer");
+  if (!forward_only && !buf->action) return fail("grx_kitchen_step: null action buffer");
+  if (n_worlds <= 0) return 0;
+  GrxKitchenTask t; memcpy(&t, task, sizeof(t));
+  GrxKitchenBuffers b; memcpy(&b, buf, sizeof(b));
+  const GrxModel& g = m->dev;
+  if (g.nu != GRX_KITCHEN_NROBOT || t.obs_dim != g.nq + g.nv || t.obs_dim > GRX_KITCHEN_OBS || t.n_substeps <= 0) return fail("grx_kitchen_step: the model is not the kitchen scene (nu 9, obs = nq + nv <= 59)");
+  for (int j = 0; j < GRX_KITCHEN_NTASK; j++)
+    if (t.task_adr[j] < 0 || t.task_num[j] < 0 || t.task_adr[j] + t.task_num[j] > g.nq) return fail("grx_kitchen_step: task qpos slice out of range");
+  const int e = grx_tu_kitchen_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  if (e) return fail(std::string("grx_kitchen_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
 
@@ -1023,6 +1100,17 @@ extern "C" int grx_fetch_sample_resets(uint64_t* states, const int64_t* idx, int
       if (target_in_the_air && grx_pcg64_uniform(st, 0.0, 1.0) < 0.5) g[2] += grx_pcg64_uniform(st, 0.0, 0.45);
     }
     for (int e = 0; e < 3; e++) out_goal[3 * k + e] = g[e];
+  }
+  return 0;
+}
+
+// count consecutive Generator.uniform(-1, 1) draws of each listed world's numpy PCG64 stream, as float32 rows (FrankaKitchen's observation noise:
+// franka_env.py:118-127 + kitchen_env.py:361-369 draw 9 + 9 + 21 + 20 per observation).  states as in grx_fetch_sample_resets; HOST pointers.
+extern "C" int grx_sample_uniform_rows(uint64_t* states, const int64_t* idx, int n, int count, float* out) {
+  if (!states || !out) return fail("grx_sample_uniform_rows: null argument");
+  for (int k = 0; k < n; k++) {
+    uint64_t* st = states + 4 * (idx ? idx[k] : k);
+    for (int e = 0; e < count; e++) out[(size_t)k * count + e] = (float)grx_pcg64_uniform(st, -1.0, 1.0);
   }
   return 0;
 }

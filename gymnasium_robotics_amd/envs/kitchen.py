@@ -1,0 +1,264 @@
+"""Batched FrankaKitchen-v1 environments on the MI355X engine (host side, Python).
+
+Vectorised drop-in for KitchenEnv (/root/reference/gymnasium_robotics/envs/franka_kitchen/kitchen_env.py, id FrankaKitchen-v1,
+gymnasium_robotics/__init__.py:1117-1122) and the FrankaRobot it wraps (franka_env.py).  Per step: ONE launch of grx_kitchen_step_kernel
+(velocity command -> position targets on the previous noisy joint reading, 40 physics substeps on the 124-geom scene with its five joint equalities,
+the 59-vector observation with noise, the seven tasks' completion tests).  Host side: the observation noise -- 59 uniform(-1, 1) draws per world and
+step from each world's numpy PCG64 stream, advanced bit-exactly in C (grx_sample_uniform_rows) and uploaded with one copy -- and the task bookkeeping
+of KitchenEnv.step (tasks_to_complete / episode completions as per-world bit masks).
+
+Observations: {"observation": (N, 59), "achieved_goal": {task: (N, k)}, "desired_goal": {task: (N, k)}} -- the reference's dict-of-dicts with a
+leading world axis.  reward = number of still-open tasks completed in this step; terminated when every task of the episode has been completed
+(terminate_on_tasks_completed).
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..core import GoalVecEnv, np_random
+from ..mjcf import CompiledModel
+from ..spaces import Box, Dict, batch_space
+from .kitchen_spec import (INIT_QPOS, MAX_EPISODE_STEPS, OBS_DIM, OBS_ELEMENT_GOALS, OBS_ELEMENT_INDICES, TASKS, load_kitchen_model, make_kitchen_task, task_mask)
+
+
+class KitchenVecEnv(GoalVecEnv):
+    """autoreset_mode: "next_step" (Gymnasium >= 1.0 default), "same_step" or "disabled"; output: "numpy" (float64 arrays like the reference) or
+    "torch" (the fp32 device tensors the kernel wrote; achieved goals are views of the qpos buffer)."""
+
+    def __init__(self, env_id: str = "FrankaKitchen-v1", num_envs: int = 1, device: Optional[str] = None, tasks_to_complete=None,
+                 terminate_on_tasks_completed: bool = True, remove_task_when_completed: bool = True, object_noise_ratio: float = 0.0005,
+                 robot_noise_ratio: float = 0.01, max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step", output: str = "numpy",
+                 assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
+        if env_id != "FrankaKitchen-v1":
+            raise KeyError(f"unknown / unsupported kitchen env id {env_id}")
+        if autoreset_mode not in ("next_step", "same_step", "disabled"):
+            raise ValueError(f"unknown autoreset_mode {autoreset_mode}")
+        self.env_id = env_id
+        self.tasks = list(OBS_ELEMENT_GOALS) if tasks_to_complete is None else list(tasks_to_complete)
+        self._all_mask = task_mask(self.tasks)                 # raises the reference's ValueError for an unknown task (kitchen_env.py:291-294)
+        self.terminate_on_tasks_completed, self.remove_task_when_completed = bool(terminate_on_tasks_completed), bool(remove_task_when_completed)
+        self.robot_noise_ratio, self.object_noise_ratio = float(robot_noise_ratio), float(object_noise_ratio)
+        self.num_envs, self.max_episode_steps, self.autoreset_mode, self.output, self.seed_offset = int(num_envs), max_episode_steps, autoreset_mode, output, int(seed_offset)
+        if not torch.cuda.is_available():
+            raise RuntimeError("KitchenVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
+        self.device = torch.device(device or "cuda:0")
+        self.model = model or load_kitchen_model(assets_root)
+        self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
+        self.obs_dim = OBS_DIM
+        self._L = _native.lib()
+        H, I, F = self.model.pack()
+        self._h = ctypes.c_void_p()
+        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0, ctypes.byref(self._h)))
+        self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
+        self.task = make_kitchen_task(self.model, self.robot_noise_ratio, self.object_noise_ratio)
+        self._noisy = self.robot_noise_ratio != 0.0 or self.object_noise_ratio != 0.0
+        n, d = self.num_envs, self.device
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
+        self.qpos, self.qvel, self.qacc_ws, self.last_qpos = z(n, self.nq), z(n, self.nv), z(n, self.nv), z(n, 9)
+        self.action, self.obs, self.noise = z(n, self.nu), z(n, self.obs_dim), z(n, self.obs_dim)
+        self.completed, self.status, self.mask = z(n, dtype=torch.int32), z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
+        self._noise_host = torch.empty(n, self.obs_dim, dtype=torch.float32, pin_memory=True)
+        self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float64)                     # franka_env.py:88
+        goal_space = Dict({t: Box(-np.inf, np.inf, OBS_ELEMENT_GOALS[t].shape, np.float64) for t in self.tasks})
+        self.single_observation_space = Dict(dict(desired_goal=goal_space, achieved_goal=Dict(dict(goal_space)),
+                                                  observation=Box(-np.inf, np.inf, (self.obs_dim,), np.float64)))   # kitchen_env.py:315-338
+        self.action_space = batch_space(self.single_action_space, n)
+        self.observation_space = batch_space(self.single_observation_space, n)
+        self._init_qpos = torch.from_numpy(INIT_QPOS.astype(np.float32)).to(d)
+        self._goal_np = {t: np.tile(OBS_ELEMENT_GOALS[t], (n, 1)) for t in self.tasks}
+        self._goal_t = {t: torch.from_numpy(self._goal_np[t].astype(np.float32)).to(d) for t in self.tasks}
+        self.tasks_to_complete = np.full(n, self._all_mask, np.int64)          # per-world bit masks (bit k = TASKS[k])
+        self.episode_task_completions = np.zeros(n, np.int64)
+        self._seed_worlds([None] * n)
+        self._elapsed = np.zeros(n, np.int64)
+        self._needs_reset = np.zeros(n, bool)
+        self._has_reset = False
+        self.kernel_events = None
+
+    def _make_bufs(self, mask):
+        b = _native.KitchenBuffersStruct()
+        for name in ("qpos", "qvel", "qacc_ws", "last_qpos", "action", "obs", "completed", "status"):
+            setattr(b, name, getattr(self, name).data_ptr())
+        b.noise = self.noise.data_ptr() if self._noisy else None
+        b.mask = None if mask is None else mask.data_ptr()
+        return b
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ per-world numpy PCG64 streams, advanced in C
+    def _seed_worlds(self, seeds):
+        st, mask = np.zeros((self.num_envs, 4), np.uint64), (1 << 64) - 1
+        for i, sd in enumerate(seeds):
+            s = np_random(sd)[0].bit_generator.state["state"]
+            st[i] = [s["state"] >> 64, s["state"] & mask, s["inc"] >> 64, s["inc"] & mask]
+        self._rng_state = st
+
+    def _draw_noise(self, idx=None):
+        """the 59 uniform(-1, 1) draws of one observation for the listed worlds (all: None) -> rows of self.noise (one async copy)"""
+        if not self._noisy:
+            return
+        if idx is None:
+            _native.check(self._L.grx_sample_uniform_rows(self._rng_state.ctypes.data, None, self.num_envs, self.obs_dim, self._noise_host.data_ptr()))
+            self.noise.copy_(self._noise_host, non_blocking=True)
+        else:
+            idx64 = np.ascontiguousarray(idx, dtype=np.int64)
+            rows = np.empty((len(idx64), self.obs_dim), np.float32)
+            _native.check(self._L.grx_sample_uniform_rows(self._rng_state.ctypes.data, idx64.ctypes.data, len(idx64), self.obs_dim, rows.ctypes.data))
+            self.noise[torch.from_numpy(idx64).to(self.device)] = torch.from_numpy(rows).to(self.device)
+
+    def _launch(self, bufs, forward_only):
+        timed = self.kernel_events is not None and not forward_only
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _native.check(self._L.grx_kitchen_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, int(forward_only), self._stream()))
+        if timed:
+            e1.record()
+            self.kernel_events.append((e0, e1))
+
+    # ------------------------------------------------------------------ reset (kitchen_env.py:425-437 -> FrankaRobot.reset -> reset_model, franka_env.py:133-139)
+    def _reset_worlds(self, idx):
+        if len(idx) == 0:
+            return None
+        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        self.qpos[ti] = self._init_qpos
+        self.qvel[ti] = 0.0
+        self.qacc_ws[ti] = 0.0
+        self._draw_noise(idx if len(idx) < self.num_envs else None)
+        self.mask.zero_()
+        self.mask[ti] = 1
+        self._launch(self._bufs_masked, True)
+        self.tasks_to_complete[idx] = self._all_mask
+        self.episode_task_completions[idx] = 0
+        self._elapsed[idx] = 0
+        self._needs_reset[idx] = False
+        return ti
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
+            self._seed_worlds(seeds)
+        with torch.cuda.device(self.device):
+            self._reset_worlds(np.arange(self.num_envs))
+        self._has_reset = True
+        return self._obs_dict(), self._info(np.zeros(self.num_envs, np.int64))
+
+    # ------------------------------------------------------------------ step (kitchen_env.py:386-423)
+    def step(self, actions):
+        if not self._has_reset:
+            raise RuntimeError("Cannot call env.step() before calling env.reset()")
+        a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions, dtype=np.float32))
+        if tuple(a.shape) != (self.num_envs, self.nu):
+            raise ValueError(f"Action dimension mismatch. Expected {(self.num_envs, self.nu)}, found {tuple(a.shape)}")
+        self.action.copy_(a.to(torch.float32), non_blocking=True)
+        info = {}
+        with torch.cuda.device(self.device):
+            pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
+            stepped = ~self._needs_reset
+            self._draw_noise(None if not len(pending) else np.nonzero(stepped)[0])
+            if len(pending):
+                self.mask.fill_(1)
+                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                self._launch(self._bufs_masked, False)
+            else:
+                self._launch(self._bufs, False)
+            done_bits = self.completed.cpu().numpy().astype(np.int64)
+            # compute_reward over the tasks still open, bookkeeping of KitchenEnv.step
+            step_done = np.where(stepped, done_bits & self.tasks_to_complete, 0)
+            reward = np.array([bin(int(x)).count("1") for x in step_done], dtype=np.float64) if self.num_envs <= 64 else _popcount(step_done).astype(np.float64)
+            if self.remove_task_when_completed:
+                self.tasks_to_complete &= ~step_done
+            self.episode_task_completions |= step_done
+            terminated = np.zeros(self.num_envs, bool)
+            if self.terminate_on_tasks_completed:
+                terminated = stepped & (self.episode_task_completions == self._all_mask)
+            self._elapsed[stepped] += 1
+            truncated = np.zeros(self.num_envs, bool)
+            if self.max_episode_steps is not None:
+                truncated = stepped & (self._elapsed >= self.max_episode_steps)
+            step_info = self._info(step_done)
+            if len(pending):
+                self._reset_worlds(pending)
+                reward[pending] = 0.0
+                step_info = self._info(step_done)
+            done = terminated | truncated
+            if self.autoreset_mode == "same_step" and done.any():
+                idx = np.nonzero(done)[0]
+                info["final_obs"] = self._obs_dict(rows=idx)
+                info["final_info"] = {k: (v[idx] if isinstance(v, np.ndarray) else v) for k, v in step_info.items()}
+                keep = self.status.clone()
+                self._reset_worlds(idx)
+                self.status.copy_((keep & 0xFFFF) | (self.status & -65536))
+                fresh = np.asarray(step_done).copy()
+                fresh[idx] = 0
+                step_info = self._info(fresh)          # the reset worlds report their new episode (gymnasium's same-step convention); the last step's info is in final_info
+            elif self.autoreset_mode == "next_step":
+                self._needs_reset |= done
+        info.update(step_info)
+        r = torch.from_numpy(reward).to(self.device) if self.output == "torch" else reward
+        if self.output == "torch":
+            return self._obs_dict(), r, torch.from_numpy(terminated), torch.from_numpy(truncated), self._status_info(info)
+        return self._obs_dict(), r, terminated, truncated, self._status_info(info)
+
+    def _info(self, step_done):
+        """the reference's info lists as per-world bit masks over kitchen_spec.TASKS (bit k = TASKS[k]); task_names(mask) turns one into the list of names"""
+        return dict(tasks_to_complete=self.tasks_to_complete.copy(), step_task_completions=np.asarray(step_done, dtype=np.int64).copy(),
+                    episode_task_completions=self.episode_task_completions.copy())
+
+    @staticmethod
+    def task_names(mask: int):
+        return [t for k, t in enumerate(TASKS) if (int(mask) >> k) & 1]
+
+    def _obs_dict(self, rows=None):
+        if self.output == "torch":
+            sel = (lambda t: t) if rows is None else (lambda t: t[torch.from_numpy(np.asarray(rows)).to(self.device)])
+            qp = sel(self.qpos)
+            return {"observation": sel(self.obs), "achieved_goal": {t: qp[:, OBS_ELEMENT_INDICES[t][0]: OBS_ELEMENT_INDICES[t][-1] + 1] for t in self.tasks},
+                    "desired_goal": {t: sel(self._goal_t[t]) for t in self.tasks}}
+        sel = (lambda a: a) if rows is None else (lambda a: a[rows])
+        qp = sel(self.qpos.double().cpu().numpy())
+        return {"observation": sel(self.obs.double().cpu().numpy()), "achieved_goal": {t: qp[:, OBS_ELEMENT_INDICES[t]] for t in self.tasks},
+                "desired_goal": {t: sel(self._goal_np[t]) for t in self.tasks}}
+
+    # ------------------------------------------------------------------ GoalEnv API (kitchen_env.py:340-354), batched
+    def compute_reward(self, achieved_goal, desired_goal, info=None):
+        """number of the env's tasks whose achieved goal is within BONUS_THRESH of the desired one, per leading index (the reference counts over its
+        CURRENT tasks_to_complete, a per-env set; pass info={"tasks_to_complete": masks} to restrict the count the same way)"""
+        from .kitchen_spec import BONUS_THRESH
+
+        total = None
+        masks = None if not info or "tasks_to_complete" not in info else np.asarray(info["tasks_to_complete"])
+        for t in self.tasks:
+            d = np.linalg.norm(np.asarray(achieved_goal[t], dtype=np.float64) - np.asarray(desired_goal[t], dtype=np.float64), axis=-1)
+            c = (d < BONUS_THRESH).astype(np.float64)
+            if masks is not None:
+                c = c * ((masks >> TASKS.index(t)) & 1)
+            total = c if total is None else total + c
+        return total
+
+    def compute_terminated(self, achieved_goal, desired_goal, info=None):
+        return np.zeros(np.asarray(next(iter(achieved_goal.values()))).shape[:-1], bool)
+
+    def compute_truncated(self, achieved_goal, desired_goal, info=None):
+        return np.zeros(np.asarray(next(iter(achieved_goal.values()))).shape[:-1], bool)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.grx_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _popcount(x):
+    x = np.asarray(x, dtype=np.int64)
+    return sum((x >> k) & 1 for k in range(len(TASKS)))

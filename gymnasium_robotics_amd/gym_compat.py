@@ -156,6 +156,8 @@ def max_episode_steps_of(env_id: str) -> int:
         return 100                     # __init__.py:141 ...
     if family == "adroit":
         return 200                     # __init__.py:1092-1113
+    if family == "kitchen":
+        return 280                     # __init__.py:1120
     return (maze_spec.parse_point_maze_id if family == "point_maze" else maze_spec.parse_ant_maze_id)(env_id)[2]
 
 

@@ -151,6 +151,27 @@ typedef struct grx_adroit_buffers {
   const unsigned char* mask;       /* [N] or NULL */
 } grx_adroit_buffers;
 
+/* mirrors struct GrxKitchenTask / GrxKitchenBuffers (csrc/grx_kitchen_task.h): FrankaKitchen-v1 */
+typedef struct grx_kitchen_task {
+  int n_substeps, obs_dim;          /* 40 (franka_env.py:54), 59 (kitchen_env.py:109) */
+  float dt;                         /* MujocoEnv.dt = timestep * frame_skip */
+  float vel_lo[9], vel_hi[9], pos_lo[9], pos_hi[9];   /* franka_config.xml: vel_bound / pos_bound of the nine robot joints (franka_env.py:136-171) */
+  float noise_scale[59];            /* noise ratio * amplitude per observation element (franka_env.py:118-127, kitchen_env.py:361-369) */
+  int task_adr[7], task_num[7];     /* qpos slices OBS_ELEMENT_INDICES (kitchen_env.py:19-27) */
+  float task_goal[17];              /* OBS_ELEMENT_GOALS, concatenated (:28-37) */
+  float bonus_thresh;               /* BONUS_THRESH 0.3 (:38) */
+} grx_kitchen_task;
+typedef struct grx_kitchen_buffers {
+  float *qpos, *qvel, *qacc_ws;     /* [N,30] [N,29] [N,29] */
+  float* last_qpos;                 /* [N,9] in/out: FrankaRobot._last_robot_qpos, the (noisy) joint reading of the previous observation */
+  const float* action;              /* [N,9] (may be NULL when forward_only) */
+  const float* noise;               /* [N,59] uniform(-1, 1) draws of this observation (grx_sample_uniform_rows) or NULL */
+  float* obs;                       /* [N,59] */
+  int* completed;                   /* [N] bit k: |qpos[task k] - goal k| < bonus_thresh (compute_reward's per-task test, kitchen_env.py:346-351) */
+  int* status;                      /* [N] */
+  const unsigned char* mask;        /* [N] or NULL */
+} grx_kitchen_buffers;
+
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);
 int grx_model_destroy(grx_model* m);
 int grx_model_set_table(grx_model* m, const char* name, const double* data, int n);
@@ -193,6 +214,12 @@ int grx_hand_step(const grx_model* m, const grx_hand_task* task, const grx_hand_
  * noslip post-solver, adroit_assets.xml:3) + _get_obs + reward + success (envs/adroit_hand/adroit_hammer.py:291-357, adroit_door.py:281-347,
  * adroit_pen.py:288-365, adroit_relocate.py:290-338); forward_only != 0: the reset path (set_state -> mj_forward, _get_obs) */
 int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, const grx_adroit_buffers* buf, int n_worlds, int forward_only, void* stream);
+/* KitchenEnv.step for N worlds: FrankaRobot.step (clip, velocity command -> position target on the previous noisy reading, bounds, do_simulation(ctrl, 40))
+ * + FrankaRobot._get_obs + KitchenEnv._get_obs (59-vector with observation noise) + the per-task completion tests of compute_reward
+ * (envs/franka_kitchen/franka_env.py:92-171, kitchen_env.py:340-384); forward_only != 0: the reset path (set_state -> mj_forward, _get_obs) */
+int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task, const grx_kitchen_buffers* buf, int n_worlds, int forward_only, void* stream);
+/* `count` consecutive np_random.uniform(-1, 1) draws per listed world, float32 rows (states / idx as in grx_fetch_sample_resets; idx NULL = worlds 0..n-1).  HOST pointers. */
+int grx_sample_uniform_rows(uint64_t* states, const int64_t* idx, int n, int count, float* out);
 int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
                             float* reward_out, void* stream);
 /* batched MujocoManipulateEnv.compute_reward on 7-vector pose goals (shadow_dexterous_hand/manipulate.py:87-142) */

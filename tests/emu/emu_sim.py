@@ -77,6 +77,17 @@ class EmuSim:
                                  ctypes.c_int(nstep))
         return ncon.value, nefc.value
 
+    def kitchen_step(self, action, last_qpos, noise=None, forward_only=False):
+        """FrankaKitchen env.step() (or the reset-time forward pass) of one world; last_qpos is updated in place; returns (obs[59], completed mask)"""
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        nz = None if noise is None else p(np.ascontiguousarray(noise, dtype=np.float32))
+        obs, done = np.zeros(int(self.task.obs_dim), np.float32), ctypes.c_int(0)
+        assert last_qpos.dtype == np.float32 and last_qpos.shape == (9,)
+        self.L.emu_kitchen_step(ctypes.c_void_p(self.h), ctypes.byref(self.task), p(self.qpos), p(self.qvel), p(self.qacc_ws), p(last_qpos), p(a), nz, p(obs),
+                                ctypes.byref(done), ctypes.byref(self.status), ctypes.c_int(int(forward_only)))
+        return obs, done.value
+
     def point_step(self, action):
         a = np.ascontiguousarray(action, dtype=np.float32)
         p = lambda x: x.ctypes.data_as(ctypes.c_void_p)

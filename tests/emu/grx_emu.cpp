@@ -29,6 +29,7 @@
 #include "../../gymnasium_robotics_amd/csrc/grx_point_task.h"
 #include "../../gymnasium_robotics_amd/csrc/grx_hand_task.h"
 #include "../../gymnasium_robotics_amd/csrc/grx_adroit_task.h"
+#include "../../gymnasium_robotics_amd/csrc/grx_kitchen_task.h"
 #include "../../gymnasium_robotics_amd/csrc/grx_host_model.h"
 
 struct Emu {
@@ -144,6 +145,18 @@ void emu_adroit_step(void* h, const GrxAdroitTask* t, float* qpos, float* qvel, 
   if (forward_only) GrxEngine<GrxShapeAny>::grx_forward_euler(&e->m, &e->c, 0, 0);
   else GrxAdroit<GrxShapeAny>::grx_adroit_sim_world(&e->m, t, &e->c, action, act_mean, act_rng, 0);
   GrxAdroit<GrxShapeAny>::grx_adroit_outputs(&e->m, t, &e->c, target, obs, reward, success, 0);
+  store_state(e, qpos, qvel, qacc_ws, mocap, status);
+}
+
+// FrankaKitchen env.step() of one world (forward_only: mj_forward + outputs, the reset path)
+void emu_kitchen_step(void* h, const GrxKitchenTask* t, float* qpos, float* qvel, float* qacc_ws, float* last_qpos, const float* action, const float* noise, float* obs,
+                      int* completed, int* status, int forward_only) {
+  Emu* e = (Emu*)h;
+  float mocap[8] = {0};
+  load_state(e, qpos, qvel, qacc_ws, mocap);
+  if (forward_only) GrxEngine<GrxShapeAny>::grx_forward_euler(&e->m, &e->c, 0, 0);
+  else GrxKitchen<GrxShapeAny>::grx_kitchen_sim_world(&e->m, t, &e->c, action, last_qpos, 0);
+  GrxKitchen<GrxShapeAny>::grx_kitchen_outputs(&e->m, t, &e->c, noise, obs, last_qpos, completed, 0);
   store_state(e, qpos, qvel, qacc_ws, mocap, status);
 }
 

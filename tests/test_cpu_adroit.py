@@ -19,8 +19,6 @@ def test_registry_and_model_dimensions(model):
     import gymnasium_robotics_amd as grx
 
     assert grx.env_family("AdroitHandHammer-v2") == "adroit" and grx.env_family("AdroitHandPenSparse-v2") == "adroit"
-    with pytest.raises(grx.UnsupportedEnvError):
-        grx.env_family("FrankaKitchen-v1")
     # door 30 / 30 / 28, pen 30 / 30 / 24, relocate 36 / 36 / 30; every dof carries a friction-loss row (adroit_assets.xml:12)
     from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_model
     for task, dims in (("door", (30, 30, 28)), ("pen", (30, 30, 24)), ("relocate", (36, 36, 30))):

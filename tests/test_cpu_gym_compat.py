@@ -44,7 +44,7 @@ def test_every_served_id_is_registered_with_the_reference_time_limit(fake_gymnas
     # the reference's register() calls (gymnasium_robotics/__init__.py): max_episode_steps per family
     want = {"grx/FetchPickAndPlace-v4": 50, "grx/HandReachDense-v3": 50, "grx/HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1": 100,
             "grx/AdroitHandRelocateSparse-v2": 200, "grx/PointMaze_UMaze-v3": 300, "grx/PointMaze_Large_Diverse_GR-v3": 800, "grx/AntMaze_UMaze-v5": 700,
-            "grx/AntMaze_Large_Diverse_GR-v5": 1000, "grx/AntMaze_Medium-v5": 1000, "grx/PointMaze_MediumDense-v3": 600}
+            "grx/AntMaze_Large_Diverse_GR-v5": 1000, "grx/AntMaze_Medium-v5": 1000, "grx/PointMaze_MediumDense-v3": 600, "grx/FrankaKitchen-v1": 280}
     for gid, limit in want.items():
         assert by_id[gid]["max_episode_steps"] == limit, gid
         assert by_id[gid]["kwargs"] == {"env_id": gid[4:]}

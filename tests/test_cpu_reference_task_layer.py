@@ -294,3 +294,32 @@ def test_reference_adroit_door_pen_relocate_on_oracle_physics(task, reward_type)
     assert all(np.allclose(st2[k], st[k], atol=1e-12) for k in ref._state_space.spaces) and np.allclose(b_env.model_edit, edit, atol=1e-12)
     nj = {"door": 27, "pen": 24, "relocate": 30}[task]
     assert np.array_equal(ref._get_obs()[:nj], before[:nj])
+
+
+@pytest.mark.parametrize("kwargs", [{}, {"tasks_to_complete": ["microwave", "kettle"], "remove_task_when_completed": False}])
+def test_reference_kitchen_on_oracle_physics(kwargs):
+    """franka_env.py:92-171 and kitchen_env.py:340-437 executed as they are (velocity command on the previous noisy reading, position / velocity
+    bounds read from franka_config.xml by the reference's own parser, do_simulation(ctrl, 40), both _get_obs with their PCG64 noise draws,
+    compute_reward, task bookkeeping, termination) on the oracle physics: identical to the restated task layer (oracle/kitchen_oracle.py), bit for bit."""
+    from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model
+    from oracle.kitchen_oracle import OracleKitchenEnv
+
+    ref_harness.install()
+    model = load_kitchen_model()
+    a_env, b_env = OracleKitchenEnv(model, **kwargs), OracleKitchenEnv(model, **kwargs)
+    ref = ref_harness.kitchen_on_oracle(b_env)
+    rng = np.random.default_rng(1)
+    for seed in (0, 3):
+        (oa, ia), (ob, ib) = a_env.reset(seed=seed), ref.reset(seed=seed)
+        assert ob["observation"].shape == (59,) and np.array_equal(oa["observation"], ob["observation"]) and sorted(ia["tasks_to_complete"]) == sorted(ib["tasks_to_complete"])
+        for t in range(10):
+            act = rng.uniform(-1.3, 1.3, 9)
+            if t == 4:   # put the microwave door at its goal: a completion (and, with the two-task list, not yet termination) on both sides
+                a_env.sim.qpos[22] = b_env.sim.qpos[22] = -0.75
+            sa, sb = a_env.step(act), ref.step(act)
+            assert np.array_equal(sa[0]["observation"], sb[0]["observation"]), (seed, t, np.abs(sa[0]["observation"] - sb[0]["observation"]).max())
+            assert sa[1] == sb[1] and sa[2] == sb[2] and sb[3] is False and sorted(sa[4]["tasks_to_complete"]) == sorted(sb[4]["tasks_to_complete"])
+            assert sa[4]["step_task_completions"] == sb[4]["step_task_completions"] and sa[4]["episode_task_completions"] == sb[4]["episode_task_completions"]
+            for k in sa[0]["achieved_goal"]:
+                assert np.array_equal(sa[0]["achieved_goal"][k], sb[0]["achieved_goal"][k]) and np.array_equal(sa[0]["desired_goal"][k], sb[0]["desired_goal"][k])
+        assert "microwave" in sa[4]["episode_task_completions"]

@@ -84,3 +84,11 @@ for task, spec in ADROIT_SPECS.items():
     save_model(m, out)
     print(f"adroit_hand/{spec['xml']} ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "nsite", "npair")}, "unsupported pairs:", m.info["unsupported_pairs"],
           f"{os.path.getsize(out) / 1024:.0f} KiB")
+
+from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model  # noqa: E402
+
+m = load_kitchen_model(ASSETS)      # compiles kitchen_env_model.xml and attaches the numbers of franka_config.xml (model.info["franka_config"])
+out = os.path.join(OUT, "kitchen.npz")
+save_model(m, out)
+print("kitchen_franka/kitchen_assets/kitchen_env_model.xml ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "joint equalities:", len(m.tables["jeq_eq"]),
+      "unsupported pairs:", m.info["unsupported_pairs"], f"{os.path.getsize(out) / 1024:.0f} KiB")
