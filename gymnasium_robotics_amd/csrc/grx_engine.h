@@ -765,12 +765,13 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit 
   if (n == 14) return grx_sym_solve_reg<14>(A, n, x, lane_);
   if (n == 15) return grx_sym_solve_reg<15>(A, n, x, lane_);
   if (n == 24) return grx_sym_solve_reg<24>(A, n, x, lane_);
+  if (n == 29) return grx_sym_solve_reg<29>(A, n, x, lane_);
   if (n == 30) return grx_sym_solve_reg<30>(A, n, x, lane_);
   if (n == 33) return grx_sym_solve_reg<33>(A, n, x, lane_);
   if (n == 36) return grx_sym_solve_reg<36>(A, n, x, lane_);
 #endif
 #if defined(GRX_EMU)
-  if (n == 21 || n == 14 || n == 15 || n == 24 || n == 30 || n == 33 || n == 36) {   // mirror the device: these sizes are solved without touching A
+  if (n == 21 || n == 14 || n == 15 || n == 24 || n == 29 || n == 30 || n == 33 || n == 36) {   // mirror the device: these sizes are solved without touching A
     static float copy[36 * 36];
     for (int i = 0; i < n * n; i++) copy[i] = A[i];
     int bad_ = grx_sym_factor(copy, n, lane_);
@@ -1845,16 +1846,23 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   // Models with more than one wave of candidates (the Fetch arm: 163, most of them hull pairs): a first sweep runs only the bounding-sphere /
   // plane-distance test and compacts the survivors (ballot prefix, pair order), so the narrow phases and the bounding-box tests below see
   // ONE dense pass instead of one sparse, divergent pass per 64 candidates.
+  // Scenes with more candidates than the survivor list has room for (the kitchen: 3 736) are swept in chunks of that size: pair order is kept.
   const int ndp = m->ndevpair;
-  int nsurv = ndp; const int* surv = nullptr;
-  if (ndp > 64 && 256 + ndp <= c->jpool) {
+  const int cap = c->jpool - 256, compact = ndp > 64 && cap >= 64;
+  constexpr bool kChunked = !S::kFixed || S::NG > 64;   // small scenes (every specialised shape but the kitchen): one pass, no loop around the sweep
+  const int chunk = (kChunked && compact && cap < ndp) ? cap : (ndp > 0 ? ndp : 1);
+  int c0 = 0;
+  do {
+  const int cend = c0 + chunk < ndp ? c0 + chunk : ndp;
+  int nsurv = cend - c0; const int* surv = nullptr;
+  if (compact) {
     int* sv = (int*)(c->Jp + 256);   // the Jacobian pool is free until the constraint stage ([0, 128) is c->red, [128, 222) the hull-pair queue + portal)
     int ns = 0;
-    for (int base = 0; base < ndp; base += 64) {
+    for (int base = c0; base < cend; base += 64) {
       GRX_LANEVAR_I(ps);
       FOR_LANES {
         const int k = base + lane; int pass = 0;
-        if (k < ndp) {
+        if (k < cend) {
           const unsigned rec = (unsigned)m->devpair_geoms[k];
           const int g1 = rec & 0xFFF, g2 = (rec >> 12) & 0xFFF, t1 = (rec >> 24) & 0xF;
           const float margin = m->devpair_bound[2 * k], rb = m->devpair_bound[2 * k + 1];
@@ -1988,6 +1996,8 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
       WAVE_SYNC();
     }
   }
+  c0 += chunk;
+  } while (kChunked && c0 < ndp);
   LANE0 { if (c->cnt[0] > c->maxcon) c->cnt[0] = c->maxcon; }
   WAVE_SYNC();
   // The noslip sweeps are Gauss-Seidel over the contact list: while they have not converged their iterates depend on the ORDER of the list.
@@ -2828,7 +2838,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const int implicit_damp = (m->anydamp && m->eulerdamp);
   int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0, g0_ready = 0;
   // the linear solve leaves c->A intact where it runs from registers (grx_sym_solve_full): the Hessian can then be corrected in place
-  const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 30 || nv == 33 || nv == 36);
+  const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 29 || nv == 30 || nv == 33 || nv == 36);
   // Newton starts from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart,
   // M^-1 qfrc_smooth); the minimiser of the strictly convex problem does not depend on the start, and skipping the
   // comparison saves one factorisation of M per substep.

@@ -16,10 +16,11 @@ _native.LIB_PATH = prof_so
 from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
 from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv, HandReachVecEnv
 from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv
-from gymnasium_robotics_amd.envs.adroit import AdroitHammerVecEnv
+from gymnasium_robotics_amd.envs.adroit import AdroitVecEnv as AdroitHammerVecEnv
+from gymnasium_robotics_amd.envs.kitchen import KitchenVecEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env_id = sys.argv[2] if len(sys.argv) > 2 else "FetchPickAndPlace-v4"
-Env = AdroitHammerVecEnv if env_id.startswith("Adroit") else FetchVecEnv if env_id.startswith("Fetch") else AntMazeVecEnv if env_id.startswith("AntMaze") else (HandReachVecEnv if env_id.startswith("HandReach") else HandBlockVecEnv)
+Env = KitchenVecEnv if env_id.startswith("FrankaKitchen") else AdroitHammerVecEnv if env_id.startswith("Adroit") else FetchVecEnv if env_id.startswith("Fetch") else AntMazeVecEnv if env_id.startswith("AntMaze") else (HandReachVecEnv if env_id.startswith("HandReach") else HandBlockVecEnv)
 env = Env(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
 env.reset(seed=0)
 NA = env.single_action_space.shape[0]
