@@ -27,6 +27,7 @@ CASES = {
     "AdroitDoor": ("AdroitHandDoor-v2", "adroit_door_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift"), {"qpos": np.r_[0:29], "positions": np.r_[29:38]}),
     "AdroitPen": ("AdroitHandPen-v2", "adroit_pen_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift"),
                   {"qpos": np.r_[0:24], "pen_position_orientation": np.r_[24:27, 33:36, 39:45], "pen_velocity": np.r_[27:33]}),
+    "FrankaKitchen": ("FrankaKitchen-v1", "kitchen_teacher.npz", ("qpos", "qvel", "qacc_ws", "last_qpos"), {"positions": np.r_[0:9, 18:39], "velocities": np.r_[9:18, 39:59]}),
     "AdroitRelocate": ("AdroitHandRelocate-v2", "adroit_relocate_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift", "target"), {"qpos": np.r_[0:30], "positions": np.r_[30:39]}),
 }
 
@@ -44,6 +45,9 @@ def family_errors(name):
     env.reset(seed=0)
     for k in keys:
         getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    if name == "FrankaKitchen":      # the fixture's recorded noise draws instead of the env's own streams
+        noise = torch.from_numpy(g["noise"].astype(np.float32)).to(env.device)
+        env._draw_noise = lambda idx=None: env.noise.copy_(noise)
     out = env.step(g["action"])
     obs = out[0]["observation"] if isinstance(out[0], dict) else out[0]
     e = np.abs(obs - g["obs"])
