@@ -97,19 +97,37 @@ class KitchenVecEnv(GoalVecEnv):
             s = np_random(sd)[0].bit_generator.state["state"]
             st[i] = [s["state"] >> 64, s["state"] & mask, s["inc"] >> 64, s["inc"] & mask]
         self._rng_state = st
+        self._noise_uploaded = None
+        self._refill_noise(None)
 
+    # Every world's NEXT 59 draws are always sitting in the pinned `_noise_host` rows: an observation (step or reset) uploads its worlds' rows, and
+    # the rows are refilled from the streams while the kernel that consumes them runs -- the streams advance in exactly the order of the observations.
     def _draw_noise(self, idx=None):
-        """the 59 uniform(-1, 1) draws of one observation for the listed worlds (all: None) -> rows of self.noise (one async copy)"""
+        """upload the pending draws of the listed worlds (all: None) into self.noise (async); _refill_noise(idx) must follow the launch"""
         if not self._noisy:
             return
         if idx is None:
-            _native.check(self._L.grx_sample_uniform_rows(self._rng_state.ctypes.data, None, self.num_envs, self.obs_dim, self._noise_host.data_ptr()))
             self.noise.copy_(self._noise_host, non_blocking=True)
+        else:
+            ti = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64))
+            self.noise[ti.to(self.device)] = self._noise_host[ti].to(self.device)
+        self._noise_uploaded = torch.cuda.Event()
+        self._noise_uploaded.record(torch.cuda.current_stream(self.device))
+
+    def _refill_noise(self, idx=None):
+        """draw the next 59 uniform(-1, 1) values of the listed worlds' streams (C, bit-exact with Generator.uniform) into their pinned rows"""
+        if not self._noisy:
+            return
+        if getattr(self, "_noise_uploaded", None) is not None:
+            self._noise_uploaded.synchronize()          # the copy that reads the rows must be done before they are overwritten (it precedes the kernel)
+            self._noise_uploaded = None
+        if idx is None:
+            _native.check(self._L.grx_sample_uniform_rows(self._rng_state.ctypes.data, None, self.num_envs, self.obs_dim, self._noise_host.data_ptr()))
         else:
             idx64 = np.ascontiguousarray(idx, dtype=np.int64)
             rows = np.empty((len(idx64), self.obs_dim), np.float32)
             _native.check(self._L.grx_sample_uniform_rows(self._rng_state.ctypes.data, idx64.ctypes.data, len(idx64), self.obs_dim, rows.ctypes.data))
-            self.noise[torch.from_numpy(idx64).to(self.device)] = torch.from_numpy(rows).to(self.device)
+            self._noise_host[torch.from_numpy(idx64)] = torch.from_numpy(rows)
 
     def _launch(self, bufs, forward_only):
         timed = self.kernel_events is not None and not forward_only
@@ -129,10 +147,12 @@ class KitchenVecEnv(GoalVecEnv):
         self.qpos[ti] = self._init_qpos
         self.qvel[ti] = 0.0
         self.qacc_ws[ti] = 0.0
-        self._draw_noise(idx if len(idx) < self.num_envs else None)
+        which = idx if len(idx) < self.num_envs else None
+        self._draw_noise(which)
         self.mask.zero_()
         self.mask[ti] = 1
         self._launch(self._bufs_masked, True)
+        self._refill_noise(which)
         self.tasks_to_complete[idx] = self._all_mask
         self.episode_task_completions[idx] = 0
         self._elapsed[idx] = 0
@@ -160,13 +180,15 @@ class KitchenVecEnv(GoalVecEnv):
         with torch.cuda.device(self.device):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
             stepped = ~self._needs_reset
-            self._draw_noise(None if not len(pending) else np.nonzero(stepped)[0])
+            which = None if not len(pending) else np.nonzero(stepped)[0]
+            self._draw_noise(which)
             if len(pending):
                 self.mask.fill_(1)
                 self.mask[torch.from_numpy(pending).to(self.device)] = 0
                 self._launch(self._bufs_masked, False)
             else:
                 self._launch(self._bufs, False)
+            self._refill_noise(which)          # host draws for the NEXT observation of these worlds while the kernel runs
             done_bits = self.completed.cpu().numpy().astype(np.int64)
             # compute_reward over the tasks still open, bookkeeping of KitchenEnv.step
             step_done = np.where(stepped, done_bits & self.tasks_to_complete, 0)
