@@ -1858,23 +1858,36 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   if (compact) {
     int* sv = (int*)(c->Jp + 256);   // the Jacobian pool is free until the constraint stage ([0, 128) is c->red, [128, 222) the hull-pair queue + portal)
     int ns = 0;
-    for (int base = c0; base < cend; base += 64) {
-      GRX_LANEVAR_I(ps);
+    // four groups of 64 candidates per round: their table records (global memory, one dependent load chain per candidate) are fetched together,
+    // so that a round pays one memory latency instead of four
+    for (int base = c0; base < cend; base += 256) {
+      GRX_LANEVAR_I(ps0); GRX_LANEVAR_I(ps1); GRX_LANEVAR_I(ps2); GRX_LANEVAR_I(ps3);
       FOR_LANES {
-        const int k = base + lane; int pass = 0;
-        if (k < cend) {
-          const unsigned rec = (unsigned)m->devpair_geoms[k];
-          const int g1 = rec & 0xFFF, g2 = (rec >> 12) & 0xFFF, t1 = (rec >> 24) & 0xF;
-          const float margin = m->devpair_bound[2 * k], rb = m->devpair_bound[2 * k + 1];
-          float dx[3] = {c->gxpos[3 * g2] - c->gxpos[3 * g1], c->gxpos[3 * g2 + 1] - c->gxpos[3 * g1 + 1], c->gxpos[3 * g2 + 2] - c->gxpos[3 * g1 + 2]};
-          if (t1 == 0) { float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}; pass = dot3f(dx, n) <= rb + margin; }
-          else { const float r = rb + margin; pass = dot3f(dx, dx) <= r * r; }
+        unsigned rec[4]; float mg[4], rb[4]; int ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = base + 64 * u + lane;
+          ok[u] = k < cend;
+          const int kk = ok[u] ? k : c0;
+          rec[u] = (unsigned)m->devpair_geoms[kk]; mg[u] = m->devpair_bound[2 * kk]; rb[u] = m->devpair_bound[2 * kk + 1];
         }
-        LV(ps) = pass;
+        int pass[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int g1 = rec[u] & 0xFFF, g2 = (rec[u] >> 12) & 0xFFF, t1 = (rec[u] >> 24) & 0xF;
+          float dx[3] = {c->gxpos[3 * g2] - c->gxpos[3 * g1], c->gxpos[3 * g2 + 1] - c->gxpos[3 * g1 + 1], c->gxpos[3 * g2 + 2] - c->gxpos[3 * g1 + 2]};
+          int ps;
+          if (t1 == 0) { float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}; ps = dot3f(dx, n) <= rb[u] + mg[u]; }
+          else { const float r = rb[u] + mg[u]; ps = dot3f(dx, dx) <= r * r; }
+          pass[u] = ok[u] && ps;
+        }
+        LV(ps0) = pass[0]; LV(ps1) = pass[1]; LV(ps2) = pass[2]; LV(ps3) = pass[3];
       }
-      const unsigned long long bm = GRX_BALLOT(ps);
-      FOR_LANES { if (LV(ps)) sv[ns + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = base + lane; }
-      ns += __builtin_popcountll(bm);
+#define GRX_COMPACT_GROUP(PS, U) { const unsigned long long bm = GRX_BALLOT(PS); \
+        FOR_LANES { if (LV(PS)) sv[ns + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = base + 64 * (U) + lane; } \
+        ns += __builtin_popcountll(bm); }
+      GRX_COMPACT_GROUP(ps0, 0) GRX_COMPACT_GROUP(ps1, 1) GRX_COMPACT_GROUP(ps2, 2) GRX_COMPACT_GROUP(ps3, 3)
+#undef GRX_COMPACT_GROUP
     }
     WAVE_SYNC();
     nsurv = ns; surv = sv;
