@@ -1,8 +1,14 @@
+# round-end evidence run (ON the GPU box, from the repo root): every bench line with its CPU baseline, rocprofv3 kernel stats + PMC traffic of every workload
 set -x
 mkdir -p gpurun_out
-for w in fetch hand_touch hand_reach antmaze adroit adroit_door adroit_pen adroit_relocate; do
+python tools/collect_profiles.py r02 > gpurun_out/collect_fetch.log 2>&1
+python tools/collect_profiles.py r02 workloads antmaze hand_touch hand_reach adroit adroit_door adroit_pen adroit_relocate kitchen > gpurun_out/collect_workloads.log 2>&1
+for w in fetch hand_touch hand_reach antmaze adroit adroit_door adroit_pen adroit_relocate kitchen; do
   python bench.py --workload $w > gpurun_out/bench_r02_$w.json 2> gpurun_out/bench_r02_$w.err
-  tail -c 300 gpurun_out/bench_r02_$w.json
+  tail -c 200 gpurun_out/bench_r02_$w.json
 done
 python bench.py --no-stagger --no-cpu-baseline > gpurun_out/bench_r02_fetch_lockstep.json 2>/dev/null
-python bench.py --workload hand_touch --no-stagger --no-cpu-baseline > gpurun_out/bench_r02_hand_touch_lockstep.json 2>/dev/null
+# the raw rocprofv3 output directories are tens of MB each: only the summaries travel back (gpurun_out/ is capped at 64 MiB)
+find gpurun_out -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+rm -f gpurun_out/*.log
+du -sh gpurun_out
