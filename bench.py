@@ -169,13 +169,13 @@ def run_rank(args, rank, world_size, local_rank):
 
         replay = HerReplay(env, horizon=w["horizon"], capacity=HER_K * n * 8, seed=rank, continuous=True)
         replay.begin_episode(env.packed)
-        replay.episode_start.copy_(torch.from_numpy(-env._elapsed.astype(np.int32)).to(device))   # staggered: world i is elapsed[i] steps into its episode
+        replay.set_episode_start(-env._elapsed)   # staggered: world i is elapsed[i] steps into its episode
 
     def one_step():
         a = torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1
         obs, r, term, trunc, info = env.step(a)
         if her:
-            replay.append(a, env.packed, (term | trunc).to(device, non_blocking=True))
+            replay.append(a, env.packed, term | trunc)
             replay.relabel(HER_K * n, k_future=HER_K)
         if dist:   # the step kernel wrote the packed [obs | achieved | desired | reward | success] rows: one collective, no pack kernels
             dist.all_gather_into_tensor(gathered, out_rows)

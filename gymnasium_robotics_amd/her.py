@@ -68,6 +68,7 @@ class HerReplay:
         self.R = self.T + 1
         self.episode, self.actions = z(self.R, self.N, self.W), z(self.R, self.N, self.act_dim)   # actions[r] = the action that led to row r
         self.episode_start = z(self.N, dtype=torch.int32)
+        self._start_host = np.zeros(self.N, np.int64)          # host mirror of episode_start: decides without a device sync whether anything can be sampled
         self.rows, self.capacity, self.head, self.size = z(int(capacity), self.OW), int(capacity), 0, 0
         self.t = 0                                 # absolute index of the newest row
         self._gen = torch.Generator(device=self.device)
@@ -78,6 +79,7 @@ class HerReplay:
     def begin_episode(self, packed_rows: torch.Tensor):
         self.episode[0].copy_(packed_rows)
         self.episode_start.zero_()
+        self._start_host[:] = 0
         self.t = 0
 
     def append(self, actions: torch.Tensor, packed_rows: torch.Tensor, reset_mask: Optional[torch.Tensor] = None):
@@ -89,8 +91,16 @@ class HerReplay:
         r = self.t % self.R
         self.actions[r].copy_(actions)
         self.episode[r].copy_(packed_rows)
-        if reset_mask is not None:
-            self.episode_start.masked_fill_(reset_mask, self.t)
+        if reset_mask is not None:     # bool [N]: numpy / CPU tensor (what the envs return) or a device tensor
+            host = reset_mask.cpu().numpy() if isinstance(reset_mask, torch.Tensor) else np.asarray(reset_mask)
+            self._start_host[host.astype(bool)] = self.t
+            dev = reset_mask if isinstance(reset_mask, torch.Tensor) and reset_mask.device == self.device else torch.from_numpy(host.astype(bool)).to(self.device, non_blocking=True)
+            self.episode_start.masked_fill_(dev, self.t)
+
+    def set_episode_start(self, starts):
+        """absolute row at which every world's current episode began (e.g. negative values for episodes that were already under way at row 0)"""
+        self._start_host[:] = np.asarray(starts, dtype=np.int64)
+        self.episode_start.copy_(torch.from_numpy(self._start_host.astype(np.int32)).to(self.device))
 
     # ---------------------------------------------------------------- sampling + the fused relabel kernel
     def sample_indices(self, batch: int, k_future: int = 4):
@@ -98,6 +108,8 @@ class HerReplay:
         probability k / (k + 1) the goal achieved at a uniformly drawn LATER row of the same episode (the "future" strategy of Andrychowicz et al.
         2017), else -1 = keep the episode's goal.  Worlds whose episode has no transition yet (just reset) are not drawn."""
         g, d = self._gen, self.device
+        if not (np.maximum(self._start_host, max(self.t - self.T, 0)) < self.t).any():
+            return None                                                                   # every world has just been reset: nothing to sample
         lo_all = torch.clamp(self.episode_start, min=max(self.t - self.T, 0))             # first row of the episode that is still stored (rows start at 0)
         has = (lo_all < self.t).to(torch.float32)                                         # worlds whose current episode has a transition already
         w = torch.multinomial(has, batch, replacement=True, generator=g).to(torch.int32)  # uniform over those worlds (no host sync)
@@ -128,7 +140,10 @@ class HerReplay:
             raise ValueError("batch larger than the replay capacity")
         if self.head + batch > self.capacity:
             self.head = 0                                    # keep every batch contiguous (a ring of whole batches)
-        t, w, tg = self.sample_indices(batch, k_future)
+        idx = self.sample_indices(batch, k_future)
+        if idx is None:
+            return self.rows[self.head: self.head]
+        t, w, tg = idx
         view = self.rows[self.head: self.head + batch]
         self.relabel_into(view, t, w, tg)
         self.head += batch

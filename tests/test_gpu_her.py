@@ -105,7 +105,7 @@ def test_continuous_ring_respects_episode_boundaries():
         a = torch.rand(n, 4, device="cuda:0", generator=g) * 2 - 1
         _, _, term, trunc, _ = env.step(a)
         done = (term | trunc)
-        buf.append(a, env.packed, done.to("cuda:0"))
+        buf.append(a, env.packed, done)
         log_rows.append(env.packed.cpu().numpy().copy()); log_acts.append(a.cpu().numpy().copy())
         starts[done.numpy()] = t + 1
     assert np.array_equal(buf.episode_start.cpu().numpy(), starts)
@@ -123,3 +123,24 @@ def test_continuous_ring_respects_episode_boundaries():
     d = np.linalg.norm(L[t + 1, w][:, o: o + gd].astype(np.float64) - goal, axis=1)
     far = np.abs(d - 0.05) > 1e-6
     assert np.array_equal(got["reward"][far, 0], -(d[far] > 0.05).astype(np.float32))        # fetch_env.py:74-80, sparse
+
+
+def test_nothing_to_sample_right_after_a_lockstep_reset():
+    """all worlds reset in the same step (episodes in lock-step): the ring holds no transition of any current episode -> relabel() writes nothing"""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+    from gymnasium_robotics_amd.her import HerReplay
+
+    env = grx.make_vec("FetchReach-v4", num_envs=8, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=3)
+    buf = HerReplay(env, horizon=3, capacity=256, continuous=True)
+    env.reset(seed=0)
+    buf.begin_episode(env.packed)
+    sizes = []
+    for t in range(7):
+        a = torch.zeros(8, 4, device="cuda:0")
+        _, _, term, trunc, _ = env.step(a)
+        buf.append(a, env.packed, term | trunc)
+        sizes.append(len(buf.relabel(32)))
+    assert sizes == [32, 32, 0, 32, 32, 0, 32]
+    torch.cuda.synchronize()
