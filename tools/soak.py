@@ -11,7 +11,10 @@ import gymnasium_robotics_amd as grx  # noqa: E402
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 CASES = [("FetchPickAndPlace-v4", 4096), ("FetchSlide-v4", 4096), ("HandReach-v3", 4096), ("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", 4096),
-         ("HandManipulateEggRotate-v1", 4096), ("AntMaze_Large_Diverse_GR-v5", 4096), ("PointMaze_Medium-v3", 4096)]
+         ("HandManipulateEggRotate-v1", 4096), ("AntMaze_Large_Diverse_GR-v5", 4096), ("PointMaze_Medium-v3", 4096), ("AdroitHandHammer-v2", 4096),
+         ("AdroitHandDoor-v2", 4096), ("AdroitHandPen-v2", 4096), ("AdroitHandRelocate-v2", 4096), ("FrankaKitchen-v1", 2048)]
+if len(sys.argv) > 2:
+    CASES = [c for c in CASES if any(c[0].startswith(p) for p in sys.argv[2:])]
 for env_id, n in CASES:
     env = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step")
     obs, _ = env.reset(seed=0)
@@ -24,9 +27,10 @@ for env_id, n in CASES:
         obs, r, term, trunc, info = env.step(torch.rand(n, na, device="cuda:0", generator=g) * 2 - 1)
         counts += ((env.status.unsqueeze(1) & bits) != 0).sum(dim=0)
         if t % 50 == 49:
-            finite = finite and bool(torch.isfinite(obs["observation"]).all()) and bool(torch.isfinite(r).all())
-            key = "is_success" if "is_success" in info else "success"
-            succ += float(torch.as_tensor(info[key]).float().mean())
+            o = obs["observation"] if isinstance(obs, dict) else obs
+            finite = finite and bool(torch.isfinite(o).all()) and bool(torch.isfinite(torch.as_tensor(r)).all())
+            key = "is_success" if "is_success" in info else ("success" if "success" in info else None)
+            succ += float(torch.as_tensor(info[key]).float().mean()) if key else 0.0
     torch.cuda.synchronize()
     dt = time.time() - t0
     flags = {int(b): int(c) for b, c in zip(bits.tolist(), counts.tolist())}
