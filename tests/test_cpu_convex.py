@@ -122,15 +122,18 @@ def test_emulated_egg_step_matches_golden():
     # 20 substeps with ~3 egg contacts, 24 joint limits and the tendon limits: nearly every snapshot has some unilateral row within 1e-5 m of
     # switching (median activation gap of the fixture: 3.5e-6 m), and the distance of a convex contact carries the portal's tolerance-level
     # noise on top of the fp32 drift.  Asserted: the bulk agrees tightly, every snapshot agrees loosely (above).
+    # measured quantiles of this fixture (p50 / p75 / p90 / p99 / max): positions 4.5e-7 / 4.2e-5 / 5.7e-4 / 2.7e-3 / 6.5e-3, velocities
+    # 4.5e-5 / 1.6e-3 / 3.6e-2 / 0.21 / 0.38 (the same numbers as the GPU's: tests/golden/tolerance_table.json, HandEgg); asserted at 2x
     pos_err, vel_err = np.array(pos_err), np.array(vel_err)
-    assert np.mean((pos_err < 2e-4) & (vel_err < 2e-2)) >= 0.75, np.mean((pos_err < 2e-4) & (vel_err < 2e-2))
-    assert np.median(pos_err) < 1e-5 and np.median(vel_err) < 3e-4, (np.median(pos_err), np.median(vel_err))
+    for err, bounds in ((pos_err, (1e-6, 1e-4, 1.2e-3, 1.3e-2)), (vel_err, (1e-4, 3.2e-3, 7.2e-2, 0.76))):
+        got = (np.median(err), np.quantile(err, 0.75), np.quantile(err, 0.9), err.max())
+        assert all(a <= b for a, b in zip(got, bounds)), (got, bounds)
 
 
 def test_emulated_egg_touch_matches_golden():
     model, g, emu = _emu_hand("egg", "hand_Egg_touch_teacher.npz", touch="sensordata")
     assert len(model.tables["touch_body"]) == 92
-    rel, same = [], 0
+    rel, bits, same = [], [], 0
     for i in range(g["obs"].shape[0]):
         for k in ("qpos", "qvel", "qacc_ws"):
             getattr(emu, k)[:] = g[k][i]
@@ -139,4 +142,8 @@ def test_emulated_egg_touch_matches_golden():
         touch, ref = emu.hand_obs[61:153], g["obs"][i][61:]
         rel.append(np.abs(touch - ref).max() / max(1.0, ref.max()))
         same += np.array_equal(touch > 0, ref > 0)
-    assert np.median(rel) < 2e-3 and same >= 0.85 * g["obs"].shape[0], (np.median(rel), same)
+        bits.append(np.mean((touch > 0) == (ref > 0)))
+    # measured: the on / off pattern of the 92 sensors equals the oracle's in 114 of 120 snapshots, 99.90 % of all sensor bits agree (worst snapshot:
+    # 90 of 92), relative reading error p50 3.5e-5 / p75 9e-4 (a contact that switches sides of a zone boundary moves a whole reading: max 0.36)
+    assert same >= 112 and np.mean(bits) > 0.998 and min(bits) >= 88 / 92, (same, np.mean(bits), min(bits))
+    assert np.median(rel) < 1e-4 and np.quantile(rel, 0.75) < 2e-3, (np.median(rel), np.quantile(rel, 0.75))

@@ -106,7 +106,8 @@ def test_emulated_ant_kernel_matches_oracle_teacher_forced():
         assert emu.status.value == 0 and s.bad_state == 0
         errs.append(max(np.abs(emu.obs - obs["observation"]).max(), np.abs(emu.achieved[:2] - obs["achieved_goal"]).max()))
     errs = np.array(errs)
-    assert np.mean(errs < 1e-4) >= 0.9 and errs.max() < 5e-3, (np.quantile(errs, [0.5, 0.9, 1.0]))
+    # measured on this rollout: p50 1.4e-6, p90 3.2e-6, max 2.3e-5 (RK4, contacts and limits included): every step inside the 1e-4 of north_star
+    assert errs.max() < 1e-4 and np.median(errs) < 5e-6, (np.quantile(errs, [0.5, 0.9, 1.0]))
 
 
 def test_redraw_goal_draw_order_and_contract():

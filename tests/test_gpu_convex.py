@@ -53,9 +53,12 @@ def test_egg_reset_keeps_the_egg_on_the_palm_and_touch_variant_runs():
     obs, r, _, _, info = env.step(g["action"])
     assert int(info["status"].max()) == 0
     touch, ref = obs["observation"][:, 61:], g["obs"][:, 61:]
-    same = (np.equal(touch > 0, ref > 0).all(axis=1)).mean()
+    same = int(np.equal(touch > 0, ref > 0).all(axis=1).sum())
+    bits = np.equal(touch > 0, ref > 0).mean(axis=1)
     rel = np.abs(touch - ref).max(axis=1) / np.maximum(1.0, ref.max(axis=1))
-    assert same >= 0.85 and np.median(rel) < 2e-3, (same, float(np.median(rel)))
+    # the emulator's numbers for this fixture (tests/test_cpu_convex.py): 114 of 120 on / off patterns equal, 99.90 % of the sensor bits, reading error p50 3.5e-5
+    assert same >= 112 and bits.mean() > 0.998 and bits.min() >= 88 / 92, (same, float(bits.mean()), float(bits.min()))
+    assert np.median(rel) < 1e-4 and np.quantile(rel, 0.75) < 2e-3, (float(np.median(rel)), float(np.quantile(rel, 0.75)))
     r2 = env.compute_reward(obs["achieved_goal"].astype(np.float32), obs["desired_goal"].astype(np.float32), info)
     assert np.array_equal(r, r2)
 
