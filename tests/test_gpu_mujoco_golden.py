@@ -23,6 +23,8 @@ def test_teacher_forced_step_matches_mujoco(path):
     env_id = os.path.basename(path)[len("mujoco_"):-len(".npz")]
     g = np.load(path)
     n = g["obs"].shape[0]
+    if not env_id.startswith(("Fetch", "HandReach", "HandManipulate")):
+        return _plain_family(env_id, g, n)
     cls = FetchVecEnv if env_id.startswith("Fetch") else (HandReachVecEnv if env_id.startswith("HandReach") else HandBlockVecEnv)
     env = cls(env_id, num_envs=n, device="cuda:0", output="numpy", autoreset_mode="disabled", max_episode_steps=None)
     env.reset(seed=0)
@@ -35,3 +37,31 @@ def test_teacher_forced_step_matches_mujoco(path):
     err = np.abs(obs["observation"] - g["obs"]).max(axis=1)
     assert np.quantile(err, 0.98) < 1e-4, (env_id, float(np.quantile(err, 0.98)), float(err.max()))
     assert np.abs(obs["achieved_goal"] - g["achieved"]).max() < 1e-3
+
+
+def _plain_family(env_id, g, n):
+    """Adroit / FrankaKitchen / maze fixtures of tools/record_golden.py:record_plain"""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    kw = dict(robot_noise_ratio=0.0, object_noise_ratio=0.0) if env_id.startswith("FrankaKitchen") else {}
+    env = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="numpy", autoreset_mode="disabled", max_episode_steps=None, **kw)
+    env.reset(seed=0)
+    put = lambda name, arr: getattr(env, name).copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(env.device))
+    put("qpos", g["qpos"][:, :env.nq]); put("qvel", g["qvel"][:, :env.nv]); put("qacc_ws", g["qacc_ws"][:, :env.nv])
+    if env_id.startswith("AdroitHand"):
+        from gymnasium_robotics_amd.envs.adroit_spec import group_shift
+
+        shifts = group_shift(env.model, quat=g["edit"]) if env.task_name == "pen" else group_shift(env.model, pos=g["edit"][:, :3])
+        put("shift", shifts)
+        if env.target is not None:
+            put("target", g["target"])
+    elif env_id.startswith("FrankaKitchen"):
+        put("last_qpos", g["last_qpos"])
+    else:
+        put("goal", g["goal"])
+    out = env.step(g["action"])
+    obs = out[0]["observation"] if isinstance(out[0], dict) else out[0]
+    err = np.abs(obs - g["obs"]).max(axis=1)
+    assert np.quantile(err, 0.9) < 1e-4, (env_id, float(np.quantile(err, 0.9)), float(err.max()))

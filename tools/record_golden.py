@@ -16,7 +16,52 @@ import sys
 import numpy as np
 
 DEFAULT_IDS = ["FetchReach-v4", "FetchPush-v4", "FetchSlide-v4", "FetchPickAndPlace-v4", "HandReach-v3", "HandManipulateBlockRotateXYZ-v1",
-               "HandManipulateEggRotate-v1", "HandManipulatePenRotate-v1"]   # Slide / Egg exercise MuJoCo's convex collider: record mujoco.__version__ (libccd MPR <= 3.1, native GJK/EPA later)
+               "HandManipulateEggRotate-v1", "HandManipulatePenRotate-v1",   # Slide / Egg exercise MuJoCo's convex collider: record mujoco.__version__ (libccd MPR <= 3.1, native GJK/EPA later)
+               "AdroitHandHammer-v2", "AdroitHandDoor-v2", "AdroitHandPen-v2", "AdroitHandRelocate-v2", "FrankaKitchen-v1", "AntMaze_UMaze-v5", "PointMaze_UMaze-v3"]
+
+
+def record_plain(env_id, episodes=6, steps=50, seed0=0):
+    """Adroit (plain Env; the per-episode MODEL edits of reset_model are recorded: body_pos / body_quat / site_pos rows), FrankaKitchen (noise ratios 0: the
+    device path is fed no noise; _last_robot_qpos recorded) and the mazes (goal = the target site)."""
+    import gymnasium as gym
+    import gymnasium_robotics
+    import mujoco
+
+    gym.register_envs(gymnasium_robotics)
+    kw = dict(robot_noise_ratio=0.0, object_noise_ratio=0.0) if env_id.startswith("FrankaKitchen") else {}
+    top = gym.make(env_id, **kw).unwrapped
+    sim = top.robot_env if env_id.startswith("FrankaKitchen") else (getattr(top, "ant_env", None) or getattr(top, "point_env", None) or top)
+    model, data = sim.model, sim.data
+    rng = np.random.default_rng(1234)
+    rec = {k: [] for k in ("qpos", "qvel", "qacc_ws", "action", "obs", "reward", "success", "seed", "t", "edit", "target", "last_qpos", "goal")}
+    bid = lambda name: mujoco.mj_name2id(model, mujoco.mjtObj.mjOBJ_BODY, name)
+    for ep in range(episodes):
+        top.reset(seed=seed0 + ep)
+        for t in range(steps):
+            a = rng.uniform(-1, 1, top.action_space.shape[0]).astype(np.float32)
+            rec["qpos"].append(data.qpos.copy()); rec["qvel"].append(data.qvel.copy()); rec["qacc_ws"].append(data.qacc_warmstart.copy()); rec["action"].append(a)
+            edit, target, last, goal = np.zeros(4), np.zeros(3), np.zeros(9), np.zeros(2)
+            if env_id.startswith("AdroitHandHammer"):
+                edit[:3] = model.body_pos[bid("nail_board")]
+            elif env_id.startswith("AdroitHandDoor"):
+                edit[:3] = model.body_pos[bid("frame")]
+            elif env_id.startswith("AdroitHandPen"):
+                edit[:] = model.body_quat[bid("target")]
+            elif env_id.startswith("AdroitHandRelocate"):
+                edit[:3] = model.body_pos[bid("Object")]
+                target[:] = model.site_pos[mujoco.mj_name2id(model, mujoco.mjtObj.mjOBJ_SITE, "target")]
+            elif env_id.startswith("FrankaKitchen"):
+                last[:] = sim._last_robot_qpos
+            else:
+                goal[:] = top.goal
+            rec["edit"].append(edit); rec["target"].append(target); rec["last_qpos"].append(last); rec["goal"].append(goal)
+            obs, r, term, trunc, info = top.step(a)
+            rec["obs"].append(obs["observation"] if isinstance(obs, dict) else obs); rec["reward"].append(r)
+            rec["success"].append(float(info.get("success", info.get("is_success", 0.0)))); rec["seed"].append(seed0 + ep); rec["t"].append(t)
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out["mujoco_version"] = np.frombuffer(mujoco.__version__.encode(), dtype=np.uint8)
+    out["nq"], out["nv"] = np.int64(model.nq), np.int64(model.nv)
+    return out
 
 
 def record(env_id, episodes=6, steps=50, seed0=0):
@@ -54,7 +99,7 @@ if __name__ == "__main__":
 
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
     for env_id in (sys.argv[1:] or DEFAULT_IDS):
-        d = record(env_id)
+        d = record(env_id) if env_id.startswith(("Fetch", "HandReach", "HandManipulate")) else record_plain(env_id)
         path = os.path.join(out_dir, f"mujoco_{env_id}.npz")
         np.savez_compressed(path, **d)
         print(env_id, d["obs"].shape, "->", path)
