@@ -1,33 +1,77 @@
-import os, sys
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
-import sys, ctypes; sys.path.insert(0,'tests'); sys.path.insert(0,'tests/emu')
+"""The kernel source compiled in fp64 (tests/emu/grx_emu.cpp with -DGRX_EMU_FP64, the portal routine's epsilon set to the fp64 one) against the oracle's
+golden fixtures: separates ROUNDING (the fp32 build's error quantiles in tests/golden/tolerance_table.json) from LOGIC (anything left here).
+
+    g++ -O2 -fPIC -shared -std=c++17 -DGRX_EMU_FP64 -DGRX_MPR_EPS=2.220446049250313e-16 -o /tmp/libgrx_emu64.so tests/emu/grx_emu.cpp
+    python tools/emu_fp64_check.py /tmp/libgrx_emu64.so hammer door pen relocate kitchen
+"""
+import ctypes
+import os
+import sys
+
 import numpy as np
-from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_model, make_adroit_task, action_scaling
-lib=sys.argv[1]
-for task in sys.argv[2:]:
-    m=load_adroit_model(task)
-    g=np.load(f'tests/golden/adroit_{task}_teacher.npz')
-    L=ctypes.CDLL(lib)
-    L.emu_create.restype=ctypes.c_void_p; L.emu_create.argtypes=[ctypes.c_void_p]*3
-    H,I,F=m.pack(); h=L.emu_create(H.ctypes.data,I.ctypes.data,F.ctypes.data)
-    task_s=make_adroit_task(m,"dense",task)
-    class T64(ctypes.Structure):
-        _fields_=[("n_substeps",ctypes.c_int),("sparse_reward",ctypes.c_int),("kind",ctypes.c_int),("site",ctypes.c_int*5),("obj_body",ctypes.c_int),("nq_obs",ctypes.c_int),("obs_dim",ctypes.c_int),("qadr",ctypes.c_int*2),("len",ctypes.c_double*2)]
-    t=T64()
-    for f,_ in T64._fields_:
-        v=getattr(task_s,f)
-        if f in("site","qadr","len"):
-            for k in range(len(v)): getattr(t,f)[k]=v[k]
-        else: setattr(t,f,v)
-    am,ar=action_scaling(m)
-    p=lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    E=[]
-    for i in range(0,420,3):
-        qp,qv,qa=g["qpos"][i].astype(np.float64).copy(), g["qvel"][i].astype(np.float64).copy(), g["qacc_ws"][i].astype(np.float64).copy()
-        sh=g["shift"][i].astype(np.float64).copy(); tg=g["target"][i].astype(np.float64).copy(); a=g["action"][i].astype(np.float64).copy()
-        obs=np.zeros(task_s.obs_dim); rew=ctypes.c_double(0); suc=ctypes.c_ubyte(0); st=ctypes.c_int(0)
-        L.emu_adroit_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp),p(qv),p(qa),p(sh),p(tg),p(a),p(am.copy()),p(ar.copy()),p(obs),ctypes.byref(rew),ctypes.byref(suc),ctypes.byref(st),ctypes.c_int(0))
-        E.append(np.abs(obs-g["obs"][i]).max())
-    E=np.array(E)
-    print('  outliers:', [(int(3*k), float('%.1e'%E[k]), int(g['ncon'][3*k]), int(g['nefc'][3*k]), int(g['noslip_iter'][3*k])) for k in np.nonzero(E>1e-6)[0]])
-    print(task,'fp64 emulator: p50 %.1e p90 %.1e p99 %.1e max %.1e; n>1e-6: %d of %d'%(np.median(E),np.quantile(E,.9),np.quantile(E,.99),E.max(),(E>1e-6).sum(),len(E)))
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def as_fp64_struct(task_s):
+    """ctypes twin of a task struct with every float field widened to double (the FP64 build's `#define float double`)"""
+    fields = []
+    for name, typ in task_s._fields_:
+        if typ is ctypes.c_float:
+            typ = ctypes.c_double
+        elif hasattr(typ, "_type_") and typ._type_ is ctypes.c_float:
+            typ = ctypes.c_double * typ._length_
+        fields.append((name, typ))
+    T = type("T64", (ctypes.Structure,), {"_fields_": fields})
+    t = T()
+    for name, typ in fields:
+        v = getattr(task_s, name)
+        if hasattr(typ, "_length_"):
+            for k in range(typ._length_):
+                getattr(t, name)[k] = v[k]
+        else:
+            setattr(t, name, v)
+    return t
+
+
+def main(lib, tasks):
+    L = ctypes.CDLL(lib)
+    L.emu_create.restype = ctypes.c_void_p
+    L.emu_create.argtypes = [ctypes.c_void_p] * 3
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64).copy()
+    for task in tasks:
+        if task == "kitchen":
+            from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model, make_kitchen_task
+            m = load_kitchen_model()
+            t = as_fp64_struct(make_kitchen_task(m, 0.01, 0.0005))
+            g = np.load(os.path.join(ROOT, "tests", "golden", "kitchen_teacher.npz"))
+        else:
+            from gymnasium_robotics_amd.envs.adroit_spec import action_scaling, load_adroit_model, make_adroit_task
+            m = load_adroit_model(task)
+            t = as_fp64_struct(make_adroit_task(m, "dense", task))
+            g = np.load(os.path.join(ROOT, "tests", "golden", f"adroit_{task}_teacher.npz"))
+            am, ar = action_scaling(m)
+        H, I, F = m.pack()
+        h = L.emu_create(H.ctypes.data, I.ctypes.data, F.ctypes.data)
+        E, idx = [], list(range(0, g["obs"].shape[0], 3))
+        for i in idx:
+            qp, qv, qa, a = f64(g["qpos"][i]), f64(g["qvel"][i]), f64(g["qacc_ws"][i]), f64(g["action"][i])
+            obs, st = np.zeros(g["obs"].shape[1]), ctypes.c_int(0)
+            if task == "kitchen":
+                last, nz, done = f64(g["last_qpos"][i]), f64(g["noise"][i]), ctypes.c_int(0)
+                L.emu_kitchen_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(last), p(a), p(nz), p(obs), ctypes.byref(done), ctypes.byref(st), ctypes.c_int(0))
+            else:
+                sh, tg, rew, suc = f64(g["shift"][i]), f64(g["target"][i]), ctypes.c_double(0), ctypes.c_ubyte(0)
+                L.emu_adroit_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(sh), p(tg), p(a), p(f64(am)), p(f64(ar)), p(obs), ctypes.byref(rew),
+                                  ctypes.byref(suc), ctypes.byref(st), ctypes.c_int(0))
+            E.append(np.abs(obs - g["obs"][i]).max())
+        E = np.array(E)
+        out = [(idx[k], float("%.1e" % E[k]), int(g["ncon"][idx[k]]), int(g["nefc"][idx[k]])) for k in np.nonzero(E > 1e-6)[0]]
+        print(f"{task}: fp64 build of the kernel source vs the oracle on {len(E)} fixtures: p50 {np.median(E):.1e} p90 {np.quantile(E, 0.9):.1e} p99 {np.quantile(E, 0.99):.1e} "
+              f"max {E.max():.1e}; above 1e-6: {len(out)} (snapshot, error, ncon, nefc): {out}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2:] or ["hammer", "door", "pen", "relocate", "kitchen"])
