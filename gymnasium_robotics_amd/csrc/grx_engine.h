@@ -2705,22 +2705,19 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
       const int r = ne + lane_;
       fr_d = GRX_ROW_IDOF(c->efc_id[r]); fr_aref = c->efc_aref[r]; fr_fl = c->efc_floss[r]; fr_f = c->efc_force[r]; fr_arr = c->minv[fr_d * nv + fr_d];
     }
-    for (int iter = 0; iter < maxiter; iter++) {
-      float improvement = iter == 0 ? improvement0 : 0.0f;
-      for (int r = 0; r < nf; r++) {
-        const int d = __builtin_amdgcn_readlane(fr_d, r);
-        const float Arr = grx_readlane_f(fr_arr, r), res = grx_readlane_f(a_l, d) - grx_readlane_f(fr_aref, r), old = grx_readlane_f(fr_f, r), fl = grx_readlane_f(fr_fl, r);
-        float fn = old - res / fmaxf(GRX_MINVAL, Arr);
-        fn = fn < -fl ? -fl : (fn > fl ? fl : fn);
-        const float dl = fn - old;
-        improvement -= 0.5f * dl * dl * Arr + dl * res;
-        fr_f = (lane_ == r) ? fn : fr_f;
-        if (dl != 0.0f) { const float col = lane_ < nv ? c->minv[lane_ * nv + d] : 0.0f; a_l = fmaf(col, dl, a_l); }
-      }
-      for (int k = 0; k < ncon; k++) {
+    // Sweep-invariant part of a contact pair: t = M^-1 J' of its two rows (one word per lane each) and A00 / A01 / A11.  For the first KC pairs (sweep
+    // order) they are formed once per substep and parked in the Newton scratch that is dead by now (grad, search, Mv, tmpv, efc_jar, efc_jv: contiguous);
+    // a sweep then costs such a pair two LDS reads per lane and the two residual reductions instead of ~4 x len LDS reads and five reductions.
+    float* const tc = c->grad;
+    const int tstride = 2 * nv + 4;
+    int KC = (int)(c->efc_force - c->grad) / tstride;
+    if (KC > 24) KC = 24;
+    {
+      int pi = 0;
+      for (int k = 0; k < ncon && pi < KC; k++) {
         const int r0 = c->con_efc[k], nr = c->con_nr[k];
         if (r0 < 0 || nr < 2) continue;
-        for (int j = r0; j + 1 < r0 + nr && j + 1 < nefc; j += 2) {
+        for (int j = r0; j + 1 < r0 + nr && j + 1 < nefc && pi < KC; j += 2, pi++) {
           const int infoA = c->efc_row[j], idA = c->efc_id[j], infoB = c->efc_row[j + 1], idB = c->efc_id[j + 1];
           float ta = 0.0f, tb = 0.0f, ja = 0.0f, jb = 0.0f;
           if (lane_ < nv) {
@@ -2737,6 +2734,55 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
             ja = pa >= 0 ? c->Jp[offA + pa] : 0.0f; jb = pb >= 0 ? c->Jp[offB + pb] : 0.0f;
           }
           const float A00 = grx_reduce_sum(ja * ta), A01 = grx_reduce_sum(ja * tb), A11 = grx_reduce_sum(jb * tb);
+          float* slot = tc + pi * tstride;
+          if (lane_ < nv) { slot[lane_] = ta; slot[nv + lane_] = tb; }
+          if (lane_ == 0) { slot[2 * nv] = A00; slot[2 * nv + 1] = A01; slot[2 * nv + 2] = A11; }
+        }
+      }
+      __syncthreads();
+    }
+    for (int iter = 0; iter < maxiter; iter++) {
+      float improvement = iter == 0 ? improvement0 : 0.0f;
+      for (int r = 0; r < nf; r++) {
+        const int d = __builtin_amdgcn_readlane(fr_d, r);
+        const float Arr = grx_readlane_f(fr_arr, r), res = grx_readlane_f(a_l, d) - grx_readlane_f(fr_aref, r), old = grx_readlane_f(fr_f, r), fl = grx_readlane_f(fr_fl, r);
+        float fn = old - res / fmaxf(GRX_MINVAL, Arr);
+        fn = fn < -fl ? -fl : (fn > fl ? fl : fn);
+        const float dl = fn - old;
+        improvement -= 0.5f * dl * dl * Arr + dl * res;
+        fr_f = (lane_ == r) ? fn : fr_f;
+        if (dl != 0.0f) { const float col = lane_ < nv ? c->minv[lane_ * nv + d] : 0.0f; a_l = fmaf(col, dl, a_l); }
+      }
+      int pi = 0;
+      for (int k = 0; k < ncon; k++) {
+        const int r0 = c->con_efc[k], nr = c->con_nr[k];
+        if (r0 < 0 || nr < 2) continue;
+        for (int j = r0; j + 1 < r0 + nr && j + 1 < nefc; j += 2, pi++) {
+          const int infoA = c->efc_row[j], idA = c->efc_id[j], infoB = c->efc_row[j + 1], idB = c->efc_id[j + 1];
+          float ta = 0.0f, tb = 0.0f, ja = 0.0f, jb = 0.0f, A00, A01, A11;
+          if (lane_ < nv) {
+            const int offA = GRX_ROW_OFF(infoA), offB = GRX_ROW_OFF(infoB);
+            const int pa = grx_row_pos(infoA, idA, lane_), pb = grx_row_pos(infoB, idB, lane_);
+            ja = pa >= 0 ? c->Jp[offA + pa] : 0.0f; jb = pb >= 0 ? c->Jp[offB + pb] : 0.0f;
+          }
+          if (pi < KC) {   // parked above
+            const float* slot = tc + pi * tstride;
+            if (lane_ < nv) { ta = slot[lane_]; tb = slot[nv + lane_]; }
+            A00 = slot[2 * nv]; A01 = slot[2 * nv + 1]; A11 = slot[2 * nv + 2];
+          } else {
+            if (lane_ < nv) {
+              const float* mi = c->minv + lane_ * nv;
+              const int offA = GRX_ROW_OFF(infoA), loA = GRX_ROW_LO(infoA), lenA = GRX_ROW_LEN(infoA), offB = GRX_ROW_OFF(infoB), loB = GRX_ROW_LO(infoB), lenB = GRX_ROW_LEN(infoB);
+              for (int e = 0; e < lenA; e++) ta += c->Jp[offA + e] * mi[loA + e];
+              for (int e = 0; e < lenB; e++) tb += c->Jp[offB + e] * mi[loB + e];
+              if (S::kTwoSpan) {
+                const int lo2A = GRX_ROWB_LO(idA), len2A = GRX_ROWB_LEN(idA), lo2B = GRX_ROWB_LO(idB), len2B = GRX_ROWB_LEN(idB);
+                for (int e = 0; e < len2A; e++) ta += c->Jp[offA + lenA + e] * mi[lo2A + e];
+                for (int e = 0; e < len2B; e++) tb += c->Jp[offB + lenB + e] * mi[lo2B + e];
+              }
+            }
+            A00 = grx_reduce_sum(ja * ta); A01 = grx_reduce_sum(ja * tb); A11 = grx_reduce_sum(jb * tb);
+          }
           const float res0 = grx_reduce_sum(ja * a_l) - c->efc_aref[j], res1 = grx_reduce_sum(jb * a_l) - c->efc_aref[j + 1];
           const float o0 = c->efc_force[j], o1 = c->efc_force[j + 1];
           const float bc0 = res0 - (A00 * o0 + A01 * o1), bc1 = res1 - (A01 * o0 + A11 * o1);
