@@ -2700,10 +2700,11 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     // a row update is a handful of v_readlane broadcasts plus one LDS read of the M^-1 column, no barrier.  Same arithmetic, same order
     // as the plain version below (which the lane emulator runs).
     float a_l = lane_ < nv ? c->qacc[lane_] : 0.0f;
-    int fr_d = 0; float fr_aref = 0.0f, fr_fl = 0.0f, fr_f = 0.0f, fr_arr = 1.0f;
+    int fr_d = 0; float fr_aref = 0.0f, fr_fl = 0.0f, fr_f = 0.0f, fr_arr = 1.0f, fr_rinv = 1.0f;
     if (lane_ < nf) {
       const int r = ne + lane_;
       fr_d = GRX_ROW_IDOF(c->efc_id[r]); fr_aref = c->efc_aref[r]; fr_fl = c->efc_floss[r]; fr_f = c->efc_force[r]; fr_arr = c->minv[fr_d * nv + fr_d];
+      fr_rinv = 1.0f / fmaxf(GRX_MINVAL, fr_arr);
     }
     // Sweep-invariant part of a contact pair: t = M^-1 J' of its two rows (one word per lane each) and A00 / A01 / A11.  For the first KC pairs (sweep
     // order) they are formed once per substep and parked in the Newton scratch that is dead by now (grad, search, Mv, tmpv, efc_jar, efc_jv: contiguous);
@@ -2743,15 +2744,22 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     }
     for (int iter = 0; iter < maxiter; iter++) {
       float improvement = iter == 0 ? improvement0 : 0.0f;
+      // one row after the other (Gauss-Seidel): the only LDS access of a row -- its column of M^-1 -- is fetched one row ahead, the division by A_rr
+      // became a multiplication by the reciprocal formed with the row state (the plain version below divides: last-ulp difference)
+      float col_next = (lane_ < nv && nf > 0) ? c->minv[lane_ * nv + __builtin_amdgcn_readlane(fr_d, 0)] : 0.0f;
       for (int r = 0; r < nf; r++) {
         const int d = __builtin_amdgcn_readlane(fr_d, r);
-        const float Arr = grx_readlane_f(fr_arr, r), res = grx_readlane_f(a_l, d) - grx_readlane_f(fr_aref, r), old = grx_readlane_f(fr_f, r), fl = grx_readlane_f(fr_fl, r);
-        float fn = old - res / fmaxf(GRX_MINVAL, Arr);
+        const float col = col_next;
+        const int dn = __builtin_amdgcn_readlane(fr_d, r + 1 < nf ? r + 1 : r);
+        col_next = lane_ < nv ? c->minv[lane_ * nv + dn] : 0.0f;
+        const float Arr = grx_readlane_f(fr_arr, r), rinv = grx_readlane_f(fr_rinv, r), res = grx_readlane_f(a_l, d) - grx_readlane_f(fr_aref, r), old = grx_readlane_f(fr_f, r),
+                    fl = grx_readlane_f(fr_fl, r);
+        float fn = old - res * rinv;
         fn = fn < -fl ? -fl : (fn > fl ? fl : fn);
         const float dl = fn - old;
         improvement -= 0.5f * dl * dl * Arr + dl * res;
         fr_f = (lane_ == r) ? fn : fr_f;
-        if (dl != 0.0f) { const float col = lane_ < nv ? c->minv[lane_ * nv + d] : 0.0f; a_l = fmaf(col, dl, a_l); }
+        a_l = fmaf(col, dl, a_l);
       }
       int pi = 0;
       for (int k = 0; k < ncon; k++) {
