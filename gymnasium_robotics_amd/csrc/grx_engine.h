@@ -398,7 +398,7 @@ struct GrxShape {
   static constexpr bool kFixed = NV_ > 0;   // nu / nmocap may legitimately be 0 in a fixed shape
   // incremental Hessian corrections between Newton iterations (grx_hessian_update): compiled into the kernels of models with a free
   // object in contact (several iterations per substep are common there); articulated-only models and the RK4 ant converge in one
-  static constexpr bool kIncrHess = (NV_ == 0) || (NQ_ != NV_ && INTEG_ == 0);
+  static constexpr bool kIncrHess = (NV_ == 0) || (NQ_ != NV_ && INTEG_ == 0) || NV_ > 33;   // ... and AdroitHandRelocate (nv 36: a full assembly = the 32 x 32 tile + four more rows / columns; A/B 17.4 -> 15.9 ms per step; door / pen / hammer measured slower or equal with it)
   static constexpr bool kConvex = (NV_ == 0) || ((CONVEX_ & 1) != 0);   // carries the general convex (MPR) narrow phase for primitive pairs: the generic kernels and the shapes of models that need it
   static constexpr bool kMesh = (NV_ == 0) || ((CONVEX_ & 2) != 0);     // carries the wave-cooperative hull-vs-convex routine (models with mesh-mesh / mesh-primitive pairs)
   static constexpr int NMESH = (CONVEX_ & 2) ? 1 : 0;
