@@ -2,7 +2,7 @@
 golden fixtures: separates ROUNDING (the fp32 build's error quantiles in tests/golden/tolerance_table.json) from LOGIC (anything left here).
 
     g++ -O2 -fPIC -shared -std=c++17 -DGRX_EMU_FP64 -DGRX_MPR_EPS=2.220446049250313e-16 -o /tmp/libgrx_emu64.so tests/emu/grx_emu.cpp
-    python tools/emu_fp64_check.py /tmp/libgrx_emu64.so hammer door pen relocate kitchen
+    python tools/emu_fp64_check.py /tmp/libgrx_emu64.so          # all fourteen fixture sets; or name some: FetchSlide hull HandEgg hammer kitchen ...
 """
 import ctypes
 import os
@@ -35,6 +35,36 @@ def as_fp64_struct(task_s):
     return t
 
 
+def _fixture(task):
+    """-> (model, fp64 task struct, fixture, kind)"""
+    G = os.path.join(ROOT, "tests", "golden")
+    if task == "kitchen":
+        from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model, make_kitchen_task
+        m = load_kitchen_model()
+        return m, as_fp64_struct(make_kitchen_task(m, 0.01, 0.0005)), np.load(os.path.join(G, "kitchen_teacher.npz")), "kitchen"
+    if task in ("hammer", "door", "pen", "relocate"):
+        from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_model, make_adroit_task
+        m = load_adroit_model(task)
+        return m, as_fp64_struct(make_adroit_task(m, "dense", task)), np.load(os.path.join(G, f"adroit_{task}_teacher.npz")), "adroit"
+    if task.startswith("Fetch") or task == "hull":
+        from gymnasium_robotics_amd.envs.fetch import load_fetch_model
+        from gymnasium_robotics_amd.envs.fetch_spec import make_fetch_task
+        name = "FetchPickAndPlace" if task == "hull" else task
+        m = load_fetch_model(name).copy()
+        m.tables["eq_data"][:, :7] = [0, 0, 0, 0, 0, 0, 1]      # reset_mocap_welds
+        return m, as_fp64_struct(make_fetch_task(m, name)), np.load(os.path.join(G, "fetch_hull_teacher.npz" if task == "hull" else f"fetch_{task}_teacher.npz")), "fetch"
+    if task == "HandReach":
+        from gymnasium_robotics_amd.envs.hand import load_hand_reach_model
+        from gymnasium_robotics_amd.envs.hand_spec import make_hand_task
+        m = load_hand_reach_model(None)
+        return m, as_fp64_struct(make_hand_task(m)), np.load(os.path.join(G, "hand_HandReach_teacher.npz")), "hand"
+    from gymnasium_robotics_amd.envs.hand import load_hand_block_model
+    from gymnasium_robotics_amd.envs.manipulate_spec import make_block_task
+    obj, fix = {"HandBlock": ("block", "hand_BlockRotateXYZ_teacher.npz"), "HandEgg": ("egg", "hand_EggRotate_teacher.npz"), "HandPen": ("pen", "hand_PenRotate_teacher.npz")}[task]
+    m = load_hand_block_model(None, touch=False, obj=obj)
+    return m, as_fp64_struct(make_block_task(m, "ignore", "xyz", "sparse", "off", obj=obj)), np.load(os.path.join(G, fix)), "hand"
+
+
 def main(lib, tasks):
     L = ctypes.CDLL(lib)
     L.emu_create.restype = ctypes.c_void_p
@@ -42,36 +72,40 @@ def main(lib, tasks):
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64).copy()
     for task in tasks:
-        if task == "kitchen":
-            from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model, make_kitchen_task
-            m = load_kitchen_model()
-            t = as_fp64_struct(make_kitchen_task(m, 0.01, 0.0005))
-            g = np.load(os.path.join(ROOT, "tests", "golden", "kitchen_teacher.npz"))
-        else:
-            from gymnasium_robotics_amd.envs.adroit_spec import action_scaling, load_adroit_model, make_adroit_task
-            m = load_adroit_model(task)
-            t = as_fp64_struct(make_adroit_task(m, "dense", task))
-            g = np.load(os.path.join(ROOT, "tests", "golden", f"adroit_{task}_teacher.npz"))
+        m, t, g, kind = _fixture(task)
+        if kind == "adroit":
+            from gymnasium_robotics_amd.envs.adroit_spec import action_scaling
             am, ar = action_scaling(m)
         H, I, F = m.pack()
         h = L.emu_create(H.ctypes.data, I.ctypes.data, F.ctypes.data)
         E, idx = [], list(range(0, g["obs"].shape[0], 3))
         for i in idx:
             qp, qv, qa, a = f64(g["qpos"][i]), f64(g["qvel"][i]), f64(g["qacc_ws"][i]), f64(g["action"][i])
-            obs, st = np.zeros(g["obs"].shape[1]), ctypes.c_int(0)
-            if task == "kitchen":
-                last, nz, done = f64(g["last_qpos"][i]), f64(g["noise"][i]), ctypes.c_int(0)
+            st = ctypes.c_int(0)
+            if kind == "kitchen":
+                obs, last, nz, done = np.zeros(g["obs"].shape[1]), f64(g["last_qpos"][i]), f64(g["noise"][i]), ctypes.c_int(0)
                 L.emu_kitchen_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(last), p(a), p(nz), p(obs), ctypes.byref(done), ctypes.byref(st), ctypes.c_int(0))
-            else:
-                sh, tg, rew, suc = f64(g["shift"][i]), f64(g["target"][i]), ctypes.c_double(0), ctypes.c_ubyte(0)
+                err = np.abs(obs - g["obs"][i])
+            elif kind == "adroit":
+                obs, sh, tg, rew, suc = np.zeros(g["obs"].shape[1]), f64(g["shift"][i]), f64(g["target"][i]), ctypes.c_double(0), ctypes.c_ubyte(0)
                 L.emu_adroit_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(sh), p(tg), p(a), p(f64(am)), p(f64(ar)), p(obs), ctypes.byref(rew),
                                   ctypes.byref(suc), ctypes.byref(st), ctypes.c_int(0))
-            E.append(np.abs(obs - g["obs"][i]).max())
+                err = np.abs(obs - g["obs"][i])
+            elif kind == "fetch":
+                obs, ach, mocap, aux = np.zeros(g["obs"].shape[1]), np.zeros(3), f64(g["mocap"][i]), f64(g["aux"][i])
+                L.emu_fetch_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(mocap), p(aux), p(a), p(obs), p(ach), ctypes.byref(st))
+                err = np.abs(obs - g["obs"][i])
+            else:
+                obs, ach, palm = np.zeros(256), np.zeros(15), np.zeros(3)
+                L.emu_hand_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(a), p(obs), p(ach), p(palm), ctypes.byref(st), ctypes.c_int(0))
+                err = np.abs(obs[:g["obs"].shape[1]] - g["obs"][i])
+            E.append(err.max())
         E = np.array(E)
-        out = [(idx[k], float("%.1e" % E[k]), int(g["ncon"][idx[k]]), int(g["nefc"][idx[k]])) for k in np.nonzero(E > 1e-6)[0]]
+        out = [(idx[k], float("%.1e" % E[k])) for k in np.nonzero(E > 1e-6)[0]]
         print(f"{task}: fp64 build of the kernel source vs the oracle on {len(E)} fixtures: p50 {np.median(E):.1e} p90 {np.quantile(E, 0.9):.1e} p99 {np.quantile(E, 0.99):.1e} "
-              f"max {E.max():.1e}; above 1e-6: {len(out)} (snapshot, error, ncon, nefc): {out}")
+              f"max {E.max():.1e}; above 1e-6: {len(out)} (snapshot, error): {out[:12]}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2:] or ["hammer", "door", "pen", "relocate", "kitchen"])
+    main(sys.argv[1], sys.argv[2:] or ["FetchReach", "FetchPush", "FetchSlide", "FetchPickAndPlace", "hull", "HandReach", "HandBlock", "HandEgg", "HandPen",
+                                       "hammer", "door", "pen", "relocate", "kitchen"])
