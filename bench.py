@@ -14,6 +14,7 @@ One "step" = one env.step() of all worlds = ONE launch of the family's step kern
     antmaze     cfg 4  AntMaze_Large_Diverse_GR-v5, 8192 worlds / GPU (65536 over 8)
     adroit      cfg 5b AdroitHandHammer-v2, 16384 worlds / GPU (adroit_door | adroit_pen | adroit_relocate: the other Adroit tasks)
     kitchen     cfg 5a FrankaKitchen-v1, 16384 worlds / GPU, default observation noise
+    mixed       cfg 5  FrankaKitchen-v1 + AdroitHandHammer-v2 side by side, 2048 + 2048 worlds / GPU (32768 over 8): two streams, two host threads
     hand_reach         HandReach-v3, 16384 worlds / GPU
 
     python bench.py --gpus 1 --steps 100 --warmup 10
@@ -48,6 +49,8 @@ WORKLOADS = {
     "kitchen": dict(env_id="FrankaKitchen-v1", worlds=16384, kernel="grx_kitchen_step_kernel", algo=4 * (165 + 97 + 60), horizon=280),
     "adroit_relocate": dict(env_id="AdroitHandRelocate-v2", worlds=16384, kernel="grx_adroit_step_kernel", algo=4 * (36 + 72 + 30 + 10 + 108 + 40) + 2, horizon=200),
 }
+MIXED = ("kitchen", "adroit")   # cfg 5: the two families of the mixed batch, half of the rank's worlds each
+MIXED_WORLDS = 4096             # per GPU (32768 over 8)
 HER_K = 4  # relabelled goals per transition ("future" strategy with k=4); 28 B per relabelled transition
 HBM_PEAK_GBS = 8000.0
 
@@ -137,8 +140,105 @@ def cpu_baseline(workload, seconds=8.0):
                       f"{WORKLOADS[workload]['env_id']}, random actions; oracle = fp64 restatement (not MuJoCo), Python task layer + C physics"}
 
 
+# ---------------------------------------------------------------------------------------------- cfg 5: two families in one job
+def run_rank_mixed(args, rank, world_size, local_rank):
+    """BASELINE cfg 5: every rank steps n/2 FrankaKitchen worlds and n/2 AdroitHandHammer worlds.  The two environments are independent (no data
+    dependence), so each is driven by its own host thread on its own HIP stream and the two step kernels share the GPU; one vector "step" =
+    one env.step() of both halves (the threads meet at the end of every step), followed by one all-gather per family of the rows the kernels wrote."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+    n = args.worlds_per_gpu or MIXED_WORLDS
+    half = n // 2
+    envs, streams, gens, gathered = [], [], [], []
+    for k, name in enumerate(MIXED):
+        env = make_env(name, half, device, rank)
+        env.reset(seed=0)
+        if args.stagger:
+            env._elapsed[:] = np.arange(half) % (env.max_episode_steps or WORKLOADS[name]["horizon"])
+        g = torch.Generator(device=device)
+        g.manual_seed(1234 + 2 * rank + k)
+        envs.append(env); streams.append(torch.cuda.Stream(device=device)); gens.append(g)
+        gathered.append(torch.empty(half * world_size, env.obs.shape[1], device=device) if dist else None)
+    torch.cuda.synchronize()
+
+    def half_step(k):
+        torch.cuda.set_device(local_rank)
+        with torch.cuda.stream(streams[k]):
+            a = torch.rand(half, envs[k].single_action_space.shape[0], device=device, generator=gens[k]) * 2 - 1
+            envs[k].step(a)
+
+    pool = ThreadPoolExecutor(2)
+
+    def one_step():
+        list(pool.map(half_step, range(2)))
+        if dist:
+            for k in range(2):
+                torch.cuda.current_stream().wait_stream(streams[k])
+                dist.all_gather_into_tensor(gathered[k], envs[k].obs)
+            for k in range(2):
+                streams[k].wait_stream(torch.cuda.current_stream())
+
+    for _ in range(args.warmup):
+        one_step()
+    for env in envs:
+        env.clear_status()
+        env.kernel_events = []
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    pool.shutdown()
+    kern_ms = [float(np.mean([a.elapsed_time(b) for a, b in env.kernel_events])) for env in envs]
+    counts = [env.status_counts() for env in envs]
+    line = None
+    if rank == 0:
+        w = WORKLOADS[MIXED[0]]     # the dominant kernel: the kitchen step (40 substeps against 5)
+        achieved = w["algo"] * half / (kern_ms[0] * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/s (whole node)", "value": n * world_size * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"mixed batch: {half} FrankaKitchen-v1 (multitask, default noise) + {half} AdroitHandHammer-v2 worlds/GPU x {world_size} GPU, uniform random "
+                                   "actions, same-step autoreset at the time limits, the two families on two streams / two host threads",
+                       "worlds_per_gpu": n, "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather per family of the kernel-written rows per step" if world_size > 1 else ""),
+                       "capacity_overflow_worlds": sum(c["con_overflow"] + c["efc_overflow"] for c in counts), "badnum_worlds": sum(c["badnum"] for c in counts),
+                       "kernel_ms": {MIXED[k]: kern_ms[k] for k in range(2)}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "kernel": w["kernel"], "kernel_ms": kern_ms[0], "algorithmic_bytes_per_launch": w["algo"] * half,
+                         "note": "duration measured while the Adroit step kernel shares the GPU; the single-family lines (--workload kitchen / adroit) carry the PMC traffic"},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            parts = [cpu_baseline(name, seconds=5.0) for name in MIXED]
+            mix = lambda key: 2.0 / sum(1.0 / p[key] for p in parts)      # a mixed batch = equal numbers of steps of both families
+            line["cpu_baseline"] = {"value": mix("value"), "unit": "env-steps/s", "cores": 1, "kind": "port", "value_all_cores": mix("value_all_cores"),
+                                    "cores_all": parts[0]["cores_all"], "sample": "equal-step mix (harmonic mean) of: " + " | ".join(p["sample"] for p in parts)}
+    if dist:
+        dist.destroy_process_group()
+    return line
+
+
 # ---------------------------------------------------------------------------------------------- one rank
 def run_rank(args, rank, world_size, local_rank):
+    if args.workload == "mixed":
+        return run_rank_mixed(args, rank, world_size, local_rank)
     w = WORKLOADS[args.workload]
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
@@ -252,7 +352,7 @@ def main():
     ap.add_argument("--worlds-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="fetch")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["mixed"], default="fetch")
     args = ap.parse_args()
 
     if "WORLD_SIZE" in os.environ:   # started by torchrun: one rank per process already

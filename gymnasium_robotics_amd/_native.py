@@ -47,7 +47,8 @@ class KitchenTaskStruct(ctypes.Structure):
 
 
 class KitchenBuffersStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "last_qpos", "action", "noise", "obs", "completed", "status", "mask")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "last_qpos", "action", "noise", "obs", "completed", "status", "mask", "skin")] + [
+        ("skin_stride", ctypes.c_int), ("skin_radius", ctypes.c_float)]
 
 
 class HerArgsStruct(ctypes.Structure):

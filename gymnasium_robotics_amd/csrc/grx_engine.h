@@ -116,6 +116,8 @@ struct GrxCtx {
   float* minv;       // models with the noslip post-solver: M^-1 (nv x nv), formed once per substep
   float* meshcache;  // models with hull-vs-convex pairs: 4 x (pair + 1, separating direction, the two support vertices) + the slot to evict next, kept across the substeps of a step (grx_mesh_pairs)
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
+  int* skin;   // large scenes: this world's skin list in HBM (grx_collision), or null: [0] entries, [1] valid, [4, 4 + 3 ngeom) reference geom positions, then the list
+  float skin_r;
   int maxefc, jpool, maxcon;  // capacities of the row tables / the packed Jacobian pool / the contact list of this model
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   long long* prof; long long* prof_last;
@@ -161,6 +163,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
 GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   const GrxDims* m = &d;
   float* p = base;
+  c->skin = nullptr; c->skin_r = 0.0f;
 #define CARVE(field, n) c->field = p; p += (n);
 #define CARVEI(field, n) c->field = (int*)p; p += (n);
   // ---- persistent
@@ -1848,12 +1851,61 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   // ONE dense pass instead of one sparse, divergent pass per 64 candidates.
   // Scenes with more candidates than the survivor list has room for (the kitchen: 3 736) are swept in chunks of that size: pair order is kept.
   const int ndp = m->ndevpair;
-  const int cap = c->jpool - 256, compact = ndp > 64 && cap >= 64;
   constexpr bool kChunked = !S::kFixed || S::NG > 64;   // small scenes (every specialised shape but the kitchen): one pass, no loop around the sweep
-  const int chunk = (kChunked && compact && cap < ndp) ? cap : (ndp > 0 ? ndp : 1);
+  // Skin list (large scenes, GPU build): the kitchen has 3 736 candidate pairs of which ~170 pass the bounding-sphere test and ~250 are within 10 cm of
+  // passing it.  The flat sweep of all candidates in every substep is replaced by a sweep of the pairs that passed the test with the radius inflated
+  // by `skin` when the list was built; the list (pair order) and the geom positions at that moment live in HBM, one row per world, across substeps
+  // AND launches.  Every substep checks the largest geom displacement since the build: while 2 * displacement <= skin no pair outside the list can pass
+  // the exact test (which only reads the two geom centres; plane geoms are static, checked by the host), so the survivors -- and everything after
+  // them -- are exactly those of the full sweep.  Otherwise (and for a zeroed row) the list is rebuilt first: one full sweep per ~40 substeps.
+  const int* slist = nullptr; int ncand = ndp;
+#if !defined(GRX_EMU)
+  if (kChunked && c->skin != nullptr && ndp > 256) {
+    volatile int* hdr = c->skin; float* gref = (float*)(c->skin + 4); int* list = c->skin + 4 + 3 * GRX_NGC;
+    const float skin = c->skin_r;
+    float d2 = 0.0f;
+    for (int g = lane_; g < GRX_NGC; g += 64) {
+      const float dx = c->gxpos[3 * g] - gref[3 * g], dy = c->gxpos[3 * g + 1] - gref[3 * g + 1], dz = c->gxpos[3 * g + 2] - gref[3 * g + 2];
+      d2 = fmaxf(d2, dx * dx + dy * dy + dz * dz);
+    }
+    const int valid = hdr[1];
+    const float dmax2 = grx_reduce_max(d2);
+    if (!valid || !(4.0f * dmax2 <= 0.81f * skin * skin)) {   // 10 % of the skin left for the rounding of the two tests
+      for (int g = lane_; g < 3 * GRX_NGC; g += 64) gref[g] = c->gxpos[g];
+      int ns = 0;
+      for (int base = 0; base < ndp; base += 256) {
+        unsigned rec[4]; float mg[4], rb[4]; int pass[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int k = base + 64 * u + lane_, kk = k < ndp ? k : 0; rec[u] = (unsigned)m->devpair_geoms[kk]; mg[u] = m->devpair_bound[2 * kk]; rb[u] = m->devpair_bound[2 * kk + 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int g1 = rec[u] & 0xFFF, g2 = (rec[u] >> 12) & 0xFFF, t1 = (rec[u] >> 24) & 0xF;
+          float dx[3] = {c->gxpos[3 * g2] - c->gxpos[3 * g1], c->gxpos[3 * g2 + 1] - c->gxpos[3 * g1 + 1], c->gxpos[3 * g2 + 2] - c->gxpos[3 * g1 + 2]};
+          const float r = rb[u] + mg[u] + skin;
+          int ps;
+          if (t1 == 0) { float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}; ps = dot3f(dx, n) <= r; }
+          else ps = dot3f(dx, dx) <= r * r;
+          pass[u] = (base + 64 * u + lane_ < ndp) && ps;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const unsigned long long bm = __ballot(pass[u]);
+          if (pass[u]) list[ns + __builtin_popcountll(bm & ((1ull << lane_) - 1ull))] = base + 64 * u + lane_;
+          ns += __builtin_popcountll(bm);
+        }
+      }
+      if (lane_ == 0) { hdr[0] = ns; hdr[1] = 1; }
+      __threadfence_block();
+      WAVE_SYNC();
+    }
+    ncand = hdr[0]; slist = list;
+  }
+#endif
+  const int cap = c->jpool - 256, compact = ncand > 64 && cap >= 64;
+  const int chunk = (kChunked && compact && cap < ncand) ? cap : (ncand > 0 ? ncand : 1);
   int c0 = 0;
   do {
-  const int cend = c0 + chunk < ndp ? c0 + chunk : ndp;
+  const int cend = c0 + chunk < ncand ? c0 + chunk : ncand;
   int nsurv = cend - c0; const int* surv = nullptr;
   if (compact) {
     int* sv = (int*)(c->Jp + 256);   // the Jacobian pool is free until the constraint stage ([0, 128) is c->red, [128, 222) the hull-pair queue + portal)
@@ -1862,15 +1914,18 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     // so that a round pays one memory latency instead of four
     for (int base = c0; base < cend; base += 256) {
       GRX_LANEVAR_I(ps0); GRX_LANEVAR_I(ps1); GRX_LANEVAR_I(ps2); GRX_LANEVAR_I(ps3);
+      GRX_LANEVAR_I(kp0); GRX_LANEVAR_I(kp1); GRX_LANEVAR_I(kp2); GRX_LANEVAR_I(kp3);
       FOR_LANES {
-        unsigned rec[4]; float mg[4], rb[4]; int ok[4];
+        unsigned rec[4]; float mg[4], rb[4]; int ok[4], kp[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int k = base + 64 * u + lane;
           ok[u] = k < cend;
-          const int kk = ok[u] ? k : c0;
-          rec[u] = (unsigned)m->devpair_geoms[kk]; mg[u] = m->devpair_bound[2 * kk]; rb[u] = m->devpair_bound[2 * kk + 1];
+          kp[u] = ok[u] ? k : c0;
+          if (kChunked && slist) kp[u] = slist[kp[u]];
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int kk = kp[u]; rec[u] = (unsigned)m->devpair_geoms[kk]; mg[u] = m->devpair_bound[2 * kk]; rb[u] = m->devpair_bound[2 * kk + 1]; }
         int pass[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -1882,11 +1937,12 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           pass[u] = ok[u] && ps;
         }
         LV(ps0) = pass[0]; LV(ps1) = pass[1]; LV(ps2) = pass[2]; LV(ps3) = pass[3];
+        LV(kp0) = kp[0]; LV(kp1) = kp[1]; LV(kp2) = kp[2]; LV(kp3) = kp[3];
       }
-#define GRX_COMPACT_GROUP(PS, U) { const unsigned long long bm = GRX_BALLOT(PS); \
-        FOR_LANES { if (LV(PS)) sv[ns + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = base + 64 * (U) + lane; } \
+#define GRX_COMPACT_GROUP(PS, KP) { const unsigned long long bm = GRX_BALLOT(PS); \
+        FOR_LANES { if (LV(PS)) sv[ns + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = LV(KP); } \
         ns += __builtin_popcountll(bm); }
-      GRX_COMPACT_GROUP(ps0, 0) GRX_COMPACT_GROUP(ps1, 1) GRX_COMPACT_GROUP(ps2, 2) GRX_COMPACT_GROUP(ps3, 3)
+      GRX_COMPACT_GROUP(ps0, kp0) GRX_COMPACT_GROUP(ps1, kp1) GRX_COMPACT_GROUP(ps2, kp2) GRX_COMPACT_GROUP(ps3, kp3)
 #undef GRX_COMPACT_GROUP
     }
     WAVE_SYNC();
@@ -1897,7 +1953,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     FOR_LANES {
       int isbox = 0, ismesh = 0, pq = 0;
       if (base + lane < nsurv) {
-        const int k = surv ? surv[base + lane] : base + lane;
+        const int k = surv ? surv[base + lane] : ((kChunked && slist) ? slist[base + lane] : base + lane);
         // one packed record per candidate (geoms, types, margin, broad-phase radius): a single level of model-table loads
         const unsigned rec = (unsigned)m->devpair_geoms[k];
         const int g1 = rec & 0xFFF, g2 = (rec >> 12) & 0xFFF, t1 = (rec >> 24) & 0xF, t2 = rec >> 28;
@@ -2010,7 +2066,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     }
   }
   c0 += chunk;
-  } while (kChunked && c0 < ndp);
+  } while (kChunked && c0 < ncand);
   LANE0 { if (c->cnt[0] > c->maxcon) c->cnt[0] = c->maxcon; }
   WAVE_SYNC();
   // The noslip sweeps are Gauss-Seidel over the contact list: while they have not converged their iterates depend on the ORDER of the list.

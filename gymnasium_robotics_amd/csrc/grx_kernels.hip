@@ -439,6 +439,7 @@ grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_
   for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
   __syncthreads();
   float* last = b.last_qpos + (size_t)w * GRX_KITCHEN_NROBOT;
+  if (b.skin) { c.skin = b.skin + (size_t)w * b.skin_stride; c.skin_r = b.skin_radius; }
   if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
   else GrxKitchen<S>::grx_kitchen_sim_world(&m, &t, &c, b.action + (size_t)w * GRX_KITCHEN_NROBOT, last, lane_);
   GrxKitchen<S>::grx_kitchen_outputs(&m, &t, &c, b.noise ? b.noise + (size_t)w * t.obs_dim : nullptr, b.obs + (size_t)w * t.obs_dim, last, b.completed + w, lane_);
@@ -930,6 +931,25 @@ extern "C" int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, 
   return 0;
 }
 
+// host tables of a model by name (the packed copy kept with the handle)
+static const int32_t* grx_host_itable(const grx_model* m, const char* name, int* n) {
+  for (size_t k = 0; k < m->pm.name.size(); k++)
+    if (m->pm.kind[k] == 'i' && m->pm.name[k] == name) { *n = m->pm.cnt[k]; return m->pm.i.data() + m->pm.off[k]; }
+  *n = 0; return nullptr;
+}
+// the skin list of grx_collision assumes that a plane geom never moves: every plane must sit on a body without a dof or a mocap id on its path to the world
+static bool grx_planes_static(const grx_model* m) {
+  int ng, nb, n;
+  const int32_t *gt = grx_host_itable(m, "geom_type", &ng), *gb = grx_host_itable(m, "geom_bodyid", &n), *bp = grx_host_itable(m, "body_parent", &nb),
+                *dn = grx_host_itable(m, "body_dofnum", &n), *mc = grx_host_itable(m, "body_mocapid", &n);
+  if (!gt || !gb || !bp || !dn || !mc) return false;
+  for (int g = 0; g < ng; g++) {
+    if (gt[g] != 0) continue;
+    for (int b = gb[g]; b > 0; b = bp[b]) if (dn[b] > 0 || mc[b] >= 0) return false;
+  }
+  return true;
+}
+
 extern "C" int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task, const grx_kitchen_buffers* buf, int n_worlds, int forward_only, void* stream) {
   if (!m || !task || !buf) return fail("grx_kitchen_step: null argument");
   if (!buf->qpos || !buf->qvel || !buf->qacc_ws || !buf->last_qpos || !buf->obs || !buf->completed || !buf->status) return fail("grx_kitchen_step: null buffer");
@@ -941,6 +961,10 @@ extern "C" int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task
   if (g.nu != GRX_KITCHEN_NROBOT || t.obs_dim != g.nq + g.nv || t.obs_dim > GRX_KITCHEN_OBS || t.n_substeps <= 0) return fail("grx_kitchen_step: the model is not the kitchen scene (nu 9, obs = nq + nv <= 59)");
   for (int j = 0; j < GRX_KITCHEN_NTASK; j++)
     if (t.task_adr[j] < 0 || t.task_num[j] < 0 || t.task_adr[j] + t.task_num[j] > g.nq) return fail("grx_kitchen_step: task qpos slice out of range");
+  if (b.skin) {
+    if (b.skin_stride < 4 + 3 * g.ngeom + g.ndevpair || !(b.skin_radius > 0.0f)) return fail("grx_kitchen_step: skin rows need 4 + 3 ngeom + ndevpair words and a positive radius");
+    if (!grx_planes_static(m)) return fail("grx_kitchen_step: the skin list needs static plane geoms");
+  }
   const int e = grx_tu_kitchen_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_kitchen_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;

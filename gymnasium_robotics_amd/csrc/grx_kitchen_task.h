@@ -34,6 +34,9 @@ struct GrxKitchenBuffers {
   int* completed;                 // [N] bit k: task k's qpos slice is within bonus_thresh of its goal
   int* status;                    // [N]
   const unsigned char* mask;      // [N] or null
+  int* skin;                      // [N, skin_stride] broad-phase skin lists (GrxEngine::grx_collision), zeroed by the host once; or null
+  int skin_stride;
+  float skin_radius;
 };
 
 template <class S>

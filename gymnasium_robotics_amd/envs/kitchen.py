@@ -31,7 +31,7 @@ class KitchenVecEnv(GoalVecEnv):
     def __init__(self, env_id: str = "FrankaKitchen-v1", num_envs: int = 1, device: Optional[str] = None, tasks_to_complete=None,
                  terminate_on_tasks_completed: bool = True, remove_task_when_completed: bool = True, object_noise_ratio: float = 0.0005,
                  robot_noise_ratio: float = 0.01, max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step", output: str = "numpy",
-                 assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
+                 assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0, skin_radius: float = 0.1):
         if env_id != "FrankaKitchen-v1":
             raise KeyError(f"unknown / unsupported kitchen env id {env_id}")
         if autoreset_mode not in ("next_step", "same_step", "disabled"):
@@ -61,6 +61,10 @@ class KitchenVecEnv(GoalVecEnv):
         self.action, self.obs, self.noise = z(n, self.nu), z(n, self.obs_dim), z(n, self.obs_dim)
         self.completed, self.status, self.mask = z(n, dtype=torch.int32), z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
         self._noise_host = torch.empty(n, self.obs_dim, dtype=torch.float32, pin_memory=True)
+        # broad-phase skin lists (csrc/grx_engine.h, grx_collision): one zeroed HBM row per world that the step kernel owns from then on -- the candidate
+        # pairs within `skin_radius` of passing the bounding test and the geom positions they were collected at (16 KB per world for the 3 736 pairs)
+        self.skin_radius = float(skin_radius)
+        self._skin = z(n, 4 + 3 * self.model.dim("ngeom") + len(self.model.tables["devpair"]), dtype=torch.int32) if self.skin_radius > 0.0 else None
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float64)                     # franka_env.py:88
         goal_space = Dict({t: Box(-np.inf, np.inf, OBS_ELEMENT_GOALS[t].shape, np.float64) for t in self.tasks})
@@ -85,6 +89,8 @@ class KitchenVecEnv(GoalVecEnv):
             setattr(b, name, getattr(self, name).data_ptr())
         b.noise = self.noise.data_ptr() if self._noisy else None
         b.mask = None if mask is None else mask.data_ptr()
+        if self._skin is not None:
+            b.skin, b.skin_stride, b.skin_radius = self._skin.data_ptr(), self._skin.shape[1], self.skin_radius
         return b
 
     def _stream(self):

@@ -170,6 +170,10 @@ typedef struct grx_kitchen_buffers {
   int* completed;                   /* [N] bit k: |qpos[task k] - goal k| < bonus_thresh (compute_reward's per-task test, kitchen_env.py:346-351) */
   int* status;                      /* [N] */
   const unsigned char* mask;        /* [N] or NULL */
+  int* skin;                        /* [N, skin_stride] zero-initialised scratch the library owns between calls (broad-phase skin list: 4 + 3 ngeom + ndevpair words
+                                       per world), or NULL: every substep sweeps the full candidate list.  Results are identical either way. */
+  int skin_stride;
+  float skin_radius;                /* metres by which the broad-phase radius is inflated when a world's list is built (0.1) */
 } grx_kitchen_buffers;
 
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);

@@ -110,3 +110,27 @@ def test_worlds_are_independent_and_deterministic():
     env1.reset(seed=5)
     solo = np.stack([env1.step(a[5:6])[0]["observation"][0] for a in acts])
     assert np.array_equal(solo, outs[0][:, 5])
+
+
+@pytest.mark.parametrize("radius", [0.1, 0.004])
+def test_skin_list_is_exact(radius):
+    """The broad-phase skin list (grx_collision: candidates within `radius` of the bounding test, rebuilt when a geom has moved radius / 2) must not change a
+    single bit: same seeds and actions with the list and with the full sweep of all 3 736 candidates in every substep (skin_radius=0).  radius 4 mm
+    forces a rebuild almost every substep, 0.1 m (the default) about once per env.step; the rollout crosses a time-limit autoreset."""
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(-1, 1, (7, 48, 9)).astype(np.float32)
+    outs = []
+    for r in (0.0, radius):
+        env = _env(48, skin_radius=r, max_episode_steps=4, autoreset_mode="same_step")
+        assert (env._skin is None) == (r == 0.0)
+        env.reset(seed=11)
+        rows = []
+        for a in acts:
+            obs, rew, term, trunc, info = env.step(a)
+            rows.append(np.concatenate([obs["observation"], rew[:, None], env.qacc_ws.cpu().numpy()], axis=1))
+        outs.append(np.stack(rows))
+        if r:
+            hdr = env._skin[:, :2].cpu().numpy()
+            assert (hdr[:, 1] == 1).all() and (hdr[:, 0] > 0).all() and (hdr[:, 0] < 3736).all()      # every world owns a valid list that is shorter than the flat one
+            print(f"skin {r}: list length p50 {np.median(hdr[:, 0]):.0f} max {hdr[:, 0].max()}")
+    assert np.array_equal(outs[0], outs[1])
