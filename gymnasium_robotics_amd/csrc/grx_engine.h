@@ -1902,6 +1902,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   }
 #endif
   const int cap = c->jpool - 256, compact = ncand > 64 && cap >= 64;
+  const bool classed = kChunked && ndp > 512 && ndp < 65536;   // a property of the MODEL (not of the kernel shape): the generic and the specialised kernel agree
   const int chunk = (kChunked && compact && cap < ncand) ? cap : (ncand > 0 ? ncand : 1);
   int c0 = 0;
   do {
@@ -1935,6 +1936,15 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           if (t1 == 0) { float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}; ps = dot3f(dx, n) <= rb[u] + mg[u]; }
           else { const float r = rb[u] + mg[u]; ps = dot3f(dx, dx) <= r * r; }
           pass[u] = ok[u] && ps;
+          if (classed) {
+            const int t2 = rec[u] >> 28;
+            // Large scenes, second filter: the bounding spheres of long thin geoms are loose (the kitchen: ~120 capsule-box candidates per substep pass
+            // the sphere test, none of them passes this one) -- separating-axis test of the two oriented bounding boxes, grown by the margin plus a
+            // rounding allowance: a pair it rejects cannot produce a contact within the margin, so the contact list does not change.
+            if (pass[u] && t1 >= 3 && t2 >= 3) pass[u] = grx_obb_overlap(m, c, g1, g2, mg[u] + 4e-6f);
+            // kind of narrow phase (see the regrouping below), carried in the bits above the pair index
+            kp[u] |= ((t2 == 7 && t1 != 0) ? 2 : ((t1 == 6 && t2 == 6) ? 1 : ((S::kConvex && t1 >= 2 && t2 <= 6 && (t1 == 4 || t1 == 5 || t2 == 4 || t2 == 5)) ? 3 : 0))) << 16;
+          }
         }
         LV(ps0) = pass[0]; LV(ps1) = pass[1]; LV(ps2) = pass[2]; LV(ps3) = pass[3];
         LV(kp0) = kp[0]; LV(kp1) = kp[1]; LV(kp2) = kp[2]; LV(kp3) = kp[3];
@@ -1947,13 +1957,41 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     }
     WAVE_SYNC();
     nsurv = ns; surv = sv;
+    GRX_SUBTICK(c, 19);
+    // Large scenes: the survivors (the kitchen: ~170 per substep, three rounds of 64) are regrouped by the KIND of narrow phase they need -- analytic
+    // primitive tests, box-box (queued), hull pairs (bounding-box test + queue), portal refinement on a lane -- so that a round of 64 lanes runs one
+    // kind instead of paying every kind's divergent branch in every round.  The contact list is put back into pair order afterwards (below).
+    if (classed && ns > 64 && 2 * ns <= cap) {
+      int* dst = sv + ns;
+      int off[4] = {0, 0, 0, 0};
+      for (int base = 0; base < ns; base += 64) {
+        GRX_LANEVAR_I(cl);
+        FOR_LANES { LV(cl) = base + lane < ns ? (sv[base + lane] >> 16) : -1; }
+        for (int q = 0; q < 3; q++) { GRX_LANEVAR_I(hit); FOR_LANES { LV(hit) = LV(cl) == q; } off[q + 1] += __builtin_popcountll(GRX_BALLOT(hit)); }
+      }
+      off[3] += off[2] + off[1]; off[2] += off[1];     // counts of the classes 0 .. 2 -> start of the classes 1 .. 3
+      for (int base = 0; base < ns; base += 64) {
+        GRX_LANEVAR_I(cl);
+        FOR_LANES { LV(cl) = base + lane < ns ? (sv[base + lane] >> 16) : -1; }
+        for (int q = 0; q < 4; q++) {
+          GRX_LANEVAR_I(hit);
+          FOR_LANES { LV(hit) = LV(cl) == q; }
+          const unsigned long long bm = GRX_BALLOT(hit);
+          FOR_LANES { if (LV(hit)) dst[off[q] + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = sv[base + lane]; }
+          off[q] += __builtin_popcountll(bm);
+        }
+      }
+      WAVE_SYNC();
+      surv = dst;
+    }
+    GRX_SUBTICK(c, 20);
   }
   for (int base = 0; base < nsurv; base += 64) {
     GRX_LANEVAR_I(boxq); GRX_LANEVAR_I(meshq); GRX_LANEVAR_I(pairq);
     FOR_LANES {
       int isbox = 0, ismesh = 0, pq = 0;
       if (base + lane < nsurv) {
-        const int k = surv ? surv[base + lane] : ((kChunked && slist) ? slist[base + lane] : base + lane);
+        const int k = surv ? (surv[base + lane] & 0xFFFF) : ((kChunked && slist) ? slist[base + lane] : base + lane);
         // one packed record per candidate (geoms, types, margin, broad-phase radius): a single level of model-table loads
         const unsigned rec = (unsigned)m->devpair_geoms[k];
         const int g1 = rec & 0xFFF, g2 = (rec >> 12) & 0xFFF, t1 = (rec >> 24) & 0xF, t2 = rec >> 28;
@@ -2072,7 +2110,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   // The noslip sweeps are Gauss-Seidel over the contact list: while they have not converged their iterates depend on the ORDER of the list.
   // The late queues above (box-box, hull pairs, large plane-mesh pairs) append their contacts after everything else; put the list back into
   // pair order (stable: a pair's contacts keep their order), the order of the reference's list.  One lane per contact, rank by counting.
-  if (S::kNoslip && m->noslip_iterations > 0) {
+  if ((S::kNoslip && m->noslip_iterations > 0) || classed) {
     const int nc = c->cnt[0];
     GRX_LANEVAR_I(rk); GRX_LANEVAR_I(pk); GRX_LANEVAR(dk); GRX_LANEVAR(x0); GRX_LANEVAR(x1); GRX_LANEVAR(x2); GRX_LANEVAR(f0); GRX_LANEVAR(f1); GRX_LANEVAR(f2);
     FOR_LANES {

@@ -46,9 +46,13 @@ for k in range(K):
         tot += np.array(list(out), dtype=np.float64) / n  # kernel sums over worlds
 tot /= (K - 2)
 s = tot.sum()
-print(f"{env_id}: cycles per env.step (20 substeps), mean over {n} worlds: {s:.0f}  (= {s/20:.0f} per substep)")
+print(f"{env_id}: cycles per env.step (all substeps of the step), mean over {n} worlds: {s:.0f}  ")
 for nm, v in zip(names, tot):
     print(f"  {nm:22s} {v:12.0f}  {100*v/s:5.1f}%")
+SUB = {0: "constraint: count", 1: "constraint: scan", 2: "constraint: equality rows", 3: "constraint: friction/limit rows", 4: "constraint: row params", 5: "constraint: contact J",
+       6: "velocity: rne a", 7: "velocity: rne b", 8: "velocity: passive/actuation", 9: "kinematics: bodies", 10: "kinematics: sites/frames", 11: "collision: box-box queue",
+       12: "collision: geom frames", 13: "collision: narrow phase rounds", 14: "inertia: cinert/cdof", 15: "inertia: crb/M", 16: "collision: hull pairs", 17: "solver aux a", 18: "solver aux b",
+       19: "collision: candidate sweep", 20: "collision: survivor regroup"}
 for k in range(16, NP):
     if tot[k] > 0:
-        print(f"  sub[{k-16:2d}]                {tot[k]:12.0f}  {100*tot[k]/s:5.1f}%")
+        print(f"  sub[{k-16:2d}] {SUB.get(k - 16, ''):32s} {tot[k]:12.0f}  {100*tot[k]/s:5.1f}%")
