@@ -157,6 +157,9 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
   if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); if (w < 16384) g_grx_world_span[2 * w] = wall_clock64(); }
 #endif
+#ifndef GRX_COST_MODEL
+  if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp (100 MHz), parked in the cost slot itself: nothing stays live across the substep loop
+#endif
   grx_load_world(m, b, c, w, lds, words, lane_);
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = b.aux[(size_t)w * 8 + k];
@@ -168,10 +171,15 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
 #ifdef GRX_PROFILE_ITER
   if (b.cost && lane_ == 0) b.cost[wl] = c.cnt[6] | (c.cnt[0] << 16);   // diagnostic build: Newton iterations of the step, contacts of the last substep
 #else
-  // cost model fitted to measured world durations (tools/profile_balance.py): ~12 us per Newton iteration of the step + ~24 us per contact of
-  // the last substep, on top of a constant.  Counting instead of timing keeps the dispatch order reproducible from run to run and keeps a
-  // 64-bit timestamp from living (spilled) across the substep loop.
+  // The cost the next launch is ordered by = the MEASURED duration of this world (device-wide 100 MHz clock, 80 ns units).  Round 1 counted instead
+  // (12 us per Newton iteration + 24 us per contact): the count knows nothing of the hull-pair refinement and of the line-search length, and a
+  // world it under-estimates starts in the second round and ends the launch alone (A/B in one process, FetchPickAndPlace 4096 worlds: 3.48 ms with
+  // the count, 3.16 ms with the measurement; -DGRX_COST_MODEL restores the count, whose dispatch order is reproducible from run to run).
+#ifdef GRX_COST_MODEL
   if (b.cost && lane_ == 0) b.cost[wl] = 12 * c.cnt[6] + 24 * c.cnt[0];
+#else
+  if (b.cost && lane_ == 0) { const int t0 = ((volatile int*)b.cost)[wl]; b.cost[wl] = ((int)wall_clock64() - t0) >> 3; }
+#endif
 #endif
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
@@ -324,6 +332,7 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
 #endif
   const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv, nu = S::kFixed ? S::NU : m.nu;
+  if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp, parked in the cost slot (see grx_fetch_step_kernel)
   for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
   __syncthreads();
   for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
@@ -352,7 +361,7 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
       b.success[w] = (d < t.distance_threshold) ? 1 : 0;
     }
     b.status[w] = grx_status_word(b.status[w], c.cnt[2]);
-    if (b.cost) b.cost[w] = 12 * c.cnt[6] + 24 * c.cnt[0];   // iterations of the step + contacts of the last substep (see grx_fetch_step_kernel)
+    if (b.cost) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = ((int)wall_clock64() - t0) >> 3; }   // measured duration of this world, 80 ns units (see grx_fetch_step_kernel)
   }
   if (b.packed) {   // [obs | achieved | desired | reward | success] row for the cross-rank gather
     float* row = b.packed + (size_t)w * (od + 2 * gd + 2);

@@ -153,7 +153,7 @@ class FetchVecEnv(GoalVecEnv):
         self.packed = z(n, self.obs_dim + 8)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather, parallel.py)
         self.cost = torch.zeros(n, dtype=torch.int32, device=d) if self.balance else None
         self.cost_ema = torch.zeros(n, dtype=torch.float32, device=d) if self.balance else None
-        self.balance_alpha = 0.1   # weight of the newest sample in the moving average the order is sorted by (A/B on FetchPickAndPlace: 1.0 -> 2.69 ms, 0.15 -> 2.64 ms per step)
+        self.balance_alpha = float(os.environ.get("GRX_BALANCE_ALPHA", 0.1))   # weight of the newest sample in the moving average the order is sorted by (A/B on FetchPickAndPlace: 1.0 -> 2.69 ms, 0.15 -> 2.64 ms per step)
         self.order = None
         if self.balance:
             per = n // 8
