@@ -28,7 +28,7 @@ class PointTaskStruct(ctypes.Structure):
 
 class PointBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask", "packed")]
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask", "packed", "order", "cost")]
 
 
 class AdroitTaskStruct(ctypes.Structure):
@@ -55,6 +55,12 @@ class HerArgsStruct(ctypes.Structure):
     _fields_ = [("rows", ctypes.c_void_p), ("acts", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in ("T", "N", "W", "obs_dim", "goal_dim", "act_dim")] + [
         (n, ctypes.c_void_p) for n in ("t_idx", "w_idx", "t_goal")] + [("kind", ctypes.c_int), ("p0", ctypes.c_float), ("p1", ctypes.c_float)] + [
         (n, ctypes.c_int) for n in ("sparse", "ignore_pos", "ignore_rot", "ignore_z")] + [("out", ctypes.c_void_p)]
+
+
+class MazeResetArgsStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("idx", "stage", "qpos0")] + [(n, ctypes.c_int) for n in ("nq", "nv", "obs_dim", "obs_skip")] + [
+        ("goal_radius", ctypes.c_float), ("keep_outcome", ctypes.c_int)] + [
+        (n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "goal", "obs", "achieved", "reward", "success", "packed")]
 
 
 class HandBuffersStruct(ctypes.Structure):
@@ -93,6 +99,7 @@ def lib():
         L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_float, ci, vp, vp]
         L.grx_manip_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]
         L.grx_order_by_cost.argtypes = [vp, vp, ctypes.c_float, ci, vp, vp]
+        L.grx_maze_reset_rows.argtypes = [vp, ci, vp]
         cd = ctypes.c_double
         L.grx_fetch_sample_resets.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         _lib = L
@@ -106,5 +113,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_maze_reset_rows", "grx_last_error",
 ]

@@ -720,6 +720,72 @@ template <int NS, bool HAND = false>
   __syncthreads();
   return __ballot((lane_ < NS) && !(rd > 0.0f)) != 0ull;   // a non-positive (or NaN) pivot: the matrix was not positive definite (GRX_ST_FACTOR)
 }
+// Newton Hessian of the hand models, H = M + J' D J (24 hand dofs [+ NOBJ = 6 dofs of a free object]).  M has the tree pattern; a limit / tendon row
+// touches dofs of one chain; a contact between a finger and the object couples that finger's chain (and the wrist) with the object dofs -- so, unless
+// two DIFFERENT fingers touch each other, H's hand block keeps the tree pattern and everything else sits in the object's rows and columns.
+// Eliminating the hand dofs leaf-to-root FIRST and the object dofs LAST creates no fill outside that pattern (a pivot k couples anc(k) and the
+// object among themselves: ancestors of one dof form a chain), so a pivot broadcasts |anc(k)| + NOBJ columns instead of all the remaining ones:
+// 83 + 24 NOBJ + NOBJ (NOBJ - 1) / 2 = 242 against 435 for the 30 dofs of hand + object; the skipped updates are exact zeros.  LINKED = false:
+// no active row links hand and object (the caller looked), the object columns are skipped as well (83 + 15).
+// The pattern is CHECKED on the values (every lane scans the off-pattern part of its row: 24 compares); returns -1 without touching x when an
+// off-pattern entry is non-zero (finger-finger contact): the caller falls back to the dense elimination.
+static constexpr unsigned kGrxHandAncTable[32] = {0x0, 0x1, 0x3, 0x7, 0xF, 0x1F, 0x3, 0x43, 0xC3, 0x1C3, 0x3, 0x403, 0xC03, 0x1C03,
+                                                  0x3, 0x4003, 0xC003, 0x1C003, 0x3C003, 0x3, 0x80003, 0x180003, 0x380003, 0x780003,
+                                                  0xFFFFFF, 0xFFFFFF, 0xFFFFFF, 0xFFFFFF, 0xFFFFFF, 0xFFFFFF, 0xFFFFFF, 0xFFFFFF};
+template <int NOBJ, bool LINKED>
+  static __device__ __forceinline__ int grx_sym_solve_hand(const float* A, int ld, float* x, int lane_) {
+  constexpr int NH = 24, NS = NH + NOBJ;
+  float a[NS];
+  const int row = lane_ < NS ? lane_ : 0;
+#pragma unroll
+  for (int i = 0; i < NS; i++) a[i] = A[row * ld + i];
+  {
+    const unsigned anc = kGrxHandAncTable[row & 31];
+    int off = 0;
+#pragma unroll
+    for (int j = 0; j < NH - 1; j++) off |= (j < row) && !((anc >> j) & 1u) && (a[j] != 0.0f);
+    if (__ballot(off && lane_ < NH) != 0ull) return -1;
+  }
+  float b = x[row], rd = 0.0f;
+  const bool obj = lane_ >= NH;
+#pragma unroll
+  for (int k = NH - 1; k >= 0; k--) {          // hand pivots, leaf to root; remaining rows: hand dofs < k (only the ancestors hold a non-zero a[k]) and the object
+    const float pinv = grx_rcp_refined(grx_readlane_f(a[k], k));
+    rd = (lane_ == k) ? pinv : rd;
+    const float mi = (lane_ < k || (LINKED && obj)) ? -a[k] * pinv : 0.0f;
+#pragma unroll
+    for (int j = 0; j < k; j++) { if ((kGrxHandAnc[k] >> j) & 1u) a[j] = fmaf(mi, grx_readlane_f(a[j], k), a[j]); }
+    if (LINKED) {
+#pragma unroll
+      for (int j = NH; j < NS; j++) a[j] = fmaf(mi, grx_readlane_f(a[j], k), a[j]);
+    }
+    b = fmaf(mi, grx_readlane_f(b, k), b);
+  }
+#pragma unroll
+  for (int k = NS - 1; k >= NH; k--) {         // object pivots: a dense NOBJ x NOBJ block
+    const float pinv = grx_rcp_refined(grx_readlane_f(a[k], k));
+    rd = (lane_ == k) ? pinv : rd;
+    const float mi = (obj && lane_ < k) ? -a[k] * pinv : 0.0f;
+#pragma unroll
+    for (int j = NH; j < k; j++) a[j] = fmaf(mi, grx_readlane_f(a[j], k), a[j]);
+    b = fmaf(mi, grx_readlane_f(b, k), b);
+  }
+  // substitution in the reverse order of the elimination: object dofs first, then the hand dofs root to leaf
+  float xo = 0.0f;
+#pragma unroll
+  for (int kk = 0; kk < NS; kk++) {
+    const int k = kk < NOBJ ? NH + kk : kk - NOBJ;
+    const float t = b * rd;
+    const float xk = grx_readlane_f(t, k);
+    xo = (lane_ == k) ? t : xo;
+    if (k >= NH && !LINKED) b = obj ? fmaf(-a[k], xk, b) : b;
+    else b = fmaf(-a[k], xk, b);
+  }
+  __syncthreads();
+  if (lane_ < NS) x[lane_] = xo;
+  __syncthreads();
+  return __ballot((lane_ < NS) && !(rd > 0.0f)) != 0ull;
+}
 // In-place Gauss-Jordan inverse of a symmetric positive definite matrix, same register layout (lane i = row i, NS registers): step k broadcasts
 // row k with v_readlane, every other row subtracts its multiple of it, the pivot column becomes the k-th column of the inverse.  No LDS traffic,
 // no barrier: ~2 NS^2 instructions against ~NS^3 / 8 dependent LDS round trips of the factor-and-substitute route (noslip needs all of M^-1).
@@ -761,6 +827,12 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit 
     int bad_ = grx_sym_solve_reg<24, true>(A, n, x, lane_);
     if (S::NV == 30) bad_ |= grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_);
     return bad_;
+  }
+  if (S::kFixed && S::NF == 24 && !tree) {     // hand shapes, Newton Hessian: structured elimination while no two fingers touch each other
+    int r_;
+    if (S::NV == 30) r_ = nsplit == 6 ? grx_sym_solve_hand<6, false>(A, n, x, lane_) : grx_sym_solve_hand<6, true>(A, n, x, lane_);
+    else r_ = grx_sym_solve_hand<0, false>(A, n, x, lane_);
+    if (r_ >= 0) return r_;
   }
   if (nsplit == 6 && n == 21) { int bad_ = grx_sym_solve_reg<15>(A, n, x, lane_); return bad_ | grx_sym_solve_reg<6>(A + 15 * n + 15, n, x + 15, lane_); }
   if (nsplit == 6 && n == 30) { int bad_ = grx_sym_solve_reg<24>(A, n, x, lane_); return bad_ | grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_); }

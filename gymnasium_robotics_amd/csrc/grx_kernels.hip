@@ -264,9 +264,10 @@ template <class S>
 __global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
 grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
-  const int w = grx_world_of_block(), lane_ = threadIdx.x;
+  const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
+  if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp, parked in the cost slot (see grx_fetch_step_kernel)
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -282,7 +283,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
   for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
   __syncthreads();
   GrxPoint<S>::grx_point_sim_world(&m, &t, &c, b.action + (size_t)w * m.nu, lane_);
-  const int wl = grx_world_of_block_late();
+  const int wl = b.order ? b.order[grx_block_late()] : grx_world_of_block_late();
   float* obs = b.obs + (size_t)wl * (m.nq + m.nv - (t.agent ? 2 : 0)); float* ach = b.achieved + (size_t)wl * 2;
   GrxPoint<S>::grx_point_outputs(&m, &t, &c, obs, ach, lane_);
   __syncthreads();
@@ -294,6 +295,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
     b.reward[wl] = grx_maze_reward(d, t.goal_radius, t.sparse_reward);
     b.success[wl] = succ; b.terminated[wl] = (!t.continuing_task && succ) ? 1 : 0;
     b.status[wl] = grx_status_word(b.status[wl], c.cnt[2]);
+    if (b.cost) { const int t0 = ((volatile int*)b.cost)[wl]; b.cost[wl] = ((int)wall_clock64() - t0) >> 3; }
   }
   if (b.packed) {   // [obs | achieved | desired | reward | success] row for the cross-rank gather
     const int od = m.nq + m.nv - (t.agent ? 2 : 0);
@@ -1075,6 +1077,46 @@ extern "C" int grx_her_relabel(const grx_her_args* args, int64_t batch, void* st
   long long blocks = (words + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(grx_her_relabel_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (long long)batch);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// maze episode reset for a compacted list of worlds (include/grx_capi.h): one 64-thread workgroup per listed world
+extern "C" __global__ void __launch_bounds__(64)
+grx_maze_reset_kernel(grx_maze_reset_args a, int n_reset) {
+  const int k = blockIdx.x, l = threadIdx.x;
+  if (k >= n_reset) return;
+  const int w = a.idx[k];
+  const float sx = a.stage[4 * k], sy = a.stage[4 * k + 1], gx = a.stage[4 * k + 2], gy = a.stage[4 * k + 3];
+  const int nobs_q = a.nq - a.obs_skip;
+  float* row = a.packed ? a.packed + (size_t)w * (a.obs_dim + 6) : nullptr;
+  for (int i = l; i < a.nq; i += 64) a.qpos[(size_t)w * a.nq + i] = i == 0 ? sx : (i == 1 ? sy : a.qpos0[i]);
+  for (int i = l; i < a.nv; i += 64) { a.qvel[(size_t)w * a.nv + i] = 0.0f; a.qacc_ws[(size_t)w * a.nv + i] = 0.0f; }
+  for (int i = l; i < a.obs_dim; i += 64) {
+    const int q = i + a.obs_skip;
+    const float v = i < nobs_q ? (q == 0 ? sx : (q == 1 ? sy : a.qpos0[q])) : 0.0f;
+    a.obs[(size_t)w * a.obs_dim + i] = v;
+    if (row) row[i] = v;
+  }
+  if (l == 0) {
+    a.goal[2 * (size_t)w] = gx; a.goal[2 * (size_t)w + 1] = gy;
+    a.achieved[2 * (size_t)w] = sx; a.achieved[2 * (size_t)w + 1] = sy;
+    const float dx = sx - gx, dy = sy - gy;
+    const int succ = sqrtf(dx * dx + dy * dy) <= a.goal_radius;
+    a.success[w] = (unsigned char)succ;
+    if (row) {
+      row[a.obs_dim] = sx; row[a.obs_dim + 1] = sy; row[a.obs_dim + 2] = gx; row[a.obs_dim + 3] = gy;
+      if (!a.keep_outcome) { row[a.obs_dim + 4] = a.reward[w]; row[a.obs_dim + 5] = succ ? 1.0f : 0.0f; }
+    }
+  }
+}
+extern "C" int grx_maze_reset_rows(const grx_maze_reset_args* args, int n_reset, void* stream) {
+  if (!args) return fail("grx_maze_reset_rows: null argument");
+  const grx_maze_reset_args& a = *args;
+  if (!a.idx || !a.stage || !a.qpos0 || !a.qpos || !a.qvel || !a.qacc_ws || !a.goal || !a.obs || !a.achieved || !a.reward || !a.success) return fail("grx_maze_reset_rows: null buffer");
+  if (a.nq < 2 || a.nv <= 0 || a.obs_skip < 0 || a.obs_skip > 2 || a.obs_dim != a.nq + a.nv - a.obs_skip) return fail("grx_maze_reset_rows: obs_dim must be nq + nv - obs_skip");
+  if (n_reset <= 0) return 0;
+  hipLaunchKernelGGL(grx_maze_reset_kernel, dim3((unsigned)n_reset), dim3(64), 0, (hipStream_t)stream, a, n_reset);
   HIP_OK(hipGetLastError());
   return 0;
 }

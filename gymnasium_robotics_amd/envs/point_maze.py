@@ -52,7 +52,8 @@ class PointMazeVecEnv(GoalVecEnv):
     def __init__(self, env_id: Optional[str] = "PointMaze_UMaze-v3", num_envs: int = 1, device: Optional[str] = None, maze_map=None,
                  reward_type: Optional[str] = None, continuing_task: bool = True, reset_target: bool = False,
                  position_noise_range: float = 0.25, max_episode_steps: Optional[int] = -1, autoreset_mode: str = "next_step",
-                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
+                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0,
+                 balance: bool = False):
         layout, rt, mes = (None, "sparse", self.DEFAULT_MAX_EPISODE_STEPS)
         if maze_map is None:
             layout, rt, mes = self._parse_id(env_id)
@@ -83,7 +84,26 @@ class PointMazeVecEnv(GoalVecEnv):
         self.success, self.terminated = z(n, dtype=torch.uint8), z(n, dtype=torch.uint8)
         self.status, self.mask = z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
         self.packed = z(n, self.obs_dim + 6)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather)
+        # cost-ordered dispatch (see FetchVecEnv._alloc): the worlds that took longest in the last launch start first; results do not depend on it.
+        # Off by default: measured neutral to -1 % for the ant (8 192 worlds are 3.2 per wave slot and their durations vary little)
+        self.balance = bool(balance) and n % 8 == 0 and 1024 <= n <= 65536 * 8
+        self.cost = z(n, dtype=torch.int32) if self.balance else None
+        self.cost_ema = z(n) if self.balance else None
+        self.order = None
+        if self.balance:
+            per = n // 8
+            self.order = (torch.arange(8, device=d, dtype=torch.int32).unsqueeze(1) * per + torch.arange(per, device=d, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        # reset staging (see _reset_worlds): pinned host rows [start xy | goal xy] + world indices, their device mirrors, the kernel's argument block
+        self._stage_host, self._idx_host = torch.empty(n, 4, dtype=torch.float32, pin_memory=True), torch.empty(n, dtype=torch.int32, pin_memory=True)
+        self._stage_dev, self._idx_dev, self._stage_event = z(n, 4), z(n, dtype=torch.int32), None
+        self._qpos0 = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32)).to(d)
+        a = _native.MazeResetArgsStruct()
+        a.idx, a.stage, a.qpos0 = self._idx_dev.data_ptr(), self._stage_dev.data_ptr(), self._qpos0.data_ptr()
+        a.nq, a.nv, a.obs_dim, a.obs_skip, a.goal_radius = self.nq, self.nv, self.obs_dim, self.OBS_SKIP, GOAL_RADIUS
+        for name in ("qpos", "qvel", "qacc_ws", "goal", "obs", "achieved", "reward", "success", "packed"):
+            setattr(a, name, getattr(self, name).data_ptr())
+        self._reset_args = a
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)
         self.single_observation_space = Dict(dict(
             observation=Box(-np.inf, np.inf, (self.obs_dim,), np.float64), achieved_goal=Box(-np.inf, np.inf, (2,), np.float64),
@@ -91,7 +111,6 @@ class PointMazeVecEnv(GoalVecEnv):
         self.action_space = batch_space(self.single_action_space, n)
         self.observation_space = batch_space(self.single_observation_space, n)
         self._check_goal_space()
-        self._qpos0 = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32)).to(d)
         self.np_randoms = [np_random(None)[0] for _ in range(n)]
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
@@ -103,32 +122,35 @@ class PointMazeVecEnv(GoalVecEnv):
         for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "packed"):
             setattr(b, name, getattr(self, name).data_ptr())
         b.mask = None if mask is None else mask.data_ptr()
+        b.order = None if self.order is None else self.order.data_ptr()
+        b.cost = None if self.cost is None else self.cost.data_ptr()
         return b
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------ reset (point_maze.py:377-390, maze_v4.py:299-358)
-    def _reset_worlds(self, idx, options=None):
-        if len(idx) == 0:
+    def _reset_worlds(self, idx, options=None, keep_outcome=False):
+        """Host: the reference's draws for the listed worlds (generate_reset_pos / generate_target_goal, maze_v4.py:299-358) into a pinned staging row per
+        world.  Device: two asynchronous copies and ONE kernel (grx_maze_reset_rows) that writes state, goal, observation and the packed row -- nothing
+        here waits for the step kernel that may still be running, so the draws overlap it."""
+        k = len(idx)
+        if k == 0:
             return
-        goals, starts = np.zeros((len(idx), 2)), np.zeros((len(idx), 2))
-        for k, w in enumerate(idx):
-            goals[k], starts[k] = sample_maze_reset(self.maze, self.np_randoms[w], self.position_noise_range, options)
-        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
-        q = self._qpos0.unsqueeze(0).repeat(len(idx), 1)  # init_qpos = the model's qpos0 with xy <- reset position
-        q[:, :2] = torch.from_numpy(starts.astype(np.float32)).to(self.device)
-        self.qpos[ti] = q
-        self.qvel[ti] = 0.0
-        self.qacc_ws[ti] = 0.0
-        self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
-        o = torch.zeros(len(idx), self.obs_dim, device=self.device)
-        o[:, : self.nq - self.OBS_SKIP] = q[:, self.OBS_SKIP:]
-        self.obs[ti] = o
-        self.achieved[ti] = q[:, :2]
-        d = torch.linalg.norm(self.achieved[ti] - self.goal[ti], dim=-1)
-        self.success[ti] = (d <= GOAL_RADIUS).to(torch.uint8)
-        self.packed[ti] = torch.cat([o, self.achieved[ti], self.goal[ti], self.reward[ti].unsqueeze(1), self.success[ti].float().unsqueeze(1)], dim=1)
+        if self._stage_event is not None:
+            self._stage_event.synchronize()          # the previous reset's copies have left the pinned buffers (normally long ago)
+        stage, ih = self._stage_host.numpy(), self._idx_host.numpy()
+        for j, w in enumerate(idx):
+            goal, start = sample_maze_reset(self.maze, self.np_randoms[w], self.position_noise_range, options)
+            stage[j, 0:2], stage[j, 2:4] = start, goal
+        ih[:k] = idx
+        self._stage_dev[:k].copy_(self._stage_host[:k], non_blocking=True)
+        self._idx_dev[:k].copy_(self._idx_host[:k], non_blocking=True)
+        self._stage_event = torch.cuda.Event()
+        self._stage_event.record()
+        a = self._reset_args
+        a.keep_outcome = int(keep_outcome)
+        _native.check(self._L.grx_maze_reset_rows(ctypes.byref(a), k, self._stream()))
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
 
@@ -170,6 +192,8 @@ class PointMazeVecEnv(GoalVecEnv):
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
+            if self.balance:
+                _native.check(self._L.grx_order_by_cost(self.cost.data_ptr(), self.cost_ema.data_ptr(), 0.1, self.num_envs, self.order.data_ptr(), self._stream()))
             stepped = ~self._needs_reset
             self._elapsed[stepped] += 1
             terminated = self.terminated.cpu().numpy().astype(bool) & stepped if not self.continuing_task else np.zeros(self.num_envs, bool)
@@ -190,15 +214,21 @@ class PointMazeVecEnv(GoalVecEnv):
             if self.autoreset_mode == "next_step":
                 self._needs_reset |= done
             elif self.autoreset_mode == "same_step" and done.any():
-                # the step's reward / success / terminal observation belong to the finished episode; the returned observation is the reset one
+                # the step's reward / success / terminal observation belong to the finished episode; the returned observation is the reset one.
+                # Everything below is enqueued behind the step kernel without waiting for it (pinned staging, device-side index list).
                 rows = np.nonzero(done)[0]
-                final_obs = self._obs_dict(rows=rows)
-                keep, step_success = self.reward.clone(), self.success.clone()
-                self._reset_worlds(rows)
-                self.reward.copy_(keep)
-                td = torch.from_numpy(rows).to(self.device)
-                self.packed[td, -2] = keep[td]
-                self.packed[td, -1] = step_success[td].float()
+                step_success = self.success.clone()
+                if self.output == "torch":
+                    if self._stage_event is not None:
+                        self._stage_event.synchronize()
+                    self._idx_host.numpy()[:len(rows)] = rows
+                    ti = self._idx_dev[:len(rows)]
+                    ti.copy_(self._idx_host[:len(rows)], non_blocking=True)
+                    ti = ti.long()
+                    final_obs = {"observation": self.obs[ti], "achieved_goal": self.achieved[ti], "desired_goal": self.goal[ti]}
+                else:
+                    final_obs = self._obs_dict(rows=rows)
+                self._reset_worlds(rows, keep_outcome=True)       # reward[] and the packed row's reward / success keep the finished episode's values
         obs = self._obs_dict()
         if new_goals is not None:
             if self.output == "torch":

@@ -91,6 +91,8 @@ typedef struct grx_point_buffers {
   int* status;                  /* [N] */
   const unsigned char* mask;    /* [N] or NULL */
   float* packed;                /* [N, obs_dim+2+2+2] or NULL: [obs | achieved | desired | reward | success] (see grx_fetch_buffers.packed) */
+  const int* order;             /* [N] or NULL: workgroup b steps world order[b] (cost-ordered dispatch, see grx_fetch_buffers.order / grx_order_by_cost) */
+  int* cost;                    /* [N] or NULL: out, measured duration of every world in this launch (80 ns units) */
 } grx_point_buffers;
 
 /* mirrors struct GrxHandTask / GrxHandBuffers (csrc/grx_hand_task.h): Shadow Dexterous Hand reach task */
@@ -247,6 +249,20 @@ typedef struct grx_her_args {
   float* out;                          /* [batch, 2 obs_dim + 3 goal_dim + act_dim + 2] */
 } grx_her_args;
 int grx_her_relabel(const grx_her_args* args, int64_t batch, void* stream);
+
+/* Episode reset of a COMPACTED list of maze worlds (maze/point_maze.py:377-390 / ant_maze_v5.py reset_model, maze_v4.py:299-358: qpos = init_qpos with
+ * xy <- the drawn reset position, qvel = 0, new goal, observation of the reset state): one kernel writes state, goal, obs / achieved / success and the
+ * packed row of the n_reset worlds idx[0..n_reset).  The draws (generate_reset_pos / generate_target_goal) stay on the host; stage = [n_reset, 4] rows
+ * (start x, start y, goal x, goal y).  keep_outcome != 0 (same-step autoreset): the last two words of the packed row keep the finished episode's
+ * reward / success.  All pointers are device pointers. */
+typedef struct grx_maze_reset_args {
+  const int* idx; const float* stage; const float* qpos0;
+  int nq, nv, obs_dim, obs_skip;        /* obs_skip: leading qpos entries left out of the observation (2 for the ant, 0 for the point mass) */
+  float goal_radius;
+  int keep_outcome;
+  float *qpos, *qvel, *qacc_ws, *goal, *obs, *achieved; const float* reward; unsigned char* success; float* packed;
+} grx_maze_reset_args;
+int grx_maze_reset_rows(const grx_maze_reset_args* args, int n_reset, void* stream);
 
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's
