@@ -63,6 +63,12 @@ class MazeResetArgsStruct(ctypes.Structure):
         (n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "goal", "obs", "achieved", "reward", "success", "packed")]
 
 
+class HandCommitArgsStruct(ctypes.Structure):
+    _fields_ = [("idx", ctypes.c_void_p), ("k", ctypes.c_int)] + [(n, ctypes.c_int) for n in ("nq", "nv", "obs_dim", "goal_dim")] + [
+        (n, ctypes.c_void_p) for n in ("s_qpos", "s_qvel", "s_qacc_ws", "s_obs", "s_achieved", "s_palm", "s_goal", "s_packed", "s_status",
+                                       "qpos", "qvel", "qacc_ws", "obs", "achieved", "palm", "goal", "packed", "status")]
+
+
 class HandBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost", "packed")]
@@ -100,6 +106,7 @@ def lib():
         L.grx_manip_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]
         L.grx_order_by_cost.argtypes = [vp, vp, ctypes.c_float, ci, vp, vp]
         L.grx_maze_reset_rows.argtypes = [vp, ci, vp]
+        L.grx_hand_commit_rows.argtypes = [vp, vp]
         cd = ctypes.c_double
         L.grx_fetch_sample_resets.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         _lib = L
@@ -113,5 +120,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_maze_reset_rows", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
 ]

@@ -1121,6 +1121,34 @@ extern "C" int grx_maze_reset_rows(const grx_maze_reset_args* args, int n_reset,
   return 0;
 }
 
+// commit of an overlapped hand-manipulate reset (include/grx_capi.h): one 64-thread workgroup per row
+extern "C" __global__ void __launch_bounds__(64)
+grx_hand_commit_kernel(grx_hand_commit_args a) {
+  const int j = blockIdx.x, l = threadIdx.x;
+  if (j >= a.k) return;
+  const size_t w = (size_t)a.idx[j], s = (size_t)j;
+  const int od = a.obs_dim, gd = a.goal_dim, pw = od + 2 * gd + 2;
+  for (int i = l; i < a.nq; i += 64) a.qpos[w * a.nq + i] = a.s_qpos[s * a.nq + i];
+  for (int i = l; i < a.nv; i += 64) { a.qvel[w * a.nv + i] = a.s_qvel[s * a.nv + i]; a.qacc_ws[w * a.nv + i] = a.s_qacc_ws[s * a.nv + i]; }
+  for (int i = l; i < od; i += 64) { const float v = a.s_obs[s * od + i]; a.obs[w * od + i] = v; }
+  for (int i = l; i < gd; i += 64) { a.achieved[w * gd + i] = a.s_achieved[s * gd + i]; a.goal[w * gd + i] = a.s_goal[s * gd + i]; }
+  if (l < 3) a.palm[w * 3 + l] = a.s_palm[s * 3 + l];
+  for (int i = l; i < od + gd; i += 64) a.packed[w * pw + i] = a.s_packed[s * pw + i];               // [obs | achieved] of the reset state
+  for (int i = l; i < gd; i += 64) a.packed[w * pw + od + gd + i] = a.s_goal[s * gd + i];           // the new goal
+  if (l == 0) a.status[w] |= a.s_status[s] & (int)0xFFFF0000;
+}
+extern "C" int grx_hand_commit_rows(const grx_hand_commit_args* args, void* stream) {
+  if (!args) return fail("grx_hand_commit_rows: null argument");
+  const grx_hand_commit_args& a = *args;
+  if (!a.idx || !a.s_qpos || !a.s_qvel || !a.s_qacc_ws || !a.s_obs || !a.s_achieved || !a.s_palm || !a.s_goal || !a.s_packed || !a.s_status || !a.qpos || !a.qvel ||
+      !a.qacc_ws || !a.obs || !a.achieved || !a.palm || !a.goal || !a.packed || !a.status) return fail("grx_hand_commit_rows: null buffer");
+  if (a.nq <= 0 || a.nv <= 0 || a.obs_dim <= 0 || a.goal_dim <= 0) return fail("grx_hand_commit_rows: bad dimensions");
+  if (a.k <= 0) return 0;
+  hipLaunchKernelGGL(grx_hand_commit_kernel, dim3((unsigned)a.k), dim3(64), 0, (hipStream_t)stream, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 // test-only entry point (tests/test_gpu_primitives.py); all pointers are device pointers
 extern "C" int grx_debug_primitive(int mode, int nv, int nefc, const float* A, const float* b, const float* J, const float* D, float* out, void* stream) {
   int bytes = (2 * nv * nv + GRX_MAXEFC * nv + 6 * GRX_MAXEFC + 2 * nv + 64) * 4;

@@ -104,6 +104,11 @@ class HandReachVecEnv(GoalVecEnv):
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
         self.kernel_events = None  # when a list: (start, end) HIP events around every step-kernel launch (benchmarks)
+        # pinned staging for the index lists / goal rows the autoreset path sends to the device: a pageable-memory copy is stream-ordered, i.e. it makes
+        # the host wait for the step kernel that was just launched; a pinned copy is only enqueued, and the host goes on to the reset draws meanwhile
+        self._pin = [dict(idx=torch.empty(n, dtype=torch.int64, pin_memory=True), rows=torch.empty(n, max(self.nq, GOAL_DIM), dtype=torch.float32, pin_memory=True), event=None)
+                     for _ in range(16)]
+        self._pin_next = 0
         self._env_setup()
 
     # ---- hooks specialised by the manipulation envs
@@ -164,6 +169,30 @@ class HandReachVecEnv(GoalVecEnv):
         self.initial_goal = self.achieved[0].double().cpu().numpy().copy()
         self.palm_xpos = self.palm[0].double().cpu().numpy().copy()
 
+    def _pin_slot(self):
+        slot = self._pin[self._pin_next]
+        self._pin_next = (self._pin_next + 1) % len(self._pin)
+        if slot["event"] is not None:
+            slot["event"].synchronize()          # sixteen uses ago: long done
+        return slot
+
+    def _dev_index(self, idx, rows=None):
+        """world indices (numpy) -> int64 device tensor [, float rows (numpy [k, w]) -> float32 device tensor], without waiting for the stream"""
+        k, slot, stream = len(idx), self._pin_slot(), torch.cuda.current_stream(self.device)
+        slot["idx"].numpy()[:k] = idx
+        ti = torch.empty(k, dtype=torch.int64, device=self.device)
+        ti.copy_(slot["idx"][:k], non_blocking=True)
+        out = ti
+        if rows is not None:
+            w = rows.shape[1]
+            slot["rows"].numpy()[:k, :w] = rows
+            tr = torch.empty(k, w, dtype=torch.float32, device=self.device)
+            tr.copy_(slot["rows"][:k, :w], non_blocking=True)
+            out = (ti, tr)
+        slot["event"] = torch.cuda.Event()
+        slot["event"].record(stream)
+        return out
+
     def _begin_overlapped_reset(self):
         return None
 
@@ -177,12 +206,12 @@ class HandReachVecEnv(GoalVecEnv):
     def _reset_worlds(self, idx):
         if len(idx) == 0:
             return
-        goals = sample_hand_reach_goal_batch([self.np_randoms[w] for w in idx], self.initial_goal, self.palm_xpos)
-        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
+        goals = sample_hand_reach_goal_batch([self.np_randoms[w] for w in idx], self.initial_goal, self.palm_xpos)   # host draws: the step kernel may still be running
+        ti, tg = self._dev_index(np.asarray(idx, dtype=np.int64), goals)
         self.qpos[ti] = self._initial_qpos
         self.qvel[ti] = 0.0
         self.qacc_ws[ti] = 0.0
-        self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
+        self.goal[ti] = tg
         self.mask.zero_()
         self.mask[ti] = 1
         self._launch(self._bufs_masked, True)
@@ -230,18 +259,20 @@ class HandReachVecEnv(GoalVecEnv):
                 self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
-                td = torch.from_numpy(done).to(self.device)
-                info["final_obs"] = self._obs_dict(rows=done)   # the terminal observation (bootstrapping), as FetchVecEnv reports it
+                td = self._dev_index(done)
+                info["final_obs"] = self._obs_dict(rows=done, ti=td)   # the terminal observation (bootstrapping), as FetchVecEnv reports it
                 keep_r, keep_s, keep_st = self.reward.clone(), self.success.clone(), self.status.clone()
                 if spec is not None:
-                    self._finish_overlapped_reset(spec, done)
+                    restore = self._finish_overlapped_reset(spec, done)     # False: every world came from a settle chain, committed by one kernel that leaves these words alone
                 else:
                     self._reset_worlds(done)
-                self.reward.copy_(keep_r)
-                self.success.copy_(keep_s)
-                self.status.copy_((keep_st & 0xFFFF) | (self.status & -65536))   # this step's flags are the step launch's, not the reset launches'; sticky bits keep accumulating
-                self.packed[td, -2] = keep_r[td]
-                self.packed[td, -1] = keep_s[td].float()
+                    restore = True
+                if restore:
+                    self.reward.copy_(keep_r)
+                    self.success.copy_(keep_s)
+                    self.status.copy_((keep_st & 0xFFFF) | (self.status & -65536))   # this step's flags are the step launch's, not the reset launches'; sticky bits keep accumulating
+                    self.packed[td, -2] = keep_r[td]
+                    self.packed[td, -1] = keep_s[td].float()
             elif self.autoreset_mode == "next_step":
                 self._needs_reset |= truncated
         obs = self._obs_dict()
@@ -253,9 +284,11 @@ class HandReachVecEnv(GoalVecEnv):
         r = self.reward.cpu().numpy()
         return obs, (r if self.reward_type == "sparse" else r.astype(np.float64)), terminated, truncated, info
 
-    def _obs_dict(self, rows=None):
+    def _obs_dict(self, rows=None, ti=None):
         if self.output == "torch":
-            sel = (lambda t: t) if rows is None else (lambda t: t[torch.from_numpy(rows).to(self.device)])
+            if rows is not None and ti is None:
+                ti = self._dev_index(rows)
+            sel = (lambda t: t) if rows is None else (lambda t: t[ti])
             return {"observation": sel(self.obs), "achieved_goal": sel(self.achieved), "desired_goal": sel(self.goal)}
         sel = (lambda a: a) if rows is None else (lambda a: a[rows])
         return {"observation": sel(self.obs.double().cpu().numpy()), "achieved_goal": sel(self.achieved.double().cpu().numpy()),
@@ -464,7 +497,7 @@ class HandBlockVecEnv(HandReachVecEnv):
         if any(lo < c["lo"] + c["k"] and c["lo"] < lo + k for c in self._chains):
             return None                                         # no room next to the chains in flight: these worlds take the sequential path
         self._ar_head = lo + k
-        ti = torch.from_numpy(worlds).to(self.device)
+        ti = self._dev_index(worlds)
         ar["qacc_ws"][lo: lo + k] = self.qacc_ws[ti]
         ar["goal"][lo: lo + k] = self.goal[ti]
         ar["status"][lo: lo + k] = 0
@@ -550,10 +583,12 @@ class HandBlockVecEnv(HandReachVecEnv):
                 self._early_goals(c)
             torch.cuda.current_stream(self.device).wait_event(c["event"])
             lo, k, ti = c["lo"], c["k"], c["ti"]
-            for name in ("qpos", "qvel", "qacc_ws", "obs", "achieved", "palm", "packed", "goal"):
-                getattr(self, name)[ti] = ar[name][lo: lo + k]
-            self.packed[ti, self.obs_dim + gd: self.obs_dim + 2 * gd] = ar["goal"][lo: lo + k]     # the reset row carries the new goal
-            self.status[ti] |= ar["status"][lo: lo + k] & -65536     # sticky flags of the settle steps
+            a = _native.HandCommitArgsStruct()     # one kernel: state, outputs, goal, the packed row (its reward / success words stay the finished episode's), sticky status bits
+            a.idx, a.k, a.nq, a.nv, a.obs_dim, a.goal_dim = ti.data_ptr(), k, self.nq, self.nv, self.obs_dim, gd
+            for name in ("qpos", "qvel", "qacc_ws", "obs", "achieved", "palm", "goal", "packed", "status"):
+                setattr(a, "s_" + name, ar[name][lo:].data_ptr())
+                setattr(a, name, getattr(self, name).data_ptr())
+            _native.check(self._L.grx_hand_commit_rows(ctypes.byref(a), self._stream()))
             failed.append(c["worlds"][~c["ok"]])
             covered[c["worlds"]] = True
             self._chain_started[c["worlds"]] = False
@@ -570,6 +605,7 @@ class HandBlockVecEnv(HandReachVecEnv):
             self._sample_goals(late)
         self._elapsed[done_idx] = 0
         self._needs_reset[done_idx] = False
+        return len(late) > 0        # settle launches ran on the main buffers: their reward / success / status words belong to the reset, not to this step
 
     def _cancel_chains(self):
         """reset() / set-state calls: settle chains in flight belong to episodes that no longer exist"""

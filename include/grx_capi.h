@@ -264,6 +264,18 @@ typedef struct grx_maze_reset_args {
 } grx_maze_reset_args;
 int grx_maze_reset_rows(const grx_maze_reset_args* args, int n_reset, void* stream);
 
+/* Commit of an overlapped hand-manipulate reset (envs/hand.py: the settle steps of _reset_sim, manipulate.py:154-224, ran on compacted side rows while the
+ * old episode was finishing): row j of the source block replaces world idx[j] of the destination buffers -- qpos, qvel, qacc_ws, obs, achieved, palm,
+ * goal, the packed row except its last two words (reward / success stay those of the finished episode, same-step autoreset) with the new goal in its
+ * desired-goal slot, and the sticky (upper 16) status bits are OR-ed in.  One launch instead of ~30 indexed copies.  All pointers are device pointers. */
+typedef struct grx_hand_commit_args {
+  const int64_t* idx; int k;
+  int nq, nv, obs_dim, goal_dim;
+  const float *s_qpos, *s_qvel, *s_qacc_ws, *s_obs, *s_achieved, *s_palm, *s_goal, *s_packed; const int* s_status;
+  float *qpos, *qvel, *qacc_ws, *obs, *achieved, *palm, *goal, *packed; int* status;
+} grx_hand_commit_args;
+int grx_hand_commit_rows(const grx_hand_commit_args* args, void* stream);
+
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's
  * numpy PCG64 (created and seeded by numpy on the Python side), advanced in place.  All pointers are HOST pointers. */
