@@ -88,6 +88,44 @@ class GoalVecEnv:
         pass
 
 
+class PinnedStager:
+    """Index lists / small float rows for the device WITHOUT waiting for the stream.  A copy from pageable memory is stream-ordered and synchronous for the
+    host: issued behind a step kernel it makes the host wait for that kernel, and the reset draws that follow run with the GPU idle.  Here the data goes
+    through a ring of pinned buffers and is only enqueued; a slot is reused sixteen calls later (its copy event is checked first)."""
+
+    def __init__(self, n: int, width: int, device, slots: int = 16):
+        import torch
+
+        self.device = device
+        self._slots = [dict(idx=torch.empty(n, dtype=torch.int64, pin_memory=True), rows=torch.empty(n, max(width, 1), dtype=torch.float32, pin_memory=True), event=None)
+                       for _ in range(slots)]
+        self._next = 0
+
+    def __call__(self, idx, rows=None):
+        """idx (numpy ints [k]) -> int64 device tensor; with rows (numpy [k, w]): (indices, float32 device tensor [k, w])"""
+        import torch
+
+        slot = self._slots[self._next]
+        self._next = (self._next + 1) % len(self._slots)
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        k = len(idx)
+        slot["idx"].numpy()[:k] = idx
+        ti = torch.empty(k, dtype=torch.int64, device=self.device)
+        ti.copy_(slot["idx"][:k], non_blocking=True)
+        out = ti
+        if rows is not None:
+            rows = np.asarray(rows).reshape(k, -1)
+            w = rows.shape[1]
+            slot["rows"].numpy()[:k, :w] = rows
+            tr = torch.empty(k, w, dtype=torch.float32, device=self.device)
+            tr.copy_(slot["rows"][:k, :w], non_blocking=True)
+            out = (ti, tr)
+        slot["event"] = torch.cuda.Event()
+        slot["event"].record(torch.cuda.current_stream(self.device))
+        return out
+
+
 def np_random(seed=None):
     """gymnasium.utils.seeding.np_random [3P]: PCG64 seeded through a SeedSequence."""
     if seed is not None and not (isinstance(seed, (int, np.integer)) and seed >= 0):

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..core import GoalVecEnv, np_random
+from ..core import GoalVecEnv, PinnedStager, np_random
 from ..mjcf import CompiledModel
 from ..spaces import Box, batch_space
 from .adroit_spec import IDENTITY_SHIFT, MAX_EPISODE_STEPS, SPECS, action_scaling, group_shift, load_adroit_model, make_adroit_task, parse_adroit_id, sample_reset_batch
@@ -72,6 +72,7 @@ class AdroitVecEnv(GoalVecEnv):
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
         self.kernel_events = None
+        self._stage = PinnedStager(n, 10, self.device)
 
     @property
     def board_z(self):
@@ -102,10 +103,15 @@ class AdroitVecEnv(GoalVecEnv):
 
     # ------------------------------------------------------------------ reset (MujocoEnv.reset [3P] -> reset_model of the task)
     def _write_edits(self, idx, shifts, targets=None):
-        ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
-        self.shift[ti] = torch.from_numpy(np.asarray(shifts, dtype=np.float32).reshape(len(idx), 7)).to(self.device)
+        """per-world model edits -> device, through pinned staging (core.PinnedStager): nothing here waits for a step kernel that is still running"""
+        k = len(idx)
+        rows = np.asarray(shifts, dtype=np.float32).reshape(k, 7)
         if targets is not None:
-            self.target[ti] = torch.from_numpy(np.asarray(targets, dtype=np.float32).reshape(len(idx), 3)).to(self.device)
+            rows = np.concatenate([rows, np.asarray(targets, dtype=np.float32).reshape(k, 3)], axis=1)
+        ti, tr = self._stage(np.asarray(idx, dtype=np.int64), rows)
+        self.shift[ti] = tr[:, :7]
+        if targets is not None:
+            self.target[ti] = tr[:, 7:10]
         return ti
 
     def _reset_worlds(self, idx):
@@ -165,7 +171,7 @@ class AdroitVecEnv(GoalVecEnv):
                 self.reward[tp] = 0.0
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
-                td = torch.from_numpy(done).to(self.device)
+                td = self._stage(done)
                 info["final_obs"] = self.obs[td].clone() if self.output == "torch" else self.obs[td].double().cpu().numpy()
                 keep_r, keep_s, keep_st = self.reward.clone(), self.success.clone(), self.status.clone()
                 self._reset_worlds(done)

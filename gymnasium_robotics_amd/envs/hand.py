@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..core import GoalVecEnv, np_random
+from ..core import GoalVecEnv, PinnedStager, np_random
 from ..mjcf import CompiledModel, compile_mjcf, load_model
 from ..spaces import Box, Dict, batch_space
 from .hand_spec import (DISTANCE_THRESHOLD, MAX_EPISODE_STEPS, N_ACTIONS, initial_qpos_vector, make_hand_task, parse_hand_reach_id,
@@ -104,11 +104,7 @@ class HandReachVecEnv(GoalVecEnv):
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
         self.kernel_events = None  # when a list: (start, end) HIP events around every step-kernel launch (benchmarks)
-        # pinned staging for the index lists / goal rows the autoreset path sends to the device: a pageable-memory copy is stream-ordered, i.e. it makes
-        # the host wait for the step kernel that was just launched; a pinned copy is only enqueued, and the host goes on to the reset draws meanwhile
-        self._pin = [dict(idx=torch.empty(n, dtype=torch.int64, pin_memory=True), rows=torch.empty(n, max(self.nq, GOAL_DIM), dtype=torch.float32, pin_memory=True), event=None)
-                     for _ in range(16)]
-        self._pin_next = 0
+        self._dev_index = PinnedStager(n, max(self.nq, GOAL_DIM), d)   # index lists / goal rows of the autoreset path: enqueued, never waited for (core.PinnedStager)
         self._env_setup()
 
     # ---- hooks specialised by the manipulation envs
@@ -168,30 +164,6 @@ class HandReachVecEnv(GoalVecEnv):
             raise RuntimeError(f"engine reported status {int(self.status[0])} during env setup")
         self.initial_goal = self.achieved[0].double().cpu().numpy().copy()
         self.palm_xpos = self.palm[0].double().cpu().numpy().copy()
-
-    def _pin_slot(self):
-        slot = self._pin[self._pin_next]
-        self._pin_next = (self._pin_next + 1) % len(self._pin)
-        if slot["event"] is not None:
-            slot["event"].synchronize()          # sixteen uses ago: long done
-        return slot
-
-    def _dev_index(self, idx, rows=None):
-        """world indices (numpy) -> int64 device tensor [, float rows (numpy [k, w]) -> float32 device tensor], without waiting for the stream"""
-        k, slot, stream = len(idx), self._pin_slot(), torch.cuda.current_stream(self.device)
-        slot["idx"].numpy()[:k] = idx
-        ti = torch.empty(k, dtype=torch.int64, device=self.device)
-        ti.copy_(slot["idx"][:k], non_blocking=True)
-        out = ti
-        if rows is not None:
-            w = rows.shape[1]
-            slot["rows"].numpy()[:k, :w] = rows
-            tr = torch.empty(k, w, dtype=torch.float32, device=self.device)
-            tr.copy_(slot["rows"][:k, :w], non_blocking=True)
-            out = (ti, tr)
-        slot["event"] = torch.cuda.Event()
-        slot["event"].record(stream)
-        return out
 
     def _begin_overlapped_reset(self):
         return None
