@@ -96,6 +96,7 @@ def lib():
         L.grx_fetch_reset.argtypes = [vp, vp, vp, vp, ci, vp]
         L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_her_relabel.argtypes = [vp, ctypes.c_int64, vp]
+        L.grx_her_sample.argtypes = [vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, vp, vp, vp, vp]
         L.grx_kitchen_step.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_sample_uniform_rows.argtypes = [vp, vp, ci, ci, vp]
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
@@ -120,5 +121,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
 ]

@@ -1081,6 +1081,48 @@ extern "C" int grx_her_relabel(const grx_her_args* args, int64_t batch, void* st
   return 0;
 }
 
+// HER index draws (include/grx_capi.h): one thread per sample, splitmix64 stream keyed by (seed, call, sample)
+static __device__ __forceinline__ unsigned long long grx_splitmix(unsigned long long& s) {
+  unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+extern "C" __global__ void __launch_bounds__(256)
+grx_her_sample_kernel(const int* __restrict__ start, int N, int t_now, int T, int k_future, unsigned long long seed, unsigned long long call, long long B,
+                      int* __restrict__ t_idx, int* __restrict__ w_idx, int* __restrict__ t_goal) {
+  const int lo_min = t_now - T > 0 ? t_now - T : 0;
+  for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
+    unsigned long long s = seed * 0xD1342543DE82EF95ull + call * 0x2545F4914F6CDD1Dull + (unsigned long long)b;
+    (void)grx_splitmix(s);
+    int w = 0, lo = t_now;
+    for (int attempt = 0; attempt < 64 && lo >= t_now; attempt++) {          // uniform over the worlds that have a transition (the caller made sure one exists)
+      w = (int)(((grx_splitmix(s) >> 32) * (unsigned long long)N) >> 32);
+      lo = start[w] > lo_min ? start[w] : lo_min;
+    }
+    for (int probe = 0; probe < N && lo >= t_now; probe++) { w = w + 1 < N ? w + 1 : 0; lo = start[w] > lo_min ? start[w] : lo_min; }
+    const unsigned long long r = grx_splitmix(s), r2 = grx_splitmix(s);
+    const float u0 = (float)(r >> 40) * (1.0f / 16777216.0f), u1 = (float)((r >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 40) * (1.0f / 16777216.0f);
+    int t = lo + (int)(u0 * (float)(t_now - lo));
+    if (t > t_now - 1) t = t_now - 1;
+    int fut = t + 1 + (int)(u1 * (float)(t_now - t));
+    if (fut > t_now) fut = t_now;
+    t_idx[b] = t; w_idx[b] = w;
+    t_goal[b] = (u2 >= (float)k_future / ((float)k_future + 1.0f)) ? -1 : fut;
+  }
+}
+extern "C" int grx_her_sample(const int* episode_start, int n_worlds, int t_now, int T, int k_future, uint64_t seed, uint64_t call, int64_t batch,
+                              int* t_idx, int* w_idx, int* t_goal, void* stream) {
+  if (!episode_start || !t_idx || !w_idx || !t_goal) return fail("grx_her_sample: null argument");
+  if (n_worlds <= 0 || T <= 0 || t_now <= 0 || k_future < 0) return fail("grx_her_sample: n_worlds, T and t_now must be positive, k_future >= 0");
+  if (batch <= 0) return 0;
+  long long blocks = (batch + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(grx_her_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, episode_start, n_worlds, t_now, T, k_future,
+                     (unsigned long long)seed, (unsigned long long)call, (long long)batch, t_idx, w_idx, t_goal);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 // maze episode reset for a compacted list of worlds (include/grx_capi.h): one 64-thread workgroup per listed world
 extern "C" __global__ void __launch_bounds__(64)
 grx_maze_reset_kernel(grx_maze_reset_args a, int n_reset) {

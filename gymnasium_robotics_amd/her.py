@@ -71,9 +71,11 @@ class HerReplay:
         self._start_host = np.zeros(self.N, np.int64)          # host mirror of episode_start: decides without a device sync whether anything can be sampled
         self.rows, self.capacity, self.head, self.size = z(int(capacity), self.OW), int(capacity), 0, 0
         self.t = 0                                 # absolute index of the newest row
-        self._gen = torch.Generator(device=self.device)
-        self._gen.manual_seed(seed)
+        self._seed, self._calls = int(seed), 0     # counter-based index stream (grx_her_sample): see reseed()
         self._L = _native.lib()
+        # reset masks reach the device through pinned buffers: a copy from pageable memory would make the host wait for the step kernel (core.PinnedStager)
+        self._mask_pin = [dict(buf=torch.empty(self.N, dtype=torch.bool, pin_memory=True), event=None) for _ in range(4)]
+        self._mask_next, self._mask_dev = 0, torch.zeros(self.N, dtype=torch.bool, device=self.device)
 
     # ---------------------------------------------------------------- episode storage (device copies of what the step kernel wrote)
     def begin_episode(self, packed_rows: torch.Tensor):
@@ -94,7 +96,18 @@ class HerReplay:
         if reset_mask is not None:     # bool [N]: numpy / CPU tensor (what the envs return) or a device tensor
             host = reset_mask.cpu().numpy() if isinstance(reset_mask, torch.Tensor) else np.asarray(reset_mask)
             self._start_host[host.astype(bool)] = self.t
-            dev = reset_mask if isinstance(reset_mask, torch.Tensor) and reset_mask.device == self.device else torch.from_numpy(host.astype(bool)).to(self.device, non_blocking=True)
+            if isinstance(reset_mask, torch.Tensor) and reset_mask.device == self.device:
+                dev = reset_mask
+            else:
+                slot = self._mask_pin[self._mask_next]
+                self._mask_next = (self._mask_next + 1) % len(self._mask_pin)
+                if slot["event"] is not None:
+                    slot["event"].synchronize()
+                slot["buf"].numpy()[:] = host.astype(bool)
+                dev = self._mask_dev
+                dev.copy_(slot["buf"], non_blocking=True)
+                slot["event"] = torch.cuda.Event()
+                slot["event"].record(torch.cuda.current_stream(self.device))
             self.episode_start.masked_fill_(dev, self.t)
 
     def set_episode_start(self, starts):
@@ -103,24 +116,22 @@ class HerReplay:
         self.episode_start.copy_(torch.from_numpy(self._start_host.astype(np.int32)).to(self.device))
 
     # ---------------------------------------------------------------- sampling + the fused relabel kernel
+    def reseed(self, seed: int):
+        """restart the index stream: the same (seed, number of sample_indices calls since) reproduces the same draws"""
+        self._seed, self._calls = int(seed), 0
+
     def sample_indices(self, batch: int, k_future: int = 4):
         """(t, world, t_goal): a uniform world, a uniform transition of that world's current episode among the rows still in the ring; with
         probability k / (k + 1) the goal achieved at a uniformly drawn LATER row of the same episode (the "future" strategy of Andrychowicz et al.
-        2017), else -1 = keep the episode's goal.  Worlds whose episode has no transition yet (just reset) are not drawn."""
-        g, d = self._gen, self.device
+        2017), else -1 = keep the episode's goal.  Worlds whose episode has no transition yet (just reset) are not drawn.  One kernel
+        (grx_her_sample) with a counter-based generator; None when nothing can be sampled."""
         if not (np.maximum(self._start_host, max(self.t - self.T, 0)) < self.t).any():
             return None                                                                   # every world has just been reset: nothing to sample
-        lo_all = torch.clamp(self.episode_start, min=max(self.t - self.T, 0))             # first row of the episode that is still stored (rows start at 0)
-        has = (lo_all < self.t).to(torch.float32)                                         # worlds whose current episode has a transition already
-        w = torch.multinomial(has, batch, replacement=True, generator=g).to(torch.int32)  # uniform over those worlds (no host sync)
-        lo = lo_all[w.long()]
-        u = torch.rand(2, batch, device=d, generator=g)
-        t = lo + torch.clamp((u[0] * (self.t - lo).to(torch.float32)).to(torch.int32), max=self.t)       # floor(U * span) in [0, span)
-        t = torch.minimum(t, torch.full_like(t, self.t - 1))
-        fut = t + 1 + (u[1] * (self.t - t).to(torch.float32)).to(torch.int32)
-        fut = torch.minimum(fut, torch.full_like(fut, self.t))
-        keep = torch.rand(batch, device=d, generator=g) >= k_future / (k_future + 1.0)
-        return t, w, torch.where(keep, torch.full_like(fut, -1), fut)
+        t, w, tg = (torch.empty(batch, dtype=torch.int32, device=self.device) for _ in range(3))
+        _native.check(self._L.grx_her_sample(self.episode_start.data_ptr(), self.N, self.t, self.T, int(k_future), self._seed, self._calls, batch,
+                                             t.data_ptr(), w.data_ptr(), tg.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self._calls += 1
+        return t, w, tg
 
     def relabel_into(self, out: torch.Tensor, t: torch.Tensor, w: torch.Tensor, t_goal: torch.Tensor):
         """the kernel alone: out[b] <- relabelled transition (t[b], w[b], t_goal[b]); int32 index tensors on the device"""

@@ -249,6 +249,12 @@ typedef struct grx_her_args {
   float* out;                          /* [batch, 2 obs_dim + 3 goal_dim + act_dim + 2] */
 } grx_her_args;
 int grx_her_relabel(const grx_her_args* args, int64_t batch, void* stream);
+/* The index draws of HER's "future" strategy (Andrychowicz et al. 2017) for `batch` samples in one kernel: a uniform world among those whose current
+ * episode has a transition in the ring (rejection sampling on episode_start), a uniform transition t of it, and with probability k / (k + 1) a uniformly
+ * drawn LATER row of the same episode as the goal (t_goal), else -1.  t_now = absolute index of the newest row, T = ring length - 1.  Counter-based
+ * generator: the same (seed, call) pair reproduces the same draws.  All pointers are device pointers. */
+int grx_her_sample(const int* episode_start, int n_worlds, int t_now, int T, int k_future, uint64_t seed, uint64_t call, int64_t batch,
+                   int* t_idx, int* w_idx, int* t_goal, void* stream);
 
 /* Episode reset of a COMPACTED list of maze worlds (maze/point_maze.py:377-390 / ant_maze_v5.py reset_model, maze_v4.py:299-358: qpos = init_qpos with
  * xy <- the drawn reset position, qvel = 0, new goal, observation of the reset state): one kernel writes state, goal, obs / achieved / success and the

@@ -36,7 +36,7 @@ def test_relabelled_rows_match_numpy_her(env_id):
     env, buf = _rollout(env_id, 24, steps)
     rows = buf.relabel(batch=1024, k_future=4).clone()
     # the same draws again (the generator is seeded; re-create it to replay the index stream)
-    buf._gen.manual_seed(0)
+    buf.reseed(0)
     t, w, tg = (x.cpu().numpy().astype(np.int64) for x in buf.sample_indices(1024, 4))
     assert (tg < 0).any() and (tg >= 0).any() and np.all((tg < 0) | ((tg > t) & (tg <= steps)))
     ep, acts = buf.episode.cpu().numpy(), buf.actions.cpu().numpy()
@@ -110,7 +110,7 @@ def test_continuous_ring_respects_episode_boundaries():
         starts[done.numpy()] = t + 1
     assert np.array_equal(buf.episode_start.cpu().numpy(), starts)
     rows = buf.relabel(1024).clone()
-    buf._gen.manual_seed(3)
+    buf.reseed(3)
     t, w, tg = (x.cpu().numpy().astype(np.int64) for x in buf.sample_indices(1024, 4))
     lo = np.maximum(starts[w], steps - H)
     assert np.all(t >= lo) and np.all(t < steps) and np.all((tg < 0) | ((tg > t) & (tg <= steps)))
@@ -144,3 +144,37 @@ def test_nothing_to_sample_right_after_a_lockstep_reset():
         sizes.append(len(buf.relabel(32)))
     assert sizes == [32, 32, 0, 32, 32, 0, 32]
     torch.cuda.synchronize()
+
+
+def test_index_sampler_distribution():
+    """grx_her_sample: worlds uniform among those with a transition, transitions uniform inside the current episode, k / (k + 1) of the goals substituted"""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+    from gymnasium_robotics_amd.her import HerReplay
+
+    n, H = 64, 20
+    env = grx.make_vec("FetchReach-v4", num_envs=n, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None)
+    buf = HerReplay(env, horizon=H, capacity=256, seed=9, continuous=True)
+    env.reset(seed=0)
+    buf.begin_episode(env.packed)
+    for _ in range(12):
+        buf.append(torch.zeros(n, 4, device="cuda:0"), env.packed)
+    starts = np.zeros(n, np.int64); starts[:8] = 12; starts[8:16] = 7      # eight worlds just reset (nothing to sample), eight five rows into a new episode
+    buf.set_episode_start(starts)
+    B = 1 << 17
+    t, w, tg = (x.cpu().numpy().astype(np.int64) for x in buf.sample_indices(B, 4))
+    cnt = np.bincount(w, minlength=n)
+    assert (cnt[:8] == 0).all() and np.abs(cnt[8:] - B / 56).max() < 6 * np.sqrt(B / 56)
+    assert np.all(t >= starts[w]) and np.all(t < 12) and np.all((tg < 0) | ((tg > t) & (tg <= 12)))
+    old = w >= 16                                                           # episodes that began at row 0: t uniform on 0 .. 11
+    ct = np.bincount(t[old], minlength=12)
+    assert np.abs(ct - old.sum() / 12).max() < 6 * np.sqrt(old.sum() / 12)
+    assert abs((tg >= 0).mean() - 0.8) < 0.01
+    last = t == 11                                                          # the newest transition has one later row only
+    assert (tg[last & (tg >= 0)] == 12).all()
+    t2, w2, tg2 = (x.cpu().numpy() for x in buf.sample_indices(B, 4))       # the stream advances with every call and replays after reseed()
+    assert not np.array_equal(t2, t)
+    buf.reseed(9)
+    t3, w3, tg3 = (x.cpu().numpy() for x in buf.sample_indices(B, 4))
+    assert np.array_equal(t3, t) and np.array_equal(w3, w) and np.array_equal(tg3, tg)
