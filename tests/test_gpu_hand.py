@@ -121,3 +121,13 @@ def test_hand_shape_needs_the_compiled_dof_tree():
     finally:
         L.grx_model_destroy(h)
     env.close()
+
+
+@pytest.mark.parametrize("output", ["torch", "numpy"])
+def test_same_step_autoreset_matches_next_step(output):
+    """HandReach: same-step autoreset (pinned staging, masked forward launch) against the next-step path, bit-equal (tests/autoreset_cases.py)"""
+    import gymnasium_robotics_amd as grx
+    from autoreset_cases import check_same_step_against_next_step
+
+    make = lambda **kw: grx.make_vec("HandReach-v3", num_envs=40, device="cuda:0", **kw)
+    check_same_step_against_next_step(make, horizon=5, steps=12, act_dim=20, output=output)

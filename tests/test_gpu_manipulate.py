@@ -171,3 +171,15 @@ def test_serialize_deserialize_with_constructor_override(env_id):
     assert env1.task.ignore_position == 0
     with pytest.raises(ValueError, match="Unknown target_rotation"):
         grx.make_vec(env_id, num_envs=2, device="cuda:0", target_rotation="fixed")
+
+
+@pytest.mark.parametrize("env_id", ["HandManipulateBlockRotateXYZ-v1", "HandManipulateEggRotate_ContinuousTouchSensors-v1"])
+def test_same_step_autoreset_matches_next_step(env_id):
+    """The overlapped same-step reset (settle chains on side streams started two steps ahead, committed by grx_hand_commit_rows) against the sequential
+    next-step reset.  Same draws and the same ten settle steps; the chain's first solve starts from the warm start the world had when the chain was
+    started, so the settled state agrees to solver tolerance, not bit for bit (tests/autoreset_cases.py)."""
+    import gymnasium_robotics_amd as grx
+    from autoreset_cases import check_same_step_against_next_step
+
+    make = lambda **kw: grx.make_vec(env_id, num_envs=40, device="cuda:0", **kw)
+    check_same_step_against_next_step(make, horizon=5, steps=12, act_dim=20, tol=2e-4, tol_max=1e-2, outlier_rows=0.15, output="torch")
