@@ -47,7 +47,9 @@ static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; ret
 // sub-stage buckets 16.. (finer breakdown inside a stage; what remains goes to the stage's own bucket)
 #define GRX_SUBTICK(c, k) GRX_TICK(c, 16 + (k))
 #define GRX_TICK(c, id) do { if (lane_ == 0) { long long t_ = clock64(); (c)->prof[id] += t_ - (c)->prof_last[0]; (c)->prof_last[0] = t_; } } while (0)
+#define GRX_COUNT(c, k, n) do { if (lane_ == 0) (c)->prof[16 + (k)] += (n); } while (0)
 #else
+#define GRX_COUNT(c, k, n) ((void)0)
 #define GRX_TICK(c, id) ((void)0)
 #define GRX_SUBTICK(c, k) ((void)0)
 #endif
@@ -1158,7 +1160,11 @@ GRX_MEM void grx_geom_support(const float* R, const float* sz, int type, const f
 }
 struct GrxMprPair { float R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // the two frames are copied into registers: ~20 support evaluations each read them twice
                     const float *v1, *v2; int n1, n2, lane;                      // hull vertices (geom frame) of mesh geoms: only read by the wave-cooperative variant
-                    GrxMprPt* pts; };                                            // wave-cooperative variant: LDS storage of the five portal points (keeps them out of the VGPR budget)
+                    GrxMprPt* pts;
+#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+                    long long* prof;
+#endif
+                  };                                            // wave-cooperative variant: LDS storage of the five portal points (keeps them out of the VGPR budget)
 // Convex hull of a mesh: the hull vertex farthest along the (geom-frame) direction dl; the lowest vertex index wins ties, like the oracle's
 // exhaustive scan.  Called from wave-uniform code: on the GPU the 64 lanes share the scan (lane l takes the vertices l, l + 64, ...; the
 // loads are coalesced) and agree on the winner through two DPP reductions -- a hull of 500 vertices costs 8 loads per lane.
@@ -1170,16 +1176,28 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const float* dl, float* 
   float best = -3.0e38f; int bi = 0;
   for (int v = 0; v < n; v++) { const float t = verts[3 * v] * dl[0] + verts[3 * v + 1] * dl[1] + verts[3 * v + 2] * dl[2]; if (t > best) { best = t; bi = v; } }
 #else
-  float best = -3.0e38f; int mine = 0;
-  for (int v0 = lane_; v0 < n; v0 += 256) {   // four independent vertex fetches in flight per lane: one memory latency per 256 vertices
-    float x[4], y[4], z[4];
+#ifndef GRX_HULL_INFLIGHT
+#define GRX_HULL_INFLIGHT 4
+#endif
+  float best = -3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f; int mine = 0;
+  for (int v0 = lane_; v0 < n; v0 += 64 * GRX_HULL_INFLIGHT) {   // several independent vertex fetches in flight per lane: one memory latency per 64 * GRX_HULL_INFLIGHT vertices
+    float x[GRX_HULL_INFLIGHT], y[GRX_HULL_INFLIGHT], z[GRX_HULL_INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const int v = v0 + 64 * u < n ? v0 + 64 * u : n - 1; x[u] = verts[3 * v]; y[u] = verts[3 * v + 1]; z[u] = verts[3 * v + 2]; }
+    for (int u = 0; u < GRX_HULL_INFLIGHT; u++) { const int v = v0 + 64 * u < n ? v0 + 64 * u : n - 1; x[u] = verts[3 * v]; y[u] = verts[3 * v + 1]; z[u] = verts[3 * v + 2]; }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const float t = x[u] * dl[0] + y[u] * dl[1] + z[u] * dl[2]; if (v0 + 64 * u < n && t > best) { best = t; mine = v0 + 64 * u; } }
+    for (int u = 0; u < GRX_HULL_INFLIGHT; u++) {
+      const float t = x[u] * dl[0] + y[u] * dl[1] + z[u] * dl[2];
+      if (v0 + 64 * u < n && t > best) { best = t; mine = v0 + 64 * u; bx = x[u]; by = y[u]; bz = z[u]; }
+    }
   }
   const float mx = grx_reduce_max(best);
   const int bi = (int)(-grx_reduce_max((best == mx) ? -(float)mine : -3.0e38f));   // vertex indices are far below 2^24: exact in fp32
+  {   // the winner's coordinates are in the registers of the lane that scanned it: no second trip to memory
+    const unsigned long long own = __ballot(best == mx && mine == bi);
+    const int src = own ? __builtin_ctzll(own) : 0;
+    r[0] = grx_readlane_f(bx, src); r[1] = grx_readlane_f(by, src); r[2] = grx_readlane_f(bz, src);
+    return bi;
+  }
 #endif
   r[0] = verts[3 * bi]; r[1] = verts[3 * bi + 1]; r[2] = verts[3 * bi + 2];
   return bi;
@@ -1208,10 +1226,19 @@ GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const float
 template <bool W>
 GRX_MEM void grx_mpr_support(const GrxMprPair* q, const float* d, GrxMprPt* o) {
   float nd[3] = {-d[0], -d[1], -d[2]}, b[3];
+#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+  if (W && q->lane == 0) { q->prof[16 + 26] += 1; q->prof[16 + 27] += (q->t1 == 7 ? q->n1 : 0) + (q->t2 == 7 ? q->n2 : 0); }
+#endif
+#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+  const long long tp0_ = clock64();
+#endif
   if (W && q->t1 == 7) { float dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); grx_mesh_support(q->v1, q->n1, dl, r, q->lane); mulMatVec3f(o->w, q->R1, r); }
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
   if (W && q->t2 == 7) { float dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); grx_mesh_support(q->v2, q->n2, dl, r, q->lane); mulMatVec3f(b, q->R2, r); }
   else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
+#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+  if (W && q->lane == 0) q->prof[16 + 28] += clock64() - tp0_;
+#endif
   for (int k = 0; k < 3; k++) { o->w[k] += d[k] * q->hm; o->v[k] = o->w[k] - (b[k] + q->c21[k] - d[k] * q->hm); }
 }
 // the portal is kept as four separate points (not an array): every access is to a named variable, so the 30 floats stay in registers
@@ -1269,8 +1296,13 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
 #define GRX_MPR_SEP(D) do { if (W && sep) { sep[0] = (D)[0]; sep[1] = (D)[1]; sep[2] = (D)[2]; sep[3] = 1.0f; } } while (0)
   // lane-per-pair variant: the portal lives in registers; wave-cooperative variant: in LDS (every lane writes the same values)
   GrxMprPt r0_, r1_, r2_, r3_, r4_;
-  GrxMprPt& P0 = W ? q->pts[0] : r0_; GrxMprPt& P1 = W ? q->pts[1] : r1_; GrxMprPt& P2 = W ? q->pts[2] : r2_; GrxMprPt& P3 = W ? q->pts[3] : r3_;
-  GrxMprPt& v4 = W ? q->pts[4] : r4_;
+#ifdef GRX_MPR_PORTAL_REGS
+  constexpr bool kLds = false;
+#else
+  constexpr bool kLds = W;
+#endif
+  GrxMprPt& P0 = kLds ? q->pts[0] : r0_; GrxMprPt& P1 = kLds ? q->pts[1] : r1_; GrxMprPt& P2 = kLds ? q->pts[2] : r2_; GrxMprPt& P3 = kLds ? q->pts[3] : r3_;
+  GrxMprPt& v4 = kLds ? q->pts[4] : r4_;
   float d[3], a[3], b[3], dotv;
   for (int k = 0; k < 3; k++) { P0.w[k] = 0.0f; P0.v[k] = -q->c21[k]; }
   if (grx_mpr_eq(P0.v[0], 0.0f) && grx_mpr_eq(P0.v[1], 0.0f) && grx_mpr_eq(P0.v[2], 0.0f)) P0.v[0] += GRX_MPR_EPS * 10.0f;
@@ -1323,6 +1355,9 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
   for (int it = 0;; it++) {
     grx_mpr_portal_dir(P1, P2, P3, d);
     grx_mpr_support<W>(q, d, &v4);
+#if defined(GRX_EMU) && defined(GRX_MPR_STATS)
+    if (W) { g_grx_mesh_stats[2]++; if (it > maxit) g_grx_mesh_stats[3]++; }
+#endif
     if (grx_mpr_reach_tolerance(P1, P2, P3, v4, d, tol) || it > maxit) {
       float w[3];
       *depth = sqrtf(grx_mpr_tri_dist2(P1.v, P2.v, P3.v, w));
@@ -1465,7 +1500,12 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = c->gxpos[3 * g2 + k] - c->gxpos[3 * g1 + k]; }
     q.v1 = q.t1 == 7 ? m->mesh_vert + 3 * m->geom_hulladr[g1] : m->mesh_vert; q.n1 = q.t1 == 7 ? m->geom_hullnum[g1] : 0;
     q.v2 = q.t2 == 7 ? m->mesh_vert + 3 * m->geom_hulladr[g2] : m->mesh_vert; q.n2 = q.t2 == 7 ? m->geom_hullnum[g2] : 0;
-    q.pts = (GrxMprPt*)(c->Jp + 192);   // 30 words behind the pair queue: the Jacobian pool is free until the constraint stage
+    q.pts = (GrxMprPt*)(c->Jp + 192);
+#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+    q.prof = c->prof;
+#endif   // 30 words behind the pair queue: the Jacobian pool is free until the constraint stage
+    GRX_SUBTICK(c, 21);   // pair set-up
+    GRX_COUNT(c, 24, 1);
     // a direction kept from an earlier substep: still separating?  (entry: pair + 1, direction, (v1 + 1) + 4096 (v2 + 1) = the support vertices)
     float* mc = c->meshcache;
     const float key = (float)(pair + 1);
@@ -1486,14 +1526,18 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
 #if defined(GRX_EMU)
         g_grx_mesh_stats[0]++;
 #endif
+        GRX_SUBTICK(c, 22);   // cached separating direction re-checked: disjoint
         continue;
       }
     }
+    GRX_SUBTICK(c, 22);
+    GRX_COUNT(c, 25, 1);
 #if defined(GRX_EMU)
     g_grx_mesh_stats[1]++;
 #endif
     float depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
+    GRX_SUBTICK(c, 23);   // portal search
 #if defined(GRX_EMU) && defined(GRX_MESH_DEBUG)
     fprintf(stderr, "meshpair %d (g %d %d) slot %d rc %d sep %g\n", pair, g1, g2, slot, rc, (double)sep[3]);
 #endif

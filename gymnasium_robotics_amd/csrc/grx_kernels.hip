@@ -92,6 +92,9 @@ extern "C" int grx_profile_read(long long* out) { return (int)hipMemcpyFromSymbo
 extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grx_prof), z, sizeof(z)); }
 // per-world start / end timestamps of the last Fetch step launch (wall_clock64: one clock for the whole device): load balance across worlds
 __device__ long long g_grx_world_span[2 * 16384];
+// per-world stage cycles of the last Fetch step launch (first 4096 worlds): which stages make a slow world slow (tools/straggler_probe.py)
+__device__ int g_grx_world_prof[4096 * GRX_NPROF];
+extern "C" int grx_profile_world_stages(int* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grx_world_prof), sizeof(int) * GRX_NPROF * n); }
 extern "C" int grx_profile_world_spans(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grx_world_span), sizeof(long long) * 2 * n); }
 #endif
 
@@ -185,6 +188,7 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   GRX_TICK(&c, GRX_P_OTHER);
   if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);  // summed over worlds
   if (lane_ == 0 && w < 16384) g_grx_world_span[2 * w + 1] = wall_clock64();
+  if (lane_ == 0 && w < 4096) for (int k = 0; k < GRX_NPROF; k++) g_grx_world_prof[w * GRX_NPROF + k] = (int)c.prof[k];
 #endif
 }
 

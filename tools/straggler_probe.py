@@ -1,0 +1,37 @@
+"""Which stages make a slow FetchPickAndPlace world slow: per-world stage cycles of one step launch (profiling build: sh tools/build_prof.sh fetch).
+    python tools/straggler_probe.py > profiles/stragglers_r02_fetch.txt"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from gymnasium_robotics_amd import _native, make_vec
+_native.LIB_PATH = os.path.join(ROOT, "gymnasium_robotics_amd", "_lib", "libgrx_hip_prof.so")
+NP, n = 48, 4096
+env = make_vec("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step")
+env.reset(seed=0); env._elapsed[:] = np.arange(n) % 50
+g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+for k in range(40):
+    env.step(torch.rand(n, 4, device="cuda:0", generator=g) * 2 - 1)
+torch.cuda.synchronize()
+L = _native.lib()
+buf = (ctypes.c_int * (NP * n))()
+L.grx_profile_world_stages.argtypes = [ctypes.c_void_p, ctypes.c_int]
+L.grx_profile_world_stages(buf, n)
+P = np.array(list(buf), dtype=np.float64).reshape(n, NP)
+tot = P.sum(axis=1)
+names = ["kinematics", "inertia", "collision", "constraint", "velocity", "M solve", "newton eval", "newton grad", "newton hessian", "newton factor", "newton linesearch", "newton final", "euler", "other"]
+SUB = {0: "constraint: count", 1: "constraint: scan", 2: "constraint: equality rows", 3: "constraint: friction/limit rows", 4: "constraint: row params", 5: "constraint: contact J",
+       6: "velocity: rne a", 7: "velocity: rne b", 8: "velocity: passive/actuation", 9: "kinematics: bodies", 10: "kinematics: sites/frames", 11: "collision: box-box queue",
+       12: "collision: geom frames", 13: "collision: narrow phase rounds", 14: "inertia: cinert/cdof", 15: "inertia: crb/M", 16: "collision: hull pairs", 19: "collision: candidate sweep", 20: "collision: regroup", 21: "hull pairs: set-up", 22: "hull pairs: cached direction check", 23: "hull pairs: portal search",
+       24: "COUNT hull pairs queued", 25: "COUNT portal searches", 26: "COUNT support evaluations in portal searches", 27: "COUNT hull vertices scanned by them", 28: "(inside portal search) cycles in the two support scans"}
+label = {k: v for k, v in enumerate(names)}
+label.update({16 + k: v for k, v in SUB.items()})
+slow = np.argsort(-tot)[:40]
+typ = np.argsort(tot)[n // 2 - 200: n // 2 + 200]
+print(f"cycles per env.step: median world {np.median(tot):.0f}, slowest 40 worlds mean {tot[slow].mean():.0f} (x{tot[slow].mean() / np.median(tot):.2f})")
+print(f"{'stage':34s} {'typical world':>14s} {'slowest 40':>12s} {'difference':>12s}")
+rows = sorted(label, key=lambda k: -(P[slow, k].mean() - P[typ, k].mean()))
+for k in rows:
+    a, b = P[typ, k].mean(), P[slow, k].mean()
+    if a > 0 or b > 0:
+        print(f"{label[k]:34s} {a:14.0f} {b:12.0f} {b - a:12.0f}")
