@@ -70,7 +70,7 @@ def make_env(workload, n, device, rank):
         from gymnasium_robotics_amd.envs.adroit import AdroitVecEnv as Env
     else:
         from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv as Env
-    if os.environ.get("GRX_BENCH_BALANCE") and (workload.startswith("hand") or workload == "antmaze"):    # A/B switch of the cost-ordered dispatch for the hand families (off by default there)
+    if os.environ.get("GRX_BENCH_BALANCE") and workload.startswith("hand"):    # A/B switch of the cost-ordered dispatch for the hand families (off by default there)
         kw["balance"] = os.environ["GRX_BENCH_BALANCE"] == "1"
     return Env(w["env_id"], **kw)
 

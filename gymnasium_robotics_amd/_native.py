@@ -28,7 +28,7 @@ class PointTaskStruct(ctypes.Structure):
 
 class PointBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask", "packed", "order", "cost")]
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask", "packed")]
 
 
 class AdroitTaskStruct(ctypes.Structure):

@@ -268,10 +268,9 @@ template <class S>
 __global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
 grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
-  const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
+  const int w = grx_world_of_block(), lane_ = threadIdx.x;
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
-  if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp, parked in the cost slot (see grx_fetch_step_kernel)
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -287,7 +286,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
   for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
   __syncthreads();
   GrxPoint<S>::grx_point_sim_world(&m, &t, &c, b.action + (size_t)w * m.nu, lane_);
-  const int wl = b.order ? b.order[grx_block_late()] : grx_world_of_block_late();
+  const int wl = grx_world_of_block_late();
   float* obs = b.obs + (size_t)wl * (m.nq + m.nv - (t.agent ? 2 : 0)); float* ach = b.achieved + (size_t)wl * 2;
   GrxPoint<S>::grx_point_outputs(&m, &t, &c, obs, ach, lane_);
   __syncthreads();
@@ -299,7 +298,6 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
     b.reward[wl] = grx_maze_reward(d, t.goal_radius, t.sparse_reward);
     b.success[wl] = succ; b.terminated[wl] = (!t.continuing_task && succ) ? 1 : 0;
     b.status[wl] = grx_status_word(b.status[wl], c.cnt[2]);
-    if (b.cost) { const int t0 = ((volatile int*)b.cost)[wl]; b.cost[wl] = ((int)wall_clock64() - t0) >> 3; }
   }
   if (b.packed) {   // [obs | achieved | desired | reward | success] row for the cross-rank gather
     const int od = m.nq + m.nv - (t.agent ? 2 : 0);

@@ -27,8 +27,6 @@ struct GrxPointBuffers {
   int* status;                   // [N]
   const unsigned char* mask;     // [N] or null
   float* packed;                 // [N, obs_dim + 2 + 2 + 2] or null: out, the row [obs | achieved | desired | reward | success]
-  const int* order;              // [N] or null: workgroup b steps world order[b] (cost-ordered dispatch)
-  int* cost;                     // [N] or null: out, measured duration of the world in this launch
 };
 
 GRX_DEV float grx_goal_distance2(const float* a, const float* b) {

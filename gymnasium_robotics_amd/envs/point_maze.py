@@ -52,8 +52,7 @@ class PointMazeVecEnv(GoalVecEnv):
     def __init__(self, env_id: Optional[str] = "PointMaze_UMaze-v3", num_envs: int = 1, device: Optional[str] = None, maze_map=None,
                  reward_type: Optional[str] = None, continuing_task: bool = True, reset_target: bool = False,
                  position_noise_range: float = 0.25, max_episode_steps: Optional[int] = -1, autoreset_mode: str = "next_step",
-                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0,
-                 balance: bool = False):
+                 output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None, seed_offset: int = 0):
         layout, rt, mes = (None, "sparse", self.DEFAULT_MAX_EPISODE_STEPS)
         if maze_map is None:
             layout, rt, mes = self._parse_id(env_id)
@@ -84,15 +83,6 @@ class PointMazeVecEnv(GoalVecEnv):
         self.success, self.terminated = z(n, dtype=torch.uint8), z(n, dtype=torch.uint8)
         self.status, self.mask = z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
         self.packed = z(n, self.obs_dim + 6)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather)
-        # cost-ordered dispatch (see FetchVecEnv._alloc): the worlds that took longest in the last launch start first; results do not depend on it.
-        # Off by default: measured neutral to -1 % for the ant (8 192 worlds are 3.2 per wave slot and their durations vary little)
-        self.balance = bool(balance) and n % 8 == 0 and 1024 <= n <= 65536 * 8
-        self.cost = z(n, dtype=torch.int32) if self.balance else None
-        self.cost_ema = z(n) if self.balance else None
-        self.order = None
-        if self.balance:
-            per = n // 8
-            self.order = (torch.arange(8, device=d, dtype=torch.int32).unsqueeze(1) * per + torch.arange(per, device=d, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
         # reset staging (see _reset_worlds): pinned host rows [start xy | goal xy] + world indices, their device mirrors, the kernel's argument block
         self._stage_host, self._idx_host = torch.empty(n, 4, dtype=torch.float32, pin_memory=True), torch.empty(n, dtype=torch.int32, pin_memory=True)
@@ -122,8 +112,6 @@ class PointMazeVecEnv(GoalVecEnv):
         for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "packed"):
             setattr(b, name, getattr(self, name).data_ptr())
         b.mask = None if mask is None else mask.data_ptr()
-        b.order = None if self.order is None else self.order.data_ptr()
-        b.cost = None if self.cost is None else self.cost.data_ptr()
         return b
 
     def _stream(self):
@@ -192,8 +180,6 @@ class PointMazeVecEnv(GoalVecEnv):
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
-            if self.balance:
-                _native.check(self._L.grx_order_by_cost(self.cost.data_ptr(), self.cost_ema.data_ptr(), 0.1, self.num_envs, self.order.data_ptr(), self._stream()))
             stepped = ~self._needs_reset
             self._elapsed[stepped] += 1
             terminated = self.terminated.cpu().numpy().astype(bool) & stepped if not self.continuing_task else np.zeros(self.num_envs, bool)

@@ -91,8 +91,6 @@ typedef struct grx_point_buffers {
   int* status;                  /* [N] */
   const unsigned char* mask;    /* [N] or NULL */
   float* packed;                /* [N, obs_dim+2+2+2] or NULL: [obs | achieved | desired | reward | success] (see grx_fetch_buffers.packed) */
-  const int* order;             /* [N] or NULL: workgroup b steps world order[b] (cost-ordered dispatch, see grx_fetch_buffers.order / grx_order_by_cost) */
-  int* cost;                    /* [N] or NULL: out, measured duration of every world in this launch (80 ns units) */
 } grx_point_buffers;
 
 /* mirrors struct GrxHandTask / GrxHandBuffers (csrc/grx_hand_task.h): Shadow Dexterous Hand reach task */
