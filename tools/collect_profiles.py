@@ -2,7 +2,7 @@
 
     python tools/collect_profiles.py <tag>
 
-1. `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 30 --warmup 5 --no-cpu-baseline`
+1. `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 100 --warmup 10 --no-cpu-baseline` (bench.py's defaults)
    -> gpurun_out/rocprof_<tag>_kernel_stats.txt (per-kernel totals / averages from the top_kernels view)
 2. two separate `rocprofv3 --pmc <C> --kernel-trace --output-format csv` passes (C = FETCH_SIZE, WRITE_SIZE; counters are
    collected in their own runs, without any other trace domain) of the same command with fewer steps
@@ -40,10 +40,10 @@ def kernel_stats(tag, workload=None):
     d = os.path.join(OUT, f"rocprof_{tag}{suffix}")
     extra = ["--workload", workload] if workload else []
     cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-           "--steps", "30", "--warmup", "5", "--no-cpu-baseline"] + extra
+           "--steps", "100", "--warmup", "10", "--no-cpu-baseline"] + extra     # bench.py's own defaults: the averages are over the same launches
     run(cmd, os.path.join(OUT, f"rocprof_{tag}{suffix}.log"))
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
-    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline {' '.join(extra)}  (MI355X, build '{tag}')",
+    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline {' '.join(extra)}  (MI355X, build '{tag}')",
              "source: top_kernels view of the rocprofv3 results database; durations in us",
              "name | total_calls | total_duration_us | average_us | percentage"]
     if dbs:
@@ -140,6 +140,10 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[2] == "sq":
         sq_mix(tag)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "stats":          # kernel stats only: fetch (name it "fetch") and / or other workloads
+        for w in sys.argv[3:]:
+            kernel_stats(tag, None if w == "fetch" else w)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "workloads":      # kernel stats + HBM traffic of the other BASELINE configs
         for w in (sys.argv[3:] or ["antmaze", "hand_touch", "adroit", "hand_reach"]):
