@@ -3114,6 +3114,8 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   const int implicit_damp = (m->anydamp && m->eulerdamp);
   int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0, g0_ready = 0;
+  GRX_COUNT(c, 30, 1);     // profiling build: constrained solves (substeps) of the step
+  GRX_COUNT(c, 31, nefc);  // ... and their constraint rows
   // the linear solve leaves c->A intact where it runs from registers (grx_sym_solve_full): the Hessian can then be corrected in place
   const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 29 || nv == 30 || nv == 33 || nv == 36);
   // Newton starts from the previous solution (qacc_warmstart).  MuJoCo starts from the cheaper of (warmstart,
@@ -3295,6 +3297,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       WAVE_SYNC();
       const float stepmax = grx_reduce_max(msp), qmax = grx_reduce_max(map_);
       LANE0 { c->cnt[6] += 1; }
+      GRX_COUNT(c, 29, 1);   // profiling build: Newton iterations of the step
 #ifdef GRX_LS_STATS
       { extern int g_ls_iters, g_ls_full; g_ls_iters++; g_ls_full += full_step; }
 #endif

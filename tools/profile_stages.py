@@ -52,7 +52,8 @@ for nm, v in zip(names, tot):
 SUB = {0: "constraint: count", 1: "constraint: scan", 2: "constraint: equality rows", 3: "constraint: friction/limit rows", 4: "constraint: row params", 5: "constraint: contact J",
        6: "velocity: rne a", 7: "velocity: rne b", 8: "velocity: passive/actuation", 9: "kinematics: bodies", 10: "kinematics: sites/frames", 11: "collision: box-box queue",
        12: "collision: geom frames", 13: "collision: narrow phase rounds", 14: "inertia: cinert/cdof", 15: "inertia: crb/M", 16: "collision: hull pairs", 17: "solver aux a", 18: "solver aux b",
-       19: "collision: candidate sweep", 20: "collision: survivor regroup"}
+       19: "collision: candidate sweep", 20: "collision: survivor regroup", 21: "hull pairs: set-up", 22: "hull pairs: cached direction check", 23: "hull pairs: portal search",
+       24: "COUNT hull pairs queued", 25: "COUNT portal searches", 26: "COUNT support evaluations", 27: "COUNT hull vertices scanned", 29: "COUNT Newton iterations", 30: "COUNT constrained solves", 31: "COUNT constraint rows (sum over solves)"}
 for k in range(16, NP):
     if tot[k] > 0:
         print(f"  sub[{k-16:2d}] {SUB.get(k - 16, ''):32s} {tot[k]:12.0f}  {100*tot[k]/s:5.1f}%")
