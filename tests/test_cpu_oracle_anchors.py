@@ -388,3 +388,57 @@ def test_anchor_21_joint_equality_couples_two_hinges():
     s.step(6000)
     assert np.abs(s.qvel).max() < 1e-7
     assert abs(s.qpos[0] - 0.6) < 1e-6 and abs(s.qpos[0] - a * s.qpos[1]) < 1e-7
+
+
+def _write_cube_stl(path, half):
+    """binary STL of an axis-aligned cube with the given half sizes (12 triangles)"""
+    import struct
+
+    hx, hy, hz = half
+    v = np.array([[sx * hx, sy * hy, sz * hz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = [t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))]
+    with open(path, "wb") as f:
+        f.write(b"\0" * 80 + struct.pack("<I", len(tris)))
+        for t in tris:
+            f.write(struct.pack("<3f", 0, 0, 0) + b"".join(struct.pack("<3f", *v[k]) for k in t) + b"\0\0")
+
+
+@pytest.mark.parametrize("support", ["box", "mesh"])
+def test_anchor_22_hull_contact_geometry(support):
+    """The hull-vs-convex narrow phase (portal refinement over the mesh's convex hull: Fetch links, kitchen fixtures) against elementary geometry.  A 10 cm
+    cube given as a MESH is placed into a static slab (a box primitive, or a second mesh) with a prescribed overlap: the routine must return ONE contact whose
+    distance is minus the overlap and whose normal is the slab's face normal -- face on face (any yaw, any lateral offset) and edge on face (cube rolled by
+    45 degrees: the overlap is that of its lowest edge).  Breaks for a depth measured along the centre ray instead of the normal, a hull that is not the mesh's
+    convex hull, or a geom frame that is not the hull's centre of mass.  (A settle test is not possible here: on ONE contact point a cube rocks for ever, in
+    MuJoCo as well -- which is why the force balance is pinned by the primitive anchors above and only the geometry here.)"""
+    with tempfile.TemporaryDirectory() as d:
+        _write_cube_stl(os.path.join(d, "cube.stl"), (0.05, 0.05, 0.05))
+        _write_cube_stl(os.path.join(d, "slab.stl"), (0.3, 0.3, 0.05))
+        slab = '<geom name="slab" type="box" size="0.3 0.3 0.05" pos="0 0 0.05" condim="1"/>' if support == "box" else \
+               '<geom name="slab" type="mesh" mesh="slab" pos="0 0 0.05" condim="1"/>'
+        xml = f"""<mujoco><option timestep="0.001"/><asset><mesh name="cube" file="cube.stl"/><mesh name="slab" file="slab.stl"/></asset><worldbody>
+        {slab}
+        <body pos="0 0 0.15"><freejoint/><geom name="cube" type="mesh" mesh="cube" mass="0.7" condim="1"/></body>
+        </worldbody></mujoco>"""
+        p = os.path.join(d, "m.xml")
+        with open(p, "w") as f:
+            f.write(xml)
+        m = compile_mjcf(p)
+    s = OracleSim(m)
+    for overlap in (1e-4, 1e-3, 5e-3):
+        for (x, y, yaw) in ((0.0, 0.0, 0.0), (0.013, -0.021, 0.0), (-0.05, 0.08, 0.6)):
+            s.qpos[:] = [x, y, 0.15 - overlap, np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+            s.qvel[:] = 0
+            s.forward()
+            con = s.contacts()
+            assert s.ncon == 1, (overlap, x, y, yaw, s.ncon)
+            assert abs(-con[0, 0] / overlap - 1) < 2e-3 and abs(con[0, 0] + overlap) < 2e-6, (overlap, con[0, 0])      # mpr_tolerance 1e-6 on the portal distance
+            assert abs(abs(con[0, 6]) - 1) < 1e-6 and np.abs(con[0, 4:6]).max() < 1e-3                                 # normal = the face normal
+            assert abs(con[0, 1] - x) < 0.0501 + 1e-6 and abs(con[0, 2] - y) < 0.0501 + 1e-6 and abs(con[0, 3] - (0.1 - 0.5 * overlap)) < 1e-5   # a point of the overlap polygon, mid-way between the faces
+        # edge on face: rolled by 45 degrees about x, the lowest edge is sqrt(2) * 0.05 below the centre
+        h = np.sqrt(2.0) * 0.05
+        s.qpos[:] = [0.01, 0.0, 0.1 + h - overlap, np.cos(np.pi / 8), np.sin(np.pi / 8), 0, 0]
+        s.forward()
+        con = s.contacts()
+        assert s.ncon == 1 and abs(con[0, 0] + overlap) < 2e-6 and abs(abs(con[0, 6]) - 1) < 1e-5 and abs(con[0, 2]) < 1e-5, (overlap, con[0, :8])
