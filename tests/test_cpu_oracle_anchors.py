@@ -512,19 +512,22 @@ def test_anchor_22_hull_contact_geometry(support):
         assert s.ncon == 1 and abs(con[0, 0] + overlap) < 2e-6 and abs(abs(con[0, 6]) - 1) < 1e-5 and abs(con[0, 2]) < 1e-5, (overlap, con[0, :8])
 
 
+@pytest.mark.parametrize("ground", ["plane", "box"])
 @pytest.mark.parametrize("shape,ncon,z0", [('type="box" size="0.1 0.07 0.05"', 4, 0.05), ('type="capsule" size="0.04 0.12" euler="0 90 0"', 2, 0.04)])
-def test_anchor_23_weight_splits_evenly_over_the_contacts_of_a_resting_primitive(shape, ncon, z0):
+def test_anchor_23_weight_splits_evenly_over_the_contacts_of_a_resting_primitive(shape, ncon, z0, ground):
     """A box lying on a plane has four corner contacts, a capsule lying on its side two (its cap centres): the analytic plane routines of the Fetch / hand /
     Adroit scenes.  By symmetry each contact carries m g / ncon on its four pyramid rows, so the rest depth solves
     [2 ncon / (mu^2 (1 + mu^2))] d^2/(1-d) k r = g (anchor 02 with ncon times the rows).  Breaks for a missing / duplicated contact, a contact at the wrong
     place (the body would tilt: checked), or a regulariser that depends on where on the body the contact sits."""
     mu = 0.8
+    g = f'<geom type="plane" size="1 1 0.1" condim="3" friction="{mu} 0.005 0.0001"/>' if ground == "plane" else \
+        f'<geom type="box" size="0.5 0.4 0.1" pos="0 0 -0.1" condim="3" friction="{mu} 0.005 0.0001"/>'      # a static slab: the box-box / capsule-box routines instead of the plane ones
     xml = f"""<mujoco><option timestep="0.001"/><worldbody>
-    <geom type="plane" size="1 1 0.1" condim="3" friction="{mu} 0.005 0.0001"/>
+    {g}
     <body pos="0 0 {z0}"><freejoint/><geom {shape} mass="1.1" condim="3" friction="{mu} 0.005 0.0001"/></body></worldbody></mujoco>"""
     s = OracleSim(_compile(xml))
     _settle(s, 6000)
-    assert s.ncon == ncon and s.nefc == 4 * ncon
+    assert s.ncon == ncon and s.nefc == 4 * ncon, (s.ncon, s.nefc)
     assert abs((z0 - s.qpos[2]) / rest_depth(2.0 * ncon / (mu * mu * (1 + mu * mu))) - 1) < 1e-7
     assert np.abs(s.qpos[:2]).max() < 1e-5 and abs(abs(s.qpos[3]) - 1) < 1e-10            # no drift beyond the settling transient, no tilt
     d = s.contacts()[:, 0]
