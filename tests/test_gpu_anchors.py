@@ -1,0 +1,90 @@
+"""The closed-form anchors of tests/test_cpu_oracle_anchors.py on the GPU build, through the C ABI (pytest -m gpu): grx_point_step is a generic free-running
+stepper (any compiled model, ctrl = action, observation = qpos | qvel), so the HIP kernels themselves -- generic shape, fp32 -- have to settle on the analytic
+rest depths, contact counts and creep speeds.  No oracle, no fixture: the expected numbers follow from MuJoCo's documented constraint model alone."""
+import ctypes
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from test_cpu_oracle_anchors import G, SPHERE, impedance, rest_depth
+
+pytestmark = pytest.mark.gpu
+
+
+def _settle_on_gpu(xml, steps, n=32):
+    import torch
+
+    from gymnasium_robotics_amd import _native
+    from gymnasium_robotics_amd.mjcf import compile_mjcf
+
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "m.xml")
+        with open(p, "w") as f:
+            f.write(xml)
+        m = compile_mjcf(p)
+    L = _native.lib()
+    H, I, F = m.pack()
+    h = ctypes.c_void_p()
+    _native.check(L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, 0, ctypes.byref(h)))
+    try:
+        nq, nv = m.dim("nq"), m.dim("nv")
+        dev = torch.device("cuda:0")
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)
+        bufs = dict(qpos=torch.from_numpy(np.tile(m.tables["qpos0"].astype(np.float32), (n, 1))).to(dev), qvel=z(n, nv), qacc_ws=z(n, nv), goal=z(n, 2), action=z(n, max(m.dim("nu"), 1)),
+                    obs=z(n, nq + nv), achieved=z(n, 2), reward=z(n), success=z(n, dtype=torch.uint8), terminated=z(n, dtype=torch.uint8), status=z(n, dtype=torch.int32))
+        b = _native.PointBuffersStruct()
+        for k, t in bufs.items():
+            setattr(b, k, t.data_ptr())
+        b.mask = b.packed = None
+        per_call = 250
+        task = _native.PointTaskStruct(per_call, 1, 1, 1, 0.45, 5.0)     # agent = 1: ctrl = action, no velocity clip; 250 raw physics steps per launch
+        for _ in range(steps // per_call):
+            _native.check(L.grx_point_step(h, ctypes.byref(task), ctypes.byref(b), n, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        torch.cuda.synchronize()
+        qpos, qvel, status = bufs["qpos"].cpu().numpy().astype(np.float64), bufs["qvel"].cpu().numpy().astype(np.float64), bufs["status"].cpu().numpy()
+    finally:
+        L.grx_model_destroy(h)
+    assert (status & 0xFFFF == 0).all() and np.isfinite(qpos).all()
+    assert np.array_equal(qpos, np.tile(qpos[:1], (n, 1))), "identical worlds must stay identical"
+    return qpos[0], qvel[0]
+
+
+@pytest.mark.parametrize("cd,mu,factor", [(1, 1.0, 1.0), (3, 0.7, 2.0 / (0.49 * 1.49)), (3, 1.0, 1.0)])
+def test_gpu_sphere_rest_depth(cd, mu, factor):
+    qpos, qvel = _settle_on_gpu(SPHERE.format(cd=cd, mu=mu, spin=0.005, mass=1.3), 4000)
+    assert np.abs(qvel).max() < 3e-5 and abs((0.1 - qpos[2]) / rest_depth(factor) - 1) < 2e-3
+
+
+@pytest.mark.parametrize("ground", ["plane", "box"])
+@pytest.mark.parametrize("shape,ncon,z0", [('type="box" size="0.1 0.07 0.05"', 4, 0.05), ('type="capsule" size="0.04 0.12" euler="0 90 0"', 2, 0.04)])
+def test_gpu_multi_contact_rest_depth(shape, ncon, z0, ground):
+    mu = 0.8
+    g = f'<geom type="plane" size="1 1 0.1" condim="3" friction="{mu} 0.005 0.0001"/>' if ground == "plane" else \
+        f'<geom type="box" size="0.5 0.4 0.1" pos="0 0 -0.1" condim="3" friction="{mu} 0.005 0.0001"/>'
+    qpos, qvel = _settle_on_gpu(f"""<mujoco><option timestep="0.001"/><worldbody>{g}
+    <body pos="0 0 {z0}"><freejoint/><geom {shape} mass="1.1" condim="3" friction="{mu} 0.005 0.0001"/></body></worldbody></mujoco>""", 6000)
+    assert np.abs(qvel).max() < 3e-5
+    assert abs((z0 - qpos[2]) / rest_depth(2.0 * ncon / (mu * mu * (1 + mu * mu))) - 1) < 3e-3          # the weight is split over ncon contacts of four rows each
+    assert np.abs(qpos[:2]).max() < 1e-4 and abs(abs(qpos[3]) - 1) < 1e-6
+
+
+@pytest.mark.parametrize("mu", [0.5, 1.0])
+def test_gpu_friction_creep_and_noslip(mu):
+    th = 0.15
+    xml = """<mujoco><option timestep="0.001" gravity="{gx} 0 {gz}" noslip_iterations="{ns}" noslip_tolerance="1e-9"/><worldbody>
+    <geom type="plane" size="2 2 0.1" condim="3" friction="{mu} 0.005 0.0001"/>
+    <body pos="0 0 0.1"><joint type="slide" axis="1 0 0"/><joint type="slide" axis="0 1 0"/><joint type="slide" axis="0 0 1"/>
+    <geom type="sphere" size="0.1" mass="0.8" condim="3" friction="{mu} 0.005 0.0001"/></body></worldbody></mujoco>"""
+    r0 = rest_depth(2.0 / (mu * mu * (1 + mu * mu)) / np.cos(th))
+    d = impedance(r0)
+    v_creep = G * np.sin(th) * (1 - d) * (1 + mu * mu) * 0.95 * 0.02 / (2 * d)
+    for ns in (0, 30):
+        qpos, qvel = _settle_on_gpu(xml.format(gx=G * np.sin(th), gz=-G * np.cos(th), ns=ns, mu=mu), 6000)
+        assert abs(-qpos[2] / r0 - 1) < 3e-3
+        if ns == 0:
+            assert abs(qvel[0] / v_creep - 1) < 2e-3            # the regularised pyramid creeps at the closed-form speed
+        else:
+            assert abs(qvel[0]) < 2e-3 * v_creep               # the noslip pass holds the body
