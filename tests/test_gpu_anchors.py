@@ -8,12 +8,12 @@ import tempfile
 import numpy as np
 import pytest
 
-from test_cpu_oracle_anchors import G, SPHERE, impedance, rest_depth
+from test_cpu_oracle_anchors import G, SLIDER, SPHERE, impedance, rest_depth
 
 pytestmark = pytest.mark.gpu
 
 
-def _settle_on_gpu(xml, steps, n=32):
+def _settle_on_gpu(xml, steps, n=32, ctrl=None, state=None):
     import torch
 
     from gymnasium_robotics_amd import _native
@@ -39,7 +39,12 @@ def _settle_on_gpu(xml, steps, n=32):
         for k, t in bufs.items():
             setattr(b, k, t.data_ptr())
         b.mask = b.packed = None
-        per_call = 250
+        if ctrl is not None:
+            bufs["action"][:] = torch.tensor(ctrl, dtype=torch.float32, device=dev)
+        if state is not None:
+            bufs["qpos"][:] = torch.tensor(state[0], dtype=torch.float32, device=dev)
+            bufs["qvel"][:] = torch.tensor(state[1], dtype=torch.float32, device=dev)
+        per_call = 250 if steps >= 250 else steps
         task = _native.PointTaskStruct(per_call, 1, 1, 1, 0.45, 5.0)     # agent = 1: ctrl = action, no velocity clip; 250 raw physics steps per launch
         for _ in range(steps // per_call):
             _native.check(L.grx_point_step(h, ctypes.byref(task), ctypes.byref(b), n, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
@@ -88,3 +93,48 @@ def test_gpu_friction_creep_and_noslip(mu):
             assert abs(qvel[0] / v_creep - 1) < 2e-3            # the regularised pyramid creeps at the closed-form speed
         else:
             assert abs(qvel[0]) < 2e-3 * v_creep               # the noslip pass holds the body
+
+
+def test_gpu_joint_limit_rest_depth_with_custom_solref_solimp():
+    """anchor 06 on the device: one limit row with the JOINT's solreflimit (dampratio 0.7) and solimplimit (power-3 impedance)"""
+    xml = """<mujoco><option timestep="0.0005"/><worldbody>
+    <body pos="0 0 1"><joint type="slide" axis="0 0 1" limited="true" range="0 1" solreflimit="0.01 0.7" solimplimit="0.8 0.99 0.002 0.3 3"/>
+    <geom type="sphere" size="0.05" mass="4" contype="0" conaffinity="0"/></body></worldbody></mujoco>"""
+    qpos, qvel = _settle_on_gpu(xml, 8000)
+    assert abs(qvel[0]) < 1e-5 and abs(-qpos[0] / rest_depth(1.0, (0.8, 0.99, 0.002, 0.3, 3.0), tc=0.01, dr=0.7) - 1) < 2e-3
+
+
+def test_gpu_frictionloss_saturation_and_creep():
+    """anchors 11 / 12 on the device: below the weight the friction-loss row saturates (free fall minus f / m), above it the mass creeps at
+    |v| = g (1 - dmin) dmax tc / (2 dmin)"""
+    qpos, qvel = _settle_on_gpu(SLIDER.format(fl=5.0, extra=""), 200)
+    assert abs(qvel[0] / (-(G - 5.0 / 2) * 0.2) - 1) < 1e-4
+    qpos, qvel = _settle_on_gpu(SLIDER.format(fl=50.0, extra=""), 3000)
+    assert abs(-qvel[0] / (G * (1 - 0.9) * 0.95 * 0.02 / (2 * 0.9)) - 1) < 1e-3
+
+
+def test_gpu_actuators_and_implicit_damping():
+    """anchors 13 / 14 on the device: a position servo holds kp (c - q) = m g, its ctrlrange clamps the command; a general-affine actuator
+    (gain ctrl + b0 + b1 q + b2 qdot, the Adroit hand's kind) drives a damped mass to (gain c + b0 - m g) / -b1"""
+    act = '<actuator><position joint="j" kp="400" ctrllimited="true" ctrlrange="-1 1"/></actuator>'
+    xml = SLIDER.replace('frictionloss="{fl}"', 'damping="30"').format(extra=act)
+    qpos, qvel = _settle_on_gpu(xml, 6000, ctrl=[0.3])
+    assert abs(qvel[0]) < 1e-5 and abs(qpos[0] - (0.3 - 2 * G / 400)) < 1e-5
+    qpos, qvel = _settle_on_gpu(xml, 6000, ctrl=[5.0])
+    assert abs(qpos[0] - (1.0 - 2 * G / 400)) < 1e-5
+    act = '<actuator><general joint="j" gainprm="10 0 0" biastype="affine" biasprm="3 -100 -20"/></actuator>'
+    qpos, qvel = _settle_on_gpu(SLIDER.format(fl=0, extra=act), 6000, ctrl=[0.7])
+    assert abs(qvel[0]) < 1e-5 and abs(qpos[0] - (10 * 0.7 + 3 - 2 * G) / 100) < 1e-5
+
+
+def test_gpu_weld_to_mocap_sags_by_the_soft_constraint_offset():
+    """anchor 10 on the device: a free body welded to a mocap body hangs below it by the rest depth of one soft row (the Fetch gripper's weld)"""
+    xml = """<mujoco><option timestep="0.001"/><worldbody>
+    <body name="mocap" mocap="true" pos="0.3 0.2 1"/>
+    <body name="b" pos="0.3 0.2 1"><freejoint/><geom type="box" size="0.05 0.04 0.03" mass="1.7" contype="0" conaffinity="0"/></body>
+    </worldbody><equality><weld body1="mocap" body2="b" solref="0.02 1" solimp="0.9 0.95 0.001"/></equality></mujoco>"""
+    qpos, qvel = _settle_on_gpu(xml, 12000)
+    # the generic stepper carries no mocap state (the maze models have none): the mocap body sits at the origin, the weld drags the body there and it
+    # comes to rest one soft-row depth below it
+    assert np.abs(qvel).max() < 3e-5 and abs(-qpos[2] / rest_depth(1.0) - 1) < 3e-3
+    assert np.allclose(qpos[[0, 1]], [0.0, 0.0], atol=1e-6) and np.allclose(np.abs(qpos[3]), 1, atol=1e-6)
