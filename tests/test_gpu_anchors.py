@@ -138,3 +138,49 @@ def test_gpu_weld_to_mocap_sags_by_the_soft_constraint_offset():
     # comes to rest one soft-row depth below it
     assert np.abs(qvel).max() < 3e-5 and abs(-qpos[2] / rest_depth(1.0) - 1) < 3e-3
     assert np.allclose(qpos[[0, 1]], [0.0, 0.0], atol=1e-6) and np.allclose(np.abs(qpos[3]), 1, atol=1e-6)
+
+
+@pytest.mark.parametrize("cd,mu,rows_over_2", [(4, 0.6, 3.0), (6, 0.7, 5.0)])
+def test_gpu_condim4_and_condim6_rest_depth(cd, mu, rows_over_2):
+    """anchors 03 / 03b on the device: 2 (condim - 1) pyramid rows that all carry the R of the first pair (Fetch finger pads, the kitchen's condim-6 pads)"""
+    xml = SPHERE.format(cd=cd, mu=mu, spin=0.03, mass=0.9).replace("0.0001", "0.002")
+    qpos, qvel = _settle_on_gpu(xml, 4000)
+    assert np.abs(qvel).max() < 3e-5 and abs((0.1 - qpos[2]) / rest_depth(rows_over_2 / (mu * mu * (1 + mu * mu))) - 1) < 2e-3
+
+
+def test_gpu_tendon_limit_rest_depth():
+    """anchor 09 on the device: two masses coupled by the fixed tendon q1 + q2 >= 0 (the Shadow hand's coupled joints): J = (1, 1), invweight 2 / m"""
+    xml = """<mujoco><option timestep="0.0005"/><worldbody>
+    <body pos="0 0 1"><joint name="a" type="slide" axis="0 0 1"/><geom type="sphere" size="0.05" mass="1.5" contype="0" conaffinity="0"/></body>
+    <body pos="1 0 1"><joint name="b" type="slide" axis="0 0 1"/><geom type="sphere" size="0.05" mass="1.5" contype="0" conaffinity="0"/></body>
+    </worldbody><tendon><fixed name="t" limited="true" range="0 1"><joint joint="a" coef="1"/><joint joint="b" coef="1"/></fixed></tendon></mujoco>"""
+    qpos, qvel = _settle_on_gpu(xml, 8000)
+    assert np.abs(qvel).max() < 1e-5 and abs(qpos[0] - qpos[1]) < 1e-6
+    assert abs(-(qpos[0] + qpos[1]) / rest_depth(0.5) - 1) < 2e-3
+
+
+def test_gpu_joint_equality_couples_two_hinges():
+    """anchor 21 on the device: <equality><joint polycoef="0 a"> (the kitchen's knob <-> burner couplings): the coupled hinge settles at q1 = a q2"""
+    a = 3.0
+    xml = f"""<mujoco><option timestep="0.002"/><worldbody>
+    <body pos="0 0 0.2"><joint name="j1" type="hinge" axis="0 0 1" damping="0.05"/><geom type="box" size="0.1 0.02 0.02" pos="0.1 0 0" mass="0.5" contype="0" conaffinity="0"/></body>
+    <body pos="0.5 0 0.2"><joint name="j2" type="hinge" axis="0 0 1" damping="0.05"/><geom type="box" size="0.05 0.02 0.02" pos="0.05 0 0" mass="0.2" contype="0" conaffinity="0"/></body>
+    </worldbody>
+    <equality><joint joint1="j1" joint2="j2" polycoef="0 {a} 0 0 0"/></equality>
+    <actuator><position joint="j1" kp="50"/></actuator></mujoco>"""
+    qpos, qvel = _settle_on_gpu(xml, 6000, ctrl=[0.6])
+    assert np.abs(qvel).max() < 1e-4 and abs(qpos[0] - 0.6) < 1e-4 and abs(qpos[0] - a * qpos[1]) < 1e-4       # fp32 jitter floor of the lightly damped pair
+
+
+def test_gpu_two_body_contact_conserves_momentum():
+    """anchor 05 on the device: two free spheres collide in zero gravity; contact forces are internal, so m1 v1 + m2 v2 is conserved through the contact
+    (fp32: to 1e-5 of the momentum) -- equal and opposite Jacobian rows on the two bodies"""
+    xml = """<mujoco><option timestep="0.001" gravity="0 0 0"/><worldbody>
+    <body pos="0 0 0"><freejoint/><geom type="sphere" size="0.1" mass="1" condim="1"/></body>
+    <body pos="0.5 0.02 0.01"><freejoint/><geom type="sphere" size="0.15" mass="3" condim="1"/></body></worldbody></mujoco>"""
+    q0 = np.array([0, 0, 0, 1, 0, 0, 0, 0.5, 0.02, 0.01, 1, 0, 0, 0.0])
+    v0 = np.array([1.0, 0, 0, 0, 0, 0, -0.5, 0, 0, 0, 0, 0.0])
+    p0 = 1.0 * v0[0:3] + 3.0 * v0[6:9]
+    qpos, qvel = _settle_on_gpu(xml, 1000, state=(q0, v0))
+    assert np.abs(1.0 * qvel[0:3] + 3.0 * qvel[6:9] - p0).max() < 2e-5
+    assert qvel[0] < 0 < qvel[6] + 0.5                     # the light sphere bounced back
