@@ -184,3 +184,24 @@ def test_gpu_two_body_contact_conserves_momentum():
     qpos, qvel = _settle_on_gpu(xml, 1000, state=(q0, v0))
     assert np.abs(1.0 * qvel[0:3] + 3.0 * qvel[6:9] - p0).max() < 2e-5
     assert qvel[0] < 0 < qvel[6] + 0.5                     # the light sphere bounced back
+
+
+def test_gpu_rk4_and_euler_orders_of_convergence():
+    """anchor 16 on the device (AntMaze integrates with RK4, ant.xml:3): pendulum angle after 0.5 s against the fp64 oracle at h = 1e-4.  Halving h halves the
+    semi-implicit Euler error; the RK4 error at h = 0.02 is four orders below Euler's at h = 0.004 and falls by ~16 per halving until it meets the fp32 floor."""
+    from oracle.oracle_sim import OracleSim
+    from test_cpu_oracle_anchors import PEND, _compile
+
+    ref_sim = OracleSim(_compile(PEND.format(h=1e-4, integ="RK4")))
+    ref_sim.qpos[0] = 0.4
+    ref_sim.step(5000)
+    ref = float(ref_sim.qpos[0])
+
+    def angle(integ, h):
+        qpos, _ = _settle_on_gpu(PEND.format(h=h, integ=integ), int(round(0.5 / h)), state=([0.4], [0.0]))
+        return qpos[0]
+
+    e = [abs(angle("Euler", h) - ref) for h in (0.004, 0.002, 0.001)]
+    assert 1.8 < e[0] / e[1] < 2.2 and 1.8 < e[1] / e[2] < 2.2, e
+    r = [abs(angle("RK4", h) - ref) for h in (0.02, 0.01)]
+    assert r[0] < 1e-3 * e[0] and r[0] / max(r[1], 1e-7) > 8 or r[0] < 2e-6, (r, e)
