@@ -1278,8 +1278,12 @@ GRX_MEM float grx_mpr_tri_dist2(const float* x0, const float* b, const float* cc
     if ((grx_mpr_zero(sp) || sp > 0.0f) && (grx_mpr_eq(sp, 1.0f) || sp < 1.0f) && (grx_mpr_zero(tp) || tp > 0.0f) && (grx_mpr_eq(tp, 1.0f) || tp < 1.0f) &&
         (grx_mpr_eq(tp + sp, 1.0f) || tp + sp < 1.0f)) {
       for (int k = 0; k < 3; k++) w[k] = x0[k] + sp * d1[k] + tp * d2[k];
-      best = sp * sp * v + tp * tp * ww + 2.0f * sp * tp * r + 2.0f * sp * p + 2.0f * tp * q + u;
-      return best > 0.0f ? best : 0.0f;
+      // |w|^2, not the expanded quadratic form sp^2 v + tp^2 ww + 2 sp tp r + 2 sp p + 2 tp q + u of the published routine: for a portal whose vertices are
+      // decimetres from an origin 0.2 mm off its plane the form's terms are ~0.1 and cancel to 4e-8, which in fp32 is rounding noise -- 25 um of depth at 0.2 mm,
+      // measured by tests/test_gpu_anchors.py (a mesh cube standing on a vertex, away from the slab's centre).  The components of w cancel too, but to 1e-4
+      // relative.  Same value in exact arithmetic (and in the fp64 oracle).
+      best = dot3f(w, w);
+      return best;
     }
   }
   float w2[3], dist;

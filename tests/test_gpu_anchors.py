@@ -8,12 +8,12 @@ import tempfile
 import numpy as np
 import pytest
 
-from test_cpu_oracle_anchors import G, SLIDER, SPHERE, impedance, rest_depth
+from test_cpu_oracle_anchors import G, SLIDER, SPHERE, _write_cube_stl, impedance, rest_depth, stiffness
 
 pytestmark = pytest.mark.gpu
 
 
-def _settle_on_gpu(xml, steps, n=32, ctrl=None, state=None):
+def _settle_on_gpu(xml, steps, n=32, ctrl=None, state=None, files=()):
     import torch
 
     from gymnasium_robotics_amd import _native
@@ -21,6 +21,8 @@ def _settle_on_gpu(xml, steps, n=32, ctrl=None, state=None):
 
     assert torch.cuda.is_available(), "these tests need the GPU"
     with tempfile.TemporaryDirectory() as d:
+        for name, half in files:
+            _write_cube_stl(os.path.join(d, name), half)
         p = os.path.join(d, "m.xml")
         with open(p, "w") as f:
             f.write(xml)
@@ -205,3 +207,29 @@ def test_gpu_rk4_and_euler_orders_of_convergence():
     assert 1.8 < e[0] / e[1] < 2.2 and 1.8 < e[1] / e[2] < 2.2, e
     r = [abs(angle("RK4", h) - ref) for h in (0.02, 0.01)]
     assert r[0] < 1e-3 * e[0] and r[0] / max(r[1], 1e-7) > 8 or r[0] < 2e-6, (r, e)
+
+
+@pytest.mark.parametrize("support", ["box", "mesh"])
+def test_gpu_hull_contact_distance(support):
+    """anchor 22 on the device: a cube given as a MESH stands on one VERTEX (body diagonal vertical: the contact point is unique and under the centre of mass)
+    in a slab (box primitive / second mesh) with a prescribed overlap, at rest.  The stepper does not hand out contacts, but ONE step does: a single frictionless
+    row through the centre of mass gives a = d k d |r| - (1 - d) g, so the velocity after one step measures the distance the hull routine reported
+    (dv / d|r| = h k d^2 = 2.5 per metre: a micrometre of distance is 2.5e-6 m/s, far above fp32).  (Face-on the contact point is any point of the overlap polygon
+    and the cube also turns: nothing closed-form to compare with.)"""
+    slab = '<geom name="slab" type="box" size="0.3 0.3 0.05" pos="0 0 0.05" condim="1"/>' if support == "box" else \
+           '<geom name="slab" type="mesh" mesh="slab" pos="0 0 0.05" condim="1"/>'
+    xml = f"""<mujoco><option timestep="0.001"/><asset><mesh name="cube" file="cube.stl"/><mesh name="slab" file="slab.stl"/></asset><worldbody>
+    {slab}<body pos="0 0 0.3"><freejoint/><geom name="cube" type="mesh" mesh="cube" mass="0.7" condim="1"/></body></worldbody></mujoco>"""
+    h, k = 0.001, stiffness()
+    u = np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0)                    # the body diagonal ...
+    axis = np.cross(u, [0.0, 0.0, -1.0]); ang = np.arccos(-u[2])     # ... turned onto -z
+    axis /= np.linalg.norm(axis)
+    quat = np.r_[np.cos(ang / 2), np.sin(ang / 2) * axis]
+    for overlap in (2e-4, 1e-3, 3e-3):
+        for (x, y) in ((0.0, 0.0), (0.11, -0.07)):
+            q0 = np.r_[x, y, 0.1 + np.sqrt(3.0) * 0.05 - overlap, quat]
+            qpos, qvel = _settle_on_gpu(xml, 1, state=(q0, [0.0] * 6), files=(("cube.stl", (0.05, 0.05, 0.05)), ("slab.stl", (0.3, 0.3, 0.05))))
+            d = impedance(overlap)
+            v = h * (d * k * d * overlap - (1 - d) * G)
+            assert abs(qvel[2] - v) < 2.5 * 3e-6 + 1e-6, (overlap, x, y, qvel[2], v)                 # the reported distance is the overlap to within 3 micrometres
+            assert np.abs(qvel[[0, 1]]).max() < 1e-5 and np.abs(qvel[3:]).max() < 2e-3               # through the centre of mass: (almost) no turn
