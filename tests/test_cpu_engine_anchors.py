@@ -71,3 +71,39 @@ def test_engine_friction_creep_and_noslip(mu):
             assert abs(float(e.qvel[0]) / v_creep - 1) < 2e-3            # the regularised pyramid creeps at the closed-form speed
         else:
             assert abs(float(e.qvel[0])) < 2e-3 * v_creep               # the noslip pass holds the body
+
+
+@pytest.mark.parametrize("support", ["box", "mesh"])
+def test_engine_hull_contact_distance(support):
+    """A mesh cube standing on one vertex in a slab (box / mesh) with a prescribed overlap: one step from rest gives v = h (d k d |r| - (1 - d) g), i.e. the
+    velocity measures the distance the hull routine reported (tests/test_gpu_anchors.py has the derivation).  Poses away from the slab's centre are the
+    ones that exposed the fp32 cancellation in the portal routine's depth (25 um at 0.2 mm, one contact missed) that grx_mpr_tri_dist2 now avoids."""
+    from emu_sim import EmuSim
+    from test_cpu_oracle_anchors import _write_cube_stl, stiffness
+
+    slab = '<geom name="slab" type="box" size="0.3 0.3 0.05" pos="0 0 0.05" condim="1"/>' if support == "box" else \
+           '<geom name="slab" type="mesh" mesh="slab" pos="0 0 0.05" condim="1"/>'
+    xml = f"""<mujoco><option timestep="0.001"/><asset><mesh name="cube" file="cube.stl"/><mesh name="slab" file="slab.stl"/></asset><worldbody>
+    {slab}<body pos="0 0 0.3"><freejoint/><geom name="cube" type="mesh" mesh="cube" mass="0.7" condim="1"/></body></worldbody></mujoco>"""
+    with tempfile.TemporaryDirectory() as d:
+        _write_cube_stl(os.path.join(d, "cube.stl"), (0.05, 0.05, 0.05))
+        _write_cube_stl(os.path.join(d, "slab.stl"), (0.3, 0.3, 0.05))
+        p = os.path.join(d, "m.xml")
+        with open(p, "w") as f:
+            f.write(xml)
+        m = compile_mjcf(p)
+    e = EmuSim(m, types.SimpleNamespace(obs_dim=1))
+    u = np.ones(3) / np.sqrt(3.0)
+    axis = np.cross(u, [0.0, 0.0, -1.0]); axis /= np.linalg.norm(axis)
+    ang = np.arccos(-u[2])
+    quat = np.r_[np.cos(ang / 2), np.sin(ang / 2) * axis]
+    h, k = 0.001, stiffness()
+    for overlap in (2e-4, 1e-3, 3e-3):
+        for (x, y) in ((0.0, 0.0), (0.11, -0.07), (0.2, 0.2), (-0.15, 0.22)):
+            e.qpos[:] = np.r_[x, y, 0.1 + np.sqrt(3.0) * 0.05 - overlap, quat]
+            e.qvel[:] = 0
+            e.qacc_ws[:] = 0
+            ncon, nefc = _run(e, 1)
+            dd = impedance(overlap)
+            v = h * (dd * k * dd * overlap - (1 - dd) * G)
+            assert (ncon, nefc) == (1, 1) and abs(float(e.qvel[2]) - v) < 2.5 * 3e-6 + 1e-6, (overlap, x, y, ncon, float(e.qvel[2]), v)
