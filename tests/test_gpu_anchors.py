@@ -233,3 +233,23 @@ def test_gpu_hull_contact_distance(support):
             v = h * (d * k * d * overlap - (1 - d) * G)
             assert abs(qvel[2] - v) < 2.5 * 3e-6 + 1e-6, (overlap, x, y, qvel[2], v)                 # the reported distance is the overlap to within 3 micrometres
             assert np.abs(qvel[[0, 1]]).max() < 1e-5 and np.abs(qvel[3:]).max() < 2e-3               # through the centre of mass: (almost) no turn
+
+
+@pytest.mark.parametrize("shape", ['type="sphere" size="0.07"', 'type="ellipsoid" size="0.07 0.07 0.07"'])
+@pytest.mark.parametrize("other", ['type="box" size="0.3 0.3 0.05" pos="0 0 0.05"', 'type="cylinder" size="0.3 0.05" pos="0 0 0.05"'])
+def test_gpu_convex_pair_distance_through_the_one_step_response(shape, other):
+    """anchor 20 on the device: a ball -- as a sphere primitive (closed-form routines; against the cylinder the lane-resident portal search) and as an ellipsoid with
+    three equal radii (portal search + the smooth-surface extent) -- pressed into a slab's flat top by a prescribed overlap, at rest, at several places on the
+    slab.  The contact normal passes through the centre of mass, so one step gives v = h (d k d |r| - (1 - d) g): the velocity measures the reported distance."""
+    xml = f"""<mujoco><option timestep="0.001"/><worldbody><geom {other} condim="1"/>
+    <body pos="0 0 0.3"><freejoint/><geom {shape} mass="0.4" condim="1"/></body></worldbody></mujoco>"""
+    h, k = 0.001, stiffness()
+    q = np.array([0.8, 0.1, -0.5, 0.3]); q /= np.linalg.norm(q)
+    for overlap in (2e-4, 1e-3, 3e-3):
+        for (x, y) in ((0.0, 0.0), (0.11, -0.07), (-0.18, 0.05)):
+            q0 = np.r_[x, y, 0.1 + 0.07 - overlap, q]
+            qpos, qvel = _settle_on_gpu(xml, 1, state=(q0, [0.0] * 6))
+            d = impedance(overlap)
+            v = h * (d * k * d * overlap - (1 - d) * G)
+            assert abs(qvel[2] - v) < 2.5 * 3e-6 + 1e-6, (overlap, x, y, qvel[2], v)                 # the reported distance is the overlap to within 3 micrometres
+            assert np.abs(qvel[[0, 1]]).max() < 1e-4        # normal within 1e-2 rad of the cap's (a portal within 1e-6 of a radius-r surface pins its normal to sqrt(2 eps / r) = 5e-3)
