@@ -253,3 +253,29 @@ def test_gpu_convex_pair_distance_through_the_one_step_response(shape, other):
             v = h * (d * k * d * overlap - (1 - d) * G)
             assert abs(qvel[2] - v) < 2.5 * 3e-6 + 1e-6, (overlap, x, y, qvel[2], v)                 # the reported distance is the overlap to within 3 micrometres
             assert np.abs(qvel[[0, 1]]).max() < 1e-4        # normal within 1e-2 rad of the cap's (a portal within 1e-6 of a radius-r surface pins its normal to sqrt(2 eps / r) = 5e-3)
+
+
+_U = np.ones(3) / np.sqrt(3.0)
+_AX = np.cross(_U, [0.0, 0.0, -1.0]) / np.linalg.norm(np.cross(_U, [0.0, 0.0, -1.0]))
+_VERTEX_DOWN = np.r_[np.cos(np.arccos(-_U[2]) / 2), np.sin(np.arccos(-_U[2]) / 2) * _AX]      # turns a cube's body diagonal onto -z
+
+
+@pytest.mark.parametrize("ground", ['type="plane" size="1 1 0.1" pos="0 0 0.1"', 'type="box" size="0.3 0.3 0.05" pos="0 0 0.05"'])
+@pytest.mark.parametrize("shape,quat,reach", [('type="box" size="0.05 0.05 0.05"', _VERTEX_DOWN, np.sqrt(3.0) * 0.05),
+                                               ('type="capsule" size="0.04 0.1"', np.array([1.0, 0, 0, 0]), 0.14),
+                                               ('type="mesh" mesh="cube"', _VERTEX_DOWN, np.sqrt(3.0) * 0.05)])
+def test_gpu_single_contact_distance_of_the_analytic_and_hull_routines(ground, shape, quat, reach):
+    """One contact through the centre of mass -- a box or a mesh cube standing on a vertex, a capsule standing on its cap -- on a plane and on a box slab, at
+    several places and depths: plane-box, plane-capsule, plane-mesh, box-box, capsule-box and hull-box routines.  One step from rest gives
+    v = h (d k d |r| - (1 - d) g) for the overlap the routine reported (see test_gpu_hull_contact_distance)."""
+    xml = f"""<mujoco><option timestep="0.001"/><asset><mesh name="cube" file="cube.stl"/></asset><worldbody><geom {ground} condim="1"/>
+    <body pos="0 0 0.4"><freejoint/><geom {shape} mass="0.6" condim="1"/></body></worldbody></mujoco>"""
+    h, k = 0.001, stiffness()
+    for overlap in (2e-4, 1e-3, 3e-3):
+        for (x, y) in ((0.0, 0.0), (0.11, -0.07), (-0.18, 0.05)):
+            q0 = np.r_[x, y, 0.1 + reach - overlap, quat]
+            qpos, qvel = _settle_on_gpu(xml, 1, state=(q0, [0.0] * 6), files=(("cube.stl", (0.05, 0.05, 0.05)),))
+            d = impedance(overlap)
+            v = h * (d * k * d * overlap - (1 - d) * G)
+            assert abs(qvel[2] - v) < 2.5 * 3e-6 + 1e-6, (overlap, x, y, qvel[2], v)
+            assert np.abs(qvel[[0, 1]]).max() < 1e-4
