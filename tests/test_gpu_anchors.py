@@ -260,13 +260,14 @@ _AX = np.cross(_U, [0.0, 0.0, -1.0]) / np.linalg.norm(np.cross(_U, [0.0, 0.0, -1
 _VERTEX_DOWN = np.r_[np.cos(np.arccos(-_U[2]) / 2), np.sin(np.arccos(-_U[2]) / 2) * _AX]      # turns a cube's body diagonal onto -z
 
 
-@pytest.mark.parametrize("ground", ['type="plane" size="1 1 0.1" pos="0 0 0.1"', 'type="box" size="0.3 0.3 0.05" pos="0 0 0.05"'])
+@pytest.mark.parametrize("ground", ['type="plane" size="1 1 0.1" pos="0 0 0.1"', 'type="box" size="0.3 0.3 0.05" pos="0 0 0.05"', 'type="cylinder" size="0.3 0.05" pos="0 0 0.05"'])
 @pytest.mark.parametrize("shape,quat,reach", [('type="box" size="0.05 0.05 0.05"', _VERTEX_DOWN, np.sqrt(3.0) * 0.05),
                                                ('type="capsule" size="0.04 0.1"', np.array([1.0, 0, 0, 0]), 0.14),
                                                ('type="mesh" mesh="cube"', _VERTEX_DOWN, np.sqrt(3.0) * 0.05)])
 def test_gpu_single_contact_distance_of_the_analytic_and_hull_routines(ground, shape, quat, reach):
     """One contact through the centre of mass -- a box or a mesh cube standing on a vertex, a capsule standing on its cap -- on a plane and on a box slab, at
-    several places and depths: plane-box, plane-capsule, plane-mesh, box-box, capsule-box and hull-box routines.  One step from rest gives
+    several places and depths: plane-box, plane-capsule, plane-mesh, box-box, capsule-box and hull-box routines, and on a cylinder's cap the portal search on a lane
+    (box-cylinder, capsule-cylinder) and over the wave (hull-cylinder).  One step from rest gives
     v = h (d k d |r| - (1 - d) g) for the overlap the routine reported (see test_gpu_hull_contact_distance)."""
     xml = f"""<mujoco><option timestep="0.001"/><asset><mesh name="cube" file="cube.stl"/></asset><worldbody><geom {ground} condim="1"/>
     <body pos="0 0 0.4"><freejoint/><geom {shape} mass="0.6" condim="1"/></body></worldbody></mujoco>"""
