@@ -269,12 +269,14 @@ def test_gpu_single_contact_distance_of_the_analytic_and_hull_routines(ground, s
     several places and depths: plane-box, plane-capsule, plane-mesh, box-box, capsule-box and hull-box routines, and on a cylinder's cap the portal search on a lane
     (box-cylinder, capsule-cylinder) and over the wave (hull-cylinder).  One step from rest gives
     v = h (d k d |r| - (1 - d) g) for the overlap the routine reported (see test_gpu_hull_contact_distance)."""
-    xml = f"""<mujoco><option timestep="0.001"/><asset><mesh name="cube" file="cube.stl"/></asset><worldbody><geom {ground} condim="1"/>
+    # the whole scene sits 1.9 m from the world origin (the Fetch table is at x = 1.3): the routines must work on differences of geom positions
+    ox, oy = 1.7, -0.85
+    xml = f"""<mujoco><option timestep="0.001"/><asset><mesh name="cube" file="cube.stl"/></asset><worldbody><body pos="{ox} {oy} 0"><geom {ground} condim="1"/></body>
     <body pos="0 0 0.4"><freejoint/><geom {shape} mass="0.6" condim="1"/></body></worldbody></mujoco>"""
     h, k = 0.001, stiffness()
     for overlap in (2e-4, 1e-3, 3e-3):
         for (x, y) in ((0.0, 0.0), (0.11, -0.07), (-0.18, 0.05)):
-            q0 = np.r_[x, y, 0.1 + reach - overlap, quat]
+            q0 = np.r_[ox + x, oy + y, 0.1 + reach - overlap, quat]
             qpos, qvel = _settle_on_gpu(xml, 1, state=(q0, [0.0] * 6), files=(("cube.stl", (0.05, 0.05, 0.05)),))
             d = impedance(overlap)
             v = h * (d * k * d * overlap - (1 - d) * G)
