@@ -282,3 +282,39 @@ def test_gpu_single_contact_distance_of_the_analytic_and_hull_routines(ground, s
             v = h * (d * k * d * overlap - (1 - d) * G)
             assert abs(qvel[2] - v) < 2.5 * 3e-6 + 1e-6, (overlap, x, y, qvel[2], v)
             assert np.abs(qvel[[0, 1]]).max() < 1e-4
+
+
+@pytest.mark.parametrize("ground", ['type="plane" size="1 1 0.1" pos="0 0 0.1"', 'type="box" size="0.4 0.4 0.05" pos="0 0 0.05"'])
+def test_gpu_off_centre_contact_turns_the_body_by_the_closed_form(ground):
+    """One contact that does NOT pass through the centre of mass: a cube tilted so that one corner is lowest, pressed into the ground by a prescribed overlap, at
+    rest.  The row sees A = 1/m + |r x n|^2 / I (cube: I = 2/3 m a^2, isotropic) and R = (1 - d)/d / m (diagApprox has the translational weight only), so
+    f = (k d |r| + g) / (A + R); one step gives v = h (f/m - g) n and omega = h I^-1 (r x n) f, the latter in the BODY frame for a free joint.  Pins the
+    rotational half of the contact Jacobian and the inertia on the device."""
+    a, m_ = 0.05, 0.9
+    xml = f"""<mujoco><option timestep="0.001"/><worldbody><geom {ground} condim="1"/>
+    <body pos="0 0 0.4"><freejoint/><geom type="box" size="{a} {a} {a}" mass="{m_}" condim="1"/></body></worldbody></mujoco>"""
+    h, k = 0.001, stiffness()
+
+    def quat_mul(p, q):
+        return np.array([p[0] * q[0] - p[1:] @ q[1:], *(p[0] * q[1:] + q[0] * p[1:] + np.cross(p[1:], q[1:]))])
+
+    qx = np.array([np.cos(0.26), np.sin(0.26), 0, 0]); qy = np.array([np.cos(0.17), 0, np.sin(0.17), 0])
+    quat = quat_mul(qy, qx)
+    w, x, y, z = quat
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    corners = np.array([[sx, sy, sz] for sx in (-a, a) for sy in (-a, a) for sz in (-a, a)]) @ Rm.T
+    low = corners[np.argmin(corners[:, 2])]
+    assert np.sort(corners[:, 2])[1] - low[2] > 5e-3                      # one corner only within reach
+    inertia = 2.0 / 3.0 * m_ * a * a
+    n = np.array([0.0, 0.0, 1.0])
+    rxn = np.cross(low, n)
+    for overlap in (2e-4, 1e-3, 3e-3):
+        q0 = np.r_[0.03, -0.02, 0.1 - low[2] - overlap, quat]
+        qpos, qvel = _settle_on_gpu(xml, 1, state=(q0, [0.0] * 6))
+        d = impedance(overlap)
+        A, R = 1.0 / m_ + rxn @ rxn / inertia, (1 - d) / d / m_
+        f = (k * d * overlap + G) / (A + R)
+        v_z, om_local = h * (f / m_ - G), Rm.T @ (h * rxn * f / inertia)
+        assert abs(qvel[2] - v_z) < 1e-5 and np.abs(qvel[[0, 1]]).max() < 1e-6, (overlap, qvel[:3], v_z)
+        assert np.abs(qvel[3:] - om_local).max() < 2e-3 * np.abs(om_local).max() + 1e-5, (overlap, qvel[3:], om_local)
