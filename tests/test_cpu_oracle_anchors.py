@@ -532,3 +532,33 @@ def test_anchor_23_weight_splits_evenly_over_the_contacts_of_a_resting_primitive
     assert np.abs(s.qpos[:2]).max() < 1e-5 and abs(abs(s.qpos[3]) - 1) < 1e-10            # no drift beyond the settling transient, no tilt
     d = s.contacts()[:, 0]
     assert np.abs(d - d.mean()).max() < 1e-12                                            # the same depth at every contact
+
+
+@pytest.mark.parametrize("ground", ['type="plane" size="1 1 0.1" pos="0 0 0.1"', 'type="box" size="0.4 0.4 0.05" pos="0 0 0.05"'])
+def test_anchor_24_off_centre_contact_force_and_turn(ground):
+    """One contact that does not pass through the centre of mass: a cube tilted onto one corner, pressed into the ground by a prescribed overlap, at rest.
+    The row sees A = J M^-1 J' = 1/m + |r x n|^2 / I (cube: I = 2/3 m a^2) while its regulariser uses the TRANSLATIONAL body weight only,
+    R = (1 - d)/d / m (MuJoCo's diagApprox for a contact's normal), so f = (k d |r| + g) / (A + R), qacc = (f/m - g) n and, in the body frame of the free
+    joint, I^-1 R' (r x n) f.  Breaks for a diagApprox that includes the rotational weight, a Jacobian with the wrong lever arm, or a world-frame omega."""
+    a, m_ = 0.05, 0.9
+    xml = f"""<mujoco><option timestep="0.001"/><worldbody><geom {ground} condim="1"/>
+    <body pos="0 0 0.4"><freejoint/><geom type="box" size="{a} {a} {a}" mass="{m_}" condim="1"/></body></worldbody></mujoco>"""
+    s = OracleSim(_compile(xml))
+    qx = np.array([np.cos(0.26), np.sin(0.26), 0, 0]); qy = np.array([np.cos(0.17), 0, np.sin(0.17), 0])
+    quat = np.array([qy[0] * qx[0] - qy[1:] @ qx[1:], *(qy[0] * qx[1:] + qx[0] * qy[1:] + np.cross(qy[1:], qx[1:]))])
+    w, x, y, z = quat
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    corners = np.array([[sx, sy, sz] for sx in (-a, a) for sy in (-a, a) for sz in (-a, a)]) @ Rm.T
+    low = corners[np.argmin(corners[:, 2])]
+    inertia, rxn = 2.0 / 3.0 * m_ * a * a, np.cross(low, [0.0, 0.0, 1.0])
+    for overlap in (2e-4, 1e-3, 3e-3):
+        s.qpos[:] = np.r_[0.03, -0.02, 0.1 - low[2] - overlap, quat]
+        s.qvel[:] = 0
+        s.forward()
+        d = impedance(overlap)
+        A, R = 1.0 / m_ + rxn @ rxn / inertia, (1 - d) / d / m_
+        f = (stiffness() * d * overlap + G) / (A + R)
+        assert s.ncon == 1 and s.nefc == 1 and abs(s.efc("R")[0] / R - 1) < 1e-12
+        assert abs(s.qacc[2] - (f / m_ - G)) < 1e-9 and np.abs(s.qacc[:2]).max() < 1e-12
+        assert np.abs(s.qacc[3:] - Rm.T @ (rxn * f / inertia)).max() < 1e-8
