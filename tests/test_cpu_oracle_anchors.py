@@ -562,3 +562,33 @@ def test_anchor_24_off_centre_contact_force_and_turn(ground):
         assert s.ncon == 1 and s.nefc == 1 and abs(s.efc("R")[0] / R - 1) < 1e-12
         assert abs(s.qacc[2] - (f / m_ - G)) < 1e-9 and np.abs(s.qacc[:2]).max() < 1e-12
         assert np.abs(s.qacc[3:] - Rm.T @ (rxn * f / inertia)).max() < 1e-8
+
+
+DOUBLE_PENDULUM = """<mujoco><option timestep="0.001"/><worldbody>
+<body pos="0 0 2"><joint type="hinge" axis="0 1 0"/><geom type="sphere" size="0.002" pos="0 0 -{l1}" mass="{m1}" contype="0" conaffinity="0"/>
+<body pos="0 0 -{l1}"><joint type="hinge" axis="0 1 0"/><geom type="sphere" size="0.002" pos="0 0 -{l2}" mass="{m2}" contype="0" conaffinity="0"/></body></body>
+</worldbody></mujoco>"""
+
+
+def double_pendulum_acc(t1, t2, w1, w2, m1, m2, l1, l2, g=G):
+    """textbook equations of motion of the planar double pendulum with point masses (absolute angles from the hanging position)"""
+    den = 2 * m1 + m2 - m2 * np.cos(2 * t1 - 2 * t2)
+    a1 = (-g * (2 * m1 + m2) * np.sin(t1) - m2 * g * np.sin(t1 - 2 * t2) - 2 * np.sin(t1 - t2) * m2 * (w2 * w2 * l2 + w1 * w1 * l1 * np.cos(t1 - t2))) / (l1 * den)
+    a2 = (2 * np.sin(t1 - t2) * (w1 * w1 * l1 * (m1 + m2) + g * (m1 + m2) * np.cos(t1) + w2 * w2 * l2 * m2 * np.cos(t1 - t2))) / (l2 * den)
+    return a1, a2
+
+
+def test_anchor_25_double_pendulum_accelerations():
+    """Two hinges, two point masses: the joint accelerations at arbitrary states against the textbook equations of motion -- composite-inertia mass matrix
+    (off-diagonal coupling), centrifugal / Coriolis bias and gravity of the RNE pass in one number each.  MuJoCo's second joint angle is relative:
+    theta2 = q1 + q2.  (The 2 mm spheres add 0.4 m r^2 of rotational inertia: 6e-6 of m l^2.)"""
+    m1, m2, l1, l2 = 0.7, 0.4, 0.5, 0.35
+    s = OracleSim(_compile(DOUBLE_PENDULUM.format(m1=m1, m2=m2, l1=l1, l2=l2)))
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        q, v = rng.uniform(-2.5, 2.5, 2), rng.uniform(-6, 6, 2)
+        s.qpos[:], s.qvel[:] = q, v
+        s.forward()
+        a1, a2 = double_pendulum_acc(q[0], q[0] + q[1], v[0], v[0] + v[1], m1, m2, l1, l2)
+        scale = max(abs(a1), abs(a2), 1.0)
+        assert abs(s.qacc[0] - a1) < 5e-5 * scale and abs(s.qacc[0] + s.qacc[1] - a2) < 5e-5 * scale, (q, v, s.qacc, a1, a2)

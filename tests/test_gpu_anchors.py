@@ -318,3 +318,22 @@ def test_gpu_off_centre_contact_turns_the_body_by_the_closed_form(ground):
         v_z, om_local = h * (f / m_ - G), Rm.T @ (h * rxn * f / inertia)
         assert abs(qvel[2] - v_z) < 1e-5 and np.abs(qvel[[0, 1]]).max() < 1e-6, (overlap, qvel[:3], v_z)
         assert np.abs(qvel[3:] - om_local).max() < 2e-3 * np.abs(om_local).max() + 1e-5, (overlap, qvel[3:], om_local)
+
+
+def test_gpu_double_pendulum_accelerations():
+    """anchor 25 on the device: one semi-implicit Euler step of a two-hinge, two-point-mass chain from arbitrary states; (v' - v) / h is the joint acceleration
+    and must equal the textbook equations of motion -- mass matrix with its off-diagonal coupling, centrifugal / Coriolis bias and gravity of the HIP kernels."""
+    from test_cpu_oracle_anchors import DOUBLE_PENDULUM, double_pendulum_acc
+
+    m1, m2, l1, l2, h = 0.7, 0.4, 0.5, 0.35, 0.001
+    xml = DOUBLE_PENDULUM.format(m1=m1, m2=m2, l1=l1, l2=l2)
+    rng = np.random.default_rng(2)
+    for _ in range(8):
+        q, v = rng.uniform(-2.5, 2.5, 2), rng.uniform(-6, 6, 2)
+        v = np.float32(v).astype(np.float64)                         # the state the device really starts from
+        q = np.float32(q).astype(np.float64)
+        qpos, qvel = _settle_on_gpu(xml, 1, state=(q, v))
+        acc = (qvel - v) / h
+        a1, a2 = double_pendulum_acc(q[0], q[0] + q[1], v[0], v[0] + v[1], m1, m2, l1, l2)
+        scale = max(abs(a1), abs(a2), 1.0)
+        assert abs(acc[0] - a1) < 2e-3 * scale and abs(acc[0] + acc[1] - a2) < 2e-3 * scale, (q, v, acc, a1, a2)      # fp32: v ~ 6 resolves acc to 6e-7 / h = 6e-4
