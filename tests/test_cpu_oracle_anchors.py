@@ -592,3 +592,28 @@ def test_anchor_25_double_pendulum_accelerations():
         a1, a2 = double_pendulum_acc(q[0], q[0] + q[1], v[0], v[0] + v[1], m1, m2, l1, l2)
         scale = max(abs(a1), abs(a2), 1.0)
         assert abs(s.qacc[0] - a1) < 5e-5 * scale and abs(s.qacc[0] + s.qacc[1] - a2) < 5e-5 * scale, (q, v, s.qacc, a1, a2)
+
+
+FREE_BOX = """<mujoco><option timestep="0.001" gravity="0 0 0"/><worldbody>
+<body pos="0 0 1"><freejoint/><geom type="box" size="0.1 0.07 0.05" mass="1.3" contype="0" conaffinity="0"/></body></worldbody></mujoco>"""
+
+
+def euler_equations_acc(w, half=(0.1, 0.07, 0.05), mass=1.3):
+    """torque-free rigid body, body frame: I w' = -w x (I w), I of a box = m/3 (b^2 + c^2, a^2 + c^2, a^2 + b^2)"""
+    a, b, c = half
+    inertia = mass / 3.0 * np.array([b * b + c * c, a * a + c * c, a * a + b * b])
+    return -np.cross(w, inertia * w) / inertia
+
+
+def test_anchor_26_torque_free_rotation_obeys_eulers_equations():
+    """A free box spinning about a non-principal axis in zero gravity: the angular part of qacc (body frame, as MuJoCo keeps a free joint's angular velocity)
+    is Euler's equations, the linear part stays zero.  The gyroscopic term of the bias force and the box inertia, in one vector."""
+    s = OracleSim(_compile(FREE_BOX))
+    rng = np.random.default_rng(5)
+    for _ in range(10):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        w = rng.uniform(-8, 8, 3)
+        s.qpos[:] = np.r_[0.1, -0.2, 1.0, q]
+        s.qvel[:] = np.r_[rng.uniform(-1, 1, 3), w]
+        s.forward()
+        assert np.abs(s.qacc[:3]).max() < 1e-12 and np.abs(s.qacc[3:] - euler_equations_acc(w)).max() < 1e-10

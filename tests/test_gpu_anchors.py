@@ -337,3 +337,18 @@ def test_gpu_double_pendulum_accelerations():
         a1, a2 = double_pendulum_acc(q[0], q[0] + q[1], v[0], v[0] + v[1], m1, m2, l1, l2)
         scale = max(abs(a1), abs(a2), 1.0)
         assert abs(acc[0] - a1) < 2e-3 * scale and abs(acc[0] + acc[1] - a2) < 2e-3 * scale, (q, v, acc, a1, a2)      # fp32: v ~ 6 resolves acc to 6e-7 / h = 6e-4
+
+
+def test_gpu_torque_free_rotation_obeys_eulers_equations():
+    """anchor 26 on the device: (v' - v) / h of a free box spinning about a non-principal axis in zero gravity = Euler's equations in the body frame"""
+    from test_cpu_oracle_anchors import FREE_BOX, euler_equations_acc
+
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        w = np.float32(rng.uniform(-8, 8, 3)).astype(np.float64)
+        v = np.r_[np.float32(rng.uniform(-1, 1, 3)).astype(np.float64), w]
+        qpos, qvel = _settle_on_gpu(FREE_BOX, 1, state=(np.r_[0.1, -0.2, 1.0, q], v))
+        acc = (qvel - v) / 0.001
+        want = euler_equations_acc(w)
+        assert np.abs(acc[:3]).max() < 1e-3 and np.abs(acc[3:] - want).max() < 2e-3 * max(np.abs(want).max(), 1.0), (w, acc, want)
