@@ -617,3 +617,23 @@ def test_anchor_26_torque_free_rotation_obeys_eulers_equations():
         s.qvel[:] = np.r_[rng.uniform(-1, 1, 3), w]
         s.forward()
         assert np.abs(s.qacc[:3]).max() < 1e-12 and np.abs(s.qacc[3:] - euler_equations_acc(w)).max() < 1e-10
+
+
+ARMATURE = """<mujoco><option timestep="0.001"/><worldbody>
+<body pos="0 0 1"><joint name="j" type="hinge" axis="0 1 0" armature="{arm}" damping="{damp}"/><geom type="sphere" size="0.002" pos="0 0 -{l}" mass="{m}" contype="0" conaffinity="0"/></body>
+</worldbody><actuator><motor joint="j" gear="{gear}"/></actuator></mujoco>"""
+
+
+def test_anchor_27_armature_gear_and_damping_of_a_driven_hinge():
+    """One hinge with a point mass, rotor inertia (armature), a geared motor and joint damping: qacc = (gear u - c w - m g l sin q) / (m l^2 + armature) in
+    mj_forward (the damping enters explicitly there; the Euler step then integrates it implicitly, anchor 15).  The Fetch and Shadow-hand joints all carry
+    armature and damping."""
+    m, l, arm, gear, damp = 0.6, 0.4, 0.02, 3.0, 0.15
+    s = OracleSim(_compile(ARMATURE.format(m=m, l=l, arm=arm, gear=gear, damp=damp)))
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        q, w, u = rng.uniform(-3, 3), rng.uniform(-5, 5), rng.uniform(-1, 1)
+        s.qpos[0], s.qvel[0], s.ctrl[0] = q, w, u
+        s.forward()
+        inertia = m * l * l + 0.4 * m * 0.002 ** 2 + arm
+        assert abs(s.qacc[0] - (gear * u - damp * w - m * G * l * np.sin(q)) / inertia) < 1e-9

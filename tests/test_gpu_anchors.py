@@ -352,3 +352,20 @@ def test_gpu_torque_free_rotation_obeys_eulers_equations():
         acc = (qvel - v) / 0.001
         want = euler_equations_acc(w)
         assert np.abs(acc[:3]).max() < 1e-3 and np.abs(acc[3:] - want).max() < 2e-3 * max(np.abs(want).max(), 1.0), (w, acc, want)
+
+
+def test_gpu_armature_gear_and_damping_of_a_driven_hinge():
+    """anchor 27 on the device: one Euler step of a hinge with rotor inertia, a geared motor and damping.  The step integrates the damping implicitly:
+    v' = v + h (gear u - c v - m g l sin q) / (I + h c) with I = m l^2 + armature (anchor 15's update), which is what (v' - v) / h is compared with."""
+    from test_cpu_oracle_anchors import ARMATURE
+
+    m, l, arm, gear, damp, h = 0.6, 0.4, 0.02, 3.0, 0.15, 0.001
+    xml = ARMATURE.format(m=m, l=l, arm=arm, gear=gear, damp=damp)
+    rng = np.random.default_rng(3)
+    inertia = m * l * l + 0.4 * m * 0.002 ** 2 + arm
+    for _ in range(6):
+        q, w, u = (float(np.float32(x)) for x in (rng.uniform(-3, 3), rng.uniform(-5, 5), rng.uniform(-1, 1)))
+        qpos, qvel = _settle_on_gpu(xml, 1, state=([q], [w]), ctrl=[u])
+        acc = (qvel[0] - w) / h
+        want = (gear * u - damp * w - m * G * l * np.sin(q)) / (inertia + h * damp)
+        assert abs(acc - want) < 2e-3 * max(abs(want), 1.0), (q, w, u, acc, want)
