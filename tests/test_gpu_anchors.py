@@ -369,3 +369,20 @@ def test_gpu_armature_gear_and_damping_of_a_driven_hinge():
         acc = (qvel[0] - w) / h
         want = (gear * u - damp * w - m * G * l * np.sin(q)) / (inertia + h * damp)
         assert abs(acc - want) < 2e-3 * max(abs(want), 1.0), (q, w, u, acc, want)
+
+
+@pytest.mark.parametrize("ground", ['type="plane" size="1 1 0.1" pos="0 0 0.1"', 'type="box" size="0.4 0.4 0.05" pos="0 0 0.05"'])
+@pytest.mark.parametrize("shape,ncon,reach", [('type="box" size="0.1 0.07 0.05"', 4, 0.05), ('type="capsule" size="0.04 0.12" euler="0 90 0"', 2, 0.04)])
+def test_gpu_symmetric_multi_contact_response(ground, shape, ncon, reach):
+    """A box lying face-on (four corner contacts) and a capsule lying on its side (two), centred, pressed in by a prescribed overlap, at rest: by symmetry the
+    body only moves vertically and every contact sees the same acceleration, so with D = m d / (1 - d) per frictionless row
+    a = (ncon d/(1-d) k d |r| - g) / (1 + ncon d/(1-d)).  One step measures it: all ncon contacts found, at the same depth, none doubled."""
+    xml = f"""<mujoco><option timestep="0.001"/><worldbody><geom {ground} condim="1"/>
+    <body pos="0 0 0.4"><freejoint/><geom {shape} mass="1.1" condim="1"/></body></worldbody></mujoco>"""
+    h, k = 0.001, stiffness()
+    for overlap in (2e-4, 1e-3, 3e-3):
+        qpos, qvel = _settle_on_gpu(xml, 1, state=([0.0, 0.0, 0.1 + reach - overlap, 1, 0, 0, 0], [0.0] * 6))
+        d = impedance(overlap)
+        w = ncon * d / (1 - d)
+        v = h * (w * k * d * overlap - G) / (1 + w)
+        assert abs(qvel[2] - v) < 1e-5 and np.abs(qvel[[0, 1, 3, 4, 5]]).max() < 2e-4, (overlap, qvel, v)
