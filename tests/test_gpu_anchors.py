@@ -386,3 +386,17 @@ def test_gpu_symmetric_multi_contact_response(ground, shape, ncon, reach):
         w = ncon * d / (1 - d)
         v = h * (w * k * d * overlap - G) / (1 + w)
         assert abs(qvel[2] - v) < 1e-5 and np.abs(qvel[[0, 1, 3, 4, 5]]).max() < 2e-4, (overlap, qvel, v)
+
+
+@pytest.mark.parametrize("ground", ['type="box" size="0.3 0.3 0.05" pos="0 0 0.05"', 'type="cylinder" size="0.3 0.05" pos="0 0 0.05"'])
+def test_gpu_standing_cylinder_on_a_flat_top(ground):
+    """FetchSlide's puck configuration: a cylinder standing flat on a box (and on another cylinder's cap).  The convex route gives ONE contact; centred on the
+    slab the centre ray is the common axis, so the contact passes through the centre of mass and one step gives v = h (d k d |r| - (1 - d) g) for the overlap."""
+    xml = f"""<mujoco><option timestep="0.001"/><worldbody><geom {ground} condim="1"/>
+    <body pos="0 0 0.4"><freejoint/><geom type="cylinder" size="0.04 0.03" mass="0.5" condim="1"/></body></worldbody></mujoco>"""
+    h, k = 0.001, stiffness()
+    for overlap in (2e-4, 1e-3, 3e-3):
+        qpos, qvel = _settle_on_gpu(xml, 1, state=([0.0, 0.0, 0.1 + 0.03 - overlap, 1, 0, 0, 0], [0.0] * 6))
+        d = impedance(overlap)
+        v = h * (d * k * d * overlap - (1 - d) * G)
+        assert abs(qvel[2] - v) < 2.5 * 3e-6 + 1e-6 and np.abs(qvel[[0, 1]]).max() < 1e-4 and np.abs(qvel[3:]).max() < 5e-2, (overlap, qvel, v)
