@@ -637,3 +637,27 @@ def test_anchor_27_armature_gear_and_damping_of_a_driven_hinge():
         s.forward()
         inertia = m * l * l + 0.4 * m * 0.002 ** 2 + arm
         assert abs(s.qacc[0] - (gear * u - damp * w - m * G * l * np.sin(q)) / inertia) < 1e-9
+
+
+POINT_ON_PLANE = """<mujoco><option timestep="0.001"/><worldbody>
+<geom type="plane" size="2 2 0.1" condim="3" friction="{mu} 0.005 0.0001"/>
+<body pos="0 0 0.1"><joint type="slide" axis="1 0 0"/><joint type="slide" axis="0 1 0"/><joint type="slide" axis="0 0 1"/>
+<geom type="sphere" size="0.1" mass="0.8" condim="3" friction="{mu} 0.005 0.0001"/></body></worldbody></mujoco>"""
+
+
+def sliding_deceleration(v, mu, d, dmax=0.95, tc=0.02):
+    """point mass at its rest depth sliding slowly: the rows n +- mu t carry D (K -+ b mu v - (a_z +- mu a_x)) with 2 mu^2 D = m d / ((1 - d)(1 + mu^2)), the
+    vertical balance is untouched and a_x = -b v d / ((1 - d)(1 + mu^2) + d), b = 2 / (dmax tc): the viscous regime of the soft friction cone"""
+    return -(2.0 / (dmax * tc)) * v * d / ((1 - d) * (1 + mu * mu) + d)
+
+
+@pytest.mark.parametrize("mu", [0.5, 1.0])
+def test_anchor_28_slow_sliding_is_viscous_with_the_solref_damping(mu):
+    r0 = rest_depth(2.0 / (mu * mu * (1 + mu * mu)))
+    s = OracleSim(_compile(POINT_ON_PLANE.format(mu=mu)))
+    for v in (1e-3, 5e-3):
+        s.qpos[:] = [0, 0, -r0]
+        s.qvel[:] = [v, 0, 0]
+        s.forward()
+        assert s.nefc == 4 and abs(s.qacc[2]) < 1e-6 and abs(s.qacc[1]) < 1e-12
+        assert abs(s.qacc[0] / sliding_deceleration(v, mu, impedance(r0)) - 1) < 1e-6

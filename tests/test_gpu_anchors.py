@@ -400,3 +400,17 @@ def test_gpu_standing_cylinder_on_a_flat_top(ground):
         d = impedance(overlap)
         v = h * (d * k * d * overlap - (1 - d) * G)
         assert abs(qvel[2] - v) < 2.5 * 3e-6 + 1e-6 and np.abs(qvel[[0, 1]]).max() < 1e-4 and np.abs(qvel[3:]).max() < 5e-2, (overlap, qvel, v)
+
+
+@pytest.mark.parametrize("mu", [0.5, 1.0])
+def test_gpu_slow_sliding_is_viscous_with_the_solref_damping(mu):
+    """anchor 28 on the device: a point mass at its rest depth sliding slowly decelerates with a_x = -b v d / ((1 - d)(1 + mu^2) + d): the velocity term of the
+    friction rows, the pyramid's R scaling and the impedance in one number"""
+    from test_cpu_oracle_anchors import POINT_ON_PLANE, sliding_deceleration
+
+    r0 = rest_depth(2.0 / (mu * mu * (1 + mu * mu)))
+    for v in (1e-3, 5e-3):
+        v32 = float(np.float32(v))
+        qpos, qvel = _settle_on_gpu(POINT_ON_PLANE.format(mu=mu), 1, state=([0.0, 0.0, -r0], [v32, 0.0, 0.0]))
+        acc = (qvel[0] - v32) / 0.001
+        assert abs(acc / sliding_deceleration(v32, mu, impedance(r0)) - 1) < 5e-3 and abs(qvel[1]) < 1e-8, (v, acc)
