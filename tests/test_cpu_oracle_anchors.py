@@ -661,3 +661,30 @@ def test_anchor_28_slow_sliding_is_viscous_with_the_solref_damping(mu):
         s.forward()
         assert s.nefc == 4 and abs(s.qacc[2]) < 1e-6 and abs(s.qacc[1]) < 1e-12
         assert abs(s.qacc[0] / sliding_deceleration(v, mu, impedance(r0)) - 1) < 1e-6
+
+
+def fast_sliding_acc(v, mu, r0, m=0.8, dmax=0.95, tc=0.02):
+    """the same point mass sliding FAST along +x: the velocity term b mu v of the row n - mu t dwarfs the stiffness term, that row alone carries force --
+    f = D (K + b mu v + g) / (1 + D (1 + mu^2) / m) from f = D (K + b mu v - a_z + mu a_x), m a_x = -mu f, m a_z = -m g + f -- and pushes the body up so hard
+    (a_z > K) that the other three rows would need negative forces: they are off"""
+    d = impedance(r0)
+    D = m * d / ((1 - d) * 2 * mu * mu * (1 + mu * mu))
+    K, b = stiffness(dmax, tc) * d * r0, 2.0 / (dmax * tc)
+    f = D * (K + b * mu * v + G) / (1 + D * (1 + mu * mu) / m)
+    ax, az = -mu * f / m, -G + f / m
+    assert D * (K - b * mu * v - az - mu * ax) < 0 and D * (K - az) < 0 < f, "not the one-row regime"
+    return ax, az
+
+
+@pytest.mark.parametrize("mu", [0.5, 1.0])
+def test_anchor_29_fast_sliding_switches_one_pyramid_row_off(mu):
+    """The inequality side of the solver: at 0.3 m/s ONE pyramid row is active and three are off (they would need negative forces); the accelerations follow
+    from that single row in closed form.  Breaks for a solver that keeps rows on (bilateral friction), a wrong active set, or a wrong velocity term in aref."""
+    r0 = rest_depth(2.0 / (mu * mu * (1 + mu * mu)))
+    s = OracleSim(_compile(POINT_ON_PLANE.format(mu=mu)))
+    s.qpos[:] = [0, 0, -r0]
+    s.qvel[:] = [0.3, 0, 0]
+    s.forward()
+    ax, az = fast_sliding_acc(0.3, mu, r0)
+    assert abs(s.qacc[0] / ax - 1) < 1e-6 and abs(s.qacc[2] / az - 1) < 1e-6 and abs(s.qacc[1]) < 1e-12
+    assert (s.efc("force") > 0).sum() == 1

@@ -414,3 +414,15 @@ def test_gpu_slow_sliding_is_viscous_with_the_solref_damping(mu):
         qpos, qvel = _settle_on_gpu(POINT_ON_PLANE.format(mu=mu), 1, state=([0.0, 0.0, -r0], [v32, 0.0, 0.0]))
         acc = (qvel[0] - v32) / 0.001
         assert abs(acc / sliding_deceleration(v32, mu, impedance(r0)) - 1) < 5e-3 and abs(qvel[1]) < 1e-8, (v, acc)
+
+
+@pytest.mark.parametrize("mu", [0.5, 1.0])
+def test_gpu_fast_sliding_switches_one_pyramid_row_off(mu):
+    """anchor 29 on the device: the active-set side of the Newton solver -- at 0.3 m/s ONE pyramid row is active, the other three are off; the accelerations follow from that row in closed form"""
+    from test_cpu_oracle_anchors import POINT_ON_PLANE, fast_sliding_acc
+
+    r0 = rest_depth(2.0 / (mu * mu * (1 + mu * mu)))
+    v32 = float(np.float32(0.3))
+    qpos, qvel = _settle_on_gpu(POINT_ON_PLANE.format(mu=mu), 1, state=([0.0, 0.0, -r0], [v32, 0.0, 0.0]))
+    ax, az = fast_sliding_acc(v32, mu, r0)
+    assert abs((qvel[0] - v32) / 0.001 / ax - 1) < 5e-3 and abs(qvel[2] / 0.001 / az - 1) < 5e-3 and abs(qvel[1]) < 1e-7, (qvel, ax, az)
