@@ -688,3 +688,27 @@ def test_anchor_29_fast_sliding_switches_one_pyramid_row_off(mu):
     ax, az = fast_sliding_acc(0.3, mu, r0)
     assert abs(s.qacc[0] / ax - 1) < 1e-6 and abs(s.qacc[2] / az - 1) < 1e-6 and abs(s.qacc[1]) < 1e-12
     assert (s.efc("force") > 0).sum() == 1
+
+
+def spin_deceleration(w, mu, mu_t, r0, m, radius, dmax=0.95, tc=0.02):
+    """a ball at its condim-4 rest depth spinning slowly about the contact normal: the torsional rows n +- mu_t e_n carry D (K -+ b mu_t w - (a_z +- mu_t alpha))
+    with the R of the FIRST pair (1/D = 2 mu^2 (1-d)/d (1+mu^2)/m), so I alpha = -2 mu_t^2 D (b w + alpha), I = 2/5 m r^2"""
+    d = impedance(r0)
+    D = m * d / ((1 - d) * 2 * mu * mu * (1 + mu * mu))
+    inertia, b = 0.4 * m * radius * radius, 2.0 / (dmax * tc)
+    return -2 * mu_t * mu_t * D * b * w / (inertia + 2 * mu_t * mu_t * D)
+
+
+def test_anchor_30_torsional_friction_of_condim4():
+    """condim 4 (the Fetch finger pads, the hand's object contacts): a sphere spinning slowly about the vertical is braked by the torsional pair, whose rows share
+    the first pair's R (anchor 03) but enter with the torsional coefficient: alpha in closed form, no linear acceleration.  Breaks for a torsional pair with its
+    own R, a missing pair, or a spin coefficient applied as a length-free number to the wrong axis."""
+    mu, mu_t, m_, rad = 0.6, 0.02, 0.8, 0.1
+    r0 = rest_depth(3.0 / (mu * mu * (1 + mu * mu)))
+    s = OracleSim(_compile(SPHERE.format(cd=4, mu=mu, spin=mu_t, mass=m_)))
+    for w in (0.01, 0.05):          # b mu_t w below the stiffness term: both torsional rows stay on
+        s.qpos[:] = [0, 0, 0.1 - r0, 1, 0, 0, 0]
+        s.qvel[:] = [0, 0, 0, 0, 0, w]
+        s.forward()
+        assert s.nefc == 6 and np.abs(s.qacc[:5]).max() < 1e-6
+        assert abs(s.qacc[5] / spin_deceleration(w, mu, mu_t, r0, m_, rad) - 1) < 1e-6

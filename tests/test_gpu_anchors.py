@@ -426,3 +426,16 @@ def test_gpu_fast_sliding_switches_one_pyramid_row_off(mu):
     qpos, qvel = _settle_on_gpu(POINT_ON_PLANE.format(mu=mu), 1, state=([0.0, 0.0, -r0], [v32, 0.0, 0.0]))
     ax, az = fast_sliding_acc(v32, mu, r0)
     assert abs((qvel[0] - v32) / 0.001 / ax - 1) < 5e-3 and abs(qvel[2] / 0.001 / az - 1) < 5e-3 and abs(qvel[1]) < 1e-7, (qvel, ax, az)
+
+
+def test_gpu_torsional_friction_of_condim4():
+    """anchor 30 on the device: a ball at its condim-4 rest depth spinning slowly about the vertical is braked by the torsional pyramid pair in closed form"""
+    from test_cpu_oracle_anchors import spin_deceleration
+
+    mu, mu_t, m_, rad = 0.6, 0.02, 0.8, 0.1
+    r0 = rest_depth(3.0 / (mu * mu * (1 + mu * mu)))
+    for w in (0.01, 0.05):          # b mu_t w below the stiffness term: both torsional rows stay on
+        w32 = float(np.float32(w))
+        qpos, qvel = _settle_on_gpu(SPHERE.format(cd=4, mu=mu, spin=mu_t, mass=m_), 1, state=([0, 0, 0.1 - r0, 1, 0, 0, 0], [0, 0, 0, 0, 0, w32]))
+        alpha = (qvel[5] - w32) / 0.001
+        assert abs(alpha / spin_deceleration(w32, mu, mu_t, r0, m_, rad) - 1) < 1e-2 and np.abs(qvel[:2]).max() < 1e-6 and np.abs(qvel[3:5]).max() < 1e-5, (w, alpha, qvel)
