@@ -77,8 +77,8 @@ class GoalVecEnv:
 
     def _status_info(self, info):
         """info["status"] (this step's flags) and info["status_sticky"] for both output modes."""
-        if self.output == "torch":
-            info["status"] = self.status
+        if self.output == "torch":      # two elementwise device ops, no sync
+            info["status"], info["status_sticky"] = self.status & 0xFFFF, self.status >> 16
         else:
             st = self.status.cpu().numpy()
             info["status"], info["status_sticky"] = st & 0xFFFF, st >> 16

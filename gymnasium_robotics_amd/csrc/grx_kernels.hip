@@ -1150,8 +1150,9 @@ grx_maze_reset_kernel(grx_maze_reset_args a, int n_reset) {
     a.success[w] = (unsigned char)succ;
     if (row) {
       row[a.obs_dim] = sx; row[a.obs_dim + 1] = sy; row[a.obs_dim + 2] = gx; row[a.obs_dim + 3] = gy;
-      if (!a.keep_outcome) { row[a.obs_dim + 4] = a.reward[w]; row[a.obs_dim + 5] = succ ? 1.0f : 0.0f; }
+      if (!a.keep_outcome) { row[a.obs_dim + 4] = 0.0f; row[a.obs_dim + 5] = succ ? 1.0f : 0.0f; }
     }
+    if (!a.keep_outcome) a.reward[w] = 0.0f;     // a reset step reports reward 0 (next-step autoreset): reward[] and the packed row agree
   }
 }
 extern "C" int grx_maze_reset_rows(const grx_maze_reset_args* args, int n_reset, void* stream) {

@@ -228,7 +228,9 @@ class HandReachVecEnv(GoalVecEnv):
             info = {}
             if len(pending):
                 self._reset_worlds(pending)
-                self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
+                tp = torch.from_numpy(pending).to(self.device)
+                self.reward[tp] = 0.0
+                self.packed[tp, -2] = 0.0      # the packed row (cross-rank gather, HER) reports the same reward as reward[]
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
                 td = self._dev_index(done)

@@ -187,8 +187,7 @@ class PointMazeVecEnv(GoalVecEnv):
             if self.max_episode_steps is not None:
                 truncated = stepped & (self._elapsed >= self.max_episode_steps)
             if len(pending):
-                self._reset_worlds(pending)
-                self.reward[torch.from_numpy(pending).to(self.device)] = 0.0
+                self._reset_worlds(pending)       # the reset kernel zeroes reward[] and the packed row's reward word of these worlds
             new_goals, final_obs, step_success = None, None, None
             if self.reset_target and self.continuing_task and len(self.maze.unique_goal_locations) > 1:
                 # MazeEnv.update_goal (maze_v4.py:400-418): the returned observation still carries the goal that was just reached

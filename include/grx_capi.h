@@ -258,13 +258,14 @@ int grx_her_sample(const int* episode_start, int n_worlds, int t_now, int T, int
  * xy <- the drawn reset position, qvel = 0, new goal, observation of the reset state): one kernel writes state, goal, obs / achieved / success and the
  * packed row of the n_reset worlds idx[0..n_reset).  The draws (generate_reset_pos / generate_target_goal) stay on the host; stage = [n_reset, 4] rows
  * (start x, start y, goal x, goal y).  keep_outcome != 0 (same-step autoreset): the last two words of the packed row keep the finished episode's
- * reward / success.  All pointers are device pointers. */
+ * reward / success; keep_outcome == 0 (reset(), next-step autoreset): reward[w] and the packed row's reward word are set to 0 (the reset step reports
+ * reward 0).  All pointers are device pointers. */
 typedef struct grx_maze_reset_args {
   const int* idx; const float* stage; const float* qpos0;
   int nq, nv, obs_dim, obs_skip;        /* obs_skip: leading qpos entries left out of the observation (2 for the ant, 0 for the point mass) */
   float goal_radius;
   int keep_outcome;
-  float *qpos, *qvel, *qacc_ws, *goal, *obs, *achieved; const float* reward; unsigned char* success; float* packed;
+  float *qpos, *qvel, *qacc_ws, *goal, *obs, *achieved, *reward; unsigned char* success; float* packed;
 } grx_maze_reset_args;
 int grx_maze_reset_rows(const grx_maze_reset_args* args, int n_reset, void* stream);
 

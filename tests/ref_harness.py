@@ -241,11 +241,37 @@ def _install_mujoco_env_stand_in():
     mjenv.MujocoEnv = MujocoEnv
     mjmod.mujoco_env, envs.mujoco, gymnasium.envs = mjenv, mjmod, envs
     sys.modules.update({"gymnasium.envs": envs, "gymnasium.envs.mujoco": mjmod, "gymnasium.envs.mujoco.mujoco_env": mjenv})
-    # the maze package __init__ also imports the AntMaze classes, which subclass gymnasium's AntEnv [3P, absent]: placeholders so that
-    # the import succeeds (nothing of them is used)
+    # AntMazeEnv (ant_maze_v5.py:221-320) drives gymnasium's AntEnv [3P, absent] through exactly three members: step(action), reset(seed=...)
+    # and init_qpos.  The stand-in restates the documented behaviour of Ant-v5 for the arguments AntMazeEnv passes
+    # (exclude_current_positions_from_observation=False, reset_noise_scale=0.0, use_contact_forces left at False):
+    #   step:        do_simulation(action, frame_skip = 5); observation = qpos | qvel (29 numbers); the locomotion reward / healthy flag it also
+    #                returns are discarded by AntMazeEnv.step ("ant_obs, _, _, _, info")
+    #   reset_model: qpos = init_qpos + U(-s, s, nq), qvel = init_qvel + s * N(0, 1, nv) with s = reset_noise_scale = 0 -- the draws come from the
+    #                ANT env's own generator (not the maze env's), and with s = 0 they do not reach the state; set_state(qpos, qvel)
+    class AntEnv(MujocoEnv):
+        frame_skip = 5
+
+        def _get_obs(self):
+            return np.concatenate((self.data.qpos.flatten(), self.data.qvel.flatten()))
+
+        def step(self, action):
+            xy_before = self.data.qpos[:2].copy()
+            self.do_simulation(action, self.frame_skip)
+            xy_after = self.data.qpos[:2].copy()
+            v = (xy_after - xy_before) / self.dt
+            info = {"x_position": xy_after[0], "y_position": xy_after[1], "distance_from_origin": np.linalg.norm(xy_after), "x_velocity": v[0], "y_velocity": v[1]}
+            return self._get_obs(), 0.0, False, False, info
+
+        def reset_model(self):
+            s = self._reset_noise_scale
+            qpos = self.init_qpos + self.np_random.uniform(low=-s, high=s, size=self.model.nq)
+            qvel = self.init_qvel + s * self.np_random.standard_normal(self.model.nv)
+            self.set_state(qpos, qvel)
+            return self._get_obs()
+
     for ver in ("ant_v4", "ant_v5"):
         mod = types.ModuleType(f"gymnasium.envs.mujoco.{ver}")
-        mod.AntEnv = type("AntEnv", (MujocoEnv,), {})
+        mod.AntEnv = AntEnv
         setattr(mjmod, ver, mod)
         sys.modules[f"gymnasium.envs.mujoco.{ver}"] = mod
 
@@ -266,6 +292,30 @@ def point_maze_on_oracle(oracle_env, maze_map, reward_type, continuing_task, res
     pe.init_qpos, pe.init_qvel = np.zeros(2), np.zeros(2)
     env = object.__new__(point_maze.PointMazeEnv)
     env.maze, env.point_env = maze, pe
+    env.reward_type, env.continuing_task, env.reset_target = reward_type, continuing_task, reset_target
+    env.position_noise_range, env.target_site_id, env.render_mode = 0.25, 0, None
+    env.observation_space = sys.modules["gymnasium"].spaces.Dict({"observation": None, "achieved_goal": None, "desired_goal": None})
+    return env
+
+
+def ant_maze_on_oracle(oracle_env, maze_map, reward_type, continuing_task, reset_target, xml_path):
+    """The reference's AntMazeEnv (ant_maze_v5.py:221-320; constructor bypassed: it builds a MuJoCo model) with the reference's own Maze
+    (Maze.make_maze, scaling 4, height 0.5), and as `ant_env` the AntEnv stand-in of _install_mujoco_env_stand_in whose model / data are
+    proxies onto the oracle simulation.  reset / step / _get_obs / update_target_site_pos and everything they inherit from MazeEnv
+    (maze_v4.py:278-418) are the reference's code."""
+    install()
+    _install_mujoco_env_stand_in()
+    from gymnasium_robotics.envs.maze import ant_maze_v5, maze_v4
+
+    maze, _tmp = maze_v4.Maze.make_maze(xml_path, maze_map, 4, 0.5)
+    s, m = oracle_env.sim, oracle_env.sim.model
+    ant = object.__new__(ant_maze_v5.AntEnv)
+    ant.model = types.SimpleNamespace(nu=m.dim("nu"), nq=m.dim("nq"), nv=m.dim("nv"), na=0, site_pos=np.zeros((4, 3)), opt=types.SimpleNamespace(timestep=m.opt("timestep")))
+    ant.data = types.SimpleNamespace(qpos=s.qpos, qvel=s.qvel, ctrl=s.ctrl, _step=lambda n: s.step(n), _forward=lambda: s.forward(), _reset=lambda: s.reset_data())
+    ant.render_mode, ant._reset_noise_scale = None, 0.0
+    ant.init_qpos, ant.init_qvel = np.array(m.tables["qpos0"], dtype=np.float64).ravel().copy(), np.zeros(m.dim("nv"))
+    env = object.__new__(ant_maze_v5.AntMazeEnv)
+    env.maze, env.ant_env = maze, ant
     env.reward_type, env.continuing_task, env.reset_target = reward_type, continuing_task, reset_target
     env.position_noise_range, env.target_site_id, env.render_mode = 0.25, 0, None
     env.observation_space = sys.modules["gymnasium"].spaces.Dict({"observation": None, "achieved_goal": None, "desired_goal": None})

@@ -110,6 +110,27 @@ def test_emulated_ant_kernel_matches_oracle_teacher_forced():
     assert errs.max() < 1e-4 and np.median(errs) < 5e-6, (np.quantile(errs, [0.5, 0.9, 1.0]))
 
 
+def test_emulated_ant_large_kernel_matches_golden_with_wall_contacts():
+    """The AntMaze_Large model (BASELINE configs[3]: wall lattice, 76 geoms) through the lane emulator on the wall-contact fixture of
+    tools/make_golden_antmaze.py; the same fixture is stepped on the MI355X in tests/test_gpu_maze.py."""
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd import _native
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ant_Large_teacher.npz"))
+    emu = EmuSim(load_model(os.path.join(MODELS, "ant_Large.npz")), _native.PointTaskStruct(5, 1, 1, 1, 0.45, 5.0))
+    pe, ve = [], []
+    for i in range(0, len(g["obs"]), 2):
+        emu.qpos[:], emu.qvel[:], emu.qacc_ws[:] = g["qpos"][i], g["qvel"][i], g["qacc_ws"][i]
+        emu.point_step(g["action"][i])
+        assert emu.status.value == 0
+        e = np.abs(emu.obs - g["obs"][i])
+        pe.append(max(e[:13].max(), np.abs(emu.achieved[:2] - g["achieved"][i]).max()))
+        ve.append(e[13:].max() / max(1.0, np.abs(g["obs"][i, 13:]).max()))
+    assert (g["wall_contact_substeps"][::2] > 0).sum() >= 40
+    assert max(pe) < 1e-4 and max(ve) < 1e-4, (max(pe), max(ve))     # measured: 2.9e-6 / 2.4e-5
+
+
 def test_redraw_goal_draw_order_and_contract():
     """MazeEnv.update_goal (maze_v4.py:400-418): goal cell index, x noise, y noise per attempt, until farther than 0.45."""
     from gymnasium_robotics_amd.core import np_random

@@ -202,6 +202,58 @@ def test_reference_point_maze_on_oracle_physics(layout, reward_type, continuing,
         assert events["success"] > 0, events                # neighbouring cells: the goal is reached
 
 
+@pytest.mark.parametrize("layout,reward_type,continuing,reset_target", [("UMaze", "sparse", True, False), ("Large_Diverse_GR", "sparse", True, False),
+                                                                        ("Medium_Diverse_G", "dense", False, False), ("Large_Diverse_G", "sparse", True, True)])
+def test_reference_ant_maze_on_oracle_physics(layout, reward_type, continuing, reset_target):
+    """ant_maze_v5.py:282-320 (AntMazeEnv.reset / step / _get_obs / update_target_site_pos) and everything they inherit from MazeEnv
+    (maze_v4.py:148-242 Maze.make_maze at scaling 4 / height 0.5, :278-418 goal / reset sampling, noise, reward, termination, update_goal) executed
+    as is on the oracle's physics; gymnasium's AntEnv [3P] is the documented-behaviour stand-in of ref_harness (obs = qpos | qvel, frame_skip 5,
+    reset_noise_scale 0).  Includes BASELINE.json configs[3]'s own layout (Large_Diverse_GR)."""
+    import os
+
+    from gymnasium_robotics_amd.envs import maze_spec
+    from gymnasium_robotics_amd.envs.point_maze import load_point_maze_model
+    from oracle.maze_oracle import OracleAntMazeEnv
+
+    base = layout.split("_")[0]
+    maze = maze_spec.Maze(maze_spec.MAPS[layout], maze_spec.ANT_MAZE_SIZE_SCALING, maze_spec.ANT_MAZE_HEIGHT)
+    model = load_point_maze_model(maze, base, None, "ant")
+    a_env = OracleAntMazeEnv(model, maze, reward_type, continuing, reset_target=reset_target)
+    b_env = OracleAntMazeEnv(model, maze, reward_type, continuing, reset_target=reset_target)
+    xml = os.path.join(ref_harness.REF_ROOT, "gymnasium_robotics", "envs", "assets", "point", "point.xml")   # make_maze only needs a worldbody to append the wall geoms to
+    ref = ref_harness.ant_maze_on_oracle(b_env, maze_spec.MAPS[layout], reward_type, continuing, reset_target, xml)
+    assert np.allclose(np.array(ref.maze.unique_goal_locations), np.array(maze.unique_goal_locations)) and np.allclose(np.array(ref.maze.unique_reset_locations), np.array(maze.unique_reset_locations))
+    assert ref.maze.maze_size_scaling == 4 and ref.maze.maze_height == 0.5
+    rng = np.random.default_rng(0)
+    events = {"success": 0, "terminated": 0, "goal_redrawn": 0}
+    for seed in (0, 9):
+        opts = {"goal_cell": np.array([1, 1]), "reset_cell": np.array([1, 2])} if seed == 9 and layout == "UMaze" else None
+        oa, ia = a_env.reset(seed=seed, options=opts)
+        ob, ib = ref.reset(seed=seed, options=opts)
+        assert ob["observation"].shape == (27,) and ob["achieved_goal"].shape == (2,)
+        for k in ("observation", "achieved_goal", "desired_goal"):
+            assert np.array_equal(ob[k], oa[k]), (seed, k)
+        assert ib["success"] == ia["success"]
+        assert np.array_equal(ref.ant_env.model.site_pos[0], np.append(a_env.goal, 1.0))      # update_target_site_pos: z = height / 2 * scaling
+        for t in range(40):
+            act = rng.uniform(-1, 1, 8).astype(np.float32)
+            if t == 20:      # carry both ants to their goal (same state edit on both simulations) so that success / termination / goal redraw happen
+                for e in (a_env, b_env):
+                    e.sim.qpos[:2] = a_env.goal + 0.1
+                    e.sim.forward()
+            g_before = a_env.goal.copy()
+            sa, sb = a_env.step(act), ref.step(act)
+            for k in ("observation", "achieved_goal", "desired_goal"):
+                assert np.array_equal(sb[0][k], sa[0][k]), (seed, t, k)
+            assert abs(float(sb[1]) - float(sa[1])) <= 1e-15 and bool(sb[2]) == bool(sa[2]) and bool(sb[3]) == bool(sa[3]) and sb[4]["success"] == sa[4]["success"]
+            assert np.array_equal(ref.goal, a_env.goal)
+            events["success"] += bool(sa[4]["success"]); events["terminated"] += bool(sa[2]); events["goal_redrawn"] += not np.array_equal(g_before, a_env.goal)
+            if sa[2]:
+                break
+    assert events["success"] > 0, events
+    assert (events["terminated"] > 0) == (not continuing) and (events["goal_redrawn"] > 0) == (continuing and reset_target), events
+
+
 # manipulate_touch_sensors.py:113-138 (_get_obs with the 92 touch readings raw / > 0 / log(x + 1)) executed as is on the oracle's sensor
 # values; the step itself is the reference's BaseRobotEnv.step.
 def _touch_case(mode):

@@ -168,3 +168,30 @@ def test_step_async_wait_equals_step():
     oa = a.step_wait()
     ob = b.step(act)
     assert bool((oa[0]["observation"] == ob[0]["observation"]).all()) and bool((oa[1] == ob[1]).all())
+
+
+@pytest.mark.parametrize("mode", ["next_step", "same_step"])
+@pytest.mark.parametrize("env_id", ["FetchPush-v4", "PointMaze_UMazeDense-v3", "AntMaze_UMaze-v5", "HandReach-v3", "HandManipulateBlockRotateZ-v1"])
+def test_packed_row_reward_equals_reward_on_autoreset_steps(env_id, mode):
+    """The packed rows [obs | achieved | desired | reward | success] the step kernels write (cross-rank gather, HER) must carry the reward / success the
+    step REPORTS, also in the step that resets a world: 0 in next-step mode (gymnasium >= 1.0: the reset step returns reward 0), the finished episode's
+    values in same-step mode."""
+    import gymnasium_robotics_amd as grx
+
+    env = grx.make_vec(env_id, num_envs=6, device="cuda:0", output="torch", autoreset_mode=mode, max_episode_steps=3)
+    env.reset(seed=1)
+    rng = np.random.default_rng(0)
+    nu = env.action_space.shape[-1]
+    resets = 0
+    for t in range(9):
+        obs, r, term, trunc, info = env.step(rng.uniform(-1, 1, (6, nu)).astype(np.float32))
+        pk = env.packed.cpu().numpy()
+        succ = info["is_success"] if "is_success" in info else info["success"]
+        assert np.array_equal(pk[:, -2], r.float().cpu().numpy()), (t, pk[:, -2], r)
+        assert np.array_equal(pk[:, -1] != 0, succ.cpu().numpy() != 0), t
+        if mode == "next_step" and t in (3, 7):       # the reset steps of a 3-step time limit
+            assert float(r.abs().max()) == 0.0
+            resets += 1
+        assert int(info["status"].max()) == 0 and "status_sticky" in info
+    assert mode == "same_step" or resets == 2
+    env.close()

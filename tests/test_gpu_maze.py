@@ -122,6 +122,36 @@ def test_ant_maze_teacher_forced_matches_oracle():
     assert err.max() < 1e-4   # every snapshot (measured max 1.2e-5, tests/golden/tolerance_table.json)
 
 
+def test_ant_maze_large_teacher_forced_matches_golden():
+    """BASELINE.json configs[3] on ITS OWN kernel instantiation (76 geoms, 819 wall pairs through the wall lattice): the 240 snapshots of
+    tests/golden/ant_Large_teacher.npz (tools/make_golden_antmaze.py: the ant pushed against one wall or into a corner of its cell, 99 snapshots with
+    wall contacts in some substep) stepped once from the oracle's own pre-step states.  Reference: __init__.py:936-958, maze_v4.py:179-212,
+    ant_maze_v5.py:295-320."""
+    import torch
+
+    from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ant_Large_teacher.npz"))
+    n = g["obs"].shape[0]
+    env = AntMazeVecEnv("AntMaze_Large_Diverse_GR-v5", num_envs=n, device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
+    env.reset(seed=0)
+    for k in ("qpos", "qvel", "qacc_ws", "goal"):
+        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    obs, r, term, trunc, info = env.step(g["action"])
+    assert int(np.abs(info["status"]).max()) == 0
+    e = np.abs(obs["observation"] - g["obs"])
+    pe = np.maximum(e[:, :13].max(axis=1), np.abs(obs["achieved_goal"] - g["achieved"]).max(axis=1))
+    ve = e[:, 13:].max(axis=1) / np.maximum(1.0, np.abs(g["obs"][:, 13:]).max(axis=1))   # the kicked ants move at up to 16 m/s
+    wall = g["wall_contact_substeps"] > 0
+    print("AntMaze_Large teacher-forced: positions p50 %.1e max %.1e (wall snapshots max %.1e), velocities (relative) p50 %.1e max %.1e, %d wall snapshots"
+          % (np.median(pe), pe.max(), pe[wall].max(), np.median(ve), ve.max(), wall.sum()))
+    assert wall.sum() >= 90
+    assert pe.max() < 1e-4 and ve.max() < 1e-4              # north_star's bound on every snapshot
+    assert np.array_equal(info["success"], g["success"]) and np.array_equal(r, g["reward"].astype(r.dtype))
+    assert np.abs(obs["desired_goal"] - g["goal"]).max() < 1e-6
+    env.close()
+
+
 def test_ant_maze_large_runs_and_flags():
     """AntMaze_Large_Diverse_GR-v5 (BASELINE.json configs[3]): 819 candidate pairs, 8 combined goal/reset cells."""
     from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv

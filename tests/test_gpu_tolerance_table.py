@@ -12,7 +12,7 @@ from tolerance_cases import CASES, TABLE, ant_errors, family_errors
 
 pytestmark = pytest.mark.gpu
 ANALYTIC = {"FetchReach": ["obs"], "FetchPush": ["obs"], "FetchPickAndPlace": ["obs"], "HandReach": ["positions", "velocities"], "HandPen": ["positions", "velocities"],
-            "HandBlock": ["positions"], "AdroitHammer": ["qpos", "positions"], "AdroitRelocate": ["qpos", "positions"], "AntMaze": ["positions", "velocities"]}
+            "HandBlock": ["positions"], "AdroitHammer": ["qpos", "positions"], "AdroitRelocate": ["qpos", "positions"], "AntMaze": ["positions", "velocities"], "AntMazeLarge": ["positions"], "HandBlockTouch": ["positions"]}
 
 
 @pytest.mark.parametrize("family", list(CASES) + ["AntMaze"])

@@ -28,6 +28,11 @@ CASES = {
     "AdroitPen": ("AdroitHandPen-v2", "adroit_pen_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift"),
                   {"qpos": np.r_[0:24], "pen_position_orientation": np.r_[24:27, 33:36, 39:45], "pen_velocity": np.r_[27:33]}),
     "FrankaKitchen": ("FrankaKitchen-v1", "kitchen_teacher.npz", ("qpos", "qvel", "qacc_ws", "last_qpos"), {"positions": np.r_[0:9, 18:39], "velocities": np.r_[9:18, 39:59]}),
+    # BASELINE configs[3] on its own model (76 geoms, wall lattice): tools/make_golden_antmaze.py pushes the ant against the walls of its cell
+    "AntMazeLarge": ("AntMaze_Large_Diverse_GR-v5", "ant_Large_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": np.r_[0:13], "velocities": np.r_[13:27]}),
+    # BASELINE configs[2]'s 153-word observation (61 + 92 touch zones); touch readings are forces (up to tens of newtons): relative to max(1, |reading|)
+    "HandBlockTouch": ("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", "hand_BlockRotateXYZ_touch_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"),
+                       {"positions": HAND_POS, "velocities": HAND_VEL, "touch_relative": np.r_[61:153]}),
     "AdroitRelocate": ("AdroitHandRelocate-v2", "adroit_relocate_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift", "target"), {"qpos": np.r_[0:30], "positions": np.r_[30:39]}),
 }
 
@@ -51,7 +56,7 @@ def family_errors(name):
     out = env.step(g["action"])
     obs = out[0]["observation"] if isinstance(out[0], dict) else out[0]
     e = np.abs(obs - g["obs"])
-    res = {c: e[:, cols].max(axis=1) for c, cols in comps.items()}
+    res = {c: (e[:, cols] / np.maximum(1.0, np.abs(g["obs"][:, cols])) if c.endswith("_relative") else e[:, cols]).max(axis=1) for c, cols in comps.items()}
     res["_far"] = (g["activation_gap"] >= 2e-5) if "activation_gap" in g.files else np.ones(n, bool)
     env.close()
     return res
