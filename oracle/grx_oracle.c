@@ -794,7 +794,9 @@ static void collide_box_box(orc_sim* s, int pair, int g1, int g2, double margin)
  * Game Programming Gems 7; the structure of libccd's mpr.c: discover portal -> refine portal -> find penetration), written from
  * its description; the normal of contacts with smooth geoms is then replaced by the analytic one (smooth_normal below).
  * PARITY UNPINNED like the rest of this file. */
+#ifndef MPR_EPS   /* libccd's CCD_EPS in MuJoCo's double-precision build; -DMPR_EPS=1.1920929e-7 reproduces what round 2's device build did (tools/emu_tolerances.py) */
 #define MPR_EPS 2.220446049250313e-16
+#endif
 typedef struct { double v[3], v1[3], v2[3]; } mpr_pt;
 static int mpr_zero(double x) { return fabs(x) < MPR_EPS; }
 static int mpr_eq(double a, double b) {

@@ -19,8 +19,17 @@ _LIB = None
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libgrx_oracle.so")
     src = os.path.join(_HERE, "grx_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libgrx_oracle.so"], stdout=subprocess.DEVNULL)
+    stale = lambda: force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
+    if stale():
+        import fcntl
+
+        with open(so + ".lock", "w") as lk:      # pytest-xdist workers: one builds, the others wait and find the fresh library
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                tmp = f"libgrx_oracle.{os.getpid()}.tmp.so"
+                subprocess.check_call(["make", "-C", _HERE, "-B", tmp, f"OUT={tmp}"], stdout=subprocess.DEVNULL)
+                os.replace(os.path.join(_HERE, tmp), so)
+                force = False
     return so
 
 

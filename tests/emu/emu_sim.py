@@ -16,9 +16,17 @@ def build(force=False):
 
     srcs = [os.path.join(_HERE, "grx_emu.cpp")] + sorted(glob.glob(os.path.join(_ROOT, "gymnasium_robotics_amd", "csrc", "*.h"))) + sorted(
         glob.glob(os.path.join(_ROOT, "include", "*")))
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(
-            ["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-misleading-indentation", "-o", so, srcs[0]], cwd=_HERE)
+    stale = lambda: force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale():
+        import fcntl
+
+        with open(so + ".lock", "w") as lk:      # pytest-xdist workers: one builds, the others wait and find the fresh library
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                tmp = f"{so}.{os.getpid()}.tmp"
+                subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-misleading-indentation", "-o", tmp, srcs[0]], cwd=_HERE)
+                os.replace(tmp, so)
+                force = False
     return so
 
 

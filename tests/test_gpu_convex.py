@@ -29,11 +29,11 @@ def test_egg_teacher_forced_step_matches_golden():
     assert int(info["status"].max()) == 0
     e = np.abs(obs["observation"] - g["obs"])
     pe, ve = np.maximum(e[:, :24].max(axis=1), e[:, 54:].max(axis=1)), e[:, 24:54].max(axis=1)
-    # quantiles instead of a pass fraction (the committed table tests/golden/tolerance_table.json holds the measured ones; see tests/test_cpu_convex.py on why
-    # the egg's single convex-routine contact is ill-conditioned): p50 at rounding level, p90 / p99 / max bounded
-    assert np.quantile(pe, 0.9) < 1.5e-3 and np.quantile(pe, 0.99) < 5e-3 and pe.max() < 2e-2, (float(np.quantile(pe, 0.9)), float(np.quantile(pe, 0.99)), float(pe.max()))
-    assert np.quantile(ve, 0.9) < 0.1 and ve.max() < 1.0, (float(np.quantile(ve, 0.9)), float(ve.max()))
-    assert np.median(pe) < 1e-5 and np.median(ve) < 3e-4, (float(np.median(pe)), float(np.median(ve)))
+    # north_star's bound on EVERY snapshot for the position components (measured max 5.8e-6 since the portal routine compares against libccd's own
+    # epsilon, grx_engine.h GRX_MPR_EPS; round 2: 79 % within 1e-4, max 6.5e-3); velocities: >= 95 % within 1e-4 (tests/golden/tolerance_table.json)
+    assert pe.max() < 1e-4, float(pe.max())
+    assert np.mean(ve < 1e-4) >= 0.95 and ve.max() < 5e-3, (float(np.mean(ve < 1e-4)), float(ve.max()))
+    assert np.median(pe) < 1e-6 and np.median(ve) < 1e-4, (float(np.median(pe)), float(np.median(ve)))
     from gymnasium_robotics_amd.envs.manipulate_spec import block_goal_distance
 
     _, d_rot = block_goal_distance(g["achieved"], g["goal"], "ignore", "xyz")
@@ -75,7 +75,7 @@ def test_slide_teacher_forced_step_matches_golden():
     assert int(np.abs(info["status"]).max()) == 0
     e = np.abs(obs["observation"] - g["obs"])
     rot = np.r_[11:14, 17:20]           # puck rotation / rotational velocity: the one flat-cap contact has no unique position
-    assert e[:, 11:14].max() < 5e-3 and e[:, 17:20].max() < 2e-2
+    assert np.mean(e[:, 11:14].max(axis=1) < 1e-4) >= 0.95 and e[:, 11:14].max() < 1e-3 and e[:, 17:20].max() < 1e-2      # measured: 97 % / 2.1e-4 / 1.9e-3 (round 2: 46 % / 1.9e-3 / 5.7e-3)
     et = np.delete(e, rot, axis=1).max(axis=1)
     posed = g["activation_gap"] >= 2e-5
     assert et[posed].max() < 1e-4 and et.max() < 5e-3, (float(et[posed].max()), float(et.max()))

@@ -30,9 +30,10 @@ def test_teacher_forced_step_matches_golden(env_and_golden):
     e = np.abs(obs["observation"] - g["obs"])
     pe, ve = np.maximum(e[:, :24].max(axis=1), e[:, 54:].max(axis=1)), e[:, 24:54].max(axis=1)
     far = g["activation_gap"] >= 2e-5
-    assert pe[far].max() < 2e-4 and ve[far].max() < 5e-3, (float(pe[far].max()), float(ve[far].max()))
-    assert pe.max() < 5e-3 and ve.max() < 0.2
-    assert np.median(pe) < 1e-5 and np.median(ve) < 3e-4
+    # the bars are the committed table's (tests/golden/tolerance_table.json, HandBlock): every snapshot's positions inside north_star's 1e-4
+    # (measured max 1.8e-6), velocities max 1.05e-4 with 99.6 % inside
+    assert pe.max() < 1e-4 and ve.max() < 3e-4 and np.mean(ve < 1e-4) >= 0.99, (float(pe.max()), float(ve.max()))
+    assert np.median(pe) < 1e-6 and np.median(ve) < 5e-5
     from gymnasium_robotics_amd.envs.manipulate_spec import block_goal_distance
     _, d_rot = block_goal_distance(g["achieved"], g["goal"], "ignore", "xyz")
     clear = np.abs(d_rot - 0.1) > 1e-3
@@ -183,4 +184,5 @@ def test_same_step_autoreset_matches_next_step(env_id):
 
     make = lambda **kw: grx.make_vec(env_id, num_envs=40, device="cuda:0", **kw)
     # the egg: a rolling object whose contact set flips under the different warm start -- its velocity components are what diverges
-    check_same_step_against_next_step(make, horizon=5, steps=12, act_dim=20, tol=2e-4, tol_max=0.3 if "Egg" in env_id else 1e-2, outlier_rows=0.3 if "Egg" in env_id else 0.15, output="torch")
+    check_same_step_against_next_step(make, horizon=5, steps=12, act_dim=20, tol=2e-4, tol_max=0.3 if "Egg" in env_id else 1e-2, outlier_rows=0.3 if "Egg" in env_id else 0.15, output="torch",
+                                      touch_from=61 if "Touch" in env_id else None)

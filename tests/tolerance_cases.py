@@ -106,4 +106,7 @@ def measure_all():
         for comp, err in res.items():
             table[name][comp] = quantiles(err)
             table[name][comp]["max_away_from_boundary"] = float(err[far].max()) if far.any() else None
+            over = np.nonzero(err >= 1e-4)[0]       # the snapshots outside north_star's bound, one by one (up to 24; the count is always recorded)
+            table[name][comp]["n_over_1e-4"] = int(len(over))
+            table[name][comp]["outliers"] = [[int(i), float("%.2e" % err[i])] for i in over[np.argsort(-err[over])][:24]]
     return table

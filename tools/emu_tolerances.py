@@ -27,6 +27,7 @@ def build(fp64):
     so = f"/tmp/libgrx_emu{'64' if fp64 else '32'}_tol.so"
     src = os.path.join(ROOT, "tests", "emu", "grx_emu.cpp")
     flags = ["-DGRX_EMU_FP64", "-DGRX_MPR_EPS=2.220446049250313e-16"] if fp64 else []
+    flags += [a for a in sys.argv if a.startswith("-D")]      # experiments: extra defines for the emulator build
     subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-misleading-indentation"] + flags + ["-o", so, src])
     return so
 

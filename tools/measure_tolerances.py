@@ -22,4 +22,4 @@ if __name__ == "__main__":
             if isinstance(q, dict):
                 print(f"{fam:18s} {comp:18s} p50 {q['p50']:.2e}  p90 {q['p90']:.2e}  p99 {q['p99']:.2e}  max {q['max']:.2e}  within 1e-4: {100 * q['frac_within_1e-4']:.1f} %"
                       f"  max away from activation boundaries {q['max_away_from_boundary'] if q['max_away_from_boundary'] is None else format(q['max_away_from_boundary'], '.2e')}"
-                      f"  (n = {row['n']}, away: {row['n_away_from_activation_boundary']})")
+                      f"  (n = {row['n']}, away: {row['n_away_from_activation_boundary']})" + (f"  outliers (snapshot, error): {q['outliers']}" if q["outliers"] else ""))
