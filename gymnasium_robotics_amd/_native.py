@@ -14,7 +14,7 @@ _lib = None
 
 class FetchBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed")]
+        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed", "hullcache")]
 
 
 class FetchResetArgsStruct(ctypes.Structure):

@@ -125,10 +125,14 @@ template <class S> static bool grx_shape_matches(const GrxModel& g) {
 }
 // last template argument: bit 0 = general convex routine for primitive pairs (ellipsoid / cylinder), bit 1 = hull-vs-convex pairs (every model with
 // collidable mesh geoms next to boxes / other meshes: all Fetch and Shadow-hand models)
-typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 144, 1984, 0, 32, 0, 2> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 144, 1984, 0, 32, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
-typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, 144, 1984, 0, 32, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, 144, 1984, 0, 32, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
+#ifndef GRX_FETCH_ME       // row / Jacobian-pool capacities the Fetch kernels are specialised for (envs/fetch.py FETCH_CAPACITY)
+#define GRX_FETCH_ME 144
+#define GRX_FETCH_JP 1984
+#endif
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 2> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
+typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
@@ -164,10 +168,12 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp (100 MHz), parked in the cost slot itself: nothing stays live across the substep loop
 #endif
   grx_load_world(m, b, c, w, lds, words, lane_);
+  if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) c.meshcache[lane_] = b.hullcache[(size_t)w * 21 + lane_];   // separating directions remembered from the previous step (re-verified before use)
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = b.aux[(size_t)w * 8 + k];
   GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_);
   const int wl = b.order ? b.order[grx_block_late()] : grx_world_of_block_late();
+  if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) b.hullcache[(size_t)wl * 21 + lane_] = c.meshcache[lane_];
   GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)wl * 8, b.obs + (size_t)wl * t.obs_dim, b.achieved + (size_t)wl * 3, lane_);
   __syncthreads();
   grx_store_world(m, t, b, c, wl, lane_);

@@ -46,7 +46,12 @@ def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledMo
     path = os.path.join(_MODELS_DIR, os.path.splitext(os.path.basename(xml))[0] + ".npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist (no packaged model and no assets_root given)")
-    return load_model(path)
+    model = load_model(path)
+    cap = os.environ.get("GRX_FETCH_CAP")     # experiments: "maxefc,jpool" other than the packaged capacities (needs a library built with -DGRX_FETCH_ME / -DGRX_FETCH_JP to stay on the specialised kernels)
+    if cap:
+        me, jp = (int(x) for x in cap.split(","))
+        model = model.with_capacity(maxefc=me, jpool=jp)
+    return model
 
 
 def sample_fetch_reset(cfg, rng, initial_gripper_xpos, height_offset):
@@ -159,10 +164,13 @@ class FetchVecEnv(GoalVecEnv):
             per = n // 8
             self._slice_base = (torch.arange(8, device=d, dtype=torch.int32) * per).unsqueeze(1)          # [8,1]
             self.order = (self._slice_base + torch.arange(per, device=d, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)   # workgroup b -> slice b & 7, position b >> 3
+        # the worlds' caches of separating directions (hull-vs-convex pairs), carried across launches: without it every env.step() starts with one portal
+        # search for the arm's permanently near pair (torso / shoulder link, 1.9 cm apart); a stale row is harmless (directions are re-verified)
+        self.hullcache = z(n, 21) if os.environ.get("GRX_NO_HULLCACHE") is None else None
         self._bufs = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action, self.obs,
-                                     self.achieved, self.reward, self.success, self.status, None, self.order, self.cost, self.packed)
+                                     self.achieved, self.reward, self.success, self.status, None, self.order, self.cost, self.packed, self.hullcache)
         self._bufs_masked = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action,
-                                            self.obs, self.achieved, self.reward, self.success, self.status, self.mask, self.order, self.cost, self.packed)
+                                            self.obs, self.achieved, self.reward, self.success, self.status, self.mask, self.order, self.cost, self.packed, self.hullcache)
 
     def _rebalance(self):
         """order <- per XCD slice, worlds by decreasing cost of the launch that just ran (in place: the buffer struct keeps its pointer)."""
