@@ -277,7 +277,7 @@ def run_rank(args, rank, world_size, local_rank):
         a = torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1
         obs, r, term, trunc, info = env.step(a)
         if her:
-            replay.append(a, env.packed, term | trunc)
+            replay.append(a, env.packed, term | trunc, final_rows=env.final_packed)   # the reset kernel parked the terminal rows there: the last transition of every episode is relabelled too
             replay.relabel(HER_K * n, k_future=HER_K)
         if dist:   # the step kernel wrote the packed [obs | achieved | desired | reward | success] rows: one collective, no pack kernels.
             # Stream-ordered, not pipelined: on one rank the collective costs 0.01 ms of the 3.3 ms step; an asynchronous gather from a staging copy, waited for two

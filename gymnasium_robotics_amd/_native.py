@@ -18,7 +18,7 @@ class FetchBuffersStruct(ctypes.Structure):
 
 
 class FetchResetArgsStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("idx", "samples", "init_qpos", "init_qvel", "init_mocap")] + [("obj_qadr", ctypes.c_int), ("keep_outcome", ctypes.c_int)]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("idx", "samples", "init_qpos", "init_qvel", "init_mocap")] + [("obj_qadr", ctypes.c_int), ("keep_outcome", ctypes.c_int), ("final_packed", ctypes.c_void_p)]
 
 
 class PointTaskStruct(ctypes.Structure):
@@ -54,7 +54,7 @@ class KitchenBuffersStruct(ctypes.Structure):
 class HerArgsStruct(ctypes.Structure):
     _fields_ = [("rows", ctypes.c_void_p), ("acts", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in ("T", "N", "W", "obs_dim", "goal_dim", "act_dim")] + [
         (n, ctypes.c_void_p) for n in ("t_idx", "w_idx", "t_goal")] + [("kind", ctypes.c_int), ("p0", ctypes.c_float), ("p1", ctypes.c_float)] + [
-        (n, ctypes.c_int) for n in ("sparse", "ignore_pos", "ignore_rot", "ignore_z")] + [("out", ctypes.c_void_p)]
+        (n, ctypes.c_int) for n in ("sparse", "ignore_pos", "ignore_rot", "ignore_z")] + [("out", ctypes.c_void_p), ("term_rows", ctypes.c_void_p), ("term_t", ctypes.c_void_p)]
 
 
 class MazeResetArgsStruct(ctypes.Structure):
@@ -97,6 +97,8 @@ def lib():
         L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_her_relabel.argtypes = [vp, ctypes.c_int64, vp]
         L.grx_her_sample.argtypes = [vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, vp, vp, vp, vp]
+        L.grx_her_sample_final.argtypes = [vp, vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, vp, vp, vp, vp]
+        L.grx_her_mark_resets.argtypes = [vp, ci, ci, vp, vp, vp, vp]
         L.grx_kitchen_step.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_sample_uniform_rows.argtypes = [vp, vp, ci, ci, vp]
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
@@ -121,5 +123,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
 ]

@@ -232,6 +232,7 @@ struct GrxFetchResetArgs {
   const float *init_qpos, *init_qvel, *init_mocap;   // [nq] [nv] [7*nmocap]: the state _env_setup left (fetch_env.py:404-428)
   int obj_qadr;            // qpos address of object0:joint, -1 without object
   int keep_outcome;        // same-step autoreset: reward / success (and the packed row's last two words) keep the finished episode's values
+  float* final_packed;     // [N, obs_dim + 8] or null: the packed row of world w (the finished episode's terminal row) is parked here before the reset overwrites it
 };
 template <class S>
 __global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))
@@ -241,6 +242,7 @@ grx_fetch_reset_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, GrxFetchRes
   if (k >= n_reset) return;
   const int w = r.idx[k];
   const GrxModel& m = g_grx_models[mslot];
+  if (r.final_packed && b.packed) { const int pw = t.obs_dim + 8; for (int i = lane_; i < pw; i += 64) r.final_packed[(size_t)w * pw + i] = b.packed[(size_t)w * pw + i]; }
   GrxCtx c;
   c.mslot = mslot;
   grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
@@ -668,7 +670,9 @@ struct GrxHerArgs {
   float p0, p1;        // kind 0 / 1: threshold; 2: goal radius; 3: position threshold, rotation threshold
   int sparse, ignore_pos, ignore_rot, ignore_z;
   float* out;
+  const float* term_rows; const int* term_t;   // terminal rows of the episodes that ended under same-step autoreset (include/grx_capi.h)
 };
+static_assert(sizeof(grx_her_args) == sizeof(GrxHerArgs), "grx_her_args must mirror GrxHerArgs");
 GRX_DEV void grx_her_outcome(const GrxHerArgs& a, const float* ag, const float* g, float* reward, float* success) {
   if (a.kind == 3) {
     float dp, dr;
@@ -691,9 +695,10 @@ grx_her_relabel_kernel(GrxHerArgs a, long long B) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B * OW; i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / OW; const int e = (int)(i - b * OW);
     const int R = a.T + 1, t = a.t_idx[b] % R, t1 = (a.t_idx[b] + 1) % R, w = a.w_idx[b], tg = a.t_goal[b];
+    const int tt = a.term_t ? a.term_t[w] : -1;   // the row index whose ring entry is the first row of a new episode; the terminal row is in term_rows[w]
     const float* r0 = a.rows + ((size_t)t * a.N + w) * a.W;
-    const float* r1 = a.rows + ((size_t)t1 * a.N + w) * a.W;
-    const float* g = tg < 0 ? r0 + od + gd : a.rows + ((size_t)(tg % R) * a.N + w) * a.W + od;   // the substituted goal: achieved at row tg
+    const float* r1 = (a.t_idx[b] + 1 == tt) ? a.term_rows + (size_t)w * a.W : a.rows + ((size_t)t1 * a.N + w) * a.W;
+    const float* g = tg < 0 ? r0 + od + gd : ((tg == tt ? a.term_rows + (size_t)w * a.W : a.rows + ((size_t)(tg % R) * a.N + w) * a.W) + od);   // the substituted goal: achieved at row tg
     float v;
     if (e < od + gd) v = r0[e];
     else if (e < od + 2 * gd) v = g[e - od - gd];
@@ -1076,6 +1081,7 @@ extern "C" int grx_her_relabel(const grx_her_args* args, int64_t batch, void* st
   if (!args) return fail("grx_her_relabel: null argument");
   GrxHerArgs a; memcpy(&a, args, sizeof(a));
   if (!a.rows || !a.acts || !a.t_idx || !a.w_idx || !a.t_goal || !a.out) return fail("grx_her_relabel: null buffer");
+  if ((a.term_rows == nullptr) != (a.term_t == nullptr)) return fail("grx_her_relabel: term_rows and term_t go together");
   if (a.T <= 0 || a.N <= 0 || a.obs_dim <= 0 || a.goal_dim <= 0 || a.goal_dim > 16 || a.act_dim <= 0 || a.W < a.obs_dim + 2 * a.goal_dim)
     return fail("grx_her_relabel: dimensions out of range (goal_dim <= 16, W >= obs_dim + 2 goal_dim)");
   if (a.kind < 0 || a.kind > 3 || (a.kind == 0 && a.goal_dim != 3) || (a.kind == 2 && a.goal_dim != 2) || (a.kind == 3 && a.goal_dim != 7))
@@ -1096,18 +1102,20 @@ static __device__ __forceinline__ unsigned long long grx_splitmix(unsigned long 
   return z ^ (z >> 31);
 }
 extern "C" __global__ void __launch_bounds__(256)
-grx_her_sample_kernel(const int* __restrict__ start, int N, int t_now, int T, int k_future, unsigned long long seed, unsigned long long call, long long B,
-                      int* __restrict__ t_idx, int* __restrict__ w_idx, int* __restrict__ t_goal) {
+grx_her_sample_kernel(const int* __restrict__ start, const int* __restrict__ prev_start, const int* __restrict__ term_t, int N, int t_now, int T, int k_future,
+                      unsigned long long seed, unsigned long long call, long long B, int* __restrict__ t_idx, int* __restrict__ w_idx, int* __restrict__ t_goal) {
   const int lo_min = t_now - T > 0 ? t_now - T : 0;
+  // first row of the episode world w is sampled from: its current one, or -- when that one began in this very step -- the one that has just ended
+#define GRX_HER_LO(W_) ((term_t && term_t[W_] == t_now) ? (prev_start[W_] > lo_min ? prev_start[W_] : lo_min) : (start[W_] > lo_min ? start[W_] : lo_min))
   for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
     unsigned long long s = seed * 0xD1342543DE82EF95ull + call * 0x2545F4914F6CDD1Dull + (unsigned long long)b;
     (void)grx_splitmix(s);
     int w = 0, lo = t_now;
     for (int attempt = 0; attempt < 64 && lo >= t_now; attempt++) {          // uniform over the worlds that have a transition (the caller made sure one exists)
       w = (int)(((grx_splitmix(s) >> 32) * (unsigned long long)N) >> 32);
-      lo = start[w] > lo_min ? start[w] : lo_min;
+      lo = GRX_HER_LO(w);
     }
-    for (int probe = 0; probe < N && lo >= t_now; probe++) { w = w + 1 < N ? w + 1 : 0; lo = start[w] > lo_min ? start[w] : lo_min; }
+    for (int probe = 0; probe < N && lo >= t_now; probe++) { w = w + 1 < N ? w + 1 : 0; lo = GRX_HER_LO(w); }
     const unsigned long long r = grx_splitmix(s), r2 = grx_splitmix(s);
     const float u0 = (float)(r >> 40) * (1.0f / 16777216.0f), u1 = (float)((r >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f), u2 = (float)(r2 >> 40) * (1.0f / 16777216.0f);
     int t = lo + (int)(u0 * (float)(t_now - lo));
@@ -1117,16 +1125,36 @@ grx_her_sample_kernel(const int* __restrict__ start, int N, int t_now, int T, in
     t_idx[b] = t; w_idx[b] = w;
     t_goal[b] = (u2 >= (float)k_future / ((float)k_future + 1.0f)) ? -1 : fut;
   }
+#undef GRX_HER_LO
 }
-extern "C" int grx_her_sample(const int* episode_start, int n_worlds, int t_now, int T, int k_future, uint64_t seed, uint64_t call, int64_t batch,
-                              int* t_idx, int* w_idx, int* t_goal, void* stream) {
+extern "C" int grx_her_sample_final(const int* episode_start, const int* prev_start, const int* term_t, int n_worlds, int t_now, int T, int k_future, uint64_t seed,
+                                    uint64_t call, int64_t batch, int* t_idx, int* w_idx, int* t_goal, void* stream) {
   if (!episode_start || !t_idx || !w_idx || !t_goal) return fail("grx_her_sample: null argument");
+  if ((prev_start == nullptr) != (term_t == nullptr)) return fail("grx_her_sample_final: prev_start and term_t go together");
   if (n_worlds <= 0 || T <= 0 || t_now <= 0 || k_future < 0) return fail("grx_her_sample: n_worlds, T and t_now must be positive, k_future >= 0");
   if (batch <= 0) return 0;
   long long blocks = (batch + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(grx_her_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, episode_start, n_worlds, t_now, T, k_future,
+  hipLaunchKernelGGL(grx_her_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, episode_start, prev_start, term_t, n_worlds, t_now, T, k_future,
                      (unsigned long long)seed, (unsigned long long)call, (long long)batch, t_idx, w_idx, t_goal);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+extern "C" int grx_her_sample(const int* episode_start, int n_worlds, int t_now, int T, int k_future, uint64_t seed, uint64_t call, int64_t batch,
+                              int* t_idx, int* w_idx, int* t_goal, void* stream) {
+  return grx_her_sample_final(episode_start, nullptr, nullptr, n_worlds, t_now, T, k_future, seed, call, batch, t_idx, w_idx, t_goal, stream);
+}
+extern "C" __global__ void __launch_bounds__(256)
+grx_her_mark_kernel(const unsigned char* __restrict__ mask, int N, int t, int* __restrict__ start, int* __restrict__ prev_start, int* __restrict__ term_t) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= N || !mask[w]) return;
+  if (prev_start) { prev_start[w] = start[w]; term_t[w] = t; }
+  start[w] = t;
+}
+extern "C" int grx_her_mark_resets(const unsigned char* reset_mask, int n_worlds, int t, int* episode_start, int* prev_start, int* term_t, void* stream) {
+  if (!reset_mask || !episode_start || n_worlds <= 0) return fail("grx_her_mark_resets: null argument");
+  if ((prev_start == nullptr) != (term_t == nullptr)) return fail("grx_her_mark_resets: prev_start and term_t go together");
+  hipLaunchKernelGGL(grx_her_mark_kernel, dim3((unsigned)((n_worlds + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reset_mask, n_worlds, t, episode_start, prev_start, term_t);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -156,6 +156,7 @@ class FetchVecEnv(GoalVecEnv):
         self.balance = bool(self.balance) and n % 8 == 0 and 1024 <= n <= 65536 * 8   # grx_order_by_cost sorts one XCD slice (n / 8 worlds, <= 65536) per workgroup in LDS
         self._reset_stage = z(n, 6)   # device side of the reset staging buffer (see _reset_worlds)
         self.packed = z(n, self.obs_dim + 8)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather, parallel.py)
+        self.final_packed = z(n, self.obs_dim + 8)   # same-step autoreset: row w = the TERMINAL packed row of world w's last finished episode (info["final_obs"], HerReplay.append(final_rows=...))
         self.cost = torch.zeros(n, dtype=torch.int32, device=d) if self.balance else None
         self.cost_ema = torch.zeros(n, dtype=torch.float32, device=d) if self.balance else None
         self.balance_alpha = float(os.environ.get("GRX_BALANCE_ALPHA", 0.1))   # weight of the newest sample in the moving average the order is sorted by (A/B on FetchPickAndPlace: 1.0 -> 2.69 ms, 0.15 -> 2.64 ms per step)
@@ -264,8 +265,9 @@ class FetchVecEnv(GoalVecEnv):
 
     def _launch_reset(self, staged, idx, keep_outcome=False):
         n, idx_dev, samples = staged
+        # same-step autoreset: the kernel parks the terminal packed row of every listed world in final_packed before it writes the reset observation
         args = _native.FetchResetArgsStruct(idx_dev.data_ptr(), samples.data_ptr(), self.initial_qpos.data_ptr(), self.initial_qvel.data_ptr(),
-                                            self._mocap0.data_ptr(), int(self._obj_qadr), int(keep_outcome))
+                                            self._mocap0.data_ptr(), int(self._obj_qadr), int(keep_outcome), self.final_packed.data_ptr() if keep_outcome else None)
         _native.check(self._L.grx_fetch_reset(self._h, ctypes.byref(self.task), ctypes.byref(self._bufs), ctypes.byref(args), n, self._stream()))
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
@@ -321,15 +323,15 @@ class FetchVecEnv(GoalVecEnv):
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
                 staged = self._stage_reset(done)
-                # the terminal observation, gathered (one kernel, from the packed rows) before the reset overwrites them; the reset kernel then
-                # leaves reward / success of these worlds at the finished episode's values (keep_outcome)
-                if self.output == "torch":
-                    fo = self.packed[staged[1].long()]
-                    info["final_obs"] = {"observation": fo[:, : self.obs_dim], "achieved_goal": fo[:, self.obs_dim: self.obs_dim + 3],
-                                         "desired_goal": fo[:, self.obs_dim + 3: self.obs_dim + 6]}
-                else:
+                # the reset kernel parks the terminal packed rows of these worlds in final_packed (info["final_obs"], the last transition for HER) and
+                # leaves reward / success at the finished episode's values (keep_outcome)
+                if self.output != "torch":
                     info["final_obs"] = self._obs_dict(rows=done)
                 self._launch_reset(staged, done, keep_outcome=True)
+                if self.output == "torch":
+                    fo = self.final_packed[staged[1].long()]
+                    info["final_obs"] = {"observation": fo[:, : self.obs_dim], "achieved_goal": fo[:, self.obs_dim: self.obs_dim + 3],
+                                         "desired_goal": fo[:, self.obs_dim + 3: self.obs_dim + 6]}
             elif self.autoreset_mode == "next_step":
                 self._needs_reset |= truncated
         obs = self._obs_dict()

@@ -68,6 +68,10 @@ class HerReplay:
         self.R = self.T + 1
         self.episode, self.actions = z(self.R, self.N, self.W), z(self.R, self.N, self.act_dim)   # actions[r] = the action that led to row r
         self.episode_start = z(self.N, dtype=torch.int32)
+        # same-step autoreset with final_rows (append): where world w's previous episode began, and the absolute row index its terminal row belongs to (-1: none)
+        self.prev_start, self.term_t = z(self.N, dtype=torch.int32), torch.full((self.N,), -1, dtype=torch.int32, device=self.device)
+        self._final_rows = None                    # the env's [N, W] buffer of terminal rows (e.g. FetchVecEnv.final_packed); read by the relabel kernel, never copied
+        self._just_ended = np.zeros(self.N, bool)  # host mirror of term_t == t
         self._start_host = np.zeros(self.N, np.int64)          # host mirror of episode_start: decides without a device sync whether anything can be sampled
         self.rows, self.capacity, self.head, self.size = z(int(capacity), self.OW), int(capacity), 0, 0
         self.t = 0                                 # absolute index of the newest row
@@ -81,12 +85,16 @@ class HerReplay:
     def begin_episode(self, packed_rows: torch.Tensor):
         self.episode[0].copy_(packed_rows)
         self.episode_start.zero_()
+        self.prev_start.zero_(); self.term_t.fill_(-1)
         self._start_host[:] = 0
+        self._just_ended[:] = False
         self.t = 0
 
-    def append(self, actions: torch.Tensor, packed_rows: torch.Tensor, reset_mask: Optional[torch.Tensor] = None):
-        """row t + 1 <- the rows of this step.  reset_mask (bool [N], device): worlds that were autoreset inside this step -- their row is the first one
-        of a new episode (the finished episode's last next-observation went to info["final_obs"], that transition is not stored)."""
+    def append(self, actions: torch.Tensor, packed_rows: torch.Tensor, reset_mask: Optional[torch.Tensor] = None, final_rows: Optional[torch.Tensor] = None):
+        """row t + 1 <- the rows of this step.  reset_mask (bool [N]): worlds that were autoreset inside this step -- their row is the first one of a new
+        episode.  final_rows ([N, W] device buffer whose row w holds the TERMINAL packed row of a world reset in this step, e.g. FetchVecEnv.final_packed):
+        the finished episode stays sampleable for this one step WITH its last transition (next observation = the terminal row), which is how a replay that
+        stores whole episodes sees it (/root/reference/README.md:66-76).  Without final_rows that last transition is not stored."""
         if self.t >= self.T and not self.continuous:
             raise RuntimeError("episode buffer is full: call begin_episode()")
         self.t += 1
@@ -108,7 +116,15 @@ class HerReplay:
                 dev.copy_(slot["buf"], non_blocking=True)
                 slot["event"] = torch.cuda.Event()
                 slot["event"].record(torch.cuda.current_stream(self.device))
-            self.episode_start.masked_fill_(dev, self.t)
+            if final_rows is not None:
+                assert tuple(final_rows.shape) == (self.N, self.W) and final_rows.is_contiguous()
+                self._final_rows = final_rows
+            track = self._final_rows is not None
+            self._just_ended = host.astype(bool) if track else self._just_ended
+            _native.check(self._L.grx_her_mark_resets(dev.data_ptr(), self.N, self.t, self.episode_start.data_ptr(), self.prev_start.data_ptr() if track else None,
+                                                      self.term_t.data_ptr() if track else None, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        elif self._final_rows is not None:
+            self._just_ended = np.zeros(self.N, bool)
 
     def set_episode_start(self, starts):
         """absolute row at which every world's current episode began (e.g. negative values for episodes that were already under way at row 0)"""
@@ -125,11 +141,13 @@ class HerReplay:
         probability k / (k + 1) the goal achieved at a uniformly drawn LATER row of the same episode (the "future" strategy of Andrychowicz et al.
         2017), else -1 = keep the episode's goal.  Worlds whose episode has no transition yet (just reset) are not drawn.  One kernel
         (grx_her_sample) with a counter-based generator; None when nothing can be sampled."""
-        if not (np.maximum(self._start_host, max(self.t - self.T, 0)) < self.t).any():
+        track = self._final_rows is not None
+        if not ((np.maximum(self._start_host, max(self.t - self.T, 0)) < self.t) | (self._just_ended if track else False)).any():
             return None                                                                   # every world has just been reset: nothing to sample
         t, w, tg = (torch.empty(batch, dtype=torch.int32, device=self.device) for _ in range(3))
-        _native.check(self._L.grx_her_sample(self.episode_start.data_ptr(), self.N, self.t, self.T, int(k_future), self._seed, self._calls, batch,
-                                             t.data_ptr(), w.data_ptr(), tg.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        _native.check(self._L.grx_her_sample_final(self.episode_start.data_ptr(), self.prev_start.data_ptr() if track else None, self.term_t.data_ptr() if track else None,
+                                                   self.N, self.t, self.T, int(k_future), self._seed, self._calls, batch,
+                                                   t.data_ptr(), w.data_ptr(), tg.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         self._calls += 1
         return t, w, tg
 
@@ -139,6 +157,8 @@ class HerReplay:
         a.rows, a.acts = self.episode.data_ptr(), self.actions.data_ptr()
         a.T, a.N, a.W, a.obs_dim, a.goal_dim, a.act_dim = self.T, self.N, self.W, self.obs_dim, self.goal_dim, self.act_dim   # ring of T + 1 rows
         a.t_idx, a.w_idx, a.t_goal, a.out = t.data_ptr(), w.data_ptr(), t_goal.data_ptr(), out.data_ptr()
+        if self._final_rows is not None:
+            a.term_rows, a.term_t = self._final_rows.data_ptr(), self.term_t.data_ptr()
         for k, v in self.spec.items():
             setattr(a, k, v)
         assert out.is_contiguous() and tuple(out.shape) == (len(t), self.OW) and t.dtype == w.dtype == t_goal.dtype == torch.int32

@@ -197,6 +197,9 @@ typedef struct grx_fetch_reset_args {
   const float *init_qpos, *init_qvel, *init_mocap; /* [nq] [nv] [7*nmocap]: the state _env_setup left (fetch_env.py:404-428) */
   int obj_qadr;          /* qpos address of object0:joint, -1 for the tasks without object */
   int keep_outcome;      /* != 0 (same-step autoreset): reward[w] / success[w] and the last two words of the packed row keep the finished episode's values */
+  float* final_packed;   /* [N, obs_dim + 8] or NULL: before world w's packed row is overwritten by the reset observation, the row the step kernel wrote (the TERMINAL
+                          * observation / achieved goal / goal / reward / success of the finished episode) is parked in final_packed[w]: info["final_obs"] and the last
+                          * transition of the episode for the HER buffer (grx_her_args.term_rows) read it from there */
 } grx_fetch_reset_args;
 int grx_fetch_reset(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, const grx_fetch_reset_args* args, int n_reset, void* stream);
 /* order <- the dispatch order for the next step launch from the per-world costs the last one wrote (grx_fetch_buffers.cost /
@@ -248,6 +251,10 @@ typedef struct grx_her_args {
   float p0, p1;                        /* 0 / 1: distance_threshold; 2: goal radius 0.45; 3: distance_threshold, rotation_threshold */
   int sparse, ignore_pos, ignore_rot, ignore_z;
   float* out;                          /* [batch, 2 obs_dim + 3 goal_dim + act_dim + 2] */
+  /* Same-step autoreset: the ring row of the step that resets world w already holds the FIRST row of w's new episode, the terminal row of the episode that just
+   * ended is in term_rows[w] ([N, W], e.g. grx_fetch_reset_args.final_packed) and term_t[w] = the absolute row index it belongs to.  A sample whose next row
+   * (t_idx + 1) or goal row (t_goal) equals term_t[w] reads the terminal row: the LAST transition of every episode is relabelled like any other.  Both NULL: off. */
+  const float* term_rows; const int* term_t;
 } grx_her_args;
 int grx_her_relabel(const grx_her_args* args, int64_t batch, void* stream);
 /* The index draws of HER's "future" strategy (Andrychowicz et al. 2017) for `batch` samples in one kernel: a uniform world among those whose current
@@ -256,6 +263,13 @@ int grx_her_relabel(const grx_her_args* args, int64_t batch, void* stream);
  * generator: the same (seed, call) pair reproduces the same draws.  All pointers are device pointers. */
 int grx_her_sample(const int* episode_start, int n_worlds, int t_now, int T, int k_future, uint64_t seed, uint64_t call, int64_t batch,
                    int* t_idx, int* w_idx, int* t_goal, void* stream);
+/* The same with finished episodes: a world whose episode ended in THIS step (term_t[w] == t_now, see grx_her_args) is sampled from the episode that just ended
+ * (rows prev_start[w] .. t_now, the last one being the terminal row) instead of being skipped; identical draws for every other world. */
+int grx_her_sample_final(const int* episode_start, const int* prev_start, const int* term_t, int n_worlds, int t_now, int T, int k_future, uint64_t seed, uint64_t call,
+                         int64_t batch, int* t_idx, int* w_idx, int* t_goal, void* stream);
+/* Episode bookkeeping of the worlds reset in the step that produced row t (reset_mask[w] != 0): prev_start[w] <- episode_start[w], term_t[w] <- t,
+ * episode_start[w] <- t.  One kernel.  prev_start / term_t may be NULL (then only episode_start is updated). */
+int grx_her_mark_resets(const unsigned char* reset_mask, int n_worlds, int t, int* episode_start, int* prev_start, int* term_t, void* stream);
 
 /* Episode reset of a COMPACTED list of maze worlds (maze/point_maze.py:377-390 / ant_maze_v5.py reset_model, maze_v4.py:299-358: qpos = init_qpos with
  * xy <- the drawn reset position, qvel = 0, new goal, observation of the reset state): one kernel writes state, goal, obs / achieved / success and the

@@ -178,3 +178,76 @@ def test_index_sampler_distribution():
     buf.reseed(9)
     t3, w3, tg3 = (x.cpu().numpy() for x in buf.sample_indices(B, 4))
     assert np.array_equal(t3, t) and np.array_equal(w3, w) and np.array_equal(tg3, tg)
+
+
+def test_last_transition_of_every_episode_is_stored_under_same_step_autoreset():
+    """README.md:66-76 / core.py:45-67: a HER replay sees WHOLE episodes.  Under same-step autoreset the row a world writes in the step that resets it is the
+    first row of its new episode; the reset kernel parks the terminal row (FetchVecEnv.final_packed) and HerReplay.append(final_rows=...) keeps the finished
+    episode sampleable for that one step, last transition included.  Checked against a numpy HER over a complete host-side log (terminal rows from
+    info["final_obs"])."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+    from gymnasium_robotics_amd.her import HerReplay
+
+    n, H, steps = 32, 10, 40              # staggered: in every step n / H worlds reach their time limit
+    env = grx.make_vec("FetchPush-v4", num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=H)
+    buf = HerReplay(env, horizon=H, capacity=8192, seed=5, continuous=True)
+    env.reset(seed=0)
+    env._elapsed[:] = np.arange(n) % H
+    buf.begin_episode(env.packed)
+    L, A = [env.packed.cpu().numpy().copy()], [np.zeros((n, 4), np.float32)]
+    starts, prev, term_t, term_rows = np.zeros(n, np.int64), np.zeros(n, np.int64), -np.ones(n, np.int64), np.zeros((n, env.packed.shape[1]), np.float32)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(2)
+    o, gd = buf.obs_dim, buf.goal_dim
+    for t in range(steps):
+        a = torch.rand(n, 4, device="cuda:0", generator=g) * 2 - 1
+        _, r, term, trunc, info = env.step(a)
+        done = (term | trunc).numpy()
+        buf.append(a, env.packed, term | trunc, final_rows=env.final_packed)
+        L.append(env.packed.cpu().numpy().copy()); A.append(a.cpu().numpy().copy())
+        if done.any():
+            fo = info["final_obs"]
+            rows = np.nonzero(done)[0]
+            fp = env.final_packed.cpu().numpy()
+            assert np.array_equal(fp[rows, :o], fo["observation"].cpu().numpy()) and np.array_equal(fp[rows, o: o + gd], fo["achieved_goal"].cpu().numpy())
+            assert np.array_equal(fp[rows, -2], r.cpu().numpy()[rows])         # the reported reward of the step IS the terminal row's
+            prev[rows], term_t[rows], starts[rows], term_rows[rows] = starts[rows], t + 1, t + 1, fp[rows]
+    assert np.array_equal(buf.episode_start.cpu().numpy(), starts) and np.array_equal(buf.term_t.cpu().numpy(), term_t) and np.array_equal(buf.prev_start.cpu().numpy(), prev)
+    just = term_t == steps
+    assert just.sum() == n // H + (1 if n % H > (steps - 1) % H else 0) or just.sum() >= 3
+    B = 4096
+    rows = buf.relabel(B).clone()
+    buf.reseed(5)
+    t, w, tg = (x.cpu().numpy().astype(np.int64) for x in buf.sample_indices(B, 4))
+    lo = np.where(just[w], np.maximum(prev[w], steps - H), np.maximum(starts[w], steps - H))
+    assert np.all(t >= lo) and np.all(t < steps) and np.all((tg < 0) | ((tg > t) & (tg <= steps)))
+    assert just[w].any() and (~just[w]).any()
+    Ls, As = np.stack(L), np.stack(A)
+    row_at = lambda tt, ww: np.where(((tt == term_t[ww]) & just[ww])[:, None], term_rows[ww], Ls[tt, ww])     # the finished episode's row `steps` is its terminal row
+    r0, r1 = Ls[t, w], row_at(t + 1, w)
+    goal = np.where((tg >= 0)[:, None], row_at(np.maximum(tg, 0), w)[:, o: o + gd], r0[:, o + gd: o + 2 * gd])
+    got = {k: v.cpu().numpy() for k, v in buf.split(rows).items()}
+    assert np.array_equal(got["observation"], r0[:, :o]) and np.array_equal(got["next_observation"], r1[:, :o]) and np.array_equal(got["next_achieved_goal"], r1[:, o: o + gd])
+    assert np.array_equal(got["action"], As[t + 1, w]) and np.array_equal(got["desired_goal"], goal)
+    last = just[w] & (t == steps - 1)
+    assert last.sum() > 0, "the last transition of a just-finished episode must be drawn"
+    assert not np.array_equal(r1[last][:, :o], Ls[steps, w[last]][:, :o])                # ... and its next observation is the terminal one, not the reset one
+    own = last & (tg < 0)
+    if own.any():                                                                          # un-relabelled: the reward the env reported for that step
+        assert np.array_equal(got["reward"][own, 0], term_rows[w[own], -2]) and np.array_equal(got["success"][own, 0], term_rows[w[own], -1])
+    d = np.linalg.norm(r1[:, o: o + gd].astype(np.float64) - goal, axis=1)
+    far = np.abs(d - 0.05) > 1e-6
+    assert np.array_equal(got["reward"][far, 0], -(d[far] > 0.05).astype(np.float32))        # fetch_env.py:74-80, sparse
+    # a world that resets in a step is no longer skipped: the buffer always has something to sample
+    env2 = grx.make_vec("FetchReach-v4", num_envs=8, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=3)
+    b2 = HerReplay(env2, horizon=3, capacity=256, continuous=True)
+    env2.reset(seed=0)
+    b2.begin_episode(env2.packed)
+    sizes = []
+    for k in range(7):
+        z = torch.zeros(8, 4, device="cuda:0")
+        _, _, term, trunc, _ = env2.step(z)
+        b2.append(z, env2.packed, term | trunc, final_rows=env2.final_packed)
+        sizes.append(len(b2.relabel(32)))
+    assert sizes == [32] * 7
