@@ -10,6 +10,16 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mujoco_*.npz")))
+REQUIRE = os.environ.get("GRX_REQUIRE_MUJOCO_GOLDEN", "0") not in ("", "0")
+
+
+def test_mujoco_fixtures_are_present_when_required():
+    """GRX_REQUIRE_MUJOCO_GOLDEN=1: the absence of the MuJoCo-recorded fixtures is a FAILURE, not a skip (until they exist every "1e-4" in this
+    repo means "against the in-repo fp64 restatement", tools/record_golden.py is the one-command recorder)."""
+    if REQUIRE:
+        assert FILES, "GRX_REQUIRE_MUJOCO_GOLDEN is set but tests/golden/mujoco_*.npz do not exist: run `python tools/record_golden.py` where mujoco + gymnasium-robotics are installed"
+    elif not FILES:
+        pytest.skip("no MuJoCo-recorded fixtures committed; parity stays pinned to the in-repo oracle only (set GRX_REQUIRE_MUJOCO_GOLDEN=1 to make this a failure)")
 
 
 @pytest.mark.skipif(not FILES, reason="no MuJoCo-recorded fixtures committed (tools/record_golden.py needs mujoco + gymnasium)")

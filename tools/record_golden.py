@@ -1,15 +1,18 @@
-"""Record TRUE-MuJoCo teacher-forcing fixtures with the reference itself.
+"""Record TRUE-MuJoCo teacher-forcing fixtures with the reference itself -- ONE command on any machine that has the reference:
 
-NOT runnable in the build image (neither `mujoco` nor `gymnasium` is installed there, and there is no network): run it on a
-machine with `pip install gymnasium-robotics mujoco`, commit the produced `tests/golden/mujoco_<id>.npz`, and
-`tests/test_gpu_mujoco_golden.py` will compare the HIP path against them (it skips while the files are absent).  That turns the
-oracle's "parity unpinned" status into parity pinned against the reference.
+    pip install gymnasium-robotics mujoco
+    python record_golden.py [--out DIR] [env ids ...]          # default DIR: <this file>/../tests/golden if it exists, else ./golden
 
-    python tools/record_golden.py [env ids ...]
+The script is SELF-CONTAINED (imports only numpy, gymnasium, gymnasium_robotics, mujoco: copy this one file anywhere) and prints the MuJoCo / gymnasium-robotics
+versions and a SHA-256 per fixture.  It cannot run in the build image (no mujoco / gymnasium wheel, no network).  Commit the produced
+`tests/golden/mujoco_<id>.npz`: `tests/test_gpu_mujoco_golden.py` (HIP path) and `tests/test_cpu_mujoco_golden.py` (oracle) then compare against them, which turns
+the oracle's "parity unpinned" status into parity pinned against the reference.  `GRX_REQUIRE_MUJOCO_GOLDEN=1` makes both test files FAIL instead of skip
+while no fixture is committed (CI of a machine that is supposed to have them).
 
 Each fixture holds, per snapshot: the full pre-step MjData state the device kernels take as input (qpos, qvel, qacc_warmstart,
 mocap pose, the stale gripper-body pose the Fetch _set_action reads), the goal, the action, and the reference's outputs
-(observation, achieved goal, reward, success), plus `mujoco.__version__`.
+(observation, achieved goal, reward, success), plus `mujoco.__version__` (libccd MPR up to 3.1, the native GJK / EPA collider later: the convex-pair
+families -- FetchSlide, the egg, Adroit pen / hammer, FrankaKitchen -- depend on it).
 """
 import sys
 
@@ -17,7 +20,10 @@ import numpy as np
 
 DEFAULT_IDS = ["FetchReach-v4", "FetchPush-v4", "FetchSlide-v4", "FetchPickAndPlace-v4", "HandReach-v3", "HandManipulateBlockRotateXYZ-v1",
                "HandManipulateEggRotate-v1", "HandManipulatePenRotate-v1",   # Slide / Egg exercise MuJoCo's convex collider: record mujoco.__version__ (libccd MPR <= 3.1, native GJK/EPA later)
-               "AdroitHandHammer-v2", "AdroitHandDoor-v2", "AdroitHandPen-v2", "AdroitHandRelocate-v2", "FrankaKitchen-v1", "AntMaze_UMaze-v5", "PointMaze_UMaze-v3"]
+               "HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1",      # BASELINE configs[2]: the 153-word observation
+               "AdroitHandHammer-v2", "AdroitHandDoor-v2", "AdroitHandPen-v2", "AdroitHandRelocate-v2", "FrankaKitchen-v1", "AntMaze_UMaze-v5",
+               "AntMaze_Large_Diverse_GR-v5",                                  # BASELINE configs[3] itself
+               "PointMaze_UMaze-v3"]
 
 
 def record_plain(env_id, episodes=6, steps=50, seed0=0):
@@ -95,11 +101,26 @@ def record(env_id, episodes=6, steps=50, seed0=0):
 
 
 if __name__ == "__main__":
+    import hashlib
     import os
 
-    out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
-    for env_id in (sys.argv[1:] or DEFAULT_IDS):
+    args = sys.argv[1:]
+    here = os.path.dirname(os.path.abspath(__file__))
+    out_dir = os.path.join(here, "..", "tests", "golden") if os.path.isdir(os.path.join(here, "..", "tests", "golden")) else os.path.join(os.getcwd(), "golden")
+    if "--out" in args:
+        k = args.index("--out")
+        out_dir = args[k + 1]
+        del args[k: k + 2]
+    os.makedirs(out_dir, exist_ok=True)
+    import gymnasium
+    import gymnasium_robotics
+    import mujoco
+
+    print(f"mujoco {mujoco.__version__}, gymnasium {gymnasium.__version__}, gymnasium-robotics {getattr(gymnasium_robotics, '__version__', '?')}, numpy {np.__version__}")
+    for env_id in (args or DEFAULT_IDS):
         d = record(env_id) if env_id.startswith(("Fetch", "HandReach", "HandManipulate")) else record_plain(env_id)
         path = os.path.join(out_dir, f"mujoco_{env_id}.npz")
         np.savez_compressed(path, **d)
-        print(env_id, d["obs"].shape, "->", path)
+        with open(path, "rb") as f:
+            digest = hashlib.sha256(f.read()).hexdigest()
+        print(f"{env_id}: {d['obs'].shape[0]} snapshots x obs {d['obs'].shape[1]} (nq {int(d['nq'])}, nv {int(d['nv'])}) -> {path}  sha256 {digest}")
