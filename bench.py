@@ -75,6 +75,49 @@ def make_env(workload, n, device, rank):
     return Env(w["env_id"], **kw)
 
 
+class _DryEnv:
+    """--dry-run: a stand-in with the vector envs' attribute surface and row shapes but NO physics (random rows on the CPU), so that everything around the step
+    kernels -- launcher, rendezvous, world sharding by seed_offset, the per-step collective on the kernel-written rows, timing, the per-rank report, the JSON
+    line -- runs in a GPU-less container over gloo (tests/test_cpu_dist.py) with the exact command line the driver uses on the 8-GPU node."""
+
+    def __init__(self, workload, n, rank):
+        import types
+
+        w = WORKLOADS[workload]
+        self.num_envs, self.max_episode_steps, self.seed_offset = n, w["horizon"], rank * n
+        act = {"fetch": 4, "antmaze": 8, "kitchen": 9, "hand_reach": 20, "hand_touch": 20}.get(workload, 28)
+        self.single_action_space = types.SimpleNamespace(shape=(act,))
+        width = {"fetch": 33, "antmaze": 33, "hand_reach": 95, "hand_touch": 169, "kitchen": 59}.get(workload, 46)
+        if workload in ("fetch", "antmaze", "hand_reach", "hand_touch"):
+            self.packed = torch.zeros(n, width)
+        else:
+            self.obs = torch.zeros(n, width)
+        self._elapsed = np.zeros(n, np.int64)
+        self.kernel_events = None
+        self._gen = torch.Generator().manual_seed(rank)
+
+    def reset(self, seed=None):
+        return None, {}
+
+    def step(self, a):
+        rows = getattr(self, "packed", None)
+        rows = self.obs if rows is None else rows
+        rows.copy_(torch.rand(rows.shape, generator=self._gen))
+        rows[:, 0] = torch.arange(self.num_envs, dtype=torch.float32) + self.seed_offset      # world id in column 0: the gathered matrix must be in world order
+        self._elapsed += 1
+        trunc = torch.from_numpy(self._elapsed >= self.max_episode_steps)
+        self._elapsed[trunc.numpy()] = 0
+        if self.kernel_events is not None:
+            self.kernel_events.append((0.0, 0.0))
+        return None, None, torch.zeros(self.num_envs, dtype=torch.bool), trunc, {}
+
+    def clear_status(self):
+        pass
+
+    def status_counts(self):
+        return {"badnum": 0, "con_overflow": 0, "efc_overflow": 0, "factor": 0, "worlds": self.num_envs}
+
+
 # ---------------------------------------------------------------------------------------------- CPU baseline (oracle, test infrastructure)
 def _oracle_env(workload):
     if workload == "fetch":
@@ -145,48 +188,57 @@ def cpu_baseline(workload, seconds=8.0):
 # ---------------------------------------------------------------------------------------------- cfg 5: two families in one job
 def run_rank_mixed(args, rank, world_size, local_rank):
     """BASELINE cfg 5: every rank steps n/2 FrankaKitchen worlds and n/2 AdroitHandHammer worlds.  The two environments are independent (no data
-    dependence), so each is driven by its own host thread on its own HIP stream and the two step kernels share the GPU; one vector "step" =
-    one env.step() of both halves (the threads meet at the end of every step), followed by one all-gather per family of the rows the kernels wrote."""
-    from concurrent.futures import ThreadPoolExecutor
+    dependence): ONE host thread enqueues both on their own HIP streams -- the kitchen step is launched (KitchenVecEnv.step_launch: no host sync), then the
+    whole Adroit step, then the kitchen step is finished (its completion bits are the one read-back) -- so the two step kernels share the GPU; one vector
+    "step" = one env.step() of both halves, followed by one all-gather per family of the rows the kernels wrote."""
+    import contextlib
 
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    dry = args.dry_run
+    device = "cpu" if dry else f"cuda:{local_rank}"
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    if not dry:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
     n = args.worlds_per_gpu or MIXED_WORLDS
     half = n // 2
     envs, streams, gens, gathered = [], [], [], []
     for k, name in enumerate(MIXED):
-        env = make_env(name, half, device, rank)
+        env = _DryEnv(name, half, rank) if dry else make_env(name, half, device, rank)
         env.reset(seed=0)
         if args.stagger:
             env._elapsed[:] = np.arange(half) % (env.max_episode_steps or WORKLOADS[name]["horizon"])
         g = torch.Generator(device=device)
         g.manual_seed(1234 + 2 * rank + k)
-        envs.append(env); streams.append(torch.cuda.Stream(device=device)); gens.append(g)
+        envs.append(env); streams.append(None if dry else torch.cuda.Stream(device=device)); gens.append(g)
         gathered.append(torch.empty(half * world_size, env.obs.shape[1], device=device) if dist else None)
-    torch.cuda.synchronize()
-
-    def half_step(k):
-        torch.cuda.set_device(local_rank)
-        with torch.cuda.stream(streams[k]):
-            a = torch.rand(half, envs[k].single_action_space.shape[0], device=device, generator=gens[k]) * 2 - 1
-            envs[k].step(a)
-
-    pool = ThreadPoolExecutor(2)
+    sync()
+    on = (lambda k: contextlib.nullcontext()) if dry else (lambda k: torch.cuda.stream(streams[k]))
+    act = lambda k: torch.rand(half, envs[k].single_action_space.shape[0], device=device, generator=gens[k]) * 2 - 1
 
     def one_step():
-        list(pool.map(half_step, range(2)))
+        with on(0):     # FrankaKitchen: enqueue only
+            (envs[0].step if dry else envs[0].step_launch)(act(0))
+        with on(1):     # AdroitHandHammer: its step never waits for the device
+            envs[1].step(act(1))
+        if not dry:
+            with on(0):
+                envs[0].step_finish()
         if dist:
             for k in range(2):
-                torch.cuda.current_stream().wait_stream(streams[k])
+                if not dry:
+                    torch.cuda.current_stream().wait_stream(streams[k])
                 dist.all_gather_into_tensor(gathered[k], envs[k].obs)
             for k in range(2):
-                streams[k].wait_stream(torch.cuda.current_stream())
+                if not dry:
+                    streams[k].wait_stream(torch.cuda.current_stream())
 
     for _ in range(args.warmup):
         one_step()
@@ -195,31 +247,38 @@ def run_rank_mixed(args, rank, world_size, local_rank):
         env.kernel_events = []
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    pool.shutdown()
-    kern_ms = [float(np.mean([a.elapsed_time(b) for a, b in env.kernel_events])) for env in envs]
+    kern_ms = [float(np.mean([0.0 if dry else a.elapsed_time(b) for a, b in env.kernel_events])) for env in envs]
     counts = [env.status_counts() for env in envs]
+    dist_report = None
+    if dist:
+        from gymnasium_robotics_amd.parallel import rank_stats
+
+        dist_report = rank_stats({"kernel_ms_" + MIXED[0]: kern_ms[0], "kernel_ms_" + MIXED[1]: kern_ms[1], "elapsed_s": own_elapsed}, device)
+        if dry:
+            for k in range(2):
+                assert torch.equal(gathered[k][:, 0], torch.arange(half * world_size, dtype=torch.float32)), "gathered rows are not in world order"
     line = None
     if rank == 0:
         w = WORKLOADS[MIXED[0]]     # the dominant kernel: the kitchen step (40 substeps against 5)
-        achieved = w["algo"] * half / (kern_ms[0] * 1e-3) / 1e9
+        achieved = 0.0 if dry else w["algo"] * half / (kern_ms[0] * 1e-3) / 1e9
         line = {
             "metric": "env-steps/s (whole node)", "value": n * world_size * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"mixed batch: {half} FrankaKitchen-v1 (multitask, default noise) + {half} AdroitHandHammer-v2 worlds/GPU x {world_size} GPU, uniform random "
-                                   "actions, same-step autoreset at the time limits, the two families on two streams / two host threads",
+                                   "actions, same-step autoreset at the time limits, the two families on two streams driven by one host thread",
                        "worlds_per_gpu": n, "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather per family of the kernel-written rows per step" if world_size > 1 else ""),
                        "capacity_overflow_worlds": sum(c["con_overflow"] + c["efc_overflow"] for c in counts), "badnum_worlds": sum(c["badnum"] for c in counts),
                        "kernel_ms": {MIXED[k]: kern_ms[k] for k in range(2)}},
@@ -227,7 +286,11 @@ def run_rank_mixed(args, rank, world_size, local_rank):
                          "kernel": w["kernel"], "kernel_ms": kern_ms[0], "algorithmic_bytes_per_launch": w["algo"] * half,
                          "note": "duration measured while the Adroit step kernel shares the GPU; the single-family lines (--workload kitchen / adroit) carry the PMC traffic"},
         }
-        if world_size == 1 and not args.no_cpu_baseline:
+        if dist_report is not None:
+            line["dist"] = dist_report
+        if dry:
+            line["data"] = "DRY RUN: no physics, random rows on the CPU over gloo (plumbing check of the multi-rank command line)"
+        if world_size == 1 and not args.no_cpu_baseline and not dry:
             parts = [cpu_baseline(name, seconds=5.0) for name in MIXED]
             mix = lambda key: 2.0 / sum(1.0 / p[key] for p in parts)      # a mixed batch = equal numbers of steps of both families
             line["cpu_baseline"] = {"value": mix("value"), "unit": "env-steps/s", "cores": 1, "kind": "port", "value_all_cores": mix("value_all_cores"),
@@ -242,16 +305,22 @@ def run_rank(args, rank, world_size, local_rank):
     if args.workload == "mixed":
         return run_rank_mixed(args, rank, world_size, local_rank)
     w = WORKLOADS[args.workload]
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    dry = args.dry_run
+    device = "cpu" if dry else f"cuda:{local_rank}"
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    if not dry:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1 or os.environ.get("GRX_BENCH_FORCE_DIST"):      # the env var runs the collective leg on a single rank (1-GPU boxes: tools/ab_dist.sh)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
     n = args.worlds_per_gpu or w["worlds"]
-    env = make_env(args.workload, n, device, rank)
+    env = _DryEnv(args.workload, n, rank) if dry else make_env(args.workload, n, device, rank)
     env.reset(seed=0)
     if args.stagger:   # steady state: every step resets its share of the worlds (world i is i mod horizon steps into its episode)
         env._elapsed[:] = np.arange(n) % (env.max_episode_steps or w["horizon"])
@@ -262,7 +331,7 @@ def run_rank(args, rank, world_size, local_rank):
     if out_rows is None:
         out_rows = env.obs   # plain (non-goal) environments: the observation rows are the per-step output
     gathered = torch.empty(n * world_size, out_rows.shape[1], device=device) if dist else None
-    her = args.workload == "fetch"
+    her = args.workload == "fetch" and not dry
     # HER "future" relabelling on the device (gymnasium_robotics_amd/her.py): the packed rows of the last `horizon` steps stay in an HBM ring; every
     # step ONE kernel gathers HER_K relabelled transitions per world (goal substitution + reward recompute + replay write)
     replay = None
@@ -290,19 +359,26 @@ def run_rank(args, rank, world_size, local_rank):
     env.kernel_events = []   # HIP events (torch's current stream = the launch stream) around every step-kernel launch of the timed region
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in env.kernel_events]))
+    kern_ms = float(np.mean([0.0 if dry else a.elapsed_time(b) for a, b in env.kernel_events]))
+    dist_report = None
+    if dist:   # the rank count as the collective library reports it + every rank's kernel / wall time (a slow rank, a rank that fell back to another device: visible in the line)
+        from gymnasium_robotics_amd.parallel import rank_stats
+
+        dist_report = rank_stats({"kernel_ms": kern_ms, "elapsed_s": own_elapsed}, device)
+        if dry:
+            assert gathered is not None and torch.equal(gathered[:, 0], torch.arange(n * world_size, dtype=torch.float32)), "gathered rows are not in world order"
     counts = env.status_counts()
 
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE
@@ -317,7 +393,7 @@ def run_rank(args, rank, world_size, local_rank):
     line = None
     if rank == 0:
         value = n * world_size * args.steps / elapsed
-        achieved = w["algo"] * n / (kern_ms * 1e-3) / 1e9
+        achieved = w["algo"] * n / (max(kern_ms, 1e-9) * 1e-3) / 1e9 if not dry else 0.0
         line = {
             "metric": "env-steps/s (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -333,7 +409,11 @@ def run_rank(args, rank, world_size, local_rank):
                          "algorithmic_bytes_per_launch": w["algo"] * n,
                          "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 5"},
         }
-        if world_size == 1 and not args.no_cpu_baseline:
+        if dist_report is not None:
+            line["dist"] = dist_report
+        if dry:
+            line["data"] = "DRY RUN: no physics, random rows on the CPU over gloo (plumbing check of the multi-rank command line)"
+        if world_size == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(args.workload)
     if dist:
         dist.destroy_process_group()
@@ -357,6 +437,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["mixed"], default="fetch")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU, no physics: random rows on the CPU over gloo -- checks the multi-rank plumbing of this exact command line")
     args = ap.parse_args()
 
     if "WORLD_SIZE" in os.environ:   # started by torchrun: one rank per process already
@@ -368,7 +449,7 @@ def main():
             print(json.dumps(line), flush=True)
         return
     if args.gpus > 1:   # plain `python bench.py --gpus N`: become the launcher (one process per GPU, RCCL over xGMI)
-        avail = torch.cuda.device_count()
+        avail = args.gpus if args.dry_run else torch.cuda.device_count()
         if avail < args.gpus:
             raise SystemExit(f"--gpus {args.gpus} requested but only {avail} HIP device(s) are visible")
         import torch.multiprocessing as mp

@@ -176,13 +176,20 @@ class KitchenVecEnv(GoalVecEnv):
 
     # ------------------------------------------------------------------ step (kitchen_env.py:386-423)
     def step(self, actions):
+        """= step_launch(actions) + step_finish(): the first half only ENQUEUES (action copy, noise upload, the step kernel, the host draws of the next
+        observation's noise while the kernel runs), the second half reads the completion bits back (the one host sync of this family: the task bookkeeping
+        of KitchenEnv.step decides termination) and does the autoresets.  A caller that drives several environments from one thread launches them all
+        before it finishes any (bench.py --workload mixed: kitchen and Adroit kernels share the GPU, no host threads)."""
+        self.step_launch(actions)
+        return self.step_finish()
+
+    def step_launch(self, actions):
         if not self._has_reset:
             raise RuntimeError("Cannot call env.step() before calling env.reset()")
         a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions, dtype=np.float32))
         if tuple(a.shape) != (self.num_envs, self.nu):
             raise ValueError(f"Action dimension mismatch. Expected {(self.num_envs, self.nu)}, found {tuple(a.shape)}")
         self.action.copy_(a.to(torch.float32), non_blocking=True)
-        info = {}
         with torch.cuda.device(self.device):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
             stepped = ~self._needs_reset
@@ -195,6 +202,13 @@ class KitchenVecEnv(GoalVecEnv):
             else:
                 self._launch(self._bufs, False)
             self._refill_noise(which)          # host draws for the NEXT observation of these worlds while the kernel runs
+        self._pending_finish = (pending, stepped)
+
+    def step_finish(self):
+        pending, stepped = self._pending_finish
+        self._pending_finish = None
+        info = {}
+        with torch.cuda.device(self.device):
             done_bits = self.completed.cpu().numpy().astype(np.int64)
             # compute_reward over the tasks still open, bookkeeping of KitchenEnv.step
             step_done = np.where(stepped, done_bits & self.tasks_to_complete, 0)

@@ -46,3 +46,18 @@ def all_gather_outputs(packed: torch.Tensor, gathered: torch.Tensor = None, grou
         gathered = torch.empty(packed.shape[0] * ws, packed.shape[1], dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(gathered, packed.contiguous(), group=group)
     return gathered
+
+
+def rank_stats(values: Dict[str, float], device, group=None) -> Dict[str, object]:
+    """What rank 0 needs to report about the whole job next to its own numbers: the rank count AS THE BACKEND SEES IT (RCCL / gloo, not the launcher's
+    argument), the backend's name, and every rank's value of each entry of `values` (kernel time, elapsed time, ...), rank-major.  One small all-gather."""
+    ws = dist.get_world_size(group)
+    keys = sorted(values)
+    mine = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=device)
+    allv = torch.empty(ws * len(keys), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(allv, mine, group=group)
+    allv = allv.view(ws, len(keys)).cpu()
+    out = {"backend": dist.get_backend(group), "nranks": ws}
+    for j, k in enumerate(keys):
+        out[k + "_per_rank"] = [float(x) for x in allv[:, j]]
+    return out

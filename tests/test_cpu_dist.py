@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -91,3 +92,25 @@ def test_sharded_env_equals_the_unsharded_one():
     assert ret[0].shape == ref.shape == (steps + 1, n_total, 33)
     assert np.array_equal(ret[0], ref) and np.array_equal(ret[1], ref)
     assert len({tuple(row[25:28]) for row in ref[0]}) == n_total      # four different worlds (different object positions), in seed order
+
+
+@pytest.mark.parametrize("workload,ranks,extra", [("antmaze", 8, ["--worlds-per-gpu", "64"]), ("mixed", 2, ["--worlds-per-gpu", "64"]), ("fetch", 2, ["--worlds-per-gpu", "32"])])
+def test_bench_multi_rank_command_line_dry_run(workload, ranks, extra):
+    """The command the driver runs on the 8-GPU node (`python bench.py --gpus N ...`), with --dry-run: no GPU, no physics (random rows on the CPU), gloo instead
+    of RCCL -- everything else is the real code path: the launcher, the rendezvous on 127.0.0.1, world sharding, the per-step all-gather of the rows (checked to
+    arrive in world order), barrier + max-over-ranks timing, the per-rank report and the one JSON line of rank 0.  The first time this meets hardware it cannot fail
+    on plumbing (BASELINE configs[3]: AntMaze on 8 ranks; configs[4]: the mixed batch)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", str(ranks), "--workload", workload, "--steps", "3", "--warmup", "1"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout          # exactly one JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == ranks and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["dist"]["backend"] == "gloo" and line["dist"]["nranks"] == ranks and len(line["dist"]["elapsed_s_per_rank"]) == ranks
+    assert line["data"].startswith("DRY RUN")
