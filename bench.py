@@ -384,7 +384,7 @@ def run_rank(args, rank, world_size, local_rank):
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE
     # cannot be read from inside the process); tools/collect_profiles.py writes the summary bench.py quotes
     traffic, traffic_src = None, None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"pmc_{tag}_hbm_traffic{'' if args.workload == 'fetch' else '_' + args.workload}.json")
         if os.path.exists(path) and n == w["worlds"]:
             with open(path) as f:

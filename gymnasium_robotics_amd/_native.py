@@ -12,9 +12,15 @@ LIB_PATH = os.environ.get("GRX_HIP_LIB") or os.path.join(_HERE, "_lib", "libgrx_
 _lib = None
 
 
+class OverflowLaneStruct(ctypes.Structure):
+    """mirrors grx_overflow_lane (include/grx_capi.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("skip", "entry_count", "entry_list", "list", "count", "next_flags", "next_count", "next_list", "ttl")] + [
+        (n, ctypes.c_int) for n in ("soft_maxefc", "soft_jpool", "soft_maxcon", "ttl_init", "grid", "entry_cap", "next_cap")]
+
+
 class FetchBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed", "hullcache")]
+        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed", "hullcache")] + [("lane", OverflowLaneStruct)]
 
 
 class FetchResetArgsStruct(ctypes.Structure):
@@ -37,7 +43,7 @@ class AdroitTaskStruct(ctypes.Structure):
 
 
 class AdroitBuffersStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")] + [("lane", OverflowLaneStruct)]
 
 
 class KitchenTaskStruct(ctypes.Structure):
@@ -48,7 +54,7 @@ class KitchenTaskStruct(ctypes.Structure):
 
 class KitchenBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "last_qpos", "action", "noise", "obs", "completed", "status", "mask", "skin")] + [
-        ("skin_stride", ctypes.c_int), ("skin_radius", ctypes.c_float)]
+        ("skin_stride", ctypes.c_int), ("skin_radius", ctypes.c_float), ("lane", OverflowLaneStruct)]
 
 
 class HerArgsStruct(ctypes.Structure):
@@ -71,7 +77,7 @@ class HandCommitArgsStruct(ctypes.Structure):
 
 class HandBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost", "packed")]
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost", "packed")] + [("lane", OverflowLaneStruct)]
 
 
 def lib():

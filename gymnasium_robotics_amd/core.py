@@ -28,7 +28,10 @@ class GoalVecEnv:
     def __setstate__(self, d):
         out = type(self)(*d["_ezpickle_args"], **d["_ezpickle_kwargs"])
         self.__dict__.update(out.__dict__)
-        out.__dict__.pop("_h", None)   # the native handle now belongs to self: do not let the temporary destroy it
+        out.__dict__.pop("_h", None)   # the native handles now belong to self: do not let the temporary destroy them
+        out.__dict__.pop("_h_big", None)
+        if getattr(self, "lane", None) is not None and hasattr(self, "_lane_make_bufs"):
+            self.lane._make_bufs = self._lane_make_bufs()     # the overflow lane's buffer factory held a weak reference to the temporary
 
     num_envs: int
     single_observation_space: Dict
@@ -132,3 +135,188 @@ def np_random(seed=None):
         raise ValueError(f"Seed must be a non-negative integer or None, got {seed!r}")
     ss = np.random.SeedSequence(seed)
     return np.random.Generator(np.random.PCG64(ss)), ss.entropy
+
+
+
+# ---------------------------------------------------------------------------------------------- the overflow lane (include/grx_capi.h, grx_overflow_lane)
+# Tables of the LARGE model of every family: 256 rows / 4 080 Jacobian-pool words (the 12-bit row offsets' limit) / the engine's 32 contacts; ~30-40 KB of LDS per
+# world on the generic kernel.  The reference never truncates a contact list (mujoco.mj_step, envs/robot_env.py:341).
+RERUN_CAPACITY = {"maxefc": 256, "jpool": 4080, "maxcon": 0}
+LANE_TTL = 8       # steps a world stays in the lane after the last step in which it came within LANE_MARGIN of a capacity of the fast kernel
+LANE_MARGIN = 0.8
+
+
+def create_rerun_model(L, model, device_index, enabled=True):
+    """handle of `model` compiled with RERUN_CAPACITY, or None when the lane is switched off (GRX_NO_OVERFLOW_RERUN=1: round-2 behaviour, contacts dropped and flagged)"""
+    import ctypes
+    import os
+
+    from . import _native
+
+    if not enabled or os.environ.get("GRX_NO_OVERFLOW_RERUN") is not None:
+        return None
+    H, I, F = model.with_capacity(**RERUN_CAPACITY).pack()
+    h = ctypes.c_void_p()
+    _native.check(L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, device_index, ctypes.byref(h)))
+    return h
+
+
+class _LaneBuf:
+    """flags [N] u8 + (next_count, entry_count) i32 in ONE tensor (zeroed by one fill), and the two index lists"""
+
+    def __init__(self, n, device):
+        import torch
+
+        self.head = torch.zeros((n + 3) // 4 + 2, dtype=torch.int32, device=device)
+        self.flags = self.head.view(torch.uint8)[:n]
+        self.counts = self.head[-2:]
+        self.next_list, self.entry_list = torch.zeros(n, dtype=torch.int32, device=device), torch.zeros(n, dtype=torch.int32, device=device)
+        base = self.counts.data_ptr()
+        self.next_count_ptr, self.entry_count_ptr = base, base + 4
+
+
+ENTRY_CAP = 256    # worlds that may overflow for the FIRST time in one step and still be re-run (more: the excess goes on with dropped contacts and the sticky flag says so)
+
+
+class OverflowLane:
+    """Host side of the overflow lane (include/grx_capi.h, grx_overflow_lane): the device-side lists / flags and the launch order of one step.  Nothing here waits
+    for the device or reads a flag back: which worlds are in the lane is known to the kernels only.
+
+        lane = OverflowLane(n, device, model, make_bufs)          # make_bufs(mask_tensor_or_None) -> a fresh buffer struct of the family (with a .lane field)
+        lane.step(mask, launch_fast, launch_large, fast_bufs)     # launch_fast(bufs), launch_large(bufs): enqueue on torch's CURRENT stream
+
+    step(): the large-table kernel (one workgroup per entry of the lane's current list) runs on a second stream CONCURRENTLY with the fast kernel; when both are done
+    it runs once more over the worlds that overflowed in this step (the only serialised part: a launch over an empty list otherwise); then the lists built in this step
+    become current.  The size of a list is bounded by the grid of the launch that will walk it (grx_overflow_lane.next_cap / entry_cap), which the host fixes one
+    step ahead from the newest counters that have reached it."""
+
+    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane"):
+        """mode "lane": worlds near a capacity move to a standing lane that runs next to the fast launch (families whose contact-rich states persist: hand + object,
+        kitchen, Adroit door / relocate: a few worlds per step and thousand).  mode "entry": no standing lane, an overflowing world is re-run right behind the fast
+        launch -- for families where an overflow is a rare event (Fetch: 2 worlds in 100 steps of 4096), whose step is too short to hide the two cross-stream waits
+        a standing lane costs per step (+0.19 ms on 3.3 ms, measured)."""
+        import os
+        self.mode = os.environ.get("GRX_LANE_MODE", mode)
+
+        import torch
+
+        from . import _native
+        from .mjcf.compiler import DIMS
+
+        self.n, self.device = n, device
+        self.cur, self.nxt, self.scratch = _LaneBuf(n, device), _LaneBuf(n, device), _LaneBuf(n, device)
+        self.ttl = torch.zeros(n, dtype=torch.int8, device=device)
+        dims = model.tables["dims"]
+        req = lambda k, default: int(dims[DIMS.index(k + "_req")]) or default
+        cap = (req("maxefc", 144), req("jpool", 2032), min(req("maxcon", 32), 32))
+        # a world moves to the lane when it comes within LANE_MARGIN of a capacity of the fast kernel (and stays `ttl` steps past the last such step): most worlds
+        # then enter the lane without ever overflowing, i.e. without the serialised re-run
+        margin, ttl = float(os.environ.get("GRX_LANE_MARGIN", LANE_MARGIN)), int(os.environ.get("GRX_LANE_TTL", ttl))      # (experiments)
+        self.soft = tuple(int(margin * v) for v in cap) + (int(ttl),)
+        self._make_bufs = make_bufs
+        self.side = torch.cuda.Stream(device=device, priority=int(os.environ.get("GRX_LANE_PRIO", "-1")))     # the lane's worlds start before the fast kernel fills the chip
+        self._Lane = _native.OverflowLaneStruct
+        # The counters reach the host with a delay (copied to pinned memory after every step, read when the copy has landed, never waited for); `cap_cur` is the
+        # capacity the CURRENT list was built under = the grid of the launch that walks it.
+        self._pin = [dict(buf=torch.zeros(2, dtype=torch.int32, pin_memory=True), event=None, age=0) for _ in range(4)]
+        self._pin_next, self._seen, self._age = 0, 0, 0
+        self.cap_cur = 64
+
+    def _refresh(self):
+        best = None
+        for slot in self._pin:
+            if slot["event"] is not None and slot["event"].query() and (best is None or slot["age"] > best["age"]):
+                best = slot
+        if best is not None:
+            self._seen = int(best["buf"][0]) + int(best["buf"][1])
+
+    def _fast(self, skip, out, next_cap, join=True):
+        L = self._Lane()
+        L.skip = None if skip is None else skip.flags.data_ptr()
+        L.entry_count, L.entry_list, L.entry_cap = out.entry_count_ptr, out.entry_list.data_ptr(), ENTRY_CAP
+        if join:      # worlds that come close to a capacity move to the lane of the next step
+            L.next_flags, L.next_count, L.next_list, L.ttl, L.next_cap = out.flags.data_ptr(), out.next_count_ptr, out.next_list.data_ptr(), self.ttl.data_ptr(), next_cap
+            L.soft_maxefc, L.soft_jpool, L.soft_maxcon, L.ttl_init = self.soft
+        return L
+
+    def _large(self, lst, count_ptr, out, grid, next_cap):
+        L = self._Lane()
+        L.grid = int(grid)
+        L.list, L.count = lst.data_ptr(), count_ptr
+        L.next_flags, L.next_count, L.next_list, L.ttl, L.next_cap = out.flags.data_ptr(), out.next_count_ptr, out.next_list.data_ptr(), self.ttl.data_ptr(), int(next_cap)
+        L.soft_maxefc, L.soft_jpool, L.soft_maxcon, L.ttl_init = self.soft
+        return L
+
+    def step(self, mask, launch_fast, launch_large, fast_bufs):
+        """mask: the uint8 tensor of the worlds this step covers (None: all); a lane world that is masked out keeps its place.  fast_bufs: the environment's own
+        buffer struct for the fast launch (its .lane is set here and cleared again)."""
+        import os
+
+        import torch
+
+        if self.mode == "entry":       # no standing lane: a world that overflows is re-run on the large tables right behind the fast launch, and that is all
+            return self.rerun_only(mask, fast_bufs, launch_fast, launch_large)
+
+        main = torch.cuda.current_stream(self.device)
+        cur, nxt = self.cur, self.nxt
+        self._refresh()
+        next_cap = int(min(self.n, 64 + 2 * self._seen))       # capacity of the list built in this step = grid of the next step's lane launch
+        nxt.head.zero_()
+        fast_bufs.lane = self._fast(cur, nxt, next_cap)
+        # The fast kernel is submitted FIRST and the lane's launch second, on the other stream.  Measured (tools/lane_cost_probe.py): with the lane's launch in front,
+        # the fast kernel does not start before the lane's kernel has ENDED (1.1 ms of a 3.1 ms Fetch step) -- on the same stream or on a second one: the completion
+        # marker behind the lane's kernel holds up the packet processor for both queues.  Behind the fast kernel the lane's workgroups start when a CU has room and
+        # end before the fast launch does.
+        b_lane = self._make_bufs(mask)
+        b_lane.lane = self._large(cur.next_list, cur.next_count_ptr, nxt, self.cap_cur, next_cap)
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        launch_fast(fast_bufs)
+        self.side.wait_event(ev0)
+        with torch.cuda.stream(self.side):
+            launch_large(b_lane)
+            ev1 = torch.cuda.Event()
+            ev1.record(self.side)
+        main.wait_event(ev1)
+        b_entry = self._make_bufs(mask)
+        b_entry.lane = self._large(nxt.entry_list, nxt.entry_count_ptr, nxt, ENTRY_CAP, next_cap)
+        launch_large(b_entry)
+        self._keep = (b_lane, b_entry)
+        fast_bufs.lane = self._Lane()       # the environment's struct is also used for reset-time launches: no stale skip list
+        slot = self._pin[self._pin_next]
+        self._pin_next = (self._pin_next + 1) % len(self._pin)
+        if os.environ.get("GRX_LANE_DBG") == "nopin":
+            pass
+        elif slot["event"] is None or slot["event"].query():      # (a slot whose copy is still in flight is skipped: the host never waits)
+            done = torch.cuda.Event()
+            done.record(main)
+            self.side.wait_event(done)
+            with torch.cuda.stream(self.side):                  # the read-back rides the side stream: a D2H copy in the main stream sits in the critical path of every step
+                slot["buf"].copy_(nxt.counts, non_blocking=True)
+                slot["event"] = torch.cuda.Event()
+                slot["event"].record(self.side)
+            self._age += 1
+            slot["age"] = self._age
+        self.cur, self.nxt, self.cap_cur = nxt, cur, next_cap
+
+    def rerun_only(self, mask, fast_bufs, launch_fast, launch_large):
+        """reset-time step launches (settle chains): every masked world is stepped by the fast kernel whatever lane it is in; a world that overflows is re-run on the
+        large tables at once.  Lane membership does not change."""
+        sc = self.scratch
+        sc.head.zero_()
+        fast_bufs.lane = self._fast(None, sc, 0, join=False)
+        launch_fast(fast_bufs)
+        fast_bufs.lane = self._Lane()
+        b = self._make_bufs(mask)
+        b.lane = self._large(sc.entry_list, sc.entry_count_ptr, sc, ENTRY_CAP, 0)
+        launch_large(b)
+
+    def count(self):
+        """worlds in the lane right now (synchronises: diagnostics only)"""
+        return 0 if self.mode == "entry" else int(min(self.cur.counts[0].item(), self.cap_cur))
+
+    def entered_last_step(self):
+        """world indices that claimed a re-run in the last step (synchronises: tests only)"""
+        buf = self.scratch if self.mode == "entry" else self.cur
+        k = int(min(buf.counts[1].item(), ENTRY_CAP))
+        return buf.entry_list[:k].cpu().numpy()

@@ -40,6 +40,7 @@ struct GrxAdroitBuffers {
   unsigned char* success;         // [N]
   int* status;                    // [N]
   const unsigned char* mask;      // [N] or null
+  GrxLane lane;                   // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 
 template <class S>
@@ -163,6 +164,7 @@ struct GrxAdroit {
     for (int s = 0; s < t->n_substeps; s++) {
       E::grx_check_state(m, c, lane_);
       E::grx_forward_euler(m, c, 1, lane_);
+      if (c->bail && grx_lane_claim(c, lane_)) break;   // a capacity overflowed and the re-run on the large tables is booked: this run will be discarded
     }
   }
 };

@@ -73,6 +73,7 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_ST_CON_OVERFLOW 2
 #define GRX_ST_EFC_OVERFLOW 4
 #define GRX_ST_FACTOR 8
+#define GRX_ST_SOFT 16      // internal (never reported): the tables of the model's FAST kernel would have overflowed in some substep (GrxCtx::soft_*; the overflow lane, include/grx_capi.h)
 
 enum { GRX_ROW_EQ = 0, GRX_ROW_FRICTION = 1, GRX_ROW_LIMIT = 2, GRX_ROW_CONTACT = 3, GRX_ROW_TENDON = 4 };
 
@@ -89,6 +90,9 @@ struct GrxModel {
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv, noslip_tolerance;
   int mpr_iterations;
 };
+
+// mirrors grx_overflow_lane (include/grx_capi.h): where the worlds go that exceed a table capacity of the fast kernel
+struct GrxLane { const unsigned char* skip; int* entry_count; int* entry_list; const int* list; const int* count; unsigned char* next_flags; int* next_count; int* next_list; signed char* ttl; int soft_maxefc, soft_jpool, soft_maxcon, ttl_init, grid, entry_cap, next_cap; };
 
 // per-world LDS working set; every pointer addresses LDS (or host memory in the emulator)
 struct GrxCtx {
@@ -118,6 +122,9 @@ struct GrxCtx {
   float* minv;       // models with the noslip post-solver: M^-1 (nv x nv), formed once per substep
   float* meshcache;  // models with hull-vs-convex pairs: 4 x (pair + 1, separating direction, the two support vertices) + the slot to evict next, kept across the substeps of a step (grx_mesh_pairs)
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
+  int bail;    // != 0: a step kernel that hands capacity overflows to a re-run at a larger capacity stops simulating at the first overflowing substep (nothing of this run is kept)
+  int soft_maxefc, soft_jpool, soft_maxcon;   // > 0 (the large-table kernel of the overflow lane): the capacities of the FAST kernel; exceeding one of them raises GRX_ST_SOFT
+  int *lane_entry_count, *lane_entry_list; int lane_entry_cap, lane_world;   // fast kernel with an overflow lane: where a world that overflows claims its re-run (grx_lane_claim)
   int* skin;   // large scenes: this world's skin list in HBM (grx_collision), or null: [0] entries, [1] valid, [4, 4 + 3 ngeom) reference geom positions, then the list
   float skin_r;
   int maxefc, jpool, maxcon;  // capacities of the row tables / the packed Jacobian pool / the contact list of this model
@@ -135,7 +142,7 @@ struct GrxCtx {
 #else
 #define GRX_MAX_MODELS 32
 static __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];   // one copy per translation unit (see csrc/grx_kernels.hip on the build)
-#define GRX_FRESH_MODEL(m, c) do { int s_ = (c)->mslot; asm volatile("" : "+s"(s_)); (m) = g_grx_models + s_; } while (0)
+#define GRX_FRESH_MODEL(m, c) do { int s_ = __builtin_amdgcn_readfirstlane((c)->mslot); asm volatile("" : "+s"(s_)); (m) = g_grx_models + s_; } while (0)
 #endif
 
 // LDS layout.  Arrays that only live in the position/velocity stages of a substep (P1: local poses, spatial inertias,
@@ -165,7 +172,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
 GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   const GrxDims* m = &d;
   float* p = base;
-  c->skin = nullptr; c->skin_r = 0.0f;
+  c->skin = nullptr; c->skin_r = 0.0f; c->bail = 0; c->soft_maxefc = c->soft_jpool = c->soft_maxcon = 0; c->lane_entry_count = nullptr; c->lane_entry_list = nullptr; c->lane_entry_cap = 0; c->lane_world = 0;
 #define CARVE(field, n) c->field = p; p += (n);
 #define CARVEI(field, n) c->field = (int*)p; p += (n);
   // ---- persistent
@@ -216,6 +223,26 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   CARVE(efc_jar, m->maxefc) CARVE(efc_jv, m->maxefc) CARVE(efc_force, m->maxefc) CARVEI(efc_quad, m->maxefc)
 #undef CARVE
 #undef CARVEI
+}
+
+// Fast kernel with an overflow lane (include/grx_capi.h, grx_overflow_lane), called after every substep: once a table capacity has overflowed the world tries to CLAIM
+// a slot of the step's entry list (the worlds that are re-run on the large tables after this launch).  1 = claimed: stop simulating, nothing of this run is kept
+// (c->bail = 2).  0 = no overflow, or the list is full (more than entry_cap worlds overflowed in this very step): the world goes on with the excess contacts dropped,
+// as without a lane, and the sticky status flag says so.
+GRX_MEM int grx_lane_claim(GrxCtx* c, int lane_) {
+#if defined(GRX_EMU)
+  (void)c; (void)lane_;
+  return 0;
+#else
+  if (c->bail != 1 || !(c->cnt[2] & (GRX_ST_CON_OVERFLOW | GRX_ST_EFC_OVERFLOW))) return 0;
+  int idx = 0;
+  if (lane_ == 0) idx = atomicAdd(c->lane_entry_count, 1);
+  idx = __builtin_amdgcn_readfirstlane(idx);
+  if (idx >= c->lane_entry_cap) { c->bail = 0; return 0; }
+  if (lane_ == 0) c->lane_entry_list[idx] = c->lane_world;
+  c->bail = 2;
+  return 1;
+#endif
 }
 
 GRX_HD GrxDims grx_dims_of(const GrxModel* m) {
@@ -2401,6 +2428,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   const int rows0 = ne + nf + nl, pool0 = wpool + nf + nlj + tpool;
   const int maxefc = c->maxefc, jpool = c->jpool;
   int overflow = (rows0 > maxefc) || (pool0 > jpool), ncon_fit = ncon, nc = nc_all;
+  if (c->soft_maxefc > 0 && (rows0 + nc_all > c->soft_maxefc || pool0 + pool_all > c->soft_jpool || c->cnt[0] > c->soft_maxcon)) { LANE0 { c->cnt[2] |= GRX_ST_SOFT; } }
   if (rows0 + nc_all > maxefc || pool0 + pool_all > jpool) {  // rare: find the first contact that does not fit
     GRX_LANEVAR(failp);
     FOR_LANES {

@@ -35,6 +35,7 @@ struct GrxFetchBuffers {
   int* cost;                             // [N] or null: out, cost estimate of this world (the next launch's ordering key)
   float* packed;                         // [N, obs_dim + 3 + 3 + 2] or null: out, the row [obs | achieved | desired | reward | success] (what the cross-rank gather ships)
   float* hullcache;                      // [N, 21] or null: in/out, GrxCtx::meshcache carried across launches (include/grx_capi.h)
+  GrxLane lane;                          // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 
 // distance with a fixed operation order so that the fused step kernel and the standalone
@@ -141,6 +142,7 @@ GRX_MEM void grx_fetch_sim_world(const GrxModel* m, const GrxFetchTask* t, GrxCt
     if (callback) { LANE0 { c->qpos[t->jq_lf] = 0.0f; c->qpos[t->jq_rf] = 0.0f; } WAVE_SYNC(); }
     else E::grx_check_state(m, c, lane_);
     E::grx_forward_euler(m, c, !callback, lane_);
+    if (c->bail && grx_lane_claim(c, lane_)) break;   // a capacity overflowed and the re-run on the large tables is booked: this run will be discarded
   }
 }
 };  // struct GrxFetch

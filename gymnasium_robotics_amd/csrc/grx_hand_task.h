@@ -44,6 +44,7 @@ struct GrxHandBuffers {
   const int* order;              // [grid] or null: world handled by workgroup b (cost-ordered dispatch, see grx_fetch_buffers)
   int* cost;                     // [N] or null: out, cost estimate of this world
   float* packed;                 // [N, obs_dim + 2 goal_dim + 2] or null: out, the row [obs | achieved | desired | reward | success]
+  GrxLane lane;                   // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 
 // Euclidean distance with a fixed accumulation order, shared by the step kernel and the recompute kernel so that
@@ -142,6 +143,7 @@ struct GrxHand {
     for (int s = 0; s < t->n_substeps; s++) {
       E::grx_check_state(m, c, lane_);
       E::grx_forward_euler(m, c, 1, lane_);
+      if (c->bail && grx_lane_claim(c, lane_)) break;   // a capacity overflowed and the re-run on the large tables is booked: this run will be discarded
     }
     grx_hand_outputs(m, t, c, obs, achieved, palm, lane_);
   }

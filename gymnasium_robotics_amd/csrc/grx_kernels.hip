@@ -59,8 +59,38 @@ __device__ __forceinline__ void grx_load_world(const GrxModel& m, const GrxFetch
 
 // status word: bits 0-15 = GRX_ST_* flags of this launch, bits 16-31 = the same flags OR-accumulated over every launch since the host
 // last cleared the buffer (sticky: a capacity overflow in step 17 is still visible after step 50)
-__device__ __forceinline__ int grx_status_word(int old, int now) { return (now & 0xFFFF) | ((((old >> 16) | now) & 0xFFFF) << 16); }
+__device__ __forceinline__ int grx_status_word(int old, int now) { now &= 15; return now | ((((old >> 16) | now) & 0xFFFF) << 16); }   // GRX_ST_SOFT and above are internal
 
+// ---- the overflow lane (include/grx_capi.h, grx_overflow_lane)
+// both kernels, before the simulation: the fast kernel may hand the world over at the first overflowing substep (grx_lane_claim, csrc/grx_engine.h), both watch the soft thresholds
+__device__ __forceinline__ void grx_lane_setup(const GrxLane& L, GrxCtx& c, int w, bool stepping) {
+  c.bail = (stepping && L.entry_count != nullptr) ? 1 : 0;
+  if (c.bail) { c.lane_entry_count = L.entry_count; c.lane_entry_list = L.entry_list; c.lane_entry_cap = L.entry_cap; c.lane_world = w; }
+  if (stepping && (L.list != nullptr || L.entry_count != nullptr)) { c.soft_maxefc = L.soft_maxefc; c.soft_jpool = L.soft_jpool; c.soft_maxcon = L.soft_maxcon; }
+}
+// fast kernel, after the simulation: true = the world claimed a re-run on the large tables: the caller returns WITHOUT writing anything of it
+__device__ __forceinline__ bool grx_lane_overflowed(const GrxCtx& c) { return c.bail == 2; }
+// append w to the lane of the next step (both kernels); a full list (next_cap: the grid of the next step's launch) leaves the world on the fast kernel
+__device__ __forceinline__ void grx_lane_append(const GrxLane& L, int w) {
+  const int idx = atomicAdd(L.next_count, 1);
+  if (idx < L.next_cap) { L.next_list[idx] = w; L.next_flags[w] = 1; }
+}
+// fast kernel, after a step that did NOT overflow but came within the soft thresholds of a capacity: the result is committed as usual and the world moves to the
+// lane for the next steps -- before it can overflow, so that entering the lane costs no serialised re-run
+__device__ __forceinline__ void grx_lane_join(const GrxLane& L, const GrxCtx& c, int w, int lane_) {
+  if (L.entry_count == nullptr || L.next_list == nullptr || lane_ != 0 || !(c.cnt[2] & GRX_ST_SOFT)) return;
+  L.ttl[w] = (signed char)L.ttl_init;
+  grx_lane_append(L, w);
+}
+// large-table kernel: the world's ticket (it stays in the lane while it is within the soft thresholds, and ttl_init steps longer); st < 0: the world was not part of this
+// step (masked out: it waits for its reset) and keeps its place
+__device__ __forceinline__ void grx_lane_ticket(const GrxLane& L, int st, int w, int lane_) {   // st: the world's status flags of this step, -1 = it was not stepped (by value: taking the context's address would keep the whole GrxCtx in scratch memory)
+  if (L.list == nullptr || lane_ != 0) return;
+  int t = L.ttl[w];
+  if (st >= 0) { t = (st & GRX_ST_SOFT) ? L.ttl_init : (t > 0 ? t - 1 : 0); L.ttl[w] = (signed char)t; }
+  else if (t <= 0) t = 1;
+  if (t > 0) grx_lane_append(L, w);
+}
 __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetchTask& t, const GrxFetchBuffers& b, GrxCtx& c, int w, int lane_, int keep_outcome = 0) {
   for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
   for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)w * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * m.nv + i] = c.qacc_ws[i]; }
@@ -103,6 +133,7 @@ extern "C" int grx_profile_world_spans(long long* out, int n) { return (int)hipM
 // fetched by up to 8 L2s and written back as 8 partial lines.  The grid is rounded up to a multiple of 8 and XCD k takes the
 // k-th contiguous slice of the worlds, so a line is read and merged in one L2 (rocprofv3 FETCH_SIZE / WRITE_SIZE: profiles/).
 static inline unsigned grx_grid_for(int n_worlds) { return (unsigned)((n_worlds + 7) & ~7); }
+#define GRX_LANE_GRID 64u   // default workgroups of a large-table launch of the overflow lane (grx_overflow_lane.grid): they walk the compacted list
 static __device__ __forceinline__ int grx_world_of_block() { return (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); }
 // the same index re-derived after the substep loop from the (architected) workgroup id: the epilogue's addresses are then computed
 // there instead of being kept -- as 64-bit VGPR pairs spilled to scratch -- across the whole simulation
@@ -133,6 +164,9 @@ typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
+// the SAME models with the tables of the overflow lane (core.RERUN_CAPACITY): only the lane kernels are instantiated for them (BASELINE configs 2 / 3 / 5a; the other
+// models' lanes run on the generic kernel, 2-3 x slower per world)
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 256, 4080, 0, 32, 0, 2> GrxShapeFetchPickLane;
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
@@ -143,22 +177,23 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 2> Gr
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 3> GrxShapeHandEgg;     // manipulate_egg.xml: the ellipsoid goes through the convex narrow phase
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 3> GrxShapeHandEggTouch;
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 2> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 256, 4080, 92, 32, 1, 2> GrxShapeHandBlockTouchLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
 
 // waves per SIMD the Fetch kernels are compiled for (VGPR budget 168 at 3, 256 at 2): the convex narrow phase needs the full budget
 #ifndef GRX_FETCH_WAVES
 #define GRX_FETCH_WAVES(S) 2   // the wave-cooperative hull routine keeps ~100 values live: at 168 VGPRs (3 waves) the step kernels spill 60-130 registers and run slower than at 2 waves even with 9 instead of 8 worlds per CU and the hull branch marked cold (measured 3.75 vs 3.44 ms per step)
 #endif
-template <class S>
-__global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))
-grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
-  extern __shared__ float lds[];
-  const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
+// one world's env.step().  LANE: called from the list-walking loop of the large-table kernel (w comes from the list; see grx_overflow_lane)
+template <class S, bool LANE>
+__device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTask& t, const GrxFetchBuffers& b, const int w, int n_worlds, int words, float* lds, const int lane_) {
   if (w >= n_worlds) return;
-  if (b.mask && !b.mask[w]) return;
+  if (b.mask && !b.mask[w]) { if (LANE) grx_lane_ticket(b.lane, -1, w, lane_); return; }
+  if (!LANE && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
   grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
+  grx_lane_setup(b.lane, c, w, true);
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
@@ -172,11 +207,15 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = b.aux[(size_t)w * 8 + k];
   GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_);
-  const int wl = b.order ? b.order[grx_block_late()] : grx_world_of_block_late();
-  if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) b.hullcache[(size_t)wl * 21 + lane_] = c.meshcache[lane_];
-  GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)wl * 8, b.obs + (size_t)wl * t.obs_dim, b.achieved + (size_t)wl * 3, lane_);
-  __syncthreads();
-  grx_store_world(m, t, b, c, wl, lane_);
+  const int wl = LANE ? w : (b.order ? b.order[grx_block_late()] : grx_world_of_block_late());
+  // a capacity overflowed (wave-uniform: the flag lives in LDS): keep nothing, the world is re-run on the large tables (grx_overflow_lane)
+  if (!grx_lane_overflowed(c)) {
+    if (LANE) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, wl, lane_); else grx_lane_join(b.lane, c, wl, lane_);
+    if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) b.hullcache[(size_t)wl * 21 + lane_] = c.meshcache[lane_];
+    GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)wl * 8, b.obs + (size_t)wl * t.obs_dim, b.achieved + (size_t)wl * 3, lane_);
+    __syncthreads();
+    grx_store_world(m, t, b, c, wl, lane_);
+  }
 #ifdef GRX_PROFILE_ITER
   if (b.cost && lane_ == 0) b.cost[wl] = c.cnt[6] | (c.cnt[0] << 16);   // diagnostic build: Newton iterations of the step, contacts of the last substep
 #else
@@ -196,6 +235,22 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   if (lane_ == 0 && w < 16384) g_grx_world_span[2 * w + 1] = wall_clock64();
   if (lane_ == 0 && w < 4096) for (int k = 0; k < GRX_NPROF; k++) g_grx_world_prof[w * GRX_NPROF + k] = (int)c.prof[k];
 #endif
+}
+template <class S>
+__global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))
+grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
+  extern __shared__ float lds[];
+  const int lane_ = threadIdx.x;
+  grx_fetch_step_world<S, false>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, lds, lane_);
+}
+// the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_fetch_lane_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (the caller sizes the grid: grx_overflow_lane.grid >= the list's cap)
+  extern __shared__ float lds[];
+  const int e = blockIdx.x;
+  if (e >= *b.lane.count) return;
+  grx_fetch_step_world<S, true>(mslot, t, b, b.lane.list[e], n_worlds, words, lds, (int)threadIdx.x);
 }
 
 // reset-time mj_forward + outputs (nstep > 0: raw settle steps first, _env_setup).  Shape-specialised like the step kernel: the generic
@@ -328,12 +383,10 @@ template <class S>
 #ifndef GRX_HANDREACH_WAVES
 #define GRX_HANDREACH_WAVES 2   // with the hull-pair routine the 168-VGPR build spills 73 registers: 11.9 ms per step at 16 384 worlds against 10.95 ms at 2 waves
 #endif
-__global__ void __launch_bounds__(64, (S::kFixed && S::JP <= 512) ? GRX_HANDREACH_WAVES : 2)   // third wave per SIMD only where the LDS footprint lets more than 8 worlds share a CU (HandReach); the object models sit at 8
-grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
-  extern __shared__ float lds[];
-  const int w = b.order ? b.order[blockIdx.x] : grx_world_of_block(), lane_ = threadIdx.x;
+__device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask& t, const GrxHandBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
   if (w >= n_worlds) return;
-  if (b.mask && !b.mask[w]) return;
+  if (b.mask && !b.mask[w]) { if (in_lane) grx_lane_ticket(b.lane, -1, w, lane_); return; }
+  if (!in_lane && !forward_only && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel (reset-time forward passes cover every masked world)
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -344,6 +397,7 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
 #endif
   const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv, nu = S::kFixed ? S::NU : m.nu;
+  grx_lane_setup(b.lane, c, w, !forward_only);
   if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp, parked in the cost slot (see grx_fetch_step_kernel)
   for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
   __syncthreads();
@@ -359,6 +413,11 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
     GrxHand<S>::grx_hand_step_world(&m, &t, &c, b.action + (size_t)w * nu, obs, ach, palm, lane_);
   }
   __syncthreads();
+  if (grx_lane_overflowed(c)) {   // capacity overflow: keep nothing (obs / achieved are outputs only), re-run on the large tables
+    if (lane_ == 0 && b.cost) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = ((int)wall_clock64() - t0) >> 3; }
+    return;
+  }
+  if (in_lane) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, w, lane_); else if (!forward_only) grx_lane_join(b.lane, c, w, lane_);
   for (int i = lane_; i < nq; i += 64) b.qpos[(size_t)w * nq + i] = c.qpos[i];
   for (int i = lane_; i < nv; i += 64) { b.qvel[(size_t)w * nv + i] = c.qvel[i]; b.qacc_ws[(size_t)w * nv + i] = c.qacc_ws[i]; }
   if (lane_ == 0) {
@@ -387,6 +446,22 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);
 #endif
 }
+template <class S>
+__global__ void __launch_bounds__(64, (S::kFixed && S::JP <= 512) ? GRX_HANDREACH_WAVES : 2)   // third wave per SIMD only where the LDS footprint lets more than 8 worlds share a CU (HandReach); the object models sit at 8
+grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
+  extern __shared__ float lds[];
+  const int lane_ = threadIdx.x;
+  grx_hand_step_world<S>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+}
+// the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_hand_lane_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (see grx_fetch_lane_kernel)
+  extern __shared__ float lds[];
+  const int e = blockIdx.x;
+  if (e >= *b.lane.count) return;
+  grx_hand_step_world<S>(mslot, t, b, b.lane.list[e], n_worlds, words, 0, lds, (int)threadIdx.x, true);
+}
 
 // AdroitHandHammer env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world, same engine + the noslip pass
 // nv = 33, every dof carries a friction-loss row (class main: 0.001; the nail: 2.5), general-affine actuators, cylinder / capsule pairs through the convex routine
@@ -397,12 +472,10 @@ typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, 144, 2032, 0, 32, 1, 13> G
 typedef GrxShape<30, 30, 24, 27, 30, 26, 5, 1, 30, 0, 144, 2032, 0, 32, 1, 29> GrxShapeAdroitPen;
 typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, 144, 2032, 0, 32, 1, 12> GrxShapeAdroitRelocate;
 template <class S>
-__global__ void __launch_bounds__(64, 2)
-grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words, int forward_only) {
-  extern __shared__ float lds[];
-  const int w = grx_world_of_block(), lane_ = threadIdx.x;
+__device__ __forceinline__ void grx_adroit_step_world(int mslot, const GrxAdroitTask& t, const GrxAdroitBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
   if (w >= n_worlds) return;
-  if (b.mask && !b.mask[w]) return;
+  if (b.mask && !b.mask[w]) { if (in_lane) grx_lane_ticket(b.lane, -1, w, lane_); return; }
+  if (!in_lane && !forward_only && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel (reset-time forward passes cover every masked world)
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -420,9 +493,12 @@ grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
   for (int i = lane_; i < 7 * m.nmocap; i += 64) { const int q = i / 7, e = i - 7 * q; if (e < 3) c.mocap_pos[3 * q + e] = m.mocap_pos0[3 * q + e]; else c.mocap_quat[4 * q + e - 3] = m.mocap_quat0[4 * q + e - 3]; }
   if (m.nshift && lane_ < 7) c.shift[lane_] = b.shift[(size_t)w * 7 + lane_];
   __syncthreads();
+  grx_lane_setup(b.lane, c, w, !forward_only);
   if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
   else GrxAdroit<S>::grx_adroit_sim_world(&m, &t, &c, b.action + (size_t)w * nu, b.act_mean, b.act_rng, lane_);
-  const int wl = grx_world_of_block_late();
+  const int wl = in_lane ? w : grx_world_of_block_late();
+  if (grx_lane_overflowed(c)) return;   // capacity overflow: keep nothing, re-run on the large tables
+  if (in_lane) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, wl, lane_); else if (!forward_only) grx_lane_join(b.lane, c, wl, lane_);
   GrxAdroit<S>::grx_adroit_outputs(&m, &t, &c, b.target ? b.target + (size_t)wl * 3 : nullptr, b.obs + (size_t)wl * t.obs_dim, b.reward + wl, b.success + wl, lane_);
   __syncthreads();
   for (int i = lane_; i < nq; i += 64) b.qpos[(size_t)wl * nq + i] = c.qpos[i];
@@ -433,17 +509,32 @@ grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
   if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);
 #endif
 }
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words, int forward_only) {
+  extern __shared__ float lds[];
+  const int lane_ = threadIdx.x;
+  grx_adroit_step_world<S>(mslot, t, b, grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+}
+// the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_adroit_lane_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (see grx_fetch_lane_kernel)
+  extern __shared__ float lds[];
+  const int e = blockIdx.x;
+  if (e >= *b.lane.count) return;
+  grx_adroit_step_world<S>(mslot, t, b, b.lane.list[e], n_worlds, words, 0, lds, (int)threadIdx.x, true);
+}
 
 // FrankaKitchen-v1 env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world; 40 substeps; nv = 29 (9 robot dofs, 5 joint
 // equalities knob <-> burner / switch <-> light, the free kettle), 124 colliding geoms / 3 736 candidate pairs, condim-6 finger pads, hull pairs
 typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 192, 2240, 0, 32, 1, 3> GrxShapeKitchen;
+typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 256, 4080, 0, 32, 1, 3> GrxShapeKitchenLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
 template <class S>
-__global__ void __launch_bounds__(64, 2)
-grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_worlds, int words, int forward_only) {
-  extern __shared__ float lds[];
-  const int w = grx_world_of_block(), lane_ = threadIdx.x;
+__device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitchenTask& t, const GrxKitchenBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
   if (w >= n_worlds) return;
-  if (b.mask && !b.mask[w]) return;
+  if (b.mask && !b.mask[w]) { if (in_lane) grx_lane_ticket(b.lane, -1, w, lane_); return; }
+  if (!in_lane && !forward_only && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel (reset-time forward passes cover every masked world)
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -461,8 +552,11 @@ grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_
   __syncthreads();
   float* last = b.last_qpos + (size_t)w * GRX_KITCHEN_NROBOT;
   if (b.skin) { c.skin = b.skin + (size_t)w * b.skin_stride; c.skin_r = b.skin_radius; }
+  grx_lane_setup(b.lane, c, w, !forward_only);
   if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
   else GrxKitchen<S>::grx_kitchen_sim_world(&m, &t, &c, b.action + (size_t)w * GRX_KITCHEN_NROBOT, last, lane_);
+  if (grx_lane_overflowed(c)) return;   // capacity overflow: keep nothing (last_qpos included), re-run on the large tables
+  if (in_lane) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, w, lane_); else if (!forward_only) grx_lane_join(b.lane, c, w, lane_);
   GrxKitchen<S>::grx_kitchen_outputs(&m, &t, &c, b.noise ? b.noise + (size_t)w * t.obs_dim : nullptr, b.obs + (size_t)w * t.obs_dim, last, b.completed + w, lane_);
   __syncthreads();
   for (int i = lane_; i < nq; i += 64) b.qpos[(size_t)w * nq + i] = c.qpos[i];
@@ -472,6 +566,22 @@ grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_
   GRX_TICK(&c, GRX_P_OTHER);
   if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);
 #endif
+}
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_worlds, int words, int forward_only) {
+  extern __shared__ float lds[];
+  const int lane_ = threadIdx.x;
+  grx_kitchen_step_world<S>(mslot, t, b, grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+}
+// the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
+template <class S>
+__global__ void __launch_bounds__(64, 2)
+grx_kitchen_lane_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (see grx_fetch_lane_kernel)
+  extern __shared__ float lds[];
+  const int e = blockIdx.x;
+  if (e >= *b.lane.count) return;
+  grx_kitchen_step_world<S>(mslot, t, b, b.lane.list[e], n_worlds, words, 0, lds, (int)threadIdx.x, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -497,11 +607,12 @@ static hipError_t grx_upload_descriptor(const GrxModel* g, int slot) {
 #if GRX_TU_FETCH
 #define GRX_FETCH_SHAPES(X) X(1, GrxShapeFetchPick) X(2, GrxShapeFetchObject) X(7, GrxShapeFetchPuck) X(3, GrxShapeFetchArm)
 extern "C" int grx_tu_fetch_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
-  GRX_LDS(grx_fetch_step_kernel<GrxShapeAny>); GRX_LDS(grx_fetch_forward_kernel<GrxShapeAny>); GRX_LDS(grx_fetch_reset_kernel<GrxShapeAny>);
+  GRX_LDS(grx_fetch_step_kernel<GrxShapeAny>); GRX_LDS(grx_fetch_forward_kernel<GrxShapeAny>); GRX_LDS(grx_fetch_reset_kernel<GrxShapeAny>); GRX_LDS(grx_fetch_lane_kernel<GrxShapeAny>);
   int found = 0;
 #define X(ID, SHAPE) if (!found && grx_shape_matches<SHAPE>(*g)) { found = ID; GRX_LDS(grx_fetch_step_kernel<SHAPE>); GRX_LDS(grx_fetch_forward_kernel<SHAPE>); GRX_LDS(grx_fetch_reset_kernel<SHAPE>); }
   GRX_FETCH_SHAPES(X)
 #undef X
+  if (!found && grx_shape_matches<GrxShapeFetchPickLane>(*g)) { found = 101; GRX_LDS(grx_fetch_lane_kernel<GrxShapeFetchPickLane>); }   // ids >= 100: lane kernel only (everything else of such a model runs generic)
   if (found) *shape = found;
   return (int)grx_upload_descriptor(g, slot);
 }
@@ -509,6 +620,11 @@ extern "C" int grx_tu_fetch_prepare(const GrxModel* g, int bytes, int slot, int*
 extern "C" int grx_tu_fetch_launch(int kind, int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxFetchTask* t, const GrxFetchBuffers* b,
                                    const GrxFetchResetArgs* r, int n, int words, int nstep) {
   const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+  if (kind == 0 && b->lane.list) {
+    if (shape == 101) hipLaunchKernelGGL(grx_fetch_lane_kernel<GrxShapeFetchPickLane>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    else hipLaunchKernelGGL(grx_fetch_lane_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    return (int)hipGetLastError();
+  }
 #define GRX_FETCH_GO(SHAPE) do { \
     if (kind == 0) hipLaunchKernelGGL(grx_fetch_step_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words); \
     else if (kind == 1) hipLaunchKernelGGL(grx_fetch_forward_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words, nstep); \
@@ -548,15 +664,21 @@ extern "C" int grx_tu_point_launch(int shape, unsigned grid, size_t lds_bytes, v
 #if GRX_TU_HAND
 #define GRX_HAND_SHAPES(X) X(4, GrxShapeHandReach) X(6, GrxShapeHandBlockTouch) X(8, GrxShapeHandEgg) X(9, GrxShapeHandEggTouch) X(5, GrxShapeHandBlock)
 extern "C" int grx_tu_hand_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
-  GRX_LDS(grx_hand_step_kernel<GrxShapeAny>);
+  GRX_LDS(grx_hand_step_kernel<GrxShapeAny>); GRX_LDS(grx_hand_lane_kernel<GrxShapeAny>);
 #define X(ID, SHAPE) if (grx_shape_matches<SHAPE>(*g)) { *shape = ID; GRX_LDS(grx_hand_step_kernel<SHAPE>); }
   GRX_HAND_SHAPES(X)
 #undef X
+  if (grx_shape_matches<GrxShapeHandBlockTouchLane>(*g)) { *shape = 106; GRX_LDS(grx_hand_lane_kernel<GrxShapeHandBlockTouchLane>); }   // ids >= 100: lane kernel only
   return (int)grx_upload_descriptor(g, slot);
 }
 extern "C" int grx_tu_hand_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxHandTask* t, const GrxHandBuffers* b, int n, int words,
                                   int forward_only) {
   const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+  if (b->lane.list) {
+    if (shape == 106) hipLaunchKernelGGL(grx_hand_lane_kernel<GrxShapeHandBlockTouchLane>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    else hipLaunchKernelGGL(grx_hand_lane_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    return (int)hipGetLastError();
+  }
   switch (shape) {
 #define X(ID, SHAPE) case ID: hipLaunchKernelGGL(grx_hand_step_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only); break;
     GRX_HAND_SHAPES(X)
@@ -568,7 +690,7 @@ extern "C" int grx_tu_hand_launch(int shape, unsigned grid, size_t lds_bytes, vo
 #endif
 #if GRX_TU_ADROIT
 extern "C" int grx_tu_adroit_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
-  GRX_LDS(grx_adroit_step_kernel<GrxShapeAny>);
+  GRX_LDS(grx_adroit_step_kernel<GrxShapeAny>); GRX_LDS(grx_adroit_lane_kernel<GrxShapeAny>);
 #define GRX_ADROIT_SHAPES(X) X(20, GrxShapeAdroitHammer) X(21, GrxShapeAdroitDoor) X(22, GrxShapeAdroitPen) X(23, GrxShapeAdroitRelocate)
   int found = 0;
 #define X(ID, SHAPE) if (!found && grx_shape_matches<SHAPE>(*g)) { found = ID; GRX_LDS(grx_adroit_step_kernel<SHAPE>); }
@@ -580,6 +702,7 @@ extern "C" int grx_tu_adroit_prepare(const GrxModel* g, int bytes, int slot, int
 extern "C" int grx_tu_adroit_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxAdroitTask* t, const GrxAdroitBuffers* b, int n, int words,
                                     int forward_only) {
   const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+  if (b->lane.list) { hipLaunchKernelGGL(grx_adroit_lane_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words); return (int)hipGetLastError(); }
   switch (shape) {
 #define X(ID, SHAPE) case ID: hipLaunchKernelGGL(grx_adroit_step_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only); break;
     GRX_ADROIT_SHAPES(X)
@@ -591,13 +714,19 @@ extern "C" int grx_tu_adroit_launch(int shape, unsigned grid, size_t lds_bytes, 
 #endif
 #if GRX_TU_KITCHEN
 extern "C" int grx_tu_kitchen_prepare(const GrxModel* g, int bytes, int slot, int* shape) {
-  GRX_LDS(grx_kitchen_step_kernel<GrxShapeAny>);
+  GRX_LDS(grx_kitchen_step_kernel<GrxShapeAny>); GRX_LDS(grx_kitchen_lane_kernel<GrxShapeAny>);
   if (grx_shape_matches<GrxShapeKitchen>(*g)) { *shape = 30; GRX_LDS(grx_kitchen_step_kernel<GrxShapeKitchen>); }
+  if (grx_shape_matches<GrxShapeKitchenLane>(*g)) { *shape = 130; GRX_LDS(grx_kitchen_lane_kernel<GrxShapeKitchenLane>); }   // ids >= 100: lane kernel only
   return (int)grx_upload_descriptor(g, slot);
 }
 extern "C" int grx_tu_kitchen_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxKitchenTask* t, const GrxKitchenBuffers* b, int n, int words,
                                      int forward_only) {
   const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
+  if (b->lane.list) {
+    if (shape == 130) hipLaunchKernelGGL(grx_kitchen_lane_kernel<GrxShapeKitchenLane>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    else hipLaunchKernelGGL(grx_kitchen_lane_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    return (int)hipGetLastError();
+  }
   if (shape == 30) hipLaunchKernelGGL(grx_kitchen_step_kernel<GrxShapeKitchen>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
   else hipLaunchKernelGGL(grx_kitchen_step_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only);
   return (int)hipGetLastError();
@@ -868,7 +997,8 @@ extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, co
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  const int e = grx_tu_fetch_launch(0, m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, 0);
+  if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_fetch_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
+  const int e = grx_tu_fetch_launch(0, m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, 0);
   if (e) return fail(std::string("grx_fetch_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -927,7 +1057,8 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   } else
     for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
-  const int e = grx_tu_hand_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_hand_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
+  const int e = grx_tu_hand_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_hand_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -950,7 +1081,8 @@ extern "C" int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, 
   if (t.kind == GRX_ADROIT_HAMMER && g.ntouch != 1) return fail("grx_adroit_step: the hammer task reads one touch sensor");
   if (t.kind == GRX_ADROIT_PEN && !(t.len[0] > 0.0f && t.len[1] > 0.0f)) return fail("grx_adroit_step: pen / target lengths must be positive");
   if (t.kind == GRX_ADROIT_RELOCATE && !buf->target) return fail("grx_adroit_step: the relocate task needs the target buffer");
-  const int e = grx_tu_adroit_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_adroit_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
+  const int e = grx_tu_adroit_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_adroit_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -989,7 +1121,8 @@ extern "C" int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task
     if (b.skin_stride < 4 + 3 * g.ngeom + g.ndevpair || !(b.skin_radius > 0.0f)) return fail("grx_kitchen_step: skin rows need 4 + 3 ngeom + ndevpair words and a positive radius");
     if (!grx_planes_static(m)) return fail("grx_kitchen_step: the skin list needs static plane geoms");
   }
-  const int e = grx_tu_kitchen_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_kitchen_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
+  const int e = grx_tu_kitchen_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_kitchen_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }

@@ -37,6 +37,7 @@ struct GrxKitchenBuffers {
   int* skin;                      // [N, skin_stride] broad-phase skin lists (GrxEngine::grx_collision), zeroed by the host once; or null
   int skin_stride;
   float skin_radius;
+  GrxLane lane;                   // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 
 template <class S>
@@ -79,6 +80,7 @@ struct GrxKitchen {
     for (int s = 0; s < t->n_substeps; s++) {
       E::grx_check_state(m, c, lane_);
       E::grx_forward_euler(m, c, 1, lane_);
+      if (c->bail && grx_lane_claim(c, lane_)) break;   // a capacity overflowed and the re-run on the large tables is booked: this run will be discarded
     }
   }
 };

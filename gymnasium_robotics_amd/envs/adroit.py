@@ -9,13 +9,14 @@ success).  Host side of a reset: the PCG64 draws of reset_model per world; the m
 body_quat / site_pos) are per-world state here (`shift`, `target`: adroit_spec.sample_reset).
 """
 import ctypes
+import weakref
 from typing import Optional
 
 import numpy as np
 import torch
 
 from .. import _native
-from ..core import GoalVecEnv, PinnedStager, np_random
+from ..core import create_rerun_model, GoalVecEnv, OverflowLane, PinnedStager, np_random
 from ..mjcf import CompiledModel
 from ..spaces import Box, batch_space
 from .adroit_spec import IDENTITY_SHIFT, MAX_EPISODE_STEPS, SPECS, action_scaling, group_shift, load_adroit_model, make_adroit_task, parse_adroit_id, sample_reset_batch
@@ -47,6 +48,7 @@ class AdroitVecEnv(GoalVecEnv):
         self._h = ctypes.c_void_p()
         _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0, ctypes.byref(self._h)))
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
+        self._h_big = create_rerun_model(self._L, self.model, self.device.index or 0)    # larger tables for the worlds that overflow a capacity (core.RERUN_CAPACITY)
         self.task = make_adroit_task(self.model, self.reward_type, self.task_name)
         n, d = self.num_envs, self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=d)
@@ -58,6 +60,8 @@ class AdroitVecEnv(GoalVecEnv):
         am, ar = action_scaling(self.model)
         self._act_mean, self._act_rng = torch.from_numpy(am.astype(np.float32)).to(d), torch.from_numpy(ar.astype(np.float32)).to(d)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
+        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode="lane" if self.task_name in ("door", "relocate") else "entry") if self._h_big is not None else None     # hammer / pen: no overflow in 4 M world-steps
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)                      # adroit_hammer.py:231-233
         self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float64)      # :205-207
         self.action_space = batch_space(self.single_action_space, n)
@@ -79,6 +83,10 @@ class AdroitVecEnv(GoalVecEnv):
         """hammer: model.body_pos[nail_board, 2] of every world"""
         return self.model_edit[:, 2]
 
+    def _lane_make_bufs(self):
+        me = weakref.ref(self)      # (the lane must not keep the environment alive: its native model slots are released by __del__)
+        return lambda m: me()._make_bufs(m)
+
     def _make_bufs(self, mask):
         b = _native.AdroitBuffersStruct()
         for name in ("qpos", "qvel", "qacc_ws", "shift", "action", "obs", "reward", "success", "status"):
@@ -92,14 +100,21 @@ class AdroitVecEnv(GoalVecEnv):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _launch(self, bufs, forward_only):
-        timed = self.kernel_events is not None and not forward_only
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _native.check(self._L.grx_adroit_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, int(forward_only), self._stream()))
-        if timed:
-            e1.record()
-            self.kernel_events.append((e0, e1))
+        def fast(b):
+            timed = self.kernel_events is not None and not forward_only
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _native.check(self._L.grx_adroit_step(self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, int(forward_only), self._stream()))
+            if timed:
+                e1.record()
+                self.kernel_events.append((e0, e1))
+
+        if self.lane is not None and not forward_only:
+            large = lambda b: _native.check(self._L.grx_adroit_step(self._h_big, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, 0, self._stream()))
+            self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs)
+        else:
+            fast(bufs)
 
     # ------------------------------------------------------------------ reset (MujocoEnv.reset [3P] -> reset_model of the task)
     def _write_edits(self, idx, shifts, targets=None):
@@ -234,6 +249,9 @@ class AdroitVecEnv(GoalVecEnv):
         if getattr(self, "_h", None):
             self._L.grx_model_destroy(self._h)
             self._h = None
+        if getattr(self, "_h_big", None):
+            self._L.grx_model_destroy(self._h_big)
+            self._h_big = None
 
     def __del__(self):
         try:

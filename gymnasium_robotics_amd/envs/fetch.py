@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..core import GoalVecEnv, np_random
+from ..core import create_rerun_model, GoalVecEnv, OverflowLane, np_random
 from ..mjcf import CompiledModel, compile_mjcf, load_model
 from ..spaces import Box, Dict, batch_space
 from .fetch_spec import DISTANCE_THRESHOLD, FETCH_TASKS, MAX_EPISODE_STEPS, N_SUBSTEPS, make_fetch_task, parse_env_id
@@ -83,7 +83,7 @@ class FetchVecEnv(GoalVecEnv):
     def __init__(self, env_id: str = "FetchPickAndPlace-v4", num_envs: int = 1, device: Optional[str] = None,
                  max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step",
                  output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None,
-                 reward_type: Optional[str] = None, seed_offset: int = 0, balance: bool = True):
+                 reward_type: Optional[str] = None, seed_offset: int = 0, balance: bool = True, overflow_rerun: bool = True):
         task, rt = parse_env_id(env_id)
         self.balance = balance   # cost-ordered dispatch of the step kernel (see _alloc); results do not depend on it
         self.env_id, self.task_name, self.reward_type = env_id, task, reward_type or rt
@@ -112,6 +112,8 @@ class FetchVecEnv(GoalVecEnv):
         _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, dev_index,
                                                ctypes.byref(self._h)))
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
+        # the same model with larger row / Jacobian-pool tables (runs on the generic kernel): where the worlds go that overflow the specialised kernel's capacities
+        self._h_big = create_rerun_model(self._L, self.model, dev_index, overflow_rerun)
         self._alloc(self.num_envs)
         self._env_setup()
         # spaces (envs/robot_env.py:87-100)
@@ -129,14 +131,21 @@ class FetchVecEnv(GoalVecEnv):
         self.kernel_events = None  # set to [] to collect (start, end) torch.cuda.Event pairs around every step-kernel launch
 
     def _launch_step(self, bufs):
-        ev = self.kernel_events
-        if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, self._stream()))
-        if ev is not None:
-            e1.record()
-            ev.append((e0, e1))
+        def fast(b):
+            ev = self.kernel_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, self._stream()))
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
+
+        if self.lane is None:
+            fast(bufs)
+        else:
+            large = lambda b: _native.check(self._L.grx_fetch_step(self._h_big, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, self._stream()))
+            self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs)
         if self.balance:
             self._rebalance()
 
@@ -168,10 +177,15 @@ class FetchVecEnv(GoalVecEnv):
         # the worlds' caches of separating directions (hull-vs-convex pairs), carried across launches: without it every env.step() starts with one portal
         # search for the arm's permanently near pair (torso / shoulder link, 1.9 cm apart); a stale row is harmless (directions are re-verified)
         self.hullcache = z(n, 21) if os.environ.get("GRX_NO_HULLCACHE") is None else None
-        self._bufs = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action, self.obs,
-                                     self.achieved, self.reward, self.success, self.status, None, self.order, self.cost, self.packed, self.hullcache)
-        self._bufs_masked = self._make_bufs(self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action,
-                                            self.obs, self.achieved, self.reward, self.success, self.status, self.mask, self.order, self.cost, self.packed, self.hullcache)
+        # No dropped contacts (core.OverflowLane / include/grx_capi.h grx_overflow_lane): a world that exceeds a table capacity of the specialised kernel writes
+        # nothing and is stepped on the SAME model with larger tables (generic kernel) -- concurrently with the fast launch once it is in the lane.
+        common = (self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action, self.obs, self.achieved, self.reward, self.success, self.status)
+        self._bufs = self._make_bufs(*common, None, self.order, self.cost, self.packed, self.hullcache)
+        self._bufs_masked = self._make_bufs(*common, self.mask, self.order, self.cost, self.packed, self.hullcache)
+        self.lane = None
+        if self._h_big is not None:
+            packed, hullcache, mk = self.packed, self.hullcache, FetchVecEnv._make_bufs      # (no reference to self: the lane must not keep the environment alive)
+            self.lane = OverflowLane(n, d, self.model, lambda m: mk(*common, m, None, None, packed, hullcache), mode="entry")     # overflows are rare events here (0.0007 % of the world-steps)
 
     def _rebalance(self):
         """order <- per XCD slice, worlds by decreasing cost of the launch that just ran (in place: the buffer struct keeps its pointer)."""
@@ -197,7 +211,7 @@ class FetchVecEnv(GoalVecEnv):
             a = int(jq[n["joint"][name]])
             q0[a: a + len(v)] = v
         one = FetchVecEnv.__new__(FetchVecEnv)  # 1-world scratch buffers sharing the model
-        one.__dict__.update(device=self.device, nq=self.nq, nv=self.nv, nmocap=self.nmocap, obs_dim=self.obs_dim, balance=False)
+        one.__dict__.update(device=self.device, nq=self.nq, nv=self.nv, nmocap=self.nmocap, obs_dim=self.obs_dim, balance=False, _h_big=None)
         one._alloc(1)
         one.qpos[0] = torch.from_numpy(q0).float()
         one.mocap[0] = torch.from_numpy(np.concatenate([T["mocap_pos0"].ravel(), T["mocap_quat0"].ravel()])).float()
@@ -388,6 +402,9 @@ class FetchVecEnv(GoalVecEnv):
         if getattr(self, "_h", None):
             self._L.grx_model_destroy(self._h)
             self._h = None
+        if getattr(self, "_h_big", None):
+            self._L.grx_model_destroy(self._h_big)
+            self._h_big = None
 
     def __del__(self):
         try:

@@ -7,6 +7,7 @@ observations (observation 63 = 24 joint positions | 24 joint velocities | 5 fing
 steps, never terminated.  One call of `step` = one launch of `grx_hand_step_kernel` (set_action + 20 substeps + obs + reward).
 """
 import ctypes
+import weakref
 import os
 from typing import Optional
 
@@ -14,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..core import GoalVecEnv, PinnedStager, np_random
+from ..core import create_rerun_model, GoalVecEnv, OverflowLane, PinnedStager, np_random
 from ..mjcf import CompiledModel, compile_mjcf, load_model
 from ..spaces import Box, Dict, batch_space
 from .hand_spec import (DISTANCE_THRESHOLD, MAX_EPISODE_STEPS, N_ACTIONS, initial_qpos_vector, make_hand_task, parse_hand_reach_id,
@@ -69,6 +70,7 @@ class HandReachVecEnv(GoalVecEnv):
         self._h = ctypes.c_void_p()
         _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0,
                                                ctypes.byref(self._h)))
+        self._h_big = create_rerun_model(self._L, self.model, self.device.index or 0)    # larger tables for the worlds that overflow a capacity (core.RERUN_CAPACITY)
         self.task = self._make_task()
         GOAL_DIM = self.GOAL_DIM
         self.obs_dim = self._obs_dim()
@@ -92,6 +94,8 @@ class HandReachVecEnv(GoalVecEnv):
             self._slice_base = (torch.arange(8, device=d, dtype=torch.int32) * per).unsqueeze(1)
             self.order = (self._slice_base + torch.arange(per, device=d, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
+        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode=self.LANE_MODE) if self._h_big is not None else None
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)
         self.single_observation_space = Dict(dict(
             observation=Box(-np.inf, np.inf, (self.obs_dim,), np.float64), achieved_goal=Box(-np.inf, np.inf, (GOAL_DIM,), np.float64),
@@ -109,6 +113,7 @@ class HandReachVecEnv(GoalVecEnv):
 
     # ---- hooks specialised by the manipulation envs
     GOAL_DIM = GOAL_DIM
+    LANE_MODE = "entry"      # HandReach: no overflow in 4 M world-steps (profiles/soak); the hand + object models keep a standing lane (core.OverflowLane)
 
     def _parse_id(self, env_id, reward_type):
         self.reward_type = reward_type or parse_hand_reach_id(env_id)
@@ -124,13 +129,18 @@ class HandReachVecEnv(GoalVecEnv):
     def _obs_dim(self):
         return self.nq + self.nv + self.GOAL_DIM
 
-    def _make_bufs(self, mask):
+    def _lane_make_bufs(self):
+        me = weakref.ref(self)      # (the lane must not keep the environment alive: its native model slots are released by __del__)
+        return lambda m: me()._make_bufs(m, large=True)
+
+    def _make_bufs(self, mask, large=False):
+        """large: buffers of a launch of the large-table kernel of the overflow lane (no cost ordering: it runs a handful of worlds)"""
         b = _native.HandBuffersStruct()
         for name in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "packed"):
             setattr(b, name, getattr(self, name).data_ptr())
         b.mask = None if mask is None else mask.data_ptr()
-        b.order = None if self.order is None else self.order.data_ptr()
-        b.cost = None if self.cost is None else self.cost.data_ptr()
+        b.order = None if (self.order is None or large) else self.order.data_ptr()
+        b.cost = None if (self.cost is None or large) else self.cost.data_ptr()
         return b
 
     def _stream(self):
@@ -138,16 +148,30 @@ class HandReachVecEnv(GoalVecEnv):
 
     def _launch(self, bufs, forward_only, settle=False):
         """settle: a reset-time settle launch of the step kernel (manipulate.py:205-224) -- not a timed env.step(), no cost re-ordering."""
+        own = bufs is self._bufs or bufs is self._bufs_masked      # the side arenas of the overlapped settle chains carry their own structs (no lane: a handful of freshly reset worlds)
+        large = lambda b: _native.check(self._L.grx_hand_step(self._h_big, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, 0, self._stream()))
         if settle:
-            _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, 0, self._stream()))
+            fast = lambda b: _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, 0, self._stream()))
+            if self.lane is not None and own:
+                self.lane.rerun_only(self.mask if bufs is self._bufs_masked else None, bufs, fast, large)     # every masked world is stepped by the fast kernel, whatever lane it is in; an overflow is re-run at once
+            else:
+                fast(bufs)
             return
-        if self.kernel_events is not None and not forward_only:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-        _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, int(forward_only), self._stream()))
-        if self.kernel_events is not None and not forward_only:
-            b.record()
-            self.kernel_events.append((a, b))
+
+        def fast(b):
+            timed = self.kernel_events is not None and not forward_only
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, int(forward_only), self._stream()))
+            if timed:
+                e1.record()
+                self.kernel_events.append((e0, e1))
+
+        if self.lane is not None and own and not forward_only:
+            self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs)
+        else:
+            fast(bufs)
         if self.balance and not forward_only:
             _native.check(self._L.grx_order_by_cost(self.cost.data_ptr(), self.cost_ema.data_ptr(), self.balance_alpha, self.num_envs, self.order.data_ptr(), self._stream()))
 
@@ -304,6 +328,9 @@ class HandReachVecEnv(GoalVecEnv):
         if getattr(self, "_h", None):
             self._L.grx_model_destroy(self._h)
             self._h = None
+        if getattr(self, "_h_big", None):
+            self._L.grx_model_destroy(self._h_big)
+            self._h_big = None
 
     def __del__(self):
         try:
@@ -342,6 +369,7 @@ class HandBlockVecEnv(HandReachVecEnv):
     (/root/reference/gymnasium_robotics/envs/shadow_dexterous_hand/manipulate.py: MujocoManipulateEnv; manipulate_block.py:214-230).
     Observation 61 = 24 robot joint positions | 24 velocities | object velocity 6 | object pose 7; goals are 7-vector poses.
     The visual-only, non-colliding `target` body of the MJCF is not simulated (its state is not observable through the env API)."""
+    LANE_MODE = "lane"
 
     GOAL_DIM = 7
 

@@ -12,13 +12,14 @@ leading world axis.  reward = number of still-open tasks completed in this step;
 (terminate_on_tasks_completed).
 """
 import ctypes
+import weakref
 from typing import Optional
 
 import numpy as np
 import torch
 
 from .. import _native
-from ..core import GoalVecEnv, np_random
+from ..core import create_rerun_model, GoalVecEnv, OverflowLane, np_random
 from ..mjcf import CompiledModel
 from ..spaces import Box, Dict, batch_space
 from .kitchen_spec import (INIT_QPOS, MAX_EPISODE_STEPS, OBS_DIM, OBS_ELEMENT_GOALS, OBS_ELEMENT_INDICES, TASKS, load_kitchen_model, make_kitchen_task, task_mask)
@@ -53,6 +54,7 @@ class KitchenVecEnv(GoalVecEnv):
         self._h = ctypes.c_void_p()
         _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0, ctypes.byref(self._h)))
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
+        self._h_big = create_rerun_model(self._L, self.model, self.device.index or 0)    # larger tables for the worlds that overflow a capacity (core.RERUN_CAPACITY)
         self.task = make_kitchen_task(self.model, self.robot_noise_ratio, self.object_noise_ratio)
         self._noisy = self.robot_noise_ratio != 0.0 or self.object_noise_ratio != 0.0
         n, d = self.num_envs, self.device
@@ -66,6 +68,8 @@ class KitchenVecEnv(GoalVecEnv):
         self.skin_radius = float(skin_radius)
         self._skin = z(n, 4 + 3 * self.model.dim("ngeom") + len(self.model.tables["devpair"]), dtype=torch.int32) if self.skin_radius > 0.0 else None
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
+        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs()) if self._h_big is not None else None
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float64)                     # franka_env.py:88
         goal_space = Dict({t: Box(-np.inf, np.inf, OBS_ELEMENT_GOALS[t].shape, np.float64) for t in self.tasks})
         self.single_observation_space = Dict(dict(desired_goal=goal_space, achieved_goal=Dict(dict(goal_space)),
@@ -82,6 +86,10 @@ class KitchenVecEnv(GoalVecEnv):
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
         self.kernel_events = None
+
+    def _lane_make_bufs(self):
+        me = weakref.ref(self)      # (the lane must not keep the environment alive: its native model slots are released by __del__)
+        return lambda m: me()._make_bufs(m)
 
     def _make_bufs(self, mask):
         b = _native.KitchenBuffersStruct()
@@ -136,14 +144,21 @@ class KitchenVecEnv(GoalVecEnv):
             self._noise_host[torch.from_numpy(idx64)] = torch.from_numpy(rows)
 
     def _launch(self, bufs, forward_only):
-        timed = self.kernel_events is not None and not forward_only
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _native.check(self._L.grx_kitchen_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), self.num_envs, int(forward_only), self._stream()))
-        if timed:
-            e1.record()
-            self.kernel_events.append((e0, e1))
+        def fast(b):
+            timed = self.kernel_events is not None and not forward_only
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _native.check(self._L.grx_kitchen_step(self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, int(forward_only), self._stream()))
+            if timed:
+                e1.record()
+                self.kernel_events.append((e0, e1))
+
+        if self.lane is not None and not forward_only:
+            large = lambda b: _native.check(self._L.grx_kitchen_step(self._h_big, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, 0, self._stream()))
+            self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs)
+        else:
+            fast(bufs)
 
     # ------------------------------------------------------------------ reset (kitchen_env.py:425-437 -> FrankaRobot.reset -> reset_model, franka_env.py:133-139)
     def _reset_worlds(self, idx):
@@ -293,6 +308,9 @@ class KitchenVecEnv(GoalVecEnv):
         if getattr(self, "_h", None):
             self._L.grx_model_destroy(self._h)
             self._h = None
+        if getattr(self, "_h_big", None):
+            self._L.grx_model_destroy(self._h_big)
+            self._h_big = None
 
     def __del__(self):
         try:

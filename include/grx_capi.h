@@ -33,6 +33,35 @@ extern "C" {
 
 typedef struct grx_model grx_model;
 
+/* The OVERFLOW LANE (all families): the shape-specialised ("fast") step kernels have fixed table capacities (contacts / constraint rows / Jacobian-pool words per
+ * world) sized so that 5-10 worlds share a CU.  A world that exceeds one in some substep would have to drop contacts, which the reference never does
+ * (mujoco.mj_step, envs/robot_env.py:341).  Instead:
+ *   fast kernel   (entry_count != NULL): leaves the worlds with skip[w] != 0 alone; a world that overflows writes NOTHING (state, outputs, status keep their
+ *                 pre-step values), appends itself to entry_list (atomic counter entry_count) and stops simulating.  A world that does not overflow but comes
+ *                 within the soft_* thresholds of a capacity (the caller passes a fraction of the tables) commits its step as usual and appends itself to
+ *                 next_list: it moves to the lane BEFORE it can overflow, so that most worlds enter without a serialised re-run.
+ *   large kernel  (list != NULL; the SAME model created with larger capacities, CompiledModel.with_capacity): one workgroup per entry of the COMPACTED list of
+ *                 worlds list[0 .. min(*count, grid)) steps its world on the large tables, commits the result, checks in every substep whether the FAST
+ *                 kernel's tables (soft_*) would have overflowed and keeps the world's ticket: ttl[w] = ttl_init after a step in which they would have, else
+ *                 ttl[w] - 1; while ttl[w] > 0 the world is appended to next_list / next_flags: it stays in the lane.
+ * One step: the caller zeroes the two counters and next_flags; launches the large kernel over the lane's current list on a second stream CONCURRENTLY with the fast
+ * kernel (skip = the current flags); when both are done, the large kernel once more over entry_list (the worlds that entered the lane in this step: the only
+ * serialised part, a launch of zero worlds otherwise); then next_* become the current list / flags.  Nothing crosses the host: which worlds are in the lane is
+ * known to the kernels only.  All pointers are device pointers; an all-zero struct switches the mechanism off (capacity overflows then drop contacts and raise
+ * GRX_STATUS_CON_OVERFLOW / GRX_STATUS_EFC_OVERFLOW, sticky in `status`). */
+typedef struct grx_overflow_lane {
+  const unsigned char* skip;            /* fast kernel, [N]: worlds in the lane this step */
+  int* entry_count; int* entry_list;    /* fast kernel: out, the worlds that overflowed ([1], [N]) */
+  const int* list; const int* count;    /* large kernel: in, the worlds to step ([N], [1]) */
+  unsigned char* next_flags; int* next_count; int* next_list;   /* large kernel: out, the lane of the next step ([N], [1], [N]) */
+  signed char* ttl;                     /* large kernel: in/out [N] */
+  int soft_maxefc, soft_jpool, soft_maxcon, ttl_init;           /* large kernel: the fast kernel's capacities; steps a world stays after its last soft overflow */
+  int grid;                             /* large kernel: workgroups of the launch = the entries of `list` it covers (one each); 0 = 64 */
+  int entry_cap, next_cap;              /* capacities of entry_list / next_list = the grids of the launches that will walk them.  A world that finds next_list full stays on
+                                         * (returns to) the fast kernel; a world that overflows when entry_list is full goes on with the excess contacts dropped and the sticky
+                                         * status flag says so (more than entry_cap worlds overflowing for the first time in ONE step) */
+} grx_overflow_lane;
+
 /* mirrors struct GrxFetchTask (csrc/grx_fetch_task.h) */
 typedef struct grx_fetch_task {
   int has_object, block_gripper, n_substeps, sparse_reward;
@@ -76,6 +105,7 @@ typedef struct grx_fetch_buffers {
   float* hullcache;                     /* [N, 21] or NULL: the world's cache of separating directions of its hull-vs-convex pairs (engine: GrxCtx::meshcache), carried from one
                                          * env.step() to the next.  A remembered direction is re-verified before it is trusted (it proves "no contact", exactly what the portal
                                          * search would report), so the rows never change a result: they save the search every launch otherwise starts with. */
+  grx_overflow_lane lane;               /* no dropped contacts: see grx_overflow_lane above */
 } grx_fetch_buffers;
 
 /* mirrors struct GrxPointTask / GrxPointBuffers (csrc/grx_point_task.h) */
@@ -122,6 +152,7 @@ typedef struct grx_hand_buffers {
   const int* order;             /* [8 * ceil(N / 8)] or NULL: cost-ordered dispatch, as in grx_fetch_buffers */
   int* cost;                    /* [N] or NULL */
   float* packed;                /* [N, obs_dim+2*goal_dim+2] or NULL: [obs | achieved | desired | reward | success] */
+  grx_overflow_lane lane;          /* no dropped contacts: see grx_overflow_lane */
 } grx_hand_buffers;
 
 /* mirrors struct GrxAdroitTask / GrxAdroitBuffers (csrc/grx_adroit_task.h): AdroitHandHammer / Door / Pen / Relocate */
@@ -152,6 +183,7 @@ typedef struct grx_adroit_buffers {
   unsigned char* success;          /* [N] */
   int* status;                     /* [N] */
   const unsigned char* mask;       /* [N] or NULL */
+  grx_overflow_lane lane;          /* no dropped contacts: see grx_overflow_lane */
 } grx_adroit_buffers;
 
 /* mirrors struct GrxKitchenTask / GrxKitchenBuffers (csrc/grx_kitchen_task.h): FrankaKitchen-v1 */
@@ -177,6 +209,7 @@ typedef struct grx_kitchen_buffers {
                                        per world), or NULL: every substep sweeps the full candidate list.  Results are identical either way. */
   int skin_stride;
   float skin_radius;                /* metres by which the broad-phase radius is inflated when a world's list is built (0.1) */
+  grx_overflow_lane lane;          /* no dropped contacts: see grx_overflow_lane */
 } grx_kitchen_buffers;
 
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);

@@ -222,3 +222,44 @@ def test_large_batch_worlds_independent():
         os_, rs, _, _, is_ = small.step(a[1000:1008])
     assert np.array_equal(ob["observation"][1000:1008], os_["observation"])
     assert int(np.abs(ib["status"]).max()) == 0
+
+
+def test_capacity_overflow_is_rerun_not_truncated():
+    """No dropped contacts (the reference never truncates, robot_env.py:341): worlds that exceed a table capacity in some substep write nothing and are stepped again
+    on the same model with larger tables (grx_fetch_buffers.redo).  Here the step kernel gets deliberately small tables (64 rows) and the contact-rich hull fixture:
+    most worlds overflow, every one of them must come out bit-identical to an environment whose tables are large to begin with, with no overflow flag left."""
+    import torch
+
+    from gymnasium_robotics_amd.envs.fetch import FetchVecEnv, load_fetch_model
+
+    g = np.load(os.path.join(GOLDEN, "fetch_hull_teacher.npz"))
+    n = g["obs"].shape[0]
+    base = load_fetch_model("FetchPickAndPlace")
+    small = FetchVecEnv("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="numpy", autoreset_mode="disabled", max_episode_steps=None,
+                        model=base.with_capacity(maxefc=64, jpool=640))
+    trunc = FetchVecEnv("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="numpy", autoreset_mode="disabled", max_episode_steps=None,
+                        model=base.with_capacity(maxefc=64, jpool=640), overflow_rerun=False)
+    big = FetchVecEnv("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="numpy", autoreset_mode="disabled", max_episode_steps=None,
+                      model=base.with_capacity(maxefc=256, jpool=4080), overflow_rerun=False)
+    outs = []
+    for env in (small, trunc, big):
+        env.reset(seed=0)
+        for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"):
+            getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+        obs, r, _, _, info = env.step(g["action"])
+        outs.append((obs["observation"], r, info["status"], info["status_sticky"], env.qpos.cpu().numpy(), env.qvel.cpu().numpy()))
+    redone = np.zeros(n, bool)
+    redone[small.lane.entered_last_step()] = True
+    assert redone.sum() >= 5, int(redone.sum())                                    # the small tables do overflow on this fixture
+    assert (outs[1][3][redone] & 6).all() and not (outs[1][3][~redone] & 6).any()     # ... and without the re-run exactly those worlds are flagged (contacts dropped)
+    assert not (outs[0][3] & 6).any() and not (outs[2][3] & 6).any()                   # re-run: no flag left
+    for k, (a, b) in enumerate(zip(outs[0], outs[2])):
+        d = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
+        assert np.array_equal(a[~redone], b[~redone]), k                           # worlds that stayed on the fast kernel: bit for bit
+        assert d.max() < 5e-5, (k, float(d.max()))                                 # re-run worlds: the large-table launch is a separately compiled instantiation of the same source (fused-multiply-add
+                                                                                   # contraction may differ): rounding level, against 1e-3 and more when contacts are dropped
+    assert np.abs(outs[1][0][redone] - outs[2][0][redone]).max() > 1e-6            # and truncation is not harmless
+    e = np.abs(outs[0][0] - g["obs"]).max(axis=1)
+    assert np.mean(e < 1e-4) > 0.95                                                # against the oracle: the fixture's own bar (tests/golden/tolerance_table.json FetchHullContacts)
+    for env in (small, trunc, big):
+        env.close()

@@ -67,18 +67,28 @@ def pmc(tag, workload=None):
     res, meta = {}, {}
     for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(OUT, f"pmc_{tag}_{cnt}{suffix}")
+        # --no-stagger: episodes in lock-step, so the 15 steps of this run contain NO reset (the masked reset-time forward launches and the hand families'
+        # settle chains run the same kernel on a handful of worlds and used to be averaged in: round 2 reported a "traffic" BELOW the algorithmic bytes)
         cmd = ["rocprofv3", "--pmc", cnt, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"] + extra
+               os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-stagger"] + extra
         run(cmd, os.path.join(OUT, f"pmc_{tag}_{cnt}{suffix}.log"))
-        vals = []
+        vals, dropped = [], 0
+        full_grid = ((w["worlds"] + 7) // 8) * 8 * 64      # threads of a launch over all worlds (grids are rounded up to a multiple of 8 workgroups)
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(path) as f:
                 for row in csv.DictReader(f):
                     if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == cnt:
+                        if int(float(row.get("Grid_Size") or 0)) != full_grid:      # a compacted side launch (settle chain, compacted reset): not a step of the whole batch
+                            dropped += 1
+                            continue
                         vals.append(float(row["Counter_Value"]))
                         meta = {k: row.get(k) for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
+        # the first launches of the run are the reset() of all worlds (forward-only over the full grid) and the warm-up: keep the timed region's step launches
+        vals = vals[-12:]
+        meta["launches_dropped_by_grid_size"] = dropped
         res[cnt] = vals
-    lines = [f"rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline {' '.join(extra)}  (separate passes, MI355X, build '{tag}')",
+    lines = [f"rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-stagger {' '.join(extra)}  (separate passes, MI355X, build '{tag}'; "
+             f"the last 12 full-grid launches of the step kernel = the timed region, no reset launches among them)",
              f"kernel dispatch info: {meta}"]
     summary = {}
     for cnt, vals in res.items():
