@@ -9,8 +9,8 @@ the batched device environments here:
     obs, info = envs.reset(seed=0)
     obs, reward, terminated, truncated, info = envs.step(actions)        # VectorEnv contract
 
-``registered_env_ids()`` lists every id this build serves; an id the reference registers but the engine does not cover
-(AdroitHandDoor / Pen / Relocate, FrankaKitchen) raises ``UnsupportedEnvError`` with the reason.
+``registered_env_ids()`` lists every id this build serves: all 121 ids the reference registers (Fetch, Shadow hand, Adroit hand, Maze, FrankaKitchen).
+``UnsupportedEnvError`` is what an id listed in ``_NOT_SERVED`` would raise (an extension hook: the table has been empty since round 2).
 Nothing here imports torch or loads the HIP library until an environment is constructed.
 """
 from typing import List
@@ -22,7 +22,7 @@ class UnsupportedEnvError(KeyError):
     """The reference registers this id, the device engine does not serve it (DESIGN.md section 6 says why)."""
 
 
-_NOT_SERVED = {}   # reference id prefix -> why the engine does not serve it (empty since round 2: FrankaKitchen was the last one)
+_NOT_SERVED = {}   # extension hook: reference id prefix -> why the engine does not serve it.  Empty since round 2 (FrankaKitchen was the last entry); env_family() consults it first
 
 
 def _fetch_ids() -> List[str]:

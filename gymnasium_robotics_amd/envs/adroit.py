@@ -132,7 +132,7 @@ class AdroitVecEnv(GoalVecEnv):
     def _reset_worlds(self, idx):
         if len(idx) == 0:
             return None
-        d = sample_reset_batch(self.task_name, [self.np_randoms[w] for w in idx], self.model)
+        d = sample_reset_batch(self.task_name, [self.np_randoms[w] for w in idx], self.model, current=self.model_edit[idx] if self.task_name in ("hammer", "relocate") else None)
         self.model_edit[idx] = d["edit"]
         if self.target_pos is not None:
             self.target_pos[idx] = d["target"]

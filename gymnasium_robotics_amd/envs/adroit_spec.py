@@ -141,11 +141,16 @@ def board_shift(model, z: float) -> np.ndarray:
     return group_shift(model, pos=p)
 
 
-def sample_reset_batch(task: str, rngs, model):
+def sample_reset_batch(task: str, rngs, model, current=None):
     """reset_model's draws for a list of per-world generators, in the reference's order -> dict(edit [k, 3 or 4] = what get_env_state reports,
-    shift [k, 7], target [k, 3] or None).  Only the draws run per world; the arithmetic on them is batched."""
+    shift [k, 7], target [k, 3] or None).  Only the draws run per world; the arithmetic on them is batched.
+    current ([k, 3]): the worlds' present model.body_pos rows.  reset_model rewrites only SOME components (hammer: board z, adroit_hammer.py:374-376; relocate:
+    ball x / y, adroit_relocate.py:353-356); what a set_env_state / options["initial_state_dict"] wrote into the others persists across resets in the
+    reference, so the rewrite starts from the current row, not from the XML pose."""
     k = len(rngs)
     p0 = np.tile(np.asarray(model.info["shift_pos0"], dtype=np.float64), (k, 1))
+    if current is not None and task in ("hammer", "relocate"):
+        p0 = np.array(current, dtype=np.float64).reshape(k, 3).copy()
     if task == "hammer":       # adroit_hammer.py:374-376
         p0[:, 2] = [r.uniform(low=0.1, high=0.25) for r in rngs]
         return dict(edit=p0, shift=group_shift(model, pos=p0), target=None)
@@ -165,9 +170,9 @@ def sample_reset_batch(task: str, rngs, model):
     raise KeyError(task)
 
 
-def sample_reset(task: str, rng, model):
+def sample_reset(task: str, rng, model, current=None):
     """one world: dict(edit, shift, target)"""
-    d = sample_reset_batch(task, [rng], model)
+    d = sample_reset_batch(task, [rng], model, current=None if current is None else np.asarray(current, dtype=np.float64).reshape(1, 3))
     return {k: (None if v is None else v[0]) for k, v in d.items()}
 
 

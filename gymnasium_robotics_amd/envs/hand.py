@@ -516,6 +516,9 @@ class HandBlockVecEnv(HandReachVecEnv):
 
         worlds, lo, k, ar = c["worlds"], c["lo"], c["k"], self._ar
         self.reset_attempts[worlds] = 1
+        # the chain draws from the worlds' own generators BEFORE their episodes have ended: if it is abandoned (an explicit reset() / set-state call) the draws are
+        # given back, so that a world's stream only ever advances by draws the reference's sequential reset would have made (_cancel_chains)
+        c["rng_states"] = [self.np_randoms[w].bit_generator.state for w in worlds]
         poses = sample_reset_object_pose_batch([self.np_randoms[w] for w in worlds], self._obj0[:3], self._obj0[3:], self.target_position, self.target_rotation,
                                                self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"])
         q = self._initial_qpos_host.unsqueeze(0).repeat(k, 1)
@@ -594,7 +597,8 @@ class HandBlockVecEnv(HandReachVecEnv):
             failed.append(c["worlds"][~c["ok"]])
             covered[c["worlds"]] = True
             self._chain_started[c["worlds"]] = False
-        assert not (covered & ~np.isin(np.arange(self.num_envs), done_idx)).any(), "a settle chain finished for a world that is not at its time limit"
+        if (covered & ~np.isin(np.arange(self.num_envs), done_idx)).any():
+            raise RuntimeError("a settle chain finished for a world that is not at its time limit")
         failed = np.concatenate(failed) if failed else np.zeros(0, np.int64)
         if len(failed):                                   # object fell off the palm: the sequential retry loop takes over from the state just copied
             self._settle_until_on_palm(failed)
@@ -615,6 +619,8 @@ class HandBlockVecEnv(HandReachVecEnv):
             for c in self._chains:
                 if c["event"] is not None:
                     c["event"].synchronize()
+                for w, st in zip(c["worlds"], c.get("rng_states", ())):      # hand the chain's draws back to the worlds' generators
+                    self.np_randoms[w].bit_generator.state = st
             self._chains, self._chain_started[:] = [], False
 
     def _launch_reward(self, ag, dg, out):

@@ -80,7 +80,7 @@ class OracleAdroitEnv:
             self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
         s = self.sim
         s.reset_data()
-        d = sample_reset(self.task, self.np_random, self.model)
+        d = sample_reset(self.task, self.np_random, self.model, current=self.model_edit if self.task in ("hammer", "relocate") else None)   # reset_model rewrites some components only: the rest persists
         self.set_model_edit(d["edit"], d["target"])
         s.qpos[:] = self.init_qpos
         s.qvel[:] = self.init_qvel
