@@ -186,3 +186,24 @@ def test_same_step_autoreset_matches_next_step(env_id):
     # the egg: a rolling object whose contact set flips under the different warm start -- its velocity components are what diverges
     check_same_step_against_next_step(make, horizon=5, steps=12, act_dim=20, tol=2e-4, tol_max=0.3 if "Egg" in env_id else 1e-2, outlier_rows=0.3 if "Egg" in env_id else 0.15, output="torch",
                                       touch_from=61 if "Touch" in env_id else None)
+
+
+def test_abandoned_settle_chains_give_their_draws_back():
+    """same-step autoreset starts the settle chains of the worlds that are about to hit their time limit one or two steps AHEAD, drawing the reset poses from the
+    worlds' own generators.  An explicit reset() in that window abandons the chains; the draws must be handed back, so that the reset observations equal those of an
+    environment that never started a chain (the reference's sequential _reset_sim, manipulate.py:154-224, draws only when the episode has really ended)."""
+    import gymnasium_robotics_amd as grx
+
+    mk = lambda mode: grx.make_vec("HandManipulateBlockRotateXYZ-v1", num_envs=12, device="cuda:0", output="numpy", autoreset_mode=mode, max_episode_steps=6)
+    A, B = mk("same_step"), mk("next_step")
+    A.reset(seed=4); B.reset(seed=4)
+    rng = np.random.default_rng(0)
+    for t in range(5):      # the fifth step starts with two steps left: A starts (and draws for) its chains there, B draws nothing before the time limit
+        a = rng.uniform(-1, 1, (12, 20)).astype(np.float32)
+        A.step(a); B.step(a)
+    assert len(A._chains) > 0
+    oa, _ = A.reset()
+    ob, _ = B.reset()
+    for k in ("observation", "desired_goal"):
+        assert np.array_equal(oa[k], ob[k]), k
+    A.close(); B.close()
