@@ -48,8 +48,10 @@ static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; ret
 #define GRX_SUBTICK(c, k) GRX_TICK(c, 16 + (k))
 #define GRX_TICK(c, id) do { if (lane_ == 0) { long long t_ = clock64(); (c)->prof[id] += t_ - (c)->prof_last[0]; (c)->prof_last[0] = t_; } } while (0)
 #define GRX_COUNT(c, k, n) do { if (lane_ == 0) (c)->prof[16 + (k)] += (n); } while (0)
+#define GRX_PMAX(c, k, n) do { if (lane_ == 0 && (c)->prof[16 + (k)] < (n)) (c)->prof[16 + (k)] = (n); } while (0)   // per-step maximum (table demand: tools/demand_probe.py)
 #else
 #define GRX_COUNT(c, k, n) ((void)0)
+#define GRX_PMAX(c, k, n) ((void)0)
 #define GRX_TICK(c, id) ((void)0)
 #define GRX_SUBTICK(c, k) ((void)0)
 #endif
@@ -86,7 +88,7 @@ struct GrxModel {
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations, iterations, njeq;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations, iterations, njeq, ngate;
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv, noslip_tolerance;
   int mpr_iterations;
 };
@@ -1526,6 +1528,16 @@ GRX_MEM int grx_obb_overlap(const GrxModel* m, const GrxCtx* c, int g1, int g2, 
   return 1;
 }
 
+// Joint-box gate of a hull pair (mjcf/pair_gates.py): the two bodies are separated by at most three hinge / slide joints, and for joint values inside the
+// gate's box the compiler has PROVEN the two margin-inflated geoms disjoint (rigorous distance bound on a grid + a Lipschitz bound in between).  1 = inside
+// the box: the pair cannot produce a contact in this configuration and leaves the candidate sweep -- the Fetch arm's torso / shoulder pair, 1.9 cm apart in
+// every pose the tasks reach, no longer walks through the bounding-box filter and the hull routine in every substep of every world.
+GRX_MEM int grx_gate_clear(const GrxModel* m, const GrxCtx* c, int gi) {
+  const int* qa = m->gate_qadr + 3 * gi; const float* bx = m->gate_box + 6 * gi;
+  int ok = 1;
+  for (int k = 0; k < 3; k++) { const int a = qa[k]; if (a >= 0) { const float q = c->qpos[a]; ok &= (q > bx[2 * k]) & (q < bx[2 * k + 1]); } }
+  return ok;
+}
 // the queued hull-vs-convex pairs of this pass, one after the other, all lanes on each (wave-uniform code)
 GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int nq, int lane_) {
   for (int e = 0; e < nq; e++) {
@@ -1572,14 +1584,49 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
 #if defined(GRX_EMU)
     g_grx_mesh_stats[1]++;
 #endif
+#ifdef GRX_EXP_NO_PORTAL
+    c->cnt[2] |= 32; continue;
+#endif
     float depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
     GRX_SUBTICK(c, 23);   // portal search
+#ifdef GRX_PROBE_HULL   // outcome of the searches (tools/hull_outcome_probe.py): contacts, separations with a direction, the pair searched last
+    GRX_COUNT(c, 29, rc == 0 ? 1 : 0); GRX_COUNT(c, 30, (rc != 0 && sep[3] != 0.0f) ? 1 : 0); GRX_PMAX(c, 31, pair);
+#endif
 #if defined(GRX_EMU) && defined(GRX_MESH_DEBUG)
     fprintf(stderr, "meshpair %d (g %d %d) slot %d rc %d sep %g\n", pair, g1, g2, slot, rc, (double)sep[3]);
 #endif
     WAVE_SYNC();
     if (rc != 0) {
+#ifndef GRX_HULL_REFINE
+#define GRX_HULL_REFINE 3
+#endif
+      if (sep[3] != 0.0f && GRX_HULL_REFINE > 0) {
+        // The direction the portal search stopped on separates the two geoms BARELY (its support point is just on the far side of the origin), and the
+        // next substep's motion breaks it: worlds whose upper arm is near the head ran a fresh search (11 support evaluations) in 17 of their 20 substeps and
+        // ended the launch alone (profiles/stragglers_r03_fetch.txt).  A few Frank-Wolfe steps towards the point of A - B nearest to the origin turn it
+        // into a direction with (nearly) the largest separation margin, which survives many substeps.  Any separating direction proves "no contact":
+        // which one is cached changes no result.
+        GrxMprPt* pt = &q.pts[4];
+        float bd[3] = {sep[0], sep[1], sep[2]};
+        grx_mpr_support<true>(&q, bd, pt);
+        float v[3] = {pt->v[0], pt->v[1], pt->v[2]}, best = dot3f(v, bd);
+        for (int it = 0; it < GRX_HULL_REFINE; it++) {
+          const float n2 = dot3f(v, v);
+          if (!(n2 > 1e-12f)) break;
+          const float in = 1.0f / sqrtf(n2), d[3] = {-v[0] * in, -v[1] * in, -v[2] * in};
+          grx_mpr_support<true>(&q, d, pt);
+          const float w[3] = {pt->v[0], pt->v[1], pt->v[2]}, sw = dot3f(w, d);
+          if (sw < best) { best = sw; bd[0] = d[0]; bd[1] = d[1]; bd[2] = d[2]; }
+          const float dv[3] = {w[0] - v[0], w[1] - v[1], w[2] - v[2]}, dd = dot3f(dv, dv);
+          if (!(dd > 1e-14f)) break;
+          const float t = fminf(1.0f, fmaxf(0.0f, -dot3f(v, dv) / dd));
+          if (t <= 0.0f) break;
+          v[0] += t * dv[0]; v[1] += t * dv[1]; v[2] += t * dv[2];
+        }
+        sep[0] = bd[0]; sep[1] = bd[1]; sep[2] = bd[2];
+        WAVE_SYNC();
+      }
       if (sep[3] != 0.0f) {   // keep the direction for the next substeps
         const int w = slot >= 0 ? slot : ((int)mc[20] & 3);   // the pair's own slot, else round robin over the four
         LANE0 { mc[5 * w] = key; mc[5 * w + 1] = sep[0]; mc[5 * w + 2] = sep[1]; mc[5 * w + 3] = sep[2]; mc[5 * w + 4] = 0.0f; if (slot < 0) mc[20] = (float)((w + 1) & 3); }
@@ -1587,6 +1634,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
       WAVE_SYNC();
       continue;
     }
+    if (slot >= 0) { LANE0 { mc[5 * slot] = 0.0f; } WAVE_SYNC(); }   // the pair is in contact: its old direction is useless, do not re-check it (two support evaluations) before every search of the next substeps
     if (dir[0] == 0.0f && dir[1] == 0.0f && dir[2] == 0.0f) continue;
     for (int k = 0; k < 3; k++) pos[k] += c->gxpos[3 * g1 + k];
     float n1[3] = {0.0f, 0.0f, 0.0f}, n2[3] = {0.0f, 0.0f, 0.0f};
@@ -2004,6 +2052,10 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   // ONE dense pass instead of one sparse, divergent pass per 64 candidates.
   // Scenes with more candidates than the survivor list has room for (the kitchen: 3 736) are swept in chunks of that size: pair order is kept.
   const int ndp = m->ndevpair;
+  const bool kGate = S::kMesh && m->ngate > 0;   // joint-box gates of hull pairs (grx_gate_clear); the skin-list sweep of the large scenes does not use them
+  unsigned long long gmask = 0ull;   // gates 0 .. 63 evaluated once per pass, one lane each (their table rows are read coalesced); the sweep tests a bit
+  if (kGate) { GRX_LANEVAR_I(gc); FOR_LANES { LV(gc) = (lane < m->ngate) ? grx_gate_clear(m, c, lane) : 0; } gmask = GRX_BALLOT(gc); }
+#define GRX_GATE_CLEAR(gi) ((gi) < 64 ? (int)((gmask >> (gi)) & 1ull) : grx_gate_clear(m, c, (gi)))
   constexpr bool kChunked = !S::kFixed || S::NG > 64;   // small scenes (every specialised shape but the kitchen): one pass, no loop around the sweep
   // Skin list (large scenes, GPU build): the kitchen has 3 736 candidate pairs of which ~170 pass the bounding-sphere test and ~250 are within 10 cm of
   // passing it.  The flat sweep of all candidates in every substep is replaced by a sweep of the pairs that passed the test with the radius inflated
@@ -2080,6 +2132,9 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int kk = kp[u]; rec[u] = (unsigned)m->devpair_geoms[kk]; mg[u] = m->devpair_bound[2 * kk]; rb[u] = m->devpair_bound[2 * kk + 1]; }
+        int gate[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) gate[u] = kGate ? m->devpair_gate[kp[u]] : -1;
         int pass[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -2089,6 +2144,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
           if (t1 == 0) { float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}; ps = dot3f(dx, n) <= rb[u] + mg[u]; }
           else { const float r = rb[u] + mg[u]; ps = dot3f(dx, dx) <= r * r; }
           pass[u] = ok[u] && ps;
+          if (kGate && pass[u] && gate[u] >= 0 && GRX_GATE_CLEAR(gate[u])) pass[u] = 0;   // proven disjoint at these joint values
           if (classed) {
             const int t2 = rec[u] >> 28;
             // Large scenes, second filter: the bounding spheres of long thin geoms are loose (the kitchen: ~120 capsule-box candidates per substep pass
@@ -2159,6 +2215,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
             float r = rb + margin;
             pass = dot3f(dx, dx) <= r * r;
           }
+          if (kGate && pass) { const int gi = m->devpair_gate[k]; if (gi >= 0 && GRX_GATE_CLEAR(gi)) pass = 0; }
         }
         pq = m->devpair[k];
         if (pass) {
@@ -2428,6 +2485,9 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   const int rows0 = ne + nf + nl, pool0 = wpool + nf + nlj + tpool;
   const int maxefc = c->maxefc, jpool = c->jpool;
   int overflow = (rows0 > maxefc) || (pool0 > jpool), ncon_fit = ncon, nc = nc_all;
+#ifndef GRX_PROBE_HULL
+  GRX_PMAX(c, 29, rows0 + nc_all); GRX_PMAX(c, 30, pool0 + pool_all); GRX_PMAX(c, 31, c->cnt[0]);
+#endif
   if (c->soft_maxefc > 0 && (rows0 + nc_all > c->soft_maxefc || pool0 + pool_all > c->soft_jpool || c->cnt[0] > c->soft_maxcon)) { LANE0 { c->cnt[2] |= GRX_ST_SOFT; } }
   if (rows0 + nc_all > maxefc || pool0 + pool_all > jpool) {  // rare: find the first contact that does not fit
     GRX_LANEVAR(failp);

@@ -305,6 +305,8 @@ def pack_blob(tables: Dict[str, np.ndarray]):
     ints, flts = [], []
     io = fo = 0
     for k, (name, kind) in enumerate(fl):
+        if name not in tables and name in ("devpair_gate", "gate_qadr", "gate_box"):      # blobs written before the pair gates existed: no gates
+            tables = dict(tables, devpair_gate=-np.ones(np.asarray(tables["devpair"]).size, np.int32), gate_qadr=np.zeros(0, np.int32), gate_box=np.zeros(0))
         a = np.ascontiguousarray(tables[name]).ravel()
         if kind == "i":
             a = a.astype(np.int32)
@@ -1674,6 +1676,13 @@ class _Lowering:
         g1s, g2s = pair_geom1[dp], pair_geom2[dp]
         T["devpair_geoms"] = (g1s | (g2s << 12) | (geom_type[g1s] << 24) | (geom_type[g2s] << 28)).astype(np.int64).astype(np.uint32).view(np.int32) if len(dp) else np.zeros(0, np.int32)
         T["devpair_bound"] = np.stack([pair_margin[dp], np.where(geom_type[g1s] == GEOM_PLANE, geom_rbound[g2s], geom_rbound[g1s] + geom_rbound[g2s])], axis=1) if len(dp) else np.zeros((0, 2))
+        # joint-box gates of the hull pairs (mjcf/pair_gates.py; requested per model family: the analysis takes a minute or two)
+        T["devpair_gate"], T["gate_qadr"], T["gate_box"] = -np.ones(len(dp), np.int32), np.zeros(0, np.int32), np.zeros(0)
+        if c.capacity.get("pair_gates") and len(dp):
+            from .pair_gates import compute_pair_gates
+
+            T["devpair_gate"], T["gate_qadr"], T["gate_box"], rep = compute_pair_gates(T)
+            info["pair_gates"] = [dict(pair=p_, geoms=[g1_, g2_], joints=j_, box=b_, slack=s_) for p_, g1_, g2_, j_, b_, s_ in rep]
         info["nmpair"] = len(mpi)
         info["nbody_full"] = nb
         info["unsupported_pairs"] = int(np.sum(pair_supported == 0))

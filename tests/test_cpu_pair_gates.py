@@ -1,0 +1,59 @@
+"""Joint-box gates of the hull pairs (gymnasium_robotics_amd/mjcf/pair_gates.py): the packaged Fetch models carry them, and the checker -- which does not know
+about gates and sends every candidate through the bounding-box filter and the portal routine -- finds NO contact for a gated pair at joint values inside its box.
+The engine-source side (the emulator runs the gated sweep, the oracle the ungated one) is covered by the teacher-forced fixtures of test_cpu_engine_emu.py."""
+import numpy as np
+import pytest
+
+from gymnasium_robotics_amd.envs.fetch import load_fetch_model
+from oracle.oracle_sim import OracleSim
+
+
+@pytest.mark.parametrize("task", ["FetchPickAndPlace", "FetchReach"])
+def test_packaged_fetch_models_carry_gates(task):
+    m = load_fetch_model(task)
+    T = m.tables
+    gate = np.asarray(T["devpair_gate"]).ravel()
+    assert gate.size == np.asarray(T["devpair"]).size and (gate >= 0).sum() >= 30
+    qa, box = np.asarray(T["gate_qadr"]).reshape(-1, 3), np.asarray(T["gate_box"]).reshape(-1, 3, 2)
+    assert len(qa) == len(box) == gate.max() + 1
+    g = m.names["geom"]
+    pairs = {(int(T["pair_geom1"][p]), int(T["pair_geom2"][p])): int(gate[k]) for k, p in enumerate(np.asarray(T["devpair"]).ravel())}
+    gi = pairs[(g["robot0:torso_lift_link"], g["robot0:shoulder_lift_link"])]      # the pair that passed the bounding-box filter in every substep of every world
+    assert gi >= 0
+    jq = {int(T["jnt_qposadr"][j]): n for n, j in m.names["joint"].items()}
+    named = {jq[int(a)]: tuple(b) for a, b in zip(qa[gi], box[gi]) if a >= 0}
+    lo, hi = named["robot0:shoulder_pan_joint"]
+    assert lo < -0.9 and hi > 0.8          # covers the pan angles the tasks reach (|pan| < 0.8 in random-action rollouts)
+    assert all(b[0] < b[1] for b in box.reshape(-1, 2) if b[0] > -1e29)
+
+
+def test_no_contact_inside_a_gate_box():
+    m = load_fetch_model("FetchPickAndPlace")
+    T = m.tables
+    sim = OracleSim(m)
+    rng = np.random.default_rng(0)
+    gate = np.asarray(T["devpair_gate"]).ravel()
+    qa, box = np.asarray(T["gate_qadr"]).reshape(-1, 3), np.asarray(T["gate_box"]).reshape(-1, 3, 2)
+    dp = np.asarray(T["devpair"]).ravel()
+    jr, jl, jq, jt = np.asarray(T["jnt_range"]).reshape(-1, 2), np.asarray(T["jnt_limited"]).ravel(), np.asarray(T["jnt_qposadr"]).ravel(), np.asarray(T["jnt_type"]).ravel()
+    q0 = np.asarray(T["qpos0"]).ravel().copy()
+    hits = tested = 0
+    for trial in range(400):
+        q = q0.copy()
+        for j in range(len(jt)):                    # every hinge / slide joint anywhere in its range (unlimited hinges: a full turn)
+            if jt[j] == 3:
+                q[jq[j]] = rng.uniform(*(jr[j] if jl[j] else (-np.pi, np.pi)))
+            elif jt[j] == 2 and jl[j]:
+                q[jq[j]] = rng.uniform(*jr[j])
+        sim.qpos[:] = q
+        sim.forward()
+        con = sim.contacts()
+        touching = {(int(c[7]), int(c[8])) for c in con}
+        for k, p in enumerate(dp):
+            if gate[k] < 0:
+                continue
+            inside = all(a < 0 or (b[0] < q[a] < b[1]) for a, b in zip(qa[gate[k]], box[gate[k]]))
+            if inside:
+                tested += 1
+                hits += (int(T["pair_geom1"][p]), int(T["pair_geom2"][p])) in touching
+    assert tested > 5000 and hits == 0

@@ -17,7 +17,7 @@ os.makedirs(OUT, exist_ok=True)
 from gymnasium_robotics_amd.envs.fetch import FETCH_CAPACITY  # noqa: E402
 
 for xml in ("fetch/reach.xml", "fetch/push.xml", "fetch/slide.xml", "fetch/pick_and_place.xml"):
-    m = compile_mjcf(os.path.join(ASSETS, xml), capacity=FETCH_CAPACITY)
+    m = compile_mjcf(os.path.join(ASSETS, xml), capacity=dict(FETCH_CAPACITY, pair_gates=True))      # joint-box gates of the hull pairs (mjcf/pair_gates.py): minutes per model, packaged blobs only
     # keep hull vertices only for meshes that take part in a supported pair
     out = os.path.join(OUT, os.path.splitext(os.path.basename(xml))[0] + ".npz")
     save_model(m, out)

@@ -19,4 +19,6 @@ if len(sys.argv) > 1:
 if "iter" not in os.environ.get("GRX_HIP_LIB", ""):
     c = raw.astype(np.float64) * 0.08   # us
     k = np.mean([a.elapsed_time(b) for a, b in env.kernel_events[10:]])
+    top = np.sort(c)[::-1]
+    print("slowest worlds (us):", " ".join(f"{x:.0f}" for x in top[:12]), "| worlds above 1.5 / 2.0 ms:", int((c > 1500).sum()), int((c > 2000).sum()))
     print(f"world durations (us): min {c.min():.0f} p10 {np.quantile(c,.1):.0f} p50 {np.median(c):.0f} p90 {np.quantile(c,.9):.0f} p99 {np.quantile(c,.99):.0f} max {c.max():.0f}; sum/2048 slots = {c.sum()/2048:.0f} us; kernel {k*1e3:.0f} us")
