@@ -114,6 +114,7 @@ def lib():
         L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_float, ci, vp, vp]
         L.grx_manip_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]
         L.grx_order_by_cost.argtypes = [vp, vp, ctypes.c_float, ci, vp, vp]
+        L.grx_order_by_cost_slots.argtypes = [vp, vp, ctypes.c_float, ci, ci, vp, vp]
         L.grx_maze_reset_rows.argtypes = [vp, ci, vp]
         L.grx_hand_commit_rows.argtypes = [vp, vp]
         cd = ctypes.c_double
@@ -129,5 +130,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
 ]

@@ -120,11 +120,14 @@ __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetc
 __device__ long long g_grx_prof[GRX_NPROF];
 extern "C" int grx_profile_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grx_prof), sizeof(long long) * GRX_NPROF); }
 extern "C" int grx_profile_reset() { long long z[GRX_NPROF] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grx_prof), z, sizeof(z)); }
-// per-world start / end timestamps of the last Fetch step launch (wall_clock64: one clock for the whole device): load balance across worlds
-__device__ long long g_grx_world_span[2 * 16384];
 // per-world stage cycles of the last Fetch step launch (first 4096 worlds): which stages make a slow world slow (tools/straggler_probe.py)
 __device__ int g_grx_world_prof[4096 * GRX_NPROF];
 extern "C" int grx_profile_world_stages(int* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grx_world_prof), sizeof(int) * GRX_NPROF * n); }
+#endif
+#if defined(GRX_PROFILE) || defined(GRX_WORLD_SPAN)
+// per-world start / end timestamps of the last Fetch step launch (wall_clock64: one clock for the whole device): load balance across worlds.  -DGRX_WORLD_SPAN alone
+// records them in a build that is otherwise the product build (same LDS footprint and occupancy: tools/span_probe.py)
+__device__ long long g_grx_world_span[2 * 16384];
 extern "C" int grx_profile_world_spans(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grx_world_span), sizeof(long long) * 2 * n); }
 #endif
 
@@ -202,6 +205,9 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
 #ifndef GRX_COST_MODEL
   if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp (100 MHz), parked in the cost slot itself: nothing stays live across the substep loop
 #endif
+#if defined(GRX_WORLD_SPAN) && !defined(GRX_PROFILE)
+  if (lane_ == 0 && w < 16384) g_grx_world_span[2 * w] = wall_clock64();
+#endif
   grx_load_world(m, b, c, w, lds, words, lane_);
   if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) c.meshcache[lane_] = b.hullcache[(size_t)w * 21 + lane_];   // separating directions remembered from the previous step (re-verified before use)
   float aux_in[8];
@@ -228,6 +234,9 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
 #else
   if (b.cost && lane_ == 0) { const int t0 = ((volatile int*)b.cost)[wl]; b.cost[wl] = ((int)wall_clock64() - t0) >> 3; }
 #endif
+#endif
+#if defined(GRX_WORLD_SPAN) && !defined(GRX_PROFILE)
+  if (lane_ == 0 && wl < 16384) g_grx_world_span[2 * wl + 1] = wall_clock64();
 #endif
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
@@ -1131,7 +1140,7 @@ extern "C" int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task
 // (bitonic, descending cost, ties by world index) and writes order[i * 8 + slice] = the i-th most expensive world of the slice --
 // workgroup b of the next step launch runs on XCD b & 7 and starts in index order.
 extern "C" __global__ void __launch_bounds__(256)
-grx_order_kernel(const int* __restrict__ cost, float* __restrict__ ema, float alpha, int per, int npow2, int* __restrict__ order) {
+grx_order_kernel(const int* __restrict__ cost, float* __restrict__ ema, float alpha, int per, int npow2, int slots, int* __restrict__ order) {
   extern __shared__ unsigned long long keys[];
   const int s = blockIdx.x, base = s * per;
   for (int i = threadIdx.x; i < npow2; i += 256) {
@@ -1158,10 +1167,42 @@ grx_order_kernel(const int* __restrict__ cost, float* __restrict__ ema, float al
       }
       __syncthreads();
     }
-  for (int i = threadIdx.x; i < per; i += 256) order[i * 8 + s] = base + (0x7FFFFFFF - (int)(unsigned)(keys[i] & 0xFFFFFFFFull));
+  // Two worlds per wave slot (per <= 2 * slots: BASELINE cfg 2, 4096 worlds on 2048 slots).  K predicted stragglers -- worlds that take longer than the two
+  // cheapest worlds one after the other (the arm resting on the head: two hull pairs in contact) -- hold their slots for the whole launch, so M = per - 2 slots + K
+  // workgroups have to be a slot's THIRD world.  With the plain descending order those are dispatched when the first slots finish their second world, two MEDIAN
+  // worlds after the start, and end the launch alone (3.02 ms against 2.68 ms for the slowest world, profiles/cost_probe_r03.txt).  Here the 3 M cheapest worlds
+  // are placed so that M slots run three CHEAP worlds back to back: the M cheapest at the end of the first round (they free their slots first), the next M at the
+  // start of the second round (dispatched onto exactly those slots), the next M at the very end (dispatched when that second cheap world ends).
+  __shared__ int sM;
+  if (threadIdx.x == 0) {
+    int M = 0;
+    if (slots > 0 && per > slots && per <= 2 * slots) {
+      const unsigned long long thr = 2ull * (keys[per - 1] >> 32);
+      int K = 0;
+      while (K < per && (keys[K] >> 32) > thr) K++;
+      M = per - 2 * slots + K;
+      if (M < 0 || 3 * M > per - slots || M > slots / 4) M = 0;
+    }
+    sM = M;
+  }
+  __syncthreads();
+  const int M = sM;
+  for (int pos = threadIdx.x; pos < per; pos += 256) {
+    int i = pos;   // index into the descending list
+    if (M > 0) {
+      if (pos < slots - M) i = pos;
+      else if (pos < slots) i = per - M + (pos - (slots - M));
+      else if (pos < slots + M) i = per - 2 * M + (pos - slots);
+      else if (pos < per - M) i = pos - 2 * M;
+      else i = per - 3 * M + (pos - (per - M));
+    }
+    order[pos * 8 + s] = base + (0x7FFFFFFF - (int)(unsigned)(keys[i] & 0xFFFFFFFFull));
+  }
 }
 
-extern "C" int grx_order_by_cost(const int* cost, float* ema, float alpha, int n_worlds, int* order, void* stream) {
+extern "C" int grx_order_by_cost_slots(const int* cost, float* ema, float alpha, int n_worlds, int slots_per_xcd, int* order, void* stream);
+extern "C" int grx_order_by_cost(const int* cost, float* ema, float alpha, int n_worlds, int* order, void* stream) { return grx_order_by_cost_slots(cost, ema, alpha, n_worlds, 0, order, stream); }
+extern "C" int grx_order_by_cost_slots(const int* cost, float* ema, float alpha, int n_worlds, int slots_per_xcd, int* order, void* stream) {
   if (!cost || !order) return fail("grx_order_by_cost: null argument");
   if (ema && !(alpha > 0.0f && alpha <= 1.0f)) return fail("grx_order_by_cost: alpha must be in (0, 1]");
   if (n_worlds <= 0 || (n_worlds & 7)) return fail("grx_order_by_cost: the number of worlds must be a positive multiple of 8 (one contiguous slice per XCD)");
@@ -1169,7 +1210,7 @@ extern "C" int grx_order_by_cost(const int* cost, float* ema, float alpha, int n
   int npow2 = 1;
   while (npow2 < per) npow2 <<= 1;
   if ((size_t)npow2 * 8 > 64 * 1024) return fail("grx_order_by_cost: more than 65536 worlds per launch are not supported");
-  hipLaunchKernelGGL(grx_order_kernel, dim3(8), dim3(256), (size_t)npow2 * 8, (hipStream_t)stream, cost, ema, alpha, per, npow2, order);
+  hipLaunchKernelGGL(grx_order_kernel, dim3(8), dim3(256), (size_t)npow2 * 8, (hipStream_t)stream, cost, ema, alpha, per, npow2, slots_per_xcd < 0 ? 0 : slots_per_xcd, order);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -170,6 +170,9 @@ class FetchVecEnv(GoalVecEnv):
         self.cost_ema = torch.zeros(n, dtype=torch.float32, device=d) if self.balance else None
         self.balance_alpha = float(os.environ.get("GRX_BALANCE_ALPHA", 0.1))   # weight of the newest sample in the moving average the order is sorted by (A/B on FetchPickAndPlace: 1.0 -> 2.69 ms, 0.15 -> 2.64 ms per step)
         self.order = None
+        # wave slots of one XCD (32 CUs): worlds per CU = what the LDS footprint allows (1 280-byte granules of 160 KB), at most the 8 waves a 2-waves-per-SIMD kernel gets;
+        # grx_order_by_cost_slots uses it in the two-worlds-per-slot regime (4096 worlds on 2048 slots), GRX_TAIL_ORDER=0 restores the plain descending order
+        self._slots_per_xcd = 32 * min(8, (160 * 1024) // (-(-self.lds_bytes // 1280) * 1280)) if (self.balance and os.environ.get("GRX_TAIL_ORDER", "1") != "0") else 0
         if self.balance:
             per = n // 8
             self._slice_base = (torch.arange(8, device=d, dtype=torch.int32) * per).unsqueeze(1)          # [8,1]
@@ -189,7 +192,7 @@ class FetchVecEnv(GoalVecEnv):
 
     def _rebalance(self):
         """order <- per XCD slice, worlds by decreasing cost of the launch that just ran (in place: the buffer struct keeps its pointer)."""
-        _native.check(self._L.grx_order_by_cost(self.cost.data_ptr(), self.cost_ema.data_ptr(), self.balance_alpha, self.num_envs, self.order.data_ptr(), self._stream()))
+        _native.check(self._L.grx_order_by_cost_slots(self.cost.data_ptr(), self.cost_ema.data_ptr(), self.balance_alpha, self.num_envs, self._slots_per_xcd, self.order.data_ptr(), self._stream()))
 
     @staticmethod
     def _make_bufs(*tensors):

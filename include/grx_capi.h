@@ -239,6 +239,10 @@ int grx_fetch_reset(const grx_model* m, const grx_fetch_task* task, const grx_fe
  * grx_hand_buffers.cost): per XCD slice of n_worlds / 8 contiguous worlds, decreasing cost.  With `ema` the key is the exponential moving
  * average ema <- (1 - alpha) ema + alpha cost, kept in the caller's buffer (measured best around alpha = 0.15).  n_worlds must be a multiple of 8. */
 int grx_order_by_cost(const int* cost, float* ema /* [N] in/out or NULL */, float alpha, int n_worlds, int* order, void* stream);
+/* The same for a launch of at most two worlds per wave slot (slots_per_xcd = worlds resident per XCD: worlds per CU x 32; 0 = the plain order above): the worlds
+ * that will be a slot's THIRD world (as many as predicted stragglers hold a slot for the whole launch) are chosen and placed so that those slots run three cheap worlds
+ * back to back instead of two median worlds and one more (csrc/grx_kernels.hip, grx_order_kernel). */
+int grx_order_by_cost_slots(const int* cost, float* ema, float alpha, int n_worlds, int slots_per_xcd, int* order, void* stream);
 int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
                              float* reward_out, void* stream);
 /* Maze family (PointMaze and AntMaze, selected by task->agent; AntMazeEnv.step: envs/maze/ant_maze_v5.py:295-310).

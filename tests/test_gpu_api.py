@@ -81,6 +81,50 @@ def test_serialize_deserialize_keeps_constructor_arguments():
     env1.close(); env2.close()
 
 
+def test_order_by_cost_slots_places_three_cheap_worlds_on_the_slots_that_run_three():
+    """grx_order_by_cost_slots in the two-worlds-per-slot regime (512 worlds per XCD slice on 256 slots): with K stragglers (cost > 2 x the cheapest) M = K workgroups
+    are a slot's third world; the M cheapest worlds end the first round, the next M start the second round, the next M end the launch, everything else keeps the
+    decreasing order; a permutation inside every slice.  slots = 0 and other regimes: the plain order."""
+    import ctypes
+
+    import torch
+
+    from gymnasium_robotics_amd import _native
+
+    L = _native.lib()
+    n, per, slots = 4096, 512, 256
+    rng = np.random.default_rng(3)
+    cost = rng.integers(1000, 1400, n).astype(np.int32)
+    strag = {s: rng.choice(per, size=3 + (s % 3), replace=False) + s * per for s in range(8)}
+    for s in range(8):
+        cost[strag[s]] = rng.integers(2900, 3400, len(strag[s]))
+    ct = torch.from_numpy(cost).to("cuda:0")
+    plain = torch.full((n,), -1, device="cuda:0", dtype=torch.int32)
+    tail = torch.full((n,), -1, device="cuda:0", dtype=torch.int32)
+    _native.check(L.grx_order_by_cost_slots(ct.data_ptr(), None, 0.0, n, 0, plain.data_ptr(), None))
+    _native.check(L.grx_order_by_cost_slots(ct.data_ptr(), None, 0.0, n, slots, tail.data_ptr(), None))
+    torch.cuda.synchronize()
+    P, T_ = plain.cpu().numpy().reshape(per, 8), tail.cpu().numpy().reshape(per, 8)
+    for s in range(8):
+        d, t = P[:, s], T_[:, s]                      # d: the decreasing list of the slice
+        assert sorted(t.tolist()) == sorted(d.tolist()) == list(range(s * per, (s + 1) * per))
+        M = len(strag[s])
+        assert set(d[:M].tolist()) == set(strag[s].tolist())
+        assert (t[:slots - M] == d[:slots - M]).all()                                   # stragglers and the expensive half first
+        assert (t[slots - M:slots] == d[per - M:]).all()                                # the M cheapest end the first round
+        assert (t[slots:slots + M] == d[per - 2 * M:per - M]).all()                     # the next M start the second round
+        assert (t[slots + M:per - M] == d[slots - M:per - 3 * M]).all()                 # the middle, still decreasing
+        assert (t[per - M:] == d[per - 3 * M:per - 2 * M]).all()                        # the next M are dispatched last
+    # three rounds and more (1024 worlds per slice on 256 slots): the plain order
+    n2 = 8192
+    c2 = torch.from_numpy(rng.integers(1000, 4000, n2).astype(np.int32)).to("cuda:0")
+    o1 = torch.empty(n2, device="cuda:0", dtype=torch.int32); o2 = torch.empty(n2, device="cuda:0", dtype=torch.int32)
+    _native.check(L.grx_order_by_cost_slots(c2.data_ptr(), None, 0.0, n2, 0, o1.data_ptr(), None))
+    _native.check(L.grx_order_by_cost_slots(c2.data_ptr(), None, 0.0, n2, slots, o2.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert (o1 == o2).all()
+
+
 def test_order_by_cost_and_balance_invariance():
     """grx_order_by_cost: per XCD slice (n / 8 contiguous worlds) decreasing cost, ties by world index, workgroup b -> slice b & 7.
     The dispatch order is a scheduling choice only: a balanced and an unbalanced env produce bit-identical outputs."""
