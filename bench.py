@@ -55,6 +55,14 @@ HER_K = 4  # relabelled goals per transition ("future" strategy with k=4); 28 B 
 HBM_PEAK_GBS = 8000.0
 
 
+def _set_elapsed(env, elapsed):
+    """episode positions of the worlds: the envs that keep their TimeLimit counters on the device take them through set_elapsed()"""
+    if hasattr(env, "set_elapsed"):
+        env.set_elapsed(elapsed)
+    else:
+        env._elapsed[:] = elapsed
+
+
 def make_env(workload, n, device, rank):
     w = WORKLOADS[workload]
     kw = dict(num_envs=n, device=device, output="torch", autoreset_mode="same_step", seed_offset=rank * n)
@@ -214,7 +222,7 @@ def run_rank_mixed(args, rank, world_size, local_rank):
         env = _DryEnv(name, half, rank) if dry else make_env(name, half, device, rank)
         env.reset(seed=0)
         if args.stagger:
-            env._elapsed[:] = np.arange(half) % (env.max_episode_steps or WORKLOADS[name]["horizon"])
+            _set_elapsed(env, np.arange(half) % (env.max_episode_steps or WORKLOADS[name]["horizon"]))
         g = torch.Generator(device=device)
         g.manual_seed(1234 + 2 * rank + k)
         envs.append(env); streams.append(None if dry else torch.cuda.Stream(device=device)); gens.append(g)
@@ -323,7 +331,7 @@ def run_rank(args, rank, world_size, local_rank):
     env = _DryEnv(args.workload, n, rank) if dry else make_env(args.workload, n, device, rank)
     env.reset(seed=0)
     if args.stagger:   # steady state: every step resets its share of the worlds (world i is i mod horizon steps into its episode)
-        env._elapsed[:] = np.arange(n) % (env.max_episode_steps or w["horizon"])
+        _set_elapsed(env, np.arange(n) % (env.max_episode_steps or w["horizon"]))
     act_dim = env.single_action_space.shape[0]
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)

@@ -57,6 +57,12 @@ class KitchenBuffersStruct(ctypes.Structure):
         ("skin_stride", ctypes.c_int), ("skin_radius", ctypes.c_float), ("lane", OverflowLaneStruct)]
 
 
+class KitchenBookStruct(ctypes.Structure):      # include/grx_capi.h, grx_kitchen_book
+    _fields_ = [(n, ctypes.c_void_p) for n in ("completed", "stepped", "tasks_to_complete", "episode_completions", "elapsed", "step_completions", "reward", "terminated",
+                                               "truncated", "needs_reset", "reset_now", "qpos", "qvel", "qacc_ws", "init_qpos")] + [
+        (n, ctypes.c_int) for n in ("nq", "nv", "all_mask", "max_steps", "remove_when_completed", "terminate_when_completed", "mode")]
+
+
 class HerArgsStruct(ctypes.Structure):
     _fields_ = [("rows", ctypes.c_void_p), ("acts", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in ("T", "N", "W", "obs_dim", "goal_dim", "act_dim")] + [
         (n, ctypes.c_void_p) for n in ("t_idx", "w_idx", "t_goal")] + [("kind", ctypes.c_int), ("p0", ctypes.c_float), ("p1", ctypes.c_float)] + [
@@ -107,6 +113,8 @@ def lib():
         L.grx_her_mark_resets.argtypes = [vp, ci, ci, vp, vp, vp, vp]
         L.grx_kitchen_step.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_sample_uniform_rows.argtypes = [vp, vp, ci, ci, vp]
+        L.grx_uniform_rows_device.argtypes = [vp, vp, ci, ci, vp, vp]
+        L.grx_kitchen_bookkeeping.argtypes = [vp, ci, vp]
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
         L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
@@ -130,5 +138,5 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_uniform_rows_device", "grx_kitchen_bookkeeping", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
 ]

@@ -1471,6 +1471,83 @@ extern "C" int grx_sample_uniform_rows(uint64_t* states, const int64_t* idx, int
   return 0;
 }
 
+// ---- the same streams advanced ON THE DEVICE (include/grx_capi.h, grx_uniform_rows_device): one thread per world walks its numpy PCG64 stream -- the 128-bit
+// LCG step in 64-bit halves (mul-hi for the carry), the XSL-RR output, numpy's 53-bit double and uniform(-1, 1) = -1 + 2 d in fp64 (2 d is exact, so an fma
+// contraction rounds like the two operations), rounded to float32 like the host routine: bit-equal rows (tests/test_gpu_kitchen.py), no upload, no host loop.
+__global__ void __launch_bounds__(256)
+grx_uniform_rows_kernel(unsigned long long* __restrict__ states, const unsigned char* __restrict__ mask, int n, int count, float* __restrict__ out) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n || (mask && !mask[w])) return;
+  unsigned long long hi = states[4 * w], lo = states[4 * w + 1];
+  const unsigned long long ihi = states[4 * w + 2], ilo = states[4 * w + 3];
+  const unsigned long long mhi = 0x2360ED051FC65DA4ULL, mlo = 0x4385DF649FCCF645ULL;
+  for (int e = 0; e < count; e++) {
+    const unsigned long long plo = lo * mlo, phi = __umul64hi(lo, mlo) + hi * mlo + lo * mhi;   // (hi:lo) * (mhi:mlo) mod 2^128
+    lo = plo + ilo;
+    hi = phi + ihi + (lo < plo ? 1ULL : 0ULL);
+    const unsigned long long x = hi ^ lo; const unsigned rot = (unsigned)(hi >> 58);
+    const unsigned long long r = (x >> rot) | (x << ((64 - rot) & 63));
+    const double d = (double)(r >> 11) * (1.0 / 9007199254740992.0);
+    out[(size_t)w * count + e] = (float)(-1.0 + 2.0 * d);
+  }
+  states[4 * w] = hi; states[4 * w + 1] = lo;
+}
+extern "C" int grx_uniform_rows_device(uint64_t* states, const unsigned char* mask, int n, int count, float* out, void* stream) {
+  if (!states || !out) return fail("grx_uniform_rows_device: null argument");
+  if (n <= 0 || count <= 0) return 0;
+  hipLaunchKernelGGL(grx_uniform_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)states, mask, n, count, out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ---- KitchenEnv.step's task bookkeeping on the device (kitchen_env.py:386-423; include/grx_capi.h, grx_kitchen_bookkeeping): one thread per world
+struct GrxKitchenBook {
+  const int* completed; const unsigned char* stepped;   // completion bits of this observation (step kernel); worlds this step covered (null = all)
+  int *tasks_to_complete, *episode_completions, *elapsed, *step_completions;
+  float* reward; unsigned char *terminated, *truncated, *needs_reset, *reset_now;
+  float *qpos, *qvel, *qacc_ws; const float* init_qpos;
+  int nq, nv, all_mask, max_steps, remove_when_completed, terminate_when_completed, mode;   // mode 0 disabled, 1 next_step, 2 same_step
+};
+static_assert(sizeof(grx_kitchen_book) == sizeof(GrxKitchenBook), "grx_kitchen_book must mirror GrxKitchenBook");
+__global__ void __launch_bounds__(256)
+grx_kitchen_book_kernel(GrxKitchenBook a, int n) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n) return;
+  const int stepped = a.stepped ? a.stepped[w] != 0 : 1;
+  const int pending = a.mode == 1 && a.needs_reset[w];     // next_step: the world finished its episode in the previous step and resets in this one
+  int ttc = a.tasks_to_complete[w], epi = a.episode_completions[w], el = a.elapsed[w];
+  const int step_done = stepped ? (a.completed[w] & ttc) : 0;
+  if (a.remove_when_completed) ttc &= ~step_done;
+  epi |= step_done;
+  const int term = a.terminate_when_completed && stepped && epi == a.all_mask;
+  if (stepped) el++;
+  const int trunc = a.max_steps > 0 && stepped && el >= a.max_steps;
+  const int done = term | trunc;
+  const int reset_now = pending || (a.mode == 2 && done);
+  a.reward[w] = pending ? 0.0f : (float)__popc((unsigned)step_done);
+  a.terminated[w] = (unsigned char)term; a.truncated[w] = (unsigned char)trunc;
+  a.step_completions[w] = (a.mode == 2 && done) ? 0 : step_done;      // a same-step reset world reports its NEW episode (the finished one is in the final_* rows)
+  if (a.mode == 1) a.needs_reset[w] = (unsigned char)(pending ? 0 : (a.needs_reset[w] | done));
+  a.reset_now[w] = (unsigned char)reset_now;
+  if (reset_now) {      // FrankaRobot.reset_model (franka_env.py:133-139): init_qpos, zero velocity; mj_resetData zeroes the warm start
+    ttc = a.all_mask; epi = 0; el = 0;
+    for (int i = 0; i < a.nq; i++) a.qpos[(size_t)w * a.nq + i] = a.init_qpos[i];
+    for (int i = 0; i < a.nv; i++) { a.qvel[(size_t)w * a.nv + i] = 0.0f; a.qacc_ws[(size_t)w * a.nv + i] = 0.0f; }
+  }
+  a.tasks_to_complete[w] = ttc; a.episode_completions[w] = epi; a.elapsed[w] = el;
+}
+extern "C" int grx_kitchen_bookkeeping(const grx_kitchen_book* args, int n_worlds, void* stream) {
+  if (!args) return fail("grx_kitchen_bookkeeping: null argument");
+  GrxKitchenBook a; memcpy(&a, args, sizeof(a));
+  if (!a.completed || !a.tasks_to_complete || !a.episode_completions || !a.elapsed || !a.step_completions || !a.reward || !a.terminated || !a.truncated || !a.needs_reset ||
+      !a.reset_now || !a.qpos || !a.qvel || !a.qacc_ws || !a.init_qpos) return fail("grx_kitchen_bookkeeping: null buffer");
+  if (a.mode < 0 || a.mode > 2 || a.nq <= 0 || a.nv <= 0) return fail("grx_kitchen_bookkeeping: bad mode / dimensions");
+  if (n_worlds <= 0) return 0;
+  hipLaunchKernelGGL(grx_kitchen_book_kernel, dim3((unsigned)((n_worlds + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, n_worlds);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
                                         float* reward_out, void* stream) {
   if (!achieved || !desired || !reward_out) return fail("grx_fetch_compute_reward: null argument");

@@ -3,9 +3,13 @@
 Vectorised drop-in for KitchenEnv (/root/reference/gymnasium_robotics/envs/franka_kitchen/kitchen_env.py, id FrankaKitchen-v1,
 gymnasium_robotics/__init__.py:1117-1122) and the FrankaRobot it wraps (franka_env.py).  Per step: ONE launch of grx_kitchen_step_kernel
 (velocity command -> position targets on the previous noisy joint reading, 40 physics substeps on the 124-geom scene with its five joint equalities,
-the 59-vector observation with noise, the seven tasks' completion tests).  Host side: the observation noise -- 59 uniform(-1, 1) draws per world and
-step from each world's numpy PCG64 stream, advanced bit-exactly in C (grx_sample_uniform_rows) and uploaded with one copy -- and the task bookkeeping
-of KitchenEnv.step (tasks_to_complete / episode completions as per-world bit masks).
+the 59-vector observation with noise, the seven tasks' completion tests).  The observation noise -- 59 uniform(-1, 1) draws per world and step from each
+world's numpy PCG64 stream -- and the task bookkeeping of KitchenEnv.step (tasks_to_complete / episode completions as per-world bit masks) run
+
+* output="torch": ON THE DEVICE.  The streams' 128-bit states live in HBM and are advanced by grx_uniform_rows_device (bit-equal to Generator.uniform), the
+  bookkeeping, the TimeLimit and the autoreset decision are one kernel (grx_kitchen_bookkeeping), the reset of the finished worlds is a masked forward launch:
+  step() enqueues eight launches and returns device tensors -- no host synchronisation, no PCIe traffic (round 2: one 64 KB read-back and 3.9 MB of noise per step);
+* output="numpy": on the host (C loop over the streams, one upload; the completion bits are read back), the path the fixtures pin.
 
 Observations: {"observation": (N, 59), "achieved_goal": {task: (N, k)}, "desired_goal": {task: (N, k)}} -- the reference's dict-of-dicts with a
 leading world axis.  reward = number of still-open tasks completed in this step; terminated when every task of the episode has been completed
@@ -81,6 +85,25 @@ class KitchenVecEnv(GoalVecEnv):
         self._goal_t = {t: torch.from_numpy(self._goal_np[t].astype(np.float32)).to(d) for t in self.tasks}
         self.tasks_to_complete = np.full(n, self._all_mask, np.int64)          # per-world bit masks (bit k = TASKS[k])
         self.episode_task_completions = np.zeros(n, np.int64)
+        # output="torch": bookkeeping, TimeLimit, autoreset and the noise streams on the device (GRX_KITCHEN_HOST_PATH=1: the round-2 host path, for A/B)
+        import os
+        self._device_path = self.output == "torch" and os.environ.get("GRX_KITCHEN_HOST_PATH") is None
+        if self._device_path:
+            i32 = lambda: torch.zeros(n, dtype=torch.int32, device=d)
+            u8 = lambda: torch.zeros(n, dtype=torch.uint8, device=d)
+            self.d_ttc, self.d_epi, self.d_elapsed, self.d_stepdone = i32(), i32(), i32(), i32()
+            self.d_reward, self.d_term, self.d_trunc, self.d_needs, self.d_resetnow = z(n), u8(), u8(), u8(), u8()
+            self.d_rng = torch.zeros(n, 4, dtype=torch.int64, device=d)          # the worlds' PCG64 states (state_hi, state_lo, inc_hi, inc_lo), uint64 bit patterns
+            self.final_obs, self.final_qpos, self.d_final_stepdone = z(n, self.obs_dim), z(n, self.nq), i32()
+            self._book = _native.KitchenBookStruct()
+            for name, t in (("completed", self.completed), ("stepped", self.mask), ("tasks_to_complete", self.d_ttc), ("episode_completions", self.d_epi), ("elapsed", self.d_elapsed),
+                            ("step_completions", self.d_stepdone), ("reward", self.d_reward), ("terminated", self.d_term), ("truncated", self.d_trunc), ("needs_reset", self.d_needs),
+                            ("reset_now", self.d_resetnow), ("qpos", self.qpos), ("qvel", self.qvel), ("qacc_ws", self.qacc_ws), ("init_qpos", self._init_qpos)):
+                setattr(self._book, name, t.data_ptr())
+            self._book.nq, self._book.nv, self._book.all_mask = self.nq, self.nv, int(self._all_mask)
+            self._book.max_steps = int(self.max_episode_steps or 0)
+            self._book.remove_when_completed, self._book.terminate_when_completed = int(self.remove_task_when_completed), int(self.terminate_on_tasks_completed)
+            self._book.mode = {"disabled": 0, "next_step": 1, "same_step": 2}[self.autoreset_mode]
         self._seed_worlds([None] * n)
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
@@ -112,6 +135,9 @@ class KitchenVecEnv(GoalVecEnv):
             st[i] = [s["state"] >> 64, s["state"] & mask, s["inc"] >> 64, s["inc"] & mask]
         self._rng_state = st
         self._noise_uploaded = None
+        if self._device_path:
+            self.d_rng.copy_(torch.from_numpy(st.view(np.int64)))      # the streams live on the device from here on (grx_uniform_rows_device)
+            return
         self._refill_noise(None)
 
     # Every world's NEXT 59 draws are always sitting in the pinned `_noise_host` rows: an observation (step or reset) uploads its worlds' rows, and
@@ -185,9 +211,64 @@ class KitchenVecEnv(GoalVecEnv):
             seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
             self._seed_worlds(seeds)
         with torch.cuda.device(self.device):
+            if self._device_path:
+                self.qpos.copy_(self._init_qpos.expand_as(self.qpos))
+                self.qvel.zero_(); self.qacc_ws.zero_()
+                self.mask.fill_(1)
+                self._device_noise(self.mask)
+                self._launch(self._bufs_masked, True)
+                self.d_ttc.fill_(int(self._all_mask))
+                for t in (self.d_epi, self.d_elapsed, self.d_stepdone, self.d_needs, self.d_resetnow, self.d_term, self.d_trunc):
+                    t.zero_()
+                self._has_reset = True
+                return self._obs_dict(), self._device_info()
             self._reset_worlds(np.arange(self.num_envs))
         self._has_reset = True
         return self._obs_dict(), self._info(np.zeros(self.num_envs, np.int64))
+
+    # ------------------------------------------------------------------ the device path (output="torch")
+    def _device_noise(self, mask):
+        """the next 59 draws of the masked worlds' streams into their rows of self.noise (grx_uniform_rows_device: bit-equal to Generator.uniform(-1, 1))"""
+        if self._noisy:
+            _native.check(self._L.grx_uniform_rows_device(self.d_rng.data_ptr(), mask.data_ptr(), self.num_envs, self.obs_dim, self.noise.data_ptr(), self._stream()))
+
+    def _device_info(self):
+        return dict(tasks_to_complete=self.d_ttc, step_task_completions=self.d_stepdone, episode_task_completions=self.d_epi)
+
+    def set_elapsed(self, elapsed):
+        """episode positions of the worlds (benchmarks stagger the episodes so that every step carries its share of resets)"""
+        self._elapsed[:] = np.asarray(elapsed, dtype=np.int64)
+        if self._device_path:
+            self.d_elapsed.copy_(torch.from_numpy(np.asarray(elapsed, dtype=np.int32)))
+
+    def _step_launch_device(self):
+        if self.autoreset_mode == "next_step":
+            torch.bitwise_xor(self.d_needs, 1, out=self.mask)      # the worlds that finished in the previous step wait for their reset at the end of this one
+        else:
+            self.mask.fill_(1)
+        self._device_noise(self.mask)
+        self._launch(self._bufs_masked, False)
+
+    def _step_finish_device(self):
+        info = {}
+        same = self.autoreset_mode == "same_step"
+        if same:      # the rows of the finished episodes, before the bookkeeping kernel rewinds their state (which worlds: _final_obs, known to the device only)
+            self.final_obs.copy_(self.obs); self.final_qpos.copy_(self.qpos)
+        _native.check(self._L.grx_kitchen_bookkeeping(ctypes.byref(self._book), self.num_envs, self._stream()))
+        if self.autoreset_mode != "disabled":
+            if same:
+                done = (self.d_term | self.d_trunc).view(torch.bool)
+                fq = self.final_qpos
+                info["final_obs"] = {"observation": self.final_obs, "achieved_goal": {t: fq[:, OBS_ELEMENT_INDICES[t][0]: OBS_ELEMENT_INDICES[t][-1] + 1] for t in self.tasks},
+                                     "desired_goal": {t: self._goal_t[t] for t in self.tasks}}
+                info["_final_obs"] = done          # gymnasium's vector convention: the mask of the worlds whose final_obs rows are valid
+            self.mask.copy_(self.d_resetnow)
+            self._device_noise(self.mask)
+            keep = self.status.clone()
+            self._launch(self._bufs_masked, True)          # mj_forward + _get_obs of the worlds that were reset (every other workgroup returns at once)
+            self.status.copy_((keep & 0xFFFF) | (self.status & -65536))
+        info.update(self._device_info())
+        return self._obs_dict(), self.d_reward, self.d_term.view(torch.bool), self.d_trunc.view(torch.bool), self._status_info(info)
 
     # ------------------------------------------------------------------ step (kitchen_env.py:386-423)
     def step(self, actions):
@@ -205,6 +286,11 @@ class KitchenVecEnv(GoalVecEnv):
         if tuple(a.shape) != (self.num_envs, self.nu):
             raise ValueError(f"Action dimension mismatch. Expected {(self.num_envs, self.nu)}, found {tuple(a.shape)}")
         self.action.copy_(a.to(torch.float32), non_blocking=True)
+        if self._device_path:
+            with torch.cuda.device(self.device):
+                self._step_launch_device()
+            self._pending_finish = None
+            return
         with torch.cuda.device(self.device):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
             stepped = ~self._needs_reset
@@ -220,6 +306,9 @@ class KitchenVecEnv(GoalVecEnv):
         self._pending_finish = (pending, stepped)
 
     def step_finish(self):
+        if self._device_path:
+            with torch.cuda.device(self.device):
+                return self._step_finish_device()
         pending, stepped = self._pending_finish
         self._pending_finish = None
         info = {}

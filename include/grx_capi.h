@@ -267,6 +267,23 @@ int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, const grx_a
 int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task, const grx_kitchen_buffers* buf, int n_worlds, int forward_only, void* stream);
 /* `count` consecutive np_random.uniform(-1, 1) draws per listed world, float32 rows (states / idx as in grx_fetch_sample_resets; idx NULL = worlds 0..n-1).  HOST pointers. */
 int grx_sample_uniform_rows(uint64_t* states, const int64_t* idx, int n, int count, float* out);
+/* The same draws ON THE DEVICE: states [N,4] uint64 and out [N,count] float32 are DEVICE pointers, mask [N] uint8 or NULL selects the worlds whose streams advance
+ * (the others' rows and states are left alone).  Bit-equal to grx_sample_uniform_rows / numpy's Generator.uniform(-1, 1) (franka_env.py:118-127, kitchen_env.py:361-369):
+ * the observation noise of 16 384 kitchen worlds no longer crosses PCIe (3.9 MB per step) and no host loop runs per step. */
+int grx_uniform_rows_device(uint64_t* states, const unsigned char* mask, int n, int count, float* out, void* stream);
+/* KitchenEnv.step's bookkeeping after the physics (kitchen_env.py:386-423) for N worlds on the device: step completions = completion bits & tasks_to_complete,
+ * reward = their count, tasks_to_complete / episode_task_completions updates, terminated (every task of the episode completed), TimeLimit truncation, and the
+ * autoreset decision: reset_now[w] = 1 for the worlds whose state rows were just rewound to init_qpos / zero velocity (mode 2 same_step: done in this step; mode 1
+ * next_step: done in the previous one) -- the caller draws their observation noise (grx_uniform_rows_device with reset_now as mask) and runs the masked forward launch.
+ * Nothing is read back: KitchenVecEnv.step(output="torch") has no host synchronisation. */
+typedef struct grx_kitchen_book {
+  const int* completed; const unsigned char* stepped;
+  int *tasks_to_complete, *episode_completions, *elapsed, *step_completions;
+  float* reward; unsigned char *terminated, *truncated, *needs_reset, *reset_now;
+  float *qpos, *qvel, *qacc_ws; const float* init_qpos;
+  int nq, nv, all_mask, max_steps, remove_when_completed, terminate_when_completed, mode;
+} grx_kitchen_book;
+int grx_kitchen_bookkeeping(const grx_kitchen_book* args, int n_worlds, void* stream);
 int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
                             float* reward_out, void* stream);
 /* batched MujocoManipulateEnv.compute_reward on 7-vector pose goals (shadow_dexterous_hand/manipulate.py:87-142) */

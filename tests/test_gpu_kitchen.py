@@ -134,3 +134,101 @@ def test_skin_list_is_exact(radius):
             assert (hdr[:, 1] == 1).all() and (hdr[:, 0] > 0).all() and (hdr[:, 0] < 3736).all()      # every world owns a valid list that is shorter than the flat one
             print(f"skin {r}: list length p50 {np.median(hdr[:, 0]):.0f} max {hdr[:, 0].max()}")
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_device_noise_streams_equal_numpy():
+    """grx_uniform_rows_device: the worlds' numpy PCG64 streams advanced on the MI355X (128-bit LCG in 64-bit halves, fp64 uniform(-1, 1), float32 rows) are bit-equal to
+    Generator.uniform(-1, 1) -- the four draws of an observation (franka_env.py:118-127: 9 + 9, kitchen_env.py:361-369: 21 + 20); masked-out worlds keep state and rows"""
+    import torch
+
+    from gymnasium_robotics_amd import _native
+    from gymnasium_robotics_amd.core import np_random
+
+    L = _native.lib()
+    n = 300
+    st, m64 = np.zeros((n, 4), np.uint64), (1 << 64) - 1
+    gens = []
+    for i in range(n):
+        g = np_random(1000 + 7 * i)[0]
+        s = g.bit_generator.state["state"]
+        st[i] = [s["state"] >> 64, s["state"] & m64, s["inc"] >> 64, s["inc"] & m64]
+        gens.append(g)
+    d_st = torch.from_numpy(st.view(np.int64)).to("cuda:0")
+    out = torch.full((n, 59), 9.0, device="cuda:0")
+    mask = torch.ones(n, dtype=torch.uint8, device="cuda:0")
+    mask[5] = 0; mask[299] = 0
+    for rep in range(3):
+        _native.check(L.grx_uniform_rows_device(d_st.data_ptr(), mask.data_ptr(), n, 59, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i in range(n):
+            if i in (5, 299):
+                assert (got[i] == 9.0).all()
+                continue
+            want = np.concatenate([gens[i].uniform(low=-1.0, high=1.0, size=k) for k in (9, 9, 21, 20)]).astype(np.float32)
+            assert np.array_equal(got[i], want), (rep, i)
+    host = d_st.cpu().numpy().view(np.uint64)
+    assert np.array_equal(host[5], st[5]) and np.array_equal(host[299], st[299])
+    s0 = gens[0].bit_generator.state["state"]
+    assert int(host[0, 0]) == s0["state"] >> 64 and int(host[0, 1]) == s0["state"] & m64
+
+
+@pytest.mark.parametrize("mode", ["same_step", "next_step"])
+def test_device_path_equals_host_path(mode):
+    """output="torch" (noise streams, bookkeeping, TimeLimit and autoreset on the device: no host synchronisation) against output="numpy" (the host path the
+    fixtures pin): the same seed gives bit-identical observations -- the noise is the same bits -- rewards, flags and task masks, step by step, resets included."""
+    import torch
+
+    kw = dict(tasks_to_complete=["microwave", "kettle"], max_episode_steps=4, autoreset_mode=mode)
+    a, b = _env(6, output="numpy", **kw), _env(6, output="torch", **kw)
+    assert b._device_path and not a._device_path
+    oa, ia = a.reset(seed=11)
+    ob, ib = b.reset(seed=11)
+    assert np.array_equal(oa["observation"].astype(np.float32), ob["observation"].cpu().numpy())
+    rng = np.random.default_rng(0)
+    for t in range(11):
+        if t in (1, 6):            # world 2: microwave door at its goal -> a completion (and, at t = 6, kettle too for world 4: both tasks done -> terminated)
+            for e in (a, b):
+                e.qpos[2, 22] = -0.75
+        if t == 6:
+            for e in (a, b):
+                e.qpos[4, 22] = -0.75
+                e.qpos[4, 23:30] = torch.tensor([-0.23, 0.75, 1.62, 0.99, 0.0, 0.0, -0.06], device="cuda:0")
+        act = rng.uniform(-1, 1, (6, 9)).astype(np.float32)
+        oa, ra, ta, ua, ia = a.step(act)
+        ob, rb, tb, ub, ib = b.step(torch.from_numpy(act).to("cuda:0"))
+        assert np.array_equal(oa["observation"].astype(np.float32), ob["observation"].cpu().numpy()), t
+        for k in oa["achieved_goal"]:
+            assert np.array_equal(oa["achieved_goal"][k].astype(np.float32), ob["achieved_goal"][k].cpu().numpy())
+        assert np.array_equal(ra, rb.cpu().numpy().astype(np.float64)) and np.array_equal(ta, tb.cpu().numpy()) and np.array_equal(ua, ub.cpu().numpy()), t
+        for k in ("tasks_to_complete", "step_task_completions", "episode_task_completions"):
+            assert np.array_equal(ia[k], ib[k].cpu().numpy().astype(np.int64)), (t, k)
+        if mode == "same_step":
+            done = ta | ua
+            assert np.array_equal(done, ib["_final_obs"].cpu().numpy())
+            if done.any():
+                idx = np.nonzero(done)[0]
+                assert np.array_equal(ia["final_obs"]["observation"].astype(np.float32), ib["final_obs"]["observation"].cpu().numpy()[idx])
+    assert (ta | ua).any() or t > 0
+
+
+def test_torch_step_does_not_synchronise():
+    """KitchenVecEnv.step(output="torch") only enqueues: with torch's synchronisation debug mode set to "error" any blocking read-back / stream wait raises"""
+    import torch
+
+    env = _env(64, output="torch", autoreset_mode="same_step", max_episode_steps=3)
+    env.reset(seed=0)
+    act = torch.zeros(64, 9, device="cuda:0")
+    env.step(act)
+    torch.cuda.synchronize()
+    try:
+        torch.cuda.set_sync_debug_mode("error")
+    except Exception:
+        pytest.skip("this torch build has no synchronisation debug mode")
+    try:
+        for _ in range(5):
+            obs, r, term, trunc, info = env.step(act)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert r.is_cuda and term.is_cuda and info["tasks_to_complete"].is_cuda and bool((info["_final_obs"] == (term | trunc)).all())
