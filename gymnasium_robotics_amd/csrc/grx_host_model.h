@@ -56,7 +56,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   }
   m.nmeshpair = 0;   // hull against a primitive or another hull: the wave-cooperative routine (grx_mesh_pairs) and its 8-word direction cache
   for (int k = 0; k < v.n_devpair_geoms; k++) { const unsigned rec = (unsigned)v.devpair_geoms[k]; if ((rec >> 28) == 7 && ((rec >> 24) & 0xF) != 0) m.nmeshpair++; }
-  m.ngate = v.n_gate_qadr / 3;
+  m.ngate = v.n_gate_qadr / 3 < 64 ? v.n_gate_qadr / 3 : 64;   // one lane per gate (mjcf/pair_gates.py keeps at most 64)
   m.nshift = 0;
   for (int k = 0; k < v.n_body_shift; k++) m.nshift += v.body_shift[k] != 0;
   for (int k = 0; k < v.n_geom_shift; k++) m.nshift += v.geom_shift[k] != 0;

@@ -122,9 +122,10 @@ def _geom_cloud(T, g):
     return v @ _q2m(gq).T + gp
 
 
-def compute_pair_gates(T, cells2=256, cells3=40, iters2=120, iters3=48, safety=5e-4, max_width=None, verbose=None):
+def compute_pair_gates(T, cells2=256, cells3=40, iters2=120, iters3=48, safety=5e-4, max_width=None, verbose=None, max_gates=64):
     """T: the table dict of a compiled model (after `devpair` is final).  Returns (devpair_gate [ndevpair] int32, gate_qadr [3 * ngate] int32, gate_box [6 * ngate] float64,
-    report list).  A gate = up to three (qpos address, lo, hi); unused slots have address -1."""
+    report list).  A gate = up to three (qpos address, lo, hi); unused slots have address -1.  At most `max_gates` gates are kept (the engine evaluates them all once
+    per collision pass, one lane each): the pairs that are NEAREST at the model's reference configuration -- a far pair fails the bounding-sphere test anyway."""
     tr = _Tree(T)
     dp = np.asarray(T["devpair"]).ravel().astype(int)
     g1s, g2s = np.asarray(T["pair_geom1"]).ravel(), np.asarray(T["pair_geom2"]).ravel()
@@ -136,7 +137,7 @@ def compute_pair_gates(T, cells2=256, cells3=40, iters2=120, iters3=48, safety=5
     bshift = np.asarray(T["body_shift"]).ravel() if "body_shift" in T and len(np.asarray(T["body_shift"]).ravel()) else np.zeros(len(tr.par), int)
     gshift = np.asarray(T["geom_shift"]).ravel() if "geom_shift" in T and len(np.asarray(T["geom_shift"]).ravel()) else np.zeros(len(gt), int)
     devpair_gate = -np.ones(len(dp), np.int32)
-    gate_qadr, gate_box, report = [], [], []
+    gate_qadr, gate_box, report, nearness = [], [], [], []
     clouds = {}
     for k, p in enumerate(dp):
         ga, gbm = int(g1s[p]), int(g2s[p])
@@ -145,7 +146,7 @@ def compute_pair_gates(T, cells2=256, cells3=40, iters2=120, iters3=48, safety=5
         if gshift[ga] or gshift[gbm]:
             continue
         a, b = int(gb[ga]), int(gb[gbm])
-        if a == 0 or b == 0 or a == b:
+        if a == b:      # (a world-fixed geom against a body at most three joints from the world is a pair like any other)
             continue
         anc_a = tr.ancestors(a)
         common = next(x for x in tr.ancestors(b) if x in anc_a)
@@ -204,6 +205,7 @@ def compute_pair_gates(T, cells2=256, cells3=40, iters2=120, iters3=48, safety=5
         n = flat[0].size
         slack = sum(r * w * 0.5 for r, w in zip(Rb, widths))
         clear = np.zeros(n, bool)
+        lbs = []
         for c0 in range(0, n, 16384):
             sl = slice(c0, min(n, c0 + 16384))
             qs = {j: f[sl] for (j, _, _), f in zip(joints, flat)}
@@ -213,7 +215,9 @@ def compute_pair_gates(T, cells2=256, cells3=40, iters2=120, iters3=48, safety=5
             Rrel = np.einsum("nji,njk->nik", Ra, Rbm)                     # pose of b's frame in a's
             prel = np.einsum("nji,nj->ni", Ra, pb - pa)
             lb = _distance_lower_bound(A, B, Rrel, prel, iters2 if len(joints) <= 2 else iters3)
+            lbs.append(lb)
             clear[sl] = lb - slack > margin[p] + safety
+        lb_all = np.concatenate(lbs).reshape(shape)
         clear = clear.reshape(shape)
         home = tuple(int(np.clip(np.searchsorted(e, tr.q0[tr.jq[j]]) - 1, 0, len(e) - 2)) for (j, _, _), e in zip(joints, axes))
         if not clear[home]:
@@ -238,6 +242,7 @@ def compute_pair_gates(T, cells2=256, cells3=40, iters2=120, iters3=48, safety=5
                             grew = True
         box = [(float(e[l]) + 1e-6, float(e[h + 1]) - 1e-6) for e, l, h in zip(axes, lo_i, hi_i)]      # (the device compares fp32 copies of the bounds)
         devpair_gate[k] = len(gate_qadr) // 3
+        nearness.append(float(lb_all[home]))
         qa = [int(tr.jq[j]) for j, _, _ in joints] + [-1] * (3 - len(joints))
         bx = box + [(-1e30, 1e30)] * (3 - len(joints))
         gate_qadr += qa
@@ -245,4 +250,11 @@ def compute_pair_gates(T, cells2=256, cells3=40, iters2=120, iters3=48, safety=5
         report.append((int(p), ga, gbm, [j for j, _, _ in joints], box, float(slack)))
         if verbose:
             verbose(report[-1])
-    return devpair_gate, np.array(gate_qadr, np.int32), np.array(gate_box, np.float64), report
+    gate_qadr, gate_box = np.array(gate_qadr, np.int32).reshape(-1, 3), np.array(gate_box, np.float64).reshape(-1, 6)
+    if len(gate_qadr) > max_gates:      # keep the gates of the nearest pairs, renumbered
+        keep = np.sort(np.argsort(np.array(nearness), kind="stable")[:max_gates])
+        renum = -np.ones(len(gate_qadr), np.int32)
+        renum[keep] = np.arange(len(keep), dtype=np.int32)
+        devpair_gate = np.where(devpair_gate >= 0, renum[np.maximum(devpair_gate, 0)], -1).astype(np.int32)
+        gate_qadr, gate_box = gate_qadr[keep], gate_box[keep]
+    return devpair_gate, gate_qadr.reshape(-1), gate_box.reshape(-1), report

@@ -87,7 +87,9 @@ for task, spec in ADROIT_SPECS.items():
 
 from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model  # noqa: E402
 
-m = load_kitchen_model(ASSETS)      # compiles kitchen_env_model.xml and attaches the numbers of franka_config.xml (model.info["franka_config"])
+from gymnasium_robotics_amd.envs.kitchen_spec import KITCHEN_CAPACITY  # noqa: E402
+
+m = load_kitchen_model(ASSETS, capacity=dict(KITCHEN_CAPACITY, pair_gates=True))      # (joint-box gates of the arm's hull pairs: mjcf/pair_gates.py) compiles kitchen_env_model.xml and attaches the numbers of franka_config.xml (model.info["franka_config"])
 out = os.path.join(OUT, "kitchen.npz")
 save_model(m, out)
 print("kitchen_franka/kitchen_assets/kitchen_env_model.xml ->", out, {k: m.dim(k) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair")}, "joint equalities:", len(m.tables["jeq_eq"]),
