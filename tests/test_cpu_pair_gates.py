@@ -57,3 +57,42 @@ def test_no_contact_inside_a_gate_box():
                 tested += 1
                 hits += (int(T["pair_geom1"][p]), int(T["pair_geom2"][p])) in touching
     assert tested > 5000 and hits == 0
+
+
+def test_gate_prover_on_a_hinged_mesh_cube_with_a_known_collision_angle():
+    """compute_pair_gates from first principles: a 10 cm mesh cube orbits a hinge at radius 0.3 m; a second, world-fixed mesh cube sits on the orbit at 40 degrees.
+    Elementary geometry: the two cubes cannot touch while the hinge angle is below ~0.36 rad (centre distance 2 r sin(delta / 2) must undercut the largest possible
+    extent sum, 2 x 0.0707); they do touch at 0.698 rad.  The proven box must contain the reference pose, reach a useful part of the clear range, stay inside it --
+    and the checker must find no contact anywhere inside it, but one beyond."""
+    import os
+    import tempfile
+
+    from gymnasium_robotics_amd.mjcf import compile_mjcf
+    from gymnasium_robotics_amd.mjcf.pair_gates import compute_pair_gates
+    from tests.test_cpu_oracle_anchors import _write_cube_stl
+
+    ang = np.deg2rad(40.0)
+    with tempfile.TemporaryDirectory() as d:
+        _write_cube_stl(os.path.join(d, "cube.stl"), (0.05, 0.05, 0.05))
+        xml = f"""<mujoco><option timestep="0.002" gravity="0 0 0"/><asset><mesh name="cube" file="cube.stl"/></asset><worldbody>
+        <geom name="post" type="mesh" mesh="cube" pos="{0.3 * np.cos(ang)} {0.3 * np.sin(ang)} 0" euler="0 0 40"/>
+        <body pos="0 0 0"><joint name="swing" type="hinge" axis="0 0 1" limited="true" range="-115 115"/><geom name="rider" type="mesh" mesh="cube" pos="0.3 0 0" mass="1"/></body>
+        </worldbody></mujoco>"""
+        p = os.path.join(d, "m.xml")
+        with open(p, "w") as f:
+            f.write(xml)
+        m = compile_mjcf(p)
+    T = m.tables
+    gate, qa, box, rep = compute_pair_gates(dict(T), cells2=128)
+    assert (gate >= 0).sum() == 1 and len(qa) == 3 and qa[0] == 0 and qa[1] == qa[2] == -1
+    lo, hi = box[0], box[1]
+    assert lo < -1.5 and 0.2 < hi < 0.55                      # (the range is +-115 degrees) clear all the way down to the limit on the far side; on the near side useful but not beyond the true onset
+    sim = OracleSim(m)
+
+    def touching(q):
+        sim.qpos[0] = q
+        sim.forward()
+        return sim.ncon > 0
+
+    assert not any(touching(q) for q in np.linspace(lo + 1e-6, hi - 1e-6, 400))
+    assert touching(ang) and touching(ang - 0.2)              # the pair does collide, beyond the box
