@@ -236,7 +236,10 @@ GRX_MEM int grx_lane_claim(GrxCtx* c, int lane_) {
   (void)c; (void)lane_;
   return 0;
 #else
-  if (c->bail != 1 || !(c->cnt[2] & (GRX_ST_CON_OVERFLOW | GRX_ST_EFC_OVERFLOW))) return 0;
+  // a contact-list overflow is only worth the re-run when the large tables hold more contacts than this kernel's: at the engine's limit (GRX_MAXCON = one lane per
+  // contact) the re-run would drop the same contacts again -- after a serialised 5 - 9 ms for a hand jammed into the door (profiles/lane_probe_r03_door.txt)
+  const int worth = (c->cnt[2] & GRX_ST_EFC_OVERFLOW) || ((c->cnt[2] & GRX_ST_CON_OVERFLOW) && c->maxcon < GRX_MAXCON);
+  if (c->bail != 1 || !worth) return 0;
   int idx = 0;
   if (lane_ == 0) idx = atomicAdd(c->lane_entry_count, 1);
   idx = __builtin_amdgcn_readfirstlane(idx);

@@ -480,6 +480,10 @@ typedef GrxShape<33, 33, 26, 29, 33, 30, 4, 1, 33, 0, 144, 2032, 1, 32, 1, 13> G
 typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, 144, 2032, 0, 32, 1, 13> GrxShapeAdroitDoor;
 typedef GrxShape<30, 30, 24, 27, 30, 26, 5, 1, 30, 0, 144, 2032, 0, 32, 1, 29> GrxShapeAdroitPen;
 typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, 144, 2032, 0, 32, 1, 12> GrxShapeAdroitRelocate;
+// the door and relocate models with the tables of the overflow lane (core.RERUN_CAPACITY): on the GENERIC large-table kernel one serialised re-run of a contact-rich door world
+// took 5 - 9 ms of a 12 ms step (profiles/lane_probe_r03_door.txt); hammer and pen do not overflow in 100 000 world-steps and keep the generic lane kernel
+typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, 256, 4080, 0, 32, 1, 13> GrxShapeAdroitDoorLane;
+typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, 256, 4080, 0, 32, 1, 12> GrxShapeAdroitRelocateLane;
 template <class S>
 __device__ __forceinline__ void grx_adroit_step_world(int mslot, const GrxAdroitTask& t, const GrxAdroitBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
   if (w >= n_worlds) return;
@@ -706,12 +710,19 @@ extern "C" int grx_tu_adroit_prepare(const GrxModel* g, int bytes, int slot, int
   GRX_ADROIT_SHAPES(X)
 #undef X
   if (found) *shape = found;
+  if (grx_shape_matches<GrxShapeAdroitDoorLane>(*g)) { *shape = 121; GRX_LDS(grx_adroit_lane_kernel<GrxShapeAdroitDoorLane>); }            // ids >= 100: lane kernel only
+  if (grx_shape_matches<GrxShapeAdroitRelocateLane>(*g)) { *shape = 123; GRX_LDS(grx_adroit_lane_kernel<GrxShapeAdroitRelocateLane>); }
   return (int)grx_upload_descriptor(g, slot);
 }
 extern "C" int grx_tu_adroit_launch(int shape, unsigned grid, size_t lds_bytes, void* stream, int slot, const GrxAdroitTask* t, const GrxAdroitBuffers* b, int n, int words,
                                     int forward_only) {
   const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
-  if (b->lane.list) { hipLaunchKernelGGL(grx_adroit_lane_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words); return (int)hipGetLastError(); }
+  if (b->lane.list) {
+    if (shape == 121) hipLaunchKernelGGL(grx_adroit_lane_kernel<GrxShapeAdroitDoorLane>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    else if (shape == 123) hipLaunchKernelGGL(grx_adroit_lane_kernel<GrxShapeAdroitRelocateLane>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    else hipLaunchKernelGGL(grx_adroit_lane_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    return (int)hipGetLastError();
+  }
   switch (shape) {
 #define X(ID, SHAPE) case ID: hipLaunchKernelGGL(grx_adroit_step_kernel<SHAPE>, g, blk, lds_bytes, st, slot, *t, *b, n, words, forward_only); break;
     GRX_ADROIT_SHAPES(X)
