@@ -190,13 +190,17 @@ class OverflowLane:
     become current.  The size of a list is bounded by the grid of the launch that will walk it (grx_overflow_lane.next_cap / entry_cap), which the host fixes one
     step ahead from the newest counters that have reached it."""
 
-    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane"):
+    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane", lane_first=False):
         """mode "lane": worlds near a capacity move to a standing lane that runs next to the fast launch (families whose contact-rich states persist: hand + object,
         kitchen, Adroit door / relocate: a few worlds per step and thousand).  mode "entry": no standing lane, an overflowing world is re-run right behind the fast
         launch -- for families where an overflow is a rare event (Fetch: 2 worlds in 100 steps of 4096), whose step is too short to hide the two cross-stream waits
         a standing lane costs per step (+0.19 ms on 3.3 ms, measured)."""
         import os
         self.mode = os.environ.get("GRX_LANE_MODE", mode)
+        # lane_first: the standing lane's launch is submitted BEFORE the fast launch (its worlds are the heaviest of the batch: a hand jammed into the door takes 5 - 9 ms
+        # against the 11 ms of the whole fast launch, so they should start first).  Measured per family (profiles/ab_r03_lane_first.txt): AdroitDoor +7 %, hand + touch -0.6 %
+        # (there the fast kernel then waits for the lane's launch: tools/lane_cost_probe.py) -- hence a per-family switch.
+        self.lane_first = bool(int(os.environ.get("GRX_LANE_FIRST", int(lane_first))))
 
         import torch
 
@@ -271,12 +275,20 @@ class OverflowLane:
         b_lane.lane = self._large(cur.next_list, cur.next_count_ptr, nxt, self.cap_cur, next_cap)
         ev0 = torch.cuda.Event()
         ev0.record(main)
-        launch_fast(fast_bufs)
-        self.side.wait_event(ev0)
-        with torch.cuda.stream(self.side):
-            launch_large(b_lane)
-            ev1 = torch.cuda.Event()
-            ev1.record(self.side)
+        if self.lane_first:
+            self.side.wait_event(ev0)
+            with torch.cuda.stream(self.side):
+                launch_large(b_lane)
+                ev1 = torch.cuda.Event()
+                ev1.record(self.side)
+            launch_fast(fast_bufs)
+        else:
+            launch_fast(fast_bufs)
+            self.side.wait_event(ev0)
+            with torch.cuda.stream(self.side):
+                launch_large(b_lane)
+                ev1 = torch.cuda.Event()
+                ev1.record(self.side)
         main.wait_event(ev1)
         b_entry = self._make_bufs(mask)
         b_entry.lane = self._large(nxt.entry_list, nxt.entry_count_ptr, nxt, ENTRY_CAP, next_cap)

@@ -61,7 +61,7 @@ class AdroitVecEnv(GoalVecEnv):
         self._act_mean, self._act_rng = torch.from_numpy(am.astype(np.float32)).to(d), torch.from_numpy(ar.astype(np.float32)).to(d)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
-        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode="lane" if self.task_name in ("door", "relocate") else "entry") if self._h_big is not None else None     # hammer / pen: no overflow in 4 M world-steps
+        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode="lane" if self.task_name in ("door", "relocate") else "entry", lane_first=True) if self._h_big is not None else None     # hammer / pen: no overflow in 4 M world-steps
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)                      # adroit_hammer.py:231-233
         self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float64)      # :205-207
         self.action_space = batch_space(self.single_action_space, n)
