@@ -15,7 +15,8 @@ _lib = None
 class OverflowLaneStruct(ctypes.Structure):
     """mirrors grx_overflow_lane (include/grx_capi.h)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("skip", "entry_count", "entry_list", "list", "count", "next_flags", "next_count", "next_list", "ttl")] + [
-        (n, ctypes.c_int) for n in ("soft_maxefc", "soft_jpool", "soft_maxcon", "ttl_init", "grid", "entry_cap", "next_cap")]
+        (n, ctypes.c_int) for n in ("soft_maxefc", "soft_jpool", "soft_maxcon", "ttl_init", "grid", "entry_cap", "next_cap")] + [
+        (n, ctypes.c_void_p) for n in ("ready", "progress", "poll_list")] + [(n, ctypes.c_int) for n in ("ready_cap", "progress_total", "poll_grid", "pad_")]
 
 
 class FetchBuffersStruct(ctypes.Structure):

@@ -144,6 +144,7 @@ def np_random(seed=None):
 RERUN_CAPACITY = {"maxefc": 256, "jpool": 4080, "maxcon": 0}
 LANE_TTL = 8       # steps a world stays in the lane after the last step in which it came within LANE_MARGIN of a capacity of the fast kernel
 LANE_MARGIN = 0.8
+LANE_POLL_GRID = 16    # entrants per step that can be re-run while the fast launch is still running (more: the serialised launch behind it takes the rest)
 
 
 def create_rerun_model(L, model, device_index, enabled=True):
@@ -225,6 +226,10 @@ class OverflowLane:
         self._pin = [dict(buf=torch.zeros(2, dtype=torch.int32, pin_memory=True), event=None, age=0) for _ in range(4)]
         self._pin_next, self._seen, self._age = 0, 0, 0
         self.cap_cur = 64
+        # polling workgroups of the standing launch (grx_overflow_lane.ready / progress / poll_*): an entrant is re-run while the fast launch is still running instead of behind it
+        self.poll_grid = int(os.environ.get("GRX_LANE_POLL", LANE_POLL_GRID)) if self.mode == "lane" else 0
+        self._poll = torch.zeros(self.poll_grid + 1, dtype=torch.int32, device=device) if self.poll_grid > 0 else None      # ready[poll_grid], progress
+        self._fast_grid = (n + 7) & ~7      # workgroups of a fast launch (csrc/grx_kernels.hip, grx_grid_for)
 
     def _refresh(self):
         best = None
@@ -241,6 +246,8 @@ class OverflowLane:
         if join:      # worlds that come close to a capacity move to the lane of the next step
             L.next_flags, L.next_count, L.next_list, L.ttl, L.next_cap = out.flags.data_ptr(), out.next_count_ptr, out.next_list.data_ptr(), self.ttl.data_ptr(), next_cap
             L.soft_maxefc, L.soft_jpool, L.soft_maxcon, L.ttl_init = self.soft
+            if self._poll is not None:      # entries are published to the polling workgroups, every workgroup reports its end
+                L.ready, L.ready_cap, L.progress = self._poll.data_ptr(), self.poll_grid, self._poll.data_ptr() + 4 * self.poll_grid
         return L
 
     def _large(self, lst, count_ptr, out, grid, next_cap):
@@ -273,6 +280,12 @@ class OverflowLane:
         # end before the fast launch does.
         b_lane = self._make_bufs(mask)
         b_lane.lane = self._large(cur.next_list, cur.next_count_ptr, nxt, self.cap_cur, next_cap)
+        if self._poll is not None:
+            self._poll.zero_()
+            L = b_lane.lane
+            L.grid = int(self.cap_cur) + self.poll_grid      # the last poll_grid workgroups poll this step's entry list
+            L.ready, L.ready_cap, L.progress, L.progress_total = self._poll.data_ptr(), self.poll_grid, self._poll.data_ptr() + 4 * self.poll_grid, self._fast_grid
+            L.poll_list, L.poll_grid = nxt.entry_list.data_ptr(), self.poll_grid
         ev0 = torch.cuda.Event()
         ev0.record(main)
         if self.lane_first:
@@ -292,6 +305,8 @@ class OverflowLane:
         main.wait_event(ev1)
         b_entry = self._make_bufs(mask)
         b_entry.lane = self._large(nxt.entry_list, nxt.entry_count_ptr, nxt, ENTRY_CAP, next_cap)
+        if self._poll is not None:      # the entries a polling workgroup has claimed are skipped
+            b_entry.lane.ready, b_entry.lane.ready_cap = self._poll.data_ptr(), self.poll_grid
         launch_large(b_entry)
         self._keep = (b_lane, b_entry)
         fast_bufs.lane = self._Lane()       # the environment's struct is also used for reset-time launches: no stale skip list

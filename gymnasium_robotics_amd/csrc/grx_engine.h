@@ -94,7 +94,8 @@ struct GrxModel {
 };
 
 // mirrors grx_overflow_lane (include/grx_capi.h): where the worlds go that exceed a table capacity of the fast kernel
-struct GrxLane { const unsigned char* skip; int* entry_count; int* entry_list; const int* list; const int* count; unsigned char* next_flags; int* next_count; int* next_list; signed char* ttl; int soft_maxefc, soft_jpool, soft_maxcon, ttl_init, grid, entry_cap, next_cap; };
+struct GrxLane { const unsigned char* skip; int* entry_count; int* entry_list; const int* list; const int* count; unsigned char* next_flags; int* next_count; int* next_list; signed char* ttl; int soft_maxefc, soft_jpool, soft_maxcon, ttl_init, grid, entry_cap, next_cap;
+                 int* ready; int* progress; const int* poll_list; int ready_cap, progress_total, poll_grid, pad_; };   // the polling workgroups of the standing lane launch (include/grx_capi.h)
 
 // per-world LDS working set; every pointer addresses LDS (or host memory in the emulator)
 struct GrxCtx {
@@ -126,7 +127,7 @@ struct GrxCtx {
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
   int bail;    // != 0: a step kernel that hands capacity overflows to a re-run at a larger capacity stops simulating at the first overflowing substep (nothing of this run is kept)
   int soft_maxefc, soft_jpool, soft_maxcon;   // > 0 (the large-table kernel of the overflow lane): the capacities of the FAST kernel; exceeding one of them raises GRX_ST_SOFT
-  int *lane_entry_count, *lane_entry_list; int lane_entry_cap, lane_world;   // fast kernel with an overflow lane: where a world that overflows claims its re-run (grx_lane_claim)
+  int *lane_entry_count, *lane_entry_list; int lane_entry_cap, lane_world; int* lane_ready; int lane_ready_cap;   // fast kernel with an overflow lane: where a world that overflows claims its re-run (grx_lane_claim)
   int* skin;   // large scenes: this world's skin list in HBM (grx_collision), or null: [0] entries, [1] valid, [4, 4 + 3 ngeom) reference geom positions, then the list
   float skin_r;
   int maxefc, jpool, maxcon;  // capacities of the row tables / the packed Jacobian pool / the contact list of this model
@@ -174,7 +175,7 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
 GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   const GrxDims* m = &d;
   float* p = base;
-  c->skin = nullptr; c->skin_r = 0.0f; c->bail = 0; c->soft_maxefc = c->soft_jpool = c->soft_maxcon = 0; c->lane_entry_count = nullptr; c->lane_entry_list = nullptr; c->lane_entry_cap = 0; c->lane_world = 0;
+  c->skin = nullptr; c->skin_r = 0.0f; c->bail = 0; c->soft_maxefc = c->soft_jpool = c->soft_maxcon = 0; c->lane_entry_count = nullptr; c->lane_entry_list = nullptr; c->lane_entry_cap = 0; c->lane_world = 0; c->lane_ready = nullptr; c->lane_ready_cap = 0;
 #define CARVE(field, n) c->field = p; p += (n);
 #define CARVEI(field, n) c->field = (int*)p; p += (n);
   // ---- persistent
@@ -244,7 +245,10 @@ GRX_MEM int grx_lane_claim(GrxCtx* c, int lane_) {
   if (lane_ == 0) idx = atomicAdd(c->lane_entry_count, 1);
   idx = __builtin_amdgcn_readfirstlane(idx);
   if (idx >= c->lane_entry_cap) { c->bail = 0; return 0; }
-  if (lane_ == 0) c->lane_entry_list[idx] = c->lane_world;
+  if (lane_ == 0) {
+    c->lane_entry_list[idx] = c->lane_world;
+    if (c->lane_ready && idx < c->lane_ready_cap) { __threadfence(); atomicExch(c->lane_ready + idx, 1); }   // published: a polling workgroup of the standing lane launch may take it now
+  }
   c->bail = 2;
   return 1;
 #endif

@@ -65,7 +65,7 @@ __device__ __forceinline__ int grx_status_word(int old, int now) { now &= 15; re
 // both kernels, before the simulation: the fast kernel may hand the world over at the first overflowing substep (grx_lane_claim, csrc/grx_engine.h), both watch the soft thresholds
 __device__ __forceinline__ void grx_lane_setup(const GrxLane& L, GrxCtx& c, int w, bool stepping) {
   c.bail = (stepping && L.entry_count != nullptr) ? 1 : 0;
-  if (c.bail) { c.lane_entry_count = L.entry_count; c.lane_entry_list = L.entry_list; c.lane_entry_cap = L.entry_cap; c.lane_world = w; }
+  if (c.bail) { c.lane_entry_count = L.entry_count; c.lane_entry_list = L.entry_list; c.lane_entry_cap = L.entry_cap; c.lane_world = w; c.lane_ready = L.ready; c.lane_ready_cap = L.ready_cap; }
   if (stepping && (L.list != nullptr || L.entry_count != nullptr)) { c.soft_maxefc = L.soft_maxefc; c.soft_jpool = L.soft_jpool; c.soft_maxcon = L.soft_maxcon; }
 }
 // fast kernel, after the simulation: true = the world claimed a re-run on the large tables: the caller returns WITHOUT writing anything of it
@@ -90,6 +90,35 @@ __device__ __forceinline__ void grx_lane_ticket(const GrxLane& L, int st, int w,
   if (st >= 0) { t = (st & GRX_ST_SOFT) ? L.ttl_init : (t > 0 ? t - 1 : 0); L.ttl[w] = (signed char)t; }
   else if (t <= 0) t = 1;
   if (t > 0) grx_lane_append(L, w);
+}
+// ---- entrants without the serialised re-run (include/grx_capi.h, grx_overflow_lane.ready / progress / poll_*).  The worlds that overflow are the heaviest of the batch and
+// their re-run used to start when the fast launch had ENDED (hand + touch: 2 ms in 60 % of the steps, a hand jammed into the door 5 - 9 ms).  The standing lane launch now
+// carries poll_grid extra workgroups; workgroup p sleeps until entry p of THIS step's entry list is published (ready[p] == 1), claims it (-> 2) and steps the world on the
+// large tables while the fast launch is still running.  It gives up when every workgroup of the fast launch has ended (progress == progress_total) or after a bounded number
+// of polls; whatever is unclaimed then is taken by the entry launch behind the fast kernel, as before.  Nothing waits for anything that is not already submitted.
+__device__ __forceinline__ void grx_lane_progress(const GrxLane& L) { if (L.progress && threadIdx.x == 0) atomicAdd(L.progress, 1); }   // fast kernel: this workgroup has ended
+// entry launch (list == the step's entry list): 1 = entry e was taken by a polling workgroup
+__device__ __forceinline__ int grx_lane_taken(const GrxLane& L, int e) {
+  if (!L.ready || L.poll_grid != 0 || e >= L.ready_cap) return 0;
+  int r = 0;
+  if (threadIdx.x == 0) r = atomicCAS(L.ready + e, 1, 2) != 1;
+  return __builtin_amdgcn_readfirstlane(r);
+}
+// polling workgroup p of the standing launch: the world to step, or -1
+__device__ __forceinline__ int grx_lane_poll(const GrxLane& L, int p) {
+  if (!L.ready || p >= L.ready_cap) return -1;
+  int w = -1;
+  if (threadIdx.x == 0) {
+    for (int it = 0; it < 40000; it++) {      // bounded: ~40000 x 2 us
+      int r = __hip_atomic_load(L.ready + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (r == 0 && __hip_atomic_load(L.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= L.progress_total)
+        r = __hip_atomic_load(L.ready + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the fast launch has ended: one last look
+      else if (r == 0) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); continue; }
+      if (r == 1 && atomicCAS(L.ready + p, 1, 2) == 1) { __threadfence(); w = ((volatile const int*)L.poll_list)[p]; }
+      break;
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(w);
 }
 __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetchTask& t, const GrxFetchBuffers& b, GrxCtx& c, int w, int lane_, int keep_outcome = 0) {
   for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)w * m.nq + i] = c.qpos[i];
@@ -461,14 +490,16 @@ grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
   grx_hand_step_world<S>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+  grx_lane_progress(b.lane);
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
 template <class S>
 __global__ void __launch_bounds__(64, 2)
 grx_hand_lane_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (see grx_fetch_lane_kernel)
   extern __shared__ float lds[];
-  const int e = blockIdx.x;
-  if (e >= *b.lane.count) return;
+  const int e = blockIdx.x, nstand = (int)gridDim.x - b.lane.poll_grid;
+  if (e >= nstand) { const int w = grx_lane_poll(b.lane, e - nstand); if (w >= 0) grx_hand_step_world<S>(mslot, t, b, w, n_worlds, words, 0, lds, (int)threadIdx.x, true); return; }
+  if (e >= *b.lane.count || grx_lane_taken(b.lane, e)) return;
   grx_hand_step_world<S>(mslot, t, b, b.lane.list[e], n_worlds, words, 0, lds, (int)threadIdx.x, true);
 }
 
@@ -528,14 +559,16 @@ grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
   grx_adroit_step_world<S>(mslot, t, b, grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+  grx_lane_progress(b.lane);
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
 template <class S>
 __global__ void __launch_bounds__(64, 2)
 grx_adroit_lane_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (see grx_fetch_lane_kernel)
   extern __shared__ float lds[];
-  const int e = blockIdx.x;
-  if (e >= *b.lane.count) return;
+  const int e = blockIdx.x, nstand = (int)gridDim.x - b.lane.poll_grid;
+  if (e >= nstand) { const int w = grx_lane_poll(b.lane, e - nstand); if (w >= 0) grx_adroit_step_world<S>(mslot, t, b, w, n_worlds, words, 0, lds, (int)threadIdx.x, true); return; }
+  if (e >= *b.lane.count || grx_lane_taken(b.lane, e)) return;
   grx_adroit_step_world<S>(mslot, t, b, b.lane.list[e], n_worlds, words, 0, lds, (int)threadIdx.x, true);
 }
 
@@ -586,14 +619,16 @@ grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
   grx_kitchen_step_world<S>(mslot, t, b, grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+  grx_lane_progress(b.lane);
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
 template <class S>
 __global__ void __launch_bounds__(64, 2)
 grx_kitchen_lane_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (see grx_fetch_lane_kernel)
   extern __shared__ float lds[];
-  const int e = blockIdx.x;
-  if (e >= *b.lane.count) return;
+  const int e = blockIdx.x, nstand = (int)gridDim.x - b.lane.poll_grid;
+  if (e >= nstand) { const int w = grx_lane_poll(b.lane, e - nstand); if (w >= 0) grx_kitchen_step_world<S>(mslot, t, b, w, n_worlds, words, 0, lds, (int)threadIdx.x, true); return; }
+  if (e >= *b.lane.count || grx_lane_taken(b.lane, e)) return;
   grx_kitchen_step_world<S>(mslot, t, b, b.lane.list[e], n_worlds, words, 0, lds, (int)threadIdx.x, true);
 }
 

@@ -60,6 +60,13 @@ typedef struct grx_overflow_lane {
   int entry_cap, next_cap;              /* capacities of entry_list / next_list = the grids of the launches that will walk them.  A world that finds next_list full stays on
                                          * (returns to) the fast kernel; a world that overflows when entry_list is full goes on with the excess contacts dropped and the sticky
                                          * status flag says so (more than entry_cap worlds overflowing for the first time in ONE step) */
+  /* Entrants without the serialised re-run (optional, all NULL / 0 = off).  fast kernel: ready[idx] <- 1 when entry idx of entry_list is published (idx < ready_cap), every
+   * workgroup adds 1 to *progress when it ends.  large kernel, standing launch: the LAST poll_grid workgroups of its grid poll -- workgroup p sleeps until ready[p] == 1, claims
+   * the entry (ready[p] <- 2) and steps world poll_list[p] (= this step's entry_list) on the large tables while the fast launch is still running; it gives up when
+   * *progress == progress_total (the fast launch's workgroups) or after a bounded number of polls.  large kernel, entry launch (poll_grid == 0, ready != NULL): skips the entries
+   * a polling workgroup has claimed. */
+  int* ready; int* progress; const int* poll_list;
+  int ready_cap, progress_total, poll_grid, pad_;
 } grx_overflow_lane;
 
 /* mirrors struct GrxFetchTask (csrc/grx_fetch_task.h) */

@@ -114,3 +114,30 @@ def test_worlds_are_independent_and_deterministic():
     env1.reset(seed=5)       # world 5 of the batch = a single env seeded 5
     solo = np.stack([env1.step(a[5:6])[0][0] for a in acts])
     assert np.array_equal(solo, outs[0][:, 5])
+
+
+def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):
+    """The polling workgroups of the standing lane launch (grx_overflow_lane.ready / progress / poll_*) re-run an entrant while the fast launch is still running; the
+    serialised launch behind the fast kernel takes whatever they did not claim.  Who re-runs a world must not matter: a rollout with 16 polling workgroups, one with a single
+    polling workgroup (so that the entry launch gets work too) and one without polling are bit-identical, world by world, and entrants did occur."""
+    import torch
+
+    from gymnasium_robotics_amd import make_vec
+
+    n, envs = 4096, []
+    for poll in ("16", "1", "0"):
+        monkeypatch.setenv("GRX_LANE_POLL", poll)
+        e = make_vec("AdroitHandDoor-v2", num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step")
+        assert e.lane is not None and e.lane.mode == "lane" and e.lane.poll_grid == int(poll)
+        e.reset(seed=3)
+        envs.append(e)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(5)
+    entered = 0
+    for t in range(14):
+        a = torch.rand(n, envs[0].single_action_space.shape[0], device="cuda:0", generator=g) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        entered += len(envs[2].lane.entered_last_step())
+        for e, o in zip(envs[:2], outs[:2]):
+            assert torch.equal(e.qpos, envs[2].qpos) and torch.equal(e.qvel, envs[2].qvel) and torch.equal(o[0], outs[2][0]) and torch.equal(o[1], outs[2][1]), t
+            assert torch.equal(e.status & 0xFFFF, envs[2].status & 0xFFFF)
+    assert entered >= 3, entered      # the rollout does push worlds over the fast kernel's tables
