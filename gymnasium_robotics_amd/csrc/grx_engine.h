@@ -43,7 +43,7 @@ static inline int grx_emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; ret
 
 // optional per-stage cycle accounting (tools/profile_stages.py builds a -DGRX_PROFILE variant; empty otherwise)
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
-#define GRX_NPROF 48
+#define GRX_NPROF 56
 // sub-stage buckets 16.. (finer breakdown inside a stage; what remains goes to the stage's own bucket)
 #define GRX_SUBTICK(c, k) GRX_TICK(c, 16 + (k))
 #define GRX_TICK(c, id) do { if (lane_ == 0) { long long t_ = clock64(); (c)->prof[id] += t_ - (c)->prof_last[0]; (c)->prof_last[0] = t_; } } while (0)
@@ -1591,49 +1591,17 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
 #if defined(GRX_EMU)
     g_grx_mesh_stats[1]++;
 #endif
-#ifdef GRX_EXP_NO_PORTAL
-    c->cnt[2] |= 32; continue;
-#endif
     float depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
     GRX_SUBTICK(c, 23);   // portal search
 #ifdef GRX_PROBE_HULL   // outcome of the searches (tools/hull_outcome_probe.py): contacts, separations with a direction, the pair searched last
-    GRX_COUNT(c, 29, rc == 0 ? 1 : 0); GRX_COUNT(c, 30, (rc != 0 && sep[3] != 0.0f) ? 1 : 0); GRX_PMAX(c, 31, pair);
+    GRX_COUNT(c, 35, rc == 0 ? 1 : 0); GRX_COUNT(c, 36, (rc != 0 && sep[3] != 0.0f) ? 1 : 0); GRX_PMAX(c, 37, pair);
 #endif
 #if defined(GRX_EMU) && defined(GRX_MESH_DEBUG)
     fprintf(stderr, "meshpair %d (g %d %d) slot %d rc %d sep %g\n", pair, g1, g2, slot, rc, (double)sep[3]);
 #endif
     WAVE_SYNC();
     if (rc != 0) {
-#ifndef GRX_HULL_REFINE
-#define GRX_HULL_REFINE 3
-#endif
-      if (sep[3] != 0.0f && GRX_HULL_REFINE > 0) {
-        // The direction the portal search stopped on separates the two geoms BARELY (its support point is just on the far side of the origin), and the
-        // next substep's motion breaks it: worlds whose upper arm is near the head ran a fresh search (11 support evaluations) in 17 of their 20 substeps and
-        // ended the launch alone (profiles/stragglers_r03_fetch.txt).  A few Frank-Wolfe steps towards the point of A - B nearest to the origin turn it
-        // into a direction with (nearly) the largest separation margin, which survives many substeps.  Any separating direction proves "no contact":
-        // which one is cached changes no result.
-        GrxMprPt* pt = &q.pts[4];
-        float bd[3] = {sep[0], sep[1], sep[2]};
-        grx_mpr_support<true>(&q, bd, pt);
-        float v[3] = {pt->v[0], pt->v[1], pt->v[2]}, best = dot3f(v, bd);
-        for (int it = 0; it < GRX_HULL_REFINE; it++) {
-          const float n2 = dot3f(v, v);
-          if (!(n2 > 1e-12f)) break;
-          const float in = 1.0f / sqrtf(n2), d[3] = {-v[0] * in, -v[1] * in, -v[2] * in};
-          grx_mpr_support<true>(&q, d, pt);
-          const float w[3] = {pt->v[0], pt->v[1], pt->v[2]}, sw = dot3f(w, d);
-          if (sw < best) { best = sw; bd[0] = d[0]; bd[1] = d[1]; bd[2] = d[2]; }
-          const float dv[3] = {w[0] - v[0], w[1] - v[1], w[2] - v[2]}, dd = dot3f(dv, dv);
-          if (!(dd > 1e-14f)) break;
-          const float t = fminf(1.0f, fmaxf(0.0f, -dot3f(v, dv) / dd));
-          if (t <= 0.0f) break;
-          v[0] += t * dv[0]; v[1] += t * dv[1]; v[2] += t * dv[2];
-        }
-        sep[0] = bd[0]; sep[1] = bd[1]; sep[2] = bd[2];
-        WAVE_SYNC();
-      }
       if (sep[3] != 0.0f) {   // keep the direction for the next substeps
         const int w = slot >= 0 ? slot : ((int)mc[20] & 3);   // the pair's own slot, else round robin over the four
         LANE0 { mc[5 * w] = key; mc[5 * w + 1] = sep[0]; mc[5 * w + 2] = sep[1]; mc[5 * w + 3] = sep[2]; mc[5 * w + 4] = 0.0f; if (slot < 0) mc[20] = (float)((w + 1) & 3); }
@@ -2492,9 +2460,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   const int rows0 = ne + nf + nl, pool0 = wpool + nf + nlj + tpool;
   const int maxefc = c->maxefc, jpool = c->jpool;
   int overflow = (rows0 > maxefc) || (pool0 > jpool), ncon_fit = ncon, nc = nc_all;
-#ifndef GRX_PROBE_HULL
-  GRX_PMAX(c, 29, rows0 + nc_all); GRX_PMAX(c, 30, pool0 + pool_all); GRX_PMAX(c, 31, c->cnt[0]);
-#endif
+  GRX_PMAX(c, 32, rows0 + nc_all); GRX_PMAX(c, 33, pool0 + pool_all); GRX_PMAX(c, 34, c->cnt[0]);
   if (c->soft_maxefc > 0 && (rows0 + nc_all > c->soft_maxefc || pool0 + pool_all > c->soft_jpool || c->cnt[0] > c->soft_maxcon)) { LANE0 { c->cnt[2] |= GRX_ST_SOFT; } }
   if (rows0 + nc_all > maxefc || pool0 + pool_all > jpool) {  // rare: find the first contact that does not fit
     GRX_LANEVAR(failp);

@@ -7,8 +7,8 @@ import numpy as np, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from gymnasium_robotics_amd import _native, make_vec
-_native.LIB_PATH = os.path.join(ROOT, "gymnasium_robotics_amd", "_lib", "libgrx_hip_prof.so")
-NP, n = 48, 4096
+_native.LIB_PATH = os.path.join(ROOT, "gymnasium_robotics_amd", "_lib", os.environ.get("GRX_PROF_LIB", "libgrx_hip_prof.so"))
+NP, n = 56, 4096
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 env = make_vec("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step")
 env.reset(seed=0); env._elapsed[:] = np.arange(n) % 50
@@ -22,7 +22,7 @@ for k in range(steps):
     torch.cuda.synchronize()
     L.grx_profile_world_stages(buf, n)
     P = np.frombuffer(buf, dtype=np.int32).reshape(n, NP)
-    rows.append(P[:, 16 + 29].copy()); pool.append(P[:, 16 + 30].copy()); ncon.append(P[:, 16 + 31].copy()); srch.append(P[:, 16 + 25].copy()); queued.append(P[:, 16 + 24].copy())
+    rows.append(P[:, 16 + 32].copy()); pool.append(P[:, 16 + 33].copy()); ncon.append(P[:, 16 + 34].copy()); srch.append(P[:, 16 + 25].copy()); queued.append(P[:, 16 + 24].copy())
 rows, pool, ncon, srch, queued = (np.array(x) for x in (rows, pool, ncon, srch, queued))      # [steps, n]
 q = [50, 90, 95, 98, 99, 99.5, 99.9, 100]
 print(f"FetchPickAndPlace-v4, {n} worlds, {steps} steps, uniform random actions, staggered same-step resets; per world and env.step")

@@ -5,8 +5,8 @@ import numpy as np, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from gymnasium_robotics_amd import _native, make_vec
-_native.LIB_PATH = os.path.join(ROOT, "gymnasium_robotics_amd", "_lib", "libgrx_hip_prof.so")
-NP, n = 48, 4096
+_native.LIB_PATH = os.path.join(ROOT, "gymnasium_robotics_amd", "_lib", os.environ.get("GRX_PROF_LIB", "libgrx_hip_prof.so"))
+NP, n = 56, 4096
 env = make_vec("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step")
 env.reset(seed=0); env._elapsed[:] = np.arange(n) % 50
 g = torch.Generator(device="cuda:0"); g.manual_seed(0)
@@ -18,7 +18,7 @@ buf = (ctypes.c_int * (NP * n))()
 L.grx_profile_world_stages.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.grx_profile_world_stages(buf, n)
 P = np.array(list(buf), dtype=np.float64).reshape(n, NP)
-tot = P.sum(axis=1)
+tot = P[:, :16 + 24].sum(axis=1)      # the time slots only: every cycle is booked on exactly one of them; the slots behind are counters
 names = ["kinematics", "inertia", "collision", "constraint", "velocity", "M solve", "newton eval", "newton grad", "newton hessian", "newton factor", "newton linesearch", "newton final", "euler", "other"]
 SUB = {0: "constraint: count", 1: "constraint: scan", 2: "constraint: equality rows", 3: "constraint: friction/limit rows", 4: "constraint: row params", 5: "constraint: contact J",
        6: "velocity: rne a", 7: "velocity: rne b", 8: "velocity: passive/actuation", 9: "kinematics: bodies", 10: "kinematics: sites/frames", 11: "collision: box-box queue",
