@@ -191,7 +191,7 @@ class OverflowLane:
     become current.  The size of a list is bounded by the grid of the launch that will walk it (grx_overflow_lane.next_cap / entry_cap), which the host fixes one
     step ahead from the newest counters that have reached it."""
 
-    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane", lane_first=False):
+    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane", lane_first=False, margin=LANE_MARGIN):
         """mode "lane": worlds near a capacity move to a standing lane that runs next to the fast launch (families whose contact-rich states persist: hand + object,
         kitchen, Adroit door / relocate: a few worlds per step and thousand).  mode "entry": no standing lane, an overflowing world is re-run right behind the fast
         launch -- for families where an overflow is a rare event (Fetch: 2 worlds in 100 steps of 4096), whose step is too short to hide the two cross-stream waits
@@ -216,7 +216,7 @@ class OverflowLane:
         cap = (req("maxefc", 144), req("jpool", 2032), min(req("maxcon", 32), 32))
         # a world moves to the lane when it comes within LANE_MARGIN of a capacity of the fast kernel (and stays `ttl` steps past the last such step): most worlds
         # then enter the lane without ever overflowing, i.e. without the serialised re-run
-        margin, ttl = float(os.environ.get("GRX_LANE_MARGIN", LANE_MARGIN)), int(os.environ.get("GRX_LANE_TTL", ttl))      # (experiments)
+        margin, ttl = float(os.environ.get("GRX_LANE_MARGIN", margin)), int(os.environ.get("GRX_LANE_TTL", ttl))      # (experiments)
         self.soft = tuple(int(margin * v) for v in cap) + (int(ttl),)
         self._make_bufs = make_bufs
         self.side = torch.cuda.Stream(device=device, priority=int(os.environ.get("GRX_LANE_PRIO", "-1")))     # the lane's worlds start before the fast kernel fills the chip

@@ -95,7 +95,8 @@ class HandReachVecEnv(GoalVecEnv):
             self.order = (self._slice_base + torch.arange(per, device=d, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
-        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode=self.LANE_MODE) if self._h_big is not None else None
+        # (with the entrants picked up by polling workgroups a smaller standing lane is cheaper: margin 0.9 / ttl 4 against 0.8 / 8, +1 % on hand + touch, profiles/ab_r03_lane_size_with_polling.txt)
+        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode=self.LANE_MODE, margin=0.9, ttl=4) if self._h_big is not None else None
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)
         self.single_observation_space = Dict(dict(
             observation=Box(-np.inf, np.inf, (self.obs_dim,), np.float64), achieved_goal=Box(-np.inf, np.inf, (GOAL_DIM,), np.float64),
