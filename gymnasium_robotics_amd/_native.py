@@ -61,7 +61,7 @@ class KitchenBuffersStruct(ctypes.Structure):
 class KitchenBookStruct(ctypes.Structure):      # include/grx_capi.h, grx_kitchen_book
     _fields_ = [(n, ctypes.c_void_p) for n in ("completed", "stepped", "tasks_to_complete", "episode_completions", "elapsed", "step_completions", "reward", "terminated",
                                                "truncated", "needs_reset", "reset_now", "qpos", "qvel", "qacc_ws", "init_qpos")] + [
-        (n, ctypes.c_int) for n in ("nq", "nv", "all_mask", "max_steps", "remove_when_completed", "terminate_when_completed", "mode")]
+        (n, ctypes.c_int) for n in ("nq", "nv", "all_mask", "max_steps", "remove_when_completed", "terminate_when_completed", "mode")] + [("final_info", ctypes.c_void_p)]
 
 
 class HerArgsStruct(ctypes.Structure):

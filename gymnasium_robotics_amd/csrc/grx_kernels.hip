@@ -1553,6 +1553,7 @@ struct GrxKitchenBook {
   float* reward; unsigned char *terminated, *truncated, *needs_reset, *reset_now;
   float *qpos, *qvel, *qacc_ws; const float* init_qpos;
   int nq, nv, all_mask, max_steps, remove_when_completed, terminate_when_completed, mode;   // mode 0 disabled, 1 next_step, 2 same_step
+  int* final_info;   // [N,3] or null: (tasks_to_complete, step_task_completions, episode_task_completions) of a same-step reset world's FINISHED episode (info["final_info"])
 };
 static_assert(sizeof(grx_kitchen_book) == sizeof(GrxKitchenBook), "grx_kitchen_book must mirror GrxKitchenBook");
 __global__ void __launch_bounds__(256)
@@ -1575,6 +1576,7 @@ grx_kitchen_book_kernel(GrxKitchenBook a, int n) {
   a.step_completions[w] = (a.mode == 2 && done) ? 0 : step_done;      // a same-step reset world reports its NEW episode (the finished one is in the final_* rows)
   if (a.mode == 1) a.needs_reset[w] = (unsigned char)(pending ? 0 : (a.needs_reset[w] | done));
   a.reset_now[w] = (unsigned char)reset_now;
+  if (a.final_info && a.mode == 2 && done) { a.final_info[3 * w] = ttc; a.final_info[3 * w + 1] = step_done; a.final_info[3 * w + 2] = epi; }
   if (reset_now) {      // FrankaRobot.reset_model (franka_env.py:133-139): init_qpos, zero velocity; mj_resetData zeroes the warm start
     ttc = a.all_mask; epi = 0; el = 0;
     for (int i = 0; i < a.nq; i++) a.qpos[(size_t)w * a.nq + i] = a.init_qpos[i];

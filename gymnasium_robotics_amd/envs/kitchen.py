@@ -94,7 +94,7 @@ class KitchenVecEnv(GoalVecEnv):
             self.d_ttc, self.d_epi, self.d_elapsed, self.d_stepdone = i32(), i32(), i32(), i32()
             self.d_reward, self.d_term, self.d_trunc, self.d_needs, self.d_resetnow = z(n), u8(), u8(), u8(), u8()
             self.d_rng = torch.zeros(n, 4, dtype=torch.int64, device=d)          # the worlds' PCG64 states (state_hi, state_lo, inc_hi, inc_lo), uint64 bit patterns
-            self.final_obs, self.final_qpos, self.d_final_stepdone = z(n, self.obs_dim), z(n, self.nq), i32()
+            self.final_obs, self.final_qpos, self.d_final_info = z(n, self.obs_dim), z(n, self.nq), torch.zeros(n, 3, dtype=torch.int32, device=d)
             self._book = _native.KitchenBookStruct()
             for name, t in (("completed", self.completed), ("stepped", self.mask), ("tasks_to_complete", self.d_ttc), ("episode_completions", self.d_epi), ("elapsed", self.d_elapsed),
                             ("step_completions", self.d_stepdone), ("reward", self.d_reward), ("terminated", self.d_term), ("truncated", self.d_trunc), ("needs_reset", self.d_needs),
@@ -104,6 +104,7 @@ class KitchenVecEnv(GoalVecEnv):
             self._book.max_steps = int(self.max_episode_steps or 0)
             self._book.remove_when_completed, self._book.terminate_when_completed = int(self.remove_task_when_completed), int(self.terminate_on_tasks_completed)
             self._book.mode = {"disabled": 0, "next_step": 1, "same_step": 2}[self.autoreset_mode]
+            self._book.final_info = self.d_final_info.data_ptr()
         self._seed_worlds([None] * n)
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
@@ -262,6 +263,9 @@ class KitchenVecEnv(GoalVecEnv):
                 info["final_obs"] = {"observation": self.final_obs, "achieved_goal": {t: fq[:, OBS_ELEMENT_INDICES[t][0]: OBS_ELEMENT_INDICES[t][-1] + 1] for t in self.tasks},
                                      "desired_goal": {t: self._goal_t[t] for t in self.tasks}}
                 info["_final_obs"] = done          # gymnasium's vector convention: the mask of the worlds whose final_obs rows are valid
+                fi = self.d_final_info
+                info["final_info"] = dict(tasks_to_complete=fi[:, 0], step_task_completions=fi[:, 1], episode_task_completions=fi[:, 2])
+                info["_final_info"] = done
             self.mask.copy_(self.d_resetnow)
             self._device_noise(self.mask)
             keep = self.status.clone()

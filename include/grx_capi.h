@@ -289,6 +289,7 @@ typedef struct grx_kitchen_book {
   float* reward; unsigned char *terminated, *truncated, *needs_reset, *reset_now;
   float *qpos, *qvel, *qacc_ws; const float* init_qpos;
   int nq, nv, all_mask, max_steps, remove_when_completed, terminate_when_completed, mode;
+  int* final_info;      /* [N,3] or NULL: (tasks_to_complete, step_task_completions, episode_task_completions) of the episode a same-step reset world has just finished */
 } grx_kitchen_book;
 int grx_kitchen_bookkeeping(const grx_kitchen_book* args, int n_worlds, void* stream);
 int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,

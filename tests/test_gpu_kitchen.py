@@ -209,6 +209,8 @@ def test_device_path_equals_host_path(mode):
             if done.any():
                 idx = np.nonzero(done)[0]
                 assert np.array_equal(ia["final_obs"]["observation"].astype(np.float32), ib["final_obs"]["observation"].cpu().numpy()[idx])
+                for k in ("tasks_to_complete", "step_task_completions", "episode_task_completions"):
+                    assert np.array_equal(ia["final_info"][k], ib["final_info"][k].cpu().numpy()[idx].astype(np.int64)), (t, k)
     assert (ta | ua).any() or t > 0
 
 
