@@ -108,3 +108,34 @@ def test_emulated_reset_forward_matches_golden(model):
         last = np.zeros(9, np.float32)
         obs, _ = emu.kitchen_step(np.zeros(9, np.float32), last, noise=g["reset_noise"][k], forward_only=True)
         assert np.abs(obs - g["reset_obs"][k]).max() < 1e-6
+
+
+def test_gated_engine_source_finds_the_ungated_checker_contact_set(model):
+    """The kitchen scene carries 64 joint-box gates (mjcf/pair_gates.py: arm link against arm link, arm link against the world-fixed hulls).  The engine source in the lane
+    emulator evaluates them; the checker knows nothing about gates.  Over random Franka configurations anywhere in the joint ranges the two must find the same geom pairs in contact."""
+    from emu_sim import EmuSim
+
+    from gymnasium_robotics_amd.envs.kitchen_spec import INIT_QPOS, make_kitchen_task
+    from oracle.oracle_sim import OracleSim
+
+    T = model.tables
+    assert (np.asarray(T["devpair_gate"]).ravel() >= 0).sum() == 64 and len(np.asarray(T["gate_qadr"]).ravel()) == 3 * 64
+    emu, sim = EmuSim(model, make_kitchen_task(model, 0.0, 0.0)), OracleSim(model)
+    jr = np.asarray(T["jnt_range"]).reshape(-1, 2)
+    rng = np.random.default_rng(4)
+    with_contacts = 0
+    for trial in range(24):
+        q = INIT_QPOS.astype(np.float64).copy()
+        q[:7] = rng.uniform(jr[:7, 0], jr[:7, 1])          # the seven arm joints anywhere in their ranges (the arm may well be inside the furniture: both sides must agree there too)
+        q[7:9] = rng.uniform(0.0, 0.04, 2)
+        sim.qpos[:] = q; sim.qvel[:] = 0
+        sim.forward()
+        want = sorted((int(c[7]), int(c[8])) for c in sim.contacts())
+        emu.qpos[:] = q.astype(np.float32); emu.qvel[:] = 0; emu.qacc_ws[:] = 0
+        ncon, _ = emu.physics_steps(1)
+        pairs = emu.ctx("con_pair", max(ncon, 1), np.int32)[:ncon]
+        got = sorted((int(T["pair_geom1"][p]), int(T["pair_geom2"][p])) for p in pairs)
+        if len(want) <= 32:                                  # (the engine's contact list holds 32; beyond that the checker's list is longer by construction)
+            assert got == want, (trial, got, want)
+            with_contacts += len(want) > 0
+    assert with_contacts >= 10
