@@ -234,3 +234,24 @@ def test_torch_step_does_not_synchronise():
         torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
     assert r.is_cuda and term.is_cuda and info["tasks_to_complete"].is_cuda and bool((info["_final_obs"] == (term | trunc)).all())
+
+
+def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):
+    """kitchen: the polling workgroups of the standing lane launch against the serialised re-run (see tests/test_gpu_adroit.py): bit-identical rollouts"""
+    import torch
+
+    n, envs = 8192, []
+    for poll in ("16", "0"):
+        monkeypatch.setenv("GRX_LANE_POLL", poll)
+        e = _env(n, output="torch", autoreset_mode="disabled", max_episode_steps=None)
+        assert e.lane is not None and e.lane.poll_grid == int(poll)
+        e.reset(seed=8)
+        envs.append(e)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(2)
+    entered = 0
+    for t in range(70):
+        a = torch.rand(n, 9, device="cuda:0", generator=g) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        entered += len(envs[1].lane.entered_last_step())
+        assert torch.equal(envs[0].qpos, envs[1].qpos) and torch.equal(envs[0].qvel, envs[1].qvel) and torch.equal(outs[0][0]["observation"], outs[1][0]["observation"]), t
+    assert entered >= 1, entered

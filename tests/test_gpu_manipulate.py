@@ -207,3 +207,26 @@ def test_abandoned_settle_chains_give_their_draws_back():
     for k in ("observation", "desired_goal"):
         assert np.array_equal(oa[k], ob[k]), k
     A.close(); B.close()
+
+
+def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):
+    """hand + touch sensors: the polling workgroups of the standing lane launch against the serialised re-run (see tests/test_gpu_adroit.py): bit-identical rollouts"""
+    import torch
+
+    from gymnasium_robotics_amd import make_vec
+
+    n, envs = 4096, []
+    for poll in ("16", "0"):
+        monkeypatch.setenv("GRX_LANE_POLL", poll)
+        e = make_vec("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", num_envs=n, device="cuda:0", output="torch", autoreset_mode="disabled")
+        assert e.lane is not None and e.lane.poll_grid == int(poll)
+        e.reset(seed=4)
+        envs.append(e)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(6)
+    entered = 0
+    for t in range(30):
+        a = torch.rand(n, 20, device="cuda:0", generator=g) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        entered += len(envs[1].lane.entered_last_step())
+        assert torch.equal(envs[0].qpos, envs[1].qpos) and torch.equal(envs[0].qvel, envs[1].qvel) and torch.equal(outs[0][0]["observation"], outs[1][0]["observation"]), t
+    assert entered >= 1, entered
