@@ -170,14 +170,29 @@ GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom,
   return pers + (p1 > p2 ? p1 : p2) + 8;
 }
 
+#if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)
+struct GrxEmuField { const char* name; void* ptr; int n, isint; };
+static GrxEmuField g_grx_emu_fields[128]; static int g_grx_emu_nfields = 0;
+static void grx_emu_carve_rec(const char* name, void* ptr, int n, int isint) { if (g_grx_emu_nfields < 128) { GrxEmuField f = {name, ptr, n, isint}; g_grx_emu_fields[g_grx_emu_nfields++] = f; } }
+static void (*g_grx_stage_hook)(int stage) = nullptr;
+static int g_grx_solve_mode = 0;   // 0 normal, 1 Newton only, 2 Euler stage only (tools/emu_mixed.py splits the solve stage)   // called by grx_forward_euler after each stage (-1: before the first)
+#define GRX_STAGE_HOOK(k) do { if (g_grx_stage_hook) g_grx_stage_hook(k); } while (0)
+#else
+#define GRX_STAGE_HOOK(k) ((void)0)
+#endif
 // dims by value: when they are compile-time constants (a specialised kernel) every LDS address below folds to an
 // immediate offset of the ds_read/ds_write instructions
 GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   const GrxDims* m = &d;
   float* p = base;
   c->skin = nullptr; c->skin_r = 0.0f; c->bail = 0; c->soft_maxefc = c->soft_jpool = c->soft_maxcon = 0; c->lane_entry_count = nullptr; c->lane_entry_list = nullptr; c->lane_entry_cap = 0; c->lane_world = 0; c->lane_ready = nullptr; c->lane_ready_cap = 0;
-#define CARVE(field, n) c->field = p; p += (n);
-#define CARVEI(field, n) c->field = (int*)p; p += (n);
+#if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)   // test infrastructure (tools/emu_mixed.py): the field map of the working set
+#define GRX_CARVE_REC(field, n, isint) grx_emu_carve_rec(#field, (void*)p, (n), (isint));
+#else
+#define GRX_CARVE_REC(field, n, isint)
+#endif
+#define CARVE(field, n) c->field = p; GRX_CARVE_REC(field, n, 0) p += (n);
+#define CARVEI(field, n) c->field = (int*)p; GRX_CARVE_REC(field, n, 1) p += (n);
   // ---- persistent
   CARVE(qpos, m->nq) CARVE(qvel, m->nv) CARVE(qacc_ws, m->nv) CARVE(mocap_pos, 3 * m->nmocap) CARVE(mocap_quat, 4 * m->nmocap)
   CARVE(ctrl, m->nu)
@@ -188,7 +203,7 @@ GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   c->maxefc = m->maxefc; c->jpool = m->jpool; c->maxcon = m->maxcon;
   CARVE(Jp, m->jpool) CARVE(efc_D, m->maxefc) CARVE(efc_aref, m->maxefc)
   c->efc_pos = c->efc_aref;  // residuals live in the aref slot until the per-row pass turns them into aref
-  c->efc_floss = p; if (m->nfric) p += m->maxefc;
+  c->efc_floss = p; if (m->nfric) { GRX_CARVE_REC(efc_floss, m->maxefc, 0) p += m->maxefc; }
   CARVEI(efc_kind, m->maxefc) CARVEI(efc_id, m->maxefc) CARVEI(efc_row, m->maxefc)
   CARVEI(ired, m->njnt > 32 ? 64 : 32) CARVEI(cnt, 8)
   CARVE(shift, m->nshift ? 8 : 0)
@@ -300,6 +315,21 @@ GRX_DEV void mulMatTVec3f(float* r, const float* m, const float* v) {
   float x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
+#ifndef GRX_EMU_FP64   // fp64 twins for the stages that run in double precision on purpose (GRX_MPR_REAL)
+GRX_DEV double dot3f(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+GRX_DEV void cross3f(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+GRX_DEV void mulMatVec3f(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+GRX_DEV void mulMatTVec3f(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+#endif
 GRX_DEV void mulMat3f(float* r, const float* a, const float* b) {
   float t[9];
   for (int i = 0; i < 3; i++)
@@ -459,6 +489,16 @@ typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NMC (S::kFixed ? S::NM : m->nmocap)
 #if defined(GRX_EMU)
 static long g_grx_mesh_stats[4];   // emulator diagnostics: hull pairs skipped by a cached separating direction / sent through the portal search
+#if defined(GRX_EMU_TRACE)
+static void grx_emu_trace(const GrxModel* m, const GrxCtx* c, int phase);   // defined at the end of this file
+#endif
+#endif
+#if defined(GRX_EMU) && defined(GRX_EMU_FP64) && defined(GRX_EMU_RNDINJ)
+// test infrastructure (tools/emu_tolerances.py --inject): the fp64 build with fp32 ROUNDING injected at chosen stage boundaries -- which stage's fp32 storage costs the parity?
+static void grx_rnd(float* p, int n) { for (int i = 0; i < n; i++) p[i] = (double)(grx_f32_t)p[i]; }
+#define GRX_RNDINJ(bit, body) do { static int mask_ = -1; if (mask_ < 0) { const char* e_ = getenv("GRX_RND_MASK"); mask_ = e_ ? atoi(e_) : 0; } if (mask_ & (1 << (bit))) { body; } } while (0)
+#else
+#define GRX_RNDINJ(bit, body) ((void)0)
 #endif
 template <class S>
 struct GrxEngine {
@@ -883,6 +923,19 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit 
   if (n == 33) return grx_sym_solve_reg<33>(A, n, x, lane_);
   if (n == 36) return grx_sym_solve_reg<36>(A, n, x, lane_);
 #endif
+#if defined(GRX_EMU) && defined(GRX_EXP_SOLVE64)
+  {   // experiment: the linear solve in double (LDL' from the last dof, like the fp32 routine)
+    static double B[40 * 40], y[40];
+    for (int i = 0; i < n * n; i++) B[i] = A[i];
+    for (int i = 0; i < n; i++) y[i] = x[i];
+    for (int k = n - 1; k >= 0; k--) { const double rinv = 1.0 / B[k * n + k]; for (int i = 0; i < k; i++) { const double ti = B[k * n + i] * rinv; for (int j = 0; j < k; j++) B[i * n + j] -= ti * B[k * n + j]; } B[k * n + k] = rinv; }
+    for (int k = n - 1; k > 0; k--) { const double yk = y[k] * B[k * n + k]; for (int i = 0; i < k; i++) y[i] -= B[k * n + i] * yk; }
+    for (int i = 0; i < n; i++) y[i] *= B[i * n + i];
+    for (int i = 0; i < n - 1; i++) { const double xi = y[i]; for (int k = i + 1; k < n; k++) y[k] -= B[k * n + i] * B[k * n + k] * xi; }
+    for (int i = 0; i < n; i++) x[i] = (float)y[i];
+    return 0;
+  }
+#endif
 #if defined(GRX_EMU)
   if (n == 21 || n == 14 || n == 15 || n == 24 || n == 29 || n == 30 || n == 33 || n == 36) {   // mirror the device: these sizes are solved without touching A
     static float copy[36 * 36];
@@ -1173,34 +1226,55 @@ GRX_MEM void grx_sphere_capsule(const GrxModel* m, GrxCtx* c, int pair, int g1, 
 #ifndef GRX_MPR_EPS
 #define GRX_MPR_EPS 2.220446e-16f
 #endif
-struct GrxMprPt { float v[3], w[3]; };
-GRX_MEM int grx_mpr_zero(float x) { return fabsf(x) < GRX_MPR_EPS; }
-GRX_MEM int grx_mpr_eq(float a, float b) {
-  float ab = fabsf(a - b);
+// Arithmetic type of the general convex routine (portal refinement + its support functions): GRX_MPR_REAL.  The routine's branch decisions compare
+// triple products of nearly coplanar portal vertices and its final triangle is the size of a resting contact's depth, so fp32 rounding inside it moves the
+// contact POINT of a line / face contact by centimetres (tools/emu_trace.py); it runs for a handful of pairs per substep, which is why it can afford fp64.
+#ifndef GRX_MPR_REAL
+#define GRX_MPR_REAL double
+#endif
+typedef GRX_MPR_REAL MF;
+#ifndef GRX_HULL_REAL
+#define GRX_HULL_REAL float
+#endif
+typedef GRX_HULL_REAL HF;   // arithmetic of the hull support scan (vertex tables are fp32)
+GRX_MEM float grx_sqrt(float x) { return sqrtf(x); }
+GRX_MEM float grx_fabs(float x) { return fabsf(x); }
+GRX_MEM float grx_fmin(float a, float b) { return fminf(a, b); }
+GRX_MEM float grx_fmax(float a, float b) { return fmaxf(a, b); }
+#ifndef GRX_EMU_FP64
+GRX_MEM double grx_sqrt(double x) { return sqrt(x); }
+GRX_MEM double grx_fabs(double x) { return fabs(x); }
+GRX_MEM double grx_fmin(double a, double b) { return fmin(a, b); }
+GRX_MEM double grx_fmax(double a, double b) { return fmax(a, b); }
+#endif
+struct GrxMprPt { MF v[3], w[3]; };
+GRX_MEM int grx_mpr_zero(MF x) { return grx_fabs(x) < GRX_MPR_EPS; }
+GRX_MEM int grx_mpr_eq(MF a, MF b) {
+  MF ab = grx_fabs(a - b);
   if (ab < GRX_MPR_EPS) return 1;
-  a = fabsf(a); b = fabsf(b);
+  a = grx_fabs(a); b = grx_fabs(b);
   return ab < GRX_MPR_EPS * (b > a ? b : a);
 }
-GRX_MEM float grx_sgn1f(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
-GRX_MEM void grx_normalize3f(float* v) { float n2 = dot3f(v, v); if (n2 > 0.0f) { float s = 1.0f / sqrtf(n2); v[0] *= s; v[1] *= s; v[2] *= s; } }
+GRX_MEM MF grx_sgn1f(MF x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+GRX_MEM void grx_normalize3f(MF* v) { MF n2 = dot3f(v, v); if (n2 > 0.0f) { MF s = 1.0f / grx_sqrt(n2); v[0] *= s; v[1] *= s; v[2] *= s; } }
 // farthest point of the geom along the world direction d, relative to the geom centre
-GRX_MEM void grx_geom_support(const float* R, const float* sz, int type, const float* d, float* out) {
-  float dl[3], r[3] = {0.0f, 0.0f, 0.0f};
+GRX_MEM void grx_geom_support(const MF* R, const MF* sz, int type, const MF* d, MF* out) {
+  MF dl[3], r[3] = {0.0f, 0.0f, 0.0f};
   mulMatTVec3f(dl, R, d);
   if (type == 2) { r[0] = dl[0] * sz[0]; r[1] = dl[1] * sz[0]; r[2] = dl[2] * sz[0]; }
   else if (type == 3) { r[0] = dl[0] * sz[0]; r[1] = dl[1] * sz[0]; r[2] = dl[2] * sz[0] + grx_sgn1f(dl[2]) * sz[1]; }
   else if (type == 4) {
-    float t[3] = {dl[0] * sz[0], dl[1] * sz[1], dl[2] * sz[2]};
+    MF t[3] = {dl[0] * sz[0], dl[1] * sz[1], dl[2] * sz[2]};
     grx_normalize3f(t);
     r[0] = t[0] * sz[0]; r[1] = t[1] * sz[1]; r[2] = t[2] * sz[2];
   } else if (type == 5) {
-    float h = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
-    if (h > GRX_MINVAL) { float ih = sz[0] / h; r[0] = dl[0] * ih; r[1] = dl[1] * ih; }
+    MF h = grx_sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+    if (h > GRX_MINVAL) { MF ih = sz[0] / h; r[0] = dl[0] * ih; r[1] = dl[1] * ih; }
     r[2] = grx_sgn1f(dl[2]) * sz[1];
   } else if (type == 6) { r[0] = grx_sgn1f(dl[0]) * sz[0]; r[1] = grx_sgn1f(dl[1]) * sz[1]; r[2] = grx_sgn1f(dl[2]) * sz[2]; }
   mulMatVec3f(out, R, r);
 }
-struct GrxMprPair { float R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // the two frames are copied into registers: ~20 support evaluations each read them twice
+struct GrxMprPair { MF R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // the two frames are copied into registers: ~20 support evaluations each read them twice
                     const float *v1, *v2; int n1, n2, lane;                      // hull vertices (geom frame) of mesh geoms: only read by the wave-cooperative variant
                     GrxMprPt* pts;
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
@@ -1210,13 +1284,14 @@ struct GrxMprPair { float R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   
 // Convex hull of a mesh: the hull vertex farthest along the (geom-frame) direction dl; the lowest vertex index wins ties, like the oracle's
 // exhaustive scan.  Called from wave-uniform code: on the GPU the 64 lanes share the scan (lane l takes the vertices l, l + 64, ...; the
 // loads are coalesced) and agree on the winner through two DPP reductions -- a hull of 500 vertices costs 8 loads per lane.
-GRX_MEM int grx_mesh_support(const float* verts, int n, const float* dl, float* r, int lane_) {
+GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, int lane_) {
   r[0] = r[1] = r[2] = 0.0f;
   if (n <= 0) return -1;
+  const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};   // the scan's own arithmetic type (GRX_HULL_REAL)
 #if defined(GRX_EMU)
   (void)lane_;
-  float best = -3.0e38f; int bi = 0;
-  for (int v = 0; v < n; v++) { const float t = verts[3 * v] * dl[0] + verts[3 * v + 1] * dl[1] + verts[3 * v + 2] * dl[2]; if (t > best) { best = t; bi = v; } }
+  HF best = -3.0e38f; int bi = 0;
+  for (int v = 0; v < n; v++) { const HF t = verts[3 * v] * dl[0] + verts[3 * v + 1] * dl[1] + verts[3 * v + 2] * dl[2]; if (t > best) { best = t; bi = v; } }
 #else
 #ifndef GRX_HULL_INFLIGHT
 #define GRX_HULL_INFLIGHT 4
@@ -1247,11 +1322,12 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const float* dl, float* 
 // The same with a guess: a hull vertex that is not lower than any of its hull neighbours along dl IS the support vertex (convexity), so a
 // vertex remembered from the previous substep is verified with one round of neighbour loads instead of a scan of the whole hull.
 // Returns the support vertex (hint, or the winner of the full scan).
-GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const float* dl, int hint, float* r, int lane_) {
+GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* dlm, int hint, MF* r, int lane_) {
   const float* verts = m->mesh_vert + 3 * adr;
+  const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};
   if (hint >= 0 && hint < n) {
     const int aa = m->mesh_adjadr[adr + hint], an = m->mesh_adjnum[adr + hint];
-    const float t0 = verts[3 * hint] * dl[0] + verts[3 * hint + 1] * dl[1] + verts[3 * hint + 2] * dl[2];
+    const HF t0 = verts[3 * hint] * dl[0] + verts[3 * hint + 1] * dl[1] + verts[3 * hint + 2] * dl[2];
 #if defined(GRX_EMU)
     int higher = 0;
     for (int k = 0; k < an; k++) { const int nb = m->mesh_adj[aa + k]; higher |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
@@ -1262,21 +1338,21 @@ GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const float
 #endif
     if (!higher) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
   }
-  return grx_mesh_support(verts, n, dl, r, lane_);
+  return grx_mesh_support(verts, n, dlm, r, lane_);
 }
 // W: wave-cooperative variant (uniform control flow, every lane holds the same values; mesh geoms allowed)
 template <bool W>
-GRX_MEM void grx_mpr_support(const GrxMprPair* q, const float* d, GrxMprPt* o) {
-  float nd[3] = {-d[0], -d[1], -d[2]}, b[3];
+GRX_MEM void grx_mpr_support(const GrxMprPair* q, const MF* d, GrxMprPt* o) {
+  MF nd[3] = {-d[0], -d[1], -d[2]}, b[3];
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   if (W && q->lane == 0) { q->prof[16 + 26] += 1; q->prof[16 + 27] += (q->t1 == 7 ? q->n1 : 0) + (q->t2 == 7 ? q->n2 : 0); }
 #endif
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   const long long tp0_ = clock64();
 #endif
-  if (W && q->t1 == 7) { float dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); grx_mesh_support(q->v1, q->n1, dl, r, q->lane); mulMatVec3f(o->w, q->R1, r); }
+  if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); grx_mesh_support(q->v1, q->n1, dl, r, q->lane); mulMatVec3f(o->w, q->R1, r); }
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
-  if (W && q->t2 == 7) { float dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); grx_mesh_support(q->v2, q->n2, dl, r, q->lane); mulMatVec3f(b, q->R2, r); }
+  if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); grx_mesh_support(q->v2, q->n2, dl, r, q->lane); mulMatVec3f(b, q->R2, r); }
   else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   if (W && q->lane == 0) q->prof[16 + 28] += clock64() - tp0_;
@@ -1284,39 +1360,39 @@ GRX_MEM void grx_mpr_support(const GrxMprPair* q, const float* d, GrxMprPt* o) {
   for (int k = 0; k < 3; k++) { o->w[k] += d[k] * q->hm; o->v[k] = o->w[k] - (b[k] + q->c21[k] - d[k] * q->hm); }
 }
 // the portal is kept as four separate points (not an array): every access is to a named variable, so the 30 floats stay in registers
-GRX_MEM void grx_mpr_portal_dir(const GrxMprPt& P1, const GrxMprPt& P2, const GrxMprPt& P3, float* dir) {
-  float a[3], b[3];
+GRX_MEM void grx_mpr_portal_dir(const GrxMprPt& P1, const GrxMprPt& P2, const GrxMprPt& P3, MF* dir) {
+  MF a[3], b[3];
   for (int k = 0; k < 3; k++) { a[k] = P2.v[k] - P1.v[k]; b[k] = P3.v[k] - P1.v[k]; }
   cross3f(dir, a, b); grx_normalize3f(dir);
 }
-GRX_MEM int grx_mpr_reach_tolerance(const GrxMprPt& P1, const GrxMprPt& P2, const GrxMprPt& P3, const GrxMprPt& v4, const float* dir, float tol) {
-  float d4 = dot3f(v4.v, dir), mn = fminf(d4 - dot3f(P1.v, dir), fminf(d4 - dot3f(P2.v, dir), d4 - dot3f(P3.v, dir)));
+GRX_MEM int grx_mpr_reach_tolerance(const GrxMprPt& P1, const GrxMprPt& P2, const GrxMprPt& P3, const GrxMprPt& v4, const MF* dir, MF tol) {
+  MF d4 = dot3f(v4.v, dir), mn = grx_fmin(d4 - dot3f(P1.v, dir), grx_fmin(d4 - dot3f(P2.v, dir), d4 - dot3f(P3.v, dir)));
   return grx_mpr_eq(mn, tol) || mn < tol;
 }
 GRX_MEM void grx_mpr_set(GrxMprPt& dst, const GrxMprPt& src, int take) {
   for (int k = 0; k < 3; k++) { dst.v[k] = take ? src.v[k] : dst.v[k]; dst.w[k] = take ? src.w[k] : dst.w[k]; }
 }
 GRX_MEM void grx_mpr_expand(const GrxMprPt& P0, GrxMprPt& P1, GrxMprPt& P2, GrxMprPt& P3, const GrxMprPt& v4) {
-  float cr[3];
+  MF cr[3];
   cross3f(cr, v4.v, P0.v);
   const int s1 = dot3f(P1.v, cr) > 0.0f, s2 = dot3f(P2.v, cr) > 0.0f, s3 = dot3f(P3.v, cr) > 0.0f;
   // s1: (s2 ? P1 : P3) <- v4;   !s1: (s3 ? P2 : P1) <- v4
   const int to1 = (s1 && s2) || (!s1 && !s3), to2 = !s1 && s3, to3 = s1 && !s2;
   grx_mpr_set(P1, v4, to1); grx_mpr_set(P2, v4, to2); grx_mpr_set(P3, v4, to3);
 }
-GRX_MEM float grx_mpr_seg_dist2(const float* a, const float* b, float* w) {
-  float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, t = -dot3f(a, d), dd = dot3f(d, d);
-  t = dd > 0.0f ? fminf(1.0f, fmaxf(0.0f, t / dd)) : 0.0f;
+GRX_MEM MF grx_mpr_seg_dist2(const MF* a, const MF* b, MF* w) {
+  MF d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, t = -dot3f(a, d), dd = dot3f(d, d);
+  t = dd > 0.0f ? grx_fmin(1.0f, grx_fmax(0.0f, t / dd)) : 0.0f;
   for (int k = 0; k < 3; k++) w[k] = a[k] + t * d[k];
   return dot3f(w, w);
 }
-GRX_MEM float grx_mpr_tri_dist2(const float* x0, const float* b, const float* cc, float* w) {
-  float d1[3], d2[3];
+GRX_MEM MF grx_mpr_tri_dist2(const MF* x0, const MF* b, const MF* cc, MF* w) {
+  MF d1[3], d2[3];
   for (int k = 0; k < 3; k++) { d1[k] = b[k] - x0[k]; d2[k] = cc[k] - x0[k]; }
-  float u = dot3f(x0, x0), v = dot3f(d1, d1), ww = dot3f(d2, d2), p = dot3f(x0, d1), q = dot3f(x0, d2), r = dot3f(d1, d2);
-  float den = ww * v - r * r, best;
+  MF u = dot3f(x0, x0), v = dot3f(d1, d1), ww = dot3f(d2, d2), p = dot3f(x0, d1), q = dot3f(x0, d2), r = dot3f(d1, d2);
+  MF den = ww * v - r * r, best;
   if (!grx_mpr_zero(den)) {
-    float sp = (q * r - ww * p) / den, tp = (-sp * r - q) / ww;
+    MF sp = (q * r - ww * p) / den, tp = (-sp * r - q) / ww;
     if ((grx_mpr_zero(sp) || sp > 0.0f) && (grx_mpr_eq(sp, 1.0f) || sp < 1.0f) && (grx_mpr_zero(tp) || tp > 0.0f) && (grx_mpr_eq(tp, 1.0f) || tp < 1.0f) &&
         (grx_mpr_eq(tp + sp, 1.0f) || tp + sp < 1.0f)) {
       for (int k = 0; k < 3; k++) w[k] = x0[k] + sp * d1[k] + tp * d2[k];
@@ -1328,7 +1404,7 @@ GRX_MEM float grx_mpr_tri_dist2(const float* x0, const float* b, const float* cc
       return best;
     }
   }
-  float w2[3], dist;
+  MF w2[3], dist;
   best = grx_mpr_seg_dist2(x0, b, w);
   dist = grx_mpr_seg_dist2(x0, cc, w2); if (dist < best) { best = dist; w[0] = w2[0]; w[1] = w2[1]; w[2] = w2[2]; }
   dist = grx_mpr_seg_dist2(b, cc, w2); if (dist < best) { best = dist; w[0] = w2[0]; w[1] = w2[1]; w[2] = w2[2]; }
@@ -1338,7 +1414,7 @@ GRX_MEM float grx_mpr_tri_dist2(const float* x0, const float* b, const float* cc
 // sep (may be null): on a -1 return caused by a support point on the far side of the origin (v . d <= 0), sep[0..2] <- that direction d
 // and sep[3] <- 1: d separates the two (inflated) geoms, which any later call can re-check with ONE support evaluation (grx_mesh_pairs)
 template <bool W>
-GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float* depth, float* dir, float* pos, float* w1, float* w2, float* sep = nullptr) {
+GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, MF tol, int maxit, MF* depth, MF* dir, MF* pos, MF* w1, MF* w2, MF* sep = nullptr) {
 #define GRX_MPR_SEP(D) do { if (W && sep) { sep[0] = (D)[0]; sep[1] = (D)[1]; sep[2] = (D)[2]; sep[3] = 1.0f; } } while (0)
   // lane-per-pair variant: the portal lives in registers; wave-cooperative variant: in LDS (every lane writes the same values)
   GrxMprPt r0_, r1_, r2_, r3_, r4_;
@@ -1349,7 +1425,7 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
 #endif
   GrxMprPt& P0 = kLds ? q->pts[0] : r0_; GrxMprPt& P1 = kLds ? q->pts[1] : r1_; GrxMprPt& P2 = kLds ? q->pts[2] : r2_; GrxMprPt& P3 = kLds ? q->pts[3] : r3_;
   GrxMprPt& v4 = kLds ? q->pts[4] : r4_;
-  float d[3], a[3], b[3], dotv;
+  MF d[3], a[3], b[3], dotv;
   for (int k = 0; k < 3; k++) { P0.w[k] = 0.0f; P0.v[k] = -q->c21[k]; }
   if (grx_mpr_eq(P0.v[0], 0.0f) && grx_mpr_eq(P0.v[1], 0.0f) && grx_mpr_eq(P0.v[2], 0.0f)) P0.v[0] += GRX_MPR_EPS * 10.0f;
   for (int k = 0; k < 3; k++) d[k] = -P0.v[k];
@@ -1361,7 +1437,7 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
   if (grx_mpr_zero(dot3f(d, d))) {
     for (int k = 0; k < 3; k++) { w1[k] = P1.w[k]; w2[k] = P1.w[k] - P1.v[k]; pos[k] = 0.5f * (w1[k] + w2[k]); }
     if (grx_mpr_eq(P1.v[0], 0.0f) && grx_mpr_eq(P1.v[1], 0.0f) && grx_mpr_eq(P1.v[2], 0.0f)) { *depth = 0.0f; dir[0] = dir[1] = dir[2] = 0.0f; return 0; }
-    dir[0] = P1.v[0]; dir[1] = P1.v[1]; dir[2] = P1.v[2]; *depth = sqrtf(dot3f(dir, dir)); grx_normalize3f(dir);
+    dir[0] = P1.v[0]; dir[1] = P1.v[1]; dir[2] = P1.v[2]; *depth = grx_sqrt(dot3f(dir, dir)); grx_normalize3f(dir);
     return 0;
   }
   grx_normalize3f(d);
@@ -1405,11 +1481,11 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
     if (W) { g_grx_mesh_stats[2]++; if (it > maxit) g_grx_mesh_stats[3]++; }
 #endif
     if (grx_mpr_reach_tolerance(P1, P2, P3, v4, d, tol) || it > maxit) {
-      float w[3];
-      *depth = sqrtf(grx_mpr_tri_dist2(P1.v, P2.v, P3.v, w));
+      MF w[3];
+      *depth = grx_sqrt(grx_mpr_tri_dist2(P1.v, P2.v, P3.v, w));
       if (grx_mpr_zero(w[0]) && grx_mpr_zero(w[1]) && grx_mpr_zero(w[2])) { w[0] = d[0]; w[1] = d[1]; w[2] = d[2]; }
       grx_normalize3f(w); dir[0] = w[0]; dir[1] = w[1]; dir[2] = w[2];
-      float bc[4], cr[3], sum;
+      MF bc[4], cr[3], sum;
       cross3f(cr, P1.v, P2.v); bc[0] = dot3f(cr, P3.v);
       cross3f(cr, P3.v, P2.v); bc[1] = dot3f(cr, P0.v);
       cross3f(cr, P0.v, P1.v); bc[2] = dot3f(cr, P3.v);
@@ -1423,9 +1499,9 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
         sum = bc[1] + bc[2] + bc[3];
       }
       // witness on geom 2 = w - v (+ the centre offset, which cancels in the relative frame except for P0: its witnesses are the two centres)
-      const float is = 1.0f / sum;
+      const MF is = 1.0f / sum;
       for (int k = 0; k < 3; k++) {
-        float p1 = 0.0f, p2 = bc[0] * q->c21[k];
+        MF p1 = 0.0f, p2 = bc[0] * q->c21[k];
         p1 += bc[1] * P1.w[k] + bc[2] * P2.w[k] + bc[3] * P3.w[k];
         p2 += bc[1] * (P1.w[k] - P1.v[k]) + bc[2] * (P2.w[k] - P2.v[k]) + bc[3] * (P3.w[k] - P3.v[k]);
         pos[k] = 0.5f * (p1 + p2) * is;
@@ -1434,7 +1510,7 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
       cross3f(cr, P2.v, P3.v); bc[1] = dot3f(cr, d);
       cross3f(cr, P3.v, P1.v); bc[2] = dot3f(cr, d);
       cross3f(cr, P1.v, P2.v); bc[3] = dot3f(cr, d);
-      const float it3 = 1.0f / (bc[1] + bc[2] + bc[3]);
+      const MF it3 = 1.0f / (bc[1] + bc[2] + bc[3]);
       for (int k = 0; k < 3; k++) {
         w1[k] = (bc[1] * P1.w[k] + bc[2] * P2.w[k] + bc[3] * P3.w[k]) * it3;
         w2[k] = (bc[1] * (P1.w[k] - P1.v[k]) + bc[2] * (P2.w[k] - P2.v[k]) + bc[3] * (P3.w[k] - P3.v[k])) * it3;
@@ -1447,45 +1523,117 @@ GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, float tol, int maxit, float
 #undef GRX_MPR_SEP
 // analytic outward normal of a smooth geom (sphere, capsule, ellipsoid) at the world point p (see the oracle: the portal direction of a
 // shallow contact is ill-conditioned, MuJoCo replaces it for smooth geoms); returns 0 for the other types
-GRX_MEM int grx_smooth_normal(const float* R, const float* ce, const float* sz, int type, const float* p, float* n) {
-  float d[3] = {p[0] - ce[0], p[1] - ce[1], p[2] - ce[2]}, loc[3], nl[3];
+GRX_MEM int grx_smooth_normal(const MF* R, const MF* ce, const MF* sz, int type, const MF* p, MF* n) {
+  MF d[3] = {p[0] - ce[0], p[1] - ce[1], p[2] - ce[2]}, loc[3], nl[3];
   mulMatTVec3f(loc, R, d);
   if (type == 2) { nl[0] = loc[0]; nl[1] = loc[1]; nl[2] = loc[2]; }
   else if (type == 3) { nl[0] = loc[0]; nl[1] = loc[1]; nl[2] = loc[2] > sz[1] ? loc[2] - sz[1] : (loc[2] < -sz[1] ? loc[2] + sz[1] : 0.0f); }
   else if (type == 4) { nl[0] = loc[0] / (sz[0] * sz[0]); nl[1] = loc[1] / (sz[1] * sz[1]); nl[2] = loc[2] / (sz[2] * sz[2]); }
   else return 0;
-  const float l2 = dot3f(nl, nl);
+  const MF l2 = dot3f(nl, nl);
   if (l2 < 1e-30f) return 0;
-  const float il = 1.0f / sqrtf(l2);
+  const MF il = 1.0f / grx_sqrt(l2);
   nl[0] *= il; nl[1] *= il; nl[2] *= il;
   mulMatVec3f(n, R, nl);
   return 1;
 }
+// Frame of geom g for the convex routine, in MF.  A geom of a FREE ROOT body (a free joint directly under the world: the manipulated objects) gets its frame
+// straight from the world's qpos in MF arithmetic -- normalised quaternion -> body frame -> geom frame, the oracle's operation order -- instead of the fp32 frames of
+// the kinematics stage: an object lying flat on a table is a line / face contact whose single contact point is decided by a tilt of ~1e-6 rad, which the ~1e-7
+// rounding of the fp32 frames moves by centimetres (tools/emu_mixed.py: the kinematics stage was the only fp32 stage the AdroitHammer fixtures noticed).
+GRX_MEM void grx_quat2mat_mf(MF* X, const MF* q) {
+  const MF w = q[0], x = q[1], y = q[2], z = q[3];
+  X[0] = w * w + x * x - y * y - z * z; X[1] = 2 * (x * y - w * z); X[2] = 2 * (x * z + w * y);
+  X[3] = 2 * (x * y + w * z); X[4] = w * w - x * x + y * y - z * z; X[5] = 2 * (y * z - w * x);
+  X[6] = 2 * (x * z - w * y); X[7] = 2 * (y * z + w * x); X[8] = w * w - x * x - y * y + z * z;
+}
+GRX_MEM void grx_geom_frame_mf(const GrxModel* m, const GrxCtx* c, int g, MF* R, MF* pos) {
+  const int b = m->geom_bodyid[g];
+#ifndef GRX_NO_FREE_FRAMES
+  // root bodies (children of the world that are not mocap bodies and not members of a shift group): the oracle's kinematics of ONE body, in MF
+  if (b > 0 && m->body_parent[b] == 0 && m->body_mocapid[b] < 0 && !(S::kShift && m->nshift && (m->geom_shift[g] || m->body_shift[b]))) {
+    const int jn = m->body_jntnum[b], ja = m->body_jntadr[b];
+    MF p[3], q[4];
+    if (jn == 1 && m->jnt_type[ja] == 0) {
+      const int qa = m->jnt_qposadr[ja];
+      for (int k = 0; k < 3; k++) p[k] = c->qpos[qa + k];
+      for (int k = 0; k < 4; k++) q[k] = c->qpos[qa + 3 + k];
+    } else {
+      for (int k = 0; k < 3; k++) p[k] = m->body_pos[3 * b + k];
+      for (int k = 0; k < 4; k++) q[k] = m->body_quat[4 * b + k];
+      for (int kk = 0; kk < jn; kk++) {
+        const int j = ja + kk;
+        MF Rq[9]; grx_quat2mat_mf(Rq, q);
+        const MF jp[3] = {m->jnt_pos[3 * j], m->jnt_pos[3 * j + 1], m->jnt_pos[3 * j + 2]}, jx[3] = {m->jnt_axis[3 * j], m->jnt_axis[3 * j + 1], m->jnt_axis[3 * j + 2]};
+        MF anchor[3], axis[3];
+        mulMatVec3f(anchor, Rq, jp); anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
+        mulMatVec3f(axis, Rq, jx);
+        const MF dq = (MF)c->qpos[m->jnt_qposadr[j]] - (MF)m->qpos0[m->jnt_qposadr[j]];
+        if (m->jnt_type[j] == 2) { p[0] += axis[0] * dq; p[1] += axis[1] * dq; p[2] += axis[2] * dq; }
+        else if (m->jnt_type[j] == 3) {
+          const MF sn = sin(0.5 * (double)dq), cs = cos(0.5 * (double)dq);
+          const MF qr[4] = {cs, jx[0] * sn, jx[1] * sn, jx[2] * sn};
+          const MF qn[4] = {q[0] * qr[0] - q[1] * qr[1] - q[2] * qr[2] - q[3] * qr[3], q[0] * qr[1] + q[1] * qr[0] + q[2] * qr[3] - q[3] * qr[2],
+                            q[0] * qr[2] - q[1] * qr[3] + q[2] * qr[0] + q[3] * qr[1], q[0] * qr[3] + q[1] * qr[2] - q[2] * qr[1] + q[3] * qr[0]};
+          for (int k = 0; k < 4; k++) q[k] = qn[k];
+          MF Rn[9], off[3]; grx_quat2mat_mf(Rn, q); mulMatVec3f(off, Rn, jp);
+          p[0] = anchor[0] - off[0]; p[1] = anchor[1] - off[1]; p[2] = anchor[2] - off[2];
+        }
+      }
+    }
+    const MF n = grx_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n > 1e-12f) { const MF r = 1.0f / n; q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r; }
+    MF X[9], L[9];
+    grx_quat2mat_mf(X, q);
+    const MF lq[4] = {m->geom_quat[4 * g], m->geom_quat[4 * g + 1], m->geom_quat[4 * g + 2], m->geom_quat[4 * g + 3]};
+    grx_quat2mat_mf(L, lq);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R[3 * i + j] = X[3 * i] * L[j] + X[3 * i + 1] * L[3 + j] + X[3 * i + 2] * L[6 + j];
+    const MF lp[3] = {m->geom_pos[3 * g], m->geom_pos[3 * g + 1], m->geom_pos[3 * g + 2]};
+    for (int i = 0; i < 3; i++) pos[i] = p[i] + (X[3 * i] * lp[0] + X[3 * i + 1] * lp[1] + X[3 * i + 2] * lp[2]);
+    return;
+  }
+#endif
+  for (int k = 0; k < 9; k++) R[k] = c->gxmat[9 * g + k];
+  for (int k = 0; k < 3; k++) pos[k] = c->gxpos[3 * g + k];
+}
 GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, int t1, int t2, float margin) {
   GrxMprPair q;
-  for (int k = 0; k < 9; k++) { q.R1[k] = c->gxmat[9 * g1 + k]; q.R2[k] = c->gxmat[9 * g2 + k]; }
+  MF p1[3], p2[3];
+  grx_geom_frame_mf(m, c, g1, q.R1, p1); grx_geom_frame_mf(m, c, g2, q.R2, p2);
   q.t1 = t1; q.t2 = t2; q.hm = 0.5f * margin;
-  for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = c->gxpos[3 * g2 + k] - c->gxpos[3 * g1 + k]; }
-  float depth, dir[3], pos[3], w1[3], w2[3];
+  for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = p2[k] - p1[k]; }
+  MF depth, dir[3], pos[3], w1[3], w2[3];
   q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr;
   if (grx_mpr_penetration<false>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;
+#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+  if (getenv("GRX_TRACE_MPR")) {
+    fprintf(stderr, "MPR pair %d g %d %d t %d %d\n R1", pair, g1, g2, t1, t2);
+    for (int k = 0; k < 9; k++) fprintf(stderr, " %.17g", (double)q.R1[k]);
+    fprintf(stderr, "\n R2"); for (int k = 0; k < 9; k++) fprintf(stderr, " %.17g", (double)q.R2[k]);
+    fprintf(stderr, "\n c21 %.17g %.17g %.17g s1 %.9g %.9g %.9g s2 %.9g %.9g %.9g hm %.9g\n depth %.17g dir %.17g %.17g %.17g pos %.17g %.17g %.17g\n", (double)q.c21[0], (double)q.c21[1], (double)q.c21[2],
+            (double)q.s1[0], (double)q.s1[1], (double)q.s1[2], (double)q.s2[0], (double)q.s2[1], (double)q.s2[2], (double)q.hm, (double)depth, (double)dir[0], (double)dir[1], (double)dir[2], (double)pos[0], (double)pos[1], (double)pos[2]);
+  }
+#endif
   if (dir[0] == 0.0f && dir[1] == 0.0f && dir[2] == 0.0f) return;
-  for (int k = 0; k < 3; k++) pos[k] += c->gxpos[3 * g1 + k];
-  float n1[3] = {0.0f, 0.0f, 0.0f}, n2[3] = {0.0f, 0.0f, 0.0f};
-  const int h1 = grx_smooth_normal(q.R1, c->gxpos + 3 * g1, q.s1, t1, pos, n1), h2 = grx_smooth_normal(q.R2, c->gxpos + 3 * g2, q.s2, t2, pos, n2);
+  // still relative to the centre of geom 1: the smooth normals are taken in that frame as well (the world offset only enters the stored contact position)
+  const MF ce1[3] = {0.0f, 0.0f, 0.0f};
+  MF n1[3] = {0.0f, 0.0f, 0.0f}, n2[3] = {0.0f, 0.0f, 0.0f};
+  const int h1 = grx_smooth_normal(q.R1, ce1, q.s1, t1, pos, n1), h2 = grx_smooth_normal(q.R2, q.c21, q.s2, t2, pos, n2);
   if (h1 || h2) {
-    float n[3] = {n1[0] - n2[0], n1[1] - n2[1], n1[2] - n2[2]};
-    const float l2 = dot3f(n, n);
+    MF n[3] = {n1[0] - n2[0], n1[1] - n2[1], n1[2] - n2[2]};
+    const MF l2 = dot3f(n, n);
     if (l2 > 1e-30f) {
-      const float il = 1.0f / sqrtf(l2); dir[0] = n[0] * il; dir[1] = n[1] * il; dir[2] = n[2] * il;
+      const MF il = 1.0f / grx_sqrt(l2); dir[0] = n[0] * il; dir[1] = n[1] * il; dir[2] = n[2] * il;
       // penetration along the corrected normal: extreme point of a smooth geom, portal witness of a box / cylinder (see the oracle)
-      float nd[3] = {-dir[0], -dir[1], -dir[2]};
+      MF nd[3] = {-dir[0], -dir[1], -dir[2]};
       if (h1) { grx_geom_support(q.R1, q.s1, t1, dir, w1); for (int k = 0; k < 3; k++) w1[k] += dir[k] * q.hm; }
       if (h2) { grx_geom_support(q.R2, q.s2, t2, nd, w2); for (int k = 0; k < 3; k++) w2[k] += q.c21[k] - dir[k] * q.hm; }
       depth = (w1[0] - w2[0]) * dir[0] + (w1[1] - w2[1]) * dir[1] + (w1[2] - w2[2]) * dir[2];
     }
   }
-  grx_add_contact(c, pair, pos, dir, margin - depth);
+  const float posw[3] = {(float)(pos[0] + p1[0]), (float)(pos[1] + p1[1]), (float)(pos[2] + p1[2])}, dirf[3] = {(float)dir[0], (float)dir[1], (float)dir[2]};
+  grx_add_contact(c, pair, posw, dirf, (float)(margin - depth));
 }
 // ------------------------------------------------------------------------------------------
 // Hull-vs-convex pairs (the convex hull of a mesh against a primitive or another hull: the Fetch arm / gripper / base links, assets/fetch/
@@ -1553,7 +1701,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     GrxMprPair q;
     for (int k = 0; k < 9; k++) { q.R1[k] = c->gxmat[9 * g1 + k]; q.R2[k] = c->gxmat[9 * g2 + k]; }
     q.t1 = m->geom_type[g1]; q.t2 = m->geom_type[g2]; q.hm = 0.5f * margin; q.lane = lane_;
-    for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = c->gxpos[3 * g2 + k] - c->gxpos[3 * g1 + k]; }
+    for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = (MF)c->gxpos[3 * g2 + k] - (MF)c->gxpos[3 * g1 + k]; }
     q.v1 = q.t1 == 7 ? m->mesh_vert + 3 * m->geom_hulladr[g1] : m->mesh_vert; q.n1 = q.t1 == 7 ? m->geom_hullnum[g1] : 0;
     q.v2 = q.t2 == 7 ? m->mesh_vert + 3 * m->geom_hulladr[g2] : m->mesh_vert; q.n2 = q.t2 == 7 ? m->geom_hullnum[g2] : 0;
     q.pts = (GrxMprPt*)(c->Jp + 192);
@@ -1567,15 +1715,15 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     const float key = (float)(pair + 1);
     const int slot = mc[0] == key ? 0 : (mc[5] == key ? 1 : (mc[10] == key ? 2 : (mc[15] == key ? 3 : -1)));
     if (slot >= 0) {
-      const float d[3] = {mc[5 * slot + 1], mc[5 * slot + 2], mc[5 * slot + 3]}, nd[3] = {-d[0], -d[1], -d[2]};
+      const MF d[3] = {mc[5 * slot + 1], mc[5 * slot + 2], mc[5 * slot + 3]}, nd[3] = {-d[0], -d[1], -d[2]};
       const int hints = (int)mc[5 * slot + 4];
       int h1 = (hints & 4095) - 1, h2 = (hints >> 12) - 1;
-      float sw[3], sb[3], dl[3], r[3];
+      MF sw[3], sb[3], dl[3], r[3];
       if (q.t1 == 7) { mulMatTVec3f(dl, q.R1, d); h1 = grx_mesh_support_hint(m, m->geom_hulladr[g1], q.n1, dl, h1, r, lane_); mulMatVec3f(sw, q.R1, r); }
       else grx_geom_support(q.R1, q.s1, q.t1, d, sw);
       if (q.t2 == 7) { mulMatTVec3f(dl, q.R2, nd); h2 = grx_mesh_support_hint(m, m->geom_hulladr[g2], q.n2, dl, h2, r, lane_); mulMatVec3f(sb, q.R2, r); }
       else grx_geom_support(q.R2, q.s2, q.t2, nd, sb);
-      float sv = 0.0f;   // v . d of the Minkowski support point (see grx_mpr_support)
+      MF sv = 0.0f;   // v . d of the Minkowski support point (see grx_mpr_support)
       for (int k = 0; k < 3; k++) sv += ((sw[k] + d[k] * q.hm) - (sb[k] + q.c21[k] - d[k] * q.hm)) * d[k];
       if (sv < -1e-6f) {   // strictly on the far side: the (inflated) geoms are disjoint
         LANE0 { mc[5 * slot + 4] = (float)((h1 + 1) + 4096 * (h2 + 1)); }
@@ -1591,7 +1739,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
 #if defined(GRX_EMU)
     g_grx_mesh_stats[1]++;
 #endif
-    float depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    MF depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
     GRX_SUBTICK(c, 23);   // portal search
 #ifdef GRX_PROBE_HULL   // outcome of the searches (tools/hull_outcome_probe.py): contacts, separations with a direction, the pair searched last
@@ -1604,28 +1752,29 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     if (rc != 0) {
       if (sep[3] != 0.0f) {   // keep the direction for the next substeps
         const int w = slot >= 0 ? slot : ((int)mc[20] & 3);   // the pair's own slot, else round robin over the four
-        LANE0 { mc[5 * w] = key; mc[5 * w + 1] = sep[0]; mc[5 * w + 2] = sep[1]; mc[5 * w + 3] = sep[2]; mc[5 * w + 4] = 0.0f; if (slot < 0) mc[20] = (float)((w + 1) & 3); }
+        LANE0 { mc[5 * w] = key; mc[5 * w + 1] = sep[0]; mc[5 * w + 2] = sep[1]; mc[5 * w + 3] = sep[2]; mc[5 * w + 4] = 0.0f; if (slot < 0) mc[20] = (MF)((w + 1) & 3); }
       }
       WAVE_SYNC();
       continue;
     }
     if (slot >= 0) { LANE0 { mc[5 * slot] = 0.0f; } WAVE_SYNC(); }   // the pair is in contact: its old direction is useless, do not re-check it (two support evaluations) before every search of the next substeps
     if (dir[0] == 0.0f && dir[1] == 0.0f && dir[2] == 0.0f) continue;
-    for (int k = 0; k < 3; k++) pos[k] += c->gxpos[3 * g1 + k];
-    float n1[3] = {0.0f, 0.0f, 0.0f}, n2[3] = {0.0f, 0.0f, 0.0f};
-    const int h1 = grx_smooth_normal(q.R1, c->gxpos + 3 * g1, q.s1, q.t1, pos, n1), h2 = grx_smooth_normal(q.R2, c->gxpos + 3 * g2, q.s2, q.t2, pos, n2);
+    const MF ce1[3] = {0.0f, 0.0f, 0.0f};
+    MF n1[3] = {0.0f, 0.0f, 0.0f}, n2[3] = {0.0f, 0.0f, 0.0f};
+    const int h1 = grx_smooth_normal(q.R1, ce1, q.s1, q.t1, pos, n1), h2 = grx_smooth_normal(q.R2, q.c21, q.s2, q.t2, pos, n2);
     if (h1 || h2) {   // a smooth primitive against the hull: analytic normal, depth along it (see grx_convex_pair)
-      float n[3] = {n1[0] - n2[0], n1[1] - n2[1], n1[2] - n2[2]};
-      const float l2 = dot3f(n, n);
+      MF n[3] = {n1[0] - n2[0], n1[1] - n2[1], n1[2] - n2[2]};
+      const MF l2 = dot3f(n, n);
       if (l2 > 1e-30f) {
-        const float il = 1.0f / sqrtf(l2); dir[0] = n[0] * il; dir[1] = n[1] * il; dir[2] = n[2] * il;
-        float nd[3] = {-dir[0], -dir[1], -dir[2]};
+        const MF il = 1.0f / grx_sqrt(l2); dir[0] = n[0] * il; dir[1] = n[1] * il; dir[2] = n[2] * il;
+        MF nd[3] = {-dir[0], -dir[1], -dir[2]};
         if (h1) { grx_geom_support(q.R1, q.s1, q.t1, dir, w1); for (int k = 0; k < 3; k++) w1[k] += dir[k] * q.hm; }
         if (h2) { grx_geom_support(q.R2, q.s2, q.t2, nd, w2); for (int k = 0; k < 3; k++) w2[k] += q.c21[k] - dir[k] * q.hm; }
         depth = (w1[0] - w2[0]) * dir[0] + (w1[1] - w2[1]) * dir[1] + (w1[2] - w2[2]) * dir[2];
       }
     }
-    LANE0 { grx_add_contact(c, pair, pos, dir, margin - depth); }
+    const float posw[3] = {(float)(pos[0] + c->gxpos[3 * g1]), (float)(pos[1] + c->gxpos[3 * g1 + 1]), (float)(pos[2] + c->gxpos[3 * g1 + 2])}, dirf[3] = {(float)dir[0], (float)dir[1], (float)dir[2]};
+    LANE0 { grx_add_contact(c, pair, posw, dirf, (float)(margin - depth)); }
     WAVE_SYNC();
   }
 }
@@ -1667,9 +1816,14 @@ GRX_MEM void grx_plane_cylinder(const GrxModel* m, GrxCtx* c, int pair, int g1, 
   }
 }
 GRX_MEM void grx_plane_ellipsoid(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
-  float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}, nd[3] = {-n[0], -n[1], -n[2]}, p[3];
-  const float sz[3] = {m->geom_size[3 * g2], m->geom_size[3 * g2 + 1], m->geom_size[3 * g2 + 2]};
-  grx_geom_support(c->gxmat + 9 * g2, sz, 4, nd, p);
+  float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]}, p[3];
+  {
+    const MF sz[3] = {m->geom_size[3 * g2], m->geom_size[3 * g2 + 1], m->geom_size[3 * g2 + 2]}, nd[3] = {-n[0], -n[1], -n[2]};
+    MF R2[9], pm[3];
+    for (int k = 0; k < 9; k++) R2[k] = c->gxmat[9 * g2 + k];
+    grx_geom_support(R2, sz, 4, nd, pm);
+    p[0] = (float)pm[0]; p[1] = (float)pm[1]; p[2] = (float)pm[2];
+  }
   float dd[3];
   for (int k = 0; k < 3; k++) { p[k] += c->gxpos[3 * g2 + k]; dd[k] = p[k] - c->gxpos[3 * g1 + k]; }
   const float dist = dot3f(dd, n);
@@ -1998,6 +2152,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   }
   LANE0 { c->cnt[0] = 0; c->cnt[7] = 0; }
   WAVE_SYNC();
+  GRX_RNDINJ(7, (grx_rnd(c->gxpos, 3 * m->ngeom), grx_rnd(c->gxmat, 9 * m->ngeom)));
   GRX_SUBTICK(c, 12);
   // Wall lattice (maze layouts): a moving sphere / capsule only meets the walls of the 3 x 3 cells around its centre -- nine table lookups per
   // mover instead of one bounding-sphere test per (mover, wall) pair of the flat list; same pairs, same tests, same narrow phase.
@@ -2380,9 +2535,12 @@ GRX_MEM int grx_row_pos(int info, int id, int d) {
   return ((unsigned)jb < (unsigned)GRX_ROWB_LEN(id)) ? GRX_ROW_LEN(info) + jb : -1;
 }
 // row r of J times a dof vector
-GRX_MEM float grx_row_dot(const GrxCtx* c, int r, const float* v) {
+#ifndef GRX_ROWDOT_ACC
+#define GRX_ROWDOT_ACC float
+#endif
+GRX_MEM GRX_ROWDOT_ACC grx_row_dot(const GrxCtx* c, int r, const float* v) {
   const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
-  float s = 0;
+  GRX_ROWDOT_ACC s = 0;
 #pragma unroll 8
   for (int j = 0; j < len; j++) s += c->Jp[off + j] * v[lo + j];
   if (S::kTwoSpan) {
@@ -2709,7 +2867,7 @@ GRX_MEM int grx_newton_eval(const GrxModel* m, GrxCtx* c, const float* a, int ne
       }
     }
     for (int r = lane; r < nefc; r += 64) {
-      float x = carried ? c->efc_jar[r] : grx_row_dot(c, r, a) - c->efc_aref[r], D = c->efc_D[r], f; int st;
+      float x = carried ? c->efc_jar[r] : (float)(grx_row_dot(c, r, a) - c->efc_aref[r]), D = c->efc_D[r], f; int st;
       int kind = c->efc_kind[r];
       if (kind == GRX_ROW_EQ) { f = -D * x; st = 1; }
       else if (kind == GRX_ROW_FRICTION) {
@@ -2876,14 +3034,18 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   }
 }
 
-// Incremental Hessian.  A row contributes to the problem through (d, k): force = -d (J a) + k, with (D, D aref) in the quadratic
-// state, (0, -+floss) for a saturated friction-loss row and (0, 0) when inactive; H = M + sum d J'J and g0 = sum k J, so that
-// J'f = -(H - M) a + g0 and the gradient is H a - qfrc_smooth - g0.  Between two Newton iterations of one substep only the rows whose
-// state flipped change (d, k): apply their rank-1 corrections to A and g0 instead of re-assembling H over all rows (one flip is the
-// common case; the iterations after the first are what separates an expensive world from a cheap one).  Returns 0 when more than
+// Incremental Hessian.  A row contributes to the problem through its state: force = -d (J a - aref) + kf, with d = D in the quadratic
+// state, (d, kf) = (0, -+floss) for a saturated friction-loss row and (0, 0) when inactive; H = M + sum d J'J.  Between two Newton
+// iterations of one substep only the rows whose state flipped change d: apply their rank-1 corrections to A instead of re-assembling H
+// over all rows (one flip is the common case; the iterations after the first are what separates an expensive world from a cheap one).
+// The GRADIENT is advanced the same way (the caller has put g_old + alpha H_old v into `gnew`: exact while no row changes state); a row
+// that flipped adds J_r' (f_new - f_old-state(jar_new)) = J_r' (-(d_new - d_old) jar_new + (kf_new - kf_old)), all of it small near the
+// solution.  (Round 3 formed the gradient as H a - qfrc_smooth - sum k J with k = D aref: terms of size D |aref| |J| ~ 400 cancelling to
+// 1e-6 -- in fp32 a noise of 2e-5 on the puck's angular dof, whose Hessian entry is 6e-4: an acceleration error of 3e-2 rad/s^2 per
+// substep, the whole FetchSlide rotation-velocity discrepancy; tools/emu_mixed.py, tools/emu_trace.py.)  Returns 0 when more than
 // GRX_HUPD_MAX rows flipped (the caller re-assembles).  Uses c->ired (row list) and c->Mv (the row, expanded) as scratch.
 #define GRX_HUPD_MAX 8
-GRX_MEM int grx_hessian_update(const GrxModel* m, GrxCtx* c, int nefc, float* g0, int lane_) {
+GRX_MEM int grx_hessian_update(const GrxModel* m, GrxCtx* c, int nefc, float* gnew, int lane_) {
   const int nv = GRX_NVC;
   int* list = c->ired;
   int nd = 0;
@@ -2899,10 +3061,11 @@ GRX_MEM int grx_hessian_update(const GrxModel* m, GrxCtx* c, int nefc, float* g0
   for (int e = 0; e < nd; e++) {
     const int r = list[e];
     const int q = c->efc_quad[r], st = q & 3, hs = (q >> 4) & 3, info = c->efc_row[r], idb = S::kTwoSpan ? c->efc_id[r] : 0;
-    const float D = c->efc_D[r], kq = D * c->efc_aref[r];
+    const float D = c->efc_D[r];
     const float fl = (st >= 2 || hs >= 2) ? c->efc_floss[r] : 0.0f;
     const float dd = (st == 1 ? D : 0.0f) - (hs == 1 ? D : 0.0f);
-    const float dk = (st == 1 ? kq : (st == 2 ? -fl : (st == 3 ? fl : 0.0f))) - (hs == 1 ? kq : (hs == 2 ? -fl : (hs == 3 ? fl : 0.0f)));
+    // change of the row force at the current point: -(d_new - d_old) jar + (kf_new - kf_old)
+    const float df = -dd * c->efc_jar[r] + ((st == 2 ? -fl : (st == 3 ? fl : 0.0f)) - (hs == 2 ? -fl : (hs == 3 ? fl : 0.0f)));
     FOR_LANES { for (int i = lane; i < nv; i += 64) { const int pos = grx_row_pos(info, idb, i); c->Mv[i] = pos >= 0 ? c->Jp[GRX_ROW_OFF(info) + pos] : 0.0f; } }
     WAVE_SYNC();
     FOR_LANES {
@@ -2911,7 +3074,7 @@ GRX_MEM int grx_hessian_update(const GrxModel* m, GrxCtx* c, int nefc, float* g0
         if (vi != 0.0f) {
           const float s_ = dd * vi;
           for (int j = 0; j < nv; j++) c->A[i * nv + j] += s_ * c->Mv[j];
-          g0[i] += dk * vi;
+          gnew[i] -= df * vi;   // gradient = M a - qfrc_smooth - J'f
         }
       }
     }
@@ -3184,7 +3347,11 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const int nefc = c->cnt[1];
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   const int implicit_damp = (m->anydamp && m->eulerdamp);
-  int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0, g0_ready = 0;
+  int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0;
+  float alpha_prev = 0.0f;   // the step length accepted by the previous Newton iteration (gradient advance of the incremental path)
+#if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)
+  if (g_grx_solve_mode == 2 && nefc) phase = 1;
+#endif
   GRX_COUNT(c, 30, 1);     // profiling build: constrained solves (substeps) of the step
   GRX_COUNT(c, 31, nefc);  // ... and their constraint rows
   // the linear solve leaves c->A intact where it runs from registers (grx_sym_solve_full): the Hessian can then be corrected in place
@@ -3200,13 +3367,23 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
     if (phase == 0) {
       // After a step, M a and J a - aref are current (carried) and convergence has already been decided: the only thing the evaluation would
       // still produce are the row forces, which nothing reads after the solve unless the model has touch sensors.
+#ifdef GRX_DBG_NO_NOSLIP
+      const int noslip = 0;
+#else
       const int noslip = S::kNoslip && m->noslip_iterations > 0;
+#endif
       const int skip_eval = done && it > 0 && (S::kFixed ? S::NT : m->ntouch) == 0 && !noslip;
+#ifdef GRX_EXP_NO_CARRY
+      const int changed = skip_eval ? 0 : grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
+#else
       const int changed = skip_eval ? 0 : grx_newton_eval(m, c, c->qacc, nefc, it > 0, lane_);
+#endif
       GRX_TICK(c, GRX_P_NEVAL);
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
+#ifndef GRX_NO_FULLSTEP_EXIT
       if (it > 0 && full_step && !changed) done = 1;
+#endif
       if (done || it >= m->iterations) {   // MuJoCo's option iterations (default 100; the hand models: 20)
         if (noslip) grx_noslip(m, c, nefc, lane_);   // re-solves the friction forces without regularisation: new qacc, new M a
         // converged: at the minimiser the gradient M a - qfrc_smooth - J'f vanishes, so the joint-space constraint force
@@ -3214,67 +3391,58 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qfrc_constraint[i] = c->Ma[i] - c->qfrc_smooth[i]; c->qacc_ws[i] = c->qacc[i]; } }
         WAVE_SYNC();
         GRX_TICK(c, GRX_P_NFINAL);
+#if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)
+        if (g_grx_solve_mode == 1) break;
+        if (do_euler) GRX_STAGE_HOOK(7);
+#endif
         if (!do_euler) break;
         phase = 1;
         continue;
       }
       // Hessian of the current active set.  First iteration of a substep: assembled over all rows together with J'f of the current
-      // row forces (one pass).  Later iterations: rank-1 corrections for the rows that flipped (grx_hessian_update); g0 = sum k J
-      // is formed on first use from the J'f of the assembly, which was taken at the acceleration a_h: g0 = J'f + (H - M) a_h.
+      // row forces (one pass).  Later iterations: rank-1 corrections for the rows that flipped (grx_hessian_update), and the gradient is
+      // ADVANCED along the accepted step instead of being re-formed: g_new = g_old + alpha H_old v is exact while no row changes state
+      // (v = the step just taken, still in c->search; H_old = c->A, which the register solve leaves intact), the flipped rows add their
+      // force change.  Every term is of the size of the gradient itself -- no cancellation of D |aref| |J|-sized numbers.
       int incremental = 0;
       if (it > 0 && keepA) {
-        if (!g0_ready) {
-          const float* ah = c->qacc_ws;   // the last assembly was the one of iteration 0, at the warm start (qacc_ws is not written before convergence)
-          FOR_LANES {
-            for (int i = lane; i < nv; i += 64) {
-              float sacc = c->tmpv[i];
+        FOR_LANES {
+          for (int i = lane; i < nv; i += 64) {
+            float sacc = 0.0f;
 #pragma unroll 8
-              for (int j = 0; j < nv; j++) sacc += (c->A[i * nv + j] - c->M[i * nv + j]) * ah[j];
-              c->tmpv[i] = sacc;
-            }
+            for (int j = 0; j < nv; j++) sacc += c->A[i * nv + j] * c->search[j];
+            c->tmpv[i] = c->grad[i] + alpha_prev * sacc;
           }
-          WAVE_SYNC();
-          g0_ready = 1;
         }
+        WAVE_SYNC();
         incremental = grx_hessian_update(m, c, nefc, c->tmpv, lane_);
       }
       if (!incremental) grx_hessian(m, c, nefc, lane_);
       GRX_TICK(c, GRX_P_NHESS);
       GRX_LANEVAR(gnp);
       if (incremental) {
-        // gradient = H a - qfrc_smooth - g0
         FOR_LANES {
           float part = 0;
-          for (int i = lane; i < nv; i += 64) {
-            float sacc = -c->qfrc_smooth[i] - c->tmpv[i];
-#pragma unroll 8
-            for (int j = 0; j < nv; j++) sacc += c->A[i * nv + j] * c->qacc[j];
-            c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc;
-          }
+          for (int i = lane; i < nv; i += 64) { const float sacc = c->tmpv[i]; c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc; }
           LV(gnp) = part;
         }
       } else {
-        // gradient = M a - qfrc_smooth - J' f ; keep J'f (and, after a re-assembly at a later iterate, turn it into g0 right away)
+        // gradient = M a - qfrc_smooth - J' f
         FOR_LANES {
           float part = 0;
           for (int i = lane; i < nv; i += 64) {
-            const float jf = c->grad[i];
-            float sacc = c->Ma[i] - c->qfrc_smooth[i] - jf;
-            float g0i = jf;
-            if (it > 0 && keepA) {
-#pragma unroll 8
-              for (int j = 0; j < nv; j++) g0i += (c->A[i * nv + j] - c->M[i * nv + j]) * c->qacc[j];
-            }
-            c->tmpv[i] = g0i;
+            const float sacc = c->Ma[i] - c->qfrc_smooth[i] - c->grad[i];
             c->grad[i] = sacc; c->search[i] = -sacc; part += sacc * sacc;
           }
           LV(gnp) = part;
         }
-        g0_ready = (it > 0);
       }
       WAVE_SYNC();
       float gn = sqrtf(grx_reduce_sum(gnp));
       GRX_TICK(c, GRX_P_NGRAD);
+#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+      if (getenv("GRX_TRACE_NEWTON")) fprintf(stderr, "NEWTON it %d gn %.6e scale*gn %.3e incremental %d\n", it, (double)gn, (double)(scale * gn), incremental);
+#endif
       if (scale * gn < 1e-8f) { done = 1; continue; }
       rhs = c->search;
     } else if (phase == 1) {
@@ -3354,7 +3522,11 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         else if (!(na > lo)) na = 2.0f * alpha;
         alpha = na;
       }
+#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+      if (getenv("GRX_TRACE_NEWTON")) fprintf(stderr, "   dphi0 %.6e stop %d alpha %.6f full_step %d\n", (double)dphi0, stop, (double)alpha, full_step);
+#endif
       if (stop) { done = 1; continue; }  // not a descent direction any more: converged to rounding
+      alpha_prev = alpha;
       GRX_LANEVAR(msp); GRX_LANEVAR(map_);
       FOR_LANES {
         float ms = 0, ma = 0;
@@ -3367,6 +3539,9 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       }
       WAVE_SYNC();
       const float stepmax = grx_reduce_max(msp), qmax = grx_reduce_max(map_);
+#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+      if (getenv("GRX_TRACE_NEWTON")) { const int d_ = atoi(getenv("GRX_TRACE_NEWTON")); fprintf(stderr, "   stepmax %.6e qmax %.4e search[d] %.6e qacc[d] %.9e grad[d] %.6e\n", (double)stepmax, (double)qmax, (double)c->search[d_], (double)c->qacc[d_], (double)c->grad[d_]); }
+#endif
       LANE0 { c->cnt[6] += 1; }
       GRX_COUNT(c, 29, 1);   // profiling build: Newton iterations of the step
 #ifdef GRX_LS_STATS
@@ -3379,7 +3554,9 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       if (stepmax <= GRX_NEWTON_RTOL * qmax + GRX_NEWTON_ATOL) done = 1;
       // an exact full step (no row changes state on [0,1], decided with the very arithmetic the carried evaluation would repeat) lands on
       // the minimiser of the current piece and leaves every row in its state: converged
+#ifndef GRX_NO_FULLSTEP_EXIT
       if (full_step == 2) done = 1;
+#endif
     } else if (phase == 2) {
       FOR_LANES { for (int i = lane; i < nv; i += 64) { float q = c->qacc_smooth[i]; c->qacc[i] = q; c->qacc_ws[i] = q; c->qfrc_constraint[i] = 0; } }
       WAVE_SYNC();
@@ -3417,17 +3594,36 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
 // ------------------------------------------------------------------------------------------
 GRX_MEM void grx_forward_euler(const GrxModel* m, GrxCtx* c, int do_euler, int lane_) {
   GRX_TICK(c, GRX_P_OTHER);
+  GRX_RNDINJ(6, (grx_rnd(c->qpos, m->nq), grx_rnd(c->qvel, m->nv), grx_rnd(c->qacc_ws, m->nv)));
+  GRX_STAGE_HOOK(-1);
   grx_kinematics(m, c, lane_);
+  GRX_STAGE_HOOK(0);
+  GRX_RNDINJ(0, (grx_rnd(c->xpos, 3 * m->nbody), grx_rnd(c->xquat, 4 * m->nbody), grx_rnd(c->xmat, 9 * m->nbody), grx_rnd(c->sxpos, 3 * m->nsite), grx_rnd(c->sxmat, 9 * m->nsite), grx_rnd(c->janchor, 3 * m->njnt), grx_rnd(c->jaxis, 3 * m->njnt)));
   GRX_TICK(c, GRX_P_KIN);
   grx_inertia_cdof(m, c, lane_);
+  GRX_STAGE_HOOK(1);
+  GRX_RNDINJ(1, (grx_rnd(c->cinert, 10 * m->nbody), grx_rnd(c->cdof, 6 * m->nv), grx_rnd(c->M, m->nv * m->nv)));
   GRX_TICK(c, GRX_P_INERTIA);
   grx_collision(m, c, lane_);
+  GRX_STAGE_HOOK(2);
+  GRX_RNDINJ(2, (grx_rnd(c->con_dist, c->maxcon), grx_rnd(c->con_pos, 3 * c->maxcon), grx_rnd(c->con_frame, 3 * c->maxcon)));
   GRX_TICK(c, GRX_P_COLLIDE);
   grx_make_constraint(m, c, lane_);
+  GRX_STAGE_HOOK(3);
+  GRX_RNDINJ(3, (grx_rnd(c->Jp, c->jpool), grx_rnd(c->efc_D, c->maxefc), grx_rnd(c->efc_aref, c->maxefc)));
   GRX_TICK(c, GRX_P_CONSTR);
   grx_velocity(m, c, lane_);
-  GRX_TICK(c, GRX_P_VEL);
+  GRX_STAGE_HOOK(4);
+  GRX_RNDINJ(4, (grx_rnd(c->qfrc_smooth, m->nv), grx_rnd(c->qacc_smooth, m->nv), grx_rnd(c->efc_aref, c->maxefc)));
+#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+  grx_emu_trace(m, c, 0);   // test infrastructure (tools/emu_trace.py): contact list / rows of this pass
+#endif
   grx_solve_integrate(m, c, do_euler, lane_);
+  GRX_STAGE_HOOK(do_euler ? 5 : 6);
+  GRX_RNDINJ(5, (grx_rnd(c->qpos, m->nq), grx_rnd(c->qvel, m->nv), grx_rnd(c->qacc_ws, m->nv)));
+#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+  grx_emu_trace(m, c, 1);
+#endif
 }
 
 // qpos <- q0 (+) hh * v  (mj_integratePos semantics: quaternion exponential for free joints), one lane per joint
@@ -3589,3 +3785,35 @@ GRX_MEM void grx_check_state(const GrxModel* m, GrxCtx* c, int lane_) {
 }
 
 };  // struct GrxEngine
+
+#if defined(GRX_EMU)
+#if defined(GRX_EMU_TRACE)
+// test infrastructure (tools/emu_trace.py): one record per forward pass -- contact list before the solve (phase 0), qacc / qvel after it (phase 1)
+#include <stdio.h>
+static void grx_emu_trace(const GrxModel* m, const GrxCtx* c, int phase) {
+  static FILE* f = nullptr;
+  if (!f) { const char* p = getenv("GRX_TRACE_FILE"); f = fopen(p ? p : "/tmp/grx_trace.txt", "w"); }
+  if (phase == 0) {
+    const int ncon = c->cnt[0] < c->maxcon ? c->cnt[0] : c->maxcon;
+    fprintf(f, "PASS ncon %d nefc %d\n", ncon, c->cnt[1]);
+    for (int k = 0; k < ncon; k++)
+      fprintf(f, "CON pair %d g %d %d dist %.12g pos %.12g %.12g %.12g n %.12g %.12g %.12g efc %d\n", c->con_pair[k], m->pair_geom1[c->con_pair[k]], m->pair_geom2[c->con_pair[k]], (double)c->con_dist[k],
+              (double)c->con_pos[3 * k], (double)c->con_pos[3 * k + 1], (double)c->con_pos[3 * k + 2], (double)c->con_frame[3 * k], (double)c->con_frame[3 * k + 1], (double)c->con_frame[3 * k + 2], c->con_efc[k]);
+    fprintf(f, "SMOOTH"); for (int i = 0; i < m->nv; i++) fprintf(f, " %.12g", (double)c->qfrc_smooth[i]); fprintf(f, "\n");
+    fprintf(f, "AREF"); for (int i = 0; i < c->cnt[1]; i++) fprintf(f, " %.12g", (double)c->efc_aref[i]); fprintf(f, "\n");
+    fprintf(f, "EFCD"); for (int i = 0; i < c->cnt[1]; i++) fprintf(f, " %.12g", (double)c->efc_D[i]); fprintf(f, "\n");
+    for (int r = 0; r < c->cnt[1]; r++) { fprintf(f, "JROW %d kind %d", r, c->efc_kind[r]); for (int i = 0; i < m->nv; i++) { const int info = c->efc_row[r], pos = GrxEngine<GrxShapeAny>::grx_row_pos(info, c->efc_id[r], i); fprintf(f, " %.12g", pos >= 0 ? (double)c->Jp[GRX_ROW_OFF(info) + pos] : 0.0); } fprintf(f, "\n"); }
+    if (m->nfric) { fprintf(f, "FLOSS"); for (int i = 0; i < c->cnt[1]; i++) fprintf(f, " %.12g", (double)c->efc_floss[i]); fprintf(f, "\n"); }
+    fprintf(f, "MDIAG"); for (int i = 0; i < m->nv; i++) fprintf(f, " %.12g", (double)c->M[i * m->nv + i]); fprintf(f, "\n");
+    fprintf(f, "MFULL"); for (int i = 0; i < m->nv * m->nv; i++) fprintf(f, " %.12g", (double)c->M[i]); fprintf(f, "\n");
+  } else {
+    fprintf(f, "QVEL"); for (int i = 0; i < m->nv; i++) fprintf(f, " %.12g", (double)c->qvel[i]); fprintf(f, "\n");
+    fprintf(f, "QPOS"); for (int i = 0; i < m->nq; i++) fprintf(f, " %.12g", (double)c->qpos[i]); fprintf(f, "\n");
+    fprintf(f, "QACC"); for (int i = 0; i < m->nv; i++) fprintf(f, " %.12g", (double)c->qacc[i]); fprintf(f, "\n");
+    fprintf(f, "EFCF"); for (int i = 0; i < c->cnt[1]; i++) fprintf(f, " %.12g", (double)c->efc_force[i]); fprintf(f, "\n");
+    fprintf(f, "NEWT %d\n", c->cnt[6]);
+    fflush(f);
+  }
+}
+#endif
+#endif

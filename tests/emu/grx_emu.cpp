@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdint.h>
 
+typedef float grx_f32_t;   // the real fp32 (rounding-injection experiments of the fp64 build)
 #ifdef GRX_EMU_FP64  // diagnostic build: the same kernel source in double precision (isolates fp32 rounding from logic)
 #define float double
 #define sqrtf sqrt
@@ -47,6 +48,9 @@ void* emu_create(const int32_t* H, const int32_t* I, const double* F) {
   e->m = grx_bind_model(e->pm, e->pm.f.data(), e->pm.i.data());
   int words = grx_ctx_words(grx_dims_of(&e->m));
   e->lds.assign((size_t)words + 64, 0.0f);
+#ifdef GRX_EMU_STAGEHOOK
+  g_grx_emu_nfields = 0;
+#endif
   grx_ctx_carve(&e->c, e->lds.data(), grx_dims_of(&e->m));
   return e;
 }
@@ -161,6 +165,42 @@ void emu_kitchen_step(void* h, const GrxKitchenTask* t, float* qpos, float* qvel
 }
 
 long emu_mesh_stat(int k) { return g_grx_mesh_stats[k]; }
+
+#ifdef GRX_EMU_STAGEHOOK
+// mixed-precision bisection harness (tools/emu_mixed.py): two builds of this file (fp32 / fp64) run the same forward pass stage by stage
+void emu_set_stage_hook(void (*hook)(int)) { g_grx_stage_hook = hook; }
+int emu_nfields() { return g_grx_emu_nfields; }
+const char* emu_field_name(int k) { return g_grx_emu_fields[k].name; }
+int emu_field_len(int k) { return g_grx_emu_fields[k].n; }
+// flat double image of the chosen fields (ints exactly), in carve order; sel[k] != 0 selects field k
+void emu_export(const unsigned char* sel, double* buf) {
+  for (int k = 0; k < g_grx_emu_nfields; k++) {
+    const GrxEmuField& f = g_grx_emu_fields[k];
+    if (sel[k]) for (int i = 0; i < f.n; i++) buf[i] = f.isint ? (double)((int*)f.ptr)[i] : (double)((float*)f.ptr)[i];
+    buf += f.n;
+  }
+}
+void emu_import(const unsigned char* sel, const double* buf) {
+  for (int k = 0; k < g_grx_emu_nfields; k++) {
+    const GrxEmuField& f = g_grx_emu_fields[k];
+    if (sel[k]) for (int i = 0; i < f.n; i++) { if (f.isint) ((int*)f.ptr)[i] = (int)buf[i]; else ((float*)f.ptr)[i] = (float)buf[i]; }
+    buf += f.n;
+  }
+}
+void emu_run_stage(void* h, int k) {
+  Emu* e = (Emu*)h; typedef GrxEngine<GrxShapeAny> E;
+  void (*keep)(int) = g_grx_stage_hook; g_grx_stage_hook = nullptr;
+  if (k == 0) E::grx_kinematics(&e->m, &e->c, 0);
+  else if (k == 1) E::grx_inertia_cdof(&e->m, &e->c, 0);
+  else if (k == 2) E::grx_collision(&e->m, &e->c, 0);
+  else if (k == 3) E::grx_make_constraint(&e->m, &e->c, 0);
+  else if (k == 4) E::grx_velocity(&e->m, &e->c, 0);
+  else if (k == 5 || k == 6) E::grx_solve_integrate(&e->m, &e->c, k == 5, 0);
+  else if (k == 7) { g_grx_solve_mode = 1; E::grx_solve_integrate(&e->m, &e->c, 1, 0); g_grx_solve_mode = 0; }   // Newton only
+  else if (k == 8) { g_grx_solve_mode = 2; E::grx_solve_integrate(&e->m, &e->c, 1, 0); g_grx_solve_mode = 0; }   // the Euler stage only
+  g_grx_stage_hook = keep;
+}
+#endif
 
 // debug access to the working set of the last call
 float* emu_ctx_ptr(void* h, const char* name) {

@@ -26,7 +26,7 @@ FAMILY_TO_TASK = {"FetchReach": "FetchReach", "FetchPush": "FetchPush", "FetchPi
 def build(fp64):
     so = f"/tmp/libgrx_emu{'64' if fp64 else '32'}_tol.so"
     src = os.path.join(ROOT, "tests", "emu", "grx_emu.cpp")
-    flags = ["-DGRX_EMU_FP64", "-DGRX_MPR_EPS=2.220446049250313e-16"] if fp64 else []
+    flags = ["-DGRX_EMU_FP64", "-DGRX_MPR_EPS=2.220446049250313e-16", "-DGRX_EMU_RNDINJ"] if fp64 else []
     flags += [a for a in sys.argv if a.startswith("-D")]      # experiments: extra defines for the emulator build
     subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-misleading-indentation"] + flags + ["-o", so, src])
     return so
@@ -36,7 +36,7 @@ def _float_struct(t64, task_like):
     return task_like
 
 
-def run_family(L, family, fp64, every=1):
+def run_family(L, family, fp64, every=1, only=None, round_inputs=False, ref=None, jitter=0):
     """per-snapshot |obs - golden| rows [n, obs_dim] of the emulated step"""
     from tolerance_cases import CASES
     task = FAMILY_TO_TASK[family]
@@ -59,8 +59,13 @@ def run_family(L, family, fp64, every=1):
     H, I, F = m.pack()
     h = L.emu_create(H.ctypes.data, I.ctypes.data, F.ctypes.data)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    f = lambda a: np.ascontiguousarray(a, dtype=dt).copy()
-    idx = list(range(0, g["obs"].shape[0], every))
+    jr = np.random.default_rng(1000 + jitter)
+    def f(a):
+        a = np.asarray(a, dtype=np.float32).astype(np.float64) if round_inputs else np.asarray(a, dtype=np.float64)
+        if jitter:   # one fp32 ulp of relative noise on every state word: what any engine that holds its state in fp32 sees after one substep
+            a = a * (1.0 + jr.uniform(-1, 1, a.shape) * 6e-8)
+        return np.ascontiguousarray(a, dtype=dt).copy()
+    idx = list(range(0, g["obs"].shape[0], every)) if only is None else [only]
     out = np.zeros((len(idx), g["obs"].shape[1]))
     status = np.zeros(len(idx), np.int64)
     for j, i in enumerate(idx):
@@ -79,7 +84,7 @@ def run_family(L, family, fp64, every=1):
         else:
             obs, ach, palm = np.zeros(256, dt), np.zeros(15, dt), np.zeros(3, dt)
             L.emu_hand_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(a), p(obs), p(ach), p(palm), ctypes.byref(st), ctypes.c_int(0))
-        out[j] = np.abs(obs[:g["obs"].shape[1]].astype(np.float64) - g["obs"][i])
+        out[j] = obs[:g["obs"].shape[1]].astype(np.float64) if isinstance(ref, str) else np.abs(obs[:g["obs"].shape[1]].astype(np.float64) - (g["obs"][i] if ref is None else ref[j]))
         status[j] = st.value
     return np.array(idx), out, status, CASES[family][3]
 
@@ -91,8 +96,29 @@ def main(argv):
     L = ctypes.CDLL(build(fp64))
     L.emu_create.restype = ctypes.c_void_p
     L.emu_create.argtypes = [ctypes.c_void_p] * 3
+    rounded = "--rounded" in argv      # reference = the fp64 build of the same source stepped from the SAME fp32-rounded states (isolates arithmetic from input rounding)
+    if rounded:
+        keep = sys.argv[:]
+        sys.argv = [a for a in sys.argv if not a.startswith("-D")]
+        L64 = ctypes.CDLL(build(True))
+        sys.argv = keep
+        L64.emu_create.restype = ctypes.c_void_p
+        L64.emu_create.argtypes = [ctypes.c_void_p] * 3
+    if "--sensitivity" in argv:      # the fp64 build against ITSELF from states jittered by one fp32 ulp: how well-posed each snapshot is for any fp32-state engine
+        L64 = ctypes.CDLL(build(True)); L64.emu_create.restype = ctypes.c_void_p; L64.emu_create.argtypes = [ctypes.c_void_p] * 3
+        for fam in fams:
+            ref = run_family(L64, fam, True, every, round_inputs=True, ref="raw")[1]
+            worst = None
+            for trial in (1, 2, 3):
+                idx, e, status, comps = run_family(L64, fam, True, every, round_inputs=True, ref=ref, jitter=trial)
+                worst = e if worst is None else np.maximum(worst, e)
+            for comp, cols in comps.items():
+                err = worst[:, cols].max(axis=1)
+                print(f"{fam:18s} {comp:26s} SENSITIVITY n={len(err):4d} p50 {np.median(err):.1e} p99 {np.quantile(err, .99):.1e} max {err.max():.1e} over 1e-4: {int((err >= 1e-4).sum())} {list(idx[err >= 1e-4])[:40]}", flush=True)
+        return
     for fam in fams:
-        idx, e, status, comps = run_family(L, fam, fp64, every)
+        ref = run_family(L64, fam, True, every, round_inputs=True, ref="raw")[1] if rounded else None
+        idx, e, status, comps = run_family(L, fam, fp64, every, round_inputs=rounded, ref=ref)
         for comp, cols in comps.items():
             err = e[:, cols].max(axis=1)
             worst = idx[np.argsort(-err)[:6]]
