@@ -30,7 +30,7 @@ class FetchResetArgsStruct(ctypes.Structure):
 
 class PointTaskStruct(ctypes.Structure):
     _fields_ = [("n_substeps", ctypes.c_int), ("sparse_reward", ctypes.c_int), ("continuing_task", ctypes.c_int), ("agent", ctypes.c_int),
-                ("goal_radius", ctypes.c_float), ("vel_clip", ctypes.c_float)]
+                ("goal_radius", ctypes.c_double), ("vel_clip", ctypes.c_float)]
 
 
 class PointBuffersStruct(ctypes.Structure):
@@ -66,13 +66,13 @@ class KitchenBookStruct(ctypes.Structure):      # include/grx_capi.h, grx_kitche
 
 class HerArgsStruct(ctypes.Structure):
     _fields_ = [("rows", ctypes.c_void_p), ("acts", ctypes.c_void_p)] + [(n, ctypes.c_int) for n in ("T", "N", "W", "obs_dim", "goal_dim", "act_dim")] + [
-        (n, ctypes.c_void_p) for n in ("t_idx", "w_idx", "t_goal")] + [("kind", ctypes.c_int), ("p0", ctypes.c_float), ("p1", ctypes.c_float)] + [
+        (n, ctypes.c_void_p) for n in ("t_idx", "w_idx", "t_goal")] + [("kind", ctypes.c_int), ("p0", ctypes.c_double), ("p1", ctypes.c_double)] + [
         (n, ctypes.c_int) for n in ("sparse", "ignore_pos", "ignore_rot", "ignore_z")] + [("out", ctypes.c_void_p), ("term_rows", ctypes.c_void_p), ("term_t", ctypes.c_void_p)]
 
 
 class MazeResetArgsStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("idx", "stage", "qpos0")] + [(n, ctypes.c_int) for n in ("nq", "nv", "obs_dim", "obs_skip")] + [
-        ("goal_radius", ctypes.c_float), ("keep_outcome", ctypes.c_int)] + [
+        ("goal_radius", ctypes.c_double), ("keep_outcome", ctypes.c_int)] + [
         (n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "goal", "obs", "achieved", "reward", "success", "packed")]
 
 
@@ -107,7 +107,7 @@ def lib():
         L.grx_fetch_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_fetch_forward.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_fetch_reset.argtypes = [vp, vp, vp, vp, ci, vp]
-        L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
+        L.grx_fetch_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_double, ci, vp, vp]
         L.grx_her_relabel.argtypes = [vp, ctypes.c_int64, vp]
         L.grx_her_sample.argtypes = [vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, vp, vp, vp, vp]
         L.grx_her_sample_final.argtypes = [vp, vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, vp, vp, vp, vp]
@@ -117,10 +117,10 @@ def lib():
         L.grx_uniform_rows_device.argtypes = [vp, vp, ci, ci, vp, vp]
         L.grx_kitchen_bookkeeping.argtypes = [vp, ci, vp]
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
-        L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_float, ci, vp, vp]
+        L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_double, ci, vp, vp]
         L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_adroit_step.argtypes = [vp, vp, vp, ci, ci, vp]
-        L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_float, ci, vp, vp]
+        L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_double, ci, vp, vp]
         L.grx_manip_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]
         L.grx_order_by_cost.argtypes = [vp, vp, ctypes.c_float, ci, vp, vp]
         L.grx_order_by_cost_slots.argtypes = [vp, vp, ctypes.c_float, ci, ci, vp, vp]

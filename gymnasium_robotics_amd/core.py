@@ -139,9 +139,9 @@ def np_random(seed=None):
 
 
 # ---------------------------------------------------------------------------------------------- the overflow lane (include/grx_capi.h, grx_overflow_lane)
-# Tables of the LARGE model of every family: 256 rows / 4 080 Jacobian-pool words (the 12-bit row offsets' limit) / the engine's 32 contacts; ~30-40 KB of LDS per
+# Tables of the LARGE model of every family: 256 rows / 4 080 Jacobian-pool words (the 12-bit row offsets' limit) / 64 contacts (one lane each: twice the fast kernels' lists); ~32-42 KB of LDS per
 # world on the generic kernel.  The reference never truncates a contact list (mujoco.mj_step, envs/robot_env.py:341).
-RERUN_CAPACITY = {"maxefc": 256, "jpool": 4080, "maxcon": 0}
+RERUN_CAPACITY = {"maxefc": 256, "jpool": 4080, "maxcon": 64}
 LANE_TTL = 8       # steps a world stays in the lane after the last step in which it came within LANE_MARGIN of a capacity of the fast kernel
 LANE_MARGIN = 0.8
 LANE_POLL_GRID = 16    # entrants per step that can be re-run while the fast launch is still running (more: the serialised launch behind it takes the rest)

@@ -61,7 +61,8 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_MINVAL 1e-15f
 #define GRX_MINIMP 0.0001f
 #define GRX_MAXIMP 0.9999f
-#define GRX_MAXCON 32    // default (and largest) contact-list capacity per world; a model may request fewer (<= 32: one lane per contact)
+#define GRX_MAXCON 64    // largest contact-list capacity per world: one lane per contact in the per-contact passes (the large tables of the overflow lane)
+#define GRX_MAXCON_DEFAULT 32   // capacity of a model that does not request one (the fast kernels: 16 - 32)
 #define GRX_MAXEFC 144   // default constraint rows per world (models with wide contact rows get more: grx_pack_model)
 #define GRX_JPOOL 2032    // default words of packed Jacobian storage per world (rows are stored over their dof span only); < 4096 (12-bit row offsets)
 #ifndef GRX_NEWTON_RTOL
@@ -154,7 +155,7 @@ static __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];   // one copy per tra
 // body frames, motion axes, M, J, row parameters) is persistent.
 struct GrxDims { int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nfric, integrator, maxefc, jpool, ntouch, maxcon, nmesh, nshift, noslip; };
 GRX_HD int grx_ctx_words(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int nsite, int nmocap, int nfric, int integrator, int maxefc = GRX_MAXEFC,
-                          int jpool = GRX_JPOOL, int ntouch = 0, int maxcon = GRX_MAXCON, int nmesh = 0, int nshift = 0, int noslip = 0) {
+                          int jpool = GRX_JPOOL, int ntouch = 0, int maxcon = GRX_MAXCON_DEFAULT, int nmesh = 0, int nshift = 0, int noslip = 0) {
   int pers = nq + nv + nv + 3 * nmocap + 4 * nmocap + nu;           // state
   pers += (3 + 4 + 9) * nbody + 12 * nsite + 6 * nv;                // xpos xquat xmat, sites, cdof
   pers += nv * nv + 4 * nv;                                          // M, qfrc_smooth qacc_smooth qfrc_constraint qacc
@@ -461,7 +462,7 @@ GRX_DEV float grx_wave_max(const float* red, int lane_) {
 // dofs unroll and their LDS loads batch) or a runtime value (NV == 0: generic fallback, also used by the emulator).
 // Model shape: the ten layout dims as compile-time constants (0 = read from the model at run time).
 template <int NQ_, int NV_, int NU_, int NBODY_, int NJNT_, int NGEOM_, int NSITE_, int NMOCAP_, int NFRIC_ = 0, int INTEG_ = 0, int MAXEFC_ = GRX_MAXEFC, int JPOOL_ = GRX_JPOOL,
-          int NTOUCH_ = 0, int MAXCON_ = GRX_MAXCON, int TWOSPAN_ = 0, int CONVEX_ = 0>
+          int NTOUCH_ = 0, int MAXCON_ = GRX_MAXCON_DEFAULT, int TWOSPAN_ = 0, int CONVEX_ = 0>
 struct GrxShape {
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NBODY_, NJ = NJNT_, NG = NGEOM_, NS = NSITE_, NM = NMOCAP_, NF = NFRIC_, INTEG = INTEG_, ME = MAXEFC_, JP = JPOOL_, NT = NTOUCH_, MC = MAXCON_;
   // rows may carry a second dof span (models compiled with split pair spans); fixed shapes without it skip that bookkeeping
@@ -1382,7 +1383,7 @@ GRX_MEM void grx_mpr_expand(const GrxMprPt& P0, GrxMprPt& P1, GrxMprPt& P2, GrxM
 }
 GRX_MEM MF grx_mpr_seg_dist2(const MF* a, const MF* b, MF* w) {
   MF d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, t = -dot3f(a, d), dd = dot3f(d, d);
-  t = dd > 0.0f ? grx_fmin(1.0f, grx_fmax(0.0f, t / dd)) : 0.0f;
+  t = dd > 0.0f ? grx_fmin((MF)1.0f, grx_fmax((MF)0.0f, t / dd)) : (MF)0.0f;
   for (int k = 0; k < 3; k++) w[k] = a[k] + t * d[k];
   return dot3f(w, w);
 }
@@ -1413,8 +1414,13 @@ GRX_MEM MF grx_mpr_tri_dist2(const MF* x0, const MF* b, const MF* cc, MF* w) {
 // 0 = penetration (depth, dir, pos, surface witnesses w1 on geom 1 / w2 on geom 2 -- all relative to the centre of geom 1), -1 = separated
 // sep (may be null): on a -1 return caused by a support point on the far side of the origin (v . d <= 0), sep[0..2] <- that direction d
 // and sep[3] <- 1: d separates the two (inflated) geoms, which any later call can re-check with ONE support evaluation (grx_mesh_pairs)
+#ifdef GRX_MPR_CALL   // the portal search behind a real call: its (fp64) register appetite stays out of the substep loop's allocation
+#define GRX_MPR_FN GRX_MEM_CALL
+#else
+#define GRX_MPR_FN GRX_MEM
+#endif
 template <bool W>
-GRX_MEM int grx_mpr_penetration(const GrxMprPair* q, MF tol, int maxit, MF* depth, MF* dir, MF* pos, MF* w1, MF* w2, MF* sep = nullptr) {
+GRX_MPR_FN int grx_mpr_penetration(const GrxMprPair* q, MF tol, int maxit, MF* depth, MF* dir, MF* pos, MF* w1, MF* w2, MF* sep = nullptr) {
 #define GRX_MPR_SEP(D) do { if (W && sep) { sep[0] = (D)[0]; sep[1] = (D)[1]; sep[2] = (D)[2]; sep[3] = 1.0f; } } while (0)
   // lane-per-pair variant: the portal lives in registers; wave-cooperative variant: in LDS (every lane writes the same values)
   GrxMprPt r0_, r1_, r2_, r3_, r4_;

@@ -17,7 +17,8 @@ struct GrxFetchTask {
   int site_grip, site_obj;       // site ids
   int jq_rf, jq_lf, jd_rf, jd_lf;  // qpos / dof addresses of the r / l finger joints
   int obs_dim, goal_dim;
-  float distance_threshold, dt;
+  float dt;
+  double distance_threshold;   // fp64: the success test / sparse reward compare the fp64 distance with the reference's fp64 threshold (fetch_env.py:74-80,168-170)
 };
 
 // per-world HBM buffers (world-major rows; one contiguous vector per world per field)
@@ -38,13 +39,15 @@ struct GrxFetchBuffers {
   GrxLane lane;                          // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 
-// distance with a fixed operation order so that the fused step kernel and the standalone
-// HER reward kernel give bit-identical rewards (invariant stated at core.py:59-62)
-GRX_DEV float grx_goal_distance3(const float* a, const float* b) {
-  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
-  return sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+// Goal distance in fp64 (goal_distance, fetch_env.py:16-18: np.linalg.norm of the fp64 difference).  The flags and the sparse reward are then EXACTLY the
+// reference's functions of the returned (fp32) achieved / desired goals -- d < 0.05 decided in the reference's own arithmetic, no rounding band around the
+// threshold -- and the fused step kernel, the standalone reward kernel and the HER relabel share this one routine (reward == compute_reward(achieved, desired)
+// bit for bit, core.py:59-62).  Three subtractions, three products (exact: 24-bit inputs) and one square root per world.
+GRX_DEV double grx_goal_distance3(const float* a, const float* b) {
+  const double dx = (double)a[0] - (double)b[0], dy = (double)a[1] - (double)b[1], dz = (double)a[2] - (double)b[2];
+  return sqrt(dx * dx + dy * dy + dz * dz);
 }
-GRX_DEV float grx_fetch_reward(float d, float thresh, int sparse) { return sparse ? -((d > thresh) ? 1.0f : 0.0f) : -d; }
+GRX_DEV float grx_fetch_reward(double d, double thresh, int sparse) { return sparse ? -((d > thresh) ? 1.0f : 0.0f) : (float)(-d); }
 
 GRX_DEV void grx_mat2euler(const float* R, float* e) {
   const float eps4 = 4.0f * 1.1920929e-07f;  // the reference uses 4*eps of float64; only the gimbal branch differs

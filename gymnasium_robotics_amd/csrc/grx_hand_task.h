@@ -19,7 +19,7 @@ struct GrxHandTask {
   int n_substeps, sparse_reward;
   int site[GRX_HAND_NTIPS];  // fingertip sites, reach.py:8-14 order
   int palm_body;             // body whose position _sample_goal offsets from (reach.py:413-416)
-  float distance_threshold;
+  double distance_threshold; // fp64, see grx_goal_distance3 (csrc/grx_fetch_task.h)
   int kind, nq_robot, obj_qadr, obj_dadr;
   int ignore_position, ignore_rotation;   // target_position == "ignore" / target_rotation == "ignore" (manipulate.py:92-97)
   float rotation_threshold;
@@ -49,12 +49,12 @@ struct GrxHandBuffers {
 
 // Euclidean distance with a fixed accumulation order, shared by the step kernel and the recompute kernel so that
 // reward == compute_reward(achieved, desired) bit for bit (core.py:59-62)
-GRX_DEV float grx_goal_distance_n(const float* a, const float* b, int n) {
-  float s = 0.0f;
-  for (int k = 0; k < n; k++) { float d = a[k] - b[k]; s = fmaf(d, d, s); }
-  return sqrtf(s);
+GRX_DEV double grx_goal_distance_n(const float* a, const float* b, int n) {
+  double s = 0.0;
+  for (int k = 0; k < n; k++) { const double d = (double)a[k] - (double)b[k]; s += d * d; }
+  return sqrt(s);
 }
-GRX_DEV float grx_hand_reward(float d, float thr, int sparse) { return sparse ? ((d > thr) ? -1.0f : -0.0f) : -d; }
+GRX_DEV float grx_hand_reward(double d, double thr, int sparse) { return sparse ? ((d > thr) ? -1.0f : -0.0f) : (float)(-d); }
 
 // manipulate.py:87-142.  The reference takes the angle as 2 acos(clip(w)) of quat_a * conj(quat_b), whose scalar part is the
 // 4-vector dot product; 2 atan2(|vector part|, w) is the same angle for unit quaternions and keeps fp32 accuracy near 0.

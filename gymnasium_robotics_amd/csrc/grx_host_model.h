@@ -74,7 +74,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.maxefc = d[GRX_MAXEFC_REQ] > 0 ? ((d[GRX_MAXEFC_REQ] + 15) / 16) * 16 : GRX_MAXEFC;
   m.jpool = d[GRX_JPOOL_REQ] > 0 ? ((d[GRX_JPOOL_REQ] + 15) / 16) * 16 : GRX_JPOOL;
   if (m.jpool > 4080) m.jpool = 4080;
-  m.maxcon = (d[GRX_MAXCON_REQ] > 0 && d[GRX_MAXCON_REQ] < GRX_MAXCON) ? d[GRX_MAXCON_REQ] : GRX_MAXCON;
+  m.maxcon = (d[GRX_MAXCON_REQ] > 0 && d[GRX_MAXCON_REQ] <= GRX_MAXCON) ? d[GRX_MAXCON_REQ] : GRX_MAXCON_DEFAULT;
   {
     static const int hand_parent[24] = GRX_HAND_DOF_PARENTS;
     m.handtree = (v.n_dof_parentid >= 24) ? 1 : 0;

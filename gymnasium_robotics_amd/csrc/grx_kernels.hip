@@ -129,7 +129,7 @@ __device__ __forceinline__ void grx_store_world(const GrxModel& m, const GrxFetc
   }
   if (lane_ == 0) {
     const float* ag = b.achieved + (size_t)w * 3;
-    float d = grx_goal_distance3(ag, b.goal + (size_t)w * 3);
+    const double d = grx_goal_distance3(ag, b.goal + (size_t)w * 3);
     if (!keep_outcome) {
       b.reward[w] = grx_fetch_reward(d, t.distance_threshold, t.sparse_reward);
       b.success[w] = (d < t.distance_threshold) ? 1 : 0;
@@ -198,7 +198,7 @@ typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
 // the SAME models with the tables of the overflow lane (core.RERUN_CAPACITY): only the lane kernels are instantiated for them (BASELINE configs 2 / 3 / 5a; the other
 // models' lanes run on the generic kernel, 2-3 x slower per world)
-typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 256, 4080, 0, 32, 0, 2> GrxShapeFetchPickLane;
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 256, 4080, 0, 64, 0, 2> GrxShapeFetchPickLane;
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
@@ -209,7 +209,7 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 2> Gr
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 3> GrxShapeHandEgg;     // manipulate_egg.xml: the ellipsoid goes through the convex narrow phase
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 3> GrxShapeHandEggTouch;
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 928, 92, 24, 1, 2> GrxShapeHandBlockTouch;  // + the 92 touch zones of robot_touch_sensors_92.xml
-typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 256, 4080, 92, 32, 1, 2> GrxShapeHandBlockTouchLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
+typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 256, 4080, 92, 64, 1, 2> GrxShapeHandBlockTouchLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
 
 // waves per SIMD the Fetch kernels are compiled for (VGPR budget 168 at 3, 256 at 2): the convex narrow phase needs the full budget
 #ifndef GRX_FETCH_WAVES
@@ -394,7 +394,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
   for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)wl * m.nq + i] = c.qpos[i];
   for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)wl * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)wl * m.nv + i] = c.qacc_ws[i]; }
   if (lane_ == 0) {
-    float d = grx_goal_distance2(ach, b.goal + (size_t)wl * 2);
+    const double d = grx_goal_distance2(ach, b.goal + (size_t)wl * 2);
     int succ = d <= t.goal_radius;
     b.reward[wl] = grx_maze_reward(d, t.goal_radius, t.sparse_reward);
     b.success[wl] = succ; b.terminated[wl] = (!t.continuing_task && succ) ? 1 : 0;
@@ -405,7 +405,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
     float* row = b.packed + (size_t)wl * (od + 6);
     for (int i = lane_; i < od; i += 64) row[i] = obs[i];
     if (lane_ == 0) {
-      const float d = grx_goal_distance2(ach, b.goal + (size_t)wl * 2);
+      const double d = grx_goal_distance2(ach, b.goal + (size_t)wl * 2);
       row[od] = ach[0]; row[od + 1] = ach[1]; row[od + 2] = b.goal[(size_t)wl * 2]; row[od + 3] = b.goal[(size_t)wl * 2 + 1];
       row[od + 4] = grx_maze_reward(d, t.goal_radius, t.sparse_reward); row[od + 5] = (d <= t.goal_radius) ? 1.0f : 0.0f;
     }
@@ -462,10 +462,10 @@ __device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask
     if (t.kind) {
       float dp, dr;
       grx_manip_distance(ach, b.goal + (size_t)w * gd, t.ignore_position, t.ignore_rotation, t.ignore_z, &dp, &dr);
-      b.reward[w] = grx_manip_reward(dp, dr, t.distance_threshold, t.rotation_threshold, t.sparse_reward);
-      b.success[w] = grx_manip_success(dp, dr, t.distance_threshold, t.rotation_threshold);
+      b.reward[w] = grx_manip_reward(dp, dr, (float)t.distance_threshold, t.rotation_threshold, t.sparse_reward);
+      b.success[w] = grx_manip_success(dp, dr, (float)t.distance_threshold, t.rotation_threshold);
     } else {
-      const float d = grx_goal_distance_n(ach, b.goal + (size_t)w * gd, gd);
+      const double d = grx_goal_distance_n(ach, b.goal + (size_t)w * gd, gd);
       b.reward[w] = grx_hand_reward(d, t.distance_threshold, t.sparse_reward);
       b.success[w] = (d < t.distance_threshold) ? 1 : 0;
     }
@@ -513,8 +513,8 @@ typedef GrxShape<30, 30, 24, 27, 30, 26, 5, 1, 30, 0, 144, 2032, 0, 32, 1, 29> G
 typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, 144, 2032, 0, 32, 1, 12> GrxShapeAdroitRelocate;
 // the door and relocate models with the tables of the overflow lane (core.RERUN_CAPACITY): on the GENERIC large-table kernel one serialised re-run of a contact-rich door world
 // took 5 - 9 ms of a 12 ms step (profiles/lane_probe_r03_door.txt); hammer and pen do not overflow in 100 000 world-steps and keep the generic lane kernel
-typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, 256, 4080, 0, 32, 1, 13> GrxShapeAdroitDoorLane;
-typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, 256, 4080, 0, 32, 1, 12> GrxShapeAdroitRelocateLane;
+typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, 256, 4080, 0, 64, 1, 13> GrxShapeAdroitDoorLane;
+typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, 256, 4080, 0, 64, 1, 12> GrxShapeAdroitRelocateLane;
 template <class S>
 __device__ __forceinline__ void grx_adroit_step_world(int mslot, const GrxAdroitTask& t, const GrxAdroitBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
   if (w >= n_worlds) return;
@@ -575,7 +575,7 @@ grx_adroit_lane_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
 // FrankaKitchen-v1 env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world; 40 substeps; nv = 29 (9 robot dofs, 5 joint
 // equalities knob <-> burner / switch <-> light, the free kettle), 124 colliding geoms / 3 736 candidate pairs, condim-6 finger pads, hull pairs
 typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 192, 2240, 0, 32, 1, 3> GrxShapeKitchen;
-typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 256, 4080, 0, 32, 1, 3> GrxShapeKitchenLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
+typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 256, 4080, 0, 64, 1, 3> GrxShapeKitchenLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
 template <class S>
 __device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitchenTask& t, const GrxKitchenBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
   if (w >= n_worlds) return;
@@ -806,7 +806,7 @@ extern "C" int grx_tu_hand_launch(int shape, unsigned grid, size_t lds_bytes, vo
                                   int forward_only);
 
 extern "C" __global__ void __launch_bounds__(256)
-grx_goal_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int dim, float thr, int sparse, float* __restrict__ out) {
+grx_goal_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int dim, double thr, int sparse, float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x)
     out[i] = grx_hand_reward(grx_goal_distance_n(ag + i * dim, dg + i * dim, dim), thr, sparse);
 }
@@ -822,7 +822,7 @@ grx_manip_reward_kernel(const float* __restrict__ ag, const float* __restrict__ 
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-grx_maze_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, float radius, int sparse, float* __restrict__ out) {
+grx_maze_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, double radius, int sparse, float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
     float a[2] = {ag[2 * i], ag[2 * i + 1]}, g[2] = {dg[2 * i], dg[2 * i + 1]};
     out[i] = grx_maze_reward(grx_goal_distance2(a, g), radius, sparse);
@@ -831,7 +831,7 @@ grx_maze_reward_kernel(const float* __restrict__ ag, const float* __restrict__ d
 
 // HER relabel: reward for B (achieved, desired) pairs; 16 B/lane loads where the layout allows
 extern "C" __global__ void __launch_bounds__(256)
-grx_fetch_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, float thresh, int sparse, float* __restrict__ out) {
+grx_fetch_reward_kernel(const float* __restrict__ ag, const float* __restrict__ dg, long long B, double thresh, int sparse, float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
     float a[3] = {ag[3 * i], ag[3 * i + 1], ag[3 * i + 2]}, g[3] = {dg[3 * i], dg[3 * i + 1], dg[3 * i + 2]};
     out[i] = grx_fetch_reward(grx_goal_distance3(a, g), thresh, sparse);
@@ -851,7 +851,7 @@ struct GrxHerArgs {
   int T, N, W, obs_dim, goal_dim, act_dim;
   const int *t_idx, *w_idx, *t_goal;
   int kind;            // 0: Euclidean goals with a distance threshold (Fetch: -(d > thr) / -d), 1: same with the hand's -0.0 convention (HandReach), 2: maze, 3: manipulate pose goals
-  float p0, p1;        // kind 0 / 1: threshold; 2: goal radius; 3: position threshold, rotation threshold
+  double p0, p1;       // kind 0 / 1: threshold; 2: goal radius; 3: position threshold, rotation threshold (fp64: the reference's own compare, see grx_goal_distance3)
   int sparse, ignore_pos, ignore_rot, ignore_z;
   float* out;
   const float* term_rows; const int* term_t;   // terminal rows of the episodes that ended under same-step autoreset (include/grx_capi.h)
@@ -861,15 +861,15 @@ GRX_DEV void grx_her_outcome(const GrxHerArgs& a, const float* ag, const float* 
   if (a.kind == 3) {
     float dp, dr;
     grx_manip_distance(ag, g, a.ignore_pos, a.ignore_rot, a.ignore_z, &dp, &dr);
-    *reward = grx_manip_reward(dp, dr, a.p0, a.p1, a.sparse); *success = grx_manip_success(dp, dr, a.p0, a.p1) ? 1.0f : 0.0f;
+    *reward = grx_manip_reward(dp, dr, (float)a.p0, (float)a.p1, a.sparse); *success = grx_manip_success(dp, dr, (float)a.p0, (float)a.p1) ? 1.0f : 0.0f;
   } else if (a.kind == 2) {
-    const float d = grx_goal_distance2(ag, g);
+    const double d = grx_goal_distance2(ag, g);
     *reward = grx_maze_reward(d, a.p0, a.sparse); *success = (d <= a.p0) ? 1.0f : 0.0f;
   } else if (a.kind == 1) {
-    const float d = grx_goal_distance_n(ag, g, a.goal_dim);
+    const double d = grx_goal_distance_n(ag, g, a.goal_dim);
     *reward = grx_hand_reward(d, a.p0, a.sparse); *success = (d < a.p0) ? 1.0f : 0.0f;
   } else {
-    const float d = grx_goal_distance3(ag, g);
+    const double d = grx_goal_distance3(ag, g);
     *reward = grx_fetch_reward(d, a.p0, a.sparse); *success = (d < a.p0) ? 1.0f : 0.0f;
   }
 }
@@ -1261,7 +1261,7 @@ extern "C" int grx_order_by_cost_slots(const int* cost, float* ema, float alpha,
   return 0;
 }
 
-extern "C" int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
+extern "C" int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, double distance_threshold, int sparse,
                                        float* reward_out, void* stream) {
   if (!achieved || !desired || !reward_out || dim <= 0) return fail("grx_goal_compute_reward: bad argument");
   if (batch <= 0) return 0;
@@ -1285,7 +1285,7 @@ extern "C" int grx_manip_compute_reward(const float* achieved, const float* desi
   return 0;
 }
 
-extern "C" int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t batch, float goal_radius, int sparse, float* reward_out,
+extern "C" int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t batch, double goal_radius, int sparse, float* reward_out,
                                        void* stream) {
   if (!achieved || !desired || !reward_out) return fail("grx_maze_compute_reward: null argument");
   if (batch <= 0) return 0;
@@ -1399,8 +1399,8 @@ grx_maze_reset_kernel(grx_maze_reset_args a, int n_reset) {
   if (l == 0) {
     a.goal[2 * (size_t)w] = gx; a.goal[2 * (size_t)w + 1] = gy;
     a.achieved[2 * (size_t)w] = sx; a.achieved[2 * (size_t)w + 1] = sy;
-    const float dx = sx - gx, dy = sy - gy;
-    const int succ = sqrtf(dx * dx + dy * dy) <= a.goal_radius;
+    const float sg[2] = {sx, sy}, gg[2] = {gx, gy};
+    const int succ = grx_goal_distance2(sg, gg) <= a.goal_radius;
     a.success[w] = (unsigned char)succ;
     if (row) {
       row[a.obs_dim] = sx; row[a.obs_dim + 1] = sy; row[a.obs_dim + 2] = gx; row[a.obs_dim + 3] = gy;
@@ -1596,7 +1596,7 @@ extern "C" int grx_kitchen_bookkeeping(const grx_kitchen_book* args, int n_world
   return 0;
 }
 
-extern "C" int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
+extern "C" int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, double distance_threshold, int sparse,
                                         float* reward_out, void* stream) {
   if (!achieved || !desired || !reward_out) return fail("grx_fetch_compute_reward: null argument");
   if (batch <= 0) return 0;

@@ -14,7 +14,8 @@
 struct GrxPointTask {
   int n_substeps, sparse_reward, continuing_task;
   int agent;  // 0 = point mass (point.py), 1 = ant (gymnasium AntEnv-v5 [3P] wrapped by ant_maze_v5.py:295-320)
-  float goal_radius, vel_clip;
+  double goal_radius;   // fp64, see grx_goal_distance3 (csrc/grx_fetch_task.h)
+  float vel_clip;
 };
 
 struct GrxPointBuffers {
@@ -29,11 +30,11 @@ struct GrxPointBuffers {
   float* packed;                 // [N, obs_dim + 2 + 2 + 2] or null: out, the row [obs | achieved | desired | reward | success]
 };
 
-GRX_DEV float grx_goal_distance2(const float* a, const float* b) {
-  float dx = a[0] - b[0], dy = a[1] - b[1];
-  return sqrtf(fmaf(dy, dy, dx * dx));
+GRX_DEV double grx_goal_distance2(const float* a, const float* b) {
+  const double dx = (double)a[0] - (double)b[0], dy = (double)a[1] - (double)b[1];
+  return sqrt(dx * dx + dy * dy);
 }
-GRX_DEV float grx_maze_reward(float d, float radius, int sparse) { return sparse ? ((d <= radius) ? 1.0f : 0.0f) : expf(-d); }
+GRX_DEV float grx_maze_reward(double d, double radius, int sparse) { return sparse ? ((d <= radius) ? 1.0f : 0.0f) : expf(-(float)d); }
 
 template <class S>
 struct GrxPoint {

@@ -51,8 +51,8 @@ class FetchTaskStruct(ctypes.Structure):
         ("sparse_reward", ctypes.c_int), ("grip_body", ctypes.c_int), ("grip_relpos", ctypes.c_float * 3),
         ("grip_relquat", ctypes.c_float * 4), ("site_grip", ctypes.c_int), ("site_obj", ctypes.c_int),
         ("jq_rf", ctypes.c_int), ("jq_lf", ctypes.c_int), ("jd_rf", ctypes.c_int), ("jd_lf", ctypes.c_int),
-        ("obs_dim", ctypes.c_int), ("goal_dim", ctypes.c_int), ("distance_threshold", ctypes.c_float),
-        ("dt", ctypes.c_float),
+        ("obs_dim", ctypes.c_int), ("goal_dim", ctypes.c_int), ("dt", ctypes.c_float),
+        ("distance_threshold", ctypes.c_double),
     ]
 
 

@@ -216,11 +216,11 @@ class HandReachVecEnv(GoalVecEnv):
         self._needs_reset[idx] = False
 
     def reset(self, *, seed=None, options=None):
-        if seed is not None:
-            seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
-            self.np_randoms = [np_random(s)[0] for s in seeds]
         with torch.cuda.device(self.device):
-            self._cancel_chains()
+            self._cancel_chains()      # BEFORE re-seeding: a cancelled chain hands its draws back to the generator they came from, never to a freshly seeded one
+            if seed is not None:
+                seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
+                self.np_randoms = [np_random(s)[0] for s in seeds]
             self._reset_worlds(np.arange(self.num_envs))
         self._has_reset = True
         return self._obs_dict(), {}

@@ -103,7 +103,7 @@ import ctypes  # noqa: E402
 
 class HandTaskStruct(ctypes.Structure):
     _fields_ = [("n_substeps", ctypes.c_int), ("sparse_reward", ctypes.c_int), ("site", ctypes.c_int * 5), ("palm_body", ctypes.c_int),
-                ("distance_threshold", ctypes.c_float), ("kind", ctypes.c_int), ("nq_robot", ctypes.c_int), ("obj_qadr", ctypes.c_int),
+                ("distance_threshold", ctypes.c_double), ("kind", ctypes.c_int), ("nq_robot", ctypes.c_int), ("obj_qadr", ctypes.c_int),
                 ("obj_dadr", ctypes.c_int), ("ignore_position", ctypes.c_int), ("ignore_rotation", ctypes.c_int), ("rotation_threshold", ctypes.c_float), ("ignore_z", ctypes.c_int), ("touch_mode", ctypes.c_int)]
 
 

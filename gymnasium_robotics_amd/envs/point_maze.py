@@ -251,7 +251,7 @@ class PointMazeVecEnv(GoalVecEnv):
         return out.double().cpu().numpy() if as_numpy else out
 
     def compute_terminated(self, achieved_goal, desired_goal, info=None):
-        d = np.linalg.norm(np.asarray(achieved_goal) - np.asarray(desired_goal), axis=-1)
+        d = np.linalg.norm(np.asarray(achieved_goal, dtype=np.float64) - np.asarray(desired_goal, dtype=np.float64), axis=-1)      # maze_v4.py:390-397: the fp64 norm
         return (d <= GOAL_RADIUS) if not self.continuing_task else np.zeros(d.shape, bool)
 
     def compute_truncated(self, achieved_goal, desired_goal, info=None):

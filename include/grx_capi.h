@@ -77,7 +77,8 @@ typedef struct grx_fetch_task {
   int site_grip, site_obj;
   int jq_rf, jq_lf, jd_rf, jd_lf;
   int obs_dim, goal_dim;
-  float distance_threshold, dt;
+  float dt;
+  double distance_threshold; /* fp64: success / sparse reward are decided in the reference's arithmetic on the returned goals (fetch_env.py:74-80,168-170) */
 } grx_fetch_task;
 
 /* bits of the per-world `status` words the step kernels write (0 = healthy; csrc/grx_engine.h GRX_ST_*).
@@ -119,7 +120,8 @@ typedef struct grx_fetch_buffers {
 typedef struct grx_point_task {
   int n_substeps, sparse_reward, continuing_task;
   int agent; /* 0 = PointMaze particle, 1 = AntMaze ant (RK4, obs without xy) */
-  float goal_radius, vel_clip;
+  double goal_radius; /* fp64 (maze_v4.py:381-388) */
+  float vel_clip;
 } grx_point_task;
 typedef struct grx_point_buffers {
   float *qpos, *qvel, *qacc_ws; /* [N,nq] [N,nv] [N,nv] */
@@ -138,7 +140,7 @@ typedef struct grx_hand_task {
   int n_substeps, sparse_reward;
   int site[5];   /* fingertip sites, envs/shadow_dexterous_hand/reach.py:8-14 order */
   int palm_body; /* body used by _sample_goal (reach.py:413-416) */
-  float distance_threshold;
+  double distance_threshold; /* fp64 (reach.py:92-100) */
   int kind;      /* 0 = HandReach (goal dim 15, obs nq+nv+15); 1 = HandManipulate* (goal dim 7, obs 2 nq_robot + 6 + 7) */
   int nq_robot, obj_qadr, obj_dadr;      /* kind 1: robot joints come first; qpos / dof address of object:joint */
   int ignore_position, ignore_rotation;  /* kind 1: target_position / target_rotation == "ignore" (manipulate.py:92-97) */
@@ -250,13 +252,13 @@ int grx_order_by_cost(const int* cost, float* ema /* [N] in/out or NULL */, floa
  * that will be a slot's THIRD world (as many as predicted stragglers hold a slot for the whole launch) are chosen and placed so that those slots run three cheap worlds
  * back to back instead of two median worlds and one more (csrc/grx_kernels.hip, grx_order_kernel). */
 int grx_order_by_cost_slots(const int* cost, float* ema, float alpha, int n_worlds, int slots_per_xcd, int* order, void* stream);
-int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, float distance_threshold, int sparse,
+int grx_fetch_compute_reward(const float* achieved, const float* desired, int64_t batch, double distance_threshold, int sparse,
                              float* reward_out, void* stream);
 /* Maze family (PointMaze and AntMaze, selected by task->agent; AntMazeEnv.step: envs/maze/ant_maze_v5.py:295-310).
  * PointMaze: PointMazeEnv.step for N worlds = clip + velocity clip + mj_step(1) + obs/reward/terminated/success
  * (envs/maze/point.py:55-77, envs/maze/point_maze.py:392-406); batched MazeEnv.compute_reward (envs/maze/maze_v4.py:381-388). */
 int grx_point_step(const grx_model* m, const grx_point_task* task, const grx_point_buffers* buf, int n_worlds, void* stream);
-int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t batch, float goal_radius, int sparse, float* reward_out,
+int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t batch, double goal_radius, int sparse, float* reward_out,
                             void* stream);
 
 /* Shadow hand reach: BaseRobotEnv.step with MujocoHandEnv._set_action (absolute position control) + mj_step(n_substeps) +
@@ -292,7 +294,7 @@ typedef struct grx_kitchen_book {
   int* final_info;      /* [N,3] or NULL: (tasks_to_complete, step_task_completions, episode_task_completions) of the episode a same-step reset world has just finished */
 } grx_kitchen_book;
 int grx_kitchen_bookkeeping(const grx_kitchen_book* args, int n_worlds, void* stream);
-int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, float distance_threshold, int sparse,
+int grx_goal_compute_reward(const float* achieved, const float* desired, int64_t batch, int dim, double distance_threshold, int sparse,
                             float* reward_out, void* stream);
 /* batched MujocoManipulateEnv.compute_reward on 7-vector pose goals (shadow_dexterous_hand/manipulate.py:87-142) */
 int grx_manip_compute_reward(const float* achieved, const float* desired, int64_t batch, int ignore_position, int ignore_rotation,
@@ -310,7 +312,7 @@ typedef struct grx_her_args {
   int T, N, W, obs_dim, goal_dim, act_dim;
   const int *t_idx, *w_idx, *t_goal;   /* [batch] */
   int kind;                            /* 0 Fetch (fetch_env.py:74-80), 1 HandReach (reach.py:92-100: -0.0 for success), 2 maze (maze_v4.py:381-388), 3 manipulate poses (manipulate.py:87-142) */
-  float p0, p1;                        /* 0 / 1: distance_threshold; 2: goal radius 0.45; 3: distance_threshold, rotation_threshold */
+  double p0, p1;                       /* 0 / 1: distance_threshold; 2: goal radius 0.45; 3: distance_threshold, rotation_threshold */
   int sparse, ignore_pos, ignore_rot, ignore_z;
   float* out;                          /* [batch, 2 obs_dim + 3 goal_dim + act_dim + 2] */
   /* Same-step autoreset: the ring row of the step that resets world w already holds the FIRST row of w's new episode, the terminal row of the episode that just
@@ -342,7 +344,7 @@ int grx_her_mark_resets(const unsigned char* reset_mask, int n_worlds, int t, in
 typedef struct grx_maze_reset_args {
   const int* idx; const float* stage; const float* qpos0;
   int nq, nv, obs_dim, obs_skip;        /* obs_skip: leading qpos entries left out of the observation (2 for the ant, 0 for the point mass) */
-  float goal_radius;
+  double goal_radius;
   int keep_outcome;
   float *qpos, *qvel, *qacc_ws, *goal, *obs, *achieved, *reward; unsigned char* success; float* packed;
 } grx_maze_reset_args;

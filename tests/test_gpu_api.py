@@ -77,7 +77,7 @@ def test_serialize_deserialize_keeps_constructor_arguments():
     env1.reset()
     env2 = pickle.loads(pickle.dumps(env1))
     assert env1.distance_threshold == env2.distance_threshold == 1e-6
-    assert env2.task.distance_threshold == np.float32(1e-6)
+    assert env2.task.distance_threshold == 1e-6
     env1.close(); env2.close()
 
 
@@ -180,15 +180,18 @@ def test_device_rewards_equal_the_reference_run_vectors():
     for env_id, key in (("FetchPush-v4", "sparse"), ("FetchPushDense-v4", "dense")):
         env = grx.make_vec(env_id, num_envs=2, device="cuda:0")
         r = env.compute_reward(ref["fetch_ag"], ref["fetch_dg"], {})
-        d = np.linalg.norm(ref["fetch_ag"] - ref["fetch_dg"], axis=-1)
-        clear = np.abs(d - 0.05) > 1e-6
+        # the device decides d > 0.05 in fp64 on the fp32-rounded goals it is handed: exactly the reference's answer for those goals
+        d = np.linalg.norm(ref["fetch_ag"].astype(np.float32).astype(np.float64) - ref["fetch_dg"].astype(np.float32).astype(np.float64), axis=-1)
         assert r.shape == ref[f"fetch_reward_{key}"].shape
+        assert np.array_equal(r, -(d > 0.05).astype(np.float32)) if key == "sparse" else np.allclose(r, -d, rtol=0, atol=2e-8)
+        clear = np.abs(np.linalg.norm(ref["fetch_ag"] - ref["fetch_dg"], axis=-1) - 0.05) > 1e-6      # the reference's own fp64 goals: equal where fp32 input rounding cannot matter
         assert np.allclose(r[clear], ref[f"fetch_reward_{key}"][clear], rtol=0, atol=1e-6)
     for env_id, key in (("HandReach-v3", "sparse"), ("HandReachDense-v3", "dense")):
         env = grx.make_vec(env_id, num_envs=2, device="cuda:0")
         r = env.compute_reward(ref["hand_reach_ag"], ref["hand_reach_dg"], {})
-        d = np.linalg.norm(ref["hand_reach_ag"] - ref["hand_reach_dg"], axis=-1)
-        clear = np.abs(d - 0.01) > 1e-6
+        d = np.linalg.norm(ref["hand_reach_ag"].astype(np.float32).astype(np.float64) - ref["hand_reach_dg"].astype(np.float32).astype(np.float64), axis=-1)
+        assert np.array_equal(r, -(d > 0.01).astype(np.float32)) if key == "sparse" else np.allclose(r, -d, rtol=0, atol=2e-8)
+        clear = np.abs(np.linalg.norm(ref["hand_reach_ag"] - ref["hand_reach_dg"], axis=-1) - 0.01) > 1e-6
         assert np.allclose(r[clear], ref[f"hand_reach_reward_{key}"][clear], rtol=0, atol=1e-6)
     for env_id, tag, key in (("HandManipulateBlockRotateXYZ-v1", "ignore_xyz", "sparse"), ("HandManipulateBlockRotateXYZDense-v1", "ignore_xyz", "dense"),
                              ("HandManipulateBlockFull-v1", "random_xyz", "sparse"), ("HandManipulateBlockFullDense-v1", "random_xyz", "dense")):

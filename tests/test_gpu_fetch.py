@@ -56,11 +56,17 @@ def test_teacher_forced_step_matches_golden(task):
     assert np.abs(obs["achieved_goal"] - g["achieved"])[posed].max() < TOL
     print(f"{task}: {posed.sum()}/{n} snapshots away from activation boundaries, max err there {err[posed].max():.2e}; all: p50 {np.median(err):.2e} "
           f"p99 {np.quantile(err, 0.99):.2e} max {err.max():.2e}")
-    # flags / sparse reward: bit-exact except where the fp64 distance sits within 1e-6 of the threshold
+    # flags / sparse reward: EXACTLY the reference's functions (fetch_env.py:74-80, 168-170: fp64 norm, d < 0.05 / d > 0.05) of the returned goals -- every snapshot,
+    # no band around the threshold (the device takes the distance and the compare in fp64, csrc/grx_fetch_task.h grx_goal_distance3)
+    d_hip = np.linalg.norm(obs["achieved_goal"].astype(np.float64) - obs["desired_goal"].astype(np.float64), axis=-1)
+    assert np.array_equal(info["is_success"], (d_hip < 0.05).astype(np.float32))
+    assert np.array_equal(r, -(d_hip > 0.05).astype(np.float32))
+    # ... and therefore the oracle's flags wherever the difference of the two achieved goals cannot flip the compare (it can for no snapshot of these fixtures)
     d = np.linalg.norm(g["achieved"] - g["goal"], axis=-1)
-    safe = np.abs(d - 0.05) > 1e-6
-    assert np.array_equal(r[safe], g["reward"][safe].astype(np.float32))
-    assert np.array_equal(info["is_success"][safe], g["success"][safe].astype(np.float32))
+    decided = np.abs(d - 0.05) > np.abs(d_hip - d)
+    assert decided.all(), int((~decided).sum())
+    assert np.array_equal(r[decided], g["reward"][decided].astype(np.float32))
+    assert np.array_equal(info["is_success"][decided], g["success"][decided].astype(np.float32))
     assert not term.any() and not trunc.any()
     # post-step state
     assert np.abs(env.qpos.cpu().numpy() - g["qpos_next"])[posed].max() < TOL
@@ -179,10 +185,9 @@ def test_reward_invariant_and_her_recompute():
         # relabel with shuffled goals against a numpy restatement of fetch_env.py:74-80
         perm = rng.permutation(128)
         rl = env.compute_reward(ag, dg[:, perm], {})
-        d = np.linalg.norm(ag.astype(np.float32) - dg[:, perm].astype(np.float32), axis=-1)
-        ref = -(d > 0.05).astype(np.float32) if env.reward_type == "sparse" else -d
-        safe = np.abs(d - 0.05) > 1e-6
-        assert np.allclose(rl[safe], ref[safe], atol=1e-6)
+        d = np.linalg.norm(ag.astype(np.float64) - dg[:, perm].astype(np.float64), axis=-1)       # the reference's fp64 norm of the (fp32) goals handed in
+        ref = -(d > 0.05).astype(np.float32) if env.reward_type == "sparse" else (-d).astype(np.float32)
+        assert np.array_equal(rl, ref) if env.reward_type == "sparse" else np.allclose(rl, ref, rtol=0, atol=2e-8)
 
 
 def test_time_limit_and_autoreset_next_step():

@@ -206,7 +206,17 @@ def test_abandoned_settle_chains_give_their_draws_back():
     ob, _ = B.reset()
     for k in ("observation", "desired_goal"):
         assert np.array_equal(oa[k], ob[k]), k
-    A.close(); B.close()
+    # reset(seed=...) with chains in flight: the seed must win -- the abandoned chains' draws go back to the OLD generators, the new ones start untouched
+    for t in range(5):
+        a = rng.uniform(-1, 1, (12, 20)).astype(np.float32)
+        A.step(a); B.step(a)
+    assert len(A._chains) > 0
+    oa, _ = A.reset(seed=11)
+    C = mk("next_step")
+    oc, _ = C.reset(seed=11)
+    for k in ("observation", "desired_goal"):
+        assert np.array_equal(oa[k], oc[k]), k
+    A.close(); B.close(); C.close()
 
 
 def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):

@@ -61,10 +61,9 @@ def test_reward_invariant_termination_and_time_limit():
         rc = env.compute_reward(obs["achieved_goal"], obs["desired_goal"], {})
         fresh = ~(env._elapsed == 0)  # worlds that were just auto-reset report reward 0
         assert np.array_equal(rc[fresh], r[fresh])  # core.py:59-62 invariant, bit-exact
-        d = np.linalg.norm(obs["achieved_goal"] - obs["desired_goal"], axis=1)
-        safe = (np.abs(d - 0.45) > 1e-5) & fresh
-        assert np.array_equal(term[safe], (d <= 0.45)[safe])
-        assert np.array_equal(env.compute_terminated(obs["achieved_goal"], obs["desired_goal"])[safe], term[safe])
+        d = np.linalg.norm(obs["achieved_goal"].astype(np.float64) - obs["desired_goal"].astype(np.float64), axis=1)      # maze_v4.py:381-388 on the returned goals, fp64
+        assert np.array_equal(term[fresh], (d <= 0.45)[fresh])
+        assert np.array_equal(env.compute_terminated(obs["achieved_goal"], obs["desired_goal"])[fresh], term[fresh])
         saw_term |= term.any()
     assert saw_term
     with pytest.raises(ValueError, match="Action dimension mismatch"):

@@ -53,8 +53,8 @@ def test_fetch_pick_and_place_4096_worlds():
     assert flagged <= 0.002 * 4096 * 50                                          # capacity flags are rare (measured ~0.035 %)
     r2 = env.compute_reward(obs["achieved_goal"], obs["desired_goal"], None)
     assert bool((r2 == r).all())
-    d = (obs["achieved_goal"] - obs["desired_goal"]).norm(dim=1)
-    assert bool(((d < 0.05 - 1e-6) <= info["is_success"].bool()).all()) and bool((info["is_success"].bool() <= (d < 0.05 + 1e-6)).all())
+    d = (obs["achieved_goal"].double() - obs["desired_goal"].double()).norm(dim=1)
+    assert bool(((d < 0.05) == info["is_success"].bool()).all())      # the reference's fp64 compare on the returned goals: exact for all 4096 worlds
     env.close()
 
 

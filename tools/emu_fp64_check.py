@@ -60,6 +60,9 @@ def _fixture(task):
         return m, as_fp64_struct(make_hand_task(m)), np.load(os.path.join(G, "hand_HandReach_teacher.npz")), "hand"
     from gymnasium_robotics_amd.envs.hand import load_hand_block_model
     from gymnasium_robotics_amd.envs.manipulate_spec import make_block_task
+    if task == "HandBlockTouch":     # BASELINE configs[2]: the 92 touch zones as raw sensordata (153-word observation)
+        m = load_hand_block_model(None, touch=True, obj="block")
+        return m, as_fp64_struct(make_block_task(m, "ignore", "xyz", "sparse", "sensordata", obj="block")), np.load(os.path.join(G, "hand_BlockRotateXYZ_touch_teacher.npz")), "hand"
     obj, fix = {"HandBlock": ("block", "hand_BlockRotateXYZ_teacher.npz"), "HandEgg": ("egg", "hand_EggRotate_teacher.npz"), "HandPen": ("pen", "hand_PenRotate_teacher.npz")}[task]
     m = load_hand_block_model(None, touch=False, obj=obj)
     return m, as_fp64_struct(make_block_task(m, "ignore", "xyz", "sparse", "off", obj=obj)), np.load(os.path.join(G, fix)), "hand"

@@ -20,7 +20,7 @@ from emu_fp64_check import _fixture, as_fp64_struct  # noqa: E402
 
 FAMILY_TO_TASK = {"FetchReach": "FetchReach", "FetchPush": "FetchPush", "FetchPickAndPlace": "FetchPickAndPlace", "FetchSlide": "FetchSlide", "FetchHullContacts": "hull",
                   "HandReach": "HandReach", "HandBlock": "HandBlock", "HandEgg": "HandEgg", "HandPen": "HandPen", "AdroitHammer": "hammer", "AdroitDoor": "door",
-                  "AdroitPen": "pen", "AdroitRelocate": "relocate", "FrankaKitchen": "kitchen"}
+                  "AdroitPen": "pen", "AdroitRelocate": "relocate", "FrankaKitchen": "kitchen", "HandBlockTouch": "HandBlockTouch"}
 
 
 def build(fp64):
@@ -120,7 +120,7 @@ def main(argv):
         ref = run_family(L64, fam, True, every, round_inputs=True, ref="raw")[1] if rounded else None
         idx, e, status, comps = run_family(L, fam, fp64, every, round_inputs=rounded, ref=ref)
         for comp, cols in comps.items():
-            err = e[:, cols].max(axis=1)
+            err = e[:, cols].max(axis=1)      # absolute, also for the "_relative" components of tests/tolerance_cases.py
             worst = idx[np.argsort(-err)[:6]]
             print(f"{fam:18s} {comp:26s} n={len(err):4d} p50 {np.median(err):.1e} p90 {np.quantile(err, .9):.1e} p99 {np.quantile(err, .99):.1e} max {err.max():.1e} "
                   f"within 1e-4: {100 * np.mean(err < 1e-4):5.1f} %  over: {int((err >= 1e-4).sum())}  worst snapshots {list(worst)}  status!=0: {int((status != 0).sum())}", flush=True)
