@@ -490,13 +490,23 @@ typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NMC (S::kFixed ? S::NM : m->nmocap)
 #if defined(GRX_EMU)
 static long g_grx_mesh_stats[4];   // emulator diagnostics: hull pairs skipped by a cached separating direction / sent through the portal search
+static long g_grx_newton_stats[4];   // emulator diagnostics: constrained solves, Newton iterations, full Hessian assemblies, incremental updates
 #if defined(GRX_EMU_TRACE)
 static void grx_emu_trace(const GrxModel* m, const GrxCtx* c, int phase);   // defined at the end of this file
 #endif
 #endif
 #if defined(GRX_EMU) && defined(GRX_EMU_FP64) && defined(GRX_EMU_RNDINJ)
 // test infrastructure (tools/emu_tolerances.py --inject): the fp64 build with fp32 ROUNDING injected at chosen stage boundaries -- which stage's fp32 storage costs the parity?
-static void grx_rnd(float* p, int n) { for (int i = 0; i < n; i++) p[i] = (double)(grx_f32_t)p[i]; }
+// GRX_RND_DITHER=seed (!= 0): the rounded value is additionally moved by up to one fp32 ulp at random -- the family of engines that hold this quantity in fp32
+static void grx_rnd(float* p, int n) {
+  static unsigned long long st_ = 0; static int dith_ = -1;
+  if (dith_ < 0) { const char* e_ = getenv("GRX_RND_DITHER"); dith_ = e_ ? atoi(e_) : 0; st_ = 0x9E3779B97F4A7C15ull * (unsigned long long)(dith_ + 1); }
+  for (int i = 0; i < n; i++) {
+    double v = p[i];
+    if (dith_) { st_ = st_ * 6364136223846793005ull + 1442695040888963407ull; const double u = (double)(st_ >> 11) * (1.0 / 9007199254740992.0); v *= 1.0 + (2.0 * u - 1.0) * 1.1920929e-07; }
+    p[i] = (double)(grx_f32_t)v;
+  }
+}
 #define GRX_RNDINJ(bit, body) do { static int mask_ = -1; if (mask_ < 0) { const char* e_ = getenv("GRX_RND_MASK"); mask_ = e_ ? atoi(e_) : 0; } if (mask_ & (1 << (bit))) { body; } } while (0)
 #else
 #define GRX_RNDINJ(bit, body) ((void)0)
@@ -1276,7 +1286,8 @@ GRX_MEM void grx_geom_support(const MF* R, const MF* sz, int type, const MF* d, 
   mulMatVec3f(out, R, r);
 }
 struct GrxMprPair { MF R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // the two frames are copied into registers: ~20 support evaluations each read them twice
-                    const float *v1, *v2; int n1, n2, lane;                      // hull vertices (geom frame) of mesh geoms: only read by the wave-cooperative variant
+                    const float *v1, *v2; int n1, n2, lane; const int *aadr1, *anum1, *aadr2, *anum2, *adj;   // hull adjacency (per hull vertex: first neighbour / count into adj)
+                                        // hull vertices (geom frame) of mesh geoms: only read by the wave-cooperative variant
                     GrxMprPt* pts;
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
                     long long* prof;
@@ -1285,19 +1296,53 @@ struct GrxMprPair { MF R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // 
 // Convex hull of a mesh: the hull vertex farthest along the (geom-frame) direction dl; the lowest vertex index wins ties, like the oracle's
 // exhaustive scan.  Called from wave-uniform code: on the GPU the 64 lanes share the scan (lane l takes the vertices l, l + 64, ...; the
 // loads are coalesced) and agree on the winner through two DPP reductions -- a hull of 500 vertices costs 8 loads per lane.
-GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, int lane_) {
+// fp64 support vertex from the fp32 scan's winner: the vertices whose projection is within fp32 rounding of the maximum form a connected cap of the convex
+// hull (a face lying flat on a table: all of its vertices tie to ~1e-7), and the reference -- a double precision scan -- picks among them by the digits the
+// fp32 products do not have; another pick moves the portal's first vertex and with it the contact normal by 0.1 rad (FetchHullContacts fixture, snapshot 93).
+// Hill climbing over the hull's edge graph in MF arithmetic from the fp32 winner reaches the fp64 winner in one or two rounds of neighbour loads; the lowest
+// index wins exact ties, like the reference's scan.  aadr / anum: per-vertex adjacency of THIS hull, adj: the model's neighbour table.
+GRX_MEM int grx_mesh_support_refine(const float* verts, const int* aadr, const int* anum, const int* adj, const MF* dlm, int cur, int lane_) {
+  if (sizeof(MF) == sizeof(HF) || aadr == nullptr) return cur;
+  for (int guard = 0; guard < 64; guard++) {
+    const MF tc = (MF)verts[3 * cur] * dlm[0] + (MF)verts[3 * cur + 1] * dlm[1] + (MF)verts[3 * cur + 2] * dlm[2];
+    const int aa = aadr[cur], an = anum[cur];
+    MF tb = tc; int nb = cur;
+#if defined(GRX_EMU)
+    (void)lane_;
+    for (int k = 0; k < an; k++) {
+      const int v = adj[aa + k];
+      const MF t = (MF)verts[3 * v] * dlm[0] + (MF)verts[3 * v + 1] * dlm[1] + (MF)verts[3 * v + 2] * dlm[2];
+      if (t > tb || (t == tb && v < nb)) { tb = t; nb = v; }
+    }
+#else
+    for (int k = lane_; k < an; k += 64) {
+      const int v = adj[aa + k];
+      const MF t = (MF)verts[3 * v] * dlm[0] + (MF)verts[3 * v + 1] * dlm[1] + (MF)verts[3 * v + 2] * dlm[2];
+      if (t > tb || (t == tb && v < nb)) { tb = t; nb = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {   // wave argmax in MF (rare path: a few times per portal search)
+      const MF to = __shfl_xor(tb, o, 64); const int no = __shfl_xor(nb, o, 64);
+      if (to > tb || (to == tb && no < nb)) { tb = to; nb = no; }
+    }
+#endif
+    if (nb == cur) break;
+    cur = nb;
+  }
+  return cur;
+}
+GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, int lane_, const int* aadr = nullptr, const int* anum = nullptr, const int* adj = nullptr) {
   r[0] = r[1] = r[2] = 0.0f;
   if (n <= 0) return -1;
   const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};   // the scan's own arithmetic type (GRX_HULL_REAL)
 #if defined(GRX_EMU)
-  (void)lane_;
   HF best = -3.0e38f; int bi = 0;
   for (int v = 0; v < n; v++) { const HF t = verts[3 * v] * dl[0] + verts[3 * v + 1] * dl[1] + verts[3 * v + 2] * dl[2]; if (t > best) { best = t; bi = v; } }
 #else
 #ifndef GRX_HULL_INFLIGHT
 #define GRX_HULL_INFLIGHT 4
 #endif
-  float best = -3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f; int mine = 0;
+  float best = -3.0e38f, second = -3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f; int mine = 0;   // second: this lane's runner-up (is the winner unique beyond fp32 rounding?)
   for (int v0 = lane_; v0 < n; v0 += 64 * GRX_HULL_INFLIGHT) {   // several independent vertex fetches in flight per lane: one memory latency per 64 * GRX_HULL_INFLIGHT vertices
     float x[GRX_HULL_INFLIGHT], y[GRX_HULL_INFLIGHT], z[GRX_HULL_INFLIGHT];
 #pragma unroll
@@ -1305,18 +1350,25 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
 #pragma unroll
     for (int u = 0; u < GRX_HULL_INFLIGHT; u++) {
       const float t = x[u] * dl[0] + y[u] * dl[1] + z[u] * dl[2];
-      if (v0 + 64 * u < n && t > best) { best = t; mine = v0 + 64 * u; bx = x[u]; by = y[u]; bz = z[u]; }
+      if (v0 + 64 * u < n) { if (t > best) { second = best; best = t; mine = v0 + 64 * u; bx = x[u]; by = y[u]; bz = z[u]; } else if (t > second) second = t; }
     }
   }
   const float mx = grx_reduce_max(best);
-  const int bi = (int)(-grx_reduce_max((best == mx) ? -(float)mine : -3.0e38f));   // vertex indices are far below 2^24: exact in fp32
-  {   // the winner's coordinates are in the registers of the lane that scanned it: no second trip to memory
-    const unsigned long long own = __ballot(best == mx && mine == bi);
-    const int src = own ? __builtin_ctzll(own) : 0;
-    r[0] = grx_readlane_f(bx, src); r[1] = grx_readlane_f(by, src); r[2] = grx_readlane_f(bz, src);
-    return bi;
+  int bi = (int)(-grx_reduce_max((best == mx) ? -(float)mine : -3.0e38f));   // vertex indices are far below 2^24: exact in fp32
+  {
+    // the winner is unique beyond the rounding of the fp32 products (|t| < 1 m: error < 3e-7) in all but face-on / edge-on directions: no refinement, and its
+    // coordinates are in the registers of the lane that scanned it -- no second trip to memory
+    const float near_ = mx - 1.0e-6f * fmaxf(1.0f, fabsf(mx));
+    const int ties = __builtin_popcountll(__ballot(best >= near_)) + __builtin_popcountll(__ballot(second >= near_));
+    if (ties <= 1 || sizeof(MF) == sizeof(HF) || aadr == nullptr) {
+      const unsigned long long own = __ballot(best == mx && mine == bi);
+      const int src = own ? __builtin_ctzll(own) : 0;
+      r[0] = grx_readlane_f(bx, src); r[1] = grx_readlane_f(by, src); r[2] = grx_readlane_f(bz, src);
+      return bi;
+    }
   }
 #endif
+  bi = grx_mesh_support_refine(verts, aadr, anum, adj, dlm, bi, lane_);
   r[0] = verts[3 * bi]; r[1] = verts[3 * bi + 1]; r[2] = verts[3 * bi + 2];
   return bi;
 }
@@ -1325,21 +1377,26 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
 // Returns the support vertex (hint, or the winner of the full scan).
 GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* dlm, int hint, MF* r, int lane_) {
   const float* verts = m->mesh_vert + 3 * adr;
-  const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};
-  if (hint >= 0 && hint < n) {
-    const int aa = m->mesh_adjadr[adr + hint], an = m->mesh_adjnum[adr + hint];
-    const HF t0 = verts[3 * hint] * dl[0] + verts[3 * hint + 1] * dl[1] + verts[3 * hint + 2] * dl[2];
+  if (hint >= 0 && hint < n) {   // one round of neighbour loads, in MF: the hint IS the support vertex when no hull neighbour lies higher
+    const int cur = grx_mesh_support_refine(verts, m->mesh_adjadr + adr, m->mesh_adjnum + adr, m->mesh_adj, dlm, hint, lane_);
+    if (sizeof(MF) != sizeof(HF)) {
+      if (cur == hint) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
+    } else {
+      const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};
+      const int aa = m->mesh_adjadr[adr + hint], an = m->mesh_adjnum[adr + hint];
+      const HF t0 = verts[3 * hint] * dl[0] + verts[3 * hint + 1] * dl[1] + verts[3 * hint + 2] * dl[2];
 #if defined(GRX_EMU)
-    int higher = 0;
-    for (int k = 0; k < an; k++) { const int nb = m->mesh_adj[aa + k]; higher |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
+      int higher = 0;
+      for (int k = 0; k < an; k++) { const int nb = m->mesh_adj[aa + k]; higher |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
 #else
-    int hi_ = 0;
-    for (int k = lane_; k < an; k += 64) { const int nb = m->mesh_adj[aa + k]; hi_ |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
-    const int higher = __ballot(hi_ != 0) != 0ull;
+      int hi_ = 0;
+      for (int k = lane_; k < an; k += 64) { const int nb = m->mesh_adj[aa + k]; hi_ |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
+      const int higher = __ballot(hi_ != 0) != 0ull;
 #endif
-    if (!higher) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
+      if (!higher) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
+    }
   }
-  return grx_mesh_support(verts, n, dlm, r, lane_);
+  return grx_mesh_support(verts, n, dlm, r, lane_, m->mesh_adjadr + adr, m->mesh_adjnum + adr, m->mesh_adj);
 }
 // W: wave-cooperative variant (uniform control flow, every lane holds the same values; mesh geoms allowed)
 template <bool W>
@@ -1351,9 +1408,9 @@ GRX_MEM void grx_mpr_support(const GrxMprPair* q, const MF* d, GrxMprPt* o) {
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   const long long tp0_ = clock64();
 #endif
-  if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); grx_mesh_support(q->v1, q->n1, dl, r, q->lane); mulMatVec3f(o->w, q->R1, r); }
+  if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); grx_mesh_support(q->v1, q->n1, dl, r, q->lane, q->aadr1, q->anum1, q->adj); mulMatVec3f(o->w, q->R1, r); }
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
-  if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); grx_mesh_support(q->v2, q->n2, dl, r, q->lane); mulMatVec3f(b, q->R2, r); }
+  if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj); mulMatVec3f(b, q->R2, r); }
   else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   if (W && q->lane == 0) q->prof[16 + 28] += clock64() - tp0_;
@@ -1610,7 +1667,7 @@ GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int
   q.t1 = t1; q.t2 = t2; q.hm = 0.5f * margin;
   for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = p2[k] - p1[k]; }
   MF depth, dir[3], pos[3], w1[3], w2[3];
-  q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr;
+  q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr; q.aadr1 = q.anum1 = q.aadr2 = q.anum2 = q.adj = nullptr;
   if (grx_mpr_penetration<false>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;
 #if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
   if (getenv("GRX_TRACE_MPR")) {
@@ -1710,6 +1767,8 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = (MF)c->gxpos[3 * g2 + k] - (MF)c->gxpos[3 * g1 + k]; }
     q.v1 = q.t1 == 7 ? m->mesh_vert + 3 * m->geom_hulladr[g1] : m->mesh_vert; q.n1 = q.t1 == 7 ? m->geom_hullnum[g1] : 0;
     q.v2 = q.t2 == 7 ? m->mesh_vert + 3 * m->geom_hulladr[g2] : m->mesh_vert; q.n2 = q.t2 == 7 ? m->geom_hullnum[g2] : 0;
+    q.aadr1 = m->mesh_adjadr + (q.t1 == 7 ? m->geom_hulladr[g1] : 0); q.anum1 = m->mesh_adjnum + (q.t1 == 7 ? m->geom_hulladr[g1] : 0);
+    q.aadr2 = m->mesh_adjadr + (q.t2 == 7 ? m->geom_hulladr[g2] : 0); q.anum2 = m->mesh_adjnum + (q.t2 == 7 ? m->geom_hulladr[g2] : 0); q.adj = m->mesh_adj;
     q.pts = (GrxMprPt*)(c->Jp + 192);
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
     q.prof = c->prof;
@@ -3341,6 +3400,75 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   WAVE_SYNC();
 }
 
+// One more Newton step in the subspace of a DECOUPLED trailing free object (m->nfreeobj = 6, no active row links it to the robot), after Newton has converged by an
+// exact full step.  H = M + J'DJ of a light body under a stiff contact carries the body's inertia at ~1e-4 of the contact's entries (the puck of FetchSlide:
+// I = 5.8e-4 against D r^2 = 4.3), so the fp32 Hessian resolves the curvature of the body's weak mode -- rocking about the contact point -- to ~4e-4 and a full
+// step of size 200 rad/s^2 leaves that mode 3e-2 rad/s^2 off the minimiser: the whole rotation-velocity discrepancy of the FetchSlide fixtures (tools/emu_mixed.py,
+// tools/emu_trace.py).  The GRADIENT in that mode, taken from the rows (M a - qfrc_smooth - J'f with f from the carried J a - aref), has no such loss, so one more
+// step with the same 6 x 6 Hessian block contracts the error by another 4e-4.  The step is only applied when it leaves every row of the object in its state (the
+// block is then exact for the piece): cost one pass over the rows for 6 lanes and a 6 x 6 solve.
+GRX_MEM void grx_refine_object_block(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
+  GRX_FRESH_MODEL(m, c);
+  const int nv = GRX_NVC, o0 = nv - 6;
+  FOR_LANES {
+    if (lane < 6) {
+      const int i = o0 + lane;
+      float acc = c->Ma[i] - c->qfrc_smooth[i];
+      for (int r = 0; r < nefc; r++) {
+        const int info = c->efc_row[r], pos = grx_row_pos(info, S::kTwoSpan ? c->efc_id[r] : 0, i);
+        if (pos < 0) continue;
+        const float x = c->efc_jar[r], D = c->efc_D[r]; const int kind = c->efc_kind[r];
+        float f;
+        if (kind == GRX_ROW_EQ) f = -D * x;
+        else if (kind == GRX_ROW_FRICTION) { const float fl = c->efc_floss[r], Rf = fl / D; f = (x <= -Rf) ? fl : ((x >= Rf) ? -fl : -D * x); }
+        else f = (x < 0.0f) ? -D * x : 0.0f;
+        acc -= c->Jp[GRX_ROW_OFF(info) + pos] * f;
+      }
+      c->search[i] = -acc;
+    }
+  }
+  WAVE_SYNC();
+#if defined(GRX_EMU)
+  {
+    static float blk[36];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) blk[6 * i + j] = c->A[(o0 + i) * nv + o0 + j];
+    if (grx_sym_factor(blk, 6, lane_)) return;
+    grx_sym_solve(blk, 6, c->search + o0, lane_);
+  }
+#else
+  if (grx_sym_solve_reg<6>(c->A + o0 * nv + o0, nv, c->search + o0, lane_)) return;
+#endif
+  WAVE_SYNC();
+  // the step must leave every row that touches the object in its state; jv of those rows
+  GRX_LANEVAR_I(flipp);
+  FOR_LANES {
+    int flip = 0;
+    for (int r = lane; r < nefc; r += 64) {
+      const int info = c->efc_row[r], idb = S::kTwoSpan ? c->efc_id[r] : 0;
+      float jv = 0.0f; int touches = 0;
+      for (int k = 0; k < 6; k++) { const int pos = grx_row_pos(info, idb, o0 + k); if (pos >= 0) { jv += c->Jp[GRX_ROW_OFF(info) + pos] * c->search[o0 + k]; touches = 1; } }
+      c->efc_jv[r] = jv;
+      if (touches) {
+        const float x0 = c->efc_jar[r], x1 = x0 + jv; const int kind = c->efc_kind[r];
+        if (kind == GRX_ROW_FRICTION) { const float Rf = c->efc_floss[r] / c->efc_D[r]; flip |= ((x0 <= -Rf) != (x1 <= -Rf)) | ((x0 >= Rf) != (x1 >= Rf)); }
+        else if (kind != GRX_ROW_EQ) flip |= ((x0 < 0.0f) != (x1 < 0.0f));
+      }
+    }
+    LV(flipp) = flip;
+  }
+  if (GRX_BALLOT(flipp) != 0ull) return;
+  FOR_LANES {
+    if (lane < 6) {
+      const int i = o0 + lane;
+      float mv = 0.0f;
+      for (int k = 0; k < 6; k++) mv += c->M[i * nv + o0 + k] * c->search[o0 + k];
+      c->qacc[i] += c->search[i]; c->Ma[i] += mv;
+    }
+    for (int r = lane; r < nefc; r += 64) c->efc_jar[r] += c->efc_jv[r];
+  }
+  WAVE_SYNC();
+}
+
 // Constraint solve (Newton) + optional semi-implicit Euler step as ONE state machine, so that the three heavy
 // primitives -- row evaluation, Hessian assembly and the register-resident linear solve -- each have a single call site
 // in the kernel: the fused 20-substep loop has to stay inside the instruction cache.
@@ -3354,11 +3482,15 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   const int implicit_damp = (m->anydamp && m->eulerdamp);
   int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0;
+  int exact_exit = 0, last_split = 0;   // converged by an exact full step (no row changed state) / the last linear solve ran on the decoupled robot | object blocks
   float alpha_prev = 0.0f;   // the step length accepted by the previous Newton iteration (gradient advance of the incremental path)
 #if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)
   if (g_grx_solve_mode == 2 && nefc) phase = 1;
 #endif
   GRX_COUNT(c, 30, 1);     // profiling build: constrained solves (substeps) of the step
+#if defined(GRX_EMU)
+  if (nefc) g_grx_newton_stats[0]++;
+#endif
   GRX_COUNT(c, 31, nefc);  // ... and their constraint rows
   // the linear solve leaves c->A intact where it runs from registers (grx_sym_solve_full): the Hessian can then be corrected in place
   const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 29 || nv == 30 || nv == 33 || nv == 36);
@@ -3388,9 +3520,12 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
 #ifndef GRX_NO_FULLSTEP_EXIT
-      if (it > 0 && full_step && !changed) done = 1;
+      if (it > 0 && full_step && !changed) { done = 1; exact_exit = 1; }
 #endif
       if (done || it >= m->iterations) {   // MuJoCo's option iterations (default 100; the hand models: 20)
+#ifndef GRX_NO_OBJ_REFINE
+        if (exact_exit && last_split == 6 && keepA) grx_refine_object_block(m, c, nefc, lane_);
+#endif
         if (noslip) grx_noslip(m, c, nefc, lane_);   // re-solves the friction forces without regularisation: new qacc, new M a
         // converged: at the minimiser the gradient M a - qfrc_smooth - J'f vanishes, so the joint-space constraint force
         // J'f of the final evaluation is M a - qfrc_smooth (to the solver's residual) -- no further pass over the rows
@@ -3423,6 +3558,9 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         WAVE_SYNC();
         incremental = grx_hessian_update(m, c, nefc, c->tmpv, lane_);
       }
+#if defined(GRX_EMU)
+      g_grx_newton_stats[incremental ? 3 : 2]++;
+#endif
       if (!incremental) grx_hessian(m, c, nefc, lane_);
       GRX_TICK(c, GRX_P_NHESS);
       GRX_LANEVAR(gnp);
@@ -3485,6 +3623,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
           nsplit = (GRX_BALLOT(nzp) == 0ull) ? 6 : 0;
         } else nsplit = 6;
       }
+      if (phase == 0) last_split = nsplit;
       if (grx_sym_solve_full(c->A, nv, rhs, lane_, nsplit, phase != 0)) { LANE0 { c->cnt[2] |= GRX_ST_FACTOR; } }
     }
     if (phase == 0) {
@@ -3549,6 +3688,9 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       if (getenv("GRX_TRACE_NEWTON")) { const int d_ = atoi(getenv("GRX_TRACE_NEWTON")); fprintf(stderr, "   stepmax %.6e qmax %.4e search[d] %.6e qacc[d] %.9e grad[d] %.6e\n", (double)stepmax, (double)qmax, (double)c->search[d_], (double)c->qacc[d_], (double)c->grad[d_]); }
 #endif
       LANE0 { c->cnt[6] += 1; }
+#if defined(GRX_EMU)
+      g_grx_newton_stats[1]++;
+#endif
       GRX_COUNT(c, 29, 1);   // profiling build: Newton iterations of the step
 #ifdef GRX_LS_STATS
       { extern int g_ls_iters, g_ls_full; g_ls_iters++; g_ls_full += full_step; }
@@ -3561,7 +3703,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       // an exact full step (no row changes state on [0,1], decided with the very arithmetic the carried evaluation would repeat) lands on
       // the minimiser of the current piece and leaves every row in its state: converged
 #ifndef GRX_NO_FULLSTEP_EXIT
-      if (full_step == 2) done = 1;
+      if (full_step == 2) { done = 1; exact_exit = 1; }
 #endif
     } else if (phase == 2) {
       FOR_LANES { for (int i = lane; i < nv; i += 64) { float q = c->qacc_smooth[i]; c->qacc[i] = q; c->qacc_ws[i] = q; c->qfrc_constraint[i] = 0; } }

@@ -178,6 +178,9 @@ void orc_reset_data(orc_sim* s) {
 }
 
 /* ------------------------------------------------------------------ K1 kinematics */
+/* A candidate contact that is rejected because it is (just) outside the margin is as much an activation boundary as a listed contact about to leave it: the fixtures'
+ * activation_gap would otherwise miss the contact that an engine with 1e-7 of state rounding lists and this one does not (FetchPush fixture, snapshot 273: 7e-8). */
+#define NEAR_MISS(dist_, margin_) do { const double g_ = fabs((dist_) - (margin_)); if (g_ > 0 && g_ < s->min_activation_gap) s->min_activation_gap = g_; } while (0)
 static void kinematics(orc_sim* s) {
   const grx_model_view* m = &s->m;
   double* xpos = s->xpos; double* xquat = s->xquat; double* xmat = s->xmat;
@@ -433,6 +436,7 @@ static void collide_plane_box(orc_sim* s, int pair, int g1, int g2, double margi
     mulMatVec3(w, bm, loc); w[0] += bp[0]; w[1] += bp[1]; w[2] += bp[2];
     double d[3] = {w[0] - pp[0], w[1] - pp[1], w[2] - pp[2]};
     double dist = dot3(d, n);
+    NEAR_MISS(dist, margin);
     if (dist > margin) continue;
     double pos[3] = {w[0] - 0.5 * dist * n[0], w[1] - 0.5 * dist * n[1], w[2] - 0.5 * dist * n[2]};
     add_contact(s, pair, pos, n, dist); cnt++;
@@ -445,6 +449,7 @@ static void collide_plane_sphere(orc_sim* s, int pair, int g1, int g2, double ma
   const double* c = s->geom_xpos + 3 * g2; double r = m->geom_size[3 * g2];
   double d[3] = {c[0] - s->geom_xpos[3 * g1], c[1] - s->geom_xpos[3 * g1 + 1], c[2] - s->geom_xpos[3 * g1 + 2]};
   double dist = dot3(d, n) - r;
+  NEAR_MISS(dist, margin);
   if (dist > margin) return;
   double pos[3] = {c[0] - n[0] * (r + 0.5 * dist), c[1] - n[1] * (r + 0.5 * dist), c[2] - n[2] * (r + 0.5 * dist)};
   add_contact(s, pair, pos, n, dist);
@@ -464,6 +469,7 @@ static void collide_sphere_box(orc_sim* s, int pair, int g1, int g2, double marg
     double dv[3] = {cl[0] - loc[0], cl[1] - loc[1], cl[2] - loc[2]};
     double len = norm3(dv);
     dist = len - r;
+    NEAR_MISS(dist, margin);
     if (dist > margin) return;
     for (int k = 0; k < 3; k++) nl[k] = dv[k] / len;
   } else {
@@ -488,6 +494,7 @@ static void collide_plane_capsule(orc_sim* s, int pair, int g1, int g2, double m
     double p[3] = {c[0] + e * hl * ax[0], c[1] + e * hl * ax[1], c[2] + e * hl * ax[2]};
     double d[3] = {p[0] - s->geom_xpos[3 * g1], p[1] - s->geom_xpos[3 * g1 + 1], p[2] - s->geom_xpos[3 * g1 + 2]};
     double dist = dot3(d, n) - r;
+    NEAR_MISS(dist, margin);
     if (dist > margin) continue;
     double pos[3] = {p[0] - n[0] * (r + 0.5 * dist), p[1] - n[1] * (r + 0.5 * dist), p[2] - n[2] * (r + 0.5 * dist)};
     add_contact(s, pair, pos, n, dist);
@@ -506,6 +513,7 @@ static int sphere_box_local(orc_sim* s, int pair, const double* bp, const double
   double d2 = box_point_dist2(sz, p, cl);
   if (d2 > 0) {
     double len = sqrt(d2); dist = len - r;
+    NEAR_MISS(dist, margin);
     if (dist > margin) return 0;
     for (int k = 0; k < 3; k++) nl[k] = (cl[k] - p[k]) / len;
   } else {
@@ -582,6 +590,7 @@ static void collide_capsule_capsule(orc_sim* s, int pair, int g1, int g2, double
   double len = norm3(n);
   if (len < MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else { n[0] /= len; n[1] /= len; n[2] /= len; }
   double dist = len - r1 - r2;
+  NEAR_MISS(dist, margin);
   if (dist > margin) return;
   double pos[3] = {p1[0] + n[0] * (r1 + 0.5 * dist), p1[1] + n[1] * (r1 + 0.5 * dist), p1[2] + n[2] * (r1 + 0.5 * dist)};
   add_contact(s, pair, pos, n, dist);
@@ -593,6 +602,7 @@ static void sphere_sphere_raw(orc_sim* s, int pair, const double* c1, double r1,
   double n[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
   double len = norm3(n);
   double dist = len - r1 - r2;
+  NEAR_MISS(dist, margin);
   if (dist > margin) return;
   if (len < MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else { n[0] /= len; n[1] /= len; n[2] /= len; }
   double pos[3] = {c1[0] + n[0] * (r1 + 0.5 * dist), c1[1] + n[1] * (r1 + 0.5 * dist), c1[2] + n[2] * (r1 + 0.5 * dist)};
@@ -627,6 +637,7 @@ static void collide_plane_mesh(orc_sim* s, int pair, int g1, int g2, double marg
     double d = dot3(m->mesh_vert + 3 * (adr + v), nl) + off;
     if (d < bd) { bd = d; best = v; }
   }
+  if (best >= 0) NEAR_MISS(bd, margin);
   if (best < 0 || bd > margin) return;
   int verts[4] = {best, -1, -1, -1}; double dists[4] = {bd, 0, 0, 0}; int cnt = 1;
   int aa = m->mesh_adjadr[adr + best], an = m->mesh_adjnum[adr + best];
@@ -677,12 +688,14 @@ static void collide_box_box(orc_sim* s, int pair, int g1, int g2, double margin)
   for (int i = 0; i < 3; i++) {
     double t = dot3(d, A[i]);
     double sep = fabs(t) - (a[i] + b[0] * Q[i][0] + b[1] * Q[i][1] + b[2] * Q[i][2]);
+    NEAR_MISS(sep, margin);
     if (sep > margin) return;
     if (sep > best) { best = sep; code = i; double sg = t < 0 ? -1 : 1; for (int k = 0; k < 3; k++) bn[k] = sg * A[i][k]; }
   }
   for (int j = 0; j < 3; j++) {
     double t = dot3(d, Bx[j]);
     double sep = fabs(t) - (b[j] + a[0] * Q[0][j] + a[1] * Q[1][j] + a[2] * Q[2][j]);
+    NEAR_MISS(sep, margin);
     if (sep > margin) return;
     if (sep > best) { best = sep; code = 3 + j; double sg = t < 0 ? -1 : 1; for (int k = 0; k < 3; k++) bn[k] = sg * Bx[j][k]; }
   }
@@ -698,6 +711,7 @@ static void collide_box_box(orc_sim* s, int pair, int g1, int g2, double margin)
       double ra = 0, rb = 0;
       for (int k = 0; k < 3; k++) { ra += a[k] * fabs(dot3(A[k], ax)); rb += b[k] * fabs(dot3(Bx[k], ax)); }
       double sep = fabs(t) - (ra + rb);
+      NEAR_MISS(sep, margin);
       if (sep > margin) return;
       if (sep > ebest) { ebest = sep; ei = i; ej = j; double sg = t < 0 ? -1 : 1; for (int k = 0; k < 3; k++) en[k] = sg * ax[k]; }
     }
@@ -771,6 +785,7 @@ static void collide_box_box(orc_sim* s, int pair, int g1, int g2, double margin)
   for (int c = 0; c < n && cnt < 8; c++) {
     double h = hq[0] + gu * (poly[c][0] - x0) + gv * (poly[c][1] - y0);
     if (fabs(det) <= 1e-14) h = hq[0];
+    NEAR_MISS(h, margin);
     if (h > margin) continue;
     /* skip duplicates */
     int dup = 0;
@@ -1055,6 +1070,7 @@ static void collide_plane_cylinder(orc_sim* s, int pair, int g1, int g2, double 
   const double prjvec = dot3(vec, n);
   ax[0] *= hl; ax[1] *= hl; ax[2] *= hl; prjaxis *= hl;
   double dist = dist0 + prjaxis + prjvec, pos[3];
+  NEAR_MISS(dist, margin);
   if (dist > margin) return;
   for (int k = 0; k < 3; k++) pos[k] = cp[k] + vec[k] + ax[k] - n[k] * dist * 0.5;
   add_contact(s, pair, pos, n, dist);
@@ -1084,6 +1100,7 @@ static void collide_plane_ellipsoid(orc_sim* s, int pair, int g1, int g2, double
   geom_support(s, g2, nd, 0.0, p);
   double dd[3] = {p[0] - s->geom_xpos[3 * g1], p[1] - s->geom_xpos[3 * g1 + 1], p[2] - s->geom_xpos[3 * g1 + 2]};
   double dist = dot3(dd, n);
+  NEAR_MISS(dist, margin);
   if (dist > margin) return;
   double pos[3] = {p[0] - 0.5 * dist * n[0], p[1] - 0.5 * dist * n[1], p[2] - 0.5 * dist * n[2]};
   add_contact(s, pair, pos, n, dist);
@@ -1237,7 +1254,9 @@ static void make_constraint(orc_sim* s) {
     for (int side = -1; side <= 1; side += 2) {
       double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - q);
       /* (de)activation gap of the limit row; an exact 0 (joint reset onto its bound) is the same in any precision */
-      if (fabs(dist - margin) > 0 && fabs(dist - margin) < s->min_activation_gap) s->min_activation_gap = fabs(dist - margin);
+      /* a limit row that switches while its joint is at rest carries no force either way (aref = -b v - k d r with v = 0 at r = 0: continuous): only a MOVING joint
+       * near its bound is an activation boundary -- the kitchen's doors and knobs rest 1e-22 ... 3e-7 off their bounds in every snapshot */
+      if (fabs(s->qvel[d]) > 1e-4 && fabs(dist - margin) > 0 && fabs(dist - margin) < s->min_activation_gap) s->min_activation_gap = fabs(dist - margin);
       if (dist < margin) {
         double* J = add_row(s, EFC_LIMIT, j, dist, margin, 0, m->dof_invweight0[d]);
         J[d] = -side;

@@ -165,6 +165,7 @@ void emu_kitchen_step(void* h, const GrxKitchenTask* t, float* qpos, float* qvel
 }
 
 long emu_mesh_stat(int k) { return g_grx_mesh_stats[k]; }
+long emu_newton_stat(int k) { return g_grx_newton_stats[k]; }
 
 #ifdef GRX_EMU_STAGEHOOK
 // mixed-precision bisection harness (tools/emu_mixed.py): two builds of this file (fp32 / fp64) run the same forward pass stage by stage

@@ -23,6 +23,9 @@ FAMILY_TO_TASK = {"FetchReach": "FetchReach", "FetchPush": "FetchPush", "FetchPi
                   "AdroitPen": "pen", "AdroitRelocate": "relocate", "FrankaKitchen": "kitchen", "HandBlockTouch": "HandBlockTouch"}
 
 
+JITTER = float(os.environ.get("GRX_JITTER", "6e-8"))      # relative amplitude of the --sensitivity perturbation
+
+
 def build(fp64):
     so = f"/tmp/libgrx_emu{'64' if fp64 else '32'}_tol.so"
     src = os.path.join(ROOT, "tests", "emu", "grx_emu.cpp")
@@ -63,7 +66,7 @@ def run_family(L, family, fp64, every=1, only=None, round_inputs=False, ref=None
     def f(a):
         a = np.asarray(a, dtype=np.float32).astype(np.float64) if round_inputs else np.asarray(a, dtype=np.float64)
         if jitter:   # one fp32 ulp of relative noise on every state word: what any engine that holds its state in fp32 sees after one substep
-            a = a * (1.0 + jr.uniform(-1, 1, a.shape) * 6e-8)
+            a = a * (1.0 + jr.uniform(-1, 1, a.shape) * JITTER)
         return np.ascontiguousarray(a, dtype=dt).copy()
     idx = list(range(0, g["obs"].shape[0], every)) if only is None else [only]
     out = np.zeros((len(idx), g["obs"].shape[1]))
@@ -109,7 +112,7 @@ def main(argv):
         for fam in fams:
             ref = run_family(L64, fam, True, every, round_inputs=True, ref="raw")[1]
             worst = None
-            for trial in (1, 2, 3):
+            for trial in range(1, 1 + int(os.environ.get("GRX_JITTER_TRIALS", "3"))):
                 idx, e, status, comps = run_family(L64, fam, True, every, round_inputs=True, ref=ref, jitter=trial)
                 worst = e if worst is None else np.maximum(worst, e)
             for comp, cols in comps.items():
@@ -118,7 +121,11 @@ def main(argv):
         return
     for fam in fams:
         ref = run_family(L64, fam, True, every, round_inputs=True, ref="raw")[1] if rounded else None
+        L.emu_newton_stat.restype = ctypes.c_long
+        n0 = [L.emu_newton_stat(k) for k in range(4)]
         idx, e, status, comps = run_family(L, fam, fp64, every, round_inputs=rounded, ref=ref)
+        n1 = [L.emu_newton_stat(k) - n0[k] for k in range(4)]
+        print(f"{fam:18s} Newton: {n1[0]} solves, {n1[1] / max(n1[0], 1):.3f} iterations / solve, {n1[2] / max(n1[0], 1):.3f} Hessian assemblies / solve, {n1[3] / max(n1[0], 1):.3f} incremental updates / solve", flush=True)
         for comp, cols in comps.items():
             err = e[:, cols].max(axis=1)      # absolute, also for the "_relative" components of tests/tolerance_cases.py
             worst = idx[np.argsort(-err)[:6]]
