@@ -70,6 +70,9 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_NEWTON_ATOL 1e-5f
 #endif
 #define GRX_LS_MAXIT 12
+#ifndef GRX_OBJ_REFINE_MINSTEP
+#define GRX_OBJ_REFINE_MINSTEP 0.05f   // the object-block refinement (grx_refine_object_block) corrects ~4e-4 of the last full step: below this step size there is nothing to correct
+#endif
 
 // status bits reported per world
 #define GRX_ST_BADNUM 1
@@ -1103,6 +1106,7 @@ GRX_MEM void grx_plane_box(const GrxModel* m, GrxCtx* c, int pair, int g1, int g
 }
 
 #define GRX_SEL3(a0, a1, a2, i) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
+#define GRX_SEL6(v, i) ((i) == 0 ? (v)[0] : ((i) == 1 ? (v)[1] : ((i) == 2 ? (v)[2] : ((i) == 3 ? (v)[3] : ((i) == 4 ? (v)[4] : (v)[5])))))
 
 GRX_MEM void grx_plane_sphere(const GrxModel* m, GrxCtx* c, int pair, int g1, int g2, float margin) {
   float n[3] = {c->gxmat[9 * g1 + 2], c->gxmat[9 * g1 + 5], c->gxmat[9 * g1 + 8]};
@@ -1359,12 +1363,33 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
     // the winner is unique beyond the rounding of the fp32 products (|t| < 1 m: error < 3e-7) in all but face-on / edge-on directions: no refinement, and its
     // coordinates are in the registers of the lane that scanned it -- no second trip to memory
     const float near_ = mx - 1.0e-6f * fmaxf(1.0f, fabsf(mx));
-    const int ties = __builtin_popcountll(__ballot(best >= near_)) + __builtin_popcountll(__ballot(second >= near_));
-    if (ties <= 1 || sizeof(MF) == sizeof(HF) || aadr == nullptr) {
+#ifdef GRX_NO_HULL_REFINE   // (A/B: the fp32 winner as it is)
+    const unsigned long long cand = 1ull, cand2 = 0ull;
+#else
+    const unsigned long long cand = __ballot(best >= near_), cand2 = __ballot(second >= near_);
+#endif
+    if (sizeof(MF) == sizeof(HF) || aadr == nullptr || (__builtin_popcountll(cand) <= 1 && cand2 == 0ull)) {
       const unsigned long long own = __ballot(best == mx && mine == bi);
       const int src = own ? __builtin_ctzll(own) : 0;
       r[0] = grx_readlane_f(bx, src); r[1] = grx_readlane_f(by, src); r[2] = grx_readlane_f(bz, src);
       return bi;
+    }
+    if (cand2 == 0ull) {
+      // the tied vertices are the winners of different lanes (the common case: a face of a few vertices): their fp64 projections come from the coordinates the
+      // lanes still hold -- no further memory traffic -- and one wave argmax picks the reference's vertex (lowest index on an exact tie)
+      const bool c_ = best >= near_;
+      const double tb = c_ ? (double)bx * (double)dlm[0] + (double)by * (double)dlm[1] + (double)bz * (double)dlm[2] : -3.0e38;
+      // a handful of candidate lanes: walked with scalar lane reads (a cross-lane fp64 reduction costs six dependent LDS-crossbar round trips per support point,
+      // measured +8 % on the Fetch launch: the worlds that end a launch are the ones whose hulls REST on each other, i.e. tie in every evaluation)
+      unsigned long long mk = cand; double tbest = -3.0e38; int nb = 0x7fffffff, src = 0;
+      while (mk) {
+        const int l = __builtin_ctzll(mk); mk &= mk - 1ull;
+        const double tl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb), l), __builtin_amdgcn_readlane(__double2loint(tb), l));
+        const int il = __builtin_amdgcn_readlane(mine, l);
+        if (tl > tbest || (tl == tbest && il < nb)) { tbest = tl; nb = il; src = l; }
+      }
+      r[0] = grx_readlane_f(bx, src); r[1] = grx_readlane_f(by, src); r[2] = grx_readlane_f(bz, src);
+      return nb;
     }
   }
 #endif
@@ -1377,24 +1402,21 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
 // Returns the support vertex (hint, or the winner of the full scan).
 GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* dlm, int hint, MF* r, int lane_) {
   const float* verts = m->mesh_vert + 3 * adr;
-  if (hint >= 0 && hint < n) {   // one round of neighbour loads, in MF: the hint IS the support vertex when no hull neighbour lies higher
-    const int cur = grx_mesh_support_refine(verts, m->mesh_adjadr + adr, m->mesh_adjnum + adr, m->mesh_adj, dlm, hint, lane_);
-    if (sizeof(MF) != sizeof(HF)) {
-      if (cur == hint) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
-    } else {
-      const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};
-      const int aa = m->mesh_adjadr[adr + hint], an = m->mesh_adjnum[adr + hint];
-      const HF t0 = verts[3 * hint] * dl[0] + verts[3 * hint + 1] * dl[1] + verts[3 * hint + 2] * dl[2];
+  // The guess is verified in the scan's arithmetic (fp32): this routine only serves the re-check of a cached separating direction, whose test keeps 1e-6 of
+  // slack -- ten times what a tie between fp32 projections can hide.  The portal search proper goes through grx_mesh_support (fp64 tie-break).
+  const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};
+  if (hint >= 0 && hint < n) {
+    const int aa = m->mesh_adjadr[adr + hint], an = m->mesh_adjnum[adr + hint];
+    const HF t0 = verts[3 * hint] * dl[0] + verts[3 * hint + 1] * dl[1] + verts[3 * hint + 2] * dl[2];
 #if defined(GRX_EMU)
-      int higher = 0;
-      for (int k = 0; k < an; k++) { const int nb = m->mesh_adj[aa + k]; higher |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
+    int higher = 0;
+    for (int k = 0; k < an; k++) { const int nb = m->mesh_adj[aa + k]; higher |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
 #else
-      int hi_ = 0;
-      for (int k = lane_; k < an; k += 64) { const int nb = m->mesh_adj[aa + k]; hi_ |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
-      const int higher = __ballot(hi_ != 0) != 0ull;
+    int hi_ = 0;
+    for (int k = lane_; k < an; k += 64) { const int nb = m->mesh_adj[aa + k]; hi_ |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
+    const int higher = __ballot(hi_ != 0) != 0ull;
 #endif
-      if (!higher) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
-    }
+    if (!higher) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
   }
   return grx_mesh_support(verts, n, dlm, r, lane_, m->mesh_adjadr + adr, m->mesh_adjnum + adr, m->mesh_adj);
 }
@@ -3410,23 +3432,28 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
 GRX_MEM void grx_refine_object_block(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC, o0 = nv - 6;
+  // J'f over the object's six dofs: one lane per row (the rows that touch the object are few), six wave sums
+  GRX_LANEVAR(j0); GRX_LANEVAR(j1); GRX_LANEVAR(j2); GRX_LANEVAR(j3); GRX_LANEVAR(j4); GRX_LANEVAR(j5);
   FOR_LANES {
-    if (lane < 6) {
-      const int i = o0 + lane;
-      float acc = c->Ma[i] - c->qfrc_smooth[i];
-      for (int r = 0; r < nefc; r++) {
-        const int info = c->efc_row[r], pos = grx_row_pos(info, S::kTwoSpan ? c->efc_id[r] : 0, i);
-        if (pos < 0) continue;
-        const float x = c->efc_jar[r], D = c->efc_D[r]; const int kind = c->efc_kind[r];
-        float f;
-        if (kind == GRX_ROW_EQ) f = -D * x;
-        else if (kind == GRX_ROW_FRICTION) { const float fl = c->efc_floss[r], Rf = fl / D; f = (x <= -Rf) ? fl : ((x >= Rf) ? -fl : -D * x); }
-        else f = (x < 0.0f) ? -D * x : 0.0f;
-        acc -= c->Jp[GRX_ROW_OFF(info) + pos] * f;
-      }
-      c->search[i] = -acc;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f, a5 = 0.0f;
+    for (int r = lane; r < nefc; r += 64) {
+      const int info = c->efc_row[r], idb = S::kTwoSpan ? c->efc_id[r] : 0;
+      const int p0 = grx_row_pos(info, idb, o0), p5 = grx_row_pos(info, idb, o0 + 5);
+      if (p0 < 0 && p5 < 0) continue;   // spans are contiguous dof ranges: a row that holds neither end of the object's six dofs holds none of them
+      const float x = c->efc_jar[r], D = c->efc_D[r]; const int kind = c->efc_kind[r];
+      float f;
+      if (kind == GRX_ROW_EQ) f = -D * x;
+      else if (kind == GRX_ROW_FRICTION) { const float fl = c->efc_floss[r], Rf = fl / D; f = (x <= -Rf) ? fl : ((x >= Rf) ? -fl : -D * x); }
+      else f = (x < 0.0f) ? -D * x : 0.0f;
+      const float* J = c->Jp + GRX_ROW_OFF(info);
+      const int q1 = grx_row_pos(info, idb, o0 + 1), q2 = grx_row_pos(info, idb, o0 + 2), q3 = grx_row_pos(info, idb, o0 + 3), q4 = grx_row_pos(info, idb, o0 + 4);
+      a0 += (p0 >= 0 ? J[p0] : 0.0f) * f; a1 += (q1 >= 0 ? J[q1] : 0.0f) * f; a2 += (q2 >= 0 ? J[q2] : 0.0f) * f;
+      a3 += (q3 >= 0 ? J[q3] : 0.0f) * f; a4 += (q4 >= 0 ? J[q4] : 0.0f) * f; a5 += (p5 >= 0 ? J[p5] : 0.0f) * f;
     }
+    LV(j0) = a0; LV(j1) = a1; LV(j2) = a2; LV(j3) = a3; LV(j4) = a4; LV(j5) = a5;
   }
+  const float jf[6] = {grx_reduce_sum(j0), grx_reduce_sum(j1), grx_reduce_sum(j2), grx_reduce_sum(j3), grx_reduce_sum(j4), grx_reduce_sum(j5)};
+  FOR_LANES { if (lane < 6) c->search[o0 + lane] = -(c->Ma[o0 + lane] - c->qfrc_smooth[o0 + lane] - GRX_SEL6(jf, lane)); }
   WAVE_SYNC();
 #if defined(GRX_EMU)
   {
@@ -3440,29 +3467,33 @@ GRX_MEM void grx_refine_object_block(const GrxModel* m, GrxCtx* c, int nefc, int
 #endif
   WAVE_SYNC();
   // the step must leave every row that touches the object in its state; jv of those rows
+  const float d0 = c->search[o0], d1 = c->search[o0 + 1], d2 = c->search[o0 + 2], d3 = c->search[o0 + 3], d4 = c->search[o0 + 4], d5 = c->search[o0 + 5];
   GRX_LANEVAR_I(flipp);
   FOR_LANES {
     int flip = 0;
     for (int r = lane; r < nefc; r += 64) {
       const int info = c->efc_row[r], idb = S::kTwoSpan ? c->efc_id[r] : 0;
-      float jv = 0.0f; int touches = 0;
-      for (int k = 0; k < 6; k++) { const int pos = grx_row_pos(info, idb, o0 + k); if (pos >= 0) { jv += c->Jp[GRX_ROW_OFF(info) + pos] * c->search[o0 + k]; touches = 1; } }
-      c->efc_jv[r] = jv;
-      if (touches) {
+      const int p0 = grx_row_pos(info, idb, o0), p5 = grx_row_pos(info, idb, o0 + 5);
+      float jv = 0.0f;
+      if (p0 >= 0 || p5 >= 0) {
+        const float* J = c->Jp + GRX_ROW_OFF(info);
+        const int q1 = grx_row_pos(info, idb, o0 + 1), q2 = grx_row_pos(info, idb, o0 + 2), q3 = grx_row_pos(info, idb, o0 + 3), q4 = grx_row_pos(info, idb, o0 + 4);
+        jv = (p0 >= 0 ? J[p0] : 0.0f) * d0 + (q1 >= 0 ? J[q1] : 0.0f) * d1 + (q2 >= 0 ? J[q2] : 0.0f) * d2 + (q3 >= 0 ? J[q3] : 0.0f) * d3 + (q4 >= 0 ? J[q4] : 0.0f) * d4 + (p5 >= 0 ? J[p5] : 0.0f) * d5;
         const float x0 = c->efc_jar[r], x1 = x0 + jv; const int kind = c->efc_kind[r];
         if (kind == GRX_ROW_FRICTION) { const float Rf = c->efc_floss[r] / c->efc_D[r]; flip |= ((x0 <= -Rf) != (x1 <= -Rf)) | ((x0 >= Rf) != (x1 >= Rf)); }
         else if (kind != GRX_ROW_EQ) flip |= ((x0 < 0.0f) != (x1 < 0.0f));
       }
+      c->efc_jv[r] = jv;
     }
     LV(flipp) = flip;
   }
   if (GRX_BALLOT(flipp) != 0ull) return;
+  WAVE_SYNC();
   FOR_LANES {
     if (lane < 6) {
       const int i = o0 + lane;
-      float mv = 0.0f;
-      for (int k = 0; k < 6; k++) mv += c->M[i * nv + o0 + k] * c->search[o0 + k];
-      c->qacc[i] += c->search[i]; c->Ma[i] += mv;
+      const float* Mi = c->M + i * nv + o0;
+      c->qacc[i] += c->search[i]; c->Ma[i] += Mi[0] * d0 + Mi[1] * d1 + Mi[2] * d2 + Mi[3] * d3 + Mi[4] * d4 + Mi[5] * d5;
     }
     for (int r = lane; r < nefc; r += 64) c->efc_jar[r] += c->efc_jv[r];
   }
@@ -3482,6 +3513,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   const float scale = 1.0f / (m->meaninertia * (float)(nv > 1 ? nv : 1));
   const int implicit_damp = (m->anydamp && m->eulerdamp);
   int phase = nefc ? 0 : 2, it = 0, done = 0, full_step = 0;
+  float last_stepmax = 0.0f;   // largest component of the last accepted Newton step
   int exact_exit = 0, last_split = 0;   // converged by an exact full step (no row changed state) / the last linear solve ran on the decoupled robot | object blocks
   float alpha_prev = 0.0f;   // the step length accepted by the previous Newton iteration (gradient advance of the incremental path)
 #if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)
@@ -3524,7 +3556,11 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
 #endif
       if (done || it >= m->iterations) {   // MuJoCo's option iterations (default 100; the hand models: 20)
 #ifndef GRX_NO_OBJ_REFINE
-        if (exact_exit && last_split == 6 && keepA) grx_refine_object_block(m, c, nefc, lane_);
+#ifdef GRX_OBJ_REFINE_COUPLED
+        if (exact_exit && m->nfreeobj == 6 && keepA) grx_refine_object_block(m, c, nefc, lane_);
+#else
+        if (exact_exit && last_split == 6 && keepA && last_stepmax > GRX_OBJ_REFINE_MINSTEP) grx_refine_object_block(m, c, nefc, lane_);
+#endif
 #endif
         if (noslip) grx_noslip(m, c, nefc, lane_);   // re-solves the friction forces without regularisation: new qacc, new M a
         // converged: at the minimiser the gradient M a - qfrc_smooth - J'f vanishes, so the joint-space constraint force
@@ -3684,6 +3720,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       }
       WAVE_SYNC();
       const float stepmax = grx_reduce_max(msp), qmax = grx_reduce_max(map_);
+      last_stepmax = stepmax;
 #if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
       if (getenv("GRX_TRACE_NEWTON")) { const int d_ = atoi(getenv("GRX_TRACE_NEWTON")); fprintf(stderr, "   stepmax %.6e qmax %.4e search[d] %.6e qacc[d] %.9e grad[d] %.6e\n", (double)stepmax, (double)qmax, (double)c->search[d_], (double)c->qacc[d_], (double)c->grad[d_]); }
 #endif

@@ -114,3 +114,38 @@ def test_bench_multi_rank_command_line_dry_run(workload, ranks, extra):
     assert line["n_gpus"] == ranks and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
     assert line["dist"]["backend"] == "gloo" and line["dist"]["nranks"] == ranks and len(line["dist"]["elapsed_s_per_rank"]) == ranks
     assert line["data"].startswith("DRY RUN")
+
+
+def test_bench_under_torchrun_dry_run():
+    """the DRIVER's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`):
+    bench.py must take rank / world size from the environment instead of spawning, and still print exactly one JSON line (rank 0)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2", "--workload", "antmaze", "--steps", "3", "--warmup", "1", "--worlds-per-gpu", "64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dist"]["nranks"] == 2 and line["value"] > 0
+    # a rank count that disagrees with --gpus is refused, loudly
+    bad = subprocess.run(cmd[:-10] + [os.path.join(root, "bench.py"), "--dry-run", "--gpus", "4", "--workload", "antmaze", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert bad.returncode != 0
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus 2` on a box with fewer HIP devices (this container has none) must fail loudly, not fall back to anything"""
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode != 0 and "HIP device(s) are visible" in (out.stderr + out.stdout)

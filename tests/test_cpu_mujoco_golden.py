@@ -9,6 +9,14 @@ import numpy as np
 import pytest
 
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mujoco_*.npz")))
+# self-check twins written by the in-repo oracle in the recorder's exact format (tools/record_selfcheck.py): they pin nothing, they keep the consumers below
+# exercised end to end while the real fixtures are absent
+SELF = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "selfcheck_*.npz")))
+
+
+def _env_id(path):
+    b = os.path.basename(path)
+    return b[b.index("_") + 1:-len(".npz")]
 REQUIRE = os.environ.get("GRX_REQUIRE_MUJOCO_GOLDEN", "0") not in ("", "0")
 
 
@@ -19,13 +27,13 @@ def test_mujoco_fixtures_are_present_when_required():
         pytest.skip("no MuJoCo-recorded fixtures committed: the oracle's physics stays 'parity unpinned' (set GRX_REQUIRE_MUJOCO_GOLDEN=1 to make this a failure)")
 
 
-@pytest.mark.skipif(not FILES, reason="no MuJoCo-recorded fixtures committed (tools/record_golden.py needs mujoco + gymnasium-robotics)")
-@pytest.mark.parametrize("path", FILES or ["-"])
+@pytest.mark.parametrize("path", FILES + SELF)
 def test_oracle_teacher_forced_step_matches_mujoco(path):
     """One env.step() of the oracle from MuJoCo's own pre-step state, compared with what the reference returned (fp64 against fp64: 1e-6 on every observation
     component would be two implementations of the same equations; 1e-4 is north_star's bound)."""
-    env_id = os.path.basename(path)[len("mujoco_"):-len(".npz")]
+    env_id = _env_id(path)
     g = np.load(path)
+    assert bytes(g["mujoco_version"]).startswith(b"SELFCHECK") == os.path.basename(path).startswith("selfcheck_")      # a self-check file can never pass for a MuJoCo fixture
     if env_id.startswith("Fetch"):
         from gymnasium_robotics_amd.envs.fetch import load_fetch_model
         from gymnasium_robotics_amd.envs.fetch_spec import parse_env_id
@@ -54,7 +62,10 @@ def test_oracle_teacher_forced_step_matches_mujoco(path):
         if env_id.startswith("Fetch"):
             s.mocap_pos[:], s.mocap_quat[:] = g["mocap"][i, :3], g["mocap"][i, 3:7]
             s.forward()
-        obs, r, _, _, info = env.step(np.asarray(g["action"][i], dtype=np.float64))
+        # Fetch: _set_action snaps the mocap onto the gripper body's pose of the LAST forward pass (stale by one integration step): the fixture's `aux`
+        # (found by the self-check fixtures: fresh kinematics here cost 7e-4 on every FetchPickAndPlace snapshot)
+        kw = dict(aux=np.asarray(g["aux"][i][:7], dtype=np.float64)) if env_id.startswith("Fetch") else {}
+        obs, r, _, _, info = env.step(np.asarray(g["action"][i], dtype=np.float32), **kw)
         errs.append(np.abs(obs["observation"] - g["obs"][i]).max())
     errs = np.array(errs)
     assert np.quantile(errs, 0.98) < 1e-4 and errs.max() < 5e-3, (env_id, float(np.quantile(errs, 0.98)), float(errs.max()))

@@ -29,10 +29,11 @@ def test_egg_teacher_forced_step_matches_golden():
     assert int(info["status"].max()) == 0
     e = np.abs(obs["observation"] - g["obs"])
     pe, ve = np.maximum(e[:, :24].max(axis=1), e[:, 54:].max(axis=1)), e[:, 24:54].max(axis=1)
-    # north_star's bound on EVERY snapshot for the position components (measured max 5.8e-6 since the portal routine compares against libccd's own
-    # epsilon, grx_engine.h GRX_MPR_EPS; round 2: 79 % within 1e-4, max 6.5e-3); velocities: >= 95 % within 1e-4 (tests/golden/tolerance_table.json)
-    assert pe.max() < 1e-4, float(pe.max())
-    assert np.mean(ve < 1e-4) >= 0.95 and ve.max() < 5e-3, (float(np.mean(ve < 1e-4)), float(ve.max()))
+    # north_star's bound on every snapshot away from an activation boundary (tests/test_gpu_tolerance_table.py), positions AND velocities, and on >= 99 % of all
+    # (the portal routine runs in fp64: round 3 had 96 % of the velocities; one snapshot, gap 5e-7, loses a contact the oracle lists at dist -5e-7 in the last substep)
+    posed = g["activation_gap"] >= 1e-6
+    assert pe[posed].max() < 1e-4 and ve[posed].max() < 1e-4, (float(pe[posed].max()), float(ve[posed].max()))
+    assert np.mean(pe < 1e-4) >= 0.99 and np.mean(ve < 1e-4) >= 0.99, (float(np.mean(pe < 1e-4)), float(np.mean(ve < 1e-4)))
     assert np.median(pe) < 1e-6 and np.median(ve) < 1e-4, (float(np.median(pe)), float(np.median(ve)))
     from gymnasium_robotics_amd.envs.manipulate_spec import block_goal_distance
 
@@ -74,12 +75,12 @@ def test_slide_teacher_forced_step_matches_golden():
     obs, r, term, trunc, info = env.step(g["action"])
     assert int(np.abs(info["status"]).max()) == 0
     e = np.abs(obs["observation"] - g["obs"])
-    rot = np.r_[11:14, 17:20]           # puck rotation / rotational velocity: the one flat-cap contact has no unique position
-    assert np.mean(e[:, 11:14].max(axis=1) < 1e-4) >= 0.95 and e[:, 11:14].max() < 1e-3 and e[:, 17:20].max() < 1e-2      # measured: 97 % / 2.1e-4 / 1.9e-3 (round 2: 46 % / 1.9e-3 / 5.7e-3)
-    et = np.delete(e, rot, axis=1).max(axis=1)
-    posed = g["activation_gap"] >= 2e-5
-    assert et[posed].max() < 1e-4 and et.max() < 5e-3, (float(et[posed].max()), float(et.max()))
-    assert np.median(et) < 1e-5
+    # the puck's rotation / rotational velocity too (round 3: 97 % / 84 % within 1e-4, max 2e-3: the fp32 Hessian resolves the puck's rocking mode to 4e-4 of a
+    # Newton step; grx_refine_object_block): every observation component, every snapshot away from an activation boundary
+    et = e.max(axis=1)
+    posed = g["activation_gap"] >= 1e-6
+    assert posed.mean() > 0.7 and et[posed].max() < 1e-4 and et.max() < 5e-3, (float(et[posed].max()), float(et.max()))
+    assert np.mean(et < 1e-4) >= 0.99 and np.median(et) < 1e-5
     d = np.linalg.norm(g["achieved"] - g["goal"], axis=-1)
     safe = np.abs(d - 0.05) > 1e-5
     assert np.array_equal(r[safe], g["reward"][safe].astype(np.float32))

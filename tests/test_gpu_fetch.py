@@ -43,15 +43,14 @@ def test_teacher_forced_step_matches_golden(task):
     obs, r, term, trunc, info = env.step(g["action"])
     assert int(np.abs(info["status"]).max()) == 0
     err = np.abs(obs["observation"] - g["obs"]).max(axis=1)
-    # fp32 vs the fp64 oracle.  MuJoCo's soft constraints are discontinuous at (de)activation: when a contact or a joint
-    # limit crosses dist == margin with non-zero approach speed the reference acceleration -b*v - k*d*r jumps, so a
-    # snapshot in which some unilateral row came within the fp32 drift (~1e-5 m over 20 substeps of stiff contact) of
-    # that boundary can legitimately differ by O(h*b*v) ~ 1e-3.  The oracle records the closest approach per snapshot
-    # ("activation_gap").  Asserted: (1) every snapshot away from a boundary is within 1e-4, (2) at least 98 % of ALL
-    # snapshots are within 1e-4, (3) nothing is off by more than 5e-3.
-    posed = g["activation_gap"] >= 2e-5
+    # fp32 vs the fp64 oracle.  MuJoCo's soft constraints are discontinuous where a row switches on or off (a contact is listed when dist < margin, and the reference
+    # acceleration -b*v - k*d*r jumps by b*v): the oracle records per snapshot how close any such switch came to its threshold during the step ("activation_gap",
+    # tests/test_gpu_tolerance_table.py).  Asserted: (1) EVERY snapshot whose gap is at least 1e-6 m -- ten times the resolution an fp32 state has at 1 m -- is
+    # within 1e-4, (2) at least 99 % of ALL snapshots are, (3) nothing is off by more than 5e-3.
+    posed = g["activation_gap"] >= 1e-6
+    assert posed.mean() > 0.7
     assert err[posed].max() < TOL, f"worst snapshot {np.nonzero(posed)[0][err[posed].argmax()]} err {err[posed].max():.3e}"
-    assert np.mean(err < TOL) >= 0.98, f"only {100 * np.mean(err < TOL):.1f}% of snapshots within 1e-4"
+    assert np.mean(err < TOL) >= 0.99, f"only {100 * np.mean(err < TOL):.1f}% of snapshots within 1e-4"
     assert err.max() < 5e-3, f"snapshot {err.argmax()} err {err.max():.3e} gap {g['activation_gap'][err.argmax()]:.2e}"
     assert np.abs(obs["achieved_goal"] - g["achieved"])[posed].max() < TOL
     print(f"{task}: {posed.sum()}/{n} snapshots away from activation boundaries, max err there {err[posed].max():.2e}; all: p50 {np.median(err):.2e} "
@@ -75,8 +74,8 @@ def test_teacher_forced_step_matches_golden(task):
 def test_teacher_forced_hull_contacts_match_golden():
     """Hull-vs-convex narrow phase (mesh-mesh / mesh-box pairs of the Fetch links, assets/fetch/robot.xml:16-93): 168 snapshots of scripted
     rollouts that fold the arm into the head / torso and press the wrist / gripper housing onto the table (tools/make_golden_hull.py), 147 of
-    them with hull contacts.  A face-face hull contact has no unique contact point (any point of the overlap polygon), so fp32 and fp64 portal
-    refinements legitimately differ there: the median is held at rounding level, the tail is bounded."""
+    them with hull contacts.  The portal refinement and its support functions run in fp64 on the device (GRX_MPR_REAL; the fp32 vertex scan's winner is refined
+    over the hull graph): every snapshot away from an activation boundary is within north_star's 1e-4 (measured max 4e-6; round 3: 98.2 %, max 1.7e-3)."""
     g = np.load(os.path.join(GOLDEN, "fetch_hull_teacher.npz"))
     n = g["obs"].shape[0]
     env = _env("FetchPickAndPlace", n, autoreset_mode="disabled", max_episode_steps=None)
@@ -88,8 +87,9 @@ def test_teacher_forced_hull_contacts_match_golden():
     hull = g["hull_contacts"] > 0
     print(f"hull snapshots: p50 {np.median(err[hull]):.2e} p90 {np.quantile(err[hull], 0.9):.2e} max {err[hull].max():.2e}; others max {err[~hull].max():.2e}")
     assert hull.sum() > 120
-    assert np.median(err[hull]) < 2e-5 and np.quantile(err[hull], 0.9) < 1e-3 and err.max() < 2e-2
-    assert err[~hull].max() < TOL
+    posed = g["activation_gap"] >= 1e-6
+    assert posed.mean() > 0.9 and err[posed].max() < TOL and np.mean(err < TOL) >= 0.99, (float(err[posed].max()), float(np.mean(err < TOL)))
+    assert np.median(err[hull]) < 2e-6 and err.max() < 5e-3
 
 
 def test_compacted_reset_kernel_matches_masked_forward():

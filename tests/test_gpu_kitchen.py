@@ -56,11 +56,12 @@ def test_teacher_forced_step_matches_golden():
     e = np.abs(obs["observation"] - g["obs"])
     pos, vel = np.concatenate([e[:, :9], e[:, 18:39]], axis=1).max(axis=1), np.concatenate([e[:, 9:18], e[:, 39:]], axis=1).max(axis=1)
     print(f"positions p50 {np.median(pos):.2e} p95 {np.quantile(pos, 0.95):.2e} max {pos.max():.2e}; velocities p50 {np.median(vel):.2e} p90 {np.quantile(vel, 0.9):.2e} max {vel.max():.2e}")
-    # 14 of the 248 fixtures, all from the contact-rich starts (arm geoms pressed against the scene, contacts switching on and off inside the step,
-    # hull / cylinder contacts through the portal routine), are off by 1e-4 ... 5e-3: the activation-flip and single-point-contact sensitivity of
-    # DESIGN.md section 7; the other 94 % sit at 4e-7
-    assert np.quantile(pos, 0.9) < 1e-4 and np.quantile(pos, 0.95) < 1e-3 and pos.max() < 1e-2
-    assert np.median(vel) < 1e-4 and np.quantile(vel, 0.9) < 5e-3 and vel.max() < 0.5
+    # north_star's bound on every snapshot away from an activation boundary (tests/test_gpu_tolerance_table.py) and on >= 99 % of all: round 3 had 14 of the 248
+    # fixtures off by 1e-4 ... 7e-2 (hull / cylinder contacts through the fp32 portal routine); two remain, both with a finger-pad contact listed or not within
+    # 2e-7 m of its margin in one of the 40 substeps
+    posed = g["activation_gap"] >= 1e-6
+    assert posed.mean() > 0.7 and pos[posed].max() < 1e-4 and vel[posed].max() < 1e-4, (float(pos[posed].max()), float(vel[posed].max()))
+    assert np.mean(pos < 1e-4) >= 0.99 and np.mean(vel < 1e-4) >= 0.99 and pos.max() < 1e-2 and vel.max() < 0.5
     assert np.array_equal(env.completed.cpu().numpy(), g["completed"])
     # every fixture world is a fresh episode with all seven tasks open: reward = number of tasks inside their threshold (kitchen_env.py:340-354)
     assert np.array_equal(r, np.array([bin(int(c)).count("1") for c in g["completed"]], dtype=np.float64))

@@ -29,10 +29,10 @@ def test_teacher_forced_step_matches_golden(env_and_golden):
     assert int(info["status"].max()) == 0
     e = np.abs(obs["observation"] - g["obs"])
     pe, ve = np.maximum(e[:, :24].max(axis=1), e[:, 54:].max(axis=1)), e[:, 24:54].max(axis=1)
-    far = g["activation_gap"] >= 2e-5
-    # the bars are the committed table's (tests/golden/tolerance_table.json, HandBlock): every snapshot's positions inside north_star's 1e-4
-    # (measured max 1.8e-6), velocities max 1.05e-4 with 99.6 % inside
-    assert pe.max() < 1e-4 and ve.max() < 3e-4 and np.mean(ve < 1e-4) >= 0.99, (float(pe.max()), float(ve.max()))
+    far = g["activation_gap"] >= 1e-6
+    # every snapshot's positions inside north_star's 1e-4 (measured max 2e-6); velocities (up to 20 rad/s): inside on every snapshot away from an activation boundary
+    # but one at 1.05e-4 (snapshot 112), 99.6 % of all
+    assert pe.max() < 1e-4 and ve.max() < 2e-4 and np.mean(ve < 1e-4) >= 0.99 and np.mean(ve[far] < 1e-4) >= 0.99, (float(pe.max()), float(ve.max()))
     assert np.median(pe) < 1e-6 and np.median(ve) < 5e-5
     from gymnasium_robotics_amd.envs.manipulate_spec import block_goal_distance
     _, d_rot = block_goal_distance(g["achieved"], g["goal"], "ignore", "xyz")
@@ -109,7 +109,7 @@ def test_touch_sensor_variants_match_golden():
         env.close()
     cont, boolean = outs["HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1"], outs["HandManipulateBlockRotateXYZ_BooleanTouchSensors-v1"]
     ref = g["obs"][:, 61:]
-    far = g["activation_gap"] >= 2e-5
+    far = g["activation_gap"] >= 1e-6
     assert np.array_equal(cont[far, 61:] > 0, ref[far] > 0)
     scale = np.maximum(1.0, ref.max(axis=1, keepdims=True))
     assert (np.abs(cont[:, 61:] - ref) / scale)[far].max() < 2e-3
@@ -138,8 +138,8 @@ def test_pen_variant_matches_golden_and_reference_distance():
     assert int(info["status"].max()) == 0
     e = np.abs(obs["observation"] - g["obs"])
     pe = np.maximum(e[:, :24].max(axis=1), e[:, 54:].max(axis=1))
-    far = g["activation_gap"] >= 2e-5
-    assert pe[far].max() < 2e-4 and pe.max() < 5e-3 and np.median(pe) < 1e-5
+    far = g["activation_gap"] >= 1e-6
+    assert pe[far].max() < 1e-4 and pe.max() < 5e-3 and np.median(pe) < 1e-5
     # the device's ignore-z goal distance against vectors produced by the reference's own rotations.py (dense reward = -d_rot here)
     ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_rotations.npz"))
     pose = lambda q: np.concatenate([np.zeros((len(q), 3)), q], axis=1).astype(np.float32)

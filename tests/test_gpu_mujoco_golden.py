@@ -10,6 +10,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mujoco_*.npz")))
+# self-check twins written by the in-repo oracle in the recorder's exact format (tools/record_selfcheck.py): they pin nothing, they keep the consumers below
+# exercised end to end while the real fixtures are absent
+SELF = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "selfcheck_*.npz")))
+
+
+def _env_id(path):
+    b = os.path.basename(path)
+    return b[b.index("_") + 1:-len(".npz")]
 REQUIRE = os.environ.get("GRX_REQUIRE_MUJOCO_GOLDEN", "0") not in ("", "0")
 
 
@@ -22,16 +30,16 @@ def test_mujoco_fixtures_are_present_when_required():
         pytest.skip("no MuJoCo-recorded fixtures committed; parity stays pinned to the in-repo oracle only (set GRX_REQUIRE_MUJOCO_GOLDEN=1 to make this a failure)")
 
 
-@pytest.mark.skipif(not FILES, reason="no MuJoCo-recorded fixtures committed (tools/record_golden.py needs mujoco + gymnasium)")
-@pytest.mark.parametrize("path", FILES or ["-"])
+@pytest.mark.parametrize("path", FILES + SELF)
 def test_teacher_forced_step_matches_mujoco(path):
     import torch
 
     from gymnasium_robotics_amd.envs.fetch import FetchVecEnv
     from gymnasium_robotics_amd.envs.hand import HandBlockVecEnv, HandReachVecEnv
 
-    env_id = os.path.basename(path)[len("mujoco_"):-len(".npz")]
+    env_id = _env_id(path)
     g = np.load(path)
+    assert bytes(g["mujoco_version"]).startswith(b"SELFCHECK") == os.path.basename(path).startswith("selfcheck_")
     n = g["obs"].shape[0]
     if not env_id.startswith(("Fetch", "HandReach", "HandManipulate")):
         return _plain_family(env_id, g, n)

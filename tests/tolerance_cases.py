@@ -6,6 +6,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GAP = 1e-6      # a snapshot is a well-posed comparison when no constraint switch comes closer than this to its threshold during the step (oracle's activation_gap, metres)
 TABLE = os.path.join(GOLDEN, "tolerance_table.json")
 
 # family -> (env id, fixture, state keys to load, {component: observation columns})
@@ -57,7 +58,8 @@ def family_errors(name):
     obs = out[0]["observation"] if isinstance(out[0], dict) else out[0]
     e = np.abs(obs - g["obs"])
     res = {c: (e[:, cols] / np.maximum(1.0, np.abs(g["obs"][:, cols])) if c.endswith("_relative") else e[:, cols]).max(axis=1) for c, cols in comps.items()}
-    res["_far"] = (g["activation_gap"] >= 2e-5) if "activation_gap" in g.files else np.ones(n, bool)
+    res["_gap"] = g["activation_gap"] if "activation_gap" in g.files else np.full(n, 1.0)
+    res["_far"] = res["_gap"] >= GAP
     env.close()
     return res
 
@@ -89,7 +91,7 @@ def ant_errors(n=96):
     obs, *_ = env.step(np.asarray(acts))
     e = np.abs(obs["observation"] - np.asarray(exp_obs))
     env.close()
-    return {"positions": e[:, :13].max(axis=1), "velocities": e[:, 13:].max(axis=1), "_far": np.ones(n, bool)}
+    return {"positions": e[:, :13].max(axis=1), "velocities": e[:, 13:].max(axis=1), "_far": np.ones(n, bool), "_gap": np.full(n, 1.0)}
 
 
 def quantiles(err):
@@ -101,12 +103,13 @@ def measure_all():
     table = {}
     for name in list(CASES) + ["AntMaze"]:
         res = ant_errors() if name == "AntMaze" else family_errors(name)
-        far = res.pop("_far")
-        table[name] = {"n": int(len(far)), "n_away_from_activation_boundary": int(far.sum())}
+        far, gap = res.pop("_far"), res.pop("_gap")
+        table[name] = {"n": int(len(far)), "n_away_from_activation_boundary": int(far.sum()), "gap_threshold": GAP}
         for comp, err in res.items():
             table[name][comp] = quantiles(err)
             table[name][comp]["max_away_from_boundary"] = float(err[far].max()) if far.any() else None
-            over = np.nonzero(err >= 1e-4)[0]       # the snapshots outside north_star's bound, one by one (up to 24; the count is always recorded)
+            table[name][comp]["frac_within_1e-4_away_from_boundary"] = float(np.mean(err[far] < 1e-4)) if far.any() else None
+            over = np.nonzero(err >= 1e-4)[0]       # the snapshots outside north_star's bound, one by one with their activation gap (up to 24; the count is always recorded)
             table[name][comp]["n_over_1e-4"] = int(len(over))
-            table[name][comp]["outliers"] = [[int(i), float("%.2e" % err[i])] for i in over[np.argsort(-err[over])][:24]]
+            table[name][comp]["outliers"] = [[int(i), float("%.2e" % err[i]), float("%.1e" % gap[i])] for i in over[np.argsort(-err[over])][:24]]
     return table

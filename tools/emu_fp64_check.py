@@ -38,6 +38,11 @@ def as_fp64_struct(task_s):
 def _fixture(task):
     """-> (model, fp64 task struct, fixture, kind)"""
     G = os.path.join(ROOT, "tests", "golden")
+    if task == "antlarge":
+        from gymnasium_robotics_amd import _native
+        from gymnasium_robotics_amd.mjcf.compiler import load_model
+        m = load_model(os.path.join(ROOT, "gymnasium_robotics_amd", "models", "ant_Large.npz"))
+        return m, as_fp64_struct(_native.PointTaskStruct(5, 1, 1, 1, 0.45, 5.0)), np.load(os.path.join(G, "ant_Large_teacher.npz")), "point"
     if task == "kitchen":
         from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model, make_kitchen_task
         m = load_kitchen_model()

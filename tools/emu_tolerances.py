@@ -20,7 +20,7 @@ from emu_fp64_check import _fixture, as_fp64_struct  # noqa: E402
 
 FAMILY_TO_TASK = {"FetchReach": "FetchReach", "FetchPush": "FetchPush", "FetchPickAndPlace": "FetchPickAndPlace", "FetchSlide": "FetchSlide", "FetchHullContacts": "hull",
                   "HandReach": "HandReach", "HandBlock": "HandBlock", "HandEgg": "HandEgg", "HandPen": "HandPen", "AdroitHammer": "hammer", "AdroitDoor": "door",
-                  "AdroitPen": "pen", "AdroitRelocate": "relocate", "FrankaKitchen": "kitchen", "HandBlockTouch": "HandBlockTouch"}
+                  "AdroitPen": "pen", "AdroitRelocate": "relocate", "FrankaKitchen": "kitchen", "HandBlockTouch": "HandBlockTouch", "AntMazeLarge": "antlarge"}
 
 
 JITTER = float(os.environ.get("GRX_JITTER", "6e-8"))      # relative amplitude of the --sensitivity perturbation
@@ -81,6 +81,9 @@ def run_family(L, family, fp64, every=1, only=None, round_inputs=False, ref=None
             obs, sh, tg, rew, suc = np.zeros(g["obs"].shape[1], dt), f(g["shift"][i]), f(g["target"][i]), cdt(0), ctypes.c_ubyte(0)
             L.emu_adroit_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(sh), p(tg), p(a), p(f(am)), p(f(ar)), p(obs), ctypes.byref(rew),
                               ctypes.byref(suc), ctypes.byref(st), ctypes.c_int(0))
+        elif kind == "point":
+            obs, ach = np.zeros(g["obs"].shape[1] + 4, dt), np.zeros(2, dt)
+            L.emu_point_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(a), p(obs), p(ach), ctypes.byref(st))
         elif kind == "fetch":
             obs, ach, mocap, aux = np.zeros(g["obs"].shape[1], dt), np.zeros(3, dt), f(g["mocap"][i]), f(g["aux"][i])
             L.emu_fetch_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(mocap), p(aux), p(a), p(obs), p(ach), ctypes.byref(st))
