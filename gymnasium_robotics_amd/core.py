@@ -156,7 +156,10 @@ def create_rerun_model(L, model, device_index, enabled=True):
 
     if not enabled or os.environ.get("GRX_NO_OVERFLOW_RERUN") is not None:
         return None
-    H, I, F = model.with_capacity(**RERUN_CAPACITY).pack()
+    cap = dict(RERUN_CAPACITY)
+    if os.environ.get("GRX_RERUN_CAPACITY"):      # "rows,pool,contacts" (experiments: which large tables leave no world of a workload with a truncated list)
+        cap = dict(zip(("maxefc", "jpool", "maxcon"), (int(x) for x in os.environ["GRX_RERUN_CAPACITY"].split(","))))
+    H, I, F = model.with_capacity(**cap).pack()
     h = ctypes.c_void_p()
     _native.check(L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, device_index, ctypes.byref(h)))
     return h

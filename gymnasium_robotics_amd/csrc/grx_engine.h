@@ -64,7 +64,7 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_MAXCON 64    // largest contact-list capacity per world: one lane per contact in the per-contact passes (the large tables of the overflow lane)
 #define GRX_MAXCON_DEFAULT 32   // capacity of a model that does not request one (the fast kernels: 16 - 32)
 #define GRX_MAXEFC 144   // default constraint rows per world (models with wide contact rows get more: grx_pack_model)
-#define GRX_JPOOL 2032    // default words of packed Jacobian storage per world (rows are stored over their dof span only); < 4096 (12-bit row offsets)
+#define GRX_JPOOL 2032    // default words of packed Jacobian storage per world (rows are stored over their dof span only); < 16384 (14-bit row offsets)
 #ifndef GRX_NEWTON_RTOL
 #define GRX_NEWTON_RTOL 1e-5f
 #define GRX_NEWTON_ATOL 1e-5f
@@ -117,7 +117,7 @@ struct GrxCtx {
   float *con_dist, *con_pos, *con_frame;
   int *con_pair, *con_efc, *con_nr, *con_b1, *con_b2, *con_span, *con_ioff;  // con_span = loA | lenA << 8 | loB << 16 | lenB << 24 (pair_span); con_ioff = first item of the contact-Jacobian pass
   // constraint rows
-  // Jacobian rows are stored packed: row r covers dofs [lo, lo+len) at Jp[off .. off+len); efc_row[r] = off | lo << 12 | len << 20
+  // Jacobian rows are stored packed: row r covers dofs [lo, lo+len) at Jp[off .. off+len); efc_row[r] = off | lo << 14 | len << 21 (GRX_ROW_PACK)
   float *Jp, *efc_pos, *efc_D, *efc_aref, *efc_jar, *efc_jv, *efc_force, *efc_floss;
   int *efc_kind, *efc_id, *efc_quad, *efc_row;  // efc_id packs (id << 4) | sub
   // scratch
@@ -1297,6 +1297,8 @@ struct GrxMprPair { MF R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // 
                     long long* prof;
 #endif
                   };                                            // wave-cooperative variant: LDS storage of the five portal points (keeps them out of the VGPR budget)
+// (Round 4, measured and removed: the scan as a leaf function behind a real call or inline with 16-byte vertex records and 8 - 16 loads in flight per lane -- one memory
+// round per hull instead of three -- is 12 % SLOWER on the Fetch launch, profiles/ab_r04_fetch_scan4.txt: the registers it needs are spilled by the substep loop.)
 // Convex hull of a mesh: the hull vertex farthest along the (geom-frame) direction dl; the lowest vertex index wins ties, like the oracle's
 // exhaustive scan.  Called from wave-uniform code: on the GPU the 64 lanes share the scan (lane l takes the vertices l, l + 64, ...; the
 // loads are coalesced) and agree on the winner through two DPP reductions -- a hull of 500 vertices costs 8 loads per lane.
@@ -2604,10 +2606,12 @@ GRX_MEM void grx_mask_span(unsigned long long msk, int* lo, int* len) {
 GRX_MEM unsigned long long grx_chainmask(const GrxModel* m, int b) {
   return ((unsigned long long)(unsigned)m->dof_chainmask[2 * b + 1] << 32) | (unsigned)m->dof_chainmask[2 * b];
 }
-#define GRX_ROW_OFF(info) ((info) & 0xFFF)
-#define GRX_ROW_LO(info) (((info) >> 12) & 0xFF)
-#define GRX_ROW_LEN(info) (((info) >> 20) & 0xFF)
-#define GRX_ROW_PACK(off, lo, len) ((off) | ((lo) << 12) | ((len) << 20))
+// efc_row[r] = off | lo << 14 | len << 21: 14-bit pool offsets (the large tables of the overflow lane hold up to 16 368 words), dof spans below 128
+#define GRX_ROW_OFF(info) ((info) & 0x3FFF)
+#define GRX_ROW_LO(info) (((info) >> 14) & 0x7F)
+#define GRX_ROW_LEN(info) (((info) >> 21) & 0x7F)
+#define GRX_ROW_PACK(off, lo, len) ((off) | ((lo) << 14) | ((len) << 21))
+#define GRX_ROW_FROM_STATIC(x) GRX_ROW_PACK((x) & 0xFFF, ((x) >> 12) & 0xFF, ((x) >> 20) & 0xFF)   // the compiler's static rows (weld_row, jeq_row): off | lo << 12 | len << 20
 // Second dof span of a row (contacts whose two body chains leave a gap of unused dofs between them): it rides in the upper bits of
 // efc_id = sub | id << 4 | loB << 12 | lenB << 20, and its entries follow the first span's entries in the pool.
 #define GRX_ROW_IDOF(id) (((id) >> 4) & 0xFF)
@@ -2727,12 +2731,12 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   // ---- descriptors
   FOR_LANES {
     if (lane < nwr) {  // welds: spans and pool offsets are static (weld_row)
-      const int r = lane, w = r / 6, sub = r - 6 * w, info0 = m->weld_row[w];
+      const int r = lane, w = r / 6, sub = r - 6 * w, info0 = GRX_ROW_FROM_STATIC(m->weld_row[w]);
       c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (m->weld_eq[w] << 4) | sub;
       c->efc_row[r] = info0 + sub * GRX_ROW_LEN(info0);  // the offset field is the low one: adding sub*len moves to row sub
     } else if (lane < ne) {  // joint equalities (sub 8: their invweight sits in the second eq_invweight slot too)
       const int r = lane, j = r - nwr;
-      c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (m->jeq_eq[j] << 4) | 8; c->efc_row[r] = m->jeq_row[j];
+      c->efc_kind[r] = GRX_ROW_EQ; c->efc_id[r] = (m->jeq_eq[j] << 4) | 8; c->efc_row[r] = GRX_ROW_FROM_STATIC(m->jeq_row[j]);
     }
     if ((S::kFixed ? S::NF > 0 : true) && nf > 0)   // compile-time dead for the shapes without friction-loss dofs
       for (int d = lane; d < nv; d += 64) {

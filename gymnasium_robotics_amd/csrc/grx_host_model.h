@@ -73,7 +73,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   // with wide / tall contact rows (dims slots GRX_MAXEFC_REQ / GRX_JPOOL_REQ, 0 = default); row offsets are 12-bit.
   m.maxefc = d[GRX_MAXEFC_REQ] > 0 ? ((d[GRX_MAXEFC_REQ] + 15) / 16) * 16 : GRX_MAXEFC;
   m.jpool = d[GRX_JPOOL_REQ] > 0 ? ((d[GRX_JPOOL_REQ] + 15) / 16) * 16 : GRX_JPOOL;
-  if (m.jpool > 4080) m.jpool = 4080;
+  if (m.jpool > 16368) m.jpool = 16368;   // 14-bit row offsets (GRX_ROW_PACK)
   m.maxcon = (d[GRX_MAXCON_REQ] > 0 && d[GRX_MAXCON_REQ] <= GRX_MAXCON) ? d[GRX_MAXCON_REQ] : GRX_MAXCON_DEFAULT;
   {
     static const int hand_parent[24] = GRX_HAND_DOF_PARENTS;
