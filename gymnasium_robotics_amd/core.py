@@ -110,7 +110,7 @@ class PinnedStager:
 
         slot = self._slots[self._next]
         self._next = (self._next + 1) % len(self._slots)
-        if slot["event"] is not None:
+        if slot["event"] is not None and not slot["event"].query():      # sixteen calls later its copy has long landed: the wait is a safety net, never the common path
             slot["event"].synchronize()
         k = len(idx)
         slot["idx"].numpy()[:k] = idx
@@ -142,12 +142,15 @@ def np_random(seed=None):
 # Tables of the LARGE model of every family: 256 rows / 4 080 Jacobian-pool words (the 12-bit row offsets' limit) / 64 contacts (one lane each: twice the fast kernels' lists); ~32-42 KB of LDS per
 # world on the generic kernel.  The reference never truncates a contact list (mujoco.mj_step, envs/robot_env.py:341).
 RERUN_CAPACITY = {"maxefc": 256, "jpool": 4080, "maxcon": 64}
+# the kitchen (124 colliding geoms, condim-6 finger pads = ten rows per contact, 29-dof spans): measured on 16 384 worlds x 100 steps of random actions -- 26 worlds with a
+# truncated list on the tables above, 5 at (320, 6128), none at (400, 8160) (profiles/capacity_r04.txt)
+KITCHEN_RERUN_CAPACITY = {"maxefc": 400, "jpool": 8160, "maxcon": 64}
 LANE_TTL = 8       # steps a world stays in the lane after the last step in which it came within LANE_MARGIN of a capacity of the fast kernel
 LANE_MARGIN = 0.8
 LANE_POLL_GRID = 16    # entrants per step that can be re-run while the fast launch is still running (more: the serialised launch behind it takes the rest)
 
 
-def create_rerun_model(L, model, device_index, enabled=True):
+def create_rerun_model(L, model, device_index, enabled=True, capacity=None):
     """handle of `model` compiled with RERUN_CAPACITY, or None when the lane is switched off (GRX_NO_OVERFLOW_RERUN=1: round-2 behaviour, contacts dropped and flagged)"""
     import ctypes
     import os
@@ -156,7 +159,7 @@ def create_rerun_model(L, model, device_index, enabled=True):
 
     if not enabled or os.environ.get("GRX_NO_OVERFLOW_RERUN") is not None:
         return None
-    cap = dict(RERUN_CAPACITY)
+    cap = dict(capacity or RERUN_CAPACITY)
     if os.environ.get("GRX_RERUN_CAPACITY"):      # "rows,pool,contacts" (experiments: which large tables leave no world of a workload with a truncated list)
         cap = dict(zip(("maxefc", "jpool", "maxcon"), (int(x) for x in os.environ["GRX_RERUN_CAPACITY"].split(","))))
     H, I, F = model.with_capacity(**cap).pack()

@@ -575,7 +575,7 @@ grx_adroit_lane_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
 // FrankaKitchen-v1 env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world; 40 substeps; nv = 29 (9 robot dofs, 5 joint
 // equalities knob <-> burner / switch <-> light, the free kettle), 124 colliding geoms / 3 736 candidate pairs, condim-6 finger pads, hull pairs
 typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 192, 2240, 0, 32, 1, 3> GrxShapeKitchen;
-typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 256, 4080, 0, 64, 1, 3> GrxShapeKitchenLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
+typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 400, 8160, 0, 64, 1, 3> GrxShapeKitchenLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
 template <class S>
 __device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitchenTask& t, const GrxKitchenBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
   if (w >= n_worlds) return;

@@ -138,10 +138,10 @@ class AdroitVecEnv(GoalVecEnv):
             self.target_pos[idx] = d["target"]
         ti = self._write_edits(idx, d["shift"], d["target"] if self.target is not None else None)
         self.qpos[ti] = self._init_qpos
-        self.qvel[ti] = 0.0
-        self.qacc_ws[ti] = 0.0
+        self.qvel.index_fill_(0, ti, 0.0)      # (x[ti] = 0.0 would upload a host scalar: a synchronising copy)
+        self.qacc_ws.index_fill_(0, ti, 0.0)
         self.mask.zero_()
-        self.mask[ti] = 1
+        self.mask.index_fill_(0, ti, 1)
         self._launch(self._bufs_masked, True)
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
@@ -183,7 +183,7 @@ class AdroitVecEnv(GoalVecEnv):
             terminated = np.zeros(self.num_envs, bool)
             if len(pending):
                 tp = self._reset_worlds(pending)
-                self.reward[tp] = 0.0
+                self.reward.index_fill_(0, tp, 0.0)
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
                 td = self._stage(done)

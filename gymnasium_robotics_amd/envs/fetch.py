@@ -335,8 +335,8 @@ class FetchVecEnv(GoalVecEnv):
             info = {}
             if len(pending):  # Gymnasium NEXT_STEP: the reset replaces the step; reward 0, flags False
                 tp = self._reset_worlds(pending)
-                self.reward[tp] = 0.0
-                self.packed[tp, -2] = 0.0
+                self.reward.index_fill_(0, tp, 0.0)
+                self.packed[:, -2].index_fill_(0, tp, 0.0)
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
                 staged = self._stage_reset(done)

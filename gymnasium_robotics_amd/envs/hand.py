@@ -109,6 +109,7 @@ class HandReachVecEnv(GoalVecEnv):
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
         self.kernel_events = None  # when a list: (start, end) HIP events around every step-kernel launch (benchmarks)
+        self._chain_stage = PinnedStager(n, max(self.nq, GOAL_DIM), d)      # the settle chains' start poses (side streams)
         self._dev_index = PinnedStager(n, max(self.nq, GOAL_DIM), d)   # index lists / goal rows of the autoreset path: enqueued, never waited for (core.PinnedStager)
         self._env_setup()
 
@@ -206,11 +207,11 @@ class HandReachVecEnv(GoalVecEnv):
         goals = sample_hand_reach_goal_batch([self.np_randoms[w] for w in idx], self.initial_goal, self.palm_xpos)   # host draws: the step kernel may still be running
         ti, tg = self._dev_index(np.asarray(idx, dtype=np.int64), goals)
         self.qpos[ti] = self._initial_qpos
-        self.qvel[ti] = 0.0
-        self.qacc_ws[ti] = 0.0
+        self.qvel.index_fill_(0, ti, 0.0)      # (x[ti] = 0.0 would upload a host scalar: a synchronising copy)
+        self.qacc_ws.index_fill_(0, ti, 0.0)
         self.goal[ti] = tg
         self.mask.zero_()
-        self.mask[ti] = 1
+        self.mask.index_fill_(0, ti, 1)
         self._launch(self._bufs_masked, True)
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
@@ -254,7 +255,7 @@ class HandReachVecEnv(GoalVecEnv):
             if len(pending):
                 self._reset_worlds(pending)
                 tp = torch.from_numpy(pending).to(self.device)
-                self.reward[tp] = 0.0
+                self.reward.index_fill_(0, tp, 0.0)
                 self.packed[tp, -2] = 0.0      # the packed row (cross-rank gather, HER) reports the same reward as reward[]
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
@@ -445,10 +446,10 @@ class HandBlockVecEnv(HandReachVecEnv):
             q = self._initial_qpos.unsqueeze(0).repeat(len(pending), 1)
             q[:, self._qa: self._qa + 7] = torch.from_numpy(poses.astype(np.float32)).to(self.device)
             self.qpos[ti] = q
-            self.qvel[ti] = 0.0
+            self.qvel.index_fill_(0, ti, 0.0)
             self.action.zero_()
             self.mask.zero_()
-            self.mask[ti] = 1
+            self.mask.index_fill_(0, ti, 1)
             for _ in range(SETTLE_STEPS):
                 self._launch(self._bufs_masked, False, settle=True)
             z = self.qpos[ti, self._qa + 2].cpu().numpy()
@@ -527,8 +528,9 @@ class HandBlockVecEnv(HandReachVecEnv):
         side = self._side[c["due_at"] & 1]
         with torch.cuda.stream(side):
             side.wait_event(c["ready"])
-            ar["qpos"][lo: lo + k] = q.to(self.device)
-            ar["qvel"][lo: lo + k] = 0.0
+            _, tq = self._chain_stage(np.arange(k), q.numpy())      # pinned staging: enqueued on the side stream, never waited for
+            ar["qpos"][lo: lo + k] = tq[:, : self.nq]
+            ar["qvel"][lo: lo + k].zero_()
             bufs, sp = self._arena_bufs(lo), ctypes.c_void_p(side.cuda_stream)
             for _ in range(SETTLE_STEPS):   # the arena's action rows stay zero: _set_action(np.zeros(20)) (manipulate.py:206-216)
                 _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), k, 0, sp))

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..core import create_rerun_model, GoalVecEnv, OverflowLane, np_random
+from ..core import KITCHEN_RERUN_CAPACITY, create_rerun_model, GoalVecEnv, OverflowLane, np_random
 from ..mjcf import CompiledModel
 from ..spaces import Box, Dict, batch_space
 from .kitchen_spec import (INIT_QPOS, MAX_EPISODE_STEPS, OBS_DIM, OBS_ELEMENT_GOALS, OBS_ELEMENT_INDICES, TASKS, load_kitchen_model, make_kitchen_task, task_mask)
@@ -58,7 +58,7 @@ class KitchenVecEnv(GoalVecEnv):
         self._h = ctypes.c_void_p()
         _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0, ctypes.byref(self._h)))
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
-        self._h_big = create_rerun_model(self._L, self.model, self.device.index or 0)    # larger tables for the worlds that overflow a capacity (core.RERUN_CAPACITY)
+        self._h_big = create_rerun_model(self._L, self.model, self.device.index or 0, capacity=KITCHEN_RERUN_CAPACITY)    # larger tables for the worlds that overflow a capacity
         self.task = make_kitchen_task(self.model, self.robot_noise_ratio, self.object_noise_ratio)
         self._noisy = self.robot_noise_ratio != 0.0 or self.object_noise_ratio != 0.0
         n, d = self.num_envs, self.device
@@ -193,12 +193,12 @@ class KitchenVecEnv(GoalVecEnv):
             return None
         ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
         self.qpos[ti] = self._init_qpos
-        self.qvel[ti] = 0.0
-        self.qacc_ws[ti] = 0.0
+        self.qvel.index_fill_(0, ti, 0.0)
+        self.qacc_ws.index_fill_(0, ti, 0.0)
         which = idx if len(idx) < self.num_envs else None
         self._draw_noise(which)
         self.mask.zero_()
-        self.mask[ti] = 1
+        self.mask.index_fill_(0, ti, 1)
         self._launch(self._bufs_masked, True)
         self._refill_noise(which)
         self.tasks_to_complete[idx] = self._all_mask
