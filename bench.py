@@ -365,6 +365,8 @@ def run_rank(args, rank, world_size, local_rank):
         one_step()
     env.clear_status()
     env.kernel_events = []   # HIP events (torch's current stream = the launch stream) around every step-kernel launch of the timed region
+    if hasattr(env, "step_events"):
+        env.step_events = []   # ... and around the whole launch group of a step (fast kernel + the overflow lane's launches on the side stream, joined before the entry launch)
     if dist:
         dist.barrier()
     sync()
@@ -380,6 +382,7 @@ def run_rank(args, rank, world_size, local_rank):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = float(np.mean([0.0 if dry else a.elapsed_time(b) for a, b in env.kernel_events]))
+    lane_ms = float(np.mean([a.elapsed_time(b) for a, b in env.step_events])) if (not dry and getattr(env, "step_events", None)) else None
     dist_report = None
     if dist:   # the rank count as the collective library reports it + every rank's kernel / wall time (a slow rank, a rank that fell back to another device: visible in the line)
         from gymnasium_robotics_amd.parallel import rank_stats
@@ -414,6 +417,7 @@ def run_rank(args, rank, world_size, local_rank):
                        "status_note": "worlds (of rank 0) whose sticky status flagged a dropped contact / bad number at least once in the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": w["kernel"], "kernel_ms": kern_ms,
+                         "kernel_plus_overflow_lane_ms": lane_ms,      # families with an overflow lane: fast launch + the lane's concurrent and serialised launches (`achieved` is the fast launch's)
                          "algorithmic_bytes_per_launch": w["algo"] * n,
                          "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 5"},
         }

@@ -287,7 +287,9 @@ __global__ void __launch_bounds__(64, 2)
 grx_fetch_lane_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (the caller sizes the grid: grx_overflow_lane.grid >= the list's cap)
   extern __shared__ float lds[];
   const int e = blockIdx.x;
-  if (e >= *b.lane.count) return;
+  // the Fetch kernels do not implement the polling protocol (core.OverflowLane mode "entry"): workgroups a caller adds for polling (lane.poll_grid) have no list entry
+  // to walk -- beyond grid - poll_grid the list holds stale or unwritten indices
+  if (e >= (int)gridDim.x - b.lane.poll_grid || e >= *b.lane.count) return;
   grx_fetch_step_world<S, true>(mslot, t, b, b.lane.list[e], n_worlds, words, lds, (int)threadIdx.x);
 }
 

@@ -109,6 +109,7 @@ class HandReachVecEnv(GoalVecEnv):
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
         self.kernel_events = None  # when a list: (start, end) HIP events around every step-kernel launch (benchmarks)
+        self.step_events = []      # ... and around the whole launch group of a step (fast kernel + the overflow lane's launches)
         self._chain_stage = PinnedStager(n, max(self.nq, GOAL_DIM), d)      # the settle chains' start poses (side streams)
         self._dev_index = PinnedStager(n, max(self.nq, GOAL_DIM), d)   # index lists / goal rows of the autoreset path: enqueued, never waited for (core.PinnedStager)
         self._env_setup()
@@ -171,7 +172,14 @@ class HandReachVecEnv(GoalVecEnv):
                 self.kernel_events.append((e0, e1))
 
         if self.lane is not None and own and not forward_only:
+            timed_all = self.kernel_events is not None and not forward_only      # the fast launch AND the lane's launches (side stream, joined before the entry launch): the step's device time
+            if timed_all:
+                l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                l0.record()
             self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs)
+            if timed_all:
+                l1.record()
+                self.step_events.append((l0, l1))
         else:
             fast(bufs)
         if self.balance and not forward_only:

@@ -109,6 +109,7 @@ class KitchenVecEnv(GoalVecEnv):
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
+        self.step_events = []      # (start, end) HIP events around the whole launch group of a step: fast kernel + the overflow lane's launches
         self.kernel_events = None
 
     def _lane_make_bufs(self):
@@ -183,7 +184,14 @@ class KitchenVecEnv(GoalVecEnv):
 
         if self.lane is not None and not forward_only:
             large = lambda b: _native.check(self._L.grx_kitchen_step(self._h_big, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, 0, self._stream()))
+            timed_all = self.kernel_events is not None and not forward_only      # the fast launch AND the lane's launches (side stream, joined before the entry launch): the step's device time
+            if timed_all:
+                l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                l0.record()
             self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs)
+            if timed_all:
+                l1.record()
+                self.step_events.append((l0, l1))
         else:
             fast(bufs)
 
