@@ -386,6 +386,21 @@ __device__ __forceinline__ float grx_reduce_sum(float v) {
   return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
          (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
 }
+// the same butterflies on an unsigned 64-bit key (two 32-bit DPP moves per step; lanes outside a row read 0 = the smallest key): wave-uniform maximum
+__device__ __forceinline__ unsigned long long grx_reduce_max_u64(unsigned long long k) {
+#define GRX_DPP_U64_STEP(CTRL) { const unsigned lo2_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)k, CTRL, 0xF, 0xF, true), \
+                                 hi2_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, 0xF, 0xF, true); \
+                                 const unsigned long long k2_ = ((unsigned long long)hi2_ << 32) | lo2_; k = k2_ > k ? k2_ : k; }
+  GRX_DPP_U64_STEP(0xB1) GRX_DPP_U64_STEP(0x4E) GRX_DPP_U64_STEP(0x141) GRX_DPP_U64_STEP(0x140)
+#undef GRX_DPP_U64_STEP
+  unsigned long long m = 0ull;
+#pragma unroll
+  for (int l = 0; l < 64; l += 16) {
+    const unsigned long long v = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, l);
+    m = v > m ? v : m;
+  }
+  return m;
+}
 __device__ __forceinline__ float grx_reduce_max(float v) {
   v = fmaxf(v, GRX_DPP_MOV(v, 0xB1)); v = fmaxf(v, GRX_DPP_MOV(v, 0x4E)); v = fmaxf(v, GRX_DPP_MOV(v, 0x141)); v = fmaxf(v, GRX_DPP_MOV(v, 0x140));
   return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))),
@@ -1356,7 +1371,15 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
 #pragma unroll
     for (int u = 0; u < GRX_HULL_INFLIGHT; u++) {
       const float t = x[u] * dl[0] + y[u] * dl[1] + z[u] * dl[2];
-      if (v0 + 64 * u < n) { if (t > best) { second = best; best = t; mine = v0 + 64 * u; bx = x[u]; by = y[u]; bz = z[u]; } else if (t > second) second = t; }
+#ifdef GRX_NO_SECOND   // (A/B only: misses two tied vertices of one lane)
+      if (v0 + 64 * u < n && t > best) { best = t; mine = v0 + 64 * u; bx = x[u]; by = y[u]; bz = z[u]; }
+#else
+      // the lane's runner-up costs ONE instruction per vertex: the second largest of {best, second, t} is their median (best >= second).  (As a compare + two
+      // selects it cost 9 % of the Fetch launch, profiles/ab_r04_fetch_tiebreak.txt: the scan loop is the hot spot of the worlds that end a launch.)
+      const float tt = (v0 + 64 * u < n) ? t : -3.0e38f;
+      second = __builtin_amdgcn_fmed3f(best, second, tt);
+      if (tt > best) { best = tt; mine = v0 + 64 * u; bx = x[u]; by = y[u]; bz = z[u]; }
+#endif
     }
   }
   const float mx = grx_reduce_max(best);
@@ -1380,15 +1403,18 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
       // the tied vertices are the winners of different lanes (the common case: a face of a few vertices): their fp64 projections come from the coordinates the
       // lanes still hold -- no further memory traffic -- and one wave argmax picks the reference's vertex (lowest index on an exact tie)
       const bool c_ = best >= near_;
-      const double tb = c_ ? (double)bx * (double)dlm[0] + (double)by * (double)dlm[1] + (double)bz * (double)dlm[2] : -3.0e38;
-      // a handful of candidate lanes: walked with scalar lane reads (a cross-lane fp64 reduction costs six dependent LDS-crossbar round trips per support point,
-      // measured +8 % on the Fetch launch: the worlds that end a launch are the ones whose hulls REST on each other, i.e. tie in every evaluation)
-      unsigned long long mk = cand; double tbest = -3.0e38; int nb = 0x7fffffff, src = 0;
-      while (mk) {
-        const int l = __builtin_ctzll(mk); mk &= mk - 1ull;
-        const double tl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tb), l), __builtin_amdgcn_readlane(__double2loint(tb), l));
-        const int il = __builtin_amdgcn_readlane(mine, l);
-        if (tl > tbest || (tl == tbest && il < nb)) { tbest = tl; nb = il; src = l; }
+      const double tb = c_ ? (double)bx * (double)dlm[0] + (double)by * (double)dlm[1] + (double)bz * (double)dlm[2] : 0.0;
+      // wave maximum of the fp64 projections through their order-preserving 64-bit integer images (DPP butterflies, no LDS round trips; a resting hull face ties
+      // with ALL of its vertices -- tens of candidates in every support evaluation of exactly the worlds that end a Fetch launch -- so a scalar walk over the
+      // candidate lanes cost 6 % of the launch); candidates get a key >= 1, everything else 0
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(tb);
+      const unsigned long long key = c_ ? ((bits >> 63) ? ~bits : (bits | 0x8000000000000000ull)) : 0ull;
+      const unsigned long long kmax = grx_reduce_max_u64(key);
+      const unsigned long long top = __ballot(c_ && key == kmax);
+      int src = __builtin_ctzll(top), nb = __builtin_amdgcn_readlane(mine, src);
+      if (top & (top - 1ull)) {   // an exact fp64 tie: the lowest vertex index wins (the reference's scan keeps the first maximum)
+        unsigned long long mk = top & (top - 1ull);
+        while (mk) { const int l = __builtin_ctzll(mk); mk &= mk - 1ull; const int il = __builtin_amdgcn_readlane(mine, l); if (il < nb) { nb = il; src = l; } }
       }
       r[0] = grx_readlane_f(bx, src); r[1] = grx_readlane_f(by, src); r[2] = grx_readlane_f(bz, src);
       return nb;

@@ -439,3 +439,61 @@ def test_gpu_torsional_friction_of_condim4():
         qpos, qvel = _settle_on_gpu(SPHERE.format(cd=4, mu=mu, spin=mu_t, mass=m_), 1, state=([0, 0, 0.1 - r0, 1, 0, 0, 0], [0, 0, 0, 0, 0, w32]))
         alpha = (qvel[5] - w32) / 0.001
         assert abs(alpha / spin_deceleration(w32, mu, mu_t, r0, m_, rad) - 1) < 1e-2 and np.abs(qvel[:2]).max() < 1e-6 and np.abs(qvel[3:5]).max() < 1e-5, (w, alpha, qvel)
+
+
+def test_gpu_more_than_32_contacts_equal_the_oracle(tmp_path):
+    """The reference never truncates a contact list (mujoco.mj_step, envs/robot_env.py:340-341; the kitchen scene of franka_env.py:92-110 has 258 geoms).  The large
+    tables of the overflow lane hold 64 contacts (one lane each): nine boxes sliding on the floor are 36 contacts / 144 pyramid rows, and the HIP kernel on those
+    tables follows the oracle (MAXCON 128), contact list for contact list, step by step; on 32-contact tables the same state raises the overflow flag that sends a
+    world of a fast kernel to the large ones."""
+    import torch
+
+    from gymnasium_robotics_amd import _native
+    from gymnasium_robotics_amd.mjcf import compile_mjcf
+    from oracle.oracle_sim import OracleSim
+
+    bodies = "".join(f'<body pos="{0.25 * (i % 4):.2f} {0.25 * (i // 4):.2f} 0.0405"><freejoint/><geom type="box" size="0.1 0.08 0.04" mass="{0.3 + 0.05 * i:.2f}"/></body>' for i in range(9))
+    path = os.path.join(tmp_path, "many.xml")
+    with open(path, "w") as f:
+        f.write(f'<mujoco><option timestep="0.002"/><worldbody><geom name="floor" type="plane" size="3 3 0.1"/>{bodies}</worldbody></mujoco>')
+    big = compile_mjcf(path, capacity={"maxcon": 64, "maxefc": 256, "jpool": 4080})
+    s = OracleSim(big)
+    s.qvel[:] = 0.2 * np.random.default_rng(5).standard_normal(s.qvel.shape)
+    L, dev = _native.lib(), torch.device("cuda:0")
+    nq, nv = big.dim("nq"), big.dim("nv")
+
+    def make(model):
+        H, I, F = model.pack()
+        h = ctypes.c_void_p()
+        _native.check(L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, 0, ctypes.byref(h)))
+        return h
+
+    def gpu_step(h, qpos, qvel, ws):
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)[None]).to(dev)
+        z = lambda *sh, dtype=torch.float32: torch.zeros(*sh, dtype=dtype, device=dev)
+        bufs = dict(qpos=f32(qpos), qvel=f32(qvel), qacc_ws=f32(ws), goal=z(1, 2), action=z(1, 1), obs=z(1, nq + nv), achieved=z(1, 2), reward=z(1), success=z(1, dtype=torch.uint8),
+                    terminated=z(1, dtype=torch.uint8), status=z(1, dtype=torch.int32))
+        b = _native.PointBuffersStruct()
+        for k, t in bufs.items():
+            setattr(b, k, t.data_ptr())
+        b.mask = b.packed = None
+        task = _native.PointTaskStruct(1, 1, 1, 1, 0.45, 5.0)
+        _native.check(L.grx_point_step(h, ctypes.byref(task), ctypes.byref(b), 1, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        torch.cuda.synchronize()
+        return bufs["qpos"][0].cpu().numpy().astype(np.float64), bufs["qvel"][0].cpu().numpy().astype(np.float64), int(bufs["status"][0])
+
+    h_big, h_small = make(big), make(big.with_capacity(maxcon=32, maxefc=256, jpool=4080))
+    try:
+        worst, most = 0.0, 0
+        for t in range(40):
+            q0, v0, w0 = s.qpos.copy(), s.qvel.copy(), s.qacc_warmstart.copy()
+            s.step(1)
+            most = max(most, s.ncon)
+            qg, vg, st = gpu_step(h_big, q0, v0, w0)
+            assert st & 0xFFFF == 0, (t, st)
+            worst = max(worst, np.abs(qg - s.qpos).max(), np.abs(vg - s.qvel).max())
+        assert most == 36 and worst < 1e-4, (most, worst)
+        _, _, st = gpu_step(h_small, q0, v0, w0)
+        assert st & 2      # GRX_ST_CON_OVERFLOW
+    finally:
+        L.grx_model_destroy(h_big); L.grx_model_destroy(h_small)
