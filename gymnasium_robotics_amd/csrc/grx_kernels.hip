@@ -1508,6 +1508,60 @@ extern "C" int grx_fetch_sample_resets(uint64_t* states, const int64_t* idx, int
   return 0;
 }
 
+// ---- the same draws ON THE DEVICE (include/grx_capi.h, grx_fetch_sample_resets_device): the worlds' numpy PCG64 streams live in HBM ([N,4] uint64), one thread per
+// world to reset walks its stream through the data-dependent loops of _reset_sim / _sample_goal (fetch_env.py:153-166, 388-391) in the reference's fp64 arithmetic
+// (explicitly rounded multiplies / adds: no fused contraction, the host routine and numpy have none) and writes the float32 sample row the reset kernel reads.
+// Bit-equal to the host routine and therefore to Generator.uniform (tests/test_gpu_fetch.py); nothing is drawn, staged or uploaded by the host.
+__device__ __forceinline__ double grx_pcg64_uniform_dev(unsigned long long& hi, unsigned long long& lo, unsigned long long ihi, unsigned long long ilo, double a, double b) {
+  const unsigned long long mhi = 0x2360ED051FC65DA4ULL, mlo = 0x4385DF649FCCF645ULL;
+  const unsigned long long plo = lo * mlo, phi = __umul64hi(lo, mlo) + hi * mlo + lo * mhi;
+  lo = plo + ilo;
+  hi = phi + ihi + (lo < plo ? 1ULL : 0ULL);
+  const unsigned long long x = hi ^ lo; const unsigned rot = (unsigned)(hi >> 58);
+  const unsigned long long r = (x >> rot) | (x << ((64 - rot) & 63));
+  const double d = __dmul_rn((double)(r >> 11), 1.0 / 9007199254740992.0);
+  return __dadd_rn(a, __dmul_rn(__dsub_rn(b, a), d));
+}
+__global__ void __launch_bounds__(64)
+grx_fetch_sample_kernel(unsigned long long* __restrict__ states, const int* __restrict__ idx, int n, int has_object, int in_air, double obj_range, double target_range,
+                        double t0, double t1, double t2, double g0, double g1, double g2, double height_offset, float* __restrict__ samples) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n) return;
+  const int w = idx[k];
+  unsigned long long hi = states[4 * w], lo = states[4 * w + 1];
+  const unsigned long long ihi = states[4 * w + 2], ilo = states[4 * w + 3];
+  double ox = g0, oy = g1;
+  if (has_object) {
+    for (;;) {
+      const double dx = __dsub_rn(ox, g0), dy = __dsub_rn(oy, g1);
+      if (!(__dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))) < 0.1)) break;
+      ox = __dadd_rn(g0, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -obj_range, obj_range));
+      oy = __dadd_rn(g1, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -obj_range, obj_range));
+    }
+  }
+  double g[3];
+  g[0] = __dadd_rn(g0, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -target_range, target_range));
+  g[1] = __dadd_rn(g1, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -target_range, target_range));
+  g[2] = __dadd_rn(g2, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -target_range, target_range));
+  if (has_object) {
+    g[0] = __dadd_rn(g[0], t0); g[1] = __dadd_rn(g[1], t1); g[2] = __dadd_rn(g[2], t2);
+    g[2] = height_offset;
+    if (in_air && grx_pcg64_uniform_dev(hi, lo, ihi, ilo, 0.0, 1.0) < 0.5) g[2] = __dadd_rn(g[2], grx_pcg64_uniform_dev(hi, lo, ihi, ilo, 0.0, 0.45));
+  }
+  states[4 * w] = hi; states[4 * w + 1] = lo;
+  float* s = samples + 5 * (size_t)k;
+  s[0] = (float)ox; s[1] = (float)oy; s[2] = (float)g[0]; s[3] = (float)g[1]; s[4] = (float)g[2];
+}
+extern "C" int grx_fetch_sample_resets_device(uint64_t* states, const int* idx, int n, int has_object, int target_in_the_air, double obj_range, double target_range,
+                                              const double* target_offset, const double* gripper_xpos, double height_offset, float* samples, void* stream) {
+  if (!states || !idx || !samples || !gripper_xpos || !target_offset) return fail("grx_fetch_sample_resets_device: null argument");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(grx_fetch_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)states, idx, n, has_object, target_in_the_air, obj_range,
+                     target_range, target_offset[0], target_offset[1], target_offset[2], gripper_xpos[0], gripper_xpos[1], gripper_xpos[2], height_offset, samples);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 // count consecutive Generator.uniform(-1, 1) draws of each listed world's numpy PCG64 stream, as float32 rows (FrankaKitchen's observation noise:
 // franka_env.py:118-127 + kitchen_env.py:361-369 draw 9 + 9 + 21 + 20 per observation).  states as in grx_fetch_sample_resets; HOST pointers.
 extern "C" int grx_sample_uniform_rows(uint64_t* states, const int64_t* idx, int n, int count, float* out) {

@@ -237,14 +237,19 @@ class FetchVecEnv(GoalVecEnv):
 
     # ------------------------------------------------------------------ reset (robot_env.py:154-186)
     def _seed_worlds(self, seeds):
-        """One numpy PCG64 per world, seeded like gymnasium.utils.seeding.np_random [3P]; only the raw 128-bit
-        (state, inc) pairs are kept -- the stream is advanced by grx_fetch_sample_resets (bit-exact with numpy)."""
+        """One numpy PCG64 per world, seeded like gymnasium.utils.seeding.np_random [3P]; only the raw 128-bit (state, inc) pairs are kept, ON THE DEVICE: the
+        streams are advanced by grx_fetch_sample_resets_device (bit-exact with numpy's Generator.uniform), the host never draws."""
         st = np.zeros((self.num_envs, 4), np.uint64)
         mask = (1 << 64) - 1
         for i, sd in enumerate(seeds):
             s = np_random(sd)[0].bit_generator.state["state"]
             st[i] = [s["state"] >> 64, s["state"] & mask, s["inc"] >> 64, s["inc"] & mask]
-        self._rng_state = st
+        self._rng_dev = torch.from_numpy(st.view(np.int64)).to(self.device)
+
+    @property
+    def _rng_state(self):
+        """host copy of the worlds' stream positions (inspection / tests: synchronises)"""
+        return self._rng_dev.cpu().numpy().view(np.uint64)
 
     def world_rng(self, i):
         """numpy Generator positioned at world i's current stream position (for inspection / tests)."""
@@ -256,29 +261,22 @@ class FetchVecEnv(GoalVecEnv):
         return np.random.Generator(bg)
 
     def _stage_reset(self, idx: np.ndarray):
-        """Host: the PCG64 draws of the listed worlds (bit-exact C sampler) into a pinned staging buffer; device: ONE asynchronous copy.
-        _launch_reset then runs the compacted, shape-specialised reset kernel (grx_fetch_reset).  Nothing here waits for the device."""
+        """The listed worlds' indices go to the device through pinned memory (one asynchronous copy); their PCG64 draws -- the rejection loop of _reset_sim, the goal of
+        _sample_goal -- are made ON THE DEVICE from the worlds' device-resident streams (grx_fetch_sample_resets_device, bit-exact with numpy).  _launch_reset then
+        runs the compacted, shape-specialised reset kernel (grx_fetch_reset).  Nothing here waits for the device, nothing is drawn on the host."""
         n = len(idx)
-        goals64 = np.zeros((n, 3), np.float64)
-        oxy64 = np.zeros((n, 2), np.float64)
-        idx64 = np.ascontiguousarray(idx, dtype=np.int64)
         cfg = self.cfg
+        stage = torch.empty(n, dtype=torch.int32, pin_memory=True)
+        stage.numpy()[:] = np.ascontiguousarray(idx, dtype=np.int32)
+        dev = self._reset_stage.view(-1)[: 6 * n]
+        idx_dev, samples = dev[:n].view(torch.int32), dev[n:]
+        idx_dev.copy_(stage, non_blocking=True)
         toff = np.ascontiguousarray(np.broadcast_to(np.asarray(cfg["target_offset"], dtype=np.float64), (3,)))
         g0 = np.ascontiguousarray(self.initial_gripper_xpos, dtype=np.float64)
-        _native.check(self._L.grx_fetch_sample_resets(
-            self._rng_state.ctypes.data, idx64.ctypes.data, n, int(cfg["has_object"]), int(cfg["target_in_the_air"]),
-            float(cfg["obj_range"]), float(cfg["target_range"]), toff.ctypes.data, g0.ctypes.data, float(self.height_offset),
-            oxy64.ctypes.data, goals64.ctypes.data))
-        # staging: n world indices (int32 bits) followed by n x (object x, y, goal x, y, z), in pinned memory -> device, asynchronously
-        stage = torch.empty(6 * n, dtype=torch.float32, pin_memory=True)
-        sv = stage.numpy()
-        sv[:n] = idx64.astype(np.int32).view(np.float32)
-        sm = sv[n:].reshape(n, 5)
-        sm[:, 0:2] = oxy64
-        sm[:, 2:5] = goals64
-        dev = self._reset_stage.view(-1)[: 6 * n]
-        dev.copy_(stage, non_blocking=True)
-        return n, dev[:n].view(torch.int32), dev[n:]
+        _native.check(self._L.grx_fetch_sample_resets_device(
+            self._rng_dev.data_ptr(), idx_dev.data_ptr(), n, int(cfg["has_object"]), int(cfg["target_in_the_air"]), float(cfg["obj_range"]), float(cfg["target_range"]),
+            toff.ctypes.data, g0.ctypes.data, float(self.height_offset), samples.data_ptr(), self._stream()))
+        return n, idx_dev, samples
 
     def _launch_reset(self, staged, idx, keep_outcome=False):
         n, idx_dev, samples = staged

@@ -16,7 +16,7 @@
  *   grx_fetch_forward ....... mujoco.mj_forward after a reset + _get_obs fetch/fetch_env.py:401, envs/robot_env.py:183
  *                              (nstep > 0: the raw mj_step settle loop of _env_setup, fetch/fetch_env.py:419-420)
  *   grx_fetch_compute_reward  GoalEnv.compute_reward on a batch (HER)   fetch/fetch_env.py:74-80, core.py:45-67
- *   grx_fetch_sample_resets . np_random.uniform draws of _reset_sim/_sample_goal  fetch/fetch_env.py:153-166,388-391
+ *   grx_fetch_sample_resets[_device] . np_random.uniform draws of _reset_sim/_sample_goal  fetch/fetch_env.py:153-166,388-391 (host / on the device)
  *
  * All array arguments are plain device (HBM) pointers; rows are world-major.  `stream` is a
  * hipStream_t passed as void*.  Every function returns 0 on success, a negative value on error
@@ -368,6 +368,10 @@ int grx_hand_commit_rows(const grx_hand_commit_args* args, void* stream);
 int grx_fetch_sample_resets(uint64_t* states, const int64_t* idx, int n, int has_object, int target_in_the_air, double obj_range,
                             double target_range, const double* target_offset, const double* gripper_xpos, double height_offset,
                             double* out_oxy, double* out_goal);
+/* The same draws ON THE DEVICE (fetch/fetch_env.py:153-166, 388-391): states [n_total,4] uint64 in HBM (advanced in place), idx [n] int32 device world indices,
+ * samples [n,5] float32 out (object x, y, goal x, y, z) -- the row grx_fetch_reset reads.  Bit-equal to grx_fetch_sample_resets / numpy; the host draws nothing. */
+int grx_fetch_sample_resets_device(uint64_t* states, const int* idx, int n, int has_object, int target_in_the_air, double obj_range, double target_range,
+                                   const double* target_offset, const double* gripper_xpos, double height_offset, float* samples, void* stream);
 const char* grx_last_error(void);
 
 #ifdef __cplusplus
