@@ -125,10 +125,10 @@ def main(argv):
     for fam in fams:
         ref = run_family(L64, fam, True, every, round_inputs=True, ref="raw")[1] if rounded else None
         L.emu_newton_stat.restype = ctypes.c_long
-        n0 = [L.emu_newton_stat(k) for k in range(4)]
+        n0 = [L.emu_newton_stat(k) for k in range(6)]
         idx, e, status, comps = run_family(L, fam, fp64, every, round_inputs=rounded, ref=ref)
-        n1 = [L.emu_newton_stat(k) - n0[k] for k in range(4)]
-        print(f"{fam:18s} Newton: {n1[0]} solves, {n1[1] / max(n1[0], 1):.3f} iterations / solve, {n1[2] / max(n1[0], 1):.3f} Hessian assemblies / solve, {n1[3] / max(n1[0], 1):.3f} incremental updates / solve", flush=True)
+        n1 = [L.emu_newton_stat(k) - n0[k] for k in range(6)]
+        print(f"{fam:18s} Newton: {n1[0]} solves, {n1[1] / max(n1[0], 1):.3f} iterations / solve, {n1[2] / max(n1[0], 1):.3f} Hessian assemblies / solve, {n1[3] / max(n1[0], 1):.3f} incremental updates / solve, object-block refinements eligible {n1[4] / max(n1[0], 1):.3f} / run {n1[5] / max(n1[0], 1):.3f} per solve", flush=True)
         for comp, cols in comps.items():
             err = e[:, cols].max(axis=1)      # absolute, also for the "_relative" components of tests/tolerance_cases.py
             worst = idx[np.argsort(-err)[:6]]
