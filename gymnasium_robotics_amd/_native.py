@@ -142,3 +142,43 @@ EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
     "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_fetch_sample_resets_device", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_uniform_rows_device", "grx_kitchen_bookkeeping", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
 ]
+
+
+# ---------------------------------------------------------------------------------------------------- shared model handles
+# The native side has GRX_MAX_MODELS (32) descriptor slots per process (constant memory, csrc/grx_engine.h).  Environments never modify a model after creating it
+# (per-world model edits are per-world state), so environments built from the same compiled tables SHARE one handle: an id costs two slots (fast + overflow-lane
+# tables) however many environments of it a process holds, and the 17th environment no longer fails with "all model descriptor slots are in use".
+_MODEL_LOCK = __import__("threading").Lock()
+_MODELS = {}      # (device index, digest of the packed tables) -> [handle, reference count]
+_MODEL_KEYS = {}  # handle value -> key
+
+
+def acquire_model(H, I, F, device_index):
+    """handle of the model packed as (H, I, F) on `device_index`: created on first use, reference-counted afterwards (release_model)"""
+    import hashlib
+
+    key = (int(device_index), hashlib.sha1(H.tobytes() + I.tobytes() + F.tobytes()).hexdigest())
+    with _MODEL_LOCK:
+        ent = _MODELS.get(key)
+        if ent is None:
+            h = ctypes.c_void_p()
+            check(lib().grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, int(device_index), ctypes.byref(h)))
+            ent = _MODELS[key] = [h, 0]
+            _MODEL_KEYS[h.value] = key
+        ent[1] += 1
+        return ent[0]
+
+
+def release_model(h):
+    """drop one reference; the native model is destroyed with the last one"""
+    if h is None or not getattr(h, "value", None):
+        return
+    with _MODEL_LOCK:
+        key = _MODEL_KEYS.get(h.value)
+        if key is None:
+            return
+        ent = _MODELS[key]
+        ent[1] -= 1
+        if ent[1] <= 0:
+            del _MODELS[key], _MODEL_KEYS[h.value]
+            lib().grx_model_destroy(h)

@@ -145,7 +145,7 @@ RERUN_CAPACITY = {"maxefc": 256, "jpool": 4080, "maxcon": 64}
 # the kitchen (124 colliding geoms, condim-6 finger pads = ten rows per contact, 29-dof spans): measured on 16 384 worlds x 100 steps of random actions -- 26 worlds with a
 # truncated list on the tables above, 5 at (320, 6128), none at (400, 8160) (profiles/capacity_r04.txt)
 KITCHEN_RERUN_CAPACITY = {"maxefc": 400, "jpool": 8160, "maxcon": 64}
-LANE_TTL = 8       # steps a world stays in the lane after the last step in which it came within LANE_MARGIN of a capacity of the fast kernel
+LANE_TTL = 4       # steps a world stays in the lane after the last step in which it came within LANE_MARGIN of a capacity of the fast kernel (profiles/ab_r04_lane_parameters.txt: margin 0.5 - 0.9, ttl 2 - 32, 16 - 48 polling workgroups swept)
 LANE_MARGIN = 0.8
 LANE_POLL_GRID = 16    # entrants per step that can be re-run while the fast launch is still running (more: the serialised launch behind it takes the rest)
 
@@ -163,9 +163,7 @@ def create_rerun_model(L, model, device_index, enabled=True, capacity=None):
     if os.environ.get("GRX_RERUN_CAPACITY"):      # "rows,pool,contacts" (experiments: which large tables leave no world of a workload with a truncated list)
         cap = dict(zip(("maxefc", "jpool", "maxcon"), (int(x) for x in os.environ["GRX_RERUN_CAPACITY"].split(","))))
     H, I, F = model.with_capacity(**cap).pack()
-    h = ctypes.c_void_p()
-    _native.check(L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, device_index, ctypes.byref(h)))
-    return h
+    return _native.acquire_model(H, I, F, device_index)
 
 
 class _LaneBuf:

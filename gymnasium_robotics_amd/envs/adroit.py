@@ -45,8 +45,7 @@ class AdroitVecEnv(GoalVecEnv):
         self.obs_dim = self.spec["obs_dim"]
         self._L = _native.lib()
         H, I, F = self.model.pack()
-        self._h = ctypes.c_void_p()
-        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0, ctypes.byref(self._h)))
+        self._h = _native.acquire_model(H, I, F, self.device.index or 0)   # shared with every other environment of the same compiled tables (reference-counted)
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
         self._h_big = create_rerun_model(self._L, self.model, self.device.index or 0)    # larger tables for the worlds that overflow a capacity (core.RERUN_CAPACITY)
         self.task = make_adroit_task(self.model, self.reward_type, self.task_name)
@@ -255,10 +254,10 @@ class AdroitVecEnv(GoalVecEnv):
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.grx_model_destroy(self._h)
+            _native.release_model(self._h)
             self._h = None
         if getattr(self, "_h_big", None):
-            self._L.grx_model_destroy(self._h_big)
+            _native.release_model(self._h_big)
             self._h_big = None
 
     def __del__(self):

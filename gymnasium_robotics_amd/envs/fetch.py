@@ -107,10 +107,8 @@ class FetchVecEnv(GoalVecEnv):
         self.dt = N_SUBSTEPS * self.model.opt("timestep")
         self._L = _native.lib()
         H, I, F = self.model.pack()
-        self._h = ctypes.c_void_p()
         dev_index = self.device.index or 0
-        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, dev_index,
-                                               ctypes.byref(self._h)))
+        self._h = _native.acquire_model(H, I, F, dev_index)   # shared with every other environment of the same compiled tables (reference-counted)
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
         # the same model with larger row / Jacobian-pool tables (runs on the generic kernel): where the worlds go that overflow the specialised kernel's capacities
         self._h_big = create_rerun_model(self._L, self.model, dev_index, overflow_rerun)
@@ -401,10 +399,10 @@ class FetchVecEnv(GoalVecEnv):
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.grx_model_destroy(self._h)
+            _native.release_model(self._h)
             self._h = None
         if getattr(self, "_h_big", None):
-            self._L.grx_model_destroy(self._h_big)
+            _native.release_model(self._h_big)
             self._h_big = None
 
     def __del__(self):

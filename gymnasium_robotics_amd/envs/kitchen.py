@@ -55,8 +55,7 @@ class KitchenVecEnv(GoalVecEnv):
         self.obs_dim = OBS_DIM
         self._L = _native.lib()
         H, I, F = self.model.pack()
-        self._h = ctypes.c_void_p()
-        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0, ctypes.byref(self._h)))
+        self._h = _native.acquire_model(H, I, F, self.device.index or 0)   # shared with every other environment of the same compiled tables (reference-counted)
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
         self._h_big = create_rerun_model(self._L, self.model, self.device.index or 0, capacity=KITCHEN_RERUN_CAPACITY)    # larger tables for the worlds that overflow a capacity
         self.task = make_kitchen_task(self.model, self.robot_noise_ratio, self.object_noise_ratio)
@@ -407,10 +406,10 @@ class KitchenVecEnv(GoalVecEnv):
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.grx_model_destroy(self._h)
+            _native.release_model(self._h)
             self._h = None
         if getattr(self, "_h_big", None):
-            self._L.grx_model_destroy(self._h_big)
+            _native.release_model(self._h_big)
             self._h_big = None
 
     def __del__(self):

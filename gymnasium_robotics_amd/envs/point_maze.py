@@ -70,9 +70,7 @@ class PointMazeVecEnv(GoalVecEnv):
         self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
         self._L = _native.lib()
         H, I, F = self.model.pack()
-        self._h = ctypes.c_void_p()
-        _native.check(self._L.grx_model_create(H.ctypes.data, H.size, I.ctypes.data, I.size, F.ctypes.data, F.size, self.device.index or 0,
-                                               ctypes.byref(self._h)))
+        self._h = _native.acquire_model(H, I, F, self.device.index or 0)   # shared with every other environment of the same compiled tables (reference-counted)
         self.task = _native.PointTaskStruct(self.N_SUBSTEPS, int(self.reward_type == "sparse"), int(continuing_task), int(self.AGENT == "ant"),
                                             GOAL_RADIUS, 5.0)
         self.obs_dim = self.nq + self.nv - self.OBS_SKIP
@@ -259,7 +257,7 @@ class PointMazeVecEnv(GoalVecEnv):
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.grx_model_destroy(self._h)
+            _native.release_model(self._h)
             self._h = None
 
     def __del__(self):

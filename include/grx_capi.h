@@ -48,7 +48,11 @@ typedef struct grx_model grx_model;
  * kernel (skip = the current flags); when both are done, the large kernel once more over entry_list (the worlds that entered the lane in this step: the only
  * serialised part, a launch of zero worlds otherwise); then next_* become the current list / flags.  Nothing crosses the host: which worlds are in the lane is
  * known to the kernels only.  All pointers are device pointers; an all-zero struct switches the mechanism off (capacity overflows then drop contacts and raise
- * GRX_STATUS_CON_OVERFLOW / GRX_STATUS_EFC_OVERFLOW, sticky in `status`). */
+ * GRX_STATUS_CON_OVERFLOW / GRX_STATUS_EFC_OVERFLOW, sticky in `status`).
+ * LIMITS -- "no dropped contacts" is conditional: the large tables are finite too (the packaged environments create them with 64 contacts / 256 rows / 4 080 pool words,
+ * the kitchen 400 / 8 160; a world's contact list is at most 64 long: one lane per contact, and row offsets are 14 bits).  A world that exceeds the LARGE tables, more
+ * than 256 first-time entrants in one step, or a lane longer than the grid of its launch keep stepping with the excess contacts of that substep dropped and the sticky
+ * status bit raised -- never silently: count `status` (bench.py: capacity_overflow_worlds, 0 in every measured workload). */
 typedef struct grx_overflow_lane {
   const unsigned char* skip;            /* fast kernel, [N]: worlds in the lane this step */
   int* entry_count; int* entry_list;    /* fast kernel: out, the worlds that overflowed ([1], [N]) */
@@ -113,7 +117,7 @@ typedef struct grx_fetch_buffers {
   float* hullcache;                     /* [N, 21] or NULL: the world's cache of separating directions of its hull-vs-convex pairs (engine: GrxCtx::meshcache), carried from one
                                          * env.step() to the next.  A remembered direction is re-verified before it is trusted (it proves "no contact", exactly what the portal
                                          * search would report), so the rows never change a result: they save the search every launch otherwise starts with. */
-  grx_overflow_lane lane;               /* no dropped contacts: see grx_overflow_lane above */
+  grx_overflow_lane lane;               /* capacity overflows are re-run on larger tables instead of dropping contacts: see grx_overflow_lane above (and its LIMITS) */
 } grx_fetch_buffers;
 
 /* mirrors struct GrxPointTask / GrxPointBuffers (csrc/grx_point_task.h) */
@@ -161,7 +165,7 @@ typedef struct grx_hand_buffers {
   const int* order;             /* [8 * ceil(N / 8)] or NULL: cost-ordered dispatch, as in grx_fetch_buffers */
   int* cost;                    /* [N] or NULL */
   float* packed;                /* [N, obs_dim+2*goal_dim+2] or NULL: [obs | achieved | desired | reward | success] */
-  grx_overflow_lane lane;          /* no dropped contacts: see grx_overflow_lane */
+  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane (and its LIMITS) */
 } grx_hand_buffers;
 
 /* mirrors struct GrxAdroitTask / GrxAdroitBuffers (csrc/grx_adroit_task.h): AdroitHandHammer / Door / Pen / Relocate */
@@ -192,7 +196,7 @@ typedef struct grx_adroit_buffers {
   unsigned char* success;          /* [N] */
   int* status;                     /* [N] */
   const unsigned char* mask;       /* [N] or NULL */
-  grx_overflow_lane lane;          /* no dropped contacts: see grx_overflow_lane */
+  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane (and its LIMITS) */
 } grx_adroit_buffers;
 
 /* mirrors struct GrxKitchenTask / GrxKitchenBuffers (csrc/grx_kitchen_task.h): FrankaKitchen-v1 */
@@ -218,9 +222,11 @@ typedef struct grx_kitchen_buffers {
                                        per world), or NULL: every substep sweeps the full candidate list.  Results are identical either way. */
   int skin_stride;
   float skin_radius;                /* metres by which the broad-phase radius is inflated when a world's list is built (0.1) */
-  grx_overflow_lane lane;          /* no dropped contacts: see grx_overflow_lane */
+  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane (and its LIMITS) */
 } grx_kitchen_buffers;
 
+/* At most 32 models (descriptor slots in constant memory) exist per process at a time; creation beyond that fails with an error, destroy frees the slot.  A model is immutable
+ * once created apart from grx_model_set_table, so callers may share one handle between any number of world batches (the Python side does: _native.acquire_model). */
 int grx_model_create(const int32_t* H, int nH, const int32_t* I, int nI, const double* F, int nF, int device, grx_model** out);
 int grx_model_destroy(grx_model* m);
 int grx_model_set_table(grx_model* m, const char* name, const double* data, int n);
@@ -231,8 +237,8 @@ int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, const grx_fet
 int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task, const grx_fetch_buffers* buf, int n_worlds, int nstep, void* stream);
 /* Episode reset of a COMPACTED list of worlds: _reset_sim (fetch/fetch_env.py:375-402: initial state, object xy) + _sample_goal (:153-166)
  * + mj_forward + _get_obs (envs/robot_env.py:154-186) for the n_reset worlds idx[0..n_reset): one workgroup per listed world, shape-specialised
- * like the step kernel.  The draws come from grx_fetch_sample_resets (host); all arrays here are DEVICE pointers (stage them with one
- * asynchronous copy from pinned memory: nothing on the host has to wait for the device). */
+ * like the step kernel.  The draws come from grx_fetch_sample_resets_device (a kernel on the same stream; or grx_fetch_sample_resets on the host, staged with one
+ * asynchronous copy from pinned memory); all arrays here are DEVICE pointers: nothing on the host has to wait for the device. */
 typedef struct grx_fetch_reset_args {
   const int* idx;        /* [n_reset] world indices */
   const float* samples;  /* [n_reset,5] object x, y, goal x, y, z */

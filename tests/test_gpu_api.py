@@ -275,3 +275,33 @@ def test_torch_step_only_enqueues(env_id, steps):
     torch.cuda.synchronize()
     assert out[1].is_cuda      # rewards stay on the device; terminated / truncated are host-side bookkeeping (the time limit) in the goal families, device tensors in the kitchen
     env.close()
+
+
+def test_many_environments_of_one_id_share_two_model_slots():
+    """The native side has 32 model descriptor slots per process; environments of the same compiled tables share one reference-counted handle (fast + overflow-lane
+    tables = two slots per id), so a process can hold far more than 16 environments; closing one leaves the others stepping, the last close frees the slots."""
+    import numpy as np
+
+    import gymnasium_robotics_amd as grx
+    from gymnasium_robotics_amd import _native
+
+    before = len(_native._MODELS)
+    envs = [grx.make_vec("FetchPickAndPlace-v4", num_envs=8, device="cuda:0") for _ in range(20)]
+    assert len(_native._MODELS) == before + 2
+    assert all(e._h.value == envs[0]._h.value for e in envs)
+    a = np.zeros((8, 4), np.float32)
+    ref = None
+    for e in envs[:3]:
+        e.reset(seed=5)
+        obs = e.step(a)[0]["observation"]
+        ref = obs if ref is None else ref
+        assert np.array_equal(obs, ref)
+    envs[0].close()
+    envs[1].step(a)
+    for e in envs[1:]:
+        e.close()
+    assert len(_native._MODELS) == before
+    e = grx.make_vec("FetchPickAndPlace-v4", num_envs=8, device="cuda:0")     # the slots were really freed and can be taken again
+    e.reset(seed=5)
+    assert np.array_equal(e.step(a)[0]["observation"], ref)
+    e.close()
