@@ -333,6 +333,16 @@ GRX_DEV void mulMatTVec3f(double* r, const double* m, const double* v) {
   double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
+// fp32 matrix (a frame as the kinematics stage left it in LDS), fp64 vectors: the entries are widened at use -- the same products as with a widened copy of the matrix,
+// which would cost two registers per entry for the whole portal search (GrxMprPairT<float>)
+GRX_DEV void mulMatVec3f(double* r, const float* m, const double* v) {
+  double x = (double)m[0] * v[0] + (double)m[1] * v[1] + (double)m[2] * v[2], y = (double)m[3] * v[0] + (double)m[4] * v[1] + (double)m[5] * v[2], z = (double)m[6] * v[0] + (double)m[7] * v[1] + (double)m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+GRX_DEV void mulMatTVec3f(double* r, const float* m, const double* v) {
+  double x = (double)m[0] * v[0] + (double)m[3] * v[1] + (double)m[6] * v[2], y = (double)m[1] * v[0] + (double)m[4] * v[1] + (double)m[7] * v[2], z = (double)m[2] * v[0] + (double)m[5] * v[1] + (double)m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
 #endif
 GRX_DEV void mulMat3f(float* r, const float* a, const float* b) {
   float t[9];
@@ -1267,6 +1277,10 @@ typedef GRX_MPR_REAL MF;
 #define GRX_HULL_REAL float
 #endif
 typedef GRX_HULL_REAL HF;   // arithmetic of the hull support scan (vertex tables are fp32)
+#ifndef GRX_TIE_REAL
+#define GRX_TIE_REAL double
+#endif
+typedef GRX_TIE_REAL TF;    // arithmetic that decides between hull vertices whose fp32 projections tie (grx_mesh_support)
 GRX_MEM float grx_sqrt(float x) { return sqrtf(x); }
 GRX_MEM float grx_fabs(float x) { return fabsf(x); }
 GRX_MEM float grx_fmin(float a, float b) { return fminf(a, b); }
@@ -1288,8 +1302,10 @@ GRX_MEM int grx_mpr_eq(MF a, MF b) {
 GRX_MEM MF grx_sgn1f(MF x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 GRX_MEM void grx_normalize3f(MF* v) { MF n2 = dot3f(v, v); if (n2 > 0.0f) { MF s = 1.0f / grx_sqrt(n2); v[0] *= s; v[1] *= s; v[2] *= s; } }
 // farthest point of the geom along the world direction d, relative to the geom centre
-GRX_MEM void grx_geom_support(const MF* R, const MF* sz, int type, const MF* d, MF* out) {
+template <typename RF>
+GRX_MEM void grx_geom_support(const RF* R, const RF* szf, int type, const MF* d, MF* out) {
   MF dl[3], r[3] = {0.0f, 0.0f, 0.0f};
+  const MF sz[3] = {szf[0], szf[1], szf[2]};
   mulMatTVec3f(dl, R, d);
   if (type == 2) { r[0] = dl[0] * sz[0]; r[1] = dl[1] * sz[0]; r[2] = dl[2] * sz[0]; }
   else if (type == 3) { r[0] = dl[0] * sz[0]; r[1] = dl[1] * sz[0]; r[2] = dl[2] * sz[0] + grx_sgn1f(dl[2]) * sz[1]; }
@@ -1304,7 +1320,8 @@ GRX_MEM void grx_geom_support(const MF* R, const MF* sz, int type, const MF* d, 
   } else if (type == 6) { r[0] = grx_sgn1f(dl[0]) * sz[0]; r[1] = grx_sgn1f(dl[1]) * sz[1]; r[2] = grx_sgn1f(dl[2]) * sz[2]; }
   mulMatVec3f(out, R, r);
 }
-struct GrxMprPair { MF R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // the two frames are copied into registers: ~20 support evaluations each read them twice
+template <typename RF>   // storage of the two frames and sizes: MF where the caller derived them in MF (grx_geom_frame_mf), float where they are the fp32 values of the kinematics stage (hull pairs: half the registers)
+struct GrxMprPairT { RF R1[9], R2[9], s1[3], s2[3]; MF c21[3], hm; int t1, t2;   // the two frames are copied into registers: ~20 support evaluations each read them twice
                     const float *v1, *v2; int n1, n2, lane; const int *aadr1, *anum1, *aadr2, *anum2, *adj;   // hull adjacency (per hull vertex: first neighbour / count into adj)
                                         // hull vertices (geom frame) of mesh geoms: only read by the wave-cooperative variant
                     GrxMprPt* pts;
@@ -1312,6 +1329,8 @@ struct GrxMprPair { MF R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // 
                     long long* prof;
 #endif
                   };                                            // wave-cooperative variant: LDS storage of the five portal points (keeps them out of the VGPR budget)
+typedef GrxMprPairT<MF> GrxMprPair;       // lane-per-pair convex routine (primitive pairs)
+typedef GrxMprPairT<float> GrxMprPairW;   // wave-cooperative hull pairs
 // (Round 4, measured and removed: the scan as a leaf function behind a real call or inline with 16-byte vertex records and 8 - 16 loads in flight per lane -- one memory
 // round per hull instead of three -- is 12 % SLOWER on the Fetch launch, profiles/ab_r04_fetch_scan4.txt: the registers it needs are spilled by the substep loop.)
 // Convex hull of a mesh: the hull vertex farthest along the (geom-frame) direction dl; the lowest vertex index wins ties, like the oracle's
@@ -1323,27 +1342,28 @@ struct GrxMprPair { MF R1[9], R2[9], s1[3], s2[3], c21[3], hm; int t1, t2;   // 
 // Hill climbing over the hull's edge graph in MF arithmetic from the fp32 winner reaches the fp64 winner in one or two rounds of neighbour loads; the lowest
 // index wins exact ties, like the reference's scan.  aadr / anum: per-vertex adjacency of THIS hull, adj: the model's neighbour table.
 GRX_MEM int grx_mesh_support_refine(const float* verts, const int* aadr, const int* anum, const int* adj, const MF* dlm, int cur, int lane_) {
-  if (sizeof(MF) == sizeof(HF) || aadr == nullptr) return cur;
+  if (sizeof(TF) == sizeof(HF) || aadr == nullptr) return cur;
+  const TF dlt[3] = {(TF)dlm[0], (TF)dlm[1], (TF)dlm[2]};
   for (int guard = 0; guard < 64; guard++) {
-    const MF tc = (MF)verts[3 * cur] * dlm[0] + (MF)verts[3 * cur + 1] * dlm[1] + (MF)verts[3 * cur + 2] * dlm[2];
+    const TF tc = (TF)verts[3 * cur] * dlt[0] + (TF)verts[3 * cur + 1] * dlt[1] + (TF)verts[3 * cur + 2] * dlt[2];
     const int aa = aadr[cur], an = anum[cur];
-    MF tb = tc; int nb = cur;
+    TF tb = tc; int nb = cur;
 #if defined(GRX_EMU)
     (void)lane_;
     for (int k = 0; k < an; k++) {
       const int v = adj[aa + k];
-      const MF t = (MF)verts[3 * v] * dlm[0] + (MF)verts[3 * v + 1] * dlm[1] + (MF)verts[3 * v + 2] * dlm[2];
+      const TF t = (TF)verts[3 * v] * dlt[0] + (TF)verts[3 * v + 1] * dlt[1] + (TF)verts[3 * v + 2] * dlt[2];
       if (t > tb || (t == tb && v < nb)) { tb = t; nb = v; }
     }
 #else
     for (int k = lane_; k < an; k += 64) {
       const int v = adj[aa + k];
-      const MF t = (MF)verts[3 * v] * dlm[0] + (MF)verts[3 * v + 1] * dlm[1] + (MF)verts[3 * v + 2] * dlm[2];
+      const TF t = (TF)verts[3 * v] * dlt[0] + (TF)verts[3 * v + 1] * dlt[1] + (TF)verts[3 * v + 2] * dlt[2];
       if (t > tb || (t == tb && v < nb)) { tb = t; nb = v; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {   // wave argmax in MF (rare path: a few times per portal search)
-      const MF to = __shfl_xor(tb, o, 64); const int no = __shfl_xor(nb, o, 64);
+      const TF to = __shfl_xor(tb, o, 64); const int no = __shfl_xor(nb, o, 64);
       if (to > tb || (to == tb && no < nb)) { tb = to; nb = no; }
     }
 #endif
@@ -1393,7 +1413,7 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
 #else
     const unsigned long long cand = __ballot(best >= near_), cand2 = __ballot(second >= near_);
 #endif
-    if (sizeof(MF) == sizeof(HF) || aadr == nullptr || (__builtin_popcountll(cand) <= 1 && cand2 == 0ull)) {
+    if (sizeof(TF) == sizeof(HF) || aadr == nullptr || (__builtin_popcountll(cand) <= 1 && cand2 == 0ull)) {
       const unsigned long long own = __ballot(best == mx && mine == bi);
       const int src = own ? __builtin_ctzll(own) : 0;
       r[0] = grx_readlane_f(bx, src); r[1] = grx_readlane_f(by, src); r[2] = grx_readlane_f(bz, src);
@@ -1449,8 +1469,8 @@ GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* d
   return grx_mesh_support(verts, n, dlm, r, lane_, m->mesh_adjadr + adr, m->mesh_adjnum + adr, m->mesh_adj);
 }
 // W: wave-cooperative variant (uniform control flow, every lane holds the same values; mesh geoms allowed)
-template <bool W>
-GRX_MEM void grx_mpr_support(const GrxMprPair* q, const MF* d, GrxMprPt* o) {
+template <bool W, typename Q>
+GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
   MF nd[3] = {-d[0], -d[1], -d[2]}, b[3];
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   if (W && q->lane == 0) { q->prof[16 + 26] += 1; q->prof[16 + 27] += (q->t1 == 7 ? q->n1 : 0) + (q->t2 == 7 ? q->n2 : 0); }
@@ -1526,8 +1546,8 @@ GRX_MEM MF grx_mpr_tri_dist2(const MF* x0, const MF* b, const MF* cc, MF* w) {
 #else
 #define GRX_MPR_FN GRX_MEM
 #endif
-template <bool W>
-GRX_MPR_FN int grx_mpr_penetration(const GrxMprPair* q, MF tol, int maxit, MF* depth, MF* dir, MF* pos, MF* w1, MF* w2, MF* sep = nullptr) {
+template <bool W, typename Q>
+GRX_MPR_FN int grx_mpr_penetration(const Q* q, MF tol, int maxit, MF* depth, MF* dir, MF* pos, MF* w1, MF* w2, MF* sep = nullptr) {
 #define GRX_MPR_SEP(D) do { if (W && sep) { sep[0] = (D)[0]; sep[1] = (D)[1]; sep[2] = (D)[2]; sep[3] = 1.0f; } } while (0)
   // lane-per-pair variant: the portal lives in registers; wave-cooperative variant: in LDS (every lane writes the same values)
   GrxMprPt r0_, r1_, r2_, r3_, r4_;
@@ -1636,7 +1656,9 @@ GRX_MPR_FN int grx_mpr_penetration(const GrxMprPair* q, MF tol, int maxit, MF* d
 #undef GRX_MPR_SEP
 // analytic outward normal of a smooth geom (sphere, capsule, ellipsoid) at the world point p (see the oracle: the portal direction of a
 // shallow contact is ill-conditioned, MuJoCo replaces it for smooth geoms); returns 0 for the other types
-GRX_MEM int grx_smooth_normal(const MF* R, const MF* ce, const MF* sz, int type, const MF* p, MF* n) {
+template <typename RF>
+GRX_MEM int grx_smooth_normal(const RF* R, const MF* ce, const RF* szf, int type, const MF* p, MF* n) {
+  const MF sz[3] = {szf[0], szf[1], szf[2]};
   MF d[3] = {p[0] - ce[0], p[1] - ce[1], p[2] - ce[2]}, loc[3], nl[3];
   mulMatTVec3f(loc, R, d);
   if (type == 2) { nl[0] = loc[0]; nl[1] = loc[1]; nl[2] = loc[2]; }
@@ -1811,7 +1833,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
   for (int e = 0; e < nq; e++) {
     const int pair = queue[e], g1 = m->pair_geom1[pair], g2 = m->pair_geom2[pair];
     const float margin = m->pair_margin[pair];
-    GrxMprPair q;
+    GrxMprPairW q;
     for (int k = 0; k < 9; k++) { q.R1[k] = c->gxmat[9 * g1 + k]; q.R2[k] = c->gxmat[9 * g2 + k]; }
     q.t1 = m->geom_type[g1]; q.t2 = m->geom_type[g2]; q.hm = 0.5f * margin; q.lane = lane_;
     for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = (MF)c->gxpos[3 * g2 + k] - (MF)c->gxpos[3 * g1 + k]; }

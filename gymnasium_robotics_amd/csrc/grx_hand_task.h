@@ -145,6 +145,10 @@ struct GrxHand {
       E::grx_forward_euler(m, c, 1, lane_);
       if (c->bail && grx_lane_claim(c, lane_)) break;   // a capacity overflowed and the re-run on the large tables is booked: this run will be discarded
     }
+    // A discarded run must not touch the output rows either: its re-run may already be under way in a polling workgroup of the standing lane launch on ANOTHER XCD,
+    // and a stale observation written here would sit dirty in this XCD's L2 until the end of the launch and then overwrite the re-run's row (state right,
+    // observation / achieved goal of the truncated run: found by tests/test_gpu_manipulate.py::test_overflow_lane_polling_equals_the_serialised_rerun).
+    if (c->bail == 2) return;
     grx_hand_outputs(m, t, c, obs, achieved, palm, lane_);
   }
 };

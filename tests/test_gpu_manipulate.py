@@ -237,5 +237,10 @@ def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):
         a = torch.rand(n, 20, device="cuda:0", generator=g) * 2 - 1
         outs = [e.step(a) for e in envs]
         entered += len(envs[1].lane.entered_last_step())
-        assert torch.equal(envs[0].qpos, envs[1].qpos) and torch.equal(envs[0].qvel, envs[1].qvel) and torch.equal(outs[0][0]["observation"], outs[1][0]["observation"]), t
+        o0, o1 = outs[0][0]["observation"], outs[1][0]["observation"]
+        if not torch.equal(o0, o1):
+            d = (o0 != o1).nonzero()
+            raise AssertionError(f"step {t}: {len(d)} observation entries differ; worlds {sorted(set(d[:, 0].tolist()))[:8]} columns {sorted(set(d[:, 1].tolist()))[:12]} "
+                                 f"values {[(float(o0[w, c]), float(o1[w, c])) for w, c in d[:4].tolist()]}; entrants {envs[0].lane.entered_last_step().tolist()} / {envs[1].lane.entered_last_step().tolist()}")
+        assert torch.equal(envs[0].qpos, envs[1].qpos) and torch.equal(envs[0].qvel, envs[1].qvel), t
     assert entered >= 1, entered
