@@ -117,7 +117,7 @@ typedef struct grx_fetch_buffers {
   float* hullcache;                     /* [N, 21] or NULL: the world's cache of separating directions of its hull-vs-convex pairs (engine: GrxCtx::meshcache), carried from one
                                          * env.step() to the next.  A remembered direction is re-verified before it is trusted (it proves "no contact", exactly what the portal
                                          * search would report), so the rows never change a result: they save the search every launch otherwise starts with. */
-  grx_overflow_lane lane;               /* capacity overflows are re-run on larger tables instead of dropping contacts: see grx_overflow_lane above (and its LIMITS) */
+  grx_overflow_lane lane;               /* capacity overflows are re-run on larger tables instead of dropping contacts: see grx_overflow_lane above and its LIMITS */
 } grx_fetch_buffers;
 
 /* mirrors struct GrxPointTask / GrxPointBuffers (csrc/grx_point_task.h) */
@@ -165,7 +165,7 @@ typedef struct grx_hand_buffers {
   const int* order;             /* [8 * ceil(N / 8)] or NULL: cost-ordered dispatch, as in grx_fetch_buffers */
   int* cost;                    /* [N] or NULL */
   float* packed;                /* [N, obs_dim+2*goal_dim+2] or NULL: [obs | achieved | desired | reward | success] */
-  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane (and its LIMITS) */
+  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane and its LIMITS */
 } grx_hand_buffers;
 
 /* mirrors struct GrxAdroitTask / GrxAdroitBuffers (csrc/grx_adroit_task.h): AdroitHandHammer / Door / Pen / Relocate */
@@ -196,7 +196,7 @@ typedef struct grx_adroit_buffers {
   unsigned char* success;          /* [N] */
   int* status;                     /* [N] */
   const unsigned char* mask;       /* [N] or NULL */
-  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane (and its LIMITS) */
+  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane and its LIMITS */
 } grx_adroit_buffers;
 
 /* mirrors struct GrxKitchenTask / GrxKitchenBuffers (csrc/grx_kitchen_task.h): FrankaKitchen-v1 */
@@ -222,7 +222,7 @@ typedef struct grx_kitchen_buffers {
                                        per world), or NULL: every substep sweeps the full candidate list.  Results are identical either way. */
   int skin_stride;
   float skin_radius;                /* metres by which the broad-phase radius is inflated when a world's list is built (0.1) */
-  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane (and its LIMITS) */
+  grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane and its LIMITS */
 } grx_kitchen_buffers;
 
 /* At most 32 models (descriptor slots in constant memory) exist per process at a time; creation beyond that fails with an error, destroy frees the slot.  A model is immutable
