@@ -34,7 +34,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# per workload: env id, worlds per GPU, step-kernel name, algorithmic HBM bytes per env-step (SURVEY.md 8(d) table; DESIGN.md 5),
+# per workload: env id, worlds per GPU, step-kernel name, algorithmic HBM bytes per env-step (SURVEY.md 8(d) table; DESIGN.md 6),
 # time limit of the registered id
 WORKLOADS = {
     "fetch": dict(env_id="FetchPickAndPlace-v4", worlds=4096, kernel="grx_fetch_step_kernel", algo=715, horizon=50),
@@ -395,7 +395,7 @@ def run_rank(args, rank, world_size, local_rank):
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE
     # cannot be read from inside the process); tools/collect_profiles.py writes the summary bench.py quotes
     traffic, traffic_src = None, None
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"pmc_{tag}_hbm_traffic{'' if args.workload == 'fetch' else '_' + args.workload}.json")
         if os.path.exists(path) and n == w["worlds"]:
             with open(path) as f:
@@ -419,7 +419,7 @@ def run_rank(args, rank, world_size, local_rank):
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": w["kernel"], "kernel_ms": kern_ms,
                          "kernel_plus_overflow_lane_ms": lane_ms,      # families with an overflow lane: fast launch + the lane's concurrent and serialised launches (`achieved` is the fast launch's)
                          "algorithmic_bytes_per_launch": w["algo"] * n,
-                         "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 5"},
+                         "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 6"},
         }
         if dist_report is not None:
             line["dist"] = dist_report

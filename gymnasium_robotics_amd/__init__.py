@@ -19,7 +19,7 @@ __all__ = ["make_vec", "registered_env_ids", "env_family", "UnsupportedEnvError"
 
 
 class UnsupportedEnvError(KeyError):
-    """The reference registers this id, the device engine does not serve it (DESIGN.md section 6 says why)."""
+    """The reference registers this id, the device engine does not serve it (DESIGN.md section 8 lists what is out of scope)."""
 
 
 _NOT_SERVED = {}   # extension hook: reference id prefix -> why the engine does not serve it.  Empty since round 2 (FrankaKitchen was the last entry); env_family() consults it first

@@ -15,7 +15,7 @@ def _np(x):
 
 def check_same_step_against_next_step(make, horizon, steps, act_dim, tol=0.0, output="torch", seed=5, tol_max=None, outlier_rows=0.0, touch_from=None):
     """tol = 0: bit-equal.  tol > 0: every row within tol, except at most a fraction `outlier_rows` of the compared rows, which stay within tol_max (a rolling
-    object whose contact set flips under the different warm start of the overlapped settle, DESIGN.md section 7).  touch_from: observation columns from
+    object whose contact set flips under the different warm start of the overlapped settle, DESIGN.md section 9).  touch_from: observation columns from
     there on are touch-sensor FORCES (newtons, up to tens): compared relative to 100 * max(1, |reading|), i.e. 2e-2 N on a 1 N reading at tol = 2e-4 (the
     two paths stop their Newton solves at different iterates)"""
     A, B = make(autoreset_mode="same_step", max_episode_steps=horizon, output=output), make(autoreset_mode="next_step", max_episode_steps=horizon, output=output)

@@ -89,11 +89,13 @@ def test_emulated_kernel_matches_golden(model):
     e = np.array(errs)
     pos, vel = np.concatenate([e[:, :9], e[:, 18:39]], axis=1).max(axis=1), np.concatenate([e[:, 9:18], e[:, 39:]], axis=1).max(axis=1)
     print(f"positions p50 {np.median(pos):.2e} max {pos.max():.2e}; velocities p50 {np.median(vel):.2e} p90 {np.quantile(vel, 0.9):.2e} max {vel.max():.2e}")
-    # 14 of the 248 fixtures, all from the contact-rich starts (arm geoms pressed against the scene, contacts switching on and off inside the step,
-    # hull / cylinder contacts through the portal routine), are off by 1e-4 ... 5e-3: the activation-flip and single-point-contact sensitivity of
-    # DESIGN.md section 7; the other 94 % sit at 4e-7
-    assert np.quantile(pos, 0.9) < 1e-4 and np.quantile(pos, 0.95) < 1e-3 and pos.max() < 1e-2
-    assert np.median(vel) < 1e-4 and np.quantile(vel, 0.9) < 5e-3 and vel.max() < 0.5
+    # With the portal routine in fp64 ("Mixed precision") every snapshot that is not within 1e-6 of a constraint-activation boundary is within 1e-4
+    # -- the policy of tests/test_gpu_tolerance_table.py, which runs all 248 on the MI355X; here every fourth, emulated.
+    gap = g["activation_gap"][::4][: len(pos)] if "activation_gap" in g.files else np.full(len(pos), np.inf)
+    posed = gap >= 1e-6
+    assert posed.mean() > 0.6
+    assert pos[posed].max() < 1e-4 and vel[posed].max() < 1e-4, (pos[posed].max(), vel[posed].max())
+    assert np.mean(pos < 1e-4) >= 0.98 and np.mean(vel < 1e-4) >= 0.98 and pos.max() < 1e-2 and vel.max() < 0.5
 
 
 def test_emulated_reset_forward_matches_golden(model):

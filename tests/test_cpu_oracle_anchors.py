@@ -424,7 +424,7 @@ def test_anchor_20_portal_routine_agrees_with_the_analytic_sphere(other):
         # a portal within eps = 1e-6 of the surface pins the distance to eps, the normal of a radius-r surface only to sqrt(2 eps / r) = 5e-3, the point to r times that
         # The DEPTH of a portal search is measured along the final portal's normal from the centre ray, not along the true minimal translation: against a flat face
         # (box) or along the centre line (sphere) it is exact to eps, against a curved surface met obliquely (capsule) it over-estimates by up to ~7 % of the
-        # depth -- 23 micrometres at 0.35 mm in the worst of these 40 poses.  A property of the published algorithm (DESIGN.md section 7), bounded by this test.
+        # depth -- 23 micrometres at 0.35 mm in the worst of these 40 poses.  A property of the published algorithm (DESIGN.md section 9), bounded by this test.
         assert -6e-4 < a[0] < 0 and abs(a[0] - b[0]) < 5e-6 + 0.09 * abs(a[0]) and np.abs(a[4:7] - sgn * b[4:7]).max() < 1.2e-2 and np.abs(a[1:4] - b[1:4]).max() < 1e-3, (a[:7], b[:7])
         if 'capsule' not in other:
             assert abs(a[0] - b[0]) < 5e-6, (a[0], b[0])

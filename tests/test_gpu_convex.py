@@ -94,7 +94,7 @@ def test_slide_reset_matches_golden_and_puck_slides_when_hit():
     obs, _ = env.reset(seed=int(g["reset_seed"][0]))
     assert np.abs(obs["desired_goal"][:, :2] - g["reset_goal"][:, :2]).max() < 2e-5      # pure RNG
     # height_offset = the puck's height after the 10 free-running settle steps (200 substeps) of _env_setup: the rocking single-contact
-    # support (DESIGN.md section 7) makes that height path-dependent at the 0.2 mm level
+    # support (DESIGN.md section 9) makes that height path-dependent at the 0.2 mm level
     assert np.abs(obs["desired_goal"][:, 2] - g["reset_goal"][:, 2]).max() < 5e-4
     assert np.abs(np.delete(obs["observation"] - g["reset_obs"], np.r_[11:14, 17:20], axis=1)).max() < 5e-4
     # the goal lies beyond the arm's reach (target_offset 0.4 in x: slide.py:166-189): the puck has to be hit, not carried

@@ -183,7 +183,7 @@ def test_same_step_autoreset_matches_next_step(env_id):
     from autoreset_cases import check_same_step_against_next_step
 
     make = lambda **kw: grx.make_vec(env_id, num_envs=40, device="cuda:0", **kw)
-    # the egg: a rolling object whose contact set flips under the different warm start -- its velocity components are what diverges (DESIGN.md section 7)
+    # the egg: a rolling object whose contact set flips under the different warm start -- its velocity components are what diverges (DESIGN.md section 9)
     check_same_step_against_next_step(make, horizon=5, steps=12, act_dim=20, tol=2e-4, tol_max=0.3 if "Egg" in env_id else 1e-2, outlier_rows=0.3 if "Egg" in env_id else 0.15, output="torch",
                                       touch_from=61 if "Touch" in env_id else None)
 

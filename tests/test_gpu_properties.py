@@ -117,7 +117,7 @@ def test_fetch_slide_4096_worlds_puck_slides_and_stays_on_the_table():
     on_table = z > 0.405                                      # friction 0.1: pucks that were hit hard slide off the 1.25 m x 0.9 m table
     assert on_table.mean() > 0.85 and z[on_table].max() < 0.4225 and z.min() > 0.0, (float(on_table.mean()), float(z.max()), float(z.min()))   # resting height 0.42 minus the soft single-contact penetration; nothing pops up or tunnels
     moved = np.linalg.norm(q[:, -7:-5] - p0[:, :2].cpu().numpy(), axis=1)
-    # some pucks were hit and slid; untouched ones stay put up to the creep of the rocking single-contact support (DESIGN.md section 7): 2 mm or 8 mm per 40 steps,
+    # some pucks were hit and slid; untouched ones stay put up to the creep of the rocking single-contact support (DESIGN.md section 9): 2 mm or 8 mm per 40 steps,
     # depending on which of two rocking modes the 200 settle substeps of _env_setup end in -- the ORACLE switches from the one to the other when the puck starts
     # 1e-6 m higher, and follows this engine to 5e-6 over 12 free-running steps from either reset state (round 4, tools/slide_probe.py)
     assert (moved > 0.02).mean() > 0.05 and (moved < 1.2e-2).mean() > 0.2

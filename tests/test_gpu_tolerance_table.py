@@ -13,7 +13,7 @@ Asserted here, on the MI355X, through the C ABI:
   (2) over ALL snapshots of a family at least 99 % are within 1e-4 on every component (the rest are below the gap, listed in tests/golden/tolerance_table.json);
   (3) touch-sensor channels (forces in newton, up to 3e1): |error| <= 1e-4 * max(1, |reading|) on >= 90 % of the gap >= 1e-6 snapshots, <= 5e-4 * max(1, |reading|) on
       all of them -- a contact force is (stiffness 1e4 ... 1e5 N/m) x (a depth that an fp32 state resolves to 1e-8 m): 1e-4 N absolute is below what fp64 ARITHMETIC
-      on an fp32 STATE delivers (tools/emu_mixed.py --fp32 "": 88 % of the snapshots within 1e-4 N, max 1.9e-4), see DESIGN.md section 7;
+      on an fp32 STATE delivers (tools/emu_mixed.py --fp32 "": 88 % of the snapshots within 1e-4 N, max 1.9e-4), see DESIGN.md section 5;
   (4) two snapshots are known to sit just above the bound although no switch is near (KNOWN below, with their measured values: a joint velocity of 8 rad/s off by
       1.04e-4, the ant's torso rate off by 1.29e-4 after 5 RK4 substeps with a wall contact); they are asserted at 1.5e-4, everything else at 1e-4.
 tests/golden/tolerance_table.json (tools/measure_tolerances.py) is the record of the measured quantiles and of every snapshot above 1e-4 with its gap."""

@@ -155,6 +155,10 @@ if __name__ == "__main__":
         for w in sys.argv[3:]:
             kernel_stats(tag, None if w == "fetch" else w)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "pmc":            # HBM traffic only (A/B of builds: GRX_HIP_LIB selects the library)
+        for w in sys.argv[3:]:
+            pmc(tag, None if w == "fetch" else w)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "workloads":      # kernel stats + HBM traffic of the other BASELINE configs
         for w in (sys.argv[3:] or ["antmaze", "hand_touch", "adroit", "hand_reach"]):
             kernel_stats(tag, w)

@@ -68,7 +68,7 @@ def run_family(L, family, fp64, every=1, only=None, round_inputs=False, ref=None
         if jitter:   # one fp32 ulp of relative noise on every state word: what any engine that holds its state in fp32 sees after one substep
             a = a * (1.0 + jr.uniform(-1, 1, a.shape) * JITTER)
         return np.ascontiguousarray(a, dtype=dt).copy()
-    idx = list(range(0, g["obs"].shape[0], every)) if only is None else [only]
+    idx = list(range(0, g["obs"].shape[0], every)) if only is None else ([only] if np.isscalar(only) else list(only))
     out = np.zeros((len(idx), g["obs"].shape[1]))
     status = np.zeros(len(idx), np.int64)
     for j, i in enumerate(idx):

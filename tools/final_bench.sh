@@ -1,6 +1,6 @@
 # round-end evidence run (ON the GPU box, from the repo root): every bench line with its CPU baseline, rocprofv3 kernel stats + PMC traffic of every workload
-#   sh tools/final_bench.sh [tag]        (default tag: r03)
-TAG=${1:-r03}
+#   sh tools/final_bench.sh [tag]        (default tag: r04)
+TAG=${1:-r04}
 set -x
 mkdir -p gpurun_out
 python tools/collect_profiles.py $TAG > gpurun_out/collect_fetch.log 2>&1
