@@ -118,16 +118,12 @@ def test_emulated_egg_step_matches_golden():
         e = np.abs(emu.hand_obs[:61] - g["obs"][i])
         pe, ve = max(e[:24].max(), e[54:].max()), e[24:54].max()
         pos_err.append(pe); vel_err.append(ve)
-        assert pe < 2e-2 and ve < 2.0, (i, pe, ve, g["activation_gap"][i])
-    # 20 substeps with ~3 egg contacts, 24 joint limits and the tendon limits: nearly every snapshot has some unilateral row within 1e-5 m of
-    # switching (median activation gap of the fixture: 3.5e-6 m), and the distance of a convex contact carries the portal's tolerance-level
-    # noise on top of the fp32 drift.  Asserted: the bulk agrees tightly, every snapshot agrees loosely (above).
-    # measured quantiles of this fixture (p50 / p75 / p90 / p99 / max): positions 4.5e-7 / 4.2e-5 / 5.7e-4 / 2.7e-3 / 6.5e-3, velocities
-    # 4.5e-5 / 1.6e-3 / 3.6e-2 / 0.21 / 0.38 (the same numbers as the GPU's: tests/golden/tolerance_table.json, HandEgg); asserted at 2x
+        assert (pe < 1e-4 and ve < 1e-4) if g["activation_gap"][i] >= 1e-6 else (pe < 2e-2 and ve < 2.0), (i, pe, ve, g["activation_gap"][i])
+    # With the portal search in fp64 (round 4) every well-posed snapshot meets 1e-4 (above); over the whole fixture (HandEgg row of tests/golden/tolerance_table.json:
+    # positions p99 1.1e-6, velocities p99 5.5e-5, one snapshot 5e-7 m from a contact switch at 9.9e-2) the bulk sits at rounding level:
     pos_err, vel_err = np.array(pos_err), np.array(vel_err)
-    for err, bounds in ((pos_err, (1e-6, 1e-4, 1.2e-3, 1.3e-2)), (vel_err, (1e-4, 3.2e-3, 7.2e-2, 0.76))):
-        got = (np.median(err), np.quantile(err, 0.75), np.quantile(err, 0.9), err.max())
-        assert all(a <= b for a, b in zip(got, bounds)), (got, bounds)
+    assert np.median(pos_err) < 1e-6 and np.quantile(pos_err, 0.9) < 1e-5 and np.median(vel_err) < 5e-5 and np.quantile(vel_err, 0.9) < 1e-4, (
+        np.median(pos_err), np.quantile(pos_err, 0.9), np.median(vel_err), np.quantile(vel_err, 0.9))
 
 
 def test_emulated_egg_touch_matches_golden():

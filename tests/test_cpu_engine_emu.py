@@ -34,14 +34,10 @@ def test_emulated_kernel_step_matches_golden(emu_factory, task, stride):
         emu.step(g["action"][i])
         assert emu.status.value == 0
         e = np.abs(emu.obs - g["obs"][i])
-        if task == "FetchSlide":
-            # The puck rests on ONE contact whose position inside the flat cap is not unique (the convex narrow phase reports some
-            # point of the portal): fp32 and fp64 legitimately pick different points, the torque differs and so do the puck's rotation
-            # (obs 11:14) and rotational velocity (17:20).  Everything translational is held to the usual bounds.
-            assert e[11:14].max() < 5e-3 and e[17:20].max() < 2e-2, (i, e[11:14].max(), e[17:20].max())
-            e = np.delete(e, np.r_[11:14, 17:20])
+        # (FetchSlide's puck rests on ONE contact of the convex routine; with the portal search in fp64 and the object-block refinement of the Newton solve its rotation
+        # meets the same 1e-4 as everything else: DESIGN.md section 4, "Mixed precision".)
         err = e.max()
-        if g["activation_gap"][i] >= 2e-5:
+        if g["activation_gap"][i] >= 1e-6:      # the policy of tests/test_gpu_tolerance_table.py / test_cpu_emu_tolerance_policy.py
             worst = max(worst, err)
             assert err < 1e-4, (i, err)
         else:
@@ -64,9 +60,8 @@ def test_emulated_kernel_hull_contacts_match_golden(emu_factory):
     errs = np.array(errs)
     sel = hull[::2]
     assert sel.sum() > 60
-    # fp32 vs fp64 portal refinement: the contact point of a face-face hull contact is not unique (any point of the overlap polygon), so the
-    # tolerance is wider than for the analytic pairs; the median stays at rounding level
-    assert np.median(errs[sel]) < 2e-5 and np.quantile(errs[sel], 0.9) < 1e-3 and errs.max() < 2e-2, (np.median(errs[sel]), np.quantile(errs[sel], 0.9), errs.max())
+    # the portal search runs in fp64 and hull-vertex ties are broken in fp64 (round 4): hull contacts meet the bound of the analytic pairs
+    assert np.median(errs[sel]) < 2e-6 and errs.max() < 1e-4, (np.median(errs[sel]), errs.max())
 
 
 def test_emulated_reset_forward_matches_golden(emu_factory):

@@ -101,7 +101,7 @@ def test_emulated_hand_step_matches_golden(hand_model):
         err = np.abs(emu.hand_obs[:63] - g["obs"][i]).max()
         errs.append(err)
         tendon_steps += int(g["ntendon_rows"][i] > 0); contact_steps += int(g["ncon"][i] > 0)
-        assert err < (2e-4 if g["activation_gap"][i] >= 2e-5 else 5e-3), (i, err)
+        assert err < (1e-4 if g["activation_gap"][i] >= 1e-6 else 5e-3), (i, err)
         assert np.array_equal(emu.hand_achieved, emu.hand_obs[48:63])
     assert tendon_steps > 50 and contact_steps > 30   # the fixture exercises tendon-limit rows and the explicit contact pairs
     assert np.median(errs) < 2e-5
