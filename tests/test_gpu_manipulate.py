@@ -243,4 +243,6 @@ def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):
             raise AssertionError(f"step {t}: {len(d)} observation entries differ; worlds {sorted(set(d[:, 0].tolist()))[:8]} columns {sorted(set(d[:, 1].tolist()))[:12]} "
                                  f"values {[(float(o0[w, c]), float(o1[w, c])) for w, c in d[:4].tolist()]}; entrants {envs[0].lane.entered_last_step().tolist()} / {envs[1].lane.entered_last_step().tolist()}")
         assert torch.equal(envs[0].qpos, envs[1].qpos) and torch.equal(envs[0].qvel, envs[1].qvel), t
+        for e, o in zip(envs, (o0, o1)):      # the observation row belongs to the state row it is returned with (a discarded fast-kernel run must not leave its row behind)
+            assert torch.equal(o[:, :24], e.qpos[:, :24]) and torch.equal(o[:, 24:48], e.qvel[:, :24]), t
     assert entered >= 1, entered
