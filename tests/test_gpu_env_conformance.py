@@ -29,6 +29,11 @@ def _equal(a, b):
     return fa.keys() == fb.keys() and all(np.array_equal(fa[k], fb[k]) for k in fa)
 
 
+def _close(a, b, atol):
+    fa, fb = dict(_flat(a)), dict(_flat(b))
+    return fa.keys() == fb.keys() and all(np.allclose(fa[k], fb[k], rtol=1e-5, atol=atol) for k in fa)
+
+
 def _check_obs(env, obs, n):
     assert env.observation_space.contains(obs), "observation outside observation_space"
     for name, arr in _flat(obs):
@@ -48,16 +53,20 @@ def test_registered_id_conforms(env_id):
     goal_env = isinstance(e1.single_observation_space, dict)
     if goal_env:
         assert {"observation", "achieved_goal", "desired_goal"} <= set(e1.single_observation_space.keys())      # core.py:33-43
-    # reset: (obs, info), obs in the space, the same seed reproduces it, another seed gives another episode
+    # reset: (obs, info), obs in the space, the same seed reproduces it, another seed gives another episode.  Both environments go through the SAME sequence of resets:
+    # the manipulation resets run their ten settle steps from the solver warm start the previous episode left, in the reference as here (manipulate.py:205-224), so two
+    # environments agree bit for bit only after the same history, and a repeated reset(seed=) of one environment agrees to solver tolerance (fp32 here) -- which is also what
+    # check_env asks for: it compares the two resets with data_equivalence's tolerance, not bit for bit [3P]
+    o3, _ = e1.reset(seed=456)
+    e2.reset(seed=456)
     o1, i1 = e1.reset(seed=123)
     o2, i2 = e2.reset(seed=123)
     assert isinstance(i1, dict) and _equal(o1, o2)
     _check_obs(e1, o1, n)
-    o1b, _ = e1.reset(seed=123)
-    assert _equal(o1, o1b), "reset(seed=) is not deterministic"
-    o3, _ = e2.reset(seed=456)
     assert not _equal(o1, o3), "a different seed gave the same first observation"
+    o1b, _ = e1.reset(seed=123)
     e2.reset(seed=123)
+    assert _close(o1, o1b, 5e-5), "reset(seed=) is not deterministic"
     # step: types, shapes, membership; the seeded two-env rollout of test_envs.py:64-117
     e1.action_space.seed(0)
     for t in range(4):
