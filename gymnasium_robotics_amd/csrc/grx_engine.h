@@ -962,19 +962,6 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit 
   if (n == 33) return grx_sym_solve_reg<33>(A, n, x, lane_);
   if (n == 36) return grx_sym_solve_reg<36>(A, n, x, lane_);
 #endif
-#if defined(GRX_EMU) && defined(GRX_EXP_SOLVE64)
-  {   // experiment: the linear solve in double (LDL' from the last dof, like the fp32 routine)
-    static double B[40 * 40], y[40];
-    for (int i = 0; i < n * n; i++) B[i] = A[i];
-    for (int i = 0; i < n; i++) y[i] = x[i];
-    for (int k = n - 1; k >= 0; k--) { const double rinv = 1.0 / B[k * n + k]; for (int i = 0; i < k; i++) { const double ti = B[k * n + i] * rinv; for (int j = 0; j < k; j++) B[i * n + j] -= ti * B[k * n + j]; } B[k * n + k] = rinv; }
-    for (int k = n - 1; k > 0; k--) { const double yk = y[k] * B[k * n + k]; for (int i = 0; i < k; i++) y[i] -= B[k * n + i] * yk; }
-    for (int i = 0; i < n; i++) y[i] *= B[i * n + i];
-    for (int i = 0; i < n - 1; i++) { const double xi = y[i]; for (int k = i + 1; k < n; k++) y[k] -= B[k * n + i] * B[k * n + k] * xi; }
-    for (int i = 0; i < n; i++) x[i] = (float)y[i];
-    return 0;
-  }
-#endif
 #if defined(GRX_EMU)
   if (n == 21 || n == 14 || n == 15 || n == 24 || n == 29 || n == 30 || n == 33 || n == 36) {   // mirror the device: these sizes are solved without touching A
     static float copy[36 * 36];
@@ -2674,12 +2661,9 @@ GRX_MEM int grx_row_pos(int info, int id, int d) {
   return ((unsigned)jb < (unsigned)GRX_ROWB_LEN(id)) ? GRX_ROW_LEN(info) + jb : -1;
 }
 // row r of J times a dof vector
-#ifndef GRX_ROWDOT_ACC
-#define GRX_ROWDOT_ACC float
-#endif
-GRX_MEM GRX_ROWDOT_ACC grx_row_dot(const GrxCtx* c, int r, const float* v) {
+GRX_MEM float grx_row_dot(const GrxCtx* c, int r, const float* v) {
   const int info = c->efc_row[r], off = GRX_ROW_OFF(info), lo = GRX_ROW_LO(info), len = GRX_ROW_LEN(info);
-  GRX_ROWDOT_ACC s = 0;
+  float s = 0;
 #pragma unroll 8
   for (int j = 0; j < len; j++) s += c->Jp[off + j] * v[lo + j];
   if (S::kTwoSpan) {
@@ -3589,28 +3573,15 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
     if (phase == 0) {
       // After a step, M a and J a - aref are current (carried) and convergence has already been decided: the only thing the evaluation would
       // still produce are the row forces, which nothing reads after the solve unless the model has touch sensors.
-#ifdef GRX_DBG_NO_NOSLIP
-      const int noslip = 0;
-#else
       const int noslip = S::kNoslip && m->noslip_iterations > 0;
-#endif
       const int skip_eval = done && it > 0 && (S::kFixed ? S::NT : m->ntouch) == 0 && !noslip;
-#ifdef GRX_EXP_NO_CARRY
-      const int changed = skip_eval ? 0 : grx_newton_eval(m, c, c->qacc, nefc, 0, lane_);
-#else
       const int changed = skip_eval ? 0 : grx_newton_eval(m, c, c->qacc, nefc, it > 0, lane_);
-#endif
       GRX_TICK(c, GRX_P_NEVAL);
       // a full Newton step (alpha = 1 accepted) that did not change any row state landed on the exact minimiser of the
       // piecewise-quadratic cost: no further iteration can move it beyond rounding
-#ifndef GRX_NO_FULLSTEP_EXIT
       if (it > 0 && full_step && !changed) { done = 1; exact_exit = 1; }
-#endif
       if (done || it >= m->iterations) {   // MuJoCo's option iterations (default 100; the hand models: 20)
 #ifndef GRX_NO_OBJ_REFINE
-#ifdef GRX_OBJ_REFINE_COUPLED
-        if (exact_exit && m->nfreeobj == 6 && keepA) grx_refine_object_block(m, c, nefc, lane_);
-#else
         // only models whose free object can rest on ONE contact of the general convex routine (puck, egg, pen: a flat-on-flat or line contact stands on a single point, the
         // object block of the Hessian has a weak rocking mode and fp32 resolves the full step to ~4e-4 of its size there); a box object stands on its corner contacts and
         // the refinement changes nothing at the 1e-7 level (tools/emu_tolerances.py with -DGRX_NO_OBJ_REFINE: FetchPush / PickAndPlace identical), at 3 % of the step
@@ -3619,7 +3590,6 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         if (exact_exit && last_split == 6 && keepA && weak_object) { g_grx_newton_stats[4]++; if (last_stepmax > GRX_OBJ_REFINE_MINSTEP) g_grx_newton_stats[5]++; }
 #endif
         if (exact_exit && last_split == 6 && keepA && weak_object && last_stepmax > GRX_OBJ_REFINE_MINSTEP) grx_refine_object_block(m, c, nefc, lane_);
-#endif
 #endif
         if (noslip) grx_noslip(m, c, nefc, lane_);   // re-solves the friction forces without regularisation: new qacc, new M a
         // converged: at the minimiser the gradient M a - qfrc_smooth - J'f vanishes, so the joint-space constraint force
@@ -3798,9 +3768,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       if (stepmax <= GRX_NEWTON_RTOL * qmax + GRX_NEWTON_ATOL) done = 1;
       // an exact full step (no row changes state on [0,1], decided with the very arithmetic the carried evaluation would repeat) lands on
       // the minimiser of the current piece and leaves every row in its state: converged
-#ifndef GRX_NO_FULLSTEP_EXIT
       if (full_step == 2) { done = 1; exact_exit = 1; }
-#endif
     } else if (phase == 2) {
       FOR_LANES { for (int i = lane; i < nv; i += 64) { float q = c->qacc_smooth[i]; c->qacc[i] = q; c->qacc_ws[i] = q; c->qfrc_constraint[i] = 0; } }
       WAVE_SYNC();
