@@ -1512,6 +1512,10 @@ extern "C" int grx_fetch_sample_resets(uint64_t* states, const int64_t* idx, int
 // world to reset walks its stream through the data-dependent loops of _reset_sim / _sample_goal (fetch_env.py:153-166, 388-391) in the reference's fp64 arithmetic
 // (explicitly rounded multiplies / adds: no fused contraction, the host routine and numpy have none) and writes the float32 sample row the reset kernel reads.
 // Bit-equal to the host routine and therefore to Generator.uniform (tests/test_gpu_fetch.py); nothing is drawn, staged or uploaded by the host.
+// (`__dmul_rn` / `__dadd_rn` are plain `*` / `+` in HIP, and hipcc's default -ffp-contract=fast fuses them -- ignoring `#pragma clang fp contract(off)` -- into one fma: the
+// fused a + (b - a) d differs from numpy's two roundings in ~12 % of the draws, in the last bit: invisible in the float32 Fetch rows, visible in the float64 Adroit rows.  The
+// rounded product is therefore passed through an empty asm statement the optimiser cannot look through.)
+__device__ __forceinline__ double grx_rounded(double x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double grx_pcg64_uniform_dev(unsigned long long& hi, unsigned long long& lo, unsigned long long ihi, unsigned long long ilo, double a, double b) {
   const unsigned long long mhi = 0x2360ED051FC65DA4ULL, mlo = 0x4385DF649FCCF645ULL;
   const unsigned long long plo = lo * mlo, phi = __umul64hi(lo, mlo) + hi * mlo + lo * mhi;
@@ -1520,7 +1524,7 @@ __device__ __forceinline__ double grx_pcg64_uniform_dev(unsigned long long& hi, 
   const unsigned long long x = hi ^ lo; const unsigned rot = (unsigned)(hi >> 58);
   const unsigned long long r = (x >> rot) | (x << ((64 - rot) & 63));
   const double d = __dmul_rn((double)(r >> 11), 1.0 / 9007199254740992.0);
-  return __dadd_rn(a, __dmul_rn(__dsub_rn(b, a), d));
+  return __dadd_rn(a, grx_rounded(__dmul_rn(grx_rounded(__dsub_rn(b, a)), d)));
 }
 __global__ void __launch_bounds__(64)
 grx_fetch_sample_kernel(unsigned long long* __restrict__ states, const int* __restrict__ idx, int n, int has_object, int in_air, double obj_range, double target_range,
@@ -1534,7 +1538,7 @@ grx_fetch_sample_kernel(unsigned long long* __restrict__ states, const int* __re
   if (has_object) {
     for (;;) {
       const double dx = __dsub_rn(ox, g0), dy = __dsub_rn(oy, g1);
-      if (!(__dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))) < 0.1)) break;
+      if (!(__dsqrt_rn(__dadd_rn(grx_rounded(__dmul_rn(dx, dx)), grx_rounded(__dmul_rn(dy, dy)))) < 0.1)) break;
       ox = __dadd_rn(g0, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -obj_range, obj_range));
       oy = __dadd_rn(g1, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -obj_range, obj_range));
     }
@@ -1558,6 +1562,45 @@ extern "C" int grx_fetch_sample_resets_device(uint64_t* states, const int* idx, 
   if (n <= 0) return 0;
   hipLaunchKernelGGL(grx_fetch_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)states, idx, n, has_object, target_in_the_air, obj_range,
                      target_range, target_offset[0], target_offset[1], target_offset[2], gripper_xpos[0], gripper_xpos[1], gripper_xpos[2], height_offset, samples);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ---- reset_model's draws of AdroitHandHammer / Door / Relocate ON THE DEVICE (include/grx_capi.h, grx_adroit_sample_resets_device; adroit_hammer.py:374-376,
+// adroit_door.py:362-370, adroit_relocate.py:353-372): one thread per world to reset draws the task's uniforms from the world's PCG64 stream in HBM (the reference's
+// fp64 arithmetic, explicitly rounded) and rewrites the world's model edit: the fp64 body_pos row get_env_state reports, the fp32 shift pose the engine applies
+// (translation = body_pos - the XML pose, identity rotation) and, for relocate, the target site.  reset_model rewrites only SOME components of body_pos (hammer: z,
+// relocate: x / y): the others keep what a set_env_state wrote, as in the reference.  (The pen's draws stay on the host: euler2quat goes through sin / cos.)
+__global__ void __launch_bounds__(64)
+grx_adroit_sample_kernel(unsigned long long* __restrict__ states, const long long* __restrict__ idx, int n, int kind, double p0x, double p0y, double p0z,
+                         double* __restrict__ edit, double* __restrict__ target64, float* __restrict__ shift, float* __restrict__ target) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n) return;
+  const int w = (int)idx[k];
+  unsigned long long hi = states[4 * w], lo = states[4 * w + 1];
+  const unsigned long long ihi = states[4 * w + 2], ilo = states[4 * w + 3];
+  double ex = edit[3 * w], ey = edit[3 * w + 1], ez = edit[3 * w + 2];
+  if (kind == 0) ez = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, 0.1, 0.25);
+  else if (kind == 1) { ex = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -0.3, -0.2); ey = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, 0.25, 0.35); ez = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, 0.252, 0.35); }
+  else {
+    ex = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -0.15, 0.15); ey = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -0.15, 0.3);
+    const double tx = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -0.2, 0.2), ty = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -0.2, 0.2), tz = grx_pcg64_uniform_dev(hi, lo, ihi, ilo, 0.15, 0.35);
+    target64[3 * w] = tx; target64[3 * w + 1] = ty; target64[3 * w + 2] = tz;
+    target[3 * w] = (float)tx; target[3 * w + 1] = (float)ty; target[3 * w + 2] = (float)tz;
+  }
+  states[4 * w] = hi; states[4 * w + 1] = lo;
+  edit[3 * w] = ex; edit[3 * w + 1] = ey; edit[3 * w + 2] = ez;
+  float* s = shift + 7 * (size_t)w;
+  s[0] = (float)__dsub_rn(ex, p0x); s[1] = (float)__dsub_rn(ey, p0y); s[2] = (float)__dsub_rn(ez, p0z); s[3] = 1.0f; s[4] = 0.0f; s[5] = 0.0f; s[6] = 0.0f;
+}
+extern "C" int grx_adroit_sample_resets_device(uint64_t* states, const int64_t* idx, int n, int kind, const double* shift_pos0, double* edit, double* target64, float* shift,
+                                               float* target, void* stream) {
+  if (!states || !idx || !shift_pos0 || !edit || !shift) return fail("grx_adroit_sample_resets_device: null argument");
+  if (kind != 0 && kind != 1 && kind != 3) return fail("grx_adroit_sample_resets_device: kind must be 0 (hammer), 1 (door) or 3 (relocate)");
+  if (kind == 3 && (!target || !target64)) return fail("grx_adroit_sample_resets_device: relocate needs the target rows");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(grx_adroit_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)states, (const long long*)idx, n, kind, shift_pos0[0],
+                     shift_pos0[1], shift_pos0[2], edit, target64, shift, target);
   HIP_OK(hipGetLastError());
   return 0;
 }

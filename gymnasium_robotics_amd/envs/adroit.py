@@ -68,15 +68,51 @@ class AdroitVecEnv(GoalVecEnv):
         self._init_qpos = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32)).to(d)   # MujocoEnv.init_qpos [3P]: data.qpos after mj_resetData
         # the model edit of each world as the reference's get_env_state reports it: body_pos (hammer board, door frame, relocate ball) or body_quat (pen target)
         edit0 = self.model.info["shift_quat0"] if self.task_name == "pen" else self.model.info["shift_pos0"]
-        self.model_edit = np.tile(np.asarray(edit0, dtype=np.float64), (n, 1))
-        self.target_pos = np.zeros((n, 3)) if self.task_name == "relocate" else None
-        self.np_randoms = [np_random(None)[0] for _ in range(n)]
+        # hammer / door / relocate: reset_model's draws are uniforms plus additions -- they are made ON THE DEVICE from device-resident PCG64 streams
+        # (grx_adroit_sample_resets_device, bit-equal to numpy), and the fp64 rows get_env_state reports live in HBM next to them.  The pen's draws go through
+        # euler2quat (sin / cos: no bit-exact device twin of numpy's libm) and stay per-world numpy generators on the host, staged through pinned memory.
+        self._device_draws = self.task_name in ("hammer", "door", "relocate")
+        if self._device_draws:
+            self._edit_dev = torch.from_numpy(np.tile(np.asarray(edit0, dtype=np.float64), (n, 1))).to(d)
+            self._target_dev = torch.zeros(n, 3, dtype=torch.float64, device=d) if self.task_name == "relocate" else None
+            self._shift_pos0 = np.ascontiguousarray(self.model.info["shift_pos0"], dtype=np.float64)
+            self._seed_worlds([None] * n)
+        else:
+            self._model_edit = np.tile(np.asarray(edit0, dtype=np.float64), (n, 1))
+            self.np_randoms = [np_random(None)[0] for _ in range(n)]
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
         self.step_events = []      # (start, end) HIP events around the whole launch group of a step: fast kernel + the overflow lane's launches
         self.kernel_events = None
         self._stage = PinnedStager(n, 10, self.device)
+
+    def _seed_worlds(self, seeds):
+        """one numpy PCG64 per world, seeded like gymnasium.utils.seeding.np_random [3P]; only the raw 128-bit (state, inc) pairs are kept, on the device"""
+        st = np.zeros((self.num_envs, 4), np.uint64)
+        mask = (1 << 64) - 1
+        for i, sd in enumerate(seeds):
+            s = np_random(sd)[0].bit_generator.state["state"]
+            st[i] = [s["state"] >> 64, s["state"] & mask, s["inc"] >> 64, s["inc"] & mask]
+        self._rng_dev = torch.from_numpy(st.view(np.int64)).to(self.device)
+
+    # model.body_pos / body_quat of every world as the reference's get_env_state reports it (float64 [N, 3 or 4]); reading it from a device-draw task synchronises
+    @property
+    def model_edit(self):
+        return self._edit_dev.cpu().numpy() if self._device_draws else self._model_edit
+
+    @model_edit.setter
+    def model_edit(self, value):
+        value = np.asarray(value, dtype=np.float64).reshape(self.num_envs, -1)
+        if self._device_draws:
+            self._edit_dev.copy_(torch.from_numpy(np.ascontiguousarray(value)).to(self.device))
+        else:
+            self._model_edit = value.copy()
+
+    @property
+    def target_pos(self):
+        """relocate: model.site_pos[target] of every world (float64 [N, 3]); None for the other tasks"""
+        return None if self.task_name != "relocate" else self._target_dev.cpu().numpy()
 
     @property
     def board_z(self):
@@ -139,11 +175,15 @@ class AdroitVecEnv(GoalVecEnv):
     def _reset_worlds(self, idx):
         if len(idx) == 0:
             return None
-        d = sample_reset_batch(self.task_name, [self.np_randoms[w] for w in idx], self.model, current=self.model_edit[idx] if self.task_name in ("hammer", "relocate") else None)
-        self.model_edit[idx] = d["edit"]
-        if self.target_pos is not None:
-            self.target_pos[idx] = d["target"]
-        ti = self._write_edits(idx, d["shift"], d["target"] if self.target is not None else None)
+        if self._device_draws:      # the index list goes up through pinned memory; the draws, the fp64 edit rows and the fp32 shift / target rows are written by one kernel
+            ti = self._stage(np.asarray(idx, dtype=np.int64))
+            _native.check(self._L.grx_adroit_sample_resets_device(
+                self._rng_dev.data_ptr(), ti.data_ptr(), len(idx), int(self.task.kind), self._shift_pos0.ctypes.data, self._edit_dev.data_ptr(),
+                None if self._target_dev is None else self._target_dev.data_ptr(), self.shift.data_ptr(), None if self.target is None else self.target.data_ptr(), self._stream()))
+        else:
+            d = sample_reset_batch(self.task_name, [self.np_randoms[w] for w in idx], self.model)
+            self._model_edit[idx] = d["edit"]
+            ti = self._write_edits(idx, d["shift"], None)
         self.qpos[ti] = self._init_qpos
         self.qvel.index_fill_(0, ti, 0.0)      # (x[ti] = 0.0 would upload a host scalar: a synchronising copy)
         self.qacc_ws.index_fill_(0, ti, 0.0)
@@ -157,7 +197,10 @@ class AdroitVecEnv(GoalVecEnv):
     def reset(self, *, seed=None, options=None):
         if seed is not None:
             seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
-            self.np_randoms = [np_random(s)[0] for s in seeds]
+            if self._device_draws:
+                self._seed_worlds(seeds)
+            else:
+                self.np_randoms = [np_random(s)[0] for s in seeds]
         with torch.cuda.device(self.device):
             self._reset_worlds(np.arange(self.num_envs))
             if options is not None and "initial_state_dict" in options:
@@ -240,13 +283,13 @@ class AdroitVecEnv(GoalVecEnv):
         else:
             if self.task_name == "relocate":   # model.body_pos[Object] = obj_pos - qpos[OBJTx..OBJTz] (adroit_relocate.py:405-407)
                 edit = np.asarray(state_dict["obj_pos"], dtype=np.float64) - qp[:, 30:33]
-                self.target_pos[:] = np.asarray(state_dict["target_pos"], dtype=np.float64)
+                self._target_dev.copy_(torch.from_numpy(np.ascontiguousarray(state_dict["target_pos"], dtype=np.float64)).to(self.device))
             else:
                 edit = np.asarray(state_dict[need[0][0]], dtype=np.float64)
             shifts = group_shift(self.model, pos=edit)
-        self.model_edit[:] = edit
+        self.model_edit = edit
         with torch.cuda.device(self.device):
-            self._write_edits(np.arange(n), shifts, self.target_pos)
+            self._write_edits(np.arange(n), shifts, None if self.task_name != "relocate" else np.asarray(state_dict["target_pos"], dtype=np.float64))
             self.qpos.copy_(torch.from_numpy(qp.astype(np.float32)).to(self.device))
             self.qvel.copy_(torch.from_numpy(np.asarray(state_dict["qvel"], dtype=np.float32)).to(self.device))
             self.qacc_ws.zero_()

@@ -16,6 +16,7 @@
  *   grx_fetch_forward ....... mujoco.mj_forward after a reset + _get_obs fetch/fetch_env.py:401, envs/robot_env.py:183
  *                              (nstep > 0: the raw mj_step settle loop of _env_setup, fetch/fetch_env.py:419-420)
  *   grx_fetch_compute_reward  GoalEnv.compute_reward on a batch (HER)   fetch/fetch_env.py:74-80, core.py:45-67
+ *   grx_adroit_sample_resets_device . np_random.uniform draws of the Adroit reset_model methods  adroit_hammer.py:374-376, adroit_door.py:362-370, adroit_relocate.py:353-372
  *   grx_fetch_sample_resets[_device] . np_random.uniform draws of _reset_sim/_sample_goal  fetch/fetch_env.py:153-166,388-391 (host / on the device)
  *
  * All array arguments are plain device (HBM) pointers; rows are world-major.  `stream` is a
@@ -378,6 +379,12 @@ int grx_fetch_sample_resets(uint64_t* states, const int64_t* idx, int n, int has
  * samples [n,5] float32 out (object x, y, goal x, y, z) -- the row grx_fetch_reset reads.  Bit-equal to grx_fetch_sample_resets / numpy; the host draws nothing. */
 int grx_fetch_sample_resets_device(uint64_t* states, const int* idx, int n, int has_object, int target_in_the_air, double obj_range, double target_range,
                                    const double* target_offset, const double* gripper_xpos, double height_offset, float* samples, void* stream);
+/* reset_model's draws of AdroitHandHammer (kind 0: board z, adroit_hammer.py:374-376), Door (1: frame position, adroit_door.py:362-370) and Relocate (3: ball x / y + target site,
+ * adroit_relocate.py:353-372) ON THE DEVICE: states [N,4] uint64 PCG64 streams in HBM (advanced in place), idx [n] int64 device world indices, shift_pos0 [3] HOST (the XML
+ * body_pos), edit [N,3] float64 DEVICE in / out (model.body_pos of every world as get_env_state reports it; components the task does not redraw are kept), target64 [N,3] float64 and
+ * target [N,3] float32 (relocate only, else NULL), shift [N,7] float32 (the pose the engine applies).  Bit-equal to np_random.uniform(low, high) in the reference's order. */
+int grx_adroit_sample_resets_device(uint64_t* states, const int64_t* idx, int n, int kind, const double* shift_pos0, double* edit, double* target64, float* shift, float* target,
+                                    void* stream);
 const char* grx_last_error(void);
 
 #ifdef __cplusplus

@@ -58,6 +58,37 @@ def test_reset_matches_golden_and_reference_draws(task):
     if task == "relocate":
         assert np.abs(env.target_pos - g["reset_target"]).max() == 0.0
     assert np.abs(obs - g["reset_obs"]).max() < 1e-5
+    # hammer / door / relocate draw ON THE DEVICE (grx_adroit_sample_resets_device): over further ragged resets the fp64 edit rows, the fp32 shift poses and the stream
+    # positions stay bit-equal to the host routine fed by numpy generators (adroit_spec.sample_reset_batch = the reference's draw order)
+    if task != "pen":
+        import torch
+
+        from gymnasium_robotics_amd.core import np_random
+        from gymnasium_robotics_amd.envs.adroit_spec import sample_reset_batch
+
+        assert env._device_draws
+        seeds = [int(g["reset_seed"][0]) + i for i in range(n)]
+        rngs = [np_random(sd)[0] for sd in seeds]
+        edit = np.tile(np.asarray(env.model.info["shift_pos0"], dtype=np.float64), (n, 1))
+        shift, target = np.zeros((n, 7), np.float32), np.zeros((n, 3), np.float32)
+        for idx in (np.arange(n), np.arange(0, n, 3), np.array([n - 1, 0]), np.arange(n)[::-1].copy()):
+            if len(idx) < n or not np.array_equal(idx, np.arange(n)) or shift.any():
+                torch.cuda.set_sync_debug_mode("error")      # the draws are enqueued, nothing is read back
+                try:
+                    env._reset_worlds(idx)
+                finally:
+                    torch.cuda.set_sync_debug_mode("default")
+            d = sample_reset_batch(task, [rngs[w] for w in idx], env.model, current=edit[idx] if task in ("hammer", "relocate") else None)
+            edit[idx] = d["edit"]; shift[idx] = d["shift"].astype(np.float32)
+            if task == "relocate":
+                target[idx] = d["target"].astype(np.float32)
+            assert np.array_equal(env.model_edit, edit) and np.array_equal(env.shift.cpu().numpy(), shift)
+            if task == "relocate":
+                assert np.array_equal(env.target.cpu().numpy(), target) and np.array_equal(env.target_pos[idx], d["target"])
+        st = env._rng_dev.cpu().numpy().view(np.uint64)
+        for w in (0, n - 1):
+            s = rngs[w].bit_generator.state["state"]["state"]
+            assert (int(st[w, 0]) << 64 | int(st[w, 1])) == s
 
 
 @pytest.mark.parametrize("task", ["door", "pen", "relocate"])
