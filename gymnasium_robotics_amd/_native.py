@@ -130,6 +130,7 @@ def lib():
         L.grx_fetch_sample_resets.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         L.grx_fetch_sample_resets_device.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         L.grx_adroit_sample_resets_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.grx_maze_sample_resets_device.argtypes = [vp, vp, ci, vp, ci, vp, ci, cd, cd, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -141,7 +142,7 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_fetch_sample_resets_device", "grx_adroit_sample_resets_device", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_uniform_rows_device", "grx_kitchen_bookkeeping", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_fetch_sample_resets_device", "grx_adroit_sample_resets_device", "grx_maze_sample_resets_device", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_uniform_rows_device", "grx_kitchen_bookkeeping", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_last_error",
 ]
 
 

@@ -1536,7 +1536,7 @@ grx_fetch_sample_kernel(unsigned long long* __restrict__ states, const int* __re
   const unsigned long long ihi = states[4 * w + 2], ilo = states[4 * w + 3];
   double ox = g0, oy = g1;
   if (has_object) {
-    for (;;) {
+    for (int guard = 0; guard < 65536; guard++) {      // (bounded: a kernel must not spin; the acceptance probability of the reference's ranges is 0.65)
       const double dx = __dsub_rn(ox, g0), dy = __dsub_rn(oy, g1);
       if (!(__dsqrt_rn(__dadd_rn(grx_rounded(__dmul_rn(dx, dx)), grx_rounded(__dmul_rn(dy, dy)))) < 0.1)) break;
       ox = __dadd_rn(g0, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -obj_range, obj_range));
@@ -1601,6 +1601,78 @@ extern "C" int grx_adroit_sample_resets_device(uint64_t* states, const int64_t* 
   if (n <= 0) return 0;
   hipLaunchKernelGGL(grx_adroit_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)states, (const long long*)idx, n, kind, shift_pos0[0],
                      shift_pos0[1], shift_pos0[2], edit, target64, shift, target);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ---- MazeEnv.reset's draws ON THE DEVICE (include/grx_capi.h, grx_maze_sample_resets_device; maze_v4.py:299-358): goal cell, xy noise, the reset cell drawn until it is
+// farther than half a cell from the goal, xy noise -- integers() and uniform() of the world's numpy PCG64 stream.  Generator.integers(0, K) for K <= 2^32 is Lemire's
+// multiply-shift on 32-bit draws with rejection, and the bit generator hands out a 64-bit output in two 32-bit halves (low first, the high half buffered): the buffer is part of
+// the stream state (states[5 w + 4] = has << 32 | value).  integers(0, 1) consumes nothing.  Validated draw for draw against numpy on the host twin of this routine
+// (tests/test_cpu_host.py) and on the device (tests/test_gpu_maze.py).
+__device__ __forceinline__ unsigned long long grx_pcg64_next64_dev(unsigned long long& hi, unsigned long long& lo, unsigned long long ihi, unsigned long long ilo) {
+  const unsigned long long mhi = 0x2360ED051FC65DA4ULL, mlo = 0x4385DF649FCCF645ULL;
+  const unsigned long long plo = lo * mlo, phi = __umul64hi(lo, mlo) + hi * mlo + lo * mhi;
+  lo = plo + ilo;
+  hi = phi + ihi + (lo < plo ? 1ULL : 0ULL);
+  const unsigned long long x = hi ^ lo; const unsigned rot = (unsigned)(hi >> 58);
+  return (x >> rot) | (x << ((64 - rot) & 63));
+}
+__device__ __forceinline__ unsigned grx_pcg64_next32_dev(unsigned long long& hi, unsigned long long& lo, unsigned long long ihi, unsigned long long ilo, unsigned long long& buf) {
+  if (buf >> 32) { const unsigned v = (unsigned)buf; buf = 0ULL; return v; }
+  const unsigned long long n = grx_pcg64_next64_dev(hi, lo, ihi, ilo);
+  buf = (1ULL << 32) | (n >> 32);
+  return (unsigned)n;
+}
+__device__ __forceinline__ int grx_pcg64_integers_dev(unsigned long long& hi, unsigned long long& lo, unsigned long long ihi, unsigned long long ilo, unsigned long long& buf, unsigned count) {
+  if (count <= 1u) return 0;
+  const unsigned rng = count - 1u;
+  unsigned long long m = (unsigned long long)grx_pcg64_next32_dev(hi, lo, ihi, ilo, buf) * count;
+  unsigned left = (unsigned)m;
+  if (left < count) {
+    const unsigned thr = (0xFFFFFFFFu - rng) % count;
+    while (left < thr) { m = (unsigned long long)grx_pcg64_next32_dev(hi, lo, ihi, ilo, buf) * count; left = (unsigned)m; }
+  }
+  return (int)(m >> 32);
+}
+__global__ void __launch_bounds__(64)
+grx_maze_sample_kernel(unsigned long long* __restrict__ states, const int* __restrict__ idx, int n, const double* __restrict__ goal_xy, int n_goal, const double* __restrict__ reset_xy,
+                       int n_reset, double noise, double scaling, int fixed_goal, double fgx, double fgy, int fixed_reset, double frx, double fry, float* __restrict__ stage) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n) return;
+  const int w = idx[k];
+  unsigned long long hi = states[5 * w], lo = states[5 * w + 1], buf = states[5 * w + 4];
+  const unsigned long long ihi = states[5 * w + 2], ilo = states[5 * w + 3];
+  double gx = fgx, gy = fgy;
+  if (!fixed_goal) { const int c = grx_pcg64_integers_dev(hi, lo, ihi, ilo, buf, (unsigned)n_goal); gx = goal_xy[2 * c]; gy = goal_xy[2 * c + 1]; }
+  gx = __dadd_rn(gx, grx_rounded(__dmul_rn(grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -noise, noise), scaling)));
+  gy = __dadd_rn(gy, grx_rounded(__dmul_rn(grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -noise, noise), scaling)));
+  double rx = frx, ry = fry;
+  if (!fixed_reset) {
+    rx = gx; ry = gy;
+    const double far = __dmul_rn(0.5, scaling);
+    // (bounded: with ONE reset cell that is also the goal cell the reference's loop never ends -- integers(0, 1) draws nothing; a kernel must not spin)
+    for (int guard = 0; guard < 65536; guard++) {
+      const double dx = __dsub_rn(rx, gx), dy = __dsub_rn(ry, gy);
+      if (!(__dsqrt_rn(__dadd_rn(grx_rounded(__dmul_rn(dx, dx)), grx_rounded(__dmul_rn(dy, dy)))) <= far)) break;
+      const int c = grx_pcg64_integers_dev(hi, lo, ihi, ilo, buf, (unsigned)n_reset);
+      rx = reset_xy[2 * c]; ry = reset_xy[2 * c + 1];
+    }
+  }
+  rx = __dadd_rn(rx, grx_rounded(__dmul_rn(grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -noise, noise), scaling)));
+  ry = __dadd_rn(ry, grx_rounded(__dmul_rn(grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -noise, noise), scaling)));
+  states[5 * w] = hi; states[5 * w + 1] = lo; states[5 * w + 4] = buf;
+  float* s = stage + 4 * (size_t)k;
+  s[0] = (float)rx; s[1] = (float)ry; s[2] = (float)gx; s[3] = (float)gy;
+}
+extern "C" int grx_maze_sample_resets_device(uint64_t* states, const int* idx, int n, const double* goal_xy, int n_goal, const double* reset_xy, int n_reset, double noise_range,
+                                             double scaling, const double* fixed_goal_xy, const double* fixed_reset_xy, float* stage, void* stream) {
+  if (!states || !idx || !goal_xy || !reset_xy || !stage) return fail("grx_maze_sample_resets_device: null argument");
+  if (n_goal < 1 || n_reset < 1) return fail("grx_maze_sample_resets_device: empty cell list");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(grx_maze_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)states, idx, n, goal_xy, n_goal, reset_xy, n_reset, noise_range,
+                     scaling, fixed_goal_xy ? 1 : 0, fixed_goal_xy ? fixed_goal_xy[0] : 0.0, fixed_goal_xy ? fixed_goal_xy[1] : 0.0, fixed_reset_xy ? 1 : 0,
+                     fixed_reset_xy ? fixed_reset_xy[0] : 0.0, fixed_reset_xy ? fixed_reset_xy[1] : 0.0, stage);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -99,7 +99,16 @@ class PointMazeVecEnv(GoalVecEnv):
         self.action_space = batch_space(self.single_action_space, n)
         self.observation_space = batch_space(self.single_observation_space, n)
         self._check_goal_space()
-        self.np_randoms = [np_random(None)[0] for _ in range(n)]
+        # The reset draws (goal cell, reset cell, xy noise: integers / uniform of the world's numpy PCG64 stream) are made ON THE DEVICE from device-resident streams
+        # (grx_maze_sample_resets_device, bit-equal to numpy).  With reset_target=True the same stream also feeds MazeEnv.update_goal in the middle of an episode -- host
+        # logic that reads which worlds reached their goal -- so that mode keeps per-world numpy generators on the host for both.
+        self._device_draws = not self.reset_target
+        if self._device_draws:
+            self._goal_xy = torch.from_numpy(np.ascontiguousarray(np.asarray(self.maze.unique_goal_locations, dtype=np.float64).reshape(-1, 2))).to(self.device)
+            self._reset_xy = torch.from_numpy(np.ascontiguousarray(np.asarray(self.maze.unique_reset_locations, dtype=np.float64).reshape(-1, 2))).to(self.device)
+            self._seed_worlds([None] * n)
+        else:
+            self.np_randoms = [np_random(None)[0] for _ in range(n)]
         self._elapsed = np.zeros(n, np.int64)
         self._needs_reset = np.zeros(n, bool)
         self._has_reset = False
@@ -115,6 +124,50 @@ class PointMazeVecEnv(GoalVecEnv):
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _seed_worlds(self, seeds):
+        """one numpy PCG64 per world, seeded like gymnasium.utils.seeding.np_random [3P]; the raw (state, inc) pairs and the empty 32-bit buffer go to the device"""
+        st = np.zeros((self.num_envs, 5), np.uint64)
+        mask = (1 << 64) - 1
+        for i, sd in enumerate(seeds):
+            s = np_random(sd)[0].bit_generator.state
+            st[i] = [s["state"]["state"] >> 64, s["state"]["state"] & mask, s["state"]["inc"] >> 64, s["state"]["inc"] & mask, (int(s["has_uint32"]) << 32) | int(s["uinteger"])]
+        self._rng_dev = torch.from_numpy(st.view(np.int64)).to(self.device)
+
+    def world_rng(self, i):
+        """numpy Generator positioned at world i's current stream position (inspection / tests: synchronises)"""
+        if not self._device_draws:
+            return self.np_randoms[i]
+        a = [int(x) for x in self._rng_dev[i].cpu().numpy().view(np.uint64)]
+        bg = np.random.PCG64()
+        st = bg.state
+        st["state"] = {"state": (a[0] << 64) | a[1], "inc": (a[2] << 64) | a[3]}
+        st["has_uint32"], st["uinteger"] = int(a[4] >> 32), int(a[4] & 0xFFFFFFFF)
+        bg.state = st
+        return np.random.Generator(bg)
+
+    def _sample_on_device(self, idx, options):
+        """index list through pinned memory, the draws by one kernel into the staging rows grx_maze_reset_rows reads; nothing waits"""
+        k = len(idx)
+        if self._stage_event is not None:
+            self._stage_event.synchronize()
+        self._idx_host.numpy()[:k] = idx
+        self._idx_dev[:k].copy_(self._idx_host[:k], non_blocking=True)
+        self._stage_event = torch.cuda.Event()
+        self._stage_event.record()
+        fixed = []
+        for key, what in (("goal_cell", "Goal"), ("reset_cell", "Reset")):
+            cell = (options or {}).get(key)
+            if cell is None:
+                fixed.append(None)
+                continue
+            assert self.maze.map_length > cell[0] and self.maze.map_width > cell[1]
+            assert self.maze.maze_map[cell[0]][cell[1]] != 1, f"{what} can't be placed in a wall cell, {cell}"
+            fixed.append(np.ascontiguousarray(self.maze.cell_rowcol_to_xy(cell), dtype=np.float64))
+        _native.check(self._L.grx_maze_sample_resets_device(
+            self._rng_dev.data_ptr(), self._idx_dev.data_ptr(), k, self._goal_xy.data_ptr(), int(self._goal_xy.shape[0]), self._reset_xy.data_ptr(), int(self._reset_xy.shape[0]),
+            float(self.position_noise_range), float(self.maze.maze_size_scaling), None if fixed[0] is None else fixed[0].ctypes.data, None if fixed[1] is None else fixed[1].ctypes.data,
+            self._stage_dev.data_ptr(), self._stream()))
+
     # ------------------------------------------------------------------ reset (point_maze.py:377-390, maze_v4.py:299-358)
     def _reset_worlds(self, idx, options=None, keep_outcome=False):
         """Host: the reference's draws for the listed worlds (generate_reset_pos / generate_target_goal, maze_v4.py:299-358) into a pinned staging row per
@@ -123,17 +176,20 @@ class PointMazeVecEnv(GoalVecEnv):
         k = len(idx)
         if k == 0:
             return
-        if self._stage_event is not None:
-            self._stage_event.synchronize()          # the previous reset's copies have left the pinned buffers (normally long ago)
-        stage, ih = self._stage_host.numpy(), self._idx_host.numpy()
-        for j, w in enumerate(idx):
-            goal, start = sample_maze_reset(self.maze, self.np_randoms[w], self.position_noise_range, options)
-            stage[j, 0:2], stage[j, 2:4] = start, goal
-        ih[:k] = idx
-        self._stage_dev[:k].copy_(self._stage_host[:k], non_blocking=True)
-        self._idx_dev[:k].copy_(self._idx_host[:k], non_blocking=True)
-        self._stage_event = torch.cuda.Event()
-        self._stage_event.record()
+        if self._device_draws:
+            self._sample_on_device(idx, options)
+        else:
+            if self._stage_event is not None:
+                self._stage_event.synchronize()          # the previous reset's copies have left the pinned buffers (normally long ago)
+            stage, ih = self._stage_host.numpy(), self._idx_host.numpy()
+            for j, w in enumerate(idx):
+                goal, start = sample_maze_reset(self.maze, self.np_randoms[w], self.position_noise_range, options)
+                stage[j, 0:2], stage[j, 2:4] = start, goal
+            ih[:k] = idx
+            self._stage_dev[:k].copy_(self._stage_host[:k], non_blocking=True)
+            self._idx_dev[:k].copy_(self._idx_host[:k], non_blocking=True)
+            self._stage_event = torch.cuda.Event()
+            self._stage_event.record()
         a = self._reset_args
         a.keep_outcome = int(keep_outcome)
         _native.check(self._L.grx_maze_reset_rows(ctypes.byref(a), k, self._stream()))
@@ -143,7 +199,10 @@ class PointMazeVecEnv(GoalVecEnv):
     def reset(self, *, seed=None, options=None):
         if seed is not None:
             seeds = [seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed)
-            self.np_randoms = [np_random(s)[0] for s in seeds]
+            if self._device_draws:
+                self._seed_worlds(seeds)
+            else:
+                self.np_randoms = [np_random(s)[0] for s in seeds]
         with torch.cuda.device(self.device):
             self._reset_worlds(np.arange(self.num_envs), options)
         self._has_reset = True

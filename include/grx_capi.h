@@ -16,6 +16,7 @@
  *   grx_fetch_forward ....... mujoco.mj_forward after a reset + _get_obs fetch/fetch_env.py:401, envs/robot_env.py:183
  *                              (nstep > 0: the raw mj_step settle loop of _env_setup, fetch/fetch_env.py:419-420)
  *   grx_fetch_compute_reward  GoalEnv.compute_reward on a batch (HER)   fetch/fetch_env.py:74-80, core.py:45-67
+ *   grx_maze_sample_resets_device ... np_random.integers / uniform draws of MazeEnv.reset       maze/maze_v4.py:299-358
  *   grx_adroit_sample_resets_device . np_random.uniform draws of the Adroit reset_model methods  adroit_hammer.py:374-376, adroit_door.py:362-370, adroit_relocate.py:353-372
  *   grx_fetch_sample_resets[_device] . np_random.uniform draws of _reset_sim/_sample_goal  fetch/fetch_env.py:153-166,388-391 (host / on the device)
  *
@@ -385,6 +386,13 @@ int grx_fetch_sample_resets_device(uint64_t* states, const int* idx, int n, int 
  * target [N,3] float32 (relocate only, else NULL), shift [N,7] float32 (the pose the engine applies).  Bit-equal to np_random.uniform(low, high) in the reference's order. */
 int grx_adroit_sample_resets_device(uint64_t* states, const int64_t* idx, int n, int kind, const double* shift_pos0, double* edit, double* target64, float* shift, float* target,
                                     void* stream);
+/* MazeEnv.reset's draws ON THE DEVICE (maze/maze_v4.py:299-358: generate_target_goal, generate_reset_pos, add_xy_position_noise): states [N,5] uint64 in HBM = the world's numpy
+ * PCG64 (state_hi, state_lo, inc_hi, inc_lo) and its buffered 32-bit half (has_uint32 << 32 | uinteger), advanced in place; idx [n] int32 DEVICE world indices; goal_xy [n_goal,2]
+ * / reset_xy [n_reset,2] float64 DEVICE cell centres (maze.unique_goal_locations / unique_reset_locations); fixed_goal_xy / fixed_reset_xy: HOST [2] or NULL = options["goal_cell"]
+ * / ["reset_cell"] of reset(); stage [n,4] float32 out (start x, y, goal x, y): the rows grx_maze_reset_rows reads.  Bit-equal to Generator.integers / uniform in the
+ * reference's order. */
+int grx_maze_sample_resets_device(uint64_t* states, const int* idx, int n, const double* goal_xy, int n_goal, const double* reset_xy, int n_reset, double noise_range, double scaling,
+                                  const double* fixed_goal_xy, const double* fixed_reset_xy, float* stage, void* stream);
 const char* grx_last_error(void);
 
 #ifdef __cplusplus
