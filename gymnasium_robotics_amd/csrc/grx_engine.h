@@ -95,7 +95,12 @@ struct GrxModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations, iterations, njeq, ngate;
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv, noslip_tolerance;
   int mpr_iterations;
+  // derived at model creation (grx_host_model.h), not part of the compiled blob: per hull vertex 16 records of 4 floats -- the vertex itself (x, y, z, degree; degree -1 when
+  // it has more than 15 hull neighbours) and its hull neighbours (x, y, z, local id) -- so that a GUESSED support vertex is verified with ONE coalesced fetch (grx_mesh_support)
+  const float* mesh_nbr;
 };
+#define GRX_NBR_RECS 16
+#define GRX_HULLCACHE_WORDS 90   // per-world HBM row of the hull pairs: 21 words of cached separating directions (GrxCtx::meshcache) + 4 x (key + 16 guess words) + a round-robin counter
 
 // mirrors grx_overflow_lane (include/grx_capi.h): where the worlds go that exceed a table capacity of the fast kernel
 struct GrxLane { const unsigned char* skip; int* entry_count; int* entry_list; const int* list; const int* count; unsigned char* next_flags; int* next_count; int* next_list; signed char* ttl; int soft_maxefc, soft_jpool, soft_maxcon, ttl_init, grid, entry_cap, next_cap;
@@ -127,6 +132,7 @@ struct GrxCtx {
   int* cnt;    // [0]=ncon [1]=nefc [2]=status [3]=ne [4]=nlimit ...
   float* shift;      // models with a shift group: the world's offset t[3] and rotation q[4] (state, loaded with qpos); flag 1 = x + t, flag 2 = R(q) x + t
   float* minv;       // models with the noslip post-solver: M^-1 (nv x nv), formed once per substep
+  float* hullhint;   // HBM, or null: 4 x (pair + 1, 16 words of support-vertex guesses) + a round-robin counter, kept across substeps and steps (grx_mesh_pairs)
   float* meshcache;  // models with hull-vs-convex pairs: 4 x (pair + 1, separating direction, the two support vertices) + the slot to evict next, kept across the substeps of a step (grx_mesh_pairs)
   int mslot;   // slot of this world's model in g_grx_models (GPU build)
   int bail;    // != 0: a step kernel that hands capacity overflows to a re-run at a larger capacity stops simulating at the first overflowing substep (nothing of this run is kept)
@@ -189,7 +195,7 @@ static int g_grx_solve_mode = 0;   // 0 normal, 1 Newton only, 2 Euler stage onl
 GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   const GrxDims* m = &d;
   float* p = base;
-  c->skin = nullptr; c->skin_r = 0.0f; c->bail = 0; c->soft_maxefc = c->soft_jpool = c->soft_maxcon = 0; c->lane_entry_count = nullptr; c->lane_entry_list = nullptr; c->lane_entry_cap = 0; c->lane_world = 0; c->lane_ready = nullptr; c->lane_ready_cap = 0;
+  c->hullhint = nullptr; c->skin = nullptr; c->skin_r = 0.0f; c->bail = 0; c->soft_maxefc = c->soft_jpool = c->soft_maxcon = 0; c->lane_entry_count = nullptr; c->lane_entry_list = nullptr; c->lane_entry_cap = 0; c->lane_world = 0; c->lane_ready = nullptr; c->lane_ready_cap = 0;
 #if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)   // test infrastructure (tools/emu_mixed.py): the field map of the working set
 #define GRX_CARVE_REC(field, n, isint) grx_emu_carve_rec(#field, (void*)p, (n), (isint));
 #else
@@ -1312,6 +1318,8 @@ struct GrxMprPairT { RF R1[9], R2[9], s1[3], s2[3]; MF c21[3], hm; int t1, t2;  
                     const float *v1, *v2; int n1, n2, lane; const int *aadr1, *anum1, *aadr2, *anum2, *adj;   // hull adjacency (per hull vertex: first neighbour / count into adj)
                                         // hull vertices (geom frame) of mesh geoms: only read by the wave-cooperative variant
                     GrxMprPt* pts;
+                    const float *nbr1, *nbr2;   // neighbour records of the two hulls (GrxModel::mesh_nbr + 64 * first hull vertex), or null
+                    mutable int hint, hk;       // wave-cooperative variant: lane e holds the guessed support vertices of evaluation e ((v1 + 1) | (v2 + 1) << 16); evaluations so far
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
                     long long* prof;
 #endif
@@ -1359,9 +1367,36 @@ GRX_MEM int grx_mesh_support_refine(const float* verts, const int* aadr, const i
   }
   return cur;
 }
-GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, int lane_, const int* aadr = nullptr, const int* anum = nullptr, const int* adj = nullptr) {
+// hint / nbr: a GUESS of the support vertex (the one the same evaluation of the same pair's portal search found in the previous substep) and the hull's neighbour records.
+// The guess is accepted only if its projection exceeds that of every hull neighbour by 1e-6 |d| (metres): a clear local maximum over the hull's edge graph is the unique
+// global maximum (convexity), so the exhaustive scan below -- fp32 scan, fp64 decision among the near-ties -- returns the same vertex.  The margin is what makes this
+// rigorous on REAL hull tables: qhull's triangulation of the float32-rounded vertices contains near-coplanar facets whose diagonals are "concave" at the 1e-9 m level, so
+// a vertex can top all of its listed neighbours by up to 7e-9 m without being the maximum (tests/test_cpu_hull_hints.py measures this on every packaged hull: nothing
+// above 1e-7 m over 10^5 face-normal, chord and random directions).  One coalesced fetch of 16 records instead of a scan of the whole hull; anything else (a near-tie, a
+// vertex with more than 15 neighbours, a stale guess) falls through to the scan.
+GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, int lane_, const int* aadr = nullptr, const int* anum = nullptr, const int* adj = nullptr, int hint = -1,
+                             const float* nbr = nullptr) {
   r[0] = r[1] = r[2] = 0.0f;
   if (n <= 0) return -1;
+#if !defined(GRX_EMU) && !defined(GRX_NO_HULL_HINTS)
+  if (hint >= 0 && hint < n && nbr != nullptr) {
+    const float4 p = ((const float4*)nbr)[GRX_NBR_RECS * hint + (lane_ & (GRX_NBR_RECS - 1))];
+    const int deg = (int)grx_readlane_f(p.w, 0);
+    if (deg >= 1) {
+      const double t = (double)p.x * (double)dlm[0] + (double)p.y * (double)dlm[1] + (double)p.z * (double)dlm[2];
+      const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+      const double t0 = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(tb >> 32), 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)tb, 0)));
+      const double dn = sqrt((double)dlm[0] * (double)dlm[0] + (double)dlm[1] * (double)dlm[1] + (double)dlm[2] * (double)dlm[2]);
+      const bool beaten = lane_ >= 1 && lane_ <= deg && !(t0 - t > 1.0e-6 * dn);
+      if (__ballot(beaten) == 0ull) {
+        r[0] = grx_readlane_f(p.x, 0); r[1] = grx_readlane_f(p.y, 0); r[2] = grx_readlane_f(p.z, 0);
+        return hint;
+      }
+    }
+  }
+#else
+  (void)hint; (void)nbr;
+#endif
   const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};   // the scan's own arithmetic type (GRX_HULL_REAL)
 #if defined(GRX_EMU)
   HF best = -3.0e38f; int bi = 0;
@@ -1465,10 +1500,21 @@ GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   const long long tp0_ = clock64();
 #endif
-  if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); grx_mesh_support(q->v1, q->n1, dl, r, q->lane, q->aadr1, q->anum1, q->adj); mulMatVec3f(o->w, q->R1, r); }
+  int h1 = -1, h2 = -1, f1 = -1, f2 = -1, ek = 0;
+#if !defined(GRX_EMU)
+  if (W) {
+    ek = __builtin_amdgcn_readfirstlane(q->hk);
+    if (ek < 16) { const int pk = __builtin_amdgcn_readlane(q->hint, ek); h1 = (pk & 0xFFFF) - 1; h2 = (int)((unsigned)pk >> 16) - 1; }
+    q->hk = ek + 1;
+  }
+#endif
+  if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); f1 = grx_mesh_support(q->v1, q->n1, dl, r, q->lane, q->aadr1, q->anum1, q->adj, h1, q->nbr1); mulMatVec3f(o->w, q->R1, r); }
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
-  if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj); mulMatVec3f(b, q->R2, r); }
+  if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); f2 = grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj, h2, q->nbr2); mulMatVec3f(b, q->R2, r); }
   else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
+#if !defined(GRX_EMU)
+  if (W && ek < 16 && q->lane == ek) q->hint = ((f1 + 1) & 0xFFFF) | ((f2 + 1) << 16);   // the winners become the guesses of this evaluation in the next substep
+#endif
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   if (W && q->lane == 0) q->prof[16 + 28] += clock64() - tp0_;
 #endif
@@ -1726,7 +1772,7 @@ GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int
   q.t1 = t1; q.t2 = t2; q.hm = 0.5f * margin;
   for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = p2[k] - p1[k]; }
   MF depth, dir[3], pos[3], w1[3], w2[3];
-  q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr; q.aadr1 = q.anum1 = q.aadr2 = q.anum2 = q.adj = nullptr;
+  q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr; q.aadr1 = q.anum1 = q.aadr2 = q.anum2 = q.adj = nullptr; q.nbr1 = q.nbr2 = nullptr; q.hint = q.hk = 0;
   if (grx_mpr_penetration<false>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;
 #if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
   if (getenv("GRX_TRACE_MPR")) {
@@ -1829,6 +1875,9 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     q.aadr1 = m->mesh_adjadr + (q.t1 == 7 ? m->geom_hulladr[g1] : 0); q.anum1 = m->mesh_adjnum + (q.t1 == 7 ? m->geom_hulladr[g1] : 0);
     q.aadr2 = m->mesh_adjadr + (q.t2 == 7 ? m->geom_hulladr[g2] : 0); q.anum2 = m->mesh_adjnum + (q.t2 == 7 ? m->geom_hulladr[g2] : 0); q.adj = m->mesh_adj;
     q.pts = (GrxMprPt*)(c->Jp + 192);
+    q.nbr1 = (q.t1 == 7 && m->mesh_nbr) ? m->mesh_nbr + (size_t)4 * GRX_NBR_RECS * m->geom_hulladr[g1] : nullptr;
+    q.nbr2 = (q.t2 == 7 && m->mesh_nbr) ? m->mesh_nbr + (size_t)4 * GRX_NBR_RECS * m->geom_hulladr[g2] : nullptr;
+    q.hint = 0; q.hk = 0;
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
     q.prof = c->prof;
 #endif   // 30 words behind the pair queue: the Jacobian pool is free until the constraint stage
@@ -1863,8 +1912,28 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
 #if defined(GRX_EMU)
     g_grx_mesh_stats[1]++;
 #endif
+    // guesses of the support vertices, one word per evaluation of this pair's search (the world's HBM row, 4 blocks of key + 16 words): a pair in persistent contact -- the
+    // upper arm resting on the head link, the worlds that end a Fetch launch -- repeats its search substep after substep with almost the same directions
+    int hblk = -1;
+#if !defined(GRX_EMU)
+    if (c->hullhint) {
+      const float hk0 = c->hullhint[0], hk1 = c->hullhint[17], hk2 = c->hullhint[34], hk3 = c->hullhint[51];
+      hblk = hk0 == key ? 0 : (hk1 == key ? 1 : (hk2 == key ? 2 : (hk3 == key ? 3 : -1)));
+      hblk = __builtin_amdgcn_readfirstlane(hblk);
+      if (hblk >= 0 && lane_ < 16) q.hint = __float_as_int(c->hullhint[17 * hblk + 1 + lane_]);
+    }
+#endif
     MF depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
+#if !defined(GRX_EMU)
+    if (c->hullhint && rc == 0) {   // in contact: this search will run again in the next substep
+      int wblk = hblk;
+      if (wblk < 0) { wblk = ((int)c->hullhint[68]) & 3; if (lane_ == 0) c->hullhint[68] = (float)((wblk + 1) & 3); }
+      wblk = __builtin_amdgcn_readfirstlane(wblk);
+      if (lane_ < 16) c->hullhint[17 * wblk + 1 + lane_] = __int_as_float(lane_ < q.hk ? q.hint : 0);
+      if (lane_ == 0) c->hullhint[17 * wblk] = key;
+    }
+#endif
     GRX_SUBTICK(c, 23);   // portal search
 #ifdef GRX_PROBE_HULL   // outcome of the searches (tools/hull_outcome_probe.py): contacts, separations with a direction, the pair searched last
     GRX_COUNT(c, 35, rc == 0 ? 1 : 0); GRX_COUNT(c, 36, (rc != 0 && sep[3] != 0.0f) ? 1 : 0); GRX_PMAX(c, 37, pair);

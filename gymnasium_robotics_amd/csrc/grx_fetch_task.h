@@ -35,7 +35,7 @@ struct GrxFetchBuffers {
   const int* order;                      // [grid] or null: world handled by workgroup b (dispatch order = cost order, see grx_fetch_step_kernel)
   int* cost;                             // [N] or null: out, cost estimate of this world (the next launch's ordering key)
   float* packed;                         // [N, obs_dim + 3 + 3 + 2] or null: out, the row [obs | achieved | desired | reward | success] (what the cross-rank gather ships)
-  float* hullcache;                      // [N, 21] or null: in/out, GrxCtx::meshcache carried across launches (include/grx_capi.h)
+  float* hullcache;                      // [N, GRX_HULLCACHE_WORDS] or null: in/out, GrxCtx::meshcache carried across launches + the support-vertex guesses (include/grx_capi.h)
   GrxLane lane;                          // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 

@@ -15,6 +15,7 @@ struct GrxPackedModel {
   std::vector<int> off, cnt;  // per table (in .def order): offset inside f or i, element count
   std::vector<char> kind;     // 'f' or 'i'
   std::vector<std::string> name;
+  int off_mesh_nbr = -1;      // offset of the derived neighbour-record table inside f (-1: the model has no hulls)
   GrxModel proto;             // scalar members filled; pointers unset
 };
 
@@ -29,6 +30,31 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
+  // derived table (GrxModel::mesh_nbr): for every hull vertex the vertex and its hull neighbours as (x, y, z, tag) records, 16 per vertex
+  out->off_mesh_nbr = -1;
+  if (v.n_mesh_vert >= 3 && v.n_mesh_adjadr * 3 == v.n_mesh_vert) {
+    const int nvert = v.n_mesh_vert / 3;
+    out->off_mesh_nbr = (int)out->f.size();
+    out->f.resize(out->f.size() + (size_t)nvert * GRX_NBR_RECS * 4, 0.0f);
+    float* T = out->f.data() + out->off_mesh_nbr;
+    for (int g = 0; g < nvert; g++) { float* r = T + (size_t)g * GRX_NBR_RECS * 4; for (int k = 0; k < GRX_NBR_RECS; k++) r[4 * k + 3] = -1.0f; }   // unusable until a hull claims the vertex
+    for (int gi = 0; gi < v.n_geom_hulladr; gi++) {
+      const int adr = v.geom_hulladr[gi], num = v.geom_hullnum[gi];
+      if (adr < 0 || num <= 0 || adr + num > nvert) continue;
+      for (int lv = 0; lv < num; lv++) {
+        const int g = adr + lv, aa = v.mesh_adjadr[g], an = v.mesh_adjnum[g];
+        float* r = T + (size_t)g * GRX_NBR_RECS * 4;
+        r[0] = (float)v.mesh_vert[3 * g]; r[1] = (float)v.mesh_vert[3 * g + 1]; r[2] = (float)v.mesh_vert[3 * g + 2];
+        r[3] = (an >= 1 && an <= GRX_NBR_RECS - 1) ? (float)an : -1.0f;
+        for (int k = 0; k < an && k < GRX_NBR_RECS - 1; k++) {
+          const int nb = v.mesh_adj[aa + k], gn = adr + nb;
+          if (nb < 0 || nb >= num) { r[3] = -1.0f; break; }
+          float* q = r + 4 * (k + 1);
+          q[0] = (float)v.mesh_vert[3 * gn]; q[1] = (float)v.mesh_vert[3 * gn + 1]; q[2] = (float)v.mesh_vert[3 * gn + 2]; q[3] = (float)nb;
+        }
+      }
+    }
+  }
   GrxModel& m = out->proto;
   std::memset(&m, 0, sizeof(m));
   const int32_t* d = v.dims;
@@ -98,6 +124,7 @@ inline GrxModel grx_bind_model(const GrxPackedModel& p, const float* fbase, cons
 #include "../../include/grx_model_fields.def"
 #undef GRX_FI
 #undef GRX_FF
+  m.mesh_nbr = p.off_mesh_nbr >= 0 ? fbase + p.off_mesh_nbr : nullptr;
   return m;
 }
 

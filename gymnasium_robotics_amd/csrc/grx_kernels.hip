@@ -238,7 +238,8 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
   if (lane_ == 0 && w < 16384) g_grx_world_span[2 * w] = wall_clock64();
 #endif
   grx_load_world(m, b, c, w, lds, words, lane_);
-  if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) c.meshcache[lane_] = b.hullcache[(size_t)w * 21 + lane_];   // separating directions remembered from the previous step (re-verified before use)
+  if (S::kMesh && m.nmeshpair > 0 && b.hullcache) c.hullhint = b.hullcache + (size_t)w * GRX_HULLCACHE_WORDS + 21;   // support-vertex guesses of the world's persistent hull contacts: used in place (HBM)
+  if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) c.meshcache[lane_] = b.hullcache[(size_t)w * GRX_HULLCACHE_WORDS + lane_];   // separating directions remembered from the previous step (re-verified before use)
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = b.aux[(size_t)w * 8 + k];
   GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_);
@@ -246,7 +247,7 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
   // a capacity overflowed (wave-uniform: the flag lives in LDS): keep nothing, the world is re-run on the large tables (grx_overflow_lane)
   if (!grx_lane_overflowed(c)) {
     if (LANE) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, wl, lane_); else grx_lane_join(b.lane, c, wl, lane_);
-    if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) b.hullcache[(size_t)wl * 21 + lane_] = c.meshcache[lane_];
+    if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) b.hullcache[(size_t)wl * GRX_HULLCACHE_WORDS + lane_] = c.meshcache[lane_];
     GrxFetch<S>::grx_fetch_outputs(&m, &t, &c, b.aux + (size_t)wl * 8, b.obs + (size_t)wl * t.obs_dim, b.achieved + (size_t)wl * 3, lane_);
     __syncthreads();
     grx_store_world(m, t, b, c, wl, lane_);

@@ -177,7 +177,7 @@ class FetchVecEnv(GoalVecEnv):
             self.order = (self._slice_base + torch.arange(per, device=d, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)   # workgroup b -> slice b & 7, position b >> 3
         # the worlds' caches of separating directions (hull-vs-convex pairs), carried across launches: without it every env.step() starts with one portal
         # search for the arm's permanently near pair (torso / shoulder link, 1.9 cm apart); a stale row is harmless (directions are re-verified)
-        self.hullcache = z(n, 21) if os.environ.get("GRX_NO_HULLCACHE") is None else None
+        self.hullcache = z(n, 90) if os.environ.get("GRX_NO_HULLCACHE") is None else None      # GRX_HULLCACHE_WORDS (csrc/grx_engine.h)
         # No dropped contacts (core.OverflowLane / include/grx_capi.h grx_overflow_lane): a world that exceeds a table capacity of the specialised kernel writes
         # nothing and is stepped on the SAME model with larger tables (generic kernel) -- concurrently with the fast launch once it is in the lane.
         common = (self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action, self.obs, self.achieved, self.reward, self.success, self.status)

@@ -116,7 +116,7 @@ typedef struct grx_fetch_buffers {
   int* cost;                            /* [N] or NULL */
   float* packed;                        /* [N, obs_dim+3+3+2] or NULL: the row [obs | achieved | desired | reward | success], written by the step kernel itself so
                                          * that the cross-rank exchange (RCCL all-gather) ships one buffer and needs no pack kernels */
-  float* hullcache;                     /* [N, 21] or NULL: the world's cache of separating directions of its hull-vs-convex pairs (engine: GrxCtx::meshcache), carried from one
+  float* hullcache;                     /* [N, 90] or NULL (zero-initialised; 21 words of separating directions + 69 words of support-vertex guesses of persistent hull contacts): the world's cache of separating directions of its hull-vs-convex pairs (engine: GrxCtx::meshcache), carried from one
                                          * env.step() to the next.  A remembered direction is re-verified before it is trusted (it proves "no contact", exactly what the portal
                                          * search would report), so the rows never change a result: they save the search every launch otherwise starts with. */
   grx_overflow_lane lane;               /* capacity overflows are re-run on larger tables instead of dropping contacts: see grx_overflow_lane above and its LIMITS */

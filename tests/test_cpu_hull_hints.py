@@ -1,0 +1,63 @@
+"""The premise of the guessed support vertex (csrc/grx_engine.h, grx_mesh_support): on the convex hulls the models are packaged with, a vertex whose projection on a unit
+direction exceeds that of every neighbour in the hull's edge graph by the routine's margin (1e-6 m) IS the vertex an exhaustive fp64 scan returns -- for every hull of the
+Fetch and kitchen models and thousands of directions (random ones, and normals of vertex triples -- faces and chords -- with perturbations of 1e-7 and 1e-5, where several
+vertices nearly tie).  Without a margin the premise FAILS on real tables (near-coplanar facets of the float32-rounded hulls): the test also pins how far -- a false local
+maximum tops its neighbours by less than 1e-7 m."""
+import numpy as np
+import pytest
+
+
+def _hulls(model):
+    T = model.tables
+    V, adr, num, adj = T["mesh_vert"].astype(np.float32).astype(np.float64), T["mesh_adjadr"], T["mesh_adjnum"], T["mesh_adj"]
+    seen = set()
+    for g in range(len(T["geom_hulladr"])):
+        a, n = int(T["geom_hulladr"][g]), int(T["geom_hullnum"][g])
+        if a < 0 or n <= 0 or (a, n) in seen:
+            continue
+        seen.add((a, n))
+        nb = -np.ones((n, 15), np.int64)
+        usable = np.ones(n, bool)
+        for v in range(n):
+            k = int(num[a + v])
+            if k < 1 or k > 15:
+                usable[v] = False
+                continue
+            nb[v, :k] = adj[adr[a + v]: adr[a + v] + k]
+        yield V[a: a + n], nb, usable
+
+
+@pytest.mark.parametrize("which", ["fetch", "kitchen"])
+def test_strict_local_maximum_over_the_edge_graph_is_the_scan_winner(which):
+    if which == "fetch":
+        from gymnasium_robotics_amd.envs.fetch import load_fetch_model
+        model = load_fetch_model("FetchPickAndPlace")
+    else:
+        from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model
+        model = load_kitchen_model()
+    rng = np.random.default_rng(0)
+    hulls, accepted = 0, 0
+    for V, nb, usable in _hulls(model):
+        hulls += 1
+        n = len(V)
+        D = rng.normal(size=(400, 3))
+        # near-tie directions: normals of random vertex triples (faces and chords) and their slight perturbations
+        tri = rng.integers(0, n, size=(600, 3))
+        nrm = np.cross(V[tri[:, 1]] - V[tri[:, 0]], V[tri[:, 2]] - V[tri[:, 0]])
+        nrm = nrm[np.linalg.norm(nrm, axis=1) > 1e-12]
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        D = np.concatenate([D, nrm, nrm + 1e-7 * rng.normal(size=nrm.shape), nrm + 1e-5 * rng.normal(size=nrm.shape), np.eye(3), -np.eye(3)])
+        D /= np.linalg.norm(D, axis=1, keepdims=True)
+        P = D @ V.T                                   # [ndir, n] fp64 projections
+        best = P.argmax(axis=1)                       # the exhaustive scan (first maximum = lowest index on an exact tie)
+        Pn = np.where(nb[None, :, :] >= 0, P[:, np.clip(nb, 0, n - 1)], -np.inf)      # [ndir, n, 15] neighbours' projections
+        excess = (P[:, :, None] - Pn).min(axis=2)      # by how much every vertex tops its best neighbour
+        ok = usable[None, :] & (excess > 1.0e-6)       # the routine's acceptance test, for EVERY vertex as the guess
+        d_idx, v_idx = np.nonzero(ok)
+        assert np.array_equal(v_idx, best[d_idx]), (which, hulls, int((v_idx != best[d_idx]).sum()))
+        accepted += len(d_idx)
+        assert ok.sum(axis=1).max() <= 1
+        d0, v0 = np.nonzero(usable[None, :] & (excess > 0.0))      # without the margin: false local maxima exist, and they are all shallower than a tenth of the margin
+        false_max = v0 != best[d0]
+        assert not false_max.any() or excess[d0[false_max], v0[false_max]].max() < 1.0e-7, (which, hulls, float(excess[d0[false_max], v0[false_max]].max()))
+    assert hulls >= 8 and accepted > 2000, (hulls, accepted)
