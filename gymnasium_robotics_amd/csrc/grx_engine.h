@@ -1378,7 +1378,7 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
                              const float* nbr = nullptr) {
   r[0] = r[1] = r[2] = 0.0f;
   if (n <= 0) return -1;
-#if !defined(GRX_EMU) && !defined(GRX_NO_HULL_HINTS)
+#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
   if (hint >= 0 && hint < n && nbr != nullptr) {
     const float4 p = ((const float4*)nbr)[GRX_NBR_RECS * hint + (lane_ & (GRX_NBR_RECS - 1))];
     const int deg = (int)grx_readlane_f(p.w, 0);
@@ -1501,7 +1501,7 @@ GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
   const long long tp0_ = clock64();
 #endif
   int h1 = -1, h2 = -1, f1 = -1, f2 = -1, ek = 0;
-#if !defined(GRX_EMU)
+#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
   if (W) {
     ek = __builtin_amdgcn_readfirstlane(q->hk);
     if (ek < 16) { const int pk = __builtin_amdgcn_readlane(q->hint, ek); h1 = (pk & 0xFFFF) - 1; h2 = (int)((unsigned)pk >> 16) - 1; }
@@ -1512,7 +1512,7 @@ GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
   if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); f2 = grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj, h2, q->nbr2); mulMatVec3f(b, q->R2, r); }
   else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
-#if !defined(GRX_EMU)
+#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
   if (W && ek < 16 && q->lane == ek) q->hint = ((f1 + 1) & 0xFFFF) | ((f2 + 1) << 16);   // the winners become the guesses of this evaluation in the next substep
 #endif
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
@@ -1915,7 +1915,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     // guesses of the support vertices, one word per evaluation of this pair's search (the world's HBM row, 4 blocks of key + 16 words): a pair in persistent contact -- the
     // upper arm resting on the head link, the worlds that end a Fetch launch -- repeats its search substep after substep with almost the same directions
     int hblk = -1;
-#if !defined(GRX_EMU)
+#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
     if (c->hullhint) {
       const float hk0 = c->hullhint[0], hk1 = c->hullhint[17], hk2 = c->hullhint[34], hk3 = c->hullhint[51];
       hblk = hk0 == key ? 0 : (hk1 == key ? 1 : (hk2 == key ? 2 : (hk3 == key ? 3 : -1)));
@@ -1925,7 +1925,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
 #endif
     MF depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
-#if !defined(GRX_EMU)
+#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
     if (c->hullhint && rc == 0) {   // in contact: this search will run again in the next substep
       int wblk = hblk;
       if (wblk < 0) { wblk = ((int)c->hullhint[68]) & 3; if (lane_ == 0) c->hullhint[68] = (float)((wblk + 1) & 3); }

@@ -16,6 +16,11 @@
 #define GRX_TU_KITCHEN 1
 #define GRX_TU_API 1
 #endif
+// The guessed support vertices of persistent hull contacts (grx_engine.h, grx_mesh_support) need a per-world HBM row, which only the Fetch buffers carry (hullcache): the
+// code is compiled into the Fetch kernels only -- in the hand / kitchen kernels it would be dead weight in a register-starved routine (measured: -1 ... -2.5 %).
+#if GRX_TU_FETCH && !defined(GRX_NO_HULL_HINTS)
+#define GRX_HULL_HINTS 1
+#endif
 #include <hip/hip_runtime.h>
 
 #include <cmath>
