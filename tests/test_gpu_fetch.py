@@ -92,6 +92,34 @@ def test_teacher_forced_hull_contacts_match_golden():
     assert np.median(err[hull]) < 2e-6 and err.max() < 5e-3
 
 
+def test_hull_caches_do_not_change_the_rollout(monkeypatch):
+    """The per-world HBM row of the hull pairs (cached separating directions, guessed support vertices of persistent contacts: csrc/grx_engine.h, grx_mesh_pairs /
+    grx_mesh_support) only replaces work whose outcome it proves: free-running from the 168 folded-arm poses of the hull fixture -- arm on head, wrist on the table, hull
+    contacts in most steps -- the rollout with the row is bit-identical to the rollout without it (GRX_NO_HULLCACHE: every portal search scans its hulls)."""
+    import torch
+
+    g = np.load(os.path.join(GOLDEN, "fetch_hull_teacher.npz"))
+    n = g["obs"].shape[0]
+    envs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("GRX_NO_HULLCACHE", "1")
+        e = _env("FetchPickAndPlace", n, autoreset_mode="disabled", max_episode_steps=None, output="torch")
+        assert (e.hullcache is None) == off
+        e.reset(seed=0)
+        _load_state(e, g, slice(None))
+        envs.append(e)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(3)
+    a0 = torch.from_numpy(g["action"].astype(np.float32)).cuda()
+    for t in range(30):
+        a = a0 if t < 10 else (a0 * 0.2 + 0.3 * (torch.rand(n, 4, device="cuda:0", generator=gen) * 2 - 1))     # keep pressing, with a little noise
+        for e in envs:
+            e.step(a)
+        assert torch.equal(envs[0].qpos, envs[1].qpos) and torch.equal(envs[0].qvel, envs[1].qvel) and torch.equal(envs[0].obs, envs[1].obs), t
+    used = envs[0].hullcache[:, 21:].abs().sum(dim=1) > 0
+    assert int(used.sum()) > 20      # the guesses were really in play: worlds with a persistent hull contact wrote their rows
+
+
 def test_compacted_reset_kernel_matches_masked_forward():
     """grx_fetch_reset (compacted list, initial rows + host draws applied on the device) gives the rows the old path produced:
     initial state written by the host + masked grx_fetch_forward."""
