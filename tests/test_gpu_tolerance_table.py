@@ -9,7 +9,7 @@ EVERY served family, with one qualification that is a property of the REFERENCE,
     well-posed comparison for ANY engine that keeps its state in fp32: the reference's own answer changes by up to 1e-1 under a perturbation of that size.
 
 Asserted here, on the MI355X, through the C ABI:
-  (1) every snapshot with activation_gap >= 1e-6 m (70 - 95 % of each family's fixture) is within 1e-4 on every component -- no allow-list, no ratchet;
+  (1) every snapshot with activation_gap >= 1e-6 m (67 - 100 % of each family's fixture: tests/golden/tolerance_table.json, `n_away_from_activation_boundary`) is within 1e-4 on every component -- no allow-list, no ratchet;
   (2) over ALL snapshots of a family at least 99 % are within 1e-4 on every component (the rest are below the gap, listed in tests/golden/tolerance_table.json);
   (3) touch-sensor channels (forces in newton, up to 3e1): |error| <= 1e-4 * max(1, |reading|) on >= 90 % of the gap >= 1e-6 snapshots, <= 5e-4 * max(1, |reading|) on
       all of them -- a contact force is (stiffness 1e4 ... 1e5 N/m) x (a depth that an fp32 state resolves to 1e-8 m): 1e-4 N absolute is below what fp64 ARITHMETIC
@@ -20,7 +20,9 @@ tests/golden/tolerance_table.json (tools/measure_tolerances.py) is the record of
 import numpy as np
 import pytest
 
-from tolerance_cases import CASES, ant_errors, family_errors
+import json
+
+from tolerance_cases import CASES, TABLE, ant_errors, family_errors
 
 pytestmark = pytest.mark.gpu
 GAP = 1e-6
@@ -34,7 +36,11 @@ def test_family_meets_the_north_star_bound(family):
     gap = res.pop("_gap")
     res.pop("_far")
     posed = gap >= GAP
-    assert posed.mean() >= 0.6, (family, float(posed.mean()))
+    # the well-posed share is a property of the FIXTURE (the oracle's recorded gaps): 67 - 100 % per family (tests/golden/tolerance_table.json: HandPen 80 / 120, HandBlockTouch
+    # 83 / 120, FetchReach 143 / 200, FetchSlide 219 / 300 at the low end); the floor is the recorded share - 5 points, so a regenerated fixture cannot quietly thin the strict set
+    with open(TABLE) as f:
+        rec = json.load(f)[family]
+    assert posed.mean() >= rec["n_away_from_activation_boundary"] / rec["n"] - 0.05, (family, float(posed.mean()), rec["n_away_from_activation_boundary"] / rec["n"])
     for comp, err in res.items():
         if comp.startswith("touch"):
             assert np.mean(err[posed] < TOL) >= 0.90 and err[posed].max() < 5e-4, (family, comp, float(np.mean(err[posed] < TOL)), float(err[posed].max()))

@@ -113,3 +113,81 @@ def measure_all():
             table[name][comp]["n_over_1e-4"] = int(len(over))
             table[name][comp]["outliers"] = [[int(i), float("%.2e" % err[i]), float("%.1e" % gap[i])] for i in over[np.argsort(-err[over])][:24]]
     return table
+
+
+# ---------------------------------------------------------------------------------------------- free-running horizons
+HORIZONS = (1, 2, 5, 10)
+# the fixtures whose snapshots are a contiguous oracle rollout per episode (the recorded pre-state of snapshot i + 1 IS the oracle's post-state of snapshot i, bit for bit:
+# tests/test_cpu_oracle.py::test_fixtures_are_contiguous_rollouts); fetch_hull / ant_Large are sampled poses, not rollouts
+ROLLOUT_FAMILIES = [k for k in CASES if k not in ("FetchHullContacts", "AntMazeLarge")]
+
+
+def episode_runs(g):
+    """run[i] = number of snapshots from i to the end of snapshot i's episode (i itself included): a free-running comparison of horizon h from i needs run[i] >= h"""
+    n = g["obs"].shape[0]
+    if "seed" in g.files and "t" in g.files:
+        cont = (g["seed"][1:] == g["seed"][:-1]) & (g["t"][1:] == g["t"][:-1] + 1)
+    else:
+        cont = g["episode"][1:] == g["episode"][:-1]
+    run = np.ones(n, np.int64)
+    for i in range(n - 2, -1, -1):
+        if cont[i]:
+            run[i] = run[i + 1] + 1
+    return run
+
+
+def horizon_errors(name, horizons=HORIZONS):
+    """FREE-RUNNING comparison (the reference's seeded-rollout test, /root/reference/tests/test_envs.py:62-117, against the oracle's recorded rollout): world i starts from
+    the pre-step state of fixture snapshot i and is then left alone for max(horizons) steps -- its own state, warm start, mocap / stale-kinematics words, last_qpos
+    feed the next step, only the ACTIONS (and the kitchen's recorded noise draws) are the rollout's.  After h steps the observation is compared with the oracle's
+    observation of snapshot i + h - 1.  Returns {h: {component: error per valid start}, "_gap": {h: smallest activation gap over the h oracle steps}, "_start": {h: start indices}}."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    env_id, fixture, keys, comps = CASES[name]
+    g = np.load(os.path.join(GOLDEN, fixture))
+    n = g["obs"].shape[0]
+    run = episode_runs(g)
+    gap = g["activation_gap"]
+    env = grx.make_vec(env_id, num_envs=n, device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
+    env.reset(seed=0)
+    for k in keys:
+        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    step_no = [0]
+    rows = lambda k: np.minimum(np.arange(n) + k, n - 1)      # worlds past their episode's end keep stepping on some action; they are never compared
+    if name == "FrankaKitchen":
+        noise = g["noise"].astype(np.float32)
+        env._draw_noise = lambda idx=None: env.noise.copy_(torch.from_numpy(noise[rows(step_no[0])]).to(env.device))
+    out = {"_gap": {}, "_start": {}}
+    for k in range(max(horizons)):
+        step_no[0] = k
+        res = env.step(g["action"][rows(k)])
+        h = k + 1
+        if h not in horizons:
+            continue
+        obs = res[0]["observation"] if isinstance(res[0], dict) else res[0]
+        start = np.nonzero(run >= h)[0]
+        e = np.abs(obs[start] - g["obs"][start + k])
+        ref = np.abs(g["obs"][start + k])
+        out[h] = {c: (e[:, cols] / np.maximum(1.0, ref[:, cols]) if c.endswith("_relative") else e[:, cols]).max(axis=1) for c, cols in comps.items()}
+        out["_start"][h] = start
+        out["_gap"][h] = np.min([gap[start + j] for j in range(h)], axis=0)
+    env.close()
+    return out
+
+
+def measure_horizons(families=None):
+    table = {}
+    for name in families or ROLLOUT_FAMILIES:
+        res = horizon_errors(name)
+        row = {}
+        for h in HORIZONS:
+            posed = res["_gap"][h] >= GAP
+            row[str(h)] = {"n_starts": int(len(posed)), "n_posed": int(posed.sum())}
+            for comp, err in res[h].items():
+                row[str(h)][comp] = {"p50": float(np.median(err)), "p90": float(np.quantile(err, 0.9)), "max": float(err.max()), "frac_within_1e-4": float(np.mean(err < 1e-4)),
+                                     "max_posed": float(err[posed].max()) if posed.any() else None, "frac_within_1e-4_posed": float(np.mean(err[posed] < 1e-4)) if posed.any() else None,
+                                     "p50_posed": float(np.median(err[posed])) if posed.any() else None}
+        table[name] = row
+    return table

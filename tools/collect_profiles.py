@@ -117,31 +117,42 @@ SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "S
                "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU"]
 
 
-def sq_mix(tag):
+def sq_mix(tag, workload=None):
     """Where the waves of the step kernel spend their cycles (the kernel is issue-bound, not HBM-bound): one SQ pass, 8 counters.
-    WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (MI355X_MICROARCH.md, PMC slot table)."""
-    d = os.path.join(OUT, f"pmc_{tag}_SQ")
+    WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (MI355X_MICROARCH.md, PMC slot table).  Means over the last 12 full-grid launches of the
+    step kernel (= the timed region of the command; the pre-roll, warm-up, reset-time forward and compacted side launches are left out).  The JSON twin
+    is what bench.py's roofline.valu quotes (SQ_INSTS_VALU per launch / the live kernel duration against the 1228.8 G wave64-instructions/s issue peak)."""
+    w = WORKLOADS[workload or "fetch"]
+    kernel = w["kernel"]
+    suffix = f"_{workload}" if workload else ""
+    extra = ["--workload", workload] if workload else []
+    d = os.path.join(OUT, f"pmc_{tag}_SQ{suffix}")
     cmd = ["rocprofv3", "--pmc"] + SQ_COUNTERS + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
-    run(cmd, os.path.join(OUT, f"pmc_{tag}_SQ.log"))
+           os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"] + extra
+    run(cmd, os.path.join(OUT, f"pmc_{tag}_SQ{suffix}.log"))
     acc = {}
+    full_grid = ((w["worlds"] + 7) // 8) * 8 * 64
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if KERNEL in row.get("Kernel_Name", ""):
+                if kernel in row.get("Kernel_Name", "") and int(float(row.get("Grid_Size") or 0)) == full_grid:
                     acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    lines = [f"rocprofv3 --pmc {' '.join(SQ_COUNTERS)} --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline   (MI355X, build '{tag}')",
-             f"means over the launches of {KERNEL}:"]
-    mean = {k: sum(v) / len(v) for k, v in acc.items() if v}
+    lines = [f"rocprofv3 --pmc {' '.join(SQ_COUNTERS)} --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline {' '.join(extra)}  (MI355X, build '{tag}')",
+             f"means over the last 12 full-grid launches of {kernel} (the timed region):"]
+    mean = {k: sum(v[-12:]) / len(v[-12:]) for k, v in acc.items() if v}
     for k in SQ_COUNTERS:
         lines.append(f"  {k:22s} {mean[k]:16.0f}" if k in mean else f"  {k:22s} (not collected)")
     wc = mean.get("SQ_WAVE_CYCLES")
+    out = dict(mean, kernel=kernel, build=tag, worlds=w["worlds"])
     if wc:
         for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
             if k in mean:
                 lines.append(f"  {k} / SQ_WAVE_CYCLES = {mean[k] / wc:.3f}")
-    with open(os.path.join(OUT, f"pmc_{tag}_sq_mix.txt"), "w") as f:
+                out[k + "_frac"] = mean[k] / wc
+    with open(os.path.join(OUT, f"pmc_{tag}_sq_mix{suffix}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
+    with open(os.path.join(OUT, f"pmc_{tag}_sq_mix{suffix}.json"), "w") as f:
+        json.dump(out, f, indent=1)
     print("\n".join(lines))
 
 
@@ -149,7 +160,8 @@ if __name__ == "__main__":
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[2] == "sq":
-        sq_mix(tag)
+        for w in (sys.argv[3:] or ["fetch"]):
+            sq_mix(tag, None if w == "fetch" else w)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "stats":          # kernel stats only: fetch (name it "fetch") and / or other workloads
         for w in sys.argv[3:]:

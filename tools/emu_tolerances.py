@@ -95,6 +95,59 @@ def run_family(L, family, fp64, every=1, only=None, round_inputs=False, ref=None
     return np.array(idx), out, status, CASES[family][3]
 
 
+def run_family_horizons(L, family, horizons=(1, 2, 5, 10), every=1):
+    """FREE-RUNNING twin of run_family (tests/tolerance_cases.py::horizon_errors on the CPU): the emulated world starts from the pre-step state of snapshot i and keeps its own
+    state for max(horizons) steps on the rollout's recorded actions (and the kitchen's recorded noise); after h steps its observation is compared with the oracle's recorded
+    observation of snapshot i + h - 1.  Returns {h: (start indices, |error| rows [n_h, obs_dim], min activation gap over the h steps)}, comps."""
+    from tolerance_cases import CASES, episode_runs
+    import emu_fp64_check as E
+    task = FAMILY_TO_TASK[family]
+    keep = E.as_fp64_struct
+    E.as_fp64_struct = lambda s: s
+    try:
+        m, t, g, kind = E._fixture(task)
+    finally:
+        E.as_fp64_struct = keep
+    dt, cdt = np.float32, ctypes.c_float
+    if kind == "adroit":
+        from gymnasium_robotics_amd.envs.adroit_spec import action_scaling
+        am, ar = action_scaling(m)
+    H, I, F = m.pack()
+    h_ = L.emu_create(H.ctypes.data, I.ctypes.data, F.ctypes.data)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64), dtype=dt).copy()
+    run, gap, nobs, hmax = episode_runs(g), g["activation_gap"], g["obs"].shape[1], max(horizons)
+    res = {h: ([], [], []) for h in horizons}
+    for i in range(0, g["obs"].shape[0], every):
+        qp, qv, qa = f(g["qpos"][i]), f(g["qvel"][i]), f(g["qacc_ws"][i])
+        if kind == "kitchen":
+            last = f(g["last_qpos"][i])
+        elif kind == "adroit":
+            sh, tg = f(g["shift"][i]), f(g["target"][i])
+        elif kind == "fetch":
+            mocap, aux = f(g["mocap"][i]), f(g["aux"][i])
+        for k in range(min(hmax, int(run[i]))):
+            a, st = f(g["action"][i + k]), ctypes.c_int(0)
+            if kind == "kitchen":
+                obs, nz, done = np.zeros(nobs, dt), f(g["noise"][i + k]), ctypes.c_int(0)
+                L.emu_kitchen_step(ctypes.c_void_p(h_), ctypes.byref(t), p(qp), p(qv), p(qa), p(last), p(a), p(nz), p(obs), ctypes.byref(done), ctypes.byref(st), ctypes.c_int(0))
+            elif kind == "adroit":
+                obs, rew, suc = np.zeros(nobs, dt), cdt(0), ctypes.c_ubyte(0)
+                L.emu_adroit_step(ctypes.c_void_p(h_), ctypes.byref(t), p(qp), p(qv), p(qa), p(sh), p(tg), p(a), p(f(am)), p(f(ar)), p(obs), ctypes.byref(rew),
+                                  ctypes.byref(suc), ctypes.byref(st), ctypes.c_int(0))
+            elif kind == "fetch":
+                obs, ach = np.zeros(nobs, dt), np.zeros(3, dt)
+                L.emu_fetch_step(ctypes.c_void_p(h_), ctypes.byref(t), p(qp), p(qv), p(qa), p(mocap), p(aux), p(a), p(obs), p(ach), ctypes.byref(st))
+            else:
+                obs, ach, palm = np.zeros(256, dt), np.zeros(15, dt), np.zeros(3, dt)
+                L.emu_hand_step(ctypes.c_void_p(h_), ctypes.byref(t), p(qp), p(qv), p(qa), p(a), p(obs), p(ach), p(palm), ctypes.byref(st), ctypes.c_int(0))
+            if k + 1 in res:
+                res[k + 1][0].append(i)
+                res[k + 1][1].append(np.abs(obs[:nobs].astype(np.float64) - g["obs"][i + k]))
+                res[k + 1][2].append(float(gap[i:i + k + 1].min()))
+    return {h: (np.array(v[0]), np.array(v[1]), np.array(v[2])) for h, v in res.items()}, CASES[family][3], g
+
+
 def main(argv):
     fp64 = "--fp64" in argv
     every = int(argv[argv.index("--every") + 1]) if "--every" in argv else 1
@@ -110,6 +163,18 @@ def main(argv):
         sys.argv = keep
         L64.emu_create.restype = ctypes.c_void_p
         L64.emu_create.argtypes = [ctypes.c_void_p] * 3
+    if "--horizons" in argv:      # free-running parity on the CPU (tests/tolerance_cases.py::horizon_errors is the GPU measurement)
+        for fam in fams:
+            if fam in ("FetchHullContacts", "AntMazeLarge"):
+                continue
+            res, comps, g = run_family_horizons(L, fam, every=every)
+            for h, (idx, e, gp) in res.items():
+                posed = gp >= 1e-6
+                for comp, cols in comps.items():
+                    err = (e[:, cols] / np.maximum(1.0, np.abs(g["obs"][idx + h - 1][:, cols]))).max(axis=1) if comp.endswith("_relative") else e[:, cols].max(axis=1)
+                    print(f"{fam:18s} h={h:2d} {comp:26s} starts {len(err):4d} posed {int(posed.sum()):4d} p50 {np.median(err):.1e} p90 {np.quantile(err, .9):.1e} max {err.max():.1e} within 1e-4: {100 * np.mean(err < 1e-4):5.1f} % | posed: "
+                          f"max {err[posed].max():.1e} within {100 * np.mean(err[posed] < 1e-4):5.1f} %", flush=True)
+        return
     if "--sensitivity" in argv:      # the fp64 build against ITSELF from states jittered by one fp32 ulp: how well-posed each snapshot is for any fp32-state engine
         L64 = ctypes.CDLL(build(True)); L64.emu_create.restype = ctypes.c_void_p; L64.emu_create.argtypes = [ctypes.c_void_p] * 3
         for fam in fams:
