@@ -343,14 +343,6 @@ def run_rank(args, rank, world_size, local_rank):
     if out_rows is None:
         out_rows = env.obs   # plain (non-goal) environments: the observation rows are the per-step output
     gathered = torch.empty(n * world_size, out_rows.shape[1], device=device) if dist else None
-    # Steady state before anything is timed (VERDICT r04 item 2): a fresh batch is not what a training run sees -- the worlds of a Fetch batch that end up with the upper arm
-    # resting on the head link (the stragglers that end a launch) accumulate over an episode, so the first ~25 steps after reset() are ~10 % faster than the stationary
-    # regime.  One full horizon of untimed staggered steps puts every world through every phase of its episode; `--steps 20 --warmup 5` then reports what `--steps 100` reports.
-    preroll = (env.max_episode_steps or w["horizon"]) if args.preroll < 0 else args.preroll
-    if dry:
-        preroll = min(preroll, 3)
-    for _ in range(preroll):
-        env.step(torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1)
     her = args.workload == "fetch" and not dry
     # HER "future" relabelling on the device (gymnasium_robotics_amd/her.py): the packed rows of the last `horizon` steps stay in an HBM ring; every
     # step ONE kernel gathers HER_K relabelled transitions per world (goal substitution + reward recompute + replay write)
@@ -373,7 +365,14 @@ def run_rank(args, rank, world_size, local_rank):
             # steps later, measured 0.2 - 0.9 ms SLOWER per step (cross-stream dependencies in both directions every step; tools/ab_dist.sh)
             dist.all_gather_into_tensor(gathered, out_rows)
 
-    for _ in range(args.warmup):
+    # Steady state before anything is timed (VERDICT r04 item 2): a fresh batch is not what a training run sees -- the worlds of a Fetch batch that end up with the upper arm
+    # resting on the head link (the stragglers that end a launch) accumulate over an episode, and the HER ring holds fewer steps than its horizon -- so the first ~25 steps
+    # after reset() are ~10 % faster than the stationary regime.  One full horizon of untimed steps of the WHOLE step (HER append + relabel and the collective included) puts
+    # every world through every phase of its episode; `--steps 20 --warmup 5` then reports what `--steps 100` reports.
+    preroll = (env.max_episode_steps or w["horizon"]) if args.preroll < 0 else args.preroll
+    if dry:
+        preroll = min(preroll, 3)
+    for _ in range(preroll + args.warmup):
         one_step()
     env.clear_status()
     env.kernel_events = []   # HIP events (torch's current stream = the launch stream) around every step-kernel launch of the timed region
