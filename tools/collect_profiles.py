@@ -63,7 +63,7 @@ def pmc(tag, workload=None):
     w = WORKLOADS[workload or "fetch"]
     kernel, algo_bytes = w["kernel"], w["algo"] * w["worlds"]
     suffix = f"_{workload}" if workload else ""
-    extra = ["--workload", workload] if workload else []
+    extra = (["--workload", workload] if workload else []) + os.environ.get("GRX_COLLECT_EXTRA", "").split()      # (A/B runs: e.g. "--preroll 0")
     res, meta = {}, {}
     for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(OUT, f"pmc_{tag}_{cnt}{suffix}")

@@ -193,6 +193,12 @@ def main(argv):
         n0 = [L.emu_newton_stat(k) for k in range(6)]
         idx, e, status, comps = run_family(L, fam, fp64, every, round_inputs=rounded, ref=ref)
         n1 = [L.emu_newton_stat(k) - n0[k] for k in range(6)]
+        if hasattr(L, "emu_cert_stat"):
+            L.emu_cert_stat.restype = ctypes.c_long
+            cs = [L.emu_cert_stat(k) for k in range(4)]
+            cs0 = getattr(main, "_cs", [0, 0, 0, 0]); main._cs = cs
+            d = [a - b for a, b in zip(cs, cs0)]
+            print(f"{fam:18s} certified fp32 portal: primitive pairs {d[0]} attempts, {d[1]} undecided ({100 * d[1] / max(d[0], 1):.1f} %); hull pairs {d[2]} attempts, {d[3]} undecided ({100 * d[3] / max(d[2], 1):.1f} %)", flush=True)
         print(f"{fam:18s} Newton: {n1[0]} solves, {n1[1] / max(n1[0], 1):.3f} iterations / solve, {n1[2] / max(n1[0], 1):.3f} Hessian assemblies / solve, {n1[3] / max(n1[0], 1):.3f} incremental updates / solve, object-block refinements eligible {n1[4] / max(n1[0], 1):.3f} / run {n1[5] / max(n1[0], 1):.3f} per solve", flush=True)
         for comp, cols in comps.items():
             err = e[:, cols].max(axis=1)      # absolute, also for the "_relative" components of tests/tolerance_cases.py
