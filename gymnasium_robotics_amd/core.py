@@ -90,6 +90,99 @@ class GoalVecEnv:
     def close(self):
         pass
 
+    # ------------------------------------------------------------------ checkpoint / resume (the reference's own round trip: adroit_hand/adroit_hammer.py:380-402,
+    # /root/reference/tests/envs/adroit_hand/test_adroit_hammer.py:10-68 -- get_env_state / set_env_state carry EVERYTHING that determines the future of the episode)
+    CKPT_SCALARS = ("_has_reset", "_ar_head", "_step_no", "cap_cur")      # python scalars that are state (everything else that is a scalar is configuration)
+    CKPT_SKIP = ("_ezpickle_args", "_ezpickle_kwargs")
+
+    def _ckpt_quiesce(self):
+        """nothing of this environment may be in flight on a side stream when the tensors are read or overwritten (families with side-stream work override)"""
+
+    def _ckpt_extra_get(self):
+        return {}
+
+    def _ckpt_extra_set(self, extra):
+        pass
+
+    def get_state(self):
+        """Everything that determines the future of this vector environment at a step boundary, as a dict of clones: every device tensor the environment owns (state rows,
+        warm start, mocap / stale-kinematics words, goals, per-world model edits, the DEVICE-RESIDENT PCG64 streams, TimeLimit counters, task bookkeeping, the last outputs,
+        sticky status words, dispatch order and measured world costs, hull caches), every host array (`_elapsed`, `_needs_reset`, reset attempts ...), the host-side numpy
+        generators of the families that draw on the host, the overflow lane's membership lists and time-to-live counters, and the settle chains in flight of the hand
+        families.  `set_state(env.get_state())` followed by the same actions reproduces the uninterrupted rollout bit for bit, across autoresets
+        (tests/test_gpu_checkpoint.py).  Synchronises the device; does not change the environment."""
+        import copy
+
+        import torch
+
+        self._ckpt_quiesce()
+        torch.cuda.synchronize(self.device)
+        st = dict(cls=type(self).__name__, env_id=getattr(self, "env_id", None), num_envs=int(self.num_envs), tensors={}, arrays={}, scalars={}, rng={}, dicts={})
+        for k, v in self.__dict__.items():
+            if k in self.CKPT_SKIP:
+                continue
+            if isinstance(v, torch.Tensor):
+                st["tensors"][k] = v.detach().clone()
+            elif isinstance(v, np.ndarray):
+                st["arrays"][k] = v.copy()
+            elif isinstance(v, dict) and v and all(isinstance(x, torch.Tensor) for x in v.values()):
+                st["dicts"][k] = {kk: vv.detach().clone() for kk, vv in v.items()}
+            elif isinstance(v, list) and v and all(isinstance(g, np.random.Generator) for g in v):
+                st["rng"][k] = [copy.deepcopy(g.bit_generator.state) for g in v]
+        for k in self.CKPT_SCALARS:
+            if k in self.__dict__:
+                st["scalars"][k] = self.__dict__[k]
+        lane = getattr(self, "lane", None)
+        if lane is not None:
+            st["lane"] = lane.get_state()
+        st["extra"] = self._ckpt_extra_get()
+        return st
+
+    def set_state(self, state):
+        """Restore a get_state() checkpoint (of this environment or of another instance of the same id and size) IN PLACE: tensors are copied into the existing buffers, so
+        every native buffer struct keeps its pointers.  Also accepts a plain {name: tensor} mapping (state rows only)."""
+        import torch
+
+        if "tensors" not in state:      # a plain mapping of state rows
+            for k, v in state.items():
+                getattr(self, k).copy_(v)
+            return
+        if state["cls"] != type(self).__name__ or state["num_envs"] != self.num_envs or state["env_id"] != getattr(self, "env_id", None):
+            raise ValueError(f"checkpoint of {state['cls']}({state['env_id']!r}, num_envs={state['num_envs']}) does not fit {type(self).__name__}({getattr(self, 'env_id', None)!r}, num_envs={self.num_envs})")
+        self._ckpt_quiesce()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            for k, v in state["tensors"].items():
+                cur = self.__dict__.get(k)
+                if isinstance(cur, torch.Tensor) and cur.shape == v.shape and cur.dtype == v.dtype:
+                    cur.copy_(v)
+                else:
+                    self.__dict__[k] = v.to(self.device).clone() if v.is_cuda else v.clone()
+            self._ckpt_extra_set(state.get("extra", {}))      # (families with lazily created arenas make them here, before their tensors are filled)
+            for k, d in state["dicts"].items():
+                cur = self.__dict__.get(k)
+                for kk, vv in d.items():
+                    if isinstance(cur, dict) and kk in cur and cur[kk].shape == vv.shape:
+                        cur[kk].copy_(vv)
+                    else:
+                        self.__dict__.setdefault(k, {})[kk] = vv.clone()
+            for k, v in state["arrays"].items():
+                cur = self.__dict__.get(k)
+                if isinstance(cur, np.ndarray) and cur.shape == v.shape and cur.dtype == v.dtype:
+                    cur[...] = v
+                else:
+                    self.__dict__[k] = v.copy()
+            for k, v in state["scalars"].items():
+                self.__dict__[k] = v
+            for k, states in state["rng"].items():
+                gens = self.__dict__.get(k)
+                for g, s in zip(gens, states):
+                    g.bit_generator.state = s
+            lane = getattr(self, "lane", None)
+            if lane is not None and "lane" in state:
+                lane.set_state(state["lane"])
+            torch.cuda.synchronize(self.device)
+
 
 class PinnedStager:
     """Index lists / small float rows for the device WITHOUT waiting for the stream.  A copy from pageable memory is stream-ordered and synchronous for the
@@ -341,6 +434,24 @@ class OverflowLane:
         b = self._make_bufs(mask)
         b.lane = self._large(sc.entry_list, sc.entry_count_ptr, sc, ENTRY_CAP, 0)
         launch_large(b)
+
+    def get_state(self):
+        """membership of the lane at a step boundary (the list the NEXT step's lane launch walks, the flags the fast launch skips by, the time-to-live counters) and the
+        grid that list was built under; the delayed host view of the counters (`_seen`) rides along so that the capacities of the following steps repeat as well"""
+        cur = self.cur
+        return dict(head=cur.head.clone(), next_list=cur.next_list.clone(), entry_list=cur.entry_list.clone(), ttl=self.ttl.clone(), cap_cur=int(self.cap_cur), seen=int(self._seen))
+
+    def set_state(self, st):
+        import torch
+
+        cur = self.cur
+        cur.head.copy_(st["head"]); cur.next_list.copy_(st["next_list"]); cur.entry_list.copy_(st["entry_list"]); self.ttl.copy_(st["ttl"])
+        self.cap_cur, self._seen = int(st["cap_cur"]), int(st["seen"])
+        for slot in self._pin:      # counter read-backs in flight belong to the run that was replaced
+            if slot["event"] is not None:
+                slot["event"].synchronize()
+            slot["event"], slot["age"] = None, 0
+        self._age = 0
 
     def count(self):
         """worlds in the lane right now (synchronises: diagnostics only)"""

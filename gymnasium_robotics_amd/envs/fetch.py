@@ -389,13 +389,7 @@ class FetchVecEnv(GoalVecEnv):
     def compute_truncated(self, achieved_goal, desired_goal, info=None):
         return np.zeros(np.asarray(achieved_goal).shape[:-1], bool)  # robot_env.py:110-112
 
-    # ------------------------------------------------------------------ state access (checkpoint / tests)
-    def get_state(self):
-        return {k: getattr(self, k).clone() for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal")}
-
-    def set_state(self, state):
-        for k, v in state.items():
-            getattr(self, k).copy_(v)
+    # checkpoint / resume: core.GoalVecEnv.get_state / set_state (state rows, the device-resident PCG64 streams, TimeLimit counters, hull caches, dispatch order, lane)
 
     def close(self):
         if getattr(self, "_h", None):

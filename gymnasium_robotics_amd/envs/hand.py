@@ -325,12 +325,34 @@ class HandReachVecEnv(GoalVecEnv):
     def compute_truncated(self, achieved_goal, desired_goal, info=None):
         return np.zeros(np.asarray(achieved_goal).shape[:-1], bool)  # robot_env.py:110-112
 
-    def get_state(self):
-        return {k: getattr(self, k).clone() for k in ("qpos", "qvel", "qacc_ws", "goal")}
+    # ---- checkpoint hooks (core.GoalVecEnv.get_state / set_state): the settle chains of the overlapped same-step autoreset are state -- arena rows, the worlds they
+    # belong to, the step they are due at, the generator positions they would hand back -- and they live on side streams
+    def _ckpt_quiesce(self):
+        for c in getattr(self, "_chains", None) or ():
+            if c["event"] is not None:
+                c["event"].synchronize()
 
-    def set_state(self, state):
-        for k, v in state.items():
-            getattr(self, k).copy_(v)
+    def _ckpt_extra_get(self):
+        import copy
+
+        chains = [dict(worlds=np.asarray(c["worlds"]).copy(), lo=int(c["lo"]), k=int(c["k"]), due_at=int(c["due_at"]), ok=None if c["ok"] is None else np.asarray(c["ok"]).copy(),
+                       rng_states=copy.deepcopy(c.get("rng_states", []))) for c in (getattr(self, "_chains", None) or ())]
+        return {"chains": chains, "arena": getattr(self, "_ar", None) is not None}
+
+    def _ckpt_extra_set(self, extra):
+        if getattr(self, "_ar", None) is not None:      # chains of the run that is being replaced: wait for them, drop them (their draws are overwritten with the generators' states)
+            self._ckpt_quiesce()
+            self._chains, self._chain_started[:] = [], False
+        if not extra.get("arena"):
+            return
+        self._arena()
+        chains = []
+        for c in extra["chains"]:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))      # (set_state synchronises before it returns: the arena rows restored behind this are in place when the event is consulted)
+            chains.append(dict(worlds=c["worlds"].copy(), ti=self._dev_index(c["worlds"]), lo=c["lo"], k=c["k"], due_at=c["due_at"], ready=ev, event=ev, ok=None if c["ok"] is None else c["ok"].copy(),
+                               rng_states=c["rng_states"]))
+        self._chains = chains
 
     def close(self):
         if getattr(self, "_h", None):
