@@ -159,7 +159,8 @@ def acquire_model(H, I, F, device_index):
     """handle of the model packed as (H, I, F) on `device_index`: created on first use, reference-counted afterwards (release_model)"""
     import hashlib
 
-    key = (int(device_index), hashlib.sha1(H.tobytes() + I.tobytes() + F.tobytes()).hexdigest())
+    # (GRX_NO_HULLCELLS changes what grx_model_create derives from the tables -- the A/B switch of the hulls' support-candidate lists -- so it is part of the key)
+    key = (int(device_index), hashlib.sha1(H.tobytes() + I.tobytes() + F.tobytes()).hexdigest(), os.environ.get("GRX_NO_HULLCELLS") is not None)
     with _MODEL_LOCK:
         ent = _MODELS.get(key)
         if ent is None:

@@ -90,6 +90,45 @@ class GoalVecEnv:
     def close(self):
         pass
 
+    def _stage_idx(self, idx):
+        """index list -> int64 device tensor through pinned memory, enqueued and never waited for (a `.to(device)` of a pageable array is a synchronising copy: issued behind
+        a step kernel it makes the host wait for that kernel)"""
+        st = self.__dict__.get("_idx_stager")
+        if st is None:
+            st = self.__dict__["_idx_stager"] = PinnedStager(self.num_envs, 1, self.device)
+        return st(np.asarray(idx, dtype=np.int64))
+
+    # ---- per-world PCG64 streams of the families that draw on the device (`_rng_dev`: [N, 4] uint64 bit patterns state_hi, state_lo, inc_hi, inc_lo; the mazes carry a fifth
+    # word, numpy's buffered 32-bit half).  The per-world host generators (`np_randoms`) exist only for the tasks whose draws stay on the host.
+    def world_rng(self, i):
+        """numpy Generator positioned at world i's current stream position (inspection / tests: synchronises)"""
+        if getattr(self, "_rng_dev", None) is None or not getattr(self, "_device_draws", True):
+            return self.np_randoms[i]
+        a = [int(x) for x in self._rng_dev[i].cpu().numpy().view(np.uint64)]
+        bg = np.random.PCG64()
+        st = bg.state
+        st["state"] = {"state": (a[0] << 64) | a[1], "inc": (a[2] << 64) | a[3]}
+        if len(a) > 4:
+            st["has_uint32"], st["uinteger"] = int(a[4] >> 32), int(a[4] & 0xFFFFFFFF)
+        bg.state = st
+        return np.random.Generator(bg)
+
+    def set_world_rng(self, i, generator):
+        """position world i's stream at `generator`'s (a numpy PCG64 Generator): the device-resident row is overwritten, or the host generator replaced"""
+        import torch
+
+        if getattr(self, "_rng_dev", None) is None or not getattr(self, "_device_draws", True):
+            self.np_randoms[i] = generator
+            return
+        s = generator.bit_generator.state
+        if s["bit_generator"] != "PCG64":
+            raise ValueError("the device streams are numpy PCG64 streams")
+        mask = (1 << 64) - 1
+        row = [s["state"]["state"] >> 64, s["state"]["state"] & mask, s["state"]["inc"] >> 64, s["state"]["inc"] & mask]
+        if self._rng_dev.shape[1] > 4:
+            row.append((int(s["has_uint32"]) << 32) | int(s["uinteger"]))
+        self._rng_dev[i] = torch.from_numpy(np.array(row, dtype=np.uint64).view(np.int64)).to(self.device)
+
     # ------------------------------------------------------------------ checkpoint / resume (SURVEY.md 5; the reference's own round trip: adroit_hand/adroit_hammer.py:380-402,
     # /root/reference/tests/envs/adroit_hand/test_adroit_hammer.py:10-68 -- get_env_state / set_env_state carry EVERYTHING that determines the future of the episode)
     CKPT_SCALARS = ("_has_reset", "_ar_head", "_step_no", "cap_cur")      # python scalars that are state (everything else that is a scalar is configuration)
@@ -232,7 +271,7 @@ def np_random(seed=None):
 
 
 # ---------------------------------------------------------------------------------------------- the overflow lane (include/grx_capi.h, grx_overflow_lane)
-# Tables of the LARGE model of every family: 256 rows / 4 080 Jacobian-pool words (the 12-bit row offsets' limit) / 64 contacts (one lane each: twice the fast kernels' lists); ~32-42 KB of LDS per
+# Tables of the LARGE model of every family: 256 rows / 4 080 Jacobian-pool words (row offsets are 14 bits, GRX_ROW_PACK: the kitchen's 8 160 fit as well) / 64 contacts (one lane each: twice the fast kernels' lists); ~32-42 KB of LDS per
 # world on the generic kernel.  The reference never truncates a contact list (mujoco.mj_step, envs/robot_env.py:341).
 RERUN_CAPACITY = {"maxefc": 256, "jpool": 4080, "maxcon": 64}
 # the kitchen (124 colliding geoms, condim-6 finger pads = ten rows per contact, 29-dof spans): measured on 16 384 worlds x 100 steps of random actions -- 26 worlds with a

@@ -98,8 +98,31 @@ struct GrxModel {
   // derived at model creation (grx_host_model.h), not part of the compiled blob: per hull vertex 16 records of 4 floats -- the vertex itself (x, y, z, degree; degree -1 when
   // it has more than 15 hull neighbours) and its hull neighbours (x, y, z, local id) -- so that a GUESSED support vertex is verified with ONE coalesced fetch (grx_mesh_support)
   const float* mesh_nbr;
+  // derived at model creation too (grx_host_model.h, grx_build_hull_cells): the SUPPORT-CANDIDATE LISTS of every hull.  The unit sphere of directions (in the geom frame) is cut
+  // into 6 x GRX_CELL_G x GRX_CELL_G cube-map cells; for every cell the list holds every hull vertex that can be the support vertex -- or tie with it inside the scan's 1e-6 m
+  // band -- for ANY direction of the cell (a rigorous superset: v is listed unless (w - v) . dc > rho |w - v| + band, w = the support vertex of the cell's centre direction dc,
+  // rho = the cell's chord radius).  A support evaluation whose guess (mesh_nbr) failed reads ONE cell header and ONE round of <= 64 coalesced 16-byte records (x, y, z, vertex
+  // id) instead of scanning the hull (the Fetch head link: 1061 vertices, 17 rounds of loads): same winner, same tie-break, by construction and by test
+  // (tests/test_cpu_hull_cells.py; the lane emulator checks every evaluation of every fixture against the list).
+  const int* mesh_cellhdr;     // per (hull, cell): offset into mesh_cellrec (records), count (0: no list, scan the hull)
+  const float* mesh_cellrec;
+  const int* geom_cellbase;    // per geom: first header of its hull (in header pairs), -1 = none
 };
 #define GRX_NBR_RECS 16
+#define GRX_CELL_G 16
+#define GRX_CELL_MAX 64      // a cell whose list would be longer keeps none (count 0): the hull is scanned
+// cube-map cell of a direction (any length > 0): the same arithmetic on the host (list construction, with the cells dilated by more than its rounding) and on the device
+GRX_HD int grx_hull_cell(float x, float y, float z) {
+  const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+  int face; float ma, u, v;
+  if (ax >= ay && ax >= az) { face = x < 0.0f ? 1 : 0; ma = ax; u = y; v = z; }
+  else if (ay >= az) { face = y < 0.0f ? 3 : 2; ma = ay; u = x; v = z; }
+  else { face = z < 0.0f ? 5 : 4; ma = az; u = x; v = y; }
+  const float s = (0.5f * GRX_CELL_G) / fmaxf(ma, 1e-30f);
+  int iu = (int)floorf(u * s + 0.5f * GRX_CELL_G), iv = (int)floorf(v * s + 0.5f * GRX_CELL_G);
+  iu = iu < 0 ? 0 : (iu > GRX_CELL_G - 1 ? GRX_CELL_G - 1 : iu); iv = iv < 0 ? 0 : (iv > GRX_CELL_G - 1 ? GRX_CELL_G - 1 : iv);
+  return (face * GRX_CELL_G + iu) * GRX_CELL_G + iv;
+}
 #define GRX_HULLCACHE_WORDS 90   // per-world HBM row of the hull pairs: 21 words of cached separating directions (GrxCtx::meshcache) + 4 x (key + 16 guess words) + a round-robin counter
 
 // mirrors grx_overflow_lane (include/grx_capi.h): where the worlds go that exceed a table capacity of the fast kernel
@@ -524,6 +547,7 @@ typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NMC (S::kFixed ? S::NM : m->nmocap)
 #if defined(GRX_EMU)
 static long g_grx_mesh_stats[4];   // emulator diagnostics: hull pairs skipped by a cached separating direction / sent through the portal search
+static long g_grx_cell_stats[4];   // emulator: hull support evaluations with a cell table / with a list in their cell / total list entries seen / near-tie vertices MISSING from a list (must be 0)
 static long g_grx_newton_stats[6];   // emulator diagnostics: constrained solves, Newton iterations, full Hessian assemblies, incremental updates
 #if defined(GRX_EMU_TRACE)
 static void grx_emu_trace(const GrxModel* m, const GrxCtx* c, int phase);   // defined at the end of this file
@@ -1319,6 +1343,7 @@ struct GrxMprPairT { RF R1[9], R2[9], s1[3], s2[3]; MF c21[3], hm; int t1, t2;  
                                         // hull vertices (geom frame) of mesh geoms: only read by the wave-cooperative variant
                     GrxMprPt* pts;
                     const float *nbr1, *nbr2;   // neighbour records of the two hulls (GrxModel::mesh_nbr + 64 * first hull vertex), or null
+                    const int *cell1, *cell2; const float* cellrec;   // support-candidate lists of the two hulls (GrxModel::mesh_cellhdr + 2 * geom_cellbase, mesh_cellrec), or null
                     mutable int hint, hk;       // wave-cooperative variant: lane e holds the guessed support vertices of evaluation e ((v1 + 1) | (v2 + 1) << 16); evaluations so far
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
                     long long* prof;
@@ -1375,7 +1400,7 @@ GRX_MEM int grx_mesh_support_refine(const float* verts, const int* aadr, const i
 // above 1e-7 m over 10^5 face-normal, chord and random directions).  One coalesced fetch of 16 records instead of a scan of the whole hull; anything else (a near-tie, a
 // vertex with more than 15 neighbours, a stale guess) falls through to the scan.
 GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, int lane_, const int* aadr = nullptr, const int* anum = nullptr, const int* adj = nullptr, int hint = -1,
-                             const float* nbr = nullptr) {
+                             const float* nbr = nullptr, const int* cellhdr = nullptr, const float* cellrec = nullptr) {
   r[0] = r[1] = r[2] = 0.0f;
   if (n <= 0) return -1;
 #if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
@@ -1401,12 +1426,42 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
 #if defined(GRX_EMU)
   HF best = -3.0e38f; int bi = 0;
   for (int v = 0; v < n; v++) { const HF t = verts[3 * v] * dl[0] + verts[3 * v + 1] * dl[1] + verts[3 * v + 2] * dl[2]; if (t > best) { best = t; bi = v; } }
+  if (cellhdr) {   // the emulator scans the hull; it CHECKS that the device's candidate list of this direction's cell holds every vertex inside the tie band (what the device reads instead)
+    const int cell = grx_hull_cell((float)dl[0], (float)dl[1], (float)dl[2]), off = cellhdr[2 * cell], cnt = cellhdr[2 * cell + 1];
+    g_grx_cell_stats[0]++;
+    if (cnt > 0) {
+      g_grx_cell_stats[1]++; g_grx_cell_stats[2] += cnt;
+      const HF near_ = best - 1.0e-6f * fmaxf(1.0f, fabsf(best));
+      for (int v = 0; v < n; v++) {
+        const HF t = verts[3 * v] * dl[0] + verts[3 * v + 1] * dl[1] + verts[3 * v + 2] * dl[2];
+        if (t < near_) continue;
+        int found = 0;
+        for (int k = 0; k < cnt; k++) {
+          const float* rec = cellrec + 4 * (size_t)(off + k); int id; memcpy(&id, rec + 3, 4);
+          if (id == v) { found = (rec[0] == verts[3 * v] && rec[1] == verts[3 * v + 1] && rec[2] == verts[3 * v + 2]); break; }
+        }
+        if (!found) g_grx_cell_stats[3]++;   // a vertex the device would not have seen: must stay 0 (tests/test_cpu_hull_cells.py)
+      }
+    }
+  }
 #else
 #ifndef GRX_HULL_INFLIGHT
 #define GRX_HULL_INFLIGHT 4
 #endif
   float best = -3.0e38f, second = -3.0e38f, bx = 0.0f, by = 0.0f, bz = 0.0f; int mine = 0;   // second: this lane's runner-up (is the winner unique beyond fp32 rounding?)
-  for (int v0 = lane_; v0 < n; v0 += 64 * GRX_HULL_INFLIGHT) {   // several independent vertex fetches in flight per lane: one memory latency per 64 * GRX_HULL_INFLIGHT vertices
+  int listed = 0;
+  if (cellhdr) {   // the candidate list of the direction's cell: every vertex that can win or tie is in it (GrxModel::mesh_cellhdr), one record per lane
+    const int cell = grx_hull_cell(dl[0], dl[1], dl[2]);
+    const int off = __builtin_amdgcn_readfirstlane(cellhdr[2 * cell]), cnt = __builtin_amdgcn_readfirstlane(cellhdr[2 * cell + 1]);
+    if (cnt > 0) {
+      listed = 1;
+      if (lane_ < cnt) {
+        const float4 p = ((const float4*)cellrec)[off + lane_];
+        best = p.x * dl[0] + p.y * dl[1] + p.z * dl[2]; mine = __float_as_int(p.w); bx = p.x; by = p.y; bz = p.z;
+      }
+    }
+  }
+  for (int v0 = lane_; !listed && v0 < n; v0 += 64 * GRX_HULL_INFLIGHT) {   // several independent vertex fetches in flight per lane: one memory latency per 64 * GRX_HULL_INFLIGHT vertices
     float x[GRX_HULL_INFLIGHT], y[GRX_HULL_INFLIGHT], z[GRX_HULL_INFLIGHT];
 #pragma unroll
     for (int u = 0; u < GRX_HULL_INFLIGHT; u++) { const int v = v0 + 64 * u < n ? v0 + 64 * u : n - 1; x[u] = verts[3 * v]; y[u] = verts[3 * v + 1]; z[u] = verts[3 * v + 2]; }
@@ -1470,7 +1525,7 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
 // The same with a guess: a hull vertex that is not lower than any of its hull neighbours along dl IS the support vertex (convexity), so a
 // vertex remembered from the previous substep is verified with one round of neighbour loads instead of a scan of the whole hull.
 // Returns the support vertex (hint, or the winner of the full scan).
-GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* dlm, int hint, MF* r, int lane_) {
+GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* dlm, int hint, MF* r, int lane_, const int* cellhdr = nullptr) {
   const float* verts = m->mesh_vert + 3 * adr;
   // The guess is verified in the scan's arithmetic (fp32): this routine only serves the re-check of a cached separating direction, whose test keeps 1e-6 of
   // slack -- ten times what a tie between fp32 projections can hide.  The portal search proper goes through grx_mesh_support (fp64 tie-break).
@@ -1488,7 +1543,7 @@ GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* d
 #endif
     if (!higher) { r[0] = verts[3 * hint]; r[1] = verts[3 * hint + 1]; r[2] = verts[3 * hint + 2]; return hint; }
   }
-  return grx_mesh_support(verts, n, dlm, r, lane_, m->mesh_adjadr + adr, m->mesh_adjnum + adr, m->mesh_adj);
+  return grx_mesh_support(verts, n, dlm, r, lane_, m->mesh_adjadr + adr, m->mesh_adjnum + adr, m->mesh_adj, -1, nullptr, cellhdr, m->mesh_cellrec);
 }
 // W: wave-cooperative variant (uniform control flow, every lane holds the same values; mesh geoms allowed)
 template <bool W, typename Q>
@@ -1508,12 +1563,15 @@ GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
     q->hk = ek + 1;
   }
 #endif
-  if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); f1 = grx_mesh_support(q->v1, q->n1, dl, r, q->lane, q->aadr1, q->anum1, q->adj, h1, q->nbr1); mulMatVec3f(o->w, q->R1, r); }
+  if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); f1 = grx_mesh_support(q->v1, q->n1, dl, r, q->lane, q->aadr1, q->anum1, q->adj, h1, q->nbr1, q->cell1, q->cellrec); mulMatVec3f(o->w, q->R1, r); }
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
-  if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); f2 = grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj, h2, q->nbr2); mulMatVec3f(b, q->R2, r); }
+  if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); f2 = grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj, h2, q->nbr2, q->cell2, q->cellrec); mulMatVec3f(b, q->R2, r); }
   else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
 #if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
-  if (W && ek < 16 && q->lane == ek) q->hint = ((f1 + 1) & 0xFFFF) | ((f2 + 1) << 16);   // the winners become the guesses of this evaluation in the next substep
+  // the winners become the guesses of this evaluation in the next substep.  (The guess words live in the world's HBM row, written and read by the lanes of ONE wave without a
+  // fence: a stale, torn or foreign word can never change a result, because a guess is only ever a CANDIDATE -- grx_mesh_support accepts it when it provably is the support
+  // vertex (tops every hull neighbour by the margin) and scans otherwise; tests/test_gpu_fetch.py::test_hull_caches_do_not_change_the_rollout.)
+  if (W && ek < 16 && q->lane == ek) q->hint = ((f1 + 1) & 0xFFFF) | ((f2 + 1) << 16);
 #endif
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   if (W && q->lane == 0) q->prof[16 + 28] += clock64() - tp0_;
@@ -1719,7 +1777,11 @@ GRX_MEM void grx_geom_frame_mf(const GrxModel* m, const GrxCtx* c, int g, MF* R,
   const int b = m->geom_bodyid[g];
 #ifndef GRX_NO_FREE_FRAMES
   // root bodies (children of the world that are not mocap bodies and not members of a shift group): the oracle's kinematics of ONE body, in MF
-  if (b > 0 && m->body_parent[b] == 0 && m->body_mocapid[b] < 0 && !(S::kShift && m->nshift && (m->geom_shift[g] || m->body_shift[b]))) {
+  // (joint types this routine restates: free 0, slide 2, hinge 3.  A BALL joint -- type 1 -- on a root body is not restated: such a body keeps the fp32 frame of the kinematics
+  // stage, which is also what the Jacobians of its contacts are built from; no packaged model has one, compile_mjcf is a general compiler)
+  int supported = b > 0 && m->body_parent[b] == 0 && m->body_mocapid[b] < 0 && !(S::kShift && m->nshift && (m->geom_shift[g] || m->body_shift[b]));
+  if (supported) { const int jn0 = m->body_jntnum[b], ja0 = m->body_jntadr[b]; for (int kk = 0; kk < jn0; kk++) { const int ty = m->jnt_type[ja0 + kk]; if (ty != 0 && ty != 2 && ty != 3) supported = 0; } }
+  if (supported) {
     const int jn = m->body_jntnum[b], ja = m->body_jntadr[b];
     MF p[3], q[4];
     if (jn == 1 && m->jnt_type[ja] == 0) {
@@ -1772,7 +1834,7 @@ GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int
   q.t1 = t1; q.t2 = t2; q.hm = 0.5f * margin;
   for (int k = 0; k < 3; k++) { q.s1[k] = m->geom_size[3 * g1 + k]; q.s2[k] = m->geom_size[3 * g2 + k]; q.c21[k] = p2[k] - p1[k]; }
   MF depth, dir[3], pos[3], w1[3], w2[3];
-  q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr; q.aadr1 = q.anum1 = q.aadr2 = q.anum2 = q.adj = nullptr; q.nbr1 = q.nbr2 = nullptr; q.hint = q.hk = 0;
+  q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr; q.aadr1 = q.anum1 = q.aadr2 = q.anum2 = q.adj = nullptr; q.nbr1 = q.nbr2 = nullptr; q.hint = q.hk = 0; q.cell1 = q.cell2 = nullptr; q.cellrec = nullptr;
   if (grx_mpr_penetration<false>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;
 #if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
   if (getenv("GRX_TRACE_MPR")) {
@@ -1878,6 +1940,9 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     q.nbr1 = (q.t1 == 7 && m->mesh_nbr) ? m->mesh_nbr + (size_t)4 * GRX_NBR_RECS * m->geom_hulladr[g1] : nullptr;
     q.nbr2 = (q.t2 == 7 && m->mesh_nbr) ? m->mesh_nbr + (size_t)4 * GRX_NBR_RECS * m->geom_hulladr[g2] : nullptr;
     q.hint = 0; q.hk = 0;
+    q.cell1 = (q.t1 == 7 && m->mesh_cellhdr && m->geom_cellbase[g1] >= 0) ? m->mesh_cellhdr + 2 * (size_t)m->geom_cellbase[g1] : nullptr;
+    q.cell2 = (q.t2 == 7 && m->mesh_cellhdr && m->geom_cellbase[g2] >= 0) ? m->mesh_cellhdr + 2 * (size_t)m->geom_cellbase[g2] : nullptr;
+    q.cellrec = m->mesh_cellrec;
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
     q.prof = c->prof;
 #endif   // 30 words behind the pair queue: the Jacobian pool is free until the constraint stage
@@ -1892,9 +1957,9 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
       const int hints = (int)mc[5 * slot + 4];
       int h1 = (hints & 4095) - 1, h2 = (hints >> 12) - 1;
       MF sw[3], sb[3], dl[3], r[3];
-      if (q.t1 == 7) { mulMatTVec3f(dl, q.R1, d); h1 = grx_mesh_support_hint(m, m->geom_hulladr[g1], q.n1, dl, h1, r, lane_); mulMatVec3f(sw, q.R1, r); }
+      if (q.t1 == 7) { mulMatTVec3f(dl, q.R1, d); h1 = grx_mesh_support_hint(m, m->geom_hulladr[g1], q.n1, dl, h1, r, lane_, q.cell1); mulMatVec3f(sw, q.R1, r); }
       else grx_geom_support(q.R1, q.s1, q.t1, d, sw);
-      if (q.t2 == 7) { mulMatTVec3f(dl, q.R2, nd); h2 = grx_mesh_support_hint(m, m->geom_hulladr[g2], q.n2, dl, h2, r, lane_); mulMatVec3f(sb, q.R2, r); }
+      if (q.t2 == 7) { mulMatTVec3f(dl, q.R2, nd); h2 = grx_mesh_support_hint(m, m->geom_hulladr[g2], q.n2, dl, h2, r, lane_, q.cell2); mulMatVec3f(sb, q.R2, r); }
       else grx_geom_support(q.R2, q.s2, q.t2, nd, sb);
       MF sv = 0.0f;   // v . d of the Minkowski support point (see grx_mpr_support)
       for (int k = 0; k < 3; k++) sv += ((sw[k] + d[k] * q.hm) - (sb[k] + q.c21[k] - d[k] * q.hm)) * d[k];

@@ -2,6 +2,8 @@
 // into one fp32 and one int32 array, and a GrxModel whose table pointers address those arrays
 // relative to arbitrary base pointers (host memory for the lane emulator, HBM for the GPU).
 #pragma once
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,8 +18,55 @@ struct GrxPackedModel {
   std::vector<char> kind;     // 'f' or 'i'
   std::vector<std::string> name;
   int off_mesh_nbr = -1;      // offset of the derived neighbour-record table inside f (-1: the model has no hulls)
+  int off_cellhdr = -1, off_cellbase = -1, off_cellrec = -1;   // derived support-candidate lists (GrxModel::mesh_cellhdr / geom_cellbase inside i, mesh_cellrec inside f; -1: none)
   GrxModel proto;             // scalar members filled; pointers unset
 };
+
+// Support-candidate lists of one hull (GrxModel::mesh_cellhdr): for every cube-map cell of directions the vertices that can be the support vertex, or tie with it inside the
+// device scan's band, for SOME direction of the cell.  With w the support vertex of the cell's centre direction dc and rho >= |d - dc| for every unit d of the (dilated) cell:
+// a vertex v with v . d >= max_u u . d - band has (w - v) . d <= band, hence (w - v) . dc <= band + rho |w - v|; everything else is left out.  band = 5e-6 m covers the scan's
+// tie band (1e-6 max(1, |t|)), the rounding of its fp32 projections and a direction that is unit only to fp32; the cells are dilated by 1e-3 in cube-map coordinates, a thousand
+// times the rounding of grx_hull_cell's index arithmetic (and it makes the lists of neighbouring faces overlap where the major axis is a tie).
+inline void grx_build_hull_cells(const double* vert, int num, std::vector<int32_t>* hdr, std::vector<float>* rec) {
+  const int G = GRX_CELL_G;
+  const double band = 5.0e-6, dil = 1.0e-3;
+  std::vector<int> list;
+  for (int face = 0; face < 6; face++)
+    for (int iu = 0; iu < G; iu++)
+      for (int iv = 0; iv < G; iv++) {
+        auto dir = [&](double u, double v, double* d) {
+          double x[3];
+          const double sgn = (face & 1) ? -1.0 : 1.0;
+          if (face < 2) { x[0] = sgn; x[1] = u; x[2] = v; } else if (face < 4) { x[0] = u; x[1] = sgn; x[2] = v; } else { x[0] = u; x[1] = v; x[2] = sgn; }
+          const double n = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+          d[0] = x[0] / n; d[1] = x[1] / n; d[2] = x[2] / n;
+        };
+        // grx_hull_cell: u / |major| in [-1, 1] is cut into G equal steps
+        const double u0 = -1.0 + 2.0 * iu / G - dil, u1 = -1.0 + 2.0 * (iu + 1) / G + dil, v0 = -1.0 + 2.0 * iv / G - dil, v1 = -1.0 + 2.0 * (iv + 1) / G + dil;
+        double dc[3], dk[3], rho = 0.0;
+        dir(0.5 * (u0 + u1), 0.5 * (v0 + v1), dc);
+        const double cu[4] = {u0, u0, u1, u1}, cv[4] = {v0, v1, v0, v1};
+        for (int k = 0; k < 4; k++) {   // the patch is the central projection of a square: its farthest point from the centre direction is a corner
+          dir(cu[k], cv[k], dk);
+          const double e = std::sqrt((dk[0] - dc[0]) * (dk[0] - dc[0]) + (dk[1] - dc[1]) * (dk[1] - dc[1]) + (dk[2] - dc[2]) * (dk[2] - dc[2]));
+          if (e > rho) rho = e;
+        }
+        rho *= 1.05;
+        int w = 0; double tw = -1e300;
+        for (int k = 0; k < num; k++) { const double t = vert[3 * k] * dc[0] + vert[3 * k + 1] * dc[1] + vert[3 * k + 2] * dc[2]; if (t > tw) { tw = t; w = k; } }
+        list.clear();
+        for (int k = 0; k < num; k++) {
+          const double dx = vert[3 * w] - vert[3 * k], dy = vert[3 * w + 1] - vert[3 * k + 1], dz = vert[3 * w + 2] - vert[3 * k + 2];
+          if (dx * dc[0] + dy * dc[1] + dz * dc[2] <= band + rho * std::sqrt(dx * dx + dy * dy + dz * dz)) list.push_back(k);
+        }
+        if ((int)list.size() > GRX_CELL_MAX) { hdr->push_back(0); hdr->push_back(0); continue; }   // (a face seen head-on with more vertices than a wave has lanes: the device scans the hull)
+        hdr->push_back((int32_t)(rec->size() / 4)); hdr->push_back((int32_t)list.size());
+        for (int k : list) {
+          float id; const int32_t ki = k; std::memcpy(&id, &ki, 4);
+          rec->push_back((float)vert[3 * k]); rec->push_back((float)vert[3 * k + 1]); rec->push_back((float)vert[3 * k + 2]); rec->push_back(id);
+        }
+      }
+}
 
 inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, GrxPackedModel* out) {
   grx_model_view v;
@@ -31,8 +80,11 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
 #undef GRX_FI
 #undef GRX_FF
   // derived table (GrxModel::mesh_nbr): for every hull vertex the vertex and its hull neighbours as (x, y, z, tag) records, 16 per vertex
+  // (only for models that HAVE a hull-vs-convex candidate pair: the records are 256 bytes per hull vertex of HBM and upload; a model whose hulls only meet planes never reads them)
   out->off_mesh_nbr = -1;
-  if (v.n_mesh_vert >= 3 && v.n_mesh_adjadr * 3 == v.n_mesh_vert) {
+  bool any_hull_pair = false;
+  for (int k = 0; k < v.n_devpair_geoms; k++) { const unsigned rec = (unsigned)v.devpair_geoms[k]; if ((rec >> 28) == 7 && ((rec >> 24) & 0xF) != 0) any_hull_pair = true; }
+  if (any_hull_pair && v.n_mesh_vert >= 3 && v.n_mesh_adjadr * 3 == v.n_mesh_vert) {
     const int nvert = v.n_mesh_vert / 3;
     out->off_mesh_nbr = (int)out->f.size();
     out->f.resize(out->f.size() + (size_t)nvert * GRX_NBR_RECS * 4, 0.0f);
@@ -53,6 +105,36 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
           q[0] = (float)v.mesh_vert[3 * gn]; q[1] = (float)v.mesh_vert[3 * gn + 1]; q[2] = (float)v.mesh_vert[3 * gn + 2]; q[3] = (float)nb;
         }
       }
+    }
+  }
+  // derived tables (GrxModel::mesh_cellhdr / geom_cellbase / mesh_cellrec): support-candidate lists of the hulls that take part in a hull-vs-convex candidate pair
+  out->off_cellhdr = out->off_cellbase = out->off_cellrec = -1;
+  if (v.n_mesh_vert >= 3 && v.n_geom_hulladr > 0 && !getenv("GRX_NO_HULLCELLS")) {
+    std::vector<char> used(v.n_geom_hulladr, 0);
+    for (int k = 0; k < v.n_devpair_geoms; k++) {
+      const unsigned rec = (unsigned)v.devpair_geoms[k];
+      const int g1 = rec & 0xFFF, g2 = (rec >> 12) & 0xFFF, t1 = (rec >> 24) & 0xF, t2 = rec >> 28;
+      if (t2 == 7 && t1 != 0) { if (g2 < v.n_geom_hulladr) used[g2] = 1; if (t1 == 7 && g1 < v.n_geom_hulladr) used[g1] = 1; }
+    }
+    std::vector<int32_t> hdr, base(v.n_geom_hulladr, -1);
+    std::vector<float> rec;
+    const int nvert = v.n_mesh_vert / 3;
+    for (int gi = 0; gi < v.n_geom_hulladr; gi++) {
+      const int adr = v.geom_hulladr[gi], num = v.geom_hullnum[gi];
+      if (!used[gi] || adr < 0 || num < GRX_CELL_MAX || adr + num > nvert) continue;   // (a hull of fewer vertices than a wave has lanes is one round of loads anyway)
+      for (int gj = 0; gj < gi; gj++) if (base[gj] >= 0 && v.geom_hulladr[gj] == adr && v.geom_hullnum[gj] == num) { base[gi] = base[gj]; break; }   // two geoms of one mesh share the lists
+      if (base[gi] >= 0) continue;
+      base[gi] = (int32_t)(hdr.size() / 2);
+      grx_build_hull_cells(v.mesh_vert + 3 * (size_t)adr, num, &hdr, &rec);
+    }
+    if (!hdr.empty()) {
+      while (out->i.size() % 4) out->i.push_back(0);
+      out->off_cellhdr = (int)out->i.size(); out->i.insert(out->i.end(), hdr.begin(), hdr.end());
+      while (out->i.size() % 4) out->i.push_back(0);
+      out->off_cellbase = (int)out->i.size(); out->i.insert(out->i.end(), base.begin(), base.end());
+      while (out->i.size() % 4) out->i.push_back(0);
+      while (out->f.size() % 4) out->f.push_back(0.0f);      // 16-byte records
+      out->off_cellrec = (int)out->f.size(); out->f.insert(out->f.end(), rec.begin(), rec.end());
     }
   }
   GrxModel& m = out->proto;
@@ -96,7 +178,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   for (int k = 0; k < v.n_dof_frictionloss; k++) if (v.dof_frictionloss[k] > 0) m.nfric++;
   for (int k = 0; k < v.n_eq_type; k++) if (v.eq_active[k] && v.eq_type[k] == GRX_EQ_WELD) m.nweld++;
   // Capacities of the row tables and of the packed-Jacobian pool: the compiler may request more than the defaults for models
-  // with wide / tall contact rows (dims slots GRX_MAXEFC_REQ / GRX_JPOOL_REQ, 0 = default); row offsets are 12-bit.
+  // with wide / tall contact rows (dims slots GRX_MAXEFC_REQ / GRX_JPOOL_REQ, 0 = default); row offsets are 14 bits (GRX_ROW_PACK).
   m.maxefc = d[GRX_MAXEFC_REQ] > 0 ? ((d[GRX_MAXEFC_REQ] + 15) / 16) * 16 : GRX_MAXEFC;
   m.jpool = d[GRX_JPOOL_REQ] > 0 ? ((d[GRX_JPOOL_REQ] + 15) / 16) * 16 : GRX_JPOOL;
   if (m.jpool > 16368) m.jpool = 16368;   // 14-bit row offsets (GRX_ROW_PACK)
@@ -125,6 +207,9 @@ inline GrxModel grx_bind_model(const GrxPackedModel& p, const float* fbase, cons
 #undef GRX_FI
 #undef GRX_FF
   m.mesh_nbr = p.off_mesh_nbr >= 0 ? fbase + p.off_mesh_nbr : nullptr;
+  m.mesh_cellhdr = p.off_cellhdr >= 0 ? ibase + p.off_cellhdr : nullptr;
+  m.geom_cellbase = p.off_cellbase >= 0 ? ibase + p.off_cellbase : nullptr;
+  m.mesh_cellrec = p.off_cellrec >= 0 ? fbase + p.off_cellrec : nullptr;
   return m;
 }
 

@@ -205,10 +205,10 @@ typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 
 // models' lanes run on the generic kernel, 2-3 x slower per world)
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 256, 4080, 0, 64, 0, 2> GrxShapeFetchPickLane;
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
-typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntLarge;
-typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntMedium;
-typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntOpen;
-typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1, 96, 1024, 0, 16> GrxShapeAntUMaze;
+typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 64, 512, 0, 16> GrxShapeAntLarge;
+typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 64, 512, 0, 16> GrxShapeAntMedium;
+typedef GrxShape<15, 14, 8, 10, 9, 34, 1, 0, 0, 1, 64, 512, 0, 16> GrxShapeAntOpen;
+typedef GrxShape<15, 14, 8, 10, 9, 32, 1, 0, 0, 1, 64, 512, 0, 16> GrxShapeAntUMaze;
 typedef GrxShape<24, 24, 20, 25, 24, 23, 5, 0, 24, 0, 96, 512, 0, 16, 1, 2> GrxShapeHandReach;  // Shadow hand, reach.xml: 24 hinges, 24 friction-loss dofs, the 5 fingertip sites, 16 contact slots
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 2> GrxShapeHandBlock;  // Shadow hand + free block (manipulate_block.xml without the visual-only target body)
 typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 112, 1024, 0, 24, 1, 3> GrxShapeHandEgg;     // manipulate_egg.xml: the ellipsoid goes through the convex narrow phase
@@ -513,12 +513,28 @@ grx_hand_lane_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
 
 // AdroitHandHammer env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world, same engine + the noslip pass
 // nv = 33, every dof carries a friction-loss row (class main: 0.001; the nail: 2.5), general-affine actuators, cylinder / capsule pairs through the convex routine
-typedef GrxShape<33, 33, 26, 29, 33, 30, 4, 1, 33, 0, 144, 2032, 1, 32, 1, 13> GrxShapeAdroitHammer;   // CONVEX bits: 1 (cylinders) | 4 (board shift group) | 8 (noslip)
+// capacities of the Adroit FAST kernels (rows, Jacobian-pool words, contacts): the worlds that exceed one are stepped on the large tables of the overflow lane, so these are a
+// throughput choice, not a correctness one -- they decide the LDS footprint, i.e. how many worlds a CU holds, and the step kernels' throughput is nearly proportional to that
+// (profiles/ab_r05_two_worlds_occupancy.txt).  Measured per task (profiles/ab_r05_adroit_capacity.txt, 16 384 worlds, MI355X): hammer 144 / 2 032 / 32 (5 worlds per CU) 1.07 M ->
+// 96 / 1 024 / 24 (7 per CU) 1.31 M env-steps/s; pen 1.81 M -> 112 / 1 280 / 24 (7 per CU) 2.03 M; door and relocate LOSE with smaller tables (their overflow lane -- hands jammed
+// into the door, the ball pressed into the table -- is already what the step waits for: door 1.17 M -> 1.15 M -> 0.87 M) and keep the defaults.  envs/adroit_spec.py ADROIT_CAPACITY must agree.
+#ifndef GRX_ADROIT_ME      // (-DGRX_ADROIT_ME / _JP / _MC: one capacity for all four tasks, the A/B builds)
+#define GRX_ADROIT_HAMMER_CAP 96, 1024, 1, 24
+#define GRX_ADROIT_PEN_CAP 112, 1280, 0, 24
+#define GRX_ADROIT_DOOR_CAP 144, 2032, 0, 32
+#define GRX_ADROIT_RELOCATE_CAP 144, 2032, 0, 32
+#else
+#define GRX_ADROIT_HAMMER_CAP GRX_ADROIT_ME, GRX_ADROIT_JP, 1, GRX_ADROIT_MC
+#define GRX_ADROIT_PEN_CAP GRX_ADROIT_ME, GRX_ADROIT_JP, 0, GRX_ADROIT_MC
+#define GRX_ADROIT_DOOR_CAP GRX_ADROIT_ME, GRX_ADROIT_JP, 0, GRX_ADROIT_MC
+#define GRX_ADROIT_RELOCATE_CAP GRX_ADROIT_ME, GRX_ADROIT_JP, 0, GRX_ADROIT_MC
+#endif
+typedef GrxShape<33, 33, 26, 29, 33, 30, 4, 1, 33, 0, GRX_ADROIT_HAMMER_CAP, 1, 13> GrxShapeAdroitHammer;   // CONVEX bits: 1 (cylinders) | 4 (board shift group) | 8 (noslip)
 // AdroitHandDoor (nv 30: 4 arm + 24 hand + hinge + latch; the door frame is the shift group), AdroitHandPen (nv 30: 24 hand + 6 pen joints; the target
 // cylinder is a ROTATING shift group: bit 16), AdroitHandRelocate (nv 36: 6 arm + 24 hand + 6 ball joints; the ball's body is the shift group, no cylinders)
-typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, 144, 2032, 0, 32, 1, 13> GrxShapeAdroitDoor;
-typedef GrxShape<30, 30, 24, 27, 30, 26, 5, 1, 30, 0, 144, 2032, 0, 32, 1, 29> GrxShapeAdroitPen;
-typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, 144, 2032, 0, 32, 1, 12> GrxShapeAdroitRelocate;
+typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, GRX_ADROIT_DOOR_CAP, 1, 13> GrxShapeAdroitDoor;
+typedef GrxShape<30, 30, 24, 27, 30, 26, 5, 1, 30, 0, GRX_ADROIT_PEN_CAP, 1, 29> GrxShapeAdroitPen;
+typedef GrxShape<36, 36, 30, 28, 36, 25, 1, 1, 36, 0, GRX_ADROIT_RELOCATE_CAP, 1, 12> GrxShapeAdroitRelocate;
 // the door and relocate models with the tables of the overflow lane (core.RERUN_CAPACITY): on the GENERIC large-table kernel one serialised re-run of a contact-rich door world
 // took 5 - 9 ms of a 12 ms step (profiles/lane_probe_r03_door.txt); hammer and pen do not overflow in 100 000 world-steps and keep the generic lane kernel
 typedef GrxShape<30, 30, 28, 29, 30, 32, 2, 1, 30, 0, 256, 4080, 0, 64, 1, 13> GrxShapeAdroitDoorLane;
@@ -582,7 +598,10 @@ grx_adroit_lane_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
 
 // FrankaKitchen-v1 env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world; 40 substeps; nv = 29 (9 robot dofs, 5 joint
 // equalities knob <-> burner / switch <-> light, the free kettle), 124 colliding geoms / 3 736 candidate pairs, condim-6 finger pads, hull pairs
-typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 192, 2240, 0, 32, 1, 3> GrxShapeKitchen;
+#ifndef GRX_KITCHEN_CAP      // rows, pool words, touch zones, contacts of the kitchen's FAST kernel (the overflow lane steps the worlds that exceed them): envs/kitchen_spec.py KITCHEN_CAPACITY must agree
+#define GRX_KITCHEN_CAP 192, 2240, 0, 32
+#endif
+typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, GRX_KITCHEN_CAP, 1, 3> GrxShapeKitchen;
 typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 400, 8160, 0, 64, 1, 3> GrxShapeKitchenLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
 template <class S>
 __device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitchenTask& t, const GrxKitchenBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
@@ -954,6 +973,7 @@ struct grx_model {
   int words = 0;
   int slot = -1;  // index of the device-side descriptor in g_grx_models (constant memory)
   int shape = 0;  // 0 = generic step kernel, else index of the specialised GrxShape
+  int lds_pad = 0;  // GRX_LDS_PAD_BYTES (occupancy experiments)
 };
 
 static thread_local std::string g_err;
@@ -980,7 +1000,10 @@ static int grx_model_create_impl(const int32_t* H, const int32_t* I, const doubl
   m->dev = grx_bind_model(m->pm, m->d_f, m->d_i);
   const GrxModel& g = m->dev;
   m->words = grx_ctx_words(grx_dims_of(&g));
-  int bytes = m->words * 4;
+  // GRX_LDS_PAD_BYTES (occupancy experiments, tools/occupancy_sweep.py): every launch of this model asks for that much dynamic LDS on top of its working set, which lowers the
+  // number of worlds resident per CU without touching the code
+  m->lds_pad = getenv("GRX_LDS_PAD_BYTES") ? atoi(getenv("GRX_LDS_PAD_BYTES")) : 0;
+  int bytes = m->words * 4 + m->lds_pad;
   if (bytes > 160 * 1024) return fail("model working set exceeds the 160 KiB LDS of a CU");
   if (g.njnt > 64) return fail("engine limit: at most 64 joints per world (one lane per joint)");
   if (g.nv > 64) return fail("engine limit: at most 64 dofs per world (dof-chain masks are 64-bit)");
@@ -1061,7 +1084,7 @@ extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, co
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
   if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_fetch_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
-  const int e = grx_tu_fetch_launch(0, m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, 0);
+  const int e = grx_tu_fetch_launch(0, m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, 0);
   if (e) return fail(std::string("grx_fetch_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -1072,7 +1095,7 @@ extern "C" int grx_fetch_forward(const grx_model* m, const grx_fetch_task* task,
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  const int e = grx_tu_fetch_launch(1, m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, nstep);
+  const int e = grx_tu_fetch_launch(1, m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, nstep);
   if (e) return fail(std::string("grx_fetch_forward launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -1087,7 +1110,7 @@ extern "C" int grx_fetch_reset(const grx_model* m, const grx_fetch_task* task, c
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
   GrxFetchResetArgs r; memcpy(&r, args, sizeof(r));
-  const int e = grx_tu_fetch_launch(2, m->shape, (unsigned)n_reset, (size_t)m->words * 4, stream, m->slot, &t, &b, &r, n_reset, m->words, 0);
+  const int e = grx_tu_fetch_launch(2, m->shape, (unsigned)n_reset, (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, &r, n_reset, m->words, 0);
   if (e) return fail(std::string("grx_fetch_reset launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -1100,7 +1123,7 @@ extern "C" int grx_point_step(const grx_model* m, const grx_point_task* task, co
   if (n_worlds <= 0) return 0;
   GrxPointTask t; memcpy(&t, task, sizeof(t));
   GrxPointBuffers b; memcpy(&b, buf, sizeof(b));
-  const int e = grx_tu_point_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words);
+  const int e = grx_tu_point_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words);
   if (e) return fail(std::string("grx_point_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -1121,7 +1144,7 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
     for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
   if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_hand_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
-  const int e = grx_tu_hand_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  const int e = grx_tu_hand_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_hand_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -1145,7 +1168,7 @@ extern "C" int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, 
   if (t.kind == GRX_ADROIT_PEN && !(t.len[0] > 0.0f && t.len[1] > 0.0f)) return fail("grx_adroit_step: pen / target lengths must be positive");
   if (t.kind == GRX_ADROIT_RELOCATE && !buf->target) return fail("grx_adroit_step: the relocate task needs the target buffer");
   if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_adroit_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
-  const int e = grx_tu_adroit_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  const int e = grx_tu_adroit_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_adroit_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -1185,7 +1208,7 @@ extern "C" int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task
     if (!grx_planes_static(m)) return fail("grx_kitchen_step: the skin list needs static plane geoms");
   }
   if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_kitchen_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
-  const int e = grx_tu_kitchen_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  const int e = grx_tu_kitchen_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_kitchen_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -1542,12 +1565,16 @@ grx_fetch_sample_kernel(unsigned long long* __restrict__ states, const int* __re
   const unsigned long long ihi = states[4 * w + 2], ilo = states[4 * w + 3];
   double ox = g0, oy = g1;
   if (has_object) {
-    for (int guard = 0; guard < 65536; guard++) {      // (bounded: a kernel must not spin; the acceptance probability of the reference's ranges is 0.65)
+    int guard = 0;
+    for (; guard < 65536; guard++) {      // (bounded: a kernel must not spin; the acceptance probability of the reference's ranges is 0.65)
       const double dx = __dsub_rn(ox, g0), dy = __dsub_rn(oy, g1);
       if (!(__dsqrt_rn(__dadd_rn(grx_rounded(__dmul_rn(dx, dx)), grx_rounded(__dmul_rn(dy, dy)))) < 0.1)) break;
       ox = __dadd_rn(g0, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -obj_range, obj_range));
       oy = __dadd_rn(g1, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -obj_range, obj_range));
     }
+    // the loop gave up (an obj_range that can never clear the 0.1 m ring: the reference would spin forever): the sample is poisoned, NOT silently accepted -- the world's
+    // state turns NaN and the engine raises its sticky GRX_STATUS_BADNUM bit at the next step
+    if (guard == 65536) ox = oy = __longlong_as_double(0x7FF8000000000000LL);
   }
   double g[3];
   g[0] = __dadd_rn(g0, grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -target_range, target_range));
@@ -1658,12 +1685,14 @@ grx_maze_sample_kernel(unsigned long long* __restrict__ states, const int* __res
     rx = gx; ry = gy;
     const double far = __dmul_rn(0.5, scaling);
     // (bounded: with ONE reset cell that is also the goal cell the reference's loop never ends -- integers(0, 1) draws nothing; a kernel must not spin)
-    for (int guard = 0; guard < 65536; guard++) {
+    int guard = 0;
+    for (; guard < 65536; guard++) {
       const double dx = __dsub_rn(rx, gx), dy = __dsub_rn(ry, gy);
       if (!(__dsqrt_rn(__dadd_rn(grx_rounded(__dmul_rn(dx, dx)), grx_rounded(__dmul_rn(dy, dy)))) <= far)) break;
       const int c = grx_pcg64_integers_dev(hi, lo, ihi, ilo, buf, (unsigned)n_reset);
       rx = reset_xy[2 * c]; ry = reset_xy[2 * c + 1];
     }
+    if (guard == 65536) rx = ry = __longlong_as_double(0x7FF8000000000000LL);   // never silently: a poisoned reset position raises GRX_STATUS_BADNUM (the host refuses the degenerate maze up front, envs/point_maze.py)
   }
   rx = __dadd_rn(rx, grx_rounded(__dmul_rn(grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -noise, noise), scaling)));
   ry = __dadd_rn(ry, grx_rounded(__dmul_rn(grx_pcg64_uniform_dev(hi, lo, ihi, ilo, -noise, noise), scaling)));

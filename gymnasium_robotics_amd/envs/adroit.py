@@ -221,7 +221,7 @@ class AdroitVecEnv(GoalVecEnv):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
             if len(pending):
                 self.mask.fill_(1)
-                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                self.mask.index_fill_(0, self._stage_idx(pending), 0)      # (pinned staging + index_fill_: nothing here waits for the running kernel)
                 self._launch(self._bufs_masked, False)
             else:
                 self._launch(self._bufs, False)

@@ -65,17 +65,26 @@ def apply_actuator_overrides(model):
     return model
 
 
+# capacities of the fast kernels' tables per task (None: the engine defaults, 144 rows / 2 032 pool words / 32 contacts): they set the LDS footprint = the worlds a CU holds; the
+# overflow lane steps the worlds that exceed them, so they are a throughput choice (measured: profiles/ab_r05_adroit_capacity.txt); csrc/grx_kernels.hip GRX_ADROIT_*_CAP must agree
+ADROIT_CAPACITY = {"hammer": dict(maxefc=96, jpool=1024, maxcon=24), "pen": dict(maxefc=112, jpool=1280, maxcon=24), "door": None, "relocate": None}
+
+
 def load_adroit_model(task: str, assets_root: Optional[str] = None, capacity=None):
     from ..mjcf import compile_mjcf, load_model
 
     spec = SPECS[task]
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
-        return apply_actuator_overrides(compile_mjcf(os.path.join(assets_root, "adroit_hand", spec["xml"]), capacity=capacity, **spec["compile"]))
+        return apply_actuator_overrides(compile_mjcf(os.path.join(assets_root, "adroit_hand", spec["xml"]), capacity=capacity or ADROIT_CAPACITY[task], **spec["compile"]))
     path = os.path.join(_MODELS_DIR, spec["npz"])
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist (no packaged model and no assets_root given)")
-    return load_model(path)   # the packaged blob already carries the constructor's actuator rewrite
+    model = load_model(path)   # the packaged blob already carries the constructor's actuator rewrite
+    cap = capacity or ADROIT_CAPACITY[task]
+    if os.environ.get("GRX_ADROIT_CAP"):      # "rows,pool,contacts" (A/B of the fast kernels' tables; needs a library built with the matching -DGRX_ADROIT_ME / _JP / _MC to stay on the specialised kernels)
+        cap = dict(zip(("maxefc", "jpool", "maxcon"), (int(x) for x in os.environ["GRX_ADROIT_CAP"].split(","))))
+    return model.with_capacity(**cap) if cap else model
 
 
 def load_adroit_hammer_model(assets_root: Optional[str] = None, capacity=None):

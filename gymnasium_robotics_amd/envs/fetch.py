@@ -246,17 +246,13 @@ class FetchVecEnv(GoalVecEnv):
 
     @property
     def _rng_state(self):
-        """host copy of the worlds' stream positions (inspection / tests: synchronises)"""
+        """host COPY of the worlds' stream positions (inspection / tests: synchronises); assign the whole [N, 4] uint64 array to upload new positions, or use set_world_rng"""
         return self._rng_dev.cpu().numpy().view(np.uint64)
 
-    def world_rng(self, i):
-        """numpy Generator positioned at world i's current stream position (for inspection / tests)."""
-        bg = np.random.PCG64()
-        st = bg.state
-        a = [int(x) for x in self._rng_state[i]]
-        st["state"] = {"state": (a[0] << 64) | a[1], "inc": (a[2] << 64) | a[3]}
-        bg.state = st
-        return np.random.Generator(bg)
+    @_rng_state.setter
+    def _rng_state(self, value):
+        value = np.ascontiguousarray(value, dtype=np.uint64).reshape(self.num_envs, 4)
+        self._rng_dev.copy_(torch.from_numpy(value.view(np.int64)).to(self.device))
 
     def _stage_reset(self, idx: np.ndarray):
         """The listed worlds' indices go to the device through pinned memory (one asynchronous copy); their PCG64 draws -- the rejection loop of _reset_sim, the goal of
@@ -318,7 +314,7 @@ class FetchVecEnv(GoalVecEnv):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
             if len(pending):
                 self.mask.fill_(1)
-                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                self.mask.index_fill_(0, self._stage_idx(pending), 0)      # (pinned staging + index_fill_: nothing here waits for the running kernel)
                 self._launch_step(self._bufs_masked)
             else:
                 self._launch_step(self._bufs)

@@ -245,7 +245,7 @@ class HandReachVecEnv(GoalVecEnv):
             spec = self._begin_overlapped_reset() if self.autoreset_mode == "same_step" else None
             if len(pending):
                 self.mask.fill_(1)
-                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                self.mask.index_fill_(0, self._stage_idx(pending), 0)      # (pinned staging + index_fill_: nothing here waits for the running kernel)
                 self._launch(self._bufs_masked, False)
             else:
                 self._launch(self._bufs, False)
@@ -260,9 +260,9 @@ class HandReachVecEnv(GoalVecEnv):
             info = {}
             if len(pending):
                 self._reset_worlds(pending)
-                tp = torch.from_numpy(pending).to(self.device)
+                tp = self._stage_idx(pending)
                 self.reward.index_fill_(0, tp, 0.0)
-                self.packed[tp, -2] = 0.0      # the packed row (cross-rank gather, HER) reports the same reward as reward[]
+                self.packed[:, -2].index_fill_(0, tp, 0.0)      # the packed row (cross-rank gather, HER) reports the same reward as reward[]
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
                 td = self._dev_index(done)

@@ -65,7 +65,10 @@ def load_kitchen_model(assets_root: Optional[str] = None, capacity=None):
     path = os.path.join(_MODELS_DIR, "kitchen.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist (no packaged model and no assets_root given)")
-    return load_model(path)
+    cap = dict(capacity or KITCHEN_CAPACITY)
+    if os.environ.get("GRX_KITCHEN_CAP"):      # "rows,pool,contacts": A/B of the fast kernel's tables (needs a library built with the matching -DGRX_KITCHEN_CAP to stay on the specialised kernel)
+        cap = dict(zip(("maxefc", "jpool", "maxcon"), (int(x) for x in os.environ["GRX_KITCHEN_CAP"].split(","))))
+    return load_model(path).with_capacity(**cap)
 
 
 def franka_config(model):

@@ -23,9 +23,12 @@ from .maze_spec import (redraw_goal, ANT_FRAME_SKIP, ANT_MAZE_HEIGHT, ANT_MAZE_S
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
 
 
-# Engine capacities of the ant models: random rollouts peak at 4 contacts / 18 rows / ~200 Jacobian-pool words; 16 / 96 / 1 024 leave a
-# wide margin (the legs can touch at most a few walls and the floor at once) and cut the per-world LDS footprint to 10 worlds per CU.
-ANT_CAPACITY = {"maxcon": 16, "maxefc": 96, "jpool": 1024, "split_spans": False}
+# Engine capacities of the ant models: random rollouts peak at 4 contacts / 18 rows / ~200 Jacobian-pool words, the wall-pushing fixture (tests/golden/ant_Large_teacher.npz)
+# at 3 / 16.  16 contacts / 64 rows / 512 pool words keep a 3.5x margin and make the working set 12 488 B = 10 allocation granules = TWELVE worlds per CU -- what the
+# kernel's 168 VGPRs allow anyway (3 waves per SIMD).  Round 5 measured that the step kernel's throughput is nearly PROPORTIONAL to the resident worlds (a wave's time is set
+# by its dependent chains, not by issue slots: profiles/ab_r05_two_worlds_occupancy.txt -- 8 -> 10 worlds per CU: +15 %), so LDS bytes are the lever; rounds 1 - 4 ran
+# 96 rows / 1 024 words = 15 176 B = 10 worlds per CU.  A world that exceeds a capacity drops the excess contacts for that substep and raises the sticky status bit.
+ANT_CAPACITY = {"maxcon": 16, "maxefc": 64, "jpool": 512, "split_spans": False}
 
 
 def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: Optional[str] = None, agent: str = "point") -> CompiledModel:
@@ -41,7 +44,9 @@ def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: O
     path = os.path.join(_MODELS_DIR, f"{agent}_{layout_name.split('_')[0]}.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")
-    return load_model(path)
+    model = load_model(path)
+    # (the packaged blobs were compiled with round 1's capacity requests: the current ones are applied here, the tables themselves do not depend on them)
+    return model.with_capacity(**{k: ANT_CAPACITY[k] for k in ("maxcon", "maxefc", "jpool")}) if agent == "ant" else model
 
 
 class PointMazeVecEnv(GoalVecEnv):
@@ -103,6 +108,11 @@ class PointMazeVecEnv(GoalVecEnv):
         # (grx_maze_sample_resets_device, bit-equal to numpy).  With reset_target=True the same stream also feeds MazeEnv.update_goal in the middle of an episode -- host
         # logic that reads which worlds reached their goal -- so that mode keeps per-world numpy generators on the host for both.
         self._device_draws = not self.reset_target
+        # a maze whose ONLY reset cell is also its only goal cell: the reference's generate_reset_pos (maze/maze_v4.py:400-418) redraws the reset cell until it is farther than
+        # half a cell from the goal and would never return; refused here, loudly, instead of spinning (host draws) or being cut short (the device loop is bounded)
+        ug, ur = np.asarray(self.maze.unique_goal_locations, dtype=np.float64).reshape(-1, 2), np.asarray(self.maze.unique_reset_locations, dtype=np.float64).reshape(-1, 2)
+        if len(ur) == 1 and len(ug) == 1 and np.linalg.norm(ur[0] - ug[0]) <= 0.5 * self.maze.maze_size_scaling + 2 * 0.25 * self.maze.maze_size_scaling:
+            raise ValueError("this maze has a single reset cell that is also its single goal cell: a reset position farther than half a cell from the goal does not exist")
         if self._device_draws:
             self._goal_xy = torch.from_numpy(np.ascontiguousarray(np.asarray(self.maze.unique_goal_locations, dtype=np.float64).reshape(-1, 2))).to(self.device)
             self._reset_xy = torch.from_numpy(np.ascontiguousarray(np.asarray(self.maze.unique_reset_locations, dtype=np.float64).reshape(-1, 2))).to(self.device)
@@ -132,18 +142,6 @@ class PointMazeVecEnv(GoalVecEnv):
             s = np_random(sd)[0].bit_generator.state
             st[i] = [s["state"]["state"] >> 64, s["state"]["state"] & mask, s["state"]["inc"] >> 64, s["state"]["inc"] & mask, (int(s["has_uint32"]) << 32) | int(s["uinteger"])]
         self._rng_dev = torch.from_numpy(st.view(np.int64)).to(self.device)
-
-    def world_rng(self, i):
-        """numpy Generator positioned at world i's current stream position (inspection / tests: synchronises)"""
-        if not self._device_draws:
-            return self.np_randoms[i]
-        a = [int(x) for x in self._rng_dev[i].cpu().numpy().view(np.uint64)]
-        bg = np.random.PCG64()
-        st = bg.state
-        st["state"] = {"state": (a[0] << 64) | a[1], "inc": (a[2] << 64) | a[3]}
-        st["has_uint32"], st["uinteger"] = int(a[4] >> 32), int(a[4] & 0xFFFFFFFF)
-        bg.state = st
-        return np.random.Generator(bg)
 
     def _sample_on_device(self, idx, options):
         """index list through pinned memory, the draws by one kernel into the staging rows grx_maze_reset_rows reads; nothing waits"""
@@ -227,7 +225,7 @@ class PointMazeVecEnv(GoalVecEnv):
             bufs = self._bufs
             if len(pending):
                 self.mask.fill_(1)
-                self.mask[torch.from_numpy(pending).to(self.device)] = 0
+                self.mask.index_fill_(0, self._stage_idx(pending), 0)      # (pinned staging + index_fill_: nothing here waits for the running kernel)
                 bufs = self._bufs_masked
             ev = self.kernel_events
             if ev is not None:

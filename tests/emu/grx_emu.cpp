@@ -166,6 +166,21 @@ void emu_kitchen_step(void* h, const GrxKitchenTask* t, float* qpos, float* qvel
 
 long emu_mesh_stat(int k) { return g_grx_mesh_stats[k]; }
 long emu_newton_stat(int k) { return g_grx_newton_stats[k]; }
+// support-candidate lists (GrxModel::mesh_cellhdr): evaluations with a table / with a list / list entries seen / near-tie vertices MISSING from a list (must stay 0)
+long emu_cell_stat(int k) { return g_grx_cell_stats[k]; }
+// the hull support function of geom g for n geom-frame directions (dirs[3 n]): the emulator scans the hull and checks the candidate list of every direction's cell against the
+// scan (g_grx_cell_stats); out[k] = the support vertex.  Returns the number of header pairs of the hull (0: the geom has no lists)
+int emu_hull_support(void* h, int g, const float* dirs, int n, int* out) {
+  Emu* e = (Emu*)h; const GrxModel* m = &e->m; typedef GrxEngine<GrxShapeAny> E;
+  if (g < 0 || g >= m->ngeom || m->geom_type[g] != 7) return -1;
+  const int adr = m->geom_hulladr[g], num = m->geom_hullnum[g];
+  const int* cell = (m->mesh_cellhdr && m->geom_cellbase[g] >= 0) ? m->mesh_cellhdr + 2 * (size_t)m->geom_cellbase[g] : nullptr;
+  for (int k = 0; k < n; k++) {
+    E::MF dl[3] = {dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]}, r[3];
+    out[k] = E::grx_mesh_support(m->mesh_vert + 3 * adr, num, dl, r, 0, m->mesh_adjadr + adr, m->mesh_adjnum + adr, m->mesh_adj, -1, nullptr, cell, m->mesh_cellrec);
+  }
+  return cell ? 6 * GRX_CELL_G * GRX_CELL_G : 0;
+}
 
 #ifdef GRX_EMU_STAGEHOOK
 // mixed-precision bisection harness (tools/emu_mixed.py): two builds of this file (fp32 / fp64) run the same forward pass stage by stage

@@ -1,0 +1,103 @@
+"""The support-candidate lists of the hulls (GrxModel::mesh_cellhdr / mesh_cellrec, built at model creation by csrc/grx_host_model.h::grx_build_hull_cells): on the device a
+hull support evaluation reads the <= 64 records of its direction's cube-map cell INSTEAD of scanning the hull, so a list must hold every vertex that wins -- or ties inside the
+scan's 1e-6 m band -- for ANY direction of its cell.  The lane emulator scans the hull and checks the list of every evaluation against the scan (g_grx_cell_stats[3] counts the
+vertices a list lacks).  Checked here on every hull of the Fetch and kitchen models for random directions, the adversarial ones -- normals of vertex triples (faces and chords:
+whole faces tie), their 1e-7 / 1e-5 perturbations, directions ON the cell boundaries and the cube-map face boundaries, the coordinate axes -- and, through the fixtures, every
+support evaluation of the hull-contact rollouts."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emu"))
+sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+G = 16      # GRX_CELL_G
+
+
+def _lib():
+    import emu_sim
+
+    L = ctypes.CDLL(emu_sim.build())
+    L.emu_create.restype = ctypes.c_void_p
+    L.emu_create.argtypes = [ctypes.c_void_p] * 3
+    L.emu_cell_stat.restype = ctypes.c_long
+    L.emu_hull_support.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    return L
+
+
+def _directions(V, rng):
+    n = len(V)
+    d = [rng.normal(size=(4000, 3))]
+    tri = rng.integers(0, n, size=(3000, 3))
+    nrm = np.cross(V[tri[:, 1]] - V[tri[:, 0]], V[tri[:, 2]] - V[tri[:, 0]])
+    nrm = nrm[np.linalg.norm(nrm, axis=1) > 1e-12]
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    for eps in (0.0, 1e-7, 1e-5):
+        d += [nrm + eps * rng.normal(size=nrm.shape), -nrm + eps * rng.normal(size=nrm.shape)]
+    # cell boundaries and face boundaries of the cube map (u or v an exact multiple of 2 / G, |u| = 1), every face, with the last-bit neighbours of the boundary value
+    ticks = np.arange(-G // 2, G // 2 + 1) / (G / 2)
+    for face in range(6):
+        u, v = np.meshgrid(ticks, rng.uniform(-1, 1, 12))
+        for uu in (u, np.nextafter(u.astype(np.float32), np.float32(2)).astype(np.float64), np.nextafter(u.astype(np.float32), np.float32(-2)).astype(np.float64)):
+            for a, b in ((uu, v), (v, uu)):
+                x = np.stack([np.ones_like(a), a, b], axis=-1).reshape(-1, 3)
+                x = np.roll(x, face // 2, axis=1) * (1 if face % 2 == 0 else -1)
+                d.append(x)
+    d.append(np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [1, 1, 0], [1, -1, 0], [1, 1, 1], [-1, 1, -1]], dtype=np.float64))
+    d = np.concatenate(d)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.ascontiguousarray(d, dtype=np.float32)
+
+
+@pytest.mark.parametrize("which", ["fetch", "kitchen"])
+def test_cell_lists_hold_every_vertex_the_scan_could_pick(which):
+    if which == "fetch":
+        from gymnasium_robotics_amd.envs.fetch import load_fetch_model
+        model = load_fetch_model("FetchPickAndPlace")
+    else:
+        from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model
+        model = load_kitchen_model()
+    L = _lib()
+    H, I, F = model.pack()
+    h = L.emu_create(H.ctypes.data, I.ctypes.data, F.ctypes.data)
+    T = model.tables
+    V = T["mesh_vert"].reshape(-1, 3).astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(0)
+    s0 = [L.emu_cell_stat(k) for k in range(4)]
+    hulls = 0
+    for g in range(len(T["geom_hulladr"].ravel())):
+        a, n = int(T["geom_hulladr"].ravel()[g]), int(T["geom_hullnum"].ravel()[g])
+        if n <= 0:
+            continue
+        d = _directions(V[a: a + n], rng)
+        out = np.zeros(len(d), np.int32)
+        rc = L.emu_hull_support(ctypes.c_void_p(h), g, d.ctypes.data, len(d), out.ctypes.data)
+        if rc <= 0:
+            continue      # (no lists: a small hull, or a hull that takes part in no hull-vs-convex candidate pair)
+        hulls += 1
+        # the emulator's winner is the exhaustive scan's: cross-check a sample against numpy in fp64 (ties aside)
+        t = V[a: a + n] @ d[:200].astype(np.float64).T
+        top = t.max(axis=0)
+        assert np.all(top - t[out[:200], np.arange(200)] < 2e-6)
+    s = [L.emu_cell_stat(k) - s0[k] for k in range(4)]
+    assert hulls >= (10 if which == "fetch" else 1), hulls
+    assert s[0] > 10000 and s[1] > 0.9 * s[0], s            # nearly every direction has a list ...
+    assert s[2] / s[1] < 40, s                              # ... of a few dozen records at most on average (the hulls have 200 - 2100 vertices)
+    assert s[3] == 0, f"{s[3]} near-tie vertices are missing from their cell's list"
+
+
+def test_every_support_evaluation_of_the_hull_contact_fixture_is_covered():
+    """the FetchHullContacts rollouts (folded-arm poses: hull pairs in resting contact, the worlds that end a Fetch launch) through the emulator: every support evaluation of every
+    portal search and cached-direction check had its winner and all near-ties in the device's list"""
+    import emu_tolerances as T
+
+    L = _lib()
+    s0 = [L.emu_cell_stat(k) for k in range(4)]
+    idx, e, status, comps = T.run_family(L, "FetchHullContacts", False, 2)
+    s = [L.emu_cell_stat(k) - s0[k] for k in range(4)]
+    assert (status == 0).all()
+    assert s[0] > 1000 and s[1] > 0.8 * s[0], s
+    assert s[3] == 0, s

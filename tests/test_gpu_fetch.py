@@ -120,6 +120,37 @@ def test_hull_caches_do_not_change_the_rollout(monkeypatch):
     assert int(used.sum()) > 20      # the guesses were really in play: worlds with a persistent hull contact wrote their rows
 
 
+def test_hull_candidate_lists_do_not_change_the_rollout(monkeypatch):
+    """The support-candidate lists of the hulls (GrxModel::mesh_cellhdr: a support evaluation reads the <= 64 records of its direction's cube-map cell instead of scanning the
+    hull) hold, for every direction, every vertex the scan could pick or tie with (tests/test_cpu_hull_cells.py): free-running from the 168 folded-arm poses of the hull
+    fixture, the rollout of a model created WITH the lists is bit-identical to the rollout of one created without them (GRX_NO_HULLCELLS: every evaluation whose guess fails
+    scans the hull), with and without the per-world guesses."""
+    import torch
+
+    g = np.load(os.path.join(GOLDEN, "fetch_hull_teacher.npz"))
+    n = g["obs"].shape[0]
+    envs = []
+    for cells_off, cache_off in ((False, False), (True, False), (False, True), (True, True)):
+        for var, off in (("GRX_NO_HULLCELLS", cells_off), ("GRX_NO_HULLCACHE", cache_off)):
+            if off:
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
+        e = _env("FetchPickAndPlace", n, autoreset_mode="disabled", max_episode_steps=None, output="torch")
+        e.reset(seed=0)
+        _load_state(e, g, slice(None))
+        envs.append(e)
+    assert len({e._h.value for e in envs[:2]}) == 2      # two native models: one with the lists, one without
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(3)
+    a0 = torch.from_numpy(g["action"].astype(np.float32)).cuda()
+    for t in range(30):
+        a = a0 if t < 10 else (a0 * 0.2 + 0.3 * (torch.rand(n, 4, device="cuda:0", generator=gen) * 2 - 1))
+        for e in envs:
+            e.step(a)
+        for e in envs[1:]:
+            assert torch.equal(envs[0].qpos, e.qpos) and torch.equal(envs[0].qvel, e.qvel) and torch.equal(envs[0].obs, e.obs), t
+
+
 def test_compacted_reset_kernel_matches_masked_forward():
     """grx_fetch_reset (compacted list, initial rows + host draws applied on the device) gives the rows the old path produced:
     initial state written by the host + masked grx_fetch_forward."""
