@@ -599,7 +599,7 @@ grx_adroit_lane_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
 // FrankaKitchen-v1 env.step() (or, forward_only, the reset-time mj_forward + observation): one wavefront per world; 40 substeps; nv = 29 (9 robot dofs, 5 joint
 // equalities knob <-> burner / switch <-> light, the free kettle), 124 colliding geoms / 3 736 candidate pairs, condim-6 finger pads, hull pairs
 #ifndef GRX_KITCHEN_CAP      // rows, pool words, touch zones, contacts of the kitchen's FAST kernel (the overflow lane steps the worlds that exceed them): envs/kitchen_spec.py KITCHEN_CAPACITY must agree
-#define GRX_KITCHEN_CAP 192, 2240, 0, 32
+#define GRX_KITCHEN_CAP 128, 1280, 0, 24   // 26.1 KB = 6 worlds per CU (rounds 2 - 4: 192 / 2 240 / 32 = 31.9 KB = 5): +5.7 % with the lane taking more worlds (profiles/ab_r05_kitchen_capacity.txt)
 #endif
 typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, GRX_KITCHEN_CAP, 1, 3> GrxShapeKitchen;
 typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 400, 8160, 0, 64, 1, 3> GrxShapeKitchenLane;   // overflow-lane tables (see GrxShapeFetchPickLane)

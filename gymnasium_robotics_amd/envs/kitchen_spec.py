@@ -36,9 +36,12 @@ INIT_QPOS = np.array([
     -2.66279850e-04, -5.18043486e-05, 3.12877220e-05, -4.51199853e-05, -3.90842156e-06, -4.22629655e-05, 6.28065475e-05, 4.04984708e-05, 4.62730939e-04,
     -2.26906415e-04, -4.65501369e-04, -6.44129196e-03, -1.77048263e-03, 1.08009684e-03, -2.69397440e-01, 3.50383255e-01, 1.61944683e00, 1.00618764e00,
     4.06395120e-03, -6.62095997e-03, -2.68278933e-04])
-# no engine sites (the task reads qpos only).  Capacities: a finger pad pressed flat on a box is a box-box pair with up to 8 contacts of 10 pyramid rows
-# (condim 6) each, so the row table gets 192 rows and the Jacobian pool 2 240 words: 31.9 KB of LDS = 25 granules = 5 worlds per CU
-KITCHEN_CAPACITY = {"maxcon": 32, "maxefc": 192, "jpool": 2240}
+# no engine sites (the task reads qpos only).  Capacities of the FAST kernel: a finger pad pressed flat on a box is a box-box pair with up to 8 contacts of 10 pyramid rows
+# (condim 6) each; rounds 2 - 4 gave the fast kernel 192 rows / 2 240 pool words / 32 contacts = 31.9 KB of LDS = 5 worlds per CU.  The step kernel's throughput is nearly
+# proportional to the worlds a CU holds (profiles/ab_r05_two_worlds_occupancy.txt) and the overflow lane (400 / 8 160 / 64 tables) steps whatever exceeds the fast tables, so the
+# fast tables are a throughput choice: 128 / 1 280 / 24 = 26.1 KB = 6 worlds per CU measures +5.7 % (fast launch 47.6 -> 41.7 ms, the lane's launches then end the step at 45.2 ms:
+# profiles/ab_r05_kitchen_capacity.txt).  csrc/grx_kernels.hip GRX_KITCHEN_CAP must agree.
+KITCHEN_CAPACITY = {"maxcon": 24, "maxefc": 128, "jpool": 1280}
 KITCHEN_COMPILE = dict(keep_sites=[])
 
 

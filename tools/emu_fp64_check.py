@@ -45,11 +45,13 @@ def _fixture(task):
         return m, as_fp64_struct(_native.PointTaskStruct(5, 1, 1, 1, 0.45, 5.0)), np.load(os.path.join(G, "ant_Large_teacher.npz")), "point"
     if task == "kitchen":
         from gymnasium_robotics_amd.envs.kitchen_spec import load_kitchen_model, make_kitchen_task
-        m = load_kitchen_model()
+        from gymnasium_robotics_amd.core import KITCHEN_RERUN_CAPACITY
+        m = load_kitchen_model().with_capacity(**KITCHEN_RERUN_CAPACITY)      # the emulator has no overflow lane: it runs the engine on the LANE's tables (the fast kernel's are a throughput choice)
         return m, as_fp64_struct(make_kitchen_task(m, 0.01, 0.0005)), np.load(os.path.join(G, "kitchen_teacher.npz")), "kitchen"
     if task in ("hammer", "door", "pen", "relocate"):
         from gymnasium_robotics_amd.envs.adroit_spec import load_adroit_model, make_adroit_task
-        m = load_adroit_model(task)
+        from gymnasium_robotics_amd.core import RERUN_CAPACITY
+        m = load_adroit_model(task).with_capacity(**RERUN_CAPACITY)      # (as for the kitchen: the lane's tables)
         return m, as_fp64_struct(make_adroit_task(m, "dense", task)), np.load(os.path.join(G, f"adroit_{task}_teacher.npz")), "adroit"
     if task.startswith("Fetch") or task == "hull":
         from gymnasium_robotics_amd.envs.fetch import load_fetch_model
