@@ -125,7 +125,7 @@ def sq_mix(tag, workload=None):
     w = WORKLOADS[workload or "fetch"]
     kernel = w["kernel"]
     suffix = f"_{workload}" if workload else ""
-    extra = ["--workload", workload] if workload else []
+    extra = (["--workload", workload] if workload else []) + os.environ.get("GRX_COLLECT_EXTRA", "").split()
     d = os.path.join(OUT, f"pmc_{tag}_SQ{suffix}")
     cmd = ["rocprofv3", "--pmc"] + SQ_COUNTERS + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
            os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"] + extra
