@@ -327,7 +327,7 @@ class OverflowLane:
     become current.  The size of a list is bounded by the grid of the launch that will walk it (grx_overflow_lane.next_cap / entry_cap), which the host fixes one
     step ahead from the newest counters that have reached it."""
 
-    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane", lane_first=False, margin=LANE_MARGIN):
+    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane", lane_first=False, margin=LANE_MARGIN, poll_grid=LANE_POLL_GRID):
         """mode "lane": worlds near a capacity move to a standing lane that runs next to the fast launch (families whose contact-rich states persist: hand + object,
         kitchen, Adroit door / relocate: a few worlds per step and thousand).  mode "entry": no standing lane, an overflowing world is re-run right behind the fast
         launch -- for families where an overflow is a rare event (Fetch: 2 worlds in 100 steps of 4096), whose step is too short to hide the two cross-stream waits
@@ -363,7 +363,7 @@ class OverflowLane:
         self._pin_next, self._seen, self._age = 0, 0, 0
         self.cap_cur = 64
         # polling workgroups of the standing launch (grx_overflow_lane.ready / progress / poll_*): an entrant is re-run while the fast launch is still running instead of behind it
-        self.poll_grid = int(os.environ.get("GRX_LANE_POLL", LANE_POLL_GRID)) if self.mode == "lane" else 0
+        self.poll_grid = int(os.environ.get("GRX_LANE_POLL", poll_grid)) if self.mode == "lane" else 0      # per family: the kitchen, whose fast tables are small by choice, runs 32 (profiles/ab_r05_kitchen_lane_params.txt)
         self._poll = torch.zeros(self.poll_grid + 1, dtype=torch.int32, device=device) if self.poll_grid > 0 else None      # ready[poll_grid], progress
         self._fast_grid = (n + 7) & ~7      # workgroups of a fast launch (csrc/grx_kernels.hip, grx_grid_for)
 
