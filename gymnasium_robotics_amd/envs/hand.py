@@ -336,7 +336,7 @@ class HandReachVecEnv(GoalVecEnv):
         import copy
 
         chains = [dict(worlds=np.asarray(c["worlds"]).copy(), lo=int(c["lo"]), k=int(c["k"]), due_at=int(c["due_at"]), ok=None if c["ok"] is None else np.asarray(c["ok"]).copy(),
-                       rng_states=copy.deepcopy(c.get("rng_states", []))) for c in (getattr(self, "_chains", None) or ())]
+                       rng_states=copy.deepcopy(c.get("rng_states", [])), obj=c["obj_host"][: c["k"]].numpy().copy()) for c in (getattr(self, "_chains", None) or ())]
         return {"chains": chains, "arena": getattr(self, "_ar", None) is not None}
 
     def _ckpt_extra_set(self, extra):
@@ -350,8 +350,10 @@ class HandReachVecEnv(GoalVecEnv):
         for c in extra["chains"]:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))      # (set_state synchronises before it returns: the arena rows restored behind this are in place when the event is consulted)
+            buf = self._chain_obj[c["due_at"] % len(self._chain_obj)]
+            buf[: c["k"]] = torch.from_numpy(c["obj"])
             chains.append(dict(worlds=c["worlds"].copy(), ti=self._dev_index(c["worlds"]), lo=c["lo"], k=c["k"], due_at=c["due_at"], ready=ev, event=ev, ok=None if c["ok"] is None else c["ok"].copy(),
-                               rng_states=c["rng_states"]))
+                               rng_states=c["rng_states"], obj_host=buf))
         self._chains = chains
 
     def close(self):
@@ -400,6 +402,8 @@ class HandBlockVecEnv(HandReachVecEnv):
     Observation 61 = 24 robot joint positions | 24 velocities | object velocity 6 | object pose 7; goals are 7-vector poses.
     The visual-only, non-colliding `target` body of the MJCF is not simulated (its state is not observable through the env API)."""
     LANE_MODE = "lane"
+    chain_events = None      # set to [] to collect (step started, step due, worlds, start event, end event) of every settle chain
+    CHAIN_LOOKAHEAD = int(os.environ.get("GRX_CHAIN_LOOKAHEAD", 2))      # steps before the time limit at which a world's settle chain is started (same-step autoreset); 3 measured no faster (below)
 
     GOAL_DIM = 7
 
@@ -512,7 +516,8 @@ class HandBlockVecEnv(HandReachVecEnv):
             ar.update(reward=z(n), success=z(n, dtype=torch.uint8), status=z(n, dtype=torch.int32))
             self._ar, self._ar_head, self._chains, self._step_no = ar, 0, [], 0
             self._chain_started = np.zeros(self.num_envs, bool)
-            self._side = [torch.cuda.Stream(device=d, priority=-1) for _ in range(2)]   # priority makes no measurable difference (A/B: 17.96 vs 18.07 ms per step)
+            self._chain_obj = [torch.empty(self.num_envs, 7, dtype=torch.float32, pin_memory=True) for _ in range(self.CHAIN_LOOKAHEAD + 2)]      # settled object poses of the chains in flight (one buffer per due step)
+            self._side = [torch.cuda.Stream(device=d, priority=-1) for _ in range(3)]   # one per chain generation in flight; priority makes no measurable difference (A/B: 17.96 vs 18.07 ms per step)
         return self._ar
 
     def _arena_bufs(self, lo):
@@ -553,32 +558,40 @@ class HandBlockVecEnv(HandReachVecEnv):
                                                self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"])
         q = self._initial_qpos_host.unsqueeze(0).repeat(k, 1)
         q[:, self._qa: self._qa + 7] = torch.from_numpy(poses.astype(np.float32))
-        side = self._side[c["due_at"] & 1]
+        side = self._side[c["due_at"] % 3]
         with torch.cuda.stream(side):
             side.wait_event(c["ready"])
+            if self.chain_events is not None:      # (diagnostics: device time of a settle chain, tools/host_profile_hand.py)
+                e0 = torch.cuda.Event(enable_timing=True); e0.record(side)
             _, tq = self._chain_stage(np.arange(k), q.numpy())      # pinned staging: enqueued on the side stream, never waited for
             ar["qpos"][lo: lo + k] = tq[:, : self.nq]
             ar["qvel"][lo: lo + k].zero_()
             bufs, sp = self._arena_bufs(lo), ctypes.c_void_p(side.cuda_stream)
             for _ in range(SETTLE_STEPS):   # the arena's action rows stay zero: _set_action(np.zeros(20)) (manipulate.py:206-216)
                 _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), k, 0, sp))
-            c["event"] = torch.cuda.Event()
+            # the settled object poses travel to a pinned host buffer behind the last settle launch: when the goals are drawn they are already there (round 4 read them with a
+            # blocking .cpu() at that point: a one-block kernel and a copy that had to find a slot on a GPU saturated by the step kernel)
+            c["obj_host"] = self._chain_obj[c["due_at"] % len(self._chain_obj)]
+            c["obj_host"][:k].copy_(ar["qpos"][lo: lo + k, self._qa: self._qa + 7], non_blocking=True)
+            c["event"] = torch.cuda.Event(enable_timing=self.chain_events is not None)
             c["event"].record(side)
+            if self.chain_events is not None:
+                self.chain_events.append((self._step_no, c["due_at"], k, e0, c["event"]))
 
     def _early_goals(self, c):
         """a chain that is committed at the end of THIS step: wait for it (it has had a whole step), read the settled object poses through the side stream,
         draw the goals of the worlds whose object stayed on the palm and park them in the arena -- all while the step kernel runs"""
         from .manipulate_spec import PALM_HEIGHT, sample_block_goal_batch
 
-        lo, k, ar, side = c["lo"], c["k"], self._ar, self._side[c["due_at"] & 1]
+        lo, k, ar, side = c["lo"], c["k"], self._ar, self._side[c["due_at"] % 3]
         with torch.cuda.stream(side):
-            c["event"].synchronize()
-            obj = ar["qpos"][lo: lo + k, self._qa: self._qa + 7].double().cpu().numpy()
+            c["event"].synchronize()      # (started CHAIN_LOOKAHEAD steps ago: normally long done)
+            obj = c["obj_host"][:k].numpy().astype(np.float64)      # the fp32 rows the kernel wrote, widened on the host (what .double() did on the device)
             ok = obj[:, 2] > PALM_HEIGHT
             if ok.any():
                 goals = sample_block_goal_batch([self.np_randoms[w] for w in c["worlds"][ok]], obj[ok], self.target_position, self.target_rotation, self._pquats)
-                rows = torch.from_numpy(np.nonzero(ok)[0] + lo).to(self.device)
-                ar["goal"][rows] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
+                rows, tg = self._chain_stage(np.nonzero(ok)[0] + lo, goals.astype(np.float32))      # pinned staging: enqueued, never waited for
+                ar["goal"][rows] = tg[:, : ar["goal"].shape[1]]
             c["ok"] = ok
             c["event"] = torch.cuda.Event()
             c["event"].record(side)
@@ -591,9 +604,14 @@ class HandBlockVecEnv(HandReachVecEnv):
         rem = self.max_episode_steps - self._elapsed            # steps left before this one
         fresh = ~self._needs_reset & ~self._chain_started
         new = []
-        for worlds, due_at in ((np.nonzero(fresh & (rem <= 1))[0], self._step_no), (np.nonzero(fresh & (rem == 2))[0], self._step_no + 1)):
+        # a chain is started CHAIN_LOOKAHEAD steps before its worlds hit the limit (start-up: as late as it must).  Round 5 measured the chains (tools/host_profile_hand.py): ten
+        # dependent settle launches beside a 16.7 ms step kernel take 19 - 33 ms of device time, i.e. a chain started in step s is done before the kernel of step s + 2 starts.
+        # The host's wait for it (13 ms per step inside Event.synchronize) is BACK-PRESSURE -- the host runs one step ahead of the device and needs the settled poses to draw
+        # the goals -- not device idle time: a lookahead of 3 (one more step of slack, a staler warm start) measured 0.907 M against 0.918 M env-steps/s for 2.
+        for k in range(1, self.CHAIN_LOOKAHEAD + 1):
+            worlds = np.nonzero(fresh & ((rem <= 1) if k == 1 else (rem == k)))[0]
             if len(worlds):
-                c = self._reserve_chain(worlds, due_at)
+                c = self._reserve_chain(worlds, self._step_no + k - 1)
                 if c is not None:
                     new.append(c)
         return self._step_no, new
