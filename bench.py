@@ -442,6 +442,9 @@ def run_rank(args, rank, world_size, local_rank):
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_ratio": (traffic / (w["algo"] * n)) if traffic else None,      # PMC bytes / algorithmic bytes per launch: scratch + model-table re-reads
                          "valu": valu, "kernel": w["kernel"], "kernel_ms": kern_ms,
                          "kernel_plus_overflow_lane_ms": lane_ms,      # families with an overflow lane: fast launch + the lane's concurrent and serialised launches (`achieved` is the fast launch's)
+                         # Fetch: the few worlds per 100 steps that exceed the fast tables are re-run behind the launch, 1 - 3 ms ONCE each: a 20-step window holds 0 - 3 of them, so
+                         # short runs scatter by +-4 % around the long-run mean
+                         "overflow_rerun_ms_per_step": (lane_ms - kern_ms) if lane_ms is not None else None,
                          "algorithmic_bytes_per_launch": w["algo"] * n,
                          "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 6"},
         }

@@ -516,11 +516,16 @@ grx_hand_lane_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, i
 // capacities of the Adroit FAST kernels (rows, Jacobian-pool words, contacts): the worlds that exceed one are stepped on the large tables of the overflow lane, so these are a
 // throughput choice, not a correctness one -- they decide the LDS footprint, i.e. how many worlds a CU holds, and the step kernels' throughput is nearly proportional to that
 // (profiles/ab_r05_two_worlds_occupancy.txt).  Measured per task (profiles/ab_r05_adroit_capacity.txt, 16 384 worlds, MI355X): hammer 144 / 2 032 / 32 (5 worlds per CU) 1.07 M ->
-// 96 / 1 024 / 24 (7 per CU) 1.31 M env-steps/s; pen 1.81 M -> 112 / 1 280 / 24 (7 per CU) 2.03 M; door and relocate LOSE with smaller tables (their overflow lane -- hands jammed
+// 96 / 1 024 / 24 (7 per CU) 1.31 - 1.34 M env-steps/s (8 per CU: the lane's launches end the step, 1.03 - 1.13 M); pen 1.81 M -> 112 / 1 280 / 24 (7 per CU) 2.03 M -> 80 / 896 / 24 (8 per CU) 2.22 M
+// (profiles/ab_r05_adroit_capacity2.txt); door and relocate LOSE with smaller tables (their overflow lane -- hands jammed
 // into the door, the ball pressed into the table -- is already what the step waits for: door 1.17 M -> 1.15 M -> 0.87 M) and keep the defaults.  envs/adroit_spec.py ADROIT_CAPACITY must agree.
-#ifndef GRX_ADROIT_ME      // (-DGRX_ADROIT_ME / _JP / _MC: one capacity for all four tasks, the A/B builds)
+#ifndef GRX_ADROIT_ME      // (-DGRX_ADROIT_ME / _JP / _MC: one capacity for all four tasks; -DGRX_ADROIT_<TASK>_CAP=rows,pool,touch,contacts: one task -- the A/B builds)
+#ifndef GRX_ADROIT_HAMMER_CAP
 #define GRX_ADROIT_HAMMER_CAP 96, 1024, 1, 24
-#define GRX_ADROIT_PEN_CAP 112, 1280, 0, 24
+#endif
+#ifndef GRX_ADROIT_PEN_CAP
+#define GRX_ADROIT_PEN_CAP 80, 896, 0, 24
+#endif
 #define GRX_ADROIT_DOOR_CAP 144, 2032, 0, 32
 #define GRX_ADROIT_RELOCATE_CAP 144, 2032, 0, 32
 #else

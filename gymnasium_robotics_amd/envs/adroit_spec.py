@@ -66,8 +66,8 @@ def apply_actuator_overrides(model):
 
 
 # capacities of the fast kernels' tables per task (None: the engine defaults, 144 rows / 2 032 pool words / 32 contacts): they set the LDS footprint = the worlds a CU holds; the
-# overflow lane steps the worlds that exceed them, so they are a throughput choice (measured: profiles/ab_r05_adroit_capacity.txt); csrc/grx_kernels.hip GRX_ADROIT_*_CAP must agree
-ADROIT_CAPACITY = {"hammer": dict(maxefc=96, jpool=1024, maxcon=24), "pen": dict(maxefc=112, jpool=1280, maxcon=24), "door": None, "relocate": None}
+# overflow lane steps the worlds that exceed them, so they are a throughput choice (measured: profiles/ab_r05_adroit_capacity.txt, ab_r05_adroit_capacity2.txt); csrc/grx_kernels.hip GRX_ADROIT_*_CAP must agree
+ADROIT_CAPACITY = {"hammer": dict(maxefc=96, jpool=1024, maxcon=24), "pen": dict(maxefc=80, jpool=896, maxcon=24), "door": None, "relocate": None}
 
 
 def load_adroit_model(task: str, assets_root: Optional[str] = None, capacity=None):

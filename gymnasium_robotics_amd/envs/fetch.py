@@ -127,6 +127,7 @@ class FetchVecEnv(GoalVecEnv):
         self._needs_reset = np.zeros(self.num_envs, bool)
         self._has_reset = False
         self.kernel_events = None  # set to [] to collect (start, end) torch.cuda.Event pairs around every step-kernel launch
+        self.step_events = None    # ... and [] to collect the pairs around the whole launch group of a step (fast launch + the serialised re-run of the worlds that overflowed its tables)
 
     def _launch_step(self, bufs):
         def fast(b):
@@ -143,7 +144,14 @@ class FetchVecEnv(GoalVecEnv):
             fast(bufs)
         else:
             large = lambda b: _native.check(self._L.grx_fetch_step(self._h_big, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, self._stream()))
+            timed = self.kernel_events is not None and self.step_events is not None      # the fast launch AND the re-run of the worlds that overflowed its tables (behind it, same stream)
+            if timed:
+                l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                l0.record()
             self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs)
+            if timed:
+                l1.record()
+                self.step_events.append((l0, l1))
         if self.balance:
             self._rebalance()
 
