@@ -71,6 +71,11 @@ class PointMazeVecEnv(GoalVecEnv):
             raise RuntimeError("PointMazeVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
         self.device = torch.device(device or "cuda:0")
         self.maze = Maze(maze_map, *self.MAZE_GEOMETRY)
+        # a maze whose ONLY reset cell is also its only goal cell: the reference's generate_reset_pos (maze/maze_v4.py:400-418) redraws the reset cell until it is farther than
+        # half a cell from the goal and would never return; refused here, loudly, instead of spinning (host draws) or being cut short (the device loop is bounded)
+        ug, ur = np.asarray(self.maze.unique_goal_locations, dtype=np.float64).reshape(-1, 2), np.asarray(self.maze.unique_reset_locations, dtype=np.float64).reshape(-1, 2)
+        if len(ur) == 1 and len(ug) == 1 and np.linalg.norm(ur[0] - ug[0]) <= 0.5 * self.maze.maze_size_scaling + 2 * 0.25 * self.maze.maze_size_scaling:
+            raise ValueError("this maze has a single reset cell that is also its single goal cell: a reset position farther than half a cell from the goal does not exist")
         self.model = model or load_point_maze_model(self.maze, layout, assets_root, self.AGENT)
         self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
         self._L = _native.lib()
@@ -108,11 +113,6 @@ class PointMazeVecEnv(GoalVecEnv):
         # (grx_maze_sample_resets_device, bit-equal to numpy).  With reset_target=True the same stream also feeds MazeEnv.update_goal in the middle of an episode -- host
         # logic that reads which worlds reached their goal -- so that mode keeps per-world numpy generators on the host for both.
         self._device_draws = not self.reset_target
-        # a maze whose ONLY reset cell is also its only goal cell: the reference's generate_reset_pos (maze/maze_v4.py:400-418) redraws the reset cell until it is farther than
-        # half a cell from the goal and would never return; refused here, loudly, instead of spinning (host draws) or being cut short (the device loop is bounded)
-        ug, ur = np.asarray(self.maze.unique_goal_locations, dtype=np.float64).reshape(-1, 2), np.asarray(self.maze.unique_reset_locations, dtype=np.float64).reshape(-1, 2)
-        if len(ur) == 1 and len(ug) == 1 and np.linalg.norm(ur[0] - ug[0]) <= 0.5 * self.maze.maze_size_scaling + 2 * 0.25 * self.maze.maze_size_scaling:
-            raise ValueError("this maze has a single reset cell that is also its single goal cell: a reset position farther than half a cell from the goal does not exist")
         if self._device_draws:
             self._goal_xy = torch.from_numpy(np.ascontiguousarray(np.asarray(self.maze.unique_goal_locations, dtype=np.float64).reshape(-1, 2))).to(self.device)
             self._reset_xy = torch.from_numpy(np.ascontiguousarray(np.asarray(self.maze.unique_reset_locations, dtype=np.float64).reshape(-1, 2))).to(self.device)

@@ -305,3 +305,44 @@ def test_many_environments_of_one_id_share_two_model_slots():
     e.reset(seed=5)
     assert np.array_equal(e.step(a)[0]["observation"], ref)
     e.close()
+
+
+def test_world_rng_round_trip_on_device_streams():
+    """the families whose reset draws live on the device expose world_rng(i) / set_world_rng(i, g): positioning a world's stream from the host changes exactly that
+    world's next reset, and _rng_state assignment (FetchVecEnv) uploads instead of being dropped."""
+    import gymnasium_robotics_amd as grx
+
+    for env_id in ("FetchPush-v4", "PointMaze_UMaze-v3", "AdroitHandHammer-v2"):
+        a = grx.make_vec(env_id, num_envs=6, device="cuda:0", output="numpy")
+        b = grx.make_vec(env_id, num_envs=6, device="cuda:0", output="numpy")
+        a.reset(seed=3); b.reset(seed=40)
+        for i in range(6):
+            b.set_world_rng(i, a.world_rng(i))
+            assert b.world_rng(i).bit_generator.state == a.world_rng(i).bit_generator.state
+        oa, _ = a.reset(); ob, _ = b.reset()
+        _assert_equal(oa, ob)
+        a.close(); b.close()
+    f = grx.make_vec("FetchPush-v4", num_envs=4, device="cuda:0")
+    f.reset(seed=1)
+    st = f._rng_state.copy()
+    st[2] = st[0]
+    f._rng_state = st
+    assert np.array_equal(f._rng_state, st)
+    f.close()
+
+
+def test_degenerate_maze_is_refused_and_an_exhausted_rejection_loop_is_flagged():
+    """a device rejection loop must never hand back a sample that violates the reference's condition.  (i) A maze whose single reset cell is its single goal cell is
+    refused by the constructor (the reference's generate_reset_pos would spin, maze_v4.py:400-418).  (ii) Fetch with an object range that can never leave the 0.1 m ring around the
+    gripper: the loop gives up after 65 536 draws, the sample is NaN, the next step flags the world (sticky GRX_STATUS_BADNUM) instead of stepping a silently wrong state."""
+    import gymnasium_robotics_amd as grx
+    from gymnasium_robotics_amd.envs.point_maze import PointMazeVecEnv
+
+    with pytest.raises(ValueError, match="single reset cell"):
+        PointMazeVecEnv("PointMaze_UMaze-v3", num_envs=2, device="cuda:0", maze_map=[[1, 1, 1], [1, "c", 1], [1, 1, 1]])
+    env = grx.make_vec("FetchPush-v4", num_envs=4, device="cuda:0", output="numpy")
+    env.cfg = dict(env.cfg, obj_range=0.01)
+    env.reset(seed=0)
+    out = env.step(np.zeros((4, 4), np.float32))
+    assert (out[4]["status_sticky"] & 1).all()
+    env.close()
