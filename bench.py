@@ -7,6 +7,14 @@ autoresets (4096 / 50 = 82 worlds per step: host draws + the reset kernel), not 
 Weak scaling: the same number of worlds on every GPU; worlds are tile-sharded over the ranks and the only collective is
 ONE RCCL all-gather per step of the packed output rows the step kernel itself wrote.
 
+Before anything is timed the workload is PRE-ROLLED by one full episode horizon of whole steps (--preroll, HER included): a fresh batch is 3 - 8 % faster than the
+stationary regime (fewer arm-on-head stragglers, an empty HER ring, fewer worlds in the overflow lanes), and the driver's `--steps 20 --warmup 5` must report the
+stationary number.  What still scatters short Fetch windows by +-4 %: the 2 - 5 worlds per 100 steps that exceed the fast kernel's tables and are re-run behind the launch,
+1 - 3 ms once each (`roofline.overflow_rerun_ms_per_step`).
+`roofline` carries the HBM fraction SURVEY.md 8(d) asks for (tiny by construction: the fused step does ~2e3 FLOP per HBM byte) AND the bound that binds: `roofline.valu` =
+wave64 VALU instructions per second against the chip's issue peak (SQ_INSTS_VALU from the SQ pass of tools/collect_profiles.py / the live kernel time), `traffic_ratio` =
+PMC bytes / algorithmic bytes.
+
 One "step" = one env.step() of all worlds = ONE launch of the family's step kernel (+ the HER reward kernel for cfg 2).
 --workload selects the other BASELINE configs under the same contract and the same JSON schema:
     fetch       cfg 2  FetchPickAndPlace-v4, 4096 worlds / GPU
