@@ -195,12 +195,15 @@ template <class S> static bool grx_shape_matches(const GrxModel& g) {
 // collidable mesh geoms next to boxes / other meshes: all Fetch and Shadow-hand models)
 #ifndef GRX_FETCH_ME       // row / Jacobian-pool capacities the Fetch kernels are specialised for (envs/fetch.py FETCH_CAPACITY)
 #define GRX_FETCH_ME 144
-#define GRX_FETCH_JP 1984
+#define GRX_FETCH_JP 2032     // round 5: 1 984 -> 2 032 words paid for by 32 -> 28 contacts (observed maximum 26): the same 16 LDS granules, half as many worlds exceed the fast tables (profiles/demand_r05_fetch.txt)
 #endif
-typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 2> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
-typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
-typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, 32, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
+#ifndef GRX_FETCH_MC
+#define GRX_FETCH_MC 28
+#endif
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, 2> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
+typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
+typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)
 // the SAME models with the tables of the overflow lane (core.RERUN_CAPACITY): only the lane kernels are instantiated for them (BASELINE configs 2 / 3 / 5a; the other
 // models' lanes run on the generic kernel, 2-3 x slower per world)
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 256, 4080, 0, 64, 0, 2> GrxShapeFetchPickLane;

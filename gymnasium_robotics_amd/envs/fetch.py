@@ -29,11 +29,14 @@ from .fetch_spec import DISTANCE_THRESHOLD, FETCH_TASKS, MAX_EPISODE_STEPS, N_SU
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "models")
 
 
-# Engine capacities of the Fetch models: 32 contacts / 144 rows / 1 984 Jacobian-pool words = 20.4 KB of LDS per world = 16 allocation
+# Engine capacities of the Fetch models: 28 contacts / 144 rows / 2 032 Jacobian-pool words (rounds 2 - 4: 32 / 144 / 1 984) = 20.4 KB of LDS per world = 16 allocation
 # granules = 8 worlds per CU, which is also what the register budget of the step kernels allows (2 waves per SIMD: the hull-vs-convex
 # routine needs more than the 168 VGPRs of a 3-wave build).  Round 1 ran 112 rows / 1 520 words for 9 worlds per CU and dropped contacts
 # in 0.035 % of the world-steps; at these capacities the measured rate is 0.004 % (GRX_STATUS_EFC_OVERFLOW, sticky in `status`).
-FETCH_CAPACITY = {"maxcon": 32, "maxefc": 144, "jpool": 1984, "split_spans": False}   # the arm chain is (nearly) contiguous: single-span rows
+# Round 5 (profiles/demand_r05_fetch.txt: per world and step maxima over 400 steps of the bench rollout): the worlds that exceed these tables -- and are re-run behind the launch on
+# the large ones, 1 - 3 ms once each -- exceed the POOL by a few dozen words (2 005 .. 2 054 of 1 984) while the contact list peaks at 26 of 32: 28 contacts / 2 032 words fit the
+# same 16 granules (20 424 B) and halve the re-runs.
+FETCH_CAPACITY = {"maxcon": 28, "maxefc": 144, "jpool": 2032, "split_spans": False}   # the arm chain is (nearly) contiguous: single-span rows
 
 
 def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledModel:
@@ -46,7 +49,7 @@ def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledMo
     path = os.path.join(_MODELS_DIR, os.path.splitext(os.path.basename(xml))[0] + ".npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist (no packaged model and no assets_root given)")
-    model = load_model(path)
+    model = load_model(path).with_capacity(**{k: FETCH_CAPACITY[k] for k in ("maxcon", "maxefc", "jpool")})      # (the packaged blobs carry round 2's requests; the tables do not depend on them)
     cap = os.environ.get("GRX_FETCH_CAP")     # experiments: "maxefc,jpool" other than the packaged capacities (needs a library built with -DGRX_FETCH_ME / -DGRX_FETCH_JP to stay on the specialised kernels)
     if cap:
         me, jp = (int(x) for x in cap.split(","))

@@ -24,6 +24,8 @@ for k in range(steps):
     P = np.frombuffer(buf, dtype=np.int32).reshape(n, NP)
     rows.append(P[:, 16 + 32].copy()); pool.append(P[:, 16 + 33].copy()); ncon.append(P[:, 16 + 34].copy()); srch.append(P[:, 16 + 25].copy()); queued.append(P[:, 16 + 24].copy())
 rows, pool, ncon, srch, queued = (np.array(x) for x in (rows, pool, ncon, srch, queued))      # [steps, n]
+if os.environ.get("GRX_DEMAND_NPZ"):      # the raw per-world-step maxima, for offline evaluation of capacity triples
+    np.savez_compressed(os.environ["GRX_DEMAND_NPZ"], rows=rows.astype(np.int16), pool=pool.astype(np.int16), ncon=ncon.astype(np.int16))
 q = [50, 90, 95, 98, 99, 99.5, 99.9, 100]
 print(f"FetchPickAndPlace-v4, {n} worlds, {steps} steps, uniform random actions, staggered same-step resets; per world and env.step")
 for name, a in (("rows (max over the substeps)", rows), ("Jacobian-pool words", pool), ("contacts", ncon), ("hull pairs queued per step (20 substeps)", queued), ("portal searches per step", srch)):
