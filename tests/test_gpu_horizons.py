@@ -19,7 +19,7 @@ import json
 import numpy as np
 import pytest
 
-from tolerance_cases import GAP, HORIZONS, ROLLOUT_FAMILIES, TABLE, horizon_errors
+from tolerance_cases import GAP, HORIZONS, ROLLOUT_FAMILIES, TABLE, episode_errors, horizon_errors
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -51,3 +51,29 @@ def test_free_running_rollout_stays_within_the_measured_bound(family):
                 assert np.mean(err[posed] < TOL) >= rec["frac_within_1e-4_posed"] - 0.10, (family, h, comp, float(np.mean(err[posed] < TOL)), rec["frac_within_1e-4_posed"])
             if not touch and (family, comp) not in CHAOTIC:
                 assert np.mean(err < TOL) >= (0.90 if h <= 5 else 0.85), (family, h, comp, float(np.mean(err < TOL)))
+
+
+@pytest.mark.parametrize("family", ROLLOUT_FAMILIES)
+def test_whole_episode_free_running(family):
+    """The reference's seeded-rollout test itself (/root/reference/tests/test_envs.py:62-117: a whole episode): every fixture episode (30 - 70 steps; FetchPickAndPlace: 8 episodes of
+    50) replayed free-running from its first state, compared with the oracle after EVERY step.  Measured on the MI355X (tests/golden/tolerance_table.json "episodes",
+    profiles/horizons_r05.txt): 7 of the 8 FetchPickAndPlace episodes, all 6 AdroitHammer / Relocate episodes (70 steps), 10 of the 11 kitchen runs stay within 1e-4 on every
+    component THROUGHOUT; the median error after the last step is 5e-7 (Fetch), 3e-7 (hammer), 2e-6 (kitchen positions).  An episode that leaves 1e-4 does so at an activation
+    switch the two engines cross a step apart (section 5 of DESIGN.md), not by drift.  Asserted: per component, the number of episodes within 1e-4 throughout >= recorded - 1,
+    the median error after the last step <= 3 x recorded (and < 1e-4 for every non-touch component whose recorded median is), nothing non-finite."""
+    with open(TABLE) as f:
+        recorded = json.load(f)["episodes"][family]
+    res, lens = episode_errors(family)
+    assert [int(x) for x in lens] == recorded["steps"]
+    for comp, err in res.items():
+        rec = recorded[comp]
+        final = np.array([err[i, lens[i] - 1] for i in range(len(lens))])
+        worst = np.nanmax(err, axis=1)
+        assert np.isfinite(final).all() and np.isfinite(worst).all(), (family, comp)
+        assert int(np.sum(worst < TOL)) >= rec["episodes_within_1e-4_throughout"] - 1, (family, comp, int(np.sum(worst < TOL)), rec["episodes_within_1e-4_throughout"])
+        assert np.median(final) <= max(3.0 * rec["final_median"], 1e-6), (family, comp, float(np.median(final)), rec["final_median"])
+        if rec["final_median"] < TOL and not comp.startswith("touch"):
+            assert np.median(final) < TOL, (family, comp, float(np.median(final)))
+    if family == "FetchPickAndPlace":      # BASELINE configs[1]: the claim in numbers
+        worst = np.nanmax(res["obs"], axis=1)
+        assert int(np.sum(worst < TOL)) >= 6 and np.median([res["obs"][i, lens[i] - 1] for i in range(len(lens))]) < 5e-6

@@ -191,3 +191,58 @@ def measure_horizons(families=None):
                                      "p50_posed": float(np.median(err[posed])) if posed.any() else None}
         table[name] = row
     return table
+
+
+# ---------------------------------------------------------------------------------------------- whole-episode free running
+def episode_errors(name):
+    """The reference's generic test rolls a whole seeded episode (/root/reference/tests/test_envs.py:62-117: 50 steps): here every fixture EPISODE (its first snapshot to its
+    last, 20 - 100 steps) is replayed free-running on the MI355X -- one world per episode, started from the episode's first pre-step state, fed the recorded actions -- and
+    compared with the oracle's recorded observation after EVERY step.  Returns {component: [n_episodes, T] max-abs error per step (nan past an episode's end)}, lengths [n_episodes]."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    env_id, fixture, keys, comps = CASES[name]
+    g = np.load(os.path.join(GOLDEN, fixture))
+    run = episode_runs(g)
+    n = g["obs"].shape[0]
+    starts = np.array([i for i in range(n) if i == 0 or run[i - 1] == 1])      # first snapshot of every contiguous run
+    lens = run[starts]
+    T = int(lens.max())
+    env = grx.make_vec(env_id, num_envs=len(starts), device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
+    env.reset(seed=0)
+    for k in keys:
+        getattr(env, k).copy_(torch.from_numpy(g[k][starts].astype(np.float32)).to(env.device))
+    step_no = [0]
+    rows = lambda k: np.minimum(starts + k, n - 1)
+    if name == "FrankaKitchen":
+        noise = g["noise"].astype(np.float32)
+        env._draw_noise = lambda idx=None: env.noise.copy_(torch.from_numpy(noise[rows(step_no[0])]).to(env.device))
+    out = {c: np.full((len(starts), T), np.nan) for c in comps}
+    for k in range(T):
+        step_no[0] = k
+        res = env.step(g["action"][rows(k)])
+        obs = res[0]["observation"] if isinstance(res[0], dict) else res[0]
+        live = lens > k
+        e = np.abs(obs - g["obs"][rows(k)])
+        ref = np.abs(g["obs"][rows(k)])
+        for c, cols in comps.items():
+            v = (e[:, cols] / np.maximum(1.0, ref[:, cols]) if c.endswith("_relative") else e[:, cols]).max(axis=1)
+            out[c][live, k] = v[live]
+    env.close()
+    return out, lens
+
+
+def measure_episodes(families=None):
+    table = {}
+    for name in families or ROLLOUT_FAMILIES:
+        res, lens = episode_errors(name)
+        row = {"episodes": int(len(lens)), "steps": [int(x) for x in lens]}
+        for comp, err in res.items():
+            final = np.array([err[i, lens[i] - 1] for i in range(len(lens))])
+            worst = np.nanmax(err, axis=1)
+            first_over = [int(np.argmax(err[i, :lens[i]] >= 1e-4)) if (err[i, :lens[i]] >= 1e-4).any() else int(lens[i]) for i in range(len(lens))]
+            row[comp] = {"final_median": float(np.median(final)), "final_max": float(final.max()), "worst_median": float(np.median(worst)), "worst_max": float(worst.max()),
+                         "episodes_within_1e-4_throughout": int(np.sum(worst < 1e-4)), "steps_before_first_1e-4_median": float(np.median(first_over)), "steps_before_first_1e-4_min": int(np.min(first_over))}
+        table[name] = row
+    return table
