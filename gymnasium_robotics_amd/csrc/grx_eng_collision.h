@@ -123,6 +123,13 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
       hblk = __builtin_amdgcn_readfirstlane(hblk);
       if (hblk >= 0 && lane_ < 16) q.hint = __float_as_int(c->hullhint[17 * hblk + 1 + lane_]);
     }
+#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+    for (int l = 0; l < 16; l++) q.hints[l] = 0;
+    if (c->hullhint && g_grx_emu_hints_on) {      // emulator twin: the same row, the same four blocks
+      const float hk0 = c->hullhint[0], hk1 = c->hullhint[17], hk2 = c->hullhint[34], hk3 = c->hullhint[51];
+      hblk = hk0 == key ? 0 : (hk1 == key ? 1 : (hk2 == key ? 2 : (hk3 == key ? 3 : -1)));
+      if (hblk >= 0) for (int l = 0; l < 16; l++) memcpy(&q.hints[l], &c->hullhint[17 * hblk + 1 + l], 4);
+    }
 #endif
     MF depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
@@ -133,6 +140,13 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
       wblk = __builtin_amdgcn_readfirstlane(wblk);
       if (lane_ < 16) c->hullhint[17 * wblk + 1 + lane_] = __int_as_float(lane_ < q.hk ? q.hint : 0);
       if (lane_ == 0) c->hullhint[17 * wblk] = key;
+    }
+#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+    if (c->hullhint && g_grx_emu_hints_on && rc == 0) {
+      int wblk = hblk;
+      if (wblk < 0) { wblk = ((int)c->hullhint[68]) & 3; c->hullhint[68] = (float)((wblk + 1) & 3); }
+      for (int l = 0; l < 16; l++) { const int wv = l < q.hk ? q.hints[l] : 0; memcpy(&c->hullhint[17 * wblk + 1 + l], &wv, 4); }
+      c->hullhint[17 * wblk] = key;
     }
 #endif
     GRX_SUBTICK(c, 23);   // portal search

@@ -78,6 +78,9 @@ struct GrxMprPairT { RF R1[9], R2[9], s1[3], s2[3]; MF c21[3], hm; int t1, t2;  
                     const float *nbr1, *nbr2;   // neighbour records of the two hulls (GrxModel::mesh_nbr + 64 * first hull vertex), or null
                     const int *cell1, *cell2; const float* cellrec;   // support-candidate lists of the two hulls (GrxModel::mesh_cellhdr + 2 * geom_cellbase, mesh_cellrec), or null
                     mutable int hint, hk;       // wave-cooperative variant: lane e holds the guessed support vertices of evaluation e ((v1 + 1) | (v2 + 1) << 16); evaluations so far
+#if defined(GRX_EMU)
+                    mutable int hints[16];      // the emulator's stand-in for `hint` (one register per lane on the device: lane e holds word e)
+#endif
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
                     long long* prof;
 #endif
@@ -151,6 +154,25 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
         return hint;
       }
     }
+  }
+#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+  // emulator twin of the guess check above (same records, same margin, fp64 projections): the CPU suite then exercises "a stale / foreign / wrong guess never changes a result"
+  // and "an accepted guess is the scan's vertex" on every hull fixture (tests/test_cpu_hull_hints.py)
+  if (g_grx_emu_hints_on && hint >= 0 && hint < n && nbr != nullptr) {
+    const float* p0 = nbr + 4 * GRX_NBR_RECS * (size_t)hint;
+    const int deg = (int)p0[3];
+    if (deg >= 1) {
+      const double dn = sqrt((double)dlm[0] * (double)dlm[0] + (double)dlm[1] * (double)dlm[1] + (double)dlm[2] * (double)dlm[2]);
+      const double t0 = (double)p0[0] * (double)dlm[0] + (double)p0[1] * (double)dlm[1] + (double)p0[2] * (double)dlm[2];
+      int beaten = 0;
+      for (int k = 1; k <= deg; k++) {
+        const float* p = p0 + 4 * k;
+        const double t = (double)p[0] * (double)dlm[0] + (double)p[1] * (double)dlm[1] + (double)p[2] * (double)dlm[2];
+        if (!(t0 - t > 1.0e-6 * dn)) beaten = 1;
+      }
+      if (!beaten) { r[0] = p0[0]; r[1] = p0[1]; r[2] = p0[2]; g_grx_hint_stats[0]++; return hint; }
+    }
+    g_grx_hint_stats[1]++;
   }
 #else
   (void)hint; (void)nbr;
@@ -295,6 +317,12 @@ GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
     if (ek < 16) { const int pk = __builtin_amdgcn_readlane(q->hint, ek); h1 = (pk & 0xFFFF) - 1; h2 = (int)((unsigned)pk >> 16) - 1; }
     q->hk = ek + 1;
   }
+#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+  if (W) {
+    ek = q->hk;
+    if (ek < 16) { const int pk = q->hints[ek]; h1 = (pk & 0xFFFF) - 1; h2 = (int)((unsigned)pk >> 16) - 1; }
+    q->hk = ek + 1;
+  }
 #endif
   if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); f1 = grx_mesh_support(q->v1, q->n1, dl, r, q->lane, q->aadr1, q->anum1, q->adj, h1, q->nbr1, q->cell1, q->cellrec); mulMatVec3f(o->w, q->R1, r); }
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
@@ -305,6 +333,8 @@ GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
   // fence: a stale, torn or foreign word can never change a result, because a guess is only ever a CANDIDATE -- grx_mesh_support accepts it when it provably is the support
   // vertex (tops every hull neighbour by the margin) and scans otherwise; tests/test_gpu_fetch.py::test_hull_caches_do_not_change_the_rollout.)
   if (W && ek < 16 && q->lane == ek) q->hint = ((f1 + 1) & 0xFFFF) | ((f2 + 1) << 16);
+#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+  if (W && ek < 16) q->hints[ek] = ((f1 + 1) & 0xFFFF) | ((f2 + 1) << 16);
 #endif
 #if defined(GRX_PROFILE) && !defined(GRX_EMU)
   if (W && q->lane == 0) q->prof[16 + 28] += clock64() - tp0_;

@@ -558,6 +558,7 @@ static inline void grx_emu_mfma_32x32x2(const float* a, const float* b, float (*
     }
 }
 static long g_grx_mesh_stats[4];   // emulator diagnostics: hull pairs skipped by a cached separating direction / sent through the portal search
+static int g_grx_emu_hints_on = 1; static long g_grx_hint_stats[2];   // emulator twin of the guessed support vertices (GRX_HULL_HINTS): switch (tests A/B it), guesses accepted / rejected
 static long g_grx_cell_stats[4];   // emulator: hull support evaluations with a cell table / with a list in their cell / total list entries seen / near-tie vertices MISSING from a list (must be 0)
 static long g_grx_newton_stats[6];   // emulator diagnostics: constrained solves, Newton iterations, full Hessian assemblies, incremental updates
 #if defined(GRX_EMU_TRACE)

@@ -5,6 +5,7 @@
 // (lanes are executed one after another inside each FOR_LANES block).  Never loaded by the
 // product; the product path is the HIP build of the same headers (csrc/grx_kernels.hip).
 #define GRX_EMU 1
+#define GRX_HULL_HINTS 1   // the emulator runs a twin of the guessed support vertices (the device's Fetch kernels carry the real thing)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -37,6 +38,7 @@ struct Emu {
   GrxPackedModel pm;
   GrxModel m;
   std::vector<float> lds;
+  std::vector<float> hull;   // the world's row of guessed support vertices (GRX_HULLCACHE_WORDS; on the device: HBM, kept across launches)
   GrxCtx c;
 };
 
@@ -52,6 +54,8 @@ void* emu_create(const int32_t* H, const int32_t* I, const double* F) {
   g_grx_emu_nfields = 0;
 #endif
   grx_ctx_carve(&e->c, e->lds.data(), grx_dims_of(&e->m));
+  e->hull.assign(GRX_HULLCACHE_WORDS, 0.0f);
+  e->c.hullhint = e->m.mesh_nbr ? e->hull.data() + 21 : nullptr;      // kept across the emulator's steps, whatever state they start from: a stale guess must be harmless
   return e;
 }
 void emu_destroy(void* h) { delete (Emu*)h; }
@@ -168,6 +172,8 @@ long emu_mesh_stat(int k) { return g_grx_mesh_stats[k]; }
 long emu_newton_stat(int k) { return g_grx_newton_stats[k]; }
 // support-candidate lists (GrxModel::mesh_cellhdr): evaluations with a table / with a list / list entries seen / near-tie vertices MISSING from a list (must stay 0)
 long emu_cell_stat(int k) { return g_grx_cell_stats[k]; }
+long emu_hint_stat(int k) { return g_grx_hint_stats[k]; }      // guessed support vertices: accepted / rejected
+void emu_set_hints(int on) { g_grx_emu_hints_on = on; }
 // the hull support function of geom g for n geom-frame directions (dirs[3 n]): the emulator scans the hull and checks the candidate list of every direction's cell against the
 // scan (g_grx_cell_stats); out[k] = the support vertex.  Returns the number of header pairs of the hull (0: the geom has no lists)
 int emu_hull_support(void* h, int g, const float* dirs, int n, int* out) {

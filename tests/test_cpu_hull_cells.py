@@ -95,8 +95,12 @@ def test_every_support_evaluation_of_the_hull_contact_fixture_is_covered():
     import emu_tolerances as T
 
     L = _lib()
+    L.emu_set_hints(0)      # every evaluation through the scan (and the list check), none short-cut by a guessed vertex
     s0 = [L.emu_cell_stat(k) for k in range(4)]
-    idx, e, status, comps = T.run_family(L, "FetchHullContacts", False, 2)
+    try:
+        idx, e, status, comps = T.run_family(L, "FetchHullContacts", False, 2)
+    finally:
+        L.emu_set_hints(1)
     s = [L.emu_cell_stat(k) - s0[k] for k in range(4)]
     assert (status == 0).all()
     assert s[0] > 1000 and s[1] > 0.8 * s[0], s

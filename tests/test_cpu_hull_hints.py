@@ -61,3 +61,38 @@ def test_strict_local_maximum_over_the_edge_graph_is_the_scan_winner(which):
         false_max = v0 != best[d0]
         assert not false_max.any() or excess[d0[false_max], v0[false_max]].max() < 1.0e-7, (which, hulls, float(excess[d0[false_max], v0[false_max]].max()))
     assert hulls >= 8 and accepted > 2000, (hulls, accepted)
+
+
+def test_emulated_guesses_never_change_a_result():
+    """The lane emulator runs a twin of the device's guessed support vertices (csrc/grx_eng_convex.h, grx_mesh_support / grx_mpr_support; csrc/grx_eng_collision.h, grx_mesh_pairs: the
+    world's row of guesses, kept across substeps AND across the emulator's steps, whatever unrelated state the next snapshot starts from).  The folded-arm fixture (hull pairs in
+    resting contact) stepped with the guesses on and off gives bit-identical observations, thousands of guesses are accepted (each one replaced a scan of a hull), and the stale ones
+    left behind by the previous snapshot are rejected, not believed."""
+    import ctypes
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "emu"))
+    sys.path.insert(0, os.path.join(here, "..", "tools"))
+    import emu_sim
+    import emu_tolerances as T
+
+    L = ctypes.CDLL(emu_sim.build())
+    L.emu_create.restype = ctypes.c_void_p
+    L.emu_create.argtypes = [ctypes.c_void_p] * 3
+    L.emu_hint_stat.restype = ctypes.c_long
+    outs = []
+    for on in (1, 0):
+        L.emu_set_hints(on)
+        s0 = [L.emu_hint_stat(k) for k in range(2)]
+        idx, raw, status, comps = T.run_family(L, "FetchHullContacts", False, 3, ref="raw")
+        outs.append(raw.copy())
+        s = [L.emu_hint_stat(k) - s0[k] for k in range(2)]
+        assert (status == 0).all()
+        if on:
+            assert s[0] > 2000 and s[1] > 0, s      # accepted (each replaced a hull scan) and rejected (stale / beaten guesses fell through to the scan)
+        else:
+            assert s == [0, 0], s
+    L.emu_set_hints(1)
+    assert np.array_equal(outs[0], outs[1])
