@@ -1487,6 +1487,39 @@ extern "C" int grx_hand_commit_rows(const grx_hand_commit_args* args, void* stre
   return 0;
 }
 
+// commit of an overlapped Fetch reset (include/grx_capi.h): one 64-thread workgroup per listed world; staged rows are indexed by WORLD (the reset kernel wrote them through a
+// second grx_fetch_buffers)
+extern "C" __global__ void __launch_bounds__(64)
+grx_fetch_commit_kernel(grx_fetch_commit_args a) {
+  const int j = blockIdx.x, l = threadIdx.x;
+  if (j >= a.k) return;
+  const size_t w = (size_t)a.idx[j];
+  const int od = a.obs_dim, pw = od + 8;
+  for (int i = l; i < a.nq; i += 64) a.qpos[w * a.nq + i] = a.s_qpos[w * a.nq + i];
+  for (int i = l; i < a.nv; i += 64) { a.qvel[w * a.nv + i] = a.s_qvel[w * a.nv + i]; a.qacc_ws[w * a.nv + i] = a.s_qacc_ws[w * a.nv + i]; }
+  for (int i = l; i < a.mocap_words; i += 64) a.mocap[w * a.mocap_words + i] = a.s_mocap[w * a.mocap_words + i];
+  if (l < 8) a.aux[w * 8 + l] = a.s_aux[w * 8 + l];
+  if (l < 3) { a.goal[w * 3 + l] = a.s_goal[w * 3 + l]; a.achieved[w * 3 + l] = a.s_achieved[w * 3 + l]; }
+  for (int i = l; i < od; i += 64) a.obs[w * od + i] = a.s_obs[w * od + i];
+  for (int i = l; i < pw; i += 64) {      // the thread that parks a word of the terminal row is the one that overwrites it
+    const float old = a.packed[w * pw + i];
+    if (a.final_packed) a.final_packed[w * pw + i] = old;
+    a.packed[w * pw + i] = i < od ? a.s_obs[w * od + i] : (i < od + 3 ? a.s_achieved[w * 3 + i - od] : (i < od + 6 ? a.s_goal[w * 3 + i - od - 3] : old));
+  }
+  if (l == 0) a.status[w] = grx_status_word(a.status[w], a.s_status[w]);
+}
+extern "C" int grx_fetch_commit_rows(const grx_fetch_commit_args* args, void* stream) {
+  if (!args) return fail("grx_fetch_commit_rows: null argument");
+  const grx_fetch_commit_args& a = *args;
+  if (!a.idx || !a.s_qpos || !a.s_qvel || !a.s_qacc_ws || !a.s_aux || !a.s_goal || !a.s_obs || !a.s_achieved || !a.s_status || !a.qpos || !a.qvel || !a.qacc_ws || !a.aux ||
+      !a.goal || !a.obs || !a.achieved || !a.packed || !a.status || (a.mocap_words > 0 && (!a.s_mocap || !a.mocap))) return fail("grx_fetch_commit_rows: null buffer");
+  if (a.nq <= 0 || a.nv <= 0 || a.obs_dim <= 0 || a.mocap_words < 0) return fail("grx_fetch_commit_rows: bad dimensions");
+  if (a.k <= 0) return 0;
+  hipLaunchKernelGGL(grx_fetch_commit_kernel, dim3((unsigned)a.k), dim3(64), 0, (hipStream_t)stream, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 // test-only entry point (tests/test_gpu_primitives.py); all pointers are device pointers
 extern "C" int grx_debug_primitive(int mode, int nv, int nefc, const float* A, const float* b, const float* J, const float* D, float* out, void* stream) {
   int bytes = (2 * nv * nv + GRX_MAXEFC * nv + 6 * GRX_MAXEFC + 2 * nv + 64) * 4;

@@ -83,6 +83,8 @@ class FetchVecEnv(GoalVecEnv):
             device tensors the kernel wrote (valid until the next step) -- no PCIe traffic.
     """
 
+    CKPT_SKIP = GoalVecEnv.CKPT_SKIP + ("_ahead",)      # staging rows of the overlapped reset: written and consumed inside one step() call, never state
+
     def __init__(self, env_id: str = "FetchPickAndPlace-v4", num_envs: int = 1, device: Optional[str] = None,
                  max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step",
                  output: str = "numpy", assets_root: Optional[str] = None, model: Optional[CompiledModel] = None,
@@ -198,6 +200,18 @@ class FetchVecEnv(GoalVecEnv):
         if self._h_big is not None:
             packed, hullcache, mk = self.packed, self.hullcache, FetchVecEnv._make_bufs      # (no reference to self: the lane must not keep the environment alive)
             self.lane = OverflowLane(n, d, self.model, lambda m: mk(*common, m, None, None, packed, hullcache), mode="entry")     # overflows are rare events here (0.0007 % of the world-steps)
+        # Overlapped same-step reset (include/grx_capi.h, grx_fetch_commit_rows): Fetch episodes end by the time limit only, so the worlds a step will reset are known before
+        # it is launched and their reset state depends on nothing the step computes.  The reset kernel runs for them on a side stream, beside the step kernel, into this second
+        # set of world rows; ONE small kernel behind the step commits them (parks the terminal rows, copies the staged ones).  The in-line reset (88 us of a 3.3 ms step at
+        # 4 096 worlds: a forward pass of ~82 worlds on an otherwise idle chip) leaves the critical path.  GRX_FETCH_AHEAD_RESET=0: the in-line path (A/B, tests).
+        self._ahead = None
+        if n > 1 and os.environ.get("GRX_FETCH_AHEAD_RESET", "1") != "0":
+            sq, sv, sa, sm, sx, sg, so, sh = z(n, self.nq), z(n, self.nv), z(n, self.nv), z(n, 7 * self.nmocap), z(n, 8), z(n, 3), z(n, self.obs_dim), z(n, 3)
+            sr, ss, st = z(n), z(n, dtype=torch.uint8), z(n, dtype=torch.int32)
+            self._ahead = dict(qpos=sq, qvel=sv, qacc_ws=sa, mocap=sm, aux=sx, goal=sg, obs=so, achieved=sh, reward=sr, success=ss, status=st)
+            self._ahead_bufs = self._make_bufs(sq, sv, sa, sm, sx, sg, self.action, so, sh, sr, ss, st, None, None, None, None, None)
+            self._ahead_stream = torch.cuda.Stream(device=d)
+            self._ahead_late = os.environ.get("GRX_FETCH_AHEAD_ORDER", "after") == "after"      # (A/B tools/ab_fetch_ahead_reset.sh: queued before the step launch the reset workgroups take wave slots from its first, expensive worlds)
 
     def _rebalance(self):
         """order <- per XCD slice, worlds by decreasing cost of the launch that just ran (in place: the buffer struct keeps its pointer)."""
@@ -292,6 +306,37 @@ class FetchVecEnv(GoalVecEnv):
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
 
+    def _launch_reset_ahead(self, idx: np.ndarray, after=None):
+        """The listed worlds' reset -- index upload, the device-side PCG64 draws, the reset kernel -- on the side stream, into the staged rows (see _alloc): runs beside the step
+        kernel the caller launches next.  The side stream first waits for everything already queued on the caller's stream (the previous step's commit read these buffers)."""
+        if after is None:
+            self._ahead_stream.wait_stream(torch.cuda.current_stream(self.device))
+        else:
+            self._ahead_stream.wait_event(after)
+        with torch.cuda.stream(self._ahead_stream):
+            staged = self._stage_reset(idx)
+            n, idx_dev, samples = staged
+            args = _native.FetchResetArgsStruct(idx_dev.data_ptr(), samples.data_ptr(), self.initial_qpos.data_ptr(), self.initial_qvel.data_ptr(),
+                                                self._mocap0.data_ptr(), int(self._obj_qadr), 1, None)
+            _native.check(self._L.grx_fetch_reset(self._h, ctypes.byref(self.task), ctypes.byref(self._ahead_bufs), ctypes.byref(args), n, self._stream()))
+            done = torch.cuda.Event()
+            done.record(self._ahead_stream)
+        return staged, done
+
+    def _commit_ahead(self, ahead, idx):
+        """behind the step kernel (and the re-run of the worlds that overflowed its tables): the staged reset rows replace the live ones (grx_fetch_commit_rows)"""
+        (n, idx_dev, _), done = ahead
+        torch.cuda.current_stream(self.device).wait_event(done)
+        A = self._ahead
+        a = _native.FetchCommitArgsStruct(idx_dev.data_ptr(), n, self.nq, self.nv, 7 * self.nmocap, self.obs_dim,
+                                          A["qpos"].data_ptr(), A["qvel"].data_ptr(), A["qacc_ws"].data_ptr(), A["mocap"].data_ptr(), A["aux"].data_ptr(), A["goal"].data_ptr(),
+                                          A["obs"].data_ptr(), A["achieved"].data_ptr(), A["status"].data_ptr(),
+                                          self.qpos.data_ptr(), self.qvel.data_ptr(), self.qacc_ws.data_ptr(), self.mocap.data_ptr(), self.aux.data_ptr(), self.goal.data_ptr(),
+                                          self.obs.data_ptr(), self.achieved.data_ptr(), self.packed.data_ptr(), self.final_packed.data_ptr(), self.status.data_ptr())
+        _native.check(self._L.grx_fetch_commit_rows(ctypes.byref(a), self._stream()))
+        self._elapsed[idx] = 0
+        self._needs_reset[idx] = False
+
     def _reset_worlds(self, idx: np.ndarray):
         if len(idx) == 0:
             return None
@@ -323,12 +368,22 @@ class FetchVecEnv(GoalVecEnv):
             self.action.copy_(torch.from_numpy(a), non_blocking=True)
         with torch.cuda.device(self.device):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
+            ahead = None
+            if self._ahead is not None and self.autoreset_mode == "same_step" and self.max_episode_steps is not None:
+                will = np.nonzero(self._elapsed + 1 >= self.max_episode_steps)[0]      # the worlds this step truncates: Fetch has no other episode end (compute_terminated)
+                if len(will) and not self._ahead_late:
+                    ahead = (will, self._launch_reset_ahead(will))
+                elif len(will):
+                    before = torch.cuda.Event()
+                    before.record(torch.cuda.current_stream(self.device))
             if len(pending):
                 self.mask.fill_(1)
                 self.mask.index_fill_(0, self._stage_idx(pending), 0)      # (pinned staging + index_fill_: nothing here waits for the running kernel)
                 self._launch_step(self._bufs_masked)
             else:
                 self._launch_step(self._bufs)
+            if ahead is None and self._ahead is not None and self._ahead_late and self.autoreset_mode == "same_step" and self.max_episode_steps is not None and len(will):
+                ahead = (will, self._launch_reset_ahead(will, after=before))      # queued behind the step launch: its workgroups take the slots the first finished worlds free
             stepped = ~self._needs_reset if len(pending) else np.ones(self.num_envs, bool)
             self._elapsed[stepped] += 1
             truncated = np.zeros(self.num_envs, bool)
@@ -342,12 +397,20 @@ class FetchVecEnv(GoalVecEnv):
                 self.packed[:, -2].index_fill_(0, tp, 0.0)
             if self.autoreset_mode == "same_step" and truncated.any():
                 done = np.nonzero(truncated)[0]
-                staged = self._stage_reset(done)
-                # the reset kernel parks the terminal packed rows of these worlds in final_packed (info["final_obs"], the last transition for HER) and
+                # the reset parks the terminal packed rows of these worlds in final_packed (info["final_obs"], the last transition for HER) and
                 # leaves reward / success at the finished episode's values (keep_outcome)
-                if self.output != "torch":
-                    info["final_obs"] = self._obs_dict(rows=done)
-                self._launch_reset(staged, done, keep_outcome=True)
+                if ahead is not None:
+                    if not np.array_equal(ahead[0], done):
+                        raise RuntimeError("overlapped reset: the worlds reset ahead of the step are not the ones it truncated")
+                    staged = ahead[1][0]
+                    if self.output != "torch":
+                        info["final_obs"] = self._obs_dict(rows=done)
+                    self._commit_ahead(ahead[1], done)
+                else:
+                    staged = self._stage_reset(done)
+                    if self.output != "torch":
+                        info["final_obs"] = self._obs_dict(rows=done)
+                    self._launch_reset(staged, done, keep_outcome=True)
                 if self.output == "torch":
                     fo = self.final_packed[staged[1].long()]
                     info["final_obs"] = {"observation": fo[:, : self.obs_dim], "achieved_goal": fo[:, self.obs_dim: self.obs_dim + 3],

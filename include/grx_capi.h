@@ -370,6 +370,20 @@ typedef struct grx_hand_commit_args {
 } grx_hand_commit_args;
 int grx_hand_commit_rows(const grx_hand_commit_args* args, void* stream);
 
+/* Commit of an overlapped Fetch reset (envs/fetch.py).  Fetch episodes end by the time limit only (compute_terminated is constant False, fetch_env.py / robot_env.py:140-148),
+ * so the worlds a step will reset are known BEFORE it is launched and their reset state depends on nothing the step computes: grx_fetch_reset runs for them on a side stream,
+ * beside the step kernel, into a SECOND set of [N, ...] buffers (same world rows), and this call -- behind the step kernel -- parks the terminal packed row of world idx[j] in
+ * final_packed, copies the staged qpos / qvel / qacc_ws / mocap / aux / goal / obs / achieved rows over the live ones, rewrites the packed row's [obs | achieved | desired] words
+ * (reward / success stay those of the finished episode: same-step autoreset) and folds the reset launch's status flags into the world's status word exactly as
+ * grx_fetch_reset would have.  Bit-identical to the in-line reset (tests/test_gpu_fetch.py).  All pointers are device pointers; idx as in grx_fetch_reset_args. */
+typedef struct grx_fetch_commit_args {
+  const int* idx; int k;
+  int nq, nv, mocap_words, obs_dim;     /* mocap_words = 7 * nmocap */
+  const float *s_qpos, *s_qvel, *s_qacc_ws, *s_mocap, *s_aux, *s_goal, *s_obs, *s_achieved; const int* s_status;
+  float *qpos, *qvel, *qacc_ws, *mocap, *aux, *goal, *obs, *achieved, *packed, *final_packed; int* status;
+} grx_fetch_commit_args;
+int grx_fetch_commit_rows(const grx_fetch_commit_args* args, void* stream);
+
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's
  * numpy PCG64 (created and seeded by numpy on the Python side), advanced in place.  All pointers are HOST pointers. */

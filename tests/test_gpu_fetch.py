@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 TOL = 1e-4
-IDS = {"FetchReach": "FetchReach-v4", "FetchPush": "FetchPush-v4", "FetchPickAndPlace": "FetchPickAndPlace-v4"}
+IDS = {"FetchReach": "FetchReach-v4", "FetchPush": "FetchPush-v4", "FetchPickAndPlace": "FetchPickAndPlace-v4", "FetchSlide": "FetchSlide-v4"}
 
 
 def _env(task, n, **kw):
@@ -149,6 +149,47 @@ def test_hull_candidate_lists_do_not_change_the_rollout(monkeypatch):
             e.step(a)
         for e in envs[1:]:
             assert torch.equal(envs[0].qpos, e.qpos) and torch.equal(envs[0].qvel, e.qvel) and torch.equal(envs[0].obs, e.obs), t
+
+
+@pytest.mark.parametrize("task,output,order", [("FetchPickAndPlace", "torch", "before"), ("FetchPickAndPlace", "numpy", "before"), ("FetchPickAndPlace", "torch", "after"),
+                                               ("FetchSlide", "torch", "before"), ("FetchReach", "torch", "before")])
+def test_overlapped_reset_is_the_inline_reset(monkeypatch, task, output, order):
+    """Same-step autoreset, two ways: the reset kernel of the worlds a step will truncate run AHEAD of it on a side stream into staged rows and committed behind the step
+    kernel (grx_fetch_commit_rows, the default), against the in-line reset behind the step (GRX_FETCH_AHEAD_RESET=0).  Staggered episodes (some worlds reset in every
+    step, a few steps reset none), 130 steps = every world through two or three resets: state rows, outputs, packed and parked terminal rows, goals, status words, the
+    device-resident PCG64 streams, flags and info["final_obs"] are bit-identical after every step."""
+    import torch
+
+    n, horizon = 192, 50
+    envs = []
+    monkeypatch.setenv("GRX_FETCH_AHEAD_ORDER", order)
+    for on in ("1", "0"):
+        monkeypatch.setenv("GRX_FETCH_AHEAD_RESET", on)
+        e = _env(task, n, autoreset_mode="same_step", max_episode_steps=horizon, output=output)
+        e.reset(seed=11)
+        e._elapsed[:] = (np.arange(n) * 7) % 41      # phases 41 .. 49 are empty: 9 steps of every 50 reset no world
+        envs.append(e)
+    assert envs[0]._ahead is not None and envs[1]._ahead is None
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+    resets = 0
+    for t in range(130):
+        a = torch.rand(n, 4, device="cuda:0", generator=gen) * 2 - 1
+        outs = [e.step(a if output == "torch" else a.cpu().numpy()) for e in envs]
+        (o0, r0, te0, tr0, i0), (o1, r1, te1, tr1, i1) = outs
+        eq = torch.equal if output == "torch" else np.array_equal
+        for k in o0:
+            assert eq(o0[k], o1[k]), (t, k)
+        assert eq(r0, r1) and eq(te0, te1) and eq(tr0, tr1) and eq(i0["is_success"], i1["is_success"]), t
+        assert ("final_obs" in i0) == ("final_obs" in i1), t
+        if "final_obs" in i0:
+            resets += 1
+            for k in i0["final_obs"]:
+                assert eq(i0["final_obs"][k], i1["final_obs"][k]), (t, k)
+        a_, b_ = envs
+        for name in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "obs", "achieved", "reward", "success", "status", "packed", "final_packed", "_rng_dev"):
+            assert torch.equal(getattr(a_, name), getattr(b_, name)), (t, name)
+        assert np.array_equal(a_._elapsed, b_._elapsed)
+    assert 100 <= resets < 130
 
 
 def test_compacted_reset_kernel_matches_masked_forward():
