@@ -44,7 +44,7 @@ class AdroitTaskStruct(ctypes.Structure):
 
 
 class AdroitBuffersStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")] + [("lane", OverflowLaneStruct)]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")] + [("lane", OverflowLaneStruct), ("compact", ctypes.c_void_p), ("n_compact", ctypes.c_int)]
 
 
 class KitchenTaskStruct(ctypes.Structure):
@@ -86,6 +86,11 @@ class FetchCommitArgsStruct(ctypes.Structure):      # include/grx_capi.h, grx_fe
     _fields_ = [("idx", ctypes.c_void_p), ("k", ctypes.c_int)] + [(n, ctypes.c_int) for n in ("nq", "nv", "mocap_words", "obs_dim")] + [
         (n, ctypes.c_void_p) for n in ("s_qpos", "s_qvel", "s_qacc_ws", "s_mocap", "s_aux", "s_goal", "s_obs", "s_achieved", "s_status",
                                        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "obs", "achieved", "packed", "final_packed", "status")]
+
+
+class AdroitCommitArgsStruct(ctypes.Structure):      # include/grx_capi.h, grx_adroit_commit_args
+    _fields_ = [("idx", ctypes.c_void_p), ("k", ctypes.c_int)] + [(n, ctypes.c_int) for n in ("nq", "nv", "obs_dim")] + [
+        (n, ctypes.c_void_p) for n in ("s_qpos", "s_qvel", "s_qacc_ws", "s_shift", "s_target", "s_obs", "s_status", "qpos", "qvel", "qacc_ws", "shift", "target", "obs", "status")]
 
 
 class HandBuffersStruct(ctypes.Structure):
@@ -133,6 +138,7 @@ def lib():
         L.grx_maze_reset_rows.argtypes = [vp, ci, vp]
         L.grx_hand_commit_rows.argtypes = [vp, vp]
         L.grx_fetch_commit_rows.argtypes = [vp, vp]
+        L.grx_adroit_commit_rows.argtypes = [vp, vp]
         cd = ctypes.c_double
         L.grx_fetch_sample_resets.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
         L.grx_fetch_sample_resets_device.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp, cd, vp, vp]
@@ -149,7 +155,7 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_fetch_sample_resets_device", "grx_adroit_sample_resets_device", "grx_maze_sample_resets_device", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_uniform_rows_device", "grx_kitchen_bookkeeping", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_fetch_commit_rows", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_fetch_sample_resets_device", "grx_adroit_sample_resets_device", "grx_maze_sample_resets_device", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_uniform_rows_device", "grx_kitchen_bookkeeping", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_fetch_commit_rows", "grx_adroit_commit_rows", "grx_last_error",
 ]
 
 

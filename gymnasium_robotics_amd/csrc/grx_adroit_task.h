@@ -41,6 +41,8 @@ struct GrxAdroitBuffers {
   int* status;                    // [N]
   const unsigned char* mask;      // [N] or null
   GrxLane lane;                   // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
+  const long long* compact;       // [n_compact] world indices or null: workgroup j of a launch of n_compact workgroups handles world compact[j]
+  int n_compact;
 };
 
 template <class S>

@@ -572,7 +572,7 @@ __device__ __forceinline__ void grx_adroit_step_world(int mslot, const GrxAdroit
   grx_lane_setup(b.lane, c, w, !forward_only);
   if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
   else GrxAdroit<S>::grx_adroit_sim_world(&m, &t, &c, b.action + (size_t)w * nu, b.act_mean, b.act_rng, lane_);
-  const int wl = in_lane ? w : grx_world_of_block_late();
+  const int wl = in_lane ? w : (b.compact ? (int)b.compact[blockIdx.x] : grx_world_of_block_late());   // (recomputed, not kept live across the simulation)
   if (grx_lane_overflowed(c)) return;   // capacity overflow: keep nothing, re-run on the large tables
   if (in_lane) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, wl, lane_); else if (!forward_only) grx_lane_join(b.lane, c, wl, lane_);
   GrxAdroit<S>::grx_adroit_outputs(&m, &t, &c, b.target ? b.target + (size_t)wl * 3 : nullptr, b.obs + (size_t)wl * t.obs_dim, b.reward + wl, b.success + wl, lane_);
@@ -590,7 +590,8 @@ __global__ void __launch_bounds__(64, 2)
 grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
-  grx_adroit_step_world<S>(mslot, t, b, grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+  const int w = b.compact ? ((int)blockIdx.x < b.n_compact ? (int)b.compact[blockIdx.x] : n_worlds) : grx_world_of_block();
+  grx_adroit_step_world<S>(mslot, t, b, w, n_worlds, words, forward_only, lds, lane_, false);
   grx_lane_progress(b.lane);
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
@@ -1176,7 +1177,8 @@ extern "C" int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, 
   if (t.kind == GRX_ADROIT_PEN && !(t.len[0] > 0.0f && t.len[1] > 0.0f)) return fail("grx_adroit_step: pen / target lengths must be positive");
   if (t.kind == GRX_ADROIT_RELOCATE && !buf->target) return fail("grx_adroit_step: the relocate task needs the target buffer");
   if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_adroit_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
-  const int e = grx_tu_adroit_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  if (b.compact && (b.n_compact <= 0 || b.lane.list)) return fail("grx_adroit_step: a compacted launch needs n_compact > 0 and is not a lane launch");
+  const int e = grx_tu_adroit_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : (b.compact ? (unsigned)b.n_compact : grx_grid_for(n_worlds))), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_adroit_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }
@@ -1516,6 +1518,31 @@ extern "C" int grx_fetch_commit_rows(const grx_fetch_commit_args* args, void* st
   if (a.nq <= 0 || a.nv <= 0 || a.obs_dim <= 0 || a.mocap_words < 0) return fail("grx_fetch_commit_rows: bad dimensions");
   if (a.k <= 0) return 0;
   hipLaunchKernelGGL(grx_fetch_commit_kernel, dim3((unsigned)a.k), dim3(64), 0, (hipStream_t)stream, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// commit of an overlapped Adroit reset (include/grx_capi.h): one 64-thread workgroup per listed world, staged rows indexed by WORLD
+extern "C" __global__ void __launch_bounds__(64)
+grx_adroit_commit_kernel(grx_adroit_commit_args a) {
+  const int j = blockIdx.x, l = threadIdx.x;
+  if (j >= a.k) return;
+  const size_t w = (size_t)a.idx[j];
+  for (int i = l; i < a.nq; i += 64) a.qpos[w * a.nq + i] = a.s_qpos[w * a.nq + i];
+  for (int i = l; i < a.nv; i += 64) { a.qvel[w * a.nv + i] = a.s_qvel[w * a.nv + i]; a.qacc_ws[w * a.nv + i] = a.s_qacc_ws[w * a.nv + i]; }
+  for (int i = l; i < a.obs_dim; i += 64) a.obs[w * a.obs_dim + i] = a.s_obs[w * a.obs_dim + i];
+  if (a.shift && l < 7) a.shift[w * 7 + l] = a.s_shift[w * 7 + l];
+  if (a.target && l < 3) a.target[w * 3 + l] = a.s_target[w * 3 + l];
+  if (l == 0) a.status[w] = (a.status[w] & 0xFFFF) | ((((a.status[w] >> 16) | (a.s_status[w] & 15)) & 0xFFFF) << 16);   // the step's own flags stay; the forward pass's join the sticky half
+}
+extern "C" int grx_adroit_commit_rows(const grx_adroit_commit_args* args, void* stream) {
+  if (!args) return fail("grx_adroit_commit_rows: null argument");
+  const grx_adroit_commit_args& a = *args;
+  if (!a.idx || !a.s_qpos || !a.s_qvel || !a.s_qacc_ws || !a.s_obs || !a.s_status || !a.qpos || !a.qvel || !a.qacc_ws || !a.obs || !a.status) return fail("grx_adroit_commit_rows: null buffer");
+  if ((a.shift != nullptr) != (a.s_shift != nullptr) || (a.target != nullptr) != (a.s_target != nullptr)) return fail("grx_adroit_commit_rows: shift / target need both the staged and the live buffer");
+  if (a.nq <= 0 || a.nv <= 0 || a.obs_dim <= 0) return fail("grx_adroit_commit_rows: bad dimensions");
+  if (a.k <= 0) return 0;
+  hipLaunchKernelGGL(grx_adroit_commit_kernel, dim3((unsigned)a.k), dim3(64), 0, (hipStream_t)stream, a);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -9,6 +9,7 @@ success).  Host side of a reset: the PCG64 draws of reset_model per world; the m
 body_quat / site_pos) are per-world state here (`shift`, `target`: adroit_spec.sample_reset).
 """
 import ctypes
+import os
 import weakref
 from typing import Optional
 
@@ -25,6 +26,8 @@ from .adroit_spec import IDENTITY_SHIFT, MAX_EPISODE_STEPS, SPECS, action_scalin
 class AdroitVecEnv(GoalVecEnv):
     """autoreset_mode: "next_step" (Gymnasium >= 1.0 default), "same_step" or "disabled"; output: "numpy" (float64 arrays like the reference)
     or "torch" (the fp32 device tensors the kernel wrote)."""
+
+    CKPT_SKIP = GoalVecEnv.CKPT_SKIP + ("_ahead",)      # staging rows of the overlapped reset: written and consumed inside one step() call, never state
 
     def __init__(self, env_id: str = "AdroitHandHammer-v2", num_envs: int = 1, device: Optional[str] = None, reward_type: Optional[str] = None,
                  max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step", output: str = "numpy",
@@ -59,6 +62,7 @@ class AdroitVecEnv(GoalVecEnv):
         am, ar = action_scaling(self.model)
         self._act_mean, self._act_rng = torch.from_numpy(am.astype(np.float32)).to(d), torch.from_numpy(ar.astype(np.float32)).to(d)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        self._compact_resets = os.environ.get("GRX_ADROIT_COMPACT_RESET", "1") != "0"      # (0: the masked whole-grid forward launch of rounds 3 - 4; A/B, tests)
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
         self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode="lane" if self.task_name in ("door", "relocate") else "entry", lane_first=True) if self._h_big is not None else None     # hammer / pen: no overflow in 4 M world-steps
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)                      # adroit_hammer.py:231-233
@@ -72,6 +76,23 @@ class AdroitVecEnv(GoalVecEnv):
         # (grx_adroit_sample_resets_device, bit-equal to numpy), and the fp64 rows get_env_state reports live in HBM next to them.  The pen's draws go through
         # euler2quat (sin / cos: no bit-exact device twin of numpy's libm) and stay per-world numpy generators on the host, staged through pinned memory.
         self._device_draws = self.task_name in ("hammer", "door", "relocate")
+        # Overlapped same-step reset (include/grx_capi.h, grx_adroit_commit_rows): the Adroit tasks never terminate, so the worlds a step truncates are known before its launch;
+        # their draws and the reset-time forward pass (0.4 ms: one world's dependent chain, in line behind a 12 ms step kernel) run on a side stream beside the step kernel into
+        # staged rows, one small kernel commits them behind it.  Only where the draws are made on the device.  GRX_ADROIT_AHEAD_RESET=0: the in-line path (A/B, tests).
+        self._ahead = None
+        if self._device_draws and self.num_envs > 1 and os.environ.get("GRX_ADROIT_AHEAD_RESET", "1") != "0":
+            A = dict(qpos=self._init_qpos.expand(n, -1).contiguous(), qvel=z(n, self.nv), qacc_ws=z(n, self.nv), shift=self.shift.clone(), obs=z(n, self.obs_dim), reward=z(n),
+                     success=z(n, dtype=torch.uint8), status=z(n, dtype=torch.int32))
+            if self.target is not None:
+                A["target"] = z(n, 3)
+            self._ahead = A
+            b = _native.AdroitBuffersStruct()
+            for name in ("qpos", "qvel", "qacc_ws", "shift", "obs", "reward", "success", "status"):
+                setattr(b, name, A[name].data_ptr())
+            b.target = A["target"].data_ptr() if "target" in A else None
+            b.action, b.act_mean, b.act_rng, b.mask = self.action.data_ptr(), self._act_mean.data_ptr(), self._act_rng.data_ptr(), None
+            self._ahead_bufs = b
+            self._ahead_stream = torch.cuda.Stream(device=d)
         if self._device_draws:
             self._edit_dev = torch.from_numpy(np.tile(np.asarray(edit0, dtype=np.float64), (n, 1))).to(d)
             self._target_dev = torch.zeros(n, 3, dtype=torch.float64, device=d) if self.task_name == "relocate" else None
@@ -172,6 +193,41 @@ class AdroitVecEnv(GoalVecEnv):
             self.target[ti] = tr[:, 7:10]
         return ti
 
+    def _launch_reset_ahead(self, idx, after):
+        """draws + init rows + forward pass of the listed worlds on the side stream, into the staged rows; `after`: an event of the caller's stream recorded BEFORE the step
+        launch (the previous commit read the staged rows; queued behind the step launch the forward's workgroups take wave slots its first finished worlds free)"""
+        A, k = self._ahead, len(idx)
+        self._ahead_stream.wait_event(after)
+        with torch.cuda.stream(self._ahead_stream):
+            ti = self._stage(np.asarray(idx, dtype=np.int64))
+            _native.check(self._L.grx_adroit_sample_resets_device(
+                self._rng_dev.data_ptr(), ti.data_ptr(), k, int(self.task.kind), self._shift_pos0.ctypes.data, self._edit_dev.data_ptr(),
+                None if self._target_dev is None else self._target_dev.data_ptr(), A["shift"].data_ptr(), A["target"].data_ptr() if "target" in A else None, self._stream()))
+            A["qpos"][ti] = self._init_qpos
+            A["qvel"].index_fill_(0, ti, 0.0)
+            A["qacc_ws"].index_fill_(0, ti, 0.0)
+            b = self._ahead_bufs
+            b.compact, b.n_compact = ti.data_ptr(), k
+            _native.check(self._L.grx_adroit_step(self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, 1, self._stream()))
+            done = torch.cuda.Event()
+            done.record(self._ahead_stream)
+        return ti, done
+
+    def _commit_ahead(self, ahead, idx):
+        """behind the step kernel and the lane's launches: the staged rows replace the live ones (grx_adroit_commit_rows)"""
+        ti, done = ahead
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(done)
+        A = self._ahead
+        p = lambda t: None if t is None else t.data_ptr()
+        a = _native.AdroitCommitArgsStruct(ti.data_ptr(), len(idx), self.nq, self.nv, self.obs_dim, A["qpos"].data_ptr(), A["qvel"].data_ptr(), A["qacc_ws"].data_ptr(),
+                                           A["shift"].data_ptr(), p(A.get("target")), A["obs"].data_ptr(), A["status"].data_ptr(),
+                                           self.qpos.data_ptr(), self.qvel.data_ptr(), self.qacc_ws.data_ptr(), self.shift.data_ptr(), p(self.target), self.obs.data_ptr(), self.status.data_ptr())
+        _native.check(self._L.grx_adroit_commit_rows(ctypes.byref(a), self._stream()))
+        ti.record_stream(main)      # allocated under the side stream, read by the commit on this one
+        self._elapsed[idx] = 0
+        self._needs_reset[idx] = False
+
     def _reset_worlds(self, idx):
         if len(idx) == 0:
             return None
@@ -187,9 +243,14 @@ class AdroitVecEnv(GoalVecEnv):
         self.qpos[ti] = self._init_qpos
         self.qvel.index_fill_(0, ti, 0.0)      # (x[ti] = 0.0 would upload a host scalar: a synchronising copy)
         self.qacc_ws.index_fill_(0, ti, 0.0)
-        self.mask.zero_()
-        self.mask.index_fill_(0, ti, 1)
-        self._launch(self._bufs_masked, True)
+        if self._compact_resets:     # one workgroup per listed world (grx_adroit_buffers.compact) instead of a masked launch over all N
+            b = self._make_bufs(None)
+            b.compact, b.n_compact = ti.data_ptr(), len(idx)
+            self._launch(b, True)
+        else:
+            self.mask.zero_()
+            self.mask.index_fill_(0, ti, 1)
+            self._launch(self._bufs_masked, True)
         self._elapsed[idx] = 0
         self._needs_reset[idx] = False
         return ti
@@ -219,12 +280,20 @@ class AdroitVecEnv(GoalVecEnv):
         info = {}
         with torch.cuda.device(self.device):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
+            will, ahead = np.zeros(0, np.int64), None
+            if self._ahead is not None and self.autoreset_mode == "same_step" and self.max_episode_steps is not None:
+                will = np.nonzero(self._elapsed + 1 >= self.max_episode_steps)[0]      # the worlds this step truncates: the Adroit tasks have no other episode end
+                if len(will):
+                    before = torch.cuda.Event()
+                    before.record(torch.cuda.current_stream(self.device))
             if len(pending):
                 self.mask.fill_(1)
                 self.mask.index_fill_(0, self._stage_idx(pending), 0)      # (pinned staging + index_fill_: nothing here waits for the running kernel)
                 self._launch(self._bufs_masked, False)
             else:
                 self._launch(self._bufs, False)
+            if len(will):
+                ahead = self._launch_reset_ahead(will, before)
             stepped = ~self._needs_reset
             self._elapsed[stepped] += 1
             truncated = np.zeros(self.num_envs, bool)
@@ -235,6 +304,14 @@ class AdroitVecEnv(GoalVecEnv):
                 tp = self._reset_worlds(pending)
                 self.reward.index_fill_(0, tp, 0.0)
             if self.autoreset_mode == "same_step" and truncated.any():
+                done = np.nonzero(truncated)[0]
+                if ahead is not None:
+                    if not np.array_equal(will, done):
+                        raise RuntimeError("overlapped reset: the worlds reset ahead of the step are not the ones it truncated")
+                    torch.cuda.current_stream(self.device).wait_event(ahead[1])      # (the index list was uploaded on the side stream)
+                    info["final_obs"] = self.obs[ahead[0]] if self.output == "torch" else self.obs[ahead[0]].double().cpu().numpy()
+                    self._commit_ahead(ahead, done)
+            if self.autoreset_mode == "same_step" and truncated.any() and ahead is None:
                 done = np.nonzero(truncated)[0]
                 td = self._stage(done)
                 info["final_obs"] = self.obs[td].clone() if self.output == "torch" else self.obs[td].double().cpu().numpy()

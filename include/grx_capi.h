@@ -199,6 +199,9 @@ typedef struct grx_adroit_buffers {
   int* status;                     /* [N] */
   const unsigned char* mask;       /* [N] or NULL */
   grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane and its LIMITS */
+  const int64_t* compact;          /* [n_compact] device world indices or NULL: a launch of n_compact workgroups, workgroup j handles world compact[j] (the reset-time forward pass of the ~0.5 %
+                                      of the worlds an env.step() resets: a masked launch over all N worlds spends 0.5 ms dispatching workgroups that return at once) */
+  int n_compact;
 } grx_adroit_buffers;
 
 /* mirrors struct GrxKitchenTask / GrxKitchenBuffers (csrc/grx_kitchen_task.h): FrankaKitchen-v1 */
@@ -383,6 +386,20 @@ typedef struct grx_fetch_commit_args {
   float *qpos, *qvel, *qacc_ws, *mocap, *aux, *goal, *obs, *achieved, *packed, *final_packed; int* status;
 } grx_fetch_commit_args;
 int grx_fetch_commit_rows(const grx_fetch_commit_args* args, void* stream);
+
+/* Commit of an overlapped Adroit reset (envs/adroit.py; hammer / door / relocate, whose reset_model draws are made on the device).  The Adroit tasks never terminate
+ * (adroit_hammer.py:291-329 returns terminated = False), so the worlds a step truncates are known before it is launched: the draws (grx_adroit_sample_resets_device writing the
+ * STAGED shift / target rows -- the running step still reads the finished episode's), init rows and the reset-time forward pass (grx_adroit_step, forward_only, `compact` list, a
+ * second grx_adroit_buffers over staged [N, ...] arrays) run on a side stream beside the step kernel; this call, behind it, copies the staged qpos / qvel / qacc_ws / shift /
+ * target / obs rows of world idx[j] over the live ones and ORs the forward pass's status flags into the sticky half of the world's status word.  reward / success / the step's
+ * own status flags stay those of the finished episode (same-step autoreset).  Bit-identical to the in-line reset (tests/test_gpu_adroit.py).  Device pointers. */
+typedef struct grx_adroit_commit_args {
+  const int64_t* idx; int k;
+  int nq, nv, obs_dim;
+  const float *s_qpos, *s_qvel, *s_qacc_ws, *s_shift, *s_target, *s_obs; const int* s_status;    /* shift / target pairs may be NULL (no shift group / not relocate) */
+  float *qpos, *qvel, *qacc_ws, *shift, *target, *obs; int* status;
+} grx_adroit_commit_args;
+int grx_adroit_commit_rows(const grx_adroit_commit_args* args, void* stream);
 
 /* Host-side reset sampling: replaces the numpy PCG64 draws of _reset_sim / _sample_goal (fetch/fetch_env.py:153-166,388-391)
  * for the listed worlds, bit-exactly.  states: [n_total,4] uint64 = (state_hi, state_lo, inc_hi, inc_lo) of each world's

@@ -172,3 +172,60 @@ def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):
             assert torch.equal(e.qpos, envs[2].qpos) and torch.equal(e.qvel, envs[2].qvel) and torch.equal(o[0], outs[2][0]) and torch.equal(o[1], outs[2][1]), t
             assert torch.equal(e.status & 0xFFFF, envs[2].status & 0xFFFF)
     assert entered >= 3, entered      # the rollout does push worlds over the fast kernel's tables
+
+
+@pytest.mark.parametrize("task", ["hammer", "door", "pen", "relocate"])
+def test_compacted_reset_launch_is_the_masked_one(monkeypatch, task):
+    """The reset-time forward pass as one workgroup per reset world (grx_adroit_buffers.compact, the default) against the masked launch over all N worlds
+    (GRX_ADROIT_COMPACT_RESET=0): staggered same-step autoresets, state rows, observations, rewards and status words bit-identical after every step."""
+    import torch
+
+    n, horizon = 256, 20
+    envs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("GRX_ADROIT_COMPACT_RESET", on)
+        e = _env(n, ENV_ID[task], output="torch", autoreset_mode="same_step", max_episode_steps=horizon)
+        e.reset(seed=7)
+        e._elapsed[:] = (np.arange(n) * 3) % 17      # phases 17 .. 19 are empty: some steps reset no world
+        envs.append(e)
+    assert envs[0]._compact_resets and not envs[1]._compact_resets
+    assert torch.equal(envs[0].obs, envs[1].obs) and float(envs[0].obs.abs().max()) > 0.1      # reset(): the compacted launch covers every world
+    g = torch.Generator(device="cuda:0"); g.manual_seed(2)
+    for t in range(50):
+        a = torch.rand(n, envs[0].single_action_space.shape[0], device="cuda:0", generator=g) * 2 - 1
+        (o0, r0, _, tr0, _), (o1, r1, _, tr1, _) = [e.step(a) for e in envs]
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(tr0, tr1), t
+        for name in ("qpos", "qvel", "qacc_ws", "shift", "status"):
+            assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), (t, name)
+
+
+@pytest.mark.parametrize("task,output", [("hammer", "torch"), ("hammer", "numpy"), ("door", "torch"), ("relocate", "torch")])
+def test_overlapped_reset_is_the_inline_reset(monkeypatch, task, output):
+    """Same-step autoreset of the device-draw tasks, two ways: draws + forward pass of the worlds a step will truncate on a side stream beside the step kernel, committed
+    behind it (grx_adroit_commit_rows, the default), against the in-line reset (GRX_ADROIT_AHEAD_RESET=0).  Staggered episodes, 70 steps = three or four resets per world:
+    state rows, per-world model edits (shift / target rows, the fp64 edit rows), outputs, status words, PCG64 streams and info["final_obs"] bit-identical after every step."""
+    import torch
+
+    n, horizon = 256, 20
+    envs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("GRX_ADROIT_AHEAD_RESET", on)
+        e = _env(n, ENV_ID[task], output=output, autoreset_mode="same_step", max_episode_steps=horizon)
+        e.reset(seed=7)
+        e._elapsed[:] = (np.arange(n) * 3) % 17
+        envs.append(e)
+    assert envs[0]._ahead is not None and envs[1]._ahead is None
+    g = torch.Generator(device="cuda:0"); g.manual_seed(2)
+    eq = torch.equal if output == "torch" else np.array_equal
+    resets = 0
+    for t in range(70):
+        a = torch.rand(n, envs[0].single_action_space.shape[0], device="cuda:0", generator=g) * 2 - 1
+        (o0, r0, _, tr0, i0), (o1, r1, _, tr1, i1) = [e.step(a if output == "torch" else a.cpu().numpy()) for e in envs]
+        assert eq(o0, o1) and eq(r0, r1) and eq(tr0, tr1) and eq(i0["success"], i1["success"]), t
+        assert ("final_obs" in i0) == ("final_obs" in i1)
+        if "final_obs" in i0:
+            resets += 1
+            assert eq(i0["final_obs"], i1["final_obs"]), t
+        for name in ("qpos", "qvel", "qacc_ws", "shift", "obs", "reward", "success", "status", "_rng_dev", "_edit_dev") + (("target", "_target_dev") if task == "relocate" else ()):
+            assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), (t, name)
+    assert 50 <= resets < 70
