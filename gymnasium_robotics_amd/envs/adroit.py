@@ -78,9 +78,9 @@ class AdroitVecEnv(GoalVecEnv):
         self._device_draws = self.task_name in ("hammer", "door", "relocate")
         # Overlapped same-step reset (include/grx_capi.h, grx_adroit_commit_rows): the Adroit tasks never terminate, so the worlds a step truncates are known before its launch;
         # their draws and the reset-time forward pass (0.4 ms: one world's dependent chain, in line behind a 12 ms step kernel) run on a side stream beside the step kernel into
-        # staged rows, one small kernel commits them behind it.  Only where the draws are made on the device.  GRX_ADROIT_AHEAD_RESET=0: the in-line path (A/B, tests).
+        # staged rows, one small kernel commits them behind it (AdroitHandPen: the host draws, made at the same point of every world's stream, travel through pinned memory).  GRX_ADROIT_AHEAD_RESET=0: the in-line path (A/B, tests).
         self._ahead = None
-        if self._device_draws and self.num_envs > 1 and os.environ.get("GRX_ADROIT_AHEAD_RESET", "1") != "0":
+        if self.num_envs > 1 and os.environ.get("GRX_ADROIT_AHEAD_RESET", "1") != "0":
             A = dict(qpos=self._init_qpos.expand(n, -1).contiguous(), qvel=z(n, self.nv), qacc_ws=z(n, self.nv), shift=self.shift.clone(), obs=z(n, self.obs_dim), reward=z(n),
                      success=z(n, dtype=torch.uint8), status=z(n, dtype=torch.int32))
             if self.target is not None:
@@ -199,10 +199,16 @@ class AdroitVecEnv(GoalVecEnv):
         A, k = self._ahead, len(idx)
         self._ahead_stream.wait_event(after)
         with torch.cuda.stream(self._ahead_stream):
-            ti = self._stage(np.asarray(idx, dtype=np.int64))
-            _native.check(self._L.grx_adroit_sample_resets_device(
-                self._rng_dev.data_ptr(), ti.data_ptr(), k, int(self.task.kind), self._shift_pos0.ctypes.data, self._edit_dev.data_ptr(),
-                None if self._target_dev is None else self._target_dev.data_ptr(), A["shift"].data_ptr(), A["target"].data_ptr() if "target" in A else None, self._stream()))
+            if self._device_draws:
+                ti = self._stage(np.asarray(idx, dtype=np.int64))
+                _native.check(self._L.grx_adroit_sample_resets_device(
+                    self._rng_dev.data_ptr(), ti.data_ptr(), k, int(self.task.kind), self._shift_pos0.ctypes.data, self._edit_dev.data_ptr(),
+                    None if self._target_dev is None else self._target_dev.data_ptr(), A["shift"].data_ptr(), A["target"].data_ptr() if "target" in A else None, self._stream()))
+            else:      # (AdroitHandPen: the target orientation, adroit_pen.py:379-383 -- libm calls with no bit-exact device twin)
+                d = sample_reset_batch(self.task_name, [self.np_randoms[w] for w in idx], self.model)
+                self._model_edit[idx] = d["edit"]
+                ti, tr = self._stage(np.asarray(idx, dtype=np.int64), np.asarray(d["shift"], dtype=np.float32).reshape(k, 7))
+                A["shift"][ti] = tr
             A["qpos"][ti] = self._init_qpos
             A["qvel"].index_fill_(0, ti, 0.0)
             A["qacc_ws"].index_fill_(0, ti, 0.0)

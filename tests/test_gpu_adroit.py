@@ -199,7 +199,7 @@ def test_compacted_reset_launch_is_the_masked_one(monkeypatch, task):
             assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), (t, name)
 
 
-@pytest.mark.parametrize("task,output", [("hammer", "torch"), ("hammer", "numpy"), ("door", "torch"), ("relocate", "torch")])
+@pytest.mark.parametrize("task,output", [("hammer", "torch"), ("hammer", "numpy"), ("door", "torch"), ("relocate", "torch"), ("pen", "torch")])
 def test_overlapped_reset_is_the_inline_reset(monkeypatch, task, output):
     """Same-step autoreset of the device-draw tasks, two ways: draws + forward pass of the worlds a step will truncate on a side stream beside the step kernel, committed
     behind it (grx_adroit_commit_rows, the default), against the in-line reset (GRX_ADROIT_AHEAD_RESET=0).  Staggered episodes, 70 steps = three or four resets per world:
@@ -226,6 +226,9 @@ def test_overlapped_reset_is_the_inline_reset(monkeypatch, task, output):
         if "final_obs" in i0:
             resets += 1
             assert eq(i0["final_obs"], i1["final_obs"]), t
-        for name in ("qpos", "qvel", "qacc_ws", "shift", "obs", "reward", "success", "status", "_rng_dev", "_edit_dev") + (("target", "_target_dev") if task == "relocate" else ()):
+        for name in ("qpos", "qvel", "qacc_ws", "shift", "obs", "reward", "success", "status") + (("_rng_dev", "_edit_dev") if task != "pen" else ()) + (("target", "_target_dev") if task == "relocate" else ()):
             assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), (t, name)
+        assert np.array_equal(envs[0].model_edit, envs[1].model_edit), t
+        if task == "pen":
+            assert all(a_.bit_generator.state == b_.bit_generator.state for a_, b_ in zip(envs[0].np_randoms[::37], envs[1].np_randoms[::37])), t
     assert 50 <= resets < 70
