@@ -138,8 +138,12 @@ def sq_mix(tag, workload=None):
                 if kernel in row.get("Kernel_Name", "") and int(float(row.get("Grid_Size") or 0)) == full_grid:
                     acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     lines = [f"rocprofv3 --pmc {' '.join(SQ_COUNTERS)} --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline {' '.join(extra)}  (MI355X, build '{tag}')",
-             f"means over the last 12 full-grid launches of {kernel} (the timed region):"]
-    mean = {k: sum(v[-12:]) / len(v[-12:]) for k, v in acc.items() if v}
+             f"means over the last 12 full-grid STEP launches of {kernel} (the timed region; masked full-grid forward passes of resets are recognised by their wave cycles and left out):"]
+    # a reset-time forward pass launched over the full grid with a mask (the kitchen's device-resident reset mask) carries the step kernel's name and grid but a tiny share
+    # of its work: averaged in, it halved every count (round 5 found the kitchen's and -- before its resets were compacted -- the hammer's VALU fraction reported at half)
+    wave = acc.get("SQ_WAVE_CYCLES", [])[-24:]
+    steps = [i for i, x in enumerate(wave) if x >= 0.5 * max(wave)][-12:] if wave else []
+    mean = {k: sum(v[-24:][i] for i in steps) / len(steps) for k, v in acc.items() if v and steps and len(v[-24:]) == len(wave)}
     for k in SQ_COUNTERS:
         lines.append(f"  {k:22s} {mean[k]:16.0f}" if k in mean else f"  {k:22s} (not collected)")
     wc = mean.get("SQ_WAVE_CYCLES")
