@@ -320,10 +320,117 @@ def run_rank_mixed(args, rank, world_size, local_rank):
     return line
 
 
+# ---------------------------------------------------------------------------------------------- out-of-phase sub-batches (--stages K)
+def run_rank_stages(args, rank, world_size, local_rank):
+    """`--stages K`: the rank's worlds as K sub-batches on K streams (gymnasium_robotics_amd.pipeline.PipelinedVecEnv), walked round-robin by one host thread that
+    only enqueues.  One "step" = one env.step() of EVERY stage (all n worlds advance once), with everything the plain workload has in its timed region (resets, the
+    overflow re-runs, HER append + relabel per stage, the per-stage gather on more than one rank).  The stages drift out of phase, so the tail of one stage's step
+    launch -- a launch ends when its slowest world does -- is filled by the next stage's worlds."""
+    from gymnasium_robotics_amd.pipeline import PipelinedVecEnv
+
+    if args.dry_run:
+        raise SystemExit("--stages has no --dry-run twin")
+    w, K = WORKLOADS[args.workload], args.stages
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+    n = args.worlds_per_gpu or w["worlds"]
+    pe = PipelinedVecEnv(w["env_id"], n, stages=K, device=device, seed_offset=rank * n, output="torch", autoreset_mode="same_step")
+    m = pe.stage_size
+    pe.reset(seed=0)
+    her = args.workload == "fetch"
+    gens, replays, gathered = [], [], []
+    for k, env in enumerate(pe.stage_envs):
+        with pe.on(k):
+            if args.stagger:
+                _set_elapsed(env, (np.arange(m) + k * m) % (env.max_episode_steps or w["horizon"]))
+            g = torch.Generator(device=device)
+            g.manual_seed(1234 + rank * K + k)
+            gens.append(g)
+            rows = getattr(env, "packed", None)
+            rows = env.obs if rows is None else rows
+            gathered.append(torch.empty(m * world_size, rows.shape[1], device=device) if dist else None)
+            if her:
+                from gymnasium_robotics_amd.her import HerReplay
+
+                r = HerReplay(env, horizon=w["horizon"], capacity=HER_K * m * 8, seed=rank * K + k, continuous=True)
+                r.begin_episode(env.packed)
+                r.set_episode_start(-env._elapsed)
+                replays.append(r)
+    act_dim = pe.single_action_space.shape[0]
+
+    def one_step():
+        for k, env in enumerate(pe.stage_envs):
+            with pe.on(k):
+                a = torch.rand(m, act_dim, device=device, generator=gens[k]) * 2 - 1
+                obs, r, term, trunc, info = env.step(a)
+                if her:
+                    replays[k].append(a, env.packed, term | trunc, final_rows=env.final_packed)
+                    replays[k].relabel(HER_K * m, k_future=HER_K)
+                if dist:
+                    rows = getattr(env, "packed", None)
+                    dist.all_gather_into_tensor(gathered[k], env.obs if rows is None else rows)
+
+    preroll = (pe.max_episode_steps or w["horizon"]) if args.preroll < 0 else args.preroll
+    for _ in range(preroll + args.warmup):
+        one_step()
+    for env in pe.stage_envs:
+        env.clear_status()
+        env.kernel_events = []
+        if hasattr(env, "step_events"):
+            env.step_events = []
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for env in pe.stage_envs for a, b in env.kernel_events]))
+    counts = [env.status_counts() for env in pe.stage_envs]
+    line = None
+    if rank == 0:
+        achieved = w["algo"] * m / (max(kern_ms, 1e-9) * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/s (whole node)", "value": n * world_size * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w['env_id']}, {n} worlds/GPU x {world_size} GPU as {K} out-of-phase sub-batches of {m} worlds on {K} streams (one host thread, enqueue only; "
+                                   f"one step = one env.step() of every sub-batch), uniform random actions, same-step autoreset at the time limit "
+                                   f"({'episodes staggered' if args.stagger else 'episodes in lock-step'})"
+                                   + (f", sparse reward + on-device HER relabel + replay write per sub-batch ({HER_K} transitions per world and step)" if her else ""),
+                       "worlds_per_gpu": n, "stages": K, "preroll_steps": preroll,
+                       "parallelism": f"world-shard x{world_size}" + (", one RCCL all_gather of kernel-packed output rows per sub-batch and step" if world_size > 1 else ""),
+                       "capacity_overflow_worlds": sum(c["con_overflow"] + c["efc_overflow"] for c in counts), "badnum_worlds": sum(c["badnum"] for c in counts)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "kernel": w["kernel"], "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": w["algo"] * m,
+                         "note": f"kernel_ms = mean duration of a sub-batch's step launch ({m} worlds) WHILE the other sub-batches share the GPU: K launches overlap, so K x kernel_ms exceeds "
+                                 "ms_per_step; the single-batch line (no --stages) carries the PMC traffic and the VALU issue fraction of the kernel"},
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+    if dist:
+        dist.destroy_process_group()
+    return line
+
+
 # ---------------------------------------------------------------------------------------------- one rank
 def run_rank(args, rank, world_size, local_rank):
     if args.workload == "mixed":
         return run_rank_mixed(args, rank, world_size, local_rank)
+    if args.stages > 1:
+        return run_rank_stages(args, rank, world_size, local_rank)
     w = WORKLOADS[args.workload]
     dry = args.dry_run
     device = "cpu" if dry else f"cuda:{local_rank}"
@@ -485,6 +592,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["mixed"], default="fetch")
+    ap.add_argument("--stages", type=int, default=1, help="K > 1: the rank's worlds as K out-of-phase sub-batches on K streams (gymnasium_robotics_amd.pipeline; not for --workload mixed)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU, no physics: random rows on the CPU over gloo -- checks the multi-rank plumbing of this exact command line")
     args = ap.parse_args()
 

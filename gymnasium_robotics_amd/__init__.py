@@ -15,7 +15,7 @@ Nothing here imports torch or loads the HIP library until an environment is cons
 """
 from typing import List
 
-__all__ = ["make_vec", "registered_env_ids", "env_family", "UnsupportedEnvError"]
+__all__ = ["make_vec", "registered_env_ids", "env_family", "UnsupportedEnvError", "PipelinedVecEnv"]
 
 
 class UnsupportedEnvError(KeyError):
@@ -104,3 +104,11 @@ def make_vec(env_id: str, num_envs: int = 1, **kwargs):
     else:
         from .envs.point_maze import AntMazeVecEnv as cls
     return cls(env_id, num_envs=num_envs, **kwargs)
+
+
+def __getattr__(name):      # (lazy: the pipeline module is only needed by callers that step sub-batches out of phase)
+    if name == "PipelinedVecEnv":
+        from .pipeline import PipelinedVecEnv
+
+        return PipelinedVecEnv
+    raise AttributeError(name)

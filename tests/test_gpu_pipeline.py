@@ -1,0 +1,47 @@
+"""Out-of-phase sub-batches on the device (gymnasium_robotics_amd/pipeline.py): K stages on K streams give, world by world, what ONE plain environment of the same
+worlds gives -- resets, autoresets, flags included -- whatever the interleaving of the stages."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env_id,stages", [("FetchPickAndPlace-v4", 2), ("FetchPickAndPlace-v4", 4), ("AdroitHandHammer-v2", 2), ("AntMaze_UMaze-v5", 2)])
+def test_stages_equal_the_plain_environment(env_id, stages):
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    n, dev = 256, "cuda:0"
+    kw = dict(device=dev, output="torch", autoreset_mode="same_step", max_episode_steps=12)
+    plain = grx.make_vec(env_id, num_envs=n, **kw)
+    pe = grx.PipelinedVecEnv(env_id, n, stages=stages, **kw)
+    assert pe.stage_size == n // stages and pe.stream(0) is not None and pe.stream(0) != pe.stream(1)
+    o_plain, _ = plain.reset(seed=11)
+    outs = pe.reset(seed=11)
+    pe.synchronize(); torch.cuda.synchronize()
+    rows = lambda o: o["observation"] if isinstance(o, dict) else o
+    for k, (o, _) in enumerate(outs):
+        assert torch.equal(rows(o), rows(o_plain)[pe.world_slice(k)]), k
+    phase = (np.arange(n) * 5) % 11
+    plain._elapsed[:] = phase
+    for k, e in enumerate(pe.stage_envs):
+        e._elapsed[:] = phase[pe.world_slice(k)]
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    na = plain.single_action_space.shape[0]
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        a = torch.rand(n, na, device=dev, generator=g) * 2 - 1
+        torch.cuda.synchronize()      # (the actions were drawn on the default stream)
+        o0, r0, te0, tr0, i0 = plain.step(a)
+        res = {}
+        for k in rng.permutation(stages):      # any order: the stages are independent
+            res[int(k)] = pe.step_stage(int(k), a[pe.world_slice(int(k))])
+        pe.synchronize(); torch.cuda.synchronize()
+        for k in range(stages):
+            o, r, te, tr, i = res[k]
+            sl = pe.world_slice(k)
+            assert torch.equal(rows(o), rows(o0)[sl]) and torch.equal(r, r0[sl]) and torch.equal(tr, tr0[sl]) and torch.equal(te, te0[sl]), (t, k)
+            if isinstance(o, dict):
+                assert torch.equal(o["achieved_goal"], o0["achieved_goal"][sl]) and torch.equal(o["desired_goal"], o0["desired_goal"][sl]), (t, k)
+            assert torch.equal(pe.stage_envs[k].qpos, plain.qpos[sl]) and torch.equal(pe.stage_envs[k].status & 0xFFFF, plain.status[sl] & 0xFFFF), (t, k)
