@@ -334,10 +334,11 @@ def run_rank_stages(args, rank, world_size, local_rank):
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world_size > 1:
+    if world_size > 1 or os.environ.get("GRX_BENCH_FORCE_DIST"):      # (the env var runs the collective leg on a single rank, as in run_rank)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
     n = args.worlds_per_gpu or w["worlds"]
     pe = PipelinedVecEnv(w["env_id"], n, stages=K, device=device, seed_offset=rank * n, output="torch", autoreset_mode="same_step")
