@@ -368,21 +368,21 @@ class FetchVecEnv(GoalVecEnv):
             self.action.copy_(torch.from_numpy(a), non_blocking=True)
         with torch.cuda.device(self.device):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
-            ahead = None
+            ahead, will, before = None, np.zeros(0, np.int64), None
             if self._ahead is not None and self.autoreset_mode == "same_step" and self.max_episode_steps is not None:
                 will = np.nonzero(self._elapsed + 1 >= self.max_episode_steps)[0]      # the worlds this step truncates: Fetch has no other episode end (compute_terminated)
-                if len(will) and not self._ahead_late:
-                    ahead = (will, self._launch_reset_ahead(will))
-                elif len(will):
+                if len(will) and self._ahead_late:      # the side stream waits for what is queued NOW, not for the step launch that follows
                     before = torch.cuda.Event()
                     before.record(torch.cuda.current_stream(self.device))
+                elif len(will):
+                    ahead = (will, self._launch_reset_ahead(will))
             if len(pending):
                 self.mask.fill_(1)
                 self.mask.index_fill_(0, self._stage_idx(pending), 0)      # (pinned staging + index_fill_: nothing here waits for the running kernel)
                 self._launch_step(self._bufs_masked)
             else:
                 self._launch_step(self._bufs)
-            if ahead is None and self._ahead is not None and self._ahead_late and self.autoreset_mode == "same_step" and self.max_episode_steps is not None and len(will):
+            if before is not None:
                 ahead = (will, self._launch_reset_ahead(will, after=before))      # queued behind the step launch: its workgroups take the slots the first finished worlds free
             stepped = ~self._needs_reset if len(pending) else np.ones(self.num_envs, bool)
             self._elapsed[stepped] += 1

@@ -38,7 +38,7 @@ def kernel_stats(tag, workload=None):
     """workload: one of bench.py's --workload names (antmaze, hand_touch, hand_reach): kernel stats of that BASELINE config instead of cfg 2"""
     suffix = f"_{workload}" if workload else ""
     d = os.path.join(OUT, f"rocprof_{tag}{suffix}")
-    extra = ["--workload", workload] if workload else []
+    extra = (["--workload", workload] if workload else []) + os.environ.get("GRX_COLLECT_STATS_EXTRA", "").split()      # (e.g. "--stages 2": rename the summary afterwards)
     cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "bench", "--", sys.executable, os.path.join(ROOT, "bench.py"),
            "--steps", "100", "--warmup", "10", "--no-cpu-baseline"] + extra     # bench.py's own defaults: the averages are over the same launches
     run(cmd, os.path.join(OUT, f"rocprof_{tag}{suffix}.log"))
