@@ -6,7 +6,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("env_id,stages", [("FetchPickAndPlace-v4", 2), ("FetchPickAndPlace-v4", 4), ("AdroitHandHammer-v2", 2), ("AntMaze_UMaze-v5", 2)])
+@pytest.mark.parametrize("env_id,stages", [("FetchPickAndPlace-v4", 2), ("FetchPickAndPlace-v4", 4), ("AdroitHandHammer-v2", 2), ("AntMaze_UMaze-v5", 2), ("FrankaKitchen-v1", 2), ("HandReach-v3", 2),
+                                            ("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", 2)])
 def test_stages_equal_the_plain_environment(env_id, stages):
     import torch
 
@@ -43,5 +44,9 @@ def test_stages_equal_the_plain_environment(env_id, stages):
             sl = pe.world_slice(k)
             assert torch.equal(rows(o), rows(o0)[sl]) and torch.equal(r, r0[sl]) and torch.equal(tr, tr0[sl]) and torch.equal(te, te0[sl]), (t, k)
             if isinstance(o, dict):
-                assert torch.equal(o["achieved_goal"], o0["achieved_goal"][sl]) and torch.equal(o["desired_goal"], o0["desired_goal"][sl]), (t, k)
+                for key in ("achieved_goal", "desired_goal"):
+                    if isinstance(o[key], dict):      # the kitchen: one entry per task
+                        assert all(torch.equal(torch.as_tensor(o[key][name]), torch.as_tensor(o0[key][name])[sl]) for name in o[key]), (t, k, key)
+                    else:
+                        assert torch.equal(o[key], o0[key][sl]), (t, k, key)
             assert torch.equal(pe.stage_envs[k].qpos, plain.qpos[sl]) and torch.equal(pe.stage_envs[k].status & 0xFFFF, plain.status[sl] & 0xFFFF), (t, k)
