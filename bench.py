@@ -16,6 +16,9 @@ wave64 VALU instructions per second against the chip's issue peak (SQ_INSTS_VALU
 PMC bytes / algorithmic bytes.
 
 One "step" = one env.step() of all worlds = ONE launch of the family's step kernel (+ the HER reward kernel for cfg 2).
+`--stages K` steps the rank's worlds as K out-of-phase sub-batches on K streams instead (gymnasium_robotics_amd.pipeline; one "step" = one env.step() of every sub-batch): +10 - 25 % from the same
+kernels.  The plain 1-GPU line reports that mode BESIDE its value (`sub_batches`: the same worlds and timed region, K = 2, measured right after the plain region) -- `value` itself is always the
+plain vector environment.
 --workload selects the other BASELINE configs under the same contract and the same JSON schema:
     fetch       cfg 2  FetchPickAndPlace-v4, 4096 worlds / GPU
     hand_touch  cfg 3  HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1, 16384 worlds / GPU
@@ -30,6 +33,9 @@ One "step" = one env.step() of all worlds = ONE launch of the family's step kern
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import os as _os
+
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call: streams that share a hardware queue serialise (the sub-batch legs keep 4 - 6 streams busy; no effect on the plain lines: profiles/ab_r05_hw_queues.txt)
 import json
 import os
 import socket
@@ -568,10 +574,26 @@ def run_rank(args, rank, world_size, local_rank):
             line["dist"] = dist_report
         if dry:
             line["data"] = "DRY RUN: no physics, random rows on the CPU over gloo (plumbing check of the multi-rank command line)"
-        if world_size == 1 and not args.no_cpu_baseline and not dry:
-            line["cpu_baseline"] = cpu_baseline(args.workload)
     if dist:
         dist.destroy_process_group()
+    # The same worlds as two out-of-phase sub-batches (run_rank_stages), measured in the same process right after the plain line: reported BESIDE
+    # `value`, never as it -- `value` stays env.step() over all worlds of one vector environment, the configuration BASELINE.json names.
+    if line is not None and world_size == 1 and not dist and not dry and args.sub_batches and not args.no_cpu_baseline and args.workload != "hand_touch":      # (like cpu_baseline: a reporting extra of the full line; the A/B and profiling tools pass --no-cpu-baseline)
+        try:
+            import copy
+
+            del env, replay
+            torch.cuda.empty_cache()
+            a2 = copy.copy(args)
+            a2.stages, a2.no_cpu_baseline = 2, True
+            l2 = run_rank_stages(a2, rank, world_size, local_rank)
+            line["sub_batches"] = {"stages": 2, "value": l2["value"], "ms_per_step": l2["ms_per_step"], "capacity_overflow_worlds": l2["config"]["capacity_overflow_worlds"],
+                                   "note": "the same worlds, timed region and step count as `value`, stepped as 2 out-of-phase sub-batches on 2 streams (python bench.py --stages 2; "
+                                           "gymnasium_robotics_amd.pipeline.PipelinedVecEnv): for callers that act on half a batch at a time"}
+        except Exception as e:      # the extra leg must never cost the line
+            line["sub_batches"] = {"error": repr(e)}
+    if line is not None and world_size == 1 and not args.no_cpu_baseline and not dry:      # (last: its worker processes load the host)
+        line["cpu_baseline"] = cpu_baseline(args.workload)
     return line
 
 
@@ -593,6 +615,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["mixed"], default="fetch")
+    ap.add_argument("--no-sub-batches", dest="sub_batches", action="store_false", help="skip the extra leg that reports the same worlds stepped as 2 out-of-phase sub-batches beside `value` (1 GPU, and only when the CPU baseline leg runs too)")
     ap.add_argument("--stages", type=int, default=1, help="K > 1: the rank's worlds as K out-of-phase sub-batches on K streams (gymnasium_robotics_amd.pipeline; not for --workload mixed)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU, no physics: random rows on the CPU over gloo -- checks the multi-rank plumbing of this exact command line")
     args = ap.parse_args()
