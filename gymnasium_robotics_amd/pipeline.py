@@ -71,6 +71,22 @@ class PipelinedVecEnv:
         with self.on(k):
             return self.stage_envs[k].step(actions)
 
+    def get_state(self):
+        """checkpoint of every stage (GoalVecEnv.get_state: everything that determines the future at a step boundary); synchronises"""
+        out = []
+        for k, e in enumerate(self.stage_envs):
+            with self.on(k):
+                out.append(e.get_state())
+        return {"stages": out, "num_envs": self.num_envs, "env_id": self.env_id}
+
+    def set_state(self, state):
+        if state.get("num_envs") != self.num_envs or state.get("env_id") != self.env_id or len(state.get("stages", ())) != self.num_stages:
+            raise ValueError(f"checkpoint of {state.get('env_id')!r} with {state.get('num_envs')} worlds in {len(state.get('stages', ()))} stages does not fit "
+                             f"{self.env_id!r} with {self.num_envs} worlds in {self.num_stages} stages")
+        for k, (e, st) in enumerate(zip(self.stage_envs, state["stages"])):
+            with self.on(k):
+                e.set_state(st)
+
     def synchronize(self):
         for s in self._streams or ():
             s.synchronize()

@@ -21,6 +21,13 @@ class _Stage:
     def close(self):
         self.closed = True
 
+    def get_state(self):
+        return {"steps": self.steps, "off": self.seed_offset}
+
+    def set_state(self, st):
+        assert st["off"] == self.seed_offset
+        self.steps = st["steps"]
+
 
 def test_stages_are_the_plain_environments_worlds():
     import gymnasium_robotics_amd as grx
@@ -36,6 +43,13 @@ def test_stages_are_the_plain_environments_worlds():
     with pe.on(2):
         o, *_ , info = pe.step_stage(2, np.zeros(4))
     assert np.array_equal(o, np.full(4, 108.0)) and info["stage_steps"] == 1 and [e.steps for e in pe.stage_envs] == [0, 0, 1]
+    ck = pe.get_state()
+    pe.step_stage(0, np.zeros(4)); pe.step_stage(2, np.zeros(4))
+    pe.set_state(ck)
+    assert [e.steps for e in pe.stage_envs] == [0, 0, 1]
+    other = grx.PipelinedVecEnv("FetchPickAndPlace-v4", 12, stages=2, device="cpu", make_stage=_Stage)
+    with pytest.raises(ValueError, match="does not fit"):
+        other.set_state(ck)
     pe.synchronize(); pe.close()
     assert all(e.closed for e in pe.stage_envs)
 

@@ -50,3 +50,34 @@ def test_stages_equal_the_plain_environment(env_id, stages):
                     else:
                         assert torch.equal(o[key], o0[key][sl]), (t, k, key)
             assert torch.equal(pe.stage_envs[k].qpos, plain.qpos[sl]) and torch.equal(pe.stage_envs[k].status & 0xFFFF, plain.status[sl] & 0xFFFF), (t, k)
+
+
+def test_checkpoint_of_a_staged_environment():
+    """get_state / set_state of the stages: save -> 12 steps -> restore -> the same 12 steps repeat bit for bit (autoresets inside)"""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    n, dev = 128, "cuda:0"
+    pe = grx.PipelinedVecEnv("FetchPickAndPlace-v4", n, stages=2, device=dev, output="torch", autoreset_mode="same_step", max_episode_steps=9)
+    pe.reset(seed=3)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    acts = [torch.rand(n, 4, device=dev, generator=g) * 2 - 1 for _ in range(16)]
+    torch.cuda.synchronize()
+
+    def run(lo, hi):
+        out = []
+        for t in range(lo, hi):
+            for k in range(2):
+                with pe.on(k):      # (the copies are ordered behind the step on the stage's stream)
+                    o, r, *_ = pe.step_stage(k, acts[t][pe.world_slice(k)])
+                    out.append((o["observation"].clone(), r.clone()))
+        pe.synchronize()
+        return out
+
+    run(0, 4)
+    ck = pe.get_state()
+    first = run(4, 16)
+    pe.set_state(ck)
+    again = run(4, 16)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(first, again))
