@@ -19,6 +19,8 @@
  *   grx_maze_sample_resets_device ... np_random.integers / uniform draws of MazeEnv.reset       maze/maze_v4.py:299-358
  *   grx_adroit_sample_resets_device . np_random.uniform draws of the Adroit reset_model methods  adroit_hammer.py:374-376, adroit_door.py:362-370, adroit_relocate.py:353-372
  *   grx_fetch_sample_resets[_device] . np_random.uniform draws of _reset_sim/_sample_goal  fetch/fetch_env.py:153-166,388-391 (host / on the device)
+ *   grx_fetch_commit_rows ........... commit of a Fetch reset that ran BESIDE the step kernel into staged rows      fetch/fetch_env.py:375-402, envs/robot_env.py:154-186
+ *   grx_adroit_commit_rows .......... the same for the Adroit tasks (reset_model + mj_forward on staged rows)       adroit_hammer.py:372-378, adroit_door.py:359-371, adroit_pen.py:379-397, adroit_relocate.py:354-373
  *
  * All array arguments are plain device (HBM) pointers; rows are world-major.  `stream` is a
  * hipStream_t passed as void*.  Every function returns 0 on success, a negative value on error
