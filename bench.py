@@ -103,11 +103,12 @@ class _DryEnv:
     kernels -- launcher, rendezvous, world sharding by seed_offset, the per-step collective on the kernel-written rows, timing, the per-rank report, the JSON
     line -- runs in a GPU-less container over gloo (tests/test_cpu_dist.py) with the exact command line the driver uses on the 8-GPU node."""
 
-    def __init__(self, workload, n, rank):
+    def __init__(self, workload, n, rank, seed_offset=None):
         import types
 
         w = WORKLOADS[workload]
-        self.num_envs, self.max_episode_steps, self.seed_offset = n, w["horizon"], rank * n
+        self.num_envs, self.max_episode_steps, self.seed_offset = n, w["horizon"], rank * n if seed_offset is None else seed_offset
+        self.device = "cpu"
         act = {"fetch": 4, "antmaze": 8, "kitchen": 9, "hand_reach": 20, "hand_touch": 20}.get(workload, 28)
         self.single_action_space = types.SimpleNamespace(shape=(act,))
         width = {"fetch": 33, "antmaze": 33, "hand_reach": 95, "hand_touch": 169, "kitchen": 59}.get(workload, 46)
@@ -119,7 +120,7 @@ class _DryEnv:
         self.kernel_events = None
         self._gen = torch.Generator().manual_seed(rank)
 
-    def reset(self, seed=None):
+    def reset(self, seed=None, options=None):
         return None, {}
 
     def step(self, a):
@@ -334,23 +335,31 @@ def run_rank_stages(args, rank, world_size, local_rank):
     launch -- a launch ends when its slowest world does -- is filled by the next stage's worlds."""
     from gymnasium_robotics_amd.pipeline import PipelinedVecEnv
 
-    if args.dry_run:
-        raise SystemExit("--stages has no --dry-run twin")
+    dry = args.dry_run      # no GPU, no physics: _DryEnv stages on the CPU over gloo (the multi-rank plumbing of this command line, tests/test_cpu_dist.py)
     w, K = WORKLOADS[args.workload], args.stages
-    device = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
+    device = "cpu" if dry else f"cuda:{local_rank}"
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    if not dry:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1 or os.environ.get("GRX_BENCH_FORCE_DIST"):      # (the env var runs the collective leg on a single rank, as in run_rank)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
     n = args.worlds_per_gpu or w["worlds"]
-    pe = PipelinedVecEnv(w["env_id"], n, stages=K, device=device, seed_offset=rank * n, output="torch", autoreset_mode="same_step")
+    if dry:
+        pe = PipelinedVecEnv(w["env_id"], n, stages=K, device="cpu", seed_offset=rank * n,
+                             make_stage=lambda env_id, num_envs, device=None, seed_offset=0, **kw: _DryEnv(args.workload, num_envs, rank, seed_offset=seed_offset))
+    else:
+        pe = PipelinedVecEnv(w["env_id"], n, stages=K, device=device, seed_offset=rank * n, output="torch", autoreset_mode="same_step")
     m = pe.stage_size
     pe.reset(seed=0)
-    her = args.workload == "fetch"
+    her = args.workload == "fetch" and not dry
     gens, replays, gathered = [], [], []
     for k, env in enumerate(pe.stage_envs):
         with pe.on(k):
@@ -384,6 +393,8 @@ def run_rank_stages(args, rank, world_size, local_rank):
                     dist.all_gather_into_tensor(gathered[k], env.obs if rows is None else rows)
 
     preroll = (pe.max_episode_steps or w["horizon"]) if args.preroll < 0 else args.preroll
+    if dry:
+        preroll = min(preroll, 3)
     for _ in range(preroll + args.warmup):
         one_step()
     for env in pe.stage_envs:
@@ -393,20 +404,29 @@ def run_rank_stages(args, rank, world_size, local_rank):
             env.step_events = []
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for env in pe.stage_envs for a, b in env.kernel_events]))
+    kern_ms = float(np.mean([0.0 if dry else a.elapsed_time(b) for env in pe.stage_envs for a, b in env.kernel_events]))
     counts = [env.status_counts() for env in pe.stage_envs]
+    dist_report = None
+    if dist:
+        from gymnasium_robotics_amd.parallel import rank_stats
+
+        dist_report = rank_stats({"kernel_ms": kern_ms, "elapsed_s": own_elapsed}, device)
+        if dry:      # stage k of rank r holds the worlds r * n + k * m ... : every gathered matrix must list them rank by rank
+            for k in range(K):
+                want = torch.cat([torch.arange(m, dtype=torch.float32) + r_ * n + k * m for r_ in range(world_size)])
+                assert torch.equal(gathered[k][:, 0], want), f"gathered rows of sub-batch {k} are not in world order"
     line = None
     if rank == 0:
         achieved = w["algo"] * m / (max(kern_ms, 1e-9) * 1e-3) / 1e9
@@ -425,7 +445,11 @@ def run_rank_stages(args, rank, world_size, local_rank):
                          "note": f"kernel_ms = mean duration of a sub-batch's step launch ({m} worlds) WHILE the other sub-batches share the GPU: K launches overlap, so K x kernel_ms exceeds "
                                  "ms_per_step; the single-batch line (no --stages) carries the PMC traffic and the VALU issue fraction of the kernel"},
         }
-        if not args.no_cpu_baseline and world_size == 1:
+        if dist_report is not None:
+            line["dist"] = dist_report
+        if dry:
+            line["data"] = "DRY RUN: no physics, random rows on the CPU over gloo (plumbing check of the multi-rank command line)"
+        if not args.no_cpu_baseline and world_size == 1 and not dry:
             line["cpu_baseline"] = cpu_baseline(args.workload)
     if dist:
         dist.destroy_process_group()

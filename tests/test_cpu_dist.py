@@ -94,7 +94,8 @@ def test_sharded_env_equals_the_unsharded_one():
     assert len({tuple(row[25:28]) for row in ref[0]}) == n_total      # four different worlds (different object positions), in seed order
 
 
-@pytest.mark.parametrize("workload,ranks,extra", [("antmaze", 8, ["--worlds-per-gpu", "64"]), ("mixed", 2, ["--worlds-per-gpu", "64"]), ("fetch", 2, ["--worlds-per-gpu", "32"])])
+@pytest.mark.parametrize("workload,ranks,extra", [("antmaze", 8, ["--worlds-per-gpu", "64"]), ("mixed", 2, ["--worlds-per-gpu", "64"]), ("fetch", 2, ["--worlds-per-gpu", "32"]),
+                                                  ("fetch", 2, ["--worlds-per-gpu", "32", "--stages", "2"])])      # (the last: out-of-phase sub-batches, one gather per sub-batch)
 def test_bench_multi_rank_command_line_dry_run(workload, ranks, extra):
     """The command the driver runs on the 8-GPU node (`python bench.py --gpus N ...`), with --dry-run: no GPU, no physics (random rows on the CPU), gloo instead
     of RCCL -- everything else is the real code path: the launcher, the rendezvous on 127.0.0.1, world sharding, the per-step all-gather of the rows (checked to
