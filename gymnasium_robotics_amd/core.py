@@ -90,6 +90,20 @@ class GoalVecEnv:
     def close(self):
         pass
 
+    # ---- frames: the device rows live in the compiled model's (workspace-centred) world frame, the reference / the oracle / fixtures in the MJCF's (mjcf.CompiledModel.origin)
+    def load_world_rows(self, rows=None, **more):
+        """Overwrite state rows ([N, width] arrays, one per name: qpos, qvel, qacc_ws, mocap, aux, goal, ...) with values given in the MJCF's WORLD frame -- what `MjData` holds in
+        the reference, what the oracle and the golden fixtures record.  World positions inside `qpos` / `mocap` are moved into the model's frame in fp64 and rounded once."""
+        import torch
+
+        for k, v in {**(rows or {}), **more}.items():
+            t = getattr(self, k)
+            t.copy_(torch.from_numpy(np.ascontiguousarray(self.model.rows_from_world(k, v)).astype(np.float32)).to(t.device))
+
+    def world_rows(self, key):
+        """the device rows `key` as an fp64 array in the MJCF's world frame (synchronises)"""
+        return self.model.rows_to_world(key, getattr(self, key).double().cpu().numpy())
+
     def _stage_idx(self, idx):
         """index list -> int64 device tensor through pinned memory, enqueued and never waited for (a `.to(device)` of a pageable array is a synchronising copy: issued behind
         a step kernel it makes the host wait for that kernel)"""

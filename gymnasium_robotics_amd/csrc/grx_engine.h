@@ -95,6 +95,9 @@ struct GrxModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, neq, npair, ndevpair, nmpair, maxdepth, eulerdamp, anydamp, nfric, nweld, integrator, njump, wpool, ntendon, maxefc, jpool, ntouch, maxcon, twospan, nconvex, nfreeobj, ngridgeom, ngridwall, gridnx, gridny, handtree, nmeshpair, nshift, noslip_iterations, iterations, njeq, ngate;
   float timestep, gravity[3], meaninertia, impratio, mpr_tolerance, gridx0, gridy0, gridinv, noslip_tolerance;
   int mpr_iterations;
+  // MJCF coordinates of this model's world origin (include/grx_model.h GRX_ORIGIN_*; zeros for a model compiled in the MJCF's own frame).  The engine never reads it: it works in
+  // the model's frame.  The task code adds it back, in fp64, to every world position it writes out (grx_world_out below).
+  double origin[3];
   // derived at model creation (grx_host_model.h), not part of the compiled blob: per hull vertex 16 records of 4 floats -- the vertex itself (x, y, z, degree; degree -1 when
   // it has more than 15 hull neighbours) and its hull neighbours (x, y, z, local id) -- so that a GUESSED support vertex is verified with ONE coalesced fetch (grx_mesh_support)
   const float* mesh_nbr;
@@ -311,6 +314,8 @@ GRX_HD int grx_ctx_words(const GrxDims d) { return grx_ctx_words(d.nq, d.nv, d.n
 // ------------------------------------------------------------------------------------------
 // small math (all per-lane, registers)
 // ------------------------------------------------------------------------------------------
+// a world position of the model's (workspace-centred) frame -> the MJCF's world frame, rounded once to the output type
+GRX_DEV float grx_world_out(float x, double origin) { return (float)((double)x + origin); }
 GRX_DEV float dot3f(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 GRX_DEV void cross3f(float* r, const float* a, const float* b) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];

@@ -109,8 +109,9 @@ struct GrxHand {
       FOR_LANES {
         for (int i = lane; i < nr; i += 64) { obs[i] = c->qpos[i]; obs[nr + i] = c->qvel[i]; }
         for (int i = lane; i < 6; i += 64) obs[2 * nr + i] = c->qvel[t->obj_dadr + i];
-        for (int i = lane; i < 7; i += 64) { const float v = c->qpos[t->obj_qadr + i]; obs[2 * nr + 6 + i] = v; achieved[i] = v; }
-        for (int i = lane; i < 3; i += 64) palm[i] = c->xpos[3 * t->palm_body + i];
+        // the object's position leaves the engine in the MJCF's world frame (origin added in fp64, grx_engine.h grx_world_out); the quaternion as it is
+        for (int i = lane; i < 7; i += 64) { const float q = c->qpos[t->obj_qadr + i], v = i < 3 ? grx_world_out(q, m->origin[i]) : q; obs[2 * nr + 6 + i] = v; achieved[i] = v; }
+        for (int i = lane; i < 3; i += 64) palm[i] = grx_world_out(c->xpos[3 * t->palm_body + i], m->origin[i]);
       }
       WAVE_SYNC();
       if (t->touch_mode) E::grx_touch_sensors(m, c, obs + 2 * nr + 13, t->touch_mode, lane_);   // same forward pass as the contacts
@@ -121,10 +122,10 @@ struct GrxHand {
       for (int i = lane; i < nv; i += 64) obs[nq + i] = c->qvel[i];
       for (int i = lane; i < 3 * GRX_HAND_NTIPS; i += 64) {
         const int k = i / 3, e = i - 3 * k;
-        const float v = c->sxpos[3 * t->site[k] + e];
+        const float v = grx_world_out(c->sxpos[3 * t->site[k] + e], m->origin[e]);
         obs[nq + nv + i] = v; achieved[i] = v;
       }
-      for (int i = lane; i < 3; i += 64) palm[i] = c->xpos[3 * t->palm_body + i];
+      for (int i = lane; i < 3; i += 64) palm[i] = grx_world_out(c->xpos[3 * t->palm_body + i], m->origin[i]);
     }
     WAVE_SYNC();
   }

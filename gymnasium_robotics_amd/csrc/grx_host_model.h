@@ -195,6 +195,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.gravity[0] = (float)v.opt[GRX_GRAVITY_X]; m.gravity[1] = (float)v.opt[GRX_GRAVITY_Y]; m.gravity[2] = (float)v.opt[GRX_GRAVITY_Z];
   m.meaninertia = (float)v.opt[GRX_MEANINERTIA]; m.impratio = (float)v.opt[GRX_IMPRATIO];
   m.mpr_tolerance = (float)v.opt[GRX_MPR_TOLERANCE]; m.mpr_iterations = (int)v.opt[GRX_MPR_ITERATIONS];
+  m.origin[0] = v.opt[GRX_ORIGIN_X]; m.origin[1] = v.opt[GRX_ORIGIN_Y]; m.origin[2] = v.opt[GRX_ORIGIN_Z];
 }
 
 // model view whose tables live at (fbase, ibase)

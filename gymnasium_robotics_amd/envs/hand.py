@@ -31,11 +31,17 @@ GOAL_DIM = 15
 HAND_REACH_COMPILE = dict(keep_sites=["robot0:S_fftip", "robot0:S_mftip", "robot0:S_rftip", "robot0:S_lftip", "robot0:S_thtip"], capacity={"maxcon": 16, "maxefc": 96, "jpool": 512})
 
 
+# World origin of the compiled hand models (MJCF coordinates): the hand mount sits at (1, 1.25, 0.15) (assets/hand/robot.xml:3), the object starts at (1, 0.87, 0.2)
+# (manipulate_block.xml:27), so every position of the palm's workspace is within 0.3 m of this point: an fp32 ulp of 1.5e-8 .. 3e-8 m instead of 1.2e-7
+# (compile_mjcf(origin=...); measured on the fixtures: touch forces 79 % -> 100 % within 1e-4 ABSOLUTE, velocity medians 1.0e-5 -> 2.5e-6: profiles/origin_r06_emu.txt)
+HAND_ORIGIN = (1.0, 1.0, 0.2)
+
+
 def load_hand_reach_model(assets_root: Optional[str] = None) -> CompiledModel:
     """hand/reach.xml compiled from MJCF when an asset tree is given (assets_root / $GRX_ASSETS_ROOT), else the packaged blob."""
     assets_root = assets_root or os.environ.get("GRX_ASSETS_ROOT")
     if assets_root:
-        return compile_mjcf(os.path.join(assets_root, "hand", "reach.xml"), **HAND_REACH_COMPILE)
+        return compile_mjcf(os.path.join(assets_root, "hand", "reach.xml"), origin=HAND_ORIGIN, **HAND_REACH_COMPILE)
     path = os.path.join(_MODELS_DIR, "hand_reach.npz")
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist")
@@ -386,7 +392,7 @@ def load_hand_block_model(assets_root: Optional[str] = None, touch: bool = False
     if assets_root:
         xml = OBJECTS[obj]["xml"] + ("_touch_sensors.xml" if touch else ".xml")
         # the task reads no site (manipulate.py:298-316 use qpos / qvel only): none is tracked by the engine
-        return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None, keep_sites=[],
+        return compile_mjcf(os.path.join(assets_root, "hand", xml), mutate=drop_target_body, touch_filter=touch_filter if touch else None, keep_sites=[], origin=HAND_ORIGIN,
                             capacity=dict(HAND_MANIP_CAPACITY, jpool=928) if touch else HAND_MANIP_CAPACITY)   # touch keeps contact data out of the overlay: same 16 LDS granules with a slightly smaller pool
     path = os.path.join(_MODELS_DIR, f"hand_{obj}_touch.npz" if touch else f"hand_{obj}.npz")
     if not os.path.exists(path):
@@ -451,8 +457,23 @@ class HandBlockVecEnv(HandReachVecEnv):
         self._initial_qpos = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32)).to(self.device)
         self._initial_qpos_host = torch.from_numpy(self.model.tables["qpos0"].astype(np.float32))
         self._qa = int(self.task.obj_qadr)
-        self._obj0 = self.model.tables["qpos0"][self._qa: self._qa + 7].astype(np.float64)
+        # The model's world frame is palm-centred (load_hand_block_model: HAND_ORIGIN): the qpos ROWS hold the object's position relative to model.origin, in fp32;
+        # the reference's arithmetic on object positions (reset pose, on-palm test, goal) is done here in fp64 in the MJCF's frame, _obj_rows / _obj_world convert.
+        self._origin = self.model.origin
+        self._obj0 = self._obj_world(self.model.tables["qpos0"][self._qa: self._qa + 7].astype(np.float64)[None])[0]
         self.reset_attempts = np.zeros(self.num_envs, np.int64)
+
+    def _obj_world(self, rows):
+        """object pose rows [k, 7] of the device state (model frame) -> fp64 poses in the MJCF's world frame"""
+        out = np.array(rows, dtype=np.float64)
+        out[:, :3] += self._origin
+        return out
+
+    def _obj_rows(self, poses):
+        """fp64 object poses [k, 7] in the MJCF's world frame -> float32 rows of the device state (model frame); the subtraction is done in fp64"""
+        out = np.array(poses, dtype=np.float64)
+        out[:, :3] -= self._origin
+        return out.astype(np.float32)
 
     # manipulate.py:154-224 (_reset_sim: pose randomisation, ten settle steps with a zero action, on-palm test, retried until it
     # holds -- robot_env.py:163-171) and :226-279 (_sample_goal from the settled pose).  The reference does not call mj_resetData
@@ -476,7 +497,7 @@ class HandBlockVecEnv(HandReachVecEnv):
                                                    self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"])
             ti = torch.from_numpy(pending).to(self.device)
             q = self._initial_qpos.unsqueeze(0).repeat(len(pending), 1)
-            q[:, self._qa: self._qa + 7] = torch.from_numpy(poses.astype(np.float32)).to(self.device)
+            q[:, self._qa: self._qa + 7] = torch.from_numpy(self._obj_rows(poses)).to(self.device)
             self.qpos[ti] = q
             self.qvel.index_fill_(0, ti, 0.0)
             self.action.zero_()
@@ -484,7 +505,7 @@ class HandBlockVecEnv(HandReachVecEnv):
             self.mask.index_fill_(0, ti, 1)
             for _ in range(SETTLE_STEPS):
                 self._launch(self._bufs_masked, False, settle=True)
-            z = self.qpos[ti, self._qa + 2].cpu().numpy()
+            z = self.qpos[ti, self._qa + 2].double().cpu().numpy() + self._origin[2]
             pending = pending[~(z > PALM_HEIGHT)]
         self.action.copy_(saved_action)
 
@@ -492,7 +513,7 @@ class HandBlockVecEnv(HandReachVecEnv):
         from .manipulate_spec import sample_block_goal_batch
 
         ti = torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.device)
-        obj = self.qpos[ti, self._qa: self._qa + 7].double().cpu().numpy()
+        obj = self._obj_world(self.qpos[ti, self._qa: self._qa + 7].double().cpu().numpy())
         goals = sample_block_goal_batch([self.np_randoms[w] for w in idx], obj, self.target_position, self.target_rotation, self._pquats)
         self.goal[ti] = torch.from_numpy(goals.astype(np.float32)).to(self.device)
         gd = self.goal.shape[1]   # the settle launches wrote the packed rows against the PREVIOUS goal: the reset row carries the new one
@@ -557,7 +578,7 @@ class HandBlockVecEnv(HandReachVecEnv):
         poses = sample_reset_object_pose_batch([self.np_randoms[w] for w in worlds], self._obj0[:3], self._obj0[3:], self.target_position, self.target_rotation,
                                                self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"])
         q = self._initial_qpos_host.unsqueeze(0).repeat(k, 1)
-        q[:, self._qa: self._qa + 7] = torch.from_numpy(poses.astype(np.float32))
+        q[:, self._qa: self._qa + 7] = torch.from_numpy(self._obj_rows(poses))
         side = self._side[c["due_at"] % 3]
         with torch.cuda.stream(side):
             side.wait_event(c["ready"])
@@ -586,7 +607,7 @@ class HandBlockVecEnv(HandReachVecEnv):
         lo, k, ar, side = c["lo"], c["k"], self._ar, self._side[c["due_at"] % 3]
         with torch.cuda.stream(side):
             c["event"].synchronize()      # (started CHAIN_LOOKAHEAD steps ago: normally long done)
-            obj = c["obj_host"][:k].numpy().astype(np.float64)      # the fp32 rows the kernel wrote, widened on the host (what .double() did on the device)
+            obj = self._obj_world(c["obj_host"][:k].numpy())      # the fp32 rows the kernel wrote, widened on the host (what .double() did on the device), in the MJCF's frame
             ok = obj[:, 2] > PALM_HEIGHT
             if ok.any():
                 goals = sample_block_goal_batch([self.np_randoms[w] for w in c["worlds"][ok]], obj[ok], self.target_position, self.target_rotation, self._pquats)

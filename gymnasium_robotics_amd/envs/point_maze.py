@@ -71,10 +71,12 @@ class PointMazeVecEnv(GoalVecEnv):
             raise RuntimeError("PointMazeVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
         self.device = torch.device(device or "cuda:0")
         self.maze = Maze(maze_map, *self.MAZE_GEOMETRY)
-        # a maze whose ONLY reset cell is also its only goal cell: the reference's generate_reset_pos (maze/maze_v4.py:400-418) redraws the reset cell until it is farther than
-        # half a cell from the goal and would never return; refused here, loudly, instead of spinning (host draws) or being cut short (the device loop is bounded)
+        # a maze whose ONLY reset cell is also its only goal cell: the reference's generate_reset_pos (maze/maze_v4.py:284-297, 400-418) redraws the reset CELL CENTRE until it is
+        # farther than half a cell from the noisy goal and would never return; refused here, loudly, instead of spinning (host draws) or being cut short (the device loop is
+        # bounded).  Two DISTINCT cells are at least one cell pitch apart, so the centre of the reset cell is >= 0.75 cells from a goal that carries <= 0.25 cells of noise:
+        # the reference's loop ends on its first draw there (an 'r' cell next to a 'g' cell is a valid maze).
         ug, ur = np.asarray(self.maze.unique_goal_locations, dtype=np.float64).reshape(-1, 2), np.asarray(self.maze.unique_reset_locations, dtype=np.float64).reshape(-1, 2)
-        if len(ur) == 1 and len(ug) == 1 and np.linalg.norm(ur[0] - ug[0]) <= 0.5 * self.maze.maze_size_scaling + 2 * 0.25 * self.maze.maze_size_scaling:
+        if len(ur) == 1 and len(ug) == 1 and np.linalg.norm(ur[0] - ug[0]) < 0.5 * self.maze.maze_size_scaling:
             raise ValueError("this maze has a single reset cell that is also its single goal cell: a reset position farther than half a cell from the goal does not exist")
         self.model = model or load_point_maze_model(self.maze, layout, assets_root, self.AGENT)
         self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")

@@ -56,7 +56,8 @@ DIMS = [
     "eulerdamp", "ntree", "maxdepth", "maxefc_req", "jpool_req", "maxcon_req",
 ]
 NDIMS = 32
-OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia", "mpr_tolerance", "mpr_iterations", "noslip_tolerance"]
+OPTS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia", "mpr_tolerance", "mpr_iterations", "noslip_tolerance",
+        "origin_x", "origin_y", "origin_z"]
 NOPTS = 16
 
 
@@ -264,6 +265,78 @@ class CompiledModel:
     def pack(self):
         return pack_blob(self.tables)
 
+    @property
+    def origin(self) -> np.ndarray:
+        """MJCF coordinates of the compiled model's world origin (compile_mjcf(origin=...)); zeros for a model compiled in the MJCF's own frame
+        (blobs written before the field existed carry zeros in these opt slots)."""
+        o = self.tables["opt"]
+        return np.array([o[OPTS.index("origin_x")], o[OPTS.index("origin_y")], o[OPTS.index("origin_z")]], dtype=np.float64)
+
+    # ---- frames.  A model compiled with origin != 0 lives in a translated world frame; these helpers are the ONLY place that knows which words of a state row are world positions.
+    def world_columns(self, key: str):
+        """(columns, axes) of the state row `key` ("qpos" | "mocap" | "aux") that hold a world position: the translation of every free joint whose body hangs on the world,
+        the position triple of every mocap body.  Other rows (qvel, warm start, ctrl, goals, ...) carry no absolute position."""
+        t = self.tables
+        cols, axes = [], []
+        if key == "qpos":
+            jt, ja, jb = np.asarray(t["jnt_type"]).reshape(-1), np.asarray(t["jnt_qposadr"]).reshape(-1), np.asarray(t["jnt_bodyid"]).reshape(-1)
+            par = np.asarray(t["body_parent"]).reshape(-1)
+            for j in range(len(jt)):
+                if int(jt[j]) == 0 and int(par[int(jb[j])]) == 0:
+                    cols += [int(ja[j]) + e for e in range(3)]
+                    axes += [0, 1, 2]
+        elif key == "mocap":
+            for k in range(self.dim("nmocap")):
+                cols += [7 * k + e for e in range(3)]
+                axes += [0, 1, 2]
+        elif key == "aux" and self.dim("nmocap"):      # Fetch: pose of gripper_link at the last forward pass (csrc/grx_fetch_task.h GrxFetchBuffers::aux), position first
+            cols, axes = [0, 1, 2], [0, 1, 2]
+        return np.asarray(cols, dtype=np.int64), np.asarray(axes, dtype=np.int64)
+
+    def rows_from_world(self, key: str, values) -> np.ndarray:
+        """state rows given in the MJCF's world frame (what the reference / the oracle / a fixture holds) -> the same rows in THIS model's frame, fp64 (the caller rounds to fp32)"""
+        out = np.array(values, dtype=np.float64)
+        cols, axes = self.world_columns(key)
+        if len(cols) and self.origin.any():
+            out[..., cols] -= self.origin[axes]
+        return out
+
+    def rows_to_world(self, key: str, rows) -> np.ndarray:
+        """inverse of rows_from_world, fp64"""
+        out = np.array(rows, dtype=np.float64)
+        cols, axes = self.world_columns(key)
+        if len(cols) and self.origin.any():
+            out[..., cols] += self.origin[axes]
+        return out
+
+    def in_mjcf_frame(self) -> "CompiledModel":
+        """The same model in the MJCF's own world frame (origin 0): what hangs directly on the world is translated back.  The oracle runs THIS (oracle/oracle_sim.py), so that the
+        checker keeps restating the reference on the reference's own coordinates; tests/test_cpu_origin.py pins it against a compilation with origin 0."""
+        o = self.origin
+        if not o.any():
+            return self
+        m = self.copy()
+        t = m.tables
+        par = np.asarray(t["body_parent"]).reshape(-1)
+        bp = np.array(t["body_pos"], dtype=np.float64).reshape(-1, 3)
+        bp[1:][par[1:] == 0] += o
+        t["body_pos"] = bp.reshape(np.asarray(t["body_pos"]).shape)
+        for pos, bid in (("geom_pos", "geom_bodyid"), ("site_pos", "site_bodyid")):
+            a = np.array(t[pos], dtype=np.float64).reshape(-1, 3)
+            if len(a):
+                a[np.asarray(t[bid]).reshape(-1) == 0] += o
+            t[pos] = a.reshape(np.asarray(t[pos]).shape)
+        if "mocap_pos0" in t and np.asarray(t["mocap_pos0"]).size:
+            t["mocap_pos0"] = np.array(t["mocap_pos0"], dtype=np.float64) + o
+        q0 = np.array(t["qpos0"], dtype=np.float64)
+        cols, axes = self.world_columns("qpos")
+        q0[cols] += o[axes]
+        t["qpos0"] = q0
+        for k, name in enumerate(("origin_x", "origin_y", "origin_z")):
+            t["opt"][OPTS.index(name)] = 0.0
+        m.info["origin"] = [0.0, 0.0, 0.0]
+        return m
+
     def with_capacity(self, **capacity) -> "CompiledModel":
         """Copy of the model with other engine table capacities (maxcon / maxefc / jpool; 0 = engine default).  The capacities are
         requests stored in the dims block, so no recompilation is needed; a model whose capacities match no specialised kernel runs on
@@ -348,9 +421,15 @@ def load_model(path: str) -> CompiledModel:
 # the compiler
 # ----------------------------------------------------------------------------
 class MjcfCompiler:
-    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None, shift_rotates=False):
+    def __init__(self, xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None, shift_rotates=False, origin=None):
         """mutate: optional callable(root_element) applied after <include> expansion, before compilation -- the
-        in-memory equivalent of the reference's Maze.make_maze XML rewrite (envs/maze/maze_v4.py:168-242)."""
+        in-memory equivalent of the reference's Maze.make_maze XML rewrite (envs/maze/maze_v4.py:168-242).
+        origin: world point (MJCF coordinates) that becomes the origin of the COMPILED model's world frame: every direct child of the
+        worldbody (bodies incl. free and mocap bodies, static geoms, sites) is translated by -origin.  Rigid-body physics is translation
+        invariant, fp32 is not: the Shadow hand sits at (1, 1.25, 0.15) in its MJCF (assets/hand/robot.xml:3), where an fp32 position carries
+        an ulp of 1.2e-7 m; in a palm-centred frame the same positions carry 1.5e-8 .. 3e-8.  The value is stored in the model
+        (opt origin_x/y/z, info["origin"]); the task layers add it back in fp64 wherever a world position leaves the engine."""
+        self.origin = np.zeros(3) if origin is None else np.asarray(origin, dtype=np.float64).reshape(3).copy()
         self.xml_path = os.path.abspath(xml_path)
         self.dir = os.path.dirname(self.xml_path)
         self.root = _load_xml(self.xml_path)
@@ -701,6 +780,16 @@ class MjcfCompiler:
             for ch in wb:
                 if ch.tag == "body":
                     self._parse_body(ch, 0, None)
+        if self.origin.any():      # the compiled world frame = the MJCF's translated by -origin: only what hangs directly on the world carries an absolute position
+            if self.shift_rotates:
+                raise NotImplementedError("origin with a rotating shift group (the group turns about the MJCF's world origin)")
+            for g in world.geoms:
+                g.pos = g.pos - self.origin
+            for st in world.sites:
+                st.pos = st.pos - self.origin
+            for b in self.bodies[1:]:
+                if b.parent == 0:
+                    b.pos = b.pos - self.origin
         for b in self.bodies[1:]:
             self._derive_inertia(b)
         return _Lowering(self).run()
@@ -1448,7 +1537,7 @@ class _Lowering:
         for k, v in dict(timestep=c.opt["timestep"], gravity_x=g[0], gravity_y=g[1], gravity_z=g[2],
                          tolerance=c.opt["tolerance"], impratio=c.opt["impratio"], meaninertia=meaninertia,
                          mpr_tolerance=c.opt["mpr_tolerance"], mpr_iterations=c.opt["mpr_iterations"],
-                         noslip_tolerance=c.opt["noslip_tolerance"]).items():
+                         noslip_tolerance=c.opt["noslip_tolerance"], origin_x=c.origin[0], origin_y=c.origin[1], origin_z=c.origin[2]).items():
             optv[OPTS.index(k)] = v
         T.update(
             dims=dims, opt=optv, qpos0=qpos0,
@@ -1686,11 +1775,12 @@ class _Lowering:
         info["nmpair"] = len(mpi)
         info["nbody_full"] = nb
         info["unsupported_pairs"] = int(np.sum(pair_supported == 0))
+        info["origin"] = c.origin.tolist()
         return CompiledModel(T, names, info)
 
 
-def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None, shift_rotates=False) -> CompiledModel:
+def compile_mjcf(xml_path: str, mutate=None, capacity=None, touch_filter=None, keep_sites=None, shift_body=None, shift_rotates=False, origin=None) -> CompiledModel:
     """capacity: optional {"maxefc": rows, "jpool": words, "maxcon": contacts, "split_spans": bool} request for the engine's per-world constraint tables.
     touch_filter: optional callable(sensor name) selecting the <touch> sensors the engine evaluates.
     keep_sites: optional list of site names whose world frames the engine tracks (default: every site of the model)."""
-    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites, shift_body=shift_body, shift_rotates=shift_rotates).compile()
+    return MjcfCompiler(xml_path, mutate=mutate, capacity=capacity, touch_filter=touch_filter, keep_sites=keep_sites, shift_body=shift_body, shift_rotates=shift_rotates, origin=origin).compile()

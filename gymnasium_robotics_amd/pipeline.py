@@ -59,12 +59,35 @@ class PipelinedVecEnv:
         return torch.cuda.stream(self._streams[k])
 
     def reset(self, *, seed=None, options=None):
-        """every stage reset on its own stream; returns [(obs, info)] per stage.  A scalar seed gives world i of the WHOLE batch the seed `seed + i`, as the plain environment does."""
+        """every stage reset on its own stream; returns [(obs, info)] per stage.  A scalar seed gives world i of the WHOLE batch the seed `seed + i`, as the plain environment
+        does (the stages carry their `seed_offset`); a SEQUENCE of seeds -- one per world of the whole batch -- and per-world entries of `options` (_slice_options) are sliced per stage, so that world i gets the i-th seed / option row whatever stage holds it."""
+        import numpy as np
+
+        if seed is not None and not np.isscalar(seed):
+            seed = list(seed)
+            if len(seed) != self.num_envs:
+                raise ValueError(f"reset(seed=<sequence>) needs one seed per world: got {len(seed)}, expected {self.num_envs}")
         out = []
         for k, e in enumerate(self.stage_envs):
+            sl = self.world_slice(k)
+            sd = seed if (seed is None or np.isscalar(seed)) else seed[sl]
+            opt = self._slice_options(options, sl)
             with self.on(k):
-                out.append(e.reset(seed=seed, options=options))
+                out.append(e.reset(seed=sd, options=opt))
         return out
+
+    def _slice_options(self, options, sl):
+        """per-world entries of `options` -- arrays of two or more dimensions whose leading one is num_envs, e.g. the [N, nq] rows of Adroit's options["initial_state_dict"]
+        (adroit_hammer.py:343-345) -- cut to the stage's worlds, nested dicts followed; scalars and vectors (the mazes' 'goal_cell' / 'reset_cell') are shared by every world"""
+        import numpy as np
+
+        if isinstance(options, dict):
+            return {name: self._slice_options(v, sl) for name, v in options.items()}
+        if isinstance(options, (list, tuple, np.ndarray)):
+            a = np.asarray(options)
+            if a.ndim >= 2 and a.shape[0] == self.num_envs:
+                return a[sl]
+        return options
 
     def step_stage(self, k: int, actions):
         """`env.step(actions)` of stage k, enqueued on its stream: (obs, reward, terminated, truncated, info) of its `stage_size` worlds"""

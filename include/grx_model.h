@@ -18,6 +18,10 @@ enum grx_opt {
   GRX_TIMESTEP = 0, GRX_GRAVITY_X, GRX_GRAVITY_Y, GRX_GRAVITY_Z, GRX_TOLERANCE, GRX_IMPRATIO, GRX_MEANINERTIA,
   GRX_MPR_TOLERANCE, GRX_MPR_ITERATIONS,   /* convex (MPR) narrow phase: MuJoCo option mpr_tolerance (1e-6) / mpr_iterations (50) */
   GRX_NOSLIP_TOLERANCE,                    /* MuJoCo option noslip_tolerance (1e-6) */
+  /* WORLD ORIGIN of the compiled model (compile_mjcf(origin=...)): the model's world frame is the MJCF's translated by -origin, so that the fp32 positions of the
+   * workspace (hand: palm, Fetch: table top) are small numbers -- physics is translation invariant, an fp32 ulp is not.  State rows that hold world positions (free-joint
+   * roots, mocap) are in the MODEL's frame; everything that leaves a kernel as a world position (observation, achieved goal) gets the origin added back in fp64. */
+  GRX_ORIGIN_X, GRX_ORIGIN_Y, GRX_ORIGIN_Z,
   GRX_NOPTS = 16
 };
 

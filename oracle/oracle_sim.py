@@ -59,7 +59,9 @@ def lib():
 
 class OracleSim:
     def __init__(self, model):
-        """model: gymnasium_robotics_amd.mjcf.CompiledModel"""
+        """model: gymnasium_robotics_amd.mjcf.CompiledModel.  The oracle always works in the MJCF's own world frame -- the coordinates the reference's
+        MjData holds -- whatever workspace-centred frame the product model was compiled in (CompiledModel.in_mjcf_frame: the identity for origin 0)."""
+        model = model.in_mjcf_frame()
         self.model = model
         H, I, F = model.pack()
         self._L = lib()

@@ -53,6 +53,12 @@ class EmuSim:
         self.achieved = np.zeros(3, np.float32)
         self.status = ctypes.c_int(0)
 
+    def load_world(self, g, i, keys=("qpos", "qvel", "qacc_ws")):
+        """state of fixture snapshot i -- recorded by the oracle in the MJCF's world frame -- into the emulated world's rows, which live in the MODEL's frame
+        (CompiledModel.rows_from_world: the subtraction in fp64, one rounding to fp32)"""
+        for k in keys:
+            getattr(self, k)[:] = self.model.rows_from_world(k, g[k][i])
+
     def set_table(self, name, data):
         data = np.ascontiguousarray(data, dtype=np.float64)
         assert self.L.emu_set_table(ctypes.c_void_p(self.h), name.encode(), data.ctypes.data, data.size) == 0

@@ -8,8 +8,7 @@ for task in ("FetchReach", "FetchPush", "FetchPickAndPlace"):
     n = g["obs"].shape[0]
     env = FetchVecEnv(task + "-v4", num_envs=n, device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
     env.reset(seed=0)
-    for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"):
-        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).cuda())
+    env.load_world_rows({k: g[k] for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal")})
     obs, r, _, _, info = env.step(g["action"])
     err = np.abs(obs["observation"] - g["obs"]).max(axis=1)
     order = np.argsort(-err)[:8]

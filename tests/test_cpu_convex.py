@@ -111,8 +111,7 @@ def test_emulated_egg_step_matches_golden():
     assert g["ncon"].max() >= 4 and (g["ncon"] > 0).mean() > 0.9          # contact-rich fixture
     pos_err, vel_err = [], []
     for i in range(0, g["obs"].shape[0], 2):
-        for k in ("qpos", "qvel", "qacc_ws"):
-            getattr(emu, k)[:] = g[k][i]
+        emu.load_world(g, i, ("qpos", "qvel", "qacc_ws"))
         emu.hand_step(g["action"][i])
         assert emu.status.value == 0
         e = np.abs(emu.hand_obs[:61] - g["obs"][i])
@@ -131,8 +130,7 @@ def test_emulated_egg_touch_matches_golden():
     assert len(model.tables["touch_body"]) == 92
     rel, bits, same = [], [], 0
     for i in range(g["obs"].shape[0]):
-        for k in ("qpos", "qvel", "qacc_ws"):
-            getattr(emu, k)[:] = g[k][i]
+        emu.load_world(g, i, ("qpos", "qvel", "qacc_ws"))
         emu.hand_step(g["action"][i])
         assert emu.status.value == 0
         touch, ref = emu.hand_obs[61:153], g["obs"][i][61:]

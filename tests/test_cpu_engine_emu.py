@@ -29,8 +29,7 @@ def test_emulated_kernel_step_matches_golden(emu_factory, task, stride):
     emu = emu_factory(task)
     worst = 0.0
     for i in range(0, g["obs"].shape[0], stride):
-        for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux"):
-            getattr(emu, k)[:] = g[k][i]
+        emu.load_world(g, i, ("qpos", "qvel", "qacc_ws", "mocap", "aux"))
         emu.step(g["action"][i])
         assert emu.status.value == 0
         e = np.abs(emu.obs - g["obs"][i])
@@ -52,8 +51,7 @@ def test_emulated_kernel_hull_contacts_match_golden(emu_factory):
     emu = emu_factory("FetchPickAndPlace")
     errs, hull = [], g["hull_contacts"] > 0
     for i in range(0, g["obs"].shape[0], 2):
-        for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux"):
-            getattr(emu, k)[:] = g[k][i]
+        emu.load_world(g, i, ("qpos", "qvel", "qacc_ws", "mocap", "aux"))
         emu.step(g["action"][i])
         assert (emu.status.value & ~6) == 0   # no bad number, no solver failure (capacity flags may fire in the folded poses)
         errs.append(np.abs(emu.obs - g["obs"][i]).max())
@@ -84,8 +82,7 @@ def test_emulated_bad_state_resets_world(emu_factory, fetch_models):
     """mj_checkPos/mj_checkVel behaviour: a NaN coordinate resets the world to qpos0 and flags the status word."""
     g = np.load(os.path.join(GOLDEN, "fetch_FetchReach_teacher.npz"))
     emu = emu_factory("FetchReach")
-    for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux"):
-        getattr(emu, k)[:] = g[k][0]
+    emu.load_world(g, 0, ("qpos", "qvel", "qacc_ws", "mocap", "aux"))
     emu.qvel[3] = np.nan
     emu.step(np.zeros(4, np.float32))
     assert emu.status.value & 1  # GRX_ST_BADNUM

@@ -94,8 +94,7 @@ def test_emulated_hand_step_matches_golden(hand_model):
     emu = EmuSim(hand_model, make_hand_task(hand_model))
     errs, tendon_steps, contact_steps = [], 0, 0
     for i in range(0, g["obs"].shape[0], 2):
-        for k in ("qpos", "qvel", "qacc_ws"):
-            getattr(emu, k)[:] = g[k][i]
+        emu.load_world(g, i, ("qpos", "qvel", "qacc_ws"))
         emu.hand_step(g["action"][i])
         assert emu.status.value == 0
         err = np.abs(emu.hand_obs[:63] - g["obs"][i]).max()

@@ -82,8 +82,7 @@ def test_emulated_block_step_matches_golden():
     emu = EmuSim(model, make_block_task(model, "ignore", "xyz", "sparse"))
     pos_err, vel_err = [], []
     for i in range(0, g["obs"].shape[0], 3):
-        for k in ("qpos", "qvel", "qacc_ws"):
-            getattr(emu, k)[:] = g[k][i]
+        emu.load_world(g, i, ("qpos", "qvel", "qacc_ws"))
         emu.hand_step(g["action"][i])
         assert emu.status.value == 0
         e = np.abs(emu.hand_obs[:61] - g["obs"][i])
@@ -110,8 +109,7 @@ def test_emulated_touch_sensors_match_golden():
     emu = EmuSim(model, make_block_task(model, "ignore", "xyz", "sparse", "sensordata"))
     hits, rel = 0, []
     for i in range(g["obs"].shape[0]):
-        for k in ("qpos", "qvel", "qacc_ws"):
-            getattr(emu, k)[:] = g[k][i]
+        emu.load_world(g, i, ("qpos", "qvel", "qacc_ws"))
         emu.hand_step(g["action"][i])
         assert emu.status.value == 0
         touch, ref = emu.hand_obs[61:153], g["obs"][i][61:]
@@ -138,8 +136,7 @@ def test_emulated_pen_step_matches_golden():
     emu = EmuSim(model, task)
     pe_all = []
     for i in range(0, g["obs"].shape[0], 2):
-        for k in ("qpos", "qvel", "qacc_ws"):
-            getattr(emu, k)[:] = g[k][i]
+        emu.load_world(g, i, ("qpos", "qvel", "qacc_ws"))
         emu.hand_step(g["action"][i])
         assert emu.status.value == 0
         e = np.abs(emu.hand_obs[:61] - g["obs"][i])

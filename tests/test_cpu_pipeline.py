@@ -11,7 +11,10 @@ class _Stage:
         self.single_action_space = self.single_observation_space = None
 
     def reset(self, *, seed=None, options=None):
-        self.seeds = None if seed is None else [seed + self.seed_offset + i for i in range(self.num_envs)]
+        # (what every family does: a scalar seed fans out over the stage's worlds with the stage's offset, a sequence is one seed per world of THIS environment)
+        self.seeds = None if seed is None else ([seed + self.seed_offset + i for i in range(self.num_envs)] if np.isscalar(seed) else list(seed))
+        self.options = options
+        assert self.seeds is None or len(self.seeds) == self.num_envs
         return np.asarray(self.seeds, dtype=np.float64), {}
 
     def step(self, a):
@@ -52,6 +55,26 @@ def test_stages_are_the_plain_environments_worlds():
         other.set_state(ck)
     pe.synchronize(); pe.close()
     assert all(e.closed for e in pe.stage_envs)
+
+
+def test_per_world_seeds_and_options_are_sliced_per_stage():
+    """a sequence of seeds (one per world of the whole batch) and per-world option rows reach the stage that holds the world; shared option values reach every stage"""
+    import gymnasium_robotics_amd as grx
+
+    pe = grx.PipelinedVecEnv("AdroitHandHammer-v2", 12, stages=3, device="cpu", make_stage=_Stage)
+    seeds = [1000 + 7 * i for i in range(12)]
+    rows = np.arange(12 * 5, dtype=np.float64).reshape(12, 5)
+    outs = pe.reset(seed=seeds, options={"goal_cell": np.array([3, 4]), "initial_state_dict": {"qpos": rows, "board_pos": rows[:, :3].tolist()}, "flag": True})
+    assert np.array_equal(np.concatenate([o for o, _ in outs]), np.asarray(seeds, dtype=np.float64))      # no stage saw another stage's seeds
+    for k, e in enumerate(pe.stage_envs):
+        sl = pe.world_slice(k)
+        assert np.array_equal(e.options["goal_cell"], [3, 4]) and e.options["flag"] is True
+        assert np.array_equal(e.options["initial_state_dict"]["qpos"], rows[sl]) and np.array_equal(e.options["initial_state_dict"]["board_pos"], rows[sl, :3])
+    with pytest.raises(ValueError, match="one seed per world"):
+        pe.reset(seed=[1, 2, 3])
+    a12 = grx.PipelinedVecEnv("PointMaze_UMaze-v3", 2, stages=2, device="cpu", make_stage=_Stage)      # a 2-vector option with num_envs == 2 is still a shared cell, not per-world rows
+    a12.reset(seed=None, options={"goal_cell": np.array([1, 1])})
+    assert all(np.array_equal(e.options["goal_cell"], [1, 1]) for e in a12.stage_envs)
 
 
 def test_argument_checks():

@@ -13,8 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 def _load(env, g, keys):
     import torch
 
-    for k in keys:
-        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    env.load_world_rows({k: g[k] for k in keys})
 
 
 def test_egg_teacher_forced_step_matches_golden():

@@ -29,8 +29,7 @@ def _load_state(env, g, sel):
     import torch
 
     dev = env.device
-    for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"):
-        getattr(env, k).copy_(torch.from_numpy(g[k][sel].astype(np.float32)).to(dev))
+    env.load_world_rows({k: g[k][sel] for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal")})
 
 
 @pytest.mark.parametrize("task", ["FetchReach", "FetchPush", "FetchPickAndPlace"])
@@ -387,8 +386,7 @@ def test_capacity_overflow_is_rerun_not_truncated():
     outs = []
     for env in (small, trunc, big):
         env.reset(seed=0)
-        for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal"):
-            getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+        env.load_world_rows({k: g[k] for k in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "goal")})
         obs, r, _, _, info = env.step(g["action"])
         outs.append((obs["observation"], r, info["status"], info["status_sticky"], env.qpos.cpu().numpy(), env.qvel.cpu().numpy()))
     redone = np.zeros(n, bool)

@@ -41,8 +41,7 @@ def test_teacher_forced_step_matches_golden(env_and_golden):
     env, g, torch = env_and_golden
     env.reset(seed=0)
     dev = env.device
-    for k in ("qpos", "qvel", "qacc_ws", "goal"):
-        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(dev))
+    env.load_world_rows({k: g[k] for k in ("qpos", "qvel", "qacc_ws", "goal")})
     obs, r, term, trunc, info = env.step(g["action"])
     assert int(info["status"].max()) == 0
     err = np.abs(obs["observation"] - g["obs"]).max(axis=1)

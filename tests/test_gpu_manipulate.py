@@ -23,8 +23,7 @@ def env_and_golden():
 def test_teacher_forced_step_matches_golden(env_and_golden):
     env, g, torch = env_and_golden
     env.reset(seed=0)
-    for k in ("qpos", "qvel", "qacc_ws", "goal"):
-        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    env.load_world_rows({k: g[k] for k in ("qpos", "qvel", "qacc_ws", "goal")})
     obs, r, term, trunc, info = env.step(g["action"])
     assert int(info["status"].max()) == 0
     e = np.abs(obs["observation"] - g["obs"])
@@ -101,8 +100,7 @@ def test_touch_sensor_variants_match_golden():
         obs, _ = env.reset(seed=0)
         assert obs["observation"].shape == (n, 153)                                    # 61 + 92 (SURVEY.md 8(d) cfg 3)
         assert (obs["observation"][:, 61:] > 0).any(axis=1).all()                       # a settled block presses on some zone
-        for k in ("qpos", "qvel", "qacc_ws", "goal"):
-            getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+        env.load_world_rows({k: g[k] for k in ("qpos", "qvel", "qacc_ws", "goal")})
         obs, r, _, _, info = env.step(g["action"])
         assert int(info["status"].max()) == 0
         outs[env_id] = obs["observation"]

@@ -134,8 +134,7 @@ def test_ant_maze_large_teacher_forced_matches_golden():
     n = g["obs"].shape[0]
     env = AntMazeVecEnv("AntMaze_Large_Diverse_GR-v5", num_envs=n, device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
     env.reset(seed=0)
-    for k in ("qpos", "qvel", "qacc_ws", "goal"):
-        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    env.load_world_rows({k: g[k] for k in ("qpos", "qvel", "qacc_ws", "goal")})
     obs, r, term, trunc, info = env.step(g["action"])
     assert int(np.abs(info["status"]).max()) == 0
     e = np.abs(obs["observation"] - g["obs"])

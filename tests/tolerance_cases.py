@@ -49,8 +49,7 @@ def family_errors(name):
     n = g["obs"].shape[0]
     env = grx.make_vec(env_id, num_envs=n, device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
     env.reset(seed=0)
-    for k in keys:
-        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    env.load_world_rows({k: g[k] for k in keys})
     if name == "FrankaKitchen":      # the fixture's recorded noise draws instead of the env's own streams
         noise = torch.from_numpy(g["noise"].astype(np.float32)).to(env.device)
         env._draw_noise = lambda idx=None: env.noise.copy_(noise)
@@ -152,8 +151,7 @@ def horizon_errors(name, horizons=HORIZONS):
     gap = g["activation_gap"]
     env = grx.make_vec(env_id, num_envs=n, device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
     env.reset(seed=0)
-    for k in keys:
-        getattr(env, k).copy_(torch.from_numpy(g[k].astype(np.float32)).to(env.device))
+    env.load_world_rows({k: g[k] for k in keys})
     step_no = [0]
     rows = lambda k: np.minimum(np.arange(n) + k, n - 1)      # worlds past their episode's end keep stepping on some action; they are never compared
     if name == "FrankaKitchen":
@@ -211,8 +209,7 @@ def episode_errors(name):
     T = int(lens.max())
     env = grx.make_vec(env_id, num_envs=len(starts), device="cuda:0", autoreset_mode="disabled", max_episode_steps=None)
     env.reset(seed=0)
-    for k in keys:
-        getattr(env, k).copy_(torch.from_numpy(g[k][starts].astype(np.float32)).to(env.device))
+    env.load_world_rows({k: g[k][starts] for k in keys})
     step_no = [0]
     rows = lambda k: np.minimum(starts + k, n - 1)
     if name == "FrankaKitchen":

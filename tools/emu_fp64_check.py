@@ -90,7 +90,7 @@ def main(lib, tasks):
         h = L.emu_create(H.ctypes.data, I.ctypes.data, F.ctypes.data)
         E, idx = [], list(range(0, g["obs"].shape[0], 3))
         for i in idx:
-            qp, qv, qa, a = f64(g["qpos"][i]), f64(g["qvel"][i]), f64(g["qacc_ws"][i]), f64(g["action"][i])
+            qp, qv, qa, a = f64(m.rows_from_world("qpos", g["qpos"][i])), f64(g["qvel"][i]), f64(g["qacc_ws"][i]), f64(g["action"][i])
             st = ctypes.c_int(0)
             if kind == "kitchen":
                 obs, last, nz, done = np.zeros(g["obs"].shape[1]), f64(g["last_qpos"][i]), f64(g["noise"][i]), ctypes.c_int(0)
@@ -102,7 +102,7 @@ def main(lib, tasks):
                                   ctypes.byref(suc), ctypes.byref(st), ctypes.c_int(0))
                 err = np.abs(obs - g["obs"][i])
             elif kind == "fetch":
-                obs, ach, mocap, aux = np.zeros(g["obs"].shape[1]), np.zeros(3), f64(g["mocap"][i]), f64(g["aux"][i])
+                obs, ach, mocap, aux = np.zeros(g["obs"].shape[1]), np.zeros(3), f64(m.rows_from_world("mocap", g["mocap"][i])), f64(m.rows_from_world("aux", g["aux"][i]))
                 L.emu_fetch_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(mocap), p(aux), p(a), p(obs), p(ach), ctypes.byref(st))
                 err = np.abs(obs - g["obs"][i])
             else:

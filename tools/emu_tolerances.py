@@ -72,7 +72,7 @@ def run_family(L, family, fp64, every=1, only=None, round_inputs=False, ref=None
     out = np.zeros((len(idx), g["obs"].shape[1]))
     status = np.zeros(len(idx), np.int64)
     for j, i in enumerate(idx):
-        qp, qv, qa, a = f(g["qpos"][i]), f(g["qvel"][i]), f(g["qacc_ws"][i]), f(g["action"][i])
+        qp, qv, qa, a = f(m.rows_from_world("qpos", g["qpos"][i])), f(g["qvel"][i]), f(g["qacc_ws"][i]), f(g["action"][i])      # fixtures hold MJCF-frame states, the rows are in the model's frame
         st = ctypes.c_int(0)
         if kind == "kitchen":
             obs, last, nz, done = np.zeros(g["obs"].shape[1], dt), f(g["last_qpos"][i]), f(g["noise"][i]), ctypes.c_int(0)
@@ -85,7 +85,7 @@ def run_family(L, family, fp64, every=1, only=None, round_inputs=False, ref=None
             obs, ach = np.zeros(g["obs"].shape[1] + 4, dt), np.zeros(2, dt)
             L.emu_point_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(a), p(obs), p(ach), ctypes.byref(st))
         elif kind == "fetch":
-            obs, ach, mocap, aux = np.zeros(g["obs"].shape[1], dt), np.zeros(3, dt), f(g["mocap"][i]), f(g["aux"][i])
+            obs, ach, mocap, aux = np.zeros(g["obs"].shape[1], dt), np.zeros(3, dt), f(m.rows_from_world("mocap", g["mocap"][i])), f(m.rows_from_world("aux", g["aux"][i]))
             L.emu_fetch_step(ctypes.c_void_p(h), ctypes.byref(t), p(qp), p(qv), p(qa), p(mocap), p(aux), p(a), p(obs), p(ach), ctypes.byref(st))
         else:
             obs, ach, palm = np.zeros(256, dt), np.zeros(15, dt), np.zeros(3, dt)
@@ -119,13 +119,13 @@ def run_family_horizons(L, family, horizons=(1, 2, 5, 10), every=1):
     run, gap, nobs, hmax = episode_runs(g), g["activation_gap"], g["obs"].shape[1], max(horizons)
     res = {h: ([], [], []) for h in horizons}
     for i in range(0, g["obs"].shape[0], every):
-        qp, qv, qa = f(g["qpos"][i]), f(g["qvel"][i]), f(g["qacc_ws"][i])
+        qp, qv, qa = f(m.rows_from_world("qpos", g["qpos"][i])), f(g["qvel"][i]), f(g["qacc_ws"][i])
         if kind == "kitchen":
             last = f(g["last_qpos"][i])
         elif kind == "adroit":
             sh, tg = f(g["shift"][i]), f(g["target"][i])
         elif kind == "fetch":
-            mocap, aux = f(g["mocap"][i]), f(g["aux"][i])
+            mocap, aux = f(m.rows_from_world("mocap", g["mocap"][i])), f(m.rows_from_world("aux", g["aux"][i]))
         for k in range(min(hmax, int(run[i]))):
             a, st = f(g["action"][i + k]), ctypes.c_int(0)
             if kind == "kitchen":
