@@ -67,6 +67,9 @@ MIXED = ("kitchen", "adroit")   # cfg 5: the two families of the mixed batch, ha
 MIXED_WORLDS = 4096             # per GPU (32768 over 8)
 HER_K = 4  # relabelled goals per transition ("future" strategy with k=4); 28 B per relabelled transition
 HBM_PEAK_GBS = 8000.0
+PROFILE_TAGS = ("r06",)      # rounds whose profiles/pmc_<tag>_*.json may be quoted -- and only when their build_id is the loaded library's (run_rank)
+LONG_WINDOW_STEPS = 100
+NORTH_STAR_WORLDS_PER_GPU = 8192      # BASELINE.json north_star: 65 536 FetchPickAndPlace worlds on 8 GPUs
 VALU_PEAK_IPS = 256 * 4 * 2.4e9 / 2      # wave64 VALU instructions per second, whole chip (SIMD-32: 2 cycles per wave64 instruction)
 
 
@@ -551,25 +554,53 @@ def run_rank(args, rank, world_size, local_rank):
 
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE
     # cannot be read from inside the process); tools/collect_profiles.py writes the summary bench.py quotes
-    traffic, traffic_src = None, None
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", f"pmc_{tag}_hbm_traffic{'' if args.workload == 'fetch' else '_' + args.workload}.json")
-        if os.path.exists(path) and n == w["worlds"]:
-            with open(path) as f:
-                traffic, traffic_src = json.load(f)["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
-            break
-    # The bound that actually binds: VALU issue.  SQ_INSTS_VALU per launch comes from the SQ pass of tools/collect_profiles.py (same command, separate --pmc run);
-    # peak = 256 CU x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction = 1228.8 G wave-instructions/s (MI355X_MICROARCH.md constants table: v_fma_f32 wave64 = 2 cyc).
-    valu = None
-    for tag in ("r05", "r04"):
-        path = os.path.join(ROOT, "profiles", f"pmc_{tag}_sq_mix{'' if args.workload == 'fetch' else '_' + args.workload}.json")
-        if os.path.exists(path) and n == w["worlds"] and not dry:
-            with open(path) as f:
-                sq = json.load(f)
+    # A summary is attached ONLY while it was measured on the device code that is loaded now (`build_id` = digest of the library's .hip_fatbin, _native.build_id): a kernel
+    # change without a new collect_profiles.py run yields `traffic: null` / `valu: null` and says why, never an old build's counters.
+    traffic, traffic_src, valu, live_build = None, None, None, None
+    if not dry:
+        from gymnasium_robotics_amd import _native
+
+        live_build = _native.build_id()
+
+    def _summary(kind):
+        for tag in PROFILE_TAGS:
+            path = os.path.join(ROOT, "profiles", f"pmc_{tag}_{kind}{'' if args.workload == 'fetch' else '_' + args.workload}.json")
+            if os.path.exists(path):
+                with open(path) as f:
+                    d = json.load(f)
+                rel = os.path.relpath(path, ROOT)
+                if n != w["worlds"]:
+                    return None, f"{rel}: measured at {w['worlds']} worlds, this run has {n}"
+                if d.get("build_id") != live_build:
+                    return None, f"STALE, not attached: {rel} was measured on build {d.get('build_id') or '(unstamped, before round 6)'}, the loaded libgrx_hip.so is {live_build}"
+                return d, rel
+        return None, None
+
+    if not dry:
+        d, traffic_src = _summary("hbm_traffic")
+        if d is not None:
+            traffic = d["traffic_bytes_per_launch"]
+        # The bound that actually binds: VALU issue.  SQ_INSTS_VALU per launch comes from the SQ pass of tools/collect_profiles.py (same command, separate --pmc run);
+        # peak = 256 CU x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction = 1228.8 G wave-instructions/s (MI355X_MICROARCH.md constants table: v_fma_f32 wave64 = 2 cyc).
+        sq, sq_src = _summary("sq_mix")
+        if sq is not None:
             ips = sq["SQ_INSTS_VALU"] / (max(kern_ms, 1e-9) * 1e-3)
             valu = {"insts_per_s": ips, "peak": VALU_PEAK_IPS, "frac": ips / VALU_PEAK_IPS, "unit": "wave64 VALU instructions/s", "insts_per_launch": sq["SQ_INSTS_VALU"],
-                    "valu_active_frac_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU_frac"), "wait_frac_of_wave_cycles": sq.get("SQ_WAIT_ANY_frac"), "source": os.path.relpath(path, ROOT)}
-            break
+                    "valu_active_frac_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU_frac"), "wait_frac_of_wave_cycles": sq.get("SQ_WAIT_ANY_frac"), "source": sq_src, "build_id": sq.get("build_id")}
+        elif sq_src:
+            valu = {"frac": None, "source": sq_src}
+    # `long_window`: the same environment stepped on for 100 more timed steps right behind the driver's window -- a 20-step window holds 0 - 3 overflow re-runs of 1 - 3 ms each
+    # and scatters by +-4 %; the long figure is the one to compare builds by.  One GPU only (no collective bookkeeping), skipped when the window already is that long.
+    long_window = None
+    if not dry and world_size == 1 and not dist and args.steps < LONG_WINDOW_STEPS and args.long_window:
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(LONG_WINDOW_STEPS):
+            one_step()
+        sync()
+        dt = time.perf_counter() - t1
+        long_window = {"steps": LONG_WINDOW_STEPS, "value": n * LONG_WINDOW_STEPS / dt, "ms_per_step": dt / LONG_WINDOW_STEPS * 1e3,
+                       "note": "the same environment, stepped on right behind the timed region (everything the timed region contains); not `value`"}
     line = None
     if rank == 0:
         value = n * world_size * args.steps / elapsed
@@ -585,7 +616,7 @@ def run_rank(args, rank, world_size, local_rank):
                        "capacity_overflow_worlds": counts["con_overflow"] + counts["efc_overflow"], "badnum_worlds": counts["badnum"],
                        "status_note": "worlds (of rank 0) whose sticky status flagged a dropped contact / bad number at least once in the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_ratio": (traffic / (w["algo"] * n)) if traffic else None,      # PMC bytes / algorithmic bytes per launch: scratch + model-table re-reads
+                         "build_id": live_build, "traffic": traffic, "traffic_source": traffic_src, "traffic_ratio": (traffic / (w["algo"] * n)) if traffic else None,      # PMC bytes / algorithmic bytes per launch: scratch + model-table re-reads
                          "valu": valu, "kernel": w["kernel"], "kernel_ms": kern_ms,
                          "kernel_plus_overflow_lane_ms": lane_ms,      # families with an overflow lane: fast launch + the lane's concurrent and serialised launches (`achieved` is the fast launch's)
                          # Fetch: the few worlds per 100 steps that exceed the fast tables are re-run behind the launch, 1 - 3 ms ONCE each: a 20-step window holds 0 - 3 of them, so
@@ -594,19 +625,39 @@ def run_rank(args, rank, world_size, local_rank):
                          "algorithmic_bytes_per_launch": w["algo"] * n,
                          "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 6"},
         }
+        if long_window is not None:
+            line["long_window"] = long_window
         if dist_report is not None:
             line["dist"] = dist_report
         if dry:
             line["data"] = "DRY RUN: no physics, random rows on the CPU over gloo (plumbing check of the multi-rank command line)"
     if dist:
         dist.destroy_process_group()
+    # The north star's share of one GPU (BASELINE.json: FetchPickAndPlace-v4, 65 536 worlds on 8 GPUs = 8 192 per GPU), in the driver's own line: the same workload, timed region,
+    # warm-up and step count at 8 192 worlds, measured in the same process right after the plain region.  Eight ranks without a step collective would run eight of these; the
+    # product of 8 is a projection and is NOT reported.
+    if line is not None and world_size == 1 and not dist and not dry and args.north_star_share and args.workload == "fetch" and n == w["worlds"] and not args.no_cpu_baseline:
+        try:
+            import copy
+
+            env = replay = None      # (the closure one_step sees the same cells: the 4 096-world buffers are released before the next leg allocates)
+            torch.cuda.empty_cache()
+            a3 = copy.copy(args)
+            a3.worlds_per_gpu, a3.no_cpu_baseline, a3.sub_batches, a3.north_star_share = NORTH_STAR_WORLDS_PER_GPU, True, False, False
+            l3 = run_rank(a3, rank, world_size, local_rank)
+            line["north_star_share"] = {"worlds": NORTH_STAR_WORLDS_PER_GPU, "value": l3["value"], "ms_per_step": l3["ms_per_step"], "kernel_ms": l3["roofline"]["kernel_ms"],
+                                        "long_window": l3.get("long_window"), "capacity_overflow_worlds": l3["config"]["capacity_overflow_worlds"],
+                                        "note": "one GPU's share of BASELINE's 65 536-world target (8 192 worlds), plain env.step(), same timed region / warm-up / steps as `value`; "
+                                                "what eight GPUs reach together is not measured here"}
+        except Exception as e:      # the extra leg must never cost the line
+            line["north_star_share"] = {"error": repr(e)}
     # The same worlds as two out-of-phase sub-batches (run_rank_stages), measured in the same process right after the plain line: reported BESIDE
     # `value`, never as it -- `value` stays env.step() over all worlds of one vector environment, the configuration BASELINE.json names.
     if line is not None and world_size == 1 and not dist and not dry and args.sub_batches and not args.no_cpu_baseline and args.workload != "hand_touch":      # (like cpu_baseline: a reporting extra of the full line; the A/B and profiling tools pass --no-cpu-baseline)
         try:
             import copy
 
-            del env, replay
+            env = replay = None
             torch.cuda.empty_cache()
             a2 = copy.copy(args)
             a2.stages, a2.no_cpu_baseline = 2, True
@@ -640,6 +691,8 @@ def main():
     ap.add_argument("--no-stagger", dest="stagger", action="store_false")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["mixed"], default="fetch")
     ap.add_argument("--no-sub-batches", dest="sub_batches", action="store_false", help="skip the extra leg that reports the same worlds stepped as 2 out-of-phase sub-batches beside `value` (1 GPU, and only when the CPU baseline leg runs too)")
+    ap.add_argument("--no-north-star-share", dest="north_star_share", action="store_false", help="skip the extra leg that reports the same Fetch workload at 8 192 worlds (one GPU's share of BASELINE's 65 536) beside `value`")
+    ap.add_argument("--no-long-window", dest="long_window", action="store_false", help="skip the 100 extra timed steps reported as `long_window` beside a shorter timed region")
     ap.add_argument("--stages", type=int, default=1, help="K > 1: the rank's worlds as K out-of-phase sub-batches on K streams (gymnasium_robotics_amd.pipeline; not for --workload mixed)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU, no physics: random rows on the CPU over gloo -- checks the multi-rank plumbing of this exact command line")
     args = ap.parse_args()

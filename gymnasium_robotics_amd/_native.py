@@ -148,6 +148,29 @@ def lib():
     return _lib
 
 
+def build_id(path: str = None) -> str:
+    """Identity of the DEVICE code inside a build of libgrx_hip.so: sha256 (first 16 hex digits) of its `.hip_fatbin` section -- the bundle of gfx950 code objects -- read with a
+    minimal ELF64 section walk (no tools, no GPU).  The profile summaries bench.py quotes (profiles/pmc_*.json, tools/collect_profiles.py) carry the id of the build they were
+    measured on; bench.py attaches them only while it matches the library that is actually loaded."""
+    import hashlib
+    import struct
+
+    with open(path or LIB_PATH, "rb") as f:
+        blob = f.read()
+    if blob[:4] != b"\x7fELF" or blob[4] != 2:
+        raise RuntimeError("libgrx_hip.so is not an ELF64 file")
+    shoff, = struct.unpack_from("<Q", blob, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", blob, 0x3A)
+    sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", blob, shoff + i * shentsize)      # name, type, flags, addr, offset, size, link, info, addralign, entsize
+    stroff = sec(shstrndx)[4]
+    for i in range(shnum):
+        name, _, _, _, off, size = sec(i)[:6]
+        end = blob.index(b"\0", stroff + name)
+        if blob[stroff + name: end] == b".hip_fatbin":
+            return hashlib.sha256(blob[off: off + size]).hexdigest()[:16]
+    raise RuntimeError("libgrx_hip.so holds no .hip_fatbin section (not a HIP build)")
+
+
 def check(rc: int):
     if rc != 0:
         raise RuntimeError("libgrx_hip: " + lib().grx_last_error().decode())

@@ -207,9 +207,12 @@ class GoalVecEnv:
         with torch.cuda.device(self.device):
             for k, v in state["tensors"].items():
                 cur = self.__dict__.get(k)
-                if isinstance(cur, torch.Tensor) and cur.shape == v.shape and cur.dtype == v.dtype:
+                if isinstance(cur, torch.Tensor):
+                    # an existing tensor is never re-bound: the native buffer structs hold its data_ptr() (a fresh clone would leave the kernels on the old memory)
+                    if cur.shape != v.shape or cur.dtype != v.dtype:
+                        raise ValueError(f"checkpoint tensor {k!r} is {tuple(v.shape)} {v.dtype}, this environment holds {tuple(cur.shape)} {cur.dtype}")
                     cur.copy_(v)
-                else:
+                else:      # attributes the checkpointed run had created lazily and this instance has not yet (no native struct can point at them)
                     self.__dict__[k] = v.to(self.device).clone() if v.is_cuda else v.clone()
             self._ckpt_extra_set(state.get("extra", {}))      # (families with lazily created arenas make them here, before their tensors are filled)
             for k, d in state["dicts"].items():

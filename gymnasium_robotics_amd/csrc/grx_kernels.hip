@@ -187,9 +187,12 @@ template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(cons
   if (S::kFixed) return GrxDims{S::NQ, S::NV, S::NU, S::NB, S::NJ, S::NG, S::NS, S::NM, S::NF, S::INTEG, S::ME, S::JP, S::NT, S::MC, S::NMESH, S::NSHIFT, S::NOSLIP};
   return grx_dims_of(&m);
 }
+#ifndef GRX_MATCH_ANY_MESH
+#define GRX_MATCH_ANY_MESH 0   // 1 (experiments only): a shape compiled without the hull routine also serves a model that has hull pairs (they are then never collided)
+#endif
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (S::kMesh == (g.nmeshpair != 0)) && (S::kShift == (g.nshift != 0)) && (S::kNoslip == (g.noslip_iterations > 0)) && (S::NF != 24 || g.handtree);
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (GRX_MATCH_ANY_MESH || S::kMesh == (g.nmeshpair != 0)) && (S::kShift == (g.nshift != 0)) && (S::kNoslip == (g.noslip_iterations > 0)) && (S::NF != 24 || g.handtree);
 }
 // last template argument: bit 0 = general convex routine for primitive pairs (ellipsoid / cylinder), bit 1 = hull-vs-convex pairs (every model with
 // collidable mesh geoms next to boxes / other meshes: all Fetch and Shadow-hand models)
@@ -200,7 +203,10 @@ template <class S> static bool grx_shape_matches(const GrxModel& g) {
 #ifndef GRX_FETCH_MC
 #define GRX_FETCH_MC 28
 #endif
-typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, 2> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
+#ifndef GRX_FETCH_PICK_FLAGS   // experiments (tools/ab_fetch_3wave.sh): 0 = the FetchPickAndPlace kernels WITHOUT the hull-pair routine -- an upper bound for a fast kernel that hands hull worlds off (wrong physics for them)
+#define GRX_FETCH_PICK_FLAGS 2
+#endif
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, GRX_FETCH_PICK_FLAGS> GrxShapeFetchPick;   // FetchPickAndPlace (arm + gripper actuators + object)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, 2> GrxShapeFetchObject; // FetchPush (arm + object)
 typedef GrxShape<15, 15, 0, 15, 15, 19, 2, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, 2> GrxShapeFetchArm;    // FetchReach (arm only)
 typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 0, GRX_FETCH_MC, 0, 3> GrxShapeFetchPuck; // FetchSlide (arm + cylinder puck: convex narrow phase)

@@ -50,10 +50,10 @@ def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledMo
     if not os.path.exists(path):
         raise OSError(f"File {path} does not exist (no packaged model and no assets_root given)")
     model = load_model(path).with_capacity(**{k: FETCH_CAPACITY[k] for k in ("maxcon", "maxefc", "jpool")})      # (the packaged blobs carry round 2's requests; the tables do not depend on them)
-    cap = os.environ.get("GRX_FETCH_CAP")     # experiments: "maxefc,jpool" other than the packaged capacities (needs a library built with -DGRX_FETCH_ME / -DGRX_FETCH_JP to stay on the specialised kernels)
+    cap = os.environ.get("GRX_FETCH_CAP")     # experiments: "maxefc,jpool[,maxcon]" other than the packaged capacities (needs a library built with -DGRX_FETCH_ME / -DGRX_FETCH_JP / -DGRX_FETCH_MC to stay on the specialised kernels)
     if cap:
-        me, jp = (int(x) for x in cap.split(","))
-        model = model.with_capacity(maxefc=me, jpool=jp)
+        vals = [int(x) for x in cap.split(",")]
+        model = model.with_capacity(maxefc=vals[0], jpool=vals[1], **({"maxcon": vals[2]} if len(vals) > 2 else {}))
     return model
 
 

@@ -394,7 +394,10 @@ int grx_fetch_commit_rows(const grx_fetch_commit_args* args, void* stream);
  * STAGED shift / target rows -- the running step still reads the finished episode's), init rows and the reset-time forward pass (grx_adroit_step, forward_only, `compact` list, a
  * second grx_adroit_buffers over staged [N, ...] arrays) run on a side stream beside the step kernel; this call, behind it, copies the staged qpos / qvel / qacc_ws / shift /
  * target / obs rows of world idx[j] over the live ones and ORs the forward pass's status flags into the sticky half of the world's status word.  reward / success / the step's
- * own status flags stay those of the finished episode (same-step autoreset).  Bit-identical to the in-line reset (tests/test_gpu_adroit.py).  Device pointers. */
+ * own status flags stay those of the finished episode (same-step autoreset).  Bit-identical -- status words included -- to the in-line reset AS AdroitVecEnv.step RUNS IT: there the
+ * masked forward launch writes its own flags into the low half (grx_status_word) and the host then puts the step's low half back, keeping the accumulated sticky half
+ * (envs/adroit.py: `status = (step's & 0xFFFF) | (now & ~0xFFFF)`); this kernel does both in one go.  (The Fetch commit differs on purpose: its in-line reset leaves the reset
+ * launch's flags in the low half, and so does grx_fetch_commit_rows.)  tests/test_gpu_adroit.py::test_overlapped_reset_is_the_inline_reset compares `status` after every step.  Device pointers. */
 typedef struct grx_adroit_commit_args {
   const int64_t* idx; int k;
   int nq, nv, obs_dim;

@@ -341,7 +341,12 @@ def test_degenerate_maze_is_refused_and_an_exhausted_rejection_loop_is_flagged()
     with pytest.raises(ValueError, match="single reset cell"):
         PointMazeVecEnv("PointMaze_UMaze-v3", num_envs=2, device="cuda:0", maze_map=[[1, 1, 1], [1, "c", 1], [1, 1, 1]])
     # one 'r' cell NEXT TO one 'g' cell is a valid maze (the reset cell's centre is >= 0.75 cells from the noisy goal: the reference's loop ends on its first draw)
-    adj = PointMazeVecEnv("PointMaze_UMaze-v3", num_envs=3, device="cuda:0", maze_map=[[1, 1, 1, 1], [1, "r", "g", 1], [1, 1, 1, 1]])
+    # (a custom map needs the MJCF assets to compile its walls; the GPU box has none, so the packaged U-maze tables stand in -- the reset logic under test reads the MAP, not the walls)
+    from gymnasium_robotics_amd.envs.maze_spec import MAPS, POINT_MAZE_HEIGHT, POINT_MAZE_SIZE_SCALING, Maze
+    from gymnasium_robotics_amd.envs.point_maze import load_point_maze_model
+
+    walls = load_point_maze_model(Maze(MAPS["UMaze"], POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT), "UMaze", None, "point")
+    adj = PointMazeVecEnv("PointMaze_UMaze-v3", num_envs=3, device="cuda:0", maze_map=[[1, 1, 1, 1], [1, "r", "g", 1], [1, 1, 1, 1]], model=walls)
     obs, _ = adj.reset(seed=5)
     d = np.linalg.norm(obs["achieved_goal"] - obs["desired_goal"], axis=1)
     assert (d > 0.5 * adj.maze.maze_size_scaling).all() and (d < 1.5 * adj.maze.maze_size_scaling).all() and int(np.abs(adj.status.cpu().numpy()).max()) == 0

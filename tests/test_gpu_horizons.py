@@ -5,15 +5,16 @@ kinematics words of Fetch, the kitchen's last_qpos) for 1, 2, 5 and 10 env.step(
 fp64 oracle observed at the same point of ITS rollout (tests/tolerance_cases.py::horizon_errors).  BASELINE configs 2 (FetchPickAndPlace), 3 (HandBlock + 92 touch
 channels), 5 (FrankaKitchen, AdroitHammer) and every other rollout family.
 
-Asserted:
-  (1) horizons 1 and 2: every start whose oracle steps all keep an activation gap >= 1e-6 m is within 1e-4 on every component (same two documented exceptions at
-      1.5e-4 and the same relative treatment of the touch channels as tests/test_gpu_tolerance_table.py);
-  (2) horizons 5 and 10 (a chaotic contact system: the bound beyond two steps is a MEASURED growth bound, tests/golden/tolerance_table.json "horizons", written by
-      tools/measure_horizons.py on the MI355X): the median error stays below 3 x the recorded median (and below 1e-4 outright), the share of ALL starts within 1e-4
-      stays within 5 points of the recorded share, and well-posed starts (no switch within 1e-6 m over the whole horizon) keep >= the recorded share - 10 points;
-  (3) >= 90 % of ALL starts (well-posed or not) are within 1e-4 on every non-touch component up to horizon 5 and >= 85 % at horizon 10 (measured: 95 - 100 % and 87 - 100 %;
-      the low end is the hand + block with its ~40 simultaneous contacts; FetchSlide's puck rotation, whose rocking mode the oracle itself flips under a 1e-6 m perturbation
-      -- DESIGN.md 9 -- is held to its recorded share only)."""
+Asserted (no allow-list in this file: every exception is a number tools/measure_horizons.py measured on the MI355X and wrote into tests/golden/tolerance_table.json "horizons"):
+  (1) horizons 1 and 2: every start whose oracle steps all keep an activation gap >= 1e-6 m is within 1e-4 on every component, the touch forces of cfg 3 included (absolute);
+      where the table records well-posed starts above 1e-4 (`n_over_1e-4_posed` > 0: at the time of writing ONE touch reading, 1.03e-4 N, at horizon 1) the component is held
+      to that count and to 1.25 x the recorded maximum;
+  (2) horizons 5 and 10 (a chaotic contact system: the bound beyond two steps is a MEASURED growth bound): the median error stays below 3 x the recorded median (and below 1e-4
+      outright), the share of ALL starts within 1e-4 stays within 5 points of the recorded share, and well-posed starts (no switch within 1e-6 m over the whole horizon) keep
+      >= the recorded share - 10 points;
+  (3) >= 90 % of ALL starts (well-posed or not) are within 1e-4 on every component up to horizon 5 and >= 85 % at horizon 10 -- unless the RECORDED share of that component
+      is itself below that floor + 5 points (measured: FetchSlide's puck rotation only, whose rocking mode the oracle itself flips under a 1e-6 m perturbation, DESIGN.md 9;
+      tests/golden/tolerance_table.json "reference_sensitivity" gives the oracle's own spread), in which case it is held to its recorded share - 5 points by (2)."""
 import json
 
 import numpy as np
@@ -23,8 +24,6 @@ from tolerance_cases import GAP, HORIZONS, ROLLOUT_FAMILIES, TABLE, episode_erro
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-KNOWN_1E4 = {("HandBlock", "velocities")}      # snapshot 112's joint velocity (1.04e-4 teacher-forced: tests/test_gpu_tolerance_table.py item 4): asserted at 1.5e-4 at horizons 1 and 2
-CHAOTIC = {("FetchSlide", "puck_rotation"), ("FetchSlide", "puck_rot_velocity")}
 
 
 @pytest.mark.parametrize("family", ROLLOUT_FAMILIES)
@@ -36,21 +35,19 @@ def test_free_running_rollout_stays_within_the_measured_bound(family):
         posed = res["_gap"][h] >= GAP
         for comp, err in res[h].items():
             rec = recorded[str(h)][comp]
-            touch = comp.startswith("touch")
             if h <= 2 and posed.any():
-                if touch:
-                    assert np.mean(err[posed] < TOL) >= 0.75 and err[posed].max() < 1e-3, (family, h, comp, float(np.mean(err[posed] < TOL)), float(err[posed].max()))
+                allowed = int(rec.get("n_over_1e-4_posed", 0))      # measured exceptions, module docstring (1)
+                if allowed == 0:
+                    assert err[posed].max() < TOL, (family, h, comp, int(res["_start"][h][posed][err[posed].argmax()]), float(err[posed].max()))
                 else:
-                    bound = 1.5e-4 if (family, comp) in KNOWN_1E4 else TOL
-                    assert err[posed].max() < bound, (family, h, comp, int(res["_start"][h][posed][err[posed].argmax()]), float(err[posed].max()))
-                    if bound != TOL:
-                        assert np.sum(err[posed] >= TOL) <= 1, (family, h, comp)
+                    assert int(np.sum(err[posed] >= TOL)) <= allowed and err[posed].max() < 1.25 * rec["max_posed"] < 2e-4, (family, h, comp, float(err[posed].max()), rec["max_posed"])
             assert np.median(err) < min(TOL, max(3.0 * rec["p50"], 1e-6)), (family, h, comp, float(np.median(err)), rec["p50"])
             assert np.mean(err < TOL) >= rec["frac_within_1e-4"] - 0.05, (family, h, comp, float(np.mean(err < TOL)), rec["frac_within_1e-4"])
             if posed.sum() >= 10 and rec["frac_within_1e-4_posed"] is not None:
                 assert np.mean(err[posed] < TOL) >= rec["frac_within_1e-4_posed"] - 0.10, (family, h, comp, float(np.mean(err[posed] < TOL)), rec["frac_within_1e-4_posed"])
-            if not touch and (family, comp) not in CHAOTIC:
-                assert np.mean(err < TOL) >= (0.90 if h <= 5 else 0.85), (family, h, comp, float(np.mean(err < TOL)))
+            floor = 0.90 if h <= 5 else 0.85
+            if rec["frac_within_1e-4"] >= floor + 0.05:      # (3): the flat floor applies wherever the measured share leaves room for it; below that the recorded share - 5 points (above) is the bar
+                assert np.mean(err < TOL) >= floor, (family, h, comp, float(np.mean(err < TOL)))
 
 
 @pytest.mark.parametrize("family", ROLLOUT_FAMILIES)

@@ -9,14 +9,15 @@ EVERY served family, with one qualification that is a property of the REFERENCE,
     well-posed comparison for ANY engine that keeps its state in fp32: the reference's own answer changes by up to 1e-1 under a perturbation of that size.
 
 Asserted here, on the MI355X, through the C ABI:
-  (1) every snapshot with activation_gap >= 1e-6 m (67 - 100 % of each family's fixture: tests/golden/tolerance_table.json, `n_away_from_activation_boundary`) is within 1e-4 on every component -- no allow-list, no ratchet;
+  (1) every snapshot with activation_gap >= 1e-6 m (67 - 100 % of each family's fixture: tests/golden/tolerance_table.json, `n_away_from_activation_boundary`) is within 1e-4 on every
+      component, the 92 touch-sensor forces of cfg 3 included, ABSOLUTE (since round 6 the hand models live in a palm-centred world frame: profiles/origin_r06_emu.txt);
   (2) over ALL snapshots of a family at least 99 % are within 1e-4 on every component (the rest are below the gap, listed in tests/golden/tolerance_table.json);
-  (3) touch-sensor channels (forces in newton, up to 3e1): |error| <= 1e-4 * max(1, |reading|) on >= 90 % of the gap >= 1e-6 snapshots, <= 5e-4 * max(1, |reading|) on
-      all of them -- a contact force is (stiffness 1e4 ... 1e5 N/m) x (a depth that an fp32 state resolves to 1e-8 m): 1e-4 N absolute is below what fp64 ARITHMETIC
-      on an fp32 STATE delivers (tools/emu_mixed.py --fp32 "": 88 % of the snapshots within 1e-4 N, max 1.9e-4), see DESIGN.md section 5;
-  (4) two snapshots are known to sit just above the bound although no switch is near (KNOWN below, with their measured values: a joint velocity of 8 rad/s off by
-      1.04e-4, the ant's torso rate off by 1.29e-4 after 5 RK4 substeps with a wall contact); they are asserted at 1.5e-4, everything else at 1e-4.
-tests/golden/tolerance_table.json (tools/measure_tolerances.py) is the record of the measured quantiles and of every snapshot above 1e-4 with its gap."""
+  (3) there is NO allow-list in this file.  Where the MEASURED table records well-posed snapshots above 1e-4 for a (family, component) -- `n_over_1e-4_away_from_boundary` > 0; at the
+      time of writing two entries, one snapshot each: the ant's torso rate after 5 RK4 substeps against a wall, 1.29e-4 on 19 rad/s at 18 m from the origin, and one touch force,
+      1.03e-4 N on a reading of tens of newtons -- the test holds the component to that recorded COUNT and to 1.25 x the recorded maximum; every other component has no
+      exception and is asserted at 1e-4 flat.  An exception therefore exists only as a number the GPU measured (tools/measure_tolerances.py), with its snapshot and gap.
+tests/golden/tolerance_table.json (tools/measure_tolerances.py) is the record of the measured quantiles and of every snapshot above 1e-4 with its gap; its "reference_sensitivity"
+section (tools/oracle_sensitivity.py) is the yardstick: how far the fp64 ORACLE's own answer moves when its input state is perturbed by 1e-7 relative."""
 import numpy as np
 import pytest
 
@@ -27,7 +28,6 @@ from tolerance_cases import CASES, TABLE, ant_errors, family_errors
 pytestmark = pytest.mark.gpu
 GAP = 1e-6
 TOL = 1e-4
-KNOWN = {("HandBlock", "velocities"): [112], ("AntMazeLarge", "velocities"): [180]}      # (4) of the module docstring: asserted at 1.5e-4
 
 
 @pytest.mark.parametrize("family", list(CASES) + ["AntMaze"])
@@ -42,12 +42,10 @@ def test_family_meets_the_north_star_bound(family):
         rec = json.load(f)[family]
     assert posed.mean() >= rec["n_away_from_activation_boundary"] / rec["n"] - 0.05, (family, float(posed.mean()), rec["n_away_from_activation_boundary"] / rec["n"])
     for comp, err in res.items():
-        if comp.startswith("touch"):
-            assert np.mean(err[posed] < TOL) >= 0.90 and err[posed].max() < 5e-4, (family, comp, float(np.mean(err[posed] < TOL)), float(err[posed].max()))
-            continue
-        strict = posed.copy()
-        for i in KNOWN.get((family, comp), []):
-            assert err[i] < 1.5e-4, (family, comp, i, float(err[i]))
-            strict[i] = False
-        assert err[strict].max() < TOL, (family, comp, int(np.nonzero(strict)[0][err[strict].argmax()]), float(err[strict].max()))
+        allowed = int(rec[comp].get("n_over_1e-4_away_from_boundary", 0))      # measured exceptions (module docstring (3)): 0 for all but two components
+        if allowed == 0:
+            assert err[posed].max() < TOL, (family, comp, int(np.nonzero(posed)[0][err[posed].argmax()]), float(err[posed].max()))
+        else:
+            assert int(np.sum(err[posed] >= TOL)) <= allowed, (family, comp, int(np.sum(err[posed] >= TOL)), allowed)
+            assert err[posed].max() < 1.25 * rec[comp]["max_away_from_boundary"] < 2e-4, (family, comp, float(err[posed].max()), rec[comp]["max_away_from_boundary"])
         assert np.mean(err < TOL) >= 0.99, (family, comp, float(np.mean(err < TOL)))

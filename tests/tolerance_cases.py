@@ -31,9 +31,11 @@ CASES = {
     "FrankaKitchen": ("FrankaKitchen-v1", "kitchen_teacher.npz", ("qpos", "qvel", "qacc_ws", "last_qpos"), {"positions": np.r_[0:9, 18:39], "velocities": np.r_[9:18, 39:59]}),
     # BASELINE configs[3] on its own model (76 geoms, wall lattice): tools/make_golden_antmaze.py pushes the ant against the walls of its cell
     "AntMazeLarge": ("AntMaze_Large_Diverse_GR-v5", "ant_Large_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"), {"positions": np.r_[0:13], "velocities": np.r_[13:27]}),
-    # BASELINE configs[2]'s 153-word observation (61 + 92 touch zones); touch readings are forces (up to tens of newtons): relative to max(1, |reading|)
+    # BASELINE configs[2]'s 153-word observation (61 + 92 touch zones).  Touch readings are forces (up to tens of newtons); since the hand models live in a palm-centred
+    # frame (round 6, profiles/origin_r06_emu.txt) they are held to north_star's ABSOLUTE 1e-4 like every other component ("touch"); the relative figure
+    # (error / max(1, |reading|), what rounds 4 - 5 could assert) is still recorded beside it
     "HandBlockTouch": ("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", "hand_BlockRotateXYZ_touch_teacher.npz", ("qpos", "qvel", "qacc_ws", "goal"),
-                       {"positions": HAND_POS, "velocities": HAND_VEL, "touch_relative": np.r_[61:153]}),
+                       {"positions": HAND_POS, "velocities": HAND_VEL, "touch": np.r_[61:153], "touch_relative": np.r_[61:153]}),
     "AdroitRelocate": ("AdroitHandRelocate-v2", "adroit_relocate_teacher.npz", ("qpos", "qvel", "qacc_ws", "shift", "target"), {"qpos": np.r_[0:30], "positions": np.r_[30:39]}),
 }
 
@@ -110,6 +112,7 @@ def measure_all():
             table[name][comp]["frac_within_1e-4_away_from_boundary"] = float(np.mean(err[far] < 1e-4)) if far.any() else None
             over = np.nonzero(err >= 1e-4)[0]       # the snapshots outside north_star's bound, one by one with their activation gap (up to 24; the count is always recorded)
             table[name][comp]["n_over_1e-4"] = int(len(over))
+            table[name][comp]["n_over_1e-4_away_from_boundary"] = int(np.sum(err[far] >= 1e-4))      # > 0: a MEASURED exception -- the test holds it to this count and to 1.25 x max_away_from_boundary
             table[name][comp]["outliers"] = [[int(i), float("%.2e" % err[i]), float("%.1e" % gap[i])] for i in over[np.argsort(-err[over])][:24]]
     return table
 
@@ -185,6 +188,7 @@ def measure_horizons(families=None):
             row[str(h)] = {"n_starts": int(len(posed)), "n_posed": int(posed.sum())}
             for comp, err in res[h].items():
                 row[str(h)][comp] = {"p50": float(np.median(err)), "p90": float(np.quantile(err, 0.9)), "max": float(err.max()), "frac_within_1e-4": float(np.mean(err < 1e-4)),
+                                     "n_over_1e-4_posed": int(np.sum(err[posed] >= 1e-4)),
                                      "max_posed": float(err[posed].max()) if posed.any() else None, "frac_within_1e-4_posed": float(np.mean(err[posed] < 1e-4)) if posed.any() else None,
                                      "p50_posed": float(np.median(err[posed])) if posed.any() else None}
         table[name] = row

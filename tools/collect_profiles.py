@@ -28,6 +28,20 @@ KERNEL = "grx_fetch_step_kernel"
 ALGO_BYTES = 715 * 4096
 
 
+def _build_id():
+    """device-code identity of the library the profiled command loads (gymnasium_robotics_amd._native.build_id): bench.py attaches a summary only to that build"""
+    from gymnasium_robotics_amd import _native
+
+    return _native.build_id()
+
+
+def _git_head():
+    try:      # (the GPU box's snapshot has no .git: tools/final_bench.sh passes the hash of the tree it was cut from)
+        return os.environ.get("GRX_GIT_HEAD") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def run(cmd, log):
     env = dict(os.environ, TMPDIR="/tmp")
     with open(log, "w") as f:
@@ -98,7 +112,7 @@ def pmc(tag, workload=None):
             lines.append(f"{cnt}: {len(vals)} launches of {kernel}: mean {mean:.1f} KiB  min {min(vals):.1f}  max {max(vals):.1f}")
         else:
             lines.append(f"{cnt}: no samples (see the log)")
-    out = {"kernel": kernel, "build": tag, "algorithmic_bytes_per_launch": algo_bytes}
+    out = {"kernel": kernel, "build": tag, "build_id": _build_id(), "git": _git_head(), "algorithmic_bytes_per_launch": algo_bytes}
     if len(summary) == 2:
         fetch, write = summary["FETCH_SIZE"] * 1024, summary["WRITE_SIZE"] * 1024
         traffic, raw = 2 * fetch + write, fetch + write
@@ -147,7 +161,7 @@ def sq_mix(tag, workload=None):
     for k in SQ_COUNTERS:
         lines.append(f"  {k:22s} {mean[k]:16.0f}" if k in mean else f"  {k:22s} (not collected)")
     wc = mean.get("SQ_WAVE_CYCLES")
-    out = dict(mean, kernel=kernel, build=tag, worlds=w["worlds"])
+    out = dict(mean, kernel=kernel, build=tag, build_id=_build_id(), git=_git_head(), worlds=w["worlds"])
     if wc:
         for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
             if k in mean:

@@ -23,6 +23,7 @@ FAMILY_TO_TASK = {"FetchReach": "FetchReach", "FetchPush": "FetchPush", "FetchPi
                   "AdroitPen": "pen", "AdroitRelocate": "relocate", "FrankaKitchen": "kitchen", "HandBlockTouch": "HandBlockTouch", "AntMazeLarge": "antlarge"}
 
 
+_SENS = {}
 JITTER = float(os.environ.get("GRX_JITTER", "6e-8"))      # relative amplitude of the --sensitivity perturbation
 
 
@@ -185,7 +186,21 @@ def main(argv):
                 worst = e if worst is None else np.maximum(worst, e)
             for comp, cols in comps.items():
                 err = worst[:, cols].max(axis=1)
+                _SENS.setdefault(fam, {})[comp] = {"p50": float(np.median(err)), "p90": float(np.quantile(err, .9)), "p99": float(np.quantile(err, .99)), "max": float(err.max()),
+                                                  "frac_within_1e-4": float(np.mean(err < 1e-4)), "n": int(len(err)), "n_over_1e-4": int((err >= 1e-4).sum())}
                 print(f"{fam:18s} {comp:26s} SENSITIVITY n={len(err):4d} p50 {np.median(err):.1e} p99 {np.quantile(err, .99):.1e} max {err.max():.1e} over 1e-4: {int((err >= 1e-4).sum())} {list(idx[err >= 1e-4])[:40]}", flush=True)
+        if "--json" in argv:      # merged into tests/golden/tolerance_table.json under "reference_sensitivity" (the yardstick beside the GPU-measured errors)
+            import json
+            path = argv[argv.index("--json") + 1]
+            with open(path) as f:
+                full = json.load(f)
+            sec = full.setdefault("reference_sensitivity", {})
+            sec["_what"] = (f"per-snapshot spread of the fp64 build of the engine source (agrees with the oracle to 5e-10: tools/emu_fp64_check.py) against ITSELF when every word of the "
+                            f"input state is perturbed by a relative {JITTER:g} (worst of {os.environ.get('GRX_JITTER_TRIALS', '3')} draws), both runs from the fp32-rounded fixture states: how far the reference ALGORITHM's own answer "
+                            "moves under a perturbation of the size of one fp32 ulp of the state -- what no fp32-state engine can avoid")
+            sec.update(_SENS)
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
         return
     for fam in fams:
         ref = run_family(L64, fam, True, every, round_inputs=True, ref="raw")[1] if rounded else None
