@@ -21,7 +21,8 @@ class OverflowLaneStruct(ctypes.Structure):
 
 class FetchBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed", "hullcache")] + [("lane", OverflowLaneStruct)]
+        "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed", "hullcache", "handoff")] + [
+        ("handoff_stride", ctypes.c_int), ("handoff_large", ctypes.c_int), ("lane", OverflowLaneStruct)]
 
 
 class FetchResetArgsStruct(ctypes.Structure):

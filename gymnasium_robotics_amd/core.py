@@ -344,17 +344,22 @@ class OverflowLane:
     become current.  The size of a list is bounded by the grid of the launch that will walk it (grx_overflow_lane.next_cap / entry_cap), which the host fixes one
     step ahead from the newest counters that have reached it."""
 
-    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane", lane_first=False, margin=LANE_MARGIN, poll_grid=LANE_POLL_GRID):
+    def __init__(self, n, device, model, make_bufs, ttl=LANE_TTL, mode="lane", lane_first=False, margin=LANE_MARGIN, poll_grid=LANE_POLL_GRID, handoff=False):
         """mode "lane": worlds near a capacity move to a standing lane that runs next to the fast launch (families whose contact-rich states persist: hand + object,
         kitchen, Adroit door / relocate: a few worlds per step and thousand).  mode "entry": no standing lane, an overflowing world is re-run right behind the fast
         launch -- for families where an overflow is a rare event (Fetch: 2 worlds in 100 steps of 4096), whose step is too short to hide the two cross-stream waits
         a standing lane costs per step (+0.19 ms on 3.3 ms, measured)."""
         import os
         self.mode = os.environ.get("GRX_LANE_MODE", mode)
+        # handoff (FetchPickAndPlace, include/grx_capi.h grx_fetch_buffers.handoff): three tiers -- the fast kernel hands worlds off MID-STEP to the standing lane's launch (the middle
+        # tables, `launch_lane` of step()), which hands what exceeds ITS tables on to the entry launch (the large tables); entries are resumed at their substep, never re-run
+        self.handoff = bool(handoff)
+        self.entry_cap = max(ENTRY_CAP, n // 16) if self.handoff else ENTRY_CAP
         # lane_first: the standing lane's launch is submitted BEFORE the fast launch (its worlds are the heaviest of the batch: a hand jammed into the door takes 5 - 9 ms
         # against the 11 ms of the whole fast launch, so they should start first).  Measured per family (profiles/ab_r03_lane_first.txt): AdroitDoor +7 %, hand + touch -0.6 %
         # (there the fast kernel then waits for the lane's launch: tools/lane_cost_probe.py) -- hence a per-family switch.
         self.lane_first = bool(int(os.environ.get("GRX_LANE_FIRST", int(lane_first))))
+        self.spacer = int(os.environ.get("GRX_LANE_SPACER", 0))      # GPU cycles the main stream idles between the lane's launch and the fast launch (lane_first only)
 
         import torch
 
@@ -395,7 +400,7 @@ class OverflowLane:
     def _fast(self, skip, out, next_cap, join=True):
         L = self._Lane()
         L.skip = None if skip is None else skip.flags.data_ptr()
-        L.entry_count, L.entry_list, L.entry_cap = out.entry_count_ptr, out.entry_list.data_ptr(), ENTRY_CAP
+        L.entry_count, L.entry_list, L.entry_cap = out.entry_count_ptr, out.entry_list.data_ptr(), self.entry_cap
         if join:      # worlds that come close to a capacity move to the lane of the next step
             L.next_flags, L.next_count, L.next_list, L.ttl, L.next_cap = out.flags.data_ptr(), out.next_count_ptr, out.next_list.data_ptr(), self.ttl.data_ptr(), next_cap
             L.soft_maxefc, L.soft_jpool, L.soft_maxcon, L.ttl_init = self.soft
@@ -411,9 +416,10 @@ class OverflowLane:
         L.soft_maxefc, L.soft_jpool, L.soft_maxcon, L.ttl_init = self.soft
         return L
 
-    def step(self, mask, launch_fast, launch_large, fast_bufs):
+    def step(self, mask, launch_fast, launch_large, fast_bufs, launch_lane=None):
         """mask: the uint8 tensor of the worlds this step covers (None: all); a lane world that is masked out keeps its place.  fast_bufs: the environment's own
-        buffer struct for the fast launch (its .lane is set here and cleared again)."""
+        buffer struct for the fast launch (its .lane is set here and cleared again).  launch_lane: the launcher of the STANDING lane's kernel when it is not the large-table
+        one (hand-off mode: the middle tables); default launch_large."""
         import os
 
         import torch
@@ -431,36 +437,56 @@ class OverflowLane:
         # the fast kernel does not start before the lane's kernel has ENDED (1.1 ms of a 3.1 ms Fetch step) -- on the same stream or on a second one: the completion
         # marker behind the lane's kernel holds up the packet processor for both queues.  Behind the fast kernel the lane's workgroups start when a CU has room and
         # end before the fast launch does.
+        launch_lane = launch_lane or launch_large
         b_lane = self._make_bufs(mask)
         b_lane.lane = self._large(cur.next_list, cur.next_count_ptr, nxt, self.cap_cur, next_cap)
+        if self.handoff:      # the standing lane's kernel runs the middle tables: what exceeds them is handed on (entries flagged "large": the polling workgroups leave them to the entry launch)
+            b_lane.handoff_large = 1
+            b_lane.lane.entry_count, b_lane.lane.entry_list, b_lane.lane.entry_cap = nxt.entry_count_ptr, nxt.entry_list.data_ptr(), self.entry_cap
         if self._poll is not None:
             self._poll.zero_()
             L = b_lane.lane
             L.grid = int(self.cap_cur) + self.poll_grid      # the last poll_grid workgroups poll this step's entry list
             L.ready, L.ready_cap, L.progress, L.progress_total = self._poll.data_ptr(), self.poll_grid, self._poll.data_ptr() + 4 * self.poll_grid, self._fast_grid
             L.poll_list, L.poll_grid = nxt.entry_list.data_ptr(), self.poll_grid
-        ev0 = torch.cuda.Event()
+        trace = getattr(self, "trace", None)      # diagnostics (tools/lane_dbg_fetch.py): set to [] to collect (step start, lane start, lane end, entry start, entry end) timing events
+        ev0 = torch.cuda.Event(enable_timing=trace is not None)
         ev0.record(main)
+        if trace is not None:
+            _launch_lane = launch_lane
+
+            def launch_lane(b):
+                t0 = torch.cuda.Event(enable_timing=True); t0.record()
+                _launch_lane(b)
+                t1 = torch.cuda.Event(enable_timing=True); t1.record()
+                trace.append([ev0, t0, t1])
         if self.lane_first:
             self.side.wait_event(ev0)
             with torch.cuda.stream(self.side):
-                launch_large(b_lane)
+                launch_lane(b_lane)
                 ev1 = torch.cuda.Event()
                 ev1.record(self.side)
+            if self.spacer > 0:      # the lane's workgroups must be RESIDENT before the fast launch fills every wave slot: a few microseconds of nothing on the main stream
+                torch.cuda._sleep(self.spacer)
             launch_fast(fast_bufs)
         else:
             launch_fast(fast_bufs)
             self.side.wait_event(ev0)
             with torch.cuda.stream(self.side):
-                launch_large(b_lane)
+                launch_lane(b_lane)
                 ev1 = torch.cuda.Event()
                 ev1.record(self.side)
         main.wait_event(ev1)
         b_entry = self._make_bufs(mask)
-        b_entry.lane = self._large(nxt.entry_list, nxt.entry_count_ptr, nxt, ENTRY_CAP, next_cap)
+        b_entry.lane = self._large(nxt.entry_list, nxt.entry_count_ptr, nxt, self.entry_cap, next_cap)
         if self._poll is not None:      # the entries a polling workgroup has claimed are skipped
             b_entry.lane.ready, b_entry.lane.ready_cap = self._poll.data_ptr(), self.poll_grid
+        if trace is not None:
+            x0 = torch.cuda.Event(enable_timing=True); x0.record()
         launch_large(b_entry)
+        if trace is not None:
+            x1 = torch.cuda.Event(enable_timing=True); x1.record()
+            trace[-1] += [x0, x1]
         self._keep = (b_lane, b_entry)
         fast_bufs.lane = self._Lane()       # the environment's struct is also used for reset-time launches: no stale skip list
         slot = self._pin[self._pin_next]
@@ -516,5 +542,5 @@ class OverflowLane:
     def entered_last_step(self):
         """world indices that claimed a re-run in the last step (synchronises: tests only)"""
         buf = self.scratch if self.mode == "entry" else self.cur
-        k = int(min(buf.counts[1].item(), ENTRY_CAP))
+        k = int(min(buf.counts[1].item(), self.entry_cap))
         return buf.entry_list[:k].cpu().numpy()

@@ -590,7 +590,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   // ONE dense pass instead of one sparse, divergent pass per 64 candidates.
   // Scenes with more candidates than the survivor list has room for (the kitchen: 3 736) are swept in chunks of that size: pair order is kept.
   const int ndp = m->ndevpair;
-  const bool kGate = S::kMesh && m->ngate > 0;   // joint-box gates of hull pairs (grx_gate_clear); the skin-list sweep of the large scenes does not use them
+  const bool kGate = S::kHullFilter && m->ngate > 0;   // joint-box gates of hull pairs (grx_gate_clear); the skin-list sweep of the large scenes does not use them
   unsigned long long gmask = 0ull;   // the model's gates (at most 64: the compiler keeps those of the nearest pairs) evaluated once per pass, one lane each; the sweep tests a bit
   if (kGate) { GRX_LANEVAR_I(gc); FOR_LANES { LV(gc) = (lane < m->ngate) ? grx_gate_clear(m, c, lane) : 0; } gmask = GRX_BALLOT(gc); }
 #define GRX_GATE_CLEAR(gi) ((int)((gmask >> ((gi) & 63)) & 1ull))
@@ -759,9 +759,9 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
         if (pass) {
           const int p = pq;
 #ifdef GRX_DBG_NO_OBB
-          if (t2 == 7 && t1 != 0) { if (S::kMesh) ismesh = 1; }
+          if (t2 == 7 && t1 != 0) { if (S::kHullFilter) ismesh = 1; }
 #else
-          if (t2 == 7 && t1 != 0) { if (S::kMesh) ismesh = grx_obb_overlap(m, c, g1, g2, margin); }
+          if (t2 == 7 && t1 != 0) { if (S::kHullFilter) ismesh = grx_obb_overlap(m, c, g1, g2, margin); }
 #endif
           else if (t1 == 2 && t2 == 2) grx_sphere_sphere_raw(c, p, c->gxpos + 3 * g1, m->geom_size[3 * g1], c->gxpos + 3 * g2, m->geom_size[3 * g2], margin);
           else if (t1 == 2 && t2 == 3) grx_sphere_capsule(m, c, p, g1, g2, margin);
@@ -788,12 +788,19 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     if (S::kMesh) {   // hull-vs-convex pairs that passed the bounding-box filter: pair order, the whole wave on each
       const unsigned long long mm = GRX_BALLOT(meshq);
       if (__builtin_expect(mm != 0ull, 0)) {   // marked cold: the register allocator then places the spill code this region needs around IT instead of inside the hot stages
+        if (c->handoff != nullptr && c->soft_maxefc > 0) { LANE0 { c->cnt[2] |= GRX_ST_SOFT; } }   // launches that serve as the standing lane of a hull-less fast kernel: hull activity keeps the world in the lane (grx_lane_ticket)
         int* queue = (int*)(c->Jp + 128);   // the Jacobian pool is free until the constraint stage; [0, 128) is c->red
         FOR_LANES { if (LV(meshq)) queue[__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = LV(pairq); }
         WAVE_SYNC();
 #ifndef GRX_DBG_NO_MESHPAIRS
         grx_mesh_pairs(m, c, queue, __builtin_popcountll(mm), lane_);
 #endif
+      }
+    }
+    if (S::kHandoff) {   // no hull routine in this kernel: a pair that passed the filters ends the substep here, the world is handed off (grx_forward_euler returns, grx_lane_handoff)
+      if (GRX_BALLOT(meshq) != 0ull) {
+        if (c->bail == 1 && c->handoff != nullptr) { LANE0 { c->cnt[2] |= GRX_ST_HULL; } WAVE_SYNC(); return; }
+        LANE0 { c->cnt[2] |= GRX_ST_CON_OVERFLOW; }   // no lane to hand it to (entry list full, or a launch without one): the pair is NOT collided, and the sticky flag says so
       }
     }
     GRX_SUBTICK(c, 16);

@@ -17,10 +17,12 @@ GRX_MEM void grx_forward_euler(const GrxModel* m, GrxCtx* c, int do_euler, int l
   GRX_RNDINJ(1, (grx_rnd(c->cinert, 10 * m->nbody), grx_rnd(c->cdof, 6 * m->nv), grx_rnd(c->M, m->nv * m->nv)));
   GRX_TICK(c, GRX_P_INERTIA);
   grx_collision(m, c, lane_);
+  if (S::kHandoff && (c->cnt[2] & GRX_ST_HULL)) return;   // a hull pair came near in a kernel without the hull routine: the state is untouched, the caller hands the world off at this substep
   GRX_STAGE_HOOK(2);
   GRX_RNDINJ(2, (grx_rnd(c->con_dist, c->maxcon), grx_rnd(c->con_pos, 3 * c->maxcon), grx_rnd(c->con_frame, 3 * c->maxcon)));
   GRX_TICK(c, GRX_P_COLLIDE);
   grx_make_constraint(m, c, lane_);
+  if (grx_handoff_due(c)) return;   // (kernels with a hand-off row only) a table capacity is exceeded: stop BEFORE the solve touches the state, the world resumes at this substep on larger tables
   GRX_STAGE_HOOK(3);
   GRX_RNDINJ(3, (grx_rnd(c->Jp, c->jpool), grx_rnd(c->efc_D, c->maxefc), grx_rnd(c->efc_aref, c->maxefc)));
   GRX_TICK(c, GRX_P_CONSTR);

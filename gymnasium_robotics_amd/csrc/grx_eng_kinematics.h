@@ -30,7 +30,7 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
 #endif
       if (jt0 == 0) {  // free joint: qpos is the world pose
         float q[4] = {c->qpos[qa + 3], c->qpos[qa + 4], c->qpos[qa + 5], c->qpos[qa + 6]};
-        normalize4f(q);
+        if (!c->resume_first) normalize4f(q);   // (a world resumed mid-step: this substep's normalisation was done, in place, by the kernel that handed it off; doing it twice is not bit-neutral)
         pl[0] = c->qpos[qa]; pl[1] = c->qpos[qa + 1]; pl[2] = c->qpos[qa + 2];
         for (int k = 0; k < 4; k++) { ql[k] = q[k]; c->qpos[qa + 3 + k] = q[k]; }
         for (int k = 0; k < 3; k++) { c->janchor[3 * ja + k] = pl[k]; c->jaxis[3 * ja + k] = (k == 2) ? 1.0f : 0.0f; }

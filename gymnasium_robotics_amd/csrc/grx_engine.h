@@ -80,6 +80,7 @@ enum { GRX_P_KIN = 0, GRX_P_INERTIA, GRX_P_COLLIDE, GRX_P_CONSTR, GRX_P_VEL, GRX
 #define GRX_ST_EFC_OVERFLOW 4
 #define GRX_ST_FACTOR 8
 #define GRX_ST_SOFT 16      // internal (never reported): the tables of the model's FAST kernel would have overflowed in some substep (GrxCtx::soft_*; the overflow lane, include/grx_capi.h)
+#define GRX_ST_HULL 32      // internal (never reported): a hull-vs-convex pair passed the bounding-box filter in a kernel that carries no hull routine (GrxShape::kHandoff): the world is handed off mid-step
 
 enum { GRX_ROW_EQ = 0, GRX_ROW_FRICTION = 1, GRX_ROW_LIMIT = 2, GRX_ROW_CONTACT = 3, GRX_ROW_TENDON = 4 };
 
@@ -164,6 +165,11 @@ struct GrxCtx {
   int bail;    // != 0: a step kernel that hands capacity overflows to a re-run at a larger capacity stops simulating at the first overflowing substep (nothing of this run is kept)
   int soft_maxefc, soft_jpool, soft_maxcon;   // > 0 (the large-table kernel of the overflow lane): the capacities of the FAST kernel; exceeding one of them raises GRX_ST_SOFT
   int *lane_entry_count, *lane_entry_list; int lane_entry_cap, lane_world; int* lane_ready; int lane_ready_cap;   // fast kernel with an overflow lane: where a world that overflows claims its re-run (grx_lane_claim)
+  // MID-STEP HAND-OFF (include/grx_capi.h, grx_fetch_buffers.handoff): a kernel that cannot go on with this world -- a table capacity is exceeded, or it carries no hull routine and a
+  // hull pair came near -- stops at the START of the substep in question (nothing of it has touched the state yet), writes the world's row [substep + 1 | status | ctrl | mocap |
+  // qpos | qvel | qacc_ws] and claims an entry; the kernel that takes the entry resumes AT that substep instead of re-running the step from its first one.
+  float* handoff; int handoff_stride, handoff_large;   // handoff_large: claims from this launch need the LARGE tables (it already runs the middle ones): polling workgroups leave them to the entry launch
+  int resume_first;   // 1 during the first substep of a resumed world: the free-joint quaternions in qpos were normalised by the kernel that handed it off (grx_kinematics normalises in place)
   int* skin;   // large scenes: this world's skin list in HBM (grx_collision), or null: [0] entries, [1] valid, [4, 4 + 3 ngeom) reference geom positions, then the list
   float skin_r;
   int maxefc, jpool, maxcon;  // capacities of the row tables / the packed Jacobian pool / the contact list of this model
@@ -221,7 +227,7 @@ static int g_grx_solve_mode = 0;   // 0 normal, 1 Newton only, 2 Euler stage onl
 GRX_DEV void grx_ctx_carve(GrxCtx* c, float* base, const GrxDims d) {
   const GrxDims* m = &d;
   float* p = base;
-  c->hullhint = nullptr; c->skin = nullptr; c->skin_r = 0.0f; c->bail = 0; c->soft_maxefc = c->soft_jpool = c->soft_maxcon = 0; c->lane_entry_count = nullptr; c->lane_entry_list = nullptr; c->lane_entry_cap = 0; c->lane_world = 0; c->lane_ready = nullptr; c->lane_ready_cap = 0;
+  c->hullhint = nullptr; c->skin = nullptr; c->skin_r = 0.0f; c->bail = 0; c->handoff = nullptr; c->handoff_stride = 0; c->handoff_large = 0; c->resume_first = 0; c->soft_maxefc = c->soft_jpool = c->soft_maxcon = 0; c->lane_entry_count = nullptr; c->lane_entry_list = nullptr; c->lane_entry_cap = 0; c->lane_world = 0; c->lane_ready = nullptr; c->lane_ready_cap = 0;
 #if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)   // test infrastructure (tools/emu_mixed.py): the field map of the working set
 #define GRX_CARVE_REC(field, n, isint) grx_emu_carve_rec(#field, (void*)p, (n), (isint));
 #else
@@ -299,6 +305,47 @@ GRX_MEM int grx_lane_claim(GrxCtx* c, int lane_) {
   if (lane_ == 0) {
     c->lane_entry_list[idx] = c->lane_world;
     if (c->lane_ready && idx < c->lane_ready_cap) { __threadfence(); atomicExch(c->lane_ready + idx, 1); }   // published: a polling workgroup of the standing lane launch may take it now
+  }
+  c->bail = 2;
+  return 1;
+#endif
+}
+
+// words of a hand-off row (GrxCtx::handoff): [0] substep + 1 (0 = none) as int, [1] status flags as int, ctrl[nu], mocap pos / quat [7 nmocap], qpos, qvel, qacc_ws
+GRX_HD int grx_handoff_words(int nq, int nv, int nu, int nmocap) { return 2 + nu + 7 * nmocap + nq + 2 * nv; }
+// is a hand-off due?  (wave-uniform: the flags live in LDS, read after a WAVE_SYNC)
+GRX_DEV int grx_handoff_due(const GrxCtx* c) {
+  return c->handoff != nullptr && c->bail == 1 &&
+         ((c->cnt[2] & (GRX_ST_HULL | GRX_ST_EFC_OVERFLOW)) || ((c->cnt[2] & GRX_ST_CON_OVERFLOW) && c->maxcon < GRX_MAXCON));
+}
+// The hand-off itself, called at the substep boundary: 1 = the world's row is written and its entry published: stop, nothing of this run is kept (c->bail = 2).
+// 0 = the step's entry list is full: the world goes on in THIS kernel without a lane (c->bail = 0; the caller repeats the substep to its end -- the contacts that do not
+// fit, or the hull pairs this kernel cannot collide, are dropped and the sticky status flag says so).
+GRX_MEM int grx_lane_handoff(GrxCtx* c, int substep, int nq, int nv, int nu, int nmocap, int lane_) {
+#if defined(GRX_EMU)
+  (void)c; (void)substep; (void)nq; (void)nv; (void)nu; (void)nmocap; (void)lane_;
+  return 0;
+#else
+  int idx = 0;
+  if (lane_ == 0) idx = atomicAdd(c->lane_entry_count, 1);
+  idx = __builtin_amdgcn_readfirstlane(idx);
+  if (idx >= c->lane_entry_cap) { c->bail = 0; return 0; }
+  float* row = c->handoff + (size_t)c->lane_world * c->handoff_stride;
+  int o = 2;
+  for (int i = lane_; i < nu; i += 64) row[o + i] = c->ctrl[i];
+  o += nu;
+  for (int i = lane_; i < 7 * nmocap; i += 64) { const int k = i / 7, e = i - 7 * k; row[o + i] = (e < 3) ? c->mocap_pos[3 * k + e] : c->mocap_quat[4 * k + e - 3]; }
+  o += 7 * nmocap;
+  for (int i = lane_; i < nq; i += 64) row[o + i] = c->qpos[i];
+  o += nq;
+  for (int i = lane_; i < nv; i += 64) { row[o + i] = c->qvel[i]; row[o + nv + i] = c->qacc_ws[i]; }
+  if (lane_ == 0) { ((int*)row)[1] = c->cnt[2] & ~(GRX_ST_HULL | GRX_ST_EFC_OVERFLOW | GRX_ST_CON_OVERFLOW); ((int*)row)[0] = substep + 1; }
+  __threadfence();      // every lane: its part of the row is written back before the entry can be seen (the taker may run on another XCD, behind another L2)
+  __syncthreads();
+  if (lane_ == 0) {
+    c->lane_entry_list[idx] = c->lane_world | (c->handoff_large ? (1 << 30) : 0);
+    __threadfence();
+    if (c->lane_ready && idx < c->lane_ready_cap) atomicExch(c->lane_ready + idx, 1);   // published: a polling workgroup of the standing lane launch may take it now
   }
   c->bail = 2;
   return 1;
@@ -535,6 +582,10 @@ struct GrxShape {
   static constexpr bool kIncrHess = (NV_ == 0) || (NQ_ != NV_ && INTEG_ == 0) || NV_ > 33;   // ... and AdroitHandRelocate (nv 36: a full assembly = the 32 x 32 tile + four more rows / columns; A/B 17.4 -> 15.9 ms per step; door / pen / hammer measured slower or equal with it)
   static constexpr bool kConvex = (NV_ == 0) || ((CONVEX_ & 1) != 0);   // carries the general convex (MPR) narrow phase for primitive pairs: the generic kernels and the shapes of models that need it
   static constexpr bool kMesh = (NV_ == 0) || ((CONVEX_ & 2) != 0);     // carries the wave-cooperative hull-vs-convex routine (models with mesh-mesh / mesh-primitive pairs)
+  // bit 5: the model HAS hull pairs but this kernel carries no routine for them (it fits 168 VGPRs = a third wave per SIMD): gates and the bounding-box filter run as usual,
+  // a pair that passes them hands the world off mid-step to a kernel that has the routine (GRX_ST_HULL, grx_lane_handoff)
+  static constexpr bool kHandoff = (NV_ != 0) && ((CONVEX_ & 32) != 0);
+  static constexpr bool kHullFilter = kMesh || kHandoff;
   static constexpr int NMESH = (CONVEX_ & 2) ? 1 : 0;
   static constexpr int NSHIFT = (CONVEX_ & 4) ? 1 : 0;   // the model has a per-world shift group (Adroit's nail board)
   static constexpr int NOSLIP = (CONVEX_ & 8) ? 1 : 0;   // the model runs the noslip post-solver

@@ -36,6 +36,8 @@ struct GrxFetchBuffers {
   int* cost;                             // [N] or null: out, cost estimate of this world (the next launch's ordering key)
   float* packed;                         // [N, obs_dim + 3 + 3 + 2] or null: out, the row [obs | achieved | desired | reward | success] (what the cross-rank gather ships)
   float* hullcache;                      // [N, GRX_HULLCACHE_WORDS] or null: in/out, GrxCtx::meshcache carried across launches + the support-vertex guesses (include/grx_capi.h)
+  float* handoff;                        // [N, handoff_stride] or null: the worlds' mid-step hand-off rows (include/grx_capi.h; GrxCtx::handoff); word 0 of a row = substep + 1, 0 = none
+  int handoff_stride, handoff_large;     // words per row (>= grx_handoff_words); handoff_large: entries claimed by THIS launch need the large tables (see grx_overflow_lane)
   GrxLane lane;                          // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 
@@ -134,17 +136,27 @@ GRX_MEM void grx_fetch_step_world(const GrxModel* m, const GrxFetchTask* t, GrxC
   grx_fetch_sim_world(m, t, c, aux_in, action, lane_);
   grx_fetch_outputs(m, t, c, aux_out, obs, achieved, lane_);
 }
-// the simulation part alone: the step kernel derives the output pointers after it, so no global address stays live across the substeps
-GRX_MEM void grx_fetch_sim_world(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux_in, const float* action, int lane_) {
-  grx_fetch_set_action(m, t, c, aux_in, action, lane_);
+// the simulation part alone: the step kernel derives the output pointers after it, so no global address stays live across the substeps.
+// s0 > 0: the world RESUMES at substep s0 -- the caller has restored ctrl, mocap, qpos, qvel and the warm start from its hand-off row (GrxCtx::handoff) and set c->resume_first.
+GRX_MEM void grx_fetch_sim_world(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux_in, const float* action, int lane_, int s0 = 0) {
+  if (s0 == 0) grx_fetch_set_action(m, t, c, aux_in, action, lane_);
   // n_substeps x mj_step, plus (block_gripper tasks) the _step_callback: zero the finger qpos and run one mj_forward.
   // One loop, one call site of the physics, so the loop body stays resident in the instruction cache.
   const int total = t->n_substeps + (t->block_gripper ? 1 : 0);
-  for (int s = 0; s < total; s++) {
+  for (int s = s0; s < total; s++) {
     const int callback = (s == t->n_substeps);
     if (callback) { LANE0 { c->qpos[t->jq_lf] = 0.0f; c->qpos[t->jq_rf] = 0.0f; } WAVE_SYNC(); }
     else E::grx_check_state(m, c, lane_);
     E::grx_forward_euler(m, c, !callback, lane_);
+    c->resume_first = 0;
+    if (grx_handoff_due(c)) {   // (kernels launched with a hand-off row) the substep stopped before it touched the state: hand the world off AT this substep
+      if (grx_lane_handoff(c, s, GRX_NQC, GRX_NVC, GRX_NUC, GRX_NMC, lane_)) break;
+      // the step's entry list is full (c->bail is 0 now): this kernel finishes the substep itself, dropping what it cannot hold / collide; the sticky status flag says so
+      LANE0 { c->cnt[2] &= ~GRX_ST_HULL; }
+      WAVE_SYNC();
+      c->resume_first = 1; s--;
+      continue;
+    }
     if (c->bail && grx_lane_claim(c, lane_)) break;   // a capacity overflowed and the re-run on the large tables is booked: this run will be discarded
   }
 }

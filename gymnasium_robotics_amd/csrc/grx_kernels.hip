@@ -192,7 +192,7 @@ template <class S> static __device__ __forceinline__ GrxDims grx_shape_dims(cons
 #endif
 template <class S> static bool grx_shape_matches(const GrxModel& g) {
   return g.nq == S::NQ && g.nv == S::NV && g.nu == S::NU && g.nbody == S::NB && g.njnt == S::NJ && g.ngeom == S::NG && g.nsite == S::NS &&
-         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (GRX_MATCH_ANY_MESH || S::kMesh == (g.nmeshpair != 0)) && (S::kShift == (g.nshift != 0)) && (S::kNoslip == (g.noslip_iterations > 0)) && (S::NF != 24 || g.handtree);
+         g.nmocap == S::NM && g.nfric == S::NF && g.integrator == S::INTEG && g.maxefc == S::ME && g.jpool == S::JP && g.ntouch == S::NT && g.maxcon == S::MC && (S::kTwoSpan || !g.twospan) && (S::kConvex == (g.nconvex != 0)) && (GRX_MATCH_ANY_MESH || S::kHullFilter == (g.nmeshpair != 0)) && (S::kShift == (g.nshift != 0)) && (S::kNoslip == (g.noslip_iterations > 0)) && (S::NF != 24 || g.handtree);
 }
 // last template argument: bit 0 = general convex routine for primitive pairs (ellipsoid / cylinder), bit 1 = hull-vs-convex pairs (every model with
 // collidable mesh geoms next to boxes / other meshes: all Fetch and Shadow-hand models)
@@ -213,6 +213,16 @@ typedef GrxShape<22, 21, 0, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_ME, GRX_FETCH_JP, 
 // the SAME models with the tables of the overflow lane (core.RERUN_CAPACITY): only the lane kernels are instantiated for them (BASELINE configs 2 / 3 / 5a; the other
 // models' lanes run on the generic kernel, 2-3 x slower per world)
 typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, 256, 4080, 0, 64, 0, 2> GrxShapeFetchPickLane;
+// Round 6: the FAST FetchPickAndPlace step kernel.  No hull routine (flag 32: GrxShape::kHandoff) -> 168 VGPRs, a third wave per SIMD; 96 rows / 1 024 pool words / 24 contacts ->
+// 15.2 KB of LDS, ten worlds per CU.  A world in which a hull pair passes the bounding-box filter (8 % of the worlds of a stationary batch, profiles/hull_share_r06_fetch.txt) or
+// that exceeds a table is handed off MID-STEP (grx_lane_handoff) to the standing lane, which runs GrxShapeFetchPick -- today's kernel -- as the lane kernel; what exceeds
+// THAT kernel's tables goes on to GrxShapeFetchPickLane.  Step kernel only: forward / reset launches of the model use GrxShapeFetchPick.
+#ifndef GRX_FETCH_FAST_ME
+#define GRX_FETCH_FAST_ME 96
+#define GRX_FETCH_FAST_JP 1024
+#define GRX_FETCH_FAST_MC 24
+#endif
+typedef GrxShape<22, 21, 2, 16, 16, 20, 3, 1, 0, 0, GRX_FETCH_FAST_ME, GRX_FETCH_FAST_JP, 0, GRX_FETCH_FAST_MC, 0, 32> GrxShapeFetchPickFast;
 // ant.xml + maze walls (RK4): the geom count depends on the maze layout (Large / Medium / Open / UMaze of maze/maps.py)
 typedef GrxShape<15, 14, 8, 10, 9, 76, 1, 0, 0, 1, 64, 512, 0, 16> GrxShapeAntLarge;
 typedef GrxShape<15, 14, 8, 10, 9, 52, 1, 0, 0, 1, 64, 512, 0, 16> GrxShapeAntMedium;
@@ -227,7 +237,7 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 256, 4080, 92, 64, 1, 2> G
 
 // waves per SIMD the Fetch kernels are compiled for (VGPR budget 168 at 3, 256 at 2): the convex narrow phase needs the full budget
 #ifndef GRX_FETCH_WAVES
-#define GRX_FETCH_WAVES(S) 2   // the wave-cooperative hull routine keeps ~100 values live: at 168 VGPRs (3 waves) the step kernels spill 60-130 registers and run slower than at 2 waves even with 9 instead of 8 worlds per CU and the hull branch marked cold (measured 3.75 vs 3.44 ms per step)
+#define GRX_FETCH_WAVES(S) (S::kHandoff ? 3 : 2)   // the wave-cooperative hull routine keeps ~100 values live: at 168 VGPRs (3 waves) the step kernels spill 60-130 registers and run slower than at 2 waves even with 9 instead of 8 worlds per CU and the hull branch marked cold (measured 3.75 vs 3.44 ms per step)
 #endif
 // one world's env.step().  LANE: called from the list-walking loop of the large-table kernel (w comes from the list; see grx_overflow_lane)
 template <class S, bool LANE>
@@ -240,6 +250,7 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
   c.mslot = mslot;
   grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
   grx_lane_setup(b.lane, c, w, true);
+  if (b.handoff && c.bail) { c.handoff = b.handoff; c.handoff_stride = b.handoff_stride; c.handoff_large = b.handoff_large; }   // this launch can hand a world off mid-step (it has an entry list to claim from)
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
@@ -256,7 +267,28 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
   if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) c.meshcache[lane_] = b.hullcache[(size_t)w * GRX_HULLCACHE_WORDS + lane_];   // separating directions remembered from the previous step (re-verified before use)
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = b.aux[(size_t)w * 8 + k];
-  GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_);
+  int s0 = 0;
+  if (LANE && b.handoff) {   // a world another kernel of this step handed off: resume AT the substep it stopped before (its row was written during this very launch group, possibly
+                             // behind another XCD's L2: volatile = cache-bypassing loads, ordered behind the claim of the entry by the caller's fence)
+    volatile const float* row = b.handoff + (size_t)w * b.handoff_stride;
+    const int hs = __builtin_amdgcn_readfirstlane(((volatile const int*)row)[0]);
+    if (hs > 0) {
+      GrxFetch<S>::grx_fetch_set_action(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_);   // (everything it computes is overwritten below; kept so that the resumed path differs from the plain one by loads only)
+      const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv, nu = S::kFixed ? S::NU : m.nu, nmo = S::kFixed ? S::NM : m.nmocap;
+      int o = 2;
+      for (int i = lane_; i < nu; i += 64) c.ctrl[i] = row[o + i];
+      o += nu;
+      for (int i = lane_; i < 7 * nmo; i += 64) { const int k = i / 7, e = i - 7 * k; const float v = row[o + i]; if (e < 3) c.mocap_pos[3 * k + e] = v; else c.mocap_quat[4 * k + e - 3] = v; }
+      o += 7 * nmo;
+      for (int i = lane_; i < nq; i += 64) c.qpos[i] = row[o + i];
+      o += nq;
+      for (int i = lane_; i < nv; i += 64) { c.qvel[i] = row[o + i]; c.qacc_ws[i] = row[o + nv + i]; }
+      if (lane_ == 0) { c.cnt[2] |= ((volatile const int*)row)[1]; ((volatile int*)row)[0] = 0; }   // the flags of the substeps the other kernel ran; the row is consumed
+      __syncthreads();
+      c.resume_first = 1; s0 = hs - 1;
+    }
+  }
+  GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_, s0);
   const int wl = LANE ? w : (b.order ? b.order[grx_block_late()] : grx_world_of_block_late());
   // a capacity overflowed (wave-uniform: the flag lives in LDS): keep nothing, the world is re-run on the large tables (grx_overflow_lane)
   if (!grx_lane_overflowed(c)) {
@@ -295,17 +327,24 @@ grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
   grx_fetch_step_world<S, false>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, lds, lane_);
+  grx_lane_progress(b.lane);   // (launches with polling workgroups behind them: this workgroup has ended)
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
 template <class S>
 __global__ void __launch_bounds__(64, 2)
 grx_fetch_lane_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {   // one workgroup per entry of the compacted list (the caller sizes the grid: grx_overflow_lane.grid >= the list's cap)
   extern __shared__ float lds[];
-  const int e = blockIdx.x;
-  // the Fetch kernels do not implement the polling protocol (core.OverflowLane mode "entry"): workgroups a caller adds for polling (lane.poll_grid) have no list entry
-  // to walk -- beyond grid - poll_grid the list holds stale or unwritten indices
-  if (e >= (int)gridDim.x - b.lane.poll_grid || e >= *b.lane.count) return;
-  grx_fetch_step_world<S, true>(mslot, t, b, b.lane.list[e], n_worlds, words, lds, (int)threadIdx.x);
+  const int e = blockIdx.x, nstand = (int)gridDim.x - b.lane.poll_grid;
+  // entries carry the world in their low 30 bits; bit 30 = "needs the LARGE tables" (claimed by a launch that already ran the middle ones, GrxCtx::handoff_large)
+  if (e >= nstand) {   // a polling workgroup (grx_lane_poll): takes entry e - nstand of THIS step's entry list while the fast launch is still running
+    const int ent = grx_lane_poll(b.lane, e - nstand);
+    if (ent < 0) return;
+    if ((ent >> 30) & 1) { if (threadIdx.x == 0) atomicExch(b.lane.ready + (e - nstand), 1); return; }   // not for these tables: give the entry back, the entry launch behind the fast kernel takes it
+    grx_fetch_step_world<S, true>(mslot, t, b, ent & 0x3FFFFFFF, n_worlds, words, lds, (int)threadIdx.x);
+    return;
+  }
+  if (e >= *b.lane.count || grx_lane_taken(b.lane, e)) return;
+  grx_fetch_step_world<S, true>(mslot, t, b, b.lane.list[e] & 0x3FFFFFFF, n_worlds, words, lds, (int)threadIdx.x);
 }
 
 // reset-time mj_forward + outputs (nstep > 0: raw settle steps first, _env_setup).  Shape-specialised like the step kernel: the generic
@@ -702,6 +741,8 @@ extern "C" int grx_tu_fetch_prepare(const GrxModel* g, int bytes, int slot, int*
 #define X(ID, SHAPE) if (!found && grx_shape_matches<SHAPE>(*g)) { found = ID; GRX_LDS(grx_fetch_step_kernel<SHAPE>); GRX_LDS(grx_fetch_forward_kernel<SHAPE>); GRX_LDS(grx_fetch_reset_kernel<SHAPE>); }
   GRX_FETCH_SHAPES(X)
 #undef X
+  if (found == 1) GRX_LDS(grx_fetch_lane_kernel<GrxShapeFetchPick>);   // today's FetchPickAndPlace kernel as the standing lane of the fast one (round 6)
+  if (!found && grx_shape_matches<GrxShapeFetchPickFast>(*g)) { found = 8; GRX_LDS(grx_fetch_step_kernel<GrxShapeFetchPickFast>); }   // step kernel only
   if (!found && grx_shape_matches<GrxShapeFetchPickLane>(*g)) { found = 101; GRX_LDS(grx_fetch_lane_kernel<GrxShapeFetchPickLane>); }   // ids >= 100: lane kernel only (everything else of such a model runs generic)
   if (found) *shape = found;
   return (int)grx_upload_descriptor(g, slot);
@@ -712,7 +753,13 @@ extern "C" int grx_tu_fetch_launch(int kind, int shape, unsigned grid, size_t ld
   const dim3 g(grid), blk(64); hipStream_t st = (hipStream_t)stream;
   if (kind == 0 && b->lane.list) {
     if (shape == 101) hipLaunchKernelGGL(grx_fetch_lane_kernel<GrxShapeFetchPickLane>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    else if (shape == 1) hipLaunchKernelGGL(grx_fetch_lane_kernel<GrxShapeFetchPick>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
     else hipLaunchKernelGGL(grx_fetch_lane_kernel<GrxShapeAny>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
+    return (int)hipGetLastError();
+  }
+  if (shape == 8) {   // the fast FetchPickAndPlace model: its shape exists as a step kernel only
+    if (kind != 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(grx_fetch_step_kernel<GrxShapeFetchPickFast>, g, blk, lds_bytes, st, slot, *t, *b, n, words);
     return (int)hipGetLastError();
   }
 #define GRX_FETCH_GO(SHAPE) do { \
@@ -1098,7 +1145,9 @@ extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, co
   if (n_worlds <= 0) return 0;
   GrxFetchTask t; memcpy(&t, task, sizeof(t));
   GrxFetchBuffers b; memcpy(&b, buf, sizeof(b));
-  if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_fetch_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
+  if (b.lane.list && m->shape != 0 && m->shape != 1 && m->shape < 100) return fail("grx_fetch_step: a lane launch needs a model with a lane kernel (the generic kernel, FetchPickAndPlace's own shape, or its large-table shape)");
+  if (m->shape == 8 && !(b.handoff && b.lane.entry_count && b.lane.entry_list && b.handoff_stride >= grx_handoff_words(m->dev.nq, m->dev.nv, m->dev.nu, m->dev.nmocap)))
+    return fail("grx_fetch_step: the fast FetchPickAndPlace kernel carries no hull routine: it needs hand-off rows (handoff, handoff_stride) and an entry list to hand hull worlds to");
   const int e = grx_tu_fetch_launch(0, m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, 0);
   if (e) return fail(std::string("grx_fetch_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;

@@ -37,6 +37,11 @@ _MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mo
 # the large ones, 1 - 3 ms once each -- exceed the POOL by a few dozen words (2 005 .. 2 054 of 1 984) while the contact list peaks at 26 of 32: 28 contacts / 2 032 words fit the
 # same 16 granules (20 424 B) and halve the re-runs.
 FETCH_CAPACITY = {"maxcon": 28, "maxefc": 144, "jpool": 2032, "split_spans": False}   # the arm chain is (nearly) contiguous: single-span rows
+# Round 6 (opt-in, GRX_FETCH_HANDOFF=1; see __init__): tables of the FAST FetchPickAndPlace step kernel (csrc/grx_kernels.hip GrxShapeFetchPickFast: no hull routine, 168 VGPRs = three waves per SIMD, 15.2 KB of LDS = ten
+# worlds per CU).  ~0.1 % of the world-steps exceed 1 024 pool words, none 24 contacts (profiles/hull_share_r06_fetch.txt); a world that does -- or in which a hull pair passes the
+# bounding-box filter -- is handed off MID-STEP to the standing lane, which runs the kernel on FETCH_CAPACITY above (include/grx_capi.h, grx_fetch_buffers.handoff).
+FETCH_FAST_CAPACITY = {"maxcon": 24, "maxefc": 96, "jpool": 1024}
+HANDOFF_TASKS = ("FetchPickAndPlace",)
 
 
 def load_fetch_model(task: str, assets_root: Optional[str] = None) -> CompiledModel:
@@ -117,6 +122,15 @@ class FetchVecEnv(GoalVecEnv):
         self.lds_bytes = self._L.grx_model_lds_bytes(self._h)
         # the same model with larger row / Jacobian-pool tables (runs on the generic kernel): where the worlds go that overflow the specialised kernel's capacities
         self._h_big = create_rerun_model(self._L, self.model, dev_index, overflow_rerun)
+        # Fast step kernel + mid-step hand-off: BUILT, bit-identical to the full kernel's rollout (tests/test_gpu_fetch.py::test_handoff_is_the_full_kernels_rollout), and OFF by
+        # default -- measured (profiles/ab_r06_fetch_handoff.txt): +4 % at 4 096 worlds, 0 % at 8 192, -8 % at 16 384.  The third wave per SIMD buys nothing for this kernel (a world
+        # runs 1.27x longer at ten per CU than at eight), and the 8 - 19 % of the worlds that live in the hull lane keep their 256-VGPR kernel.  GRX_FETCH_HANDOFF=1 switches it on.
+        self._h_fast, self._fast_model = None, None
+        if task in HANDOFF_TASKS and self._h_big is not None and self.num_envs >= 64 and os.environ.get("GRX_FETCH_HANDOFF", "0") == "1" and os.environ.get("GRX_FETCH_CAP") is None:
+            self._fast_model = self.model.with_capacity(**FETCH_FAST_CAPACITY)
+            Hf, If, Ff = self._fast_model.pack()
+            self._h_fast = _native.acquire_model(Hf, If, Ff, dev_index)
+            self.lds_bytes = self._L.grx_model_lds_bytes(self._h_fast)      # the step kernel's footprint (slots of the cost-ordered dispatch)
         self._alloc(self.num_envs)
         self._env_setup()
         # spaces (envs/robot_env.py:87-100)
@@ -140,7 +154,7 @@ class FetchVecEnv(GoalVecEnv):
             if ev is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, self._stream()))
+            _native.check(self._L.grx_fetch_step(self._h_fast or self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, self._stream()))
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
@@ -149,11 +163,13 @@ class FetchVecEnv(GoalVecEnv):
             fast(bufs)
         else:
             large = lambda b: _native.check(self._L.grx_fetch_step(self._h_big, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, self._stream()))
+            # with the fast kernel: the standing lane (hull worlds, worlds near a capacity of the fast tables) runs the model's own kernel on FETCH_CAPACITY
+            middle = (lambda b: _native.check(self._L.grx_fetch_step(self._h, ctypes.byref(self.task), ctypes.byref(b), self.num_envs, self._stream()))) if self._h_fast else None
             timed = self.kernel_events is not None and self.step_events is not None      # the fast launch AND the re-run of the worlds that overflowed its tables (behind it, same stream)
             if timed:
                 l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 l0.record()
-            self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs)
+            self.lane.step(self.mask if bufs is self._bufs_masked else None, fast, large, fast_bufs=bufs, launch_lane=middle)
             if timed:
                 l1.record()
                 self.step_events.append((l0, l1))
@@ -183,7 +199,7 @@ class FetchVecEnv(GoalVecEnv):
         self.order = None
         # wave slots of one XCD (32 CUs): worlds per CU = what the LDS footprint allows (1 280-byte granules of 160 KB), at most the 8 waves a 2-waves-per-SIMD kernel gets;
         # grx_order_by_cost_slots uses it in the two-worlds-per-slot regime (4096 worlds on 2048 slots), GRX_TAIL_ORDER=0 restores the plain descending order
-        self._slots_per_xcd = 32 * min(8, (160 * 1024) // (-(-self.lds_bytes // 1280) * 1280)) if (self.balance and os.environ.get("GRX_TAIL_ORDER", "1") != "0") else 0
+        self._slots_per_xcd = 32 * min(12 if self._h_fast else 8, (160 * 1024) // (-(-self.lds_bytes // 1280) * 1280)) if (self.balance and os.environ.get("GRX_TAIL_ORDER", "1") != "0") else 0
         if self.balance:
             per = n // 8
             self._slice_base = (torch.arange(8, device=d, dtype=torch.int32) * per).unsqueeze(1)          # [8,1]
@@ -194,12 +210,29 @@ class FetchVecEnv(GoalVecEnv):
         # No dropped contacts (core.OverflowLane / include/grx_capi.h grx_overflow_lane): a world that exceeds a table capacity of the specialised kernel writes
         # nothing and is stepped on the SAME model with larger tables (generic kernel) -- concurrently with the fast launch once it is in the lane.
         common = (self.qpos, self.qvel, self.qacc_ws, self.mocap, self.aux, self.goal, self.action, self.obs, self.achieved, self.reward, self.success, self.status)
-        self._bufs = self._make_bufs(*common, None, self.order, self.cost, self.packed, self.hullcache)
-        self._bufs_masked = self._make_bufs(*common, self.mask, self.order, self.cost, self.packed, self.hullcache)
+        # mid-step hand-off rows (include/grx_capi.h grx_fetch_buffers.handoff): [substep + 1 | status | ctrl | mocap | qpos | qvel | warm start], 16-word aligned; all zero between steps
+        self.handoff, self._handoff_stride = None, 0
+        if getattr(self, "_h_fast", None):
+            self._handoff_stride = -(-(2 + self.model.dim("nu") + 7 * self.nmocap + self.nq + 2 * self.nv) // 16) * 16
+            self.handoff = z(n, self._handoff_stride)
+        self._bufs = self._make_bufs(*common, None, self.order, self.cost, self.packed, self.hullcache, self.handoff)
+        self._bufs_masked = self._make_bufs(*common, self.mask, self.order, self.cost, self.packed, self.hullcache, self.handoff)
+        self._bufs.handoff_stride = self._bufs_masked.handoff_stride = self._handoff_stride
         self.lane = None
         if self._h_big is not None:
-            packed, hullcache, mk = self.packed, self.hullcache, FetchVecEnv._make_bufs      # (no reference to self: the lane must not keep the environment alive)
-            self.lane = OverflowLane(n, d, self.model, lambda m: mk(*common, m, None, None, packed, hullcache), mode="entry")     # overflows are rare events here (0.0007 % of the world-steps)
+            packed, hullcache, handoff, stride, mk = self.packed, self.hullcache, self.handoff, self._handoff_stride, FetchVecEnv._make_bufs      # (no reference to self: the lane must not keep the environment alive)
+
+            def lane_bufs(m):
+                b = mk(*common, m, None, None, packed, hullcache, handoff)
+                b.handoff_stride = stride
+                return b
+
+            if handoff is not None:
+                # hull activity persists for a few steps and 8 % of a stationary batch shows it: a STANDING lane with polling workgroups for the ~1 % of the worlds that enter per step
+                self.lane = OverflowLane(n, d, self._fast_model, lane_bufs, mode="lane", handoff=True, poll_grid=int(os.environ.get("GRX_FETCH_POLL", max(64, n // 32))),
+                                         ttl=int(os.environ.get("GRX_FETCH_TTL", 4)), margin=0.9)
+            else:
+                self.lane = OverflowLane(n, d, self.model, lane_bufs, mode="entry")     # overflows are rare events here (0.0007 % of the world-steps)
         # Overlapped same-step reset (include/grx_capi.h, grx_fetch_commit_rows): Fetch episodes end by the time limit only, so the worlds a step will reset are known before
         # it is launched and their reset state depends on nothing the step computes.  The reset kernel runs for them on a side stream, beside the step kernel, into this second
         # set of world rows; ONE small kernel behind the step commits them (parks the terminal rows, copies the staged ones).  The in-line reset (88 us of a 3.3 ms step at
@@ -468,6 +501,9 @@ class FetchVecEnv(GoalVecEnv):
         if getattr(self, "_h_big", None):
             _native.release_model(self._h_big)
             self._h_big = None
+        if getattr(self, "_h_fast", None):
+            _native.release_model(self._h_fast)
+            self._h_fast = None
 
     def __del__(self):
         try:

@@ -59,7 +59,8 @@ typedef struct grx_model grx_model;
  * status bit raised -- never silently: count `status` (bench.py: capacity_overflow_worlds, 0 in every measured workload). */
 typedef struct grx_overflow_lane {
   const unsigned char* skip;            /* fast kernel, [N]: worlds in the lane this step */
-  int* entry_count; int* entry_list;    /* fast kernel: out, the worlds that overflowed ([1], [N]) */
+  int* entry_count; int* entry_list;    /* fast kernel: out, the worlds that overflowed ([1], [N]); an entry = world id | (1 << 30 when it needs the LARGE tables: claimed by a lane launch that
+                                         * already runs the middle ones, grx_fetch_buffers.handoff_large -- polling workgroups of such a launch give these back to the entry launch) */
   const int* list; const int* count;    /* large kernel: in, the worlds to step ([N], [1]) */
   unsigned char* next_flags; int* next_count; int* next_list;   /* large kernel: out, the lane of the next step ([N], [1], [N]) */
   signed char* ttl;                     /* large kernel: in/out [N] */
@@ -121,6 +122,15 @@ typedef struct grx_fetch_buffers {
   float* hullcache;                     /* [N, 90] or NULL (zero-initialised; 21 words of separating directions + 69 words of support-vertex guesses of persistent hull contacts): the world's cache of separating directions of its hull-vs-convex pairs (engine: GrxCtx::meshcache), carried from one
                                          * env.step() to the next.  A remembered direction is re-verified before it is trusted (it proves "no contact", exactly what the portal
                                          * search would report), so the rows never change a result: they save the search every launch otherwise starts with. */
+  /* MID-STEP HAND-OFF (round 6; NULL / 0 = off).  A launch that has an entry list to claim from (lane.entry_count) and these rows does not re-run a world it cannot finish from
+   * the first substep: it stops at the START of the substep in question -- a table capacity is exceeded, or the kernel carries no hull routine (the fast FetchPickAndPlace
+   * kernel: 168 VGPRs, a third wave per SIMD) and a hull pair has passed the bounding-box filter; nothing of that substep has touched the state -- writes the world's row
+   * [substep + 1 | status flags | ctrl[nu] | mocap[7 nmocap] | qpos[nq] | qvel[nv] | qacc_warmstart[nv]] and publishes the entry (world id, bit 30 = handoff_large).  A lane
+   * launch (lane.list != NULL) that finds word 0 of a world's row non-zero restores the row, clears the word and resumes AT that substep; results are bit-identical to a
+   * step run by the lane's kernel alone (tests/test_gpu_fetch.py::test_handoff_is_the_full_kernels_rollout).  Rows must be zero before the first launch. */
+  float* handoff;                       /* [N, handoff_stride] or NULL */
+  int handoff_stride;                   /* words per row, >= 2 + nu + 7 nmocap + nq + 2 nv */
+  int handoff_large;                    /* 1: entries claimed by THIS launch need the large tables (it runs the middle ones): polling workgroups give them back to the entry launch */
   grx_overflow_lane lane;               /* capacity overflows are re-run on larger tables instead of dropping contacts: see grx_overflow_lane above and its LIMITS */
 } grx_fetch_buffers;
 

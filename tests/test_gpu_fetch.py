@@ -150,6 +150,49 @@ def test_hull_candidate_lists_do_not_change_the_rollout(monkeypatch):
             assert torch.equal(envs[0].qpos, e.qpos) and torch.equal(envs[0].qvel, e.qvel) and torch.equal(envs[0].obs, e.obs), t
 
 
+@pytest.mark.parametrize("start", ["hull_poses", "rollout"])
+def test_handoff_is_the_full_kernels_rollout(monkeypatch, start):
+    """Round 6: FetchPickAndPlace steps on a FAST kernel without the hull-pair routine (168 VGPRs, three waves per SIMD, ten worlds per CU); a world in which a hull pair passes
+    the bounding-box filter, or that exceeds the fast tables, is handed off MID-STEP -- at the substep in question, state untouched -- to the standing lane, which runs the
+    model's full kernel and resumes AT that substep (include/grx_capi.h, grx_fetch_buffers.handoff).  Opt-in (GRX_FETCH_HANDOFF=1: measured no faster).  Against
+    the same rollout with every world on the full kernel (the default, what rounds 1 - 5 ran): state rows, observations, rewards, flags and status words are BIT-IDENTICAL after every step, from the 168 folded-arm poses of
+    the hull fixture (every world has hull activity from the first substep) and over staggered episodes with same-step autoresets (worlds enter and leave the lane)."""
+    import torch
+
+    envs = []
+    monkeypatch.setenv("GRX_LANE_FIRST", "1"); monkeypatch.setenv("GRX_LANE_SPACER", "50000")      # the launch order the A/B found best (the lane's workgroups resident before the fast launch)
+    for off in (False, True):
+        monkeypatch.setenv("GRX_FETCH_HANDOFF", "0" if off else "1")
+        if start == "hull_poses":
+            g = np.load(os.path.join(GOLDEN, "fetch_hull_teacher.npz"))
+            n = g["obs"].shape[0]
+            e = _env("FetchPickAndPlace", n, autoreset_mode="disabled", max_episode_steps=None, output="torch")
+            e.reset(seed=0)
+            _load_state(e, g, slice(None))
+        else:
+            n = 1024
+            e = _env("FetchPickAndPlace", n, autoreset_mode="same_step", max_episode_steps=50, output="torch")
+            e.reset(seed=11)
+            e._elapsed[:] = np.arange(n) % 50
+        envs.append(e)
+    fast, full = envs
+    assert fast._h_fast is not None and full._h_fast is None and fast.lane.mode == "lane" and full.lane.mode == "entry"
+    assert fast.lds_bytes < full.lds_bytes and (160 * 1024) // (-(-fast.lds_bytes // 1280) * 1280) >= 10      # ten worlds per CU by LDS
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+    lane_sizes, entrants = [], 0
+    for t in range(40 if start == "hull_poses" else 130):
+        a = torch.rand(n, 4, device="cuda:0", generator=gen) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        for name in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "obs", "achieved", "reward", "success", "packed", "goal"):
+            assert torch.equal(getattr(fast, name), getattr(full, name)), (t, name, int((getattr(fast, name) != getattr(full, name)).sum()))
+        assert torch.equal(fast.status & 0xFFFF, full.status & 0xFFFF) and torch.equal(fast.status >> 16, full.status >> 16), t
+        assert torch.equal(outs[0][3], outs[1][3])
+        assert int(fast.handoff[:, 0].view(torch.int32).abs().max()) == 0, t      # every hand-off row was consumed inside the step
+        lane_sizes.append(fast.lane.count()); entrants += len(fast.lane.entered_last_step())
+    assert int(fast.status.abs().max()) == 0
+    assert max(lane_sizes) > (100 if start == "hull_poses" else 20) and entrants > 20, (max(lane_sizes), entrants)      # the mechanism was really in play
+
+
 @pytest.mark.parametrize("task,output,order", [("FetchPickAndPlace", "torch", "before"), ("FetchPickAndPlace", "numpy", "before"), ("FetchPickAndPlace", "torch", "after"),
                                                ("FetchSlide", "torch", "before"), ("FetchReach", "torch", "before")])
 def test_overlapped_reset_is_the_inline_reset(monkeypatch, task, output, order):
