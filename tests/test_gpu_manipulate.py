@@ -130,8 +130,7 @@ def test_pen_variant_matches_golden_and_reference_distance():
     k = len(g["reset_seed"])
     assert (env.reset_attempts[:k] == g["reset_attempts"]).all() and (obs["observation"][:, 56] > 0.04).all()
     assert np.abs(obs["observation"][:k, 54:57] - g["reset_obs"][:, 54:57]).max() < 2e-3
-    for name in ("qpos", "qvel", "qacc_ws", "goal"):
-        getattr(env, name).copy_(torch.from_numpy(g[name].astype(np.float32)).to(env.device))
+    env.load_world_rows({name: g[name] for name in ("qpos", "qvel", "qacc_ws", "goal")})
     obs, r, _, _, info = env.step(g["action"])
     assert int(info["status"].max()) == 0
     e = np.abs(obs["observation"] - g["obs"])

@@ -48,7 +48,7 @@ def test_teacher_forced_step_matches_mujoco(path):
     cls = FetchVecEnv if env_id.startswith("Fetch") else (HandReachVecEnv if env_id.startswith("HandReach") else HandBlockVecEnv)
     env = cls(env_id, num_envs=n, device="cuda:0", output="numpy", autoreset_mode="disabled", max_episode_steps=None)
     env.reset(seed=0)
-    put = lambda name, arr: getattr(env, name).copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(env.device))
+    put = lambda name, arr: env.load_world_rows({name: arr})      # a MuJoCo-recorded state is in the MJCF's world frame; the device rows live in the model's (mjcf.CompiledModel.origin)
     nq, nv = env.nq, env.nv                       # the device model drops the visual-only target body of the hand-manipulation MJCFs
     put("qpos", g["qpos"][:, :nq]); put("qvel", g["qvel"][:, :nv]); put("qacc_ws", g["qacc_ws"][:, :nv]); put("goal", g["goal"])
     if env_id.startswith("Fetch"):
@@ -73,7 +73,7 @@ def _plain_family(env_id, g, n):
     kw = dict(robot_noise_ratio=0.0, object_noise_ratio=0.0) if env_id.startswith("FrankaKitchen") else {}
     env = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="numpy", autoreset_mode="disabled", max_episode_steps=None, **kw)
     env.reset(seed=0)
-    put = lambda name, arr: getattr(env, name).copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(env.device))
+    put = lambda name, arr: env.load_world_rows({name: arr})
     put("qpos", g["qpos"][:, :env.nq]); put("qvel", g["qvel"][:, :env.nv]); put("qacc_ws", g["qacc_ws"][:, :env.nv])
     if env_id.startswith("AdroitHand"):
         from gymnasium_robotics_amd.envs.adroit_spec import group_shift

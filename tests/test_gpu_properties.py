@@ -65,7 +65,7 @@ def test_hand_block_touch_16384_worlds():
                           autoreset_mode="disabled", max_episode_steps=None)
     obs, r, info, flagged = _rollout(env, 12, 20)
     o = obs["observation"].cpu().numpy()
-    q = env.qpos.cpu().numpy()
+    q = env.world_rows("qpos")      # (the device rows are palm-centred: the MJCF's frame for the floor test below)
     assert o.shape == (16384, 153) and np.isfinite(o).all()
     assert np.abs(np.linalg.norm(q[:, 27:31], axis=1) - 1).max() < 1e-5          # block orientation
     touch = o[:, 61:]
