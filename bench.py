@@ -629,6 +629,10 @@ def run_rank(args, rank, world_size, local_rank):
                          "algorithmic_bytes_per_launch": w["algo"] * n,
                          "note": "fused path is instruction-issue / latency bound (~2e3 FLOP/B), HBM fraction is tiny by construction; see DESIGN.md 6"},
         }
+        # the ant family has no overflow lane and tables smaller than a full contact list (envs/point_maze.py ANT_CAPACITY: 16 contacts / 64 rows / 512 pool words against a measured
+        # peak of 4 / 18 / ~200): a world that exceeds them DROPS contacts, which the reference never does -- such a run is not a measurement
+        if not dry and args.workload == "antmaze" and line["config"]["capacity_overflow_worlds"] > 0:
+            raise SystemExit(f"bench.py: {line['config']['capacity_overflow_worlds']} ant worlds exceeded the engine tables (dropped contacts): raise ANT_CAPACITY")
         if long_window is not None:
             line["long_window"] = long_window
         if dist_report is not None:

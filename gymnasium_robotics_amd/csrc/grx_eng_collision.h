@@ -343,13 +343,14 @@ GRX_MEM void grx_plane_mesh_small(const GrxModel* m, GrxCtx* c, int pair, int g1
 // winners are found with DPP reductions inside the octet and the surviving candidates are compacted, in candidate
 // order, with wave ballots.  Up to eight pairs per pass; the pair queue is filled by grx_collision.
 // Everything stays in registers (no dynamically indexed local arrays): axes are selected with GRX_SEL3.
-#define GRX_BB_LOAD(PAIR) \
-  const int g1 = m->pair_geom1[PAIR], g2 = m->pair_geom2[PAIR]; const float margin = m->pair_margin[PAIR]; \
+#define GRX_BB_LOAD(PAIR) /* the pair's record (GrxModel::reci_pair / recf_pair): geoms, margin and both boxes' half sizes in one volley of reads */ \
+  const int* PI_ = m->reci_pair + GRX_RPI * (PAIR); const float* PF_ = m->recf_pair + GRX_RPF * (PAIR); \
+  const int g1 = PI_[1], g2 = PI_[2]; const float margin = PF_[0]; \
   const float* p1 = c->gxpos + 3 * g1; const float* R1 = c->gxmat + 9 * g1; const float* p2 = c->gxpos + 3 * g2; const float* R2 = c->gxmat + 9 * g2; \
   const float A0[3] = {R1[0], R1[3], R1[6]}, A1[3] = {R1[1], R1[4], R1[7]}, A2[3] = {R1[2], R1[5], R1[8]}; \
   const float B0[3] = {R2[0], R2[3], R2[6]}, B1[3] = {R2[1], R2[4], R2[7]}, B2[3] = {R2[2], R2[5], R2[8]}; \
-  const float a0 = m->geom_size[3 * g1], a1 = m->geom_size[3 * g1 + 1], a2 = m->geom_size[3 * g1 + 2]; \
-  const float b0 = m->geom_size[3 * g2], b1 = m->geom_size[3 * g2 + 1], b2 = m->geom_size[3 * g2 + 2]; \
+  const float a0 = PF_[20], a1 = PF_[21], a2 = PF_[22]; \
+  const float b0 = PF_[24], b1 = PF_[25], b2 = PF_[26]; \
   const float d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
 // axis T (0-2: faces of box 1, 3-5: faces of box 2, 6-14: edge i of box 1 x edge j of box 2): unit axis, projection of d, separation
 #define GRX_BB_AXIS(T, AXV, TP, SEP, OK) { \

@@ -20,11 +20,11 @@ GRX_MEM float grx_impedance(const float* solimp, float pos) {
 }
 
 // column d of the translational / rotational Jacobian of a world point on body b (zero if d not in chain)
-GRX_MEM void grx_jac_col(const GrxModel* m, const GrxCtx* c, int b, const float* point, int d, float* jp, float* jr) {
-  unsigned lo = (unsigned)m->dof_chainmask[2 * b], hi = (unsigned)m->dof_chainmask[2 * b + 1];
+// (the body's dof-chain mask and tree root come from its record -- GrxModel::reci_chain, or the weld's own record -- loaded by the caller in its one volley of table reads)
+GRX_MEM void grx_jac_col(const GrxCtx* c, unsigned lo, unsigned hi, int rootid, const float* point, int d, float* jp, float* jr) {
   int in = d < 32 ? (lo >> d) & 1u : (hi >> (d - 32)) & 1u;
   if (!in) { jp[0] = jp[1] = jp[2] = 0; jr[0] = jr[1] = jr[2] = 0; return; }
-  const float* cref = c->xpos + 3 * m->body_rootid[b];
+  const float* cref = c->xpos + 3 * rootid;
   float off[3] = {point[0] - cref[0], point[1] - cref[1], point[2] - cref[2]}, t[3];
   const float* cd = c->cdof + 6 * d;
   float w[3] = {cd[0], cd[1], cd[2]};
@@ -89,27 +89,33 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   const int nwr = 6 * m->nweld, ne = nwr + m->njeq, nf = m->nfric, wpool = m->wpool;   // equality rows: the welds' six each, then one per joint equality
   GRX_LANEVAR_I(limc); GRX_LANEVAR_I(conr); GRX_LANEVAR_I(conw); GRX_LANEVAR_I(coni);
   GRX_LANEVAR_I(tenf); GRX_LANEVAR_I(tenc); GRX_LANEVAR_I(tenw); GRX_LANEVAR(tenl);
+  GRX_LANEVAR_I(jdd); GRX_LANEVAR(jq); GRX_LANEVAR(jr0); GRX_LANEVAR(jr1);   // the joint's lane keeps what its limit rows need: dof, joint value, range
   FOR_LANES {
     int f = 0;
+    LV(jdd) = 0; LV(jq) = 0.0f; LV(jr0) = 0.0f; LV(jr1) = 0.0f;
     if (lane < GRX_NJC) {
       const int j = lane;
-      if (m->jnt_limited[j] && m->jnt_type[j] >= 2) {
-        float q = c->qpos[m->jnt_qposadr[j]], mg = m->jnt_margin[j];
-        if (q - m->jnt_range[2 * j] < mg) f |= 1;
-        if (m->jnt_range[2 * j + 1] - q < mg) f |= 2;
+      const int* JI = m->reci_jnt + GRX_RJI * j; const float* JF = m->recf_jnt + GRX_RJF * j;   // one record per joint (GrxModel::reci_jnt): no table walk
+      const int lim = JI[6], qa = JI[0], dd = JI[3]; const float mg = JF[12 + GRX_PRM_MARGIN], r0 = JF[8], r1 = JF[9];
+      if (lim) {
+        float q = c->qpos[qa];
+        if (q - r0 < mg) f |= 1;
+        if (r1 - q < mg) f |= 2;
+        LV(jq) = q;
       }
+      LV(jdd) = dd; LV(jr0) = r0; LV(jr1) = r1;
       c->ired[j] = f;
     }
     LV(limc) = (f & 1) + ((f >> 1) & 1);
     int nr = 0, slen = 0;
     if (lane < ncon) {
       const int k = lane;
-      int p = c->con_pair[k], dim = m->pair_condim[p];
-      int active = c->con_dist[k] < m->pair_margin[p] - m->pair_gap[p];
+      const int p = c->con_pair[k];
+      const int* PI = m->reci_pair + GRX_RPI * p; const float* PF = m->recf_pair + GRX_RPF * p;   // one record per candidate pair (GrxModel::reci_pair)
+      const int dim = PI[0], cb1 = PI[3], cb2 = PI[4], sp = PI[5];   // sp, static: the two dof spans of the pair's body chains
+      int active = c->con_dist[k] < PF[2];   // margin - gap
       nr = active ? ((dim == 1) ? 1 : 2 * (dim - 1)) : 0;
-      int cb1 = m->geom_bodyid[m->pair_geom1[p]], cb2 = m->geom_bodyid[m->pair_geom2[p]];
       c->con_b1[k] = cb1; c->con_b2[k] = cb2;
-      const int sp = m->pair_span[p];   // static: the two dof spans of the pair's body chains
       slen = ((sp >> 8) & 0xFF) + ((sp >> 24) & 0xFF);
       c->con_span[k] = sp;
     }
@@ -177,13 +183,13 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
           c->efc_kind[r] = GRX_ROW_FRICTION; c->efc_id[r] = d << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), d, 1);
         }
       }
-    if (lane < GRX_NJC) {
+    if (lane < GRX_NJC) {   // joint limits: the joint's lane writes the whole row -- descriptor, the single Jacobian entry and the residual (it holds the joint value and the range)
       const int j = lane, f = c->ired[j];
       if (f) {
         int r = ne + nf + LV(limx);
-        int dd = m->jnt_dofadr[j];
-        if (f & 1) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); } r++; }
-        if (f & 2) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = (j << 4) | 1; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); } }
+        const int dd = LV(jdd); const float q = LV(jq);
+        if (f & 1) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = j << 4; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); c->Jp[wpool + (r - ne)] = 1.0f; c->efc_pos[r] = q - LV(jr0); } r++; }
+        if (f & 2) { if (r < nefc) { c->efc_kind[r] = GRX_ROW_LIMIT; c->efc_id[r] = (j << 4) | 1; c->efc_row[r] = GRX_ROW_PACK(wpool + (r - ne), dd, 1); c->Jp[wpool + (r - ne)] = -1.0f; c->efc_pos[r] = LV(jr1) - q; } }
       }
     }
     if (LV(tenf)) {
@@ -215,9 +221,9 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     // welds: one lane per (weld, dof)
     for (int it = lane; it < (nwr / 6) * nv; it += 64) {
       int w = it / nv, d = it - w * nv;
-      int e = m->weld_eq[w];
-      int b0 = m->eq_obj1[e], b1 = m->eq_obj2[e];
-      const float* data = m->eq_data + 11 * e; const float* rel = m->eq_relpose + 14 * e;
+      const int* WI = m->reci_weld + GRX_RWI * w; const float* data = m->recf_weld + GRX_RWF * w; const float* rel = data + 12;   // one record per weld: bodies, their dof chains, eq_data, eq_relpose
+      const int b0 = WI[1], b1 = WI[2];
+      const unsigned c0lo = (unsigned)WI[4], c0hi = (unsigned)WI[5], c1lo = (unsigned)WI[7], c1hi = (unsigned)WI[8]; const int root0 = WI[6], root1 = WI[9];
       float bx[2][3], bq[2][4], pos[2][3];
       for (int s = 0; s < 2; s++) {
         int bb = s ? b1 : b0; float v[3], rp[3] = {rel[7 * s], rel[7 * s + 1], rel[7 * s + 2]}, rq[4] = {rel[7 * s + 3], rel[7 * s + 4], rel[7 * s + 5], rel[7 * s + 6]};
@@ -229,7 +235,7 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
         for (int k = 0; k < 3; k++) pos[s][k] = bx[s][k] + v[k];
       }
       float jp0[3], jr0[3], jp1[3], jr1[3];
-      grx_jac_col(m, c, b0, pos[0], d, jp0, jr0); grx_jac_col(m, c, b1, pos[1], d, jp1, jr1);
+      grx_jac_col(c, c0lo, c0hi, root0, pos[0], d, jp0, jr0); grx_jac_col(c, c1lo, c1hi, root1, pos[1], d, jp1, jr1);
       float ts = data[10];
       float relq[4] = {data[6], data[7], data[8], data[9]}, quat[4], quat1[4] = {bq[1][0], -bq[1][1], -bq[1][2], -bq[1][3]};
       mulQuatf(quat, bq[0], relq);
@@ -257,15 +263,9 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
     }
     // frictionloss + limits: one lane per row
     GRX_SUBTICK(c, 3);
-    for (int r = ne + lane; r < ne + nf + nlj && r < nefc; r += 64) {
-      if (c->efc_kind[r] == GRX_ROW_FRICTION) {
-        c->Jp[GRX_ROW_OFF(c->efc_row[r])] = 1.0f;
-        c->efc_pos[r] = 0;
-      } else {
-        int j = GRX_ROW_IDOF(c->efc_id[r]), side = c->efc_id[r] & 15; float q = c->qpos[m->jnt_qposadr[j]];
-        c->Jp[GRX_ROW_OFF(c->efc_row[r])] = side ? -1.0f : 1.0f;
-        c->efc_pos[r] = side ? m->jnt_range[2 * j + 1] - q : q - m->jnt_range[2 * j];
-      }
+    for (int r = ne + lane; r < ne + nf && r < nefc; r += 64) {   // (the limit rows that follow them were written by their joints' lanes above)
+      c->Jp[GRX_ROW_OFF(c->efc_row[r])] = 1.0f;
+      c->efc_pos[r] = 0;
     }
     // tendon limits: one lane per tendon writes its (up to two) rows over the tendon's dof span
     if (LV(tenf)) {
@@ -293,9 +293,13 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       int d = jd < slena ? (sp & 0xFF) + jd : ((sp >> 16) & 0xFF) + jd - slena;
       int p = c->con_pair[k], nrk = c->con_nr[k], dim = (nrk == 1) ? 1 : nrk / 2 + 1;
       int b1 = c->con_b1[k], b2 = c->con_b2[k];
+      // one volley of table reads per item: the two bodies' chain records and the pair's friction coefficients
+      const int* C1 = m->reci_chain + GRX_RCI * b1; const int* C2 = m->reci_chain + GRX_RCI * b2; const float* PFr = m->recf_pair + GRX_RPF * p + 3;
+      const unsigned c1lo = (unsigned)C1[0], c1hi = (unsigned)C1[1], c2lo = (unsigned)C2[0], c2hi = (unsigned)C2[1]; const int root1 = C1[2], root2 = C2[2];
+      const float mu0 = PFr[0], mu1 = PFr[1], mu2 = PFr[2], mu3 = PFr[3], mu4 = PFr[4];
       float pos[3] = {c->con_pos[3 * k], c->con_pos[3 * k + 1], c->con_pos[3 * k + 2]};
       float jp1[3], jr1[3], jp2[3], jr2[3];
-      grx_jac_col(m, c, b1, pos, d, jp1, jr1); grx_jac_col(m, c, b2, pos, d, jp2, jr2);
+      grx_jac_col(c, c1lo, c1hi, root1, pos, d, jp1, jr1); grx_jac_col(c, c2lo, c2hi, root2, pos, d, jp2, jr2);
       float dp[3] = {jp2[0] - jp1[0], jp2[1] - jp1[1], jp2[2] - jp1[2]}, dr[3] = {jr2[0] - jr1[0], jr2[1] - jr1[1], jr2[2] - jr1[2]};
       float fr[9] = {c->con_frame[3 * k], c->con_frame[3 * k + 1], c->con_frame[3 * k + 2], 0, 0, 0, 0, 0, 0};
       grx_make_frame(fr);
@@ -303,13 +307,17 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
       for (int r = 0; r < 3; r++) { jc[r] = fr[3 * r] * dp[0] + fr[3 * r + 1] * dp[1] + fr[3 * r + 2] * dp[2]; jc[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2]; }
       const int off0 = GRX_ROW_OFF(c->efc_row[r0]);
       if (dim == 1) c->Jp[off0 + jd] = jc[0];
-      else
-        for (int q = 1; q < dim; q++) {
-          float mu = m->pair_friction[5 * p + q - 1];
-          int ro = off0 + 2 * (q - 1) * slen + jd;
-          c->Jp[ro] = jc[0] + mu * jc[q];
-          c->Jp[ro + slen] = jc[0] - mu * jc[q];
+      else {
+#pragma unroll
+        for (int q = 1; q < 6; q++) {   // (condim <= 6; unrolled: the coefficient and jc[q] are registers, not a dynamically indexed array)
+          if (q < dim) {
+            const float mu = q == 1 ? mu0 : (q == 2 ? mu1 : (q == 3 ? mu2 : (q == 4 ? mu3 : mu4)));
+            int ro = off0 + 2 * (q - 1) * slen + jd;
+            c->Jp[ro] = jc[0] + mu * jc[q];
+            c->Jp[ro + slen] = jc[0] - mu * jc[q];
+          }
         }
+      }
     }
   }
   WAVE_SYNC();
@@ -318,33 +326,24 @@ GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
   FOR_LANES {
     for (int r = lane; r < nefc; r += 64) {
       int kind = c->efc_kind[r], id = GRX_ROW_IDOF(c->efc_id[r]), sub = c->efc_id[r] & 15;
-      float solref[2], solimp[5], pos, margin = 0, dA, floss = 0, rscale = 1.0f;
-      if (kind == GRX_ROW_EQ) {
-        for (int k = 0; k < 2; k++) solref[k] = m->eq_solref[2 * id + k];
-        for (int k = 0; k < 5; k++) solimp[k] = m->eq_solimp[5 * id + k];
-        pos = c->efc_pos[r]; dA = m->eq_invweight[2 * id + (sub >= 3)];
-      } else if (kind == GRX_ROW_FRICTION) {
-        for (int k = 0; k < 2; k++) solref[k] = m->dof_solref[2 * id + k];
-        for (int k = 0; k < 5; k++) solimp[k] = m->dof_solimp[5 * id + k];
-        pos = 0; dA = m->dof_invweight0[id]; floss = m->dof_frictionloss[id];
-      } else if (kind == GRX_ROW_LIMIT) {
-        for (int k = 0; k < 2; k++) solref[k] = m->jnt_solref[2 * id + k];
-        for (int k = 0; k < 5; k++) solimp[k] = m->jnt_solimp[5 * id + k];
-        pos = c->efc_pos[r]; margin = m->jnt_margin[id]; dA = m->dof_invweight0[m->jnt_dofadr[id]];
-      } else if (kind == GRX_ROW_TENDON) {
-        for (int k = 0; k < 2; k++) solref[k] = m->tendon_solref[2 * id + k];
-        for (int k = 0; k < 5; k++) solimp[k] = m->tendon_solimp[5 * id + k];
-        pos = c->efc_pos[r]; margin = m->tendon_margin[id]; dA = m->tendon_invweight0[id];
-      } else {
-        int p = c->con_pair[id], dim = m->pair_condim[p];
-        for (int k = 0; k < 2; k++) solref[k] = m->pair_solref[2 * p + k];
-        for (int k = 0; k < 5; k++) solimp[k] = m->pair_solimp[5 * p + k];
-        pos = c->con_dist[id]; margin = m->pair_margin[p] - m->pair_gap[p];
-        int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
-        float tran = m->geom_invweight0[2 * g1] + m->geom_invweight0[2 * g2];
-        if (dim == 1) dA = tran;
+      // ONE row-parameter block per row, whatever its kind (GRX_PRM_*: solref, solimp, margin, diagonal approximation, friction / friction loss), at a kind-specific place of the
+      // entity's record: one volley of table reads for the whole wave instead of one dependent chain per kind (the kinds' branches ran one after the other)
+      const float* P; float pos; int iscon = 0;
+      if (kind == GRX_ROW_EQ) { P = m->recf_eq + GRX_REF * id; pos = c->efc_pos[r]; }
+      else if (kind == GRX_ROW_FRICTION) { P = m->recf_dof + GRX_RDF * id + 4; pos = 0; }
+      else if (kind == GRX_ROW_LIMIT) { P = m->recf_jnt + GRX_RJF * id + 12; pos = c->efc_pos[r]; }
+      else if (kind == GRX_ROW_TENDON) { P = m->recf_ten + GRX_RTF * id; pos = c->efc_pos[r]; }
+      else { const int p = c->con_pair[id]; P = m->recf_pair + GRX_RPF * p + 8; pos = c->con_dist[id]; iscon = 1; }
+      float solref[2] = {P[GRX_PRM_SOLREF], P[GRX_PRM_SOLREF + 1]}, solimp[5] = {P[GRX_PRM_SOLIMP], P[GRX_PRM_SOLIMP + 1], P[GRX_PRM_SOLIMP + 2], P[GRX_PRM_SOLIMP + 3], P[GRX_PRM_SOLIMP + 4]};
+      const float margin = P[GRX_PRM_MARGIN], da0 = P[GRX_PRM_DA], aux = P[GRX_PRM_AUX], da2 = P[GRX_PRM_DA2];
+      float dA = da0, floss = 0, rscale = 1.0f;
+      if (kind == GRX_ROW_EQ) dA = (sub >= 3) ? da2 : da0;
+      else if (kind == GRX_ROW_FRICTION) floss = aux;
+      else if (iscon) {
+        const float tran = da0;
+        if (da2 == 1.0f) dA = tran;   // condim 1 (the pair record keeps condim in the block's spare slot)
         else {  // every pyramid row of a contact shares R = 2 mu^2 R(first row)
-          float f0 = m->pair_friction[5 * p];
+          float f0 = aux;
           dA = tran + f0 * f0 * tran;
           float mu = f0 / sqrtf(m->impratio);
           rscale = 2.0f * mu * mu;

@@ -7,6 +7,16 @@
 GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
   GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC;
+  // One lane per dof (grx_model_create refuses more than 64): everything dof d's lane needs from the model in this stage comes from ONE record (GrxModel::reci_dof / recf_dof),
+  // read in one volley -- the table walk it replaces (`j = dof_jntid[d]` ... `jnt_stiffness[j]` ... `jnt_qposadr[j]`, `dof_bodyid[dof_cvelstart[d]]` ... `body_dofadr[..]`) was
+  // three dependent vector-L1 round trips (profiles/cpi_r06_fetch.txt).
+  GRX_LANEVAR(damp); GRX_LANEVAR(stiff); GRX_LANEVAR(sref); GRX_LANEVAR_I(jqa); GRX_LANEVAR_I(jtyp); GRX_LANEVAR_I(jda); GRX_LANEVAR_I(ve0); GRX_LANEVAR_I(vbb); GRX_LANEVAR_I(vlast); GRX_LANEVAR_I(dbody);
+  FOR_LANES {
+    const int d = lane < nv ? lane : 0;
+    const int* DI = m->reci_dof + GRX_RDI * d; const float* DF = m->recf_dof + GRX_RDF * d;
+    LV(jqa) = DI[0]; LV(jtyp) = DI[1]; LV(jda) = DI[2]; LV(ve0) = DI[3]; LV(vbb) = DI[4]; LV(vlast) = DI[5]; LV(dbody) = DI[6];
+    LV(damp) = DF[0]; LV(stiff) = DF[1]; LV(sref) = DF[2];
+  }
   // body spatial velocities = sum over the dof chain (parallel, no tree walk)
   FOR_LANES {
     for (int it = lane; it < 6 * GRX_NBC; it += 64) {
@@ -18,10 +28,10 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
       c->cvel[it] = s;
     }
     // passive forces
-    for (int d = lane; d < nv; d += 64) {
-      float f = -m->dof_damping[d] * c->qvel[d];
-      int j = m->dof_jntid[d];
-      if (m->jnt_stiffness[j] != 0.0f && m->jnt_type[j] >= 2) f -= m->jnt_stiffness[j] * (c->qpos[m->jnt_qposadr[j]] - m->jnt_springref[j]);
+    if (lane < nv) {
+      const int d = lane;
+      float f = -LV(damp) * c->qvel[d];
+      if (LV(stiff) != 0.0f && LV(jtyp) >= 2) f -= LV(stiff) * (c->qpos[LV(jqa)] - LV(sref));
       c->qfrc_passive[d] = f;
       c->qfrc_actuator[d] = 0;
     }
@@ -30,17 +40,17 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
   FOR_LANES {
     // cdof_dot = crossMotion(velocity just before this dof, cdof).  That velocity is the spatial velocity of the body
     // owning dof_cvelstart[d], minus the dofs of that body that come after it (only multi-dof joints have any).
-    for (int d = lane; d < nv; d += 64) {
+    if (lane < nv) {
+      const int d = lane;
       float v[6] = {0, 0, 0, 0, 0, 0}, cd[6], r[6];
-      const int e0 = m->dof_cvelstart[d];
+      const int e0 = LV(ve0);
       if (e0 >= 0) {
-        const int bb = m->dof_bodyid[e0], last = m->body_dofadr[bb] + m->body_dofnum[bb] - 1;
+        const int bb = LV(vbb), last = LV(vlast);
         for (int k = 0; k < 6; k++) v[k] = c->cvel[6 * bb + k];
         for (int e = e0 + 1; e <= last; e++) { float qd = c->qvel[e]; for (int k = 0; k < 6; k++) v[k] -= c->cdof[6 * e + k] * qd; }
       }
       for (int k = 0; k < 6; k++) cd[k] = c->cdof[6 * d + k];
-      int jt = m->jnt_type[m->dof_jntid[d]];
-      if (jt == 0 && d - m->jnt_dofadr[m->dof_jntid[d]] < 3) { for (int k = 0; k < 6; k++) r[k] = 0; }
+      if (LV(jtyp) == 0 && d - LV(jda) < 3) { for (int k = 0; k < 6; k++) r[k] = 0; }
       else crossMotionf(r, v, cd);
       for (int k = 0; k < 6; k++) c->cdof_dot[6 * d + k] = r[k];
     }
@@ -65,17 +75,20 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
     }
     // actuators (one lane each; joint transmission)
     for (int i = lane; i < GRX_NUC; i += 64) {
-      int j = m->act_trnid[i]; float gear = m->act_gear[i];
-      float len = gear * c->qpos[m->jnt_qposadr[j]], vel = gear * c->qvel[m->jnt_dofadr[j]];
+      // one record per actuator (GrxModel::reci_act / recf_act), every field read up front: the flags used to guard the reads of the values they select, one round trip each
+      const int* AI = m->reci_act + GRX_RAI * i; const float* AF = m->recf_act + GRX_RAF * i;
+      const int qadr = AI[0], dadr = AI[1], ctrllimited = AI[2], gaintype = AI[3], biastype = AI[4], forcelimited = AI[5];
+      const float gear = AF[0], cr0 = AF[1], cr1 = AF[2], g0 = AF[3], g1 = AF[4], g2 = AF[5], b0 = AF[6], b1 = AF[7], b2 = AF[8], fr0 = AF[9], fr1 = AF[10];
+      float len = gear * c->qpos[qadr], vel = gear * c->qvel[dadr];
       float u = c->ctrl[i];
-      if (m->act_ctrllimited[i]) u = fminf(m->act_ctrlrange[2 * i + 1], fmaxf(m->act_ctrlrange[2 * i], u));
-      float gain = m->act_gainprm[3 * i];
-      if (m->act_gaintype[i] == 1) gain += m->act_gainprm[3 * i + 1] * len + m->act_gainprm[3 * i + 2] * vel;
+      if (ctrllimited) u = fminf(cr1, fmaxf(cr0, u));
+      float gain = g0;
+      if (gaintype == 1) gain += g1 * len + g2 * vel;
       float bias = 0;
-      if (m->act_biastype[i] == 1) bias = m->act_biasprm[3 * i] + m->act_biasprm[3 * i + 1] * len + m->act_biasprm[3 * i + 2] * vel;
+      if (biastype == 1) bias = b0 + b1 * len + b2 * vel;
       float f = gain * u + bias;
-      if (m->act_forcelimited[i]) f = fminf(m->act_forcerange[2 * i + 1], fmaxf(m->act_forcerange[2 * i], f));
-      c->qfrc_actuator[m->jnt_dofadr[j]] = gear * f;  // models in scope have at most one actuator per dof
+      if (forcelimited) f = fminf(fr1, fmaxf(fr0, f));
+      c->qfrc_actuator[dadr] = gear * f;  // models in scope have at most one actuator per dof
     }
   }
   WAVE_SYNC();
@@ -94,8 +107,9 @@ GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
   WAVE_SYNC();
   GRX_SUBTICK(c, 8);
   FOR_LANES {
-    for (int d = lane; d < nv; d += 64) {
-      float s = 0; int b = m->dof_bodyid[d];
+    if (lane < nv) {
+      const int d = lane;
+      float s = 0; int b = LV(dbody);
       for (int k = 0; k < 6; k++) s += c->cdof[6 * d + k] * c->cfrc[6 * b + k];
       c->qfrc_bias[d] = s;
       float f = c->qfrc_passive[d] - s + c->qfrc_actuator[d];

@@ -111,7 +111,28 @@ struct GrxModel {
   const int* mesh_cellhdr;     // per (hull, cell): offset into mesh_cellrec (records), count (0: no list, scan the hull)
   const float* mesh_cellrec;
   const int* geom_cellbase;    // per geom: first header of its hull (in header pairs), -1 = none
+  // derived at model creation too (grx_host_model.h, grx_build_records): per-stage RECORDS.  A stage's lane used to walk the model tables level by level -- `j = dof_jntid[d]`,
+  // then `jnt_stiffness[j]`, then `qpos0[jnt_qposadr[j]]` -- one vector-L1 round trip per level and per divergent branch (profiles/cpi_r06_fetch.txt: ~60 dependent round trips per
+  // substep, a third of the memory wait).  A record holds everything ONE entity's lane needs in ONE stage, gathered at model creation: one volley of loads per stage.  Integer
+  // fields live in reci_* (int table), fp fields in recf_* (fp table), same index; the values are the tables' own fp32 values (sums that the stage used to form, like
+  // margin - gap, are formed here in the same arithmetic), so results are bit-identical to the table walk.  Layouts: the GRX_R* enums below.
+  const int *reci_body, *reci_jnt, *reci_pair, *reci_chain, *reci_weld, *reci_act, *reci_dof, *reci_mpair;
+  const float *recf_body, *recf_jnt, *recf_pair, *recf_weld, *recf_eq, *recf_act, *recf_dof, *recf_ten, *recf_mpair;
 };
+// record strides (words) and field offsets
+enum { GRX_RBI = 16, GRX_RBF = 16,    // body (kinematics): I mocapid, jntadr, jntnum, jt0 (type of the ONLY joint, else -1), qa0 (qpos address of the first joint), flags (1: shift child, 2: free or mocap body),
+                                      //   type of the first joint, -, then body_jump[s] for s < 8;  F pos[3], qpos0[qa0], quat[4], first joint's pos[3], -, first joint's axis[3], -
+       GRX_RJI = 8, GRX_RJF = 24,     // joint: I qposadr, type, bodyid, dofadr, parent of its body, root of its body, limited (jnt_limited && type >= 2), -;
+                                      //   F pos[3], qpos0[qposadr], axis[3], -, range[2], -, -, then the row-parameter block (GRX_PRM_*) of its limit rows
+       GRX_RPI = 8, GRX_RPF = 28,     // candidate pair: I condim, geom1, geom2, body1, body2, span, -, -;  F margin, gap, margin - gap, friction[5], row-parameter block [8, 18), -, -, size of geom1 [20, 23), -, size of geom2 [24, 27), -
+       GRX_RCI = 4,                   // body (Jacobian columns): I dof_chainmask lo, hi, rootid, -
+       GRX_RWI = 12, GRX_RWF = 28,    // active weld: I eq, body1, body2, weld_row, chainmask lo / hi / root of body1, of body2, -, -;  F eq_data[11], -, eq_relpose[14], -, -
+       GRX_REF = 12,                  // equality (row parameters): F row-parameter block with invweight[0] at GRX_PRM_DA and invweight[1] at GRX_PRM_DA2, -
+       GRX_RAI = 8, GRX_RAF = 12,     // actuator: I qposadr / dofadr of its joint, ctrllimited, gaintype, biastype, forcelimited, -, -;  F gear, ctrlrange[2], gainprm[3], biasprm[3], forcerange[2], -
+       GRX_RDI = 8, GRX_RDF = 16,     // dof: I qposadr / type / dofadr of its joint, cvelstart, body of that dof, last dof of that body, bodyid, -;  F damping, stiffness, springref, armature, row-parameter block [4, 14) of its friction-loss row, -, -
+       GRX_RMI = 4,                   // mass-matrix entry: I i, j, body of dof i, -;  F (one word) armature of dof i
+       GRX_RTF = 12 };                // fixed tendon (row parameters): F row-parameter block, -, -
+enum { GRX_PRM_SOLREF = 0, GRX_PRM_SOLIMP = 2, GRX_PRM_MARGIN = 7, GRX_PRM_DA = 8, GRX_PRM_AUX = 9, GRX_PRM_DA2 = 10 };   // AUX: friction[0] of a contact pair, frictionloss of a dof
 #define GRX_NBR_RECS 16
 #define GRX_CELL_G 16
 #define GRX_CELL_MAX 64      // a cell whose list would be longer keeps none (count 0): the hull is scanned

@@ -19,8 +19,12 @@ struct GrxPackedModel {
   std::vector<std::string> name;
   int off_mesh_nbr = -1;      // offset of the derived neighbour-record table inside f (-1: the model has no hulls)
   int off_cellhdr = -1, off_cellbase = -1, off_cellrec = -1;   // derived support-candidate lists (GrxModel::mesh_cellhdr / geom_cellbase inside i, mesh_cellrec inside f; -1: none)
+  // derived per-stage record tables (GrxModel::reci_* inside i, recf_* inside f; grx_build_records): offsets, and the [begin, end) ranges they occupy (re-uploaded after grx_model_set_table)
+  struct { int i_body, i_jnt, i_pair, i_chain, i_weld, i_act, i_dof, i_mpair, f_body, f_jnt, f_pair, f_weld, f_eq, f_act, f_dof, f_ten, f_mpair; } rec;
+  int rec_i0 = 0, rec_i1 = 0, rec_f0 = 0, rec_f1 = 0;
   GrxModel proto;             // scalar members filled; pointers unset
 };
+inline void grx_build_records(GrxPackedModel* out, bool allocate);
 
 // Support-candidate lists of one hull (GrxModel::mesh_cellhdr): for every cube-map cell of directions the vertices that can be the support vertex, or tie with it inside the
 // device scan's band, for SOME direction of the cell.  With w the support vertex of the cell's centre direction dc and rho >= |d - dc| for every unit d of the (dilated) cell:
@@ -196,6 +200,7 @@ inline void grx_pack_model(const int32_t* H, const int32_t* I, const double* F, 
   m.meaninertia = (float)v.opt[GRX_MEANINERTIA]; m.impratio = (float)v.opt[GRX_IMPRATIO];
   m.mpr_tolerance = (float)v.opt[GRX_MPR_TOLERANCE]; m.mpr_iterations = (int)v.opt[GRX_MPR_ITERATIONS];
   m.origin[0] = v.opt[GRX_ORIGIN_X]; m.origin[1] = v.opt[GRX_ORIGIN_Y]; m.origin[2] = v.opt[GRX_ORIGIN_Z];
+  grx_build_records(out, true);
 }
 
 // model view whose tables live at (fbase, ibase)
@@ -211,10 +216,115 @@ inline GrxModel grx_bind_model(const GrxPackedModel& p, const float* fbase, cons
   m.mesh_cellhdr = p.off_cellhdr >= 0 ? ibase + p.off_cellhdr : nullptr;
   m.geom_cellbase = p.off_cellbase >= 0 ? ibase + p.off_cellbase : nullptr;
   m.mesh_cellrec = p.off_cellrec >= 0 ? fbase + p.off_cellrec : nullptr;
+  m.reci_body = ibase + p.rec.i_body; m.reci_jnt = ibase + p.rec.i_jnt; m.reci_pair = ibase + p.rec.i_pair; m.reci_chain = ibase + p.rec.i_chain; m.reci_weld = ibase + p.rec.i_weld;
+  m.reci_act = ibase + p.rec.i_act; m.reci_dof = ibase + p.rec.i_dof; m.reci_mpair = ibase + p.rec.i_mpair;
+  m.recf_body = fbase + p.rec.f_body; m.recf_jnt = fbase + p.rec.f_jnt; m.recf_pair = fbase + p.rec.f_pair; m.recf_weld = fbase + p.rec.f_weld; m.recf_eq = fbase + p.rec.f_eq;
+  m.recf_act = fbase + p.rec.f_act; m.recf_dof = fbase + p.rec.f_dof; m.recf_ten = fbase + p.rec.f_ten; m.recf_mpair = fbase + p.rec.f_mpair;
   return m;
 }
 
 inline int grx_find_table(const GrxPackedModel& p, const char* name) {
   for (size_t k = 0; k < p.name.size(); k++) if (p.name[k] == name) return (int)k;
   return -1;
+}
+
+// Per-stage records (GrxModel::reci_* / recf_*, layouts: the GRX_R* enums of grx_engine.h).  Built from the PACKED tables (the fp32 values the device reads), so a record field
+// is bit for bit what the table walk it replaces would have loaded; the few sums a stage used to form from two table values (margin - gap, the two geoms' invweight0) are formed
+// here in the same `float` arithmetic.  allocate: append the (zeroed) regions to the packed arrays first; otherwise refill them in place (after a table edit).
+inline void grx_build_records(GrxPackedModel* out, bool allocate) {
+  const GrxModel& d = out->proto;
+  auto C = [&](const char* n) { const int k = grx_find_table(*out, n); return k >= 0 ? out->cnt[k] : 0; };
+  const int nbody = d.nbody, njnt = d.njnt, nv = d.nv, nu = d.nu, npair = C("pair_geom1"), nweld = C("weld_eq"), neq = C("eq_type"), nten = C("tendon_adr"), nmp = C("mpair_i"), njump = d.njump;
+  if (allocate) {
+    auto AI = [&](int n) { while (out->i.size() % 4) out->i.push_back(0); const int o = (int)out->i.size(); out->i.resize(out->i.size() + (size_t)n, 0); return o; };
+    auto AF = [&](int n) { while (out->f.size() % 4) out->f.push_back(0.0f); const int o = (int)out->f.size(); out->f.resize(out->f.size() + (size_t)n, 0.0f); return o; };
+    while (out->i.size() % 4) out->i.push_back(0);
+    while (out->f.size() % 4) out->f.push_back(0.0f);
+    out->rec_i0 = (int)out->i.size(); out->rec_f0 = (int)out->f.size();
+    out->rec.i_body = AI(GRX_RBI * nbody); out->rec.i_jnt = AI(GRX_RJI * njnt); out->rec.i_pair = AI(GRX_RPI * npair); out->rec.i_chain = AI(GRX_RCI * nbody); out->rec.i_weld = AI(GRX_RWI * nweld);
+    out->rec.i_act = AI(GRX_RAI * nu); out->rec.i_dof = AI(GRX_RDI * nv); out->rec.i_mpair = AI(GRX_RMI * nmp);
+    out->rec.f_body = AF(GRX_RBF * nbody); out->rec.f_jnt = AF(GRX_RJF * njnt); out->rec.f_pair = AF(GRX_RPF * npair); out->rec.f_weld = AF(GRX_RWF * nweld); out->rec.f_eq = AF(GRX_REF * neq);
+    out->rec.f_act = AF(GRX_RAF * nu); out->rec.f_dof = AF(GRX_RDF * nv); out->rec.f_ten = AF(GRX_RTF * nten); out->rec.f_mpair = AF(nmp);
+    out->rec_i1 = (int)out->i.size(); out->rec_f1 = (int)out->f.size();
+  }
+  const GrxModel h = grx_bind_model(*out, out->f.data(), out->i.data());
+  int32_t* ri = out->i.data(); float* rf = out->f.data();
+  auto prm = [&](float* P, const float* solref, const float* solimp, float margin, float dA, float aux) {
+    P[GRX_PRM_SOLREF] = solref[0]; P[GRX_PRM_SOLREF + 1] = solref[1];
+    for (int k = 0; k < 5; k++) P[GRX_PRM_SOLIMP + k] = solimp[k];
+    P[GRX_PRM_MARGIN] = margin; P[GRX_PRM_DA] = dA; P[GRX_PRM_AUX] = aux;
+  };
+  const bool has_bshift = C("body_shift") >= nbody;
+  for (int b = 0; b < nbody; b++) {
+    int32_t* I = ri + out->rec.i_body + GRX_RBI * b; float* F = rf + out->rec.f_body + GRX_RBF * b;
+    const int mid = h.body_mocapid[b], ja = h.body_jntadr[b], jn = h.body_jntnum[b], jf = (jn >= 1 && ja >= 0 && ja < njnt) ? ja : -1;
+    I[0] = mid; I[1] = ja; I[2] = jn; I[3] = (jn == 1 && jf >= 0) ? h.jnt_type[jf] : -1; I[4] = jf >= 0 ? h.jnt_qposadr[jf] : 0;
+    I[5] = ((has_bshift && h.body_shift[b]) ? 1 : 0) | ((mid >= 0 || (jn == 1 && jf >= 0 && h.jnt_type[jf] == 0)) ? 2 : 0);
+    I[6] = jf >= 0 ? h.jnt_type[jf] : -1; I[7] = 0;
+    for (int s_ = 0; s_ < 8; s_++) I[8 + s_] = s_ < njump ? h.body_jump[s_ * nbody + b] : 0;
+    for (int k = 0; k < 3; k++) F[k] = h.body_pos[3 * b + k];
+    F[3] = jf >= 0 ? h.qpos0[h.jnt_qposadr[jf]] : 0.0f;
+    for (int k = 0; k < 4; k++) F[4 + k] = h.body_quat[4 * b + k];
+    for (int k = 0; k < 3; k++) { F[8 + k] = jf >= 0 ? h.jnt_pos[3 * jf + k] : 0.0f; F[12 + k] = jf >= 0 ? h.jnt_axis[3 * jf + k] : 0.0f; }
+    int32_t* Cc = ri + out->rec.i_chain + GRX_RCI * b;
+    Cc[0] = h.dof_chainmask[2 * b]; Cc[1] = h.dof_chainmask[2 * b + 1]; Cc[2] = h.body_rootid[b]; Cc[3] = 0;
+  }
+  for (int j = 0; j < njnt; j++) {
+    int32_t* I = ri + out->rec.i_jnt + GRX_RJI * j; float* F = rf + out->rec.f_jnt + GRX_RJF * j;
+    const int b = h.jnt_bodyid[j], da = h.jnt_dofadr[j], qa = h.jnt_qposadr[j], jt = h.jnt_type[j];
+    I[0] = qa; I[1] = jt; I[2] = b; I[3] = da; I[4] = h.body_parent[b]; I[5] = h.body_rootid[b]; I[6] = (h.jnt_limited[j] && jt >= 2) ? 1 : 0; I[7] = 0;
+    for (int k = 0; k < 3; k++) { F[k] = h.jnt_pos[3 * j + k]; F[4 + k] = h.jnt_axis[3 * j + k]; }
+    F[3] = h.qpos0[qa]; F[8] = h.jnt_range[2 * j]; F[9] = h.jnt_range[2 * j + 1];
+    prm(F + 12, h.jnt_solref + 2 * j, h.jnt_solimp + 5 * j, h.jnt_margin[j], h.dof_invweight0[da], 0.0f);
+  }
+  for (int p = 0; p < npair; p++) {
+    int32_t* I = ri + out->rec.i_pair + GRX_RPI * p; float* F = rf + out->rec.f_pair + GRX_RPF * p;
+    const int g1 = h.pair_geom1[p], g2 = h.pair_geom2[p];
+    I[0] = h.pair_condim[p]; I[1] = g1; I[2] = g2; I[3] = h.geom_bodyid[g1]; I[4] = h.geom_bodyid[g2]; I[5] = h.pair_span[p]; I[6] = I[7] = 0;
+    F[0] = h.pair_margin[p]; F[1] = h.pair_gap[p]; F[2] = h.pair_margin[p] - h.pair_gap[p];
+    for (int k = 0; k < 5; k++) F[3 + k] = h.pair_friction[5 * p + k];
+    const float tran = h.geom_invweight0[2 * g1] + h.geom_invweight0[2 * g2];
+    prm(F + 8, h.pair_solref + 2 * p, h.pair_solimp + 5 * p, F[2], tran, h.pair_friction[5 * p]);
+    F[8 + GRX_PRM_DA2] = (float)h.pair_condim[p];   // the row-parameter pass tells condim 1 from the pyramidal ones here
+    for (int k = 0; k < 3; k++) { F[20 + k] = h.geom_size[3 * g1 + k]; F[24 + k] = h.geom_size[3 * g2 + k]; }
+  }
+  for (int w = 0; w < nweld; w++) {
+    int32_t* I = ri + out->rec.i_weld + GRX_RWI * w; float* F = rf + out->rec.f_weld + GRX_RWF * w;
+    const int e = h.weld_eq[w], b0 = h.eq_obj1[e], b1 = h.eq_obj2[e];
+    I[0] = e; I[1] = b0; I[2] = b1; I[3] = h.weld_row[w];
+    I[4] = h.dof_chainmask[2 * b0]; I[5] = h.dof_chainmask[2 * b0 + 1]; I[6] = h.body_rootid[b0];
+    I[7] = h.dof_chainmask[2 * b1]; I[8] = h.dof_chainmask[2 * b1 + 1]; I[9] = h.body_rootid[b1]; I[10] = I[11] = 0;
+    for (int k = 0; k < 11; k++) F[k] = h.eq_data[11 * e + k];
+    for (int k = 0; k < 14; k++) F[12 + k] = h.eq_relpose[14 * e + k];
+  }
+  for (int e = 0; e < neq; e++) {
+    float* F = rf + out->rec.f_eq + GRX_REF * e;
+    prm(F, h.eq_solref + 2 * e, h.eq_solimp + 5 * e, 0.0f, h.eq_invweight[2 * e], 0.0f);
+    F[GRX_PRM_DA2] = h.eq_invweight[2 * e + 1];
+  }
+  for (int a = 0; a < nu; a++) {
+    int32_t* I = ri + out->rec.i_act + GRX_RAI * a; float* F = rf + out->rec.f_act + GRX_RAF * a;
+    const int j = h.act_trnid[a];
+    I[0] = h.jnt_qposadr[j]; I[1] = h.jnt_dofadr[j]; I[2] = h.act_ctrllimited[a]; I[3] = h.act_gaintype[a]; I[4] = h.act_biastype[a]; I[5] = h.act_forcelimited[a]; I[6] = I[7] = 0;
+    F[0] = h.act_gear[a]; F[1] = h.act_ctrlrange[2 * a]; F[2] = h.act_ctrlrange[2 * a + 1];
+    for (int k = 0; k < 3; k++) { F[3 + k] = h.act_gainprm[3 * a + k]; F[6 + k] = h.act_biasprm[3 * a + k]; }
+    F[9] = h.act_forcerange[2 * a]; F[10] = h.act_forcerange[2 * a + 1];
+  }
+  const bool has_dofprm = C("dof_solref") >= 2 * nv && C("dof_solimp") >= 5 * nv;
+  for (int q = 0; q < nv; q++) {
+    int32_t* I = ri + out->rec.i_dof + GRX_RDI * q; float* F = rf + out->rec.f_dof + GRX_RDF * q;
+    const int j = h.dof_jntid[q], e0 = h.dof_cvelstart[q], bb = h.dof_bodyid[e0 >= 0 ? e0 : 0];
+    I[0] = h.jnt_qposadr[j]; I[1] = h.jnt_type[j]; I[2] = h.jnt_dofadr[j]; I[3] = e0; I[4] = bb; I[5] = h.body_dofadr[bb] + h.body_dofnum[bb] - 1; I[6] = h.dof_bodyid[q]; I[7] = 0;
+    F[0] = h.dof_damping[q]; F[1] = h.jnt_stiffness[j]; F[2] = h.jnt_springref[j]; F[3] = h.dof_armature[q];
+    if (has_dofprm) prm(F + 4, h.dof_solref + 2 * q, h.dof_solimp + 5 * q, 0.0f, h.dof_invweight0[q], h.dof_frictionloss[q]);
+  }
+  for (int e = 0; e < nmp; e++) {
+    int32_t* I = ri + out->rec.i_mpair + GRX_RMI * e;
+    I[0] = h.mpair_i[e]; I[1] = h.mpair_j[e]; I[2] = h.dof_bodyid[h.mpair_i[e]]; I[3] = 0;
+    rf[out->rec.f_mpair + e] = h.dof_armature[h.mpair_i[e]];
+  }
+  for (int t = 0; t < nten; t++) {
+    float* F = rf + out->rec.f_ten + GRX_RTF * t;
+    prm(F, h.tendon_solref + 2 * t, h.tendon_solimp + 5 * t, h.tendon_margin[t], h.tendon_invweight0[t], 0.0f);
+  }
 }

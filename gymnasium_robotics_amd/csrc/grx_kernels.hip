@@ -1112,6 +1112,10 @@ extern "C" int grx_model_set_table(grx_model* m, const char* name, const double*
   for (int i = 0; i < n; i++) m->pm.f[m->pm.off[k] + i] = (float)data[i];
   HIP_OK(hipSetDevice(m->device));
   HIP_OK(hipMemcpy(m->d_f + m->pm.off[k], m->pm.f.data() + m->pm.off[k], sizeof(float) * n, hipMemcpyHostToDevice));
+  // the per-stage records (GrxModel::recf_* / reci_*) are gathered from the tables: refill them in place and upload their two regions
+  grx_build_records(&m->pm, false);
+  if (m->pm.rec_f1 > m->pm.rec_f0) HIP_OK(hipMemcpy(m->d_f + m->pm.rec_f0, m->pm.f.data() + m->pm.rec_f0, sizeof(float) * (size_t)(m->pm.rec_f1 - m->pm.rec_f0), hipMemcpyHostToDevice));
+  if (m->pm.rec_i1 > m->pm.rec_i0) HIP_OK(hipMemcpy(m->d_i + m->pm.rec_i0, m->pm.i.data() + m->pm.rec_i0, sizeof(int32_t) * (size_t)(m->pm.rec_i1 - m->pm.rec_i0), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -1588,7 +1592,7 @@ grx_adroit_commit_kernel(grx_adroit_commit_args a) {
   for (int i = l; i < a.obs_dim; i += 64) a.obs[w * a.obs_dim + i] = a.s_obs[w * a.obs_dim + i];
   if (a.shift && l < 7) a.shift[w * 7 + l] = a.s_shift[w * 7 + l];
   if (a.target && l < 3) a.target[w * 3 + l] = a.s_target[w * 3 + l];
-  if (l == 0) a.status[w] = (a.status[w] & 0xFFFF) | ((((a.status[w] >> 16) | (a.s_status[w] & 15)) & 0xFFFF) << 16);   // the step's own flags stay; the forward pass's join the sticky half
+  if (l == 0) a.status[w] = grx_status_word(a.status[w], a.s_status[w]);   // as the in-line reset (and grx_fetch_commit_kernel): the low half reports the reset's forward pass, its flags join the sticky half
 }
 extern "C" int grx_adroit_commit_rows(const grx_adroit_commit_args* args, void* stream) {
   if (!args) return fail("grx_adroit_commit_rows: null argument");

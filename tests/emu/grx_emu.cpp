@@ -66,6 +66,7 @@ int emu_set_table(void* h, const char* name, const double* data, int n) {
   int k = grx_find_table(e->pm, name);
   if (k < 0 || e->pm.kind[k] != 'f' || n > e->pm.cnt[k]) return -1;
   for (int i = 0; i < n; i++) e->pm.f[e->pm.off[k] + i] = (float)data[i];
+  grx_build_records(&e->pm, false);   // the per-stage records are gathered from the tables
   return 0;
 }
 

@@ -38,4 +38,6 @@ for env_id, n in CASES:
     print(f"{env_id}: {n} worlds x {STEPS} steps in {dt:.1f} s ({tot / dt:,.0f} env-steps/s incl. resets); finite {finite}; world-steps flagged: "
           f"bad-number {flags[1]} ({100 * flags[1] / tot:.4f} %), contact-capacity {flags[2]} ({100 * flags[2] / tot:.4f} %), row/pool-capacity {flags[4]} "
           f"({100 * flags[4] / tot:.4f} %), factorisation {flags[8]}; mean success rate at sampled steps {succ / max(1, STEPS // 50):.4f}")
+    if env_id.startswith("AntMaze"):   # no overflow lane behind the ant kernels, tables below a full contact list (envs/point_maze.py ANT_CAPACITY): an excess would be DROPPED contacts
+        assert flags[2] == 0 and flags[4] == 0, "ant worlds exceeded the engine tables: raise ANT_CAPACITY"
     env.close()
