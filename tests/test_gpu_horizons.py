@@ -6,9 +6,11 @@ fp64 oracle observed at the same point of ITS rollout (tests/tolerance_cases.py:
 channels), 5 (FrankaKitchen, AdroitHammer) and every other rollout family.
 
 Asserted (no allow-list in this file: every exception is a number tools/measure_horizons.py measured on the MI355X and wrote into tests/golden/tolerance_table.json "horizons"):
-  (1) horizons 1 and 2: every start whose oracle steps all keep an activation gap >= 1e-6 m is within 1e-4 on every component, the touch forces of cfg 3 included (absolute);
-      where the table records well-posed starts above 1e-4 (`n_over_1e-4_posed` > 0: at the time of writing ONE touch reading, 1.03e-4 N, at horizon 1) the component is held
-      to that count and to 1.25 x the recorded maximum;
+  (1) horizons 1 and 2: every start whose oracle steps all keep an activation gap >= 1e-6 m, and at which the reference algorithm's own answer does not move by >= 1e-5 under a
+      one-ulp perturbation of the start state (tests/tolerance_cases.py::posed_starts; the table's "reference_sensitivity_horizons"), is within 1e-4 on every component, the touch
+      forces of cfg 3 included (absolute).  The round-6 table records NO well-posed start above 1e-4 at horizons 1 and 2 in any family (`n_over_1e-4_posed` = 0 everywhere); should a
+      re-measured table record one, the component is held to that count and to 1.25 x the recorded maximum (itself < 2e-4).  profiles/fetchslide_start169_r06.txt is the worked
+      example of what the second yardstick removes: a start 7.9e-6 m from a switch where the fp64 algorithm, continued from the engine's own state after step 1, gives the engine's answer;
   (2) horizons 5 and 10 (a chaotic contact system: the bound beyond two steps is a MEASURED growth bound): the median error stays below 3 x the recorded median (and below 1e-4
       outright), the share of ALL starts within 1e-4 stays within 5 points of the recorded share, and well-posed starts (no switch within 1e-6 m over the whole horizon) keep
       >= the recorded share - 10 points;
@@ -20,7 +22,7 @@ import json
 import numpy as np
 import pytest
 
-from tolerance_cases import GAP, HORIZONS, ROLLOUT_FAMILIES, TABLE, episode_errors, horizon_errors
+from tolerance_cases import HORIZONS, ROLLOUT_FAMILIES, TABLE, episode_errors, horizon_errors, posed_starts
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -32,7 +34,7 @@ def test_free_running_rollout_stays_within_the_measured_bound(family):
         recorded = json.load(f)["horizons"][family]
     res = horizon_errors(family)
     for h in HORIZONS:
-        posed = res["_gap"][h] >= GAP
+        posed = posed_starts(family, h, res["_start"][h], res["_gap"][h])
         for comp, err in res[h].items():
             rec = recorded[str(h)][comp]
             if h <= 2 and posed.any():
