@@ -544,6 +544,7 @@ GRX_MEM void grx_box_box_queue(const GrxModel* m, GrxCtx* c, const int* queue, i
 #undef GRX_BB_LOAD
 
 GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_OPAQUE_STAGE(lane_);
   GRX_FRESH_MODEL(m, c);
   // geom frames (they share LDS with the composite inertias of the previous stage)
   FOR_LANES {

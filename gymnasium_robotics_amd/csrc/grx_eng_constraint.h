@@ -75,12 +75,9 @@ GRX_MEM float grx_row_dot(const GrxCtx* c, int r, const float* v) {
 }
 
 GRX_MEM void grx_make_constraint(const GrxModel* m, GrxCtx* c, int lane_) {
-#if !defined(GRX_EMU)
-  // The lane index is made opaque for this stage: its cheap lane-derived values (packed row descriptors) are then recomputed here
-  // instead of being hoisted out of the 20-substep loop, kept live across it and spilled to scratch (one dword per lane, but written
-  // back to HBM by every wave).  Doing this for the whole pass costs more recomputation than it saves (measured -3 % on the hand models).
-  asm volatile("" : "+v"(lane_));
-#endif
+  // The lane index is made opaque for this stage (GRX_OPAQUE_LANE, grx_engine.h): its cheap lane-derived values (packed row descriptors) are recomputed here.
+  // Doing this for the whole pass costs more recomputation than it saves (measured -3 % on the hand models).
+  GRX_OPAQUE_LANE(lane_);
   GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC;
   const int ncon = c->cnt[0];

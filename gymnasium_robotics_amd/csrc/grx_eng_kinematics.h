@@ -5,6 +5,7 @@
 // K1 forward kinematics
 // ------------------------------------------------------------------------------------------
 GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_OPAQUE_STAGE(lane_);   // record addresses and lane masks of this stage are recomputed here, not carried (spilled) across the substep loop
   GRX_FRESH_MODEL(m, c);
   // One lane per body (grx_model_create refuses more than 64).  Everything the body's lane needs from the model in this stage -- its own pose, its first joint, the
   // pointer-jumping schedule of the rounds below, whether its quaternion is re-normalised at the end -- comes from ONE record (GrxModel::reci_body / recf_body), read in one
@@ -141,6 +142,7 @@ GRX_MEM void grx_kinematics(const GrxModel* m, GrxCtx* c, int lane_) {
 // reference point of each kinematic tree = xpos of its root body (any point is valid)
 // ------------------------------------------------------------------------------------------
 GRX_MEM void grx_inertia_cdof(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_OPAQUE_STAGE(lane_);   // record addresses and lane masks of this stage are recomputed here, not carried (spilled) across the substep loop
   GRX_FRESH_MODEL(m, c);
   FOR_LANES {
     for (int b = 1 + lane; b < GRX_NBC; b += 64) {

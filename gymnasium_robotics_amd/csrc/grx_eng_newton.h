@@ -74,6 +74,7 @@ GRX_MEM void grx_ls_eval(GrxCtx* c, int nefc, float alpha, float q1, float q2, f
 // Also returns J' f (the constraint force in joint space for the row forces of the last evaluation) in c->grad: on the
 // matrix-core path it rides along as one extra output column of the same MFMA chain.
 GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
+  GRX_OPAQUE_STAGE(lane_);
   const int nv = GRX_NVC;
     // Hessian H = M + J' diag(D_active) J
   FOR_LANES {

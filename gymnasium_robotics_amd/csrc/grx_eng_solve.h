@@ -336,6 +336,7 @@ GRX_MEM void grx_refine_object_block(const GrxModel* m, GrxCtx* c, int nefc, int
 //   phase 2: no constraint rows at all                      (A = M,               rhs = qfrc_smooth)
 //   phase 1: Euler velocity update with implicit damping    (A = M + h diag(B),   rhs = qfrc_smooth + qfrc_constraint)
 GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int lane_) {
+  GRX_OPAQUE_STAGE(lane_);
   GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC; const float h = m->timestep;
   const int nefc = c->cnt[1];

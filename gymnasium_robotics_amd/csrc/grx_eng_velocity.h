@@ -5,6 +5,7 @@
 // velocity stage: cvel, cdof_dot, RNE bias (K2/K5), passive (K6), actuation (K7)
 // ------------------------------------------------------------------------------------------
 GRX_MEM void grx_velocity(const GrxModel* m, GrxCtx* c, int lane_) {
+  GRX_OPAQUE_STAGE(lane_);   // record addresses and lane masks of this stage are recomputed here, not carried (spilled) across the substep loop
   GRX_FRESH_MODEL(m, c);
   const int nv = GRX_NVC;
   // One lane per dof (grx_model_create refuses more than 64): everything dof d's lane needs from the model in this stage comes from ONE record (GrxModel::reci_dof / recf_dof),

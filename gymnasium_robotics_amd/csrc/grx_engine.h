@@ -203,9 +203,18 @@ struct GrxCtx {
 // model pointer from the slot index through an opaque scalar: the table pointers a stage needs are then fetched with
 // s_load at the top of that stage and die at its end, instead of ~100 pointers staying live (and spilled) across the
 // whole substep loop.
+// GRX_OPAQUE_LANE(l): the lane index is made opaque at the top of a stage: its lane-derived values (record addresses lane * stride, `lane < n` masks) are recomputed there --
+// two or three VALU instructions -- instead of being hoisted out of the 20-substep loop, kept live across it and spilled to scratch (a dword per lane each, written once by
+// every wave and written back to HBM when the line leaves the L2: profiles/ab_r06_opaque_lane.txt).
+// Which stages do it is a property of the kernel shape (GrxShape::kOpaque), measured per family (profiles/ab_r06_opaque_lane.txt): every stage for Fetch, the mazes, Adroit and the
+// kitchen (kitchen scratch 496 -> 256 B per lane, +4 %; ant +4 %; Fetch HBM traffic 17.6 x -> 6.2 x algorithmic, +2 %), only the constraint stage for the hand models (-2 % otherwise).
 #if defined(GRX_EMU)
+#define GRX_OPAQUE_LANE(l) ((void)0)
+#define GRX_OPAQUE_STAGE(l) ((void)0)
 #define GRX_FRESH_MODEL(m, c) ((void)0)
 #else
+#define GRX_OPAQUE_LANE(l) asm volatile("" : "+v"(l))
+#define GRX_OPAQUE_STAGE(l) do { if constexpr (S::kOpaque) GRX_OPAQUE_LANE(l); } while (0)
 #define GRX_MAX_MODELS 32
 static __constant__ GrxModel g_grx_models[GRX_MAX_MODELS];   // one copy per translation unit (see csrc/grx_kernels.hip on the build)
 #define GRX_FRESH_MODEL(m, c) do { int s_ = __builtin_amdgcn_readfirstlane((c)->mslot); asm volatile("" : "+s"(s_)); (m) = g_grx_models + s_; } while (0)
@@ -612,6 +621,7 @@ struct GrxShape {
   static constexpr int NOSLIP = (CONVEX_ & 8) ? 1 : 0;   // the model runs the noslip post-solver
   static constexpr bool kShift = (NV_ == 0) || NSHIFT, kNoslip = (NV_ == 0) || NOSLIP;
   static constexpr bool kShiftRot = (NV_ == 0) || ((CONVEX_ & 16) != 0);   // the shift group also rotates (flag 2: Adroit pen's target body, model.body_quat edits)
+  static constexpr bool kOpaque = !(NV_ > 0 && NFRIC_ == 24);   // GRX_OPAQUE_STAGE: every family but the Shadow hand (24 friction-loss dofs), where recomputing the lane-derived values costs more than their spills
 };
 typedef GrxShape<0, 0, 0, 0, 0, 0, 0, 0> GrxShapeAny;
 #define GRX_NVC (S::kFixed ? S::NV : m->nv)

@@ -18,14 +18,14 @@ if __name__ == "__main__":
     if os.path.exists(TABLE):      # the free-running section (tools/measure_horizons.py) lives in the same file
         with open(TABLE) as f:
             old = json.load(f)
-        for sec in ("horizons", "episodes", "reference_sensitivity"):      # written by tools/measure_horizons.py / tools/emu_tolerances.py --sensitivity --json
+        for sec in ("horizons", "episodes", "reference_sensitivity", "reference_sensitivity_horizons"):      # written by tools/measure_horizons.py / tools/emu_tolerances.py --sensitivity --json
             if sec in old:
                 table[sec] = old[sec]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "tolerance_table.json"), "w") as f:
         json.dump(table, f, indent=1)
     for fam, row in table.items():
-        if fam in ("horizons", "episodes", "reference_sensitivity"):
+        if fam in ("horizons", "episodes", "reference_sensitivity", "reference_sensitivity_horizons"):
             continue
         for comp, q in row.items():
             if isinstance(q, dict):
