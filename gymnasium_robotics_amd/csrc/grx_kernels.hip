@@ -692,6 +692,7 @@ __device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitch
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
   if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);
+  if (lane_ == 0 && w < 4096 && !forward_only) for (int k = 0; k < GRX_NPROF; k++) g_grx_world_prof[w * GRX_NPROF + k] = (int)c.prof[k];   // per-world rows (tools/straggler_probe.py): lane worlds included
 #endif
 }
 template <class S>

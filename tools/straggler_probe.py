@@ -1,17 +1,21 @@
-"""Which stages make a slow FetchPickAndPlace world slow: per-world stage cycles of one step launch (profiling build: sh tools/build_prof.sh fetch).
-    python tools/straggler_probe.py > profiles/stragglers_r02_fetch.txt"""
+"""Which stages make a slow world slow: per-world stage cycles of one step launch (profiling build: sh tools/build_prof.sh fetch|kitchen|...).
+    python tools/straggler_probe.py [env id] [worlds] [pre-roll steps] > profiles/stragglers_r02_fetch.txt"""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from gymnasium_robotics_amd import _native, make_vec
 _native.LIB_PATH = os.path.join(ROOT, "gymnasium_robotics_amd", "_lib", os.environ.get("GRX_PROF_LIB", "libgrx_hip_prof.so"))
-NP, n = 56, 4096
-env = make_vec("FetchPickAndPlace-v4", num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step")
-env.reset(seed=0); env._elapsed[:] = np.arange(n) % 50
+NP = 56
+env_id = sys.argv[1] if len(sys.argv) > 1 else "FetchPickAndPlace-v4"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+pre = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+env = make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step")
+env.reset(seed=0); env._elapsed[:] = np.arange(n) % (env.max_episode_steps or 50)
 g = torch.Generator(device="cuda:0"); g.manual_seed(0)
-for k in range(40):
-    env.step(torch.rand(n, 4, device="cuda:0", generator=g) * 2 - 1)
+NA = env.single_action_space.shape[0]
+for k in range(pre):
+    env.step(torch.rand(n, NA, device="cuda:0", generator=g) * 2 - 1)
 torch.cuda.synchronize()
 L = _native.lib()
 buf = (ctypes.c_int * (NP * n))()
@@ -28,6 +32,14 @@ label = {k: v for k, v in enumerate(names)}
 label.update({16 + k: v for k, v in SUB.items()})
 slow = np.argsort(-tot)[:40]
 typ = np.argsort(tot)[n // 2 - 200: n // 2 + 200]
+q = np.quantile(tot, [0.5, 0.9, 0.99, 0.999, 1.0])
+print(f"{env_id} @{n}: cycles per env.step p50 {q[0]:.0f} p90 {q[1]:.0f} p99 {q[2]:.0f} p99.9 {q[3]:.0f} max {q[4]:.0f}; sum over worlds {tot.sum():.3e}; worlds above 2 x median: {int((tot > 2 * q[0]).sum())} holding {100 * tot[tot > 2 * q[0]].sum() / tot.sum():.1f} % of all cycles")
+lane = getattr(env, "lane", None)
+if lane is not None and getattr(lane, "mode", "") == "lane":
+    torch.cuda.synchronize()
+    fl = lane.nxt.flags.cpu().numpy().astype(bool)[:n]      # (after a step: nxt = the list the LAST step's lane launch walked)
+    if fl is not None and fl.any():
+        print(f"worlds in the standing lane: {int(fl.sum())}; their cycles: mean {tot[fl].mean():.0f} (x{tot[fl].mean() / q[0]:.2f} the median world) p90 {np.quantile(tot[fl], .9):.0f} max {tot[fl].max():.0f}; share of all cycles {100 * tot[fl].sum() / tot.sum():.1f} %")
 print(f"cycles per env.step: median world {np.median(tot):.0f}, slowest 40 worlds mean {tot[slow].mean():.0f} (x{tot[slow].mean() / np.median(tot):.2f})")
 print(f"{'stage':34s} {'typical world':>14s} {'slowest 40':>12s} {'difference':>12s}")
 rows = sorted(label, key=lambda k: -(P[slow, k].mean() - P[typ, k].mean()))
