@@ -460,6 +460,25 @@ def run_rank_stages(args, rank, world_size, local_rank):
 
 
 # ---------------------------------------------------------------------------------------------- one rank
+def pmc_summary(kind, workload, n, worlds, live_build, root=None):
+    """The committed rocprofv3 PMC summary of `kind` ("hbm_traffic" / "sq_mix") for a workload, or (None, reason).  A summary is attached ONLY when it was measured at this batch size
+    AND on the device code that is loaded now (`build_id`, stamped by tools/collect_profiles.py = _native.build_id() of the profiled library): a kernel change without a new
+    collect_profiles.py run yields `traffic: null` / `valu: null` and a `traffic_source` that says why -- never an old build's counters (tests/test_cpu_bench_profiles.py)."""
+    root = root or ROOT
+    for tag in PROFILE_TAGS:
+        path = os.path.join(root, "profiles", f"pmc_{tag}_{kind}{'' if workload == 'fetch' else '_' + workload}.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            rel = os.path.relpath(path, root)
+            if n != worlds:
+                return None, f"{rel}: measured at {worlds} worlds, this run has {n}"
+            if d.get("build_id") != live_build:
+                return None, f"STALE, not attached: {rel} was measured on build {d.get('build_id') or '(unstamped, before round 6)'}, the loaded libgrx_hip.so is {live_build}"
+            return d, rel
+    return None, None
+
+
 def run_rank(args, rank, world_size, local_rank):
     if args.workload == "mixed":
         return run_rank_mixed(args, rank, world_size, local_rank)
@@ -563,18 +582,7 @@ def run_rank(args, rank, world_size, local_rank):
         live_build = _native.build_id()
 
     def _summary(kind):
-        for tag in PROFILE_TAGS:
-            path = os.path.join(ROOT, "profiles", f"pmc_{tag}_{kind}{'' if args.workload == 'fetch' else '_' + args.workload}.json")
-            if os.path.exists(path):
-                with open(path) as f:
-                    d = json.load(f)
-                rel = os.path.relpath(path, ROOT)
-                if n != w["worlds"]:
-                    return None, f"{rel}: measured at {w['worlds']} worlds, this run has {n}"
-                if d.get("build_id") != live_build:
-                    return None, f"STALE, not attached: {rel} was measured on build {d.get('build_id') or '(unstamped, before round 6)'}, the loaded libgrx_hip.so is {live_build}"
-                return d, rel
-        return None, None
+        return pmc_summary(kind, args.workload, n, w["worlds"], live_build)
 
     if not dry:
         d, traffic_src = _summary("hbm_traffic")

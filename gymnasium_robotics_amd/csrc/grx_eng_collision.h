@@ -79,7 +79,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     q.cell1 = (q.t1 == 7 && m->mesh_cellhdr && m->geom_cellbase[g1] >= 0) ? m->mesh_cellhdr + 2 * (size_t)m->geom_cellbase[g1] : nullptr;
     q.cell2 = (q.t2 == 7 && m->mesh_cellhdr && m->geom_cellbase[g2] >= 0) ? m->mesh_cellhdr + 2 * (size_t)m->geom_cellbase[g2] : nullptr;
     q.cellrec = m->mesh_cellrec;
-#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+#if GRX_DEVICE_PROFILE
     q.prof = c->prof;
 #endif   // 30 words behind the pair queue: the Jacobian pool is free until the constraint stage
     GRX_SUBTICK(c, 21);   // pair set-up
@@ -101,7 +101,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
       for (int k = 0; k < 3; k++) sv += ((sw[k] + d[k] * q.hm) - (sb[k] + q.c21[k] - d[k] * q.hm)) * d[k];
       if (sv < -1e-6f) {   // strictly on the far side: the (inflated) geoms are disjoint
         LANE0 { mc[5 * slot + 4] = (float)((h1 + 1) + 4096 * (h2 + 1)); }
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
         g_grx_mesh_stats[0]++;
 #endif
         GRX_SUBTICK(c, 22);   // cached separating direction re-checked: disjoint
@@ -110,20 +110,20 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
     }
     GRX_SUBTICK(c, 22);
     GRX_COUNT(c, 25, 1);
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
     g_grx_mesh_stats[1]++;
 #endif
     // guesses of the support vertices, one word per evaluation of this pair's search (the world's HBM row, 4 blocks of key + 16 words): a pair in persistent contact -- the
     // upper arm resting on the head link, the worlds that end a Fetch launch -- repeats its search substep after substep with almost the same directions
     int hblk = -1;
-#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#if GRX_DEVICE_HULL_HINTS
     if (c->hullhint) {
       const float hk0 = c->hullhint[0], hk1 = c->hullhint[17], hk2 = c->hullhint[34], hk3 = c->hullhint[51];
       hblk = hk0 == key ? 0 : (hk1 == key ? 1 : (hk2 == key ? 2 : (hk3 == key ? 3 : -1)));
       hblk = __builtin_amdgcn_readfirstlane(hblk);
       if (hblk >= 0 && lane_ < 16) q.hint = __float_as_int(c->hullhint[17 * hblk + 1 + lane_]);
     }
-#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#elif GRX_TWIN_HULL_HINTS
     for (int l = 0; l < 16; l++) q.hints[l] = 0;
     if (c->hullhint && g_grx_emu_hints_on) {      // emulator twin: the same row, the same four blocks
       const float hk0 = c->hullhint[0], hk1 = c->hullhint[17], hk2 = c->hullhint[34], hk3 = c->hullhint[51];
@@ -133,7 +133,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
 #endif
     MF depth, dir[3], pos[3], w1[3], w2[3], sep[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int rc = grx_mpr_penetration<true>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2, sep);
-#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#if GRX_DEVICE_HULL_HINTS
     if (c->hullhint && rc == 0) {   // in contact: this search will run again in the next substep
       int wblk = hblk;
       if (wblk < 0) { wblk = ((int)c->hullhint[68]) & 3; if (lane_ == 0) c->hullhint[68] = (float)((wblk + 1) & 3); }
@@ -141,7 +141,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
       if (lane_ < 16) c->hullhint[17 * wblk + 1 + lane_] = __int_as_float(lane_ < q.hk ? q.hint : 0);
       if (lane_ == 0) c->hullhint[17 * wblk] = key;
     }
-#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#elif GRX_TWIN_HULL_HINTS
     if (c->hullhint && g_grx_emu_hints_on && rc == 0) {
       int wblk = hblk;
       if (wblk < 0) { wblk = ((int)c->hullhint[68]) & 3; c->hullhint[68] = (float)((wblk + 1) & 3); }
@@ -153,7 +153,7 @@ GRX_MEM void grx_mesh_pairs(const GrxModel* m, GrxCtx* c, const int* queue, int 
 #ifdef GRX_PROBE_HULL   // outcome of the searches (tools/hull_outcome_probe.py): contacts, separations with a direction, the pair searched last
     GRX_COUNT(c, 35, rc == 0 ? 1 : 0); GRX_COUNT(c, 36, (rc != 0 && sep[3] != 0.0f) ? 1 : 0); GRX_PMAX(c, 37, pair);
 #endif
-#if defined(GRX_EMU) && defined(GRX_MESH_DEBUG)
+#if GRX_TWIN_MESH_DEBUG
     fprintf(stderr, "meshpair %d (g %d %d) slot %d rc %d sep %g\n", pair, g1, g2, slot, rc, (double)sep[3]);
 #endif
     WAVE_SYNC();
@@ -604,7 +604,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
   // the exact test (which only reads the two geom centres; plane geoms are static, checked by the host), so the survivors -- and everything after
   // them -- are exactly those of the full sweep.  Otherwise (and for a zeroed row) the list is rebuilt first: one full sweep per ~40 substeps.
   const int* slist = nullptr; int ncand = ndp;
-#if !defined(GRX_EMU)
+#if GRX_ON_DEVICE
   if (kChunked && c->skin != nullptr && ndp > 256) {
     volatile int* hdr = c->skin; float* gref = (float*)(c->skin + 4); int* list = c->skin + 4 + 3 * GRX_NGC;
     const float skin = c->skin_r;

@@ -35,7 +35,7 @@ GRX_MEM float grx_sqrt(float x) { return sqrtf(x); }
 GRX_MEM float grx_fabs(float x) { return fabsf(x); }
 GRX_MEM float grx_fmin(float a, float b) { return fminf(a, b); }
 GRX_MEM float grx_fmax(float a, float b) { return fmaxf(a, b); }
-#ifndef GRX_EMU_FP64
+#if !GRX_REAL_IS_DOUBLE
 GRX_MEM double grx_sqrt(double x) { return sqrt(x); }
 GRX_MEM double grx_fabs(double x) { return fabs(x); }
 GRX_MEM double grx_fmin(double a, double b) { return fmin(a, b); }
@@ -78,10 +78,10 @@ struct GrxMprPairT { RF R1[9], R2[9], s1[3], s2[3]; MF c21[3], hm; int t1, t2;  
                     const float *nbr1, *nbr2;   // neighbour records of the two hulls (GrxModel::mesh_nbr + 64 * first hull vertex), or null
                     const int *cell1, *cell2; const float* cellrec;   // support-candidate lists of the two hulls (GrxModel::mesh_cellhdr + 2 * geom_cellbase, mesh_cellrec), or null
                     mutable int hint, hk;       // wave-cooperative variant: lane e holds the guessed support vertices of evaluation e ((v1 + 1) | (v2 + 1) << 16); evaluations so far
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
                     mutable int hints[16];      // the emulator's stand-in for `hint` (one register per lane on the device: lane e holds word e)
 #endif
-#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+#if GRX_DEVICE_PROFILE
                     long long* prof;
 #endif
                   };                                            // wave-cooperative variant: LDS storage of the five portal points (keeps them out of the VGPR budget)
@@ -104,7 +104,7 @@ GRX_MEM int grx_mesh_support_refine(const float* verts, const int* aadr, const i
     const TF tc = (TF)verts[3 * cur] * dlt[0] + (TF)verts[3 * cur + 1] * dlt[1] + (TF)verts[3 * cur + 2] * dlt[2];
     const int aa = aadr[cur], an = anum[cur];
     TF tb = tc; int nb = cur;
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
     (void)lane_;
     for (int k = 0; k < an; k++) {
       const int v = adj[aa + k];
@@ -139,7 +139,7 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
                              const float* nbr = nullptr, const int* cellhdr = nullptr, const float* cellrec = nullptr) {
   r[0] = r[1] = r[2] = 0.0f;
   if (n <= 0) return -1;
-#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#if GRX_DEVICE_HULL_HINTS
   if (hint >= 0 && hint < n && nbr != nullptr) {
     const float4 p = ((const float4*)nbr)[GRX_NBR_RECS * hint + (lane_ & (GRX_NBR_RECS - 1))];
     const int deg = (int)grx_readlane_f(p.w, 0);
@@ -155,7 +155,7 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
       }
     }
   }
-#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#elif GRX_TWIN_HULL_HINTS
   // emulator twin of the guess check above (same records, same margin, fp64 projections): the CPU suite then exercises "a stale / foreign / wrong guess never changes a result"
   // and "an accepted guess is the scan's vertex" on every hull fixture (tests/test_cpu_hull_hints.py)
   if (g_grx_emu_hints_on && hint >= 0 && hint < n && nbr != nullptr) {
@@ -178,7 +178,7 @@ GRX_MEM int grx_mesh_support(const float* verts, int n, const MF* dlm, MF* r, in
   (void)hint; (void)nbr;
 #endif
   const HF dl[3] = {(HF)dlm[0], (HF)dlm[1], (HF)dlm[2]};   // the scan's own arithmetic type (GRX_HULL_REAL)
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
   HF best = -3.0e38f; int bi = 0;
   for (int v = 0; v < n; v++) { const HF t = verts[3 * v] * dl[0] + verts[3 * v + 1] * dl[1] + verts[3 * v + 2] * dl[2]; if (t > best) { best = t; bi = v; } }
   if (cellhdr) {   // the emulator scans the hull; it CHECKS that the device's candidate list of this direction's cell holds every vertex inside the tie band (what the device reads instead)
@@ -288,7 +288,7 @@ GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* d
   if (hint >= 0 && hint < n) {
     const int aa = m->mesh_adjadr[adr + hint], an = m->mesh_adjnum[adr + hint];
     const HF t0 = verts[3 * hint] * dl[0] + verts[3 * hint + 1] * dl[1] + verts[3 * hint + 2] * dl[2];
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
     int higher = 0;
     for (int k = 0; k < an; k++) { const int nb = m->mesh_adj[aa + k]; higher |= (verts[3 * nb] * dl[0] + verts[3 * nb + 1] * dl[1] + verts[3 * nb + 2] * dl[2] > t0); }
 #else
@@ -304,20 +304,20 @@ GRX_MEM int grx_mesh_support_hint(const GrxModel* m, int adr, int n, const MF* d
 template <bool W, typename Q>
 GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
   MF nd[3] = {-d[0], -d[1], -d[2]}, b[3];
-#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+#if GRX_DEVICE_PROFILE
   if (W && q->lane == 0) { q->prof[16 + 26] += 1; q->prof[16 + 27] += (q->t1 == 7 ? q->n1 : 0) + (q->t2 == 7 ? q->n2 : 0); }
 #endif
-#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+#if GRX_DEVICE_PROFILE
   const long long tp0_ = clock64();
 #endif
   int h1 = -1, h2 = -1, f1 = -1, f2 = -1, ek = 0;
-#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#if GRX_DEVICE_HULL_HINTS
   if (W) {
     ek = __builtin_amdgcn_readfirstlane(q->hk);
     if (ek < 16) { const int pk = __builtin_amdgcn_readlane(q->hint, ek); h1 = (pk & 0xFFFF) - 1; h2 = (int)((unsigned)pk >> 16) - 1; }
     q->hk = ek + 1;
   }
-#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#elif GRX_TWIN_HULL_HINTS
   if (W) {
     ek = q->hk;
     if (ek < 16) { const int pk = q->hints[ek]; h1 = (pk & 0xFFFF) - 1; h2 = (int)((unsigned)pk >> 16) - 1; }
@@ -328,15 +328,15 @@ GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
   if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); f2 = grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj, h2, q->nbr2, q->cell2, q->cellrec); mulMatVec3f(b, q->R2, r); }
   else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
-#if !defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#if GRX_DEVICE_HULL_HINTS
   // the winners become the guesses of this evaluation in the next substep.  (The guess words live in the world's HBM row, written and read by the lanes of ONE wave without a
   // fence: a stale, torn or foreign word can never change a result, because a guess is only ever a CANDIDATE -- grx_mesh_support accepts it when it provably is the support
   // vertex (tops every hull neighbour by the margin) and scans otherwise; tests/test_gpu_fetch.py::test_hull_caches_do_not_change_the_rollout.)
   if (W && ek < 16 && q->lane == ek) q->hint = ((f1 + 1) & 0xFFFF) | ((f2 + 1) << 16);
-#elif defined(GRX_EMU) && defined(GRX_HULL_HINTS)
+#elif GRX_TWIN_HULL_HINTS
   if (W && ek < 16) q->hints[ek] = ((f1 + 1) & 0xFFFF) | ((f2 + 1) << 16);
 #endif
-#if defined(GRX_PROFILE) && !defined(GRX_EMU)
+#if GRX_DEVICE_PROFILE
   if (W && q->lane == 0) q->prof[16 + 28] += clock64() - tp0_;
 #endif
   for (int k = 0; k < 3; k++) { o->w[k] += d[k] * q->hm; o->v[k] = o->w[k] - (b[k] + q->c21[k] - d[k] * q->hm); }
@@ -464,7 +464,7 @@ GRX_MPR_FN int grx_mpr_penetration(const Q* q, MF tol, int maxit, MF* depth, MF*
   for (int it = 0;; it++) {
     grx_mpr_portal_dir(P1, P2, P3, d);
     grx_mpr_support<W>(q, d, &v4);
-#if defined(GRX_EMU) && defined(GRX_MPR_STATS)
+#if GRX_TWIN_MPR_STATS
     if (W) { g_grx_mesh_stats[2]++; if (it > maxit) g_grx_mesh_stats[3]++; }
 #endif
     if (grx_mpr_reach_tolerance(P1, P2, P3, v4, d, tol) || it > maxit) {
@@ -599,7 +599,7 @@ GRX_MEM void grx_convex_pair(const GrxModel* m, GrxCtx* c, int pair, int g1, int
   MF depth, dir[3], pos[3], w1[3], w2[3];
   q.v1 = q.v2 = nullptr; q.n1 = q.n2 = 0; q.lane = 0; q.pts = nullptr; q.aadr1 = q.anum1 = q.aadr2 = q.anum2 = q.adj = nullptr; q.nbr1 = q.nbr2 = nullptr; q.hint = q.hk = 0; q.cell1 = q.cell2 = nullptr; q.cellrec = nullptr;
   if (grx_mpr_penetration<false>(&q, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, w1, w2) != 0) return;
-#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+#if GRX_TWIN_TRACE
   if (getenv("GRX_TRACE_MPR")) {
     fprintf(stderr, "MPR pair %d g %d %d t %d %d\n R1", pair, g1, g2, t1, t2);
     for (int k = 0; k < 9; k++) fprintf(stderr, " %.17g", (double)q.R1[k]);

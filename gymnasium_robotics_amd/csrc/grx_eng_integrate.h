@@ -29,13 +29,13 @@ GRX_MEM void grx_forward_euler(const GrxModel* m, GrxCtx* c, int do_euler, int l
   grx_velocity(m, c, lane_);
   GRX_STAGE_HOOK(4);
   GRX_RNDINJ(4, (grx_rnd(c->qfrc_smooth, m->nv), grx_rnd(c->qacc_smooth, m->nv), grx_rnd(c->efc_aref, c->maxefc)));
-#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+#if GRX_TWIN_TRACE
   grx_emu_trace(m, c, 0);   // test infrastructure (tools/emu_trace.py): contact list / rows of this pass
 #endif
   grx_solve_integrate(m, c, do_euler, lane_);
   GRX_STAGE_HOOK(do_euler ? 5 : 6);
   GRX_RNDINJ(5, (grx_rnd(c->qpos, m->nq), grx_rnd(c->qvel, m->nv), grx_rnd(c->qacc_ws, m->nv)));
-#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+#if GRX_TWIN_TRACE
   grx_emu_trace(m, c, 1);
 #endif
 }

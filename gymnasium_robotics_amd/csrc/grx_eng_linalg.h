@@ -49,7 +49,7 @@ GRX_MEM void grx_sym_solve(const float* A, int n, float* x, int lane_) {
 // A x = b in one call.  On the GPU, for the dof counts of the models in scope, the whole system is held in
 // registers: lane j owns column j of A (lane nv owns b), the pivot column is broadcast with v_readlane and the
 // elimination runs from the last dof to the first exactly like grx_sym_factor -- no LDS round trips, no barriers.
-#if !defined(GRX_EMU)
+#if GRX_ON_DEVICE
 // v_readlane_b32 moves raw bits: the builtin is typed (int,int), so floats go through a bit cast
 static __device__ __forceinline__ float grx_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 // reciprocal of a strictly positive pivot: v_rcp_f32 (1 ulp) + one Newton step
@@ -196,7 +196,7 @@ template <int NS>
 // blocks are then solved one after the other -- the same arithmetic as the full elimination, in which every multiplier between the
 // blocks is an exact zero, at (nr^2 + 36) / n^2 of its broadcasts (15 + 6 instead of 21: 43 % fewer).
 GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit = 0, int tree = 0) {
-#if !defined(GRX_EMU)
+#if GRX_ON_DEVICE
   if (S::kFixed && S::NF == 24 && tree) {      // hand shapes (the host matched m->handtree): M / M + h B solves
     int bad_ = grx_sym_solve_reg<24, true>(A, n, x, lane_);
     if (S::NV == 30) bad_ |= grx_sym_solve_reg<6>(A + 24 * n + 24, n, x + 24, lane_);
@@ -219,7 +219,7 @@ GRX_MEM int grx_sym_solve_full(float* A, int n, float* x, int lane_, int nsplit 
   if (n == 33) return grx_sym_solve_reg<33>(A, n, x, lane_);
   if (n == 36) return grx_sym_solve_reg<36>(A, n, x, lane_);
 #endif
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
   if (n == 21 || n == 14 || n == 15 || n == 24 || n == 29 || n == 30 || n == 33 || n == 36) {   // mirror the device: these sizes are solved without touching A
     static float copy[36 * 36];
     for (int i = 0; i < n * n; i++) copy[i] = A[i];

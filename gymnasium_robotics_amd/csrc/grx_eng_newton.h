@@ -85,7 +85,7 @@ GRX_MEM void grx_hessian(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     }
   }
   WAVE_SYNC();
-#if !defined(GRX_EMU)
+#if GRX_ON_DEVICE
   if (nv < 32 || (S::kFixed && S::NV <= 40)) {
     // matrix cores: [H | J'f] = J' [D J | f] as a chain of v_mfma_f32_32x32x2_f32 (exact f32, two constraint rows per instruction).
     // nv >= 32 (Adroit: 33): the chain forms the leading 32 x 32 block; the remaining rows / columns and J'f follow in a lane-per-dof pass.

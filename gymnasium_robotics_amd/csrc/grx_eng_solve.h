@@ -17,7 +17,7 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
   const int ne = c->cnt[3], nf = c->cnt[4], ncon = c->cnt[0] < c->maxcon ? c->cnt[0] : c->maxcon;
   GRX_TICK(c, GRX_P_NEVAL);
   // ---- M^-1 into c->minv (= the Hessian's buffer: Newton is done with it).  Specialised shapes on the GPU: Gauss-Jordan in registers.
-#if !defined(GRX_EMU)
+#if GRX_ON_DEVICE
   if (S::kFixed && S::NV > 0 && S::NV <= 40) grx_sym_inverse_reg<(S::NV > 0 && S::NV <= 40) ? S::NV : 1>(c->M, nv, c->minv, lane_);
   else
 #endif
@@ -54,7 +54,7 @@ GRX_MEM void grx_noslip(const GrxModel* m, GrxCtx* c, int nefc, int lane_) {
     FOR_LANES { float sacc = 0.0f; for (int r = lane; r < nefc; r += 64) { const float f = c->efc_force[r]; sacc += 0.5f * f * f / c->efc_D[r]; } LV(ip) = sacc; }
     improvement0 = grx_reduce_sum(ip);
   }
-#if !defined(GRX_EMU)
+#if GRX_ON_DEVICE
   {
     // GPU: the sweep state lives in registers -- lane i holds a_i, lane r holds the r-th friction-loss row (dof, aref, bound, force, A_rr);
     // a row update is a handful of v_readlane broadcasts plus one LDS read of the M^-1 column, no barrier.  Same arithmetic, same order
@@ -284,7 +284,7 @@ GRX_MEM void grx_refine_object_block(const GrxModel* m, GrxCtx* c, int nefc, int
   const float jf[6] = {grx_reduce_sum(j0), grx_reduce_sum(j1), grx_reduce_sum(j2), grx_reduce_sum(j3), grx_reduce_sum(j4), grx_reduce_sum(j5)};
   FOR_LANES { if (lane < 6) c->search[o0 + lane] = -(c->Ma[o0 + lane] - c->qfrc_smooth[o0 + lane] - GRX_SEL6(jf, lane)); }
   WAVE_SYNC();
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
   {
     static float blk[36];
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) blk[6 * i + j] = c->A[(o0 + i) * nv + o0 + j];
@@ -346,13 +346,11 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
   float last_stepmax = 0.0f;   // largest component of the last accepted Newton step
   int exact_exit = 0, last_split = 0;   // converged by an exact full step (no row changed state) / the last linear solve ran on the decoupled robot | object blocks
   float alpha_prev = 0.0f;   // the step length accepted by the previous Newton iteration (gradient advance of the incremental path)
-#if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)
+#if GRX_TWIN_STAGEHOOK
   if (g_grx_solve_mode == 2 && nefc) phase = 1;
 #endif
   GRX_COUNT(c, 30, 1);     // profiling build: constrained solves (substeps) of the step
-#if defined(GRX_EMU)
-  if (nefc) g_grx_newton_stats[0]++;
-#endif
+  if (nefc) GRX_TWIN_STAT(0);
   GRX_COUNT(c, 31, nefc);  // ... and their constraint rows
   // the linear solve leaves c->A intact where it runs from registers (grx_sym_solve_full): the Hessian can then be corrected in place
   const int keepA = S::kIncrHess && (nv == 21 || nv == 14 || nv == 15 || nv == 24 || nv == 29 || nv == 30 || nv == 33 || nv == 36);
@@ -380,7 +378,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         // object block of the Hessian has a weak rocking mode and fp32 resolves the full step to ~4e-4 of its size there); a box object stands on its corner contacts and
         // the refinement changes nothing at the 1e-7 level (tools/emu_tolerances.py with -DGRX_NO_OBJ_REFINE: FetchPush / PickAndPlace identical), at 3 % of the step
         const int weak_object = (S::kFixed ? S::kConvex : (m->nconvex != 0));
-#if defined(GRX_EMU)
+#if !GRX_ON_DEVICE
         if (exact_exit && last_split == 6 && keepA && weak_object) { g_grx_newton_stats[4]++; if (last_stepmax > GRX_OBJ_REFINE_MINSTEP) g_grx_newton_stats[5]++; }
 #endif
         if (exact_exit && last_split == 6 && keepA && weak_object && last_stepmax > GRX_OBJ_REFINE_MINSTEP) grx_refine_object_block(m, c, nefc, lane_);
@@ -391,7 +389,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         FOR_LANES { for (int i = lane; i < nv; i += 64) { c->qfrc_constraint[i] = c->Ma[i] - c->qfrc_smooth[i]; c->qacc_ws[i] = c->qacc[i]; } }
         WAVE_SYNC();
         GRX_TICK(c, GRX_P_NFINAL);
-#if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)
+#if GRX_TWIN_STAGEHOOK
         if (g_grx_solve_mode == 1) break;
         if (do_euler) GRX_STAGE_HOOK(7);
 #endif
@@ -417,9 +415,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         WAVE_SYNC();
         incremental = grx_hessian_update(m, c, nefc, c->tmpv, lane_);
       }
-#if defined(GRX_EMU)
-      g_grx_newton_stats[incremental ? 3 : 2]++;
-#endif
+      GRX_TWIN_STAT(incremental ? 3 : 2);
       if (!incremental) grx_hessian(m, c, nefc, lane_);
       GRX_TICK(c, GRX_P_NHESS);
       GRX_LANEVAR(gnp);
@@ -443,7 +439,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       WAVE_SYNC();
       float gn = sqrtf(grx_reduce_sum(gnp));
       GRX_TICK(c, GRX_P_NGRAD);
-#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+#if GRX_TWIN_TRACE
       if (getenv("GRX_TRACE_NEWTON")) fprintf(stderr, "NEWTON it %d gn %.6e scale*gn %.3e incremental %d\n", it, (double)gn, (double)(scale * gn), incremental);
 #endif
       if (scale * gn < 1e-8f) { done = 1; continue; }
@@ -526,7 +522,7 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
         else if (!(na > lo)) na = 2.0f * alpha;
         alpha = na;
       }
-#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+#if GRX_TWIN_TRACE
       if (getenv("GRX_TRACE_NEWTON")) fprintf(stderr, "   dphi0 %.6e stop %d alpha %.6f full_step %d\n", (double)dphi0, stop, (double)alpha, full_step);
 #endif
       if (stop) { done = 1; continue; }  // not a descent direction any more: converged to rounding
@@ -544,13 +540,11 @@ GRX_MEM void grx_solve_integrate(const GrxModel* m, GrxCtx* c, int do_euler, int
       WAVE_SYNC();
       const float stepmax = grx_reduce_max(msp), qmax = grx_reduce_max(map_);
       last_stepmax = stepmax;
-#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+#if GRX_TWIN_TRACE
       if (getenv("GRX_TRACE_NEWTON")) { const int d_ = atoi(getenv("GRX_TRACE_NEWTON")); fprintf(stderr, "   stepmax %.6e qmax %.4e search[d] %.6e qacc[d] %.9e grad[d] %.6e\n", (double)stepmax, (double)qmax, (double)c->search[d_], (double)c->qacc[d_], (double)c->grad[d_]); }
 #endif
       LANE0 { c->cnt[6] += 1; }
-#if defined(GRX_EMU)
-      g_grx_newton_stats[1]++;
-#endif
+      GRX_TWIN_STAT(1);
       GRX_COUNT(c, 29, 1);   // profiling build: Newton iterations of the step
 #ifdef GRX_LS_STATS
       { extern int g_ls_iters, g_ls_full; g_ls_iters++; g_ls_full += full_step; }

@@ -20,6 +20,57 @@
 #include <math.h>
 #include <stdint.h>
 
+// ---- Build personality.  This header is the ONLY engine file that names GRX_EMU (the lane-emulator build of tests/emu: test infrastructure, never shipped): the stage fragments
+// csrc/grx_eng_*.h ask for a FEATURE below.  GRX_ON_DEVICE: wave intrinsics exist (readlane / DPP / MFMA / ballot: the register-resident solvers, the matrix-core Hessian, the
+// HBM-resident skin lists); the emulator personality runs the LDS twins of the same arithmetic.  The other switches are test / profiling instrumentation of one personality.
+#if defined(GRX_EMU)
+#define GRX_ON_DEVICE 0
+#else
+#define GRX_ON_DEVICE 1
+#endif
+#if GRX_ON_DEVICE && defined(GRX_PROFILE)
+#define GRX_DEVICE_PROFILE 1      // per-stage cycle counters (tools/profile_stages.py)
+#else
+#define GRX_DEVICE_PROFILE 0
+#endif
+#if defined(GRX_HULL_HINTS)
+#define GRX_DEVICE_HULL_HINTS GRX_ON_DEVICE        // guessed support vertices kept in HBM rows
+#define GRX_TWIN_HULL_HINTS (!GRX_ON_DEVICE)       // ... and their emulator twin (a host array)
+#else
+#define GRX_DEVICE_HULL_HINTS 0
+#define GRX_TWIN_HULL_HINTS 0
+#endif
+#if defined(GRX_EMU) && defined(GRX_EMU_TRACE)
+#define GRX_TWIN_TRACE 1          // tools/emu_trace.py: contact lists / Newton iterations printed per pass
+#else
+#define GRX_TWIN_TRACE 0
+#endif
+#if defined(GRX_EMU) && defined(GRX_EMU_STAGEHOOK)
+#define GRX_TWIN_STAGEHOOK 1      // tools/emu_mixed.py: per-stage precision experiments
+#else
+#define GRX_TWIN_STAGEHOOK 0
+#endif
+#if defined(GRX_EMU) && defined(GRX_MPR_STATS)
+#define GRX_TWIN_MPR_STATS 1
+#else
+#define GRX_TWIN_MPR_STATS 0
+#endif
+#if defined(GRX_EMU) && defined(GRX_MESH_DEBUG)
+#define GRX_TWIN_MESH_DEBUG 1
+#else
+#define GRX_TWIN_MESH_DEBUG 0
+#endif
+#if defined(GRX_EMU_FP64)
+#define GRX_REAL_IS_DOUBLE 1      // the emulator's fp64 personality (float is #defined to double: tools/emu_fp64_check.py): the (double) overloads would be duplicates
+#else
+#define GRX_REAL_IS_DOUBLE 0
+#endif
+#if defined(GRX_EMU)
+#define GRX_TWIN_STAT(k) (g_grx_newton_stats[k]++)      // solver statistics read by tools/emu_tolerances.py
+#else
+#define GRX_TWIN_STAT(k) ((void)0)
+#endif
+
 #if defined(GRX_EMU)
 #define GRX_DEV static inline
 #define GRX_MEM static inline

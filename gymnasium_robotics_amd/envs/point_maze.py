@@ -67,9 +67,6 @@ class PointMazeVecEnv(GoalVecEnv):
         self.continuing_task, self.position_noise_range = continuing_task, position_noise_range
         self.max_episode_steps = mes if max_episode_steps == -1 else max_episode_steps
         self.autoreset_mode, self.output, self.num_envs, self.seed_offset = autoreset_mode, output, int(num_envs), int(seed_offset)
-        if not torch.cuda.is_available():
-            raise RuntimeError("PointMazeVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
-        self.device = torch.device(device or "cuda:0")
         self.maze = Maze(maze_map, *self.MAZE_GEOMETRY)
         # a maze whose ONLY reset cell is also its only goal cell: the reference's generate_reset_pos (maze/maze_v4.py:284-297, 400-418) redraws the reset CELL CENTRE until it is
         # farther than half a cell from the noisy goal and would never return; refused here, loudly, instead of spinning (host draws) or being cut short (the device loop is
@@ -78,6 +75,9 @@ class PointMazeVecEnv(GoalVecEnv):
         ug, ur = np.asarray(self.maze.unique_goal_locations, dtype=np.float64).reshape(-1, 2), np.asarray(self.maze.unique_reset_locations, dtype=np.float64).reshape(-1, 2)
         if len(ur) == 1 and len(ug) == 1 and np.linalg.norm(ur[0] - ug[0]) < 0.5 * self.maze.maze_size_scaling:
             raise ValueError("this maze has a single reset cell that is also its single goal cell: a reset position farther than half a cell from the goal does not exist")
+        if not torch.cuda.is_available():      # (after the map checks: a bad map is reported as such on any machine, tests/test_cpu_maze.py)
+            raise RuntimeError("PointMazeVecEnv needs an MI355X (no HIP device visible); there is no CPU fallback")
+        self.device = torch.device(device or "cuda:0")
         self.model = model or load_point_maze_model(self.maze, layout, assets_root, self.AGENT)
         self.nq, self.nv, self.nu = self.model.dim("nq"), self.model.dim("nv"), self.model.dim("nu")
         self._L = _native.lib()

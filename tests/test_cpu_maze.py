@@ -166,3 +166,26 @@ def test_map_tables_equal_the_reference_module():
     assert set(ref["maps"]) == set(maze_spec.MAPS)
     for name, table in ref["maps"].items():
         assert maze_spec.MAPS[name] == table, name
+
+
+def test_degenerate_map_guard_refuses_only_a_coinciding_reset_and_goal_cell():
+    """the reference's generate_reset_pos (/root/reference/gymnasium_robotics/envs/maze/maze_v4.py:284-297) redraws the reset cell centre until it is farther than
+    half a cell from the noisy goal: with ONE cell that is both the only reset and the only goal cell it never returns (refused: ValueError); an 'r' cell NEXT to a 'g' cell is
+    a valid maze (centre to noisy goal >= 0.75 cells) and must get past the map checks -- on this GPU-less machine that means reaching the 'no HIP device' error, not ValueError."""
+    import torch
+
+    from gymnasium_robotics_amd.envs.point_maze import AntMazeVecEnv, PointMazeVecEnv
+
+    if torch.cuda.is_available():
+        pytest.skip("the map checks are exercised through the constructor's GPU-less error path")
+    adjacent = [[1, 1, 1, 1], [1, "r", "g", 1], [1, 1, 1, 1]]
+    single = [[1, 1, 1], [1, "c", 1], [1, 1, 1]]
+    for cls, env_id in ((PointMazeVecEnv, "PointMaze_UMaze-v3"), (AntMazeVecEnv, "AntMaze_UMaze-v5")):
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            cls(env_id, num_envs=2, maze_map=adjacent)
+        with pytest.raises(ValueError, match="single reset cell"):
+            cls(env_id, num_envs=2, maze_map=single)
+    # the geometry the guard relies on: distinct lattice cells are at least one pitch apart
+    m = Maze(adjacent, 1.0, 0.4)
+    ur, ug = np.asarray(m.unique_reset_locations).reshape(-1, 2), np.asarray(m.unique_goal_locations).reshape(-1, 2)
+    assert np.linalg.norm(ur[0] - ug[0]) >= 1.0 - 1e-12
