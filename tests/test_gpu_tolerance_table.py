@@ -16,6 +16,10 @@ Asserted here, on the MI355X, through the C ABI:
       time of writing two entries, one snapshot each: the ant's torso rate after 5 RK4 substeps against a wall, 1.29e-4 on 19 rad/s at 18 m from the origin, and one touch force,
       1.03e-4 N on a reading of tens of newtons -- the test holds the component to that recorded COUNT and to 1.25 x the recorded maximum; every other component has no
       exception and is asserted at 1e-4 flat.  An exception therefore exists only as a number the GPU measured (tools/measure_tolerances.py), with its snapshot and gap.
+  (4) where the measured table records NO snapshot above 1e-4 for a (family, component), well-posed or not (`frac_within_1e-4` = 1: 30 of the 36 components in round 6 -- every
+      position / velocity component of the hand, Adroit, FetchReach / PickAndPlace / hull and ant fixtures), the bound is asserted on EVERY snapshot: for those the activation-gap
+      qualification above is not used at all.  The six that keep it: FetchPush obs (1 snapshot of 300), FetchSlide translational (3), kitchen positions / velocities (1 of 248),
+      AntMaze_Large velocities (1) and the touch forces (1 of 120 at 1.02e-4).
 tests/golden/tolerance_table.json (tools/measure_tolerances.py) is the record of the measured quantiles and of every snapshot above 1e-4 with its gap; its "reference_sensitivity"
 section (tools/oracle_sensitivity.py) is the yardstick: how far the fp64 ORACLE's own answer moves when its input state is perturbed by 1e-7 relative."""
 import numpy as np
@@ -49,3 +53,5 @@ def test_family_meets_the_north_star_bound(family):
             assert int(np.sum(err[posed] >= TOL)) <= allowed, (family, comp, int(np.sum(err[posed] >= TOL)), allowed)
             assert err[posed].max() < 1.25 * rec[comp]["max_away_from_boundary"] < 2e-4, (family, comp, float(err[posed].max()), rec[comp]["max_away_from_boundary"])
         assert np.mean(err < TOL) >= 0.99, (family, comp, float(np.mean(err < TOL)))
+        if rec[comp]["frac_within_1e-4"] == 1.0:      # (4): no exclusion at all where the measured table has none -- 30 of the 36 components in round 6
+            assert err.max() < TOL, (family, comp, int(err.argmax()), float(err.max()), float(gap[err.argmax()]))
