@@ -646,6 +646,8 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     ncand = hdr[0]; slist = list;
   }
 #endif
+  GRX_SUBTICK(c, 36);        // profiling build: skin-list validity check (+ the rebuilds) apart from the sweep of the listed pairs
+  GRX_COUNT(c, 37, ncand);   // ... candidates swept per substep (summed over the step)
   const int cap = c->jpool - 256, compact = ncand > 64 && cap >= 64;
   const bool classed = kChunked && ndp > 512 && ndp < 65536;   // a property of the MODEL (not of the kernel shape): the generic and the specialised kernel agree
   const int chunk = (kChunked && compact && cap < ncand) ? cap : (ncand > 0 ? ncand : 1);
@@ -707,6 +709,7 @@ GRX_MEM void grx_collision(const GrxModel* m, GrxCtx* c, int lane_) {
     WAVE_SYNC();
     nsurv = ns; surv = sv;
     GRX_SUBTICK(c, 19);
+    GRX_COUNT(c, 38, ns);    // profiling build: survivors of the sweep (sphere / plane test + bounding-box filter)
     // Large scenes: the survivors (the kitchen: ~170 per substep, three rounds of 64) are regrouped by the KIND of narrow phase they need -- analytic
     // primitive tests, box-box (queued), hull pairs (bounding-box test + queue), portal refinement on a lane -- so that a round of 64 lanes runs one
     // kind instead of paying every kind's divergent branch in every round.  The contact list is put back into pair order afterwards (below).

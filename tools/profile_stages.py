@@ -54,7 +54,7 @@ SUB = {0: "constraint: count", 1: "constraint: scan", 2: "constraint: equality r
        12: "collision: geom frames", 13: "collision: narrow phase rounds", 14: "inertia: cinert/cdof", 15: "inertia: crb/M", 16: "collision: hull pairs", 17: "solver aux a", 18: "solver aux b",
        19: "collision: candidate sweep", 20: "collision: survivor regroup", 21: "hull pairs: set-up", 22: "hull pairs: cached direction check", 23: "hull pairs: portal search",
        24: "COUNT hull pairs queued", 25: "COUNT portal searches", 26: "COUNT support evaluations", 27: "COUNT hull vertices scanned", 28: "(inside the portal searches) cycles in the support scans", 29: "COUNT Newton iterations", 30: "COUNT constrained solves", 31: "COUNT constraint rows (sum over solves)",
-       32: "MAX rows demanded (per world; summed over worlds here)", 33: "MAX Jacobian-pool words demanded", 34: "MAX contacts"}
+       32: "MAX rows demanded (per world; summed over worlds here)", 33: "MAX Jacobian-pool words demanded", 34: "MAX contacts", 36: "collision: skin-list check / rebuild", 37: "COUNT candidates swept (sum over substeps)", 38: "COUNT sweep survivors (sum over substeps)"}
 for k in range(16, NP):
     if tot[k] > 0:
         print(f"  sub[{k-16:2d}] {SUB.get(k - 16, ''):32s} {tot[k]:12.0f}  {100*tot[k]/s:5.1f}%")
