@@ -22,7 +22,7 @@ class OverflowLaneStruct(ctypes.Structure):
 class FetchBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "qpos", "qvel", "qacc_ws", "mocap", "aux", "goal", "action", "obs", "achieved", "reward", "success", "status", "mask", "order", "cost", "packed", "hullcache", "handoff")] + [
-        ("handoff_stride", ctypes.c_int), ("handoff_large", ctypes.c_int), ("lane", OverflowLaneStruct)]
+        ("handoff_stride", ctypes.c_int), ("handoff_large", ctypes.c_int), ("split_state", ctypes.c_void_p), ("split_parts", ctypes.c_int), ("split_pad_", ctypes.c_int), ("lane", OverflowLaneStruct)]
 
 
 class FetchResetArgsStruct(ctypes.Structure):

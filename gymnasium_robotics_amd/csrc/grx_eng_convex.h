@@ -324,9 +324,35 @@ GRX_MEM void grx_mpr_support(const Q* q, const MF* d, GrxMprPt* o) {
     q->hk = ek + 1;
   }
 #endif
-  if (W && q->t1 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); f1 = grx_mesh_support(q->v1, q->n1, dl, r, q->lane, q->aadr1, q->anum1, q->adj, h1, q->nbr1, q->cell1, q->cellrec); mulMatVec3f(o->w, q->R1, r); }
+  bool got1 = false, got2 = false;
+#if GRX_DEVICE_HULL_HINTS && !defined(GRX_NO_DUAL_HINT)
+  // Hull against hull with a guess for BOTH (the arm resting on the head link: the worlds that end a Fetch launch): the two guesses are verified in ONE round -- lanes 0-15 fetch
+  // the 16 neighbour records of hull 1's guess, lanes 16-31 those of hull 2's, each half projects on ITS direction -- instead of two dependent fetch / project / ballot rounds one
+  // after the other.  Same records, same fp64 projections, same margin as the guess check of grx_mesh_support: an accepted guess is the vertex that routine returns; a
+  // hull whose guess fails goes through it without a guess (which is what it does itself after a failed check).
+  if (W && q->t1 == 7 && q->t2 == 7 && h1 >= 0 && h1 < q->n1 && h2 >= 0 && h2 < q->n2 && q->nbr1 != nullptr && q->nbr2 != nullptr) {
+    MF dl1[3], dl2[3];
+    mulMatTVec3f(dl1, q->R1, d); mulMatTVec3f(dl2, q->R2, nd);
+    const int l_ = q->lane, k_ = l_ & (GRX_NBR_RECS - 1); const bool sec = (l_ & GRX_NBR_RECS) != 0;
+    const float4 p = ((const float4*)(sec ? q->nbr2 : q->nbr1))[GRX_NBR_RECS * (sec ? h2 : h1) + k_];
+    const int deg1 = (int)grx_readlane_f(p.w, 0), deg2 = (int)grx_readlane_f(p.w, GRX_NBR_RECS);
+    const double dx = sec ? (double)dl2[0] : (double)dl1[0], dy = sec ? (double)dl2[1] : (double)dl1[1], dz = sec ? (double)dl2[2] : (double)dl1[2];
+    const double t = (double)p.x * dx + (double)p.y * dy + (double)p.z * dz;
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+    const double t01 = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(tb >> 32), 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)tb, 0)));
+    const double t02 = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(tb >> 32), GRX_NBR_RECS) << 32) | (unsigned)__builtin_amdgcn_readlane((int)tb, GRX_NBR_RECS)));
+    const double dn = sqrt(dx * dx + dy * dy + dz * dz), t0 = sec ? t02 : t01;
+    const bool beaten = k_ >= 1 && k_ <= (sec ? deg2 : deg1) && !(t0 - t > 1.0e-6 * dn);
+    const unsigned long long bal = __ballot(beaten);
+    got1 = deg1 >= 1 && (bal & 0xFFFFull) == 0ull; got2 = deg2 >= 1 && ((bal >> GRX_NBR_RECS) & 0xFFFFull) == 0ull;
+    if (got1) { MF r[3] = {grx_readlane_f(p.x, 0), grx_readlane_f(p.y, 0), grx_readlane_f(p.z, 0)}; f1 = h1; mulMatVec3f(o->w, q->R1, r); }
+    if (got2) { MF r[3] = {grx_readlane_f(p.x, GRX_NBR_RECS), grx_readlane_f(p.y, GRX_NBR_RECS), grx_readlane_f(p.z, GRX_NBR_RECS)}; f2 = h2; mulMatVec3f(b, q->R2, r); }
+    h1 = h2 = -1;   // checked: a failed guess is not checked again
+  }
+#endif
+  if (W && q->t1 == 7) { if (!got1) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R1, d); f1 = grx_mesh_support(q->v1, q->n1, dl, r, q->lane, q->aadr1, q->anum1, q->adj, h1, q->nbr1, q->cell1, q->cellrec); mulMatVec3f(o->w, q->R1, r); } }
   else grx_geom_support(q->R1, q->s1, q->t1, d, o->w);
-  if (W && q->t2 == 7) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); f2 = grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj, h2, q->nbr2, q->cell2, q->cellrec); mulMatVec3f(b, q->R2, r); }
+  if (W && q->t2 == 7) { if (!got2) { MF dl[3], r[3]; mulMatTVec3f(dl, q->R2, nd); f2 = grx_mesh_support(q->v2, q->n2, dl, r, q->lane, q->aadr2, q->anum2, q->adj, h2, q->nbr2, q->cell2, q->cellrec); mulMatVec3f(b, q->R2, r); } }
   else grx_geom_support(q->R2, q->s2, q->t2, nd, b);
 #if GRX_DEVICE_HULL_HINTS
   // the winners become the guesses of this evaluation in the next substep.  (The guess words live in the world's HBM row, written and read by the lanes of ONE wave without a

@@ -38,6 +38,8 @@ struct GrxFetchBuffers {
   float* hullcache;                      // [N, GRX_HULLCACHE_WORDS] or null: in/out, GrxCtx::meshcache carried across launches + the support-vertex guesses (include/grx_capi.h)
   float* handoff;                        // [N, handoff_stride] or null: the worlds' mid-step hand-off rows (include/grx_capi.h; GrxCtx::handoff); word 0 of a row = substep + 1, 0 = none
   int handoff_stride, handoff_large;     // words per row (>= grx_handoff_words); handoff_large: entries claimed by THIS launch need the large tables (see grx_overflow_lane)
+  int* split_state;                      // [N, 2] or null: split step (include/grx_capi.h): [2 w] = parts of world w done in this launch (< 0: aborted, re-run booked), [2 w + 1] = their measured duration
+  int split_parts, split_pad_;           // >= 2: the launch has split_parts workgroups per world, each running its share of the substeps (the hand-off rows carry the state between them)
   GrxLane lane;                          // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 
@@ -138,11 +140,12 @@ GRX_MEM void grx_fetch_step_world(const GrxModel* m, const GrxFetchTask* t, GrxC
 }
 // the simulation part alone: the step kernel derives the output pointers after it, so no global address stays live across the substeps.
 // s0 > 0: the world RESUMES at substep s0 -- the caller has restored ctrl, mocap, qpos, qvel and the warm start from its hand-off row (GrxCtx::handoff) and set c->resume_first.
-GRX_MEM void grx_fetch_sim_world(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux_in, const float* action, int lane_, int s0 = 0) {
+// s_end >= 0: stop BEFORE substep s_end (a part of a split step, include/grx_capi.h grx_fetch_buffers.split_parts: the caller writes the state to the world's row).
+GRX_MEM void grx_fetch_sim_world(const GrxModel* m, const GrxFetchTask* t, GrxCtx* c, const float* aux_in, const float* action, int lane_, int s0 = 0, int s_end = -1) {
   if (s0 == 0) grx_fetch_set_action(m, t, c, aux_in, action, lane_);
   // n_substeps x mj_step, plus (block_gripper tasks) the _step_callback: zero the finger qpos and run one mj_forward.
   // One loop, one call site of the physics, so the loop body stays resident in the instruction cache.
-  const int total = t->n_substeps + (t->block_gripper ? 1 : 0);
+  const int total = s_end >= 0 ? s_end : t->n_substeps + (t->block_gripper ? 1 : 0);
   for (int s = s0; s < total; s++) {
     const int callback = (s == t->n_substeps);
     if (callback) { LANE0 { c->qpos[t->jq_lf] = 0.0f; c->qpos[t->jq_rf] = 0.0f; } WAVE_SYNC(); }

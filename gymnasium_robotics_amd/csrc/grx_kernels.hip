@@ -175,6 +175,12 @@ static __device__ __forceinline__ int grx_world_of_block() { return (int)((block
 // the same index re-derived after the substep loop from the (architected) workgroup id: the epilogue's addresses are then computed
 // there instead of being kept -- as 64-bit VGPR pairs spilled to scratch -- across the whole simulation
 static __device__ __forceinline__ unsigned grx_block_late() { unsigned bx = blockIdx.x; asm volatile("" : "+s"(bx)); return bx; }
+// (split step: `parts` workgroups per world, workgroup index = part * G + slot with G = gridDim.x / parts)
+static __device__ __forceinline__ int grx_world_of_slot_late(const int* order, int parts) {
+  unsigned bx = blockIdx.x; asm volatile("" : "+s"(bx));
+  const unsigned G = parts > 1 ? gridDim.x / (unsigned)parts : gridDim.x, slot = parts > 1 ? bx % G : bx;
+  return order ? order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3));
+}
 static __device__ __forceinline__ int grx_world_of_block_late() {
   unsigned bx = blockIdx.x; asm volatile("" : "+s"(bx));
   return (int)((bx & 7u) * (gridDim.x >> 3) + (bx >> 3));
@@ -240,17 +246,35 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 256, 4080, 92, 64, 1, 2> G
 #define GRX_FETCH_WAVES(S) (S::kHandoff ? 3 : 2)   // the wave-cooperative hull routine keeps ~100 values live: at 168 VGPRs (3 waves) the step kernels spill 60-130 registers and run slower than at 2 waves even with 9 instead of 8 worlds per CU and the hull branch marked cold (measured 3.75 vs 3.44 ms per step)
 #endif
 // one world's env.step().  LANE: called from the list-walking loop of the large-table kernel (w comes from the list; see grx_overflow_lane)
+// SPLIT (include/grx_capi.h, grx_fetch_buffers.split_parts): `part` of `parts` workgroups of this world, each running its share of the substeps; 0 of 1 = the whole step.
+#define GRX_SPLIT_SPIN_LIMIT (1 << 22)   // polls (~64 cycles each: > 100 ms) before a part gives its predecessor up: never reached while workgroups of an XCD start in index order
 template <class S, bool LANE>
-__device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTask& t, const GrxFetchBuffers& b, const int w, int n_worlds, int words, float* lds, const int lane_) {
+__device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTask& t, const GrxFetchBuffers& b, const int w, int n_worlds, int words, float* lds, const int lane_,
+                                                     const int part = 0, const int parts = 1) {
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) { if (LANE) grx_lane_ticket(b.lane, -1, w, lane_); return; }
   if (!LANE && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel
+  const bool split = !LANE && parts > 1, last_part = part == parts - 1;
+  if (split && part > 0) {   // wait for the part before this one (it was dispatched earlier on the same XCD: it is running or done)
+    volatile int* st = b.split_state + 2 * (size_t)w;
+    int v = 0;
+    for (int spins = 0; spins < GRX_SPLIT_SPIN_LIMIT; spins++) {
+      v = __builtin_amdgcn_readfirstlane(st[0]);
+      if (v == part || v < 0) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (v != part) {   // the earlier part booked the world's re-run (v < 0), or never came (v < part: flagged): nothing to do here; the last part leaves the word clean
+      if (lane_ == 0) { if (v >= 0) b.status[w] |= GRX_ST_BADNUM | (GRX_ST_BADNUM << 16); if (last_part) st[0] = 0; }
+      return;
+    }
+    __threadfence();
+  }
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
   grx_ctx_carve(&c, lds, grx_shape_dims<S>(m));
   grx_lane_setup(b.lane, c, w, true);
-  if (b.handoff && c.bail) { c.handoff = b.handoff; c.handoff_stride = b.handoff_stride; c.handoff_large = b.handoff_large; }   // this launch can hand a world off mid-step (it has an entry list to claim from)
+  if (b.handoff && c.bail && !split) { c.handoff = b.handoff; c.handoff_stride = b.handoff_stride; c.handoff_large = b.handoff_large; }   // this launch can hand a world off mid-step (it has an entry list to claim from)
 #ifdef GRX_PROFILE
   __shared__ long long prof_s[GRX_NPROF + 1];
   c.prof = prof_s; c.prof_last = prof_s + GRX_NPROF;
@@ -264,11 +288,12 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
 #endif
   grx_load_world(m, b, c, w, lds, words, lane_);
   if (S::kMesh && m.nmeshpair > 0 && b.hullcache) c.hullhint = b.hullcache + (size_t)w * GRX_HULLCACHE_WORDS + 21;   // support-vertex guesses of the world's persistent hull contacts: used in place (HBM)
-  if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) c.meshcache[lane_] = b.hullcache[(size_t)w * GRX_HULLCACHE_WORDS + lane_];   // separating directions remembered from the previous step (re-verified before use)
+  if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21)   // separating directions remembered from the previous step (re-verified before use); a later part of a split step reads what the part before it wrote (another CU: past the L1)
+    c.meshcache[lane_] = (split && part > 0) ? ((volatile const float*)b.hullcache)[(size_t)w * GRX_HULLCACHE_WORDS + lane_] : b.hullcache[(size_t)w * GRX_HULLCACHE_WORDS + lane_];
   float aux_in[8];
   for (int k = 0; k < 8; k++) aux_in[k] = b.aux[(size_t)w * 8 + k];
   int s0 = 0;
-  if (LANE && b.handoff) {   // a world another kernel of this step handed off: resume AT the substep it stopped before (its row was written during this very launch group, possibly
+  if ((LANE && b.handoff) || (split && part > 0)) {   // a world another kernel of this step handed off (or the part before this one of a split step): resume AT the substep it stopped before (its row was written during this very launch group, possibly
                              // behind another XCD's L2: volatile = cache-bypassing loads, ordered behind the claim of the entry by the caller's fence)
     volatile const float* row = b.handoff + (size_t)w * b.handoff_stride;
     const int hs = __builtin_amdgcn_readfirstlane(((volatile const int*)row)[0]);
@@ -285,11 +310,39 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
       for (int i = lane_; i < nv; i += 64) { c.qvel[i] = row[o + i]; c.qacc_ws[i] = row[o + nv + i]; }
       if (lane_ == 0) { c.cnt[2] |= ((volatile const int*)row)[1]; ((volatile int*)row)[0] = 0; }   // the flags of the substeps the other kernel ran; the row is consumed
       __syncthreads();
-      c.resume_first = 1; s0 = hs - 1;
+      c.resume_first = (split && part > 0) ? 0 : 1;   // (a part of a split step ended at a substep BOUNDARY: the next substep normalises the free-joint quaternions as the plain step does)
+      s0 = hs - 1;
     }
   }
-  GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_, s0);
-  const int wl = LANE ? w : (b.order ? b.order[grx_block_late()] : grx_world_of_block_late());
+  const int total_ = t.n_substeps + (t.block_gripper ? 1 : 0), s_end = (split && !last_part) ? ((part + 1) * total_) / parts : -1;
+  GrxFetch<S>::grx_fetch_sim_world(&m, &t, &c, aux_in, b.action + (size_t)w * 4, lane_, s0, s_end);
+  const int wl = LANE ? w : grx_world_of_slot_late(b.order, parts);
+  if (split && !last_part) {   // an earlier part of a split step: the state goes to the world's row, nothing else is written
+    volatile int* st = b.split_state + 2 * (size_t)wl;
+    if (grx_lane_overflowed(c)) { if (lane_ == 0) st[0] = -1; }      // the re-run on the large tables is booked: the later parts return
+    else {
+      if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) b.hullcache[(size_t)wl * GRX_HULLCACHE_WORDS + lane_] = c.meshcache[lane_];
+      const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv, nu = S::kFixed ? S::NU : m.nu, nmo = S::kFixed ? S::NM : m.nmocap;
+      float* row = b.handoff + (size_t)wl * b.handoff_stride;
+      int o = 2;
+      for (int i = lane_; i < nu; i += 64) row[o + i] = c.ctrl[i];
+      o += nu;
+      for (int i = lane_; i < 7 * nmo; i += 64) { const int k = i / 7, e = i - 7 * k; row[o + i] = (e < 3) ? c.mocap_pos[3 * k + e] : c.mocap_quat[4 * k + e - 3]; }
+      o += 7 * nmo;
+      for (int i = lane_; i < nq; i += 64) row[o + i] = c.qpos[i];
+      o += nq;
+      for (int i = lane_; i < nv; i += 64) { row[o + i] = c.qvel[i]; row[o + nv + i] = c.qacc_ws[i]; }
+      if (lane_ == 0) { ((int*)row)[1] = c.cnt[2]; ((int*)row)[0] = s_end + 1; }
+      __threadfence();
+      __syncthreads();
+      if (lane_ == 0) {
+        if (b.cost) { const int t0 = ((volatile int*)b.cost)[wl]; st[1] = (part > 0 ? st[1] : 0) + (((int)wall_clock64() - t0) >> 3); }
+        __threadfence();
+        st[0] = part + 1;
+      }
+    }
+    return;
+  }
   // a capacity overflowed (wave-uniform: the flag lives in LDS): keep nothing, the world is re-run on the large tables (grx_overflow_lane)
   if (!grx_lane_overflowed(c)) {
     if (LANE) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, wl, lane_); else grx_lane_join(b.lane, c, wl, lane_);
@@ -308,9 +361,10 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
 #ifdef GRX_COST_MODEL
   if (b.cost && lane_ == 0) b.cost[wl] = 12 * c.cnt[6] + 24 * c.cnt[0];
 #else
-  if (b.cost && lane_ == 0) { const int t0 = ((volatile int*)b.cost)[wl]; b.cost[wl] = ((int)wall_clock64() - t0) >> 3; }
+  if (b.cost && lane_ == 0) { const int t0 = ((volatile int*)b.cost)[wl]; b.cost[wl] = (((int)wall_clock64() - t0) >> 3) + (split ? ((volatile int*)b.split_state)[2 * (size_t)wl + 1] : 0); }
 #endif
 #endif
+  if (split && lane_ == 0) ((volatile int*)b.split_state)[2 * (size_t)wl] = 0;   // the last part leaves the world's word clean for the next launch
 #if defined(GRX_WORLD_SPAN) && !defined(GRX_PROFILE)
   if (lane_ == 0 && wl < 16384) g_grx_world_span[2 * wl + 1] = wall_clock64();
 #endif
@@ -326,6 +380,11 @@ __global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))
 grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
+  const int parts = b.split_parts > 1 ? b.split_parts : 1;
+  if (parts > 1) {
+    const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot and slot + G, slot + 2 G ... share blockIdx.x mod 8: one XCD, one L2 for all parts of a world
+    grx_fetch_step_world<S, false>(mslot, t, b, b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)), n_worlds, words, lds, lane_, (int)part, parts);
+  } else
   grx_fetch_step_world<S, false>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, lds, lane_);
   grx_lane_progress(b.lane);   // (launches with polling workgroups behind them: this workgroup has ended)
 }
@@ -1153,7 +1212,13 @@ extern "C" int grx_fetch_step(const grx_model* m, const grx_fetch_task* task, co
   if (b.lane.list && m->shape != 0 && m->shape != 1 && m->shape < 100) return fail("grx_fetch_step: a lane launch needs a model with a lane kernel (the generic kernel, FetchPickAndPlace's own shape, or its large-table shape)");
   if (m->shape == 8 && !(b.handoff && b.lane.entry_count && b.lane.entry_list && b.handoff_stride >= grx_handoff_words(m->dev.nq, m->dev.nv, m->dev.nu, m->dev.nmocap)))
     return fail("grx_fetch_step: the fast FetchPickAndPlace kernel carries no hull routine: it needs hand-off rows (handoff, handoff_stride) and an entry list to hand hull worlds to");
-  const int e = grx_tu_fetch_launch(0, m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, 0);
+  if (b.split_parts > 1) {
+    if (b.lane.list || m->shape == 8) return fail("grx_fetch_step: split_parts applies to the step launch of a full kernel (not to a lane launch, not to the hull-less fast kernel)");
+    if (!b.split_state || !b.handoff || b.handoff_stride < grx_handoff_words(m->dev.nq, m->dev.nv, m->dev.nu, m->dev.nmocap)) return fail("grx_fetch_step: a split step needs split_state [N, 2] and hand-off rows (handoff, handoff_stride) as carrier");
+    if (b.split_parts > 8) return fail("grx_fetch_step: split_parts <= 8");
+  } else b.split_parts = 0;
+  const unsigned split_mul = b.split_parts > 1 ? (unsigned)b.split_parts : 1u;
+  const int e = grx_tu_fetch_launch(0, m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : split_mul * grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, nullptr, n_worlds, m->words, 0);
   if (e) return fail(std::string("grx_fetch_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }

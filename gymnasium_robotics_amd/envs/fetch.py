@@ -41,6 +41,7 @@ FETCH_CAPACITY = {"maxcon": 28, "maxefc": 144, "jpool": 2032, "split_spans": Fal
 # worlds per CU).  ~0.1 % of the world-steps exceed 1 024 pool words, none 24 contacts (profiles/hull_share_r06_fetch.txt); a world that does -- or in which a hull pair passes the
 # bounding-box filter -- is handed off MID-STEP to the standing lane, which runs the kernel on FETCH_CAPACITY above (include/grx_capi.h, grx_fetch_buffers.handoff).
 FETCH_FAST_CAPACITY = {"maxcon": 24, "maxefc": 96, "jpool": 1024}
+FETCH_SPLIT_PARTS = 2     # default of GRX_FETCH_SPLIT for batches of more than one round of worlds (see FetchVecEnv._alloc; profiles/ab_r06_fetch_split.txt: 2 is the optimum at 4 096 - 16 384 worlds)
 HANDOFF_TASKS = ("FetchPickAndPlace",)
 
 
@@ -218,6 +219,18 @@ class FetchVecEnv(GoalVecEnv):
         self._bufs = self._make_bufs(*common, None, self.order, self.cost, self.packed, self.hullcache, self.handoff)
         self._bufs_masked = self._make_bufs(*common, self.mask, self.order, self.cost, self.packed, self.hullcache, self.handoff)
         self._bufs.handoff_stride = self._bufs_masked.handoff_stride = self._handoff_stride
+        # SPLIT STEP (include/grx_capi.h grx_fetch_buffers.split_parts): the step launch has P workgroups per world, each running 1 / P of the substeps (the state travels through the
+        # world's hand-off row): the launch's tail -- the duration of the LAST workgroup started, a whole world-step otherwise -- shrinks to 1 / P of it.  Bit-identical to the unsplit
+        # launch (tests/test_gpu_fetch.py::test_split_step_is_the_plain_step).  GRX_FETCH_SPLIT=P (1: off); not combined with the hull-less fast kernel.
+        # Default: 2 parts for batches of more than 2 048 worlds (one round of the chip's wave slots at 8 worlds per CU: below that every workgroup starts at once and there is no tail
+        # to shorten).  Measured (profiles/ab_r06_fetch_split.txt): 4 096 worlds 1.263 -> 1.381 M (+9.3 %), 8 192: 1.542 -> 1.630 M (+5.7 %), 16 384: 1.717 -> 1.764 M (+2.8 %); 3 parts
+        # lose to 2 (each part re-enters the kernel), 5 lose to none.
+        self._split = max(1, int(os.environ.get("GRX_FETCH_SPLIT", str(FETCH_SPLIT_PARTS if n > 2048 else 1)))) if self.handoff is None and n >= 64 else 1
+        if self._split > 1:
+            stride = -(-(2 + self.model.dim("nu") + 7 * self.nmocap + self.nq + 2 * self.nv) // 16) * 16
+            self._split_rows, self._split_state = z(n, stride), z(n, 2, dtype=torch.int32)
+            for b in (self._bufs, self._bufs_masked):
+                b.handoff, b.handoff_stride, b.split_state, b.split_parts = self._split_rows.data_ptr(), stride, self._split_state.data_ptr(), self._split
         self.lane = None
         if self._h_big is not None:
             packed, hullcache, handoff, stride, mk = self.packed, self.hullcache, self.handoff, self._handoff_stride, FetchVecEnv._make_bufs      # (no reference to self: the lane must not keep the environment alive)

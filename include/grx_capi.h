@@ -131,6 +131,16 @@ typedef struct grx_fetch_buffers {
   float* handoff;                       /* [N, handoff_stride] or NULL */
   int handoff_stride;                   /* words per row, >= 2 + nu + 7 nmocap + nq + 2 nv */
   int handoff_large;                    /* 1: entries claimed by THIS launch need the large tables (it runs the middle ones): polling workgroups give them back to the entry launch */
+  /* SPLIT STEP (round 6; step launches only, not lane launches, not the hull-less fast kernel).  A launch of N worlds on S wave slots ends Sum(work) / S + the duration of the LAST
+   * workgroup started -- a whole world-step (0.85 ms of FetchPickAndPlace's 2.9 ms launch at 4 096 worlds).  With split_parts = P >= 2 the launch has P workgroups per world,
+   * workgroup p * grid + g running substeps [p T / P, (p + 1) T / P) of the world of slot g (same XCD for every part of a world): part p < P - 1 ends by writing the world's hand-off row
+   * (the `handoff` rows above serve as the carrier: same layout, same bit-identical resume as the mid-step hand-off) and publishing p + 1 in split_state[2 w]; part p > 0 waits for
+   * that word (its predecessor was dispatched before it: workgroups of one XCD start in index order), resumes from the row; only the last part writes state rows and outputs.  A part
+   * that exceeds a table books the world's re-run as usual and marks the word negative (the later parts return).  split_state[2 w + 1] carries the measured duration of the
+   * earlier parts (cost).  Results are bit-identical to the unsplit launch (tests/test_gpu_fetch.py::test_split_step_is_the_plain_step).  Zeroed before the first launch. */
+  int* split_state;                     /* [N, 2] or NULL */
+  int split_parts;                      /* 0 / 1: one workgroup per world */
+  int split_pad_;
   grx_overflow_lane lane;               /* capacity overflows are re-run on larger tables instead of dropping contacts: see grx_overflow_lane above and its LIMITS */
 } grx_fetch_buffers;
 

@@ -150,6 +150,44 @@ def test_hull_candidate_lists_do_not_change_the_rollout(monkeypatch):
             assert torch.equal(envs[0].qpos, e.qpos) and torch.equal(envs[0].qvel, e.qvel) and torch.equal(envs[0].obs, e.obs), t
 
 
+@pytest.mark.parametrize("task,parts,start", [("FetchPickAndPlace", 2, "rollout"), ("FetchPickAndPlace", 4, "rollout"), ("FetchPickAndPlace", 3, "hull_poses"), ("FetchPush", 2, "rollout"), ("FetchReach", 5, "rollout"),
+                                              ("FetchSlide", 2, "rollout")])
+def test_split_step_is_the_plain_step(monkeypatch, task, parts, start):
+    """Round 6: the step launch with P workgroups per world, each running 1 / P of the substeps (include/grx_capi.h, grx_fetch_buffers.split_parts: the state travels through the world's
+    hand-off row, a part waits for the one before it) against the plain launch (one workgroup per world): state rows, observations, rewards, flags, status words and the hull
+    caches are BIT-IDENTICAL after every step -- staggered episodes with same-step autoresets, the hull fixture (portal searches in every substep), block_gripper tasks (21 passes:
+    uneven shares), the cost-ordered dispatch on.  The reference's step is one env.step() whatever the launch geometry (/root/reference/gymnasium_robotics/envs/robot_env.py:114-152)."""
+    import torch
+
+    envs = []
+    for p_ in (1, parts):
+        monkeypatch.setenv("GRX_FETCH_SPLIT", str(p_))
+        if start == "hull_poses":
+            g = np.load(os.path.join(GOLDEN, "fetch_hull_teacher.npz"))
+            n = g["obs"].shape[0]
+            e = _env(task, n, autoreset_mode="disabled", max_episode_steps=None, output="torch")
+            e.reset(seed=0)
+            _load_state(e, g, slice(None))
+        else:
+            n = 2048
+            e = _env(task, n, autoreset_mode="same_step", max_episode_steps=50, output="torch")
+            e.reset(seed=7)
+            e._elapsed[:] = np.arange(n) % 50
+        envs.append(e)
+    plain, split = envs
+    assert plain._split == 1 and split._split == parts
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(3)
+    for t in range(30 if start == "hull_poses" else 110):
+        a = torch.rand(n, 4, device="cuda:0", generator=gen) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        for name in ("qpos", "qvel", "qacc_ws", "mocap", "aux", "obs", "achieved", "reward", "success", "packed", "goal", "status"):
+            assert torch.equal(getattr(split, name), getattr(plain, name)), (t, name, int((getattr(split, name) != getattr(plain, name)).sum()))
+        assert torch.equal(outs[0][3], outs[1][3])
+        assert int(split._split_state[:, 0].abs().max()) == 0, t      # every world's word is clean again
+    assert int(split.status.abs().max()) == 0
+    assert split.cost is None or int(split.cost.min()) > 0      # the measured durations of the parts add up to a cost for the next launch's order
+
+
 @pytest.mark.parametrize("start", ["hull_poses", "rollout"])
 def test_handoff_is_the_full_kernels_rollout(monkeypatch, start):
     """Round 6: FetchPickAndPlace steps on a FAST kernel without the hull-pair routine (168 VGPRs, three waves per SIMD, ten worlds per CU); a world in which a hull pair passes
