@@ -522,8 +522,10 @@ def run_rank(args, rank, world_size, local_rank):
         replay.begin_episode(env.packed)
         replay.set_episode_start(-env._elapsed)   # staggered: world i is elapsed[i] steps into its episode
 
+    act_buf = torch.empty(n, act_dim, device=device)
+
     def one_step():
-        a = torch.rand(n, act_dim, device=device, generator=gen) * 2 - 1
+        a = act_buf.uniform_(-1.0, 1.0, generator=gen)      # uniform random actions: one kernel
         obs, r, term, trunc, info = env.step(a)
         if her:
             replay.append(a, env.packed, term | trunc, final_rows=env.final_packed)   # the reset kernel parked the terminal rows there: the last transition of every episode is relabelled too

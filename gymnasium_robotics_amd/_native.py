@@ -45,7 +45,7 @@ class AdroitTaskStruct(ctypes.Structure):
 
 
 class AdroitBuffersStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")] + [("lane", OverflowLaneStruct), ("compact", ctypes.c_void_p), ("n_compact", ctypes.c_int)]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")] + [("lane", OverflowLaneStruct), ("compact", ctypes.c_void_p), ("n_compact", ctypes.c_int), ("order", ctypes.c_void_p), ("cost", ctypes.c_void_p)]
 
 
 class KitchenTaskStruct(ctypes.Structure):
@@ -56,7 +56,7 @@ class KitchenTaskStruct(ctypes.Structure):
 
 class KitchenBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "last_qpos", "action", "noise", "obs", "completed", "status", "mask", "skin")] + [
-        ("skin_stride", ctypes.c_int), ("skin_radius", ctypes.c_float), ("lane", OverflowLaneStruct)]
+        ("skin_stride", ctypes.c_int), ("skin_radius", ctypes.c_float), ("order", ctypes.c_void_p), ("cost", ctypes.c_void_p), ("lane", OverflowLaneStruct)]
 
 
 class KitchenBookStruct(ctypes.Structure):      # include/grx_capi.h, grx_kitchen_book

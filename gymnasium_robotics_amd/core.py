@@ -80,8 +80,11 @@ class GoalVecEnv:
 
     def _status_info(self, info):
         """info["status"] (this step's flags) and info["status_sticky"] for both output modes."""
-        if self.output == "torch":      # two elementwise device ops, no sync
-            info["status"], info["status_sticky"] = self.status & 0xFFFF, self.status >> 16
+        if self.output == "torch":      # the two 16-bit halves of the status words as int16 VIEWS (little endian; the flags use bits 0 - 5): no kernel, no sync; valid until the next step like every torch output
+            import torch
+
+            halves = self.status.view(torch.int16).view(-1, 2)
+            info["status"], info["status_sticky"] = halves[:, 0], halves[:, 1]
         else:
             st = self.status.cpu().numpy()
             info["status"], info["status_sticky"] = st & 0xFFFF, st >> 16
@@ -297,6 +300,32 @@ KITCHEN_RERUN_CAPACITY = {"maxefc": 400, "jpool": 8160, "maxcon": 64}
 LANE_TTL = 4       # steps a world stays in the lane after the last step in which it came within LANE_MARGIN of a capacity of the fast kernel (profiles/ab_r04_lane_parameters.txt: margin 0.5 - 0.9, ttl 2 - 32, 16 - 48 polling workgroups swept)
 LANE_MARGIN = 0.8
 LANE_POLL_GRID = 16    # entrants per step that can be re-run while the fast launch is still running (more: the serialised launch behind it takes the rest)
+
+
+def cost_order_alloc(env, n, device, *bufs):
+    """Cost-ordered dispatch for a family whose buffer struct has `order` / `cost` (include/grx_capi.h, grx_kitchen_buffers.order): allocates env.cost / env.cost_ema / env.order
+    (the identity order: workgroup j -> XCD slice j & 7, position j >> 3, as grx_world_of_block maps it) and points the given STEP buffer structs at them.  The lane's and the
+    compact launches keep their own structs (no order).  False when the batch does not qualify (grx_order_by_cost: a multiple of 8 worlds, at most 8 192 per XCD slice)."""
+    import torch
+
+    if n % 8 != 0 or not (1024 <= n <= 65536):
+        return False
+    per = n // 8
+    env.cost, env.cost_ema = torch.zeros(n, dtype=torch.int32, device=device), torch.zeros(n, dtype=torch.float32, device=device)
+    env.order = ((torch.arange(8, device=device, dtype=torch.int32) * per).unsqueeze(1) + torch.arange(per, device=device, dtype=torch.int32).unsqueeze(0)).t().contiguous().view(-1)
+    for b in bufs:
+        b.order, b.cost = env.order.data_ptr(), env.cost.data_ptr()
+    return True
+
+
+def cost_order_update(env, alpha=None):
+    """order <- per XCD slice, worlds by decreasing (moving average of the) measured duration of the launches so far; in place, on the environment's stream"""
+    import os
+
+    from . import _native
+
+    alpha = float(os.environ.get("GRX_BALANCE_ALPHA", 0.1 if alpha is None else alpha))      # weight of the newest sample in the moving average the order is sorted by
+    _native.check(env._L.grx_order_by_cost(env.cost.data_ptr(), env.cost_ema.data_ptr(), alpha, env.num_envs, env.order.data_ptr(), env._stream()))
 
 
 def create_rerun_model(L, model, device_index, enabled=True, capacity=None):

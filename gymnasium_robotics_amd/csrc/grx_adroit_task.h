@@ -43,6 +43,8 @@ struct GrxAdroitBuffers {
   GrxLane lane;                   // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
   const long long* compact;       // [n_compact] world indices or null: workgroup j of a launch of n_compact workgroups handles world compact[j]
   int n_compact;
+  const int* order;               // [grid] or null: workgroup j steps world order[j] (cost-ordered dispatch, include/grx_capi.h); ignored by compact launches
+  int* cost;                      // [N] or null: measured duration of each world's step (80 ns units), written by step launches
 };
 
 template <class S>

@@ -674,9 +674,12 @@ __device__ __forceinline__ void grx_adroit_step_world(int mslot, const GrxAdroit
   if (m.nshift && lane_ < 7) c.shift[lane_] = b.shift[(size_t)w * 7 + lane_];
   __syncthreads();
   grx_lane_setup(b.lane, c, w, !forward_only);
+  const bool timed = b.cost && !forward_only && !in_lane && !b.compact;   // cost-ordered dispatch (include/grx_capi.h grx_adroit_buffers.order / .cost): the start stamp (100 MHz) is parked in the cost slot itself
+  if (timed && lane_ == 0) b.cost[w] = (int)wall_clock64();
   if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
   else GrxAdroit<S>::grx_adroit_sim_world(&m, &t, &c, b.action + (size_t)w * nu, b.act_mean, b.act_rng, lane_);
-  const int wl = in_lane ? w : (b.compact ? (int)b.compact[blockIdx.x] : grx_world_of_block_late());   // (recomputed, not kept live across the simulation)
+  const int wl = in_lane ? w : (b.compact ? (int)b.compact[blockIdx.x] : (b.order ? b.order[grx_block_late()] : grx_world_of_block_late()));   // (recomputed, not kept live across the simulation)
+  if (timed && lane_ == 0) { const int t0 = ((volatile int*)b.cost)[wl]; b.cost[wl] = ((int)wall_clock64() - t0) >> 3; }   // measured duration of this world, 80 ns units
   if (grx_lane_overflowed(c)) return;   // capacity overflow: keep nothing, re-run on the large tables
   if (in_lane) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, wl, lane_); else if (!forward_only) grx_lane_join(b.lane, c, wl, lane_);
   GrxAdroit<S>::grx_adroit_outputs(&m, &t, &c, b.target ? b.target + (size_t)wl * 3 : nullptr, b.obs + (size_t)wl * t.obs_dim, b.reward + wl, b.success + wl, lane_);
@@ -694,7 +697,7 @@ __global__ void __launch_bounds__(64, 2)
 grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
-  const int w = b.compact ? ((int)blockIdx.x < b.n_compact ? (int)b.compact[blockIdx.x] : n_worlds) : grx_world_of_block();
+  const int w = b.compact ? ((int)blockIdx.x < b.n_compact ? (int)b.compact[blockIdx.x] : n_worlds) : (b.order ? b.order[blockIdx.x] : grx_world_of_block());
   grx_adroit_step_world<S>(mslot, t, b, w, n_worlds, words, forward_only, lds, lane_, false);
   grx_lane_progress(b.lane);
 }
@@ -739,8 +742,11 @@ __device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitch
   float* last = b.last_qpos + (size_t)w * GRX_KITCHEN_NROBOT;
   if (b.skin) { c.skin = b.skin + (size_t)w * b.skin_stride; c.skin_r = b.skin_radius; }
   grx_lane_setup(b.lane, c, w, !forward_only);
+  const bool timed = b.cost && !forward_only && !in_lane;   // cost-ordered dispatch (include/grx_capi.h grx_kitchen_buffers.order / .cost): the start stamp (100 MHz) is parked in the cost slot itself
+  if (timed && lane_ == 0) b.cost[w] = (int)wall_clock64();
   if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
   else GrxKitchen<S>::grx_kitchen_sim_world(&m, &t, &c, b.action + (size_t)w * GRX_KITCHEN_NROBOT, last, lane_);
+  if (timed && lane_ == 0) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = ((int)wall_clock64() - t0) >> 3; }   // measured duration of this world, 80 ns units (a world that overflowed a table too: it ran up to there)
   if (grx_lane_overflowed(c)) return;   // capacity overflow: keep nothing (last_qpos included), re-run on the large tables
   if (in_lane) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, w, lane_); else if (!forward_only) grx_lane_join(b.lane, c, w, lane_);
   GrxKitchen<S>::grx_kitchen_outputs(&m, &t, &c, b.noise ? b.noise + (size_t)w * t.obs_dim : nullptr, b.obs + (size_t)w * t.obs_dim, last, b.completed + w, lane_);
@@ -759,7 +765,7 @@ __global__ void __launch_bounds__(64, 2)
 grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
-  grx_kitchen_step_world<S>(mslot, t, b, grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+  grx_kitchen_step_world<S>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
   grx_lane_progress(b.lane);
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only

@@ -37,6 +37,8 @@ struct GrxKitchenBuffers {
   int* skin;                      // [N, skin_stride] broad-phase skin lists (GrxEngine::grx_collision), zeroed by the host once; or null
   int skin_stride;
   float skin_radius;
+  const int* order;               // [grid] or null: workgroup j steps world order[j] (cost-ordered dispatch, include/grx_capi.h)
+  int* cost;                      // [N] or null: measured duration of each world's step (80 ns units), written by step launches
   GrxLane lane;                   // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
 };
 

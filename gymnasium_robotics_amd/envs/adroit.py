@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..core import create_rerun_model, GoalVecEnv, OverflowLane, PinnedStager, np_random
+from ..core import cost_order_alloc, cost_order_update, create_rerun_model, GoalVecEnv, OverflowLane, PinnedStager, np_random
 from ..mjcf import CompiledModel
 from ..spaces import Box, batch_space
 from .adroit_spec import IDENTITY_SHIFT, MAX_EPISODE_STEPS, SPECS, action_scaling, group_shift, load_adroit_model, make_adroit_task, parse_adroit_id, sample_reset_batch
@@ -62,6 +62,12 @@ class AdroitVecEnv(GoalVecEnv):
         am, ar = action_scaling(self.model)
         self._act_mean, self._act_rng = torch.from_numpy(am.astype(np.float32)).to(d), torch.from_numpy(ar.astype(np.float32)).to(d)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        # Cost-ordered dispatch (include/grx_capi.h grx_adroit_buffers.order / .cost; see KitchenVecEnv): the step launch starts the worlds that took longest in the previous launches
+        # first.  Measured at 16 384 worlds (profiles/ab_r06_cost_order.txt): hammer 1.348 -> 1.441 M (+6.9 %), door 1.230 -> 1.326 M (+7.8 %), relocate 1.088 -> 1.203 M (+10.6 %);
+        # the pen's worlds all cost the same and the launch only loses the locality of the index order (2.30 -> 2.18 M): off there.  GRX_ADROIT_BALANCE=0 / 1 overrides (A/B, tests).
+        self.cost = self.cost_ema = self.order = None
+        self.balance_alpha = 0.3      # weight of the newest sample in the moving average (profiles/ab_r06_cost_order_lane.txt: 0.3 against 0.1: hammer +2 %, relocate +3.5 %, door -1.5 %)
+        self.balance = os.environ.get("GRX_ADROIT_BALANCE", "0" if self.task_name == "pen" else "1") != "0" and cost_order_alloc(self, n, d, self._bufs, self._bufs_masked)
         self._compact_resets = os.environ.get("GRX_ADROIT_COMPACT_RESET", "1") != "0"      # (0: the masked whole-grid forward launch of rounds 3 - 4; A/B, tests)
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
         self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode="lane" if self.task_name in ("door", "relocate") else "entry", lane_first=True) if self._h_big is not None else None     # hammer / pen: no overflow in 4 M world-steps
@@ -179,6 +185,8 @@ class AdroitVecEnv(GoalVecEnv):
                 self.step_events.append((l0, l1))
         else:
             fast(bufs)
+        if self.balance and not forward_only:
+            cost_order_update(self, self.balance_alpha)
 
     # ------------------------------------------------------------------ reset (MujocoEnv.reset [3P] -> reset_model of the task)
     def _write_edits(self, idx, shifts, targets=None):

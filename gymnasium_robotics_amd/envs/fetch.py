@@ -458,7 +458,7 @@ class FetchVecEnv(GoalVecEnv):
                         info["final_obs"] = self._obs_dict(rows=done)
                     self._launch_reset(staged, done, keep_outcome=True)
                 if self.output == "torch":
-                    fo = self.final_packed[staged[1].long()]
+                    fo = self.final_packed[staged[1]]      # (int32 device indices: one gather kernel)
                     info["final_obs"] = {"observation": fo[:, : self.obs_dim], "achieved_goal": fo[:, self.obs_dim: self.obs_dim + 3],
                                          "desired_goal": fo[:, self.obs_dim + 3: self.obs_dim + 6]}
             elif self.autoreset_mode == "next_step":

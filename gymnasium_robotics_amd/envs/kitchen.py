@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..core import KITCHEN_RERUN_CAPACITY, create_rerun_model, GoalVecEnv, OverflowLane, np_random
+from ..core import KITCHEN_RERUN_CAPACITY, cost_order_alloc, cost_order_update, create_rerun_model, GoalVecEnv, OverflowLane, np_random
 from ..mjcf import CompiledModel
 from ..spaces import Box, Dict, batch_space
 from .kitchen_spec import (INIT_QPOS, MAX_EPISODE_STEPS, OBS_DIM, OBS_ELEMENT_GOALS, OBS_ELEMENT_INDICES, TASKS, load_kitchen_model, make_kitchen_task, task_mask)
@@ -71,6 +71,11 @@ class KitchenVecEnv(GoalVecEnv):
         self.skin_radius = float(skin_radius)
         self._skin = z(n, 4 + 3 * self.model.dim("ngeom") + len(self.model.tables["devpair"]), dtype=torch.int32) if self.skin_radius > 0.0 else None
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        # Cost-ordered dispatch (include/grx_capi.h grx_kitchen_buffers.order / .cost): a kitchen world takes 2.9 ms at the median and 11.5 ms at the worst, and what it costs persists
+        # from step to step (which fixtures the arm touches); in index order the launch's slowest worlds start anywhere.  Measured at 16 384 worlds (profiles/ab_r06_cost_order.txt): step kernel 39.5 -> 38.3 ms, 0.4035 -> 0.410 M (+1.7 %: the lane's launch, 39.5 ms, is what the step waits for then); the kitchen + hammer batch of cfg 5: 0.399 -> 0.436 M (+9 %).  GRX_KITCHEN_BALANCE=0: off (A/B).
+        import os
+        self.cost = self.cost_ema = self.order = None
+        self.balance = os.environ.get("GRX_KITCHEN_BALANCE", "1") != "0" and cost_order_alloc(self, n, d, self._bufs, self._bufs_masked)
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
         # (32 polling workgroups: with the fast tables cut to 128 rows / 1 280 words / 24 contacts more worlds ENTER the lane per step; measured 16 -> 0.357 M, 32 -> 0.374 M, 48 -> 0.365 M, 96 -> 0.341 M env-steps/s)
         self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), poll_grid=32) if self._h_big is not None else None
@@ -194,6 +199,8 @@ class KitchenVecEnv(GoalVecEnv):
                 self.step_events.append((l0, l1))
         else:
             fast(bufs)
+        if self.balance and not forward_only:
+            cost_order_update(self)
 
     # ------------------------------------------------------------------ reset (kitchen_env.py:425-437 -> FrankaRobot.reset -> reset_model, franka_env.py:133-139)
     def _reset_worlds(self, idx):

@@ -224,6 +224,8 @@ typedef struct grx_adroit_buffers {
   const int64_t* compact;          /* [n_compact] device world indices or NULL: a launch of n_compact workgroups, workgroup j handles world compact[j] (the reset-time forward pass of the ~0.5 %
                                       of the worlds an env.step() resets: a masked launch over all N worlds spends 0.5 ms dispatching workgroups that return at once) */
   int n_compact;
+  const int* order;                /* [grid] or NULL: cost-ordered dispatch, see grx_kitchen_buffers.order; ignored by compact launches */
+  int* cost;                       /* [N] or NULL: measured duration of each world's step (80 ns units), written by step launches */
 } grx_adroit_buffers;
 
 /* mirrors struct GrxKitchenTask / GrxKitchenBuffers (csrc/grx_kitchen_task.h): FrankaKitchen-v1 */
@@ -249,6 +251,12 @@ typedef struct grx_kitchen_buffers {
                                        per world), or NULL: every substep sweeps the full candidate list.  Results are identical either way. */
   int skin_stride;
   float skin_radius;                /* metres by which the broad-phase radius is inflated when a world's list is built (0.1) */
+  /* COST-ORDERED DISPATCH (round 6; the Fetch family has had it since round 2: grx_fetch_buffers.order / .cost).  A launch of N worlds on S wave slots ends when the queue runs
+   * dry PLUS the longest remaining world; a kitchen world takes 2.9 ms at the median and 11.5 ms at the worst (profiles/stragglers_r06_kitchen.txt), so a launch in index order
+   * ends ~5 ms (14 %) after the slots' mean.  With `order` workgroup j steps world order[j]; every step launch writes each world's measured duration to cost[w]
+   * and grx_order_by_cost turns that into the next launch's order (longest first, per XCD slice).  Results do not depend on the order. */
+  const int* order;                 /* [grid] or NULL */
+  int* cost;                        /* [N] or NULL: 80 ns units */
   grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane and its LIMITS */
 } grx_kitchen_buffers;
 

@@ -168,6 +168,39 @@ def test_order_by_cost_and_balance_invariance():
     assert int(a.cost.min()) >= 12 * 20 and not np.array_equal(a.order.cpu().numpy(), np.arange(1024).reshape(8, 128).T.ravel())
 
 
+@pytest.mark.parametrize("env_id,var", [("FrankaKitchen-v1", "GRX_KITCHEN_BALANCE"), ("AdroitHandHammer-v2", "GRX_ADROIT_BALANCE"), ("AdroitHandRelocate-v2", "GRX_ADROIT_BALANCE")])
+def test_cost_order_of_kitchen_and_adroit_is_scheduling_only(monkeypatch, env_id, var):
+    """Round 6: the kitchen and the Adroit step launches are dispatched longest-world-first from the durations the previous launches measured (include/grx_capi.h
+    grx_kitchen_buffers.order / .cost): the order is a permutation of the worlds that changes after the first steps, every world's duration is recorded, and the rollout -- observations,
+    rewards, flags, state rows, same-step autoresets included -- is bit-identical to the launch in index order."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    n, envs = 1024, []
+    for on in ("1", "0"):
+        monkeypatch.setenv(var, on)
+        e = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=6)
+        e.reset(seed=11)
+        envs.append(e)
+    a, b = envs
+    assert a.balance and a.order is not None and not b.balance and b.order is None
+    identity = a.order.clone()
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(2)
+    act_dim = a.single_action_space.shape[0]
+    for t in range(9):
+        act = torch.rand(n, act_dim, device="cuda:0", generator=gen) * 2 - 1
+        oa, ob = a.step(act), b.step(act)
+        obs_a, obs_b = (oa[0]["observation"], ob[0]["observation"]) if isinstance(oa[0], dict) else (oa[0], ob[0])
+        assert torch.equal(obs_a, obs_b) and torch.equal(torch.as_tensor(oa[1]), torch.as_tensor(ob[1])), t
+        assert torch.equal(torch.as_tensor(oa[2]), torch.as_tensor(ob[2])) and torch.equal(torch.as_tensor(oa[3]), torch.as_tensor(ob[3])), t
+        for name in ("qpos", "qvel", "qacc_ws", "status"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (t, name)
+    torch.cuda.synchronize()
+    assert sorted(a.order.cpu().tolist()) == list(range(n)) and not torch.equal(a.order, identity)
+    assert int(a.cost.min()) > 0 and int(a.cost.max()) < 10_000_000      # 80 ns units: every world was timed, no start stamp was left behind
+
+
 def test_device_rewards_equal_the_reference_run_vectors():
     """The batched reward kernels (the HER relabelling entry points) against rewards computed by the reference's own methods
     (tests/golden/ref_host_logic.npz, tools/make_reference_host_vectors.py); fp32 device arithmetic: pairs whose distance sits on a
