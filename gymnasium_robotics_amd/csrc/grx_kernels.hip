@@ -1396,8 +1396,8 @@ grx_order_kernel(const int* __restrict__ cost, float* __restrict__ ema, float al
     int M = 0;
     if (slots > 0 && per > slots && per <= 2 * slots) {
       const unsigned long long thr = 2ull * (keys[per - 1] >> 32);
-      int K = 0;
-      while (K < per && (keys[K] >> 32) > thr) K++;
+      int K = 0, hi = per;      // the list is sorted (descending): K = the first position whose key is <= thr, by bisection (a linear walk costs 25 us when half the slice is above it)
+      while (K < hi) { const int mid = (K + hi) >> 1; if ((keys[mid] >> 32) > thr) K = mid + 1; else hi = mid; }
       M = per - 2 * slots + K;
       if (M < 0 || 3 * M > per - slots || M > slots / 4) M = 0;
     }
