@@ -475,6 +475,9 @@ def pmc_summary(kind, workload, n, worlds, live_build, root=None):
                 return None, f"{rel}: measured at {worlds} worlds, this run has {n}"
             if d.get("build_id") != live_build:
                 return None, f"STALE, not attached: {rel} was measured on build {d.get('build_id') or '(unstamped, before round 6)'}, the loaded libgrx_hip.so is {live_build}"
+            need = {"hbm_traffic": "traffic_bytes_per_launch", "sq_mix": "SQ_INSTS_VALU"}.get(kind)
+            if need and need not in d:      # a collector pass that found no launch of the step kernel writes a summary without the figure: say so, never fail the bench line over it
+                return None, f"INCOMPLETE, not attached: {rel} holds no {need} (the counter pass collected no sample)"
             return d, rel
     return None, None
 

@@ -131,6 +131,7 @@ def lib():
         L.grx_point_step.argtypes = [vp, vp, vp, ci, vp]
         L.grx_maze_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_double, ci, vp, vp]
         L.grx_hand_step.argtypes = [vp, vp, vp, ci, ci, vp]
+        L.grx_hand_step_repeat.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_adroit_step.argtypes = [vp, vp, vp, ci, ci, vp]
         L.grx_goal_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ctypes.c_double, ci, vp, vp]
         L.grx_manip_compute_reward.argtypes = [vp, vp, ctypes.c_int64, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]
@@ -179,7 +180,7 @@ def check(rc: int):
 
 EXPORTED_SYMBOLS = [
     "grx_model_create", "grx_model_destroy", "grx_model_set_table", "grx_model_lds_bytes", "grx_model_dim",
-    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_fetch_sample_resets_device", "grx_adroit_sample_resets_device", "grx_maze_sample_resets_device", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_uniform_rows_device", "grx_kitchen_bookkeeping", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_fetch_commit_rows", "grx_adroit_commit_rows", "grx_last_error",
+    "grx_fetch_step", "grx_fetch_forward", "grx_fetch_reset", "grx_fetch_compute_reward", "grx_her_relabel", "grx_her_sample", "grx_her_sample_final", "grx_her_mark_resets", "grx_fetch_sample_resets", "grx_fetch_sample_resets_device", "grx_adroit_sample_resets_device", "grx_maze_sample_resets_device", "grx_point_step", "grx_maze_compute_reward", "grx_hand_step", "grx_hand_step_repeat", "grx_adroit_step", "grx_kitchen_step", "grx_sample_uniform_rows", "grx_uniform_rows_device", "grx_kitchen_bookkeeping", "grx_goal_compute_reward", "grx_manip_compute_reward", "grx_order_by_cost", "grx_order_by_cost_slots", "grx_maze_reset_rows", "grx_hand_commit_rows", "grx_fetch_commit_rows", "grx_adroit_commit_rows", "grx_last_error",
 ]
 
 

@@ -539,7 +539,7 @@ template <class S>
 __device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask& t, const GrxHandBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) { if (in_lane) grx_lane_ticket(b.lane, -1, w, lane_); return; }
-  if (!in_lane && !forward_only && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel (reset-time forward passes cover every masked world)
+  if (!in_lane && forward_only != 1 && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel (reset-time forward passes cover every masked world)
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -550,15 +550,22 @@ __device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask
   if (lane_ == 0) { for (int k = 0; k < GRX_NPROF; k++) prof_s[k] = 0; prof_s[GRX_NPROF] = clock64(); }
 #endif
   const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv, nu = S::kFixed ? S::NU : m.nu;
+  // REPEAT launches (grx_hand_step_repeat: forward_only carries the count, >= 2): that many consecutive env.step()s of the same action rows without leaving the kernel -- each one
+  // the whole body below, state rows written and read back exactly as between two launches (bit-identical to them), so a reset's ten settle steps (manipulate.py:205-224) are
+  // one launch: one wait for a wave slot, one tail, instead of ten of each beside a step kernel that fills the chip
+  const int nrep = forward_only > 1 ? forward_only : 1;
+  forward_only = forward_only == 1;
   grx_lane_setup(b.lane, c, w, !forward_only);
+  const int od = grx_hand_obs_dim(&t, nq, nv, m.ntouch), gd = grx_hand_goal_dim(&t);
+  float* obs = b.obs + (size_t)w * od; float* ach = b.achieved + (size_t)w * gd; float* palm = b.palm + (size_t)w * 3;
+  for (int rep = 0; rep < nrep; rep++) {
+  if (rep > 0) { __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }   // the rows this wave wrote in the previous repetition are read back below
   if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp, parked in the cost slot (see grx_fetch_step_kernel)
   for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
   __syncthreads();
   for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
   for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
   __syncthreads();
-  const int od = grx_hand_obs_dim(&t, nq, nv, m.ntouch), gd = grx_hand_goal_dim(&t);
-  float* obs = b.obs + (size_t)w * od; float* ach = b.achieved + (size_t)w * gd; float* palm = b.palm + (size_t)w * 3;
   if (forward_only) {
     GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
     GrxHand<S>::grx_hand_outputs(&m, &t, &c, obs, ach, palm, lane_);
@@ -594,6 +601,7 @@ __device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask
     for (int i = lane_; i < gd; i += 64) { row[od + i] = ach[i]; row[od + gd + i] = b.goal[(size_t)w * gd + i]; }
     if (lane_ == 0) { row[od + 2 * gd] = b.reward[w]; row[od + 2 * gd + 1] = b.success[w] ? 1.0f : 0.0f; }
   }
+  }   // repetitions
 #ifdef GRX_PROFILE
   GRX_TICK(&c, GRX_P_OTHER);
   if (lane_ == 0) for (int k = 0; k < GRX_NPROF; k++) atomicAdd((unsigned long long*)&g_grx_prof[k], (unsigned long long)c.prof[k]);
@@ -1287,6 +1295,14 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
   const int e = grx_tu_hand_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_hand_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
+}
+
+extern "C" int grx_hand_step_repeat(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int repeat, void* stream) {
+  if (!buf) return fail("grx_hand_step_repeat: null argument");
+  if (repeat < 1 || repeat > 1024) return fail("grx_hand_step_repeat: repeat must be in 1 .. 1024");
+  if (buf->lane.list || buf->lane.skip || buf->lane.entry_list || buf->lane.next_list) return fail("grx_hand_step_repeat: not for launches with an overflow lane (a world that exceeds a table drops the contact and flags it, as in any launch without a lane)");
+  if (!buf->action) return fail("grx_hand_step_repeat: null action buffer");
+  return grx_hand_step(m, task, buf, n_worlds, repeat == 1 ? 0 : repeat, stream);
 }
 
 extern "C" int grx_adroit_step(const grx_model* m, const grx_adroit_task* task, const grx_adroit_buffers* buf, int n_worlds, int forward_only, void* stream) {

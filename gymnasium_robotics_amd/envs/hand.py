@@ -411,6 +411,8 @@ class HandBlockVecEnv(HandReachVecEnv):
     chain_events = None      # set to [] to collect (step started, step due, worlds, start event, end event) of every settle chain
     CHAIN_LOOKAHEAD = int(os.environ.get("GRX_CHAIN_LOOKAHEAD", 2))      # steps before the time limit at which a world's settle chain is started (same-step autoreset); 3 measured no faster (below)
 
+    _fused_settle = os.environ.get("GRX_HAND_FUSED_SETTLE", "1") != "0"      # a chain's ten settle steps as ONE repeat launch (include/grx_capi.h grx_hand_step_repeat); 0: ten launches (A/B)
+
     GOAL_DIM = 7
 
     def __init__(self, env_id: str = "HandManipulateBlockRotateXYZ-v1", num_envs: int = 1, max_episode_steps: Optional[int] = 100,
@@ -538,7 +540,7 @@ class HandBlockVecEnv(HandReachVecEnv):
             self._ar, self._ar_head, self._chains, self._step_no = ar, 0, [], 0
             self._chain_started = np.zeros(self.num_envs, bool)
             self._chain_obj = [torch.empty(self.num_envs, 7, dtype=torch.float32, pin_memory=True) for _ in range(self.CHAIN_LOOKAHEAD + 2)]      # settled object poses of the chains in flight (one buffer per due step)
-            self._side = [torch.cuda.Stream(device=d, priority=-1) for _ in range(3)]   # one per chain generation in flight; priority makes no measurable difference (A/B: 17.96 vs 18.07 ms per step)
+            self._side = [torch.cuda.Stream(device=d, priority=int(os.environ.get("GRX_CHAIN_PRIO", "-1"))) for _ in range(int(os.environ.get("GRX_CHAIN_STREAMS", "3")))]   # one per chain generation in flight; priority makes no measurable difference (A/B: 17.96 vs 18.07 ms per step)
         return self._ar
 
     def _arena_bufs(self, lo):
@@ -579,7 +581,7 @@ class HandBlockVecEnv(HandReachVecEnv):
                                                self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"])
         q = self._initial_qpos_host.unsqueeze(0).repeat(k, 1)
         q[:, self._qa: self._qa + 7] = torch.from_numpy(self._obj_rows(poses))
-        side = self._side[c["due_at"] % 3]
+        side = self._side[c["due_at"] % len(self._side)]
         with torch.cuda.stream(side):
             side.wait_event(c["ready"])
             if self.chain_events is not None:      # (diagnostics: device time of a settle chain, tools/host_profile_hand.py)
@@ -588,8 +590,13 @@ class HandBlockVecEnv(HandReachVecEnv):
             ar["qpos"][lo: lo + k] = tq[:, : self.nq]
             ar["qvel"][lo: lo + k].zero_()
             bufs, sp = self._arena_bufs(lo), ctypes.c_void_p(side.cuda_stream)
-            for _ in range(SETTLE_STEPS):   # the arena's action rows stay zero: _set_action(np.zeros(20)) (manipulate.py:206-216)
-                _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), k, 0, sp))
+            # the arena's action rows stay zero: _set_action(np.zeros(20)) (manipulate.py:206-216).  ONE repeat launch (include/grx_capi.h grx_hand_step_repeat: bit-identical to the ten
+            # launches, which beside the step kernel each wait for wave slots and end with their slowest world); GRX_HAND_FUSED_SETTLE=0: the ten launches (A/B)
+            if self._fused_settle:
+                _native.check(self._L.grx_hand_step_repeat(self._h, ctypes.byref(self.task), ctypes.byref(bufs), k, SETTLE_STEPS, sp))
+            else:
+                for _ in range(SETTLE_STEPS):
+                    _native.check(self._L.grx_hand_step(self._h, ctypes.byref(self.task), ctypes.byref(bufs), k, 0, sp))
             # the settled object poses travel to a pinned host buffer behind the last settle launch: when the goals are drawn they are already there (round 4 read them with a
             # blocking .cpu() at that point: a one-block kernel and a copy that had to find a slot on a GPU saturated by the step kernel)
             c["obj_host"] = self._chain_obj[c["due_at"] % len(self._chain_obj)]
@@ -604,7 +611,7 @@ class HandBlockVecEnv(HandReachVecEnv):
         draw the goals of the worlds whose object stayed on the palm and park them in the arena -- all while the step kernel runs"""
         from .manipulate_spec import PALM_HEIGHT, sample_block_goal_batch
 
-        lo, k, ar, side = c["lo"], c["k"], self._ar, self._side[c["due_at"] % 3]
+        lo, k, ar, side = c["lo"], c["k"], self._ar, self._side[c["due_at"] % len(self._side)]
         with torch.cuda.stream(side):
             c["event"].synchronize()      # (started CHAIN_LOOKAHEAD steps ago: normally long done)
             obj = self._obj_world(c["obj_host"][:k].numpy())      # the fp32 rows the kernel wrote, widened on the host (what .double() did on the device), in the MJCF's frame

@@ -307,6 +307,12 @@ int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t
  * envs/shadow_dexterous_hand/hand_env.py:36-58, reach.py:92-134,398-428).  forward_only != 0: mj_forward + outputs (reset path,
  * robot_env.py:300-313, and _env_setup, reach.py:408-416).  grx_goal_compute_reward: batched compute_reward for dim-vector goals. */
 int grx_hand_step(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int forward_only, void* stream);
+/* `repeat` consecutive env.step()s of the same action rows in ONE launch -- the loop of MujocoManipulateEnv._reset_sim, `for _ in range(10): self._set_action(np.zeros(20));
+ * mj_step(nstep=n_substeps)` (envs/shadow_dexterous_hand/manipulate.py:205-224), for the worlds of `buf`.  Each repetition is the whole step of grx_hand_step, its state rows written
+ * and read back as between two launches: results are bit-identical to `repeat` calls of grx_hand_step (tests/test_gpu_manipulate.py::test_repeat_launch_is_the_sequence_of_launches),
+ * outputs are the last repetition's, status flags accumulate in the sticky half.  Why: beside a step kernel that fills the chip every launch of a reset's 164 worlds waits for wave
+ * slots and ends with its slowest world; ten dependent launches took 22 - 34 ms, more than the two env.step()s the overlapped reset has (round 6).  Not for launches with an overflow lane. */
+int grx_hand_step_repeat(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int repeat, void* stream);
 /* AdroitHand{Hammer,Door,Pen,Relocate}Env.step for N worlds: clip + a = act_mean + a * act_rng + do_simulation(a, 5) (= mj_step x 5 with the
  * noslip post-solver, adroit_assets.xml:3) + _get_obs + reward + success (envs/adroit_hand/adroit_hammer.py:291-357, adroit_door.py:281-347,
  * adroit_pen.py:288-365, adroit_relocate.py:290-338); forward_only != 0: the reset path (set_state -> mj_forward, _get_obs) */

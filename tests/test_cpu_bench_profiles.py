@@ -43,3 +43,23 @@ def test_the_committed_summaries_carry_a_build_id():
     for n in names:
         with open(os.path.join(root, n)) as f:
             assert json.load(f).get("build_id"), n
+
+
+def test_a_summary_without_its_figure_is_refused_not_fatal(tmp_path):
+    """a counter pass that matched no launch of the step kernel (round 6: the split step's grid is 2 x the worlds, the collector filtered it out) writes a summary without
+    `traffic_bytes_per_launch`: the bench line must say so and carry `traffic: null`, not die on a KeyError"""
+    tag = bench.PROFILE_TAGS[0]
+    _write(tmp_path, f"pmc_{tag}_hbm_traffic.json", {"build_id": "aaaa", "algorithmic_bytes_per_launch": 1})
+    _write(tmp_path, f"pmc_{tag}_sq_mix.json", {"build_id": "aaaa", "kernel": "k"})
+    for kind in ("hbm_traffic", "sq_mix"):
+        d, src = bench.pmc_summary(kind, "fetch", 4096, 4096, "aaaa", root=str(tmp_path))
+        assert d is None and src.startswith("INCOMPLETE")
+
+
+def test_the_collector_counts_split_step_launches_as_whole_batch_launches():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import collect_profiles as cp
+
+    full = 4096 * 64
+    assert cp._whole_batch(full, full) and cp._whole_batch(2 * full, full) and cp._whole_batch(8 * full, full)
+    assert not cp._whole_batch(82 * 64, full) and not cp._whole_batch(9 * full, full) and not cp._whole_batch(full + 64, full) and not cp._whole_batch(0, full)

@@ -243,3 +243,50 @@ def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):
         for e, o in zip(envs, (o0, o1)):      # the observation row belongs to the state row it is returned with (a discarded fast-kernel run must not leave its row behind)
             assert torch.equal(o[:, :24], e.qpos[:, :24]) and torch.equal(o[:, 24:48], e.qvel[:, :24]), t
     assert entered >= 1, entered
+
+
+@pytest.mark.parametrize("env_id", ["HandManipulateBlockRotateXYZ-v1", "HandManipulateEggRotate_ContinuousTouchSensors-v1", "HandManipulatePenRotate-v1"])
+def test_repeat_launch_is_the_sequence_of_launches(env_id):
+    """Round 6: grx_hand_step_repeat -- the ten settle steps of MujocoManipulateEnv._reset_sim (/root/reference/gymnasium_robotics/envs/shadow_dexterous_hand/manipulate.py:205-224:
+    `for _ in range(10): self._set_action(np.zeros(20)); mj_step`) as ONE launch -- against ten launches of grx_hand_step on the same rows: state rows, observations (touch
+    words included), achieved goals, rewards, success flags, status words and packed rows are BIT-IDENTICAL, from freshly reset worlds (object dropping onto the palm: contacts
+    switching on) and from worlds mid-rollout; a repeat of 1 is the plain step; launches with an overflow lane are refused."""
+    import ctypes
+
+    import torch
+
+    import gymnasium_robotics_amd as grx
+    from gymnasium_robotics_amd import _native
+
+    n, L = 96, _native.lib()
+    envs = [grx.make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="disabled", max_episode_steps=None) for _ in range(2)]
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(4)
+    names = ("qpos", "qvel", "qacc_ws", "obs", "achieved", "palm", "reward", "success", "status", "packed")
+    for e in envs:
+        e.reset(seed=21)
+    seq, rep = envs
+    for phase, repeat in (("after reset", 10), ("mid rollout", 10), ("single", 1)):
+        if phase == "mid rollout":
+            for t in range(4):
+                a = torch.rand(n, 20, device="cuda:0", generator=gen) * 2 - 1
+                for e in envs:
+                    e.step(a)
+            for name in names:
+                assert torch.equal(getattr(seq, name), getattr(rep, name)), (phase, "rollout", name)
+        act = torch.zeros(n, 20, device="cuda:0") if phase != "single" else torch.rand(n, 20, device="cuda:0", generator=gen) * 2 - 1
+        for e in envs:
+            e.action.copy_(act)
+        sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(repeat):
+            _native.check(L.grx_hand_step(seq._h, ctypes.byref(seq.task), ctypes.byref(seq._bufs), n, 0, sp))
+        _native.check(L.grx_hand_step_repeat(rep._h, ctypes.byref(rep.task), ctypes.byref(rep._bufs), n, repeat, sp))
+        torch.cuda.synchronize()
+        for name in names:
+            assert torch.equal(getattr(seq, name), getattr(rep, name)), (phase, name, int((getattr(seq, name) != getattr(rep, name)).sum()))
+        assert torch.isfinite(rep.qpos).all() and int((rep.status & 1).max()) == 0
+    b = rep._make_bufs(None)
+    b.lane.skip = rep.mask.data_ptr()
+    with pytest.raises(RuntimeError, match="overflow lane"):
+        _native.check(L.grx_hand_step_repeat(rep._h, ctypes.byref(rep.task), ctypes.byref(b), n, 10, None))
+    with pytest.raises(RuntimeError, match="repeat must be"):
+        _native.check(L.grx_hand_step_repeat(rep._h, ctypes.byref(rep.task), ctypes.byref(rep._bufs), n, 0, None))

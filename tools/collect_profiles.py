@@ -42,6 +42,11 @@ def _git_head():
         return None
 
 
+def _whole_batch(grid_threads, full_grid):
+    """a launch over ALL worlds: one workgroup per world, or (the Fetch split step, include/grx_capi.h grx_fetch_buffers.split_parts) 2 - 8 workgroups per world"""
+    return grid_threads > 0 and grid_threads % full_grid == 0 and grid_threads // full_grid <= 8
+
+
 def run(cmd, log):
     env = dict(os.environ, TMPDIR="/tmp")
     with open(log, "w") as f:
@@ -92,7 +97,7 @@ def pmc(tag, workload=None):
             with open(path) as f:
                 for row in csv.DictReader(f):
                     if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == cnt:
-                        if int(float(row.get("Grid_Size") or 0)) != full_grid:      # a compacted side launch (settle chain, compacted reset): not a step of the whole batch
+                        if not _whole_batch(int(float(row.get("Grid_Size") or 0)), full_grid):      # a compacted side launch (settle chain, compacted reset): not a step of the whole batch
                             dropped += 1
                             continue
                         vals.append(float(row["Counter_Value"]))
@@ -149,7 +154,7 @@ def sq_mix(tag, workload=None):
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if kernel in row.get("Kernel_Name", "") and int(float(row.get("Grid_Size") or 0)) == full_grid:
+                if kernel in row.get("Kernel_Name", "") and _whole_batch(int(float(row.get("Grid_Size") or 0)), full_grid):
                     acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     lines = [f"rocprofv3 --pmc {' '.join(SQ_COUNTERS)} --kernel-trace --output-format csv -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline {' '.join(extra)}  (MI355X, build '{tag}')",
              f"means over the last 12 full-grid STEP launches of {kernel} (the timed region; masked full-grid forward passes of resets are recognised by their wave cycles and left out):"]
