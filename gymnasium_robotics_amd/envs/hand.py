@@ -538,9 +538,12 @@ class HandBlockVecEnv(HandReachVecEnv):
             ar = {k: z(n, getattr(self, k).shape[1]) for k in ("qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "packed")}
             ar.update(reward=z(n), success=z(n, dtype=torch.uint8), status=z(n, dtype=torch.int32))
             self._ar, self._ar_head, self._chains, self._step_no = ar, 0, [], 0
+            self._chain_pin, self._chain_pin_ref, self._chain_ms = None, 0.0, {}
+            self._chain_pin_enabled = os.environ.get("GRX_CHAIN_PIN", "0") != "0"      # opt-in: see _pin_chain_stream
             self._chain_started = np.zeros(self.num_envs, bool)
             self._chain_obj = [torch.empty(self.num_envs, 7, dtype=torch.float32, pin_memory=True) for _ in range(self.CHAIN_LOOKAHEAD + 2)]      # settled object poses of the chains in flight (one buffer per due step)
-            self._side = [torch.cuda.Stream(device=d, priority=int(os.environ.get("GRX_CHAIN_PRIO", "-1"))) for _ in range(int(os.environ.get("GRX_CHAIN_STREAMS", "3")))]   # one per chain generation in flight; priority makes no measurable difference (A/B: 17.96 vs 18.07 ms per step)
+            self._side = [torch.cuda.Stream(device=d, priority=int(os.environ.get("GRX_CHAIN_PRIO", "-1"))) for _ in range(int(os.environ.get("GRX_CHAIN_STREAMS", "3")))]   # one per chain generation in flight (round 6: until one of them is found to be the fast one, _pin_chain_stream)
+            self._goal_side = torch.cuda.Stream(device=d)      # the goal rows of finished chains (_early_goals)
         return self._ar
 
     def _arena_bufs(self, lo):
@@ -581,11 +584,15 @@ class HandBlockVecEnv(HandReachVecEnv):
                                                self._pquats, randomize_initial_rotation=self._objcfg["randomize_initial_rotation"])
         q = self._initial_qpos_host.unsqueeze(0).repeat(k, 1)
         q[:, self._qa: self._qa + 7] = torch.from_numpy(self._obj_rows(poses))
-        side = self._side[c["due_at"] % len(self._side)]
+        # Which side stream: round-robin -- until the measured chain times say that ONE of the streams gets wave slots beside the step kernel and the others do not
+        # (profiles/chain_probe_r06.txt: of K high-priority streams exactly one runs a chain in 17 ms, the others in 30 ms = behind the step launch's dispatch, whatever the
+        # lane's priority or the number of hardware queues); then every chain goes to that stream (_pin_chain_stream).  A chain is a single launch of ~17 ms and one is started
+        # per step, so they follow each other on one stream; the goal rows go through another stream (_early_goals), never behind the next chain's kernel.
+        c["stream_idx"] = self._chain_pin if self._chain_pin is not None else c["due_at"] % len(self._side)
+        side = self._side[c["stream_idx"]]
         with torch.cuda.stream(side):
             side.wait_event(c["ready"])
-            if self.chain_events is not None:      # (diagnostics: device time of a settle chain, tools/host_profile_hand.py)
-                e0 = torch.cuda.Event(enable_timing=True); e0.record(side)
+            e0 = c["t0"] = torch.cuda.Event(enable_timing=True); e0.record(side)
             _, tq = self._chain_stage(np.arange(k), q.numpy())      # pinned staging: enqueued on the side stream, never waited for
             ar["qpos"][lo: lo + k] = tq[:, : self.nq]
             ar["qvel"][lo: lo + k].zero_()
@@ -601,7 +608,7 @@ class HandBlockVecEnv(HandReachVecEnv):
             # blocking .cpu() at that point: a one-block kernel and a copy that had to find a slot on a GPU saturated by the step kernel)
             c["obj_host"] = self._chain_obj[c["due_at"] % len(self._chain_obj)]
             c["obj_host"][:k].copy_(ar["qpos"][lo: lo + k, self._qa: self._qa + 7], non_blocking=True)
-            c["event"] = torch.cuda.Event(enable_timing=self.chain_events is not None)
+            c["event"] = torch.cuda.Event(enable_timing=True)
             c["event"].record(side)
             if self.chain_events is not None:
                 self.chain_events.append((self._step_no, c["due_at"], k, e0, c["event"]))
@@ -611,9 +618,10 @@ class HandBlockVecEnv(HandReachVecEnv):
         draw the goals of the worlds whose object stayed on the palm and park them in the arena -- all while the step kernel runs"""
         from .manipulate_spec import PALM_HEIGHT, sample_block_goal_batch
 
-        lo, k, ar, side = c["lo"], c["k"], self._ar, self._side[c["due_at"] % len(self._side)]
+        lo, k, ar, side = c["lo"], c["k"], self._ar, self._goal_side
         with torch.cuda.stream(side):
             c["event"].synchronize()      # (started CHAIN_LOOKAHEAD steps ago: normally long done)
+            self._pin_chain_stream(c)
             obj = self._obj_world(c["obj_host"][:k].numpy())      # the fp32 rows the kernel wrote, widened on the host (what .double() did on the device), in the MJCF's frame
             ok = obj[:, 2] > PALM_HEIGHT
             if ok.any():
@@ -623,6 +631,26 @@ class HandBlockVecEnv(HandReachVecEnv):
             c["ok"] = ok
             c["event"] = torch.cuda.Event()
             c["event"].record(side)
+
+    def _pin_chain_stream(self, c):
+        """measured device time of a finished chain -> which side stream the next chains use (see _start_chain).  Pinned when one stream's chains take less than 3/4 of every
+        other stream's (medians of the last samples); released when the pinned stream stops being that fast.  OPT-IN (GRX_CHAIN_PIN=1): with the goal rows on their own stream
+        (_goal_side, which alone measured +1.5 %) no stream was the fast one any more in the A/B (profiles/ab_r06_hand_chain_pin.txt: every chain 29 - 30 ms, pinned = round-robin),
+        so the pinned state never occurred there."""
+        if not self._chain_pin_enabled or c.get("t0") is None or len(self._side) < 2:
+            return
+        ms = c["t0"].elapsed_time(c["event"])
+        hist = self._chain_ms.setdefault(c["stream_idx"], [])
+        hist.append(ms)
+        del hist[:-4]
+        med = {i: sorted(h)[len(h) // 2] for i, h in self._chain_ms.items() if len(h) >= 2}
+        if self._chain_pin is None:
+            if len(med) == len(self._side):
+                best = min(med, key=med.get)
+                if all(med[best] < 0.75 * v for i, v in med.items() if i != best):
+                    self._chain_pin, self._chain_pin_ref = best, min(v for i, v in med.items() if i != best)
+        elif c["stream_idx"] == self._chain_pin and len(hist) >= 2 and med[self._chain_pin] > 0.9 * self._chain_pin_ref:
+            self._chain_pin, self._chain_ms = None, {}      # no longer the fast one: measure again
 
     def _begin_overlapped_reset(self):
         if self.max_episode_steps is None:
