@@ -36,7 +36,8 @@ class PointTaskStruct(ctypes.Structure):
 
 class PointBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask", "packed")]
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "reward", "success", "terminated", "status", "mask", "packed", "split_state")] + [
+        ("split_parts", ctypes.c_int), ("split_pad_", ctypes.c_int)]
 
 
 class AdroitTaskStruct(ctypes.Structure):

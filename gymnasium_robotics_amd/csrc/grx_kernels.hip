@@ -484,9 +484,29 @@ template <class S>
 __global__ void __launch_bounds__(64, S::kFixed ? 3 : 2)
 grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
-  const int w = grx_world_of_block(), lane_ = threadIdx.x;
+  const int lane_ = threadIdx.x;
+  // SPLIT STEP (include/grx_capi.h grx_point_buffers.split_parts; the Fetch family's: grx_fetch_buffers.split_parts): P workgroups per world, workgroup part * G + slot running the
+  // substeps [part T / P, (part + 1) T / P) of the slot's world.  The carrier is the world's own state row: at a substep boundary qpos / qvel / warm start are the whole state.
+  const int parts = b.split_parts > 1 ? b.split_parts : 1;
+  const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot, slot + G, ... share blockIdx.x mod 8: one XCD (one L2) for all parts of a world
+  const int w = (int)((slot & 7u) * (G >> 3) + (slot >> 3));
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) return;
+  const bool split = parts > 1, last_part = (int)part == parts - 1;
+  if (split && part > 0) {   // wait for the part before this one (dispatched earlier on the same XCD: running or done)
+    volatile int* st = b.split_state + 2 * (size_t)w;
+    int v = 0;
+    for (int spins = 0; spins < GRX_SPLIT_SPIN_LIMIT; spins++) {
+      v = __builtin_amdgcn_readfirstlane(st[0]);
+      if (v == (int)part) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (v != (int)part) {   // the earlier part never came: flagged; the last part leaves the words clean
+      if (lane_ == 0) { b.status[w] |= GRX_ST_BADNUM | (GRX_ST_BADNUM << 16); if (last_part) { st[0] = 0; st[1] = 0; } }
+      return;
+    }
+    __threadfence();
+  }
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -498,11 +518,36 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
 #endif
   for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
   __syncthreads();
+  if (split && part > 0) {   // rows the part before this one wrote on another CU during this launch: cache-bypassing loads, ordered behind its flag by the fence above
+    volatile const float *vq = b.qpos + (size_t)w * m.nq, *vv = b.qvel + (size_t)w * m.nv, *va = b.qacc_ws + (size_t)w * m.nv;
+    for (int i = lane_; i < m.nq; i += 64) c.qpos[i] = vq[i];
+    for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = vv[i]; c.qacc_ws[i] = va[i]; }
+  } else {
   for (int i = lane_; i < m.nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * m.nq + i];
   for (int i = lane_; i < m.nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * m.nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * m.nv + i]; }
+  }
   __syncthreads();
-  GrxPoint<S>::grx_point_sim_world(&m, &t, &c, b.action + (size_t)w * m.nu, lane_);
-  const int wl = grx_world_of_block_late();
+  const int s0 = split ? ((int)part * t.n_substeps) / parts : 0, s1 = split ? (((int)part + 1) * t.n_substeps) / parts : t.n_substeps;
+  GrxPoint<S>::grx_point_sim_world(&m, &t, &c, b.action + (size_t)w * m.nu, lane_, s0, s1);
+  unsigned bx_ = blockIdx.x; asm volatile("" : "+s"(bx_));   // (re-derived, not kept live across the simulation)
+  const unsigned Gl = gridDim.x / (unsigned)parts, sl = bx_ % Gl;
+  const int wl = (int)((sl & 7u) * (Gl >> 3) + (sl >> 3));
+  if (split && !last_part) {   // an earlier part: the state row IS the carrier; the flags of its substeps travel in the world's second word
+    __syncthreads();
+    for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)wl * m.nq + i] = c.qpos[i];
+    for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)wl * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)wl * m.nv + i] = c.qacc_ws[i]; }
+    __threadfence();
+    __syncthreads();
+    if (lane_ == 0) {
+      volatile int* st = b.split_state + 2 * (size_t)wl;
+      st[1] = (part > 0 ? st[1] : 0) | c.cnt[2];
+      __threadfence();
+      st[0] = (int)part + 1;
+    }
+    return;
+  }
+  if (split && lane_ == 0) { volatile int* st = b.split_state + 2 * (size_t)wl; c.cnt[2] |= st[1]; st[0] = 0; st[1] = 0; }   // the flags of the earlier parts; the words are clean for the next launch
+  if (split) __syncthreads();
   float* obs = b.obs + (size_t)wl * (m.nq + m.nv - (t.agent ? 2 : 0)); float* ach = b.achieved + (size_t)wl * 2;
   GrxPoint<S>::grx_point_outputs(&m, &t, &c, obs, ach, lane_);
   __syncthreads();
@@ -1271,7 +1316,11 @@ extern "C" int grx_point_step(const grx_model* m, const grx_point_task* task, co
   if (n_worlds <= 0) return 0;
   GrxPointTask t; memcpy(&t, task, sizeof(t));
   GrxPointBuffers b; memcpy(&b, buf, sizeof(b));
-  const int e = grx_tu_point_launch(m->shape, grx_grid_for(n_worlds), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words);
+  if (b.split_parts > 1) {
+    if (!b.split_state) return fail("grx_point_step: a split step needs split_state [N, 2]");
+    if (b.split_parts > t.n_substeps || b.split_parts > 8) return fail("grx_point_step: split_parts <= min(frame_skip, 8): a part runs whole substeps");
+  } else b.split_parts = 0;
+  const int e = grx_tu_point_launch(m->shape, (b.split_parts > 1 ? (unsigned)b.split_parts : 1u) * grx_grid_for(n_worlds), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words);
   if (e) return fail(std::string("grx_point_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }

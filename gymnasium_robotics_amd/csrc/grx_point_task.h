@@ -28,6 +28,8 @@ struct GrxPointBuffers {
   int* status;                   // [N]
   const unsigned char* mask;     // [N] or null
   float* packed;                 // [N, obs_dim + 2 + 2 + 2] or null: out, the row [obs | achieved | desired | reward | success]
+  int* split_state;              // [N, 2] or null: split step (include/grx_capi.h): [2 w] = parts of world w done in this launch, [2 w + 1] = their status flags
+  int split_parts, split_pad_;   // >= 2: the launch has split_parts workgroups per world, each running its share of the substeps
 };
 
 GRX_DEV double grx_goal_distance2(const float* a, const float* b) {
@@ -45,18 +47,20 @@ struct GrxPoint {
     grx_point_outputs(m, t, c, obs, achieved, lane_);
   }
   // simulation and observation parts: the step kernel derives the output addresses between the two (nothing global live across the substeps)
-  GRX_MEM void grx_point_sim_world(const GrxModel* m, const GrxPointTask* t, GrxCtx* c, const float* action, int lane_) {
+  // s0 / s1: the substeps [s0, s1) of the step (a part of a split step, include/grx_capi.h grx_point_buffers.split_parts); default: all of them
+  GRX_MEM void grx_point_sim_world(const GrxModel* m, const GrxPointTask* t, GrxCtx* c, const float* action, int lane_, int s0 = 0, int s1 = -1) {
     const int ant = t->agent;
+    if (s1 < 0) s1 = t->n_substeps;
     FOR_LANES {
-      // point: np.clip(action, -1, 1) and the velocity clip of point.py:57,73-77; ant: ctrl = action (ctrlrange is applied by the actuator model)
+      // point: np.clip(action, -1, 1) and the velocity clip of point.py:57,73-77 (once per step: before its first substep); ant: ctrl = action (ctrlrange is applied by the actuator model)
       for (int i = lane; i < GRX_NUC; i += 64) c->ctrl[i] = ant ? action[i] : fminf(1.0f, fmaxf(-1.0f, action[i]));
-      if (!ant) for (int i = lane; i < GRX_NVC; i += 64) c->qvel[i] = fminf(t->vel_clip, fmaxf(-t->vel_clip, c->qvel[i]));
+      if (!ant && s0 == 0) for (int i = lane; i < GRX_NVC; i += 64) c->qvel[i] = fminf(t->vel_clip, fmaxf(-t->vel_clip, c->qvel[i]));
     }
     WAVE_SYNC();
     // Euler models: one forward+integrate per substep.  RK4 models: four forward passes per substep.  One loop, one call site.
     const int rk4 = (m->integrator == 1);
-    const int total = rk4 ? 4 * t->n_substeps : t->n_substeps;
-    for (int it = 0; it < total; it++) {
+    const int total = rk4 ? 4 * s1 : s1;
+    for (int it = rk4 ? 4 * s0 : s0; it < total; it++) {
       const int stage = it & 3;
       if (!rk4 || stage == 0) E::grx_check_state(m, c, lane_);
       E::grx_forward_euler(m, c, !rk4, lane_);

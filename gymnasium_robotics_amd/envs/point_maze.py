@@ -49,6 +49,9 @@ def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: O
     return model.with_capacity(**{k: ANT_CAPACITY[k] for k in ("maxcon", "maxefc", "jpool")}) if agent == "ant" else model
 
 
+MAZE_SPLIT_PARTS = 2      # default of GRX_MAZE_SPLIT for batches of more than one round of worlds (see PointMazeVecEnv.__init__; profiles/ab_r06_maze_split.txt: AntMaze_Large @8 192: 2 parts 3.81 -> 3.95 M (+3.6 %), 3 parts +1 %, 5 parts -17 %: every part re-enters the kernel)
+
+
 class PointMazeVecEnv(GoalVecEnv):
     AGENT, N_SUBSTEPS, OBS_SKIP, DEFAULT_MAX_EPISODE_STEPS = "point", 1, 0, 300
     MAZE_GEOMETRY = (POINT_MAZE_SIZE_SCALING, POINT_MAZE_HEIGHT)
@@ -94,6 +97,15 @@ class PointMazeVecEnv(GoalVecEnv):
         self.status, self.mask = z(n, dtype=torch.int32), torch.ones(n, dtype=torch.uint8, device=d)
         self.packed = z(n, self.obs_dim + 6)   # [obs | achieved | desired | reward | success] rows written by the step kernel (cross-rank gather)
         self._bufs, self._bufs_masked = self._make_bufs(None), self._make_bufs(self.mask)
+        # SPLIT STEP (include/grx_capi.h grx_point_buffers.split_parts): P workgroups per world, each running its share of the frame_skip substeps -- a launch whose worlds do not fill a
+        # whole number of rounds of wave slots (8 192 ant worlds on 3 072 slots: 2.67) no longer pays for the round it does not fill.  Bit-identical to the plain launch
+        # (tests/test_gpu_maze.py::test_split_step_is_the_plain_step).  GRX_MAZE_SPLIT=P (1: off); default: MAZE_SPLIT_PARTS for batches of more than one round of worlds.
+        import os
+        self._split = max(1, min(self.N_SUBSTEPS, 8, int(os.environ.get("GRX_MAZE_SPLIT", MAZE_SPLIT_PARTS if n > 3072 else 1)))) if n >= 64 else 1
+        if self._split > 1:
+            self._split_state = z(n, 2, dtype=torch.int32)
+            for b in (self._bufs, self._bufs_masked):
+                b.split_state, b.split_parts = self._split_state.data_ptr(), self._split
         # reset staging (see _reset_worlds): pinned host rows [start xy | goal xy] + world indices, their device mirrors, the kernel's argument block
         self._stage_host, self._idx_host = torch.empty(n, 4, dtype=torch.float32, pin_memory=True), torch.empty(n, dtype=torch.int32, pin_memory=True)
         self._stage_dev, self._idx_dev, self._stage_event = z(n, 4), z(n, dtype=torch.int32), None

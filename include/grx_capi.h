@@ -161,6 +161,13 @@ typedef struct grx_point_buffers {
   int* status;                  /* [N] */
   const unsigned char* mask;    /* [N] or NULL */
   float* packed;                /* [N, obs_dim+2+2+2] or NULL: [obs | achieved | desired | reward | success] (see grx_fetch_buffers.packed) */
+  /* SPLIT STEP (round 6; grx_fetch_buffers.split_parts explains the mechanism).  8 192 ant worlds on 3 072 wave slots are 2.67 rounds of workgroups, i.e. three: the last one runs
+   * on a chip that is two thirds full.  With split_parts = P (2 <= P <= frame_skip) the launch has P workgroups per world, each running its share of the substeps and handing the
+   * world on through its own state row (at a substep boundary qpos / qvel / warm start are the whole state; the RK4 stages of a substep stay in one part); only the last part writes
+   * outputs.  Results are bit-identical to the one-workgroup launch (tests/test_gpu_maze.py::test_split_step_is_the_plain_step).  split_state: zeroed before the first launch. */
+  int* split_state;             /* [N, 2] or NULL */
+  int split_parts;              /* 0 / 1: one workgroup per world */
+  int split_pad_;
 } grx_point_buffers;
 
 /* mirrors struct GrxHandTask / GrxHandBuffers (csrc/grx_hand_task.h): Shadow Dexterous Hand reach task */

@@ -258,3 +258,33 @@ def test_device_reset_draws_equal_numpy_bit_for_bit(env_id):
         a, b = env.world_rng(w).bit_generator.state, rngs[w].bit_generator.state
         assert a["state"] == b["state"] and a["has_uint32"] == b["has_uint32"] and (not a["has_uint32"] or a["uinteger"] == b["uinteger"]), w
     env.close()
+
+
+@pytest.mark.parametrize("env_id,parts", [("AntMaze_Large_Diverse_GR-v5", 5), ("AntMaze_UMaze-v5", 2), ("AntMaze_Medium-v5", 3), ("PointMaze_Large_Diverse_GR-v3", 2)])
+def test_split_step_is_the_plain_step(monkeypatch, env_id, parts):
+    """Round 6: the maze step launch with P workgroups per world, each running its share of the frame_skip substeps and handing the world on through its own state row (include/grx_capi.h
+    grx_point_buffers.split_parts), against the plain launch: state rows, observations, achieved goals, rewards, flags, status words and packed rows are BIT-IDENTICAL after every
+    step -- RK4 ants (the four stages of a substep stay in one part; 5 substeps in 2, 3 and 5 uneven shares) and the Euler point (velocity clip once per step), same-step autoresets
+    at a short time limit included.  The reference's step is one env.step() whatever the launch geometry (/root/reference/gymnasium_robotics/envs/maze/ant_maze_v5.py:295-310)."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    n, envs = 2048, []
+    for p_ in (1, parts):
+        monkeypatch.setenv("GRX_MAZE_SPLIT", str(p_))
+        e = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=7)
+        e.reset(seed=5)
+        envs.append(e)
+    plain, split = envs
+    assert plain._split == 1 and split._split == min(parts, split.N_SUBSTEPS)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(9)
+    act_dim = plain.single_action_space.shape[0]
+    for t in range(18):
+        a = torch.rand(n, act_dim, device="cuda:0", generator=gen) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        for name in ("qpos", "qvel", "qacc_ws", "obs", "achieved", "reward", "success", "terminated", "status", "packed", "goal"):
+            assert torch.equal(getattr(split, name), getattr(plain, name)), (t, name, int((getattr(split, name) != getattr(plain, name)).sum()))
+        assert torch.equal(torch.as_tensor(outs[0][3]), torch.as_tensor(outs[1][3]))
+        assert split._split == 1 or int(split._split_state.abs().max()) == 0, t      # every world's words are clean again (the point's single substep cannot be split: one part)
+    assert int((split.status & 1).max()) == 0 and torch.isfinite(split.qpos).all()
