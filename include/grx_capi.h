@@ -312,7 +312,8 @@ int grx_maze_compute_reward(const float* achieved, const float* desired, int64_t
 /* Shadow hand reach: BaseRobotEnv.step with MujocoHandEnv._set_action (absolute position control) + mj_step(n_substeps) +
  * MujocoHandReachEnv._get_obs / compute_reward / _is_success for N worlds (envs/robot_env.py:114-152,
  * envs/shadow_dexterous_hand/hand_env.py:36-58, reach.py:92-134,398-428).  forward_only != 0: mj_forward + outputs (reset path,
- * robot_env.py:300-313, and _env_setup, reach.py:408-416).  grx_goal_compute_reward: batched compute_reward for dim-vector goals. */
+ * robot_env.py:300-313, and _env_setup, reach.py:408-416).  forward_only takes 0 or 1 (values >= 2 are the repeat count of grx_hand_step_repeat below: call that instead).
+ * grx_goal_compute_reward: batched compute_reward for dim-vector goals. */
 int grx_hand_step(const grx_model* m, const grx_hand_task* task, const grx_hand_buffers* buf, int n_worlds, int forward_only, void* stream);
 /* `repeat` consecutive env.step()s of the same action rows in ONE launch -- the loop of MujocoManipulateEnv._reset_sim, `for _ in range(10): self._set_action(np.zeros(20));
  * mj_step(nstep=n_substeps)` (envs/shadow_dexterous_hand/manipulate.py:205-224), for the worlds of `buf`.  Each repetition is the whole step of grx_hand_step, its state rows written
