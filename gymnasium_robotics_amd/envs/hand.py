@@ -212,6 +212,9 @@ class HandReachVecEnv(GoalVecEnv):
     def _cancel_chains(self):
         pass
 
+    def _before_step_launch(self, spec):
+        pass
+
     # ------------------------------------------------------------------ reset (robot_env.py:154-182, 300-313; reach.py:99-126)
     def _reset_worlds(self, idx):
         if len(idx) == 0:
@@ -249,6 +252,8 @@ class HandReachVecEnv(GoalVecEnv):
         with torch.cuda.device(self.device):
             pending = np.nonzero(self._needs_reset)[0] if self.autoreset_mode == "next_step" else np.zeros(0, np.int64)
             spec = self._begin_overlapped_reset() if self.autoreset_mode == "same_step" else None
+            if spec is not None:
+                self._before_step_launch(spec)
             if len(pending):
                 self.mask.fill_(1)
                 self.mask.index_fill_(0, self._stage_idx(pending), 0)      # (pinned staging + index_fill_: nothing here waits for the running kernel)
@@ -411,6 +416,7 @@ class HandBlockVecEnv(HandReachVecEnv):
     chain_events = None      # set to [] to collect (step started, step due, worlds, start event, end event) of every settle chain
     CHAIN_LOOKAHEAD = int(os.environ.get("GRX_CHAIN_LOOKAHEAD", 2))      # steps before the time limit at which a world's settle chain is started (same-step autoreset); 3 measured no faster (below)
 
+    _chain_first = os.environ.get("GRX_CHAIN_FIRST", "0") != "0"      # settle chains launched ahead of the step launch (see _before_step_launch)
     _fused_settle = os.environ.get("GRX_HAND_FUSED_SETTLE", "1") != "0"      # a chain's ten settle steps as ONE repeat launch (include/grx_capi.h grx_hand_step_repeat); 0: ten launches (A/B)
 
     GOAL_DIM = 7
@@ -597,6 +603,8 @@ class HandBlockVecEnv(HandReachVecEnv):
             ar["qpos"][lo: lo + k] = tq[:, : self.nq]
             ar["qvel"][lo: lo + k].zero_()
             bufs, sp = self._arena_bufs(lo), ctypes.c_void_p(side.cuda_stream)
+            c["pre"] = torch.cuda.Event()
+            c["pre"].record(side)      # (everything of this chain but its settle launch is done when this fires: see _before_step_launch)
             # the arena's action rows stay zero: _set_action(np.zeros(20)) (manipulate.py:206-216).  ONE repeat launch (include/grx_capi.h grx_hand_step_repeat: bit-identical to the ten
             # launches, which beside the step kernel each wait for wave slots and end with their slowest world); GRX_HAND_FUSED_SETTLE=0: the ten launches (A/B)
             if self._fused_settle:
@@ -672,10 +680,22 @@ class HandBlockVecEnv(HandReachVecEnv):
                     new.append(c)
         return self._step_no, new
 
+    def _before_step_launch(self, spec):
+        """GRX_CHAIN_FIRST=1: the new chains' launches go to the device AHEAD of the step launch, which waits (on the device) until the chain's kernel is the next packet of its
+        queue.  Beside a step launch that is still dispatching, a side stream's workgroups get no wave slot (profiles/chain_probe_r06.txt: 30 ms chains = the step launch's
+        dispatch + their own 16 ms); started first, a chain's 164 workgroups take their slots at once and the step launch fills the rest of the chip."""
+        if not self._chain_first:
+            return
+        main = torch.cuda.current_stream(self.device)
+        for c in spec[1]:
+            self._start_chain(c)
+            main.wait_event(c["pre"])
+
     def _after_step_launch(self, spec):
         step_no, new = spec
         for c in new:                      # first: the new chains need every millisecond of the two steps they have
-            self._start_chain(c)
+            if c.get("event") is None:
+                self._start_chain(c)
         for c in self._chains:
             if c["due_at"] <= step_no and c["ok"] is None and not any(c is x for x in new):
                 self._early_goals(c)

@@ -390,3 +390,28 @@ def test_degenerate_maze_is_refused_and_an_exhausted_rejection_loop_is_flagged()
     out = env.step(np.zeros((4, 4), np.float32))
     assert (out[4]["status_sticky"] & 1).all()
     env.close()
+
+
+@pytest.mark.parametrize("env_id,n,var,act_dim", [("FetchPickAndPlace-v4", 2050, "GRX_FETCH_SPLIT", 4), ("FetchPickAndPlace-v4", 1001, "GRX_FETCH_SPLIT", 4),
+                                                  ("AntMaze_Large_Diverse_GR-v5", 3083, "GRX_MAZE_SPLIT", 8), ("AntMaze_Large_Diverse_GR-v5", 100, "GRX_MAZE_SPLIT", 8)])
+def test_split_steps_at_batch_sizes_that_are_no_multiple_of_eight(monkeypatch, env_id, n, var, act_dim):
+    """The split launches (include/grx_capi.h grx_fetch_buffers.split_parts / grx_point_buffers.split_parts) map workgroup -> (part, slot) -> world over a grid rounded up to 8 slots per
+    part: the padding workgroups of every part return before they wait for anything, and the rollout is the plain launch's bit for bit (same-step autoresets included)."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    envs = []
+    for p in ("1", "2"):
+        monkeypatch.setenv(var, p)
+        e = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=5)
+        e.reset(seed=3)
+        envs.append(e)
+    assert envs[0]._split == 1 and envs[1]._split == 2
+    g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+    for t in range(12):
+        a = torch.rand(n, act_dim, device="cuda:0", generator=g) * 2 - 1
+        for e in envs:
+            e.step(a)
+        for name in ("qpos", "qvel", "qacc_ws", "obs", "reward", "status", "packed"):
+            assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), (t, name)
