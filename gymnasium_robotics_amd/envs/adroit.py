@@ -70,7 +70,7 @@ class AdroitVecEnv(GoalVecEnv):
         self.balance = os.environ.get("GRX_ADROIT_BALANCE", "0" if self.task_name == "pen" else "1") != "0" and cost_order_alloc(self, n, d, self._bufs, self._bufs_masked)
         self._compact_resets = os.environ.get("GRX_ADROIT_COMPACT_RESET", "1") != "0"      # (0: the masked whole-grid forward launch of rounds 3 - 4; A/B, tests)
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
-        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode="lane" if self.task_name in ("door", "relocate") else "entry", lane_first=True) if self._h_big is not None else None     # hammer / pen: no overflow in 4 M world-steps
+        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode="lane" if self.task_name in ("door", "relocate") else "entry", lane_first=True, ttl=1) if self._h_big is not None else None      # (ttl 4 -> 1 with the cost-ordered dispatch: door +1.8 %, relocate +1 %: profiles/ab_r06_lane_ttl.txt)     # hammer / pen: no overflow in 4 M world-steps
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)                      # adroit_hammer.py:231-233
         self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float64)      # :205-207
         self.action_space = batch_space(self.single_action_space, n)

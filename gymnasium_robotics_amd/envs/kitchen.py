@@ -78,7 +78,8 @@ class KitchenVecEnv(GoalVecEnv):
         self.balance = os.environ.get("GRX_KITCHEN_BALANCE", "1") != "0" and cost_order_alloc(self, n, d, self._bufs, self._bufs_masked)
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
         # (32 polling workgroups: with the fast tables cut to 128 rows / 1 280 words / 24 contacts more worlds ENTER the lane per step; measured 16 -> 0.357 M, 32 -> 0.374 M, 48 -> 0.365 M, 96 -> 0.341 M env-steps/s)
-        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), poll_grid=32) if self._h_big is not None else None
+        # (round 6, with the cost-ordered dispatch: a world leaves the lane one step after it was last near a capacity and enters it at 0.9 of one -- fewer worlds on the slower large-table kernel: ttl 4 -> 1: 0.409 -> 0.418 M, margin 0.8 -> 0.9: 0.421 M; ttl 0 and margin 0.7 lose: profiles/ab_r06_kitchen_ttl*.txt)
+        self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), poll_grid=32, ttl=1, margin=0.9) if self._h_big is not None else None
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float64)                     # franka_env.py:88
         goal_space = Dict({t: Box(-np.inf, np.inf, OBS_ELEMENT_GOALS[t].shape, np.float64) for t in self.tasks})
         self.single_observation_space = Dict(dict(desired_goal=goal_space, achieved_goal=Dict(dict(goal_space)),
