@@ -247,6 +247,20 @@ typedef GrxShape<31, 30, 20, 26, 25, 24, 0, 0, 24, 0, 256, 4080, 92, 64, 1, 2> G
 #endif
 // one world's env.step().  LANE: called from the list-walking loop of the large-table kernel (w comes from the list; see grx_overflow_lane)
 // SPLIT (include/grx_capi.h, grx_fetch_buffers.split_parts): `part` of `parts` workgroups of this world, each running its share of the substeps; 0 of 1 = the whole step.
+// How a part of a split step hands the world to the next one (MI355X_MICROARCH.md, workgroup dispatch / hand-off forms): the carrier row is written with write-through (volatile = sc0 sc1)
+// stores, drained with s_waitcnt vmcnt(0), then the flag word is stored the same way; the reader polls the flag and reads the row with L1-bypassing (volatile) loads.  Valid for any
+// workgroup -> XCD placement, and without an agent-scope release: `__threadfence()` writes back EVERY dirty line of the XCD's L2 (buffer_wbl2) -- the scratch of all resident waves --
+// once per part and wave: that was 19 MB of write-back per launch of 4 096 worlds (PMC traffic 3.9x -> 10.6x algorithmic) and what made a third and fourth part cost more than they
+// saved.  -DGRX_SPLIT_AGENT_FENCES restores the fences (A/B: tools/ab_split_fences.sh).
+#ifdef GRX_SPLIT_AGENT_FENCES
+#define GRX_SPLIT_ROW float
+#define GRX_SPLIT_DRAIN() __threadfence()
+#define GRX_SPLIT_ACQUIRE() __threadfence()
+#else
+#define GRX_SPLIT_ROW volatile float
+#define GRX_SPLIT_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GRX_SPLIT_ACQUIRE() asm volatile("" ::: "memory")
+#endif
 #define GRX_SPLIT_SPIN_LIMIT (1 << 22)   // polls (~64 cycles each: > 100 ms) before a part gives its predecessor up: never reached while workgroups of an XCD start in index order
 template <class S, bool LANE>
 __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTask& t, const GrxFetchBuffers& b, const int w, int n_worlds, int words, float* lds, const int lane_,
@@ -267,7 +281,7 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
       if (lane_ == 0) { if (v >= 0) b.status[w] |= GRX_ST_BADNUM | (GRX_ST_BADNUM << 16); if (last_part) st[0] = 0; }
       return;
     }
-    __threadfence();
+    GRX_SPLIT_ACQUIRE();
   }
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
@@ -321,9 +335,9 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
     volatile int* st = b.split_state + 2 * (size_t)wl;
     if (grx_lane_overflowed(c)) { if (lane_ == 0) st[0] = -1; }      // the re-run on the large tables is booked: the later parts return
     else {
-      if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) b.hullcache[(size_t)wl * GRX_HULLCACHE_WORDS + lane_] = c.meshcache[lane_];
+      if (S::kMesh && m.nmeshpair > 0 && b.hullcache && lane_ < 21) ((GRX_SPLIT_ROW*)b.hullcache)[(size_t)wl * GRX_HULLCACHE_WORDS + lane_] = c.meshcache[lane_];
       const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv, nu = S::kFixed ? S::NU : m.nu, nmo = S::kFixed ? S::NM : m.nmocap;
-      float* row = b.handoff + (size_t)wl * b.handoff_stride;
+      GRX_SPLIT_ROW* row = b.handoff + (size_t)wl * b.handoff_stride;
       int o = 2;
       for (int i = lane_; i < nu; i += 64) row[o + i] = c.ctrl[i];
       o += nu;
@@ -332,12 +346,12 @@ __device__ __forceinline__ void grx_fetch_step_world(int mslot, const GrxFetchTa
       for (int i = lane_; i < nq; i += 64) row[o + i] = c.qpos[i];
       o += nq;
       for (int i = lane_; i < nv; i += 64) { row[o + i] = c.qvel[i]; row[o + nv + i] = c.qacc_ws[i]; }
-      if (lane_ == 0) { ((int*)row)[1] = c.cnt[2]; ((int*)row)[0] = s_end + 1; }
-      __threadfence();
+      if (lane_ == 0) { ((volatile int*)row)[1] = c.cnt[2]; ((volatile int*)row)[0] = s_end + 1; }
+      GRX_SPLIT_DRAIN();
       __syncthreads();
       if (lane_ == 0) {
         if (b.cost) { const int t0 = ((volatile int*)b.cost)[wl]; st[1] = (part > 0 ? st[1] : 0) + (((int)wall_clock64() - t0) >> 3); }
-        __threadfence();
+        GRX_SPLIT_DRAIN();
         st[0] = part + 1;
       }
     }
@@ -505,7 +519,7 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
       if (lane_ == 0) { b.status[w] |= GRX_ST_BADNUM | (GRX_ST_BADNUM << 16); if (last_part) { st[0] = 0; st[1] = 0; } }
       return;
     }
-    __threadfence();
+    GRX_SPLIT_ACQUIRE();
   }
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
@@ -534,14 +548,15 @@ grx_point_step_kernel(int mslot, GrxPointTask t, GrxPointBuffers b, int n_worlds
   const int wl = (int)((sl & 7u) * (Gl >> 3) + (sl >> 3));
   if (split && !last_part) {   // an earlier part: the state row IS the carrier; the flags of its substeps travel in the world's second word
     __syncthreads();
-    for (int i = lane_; i < m.nq; i += 64) b.qpos[(size_t)wl * m.nq + i] = c.qpos[i];
-    for (int i = lane_; i < m.nv; i += 64) { b.qvel[(size_t)wl * m.nv + i] = c.qvel[i]; b.qacc_ws[(size_t)wl * m.nv + i] = c.qacc_ws[i]; }
-    __threadfence();
+    GRX_SPLIT_ROW *rq = b.qpos + (size_t)wl * m.nq, *rv = b.qvel + (size_t)wl * m.nv, *ra = b.qacc_ws + (size_t)wl * m.nv;
+    for (int i = lane_; i < m.nq; i += 64) rq[i] = c.qpos[i];
+    for (int i = lane_; i < m.nv; i += 64) { rv[i] = c.qvel[i]; ra[i] = c.qacc_ws[i]; }
+    GRX_SPLIT_DRAIN();
     __syncthreads();
     if (lane_ == 0) {
       volatile int* st = b.split_state + 2 * (size_t)wl;
       st[1] = (part > 0 ? st[1] : 0) | c.cnt[2];
-      __threadfence();
+      GRX_SPLIT_DRAIN();
       st[0] = (int)part + 1;
     }
     return;
@@ -604,7 +619,7 @@ __device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask
   const int od = grx_hand_obs_dim(&t, nq, nv, m.ntouch), gd = grx_hand_goal_dim(&t);
   float* obs = b.obs + (size_t)w * od; float* ach = b.achieved + (size_t)w * gd; float* palm = b.palm + (size_t)w * 3;
   for (int rep = 0; rep < nrep; rep++) {
-  if (rep > 0) { __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }   // the rows this wave wrote in the previous repetition are read back below
+  if (rep > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }   // the rows this wave wrote in the previous repetition are read back below: its stores have reached the L2, this CU's L1 is invalidated (no release fence: that would write back the whole L2, see GRX_SPLIT_DRAIN)
   if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp, parked in the cost slot (see grx_fetch_step_kernel)
   for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
   __syncthreads();

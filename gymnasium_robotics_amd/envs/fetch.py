@@ -41,7 +41,8 @@ FETCH_CAPACITY = {"maxcon": 28, "maxefc": 144, "jpool": 2032, "split_spans": Fal
 # worlds per CU).  ~0.1 % of the world-steps exceed 1 024 pool words, none 24 contacts (profiles/hull_share_r06_fetch.txt); a world that does -- or in which a hull pair passes the
 # bounding-box filter -- is handed off MID-STEP to the standing lane, which runs the kernel on FETCH_CAPACITY above (include/grx_capi.h, grx_fetch_buffers.handoff).
 FETCH_FAST_CAPACITY = {"maxcon": 24, "maxefc": 96, "jpool": 1024}
-FETCH_SPLIT_PARTS = 2     # default of GRX_FETCH_SPLIT for batches of more than one round of worlds (see FetchVecEnv._alloc; profiles/ab_r06_fetch_split.txt: 2 is the optimum at 4 096 - 16 384 worlds)
+FETCH_SPLIT_PARTS = 4     # default of GRX_FETCH_SPLIT for batches of more than one round of worlds up to FETCH_SPLIT_WIDE (see FetchVecEnv._alloc; profiles/ab_r06_split_fences.txt)
+FETCH_SPLIT_WIDE = 12288  # above: 2 parts (16 384 worlds: 2 parts 1.796 M, 4 parts 1.789 M)
 HANDOFF_TASKS = ("FetchPickAndPlace",)
 
 
@@ -222,10 +223,11 @@ class FetchVecEnv(GoalVecEnv):
         # SPLIT STEP (include/grx_capi.h grx_fetch_buffers.split_parts): the step launch has P workgroups per world, each running 1 / P of the substeps (the state travels through the
         # world's hand-off row): the launch's tail -- the duration of the LAST workgroup started, a whole world-step otherwise -- shrinks to 1 / P of it.  Bit-identical to the unsplit
         # launch (tests/test_gpu_fetch.py::test_split_step_is_the_plain_step).  GRX_FETCH_SPLIT=P (1: off); not combined with the hull-less fast kernel.
-        # Default: 2 parts for batches of more than 2 048 worlds (one round of the chip's wave slots at 8 worlds per CU: below that every workgroup starts at once and there is no tail
-        # to shorten).  Measured (profiles/ab_r06_fetch_split.txt): 4 096 worlds 1.263 -> 1.381 M (+9.3 %), 8 192: 1.542 -> 1.630 M (+5.7 %), 16 384: 1.717 -> 1.764 M (+2.8 %); 3 parts
-        # lose to 2 (each part re-enters the kernel), 5 lose to none.
-        self._split = max(1, int(os.environ.get("GRX_FETCH_SPLIT", str(FETCH_SPLIT_PARTS if n > 2048 else 1)))) if self.handoff is None and n >= 64 else 1
+        # Default: 4 parts for batches of more than 2 048 worlds (one round of the chip's wave slots at 8 worlds per CU: below that every workgroup starts at once and there is no tail
+        # to shorten), 2 above FETCH_SPLIT_WIDE.  Measured, same call (profiles/ab_r06_split_fences.txt): 4 096 worlds 1.271 M unsplit -> 1.431 / 1.442 / 1.443 / 1.430 M for 2 / 3 / 4 / 5
+        # parts, 8 192: 1.540 -> 1.667 / 1.683 / 1.698 / 1.696 M, 16 384: 1.724 -> 1.796 / 1.795 / 1.789 / 1.778 M.  (With agent-scope fences in the hand-off -- the first version,
+        # profiles/ab_r06_fetch_split.txt -- every part wrote the XCD's L2 back: 2 parts 1.382 M @4 096, more parts lost.)
+        self._split = max(1, int(os.environ.get("GRX_FETCH_SPLIT", str((FETCH_SPLIT_PARTS if n <= FETCH_SPLIT_WIDE else 2) if n > 2048 else 1)))) if self.handoff is None and n >= 64 else 1
         if self._split > 1:
             stride = -(-(2 + self.model.dim("nu") + 7 * self.nmocap + self.nq + 2 * self.nv) // 16) * 16
             self._split_rows, self._split_state = z(n, stride), z(n, 2, dtype=torch.int32)

@@ -49,7 +49,7 @@ def load_point_maze_model(maze: Maze, layout_name: Optional[str], assets_root: O
     return model.with_capacity(**{k: ANT_CAPACITY[k] for k in ("maxcon", "maxefc", "jpool")}) if agent == "ant" else model
 
 
-MAZE_SPLIT_PARTS = 2      # default of GRX_MAZE_SPLIT for batches of more than one round of worlds (see PointMazeVecEnv.__init__; profiles/ab_r06_maze_split.txt: AntMaze_Large @8 192: 2 parts 3.81 -> 3.95 M (+3.6 %), 3 parts +1 %, 5 parts -17 %: every part re-enters the kernel)
+MAZE_SPLIT_PARTS = 5      # default of GRX_MAZE_SPLIT for batches of more than one round of worlds, clamped to frame_skip (see PointMazeVecEnv.__init__; profiles/ab_r06_split_fences.txt: AntMaze_Large @8 192: 3.78 M unsplit -> 4.01 / 4.15 / 4.28 M for 2 / 3 / 5 parts; @4 096: 2.88 -> 3.90 M; @16 384: 4.25 -> 4.45 M)
 
 
 class PointMazeVecEnv(GoalVecEnv):
