@@ -46,7 +46,7 @@ class AdroitTaskStruct(ctypes.Structure):
 
 
 class AdroitBuffersStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")] + [("lane", OverflowLaneStruct), ("compact", ctypes.c_void_p), ("n_compact", ctypes.c_int), ("order", ctypes.c_void_p), ("cost", ctypes.c_void_p)]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "shift", "target", "action", "act_mean", "act_rng", "obs", "reward", "success", "status", "mask")] + [("lane", OverflowLaneStruct), ("compact", ctypes.c_void_p), ("n_compact", ctypes.c_int), ("order", ctypes.c_void_p), ("cost", ctypes.c_void_p), ("split_rows", ctypes.c_void_p), ("split_state", ctypes.c_void_p), ("split_stride", ctypes.c_int), ("split_parts", ctypes.c_int)]
 
 
 class KitchenTaskStruct(ctypes.Structure):

@@ -23,6 +23,10 @@ from ..spaces import Box, batch_space
 from .adroit_spec import IDENTITY_SHIFT, MAX_EPISODE_STEPS, SPECS, action_scaling, group_shift, load_adroit_model, make_adroit_task, parse_adroit_id, sample_reset_batch
 
 
+ADROIT_SPLIT_PARTS = 5      # default of GRX_ADROIT_SPLIT for batches of more than 2 048 worlds = one part per substep (see AdroitVecEnv.__init__; profiles/ab_r06_adroit_split*.txt, 16 384 worlds, 1 / 2 / 3 / 5 parts:
+                            # hammer 1.477 / 1.556 / 1.589 / 1.606 M, pen 2.330 / 2.463 / 2.530 / 2.576 M, relocate 1.228 / 1.200 / 1.229 / 1.278 M, door 1.395 / 1.431 / 1.458 / 1.468 M -- the last two end with their lane's launch)
+
+
 class AdroitVecEnv(GoalVecEnv):
     """autoreset_mode: "next_step" (Gymnasium >= 1.0 default), "same_step" or "disabled"; output: "numpy" (float64 arrays like the reference)
     or "torch" (the fp32 device tensors the kernel wrote)."""
@@ -71,6 +75,17 @@ class AdroitVecEnv(GoalVecEnv):
         self._compact_resets = os.environ.get("GRX_ADROIT_COMPACT_RESET", "1") != "0"      # (0: the masked whole-grid forward launch of rounds 3 - 4; A/B, tests)
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
         self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode="lane" if self.task_name in ("door", "relocate") else "entry", lane_first=True, ttl=1) if self._h_big is not None else None      # (ttl 4 -> 1 with the cost-ordered dispatch: door +1.8 %, relocate +1 %: profiles/ab_r06_lane_ttl.txt)     # hammer / pen: no overflow in 4 M world-steps
+        # SPLIT STEP (include/grx_capi.h grx_adroit_buffers.split_parts): P workgroups per world, each running its share of the 5 substeps, the world handed on through carrier rows.  An Adroit
+        # world's cost changes from step to step, the cost order predicts it poorly, and a launch ended 15 - 40 % after the mean of its wave slots (profiles/tail_probe_r06.txt).
+        # Bit-identical to the plain launch (tests/test_gpu_adroit.py::test_split_step_is_the_plain_step).  GRX_ADROIT_SPLIT=P (1: off).
+        self._split = max(1, min(int(self.task.n_substeps), 8, int(os.environ.get("GRX_ADROIT_SPLIT", ADROIT_SPLIT_PARTS if n > 2048 else 1)))) if n >= 64 else 1
+        if self._split > 1:
+            stride = -(-(self.nq + 2 * self.nv) // 16) * 16
+            self._split_rows, self._split_state = z(n, stride), z(n, 4, dtype=torch.int32)
+            for b in (self._bufs, self._bufs_masked):
+                b.split_rows, b.split_state, b.split_stride, b.split_parts = self._split_rows.data_ptr(), self._split_state.data_ptr(), stride, self._split
+            if self.lane is not None:
+                self.lane._fast_grid *= self._split      # (polling workgroups of the standing lane wait for EVERY workgroup of the fast launch: grx_overflow_lane.progress_total)
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)                      # adroit_hammer.py:231-233
         self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float64)      # :205-207
         self.action_space = batch_space(self.single_action_space, n)

@@ -233,6 +233,15 @@ typedef struct grx_adroit_buffers {
   int n_compact;
   const int* order;                /* [grid] or NULL: cost-ordered dispatch, see grx_kitchen_buffers.order; ignored by compact launches */
   int* cost;                       /* [N] or NULL: measured duration of each world's step (80 ns units), written by step launches */
+  /* SPLIT STEP (round 6; grx_fetch_buffers.split_parts explains the mechanism): split_parts = P (2 <= P <= frame_skip) workgroups per world, each running its share of the substeps and
+   * handing the world on through its row of split_rows ([qpos | qvel | warm start]; the state rows stay untouched until the last part, so a world that exceeds a table is re-run from
+   * them as usual).  An Adroit world's cost changes from step to step (the hammer meets the nail for a few steps), so the cost order predicts it poorly: launches ended 15 - 40 % after
+   * the mean of their wave slots (profiles/tail_probe_r06.txt).  Step launches only (not compact, not forward_only, not the lane's).  Bit-identical to split_parts = 0
+   * (tests/test_gpu_adroit.py::test_split_step_is_the_plain_step).  With polling workgroups the standing lane launch's grx_overflow_lane.progress_total must count every part
+   * (split_parts x the grid of a plain launch): every workgroup of the fast launch reports its end. */
+  float* split_rows;               /* [N, split_stride] or NULL */
+  int* split_state;                /* [N, 4] or NULL, zeroed before the first launch */
+  int split_stride, split_parts;
 } grx_adroit_buffers;
 
 /* mirrors struct GrxKitchenTask / GrxKitchenBuffers (csrc/grx_kitchen_task.h): FrankaKitchen-v1 */

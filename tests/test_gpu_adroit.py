@@ -232,3 +232,34 @@ def test_overlapped_reset_is_the_inline_reset(monkeypatch, task, output):
         if task == "pen":
             assert all(a_.bit_generator.state == b_.bit_generator.state for a_, b_ in zip(envs[0].np_randoms[::37], envs[1].np_randoms[::37])), t
     assert 50 <= resets < 70
+
+
+@pytest.mark.parametrize("env_id,parts", [("AdroitHandHammer-v2", 5), ("AdroitHandPen-v2", 2), ("AdroitHandRelocate-v2", 5), ("AdroitHandDoor-v2", 3)])
+def test_split_step_is_the_plain_step(monkeypatch, env_id, parts):
+    """Round 6: the Adroit step launch with P workgroups per world, each running its share of the 5 substeps and handing the world on through a carrier row (include/grx_capi.h
+    grx_adroit_buffers.split_parts), against the plain launch: state rows, observations, rewards, success flags and status words are BIT-IDENTICAL after every step -- same-step autoresets at a
+    short time limit (compact reset launches, the overlapped reset), the cost-ordered dispatch on, the standing overflow lane of door / relocate with its polling workgroups counting every part.
+    The reference's step is one env.step() whatever the launch geometry (/root/reference/gymnasium_robotics/envs/adroit_hand/adroit_hammer.py:291-357)."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    n, envs = 2048, []
+    for p_ in (1, parts):
+        monkeypatch.setenv("GRX_ADROIT_SPLIT", str(p_))
+        e = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=9)
+        e.reset(seed=5)
+        envs.append(e)
+    plain, split = envs
+    assert plain._split == 1 and split._split == parts
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(9)
+    act_dim = plain.single_action_space.shape[0]
+    for t in range(24):
+        a = torch.rand(n, act_dim, device="cuda:0", generator=gen) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        for name in ("qpos", "qvel", "qacc_ws", "obs", "reward", "success", "status"):
+            assert torch.equal(getattr(split, name), getattr(plain, name)), (t, name, int((getattr(split, name) != getattr(plain, name)).sum()))
+        assert torch.equal(torch.as_tensor(outs[0][3]), torch.as_tensor(outs[1][3]))
+        assert int(split._split_state.abs().max()) == 0, t      # every world's words are clean again
+    assert int((split.status & 1).max()) == 0 and torch.isfinite(split.qpos).all()
+    assert split.cost is None or (int(split.cost.min()) > 0 and int(split.cost.max()) < 10_000_000)      # (the pen runs without the cost order)
