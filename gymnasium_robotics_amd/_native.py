@@ -57,7 +57,8 @@ class KitchenTaskStruct(ctypes.Structure):
 
 class KitchenBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("qpos", "qvel", "qacc_ws", "last_qpos", "action", "noise", "obs", "completed", "status", "mask", "skin")] + [
-        ("skin_stride", ctypes.c_int), ("skin_radius", ctypes.c_float), ("order", ctypes.c_void_p), ("cost", ctypes.c_void_p), ("lane", OverflowLaneStruct)]
+        ("skin_stride", ctypes.c_int), ("skin_radius", ctypes.c_float), ("order", ctypes.c_void_p), ("cost", ctypes.c_void_p), ("lane", OverflowLaneStruct),
+        ("split_rows", ctypes.c_void_p), ("split_state", ctypes.c_void_p), ("split_stride", ctypes.c_int), ("split_parts", ctypes.c_int)]
 
 
 class KitchenBookStruct(ctypes.Structure):      # include/grx_capi.h, grx_kitchen_book

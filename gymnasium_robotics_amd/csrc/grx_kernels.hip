@@ -847,10 +847,27 @@ grx_adroit_lane_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_wor
 typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, GRX_KITCHEN_CAP, 1, 3> GrxShapeKitchen;
 typedef GrxShape<30, 29, 9, 25, 24, 124, 0, 0, 6, 0, 400, 8160, 0, 64, 1, 3> GrxShapeKitchenLane;   // overflow-lane tables (see GrxShapeFetchPickLane)
 template <class S>
-__device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitchenTask& t, const GrxKitchenBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
+__device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitchenTask& t, const GrxKitchenBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane,
+                                                       const int part = 0, const int parts = 1) {
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) { if (in_lane) grx_lane_ticket(b.lane, -1, w, lane_); return; }
   if (!in_lane && !forward_only && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel (reset-time forward passes cover every masked world)
+  // SPLIT STEP (include/grx_capi.h grx_kitchen_buffers.split_parts; see grx_adroit_step_world): part `part` of `parts` workgroups of this world, each running its share of the 40 substeps
+  const bool split = parts > 1, last_part = part == parts - 1;
+  if (split && part > 0) {
+    volatile int* st = b.split_state + 4 * (size_t)w;
+    int v = 0;
+    for (int spins = 0; spins < GRX_SPLIT_SPIN_LIMIT; spins++) {
+      v = __builtin_amdgcn_readfirstlane(st[0]);
+      if (v == part || v < 0) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (v != part) {   // the earlier part booked the world's re-run (v < 0), or never came (flagged): nothing to do here; the last part leaves the words clean
+      if (lane_ == 0) { if (v >= 0) b.status[w] |= GRX_ST_BADNUM | (GRX_ST_BADNUM << 16); if (last_part) { st[0] = 0; st[1] = 0; st[2] = 0; } }
+      return;
+    }
+    GRX_SPLIT_ACQUIRE();
+  }
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -863,17 +880,53 @@ __device__ __forceinline__ void grx_kitchen_step_world(int mslot, const GrxKitch
   const int nq = S::kFixed ? S::NQ : m.nq, nv = S::kFixed ? S::NV : m.nv;
   for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
   __syncthreads();
+  if (split && part > 0) {   // the row the part before this one wrote on another CU during this launch: cache-bypassing loads
+    volatile const float* row = b.split_rows + (size_t)w * b.split_stride;
+    for (int i = lane_; i < nq; i += 64) c.qpos[i] = row[i];
+    for (int i = lane_; i < nv; i += 64) { c.qvel[i] = row[nq + i]; c.qacc_ws[i] = row[nq + nv + i]; }
+  } else {
   for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
   for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
+  }
   __syncthreads();
   float* last = b.last_qpos + (size_t)w * GRX_KITCHEN_NROBOT;
   if (b.skin) { c.skin = b.skin + (size_t)w * b.skin_stride; c.skin_r = b.skin_radius; }
+  if (split && part > 0 && b.skin) {   // the world's skin list was (re)written by another CU during this launch with plain stores: this part does not read it, it REBUILDS it in its first substep (results are identical with any valid list or none)
+    if (lane_ == 0) ((volatile int*)c.skin)[1] = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   grx_lane_setup(b.lane, c, w, !forward_only);
   const bool timed = b.cost && !forward_only && !in_lane;   // cost-ordered dispatch (include/grx_capi.h grx_kitchen_buffers.order / .cost): the start stamp (100 MHz) is parked in the cost slot itself
   if (timed && lane_ == 0) b.cost[w] = (int)wall_clock64();
+  const int s0 = split ? (part * t.n_substeps) / parts : 0, s1 = split ? ((part + 1) * t.n_substeps) / parts : t.n_substeps;
   if (forward_only) GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
-  else GrxKitchen<S>::grx_kitchen_sim_world(&m, &t, &c, b.action + (size_t)w * GRX_KITCHEN_NROBOT, last, lane_);
-  if (timed && lane_ == 0) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = ((int)wall_clock64() - t0) >> 3; }   // measured duration of this world, 80 ns units (a world that overflowed a table too: it ran up to there)
+  else GrxKitchen<S>::grx_kitchen_sim_world(&m, &t, &c, b.action + (size_t)w * GRX_KITCHEN_NROBOT, last, lane_, s0, s1);
+  if (split && !last_part) {   // an earlier part: the state goes to the world's carrier row (write-through + drained flag: GRX_SPLIT_DRAIN), nothing else is written
+    volatile int* st = b.split_state + 4 * (size_t)w;
+    if (grx_lane_overflowed(c)) { if (lane_ == 0) st[0] = -1; }      // the re-run on the large tables is booked: the later parts return
+    else {
+      GRX_SPLIT_ROW* row = b.split_rows + (size_t)w * b.split_stride;
+      __syncthreads();
+      for (int i = lane_; i < nq; i += 64) row[i] = c.qpos[i];
+      for (int i = lane_; i < nv; i += 64) { row[nq + i] = c.qvel[i]; row[nq + nv + i] = c.qacc_ws[i]; }
+      GRX_SPLIT_DRAIN();
+      __syncthreads();
+      if (lane_ == 0) {
+        st[1] = (part > 0 ? st[1] : 0) | c.cnt[2];
+        if (timed) { const int t0 = ((volatile int*)b.cost)[w]; st[2] = (part > 0 ? st[2] : 0) + (((int)wall_clock64() - t0) >> 3); }
+        GRX_SPLIT_DRAIN();
+        st[0] = part + 1;
+      }
+    }
+    return;
+  }
+  int earlier = 0;
+  if (split) {   // the last part: the flags and the measured time of the earlier parts; the words are clean for the next launch
+    if (lane_ == 0) { volatile int* st = b.split_state + 4 * (size_t)w; c.cnt[2] |= st[1]; earlier = st[2]; st[0] = 0; st[1] = 0; st[2] = 0; }
+    __syncthreads();
+  }
+  if (timed && lane_ == 0) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = (((int)wall_clock64() - t0) >> 3) + earlier; }   // measured duration of this world, 80 ns units (a world that overflowed a table too: it ran up to there)
   if (grx_lane_overflowed(c)) return;   // capacity overflow: keep nothing (last_qpos included), re-run on the large tables
   if (in_lane) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, w, lane_); else if (!forward_only) grx_lane_join(b.lane, c, w, lane_);
   GrxKitchen<S>::grx_kitchen_outputs(&m, &t, &c, b.noise ? b.noise + (size_t)w * t.obs_dim : nullptr, b.obs + (size_t)w * t.obs_dim, last, b.completed + w, lane_);
@@ -892,6 +945,11 @@ __global__ void __launch_bounds__(64, 2)
 grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
+  const int parts = (b.split_parts > 1 && !forward_only) ? b.split_parts : 1;
+  if (parts > 1) {
+    const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot, slot + G, ... share blockIdx.x mod 8
+    grx_kitchen_step_world<S>(mslot, t, b, b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)), n_worlds, words, forward_only, lds, lane_, false, (int)part, parts);
+  } else
   grx_kitchen_step_world<S>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
   grx_lane_progress(b.lane);
 }
@@ -1493,7 +1551,12 @@ extern "C" int grx_kitchen_step(const grx_model* m, const grx_kitchen_task* task
     if (!grx_planes_static(m)) return fail("grx_kitchen_step: the skin list needs static plane geoms");
   }
   if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_kitchen_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
-  const int e = grx_tu_kitchen_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  const bool split = b.split_parts > 1 && !forward_only && !b.lane.list;      // step launches only
+  if (split) {
+    if (!b.split_state || !b.split_rows || b.split_stride < g.nq + 2 * g.nv) return fail("grx_kitchen_step: a split step needs split_state [N, 4] and carrier rows split_rows [N, split_stride >= nq + 2 nv]");
+    if (b.split_parts > t.n_substeps || b.split_parts > 8) return fail("grx_kitchen_step: split_parts <= min(n_substeps, 8): a part runs whole substeps");
+  } else b.split_parts = 0;
+  const int e = grx_tu_kitchen_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : (split ? (unsigned)b.split_parts : 1u) * grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_kitchen_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }

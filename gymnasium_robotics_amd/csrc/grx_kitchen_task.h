@@ -40,6 +40,9 @@ struct GrxKitchenBuffers {
   const int* order;               // [grid] or null: workgroup j steps world order[j] (cost-ordered dispatch, include/grx_capi.h)
   int* cost;                      // [N] or null: measured duration of each world's step (80 ns units), written by step launches
   GrxLane lane;                   // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
+  float* split_rows;              // [N, split_stride] or null: carrier rows of the split step [qpos | qvel | warm start] (include/grx_capi.h)
+  int* split_state;               // [N, 4] or null: [4 w] = parts of world w done in this launch (< 0: re-run booked), [4 w + 1] = their status flags, [4 w + 2] = their measured duration
+  int split_stride, split_parts;  // words per carrier row (>= nq + 2 nv); >= 2: the step launch has split_parts workgroups per world
 };
 
 template <class S>
@@ -70,7 +73,8 @@ struct GrxKitchen {
     WAVE_SYNC();
   }
 
-  GRX_MEM void grx_kitchen_sim_world(const GrxModel* m, const GrxKitchenTask* t, GrxCtx* c, const float* action, const float* last_qpos, int lane_) {
+  // s0 / s1: the substeps [s0, s1) of the step (a part of a split step, include/grx_capi.h grx_kitchen_buffers.split_parts); default: all of them
+  GRX_MEM void grx_kitchen_sim_world(const GrxModel* m, const GrxKitchenTask* t, GrxCtx* c, const float* action, const float* last_qpos, int lane_, int s0 = 0, int s1 = -1) {
     FOR_LANES {
       for (int i = lane; i < GRX_KITCHEN_NROBOT; i += 64) {
         const float a = 2.0f * fminf(1.0f, fmaxf(-1.0f, action[i]));
@@ -79,7 +83,8 @@ struct GrxKitchen {
       }
     }
     WAVE_SYNC();
-    for (int s = 0; s < t->n_substeps; s++) {
+    if (s1 < 0) s1 = t->n_substeps;
+    for (int s = s0; s < s1; s++) {
       E::grx_check_state(m, c, lane_);
       E::grx_forward_euler(m, c, 1, lane_);
       if (c->bail && grx_lane_claim(c, lane_)) break;   // a capacity overflowed and the re-run on the large tables is booked: this run will be discarded

@@ -29,6 +29,10 @@ from ..spaces import Box, Dict, batch_space
 from .kitchen_spec import (INIT_QPOS, MAX_EPISODE_STEPS, OBS_DIM, OBS_ELEMENT_GOALS, OBS_ELEMENT_INDICES, TASKS, load_kitchen_model, make_kitchen_task, task_mask)
 
 
+KITCHEN_SPLIT_PARTS = 1      # default of GRX_KITCHEN_SPLIT (see KitchenVecEnv.__init__): OFF -- measured (profiles/ab_r06_kitchen_split.txt, 16 384 worlds): 2 parts take the step kernel from 36.7 to 35.5 ms but the step still ends
+                             # with the lane's launch (38.9 ms: its last entrant's re-run): 0.418 -> 0.419 M; 4 / 5 / 8 parts lose 2 - 5 % (every part rebuilds the skin list)
+
+
 class KitchenVecEnv(GoalVecEnv):
     """autoreset_mode: "next_step" (Gymnasium >= 1.0 default), "same_step" or "disabled"; output: "numpy" (float64 arrays like the reference) or
     "torch" (the fp32 device tensors the kernel wrote; achieved goals are views of the qpos buffer)."""
@@ -80,6 +84,16 @@ class KitchenVecEnv(GoalVecEnv):
         # (32 polling workgroups: with the fast tables cut to 128 rows / 1 280 words / 24 contacts more worlds ENTER the lane per step; measured 16 -> 0.357 M, 32 -> 0.374 M, 48 -> 0.365 M, 96 -> 0.341 M env-steps/s)
         # (round 6, with the cost-ordered dispatch: a world leaves the lane one step after it was last near a capacity and enters it at 0.9 of one -- fewer worlds on the slower large-table kernel: ttl 4 -> 1: 0.409 -> 0.418 M, margin 0.8 -> 0.9: 0.421 M; ttl 0 and margin 0.7 lose: profiles/ab_r06_kitchen_ttl*.txt)
         self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), poll_grid=32, ttl=1, margin=0.9) if self._h_big is not None else None
+        # SPLIT STEP (include/grx_capi.h grx_kitchen_buffers.split_parts; see AdroitVecEnv): a kitchen launch ended 15 % after the mean of its wave slots (profiles/tail_probe_r06.txt).
+        # GRX_KITCHEN_SPLIT=P (1: off).  Bit-identical to the plain launch (tests/test_gpu_kitchen.py::test_split_step_is_the_plain_step).
+        self._split = max(1, min(8, int(os.environ.get("GRX_KITCHEN_SPLIT", KITCHEN_SPLIT_PARTS if n > 2048 else 1)))) if n >= 64 else 1
+        if self._split > 1:
+            stride = -(-(self.nq + 2 * self.nv) // 16) * 16
+            self._split_rows, self._split_state = z(n, stride), z(n, 4, dtype=torch.int32)
+            for b in (self._bufs, self._bufs_masked):
+                b.split_rows, b.split_state, b.split_stride, b.split_parts = self._split_rows.data_ptr(), self._split_state.data_ptr(), stride, self._split
+            if self.lane is not None:
+                self.lane._fast_grid *= self._split      # (polling workgroups of the standing lane wait for EVERY workgroup of the fast launch)
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float64)                     # franka_env.py:88
         goal_space = Dict({t: Box(-np.inf, np.inf, OBS_ELEMENT_GOALS[t].shape, np.float64) for t in self.tasks})
         self.single_observation_space = Dict(dict(desired_goal=goal_space, achieved_goal=Dict(dict(goal_space)),

@@ -274,6 +274,12 @@ typedef struct grx_kitchen_buffers {
   const int* order;                 /* [grid] or NULL */
   int* cost;                        /* [N] or NULL: 80 ns units */
   grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane and its LIMITS */
+  /* SPLIT STEP (round 6; as grx_adroit_buffers.split_parts): split_parts = P (2 <= P <= 8) workgroups per world, each running its share of the 40 substeps and handing the world on
+   * through its row of split_rows.  A part does not read the skin list another part (another CU) wrote: it rebuilds it in its first substep (one full candidate sweep per part).
+   * Bit-identical to split_parts = 0 (tests/test_gpu_kitchen.py::test_split_step_is_the_plain_step).  Step launches only. */
+  float* split_rows;               /* [N, split_stride >= nq + 2 nv] or NULL */
+  int* split_state;                /* [N, 4] or NULL, zeroed before the first launch */
+  int split_stride, split_parts;
 } grx_kitchen_buffers;
 
 /* At most 32 models (descriptor slots in constant memory) exist per process at a time; creation beyond that fails with an error, destroy frees the slot.  A model is immutable

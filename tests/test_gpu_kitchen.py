@@ -256,3 +256,31 @@ def test_overflow_lane_polling_equals_the_serialised_rerun(monkeypatch):
         entered += len(envs[1].lane.entered_last_step())
         assert torch.equal(envs[0].qpos, envs[1].qpos) and torch.equal(envs[0].qvel, envs[1].qvel) and torch.equal(outs[0][0]["observation"], outs[1][0]["observation"]), t
     assert entered >= 1, entered
+
+
+@pytest.mark.parametrize("parts", [2, 5])
+def test_split_step_is_the_plain_step(monkeypatch, parts):
+    """Round 6: the kitchen step launch with P workgroups per world, each running its share of the 40 substeps and handing the world on through a carrier row (include/grx_capi.h
+    grx_kitchen_buffers.split_parts; a part rebuilds the broad-phase skin list instead of reading what another CU wrote), against the plain launch: state rows, observations,
+    completion bits, last_qpos and status words are BIT-IDENTICAL after every step -- same-step autoresets at a short time limit, the noise streams on, the standing overflow lane with its
+    polling workgroups, the cost-ordered dispatch.  The reference's step is one env.step() whatever the launch geometry (/root/reference/gymnasium_robotics/envs/franka_kitchen/kitchen_env.py:399-423)."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    n, envs = 2048, []
+    for p_ in (1, parts):
+        monkeypatch.setenv("GRX_KITCHEN_SPLIT", str(p_))
+        e = grx.make_vec("FrankaKitchen-v1", num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=7)
+        e.reset(seed=5)
+        envs.append(e)
+    plain, split = envs
+    assert plain._split == 1 and split._split == parts
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(9)
+    for t in range(16):
+        a = torch.rand(n, 9, device="cuda:0", generator=gen) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        for name in ("qpos", "qvel", "qacc_ws", "obs", "completed", "last_qpos", "status"):
+            assert torch.equal(getattr(split, name), getattr(plain, name)), (t, name, int((getattr(split, name) != getattr(plain, name)).sum()))
+        assert int(split._split_state.abs().max()) == 0, t      # every world's words are clean again
+    assert int((split.status & 1).max()) == 0 and torch.isfinite(split.qpos).all()
