@@ -98,7 +98,8 @@ class AdroitCommitArgsStruct(ctypes.Structure):      # include/grx_capi.h, grx_a
 
 class HandBuffersStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost", "packed")] + [("lane", OverflowLaneStruct)]
+        "qpos", "qvel", "qacc_ws", "goal", "action", "obs", "achieved", "palm", "reward", "success", "status", "mask", "order", "cost", "packed")] + [("lane", OverflowLaneStruct),
+        ("split_rows", ctypes.c_void_p), ("split_state", ctypes.c_void_p), ("split_stride", ctypes.c_int), ("split_parts", ctypes.c_int)]
 
 
 def lib():

@@ -45,6 +45,9 @@ struct GrxHandBuffers {
   int* cost;                     // [N] or null: out, cost estimate of this world
   float* packed;                 // [N, obs_dim + 2 goal_dim + 2] or null: out, the row [obs | achieved | desired | reward | success]
   GrxLane lane;                   // the overflow lane (include/grx_capi.h grx_overflow_lane): no dropped contacts
+  float* split_rows;              // [N, split_stride] or null: carrier rows of the split step [qpos | qvel | warm start] (include/grx_capi.h)
+  int* split_state;               // [N, 4] or null: [4 w] = parts of world w done in this launch (< 0: re-run booked), [4 w + 1] = their status flags, [4 w + 2] = their measured duration
+  int split_stride, split_parts;  // words per carrier row (>= nq + 2 nv); >= 2: the step launch has split_parts workgroups per world
 };
 
 // Euclidean distance with a fixed accumulation order, shared by the step kernel and the recompute kernel so that
@@ -130,8 +133,9 @@ struct GrxHand {
     WAVE_SYNC();
   }
 
+  // s0 / s1: the substeps [s0, s1) of the step, outputs: write the observation rows behind them (parts of a split step, include/grx_capi.h grx_hand_buffers.split_parts; default: the whole step)
   GRX_MEM void grx_hand_step_world(const GrxModel* m, const GrxHandTask* t, GrxCtx* c, const float* action, float* obs, float* achieved, float* palm,
-                                   int lane_) {
+                                   int lane_, int s0 = 0, int s1 = -1, bool outputs = true) {
     GRX_FRESH_MODEL(m, c);
     FOR_LANES {
       for (int i = lane; i < GRX_NUC; i += 64) {
@@ -141,11 +145,13 @@ struct GrxHand {
       }
     }
     WAVE_SYNC();
-    for (int s = 0; s < t->n_substeps; s++) {
+    if (s1 < 0) s1 = t->n_substeps;
+    for (int s = s0; s < s1; s++) {
       E::grx_check_state(m, c, lane_);
       E::grx_forward_euler(m, c, 1, lane_);
       if (c->bail && grx_lane_claim(c, lane_)) break;   // a capacity overflowed and the re-run on the large tables is booked: this run will be discarded
     }
+    if (!outputs) return;
     // A discarded run must not touch the output rows either: its re-run may already be under way in a polling workgroup of the standing lane launch on ANOTHER XCD,
     // and a stale observation written here would sit dirty in this XCD's L2 until the end of the launch and then overwrite the re-run's row (state right,
     // observation / achieved goal of the truncated run: found by tests/test_gpu_manipulate.py::test_overflow_lane_polling_equals_the_serialised_rerun).

@@ -394,12 +394,9 @@ __global__ void __launch_bounds__(64, GRX_FETCH_WAVES(S))
 grx_fetch_step_kernel(int mslot, GrxFetchTask t, GrxFetchBuffers b, int n_worlds, int words) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
-  const int parts = b.split_parts > 1 ? b.split_parts : 1;
-  if (parts > 1) {
-    const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot and slot + G, slot + 2 G ... share blockIdx.x mod 8: one XCD, one L2 for all parts of a world
-    grx_fetch_step_world<S, false>(mslot, t, b, b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)), n_worlds, words, lds, lane_, (int)part, parts);
-  } else
-  grx_fetch_step_world<S, false>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, lds, lane_);
+  const int parts = b.split_parts > 1 ? b.split_parts : 1;      // (one part: G = the grid, part 0, slot = the workgroup: grx_world_of_block)
+  const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot and slot + G, slot + 2 G ... share blockIdx.x mod 8: one XCD, one L2 for all parts of a world; ONE call site of the step (code size, compile time)
+  grx_fetch_step_world<S, false>(mslot, t, b, b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)), n_worlds, words, lds, lane_, (int)part, parts);
   grx_lane_progress(b.lane);   // (launches with polling workgroups behind them: this workgroup has ended)
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
@@ -596,10 +593,27 @@ template <class S>
 #ifndef GRX_HANDREACH_WAVES
 #define GRX_HANDREACH_WAVES 2   // with the hull-pair routine the 168-VGPR build spills 73 registers: 11.9 ms per step at 16 384 worlds against 10.95 ms at 2 waves
 #endif
-__device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask& t, const GrxHandBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane) {
+__device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask& t, const GrxHandBuffers& b, const int w, int n_worlds, int words, int forward_only, float* lds, const int lane_, const bool in_lane,
+                                                    const int part = 0, const int parts = 1) {
   if (w >= n_worlds) return;
   if (b.mask && !b.mask[w]) { if (in_lane) grx_lane_ticket(b.lane, -1, w, lane_); return; }
   if (!in_lane && forward_only != 1 && b.lane.skip && b.lane.skip[w]) return;   // in the overflow lane: stepped by the large-table kernel (reset-time forward passes cover every masked world)
+  // SPLIT STEP (include/grx_capi.h grx_hand_buffers.split_parts; see grx_adroit_step_world): part `part` of `parts` workgroups of this world, each running its share of the substeps (plain step launches only)
+  const bool split = parts > 1, last_part = part == parts - 1;
+  if (split && part > 0) {
+    volatile int* st = b.split_state + 4 * (size_t)w;
+    int v = 0;
+    for (int spins = 0; spins < GRX_SPLIT_SPIN_LIMIT; spins++) {
+      v = __builtin_amdgcn_readfirstlane(st[0]);
+      if (v == part || v < 0) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (v != part) {   // the earlier part booked the world's re-run (v < 0), or never came (flagged): nothing to do here; the last part leaves the words clean
+      if (lane_ == 0) { if (v >= 0) b.status[w] |= GRX_ST_BADNUM | (GRX_ST_BADNUM << 16); if (last_part) { st[0] = 0; st[1] = 0; st[2] = 0; } }
+      return;
+    }
+    GRX_SPLIT_ACQUIRE();
+  }
   const GrxModel& m = g_grx_models[mslot];
   GrxCtx c;
   c.mslot = mslot;
@@ -623,18 +637,48 @@ __device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask
   if (b.cost && lane_ == 0) b.cost[w] = (int)wall_clock64();   // start stamp, parked in the cost slot (see grx_fetch_step_kernel)
   for (int i = lane_; i < words; i += 64) lds[i] = 0.0f;
   __syncthreads();
+  if (split && part > 0) {   // the row the part before this one wrote on another CU during this launch: cache-bypassing loads
+    volatile const float* row = b.split_rows + (size_t)w * b.split_stride;
+    for (int i = lane_; i < nq; i += 64) c.qpos[i] = row[i];
+    for (int i = lane_; i < nv; i += 64) { c.qvel[i] = row[nq + i]; c.qacc_ws[i] = row[nq + nv + i]; }
+  } else {
   for (int i = lane_; i < nq; i += 64) c.qpos[i] = b.qpos[(size_t)w * nq + i];
   for (int i = lane_; i < nv; i += 64) { c.qvel[i] = b.qvel[(size_t)w * nv + i]; c.qacc_ws[i] = b.qacc_ws[(size_t)w * nv + i]; }
+  }
   __syncthreads();
   if (forward_only) {
     GrxEngine<S>::grx_forward_euler(&m, &c, 0, lane_);
     GrxHand<S>::grx_hand_outputs(&m, &t, &c, obs, ach, palm, lane_);
   } else {
-    GrxHand<S>::grx_hand_step_world(&m, &t, &c, b.action + (size_t)w * nu, obs, ach, palm, lane_);
+    const int s0 = split ? (part * t.n_substeps) / parts : 0, s1 = split ? ((part + 1) * t.n_substeps) / parts : t.n_substeps;
+    GrxHand<S>::grx_hand_step_world(&m, &t, &c, b.action + (size_t)w * nu, obs, ach, palm, lane_, s0, s1, !split || last_part);
   }
   __syncthreads();
+  if (split && !last_part) {   // an earlier part: the state goes to the world's carrier row (write-through + drained flag: GRX_SPLIT_DRAIN), nothing else is written
+    volatile int* st = b.split_state + 4 * (size_t)w;
+    if (grx_lane_overflowed(c)) { if (lane_ == 0) st[0] = -1; }      // the re-run on the large tables is booked: the later parts return
+    else {
+      GRX_SPLIT_ROW* row = b.split_rows + (size_t)w * b.split_stride;
+      for (int i = lane_; i < nq; i += 64) row[i] = c.qpos[i];
+      for (int i = lane_; i < nv; i += 64) { row[nq + i] = c.qvel[i]; row[nq + nv + i] = c.qacc_ws[i]; }
+      GRX_SPLIT_DRAIN();
+      __syncthreads();
+      if (lane_ == 0) {
+        st[1] = (part > 0 ? st[1] : 0) | c.cnt[2];
+        if (b.cost) { const int t0 = ((volatile int*)b.cost)[w]; st[2] = (part > 0 ? st[2] : 0) + (((int)wall_clock64() - t0) >> 3); }
+        GRX_SPLIT_DRAIN();
+        st[0] = part + 1;
+      }
+    }
+    return;
+  }
+  int earlier = 0;
+  if (split) {   // the last part: the flags and the measured time of the earlier parts; the words are clean for the next launch
+    if (lane_ == 0) { volatile int* st = b.split_state + 4 * (size_t)w; c.cnt[2] |= st[1]; earlier = st[2]; st[0] = 0; st[1] = 0; st[2] = 0; }
+    __syncthreads();
+  }
   if (grx_lane_overflowed(c)) {   // capacity overflow: keep nothing (obs / achieved are outputs only), re-run on the large tables
-    if (lane_ == 0 && b.cost) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = ((int)wall_clock64() - t0) >> 3; }
+    if (lane_ == 0 && b.cost) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = (((int)wall_clock64() - t0) >> 3) + earlier; }
     return;
   }
   if (in_lane) grx_lane_ticket(b.lane, c.cnt[2] & 0xFFFF, w, lane_); else if (!forward_only) grx_lane_join(b.lane, c, w, lane_);
@@ -652,7 +696,7 @@ __device__ __forceinline__ void grx_hand_step_world(int mslot, const GrxHandTask
       b.success[w] = (d < t.distance_threshold) ? 1 : 0;
     }
     b.status[w] = grx_status_word(b.status[w], c.cnt[2]);
-    if (b.cost) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = ((int)wall_clock64() - t0) >> 3; }   // measured duration of this world, 80 ns units (see grx_fetch_step_kernel)
+    if (b.cost) { const int t0 = ((volatile int*)b.cost)[w]; b.cost[w] = (((int)wall_clock64() - t0) >> 3) + earlier; }   // measured duration of this world, 80 ns units (see grx_fetch_step_kernel)
   }
   if (b.packed) {   // [obs | achieved | desired | reward | success] row for the cross-rank gather
     float* row = b.packed + (size_t)w * (od + 2 * gd + 2);
@@ -672,7 +716,9 @@ __global__ void __launch_bounds__(64, (S::kFixed && S::JP <= 512) ? GRX_HANDREAC
 grx_hand_step_kernel(int mslot, GrxHandTask t, GrxHandBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
-  grx_hand_step_world<S>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+  const int parts = (b.split_parts > 1 && forward_only == 0) ? b.split_parts : 1;      // (one part: G = the grid, part 0, slot = the workgroup: grx_world_of_block)
+  const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot, slot + G, ... share blockIdx.x mod 8; ONE call site of the step (code size, compile time)
+  grx_hand_step_world<S>(mslot, t, b, b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)), n_worlds, words, forward_only, lds, lane_, false, (int)part, parts);
   grx_lane_progress(b.lane);
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
@@ -817,15 +863,10 @@ __global__ void __launch_bounds__(64, 2)
 grx_adroit_step_kernel(int mslot, GrxAdroitTask t, GrxAdroitBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
-  const int parts = (b.split_parts > 1 && !b.compact && !forward_only) ? b.split_parts : 1;
-  if (parts > 1) {
-    const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot, slot + G, ... share blockIdx.x mod 8
-    grx_adroit_step_world<S>(mslot, t, b, b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)), n_worlds, words, forward_only, lds, lane_, false, (int)part, parts);
-    grx_lane_progress(b.lane);
-    return;
-  }
-  const int w = b.compact ? ((int)blockIdx.x < b.n_compact ? (int)b.compact[blockIdx.x] : n_worlds) : (b.order ? b.order[blockIdx.x] : grx_world_of_block());
-  grx_adroit_step_world<S>(mslot, t, b, w, n_worlds, words, forward_only, lds, lane_, false);
+  const int parts = (b.split_parts > 1 && !b.compact && !forward_only) ? b.split_parts : 1;      // (one part: G = the grid, part 0, slot = the workgroup: grx_world_of_block)
+  const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot, slot + G, ... share blockIdx.x mod 8; ONE call site of the step (code size, compile time)
+  const int w = b.compact ? ((int)blockIdx.x < b.n_compact ? (int)b.compact[blockIdx.x] : n_worlds) : (b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)));
+  grx_adroit_step_world<S>(mslot, t, b, w, n_worlds, words, forward_only, lds, lane_, false, (int)part, parts);
   grx_lane_progress(b.lane);
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
@@ -945,12 +986,9 @@ __global__ void __launch_bounds__(64, 2)
 grx_kitchen_step_kernel(int mslot, GrxKitchenTask t, GrxKitchenBuffers b, int n_worlds, int words, int forward_only) {
   extern __shared__ float lds[];
   const int lane_ = threadIdx.x;
-  const int parts = (b.split_parts > 1 && !forward_only) ? b.split_parts : 1;
-  if (parts > 1) {
-    const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot, slot + G, ... share blockIdx.x mod 8
-    grx_kitchen_step_world<S>(mslot, t, b, b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)), n_worlds, words, forward_only, lds, lane_, false, (int)part, parts);
-  } else
-  grx_kitchen_step_world<S>(mslot, t, b, b.order ? b.order[blockIdx.x] : grx_world_of_block(), n_worlds, words, forward_only, lds, lane_, false);
+  const int parts = (b.split_parts > 1 && !forward_only) ? b.split_parts : 1;      // (one part: G = the grid, part 0, slot = the workgroup: grx_world_of_block)
+  const unsigned G = gridDim.x / (unsigned)parts, part = blockIdx.x / G, slot = blockIdx.x - part * G;   // slot, slot + G, ... share blockIdx.x mod 8; ONE call site of the step (code size, compile time)
+  grx_kitchen_step_world<S>(mslot, t, b, b.order ? b.order[slot] : (int)((slot & 7u) * (G >> 3) + (slot >> 3)), n_worlds, words, forward_only, lds, lane_, false, (int)part, parts);
   grx_lane_progress(b.lane);
 }
 // the large-table kernel of the overflow lane (grx_overflow_lane): a small fixed grid walks the compacted list of worlds; generic shape only
@@ -1473,7 +1511,12 @@ extern "C" int grx_hand_step(const grx_model* m, const grx_hand_task* task, cons
     for (int k = 0; k < GRX_HAND_NTIPS; k++) if (t.site[k] < 0 || t.site[k] >= m->dev.nsite) return fail("grx_hand_step: fingertip site out of range");
   if (t.palm_body < 0 || t.palm_body >= m->dev.nbody) return fail("grx_hand_step: palm body out of range");
   if (b.lane.list && m->shape != 0 && m->shape < 100) return fail("grx_hand_step: the large-table launch of the overflow lane needs a model that runs on the generic kernel (capacities that match no specialised shape)");
-  const int e = grx_tu_hand_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
+  const bool split = b.split_parts > 1 && forward_only == 0 && !b.lane.list;      // plain step launches only (not forward-only, not a repeat launch, not the lane's)
+  if (split) {
+    if (!b.split_state || !b.split_rows || b.split_stride < m->dev.nq + 2 * m->dev.nv) return fail("grx_hand_step: a split step needs split_state [N, 4] and carrier rows split_rows [N, split_stride >= nq + 2 nv]");
+    if (b.split_parts > t.n_substeps || b.split_parts > 8) return fail("grx_hand_step: split_parts <= min(n_substeps, 8): a part runs whole substeps");
+  } else b.split_parts = 0;
+  const int e = grx_tu_hand_launch(m->shape, (b.lane.list ? (unsigned)(b.lane.grid > 0 ? b.lane.grid : GRX_LANE_GRID) : (split ? (unsigned)b.split_parts : 1u) * grx_grid_for(n_worlds)), (size_t)m->words * 4 + m->lds_pad, stream, m->slot, &t, &b, n_worlds, m->words, forward_only);
   if (e) return fail(std::string("grx_hand_step launch: ") + hipGetErrorString((hipError_t)e));
   return 0;
 }

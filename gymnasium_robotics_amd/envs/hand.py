@@ -48,6 +48,10 @@ def load_hand_reach_model(assets_root: Optional[str] = None) -> CompiledModel:
     return load_model(path)
 
 
+HAND_SPLIT_PARTS = {"HandReachVecEnv": 4, "HandBlockVecEnv": 2}      # default of GRX_HAND_SPLIT for batches of more than 2 048 worlds (see HandReachVecEnv.__init__; profiles/ab_r06_hand_split.txt, 16 384 worlds, 1 / 2 / 4 / 5 parts:
+                                                                    # HandReach 1.51 / 1.553 / 1.558 / 1.549 M; hand + touch (throughput-bound with its settle chains) 0.983 / 0.993 / 0.975 / 0.971 M)
+
+
 class HandReachVecEnv(GoalVecEnv):
     def __init__(self, env_id: str = "HandReach-v3", num_envs: int = 1, device: Optional[str] = None, reward_type: Optional[str] = None,
                  relative_control: bool = False, max_episode_steps: Optional[int] = MAX_EPISODE_STEPS, autoreset_mode: str = "next_step",
@@ -101,6 +105,16 @@ class HandReachVecEnv(GoalVecEnv):
         # no dropped contacts: the worlds that exceed a table capacity of the fast kernel are stepped on larger tables (core.OverflowLane)
         # (with the entrants picked up by polling workgroups a smaller standing lane is cheaper: margin 0.9 / ttl 4 against 0.8 / 8, +1 % on hand + touch, profiles/ab_r03_lane_size_with_polling.txt)
         self.lane = OverflowLane(n, d, self.model, self._lane_make_bufs(), mode=self.LANE_MODE, margin=0.9, ttl=4) if self._h_big is not None else None
+        # SPLIT STEP (include/grx_capi.h grx_hand_buffers.split_parts; see AdroitVecEnv): a hand launch ended 15 - 17 % after the mean of its wave slots (profiles/tail_probe_r06.txt).
+        # GRX_HAND_SPLIT=P (1: off).  Bit-identical to the plain launch (tests/test_gpu_hand.py::test_split_step_is_the_plain_step).
+        self._split = max(1, min(int(self.task.n_substeps), 8, int(os.environ.get("GRX_HAND_SPLIT", HAND_SPLIT_PARTS.get(type(self).__name__, 1) if n > 2048 else 1)))) if n >= 64 else 1
+        if self._split > 1:
+            stride = -(-(self.nq + 2 * self.nv) // 16) * 16
+            self._split_rows, self._split_state = z(n, stride), z(n, 4, dtype=torch.int32)
+            for b in (self._bufs, self._bufs_masked):
+                b.split_rows, b.split_state, b.split_stride, b.split_parts = self._split_rows.data_ptr(), self._split_state.data_ptr(), stride, self._split
+            if self.lane is not None:
+                self.lane._fast_grid *= self._split      # (polling workgroups of the standing lane wait for EVERY workgroup of the fast launch)
         self.single_action_space = Box(-1.0, 1.0, (self.nu,), np.float32)
         self.single_observation_space = Dict(dict(
             observation=Box(-np.inf, np.inf, (self.obs_dim,), np.float64), achieved_goal=Box(-np.inf, np.inf, (GOAL_DIM,), np.float64),

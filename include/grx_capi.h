@@ -197,6 +197,12 @@ typedef struct grx_hand_buffers {
   int* cost;                    /* [N] or NULL */
   float* packed;                /* [N, obs_dim+2*goal_dim+2] or NULL: [obs | achieved | desired | reward | success] */
   grx_overflow_lane lane;          /* capacity overflows re-run on larger tables: see grx_overflow_lane and its LIMITS */
+  /* SPLIT STEP (round 6; as grx_adroit_buffers.split_parts): split_parts = P (2 <= P <= 8) workgroups per world, each running its share of the substeps and handing the world on through
+   * its row of split_rows; plain step launches only (forward_only = 0, not grx_hand_step_repeat, not the lane's).  Bit-identical to split_parts = 0
+   * (tests/test_gpu_hand.py::test_split_step_is_the_plain_step). */
+  float* split_rows;               /* [N, split_stride >= nq + 2 nv] or NULL */
+  int* split_state;                /* [N, 4] or NULL, zeroed before the first launch */
+  int split_stride, split_parts;
 } grx_hand_buffers;
 
 /* mirrors struct GrxAdroitTask / GrxAdroitBuffers (csrc/grx_adroit_task.h): AdroitHandHammer / Door / Pen / Relocate */

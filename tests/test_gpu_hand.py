@@ -130,3 +130,32 @@ def test_same_step_autoreset_matches_next_step(output):
 
     make = lambda **kw: grx.make_vec("HandReach-v3", num_envs=40, device="cuda:0", **kw)
     check_same_step_against_next_step(make, horizon=5, steps=12, act_dim=20, output=output)
+
+
+@pytest.mark.parametrize("env_id,parts", [("HandReach-v3", 4), ("HandManipulateBlockRotateXYZ_ContinuousTouchSensors-v1", 5), ("HandManipulateEggRotate-v1", 2)])
+def test_split_step_is_the_plain_step(monkeypatch, env_id, parts):
+    """Round 6: the hand step launch with P workgroups per world, each running its share of the substeps and handing the world on through a carrier row (include/grx_capi.h
+    grx_hand_buffers.split_parts), against the plain launch: state rows, observations (touch words included), achieved goals, rewards, success flags, status words and packed rows are
+    BIT-IDENTICAL after every step -- same-step autoresets at a short time limit (the manipulation families' settle chains run their own, unsplit, repeat launches), the standing overflow
+    lane with its polling workgroups counting every part.  The reference's step is one env.step() whatever the launch geometry
+    (/root/reference/gymnasium_robotics/envs/robot_env.py:114-152)."""
+    import torch
+
+    import gymnasium_robotics_amd as grx
+
+    n, envs = 2048, []
+    for p_ in (1, parts):
+        monkeypatch.setenv("GRX_HAND_SPLIT", str(p_))
+        e = grx.make_vec(env_id, num_envs=n, device="cuda:0", output="torch", autoreset_mode="same_step", max_episode_steps=8)
+        e.reset(seed=5)
+        envs.append(e)
+    plain, split = envs
+    assert plain._split == 1 and split._split == parts
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(9)
+    for t in range(20):
+        a = torch.rand(n, 20, device="cuda:0", generator=gen) * 2 - 1
+        outs = [e.step(a) for e in envs]
+        for name in ("qpos", "qvel", "qacc_ws", "obs", "achieved", "palm", "reward", "success", "status", "packed", "goal"):
+            assert torch.equal(getattr(split, name), getattr(plain, name)), (t, name, int((getattr(split, name) != getattr(plain, name)).sum()))
+        assert int(split._split_state.abs().max()) == 0, t      # every world's words are clean again
+    assert int((split.status & 1).max()) == 0 and torch.isfinite(split.qpos).all()
